@@ -1,0 +1,160 @@
+/*
+ * rtoc.h -- C ABI of the MI355X-native Riccati / KKT-condensation engine.
+ *
+ * This is the drop-in boundary for robotoc's per-iteration KKT hot path.  The
+ * reference (mayataka/robotoc) has no FFI of its own: the seam is its C++ class
+ * API.  Every entry point below therefore names the reference C++ method it
+ * replaces (paths relative to the reference tree):
+ *
+ *   rtoc_condense              DirectMultipleShooting::evalKKT tail
+ *                              (src/ocp/intermediate_stage.cpp:134-148,
+ *                               src/ocp/impact_stage.cpp:108-121):
+ *                              Constraints::condenseSlackAndDual
+ *                              (src/constraints/constraints.cpp:322-357),
+ *                              condenseContactDynamics
+ *                              (src/dynamics/contact_dynamics.cpp:55-164),
+ *                              condenseImpactDynamics
+ *                              (src/dynamics/impact_dynamics.cpp:38-80)
+ *   rtoc_riccati_backward      RiccatiRecursion::backwardRiccatiRecursion
+ *                              (src/riccati/riccati_recursion.cpp:32-80)
+ *   rtoc_riccati_forward       RiccatiRecursion::forwardRiccatiRecursion
+ *                              (src/riccati/riccati_recursion.cpp:83-131)
+ *   rtoc_unconstr_backward /   UnconstrRiccatiRecursion::{backward,forward}RiccatiRecursion
+ *   rtoc_unconstr_forward      (src/riccati/unconstr_riccati_recursion.cpp:26-48)
+ *   rtoc_expand                DirectMultipleShooting::computeStepSizes + the
+ *                              expandDual half of integrateSolution
+ *                              (src/ocp/direct_multiple_shooting.cpp:174-241;
+ *                               src/dynamics/contact_dynamics.cpp:167-202;
+ *                               src/constraints/constraints.cpp:360-458)
+ *   rtoc_update                Constraints::updateSlack/updateDual
+ *                              (include/robotoc/constraints/constraints_impl.hxx:167-182)
+ *
+ * Conventions
+ *   - plain C, no torch / Eigen types; all matrices are IEEE fp64, column-major
+ *     (Eigen default), except LQRPolicy::K which is row-major as in the reference
+ *     (include/robotoc/riccati/lqr_policy.hpp:18-19).
+ *   - data live in packed, stage-contiguous records: buffer[instance][stage][field].
+ *     Field offsets come from rtoc_compute_layout() (rtoc_layout.h); every field
+ *     starts on a 64-byte boundary.
+ *   - every call returns an int status (RTOC_OK == 0, negative = API misuse);
+ *     numerical failures (non-SPD Quu / S, NaN) never throw, they set bits in the
+ *     per-instance status words readable with rtoc_status().
+ *   - calls are asynchronous on the context's HIP stream; rtoc_download /
+ *     rtoc_status / rtoc_sync synchronise.
+ *   - the HIP path has NO CPU fallback: if the device or the kernels are not
+ *     available rtoc_create fails with RTOC_ERR_NO_DEVICE.
+ */
+#ifndef RTOC_H_
+#define RTOC_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "rtoc_layout.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- return codes -------------------------------------------------------- */
+#define RTOC_OK 0
+#define RTOC_ERR_BAD_ARG (-1)
+#define RTOC_ERR_UNSUPPORTED_DIMS (-2)
+#define RTOC_ERR_NO_DEVICE (-3)
+#define RTOC_ERR_HIP (-4)
+#define RTOC_ERR_NOT_READY (-5)
+#define RTOC_ERR_RCCL (-6)
+
+/* ---- per-instance numerical status bits (rtoc_status) --------------------- */
+#define RTOC_STAT_QUU_NOT_SPD 0x1u  /* LLT(Quu) hit a non-positive pivot (riccati_factorizer.cpp:49-50) */
+#define RTOC_STAT_S_NOT_SPD 0x2u    /* LLT(S) of the switching-constraint Schur complement (:63-64)   */
+#define RTOC_STAT_NAN 0x4u          /* NaN/Inf in K, k, M, m (:75-79)                                   */
+#define RTOC_STAT_M_NOT_SPD 0x8u    /* LLT(dIDda) or LLT(J Minv J^T) failed in computeMJtJinv           */
+
+/* ---- buffers ---------------------------------------------------------------- */
+enum rtoc_buffer {
+  RTOC_BUF_KKT = 0,  /* [batch][stages][kkt.stride]  condensed KKT system (SplitKKTMatrix/Residual) */
+  RTOC_BUF_RIC = 1,  /* [batch][stages][ric.stride]  SplitRiccatiFactorization + LQRPolicy + STOPolicy */
+  RTOC_BUF_DIR = 2,  /* [batch][stages][dir.stride]  SplitDirection */
+  RTOC_BUF_CDD = 3,  /* [batch][stages][cdd.stride]  ContactDynamicsData (+ pre-condensation KKT parts) */
+  RTOC_BUF_CON = 4,  /* [batch][stages][con.stride]  ConstraintComponentData of the PDIPM rows */
+  RTOC_BUF_DX0 = 5,  /* [batch][nx]                  initial state direction d[0].dx */
+  RTOC_BUF_STEP = 6, /* [batch][2]                   max primal / dual step sizes */
+  RTOC_NUM_BUFFERS = 7
+};
+
+/* kernel-variant knobs (rtoc_set_option) */
+enum rtoc_option {
+  RTOC_OPT_WRITEBACK_KKT = 0, /* 1: backward writes the mutated Qxx,Qxu,Quu,lu back (reference in-place semantics) */
+  RTOC_OPT_MAX_DTS0 = 1,      /* RiccatiRecursion(ocp, max_dts0) / setRegularization; value = double bits */
+  RTOC_OPT_BACKWARD_WAVES = 2 /* waves per OCP instance in the backward kernel (0 = default for the dims) */
+};
+
+typedef struct rtoc_ctx rtoc_ctx;
+
+/* Library / device discovery. rtoc_device_count() < 1 means the HIP path is unusable. */
+int rtoc_version(void);
+int rtoc_device_count(void);
+/* 1 if (nv,nu,np) has a compiled kernel specialisation, else 0. */
+int rtoc_dims_supported(const rtoc_dims* dims);
+
+/* Create a context for `batch` independent OCP instances of at most
+ * `max_stages` grid points each (= N+1+lifts+2*impacts, time_discretization.cpp:45)
+ * on HIP device `device`. Allocates all RTOC_BUF_* buffers in HBM.
+ * Mirrors the sizing done in OCPSolver's constructor (src/solver/ocp_solver.cpp:20-24). */
+int rtoc_create(const rtoc_dims* dims, int max_stages, int batch, int device, rtoc_ctx** out);
+int rtoc_destroy(rtoc_ctx* ctx);
+
+/* Layout actually used by the context (identical to rtoc_compute_layout(dims)). */
+int rtoc_get_layout(const rtoc_ctx* ctx, rtoc_layout* out);
+
+/* Grid of the current discretisation: `nstages` = TimeDiscretization::size()
+ * (terminal stage included, its type must be RTOC_GRID_TERMINAL). Shared by all
+ * instances of the batch. Mirrors RiccatiRecursion::resizeData. */
+int rtoc_set_grid(rtoc_ctx* ctx, const rtoc_grid* grid, int nstages);
+
+/* Use a caller-owned HIP stream (hipStream_t passed as void*); NULL = the context's own stream. */
+int rtoc_set_stream(rtoc_ctx* ctx, void* hip_stream);
+int rtoc_set_option(rtoc_ctx* ctx, int option, int64_t value);
+
+/* Host <-> HBM transfers of whole buffers (count in doubles, from the buffer start +offset). */
+int rtoc_upload(rtoc_ctx* ctx, int buffer, size_t offset, const double* host, size_t count);
+int rtoc_download(rtoc_ctx* ctx, int buffer, size_t offset, double* host, size_t count);
+/* Device pointer / element count of a buffer (for zero-copy interop and RCCL). */
+void* rtoc_device_ptr(rtoc_ctx* ctx, int buffer);
+size_t rtoc_buffer_count(const rtoc_ctx* ctx, int buffer);
+/* Replace a buffer by caller-owned device memory of at least rtoc_buffer_count doubles. */
+int rtoc_bind(rtoc_ctx* ctx, int buffer, void* device_ptr);
+
+/* ---- the hot path ---------------------------------------------------------- */
+int rtoc_condense(rtoc_ctx* ctx);
+int rtoc_riccati_backward(rtoc_ctx* ctx);
+int rtoc_riccati_forward(rtoc_ctx* ctx);
+int rtoc_unconstr_backward(rtoc_ctx* ctx, double dt);
+int rtoc_unconstr_forward(rtoc_ctx* ctx, double dt);
+/* expandPrimal + fraction-to-boundary + expandDual; step sizes land in RTOC_BUF_STEP. */
+int rtoc_expand(rtoc_ctx* ctx, double fraction_to_boundary_rule);
+/* slack/dual update with the per-instance step sizes in RTOC_BUF_STEP. */
+int rtoc_update(rtoc_ctx* ctx);
+
+/* Per-instance status words (RTOC_STAT_* bits), synchronises the stream. */
+int rtoc_status(rtoc_ctx* ctx, uint32_t* host_flags, int count);
+int rtoc_clear_status(rtoc_ctx* ctx);
+int rtoc_sync(rtoc_ctx* ctx);
+
+/* Time `reps` back-to-back launches of one phase with HIP events recorded on the
+ * context's stream; returns the mean milliseconds per launch in *ms.
+ * phase: 0 backward, 1 forward, 2 condense, 3 expand, 4 backward+forward. */
+int rtoc_time_phase(rtoc_ctx* ctx, int phase, int reps, float* ms);
+
+/* Multi-GPU: all-gather the direction buffers of all ranks over RCCL.
+ * `nccl_comm` is an ncclComm_t passed as void*; `out` is device memory of
+ * world_size * rtoc_buffer_count(ctx, RTOC_BUF_DIR) doubles. */
+int rtoc_gather_directions(rtoc_ctx* ctx, void* nccl_comm, double* out);
+
+const char* rtoc_error_string(int code);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTOC_H_ */

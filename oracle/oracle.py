@@ -1,0 +1,100 @@
+"""ctypes loader for the CPU oracle (TEST INFRASTRUCTURE ONLY).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module.  It never falls back to anything: if librtoc_oracle.so cannot be
+built/loaded an exception is raised.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from robotoc_amd.types import Dims, Grid, Layout, grid_array
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "librtoc_oracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("rtoc_oracle.c", "rtoc_oracle_condense.c")]
+    srcs += [os.path.join(_HERE, "..", "include", f) for f in ("rtoc.h", "rtoc_layout.h")]
+    stale = force or not os.path.exists(so) or any(
+        os.path.getmtime(s) > os.path.getmtime(so) for s in srcs if os.path.exists(s))
+    if stale:
+        subprocess.check_call(["make", "-C", _HERE, "-B", "librtoc_oracle.so"],
+                              stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        dp = C.POINTER(C.c_double)
+        _LIB.orc_layout.argtypes = [C.POINTER(Dims), C.POINTER(Layout)]
+        _LIB.orc_riccati_backward.argtypes = [C.POINTER(Layout), C.POINTER(Grid), C.c_int, dp, dp,
+                                              C.c_double]
+        _LIB.orc_riccati_backward.restype = C.c_uint
+        _LIB.orc_riccati_forward.argtypes = [C.POINTER(Layout), C.POINTER(Grid), C.c_int, dp, dp,
+                                             dp]
+        _LIB.orc_unconstr_backward.argtypes = [C.POINTER(Layout), C.c_int, C.c_double, dp, dp]
+        _LIB.orc_unconstr_backward.restype = C.c_uint
+        _LIB.orc_unconstr_forward.argtypes = [C.POINTER(Layout), C.c_int, C.c_double, dp, dp, dp]
+        _LIB.orc_riccati_sweep_batch.argtypes = [C.POINTER(Layout), C.POINTER(Grid), C.c_int,
+                                                 C.c_int, dp, dp, dp, dp, C.c_double,
+                                                 C.POINTER(C.c_uint), C.c_int, C.c_int]
+        _LIB.orc_unconstr_sweep_batch.argtypes = [C.POINTER(Layout), C.c_int, C.c_int, C.c_double,
+                                                  dp, dp, dp, dp, C.POINTER(C.c_uint)]
+    return _LIB
+
+
+def _p(a):
+    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def layout(dims):
+    L = Layout()
+    lib().orc_layout(C.byref(dims), C.byref(L))
+    return L
+
+
+def riccati_backward(L, grids, kkt, ric, max_dts0=0.1):
+    """kkt, ric: [stages, stride] arrays of ONE instance (kkt is mutated in place like the reference)."""
+    g = grid_array(grids)
+    return lib().orc_riccati_backward(C.byref(L), g, len(grids), _p(kkt), _p(ric), max_dts0)
+
+
+def riccati_forward(L, grids, kkt, ric, dirs):
+    g = grid_array(grids)
+    lib().orc_riccati_forward(C.byref(L), g, len(grids), _p(kkt), _p(ric), _p(dirs))
+
+
+def unconstr_backward(L, nstages, dt, kkt, ric):
+    return lib().orc_unconstr_backward(C.byref(L), nstages, dt, _p(kkt), _p(ric))
+
+
+def unconstr_forward(L, nstages, dt, kkt, ric, dirs):
+    lib().orc_unconstr_forward(C.byref(L), nstages, dt, _p(kkt), _p(ric), _p(dirs))
+
+
+def riccati_sweep_batch(L, grids, kkt, ric, dirs, dx0=None, max_dts0=0.1, backward=True,
+                        forward=True):
+    """Batched (OpenMP over instances) sweep; arrays are [batch, stages, stride]."""
+    g = grid_array(grids)
+    batch = kkt.shape[0]
+    stat = (C.c_uint * batch)()
+    lib().orc_riccati_sweep_batch(C.byref(L), g, len(grids), batch, _p(kkt), _p(ric), _p(dirs),
+                                  _p(dx0) if dx0 is not None else None, max_dts0, stat,
+                                  int(backward), int(forward))
+    return np.frombuffer(stat, dtype=np.uint32).copy()
+
+
+def unconstr_sweep_batch(L, nstages, dt, kkt, ric, dirs, dx0=None):
+    batch = kkt.shape[0]
+    stat = (C.c_uint * batch)()
+    lib().orc_unconstr_sweep_batch(C.byref(L), nstages, batch, dt, _p(kkt), _p(ric), _p(dirs),
+                                   _p(dx0) if dx0 is not None else None, stat)
+    return np.frombuffer(stat, dtype=np.uint32).copy()

@@ -1,0 +1,169 @@
+"""Deterministic synthetic workloads for the hot path.
+
+The reference cannot produce stage data here (Pinocchio is absent), so inputs are
+synthetic but structurally faithful re-creations of the reference's own test
+factories:
+  * condensed KKT stages  -- test/test_helper/kkt_factory.cpp:7-64
+  * Riccati factorisation -- test/test_helper/riccati_factory.cpp:9-17
+  * pre-condensation data -- SplitKKTMatrix::setRandom (src/core/split_kkt_matrix.cpp:153-178)
+                             and test/dynamics/contact_dynamics_test.cpp:87-120
+Everything is seeded: seed = BASE_SEED + instance index.
+"""
+import numpy as np
+
+from .grid import (ContactSequence, anymal_trot_sequence, discretize, jump_sto_sequence,
+                   uniform_grid)
+from .types import (GRID_IMPACT, GRID_TERMINAL, Records, anymal_dims, icub_dims, iiwa14_dims)
+
+BASE_SEED = 20260925
+
+
+def _rnd(rng, *shape):
+    """Eigen::MatrixXd::Random analogue: uniform in [-1, 1]."""
+    return rng.uniform(-1.0, 1.0, size=shape)
+
+
+def _spd(rng, n, shift=0.0):
+    s = _rnd(rng, n, n)
+    return s @ s.T + shift * np.eye(n)
+
+
+def fill_kkt_instance(L, grids, kkt, rng, mode="dynamics", floating_base=None):
+    """Fill one instance's condensed KKT records ([stages, stride]).
+
+    mode="factory":  Fvq, Fvv, Fvu ~ U[-1,1] exactly like kkt_factory.cpp:21-23.
+    mode="dynamics": Fvq = dt*R, Fvv = I + dt*R, Fvu = dt*R (the magnitudes
+                     condenseContactDynamics produces, contact_dynamics.cpp:130-134),
+                     which keeps a 40-stage recursion well conditioned.
+    """
+    d = L.dims
+    nv, nu, nx, ns = d.nv, d.nu, 2 * d.nv, d.ns_max
+    K = Records(L, "kkt")
+    fb = (d.np > 0) if floating_base is None else floating_base
+    for i, g in enumerate(grids):
+        rec = kkt[i]
+        if g.type == GRID_TERMINAL:
+            K.f(rec, "Qxx")[...] = _spd(rng, nx)
+            K.f(rec, "lx")[...] = _rnd(rng, nx)
+            continue
+        dt = g.dt if g.dt > 0 else 0.0
+        Fxx = K.f(rec, "Fxx")
+        Fxx[...] = 0.0
+        Fxx[:nv, :nv] = np.eye(nv)
+        if g.type != GRID_IMPACT:
+            Fxx[:nv, nv:] = dt * np.eye(nv)
+        if fb:
+            Fxx[:6, :6] = _rnd(rng, 6, 6)
+            if g.type != GRID_IMPACT:
+                Fxx[:6, nv:nv + 6] = _rnd(rng, 6, 6) * (dt if mode == "dynamics" else 1.0)
+        if mode == "factory":
+            Fxx[nv:, :nv] = _rnd(rng, nv, nv)
+            Fxx[nv:, nv:] = _rnd(rng, nv, nv)
+        else:
+            sc = dt if g.type != GRID_IMPACT else 0.1
+            Fxx[nv:, :nv] = sc * _rnd(rng, nv, nv)
+            Fxx[nv:, nv:] = np.eye(nv) + sc * _rnd(rng, nv, nv)
+        K.f(rec, "Fx")[...] = _rnd(rng, nx)
+        K.f(rec, "lx")[...] = _rnd(rng, nx)
+        if g.type == GRID_IMPACT:
+            K.f(rec, "Qxx")[...] = _spd(rng, nx)
+            continue
+        K.f(rec, "Fvu")[...] = _rnd(rng, nv, nu) * (dt if mode == "dynamics" else 1.0)
+        H = _spd(rng, nx + nu)
+        K.f(rec, "Qxx")[...] = H[:nx, :nx]
+        K.f(rec, "Qxu")[...] = H[:nx, nx:]
+        K.f(rec, "Quu")[...] = H[nx:, nx:]
+        K.f(rec, "lu")[...] = _rnd(rng, nu)
+        # STO terms (used only on sto grids but always filled, like CreateSplitKKTMatrix)
+        K.f(rec, "fx")[...] = _rnd(rng, nx)
+        K.f(rec, "hx")[...] = _rnd(rng, nx)
+        K.f(rec, "hu")[...] = _rnd(rng, nu)
+        scal = K.f(rec, "scal")
+        qtt = abs(rng.uniform(-1, 1)) + 0.1
+        scal[0] = qtt           # Qtt > 0
+        scal[1] = -qtt          # Qtt_prev = -Qtt (intermediate_stage.cpp:145)
+        scal[2] = rng.uniform(-1, 1)  # h
+        if g.dims > 0:
+            m = g.dims
+            K.f(rec, "Phix")[:m, :] = _rnd(rng, m, nx)
+            K.f(rec, "Phiu")[:m, :] = _rnd(rng, m, nu)
+            K.f(rec, "Phit")[:m] = _rnd(rng, m)
+            K.f(rec, "Pres")[:m] = _rnd(rng, m)
+
+
+def make_kkt_batch(L, grids, batch, mode="dynamics", first_instance=0):
+    K = Records(L, "kkt")
+    kkt = K.zeros(batch, len(grids))
+    for b in range(batch):
+        rng = np.random.default_rng(BASE_SEED + first_instance + b)
+        fill_kkt_instance(L, grids, kkt[b], rng, mode=mode)
+    return kkt
+
+
+def make_kkt_batch_tiled(L, grids, batch, unique=8, mode="dynamics", first_instance=0):
+    """Bench helper: `unique` distinct instances tiled to `batch` (filling 4096
+    instances record by record in numpy takes minutes; the arithmetic does not care)."""
+    u = min(unique, batch)
+    base = make_kkt_batch(L, grids, u, mode=mode, first_instance=first_instance)
+    reps = (batch + u - 1) // u
+    return np.ascontiguousarray(np.tile(base, (reps, 1, 1))[:batch])
+
+
+def make_dx0(L, batch, first_instance=0, scale=0.1):
+    """d[0].dx = (q0 - q, v0 - v) ~ U[-0.1, 0.1]."""
+    out = np.zeros((batch, 2 * L.dims.nv))
+    for b in range(batch):
+        rng = np.random.default_rng(BASE_SEED + 7919 + first_instance + b)
+        out[b] = scale * _rnd(rng, 2 * L.dims.nv)
+    return out
+
+
+def fill_unconstr_instance(L, nstages, kkt, rng):
+    """test/riccati/unconstr_riccati_recursion_test.cpp:37-45: SPD [Qxx Qxu; . Qaa], random Fx, lx, la.
+    Qaa lives in the Quu slot, la in the lu slot."""
+    d = L.dims
+    nv, nx = d.nv, 2 * d.nv
+    K = Records(L, "kkt")
+    for i in range(nstages):
+        rec = kkt[i]
+        if i == nstages - 1:
+            K.f(rec, "Qxx")[...] = _spd(rng, nx)
+            K.f(rec, "lx")[...] = _rnd(rng, nx)
+            continue
+        H = _spd(rng, nx + nv)
+        K.f(rec, "Qxx")[...] = H[:nx, :nx]
+        K.f(rec, "Qxu")[...] = H[:nx, nx:]
+        K.f(rec, "Quu")[...] = H[nx:, nx:]
+        K.f(rec, "Fx")[...] = _rnd(rng, nx)
+        K.f(rec, "lx")[...] = _rnd(rng, nx)
+        K.f(rec, "lu")[...] = _rnd(rng, nv)
+
+
+# ---- named configurations of BASELINE.json ---------------------------------------
+def config_iiwa14():
+    """configs[0]: iiwa14 UnconstrOCPSolver, nv=7, N=20, T=1 (examples/iiwa14/unconstr_ocp_benchmark.cpp:59-60)."""
+    dims = iiwa14_dims()
+    return dims, uniform_grid(20, 1.0 / 20), dict(name="iiwa14_unconstr", dt=0.05)
+
+
+def config_anymal_trot(N=40, dt=0.02):
+    """configs[1]: ANYmal trot, nv=18, 4 point contacts, N=40; 2 lifts + 2 impacts -> 47 grids."""
+    dims = anymal_dims()
+    cs = anymal_trot_sequence(t0=0.11, swing=0.2, double_support=0.1, cycles=1)
+    return dims, discretize(N, N * dt, 0.0, cs), dict(name="anymal_trot")
+
+
+def config_anymal_jump_sto(N=40, dt=0.02):
+    """configs[2]: ANYmal jump with switching-time optimisation, 3 phases, ns=12."""
+    dims = anymal_dims()
+    cs = jump_sto_sequence(ground_time=0.31, flying_time=0.2, nf=12)
+    return dims, discretize(N, N * dt, 0.0, cs, phase_based=True), dict(name="anymal_jump_sto")
+
+
+def config_icub_jump(N=30, dt=0.02, nv=35):
+    """configs[3]: iCub jump, 2 surface contacts (nf=12), stand-flight-stand."""
+    dims = icub_dims(nv)
+    cs = jump_sto_sequence(ground_time=0.21, flying_time=0.2, nf=12)
+    for e in cs.events:
+        e.sto = False
+    return dims, discretize(N, N * dt, 0.0, cs), dict(name="icub%d_jump" % nv)
