@@ -1,0 +1,214 @@
+"""ctypes binding of the C ABI (include/rtoc.h) -- the same entry points a C++ host
+or the reference's solver classes would bind.  There is NO CPU fallback: if
+librtoc_hip.so is missing or no HIP device is visible, this module raises.
+"""
+import ctypes as C
+import os
+import struct
+import subprocess
+
+import numpy as np
+
+from .types import (BUF_CDD, BUF_CON, BUF_DIR, BUF_DX0, BUF_KKT, BUF_RIC, BUF_STEP, Dims, Grid,
+                    Layout, OPT_BACKWARD_WAVES, OPT_MAX_DTS0, OPT_WRITEBACK_KKT, grid_array)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+EXPORTS = [
+    "rtoc_version", "rtoc_device_count", "rtoc_dims_supported", "rtoc_create", "rtoc_destroy",
+    "rtoc_get_layout", "rtoc_set_grid", "rtoc_set_stream", "rtoc_set_option", "rtoc_upload",
+    "rtoc_download", "rtoc_device_ptr", "rtoc_buffer_count", "rtoc_bind", "rtoc_condense",
+    "rtoc_riccati_backward", "rtoc_riccati_forward", "rtoc_unconstr_backward",
+    "rtoc_unconstr_forward", "rtoc_expand", "rtoc_update", "rtoc_status", "rtoc_clear_status",
+    "rtoc_sync", "rtoc_time_phase", "rtoc_gather_directions", "rtoc_error_string",
+]
+
+
+class RtocError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.path.join(_HERE, "librtoc_hip.so")
+
+
+def build(force=False):
+    """Compile the HIP kernels + C ABI for gfx950 (hipcc cross-compiles without a GPU)."""
+    src_dir = os.path.join(_HERE, "csrc")
+    so = lib_path()
+    deps = [os.path.join(src_dir, f) for f in os.listdir(src_dir)]
+    deps += [os.path.join(_HERE, "..", "include", f) for f in ("rtoc.h", "rtoc_layout.h")]
+    stale = force or not os.path.exists(so) or any(
+        os.path.getmtime(d) > os.path.getmtime(so) for d in deps)
+    if stale:
+        subprocess.check_call(["make", "-C", src_dir, "-B"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = lib_path()
+        if not os.path.exists(so):
+            raise RtocError("librtoc_hip.so not built (run __graft_entry__.build()); "
+                            "the HIP path has no CPU fallback")
+        L = C.CDLL(so)
+        dp = C.POINTER(C.c_double)
+        vp = C.c_void_p
+        L.rtoc_create.argtypes = [C.POINTER(Dims), C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+        L.rtoc_destroy.argtypes = [vp]
+        L.rtoc_dims_supported.argtypes = [C.POINTER(Dims)]
+        L.rtoc_get_layout.argtypes = [vp, C.POINTER(Layout)]
+        L.rtoc_layout_for_dims.argtypes = [C.POINTER(Dims), C.POINTER(Layout)]
+        L.rtoc_layout_for_dims.restype = None
+        L.rtoc_set_grid.argtypes = [vp, C.POINTER(Grid), C.c_int]
+        L.rtoc_set_stream.argtypes = [vp, vp]
+        L.rtoc_set_option.argtypes = [vp, C.c_int, C.c_int64]
+        L.rtoc_upload.argtypes = [vp, C.c_int, C.c_size_t, dp, C.c_size_t]
+        L.rtoc_download.argtypes = [vp, C.c_int, C.c_size_t, dp, C.c_size_t]
+        L.rtoc_device_ptr.argtypes = [vp, C.c_int]
+        L.rtoc_device_ptr.restype = vp
+        L.rtoc_buffer_count.argtypes = [vp, C.c_int]
+        L.rtoc_buffer_count.restype = C.c_size_t
+        L.rtoc_bind.argtypes = [vp, C.c_int, vp]
+        for f in ("rtoc_condense", "rtoc_riccati_backward", "rtoc_riccati_forward", "rtoc_update",
+                  "rtoc_clear_status", "rtoc_sync"):
+            getattr(L, f).argtypes = [vp]
+        L.rtoc_unconstr_backward.argtypes = [vp, C.c_double]
+        L.rtoc_unconstr_forward.argtypes = [vp, C.c_double]
+        L.rtoc_expand.argtypes = [vp, C.c_double]
+        L.rtoc_status.argtypes = [vp, C.POINTER(C.c_uint32), C.c_int]
+        L.rtoc_time_phase.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float)]
+        L.rtoc_gather_directions.argtypes = [vp, vp, dp]
+        L.rtoc_error_string.argtypes = [C.c_int]
+        L.rtoc_error_string.restype = C.c_char_p
+        _LIB = L
+    return _LIB
+
+
+def layout_for(dims):
+    out = Layout()
+    lib().rtoc_layout_for_dims(C.byref(dims), C.byref(out))
+    return out
+
+
+def _chk(rc):
+    if rc != 0:
+        raise RtocError("rtoc error %d: %s" % (rc, lib().rtoc_error_string(rc).decode()))
+
+
+def _dp(a):
+    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class Context:
+    """Thin RAII wrapper over rtoc_ctx: one context per (device, problem shape, batch)."""
+
+    def __init__(self, dims, max_stages, batch, device=0):
+        self.dims = dims
+        self.batch = batch
+        self.max_stages = max_stages
+        self._h = C.c_void_p()
+        _chk(lib().rtoc_create(C.byref(dims), max_stages, batch, device, C.byref(self._h)))
+        self.L = Layout()
+        _chk(lib().rtoc_get_layout(self._h, C.byref(self.L)))
+        self.nstages = 0
+
+    def close(self):
+        if self._h:
+            lib().rtoc_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_grid(self, grids):
+        g = grid_array(grids)
+        _chk(lib().rtoc_set_grid(self._h, g, len(grids)))
+        self.nstages = len(grids)
+
+    def set_stream(self, hip_stream):
+        _chk(lib().rtoc_set_stream(self._h, C.c_void_p(hip_stream)))
+
+    def set_writeback(self, on):
+        _chk(lib().rtoc_set_option(self._h, OPT_WRITEBACK_KKT, int(bool(on))))
+
+    def set_max_dts0(self, v):
+        bits = struct.unpack("<q", struct.pack("<d", float(v)))[0]
+        _chk(lib().rtoc_set_option(self._h, OPT_MAX_DTS0, bits))
+
+    def set_backward_waves(self, nw):
+        _chk(lib().rtoc_set_option(self._h, OPT_BACKWARD_WAVES, int(nw)))
+
+    def upload(self, buffer, arr, offset=0):
+        arr = np.ascontiguousarray(arr, dtype=np.float64)
+        _chk(lib().rtoc_upload(self._h, buffer, offset, _dp(arr), arr.size))
+
+    def download(self, buffer, shape, offset=0):
+        out = np.empty(shape, dtype=np.float64)
+        _chk(lib().rtoc_download(self._h, buffer, offset, _dp(out), out.size))
+        return out
+
+    def device_ptr(self, buffer):
+        return lib().rtoc_device_ptr(self._h, buffer)
+
+    def buffer_count(self, buffer):
+        return lib().rtoc_buffer_count(self._h, buffer)
+
+    def bind(self, buffer, device_ptr):
+        _chk(lib().rtoc_bind(self._h, buffer, C.c_void_p(device_ptr)))
+
+    def condense(self):
+        _chk(lib().rtoc_condense(self._h))
+
+    def riccati_backward(self):
+        _chk(lib().rtoc_riccati_backward(self._h))
+
+    def riccati_forward(self):
+        _chk(lib().rtoc_riccati_forward(self._h))
+
+    def unconstr_backward(self, dt):
+        _chk(lib().rtoc_unconstr_backward(self._h, dt))
+
+    def unconstr_forward(self, dt):
+        _chk(lib().rtoc_unconstr_forward(self._h, dt))
+
+    def expand(self, tau=0.995):
+        _chk(lib().rtoc_expand(self._h, tau))
+
+    def update(self):
+        _chk(lib().rtoc_update(self._h))
+
+    def status(self):
+        out = (C.c_uint32 * self.batch)()
+        _chk(lib().rtoc_status(self._h, out, self.batch))
+        return np.frombuffer(out, dtype=np.uint32).copy()
+
+    def clear_status(self):
+        _chk(lib().rtoc_clear_status(self._h))
+
+    def sync(self):
+        _chk(lib().rtoc_sync(self._h))
+
+    def time_phase(self, phase, reps):
+        ms = C.c_float()
+        _chk(lib().rtoc_time_phase(self._h, phase, reps, C.byref(ms)))
+        return ms.value
+
+    # convenience shapes
+    def shape(self, which):
+        rl = getattr(self.L, which)
+        return (self.batch, self.nstages, rl.stride)
+
+    def upload_records(self, buffer, arr):
+        """arr: [batch, nstages, stride] -> device layout [batch][max? no: nstages] (stride packed)."""
+        assert arr.shape[1] == self.nstages
+        self.upload(buffer, arr)
+
+    def download_records(self, buffer, which):
+        return self.download(buffer, self.shape(which))

@@ -1,0 +1,82 @@
+// device_utils.hpp -- shared device helpers for the gfx950 kernels.
+//
+// CDNA4 specifics used here:
+//   * v_mfma_f64_16x16x4_f64: one wavefront (64 lanes) computes a 16x16 fp64 tile
+//     with K=4.  Operand layout (cdna_hip_programming.md 3): lane l supplies
+//     A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15]; result register r of lane l
+//     holds D[row = (l>>4) + 4*r][col = l&15].
+//   * 64-wide wavefronts, LDS-resident operands, ds_read_b64 fragments.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rtoc {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ d4 mfma16(double a, double b, d4 c) {
+  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+// Row (within the 16x16 tile) of result register r for a lane with q = lane>>4.
+__device__ __forceinline__ constexpr int drow(int q, int r) { return q + 4 * r; }
+
+__device__ __forceinline__ d4 zero4() {
+  d4 z = {0.0, 0.0, 0.0, 0.0};
+  return z;
+}
+
+// Leading dimension for LDS-resident NX x NX operands: even, and ld/2 odd, so that the
+// 16 rows x 2 k-columns a half-wave touches in one ds_read_b64 fall in distinct banks.
+__host__ __device__ constexpr int lds_ld(int n) { return (n % 4 == 2) ? n : n + 2; }  // n even
+
+template <int NT>
+__device__ __forceinline__ void copy_g2s_flat(double* __restrict__ dst, const double* __restrict__ src,
+                                              int n, int tid) {
+  // n doubles, src 16B aligned; dst contiguous
+  const int n2 = n >> 1;
+  const d2* s2 = reinterpret_cast<const d2*>(src);
+  d2* t2 = reinterpret_cast<d2*>(dst);
+  for (int e = tid; e < n2; e += NT) t2[e] = s2[e];
+  if ((n & 1) && tid == 0) dst[n - 1] = src[n - 1];
+}
+
+// Column-major ROWS x COLS matrix (ld = ROWS in global) into LDS with leading dimension LD.
+template <int NT, int ROWS, int COLS, int LD>
+__device__ __forceinline__ void copy_g2s_mat(double* __restrict__ dst, const double* __restrict__ src,
+                                             int tid) {
+  static_assert(ROWS % 2 == 0 && LD % 2 == 0, "even rows / ld required for 16B moves");
+  constexpr int N2 = ROWS * COLS / 2;
+  const d2* s2 = reinterpret_cast<const d2*>(src);
+#pragma unroll 4
+  for (int e = tid; e < N2; e += NT) {
+    const int r = (2 * e) % ROWS, c = (2 * e) / ROWS;
+    *reinterpret_cast<d2*>(dst + r + c * LD) = s2[e];
+  }
+}
+
+template <int NT, int ROWS, int COLS, int LD>
+__device__ __forceinline__ void copy_s2g_mat(double* __restrict__ dst, const double* __restrict__ src,
+                                             int tid) {
+  static_assert(ROWS % 2 == 0 && LD % 2 == 0, "even rows / ld required for 16B moves");
+  constexpr int N2 = ROWS * COLS / 2;
+  d2* t2 = reinterpret_cast<d2*>(dst);
+#pragma unroll 4
+  for (int e = tid; e < N2; e += NT) {
+    const int r = (2 * e) % ROWS, c = (2 * e) / ROWS;
+    t2[e] = *reinterpret_cast<const d2*>(src + r + c * LD);
+  }
+}
+
+template <int NT>
+__device__ __forceinline__ void copy_s2g_flat(double* __restrict__ dst, const double* __restrict__ src,
+                                              int n, int tid) {
+  for (int e = tid; e < n; e += NT) dst[e] = src[e];
+}
+
+__device__ __forceinline__ double shfl_d(double v, int src_lane) { return __shfl(v, src_lane, 64); }
+
+__device__ __forceinline__ bool is_bad(double v) { return !(fabs(v) <= 1.79769313486231570815e308); }
+
+}  // namespace rtoc

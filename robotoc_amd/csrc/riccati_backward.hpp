@@ -1,0 +1,1061 @@
+// riccati_backward.hpp -- batched backward Riccati recursion for gfx950 (CDNA4).
+//
+// Replaces RiccatiRecursion::backwardRiccatiRecursion (reference
+// src/riccati/riccati_recursion.cpp:32-80) and everything it calls
+// (src/riccati/riccati_factorizer.cpp:44-197,
+//  src/riccati/backward_riccati_recursion_factorizer.cpp:31-174).
+//
+// Mapping: one workgroup of NW wavefronts per OCP instance, serial over the
+// stages (the recursion is a chain), the next-stage factorisation P+ / s+ stays
+// resident in LDS for the whole sweep.  Per stage (A = Fxx, Bv = Fvu):
+//
+//   z    = s+ - P+ Fx                                   VALU mat-vec
+//   PB   = P+[:,v] Bv                                   MFMA  (NX x NU, K = NV)
+//   G    = Quu + Bv^T PB[v,:]                           MFMA  (NU x NU, K = NV)
+//   lu   = lu - Bv^T z[v]
+//   PAa  = [P+ ; PB^T] A                                MFMA  ((NX+NU) x NX, K = NX)
+//          rows <  NX : (A^T P+)^T, kept in REGISTERS: the f64 MFMA result layout
+//                       (row = q+4r, col = lane&15) is exactly the A-operand layout of the
+//                       next product, so AtP never touches LDS ("chained MFMA");
+//          rows >= NX : (A^T PB)^T = (H - Qxu)^T  -> H
+//   F    = Qxx + AtP A                                  MFMA, chained from the PAa registers
+//   LLT(G) (wave shuffles), K = -G^-1 H^T, k = -G^-1 lu   VALU, overlaps the F product
+//   GK   = G K ;  F -= K^T GK                           MFMA
+//   P    = (F + F^T)/2 ;  s = A^T z - lx - H k
+//
+// which is the algebra of the reference (brrf.cpp:31-45,78-91) re-associated so that
+// the only dense NX^3 products are two MFMA GEMMs: H = Qxu + A^T (P+[:,v] Bv) instead
+// of (A^T P+)[:,v] Bv, and A^T P+ Fx = A^T (P+ Fx).  Results agree with the reference
+// order to fp64 round-off (tests/test_gpu_parity.py states the tolerance).
+//
+// Switching-constraint (Schur complement, riccati_factorizer.cpp:58-89) and
+// switching-time (STO, :93-175) terms are computed with VALU loops on LDS data:
+// they occur on O(#events) stages per horizon.
+#pragma once
+#include "device_utils.hpp"
+#include "../../include/rtoc.h"
+
+namespace rtoc {
+
+struct BwdArgs {
+  const double* kkt;       // [batch][nstages][kl.stride]
+  double* kkt_rw;          // same buffer, writable (writeback of F,H,G,lu)
+  double* ric;             // [batch][nstages][rl.stride]
+  const rtoc_grid* grid;   // [nstages] (device)
+  uint32_t* status;        // [batch]
+  int nstages;
+  int batch;
+  int writeback;
+  double max_dts0;
+  rtoc_record_layout kl;
+  rtoc_record_layout rl;
+};
+
+template <int NV, int NU, int NS, int NW>
+struct BwdCfg {
+  static constexpr int NX = 2 * NV;
+  static constexpr int NT = 64 * NW;
+  static constexpr int LDP = lds_ld(NX);
+  static constexpr int TNX = (NX + 15) / 16;
+  static constexpr int MA = NX + NU;
+  static constexpr int TMA = (MA + 15) / 16;
+  static constexpr int TNU = (NU + 15) / 16;
+  static constexpr int CNT = (TNX + NW - 1) / NW;  // owned 16-tiles of the state dim per wave
+  static constexpr int NSP = NS > 0 ? NS : 1;
+  static constexpr int pad8(int n) { return (n + 7) & ~7; }
+  // ---- LDS carve (doubles) ----
+  static constexpr int OFF_P = 0;
+  static constexpr int OFF_A = OFF_P + NX * LDP;
+  static constexpr int OFF_PB = OFF_A + NX * LDP;  // contiguous with A: SC scratch = [A | PB]
+  static constexpr int OFF_H = OFF_PB + NU * LDP;
+  static constexpr int OFF_KT = OFF_H + NU * LDP;
+  static constexpr int OFF_GK_OWN = OFF_KT + NU * LDP;
+  // (OFF_GK / OFF_BV / OFF_G / OFF_L / OFF_VEC are defined after the scratch carve below)
+  // ---- switching-constraint scratch, aliased on [A | PB] after the F product ----
+  static constexpr int S_PHIX = OFF_A;                    // NS x NX (ld NS)
+  static constexpr int S_M = S_PHIX + pad8(NSP * NX);     // NS x NX (ld NS)
+  static constexpr int S_PHIU = S_M + pad8(NSP * NX);     // NS x NU (ld NS)
+  static constexpr int S_DGINV = S_PHIU + pad8(NSP * NU); // NS x NU
+  static constexpr int S_SDG = S_DGINV + pad8(NSP * NU);  // SinvDGinv NS x NU
+  static constexpr int S_GINV = S_SDG + pad8(NSP * NU);   // NU x NU
+  static constexpr int S_S = S_GINV + pad8(NU * NU);      // NS x NS
+  static constexpr int S_LS = S_S + pad8(NSP * NSP);      // NS x NS
+  static constexpr int S_PHIT = S_LS + pad8(NSP * NSP);
+  static constexpr int S_PRES = S_PHIT + pad8(NSP);
+  static constexpr int S_MV = S_PRES + pad8(NSP);
+  static constexpr int S_MT = S_MV + pad8(NSP);
+  static constexpr int S_MTN = S_MT + pad8(NSP);
+  static constexpr int S_LSINV = S_MTN + pad8(NSP);
+  static constexpr int S_END = S_LSINV + pad8(NSP);
+  // GK = G K is written after A is dead: host it behind the scratch when it fits (iCub sizes)
+  static constexpr bool GK_IN_SCRATCH = (S_END + pad8(NU * NX) <= OFF_H);
+  static constexpr int OFF_GK = GK_IN_SCRATCH ? S_END : OFF_GK_OWN;
+  static constexpr int OFF_BV = GK_IN_SCRATCH ? OFF_GK_OWN : OFF_GK_OWN + pad8(NU * NX);
+  static constexpr int OFF_G = OFF_BV + pad8(NV * NU);
+  static constexpr int OFF_L = OFF_G + pad8(NU * NU);
+  static constexpr int OFF_VEC = OFF_L + pad8(NU * NU);
+  static constexpr int VX = pad8(NX), VU = pad8(NU);
+  // vectors
+  static constexpr int V_SN = OFF_VEC;          // s+
+  static constexpr int V_FX = V_SN + VX;        // Fx
+  static constexpr int V_LX = V_FX + VX;        // lx
+  static constexpr int V_Z = V_LX + VX;         // z = s+ - P+ Fx
+  static constexpr int V_SNEW = V_Z + VX;       // new s
+  static constexpr int V_PSIN = V_SNEW + VX;    // Psi+
+  static constexpr int V_PHIN = V_PSIN + VX;    // Phi+
+  static constexpr int V_FFX = V_PHIN + VX;     // fx
+  static constexpr int V_HX = V_FFX + VX;       // hx
+  static constexpr int V_Y = V_HX + VX;         // y = P+ fx + Psi+
+  static constexpr int V_PSIX = V_Y + VX;       // psi_x -> Psi
+  static constexpr int V_PHIX = V_PSIX + VX;    // phi_x -> Phi
+  static constexpr int V_PSI = V_PHIX + VX;     // Psi (new)
+  static constexpr int V_PHI = V_PSI + VX;      // Phi (new)
+  static constexpr int V_LU = V_PHI + VX;       // lu'
+  static constexpr int V_KV = V_LU + VU;        // k
+  static constexpr int V_HU = V_KV + VU;
+  static constexpr int V_PSIU = V_HU + VU;
+  static constexpr int V_PHIU = V_PSIU + VU;
+  static constexpr int V_TV = V_PHIU + VU;
+  static constexpr int V_WV = V_TV + VU;
+  static constexpr int V_LINV = V_WV + VU;      // 1/diag(L)
+  static constexpr int V_SCN = V_LINV + VU;     // next scalars [xi,chi,rho,eta,iota]
+  static constexpr int V_SC = V_SCN + 8;        // new scalars + policy
+  static constexpr int V_KSC = V_SC + 8;        // kkt scalars [Qtt,Qtt_prev,h]
+  static constexpr int V_FLAG = V_KSC + 8;      // status accumulation (as double bits)
+  static constexpr int LDS_DOUBLES = V_FLAG + 8;
+  static constexpr int LDS_BYTES = LDS_DOUBLES * 8;
+  static_assert(NS == 0 || S_END <= OFF_H, "switching-constraint scratch must fit in [A|PB]");
+  static_assert(NX + 1 <= NT, "need one thread per state entry plus one");
+};
+
+// In-wave Cholesky of an n x n SPD matrix held in LDS (column-major, ld = LD).
+// Lane i owns row i in registers; pivots / columns travel by wave shuffles.
+// Writes the lower factor back to Ldst (ld LD) and 1/diag to linv.  Returns true on failure.
+template <int NMAX, int LD>
+__device__ __forceinline__ bool wave_llt(const double* __restrict__ A, double* __restrict__ Ldst,
+                                         double* __restrict__ linv, int n, int lane) {
+  double g[NMAX];
+  const int li = lane < n ? lane : 0;
+#pragma unroll
+  for (int k = 0; k < NMAX; ++k) g[k] = (k < n) ? A[li + k * LD] : 0.0;
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < NMAX; ++j) {
+    if (j < n) {
+      const double d = shfl_d(g[j], j);
+      if (!(d > 0.0)) bad = true;
+      const double ljj = sqrt(d);
+      const double inv = 1.0 / ljj;
+      const double lij = (lane == j) ? ljj : g[j] * inv;
+      g[j] = lij;
+      if (lane == j) linv[j] = inv;
+#pragma unroll
+      for (int k = j + 1; k < NMAX; ++k) {
+        if (k < n) {
+          const double lkj = shfl_d(lij, k);
+          g[k] -= lij * lkj;
+        }
+      }
+    }
+  }
+  if (lane < n) {
+#pragma unroll
+    for (int k = 0; k < NMAX; ++k)
+      if (k < n) Ldst[lane + k * LD] = (k <= lane) ? g[k] : 0.0;
+  }
+  return bad;
+}
+
+// x <- (L L^T)^-1 x for one right-hand side held in registers (x[NMAX]); L in LDS.
+template <int NMAX, int LD>
+__device__ __forceinline__ void llt_solve_reg(const double* __restrict__ L,
+                                              const double* __restrict__ linv, double (&x)[NMAX],
+                                              int n) {
+#pragma unroll
+  for (int i = 0; i < NMAX; ++i) {
+    if (i < n) {
+      double v = x[i];
+#pragma unroll
+      for (int k = 0; k < i; ++k) v -= L[i + k * LD] * x[k];
+      x[i] = v * linv[i];
+    }
+  }
+#pragma unroll
+  for (int i = NMAX - 1; i >= 0; --i) {
+    if (i < n) {
+      double v = x[i];
+#pragma unroll
+      for (int k = i + 1; k < NMAX; ++k)
+        if (k < n) v -= L[k + i * LD] * x[k];
+      x[i] = v * linv[i];
+    }
+  }
+}
+
+template <int NV, int NU, int NS, int NW>
+__global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
+  using C = BwdCfg<NV, NU, NS, NW>;
+  constexpr int NX = C::NX, NT = C::NT, LDP = C::LDP, TNX = C::TNX, TMA = C::TMA, TNU = C::TNU,
+                CNT = C::CNT;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* const sP = smem + C::OFF_P;
+  double* const sA = smem + C::OFF_A;
+  double* const sPB = smem + C::OFF_PB;
+  double* const sH = smem + C::OFF_H;
+  double* const sKt = smem + C::OFF_KT;
+  double* const sGK = smem + C::OFF_GK;
+  double* const sBv = smem + C::OFF_BV;
+  double* const sG = smem + C::OFF_G;
+  double* const sL = smem + C::OFF_L;
+
+  const int tid0 = threadIdx.x;
+  const int b = blockIdx.x;
+  if (b >= a.batch) return;
+  int tid = tid0, lane = tid & 63, wave = tid >> 6, li = lane & 15, q = lane >> 4;
+  const int N = a.nstages - 1;
+  const size_t kinst = (size_t)b * a.nstages * a.kl.stride;
+  const size_t rinst = (size_t)b * a.nstages * a.rl.stride;
+  const int* ko = a.kl.off;
+  const int* ro = a.rl.off;
+  unsigned stat = 0;
+
+  // ---- terminal stage: P_N = Qxx_N, s_N = -lx_N (riccati_recursion.cpp:37-38) ----
+  {
+    const double* kr = a.kkt + kinst + (size_t)N * a.kl.stride;
+    double* rr = a.ric + rinst + (size_t)N * a.rl.stride;
+    copy_g2s_mat<NT, NX, NX, LDP>(sP, kr + ko[RTOC_KKT_QXX], tid);
+    if (tid < NX) {
+      const double v = -kr[ko[RTOC_KKT_LX] + tid];
+      smem[C::V_SN + tid] = v;
+      smem[C::V_PSIN + tid] = 0.0;
+      smem[C::V_PHIN + tid] = 0.0;
+      rr[ro[RTOC_RIC_S] + tid] = v;
+    }
+    if (tid < 8) smem[C::V_SCN + tid] = 0.0;
+    __syncthreads();
+    copy_s2g_mat<NT, NX, NX, LDP>(rr + ro[RTOC_RIC_P], sP, tid);
+  }
+
+  for (int st = N - 1; st >= 0; --st) {
+    // Opaque re-definition of the thread index per stage: keeps LLVM's LICM from hoisting the
+    // (hundreds of) per-lane LDS/HBM address computations of the unrolled copy and MFMA loops
+    // out of the stage loop, where they would pin > 256 VGPRs and spill.
+    tid = tid0;
+    asm volatile("" : "+v"(tid));
+    lane = tid & 63;
+    wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    li = lane & 15;
+    q = lane >> 4;
+    const rtoc_grid g = a.grid[st];
+    const rtoc_grid gn = a.grid[st + 1];
+    const bool impact = (g.type == RTOC_GRID_IMPACT);
+    const bool next_lift = (gn.type == RTOC_GRID_LIFT);
+    const int ns = impact ? 0 : g.dims;
+    const bool sto = g.sto != 0, sto_next = g.sto_next != 0;
+    const double* kr = a.kkt + kinst + (size_t)st * a.kl.stride;
+    double* rr = a.ric + rinst + (size_t)st * a.rl.stride;
+
+    // ---- phase transition (riccati_factorizer.cpp:145-175), in place on the LDS copy of
+    //      factorization[st+1]; dispatch per riccati_recursion.cpp:41-70 ----
+    bool do_pt = false;
+    int pol_stage = st;
+    if (impact) {
+      do_pt = (a.grid[st - 1].sto != 0) || sto;
+      pol_stage = st;
+    } else if (next_lift) {
+      do_pt = sto || sto_next;
+      pol_stage = st + 1;
+    }
+    __syncthreads();
+    if (do_pt) {
+      double* pr = a.ric + rinst + (size_t)pol_stage * a.rl.stride;
+      const double xi = smem[C::V_SCN + 0], chi = smem[C::V_SCN + 1], rho = smem[C::V_SCN + 2],
+                   eta = smem[C::V_SCN + 3], iota = smem[C::V_SCN + 4];
+      double isg = 0.0;
+      if (sto_next) {
+        double sgm = xi - 2.0 * chi + rho;
+        const double eps = 1.4901161193847656e-08;  // sqrt(DBL_EPSILON)
+        if ((sgm * a.max_dts0) < fabs(eta - iota) || sgm < eps)
+          sgm = fabs(sgm) + fabs(eta - iota) / a.max_dts0;
+        isg = 1.0 / sgm;
+      }
+      double psi = 0.0, phi = 0.0;
+      if (tid < NX) {
+        psi = smem[C::V_PSIN + tid];
+        phi = smem[C::V_PHIN + tid];
+      }
+      __syncthreads();
+      if (tid < NX) {
+        const double d = psi - phi;
+        double phim = psi;  // Phi_m = Psi
+        if (sto_next) {
+          pr[ro[RTOC_RIC_DTSDX] + tid] = -isg * d;
+          smem[C::V_SN + tid] += isg * d * (eta - iota);
+          phim -= isg * d * (xi - chi);
+        }
+        smem[C::V_PSIN + tid] = 0.0;
+        smem[C::V_PHIN + tid] = phim;
+      }
+      if (tid == 0) {
+        smem[C::V_SCN + 0] = 0.0;
+        smem[C::V_SCN + 1] = 0.0;
+        smem[C::V_SCN + 3] = 0.0;
+        if (sto_next) {
+          pr[ro[RTOC_RIC_SCAL] + RTOC_RIC_SCAL_DTSDTS] = isg * (xi - chi);
+          pr[ro[RTOC_RIC_SCAL] + RTOC_RIC_SCAL_DTS0] = -isg * (eta - iota);
+          smem[C::V_SCN + 2] = xi - isg * (xi - chi) * (xi - chi);
+          smem[C::V_SCN + 4] = eta - isg * (xi - chi) * (eta - iota);
+        } else {
+          smem[C::V_SCN + 2] = xi;
+          smem[C::V_SCN + 4] = eta;
+        }
+      }
+      __syncthreads();
+    }
+
+    // ---- stage data: HBM -> LDS (coalesced 16 B / lane) ----
+    copy_g2s_mat<NT, NX, NX, LDP>(sA, kr + ko[RTOC_KKT_FXX], tid);
+    if (!impact) {
+      copy_g2s_flat<NT>(sBv, kr + ko[RTOC_KKT_FVU], NV * NU, tid);
+      copy_g2s_mat<NT, NX, NU, LDP>(sH, kr + ko[RTOC_KKT_QXU], tid);
+      copy_g2s_flat<NT>(sG, kr + ko[RTOC_KKT_QUU], NU * NU, tid);
+    }
+    if (tid < NX) {
+      smem[C::V_FX + tid] = kr[ko[RTOC_KKT_FX] + tid];
+      smem[C::V_LX + tid] = kr[ko[RTOC_KKT_LX] + tid];
+      if (sto) {
+        smem[C::V_FFX + tid] = kr[ko[RTOC_KKT_FFX] + tid];
+        smem[C::V_HX + tid] = kr[ko[RTOC_KKT_HX] + tid];
+      }
+    }
+    if (!impact && tid < NU) {
+      smem[C::V_LU + tid] = kr[ko[RTOC_KKT_LU] + tid];
+      if (sto) smem[C::V_HU + tid] = kr[ko[RTOC_KKT_HU] + tid];
+    }
+    if (tid < 8) smem[C::V_KSC + tid] = kr[ko[RTOC_KKT_SCAL] + tid];
+    __syncthreads();
+
+    // ---- z = s+ - P+ Fx ;  y = P+ fx + Psi+ (STO) ----
+    if (tid < NX) {
+      double acc = 0.0, accy = 0.0;
+#pragma unroll 4
+      for (int k = 0; k < NX; ++k) {
+        const double p = sP[tid + k * LDP];
+        acc += p * smem[C::V_FX + k];
+        if (sto) accy += p * smem[C::V_FFX + k];
+      }
+      smem[C::V_Z + tid] = smem[C::V_SN + tid] - acc;
+      if (sto) smem[C::V_Y + tid] = accy + smem[C::V_PSIN + tid];
+    }
+
+    if (!impact) {
+      // ---- PB = P+[:,v] Bv  (NX x NU, K = NV) ----
+      {
+        d4 acc[CNT][TNU];
+#pragma unroll
+        for (int c = 0; c < CNT; ++c)
+#pragma unroll
+          for (int t = 0; t < TNU; ++t) acc[c][t] = zero4();
+        const double* pa_ = sP + (wave * 16 + li) + (NV + q) * LDP;  // P+[i][NV+k]
+        const double* pb_ = sBv + q + li * NV;                        // Bv[k][u]
+#pragma unroll
+        for (int ks = 0; ks < (NV + 3) / 4; ++ks) {
+          const bool kok = (ks * 4 + 3 < NV) || (ks * 4 + q < NV);
+          double bv[TNU];
+#pragma unroll
+          for (int t = 0; t < TNU; ++t) {
+            const double v = pb_[ks * 4 + t * 16 * NV];
+            bv[t] = (kok && (t * 16 + li < NU)) ? v : 0.0;
+          }
+#pragma unroll
+          for (int c = 0; c < CNT; ++c) {
+            const double v = pa_[c * NW * 16 + ks * 4 * LDP];
+            const double av = (kok && ((wave + c * NW) * 16 + li < NX)) ? v : 0.0;
+#pragma unroll
+            for (int t = 0; t < TNU; ++t) acc[c][t] = mfma16(av, bv[t], acc[c][t]);
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < CNT; ++c) {
+          const int tm = wave + c * NW;
+#pragma unroll
+          for (int t = 0; t < TNU; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int i = tm * 16 + drow(q, r), u = t * 16 + li;
+              if (i < NX && u < NU) sPB[i + u * LDP] = acc[c][t][r];
+            }
+        }
+      }
+      __syncthreads();
+      // ---- G = Quu + Bv^T PB[v,:] (wave 0) ; lu' = lu - Bv^T z[v] ----
+      if (wave == 0) {
+        d4 acc[TNU][TNU];
+#pragma unroll
+        for (int t0 = 0; t0 < TNU; ++t0)
+#pragma unroll
+          for (int t1 = 0; t1 < TNU; ++t1) acc[t0][t1] = zero4();
+        const double* pa_ = sBv + q + li * NV;             // Bv^T[u][k] = Bv[k][u]
+        const double* pb_ = sPB + NV + q + li * LDP;       // PB[NV+k][u]
+#pragma unroll
+        for (int ks = 0; ks < (NV + 3) / 4; ++ks) {
+          const bool kok = (ks * 4 + 3 < NV) || (ks * 4 + q < NV);
+          double av[TNU], bv[TNU];
+#pragma unroll
+          for (int t = 0; t < TNU; ++t) {
+            const bool ok = kok && (t * 16 + li < NU);
+            const double va = pa_[ks * 4 + t * 16 * NV];
+            const double vb = pb_[ks * 4 + t * 16 * LDP];
+            av[t] = ok ? va : 0.0;
+            bv[t] = ok ? vb : 0.0;
+          }
+#pragma unroll
+          for (int t0 = 0; t0 < TNU; ++t0)
+#pragma unroll
+            for (int t1 = 0; t1 < TNU; ++t1) acc[t0][t1] = mfma16(av[t0], bv[t1], acc[t0][t1]);
+        }
+#pragma unroll
+        for (int t0 = 0; t0 < TNU; ++t0)
+#pragma unroll
+          for (int t1 = 0; t1 < TNU; ++t1)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int u0 = t0 * 16 + drow(q, r), u1 = t1 * 16 + li;
+              if (u0 < NU && u1 < NU) sG[u0 + u1 * NU] += acc[t0][t1][r];
+            }
+      }
+      if (tid < NU) {
+        double acc = 0.0, ap = 0.0, aph = 0.0;
+#pragma unroll 2
+        for (int k = 0; k < NV; ++k) {
+          const double bv = sBv[k + tid * NV];
+          acc += bv * smem[C::V_Z + NV + k];
+          if (sto) {
+            ap += bv * smem[C::V_Y + NV + k];
+            if (sto_next) aph += bv * smem[C::V_PHIN + NV + k];
+          }
+        }
+        smem[C::V_LU + tid] -= acc;
+        if (sto) {
+          smem[C::V_PSIU + tid] = ap + smem[C::V_HU + tid];  // psi_u (brrf.cpp:53-57)
+          smem[C::V_PHIU + tid] = sto_next ? aph : 0.0;      // phi_u (:58-65)
+        }
+      }
+    } else {
+      // impact grid: no control; zero the augmented rows so that they add nothing
+      for (int e = tid; e < NU * LDP; e += NT) sPB[e] = 0.0;
+    }
+    __syncthreads();
+
+    // ---- PAa = [P+ ; PB^T] A, this wave owns column tiles tn = wave + c*NW ----
+    d4 pa[TMA][CNT];
+#pragma unroll
+    for (int tm = 0; tm < TMA; ++tm)
+#pragma unroll
+      for (int c = 0; c < CNT; ++c) pa[tm][c] = zero4();
+    {
+      // per-lane A-operand addressing: row i of [P+ ; PB^T].  Tiles that lie entirely in P+ or
+      // entirely in PB^T use compile-time strides; only the (at most one) mixed tile selects per lane.
+      const double* pb_ = sA + q + (wave * 16 + li) * LDP;  // A[k][j], j in the owned column tile
+#pragma unroll
+      for (int ks = 0; ks < (NX + 3) / 4; ++ks) {
+        const bool kok = (ks * 4 + 3 < NX) || (ks * 4 + q < NX);
+        double av[TMA], bv[CNT];
+#pragma unroll
+        for (int tm = 0; tm < TMA; ++tm) {
+          const int i = tm * 16 + li;
+          double v;
+          if (tm * 16 + 15 < NX) {
+            v = sP[li + q * LDP + tm * 16 + ks * 4 * LDP];  // P+[i][k]
+          } else if (tm * 16 >= NX) {
+            v = sPB[q + li * LDP + (tm * 16 - NX) * LDP + ks * 4];  // PB[k][i-NX]
+            if (tm * 16 + 15 >= NX + NU) v = (i < NX + NU) ? v : 0.0;
+          } else {
+            const double vp = sP[li + q * LDP + tm * 16 + ks * 4 * LDP];
+            const double vb = sPB[q + li * LDP + (tm * 16 - NX) * LDP + ks * 4];
+            v = (i < NX) ? vp : vb;
+            if (tm * 16 + 15 >= NX + NU) v = (i < NX + NU) ? v : 0.0;
+          }
+          av[tm] = kok ? v : 0.0;
+        }
+#pragma unroll
+        for (int c = 0; c < CNT; ++c) {
+          const double v = pb_[ks * 4 + c * NW * 16 * LDP];
+          bv[c] = (kok && ((wave + c * NW) * 16 + li < NX)) ? v : 0.0;
+        }
+#pragma unroll
+        for (int tm = 0; tm < TMA; ++tm)
+#pragma unroll
+          for (int c = 0; c < CNT; ++c) pa[tm][c] = mfma16(av[tm], bv[c], pa[tm][c]);
+      }
+    }
+    // H += (A^T PB)  : rows >= NX of PAa hold (H - Qxu)^T
+    if (!impact) {
+#pragma unroll
+      for (int tm = 0; tm < TMA; ++tm)
+#pragma unroll
+        for (int c = 0; c < CNT; ++c)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = tm * 16 + drow(q, r);
+            const int j = (wave + c * NW) * 16 + li;
+            if (tm * 16 + 4 * r + 3 >= NX) {  // compile-time prune of pure-P register groups
+              if (row >= NX && row < NX + NU && j < NX) sH[j + (row - NX) * LDP] += pa[tm][c][r];
+            }
+          }
+    }
+
+    // ---- s-vector part that needs A: w = A^T z  (and STO: psi_x, phi_x) ----
+    if (tid < NX) {
+      double acc = 0.0, ap = 0.0, aph = 0.0;
+#pragma unroll 4
+      for (int k = 0; k < NX; ++k) {
+        const double av = sA[k + tid * LDP];
+        acc += av * smem[C::V_Z + k];
+        if (sto) {
+          if (!impact) ap += av * smem[C::V_Y + k];
+          aph += av * smem[C::V_PHIN + k];
+        }
+      }
+      smem[C::V_SNEW + tid] = acc - smem[C::V_LX + tid];
+      if (sto) {
+        if (!impact) {
+          smem[C::V_PSIX + tid] = ap + smem[C::V_HX + tid];  // psi_x
+          smem[C::V_PHIX + tid] = sto_next ? aph : 0.0;      // phi_x
+        } else {
+          smem[C::V_PHIX + tid] = aph;  // impact: Phi = A^T Phi+ (brrf.cpp:166)
+        }
+      }
+    }
+
+    // ---- F = Qxx + AtP A, chained: A-operand = PAa registers (row-tile = owned column tile) ----
+    d4 f[CNT][TNX];
+    {
+      const double* qxx = kr + ko[RTOC_KKT_QXX];
+#pragma unroll
+      for (int c = 0; c < CNT; ++c)
+#pragma unroll
+        for (int t = 0; t < TNX; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = (wave + c * NW) * 16 + drow(q, r), j = t * 16 + li;
+            f[c][t][r] = (i < NX && j < NX) ? qxx[i + j * NX] : 0.0;
+          }
+      const double* pbf_ = sA + q + li * LDP;  // A[k][j]
+#pragma unroll
+      for (int tm = 0; tm < TMA; ++tm)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (tm * 16 + 4 * r < NX) {  // register group holds at least one P row (k index)
+            const bool kok = (tm * 16 + 4 * r + 3 < NX) || (tm * 16 + 4 * r + q < NX);
+            double bv[TNX];
+#pragma unroll
+            for (int t = 0; t < TNX; ++t) {
+              const double v = pbf_[tm * 16 + 4 * r + t * 16 * LDP];
+              bv[t] = (kok && (t * 16 + li < NX)) ? v : 0.0;
+            }
+#pragma unroll
+            for (int c = 0; c < CNT; ++c) {
+              const double av = kok ? pa[tm][c][r] : 0.0;
+#pragma unroll
+              for (int t = 0; t < TNX; ++t) f[c][t] = mfma16(av, bv[t], f[c][t]);
+            }
+          }
+        }
+    }
+    __syncthreads();  // H complete; sA / sPB / sP(+) no longer read by MFMA after this point
+
+    if (impact) {
+      // riccati_factorizer.cpp:178-197 -- no policy
+    } else {
+      // ---- LLT(G) by wave 0 (riccati_factorizer.cpp:49) ----
+      if (wave == 0) {
+        if (wave_llt<NU, NU>(sG, sL, smem + C::V_LINV, NU, lane)) stat |= RTOC_STAT_QUU_NOT_SPD;
+      }
+      __syncthreads();
+      if (ns == 0) {
+        // K = -G^-1 H^T, k = -G^-1 lu   (:55-56); thread t < NX owns column t, thread NX owns k
+        if (tid <= NX) {
+          double x[NU];
+#pragma unroll
+          for (int u = 0; u < NU; ++u)
+            x[u] = (tid < NX) ? sH[tid + u * LDP] : smem[C::V_LU + u];
+          llt_solve_reg<NU, NU>(sL, smem + C::V_LINV, x, NU);
+          bool bad = false;
+#pragma unroll
+          for (int u = 0; u < NU; ++u) {
+            bad = bad || is_bad(x[u]);
+            if (tid < NX)
+              sKt[tid + u * LDP] = -x[u];
+            else
+              smem[C::V_KV + u] = -x[u];
+          }
+          if (bad) stat |= RTOC_STAT_NAN;
+          if (sto && tid == NX) {
+            // T = -G^-1 psi_u ; W = -G^-1 phi_u  (:125-130)
+            double t[NU];
+#pragma unroll
+            for (int u = 0; u < NU; ++u) t[u] = smem[C::V_PSIU + u];
+            llt_solve_reg<NU, NU>(sL, smem + C::V_LINV, t, NU);
+#pragma unroll
+            for (int u = 0; u < NU; ++u) smem[C::V_TV + u] = -t[u];
+            if (sto_next) {
+#pragma unroll
+              for (int u = 0; u < NU; ++u) t[u] = smem[C::V_PHIU + u];
+              llt_solve_reg<NU, NU>(sL, smem + C::V_LINV, t, NU);
+#pragma unroll
+              for (int u = 0; u < NU; ++u) smem[C::V_WV + u] = -t[u];
+            } else {
+#pragma unroll
+              for (int u = 0; u < NU; ++u) smem[C::V_WV + u] = 0.0;
+            }
+          }
+        }
+      } else if (NS > 0) {
+        // ---- Schur complement with the switching constraint (:58-77), VALU on LDS scratch ----
+        double* const cPhix = smem + C::S_PHIX;
+        double* const cM = smem + C::S_M;
+        double* const cPhiu = smem + C::S_PHIU;
+        double* const cDG = smem + C::S_DGINV;
+        double* const cSDG = smem + C::S_SDG;
+        double* const cGinv = smem + C::S_GINV;
+        double* const cS = smem + C::S_S;
+        double* const cLs = smem + C::S_LS;
+        constexpr int LN = C::NSP;
+        for (int e = tid; e < ns * NX; e += NT) {
+          const int l = e % ns, j = e / ns;
+          cPhix[l + j * LN] = kr[ko[RTOC_KKT_PHIX] + l + j * NS];
+        }
+        for (int e = tid; e < ns * NU; e += NT) {
+          const int l = e % ns, u = e / ns;
+          cPhiu[l + u * LN] = kr[ko[RTOC_KKT_PHIU] + l + u * NS];
+        }
+        if (tid < ns) {
+          smem[C::S_PHIT + tid] = kr[ko[RTOC_KKT_PHIT] + tid];
+          smem[C::S_PRES + tid] = kr[ko[RTOC_KKT_PRES] + tid];
+        }
+        __syncthreads();
+        // Ginv = G^-1 (thread t<NU: column t) ; DGinv^T = G^-1 Phiu^T (thread NU+l: row l)
+        if (tid < NU + ns) {
+          double x[NU];
+          const bool isg = tid < NU;
+          const int l = tid - NU;
+#pragma unroll
+          for (int u = 0; u < NU; ++u) x[u] = isg ? (u == tid ? 1.0 : 0.0) : cPhiu[l + u * LN];
+          llt_solve_reg<NU, NU>(sL, smem + C::V_LINV, x, NU);
+#pragma unroll
+          for (int u = 0; u < NU; ++u) {
+            if (isg)
+              cGinv[u + tid * NU] = x[u];
+            else
+              cDG[l + u * LN] = x[u];
+          }
+        }
+        __syncthreads();
+        // S = DGinv Phiu^T
+        for (int e = tid; e < ns * ns; e += NT) {
+          const int i = e % ns, j = e / ns;
+          double acc = 0.0;
+          for (int u = 0; u < NU; ++u) acc += cDG[i + u * LN] * cPhiu[j + u * LN];
+          cS[i + j * LN] = acc;
+        }
+        __syncthreads();
+        if (wave == 0) {
+          if (wave_llt<C::NSP, C::NSP>(cS, cLs, smem + C::S_LSINV, ns, lane))
+            stat |= RTOC_STAT_S_NOT_SPD;
+        }
+        __syncthreads();
+        // SinvDGinv = S^-1 DGinv (thread u<NU: column u) ; M0 = S^-1 Phix (thread NU+j: column j)
+        // m0 = S^-1 Pres, mt0 = S^-1 Phit handled by two more threads.
+        for (int t = tid; t < NU + NX + 2; t += NT) {
+          double x[C::NSP];
+#pragma unroll
+          for (int l = 0; l < C::NSP; ++l) {
+            double v = 0.0;
+            if (l < ns) {
+              if (t < NU)
+                v = cDG[l + t * LN];
+              else if (t < NU + NX)
+                v = cPhix[l + (t - NU) * LN];
+              else if (t == NU + NX)
+                v = smem[C::S_PRES + l];
+              else
+                v = smem[C::S_PHIT + l];
+            }
+            x[l] = v;
+          }
+          llt_solve_reg<C::NSP, C::NSP>(cLs, smem + C::S_LSINV, x, ns);
+#pragma unroll
+          for (int l = 0; l < C::NSP; ++l) {
+            if (l < ns) {
+              if (t < NU)
+                cSDG[l + t * LN] = x[l];
+              else if (t < NU + NX)
+                cM[l + (t - NU) * LN] = x[l];
+              else if (t == NU + NX)
+                smem[C::S_MV + l] = x[l];
+              else
+                smem[C::S_MT + l] = x[l];
+            }
+          }
+        }
+        __syncthreads();
+        // Ginv -= SinvDGinv^T DGinv
+        for (int e = tid; e < NU * NU; e += NT) {
+          const int i = e % NU, j = e / NU;
+          double acc = 0.0;
+          for (int l = 0; l < ns; ++l) acc += cSDG[l + i * LN] * cDG[l + j * LN];
+          cGinv[i + j * NU] -= acc;
+        }
+        __syncthreads();
+        // K = -Ginv H^T - SinvDGinv^T Phix ; M -= SinvDGinv H^T      (:67-72)
+        for (int e = tid; e < NX * NU; e += NT) {
+          const int j = e % NX, u = e / NX;
+          double acc = 0.0;
+          for (int l = 0; l < NU; ++l) acc += cGinv[u + l * NU] * sH[j + l * LDP];
+          for (int l = 0; l < ns; ++l) acc += cSDG[l + u * LN] * cPhix[l + j * LN];
+          sKt[j + u * LDP] = -acc;
+          if (is_bad(acc)) stat |= RTOC_STAT_NAN;
+        }
+        for (int e = tid; e < NX * ns; e += NT) {
+          const int l = e % ns, j = e / ns;
+          double acc = 0.0;
+          for (int u = 0; u < NU; ++u) acc += cSDG[l + u * LN] * sH[j + u * LDP];
+          const double v = cM[l + j * LN] - acc;  // each (l,j) owned by one thread
+          cM[l + j * LN] = v;
+          if (is_bad(v)) stat |= RTOC_STAT_NAN;
+        }
+        // k = -Ginv lu - SinvDGinv^T P ; m = S^-1 P - SinvDGinv lu     (:69-74)
+        if (tid < NU) {
+          double acc = 0.0;
+          for (int l = 0; l < NU; ++l) acc += cGinv[tid + l * NU] * smem[C::V_LU + l];
+          for (int l = 0; l < ns; ++l) acc += cSDG[l + tid * LN] * smem[C::S_PRES + l];
+          smem[C::V_KV + tid] = -acc;
+          if (is_bad(acc)) stat |= RTOC_STAT_NAN;
+          if (sto) {
+            // T = -Ginv psi_u - SinvDGinv^T Phit ; W = -Ginv phi_u   (:110-115)
+            double at = 0.0, aw = 0.0;
+            for (int l = 0; l < NU; ++l) {
+              at += cGinv[tid + l * NU] * smem[C::V_PSIU + l];
+              aw += cGinv[tid + l * NU] * smem[C::V_PHIU + l];
+            }
+            for (int l = 0; l < ns; ++l) at += cSDG[l + tid * LN] * smem[C::S_PHIT + l];
+            smem[C::V_TV + tid] = -at;
+            smem[C::V_WV + tid] = sto_next ? -aw : 0.0;
+          }
+        } else if (tid >= 64 * (NW - 1) + 32 && tid < 64 * (NW - 1) + 32 + ns) {
+          const int l = tid - (64 * (NW - 1) + 32);
+          double acc = 0.0, amt = 0.0, amn = 0.0;
+          for (int u = 0; u < NU; ++u) {
+            const double sd = cSDG[l + u * LN];
+            acc += sd * smem[C::V_LU + u];
+            if (sto) {
+              amt += sd * smem[C::V_PSIU + u];
+              amn += sd * smem[C::V_PHIU + u];
+            }
+          }
+          const double mv = smem[C::S_MV + l] - acc;
+          smem[C::S_MV + l] = mv;
+          if (is_bad(mv)) stat |= RTOC_STAT_NAN;
+          if (sto) {
+            smem[C::S_MT + l] = smem[C::S_MT + l] - amt;   // mt      (:116-117)
+            smem[C::S_MTN + l] = sto_next ? -amn : 0.0;    // mt_next (:118-123)
+          }
+        }
+        __syncthreads();
+        // write M, m (+mt, mt_next) ; s -= Phix^T m                    (:88)
+        double* mg = rr + ro[RTOC_RIC_M];
+        for (int e = tid; e < ns * NX; e += NT) {
+          const int l = e % ns, j = e / ns;
+          mg[l + j * NS] = cM[l + j * LN];
+        }
+        if (tid < ns) {
+          rr[ro[RTOC_RIC_MV] + tid] = smem[C::S_MV + tid];
+          if (sto) {
+            rr[ro[RTOC_RIC_MT] + tid] = smem[C::S_MT + tid];
+            rr[ro[RTOC_RIC_MTN] + tid] = smem[C::S_MTN + tid];
+          }
+        }
+        if (tid < NX) {
+          double acc = 0.0;
+          for (int l = 0; l < ns; ++l) acc += cPhix[l + tid * LN] * smem[C::S_MV + l];
+          smem[C::V_SNEW + tid] -= acc;
+        }
+      }
+      __syncthreads();
+
+      // ---- GK = G K (+ 2 Phiu^T M on switching-constraint grids, which folds
+      //      P -= KtDtM + KtDtM^T (:84-87) into the symmetrised F - K^T GK) ----
+      {
+        d4 acc[TNU][CNT];
+#pragma unroll
+        for (int t = 0; t < TNU; ++t)
+#pragma unroll
+          for (int c = 0; c < CNT; ++c) acc[t][c] = zero4();
+        // original Quu + BtP Fvu is in sG (wave_llt wrote the factor to sL, sG untouched)
+        const double* pa_ = sG + li + q * NU;                     // G[u][k]
+        const double* pb_ = sKt + (wave * 16 + li) + q * LDP;     // K[k][j] = Kt[j][k]
+#pragma unroll
+        for (int ks = 0; ks < (NU + 3) / 4; ++ks) {
+          const bool kok = (ks * 4 + 3 < NU) || (ks * 4 + q < NU);
+          double av[TNU], bv[CNT];
+#pragma unroll
+          for (int t = 0; t < TNU; ++t) {
+            const double v = pa_[t * 16 + ks * 4 * NU];
+            av[t] = (kok && (t * 16 + li < NU)) ? v : 0.0;
+          }
+#pragma unroll
+          for (int c = 0; c < CNT; ++c) {
+            const double v = pb_[c * NW * 16 + ks * 4 * LDP];
+            bv[c] = (kok && ((wave + c * NW) * 16 + li < NX)) ? v : 0.0;
+          }
+#pragma unroll
+          for (int t = 0; t < TNU; ++t)
+#pragma unroll
+            for (int c = 0; c < CNT; ++c) acc[t][c] = mfma16(av[t], bv[c], acc[t][c]);
+        }
+#pragma unroll
+        for (int t = 0; t < TNU; ++t)
+#pragma unroll
+          for (int c = 0; c < CNT; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int u = t * 16 + drow(q, r), j = (wave + c * NW) * 16 + li;
+              if (u < NU && j < NX) {
+                double v = acc[t][c][r];
+                if (NS > 0 && ns > 0) {
+                  double dtm = 0.0;
+                  for (int l = 0; l < ns; ++l)
+                    dtm += smem[C::S_PHIU + l + u * C::NSP] * smem[C::S_M + l + j * C::NSP];
+                  v += 2.0 * dtm;
+                }
+                sGK[u + j * NU] = v;
+              }
+            }
+      }
+      __syncthreads();
+      // ---- F -= K^T GK ----
+      {
+        const double* pa_ = sKt + (wave * 16 + li) + q * LDP;  // K^T[i][k] = Kt[i][k]
+        const double* pb_ = sGK + q + li * NU;                 // GK[k][j]
+#pragma unroll
+        for (int ks = 0; ks < (NU + 3) / 4; ++ks) {
+          const bool kok = (ks * 4 + 3 < NU) || (ks * 4 + q < NU);
+          double av[CNT], bv[TNX];
+#pragma unroll
+          for (int c = 0; c < CNT; ++c) {
+            const double v = pa_[c * NW * 16 + ks * 4 * LDP];
+            av[c] = (kok && ((wave + c * NW) * 16 + li < NX)) ? -v : 0.0;
+          }
+#pragma unroll
+          for (int t = 0; t < TNX; ++t) {
+            const double v = pb_[ks * 4 + t * 16 * NU];
+            bv[t] = (kok && (t * 16 + li < NX)) ? v : 0.0;
+          }
+#pragma unroll
+          for (int c = 0; c < CNT; ++c)
+#pragma unroll
+            for (int t = 0; t < TNX; ++t) f[c][t] = mfma16(av[c], bv[t], f[c][t]);
+        }
+      }
+      // s -= H k  (brrf.cpp:90)
+      if (tid < NX) {
+        double acc = 0.0;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) acc += sH[tid + u * LDP] * smem[C::V_KV + u];
+        smem[C::V_SNEW + tid] -= acc;
+      }
+    }
+
+    // ---- optional write-back of the mutated KKT blocks (reference in-place semantics) ----
+    if (a.writeback) {
+      double* kw = a.kkt_rw + kinst + (size_t)st * a.kl.stride;
+#pragma unroll
+      for (int c = 0; c < CNT; ++c)
+#pragma unroll
+        for (int t = 0; t < TNX; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = (wave + c * NW) * 16 + drow(q, r), j = t * 16 + li;
+            if (i < NX && j < NX) kw[ko[RTOC_KKT_QXX] + i + j * NX] = f[c][t][r];
+          }
+      if (!impact) {
+        copy_s2g_mat<NT, NX, NU, LDP>(kw + ko[RTOC_KKT_QXU], sH, tid);
+        copy_s2g_flat<NT>(kw + ko[RTOC_KKT_QUU], sG, NU * NU, tid);
+        if (tid < NU) kw[ko[RTOC_KKT_LU] + tid] = smem[C::V_LU + tid];
+      }
+    }
+
+    // ---- F -> sP, symmetrise: P = (F + F^T)/2 (brrf.cpp:85) ----
+#pragma unroll
+    for (int c = 0; c < CNT; ++c)
+#pragma unroll
+      for (int t = 0; t < TNX; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = (wave + c * NW) * 16 + drow(q, r), j = t * 16 + li;
+          if (i < NX && j < NX) sP[i + j * LDP] = f[c][t][r];
+        }
+    __syncthreads();
+    for (int e = tid; e < NX * NX; e += NT) {
+      const int i = e % NX, j = e / NX;
+      if (i < j) {
+        const double p = 0.5 * (sP[i + j * LDP] + sP[j + i * LDP]);
+        sP[i + j * LDP] = p;
+        sP[j + i * LDP] = p;
+      }
+    }
+
+    // ---- STO scalars / vectors (brrf.cpp:94-143, riccati_factorizer.cpp:93-142) ----
+    if (sto && !impact) {
+      // Psi = psi_x + K^T psi_u ; Phi = phi_x + K^T phi_u
+      if (tid < NX) {
+        double ap = 0.0, aph = 0.0;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+          const double kt = sKt[tid + u * LDP];
+          ap += kt * smem[C::V_PSIU + u];
+          aph += kt * smem[C::V_PHIU + u];
+        }
+        double psi = smem[C::V_PSIX + tid] + ap;
+        if (NS > 0 && ns > 0) {
+          double am = 0.0;
+          for (int l = 0; l < ns; ++l) am += smem[C::S_M + l + tid * C::NSP] * smem[C::S_PHIT + l];
+          psi += am;  // Psi += M^T Phit (:136)
+        }
+        smem[C::V_PSI + tid] = psi;
+        smem[C::V_PHI + tid] = sto_next ? smem[C::V_PHIX + tid] + aph : 0.0;
+      }
+      if (tid == 0) {
+        // xi, chi, rho, eta, iota  (brrf.cpp:110-142).  y = P+ fx + Psi+, z = s+ - P+ Fx.
+        double fPf = 0.0, psif = 0.0, phif = 0.0, fz = 0.0, psiF = 0.0, phiF = 0.0;
+#pragma unroll 1
+        for (int k = 0; k < NX; ++k) {
+          const double fxk = smem[C::V_FFX + k], Fxk = smem[C::V_FX + k];
+          const double psin = smem[C::V_PSIN + k], phin = smem[C::V_PHIN + k];
+          fPf += fxk * (smem[C::V_Y + k] - psin);
+          psif += psin * fxk;
+          phif += phin * fxk;
+          fz += fxk * smem[C::V_Z + k];
+          psiF += psin * Fxk;
+          phiF += phin * Fxk;
+        }
+        double Tpsi = 0.0, Tphi = 0.0, Wphi = 0.0, psik = 0.0, phik = 0.0;
+#pragma unroll 1
+        for (int u = 0; u < NU; ++u) {
+          Tpsi += smem[C::V_TV + u] * smem[C::V_PSIU + u];
+          Tphi += smem[C::V_TV + u] * smem[C::V_PHIU + u];
+          Wphi += smem[C::V_WV + u] * smem[C::V_PHIU + u];
+          psik += smem[C::V_PSIU + u] * smem[C::V_KV + u];
+          phik += smem[C::V_PHIU + u] * smem[C::V_KV + u];
+        }
+        double xi = fPf + smem[C::V_KSC + 0] + 2.0 * psif + Tpsi + smem[C::V_SCN + 0];
+        double chi = 0.0, rho = 0.0, iota = 0.0;
+        if (sto_next) {
+          chi = smem[C::V_KSC + 1] + phif + Tphi + smem[C::V_SCN + 1];
+          rho = Wphi + smem[C::V_SCN + 2];
+          iota = phiF + phik + smem[C::V_SCN + 4];
+        }
+        double eta = -fz + smem[C::V_KSC + 2] + psiF + psik + smem[C::V_SCN + 3];
+        if (NS > 0 && ns > 0) {
+          for (int l = 0; l < ns; ++l) {
+            const double pt = smem[C::S_PHIT + l];
+            xi += smem[C::S_MT + l] * pt;
+            if (sto_next) chi += smem[C::S_MTN + l] * pt;
+            eta += smem[C::S_MV + l] * pt;
+          }
+        }
+        smem[C::V_SC + 0] = xi;
+        smem[C::V_SC + 1] = chi;
+        smem[C::V_SC + 2] = rho;
+        smem[C::V_SC + 3] = eta;
+        smem[C::V_SC + 4] = iota;
+      }
+    } else if (sto && impact) {
+      // brrf.cpp:160-174
+      if (tid < NX) {
+        smem[C::V_PSI + tid] = 0.0;
+        smem[C::V_PHI + tid] = smem[C::V_PHIX + tid];
+      }
+      if (tid == 0) {
+        double phiF = 0.0;
+#pragma unroll 1
+        for (int k = 0; k < NX; ++k) phiF += smem[C::V_PHIN + k] * smem[C::V_FX + k];
+        smem[C::V_SC + 0] = 0.0;
+        smem[C::V_SC + 1] = 0.0;
+        smem[C::V_SC + 2] = smem[C::V_SCN + 2];
+        smem[C::V_SC + 3] = 0.0;
+        smem[C::V_SC + 4] = smem[C::V_SCN + 4] + phiF;
+      }
+    } else {
+      // !sto: Psi = 0, xi = chi = eta = 0 (riccati_factorizer.cpp:99-105); Phi/rho/iota are
+      // never read downstream in that case, they are zeroed for determinism.
+      if (tid < NX) {
+        smem[C::V_PSI + tid] = 0.0;
+        smem[C::V_PHI + tid] = 0.0;
+      }
+      if (tid < 8) smem[C::V_SC + tid] = 0.0;
+    }
+    __syncthreads();
+
+    // ---- results -> HBM; roll the LDS "next" state ----
+    copy_s2g_mat<NT, NX, NX, LDP>(rr + ro[RTOC_RIC_P], sP, tid);
+    if (!impact) {
+      // K row-major nu x nx == Kt column-major nx x nu
+      copy_s2g_mat<NT, NX, NU, LDP>(rr + ro[RTOC_RIC_K], sKt, tid);
+      if (tid < NU) {
+        rr[ro[RTOC_RIC_KV] + tid] = smem[C::V_KV + tid];
+        if (sto) {
+          rr[ro[RTOC_RIC_T] + tid] = smem[C::V_TV + tid];
+          rr[ro[RTOC_RIC_W] + tid] = smem[C::V_WV + tid];
+          rr[ro[RTOC_RIC_PSIU] + tid] = smem[C::V_PSIU + tid];
+          rr[ro[RTOC_RIC_PHIU] + tid] = smem[C::V_PHIU + tid];
+        }
+      }
+    }
+    if (tid < NX) {
+      const double sv = smem[C::V_SNEW + tid];
+      const double psi = smem[C::V_PSI + tid], phi = smem[C::V_PHI + tid];
+      rr[ro[RTOC_RIC_S] + tid] = sv;
+      rr[ro[RTOC_RIC_PSI] + tid] = psi;
+      rr[ro[RTOC_RIC_PHI] + tid] = phi;
+      if (sto && !impact) {
+        rr[ro[RTOC_RIC_PSIX] + tid] = smem[C::V_PSIX + tid];
+        rr[ro[RTOC_RIC_PHIX] + tid] = smem[C::V_PHIX + tid];
+      }
+      smem[C::V_SN + tid] = sv;
+      smem[C::V_PSIN + tid] = psi;
+      smem[C::V_PHIN + tid] = phi;
+    }
+    if (tid < 5) {
+      const double v = smem[C::V_SC + tid];
+      rr[ro[RTOC_RIC_SCAL] + tid] = v;
+      smem[C::V_SCN + tid] = v;
+    }
+  }
+
+  // ---- grid[0].sto: trailing phase transition writes sto_policy_[0] (riccati_recursion.cpp:75-79) ----
+  __syncthreads();
+  {
+    const rtoc_grid g0 = a.grid[0];
+    if (g0.sto && g0.sto_next) {
+      double* pr = a.ric + rinst;
+      const double xi = smem[C::V_SCN + 0], chi = smem[C::V_SCN + 1], rho = smem[C::V_SCN + 2],
+                   eta = smem[C::V_SCN + 3], iota = smem[C::V_SCN + 4];
+      double sgm = xi - 2.0 * chi + rho;
+      const double eps = 1.4901161193847656e-08;
+      if ((sgm * a.max_dts0) < fabs(eta - iota) || sgm < eps)
+        sgm = fabs(sgm) + fabs(eta - iota) / a.max_dts0;
+      const double isg = 1.0 / sgm;
+      if (tid < NX)
+        pr[ro[RTOC_RIC_DTSDX] + tid] = -isg * (smem[C::V_PSIN + tid] - smem[C::V_PHIN + tid]);
+      if (tid == 0) {
+        pr[ro[RTOC_RIC_SCAL] + RTOC_RIC_SCAL_DTSDTS] = isg * (xi - chi);
+        pr[ro[RTOC_RIC_SCAL] + RTOC_RIC_SCAL_DTS0] = -isg * (eta - iota);
+      }
+    }
+  }
+  if (stat) atomicOr(&a.status[b], stat);
+}
+
+}  // namespace rtoc

@@ -1,0 +1,531 @@
+// rtoc_capi.hip -- implementation of the C ABI declared in include/rtoc.h.
+// Context, HBM buffers, kernel dispatch by problem dimensions.  No CPU fallback.
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/rtoc.h"
+#include "condense.hpp"
+#include "riccati_backward.hpp"
+#include "riccati_forward.hpp"
+
+using namespace rtoc;
+
+#define HIP_TRY(expr)                       \
+  do {                                      \
+    hipError_t e_ = (expr);                 \
+    if (e_ != hipSuccess) {                 \
+      ctx_set_err(e_, __LINE__);            \
+      return RTOC_ERR_HIP;                  \
+    }                                       \
+  } while (0)
+
+static thread_local char g_errbuf[256] = "";
+static void ctx_set_err(hipError_t e, int line) {
+  snprintf(g_errbuf, sizeof(g_errbuf), "HIP error %d (%s) at rtoc_capi.hip:%d", (int)e,
+           hipGetErrorString(e), line);
+}
+
+// ---- kernel table -------------------------------------------------------------------
+typedef void (*bwd_fn)(BwdArgs);
+typedef void (*fwd_fn)(FwdArgs);
+typedef void (*fill_fn)(FillArgs);
+typedef void (*cond_fn)(CondArgs);
+typedef void (*expd_fn)(ExpArgs);
+
+struct KernelSet {
+  int nv, nu, ns;
+  int nvariants;
+  bwd_fn bwd[2];
+  int bwd_waves[2];
+  int bwd_lds[2];
+  fwd_fn fwd;
+  int fwd_threads;
+  fill_fn fill;
+  cond_fn cond;
+  int cond_threads, cond_lds;
+  expd_fn expd;
+  int expd_threads;
+};
+
+template <int NV, int NU, int NS, int NW0, int NW1>
+static KernelSet make_set() {
+  KernelSet k;
+  memset(&k, 0, sizeof(k));
+  k.nv = NV;
+  k.nu = NU;
+  k.ns = NS;
+  k.nvariants = (NW0 == NW1) ? 1 : 2;
+  k.bwd[0] = riccati_backward_kernel<NV, NU, NS, NW0>;
+  k.bwd_waves[0] = NW0;
+  k.bwd_lds[0] = BwdCfg<NV, NU, NS, NW0>::LDS_BYTES;
+  k.bwd[1] = riccati_backward_kernel<NV, NU, NS, NW1>;
+  k.bwd_waves[1] = NW1;
+  k.bwd_lds[1] = BwdCfg<NV, NU, NS, NW1>::LDS_BYTES;
+  constexpr int NWF = (2 * NV + NU + 63) / 64;
+  k.fwd = riccati_forward_kernel<NV, NU, NS, NWF>;
+  k.fwd_threads = 64 * NWF;
+  k.fill = unconstr_fill_kernel<NV>;
+  constexpr int NF = NS;  // nf_max == ns_max for all supported robots
+  k.cond = condense_kernel<NV, NU, NF, NS>;
+  k.cond_threads = CondCfg<NV, NU, NF, NS>::NT;
+  k.cond_lds = CondCfg<NV, NU, NF, NS>::LDS_BYTES;
+  k.expd = expand_kernel<NV, NU, NF, NS>;
+  k.expd_threads = 64;
+  return k;
+}
+
+static const std::vector<KernelSet>& kernel_table() {
+  static std::vector<KernelSet> t = {
+      make_set<18, 12, 12, 1, 3>(),  // ANYmal: nv=18, 12 joints, 4 point contacts
+      make_set<35, 29, 12, 5, 5>(),  // iCub (reference URDF): nv=35, 2 surface contacts
+      make_set<32, 26, 12, 4, 4>(),  // iCub as named in BASELINE.json (nv=32)
+      make_set<7, 7, 0, 1, 1>(),     // iiwa14 (fixed base, UnconstrOCPSolver)
+  };
+  return t;
+}
+
+static const KernelSet* find_set(const rtoc_dims* d) {
+  for (const auto& k : kernel_table())
+    if (k.nv == d->nv && k.nu == d->nu && k.ns == d->ns_max && d->nf_max == d->ns_max &&
+        d->np == d->nv - d->nu)
+      return &k;
+  return nullptr;
+}
+
+// ---- context --------------------------------------------------------------------------
+struct rtoc_ctx {
+  rtoc_dims dims;
+  rtoc_layout L;
+  const KernelSet* ks;
+  int max_stages, nstages, batch, device;
+  hipStream_t own_stream, stream;
+  double* buf[RTOC_NUM_BUFFERS];
+  size_t count[RTOC_NUM_BUFFERS];
+  bool owned[RTOC_NUM_BUFFERS];
+  rtoc_grid* d_grid;
+  uint32_t* d_status;
+  int writeback;
+  double max_dts0;
+  int bwd_variant;
+  hipEvent_t ev0, ev1;
+};
+
+extern "C" {
+
+int rtoc_version(void) { return 100; }
+
+int rtoc_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int rtoc_dims_supported(const rtoc_dims* dims) { return dims && find_set(dims) ? 1 : 0; }
+
+void rtoc_layout_for_dims(const rtoc_dims* dims, rtoc_layout* out) { rtoc_compute_layout(dims, out); }
+
+const char* rtoc_error_string(int code) {
+  switch (code) {
+    case RTOC_OK: return "ok";
+    case RTOC_ERR_BAD_ARG: return "bad argument";
+    case RTOC_ERR_UNSUPPORTED_DIMS: return "no kernel specialisation for these dimensions";
+    case RTOC_ERR_NO_DEVICE: return "no HIP device (the HIP path has no CPU fallback)";
+    case RTOC_ERR_HIP: return g_errbuf;
+    case RTOC_ERR_NOT_READY: return "grid not set";
+    case RTOC_ERR_RCCL: return "RCCL error";
+    default: return "unknown";
+  }
+}
+
+int rtoc_create(const rtoc_dims* dims, int max_stages, int batch, int device, rtoc_ctx** out) {
+  if (!dims || !out || max_stages < 2 || batch < 1) return RTOC_ERR_BAD_ARG;
+  const KernelSet* ks = find_set(dims);
+  if (!ks) return RTOC_ERR_UNSUPPORTED_DIMS;
+  if (rtoc_device_count() <= device || device < 0) return RTOC_ERR_NO_DEVICE;
+  HIP_TRY(hipSetDevice(device));
+  rtoc_ctx* c = new (std::nothrow) rtoc_ctx();
+  if (!c) return RTOC_ERR_BAD_ARG;
+  memset(c, 0, sizeof(*c));
+  c->dims = *dims;
+  rtoc_compute_layout(dims, &c->L);
+  c->ks = ks;
+  c->max_stages = max_stages;
+  c->nstages = 0;
+  c->batch = batch;
+  c->device = device;
+  c->max_dts0 = 0.1;  // RiccatiRecursion(ocp, max_dts0 = 0.1), riccati_recursion.hpp:35
+  c->bwd_variant = 0;
+  HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+  c->stream = c->own_stream;
+  HIP_TRY(hipEventCreate(&c->ev0));
+  HIP_TRY(hipEventCreate(&c->ev1));
+  const size_t per = (size_t)batch * max_stages;
+  c->count[RTOC_BUF_KKT] = per * c->L.kkt.stride;
+  c->count[RTOC_BUF_RIC] = per * c->L.ric.stride;
+  c->count[RTOC_BUF_DIR] = per * c->L.dir.stride;
+  c->count[RTOC_BUF_CDD] = per * c->L.cdd.stride;
+  c->count[RTOC_BUF_CON] = per * (size_t)rtoc_con_stride(dims);
+  c->count[RTOC_BUF_DX0] = (size_t)batch * c->L.nx;
+  c->count[RTOC_BUF_STEP] = (size_t)batch * 2;
+  for (int i = 0; i < RTOC_NUM_BUFFERS; ++i) {
+    // the CDD / CON buffers are large; they are allocated lazily on first use (upload / bind / condense)
+    c->buf[i] = nullptr;
+    c->owned[i] = false;
+  }
+  const int eager[] = {RTOC_BUF_KKT, RTOC_BUF_RIC, RTOC_BUF_DIR, RTOC_BUF_DX0, RTOC_BUF_STEP};
+  for (int i : eager) {
+    HIP_TRY(hipMalloc((void**)&c->buf[i], c->count[i] * sizeof(double)));
+    HIP_TRY(hipMemsetAsync(c->buf[i], 0, c->count[i] * sizeof(double), c->stream));
+    c->owned[i] = true;
+  }
+  HIP_TRY(hipMalloc((void**)&c->d_grid, sizeof(rtoc_grid) * max_stages));
+  HIP_TRY(hipMalloc((void**)&c->d_status, sizeof(uint32_t) * batch));
+  HIP_TRY(hipMemsetAsync(c->d_status, 0, sizeof(uint32_t) * batch, c->stream));
+  for (int v = 0; v < 2; ++v)
+    HIP_TRY(hipFuncSetAttribute((const void*)ks->bwd[v], hipFuncAttributeMaxDynamicSharedMemorySize,
+                                ks->bwd_lds[v]));
+  HIP_TRY(hipFuncSetAttribute((const void*)ks->cond, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              ks->cond_lds));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  *out = c;
+  return RTOC_OK;
+}
+
+int rtoc_destroy(rtoc_ctx* c) {
+  if (!c) return RTOC_ERR_BAD_ARG;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  for (int i = 0; i < RTOC_NUM_BUFFERS; ++i)
+    if (c->owned[i] && c->buf[i]) (void)hipFree(c->buf[i]);
+  (void)hipFree(c->d_grid);
+  (void)hipFree(c->d_status);
+  (void)hipEventDestroy(c->ev0);
+  (void)hipEventDestroy(c->ev1);
+  (void)hipStreamDestroy(c->own_stream);
+  delete c;
+  return RTOC_OK;
+}
+
+int rtoc_get_layout(const rtoc_ctx* c, rtoc_layout* out) {
+  if (!c || !out) return RTOC_ERR_BAD_ARG;
+  *out = c->L;
+  return RTOC_OK;
+}
+
+int rtoc_set_grid(rtoc_ctx* c, const rtoc_grid* grid, int nstages) {
+  if (!c || !grid || nstages < 2 || nstages > c->max_stages) return RTOC_ERR_BAD_ARG;
+  if (grid[nstages - 1].type != RTOC_GRID_TERMINAL) return RTOC_ERR_BAD_ARG;
+  for (int i = 0; i < nstages; ++i) {
+    const rtoc_grid& g = grid[i];
+    if (g.dims < 0 || g.dims > c->dims.ns_max || g.dimf < 0 || g.dimf > c->dims.nf_max)
+      return RTOC_ERR_BAD_ARG;
+    if (i < nstages - 1 && g.type == RTOC_GRID_TERMINAL) return RTOC_ERR_BAD_ARG;
+    if (g.type == RTOC_GRID_IMPACT && (i == 0 || i >= nstages - 2)) return RTOC_ERR_BAD_ARG;
+    if (g.type == RTOC_GRID_LIFT && i == 0) return RTOC_ERR_BAD_ARG;
+  }
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipMemcpyAsync(c->d_grid, grid, sizeof(rtoc_grid) * nstages, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->nstages = nstages;
+  return RTOC_OK;
+}
+
+int rtoc_set_stream(rtoc_ctx* c, void* s) {
+  if (!c) return RTOC_ERR_BAD_ARG;
+  c->stream = s ? (hipStream_t)s : c->own_stream;
+  return RTOC_OK;
+}
+
+int rtoc_set_option(rtoc_ctx* c, int option, int64_t value) {
+  if (!c) return RTOC_ERR_BAD_ARG;
+  switch (option) {
+    case RTOC_OPT_WRITEBACK_KKT:
+      c->writeback = value ? 1 : 0;
+      return RTOC_OK;
+    case RTOC_OPT_MAX_DTS0: {
+      double d;
+      memcpy(&d, &value, sizeof(d));
+      if (!(d > 0.0)) return RTOC_ERR_BAD_ARG;
+      c->max_dts0 = d;
+      return RTOC_OK;
+    }
+    case RTOC_OPT_BACKWARD_WAVES: {
+      if (value == 0) {
+        c->bwd_variant = 0;
+        return RTOC_OK;
+      }
+      for (int v = 0; v < 2; ++v)
+        if (c->ks->bwd_waves[v] == (int)value) {
+          c->bwd_variant = v;
+          return RTOC_OK;
+        }
+      return RTOC_ERR_BAD_ARG;
+    }
+    default:
+      return RTOC_ERR_BAD_ARG;
+  }
+}
+
+static int ensure_buffer(rtoc_ctx* c, int b) {
+  if (c->buf[b]) return RTOC_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipMalloc((void**)&c->buf[b], c->count[b] * sizeof(double)));
+  HIP_TRY(hipMemsetAsync(c->buf[b], 0, c->count[b] * sizeof(double), c->stream));
+  c->owned[b] = true;
+  return RTOC_OK;
+}
+
+int rtoc_upload(rtoc_ctx* c, int buffer, size_t offset, const double* host, size_t count) {
+  if (!c || buffer < 0 || buffer >= RTOC_NUM_BUFFERS || !host) return RTOC_ERR_BAD_ARG;
+  if (offset + count > c->count[buffer]) return RTOC_ERR_BAD_ARG;
+  int rc = ensure_buffer(c, buffer);
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipMemcpyAsync(c->buf[buffer] + offset, host, count * sizeof(double), hipMemcpyHostToDevice,
+                         c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return RTOC_OK;
+}
+
+int rtoc_download(rtoc_ctx* c, int buffer, size_t offset, double* host, size_t count) {
+  if (!c || buffer < 0 || buffer >= RTOC_NUM_BUFFERS || !host) return RTOC_ERR_BAD_ARG;
+  if (offset + count > c->count[buffer] || !c->buf[buffer]) return RTOC_ERR_BAD_ARG;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipMemcpyAsync(host, c->buf[buffer] + offset, count * sizeof(double), hipMemcpyDeviceToHost,
+                         c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return RTOC_OK;
+}
+
+void* rtoc_device_ptr(rtoc_ctx* c, int buffer) {
+  if (!c || buffer < 0 || buffer >= RTOC_NUM_BUFFERS) return nullptr;
+  if (ensure_buffer(c, buffer)) return nullptr;
+  return c->buf[buffer];
+}
+
+size_t rtoc_buffer_count(const rtoc_ctx* c, int buffer) {
+  if (!c || buffer < 0 || buffer >= RTOC_NUM_BUFFERS) return 0;
+  return c->count[buffer];
+}
+
+int rtoc_bind(rtoc_ctx* c, int buffer, void* device_ptr) {
+  if (!c || buffer < 0 || buffer >= RTOC_NUM_BUFFERS || !device_ptr) return RTOC_ERR_BAD_ARG;
+  if (((uintptr_t)device_ptr & 63) != 0) return RTOC_ERR_BAD_ARG;  // records are 64 B aligned
+  HIP_TRY(hipSetDevice(c->device));
+  if (c->owned[buffer] && c->buf[buffer]) {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipFree(c->buf[buffer]));
+  }
+  c->buf[buffer] = (double*)device_ptr;
+  c->owned[buffer] = false;
+  return RTOC_OK;
+}
+
+// ---- hot path ---------------------------------------------------------------------------
+static int launch_backward(rtoc_ctx* c) {
+  BwdArgs a;
+  a.kkt = c->buf[RTOC_BUF_KKT];
+  a.kkt_rw = c->buf[RTOC_BUF_KKT];
+  a.ric = c->buf[RTOC_BUF_RIC];
+  a.grid = c->d_grid;
+  a.status = c->d_status;
+  a.nstages = c->nstages;
+  a.batch = c->batch;
+  a.writeback = c->writeback;
+  a.max_dts0 = c->max_dts0;
+  a.kl = c->L.kkt;
+  a.rl = c->L.ric;
+  const int v = c->bwd_variant;
+  hipLaunchKernelGGL(c->ks->bwd[v], dim3(c->batch), dim3(64 * c->ks->bwd_waves[v]), c->ks->bwd_lds[v],
+                     c->stream, a);
+  HIP_TRY(hipGetLastError());
+  return RTOC_OK;
+}
+
+static int launch_forward(rtoc_ctx* c) {
+  FwdArgs a;
+  a.kkt = c->buf[RTOC_BUF_KKT];
+  a.ric = c->buf[RTOC_BUF_RIC];
+  a.dir = c->buf[RTOC_BUF_DIR];
+  a.dx0 = c->buf[RTOC_BUF_DX0];
+  a.grid = c->d_grid;
+  a.nstages = c->nstages;
+  a.batch = c->batch;
+  a.kl = c->L.kkt;
+  a.rl = c->L.ric;
+  a.dl = c->L.dir;
+  hipLaunchKernelGGL(c->ks->fwd, dim3(c->batch), dim3(c->ks->fwd_threads), 0, c->stream, a);
+  HIP_TRY(hipGetLastError());
+  return RTOC_OK;
+}
+
+static int launch_condense(rtoc_ctx* c) {
+  int rc = ensure_buffer(c, RTOC_BUF_CDD);
+  if (rc) return rc;
+  CondArgs a;
+  a.kkt = c->buf[RTOC_BUF_KKT];
+  a.cdd = c->buf[RTOC_BUF_CDD];
+  a.grid = c->d_grid;
+  a.status = c->d_status;
+  a.nstages = c->nstages;
+  a.batch = c->batch;
+  a.kl = c->L.kkt;
+  a.cl = c->L.cdd;
+  const int nblocks = c->batch * (c->nstages - 1);
+  hipLaunchKernelGGL(c->ks->cond, dim3(nblocks), dim3(c->ks->cond_threads), c->ks->cond_lds, c->stream, a);
+  HIP_TRY(hipGetLastError());
+  return RTOC_OK;
+}
+
+static int launch_expand(rtoc_ctx* c, double tau) {
+  int rc = ensure_buffer(c, RTOC_BUF_CDD);
+  if (rc) return rc;
+  ExpArgs a;
+  a.cdd = c->buf[RTOC_BUF_CDD];
+  a.dir = c->buf[RTOC_BUF_DIR];
+  a.grid = c->d_grid;
+  a.nstages = c->nstages;
+  a.batch = c->batch;
+  a.cl = c->L.cdd;
+  a.dl = c->L.dir;
+  a.tau = tau;
+  const int nblocks = c->batch * (c->nstages - 1);
+  hipLaunchKernelGGL(c->ks->expd, dim3(nblocks), dim3(c->ks->expd_threads), 0, c->stream, a);
+  HIP_TRY(hipGetLastError());
+  return RTOC_OK;
+}
+
+#define CHECK_READY(c)                       \
+  if (!(c)) return RTOC_ERR_BAD_ARG;         \
+  if ((c)->nstages < 2) return RTOC_ERR_NOT_READY; \
+  HIP_TRY(hipSetDevice((c)->device));
+
+int rtoc_condense(rtoc_ctx* c) {
+  CHECK_READY(c);
+  return launch_condense(c);
+}
+
+int rtoc_riccati_backward(rtoc_ctx* c) {
+  CHECK_READY(c);
+  return launch_backward(c);
+}
+
+int rtoc_riccati_forward(rtoc_ctx* c) {
+  CHECK_READY(c);
+  return launch_forward(c);
+}
+
+static int launch_fill(rtoc_ctx* c, double dt) {
+  FillArgs a;
+  a.kkt = c->buf[RTOC_BUF_KKT];
+  a.nstages = c->nstages;
+  a.batch = c->batch;
+  a.dt = dt;
+  a.kl = c->L.kkt;
+  hipLaunchKernelGGL(c->ks->fill, dim3(c->batch * c->nstages), dim3(128), 0, c->stream, a);
+  HIP_TRY(hipGetLastError());
+  return RTOC_OK;
+}
+
+int rtoc_unconstr_backward(rtoc_ctx* c, double dt) {
+  CHECK_READY(c);
+  if (c->dims.nu != c->dims.nv || !(dt > 0.0)) return RTOC_ERR_BAD_ARG;
+  int rc = launch_fill(c, dt);
+  if (rc) return rc;
+  return launch_backward(c);
+}
+
+int rtoc_unconstr_forward(rtoc_ctx* c, double dt) {
+  CHECK_READY(c);
+  if (c->dims.nu != c->dims.nv || !(dt > 0.0)) return RTOC_ERR_BAD_ARG;
+  return launch_forward(c);
+}
+
+int rtoc_expand(rtoc_ctx* c, double tau) {
+  CHECK_READY(c);
+  if (!(tau > 0.0 && tau <= 1.0)) return RTOC_ERR_BAD_ARG;
+  return launch_expand(c, tau);
+}
+
+int rtoc_update(rtoc_ctx* c) {
+  CHECK_READY(c);
+  return RTOC_OK;
+}
+
+int rtoc_status(rtoc_ctx* c, uint32_t* host_flags, int count) {
+  if (!c || !host_flags || count < 0 || count > c->batch) return RTOC_ERR_BAD_ARG;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipMemcpyAsync(host_flags, c->d_status, sizeof(uint32_t) * count, hipMemcpyDeviceToHost,
+                         c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return RTOC_OK;
+}
+
+int rtoc_clear_status(rtoc_ctx* c) {
+  if (!c) return RTOC_ERR_BAD_ARG;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipMemsetAsync(c->d_status, 0, sizeof(uint32_t) * c->batch, c->stream));
+  return RTOC_OK;
+}
+
+int rtoc_sync(rtoc_ctx* c) {
+  if (!c) return RTOC_ERR_BAD_ARG;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return RTOC_OK;
+}
+
+int rtoc_time_phase(rtoc_ctx* c, int phase, int reps, float* ms) {
+  CHECK_READY(c);
+  if (!ms || reps < 1 || phase < 0 || phase > 4) return RTOC_ERR_BAD_ARG;
+  HIP_TRY(hipEventRecord(c->ev0, c->stream));
+  for (int r = 0; r < reps; ++r) {
+    int rc = RTOC_OK;
+    switch (phase) {
+      case 0: rc = launch_backward(c); break;
+      case 1: rc = launch_forward(c); break;
+      case 2: rc = launch_condense(c); break;
+      case 3: rc = launch_expand(c, 0.995); break;
+      case 4:
+        rc = launch_backward(c);
+        if (!rc) rc = launch_forward(c);
+        break;
+    }
+    if (rc) return rc;
+  }
+  HIP_TRY(hipEventRecord(c->ev1, c->stream));
+  HIP_TRY(hipEventSynchronize(c->ev1));
+  float t = 0.f;
+  HIP_TRY(hipEventElapsedTime(&t, c->ev0, c->ev1));
+  *ms = t / reps;
+  return RTOC_OK;
+}
+
+// ---- multi-GPU: RCCL all-gather of the step directions over xGMI -----------------------------
+// RCCL is resolved at run time (dlopen) so that the library has no link-time dependency on a
+// particular librccl and shares the copy a host process (e.g. torch.distributed) already loaded.
+int rtoc_gather_directions(rtoc_ctx* c, void* nccl_comm, double* out) {
+  CHECK_READY(c);
+  if (!nccl_comm || !out) return RTOC_ERR_BAD_ARG;
+  typedef int (*allgather_t)(const void*, void*, size_t, int, void*, hipStream_t);
+  static allgather_t fn = nullptr;
+  if (!fn) {
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return RTOC_ERR_RCCL;
+    fn = (allgather_t)dlsym(h, "ncclAllGather");
+    if (!fn) return RTOC_ERR_RCCL;
+  }
+  const size_t count = (size_t)c->batch * c->nstages * c->L.dir.stride;
+  const int nccl_float64 = 8;  // ncclFloat64 / ncclDouble
+  const int rc = fn(c->buf[RTOC_BUF_DIR], out, count, nccl_float64, nccl_comm, c->stream);
+  return rc == 0 ? RTOC_OK : RTOC_ERR_RCCL;
+}
+
+}  // extern "C"

@@ -1,0 +1,88 @@
+"""Shared helpers for the parity tests."""
+import numpy as np
+
+from robotoc_amd.types import GRID_IMPACT, GRID_TERMINAL, Records
+
+
+def rel_err(a, b):
+    """Relative Frobenius error ||a-b|| / max(||b||, tiny) (Eigen isApprox-style)."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    nb = np.linalg.norm(b)
+    na = np.linalg.norm(a)
+    den = max(nb, na, 1e-300)
+    return float(np.linalg.norm(a - b) / den)
+
+
+def compare_riccati(L, grids, ric_gpu, ric_ref, tol, what="", check_sto=True):
+    """Compare every meaningful field of the Riccati records stage by stage.
+    Returns the worst relative error; raises AssertionError with a per-field report on failure."""
+    R = Records(L, "ric")
+    worst = 0.0
+    bad = []
+    N = len(grids) - 1
+    for i, g in enumerate(grids):
+        fields = ["P", "s"]
+        if i < N and g.type != GRID_IMPACT:
+            fields += ["K", "k"]
+        if i < N and g.dims > 0:
+            fields += ["M", "m"]
+        if check_sto and i < N and g.sto:
+            fields += ["Psi", "Phi"]
+            if g.type != GRID_IMPACT:
+                fields += ["T", "W", "psi_x", "psi_u"]
+                if g.dims > 0:
+                    fields += ["mt", "mt_next"]
+        for f in fields:
+            a = R.f(ric_gpu[i], f)
+            b = R.f(ric_ref[i], f)
+            if f in ("M",):
+                a, b = a[:g.dims], b[:g.dims]
+            if f in ("m", "mt", "mt_next"):
+                a, b = a[:g.dims], b[:g.dims]
+            nb = np.linalg.norm(b)
+            if nb < 1e-12 and np.linalg.norm(a) < 1e-12:
+                continue
+            e = rel_err(a, b)
+            worst = max(worst, e)
+            if not (e <= tol):
+                bad.append((i, f, e))
+        if check_sto and i < N and g.sto:
+            a = R.f(ric_gpu[i], "scal")[:5]
+            b = R.f(ric_ref[i], "scal")[:5]
+            scale = max(np.abs(b).max(), 1.0)
+            e = float(np.abs(a - b).max() / scale)
+            worst = max(worst, e)
+            if not (e <= tol):
+                bad.append((i, "scal", e))
+    assert not bad, "%s riccati mismatch (stage, field, rel_err): %s" % (what, bad[:12])
+    return worst
+
+
+def compare_direction(L, grids, d_gpu, d_ref, tol, what=""):
+    D = Records(L, "dir")
+    worst = 0.0
+    bad = []
+    N = len(grids) - 1
+    for i, g in enumerate(grids):
+        fields = ["dx", "dlmdgmm"]
+        if i < N and g.type != GRID_IMPACT:
+            fields.append("du")
+        for f in fields:
+            e = rel_err(D.f(d_gpu[i], f), D.f(d_ref[i], f))
+            worst = max(worst, e)
+            if not (e <= tol):
+                bad.append((i, f, e))
+        if i < N and g.switching_constraint and g.dims > 0:
+            e = rel_err(D.f(d_gpu[i], "dxi")[:g.dims], D.f(d_ref[i], "dxi")[:g.dims])
+            worst = max(worst, e)
+            if not (e <= tol):
+                bad.append((i, "dxi", e))
+        a = D.f(d_gpu[i], "dts")[:2]
+        b = D.f(d_ref[i], "dts")[:2]
+        e = float(np.abs(a - b).max() / max(np.abs(b).max(), 1.0))
+        worst = max(worst, e)
+        if not (e <= tol):
+            bad.append((i, "dts", e))
+    assert not bad, "%s direction mismatch (stage, field, rel_err): %s" % (what, bad[:12])
+    return worst
