@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""bench.py -- Riccati sweeps/s on the ANYmal trot workload (BASELINE.json metric).
+
+A "step" is one pass of the hot path over one batch: the backward Riccati recursion
+followed by the forward recursion for PER_GPU_BATCH independent ANYmal trot OCP
+instances (nv=18, 4 point contacts, N=40 -> 47 grids with 2 lifts + 2 impacts),
+inputs resident in HBM.  One process per GPU; instances are sharded across ranks
+with no data-path collective (weak scaling: fixed work per GPU); after the timed
+region the step directions are all-gathered over RCCL (the one real exchange step,
+SURVEY 8e) to validate the multi-GPU path.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PER_GPU_BATCH = 4096
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def algorithmic_bytes(L, grids, batch, which):
+    """algorithmic HBM bytes of one launch (dense-as-handed-over fields,
+    P+ resident on chip), summed over the stages of the grid actually launched."""
+    from robotoc_amd.types import GRID_IMPACT
+    d = L.dims
+    nv, nu, nx = d.nv, d.nu, 2 * d.nv
+    total = 0
+    N = len(grids) - 1
+    for i, g in enumerate(grids):
+        if i == N:
+            if which == "backward":
+                total += 2 * (nx * nx + nx)  # read Qxx,lx; write P,s
+            else:
+                total += nx * nx + nx + nx + nx  # read P,s,dx ; write dlmdgmm
+            continue
+        ns = g.dims
+        if which == "backward":
+            if g.type == GRID_IMPACT:
+                rd = 2 * nx * nx + 2 * nx
+                wr = nx * nx + nx
+            else:
+                rd = 2 * nx * nx + nx * nu + nu * nu + nv * nu + 2 * nx + nu
+                wr = nx * nx + nx + nu * nx + nu
+                if ns:
+                    rd += ns * nx + ns * nu + ns
+                    wr += ns * nx + ns
+            total += rd + wr
+        else:
+            if g.type == GRID_IMPACT:
+                rd = 2 * nx * nx + 2 * nx
+                wr = 2 * nx
+            else:
+                rd = 2 * nx * nx + nu * nx + nv * nu + 2 * nx + nu
+                wr = 2 * nx + nu
+                if ns:
+                    rd += ns * nx + ns
+                    wr += ns
+            total += rd + wr
+    return total * 8 * batch
+
+
+def cpu_baseline(L, grids, dx0_small, kkt_small, budget_s=12.0):
+    """Oracle (CPU port of the reference algorithm) timed on this box's host cores, OpenMP over
+    instances.  Bounded sample: repeat a small batch until ~budget_s of CPU work."""
+    from oracle import oracle as orc
+    from robotoc_amd.types import Records
+    nthreads = os.cpu_count() or 1
+    # at least two instances per hardware thread so that every core has work
+    reps_b = max(1, (2 * nthreads + kkt_small.shape[0] - 1) // kkt_small.shape[0])
+    kkt_small = np.ascontiguousarray(np.tile(kkt_small, (reps_b, 1, 1)))
+    dx0_small = np.ascontiguousarray(np.tile(dx0_small, (reps_b, 1)))
+    B = kkt_small.shape[0]
+    ric = Records(L, "ric").zeros(B, len(grids))
+    d = Records(L, "dir").zeros(B, len(grids))
+    work = kkt_small.copy()
+    orc.riccati_sweep_batch(L, grids, work, ric, d, dx0=dx0_small)  # warm-up (page faults)
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        work[...] = kkt_small  # the oracle mutates the KKT blocks in place like the reference
+        orc.riccati_sweep_batch(L, grids, work, ric, d, dx0=dx0_small)
+        reps += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return dict(value=B * reps / dt, unit="sweeps/s", cores=nthreads, kind="port",
+                sample="%d instances x %d repeats of the same ANYmal trot sweep, OpenMP over "
+                       "instances (%d threads), includes the memcpy that restores the in-place "
+                       "mutated KKT blocks" % (B, reps, nthreads))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="instances per GPU")
+    ap.add_argument("--waves", type=int, default=0, help="backward-kernel waves per instance (0=default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise RuntimeError("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world)  # "nccl" is RCCL on ROCm
+
+    from robotoc_amd import capi, problems as pr
+    from robotoc_amd.types import BUF_DIR, BUF_DX0, BUF_KKT
+
+    dims, grids, _ = pr.config_anymal_trot()
+    batch = args.batch
+    ctx = capi.Context(dims, len(grids), batch, local_rank)
+    L = ctx.L
+    ctx.set_grid(grids)
+    if args.waves:
+        ctx.set_backward_waves(args.waves)
+    # per-rank shard of the instance range: seeds are offset by rank*batch
+    uniq = 16
+    kkt_small = pr.make_kkt_batch(L, grids, uniq, first_instance=rank * batch)
+    dx0_small = pr.make_dx0(L, uniq, first_instance=rank * batch)
+    reps = (batch + uniq - 1) // uniq
+    kkt = np.ascontiguousarray(np.tile(kkt_small, (reps, 1, 1))[:batch])
+    dx0 = np.ascontiguousarray(np.tile(dx0_small, (reps, 1))[:batch])
+    # the direction buffer lives in a torch tensor so that torch.distributed (RCCL) can gather it
+    dir_t = torch.zeros(ctx.buffer_count(BUF_DIR), dtype=torch.float64, device="cuda")
+    ctx.bind(BUF_DIR, dir_t.data_ptr())
+    stream = torch.cuda.current_stream()
+    ctx.set_stream(stream.cuda_stream)
+    ctx.upload(BUF_KKT, kkt)
+    ctx.upload(BUF_DX0, dx0)
+
+    def step():
+        ctx.riccati_backward()
+        ctx.riccati_forward()
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync_all()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    bad = int((ctx.status() != 0).sum())
+
+    # dominant kernel (backward) and forward timed with HIP events on the launch stream
+    ms_b = ctx.time_phase(0, max(3, args.steps // 2))
+    ms_f = ctx.time_phase(1, max(3, args.steps // 2))
+    nsl = len(grids) * L.dir.stride
+    gathered_ok = None
+    if world > 1:
+        out = [torch.empty_like(dir_t[:batch * nsl]) for _ in range(world)]
+        dist.all_gather(out, dir_t[:batch * nsl])
+        torch.cuda.synchronize()
+        gathered_ok = bool(all(torch.isfinite(o).all().item() for o in out))
+
+    if rank == 0:
+        total_sweeps = world * batch * args.steps
+        value = total_sweeps / dt
+        bytes_b = algorithmic_bytes(L, grids, batch, "backward")
+        bytes_f = algorithmic_bytes(L, grids, batch, "forward")
+        ach = bytes_b / (ms_b * 1e-3) / 1e9
+        res = {
+            "metric": "riccati_sweeps_per_sec",
+            "value": value,
+            "unit": "sweeps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "anymal_trot_N40 (nv=18,nu=12, 47 grids: 2 lifts + 2 impacts, "
+                                   "switching constraints ns=6), %d OCP instances per GPU, "
+                                   "backward+forward Riccati sweep" % batch,
+                       "per_gpu_batch": batch, "stages": len(grids), "parallelism": "instances sharded, dp%d" % world,
+                       "backward_waves": args.waves},
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "riccati_backward_kernel", "kernel_ms": ms_b,
+                         "algorithmic_bytes_per_launch": bytes_b,
+                         "forward_kernel_ms": ms_f,
+                         "forward_achieved": bytes_f / (ms_f * 1e-3) / 1e9,
+                         "forward_algorithmic_bytes_per_launch": bytes_f},
+            "status_nonzero_instances": bad,
+        }
+        if gathered_ok is not None:
+            res["rccl_gather_ok"] = gathered_ok
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(L, grids, dx0_small, kkt_small)
+        print(json.dumps(res))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

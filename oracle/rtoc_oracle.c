@@ -51,6 +51,7 @@ static void gemm(int ta, int tb, int M, int N, int K, double alpha, const double
       for (int k = 0; k < K; ++k) {
         const double b = alpha * (tb ? B[j + (size_t)k * ldb] : B[k + (size_t)j * ldb]);
         const double* a = A + (size_t)k * lda;
+#pragma omp simd
         for (int i = 0; i < M; ++i) c[i] += a[i] * b;
       }
     } else {
@@ -59,6 +60,7 @@ static void gemm(int ta, int tb, int M, int N, int K, double alpha, const double
         double acc = 0.0;
         if (!tb) {
           const double* b = B + (size_t)j * ldb;
+#pragma omp simd reduction(+ : acc)
           for (int k = 0; k < K; ++k) acc += a[k] * b[k];
         } else {
           for (int k = 0; k < K; ++k) acc += a[k] * B[j + (size_t)k * ldb];

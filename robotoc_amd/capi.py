@@ -212,3 +212,12 @@ class Context:
 
     def download_records(self, buffer, which):
         return self.download(buffer, self.shape(which))
+
+
+def debug_profile(ctx):
+    """Tuning aid: first call attaches the stamp buffer, later calls return [max_stages,16] int64."""
+    L = lib()
+    L.rtoc_debug_profile.argtypes = [C.c_void_p, C.c_void_p]
+    out = np.zeros((ctx.max_stages, 16), dtype=np.int64)
+    _chk(L.rtoc_debug_profile(ctx._h, out.ctypes.data_as(C.c_void_p)))
+    return out

@@ -37,12 +37,19 @@
 
 namespace rtoc {
 
+// Phase time-stamps (s_memtime) of block 0, written only when a profiling buffer is attached.
+#define RTOC_PROF(k)                                                             \
+  do {                                                                          \
+    if (a.prof && b == 0 && tid0 == 0) a.prof[st * 16 + (k)] = (long long)__builtin_readcyclecounter(); \
+  } while (0)
+
 struct BwdArgs {
   const double* kkt;       // [batch][nstages][kl.stride]
   double* kkt_rw;          // same buffer, writable (writeback of F,H,G,lu)
   double* ric;             // [batch][nstages][rl.stride]
   const rtoc_grid* grid;   // [nstages] (device)
   uint32_t* status;        // [batch]
+  long long* prof;         // optional [nstages][16] cycle stamps of block 0 (tuning aid), or nullptr
   int nstages;
   int batch;
   int writeback;
@@ -255,6 +262,7 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
     const double* kr = a.kkt + kinst + (size_t)st * a.kl.stride;
     double* rr = a.ric + rinst + (size_t)st * a.rl.stride;
 
+    RTOC_PROF(0);
     // ---- phase transition (riccati_factorizer.cpp:145-175), in place on the LDS copy of
     //      factorization[st+1]; dispatch per riccati_recursion.cpp:41-70 ----
     bool do_pt = false;
@@ -313,6 +321,7 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
       __syncthreads();
     }
 
+    RTOC_PROF(1);
     // ---- stage data: HBM -> LDS (coalesced 16 B / lane) ----
     copy_g2s_mat<NT, NX, NX, LDP>(sA, kr + ko[RTOC_KKT_FXX], tid);
     if (!impact) {
@@ -335,6 +344,7 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
     if (tid < 8) smem[C::V_KSC + tid] = kr[ko[RTOC_KKT_SCAL] + tid];
     __syncthreads();
 
+    RTOC_PROF(2);
     // ---- z = s+ - P+ Fx ;  y = P+ fx + Psi+ (STO) ----
     if (tid < NX) {
       double acc = 0.0, accy = 0.0;
@@ -447,6 +457,7 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
     }
     __syncthreads();
 
+    RTOC_PROF(3);
     // ---- PAa = [P+ ; PB^T] A, this wave owns column tiles tn = wave + c*NW ----
     d4 pa[TMA][CNT];
 #pragma unroll
@@ -505,6 +516,7 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
           }
     }
 
+    RTOC_PROF(4);
     // ---- s-vector part that needs A: w = A^T z  (and STO: psi_x, phi_x) ----
     if (tid < NX) {
       double acc = 0.0, ap = 0.0, aph = 0.0;
@@ -528,6 +540,7 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
       }
     }
 
+    RTOC_PROF(5);
     // ---- F = Qxx + AtP A, chained: A-operand = PAa registers (row-tile = owned column tile) ----
     d4 f[CNT][TNX];
     {
@@ -563,6 +576,7 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
           }
         }
     }
+    RTOC_PROF(6);
     __syncthreads();  // H complete; sA / sPB / sP(+) no longer read by MFMA after this point
 
     if (impact) {
@@ -784,6 +798,7 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
       }
       __syncthreads();
 
+      RTOC_PROF(7);
       // ---- GK = G K (+ 2 Phiu^T M on switching-constraint grids, which folds
       //      P -= KtDtM + KtDtM^T (:84-87) into the symmetrised F - K^T GK) ----
       {
@@ -834,6 +849,7 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
             }
       }
       __syncthreads();
+      RTOC_PROF(8);
       // ---- F -= K^T GK ----
       {
         const double* pa_ = sKt + (wave * 16 + li) + q * LDP;  // K^T[i][k] = Kt[i][k]
@@ -867,6 +883,7 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
       }
     }
 
+    RTOC_PROF(9);
     // ---- optional write-back of the mutated KKT blocks (reference in-place semantics) ----
     if (a.writeback) {
       double* kw = a.kkt_rw + kinst + (size_t)st * a.kl.stride;
@@ -906,6 +923,7 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
       }
     }
 
+    RTOC_PROF(10);
     // ---- STO scalars / vectors (brrf.cpp:94-143, riccati_factorizer.cpp:93-142) ----
     if (sto && !impact) {
       // Psi = psi_x + K^T psi_u ; Phi = phi_x + K^T phi_u
@@ -998,6 +1016,7 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
     }
     __syncthreads();
 
+    RTOC_PROF(11);
     // ---- results -> HBM; roll the LDS "next" state ----
     copy_s2g_mat<NT, NX, NX, LDP>(rr + ro[RTOC_RIC_P], sP, tid);
     if (!impact) {
@@ -1032,6 +1051,7 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
       rr[ro[RTOC_RIC_SCAL] + tid] = v;
       smem[C::V_SCN + tid] = v;
     }
+    RTOC_PROF(12);
   }
 
   // ---- grid[0].sto: trailing phase transition writes sto_policy_[0] (riccati_recursion.cpp:75-79) ----

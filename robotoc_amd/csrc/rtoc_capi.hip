@@ -110,6 +110,7 @@ struct rtoc_ctx {
   bool owned[RTOC_NUM_BUFFERS];
   rtoc_grid* d_grid;
   uint32_t* d_status;
+  long long* d_prof;
   int writeback;
   double max_dts0;
   int bwd_variant;
@@ -205,6 +206,7 @@ int rtoc_destroy(rtoc_ctx* c) {
     if (c->owned[i] && c->buf[i]) (void)hipFree(c->buf[i]);
   (void)hipFree(c->d_grid);
   (void)hipFree(c->d_status);
+  if (c->d_prof) (void)hipFree(c->d_prof);
   (void)hipEventDestroy(c->ev0);
   (void)hipEventDestroy(c->ev1);
   (void)hipStreamDestroy(c->own_stream);
@@ -335,6 +337,7 @@ static int launch_backward(rtoc_ctx* c) {
   a.ric = c->buf[RTOC_BUF_RIC];
   a.grid = c->d_grid;
   a.status = c->d_status;
+  a.prof = c->d_prof;
   a.nstages = c->nstages;
   a.batch = c->batch;
   a.writeback = c->writeback;
@@ -471,6 +474,24 @@ int rtoc_clear_status(rtoc_ctx* c) {
   if (!c) return RTOC_ERR_BAD_ARG;
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipMemsetAsync(c->d_status, 0, sizeof(uint32_t) * c->batch, c->stream));
+  return RTOC_OK;
+}
+
+// Tuning aid (not part of the drop-in surface): attach a device buffer of nstages*16 int64 that
+// block 0 of the backward kernel fills with phase cycle stamps; nullptr detaches.
+int rtoc_debug_profile(rtoc_ctx* c, long long* host_out) {
+  if (!c) return RTOC_ERR_BAD_ARG;
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t n = (size_t)c->max_stages * 16;
+  if (!c->d_prof) {
+    HIP_TRY(hipMalloc((void**)&c->d_prof, n * sizeof(long long)));
+    HIP_TRY(hipMemsetAsync(c->d_prof, 0, n * sizeof(long long), c->stream));
+    return RTOC_OK;
+  }
+  if (host_out) {
+    HIP_TRY(hipMemcpyAsync(host_out, c->d_prof, n * sizeof(long long), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+  }
   return RTOC_OK;
 }
 

@@ -67,10 +67,51 @@ def test_anymal_trot_sweep(oracle, waves, mode):
 
 @pytest.mark.parametrize("waves", [1, 3])
 def test_anymal_jump_sto_sweep(oracle, waves):
-    """configs[2]: ANYmal jump with switching-time optimisation (STO policy, phase transitions, ns=12)."""
+    """configs[2]: ANYmal jump with switching-time optimisation (STO policy, phase transitions, ns=12).
+    "dynamics"-scaled data keep the 44-grid STO system well conditioned (a 1e-15 relative input
+    perturbation moves the oracle's own dxi by ~3e-11), so the 1e-8 tolerance is meaningful."""
     dims, grids, _ = pr.config_anymal_jump_sto()
     assert any(g.sto for g in grids)
-    _run_case(oracle, dims, grids, 4, "factory", waves=waves, tol=1e-8)
+    _run_case(oracle, dims, grids, 4, "dynamics", waves=waves, tol=1e-8)
+
+
+def test_anymal_jump_sto_ill_conditioned(oracle):
+    """Same grid with the reference's fully random factory data (kkt_factory.cpp:21-23): the STO
+    system is ill conditioned (fx, Fvq ~ U[-1,1]); the GPU must stay within the oracle's own
+    sensitivity to a 1e-15 relative perturbation of the inputs (x100 safety factor)."""
+    from robotoc_amd import capi
+    dims, grids, _ = pr.config_anymal_jump_sto()
+    batch = 2
+    ctx = capi.Context(dims, len(grids), batch, 0)
+    try:
+        L = ctx.L
+        ctx.set_grid(grids)
+        kkt = pr.make_kkt_batch(L, grids, batch, mode="factory")
+        dx0 = pr.make_dx0(L, batch)
+        ctx.upload(BUF_KKT, kkt)
+        ctx.upload(BUF_DX0, dx0)
+        ctx.riccati_backward()
+        ctx.riccati_forward()
+        d = ctx.download_records(BUF_DIR, "dir")
+        D = Records(L, "dir")
+        R = Records(L, "ric")
+
+        def run(k):
+            r_ = R.zeros(batch, len(grids))
+            d_ = D.zeros(batch, len(grids))
+            oracle.riccati_sweep_batch(L, grids, k.copy(), r_, d_, dx0=dx0)
+            return d_
+        d_ref = run(kkt)
+        rng = np.random.default_rng(1)
+        d_pert = run(kkt * (1.0 + 1e-15 * rng.standard_normal(kkt.shape)))
+        from helpers import rel_err
+        for f in ("dx", "du", "dlmdgmm", "dxi"):
+            sens = rel_err(D.f(d_pert, f), D.f(d_ref, f))
+            err = rel_err(D.f(d, f), D.f(d_ref, f))
+            print("%s: gpu-vs-oracle %.2e, oracle sensitivity %.2e" % (f, err, sens))
+            assert err <= max(1e-9, 100.0 * sens), (f, err, sens)
+    finally:
+        ctx.close()
 
 
 @pytest.mark.parametrize("nv", [35, 32])
