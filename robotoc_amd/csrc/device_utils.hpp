@@ -42,30 +42,48 @@ __device__ __forceinline__ void copy_g2s_flat(double* __restrict__ dst, const do
   if ((n & 1) && tid == 0) dst[n - 1] = src[n - 1];
 }
 
-// Column-major ROWS x COLS matrix (ld = ROWS in global) into LDS with leading dimension LD.
+// Column-major ROWS x COLS matrix copies (ld = ROWS in HBM, LD in LDS), 16 B per lane.
+// Lane mapping "column groups": CPL = ROWS/2 lanes cover one column, CPP = NT/CPL columns are
+// moved per pass.  (row pair, column offset) are computed once per call, every pass then uses
+// constant strides: no per-element div/mod, LDS and HBM addresses are affine in the pass index.
+template <int NT, int ROWS>
+struct MatMap {
+  static_assert(ROWS % 2 == 0, "even rows required for 16 B moves");
+  static constexpr int CPL = ROWS / 2;
+  static_assert(CPL <= NT, "one pass must cover at least one column");
+  static constexpr int CPP = NT / CPL;
+  static constexpr int passes(int cols) { return (cols + CPP - 1) / CPP; }
+};
+
 template <int NT, int ROWS, int COLS, int LD>
 __device__ __forceinline__ void copy_g2s_mat(double* __restrict__ dst, const double* __restrict__ src,
                                              int tid) {
-  static_assert(ROWS % 2 == 0 && LD % 2 == 0, "even rows / ld required for 16B moves");
-  constexpr int N2 = ROWS * COLS / 2;
-  const d2* s2 = reinterpret_cast<const d2*>(src);
-#pragma unroll 4
-  for (int e = tid; e < N2; e += NT) {
-    const int r = (2 * e) % ROWS, c = (2 * e) / ROWS;
-    *reinterpret_cast<d2*>(dst + r + c * LD) = s2[e];
+  using M = MatMap<NT, ROWS>;
+  static_assert(LD % 2 == 0, "even ld");
+  const int r2 = tid % M::CPL, c0 = tid / M::CPL;
+  const d2* s2 = reinterpret_cast<const d2*>(src) + r2 + c0 * M::CPL;
+  double* d = dst + 2 * r2 + c0 * LD;
+  const bool act = c0 < M::CPP;
+#pragma unroll
+  for (int k = 0; k < M::passes(COLS); ++k) {
+    if (act && (k * M::CPP + c0 < COLS))
+      *reinterpret_cast<d2*>(d + k * M::CPP * LD) = s2[k * M::CPP * M::CPL];
   }
 }
 
 template <int NT, int ROWS, int COLS, int LD>
 __device__ __forceinline__ void copy_s2g_mat(double* __restrict__ dst, const double* __restrict__ src,
                                              int tid) {
-  static_assert(ROWS % 2 == 0 && LD % 2 == 0, "even rows / ld required for 16B moves");
-  constexpr int N2 = ROWS * COLS / 2;
-  d2* t2 = reinterpret_cast<d2*>(dst);
-#pragma unroll 4
-  for (int e = tid; e < N2; e += NT) {
-    const int r = (2 * e) % ROWS, c = (2 * e) / ROWS;
-    t2[e] = *reinterpret_cast<const d2*>(src + r + c * LD);
+  using M = MatMap<NT, ROWS>;
+  static_assert(LD % 2 == 0, "even ld");
+  const int r2 = tid % M::CPL, c0 = tid / M::CPL;
+  d2* t2 = reinterpret_cast<d2*>(dst) + r2 + c0 * M::CPL;
+  const double* sp = src + 2 * r2 + c0 * LD;
+  const bool act = c0 < M::CPP;
+#pragma unroll
+  for (int k = 0; k < M::passes(COLS); ++k) {
+    if (act && (k * M::CPP + c0 < COLS))
+      t2[k * M::CPP * M::CPL] = *reinterpret_cast<const d2*>(sp + k * M::CPP * LD);
   }
 }
 

@@ -73,20 +73,21 @@ struct BwdCfg {
   // ---- LDS carve (doubles) ----
   static constexpr int OFF_P = 0;
   static constexpr int OFF_A = OFF_P + NX * LDP;
-  static constexpr int OFF_PB = OFF_A + NX * LDP;  // contiguous with A: SC scratch = [A | PB]
-  static constexpr int OFF_H = OFF_PB + NU * LDP;
-  static constexpr int OFF_KT = OFF_H + NU * LDP;
-  static constexpr int OFF_GK_OWN = OFF_KT + NU * LDP;
-  // (OFF_GK / OFF_BV / OFF_G / OFF_L / OFF_VEC are defined after the scratch carve below)
-  // ---- switching-constraint scratch, aliased on [A | PB] after the F product ----
-  static constexpr int S_PHIX = OFF_A;                    // NS x NX (ld NS)
-  static constexpr int S_M = S_PHIX + pad8(NSP * NX);     // NS x NX (ld NS)
+  static constexpr int OFF_PB = OFF_A + NX * LDP;   // PB = P+[:,v] Bv; dead after PAa -> reused for K^T
+  static constexpr int OFF_KT = OFF_PB;
+  static constexpr int OFF_H = OFF_PB + NU * LDP;   // H = Qxu'; dead after the K solve -> reused for GK
+  static constexpr int OFF_GK = OFF_H;
+  static constexpr int OFF_BV = OFF_H + NU * LDP;
+  static constexpr int OFF_G = OFF_BV + pad8(NV * NU);
+  static constexpr int OFF_L = OFF_G + pad8(NU * NU);
+  static constexpr int OFF_VEC = OFF_L + pad8(NU * NU);
+  // ---- switching-constraint scratch, aliased on A after the F product ----
+  static constexpr int S_M = OFF_A;                       // NS x NX (ld NS)
   static constexpr int S_PHIU = S_M + pad8(NSP * NX);     // NS x NU (ld NS)
   static constexpr int S_DGINV = S_PHIU + pad8(NSP * NU); // NS x NU
   static constexpr int S_SDG = S_DGINV + pad8(NSP * NU);  // SinvDGinv NS x NU
   static constexpr int S_GINV = S_SDG + pad8(NSP * NU);   // NU x NU
-  static constexpr int S_S = S_GINV + pad8(NU * NU);      // NS x NS
-  static constexpr int S_LS = S_S + pad8(NSP * NSP);      // NS x NS
+  static constexpr int S_LS = S_GINV + pad8(NU * NU);     // NS x NS: S, factorised in place
   static constexpr int S_PHIT = S_LS + pad8(NSP * NSP);
   static constexpr int S_PRES = S_PHIT + pad8(NSP);
   static constexpr int S_MV = S_PRES + pad8(NSP);
@@ -94,13 +95,6 @@ struct BwdCfg {
   static constexpr int S_MTN = S_MT + pad8(NSP);
   static constexpr int S_LSINV = S_MTN + pad8(NSP);
   static constexpr int S_END = S_LSINV + pad8(NSP);
-  // GK = G K is written after A is dead: host it behind the scratch when it fits (iCub sizes)
-  static constexpr bool GK_IN_SCRATCH = (S_END + pad8(NU * NX) <= OFF_H);
-  static constexpr int OFF_GK = GK_IN_SCRATCH ? S_END : OFF_GK_OWN;
-  static constexpr int OFF_BV = GK_IN_SCRATCH ? OFF_GK_OWN : OFF_GK_OWN + pad8(NU * NX);
-  static constexpr int OFF_G = OFF_BV + pad8(NV * NU);
-  static constexpr int OFF_L = OFF_G + pad8(NU * NU);
-  static constexpr int OFF_VEC = OFF_L + pad8(NU * NU);
   static constexpr int VX = pad8(NX), VU = pad8(NU);
   // vectors
   static constexpr int V_SN = OFF_VEC;          // s+
@@ -131,9 +125,61 @@ struct BwdCfg {
   static constexpr int V_FLAG = V_KSC + 8;      // status accumulation (as double bits)
   static constexpr int LDS_DOUBLES = V_FLAG + 8;
   static constexpr int LDS_BYTES = LDS_DOUBLES * 8;
-  static_assert(NS == 0 || S_END <= OFF_H, "switching-constraint scratch must fit in [A|PB]");
+  static_assert(NS == 0 || S_END <= OFF_PB, "switching-constraint scratch must fit in A");
   static_assert(NX + 1 <= NT, "need one thread per state entry plus one");
 };
+
+// ---- register prefetch of the next stage's record (HBM latency hidden behind the current stage) ----
+template <int NT, int N2>
+struct PreCnt { static constexpr int value = (N2 + NT - 1) / NT; };
+template <int CNT>
+struct PreBuf { d2 v[CNT]; };
+
+template <int NT, int N2>
+__device__ __forceinline__ void pre_load(PreBuf<PreCnt<NT, N2>::value>& buf, const double* __restrict__ src, int tid) {
+  d2* v = buf.v;
+  const d2* s2 = reinterpret_cast<const d2*>(src);
+#pragma unroll
+  for (int k = 0; k < PreCnt<NT, N2>::value; ++k) {
+    const int e = tid + k * NT;
+    if (e < N2) v[k] = s2[e];
+  }
+}
+
+template <int NT, int ROWS, int COLS>
+__device__ __forceinline__ void pre_load_mat(PreBuf<MatMap<NT, ROWS>::passes(COLS)>& buf,
+                                             const double* __restrict__ src, int tid) {
+  using M = MatMap<NT, ROWS>;
+  const int r2 = tid % M::CPL, c0 = tid / M::CPL;
+  const d2* s2 = reinterpret_cast<const d2*>(src) + r2 + c0 * M::CPL;
+  const bool act = c0 < M::CPP;
+#pragma unroll
+  for (int k = 0; k < M::passes(COLS); ++k)
+    if (act && (k * M::CPP + c0 < COLS)) buf.v[k] = s2[k * M::CPP * M::CPL];
+}
+
+template <int NT, int ROWS, int COLS, int LD>
+__device__ __forceinline__ void pre_store_mat(double* __restrict__ dst,
+                                              const PreBuf<MatMap<NT, ROWS>::passes(COLS)>& buf, int tid) {
+  using M = MatMap<NT, ROWS>;
+  static_assert(LD % 2 == 0, "even ld");
+  const int r2 = tid % M::CPL, c0 = tid / M::CPL;
+  double* d = dst + 2 * r2 + c0 * LD;
+  const bool act = c0 < M::CPP;
+#pragma unroll
+  for (int k = 0; k < M::passes(COLS); ++k)
+    if (act && (k * M::CPP + c0 < COLS)) *reinterpret_cast<d2*>(d + k * M::CPP * LD) = buf.v[k];
+}
+
+template <int NT, int N2>
+__device__ __forceinline__ void pre_store_flat(double* __restrict__ dst, const PreBuf<PreCnt<NT, N2>::value>& buf, int tid) {
+  const d2* v = buf.v;
+#pragma unroll
+  for (int k = 0; k < PreCnt<NT, N2>::value; ++k) {
+    const int e = tid + k * NT;
+    if (e < N2) reinterpret_cast<d2*>(dst)[e] = v[k];
+  }
+}
 
 // In-wave Cholesky of an n x n SPD matrix held in LDS (column-major, ld = LD).
 // Lane i owns row i in registers; pivots / columns travel by wave shuffles.
@@ -243,6 +289,31 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
     copy_s2g_mat<NT, NX, NX, LDP>(rr + ro[RTOC_RIC_P], sP, tid);
   }
 
+  // prefetch registers (next stage's record, loaded one stage ahead)
+  constexpr int N2B = (NV * NU + 1) / 2, N2G = (NU * NU + 1) / 2;
+  PreBuf<MatMap<NT, NX>::passes(NX)> preA, preQ;
+  PreBuf<MatMap<NT, NX>::passes(NU)> preH;
+  PreBuf<PreCnt<NT, N2B>::value> preB;
+  PreBuf<PreCnt<NT, N2G>::value> preG;
+  double preFx = 0.0, preLx = 0.0, preLu = 0.0;
+  auto issue_loads = [&](int stage) {
+    const double* kp = a.kkt + kinst + (size_t)stage * a.kl.stride;
+    const bool imp = a.grid[stage].type == RTOC_GRID_IMPACT;
+    pre_load_mat<NT, NX, NX>(preA, kp + ko[RTOC_KKT_FXX], tid);
+    pre_load_mat<NT, NX, NX>(preQ, kp + ko[RTOC_KKT_QXX], tid);
+    if (!imp) {
+      pre_load_mat<NT, NX, NU>(preH, kp + ko[RTOC_KKT_QXU], tid);
+      pre_load<NT, N2B>(preB, kp + ko[RTOC_KKT_FVU], tid);
+      pre_load<NT, N2G>(preG, kp + ko[RTOC_KKT_QUU], tid);
+    }
+    if (tid < NX) {
+      preFx = kp[ko[RTOC_KKT_FX] + tid];
+      preLx = kp[ko[RTOC_KKT_LX] + tid];
+    }
+    if (!imp && tid < NU) preLu = kp[ko[RTOC_KKT_LU] + tid];
+  };
+  if (N >= 1) issue_loads(N - 1);
+
   for (int st = N - 1; st >= 0; --st) {
     // Opaque re-definition of the thread index per stage: keeps LLVM's LICM from hoisting the
     // (hundreds of) per-lane LDS/HBM address computations of the unrolled copy and MFMA loops
@@ -322,33 +393,33 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
     }
 
     RTOC_PROF(1);
-    // ---- stage data: HBM -> LDS (coalesced 16 B / lane) ----
-    copy_g2s_mat<NT, NX, NX, LDP>(sA, kr + ko[RTOC_KKT_FXX], tid);
+    // ---- stage data: prefetched registers -> LDS (the HBM loads were issued one stage ahead) ----
+    pre_store_mat<NT, NX, NX, LDP>(sA, preA, tid);
     if (!impact) {
-      copy_g2s_flat<NT>(sBv, kr + ko[RTOC_KKT_FVU], NV * NU, tid);
-      copy_g2s_mat<NT, NX, NU, LDP>(sH, kr + ko[RTOC_KKT_QXU], tid);
-      copy_g2s_flat<NT>(sG, kr + ko[RTOC_KKT_QUU], NU * NU, tid);
+      pre_store_flat<NT, N2B>(sBv, preB, tid);
+      pre_store_mat<NT, NX, NU, LDP>(sH, preH, tid);
+      pre_store_flat<NT, N2G>(sG, preG, tid);
     }
     if (tid < NX) {
-      smem[C::V_FX + tid] = kr[ko[RTOC_KKT_FX] + tid];
-      smem[C::V_LX + tid] = kr[ko[RTOC_KKT_LX] + tid];
+      smem[C::V_FX + tid] = preFx;
+      smem[C::V_LX + tid] = preLx;
       if (sto) {
         smem[C::V_FFX + tid] = kr[ko[RTOC_KKT_FFX] + tid];
         smem[C::V_HX + tid] = kr[ko[RTOC_KKT_HX] + tid];
       }
     }
     if (!impact && tid < NU) {
-      smem[C::V_LU + tid] = kr[ko[RTOC_KKT_LU] + tid];
+      smem[C::V_LU + tid] = preLu;
       if (sto) smem[C::V_HU + tid] = kr[ko[RTOC_KKT_HU] + tid];
     }
-    if (tid < 8) smem[C::V_KSC + tid] = kr[ko[RTOC_KKT_SCAL] + tid];
+    if (sto && tid < 8) smem[C::V_KSC + tid] = kr[ko[RTOC_KKT_SCAL] + tid];
     __syncthreads();
 
     RTOC_PROF(2);
     // ---- z = s+ - P+ Fx ;  y = P+ fx + Psi+ (STO) ----
     if (tid < NX) {
       double acc = 0.0, accy = 0.0;
-#pragma unroll 4
+#pragma unroll
       for (int k = 0; k < NX; ++k) {
         const double p = sP[tid + k * LDP];
         acc += p * smem[C::V_FX + k];
@@ -436,7 +507,7 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
       }
       if (tid < NU) {
         double acc = 0.0, ap = 0.0, aph = 0.0;
-#pragma unroll 2
+#pragma unroll
         for (int k = 0; k < NV; ++k) {
           const double bv = sBv[k + tid * NV];
           acc += bv * smem[C::V_Z + NV + k];
@@ -520,7 +591,7 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
     // ---- s-vector part that needs A: w = A^T z  (and STO: psi_x, phi_x) ----
     if (tid < NX) {
       double acc = 0.0, ap = 0.0, aph = 0.0;
-#pragma unroll 4
+#pragma unroll
       for (int k = 0; k < NX; ++k) {
         const double av = sA[k + tid * LDP];
         acc += av * smem[C::V_Z + k];
@@ -544,7 +615,11 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
     // ---- F = Qxx + AtP A, chained: A-operand = PAa registers (row-tile = owned column tile) ----
     d4 f[CNT][TNX];
     {
-      const double* qxx = kr + ko[RTOC_KKT_QXX];
+      // Qxx (prefetched, coalesced) -> sP staging (P+ is dead: every wave finished PAa) -> MFMA C layout
+      __syncthreads();
+      pre_store_mat<NT, NX, NX, LDP>(sP, preQ, tid);
+      __syncthreads();
+      const double* pq_ = sP + (wave * 16 + q) + li * LDP;
 #pragma unroll
       for (int c = 0; c < CNT; ++c)
 #pragma unroll
@@ -552,8 +627,16 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int i = (wave + c * NW) * 16 + drow(q, r), j = t * 16 + li;
-            f[c][t][r] = (i < NX && j < NX) ? qxx[i + j * NX] : 0.0;
+            const double v = pq_[c * NW * 16 + 4 * r + t * 16 * LDP];
+            f[c][t][r] = (i < NX && j < NX) ? v : 0.0;
           }
+      // next stage's record: HBM -> registers, in flight for the rest of this stage
+      if (st > 0) issue_loads(st - 1);
+      // ---- LLT(G) by wave 0 (riccati_factorizer.cpp:49): VALU / shuffle work issued next to the
+      //      independent F-chain MFMAs below so that the two pipes overlap ----
+      if (!impact && wave == 0) {
+        if (wave_llt<NU, NU>(sG, sL, smem + C::V_LINV, NU, lane)) stat |= RTOC_STAT_QUU_NOT_SPD;
+      }
       const double* pbf_ = sA + q + li * LDP;  // A[k][j]
 #pragma unroll
       for (int tm = 0; tm < TMA; ++tm)
@@ -577,16 +660,11 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
         }
     }
     RTOC_PROF(6);
-    __syncthreads();  // H complete; sA / sPB / sP(+) no longer read by MFMA after this point
+    __syncthreads();  // L published; sA / sPB no longer read by MFMA after this point
 
     if (impact) {
       // riccati_factorizer.cpp:178-197 -- no policy
     } else {
-      // ---- LLT(G) by wave 0 (riccati_factorizer.cpp:49) ----
-      if (wave == 0) {
-        if (wave_llt<NU, NU>(sG, sL, smem + C::V_LINV, NU, lane)) stat |= RTOC_STAT_QUU_NOT_SPD;
-      }
-      __syncthreads();
       if (ns == 0) {
         // K = -G^-1 H^T, k = -G^-1 lu   (:55-56); thread t < NX owns column t, thread NX owns k
         if (tid <= NX) {
@@ -627,19 +705,14 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
         }
       } else if (NS > 0) {
         // ---- Schur complement with the switching constraint (:58-77), VALU on LDS scratch ----
-        double* const cPhix = smem + C::S_PHIX;
+        const double* const gPhix = kr + ko[RTOC_KKT_PHIX];  // ns x NX, ld NS, read from HBM/L2
         double* const cM = smem + C::S_M;
         double* const cPhiu = smem + C::S_PHIU;
         double* const cDG = smem + C::S_DGINV;
         double* const cSDG = smem + C::S_SDG;
         double* const cGinv = smem + C::S_GINV;
-        double* const cS = smem + C::S_S;
         double* const cLs = smem + C::S_LS;
         constexpr int LN = C::NSP;
-        for (int e = tid; e < ns * NX; e += NT) {
-          const int l = e % ns, j = e / ns;
-          cPhix[l + j * LN] = kr[ko[RTOC_KKT_PHIX] + l + j * NS];
-        }
         for (int e = tid; e < ns * NU; e += NT) {
           const int l = e % ns, u = e / ns;
           cPhiu[l + u * LN] = kr[ko[RTOC_KKT_PHIU] + l + u * NS];
@@ -671,11 +744,11 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
           const int i = e % ns, j = e / ns;
           double acc = 0.0;
           for (int u = 0; u < NU; ++u) acc += cDG[i + u * LN] * cPhiu[j + u * LN];
-          cS[i + j * LN] = acc;
+          cLs[i + j * LN] = acc;
         }
         __syncthreads();
         if (wave == 0) {
-          if (wave_llt<C::NSP, C::NSP>(cS, cLs, smem + C::S_LSINV, ns, lane))
+          if (wave_llt<C::NSP, C::NSP>(cLs, cLs, smem + C::S_LSINV, ns, lane))
             stat |= RTOC_STAT_S_NOT_SPD;
         }
         __syncthreads();
@@ -690,7 +763,7 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
               if (t < NU)
                 v = cDG[l + t * LN];
               else if (t < NU + NX)
-                v = cPhix[l + (t - NU) * LN];
+                v = gPhix[l + (t - NU) * NS];
               else if (t == NU + NX)
                 v = smem[C::S_PRES + l];
               else
@@ -727,7 +800,7 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
           const int j = e % NX, u = e / NX;
           double acc = 0.0;
           for (int l = 0; l < NU; ++l) acc += cGinv[u + l * NU] * sH[j + l * LDP];
-          for (int l = 0; l < ns; ++l) acc += cSDG[l + u * LN] * cPhix[l + j * LN];
+          for (int l = 0; l < ns; ++l) acc += cSDG[l + u * LN] * gPhix[l + j * NS];
           sKt[j + u * LDP] = -acc;
           if (is_bad(acc)) stat |= RTOC_STAT_NAN;
         }
@@ -792,13 +865,21 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
         }
         if (tid < NX) {
           double acc = 0.0;
-          for (int l = 0; l < ns; ++l) acc += cPhix[l + tid * LN] * smem[C::S_MV + l];
+          for (int l = 0; l < ns; ++l) acc += gPhix[l + tid * NS] * smem[C::S_MV + l];
+          for (int u = 0; u < NU; ++u) acc += sH[tid + u * LDP] * smem[C::V_KV + u];  // + H k (brrf.cpp:90)
           smem[C::V_SNEW + tid] -= acc;
         }
       }
       __syncthreads();
 
       RTOC_PROF(7);
+      if (a.writeback) {  // mutated Qxu, Quu, lu (reference in-place semantics), before H is reused
+        double* kw = a.kkt_rw + kinst + (size_t)st * a.kl.stride;
+        copy_s2g_mat<NT, NX, NU, LDP>(kw + ko[RTOC_KKT_QXU], sH, tid);
+        copy_s2g_flat<NT>(kw + ko[RTOC_KKT_QUU], sG, NU * NU, tid);
+        if (tid < NU) kw[ko[RTOC_KKT_LU] + tid] = smem[C::V_LU + tid];
+        __syncthreads();
+      }
       // ---- GK = G K (+ 2 Phiu^T M on switching-constraint grids, which folds
       //      P -= KtDtM + KtDtM^T (:84-87) into the symmetrised F - K^T GK) ----
       {
@@ -874,11 +955,12 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
             for (int t = 0; t < TNX; ++t) f[c][t] = mfma16(av[c], bv[t], f[c][t]);
         }
       }
-      // s -= H k  (brrf.cpp:90)
-      if (tid < NX) {
+      // s -= H k  (brrf.cpp:90).  Without switching constraint K^T = -H G^-1, hence H k = K^T lu'
+      // (H itself has been overwritten by GK); the constrained path subtracted H k above.
+      if (ns == 0 && tid < NX) {
         double acc = 0.0;
 #pragma unroll
-        for (int u = 0; u < NU; ++u) acc += sH[tid + u * LDP] * smem[C::V_KV + u];
+        for (int u = 0; u < NU; ++u) acc += sKt[tid + u * LDP] * smem[C::V_LU + u];
         smem[C::V_SNEW + tid] -= acc;
       }
     }
@@ -896,31 +978,43 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
             const int i = (wave + c * NW) * 16 + drow(q, r), j = t * 16 + li;
             if (i < NX && j < NX) kw[ko[RTOC_KKT_QXX] + i + j * NX] = f[c][t][r];
           }
-      if (!impact) {
-        copy_s2g_mat<NT, NX, NU, LDP>(kw + ko[RTOC_KKT_QXU], sH, tid);
-        copy_s2g_flat<NT>(kw + ko[RTOC_KKT_QUU], sG, NU * NU, tid);
-        if (tid < NU) kw[ko[RTOC_KKT_LU] + tid] = smem[C::V_LU + tid];
-      }
     }
 
-    // ---- F -> sP, symmetrise: P = (F + F^T)/2 (brrf.cpp:85) ----
+    // ---- P = (F + F^T)/2 (brrf.cpp:85): F -> sP, read back the transposed element in the MFMA
+    //      register layout (affine LDS addresses), average, store.  0.5*(a+b) is commutative, so
+    //      P is exactly symmetric. ----
+    {
+      double* pw_ = sP + (wave * 16 + q) + li * LDP;        // F[i][j] at i + j*LDP
+      const double* pr_ = sP + li + (wave * 16 + q) * LDP;  // F[j][i]
 #pragma unroll
-    for (int c = 0; c < CNT; ++c)
+      for (int c = 0; c < CNT; ++c)
 #pragma unroll
-      for (int t = 0; t < TNX; ++t)
+        for (int t = 0; t < TNX; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int i = (wave + c * NW) * 16 + drow(q, r), j = t * 16 + li;
-          if (i < NX && j < NX) sP[i + j * LDP] = f[c][t][r];
-        }
-    __syncthreads();
-    for (int e = tid; e < NX * NX; e += NT) {
-      const int i = e % NX, j = e / NX;
-      if (i < j) {
-        const double p = 0.5 * (sP[i + j * LDP] + sP[j + i * LDP]);
-        sP[i + j * LDP] = p;
-        sP[j + i * LDP] = p;
-      }
+          for (int r = 0; r < 4; ++r) {
+            const int i = (wave + c * NW) * 16 + drow(q, r), j = t * 16 + li;
+            if (i < NX && j < NX) pw_[c * NW * 16 + 4 * r + t * 16 * LDP] = f[c][t][r];
+          }
+      __syncthreads();
+#pragma unroll
+      for (int c = 0; c < CNT; ++c)
+#pragma unroll
+        for (int t = 0; t < TNX; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const double v = pr_[t * 16 + (c * NW * 16 + 4 * r) * LDP];
+            f[c][t][r] = 0.5 * (f[c][t][r] + v);
+          }
+      __syncthreads();
+#pragma unroll
+      for (int c = 0; c < CNT; ++c)
+#pragma unroll
+        for (int t = 0; t < TNX; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = (wave + c * NW) * 16 + drow(q, r), j = t * 16 + li;
+            if (i < NX && j < NX) pw_[c * NW * 16 + 4 * r + t * 16 * LDP] = f[c][t][r];
+          }
     }
 
     RTOC_PROF(10);
