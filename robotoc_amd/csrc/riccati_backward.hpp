@@ -704,171 +704,7 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
           }
         }
       } else if (NS > 0) {
-        // ---- Schur complement with the switching constraint (:58-77), VALU on LDS scratch ----
-        const double* const gPhix = kr + ko[RTOC_KKT_PHIX];  // ns x NX, ld NS, read from HBM/L2
-        double* const cM = smem + C::S_M;
-        double* const cPhiu = smem + C::S_PHIU;
-        double* const cDG = smem + C::S_DGINV;
-        double* const cSDG = smem + C::S_SDG;
-        double* const cGinv = smem + C::S_GINV;
-        double* const cLs = smem + C::S_LS;
-        constexpr int LN = C::NSP;
-        for (int e = tid; e < ns * NU; e += NT) {
-          const int l = e % ns, u = e / ns;
-          cPhiu[l + u * LN] = kr[ko[RTOC_KKT_PHIU] + l + u * NS];
-        }
-        if (tid < ns) {
-          smem[C::S_PHIT + tid] = kr[ko[RTOC_KKT_PHIT] + tid];
-          smem[C::S_PRES + tid] = kr[ko[RTOC_KKT_PRES] + tid];
-        }
-        __syncthreads();
-        // Ginv = G^-1 (thread t<NU: column t) ; DGinv^T = G^-1 Phiu^T (thread NU+l: row l)
-        if (tid < NU + ns) {
-          double x[NU];
-          const bool isg = tid < NU;
-          const int l = tid - NU;
-#pragma unroll
-          for (int u = 0; u < NU; ++u) x[u] = isg ? (u == tid ? 1.0 : 0.0) : cPhiu[l + u * LN];
-          llt_solve_reg<NU, NU>(sL, smem + C::V_LINV, x, NU);
-#pragma unroll
-          for (int u = 0; u < NU; ++u) {
-            if (isg)
-              cGinv[u + tid * NU] = x[u];
-            else
-              cDG[l + u * LN] = x[u];
-          }
-        }
-        __syncthreads();
-        // S = DGinv Phiu^T
-        for (int e = tid; e < ns * ns; e += NT) {
-          const int i = e % ns, j = e / ns;
-          double acc = 0.0;
-          for (int u = 0; u < NU; ++u) acc += cDG[i + u * LN] * cPhiu[j + u * LN];
-          cLs[i + j * LN] = acc;
-        }
-        __syncthreads();
-        if (wave == 0) {
-          if (wave_llt<C::NSP, C::NSP>(cLs, cLs, smem + C::S_LSINV, ns, lane))
-            stat |= RTOC_STAT_S_NOT_SPD;
-        }
-        __syncthreads();
-        // SinvDGinv = S^-1 DGinv (thread u<NU: column u) ; M0 = S^-1 Phix (thread NU+j: column j)
-        // m0 = S^-1 Pres, mt0 = S^-1 Phit handled by two more threads.
-        for (int t = tid; t < NU + NX + 2; t += NT) {
-          double x[C::NSP];
-#pragma unroll
-          for (int l = 0; l < C::NSP; ++l) {
-            double v = 0.0;
-            if (l < ns) {
-              if (t < NU)
-                v = cDG[l + t * LN];
-              else if (t < NU + NX)
-                v = gPhix[l + (t - NU) * NS];
-              else if (t == NU + NX)
-                v = smem[C::S_PRES + l];
-              else
-                v = smem[C::S_PHIT + l];
-            }
-            x[l] = v;
-          }
-          llt_solve_reg<C::NSP, C::NSP>(cLs, smem + C::S_LSINV, x, ns);
-#pragma unroll
-          for (int l = 0; l < C::NSP; ++l) {
-            if (l < ns) {
-              if (t < NU)
-                cSDG[l + t * LN] = x[l];
-              else if (t < NU + NX)
-                cM[l + (t - NU) * LN] = x[l];
-              else if (t == NU + NX)
-                smem[C::S_MV + l] = x[l];
-              else
-                smem[C::S_MT + l] = x[l];
-            }
-          }
-        }
-        __syncthreads();
-        // Ginv -= SinvDGinv^T DGinv
-        for (int e = tid; e < NU * NU; e += NT) {
-          const int i = e % NU, j = e / NU;
-          double acc = 0.0;
-          for (int l = 0; l < ns; ++l) acc += cSDG[l + i * LN] * cDG[l + j * LN];
-          cGinv[i + j * NU] -= acc;
-        }
-        __syncthreads();
-        // K = -Ginv H^T - SinvDGinv^T Phix ; M -= SinvDGinv H^T      (:67-72)
-        for (int e = tid; e < NX * NU; e += NT) {
-          const int j = e % NX, u = e / NX;
-          double acc = 0.0;
-          for (int l = 0; l < NU; ++l) acc += cGinv[u + l * NU] * sH[j + l * LDP];
-          for (int l = 0; l < ns; ++l) acc += cSDG[l + u * LN] * gPhix[l + j * NS];
-          sKt[j + u * LDP] = -acc;
-          if (is_bad(acc)) stat |= RTOC_STAT_NAN;
-        }
-        for (int e = tid; e < NX * ns; e += NT) {
-          const int l = e % ns, j = e / ns;
-          double acc = 0.0;
-          for (int u = 0; u < NU; ++u) acc += cSDG[l + u * LN] * sH[j + u * LDP];
-          const double v = cM[l + j * LN] - acc;  // each (l,j) owned by one thread
-          cM[l + j * LN] = v;
-          if (is_bad(v)) stat |= RTOC_STAT_NAN;
-        }
-        // k = -Ginv lu - SinvDGinv^T P ; m = S^-1 P - SinvDGinv lu     (:69-74)
-        if (tid < NU) {
-          double acc = 0.0;
-          for (int l = 0; l < NU; ++l) acc += cGinv[tid + l * NU] * smem[C::V_LU + l];
-          for (int l = 0; l < ns; ++l) acc += cSDG[l + tid * LN] * smem[C::S_PRES + l];
-          smem[C::V_KV + tid] = -acc;
-          if (is_bad(acc)) stat |= RTOC_STAT_NAN;
-          if (sto) {
-            // T = -Ginv psi_u - SinvDGinv^T Phit ; W = -Ginv phi_u   (:110-115)
-            double at = 0.0, aw = 0.0;
-            for (int l = 0; l < NU; ++l) {
-              at += cGinv[tid + l * NU] * smem[C::V_PSIU + l];
-              aw += cGinv[tid + l * NU] * smem[C::V_PHIU + l];
-            }
-            for (int l = 0; l < ns; ++l) at += cSDG[l + tid * LN] * smem[C::S_PHIT + l];
-            smem[C::V_TV + tid] = -at;
-            smem[C::V_WV + tid] = sto_next ? -aw : 0.0;
-          }
-        } else if (tid >= 64 * (NW - 1) + 32 && tid < 64 * (NW - 1) + 32 + ns) {
-          const int l = tid - (64 * (NW - 1) + 32);
-          double acc = 0.0, amt = 0.0, amn = 0.0;
-          for (int u = 0; u < NU; ++u) {
-            const double sd = cSDG[l + u * LN];
-            acc += sd * smem[C::V_LU + u];
-            if (sto) {
-              amt += sd * smem[C::V_PSIU + u];
-              amn += sd * smem[C::V_PHIU + u];
-            }
-          }
-          const double mv = smem[C::S_MV + l] - acc;
-          smem[C::S_MV + l] = mv;
-          if (is_bad(mv)) stat |= RTOC_STAT_NAN;
-          if (sto) {
-            smem[C::S_MT + l] = smem[C::S_MT + l] - amt;   // mt      (:116-117)
-            smem[C::S_MTN + l] = sto_next ? -amn : 0.0;    // mt_next (:118-123)
-          }
-        }
-        __syncthreads();
-        // write M, m (+mt, mt_next) ; s -= Phix^T m                    (:88)
-        double* mg = rr + ro[RTOC_RIC_M];
-        for (int e = tid; e < ns * NX; e += NT) {
-          const int l = e % ns, j = e / ns;
-          mg[l + j * NS] = cM[l + j * LN];
-        }
-        if (tid < ns) {
-          rr[ro[RTOC_RIC_MV] + tid] = smem[C::S_MV + tid];
-          if (sto) {
-            rr[ro[RTOC_RIC_MT] + tid] = smem[C::S_MT + tid];
-            rr[ro[RTOC_RIC_MTN] + tid] = smem[C::S_MTN + tid];
-          }
-        }
-        if (tid < NX) {
-          double acc = 0.0;
-          for (int l = 0; l < ns; ++l) acc += gPhix[l + tid * NS] * smem[C::S_MV + l];
-          for (int u = 0; u < NU; ++u) acc += sH[tid + u * LDP] * smem[C::V_KV + u];  // + H k (brrf.cpp:90)
-          smem[C::V_SNEW + tid] -= acc;
-        }
+#include "riccati_sc_block.inc"
       }
       __syncthreads();
 
@@ -1018,96 +854,7 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
     }
 
     RTOC_PROF(10);
-    // ---- STO scalars / vectors (brrf.cpp:94-143, riccati_factorizer.cpp:93-142) ----
-    if (sto && !impact) {
-      // Psi = psi_x + K^T psi_u ; Phi = phi_x + K^T phi_u
-      if (tid < NX) {
-        double ap = 0.0, aph = 0.0;
-#pragma unroll
-        for (int u = 0; u < NU; ++u) {
-          const double kt = sKt[tid + u * LDP];
-          ap += kt * smem[C::V_PSIU + u];
-          aph += kt * smem[C::V_PHIU + u];
-        }
-        double psi = smem[C::V_PSIX + tid] + ap;
-        if (NS > 0 && ns > 0) {
-          double am = 0.0;
-          for (int l = 0; l < ns; ++l) am += smem[C::S_M + l + tid * C::NSP] * smem[C::S_PHIT + l];
-          psi += am;  // Psi += M^T Phit (:136)
-        }
-        smem[C::V_PSI + tid] = psi;
-        smem[C::V_PHI + tid] = sto_next ? smem[C::V_PHIX + tid] + aph : 0.0;
-      }
-      if (tid == 0) {
-        // xi, chi, rho, eta, iota  (brrf.cpp:110-142).  y = P+ fx + Psi+, z = s+ - P+ Fx.
-        double fPf = 0.0, psif = 0.0, phif = 0.0, fz = 0.0, psiF = 0.0, phiF = 0.0;
-#pragma unroll 1
-        for (int k = 0; k < NX; ++k) {
-          const double fxk = smem[C::V_FFX + k], Fxk = smem[C::V_FX + k];
-          const double psin = smem[C::V_PSIN + k], phin = smem[C::V_PHIN + k];
-          fPf += fxk * (smem[C::V_Y + k] - psin);
-          psif += psin * fxk;
-          phif += phin * fxk;
-          fz += fxk * smem[C::V_Z + k];
-          psiF += psin * Fxk;
-          phiF += phin * Fxk;
-        }
-        double Tpsi = 0.0, Tphi = 0.0, Wphi = 0.0, psik = 0.0, phik = 0.0;
-#pragma unroll 1
-        for (int u = 0; u < NU; ++u) {
-          Tpsi += smem[C::V_TV + u] * smem[C::V_PSIU + u];
-          Tphi += smem[C::V_TV + u] * smem[C::V_PHIU + u];
-          Wphi += smem[C::V_WV + u] * smem[C::V_PHIU + u];
-          psik += smem[C::V_PSIU + u] * smem[C::V_KV + u];
-          phik += smem[C::V_PHIU + u] * smem[C::V_KV + u];
-        }
-        double xi = fPf + smem[C::V_KSC + 0] + 2.0 * psif + Tpsi + smem[C::V_SCN + 0];
-        double chi = 0.0, rho = 0.0, iota = 0.0;
-        if (sto_next) {
-          chi = smem[C::V_KSC + 1] + phif + Tphi + smem[C::V_SCN + 1];
-          rho = Wphi + smem[C::V_SCN + 2];
-          iota = phiF + phik + smem[C::V_SCN + 4];
-        }
-        double eta = -fz + smem[C::V_KSC + 2] + psiF + psik + smem[C::V_SCN + 3];
-        if (NS > 0 && ns > 0) {
-          for (int l = 0; l < ns; ++l) {
-            const double pt = smem[C::S_PHIT + l];
-            xi += smem[C::S_MT + l] * pt;
-            if (sto_next) chi += smem[C::S_MTN + l] * pt;
-            eta += smem[C::S_MV + l] * pt;
-          }
-        }
-        smem[C::V_SC + 0] = xi;
-        smem[C::V_SC + 1] = chi;
-        smem[C::V_SC + 2] = rho;
-        smem[C::V_SC + 3] = eta;
-        smem[C::V_SC + 4] = iota;
-      }
-    } else if (sto && impact) {
-      // brrf.cpp:160-174
-      if (tid < NX) {
-        smem[C::V_PSI + tid] = 0.0;
-        smem[C::V_PHI + tid] = smem[C::V_PHIX + tid];
-      }
-      if (tid == 0) {
-        double phiF = 0.0;
-#pragma unroll 1
-        for (int k = 0; k < NX; ++k) phiF += smem[C::V_PHIN + k] * smem[C::V_FX + k];
-        smem[C::V_SC + 0] = 0.0;
-        smem[C::V_SC + 1] = 0.0;
-        smem[C::V_SC + 2] = smem[C::V_SCN + 2];
-        smem[C::V_SC + 3] = 0.0;
-        smem[C::V_SC + 4] = smem[C::V_SCN + 4] + phiF;
-      }
-    } else {
-      // !sto: Psi = 0, xi = chi = eta = 0 (riccati_factorizer.cpp:99-105); Phi/rho/iota are
-      // never read downstream in that case, they are zeroed for determinism.
-      if (tid < NX) {
-        smem[C::V_PSI + tid] = 0.0;
-        smem[C::V_PHI + tid] = 0.0;
-      }
-      if (tid < 8) smem[C::V_SC + tid] = 0.0;
-    }
+#include "riccati_sto_block.inc"
     __syncthreads();
 
     RTOC_PROF(11);
