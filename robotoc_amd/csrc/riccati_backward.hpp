@@ -232,6 +232,9 @@ __device__ __forceinline__ void llt_solve_reg(const double* __restrict__ L,
       for (int k = 0; k < i; ++k) v -= L[i + k * LD] * x[k];
       x[i] = v * linv[i];
     }
+    // keep the scheduler from hoisting the (uniform) loads of the whole factor ahead of the chain:
+    // the rows are serially dependent anyway, and ~80 hoisted doubles cost 160 VGPRs
+    if ((i & 1) == 1) __builtin_amdgcn_sched_barrier(0);
   }
 #pragma unroll
   for (int i = NMAX - 1; i >= 0; --i) {
@@ -242,6 +245,7 @@ __device__ __forceinline__ void llt_solve_reg(const double* __restrict__ L,
         if (k < n) v -= L[k + i * LD] * x[k];
       x[i] = v * linv[i];
     }
+    if ((i & 1) == 0) __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -334,64 +338,7 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
     double* rr = a.ric + rinst + (size_t)st * a.rl.stride;
 
     RTOC_PROF(0);
-    // ---- phase transition (riccati_factorizer.cpp:145-175), in place on the LDS copy of
-    //      factorization[st+1]; dispatch per riccati_recursion.cpp:41-70 ----
-    bool do_pt = false;
-    int pol_stage = st;
-    if (impact) {
-      do_pt = (a.grid[st - 1].sto != 0) || sto;
-      pol_stage = st;
-    } else if (next_lift) {
-      do_pt = sto || sto_next;
-      pol_stage = st + 1;
-    }
-    __syncthreads();
-    if (do_pt) {
-      double* pr = a.ric + rinst + (size_t)pol_stage * a.rl.stride;
-      const double xi = smem[C::V_SCN + 0], chi = smem[C::V_SCN + 1], rho = smem[C::V_SCN + 2],
-                   eta = smem[C::V_SCN + 3], iota = smem[C::V_SCN + 4];
-      double isg = 0.0;
-      if (sto_next) {
-        double sgm = xi - 2.0 * chi + rho;
-        const double eps = 1.4901161193847656e-08;  // sqrt(DBL_EPSILON)
-        if ((sgm * a.max_dts0) < fabs(eta - iota) || sgm < eps)
-          sgm = fabs(sgm) + fabs(eta - iota) / a.max_dts0;
-        isg = 1.0 / sgm;
-      }
-      double psi = 0.0, phi = 0.0;
-      if (tid < NX) {
-        psi = smem[C::V_PSIN + tid];
-        phi = smem[C::V_PHIN + tid];
-      }
-      __syncthreads();
-      if (tid < NX) {
-        const double d = psi - phi;
-        double phim = psi;  // Phi_m = Psi
-        if (sto_next) {
-          pr[ro[RTOC_RIC_DTSDX] + tid] = -isg * d;
-          smem[C::V_SN + tid] += isg * d * (eta - iota);
-          phim -= isg * d * (xi - chi);
-        }
-        smem[C::V_PSIN + tid] = 0.0;
-        smem[C::V_PHIN + tid] = phim;
-      }
-      if (tid == 0) {
-        smem[C::V_SCN + 0] = 0.0;
-        smem[C::V_SCN + 1] = 0.0;
-        smem[C::V_SCN + 3] = 0.0;
-        if (sto_next) {
-          pr[ro[RTOC_RIC_SCAL] + RTOC_RIC_SCAL_DTSDTS] = isg * (xi - chi);
-          pr[ro[RTOC_RIC_SCAL] + RTOC_RIC_SCAL_DTS0] = -isg * (eta - iota);
-          smem[C::V_SCN + 2] = xi - isg * (xi - chi) * (xi - chi);
-          smem[C::V_SCN + 4] = eta - isg * (xi - chi) * (eta - iota);
-        } else {
-          smem[C::V_SCN + 2] = xi;
-          smem[C::V_SCN + 4] = eta;
-        }
-      }
-      __syncthreads();
-    }
-
+#include "riccati_pt_block.inc"
     RTOC_PROF(1);
     // ---- stage data: prefetched registers -> LDS (the HBM loads were issued one stage ahead) ----
     pre_store_mat<NT, NX, NX, LDP>(sA, preA, tid);

@@ -12,6 +12,7 @@
 #include "../../include/rtoc.h"
 #include "condense.hpp"
 #include "riccati_backward.hpp"
+#include "riccati_backward_rs.hpp"
 #include "riccati_forward.hpp"
 
 using namespace rtoc;
@@ -41,9 +42,9 @@ typedef void (*expd_fn)(ExpArgs);
 struct KernelSet {
   int nv, nu, ns;
   int nvariants;
-  bwd_fn bwd[2];
-  int bwd_waves[2];
-  int bwd_lds[2];
+  bwd_fn bwd[3];
+  int bwd_waves[3];
+  int bwd_lds[3];
   fwd_fn fwd;
   int fwd_threads;
   fill_fn fill;
@@ -60,13 +61,19 @@ static KernelSet make_set() {
   k.nv = NV;
   k.nu = NU;
   k.ns = NS;
-  k.nvariants = (NW0 == NW1) ? 1 : 2;
+  k.nvariants = 2;
   k.bwd[0] = riccati_backward_kernel<NV, NU, NS, NW0>;
   k.bwd_waves[0] = NW0;
   k.bwd_lds[0] = BwdCfg<NV, NU, NS, NW0>::LDS_BYTES;
   k.bwd[1] = riccati_backward_kernel<NV, NU, NS, NW1>;
   k.bwd_waves[1] = NW1;
   k.bwd_lds[1] = BwdCfg<NV, NU, NS, NW1>::LDS_BYTES;
+  if constexpr (2 * NV + 1 <= 64) {  // role-split kernel: matrix wave + vector wave per instance
+    k.bwd[2] = riccati_backward_rs_kernel<NV, NU, NS>;
+    k.bwd_waves[2] = 2;
+    k.bwd_lds[2] = BwdCfg<NV, NU, NS, 2>::LDS_BYTES;
+    k.nvariants = 3;
+  }
   constexpr int NWF = (2 * NV + NU + 63) / 64;
   k.fwd = riccati_forward_kernel<NV, NU, NS, NWF>;
   k.fwd_threads = 64 * NWF;
@@ -161,7 +168,7 @@ int rtoc_create(const rtoc_dims* dims, int max_stages, int batch, int device, rt
   c->batch = batch;
   c->device = device;
   c->max_dts0 = 0.1;  // RiccatiRecursion(ocp, max_dts0 = 0.1), riccati_recursion.hpp:35
-  c->bwd_variant = 0;
+  c->bwd_variant = (ks->nvariants == 3) ? 2 : 0;  // role-split kernel where it exists
   HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
   c->stream = c->own_stream;
   HIP_TRY(hipEventCreate(&c->ev0));
@@ -188,7 +195,7 @@ int rtoc_create(const rtoc_dims* dims, int max_stages, int batch, int device, rt
   HIP_TRY(hipMalloc((void**)&c->d_grid, sizeof(rtoc_grid) * max_stages));
   HIP_TRY(hipMalloc((void**)&c->d_status, sizeof(uint32_t) * batch));
   HIP_TRY(hipMemsetAsync(c->d_status, 0, sizeof(uint32_t) * batch, c->stream));
-  for (int v = 0; v < 2; ++v)
+  for (int v = 0; v < ks->nvariants; ++v)
     HIP_TRY(hipFuncSetAttribute((const void*)ks->bwd[v], hipFuncAttributeMaxDynamicSharedMemorySize,
                                 ks->bwd_lds[v]));
   HIP_TRY(hipFuncSetAttribute((const void*)ks->cond, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -259,10 +266,10 @@ int rtoc_set_option(rtoc_ctx* c, int option, int64_t value) {
     }
     case RTOC_OPT_BACKWARD_WAVES: {
       if (value == 0) {
-        c->bwd_variant = 0;
+        c->bwd_variant = (c->ks->nvariants == 3) ? 2 : 0;
         return RTOC_OK;
       }
-      for (int v = 0; v < 2; ++v)
+      for (int v = 0; v < c->ks->nvariants; ++v)
         if (c->ks->bwd_waves[v] == (int)value) {
           c->bwd_variant = v;
           return RTOC_OK;

@@ -7,7 +7,7 @@ from robotoc_amd.types import BUF_KKT, BUF_DX0
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 dims, grids, _ = pr.config_anymal_trot()
 names = ["phase-trans", "g2s copies", "z + PB + G + lu", "PAa mfma + H", "w=A^T z", "F init+chain mfma", "LLT+solve", "GK mfma", "KtGK mfma + Hk", "F->sP, sym", "sto scal", "writes", "end"]
-for nw in (1, 3):
+for nw in (1, 2, 3):
     ctx = capi.Context(dims, len(grids), batch, 0)
     ctx.set_grid(grids); ctx.set_backward_waves(nw)
     L = ctx.L

@@ -15,7 +15,7 @@ def main():
     dx0 = np.tile(pr.make_dx0(L, 8), (batch // 8 + 1, 1))[:batch]
     ctx.upload(BUF_KKT, kkt); ctx.upload(BUF_DX0, dx0)
     nst = len(grids)
-    for nw in (1, 3):
+    for nw in (1, 2, 3):
         ctx.set_backward_waves(nw)
         ctx.time_phase(0, 2)
         ms = ctx.time_phase(0, 5)
