@@ -47,6 +47,11 @@ def lib():
                                                  C.POINTER(C.c_uint), C.c_int, C.c_int]
         _LIB.orc_unconstr_sweep_batch.argtypes = [C.POINTER(Layout), C.c_int, C.c_int, C.c_double,
                                                   dp, dp, dp, dp, C.POINTER(C.c_uint)]
+        _LIB.orc_stage_backward.argtypes = [C.POINTER(Layout), dp, dp, dp, C.c_int, C.c_int, C.c_int]
+        _LIB.orc_stage_backward.restype = C.c_uint
+        _LIB.orc_stage_backward_impact.argtypes = [C.POINTER(Layout), dp, dp, dp, C.c_int]
+        _LIB.orc_stage_phase_transition.argtypes = [C.POINTER(Layout), dp, dp, dp, C.c_int,
+                                                    C.c_double]
     return _LIB
 
 
@@ -98,3 +103,19 @@ def unconstr_sweep_batch(L, nstages, dt, kkt, ric, dirs, dx0=None):
     lib().orc_unconstr_sweep_batch(C.byref(L), nstages, batch, dt, _p(kkt), _p(ric), _p(dirs),
                                    _p(dx0) if dx0 is not None else None, stat)
     return np.frombuffer(stat, dtype=np.uint32).copy()
+
+
+def stage_backward(L, kkt_rec, ric_next_rec, ric_out_rec, ns=0, sto=False, sto_next=False):
+    """RiccatiFactorizer::backwardRiccatiRecursion (7-arg) on single records."""
+    return lib().orc_stage_backward(C.byref(L), _p(kkt_rec), _p(ric_next_rec), _p(ric_out_rec), ns,
+                                    int(sto), int(sto_next))
+
+
+def stage_backward_impact(L, kkt_rec, ric_next_rec, ric_out_rec, sto=False):
+    lib().orc_stage_backward_impact(C.byref(L), _p(kkt_rec), _p(ric_next_rec), _p(ric_out_rec),
+                                    int(sto))
+
+
+def stage_phase_transition(L, ric_rec, ric_m_rec, policy_rec, sto_next, max_dts0):
+    lib().orc_stage_phase_transition(C.byref(L), _p(ric_rec), _p(ric_m_rec), _p(policy_rec),
+                                     int(sto_next), max_dts0)

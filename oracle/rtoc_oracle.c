@@ -823,3 +823,36 @@ void orc_unconstr_sweep_batch(const rtoc_layout* L, int nstages, int batch, doub
 }
 
 void orc_layout(const rtoc_dims* d, rtoc_layout* L) { rtoc_compute_layout(d, L); }
+
+/* ------------------------------------------------------------------------- */
+/* single-stage hooks for tests/test_oracle_reference_identities.py             */
+/* (the per-stage entry points of RiccatiFactorizer, riccati_factorizer.hpp)     */
+/* ------------------------------------------------------------------------- */
+unsigned orc_stage_backward(const rtoc_layout* L, double* kkt_rec, double* ric_next_rec,
+                            double* ric_rec_out, int ns, int sto, int sto_next) {
+  ric_scratch w = scratch_alloc(L);
+  kkt_view q = kkt_at(L, kkt_rec, 0);
+  ric_view rn = ric_rec(L, ric_next_rec);
+  ric_view r = ric_rec(L, ric_rec_out);
+  unsigned st = backward_stage(L, &rn, &q, &r, &w, ns, sto, sto_next);
+  scratch_free(&w);
+  return st;
+}
+
+void orc_stage_backward_impact(const rtoc_layout* L, double* kkt_rec, double* ric_next_rec,
+                               double* ric_rec_out, int sto) {
+  ric_scratch w = scratch_alloc(L);
+  kkt_view q = kkt_at(L, kkt_rec, 0);
+  ric_view rn = ric_rec(L, ric_next_rec);
+  ric_view r = ric_rec(L, ric_rec_out);
+  backward_impact_stage(L, &rn, &q, &r, &w, sto);
+  scratch_free(&w);
+}
+
+void orc_stage_phase_transition(const rtoc_layout* L, double* ric_rec_in, double* ric_m_rec,
+                                double* policy_rec, int sto_next, double max_dts0) {
+  ric_view r = ric_rec(L, ric_rec_in);
+  ric_view m = ric_rec(L, ric_m_rec);
+  ric_view pol = ric_rec(L, policy_rec);
+  phase_transition(L, &r, &m, &pol, sto_next, max_dts0);
+}

@@ -15,7 +15,8 @@ def main():
     dx0 = np.tile(pr.make_dx0(L, 8), (batch // 8 + 1, 1))[:batch]
     ctx.upload(BUF_KKT, kkt); ctx.upload(BUF_DX0, dx0)
     nst = len(grids)
-    for nw in (1, 2, 3):
+    only = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    for nw in ((only,) if only else (1, 2, 3)):
         ctx.set_backward_waves(nw)
         ctx.time_phase(0, 2)
         ms = ctx.time_phase(0, 5)
