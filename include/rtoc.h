@@ -87,7 +87,8 @@ enum rtoc_buffer {
 enum rtoc_option {
   RTOC_OPT_WRITEBACK_KKT = 0, /* 1: backward writes the mutated Qxx,Qxu,Quu,lu back (reference in-place semantics) */
   RTOC_OPT_MAX_DTS0 = 1,      /* RiccatiRecursion(ocp, max_dts0) / setRegularization; value = double bits */
-  RTOC_OPT_BACKWARD_WAVES = 2 /* waves per OCP instance in the backward kernel (0 = default for the dims) */
+  RTOC_OPT_BACKWARD_WAVES = 2, /* waves per OCP instance in the backward kernel (0 = default for the dims) */
+  RTOC_OPT_CONTACT_INV_DAMPING = 3 /* RobotModelInfo::contact_inv_damping (robot.hxx:662-664); value = double bits */
 };
 
 typedef struct rtoc_ctx rtoc_ctx;

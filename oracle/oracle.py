@@ -52,6 +52,16 @@ def lib():
         _LIB.orc_stage_backward_impact.argtypes = [C.POINTER(Layout), dp, dp, dp, C.c_int]
         _LIB.orc_stage_phase_transition.argtypes = [C.POINTER(Layout), dp, dp, dp, C.c_int,
                                                     C.c_double]
+        _LIB.orc_compute_MJtJinv.argtypes = [C.c_int, C.c_int, dp, dp, C.c_int, C.c_double, dp, C.c_int]
+        _LIB.orc_compute_MJtJinv.restype = C.c_int
+        _LIB.orc_condense_stage.argtypes = [C.POINTER(Layout), C.POINTER(Grid), dp, dp, C.c_double]
+        _LIB.orc_condense_stage.restype = C.c_uint
+        _LIB.orc_condense_impact_stage.argtypes = [C.POINTER(Layout), C.POINTER(Grid), dp, dp, C.c_double]
+        _LIB.orc_condense_impact_stage.restype = C.c_uint
+        _LIB.orc_expand_stage.argtypes = [C.POINTER(Layout), C.POINTER(Grid), dp, dp, dp]
+        _LIB.orc_condense_batch.argtypes = [C.POINTER(Layout), C.POINTER(Grid), C.c_int, C.c_int, dp, dp,
+                                            C.c_double, C.POINTER(C.c_uint)]
+        _LIB.orc_expand_batch.argtypes = [C.POINTER(Layout), C.POINTER(Grid), C.c_int, C.c_int, dp, dp]
     return _LIB
 
 
@@ -119,3 +129,36 @@ def stage_backward_impact(L, kkt_rec, ric_next_rec, ric_out_rec, sto=False):
 def stage_phase_transition(L, ric_rec, ric_m_rec, policy_rec, sto_next, max_dts0):
     lib().orc_stage_phase_transition(C.byref(L), _p(ric_rec), _p(ric_m_rec), _p(policy_rec),
                                      int(sto_next), max_dts0)
+
+
+def compute_MJtJinv(M, J, damping=0.0):
+    """Robot::computeMJtJinv on numpy arrays (M nv x nv, J nf x nv)."""
+    nv, nf = M.shape[0], J.shape[0]
+    Mf = np.asfortranarray(M).ravel(order="K").copy()
+    Jf = np.asfortranarray(J).ravel(order="K").copy() if nf else np.zeros(1)
+    out = np.zeros((nv + nf) * (nv + nf))
+    bad = lib().orc_compute_MJtJinv(nv, nf, _p(Mf), _p(Jf), max(nf, 1), damping, _p(out), nv + nf)
+    return out.reshape(nv + nf, nv + nf).T.copy(), bad
+
+
+def condense_stage(L, g, kkt_rec, cdd_rec, damping=0.0):
+    from robotoc_amd.types import GRID_IMPACT
+    f = lib().orc_condense_impact_stage if g.type == GRID_IMPACT else lib().orc_condense_stage
+    return f(C.byref(L), C.byref(g), _p(kkt_rec), _p(cdd_rec), damping)
+
+
+def expand_stage(L, g, cdd_rec, dir_rec, dir_next_rec):
+    lib().orc_expand_stage(C.byref(L), C.byref(g), _p(cdd_rec), _p(dir_rec), _p(dir_next_rec))
+
+
+def condense_batch(L, grids, kkt, cdd, damping=0.0):
+    g = grid_array(grids)
+    batch = kkt.shape[0]
+    stat = (C.c_uint * batch)()
+    lib().orc_condense_batch(C.byref(L), g, len(grids), batch, _p(kkt), _p(cdd), damping, stat)
+    return np.frombuffer(stat, dtype=np.uint32).copy()
+
+
+def expand_batch(L, grids, cdd, dirs):
+    g = grid_array(grids)
+    lib().orc_expand_batch(C.byref(L), g, len(grids), cdd.shape[0], _p(cdd), _p(dirs))

@@ -1,0 +1,380 @@
+/*
+ * rtoc_oracle_condense.c -- CPU restatement of robotoc's per-stage KKT condensation /
+ * expansion (TEST INFRASTRUCTURE ONLY, see rtoc_oracle.c for the rules and the parity status).
+ *
+ * Follows, line by line:
+ *   Robot::computeMJtJinv            include/robotoc/robot/robot.hxx:642-684
+ *                                    (Pinocchio's sparse Cholesky of M is replaced by a dense
+ *                                    LLT: same matrix, different elimination order; validated by
+ *                                    the defining identity [[M,J^T],[J,0]] * MJtJinv = I)
+ *   condenseContactDynamics          src/dynamics/contact_dynamics.cpp:55-164
+ *   expandContactDynamicsPrimal/Dual src/dynamics/contact_dynamics.cpp:167-202
+ *   condenseImpactDynamics           src/dynamics/impact_dynamics.cpp:38-80
+ *   expandImpactDynamicsPrimal/Dual  src/dynamics/impact_dynamics.cpp:83-96
+ *   IntermediateStage::evalKKT tail  src/ocp/intermediate_stage.cpp:140-148
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <float.h>
+
+#include "../include/rtoc.h"
+
+#define AT(A, ld, i, j) (A)[(i) + (size_t)(j) * (ld)]
+
+static int c_llt(double* A, int n, int lda) {
+  int bad = 0;
+  for (int j = 0; j < n; ++j) {
+    double d = AT(A, lda, j, j);
+    for (int k = 0; k < j; ++k) d -= AT(A, lda, j, k) * AT(A, lda, j, k);
+    if (!(d > 0.0)) bad = 1;
+    const double ljj = sqrt(d);
+    AT(A, lda, j, j) = ljj;
+    for (int i = j + 1; i < n; ++i) {
+      double v = AT(A, lda, i, j);
+      for (int k = 0; k < j; ++k) v -= AT(A, lda, i, k) * AT(A, lda, j, k);
+      AT(A, lda, i, j) = v / ljj;
+    }
+  }
+  return bad;
+}
+
+static void c_llt_solve(const double* L, int n, int ldl, double* B, int nrhs, int ldb) {
+  for (int c = 0; c < nrhs; ++c) {
+    double* b = B + (size_t)c * ldb;
+    for (int i = 0; i < n; ++i) {
+      double v = b[i];
+      for (int k = 0; k < i; ++k) v -= AT(L, ldl, i, k) * b[k];
+      b[i] = v / AT(L, ldl, i, i);
+    }
+    for (int i = n - 1; i >= 0; --i) {
+      double v = b[i];
+      for (int k = i + 1; k < n; ++k) v -= AT(L, ldl, k, i) * b[k];
+      b[i] = v / AT(L, ldl, i, i);
+    }
+  }
+}
+
+/* C(MxN) = beta*C + alpha*op(A)op(B), generic strides; small sizes */
+static void c_gemm(int ta, int tb, int M, int N, int K, double alpha, const double* A, int lda,
+                   const double* B, int ldb, double beta, double* C, int ldc) {
+  for (int j = 0; j < N; ++j)
+    for (int i = 0; i < M; ++i) {
+      double acc = 0.0;
+      for (int k = 0; k < K; ++k) {
+        const double a = ta ? AT(A, lda, k, i) : AT(A, lda, i, k);
+        const double b = tb ? AT(B, ldb, j, k) : AT(B, ldb, k, j);
+        acc += a * b;
+      }
+      AT(C, ldc, i, j) = (beta == 0.0 ? 0.0 : beta * AT(C, ldc, i, j)) + alpha * acc;
+    }
+}
+
+/* Robot::computeMJtJinv, robot.hxx:642-684.  M nv x nv (ld nv), J nf x nv (ld ldj),
+ * out (nv+nf) x (nv+nf) with ld ldo.  Returns nonzero if a factorisation failed. */
+int orc_compute_MJtJinv(int nv, int nf, const double* M, const double* J, int ldj, double damping,
+                        double* out, int ldo) {
+  int bad = 0;
+  double* Lm = (double*)malloc(sizeof(double) * nv * nv);
+  double* Minv = (double*)calloc((size_t)nv * nv, sizeof(double));
+  memcpy(Lm, M, sizeof(double) * nv * nv);
+  bad |= c_llt(Lm, nv, nv);
+  for (int i = 0; i < nv; ++i) Minv[i + (size_t)i * nv] = 1.0;
+  c_llt_solve(Lm, nv, nv, Minv, nv, nv); /* topLeft = M^-1 (:674-676) */
+  for (int j = 0; j < nv; ++j)
+    for (int i = 0; i < nv; ++i) AT(out, ldo, i, j) = Minv[i + (size_t)j * nv];
+  if (nf > 0) {
+    double* JMinv = (double*)malloc(sizeof(double) * nf * nv);
+    double* S = (double*)malloc(sizeof(double) * nf * nf);
+    double* BR = (double*)calloc((size_t)nf * nf, sizeof(double));
+    c_gemm(0, 0, nf, nv, nv, 1.0, J, ldj, Minv, nv, 0.0, JMinv, nf);   /* bottomLeft = J M^-1 (:677) */
+    c_gemm(0, 1, nf, nf, nv, 1.0, JMinv, nf, J, ldj, 0.0, S, nf);      /* JMinvJt (:660-661) */
+    for (int i = 0; i < nf; ++i) S[i + (size_t)i * nf] += damping;     /* (:662-664) */
+    bad |= c_llt(S, nf, nf);                                           /* (:665) */
+    for (int i = 0; i < nf; ++i) BR[i + (size_t)i * nf] = -1.0;        /* bottomRight = -I (:673) */
+    c_llt_solve(S, nf, nf, BR, nf, nf);                                /* = -(JMinvJt)^-1 (:675) */
+    /* topRight = bottomLeft^T * (-bottomRight)  (:678) */
+    for (int j = 0; j < nf; ++j)
+      for (int i = 0; i < nv; ++i) {
+        double acc = 0.0;
+        for (int k = 0; k < nf; ++k) acc += JMinv[k + (size_t)i * nf] * (-BR[k + (size_t)j * nf]);
+        AT(out, ldo, i, nv + j) = acc;
+      }
+    /* topLeft -= topRight * bottomLeft (:679) */
+    for (int j = 0; j < nv; ++j)
+      for (int i = 0; i < nv; ++i) {
+        double acc = 0.0;
+        for (int k = 0; k < nf; ++k) acc += AT(out, ldo, i, nv + k) * JMinv[k + (size_t)j * nf];
+        AT(out, ldo, i, j) -= acc;
+      }
+    /* bottomLeft = topRight^T (:680) ; bottomRight */
+    for (int j = 0; j < nv; ++j)
+      for (int i = 0; i < nf; ++i) AT(out, ldo, nv + i, j) = AT(out, ldo, j, nv + i);
+    for (int j = 0; j < nf; ++j)
+      for (int i = 0; i < nf; ++i) AT(out, ldo, nv + i, nv + j) = BR[i + (size_t)j * nf];
+    free(JMinv); free(S); free(BR);
+  }
+  free(Lm); free(Minv);
+  return bad;
+}
+
+typedef struct {
+  double *dIDda, *D, *dCda, *IDC, *Qaa, *Qff, *Qqf, *la, *lf, *ha, *hf, *Phia, *lup;
+  double *Lam, *LD, *Lr, *Qafqv, *Qafu, *laf, *Qxup, *Quuptr, *haf;
+} cdd_view;
+
+static cdd_view cdd_at(const rtoc_layout* L, double* r) {
+  const int* o = L->cdd.off;
+  cdd_view v = {r + o[RTOC_CDD_DIDDA], r + o[RTOC_CDD_DIDCDQV], r + o[RTOC_CDD_DCDA],
+                r + o[RTOC_CDD_IDC],   r + o[RTOC_CDD_QAA],     r + o[RTOC_CDD_QFF],
+                r + o[RTOC_CDD_QQF],   r + o[RTOC_CDD_LA],      r + o[RTOC_CDD_LF],
+                r + o[RTOC_CDD_HA],    r + o[RTOC_CDD_HF],      r + o[RTOC_CDD_PHIA],
+                r + o[RTOC_CDD_LUP],   r + o[RTOC_CDD_MJTJINV], r + o[RTOC_CDD_MJD],
+                r + o[RTOC_CDD_MJIDC], r + o[RTOC_CDD_QAFQV],   r + o[RTOC_CDD_QAFU],
+                r + o[RTOC_CDD_LAF],   r + o[RTOC_CDD_QXUP],    r + o[RTOC_CDD_QUUPTR],
+                r + o[RTOC_CDD_HAF]};
+  return v;
+}
+
+/* condenseContactDynamics (contact_dynamics.cpp:55-164) followed by the STO scalings of
+ * IntermediateStage::evalKKT (intermediate_stage.cpp:140-148).  One stage, in place. */
+unsigned orc_condense_stage(const rtoc_layout* L, const rtoc_grid* g, double* kkt_rec,
+                            double* cdd_rec, double damping) {
+  const int nv = L->dims.nv, nu = L->dims.nu, np = L->dims.np, nx = L->nx;
+  const int nf = g->dimf, nvf = nv + nf, ns = g->dims;
+  const int ldv = L->nvf_max, ldf = L->dims.nf_max, lds = L->dims.ns_max;
+  const double dt = g->dt;
+  const int* ko = L->kkt.off;
+  double* Fxx = kkt_rec + ko[RTOC_KKT_FXX];
+  double* Fvu = kkt_rec + ko[RTOC_KKT_FVU];
+  double* Qxx = kkt_rec + ko[RTOC_KKT_QXX];
+  double* Qxu = kkt_rec + ko[RTOC_KKT_QXU];
+  double* Quu = kkt_rec + ko[RTOC_KKT_QUU];
+  double* Fx = kkt_rec + ko[RTOC_KKT_FX];
+  double* lx = kkt_rec + ko[RTOC_KKT_LX];
+  double* lu = kkt_rec + ko[RTOC_KKT_LU];
+  double* hx = kkt_rec + ko[RTOC_KKT_HX];
+  double* hu = kkt_rec + ko[RTOC_KKT_HU];
+  double* fx = kkt_rec + ko[RTOC_KKT_FFX];
+  double* scal = kkt_rec + ko[RTOC_KKT_SCAL];
+  double* Phix = kkt_rec + ko[RTOC_KKT_PHIX];
+  double* Phiu = kkt_rec + ko[RTOC_KKT_PHIU];
+  double* Phit = kkt_rec + ko[RTOC_KKT_PHIT];
+  double* Pres = kkt_rec + ko[RTOC_KKT_PRES];
+  cdd_view c = cdd_at(L, cdd_rec);
+  unsigned stat = 0;
+  /* :63-65 */
+  if (orc_compute_MJtJinv(nv, nf, c.dIDda, c.dCda, ldf, damping, c.Lam, ldv)) stat |= RTOC_STAT_M_NOT_SPD;
+  c_gemm(0, 0, nvf, nx, nvf, 1.0, c.Lam, ldv, c.D, ldv, 0.0, c.LD, ldv);
+  c_gemm(0, 0, nvf, 1, nvf, 1.0, c.Lam, ldv, c.IDC, nvf, 0.0, c.Lr, nvf);
+  /* Qafqv :67-74 */
+  for (int j = 0; j < nx; ++j)
+    for (int i = 0; i < nv; ++i) AT(c.Qafqv, ldv, i, j) = -c.Qaa[i] * AT(c.LD, ldv, i, j);
+  if (nf > 0) {
+    c_gemm(0, 0, nf, nx, nf, -1.0, c.Qff, ldf, c.LD + nv, ldv, 0.0, c.Qafqv + nv, ldv);
+    for (int j = 0; j < nv; ++j)
+      for (int i = 0; i < nf; ++i) AT(c.Qafqv, ldv, nv + i, j) -= AT(c.Qqf, nv, j, i);
+  }
+  /* Qafu_full :75-80 */
+  for (int j = 0; j < nv; ++j)
+    for (int i = 0; i < nv; ++i) AT(c.Qafu, ldv, i, j) = c.Qaa[i] * AT(c.Lam, ldv, i, j);
+  if (nf > 0) c_gemm(0, 0, nf, nv, nf, 1.0, c.Qff, ldf, c.Lam + nv, ldv, 0.0, c.Qafu + nv, ldv);
+  /* laf :81-88 */
+  for (int i = 0; i < nv; ++i) c.laf[i] = c.la[i] - c.Qaa[i] * c.Lr[i];
+  for (int i = 0; i < nf; ++i) {
+    double acc = 0.0;
+    for (int k = 0; k < nf; ++k) acc += AT(c.Qff, ldf, i, k) * c.Lr[nv + k];
+    c.laf[nv + i] = -c.lf[i] - acc;
+  }
+  /* Qxx :90-93 */
+  c_gemm(1, 0, nx, nx, nvf, -1.0, c.LD, ldv, c.Qafqv, ldv, 1.0, Qxx, nx);
+  if (nf > 0) c_gemm(0, 0, nv, nx, nf, 1.0, c.Qqf, nv, c.LD + nv, ldv, 1.0, Qxx, nx);
+  /* Qxu (+ passive part) :94-109 */
+  if (np > 0) {
+    c_gemm(1, 0, nx, np, nvf, -1.0, c.LD, ldv, c.Qafu, ldv, 0.0, c.Qxup, nx);
+    if (nf > 0) c_gemm(0, 0, nv, np, nf, -1.0, c.Qqf, nv, c.Lam + nv, ldv, 1.0, c.Qxup, nx);
+  }
+  c_gemm(1, 0, nx, nu, nvf, -1.0, c.LD, ldv, c.Qafu + (size_t)np * ldv, ldv, 1.0, Qxu, nx);
+  if (nf > 0)
+    c_gemm(0, 0, nv, nu, nf, -1.0, c.Qqf, nv, c.Lam + nv + (size_t)np * ldv, ldv, 1.0, Qxu, nx);
+  /* lx :110-113 */
+  c_gemm(1, 0, nx, 1, nvf, -1.0, c.LD, ldv, c.laf, nvf, 1.0, lx, nx);
+  if (nf > 0) c_gemm(0, 0, nv, 1, nf, 1.0, c.Qqf, nv, c.Lr + nv, nf, 1.0, lx, nx);
+  /* Quu, lu (+ passive) :115-130 */
+  if (np > 0) {
+    c_gemm(0, 0, np, nu, nvf, 1.0, c.Lam, ldv, c.Qafu + (size_t)np * ldv, ldv, 0.0, c.Quuptr, np);
+    c_gemm(0, 0, np, 1, nvf, 1.0, c.Lam, ldv, c.laf, nvf, 1.0, c.lup, np);
+  }
+  c_gemm(0, 0, nu, nu, nvf, 1.0, c.Lam + np, ldv, c.Qafu + (size_t)np * ldv, ldv, 1.0, Quu, nu);
+  c_gemm(0, 0, nu, 1, nvf, 1.0, c.Lam + np, ldv, c.laf, nvf, 1.0, lu, nu);
+  /* dynamics :132-136 */
+  for (int j = 0; j < nv; ++j)
+    for (int i = 0; i < nv; ++i) {
+      AT(Fxx, nx, nv + i, j) = -dt * AT(c.LD, ldv, i, j);
+      AT(Fxx, nx, nv + i, nv + j) = -dt * AT(c.LD, ldv, i, nv + j) + (i == j ? 1.0 : 0.0);
+    }
+  for (int j = 0; j < nu; ++j)
+    for (int i = 0; i < nv; ++i) AT(Fvu, nv, i, j) = dt * AT(c.Lam, ldv, i, np + j);
+  for (int i = 0; i < nv; ++i) Fx[nv + i] -= dt * c.Lr[i];
+  /* switching constraint :138-153 */
+  if (ns > 0) {
+    c_gemm(0, 0, ns, nx, nv, -1.0, c.Phia, lds, c.LD, ldv, 1.0, Phix, lds);
+    c_gemm(0, 0, ns, nu, nv, 1.0, c.Phia, lds, c.Lam + (size_t)np * ldv, ldv, 0.0, Phiu, lds);
+    for (int i = 0; i < ns; ++i) {
+      double acc = 0.0;
+      for (int k = 0; k < nv; ++k) acc += AT(c.Phia, lds, i, k) * c.Lr[k];
+      Phit[i] -= acc;
+      Pres[i] -= acc;
+    }
+  }
+  /* STO sensitivities :156-163 */
+  for (int i = 0; i < nv; ++i) c.haf[i] = c.ha[i];
+  for (int i = 0; i < nf; ++i) c.haf[nv + i] = -c.hf[i];
+  {
+    double acc = 0.0;
+    for (int i = 0; i < nvf; ++i) acc += c.Lr[i] * c.haf[i];
+    scal[RTOC_KKT_SCAL_H] -= acc;
+  }
+  c_gemm(1, 0, nx, 1, nvf, -1.0, c.LD, ldv, c.haf, nvf, 1.0, hx, nx);
+  if (nf > 0) c_gemm(0, 0, nv, 1, nf, 1.0 / dt, c.Qqf, nv, c.Lr + nv, nf, 1.0, hx, nx);
+  c_gemm(0, 0, nu, 1, nvf, 1.0, c.Lam + np, ldv, c.haf, nvf, 1.0, hu, nu);
+  /* IntermediateStage::evalKKT tail, intermediate_stage.cpp:140-148 */
+  {
+    const double inv = 1.0 / (double)g->num_grids_in_phase;
+    scal[RTOC_KKT_SCAL_H] *= inv;
+    for (int i = 0; i < nx; ++i) hx[i] *= inv;
+    for (int i = 0; i < nu; ++i) hu[i] *= inv;
+    for (int i = 0; i < nx; ++i) fx[i] *= inv;
+    scal[RTOC_KKT_SCAL_QTT] *= inv * inv;
+    scal[RTOC_KKT_SCAL_QTT_PREV] = -scal[RTOC_KKT_SCAL_QTT];
+    if (g->switching_constraint)
+      for (int i = 0; i < ns; ++i) Phit[i] *= inv;
+  }
+  return stat;
+}
+
+/* condenseImpactDynamics, impact_dynamics.cpp:38-80.  dIDda slot = dIDddv, dCda slot = dCdv
+ * (the reference reads dCdv() = dIDCdqv().bottomRightCorner: the D block rows nv.., cols nv..),
+ * Qaa slot = Qdvdv.diagonal(), la slot = ldv. */
+unsigned orc_condense_impact_stage(const rtoc_layout* L, const rtoc_grid* g, double* kkt_rec,
+                                   double* cdd_rec, double damping) {
+  const int nv = L->dims.nv, nx = L->nx;
+  const int nf = g->dimf, nvf = nv + nf;
+  const int ldv = L->nvf_max, ldf = L->dims.nf_max;
+  const int* ko = L->kkt.off;
+  double* Fxx = kkt_rec + ko[RTOC_KKT_FXX];
+  double* Qxx = kkt_rec + ko[RTOC_KKT_QXX];
+  double* Fx = kkt_rec + ko[RTOC_KKT_FX];
+  double* lx = kkt_rec + ko[RTOC_KKT_LX];
+  cdd_view c = cdd_at(L, cdd_rec);
+  unsigned stat = 0;
+  const double* dCdv = c.D + nv + (size_t)nv * ldv; /* nf x nv, ld ldv */
+  if (orc_compute_MJtJinv(nv, nf, c.dIDda, dCdv, ldv, damping, c.Lam, ldv)) stat |= RTOC_STAT_M_NOT_SPD;
+  /* :44-50: left half dense product, right half only through dCdv */
+  c_gemm(0, 0, nvf, nv, nvf, 1.0, c.Lam, ldv, c.D, ldv, 0.0, c.LD, ldv);
+  c_gemm(0, 0, nv, nv, nf, 1.0, c.Lam + (size_t)nv * ldv, ldv, dCdv, ldv, 0.0, c.LD + (size_t)nv * ldv, ldv);
+  c_gemm(0, 0, nf, nv, nf, 1.0, c.Lam + nv + (size_t)nv * ldv, ldv, dCdv, ldv, 0.0,
+         c.LD + nv + (size_t)nv * ldv, ldv);
+  c_gemm(0, 0, nvf, 1, nvf, 1.0, c.Lam, ldv, c.IDC, nvf, 0.0, c.Lr, nvf);
+  /* :52-63 */
+  for (int j = 0; j < nx; ++j)
+    for (int i = 0; i < nv; ++i) AT(c.Qafqv, ldv, i, j) = -c.Qaa[i] * AT(c.LD, ldv, i, j);
+  c_gemm(0, 0, nf, nx, nf, -1.0, c.Qff, ldf, c.LD + nv, ldv, 0.0, c.Qafqv + nv, ldv);
+  for (int j = 0; j < nv; ++j)
+    for (int i = 0; i < nf; ++i) AT(c.Qafqv, ldv, nv + i, j) -= AT(c.Qqf, nv, j, i);
+  for (int i = 0; i < nv; ++i) c.laf[i] = c.la[i] - c.Qaa[i] * c.Lr[i];
+  for (int i = 0; i < nf; ++i) {
+    double acc = 0.0;
+    for (int k = 0; k < nf; ++k) acc += AT(c.Qff, ldf, i, k) * c.Lr[nv + k];
+    c.laf[nv + i] = -c.lf[i] - acc;
+  }
+  /* :65-72 */
+  c_gemm(1, 0, nx, nx, nvf, -1.0, c.LD, ldv, c.Qafqv, ldv, 1.0, Qxx, nx);
+  c_gemm(0, 0, nv, nx, nf, 1.0, c.Qqf, nv, c.LD + nv, ldv, 1.0, Qxx, nx);
+  c_gemm(1, 0, nx, 1, nvf, -1.0, c.LD, ldv, c.laf, nvf, 1.0, lx, nx);
+  c_gemm(0, 0, nv, 1, nf, 1.0, c.Qqf, nv, c.Lr + nv, nf, 1.0, lx, nx);
+  /* :74-77 */
+  for (int j = 0; j < nv; ++j)
+    for (int i = 0; i < nv; ++i) {
+      AT(Fxx, nx, nv + i, j) = -AT(c.LD, ldv, i, j);
+      AT(Fxx, nx, nv + i, nv + j) = (i == j ? 1.0 : 0.0) - AT(c.LD, ldv, i, nv + j);
+    }
+  for (int i = 0; i < nv; ++i) Fx[nv + i] -= c.Lr[i];
+  return stat;
+}
+
+/* expandContactDynamicsPrimal + expandContactDynamicsDual (contact_dynamics.cpp:167-202) and the
+ * impact forms (impact_dynamics.cpp:83-96).  dgmm_next = d_next.dlmdgmm[nv:], dts as computed by
+ * IntermediateStage::expandDual (intermediate_stage.cpp:172-180). */
+void orc_expand_stage(const rtoc_layout* L, const rtoc_grid* g, double* cdd_rec, double* dir_rec,
+                      const double* dir_next_rec) {
+  const int nv = L->dims.nv, nu = L->dims.nu, np = L->dims.np, nx = L->nx;
+  const int nf = g->dimf, nvf = nv + nf, ns = g->dims;
+  const int ldv = L->nvf_max, lds = L->dims.ns_max;
+  const int impact = g->type == RTOC_GRID_IMPACT;
+  const double dt = g->dt;
+  cdd_view c = cdd_at(L, cdd_rec);
+  const int* o = L->dir.off;
+  double* dx = dir_rec + o[RTOC_DIR_DX];
+  double* du = dir_rec + o[RTOC_DIR_DU];
+  double* dxi = dir_rec + o[RTOC_DIR_DXI];
+  double* dts = dir_rec + o[RTOC_DIR_DTS];
+  double* daf = dir_rec + o[RTOC_DIR_DAF];
+  double* dbetamu = dir_rec + o[RTOC_DIR_DBETAMU];
+  double* dnup = dir_rec + o[RTOC_DIR_DNUP];
+  const double* dgmm_next = dir_next_rec + o[RTOC_DIR_DLMDGMM] + nv;
+  /* primal :167-174 / impact :83-88 */
+  c_gemm(0, 0, nvf, 1, nx, -1.0, c.LD, ldv, dx, nx, 0.0, daf, nvf);
+  if (!impact) c_gemm(0, 0, nvf, 1, nu, 1.0, c.Lam + (size_t)np * ldv, ldv, du, nu, 1.0, daf, nvf);
+  for (int i = 0; i < nvf; ++i) daf[i] -= c.Lr[i];
+  for (int i = 0; i < nf; ++i) daf[nv + i] *= -1.0;
+  /* dual :177-201 / impact :91-96 */
+  if (!impact && np > 0) {
+    for (int i = 0; i < np; ++i) dnup[i] = -c.lup[i];
+    c_gemm(0, 0, np, 1, nu, -1.0, c.Quuptr, np, du, nu, 1.0, dnup, np);
+    c_gemm(1, 0, np, 1, nx, -1.0, c.Qxup, nx, dx, nx, 1.0, dnup, np);
+    c_gemm(0, 0, np, 1, nv, -dt, c.Lam, ldv, dgmm_next, nv, 1.0, dnup, np);
+  }
+  c_gemm(0, 0, nvf, 1, nx, 1.0, c.Qafqv, ldv, dx, nx, 1.0, c.laf, nvf);
+  if (!impact) {
+    c_gemm(0, 0, nvf, 1, nu, 1.0, c.Qafu + (size_t)np * ldv, ldv, du, nu, 1.0, c.laf, nvf);
+    for (int i = 0; i < nv; ++i) c.laf[i] += dt * dgmm_next[i];
+    if (ns > 0) c_gemm(1, 0, nv, 1, ns, 1.0, c.Phia, lds, dxi, ns, 1.0, c.laf, nv);
+    double dtsv = 0.0;
+    if (g->num_grids_in_phase > 0) dtsv = (dts[1] - dts[0]) / (double)g->num_grids_in_phase;
+    if (dtsv < -DBL_EPSILON || dtsv > DBL_EPSILON)
+      for (int i = 0; i < nvf; ++i) c.laf[i] += dtsv * c.haf[i];
+  } else {
+    for (int i = 0; i < nv; ++i) c.laf[i] += dgmm_next[i];
+  }
+  c_gemm(0, 0, nvf, 1, nvf, -1.0, c.Lam, ldv, c.laf, nvf, 0.0, dbetamu, nvf);
+}
+
+/* batch drivers */
+void orc_condense_batch(const rtoc_layout* L, const rtoc_grid* grid, int nstages, int batch,
+                        double* kkt, double* cdd, double damping, unsigned* stat) {
+#pragma omp parallel for schedule(static)
+  for (int b = 0; b < batch; ++b) {
+    unsigned st = 0;
+    for (int i = 0; i < nstages - 1; ++i) {
+      double* kr = kkt + ((size_t)b * nstages + i) * L->kkt.stride;
+      double* cr = cdd + ((size_t)b * nstages + i) * L->cdd.stride;
+      if (grid[i].type == RTOC_GRID_IMPACT)
+        st |= orc_condense_impact_stage(L, &grid[i], kr, cr, damping);
+      else
+        st |= orc_condense_stage(L, &grid[i], kr, cr, damping);
+    }
+    if (stat) stat[b] = st;
+  }
+}
+
+void orc_expand_batch(const rtoc_layout* L, const rtoc_grid* grid, int nstages, int batch,
+                      double* cdd, double* dir) {
+#pragma omp parallel for schedule(static)
+  for (int b = 0; b < batch; ++b)
+    for (int i = 0; i < nstages - 1; ++i) {
+      double* cr = cdd + ((size_t)b * nstages + i) * L->cdd.stride;
+      double* dr = dir + ((size_t)b * nstages + i) * L->dir.stride;
+      orc_expand_stage(L, &grid[i], cr, dr, dr + L->dir.stride);
+    }
+}

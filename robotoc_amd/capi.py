@@ -142,6 +142,10 @@ class Context:
         bits = struct.unpack("<q", struct.pack("<d", float(v)))[0]
         _chk(lib().rtoc_set_option(self._h, OPT_MAX_DTS0, bits))
 
+    def set_contact_inv_damping(self, v):
+        bits = struct.unpack("<q", struct.pack("<d", float(v)))[0]
+        _chk(lib().rtoc_set_option(self._h, 3, bits))
+
     def set_backward_waves(self, nw):
         _chk(lib().rtoc_set_option(self._h, OPT_BACKWARD_WAVES, int(nw)))
 

@@ -120,6 +120,7 @@ struct rtoc_ctx {
   long long* d_prof;
   int writeback;
   double max_dts0;
+  double contact_inv_damping;
   int bwd_variant;
   hipEvent_t ev0, ev1;
 };
@@ -264,6 +265,13 @@ int rtoc_set_option(rtoc_ctx* c, int option, int64_t value) {
       c->max_dts0 = d;
       return RTOC_OK;
     }
+    case RTOC_OPT_CONTACT_INV_DAMPING: {
+      double d;
+      memcpy(&d, &value, sizeof(d));
+      if (!(d >= 0.0)) return RTOC_ERR_BAD_ARG;
+      c->contact_inv_damping = d;
+      return RTOC_OK;
+    }
     case RTOC_OPT_BACKWARD_WAVES: {
       if (value == 0) {
         c->bwd_variant = (c->ks->nvariants == 3) ? 2 : 0;
@@ -385,6 +393,7 @@ static int launch_condense(rtoc_ctx* c) {
   a.status = c->d_status;
   a.nstages = c->nstages;
   a.batch = c->batch;
+  a.damping = c->contact_inv_damping;
   a.kl = c->L.kkt;
   a.cl = c->L.cdd;
   const int nblocks = c->batch * (c->nstages - 1);

@@ -167,3 +167,79 @@ def config_icub_jump(N=30, dt=0.02, nv=35):
     for e in cs.events:
         e.sto = False
     return dims, discretize(N, N * dt, 0.0, cs), dict(name="icub%d_jump" % nv)
+
+
+# ---- pre-condensation stage data (inputs of condenseContactDynamics / condenseImpactDynamics) ----
+def fill_precondense_instance(L, grids, kkt, cdd, rng):
+    """One instance: the un-condensed KKT pieces a robotoc stage holds right before
+    condenseContactDynamics (intermediate_stage.cpp:134-136), synthetic but structurally faithful
+    (SURVEY 8d): M = dIDda SPD (L L^T + I), J = dCda random full row rank, dIDCdqv / IDC random,
+    Qaa diagonal positive, Qff SPD, Qqf random, cost Hessians SPD, state equation blocks as
+    linearizeStateEquation leaves them (Fqq = I with a 6x6 corner, Fqv = dt I)."""
+    d = L.dims
+    nv, nu, nx, npv = d.nv, d.nu, 2 * d.nv, d.np
+    K, Cd = Records(L, "kkt"), Records(L, "cdd")
+    for i, g in enumerate(grids):
+        kr, cr = kkt[i], cdd[i]
+        if g.type == GRID_TERMINAL:
+            K.f(kr, "Qxx")[...] = _spd(rng, nx)
+            K.f(kr, "lx")[...] = _rnd(rng, nx)
+            continue
+        nf, ns = g.dimf, g.dims
+        nvf = nv + nf
+        impact = g.type == GRID_IMPACT
+        dt = g.dt
+        A = K.f(kr, "Fxx")
+        A[...] = 0.0
+        A[:nv, :nv] = np.eye(nv)
+        if npv > 0:
+            A[:6, :6] = _rnd(rng, 6, 6)
+        if not impact:
+            A[:nv, nv:] = dt * np.eye(nv)
+        K.f(kr, "Fx")[...] = _rnd(rng, nx)
+        K.f(kr, "lx")[...] = _rnd(rng, nx)
+        K.f(kr, "Qxx")[...] = _spd(rng, nx)
+        if not impact:
+            K.f(kr, "Qxu")[...] = 0.1 * _rnd(rng, nx, nu)
+            K.f(kr, "Quu")[...] = np.diag(np.abs(_rnd(rng, nu)) + 0.1)
+            K.f(kr, "lu")[...] = _rnd(rng, nu)
+            K.f(kr, "hx")[...] = _rnd(rng, nx)
+            K.f(kr, "hu")[...] = _rnd(rng, nu)
+            K.f(kr, "fx")[...] = _rnd(rng, nx)
+            sc = K.f(kr, "scal")
+            sc[0] = abs(rng.uniform(-1, 1)) + 0.1
+            sc[1] = -sc[0]
+            sc[2] = rng.uniform(-1, 1)
+            if ns > 0:
+                K.f(kr, "Phix")[:ns] = _rnd(rng, ns, nx)
+                K.f(kr, "Phit")[:ns] = _rnd(rng, ns)
+                K.f(kr, "Pres")[:ns] = _rnd(rng, ns)
+                Cd.f(cr, "Phia")[:ns] = _rnd(rng, ns, nv)
+        Lm = np.tril(_rnd(rng, nv, nv))
+        Cd.f(cr, "dIDda")[...] = Lm @ Lm.T + np.eye(nv)
+        D = Cd.f(cr, "dIDCdqv")
+        D[:nvf, :] = _rnd(rng, nvf, nx)
+        if impact:
+            D[:nv, nv:] = 0.0  # RNEAImpactDerivatives has no velocity block (impact_dynamics.cpp:44-50)
+        elif nf > 0:
+            Cd.f(cr, "dCda")[:nf] = _rnd(rng, nf, nv)
+        Cd.f(cr, "IDC")[:nvf] = _rnd(rng, nvf)
+        Cd.f(cr, "Qaa")[...] = np.abs(_rnd(rng, nv)) + 0.1
+        if nf > 0:
+            Cd.f(cr, "Qff")[:nf, :nf] = _spd(rng, nf)
+            Cd.f(cr, "Qqf")[:, :nf] = _rnd(rng, nv, nf)
+            Cd.f(cr, "lf")[:nf] = _rnd(rng, nf)
+            Cd.f(cr, "hf")[:nf] = _rnd(rng, nf)
+        Cd.f(cr, "la")[...] = _rnd(rng, nv)
+        Cd.f(cr, "ha")[...] = _rnd(rng, nv)
+        if npv > 0:
+            Cd.f(cr, "lu_passive")[:npv] = _rnd(rng, npv)
+
+
+def make_precondense_batch(L, grids, batch, first_instance=0):
+    kkt = Records(L, "kkt").zeros(batch, len(grids))
+    cdd = Records(L, "cdd").zeros(batch, len(grids))
+    for b in range(batch):
+        rng = np.random.default_rng(BASE_SEED + 104729 + first_instance + b)
+        fill_precondense_instance(L, grids, kkt[b], cdd[b], rng)
+    return kkt, cdd

@@ -217,3 +217,78 @@ def test_full_size_batch_properties(oracle):
             compare_direction(L, grids, d[b], d_ref[b], TOL)
     finally:
         ctx.close()
+
+
+def _compare_records(R, gpu, ref, fields, tol, what, grids=None, skip_terminal=True):
+    from helpers import rel_err
+    bad = []
+    worst = 0.0
+    n = gpu.shape[0]
+    for i in range(n - (1 if skip_terminal else 0)):
+        for f in fields:
+            e = rel_err(R.f(gpu[i], f), R.f(ref[i], f), 1e-12)
+            worst = max(worst, e)
+            if not (e <= tol):
+                bad.append((i, f, e))
+    assert not bad, "%s mismatch (stage, field, rel_err): %s" % (what, bad[:10])
+    return worst
+
+
+@pytest.mark.parametrize("cfg", ["anymal_trot", "anymal_jump_sto", "icub35"])
+def test_sqp_iteration_hot_path(oracle, cfg):
+    """condense -> backward -> forward -> expand on pre-condensation stage data (the part of
+    OCPSolver::updateSolution downstream of the Pinocchio linearisation, ocp_solver.cpp:118-142),
+    GPU vs oracle, every stage type (contact phases nf=12/6/0, impact, lift, switching constraint)."""
+    from robotoc_amd import capi
+    from robotoc_amd.types import BUF_CDD
+    if cfg == "anymal_trot":
+        dims, grids, _ = pr.config_anymal_trot()
+    elif cfg == "anymal_jump_sto":
+        dims, grids, _ = pr.config_anymal_jump_sto()
+    else:
+        dims, grids, _ = pr.config_icub_jump(nv=35, N=12)
+    batch = 3
+    ctx = capi.Context(dims, len(grids), batch, 0)
+    try:
+        L = ctx.L
+        ctx.set_grid(grids)
+        kkt, cdd = pr.make_precondense_batch(L, grids, batch)
+        dx0 = pr.make_dx0(L, batch)
+        ctx.upload(BUF_KKT, kkt)
+        ctx.upload(BUF_CDD, cdd)
+        ctx.upload(BUF_DX0, dx0)
+        ctx.condense()
+        kkt_gpu = ctx.download_records(BUF_KKT, "kkt")
+        ctx.riccati_backward()
+        ctx.riccati_forward()
+        ctx.expand()
+        assert (ctx.status() == 0).all()
+        cdd_gpu = ctx.download_records(BUF_CDD, "cdd")
+        ric_gpu = ctx.download_records(BUF_RIC, "ric")
+        d_gpu = ctx.download_records(BUF_DIR, "dir")
+        # oracle
+        K, Cd, R, D = (Records(L, w) for w in ("kkt", "cdd", "ric", "dir"))
+        kk, cc = kkt.copy(), cdd.copy()
+        assert (oracle.condense_batch(L, grids, kk, cc) == 0).all()
+        kkt_ref = kk.copy()
+        ric_ref, d_ref = R.zeros(batch, len(grids)), D.zeros(batch, len(grids))
+        oracle.riccati_sweep_batch(L, grids, kk, ric_ref, d_ref, dx0=dx0)
+        oracle.expand_batch(L, grids, cc, d_ref)
+        worst = 0.0
+        for b in range(batch):
+            worst = max(worst, _compare_records(
+                K, kkt_gpu[b], kkt_ref[b],
+                ["Fxx", "Fvu", "Qxx", "Qxu", "Quu", "Fx", "lx", "lu", "hx", "hu", "fx", "scal", "Phix",
+                 "Phiu", "Phit", "Pres"], 1e-9, "condensed KKT inst %d" % b))
+            worst = max(worst, _compare_records(
+                Cd, cdd_gpu[b], cc[b],
+                ["MJtJinv", "MJtJinv_dIDCdqv", "MJtJinv_IDC", "Qafqv", "laf", "haf", "Qxu_passive",
+                 "Quu_passive_topRight", "lu_passive"], 1e-8, "contact dynamics data inst %d" % b))
+            worst = max(worst, compare_riccati(L, grids, ric_gpu[b], ric_ref[b], 1e-7, "inst %d" % b,
+                                               check_sto=False))
+            worst = max(worst, compare_direction(L, grids, d_gpu[b], d_ref[b], 1e-7, "inst %d" % b))
+            worst = max(worst, _compare_records(D, d_gpu[b], d_ref[b], ["daf", "dbetamu", "dnu_passive"],
+                                                1e-7, "expansion inst %d" % b))
+        print("sqp hot path %s: worst rel err %.3e" % (cfg, worst))
+    finally:
+        ctx.close()
