@@ -106,6 +106,7 @@ def main():
     ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="instances per GPU")
     ap.add_argument("--waves", type=int, default=0, help="backward-kernel waves per instance (0=default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sqp", action="store_true", help="skip the SQP-iteration phase timing")
     args = ap.parse_args()
 
     import torch
@@ -182,6 +183,40 @@ def main():
         torch.cuda.synchronize()
         gathered_ok = bool(all(torch.isfinite(o).all().item() for o in out))
 
+    # ---- SQP-iteration hot path (condense -> backward -> forward -> expand) on pre-condensation
+    #      stage data; each phase timed with HIP events on the launch stream, the (untimed)
+    #      device-to-device restore of the in-place-mutated records happens between repetitions ----
+    sqp = None
+    if not args.no_sqp:
+        from robotoc_amd.types import BUF_CDD
+        kkt_pre_s, cdd_pre_s = pr.make_precondense_batch(L, grids, 4, first_instance=rank * batch)
+        rp = (batch + 3) // 4
+        kkt0 = torch.from_numpy(np.ascontiguousarray(np.tile(kkt_pre_s, (rp, 1, 1))[:batch])).cuda()
+        cdd0 = torch.from_numpy(np.ascontiguousarray(np.tile(cdd_pre_s, (rp, 1, 1))[:batch])).cuda()
+        kkt_w = torch.empty(ctx.buffer_count(BUF_KKT), dtype=torch.float64, device="cuda")
+        cdd_w = torch.empty(ctx.buffer_count(BUF_CDD), dtype=torch.float64, device="cuda")
+        ctx.bind(BUF_KKT, kkt_w.data_ptr())
+        ctx.bind(BUF_CDD, cdd_w.data_ptr())
+        ph = {"condense": 2, "backward": 0, "forward": 1, "expand": 3}
+        acc = {k: 0.0 for k in ph}
+        nrep = 3
+        for rep in range(nrep + 1):
+            kkt_w[:kkt0.numel()].copy_(kkt0.view(-1))
+            cdd_w[:cdd0.numel()].copy_(cdd0.view(-1))
+            torch.cuda.synchronize()
+            for name in ("condense", "backward", "forward", "expand"):
+                ms = ctx.time_phase(ph[name], 1)
+                if rep > 0:
+                    acc[name] += ms / nrep
+        bad_sqp = int((ctx.status() != 0).sum())
+        tot = sum(acc.values())
+        sqp = {"ms": acc, "total_ms": tot, "iters_per_sec_per_gpu": batch / tot * 1e3,
+               "status_nonzero_instances": bad_sqp,
+               "scope": "PDIPM-free hot path downstream of the Pinocchio linearisation: "
+                        "computeMJtJinv + condenseContact/ImpactDynamics + Riccati backward/forward "
+                        "+ expandContactDynamics primal/dual; linearisation, cost and the manifold "
+                        "update of q are CPU-side and excluded on both GPU and CPU sides"}
+
     if rank == 0:
         total_sweeps = world * batch * args.steps
         value = total_sweeps / dt
@@ -215,6 +250,8 @@ def main():
                          "forward_algorithmic_bytes_per_launch": bytes_f},
             "status_nonzero_instances": bad,
         }
+        if sqp is not None:
+            res["sqp_iteration"] = sqp
         if gathered_ok is not None:
             res["rccl_gather_ok"] = gathered_ok
         if world == 1 and not args.no_cpu_baseline:
