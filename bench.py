@@ -68,6 +68,21 @@ def algorithmic_bytes(L, grids, batch, which):
     return total * 8 * batch
 
 
+def pmc_traffic(waves, batch):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this
+    same command (profiles/r01_traffic.json: 2*FETCH_SIZE + WRITE_SIZE, separate --pmc runs).
+    PMC counters cannot be collected from inside the timed process; null if the committed pass
+    does not match the configuration being run."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if waves not in (0, 2) or batch != PER_GPU_BATCH or not os.path.exists(path):
+        return None
+    t = json.load(open(path))
+    for k, v in t.items():
+        if "backward_rs" in k:
+            return v["hbm_bytes"]
+    return None
+
+
 def cpu_baseline(L, grids, dx0_small, kkt_small, budget_s=12.0):
     """Oracle (CPU port of the reference algorithm) timed on this box's host cores, OpenMP over
     instances.  Bounded sample: repeat a small batch until ~budget_s of CPU work."""
@@ -178,10 +193,11 @@ def main():
     nsl = len(grids) * L.dir.stride
     gathered_ok = None
     if world > 1:
-        out = [torch.empty_like(dir_t[:batch * nsl]) for _ in range(world)]
-        dist.all_gather(out, dir_t[:batch * nsl])
+        from robotoc_amd.sharding import gather_directions
+        full = gather_directions(dir_t[:batch * nsl].view(batch, len(grids), L.dir.stride),
+                                 world * batch, world, rank)
         torch.cuda.synchronize()
-        gathered_ok = bool(all(torch.isfinite(o).all().item() for o in out))
+        gathered_ok = bool(full.shape[0] == world * batch and torch.isfinite(full).all().item())
 
     # ---- SQP-iteration hot path (condense -> backward -> forward -> expand) on pre-condensation
     #      stage data; each phase timed with HIP events on the launch stream, the (untimed)
@@ -242,7 +258,7 @@ def main():
                        "per_gpu_batch": batch, "stages": len(grids), "parallelism": "instances sharded, dp%d" % world,
                        "backward_waves": args.waves},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(args.waves, batch),
                          "kernel": "riccati_backward_kernel", "kernel_ms": ms_b,
                          "algorithmic_bytes_per_launch": bytes_b,
                          "forward_kernel_ms": ms_f,

@@ -1,0 +1,343 @@
+// robotoc_hip.hpp -- C++ host mirror of the robotoc classes that sit directly on the hot path,
+// backed by the C ABI (include/rtoc.h).  Header-only, C++11, no Eigen (it is absent from this
+// image): the containers expose the reference's member names over a minimal column-major
+// `Mat`/`Vec` value type with Eigen-like `(i,j)` access, so that a robotoc maintainer can see
+// one-to-one what is packed where.  With Eigen available the same pack/unpack code works on
+// `Eigen::MatrixXd::data()` (column-major, identical element order).
+//
+// Mirrors (reference paths):
+//   robotoc::GridInfo / GridType            include/robotoc/ocp/grid_info.hpp:13-93
+//   robotoc::TimeDiscretization (size/[])   include/robotoc/ocp/time_discretization.hpp
+//   robotoc::SplitKKTMatrix / Residual      include/robotoc/core/split_kkt_matrix.hpp:18, split_kkt_residual.hpp
+//   robotoc::SplitRiccatiFactorization      include/robotoc/riccati/split_riccati_factorization.hpp:15
+//   robotoc::LQRPolicy                      include/robotoc/riccati/lqr_policy.hpp:16
+//   robotoc::SplitDirection                 include/robotoc/core/split_direction.hpp
+//   robotoc::RiccatiRecursion               include/robotoc/riccati/riccati_recursion.hpp:26-117
+//       RiccatiRecursion(ocp, max_dts0) / setRegularization / backwardRiccatiRecursion /
+//       forwardRiccatiRecursion / getLQRPolicy / resizeData -- same names, argument order and
+//       in-place semantics (backward mutates kkt_matrix.{Qxx,Qxu,Quu}, kkt_residual.lu).
+// Error behaviour: argument misuse throws std::invalid_argument / std::out_of_range like the
+// reference's solver layer (src/solver/ocp_solver.cpp:29-49,150-155); numerical failure, which the
+// reference only asserts in Debug builds, is reported by RiccatiRecursion::status().
+#ifndef ROBOTOC_HIP_HPP_
+#define ROBOTOC_HIP_HPP_
+
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/rtoc.h"
+
+namespace robotoc {
+
+enum class GridType { Intermediate = 0, Impact = 1, Lift = 2, Terminal = 3 };
+
+struct GridInfo {
+  GridType type = GridType::Intermediate;
+  double t0 = 0, t = 0, dt = 0, dt_next = 0;
+  int phase = 0, stage = 0, impact_index = -1, lift_index = -1, stage_in_phase = 0;
+  int num_grids_in_phase = 0;
+  bool sto = false, sto_next = false, switching_constraint = false;
+  // the two per-stage dimensions the reference reads from ContactSequence
+  int dimf = 0;  // contactStatus(phase).dimf()  (impactStatus(impact_index).dimf() on Impact grids)
+  int dims = 0;  // impactStatus(impact_index+1).dimf() when switching_constraint
+};
+
+class TimeDiscretization {
+ public:
+  TimeDiscretization() {}
+  explicit TimeDiscretization(const std::vector<GridInfo>& grid) : grid_(grid) {}
+  int size() const { return static_cast<int>(grid_.size()); }
+  const GridInfo& operator[](int i) const { return grid_.at(i); }
+  const GridInfo& grid(int i) const { return grid_.at(i); }
+  std::vector<GridInfo>& grids() { return grid_; }
+
+ private:
+  std::vector<GridInfo> grid_;
+};
+
+class Vec {
+ public:
+  Vec() {}
+  explicit Vec(int n) : d_(n, 0.0) {}
+  int size() const { return static_cast<int>(d_.size()); }
+  double& operator()(int i) { return d_[i]; }
+  double operator()(int i) const { return d_[i]; }
+  double* data() { return d_.data(); }
+  const double* data() const { return d_.data(); }
+  void setZero() { std::fill(d_.begin(), d_.end(), 0.0); }
+
+ private:
+  std::vector<double> d_;
+};
+
+class Mat {  // column-major like Eigen::MatrixXd
+ public:
+  Mat() : r_(0), c_(0) {}
+  Mat(int r, int c) : r_(r), c_(c), d_(static_cast<size_t>(r) * c, 0.0) {}
+  int rows() const { return r_; }
+  int cols() const { return c_; }
+  double& operator()(int i, int j) { return d_[i + static_cast<size_t>(j) * r_]; }
+  double operator()(int i, int j) const { return d_[i + static_cast<size_t>(j) * r_]; }
+  double* data() { return d_.data(); }
+  const double* data() const { return d_.data(); }
+  void setZero() { std::fill(d_.begin(), d_.end(), 0.0); }
+
+ private:
+  int r_, c_;
+  std::vector<double> d_;
+};
+
+struct RobotDims {  // what the hot path reads from robotoc::Robot
+  int dimv, dimu, dim_passive, max_dimf;
+  rtoc_dims c() const { return rtoc_dims{dimv, dimu, dim_passive, max_dimf, max_dimf, 0}; }
+};
+
+struct OCP {  // robotoc::OCP (include/robotoc/ocp/ocp.hpp:22-147): the members RiccatiRecursion uses
+  RobotDims robot;
+  int N = 0;
+  int reserved_num_discrete_events = 0;
+};
+
+class SplitKKTMatrix {
+ public:
+  SplitKKTMatrix() {}
+  explicit SplitKKTMatrix(const RobotDims& r)
+      : Fxx(2 * r.dimv, 2 * r.dimv), Fvu(r.dimv, r.dimu), Qxx(2 * r.dimv, 2 * r.dimv),
+        Qxu(2 * r.dimv, r.dimu), Quu(r.dimu, r.dimu), fx(2 * r.dimv), hx(2 * r.dimv), hu(r.dimu),
+        Phix_full(r.max_dimf, 2 * r.dimv), Phiu_full(r.max_dimf, r.dimu), Phit_full(r.max_dimf) {}
+  Mat Fxx, Fvu, Qxx, Qxu, Quu;
+  Vec fx, hx, hu;
+  double Qtt = 0, Qtt_prev = 0;
+  Mat Phix_full, Phiu_full;  // max-size backing; active rows = dims()
+  Vec Phit_full;
+  void setSwitchingConstraintDimension(int dims) { dims_ = dims; }
+  int dims() const { return dims_; }
+
+ private:
+  int dims_ = 0;
+};
+
+class SplitKKTResidual {
+ public:
+  SplitKKTResidual() {}
+  explicit SplitKKTResidual(const RobotDims& r)
+      : Fx(2 * r.dimv), lx(2 * r.dimv), lu(r.dimu), P_full(r.max_dimf) {}
+  Vec Fx, lx, lu, P_full;
+  double h = 0;
+};
+
+class SplitRiccatiFactorization {
+ public:
+  SplitRiccatiFactorization() {}
+  explicit SplitRiccatiFactorization(const RobotDims& r)
+      : P(2 * r.dimv, 2 * r.dimv), s(2 * r.dimv), psi_x(2 * r.dimv), psi_u(r.dimu), Psi(2 * r.dimv),
+        phi_x(2 * r.dimv), phi_u(r.dimu), Phi(2 * r.dimv), M_full(r.max_dimf, 2 * r.dimv),
+        m_full(r.max_dimf), mt_full(r.max_dimf), mt_next_full(r.max_dimf) {}
+  Mat P;
+  Vec s, psi_x, psi_u, Psi, phi_x, phi_u, Phi;
+  double xi = 0, chi = 0, rho = 0, eta = 0, iota = 0;
+  Mat M_full;
+  Vec m_full, mt_full, mt_next_full;
+};
+
+class LQRPolicy {
+ public:
+  LQRPolicy() {}
+  explicit LQRPolicy(const RobotDims& r) : Kt(2 * r.dimv, r.dimu), k(r.dimu), T(r.dimu), W(r.dimu) {}
+  // K is row-major dimu x dimx in the reference (lqr_policy.hpp:18-19); stored here as its
+  // column-major transpose Kt (identical memory), K(i,j) == Kt(j,i).
+  Mat Kt;
+  double K(int i, int j) const { return Kt(j, i); }
+  Vec k, T, W;
+};
+
+class SplitDirection {
+ public:
+  SplitDirection() {}
+  explicit SplitDirection(const RobotDims& r)
+      : dx(2 * r.dimv), du(r.dimu), dlmdgmm(2 * r.dimv), dxi_full(r.max_dimf) {}
+  Vec dx, du, dlmdgmm, dxi_full;
+  double dts = 0, dts_next = 0;
+};
+
+typedef std::vector<SplitKKTMatrix> KKTMatrix;
+typedef std::vector<SplitKKTResidual> KKTResidual;
+typedef std::vector<SplitRiccatiFactorization> RiccatiFactorization;
+typedef std::vector<SplitDirection> Direction;
+
+class RiccatiRecursion {
+ public:
+  RiccatiRecursion(const OCP& ocp, const double max_dts0 = 0.1, const int device = 0)
+      : robot_(ocp.robot), max_stages_(ocp.N + 1 + 3 * ocp.reserved_num_discrete_events + 1),
+        lqr_policy_(ocp.N + 1 + ocp.reserved_num_discrete_events, LQRPolicy(ocp.robot)), ctx_(nullptr) {
+    if (max_dts0 <= 0) throw std::out_of_range("[RiccatiRecursion] invalid argument: max_dts0 must be positive!");
+    const rtoc_dims d = robot_.c();
+    check(rtoc_create(&d, max_stages_, 1, device, &ctx_), "rtoc_create");
+    check(rtoc_get_layout(ctx_, &L_), "rtoc_get_layout");
+    check(rtoc_set_option(ctx_, RTOC_OPT_WRITEBACK_KKT, 1), "rtoc_set_option");  // reference in-place semantics
+    setRegularization(max_dts0);
+  }
+  ~RiccatiRecursion() {
+    if (ctx_) rtoc_destroy(ctx_);
+  }
+  RiccatiRecursion(const RiccatiRecursion&) = delete;
+  RiccatiRecursion& operator=(const RiccatiRecursion&) = delete;
+
+  void setRegularization(const double max_dts0) {
+    if (max_dts0 <= 0) throw std::out_of_range("[RiccatiRecursion] invalid argument: max_dts0 must be positive!");
+    int64_t bits;
+    std::memcpy(&bits, &max_dts0, sizeof(bits));
+    check(rtoc_set_option(ctx_, RTOC_OPT_MAX_DTS0, bits), "rtoc_set_option");
+  }
+
+  void resizeData(const TimeDiscretization& td) {
+    const int N = td.size() - 1;
+    while (static_cast<int>(lqr_policy_.size()) < N + 1) lqr_policy_.push_back(lqr_policy_.back());
+  }
+
+  void backwardRiccatiRecursion(const TimeDiscretization& td, KKTMatrix& kkt_matrix,
+                                KKTResidual& kkt_residual, RiccatiFactorization& factorization) {
+    resizeData(td);
+    const int n = td.size();
+    if (n > max_stages_ || static_cast<int>(kkt_matrix.size()) < n || static_cast<int>(kkt_residual.size()) < n ||
+        static_cast<int>(factorization.size()) < n)
+      throw std::invalid_argument("[RiccatiRecursion] horizon containers smaller than the discretisation");
+    setGrid(td);
+    std::vector<double> buf(static_cast<size_t>(n) * L_.kkt.stride, 0.0);
+    for (int i = 0; i < n; ++i) packKKT(kkt_matrix[i], kkt_residual[i], &buf[static_cast<size_t>(i) * L_.kkt.stride]);
+    check(rtoc_upload(ctx_, RTOC_BUF_KKT, 0, buf.data(), buf.size()), "rtoc_upload");
+    check(rtoc_clear_status(ctx_), "rtoc_clear_status");
+    check(rtoc_riccati_backward(ctx_), "rtoc_riccati_backward");
+    check(rtoc_download(ctx_, RTOC_BUF_KKT, 0, buf.data(), buf.size()), "rtoc_download");
+    for (int i = 0; i < n - 1; ++i)  // mutated blocks, like the reference (brrf.cpp:37-44,82-83)
+      unpackMutatedKKT(&buf[static_cast<size_t>(i) * L_.kkt.stride], td[i], kkt_matrix[i], kkt_residual[i]);
+    std::vector<double> rb(static_cast<size_t>(n) * L_.ric.stride);
+    check(rtoc_download(ctx_, RTOC_BUF_RIC, 0, rb.data(), rb.size()), "rtoc_download");
+    for (int i = 0; i < n; ++i) unpackRiccati(&rb[static_cast<size_t>(i) * L_.ric.stride], factorization[i], lqr_policy_[i]);
+  }
+
+  void forwardRiccatiRecursion(const TimeDiscretization& td, const KKTMatrix&, const KKTResidual&,
+                               const RiccatiFactorization&, Direction& d) const {
+    // kkt_matrix / kkt_residual / factorization of the preceding backward pass are resident in HBM
+    const int n = td.size();
+    if (static_cast<int>(d.size()) < n) throw std::invalid_argument("[RiccatiRecursion] direction too short");
+    check(rtoc_upload(ctx_, RTOC_BUF_DX0, 0, d[0].dx.data(), 2 * robot_.dimv), "rtoc_upload");
+    check(rtoc_riccati_forward(ctx_), "rtoc_riccati_forward");
+    std::vector<double> db(static_cast<size_t>(n) * L_.dir.stride);
+    check(rtoc_download(ctx_, RTOC_BUF_DIR, 0, db.data(), db.size()), "rtoc_download");
+    for (int i = 0; i < n; ++i) {
+      const double* r = &db[static_cast<size_t>(i) * L_.dir.stride];
+      std::memcpy(d[i].dx.data(), r + L_.dir.off[RTOC_DIR_DX], sizeof(double) * 2 * robot_.dimv);
+      std::memcpy(d[i].du.data(), r + L_.dir.off[RTOC_DIR_DU], sizeof(double) * robot_.dimu);
+      std::memcpy(d[i].dlmdgmm.data(), r + L_.dir.off[RTOC_DIR_DLMDGMM], sizeof(double) * 2 * robot_.dimv);
+      std::memcpy(d[i].dxi_full.data(), r + L_.dir.off[RTOC_DIR_DXI], sizeof(double) * robot_.max_dimf);
+      d[i].dts = r[L_.dir.off[RTOC_DIR_DTS] + 0];
+      d[i].dts_next = r[L_.dir.off[RTOC_DIR_DTS] + 1];
+    }
+  }
+
+  const std::vector<LQRPolicy>& getLQRPolicy() const { return lqr_policy_; }
+
+  // RTOC_STAT_* bits of the last backward pass (the reference asserts in Debug builds only)
+  unsigned status() const {
+    uint32_t s = 0;
+    check(rtoc_status(ctx_, &s, 1), "rtoc_status");
+    return s;
+  }
+
+ private:
+  static void check(int rc, const char* what) {
+    if (rc != RTOC_OK) throw std::runtime_error(std::string("[RiccatiRecursion] ") + what + ": " + rtoc_error_string(rc));
+  }
+  void setGrid(const TimeDiscretization& td) {
+    std::vector<rtoc_grid> g(td.size());
+    for (int i = 0; i < td.size(); ++i) {
+      const GridInfo& gi = td[i];
+      g[i].type = static_cast<int>(gi.type);
+      g[i].sto = gi.sto;
+      g[i].sto_next = gi.sto_next;
+      g[i].switching_constraint = gi.switching_constraint;
+      g[i].dimf = gi.dimf;
+      g[i].dims = gi.switching_constraint ? gi.dims : 0;
+      g[i].num_grids_in_phase = gi.num_grids_in_phase;
+      g[i].time_stage = gi.type == GridType::Impact ? -1 : gi.stage;
+      g[i].dt = gi.dt;
+    }
+    check(rtoc_set_grid(ctx_, g.data(), td.size()), "rtoc_set_grid");
+  }
+  static void cp(double* dst, const double* src, size_t n) { std::memcpy(dst, src, n * sizeof(double)); }
+  void packKKT(const SplitKKTMatrix& m, const SplitKKTResidual& r, double* rec) const {
+    const int nv = robot_.dimv, nu = robot_.dimu, nx = 2 * nv, ns = robot_.max_dimf;
+    const int* o = L_.kkt.off;
+    cp(rec + o[RTOC_KKT_FXX], m.Fxx.data(), static_cast<size_t>(nx) * nx);
+    cp(rec + o[RTOC_KKT_FVU], m.Fvu.data(), static_cast<size_t>(nv) * nu);
+    cp(rec + o[RTOC_KKT_QXX], m.Qxx.data(), static_cast<size_t>(nx) * nx);
+    cp(rec + o[RTOC_KKT_QXU], m.Qxu.data(), static_cast<size_t>(nx) * nu);
+    cp(rec + o[RTOC_KKT_QUU], m.Quu.data(), static_cast<size_t>(nu) * nu);
+    cp(rec + o[RTOC_KKT_FX], r.Fx.data(), nx);
+    cp(rec + o[RTOC_KKT_LX], r.lx.data(), nx);
+    cp(rec + o[RTOC_KKT_LU], r.lu.data(), nu);
+    cp(rec + o[RTOC_KKT_FFX], m.fx.data(), nx);
+    cp(rec + o[RTOC_KKT_HX], m.hx.data(), nx);
+    cp(rec + o[RTOC_KKT_HU], m.hu.data(), nu);
+    rec[o[RTOC_KKT_SCAL] + RTOC_KKT_SCAL_QTT] = m.Qtt;
+    rec[o[RTOC_KKT_SCAL] + RTOC_KKT_SCAL_QTT_PREV] = m.Qtt_prev;
+    rec[o[RTOC_KKT_SCAL] + RTOC_KKT_SCAL_H] = r.h;
+    if (ns > 0) {
+      cp(rec + o[RTOC_KKT_PHIX], m.Phix_full.data(), static_cast<size_t>(ns) * nx);
+      cp(rec + o[RTOC_KKT_PHIU], m.Phiu_full.data(), static_cast<size_t>(ns) * nu);
+      cp(rec + o[RTOC_KKT_PHIT], m.Phit_full.data(), ns);
+      cp(rec + o[RTOC_KKT_PRES], r.P_full.data(), ns);
+    }
+  }
+  void unpackMutatedKKT(const double* rec, const GridInfo& g, SplitKKTMatrix& m, SplitKKTResidual& r) const {
+    const int nv = robot_.dimv, nu = robot_.dimu, nx = 2 * nv;
+    const int* o = L_.kkt.off;
+    cp(m.Qxx.data(), rec + o[RTOC_KKT_QXX], static_cast<size_t>(nx) * nx);
+    if (g.type != GridType::Impact) {
+      cp(m.Qxu.data(), rec + o[RTOC_KKT_QXU], static_cast<size_t>(nx) * nu);
+      cp(m.Quu.data(), rec + o[RTOC_KKT_QUU], static_cast<size_t>(nu) * nu);
+      cp(r.lu.data(), rec + o[RTOC_KKT_LU], nu);
+    }
+  }
+  void unpackRiccati(const double* rec, SplitRiccatiFactorization& f, LQRPolicy& p) const {
+    const int nv = robot_.dimv, nu = robot_.dimu, nx = 2 * nv, ns = robot_.max_dimf;
+    const int* o = L_.ric.off;
+    cp(f.P.data(), rec + o[RTOC_RIC_P], static_cast<size_t>(nx) * nx);
+    cp(f.s.data(), rec + o[RTOC_RIC_S], nx);
+    cp(f.Psi.data(), rec + o[RTOC_RIC_PSI], nx);
+    cp(f.Phi.data(), rec + o[RTOC_RIC_PHI], nx);
+    cp(f.psi_x.data(), rec + o[RTOC_RIC_PSIX], nx);
+    cp(f.phi_x.data(), rec + o[RTOC_RIC_PHIX], nx);
+    cp(f.psi_u.data(), rec + o[RTOC_RIC_PSIU], nu);
+    cp(f.phi_u.data(), rec + o[RTOC_RIC_PHIU], nu);
+    const double* sc = rec + o[RTOC_RIC_SCAL];
+    f.xi = sc[RTOC_RIC_SCAL_XI];
+    f.chi = sc[RTOC_RIC_SCAL_CHI];
+    f.rho = sc[RTOC_RIC_SCAL_RHO];
+    f.eta = sc[RTOC_RIC_SCAL_ETA];
+    f.iota = sc[RTOC_RIC_SCAL_IOTA];
+    if (ns > 0) {
+      cp(f.M_full.data(), rec + o[RTOC_RIC_M], static_cast<size_t>(ns) * nx);
+      cp(f.m_full.data(), rec + o[RTOC_RIC_MV], ns);
+      cp(f.mt_full.data(), rec + o[RTOC_RIC_MT], ns);
+      cp(f.mt_next_full.data(), rec + o[RTOC_RIC_MTN], ns);
+    }
+    cp(p.Kt.data(), rec + o[RTOC_RIC_K], static_cast<size_t>(nx) * nu);
+    cp(p.k.data(), rec + o[RTOC_RIC_KV], nu);
+    cp(p.T.data(), rec + o[RTOC_RIC_T], nu);
+    cp(p.W.data(), rec + o[RTOC_RIC_W], nu);
+  }
+
+  RobotDims robot_;
+  int max_stages_;
+  std::vector<LQRPolicy> lqr_policy_;
+  rtoc_ctx* ctx_;
+  rtoc_layout L_;
+};
+
+}  // namespace robotoc
+
+#endif  // ROBOTOC_HIP_HPP_
