@@ -25,6 +25,11 @@
 
 namespace rtoc {
 
+#define RTOC_CPROF(k)                                                                   \
+  do {                                                                                  \
+    if (a.prof && blockIdx.x == 0 && threadIdx.x == 0) a.prof[(k)] = (long long)__builtin_readcyclecounter(); \
+  } while (0)
+
 struct CondArgs {
   double* kkt;
   double* cdd;
@@ -32,6 +37,7 @@ struct CondArgs {
   uint32_t* status;
   int nstages, batch;
   double damping;  // RobotModelInfo::contact_inv_damping (robot_model_info.hpp:95)
+  long long* prof;  // optional cycle stamps of work item 0 (tuning aid)
   rtoc_record_layout kl, cl;
 };
 
@@ -46,16 +52,34 @@ struct ExpArgs {
 
 template <int NV, int NU, int NF, int NS>
 struct CondCfg {
-  static constexpr int NT = 64;
+  static constexpr int NW = 2;          // wavefronts per work item (tile pairs dealt round-robin)
+  static constexpr int NT = 64 * NW;
+  static constexpr int NX = 2 * NV;
   static constexpr int NFP = NF > 0 ? NF : 1;
+  static constexpr int LDV = NV + NF;
   static constexpr int pad8(int n) { return (n + 7) & ~7; }
-  static constexpr int O_L = 0;                          // Cholesky factor of M      NV x NV
-  static constexpr int O_JM = O_L + pad8(NV * NV);       // J Minv                    NF x NV (ld NFP)
-  static constexpr int O_S = O_JM + pad8(NFP * NV);      // J Minv J^T and its factor NF x NF
-  static constexpr int O_BR = O_S + pad8(NFP * NFP);     // -(J Minv J^T)^-1          NF x NF
-  static constexpr int O_LINV = O_BR + pad8(NFP * NFP);  // 1/diag
-  static constexpr int O_SINV = O_LINV + 64;
-  static constexpr int LDS_DOUBLES = O_SINV + 64;
+  // LDS carve (doubles): one work item = one (instance, grid point); everything the stage
+  // touches more than once lives here, HBM sees each record field once in and once out.
+  static constexpr int O_LAM = 0;                              // MJtJinv            LDV x LDV
+  static constexpr int O_D = O_LAM + pad8(LDV * LDV);          // dIDCdqv, later Qafqv  LDV x NX
+  static constexpr int O_LD = O_D + pad8(LDV * NX);            // MJtJinv_dIDCdqv    LDV x NX
+  // region X: {M -> L, J, J Minv, S, -(S)^-1} while MJtJinv is built, then Qafu_full
+  static constexpr int O_X = O_LD + pad8(LDV * NX);
+  static constexpr int O_L = O_X;                              // NV x NV
+  static constexpr int O_J = O_L + pad8(NV * NV);              // NF x NV (ld NFP)
+  static constexpr int O_JM = O_J + pad8(NFP * NV);            // NF x NV
+  static constexpr int O_S = O_JM + pad8(NFP * NV);            // NF x NF
+  static constexpr int O_BR = O_S + pad8(NFP * NFP);           // NF x NF
+  static constexpr int X_A = O_BR + pad8(NFP * NFP) - O_X;
+  static constexpr int X_B = pad8(LDV * NV);                   // Qafu_full LDV x NV
+  static constexpr int O_QAFU = O_X;
+  static constexpr int O_QFF = O_X + (X_A > X_B ? X_A : X_B);  // NF x NF
+  static constexpr int O_QQF = O_QFF + pad8(NFP * NFP);        // NV x NF
+  static constexpr int O_VEC = O_QQF + pad8(NV * NFP);
+  static constexpr int V_IDC = O_VEC, V_LR = V_IDC + pad8(LDV), V_LAF = V_LR + pad8(LDV),
+                       V_HAF = V_LAF + pad8(LDV), V_QAA = V_HAF + pad8(LDV), V_LINV = V_QAA + pad8(NV),
+                       V_SINV = V_LINV + pad8(NV);
+  static constexpr int LDS_DOUBLES = V_SINV + pad8(NFP);
   static constexpr int LDS_BYTES = LDS_DOUBLES * 8;
 };
 
@@ -63,72 +87,137 @@ struct CondCfg {
 //   C(i,j) = beta * C(i,j) + alpha * sum_k A(i,k) B(k,j),  A(i,k) = A[i*ars + k*acs], ...
 // Operands may live in HBM/L2 or LDS (flat addressing).  Runtime dimensions; tiles are
 // processed two column tiles at a time to keep two MFMA chains in flight.
+template <int NW>
 __device__ __forceinline__ void wave_gemm(int M, int N, int K, double alpha, const double* A, int ars,
                                           int acs, const double* B, int brs, int bcs, double beta,
-                                          double* C, int crs, int ccs, int lane) {
+                                          double* C, int crs, int ccs, int tid,
+                                          // optional second product accumulated into the rows < M2 of
+                                          // the same tiles (one read-modify-write of C instead of two):
+                                          int M2 = 0, int K2 = 0, double alpha2 = 0.0,
+                                          const double* A2 = nullptr, int a2rs = 0, int a2cs = 0,
+                                          const double* B2 = nullptr, int b2rs = 0, int b2cs = 0) {
+  const int lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, q = lane >> 4;
-  const int tmn = (M + 15) >> 4, tnn = (N + 15) >> 4, ksn = (K + 3) >> 2;
-  for (int tm = 0; tm < tmn; ++tm) {
+  const int tmn = (M + 15) >> 4, tnp = (((N + 15) >> 4) + 1) >> 1, ksn = (K + 3) >> 2;
+  // tile pairs (16 rows x 32 columns) are dealt round-robin to the NW waves of the work item
+  for (int tp = wave; tp < tmn * tnp; tp += NW) {
+    const int tm = tp / tnp, tn = (tp - tm * tnp) * 2;
     const int i = tm * 16 + li;
     const bool iok = i < M;
     const double* ap = A + (size_t)(iok ? i : 0) * ars;
-    for (int tn = 0; tn < tnn; tn += 2) {
-      const int j0 = tn * 16 + li, j1 = j0 + 16;
-      const bool j0ok = j0 < N, j1ok = j1 < N;
-      const double* bp0 = B + (size_t)(j0ok ? j0 : 0) * bcs;
-      const double* bp1 = B + (size_t)(j1ok ? j1 : 0) * bcs;
-      d4 acc0 = zero4(), acc1 = zero4();
-      for (int ks = 0; ks < ksn; ++ks) {
-        const int k = ks * 4 + q;
+    const int j0 = tn * 16 + li, j1 = j0 + 16;
+    const bool j0ok = j0 < N, j1ok = j1 < N;
+    const double* bp0 = B + (size_t)(j0ok ? j0 : 0) * bcs;
+    const double* bp1 = B + (size_t)(j1ok ? j1 : 0) * bcs;
+    // read-modify-write targets are fetched BEFORE the k-loop: when C lives in HBM (in-place
+    // update of the KKT record) the load latency overlaps the MFMA work instead of trailing it
+    double c0[4], c1[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = tm * 16 + drow(q, r);
+      c0[r] = (beta != 0.0 && row < M && j0ok) ? C[(size_t)row * crs + (size_t)j0 * ccs] : 0.0;
+      c1[r] = (beta != 0.0 && row < M && j1ok) ? C[(size_t)row * crs + (size_t)j1 * ccs] : 0.0;
+    }
+    d4 acc0 = zero4(), acc1 = zero4();
+    // four k-steps per trip: 12 operand loads in flight before the 8 MFMAs that consume them
+    for (int ks = 0; ks < ksn; ks += 4) {
+      double av[4], b0[4], b1[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = (ks + u) * 4 + q;
         const bool kok = k < K;
         const int kc = kok ? k : 0;
-        const double av = ap[(size_t)kc * acs];
-        const double b0 = bp0[(size_t)kc * brs];
-        const double b1 = bp1[(size_t)kc * brs];
-        const double a_ = (iok && kok) ? av : 0.0;
-        acc0 = mfma16(a_, (j0ok && kok) ? b0 : 0.0, acc0);
-        acc1 = mfma16(a_, (j1ok && kok) ? b1 : 0.0, acc1);
+        const double a_ = ap[(size_t)kc * acs];
+        const double x0 = bp0[(size_t)kc * brs];
+        const double x1 = bp1[(size_t)kc * brs];
+        av[u] = (iok && kok) ? a_ : 0.0;
+        b0[u] = (j0ok && kok) ? x0 : 0.0;
+        b1[u] = (j1ok && kok) ? x1 : 0.0;
       }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = tm * 16 + drow(q, r);
-        if (row < M) {
-          if (j0ok) {
-            double* c = C + (size_t)row * crs + (size_t)j0 * ccs;
-            *c = (beta == 0.0 ? 0.0 : beta * *c) + alpha * acc0[r];
-          }
-          if (j1ok) {
-            double* c = C + (size_t)row * crs + (size_t)j1 * ccs;
-            *c = (beta == 0.0 ? 0.0 : beta * *c) + alpha * acc1[r];
-          }
+      for (int u = 0; u < 4; ++u) {
+        acc0 = mfma16(av[u], b0[u], acc0);
+        acc1 = mfma16(av[u], b1[u], acc1);
+      }
+    }
+    d4 acd0 = zero4(), acd1 = zero4();
+    if (M2 > 0 && tm * 16 < M2) {
+      const bool i2ok = i < M2;
+      const double* ap2 = A2 + (size_t)(i2ok ? i : 0) * a2rs;
+      const double* bq0 = B2 + (size_t)(j0ok ? j0 : 0) * b2cs;
+      const double* bq1 = B2 + (size_t)(j1ok ? j1 : 0) * b2cs;
+      for (int ks = 0; ks < ((K2 + 3) >> 2); ks += 4) {
+        double av[4], b0[4], b1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int k = (ks + u) * 4 + q;
+          const bool kok = k < K2;
+          const int kc = kok ? k : 0;
+          const double a_ = ap2[(size_t)kc * a2cs];
+          const double x0 = bq0[(size_t)kc * b2rs];
+          const double x1 = bq1[(size_t)kc * b2rs];
+          av[u] = (i2ok && kok) ? a_ : 0.0;
+          b0[u] = (j0ok && kok) ? x0 : 0.0;
+          b1[u] = (j1ok && kok) ? x1 : 0.0;
         }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          acd0 = mfma16(av[u], b0[u], acd0);
+          acd1 = mfma16(av[u], b1[u], acd1);
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = tm * 16 + drow(q, r);
+      if (row < M) {
+        if (j0ok) C[(size_t)row * crs + (size_t)j0 * ccs] = beta * c0[r] + alpha * acc0[r] + alpha2 * acd0[r];
+        if (j1ok) C[(size_t)row * crs + (size_t)j1 * ccs] = beta * c1[r] + alpha * acc1[r] + alpha2 * acd1[r];
       }
     }
   }
 }
 
 // y(i) = beta*y(i) + alpha * sum_k A(i,k) x(k): one lane per row, operands anywhere.
+template <int NT>
 __device__ __forceinline__ void wave_gemv(int M, int K, double alpha, const double* A, int ars, int acs,
                                           const double* x, double beta, double* y, int lane) {
-  for (int i = lane; i < M; i += 64) {
+  for (int i = lane; i < M; i += NT) {
     double acc = 0.0;
+#pragma unroll 8
     for (int k = 0; k < K; ++k) acc += A[(size_t)i * ars + (size_t)k * acs] * x[k];
     y[i] = (beta == 0.0 ? 0.0 : beta * y[i]) + alpha * acc;
   }
 }
 
 template <int NV, int NU, int NF, int NS>
-__global__ __launch_bounds__(64) void condense_kernel(CondArgs a) {
+__global__ __launch_bounds__(128) void condense_kernel(CondArgs a) {
+  static_assert(CondCfg<NV, NU, NF, NS>::NT == 128, "launch bounds must match CondCfg::NT");
   using C = CondCfg<NV, NU, NF, NS>;
-  constexpr int NX = 2 * NV, NP = NV - NU, LDV = NV + NF, LDF = C::NFP, LDS_ = NS > 0 ? NS : 1;
+  constexpr int NT = C::NT, NW = C::NW;
+  constexpr int NX = 2 * NV, NP = NV - NU, LDV = C::LDV, LDF = C::NFP, LDS_ = NS > 0 ? NS : 1;
   extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* const Lam = smem + C::O_LAM;
+  double* const D = smem + C::O_D;
+  double* const Qafqv = smem + C::O_D;  // overwrites dIDCdqv once MJtJinv_dIDCdqv exists
+  double* const LD = smem + C::O_LD;
   double* const sL = smem + C::O_L;
+  double* const sJ = smem + C::O_J;
   double* const sJM = smem + C::O_JM;
   double* const sS = smem + C::O_S;
   double* const sBR = smem + C::O_BR;
-  double* const sLinv = smem + C::O_LINV;
-  double* const sSinv = smem + C::O_SINV;
-  const int lane = threadIdx.x;
+  double* const Qafu = smem + C::O_QAFU;
+  double* const Qff = smem + C::O_QFF;
+  double* const Qqf = smem + C::O_QQF;
+  double* const IDC = smem + C::V_IDC;
+  double* const Lr = smem + C::V_LR;
+  double* const laf = smem + C::V_LAF;
+  double* const haf = smem + C::V_HAF;
+  double* const Qaa = smem + C::V_QAA;
+  double* const sLinv = smem + C::V_LINV;
+  double* const sSinv = smem + C::V_SINV;
+  const int lane = threadIdx.x;  // thread index within the work item (NT threads)
+  const int wv = lane >> 6, wl = lane & 63;
   const int item = blockIdx.x;  // instance * (nstages-1) + stage
   const int nst1 = a.nstages - 1;
   const int b = item / nst1, st = item % nst1;
@@ -141,30 +230,6 @@ __global__ __launch_bounds__(64) void condense_kernel(CondArgs a) {
   double* cr = a.cdd + ((size_t)b * a.nstages + st) * a.cl.stride;
   const int* ko = a.kl.off;
   const int* co = a.cl.off;
-  double* const M = cr + co[RTOC_CDD_DIDDA];
-  double* const D = cr + co[RTOC_CDD_DIDCDQV];
-  // J: dCda (ld NF) on contact grids, dCdv = D[nv:, nv:] (ld LDV) on impact grids
-  const double* const J = impact ? D + NV + (size_t)NV * LDV : cr + co[RTOC_CDD_DCDA];
-  const int ldj = impact ? LDV : LDF;
-  double* const IDC = cr + co[RTOC_CDD_IDC];
-  double* const Qaa = cr + co[RTOC_CDD_QAA];
-  double* const Qff = cr + co[RTOC_CDD_QFF];
-  double* const Qqf = cr + co[RTOC_CDD_QQF];
-  double* const la = cr + co[RTOC_CDD_LA];
-  double* const lf = cr + co[RTOC_CDD_LF];
-  double* const ha = cr + co[RTOC_CDD_HA];
-  double* const hf = cr + co[RTOC_CDD_HF];
-  double* const Phia = cr + co[RTOC_CDD_PHIA];
-  double* const lup = cr + co[RTOC_CDD_LUP];
-  double* const Lam = cr + co[RTOC_CDD_MJTJINV];
-  double* const LD = cr + co[RTOC_CDD_MJD];
-  double* const Lr = cr + co[RTOC_CDD_MJIDC];
-  double* const Qafqv = cr + co[RTOC_CDD_QAFQV];
-  double* const Qafu = cr + co[RTOC_CDD_QAFU];
-  double* const laf = cr + co[RTOC_CDD_LAF];
-  double* const Qxup = cr + co[RTOC_CDD_QXUP];
-  double* const Quuptr = cr + co[RTOC_CDD_QUUPTR];
-  double* const haf = cr + co[RTOC_CDD_HAF];
   double* const Fxx = kr + ko[RTOC_KKT_FXX];
   double* const Fvu = kr + ko[RTOC_KKT_FVU];
   double* const Qxx = kr + ko[RTOC_KKT_QXX];
@@ -181,33 +246,65 @@ __global__ __launch_bounds__(64) void condense_kernel(CondArgs a) {
   double* const Phiu = kr + ko[RTOC_KKT_PHIU];
   double* const Phit = kr + ko[RTOC_KKT_PHIT];
   double* const Pres = kr + ko[RTOC_KKT_PRES];
+  const double* const Phia = cr + co[RTOC_CDD_PHIA];
+  double* const lup = cr + co[RTOC_CDD_LUP];
+  double* const Qxup = cr + co[RTOC_CDD_QXUP];
+  double* const Quuptr = cr + co[RTOC_CDD_QUUPTR];
   unsigned stat = 0;
 
-  // ================= computeMJtJinv (robot.hxx:642-684) =================
-  if (wave_llt<NV, NV>(M, sL, sLinv, NV, lane)) stat |= RTOC_STAT_M_NOT_SPD;
-  __syncthreads();
-  // topLeft = M^-1: lane t < NV solves column t
+  RTOC_CPROF(0);
+  // inactive rows / columns (dimf < max_dimf) of the stored blocks stay zero, like the reference's
+  // max-size backing matrices
+  for (int e = lane; e < LDV * LDV; e += NT) Lam[e] = 0.0;
+  for (int e = lane; e < LDV * NX; e += NT) LD[e] = 0.0;
+  // ================= HBM -> LDS: every input field once, coalesced 16 B per lane =================
+  copy_g2s_flat<NT>(sL, cr + co[RTOC_CDD_DIDDA], NV * NV, lane);
+  copy_g2s_flat<NT>(D, cr + co[RTOC_CDD_DIDCDQV], LDV * NX, lane);
+  if (!impact && nf > 0) copy_g2s_flat<NT>(sJ, cr + co[RTOC_CDD_DCDA], C::NFP * NV, lane);
+  if (nf > 0) {
+    copy_g2s_flat<NT>(Qff, cr + co[RTOC_CDD_QFF], C::NFP * C::NFP, lane);
+    copy_g2s_flat<NT>(Qqf, cr + co[RTOC_CDD_QQF], NV * C::NFP, lane);
+  }
   if (lane < NV) {
+    Qaa[lane] = cr[co[RTOC_CDD_QAA] + lane];
+    laf[lane] = cr[co[RTOC_CDD_LA] + lane];
+    haf[lane] = cr[co[RTOC_CDD_HA] + lane];
+  }
+  if (lane < nf) {
+    laf[NV + lane] = -cr[co[RTOC_CDD_LF] + lane];
+    haf[NV + lane] = -cr[co[RTOC_CDD_HF] + lane];
+  }
+  if (lane < nvf) IDC[lane] = cr[co[RTOC_CDD_IDC] + lane];
+  __syncthreads();
+  // J: dCda (ld NF) on contact grids, dCdv = D[nv:, nv:] (ld LDV) on impact grids
+  const double* const J = impact ? D + NV + (size_t)NV * LDV : sJ;
+  const int ldj = impact ? LDV : LDF;
+
+  RTOC_CPROF(1);
+  // ================= computeMJtJinv (robot.hxx:642-684) =================
+  if (wv == 0 && wave_llt<NV, NV>(sL, sL, sLinv, NV, wl)) stat |= RTOC_STAT_M_NOT_SPD;
+  __syncthreads();
+  RTOC_CPROF(2);
+  if (lane < NV) {  // topLeft = M^-1: lane t solves column t
     double x[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) x[i] = (i == lane) ? 1.0 : 0.0;
     llt_solve_reg<NV, NV>(sL, sLinv, x, NV);
 #pragma unroll
-    for (int i = 0; i < NV; ++i) Lam[i + (size_t)lane * LDV] = x[i];
+    for (int i = 0; i < NV; ++i) Lam[i + lane * LDV] = x[i];
   }
   __syncthreads();
+  RTOC_CPROF(3);
   if (nf > 0) {
-    // bottomLeft = J M^-1 (:677) -> sJM ; JMinvJt (:660-661) -> sS
-    wave_gemm(nf, NV, NV, 1.0, J, 1, ldj, Lam, 1, LDV, 0.0, sJM, 1, LDF, lane);
+    wave_gemm<NW>(nf, NV, NV, 1.0, J, 1, ldj, Lam, 1, LDV, 0.0, sJM, 1, LDF, lane);  // J M^-1 (:677)
     __syncthreads();
-    wave_gemm(nf, nf, NV, 1.0, sJM, 1, LDF, J, ldj, 1, 0.0, sS, 1, LDF, lane);
+    wave_gemm<NW>(nf, nf, NV, 1.0, sJM, 1, LDF, J, ldj, 1, 0.0, sS, 1, LDF, lane);   // JMinvJt (:660-661)
     __syncthreads();
     if (lane < nf) sS[lane + lane * LDF] += a.damping;  // (:662-664)
     __syncthreads();
-    if (wave_llt<C::NFP, C::NFP>(sS, sS, sSinv, nf, lane)) stat |= RTOC_STAT_M_NOT_SPD;  // (:665)
+    if (wv == 0 && wave_llt<C::NFP, C::NFP>(sS, sS, sSinv, nf, wl)) stat |= RTOC_STAT_M_NOT_SPD;  // (:665)
     __syncthreads();
-    // bottomRight = -(JMinvJt)^-1 (:673-675): lane t < nf solves column t of -I
-    if (lane < nf) {
+    if (lane < nf) {  // bottomRight = -(JMinvJt)^-1 (:673-675)
       double x[C::NFP];
 #pragma unroll
       for (int i = 0; i < C::NFP; ++i) x[i] = (i == lane) ? -1.0 : 0.0;
@@ -216,110 +313,136 @@ __global__ __launch_bounds__(64) void condense_kernel(CondArgs a) {
       for (int i = 0; i < C::NFP; ++i)
         if (i < nf) {
           sBR[i + lane * LDF] = x[i];
-          Lam[(NV + i) + (size_t)(NV + lane) * LDV] = x[i];
+          Lam[(NV + i) + (NV + lane) * LDV] = x[i];
         }
     }
     __syncthreads();
     // topRight = bottomLeft^T * (-bottomRight) (:678)
-    wave_gemm(NV, nf, nf, -1.0, sJM, LDF, 1, sBR, 1, LDF, 0.0, Lam + (size_t)NV * LDV, 1, LDV, lane);
+    wave_gemm<NW>(NV, nf, nf, -1.0, sJM, LDF, 1, sBR, 1, LDF, 0.0, Lam + NV * LDV, 1, LDV, lane);
     __syncthreads();
     // topLeft -= topRight * bottomLeft (:679) ; bottomLeft = topRight^T (:680)
-    wave_gemm(NV, NV, nf, -1.0, Lam + (size_t)NV * LDV, 1, LDV, sJM, 1, LDF, 1.0, Lam, 1, LDV, lane);
-    for (int e = lane; e < nf * NV; e += 64) {
+    wave_gemm<NW>(NV, NV, nf, -1.0, Lam + NV * LDV, 1, LDV, sJM, 1, LDF, 1.0, Lam, 1, LDV, lane);
+    for (int e = lane; e < nf * NV; e += NT) {
       const int i = e % nf, j = e / nf;
-      Lam[(NV + i) + (size_t)j * LDV] = Lam[j + (size_t)(NV + i) * LDV];
+      Lam[(NV + i) + j * LDV] = Lam[j + (NV + i) * LDV];
     }
     __syncthreads();
   }
 
+  RTOC_CPROF(4);
   // ================= MJtJinv_dIDCdqv, MJtJinv_IDC (contact_dynamics.cpp:64-65 / impact :44-50) ===
   if (!impact) {
-    wave_gemm(nvf, NX, nvf, 1.0, Lam, 1, LDV, D, 1, LDV, 0.0, LD, 1, LDV, lane);
+    wave_gemm<NW>(nvf, NX, nvf, 1.0, Lam, 1, LDV, D, 1, LDV, 0.0, LD, 1, LDV, lane);
   } else {
-    wave_gemm(nvf, NV, nvf, 1.0, Lam, 1, LDV, D, 1, LDV, 0.0, LD, 1, LDV, lane);
-    // right half only through dCdv: [Lam[:, f]] * dCdv
-    wave_gemm(nvf, NV, nf, 1.0, Lam + (size_t)NV * LDV, 1, LDV, J, 1, ldj, 0.0, LD + (size_t)NV * LDV, 1, LDV,
-              lane);
+    wave_gemm<NW>(nvf, NV, nvf, 1.0, Lam, 1, LDV, D, 1, LDV, 0.0, LD, 1, LDV, lane);
+    wave_gemm<NW>(nvf, NV, nf, 1.0, Lam + NV * LDV, 1, LDV, J, 1, ldj, 0.0, LD + NV * LDV, 1, LDV, lane);
   }
-  wave_gemv(nvf, nvf, 1.0, Lam, 1, LDV, IDC, 0.0, Lr, lane);
+  wave_gemv<NT>(nvf, nvf, 1.0, Lam, 1, LDV, IDC, 0.0, Lr, lane);
+  __syncthreads();  // D (and J inside it) is dead from here on: its space becomes Qafqv; region X becomes Qafu
+  for (int e = lane; e < LDV * NX; e += NT) Qafqv[e] = 0.0;
+  if (!impact)
+    for (int e = lane; e < LDV * NV; e += NT) Qafu[e] = 0.0;
   __syncthreads();
 
+  RTOC_CPROF(5);
   // ================= Qafqv, Qafu_full, laf (:67-88) =================
-  for (int e = lane; e < NV * NX; e += 64) {
+  for (int e = lane; e < NV * NX; e += NT) {
     const int i = e % NV, j = e / NV;
-    Qafqv[i + (size_t)j * LDV] = -Qaa[i] * LD[i + (size_t)j * LDV];
+    Qafqv[i + j * LDV] = -Qaa[i] * LD[i + j * LDV];
   }
   if (!impact)
-    for (int e = lane; e < NV * NV; e += 64) {
+    for (int e = lane; e < NV * NV; e += NT) {
       const int i = e % NV, j = e / NV;
-      Qafu[i + (size_t)j * LDV] = Qaa[i] * Lam[i + (size_t)j * LDV];
+      Qafu[i + j * LDV] = Qaa[i] * Lam[i + j * LDV];
     }
-  if (lane < NV) laf[lane] = la[lane] - Qaa[lane] * Lr[lane];
-  if (!impact && lane < NV) haf[lane] = ha[lane];
+  if (lane < NV) laf[lane] -= Qaa[lane] * Lr[lane];
   if (nf > 0) {
-    wave_gemm(nf, NX, nf, -1.0, Qff, 1, LDF, LD + NV, 1, LDV, 0.0, Qafqv + NV, 1, LDV, lane);
-    if (!impact) wave_gemm(nf, NV, nf, 1.0, Qff, 1, LDF, Lam + NV, 1, LDV, 0.0, Qafu + NV, 1, LDV, lane);
+    wave_gemm<NW>(nf, NX, nf, -1.0, Qff, 1, LDF, LD + NV, 1, LDV, 0.0, Qafqv + NV, 1, LDV, lane);
+    if (!impact) wave_gemm<NW>(nf, NV, nf, 1.0, Qff, 1, LDF, Lam + NV, 1, LDV, 0.0, Qafu + NV, 1, LDV, lane);
     if (lane < nf) {
       double acc = 0.0;
       for (int k = 0; k < nf; ++k) acc += Qff[lane + k * LDF] * Lr[NV + k];
-      laf[NV + lane] = -lf[lane] - acc;
-      if (!impact) haf[NV + lane] = -hf[lane];
+      laf[NV + lane] -= acc;
     }
     __syncthreads();
-    for (int e = lane; e < nf * NV; e += 64) {
+    for (int e = lane; e < nf * NV; e += NT) {
       const int i = e % nf, j = e / nf;
-      Qafqv[(NV + i) + (size_t)j * LDV] -= Qqf[j + (size_t)i * NV];
+      Qafqv[(NV + i) + j * LDV] -= Qqf[j + i * NV];
     }
   }
   __syncthreads();
 
-  // ================= Schur updates of the Hessian blocks and gradients (:90-130) =================
-  wave_gemm(NX, NX, nvf, -1.0, LD, LDV, 1, Qafqv, 1, LDV, 1.0, Qxx, 1, NX, lane);
-  wave_gemv(NX, nvf, -1.0, LD, LDV, 1, laf, 1.0, lx, lane);
+  RTOC_CPROF(6);
+  // ================= Schur updates of the Hessian blocks and gradients (:90-130), in place in HBM ==
+  // Each block gets ONE read-modify-write: the Qqf corrections (:92-93,:99-100,:106-107), which touch
+  // the rows < NV only, ride along as a second product in the same tiles.
+  wave_gemm<NW>(NX, NX, nvf, -1.0, LD, LDV, 1, Qafqv, 1, LDV, 1.0, Qxx, 1, NX, lane,
+                nf > 0 ? NV : 0, nf, 1.0, Qqf, 1, NV, LD + NV, 1, LDV);
   if (!impact) {
     if (NP > 0) {
-      wave_gemm(NX, NP, nvf, -1.0, LD, LDV, 1, Qafu, 1, LDV, 0.0, Qxup, 1, NX, lane);
-      wave_gemm(NP, NU, nvf, 1.0, Lam, 1, LDV, Qafu + (size_t)NP * LDV, 1, LDV, 0.0, Quuptr, 1, NP, lane);
-      wave_gemv(NP, nvf, 1.0, Lam, 1, LDV, laf, 1.0, lup, lane);
+      wave_gemm<NW>(NX, NP, nvf, -1.0, LD, LDV, 1, Qafu, 1, LDV, 0.0, Qxup, 1, NX, lane,
+                    nf > 0 ? NV : 0, nf, -1.0, Qqf, 1, NV, Lam + NV, 1, LDV);
+      wave_gemm<NW>(NP, NU, nvf, 1.0, Lam, 1, LDV, Qafu + NP * LDV, 1, LDV, 0.0, Quuptr, 1, NP, lane);
     }
-    wave_gemm(NX, NU, nvf, -1.0, LD, LDV, 1, Qafu + (size_t)NP * LDV, 1, LDV, 1.0, Qxu, 1, NX, lane);
-    wave_gemm(NU, NU, nvf, 1.0, Lam + NP, 1, LDV, Qafu + (size_t)NP * LDV, 1, LDV, 1.0, Quu, 1, NU, lane);
-    wave_gemv(NU, nvf, 1.0, Lam + NP, 1, LDV, laf, 1.0, lu, lane);
-    // STO sensitivities (:156-163)
-    wave_gemv(NX, nvf, -1.0, LD, LDV, 1, haf, 1.0, hx, lane);
-    wave_gemv(NU, nvf, 1.0, Lam + NP, 1, LDV, haf, 1.0, hu, lane);
+    wave_gemm<NW>(NX, NU, nvf, -1.0, LD, LDV, 1, Qafu + NP * LDV, 1, LDV, 1.0, Qxu, 1, NX, lane,
+                  nf > 0 ? NV : 0, nf, -1.0, Qqf, 1, NV, Lam + NV + NP * LDV, 1, LDV);
+    wave_gemm<NW>(NU, NU, nvf, 1.0, Lam + NP, 1, LDV, Qafu + NP * LDV, 1, LDV, 1.0, Quu, 1, NU, lane);
   }
-  __syncthreads();
-  if (nf > 0) {
-    // the Qqf corrections touch rows < NV of blocks updated above
-    wave_gemm(NV, NX, nf, 1.0, Qqf, 1, NV, LD + NV, 1, LDV, 1.0, Qxx, 1, NX, lane);
-    wave_gemv(NV, nf, 1.0, Qqf, 1, NV, Lr + NV, 1.0, lx, lane);
-    if (!impact) {
-      if (NP > 0) wave_gemm(NV, NP, nf, -1.0, Qqf, 1, NV, Lam + NV, 1, LDV, 1.0, Qxup, 1, NX, lane);
-      wave_gemm(NV, NU, nf, -1.0, Qqf, 1, NV, Lam + NV + (size_t)NP * LDV, 1, LDV, 1.0, Qxu, 1, NX, lane);
-      wave_gemv(NV, nf, 1.0 / dt, Qqf, 1, NV, Lr + NV, 1.0, hx, lane);
+  // gradients: one lane per entry, every term of an entry in the same lane (:110-113,:123-130,:156-163)
+  for (int i = lane; i < NX; i += NT) {
+    double al = 0.0, ah = 0.0;
+    for (int k = 0; k < nvf; ++k) {
+      const double ld = LD[k + i * LDV];
+      al += ld * laf[k];
+      ah += ld * haf[k];
+    }
+    double l = lx[i] - al, h = impact ? 0.0 : hx[i] - ah;
+    if (i < NV && nf > 0) {
+      double aq = 0.0;
+      for (int k = 0; k < nf; ++k) aq += Qqf[i + k * NV] * Lr[NV + k];
+      l += aq;
+      h += aq / dt;
+    }
+    lx[i] = l;
+    if (!impact) hx[i] = h;
+  }
+  if (!impact) {
+    for (int i = lane; i < NV; i += NT) {
+      double al = 0.0, ah = 0.0;
+      for (int k = 0; k < nvf; ++k) {
+        const double lm = Lam[i + k * LDV];
+        al += lm * laf[k];
+        ah += lm * haf[k];
+      }
+      if (i < NP) {
+        lup[i] += al;
+      } else {
+        lu[i - NP] += al;
+        hu[i - NP] += ah;
+      }
     }
   }
 
+  RTOC_CPROF(7);
   // ================= condensed dynamics (:132-136 / impact :74-77) =================
   const double sdt = impact ? 1.0 : dt;
-  for (int e = lane; e < NV * NV; e += 64) {
+  for (int e = lane; e < NV * NV; e += NT) {
     const int i = e % NV, j = e / NV;
-    Fxx[(NV + i) + (size_t)j * NX] = -sdt * LD[i + (size_t)j * LDV];
-    Fxx[(NV + i) + (size_t)(NV + j) * NX] = -sdt * LD[i + (size_t)(NV + j) * LDV] + (i == j ? 1.0 : 0.0);
+    Fxx[(NV + i) + (size_t)j * NX] = -sdt * LD[i + j * LDV];
+    Fxx[(NV + i) + (size_t)(NV + j) * NX] = -sdt * LD[i + (NV + j) * LDV] + (i == j ? 1.0 : 0.0);
   }
   if (!impact)
-    for (int e = lane; e < NV * NU; e += 64) {
+    for (int e = lane; e < NV * NU; e += NT) {
       const int i = e % NV, j = e / NV;
-      Fvu[i + (size_t)j * NV] = dt * Lam[i + (size_t)(NP + j) * LDV];
+      Fvu[i + (size_t)j * NV] = dt * Lam[i + (NP + j) * LDV];
     }
   if (lane < NV) Fx[NV + lane] -= sdt * Lr[lane];
 
   if (!impact) {
     // ================= switching constraint (:138-153) =================
     if (NS > 0 && ns > 0) {
-      wave_gemm(ns, NX, NV, -1.0, Phia, 1, LDS_, LD, 1, LDV, 1.0, Phix, 1, LDS_, lane);
-      wave_gemm(ns, NU, NV, 1.0, Phia, 1, LDS_, Lam + (size_t)NP * LDV, 1, LDV, 0.0, Phiu, 1, LDS_, lane);
+      wave_gemm<NW>(ns, NX, NV, -1.0, Phia, 1, LDS_, LD, 1, LDV, 1.0, Phix, 1, LDS_, lane);
+      wave_gemm<NW>(ns, NU, NV, 1.0, Phia, 1, LDS_, Lam + NP * LDV, 1, LDV, 0.0, Phiu, 1, LDS_, lane);
       if (lane < ns) {
         double acc = 0.0;
         for (int k = 0; k < NV; ++k) acc += Phia[lane + k * LDS_] * Lr[k];
@@ -338,12 +461,25 @@ __global__ __launch_bounds__(64) void condense_kernel(CondArgs a) {
       scal[RTOC_KKT_SCAL_QTT] = qtt;
       scal[RTOC_KKT_SCAL_QTT_PREV] = -qtt;
     }
-    for (int i = lane; i < NX; i += 64) {
+    for (int i = lane; i < NX; i += NT) {
       hx[i] *= inv;
       fx[i] *= inv;
     }
     if (lane < NU) hu[lane] *= inv;
   }
+
+  RTOC_CPROF(8);
+  // ================= LDS -> HBM: the ContactDynamicsData the expansion needs, each field once ====
+  copy_s2g_flat16<NT>(cr + co[RTOC_CDD_MJTJINV], Lam, LDV * LDV, lane);
+  copy_s2g_flat16<NT>(cr + co[RTOC_CDD_MJD], LD, LDV * NX, lane);
+  copy_s2g_flat16<NT>(cr + co[RTOC_CDD_QAFQV], Qafqv, LDV * NX, lane);
+  if (!impact) copy_s2g_flat16<NT>(cr + co[RTOC_CDD_QAFU], Qafu, LDV * NV, lane);
+  if (lane < nvf) {
+    cr[co[RTOC_CDD_MJIDC] + lane] = Lr[lane];
+    cr[co[RTOC_CDD_LAF] + lane] = laf[lane];
+    if (!impact) cr[co[RTOC_CDD_HAF] + lane] = haf[lane];
+  }
+  RTOC_CPROF(9);
   if (stat) atomicOr(&a.status[b], stat);
 }
 

@@ -38,6 +38,7 @@ __device__ __forceinline__ void copy_g2s_flat(double* __restrict__ dst, const do
   const int n2 = n >> 1;
   const d2* s2 = reinterpret_cast<const d2*>(src);
   d2* t2 = reinterpret_cast<d2*>(dst);
+#pragma unroll 8
   for (int e = tid; e < n2; e += NT) t2[e] = s2[e];
   if ((n & 1) && tid == 0) dst[n - 1] = src[n - 1];
 }
@@ -91,6 +92,18 @@ template <int NT>
 __device__ __forceinline__ void copy_s2g_flat(double* __restrict__ dst, const double* __restrict__ src,
                                               int n, int tid) {
   for (int e = tid; e < n; e += NT) dst[e] = src[e];
+}
+
+// n doubles (n even or the tail handled), 16 B per lane, LDS -> HBM
+template <int NT>
+__device__ __forceinline__ void copy_s2g_flat16(double* __restrict__ dst, const double* __restrict__ src,
+                                                int n, int tid) {
+  const int n2 = n >> 1;
+  const d2* s2 = reinterpret_cast<const d2*>(src);
+  d2* t2 = reinterpret_cast<d2*>(dst);
+#pragma unroll 8
+  for (int e = tid; e < n2; e += NT) t2[e] = s2[e];
+  if ((n & 1) && tid == 0) dst[n - 1] = src[n - 1];
 }
 
 __device__ __forceinline__ double shfl_d(double v, int src_lane) { return __shfl(v, src_lane, 64); }

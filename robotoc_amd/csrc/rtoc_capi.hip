@@ -394,6 +394,7 @@ static int launch_condense(rtoc_ctx* c) {
   a.nstages = c->nstages;
   a.batch = c->batch;
   a.damping = c->contact_inv_damping;
+  a.prof = c->d_prof;
   a.kl = c->L.kkt;
   a.cl = c->L.cdd;
   const int nblocks = c->batch * (c->nstages - 1);
