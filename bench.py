@@ -213,14 +213,22 @@ def main():
         cdd_w = torch.empty(ctx.buffer_count(BUF_CDD), dtype=torch.float64, device="cuda")
         ctx.bind(BUF_KKT, kkt_w.data_ptr())
         ctx.bind(BUF_CDD, cdd_w.data_ptr())
-        ph = {"condense": 2, "backward": 0, "forward": 1, "expand": 3}
+        # PDIPM joint-limit rows (6 x nu box rows, examples/anymal/trot.cpp:134-146)
+        from robotoc_amd.types import BUF_CON, joint_limit_rows
+        ctx.set_constraint_rows(joint_limit_rows(dims))
+        con_s = pr.make_constraint_batch(L, grids, 4, first_instance=rank * batch)
+        con0 = torch.from_numpy(np.ascontiguousarray(np.tile(con_s, (rp, 1, 1))[:batch])).cuda()
+        con_w = torch.empty(ctx.buffer_count(BUF_CON), dtype=torch.float64, device="cuda")
+        ctx.bind(BUF_CON, con_w.data_ptr())
+        ph = {"condense": 2, "backward": 0, "forward": 1, "expand": 3, "update": 5}
         acc = {k: 0.0 for k in ph}
         nrep = 3
         for rep in range(nrep + 1):
             kkt_w[:kkt0.numel()].copy_(kkt0.view(-1))
             cdd_w[:cdd0.numel()].copy_(cdd0.view(-1))
+            con_w[:con0.numel()].copy_(con0.view(-1))
             torch.cuda.synchronize()
-            for name in ("condense", "backward", "forward", "expand"):
+            for name in ("condense", "backward", "forward", "expand", "update"):
                 ms = ctx.time_phase(ph[name], 1)
                 if rep > 0:
                     acc[name] += ms / nrep
@@ -228,10 +236,11 @@ def main():
         tot = sum(acc.values())
         sqp = {"ms": acc, "total_ms": tot, "iters_per_sec_per_gpu": batch / tot * 1e3,
                "status_nonzero_instances": bad_sqp,
-               "scope": "PDIPM-free hot path downstream of the Pinocchio linearisation: "
-                        "computeMJtJinv + condenseContact/ImpactDynamics + Riccati backward/forward "
-                        "+ expandContactDynamics primal/dual; linearisation, cost and the manifold "
-                        "update of q are CPU-side and excluded on both GPU and CPU sides"}
+               "scope": "hot path downstream of the Pinocchio linearisation: PDIPM condensation of the "
+                        "joint-limit rows + computeMJtJinv + condenseContact/ImpactDynamics + Riccati "
+                        "backward/forward + expandContactDynamics primal/dual + PDIPM expansion, "
+                        "fraction-to-boundary step sizes and slack/dual update; linearisation, cost, "
+                        "friction-cone rows and the manifold update of q are CPU-side and excluded"}
 
     if rank == 0:
         total_sweeps = world * batch * args.steps

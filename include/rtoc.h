@@ -127,6 +127,11 @@ size_t rtoc_buffer_count(const rtoc_ctx* ctx, int buffer);
 /* Replace a buffer by caller-owned device memory of at least rtoc_buffer_count doubles. */
 int rtoc_bind(rtoc_ctx* ctx, int buffer, void* device_ptr);
 
+/* Joint-limit (box) inequality rows handled by the PDIPM condensation / expansion; shared by all
+ * instances and grids (the stage mask follows rtoc_box_row::level).  nrows <= dims.nc_max.
+ * Mirrors Constraints::add(...) of the six joint-limit components (examples/anymal/trot.cpp:134-146). */
+int rtoc_set_constraint_rows(rtoc_ctx* ctx, const rtoc_box_row* rows, int nrows);
+
 /* ---- the hot path ---------------------------------------------------------- */
 int rtoc_condense(rtoc_ctx* ctx);
 int rtoc_riccati_backward(rtoc_ctx* ctx);
@@ -145,7 +150,7 @@ int rtoc_sync(rtoc_ctx* ctx);
 
 /* Time `reps` back-to-back launches of one phase with HIP events recorded on the
  * context's stream; returns the mean milliseconds per launch in *ms.
- * phase: 0 backward, 1 forward, 2 condense, 3 expand, 4 backward+forward. */
+ * phase: 0 backward, 1 forward, 2 condense, 3 expand, 4 backward+forward, 5 update. */
 int rtoc_time_phase(rtoc_ctx* ctx, int phase, int reps, float* ms);
 
 /* Multi-GPU: all-gather the direction buffers of all ranks over RCCL.

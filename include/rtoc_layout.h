@@ -155,6 +155,35 @@ enum {
   RTOC_CDD_NFIELDS
 };
 
+/* One PDIPM inequality row of a joint-limit component (the six Joint{Position,Velocity,Torques}
+ * {Lower,Upper}Limit classes, e.g. src/constraints/joint_torques_lower_limit.cpp:50-83): a bound on a
+ * single primal variable.  g(z) = sign * z[index] - bound <= 0, i.e. sign = -1 for a lower limit
+ * (xmin - x <= 0) and +1 for an upper limit (x - xmax <= 0). */
+#define RTOC_VAR_Q 0
+#define RTOC_VAR_V 1
+#define RTOC_VAR_U 2
+typedef struct rtoc_box_row {
+  int var;   /* RTOC_VAR_Q / _V / _U                                                       */
+  int index; /* entry of q / v (0..nv-1; joint limits use the tail nu entries) or u (0..nu-1) */
+  int sign;  /* -1 lower limit, +1 upper limit                                            */
+  int level; /* KinematicsLevel: 0 acceleration (torques), 1 velocity, 2 position;
+                active on a grid iff time_stage >= level (src/constraints/constraints_data.cpp:20-45),
+                never on impact grids (time_stage = -1) or the terminal grid                */
+} rtoc_box_row;
+
+/* ---- constraint record: ConstraintComponentData of all box rows
+ *      (include/robotoc/constraints/constraint_component_data.hpp:61-114); each field pad8(nc_max) */
+enum {
+  RTOC_CON_SLACK = 0,
+  RTOC_CON_DUAL,
+  RTOC_CON_RESIDUAL,
+  RTOC_CON_CMPL,
+  RTOC_CON_COND,
+  RTOC_CON_DSLACK,
+  RTOC_CON_DDUAL,
+  RTOC_CON_NFIELDS
+};
+
 typedef struct rtoc_record_layout {
   int off[24]; /* field offsets in doubles (indexed by the enums above) */
   int stride;  /* record size in doubles                                */
@@ -165,7 +194,7 @@ typedef struct rtoc_layout {
   rtoc_dims dims;
   int nx;      /* 2*nv       */
   int nvf_max; /* nv+nf_max  */
-  rtoc_record_layout kkt, ric, dir, cdd;
+  rtoc_record_layout kkt, ric, dir, cdd, con;
 } rtoc_layout;
 
 static inline RTOC_HD int rtoc_pad8(int n) { return (n + 7) & ~7; }
@@ -265,6 +294,11 @@ static inline RTOC_HD void rtoc_compute_layout(const rtoc_dims* d, rtoc_layout* 
     s[RTOC_CDD_QUUPTR] = 8 * nu;
     s[RTOC_CDD_HAF] = nvf;
     rtoc_record_finish(&L->cdd, s, RTOC_CDD_NFIELDS);
+  }
+  {
+    int s[RTOC_CON_NFIELDS];
+    for (int i = 0; i < RTOC_CON_NFIELDS; ++i) s[i] = d->nc_max;
+    rtoc_record_finish(&L->con, s, RTOC_CON_NFIELDS);
   }
 }
 

@@ -10,7 +10,7 @@ import subprocess
 
 import numpy as np
 
-from robotoc_amd.types import Dims, Grid, Layout, grid_array
+from robotoc_amd.types import BoxRow, Dims, Grid, Layout, grid_array
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
@@ -62,6 +62,8 @@ def lib():
         _LIB.orc_condense_batch.argtypes = [C.POINTER(Layout), C.POINTER(Grid), C.c_int, C.c_int, dp, dp,
                                             C.c_double, C.POINTER(C.c_uint)]
         _LIB.orc_expand_batch.argtypes = [C.POINTER(Layout), C.POINTER(Grid), C.c_int, C.c_int, dp, dp]
+        _LIB.orc_pdipm_batch.argtypes = [C.POINTER(Layout), C.POINTER(Grid), C.c_int, C.c_int,
+                                         C.POINTER(BoxRow), C.c_int, dp, dp, dp, C.c_double, dp, C.c_int]
     return _LIB
 
 
@@ -162,3 +164,28 @@ def condense_batch(L, grids, kkt, cdd, damping=0.0):
 def expand_batch(L, grids, cdd, dirs):
     g = grid_array(grids)
     lib().orc_expand_batch(C.byref(L), g, len(grids), cdd.shape[0], _p(cdd), _p(dirs))
+
+
+def _rows(rows):
+    arr = (BoxRow * max(len(rows), 1))()
+    for i, r in enumerate(rows):
+        arr[i] = r
+    return arr
+
+
+def pdipm_condense_batch(L, grids, rows, kkt, con):
+    lib().orc_pdipm_batch(C.byref(L), grid_array(grids), len(grids), kkt.shape[0], _rows(rows), len(rows),
+                          _p(kkt), _p(con), None, 0.0, None, 0)
+
+
+def pdipm_expand_batch(L, grids, rows, con, dirs, tau):
+    steps = np.ones((con.shape[0], 2))
+    lib().orc_pdipm_batch(C.byref(L), grid_array(grids), len(grids), con.shape[0], _rows(rows), len(rows),
+                          None, _p(con), _p(dirs), tau, _p(steps), 1)
+    return steps
+
+
+def pdipm_update_batch(L, grids, rows, con, steps):
+    steps = np.ascontiguousarray(steps, dtype=np.float64)
+    lib().orc_pdipm_batch(C.byref(L), grid_array(grids), len(grids), con.shape[0], _rows(rows), len(rows),
+                          None, _p(con), None, 0.0, _p(steps), 2)

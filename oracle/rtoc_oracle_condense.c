@@ -378,3 +378,99 @@ void orc_expand_batch(const rtoc_layout* L, const rtoc_grid* grid, int nstages, 
       orc_expand_stage(L, &grid[i], cr, dr, dr + L->dir.stride);
     }
 }
+
+/* ------------------------------------------------------------------------- */
+/* PDIPM slack/dual elimination for the joint-limit (box) rows                  */
+/*   include/robotoc/constraints/pdipm.hxx:66-69,121-142,176-186                 */
+/*   src/constraints/joint_*_limit.cpp (condenseSlackAndDual / expandSlackAndDual) */
+/*   stage mask: src/constraints/constraints_data.cpp:20-45                      */
+/* ------------------------------------------------------------------------- */
+static int row_active(const rtoc_box_row* r, const rtoc_grid* g) {
+  if (g->type == RTOC_GRID_IMPACT || g->type == RTOC_GRID_TERMINAL) return 0;
+  return g->time_stage >= r->level;
+}
+
+/* Constraints::condenseSlackAndDual (constraints.cpp:322-357) for box rows */
+void orc_pdipm_condense_stage(const rtoc_layout* L, const rtoc_grid* g, const rtoc_box_row* rows,
+                              int nrows, double* kkt_rec, double* con_rec) {
+  const int nv = L->dims.nv, nu = L->dims.nu, nx = L->nx;
+  const int* ko = L->kkt.off;
+  const int* o = L->con.off;
+  double* Qxx = kkt_rec + ko[RTOC_KKT_QXX];
+  double* Quu = kkt_rec + ko[RTOC_KKT_QUU];
+  double* lx = kkt_rec + ko[RTOC_KKT_LX];
+  double* lu = kkt_rec + ko[RTOC_KKT_LU];
+  for (int r = 0; r < nrows; ++r) {
+    if (!row_active(&rows[r], g)) continue;
+    const double slack = con_rec[o[RTOC_CON_SLACK] + r], dual = con_rec[o[RTOC_CON_DUAL] + r];
+    const double res = con_rec[o[RTOC_CON_RESIDUAL] + r], cmpl = con_rec[o[RTOC_CON_CMPL] + r];
+    const double cond = (dual * res - cmpl) / slack; /* pdipm.hxx:66-69 */
+    con_rec[o[RTOC_CON_COND] + r] = cond;
+    const int idx = rows[r].index;
+    if (rows[r].var == RTOC_VAR_U) {
+      AT(Quu, nu, idx, idx) += dual / slack;
+      lu[idx] += rows[r].sign * cond;
+    } else {
+      const int k = rows[r].var == RTOC_VAR_V ? nv + idx : idx;
+      AT(Qxx, nx, k, k) += dual / slack;
+      lx[k] += rows[r].sign * cond;
+    }
+  }
+}
+
+/* Constraints::expandSlackAndDual + maxSlackStepSize / maxDualStepSize
+ * (constraints.cpp:360-458, pdipm.hxx:121-142,176-186). steps[0] = primal, steps[1] = dual
+ * are min-reduced in place (start them at 1). */
+void orc_pdipm_expand_stage(const rtoc_layout* L, const rtoc_grid* g, const rtoc_box_row* rows,
+                            int nrows, const double* dir_rec, double* con_rec, double tau,
+                            double* steps) {
+  const int nv = L->dims.nv;
+  const int* o = L->con.off;
+  const double* dx = dir_rec + L->dir.off[RTOC_DIR_DX];
+  const double* du = dir_rec + L->dir.off[RTOC_DIR_DU];
+  for (int r = 0; r < nrows; ++r) {
+    if (!row_active(&rows[r], g)) continue;
+    const int idx = rows[r].index;
+    const double dz = rows[r].var == RTOC_VAR_U ? du[idx] : (rows[r].var == RTOC_VAR_V ? dx[nv + idx] : dx[idx]);
+    const double slack = con_rec[o[RTOC_CON_SLACK] + r], dual = con_rec[o[RTOC_CON_DUAL] + r];
+    const double res = con_rec[o[RTOC_CON_RESIDUAL] + r], cmpl = con_rec[o[RTOC_CON_CMPL] + r];
+    const double dslack = -rows[r].sign * dz - res;
+    const double ddual = -(dual * dslack + cmpl) / slack;
+    con_rec[o[RTOC_CON_DSLACK] + r] = dslack;
+    con_rec[o[RTOC_CON_DDUAL] + r] = ddual;
+    const double fs = -tau * (slack / dslack), fd = -tau * (dual / ddual);
+    if (fs > 0 && fs < 1 && fs < steps[0]) steps[0] = fs;
+    if (fd > 0 && fd < 1 && fd < steps[1]) steps[1] = fd;
+  }
+}
+
+/* updateSlack / updateDual (constraints_impl.hxx:167-182) */
+void orc_pdipm_update_stage(const rtoc_layout* L, const rtoc_grid* g, const rtoc_box_row* rows, int nrows,
+                            double* con_rec, double primal_step, double dual_step) {
+  const int* o = L->con.off;
+  for (int r = 0; r < nrows; ++r) {
+    if (!row_active(&rows[r], g)) continue;
+    con_rec[o[RTOC_CON_SLACK] + r] += primal_step * con_rec[o[RTOC_CON_DSLACK] + r];
+    con_rec[o[RTOC_CON_DUAL] + r] += dual_step * con_rec[o[RTOC_CON_DDUAL] + r];
+  }
+}
+
+void orc_pdipm_batch(const rtoc_layout* L, const rtoc_grid* grid, int nstages, int batch,
+                     const rtoc_box_row* rows, int nrows, double* kkt, double* con, double* dir,
+                     double tau, double* steps, int phase) {
+#pragma omp parallel for schedule(static)
+  for (int b = 0; b < batch; ++b) {
+    if (phase == 1) {
+      steps[2 * b] = 1.0;
+      steps[2 * b + 1] = 1.0;
+    }
+    for (int i = 0; i < nstages - 1; ++i) {
+      double* kr = kkt ? kkt + ((size_t)b * nstages + i) * L->kkt.stride : 0;
+      double* cr = con + ((size_t)b * nstages + i) * L->con.stride;
+      double* dr = dir ? dir + ((size_t)b * nstages + i) * L->dir.stride : 0;
+      if (phase == 0) orc_pdipm_condense_stage(L, &grid[i], rows, nrows, kr, cr);
+      if (phase == 1) orc_pdipm_expand_stage(L, &grid[i], rows, nrows, dr, cr, tau, steps + 2 * b);
+      if (phase == 2) orc_pdipm_update_stage(L, &grid[i], rows, nrows, cr, steps[2 * b], steps[2 * b + 1]);
+    }
+  }
+}

@@ -9,7 +9,7 @@ import subprocess
 
 import numpy as np
 
-from .types import (BUF_CDD, BUF_CON, BUF_DIR, BUF_DX0, BUF_KKT, BUF_RIC, BUF_STEP, Dims, Grid,
+from .types import (BoxRow, BUF_CDD, BUF_CON, BUF_DIR, BUF_DX0, BUF_KKT, BUF_RIC, BUF_STEP, Dims, Grid,
                     Layout, OPT_BACKWARD_WAVES, OPT_MAX_DTS0, OPT_WRITEBACK_KKT, grid_array)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -21,7 +21,7 @@ EXPORTS = [
     "rtoc_download", "rtoc_device_ptr", "rtoc_buffer_count", "rtoc_bind", "rtoc_condense",
     "rtoc_riccati_backward", "rtoc_riccati_forward", "rtoc_unconstr_backward",
     "rtoc_unconstr_forward", "rtoc_expand", "rtoc_update", "rtoc_status", "rtoc_clear_status",
-    "rtoc_sync", "rtoc_time_phase", "rtoc_gather_directions", "rtoc_error_string",
+    "rtoc_sync", "rtoc_time_phase", "rtoc_set_constraint_rows", "rtoc_gather_directions", "rtoc_error_string",
 ]
 
 
@@ -81,6 +81,7 @@ def lib():
         L.rtoc_status.argtypes = [vp, C.POINTER(C.c_uint32), C.c_int]
         L.rtoc_time_phase.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float)]
         L.rtoc_gather_directions.argtypes = [vp, vp, dp]
+        L.rtoc_set_constraint_rows.argtypes = [vp, C.POINTER(BoxRow), C.c_int]
         L.rtoc_error_string.argtypes = [C.c_int]
         L.rtoc_error_string.restype = C.c_char_p
         _LIB = L
@@ -131,6 +132,12 @@ class Context:
         g = grid_array(grids)
         _chk(lib().rtoc_set_grid(self._h, g, len(grids)))
         self.nstages = len(grids)
+
+    def set_constraint_rows(self, rows):
+        arr = (BoxRow * max(len(rows), 1))()
+        for i, r in enumerate(rows):
+            arr[i] = r
+        _chk(lib().rtoc_set_constraint_rows(self._h, arr, len(rows)))
 
     def set_stream(self, hip_stream):
         _chk(lib().rtoc_set_stream(self._h, C.c_void_p(hip_stream)))

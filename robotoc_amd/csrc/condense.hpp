@@ -38,12 +38,21 @@ struct CondArgs {
   int nstages, batch;
   double damping;  // RobotModelInfo::contact_inv_damping (robot_model_info.hpp:95)
   long long* prof;  // optional cycle stamps of work item 0 (tuning aid)
+  double* con;               // constraint records or nullptr
+  const rtoc_box_row* rows;  // [nrows] joint-limit rows (device)
+  int nrows;
+  rtoc_record_layout nl;
   rtoc_record_layout kl, cl;
 };
 
 struct ExpArgs {
   double* cdd;
   double* dir;
+  double* con;               // constraint records or nullptr
+  const rtoc_box_row* rows;
+  int nrows;
+  rtoc_record_layout nl;
+  unsigned long long* steps; // [batch][2] max primal / dual step (bit patterns of positive doubles)
   const rtoc_grid* grid;
   int nstages, batch;
   rtoc_record_layout cl, dl;
@@ -253,6 +262,44 @@ __global__ __launch_bounds__(128) void condense_kernel(CondArgs a) {
   unsigned stat = 0;
 
   RTOC_CPROF(0);
+  // ================= PDIPM slack/dual elimination of the joint-limit rows =================
+  // Constraints::condenseSlackAndDual (constraints.cpp:322-357, joint_*_limit.cpp, pdipm.hxx:66-69):
+  // purely additive on diag(Qqq), diag(Qvv), diag(Quu), lq, lv, lu, so it commutes with the
+  // contact-dynamics condensation below; done first, like intermediate_stage.cpp:134-136.
+  if (a.con && !impact) {
+    double* nr = a.con + ((size_t)b * a.nstages + st) * a.nl.stride;
+    const int* no = a.nl.off;
+    // one lane per primal entry (q_k, v_k, u_k): a lower and an upper limit hit the same diagonal
+    // entry, so every entry is accumulated by a single lane in row order (deterministic, no atomics)
+    for (int t = lane; t < 2 * NV + NU; t += NT) {
+      const int var = t < NV ? RTOC_VAR_Q : (t < 2 * NV ? RTOC_VAR_V : RTOC_VAR_U);
+      const int idx = t < NV ? t : (t < 2 * NV ? t - NV : t - 2 * NV);
+      double hess = 0.0, grad = 0.0;
+      bool any = false;
+      for (int r = 0; r < a.nrows; ++r) {
+        const rtoc_box_row row = a.rows[r];
+        if (row.var == var && row.index == idx && g.time_stage >= row.level) {
+          const double slack = nr[no[RTOC_CON_SLACK] + r], dual = nr[no[RTOC_CON_DUAL] + r];
+          const double cond = (dual * nr[no[RTOC_CON_RESIDUAL] + r] - nr[no[RTOC_CON_CMPL] + r]) / slack;
+          nr[no[RTOC_CON_COND] + r] = cond;
+          hess += dual / slack;
+          grad += row.sign * cond;
+          any = true;
+        }
+      }
+      if (any) {
+        if (var == RTOC_VAR_U) {
+          Quu[idx + (size_t)idx * NU] += hess;
+          lu[idx] += grad;
+        } else {
+          const int k = var == RTOC_VAR_V ? NV + idx : idx;
+          Qxx[k + (size_t)k * NX] += hess;
+          lx[k] += grad;
+        }
+      }
+    }
+    __syncthreads();
+  }
   // inactive rows / columns (dimf < max_dimf) of the stored blocks stay zero, like the reference's
   // max-size backing matrices
   for (int e = lane; e < LDV * LDV; e += NT) Lam[e] = 0.0;
@@ -557,6 +604,37 @@ __global__ __launch_bounds__(64) void expand_kernel(ExpArgs a) {
     dr[dof[RTOC_DIR_DNUP] + lane] = acc;
   }
   __syncthreads();
+  // ================= PDIPM expansion + fraction-to-boundary (constraints.cpp:360-458) =================
+  if (a.con && !impact) {
+    double* nr = a.con + ((size_t)b * a.nstages + st) * a.nl.stride;
+    const int* no = a.nl.off;
+    double fp = 1.0, fd = 1.0;
+    for (int r = lane; r < a.nrows; r += 64) {
+      const rtoc_box_row row = a.rows[r];
+      if (g.time_stage >= row.level) {
+        const double dz = row.var == RTOC_VAR_U ? sdu[row.index]
+                                                : (row.var == RTOC_VAR_V ? sdx[NV + row.index] : sdx[row.index]);
+        const double slack = nr[no[RTOC_CON_SLACK] + r], dual = nr[no[RTOC_CON_DUAL] + r];
+        const double dslack = -row.sign * dz - nr[no[RTOC_CON_RESIDUAL] + r];
+        const double ddual = -(dual * dslack + nr[no[RTOC_CON_CMPL] + r]) / slack;
+        nr[no[RTOC_CON_DSLACK] + r] = dslack;
+        nr[no[RTOC_CON_DDUAL] + r] = ddual;
+        const double fs = -a.tau * (slack / dslack), fdd = -a.tau * (dual / ddual);  // pdipm.hxx:121-142
+        if (fs > 0.0 && fs < 1.0) fp = fmin(fp, fs);
+        if (fdd > 0.0 && fdd < 1.0) fd = fmin(fd, fdd);
+      }
+    }
+    // min over the wave, then over the instance: positive doubles order like their bit patterns
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      fp = fmin(fp, __shfl_xor(fp, off, 64));
+      fd = fmin(fd, __shfl_xor(fd, off, 64));
+    }
+    if (lane == 0) {
+      atomicMin(&a.steps[2 * b + 0], (unsigned long long)__double_as_longlong(fp));
+      atomicMin(&a.steps[2 * b + 1], (unsigned long long)__double_as_longlong(fd));
+    }
+  }
   // dbetamu = -MJtJinv * laf (:201, impact :95)
   for (int i = lane; i < nvf; i += 64) {
     double acc = 0.0;
@@ -565,6 +643,39 @@ __global__ __launch_bounds__(64) void expand_kernel(ExpArgs a) {
   }
 }
 
+// updateSlack / updateDual (constraints_impl.hxx:167-182) with the per-instance step sizes
+struct UpdArgs {
+  double* con;
+  const rtoc_box_row* rows;
+  const rtoc_grid* grid;
+  const double* steps;
+  int nrows, nstages, batch;
+  rtoc_record_layout nl;
+};
+
+__global__ __launch_bounds__(64) void pdipm_update_kernel(UpdArgs a) {
+  const int item = blockIdx.x;
+  const int nst1 = a.nstages - 1;
+  const int b = item / nst1, st = item % nst1;
+  if (b >= a.batch) return;
+  const rtoc_grid g = a.grid[st];
+  if (g.type == RTOC_GRID_IMPACT) return;
+  double* nr = a.con + ((size_t)b * a.nstages + st) * a.nl.stride;
+  const int* no = a.nl.off;
+  const double ps = a.steps[2 * b], ds = a.steps[2 * b + 1];
+  for (int r = threadIdx.x; r < a.nrows; r += 64) {
+    if (g.time_stage >= a.rows[r].level) {
+      nr[no[RTOC_CON_SLACK] + r] += ps * nr[no[RTOC_CON_DSLACK] + r];
+      nr[no[RTOC_CON_DUAL] + r] += ds * nr[no[RTOC_CON_DDUAL] + r];
+    }
+  }
+}
+
+__global__ void fill_steps_kernel(double* steps, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) steps[i] = 1.0;
+}
+
 }  // namespace rtoc
 
-static inline int rtoc_con_stride(const rtoc_dims* d) { return 8 * ((d->nc_max * 7 + 7) / 8); }
+static inline int rtoc_con_stride(const rtoc_dims* d) { return RTOC_CON_NFIELDS * ((d->nc_max + 7) & ~7); }

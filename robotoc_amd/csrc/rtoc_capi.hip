@@ -116,6 +116,8 @@ struct rtoc_ctx {
   size_t count[RTOC_NUM_BUFFERS];
   bool owned[RTOC_NUM_BUFFERS];
   rtoc_grid* d_grid;
+  rtoc_box_row* d_rows;
+  int nrows;
   uint32_t* d_status;
   long long* d_prof;
   int writeback;
@@ -179,7 +181,7 @@ int rtoc_create(const rtoc_dims* dims, int max_stages, int batch, int device, rt
   c->count[RTOC_BUF_RIC] = per * c->L.ric.stride;
   c->count[RTOC_BUF_DIR] = per * c->L.dir.stride;
   c->count[RTOC_BUF_CDD] = per * c->L.cdd.stride;
-  c->count[RTOC_BUF_CON] = per * (size_t)rtoc_con_stride(dims);
+  c->count[RTOC_BUF_CON] = per * (size_t)c->L.con.stride;
   c->count[RTOC_BUF_DX0] = (size_t)batch * c->L.nx;
   c->count[RTOC_BUF_STEP] = (size_t)batch * 2;
   for (int i = 0; i < RTOC_NUM_BUFFERS; ++i) {
@@ -213,6 +215,7 @@ int rtoc_destroy(rtoc_ctx* c) {
   for (int i = 0; i < RTOC_NUM_BUFFERS; ++i)
     if (c->owned[i] && c->buf[i]) (void)hipFree(c->buf[i]);
   (void)hipFree(c->d_grid);
+  if (c->d_rows) (void)hipFree(c->d_rows);
   (void)hipFree(c->d_status);
   if (c->d_prof) (void)hipFree(c->d_prof);
   (void)hipEventDestroy(c->ev0);
@@ -395,6 +398,10 @@ static int launch_condense(rtoc_ctx* c) {
   a.batch = c->batch;
   a.damping = c->contact_inv_damping;
   a.prof = c->d_prof;
+  a.con = (c->nrows > 0) ? c->buf[RTOC_BUF_CON] : nullptr;
+  a.rows = c->d_rows;
+  a.nrows = c->nrows;
+  a.nl = c->L.con;
   a.kl = c->L.kkt;
   a.cl = c->L.cdd;
   const int nblocks = c->batch * (c->nstages - 1);
@@ -415,6 +422,13 @@ static int launch_expand(rtoc_ctx* c, double tau) {
   a.cl = c->L.cdd;
   a.dl = c->L.dir;
   a.tau = tau;
+  a.con = (c->nrows > 0) ? c->buf[RTOC_BUF_CON] : nullptr;
+  a.rows = c->d_rows;
+  a.nrows = c->nrows;
+  a.nl = c->L.con;
+  a.steps = (unsigned long long*)c->buf[RTOC_BUF_STEP];
+  hipLaunchKernelGGL(fill_steps_kernel, dim3((2 * c->batch + 255) / 256), dim3(256), 0, c->stream,
+                     c->buf[RTOC_BUF_STEP], 2 * c->batch);
   const int nblocks = c->batch * (c->nstages - 1);
   hipLaunchKernelGGL(c->ks->expd, dim3(nblocks), dim3(c->ks->expd_threads), 0, c->stream, a);
   HIP_TRY(hipGetLastError());
@@ -475,6 +489,39 @@ int rtoc_expand(rtoc_ctx* c, double tau) {
 
 int rtoc_update(rtoc_ctx* c) {
   CHECK_READY(c);
+  if (c->nrows == 0) return RTOC_OK;
+  UpdArgs a;
+  a.con = c->buf[RTOC_BUF_CON];
+  a.rows = c->d_rows;
+  a.grid = c->d_grid;
+  a.steps = c->buf[RTOC_BUF_STEP];
+  a.nrows = c->nrows;
+  a.nstages = c->nstages;
+  a.batch = c->batch;
+  a.nl = c->L.con;
+  hipLaunchKernelGGL(pdipm_update_kernel, dim3(c->batch * (c->nstages - 1)), dim3(64), 0, c->stream, a);
+  HIP_TRY(hipGetLastError());
+  return RTOC_OK;
+}
+
+int rtoc_set_constraint_rows(rtoc_ctx* c, const rtoc_box_row* rows, int nrows) {
+  if (!c || nrows < 0 || nrows > c->dims.nc_max || (nrows > 0 && !rows)) return RTOC_ERR_BAD_ARG;
+  for (int r = 0; r < nrows; ++r) {
+    const rtoc_box_row& w = rows[r];
+    const int lim = (w.var == RTOC_VAR_U) ? c->dims.nu : c->dims.nv;
+    if (w.var < 0 || w.var > 2 || w.index < 0 || w.index >= lim || (w.sign != 1 && w.sign != -1) ||
+        w.level < 0 || w.level > 2)
+      return RTOC_ERR_BAD_ARG;
+  }
+  HIP_TRY(hipSetDevice(c->device));
+  if (nrows > 0) {
+    int rc = ensure_buffer(c, RTOC_BUF_CON);
+    if (rc) return rc;
+    if (!c->d_rows) HIP_TRY(hipMalloc((void**)&c->d_rows, sizeof(rtoc_box_row) * c->dims.nc_max));
+    HIP_TRY(hipMemcpyAsync(c->d_rows, rows, sizeof(rtoc_box_row) * nrows, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+  }
+  c->nrows = nrows;
   return RTOC_OK;
 }
 
@@ -521,7 +568,7 @@ int rtoc_sync(rtoc_ctx* c) {
 
 int rtoc_time_phase(rtoc_ctx* c, int phase, int reps, float* ms) {
   CHECK_READY(c);
-  if (!ms || reps < 1 || phase < 0 || phase > 4) return RTOC_ERR_BAD_ARG;
+  if (!ms || reps < 1 || phase < 0 || phase > 5) return RTOC_ERR_BAD_ARG;
   HIP_TRY(hipEventRecord(c->ev0, c->stream));
   for (int r = 0; r < reps; ++r) {
     int rc = RTOC_OK;
@@ -534,6 +581,7 @@ int rtoc_time_phase(rtoc_ctx* c, int phase, int reps, float* ms) {
         rc = launch_backward(c);
         if (!rc) rc = launch_forward(c);
         break;
+      case 5: rc = rtoc_update(c); break;
     }
     if (rc) return rc;
   }

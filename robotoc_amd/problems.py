@@ -243,3 +243,21 @@ def make_precondense_batch(L, grids, batch, first_instance=0):
         rng = np.random.default_rng(BASE_SEED + 104729 + first_instance + b)
         fill_precondense_instance(L, grids, kkt[b], cdd[b], rng)
     return kkt, cdd
+
+
+def make_constraint_batch(L, grids, batch, barrier=1.0e-3, first_instance=0):
+    """ConstraintComponentData of the joint-limit rows right after linearizeConstraints:
+    slack > 0, dual = barrier / slack (perturbed, as after a few interior-point iterations),
+    residual = g + slack, cmpl = slack * dual - barrier (pdipm.hxx:13-40, barrier as in
+    examples/anymal/trot.cpp:132)."""
+    N = Records(L, "con")
+    con = N.zeros(batch, len(grids))
+    for b in range(batch):
+        rng = np.random.default_rng(BASE_SEED + 15485863 + first_instance + b)
+        slack = np.abs(_rnd(rng, len(grids), L.dims.nc_max)) + 0.05
+        dual = barrier / slack * (1.0 + 0.3 * _rnd(rng, len(grids), L.dims.nc_max))
+        N.f(con[b], "slack")[...] = slack
+        N.f(con[b], "dual")[...] = dual
+        N.f(con[b], "residual")[...] = 0.01 * _rnd(rng, len(grids), L.dims.nc_max)
+        N.f(con[b], "cmpl")[...] = slack * dual - barrier
+    return con

@@ -40,23 +40,45 @@ class Grid(C.Structure):
                 ("num_grids_in_phase", C.c_int), ("time_stage", C.c_int), ("dt", C.c_double)]
 
 
+class BoxRow(C.Structure):
+    _fields_ = [("var", C.c_int), ("index", C.c_int), ("sign", C.c_int), ("level", C.c_int)]
+
+
+VAR_Q, VAR_V, VAR_U = 0, 1, 2
+CON_FIELDS = ["slack", "dual", "residual", "cmpl", "cond", "dslack", "ddual"]
+
+
+def joint_limit_rows(dims):
+    """The six joint-limit components of examples/anymal/trot.cpp:134-146, in the order they are
+    added: position lower/upper (position level), velocity lower/upper (velocity level), torques
+    lower/upper (acceleration level); each acts on the tail nu entries of q / v or on u."""
+    rows = []
+    npv, nu = dims.np, dims.nu
+    for var, level in ((VAR_Q, 2), (VAR_V, 1), (VAR_U, 0)):
+        for sign in (-1, +1):
+            for j in range(nu):
+                rows.append(BoxRow(var, j if var == VAR_U else npv + j, sign, level))
+    return rows
+
+
 class RecordLayout(C.Structure):
     _fields_ = [("off", C.c_int * 24), ("stride", C.c_int), ("nfields", C.c_int)]
 
 
 class Layout(C.Structure):
     _fields_ = [("dims", Dims), ("nx", C.c_int), ("nvf_max", C.c_int), ("kkt", RecordLayout),
-                ("ric", RecordLayout), ("dir", RecordLayout), ("cdd", RecordLayout)]
+                ("ric", RecordLayout), ("dir", RecordLayout), ("cdd", RecordLayout),
+                ("con", RecordLayout)]
 
 
-def anymal_dims(nc_max=0):
+def anymal_dims(nc_max=72):
     """ANYmal: nv=18, 12 actuated joints, 4 point contacts."""
     return Dims(18, 12, 6, 12, 12, nc_max)
 
 
-def icub_dims(nv=35, nc_max=0):
+def icub_dims(nv=35, nc_max=None):
     """iCub: nv=35 per the reference URDF (BASELINE.json names nv=32); 2 surface contacts."""
-    return Dims(nv, nv - 6, 6, 12, 12, nc_max)
+    return Dims(nv, nv - 6, 6, 12, 12, 6 * (nv - 6) if nc_max is None else nc_max)
 
 
 def iiwa14_dims():
@@ -91,10 +113,12 @@ def _shapes(L, which):
                     MJtJinv_dIDCdqv=(nvf, nx), MJtJinv_IDC=(nvf,), Qafqv=(nvf, nx),
                     Qafu_full=(nvf, nv), laf=(nvf,), Qxu_passive=(nx, 8),
                     Quu_passive_topRight=(8, nu), haf=(nvf,))
+    if which == "con":
+        return {f: (d.nc_max,) for f in CON_FIELDS}
     raise KeyError(which)
 
 
-_NAMES = dict(kkt=KKT_FIELDS, ric=RIC_FIELDS, dir=DIR_FIELDS, cdd=CDD_FIELDS)
+_NAMES = dict(kkt=KKT_FIELDS, ric=RIC_FIELDS, dir=DIR_FIELDS, cdd=CDD_FIELDS, con=CON_FIELDS)
 
 
 class Records:

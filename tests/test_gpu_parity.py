@@ -254,21 +254,31 @@ def test_sqp_iteration_hot_path(oracle, cfg):
         ctx.set_grid(grids)
         kkt, cdd = pr.make_precondense_batch(L, grids, batch)
         dx0 = pr.make_dx0(L, batch)
+        from robotoc_amd.types import BUF_CON, BUF_STEP, joint_limit_rows
+        rows = joint_limit_rows(dims)
+        con = pr.make_constraint_batch(L, grids, batch)
+        ctx.set_constraint_rows(rows)
         ctx.upload(BUF_KKT, kkt)
         ctx.upload(BUF_CDD, cdd)
+        ctx.upload(BUF_CON, con)
         ctx.upload(BUF_DX0, dx0)
         ctx.condense()
         kkt_gpu = ctx.download_records(BUF_KKT, "kkt")
         ctx.riccati_backward()
         ctx.riccati_forward()
-        ctx.expand()
+        ctx.expand(0.995)
+        steps_gpu = ctx.download(BUF_STEP, (batch, 2))
+        con_exp_gpu = ctx.download_records(BUF_CON, "con")
+        ctx.update()
+        con_upd_gpu = ctx.download_records(BUF_CON, "con")
         assert (ctx.status() == 0).all()
         cdd_gpu = ctx.download_records(BUF_CDD, "cdd")
         ric_gpu = ctx.download_records(BUF_RIC, "ric")
         d_gpu = ctx.download_records(BUF_DIR, "dir")
         # oracle
         K, Cd, R, D = (Records(L, w) for w in ("kkt", "cdd", "ric", "dir"))
-        kk, cc = kkt.copy(), cdd.copy()
+        kk, cc, nn = kkt.copy(), cdd.copy(), con.copy()
+        oracle.pdipm_condense_batch(L, grids, rows, kk, nn)
         assert (oracle.condense_batch(L, grids, kk, cc) == 0).all()
         kkt_ref = kk.copy()
         ric_ref, d_ref = R.zeros(batch, len(grids)), D.zeros(batch, len(grids))
@@ -289,6 +299,15 @@ def test_sqp_iteration_hot_path(oracle, cfg):
             worst = max(worst, compare_direction(L, grids, d_gpu[b], d_ref[b], 1e-7, "inst %d" % b))
             worst = max(worst, _compare_records(D, d_gpu[b], d_ref[b], ["daf", "dbetamu", "dnu_passive"],
                                                 1e-7, "expansion inst %d" % b))
+        steps_ref = oracle.pdipm_expand_batch(L, grids, rows, nn, d_ref, 0.995)
+        Nn = Records(L, "con")
+        for f in ("cond", "dslack", "ddual"):
+            from helpers import rel_err
+            assert rel_err(Nn.f(con_exp_gpu, f), Nn.f(nn, f)) < 1e-7, f
+        assert np.allclose(steps_gpu, steps_ref, rtol=1e-6), (steps_gpu, steps_ref)
+        oracle.pdipm_update_batch(L, grids, rows, nn, steps_gpu)
+        for f in ("slack", "dual"):
+            assert rel_err(Nn.f(con_upd_gpu, f), Nn.f(nn, f)) < 1e-9, f
         print("sqp hot path %s: worst rel err %.3e" % (cfg, worst))
     finally:
         ctx.close()
