@@ -108,6 +108,24 @@ __device__ __forceinline__ void copy_s2g_flat16(double* __restrict__ dst, const 
 
 __device__ __forceinline__ double shfl_d(double v, int src_lane) { return __shfl(v, src_lane, 64); }
 
+// Broadcast of one lane's double to the whole wave through the scalar unit (v_readlane_b32 x2):
+// a few cycles, versus the ~100-cycle LDS crossbar round trip of ds_bpermute.  `src_lane` must be
+// wave-uniform (it is a compile-time constant at every call site).
+__device__ __forceinline__ double readlane_d(double v, int src_lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+  return __hiloint2double(hi, lo);
+}
+
+// 1/sqrt(d) to fp64 accuracy: hardware estimate + two Newton steps (no separate sqrt and divide)
+__device__ __forceinline__ double rsqrt_d(double d) {
+  double y = __builtin_amdgcn_rsq(d);
+  const double h = 0.5 * d;
+  y = y * __builtin_fma(-h * y, y, 1.5);
+  y = y * __builtin_fma(-h * y, y, 1.5);
+  return y;
+}
+
 __device__ __forceinline__ bool is_bad(double v) { return !(fabs(v) <= 1.79769313486231570815e308); }
 
 }  // namespace rtoc

@@ -195,17 +195,18 @@ __device__ __forceinline__ bool wave_llt(const double* __restrict__ A, double* _
 #pragma unroll
   for (int j = 0; j < NMAX; ++j) {
     if (j < n) {
-      const double d = shfl_d(g[j], j);
+      // j, k are compile-time constants (fully unrolled): pivots and column entries travel through
+      // the scalar unit (readlane), not the LDS crossbar
+      const double d = readlane_d(g[j], j);
       if (!(d > 0.0)) bad = true;
-      const double ljj = sqrt(d);
-      const double inv = 1.0 / ljj;
-      const double lij = (lane == j) ? ljj : g[j] * inv;
+      const double inv = rsqrt_d(d);
+      const double lij = g[j] * inv;  // lane j: d / sqrt(d) = sqrt(d)
       g[j] = lij;
       if (lane == j) linv[j] = inv;
 #pragma unroll
       for (int k = j + 1; k < NMAX; ++k) {
         if (k < n) {
-          const double lkj = shfl_d(lij, k);
+          const double lkj = readlane_d(lij, k);
           g[k] -= lij * lkj;
         }
       }

@@ -28,6 +28,20 @@ __device__ __forceinline__ void wave_lds_sync() {
 // One role's instruction stream.  The two roles run the SAME sequence of block barriers; keeping
 // them in two separate loop nests (instead of if/else inside one loop) keeps the register
 // live ranges of one role (MFMA accumulators / prefetch registers) out of the other role's code.
+// One-way hand-offs matrix wave -> vector wave through an LDS word (monotonic sequence number).
+// The matrix wave never consumes anything the vector wave produces before barrier B4, so the two
+// mid-stage block barriers would only couple the two instruction streams; a flag lets the matrix
+// wave run PB -> G -> PAa -> H -> F back to back while the vector wave trails it.  LDS is a single
+// in-order unit per CU: once the flag store is visible, the wave's earlier LDS stores are too.
+__device__ __forceinline__ void lds_signal(volatile int* flag, int seq, int lane) {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (lane == 0) *flag = seq;
+}
+__device__ __forceinline__ void lds_wait(volatile int* flag, int seq) {
+  while (*flag < seq) __builtin_amdgcn_s_sleep(1);
+  asm volatile("" ::: "memory");
+}
+
 template <int NV, int NU, int NS, bool MW>
 __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a) {
   using C = BwdCfg<NV, NU, NS, 2>;
@@ -44,6 +58,7 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a) {
   double* const sBv = smem + C::OFF_BV;
   double* const sG = smem + C::OFF_G;
   double* const sL = smem + C::OFF_L;
+  volatile int* const sFlag = reinterpret_cast<volatile int*>(smem + C::V_FLAG);
 
   const int tid0 = threadIdx.x;
   const int b = blockIdx.x;
@@ -68,6 +83,7 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a) {
       rr[ro[RTOC_RIC_S] + tid] = v;
     }
     if (tid < 8) smem[C::V_SCN + tid] = 0.0;
+    if (tid == 0) sFlag[0] = 0;
     __syncthreads();
     copy_s2g_mat<NT, NX, NX, LDP>(rr + ro[RTOC_RIC_P], sP, tid);
   }
@@ -272,8 +288,9 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a) {
      } else {
       for (int e = lane; e < NU * LDP; e += 64) sPB[e] = 0.0;
      }
+      lds_signal(sFlag, 2 * (N - st) - 1, lane);  // G ready
     }
-    __syncthreads();  // B2: PB, G, z, lu' ready
+    if constexpr (!MW) lds_wait(sFlag, 2 * (N - st) - 1);
 
     RTOC_PROF(3);
     // ================= interval 2: [matrix] PAa, H     || [vector] LLT(G), w = A^T z =========
@@ -363,7 +380,8 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a) {
         }
       }
     }
-    __syncthreads();  // B3: H, L, w ready; P+ is dead
+    if constexpr (MW) lds_signal(sFlag, 2 * (N - st), lane);  // H ready, PB no longer read
+    if constexpr (!MW) lds_wait(sFlag, 2 * (N - st));
 
     RTOC_PROF(4);
     RTOC_PROF(5);
