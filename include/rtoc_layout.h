@@ -25,6 +25,13 @@
 #else
 #define RTOC_HD
 #endif
+/* the layout functions are usable in C++ constant expressions (kernels bake the field offsets of
+ * their robot into immediates); plain inline functions in C */
+#if defined(__cplusplus) && __cplusplus >= 201402L
+#define RTOC_CONSTEXPR constexpr
+#else
+#define RTOC_CONSTEXPR
+#endif
 
 #ifdef __cplusplus
 extern "C" {
@@ -197,9 +204,9 @@ typedef struct rtoc_layout {
   rtoc_record_layout kkt, ric, dir, cdd, con;
 } rtoc_layout;
 
-static inline RTOC_HD int rtoc_pad8(int n) { return (n + 7) & ~7; }
+static inline RTOC_HD RTOC_CONSTEXPR int rtoc_pad8(int n) { return (n + 7) & ~7; }
 
-static inline RTOC_HD void rtoc_record_finish(rtoc_record_layout* r, const int* sizes, int n) {
+static inline RTOC_HD RTOC_CONSTEXPR void rtoc_record_finish(rtoc_record_layout* r, const int* sizes, int n) {
   int o = 0;
   for (int i = 0; i < n; ++i) {
     r->off[i] = o;
@@ -209,14 +216,14 @@ static inline RTOC_HD void rtoc_record_finish(rtoc_record_layout* r, const int* 
   r->nfields = n;
 }
 
-static inline RTOC_HD void rtoc_compute_layout(const rtoc_dims* d, rtoc_layout* L) {
+static inline RTOC_HD RTOC_CONSTEXPR void rtoc_compute_layout(const rtoc_dims* d, rtoc_layout* L) {
   const int nv = d->nv, nu = d->nu, nx = 2 * d->nv;
   const int nf = d->nf_max, ns = d->ns_max, nvf = d->nv + d->nf_max;
   L->dims = *d;
   L->nx = nx;
   L->nvf_max = nvf;
   {
-    int s[RTOC_KKT_NFIELDS];
+    int s[RTOC_KKT_NFIELDS] = {0};
     s[RTOC_KKT_FXX] = nx * nx;
     s[RTOC_KKT_FVU] = nv * nu;
     s[RTOC_KKT_QXX] = nx * nx;
@@ -236,7 +243,7 @@ static inline RTOC_HD void rtoc_compute_layout(const rtoc_dims* d, rtoc_layout* 
     rtoc_record_finish(&L->kkt, s, RTOC_KKT_NFIELDS);
   }
   {
-    int s[RTOC_RIC_NFIELDS];
+    int s[RTOC_RIC_NFIELDS] = {0};
     s[RTOC_RIC_P] = nx * nx;
     s[RTOC_RIC_S] = nx;
     s[RTOC_RIC_PSI] = nx;
@@ -258,7 +265,7 @@ static inline RTOC_HD void rtoc_compute_layout(const rtoc_dims* d, rtoc_layout* 
     rtoc_record_finish(&L->ric, s, RTOC_RIC_NFIELDS);
   }
   {
-    int s[RTOC_DIR_NFIELDS];
+    int s[RTOC_DIR_NFIELDS] = {0};
     s[RTOC_DIR_DX] = nx;
     s[RTOC_DIR_DU] = nu;
     s[RTOC_DIR_DLMDGMM] = nx;
@@ -270,7 +277,7 @@ static inline RTOC_HD void rtoc_compute_layout(const rtoc_dims* d, rtoc_layout* 
     rtoc_record_finish(&L->dir, s, RTOC_DIR_NFIELDS);
   }
   {
-    int s[RTOC_CDD_NFIELDS];
+    int s[RTOC_CDD_NFIELDS] = {0};
     s[RTOC_CDD_DIDDA] = nv * nv;
     s[RTOC_CDD_DIDCDQV] = nvf * nx;
     s[RTOC_CDD_DCDA] = nf * nv;
@@ -296,7 +303,7 @@ static inline RTOC_HD void rtoc_compute_layout(const rtoc_dims* d, rtoc_layout* 
     rtoc_record_finish(&L->cdd, s, RTOC_CDD_NFIELDS);
   }
   {
-    int s[RTOC_CON_NFIELDS];
+    int s[RTOC_CON_NFIELDS] = {0};
     for (int i = 0; i < RTOC_CON_NFIELDS; ++i) s[i] = d->nc_max;
     rtoc_record_finish(&L->con, s, RTOC_CON_NFIELDS);
   }

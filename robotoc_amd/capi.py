@@ -226,9 +226,9 @@ class Context:
 
 
 def debug_profile(ctx):
-    """Tuning aid: first call attaches the stamp buffer, later calls return [max_stages,16] int64."""
+    """Tuning aid: first call attaches the stamp buffer, later calls return [max_stages,32] int64."""
     L = lib()
     L.rtoc_debug_profile.argtypes = [C.c_void_p, C.c_void_p]
-    out = np.zeros((ctx.max_stages, 16), dtype=np.int64)
+    out = np.zeros((ctx.max_stages, 32), dtype=np.int64)
     _chk(L.rtoc_debug_profile(ctx._h, out.ctypes.data_as(C.c_void_p)))
     return out

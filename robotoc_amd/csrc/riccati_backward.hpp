@@ -40,13 +40,33 @@ namespace rtoc {
 // Phase time-stamps (s_memtime) of block 0, written only when a profiling buffer is attached.
 #define RTOC_PROF(k)                                                             \
   do {                                                                          \
-    if (a.prof && b == 0 && tid0 == 0) a.prof[st * 16 + (k)] = (long long)__builtin_readcyclecounter(); \
+    if (a.prof && b == 0 && tid0 == 0) a.prof[st * 32 + (k)] = (long long)__builtin_readcyclecounter(); \
   } while (0)
 
+// same, stamped by the first lane of the second wave (the vector wave of the role-split kernel)
+#define RTOC_PROFV(k)                                                            \
+  do {                                                                          \
+    if (a.prof && b == 0 && tid0 == 64) a.prof[st * 32 + (k)] = (long long)__builtin_readcyclecounter(); \
+  } while (0)
+
+// Field offsets of the KKT / Riccati records for a robot known at compile time: the same
+// rtoc_compute_layout() the host uses, evaluated as a constant expression, so that every offset is
+// an instruction immediate instead of a scalar register (the runtime table cost ~60 SGPRs and made
+// the compiler spill scalars through v_writelane / v_readlane all over the stage loop).
+template <int NV, int NU, int NS>
+struct StaticLayout {
+  static constexpr rtoc_layout make() {
+    rtoc_dims d = {NV, NU, 0, NS, NS, 0};
+    rtoc_layout L = {};
+    rtoc_compute_layout(&d, &L);
+    return L;
+  }
+};
+
 struct BwdArgs {
-  const double* kkt;       // [batch][nstages][kl.stride]
+  const double* kkt;       // [batch][nstages][kkt stride]
   double* kkt_rw;          // same buffer, writable (writeback of F,H,G,lu)
-  double* ric;             // [batch][nstages][rl.stride]
+  double* ric;             // [batch][nstages][ric stride]
   const rtoc_grid* grid;   // [nstages] (device)
   uint32_t* status;        // [batch]
   long long* prof;         // optional [nstages][16] cycle stamps of block 0 (tuning aid), or nullptr
@@ -54,8 +74,6 @@ struct BwdArgs {
   int batch;
   int writeback;
   double max_dts0;
-  rtoc_record_layout kl;
-  rtoc_record_layout rl;
 };
 
 template <int NV, int NU, int NS, int NW>
@@ -220,6 +238,54 @@ __device__ __forceinline__ bool wave_llt(const double* __restrict__ A, double* _
   return bad;
 }
 
+// In-wave Cholesky as wave_llt, and in the same sweep Y = L^-1 by forward substitution on the
+// identity: lane j (< n) carries column j of Y, and the column-j update of Y needs exactly the
+// broadcast factor entries L[k][j] the Cholesky update already has in scalar registers, so the
+// inverse factor costs one extra FMA per (j,k) pair and no extra cross-lane traffic.
+// Writes L / 1/diag like wave_llt and Y column-major (ld NMAX) to Ydst.  Returns true on failure.
+template <int NMAX, int LD>
+__device__ __forceinline__ bool wave_llt_inv(const double* __restrict__ A, double* __restrict__ Ldst,
+                                             double* __restrict__ linv, double* __restrict__ Ydst,
+                                             int n, int lane) {
+  double g[NMAX], acc[NMAX];
+  const int li = lane < n ? lane : 0;
+#pragma unroll
+  for (int k = 0; k < NMAX; ++k) {
+    g[k] = (k < n) ? A[li + k * LD] : 0.0;
+    acc[k] = (k == lane) ? 1.0 : 0.0;
+  }
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < NMAX; ++j) {
+    if (j < n) {
+      const double d = readlane_d(g[j], j);
+      if (!(d > 0.0)) bad = true;
+      const double inv = rsqrt_d(d);
+      const double lij = g[j] * inv;
+      g[j] = lij;
+      if (lane == j) linv[j] = inv;
+      const double yj = acc[j] * inv;  // Y[j][lane]
+      acc[j] = yj;
+#pragma unroll
+      for (int k = j + 1; k < NMAX; ++k) {
+        if (k < n) {
+          const double lkj = readlane_d(lij, k);
+          g[k] -= lij * lkj;
+          acc[k] -= lkj * yj;
+        }
+      }
+    }
+  }
+  if (lane < NMAX) {
+#pragma unroll
+    for (int k = 0; k < NMAX; ++k) {
+      if (lane < n && k < n) Ldst[lane + k * LD] = (k <= lane) ? g[k] : 0.0;
+      Ydst[k + lane * NMAX] = (lane < n && k < n) ? acc[k] : 0.0;
+    }
+  }
+  return bad;
+}
+
 // x <- (L L^T)^-1 x for one right-hand side held in registers (x[NMAX]); L in LDS.
 template <int NMAX, int LD>
 __device__ __forceinline__ void llt_solve_reg(const double* __restrict__ L,
@@ -250,11 +316,15 @@ __device__ __forceinline__ void llt_solve_reg(const double* __restrict__ L,
   }
 }
 
+// the shared stage fragments (*.inc) synchronise the threads of ONE instance through this macro
+#define RTOC_BLOCK_SYNC() __syncthreads()
 template <int NV, int NU, int NS, int NW>
 __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
   using C = BwdCfg<NV, NU, NS, NW>;
   constexpr int NX = C::NX, NT = C::NT, LDP = C::LDP, TNX = C::TNX, TMA = C::TMA, TNU = C::TNU,
                 CNT = C::CNT;
+  constexpr rtoc_layout SL = StaticLayout<NV, NU, NS>::make();
+  constexpr rtoc_record_layout KL = SL.kkt, RL = SL.ric;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* const sP = smem + C::OFF_P;
   double* const sA = smem + C::OFF_A;
@@ -271,27 +341,25 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
   if (b >= a.batch) return;
   int tid = tid0, lane = tid & 63, wave = tid >> 6, li = lane & 15, q = lane >> 4;
   const int N = a.nstages - 1;
-  const size_t kinst = (size_t)b * a.nstages * a.kl.stride;
-  const size_t rinst = (size_t)b * a.nstages * a.rl.stride;
-  const int* ko = a.kl.off;
-  const int* ro = a.rl.off;
+  const size_t kinst = (size_t)b * a.nstages * KL.stride;
+  const size_t rinst = (size_t)b * a.nstages * RL.stride;
   unsigned stat = 0;
 
   // ---- terminal stage: P_N = Qxx_N, s_N = -lx_N (riccati_recursion.cpp:37-38) ----
   {
-    const double* kr = a.kkt + kinst + (size_t)N * a.kl.stride;
-    double* rr = a.ric + rinst + (size_t)N * a.rl.stride;
-    copy_g2s_mat<NT, NX, NX, LDP>(sP, kr + ko[RTOC_KKT_QXX], tid);
+    const double* kr = a.kkt + kinst + (size_t)N * KL.stride;
+    double* rr = a.ric + rinst + (size_t)N * RL.stride;
+    copy_g2s_mat<NT, NX, NX, LDP>(sP, kr + KL.off[RTOC_KKT_QXX], tid);
     if (tid < NX) {
-      const double v = -kr[ko[RTOC_KKT_LX] + tid];
+      const double v = -kr[KL.off[RTOC_KKT_LX] + tid];
       smem[C::V_SN + tid] = v;
       smem[C::V_PSIN + tid] = 0.0;
       smem[C::V_PHIN + tid] = 0.0;
-      rr[ro[RTOC_RIC_S] + tid] = v;
+      rr[RL.off[RTOC_RIC_S] + tid] = v;
     }
     if (tid < 8) smem[C::V_SCN + tid] = 0.0;
     __syncthreads();
-    copy_s2g_mat<NT, NX, NX, LDP>(rr + ro[RTOC_RIC_P], sP, tid);
+    copy_s2g_mat<NT, NX, NX, LDP>(rr + RL.off[RTOC_RIC_P], sP, tid);
   }
 
   // prefetch registers (next stage's record, loaded one stage ahead)
@@ -302,20 +370,20 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
   PreBuf<PreCnt<NT, N2G>::value> preG;
   double preFx = 0.0, preLx = 0.0, preLu = 0.0;
   auto issue_loads = [&](int stage) {
-    const double* kp = a.kkt + kinst + (size_t)stage * a.kl.stride;
+    const double* kp = a.kkt + kinst + (size_t)stage * KL.stride;
     const bool imp = a.grid[stage].type == RTOC_GRID_IMPACT;
-    pre_load_mat<NT, NX, NX>(preA, kp + ko[RTOC_KKT_FXX], tid);
-    pre_load_mat<NT, NX, NX>(preQ, kp + ko[RTOC_KKT_QXX], tid);
+    pre_load_mat<NT, NX, NX>(preA, kp + KL.off[RTOC_KKT_FXX], tid);
+    pre_load_mat<NT, NX, NX>(preQ, kp + KL.off[RTOC_KKT_QXX], tid);
     if (!imp) {
-      pre_load_mat<NT, NX, NU>(preH, kp + ko[RTOC_KKT_QXU], tid);
-      pre_load<NT, N2B>(preB, kp + ko[RTOC_KKT_FVU], tid);
-      pre_load<NT, N2G>(preG, kp + ko[RTOC_KKT_QUU], tid);
+      pre_load_mat<NT, NX, NU>(preH, kp + KL.off[RTOC_KKT_QXU], tid);
+      pre_load<NT, N2B>(preB, kp + KL.off[RTOC_KKT_FVU], tid);
+      pre_load<NT, N2G>(preG, kp + KL.off[RTOC_KKT_QUU], tid);
     }
     if (tid < NX) {
-      preFx = kp[ko[RTOC_KKT_FX] + tid];
-      preLx = kp[ko[RTOC_KKT_LX] + tid];
+      preFx = kp[KL.off[RTOC_KKT_FX] + tid];
+      preLx = kp[KL.off[RTOC_KKT_LX] + tid];
     }
-    if (!imp && tid < NU) preLu = kp[ko[RTOC_KKT_LU] + tid];
+    if (!imp && tid < NU) preLu = kp[KL.off[RTOC_KKT_LU] + tid];
   };
   if (N >= 1) issue_loads(N - 1);
 
@@ -335,8 +403,8 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
     const bool next_lift = (gn.type == RTOC_GRID_LIFT);
     const int ns = impact ? 0 : g.dims;
     const bool sto = g.sto != 0, sto_next = g.sto_next != 0;
-    const double* kr = a.kkt + kinst + (size_t)st * a.kl.stride;
-    double* rr = a.ric + rinst + (size_t)st * a.rl.stride;
+    const double* kr = a.kkt + kinst + (size_t)st * KL.stride;
+    double* rr = a.ric + rinst + (size_t)st * RL.stride;
 
     RTOC_PROF(0);
 #include "riccati_pt_block.inc"
@@ -352,15 +420,15 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
       smem[C::V_FX + tid] = preFx;
       smem[C::V_LX + tid] = preLx;
       if (sto) {
-        smem[C::V_FFX + tid] = kr[ko[RTOC_KKT_FFX] + tid];
-        smem[C::V_HX + tid] = kr[ko[RTOC_KKT_HX] + tid];
+        smem[C::V_FFX + tid] = kr[KL.off[RTOC_KKT_FFX] + tid];
+        smem[C::V_HX + tid] = kr[KL.off[RTOC_KKT_HX] + tid];
       }
     }
     if (!impact && tid < NU) {
       smem[C::V_LU + tid] = preLu;
-      if (sto) smem[C::V_HU + tid] = kr[ko[RTOC_KKT_HU] + tid];
+      if (sto) smem[C::V_HU + tid] = kr[KL.off[RTOC_KKT_HU] + tid];
     }
-    if (sto && tid < 8) smem[C::V_KSC + tid] = kr[ko[RTOC_KKT_SCAL] + tid];
+    if (sto && tid < 8) smem[C::V_KSC + tid] = kr[KL.off[RTOC_KKT_SCAL] + tid];
     __syncthreads();
 
     RTOC_PROF(2);
@@ -658,10 +726,10 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
 
       RTOC_PROF(7);
       if (a.writeback) {  // mutated Qxu, Quu, lu (reference in-place semantics), before H is reused
-        double* kw = a.kkt_rw + kinst + (size_t)st * a.kl.stride;
-        copy_s2g_mat<NT, NX, NU, LDP>(kw + ko[RTOC_KKT_QXU], sH, tid);
-        copy_s2g_flat<NT>(kw + ko[RTOC_KKT_QUU], sG, NU * NU, tid);
-        if (tid < NU) kw[ko[RTOC_KKT_LU] + tid] = smem[C::V_LU + tid];
+        double* kw = a.kkt_rw + kinst + (size_t)st * KL.stride;
+        copy_s2g_mat<NT, NX, NU, LDP>(kw + KL.off[RTOC_KKT_QXU], sH, tid);
+        copy_s2g_flat<NT>(kw + KL.off[RTOC_KKT_QUU], sG, NU * NU, tid);
+        if (tid < NU) kw[KL.off[RTOC_KKT_LU] + tid] = smem[C::V_LU + tid];
         __syncthreads();
       }
       // ---- GK = G K (+ 2 Phiu^T M on switching-constraint grids, which folds
@@ -752,7 +820,7 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
     RTOC_PROF(9);
     // ---- optional write-back of the mutated KKT blocks (reference in-place semantics) ----
     if (a.writeback) {
-      double* kw = a.kkt_rw + kinst + (size_t)st * a.kl.stride;
+      double* kw = a.kkt_rw + kinst + (size_t)st * KL.stride;
 #pragma unroll
       for (int c = 0; c < CNT; ++c)
 #pragma unroll
@@ -760,7 +828,7 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int i = (wave + c * NW) * 16 + drow(q, r), j = t * 16 + li;
-            if (i < NX && j < NX) kw[ko[RTOC_KKT_QXX] + i + j * NX] = f[c][t][r];
+            if (i < NX && j < NX) kw[KL.off[RTOC_KKT_QXX] + i + j * NX] = f[c][t][r];
           }
     }
 
@@ -807,29 +875,29 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
 
     RTOC_PROF(11);
     // ---- results -> HBM; roll the LDS "next" state ----
-    copy_s2g_mat<NT, NX, NX, LDP>(rr + ro[RTOC_RIC_P], sP, tid);
+    copy_s2g_mat<NT, NX, NX, LDP>(rr + RL.off[RTOC_RIC_P], sP, tid);
     if (!impact) {
       // K row-major nu x nx == Kt column-major nx x nu
-      copy_s2g_mat<NT, NX, NU, LDP>(rr + ro[RTOC_RIC_K], sKt, tid);
+      copy_s2g_mat<NT, NX, NU, LDP>(rr + RL.off[RTOC_RIC_K], sKt, tid);
       if (tid < NU) {
-        rr[ro[RTOC_RIC_KV] + tid] = smem[C::V_KV + tid];
+        rr[RL.off[RTOC_RIC_KV] + tid] = smem[C::V_KV + tid];
         if (sto) {
-          rr[ro[RTOC_RIC_T] + tid] = smem[C::V_TV + tid];
-          rr[ro[RTOC_RIC_W] + tid] = smem[C::V_WV + tid];
-          rr[ro[RTOC_RIC_PSIU] + tid] = smem[C::V_PSIU + tid];
-          rr[ro[RTOC_RIC_PHIU] + tid] = smem[C::V_PHIU + tid];
+          rr[RL.off[RTOC_RIC_T] + tid] = smem[C::V_TV + tid];
+          rr[RL.off[RTOC_RIC_W] + tid] = smem[C::V_WV + tid];
+          rr[RL.off[RTOC_RIC_PSIU] + tid] = smem[C::V_PSIU + tid];
+          rr[RL.off[RTOC_RIC_PHIU] + tid] = smem[C::V_PHIU + tid];
         }
       }
     }
     if (tid < NX) {
       const double sv = smem[C::V_SNEW + tid];
       const double psi = smem[C::V_PSI + tid], phi = smem[C::V_PHI + tid];
-      rr[ro[RTOC_RIC_S] + tid] = sv;
-      rr[ro[RTOC_RIC_PSI] + tid] = psi;
-      rr[ro[RTOC_RIC_PHI] + tid] = phi;
+      rr[RL.off[RTOC_RIC_S] + tid] = sv;
+      rr[RL.off[RTOC_RIC_PSI] + tid] = psi;
+      rr[RL.off[RTOC_RIC_PHI] + tid] = phi;
       if (sto && !impact) {
-        rr[ro[RTOC_RIC_PSIX] + tid] = smem[C::V_PSIX + tid];
-        rr[ro[RTOC_RIC_PHIX] + tid] = smem[C::V_PHIX + tid];
+        rr[RL.off[RTOC_RIC_PSIX] + tid] = smem[C::V_PSIX + tid];
+        rr[RL.off[RTOC_RIC_PHIX] + tid] = smem[C::V_PHIX + tid];
       }
       smem[C::V_SN + tid] = sv;
       smem[C::V_PSIN + tid] = psi;
@@ -837,7 +905,7 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
     }
     if (tid < 5) {
       const double v = smem[C::V_SC + tid];
-      rr[ro[RTOC_RIC_SCAL] + tid] = v;
+      rr[RL.off[RTOC_RIC_SCAL] + tid] = v;
       smem[C::V_SCN + tid] = v;
     }
     RTOC_PROF(12);
@@ -857,14 +925,16 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
         sgm = fabs(sgm) + fabs(eta - iota) / a.max_dts0;
       const double isg = 1.0 / sgm;
       if (tid < NX)
-        pr[ro[RTOC_RIC_DTSDX] + tid] = -isg * (smem[C::V_PSIN + tid] - smem[C::V_PHIN + tid]);
+        pr[RL.off[RTOC_RIC_DTSDX] + tid] = -isg * (smem[C::V_PSIN + tid] - smem[C::V_PHIN + tid]);
       if (tid == 0) {
-        pr[ro[RTOC_RIC_SCAL] + RTOC_RIC_SCAL_DTSDTS] = isg * (xi - chi);
-        pr[ro[RTOC_RIC_SCAL] + RTOC_RIC_SCAL_DTS0] = -isg * (eta - iota);
+        pr[RL.off[RTOC_RIC_SCAL] + RTOC_RIC_SCAL_DTSDTS] = isg * (xi - chi);
+        pr[RL.off[RTOC_RIC_SCAL] + RTOC_RIC_SCAL_DTS0] = -isg * (eta - iota);
       }
     }
   }
   if (stat) atomicOr(&a.status[b], stat);
 }
+
+#undef RTOC_BLOCK_SYNC
 
 }  // namespace rtoc

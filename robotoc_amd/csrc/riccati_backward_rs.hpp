@@ -42,13 +42,36 @@ __device__ __forceinline__ void lds_wait(volatile int* flag, int seq) {
   asm volatile("" ::: "memory");
 }
 
-template <int NV, int NU, int NS, bool MW>
-__device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a) {
+// Barrier between the two waves of one instance.  NI == 1: the workgroup IS the instance, so the
+// hardware barrier does it.  NI > 1 (several instances per workgroup): an LDS arrival counter --
+// both waves run the same barrier sequence, so a monotonic count compared with 2 x (barriers
+// passed) needs no reset.  Only LDS traffic is drained (like __syncthreads()), prefetch loads from
+// HBM stay in flight.
+template <int NI>
+__device__ __forceinline__ void rs_sync(volatile int* cnt, int& epoch, int lane) {
+  if constexpr (NI == 1) {
+    __syncthreads();
+  } else {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    epoch += 2;
+    if (lane == 0)
+      __hip_atomic_fetch_add(const_cast<int*>(cnt), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while (__builtin_amdgcn_readfirstlane(*cnt) < epoch) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+  }
+}
+#define RTOC_BLOCK_SYNC() rs_sync<NI>(sFlag + 1, epoch, lane)
+
+template <int NV, int NU, int NS, bool MW, int NI>
+__device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a, const int slot) {
   using C = BwdCfg<NV, NU, NS, 2>;
   constexpr int NX = C::NX, NT = 128, LDP = C::LDP, TNX = C::TNX, TMA = C::TMA, TNU = C::TNU;
   constexpr int CNT = TNX;  // the matrix wave owns every 16-tile
   static_assert(NX + 1 <= 64, "role-split kernel needs one vector wave per state vector");
-  extern __shared__ __attribute__((aligned(16))) double smem[];
+  constexpr rtoc_layout SL = StaticLayout<NV, NU, NS>::make();
+  constexpr rtoc_record_layout KL = SL.kkt, RL = SL.ric;
+  extern __shared__ __attribute__((aligned(16))) double smem_all[];
+  double* const smem = smem_all + slot * C::LDS_DOUBLES;
   double* const sP = smem + C::OFF_P;
   double* const sA = smem + C::OFF_A;
   double* const sPB = smem + C::OFF_PB;
@@ -60,32 +83,30 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a) {
   double* const sL = smem + C::OFF_L;
   volatile int* const sFlag = reinterpret_cast<volatile int*>(smem + C::V_FLAG);
 
-  const int tid0 = threadIdx.x;
-  const int b = blockIdx.x;
+  const int tid0 = (MW ? 0 : 64) + (threadIdx.x & 63);  // thread index within the instance
+  const int b = blockIdx.x * NI + slot;
+  int epoch = 0;
   int tid = tid0, lane = tid & 63, wave = tid >> 6, li = lane & 15, q = lane >> 4;
   const int N = a.nstages - 1;
-  const size_t kinst = (size_t)b * a.nstages * a.kl.stride;
-  const size_t rinst = (size_t)b * a.nstages * a.rl.stride;
-  const int* ko = a.kl.off;
-  const int* ro = a.rl.off;
+  const size_t kinst = (size_t)b * a.nstages * KL.stride;
+  const size_t rinst = (size_t)b * a.nstages * RL.stride;
   unsigned stat = 0;
 
   // ---- terminal stage: P_N = Qxx_N, s_N = -lx_N (riccati_recursion.cpp:37-38) ----
   {
-    const double* kr = a.kkt + kinst + (size_t)N * a.kl.stride;
-    double* rr = a.ric + rinst + (size_t)N * a.rl.stride;
-    copy_g2s_mat<NT, NX, NX, LDP>(sP, kr + ko[RTOC_KKT_QXX], tid);
+    const double* kr = a.kkt + kinst + (size_t)N * KL.stride;
+    double* rr = a.ric + rinst + (size_t)N * RL.stride;
+    copy_g2s_mat<NT, NX, NX, LDP>(sP, kr + KL.off[RTOC_KKT_QXX], tid);
     if (tid < NX) {
-      const double v = -kr[ko[RTOC_KKT_LX] + tid];
+      const double v = -kr[KL.off[RTOC_KKT_LX] + tid];
       smem[C::V_SN + tid] = v;
       smem[C::V_PSIN + tid] = 0.0;
       smem[C::V_PHIN + tid] = 0.0;
-      rr[ro[RTOC_RIC_S] + tid] = v;
+      rr[RL.off[RTOC_RIC_S] + tid] = v;
     }
     if (tid < 8) smem[C::V_SCN + tid] = 0.0;
-    if (tid == 0) sFlag[0] = 0;
-    __syncthreads();
-    copy_s2g_mat<NT, NX, NX, LDP>(rr + ro[RTOC_RIC_P], sP, tid);
+    RTOC_BLOCK_SYNC();
+    copy_s2g_mat<NT, NX, NX, LDP>(rr + RL.off[RTOC_RIC_P], sP, tid);
   }
 
   // prefetch registers (next stage's record, loaded one stage ahead): held by the vector wave only
@@ -98,19 +119,19 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a) {
   auto issue_loads = [&](int stage) {
     if constexpr (!MW) {
       const int v_ = tid - 64;
-      const double* kp = a.kkt + kinst + (size_t)stage * a.kl.stride;
+      const double* kp = a.kkt + kinst + (size_t)stage * KL.stride;
       const bool imp = a.grid[stage].type == RTOC_GRID_IMPACT;
-      pre_load_mat<64, NX, NX>(preA, kp + ko[RTOC_KKT_FXX], v_);
+      pre_load_mat<64, NX, NX>(preA, kp + KL.off[RTOC_KKT_FXX], v_);
       if (!imp) {
-        pre_load_mat<64, NX, NU>(preH, kp + ko[RTOC_KKT_QXU], v_);
-        pre_load<64, N2B>(preB, kp + ko[RTOC_KKT_FVU], v_);
-        pre_load<64, N2G>(preG, kp + ko[RTOC_KKT_QUU], v_);
+        pre_load_mat<64, NX, NU>(preH, kp + KL.off[RTOC_KKT_QXU], v_);
+        pre_load<64, N2B>(preB, kp + KL.off[RTOC_KKT_FVU], v_);
+        pre_load<64, N2G>(preG, kp + KL.off[RTOC_KKT_QUU], v_);
       }
       if (v_ < NX) {
-        preFx = kp[ko[RTOC_KKT_FX] + v_];
-        preLx = kp[ko[RTOC_KKT_LX] + v_];
+        preFx = kp[KL.off[RTOC_KKT_FX] + v_];
+        preLx = kp[KL.off[RTOC_KKT_LX] + v_];
       }
-      if (!imp && v_ < NU) preLu = kp[ko[RTOC_KKT_LU] + v_];
+      if (!imp && v_ < NU) preLu = kp[KL.off[RTOC_KKT_LU] + v_];
     }
   };
   if (N >= 1) issue_loads(N - 1);
@@ -131,12 +152,14 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a) {
     const bool next_lift = (gn.type == RTOC_GRID_LIFT);
     const int ns = impact ? 0 : g.dims;
     const bool sto = g.sto != 0, sto_next = g.sto_next != 0;
-    const double* kr = a.kkt + kinst + (size_t)st * a.kl.stride;
-    double* rr = a.ric + rinst + (size_t)st * a.rl.stride;
+    const double* kr = a.kkt + kinst + (size_t)st * KL.stride;
+    double* rr = a.ric + rinst + (size_t)st * RL.stride;
 
     RTOC_PROF(0);
+    RTOC_PROFV(16);
 #include "riccati_pt_block.inc"
     RTOC_PROF(1);
+    RTOC_PROFV(17);
     // ---- stage data: prefetched registers -> LDS (vector wave) ----
     if constexpr (!MW) {
       pre_store_mat<64, NX, NX, LDP>(sA, preA, vt);
@@ -149,38 +172,53 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a) {
         smem[C::V_FX + vt] = preFx;
         smem[C::V_LX + vt] = preLx;
         if (sto) {
-          smem[C::V_FFX + vt] = kr[ko[RTOC_KKT_FFX] + vt];
-          smem[C::V_HX + vt] = kr[ko[RTOC_KKT_HX] + vt];
+          smem[C::V_FFX + vt] = kr[KL.off[RTOC_KKT_FFX] + vt];
+          smem[C::V_HX + vt] = kr[KL.off[RTOC_KKT_HX] + vt];
         }
       }
       if (!impact && vt < NU) {
         smem[C::V_LU + vt] = preLu;
-        if (sto) smem[C::V_HU + vt] = kr[ko[RTOC_KKT_HU] + vt];
+        if (sto) smem[C::V_HU + vt] = kr[KL.off[RTOC_KKT_HU] + vt];
       }
     }
-    if (sto && tid < 8) smem[C::V_KSC + tid] = kr[ko[RTOC_KKT_SCAL] + tid];
-    __syncthreads();  // B1
+    if (sto && tid < 8) smem[C::V_KSC + tid] = kr[KL.off[RTOC_KKT_SCAL] + tid];
+    RTOC_BLOCK_SYNC();  // B1
 
     RTOC_PROF(2);
+    RTOC_PROFV(18);
     // Qxx of THIS stage straight from HBM into the accumulator registers of the F product, in the
     // MFMA C layout (row = q+4r, col = lane&15).  Issued two intervals before its first use, so the
     // latency hides behind PB / G / PAa; the accumulators are dead until then, so this prefetch
     // costs no extra registers and no LDS staging.
     d4 f[MW ? CNT : 1][MW ? TNX : 1];
     if constexpr (MW) {
-      const double* qx_ = kr + ko[RTOC_KKT_QXX] + q + li * NX;
+      const double* qx_ = kr + KL.off[RTOC_KKT_QXX] + q + li * NX;   // Qxx[i][j]
+      const double* qxt_ = kr + KL.off[RTOC_KKT_QXX] + li + q * NX;  // Qxx[j][i]
 #pragma unroll
       for (int c = 0; c < CNT; ++c)
 #pragma unroll
         for (int t = 0; t < TNX; ++t)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
+            // Only the 16-tiles on and above the diagonal are computed: A^T P+ A and K^T G K are
+            // symmetric, so tile (t,c) is the mirror of tile (c,t).  Off-diagonal tiles start from
+            // the symmetrised Hessian block (Qxx[c][t] + Qxx[t][c]^T)/2, which makes the mirrored
+            // result equal to the reference's P = (F + F^T)/2 up to the rounding of the products.
+            if (t < c) continue;
             const int i = c * 16 + drow(q, r), j = t * 16 + li;
-            f[c][t][r] = (i < NX && j < NX) ? qx_[c * 16 + 4 * r + t * 16 * NX] : 0.0;
+            const bool ok = (i < NX && j < NX);
+            const double v = ok ? qx_[c * 16 + 4 * r + t * 16 * NX] : 0.0;
+            if (t == c) {
+              f[c][t][r] = v;
+            } else {
+              const double vt_ = ok ? qxt_[t * 16 + (c * 16 + 4 * r) * NX] : 0.0;
+              f[c][t][r] = 0.5 * (v + vt_);
+            }
           }
     }
     // ================= interval 1: [matrix] PB, G      || [vector] z, lu' =================
     if constexpr (!MW) {
+     if (sto) {
       if (vt < NX) {
         double acc = 0.0, accy = 0.0;
 #pragma unroll 9
@@ -193,6 +231,7 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a) {
         if (sto) smem[C::V_Y + vt] = accy + smem[C::V_PSIN + vt];
       }
       wave_lds_sync();
+      RTOC_PROFV(19);
       if (!impact && vt < NU) {
         double acc = 0.0, ap = 0.0, aph = 0.0;
 #pragma unroll
@@ -210,6 +249,18 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a) {
           smem[C::V_PHIU + vt] = sto_next ? aph : 0.0;
         }
       }
+     } else if (!impact && vt < NU) {
+      // lu' = lu - Bv^T z_v with z = s+ - P+ Fx: the P+ Fx part arrives from the matrix wave (it
+      // rides as an extra column of the P+ A product), so only Bv^T s+_v is summed here
+      double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+      for (int k = 0; k + 1 < NV; k += 2) {
+        acc0 += sBv[k + vt * NV] * smem[C::V_SN + NV + k];
+        acc1 += sBv[k + 1 + vt * NV] * smem[C::V_SN + NV + k + 1];
+      }
+      if (NV & 1) acc0 += sBv[NV - 1 + vt * NV] * smem[C::V_SN + 2 * NV - 1];
+      smem[C::V_LU + vt] -= acc0 + acc1;
+     }
     } else {
      if (!impact) {
       // ---- PB = P+[:,v] Bv ----
@@ -290,17 +341,27 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a) {
      }
       lds_signal(sFlag, 2 * (N - st) - 1, lane);  // G ready
     }
+    RTOC_PROFV(20);
     if constexpr (!MW) lds_wait(sFlag, 2 * (N - st) - 1);
+    RTOC_PROFV(21);
 
     RTOC_PROF(3);
     // ================= interval 2: [matrix] PAa, H     || [vector] LLT(G), w = A^T z =========
     d4 pa[MW ? TMA : 1][MW ? CNT : 1];
+    static_assert(NU <= 16, "role-split kernel keeps L^-1 in one MFMA tile");
     if constexpr (MW) {
 #pragma unroll
       for (int tm = 0; tm < TMA; ++tm)
 #pragma unroll
         for (int c = 0; c < CNT; ++c) pa[tm][c] = zero4();
       const double* pb_ = sA + q + li * LDP;
+      // last column tile: columns j < NX are A, column NX is Fx (not in STO stages, which keep the
+      // VALU path for their extra vectors) -- P+ Fx and PB^T Fx come out of the same MFMAs
+      static_assert(TNX * 16 > NX, "no spare column for Fx in the last tile");
+      constexpr int JL = (CNT - 1) * 16;
+      const bool fxcol = (JL + li == NX) && !sto;
+      const double* pbl_ = (JL + li < NX) ? (sA + q + (JL + li) * LDP) : (smem + C::V_FX + q);
+      const bool okl = (JL + li < NX) || fxcol;
       // operands of k-step ks: software-pipelined one step ahead (the scheduler otherwise hoists the
       // LDS loads of all nine steps at once and spills)
       auto load_ops = [&](int ks, double (&av)[TMA], double (&bv)[CNT]) {
@@ -324,8 +385,13 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a) {
         }
 #pragma unroll
         for (int c = 0; c < CNT; ++c) {
-          const double v = pb_[ks * 4 + c * 16 * LDP];
-          bv[c] = (kok && (c * 16 + li < NX)) ? v : 0.0;
+          if (c < CNT - 1) {
+            const double v = pb_[ks * 4 + c * 16 * LDP];
+            bv[c] = (kok && (c * 16 + li < NX)) ? v : 0.0;
+          } else {
+            const double v = pbl_[ks * 4];  // A columns, then Fx as column NX
+            bv[c] = (kok && okl) ? v : 0.0;
+          }
         }
       };
       constexpr int KSA = (NX + 3) / 4;
@@ -354,11 +420,35 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a) {
               }
             }
       }
+      if (fxcol) {
+        // column NX of [P+; PB^T] [A | Fx]: rows < NX are P+ Fx  -> z = s+ - P+ Fx (:brrf z vector),
+        // rows NX.. are PB^T Fx = Bv^T (P+ Fx)_v -> the missing part of lu'
+#pragma unroll
+        for (int tm = 0; tm < TMA; ++tm)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = tm * 16 + drow(q, r);
+            const double v = pa[tm][CNT - 1][r];
+            if (tm * 16 + 4 * r + 3 < NX) {
+              smem[C::V_Z + row] = smem[C::V_SN + row] - v;
+            } else if (tm * 16 + 4 * r >= NX) {
+              if (row < NX + NU) smem[C::V_Y + row - NX] = v;
+            } else {
+              if (row < NX)
+                smem[C::V_Z + row] = smem[C::V_SN + row] - v;
+              else if (row < NX + NU)
+                smem[C::V_Y + row - NX] = v;
+            }
+          }
+      }
     } else {
       if (!impact) {
-        if (wave_llt<NU, NU>(sG, sL, smem + C::V_LINV, NU, lane)) stat |= RTOC_STAT_QUU_NOT_SPD;
+        // LLT(G) (riccati_factorizer.cpp:49) and, in the same sweep, Y = L^-1 (column-major in the
+        // dead Bv buffer): the triangular solves of the policy become two MFMA products below
+        if (wave_llt_inv<NU, NU>(sG, sL, smem + C::V_LINV, sBv, NU, lane)) stat |= RTOC_STAT_QUU_NOT_SPD;
       }
-      if (vt < NX) {
+      RTOC_PROFV(22);
+      if (sto && vt < NX) {
         double acc = 0.0, ap = 0.0, aph = 0.0;
 #pragma unroll 9
         for (int k = 0; k < NX; ++k) {
@@ -381,7 +471,15 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a) {
       }
     }
     if constexpr (MW) lds_signal(sFlag, 2 * (N - st), lane);  // H ready, PB no longer read
+    RTOC_PROFV(23);
     if constexpr (!MW) lds_wait(sFlag, 2 * (N - st));
+    RTOC_PROFV(24);
+    if constexpr (!MW) {
+      if (!sto && !impact) {
+        if (vt < NU) smem[C::V_LU + vt] += smem[C::V_Y + vt];
+        wave_lds_sync();
+      }
+    }
 
     RTOC_PROF(4);
     RTOC_PROF(5);
@@ -408,71 +506,185 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a) {
         for (int c = 0; c < CNT; ++c) {
           const double avv = kok ? pa[gidx / 4][c][gidx % 4] : 0.0;
 #pragma unroll
-          for (int t = 0; t < TNX; ++t) f[c][t] = mfma16(avv, bvf[gidx & 1][t], f[c][t]);
+          for (int t = c; t < TNX; ++t) f[c][t] = mfma16(avv, bvf[gidx & 1][t], f[c][t]);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
     } else {
       if (!impact && ns == 0) {
-        // K = -G^-1 H^T, k = -G^-1 lu (riccati_factorizer.cpp:55-56)
-        if (vt <= NX) {
-          double x[NU];
+        // K^T = -H G^-1, k = -G^-1 lu', T = -G^-1 psi_u, W = -G^-1 phi_u
+        // (riccati_factorizer.cpp:55-56, :125-130) for all right-hand sides at once, as the two
+        // triangular solves written as products with Y = L^-1:
+        //   Z = [H; lu'^T; psi_u^T; phi_u^T] Y^T,   [K^T; k^T; T^T; W^T] = -Z Y.
+        // The three vectors ride as rows NX, NX+1, NX+2 behind the rows of H.  (G^-1 = Y^T Y is
+        // never formed: that would square the conditioning of the factor.)
+        {
+          constexpr int TKT = (NX + 3 + 15) / 16;  // row tiles of the stacked left operand
+          constexpr int KSU = (NU + 3) / 4;
+          d4 kt[TKT];
+          // per-lane source of row m = 16c + li in the tiles that are not pure H rows
+          const double* psrc[TKT];
+          const double* pzsrc[TKT];
+          int ssrc[TKT];
+          bool oksrc[TKT];
 #pragma unroll
-          for (int u = 0; u < NU; ++u) x[u] = (vt < NX) ? sH[vt + u * LDP] : smem[C::V_LU + u];
-          llt_solve_reg<NU, NU>(sL, smem + C::V_LINV, x, NU);
-          bool bad = false;
-#pragma unroll
-          for (int u = 0; u < NU; ++u) {
-            bad = bad || is_bad(x[u]);
-            if (vt < NX)
-              sKt[vt + u * LDP] = -x[u];
-            else
-              smem[C::V_KV + u] = -x[u];
+          for (int c = 0; c < TKT; ++c) {
+            kt[c] = zero4();
+            const int m = c * 16 + li;
+            const int voff = (m == NX ? C::V_LU : (m == NX + 1 ? C::V_PSIU : C::V_PHIU));
+            const int zoff = (m == NX ? C::V_KV : (m == NX + 1 ? C::V_TV : C::V_WV));
+            psrc[c] = (m < NX) ? (sH + m + q * LDP) : (smem + voff + q);
+            pzsrc[c] = (m < NX) ? (sKt + m + q * LDP) : (smem + zoff + q);
+            ssrc[c] = (m < NX) ? 4 * LDP : 4;
+            oksrc[c] = (m < NX) || m == NX || (sto && (m == NX + 1 || (m == NX + 2 && sto_next)));
           }
-          if (bad) stat |= RTOC_STAT_NAN;
-          if (sto && vt == NX) {
-            double t[NU];
+          const double* ph_ = sH + li + q * LDP;
+          const double* pyt_ = sBv + li + q * NU;  // B[k = u][n = i] = Y[i][u]
+          const double* py_ = sBv + q + li * NU;   // B[k = i][n = u] = Y[i][u]
 #pragma unroll
-            for (int u = 0; u < NU; ++u) t[u] = smem[C::V_PSIU + u];
-            llt_solve_reg<NU, NU>(sL, smem + C::V_LINV, t, NU);
+          for (int ks = 0; ks < KSU; ++ks) {
+            const bool kok = (ks * 4 + 3 < NU) || (ks * 4 + q < NU);
+            const double yv = pyt_[ks * 4 * NU];
+            const double bvv = (kok && li < NU) ? yv : 0.0;
 #pragma unroll
-            for (int u = 0; u < NU; ++u) smem[C::V_TV + u] = -t[u];
-            if (sto_next) {
-#pragma unroll
-              for (int u = 0; u < NU; ++u) t[u] = smem[C::V_PHIU + u];
-              llt_solve_reg<NU, NU>(sL, smem + C::V_LINV, t, NU);
-#pragma unroll
-              for (int u = 0; u < NU; ++u) smem[C::V_WV + u] = -t[u];
-            } else {
-#pragma unroll
-              for (int u = 0; u < NU; ++u) smem[C::V_WV + u] = 0.0;
+            for (int c = 0; c < TKT; ++c) {
+              double v;
+              bool ok;
+              if (c * 16 + 15 < NX) {
+                v = ph_[c * 16 + ks * 4 * LDP];
+                ok = kok;
+              } else {
+                v = psrc[c][ks * ssrc[c]];
+                ok = kok && oksrc[c];
+              }
+              kt[c] = mfma16(ok ? v : 0.0, bvv, kt[c]);
             }
           }
+          // destinations of the C-layout rows x = 16c + 4r + q: K^T rows, then k, T, W; register
+          // groups that straddle the end of H get a per-lane pointer (spare lanes hit a dummy slot)
+          double* const pkt_ = sKt + q + li * LDP;
+          auto mixed_dst = [&](int gb) -> double* {
+            const int x = gb + q;
+            double* d = smem + C::V_FLAG + 4;  // dummy
+            d = (x == NX + 2) ? (smem + C::V_WV + li) : d;
+            d = (x == NX + 1) ? (smem + C::V_TV + li) : d;
+            d = (x == NX) ? (smem + C::V_KV + li) : d;
+            d = (x < NX) ? (sKt + x + li * LDP) : d;
+            return d;
+          };
+          auto store_rows = [&](d4 (&t)[TKT]) {
+            if (li < NU) {
+#pragma unroll
+              for (int c = 0; c < TKT; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                  constexpr int dummy = 0;
+                  const int gb = c * 16 + 4 * r;
+                  if (gb + 3 < NX)
+                    pkt_[gb] = t[c][r];
+                  else if (gb < NX + 3)
+                    *mixed_dst(gb) = t[c][r];
+                }
+            }
+          };
+          // Z -> LDS (the K^T buffer and the k / T / W vectors), back as the left operand
+          store_rows(kt);
+#pragma unroll
+          for (int c = 0; c < TKT; ++c) kt[c] = zero4();
+          wave_lds_sync();
+          const double* pz_ = sKt + li + q * LDP;
+#pragma unroll
+          for (int ks = 0; ks < KSU; ++ks) {
+            const bool kok = (ks * 4 + 3 < NU) || (ks * 4 + q < NU);
+            const double yv = py_[ks * 4];
+            const double bvv = (kok && li < NU) ? -yv : 0.0;
+#pragma unroll
+            for (int c = 0; c < TKT; ++c) {
+              double v;
+              bool ok;
+              if (c * 16 + 15 < NX) {
+                v = pz_[c * 16 + ks * 4 * LDP];
+                ok = kok;
+              } else {
+                v = pzsrc[c][ks * ssrc[c]];
+                ok = kok && oksrc[c];
+              }
+              kt[c] = mfma16(ok ? v : 0.0, bvv, kt[c]);
+            }
+          }
+          wave_lds_sync();
+          store_rows(kt);
+          // any NaN / Inf in the policy poisons this sum (0 * Inf = NaN)
+          double chk = 0.0;
+#pragma unroll
+          for (int c = 0; c < TKT; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (c * 16 + 4 * r < NX + 1) chk = __builtin_fma(kt[c][r], 0.0, chk);
+          if (li < NU && is_bad(chk)) stat |= RTOC_STAT_NAN;
         }
-        wave_lds_sync();
+        RTOC_PROFV(25);
+      }
+      // w = A^T z - lx (brrf.cpp:87-88), off the matrix wave's critical path: z came with the H flag
+      double wacc = 0.0;
+      if (!sto && vt < NX) {
+        typedef double dbl2 __attribute__((ext_vector_type(2)));
+        static_assert((LDP & 1) == 0 && (C::OFF_A & 1) == 0 && (C::V_Z & 1) == 0, "128-bit LDS reads");
+        const dbl2* pa2 = reinterpret_cast<const dbl2*>(sA + vt * LDP);
+        const dbl2* pz2 = reinterpret_cast<const dbl2*>(smem + C::V_Z);
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+        for (int k2 = 0; k2 + 1 < NX / 2; k2 += 2) {
+          const dbl2 av0 = pa2[k2], zv0 = pz2[k2], av1 = pa2[k2 + 1], zv1 = pz2[k2 + 1];
+          a0 += av0.x * zv0.x;
+          a1 += av0.y * zv0.y;
+          a2 += av1.x * zv1.x;
+          a3 += av1.y * zv1.y;
+        }
+        if ((NX / 2) & 1) {
+          const dbl2 av0 = pa2[NX / 2 - 1], zv0 = pz2[NX / 2 - 1];
+          a0 += av0.x * zv0.x;
+          a1 += av0.y * zv0.y;
+        }
+        wacc = (a0 + a1) + (a2 + a3) - smem[C::V_LX + vt];
+      }
+      wave_lds_sync();
+      if (!impact && ns == 0) {
         // s -= H k = K^T lu' (K^T = -H G^-1)
         if (vt < NX) {
-          double acc = 0.0;
+          double acc0 = 0.0, acc1 = 0.0;
 #pragma unroll
-          for (int u = 0; u < NU; ++u) acc += sKt[vt + u * LDP] * smem[C::V_LU + u];
-          smem[C::V_SNEW + vt] -= acc;
+          for (int u = 0; u + 1 < NU; u += 2) {
+            acc0 += sKt[vt + u * LDP] * smem[C::V_LU + u];
+            acc1 += sKt[vt + (u + 1) * LDP] * smem[C::V_LU + u + 1];
+          }
+          if (NU & 1) acc0 += sKt[vt + (NU - 1) * LDP] * smem[C::V_LU + NU - 1];
+          if (sto)
+            smem[C::V_SNEW + vt] -= acc0 + acc1;
+          else
+            smem[C::V_SNEW + vt] = wacc - (acc0 + acc1);
         }
+      } else if (!sto && vt < NX) {
+        smem[C::V_SNEW + vt] = wacc;
       }
     }
-    __syncthreads();  // B4: K, k ready; F product done; A and H(after SC) free
+    RTOC_PROF(13);
+    RTOC_PROFV(14);
+    RTOC_BLOCK_SYNC();  // B4: K, k ready; F product done; A and H(after SC) free
 
     RTOC_PROF(6);
+    RTOC_PROFV(26);
     if (NS > 0 && ns > 0) {
 #include "riccati_sc_block.inc"
-      __syncthreads();
+      RTOC_BLOCK_SYNC();
     }
     RTOC_PROF(7);
     if (a.writeback && !impact) {
-      double* kw = a.kkt_rw + kinst + (size_t)st * a.kl.stride;
-      copy_s2g_mat<NT, NX, NU, LDP>(kw + ko[RTOC_KKT_QXU], sH, tid);
-      copy_s2g_flat<NT>(kw + ko[RTOC_KKT_QUU], sG, NU * NU, tid);
-      if (tid < NU) kw[ko[RTOC_KKT_LU] + tid] = smem[C::V_LU + tid];
-      __syncthreads();
+      double* kw = a.kkt_rw + kinst + (size_t)st * KL.stride;
+      copy_s2g_mat<NT, NX, NU, LDP>(kw + KL.off[RTOC_KKT_QXU], sH, tid);
+      copy_s2g_flat<NT>(kw + KL.off[RTOC_KKT_QUU], sG, NU * NU, tid);
+      if (tid < NU) kw[KL.off[RTOC_KKT_LU] + tid] = smem[C::V_LU + tid];
+      RTOC_BLOCK_SYNC();
     }
 
     // ================= interval 4: [matrix] GK, F -= K^T GK, P   || [vector] policy -> HBM ====
@@ -513,14 +725,7 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a) {
               for (int r = 0; r < 4; ++r) {
                 const int u = t * 16 + drow(q, r), j = c * 16 + li;
                 if (u < NU && j < NX) {
-                  double v = acc[t][c][r];
-                  if (NS > 0 && ns > 0) {
-                    double dtm = 0.0;
-                    for (int l = 0; l < ns; ++l)
-                      dtm += smem[C::S_PHIU + l + u * C::NSP] * smem[C::S_M + l + j * C::NSP];
-                    v += 2.0 * dtm;
-                  }
-                  sGK[u + j * NU] = v;
+                  sGK[u + j * NU] = acc[t][c][r];
                 }
               }
         }
@@ -546,96 +751,139 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a) {
 #pragma unroll
             for (int c = 0; c < CNT; ++c)
 #pragma unroll
-              for (int t = 0; t < TNX; ++t) f[c][t] = mfma16(av[c], bv[t], f[c][t]);
+              for (int t = c; t < TNX; ++t) f[c][t] = mfma16(av[c], bv[t], f[c][t]);
+          }
+        }
+        if (NS > 0 && ns > 0) {
+          // switching constraint: the reference subtracts 2 K^T Phiu^T M from Qxx and lets
+          // P = (F + F^T)/2 symmetrise it; with only the upper tiles held the symmetric form
+          // K^T D + D^T K, D = Phiu^T M, is accumulated instead (rare stage, two more passes).
+          wave_lds_sync();
+#pragma unroll 1
+          for (int e = lane; e < NU * NX; e += 64) {
+            const int u = e % NU, j = e / NU;
+            double dtm = 0.0;
+            for (int l = 0; l < ns; ++l)
+              dtm += smem[C::S_PHIU + l + u * C::NSP] * smem[C::S_M + l + j * C::NSP];
+            sGK[u + j * NU] = dtm;
+          }
+          wave_lds_sync();
+          const double* pk_ = sKt + li + q * LDP;
+          const double* pd_ = sGK + q + li * NU;
+#pragma unroll 1
+          for (int ks = 0; ks < (NU + 3) / 4; ++ks) {
+            const bool kok = (ks * 4 + 3 < NU) || (ks * 4 + q < NU);
+            double ak[TNX], ad[TNX];
+#pragma unroll
+            for (int c = 0; c < TNX; ++c) {
+              const bool ok = kok && (c * 16 + li < NX);
+              const double vk = pk_[c * 16 + ks * 4 * LDP];
+              const double vd = pd_[ks * 4 + c * 16 * NU];
+              ak[c] = ok ? -vk : 0.0;
+              ad[c] = ok ? vd : 0.0;
+            }
+#pragma unroll
+            for (int c = 0; c < CNT; ++c)
+#pragma unroll
+              for (int t = c; t < TNX; ++t) {
+                f[c][t] = mfma16(ak[c], ad[t], f[c][t]);   // -(K^T D)[i][j]
+                f[c][t] = mfma16(ad[c], ak[t], f[c][t]);   // -(D^T K)[i][j]
+              }
           }
         }
       }
       RTOC_PROF(9);
       if (a.writeback) {
-        double* kw = a.kkt_rw + kinst + (size_t)st * a.kl.stride;
+        double* kw = a.kkt_rw + kinst + (size_t)st * KL.stride;
 #pragma unroll
         for (int c = 0; c < CNT; ++c)
 #pragma unroll
-          for (int t = 0; t < TNX; ++t)
+          for (int t = c; t < TNX; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int i = c * 16 + drow(q, r), j = t * 16 + li;
-              if (i < NX && j < NX) kw[ko[RTOC_KKT_QXX] + i + j * NX] = f[c][t][r];
+              if (i < NX && j < NX) {
+                kw[KL.off[RTOC_KKT_QXX] + i + j * NX] = f[c][t][r];
+                if (t > c) kw[KL.off[RTOC_KKT_QXX] + j + i * NX] = f[c][t][r];
+              }
             }
       }
-      // ---- P = (F + F^T)/2 in the MFMA register layout (brrf.cpp:85) ----
+      // ---- P = (F + F^T)/2 (brrf.cpp:85): off-diagonal tiles are mirrored, the diagonal tiles are
+      //      symmetrised through LDS in the MFMA register layout ----
       {
-        double* pw_ = sP + q + li * LDP;
-        const double* pr_ = sP + li + q * LDP;
+        double* pw_ = sP + q + li * LDP;  // (i,j) at i + j*LDP
+        double* pm_ = sP + li + q * LDP;  // (j,i)
 #pragma unroll
         for (int c = 0; c < CNT; ++c)
 #pragma unroll
-          for (int t = 0; t < TNX; ++t)
+          for (int t = c; t < TNX; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int i = c * 16 + drow(q, r), j = t * 16 + li;
-              if (i < NX && j < NX) pw_[c * 16 + 4 * r + t * 16 * LDP] = f[c][t][r];
+              if (i < NX && j < NX) {
+                pw_[c * 16 + 4 * r + t * 16 * LDP] = f[c][t][r];
+                if (t > c) pm_[t * 16 + (c * 16 + 4 * r) * LDP] = f[c][t][r];
+              }
             }
         wave_lds_sync();
 #pragma unroll
         for (int c = 0; c < CNT; ++c)
 #pragma unroll
-          for (int t = 0; t < TNX; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const double v = pr_[t * 16 + (c * 16 + 4 * r) * LDP];
-              f[c][t][r] = 0.5 * (f[c][t][r] + v);
-            }
+          for (int r = 0; r < 4; ++r) {
+            const double v = pm_[c * 16 + (c * 16 + 4 * r) * LDP];
+            f[c][c][r] = 0.5 * (f[c][c][r] + v);
+          }
         wave_lds_sync();
 #pragma unroll
         for (int c = 0; c < CNT; ++c)
 #pragma unroll
-          for (int t = 0; t < TNX; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int i = c * 16 + drow(q, r), j = t * 16 + li;
-              if (i < NX && j < NX) pw_[c * 16 + 4 * r + t * 16 * LDP] = f[c][t][r];
-            }
+          for (int r = 0; r < 4; ++r) {
+            const int i = c * 16 + drow(q, r), j = c * 16 + li;
+            if (i < NX && j < NX) pw_[c * 16 + 4 * r + c * 16 * LDP] = f[c][c][r];
+          }
       }
     } else {
       // next stage's record: HBM -> registers of the vector wave.  Issued here, after the register-
       // hungry solve / constraint code, so that the prefetched values are not spilled.
       if (st > 0) issue_loads(st - 1);
+      RTOC_PROFV(27);
       // vector wave: LQR policy of this stage -> HBM (K row-major == Kt column-major)
       if (!impact) {
-        copy_s2g_mat<64, NX, NU, LDP>(rr + ro[RTOC_RIC_K], sKt, vt);
+        copy_s2g_mat<64, NX, NU, LDP>(rr + RL.off[RTOC_RIC_K], sKt, vt);
         if (vt < NU) {
-          rr[ro[RTOC_RIC_KV] + vt] = smem[C::V_KV + vt];
+          rr[RL.off[RTOC_RIC_KV] + vt] = smem[C::V_KV + vt];
           if (sto) {
-            rr[ro[RTOC_RIC_T] + vt] = smem[C::V_TV + vt];
-            rr[ro[RTOC_RIC_W] + vt] = smem[C::V_WV + vt];
-            rr[ro[RTOC_RIC_PSIU] + vt] = smem[C::V_PSIU + vt];
-            rr[ro[RTOC_RIC_PHIU] + vt] = smem[C::V_PHIU + vt];
+            rr[RL.off[RTOC_RIC_T] + vt] = smem[C::V_TV + vt];
+            rr[RL.off[RTOC_RIC_W] + vt] = smem[C::V_WV + vt];
+            rr[RL.off[RTOC_RIC_PSIU] + vt] = smem[C::V_PSIU + vt];
+            rr[RL.off[RTOC_RIC_PHIU] + vt] = smem[C::V_PHIU + vt];
           }
         }
       }
     }
-    __syncthreads();  // B5: P complete in sP
+    RTOC_PROFV(15);
+    RTOC_BLOCK_SYNC();  // B5: P complete in sP
 
     RTOC_PROF(10);
+    RTOC_PROFV(28);
     if (sto) {
 #include "riccati_sto_block.inc"
-      __syncthreads();
+      RTOC_BLOCK_SYNC();
     }
 
     RTOC_PROF(11);
     // ---- results -> HBM; roll the LDS "next" state ----
-    copy_s2g_mat<NT, NX, NX, LDP>(rr + ro[RTOC_RIC_P], sP, tid);
+    copy_s2g_mat<NT, NX, NX, LDP>(rr + RL.off[RTOC_RIC_P], sP, tid);
     if (tid < NX) {
       const double sv = smem[C::V_SNEW + tid];
       const double psi = sto ? smem[C::V_PSI + tid] : 0.0;
       const double phi = sto ? smem[C::V_PHI + tid] : 0.0;
-      rr[ro[RTOC_RIC_S] + tid] = sv;
-      rr[ro[RTOC_RIC_PSI] + tid] = psi;
-      rr[ro[RTOC_RIC_PHI] + tid] = phi;
+      rr[RL.off[RTOC_RIC_S] + tid] = sv;
+      rr[RL.off[RTOC_RIC_PSI] + tid] = psi;
+      rr[RL.off[RTOC_RIC_PHI] + tid] = phi;
       if (sto && !impact) {
-        rr[ro[RTOC_RIC_PSIX] + tid] = smem[C::V_PSIX + tid];
-        rr[ro[RTOC_RIC_PHIX] + tid] = smem[C::V_PHIX + tid];
+        rr[RL.off[RTOC_RIC_PSIX] + tid] = smem[C::V_PSIX + tid];
+        rr[RL.off[RTOC_RIC_PHIX] + tid] = smem[C::V_PHIX + tid];
       }
       smem[C::V_SN + tid] = sv;
       smem[C::V_PSIN + tid] = psi;
@@ -643,14 +891,15 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a) {
     }
     if (tid < 5) {
       const double v = sto ? smem[C::V_SC + tid] : 0.0;
-      rr[ro[RTOC_RIC_SCAL] + tid] = v;
+      rr[RL.off[RTOC_RIC_SCAL] + tid] = v;
       smem[C::V_SCN + tid] = v;
     }
     RTOC_PROF(12);
+    RTOC_PROFV(29);
   }
 
   // ---- grid[0].sto: trailing phase transition writes sto_policy_[0] (riccati_recursion.cpp:75-79) ----
-  __syncthreads();
+  RTOC_BLOCK_SYNC();
   {
     const rtoc_grid g0 = a.grid[0];
     if (g0.sto && g0.sto_next) {
@@ -663,10 +912,10 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a) {
         sgm = fabs(sgm) + fabs(eta - iota) / a.max_dts0;
       const double isg = 1.0 / sgm;
       if (tid < NX)
-        pr[ro[RTOC_RIC_DTSDX] + tid] = -isg * (smem[C::V_PSIN + tid] - smem[C::V_PHIN + tid]);
+        pr[RL.off[RTOC_RIC_DTSDX] + tid] = -isg * (smem[C::V_PSIN + tid] - smem[C::V_PHIN + tid]);
       if (tid == 0) {
-        pr[ro[RTOC_RIC_SCAL] + RTOC_RIC_SCAL_DTSDTS] = isg * (xi - chi);
-        pr[ro[RTOC_RIC_SCAL] + RTOC_RIC_SCAL_DTS0] = -isg * (eta - iota);
+        pr[RL.off[RTOC_RIC_SCAL] + RTOC_RIC_SCAL_DTSDTS] = isg * (xi - chi);
+        pr[RL.off[RTOC_RIC_SCAL] + RTOC_RIC_SCAL_DTS0] = -isg * (eta - iota);
       }
     }
   }
@@ -676,10 +925,53 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a) {
 template <int NV, int NU, int NS>
 __global__ __launch_bounds__(128, 2) void riccati_backward_rs_kernel(BwdArgs a) {
   if ((int)blockIdx.x >= a.batch) return;
+  extern __shared__ __attribute__((aligned(16))) double smem_all[];
+  using C = BwdCfg<NV, NU, NS, 2>;
+  if (threadIdx.x < 2) reinterpret_cast<int*>(smem_all + C::V_FLAG)[threadIdx.x] = 0;
+  __syncthreads();
   if (threadIdx.x < 64)
-    riccati_backward_rs_body<NV, NU, NS, true>(a);
+    riccati_backward_rs_body<NV, NU, NS, true, 1>(a, 0);
   else
-    riccati_backward_rs_body<NV, NU, NS, false>(a);
+    riccati_backward_rs_body<NV, NU, NS, false, 1>(a, 0);
 }
+
+// Four instances per 512-thread workgroup, one per SIMD: the matrix wave and the vector wave of
+// an instance are the two waves that the dispatcher put on the SAME SIMD.  f64 MFMA on gfx950
+// issues through the SIMD's VALU port for its whole 64 cycles (tools/probes/pipe_share_probe.hip:
+// a VALU chain of another wave on that SIMD makes no progress while MFMAs stream), so a vector
+// wave sharing a SIMD with a FOREIGN matrix wave only runs in that wave's operand-load gaps and
+// its dependent chains (Cholesky, solves) stretch 3-4x; sharing with its OWN matrix wave, it runs
+// exactly when that wave is waiting for it.  Pairing is read from HW_ID; if the dispatcher ever
+// places the waves differently the static pairing (wave, wave+4) is used -- still correct.
+template <int NV, int NU, int NS>
+__global__ __launch_bounds__(512) void riccati_backward_rs4_kernel(BwdArgs a) {
+  using C = BwdCfg<NV, NU, NS, 2>;
+  extern __shared__ __attribute__((aligned(16))) double smem_all[];
+  int* const hdr = reinterpret_cast<int*>(smem_all + 4 * C::LDS_DOUBLES);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (threadIdx.x < 4) {
+    hdr[threadIdx.x] = 0;
+    int* f = reinterpret_cast<int*>(smem_all + threadIdx.x * C::LDS_DOUBLES + C::V_FLAG);
+    f[0] = 0;
+    f[1] = 0;
+  }
+  __syncthreads();
+  unsigned hw;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+  const int simd = (hw >> 4) & 3;
+  int order = 0;
+  if (lane == 0) order = atomicAdd(&hdr[simd], 1);
+  order = __builtin_amdgcn_readfirstlane(order);
+  __syncthreads();
+  const bool paired = hdr[0] == 2 && hdr[1] == 2 && hdr[2] == 2 && hdr[3] == 2;
+  const int slot = __builtin_amdgcn_readfirstlane(paired ? simd : (wave & 3));
+  const int role = __builtin_amdgcn_readfirstlane(paired ? order : (wave >> 2));
+  if ((int)blockIdx.x * 4 + slot >= a.batch) return;
+  if (role == 0)
+    riccati_backward_rs_body<NV, NU, NS, true, 4>(a, slot);
+  else
+    riccati_backward_rs_body<NV, NU, NS, false, 4>(a, slot);
+}
+#undef RTOC_BLOCK_SYNC
 
 }  // namespace rtoc

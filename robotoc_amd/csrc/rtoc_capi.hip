@@ -42,9 +42,11 @@ typedef void (*expd_fn)(ExpArgs);
 struct KernelSet {
   int nv, nu, ns;
   int nvariants;
-  bwd_fn bwd[3];
-  int bwd_waves[3];
-  int bwd_lds[3];
+  bwd_fn bwd[4];
+  int bwd_waves[4];   // waves per workgroup
+  int bwd_lds[4];
+  int bwd_inst[4];    // OCP instances per workgroup
+  rtoc_record_layout kl, rl;  // record layouts the backward kernels were compiled for
   fwd_fn fwd;
   int fwd_threads;
   fill_fn fill;
@@ -62,6 +64,9 @@ static KernelSet make_set() {
   k.nu = NU;
   k.ns = NS;
   k.nvariants = 2;
+  for (int v = 0; v < 4; ++v) k.bwd_inst[v] = 1;
+  k.kl = StaticLayout<NV, NU, NS>::make().kkt;
+  k.rl = StaticLayout<NV, NU, NS>::make().ric;
   k.bwd[0] = riccati_backward_kernel<NV, NU, NS, NW0>;
   k.bwd_waves[0] = NW0;
   k.bwd_lds[0] = BwdCfg<NV, NU, NS, NW0>::LDS_BYTES;
@@ -73,6 +78,14 @@ static KernelSet make_set() {
     k.bwd_waves[2] = 2;
     k.bwd_lds[2] = BwdCfg<NV, NU, NS, 2>::LDS_BYTES;
     k.nvariants = 3;
+    // four instances per workgroup, both waves of an instance on one SIMD
+    if (4 * BwdCfg<NV, NU, NS, 2>::LDS_BYTES + 64 <= 160 * 1024) {
+      k.bwd[3] = riccati_backward_rs4_kernel<NV, NU, NS>;
+      k.bwd_waves[3] = 8;
+      k.bwd_lds[3] = 4 * BwdCfg<NV, NU, NS, 2>::LDS_BYTES + 64;
+      k.bwd_inst[3] = 4;
+      k.nvariants = 4;
+    }
   }
   constexpr int NWF = (2 * NV + NU + 63) / 64;
   k.fwd = riccati_forward_kernel<NV, NU, NS, NWF>;
@@ -165,13 +178,20 @@ int rtoc_create(const rtoc_dims* dims, int max_stages, int batch, int device, rt
   memset(c, 0, sizeof(*c));
   c->dims = *dims;
   rtoc_compute_layout(dims, &c->L);
+  // the backward kernels carry their record offsets as immediates: they must be the ones the host
+  // (and the caller, through rtoc_get_layout) uses
+  if (memcmp(&ks->kl, &c->L.kkt, sizeof(rtoc_record_layout)) != 0 ||
+      memcmp(&ks->rl, &c->L.ric, sizeof(rtoc_record_layout)) != 0) {
+    delete c;
+    return RTOC_ERR_BAD_ARG;
+  }
   c->ks = ks;
   c->max_stages = max_stages;
   c->nstages = 0;
   c->batch = batch;
   c->device = device;
   c->max_dts0 = 0.1;  // RiccatiRecursion(ocp, max_dts0 = 0.1), riccati_recursion.hpp:35
-  c->bwd_variant = (ks->nvariants == 3) ? 2 : 0;  // role-split kernel where it exists
+  c->bwd_variant = (ks->nvariants >= 3) ? ks->nvariants - 1 : 0;  // role-split kernel where it exists
   HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
   c->stream = c->own_stream;
   HIP_TRY(hipEventCreate(&c->ev0));
@@ -277,7 +297,7 @@ int rtoc_set_option(rtoc_ctx* c, int option, int64_t value) {
     }
     case RTOC_OPT_BACKWARD_WAVES: {
       if (value == 0) {
-        c->bwd_variant = (c->ks->nvariants == 3) ? 2 : 0;
+        c->bwd_variant = (c->ks->nvariants >= 3) ? c->ks->nvariants - 1 : 0;
         return RTOC_OK;
       }
       for (int v = 0; v < c->ks->nvariants; ++v)
@@ -360,11 +380,10 @@ static int launch_backward(rtoc_ctx* c) {
   a.batch = c->batch;
   a.writeback = c->writeback;
   a.max_dts0 = c->max_dts0;
-  a.kl = c->L.kkt;
-  a.rl = c->L.ric;
   const int v = c->bwd_variant;
-  hipLaunchKernelGGL(c->ks->bwd[v], dim3(c->batch), dim3(64 * c->ks->bwd_waves[v]), c->ks->bwd_lds[v],
-                     c->stream, a);
+  const int ni = c->ks->bwd_inst[v];
+  hipLaunchKernelGGL(c->ks->bwd[v], dim3((c->batch + ni - 1) / ni), dim3(64 * c->ks->bwd_waves[v]),
+                     c->ks->bwd_lds[v], c->stream, a);
   HIP_TRY(hipGetLastError());
   return RTOC_OK;
 }
@@ -546,7 +565,7 @@ int rtoc_clear_status(rtoc_ctx* c) {
 int rtoc_debug_profile(rtoc_ctx* c, long long* host_out) {
   if (!c) return RTOC_ERR_BAD_ARG;
   HIP_TRY(hipSetDevice(c->device));
-  const size_t n = (size_t)c->max_stages * 16;
+  const size_t n = (size_t)c->max_stages * 32;
   if (!c->d_prof) {
     HIP_TRY(hipMalloc((void**)&c->d_prof, n * sizeof(long long)));
     HIP_TRY(hipMemsetAsync(c->d_prof, 0, n * sizeof(long long), c->stream));

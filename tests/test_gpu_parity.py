@@ -56,7 +56,7 @@ def _run_case(oracle, dims, grids, batch, mode, waves=0, max_dts0=0.1, tol=TOL):
         ctx.close()
 
 
-@pytest.mark.parametrize("waves", [1, 2, 3])
+@pytest.mark.parametrize("waves", [1, 2, 3, 8])
 @pytest.mark.parametrize("mode", ["factory", "dynamics"])
 def test_anymal_trot_sweep(oracle, waves, mode):
     """configs[1]: ANYmal trot, N=40, 2 lifts + 2 impacts, switching constraints (ns=6)."""
@@ -65,7 +65,7 @@ def test_anymal_trot_sweep(oracle, waves, mode):
               tol=TOL if mode == "factory" else 1e-7)
 
 
-@pytest.mark.parametrize("waves", [1, 2, 3])
+@pytest.mark.parametrize("waves", [1, 2, 3, 8])
 def test_anymal_jump_sto_sweep(oracle, waves):
     """configs[2]: ANYmal jump with switching-time optimisation (STO policy, phase transitions, ns=12).
     "dynamics"-scaled data keep the 44-grid STO system well conditioned (a 1e-15 relative input
