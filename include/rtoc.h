@@ -19,6 +19,9 @@
  *                              (src/riccati/riccati_recursion.cpp:32-80)
  *   rtoc_riccati_forward       RiccatiRecursion::forwardRiccatiRecursion
  *                              (src/riccati/riccati_recursion.cpp:83-131)
+ *   rtoc_riccati_sweep         the two calls above back to back, as OCPSolver::updateSolution
+ *                              issues them (src/solver/ocp_solver.cpp:120-126), pipelined over
+ *                              instance chunks on two HIP streams
  *   rtoc_unconstr_backward /   UnconstrRiccatiRecursion::{backward,forward}RiccatiRecursion
  *   rtoc_unconstr_forward      (src/riccati/unconstr_riccati_recursion.cpp:26-48)
  *   rtoc_expand                DirectMultipleShooting::computeStepSizes + the
@@ -88,7 +91,8 @@ enum rtoc_option {
   RTOC_OPT_WRITEBACK_KKT = 0, /* 1: backward writes the mutated Qxx,Qxu,Quu,lu back (reference in-place semantics) */
   RTOC_OPT_MAX_DTS0 = 1,      /* RiccatiRecursion(ocp, max_dts0) / setRegularization; value = double bits */
   RTOC_OPT_BACKWARD_WAVES = 2, /* waves per OCP instance in the backward kernel (0 = default for the dims) */
-  RTOC_OPT_CONTACT_INV_DAMPING = 3 /* RobotModelInfo::contact_inv_damping (robot.hxx:662-664); value = double bits */
+  RTOC_OPT_CONTACT_INV_DAMPING = 3, /* RobotModelInfo::contact_inv_damping (robot.hxx:662-664); value = double bits */
+  RTOC_OPT_SWEEP_CHUNKS = 4 /* instance chunks of rtoc_riccati_sweep's backward/forward pipeline (1..16, default 1 = plain sequence) */
 };
 
 typedef struct rtoc_ctx rtoc_ctx;
@@ -136,6 +140,8 @@ int rtoc_set_constraint_rows(rtoc_ctx* ctx, const rtoc_box_row* rows, int nrows)
 int rtoc_condense(rtoc_ctx* ctx);
 int rtoc_riccati_backward(rtoc_ctx* ctx);
 int rtoc_riccati_forward(rtoc_ctx* ctx);
+/* backward + forward of the whole batch; same results as the two calls in sequence. */
+int rtoc_riccati_sweep(rtoc_ctx* ctx);
 int rtoc_unconstr_backward(rtoc_ctx* ctx, double dt);
 int rtoc_unconstr_forward(rtoc_ctx* ctx, double dt);
 /* expandPrimal + fraction-to-boundary + expandDual; step sizes land in RTOC_BUF_STEP. */

@@ -10,7 +10,8 @@ import subprocess
 import numpy as np
 
 from .types import (BoxRow, BUF_CDD, BUF_CON, BUF_DIR, BUF_DX0, BUF_KKT, BUF_RIC, BUF_STEP, Dims, Grid,
-                    Layout, OPT_BACKWARD_WAVES, OPT_MAX_DTS0, OPT_WRITEBACK_KKT, grid_array)
+                    Layout, OPT_BACKWARD_WAVES, OPT_MAX_DTS0, OPT_SWEEP_CHUNKS, OPT_WRITEBACK_KKT,
+                    grid_array)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
@@ -72,7 +73,7 @@ def lib():
         L.rtoc_buffer_count.argtypes = [vp, C.c_int]
         L.rtoc_buffer_count.restype = C.c_size_t
         L.rtoc_bind.argtypes = [vp, C.c_int, vp]
-        for f in ("rtoc_condense", "rtoc_riccati_backward", "rtoc_riccati_forward", "rtoc_update",
+        for f in ("rtoc_condense", "rtoc_riccati_backward", "rtoc_riccati_forward", "rtoc_riccati_sweep", "rtoc_update",
                   "rtoc_clear_status", "rtoc_sync"):
             getattr(L, f).argtypes = [vp]
         L.rtoc_unconstr_backward.argtypes = [vp, C.c_double]
@@ -182,6 +183,13 @@ class Context:
 
     def riccati_forward(self):
         _chk(lib().rtoc_riccati_forward(self._h))
+
+    def riccati_sweep(self):
+        """backward + forward, pipelined over instance chunks (rtoc_riccati_sweep)."""
+        _chk(lib().rtoc_riccati_sweep(self._h))
+
+    def set_sweep_chunks(self, n):
+        _chk(lib().rtoc_set_option(self._h, OPT_SWEEP_CHUNKS, int(n)))
 
     def unconstr_backward(self, dt):
         _chk(lib().rtoc_unconstr_backward(self._h, dt))

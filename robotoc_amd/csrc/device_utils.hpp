@@ -7,6 +7,7 @@
 //     holds D[row = (l>>4) + 4*r][col = l&15].
 //   * 64-wide wavefronts, LDS-resident operands, ds_read_b64 fragments.
 #pragma once
+#include "../../include/rtoc_layout.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -127,5 +128,19 @@ __device__ __forceinline__ double rsqrt_d(double d) {
 }
 
 __device__ __forceinline__ bool is_bad(double v) { return !(fabs(v) <= 1.79769313486231570815e308); }
+
+// Field offsets of the KKT / Riccati records for a robot known at compile time: the same
+// rtoc_compute_layout() the host uses, evaluated as a constant expression, so that every offset is
+// an instruction immediate instead of a scalar register (the runtime table cost ~60 SGPRs and made
+// the compiler spill scalars through v_writelane / v_readlane all over the stage loop).
+template <int NV, int NU, int NS>
+struct StaticLayout {
+  static constexpr rtoc_layout make() {
+    rtoc_dims d = {NV, NU, 0, NS, NS, 0};
+    rtoc_layout L = {};
+    rtoc_compute_layout(&d, &L);
+    return L;
+  }
+};
 
 }  // namespace rtoc

@@ -49,20 +49,6 @@ namespace rtoc {
     if (a.prof && b == 0 && tid0 == 64) a.prof[st * 32 + (k)] = (long long)__builtin_readcyclecounter(); \
   } while (0)
 
-// Field offsets of the KKT / Riccati records for a robot known at compile time: the same
-// rtoc_compute_layout() the host uses, evaluated as a constant expression, so that every offset is
-// an instruction immediate instead of a scalar register (the runtime table cost ~60 SGPRs and made
-// the compiler spill scalars through v_writelane / v_readlane all over the stage loop).
-template <int NV, int NU, int NS>
-struct StaticLayout {
-  static constexpr rtoc_layout make() {
-    rtoc_dims d = {NV, NU, 0, NS, NS, 0};
-    rtoc_layout L = {};
-    rtoc_compute_layout(&d, &L);
-    return L;
-  }
-};
-
 struct BwdArgs {
   const double* kkt;       // [batch][nstages][kkt stride]
   double* kkt_rw;          // same buffer, writable (writeback of F,H,G,lu)
@@ -71,7 +57,8 @@ struct BwdArgs {
   uint32_t* status;        // [batch]
   long long* prof;         // optional [nstages][16] cycle stamps of block 0 (tuning aid), or nullptr
   int nstages;
-  int batch;
+  int batch;  // instances [first, batch) are processed by this launch
+  int first;
   int writeback;
   double max_dts0;
 };
@@ -337,7 +324,7 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
   double* const sL = smem + C::OFF_L;
 
   const int tid0 = threadIdx.x;
-  const int b = blockIdx.x;
+  const int b = a.first + blockIdx.x;
   if (b >= a.batch) return;
   int tid = tid0, lane = tid & 63, wave = tid >> 6, li = lane & 15, q = lane >> 4;
   const int N = a.nstages - 1;

@@ -14,6 +14,8 @@
 // Only for state dimensions with NX + 1 <= 64 (one vector wave covers a state vector): ANYmal,
 // iiwa14.  Larger robots use the tile-split kernel of riccati_backward.hpp.
 #pragma once
+#include <type_traits>
+
 #include "riccati_backward.hpp"
 
 namespace rtoc {
@@ -84,7 +86,7 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a, const
   volatile int* const sFlag = reinterpret_cast<volatile int*>(smem + C::V_FLAG);
 
   const int tid0 = (MW ? 0 : 64) + (threadIdx.x & 63);  // thread index within the instance
-  const int b = blockIdx.x * NI + slot;
+  const int b = a.first + blockIdx.x * NI + slot;
   int epoch = 0;
   int tid = tid0, lane = tid & 63, wave = tid >> 6, li = lane & 15, q = lane >> 4;
   const int N = a.nstages - 1;
@@ -339,10 +341,10 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a, const
      } else {
       for (int e = lane; e < NU * LDP; e += 64) sPB[e] = 0.0;
      }
-      lds_signal(sFlag, 2 * (N - st) - 1, lane);  // G ready
+      lds_signal(sFlag, 3 * (N - st) - 2, lane);  // G ready
     }
     RTOC_PROFV(20);
-    if constexpr (!MW) lds_wait(sFlag, 2 * (N - st) - 1);
+    if constexpr (!MW) lds_wait(sFlag, 3 * (N - st) - 2);
     RTOC_PROFV(21);
 
     RTOC_PROF(3);
@@ -362,53 +364,89 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a, const
       const bool fxcol = (JL + li == NX) && !sto;
       const double* pbl_ = (JL + li < NX) ? (sA + q + (JL + li) * LDP) : (smem + C::V_FX + q);
       const bool okl = (JL + li < NX) || fxcol;
-      // operands of k-step ks: software-pipelined one step ahead (the scheduler otherwise hoists the
-      // LDS loads of all nine steps at once and spills)
-      auto load_ops = [&](int ks, double (&av)[TMA], double (&bv)[CNT]) {
-        const bool kok = (ks * 4 + 3 < NX) || (ks * 4 + q < NX);
+      // Row tiles in two passes: first the tiles that hold PB^T rows (H = Qxu^T-part, and PB^T Fx),
+      // so the vector wave can start the policy products while the P+ A rows are still being
+      // multiplied; then the pure P+ rows.
+      constexpr int TMH = NX / 16;  // first row tile with a PB^T row
+      constexpr int KSA = (NX + 3) / 4;
+      auto run_pass = [&](auto tm0c, auto tm1c) {
+        constexpr int TM0 = decltype(tm0c)::value, TM1 = decltype(tm1c)::value;
+        if constexpr (TM1 > TM0) {
+          // operands of k-step ks: software-pipelined one step ahead (the scheduler otherwise hoists
+          // the LDS loads of all nine steps at once and spills)
+          auto load_ops = [&](int ks, double (&av)[TMA], double (&bv)[CNT]) {
+            const bool kok = (ks * 4 + 3 < NX) || (ks * 4 + q < NX);
 #pragma unroll
-        for (int tm = 0; tm < TMA; ++tm) {
-          const int i = tm * 16 + li;
-          double v;
-          if (tm * 16 + 15 < NX) {
-            v = sP[li + q * LDP + tm * 16 + ks * 4 * LDP];
-          } else if (tm * 16 >= NX) {
-            v = sPB[q + li * LDP + (tm * 16 - NX) * LDP + ks * 4];
-            if (tm * 16 + 15 >= NX + NU) v = (i < NX + NU) ? v : 0.0;
-          } else {
-            const double vp = sP[li + q * LDP + tm * 16 + ks * 4 * LDP];
-            const double vb = sPB[q + li * LDP + (tm * 16 - NX) * LDP + ks * 4];
-            v = (i < NX) ? vp : vb;
-            if (tm * 16 + 15 >= NX + NU) v = (i < NX + NU) ? v : 0.0;
-          }
-          av[tm] = kok ? v : 0.0;
-        }
+            for (int tm = TM0; tm < TM1; ++tm) {
+              const int i = tm * 16 + li;
+              double v;
+              if (tm * 16 + 15 < NX) {
+                v = sP[li + q * LDP + tm * 16 + ks * 4 * LDP];
+              } else if (tm * 16 >= NX) {
+                v = sPB[q + li * LDP + (tm * 16 - NX) * LDP + ks * 4];
+                if (tm * 16 + 15 >= NX + NU) v = (i < NX + NU) ? v : 0.0;
+              } else {
+                const double vp = sP[li + q * LDP + tm * 16 + ks * 4 * LDP];
+                const double vb = sPB[q + li * LDP + (tm * 16 - NX) * LDP + ks * 4];
+                v = (i < NX) ? vp : vb;
+                if (tm * 16 + 15 >= NX + NU) v = (i < NX + NU) ? v : 0.0;
+              }
+              av[tm] = kok ? v : 0.0;
+            }
 #pragma unroll
-        for (int c = 0; c < CNT; ++c) {
-          if (c < CNT - 1) {
-            const double v = pb_[ks * 4 + c * 16 * LDP];
-            bv[c] = (kok && (c * 16 + li < NX)) ? v : 0.0;
-          } else {
-            const double v = pbl_[ks * 4];  // A columns, then Fx as column NX
-            bv[c] = (kok && okl) ? v : 0.0;
+            for (int c = 0; c < CNT; ++c) {
+              if (c < CNT - 1) {
+                const double v = pb_[ks * 4 + c * 16 * LDP];
+                bv[c] = (kok && (c * 16 + li < NX)) ? v : 0.0;
+              } else {
+                const double v = pbl_[ks * 4];  // A columns, then Fx as column NX
+                bv[c] = (kok && okl) ? v : 0.0;
+              }
+            }
+          };
+          double av[2][TMA], bv[2][CNT];
+          load_ops(0, av[0], bv[0]);
+#pragma unroll
+          for (int ks = 0; ks < KSA; ++ks) {
+            if (ks + 1 < KSA) load_ops(ks + 1, av[(ks + 1) & 1], bv[(ks + 1) & 1]);
+#pragma unroll
+            for (int tm = TM0; tm < TM1; ++tm)
+#pragma unroll
+              for (int c = 0; c < CNT; ++c)
+                pa[tm][c] = mfma16(av[ks & 1][tm], bv[ks & 1][c], pa[tm][c]);
+            __builtin_amdgcn_sched_barrier(0);
           }
         }
       };
-      constexpr int KSA = (NX + 3) / 4;
-      double av[2][TMA], bv[2][CNT];
-      load_ops(0, av[0], bv[0]);
+      // column NX of [P+; PB^T] [A | Fx]: rows < NX are P+ Fx -> z = s+ - P+ Fx (brrf.cpp:86),
+      // rows NX.. are PB^T Fx = Bv^T (P+ Fx)_v -> the missing part of lu'
+      auto write_fx_column = [&](auto tm0c, auto tm1c) {
+        constexpr int TM0 = decltype(tm0c)::value, TM1 = decltype(tm1c)::value;
+        if (fxcol) {
 #pragma unroll
-      for (int ks = 0; ks < KSA; ++ks) {
-        if (ks + 1 < KSA) load_ops(ks + 1, av[(ks + 1) & 1], bv[(ks + 1) & 1]);
+          for (int tm = TM0; tm < TM1; ++tm)
 #pragma unroll
-        for (int tm = 0; tm < TMA; ++tm)
-#pragma unroll
-          for (int c = 0; c < CNT; ++c) pa[tm][c] = mfma16(av[ks & 1][tm], bv[ks & 1][c], pa[tm][c]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
+            for (int r = 0; r < 4; ++r) {
+              const int row = tm * 16 + drow(q, r);
+              const double v = pa[tm][CNT - 1][r];
+              if (tm * 16 + 4 * r + 3 < NX) {
+                smem[C::V_Z + row] = smem[C::V_SN + row] - v;
+              } else if (tm * 16 + 4 * r >= NX) {
+                if (row < NX + NU) smem[C::V_Y + row - NX] = v;
+              } else {
+                if (row < NX)
+                  smem[C::V_Z + row] = smem[C::V_SN + row] - v;
+                else if (row < NX + NU)
+                  smem[C::V_Y + row - NX] = v;
+              }
+            }
+        }
+      };
+      using std::integral_constant;
+      run_pass(integral_constant<int, TMH>{}, integral_constant<int, TMA>{});
       if (!impact) {
 #pragma unroll
-        for (int tm = 0; tm < TMA; ++tm)
+        for (int tm = TMH; tm < TMA; ++tm)
 #pragma unroll
           for (int c = 0; c < CNT; ++c)
 #pragma unroll
@@ -420,27 +458,11 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a, const
               }
             }
       }
-      if (fxcol) {
-        // column NX of [P+; PB^T] [A | Fx]: rows < NX are P+ Fx  -> z = s+ - P+ Fx (:brrf z vector),
-        // rows NX.. are PB^T Fx = Bv^T (P+ Fx)_v -> the missing part of lu'
-#pragma unroll
-        for (int tm = 0; tm < TMA; ++tm)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = tm * 16 + drow(q, r);
-            const double v = pa[tm][CNT - 1][r];
-            if (tm * 16 + 4 * r + 3 < NX) {
-              smem[C::V_Z + row] = smem[C::V_SN + row] - v;
-            } else if (tm * 16 + 4 * r >= NX) {
-              if (row < NX + NU) smem[C::V_Y + row - NX] = v;
-            } else {
-              if (row < NX)
-                smem[C::V_Z + row] = smem[C::V_SN + row] - v;
-              else if (row < NX + NU)
-                smem[C::V_Y + row - NX] = v;
-            }
-          }
-      }
+      write_fx_column(integral_constant<int, TMH>{}, integral_constant<int, TMA>{});
+      lds_signal(sFlag, 3 * (N - st) - 1, lane);  // H and PB^T Fx ready, PB no longer read
+      run_pass(integral_constant<int, 0>{}, integral_constant<int, TMH>{});
+      write_fx_column(integral_constant<int, 0>{}, integral_constant<int, TMH>{});
+      lds_signal(sFlag, 3 * (N - st), lane);  // z ready
     } else {
       if (!impact) {
         // LLT(G) (riccati_factorizer.cpp:49) and, in the same sweep, Y = L^-1 (column-major in the
@@ -470,9 +492,8 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a, const
         }
       }
     }
-    if constexpr (MW) lds_signal(sFlag, 2 * (N - st), lane);  // H ready, PB no longer read
     RTOC_PROFV(23);
-    if constexpr (!MW) lds_wait(sFlag, 2 * (N - st));
+    if constexpr (!MW) lds_wait(sFlag, 3 * (N - st) - 1);
     RTOC_PROFV(24);
     if constexpr (!MW) {
       if (!sto && !impact) {
@@ -512,40 +533,46 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a, const
       }
     } else {
       if (!impact && ns == 0) {
-        // K^T = -H G^-1, k = -G^-1 lu', T = -G^-1 psi_u, W = -G^-1 phi_u
+        // K = -G^-1 H^T, k = -G^-1 lu', T = -G^-1 psi_u, W = -G^-1 phi_u
         // (riccati_factorizer.cpp:55-56, :125-130) for all right-hand sides at once, as the two
         // triangular solves written as products with Y = L^-1:
-        //   Z = [H; lu'^T; psi_u^T; phi_u^T] Y^T,   [K^T; k^T; T^T; W^T] = -Z Y.
-        // The three vectors ride as rows NX, NX+1, NX+2 behind the rows of H.  (G^-1 = Y^T Y is
-        // never formed: that would square the conditioning of the factor.)
+        //   Z^T = Y [H^T | lu' | psi_u | phi_u],   [K | k | T | W] = -Y^T Z^T.
+        // The three vectors ride as columns NX, NX+1, NX+2 behind the columns of H^T.  The C layout
+        // of Z^T (row i = q+4r, column = lane&15) is the B-operand layout of the second product, so
+        // Z^T never leaves the registers.  (G^-1 = Y^T Y is never formed: that would square the
+        // conditioning of the factor.)
         {
-          constexpr int TKT = (NX + 3 + 15) / 16;  // row tiles of the stacked left operand
+          constexpr int TKT = (NX + 3 + 15) / 16;  // column tiles of the stacked right operand
           constexpr int KSU = (NU + 3) / 4;
-          d4 kt[TKT];
-          // per-lane source of row m = 16c + li in the tiles that are not pure H rows
+          d4 zt[TKT], kk[TKT];
+          // per-lane source of column x = 16c + li in the tiles that are not pure H columns
           const double* psrc[TKT];
-          const double* pzsrc[TKT];
           int ssrc[TKT];
           bool oksrc[TKT];
 #pragma unroll
           for (int c = 0; c < TKT; ++c) {
-            kt[c] = zero4();
-            const int m = c * 16 + li;
-            const int voff = (m == NX ? C::V_LU : (m == NX + 1 ? C::V_PSIU : C::V_PHIU));
-            const int zoff = (m == NX ? C::V_KV : (m == NX + 1 ? C::V_TV : C::V_WV));
-            psrc[c] = (m < NX) ? (sH + m + q * LDP) : (smem + voff + q);
-            pzsrc[c] = (m < NX) ? (sKt + m + q * LDP) : (smem + zoff + q);
-            ssrc[c] = (m < NX) ? 4 * LDP : 4;
-            oksrc[c] = (m < NX) || m == NX || (sto && (m == NX + 1 || (m == NX + 2 && sto_next)));
+            zt[c] = zero4();
+            kk[c] = zero4();
+            const int x = c * 16 + li;
+            const int voff = (x == NX ? C::V_LU : (x == NX + 1 ? C::V_PSIU : C::V_PHIU));
+            psrc[c] = (x < NX) ? (sH + x + q * LDP) : (smem + voff + q);
+            ssrc[c] = (x < NX) ? 4 * LDP : 4;
+            oksrc[c] = (x < NX) || x == NX || (sto && (x == NX + 1 || (x == NX + 2 && sto_next)));
           }
-          const double* ph_ = sH + li + q * LDP;
-          const double* pyt_ = sBv + li + q * NU;  // B[k = u][n = i] = Y[i][u]
-          const double* py_ = sBv + q + li * NU;   // B[k = i][n = u] = Y[i][u]
+          const double* ph_ = sH + li + q * LDP;   // B[k = u][n = x] = H[x][u]
+          const double* py1_ = sBv + li + q * NU;  // A[m = i][k = u] = Y[i][u]
+          const double* py2_ = sBv + q + li * NU;  // A[m = u][k = i] = Y[i][u]
+          double y1[KSU], y2[KSU];
 #pragma unroll
           for (int ks = 0; ks < KSU; ++ks) {
             const bool kok = (ks * 4 + 3 < NU) || (ks * 4 + q < NU);
-            const double yv = pyt_[ks * 4 * NU];
-            const double bvv = (kok && li < NU) ? yv : 0.0;
+            const double v1 = py1_[ks * 4 * NU], v2 = py2_[ks * 4];
+            y1[ks] = (kok && li < NU) ? v1 : 0.0;
+            y2[ks] = (kok && li < NU) ? -v2 : 0.0;
+          }
+#pragma unroll
+          for (int ks = 0; ks < KSU; ++ks) {
+            const bool kok = (ks * 4 + 3 < NU) || (ks * 4 + q < NU);
 #pragma unroll
             for (int c = 0; c < TKT; ++c) {
               double v;
@@ -557,76 +584,45 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a, const
                 v = psrc[c][ks * ssrc[c]];
                 ok = kok && oksrc[c];
               }
-              kt[c] = mfma16(ok ? v : 0.0, bvv, kt[c]);
+              zt[c] = mfma16(y1[ks], ok ? v : 0.0, zt[c]);
             }
           }
-          // destinations of the C-layout rows x = 16c + 4r + q: K^T rows, then k, T, W; register
-          // groups that straddle the end of H get a per-lane pointer (spare lanes hit a dummy slot)
-          double* const pkt_ = sKt + q + li * LDP;
-          auto mixed_dst = [&](int gb) -> double* {
-            const int x = gb + q;
-            double* d = smem + C::V_FLAG + 4;  // dummy
-            d = (x == NX + 2) ? (smem + C::V_WV + li) : d;
-            d = (x == NX + 1) ? (smem + C::V_TV + li) : d;
-            d = (x == NX) ? (smem + C::V_KV + li) : d;
-            d = (x < NX) ? (sKt + x + li * LDP) : d;
-            return d;
-          };
-          auto store_rows = [&](d4 (&t)[TKT]) {
-            if (li < NU) {
 #pragma unroll
-              for (int c = 0; c < TKT; ++c)
+          for (int ks = 0; ks < KSU; ++ks)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                  constexpr int dummy = 0;
-                  const int gb = c * 16 + 4 * r;
-                  if (gb + 3 < NX)
-                    pkt_[gb] = t[c][r];
-                  else if (gb < NX + 3)
-                    *mixed_dst(gb) = t[c][r];
-                }
+            for (int c = 0; c < TKT; ++c) kk[c] = mfma16(y2[ks], zt[c][ks], kk[c]);
+          // K[u = q+4r][x = 16c+li] -> K^T buffer (x + u*LDP); columns NX.. -> k, T, W
+          double chk = 0.0;  // any NaN / Inf in the policy poisons this sum (0 * Inf = NaN)
+#pragma unroll
+          for (int c = 0; c < TKT; ++c) {
+            double* dst;
+            int dstride;
+            if (c * 16 + 15 < NX) {
+              dst = sKt + c * 16 + li + q * LDP;
+              dstride = 4 * LDP;
+            } else {
+              const int x = c * 16 + li;
+              double* d = smem + C::V_FLAG + 4;  // dummy slot for the spare lanes
+              d = (x == NX + 2) ? (smem + C::V_WV + q) : d;
+              d = (x == NX + 1) ? (smem + C::V_TV + q) : d;
+              d = (x == NX) ? (smem + C::V_KV + q) : d;
+              d = (x < NX) ? (sKt + x + q * LDP) : d;
+              dst = d;
+              dstride = (x < NX) ? 4 * LDP : (x < NX + 3 ? 4 : 0);
             }
-          };
-          // Z -> LDS (the K^T buffer and the k / T / W vectors), back as the left operand
-          store_rows(kt);
 #pragma unroll
-          for (int c = 0; c < TKT; ++c) kt[c] = zero4();
-          wave_lds_sync();
-          const double* pz_ = sKt + li + q * LDP;
-#pragma unroll
-          for (int ks = 0; ks < KSU; ++ks) {
-            const bool kok = (ks * 4 + 3 < NU) || (ks * 4 + q < NU);
-            const double yv = py_[ks * 4];
-            const double bvv = (kok && li < NU) ? -yv : 0.0;
-#pragma unroll
-            for (int c = 0; c < TKT; ++c) {
-              double v;
-              bool ok;
-              if (c * 16 + 15 < NX) {
-                v = pz_[c * 16 + ks * 4 * LDP];
-                ok = kok;
-              } else {
-                v = pzsrc[c][ks * ssrc[c]];
-                ok = kok && oksrc[c];
-              }
-              kt[c] = mfma16(ok ? v : 0.0, bvv, kt[c]);
+            for (int r = 0; r < KSU; ++r) {
+              if (r * 4 + 3 < NU || r * 4 + q < NU) dst[r * dstride] = kk[c][r];
+              chk = __builtin_fma(kk[c][r], 0.0, chk);
             }
           }
-          wave_lds_sync();
-          store_rows(kt);
-          // any NaN / Inf in the policy poisons this sum (0 * Inf = NaN)
-          double chk = 0.0;
-#pragma unroll
-          for (int c = 0; c < TKT; ++c)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (c * 16 + 4 * r < NX + 1) chk = __builtin_fma(kt[c][r], 0.0, chk);
-          if (li < NU && is_bad(chk)) stat |= RTOC_STAT_NAN;
+          if (is_bad(chk)) stat |= RTOC_STAT_NAN;
         }
         RTOC_PROFV(25);
       }
       // w = A^T z - lx (brrf.cpp:87-88), off the matrix wave's critical path: z came with the H flag
       double wacc = 0.0;
+      lds_wait(sFlag, 3 * (N - st));
       if (!sto && vt < NX) {
         typedef double dbl2 __attribute__((ext_vector_type(2)));
         static_assert((LDP & 1) == 0 && (C::OFF_A & 1) == 0 && (C::V_Z & 1) == 0, "128-bit LDS reads");
@@ -924,7 +920,7 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a, const
 
 template <int NV, int NU, int NS>
 __global__ __launch_bounds__(128, 2) void riccati_backward_rs_kernel(BwdArgs a) {
-  if ((int)blockIdx.x >= a.batch) return;
+  if (a.first + (int)blockIdx.x >= a.batch) return;
   extern __shared__ __attribute__((aligned(16))) double smem_all[];
   using C = BwdCfg<NV, NU, NS, 2>;
   if (threadIdx.x < 2) reinterpret_cast<int*>(smem_all + C::V_FLAG)[threadIdx.x] = 0;
@@ -966,7 +962,7 @@ __global__ __launch_bounds__(512) void riccati_backward_rs4_kernel(BwdArgs a) {
   const bool paired = hdr[0] == 2 && hdr[1] == 2 && hdr[2] == 2 && hdr[3] == 2;
   const int slot = __builtin_amdgcn_readfirstlane(paired ? simd : (wave & 3));
   const int role = __builtin_amdgcn_readfirstlane(paired ? order : (wave >> 2));
-  if ((int)blockIdx.x * 4 + slot >= a.batch) return;
+  if (a.first + (int)blockIdx.x * 4 + slot >= a.batch) return;
   if (role == 0)
     riccati_backward_rs_body<NV, NU, NS, true, 4>(a, slot);
   else

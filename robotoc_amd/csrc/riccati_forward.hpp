@@ -17,6 +17,10 @@
 
 namespace rtoc {
 
+#ifndef FWD_UNROLL
+#define FWD_UNROLL 18
+#endif
+
 struct FwdArgs {
   const double* kkt;
   const double* ric;
@@ -24,8 +28,8 @@ struct FwdArgs {
   const double* dx0;  // [batch][nx] or nullptr (then dir[...][0].dx is used as given)
   const rtoc_grid* grid;
   int nstages;
-  int batch;
-  rtoc_record_layout kl, rl, dl;
+  int batch;  // instances [first, batch) are processed by this launch
+  int first;
 };
 
 template <int NV, int NU, int NS, int NWF>
@@ -36,20 +40,19 @@ __global__ __launch_bounds__(64 * NWF) void riccati_forward_kernel(FwdArgs a) {
   __shared__ double sDu[NU + 8];
   __shared__ double sRed[8];
   const int tid = threadIdx.x;
-  const int b = blockIdx.x;
+  const int b = a.first + blockIdx.x;
   if (b >= a.batch) return;
   const int N = a.nstages - 1;
-  const int* ko = a.kl.off;
-  const int* ro = a.rl.off;
-  const int* dof = a.dl.off;
-  const double* kb = a.kkt + (size_t)b * a.nstages * a.kl.stride;
-  const double* rb = a.ric + (size_t)b * a.nstages * a.rl.stride;
-  double* db = a.dir + (size_t)b * a.nstages * a.dl.stride;
+  constexpr rtoc_layout SL = StaticLayout<NV, NU, NS>::make();
+  constexpr rtoc_record_layout KL = SL.kkt, RL = SL.ric, DL = SL.dir;
+  const double* kb = a.kkt + (size_t)b * a.nstages * KL.stride;
+  const double* rb = a.ric + (size_t)b * a.nstages * RL.stride;
+  double* db = a.dir + (size_t)b * a.nstages * DL.stride;
 
   if (tid < NX) {
-    const double v = a.dx0 ? a.dx0[(size_t)b * NX + tid] : db[dof[RTOC_DIR_DX] + tid];
+    const double v = a.dx0 ? a.dx0[(size_t)b * NX + tid] : db[DL.off[RTOC_DIR_DX] + tid];
     sDx[0][tid] = v;
-    if (a.dx0) db[dof[RTOC_DIR_DX] + tid] = v;
+    if (a.dx0) db[DL.off[RTOC_DIR_DX] + tid] = v;
   }
   __syncthreads();
   double dts = 0.0, dtsn = 0.0;  // d[i].dts, d[i].dts_next carried along (uniform)
@@ -59,8 +62,8 @@ __global__ __launch_bounds__(64 * NWF) void riccati_forward_kernel(FwdArgs a) {
       // computeSwitchingTimeDirection(sto_policy_[0], d[0], false)  (riccati_recursion.cpp:91-94)
       if (tid == 0) {
         double acc = 0.0;
-        for (int k = 0; k < NX; ++k) acc += rb[ro[RTOC_RIC_DTSDX] + k] * sDx[0][k];
-        sRed[0] = acc + rb[ro[RTOC_RIC_SCAL] + RTOC_RIC_SCAL_DTS0];
+        for (int k = 0; k < NX; ++k) acc += rb[RL.off[RTOC_RIC_DTSDX] + k] * sDx[0][k];
+        sRed[0] = acc + rb[RL.off[RTOC_RIC_SCAL] + RTOC_RIC_SCAL_DTS0];
       }
       __syncthreads();
       dtsn = sRed[0];
@@ -72,9 +75,9 @@ __global__ __launch_bounds__(64 * NWF) void riccati_forward_kernel(FwdArgs a) {
     const rtoc_grid g = a.grid[st];
     const bool impact = g.type == RTOC_GRID_IMPACT, lift = g.type == RTOC_GRID_LIFT;
     const bool sto = g.sto != 0, sto_next = g.sto_next != 0;
-    const double* kr = kb + (size_t)st * a.kl.stride;
-    const double* rr = rb + (size_t)st * a.rl.stride;
-    double* dr = db + (size_t)st * a.dl.stride;
+    const double* kr = kb + (size_t)st * KL.stride;
+    const double* rr = rb + (size_t)st * RL.stride;
+    double* dr = db + (size_t)st * DL.stride;
     const double* dx = sDx[cur];
     double* dxn = sDx[cur ^ 1];
 
@@ -84,9 +87,9 @@ __global__ __launch_bounds__(64 * NWF) void riccati_forward_kernel(FwdArgs a) {
       if (lift && sto_next) {
         if (tid == 0) {
           double acc = 0.0;
-          for (int k = 0; k < NX; ++k) acc += rr[ro[RTOC_RIC_DTSDX] + k] * dx[k];
-          acc += rr[ro[RTOC_RIC_SCAL] + RTOC_RIC_SCAL_DTS0];
-          if (sto) acc += rr[ro[RTOC_RIC_SCAL] + RTOC_RIC_SCAL_DTSDTS] * dts;
+          for (int k = 0; k < NX; ++k) acc += rr[RL.off[RTOC_RIC_DTSDX] + k] * dx[k];
+          acc += rr[RL.off[RTOC_RIC_SCAL] + RTOC_RIC_SCAL_DTS0];
+          if (sto) acc += rr[RL.off[RTOC_RIC_SCAL] + RTOC_RIC_SCAL_DTSDTS] * dts;
           sRed[0] = acc;
         }
         __syncthreads();
@@ -98,9 +101,9 @@ __global__ __launch_bounds__(64 * NWF) void riccati_forward_kernel(FwdArgs a) {
     // ---- row products: threads < NX: Fxx dx and P dx ; threads NX..NX+NU-1: K dx ----
     double acc_a = 0.0, acc_p = 0.0;
     if (tid < NX) {
-      const double* A = kr + ko[RTOC_KKT_FXX] + tid;
-      const double* P = rr + ro[RTOC_RIC_P] + tid;
-#pragma unroll 6
+      const double* A = kr + KL.off[RTOC_KKT_FXX] + tid;
+      const double* P = rr + RL.off[RTOC_RIC_P] + tid;
+#pragma unroll FWD_UNROLL
       for (int j = 0; j < NX; ++j) {
         const double x = dx[j];
         acc_a += A[j * NX] * x;
@@ -108,39 +111,39 @@ __global__ __launch_bounds__(64 * NWF) void riccati_forward_kernel(FwdArgs a) {
       }
     } else if (!impact && tid < NX + NU) {
       const int u = tid - NX;
-      const double* K = rr + ro[RTOC_RIC_K] + (size_t)u * NX;  // row u of row-major K
+      const double* K = rr + RL.off[RTOC_RIC_K] + (size_t)u * NX;  // row u of row-major K
 #pragma unroll 6
       for (int j = 0; j < NX; ++j) acc_a += K[j] * dx[j];
-      double du = acc_a + rr[ro[RTOC_RIC_KV] + u];
+      double du = acc_a + rr[RL.off[RTOC_RIC_KV] + u];
       if (sto) {
-        du += rr[ro[RTOC_RIC_T] + u] * (dtsn - dts);
-        if (sto_next) du -= rr[ro[RTOC_RIC_W] + u] * dtsn;
+        du += rr[RL.off[RTOC_RIC_T] + u] * (dtsn - dts);
+        if (sto_next) du -= rr[RL.off[RTOC_RIC_W] + u] * dtsn;
       }
       sDu[u] = du;
-      dr[dof[RTOC_DIR_DU] + u] = du;
+      dr[DL.off[RTOC_DIR_DU] + u] = du;
     }
     __syncthreads();
     if (tid < NX) {
-      double v = kr[ko[RTOC_KKT_FX] + tid] + acc_a;
+      double v = kr[KL.off[RTOC_KKT_FX] + tid] + acc_a;
       if (!impact) {
         if (tid >= NV) {
-          const double* Bv = kr + ko[RTOC_KKT_FVU] + (tid - NV);
+          const double* Bv = kr + KL.off[RTOC_KKT_FVU] + (tid - NV);
 #pragma unroll 4
           for (int u = 0; u < NU; ++u) v += Bv[u * NV] * sDu[u];
         }
-        if (sto) v += kr[ko[RTOC_KKT_FFX] + tid] * (dtsn - dts);
+        if (sto) v += kr[KL.off[RTOC_KKT_FFX] + tid] * (dtsn - dts);
       }
       dxn[tid] = v;
-      (dr + a.dl.stride)[dof[RTOC_DIR_DX] + tid] = v;
+      (dr + DL.stride)[DL.off[RTOC_DIR_DX] + tid] = v;
     }
     if (impact && sto_next) {
       // riccati_recursion.cpp:101-107: dts_next of d[i+1] from sto_policy_[i] and dx[i+1]
       __syncthreads();
       if (tid == 0) {
         double acc = 0.0;
-        for (int k = 0; k < NX; ++k) acc += rr[ro[RTOC_RIC_DTSDX] + k] * dxn[k];
-        acc += rr[ro[RTOC_RIC_SCAL] + RTOC_RIC_SCAL_DTS0];
-        if (sto) acc += rr[ro[RTOC_RIC_SCAL] + RTOC_RIC_SCAL_DTSDTS] * dts;
+        for (int k = 0; k < NX; ++k) acc += rr[RL.off[RTOC_RIC_DTSDX] + k] * dxn[k];
+        acc += rr[RL.off[RTOC_RIC_SCAL] + RTOC_RIC_SCAL_DTS0];
+        if (sto) acc += rr[RL.off[RTOC_RIC_SCAL] + RTOC_RIC_SCAL_DTSDTS] * dts;
         sRed[0] = acc;
       }
       __syncthreads();
@@ -148,51 +151,51 @@ __global__ __launch_bounds__(64 * NWF) void riccati_forward_kernel(FwdArgs a) {
     }
     // ---- costate (riccati_factorizer.cpp:243-262) ----
     if (tid < NX) {
-      double lam = acc_p - rr[ro[RTOC_RIC_S] + tid];
+      double lam = acc_p - rr[RL.off[RTOC_RIC_S] + tid];
       if (sto) {
         if (impact) {
-          lam -= rr[ro[RTOC_RIC_PHI] + tid] * dtsn;
+          lam -= rr[RL.off[RTOC_RIC_PHI] + tid] * dtsn;
         } else {
-          lam += rr[ro[RTOC_RIC_PSI] + tid] * (dtsn - dts);
-          if (sto_next) lam -= rr[ro[RTOC_RIC_PHI] + tid] * dtsn;
+          lam += rr[RL.off[RTOC_RIC_PSI] + tid] * (dtsn - dts);
+          if (sto_next) lam -= rr[RL.off[RTOC_RIC_PHI] + tid] * dtsn;
         }
       }
-      dr[dof[RTOC_DIR_DLMDGMM] + tid] = lam;
+      dr[DL.off[RTOC_DIR_DLMDGMM] + tid] = lam;
     }
     // ---- switching-constraint multiplier (:265-277) ----
     if (NS > 0 && g.switching_constraint && tid < g.dims) {
-      const double* M = rr + ro[RTOC_RIC_M] + tid;
+      const double* M = rr + RL.off[RTOC_RIC_M] + tid;
       double acc = 0.0;
       for (int j = 0; j < NX; ++j) acc += M[j * NS] * dx[j];
-      acc += rr[ro[RTOC_RIC_MV] + tid];
+      acc += rr[RL.off[RTOC_RIC_MV] + tid];
       if (sto) {
-        acc += rr[ro[RTOC_RIC_MT] + tid] * (dtsn - dts);
-        if (sto_next) acc -= rr[ro[RTOC_RIC_MTN] + tid] * dtsn;
+        acc += rr[RL.off[RTOC_RIC_MT] + tid] * (dtsn - dts);
+        if (sto_next) acc -= rr[RL.off[RTOC_RIC_MTN] + tid] * dtsn;
       }
-      dr[dof[RTOC_DIR_DXI] + tid] = acc;
+      dr[DL.off[RTOC_DIR_DXI] + tid] = acc;
     }
     if (tid == 0) {
-      dr[dof[RTOC_DIR_DTS] + 0] = dts;
-      dr[dof[RTOC_DIR_DTS] + 1] = dtsn;
+      dr[DL.off[RTOC_DIR_DTS] + 0] = dts;
+      dr[DL.off[RTOC_DIR_DTS] + 1] = dtsn;
     }
     __syncthreads();
     cur ^= 1;
   }
   // terminal costate (riccati_recursion.cpp:128-130)
   {
-    const double* rr = rb + (size_t)N * a.rl.stride;
-    double* dr = db + (size_t)N * a.dl.stride;
+    const double* rr = rb + (size_t)N * RL.stride;
+    double* dr = db + (size_t)N * DL.stride;
     const double* dx = sDx[cur];
     if (tid < NX) {
-      const double* P = rr + ro[RTOC_RIC_P] + tid;
+      const double* P = rr + RL.off[RTOC_RIC_P] + tid;
       double acc = 0.0;
 #pragma unroll 6
       for (int j = 0; j < NX; ++j) acc += P[j * NX] * dx[j];
-      dr[dof[RTOC_DIR_DLMDGMM] + tid] = acc - rr[ro[RTOC_RIC_S] + tid];
+      dr[DL.off[RTOC_DIR_DLMDGMM] + tid] = acc - rr[RL.off[RTOC_RIC_S] + tid];
     }
     if (tid == 0) {
-      dr[dof[RTOC_DIR_DTS] + 0] = dts;
-      dr[dof[RTOC_DIR_DTS] + 1] = dtsn;
+      dr[DL.off[RTOC_DIR_DTS] + 0] = dts;
+      dr[DL.off[RTOC_DIR_DTS] + 1] = dtsn;
     }
   }
 }

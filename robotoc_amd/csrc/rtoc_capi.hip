@@ -46,7 +46,7 @@ struct KernelSet {
   int bwd_waves[4];   // waves per workgroup
   int bwd_lds[4];
   int bwd_inst[4];    // OCP instances per workgroup
-  rtoc_record_layout kl, rl;  // record layouts the backward kernels were compiled for
+  rtoc_record_layout kl, rl, dl;  // record layouts the Riccati kernels were compiled for
   fwd_fn fwd;
   int fwd_threads;
   fill_fn fill;
@@ -90,6 +90,7 @@ static KernelSet make_set() {
   constexpr int NWF = (2 * NV + NU + 63) / 64;
   k.fwd = riccati_forward_kernel<NV, NU, NS, NWF>;
   k.fwd_threads = 64 * NWF;
+  k.dl = StaticLayout<NV, NU, NS>::make().dir;
   k.fill = unconstr_fill_kernel<NV>;
   constexpr int NF = NS;  // nf_max == ns_max for all supported robots
   k.cond = condense_kernel<NV, NU, NF, NS>;
@@ -119,6 +120,7 @@ static const KernelSet* find_set(const rtoc_dims* d) {
 }
 
 // ---- context --------------------------------------------------------------------------
+#define RTOC_MAX_CHUNK_EVENTS 16
 struct rtoc_ctx {
   rtoc_dims dims;
   rtoc_layout L;
@@ -138,6 +140,9 @@ struct rtoc_ctx {
   double contact_inv_damping;
   int bwd_variant;
   hipEvent_t ev0, ev1;
+  hipStream_t stream2;  // forward half of the pipelined sweep
+  hipEvent_t ev_fork, ev_join, ev_chunk[RTOC_MAX_CHUNK_EVENTS];
+  int sweep_chunks;
 };
 
 extern "C" {
@@ -181,7 +186,8 @@ int rtoc_create(const rtoc_dims* dims, int max_stages, int batch, int device, rt
   // the backward kernels carry their record offsets as immediates: they must be the ones the host
   // (and the caller, through rtoc_get_layout) uses
   if (memcmp(&ks->kl, &c->L.kkt, sizeof(rtoc_record_layout)) != 0 ||
-      memcmp(&ks->rl, &c->L.ric, sizeof(rtoc_record_layout)) != 0) {
+      memcmp(&ks->rl, &c->L.ric, sizeof(rtoc_record_layout)) != 0 ||
+      memcmp(&ks->dl, &c->L.dir, sizeof(rtoc_record_layout)) != 0) {
     delete c;
     return RTOC_ERR_BAD_ARG;
   }
@@ -196,6 +202,12 @@ int rtoc_create(const rtoc_dims* dims, int max_stages, int batch, int device, rt
   c->stream = c->own_stream;
   HIP_TRY(hipEventCreate(&c->ev0));
   HIP_TRY(hipEventCreate(&c->ev1));
+  HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+  for (int i = 0; i < RTOC_MAX_CHUNK_EVENTS; ++i)
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_chunk[i], hipEventDisableTiming));
+  c->sweep_chunks = 1;  // measured on MI355X: chunked pipelining does not pay (forward waves do not fit next to the backward waves)
   const size_t per = (size_t)batch * max_stages;
   c->count[RTOC_BUF_KKT] = per * c->L.kkt.stride;
   c->count[RTOC_BUF_RIC] = per * c->L.ric.stride;
@@ -241,6 +253,10 @@ int rtoc_destroy(rtoc_ctx* c) {
   (void)hipEventDestroy(c->ev0);
   (void)hipEventDestroy(c->ev1);
   (void)hipStreamDestroy(c->own_stream);
+  (void)hipStreamDestroy(c->stream2);
+  (void)hipEventDestroy(c->ev_fork);
+  (void)hipEventDestroy(c->ev_join);
+  for (int i = 0; i < RTOC_MAX_CHUNK_EVENTS; ++i) (void)hipEventDestroy(c->ev_chunk[i]);
   delete c;
   return RTOC_OK;
 }
@@ -307,6 +323,10 @@ int rtoc_set_option(rtoc_ctx* c, int option, int64_t value) {
         }
       return RTOC_ERR_BAD_ARG;
     }
+    case RTOC_OPT_SWEEP_CHUNKS:
+      if (value < 1 || value > RTOC_MAX_CHUNK_EVENTS) return RTOC_ERR_BAD_ARG;
+      c->sweep_chunks = (int)value;
+      return RTOC_OK;
     default:
       return RTOC_ERR_BAD_ARG;
   }
@@ -368,7 +388,7 @@ int rtoc_bind(rtoc_ctx* c, int buffer, void* device_ptr) {
 }
 
 // ---- hot path ---------------------------------------------------------------------------
-static int launch_backward(rtoc_ctx* c) {
+static int launch_backward_range(rtoc_ctx* c, int first, int end, hipStream_t stream) {
   BwdArgs a;
   a.kkt = c->buf[RTOC_BUF_KKT];
   a.kkt_rw = c->buf[RTOC_BUF_KKT];
@@ -377,18 +397,20 @@ static int launch_backward(rtoc_ctx* c) {
   a.status = c->d_status;
   a.prof = c->d_prof;
   a.nstages = c->nstages;
-  a.batch = c->batch;
+  a.batch = end;
+  a.first = first;
   a.writeback = c->writeback;
   a.max_dts0 = c->max_dts0;
   const int v = c->bwd_variant;
   const int ni = c->ks->bwd_inst[v];
-  hipLaunchKernelGGL(c->ks->bwd[v], dim3((c->batch + ni - 1) / ni), dim3(64 * c->ks->bwd_waves[v]),
-                     c->ks->bwd_lds[v], c->stream, a);
+  hipLaunchKernelGGL(c->ks->bwd[v], dim3((end - first + ni - 1) / ni), dim3(64 * c->ks->bwd_waves[v]),
+                     c->ks->bwd_lds[v], stream, a);
   HIP_TRY(hipGetLastError());
   return RTOC_OK;
 }
+static int launch_backward(rtoc_ctx* c) { return launch_backward_range(c, 0, c->batch, c->stream); }
 
-static int launch_forward(rtoc_ctx* c) {
+static int launch_forward_range(rtoc_ctx* c, int first, int end, hipStream_t stream) {
   FwdArgs a;
   a.kkt = c->buf[RTOC_BUF_KKT];
   a.ric = c->buf[RTOC_BUF_RIC];
@@ -396,12 +418,39 @@ static int launch_forward(rtoc_ctx* c) {
   a.dx0 = c->buf[RTOC_BUF_DX0];
   a.grid = c->d_grid;
   a.nstages = c->nstages;
-  a.batch = c->batch;
-  a.kl = c->L.kkt;
-  a.rl = c->L.ric;
-  a.dl = c->L.dir;
-  hipLaunchKernelGGL(c->ks->fwd, dim3(c->batch), dim3(c->ks->fwd_threads), 0, c->stream, a);
+  a.batch = end;
+  a.first = first;
+  hipLaunchKernelGGL(c->ks->fwd, dim3(end - first), dim3(c->ks->fwd_threads), 0, stream, a);
   HIP_TRY(hipGetLastError());
+  return RTOC_OK;
+}
+static int launch_forward(rtoc_ctx* c) { return launch_forward_range(c, 0, c->batch, c->stream); }
+
+// Backward + forward sweep of the whole batch as a two-stream pipeline over instance chunks: the
+// forward recursion of chunk i (HBM-bound, a few small waves per CU) runs under the backward
+// recursion of chunk i+1 (MFMA / LDS-bound, leaves most of the HBM bandwidth idle).  Results are
+// those of rtoc_riccati_backward followed by rtoc_riccati_forward.
+static int launch_sweep(rtoc_ctx* c) {
+  const int nch = (c->sweep_chunks > 0) ? c->sweep_chunks : 1;
+  if (nch == 1) {
+    int rc = launch_backward(c);
+    return rc ? rc : launch_forward(c);
+  }
+  const int per = (((c->batch + nch - 1) / nch) + 3) & ~3;  // whole 4-instance workgroups
+  HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
+  HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+  for (int i = 0; i * per < c->batch; ++i) {
+    const int first = i * per, end = (first + per < c->batch) ? first + per : c->batch;
+    int rc = launch_backward_range(c, first, end, c->stream);
+    if (rc) return rc;
+    hipEvent_t e = c->ev_chunk[i % RTOC_MAX_CHUNK_EVENTS];
+    HIP_TRY(hipEventRecord(e, c->stream));
+    HIP_TRY(hipStreamWaitEvent(c->stream2, e, 0));
+    rc = launch_forward_range(c, first, end, c->stream2);
+    if (rc) return rc;
+  }
+  HIP_TRY(hipEventRecord(c->ev_join, c->stream2));
+  HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
   return RTOC_OK;
 }
 
@@ -472,6 +521,11 @@ int rtoc_riccati_backward(rtoc_ctx* c) {
 int rtoc_riccati_forward(rtoc_ctx* c) {
   CHECK_READY(c);
   return launch_forward(c);
+}
+
+int rtoc_riccati_sweep(rtoc_ctx* c) {
+  CHECK_READY(c);
+  return launch_sweep(c);
 }
 
 static int launch_fill(rtoc_ctx* c, double dt) {
@@ -596,10 +650,7 @@ int rtoc_time_phase(rtoc_ctx* c, int phase, int reps, float* ms) {
       case 1: rc = launch_forward(c); break;
       case 2: rc = launch_condense(c); break;
       case 3: rc = launch_expand(c, 0.995); break;
-      case 4:
-        rc = launch_backward(c);
-        if (!rc) rc = launch_forward(c);
-        break;
+      case 4: rc = launch_sweep(c); break;
       case 5: rc = rtoc_update(c); break;
     }
     if (rc) return rc;

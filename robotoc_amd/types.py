@@ -22,7 +22,7 @@ CDD_FIELDS = ["dIDda", "dIDCdqv", "dCda", "IDC", "Qaa", "Qff", "Qqf", "la", "lf"
 STAT_QUU_NOT_SPD, STAT_S_NOT_SPD, STAT_NAN, STAT_M_NOT_SPD = 1, 2, 4, 8
 
 BUF_KKT, BUF_RIC, BUF_DIR, BUF_CDD, BUF_CON, BUF_DX0, BUF_STEP = range(7)
-OPT_WRITEBACK_KKT, OPT_MAX_DTS0, OPT_BACKWARD_WAVES = 0, 1, 2
+OPT_WRITEBACK_KKT, OPT_MAX_DTS0, OPT_BACKWARD_WAVES, OPT_CONTACT_INV_DAMPING, OPT_SWEEP_CHUNKS = range(5)
 
 
 class Dims(C.Structure):

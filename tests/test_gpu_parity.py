@@ -219,6 +219,36 @@ def test_full_size_batch_properties(oracle):
         ctx.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("chunks", [1, 3, 4, 16])
+def test_pipelined_sweep_equals_backward_then_forward(chunks):
+    """rtoc_riccati_sweep pipelines backward / forward over instance chunks on two streams; the
+    records must be bit-identical to the two calls in sequence (ragged last chunk included)."""
+    from robotoc_amd import capi
+    dims, grids, _ = pr.config_anymal_trot()
+    batch = 203  # not a multiple of the 4-instance workgroup nor of the chunk count
+    out = []
+    for mode in ("seq", "sweep"):
+        ctx = capi.Context(dims, len(grids), batch, 0)
+        try:
+            L = ctx.L
+            ctx.set_grid(grids)
+            ctx.upload(BUF_KKT, pr.make_kkt_batch_tiled(L, grids, batch, unique=7))
+            ctx.upload(BUF_DX0, np.tile(pr.make_dx0(L, 7), (batch // 7 + 1, 1))[:batch])
+            if mode == "seq":
+                ctx.riccati_backward()
+                ctx.riccati_forward()
+            else:
+                ctx.set_sweep_chunks(chunks)
+                ctx.riccati_sweep()
+            assert (ctx.status() == 0).all()
+            out.append((ctx.download_records(BUF_RIC, "ric"), ctx.download_records(BUF_DIR, "dir")))
+        finally:
+            ctx.close()
+    assert np.array_equal(out[0][0], out[1][0])
+    assert np.array_equal(out[0][1], out[1][1])
+
+
 def _compare_records(R, gpu, ref, fields, tol, what, grids=None, skip_terminal=True):
     from helpers import rel_err
     bad = []

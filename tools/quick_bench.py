@@ -24,6 +24,11 @@ def main():
     ctx.time_phase(1, 2)
     ms = ctx.time_phase(1, 5)
     print("forward: %.3f ms/launch" % ms)
+    for ch in (1, 4):
+        ctx.set_sweep_chunks(ch)
+        ctx.time_phase(4, 2)
+        ms = ctx.time_phase(4, 5)
+        print("sweep (backward+forward) chunks=%2d: %.3f ms  -> %.1f sweeps/s" % (ch, ms, batch / ms * 1e3))
     print("status nonzero:", int((ctx.status() != 0).sum()))
     ctx.close()
 
