@@ -226,20 +226,23 @@ __device__ __forceinline__ bool wave_llt(const double* __restrict__ A, double* _
 }
 
 // In-wave Cholesky as wave_llt, and in the same sweep Y = L^-1 by forward substitution on the
-// identity: lane j (< n) carries column j of Y, and the column-j update of Y needs exactly the
-// broadcast factor entries L[k][j] the Cholesky update already has in scalar registers, so the
-// inverse factor costs one extra FMA per (j,k) pair and no extra cross-lane traffic.
+// identity.  Lanes 0..15 carry the rows of G / L, lanes 16..31 the columns of Y (lane 16+j = column
+// j): the column-j step of both is "scale entry j by 1/l_jj, subtract (entry j) x L[k][j] from
+// entry k", with the same broadcast scalars L[k][j], so ONE instruction stream serves both -- the
+// inverse factor costs no instructions beyond the Cholesky's own.
 // Writes L / 1/diag like wave_llt and Y column-major (ld NMAX) to Ydst.  Returns true on failure.
 template <int NMAX, int LD>
 __device__ __forceinline__ bool wave_llt_inv(const double* __restrict__ A, double* __restrict__ Ldst,
                                              double* __restrict__ linv, double* __restrict__ Ydst,
                                              int n, int lane) {
-  double g[NMAX], acc[NMAX];
+  static_assert(NMAX <= 16, "rows of G and columns of Y share one 32-lane group");
+  double g[NMAX];
   const int li = lane < n ? lane : 0;
+  const bool ylane = lane >= 16;
 #pragma unroll
   for (int k = 0; k < NMAX; ++k) {
-    g[k] = (k < n) ? A[li + k * LD] : 0.0;
-    acc[k] = (k == lane) ? 1.0 : 0.0;
+    const double a = (k < n) ? A[li + k * LD] : 0.0;
+    g[k] = ylane ? ((k == lane - 16) ? 1.0 : 0.0) : a;
   }
   bool bad = false;
 #pragma unroll
@@ -248,27 +251,26 @@ __device__ __forceinline__ bool wave_llt_inv(const double* __restrict__ A, doubl
       const double d = readlane_d(g[j], j);
       if (!(d > 0.0)) bad = true;
       const double inv = rsqrt_d(d);
-      const double lij = g[j] * inv;
-      g[j] = lij;
+      const double xj = g[j] * inv;  // L[lane][j] | Y[j][lane-16]
+      g[j] = xj;
       if (lane == j) linv[j] = inv;
-      const double yj = acc[j] * inv;  // Y[j][lane]
-      acc[j] = yj;
 #pragma unroll
       for (int k = j + 1; k < NMAX; ++k) {
         if (k < n) {
-          const double lkj = readlane_d(lij, k);
-          g[k] -= lij * lkj;
-          acc[k] -= lkj * yj;
+          const double lkj = readlane_d(xj, k);
+          g[k] -= xj * lkj;
         }
       }
     }
   }
-  if (lane < NMAX) {
+  if (lane < n) {
 #pragma unroll
-    for (int k = 0; k < NMAX; ++k) {
-      if (lane < n && k < n) Ldst[lane + k * LD] = (k <= lane) ? g[k] : 0.0;
-      Ydst[k + lane * NMAX] = (lane < n && k < n) ? acc[k] : 0.0;
-    }
+    for (int k = 0; k < NMAX; ++k)
+      if (k < n) Ldst[lane + k * LD] = (k <= lane) ? g[k] : 0.0;
+  } else if (ylane && lane < 16 + NMAX) {
+    const int c = lane - 16;
+#pragma unroll
+    for (int k = 0; k < NMAX; ++k) Ydst[k + c * NMAX] = (c < n && k < n) ? g[k] : 0.0;
   }
   return bad;
 }
