@@ -74,7 +74,7 @@ def pmc_traffic(waves, batch):
     PMC counters cannot be collected from inside the timed process; null if the committed pass
     does not match the configuration being run."""
     path = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    if waves not in (0, 2) or batch != PER_GPU_BATCH or not os.path.exists(path):
+    if waves not in (0, 8) or batch != PER_GPU_BATCH or not os.path.exists(path):
         return None
     t = json.load(open(path))
     for k, v in t.items():
@@ -268,7 +268,7 @@ def main():
                        "backward_waves": args.waves},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(args.waves, batch),
-                         "kernel": "riccati_backward_kernel", "kernel_ms": ms_b,
+                         "kernel": "riccati_backward_rs4_kernel" if args.waves in (0, 8) else "riccati_backward_kernel", "kernel_ms": ms_b,
                          "algorithmic_bytes_per_launch": bytes_b,
                          "forward_kernel_ms": ms_f,
                          "forward_achieved": bytes_f / (ms_f * 1e-3) / 1e9,

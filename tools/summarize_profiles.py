@@ -1,0 +1,33 @@
+"""Condense the rocprofv3 outputs of tools/gpu_round.sh (gpurun_out/) into the tracked summaries:
+profiles/<tag>_rocprof_summary.txt and profiles/<tag>_traffic.json (+ bench json, host info)."""
+import collections, csv, json, os, shutil, sys
+
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(R, "gpurun_out")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+note = sys.argv[2] if len(sys.argv) > 2 else ""
+lines = ["# rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-sqp   (%s)" % note,
+         "# Name, Calls, TotalDurationNs, AverageNs, Percentage, MinNs, MaxNs, StdDev"]
+for r in csv.DictReader(open(os.path.join(OUT, "prof_stats", "stats_kernel_stats.csv"))):
+    lines.append(", ".join(r[k] for k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev")))
+traffic = {}
+for cname, d in (("FETCH_SIZE", "prof_fetch/fetch"), ("WRITE_SIZE", "prof_write/write")):
+    acc = collections.OrderedDict()
+    for r in csv.DictReader(open(os.path.join(OUT, d + "_counter_collection.csv"))):
+        if r["Counter_Name"] == cname:
+            acc.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
+    lines.append("# rocprofv3 --pmc %s (own pass); mean per dispatch, unit KB (rocprofv3 FETCH_SIZE/WRITE_SIZE)" % cname)
+    for k, v in acc.items():
+        m = sum(v) / len(v)
+        lines.append("%s, %s, %.1f, n=%d" % (k, cname, m, len(v)))
+        if "rtoc::" in k:
+            short = k.split("(")[0].replace("void ", "")
+            traffic.setdefault(short, {})["fetch_size_kb" if cname == "FETCH_SIZE" else "write_size_kb"] = m
+for k, v in traffic.items():
+    v["hbm_bytes"] = (2.0 * v.get("fetch_size_kb", 0.0) + v.get("write_size_kb", 0.0)) * 1024.0
+    v["note"] = "2*FETCH_SIZE (gfx950 correction, MI355X_MICROARCH.md HBM) + WRITE_SIZE (calibrated on a 295.7 MB torch fill: exact)"
+open(os.path.join(R, "profiles", tag + "_rocprof_summary.txt"), "w").write("\n".join(lines) + "\n")
+json.dump(traffic, open(os.path.join(R, "profiles", tag + "_traffic.json"), "w"), indent=1)
+shutil.copy(os.path.join(OUT, "bench.json"), os.path.join(R, "profiles", tag + "_bench.json"))
+shutil.copy(os.path.join(OUT, "host.txt"), os.path.join(R, "profiles", tag + "_host.txt"))
+print("\n".join(lines[:6])); print(json.dumps(traffic, indent=1))
