@@ -40,6 +40,7 @@ struct CondArgs {
   long long* prof;  // optional cycle stamps of work item 0 (tuning aid)
   double* con;               // constraint records or nullptr
   const rtoc_box_row* rows;  // [nrows] joint-limit rows (device)
+  const int* entry;          // CSR of the rows per primal entry: [2nv+nu+1] offsets, then row ids
   int nrows;
   rtoc_record_layout nl;
   rtoc_record_layout kl, cl;
@@ -276,9 +277,11 @@ __global__ __launch_bounds__(128) void condense_kernel(CondArgs a) {
       const int idx = t < NV ? t : (t < 2 * NV ? t - NV : t - 2 * NV);
       double hess = 0.0, grad = 0.0;
       bool any = false;
-      for (int r = 0; r < a.nrows; ++r) {
+      const int* rowid = a.entry + (2 * NV + NU + 1);
+      for (int e = a.entry[t]; e < a.entry[t + 1]; ++e) {
+        const int r = rowid[e];
         const rtoc_box_row row = a.rows[r];
-        if (row.var == var && row.index == idx && g.time_stage >= row.level) {
+        if (g.time_stage >= row.level) {
           const double slack = nr[no[RTOC_CON_SLACK] + r], dual = nr[no[RTOC_CON_DUAL] + r];
           const double cond = (dual * nr[no[RTOC_CON_RESIDUAL] + r] - nr[no[RTOC_CON_CMPL] + r]) / slack;
           nr[no[RTOC_CON_COND] + r] = cond;

@@ -132,6 +132,7 @@ struct rtoc_ctx {
   bool owned[RTOC_NUM_BUFFERS];
   rtoc_grid* d_grid;
   rtoc_box_row* d_rows;
+  int* d_entry;  // CSR over the primal entries (q_0..,v_0..,u_0..): [ne+1] offsets, then [nrows] row ids
   int nrows;
   uint32_t* d_status;
   long long* d_prof;
@@ -248,6 +249,7 @@ int rtoc_destroy(rtoc_ctx* c) {
     if (c->owned[i] && c->buf[i]) (void)hipFree(c->buf[i]);
   (void)hipFree(c->d_grid);
   if (c->d_rows) (void)hipFree(c->d_rows);
+  if (c->d_entry) (void)hipFree(c->d_entry);
   (void)hipFree(c->d_status);
   if (c->d_prof) (void)hipFree(c->d_prof);
   (void)hipEventDestroy(c->ev0);
@@ -468,6 +470,7 @@ static int launch_condense(rtoc_ctx* c) {
   a.prof = c->d_prof;
   a.con = (c->nrows > 0) ? c->buf[RTOC_BUF_CON] : nullptr;
   a.rows = c->d_rows;
+  a.entry = c->d_entry;
   a.nrows = c->nrows;
   a.nl = c->L.con;
   a.kl = c->L.kkt;
@@ -592,6 +595,20 @@ int rtoc_set_constraint_rows(rtoc_ctx* c, const rtoc_box_row* rows, int nrows) {
     if (rc) return rc;
     if (!c->d_rows) HIP_TRY(hipMalloc((void**)&c->d_rows, sizeof(rtoc_box_row) * c->dims.nc_max));
     HIP_TRY(hipMemcpyAsync(c->d_rows, rows, sizeof(rtoc_box_row) * nrows, hipMemcpyHostToDevice, c->stream));
+    // rows grouped by the primal entry they act on (ascending row index inside a group, i.e. the
+    // order in which the reference's components touch that entry)
+    const int nv = c->dims.nv, ne = 2 * nv + c->dims.nu;
+    std::vector<int> csr(ne + 1 + nrows, 0);
+    auto entry_of = [&](const rtoc_box_row& w) {
+      return w.var == RTOC_VAR_Q ? w.index : (w.var == RTOC_VAR_V ? nv + w.index : 2 * nv + w.index);
+    };
+    for (int r = 0; r < nrows; ++r) csr[entry_of(rows[r]) + 1]++;
+    for (int e = 0; e < ne; ++e) csr[e + 1] += csr[e];
+    std::vector<int> fill(csr.begin(), csr.begin() + ne);
+    for (int r = 0; r < nrows; ++r) csr[ne + 1 + fill[entry_of(rows[r])]++] = r;
+    if (!c->d_entry)
+      HIP_TRY(hipMalloc((void**)&c->d_entry, sizeof(int) * (ne + 1 + c->dims.nc_max)));
+    HIP_TRY(hipMemcpyAsync(c->d_entry, csr.data(), sizeof(int) * csr.size(), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
   }
   c->nrows = nrows;
