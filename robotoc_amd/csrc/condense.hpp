@@ -105,12 +105,16 @@ __device__ __forceinline__ void wave_gemm(int M, int N, int K, double alpha, con
                                           // the same tiles (one read-modify-write of C instead of two):
                                           int M2 = 0, int K2 = 0, double alpha2 = 0.0,
                                           const double* A2 = nullptr, int a2rs = 0, int a2cs = 0,
-                                          const double* B2 = nullptr, int b2rs = 0, int b2cs = 0) {
+                                          const double* B2 = nullptr, int b2rs = 0, int b2cs = 0,
+                                          // optional: C values of this wave's tile pairs, fetched
+                                          // earlier with prefetch_c (same M, N, strides)
+                                          const double (*cpre)[8] = nullptr) {
   const int lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, q = lane >> 4;
   const int tmn = (M + 15) >> 4, tnp = (((N + 15) >> 4) + 1) >> 1, ksn = (K + 3) >> 2;
   // tile pairs (16 rows x 32 columns) are dealt round-robin to the NW waves of the work item
-  for (int tp = wave; tp < tmn * tnp; tp += NW) {
+  int pidx = 0;
+  for (int tp = wave; tp < tmn * tnp; tp += NW, ++pidx) {
     const int tm = tp / tnp, tn = (tp - tm * tnp) * 2;
     const int i = tm * 16 + li;
     const bool iok = i < M;
@@ -125,8 +129,16 @@ __device__ __forceinline__ void wave_gemm(int M, int N, int K, double alpha, con
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = tm * 16 + drow(q, r);
-      c0[r] = (beta != 0.0 && row < M && j0ok) ? C[(size_t)row * crs + (size_t)j0 * ccs] : 0.0;
-      c1[r] = (beta != 0.0 && row < M && j1ok) ? C[(size_t)row * crs + (size_t)j1 * ccs] : 0.0;
+      if (cpre) {
+        c0[r] = cpre[pidx][r];
+        c1[r] = cpre[pidx][4 + r];
+      } else {
+        const bool ok0 = beta != 0.0 && row < M && j0ok, ok1 = beta != 0.0 && row < M && j1ok;
+        const double v0 = C[ok0 ? (size_t)row * crs + (size_t)j0 * ccs : 0];
+        const double v1 = C[ok1 ? (size_t)row * crs + (size_t)j1 * ccs : 0];
+        c0[r] = ok0 ? v0 : 0.0;
+        c1[r] = ok1 ? v1 : 0.0;
+      }
     }
     d4 acc0 = zero4(), acc1 = zero4();
     // four k-steps per trip: 12 operand loads in flight before the 8 MFMAs that consume them
@@ -184,6 +196,34 @@ __device__ __forceinline__ void wave_gemm(int M, int N, int K, double alpha, con
         if (j0ok) C[(size_t)row * crs + (size_t)j0 * ccs] = beta * c0[r] + alpha * acc0[r] + alpha2 * acd0[r];
         if (j1ok) C[(size_t)row * crs + (size_t)j1 * ccs] = beta * c1[r] + alpha * acc1[r] + alpha2 * acd1[r];
       }
+    }
+  }
+}
+
+// The C values wave_gemm<NW> would read-modify-write for (M, N, C, crs, ccs), fetched ahead of time
+// into registers: out[p] holds the p-th tile pair of this wave (MAXP must cover them, compile-time).
+template <int NW, int MAXP>
+__device__ __forceinline__ void prefetch_c(int M, int N, const double* C, int crs, int ccs, int tid,
+                                           double (&out)[MAXP][8]) {
+  const int lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, q = lane >> 4;
+  const int tmn = (M + 15) >> 4, tnp = (((N + 15) >> 4) + 1) >> 1;
+#pragma unroll
+  for (int p = 0; p < MAXP; ++p) {
+    const int tp = wave + p * NW;
+    const bool tok = tp < tmn * tnp;
+    const int tm = tp / tnp, tn = (tp - tm * tnp) * 2;
+    const int j0 = tn * 16 + li, j1 = j0 + 16;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = tm * 16 + drow(q, r);
+      // unconditional loads from clamped addresses + select: a predicated load would be compiled
+      // into a branch with its own s_waitcnt, i.e. one HBM round trip per element
+      const bool ok0 = tok && row < M && j0 < N, ok1 = tok && row < M && j1 < N;
+      const double v0 = C[ok0 ? (size_t)row * crs + (size_t)j0 * ccs : 0];
+      const double v1 = C[ok1 ? (size_t)row * crs + (size_t)j1 * ccs : 0];
+      out[p][r] = ok0 ? v0 : 0.0;
+      out[p][4 + r] = ok1 ? v1 : 0.0;
     }
   }
 }
@@ -303,28 +343,68 @@ __global__ __launch_bounds__(128) void condense_kernel(CondArgs a) {
     }
     __syncthreads();
   }
+  // ================= HBM -> registers: every input field once, all loads in flight together ======
+  // 16 B per lane; odd-sized fields read/write one double of their 64-B padding
+  constexpr int H_L = (NV * NV + 1) / 2, H_D = (LDV * NX + 1) / 2, H_J = (C::NFP * NV + 1) / 2,
+                H_F = (C::NFP * C::NFP + 1) / 2;
+  constexpr int N_L = (H_L + NT - 1) / NT, N_D = (H_D + NT - 1) / NT, N_J = (H_J + NT - 1) / NT,
+                N_F = (H_F + NT - 1) / NT;
+  typedef double dbl2 __attribute__((ext_vector_type(2)));
+  dbl2 gL[N_L], gD[N_D], gJ[N_J], gF[N_F], gQ[N_J];
+  const dbl2 zero2 = {0.0, 0.0};
+  // compile-time trip counts (arrays stay in registers) and unconditional loads from clamped
+  // addresses: every field exists in the max-size record whatever dimf is, and a load under a branch
+  // would get its own s_waitcnt -- one HBM round trip per field
+#define RTOC_LD2(dst, CNT, src, n2)                                              \
+  _Pragma("unroll") for (int k = 0; k < (CNT); ++k) {                            \
+    const int e = lane + k * NT;                                                 \
+    const dbl2 v = reinterpret_cast<const dbl2*>(src)[e < (n2) ? e : 0];         \
+    dst[k] = (e < (n2)) ? v : zero2;                                             \
+  }
+#define RTOC_ST2(dst, src, CNT, n2)                                              \
+  _Pragma("unroll") for (int k = 0; k < (CNT); ++k) {                            \
+    const int e = lane + k * NT;                                                 \
+    if (e < (n2)) reinterpret_cast<dbl2*>(dst)[e] = src[k];                      \
+  }
+  RTOC_LD2(gL, N_L, cr + co[RTOC_CDD_DIDDA], H_L)
+  RTOC_LD2(gD, N_D, cr + co[RTOC_CDD_DIDCDQV], H_D)
+  RTOC_LD2(gJ, N_J, cr + co[RTOC_CDD_DCDA], H_J)
+  RTOC_LD2(gF, N_F, cr + co[RTOC_CDD_QFF], H_F)
+  RTOC_LD2(gQ, N_J, cr + co[RTOC_CDD_QQF], H_J)
+  const int lv_ = lane < NV ? lane : 0, lf_ = lane < nf ? lane : 0, lvf_ = lane < nvf ? lane : 0;
+  const double vQaa = cr[co[RTOC_CDD_QAA] + lv_], vLa = cr[co[RTOC_CDD_LA] + lv_],
+               vHa = cr[co[RTOC_CDD_HA] + lv_], vLf = cr[co[RTOC_CDD_LF] + lf_],
+               vHf = cr[co[RTOC_CDD_HF] + lf_], vIdc = cr[co[RTOC_CDD_IDC] + lvf_];
+  // the Hessian blocks the Schur updates read-modify-write: fetched now (after the PDIPM diagonal
+  // terms above landed), consumed ~100k cycles later -- their HBM latency is off the chain
+  double cQxx[(((NX + 15) / 16) * (((NX + 15) / 16 + 1) / 2) + NW - 1) / NW][8];
+  double cQxu[(((NX + 15) / 16) * (((NU + 15) / 16 + 1) / 2) + NW - 1) / NW][8];
+  double cQuu[(((NU + 15) / 16) * (((NU + 15) / 16 + 1) / 2) + NW - 1) / NW][8];
+  prefetch_c<NW>(NX, NX, Qxx, 1, NX, lane, cQxx);
+  prefetch_c<NW>(NX, NU, Qxu, 1, NX, lane, cQxu);
+  prefetch_c<NW>(NU, NU, Quu, 1, NU, lane, cQuu);
   // inactive rows / columns (dimf < max_dimf) of the stored blocks stay zero, like the reference's
   // max-size backing matrices
   for (int e = lane; e < LDV * LDV; e += NT) Lam[e] = 0.0;
   for (int e = lane; e < LDV * NX; e += NT) LD[e] = 0.0;
-  // ================= HBM -> LDS: every input field once, coalesced 16 B per lane =================
-  copy_g2s_flat<NT>(sL, cr + co[RTOC_CDD_DIDDA], NV * NV, lane);
-  copy_g2s_flat<NT>(D, cr + co[RTOC_CDD_DIDCDQV], LDV * NX, lane);
-  if (!impact && nf > 0) copy_g2s_flat<NT>(sJ, cr + co[RTOC_CDD_DCDA], C::NFP * NV, lane);
-  if (nf > 0) {
-    copy_g2s_flat<NT>(Qff, cr + co[RTOC_CDD_QFF], C::NFP * C::NFP, lane);
-    copy_g2s_flat<NT>(Qqf, cr + co[RTOC_CDD_QQF], NV * C::NFP, lane);
-  }
+  // ================= registers -> LDS =================
+  RTOC_ST2(sL, gL, N_L, H_L)
+  RTOC_ST2(D, gD, N_D, H_D)
+  RTOC_ST2(sJ, gJ, N_J, H_J)
+  RTOC_ST2(Qff, gF, N_F, H_F)
+  RTOC_ST2(Qqf, gQ, N_J, H_J)
+#undef RTOC_LD2
+#undef RTOC_ST2
   if (lane < NV) {
-    Qaa[lane] = cr[co[RTOC_CDD_QAA] + lane];
-    laf[lane] = cr[co[RTOC_CDD_LA] + lane];
-    haf[lane] = cr[co[RTOC_CDD_HA] + lane];
+    Qaa[lane] = vQaa;
+    laf[lane] = vLa;
+    haf[lane] = vHa;
   }
   if (lane < nf) {
-    laf[NV + lane] = -cr[co[RTOC_CDD_LF] + lane];
-    haf[NV + lane] = -cr[co[RTOC_CDD_HF] + lane];
+    laf[NV + lane] = -vLf;
+    haf[NV + lane] = -vHf;
   }
-  if (lane < nvf) IDC[lane] = cr[co[RTOC_CDD_IDC] + lane];
+  if (lane < nvf) IDC[lane] = vIdc;
   __syncthreads();
   // J: dCda (ld NF) on contact grids, dCdv = D[nv:, nv:] (ld LDV) on impact grids
   const double* const J = impact ? D + NV + (size_t)NV * LDV : sJ;
@@ -427,7 +507,7 @@ __global__ __launch_bounds__(128) void condense_kernel(CondArgs a) {
   // Each block gets ONE read-modify-write: the Qqf corrections (:92-93,:99-100,:106-107), which touch
   // the rows < NV only, ride along as a second product in the same tiles.
   wave_gemm<NW>(NX, NX, nvf, -1.0, LD, LDV, 1, Qafqv, 1, LDV, 1.0, Qxx, 1, NX, lane,
-                nf > 0 ? NV : 0, nf, 1.0, Qqf, 1, NV, LD + NV, 1, LDV);
+                nf > 0 ? NV : 0, nf, 1.0, Qqf, 1, NV, LD + NV, 1, LDV, cQxx);
   if (!impact) {
     if (NP > 0) {
       wave_gemm<NW>(NX, NP, nvf, -1.0, LD, LDV, 1, Qafu, 1, LDV, 0.0, Qxup, 1, NX, lane,
@@ -435,8 +515,9 @@ __global__ __launch_bounds__(128) void condense_kernel(CondArgs a) {
       wave_gemm<NW>(NP, NU, nvf, 1.0, Lam, 1, LDV, Qafu + NP * LDV, 1, LDV, 0.0, Quuptr, 1, NP, lane);
     }
     wave_gemm<NW>(NX, NU, nvf, -1.0, LD, LDV, 1, Qafu + NP * LDV, 1, LDV, 1.0, Qxu, 1, NX, lane,
-                  nf > 0 ? NV : 0, nf, -1.0, Qqf, 1, NV, Lam + NV + NP * LDV, 1, LDV);
-    wave_gemm<NW>(NU, NU, nvf, 1.0, Lam + NP, 1, LDV, Qafu + NP * LDV, 1, LDV, 1.0, Quu, 1, NU, lane);
+                  nf > 0 ? NV : 0, nf, -1.0, Qqf, 1, NV, Lam + NV + NP * LDV, 1, LDV, cQxu);
+    wave_gemm<NW>(NU, NU, nvf, 1.0, Lam + NP, 1, LDV, Qafu + NP * LDV, 1, LDV, 1.0, Quu, 1, NU, lane, 0, 0,
+                  0.0, nullptr, 0, 0, nullptr, 0, 0, cQuu);
   }
   // gradients: one lane per entry, every term of an entry in the same lane (:110-113,:123-130,:156-163)
   for (int i = lane; i < NX; i += NT) {
