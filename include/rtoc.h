@@ -83,7 +83,9 @@ enum rtoc_buffer {
   RTOC_BUF_CON = 4,  /* [batch][stages][con.stride]  ConstraintComponentData of the PDIPM rows */
   RTOC_BUF_DX0 = 5,  /* [batch][nx]                  initial state direction d[0].dx */
   RTOC_BUF_STEP = 6, /* [batch][2]                   max primal / dual step sizes */
-  RTOC_NUM_BUFFERS = 7
+  RTOC_BUF_SE3 = 7,  /* [batch][stages][RTOC_SE3_STRIDE] floating base: Fqq_inv, Fqq_prev_inv of
+                      * StateEquationData (include/robotoc/dynamics/state_equation_data.hpp), 6x6 column-major each */
+  RTOC_NUM_BUFFERS = 8
 };
 
 /* kernel-variant knobs (rtoc_set_option) */
@@ -148,6 +150,19 @@ int rtoc_unconstr_forward(rtoc_ctx* ctx, double dt);
 int rtoc_expand(rtoc_ctx* ctx, double fraction_to_boundary_rule);
 /* slack/dual update with the per-instance step sizes in RTOC_BUF_STEP. */
 int rtoc_update(rtoc_ctx* ctx);
+
+/* ---- floating-base corrections (need RTOC_BUF_SE3; no-ops of the reference for fixed bases) ----
+ * correctLinearizeStateEquation / correctLinearizeImpactStateEquation on every grid point
+ * (src/dynamics/state_equation.cpp:68-88, impact_state_equation.cpp:57-72).  rtoc_condense calls it
+ * itself after the dynamics condensation once RTOC_BUF_SE3 has been uploaded or bound
+ * (IntermediateStage::evalKKT order, intermediate_stage.cpp:134-139). */
+int rtoc_correct_state_equation(rtoc_ctx* ctx);
+/* correctCostateDirection on every grid point (state_equation.cpp:91-96); rtoc_expand calls it
+ * itself after the dual expansion (intermediate_stage.cpp:171-173). */
+int rtoc_correct_costate_direction(rtoc_ctx* ctx);
+/* computeInitialStateDirection's floating-base part on RTOC_BUF_DX0, in place
+ * (state_equation.cpp:99-109): upload dq0 = q0 (-) q, dv0 = v0 - v, then call this once. */
+int rtoc_compute_initial_state_direction(rtoc_ctx* ctx);
 
 /* Per-instance status words (RTOC_STAT_* bits), synchronises the stream. */
 int rtoc_status(rtoc_ctx* ctx, uint32_t* host_flags, int count);

@@ -191,6 +191,11 @@ enum {
   RTOC_CON_NFIELDS
 };
 
+/* ---- RTOC_BUF_SE3 record: StateEquationData::Fqq_inv, Fqq_prev_inv (6x6, column-major) ---- */
+#define RTOC_SE3_FQQ_INV 0
+#define RTOC_SE3_FQQ_PREV_INV 36
+#define RTOC_SE3_STRIDE 72
+
 typedef struct rtoc_record_layout {
   int off[24]; /* field offsets in doubles (indexed by the enums above) */
   int stride;  /* record size in doubles                                */

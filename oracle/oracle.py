@@ -64,6 +64,8 @@ def lib():
         _LIB.orc_expand_batch.argtypes = [C.POINTER(Layout), C.POINTER(Grid), C.c_int, C.c_int, dp, dp]
         _LIB.orc_pdipm_batch.argtypes = [C.POINTER(Layout), C.POINTER(Grid), C.c_int, C.c_int,
                                          C.POINTER(BoxRow), C.c_int, dp, dp, dp, C.c_double, dp, C.c_int]
+        _LIB.orc_state_correction_batch.argtypes = [C.POINTER(Layout), C.POINTER(Grid), C.c_int, C.c_int,
+                                                    dp, dp, dp, dp]
     return _LIB
 
 
@@ -189,3 +191,12 @@ def pdipm_update_batch(L, grids, rows, con, steps):
     steps = np.ascontiguousarray(steps, dtype=np.float64)
     lib().orc_pdipm_batch(C.byref(L), grid_array(grids), len(grids), con.shape[0], _rows(rows), len(rows),
                           None, _p(con), None, 0.0, _p(steps), 2)
+
+
+def state_correction_batch(L, grids, se3, kkt=None, dirs=None, dx0=None):
+    """correctLinearize(Impact)StateEquation on kkt, correctCostateDirection on dirs,
+    computeInitialStateDirection on dx0 (each optional), state_equation.cpp:68-109."""
+    lib().orc_state_correction_batch(C.byref(L), grid_array(grids), len(grids), se3.shape[0], _p(se3),
+                                     _p(kkt) if kkt is not None else None,
+                                     _p(dirs) if dirs is not None else None,
+                                     _p(dx0) if dx0 is not None else None)

@@ -474,3 +474,80 @@ void orc_pdipm_batch(const rtoc_layout* L, const rtoc_grid* grid, int nstages, i
     }
   }
 }
+
+/* ======================================================================================
+ * Floating-base corrections of the linearised state equation
+ * (src/dynamics/state_equation.cpp:68-109, src/dynamics/impact_state_equation.cpp:57-72).
+ * se3 record: Fqq_inv (6x6 col-major) at RTOC_SE3_FQQ_INV, Fqq_prev_inv at RTOC_SE3_FQQ_PREV_INV.
+ * ====================================================================================== */
+static void neg_matmul6(const double* inv, const double* in, int ldin, double* out, int ldout, int ncols) {
+  /* out = -inv * in  (state_equation.cpp:81: noalias() = -Fqq_inv * Fqq_tmp) */
+  for (int j = 0; j < ncols; ++j)
+    for (int i = 0; i < 6; ++i) {
+      double acc = 0.0;
+      for (int k = 0; k < 6; ++k) acc += inv[i + 6 * k] * in[k + (size_t)ldin * j];
+      out[i + (size_t)ldout * j] = -acc;
+    }
+}
+
+/* correctLinearizeStateEquation (:68-88) / correctLinearizeImpactStateEquation (impact :57-72) */
+void orc_correct_state_equation_stage(const rtoc_layout* L, const rtoc_grid* g, const double* se3_rec,
+                                      double* kkt_rec) {
+  if (g->type == RTOC_GRID_TERMINAL) return;
+  const int nx = L->nx, nv = L->dims.nv;
+  const double* inv = se3_rec + RTOC_SE3_FQQ_INV;
+  double* Fxx = kkt_rec + L->kkt.off[RTOC_KKT_FXX];
+  double* Fx = kkt_rec + L->kkt.off[RTOC_KKT_FX];
+  double* fx = kkt_rec + L->kkt.off[RTOC_KKT_FFX];
+  double tmp[36], v[6];
+  for (int j = 0; j < 6; ++j)
+    for (int i = 0; i < 6; ++i) tmp[i + 6 * j] = Fxx[i + (size_t)nx * j]; /* Fqq_tmp (:80) */
+  neg_matmul6(inv, tmp, 6, Fxx, nx, 6);                                    /* (:81) */
+  if (g->type != RTOC_GRID_IMPACT)
+    for (int j = 0; j < 6; ++j)
+      for (int i = 0; i < 6; ++i) Fxx[i + (size_t)nx * (nv + j)] = -g->dt * inv[i + 6 * j]; /* (:82) */
+  for (int i = 0; i < 6; ++i) v[i] = Fx[i];
+  neg_matmul6(inv, v, 6, Fx, nx, 1); /* (:83-84) */
+  if (g->type != RTOC_GRID_IMPACT) {
+    for (int i = 0; i < 6; ++i) v[i] = fx[i];
+    neg_matmul6(inv, v, 6, fx, nx, 1); /* (:85-86) */
+  }
+}
+
+/* correctCostateDirection (:91-96): dlmd.head<6>() = -Fqq_prev_inv^T dlmd.head<6>() */
+void orc_correct_costate_stage(const rtoc_layout* L, const double* se3_rec, double* dir_rec) {
+  const double* inv = se3_rec + RTOC_SE3_FQQ_PREV_INV;
+  double* dl = dir_rec + L->dir.off[RTOC_DIR_DLMDGMM];
+  double t[6];
+  for (int i = 0; i < 6; ++i) {
+    double acc = 0.0;
+    for (int k = 0; k < 6; ++k) acc += inv[k + 6 * i] * dl[k];
+    t[i] = acc;
+  }
+  for (int i = 0; i < 6; ++i) dl[i] = -t[i];
+}
+
+/* computeInitialStateDirection, floating-base part (:99-109) */
+void orc_initial_state_direction(const double* se3_rec0, double* dx0) {
+  const double* inv = se3_rec0 + RTOC_SE3_FQQ_PREV_INV;
+  double t[6];
+  for (int i = 0; i < 6; ++i) {
+    double acc = 0.0;
+    for (int k = 0; k < 6; ++k) acc += inv[i + 6 * k] * dx0[k];
+    t[i] = acc;
+  }
+  for (int i = 0; i < 6; ++i) dx0[i] = -t[i];
+}
+
+void orc_state_correction_batch(const rtoc_layout* L, const rtoc_grid* grid, int nstages, int batch,
+                                const double* se3, double* kkt, double* dir, double* dx0) {
+#pragma omp parallel for schedule(static)
+  for (int b = 0; b < batch; ++b) {
+    for (int i = 0; i < nstages; ++i) {
+      const double* sr = se3 + ((size_t)b * nstages + i) * RTOC_SE3_STRIDE;
+      if (kkt) orc_correct_state_equation_stage(L, &grid[i], sr, kkt + ((size_t)b * nstages + i) * L->kkt.stride);
+      if (dir) orc_correct_costate_stage(L, sr, dir + ((size_t)b * nstages + i) * L->dir.stride);
+    }
+    if (dx0) orc_initial_state_direction(se3 + (size_t)b * nstages * RTOC_SE3_STRIDE, dx0 + (size_t)b * L->nx);
+  }
+}

@@ -74,6 +74,8 @@ def lib():
         L.rtoc_buffer_count.restype = C.c_size_t
         L.rtoc_bind.argtypes = [vp, C.c_int, vp]
         for f in ("rtoc_condense", "rtoc_riccati_backward", "rtoc_riccati_forward", "rtoc_riccati_sweep", "rtoc_update",
+                  "rtoc_correct_state_equation", "rtoc_correct_costate_direction",
+                  "rtoc_compute_initial_state_direction",
                   "rtoc_clear_status", "rtoc_sync"):
             getattr(L, f).argtypes = [vp]
         L.rtoc_unconstr_backward.argtypes = [vp, C.c_double]
@@ -190,6 +192,15 @@ class Context:
 
     def set_sweep_chunks(self, n):
         _chk(lib().rtoc_set_option(self._h, OPT_SWEEP_CHUNKS, int(n)))
+
+    def correct_state_equation(self):
+        _chk(lib().rtoc_correct_state_equation(self._h))
+
+    def correct_costate_direction(self):
+        _chk(lib().rtoc_correct_costate_direction(self._h))
+
+    def compute_initial_state_direction(self):
+        _chk(lib().rtoc_compute_initial_state_direction(self._h))
 
     def unconstr_backward(self, dt):
         _chk(lib().rtoc_unconstr_backward(self._h, dt))

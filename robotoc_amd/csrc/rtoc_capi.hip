@@ -11,6 +11,7 @@
 
 #include "../../include/rtoc.h"
 #include "condense.hpp"
+#include "state_equation.hpp"
 #include "riccati_backward.hpp"
 #include "riccati_backward_rs.hpp"
 #include "riccati_forward.hpp"
@@ -217,6 +218,7 @@ int rtoc_create(const rtoc_dims* dims, int max_stages, int batch, int device, rt
   c->count[RTOC_BUF_CON] = per * (size_t)c->L.con.stride;
   c->count[RTOC_BUF_DX0] = (size_t)batch * c->L.nx;
   c->count[RTOC_BUF_STEP] = (size_t)batch * 2;
+  c->count[RTOC_BUF_SE3] = per * RTOC_SE3_STRIDE;
   for (int i = 0; i < RTOC_NUM_BUFFERS; ++i) {
     // the CDD / CON buffers are large; they are allocated lazily on first use (upload / bind / condense)
     c->buf[i] = nullptr;
@@ -511,9 +513,53 @@ static int launch_expand(rtoc_ctx* c, double tau) {
   if ((c)->nstages < 2) return RTOC_ERR_NOT_READY; \
   HIP_TRY(hipSetDevice((c)->device));
 
+static int launch_state_correction(rtoc_ctx* c, int mode) {
+  if (!c->buf[RTOC_BUF_SE3]) return RTOC_ERR_BAD_ARG;
+  SeArgs a;
+  a.kkt = c->buf[RTOC_BUF_KKT];
+  a.dir = c->buf[RTOC_BUF_DIR];
+  a.dx0 = c->buf[RTOC_BUF_DX0];
+  a.se3 = c->buf[RTOC_BUF_SE3];
+  a.grid = c->d_grid;
+  a.nstages = c->nstages;
+  a.batch = c->batch;
+  a.kl = c->L.kkt;
+  a.dl = c->L.dir;
+  a.nx = c->L.nx;
+  const int nblocks = (mode == 2) ? c->batch : c->batch * c->nstages;
+  if (mode == 0)
+    hipLaunchKernelGGL(state_correction_kernel<0>, dim3(nblocks), dim3(64), 0, c->stream, a);
+  else if (mode == 1)
+    hipLaunchKernelGGL(state_correction_kernel<1>, dim3(nblocks), dim3(64), 0, c->stream, a);
+  else
+    hipLaunchKernelGGL(state_correction_kernel<2>, dim3(nblocks), dim3(64), 0, c->stream, a);
+  HIP_TRY(hipGetLastError());
+  return RTOC_OK;
+}
+
+int rtoc_correct_state_equation(rtoc_ctx* c) {
+  CHECK_READY(c);
+  if (c->dims.np != 6) return RTOC_ERR_BAD_ARG;  // floating base only (hasFloatingBase())
+  return launch_state_correction(c, 0);
+}
+
+int rtoc_correct_costate_direction(rtoc_ctx* c) {
+  CHECK_READY(c);
+  if (c->dims.np != 6) return RTOC_ERR_BAD_ARG;
+  return launch_state_correction(c, 1);
+}
+
+int rtoc_compute_initial_state_direction(rtoc_ctx* c) {
+  CHECK_READY(c);
+  if (c->dims.np != 6) return RTOC_ERR_BAD_ARG;
+  return launch_state_correction(c, 2);
+}
+
 int rtoc_condense(rtoc_ctx* c) {
   CHECK_READY(c);
-  return launch_condense(c);
+  int rc = launch_condense(c);
+  if (!rc && c->buf[RTOC_BUF_SE3] && c->dims.np == 6) rc = launch_state_correction(c, 0);
+  return rc;
 }
 
 int rtoc_riccati_backward(rtoc_ctx* c) {
@@ -560,7 +606,9 @@ int rtoc_unconstr_forward(rtoc_ctx* c, double dt) {
 int rtoc_expand(rtoc_ctx* c, double tau) {
   CHECK_READY(c);
   if (!(tau > 0.0 && tau <= 1.0)) return RTOC_ERR_BAD_ARG;
-  return launch_expand(c, tau);
+  int rc = launch_expand(c, tau);
+  if (!rc && c->buf[RTOC_BUF_SE3] && c->dims.np == 6) rc = launch_state_correction(c, 1);
+  return rc;
 }
 
 int rtoc_update(rtoc_ctx* c) {
