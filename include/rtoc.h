@@ -146,6 +146,15 @@ int rtoc_riccati_forward(rtoc_ctx* ctx);
 int rtoc_riccati_sweep(rtoc_ctx* ctx);
 int rtoc_unconstr_backward(rtoc_ctx* ctx, double dt);
 int rtoc_unconstr_forward(rtoc_ctx* ctx, double dt);
+/* UnconstrDynamics::condenseUnconstrDynamics on every non-terminal grid point
+ * (src/dynamics/unconstr_dynamics.cpp:67-88).  Records: KKT.Quu/lu/Qxu hold Qaa/la/[Qqa;Qva] (the
+ * acceleration is the Riccati control); CDD.dIDCdqv = [dID_dq | dID_dv], CDD.dIDda = dID_da,
+ * CDD.IDC = ID, CDD.Qaa = diag(Quu) and CDD.la = lu of the torque cost.  nu == nv, nf_max == 0 only. */
+int rtoc_unconstr_condense(rtoc_ctx* ctx);
+/* UnconstrDynamics::expandPrimal + expandDual (unconstr_dynamics.cpp:91-104) after
+ * rtoc_unconstr_forward: DIR.daf <- da (the Riccati control), DIR.du <- torque direction,
+ * DIR.dbetamu <- dbeta. */
+int rtoc_unconstr_expand(rtoc_ctx* ctx, double dt);
 /* expandPrimal + fraction-to-boundary + expandDual; step sizes land in RTOC_BUF_STEP. */
 int rtoc_expand(rtoc_ctx* ctx, double fraction_to_boundary_rule);
 /* slack/dual update with the per-instance step sizes in RTOC_BUF_STEP. */

@@ -66,6 +66,8 @@ def lib():
                                          C.POINTER(BoxRow), C.c_int, dp, dp, dp, C.c_double, dp, C.c_int]
         _LIB.orc_state_correction_batch.argtypes = [C.POINTER(Layout), C.POINTER(Grid), C.c_int, C.c_int,
                                                     dp, dp, dp, dp]
+        _LIB.orc_unconstr_dynamics_batch.argtypes = [C.POINTER(Layout), C.c_int, C.c_int, dp, dp, dp,
+                                                     C.c_double, C.c_int]
     return _LIB
 
 
@@ -200,3 +202,13 @@ def state_correction_batch(L, grids, se3, kkt=None, dirs=None, dx0=None):
                                      _p(kkt) if kkt is not None else None,
                                      _p(dirs) if dirs is not None else None,
                                      _p(dx0) if dx0 is not None else None)
+
+
+def unconstr_condense_batch(L, nstages, kkt, cdd):
+    """UnconstrDynamics::condenseUnconstrDynamics on every non-terminal grid point."""
+    lib().orc_unconstr_dynamics_batch(C.byref(L), nstages, kkt.shape[0], _p(kkt), _p(cdd), None, 1.0, 0)
+
+
+def unconstr_expand_batch(L, nstages, cdd, dirs, dt):
+    """UnconstrDynamics::expandPrimal + expandDual on every non-terminal grid point."""
+    lib().orc_unconstr_dynamics_batch(C.byref(L), nstages, cdd.shape[0], None, _p(cdd), _p(dirs), dt, 1)

@@ -551,3 +551,102 @@ void orc_state_correction_batch(const rtoc_layout* L, const rtoc_grid* grid, int
     if (dx0) orc_initial_state_direction(se3 + (size_t)b * nstages * RTOC_SE3_STRIDE, dx0 + (size_t)b * L->nx);
   }
 }
+
+/* ======================================================================================
+ * UnconstrDynamics (src/dynamics/unconstr_dynamics.cpp:67-104).  Record conventions as in
+ * include/rtoc.h (rtoc_unconstr_condense): KKT.Quu/lu/Qxu = Qaa/la/[Qqa;Qva]; CDD.dIDCdqv =
+ * [dID_dq | dID_dv], CDD.dIDda = dID_da, CDD.IDC = ID, CDD.Qaa = diag(Quu), CDD.la = lu (torques).
+ * ====================================================================================== */
+void orc_unconstr_condense_stage(const rtoc_layout* L, double* kkt_rec, const double* cdd_rec) {
+  const int nv = L->dims.nv, nx = L->nx;
+  const double* dq = cdd_rec + L->cdd.off[RTOC_CDD_DIDCDQV];
+  const double* dv = dq + (size_t)nv * nv;
+  const double* da = cdd_rec + L->cdd.off[RTOC_CDD_DIDDA];
+  const double* ID = cdd_rec + L->cdd.off[RTOC_CDD_IDC];
+  const double* w = cdd_rec + L->cdd.off[RTOC_CDD_QAA];
+  const double* lut = cdd_rec + L->cdd.off[RTOC_CDD_LA];
+  double* Qxx = kkt_rec + L->kkt.off[RTOC_KKT_QXX];
+  double* Qxu = kkt_rec + L->kkt.off[RTOC_KKT_QXU];
+  double* Qaa = kkt_rec + L->kkt.off[RTOC_KKT_QUU];
+  double* lx = kkt_rec + L->kkt.off[RTOC_KKT_LX];
+  double* la = kkt_rec + L->kkt.off[RTOC_KKT_LU];
+  double luc[64];
+  for (int i = 0; i < nv; ++i) luc[i] = lut[i] + w[i] * ID[i]; /* (:70-71) */
+  for (int c = 0; c < nv; ++c) {                               /* (:72-74) */
+    double aq = 0.0, av = 0.0, aa = 0.0;
+    for (int i = 0; i < nv; ++i) {
+      aq += dq[i + (size_t)c * nv] * luc[i];
+      av += dv[i + (size_t)c * nv] * luc[i];
+      aa += da[i + (size_t)c * nv] * luc[i];
+    }
+    lx[c] += aq;
+    lx[nv + c] += av;
+    la[c] += aa;
+  }
+  for (int c = 0; c < nv; ++c)
+    for (int r = 0; r < nv; ++r) {
+      double qq = 0.0, qv = 0.0, vv = 0.0, aa = 0.0, qu = 0.0, vu = 0.0;
+      for (int i = 0; i < nv; ++i) {
+        qq += dq[i + (size_t)r * nv] * (w[i] * dq[i + (size_t)c * nv]); /* dID_dq^T Quu_dID_dq (:79) */
+        qv += dq[i + (size_t)r * nv] * (w[i] * dv[i + (size_t)c * nv]); /* (:80) */
+        vv += dv[i + (size_t)r * nv] * (w[i] * dv[i + (size_t)c * nv]); /* (:82) */
+        aa += da[i + (size_t)r * nv] * (w[i] * da[i + (size_t)c * nv]); /* (:83) */
+        qu += (w[i] * dq[i + (size_t)r * nv]) * da[i + (size_t)c * nv]; /* Quu_dID_dq^T dID_da (:86) */
+        vu += (w[i] * dv[i + (size_t)r * nv]) * da[i + (size_t)c * nv]; /* (:87) */
+      }
+      const double qqv = Qxx[r + (size_t)(nv + c) * nx] + qv;
+      Qxx[r + (size_t)c * nx] += qq;
+      Qxx[r + (size_t)(nv + c) * nx] = qqv;
+      Qxx[(nv + c) + (size_t)r * nx] = qqv; /* Qvq = Qqv^T (:81) */
+      Qxx[(nv + r) + (size_t)(nv + c) * nx] += vv;
+      Qaa[r + (size_t)c * nv] += aa;
+      Qxu[r + (size_t)c * nx] = qu;
+      Qxu[(nv + r) + (size_t)c * nx] = vu;
+    }
+}
+
+/* expandPrimal (:91-96) + expandDual (:99-104) */
+void orc_unconstr_expand_stage(const rtoc_layout* L, const double* cdd_rec, double* dir_rec, double dt) {
+  const int nv = L->dims.nv;
+  const double* dq = cdd_rec + L->cdd.off[RTOC_CDD_DIDCDQV];
+  const double* dv = dq + (size_t)nv * nv;
+  const double* da = cdd_rec + L->cdd.off[RTOC_CDD_DIDDA];
+  const double* ID = cdd_rec + L->cdd.off[RTOC_CDD_IDC];
+  const double* w = cdd_rec + L->cdd.off[RTOC_CDD_QAA];
+  const double* lut = cdd_rec + L->cdd.off[RTOC_CDD_LA];
+  const double* dx = dir_rec + L->dir.off[RTOC_DIR_DX];
+  double* du = dir_rec + L->dir.off[RTOC_DIR_DU];
+  double* daf = dir_rec + L->dir.off[RTOC_DIR_DAF];
+  double* dbeta = dir_rec + L->dir.off[RTOC_DIR_DBETAMU];
+  double dacc[64];
+  for (int i = 0; i < nv; ++i) {
+    dacc[i] = du[i]; /* the Riccati control is the acceleration direction */
+    daf[i] = dacc[i];
+  }
+  for (int i = 0; i < nv; ++i) {
+    double t = ID[i], acc = 0.0;
+    for (int k = 0; k < nv; ++k) acc += dq[i + (size_t)k * nv] * dx[k];
+    t += acc;
+    acc = 0.0;
+    for (int k = 0; k < nv; ++k) acc += dv[i + (size_t)k * nv] * dx[nv + k];
+    t += acc;
+    acc = 0.0;
+    for (int k = 0; k < nv; ++k) acc += da[i + (size_t)k * nv] * dacc[k];
+    t += acc;
+    du[i] = t;
+    dbeta[i] = (lut[i] + w[i] * t) / dt;
+  }
+}
+
+void orc_unconstr_dynamics_batch(const rtoc_layout* L, int nstages, int batch, double* kkt, double* cdd,
+                                 double* dir, double dt, int expand) {
+#pragma omp parallel for schedule(static)
+  for (int b = 0; b < batch; ++b)
+    for (int i = 0; i < nstages - 1; ++i) {
+      const size_t rec = (size_t)b * nstages + i;
+      if (!expand)
+        orc_unconstr_condense_stage(L, kkt + rec * L->kkt.stride, cdd + rec * L->cdd.stride);
+      else
+        orc_unconstr_expand_stage(L, cdd + rec * L->cdd.stride, dir + rec * L->dir.stride, dt);
+    }
+}

@@ -75,11 +75,12 @@ def lib():
         L.rtoc_bind.argtypes = [vp, C.c_int, vp]
         for f in ("rtoc_condense", "rtoc_riccati_backward", "rtoc_riccati_forward", "rtoc_riccati_sweep", "rtoc_update",
                   "rtoc_correct_state_equation", "rtoc_correct_costate_direction",
-                  "rtoc_compute_initial_state_direction",
+                  "rtoc_compute_initial_state_direction", "rtoc_unconstr_condense",
                   "rtoc_clear_status", "rtoc_sync"):
             getattr(L, f).argtypes = [vp]
         L.rtoc_unconstr_backward.argtypes = [vp, C.c_double]
         L.rtoc_unconstr_forward.argtypes = [vp, C.c_double]
+        L.rtoc_unconstr_expand.argtypes = [vp, C.c_double]
         L.rtoc_expand.argtypes = [vp, C.c_double]
         L.rtoc_status.argtypes = [vp, C.POINTER(C.c_uint32), C.c_int]
         L.rtoc_time_phase.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float)]
@@ -201,6 +202,12 @@ class Context:
 
     def compute_initial_state_direction(self):
         _chk(lib().rtoc_compute_initial_state_direction(self._h))
+
+    def unconstr_condense(self):
+        _chk(lib().rtoc_unconstr_condense(self._h))
+
+    def unconstr_expand(self, dt):
+        _chk(lib().rtoc_unconstr_expand(self._h, dt))
 
     def unconstr_backward(self, dt):
         _chk(lib().rtoc_unconstr_backward(self._h, dt))

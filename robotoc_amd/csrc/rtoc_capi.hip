@@ -12,6 +12,7 @@
 #include "../../include/rtoc.h"
 #include "condense.hpp"
 #include "state_equation.hpp"
+#include "unconstr_dynamics.hpp"
 #include "riccati_backward.hpp"
 #include "riccati_backward_rs.hpp"
 #include "riccati_forward.hpp"
@@ -37,6 +38,7 @@ static void ctx_set_err(hipError_t e, int line) {
 typedef void (*bwd_fn)(BwdArgs);
 typedef void (*fwd_fn)(FwdArgs);
 typedef void (*fill_fn)(FillArgs);
+typedef void (*ud_fn)(UdArgs);
 typedef void (*cond_fn)(CondArgs);
 typedef void (*expd_fn)(ExpArgs);
 
@@ -51,6 +53,7 @@ struct KernelSet {
   fwd_fn fwd;
   int fwd_threads;
   fill_fn fill;
+  ud_fn ucond, uexp;  // UnconstrDynamics condense / expand
   cond_fn cond;
   int cond_threads, cond_lds;
   expd_fn expd;
@@ -93,6 +96,8 @@ static KernelSet make_set() {
   k.fwd_threads = 64 * NWF;
   k.dl = StaticLayout<NV, NU, NS>::make().dir;
   k.fill = unconstr_fill_kernel<NV>;
+  k.ucond = unconstr_condense_kernel<NV>;
+  k.uexp = unconstr_expand_kernel<NV>;
   constexpr int NF = NS;  // nf_max == ns_max for all supported robots
   k.cond = condense_kernel<NV, NU, NF, NS>;
   k.cond_threads = CondCfg<NV, NU, NF, NS>::NT;
@@ -595,6 +600,37 @@ int rtoc_unconstr_backward(rtoc_ctx* c, double dt) {
   int rc = launch_fill(c, dt);
   if (rc) return rc;
   return launch_backward(c);
+}
+
+static int launch_unconstr_dynamics(rtoc_ctx* c, bool expand, double dt) {
+  if (c->dims.nu != c->dims.nv || c->dims.nf_max != 0) return RTOC_ERR_BAD_ARG;
+  int rc = ensure_buffer(c, RTOC_BUF_CDD);
+  if (rc) return rc;
+  UdArgs a;
+  a.kkt = c->buf[RTOC_BUF_KKT];
+  a.cdd = c->buf[RTOC_BUF_CDD];
+  a.dir = c->buf[RTOC_BUF_DIR];
+  a.nstages = c->nstages;
+  a.batch = c->batch;
+  a.dt = dt;
+  a.kl = c->L.kkt;
+  a.cl = c->L.cdd;
+  a.dl = c->L.dir;
+  hipLaunchKernelGGL(expand ? c->ks->uexp : c->ks->ucond, dim3(c->batch * (c->nstages - 1)), dim3(64), 0,
+                     c->stream, a);
+  HIP_TRY(hipGetLastError());
+  return RTOC_OK;
+}
+
+int rtoc_unconstr_condense(rtoc_ctx* c) {
+  CHECK_READY(c);
+  return launch_unconstr_dynamics(c, false, 1.0);
+}
+
+int rtoc_unconstr_expand(rtoc_ctx* c, double dt) {
+  CHECK_READY(c);
+  if (!(dt > 0.0)) return RTOC_ERR_BAD_ARG;
+  return launch_unconstr_dynamics(c, true, dt);
 }
 
 int rtoc_unconstr_forward(rtoc_ctx* c, double dt) {
