@@ -85,7 +85,9 @@ enum rtoc_buffer {
   RTOC_BUF_STEP = 6, /* [batch][2]                   max primal / dual step sizes */
   RTOC_BUF_SE3 = 7,  /* [batch][stages][RTOC_SE3_STRIDE] floating base: Fqq_inv, Fqq_prev_inv of
                       * StateEquationData (include/robotoc/dynamics/state_equation_data.hpp), 6x6 column-major each */
-  RTOC_NUM_BUFFERS = 8
+  RTOC_BUF_CONE = 8, /* [batch][stages][rtoc_cone_stride(nv, max_contacts)] friction-cone Jacobians of the
+                      * active contacts (rtoc_layout.h); exists after rtoc_set_friction_cones */
+  RTOC_NUM_BUFFERS = 9
 };
 
 /* kernel-variant knobs (rtoc_set_option) */
@@ -137,6 +139,15 @@ int rtoc_bind(rtoc_ctx* ctx, int buffer, void* device_ptr);
  * instances and grids (the stage mask follows rtoc_box_row::level).  nrows <= dims.nc_max.
  * Mirrors Constraints::add(...) of the six joint-limit components (examples/anymal/trot.cpp:134-146). */
 int rtoc_set_constraint_rows(rtoc_ctx* ctx, const rtoc_box_row* rows, int nrows);
+
+/* Linearised friction cones (FrictionCone / ImpactFrictionCone, src/constraints/friction_cone.cpp):
+ * 5 PDIPM rows per active contact with dense Jacobians (RTOC_BUF_CONE).  Their
+ * ConstraintComponentData occupy the last 5*max_contacts rows of the RTOC_BUF_CON record
+ * (row nc_max - 5*max_contacts + 5k + j for the k-th ACTIVE contact of the grid point), so
+ * nrows + 5*max_contacts <= dims.nc_max.  contact_dim = 3 (point) or 6 (surface contact: the cone
+ * acts on the first 3 force components).  max_contacts = 0 switches them off.  Once set,
+ * rtoc_condense / rtoc_expand / rtoc_update include these rows. */
+int rtoc_set_friction_cones(rtoc_ctx* ctx, int max_contacts, int contact_dim);
 
 /* ---- the hot path ---------------------------------------------------------- */
 int rtoc_condense(rtoc_ctx* ctx);

@@ -196,6 +196,16 @@ enum {
 #define RTOC_SE3_FQQ_PREV_INV 36
 #define RTOC_SE3_STRIDE 72
 
+/* ---- RTOC_BUF_CONE record: per ACTIVE contact k of the grid point (compacted), the Jacobians of
+ *      its 5 friction-cone rows (friction_cone.cpp:143-191): dg_dq 5 x nv at k*5*nv, dg_df 5 x 3 at
+ *      rtoc_cone_dgdf_off + k*15; both column-major with leading dimension 5 ---- */
+static inline RTOC_HD RTOC_CONSTEXPR int rtoc_cone_dgdf_off(int nv, int max_contacts) {
+  return (max_contacts * 5 * nv + 7) & ~7;
+}
+static inline RTOC_HD RTOC_CONSTEXPR int rtoc_cone_stride(int nv, int max_contacts) {
+  return rtoc_cone_dgdf_off(nv, max_contacts) + ((max_contacts * 15 + 7) & ~7);
+}
+
 typedef struct rtoc_record_layout {
   int off[24]; /* field offsets in doubles (indexed by the enums above) */
   int stride;  /* record size in doubles                                */

@@ -68,6 +68,8 @@ def lib():
                                                     dp, dp, dp, dp]
         _LIB.orc_unconstr_dynamics_batch.argtypes = [C.POINTER(Layout), C.c_int, C.c_int, dp, dp, dp,
                                                      C.c_double, C.c_int]
+        _LIB.orc_cone_batch.argtypes = [C.POINTER(Layout), C.POINTER(Grid), C.c_int, C.c_int, C.c_int, C.c_int,
+                                        dp, dp, dp, dp, dp, C.c_double, dp, C.c_int]
     return _LIB
 
 
@@ -212,3 +214,21 @@ def unconstr_condense_batch(L, nstages, kkt, cdd):
 def unconstr_expand_batch(L, nstages, cdd, dirs, dt):
     """UnconstrDynamics::expandPrimal + expandDual on every non-terminal grid point."""
     lib().orc_unconstr_dynamics_batch(C.byref(L), nstages, cdd.shape[0], None, _p(cdd), _p(dirs), dt, 1)
+
+
+def cone_condense_batch(L, grids, max_contacts, contact_dim, cone, kkt, cdd, con):
+    """FrictionCone::condenseSlackAndDual on every non-terminal grid point (friction_cone.cpp:194-235)."""
+    lib().orc_cone_batch(C.byref(L), grid_array(grids), len(grids), kkt.shape[0], max_contacts, contact_dim,
+                         _p(cone), _p(kkt), _p(cdd), _p(con), None, 0.0, None, 0)
+
+
+def cone_expand_batch(L, grids, max_contacts, contact_dim, cone, con, dirs, tau, steps):
+    """FrictionCone::expandSlackAndDual + step sizes; `steps` [batch,2] is min-reduced in place."""
+    lib().orc_cone_batch(C.byref(L), grid_array(grids), len(grids), con.shape[0], max_contacts, contact_dim,
+                         _p(cone), None, None, _p(con), _p(dirs), tau, _p(steps), 1)
+
+
+def cone_update_batch(L, grids, max_contacts, contact_dim, con, steps):
+    steps = np.ascontiguousarray(steps, dtype=np.float64)
+    lib().orc_cone_batch(C.byref(L), grid_array(grids), len(grids), con.shape[0], max_contacts, contact_dim,
+                         None, None, None, _p(con), None, 0.0, _p(steps), 2)

@@ -650,3 +650,124 @@ void orc_unconstr_dynamics_batch(const rtoc_layout* L, int nstages, int batch, d
         orc_unconstr_expand_stage(L, cdd + rec * L->cdd.stride, dir + rec * L->dir.stride, dt);
     }
 }
+
+/* ======================================================================================
+ * Friction-cone PDIPM rows (src/constraints/friction_cone.cpp:194-268; ImpactFrictionCone alike).
+ * cone record: include/rtoc_layout.h (RTOC_BUF_CONE), compacted over the active contacts;
+ * constraint rows row0 + 5k + j of the con record, row0 = nc_max - 5*max_contacts.
+ * ====================================================================================== */
+void orc_cone_condense_stage(const rtoc_layout* L, const rtoc_grid* g, int max_contacts, int contact_dim,
+                             const double* cone_rec, double* kkt_rec, double* cdd_rec, double* con_rec) {
+  if (g->type == RTOC_GRID_TERMINAL) return;
+  const int nv = L->dims.nv, nx = L->nx, nfp = L->dims.nf_max > 0 ? L->dims.nf_max : 1;
+  const int nact = g->dimf / contact_dim, row0 = L->dims.nc_max - 5 * max_contacts;
+  const int* o = L->con.off;
+  double* Qxx = kkt_rec + L->kkt.off[RTOC_KKT_QXX];
+  double* lx = kkt_rec + L->kkt.off[RTOC_KKT_LX];
+  double* Qff = cdd_rec + L->cdd.off[RTOC_CDD_QFF];
+  double* Qqf = cdd_rec + L->cdd.off[RTOC_CDD_QQF];
+  double* lf = cdd_rec + L->cdd.off[RTOC_CDD_LF];
+  for (int k = 0; k < nact; ++k) {
+    const double* dq = cone_rec + (size_t)k * 5 * nv;
+    const double* df = cone_rec + rtoc_cone_dgdf_off(nv, max_contacts) + k * 15;
+    const int r0 = row0 + 5 * k, stack = k * contact_dim;
+    double cond[5], rr[5];
+    for (int j = 0; j < 5; ++j) {
+      const double slack = con_rec[o[RTOC_CON_SLACK] + r0 + j], dual = con_rec[o[RTOC_CON_DUAL] + r0 + j];
+      cond[j] = (dual * con_rec[o[RTOC_CON_RESIDUAL] + r0 + j] - con_rec[o[RTOC_CON_CMPL] + r0 + j]) / slack;
+      con_rec[o[RTOC_CON_COND] + r0 + j] = cond[j]; /* (:202) */
+      rr[j] = dual / slack;                          /* (:211-212) */
+    }
+    for (int c = 0; c < nv; ++c) { /* lq += dg_dq^T cond (:206) */
+      double acc = 0.0;
+      for (int j = 0; j < 5; ++j) acc += dq[j + 5 * c] * cond[j];
+      lx[c] += acc;
+    }
+    for (int m = 0; m < 3; ++m) { /* lf += dg_df^T cond (:207-208) */
+      double acc = 0.0;
+      for (int j = 0; j < 5; ++j) acc += df[j + 5 * m] * cond[j];
+      lf[stack + m] += acc;
+    }
+    for (int c = 0; c < nv; ++c)
+      for (int r = 0; r < nv; ++r) { /* Qqq += dg_dq^T (r dg_dq) (:213,:215-216) */
+        double acc = 0.0;
+        for (int j = 0; j < 5; ++j) acc += dq[j + 5 * r] * (rr[j] * dq[j + 5 * c]);
+        Qxx[r + (size_t)c * nx] += acc;
+      }
+    for (int m = 0; m < 3; ++m)
+      for (int r = 0; r < nv; ++r) { /* Qqf += dg_dq^T (r dg_df) (:214,:217-218) */
+        double acc = 0.0;
+        for (int j = 0; j < 5; ++j) acc += dq[j + 5 * r] * (rr[j] * df[j + 5 * m]);
+        Qqf[r + (size_t)(stack + m) * nv] += acc;
+      }
+    for (int n = 0; n < 3; ++n)
+      for (int m = 0; m < 3; ++m) { /* Qff += dg_df^T (r dg_df) (:219-220) */
+        double acc = 0.0;
+        for (int j = 0; j < 5; ++j) acc += df[j + 5 * m] * (rr[j] * df[j + 5 * n]);
+        Qff[(stack + m) + (size_t)(stack + n) * nfp] += acc;
+      }
+  }
+}
+
+/* expandSlackAndDual (:238-268) + maxSlackStepSize / maxDualStepSize; steps min-reduced in place */
+void orc_cone_expand_stage(const rtoc_layout* L, const rtoc_grid* g, int max_contacts, int contact_dim,
+                           const double* cone_rec, const double* dir_rec, double* con_rec, double tau,
+                           double* steps) {
+  if (g->type == RTOC_GRID_TERMINAL) return;
+  const int nv = L->dims.nv;
+  const int nact = g->dimf / contact_dim, row0 = L->dims.nc_max - 5 * max_contacts;
+  const int* o = L->con.off;
+  const double* dqv = dir_rec + L->dir.off[RTOC_DIR_DX];
+  const double* dfv = dir_rec + L->dir.off[RTOC_DIR_DAF] + nv;
+  for (int k = 0; k < nact; ++k) {
+    const double* dq = cone_rec + (size_t)k * 5 * nv;
+    const double* df = cone_rec + rtoc_cone_dgdf_off(nv, max_contacts) + k * 15;
+    const int stack = k * contact_dim;
+    for (int j = 0; j < 5; ++j) {
+      const int r = row0 + 5 * k + j;
+      double accq = 0.0, accf = 0.0;
+      for (int c = 0; c < nv; ++c) accq += dq[j + 5 * c] * dqv[c];
+      for (int m = 0; m < 3; ++m) accf += df[j + 5 * m] * dfv[stack + m];
+      const double slack = con_rec[o[RTOC_CON_SLACK] + r], dual = con_rec[o[RTOC_CON_DUAL] + r];
+      const double dslack = -accq - accf - con_rec[o[RTOC_CON_RESIDUAL] + r];
+      const double ddual = -(dual * dslack + con_rec[o[RTOC_CON_CMPL] + r]) / slack;
+      con_rec[o[RTOC_CON_DSLACK] + r] = dslack;
+      con_rec[o[RTOC_CON_DDUAL] + r] = ddual;
+      const double fs = -tau * (slack / dslack), fd = -tau * (dual / ddual);
+      if (fs > 0 && fs < 1 && fs < steps[0]) steps[0] = fs;
+      if (fd > 0 && fd < 1 && fd < steps[1]) steps[1] = fd;
+    }
+  }
+}
+
+void orc_cone_update_stage(const rtoc_layout* L, const rtoc_grid* g, int max_contacts, int contact_dim,
+                           double* con_rec, double primal_step, double dual_step) {
+  if (g->type == RTOC_GRID_TERMINAL) return;
+  const int nact = g->dimf / contact_dim, row0 = L->dims.nc_max - 5 * max_contacts;
+  const int* o = L->con.off;
+  for (int r = row0; r < row0 + 5 * nact; ++r) {
+    con_rec[o[RTOC_CON_SLACK] + r] += primal_step * con_rec[o[RTOC_CON_DSLACK] + r];
+    con_rec[o[RTOC_CON_DUAL] + r] += dual_step * con_rec[o[RTOC_CON_DDUAL] + r];
+  }
+}
+
+/* phase 0 condense, 1 expand (steps min-reduced, NOT reset here), 2 update */
+void orc_cone_batch(const rtoc_layout* L, const rtoc_grid* grid, int nstages, int batch, int max_contacts,
+                    int contact_dim, const double* cone, double* kkt, double* cdd, double* con,
+                    const double* dir, double tau, double* steps, int phase) {
+  const size_t cs = (size_t)rtoc_cone_stride(L->dims.nv, max_contacts);
+#pragma omp parallel for schedule(static)
+  for (int b = 0; b < batch; ++b)
+    for (int i = 0; i < nstages - 1; ++i) {
+      const size_t rec = (size_t)b * nstages + i;
+      if (phase == 0)
+        orc_cone_condense_stage(L, &grid[i], max_contacts, contact_dim, cone + rec * cs,
+                                kkt + rec * L->kkt.stride, cdd + rec * L->cdd.stride, con + rec * L->con.stride);
+      else if (phase == 1)
+        orc_cone_expand_stage(L, &grid[i], max_contacts, contact_dim, cone + rec * cs,
+                              dir + rec * L->dir.stride, con + rec * L->con.stride, tau, steps + 2 * b);
+      else
+        orc_cone_update_stage(L, &grid[i], max_contacts, contact_dim, con + rec * L->con.stride, steps[2 * b],
+                              steps[2 * b + 1]);
+    }
+}

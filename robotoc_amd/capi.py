@@ -23,6 +23,9 @@ EXPORTS = [
     "rtoc_riccati_backward", "rtoc_riccati_forward", "rtoc_unconstr_backward",
     "rtoc_unconstr_forward", "rtoc_expand", "rtoc_update", "rtoc_status", "rtoc_clear_status",
     "rtoc_sync", "rtoc_time_phase", "rtoc_set_constraint_rows", "rtoc_gather_directions", "rtoc_error_string",
+    "rtoc_riccati_sweep", "rtoc_correct_state_equation", "rtoc_correct_costate_direction",
+    "rtoc_compute_initial_state_direction", "rtoc_unconstr_condense", "rtoc_unconstr_expand",
+    "rtoc_set_friction_cones",
 ]
 
 
@@ -86,6 +89,7 @@ def lib():
         L.rtoc_time_phase.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float)]
         L.rtoc_gather_directions.argtypes = [vp, vp, dp]
         L.rtoc_set_constraint_rows.argtypes = [vp, C.POINTER(BoxRow), C.c_int]
+        L.rtoc_set_friction_cones.argtypes = [vp, C.c_int, C.c_int]
         L.rtoc_error_string.argtypes = [C.c_int]
         L.rtoc_error_string.restype = C.c_char_p
         _LIB = L
@@ -202,6 +206,9 @@ class Context:
 
     def compute_initial_state_direction(self):
         _chk(lib().rtoc_compute_initial_state_direction(self._h))
+
+    def set_friction_cones(self, max_contacts, contact_dim=3):
+        _chk(lib().rtoc_set_friction_cones(self._h, int(max_contacts), int(contact_dim)))
 
     def unconstr_condense(self):
         _chk(lib().rtoc_unconstr_condense(self._h))

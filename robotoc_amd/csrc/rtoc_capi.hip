@@ -13,6 +13,7 @@
 #include "condense.hpp"
 #include "state_equation.hpp"
 #include "unconstr_dynamics.hpp"
+#include "friction_cone.hpp"
 #include "riccati_backward.hpp"
 #include "riccati_backward_rs.hpp"
 #include "riccati_forward.hpp"
@@ -39,6 +40,7 @@ typedef void (*bwd_fn)(BwdArgs);
 typedef void (*fwd_fn)(FwdArgs);
 typedef void (*fill_fn)(FillArgs);
 typedef void (*ud_fn)(UdArgs);
+typedef void (*cone_fn)(ConeArgs);
 typedef void (*cond_fn)(CondArgs);
 typedef void (*expd_fn)(ExpArgs);
 
@@ -54,6 +56,7 @@ struct KernelSet {
   int fwd_threads;
   fill_fn fill;
   ud_fn ucond, uexp;  // UnconstrDynamics condense / expand
+  cone_fn ccond, cexp;  // friction-cone rows
   cond_fn cond;
   int cond_threads, cond_lds;
   expd_fn expd;
@@ -98,6 +101,8 @@ static KernelSet make_set() {
   k.fill = unconstr_fill_kernel<NV>;
   k.ucond = unconstr_condense_kernel<NV>;
   k.uexp = unconstr_expand_kernel<NV>;
+  k.ccond = cone_condense_kernel<NV, NS>;
+  k.cexp = cone_expand_kernel<NV, NS>;
   constexpr int NF = NS;  // nf_max == ns_max for all supported robots
   k.cond = condense_kernel<NV, NU, NF, NS>;
   k.cond_threads = CondCfg<NV, NU, NF, NS>::NT;
@@ -150,6 +155,7 @@ struct rtoc_ctx {
   hipStream_t stream2;  // forward half of the pipelined sweep
   hipEvent_t ev_fork, ev_join, ev_chunk[RTOC_MAX_CHUNK_EVENTS];
   int sweep_chunks;
+  int cone_contacts, cone_dim;  // friction cones: max contacts (0 = off), force components per contact
 };
 
 extern "C" {
@@ -224,6 +230,7 @@ int rtoc_create(const rtoc_dims* dims, int max_stages, int batch, int device, rt
   c->count[RTOC_BUF_DX0] = (size_t)batch * c->L.nx;
   c->count[RTOC_BUF_STEP] = (size_t)batch * 2;
   c->count[RTOC_BUF_SE3] = per * RTOC_SE3_STRIDE;
+  c->count[RTOC_BUF_CONE] = 0;  // sized by rtoc_set_friction_cones
   for (int i = 0; i < RTOC_NUM_BUFFERS; ++i) {
     // the CDD / CON buffers are large; they are allocated lazily on first use (upload / bind / condense)
     c->buf[i] = nullptr;
@@ -513,6 +520,41 @@ static int launch_expand(rtoc_ctx* c, double tau) {
   return RTOC_OK;
 }
 
+static int launch_cones(rtoc_ctx* c, int phase, double tau) {  // 0 condense, 1 expand, 2 update
+  if (!c->buf[RTOC_BUF_CONE] || !c->buf[RTOC_BUF_CON]) return RTOC_ERR_NOT_READY;
+  int rc = ensure_buffer(c, RTOC_BUF_CDD);
+  if (rc) return rc;
+  ConeArgs a;
+  a.kkt = c->buf[RTOC_BUF_KKT];
+  a.cdd = c->buf[RTOC_BUF_CDD];
+  a.con = c->buf[RTOC_BUF_CON];
+  a.cone = c->buf[RTOC_BUF_CONE];
+  a.dir = c->buf[RTOC_BUF_DIR];
+  a.grid = c->d_grid;
+  a.steps = (unsigned long long*)c->buf[RTOC_BUF_STEP];
+  a.nstages = c->nstages;
+  a.batch = c->batch;
+  a.max_contacts = c->cone_contacts;
+  a.contact_dim = c->cone_dim;
+  a.row0 = c->dims.nc_max - 5 * c->cone_contacts;
+  a.cone_stride = rtoc_cone_stride(c->dims.nv, c->cone_contacts);
+  a.dgdf_off = rtoc_cone_dgdf_off(c->dims.nv, c->cone_contacts);
+  a.tau = tau;
+  a.kl = c->L.kkt;
+  a.cl = c->L.cdd;
+  a.nl = c->L.con;
+  a.dl = c->L.dir;
+  const dim3 grid(c->batch * (c->nstages - 1));
+  if (phase == 0)
+    hipLaunchKernelGGL(c->ks->ccond, grid, dim3(64), 0, c->stream, a);
+  else if (phase == 1)
+    hipLaunchKernelGGL(c->ks->cexp, grid, dim3(64), 0, c->stream, a);
+  else
+    hipLaunchKernelGGL(cone_update_kernel, grid, dim3(64), 0, c->stream, a);
+  HIP_TRY(hipGetLastError());
+  return RTOC_OK;
+}
+
 #define CHECK_READY(c)                       \
   if (!(c)) return RTOC_ERR_BAD_ARG;         \
   if ((c)->nstages < 2) return RTOC_ERR_NOT_READY; \
@@ -562,7 +604,9 @@ int rtoc_compute_initial_state_direction(rtoc_ctx* c) {
 
 int rtoc_condense(rtoc_ctx* c) {
   CHECK_READY(c);
-  int rc = launch_condense(c);
+  int rc = RTOC_OK;
+  if (c->cone_contacts > 0) rc = launch_cones(c, 0, 0.0);  // Constraints::condenseSlackAndDual first
+  if (!rc) rc = launch_condense(c);
   if (!rc && c->buf[RTOC_BUF_SE3] && c->dims.np == 6) rc = launch_state_correction(c, 0);
   return rc;
 }
@@ -643,12 +687,17 @@ int rtoc_expand(rtoc_ctx* c, double tau) {
   CHECK_READY(c);
   if (!(tau > 0.0 && tau <= 1.0)) return RTOC_ERR_BAD_ARG;
   int rc = launch_expand(c, tau);
+  if (!rc && c->cone_contacts > 0) rc = launch_cones(c, 1, tau);
   if (!rc && c->buf[RTOC_BUF_SE3] && c->dims.np == 6) rc = launch_state_correction(c, 1);
   return rc;
 }
 
 int rtoc_update(rtoc_ctx* c) {
   CHECK_READY(c);
+  if (c->cone_contacts > 0) {
+    int rc = launch_cones(c, 2, 0.0);
+    if (rc) return rc;
+  }
   if (c->nrows == 0) return RTOC_OK;
   UpdArgs a;
   a.con = c->buf[RTOC_BUF_CON];
@@ -664,8 +713,33 @@ int rtoc_update(rtoc_ctx* c) {
   return RTOC_OK;
 }
 
+int rtoc_set_friction_cones(rtoc_ctx* c, int max_contacts, int contact_dim) {
+  if (!c || max_contacts < 0) return RTOC_ERR_BAD_ARG;
+  if (max_contacts == 0) {
+    c->cone_contacts = 0;
+    return RTOC_OK;
+  }
+  if ((contact_dim != 3 && contact_dim != 6) || max_contacts * contact_dim > c->dims.nf_max ||
+      c->nrows + 5 * max_contacts > c->dims.nc_max)
+    return RTOC_ERR_BAD_ARG;
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t need = (size_t)c->batch * c->max_stages * rtoc_cone_stride(c->dims.nv, max_contacts);
+  if (c->buf[RTOC_BUF_CONE] && c->count[RTOC_BUF_CONE] != need) {
+    if (c->owned[RTOC_BUF_CONE]) (void)hipFree(c->buf[RTOC_BUF_CONE]);
+    c->buf[RTOC_BUF_CONE] = nullptr;
+  }
+  c->count[RTOC_BUF_CONE] = need;
+  int rc = ensure_buffer(c, RTOC_BUF_CONE);
+  if (!rc) rc = ensure_buffer(c, RTOC_BUF_CON);
+  if (rc) return rc;
+  c->cone_contacts = max_contacts;
+  c->cone_dim = contact_dim;
+  return RTOC_OK;
+}
+
 int rtoc_set_constraint_rows(rtoc_ctx* c, const rtoc_box_row* rows, int nrows) {
-  if (!c || nrows < 0 || nrows > c->dims.nc_max || (nrows > 0 && !rows)) return RTOC_ERR_BAD_ARG;
+  if (!c || nrows < 0 || nrows + 5 * c->cone_contacts > c->dims.nc_max || (nrows > 0 && !rows))
+    return RTOC_ERR_BAD_ARG;
   for (int r = 0; r < nrows; ++r) {
     const rtoc_box_row& w = rows[r];
     const int lim = (w.var == RTOC_VAR_U) ? c->dims.nu : c->dims.nv;
@@ -749,8 +823,8 @@ int rtoc_time_phase(rtoc_ctx* c, int phase, int reps, float* ms) {
     switch (phase) {
       case 0: rc = launch_backward(c); break;
       case 1: rc = launch_forward(c); break;
-      case 2: rc = launch_condense(c); break;
-      case 3: rc = launch_expand(c, 0.995); break;
+      case 2: rc = rtoc_condense(c); break;      // incl. cone rows / state-equation correction if set
+      case 3: rc = rtoc_expand(c, 0.995); break;
       case 4: rc = launch_sweep(c); break;
       case 5: rc = rtoc_update(c); break;
     }

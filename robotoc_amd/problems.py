@@ -261,3 +261,27 @@ def make_constraint_batch(L, grids, batch, barrier=1.0e-3, first_instance=0):
         N.f(con[b], "residual")[...] = 0.01 * _rnd(rng, len(grids), L.dims.nc_max)
         N.f(con[b], "cmpl")[...] = slack * dual - barrier
     return con
+
+
+def make_cone_batch(L, grids, batch, max_contacts, first_instance=0):
+    """Friction-cone Jacobians of the active contacts of every grid point (RTOC_BUF_CONE record,
+    include/rtoc_layout.h): dg_dq 5 x nv and dg_df 5 x 3 per contact, as FrictionCone::evalDerivatives
+    would leave them (friction_cone.cpp:143-191).  dg_df is the rotated cone matrix
+    [[0,0,-1],[1,0,-mu'],[-1,0,-mu'],[0,1,-mu'],[0,-1,-mu']] R^T, dg_dq a dense random block."""
+    from .types import cone_dgdf_off, cone_stride
+    nv = L.dims.nv
+    cs, off = cone_stride(nv, max_contacts), cone_dgdf_off(nv, max_contacts)
+    out = np.zeros((batch, len(grids), cs))
+    mu = 0.7 / np.sqrt(2.0)
+    cone = np.array([[0, 0, -1.0], [1, 0, -mu], [-1, 0, -mu], [0, 1, -mu], [0, -1, -mu]])
+    for b in range(batch):
+        rng = np.random.default_rng(BASE_SEED + 7919 + first_instance + b)
+        for i in range(len(grids)):
+            for k in range(max_contacts):
+                dq = 0.3 * rng.uniform(-1, 1, (5, nv))
+                a = rng.uniform(-0.3, 0.3, 3)
+                Rm = np.eye(3) + np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+                df = cone @ Rm.T
+                out[b, i, k * 5 * nv:(k + 1) * 5 * nv] = dq.T.reshape(-1)       # column-major, ld 5
+                out[b, i, off + k * 15:off + (k + 1) * 15] = df.T.reshape(-1)
+    return out

@@ -21,7 +21,7 @@ CDD_FIELDS = ["dIDda", "dIDCdqv", "dCda", "IDC", "Qaa", "Qff", "Qqf", "la", "lf"
 
 STAT_QUU_NOT_SPD, STAT_S_NOT_SPD, STAT_NAN, STAT_M_NOT_SPD = 1, 2, 4, 8
 
-BUF_KKT, BUF_RIC, BUF_DIR, BUF_CDD, BUF_CON, BUF_DX0, BUF_STEP, BUF_SE3 = range(8)
+BUF_KKT, BUF_RIC, BUF_DIR, BUF_CDD, BUF_CON, BUF_DX0, BUF_STEP, BUF_SE3, BUF_CONE = range(9)
 SE3_STRIDE, SE3_FQQ_INV, SE3_FQQ_PREV_INV = 72, 0, 36
 OPT_WRITEBACK_KKT, OPT_MAX_DTS0, OPT_BACKWARD_WAVES, OPT_CONTACT_INV_DAMPING, OPT_SWEEP_CHUNKS = range(5)
 
@@ -72,8 +72,9 @@ class Layout(C.Structure):
                 ("con", RecordLayout)]
 
 
-def anymal_dims(nc_max=72):
-    """ANYmal: nv=18, 12 actuated joints, 4 point contacts."""
+def anymal_dims(nc_max=96):
+    """ANYmal: nv=18, 12 actuated joints, 4 point contacts; nc_max = 72 joint-limit rows
+    + 20 friction-cone rows, padded."""
     return Dims(18, 12, 6, 12, 12, nc_max)
 
 
@@ -156,3 +157,13 @@ class Records:
 
     def zeros(self, *lead):
         return np.zeros(tuple(lead) + (self.stride,), dtype=np.float64)
+
+
+def cone_dgdf_off(nv, max_contacts):
+    """include/rtoc_layout.h: rtoc_cone_dgdf_off"""
+    return (max_contacts * 5 * nv + 7) & ~7
+
+
+def cone_stride(nv, max_contacts):
+    """include/rtoc_layout.h: rtoc_cone_stride"""
+    return cone_dgdf_off(nv, max_contacts) + ((max_contacts * 15 + 7) & ~7)
