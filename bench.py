@@ -107,7 +107,18 @@ def cpu_baseline(L, grids, dx0_small, kkt_small, budget_s=12.0):
         if time.perf_counter() - t0 > budget_s:
             break
     dt = time.perf_counter() - t0
+    # the reference's Riccati recursion itself is single-threaded (riccati_recursion.cpp): one instance
+    one_k, one_d = np.ascontiguousarray(kkt_small[:1]), np.ascontiguousarray(dx0_small[:1])
+    ric1, d1, w1 = Records(L, "ric").zeros(1, len(grids)), Records(L, "dir").zeros(1, len(grids)), one_k.copy()
+    t1 = time.perf_counter()
+    n1 = 0
+    while time.perf_counter() - t1 < 2.0:
+        w1[...] = one_k
+        orc.riccati_sweep_batch(L, grids, w1, ric1, d1, dx0=one_d)
+        n1 += 1
+    single = n1 / (time.perf_counter() - t1)
     return dict(value=B * reps / dt, unit="sweeps/s", cores=nthreads, kind="port",
+                single_thread_sweeps_per_sec=single,
                 sample="%d instances x %d repeats of the same ANYmal trot sweep, OpenMP over "
                        "instances (%d threads), includes the memcpy that restores the in-place "
                        "mutated KKT blocks" % (B, reps, nthreads))
@@ -187,6 +198,20 @@ def main():
         dt = float(tt.item())
     bad = int((ctx.status() != 0).sum())
 
+    # attainable HBM bandwidth on this box: device-to-device copy of 1 GiB (read + write), same run
+    src = torch.empty(1 << 27, dtype=torch.float64, device="cuda")
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize()
+    copy_gbs = 5 * 2 * src.numel() * 8 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del src, dst
+
     # dominant kernel (backward) and forward timed with HIP events on the launch stream
     ms_b = ctx.time_phase(0, max(3, args.steps // 2))
     ms_f = ctx.time_phase(1, max(3, args.steps // 2))
@@ -220,6 +245,11 @@ def main():
         con0 = torch.from_numpy(np.ascontiguousarray(np.tile(con_s, (rp, 1, 1))[:batch])).cuda()
         con_w = torch.empty(ctx.buffer_count(BUF_CON), dtype=torch.float64, device="cuda")
         ctx.bind(BUF_CON, con_w.data_ptr())
+        # friction cones of the (up to 4) active point contacts: 5 PDIPM rows each, dense Jacobians
+        from robotoc_amd.types import BUF_CONE
+        ctx.set_friction_cones(4, 3)
+        cone_s = pr.make_cone_batch(L, grids, 4, 4, first_instance=rank * batch)
+        ctx.upload(BUF_CONE, np.ascontiguousarray(np.tile(cone_s, (rp, 1, 1))[:batch]))
         ph = {"condense": 2, "backward": 0, "forward": 1, "expand": 3, "update": 5}
         acc = {k: 0.0 for k in ph}
         nrep = 3
@@ -237,10 +267,10 @@ def main():
         sqp = {"ms": acc, "total_ms": tot, "iters_per_sec_per_gpu": batch / tot * 1e3,
                "status_nonzero_instances": bad_sqp,
                "scope": "hot path downstream of the Pinocchio linearisation: PDIPM condensation of the "
-                        "joint-limit rows + computeMJtJinv + condenseContact/ImpactDynamics + Riccati "
+                        "joint-limit and friction-cone rows + computeMJtJinv + condenseContact/ImpactDynamics + Riccati "
                         "backward/forward + expandContactDynamics primal/dual + PDIPM expansion, "
-                        "fraction-to-boundary step sizes and slack/dual update; linearisation, cost, "
-                        "friction-cone rows and the manifold update of q are CPU-side and excluded"}
+                        "fraction-to-boundary step sizes and slack/dual update; linearisation, cost "
+                        "and the manifold update of q are CPU-side and excluded"}
 
     if rank == 0:
         total_sweeps = world * batch * args.steps
@@ -268,6 +298,7 @@ def main():
                        "backward_waves": args.waves},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(args.waves, batch),
+                         "measured_copy_GBs": copy_gbs, "frac_of_measured_copy": ach / copy_gbs,
                          "kernel": "riccati_backward_rs4_kernel" if args.waves in (0, 8) else "riccati_backward_kernel", "kernel_ms": ms_b,
                          "algorithmic_bytes_per_launch": bytes_b,
                          "forward_kernel_ms": ms_f,
