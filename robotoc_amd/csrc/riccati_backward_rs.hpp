@@ -138,6 +138,9 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a, const
   };
   if (N >= 1) issue_loads(N - 1);
 
+  // the vector wave's dependent chains (Cholesky, policy) are the critical path of a stage and can
+  // only issue in the gaps of the matrix wave's MFMA stream on the shared SIMD: take those gaps first
+  if constexpr (!MW) __builtin_amdgcn_s_setprio(3);
   for (int st = N - 1; st >= 0; --st) {
     // opaque per-stage thread index: see riccati_backward.hpp (keeps LICM from pinning VGPRs)
     tid = tid0;
@@ -498,8 +501,9 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a, const
     if constexpr (!MW) {
       if (!sto && !impact) {
         if (vt < NU) smem[C::V_LU + vt] += smem[C::V_Y + vt];
-        wave_lds_sync();
       }
+      // hand-off vector -> matrix: the inverse factor Y and lu' (psi_u, phi_u) are in LDS
+      lds_signal(sFlag + 2, N - st, lane);
     }
 
     RTOC_PROF(4);
@@ -531,7 +535,9 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a, const
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-    } else {
+      // the policy products run here, on the wave that owns the MFMA stream of this SIMD: issued
+      // from the vector wave they queued behind the F chain above anyway
+      lds_wait(sFlag + 2, N - st);
       if (!impact && ns == 0) {
         // K = -G^-1 H^T, k = -G^-1 lu', T = -G^-1 psi_u, W = -G^-1 phi_u
         // (riccati_factorizer.cpp:55-56, :125-130) for all right-hand sides at once, as the two
@@ -618,8 +624,8 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a, const
           }
           if (is_bad(chk)) stat |= RTOC_STAT_NAN;
         }
-        RTOC_PROFV(25);
       }
+    } else {
       // w = A^T z - lx (brrf.cpp:87-88), off the matrix wave's critical path: z came with the H flag
       double wacc = 0.0;
       lds_wait(sFlag, 3 * (N - st));
@@ -644,25 +650,7 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a, const
         }
         wacc = (a0 + a1) + (a2 + a3) - smem[C::V_LX + vt];
       }
-      wave_lds_sync();
-      if (!impact && ns == 0) {
-        // s -= H k = K^T lu' (K^T = -H G^-1)
-        if (vt < NX) {
-          double acc0 = 0.0, acc1 = 0.0;
-#pragma unroll
-          for (int u = 0; u + 1 < NU; u += 2) {
-            acc0 += sKt[vt + u * LDP] * smem[C::V_LU + u];
-            acc1 += sKt[vt + (u + 1) * LDP] * smem[C::V_LU + u + 1];
-          }
-          if (NU & 1) acc0 += sKt[vt + (NU - 1) * LDP] * smem[C::V_LU + NU - 1];
-          if (sto)
-            smem[C::V_SNEW + vt] -= acc0 + acc1;
-          else
-            smem[C::V_SNEW + vt] = wacc - (acc0 + acc1);
-        }
-      } else if (!sto && vt < NX) {
-        smem[C::V_SNEW + vt] = wacc;
-      }
+      if (!sto && vt < NX) smem[C::V_SNEW + vt] = wacc;
     }
     RTOC_PROF(13);
     RTOC_PROFV(14);
@@ -841,6 +829,19 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a, const
     } else {
       // next stage's record: HBM -> registers of the vector wave.  Issued here, after the register-
       // hungry solve / constraint code, so that the prefetched values are not spilled.
+      if (!impact && ns == 0) {
+        // s -= H k = K^T lu' (K^T = -H G^-1); K^T came from the matrix wave before B4
+        if (vt < NX) {
+          double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+          for (int u = 0; u + 1 < NU; u += 2) {
+            acc0 += sKt[vt + u * LDP] * smem[C::V_LU + u];
+            acc1 += sKt[vt + (u + 1) * LDP] * smem[C::V_LU + u + 1];
+          }
+          if (NU & 1) acc0 += sKt[vt + (NU - 1) * LDP] * smem[C::V_LU + NU - 1];
+          smem[C::V_SNEW + vt] -= acc0 + acc1;
+        }
+      }
       if (st > 0) issue_loads(st - 1);
       RTOC_PROFV(27);
       // vector wave: LQR policy of this stage -> HBM (K row-major == Kt column-major)
@@ -923,7 +924,7 @@ __global__ __launch_bounds__(128, 2) void riccati_backward_rs_kernel(BwdArgs a) 
   if (a.first + (int)blockIdx.x >= a.batch) return;
   extern __shared__ __attribute__((aligned(16))) double smem_all[];
   using C = BwdCfg<NV, NU, NS, 2>;
-  if (threadIdx.x < 2) reinterpret_cast<int*>(smem_all + C::V_FLAG)[threadIdx.x] = 0;
+  if (threadIdx.x < 3) reinterpret_cast<int*>(smem_all + C::V_FLAG)[threadIdx.x] = 0;
   __syncthreads();
   if (threadIdx.x < 64)
     riccati_backward_rs_body<NV, NU, NS, true, 1>(a, 0);
@@ -950,6 +951,7 @@ __global__ __launch_bounds__(512) void riccati_backward_rs4_kernel(BwdArgs a) {
     int* f = reinterpret_cast<int*>(smem_all + threadIdx.x * C::LDS_DOUBLES + C::V_FLAG);
     f[0] = 0;
     f[1] = 0;
+    f[2] = 0;
   }
   __syncthreads();
   unsigned hw;
