@@ -97,7 +97,7 @@ struct CondCfg {
 //   C(i,j) = beta * C(i,j) + alpha * sum_k A(i,k) B(k,j),  A(i,k) = A[i*ars + k*acs], ...
 // Operands may live in HBM/L2 or LDS (flat addressing).  Runtime dimensions; tiles are
 // processed two column tiles at a time to keep two MFMA chains in flight.
-template <int NW>
+template <int NW, int MAXP = 0>
 __device__ __forceinline__ void wave_gemm(int M, int N, int K, double alpha, const double* A, int ars,
                                           int acs, const double* B, int brs, int bcs, double beta,
                                           double* C, int crs, int ccs, int tid,
@@ -113,8 +113,8 @@ __device__ __forceinline__ void wave_gemm(int M, int N, int K, double alpha, con
   const int li = lane & 15, q = lane >> 4;
   const int tmn = (M + 15) >> 4, tnp = (((N + 15) >> 4) + 1) >> 1, ksn = (K + 3) >> 2;
   // tile pairs (16 rows x 32 columns) are dealt round-robin to the NW waves of the work item
-  int pidx = 0;
-  for (int tp = wave; tp < tmn * tnp; tp += NW, ++pidx) {
+  // one tile pair; `cp` = its prefetched C values (or nullptr)
+  auto do_pair = [&](const int tp, const double* cp) {
     const int tm = tp / tnp, tn = (tp - tm * tnp) * 2;
     const int i = tm * 16 + li;
     const bool iok = i < M;
@@ -129,9 +129,9 @@ __device__ __forceinline__ void wave_gemm(int M, int N, int K, double alpha, con
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = tm * 16 + drow(q, r);
-      if (cpre) {
-        c0[r] = cpre[pidx][r];
-        c1[r] = cpre[pidx][4 + r];
+      if (cp) {
+        c0[r] = cp[r];
+        c1[r] = cp[4 + r];
       } else {
         const bool ok0 = beta != 0.0 && row < M && j0ok, ok1 = beta != 0.0 && row < M && j1ok;
         const double v0 = C[ok0 ? (size_t)row * crs + (size_t)j0 * ccs : 0];
@@ -197,6 +197,17 @@ __device__ __forceinline__ void wave_gemm(int M, int N, int K, double alpha, con
         if (j1ok) C[(size_t)row * crs + (size_t)j1 * ccs] = beta * c1[r] + alpha * acc1[r] + alpha2 * acd1[r];
       }
     }
+  };
+  if constexpr (MAXP > 0) {
+    // compile-time pair slots: the prefetched C values are indexed statically and stay in registers
+    // (a run-time index would put the array into scratch memory -- an HBM round trip per tile pair)
+#pragma unroll
+    for (int p = 0; p < MAXP; ++p) {
+      const int tp = wave + p * NW;
+      if (tp < tmn * tnp) do_pair(tp, cpre ? cpre[p] : nullptr);
+    }
+  } else {
+    for (int tp = wave; tp < tmn * tnp; tp += NW) do_pair(tp, nullptr);
   }
 }
 
@@ -412,44 +423,79 @@ __global__ __launch_bounds__(128) void condense_kernel(CondArgs a) {
 
   RTOC_CPROF(1);
   // ================= computeMJtJinv (robot.hxx:642-684) =================
-  if (wv == 0 && wave_llt<NV, NV>(sL, sL, sLinv, NV, wl)) stat |= RTOC_STAT_M_NOT_SPD;
-  __syncthreads();
-  RTOC_CPROF(2);
-  if (lane < NV) {  // topLeft = M^-1: lane t solves column t
-    double x[NV];
+  constexpr bool FUSED_MINV =
+      NV <= 32 && (NF == 0 || C::O_BR + C::pad8(C::NFP * C::NFP) - C::O_JM >= NV * NV);
+  if constexpr (FUSED_MINV) {
+    // Cholesky of M and, in the same instruction stream, Y = L^-1 (wave_llt_inv); M^-1 = Y^T Y on the
+    // matrix cores.  Y lives in the J M^-1 / S scratch, which is not in use yet.
+    double* const sY = sJM;
+    double* const sYs = (NF == 0) ? LD : sY;  // no contact scratch on fixed-base sets: borrow LD
+    if (wv == 0 && wave_llt_inv<NV, NV, 32>(sL, sL, sLinv, sYs, NV, wl)) stat |= RTOC_STAT_M_NOT_SPD;
+    __syncthreads();
+    RTOC_CPROF(2);
+    wave_gemm<NW>(NV, NV, NV, 1.0, sYs, NV, 1, sYs, 1, NV, 0.0, Lam, 1, LDV, lane);  // topLeft = M^-1
+    __syncthreads();
+    if (NF == 0)
+      for (int e = lane; e < LDV * NX; e += NT) LD[e] = 0.0;
+  } else {
+    if (wv == 0 && wave_llt<NV, NV>(sL, sL, sLinv, NV, wl)) stat |= RTOC_STAT_M_NOT_SPD;
+    __syncthreads();
+    RTOC_CPROF(2);
+    if (lane < NV) {  // topLeft = M^-1: lane t solves column t
+      double x[NV];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) x[i] = (i == lane) ? 1.0 : 0.0;
-    llt_solve_reg<NV, NV>(sL, sLinv, x, NV);
+      for (int i = 0; i < NV; ++i) x[i] = (i == lane) ? 1.0 : 0.0;
+      llt_solve_reg<NV, NV>(sL, sLinv, x, NV);
 #pragma unroll
-    for (int i = 0; i < NV; ++i) Lam[i + lane * LDV] = x[i];
+      for (int i = 0; i < NV; ++i) Lam[i + lane * LDV] = x[i];
+    }
   }
   __syncthreads();
   RTOC_CPROF(3);
   if (nf > 0) {
     wave_gemm<NW>(nf, NV, NV, 1.0, J, 1, ldj, Lam, 1, LDV, 0.0, sJM, 1, LDF, lane);  // J M^-1 (:677)
     __syncthreads();
+    RTOC_CPROF(16);
     wave_gemm<NW>(nf, nf, NV, 1.0, sJM, 1, LDF, J, ldj, 1, 0.0, sS, 1, LDF, lane);   // JMinvJt (:660-661)
     __syncthreads();
     if (lane < nf) sS[lane + lane * LDF] += a.damping;  // (:662-664)
     __syncthreads();
-    if (wv == 0 && wave_llt<C::NFP, C::NFP>(sS, sS, sSinv, nf, wl)) stat |= RTOC_STAT_M_NOT_SPD;  // (:665)
-    __syncthreads();
-    if (lane < nf) {  // bottomRight = -(JMinvJt)^-1 (:673-675)
-      double x[C::NFP];
+    RTOC_CPROF(17);
+    if constexpr (C::NFP <= 16) {
+      // LLT(JMinvJt) (:665) with its inverse factor Ys; bottomRight = -(JMinvJt)^-1 = -Ys^T Ys (:673-675)
+      double* const sYs2 = sL;  // the factor of M is dead
+      if (wv == 0 && wave_llt_inv<C::NFP, C::NFP, 16>(sS, sS, sSinv, sYs2, nf, wl)) stat |= RTOC_STAT_M_NOT_SPD;
+      __syncthreads();
+      RTOC_CPROF(18);
+      wave_gemm<NW>(nf, nf, nf, -1.0, sYs2, C::NFP, 1, sYs2, 1, C::NFP, 0.0, sBR, 1, LDF, lane);
+      __syncthreads();
+      for (int e = lane; e < nf * nf; e += NT) {
+        const int i = e % nf, j = e / nf;
+        Lam[(NV + i) + (NV + j) * LDV] = sBR[i + j * LDF];
+      }
+    } else {
+      if (wv == 0 && wave_llt<C::NFP, C::NFP>(sS, sS, sSinv, nf, wl)) stat |= RTOC_STAT_M_NOT_SPD;  // (:665)
+      __syncthreads();
+      RTOC_CPROF(18);
+      if (lane < nf) {  // bottomRight = -(JMinvJt)^-1 (:673-675)
+        double x[C::NFP];
 #pragma unroll
-      for (int i = 0; i < C::NFP; ++i) x[i] = (i == lane) ? -1.0 : 0.0;
-      llt_solve_reg<C::NFP, C::NFP>(sS, sSinv, x, nf);
+        for (int i = 0; i < C::NFP; ++i) x[i] = (i == lane) ? -1.0 : 0.0;
+        llt_solve_reg<C::NFP, C::NFP>(sS, sSinv, x, nf);
 #pragma unroll
-      for (int i = 0; i < C::NFP; ++i)
-        if (i < nf) {
-          sBR[i + lane * LDF] = x[i];
-          Lam[(NV + i) + (NV + lane) * LDV] = x[i];
-        }
+        for (int i = 0; i < C::NFP; ++i)
+          if (i < nf) {
+            sBR[i + lane * LDF] = x[i];
+            Lam[(NV + i) + (NV + lane) * LDV] = x[i];
+          }
+      }
     }
     __syncthreads();
+    RTOC_CPROF(19);
     // topRight = bottomLeft^T * (-bottomRight) (:678)
     wave_gemm<NW>(NV, nf, nf, -1.0, sJM, LDF, 1, sBR, 1, LDF, 0.0, Lam + NV * LDV, 1, LDV, lane);
     __syncthreads();
+    RTOC_CPROF(20);
     // topLeft -= topRight * bottomLeft (:679) ; bottomLeft = topRight^T (:680)
     wave_gemm<NW>(NV, NV, nf, -1.0, Lam + NV * LDV, 1, LDV, sJM, 1, LDF, 1.0, Lam, 1, LDV, lane);
     for (int e = lane; e < nf * NV; e += NT) {
@@ -506,19 +552,22 @@ __global__ __launch_bounds__(128) void condense_kernel(CondArgs a) {
   // ================= Schur updates of the Hessian blocks and gradients (:90-130), in place in HBM ==
   // Each block gets ONE read-modify-write: the Qqf corrections (:92-93,:99-100,:106-107), which touch
   // the rows < NV only, ride along as a second product in the same tiles.
-  wave_gemm<NW>(NX, NX, nvf, -1.0, LD, LDV, 1, Qafqv, 1, LDV, 1.0, Qxx, 1, NX, lane,
+  wave_gemm<NW, sizeof(cQxx) / sizeof(cQxx[0])>(NX, NX, nvf, -1.0, LD, LDV, 1, Qafqv, 1, LDV, 1.0, Qxx, 1, NX, lane,
                 nf > 0 ? NV : 0, nf, 1.0, Qqf, 1, NV, LD + NV, 1, LDV, cQxx);
+  RTOC_CPROF(10);
   if (!impact) {
     if (NP > 0) {
       wave_gemm<NW>(NX, NP, nvf, -1.0, LD, LDV, 1, Qafu, 1, LDV, 0.0, Qxup, 1, NX, lane,
                     nf > 0 ? NV : 0, nf, -1.0, Qqf, 1, NV, Lam + NV, 1, LDV);
       wave_gemm<NW>(NP, NU, nvf, 1.0, Lam, 1, LDV, Qafu + NP * LDV, 1, LDV, 0.0, Quuptr, 1, NP, lane);
     }
-    wave_gemm<NW>(NX, NU, nvf, -1.0, LD, LDV, 1, Qafu + NP * LDV, 1, LDV, 1.0, Qxu, 1, NX, lane,
+    RTOC_CPROF(11);
+    wave_gemm<NW, sizeof(cQxu) / sizeof(cQxu[0])>(NX, NU, nvf, -1.0, LD, LDV, 1, Qafu + NP * LDV, 1, LDV, 1.0, Qxu, 1, NX, lane,
                   nf > 0 ? NV : 0, nf, -1.0, Qqf, 1, NV, Lam + NV + NP * LDV, 1, LDV, cQxu);
-    wave_gemm<NW>(NU, NU, nvf, 1.0, Lam + NP, 1, LDV, Qafu + NP * LDV, 1, LDV, 1.0, Quu, 1, NU, lane, 0, 0,
+    wave_gemm<NW, sizeof(cQuu) / sizeof(cQuu[0])>(NU, NU, nvf, 1.0, Lam + NP, 1, LDV, Qafu + NP * LDV, 1, LDV, 1.0, Quu, 1, NU, lane, 0, 0,
                   0.0, nullptr, 0, 0, nullptr, 0, 0, cQuu);
   }
+  RTOC_CPROF(12);
   // gradients: one lane per entry, every term of an entry in the same lane (:110-113,:123-130,:156-163)
   for (int i = lane; i < NX; i += NT) {
     double al = 0.0, ah = 0.0;
@@ -537,6 +586,7 @@ __global__ __launch_bounds__(128) void condense_kernel(CondArgs a) {
     lx[i] = l;
     if (!impact) hx[i] = h;
   }
+  RTOC_CPROF(13);
   if (!impact) {
     for (int i = lane; i < NV; i += NT) {
       double al = 0.0, ah = 0.0;

@@ -231,18 +231,19 @@ __device__ __forceinline__ bool wave_llt(const double* __restrict__ A, double* _
 // entry k", with the same broadcast scalars L[k][j], so ONE instruction stream serves both -- the
 // inverse factor costs no instructions beyond the Cholesky's own.
 // Writes L / 1/diag like wave_llt and Y column-major (ld NMAX) to Ydst.  Returns true on failure.
-template <int NMAX, int LD>
+template <int NMAX, int LD, int YOFF = 16>
 __device__ __forceinline__ bool wave_llt_inv(const double* __restrict__ A, double* __restrict__ Ldst,
                                              double* __restrict__ linv, double* __restrict__ Ydst,
                                              int n, int lane) {
-  static_assert(NMAX <= 16, "rows of G and columns of Y share one 32-lane group");
+  // rows in lanes [0, YOFF), columns of Y in lanes [YOFF, 2*YOFF): YOFF = 16 (n <= 16) or 32 (n <= 32)
+  static_assert(NMAX <= YOFF && 2 * YOFF <= 64, "rows of G and columns of Y share one wave");
   double g[NMAX];
   const int li = lane < n ? lane : 0;
-  const bool ylane = lane >= 16;
+  const bool ylane = lane >= YOFF;
 #pragma unroll
   for (int k = 0; k < NMAX; ++k) {
     const double a = (k < n) ? A[li + k * LD] : 0.0;
-    g[k] = ylane ? ((k == lane - 16) ? 1.0 : 0.0) : a;
+    g[k] = ylane ? ((k == lane - YOFF) ? 1.0 : 0.0) : a;
   }
   bool bad = false;
 #pragma unroll
@@ -251,7 +252,7 @@ __device__ __forceinline__ bool wave_llt_inv(const double* __restrict__ A, doubl
       const double d = readlane_d(g[j], j);
       if (!(d > 0.0)) bad = true;
       const double inv = rsqrt_d(d);
-      const double xj = g[j] * inv;  // L[lane][j] | Y[j][lane-16]
+      const double xj = g[j] * inv;  // L[lane][j] | Y[j][lane-YOFF]
       g[j] = xj;
       if (lane == j) linv[j] = inv;
 #pragma unroll
@@ -267,8 +268,8 @@ __device__ __forceinline__ bool wave_llt_inv(const double* __restrict__ A, doubl
 #pragma unroll
     for (int k = 0; k < NMAX; ++k)
       if (k < n) Ldst[lane + k * LD] = (k <= lane) ? g[k] : 0.0;
-  } else if (ylane && lane < 16 + NMAX) {
-    const int c = lane - 16;
+  } else if (ylane && lane < YOFF + NMAX) {
+    const int c = lane - YOFF;
 #pragma unroll
     for (int k = 0; k < NMAX; ++k) Ydst[k + c * NMAX] = (c < n && k < n) ? g[k] : 0.0;
   }
