@@ -166,13 +166,16 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a, const
     RTOC_PROF(1);
     RTOC_PROFV(17);
     // ---- stage data: prefetched registers -> LDS (vector wave) ----
+    // Hand-off vector -> matrix by sequence flags instead of a barrier: Bv and Quu first (all the
+    // matrix wave needs for PB and G), then A, Qxu and the vectors while those products run.
     if constexpr (!MW) {
-      pre_store_mat<64, NX, NX, LDP>(sA, preA, vt);
       if (!impact) {
         pre_store_flat<64, N2B>(sBv, preB, vt);
-        pre_store_mat<64, NX, NU, LDP>(sH, preH, vt);
         pre_store_flat<64, N2G>(sG, preG, vt);
       }
+      lds_signal(sFlag + 2, 3 * (N - st) - 2, lane);
+      pre_store_mat<64, NX, NX, LDP>(sA, preA, vt);
+      if (!impact) pre_store_mat<64, NX, NU, LDP>(sH, preH, vt);
       if (vt < NX) {
         smem[C::V_FX + vt] = preFx;
         smem[C::V_LX + vt] = preLx;
@@ -186,8 +189,11 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a, const
         if (sto) smem[C::V_HU + vt] = kr[KL.off[RTOC_KKT_HU] + vt];
       }
     }
-    if (sto && tid < 8) smem[C::V_KSC + tid] = kr[KL.off[RTOC_KKT_SCAL] + tid];
-    RTOC_BLOCK_SYNC();  // B1
+    if constexpr (!MW) {
+      if (sto && vt < 8) smem[C::V_KSC + vt] = kr[KL.off[RTOC_KKT_SCAL] + vt];
+      lds_signal(sFlag + 2, 3 * (N - st) - 1, lane);
+    }
+    if constexpr (MW) lds_wait(sFlag + 2, 3 * (N - st) - 2);
 
     RTOC_PROF(2);
     RTOC_PROFV(18);
@@ -347,6 +353,12 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a, const
       lds_signal(sFlag, 3 * (N - st) - 2, lane);  // G ready
     }
     RTOC_PROFV(20);
+    if constexpr (!MW) {
+      // P of the previous stage (still intact in sP until the end of this stage) -> HBM, in the
+      // shadow of the matrix wave's PB / G products
+      if (st < N - 1)
+        copy_s2g_mat<64, NX, NX, LDP>(a.ric + rinst + (size_t)(st + 1) * RL.stride + RL.off[RTOC_RIC_P], sP, vt);
+    }
     if constexpr (!MW) lds_wait(sFlag, 3 * (N - st) - 2);
     RTOC_PROFV(21);
 
@@ -446,6 +458,7 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a, const
         }
       };
       using std::integral_constant;
+      lds_wait(sFlag + 2, 3 * (N - st) - 1);  // A, Qxu, Fx in LDS
       run_pass(integral_constant<int, TMH>{}, integral_constant<int, TMA>{});
       if (!impact) {
 #pragma unroll
@@ -503,7 +516,7 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a, const
         if (vt < NU) smem[C::V_LU + vt] += smem[C::V_Y + vt];
       }
       // hand-off vector -> matrix: the inverse factor Y and lu' (psi_u, phi_u) are in LDS
-      lds_signal(sFlag + 2, N - st, lane);
+      lds_signal(sFlag + 2, 3 * (N - st), lane);
     }
 
     RTOC_PROF(4);
@@ -537,7 +550,7 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a, const
       }
       // the policy products run here, on the wave that owns the MFMA stream of this SIMD: issued
       // from the vector wave they queued behind the F chain above anyway
-      lds_wait(sFlag + 2, N - st);
+      lds_wait(sFlag + 2, 3 * (N - st));
       if (!impact && ns == 0) {
         // K = -G^-1 H^T, k = -G^-1 lu', T = -G^-1 psi_u, W = -G^-1 phi_u
         // (riccati_factorizer.cpp:55-56, :125-130) for all right-hand sides at once, as the two
@@ -870,7 +883,7 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a, const
 
     RTOC_PROF(11);
     // ---- results -> HBM; roll the LDS "next" state ----
-    copy_s2g_mat<NT, NX, NX, LDP>(rr + RL.off[RTOC_RIC_P], sP, tid);
+    // (P of this stage goes to HBM from the vector wave while it waits for the next stage's G)
     if (tid < NX) {
       const double sv = smem[C::V_SNEW + tid];
       const double psi = sto ? smem[C::V_PSI + tid] : 0.0;
@@ -897,6 +910,7 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a, const
 
   // ---- grid[0].sto: trailing phase transition writes sto_policy_[0] (riccati_recursion.cpp:75-79) ----
   RTOC_BLOCK_SYNC();
+  if (N >= 1) copy_s2g_mat<NT, NX, NX, LDP>(a.ric + rinst + RL.off[RTOC_RIC_P], sP, tid0);
   {
     const rtoc_grid g0 = a.grid[0];
     if (g0.sto && g0.sto_next) {
