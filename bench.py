@@ -133,6 +133,7 @@ def main():
     ap.add_argument("--waves", type=int, default=0, help="backward-kernel waves per instance (0=default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sqp", action="store_true", help="skip the SQP-iteration phase timing")
+    ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE.json configurations")
     args = ap.parse_args()
 
     import torch
@@ -272,6 +273,45 @@ def main():
                         "fraction-to-boundary step sizes and slack/dual update; linearisation, cost "
                         "and the manifold update of q are CPU-side and excluded"}
 
+    # ---- the other BASELINE.json configurations (parity-test cases; reported, not the headline):
+    #      batch throughput and the single-instance sweep latency a robotoc OCPSolver call would see ----
+    others = None
+    if rank == 0 and not args.no_configs:
+        others = {}
+        cfgs = [("anymal_trot_N40", pr.config_anymal_trot, 0), ("anymal_jump_sto_N40", pr.config_anymal_jump_sto, 4096),
+                ("icub_nv32_jump_N30", lambda: pr.config_icub_jump(nv=32), 1024),
+                ("icub_nv35_jump_N30", lambda: pr.config_icub_jump(nv=35), 1024), ("iiwa14_unconstr_N20", pr.config_iiwa14, 4096)]
+        for name, fn, nb in cfgs:
+            d2, g2, info = fn()
+            entry = {"stages": len(g2)}
+            for label, b2 in (("single_instance", 1), ("batch", nb)):
+                if b2 == 0:
+                    continue
+                c2 = capi.Context(d2, len(g2), b2, local_rank)
+                L2 = c2.L
+                c2.set_grid(g2)
+                if name.startswith("iiwa"):
+                    from robotoc_amd.types import Records
+                    k1 = Records(L2, "kkt").zeros(1, len(g2))
+                    pr.fill_unconstr_instance(L2, len(g2), k1[0], np.random.default_rng(1))
+                    c2.upload(BUF_KKT, np.ascontiguousarray(np.tile(k1, (b2, 1, 1))))
+                    c2.unconstr_backward(info["dt"])  # materialises the structured A, B once
+                else:
+                    c2.upload(BUF_KKT, pr.make_kkt_batch_tiled(L2, g2, b2, unique=min(b2, 4)))
+                c2.upload(BUF_DX0, np.ascontiguousarray(np.tile(pr.make_dx0(L2, 1), (b2, 1))))
+                c2.time_phase(4, 1)
+                mb, mf = c2.time_phase(0, 3), c2.time_phase(1, 3)
+                ok = int((c2.status() != 0).sum()) == 0
+                if b2 == 1:
+                    entry["single_instance_sweep_ms"] = mb + mf
+                else:
+                    entry.update({"batch": b2, "backward_ms": mb, "forward_ms": mf,
+                                  "sweeps_per_sec": b2 / (mb + mf) * 1e3,
+                                  "backward_GBs_algorithmic": algorithmic_bytes(L2, g2, b2, "backward") / mb / 1e6})
+                entry["status_ok"] = entry.get("status_ok", True) and ok
+                c2.close()
+            others[name] = entry
+
     if rank == 0:
         total_sweeps = world * batch * args.steps
         value = total_sweeps / dt
@@ -308,6 +348,8 @@ def main():
         }
         if sqp is not None:
             res["sqp_iteration"] = sqp
+        if others is not None:
+            res["other_configs"] = others
         if gathered_ok is not None:
             res["rccl_gather_ok"] = gathered_ok
         if world == 1 and not args.no_cpu_baseline:

@@ -13,9 +13,9 @@ timeout 600 python bench.py ${BENCH_ARGS:-} > $OUT/bench.json 2> $OUT/bench.err
 if [ "${SKIP_PROF:-0}" != "1" ]; then
   export TMPDIR=/tmp
   cd /tmp
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -o stats -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-sqp ${BENCH_ARGS:-} > $OUT/prof_stats.log 2>&1
-  timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/prof_fetch -o fetch -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-sqp ${BENCH_ARGS:-} > $OUT/prof_fetch.log 2>&1
-  timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/prof_write -o write -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-sqp ${BENCH_ARGS:-} > $OUT/prof_write.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -o stats -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-sqp --no-configs ${BENCH_ARGS:-} > $OUT/prof_stats.log 2>&1
+  timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/prof_fetch -o fetch -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-sqp --no-configs ${BENCH_ARGS:-} > $OUT/prof_fetch.log 2>&1
+  timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/prof_write -o write -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-sqp --no-configs ${BENCH_ARGS:-} > $OUT/prof_write.log 2>&1
   cd $R
   find $OUT/prof_stats $OUT/prof_fetch $OUT/prof_write -name "*.csv" | head -20 > $OUT/prof_files.txt
 fi
