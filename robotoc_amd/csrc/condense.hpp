@@ -21,6 +21,7 @@
 #pragma once
 #include "device_utils.hpp"
 #include "riccati_backward.hpp"  // wave_llt, llt_solve_reg
+#include "lds_gemm.hpp"
 #include "../../include/rtoc.h"
 
 namespace rtoc {
@@ -239,6 +240,31 @@ __device__ __forceinline__ void prefetch_c(int M, int N, const double* C, int cr
   }
 }
 
+// The C values of the 16x16 tiles lds_gemm<NW, M, N, ...> deals to this wave (tile t -> wave t % NW,
+// slot t / NW), fetched from HBM ahead of time; C(i,j) = C[i + j*LDC].
+template <int NW, int M, int N, int LDC, int SLOTS>
+__device__ __forceinline__ void prefetch_tiles(const double* C, int tid, double (&out)[SLOTS][4]) {
+  constexpr int TM = (M + 15) / 16, TN = (N + 15) / 16;
+  static_assert(SLOTS * NW >= TM * TN, "not enough slots");
+  const int lane = tid & 63, wave = tid >> 6, li = lane & 15, q = lane >> 4;
+#pragma unroll
+  for (int t = 0; t < TM * TN; ++t) {
+    if ((t % NW) != wave) continue;
+    const int tm = t / TN, tn = t % TN;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = tm * 16 + drow(q, r), col = tn * 16 + li;
+      const bool ok = row < M && col < N;
+      const double v = C[ok ? row + col * LDC : 0];
+      out[t / NW][r] = ok ? v : 0.0;
+    }
+  }
+}
+template <int NW, int M, int N>
+struct TileSlots {
+  static constexpr int value = (((M + 15) / 16) * ((N + 15) / 16) + NW - 1) / NW;
+};
+
 // y(i) = beta*y(i) + alpha * sum_k A(i,k) x(k): one lane per row, operands anywhere.
 template <int NT>
 __device__ __forceinline__ void wave_gemv(int M, int K, double alpha, const double* A, int ars, int acs,
@@ -388,12 +414,12 @@ __global__ __launch_bounds__(128) void condense_kernel(CondArgs a) {
                vHf = cr[co[RTOC_CDD_HF] + lf_], vIdc = cr[co[RTOC_CDD_IDC] + lvf_];
   // the Hessian blocks the Schur updates read-modify-write: fetched now (after the PDIPM diagonal
   // terms above landed), consumed ~100k cycles later -- their HBM latency is off the chain
-  double cQxx[(((NX + 15) / 16) * (((NX + 15) / 16 + 1) / 2) + NW - 1) / NW][8];
-  double cQxu[(((NX + 15) / 16) * (((NU + 15) / 16 + 1) / 2) + NW - 1) / NW][8];
-  double cQuu[(((NU + 15) / 16) * (((NU + 15) / 16 + 1) / 2) + NW - 1) / NW][8];
-  prefetch_c<NW>(NX, NX, Qxx, 1, NX, lane, cQxx);
-  prefetch_c<NW>(NX, NU, Qxu, 1, NX, lane, cQxu);
-  prefetch_c<NW>(NU, NU, Quu, 1, NU, lane, cQuu);
+  double cQxx[TileSlots<NW, NX, NX>::value][4];
+  double cQxu[TileSlots<NW, NX, NU>::value][4];
+  double cQuu[TileSlots<NW, NU, NU>::value][4];
+  prefetch_tiles<NW, NX, NX, NX>(Qxx, lane, cQxx);
+  prefetch_tiles<NW, NX, NU, NX>(Qxu, lane, cQxu);
+  prefetch_tiles<NW, NU, NU, NU>(Quu, lane, cQuu);
   // inactive rows / columns (dimf < max_dimf) of the stored blocks stay zero, like the reference's
   // max-size backing matrices
   for (int e = lane; e < LDV * LDV; e += NT) Lam[e] = 0.0;
@@ -411,12 +437,26 @@ __global__ __launch_bounds__(128) void condense_kernel(CondArgs a) {
     laf[lane] = vLa;
     haf[lane] = vHa;
   }
-  if (lane < nf) {
-    laf[NV + lane] = -vLf;
-    haf[NV + lane] = -vHf;
+  if (lane < NF) {  // zero beyond the active contact dimension: the products run over the full extents
+    laf[NV + lane] = lane < nf ? -vLf : 0.0;
+    haf[NV + lane] = lane < nf ? -vHf : 0.0;
   }
-  if (lane < nvf) IDC[lane] = vIdc;
+  if (lane < LDV) IDC[lane] = lane < nvf ? vIdc : 0.0;
   __syncthreads();
+  if (nf < NF) {
+    // inactive rows / columns of the max-size blocks are unspecified in the record: zero them in
+    // LDS so that every product below can use its compile-time extents
+    for (int e = lane; e < (LDV - nvf) * NX; e += NT) D[nvf + e % (LDV - nvf) + (e / (LDV - nvf)) * LDV] = 0.0;
+    if (!impact) {
+      for (int e = lane; e < (NF - nf) * NV; e += NT) sJ[nf + e % (NF - nf) + (e / (NF - nf)) * LDF] = 0.0;
+    } else {
+      // J = dCdv lives inside D (rows NV.., columns NV..): its inactive rows were zeroed with D's
+    }
+    for (int e = lane; e < LDF * LDF; e += NT)
+      if (e % LDF >= nf || e / LDF >= nf) Qff[e] = 0.0;
+    for (int e = lane; e < NV * (NF - nf); e += NT) Qqf[nf * NV + e] = 0.0;
+    __syncthreads();
+  }
   // J: dCda (ld NF) on contact grids, dCdv = D[nv:, nv:] (ld LDV) on impact grids
   const double* const J = impact ? D + NV + (size_t)NV * LDV : sJ;
   const int ldj = impact ? LDV : LDF;
@@ -433,7 +473,8 @@ __global__ __launch_bounds__(128) void condense_kernel(CondArgs a) {
     if (wv == 0 && wave_llt_inv<NV, NV, 32>(sL, sL, sLinv, sYs, NV, wl)) stat |= RTOC_STAT_M_NOT_SPD;
     __syncthreads();
     RTOC_CPROF(2);
-    wave_gemm<NW>(NV, NV, NV, 1.0, sYs, NV, 1, sYs, 1, NV, 0.0, Lam, 1, LDV, lane);  // topLeft = M^-1
+    lds_gemm<NW, NV, NV, NV, NV, 1, 1, NV>(sYs, sYs, lane,
+                                           [&](int r, int c, double v, int, int) { Lam[r + c * LDV] = v; });  // topLeft = M^-1
     __syncthreads();
     if (NF == 0)
       for (int e = lane; e < LDV * NX; e += NT) LD[e] = 0.0;
@@ -453,10 +494,18 @@ __global__ __launch_bounds__(128) void condense_kernel(CondArgs a) {
   __syncthreads();
   RTOC_CPROF(3);
   if (nf > 0) {
-    wave_gemm<NW>(nf, NV, NV, 1.0, J, 1, ldj, Lam, 1, LDV, 0.0, sJM, 1, LDF, lane);  // J M^-1 (:677)
+    auto st_jm = [&](int r, int c, double v, int, int) { sJM[r + c * LDF] = v; };
+    if (!impact)
+      lds_gemm<NW, C::NFP, NV, NV, 1, LDF, 1, LDV>(sJ, Lam, lane, st_jm);  // J M^-1 (:677)
+    else
+      lds_gemm<NW, C::NFP, NV, NV, 1, LDV, 1, LDV>(J, Lam, lane, st_jm);
     __syncthreads();
     RTOC_CPROF(16);
-    wave_gemm<NW>(nf, nf, NV, 1.0, sJM, 1, LDF, J, ldj, 1, 0.0, sS, 1, LDF, lane);   // JMinvJt (:660-661)
+    auto st_s = [&](int r, int c, double v, int, int) { sS[r + c * LDF] = v; };
+    if (!impact)
+      lds_gemm<NW, C::NFP, C::NFP, NV, 1, LDF, LDF, 1>(sJM, sJ, lane, st_s);  // JMinvJt (:660-661)
+    else
+      lds_gemm<NW, C::NFP, C::NFP, NV, 1, LDF, LDV, 1>(sJM, J, lane, st_s);
     __syncthreads();
     if (lane < nf) sS[lane + lane * LDF] += a.damping;  // (:662-664)
     __syncthreads();
@@ -467,12 +516,10 @@ __global__ __launch_bounds__(128) void condense_kernel(CondArgs a) {
       if (wv == 0 && wave_llt_inv<C::NFP, C::NFP, 16>(sS, sS, sSinv, sYs2, nf, wl)) stat |= RTOC_STAT_M_NOT_SPD;
       __syncthreads();
       RTOC_CPROF(18);
-      wave_gemm<NW>(nf, nf, nf, -1.0, sYs2, C::NFP, 1, sYs2, 1, C::NFP, 0.0, sBR, 1, LDF, lane);
-      __syncthreads();
-      for (int e = lane; e < nf * nf; e += NT) {
-        const int i = e % nf, j = e / nf;
-        Lam[(NV + i) + (NV + j) * LDV] = sBR[i + j * LDF];
-      }
+      lds_gemm<NW, C::NFP, C::NFP, C::NFP, C::NFP, 1, 1, C::NFP>(sYs2, sYs2, lane, [&](int r, int c, double v, int, int) {
+        sBR[r + c * LDF] = -v;
+        Lam[(NV + r) + (NV + c) * LDV] = -v;
+      });
     } else {
       if (wv == 0 && wave_llt<C::NFP, C::NFP>(sS, sS, sSinv, nf, wl)) stat |= RTOC_STAT_M_NOT_SPD;  // (:665)
       __syncthreads();
@@ -493,11 +540,13 @@ __global__ __launch_bounds__(128) void condense_kernel(CondArgs a) {
     __syncthreads();
     RTOC_CPROF(19);
     // topRight = bottomLeft^T * (-bottomRight) (:678)
-    wave_gemm<NW>(NV, nf, nf, -1.0, sJM, LDF, 1, sBR, 1, LDF, 0.0, Lam + NV * LDV, 1, LDV, lane);
+    lds_gemm<NW, NV, C::NFP, C::NFP, LDF, 1, 1, LDF>(sJM, sBR, lane,
+                                                     [&](int r, int c, double v, int, int) { Lam[r + (NV + c) * LDV] = -v; });
     __syncthreads();
     RTOC_CPROF(20);
     // topLeft -= topRight * bottomLeft (:679) ; bottomLeft = topRight^T (:680)
-    wave_gemm<NW>(NV, NV, nf, -1.0, Lam + NV * LDV, 1, LDV, sJM, 1, LDF, 1.0, Lam, 1, LDV, lane);
+    lds_gemm<NW, NV, NV, C::NFP, 1, LDV, 1, LDF>(Lam + NV * LDV, sJM, lane,
+                                                 [&](int r, int c, double v, int, int) { Lam[r + c * LDV] -= v; });
     for (int e = lane; e < nf * NV; e += NT) {
       const int i = e % nf, j = e / nf;
       Lam[(NV + i) + j * LDV] = Lam[j + (NV + i) * LDV];
@@ -508,10 +557,11 @@ __global__ __launch_bounds__(128) void condense_kernel(CondArgs a) {
   RTOC_CPROF(4);
   // ================= MJtJinv_dIDCdqv, MJtJinv_IDC (contact_dynamics.cpp:64-65 / impact :44-50) ===
   if (!impact) {
-    wave_gemm<NW>(nvf, NX, nvf, 1.0, Lam, 1, LDV, D, 1, LDV, 0.0, LD, 1, LDV, lane);
+    lds_gemm<NW, LDV, NX, LDV, 1, LDV, 1, LDV>(Lam, D, lane, [&](int r, int c, double v, int, int) { LD[r + c * LDV] = v; });
   } else {
-    wave_gemm<NW>(nvf, NV, nvf, 1.0, Lam, 1, LDV, D, 1, LDV, 0.0, LD, 1, LDV, lane);
-    wave_gemm<NW>(nvf, NV, nf, 1.0, Lam + NV * LDV, 1, LDV, J, 1, ldj, 0.0, LD + NV * LDV, 1, LDV, lane);
+    lds_gemm<NW, LDV, NV, LDV, 1, LDV, 1, LDV>(Lam, D, lane, [&](int r, int c, double v, int, int) { LD[r + c * LDV] = v; });
+    lds_gemm<NW, LDV, NV, C::NFP, 1, LDV, 1, LDV>(Lam + NV * LDV, J, lane,
+                                                  [&](int r, int c, double v, int, int) { LD[r + (NV + c) * LDV] = v; });
   }
   wave_gemv<NT>(nvf, nvf, 1.0, Lam, 1, LDV, IDC, 0.0, Lr, lane);
   __syncthreads();  // D (and J inside it) is dead from here on: its space becomes Qafqv; region X becomes Qafu
@@ -533,17 +583,17 @@ __global__ __launch_bounds__(128) void condense_kernel(CondArgs a) {
     }
   if (lane < NV) laf[lane] -= Qaa[lane] * Lr[lane];
   if (nf > 0) {
-    wave_gemm<NW>(nf, NX, nf, -1.0, Qff, 1, LDF, LD + NV, 1, LDV, 0.0, Qafqv + NV, 1, LDV, lane);
-    if (!impact) wave_gemm<NW>(nf, NV, nf, 1.0, Qff, 1, LDF, Lam + NV, 1, LDV, 0.0, Qafu + NV, 1, LDV, lane);
+    // Qafqv[f rows] = -Qff (MJtJinv_dIDCdqv)[f rows] - [Qqf^T | 0]  (:76-80)
+    lds_gemm<NW, C::NFP, NX, C::NFP, 1, LDF, 1, LDV>(Qff, LD + NV, lane, [&](int r, int c, double v, int, int) {
+      Qafqv[(NV + r) + c * LDV] = -v - (c < NV ? Qqf[c + r * NV] : 0.0);
+    });
+    if (!impact)
+      lds_gemm<NW, C::NFP, NV, C::NFP, 1, LDF, 1, LDV>(Qff, Lam + NV, lane,
+                                                       [&](int r, int c, double v, int, int) { Qafu[(NV + r) + c * LDV] = v; });
     if (lane < nf) {
       double acc = 0.0;
       for (int k = 0; k < nf; ++k) acc += Qff[lane + k * LDF] * Lr[NV + k];
       laf[NV + lane] -= acc;
-    }
-    __syncthreads();
-    for (int e = lane; e < nf * NV; e += NT) {
-      const int i = e % nf, j = e / nf;
-      Qafqv[(NV + i) + j * LDV] -= Qqf[j + i * NV];
     }
   }
   __syncthreads();
@@ -552,20 +602,30 @@ __global__ __launch_bounds__(128) void condense_kernel(CondArgs a) {
   // ================= Schur updates of the Hessian blocks and gradients (:90-130), in place in HBM ==
   // Each block gets ONE read-modify-write: the Qqf corrections (:92-93,:99-100,:106-107), which touch
   // the rows < NV only, ride along as a second product in the same tiles.
-  wave_gemm<NW, sizeof(cQxx) / sizeof(cQxx[0])>(NX, NX, nvf, -1.0, LD, LDV, 1, Qafqv, 1, LDV, 1.0, Qxx, 1, NX, lane,
-                nf > 0 ? NV : 0, nf, 1.0, Qqf, 1, NV, LD + NV, 1, LDV, cQxx);
+  lds_gemm2<NW, NX, NX, LDV, LDV, 1, 1, LDV, NV, C::NFP, 1, NV, 1, LDV>(
+      LD, Qafqv, Qqf, LD + NV, nf > 0, lane, [&](int r, int c, double v1, double v2, int slot, int reg) {
+        Qxx[r + (size_t)c * NX] = cQxx[slot][reg] - v1 + v2;
+      });
   RTOC_CPROF(10);
   if (!impact) {
-    if (NP > 0) {
-      wave_gemm<NW>(NX, NP, nvf, -1.0, LD, LDV, 1, Qafu, 1, LDV, 0.0, Qxup, 1, NX, lane,
-                    nf > 0 ? NV : 0, nf, -1.0, Qqf, 1, NV, Lam + NV, 1, LDV);
-      wave_gemm<NW>(NP, NU, nvf, 1.0, Lam, 1, LDV, Qafu + NP * LDV, 1, LDV, 0.0, Quuptr, 1, NP, lane);
+    if constexpr (NP > 0) {
+      lds_gemm2<NW, NX, NP, LDV, LDV, 1, 1, LDV, NV, C::NFP, 1, NV, 1, LDV>(
+          LD, Qafu, Qqf, Lam + NV, nf > 0, lane,
+          [&](int r, int c, double v1, double v2, int, int) { Qxup[r + (size_t)c * NX] = -v1 - v2; });
+      lds_gemm<NW, NP, NU, LDV, 1, LDV, 1, LDV>(Lam, Qafu + NP * LDV, lane, [&](int r, int c, double v, int, int) {
+        Quuptr[r + (size_t)c * NP] = v;
+      });
     }
     RTOC_CPROF(11);
-    wave_gemm<NW, sizeof(cQxu) / sizeof(cQxu[0])>(NX, NU, nvf, -1.0, LD, LDV, 1, Qafu + NP * LDV, 1, LDV, 1.0, Qxu, 1, NX, lane,
-                  nf > 0 ? NV : 0, nf, -1.0, Qqf, 1, NV, Lam + NV + NP * LDV, 1, LDV, cQxu);
-    wave_gemm<NW, sizeof(cQuu) / sizeof(cQuu[0])>(NU, NU, nvf, 1.0, Lam + NP, 1, LDV, Qafu + NP * LDV, 1, LDV, 1.0, Quu, 1, NU, lane, 0, 0,
-                  0.0, nullptr, 0, 0, nullptr, 0, 0, cQuu);
+    lds_gemm2<NW, NX, NU, LDV, LDV, 1, 1, LDV, NV, C::NFP, 1, NV, 1, LDV>(
+        LD, Qafu + NP * LDV, Qqf, Lam + NV + NP * LDV, nf > 0, lane,
+        [&](int r, int c, double v1, double v2, int slot, int reg) {
+          Qxu[r + (size_t)c * NX] = cQxu[slot][reg] - v1 - v2;
+        });
+    lds_gemm<NW, NU, NU, LDV, 1, LDV, 1, LDV>(Lam + NP, Qafu + NP * LDV, lane,
+                                              [&](int r, int c, double v, int slot, int reg) {
+                                                Quu[r + (size_t)c * NU] = cQuu[slot][reg] + v;
+                                              });
   }
   RTOC_CPROF(12);
   // gradients: one lane per entry, every term of an entry in the same lane (:110-113,:123-130,:156-163)
