@@ -26,6 +26,11 @@
 
 namespace rtoc {
 
+__device__ __forceinline__ void wave_lds_sync_() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+
 #define RTOC_CPROF(k)                                                                   \
   do {                                                                                  \
     if (a.prof && blockIdx.x == 0 && threadIdx.x == 0) a.prof[(k)] = (long long)__builtin_readcyclecounter(); \
@@ -513,12 +518,19 @@ __global__ __launch_bounds__(128) void condense_kernel(CondArgs a) {
     if constexpr (C::NFP <= 16) {
       // LLT(JMinvJt) (:665) with its inverse factor Ys; bottomRight = -(JMinvJt)^-1 = -Ys^T Ys (:673-675)
       double* const sYs2 = sL;  // the factor of M is dead
-      if (wv == 0 && wave_llt_inv<C::NFP, C::NFP, 16>(sS, sS, sSinv, sYs2, nf, wl)) stat |= RTOC_STAT_M_NOT_SPD;
+      if (wv == 0) {
+        // the inactive part of S is zero: factorise the full NFP x NFP block with a unit diagonal there
+        // (compile-time size: no per-entry `k < n` tests in the unrolled factorisation)
+        if (wl >= nf && wl < C::NFP) sS[wl + wl * LDF] = 1.0;
+        wave_lds_sync_();
+        if (wave_llt_inv<C::NFP, C::NFP, 16>(sS, sS, sSinv, sYs2, C::NFP, wl)) stat |= RTOC_STAT_M_NOT_SPD;
+      }
       __syncthreads();
       RTOC_CPROF(18);
       lds_gemm<NW, C::NFP, C::NFP, C::NFP, C::NFP, 1, 1, C::NFP>(sYs2, sYs2, lane, [&](int r, int c, double v, int, int) {
-        sBR[r + c * LDF] = -v;
-        Lam[(NV + r) + (NV + c) * LDV] = -v;
+        const double w = (r < nf && c < nf) ? -v : 0.0;  // drop the padded identity block
+        sBR[r + c * LDF] = w;
+        Lam[(NV + r) + (NV + c) * LDV] = w;
       });
     } else {
       if (wv == 0 && wave_llt<C::NFP, C::NFP>(sS, sS, sSinv, nf, wl)) stat |= RTOC_STAT_M_NOT_SPD;  // (:665)
