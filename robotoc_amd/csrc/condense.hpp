@@ -252,16 +252,18 @@ __device__ __forceinline__ void prefetch_tiles(const double* C, int tid, double 
   constexpr int TM = (M + 15) / 16, TN = (N + 15) / 16;
   static_assert(SLOTS * NW >= TM * TN, "not enough slots");
   const int lane = tid & 63, wave = tid >> 6, li = lane & 15, q = lane >> 4;
+  // branch-free over the slots (tile index computed from the wave id) and no select on the loaded
+  // values: out-of-range lanes read element 0 and are never consumed (the epilogue masks them), so
+  // nothing here forces an s_waitcnt before the loads of the other fields are in flight
 #pragma unroll
-  for (int t = 0; t < TM * TN; ++t) {
-    if ((t % NW) != wave) continue;
-    const int tm = t / TN, tn = t % TN;
+  for (int p = 0; p < SLOTS; ++p) {
+    const int t = p * NW + wave;
+    const int tm = t / TN, tn = t - tm * TN;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = tm * 16 + drow(q, r), col = tn * 16 + li;
-      const bool ok = row < M && col < N;
-      const double v = C[ok ? row + col * LDC : 0];
-      out[t / NW][r] = ok ? v : 0.0;
+      const bool ok = t < TM * TN && row < M && col < N;
+      out[p][r] = C[ok ? row + col * LDC : 0];
     }
   }
 }
@@ -417,6 +419,11 @@ __global__ __launch_bounds__(128) void condense_kernel(CondArgs a) {
   const double vQaa = cr[co[RTOC_CDD_QAA] + lv_], vLa = cr[co[RTOC_CDD_LA] + lv_],
                vHa = cr[co[RTOC_CDD_HA] + lv_], vLf = cr[co[RTOC_CDD_LF] + lf_],
                vHf = cr[co[RTOC_CDD_HF] + lf_], vIdc = cr[co[RTOC_CDD_IDC] + lvf_];
+  // gradient / sensitivity entries that get one read-modify-write at the end: fetched now as well
+  const int ix_ = lane < NX ? lane : 0, iv_ = lane < NV ? lane : 0;
+  const double pLx = lx[ix_], pHx = hx[ix_], pFf = fx[ix_], pFxv = Fx[NV + iv_];
+  const double pLup = lup[iv_ < NP ? iv_ : 0], pLu = lu[iv_ >= NP ? iv_ - NP : 0], pHu = hu[iv_ >= NP ? iv_ - NP : 0];
+  const double pSh = scal[RTOC_KKT_SCAL_H], pSq = scal[RTOC_KKT_SCAL_QTT];
   // the Hessian blocks the Schur updates read-modify-write: fetched now (after the PDIPM diagonal
   // terms above landed), consumed ~100k cycles later -- their HBM latency is off the chain
   double cQxx[TileSlots<NW, NX, NX>::value][4];
@@ -425,10 +432,12 @@ __global__ __launch_bounds__(128) void condense_kernel(CondArgs a) {
   prefetch_tiles<NW, NX, NX, NX>(Qxx, lane, cQxx);
   prefetch_tiles<NW, NX, NU, NX>(Qxu, lane, cQxu);
   prefetch_tiles<NW, NU, NU, NU>(Quu, lane, cQuu);
+  RTOC_CPROF(21);
   // inactive rows / columns (dimf < max_dimf) of the stored blocks stay zero, like the reference's
   // max-size backing matrices
   for (int e = lane; e < LDV * LDV; e += NT) Lam[e] = 0.0;
   for (int e = lane; e < LDV * NX; e += NT) LD[e] = 0.0;
+  RTOC_CPROF(22);
   // ================= registers -> LDS =================
   RTOC_ST2(sL, gL, N_L, H_L)
   RTOC_ST2(D, gD, N_D, H_D)
@@ -437,6 +446,7 @@ __global__ __launch_bounds__(128) void condense_kernel(CondArgs a) {
   RTOC_ST2(Qqf, gQ, N_J, H_J)
 #undef RTOC_LD2
 #undef RTOC_ST2
+  RTOC_CPROF(23);
   if (lane < NV) {
     Qaa[lane] = vQaa;
     laf[lane] = vLa;
@@ -575,7 +585,7 @@ __global__ __launch_bounds__(128) void condense_kernel(CondArgs a) {
     lds_gemm<NW, LDV, NV, C::NFP, 1, LDV, 1, LDV>(Lam + NV * LDV, J, lane,
                                                   [&](int r, int c, double v, int, int) { LD[r + (NV + c) * LDV] = v; });
   }
-  wave_gemv<NT>(nvf, nvf, 1.0, Lam, 1, LDV, IDC, 0.0, Lr, lane);
+  wave_gemv<NT>(LDV, LDV, 1.0, Lam, 1, LDV, IDC, 0.0, Lr, lane);  // full extents: zero rows give Lr = 0 there
   __syncthreads();  // D (and J inside it) is dead from here on: its space becomes Qafqv; region X becomes Qafu
   for (int e = lane; e < LDV * NX; e += NT) Qafqv[e] = 0.0;
   if (!impact)
@@ -640,40 +650,65 @@ __global__ __launch_bounds__(128) void condense_kernel(CondArgs a) {
                                               });
   }
   RTOC_CPROF(12);
-  // gradients: one lane per entry, every term of an entry in the same lane (:110-113,:123-130,:156-163)
-  for (int i = lane; i < NX; i += NT) {
-    double al = 0.0, ah = 0.0;
-    for (int k = 0; k < nvf; ++k) {
+  // gradients: one lane per entry, every term of an entry in the same lane (:110-113,:123-130,:156-163);
+  // sums run over the full zero-padded extents with four accumulators, and the evalKKT tail scalings
+  // (intermediate_stage.cpp:140-148) are applied here so that every entry is written exactly once
+  const double inv = impact ? 1.0 : 1.0 / (double)g.num_grids_in_phase;
+  if (lane < NX) {
+    const int i = lane;
+    double al[4] = {0.0, 0.0, 0.0, 0.0}, ah[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < LDV; ++k) {
       const double ld = LD[k + i * LDV];
-      al += ld * laf[k];
-      ah += ld * haf[k];
+      al[k & 3] += ld * laf[k];
+      ah[k & 3] += ld * haf[k];
     }
-    double l = lx[i] - al, h = impact ? 0.0 : hx[i] - ah;
+    double l = pLx - ((al[0] + al[1]) + (al[2] + al[3])), h = pHx - ((ah[0] + ah[1]) + (ah[2] + ah[3]));
     if (i < NV && nf > 0) {
-      double aq = 0.0;
-      for (int k = 0; k < nf; ++k) aq += Qqf[i + k * NV] * Lr[NV + k];
-      l += aq;
-      h += aq / dt;
+      double aq0 = 0.0, aq1 = 0.0;
+#pragma unroll
+      for (int k = 0; k < NF; ++k) {
+        if (k & 1)
+          aq1 += Qqf[i + k * NV] * Lr[NV + k];
+        else
+          aq0 += Qqf[i + k * NV] * Lr[NV + k];
+      }
+      l += aq0 + aq1;
+      h += (aq0 + aq1) / dt;
     }
     lx[i] = l;
-    if (!impact) hx[i] = h;
+    if (!impact) {
+      hx[i] = h * inv;
+      fx[i] = pFf * inv;
+    }
   }
   RTOC_CPROF(13);
-  if (!impact) {
-    for (int i = lane; i < NV; i += NT) {
-      double al = 0.0, ah = 0.0;
-      for (int k = 0; k < nvf; ++k) {
-        const double lm = Lam[i + k * LDV];
-        al += lm * laf[k];
-        ah += lm * haf[k];
-      }
-      if (i < NP) {
-        lup[i] += al;
-      } else {
-        lu[i - NP] += al;
-        hu[i - NP] += ah;
-      }
+  if (!impact && lane < NV) {
+    const int i = lane;
+    double al[4] = {0.0, 0.0, 0.0, 0.0}, ah[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < LDV; ++k) {
+      const double lm = Lam[i + k * LDV];
+      al[k & 3] += lm * laf[k];
+      ah[k & 3] += lm * haf[k];
     }
+    const double sl = (al[0] + al[1]) + (al[2] + al[3]), sh = (ah[0] + ah[1]) + (ah[2] + ah[3]);
+    if (i < NP) {
+      lup[i] = pLup + sl;
+    } else {
+      lu[i - NP] = pLu + sl;
+      hu[i - NP] = (pHu + sh) * inv;
+    }
+  }
+  if (!impact && lane == NT - 1) {
+    // h -= MJtJinv_IDC . haf, then the 1/num_grids_in_phase scalings of h and Qtt (:144-147)
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < LDV; ++k) acc[k & 3] += Lr[k] * haf[k];
+    scal[RTOC_KKT_SCAL_H] = (pSh - ((acc[0] + acc[1]) + (acc[2] + acc[3]))) * inv;
+    const double qtt = pSq * inv * inv;
+    scal[RTOC_KKT_SCAL_QTT] = qtt;
+    scal[RTOC_KKT_SCAL_QTT_PREV] = -qtt;
   }
 
   RTOC_CPROF(7);
@@ -689,7 +724,7 @@ __global__ __launch_bounds__(128) void condense_kernel(CondArgs a) {
       const int i = e % NV, j = e / NV;
       Fvu[i + (size_t)j * NV] = dt * Lam[i + (NP + j) * LDV];
     }
-  if (lane < NV) Fx[NV + lane] -= sdt * Lr[lane];
+  if (lane < NV) Fx[NV + lane] = pFxv - sdt * Lr[lane];
 
   if (!impact) {
     // ================= switching constraint (:138-153) =================
@@ -703,22 +738,6 @@ __global__ __launch_bounds__(128) void condense_kernel(CondArgs a) {
         Pres[lane] -= acc;
       }
     }
-    __syncthreads();
-    // ================= h, and the evalKKT tail scalings (intermediate_stage.cpp:140-148) ========
-    const double inv = 1.0 / (double)g.num_grids_in_phase;
-    if (lane == 0) {
-      double acc = 0.0;
-      for (int k = 0; k < nvf; ++k) acc += Lr[k] * haf[k];
-      scal[RTOC_KKT_SCAL_H] = (scal[RTOC_KKT_SCAL_H] - acc) * inv;
-      const double qtt = scal[RTOC_KKT_SCAL_QTT] * inv * inv;
-      scal[RTOC_KKT_SCAL_QTT] = qtt;
-      scal[RTOC_KKT_SCAL_QTT_PREV] = -qtt;
-    }
-    for (int i = lane; i < NX; i += NT) {
-      hx[i] *= inv;
-      fx[i] *= inv;
-    }
-    if (lane < NU) hu[lane] *= inv;
   }
 
   RTOC_CPROF(8);

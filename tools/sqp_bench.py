@@ -29,6 +29,7 @@ if len(sys.argv) > 2:
     pp = capi.debug_profile(ctx).reshape(-1)
     print("KKT phase detail: Qxx %d | Qxup,Quuptr %d | Qxu,Quu %d | grad x %d | grad u %d" % (pp[10] - pp[6], pp[11] - pp[10], pp[12] - pp[11], pp[13] - pp[12], pp[7] - pp[13]))
     print("Lam phase detail: JMinv %d | S %d | LLT(S) %d | Sinv %d | TR %d | TL %d" % (pp[16] - pp[3], pp[17] - pp[16], pp[18] - pp[17], pp[19] - pp[18], pp[20] - pp[19], pp[4] - pp[20]))
+    print("load phase detail: issue %d | zero fill %d | wait+store %d | barrier,cleanup %d" % (pp[21] - pp[0], pp[22] - pp[21], pp[23] - pp[22], pp[1] - pp[23]))
     p = pp[:10]
     names = ["load", "LLT(M)", "Minv", "J..Lam", "LD,Lr", "Qafqv/Qafu", "KKT updates", "dyn+SC+tail", "s2g"]
     print("condense item 0 ticks:", {n: int(x) for n, x in zip(names, np.diff(p))}, "total", int(p[9] - p[0]))
