@@ -33,7 +33,7 @@ __device__ __forceinline__ void wave_lds_sync_() {
 
 #define RTOC_CPROF(k)                                                                   \
   do {                                                                                  \
-    if (a.prof && blockIdx.x == 0 && threadIdx.x == 0) a.prof[(k)] = (long long)__builtin_readcyclecounter(); \
+    if (a.prof && blockIdx.x == (gridDim.x >> 1) && threadIdx.x == 0) a.prof[(k)] = (long long)__builtin_readcyclecounter(); \
   } while (0)
 
 struct CondArgs {
@@ -320,30 +320,32 @@ __global__ __launch_bounds__(128) void condense_kernel(CondArgs a) {
   const bool impact = g.type == RTOC_GRID_IMPACT;
   const int nf = g.dimf, nvf = NV + nf, ns = impact ? 0 : g.dims;
   const double dt = g.dt;
-  double* kr = a.kkt + ((size_t)b * a.nstages + st) * a.kl.stride;
-  double* cr = a.cdd + ((size_t)b * a.nstages + st) * a.cl.stride;
-  const int* ko = a.kl.off;
-  const int* co = a.cl.off;
-  double* const Fxx = kr + ko[RTOC_KKT_FXX];
-  double* const Fvu = kr + ko[RTOC_KKT_FVU];
-  double* const Qxx = kr + ko[RTOC_KKT_QXX];
-  double* const Qxu = kr + ko[RTOC_KKT_QXU];
-  double* const Quu = kr + ko[RTOC_KKT_QUU];
-  double* const Fx = kr + ko[RTOC_KKT_FX];
-  double* const lx = kr + ko[RTOC_KKT_LX];
-  double* const lu = kr + ko[RTOC_KKT_LU];
-  double* const fx = kr + ko[RTOC_KKT_FFX];
-  double* const hx = kr + ko[RTOC_KKT_HX];
-  double* const hu = kr + ko[RTOC_KKT_HU];
-  double* const scal = kr + ko[RTOC_KKT_SCAL];
-  double* const Phix = kr + ko[RTOC_KKT_PHIX];
-  double* const Phiu = kr + ko[RTOC_KKT_PHIU];
-  double* const Phit = kr + ko[RTOC_KKT_PHIT];
-  double* const Pres = kr + ko[RTOC_KKT_PRES];
-  const double* const Phia = cr + co[RTOC_CDD_PHIA];
-  double* const lup = cr + co[RTOC_CDD_LUP];
-  double* const Qxup = cr + co[RTOC_CDD_QXUP];
-  double* const Quuptr = cr + co[RTOC_CDD_QUUPTR];
+  // record offsets as immediates (StaticLayout: the host checks them against the run-time layout)
+  constexpr rtoc_layout SL = StaticLayout<NV, NU, NS>::make();
+  constexpr rtoc_record_layout KL = SL.kkt, CL = SL.cdd;
+  static_assert(NF == NS, "kernel sets are built with nf_max == ns_max");
+  double* kr = a.kkt + ((size_t)b * a.nstages + st) * KL.stride;
+  double* cr = a.cdd + ((size_t)b * a.nstages + st) * CL.stride;
+  double* const Fxx = kr + KL.off[RTOC_KKT_FXX];
+  double* const Fvu = kr + KL.off[RTOC_KKT_FVU];
+  double* const Qxx = kr + KL.off[RTOC_KKT_QXX];
+  double* const Qxu = kr + KL.off[RTOC_KKT_QXU];
+  double* const Quu = kr + KL.off[RTOC_KKT_QUU];
+  double* const Fx = kr + KL.off[RTOC_KKT_FX];
+  double* const lx = kr + KL.off[RTOC_KKT_LX];
+  double* const lu = kr + KL.off[RTOC_KKT_LU];
+  double* const fx = kr + KL.off[RTOC_KKT_FFX];
+  double* const hx = kr + KL.off[RTOC_KKT_HX];
+  double* const hu = kr + KL.off[RTOC_KKT_HU];
+  double* const scal = kr + KL.off[RTOC_KKT_SCAL];
+  double* const Phix = kr + KL.off[RTOC_KKT_PHIX];
+  double* const Phiu = kr + KL.off[RTOC_KKT_PHIU];
+  double* const Phit = kr + KL.off[RTOC_KKT_PHIT];
+  double* const Pres = kr + KL.off[RTOC_KKT_PRES];
+  const double* const Phia = cr + CL.off[RTOC_CDD_PHIA];
+  double* const lup = cr + CL.off[RTOC_CDD_LUP];
+  double* const Qxup = cr + CL.off[RTOC_CDD_QXUP];
+  double* const Quuptr = cr + CL.off[RTOC_CDD_QUUPTR];
   unsigned stat = 0;
 
   RTOC_CPROF(0);
@@ -410,15 +412,15 @@ __global__ __launch_bounds__(128) void condense_kernel(CondArgs a) {
     const int e = lane + k * NT;                                                 \
     if (e < (n2)) reinterpret_cast<dbl2*>(dst)[e] = src[k];                      \
   }
-  RTOC_LD2(gL, N_L, cr + co[RTOC_CDD_DIDDA], H_L)
-  RTOC_LD2(gD, N_D, cr + co[RTOC_CDD_DIDCDQV], H_D)
-  RTOC_LD2(gJ, N_J, cr + co[RTOC_CDD_DCDA], H_J)
-  RTOC_LD2(gF, N_F, cr + co[RTOC_CDD_QFF], H_F)
-  RTOC_LD2(gQ, N_J, cr + co[RTOC_CDD_QQF], H_J)
+  RTOC_LD2(gL, N_L, cr + CL.off[RTOC_CDD_DIDDA], H_L)
+  RTOC_LD2(gD, N_D, cr + CL.off[RTOC_CDD_DIDCDQV], H_D)
+  RTOC_LD2(gJ, N_J, cr + CL.off[RTOC_CDD_DCDA], H_J)
+  RTOC_LD2(gF, N_F, cr + CL.off[RTOC_CDD_QFF], H_F)
+  RTOC_LD2(gQ, N_J, cr + CL.off[RTOC_CDD_QQF], H_J)
   const int lv_ = lane < NV ? lane : 0, lf_ = lane < nf ? lane : 0, lvf_ = lane < nvf ? lane : 0;
-  const double vQaa = cr[co[RTOC_CDD_QAA] + lv_], vLa = cr[co[RTOC_CDD_LA] + lv_],
-               vHa = cr[co[RTOC_CDD_HA] + lv_], vLf = cr[co[RTOC_CDD_LF] + lf_],
-               vHf = cr[co[RTOC_CDD_HF] + lf_], vIdc = cr[co[RTOC_CDD_IDC] + lvf_];
+  const double vQaa = cr[CL.off[RTOC_CDD_QAA] + lv_], vLa = cr[CL.off[RTOC_CDD_LA] + lv_],
+               vHa = cr[CL.off[RTOC_CDD_HA] + lv_], vLf = cr[CL.off[RTOC_CDD_LF] + lf_],
+               vHf = cr[CL.off[RTOC_CDD_HF] + lf_], vIdc = cr[CL.off[RTOC_CDD_IDC] + lvf_];
   // gradient / sensitivity entries that get one read-modify-write at the end: fetched now as well
   const int ix_ = lane < NX ? lane : 0, iv_ = lane < NV ? lane : 0;
   const double pLx = lx[ix_], pHx = hx[ix_], pFf = fx[ix_], pFxv = Fx[NV + iv_];
@@ -742,14 +744,14 @@ __global__ __launch_bounds__(128) void condense_kernel(CondArgs a) {
 
   RTOC_CPROF(8);
   // ================= LDS -> HBM: the ContactDynamicsData the expansion needs, each field once ====
-  copy_s2g_flat16<NT>(cr + co[RTOC_CDD_MJTJINV], Lam, LDV * LDV, lane);
-  copy_s2g_flat16<NT>(cr + co[RTOC_CDD_MJD], LD, LDV * NX, lane);
-  copy_s2g_flat16<NT>(cr + co[RTOC_CDD_QAFQV], Qafqv, LDV * NX, lane);
-  if (!impact) copy_s2g_flat16<NT>(cr + co[RTOC_CDD_QAFU], Qafu, LDV * NV, lane);
+  copy_s2g_flat16<NT>(cr + CL.off[RTOC_CDD_MJTJINV], Lam, LDV * LDV, lane);
+  copy_s2g_flat16<NT>(cr + CL.off[RTOC_CDD_MJD], LD, LDV * NX, lane);
+  copy_s2g_flat16<NT>(cr + CL.off[RTOC_CDD_QAFQV], Qafqv, LDV * NX, lane);
+  if (!impact) copy_s2g_flat16<NT>(cr + CL.off[RTOC_CDD_QAFU], Qafu, LDV * NV, lane);
   if (lane < nvf) {
-    cr[co[RTOC_CDD_MJIDC] + lane] = Lr[lane];
-    cr[co[RTOC_CDD_LAF] + lane] = laf[lane];
-    if (!impact) cr[co[RTOC_CDD_HAF] + lane] = haf[lane];
+    cr[CL.off[RTOC_CDD_MJIDC] + lane] = Lr[lane];
+    cr[CL.off[RTOC_CDD_LAF] + lane] = laf[lane];
+    if (!impact) cr[CL.off[RTOC_CDD_HAF] + lane] = haf[lane];
   }
   RTOC_CPROF(9);
   if (stat) atomicOr(&a.status[b], stat);
@@ -767,31 +769,31 @@ __global__ __launch_bounds__(64) void expand_kernel(ExpArgs a) {
   const bool impact = g.type == RTOC_GRID_IMPACT;
   const int nf = g.dimf, nvf = NV + nf, ns = impact ? 0 : g.dims;
   const double dt = g.dt;
-  double* cr = a.cdd + ((size_t)b * a.nstages + st) * a.cl.stride;
-  double* dr = a.dir + ((size_t)b * a.nstages + st) * a.dl.stride;
-  const double* dn = dr + a.dl.stride;
-  const int* co = a.cl.off;
-  const int* dof = a.dl.off;
-  const double* Lam = cr + co[RTOC_CDD_MJTJINV];
-  const double* LD = cr + co[RTOC_CDD_MJD];
-  const double* Lr = cr + co[RTOC_CDD_MJIDC];
-  const double* Qafqv = cr + co[RTOC_CDD_QAFQV];
-  const double* Qafu = cr + co[RTOC_CDD_QAFU];
-  double* laf = cr + co[RTOC_CDD_LAF];
-  const double* haf = cr + co[RTOC_CDD_HAF];
-  const double* Qxup = cr + co[RTOC_CDD_QXUP];
-  const double* Quuptr = cr + co[RTOC_CDD_QUUPTR];
-  const double* lup = cr + co[RTOC_CDD_LUP];
-  const double* Phia = cr + co[RTOC_CDD_PHIA];
+  constexpr rtoc_layout SL = StaticLayout<NV, NU, NS>::make();
+  constexpr rtoc_record_layout CL = SL.cdd, DL = SL.dir;
+  double* cr = a.cdd + ((size_t)b * a.nstages + st) * CL.stride;
+  double* dr = a.dir + ((size_t)b * a.nstages + st) * DL.stride;
+  const double* dn = dr + DL.stride;
+  const double* Lam = cr + CL.off[RTOC_CDD_MJTJINV];
+  const double* LD = cr + CL.off[RTOC_CDD_MJD];
+  const double* Lr = cr + CL.off[RTOC_CDD_MJIDC];
+  const double* Qafqv = cr + CL.off[RTOC_CDD_QAFQV];
+  const double* Qafu = cr + CL.off[RTOC_CDD_QAFU];
+  double* laf = cr + CL.off[RTOC_CDD_LAF];
+  const double* haf = cr + CL.off[RTOC_CDD_HAF];
+  const double* Qxup = cr + CL.off[RTOC_CDD_QXUP];
+  const double* Quuptr = cr + CL.off[RTOC_CDD_QUUPTR];
+  const double* lup = cr + CL.off[RTOC_CDD_LUP];
+  const double* Phia = cr + CL.off[RTOC_CDD_PHIA];
   __shared__ double sdx[NX + 8], sdu[NU + 8], sg[NV + 8], sxi[LDS_ + 8], slaf[LDV + 8];
-  for (int i = lane; i < NX; i += 64) sdx[i] = dr[dof[RTOC_DIR_DX] + i];
-  if (lane < NU) sdu[lane] = impact ? 0.0 : dr[dof[RTOC_DIR_DU] + lane];
-  for (int i = lane; i < NV; i += 64) sg[i] = dn[dof[RTOC_DIR_DLMDGMM] + NV + i];
-  if (lane < ns) sxi[lane] = dr[dof[RTOC_DIR_DXI] + lane];
+  for (int i = lane; i < NX; i += 64) sdx[i] = dr[DL.off[RTOC_DIR_DX] + i];
+  if (lane < NU) sdu[lane] = impact ? 0.0 : dr[DL.off[RTOC_DIR_DU] + lane];
+  for (int i = lane; i < NV; i += 64) sg[i] = dn[DL.off[RTOC_DIR_DLMDGMM] + NV + i];
+  if (lane < ns) sxi[lane] = dr[DL.off[RTOC_DIR_DXI] + lane];
   __syncthreads();
   double dtsv = 0.0;
   if (!impact && g.num_grids_in_phase > 0)
-    dtsv = (dr[dof[RTOC_DIR_DTS] + 1] - dr[dof[RTOC_DIR_DTS] + 0]) / (double)g.num_grids_in_phase;
+    dtsv = (dr[DL.off[RTOC_DIR_DTS] + 1] - dr[DL.off[RTOC_DIR_DTS] + 0]) / (double)g.num_grids_in_phase;
   const bool use_dts = (dtsv < -2.220446049250313e-16 || dtsv > 2.220446049250313e-16);
   // primal (:167-174, impact :83-88) and the laf accumulation of the dual (:190-198, impact :91-95)
   for (int i = lane; i < nvf; i += 64) {
@@ -810,7 +812,7 @@ __global__ __launch_bounds__(64) void expand_kernel(ExpArgs a) {
     }
     acc -= Lr[i];
     if (i >= NV) acc = -acc;
-    dr[dof[RTOC_DIR_DAF] + i] = acc;
+    dr[DL.off[RTOC_DIR_DAF] + i] = acc;
     if (i < NV) {
       accl += (impact ? 1.0 : dt) * sg[i];
       if (NS > 0 && ns > 0)
@@ -826,7 +828,7 @@ __global__ __launch_bounds__(64) void expand_kernel(ExpArgs a) {
     for (int j = 0; j < NU; ++j) acc -= Quuptr[lane + j * NP] * sdu[j];
     for (int j = 0; j < NX; ++j) acc -= Qxup[j + (size_t)lane * NX] * sdx[j];
     for (int j = 0; j < NV; ++j) acc -= dt * Lam[lane + (size_t)j * LDV] * sg[j];
-    dr[dof[RTOC_DIR_DNUP] + lane] = acc;
+    dr[DL.off[RTOC_DIR_DNUP] + lane] = acc;
   }
   __syncthreads();
   // ================= PDIPM expansion + fraction-to-boundary (constraints.cpp:360-458) =================
@@ -864,7 +866,7 @@ __global__ __launch_bounds__(64) void expand_kernel(ExpArgs a) {
   for (int i = lane; i < nvf; i += 64) {
     double acc = 0.0;
     for (int j = 0; j < nvf; ++j) acc -= Lam[i + (size_t)j * LDV] * slaf[j];
-    dr[dof[RTOC_DIR_DBETAMU] + i] = acc;
+    dr[DL.off[RTOC_DIR_DBETAMU] + i] = acc;
   }
 }
 

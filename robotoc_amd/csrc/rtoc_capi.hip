@@ -51,7 +51,7 @@ struct KernelSet {
   int bwd_waves[4];   // waves per workgroup
   int bwd_lds[4];
   int bwd_inst[4];    // OCP instances per workgroup
-  rtoc_record_layout kl, rl, dl;  // record layouts the Riccati kernels were compiled for
+  rtoc_record_layout kl, rl, dl, cl;  // record layouts the kernels were compiled for
   fwd_fn fwd;
   int fwd_threads;
   fill_fn fill;
@@ -98,6 +98,7 @@ static KernelSet make_set() {
   k.fwd = riccati_forward_kernel<NV, NU, NS, NWF>;
   k.fwd_threads = 64 * NWF;
   k.dl = StaticLayout<NV, NU, NS>::make().dir;
+  k.cl = StaticLayout<NV, NU, NS>::make().cdd;
   k.fill = unconstr_fill_kernel<NV>;
   k.ucond = unconstr_condense_kernel<NV>;
   k.uexp = unconstr_expand_kernel<NV>;
@@ -200,7 +201,8 @@ int rtoc_create(const rtoc_dims* dims, int max_stages, int batch, int device, rt
   // (and the caller, through rtoc_get_layout) uses
   if (memcmp(&ks->kl, &c->L.kkt, sizeof(rtoc_record_layout)) != 0 ||
       memcmp(&ks->rl, &c->L.ric, sizeof(rtoc_record_layout)) != 0 ||
-      memcmp(&ks->dl, &c->L.dir, sizeof(rtoc_record_layout)) != 0) {
+      memcmp(&ks->dl, &c->L.dir, sizeof(rtoc_record_layout)) != 0 ||
+      memcmp(&ks->cl, &c->L.cdd, sizeof(rtoc_record_layout)) != 0) {
     delete c;
     return RTOC_ERR_BAD_ARG;
   }
