@@ -229,48 +229,42 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a, const
     }
     // ================= interval 1: [matrix] PB, G      || [vector] z, lu' =================
     if constexpr (!MW) {
-     if (sto) {
-      if (vt < NX) {
-        double acc = 0.0, accy = 0.0;
-#pragma unroll 9
-        for (int k = 0; k < NX; ++k) {
-          const double p = sP[vt + k * LDP];
-          acc += p * smem[C::V_FX + k];
-          if (sto) accy += p * smem[C::V_FFX + k];
-        }
-        smem[C::V_Z + vt] = smem[C::V_SN + vt] - acc;
-        if (sto) smem[C::V_Y + vt] = accy + smem[C::V_PSIN + vt];
-      }
-      wave_lds_sync();
-      RTOC_PROFV(19);
-      if (!impact && vt < NU) {
-        double acc = 0.0, ap = 0.0, aph = 0.0;
+     if (!impact && vt < NU) {
+      // lu' = lu - Bv^T z_v with z = s+ - P+ Fx: the P+ Fx part arrives from the matrix wave (it
+      // rides as an extra column of the P+ A product), so only Bv^T s+_v is summed here.  Same for
+      // the STO vectors: psi_u = hu + Bv^T y_v, y = P+ fx + Psi+ (fx rides as a second column), and
+      // phi_u = Bv^T Phi+_v (brrf.cpp:48-66)
+      double acc0 = 0.0, acc1 = 0.0, ap0 = 0.0, ap1 = 0.0, ah0 = 0.0, ah1 = 0.0;
+      if (!sto) {  // loops unswitched by hand: a uniform test inside would sit in every iteration
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
           const double bv = sBv[k + vt * NV];
-          acc += bv * smem[C::V_Z + NV + k];
-          if (sto) {
-            ap += bv * smem[C::V_Y + NV + k];
-            if (sto_next) aph += bv * smem[C::V_PHIN + NV + k];
+          if (k & 1)
+            acc1 += bv * smem[C::V_SN + NV + k];
+          else
+            acc0 += bv * smem[C::V_SN + NV + k];
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+          const double bv = sBv[k + vt * NV];
+          const double ph = sto_next ? smem[C::V_PHIN + NV + k] : 0.0;
+          if (k & 1) {
+            acc1 += bv * smem[C::V_SN + NV + k];
+            ap1 += bv * smem[C::V_PSIN + NV + k];
+            ah1 += bv * ph;
+          } else {
+            acc0 += bv * smem[C::V_SN + NV + k];
+            ap0 += bv * smem[C::V_PSIN + NV + k];
+            ah0 += bv * ph;
           }
         }
-        smem[C::V_LU + vt] -= acc;
-        if (sto) {
-          smem[C::V_PSIU + vt] = ap + smem[C::V_HU + vt];
-          smem[C::V_PHIU + vt] = sto_next ? aph : 0.0;
-        }
       }
-     } else if (!impact && vt < NU) {
-      // lu' = lu - Bv^T z_v with z = s+ - P+ Fx: the P+ Fx part arrives from the matrix wave (it
-      // rides as an extra column of the P+ A product), so only Bv^T s+_v is summed here
-      double acc0 = 0.0, acc1 = 0.0;
-#pragma unroll
-      for (int k = 0; k + 1 < NV; k += 2) {
-        acc0 += sBv[k + vt * NV] * smem[C::V_SN + NV + k];
-        acc1 += sBv[k + 1 + vt * NV] * smem[C::V_SN + NV + k + 1];
-      }
-      if (NV & 1) acc0 += sBv[NV - 1 + vt * NV] * smem[C::V_SN + 2 * NV - 1];
       smem[C::V_LU + vt] -= acc0 + acc1;
+      if (sto) {
+        smem[C::V_PSIU + vt] = (ap0 + ap1) + smem[C::V_HU + vt];
+        smem[C::V_PHIU + vt] = sto_next ? (ah0 + ah1) : 0.0;
+      }
      }
     } else {
      if (!impact) {
@@ -374,10 +368,13 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a, const
       const double* pb_ = sA + q + li * LDP;
       // last column tile: columns j < NX are A, column NX is Fx (not in STO stages, which keep the
       // VALU path for their extra vectors) -- P+ Fx and PB^T Fx come out of the same MFMAs
-      static_assert(TNX * 16 > NX, "no spare column for Fx in the last tile");
+      static_assert(TNX * 16 >= NX + 2, "no spare columns for Fx / fx in the last tile");
       constexpr int JL = (CNT - 1) * 16;
-      const bool fxcol = (JL + li == NX) && !sto;
-      const double* pbl_ = (JL + li < NX) ? (sA + q + (JL + li) * LDP) : (smem + C::V_FX + q);
+      // column NX: Fx (-> P+ Fx, PB^T Fx); column NX+1 on STO stages: fx (-> P+ fx, PB^T fx)
+      const int colsel = (JL + li == NX) ? 1 : ((JL + li == NX + 1 && sto) ? 2 : 0);
+      const bool fxcol = colsel != 0;
+      const double* pbl_ = (JL + li < NX) ? (sA + q + (JL + li) * LDP)
+                                          : (smem + (JL + li == NX ? C::V_FX : C::V_FFX) + q);
       const bool okl = (JL + li < NX) || fxcol;
       // Row tiles in two passes: first the tiles that hold PB^T rows (H = Qxu^T-part, and PB^T Fx),
       // so the vector wave can start the policy products while the P+ A rows are still being
@@ -433,11 +430,16 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a, const
           }
         }
       };
-      // column NX of [P+; PB^T] [A | Fx]: rows < NX are P+ Fx -> z = s+ - P+ Fx (brrf.cpp:86),
-      // rows NX.. are PB^T Fx = Bv^T (P+ Fx)_v -> the missing part of lu'
+      // column NX of [P+; PB^T] [A | Fx | fx]: rows < NX are P+ Fx -> z = s+ - P+ Fx (brrf.cpp:86),
+      // rows NX.. are PB^T Fx = Bv^T (P+ Fx)_v -> the missing part of lu' (parked in the T slot).
+      // column NX+1 (STO): y = P+ fx + Psi+ (brrf.cpp:52), PB^T fx -> missing part of psi_u (W slot).
       auto write_fx_column = [&](auto tm0c, auto tm1c) {
         constexpr int TM0 = decltype(tm0c)::value, TM1 = decltype(tm1c)::value;
         if (fxcol) {
+          const double sgn = colsel == 1 ? -1.0 : 1.0;
+          const double* base = smem + (colsel == 1 ? C::V_SN : C::V_PSIN);
+          double* dstx = smem + (colsel == 1 ? C::V_Z : C::V_Y);
+          double* dstu = smem + (colsel == 1 ? C::V_TV : C::V_WV);
 #pragma unroll
           for (int tm = TM0; tm < TM1; ++tm)
 #pragma unroll
@@ -445,14 +447,14 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a, const
               const int row = tm * 16 + drow(q, r);
               const double v = pa[tm][CNT - 1][r];
               if (tm * 16 + 4 * r + 3 < NX) {
-                smem[C::V_Z + row] = smem[C::V_SN + row] - v;
+                dstx[row] = base[row] + sgn * v;
               } else if (tm * 16 + 4 * r >= NX) {
-                if (row < NX + NU) smem[C::V_Y + row - NX] = v;
+                if (row < NX + NU) dstu[row - NX] = v;
               } else {
                 if (row < NX)
-                  smem[C::V_Z + row] = smem[C::V_SN + row] - v;
+                  dstx[row] = base[row] + sgn * v;
                 else if (row < NX + NU)
-                  smem[C::V_Y + row - NX] = v;
+                  dstu[row - NX] = v;
               }
             }
         }
@@ -486,34 +488,14 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a, const
         if (wave_llt_inv<NU, NU>(sG, sL, smem + C::V_LINV, sBv, NU, lane)) stat |= RTOC_STAT_QUU_NOT_SPD;
       }
       RTOC_PROFV(22);
-      if (sto && vt < NX) {
-        double acc = 0.0, ap = 0.0, aph = 0.0;
-#pragma unroll 9
-        for (int k = 0; k < NX; ++k) {
-          const double av = sA[k + vt * LDP];
-          acc += av * smem[C::V_Z + k];
-          if (sto) {
-            if (!impact) ap += av * smem[C::V_Y + k];
-            aph += av * smem[C::V_PHIN + k];
-          }
-        }
-        smem[C::V_SNEW + vt] = acc - smem[C::V_LX + vt];
-        if (sto) {
-          if (!impact) {
-            smem[C::V_PSIX + vt] = ap + smem[C::V_HX + vt];
-            smem[C::V_PHIX + vt] = sto_next ? aph : 0.0;
-          } else {
-            smem[C::V_PHIX + vt] = aph;
-          }
-        }
-      }
     }
     RTOC_PROFV(23);
     if constexpr (!MW) lds_wait(sFlag, 3 * (N - st) - 1);
     RTOC_PROFV(24);
     if constexpr (!MW) {
-      if (!sto && !impact) {
-        if (vt < NU) smem[C::V_LU + vt] += smem[C::V_Y + vt];
+      if (!impact && vt < NU) {
+        smem[C::V_LU + vt] += smem[C::V_TV + vt];                 // + PB^T Fx
+        if (sto) smem[C::V_PSIU + vt] += smem[C::V_WV + vt];     // + PB^T fx
       }
       // hand-off vector -> matrix: the inverse factor Y and lu' (psi_u, phi_u) are in LDS
       lds_signal(sFlag + 2, 3 * (N - st), lane);
@@ -640,30 +622,59 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a, const
       }
     } else {
       // w = A^T z - lx (brrf.cpp:87-88), off the matrix wave's critical path: z came with the H flag
-      double wacc = 0.0;
       lds_wait(sFlag, 3 * (N - st));
-      if (!sto && vt < NX) {
+      if (vt < NX) {
+        // A^T z (brrf.cpp:87-88) and, on STO stages, A^T y and A^T Phi+ (brrf.cpp:53,60) in one pass
+        // over column vt of A: 128-bit LDS reads, two accumulators per product
         typedef double dbl2 __attribute__((ext_vector_type(2)));
-        static_assert((LDP & 1) == 0 && (C::OFF_A & 1) == 0 && (C::V_Z & 1) == 0, "128-bit LDS reads");
+        static_assert((LDP & 1) == 0 && (C::OFF_A & 1) == 0 && (C::V_Z & 1) == 0 && (C::V_Y & 1) == 0 &&
+                          (C::V_PHIN & 1) == 0 && (NX & 1) == 0,
+                      "128-bit LDS reads");
         const dbl2* pa2 = reinterpret_cast<const dbl2*>(sA + vt * LDP);
         const dbl2* pz2 = reinterpret_cast<const dbl2*>(smem + C::V_Z);
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        const dbl2* py2 = reinterpret_cast<const dbl2*>(smem + C::V_Y);
+        const dbl2* pf2 = reinterpret_cast<const dbl2*>(smem + C::V_PHIN);
+        double a0 = 0.0, a1 = 0.0, y0 = 0.0, y1 = 0.0, f0 = 0.0, f1 = 0.0;
+        if (!sto) {
+          double a2 = 0.0, a3 = 0.0;
 #pragma unroll
-        for (int k2 = 0; k2 + 1 < NX / 2; k2 += 2) {
-          const dbl2 av0 = pa2[k2], zv0 = pz2[k2], av1 = pa2[k2 + 1], zv1 = pz2[k2 + 1];
-          a0 += av0.x * zv0.x;
-          a1 += av0.y * zv0.y;
-          a2 += av1.x * zv1.x;
-          a3 += av1.y * zv1.y;
+          for (int k2 = 0; k2 + 1 < NX / 2; k2 += 2) {
+            const dbl2 av0 = pa2[k2], zv0 = pz2[k2], av1 = pa2[k2 + 1], zv1 = pz2[k2 + 1];
+            a0 += av0.x * zv0.x;
+            a1 += av0.y * zv0.y;
+            a2 += av1.x * zv1.x;
+            a3 += av1.y * zv1.y;
+          }
+          if ((NX / 2) & 1) {
+            const dbl2 av0 = pa2[NX / 2 - 1], zv0 = pz2[NX / 2 - 1];
+            a0 += av0.x * zv0.x;
+            a1 += av0.y * zv0.y;
+          }
+          a0 += a2;
+          a1 += a3;
+        } else {
+          const double ysel = impact ? 0.0 : 1.0;
+#pragma unroll
+          for (int k2 = 0; k2 < NX / 2; ++k2) {
+            const dbl2 av = pa2[k2], zv = pz2[k2], fv = pf2[k2], yv = py2[k2];
+            a0 += av.x * zv.x;
+            a1 += av.y * zv.y;
+            f0 += av.x * fv.x;
+            f1 += av.y * fv.y;
+            y0 += av.x * (ysel * yv.x);
+            y1 += av.y * (ysel * yv.y);
+          }
         }
-        if ((NX / 2) & 1) {
-          const dbl2 av0 = pa2[NX / 2 - 1], zv0 = pz2[NX / 2 - 1];
-          a0 += av0.x * zv0.x;
-          a1 += av0.y * zv0.y;
+        smem[C::V_SNEW + vt] = (a0 + a1) - smem[C::V_LX + vt];
+        if (sto) {
+          if (!impact) {
+            smem[C::V_PSIX + vt] = (y0 + y1) + smem[C::V_HX + vt];
+            smem[C::V_PHIX + vt] = sto_next ? (f0 + f1) : 0.0;
+          } else {
+            smem[C::V_PHIX + vt] = f0 + f1;
+          }
         }
-        wacc = (a0 + a1) + (a2 + a3) - smem[C::V_LX + vt];
       }
-      if (!sto && vt < NX) smem[C::V_SNEW + vt] = wacc;
     }
     RTOC_PROF(13);
     RTOC_PROFV(14);
