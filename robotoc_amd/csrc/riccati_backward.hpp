@@ -641,7 +641,13 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
       // ---- LLT(G) by wave 0 (riccati_factorizer.cpp:49): VALU / shuffle work issued next to the
       //      independent F-chain MFMAs below so that the two pipes overlap ----
       if (!impact && wave == 0) {
-        if (wave_llt<NU, NU>(sG, sL, smem + C::V_LINV, NU, lane)) stat |= RTOC_STAT_QUU_NOT_SPD;
+        if constexpr (NU <= 32) {
+          // with the inverse factor Y = L^-1 in the same instruction stream (dead Bv buffer): the
+          // triangular solves of the policy become MFMA products below
+          if (wave_llt_inv<NU, NU, 32>(sG, sL, smem + C::V_LINV, sBv, NU, lane)) stat |= RTOC_STAT_QUU_NOT_SPD;
+        } else {
+          if (wave_llt<NU, NU>(sG, sL, smem + C::V_LINV, NU, lane)) stat |= RTOC_STAT_QUU_NOT_SPD;
+        }
       }
       const double* pbf_ = sA + q + li * LDP;  // A[k][j]
 #pragma unroll
@@ -671,7 +677,73 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
     if (impact) {
       // riccati_factorizer.cpp:178-197 -- no policy
     } else {
-      if (ns == 0) {
+      if (ns == 0 && NU <= 32) {
+        // K = -G^-1 H^T, k = -G^-1 lu', T = -G^-1 psi_u, W = -G^-1 phi_u (riccati_factorizer.cpp:55-56,
+        // :125-130) for all right-hand sides at once, as the two triangular solves written as products
+        // with Y = L^-1:  Z^T = Y [H^T | lu' | psi_u | phi_u],  [K | k | T | W] = -Y^T Z^T.
+        // Column tiles of the right-hand side are dealt to the waves; the C layout of Z^T (row
+        // i = 16 ti + q + 4r, column = lane&15) is the B-operand layout of the second product
+        // (k-step 4 ti + r), so Z^T stays in registers.
+        constexpr int TKT = (NX + 3 + 15) / 16, TU = (NU + 15) / 16, KSU = (NU + 3) / 4;
+        const double* sY = sBv;
+        double chk = 0.0;
+        for (int c = wave; c < TKT; c += NW) {
+          const int x = c * 16 + li;
+          const double* bsrc = (x < NX) ? (sH + x + q * LDP)
+                                        : (smem + (x == NX ? C::V_LU : (x == NX + 1 ? C::V_PSIU : C::V_PHIU)) + q);
+          const int bstr = (x < NX) ? 4 * LDP : 4;
+          const bool bok = (x < NX) || x == NX || (sto && (x == NX + 1 || (x == NX + 2 && sto_next)));
+          d4 zt[TU], kk[TU];
+#pragma unroll
+          for (int t = 0; t < TU; ++t) {
+            zt[t] = zero4();
+            kk[t] = zero4();
+          }
+#pragma unroll
+          for (int ks = 0; ks < KSU; ++ks) {
+            const bool kok = (ks * 4 + 3 < NU) || (ks * 4 + q < NU);
+            const double bv0 = bsrc[(kok ? ks : 0) * bstr];
+            const double bv = (kok && bok) ? bv0 : 0.0;
+#pragma unroll
+            for (int t = 0; t < TU; ++t) {
+              const int i = t * 16 + li;
+              const double yv = sY[(i < NU ? i : 0) + ((kok ? ks * 4 + q : 0)) * NU];  // Y[i][u]
+              zt[t] = mfma16((kok && i < NU) ? yv : 0.0, bv, zt[t]);
+            }
+          }
+#pragma unroll
+          for (int ks = 0; ks < KSU; ++ks) {  // k = i = 4 ks + q
+            const bool kok = (ks * 4 + 3 < NU) || (ks * 4 + q < NU);
+#pragma unroll
+            for (int t = 0; t < TU; ++t) {
+              const int u = t * 16 + li;
+              const double yv = sY[(kok ? ks * 4 + q : 0) + (u < NU ? u : 0) * NU];  // Y[i][u]
+              kk[t] = mfma16((kok && u < NU) ? -yv : 0.0, zt[ks / 4][ks % 4], kk[t]);
+            }
+          }
+#pragma unroll
+          for (int t = 0; t < TU; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int u = t * 16 + drow(q, r);
+              const double v = kk[t][r];
+              if (u < NU) {
+                if (x < NX) {
+                  sKt[x + u * LDP] = v;
+                  chk = __builtin_fma(v, 0.0, chk);
+                } else if (x == NX) {
+                  smem[C::V_KV + u] = v;
+                  chk = __builtin_fma(v, 0.0, chk);
+                } else if (x == NX + 1) {
+                  if (sto) smem[C::V_TV + u] = v;
+                } else if (x == NX + 2) {
+                  if (sto) smem[C::V_WV + u] = sto_next ? v : 0.0;
+                }
+              }
+            }
+        }
+        if (is_bad(chk)) stat |= RTOC_STAT_NAN;
+      } else if (ns == 0) {
         // K = -G^-1 H^T, k = -G^-1 lu   (:55-56); thread t < NX owns column t, thread NX owns k
         if (tid <= NX) {
           double x[NU];
