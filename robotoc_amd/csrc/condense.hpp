@@ -95,7 +95,9 @@ struct CondCfg {
   static constexpr int V_IDC = O_VEC, V_LR = V_IDC + pad8(LDV), V_LAF = V_LR + pad8(LDV),
                        V_HAF = V_LAF + pad8(LDV), V_QAA = V_HAF + pad8(LDV), V_LINV = V_QAA + pad8(NV),
                        V_SINV = V_LINV + pad8(NV);
-  static constexpr int LDS_DOUBLES = V_SINV + pad8(NFP);
+  // PDIPM box rows: what they add to diag(Qqq), diag(Qvv), diag(Quu) and to lq, lv, lu, per primal entry
+  static constexpr int V_PH = V_SINV + pad8(NFP), V_PG = V_PH + pad8(2 * NV + NU);
+  static constexpr int LDS_DOUBLES = V_PG + pad8(2 * NV + NU);
   static constexpr int LDS_BYTES = LDS_DOUBLES * 8;
 };
 
@@ -353,42 +355,6 @@ __global__ __launch_bounds__(128) void condense_kernel(CondArgs a) {
   // Constraints::condenseSlackAndDual (constraints.cpp:322-357, joint_*_limit.cpp, pdipm.hxx:66-69):
   // purely additive on diag(Qqq), diag(Qvv), diag(Quu), lq, lv, lu, so it commutes with the
   // contact-dynamics condensation below; done first, like intermediate_stage.cpp:134-136.
-  if (a.con && !impact) {
-    double* nr = a.con + ((size_t)b * a.nstages + st) * a.nl.stride;
-    const int* no = a.nl.off;
-    // one lane per primal entry (q_k, v_k, u_k): a lower and an upper limit hit the same diagonal
-    // entry, so every entry is accumulated by a single lane in row order (deterministic, no atomics)
-    for (int t = lane; t < 2 * NV + NU; t += NT) {
-      const int var = t < NV ? RTOC_VAR_Q : (t < 2 * NV ? RTOC_VAR_V : RTOC_VAR_U);
-      const int idx = t < NV ? t : (t < 2 * NV ? t - NV : t - 2 * NV);
-      double hess = 0.0, grad = 0.0;
-      bool any = false;
-      const int* rowid = a.entry + (2 * NV + NU + 1);
-      for (int e = a.entry[t]; e < a.entry[t + 1]; ++e) {
-        const int r = rowid[e];
-        const rtoc_box_row row = a.rows[r];
-        if (g.time_stage >= row.level) {
-          const double slack = nr[no[RTOC_CON_SLACK] + r], dual = nr[no[RTOC_CON_DUAL] + r];
-          const double cond = (dual * nr[no[RTOC_CON_RESIDUAL] + r] - nr[no[RTOC_CON_CMPL] + r]) / slack;
-          nr[no[RTOC_CON_COND] + r] = cond;
-          hess += dual / slack;
-          grad += row.sign * cond;
-          any = true;
-        }
-      }
-      if (any) {
-        if (var == RTOC_VAR_U) {
-          Quu[idx + (size_t)idx * NU] += hess;
-          lu[idx] += grad;
-        } else {
-          const int k = var == RTOC_VAR_V ? NV + idx : idx;
-          Qxx[k + (size_t)k * NX] += hess;
-          lx[k] += grad;
-        }
-      }
-    }
-    __syncthreads();
-  }
   // ================= HBM -> registers: every input field once, all loads in flight together ======
   // 16 B per lane; odd-sized fields read/write one double of their 64-B padding
   constexpr int H_L = (NV * NV + 1) / 2, H_D = (LDV * NX + 1) / 2, H_J = (C::NFP * NV + 1) / 2,
@@ -426,14 +392,42 @@ __global__ __launch_bounds__(128) void condense_kernel(CondArgs a) {
   const double pLx = lx[ix_], pHx = hx[ix_], pFf = fx[ix_], pFxv = Fx[NV + iv_];
   const double pLup = lup[iv_ < NP ? iv_ : 0], pLu = lu[iv_ >= NP ? iv_ - NP : 0], pHu = hu[iv_ >= NP ? iv_ - NP : 0];
   const double pSh = scal[RTOC_KKT_SCAL_H], pSq = scal[RTOC_KKT_SCAL_QTT];
-  // the Hessian blocks the Schur updates read-modify-write: fetched now (after the PDIPM diagonal
-  // terms above landed), consumed ~100k cycles later -- their HBM latency is off the chain
+  // the Hessian blocks the Schur updates read-modify-write: fetched now, consumed ~60k cycles later --
+  // their HBM latency is off the chain
   double cQxx[TileSlots<NW, NX, NX>::value][4];
   double cQxu[TileSlots<NW, NX, NU>::value][4];
   double cQuu[TileSlots<NW, NU, NU>::value][4];
   prefetch_tiles<NW, NX, NX, NX>(Qxx, lane, cQxx);
   prefetch_tiles<NW, NX, NU, NX>(Qxu, lane, cQxu);
   prefetch_tiles<NW, NU, NU, NU>(Quu, lane, cQuu);
+  // The sums stay in LDS and enter the Hessian / gradient entries where those get their one
+  // read-modify-write below: the constraint records are then just one more set of loads in flight,
+  // not a dependent HBM round trip ahead of everything else.
+  double* const sPH = smem + C::V_PH;
+  double* const sPG = smem + C::V_PG;
+  for (int t = lane; t < 2 * NV + NU; t += NT) {
+    double hess = 0.0, grad = 0.0;
+    if (a.con && !impact) {
+      double* nr = a.con + ((size_t)b * a.nstages + st) * a.nl.stride;
+      const int* no = a.nl.off;
+      // one lane per primal entry (q_k, v_k, u_k): a lower and an upper limit hit the same diagonal
+      // entry, so every entry is accumulated by a single lane in row order (deterministic, no atomics)
+      const int* rowid = a.entry + (2 * NV + NU + 1);
+      for (int e = a.entry[t]; e < a.entry[t + 1]; ++e) {
+        const int r = rowid[e];
+        const rtoc_box_row row = a.rows[r];
+        if (g.time_stage >= row.level) {
+          const double slack = nr[no[RTOC_CON_SLACK] + r], dual = nr[no[RTOC_CON_DUAL] + r];
+          const double cond = (dual * nr[no[RTOC_CON_RESIDUAL] + r] - nr[no[RTOC_CON_CMPL] + r]) / slack;
+          nr[no[RTOC_CON_COND] + r] = cond;
+          hess += dual / slack;
+          grad += row.sign * cond;
+        }
+      }
+    }
+    sPH[t] = hess;
+    sPG[t] = grad;
+  }
   RTOC_CPROF(21);
   // inactive rows / columns (dimf < max_dimf) of the stored blocks stay zero, like the reference's
   // max-size backing matrices
@@ -628,7 +622,7 @@ __global__ __launch_bounds__(128) void condense_kernel(CondArgs a) {
   // the rows < NV only, ride along as a second product in the same tiles.
   lds_gemm2<NW, NX, NX, LDV, LDV, 1, 1, LDV, NV, C::NFP, 1, NV, 1, LDV>(
       LD, Qafqv, Qqf, LD + NV, nf > 0, lane, [&](int r, int c, double v1, double v2, int slot, int reg) {
-        Qxx[r + (size_t)c * NX] = cQxx[slot][reg] - v1 + v2;
+        Qxx[r + (size_t)c * NX] = (cQxx[slot][reg] + (r == c ? sPH[r] : 0.0)) - v1 + v2;
       });
   RTOC_CPROF(10);
   if (!impact) {
@@ -648,7 +642,8 @@ __global__ __launch_bounds__(128) void condense_kernel(CondArgs a) {
         });
     lds_gemm<NW, NU, NU, LDV, 1, LDV, 1, LDV>(Lam + NP, Qafu + NP * LDV, lane,
                                               [&](int r, int c, double v, int slot, int reg) {
-                                                Quu[r + (size_t)c * NU] = cQuu[slot][reg] + v;
+                                                Quu[r + (size_t)c * NU] =
+                                                    (cQuu[slot][reg] + (r == c ? sPH[2 * NV + r] : 0.0)) + v;
                                               });
   }
   RTOC_CPROF(12);
@@ -665,7 +660,7 @@ __global__ __launch_bounds__(128) void condense_kernel(CondArgs a) {
       al[k & 3] += ld * laf[k];
       ah[k & 3] += ld * haf[k];
     }
-    double l = pLx - ((al[0] + al[1]) + (al[2] + al[3])), h = pHx - ((ah[0] + ah[1]) + (ah[2] + ah[3]));
+    double l = (pLx + sPG[i]) - ((al[0] + al[1]) + (al[2] + al[3])), h = pHx - ((ah[0] + ah[1]) + (ah[2] + ah[3]));
     if (i < NV && nf > 0) {
       double aq0 = 0.0, aq1 = 0.0;
 #pragma unroll
@@ -698,7 +693,7 @@ __global__ __launch_bounds__(128) void condense_kernel(CondArgs a) {
     if (i < NP) {
       lup[i] = pLup + sl;
     } else {
-      lu[i - NP] = pLu + sl;
+      lu[i - NP] = (pLu + sPG[2 * NV + i - NP]) + sl;
       hu[i - NP] = (pHu + sh) * inv;
     }
   }
