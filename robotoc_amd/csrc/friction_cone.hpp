@@ -35,7 +35,7 @@ struct ConeArgs {
 
 template <int NV, int NF>
 __global__ __launch_bounds__(64) void cone_condense_kernel(ConeArgs a) {
-  constexpr int NX = 2 * NV, NFP = NF > 0 ? NF : 1;
+  constexpr int NX = 2 * NV, NFP = NF > 0 ? NF : 1, MAXC = NF / 3 > 0 ? NF / 3 : 1;
   const int lane = threadIdx.x;
   const int item = blockIdx.x;
   const int nst1 = a.nstages - 1;
@@ -54,57 +54,83 @@ __global__ __launch_bounds__(64) void cone_condense_kernel(ConeArgs a) {
   double* Qff = cr + a.cl.off[RTOC_CDD_QFF];
   double* Qqf = cr + a.cl.off[RTOC_CDD_QQF];
   double* lf = cr + a.cl.off[RTOC_CDD_LF];
-  __shared__ double dq[5 * NV], df[15], cond[5], rr[5];
-  for (int k = 0; k < nact; ++k) {  // contacts in order, like the reference's loop (:199-233)
-    const int r0 = a.row0 + 5 * k, stack = k * a.contact_dim;
-    for (int e = lane; e < 5 * NV; e += 64) dq[e] = cone[(size_t)k * 5 * NV + e];
-    if (lane < 15) df[lane] = cone[a.dgdf_off + k * 15 + lane];
-    if (lane < 5) {
-      const double slack = nr[a.nl.off[RTOC_CON_SLACK] + r0 + lane], dual = nr[a.nl.off[RTOC_CON_DUAL] + r0 + lane];
-      const double c = (dual * nr[a.nl.off[RTOC_CON_RESIDUAL] + r0 + lane] - nr[a.nl.off[RTOC_CON_CMPL] + r0 + lane]) / slack;
-      nr[a.nl.off[RTOC_CON_COND] + r0 + lane] = c;  // computeCondensingCoeffcient<5> (:202)
-      cond[lane] = c;
-      rr[lane] = dual / slack;  // (:211-212)
-    }
-    __syncthreads();
-    // lq += dg_dq^T cond ; lf += dg_df^T cond (:206-208)
-    if (lane < NV) {
+  // Everything the rows need is fetched in ONE round trip (all contacts), the Hessian / gradient
+  // entries are accumulated over the contacts in registers -- in contact order, like the reference's
+  // loop (:199-233) -- and get one read-modify-write each: two HBM latencies per grid point instead
+  // of two per contact.
+  __shared__ double dq[MAXC][5 * NV], df[MAXC][15], cond[MAXC][5], rr[MAXC][5];
+  for (int e = lane; e < nact * 5 * NV; e += 64) dq[e / (5 * NV)][e % (5 * NV)] = cone[e];
+  for (int e = lane; e < nact * 15; e += 64) df[e / 15][e % 15] = cone[a.dgdf_off + e];
+  if (lane < 5 * nact) {
+    const int r = a.row0 + lane;
+    const double slack = nr[a.nl.off[RTOC_CON_SLACK] + r], dual = nr[a.nl.off[RTOC_CON_DUAL] + r];
+    const double c = (dual * nr[a.nl.off[RTOC_CON_RESIDUAL] + r] - nr[a.nl.off[RTOC_CON_CMPL] + r]) / slack;
+    nr[a.nl.off[RTOC_CON_COND] + r] = c;  // computeCondensingCoeffcient<5> (:202)
+    cond[lane / 5][lane % 5] = c;
+    rr[lane / 5][lane % 5] = dual / slack;  // (:211-212)
+  }
+  // read-modify-write targets: issued now, consumed after the sums
+  constexpr int NQ = (NV * NV + 63) / 64;
+  double cq[NQ];
+#pragma unroll
+  for (int p = 0; p < NQ; ++p) {
+    const int e = lane + 64 * p;
+    cq[p] = Qxx[(e < NV * NV ? e % NV : 0) + (size_t)(e < NV * NV ? e / NV : 0) * NX];
+  }
+  const double clx = lx[lane < NV ? lane : 0];
+  __syncthreads();
+  // lq += dg_dq^T cond (:206)
+  if (lane < NV) {
+    double v = clx;
+    for (int k = 0; k < nact; ++k) {
       double acc = 0.0;
 #pragma unroll
-      for (int j = 0; j < 5; ++j) acc += dq[j + 5 * lane] * cond[j];
-      lx[lane] += acc;
-    } else if (lane < NV + 3) {
-      const int m = lane - NV;
-      double acc = 0.0;
-#pragma unroll
-      for (int j = 0; j < 5; ++j) acc += df[j + 5 * m] * cond[j];
-      lf[stack + m] += acc;
+      for (int j = 0; j < 5; ++j) acc += dq[k][j + 5 * lane] * cond[k][j];
+      v += acc;
     }
-    // Qqq += dg_dq^T (r dg_dq) (:215-216)
-    for (int e = lane; e < NV * NV; e += 64) {
+    lx[lane] = v;
+  }
+  // lf += dg_df^T cond (:207-208): one lane per (contact, component)
+  if (lane >= 32 && lane < 32 + 3 * nact) {
+    const int k = (lane - 32) / 3, m = (lane - 32) % 3;
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) acc += df[k][j + 5 * m] * cond[k][j];
+    lf[k * a.contact_dim + m] += acc;
+  }
+  // Qqq += sum_k dg_dq^T (r dg_dq) (:215-216)
+#pragma unroll
+  for (int p = 0; p < NQ; ++p) {
+    const int e = lane + 64 * p;
+    if (e < NV * NV) {
       const int r = e % NV, c = e / NV;
+      double v = cq[p];
+      for (int k = 0; k < nact; ++k) {
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) acc += dq[k][j + 5 * r] * (rr[k][j] * dq[k][j + 5 * c]);
+        v += acc;
+      }
+      Qxx[r + (size_t)c * NX] = v;
+    }
+  }
+  // Qqf[:, stack..+3] += dg_dq^T (r dg_df) (:217-218) ; Qff block += dg_df^T (r dg_df) (:219-220):
+  // every (contact, entry) is a distinct memory location
+  for (int e = lane; e < nact * (NV * 3 + 9); e += 64) {
+    const int k = e / (NV * 3 + 9), w = e % (NV * 3 + 9), stack = k * a.contact_dim;
+    if (w < NV * 3) {
+      const int r = w % NV, m = w / NV;
       double acc = 0.0;
 #pragma unroll
-      for (int j = 0; j < 5; ++j) acc += dq[j + 5 * r] * (rr[j] * dq[j + 5 * c]);
-      Qxx[r + (size_t)c * NX] += acc;
-    }
-    // Qqf[:, stack..+3] += dg_dq^T (r dg_df) (:217-218) ; Qff block += dg_df^T (r dg_df) (:219-220)
-    for (int e = lane; e < NV * 3 + 9; e += 64) {
-      if (e < NV * 3) {
-        const int r = e % NV, m = e / NV;
-        double acc = 0.0;
+      for (int j = 0; j < 5; ++j) acc += dq[k][j + 5 * r] * (rr[k][j] * df[k][j + 5 * m]);
+      Qqf[r + (size_t)(stack + m) * NV] += acc;
+    } else {
+      const int m = (w - NV * 3) % 3, n = (w - NV * 3) / 3;
+      double acc = 0.0;
 #pragma unroll
-        for (int j = 0; j < 5; ++j) acc += dq[j + 5 * r] * (rr[j] * df[j + 5 * m]);
-        Qqf[r + (size_t)(stack + m) * NV] += acc;
-      } else {
-        const int m = (e - NV * 3) % 3, n = (e - NV * 3) / 3;
-        double acc = 0.0;
-#pragma unroll
-        for (int j = 0; j < 5; ++j) acc += df[j + 5 * m] * (rr[j] * df[j + 5 * n]);
-        Qff[(stack + m) + (size_t)(stack + n) * NFP] += acc;
-      }
+      for (int j = 0; j < 5; ++j) acc += df[k][j + 5 * m] * (rr[k][j] * df[k][j + 5 * n]);
+      Qff[(stack + m) + (size_t)(stack + n) * NFP] += acc;
     }
-    __syncthreads();
   }
 }
 
