@@ -144,11 +144,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs a GPU: the hot path has no CPU fallback")
+    if os.environ.get("RTOC_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0  # functional test of the multi-process path on a single-GPU box
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world)  # "nccl" is RCCL on ROCm
+        # "nccl" is RCCL on ROCm; RTOC_BENCH_BACKEND=gloo only for the single-GPU functional test of
+        # this multi-process path (RCCL refuses two ranks on one device)
+        dist.init_process_group(os.environ.get("RTOC_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
 
     from robotoc_amd import capi, problems as pr
     from robotoc_amd.types import BUF_DIR, BUF_DX0, BUF_KKT
