@@ -341,3 +341,36 @@ def test_sqp_iteration_hot_path(oracle, cfg):
         print("sqp hot path %s: worst rel err %.3e" % (cfg, worst))
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("waves", [1, 2, 8])
+def test_minimal_horizon_and_ragged_batches(oracle, waves):
+    """Edge cases of the launch geometry: the shortest legal horizon (one stage + terminal), and batch
+    sizes that do not fill a 4-instance workgroup (1, 2, 3, 5 instances)."""
+    from robotoc_amd import capi
+    from robotoc_amd.grid import uniform_grid
+    dims = pr.config_anymal_trot()[0]
+    for nst, batch in ((2, 1), (2, 5), (3, 3), (5, 2)):
+        grids = uniform_grid(nst - 1, 0.02)
+        assert len(grids) == nst
+        ctx = capi.Context(dims, nst, batch, 0)
+        try:
+            L = ctx.L
+            ctx.set_grid(grids)
+            ctx.set_backward_waves(waves)
+            kkt = pr.make_kkt_batch(L, grids, batch, mode="factory")
+            dx0 = pr.make_dx0(L, batch)
+            ctx.upload(BUF_KKT, kkt)
+            ctx.upload(BUF_DX0, dx0)
+            ctx.riccati_sweep()
+            assert (ctx.status() == 0).all()
+            ric, d = ctx.download_records(BUF_RIC, "ric"), ctx.download_records(BUF_DIR, "dir")
+            ric_ref = Records(L, "ric").zeros(batch, nst)
+            d_ref = Records(L, "dir").zeros(batch, nst)
+            oracle.riccati_sweep_batch(L, grids, kkt.copy(), ric_ref, d_ref, dx0=dx0)
+            for b in range(batch):
+                compare_riccati(L, grids, ric[b], ric_ref[b], TOL)
+                compare_direction(L, grids, d[b], d_ref[b], TOL)
+        finally:
+            ctx.close()
