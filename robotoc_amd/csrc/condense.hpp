@@ -31,10 +31,14 @@ __device__ __forceinline__ void wave_lds_sync_() {
   __builtin_amdgcn_wave_barrier();
 }
 
+#ifdef RTOC_ENABLE_PROF
 #define RTOC_CPROF(k)                                                                   \
   do {                                                                                  \
     if (a.prof && blockIdx.x == (gridDim.x >> 1) && threadIdx.x == 0) a.prof[(k)] = (long long)__builtin_readcyclecounter(); \
   } while (0)
+#else
+#define RTOC_CPROF(k) do { } while (0)
+#endif
 
 struct CondArgs {
   double* kkt;

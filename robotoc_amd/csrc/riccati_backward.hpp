@@ -38,16 +38,22 @@
 namespace rtoc {
 
 // Phase time-stamps (s_memtime) of block 0, written only when a profiling buffer is attached.
+// s_memtime stamps for tools/phase_profile*.py: compiled in only with -DRTOC_ENABLE_PROF (make PROF=1);
+// thirty scalar tests per stage and two live SGPR pairs are not free in the production build
+#ifdef RTOC_ENABLE_PROF
 #define RTOC_PROF(k)                                                             \
   do {                                                                          \
     if (a.prof && b == 0 && tid0 == 0) a.prof[st * 32 + (k)] = (long long)__builtin_readcyclecounter(); \
   } while (0)
-
 // same, stamped by the first lane of the second wave (the vector wave of the role-split kernel)
 #define RTOC_PROFV(k)                                                            \
   do {                                                                          \
     if (a.prof && b == 0 && tid0 == 64) a.prof[st * 32 + (k)] = (long long)__builtin_readcyclecounter(); \
   } while (0)
+#else
+#define RTOC_PROF(k) do { } while (0)
+#define RTOC_PROFV(k) do { } while (0)
+#endif
 
 struct BwdArgs {
   const double* kkt;       // [batch][nstages][kkt stride]
