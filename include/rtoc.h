@@ -67,6 +67,7 @@ extern "C" {
 #define RTOC_ERR_HIP (-4)
 #define RTOC_ERR_NOT_READY (-5)
 #define RTOC_ERR_RCCL (-6)
+#define RTOC_ERR_IO (-7)
 
 /* ---- per-instance numerical status bits (rtoc_status) --------------------- */
 #define RTOC_STAT_QUU_NOT_SPD 0x1u  /* LLT(Quu) hit a non-positive pivot (riccati_factorizer.cpp:49-50) */
@@ -193,6 +194,27 @@ int rtoc_sync(rtoc_ctx* ctx);
  * context's stream; returns the mean milliseconds per launch in *ms.
  * phase: 0 backward, 1 forward, 2 condense, 3 expand, 4 backward+forward, 5 update. */
 int rtoc_time_phase(rtoc_ctx* ctx, int phase, int reps, float* ms);
+
+/* ---- stage dump / replay ----------------------------------------
+ * A self-describing file of everything a context holds at the evalKKT boundary
+ * (IntermediateStage::evalKKT outputs, src/ocp/intermediate_stage.cpp:113-148): dims, grid, box rows,
+ * cone set-up and the selected buffers, so that stage data recorded on a Pinocchio-equipped machine can
+ * drive the kernels elsewhere.  Layout (little endian): rtoc_dump_header, rtoc_grid[nstages],
+ * rtoc_box_row[nrows], then for every buffer with count != 0 its first `count` doubles
+ * ([batch][nstages][stride], the part the kernels index).  robotoc_amd/replay.py reads / writes the
+ * same format in numpy. */
+typedef struct rtoc_dump_header {
+  char magic[8];             /* "RTOCDMP1" */
+  unsigned int version;      /* 1 */
+  unsigned int header_bytes; /* sizeof(rtoc_dump_header) */
+  rtoc_dims dims;
+  int nstages, batch, nrows, cone_contacts, cone_dim, reserved[3];
+  unsigned long long count[16]; /* doubles stored per RTOC_BUF_* (0: absent) */
+} rtoc_dump_header;
+/* buffer_mask: bit b set = store RTOC_BUF_b if it exists. */
+int rtoc_save_stage_dump(rtoc_ctx* ctx, const char* path, unsigned int buffer_mask);
+/* Creates a context sized for the dump (max_stages = nstages), restores grid / rows / cones / buffers. */
+int rtoc_load_stage_dump(const char* path, int device, rtoc_ctx** out);
 
 /* Multi-GPU: all-gather the direction buffers of all ranks over RCCL.
  * `nccl_comm` is an ncclComm_t passed as void*; `out` is device memory of

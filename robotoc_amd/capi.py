@@ -25,7 +25,7 @@ EXPORTS = [
     "rtoc_sync", "rtoc_time_phase", "rtoc_set_constraint_rows", "rtoc_gather_directions", "rtoc_error_string",
     "rtoc_riccati_sweep", "rtoc_correct_state_equation", "rtoc_correct_costate_direction",
     "rtoc_compute_initial_state_direction", "rtoc_unconstr_condense", "rtoc_unconstr_expand",
-    "rtoc_set_friction_cones",
+    "rtoc_set_friction_cones", "rtoc_save_stage_dump", "rtoc_load_stage_dump",
 ]
 
 
@@ -90,6 +90,8 @@ def lib():
         L.rtoc_gather_directions.argtypes = [vp, vp, dp]
         L.rtoc_set_constraint_rows.argtypes = [vp, C.POINTER(BoxRow), C.c_int]
         L.rtoc_set_friction_cones.argtypes = [vp, C.c_int, C.c_int]
+        L.rtoc_save_stage_dump.argtypes = [vp, C.c_char_p, C.c_uint]
+        L.rtoc_load_stage_dump.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
         L.rtoc_error_string.argtypes = [C.c_int]
         L.rtoc_error_string.restype = C.c_char_p
         _LIB = L
@@ -124,6 +126,22 @@ class Context:
         self.L = Layout()
         _chk(lib().rtoc_get_layout(self._h, C.byref(self.L)))
         self.nstages = 0
+
+    @classmethod
+    def from_stage_dump(cls, path, device=0):
+        """rtoc_load_stage_dump: a context restored from a stage dump (robotoc_amd/replay.py format)."""
+        from .replay import read_dump
+        meta = read_dump(path)
+        self = cls.__new__(cls)
+        self.dims = meta["dims"]
+        self.batch = meta["batch"]
+        self.max_stages = len(meta["grids"])
+        self._h = C.c_void_p()
+        _chk(lib().rtoc_load_stage_dump(str(path).encode(), device, C.byref(self._h)))
+        self.L = Layout()
+        _chk(lib().rtoc_get_layout(self._h, C.byref(self.L)))
+        self.nstages = len(meta["grids"])
+        return self
 
     def close(self):
         if self._h:
@@ -206,6 +224,13 @@ class Context:
 
     def compute_initial_state_direction(self):
         _chk(lib().rtoc_compute_initial_state_direction(self._h))
+
+    def save_stage_dump(self, path, buffers):
+        """rtoc_save_stage_dump: `buffers` = iterable of RTOC_BUF_* indices."""
+        mask = 0
+        for b in buffers:
+            mask |= 1 << b
+        _chk(lib().rtoc_save_stage_dump(self._h, str(path).encode(), mask))
 
     def set_friction_cones(self, max_contacts, contact_dim=3):
         _chk(lib().rtoc_set_friction_cones(self._h, int(max_contacts), int(contact_dim)))

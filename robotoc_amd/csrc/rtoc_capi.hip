@@ -144,6 +144,8 @@ struct rtoc_ctx {
   bool owned[RTOC_NUM_BUFFERS];
   rtoc_grid* d_grid;
   rtoc_box_row* d_rows;
+  rtoc_box_row* h_rows;  // host copies (stage dump)
+  rtoc_grid* h_grid;
   int* d_entry;  // CSR over the primal entries (q_0..,v_0..,u_0..): [ne+1] offsets, then [nrows] row ids
   int nrows;
   uint32_t* d_status;
@@ -182,6 +184,7 @@ const char* rtoc_error_string(int code) {
     case RTOC_ERR_HIP: return g_errbuf;
     case RTOC_ERR_NOT_READY: return "grid not set";
     case RTOC_ERR_RCCL: return "RCCL error";
+    case RTOC_ERR_IO: return "stage dump: file error or malformed file";
     default: return "unknown";
   }
 }
@@ -265,6 +268,8 @@ int rtoc_destroy(rtoc_ctx* c) {
     if (c->owned[i] && c->buf[i]) (void)hipFree(c->buf[i]);
   (void)hipFree(c->d_grid);
   if (c->d_rows) (void)hipFree(c->d_rows);
+  free(c->h_rows);
+  free(c->h_grid);
   if (c->d_entry) (void)hipFree(c->d_entry);
   (void)hipFree(c->d_status);
   if (c->d_prof) (void)hipFree(c->d_prof);
@@ -299,6 +304,8 @@ int rtoc_set_grid(rtoc_ctx* c, const rtoc_grid* grid, int nstages) {
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipMemcpyAsync(c->d_grid, grid, sizeof(rtoc_grid) * nstages, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
+  if (!c->h_grid) c->h_grid = (rtoc_grid*)malloc(sizeof(rtoc_grid) * c->max_stages);
+  if (c->h_grid) memcpy(c->h_grid, grid, sizeof(rtoc_grid) * nstages);
   c->nstages = nstages;
   return RTOC_OK;
 }
@@ -771,6 +778,10 @@ int rtoc_set_constraint_rows(rtoc_ctx* c, const rtoc_box_row* rows, int nrows) {
     HIP_TRY(hipMemcpyAsync(c->d_entry, csr.data(), sizeof(int) * csr.size(), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
   }
+  if (nrows > 0) {
+    if (!c->h_rows) c->h_rows = (rtoc_box_row*)malloc(sizeof(rtoc_box_row) * c->dims.nc_max);
+    if (c->h_rows) memcpy(c->h_rows, rows, sizeof(rtoc_box_row) * nrows);
+  }
   c->nrows = nrows;
   return RTOC_OK;
 }
@@ -837,6 +848,105 @@ int rtoc_time_phase(rtoc_ctx* c, int phase, int reps, float* ms) {
   float t = 0.f;
   HIP_TRY(hipEventElapsedTime(&t, c->ev0, c->ev1));
   *ms = t / reps;
+  return RTOC_OK;
+}
+
+// ---- stage dump / replay --------------------------------------------------------------------
+static size_t dump_count(const rtoc_ctx* c, int b) {  // doubles of buffer b the kernels index
+  const size_t per = (size_t)c->batch * c->nstages;
+  switch (b) {
+    case RTOC_BUF_KKT: return per * c->L.kkt.stride;
+    case RTOC_BUF_RIC: return per * c->L.ric.stride;
+    case RTOC_BUF_DIR: return per * c->L.dir.stride;
+    case RTOC_BUF_CDD: return per * c->L.cdd.stride;
+    case RTOC_BUF_CON: return per * c->L.con.stride;
+    case RTOC_BUF_DX0: return (size_t)c->batch * c->L.nx;
+    case RTOC_BUF_STEP: return (size_t)c->batch * 2;
+    case RTOC_BUF_SE3: return per * RTOC_SE3_STRIDE;
+    case RTOC_BUF_CONE: return c->cone_contacts > 0 ? per * rtoc_cone_stride(c->dims.nv, c->cone_contacts) : 0;
+    default: return 0;
+  }
+}
+
+int rtoc_save_stage_dump(rtoc_ctx* c, const char* path, unsigned int mask) {
+  CHECK_READY(c);
+  if (!path || !c->h_grid) return RTOC_ERR_BAD_ARG;
+  rtoc_dump_header h;
+  memset(&h, 0, sizeof(h));
+  memcpy(h.magic, "RTOCDMP1", 8);
+  h.version = 1;
+  h.header_bytes = (unsigned)sizeof(h);
+  h.dims = c->dims;
+  h.nstages = c->nstages;
+  h.batch = c->batch;
+  h.nrows = c->nrows;
+  h.cone_contacts = c->cone_contacts;
+  h.cone_dim = c->cone_dim;
+  for (int b = 0; b < RTOC_NUM_BUFFERS; ++b)
+    if ((mask >> b & 1u) && c->buf[b]) h.count[b] = dump_count(c, b);
+  FILE* f = fopen(path, "wb");
+  if (!f) return RTOC_ERR_IO;
+  bool ok = fwrite(&h, sizeof(h), 1, f) == 1 &&
+            fwrite(c->h_grid, sizeof(rtoc_grid), c->nstages, f) == (size_t)c->nstages &&
+            (c->nrows == 0 || fwrite(c->h_rows, sizeof(rtoc_box_row), c->nrows, f) == (size_t)c->nrows);
+  std::vector<double> stage;
+  for (int b = 0; ok && b < RTOC_NUM_BUFFERS; ++b) {
+    if (!h.count[b]) continue;
+    stage.resize(h.count[b]);
+    if (hipMemcpyAsync(stage.data(), c->buf[b], h.count[b] * sizeof(double), hipMemcpyDeviceToHost, c->stream) !=
+            hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess) {
+      fclose(f);
+      return RTOC_ERR_HIP;
+    }
+    ok = fwrite(stage.data(), sizeof(double), h.count[b], f) == h.count[b];
+  }
+  ok = (fclose(f) == 0) && ok;
+  return ok ? RTOC_OK : RTOC_ERR_IO;
+}
+
+int rtoc_load_stage_dump(const char* path, int device, rtoc_ctx** out) {
+  if (!path || !out) return RTOC_ERR_BAD_ARG;
+  FILE* f = fopen(path, "rb");
+  if (!f) return RTOC_ERR_IO;
+  rtoc_dump_header h;
+  if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "RTOCDMP1", 8) != 0 || h.version != 1 ||
+      h.header_bytes != sizeof(h) || h.nstages < 2 || h.batch < 1 || h.nrows < 0 || h.nrows > h.dims.nc_max) {
+    fclose(f);
+    return RTOC_ERR_IO;
+  }
+  std::vector<rtoc_grid> grid(h.nstages);
+  std::vector<rtoc_box_row> rows(h.nrows > 0 ? h.nrows : 1);
+  if (fread(grid.data(), sizeof(rtoc_grid), h.nstages, f) != (size_t)h.nstages ||
+      (h.nrows > 0 && fread(rows.data(), sizeof(rtoc_box_row), h.nrows, f) != (size_t)h.nrows)) {
+    fclose(f);
+    return RTOC_ERR_IO;
+  }
+  rtoc_ctx* c = nullptr;
+  int rc = rtoc_create(&h.dims, h.nstages, h.batch, device, &c);
+  if (!rc) rc = rtoc_set_grid(c, grid.data(), h.nstages);
+  if (!rc && h.nrows > 0) rc = rtoc_set_constraint_rows(c, rows.data(), h.nrows);
+  if (!rc && h.cone_contacts > 0) rc = rtoc_set_friction_cones(c, h.cone_contacts, h.cone_dim);
+  std::vector<double> stage;
+  for (int b = 0; !rc && b < RTOC_NUM_BUFFERS; ++b) {
+    if (!h.count[b]) continue;
+    if (h.count[b] != dump_count(c, b)) {
+      rc = RTOC_ERR_IO;
+      break;
+    }
+    stage.resize(h.count[b]);
+    if (fread(stage.data(), sizeof(double), h.count[b], f) != h.count[b]) {
+      rc = RTOC_ERR_IO;
+      break;
+    }
+    rc = rtoc_upload(c, b, 0, stage.data(), h.count[b]);
+  }
+  fclose(f);
+  if (rc) {
+    if (c) rtoc_destroy(c);
+    return rc;
+  }
+  *out = c;
   return RTOC_OK;
 }
 
