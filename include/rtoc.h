@@ -195,6 +195,14 @@ int rtoc_sync(rtoc_ctx* ctx);
  * phase: 0 backward, 1 forward, 2 condense, 3 expand, 4 backward+forward, 5 update. */
 int rtoc_time_phase(rtoc_ctx* ctx, int phase, int reps, float* ms);
 
+/* ---- KKT error of every instance (first piece of the on-device Newton loop) ----
+ * sqrt of the squared KKT residual summed over the horizon, on the PRE-condensation records, as
+ * OCPSolver::KKTError() (src/solver/ocp_solver.cpp:429-431) without its STO term:
+ * SplitKKTResidual::KKTError (split_kkt_residual.hxx:90-104) + ContactDynamicsData::KKTError
+ * (contact_dynamics_data.hpp:204-206, if RTOC_BUF_CDD exists) + ConstraintComponentData::KKTError of the
+ * active box / cone rows (constraint_component_data.hpp:122-124, if rows are set).  host_out: [count<=batch]. */
+int rtoc_kkt_error(rtoc_ctx* ctx, double* host_out, int count);
+
 /* ---- stage dump / replay ----------------------------------------
  * A self-describing file of everything a context holds at the evalKKT boundary
  * (IntermediateStage::evalKKT outputs, src/ocp/intermediate_stage.cpp:113-148): dims, grid, box rows,

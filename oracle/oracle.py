@@ -70,6 +70,9 @@ def lib():
                                                      C.c_double, C.c_int]
         _LIB.orc_cone_batch.argtypes = [C.POINTER(Layout), C.POINTER(Grid), C.c_int, C.c_int, C.c_int, C.c_int,
                                         dp, dp, dp, dp, dp, C.c_double, dp, C.c_int]
+        _LIB.orc_kkt_error.argtypes = [C.POINTER(Layout), C.POINTER(Grid), C.c_int, dp, dp, dp, C.POINTER(BoxRow),
+                                       C.c_int, C.c_int, C.c_int]
+        _LIB.orc_kkt_error.restype = C.c_double
     return _LIB
 
 
@@ -232,3 +235,14 @@ def cone_update_batch(L, grids, max_contacts, contact_dim, con, steps):
     steps = np.ascontiguousarray(steps, dtype=np.float64)
     lib().orc_cone_batch(C.byref(L), grid_array(grids), len(grids), con.shape[0], max_contacts, contact_dim,
                          None, None, None, _p(con), None, 0.0, _p(steps), 2)
+
+
+def kkt_error(L, grids, kkt, cdd=None, con=None, rows=(), cone_contacts=0, cone_dim=3):
+    """OCPSolver::KKTError() (without the STO term) of every instance, pre-condensation records."""
+    out = np.zeros(kkt.shape[0])
+    for b in range(kkt.shape[0]):
+        out[b] = lib().orc_kkt_error(C.byref(L), grid_array(grids), len(grids), _p(kkt[b]),
+                                     _p(cdd[b]) if cdd is not None else None,
+                                     _p(con[b]) if con is not None else None, _rows(rows), len(rows),
+                                     cone_contacts, cone_dim)
+    return out

@@ -771,3 +771,59 @@ void orc_cone_batch(const rtoc_layout* L, const rtoc_grid* grid, int nstages, in
                               steps[2 * b + 1]);
     }
 }
+
+/* ======================================================================================
+ * KKT error of one instance (src/ocp/intermediate_stage.cpp:132, impact_stage.cpp, terminal_stage.cpp;
+ * SplitKKTResidual::KKTError split_kkt_residual.hxx:90-104; ContactDynamicsData::KKTError
+ * contact_dynamics_data.hpp:204-206; ConstraintComponentData::KKTError constraint_component_data.hpp:122-124;
+ * OCPSolver::KKTError ocp_solver.cpp:429-431 without the STO term), on pre-condensation records.
+ * cdd / con / rows may be NULL.
+ * ====================================================================================== */
+static double sqn(const double* p, int n) {
+  double s = 0.0;
+  for (int i = 0; i < n; ++i) s += p[i] * p[i];
+  return s;
+}
+
+double orc_kkt_error(const rtoc_layout* L, const rtoc_grid* grid, int nstages, const double* kkt,
+                     const double* cdd, const double* con, const rtoc_box_row* rows, int nrows,
+                     int cone_contacts, int cone_dim) {
+  const int nv = L->dims.nv, nu = L->dims.nu, np = L->dims.np, nx = L->nx;
+  double err = 0.0;
+  for (int i = 0; i < nstages; ++i) {
+    const rtoc_grid* g = &grid[i];
+    const double* kr = kkt + (size_t)i * L->kkt.stride;
+    err += sqn(kr + L->kkt.off[RTOC_KKT_LX], nx);
+    if (g->type == RTOC_GRID_TERMINAL) continue;
+    err += sqn(kr + L->kkt.off[RTOC_KKT_FX], nx);
+    const int impact = g->type == RTOC_GRID_IMPACT;
+    if (!impact) {
+      err += sqn(kr + L->kkt.off[RTOC_KKT_LU], nu);
+      if (g->dims > 0) err += sqn(kr + L->kkt.off[RTOC_KKT_PRES], g->dims);
+    }
+    if (cdd) {
+      const double* cr = cdd + (size_t)i * L->cdd.stride;
+      err += sqn(cr + L->cdd.off[RTOC_CDD_LA], nv);
+      err += sqn(cr + L->cdd.off[RTOC_CDD_LF], g->dimf);
+      err += sqn(cr + L->cdd.off[RTOC_CDD_IDC], nv + g->dimf);
+      if (!impact) err += sqn(cr + L->cdd.off[RTOC_CDD_LUP], np);
+    }
+    if (con) {
+      const double* nr = con + (size_t)i * L->con.stride;
+      const int* o = L->con.off;
+      for (int r = 0; r < nrows; ++r)
+        if (row_active(&rows[r], g)) {
+          const double x = nr[o[RTOC_CON_RESIDUAL] + r], y = nr[o[RTOC_CON_CMPL] + r];
+          err += x * x + y * y;
+        }
+      if (cone_contacts > 0) {
+        const int row0 = L->dims.nc_max - 5 * cone_contacts, n = 5 * (g->dimf / cone_dim);
+        for (int r = row0; r < row0 + n; ++r) {
+          const double x = nr[o[RTOC_CON_RESIDUAL] + r], y = nr[o[RTOC_CON_CMPL] + r];
+          err += x * x + y * y;
+        }
+      }
+    }
+  }
+  return sqrt(err);
+}

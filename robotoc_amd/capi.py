@@ -25,7 +25,7 @@ EXPORTS = [
     "rtoc_sync", "rtoc_time_phase", "rtoc_set_constraint_rows", "rtoc_gather_directions", "rtoc_error_string",
     "rtoc_riccati_sweep", "rtoc_correct_state_equation", "rtoc_correct_costate_direction",
     "rtoc_compute_initial_state_direction", "rtoc_unconstr_condense", "rtoc_unconstr_expand",
-    "rtoc_set_friction_cones", "rtoc_save_stage_dump", "rtoc_load_stage_dump",
+    "rtoc_set_friction_cones", "rtoc_save_stage_dump", "rtoc_load_stage_dump", "rtoc_kkt_error",
 ]
 
 
@@ -91,6 +91,7 @@ def lib():
         L.rtoc_set_constraint_rows.argtypes = [vp, C.POINTER(BoxRow), C.c_int]
         L.rtoc_set_friction_cones.argtypes = [vp, C.c_int, C.c_int]
         L.rtoc_save_stage_dump.argtypes = [vp, C.c_char_p, C.c_uint]
+        L.rtoc_kkt_error.argtypes = [vp, dp, C.c_int]
         L.rtoc_load_stage_dump.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
         L.rtoc_error_string.argtypes = [C.c_int]
         L.rtoc_error_string.restype = C.c_char_p
@@ -224,6 +225,12 @@ class Context:
 
     def compute_initial_state_direction(self):
         _chk(lib().rtoc_compute_initial_state_direction(self._h))
+
+    def kkt_error(self):
+        """rtoc_kkt_error: sqrt of the squared KKT residual of every instance."""
+        out = np.empty(self.batch, dtype=np.float64)
+        _chk(lib().rtoc_kkt_error(self._h, _dp(out), self.batch))
+        return out
 
     def save_stage_dump(self, path, buffers):
         """rtoc_save_stage_dump: `buffers` = iterable of RTOC_BUF_* indices."""

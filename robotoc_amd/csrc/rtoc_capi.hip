@@ -14,6 +14,7 @@
 #include "state_equation.hpp"
 #include "unconstr_dynamics.hpp"
 #include "friction_cone.hpp"
+#include "kkt_error.hpp"
 #include "riccati_backward.hpp"
 #include "riccati_backward_rs.hpp"
 #include "riccati_forward.hpp"
@@ -159,6 +160,7 @@ struct rtoc_ctx {
   hipEvent_t ev_fork, ev_join, ev_chunk[RTOC_MAX_CHUNK_EVENTS];
   int sweep_chunks;
   int cone_contacts, cone_dim;  // friction cones: max contacts (0 = off), force components per contact
+  double* d_kkterr;             // [batch]
 };
 
 extern "C" {
@@ -270,6 +272,7 @@ int rtoc_destroy(rtoc_ctx* c) {
   if (c->d_rows) (void)hipFree(c->d_rows);
   free(c->h_rows);
   free(c->h_grid);
+  if (c->d_kkterr) (void)hipFree(c->d_kkterr);
   if (c->d_entry) (void)hipFree(c->d_entry);
   (void)hipFree(c->d_status);
   if (c->d_prof) (void)hipFree(c->d_prof);
@@ -848,6 +851,38 @@ int rtoc_time_phase(rtoc_ctx* c, int phase, int reps, float* ms) {
   float t = 0.f;
   HIP_TRY(hipEventElapsedTime(&t, c->ev0, c->ev1));
   *ms = t / reps;
+  return RTOC_OK;
+}
+
+// ---- KKT error ------------------------------------------------------------------------------
+int rtoc_kkt_error(rtoc_ctx* c, double* host_out, int count) {
+  CHECK_READY(c);
+  if (!host_out || count < 0 || count > c->batch) return RTOC_ERR_BAD_ARG;
+  if (!c->d_kkterr) HIP_TRY(hipMalloc((void**)&c->d_kkterr, sizeof(double) * c->batch));
+  KktErrArgs a;
+  a.kkt = c->buf[RTOC_BUF_KKT];
+  a.cdd = c->buf[RTOC_BUF_CDD];
+  a.con = (c->nrows > 0 || c->cone_contacts > 0) ? c->buf[RTOC_BUF_CON] : nullptr;
+  a.rows = c->d_rows;
+  a.grid = c->d_grid;
+  a.out = c->d_kkterr;
+  a.nstages = c->nstages;
+  a.batch = c->batch;
+  a.nrows = c->nrows;
+  a.cone_contacts = c->cone_contacts;
+  a.cone_dim = c->cone_dim > 0 ? c->cone_dim : 3;
+  a.nc_max = c->dims.nc_max;
+  a.nv = c->dims.nv;
+  a.nu = c->dims.nu;
+  a.np = c->dims.np;
+  a.nx = c->L.nx;
+  a.kl = c->L.kkt;
+  a.cl = c->L.cdd;
+  a.nl = c->L.con;
+  hipLaunchKernelGGL(kkt_error_kernel, dim3(c->batch), dim3(64), 0, c->stream, a);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(host_out, c->d_kkterr, sizeof(double) * count, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
   return RTOC_OK;
 }
 
