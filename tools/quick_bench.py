@@ -24,7 +24,7 @@ def main():
     ctx.time_phase(1, 2)
     ms = ctx.time_phase(1, 5)
     print("forward: %.3f ms/launch" % ms)
-    for ch in (1, 4):
+    for ch in (() if "nosweep" in sys.argv else (1, 4)):
         ctx.set_sweep_chunks(ch)
         ctx.time_phase(4, 2)
         ms = ctx.time_phase(4, 5)
