@@ -88,7 +88,8 @@ enum rtoc_buffer {
                       * StateEquationData (include/robotoc/dynamics/state_equation_data.hpp), 6x6 column-major each */
   RTOC_BUF_CONE = 8, /* [batch][stages][rtoc_cone_stride(nv, max_contacts)] friction-cone Jacobians of the
                       * active contacts (rtoc_layout.h); exists after rtoc_set_friction_cones */
-  RTOC_NUM_BUFFERS = 9
+  RTOC_BUF_SOL = 9,  /* [batch][stages][sol.stride]  SplitSolution (rtoc_integrate_solution) */
+  RTOC_NUM_BUFFERS = 10
 };
 
 /* kernel-variant knobs (rtoc_set_option) */
@@ -202,6 +203,13 @@ int rtoc_time_phase(rtoc_ctx* ctx, int phase, int reps, float* ms);
  * (contact_dynamics_data.hpp:204-206, if RTOC_BUF_CDD exists) + ConstraintComponentData::KKTError of the
  * active box / cone rows (constraint_component_data.hpp:122-124, if rows are set).  host_out: [count<=batch]. */
 int rtoc_kkt_error(rtoc_ctx* ctx, double* host_out, int count);
+
+/* SplitSolution::integrate (src/core/split_solution.cpp:58-90) on every grid point, as the
+ * updatePrimal half of DirectMultipleShooting::integrateSolution (direct_multiple_shooting.cpp:212-241)
+ * does after rtoc_expand: RTOC_BUF_SOL += primal step (RTOC_BUF_STEP) x RTOC_BUF_DIR for v, a (dv on
+ * impact grids), u, lmd, gmm, beta, nu_passive, f, mu, xi and the joint part of q.  The floating-base
+ * part of q (first 7 entries: the SE3 integrateConfiguration of Pinocchio) is left to the CPU side. */
+int rtoc_integrate_solution(rtoc_ctx* ctx);
 
 /* ---- stage dump / replay ----------------------------------------
  * A self-describing file of everything a context holds at the evalKKT boundary

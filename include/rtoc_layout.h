@@ -191,6 +191,24 @@ enum {
   RTOC_CON_NFIELDS
 };
 
+/* ---- solution record: SplitSolution (include/robotoc/core/split_solution.hpp), the members
+ *      SplitSolution::integrate updates (src/core/split_solution.cpp:58-90).  q has nv+1 slots
+ *      (floating base: 7 base + joints); on impact grids the A slot holds dv. ---- */
+enum {
+  RTOC_SOL_Q = 0,
+  RTOC_SOL_V,
+  RTOC_SOL_A,
+  RTOC_SOL_U,
+  RTOC_SOL_F,
+  RTOC_SOL_LMD,
+  RTOC_SOL_GMM,
+  RTOC_SOL_BETA,
+  RTOC_SOL_MU,
+  RTOC_SOL_NUP,
+  RTOC_SOL_XI,
+  RTOC_SOL_NFIELDS
+};
+
 /* ---- RTOC_BUF_SE3 record: StateEquationData::Fqq_inv, Fqq_prev_inv (6x6, column-major) ---- */
 #define RTOC_SE3_FQQ_INV 0
 #define RTOC_SE3_FQQ_PREV_INV 36
@@ -216,7 +234,7 @@ typedef struct rtoc_layout {
   rtoc_dims dims;
   int nx;      /* 2*nv       */
   int nvf_max; /* nv+nf_max  */
-  rtoc_record_layout kkt, ric, dir, cdd, con;
+  rtoc_record_layout kkt, ric, dir, cdd, con, sol;
 } rtoc_layout;
 
 static inline RTOC_HD RTOC_CONSTEXPR int rtoc_pad8(int n) { return (n + 7) & ~7; }
@@ -321,6 +339,21 @@ static inline RTOC_HD RTOC_CONSTEXPR void rtoc_compute_layout(const rtoc_dims* d
     int s[RTOC_CON_NFIELDS] = {0};
     for (int i = 0; i < RTOC_CON_NFIELDS; ++i) s[i] = d->nc_max;
     rtoc_record_finish(&L->con, s, RTOC_CON_NFIELDS);
+  }
+  {
+    int s[RTOC_SOL_NFIELDS] = {0};
+    s[RTOC_SOL_Q] = nv + 1;
+    s[RTOC_SOL_V] = nv;
+    s[RTOC_SOL_A] = nv;
+    s[RTOC_SOL_U] = nu;
+    s[RTOC_SOL_F] = nf;
+    s[RTOC_SOL_LMD] = nv;
+    s[RTOC_SOL_GMM] = nv;
+    s[RTOC_SOL_BETA] = nv;
+    s[RTOC_SOL_MU] = nf;
+    s[RTOC_SOL_NUP] = 8;
+    s[RTOC_SOL_XI] = ns;
+    rtoc_record_finish(&L->sol, s, RTOC_SOL_NFIELDS);
   }
 }
 

@@ -73,6 +73,7 @@ def lib():
         _LIB.orc_kkt_error.argtypes = [C.POINTER(Layout), C.POINTER(Grid), C.c_int, dp, dp, dp, C.POINTER(BoxRow),
                                        C.c_int, C.c_int, C.c_int]
         _LIB.orc_kkt_error.restype = C.c_double
+        _LIB.orc_integrate_solution_batch.argtypes = [C.POINTER(Layout), C.POINTER(Grid), C.c_int, C.c_int, dp, dp, dp]
     return _LIB
 
 
@@ -246,3 +247,10 @@ def kkt_error(L, grids, kkt, cdd=None, con=None, rows=(), cone_contacts=0, cone_
                                      _p(con[b]) if con is not None else None, _rows(rows), len(rows),
                                      cone_contacts, cone_dim)
     return out
+
+
+def integrate_solution_batch(L, grids, steps, dirs, sol):
+    """SplitSolution::integrate (Euclidean members) with the primal step sizes steps[:, 0]."""
+    steps = np.ascontiguousarray(steps, dtype=np.float64)
+    lib().orc_integrate_solution_batch(C.byref(L), grid_array(grids), len(grids), sol.shape[0], _p(steps), _p(dirs),
+                                       _p(sol))

@@ -827,3 +827,51 @@ double orc_kkt_error(const rtoc_layout* L, const rtoc_grid* grid, int nstages, c
   }
   return sqrt(err);
 }
+
+/* ======================================================================================
+ * SplitSolution::integrate (src/core/split_solution.cpp:58-90), Euclidean members; of q only the joint
+ * part (the 7 floating-base entries need Pinocchio's integrateConfiguration).
+ * ====================================================================================== */
+void orc_integrate_solution_stage(const rtoc_layout* L, const rtoc_grid* g, double step, const double* dir_rec,
+                                  double* sol_rec) {
+  const int nv = L->dims.nv, nu = L->dims.nu, np = L->dims.np;
+  const int impact = g->type == RTOC_GRID_IMPACT;
+  const int* so = L->sol.off;
+  const int* dof = L->dir.off;
+  const double* dx = dir_rec + dof[RTOC_DIR_DX];
+  const double* dl = dir_rec + dof[RTOC_DIR_DLMDGMM];
+  const double* daf = dir_rec + dof[RTOC_DIR_DAF];
+  const double* dbm = dir_rec + dof[RTOC_DIR_DBETAMU];
+  const int nb = np == 6 ? 6 : 0;
+  for (int i = 0; i < nv - nb; ++i) sol_rec[so[RTOC_SOL_Q] + (nb ? 7 : 0) + i] += step * dx[nb + i]; /* (:62) */
+  for (int i = 0; i < nv; ++i) sol_rec[so[RTOC_SOL_V] + i] += step * dx[nv + i];                      /* (:63) */
+  for (int i = 0; i < nv; ++i) sol_rec[so[RTOC_SOL_A] + i] += step * daf[i];                          /* (:65 / :71) */
+  if (!impact) {
+    for (int i = 0; i < nu; ++i) sol_rec[so[RTOC_SOL_U] + i] += step * dir_rec[dof[RTOC_DIR_DU] + i]; /* (:67) */
+  } else {
+    for (int i = 0; i < nu; ++i) sol_rec[so[RTOC_SOL_U] + i] = 0.0;                                   /* (:72) */
+  }
+  for (int i = 0; i < nv; ++i) {
+    sol_rec[so[RTOC_SOL_LMD] + i] += step * dl[i];       /* (:74) */
+    sol_rec[so[RTOC_SOL_GMM] + i] += step * dl[nv + i];  /* (:75) */
+    sol_rec[so[RTOC_SOL_BETA] + i] += step * dbm[i];     /* (:76) */
+  }
+  if (np == 6 && !impact)
+    for (int i = 0; i < np; ++i) sol_rec[so[RTOC_SOL_NUP] + i] += step * dir_rec[dof[RTOC_DIR_DNUP] + i];
+  for (int i = 0; i < g->dimf; ++i) {
+    sol_rec[so[RTOC_SOL_F] + i] += step * daf[nv + i];   /* (:81) */
+    sol_rec[so[RTOC_SOL_MU] + i] += step * dbm[nv + i];  /* (:83) */
+  }
+  if (!impact)
+    for (int i = 0; i < g->dims; ++i) sol_rec[so[RTOC_SOL_XI] + i] += step * dir_rec[dof[RTOC_DIR_DXI] + i];
+}
+
+void orc_integrate_solution_batch(const rtoc_layout* L, const rtoc_grid* grid, int nstages, int batch,
+                                  const double* steps, const double* dir, double* sol) {
+#pragma omp parallel for schedule(static)
+  for (int b = 0; b < batch; ++b)
+    for (int i = 0; i < nstages; ++i) {
+      const size_t rec = (size_t)b * nstages + i;
+      orc_integrate_solution_stage(L, &grid[i], steps[2 * b], dir + rec * L->dir.stride, sol + rec * L->sol.stride);
+    }
+}

@@ -25,7 +25,7 @@ EXPORTS = [
     "rtoc_sync", "rtoc_time_phase", "rtoc_set_constraint_rows", "rtoc_gather_directions", "rtoc_error_string",
     "rtoc_riccati_sweep", "rtoc_correct_state_equation", "rtoc_correct_costate_direction",
     "rtoc_compute_initial_state_direction", "rtoc_unconstr_condense", "rtoc_unconstr_expand",
-    "rtoc_set_friction_cones", "rtoc_save_stage_dump", "rtoc_load_stage_dump", "rtoc_kkt_error",
+    "rtoc_set_friction_cones", "rtoc_save_stage_dump", "rtoc_load_stage_dump", "rtoc_kkt_error", "rtoc_integrate_solution",
 ]
 
 
@@ -78,7 +78,7 @@ def lib():
         L.rtoc_bind.argtypes = [vp, C.c_int, vp]
         for f in ("rtoc_condense", "rtoc_riccati_backward", "rtoc_riccati_forward", "rtoc_riccati_sweep", "rtoc_update",
                   "rtoc_correct_state_equation", "rtoc_correct_costate_direction",
-                  "rtoc_compute_initial_state_direction", "rtoc_unconstr_condense",
+                  "rtoc_compute_initial_state_direction", "rtoc_unconstr_condense", "rtoc_integrate_solution",
                   "rtoc_clear_status", "rtoc_sync"):
             getattr(L, f).argtypes = [vp]
         L.rtoc_unconstr_backward.argtypes = [vp, C.c_double]
@@ -225,6 +225,9 @@ class Context:
 
     def compute_initial_state_direction(self):
         _chk(lib().rtoc_compute_initial_state_direction(self._h))
+
+    def integrate_solution(self):
+        _chk(lib().rtoc_integrate_solution(self._h))
 
     def kkt_error(self):
         """rtoc_kkt_error: sqrt of the squared KKT residual of every instance."""

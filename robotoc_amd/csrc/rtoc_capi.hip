@@ -15,6 +15,7 @@
 #include "unconstr_dynamics.hpp"
 #include "friction_cone.hpp"
 #include "kkt_error.hpp"
+#include "integrate_solution.hpp"
 #include "riccati_backward.hpp"
 #include "riccati_backward_rs.hpp"
 #include "riccati_forward.hpp"
@@ -238,6 +239,7 @@ int rtoc_create(const rtoc_dims* dims, int max_stages, int batch, int device, rt
   c->count[RTOC_BUF_STEP] = (size_t)batch * 2;
   c->count[RTOC_BUF_SE3] = per * RTOC_SE3_STRIDE;
   c->count[RTOC_BUF_CONE] = 0;  // sized by rtoc_set_friction_cones
+  c->count[RTOC_BUF_SOL] = per * c->L.sol.stride;
   for (int i = 0; i < RTOC_NUM_BUFFERS; ++i) {
     // the CDD / CON buffers are large; they are allocated lazily on first use (upload / bind / condense)
     c->buf[i] = nullptr;
@@ -854,6 +856,29 @@ int rtoc_time_phase(rtoc_ctx* c, int phase, int reps, float* ms) {
   return RTOC_OK;
 }
 
+// ---- SplitSolution::integrate ---------------------------------------------------------------
+int rtoc_integrate_solution(rtoc_ctx* c) {
+  CHECK_READY(c);
+  if (!c->buf[RTOC_BUF_SOL]) return RTOC_ERR_NOT_READY;
+  IntArgs a;
+  a.sol = c->buf[RTOC_BUF_SOL];
+  a.dir = c->buf[RTOC_BUF_DIR];
+  a.steps = c->buf[RTOC_BUF_STEP];
+  a.grid = c->d_grid;
+  a.nstages = c->nstages;
+  a.batch = c->batch;
+  a.nv = c->dims.nv;
+  a.nu = c->dims.nu;
+  a.np = c->dims.np;
+  a.nf_max = c->dims.nf_max;
+  a.ns_max = c->dims.ns_max;
+  a.sl = c->L.sol;
+  a.dl = c->L.dir;
+  hipLaunchKernelGGL(integrate_solution_kernel, dim3(c->batch * c->nstages), dim3(64), 0, c->stream, a);
+  HIP_TRY(hipGetLastError());
+  return RTOC_OK;
+}
+
 // ---- KKT error ------------------------------------------------------------------------------
 int rtoc_kkt_error(rtoc_ctx* c, double* host_out, int count) {
   CHECK_READY(c);
@@ -899,6 +924,7 @@ static size_t dump_count(const rtoc_ctx* c, int b) {  // doubles of buffer b the
     case RTOC_BUF_STEP: return (size_t)c->batch * 2;
     case RTOC_BUF_SE3: return per * RTOC_SE3_STRIDE;
     case RTOC_BUF_CONE: return c->cone_contacts > 0 ? per * rtoc_cone_stride(c->dims.nv, c->cone_contacts) : 0;
+    case RTOC_BUF_SOL: return per * c->L.sol.stride;
     default: return 0;
   }
 }

@@ -21,7 +21,8 @@ CDD_FIELDS = ["dIDda", "dIDCdqv", "dCda", "IDC", "Qaa", "Qff", "Qqf", "la", "lf"
 
 STAT_QUU_NOT_SPD, STAT_S_NOT_SPD, STAT_NAN, STAT_M_NOT_SPD = 1, 2, 4, 8
 
-BUF_KKT, BUF_RIC, BUF_DIR, BUF_CDD, BUF_CON, BUF_DX0, BUF_STEP, BUF_SE3, BUF_CONE = range(9)
+BUF_KKT, BUF_RIC, BUF_DIR, BUF_CDD, BUF_CON, BUF_DX0, BUF_STEP, BUF_SE3, BUF_CONE, BUF_SOL = range(10)
+SOL_FIELDS = ["q", "v", "a", "u", "f", "lmd", "gmm", "beta", "mu", "nu_passive", "xi"]
 SE3_STRIDE, SE3_FQQ_INV, SE3_FQQ_PREV_INV = 72, 0, 36
 OPT_WRITEBACK_KKT, OPT_MAX_DTS0, OPT_BACKWARD_WAVES, OPT_CONTACT_INV_DAMPING, OPT_SWEEP_CHUNKS = range(5)
 
@@ -69,7 +70,7 @@ class RecordLayout(C.Structure):
 class Layout(C.Structure):
     _fields_ = [("dims", Dims), ("nx", C.c_int), ("nvf_max", C.c_int), ("kkt", RecordLayout),
                 ("ric", RecordLayout), ("dir", RecordLayout), ("cdd", RecordLayout),
-                ("con", RecordLayout)]
+                ("con", RecordLayout), ("sol", RecordLayout)]
 
 
 def anymal_dims(nc_max=96):
@@ -117,10 +118,13 @@ def _shapes(L, which):
                     Quu_passive_topRight=(8, nu), haf=(nvf,))
     if which == "con":
         return {f: (d.nc_max,) for f in CON_FIELDS}
+    if which == "sol":
+        return dict(q=(nv + 1,), v=(nv,), a=(nv,), u=(nu,), f=(nf,), lmd=(nv,), gmm=(nv,), beta=(nv,), mu=(nf,),
+                    nu_passive=(8,), xi=(ns,))
     raise KeyError(which)
 
 
-_NAMES = dict(kkt=KKT_FIELDS, ric=RIC_FIELDS, dir=DIR_FIELDS, cdd=CDD_FIELDS, con=CON_FIELDS)
+_NAMES = dict(kkt=KKT_FIELDS, ric=RIC_FIELDS, dir=DIR_FIELDS, cdd=CDD_FIELDS, con=CON_FIELDS, sol=SOL_FIELDS)
 
 
 class Records:
