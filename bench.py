@@ -68,6 +68,32 @@ def algorithmic_bytes(L, grids, batch, which):
     return total * 8 * batch
 
 
+def condense_bytes(L, grids, batch):
+    """Algorithmic HBM bytes of one rtoc_condense launch: per non-terminal grid point the
+    ContactDynamicsData inputs and the un-condensed Hessian / gradient blocks are read once, the condensed
+    blocks, the new dynamics rows and the data the expansion needs (MJtJinv, MJtJinv_dIDCdqv, Qafqv,
+    Qafu) are written once; max-size backing blocks are moved whole, like the reference stores them."""
+    from robotoc_amd.types import GRID_IMPACT, GRID_TERMINAL
+    d = L.dims
+    nv, nu, nx, nf, npas = d.nv, d.nu, 2 * d.nv, d.nf_max, d.np
+    nvf = nv + nf
+    total = 0
+    for g in grids:
+        if g.type == GRID_TERMINAL:
+            continue
+        imp = g.type == GRID_IMPACT
+        rd = nv * nv + nvf * nx + nvf + nv + nf * nf + nv * nf + 2 * nvf + nx * nx + 2 * nx + nv
+        wr = nx * nx + nv * nx + nx + nv + nvf * nvf + 2 * nvf * nx + 2 * nvf
+        if not imp:
+            rd += nf * nv + nx * nu + nu * nu + 2 * nx + 2 * nu + 2 * nvf
+            wr += nx * nu + nu * nu + nv * nu + 2 * nx + 2 * nu + nvf * nv + nx * npas + npas * nu + nvf
+            if g.dims:
+                rd += g.dims * (nv + nx + 2)
+                wr += g.dims * (nx + nu + 2)
+        total += rd + wr
+    return total * 8 * batch
+
+
 def pmc_traffic(waves, batch):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this
     same command (profiles/r01_traffic.json: 2*FETCH_SIZE + WRITE_SIZE, separate --pmc runs).
@@ -269,7 +295,9 @@ def main():
                     acc[name] += ms / nrep
         bad_sqp = int((ctx.status() != 0).sum())
         tot = sum(acc.values())
+        cb = condense_bytes(L, grids, batch)
         sqp = {"ms": acc, "total_ms": tot, "iters_per_sec_per_gpu": batch / tot * 1e3,
+               "condense_algorithmic_bytes": cb, "condense_GBs_algorithmic": cb / (acc["condense"] * 1e-3) / 1e9,
                "status_nonzero_instances": bad_sqp,
                "scope": "hot path downstream of the Pinocchio linearisation: PDIPM condensation of the "
                         "joint-limit and friction-cone rows + computeMJtJinv + condenseContact/ImpactDynamics + Riccati "
