@@ -94,10 +94,11 @@ struct RobotDims {  // what the hot path reads from robotoc::Robot
   rtoc_dims c() const { return rtoc_dims{dimv, dimu, dim_passive, max_dimf, max_dimf, 0}; }
 };
 
-struct OCP {  // robotoc::OCP (include/robotoc/ocp/ocp.hpp:22-147): the members RiccatiRecursion uses
+struct OCP {  // robotoc::OCP (include/robotoc/ocp/ocp.hpp:22-147): the members the Riccati classes use
   RobotDims robot;
   int N = 0;
   int reserved_num_discrete_events = 0;
+  double T = 0.0;  // horizon length (UnconstrRiccatiRecursion: dt = T / N)
 };
 
 class SplitKKTMatrix {
@@ -333,6 +334,110 @@ class RiccatiRecursion {
 
   RobotDims robot_;
   int max_stages_;
+  std::vector<LQRPolicy> lqr_policy_;
+  rtoc_ctx* ctx_;
+  rtoc_layout L_;
+};
+
+typedef RiccatiFactorization UnconstrRiccatiFactorization;
+
+// robotoc::UnconstrRiccatiRecursion (include/robotoc/riccati/unconstr_riccati_recursion.hpp:38-86,
+// src/riccati/unconstr_riccati_recursion.cpp:10-48): fixed-base, contact-free OCP with the acceleration
+// as the control.  As in the reference's KKT objects for this solver, kkt_matrix[i].Quu holds Qaa,
+// kkt_matrix[i].Qxu holds [Qqa; Qva] and kkt_residual[i].lu holds la
+// (unconstr_backward_riccati_recursion_factorizer.cpp:27-70); Fxx / Fvu are not read -- the structured
+// A = [[I, dt I],[0, I]], B = [0; dt I] are materialised on the device.
+class UnconstrRiccatiRecursion {
+ public:
+  explicit UnconstrRiccatiRecursion(const OCP& ocp, const int device = 0)
+      : robot_(ocp.robot), N_(ocp.N), dt_(ocp.T / ocp.N), lqr_policy_(ocp.N, LQRPolicy(ocp.robot)), ctx_(nullptr) {
+    if (ocp.N <= 0 || !(ocp.T > 0)) throw std::out_of_range("[UnconstrRiccatiRecursion] invalid argument: N and T must be positive!");
+    if (robot_.dimu != robot_.dimv || robot_.max_dimf != 0)
+      throw std::invalid_argument("[UnconstrRiccatiRecursion] robot must be fixed-base without contacts");
+    const rtoc_dims d = robot_.c();
+    check(rtoc_create(&d, N_ + 1, 1, device, &ctx_), "rtoc_create");
+    check(rtoc_get_layout(ctx_, &L_), "rtoc_get_layout");
+    std::vector<rtoc_grid> g(N_ + 1);
+    for (int i = 0; i <= N_; ++i) {
+      g[i] = rtoc_grid{i == N_ ? RTOC_GRID_TERMINAL : RTOC_GRID_INTERMEDIATE, 0, 0, 0, 0, 0, i == N_ ? 0 : N_, i,
+                       i == N_ ? 0.0 : dt_};
+    }
+    check(rtoc_set_grid(ctx_, g.data(), N_ + 1), "rtoc_set_grid");
+  }
+  ~UnconstrRiccatiRecursion() {
+    if (ctx_) rtoc_destroy(ctx_);
+  }
+  UnconstrRiccatiRecursion(const UnconstrRiccatiRecursion&) = delete;
+  UnconstrRiccatiRecursion& operator=(const UnconstrRiccatiRecursion&) = delete;
+
+  void backwardRiccatiRecursion(KKTMatrix& kkt_matrix, KKTResidual& kkt_residual,
+                                UnconstrRiccatiFactorization& factorization) {
+    const int n = N_ + 1, nv = robot_.dimv, nx = 2 * nv;
+    if (static_cast<int>(kkt_matrix.size()) < n || static_cast<int>(kkt_residual.size()) < n ||
+        static_cast<int>(factorization.size()) < n)
+      throw std::invalid_argument("[UnconstrRiccatiRecursion] horizon containers smaller than N + 1");
+    const int* o = L_.kkt.off;
+    std::vector<double> buf(static_cast<size_t>(n) * L_.kkt.stride, 0.0);
+    for (int i = 0; i < n; ++i) {
+      double* rec = &buf[static_cast<size_t>(i) * L_.kkt.stride];
+      std::memcpy(rec + o[RTOC_KKT_QXX], kkt_matrix[i].Qxx.data(), sizeof(double) * nx * nx);
+      std::memcpy(rec + o[RTOC_KKT_LX], kkt_residual[i].lx.data(), sizeof(double) * nx);
+      if (i == N_) continue;
+      std::memcpy(rec + o[RTOC_KKT_QXU], kkt_matrix[i].Qxu.data(), sizeof(double) * nx * nv);
+      std::memcpy(rec + o[RTOC_KKT_QUU], kkt_matrix[i].Quu.data(), sizeof(double) * nv * nv);
+      std::memcpy(rec + o[RTOC_KKT_FX], kkt_residual[i].Fx.data(), sizeof(double) * nx);
+      std::memcpy(rec + o[RTOC_KKT_LU], kkt_residual[i].lu.data(), sizeof(double) * nv);
+    }
+    check(rtoc_upload(ctx_, RTOC_BUF_KKT, 0, buf.data(), buf.size()), "rtoc_upload");
+    check(rtoc_clear_status(ctx_), "rtoc_clear_status");
+    check(rtoc_unconstr_backward(ctx_, dt_), "rtoc_unconstr_backward");
+    std::vector<double> rb(static_cast<size_t>(n) * L_.ric.stride);
+    check(rtoc_download(ctx_, RTOC_BUF_RIC, 0, rb.data(), rb.size()), "rtoc_download");
+    const int* ro = L_.ric.off;
+    for (int i = 0; i < n; ++i) {
+      const double* rec = &rb[static_cast<size_t>(i) * L_.ric.stride];
+      std::memcpy(factorization[i].P.data(), rec + ro[RTOC_RIC_P], sizeof(double) * nx * nx);
+      std::memcpy(factorization[i].s.data(), rec + ro[RTOC_RIC_S], sizeof(double) * nx);
+      if (i < N_) {
+        std::memcpy(lqr_policy_[i].Kt.data(), rec + ro[RTOC_RIC_K], sizeof(double) * nx * nv);
+        std::memcpy(lqr_policy_[i].k.data(), rec + ro[RTOC_RIC_KV], sizeof(double) * nv);
+      }
+    }
+  }
+
+  // d[0].dx must hold the initial state direction; on return d[i].du holds the acceleration
+  // direction da of stage i (the Riccati control of this solver), d[i].dlmdgmm the costate direction
+  void forwardRiccatiRecursion(const KKTResidual&, const UnconstrRiccatiFactorization&, Direction& d) const {
+    const int n = N_ + 1, nv = robot_.dimv, nx = 2 * nv;
+    if (static_cast<int>(d.size()) < n) throw std::invalid_argument("[UnconstrRiccatiRecursion] direction too short");
+    check(rtoc_upload(ctx_, RTOC_BUF_DX0, 0, d[0].dx.data(), nx), "rtoc_upload");
+    check(rtoc_unconstr_forward(ctx_, dt_), "rtoc_unconstr_forward");
+    std::vector<double> db(static_cast<size_t>(n) * L_.dir.stride);
+    check(rtoc_download(ctx_, RTOC_BUF_DIR, 0, db.data(), db.size()), "rtoc_download");
+    for (int i = 0; i < n; ++i) {
+      const double* r = &db[static_cast<size_t>(i) * L_.dir.stride];
+      std::memcpy(d[i].dx.data(), r + L_.dir.off[RTOC_DIR_DX], sizeof(double) * nx);
+      std::memcpy(d[i].du.data(), r + L_.dir.off[RTOC_DIR_DU], sizeof(double) * nv);
+      std::memcpy(d[i].dlmdgmm.data(), r + L_.dir.off[RTOC_DIR_DLMDGMM], sizeof(double) * nx);
+    }
+  }
+
+  const std::vector<LQRPolicy>& getLQRPolicy() const { return lqr_policy_; }
+
+  unsigned status() const {
+    uint32_t s = 0;
+    check(rtoc_status(ctx_, &s, 1), "rtoc_status");
+    return s;
+  }
+
+ private:
+  static void check(int rc, const char* what) {
+    if (rc != RTOC_OK)
+      throw std::runtime_error(std::string("[UnconstrRiccatiRecursion] ") + what + ": " + rtoc_error_string(rc));
+  }
+  RobotDims robot_;
+  int N_;
+  double dt_;
   std::vector<LQRPolicy> lqr_policy_;
   rtoc_ctx* ctx_;
   rtoc_layout L_;
