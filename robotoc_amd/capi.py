@@ -34,7 +34,9 @@ class RtocError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, "librtoc_hip.so")
+    # RTOC_HIP_LIB: an alternative build of the same library, e.g. the one with the phase stamps compiled
+    # in (make -C robotoc_amd/csrc PROF=1 OUT=../librtoc_hip_prof.so) for tools/phase_profile*.py
+    return os.environ.get("RTOC_HIP_LIB") or os.path.join(_HERE, "librtoc_hip.so")
 
 
 def build(force=False):

@@ -430,15 +430,29 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
     RTOC_PROF(2);
     // ---- z = s+ - P+ Fx ;  y = P+ fx + Psi+ (STO) ----
     if (tid < NX) {
-      double acc = 0.0, accy = 0.0;
-#pragma unroll
-      for (int k = 0; k < NX; ++k) {
-        const double p = sP[tid + k * LDP];
-        acc += p * smem[C::V_FX + k];
-        if (sto) accy += p * smem[C::V_FFX + k];
+      // four accumulators, uniform STO test hoisted out of the loop: a single dependent chain with a
+      // branch per iteration cost ~8k cycles at nx = 64
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+      static_assert(NX % 4 == 0 || NX % 2 == 0, "state dimension is even");
+#pragma unroll 2  // partial: full unrolling hoists all 2*NX loads (register explosion at nx = 64, 70)
+      for (int k = 0; k + 3 < NX; k += 4) {
+        a0 += sP[tid + k * LDP] * smem[C::V_FX + k];
+        a1 += sP[tid + (k + 1) * LDP] * smem[C::V_FX + k + 1];
+        a2 += sP[tid + (k + 2) * LDP] * smem[C::V_FX + k + 2];
+        a3 += sP[tid + (k + 3) * LDP] * smem[C::V_FX + k + 3];
       }
-      smem[C::V_Z + tid] = smem[C::V_SN + tid] - acc;
-      if (sto) smem[C::V_Y + tid] = accy + smem[C::V_PSIN + tid];
+#pragma unroll
+      for (int k = NX - NX % 4; k < NX; ++k) a0 += sP[tid + k * LDP] * smem[C::V_FX + k];
+      smem[C::V_Z + tid] = smem[C::V_SN + tid] - ((a0 + a1) + (a2 + a3));
+      if (sto) {
+        double y0 = 0.0, y1 = 0.0;
+#pragma unroll 4
+        for (int k = 0; k + 1 < NX; k += 2) {
+          y0 += sP[tid + k * LDP] * smem[C::V_FFX + k];
+          y1 += sP[tid + (k + 1) * LDP] * smem[C::V_FFX + k + 1];
+        }
+        smem[C::V_Y + tid] = (y0 + y1) + smem[C::V_PSIN + tid];
+      }
     }
 
     if (!impact) {
@@ -519,13 +533,22 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
       }
       if (tid < NU) {
         double acc = 0.0, ap = 0.0, aph = 0.0;
+        {
+          double b0 = 0.0, b1 = 0.0;
 #pragma unroll
-        for (int k = 0; k < NV; ++k) {
-          const double bv = sBv[k + tid * NV];
-          acc += bv * smem[C::V_Z + NV + k];
-          if (sto) {
+          for (int k = 0; k + 1 < NV; k += 2) {
+            b0 += sBv[k + tid * NV] * smem[C::V_Z + NV + k];
+            b1 += sBv[k + 1 + tid * NV] * smem[C::V_Z + NV + k + 1];
+          }
+          if (NV & 1) b0 += sBv[NV - 1 + tid * NV] * smem[C::V_Z + 2 * NV - 1];
+          acc = b0 + b1;
+        }
+        if (sto) {
+#pragma unroll
+          for (int k = 0; k < NV; ++k) {
+            const double bv = sBv[k + tid * NV];
             ap += bv * smem[C::V_Y + NV + k];
-            if (sto_next) aph += bv * smem[C::V_PHIN + NV + k];
+            aph += bv * (sto_next ? smem[C::V_PHIN + NV + k] : 0.0);
           }
         }
         smem[C::V_LU + tid] -= acc;
@@ -603,12 +626,32 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
     // ---- s-vector part that needs A: w = A^T z  (and STO: psi_x, phi_x) ----
     if (tid < NX) {
       double acc = 0.0, ap = 0.0, aph = 0.0;
-#pragma unroll
-      for (int k = 0; k < NX; ++k) {
-        const double av = sA[k + tid * LDP];
-        acc += av * smem[C::V_Z + k];
-        if (sto) {
-          if (!impact) ap += av * smem[C::V_Y + k];
+      {
+        typedef double dbl2 __attribute__((ext_vector_type(2)));
+        static_assert((LDP & 1) == 0 && (C::OFF_A & 1) == 0 && (C::V_Z & 1) == 0 && (NX & 1) == 0, "128-bit LDS reads");
+        const dbl2* pa2 = reinterpret_cast<const dbl2*>(sA + tid * LDP);
+        const dbl2* pz2 = reinterpret_cast<const dbl2*>(smem + C::V_Z);
+        double w0 = 0.0, w1 = 0.0, w2 = 0.0, w3 = 0.0;
+#pragma unroll 2
+        for (int k2 = 0; k2 + 1 < NX / 2; k2 += 2) {
+          const dbl2 av0 = pa2[k2], zv0 = pz2[k2], av1 = pa2[k2 + 1], zv1 = pz2[k2 + 1];
+          w0 += av0.x * zv0.x;
+          w1 += av0.y * zv0.y;
+          w2 += av1.x * zv1.x;
+          w3 += av1.y * zv1.y;
+        }
+        if ((NX / 2) & 1) {
+          const dbl2 av0 = pa2[NX / 2 - 1], zv0 = pz2[NX / 2 - 1];
+          w0 += av0.x * zv0.x;
+          w1 += av0.y * zv0.y;
+        }
+        acc = (w0 + w1) + (w2 + w3);
+      }
+      if (sto) {
+#pragma unroll 4
+        for (int k = 0; k < NX; ++k) {
+          const double av = sA[k + tid * LDP];
+          ap += av * (impact ? 0.0 : smem[C::V_Y + k]);
           aph += av * smem[C::V_PHIN + k];
         }
       }
