@@ -495,41 +495,28 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
         }
       }
       __syncthreads();
-      // ---- G = Quu + Bv^T PB[v,:] (wave 0) ; lu' = lu - Bv^T z[v] ----
-      if (wave == 0) {
-        d4 acc[TNU][TNU];
+      // ---- G = Quu + Bv^T PB[v,:] (its TNU x TNU tiles dealt to the waves) ; lu' = lu - Bv^T z[v] ----
+      {
+        const double* pa_ = sBv + q + li * NV;        // Bv^T[u][k] = Bv[k][u]
+        const double* pb_ = sPB + NV + q + li * LDP;  // PB[NV+k][u]
 #pragma unroll
-        for (int t0 = 0; t0 < TNU; ++t0)
+        for (int t = 0; t < TNU * TNU; ++t) {
+          if ((t % NW) != wave) continue;  // wave-uniform
+          const int t0 = t / TNU, t1 = t % TNU;
+          d4 acc = zero4();
 #pragma unroll
-          for (int t1 = 0; t1 < TNU; ++t1) acc[t0][t1] = zero4();
-        const double* pa_ = sBv + q + li * NV;             // Bv^T[u][k] = Bv[k][u]
-        const double* pb_ = sPB + NV + q + li * LDP;       // PB[NV+k][u]
-#pragma unroll
-        for (int ks = 0; ks < (NV + 3) / 4; ++ks) {
-          const bool kok = (ks * 4 + 3 < NV) || (ks * 4 + q < NV);
-          double av[TNU], bv[TNU];
-#pragma unroll
-          for (int t = 0; t < TNU; ++t) {
-            const bool ok = kok && (t * 16 + li < NU);
-            const double va = pa_[ks * 4 + t * 16 * NV];
-            const double vb = pb_[ks * 4 + t * 16 * LDP];
-            av[t] = ok ? va : 0.0;
-            bv[t] = ok ? vb : 0.0;
+          for (int ks = 0; ks < (NV + 3) / 4; ++ks) {
+            const bool kok = (ks * 4 + 3 < NV) || (ks * 4 + q < NV);
+            const double va = pa_[ks * 4 + t0 * 16 * NV];
+            const double vb = pb_[ks * 4 + t1 * 16 * LDP];
+            acc = mfma16((kok && t0 * 16 + li < NU) ? va : 0.0, (kok && t1 * 16 + li < NU) ? vb : 0.0, acc);
           }
 #pragma unroll
-          for (int t0 = 0; t0 < TNU; ++t0)
-#pragma unroll
-            for (int t1 = 0; t1 < TNU; ++t1) acc[t0][t1] = mfma16(av[t0], bv[t1], acc[t0][t1]);
+          for (int r = 0; r < 4; ++r) {
+            const int u0 = t0 * 16 + drow(q, r), u1 = t1 * 16 + li;
+            if (u0 < NU && u1 < NU) sG[u0 + u1 * NU] += acc[r];
+          }
         }
-#pragma unroll
-        for (int t0 = 0; t0 < TNU; ++t0)
-#pragma unroll
-          for (int t1 = 0; t1 < TNU; ++t1)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int u0 = t0 * 16 + drow(q, r), u1 = t1 * 16 + li;
-              if (u0 < NU && u1 < NU) sG[u0 + u1 * NU] += acc[t0][t1][r];
-            }
       }
       if (tid < NU) {
         double acc = 0.0, ap = 0.0, aph = 0.0;
