@@ -87,7 +87,8 @@ enum rtoc_buffer {
   RTOC_BUF_SE3 = 7,  /* [batch][stages][RTOC_SE3_STRIDE] floating base: Fqq_inv, Fqq_prev_inv of
                       * StateEquationData (include/robotoc/dynamics/state_equation_data.hpp), 6x6 column-major each */
   RTOC_BUF_CONE = 8, /* [batch][stages][rtoc_cone_stride(nv, max_contacts)] friction-cone Jacobians of the
-                      * active contacts (rtoc_layout.h); exists after rtoc_set_friction_cones */
+                      * active contacts (rtoc_layout.h); exists after rtoc_set_friction_cones.  With
+                      * rtoc_set_wrench_cones: [batch][stages][rtoc_wrench_cone_stride(max_contacts)] */
   RTOC_BUF_SOL = 9,  /* [batch][stages][sol.stride]  SplitSolution (rtoc_integrate_solution) */
   RTOC_NUM_BUFFERS = 10
 };
@@ -150,6 +151,18 @@ int rtoc_set_constraint_rows(rtoc_ctx* ctx, const rtoc_box_row* rows, int nrows)
  * acts on the first 3 force components).  max_contacts = 0 switches them off.  Once set,
  * rtoc_condense / rtoc_expand / rtoc_update include these rows. */
 int rtoc_set_friction_cones(rtoc_ctx* ctx, int max_contacts, int contact_dim);
+
+/* Contact wrench cones of surface contacts (ContactWrenchCone, src/constraints/contact_wrench_cone.cpp:
+ * condenseSlackAndDual :209-238, expandSlackAndDual :241-270): 17 PDIPM rows per active surface contact
+ * acting on its 6-d wrench only, g = cone * f.  The 17 x 6 cone matrices are handed over in the
+ * RTOC_BUF_CONE record (rtoc_layout.h; rtoc_wrench_cone_matrix fills one), the rows' ConstraintComponentData
+ * are the last 17*max_contacts rows of the RTOC_BUF_CON record (row nc_max - 17*max_contacts + 17k + j for
+ * the k-th ACTIVE contact), nrows + 17*max_contacts <= dims.nc_max, 6*max_contacts <= dims.nf_max.
+ * A context carries either friction or wrench cones: setting one kind switches the other off. */
+int rtoc_set_wrench_cones(rtoc_ctx* ctx, int max_contacts);
+/* computeCone (contact_wrench_cone.cpp:282-303): the cone matrix of a rectangular sole 2X x 2Y with
+ * friction coefficient mu; out: 17 x 6 column-major (ld 17).  Host helper, no device work. */
+int rtoc_wrench_cone_matrix(double X, double Y, double mu, double* out);
 
 /* ---- the hot path ---------------------------------------------------------- */
 int rtoc_condense(rtoc_ctx* ctx);
@@ -224,7 +237,7 @@ typedef struct rtoc_dump_header {
   unsigned int version;      /* 1 */
   unsigned int header_bytes; /* sizeof(rtoc_dump_header) */
   rtoc_dims dims;
-  int nstages, batch, nrows, cone_contacts, cone_dim, reserved[3];
+  int nstages, batch, nrows, cone_contacts, cone_dim, cone_rows /* 0|5 friction, 17 wrench */, reserved[2];
   unsigned long long count[16]; /* doubles stored per RTOC_BUF_* (0: absent) */
 } rtoc_dump_header;
 /* buffer_mask: bit b set = store RTOC_BUF_b if it exists. */

@@ -224,6 +224,16 @@ static inline RTOC_HD RTOC_CONSTEXPR int rtoc_cone_stride(int nv, int max_contac
   return rtoc_cone_dgdf_off(nv, max_contacts) + ((max_contacts * 15 + 7) & ~7);
 }
 
+/* ---- RTOC_BUF_CONE record when WRENCH cones are set (rtoc_set_wrench_cones): per ACTIVE surface
+ *      contact k of the grid point (compacted) the 17 x 6 cone matrix of ContactWrenchCone
+ *      (ConstraintComponentData::J[i], contact_wrench_cone.cpp:70-78,282-313) at k*102, column-major
+ *      with leading dimension 17 ---- */
+#define RTOC_WRENCH_ROWS 17
+#define RTOC_FRICTION_ROWS 5
+static inline RTOC_HD RTOC_CONSTEXPR int rtoc_wrench_cone_stride(int max_contacts) {
+  return (max_contacts * RTOC_WRENCH_ROWS * 6 + 7) & ~7;
+}
+
 typedef struct rtoc_record_layout {
   int off[24]; /* field offsets in doubles (indexed by the enums above) */
   int stride;  /* record size in doubles                                */

@@ -71,8 +71,13 @@ def lib():
         _LIB.orc_cone_batch.argtypes = [C.POINTER(Layout), C.POINTER(Grid), C.c_int, C.c_int, C.c_int, C.c_int,
                                         dp, dp, dp, dp, dp, C.c_double, dp, C.c_int]
         _LIB.orc_kkt_error.argtypes = [C.POINTER(Layout), C.POINTER(Grid), C.c_int, dp, dp, dp, C.POINTER(BoxRow),
-                                       C.c_int, C.c_int, C.c_int]
+                                       C.c_int, C.c_int, C.c_int, C.c_int]
         _LIB.orc_kkt_error.restype = C.c_double
+        _LIB.orc_wrench_cone_matrix.argtypes = [C.c_double, C.c_double, C.c_double, dp]
+        _LIB.orc_wrench_cone_matrix.restype = None
+        _LIB.orc_wrench_batch.argtypes = [C.POINTER(Layout), C.POINTER(Grid), C.c_int, C.c_int, C.c_int, dp, dp, dp,
+                                          dp, C.c_double, dp, C.c_int]
+        _LIB.orc_wrench_batch.restype = None
         _LIB.orc_integrate_solution_batch.argtypes = [C.POINTER(Layout), C.POINTER(Grid), C.c_int, C.c_int, dp, dp, dp]
     return _LIB
 
@@ -238,14 +243,42 @@ def cone_update_batch(L, grids, max_contacts, contact_dim, con, steps):
                          None, None, None, _p(con), None, 0.0, _p(steps), 2)
 
 
-def kkt_error(L, grids, kkt, cdd=None, con=None, rows=(), cone_contacts=0, cone_dim=3):
+def wrench_cone_matrix(X, Y, mu):
+    """ContactWrenchCone::computeCone (contact_wrench_cone.cpp:282-303) -> 17 x 6 array."""
+    out = np.zeros(102)
+    lib().orc_wrench_cone_matrix(X, Y, mu, _p(out))
+    return out.reshape(6, 17).T.copy()
+
+
+def wrench_condense_batch(L, grids, max_contacts, cone, cdd, con):
+    """ContactWrenchCone::condenseSlackAndDual on every non-terminal grid point (:209-238)."""
+    _wrench(L, grids, cdd.shape[0], max_contacts, cone, cdd, con, None, 0.0, None, 0)
+
+
+def wrench_expand_batch(L, grids, max_contacts, cone, con, dirs, tau, steps):
+    """ContactWrenchCone::expandSlackAndDual + step sizes; `steps` [batch,2] is min-reduced in place."""
+    _wrench(L, grids, con.shape[0], max_contacts, cone, None, con, dirs, tau, steps, 1)
+
+
+def wrench_update_batch(L, grids, max_contacts, con, steps):
+    _wrench(L, grids, con.shape[0], max_contacts, None, None, con, None, 0.0,
+            np.ascontiguousarray(steps, dtype=np.float64), 2)
+
+
+def _wrench(L, grids, batch, max_contacts, cone, cdd, con, dirs, tau, steps, phase):
+    opt = lambda a: _p(a) if a is not None else None
+    lib().orc_wrench_batch(C.byref(L), grid_array(grids), len(grids), batch, max_contacts, opt(cone), opt(cdd),
+                           opt(con), opt(dirs), tau, opt(steps), phase)
+
+
+def kkt_error(L, grids, kkt, cdd=None, con=None, rows=(), cone_contacts=0, cone_dim=3, cone_rows=5):
     """OCPSolver::KKTError() (without the STO term) of every instance, pre-condensation records."""
     out = np.zeros(kkt.shape[0])
     for b in range(kkt.shape[0]):
         out[b] = lib().orc_kkt_error(C.byref(L), grid_array(grids), len(grids), _p(kkt[b]),
                                      _p(cdd[b]) if cdd is not None else None,
                                      _p(con[b]) if con is not None else None, _rows(rows), len(rows),
-                                     cone_contacts, cone_dim)
+                                     cone_contacts, cone_dim, cone_rows)
     return out
 
 

@@ -773,6 +773,120 @@ void orc_cone_batch(const rtoc_layout* L, const rtoc_grid* grid, int nstages, in
 }
 
 /* ======================================================================================
+ * Contact-wrench-cone PDIPM rows (src/constraints/contact_wrench_cone.cpp): g = cone f on the 6-d
+ * wrench of every active surface contact, 17 rows each.  cone record: 17 x 6 per active contact
+ * (ld 17) at k*102; constraint rows row0 + 17k + j, row0 = nc_max - 17*max_contacts.
+ * ====================================================================================== */
+/* computeCone (:282-303), written out row by row */
+void orc_wrench_cone_matrix(double X, double Y, double mu, double* out) {
+  const double c = (X + Y) * mu;
+  const double rows[17][6] = {
+      {0, 0, -1, 0, 0, 0},        {-1, 0, -mu, 0, 0, 0},      {1, 0, -mu, 0, 0, 0},       {0, -1, -mu, 0, 0, 0},
+      {0, 1, -mu, 0, 0, 0},       {0, 0, -Y, -1, 0, 0},       {0, 0, -Y, 1, 0, 0},        {0, 0, -X, 0, -1, 0},
+      {0, 0, -X, 0, 1, 0},        {-Y, -X, -c, mu, mu, -1},   {-Y, X, -c, mu, -mu, -1},   {Y, -X, -c, -mu, mu, -1},
+      {Y, X, -c, -mu, -mu, -1},   {Y, X, -c, mu, mu, 1},      {Y, -X, -c, mu, -mu, 1},    {-Y, X, -c, -mu, mu, 1},
+      {-Y, -X, -c, -mu, -mu, 1}};
+  for (int j = 0; j < 17; ++j)
+    for (int m = 0; m < 6; ++m) out[j + 17 * m] = rows[j][m];
+}
+
+/* condenseSlackAndDual (:209-238) */
+void orc_wrench_condense_stage(const rtoc_layout* L, const rtoc_grid* g, int max_contacts, const double* cone_rec,
+                               double* cdd_rec, double* con_rec) {
+  if (g->type == RTOC_GRID_TERMINAL) return;
+  const int nfp = L->dims.nf_max > 0 ? L->dims.nf_max : 1;
+  const int nact = g->dimf / 6, row0 = L->dims.nc_max - 17 * max_contacts;
+  const int* o = L->con.off;
+  double* Qff = cdd_rec + L->cdd.off[RTOC_CDD_QFF];
+  double* lf = cdd_rec + L->cdd.off[RTOC_CDD_LF];
+  for (int r = row0; r < row0 + 17 * max_contacts; ++r) con_rec[o[RTOC_CON_COND] + r] = 0.0; /* (:213) */
+  for (int k = 0; k < nact; ++k) {
+    const double* J = cone_rec + (size_t)k * 102;
+    const int r0 = row0 + 17 * k, stack = 6 * k;
+    double cond[17], rr[17];
+    for (int j = 0; j < 17; ++j) {
+      const double slack = con_rec[o[RTOC_CON_SLACK] + r0 + j], dual = con_rec[o[RTOC_CON_DUAL] + r0 + j];
+      rr[j] = dual / slack; /* (:224-225) */
+      cond[j] = (dual * con_rec[o[RTOC_CON_RESIDUAL] + r0 + j] - con_rec[o[RTOC_CON_CMPL] + r0 + j]) / slack;
+      con_rec[o[RTOC_CON_COND] + r0 + j] = cond[j]; /* (:228) */
+    }
+    for (int n = 0; n < 6; ++n)
+      for (int m = 0; m < 6; ++m) { /* Qff block += cone^T diag(r) cone (:226-227) */
+        double acc = 0.0;
+        for (int j = 0; j < 17; ++j) acc += J[j + 17 * m] * (rr[j] * J[j + 17 * n]);
+        Qff[(stack + m) + (size_t)(stack + n) * nfp] += acc;
+      }
+    for (int m = 0; m < 6; ++m) { /* lf += cone^T cond (:229-230) */
+      double acc = 0.0;
+      for (int j = 0; j < 17; ++j) acc += J[j + 17 * m] * cond[j];
+      lf[stack + m] += acc;
+    }
+  }
+}
+
+/* expandSlackAndDual (:241-270) + maxSlackStepSize / maxDualStepSize; steps min-reduced in place */
+void orc_wrench_expand_stage(const rtoc_layout* L, const rtoc_grid* g, int max_contacts, const double* cone_rec,
+                             const double* dir_rec, double* con_rec, double tau, double* steps) {
+  if (g->type == RTOC_GRID_TERMINAL) return;
+  const int nact = g->dimf / 6, row0 = L->dims.nc_max - 17 * max_contacts;
+  if (nact == 0) return; /* the GPU path skips grid points without active contacts */
+  const int* o = L->con.off;
+  const double* dfv = dir_rec + L->dir.off[RTOC_DIR_DAF] + L->dims.nv;
+  for (int r = row0; r < row0 + 17 * max_contacts; ++r) { /* (:247-248) */
+    con_rec[o[RTOC_CON_DSLACK] + r] = 1.0;
+    con_rec[o[RTOC_CON_DDUAL] + r] = 1.0;
+  }
+  for (int k = 0; k < nact; ++k) {
+    const double* J = cone_rec + (size_t)k * 102;
+    for (int j = 0; j < 17; ++j) {
+      const int r = row0 + 17 * k + j;
+      double acc = 0.0;
+      for (int m = 0; m < 6; ++m) acc += J[j + 17 * m] * dfv[6 * k + m];
+      const double slack = con_rec[o[RTOC_CON_SLACK] + r], dual = con_rec[o[RTOC_CON_DUAL] + r];
+      const double dslack = -acc - con_rec[o[RTOC_CON_RESIDUAL] + r]; /* (:260-262) */
+      const double ddual = -(dual * dslack + con_rec[o[RTOC_CON_CMPL] + r]) / slack;
+      con_rec[o[RTOC_CON_DSLACK] + r] = dslack;
+      con_rec[o[RTOC_CON_DDUAL] + r] = ddual;
+      const double fs = -tau * (slack / dslack), fd = -tau * (dual / ddual);
+      if (fs > 0 && fs < 1 && fs < steps[0]) steps[0] = fs;
+      if (fd > 0 && fd < 1 && fd < steps[1]) steps[1] = fd;
+    }
+  }
+}
+
+void orc_wrench_update_stage(const rtoc_layout* L, const rtoc_grid* g, int max_contacts, double* con_rec,
+                             double primal_step, double dual_step) {
+  if (g->type == RTOC_GRID_TERMINAL) return;
+  const int nact = g->dimf / 6, row0 = L->dims.nc_max - 17 * max_contacts;
+  const int* o = L->con.off;
+  for (int r = row0; r < row0 + 17 * nact; ++r) {
+    con_rec[o[RTOC_CON_SLACK] + r] += primal_step * con_rec[o[RTOC_CON_DSLACK] + r];
+    con_rec[o[RTOC_CON_DUAL] + r] += dual_step * con_rec[o[RTOC_CON_DDUAL] + r];
+  }
+}
+
+/* phase 0 condense, 1 expand (steps min-reduced, NOT reset here), 2 update */
+void orc_wrench_batch(const rtoc_layout* L, const rtoc_grid* grid, int nstages, int batch, int max_contacts,
+                      const double* cone, double* cdd, double* con, const double* dir, double tau, double* steps,
+                      int phase) {
+  const size_t cs = (size_t)rtoc_wrench_cone_stride(max_contacts);
+#pragma omp parallel for schedule(static)
+  for (int b = 0; b < batch; ++b)
+    for (int i = 0; i < nstages - 1; ++i) {
+      const size_t rec = (size_t)b * nstages + i;
+      if (phase == 0)
+        orc_wrench_condense_stage(L, &grid[i], max_contacts, cone + rec * cs, cdd + rec * L->cdd.stride,
+                                  con + rec * L->con.stride);
+      else if (phase == 1)
+        orc_wrench_expand_stage(L, &grid[i], max_contacts, cone + rec * cs, dir + rec * L->dir.stride,
+                                con + rec * L->con.stride, tau, steps + 2 * b);
+      else
+        orc_wrench_update_stage(L, &grid[i], max_contacts, con + rec * L->con.stride, steps[2 * b],
+                                steps[2 * b + 1]);
+    }
+}
+
+/* ======================================================================================
  * KKT error of one instance (src/ocp/intermediate_stage.cpp:132, impact_stage.cpp, terminal_stage.cpp;
  * SplitKKTResidual::KKTError split_kkt_residual.hxx:90-104; ContactDynamicsData::KKTError
  * contact_dynamics_data.hpp:204-206; ConstraintComponentData::KKTError constraint_component_data.hpp:122-124;
@@ -787,7 +901,7 @@ static double sqn(const double* p, int n) {
 
 double orc_kkt_error(const rtoc_layout* L, const rtoc_grid* grid, int nstages, const double* kkt,
                      const double* cdd, const double* con, const rtoc_box_row* rows, int nrows,
-                     int cone_contacts, int cone_dim) {
+                     int cone_contacts, int cone_dim, int cone_rows) {
   const int nv = L->dims.nv, nu = L->dims.nu, np = L->dims.np, nx = L->nx;
   double err = 0.0;
   for (int i = 0; i < nstages; ++i) {
@@ -817,7 +931,7 @@ double orc_kkt_error(const rtoc_layout* L, const rtoc_grid* grid, int nstages, c
           err += x * x + y * y;
         }
       if (cone_contacts > 0) {
-        const int row0 = L->dims.nc_max - 5 * cone_contacts, n = 5 * (g->dimf / cone_dim);
+        const int row0 = L->dims.nc_max - cone_rows * cone_contacts, n = cone_rows * (g->dimf / cone_dim);
         for (int r = row0; r < row0 + n; ++r) {
           const double x = nr[o[RTOC_CON_RESIDUAL] + r], y = nr[o[RTOC_CON_CMPL] + r];
           err += x * x + y * y;

@@ -25,7 +25,7 @@ EXPORTS = [
     "rtoc_sync", "rtoc_time_phase", "rtoc_set_constraint_rows", "rtoc_gather_directions", "rtoc_error_string",
     "rtoc_riccati_sweep", "rtoc_correct_state_equation", "rtoc_correct_costate_direction",
     "rtoc_compute_initial_state_direction", "rtoc_unconstr_condense", "rtoc_unconstr_expand",
-    "rtoc_set_friction_cones", "rtoc_save_stage_dump", "rtoc_load_stage_dump", "rtoc_kkt_error", "rtoc_integrate_solution",
+    "rtoc_set_friction_cones", "rtoc_set_wrench_cones", "rtoc_wrench_cone_matrix", "rtoc_save_stage_dump", "rtoc_load_stage_dump", "rtoc_kkt_error", "rtoc_integrate_solution",
 ]
 
 
@@ -92,6 +92,8 @@ def lib():
         L.rtoc_gather_directions.argtypes = [vp, vp, dp]
         L.rtoc_set_constraint_rows.argtypes = [vp, C.POINTER(BoxRow), C.c_int]
         L.rtoc_set_friction_cones.argtypes = [vp, C.c_int, C.c_int]
+        L.rtoc_set_wrench_cones.argtypes = [vp, C.c_int]
+        L.rtoc_wrench_cone_matrix.argtypes = [C.c_double, C.c_double, C.c_double, C.POINTER(C.c_double)]
         L.rtoc_save_stage_dump.argtypes = [vp, C.c_char_p, C.c_uint]
         L.rtoc_kkt_error.argtypes = [vp, dp, C.c_int]
         L.rtoc_load_stage_dump.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
@@ -247,6 +249,10 @@ class Context:
     def set_friction_cones(self, max_contacts, contact_dim=3):
         _chk(lib().rtoc_set_friction_cones(self._h, int(max_contacts), int(contact_dim)))
 
+    def set_wrench_cones(self, max_contacts):
+        """ContactWrenchCone rows (17 per active surface contact); replaces friction cones if set."""
+        _chk(lib().rtoc_set_wrench_cones(self._h, int(max_contacts)))
+
     def unconstr_condense(self):
         _chk(lib().rtoc_unconstr_condense(self._h))
 
@@ -302,3 +308,10 @@ def debug_profile(ctx):
     out = np.zeros((ctx.max_stages, 32), dtype=np.int64)
     _chk(L.rtoc_debug_profile(ctx._h, out.ctypes.data_as(C.c_void_p)))
     return out
+
+
+def wrench_cone_matrix(X, Y, mu):
+    """rtoc_wrench_cone_matrix -> 17 x 6 array (ContactWrenchCone::computeCone)."""
+    out = np.zeros(102)
+    _chk(lib().rtoc_wrench_cone_matrix(X, Y, mu, _dp(out)))
+    return out.reshape(6, 17).T.copy()

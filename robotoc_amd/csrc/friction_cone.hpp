@@ -27,7 +27,7 @@ struct ConeArgs {
   const rtoc_grid* grid;
   unsigned long long* steps;  // [batch][2] bit patterns (expand) / doubles (update)
   int nstages, batch;
-  int max_contacts, contact_dim, row0;
+  int max_contacts, contact_dim, row0, rows_per_contact;
   int cone_stride, dgdf_off;
   double tau;
   rtoc_record_layout kl, cl, nl, dl;
@@ -187,12 +187,108 @@ __global__ __launch_bounds__(64) void cone_update_kernel(ConeArgs a) {
   const int b = item / nst1, st = item % nst1;
   if (b >= a.batch) return;
   const int nact = a.grid[st].dimf / a.contact_dim;
-  if (lane >= 5 * nact) return;
+  if (lane >= a.rows_per_contact * nact) return;  // <= 5*4 friction rows, <= 17*2 wrench rows
   double* nr = a.con + ((size_t)b * a.nstages + st) * a.nl.stride;
   const double* steps = reinterpret_cast<const double*>(a.steps);
   const int r = a.row0 + lane;
   nr[a.nl.off[RTOC_CON_SLACK] + r] += steps[2 * b] * nr[a.nl.off[RTOC_CON_DSLACK] + r];
   nr[a.nl.off[RTOC_CON_DUAL] + r] += steps[2 * b + 1] * nr[a.nl.off[RTOC_CON_DDUAL] + r];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Contact wrench cones (ContactWrenchCone, reference src/constraints/contact_wrench_cone.cpp): 17 rows
+// per active surface contact, g = cone * f with the 17 x 6 cone matrix of the RTOC_BUF_CONE record
+// (wrench layout, rtoc_layout.h).  Only Qff and lf are touched (:209-238); at most 3 contacts
+// (51 rows) fit the one wave that serves a grid point.
+// ---------------------------------------------------------------------------------------------
+template <int NV, int NF>
+__global__ __launch_bounds__(64) void wrench_condense_kernel(ConeArgs a) {
+  constexpr int NFP = NF > 0 ? NF : 1, MAXC = NF / 6 > 0 ? NF / 6 : 1, WR = RTOC_WRENCH_ROWS;
+  static_assert(MAXC * WR <= 64, "one lane per wrench-cone row");
+  const int lane = threadIdx.x;
+  const int item = blockIdx.x;
+  const int nst1 = a.nstages - 1;
+  const int b = item / nst1, st = item % nst1;
+  if (b >= a.batch) return;
+  const int nact = a.grid[st].dimf / 6;
+  if (nact == 0) return;
+  const size_t rec = (size_t)b * a.nstages + st;
+  double* cr = a.cdd + rec * a.cl.stride;
+  double* nr = a.con + rec * a.nl.stride;
+  const double* cone = a.cone + rec * a.cone_stride;
+  double* Qff = cr + a.cl.off[RTOC_CDD_QFF];
+  double* lf = cr + a.cl.off[RTOC_CDD_LF];
+  __shared__ double J[MAXC][WR * 6], cond[MAXC][WR], rr[MAXC][WR];
+  for (int e = lane; e < nact * WR * 6; e += 64) J[e / (WR * 6)][e % (WR * 6)] = cone[e];
+  if (lane < WR * nact) {
+    const int r = a.row0 + lane;
+    const double slack = nr[a.nl.off[RTOC_CON_SLACK] + r], dual = nr[a.nl.off[RTOC_CON_DUAL] + r];
+    const double c = (dual * nr[a.nl.off[RTOC_CON_RESIDUAL] + r] - nr[a.nl.off[RTOC_CON_CMPL] + r]) / slack;
+    nr[a.nl.off[RTOC_CON_COND] + r] = c;       // computeCondensingCoeffcient<17> (:228)
+    cond[lane / WR][lane % WR] = c;
+    rr[lane / WR][lane % WR] = dual / slack;  // (:224-225)
+  }
+  // inactive rows keep cond = 0 like data.cond.setZero() (:213)
+  if (lane >= WR * nact && lane < WR * a.max_contacts) nr[a.nl.off[RTOC_CON_COND] + a.row0 + lane] = 0.0;
+  __syncthreads();
+  for (int e = lane; e < nact * 36; e += 64) {
+    const int kk = e / 36, ww = e % 36, mm = ww % 6, nn = ww / 6, stack = kk * 6;
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < WR; ++j) acc += J[kk][j + WR * mm] * (rr[kk][j] * J[kk][j + WR * nn]);
+    Qff[(stack + mm) + (size_t)(stack + nn) * NFP] += acc;  // (:226-227)
+  }
+  if (lane < 6 * nact) {
+    const int kk = lane / 6, mm = lane % 6;
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < WR; ++j) acc += J[kk][j + WR * mm] * cond[kk][j];
+    lf[kk * 6 + mm] += acc;  // (:229-230)
+  }
+}
+
+// expandSlackAndDual (:241-270) + fraction-to-boundary (pdipm.hxx:121-142)
+template <int NV, int NF>
+__global__ __launch_bounds__(64) void wrench_expand_kernel(ConeArgs a) {
+  constexpr int WR = RTOC_WRENCH_ROWS;
+  const int lane = threadIdx.x;
+  const int item = blockIdx.x;
+  const int nst1 = a.nstages - 1;
+  const int b = item / nst1, st = item % nst1;
+  if (b >= a.batch) return;
+  const int nact = a.grid[st].dimf / 6;
+  if (nact == 0) return;
+  const size_t rec = (size_t)b * a.nstages + st;
+  double* nr = a.con + rec * a.nl.stride;
+  const double* cone = a.cone + rec * a.cone_stride;
+  const double* dfv = a.dir + rec * a.dl.stride + a.dl.off[RTOC_DIR_DAF] + NV;
+  double fp = 1.0, fd = 1.0;
+  if (lane < WR * nact) {
+    const int k = lane / WR, j = lane % WR, r = a.row0 + lane;
+    double acc = 0.0;
+#pragma unroll
+    for (int m = 0; m < 6; ++m) acc += cone[k * WR * 6 + j + WR * m] * dfv[k * 6 + m];
+    const double slack = nr[a.nl.off[RTOC_CON_SLACK] + r], dual = nr[a.nl.off[RTOC_CON_DUAL] + r];
+    const double dslack = -acc - nr[a.nl.off[RTOC_CON_RESIDUAL] + r];  // (:260-262)
+    const double ddual = -(dual * dslack + nr[a.nl.off[RTOC_CON_CMPL] + r]) / slack;
+    nr[a.nl.off[RTOC_CON_DSLACK] + r] = dslack;
+    nr[a.nl.off[RTOC_CON_DDUAL] + r] = ddual;
+    const double fs = -a.tau * (slack / dslack), fdd = -a.tau * (dual / ddual);
+    if (fs > 0.0 && fs < 1.0) fp = fs;
+    if (fdd > 0.0 && fdd < 1.0) fd = fdd;
+  } else if (lane < WR * a.max_contacts) {  // dslack.fill(1), ddual.fill(1) (:247-248)
+    nr[a.nl.off[RTOC_CON_DSLACK] + a.row0 + lane] = 1.0;
+    nr[a.nl.off[RTOC_CON_DDUAL] + a.row0 + lane] = 1.0;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    fp = fmin(fp, __shfl_xor(fp, off, 64));
+    fd = fmin(fd, __shfl_xor(fd, off, 64));
+  }
+  if (lane == 0) {
+    atomicMin(&a.steps[2 * b + 0], (unsigned long long)__double_as_longlong(fp));
+    atomicMin(&a.steps[2 * b + 1], (unsigned long long)__double_as_longlong(fd));
+  }
 }
 
 }  // namespace rtoc

@@ -23,7 +23,7 @@ struct KktErrArgs {
   const rtoc_box_row* rows;
   const rtoc_grid* grid;
   double* out;         // [batch] sqrt of the sum
-  int nstages, batch, nrows, cone_contacts, cone_dim, nc_max;
+  int nstages, batch, nrows, cone_contacts, cone_dim, cone_rows, nc_max;
   int nv, nu, np, nx;
   rtoc_record_layout kl, cl, nl;
 };
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(64) void kkt_error_kernel(KktErrArgs a) {
             acc += x * x + y * y;
           }
       if (a.cone_contacts > 0) {
-        const int row0 = a.nc_max - 5 * a.cone_contacts, n = 5 * (g.dimf / a.cone_dim);
+        const int row0 = a.nc_max - a.cone_rows * a.cone_contacts, n = a.cone_rows * (g.dimf / a.cone_dim);
         for (int r = lane; r < n; r += 64) {
           const double x = nr[a.nl.off[RTOC_CON_RESIDUAL] + row0 + r], y = nr[a.nl.off[RTOC_CON_CMPL] + row0 + r];
           acc += x * x + y * y;

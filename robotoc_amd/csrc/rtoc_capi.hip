@@ -59,6 +59,7 @@ struct KernelSet {
   fill_fn fill;
   ud_fn ucond, uexp;  // UnconstrDynamics condense / expand
   cone_fn ccond, cexp;  // friction-cone rows
+  cone_fn wcond, wexp;  // contact-wrench-cone rows
   cond_fn cond;
   int cond_threads, cond_lds;
   expd_fn expd;
@@ -106,6 +107,8 @@ static KernelSet make_set() {
   k.uexp = unconstr_expand_kernel<NV>;
   k.ccond = cone_condense_kernel<NV, NS>;
   k.cexp = cone_expand_kernel<NV, NS>;
+  k.wcond = wrench_condense_kernel<NV, NS>;
+  k.wexp = wrench_expand_kernel<NV, NS>;
   constexpr int NF = NS;  // nf_max == ns_max for all supported robots
   k.cond = condense_kernel<NV, NU, NF, NS>;
   k.cond_threads = CondCfg<NV, NU, NF, NS>::NT;
@@ -160,7 +163,8 @@ struct rtoc_ctx {
   hipStream_t stream2;  // forward half of the pipelined sweep
   hipEvent_t ev_fork, ev_join, ev_chunk[RTOC_MAX_CHUNK_EVENTS];
   int sweep_chunks;
-  int cone_contacts, cone_dim;  // friction cones: max contacts (0 = off), force components per contact
+  int cone_contacts, cone_dim;  // friction / wrench cones: max contacts (0 = off), force components per contact
+  int cone_rows;                // PDIPM rows per contact: 5 friction cone, 17 contact wrench cone
   double* d_kkterr;             // [batch]
 };
 
@@ -550,8 +554,10 @@ static int launch_cones(rtoc_ctx* c, int phase, double tau) {  // 0 condense, 1 
   a.batch = c->batch;
   a.max_contacts = c->cone_contacts;
   a.contact_dim = c->cone_dim;
-  a.row0 = c->dims.nc_max - 5 * c->cone_contacts;
-  a.cone_stride = rtoc_cone_stride(c->dims.nv, c->cone_contacts);
+  const bool wrench = c->cone_rows == RTOC_WRENCH_ROWS;
+  a.rows_per_contact = c->cone_rows;
+  a.row0 = c->dims.nc_max - c->cone_rows * c->cone_contacts;
+  a.cone_stride = wrench ? rtoc_wrench_cone_stride(c->cone_contacts) : rtoc_cone_stride(c->dims.nv, c->cone_contacts);
   a.dgdf_off = rtoc_cone_dgdf_off(c->dims.nv, c->cone_contacts);
   a.tau = tau;
   a.kl = c->L.kkt;
@@ -560,9 +566,9 @@ static int launch_cones(rtoc_ctx* c, int phase, double tau) {  // 0 condense, 1 
   a.dl = c->L.dir;
   const dim3 grid(c->batch * (c->nstages - 1));
   if (phase == 0)
-    hipLaunchKernelGGL(c->ks->ccond, grid, dim3(64), 0, c->stream, a);
+    hipLaunchKernelGGL(wrench ? c->ks->wcond : c->ks->ccond, grid, dim3(64), 0, c->stream, a);
   else if (phase == 1)
-    hipLaunchKernelGGL(c->ks->cexp, grid, dim3(64), 0, c->stream, a);
+    hipLaunchKernelGGL(wrench ? c->ks->wexp : c->ks->cexp, grid, dim3(64), 0, c->stream, a);
   else
     hipLaunchKernelGGL(cone_update_kernel, grid, dim3(64), 0, c->stream, a);
   HIP_TRY(hipGetLastError());
@@ -727,17 +733,18 @@ int rtoc_update(rtoc_ctx* c) {
   return RTOC_OK;
 }
 
-int rtoc_set_friction_cones(rtoc_ctx* c, int max_contacts, int contact_dim) {
+static int set_cones(rtoc_ctx* c, int max_contacts, int contact_dim, int rows_per_contact, size_t stride) {
   if (!c || max_contacts < 0) return RTOC_ERR_BAD_ARG;
   if (max_contacts == 0) {
     c->cone_contacts = 0;
+    c->cone_rows = 0;
     return RTOC_OK;
   }
   if ((contact_dim != 3 && contact_dim != 6) || max_contacts * contact_dim > c->dims.nf_max ||
-      c->nrows + 5 * max_contacts > c->dims.nc_max)
+      c->nrows + rows_per_contact * max_contacts > c->dims.nc_max || rows_per_contact * max_contacts > 64)
     return RTOC_ERR_BAD_ARG;
   HIP_TRY(hipSetDevice(c->device));
-  const size_t need = (size_t)c->batch * c->max_stages * rtoc_cone_stride(c->dims.nv, max_contacts);
+  const size_t need = (size_t)c->batch * c->max_stages * stride;
   if (c->buf[RTOC_BUF_CONE] && c->count[RTOC_BUF_CONE] != need) {
     if (c->owned[RTOC_BUF_CONE]) (void)hipFree(c->buf[RTOC_BUF_CONE]);
     c->buf[RTOC_BUF_CONE] = nullptr;
@@ -748,11 +755,45 @@ int rtoc_set_friction_cones(rtoc_ctx* c, int max_contacts, int contact_dim) {
   if (rc) return rc;
   c->cone_contacts = max_contacts;
   c->cone_dim = contact_dim;
+  c->cone_rows = rows_per_contact;
+  return RTOC_OK;
+}
+
+int rtoc_set_friction_cones(rtoc_ctx* c, int max_contacts, int contact_dim) {
+  if (!c) return RTOC_ERR_BAD_ARG;
+  return set_cones(c, max_contacts, contact_dim, RTOC_FRICTION_ROWS, rtoc_cone_stride(c->dims.nv, max_contacts));
+}
+
+int rtoc_set_wrench_cones(rtoc_ctx* c, int max_contacts) {
+  if (!c) return RTOC_ERR_BAD_ARG;
+  return set_cones(c, max_contacts, 6, RTOC_WRENCH_ROWS, rtoc_wrench_cone_stride(max_contacts));
+}
+
+int rtoc_wrench_cone_matrix(double X, double Y, double mu, double* out) {
+  if (!out || !(X > 0.0) || !(Y > 0.0) || !(mu > 0.0)) return RTOC_ERR_BAD_ARG;  // ctor checks :19-26
+  // Rows: unilaterality; four friction-pyramid faces; centre of pressure inside the sole (tau_x, tau_y);
+  // eight yaw-torque bounds -- one per sign pattern (sx, sy, sz) of the f_x, f_y and tau_z coefficients.
+  const double xymu = (X + Y) * mu;
+  double row[RTOC_WRENCH_ROWS][6] = {{0, 0, -1, 0, 0, 0},   {-1, 0, -mu, 0, 0, 0}, {1, 0, -mu, 0, 0, 0},
+                                     {0, -1, -mu, 0, 0, 0}, {0, 1, -mu, 0, 0, 0},  {0, 0, -Y, -1, 0, 0},
+                                     {0, 0, -Y, 1, 0, 0},   {0, 0, -X, 0, -1, 0},  {0, 0, -X, 0, 1, 0}};
+  // (sign of Y f_x, sign of X f_y) for rows 9..12; rows 13..16 mirror them with tau_z = +1
+  static const int sg[4][2] = {{-1, -1}, {-1, 1}, {1, -1}, {1, 1}};
+  for (int i = 0; i < 4; ++i) {
+    double* lo = row[9 + i];
+    double* hi = row[13 + i];
+    lo[0] = sg[i][0] * Y;  lo[1] = sg[i][1] * X;  lo[2] = -xymu;
+    lo[3] = -sg[i][0] * mu; lo[4] = -sg[i][1] * mu; lo[5] = -1;
+    hi[0] = -sg[i][0] * Y; hi[1] = -sg[i][1] * X; hi[2] = -xymu;
+    hi[3] = -sg[i][0] * mu; hi[4] = -sg[i][1] * mu; hi[5] = 1;
+  }
+  for (int j = 0; j < RTOC_WRENCH_ROWS; ++j)
+    for (int m = 0; m < 6; ++m) out[j + RTOC_WRENCH_ROWS * m] = row[j][m];
   return RTOC_OK;
 }
 
 int rtoc_set_constraint_rows(rtoc_ctx* c, const rtoc_box_row* rows, int nrows) {
-  if (!c || nrows < 0 || nrows + 5 * c->cone_contacts > c->dims.nc_max || (nrows > 0 && !rows))
+  if (!c || nrows < 0 || nrows + c->cone_rows * c->cone_contacts > c->dims.nc_max || (nrows > 0 && !rows))
     return RTOC_ERR_BAD_ARG;
   for (int r = 0; r < nrows; ++r) {
     const rtoc_box_row& w = rows[r];
@@ -896,6 +937,7 @@ int rtoc_kkt_error(rtoc_ctx* c, double* host_out, int count) {
   a.nrows = c->nrows;
   a.cone_contacts = c->cone_contacts;
   a.cone_dim = c->cone_dim > 0 ? c->cone_dim : 3;
+  a.cone_rows = c->cone_rows;
   a.nc_max = c->dims.nc_max;
   a.nv = c->dims.nv;
   a.nu = c->dims.nu;
@@ -923,7 +965,10 @@ static size_t dump_count(const rtoc_ctx* c, int b) {  // doubles of buffer b the
     case RTOC_BUF_DX0: return (size_t)c->batch * c->L.nx;
     case RTOC_BUF_STEP: return (size_t)c->batch * 2;
     case RTOC_BUF_SE3: return per * RTOC_SE3_STRIDE;
-    case RTOC_BUF_CONE: return c->cone_contacts > 0 ? per * rtoc_cone_stride(c->dims.nv, c->cone_contacts) : 0;
+    case RTOC_BUF_CONE:
+      if (c->cone_contacts <= 0) return 0;
+      return per * (c->cone_rows == RTOC_WRENCH_ROWS ? rtoc_wrench_cone_stride(c->cone_contacts)
+                                                     : rtoc_cone_stride(c->dims.nv, c->cone_contacts));
     case RTOC_BUF_SOL: return per * c->L.sol.stride;
     default: return 0;
   }
@@ -943,6 +988,7 @@ int rtoc_save_stage_dump(rtoc_ctx* c, const char* path, unsigned int mask) {
   h.nrows = c->nrows;
   h.cone_contacts = c->cone_contacts;
   h.cone_dim = c->cone_dim;
+  h.cone_rows = c->cone_contacts > 0 ? c->cone_rows : 0;
   for (int b = 0; b < RTOC_NUM_BUFFERS; ++b)
     if ((mask >> b & 1u) && c->buf[b]) h.count[b] = dump_count(c, b);
   FILE* f = fopen(path, "wb");
@@ -987,7 +1033,9 @@ int rtoc_load_stage_dump(const char* path, int device, rtoc_ctx** out) {
   int rc = rtoc_create(&h.dims, h.nstages, h.batch, device, &c);
   if (!rc) rc = rtoc_set_grid(c, grid.data(), h.nstages);
   if (!rc && h.nrows > 0) rc = rtoc_set_constraint_rows(c, rows.data(), h.nrows);
-  if (!rc && h.cone_contacts > 0) rc = rtoc_set_friction_cones(c, h.cone_contacts, h.cone_dim);
+  if (!rc && h.cone_contacts > 0)
+    rc = h.cone_rows == RTOC_WRENCH_ROWS ? rtoc_set_wrench_cones(c, h.cone_contacts)
+                                         : rtoc_set_friction_cones(c, h.cone_contacts, h.cone_dim);
   std::vector<double> stage;
   for (int b = 0; !rc && b < RTOC_NUM_BUFFERS; ++b) {
     if (!h.count[b]) continue;

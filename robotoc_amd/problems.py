@@ -285,3 +285,16 @@ def make_cone_batch(L, grids, batch, max_contacts, first_instance=0):
                 out[b, i, k * 5 * nv:(k + 1) * 5 * nv] = dq.T.reshape(-1)       # column-major, ld 5
                 out[b, i, off + k * 15:off + (k + 1) * 15] = df.T.reshape(-1)
     return out
+
+
+def make_wrench_cone_batch(L, grids, batch, max_contacts, cones):
+    """RTOC_BUF_CONE record in the wrench layout (include/rtoc_layout.h): the 17 x 6 cone matrix of the
+    k-th ACTIVE surface contact of every grid point at k*102 (column-major, ld 17) -- what
+    ContactWrenchCone::updateCone leaves in ConstraintComponentData::J (contact_wrench_cone.cpp:306-313).
+    cones: one 17 x 6 matrix per contact slot (e.g. capi.wrench_cone_matrix(X, Y, mu))."""
+    from .types import wrench_cone_stride
+    out = np.zeros((batch, len(grids), wrench_cone_stride(max_contacts)))
+    for i, g in enumerate(grids):
+        for k in range(min(g.dimf // 6, max_contacts)):
+            out[:, i, k * 102:(k + 1) * 102] = np.asarray(cones[k]).T.reshape(-1)
+    return out

@@ -17,13 +17,13 @@ _HDR = struct.Struct("<8sII6i8i16Q")  # magic, version, header_bytes, dims, nsta
 assert _HDR.size == 8 + 8 + 24 + 32 + 128
 
 
-def write_dump(path, dims, grids, batch, buffers, rows=(), cone_contacts=0, cone_dim=0):
+def write_dump(path, dims, grids, batch, buffers, rows=(), cone_contacts=0, cone_dim=0, cone_rows=0):
     """buffers: {RTOC_BUF_* index: float64 array of [batch][nstages][stride] (or [batch][n])}."""
     counts = [0] * NUM_SLOTS
     for b, arr in buffers.items():
         counts[b] = int(np.asarray(arr).size)
     hdr = _HDR.pack(MAGIC, 1, _HDR.size, dims.nv, dims.nu, dims.np, dims.nf_max, dims.ns_max, dims.nc_max,
-                    len(grids), batch, len(rows), cone_contacts, cone_dim, 0, 0, 0, *counts)
+                    len(grids), batch, len(rows), cone_contacts, cone_dim, cone_rows, 0, 0, *counts)
     with open(path, "wb") as f:
         f.write(hdr)
         for g in grids:
@@ -35,10 +35,10 @@ def write_dump(path, dims, grids, batch, buffers, rows=(), cone_contacts=0, cone
 
 
 def read_dump(path):
-    """-> dict(dims, grids, batch, rows, cone_contacts, cone_dim, buffers={index: flat float64 array})."""
+    """-> dict(dims, grids, batch, rows, cone_contacts, cone_dim, cone_rows (0|5 friction, 17 wrench), buffers={index: flat float64 array})."""
     with open(path, "rb") as f:
         raw = f.read()
-    (magic, version, hbytes, nv, nu, npas, nf, ns, nc, nstages, batch, nrows, cc, cd, _r0, _r1, _r2,
+    (magic, version, hbytes, nv, nu, npas, nf, ns, nc, nstages, batch, nrows, cc, cd, crows, _r1, _r2,
      *counts) = _HDR.unpack_from(raw, 0)
     if magic != MAGIC or version != 1 or hbytes != _HDR.size:
         raise ValueError("not a stage dump: %r" % path)
@@ -59,4 +59,4 @@ def read_dump(path):
     if off != len(raw):
         raise ValueError("trailing or missing bytes in %r" % path)
     return dict(dims=Dims(nv, nu, npas, nf, ns, nc), grids=grids, batch=batch, rows=rows, cone_contacts=cc,
-                cone_dim=cd, buffers=buffers)
+                cone_dim=cd, cone_rows=crows, buffers=buffers)

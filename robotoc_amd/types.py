@@ -171,3 +171,11 @@ def cone_dgdf_off(nv, max_contacts):
 def cone_stride(nv, max_contacts):
     """include/rtoc_layout.h: rtoc_cone_stride"""
     return cone_dgdf_off(nv, max_contacts) + ((max_contacts * 15 + 7) & ~7)
+
+
+WRENCH_ROWS, FRICTION_ROWS = 17, 5
+
+
+def wrench_cone_stride(max_contacts):
+    """include/rtoc_layout.h: rtoc_wrench_cone_stride"""
+    return (max_contacts * WRENCH_ROWS * 6 + 7) & ~7

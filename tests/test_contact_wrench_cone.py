@@ -1,0 +1,215 @@
+"""PDIPM rows of the contact wrench cones of surface contacts (reference
+src/constraints/contact_wrench_cone.cpp): 17 rows per active surface contact, g = cone f.
+Condensation into Qff / lf before the contact-dynamics condensation (:209-238), expansion of
+dslack / ddual + fraction-to-boundary (:241-270), slack / dual update.
+CPU: the cone matrix of the C ABI helper against the oracle's table and against its defining
+inequalities; the oracle against the closed form in numpy.  GPU (iCub, 2 feet): through the C ABI
+against the oracle inside the full SQP hot path, and the stage-dump round trip of the wrench set-up."""
+import numpy as np
+import pytest
+
+from helpers import rel_err
+from robotoc_amd import problems as pr
+from robotoc_amd.types import (BUF_CDD, BUF_CON, BUF_CONE, BUF_DIR, BUF_DX0, BUF_KKT, BUF_STEP, GRID_TERMINAL,
+                               Records, icub_dims, joint_limit_rows, wrench_cone_stride)
+
+MC = 2  # iCub: two feet
+X, Y, MU = 0.08, 0.04, 0.7
+
+
+def _icub(nv=32):
+    dims, grids, _ = pr.config_icub_jump(nv=nv)
+    dims = icub_dims(nv, nc_max=6 * (nv - 6) + 17 * MC + 2)
+    return dims, grids
+
+
+def test_wrench_cone_matrix_helper_matches_oracle_and_the_cone_it_describes(oracle):
+    from robotoc_amd import capi
+    for (x, y, mu) in ((X, Y, MU), (0.1, 0.05, 0.4), (0.03, 0.07, 1.1)):
+        A = capi.wrench_cone_matrix(x, y, mu)
+        assert A.shape == (17, 6)
+        assert np.array_equal(A, oracle.wrench_cone_matrix(x, y, mu))
+        # a wrench well inside the cone: pressing down, centre of pressure at the sole centre
+        assert (A @ np.array([0.0, 0.0, 10.0, 0.0, 0.0, 0.0]) < 0).all()
+        # violating faces: pulling (unilaterality), sliding (pyramid), tipping (CoP), spinning (yaw)
+        assert (A @ np.array([0.0, 0.0, -1.0, 0.0, 0.0, 0.0]))[0] > 0
+        assert (A @ np.array([1.01 * mu * 10, 0.0, 10.0, 0.0, 0.0, 0.0]))[1:5].max() > 0
+        assert (A @ np.array([0.0, 0.0, 10.0, 1.01 * y * 10, 0.0, 0.0]))[5:7].max() > 0
+        assert (A @ np.array([0.0, 0.0, 10.0, 0.0, 1.01 * x * 10, 0.0]))[7:9].max() > 0
+        assert (A @ np.array([0.0, 0.0, 10.0, 0.0, 0.0, 1.01 * mu * (x + y) * 10]))[9:].max() > 0
+        assert (A @ np.array([0.0, 0.0, 10.0, 0.0, 0.0, 0.99 * mu * (x + y) * 10]))[9:].max() < 0
+    with pytest.raises(capi.RtocError):
+        capi.wrench_cone_matrix(-1.0, 0.1, 0.7)      # ctor argument checks (:19-26)
+
+
+def _setup(oracle, batch=2):
+    from robotoc_amd import capi
+    dims, grids = _icub()
+    L = oracle.layout(dims)
+    cones = [capi.wrench_cone_matrix(X, Y, MU), capi.wrench_cone_matrix(0.9 * X, 1.1 * Y, 0.6)]
+    cone = pr.make_wrench_cone_batch(L, grids, batch, MC, cones)
+    assert cone.shape[-1] == wrench_cone_stride(MC)
+    return dims, grids, L, cones, cone
+
+
+def test_oracle_wrench_condense_closed_form(oracle):
+    dims, grids, L, cones, cone = _setup(oracle)
+    batch = cone.shape[0]
+    kkt, cdd = pr.make_precondense_batch(L, grids, batch)
+    con = pr.make_constraint_batch(L, grids, batch)
+    C, N = Records(L, "cdd"), Records(L, "con")
+    row0 = dims.nc_max - 17 * MC
+    cdd_ref, con_ref = cdd.copy(), con.copy()
+    touched = 0
+    for b in range(batch):
+        for i, g in enumerate(grids):
+            if g.type == GRID_TERMINAL:
+                continue
+            N.f(con_ref[b, i], "cond")[row0:row0 + 17 * MC] = 0.0
+            for k in range(g.dimf // 6):
+                A = cones[k]
+                r = slice(row0 + 17 * k, row0 + 17 * k + 17)
+                slack, dual = N.f(con_ref[b, i], "slack")[r], N.f(con_ref[b, i], "dual")[r]
+                cond = (dual * N.f(con_ref[b, i], "residual")[r] - N.f(con_ref[b, i], "cmpl")[r]) / slack
+                N.f(con_ref[b, i], "cond")[r] = cond
+                C.f(cdd_ref[b, i], "Qff")[6 * k:6 * k + 6, 6 * k:6 * k + 6] += A.T @ np.diag(dual / slack) @ A
+                C.f(cdd_ref[b, i], "lf")[6 * k:6 * k + 6] += A.T @ cond
+                touched += 1
+    assert touched > 20
+    oracle.wrench_condense_batch(L, grids, MC, cone, cdd, con)
+    assert np.allclose(cdd, cdd_ref, rtol=1e-13, atol=1e-13)
+    assert np.allclose(con, con_ref, rtol=1e-13, atol=1e-13)
+
+
+def test_oracle_wrench_expand_closed_form(oracle):
+    dims, grids, L, cones, cone = _setup(oracle)
+    batch = cone.shape[0]
+    con = pr.make_constraint_batch(L, grids, batch)
+    D, N = Records(L, "dir"), Records(L, "con")
+    rng = np.random.default_rng(11)
+    d = D.zeros(batch, len(grids))
+    d[...] = 0.5 * rng.uniform(-1, 1, d.shape)
+    nv, row0, tau = dims.nv, dims.nc_max - 17 * MC, 0.995
+    con_ref = con.copy()
+    steps_ref = np.ones((batch, 2))
+    for b in range(batch):
+        for i, g in enumerate(grids):
+            if g.type == GRID_TERMINAL or g.dimf == 0:
+                continue
+            N.f(con_ref[b, i], "dslack")[row0:row0 + 17 * MC] = 1.0
+            N.f(con_ref[b, i], "ddual")[row0:row0 + 17 * MC] = 1.0
+            for k in range(g.dimf // 6):
+                r = slice(row0 + 17 * k, row0 + 17 * k + 17)
+                slack, dual = N.f(con_ref[b, i], "slack")[r], N.f(con_ref[b, i], "dual")[r]
+                dslack = -cones[k] @ D.f(d[b, i], "daf")[nv + 6 * k:nv + 6 * k + 6] - N.f(con_ref[b, i], "residual")[r]
+                ddual = -(dual * dslack + N.f(con_ref[b, i], "cmpl")[r]) / slack
+                N.f(con_ref[b, i], "dslack")[r] = dslack
+                N.f(con_ref[b, i], "ddual")[r] = ddual
+                for v, dv, col in ((slack, dslack, 0), (dual, ddual, 1)):
+                    f = -tau * v / dv
+                    f = f[(f > 0) & (f < 1)]
+                    if f.size:
+                        steps_ref[b, col] = min(steps_ref[b, col], f.min())
+    steps = np.ones((batch, 2))
+    oracle.wrench_expand_batch(L, grids, MC, cone, con, d, tau, steps)
+    assert np.allclose(con, con_ref, rtol=1e-13, atol=1e-13)
+    assert np.allclose(steps, steps_ref, rtol=1e-14)
+    assert (steps < 1).any()
+
+
+@pytest.mark.gpu
+def test_gpu_sqp_hot_path_with_wrench_cones_and_joint_limits(oracle, tmp_path):
+    from robotoc_amd import capi
+    dims, grids, _, cones, _ = _setup(oracle)
+    batch = 3
+    ctx = capi.Context(dims, len(grids), batch, 0)
+    try:
+        L = ctx.L
+        ctx.set_grid(grids)
+        kkt, cdd = pr.make_precondense_batch(L, grids, batch)
+        con = pr.make_constraint_batch(L, grids, batch)
+        cone = pr.make_wrench_cone_batch(L, grids, batch, MC, cones)
+        dx0 = pr.make_dx0(L, batch)
+        rows = joint_limit_rows(dims)
+        ctx.set_constraint_rows(rows)
+        ctx.set_friction_cones(4, 3)      # switched off again by the wrench set-up
+        ctx.set_wrench_cones(MC)
+        for buf, arr in ((BUF_KKT, kkt), (BUF_CDD, cdd), (BUF_CON, con), (BUF_CONE, cone), (BUF_DX0, dx0)):
+            ctx.upload(buf, arr)
+        err_gpu = ctx.kkt_error()
+        dump = tmp_path / "wrench.rtocdump"
+        ctx.save_stage_dump(dump, (BUF_KKT, BUF_CDD, BUF_CON, BUF_CONE, BUF_DX0))
+        ctx.condense()
+        kkt_gpu = ctx.download_records(BUF_KKT, "kkt")
+        cdd_gpu = ctx.download_records(BUF_CDD, "cdd")
+        ctx.riccati_backward()
+        ctx.riccati_forward()
+        ctx.expand(0.995)
+        steps_gpu = ctx.download(BUF_STEP, (batch, 2))
+        con_exp = ctx.download_records(BUF_CON, "con")
+        d_gpu = ctx.download_records(BUF_DIR, "dir")
+        ctx.update()
+        con_upd = ctx.download_records(BUF_CON, "con")
+        assert (ctx.status() == 0).all()
+        # oracle: Constraints::condenseSlackAndDual (joint limits, wrench cones) -> contact dynamics -> Riccati
+        err_ref = oracle.kkt_error(L, grids, kkt, cdd, con, rows, MC, 6, 17)
+        assert np.allclose(err_gpu, err_ref, rtol=1e-12)
+        kk, cc, nn = kkt.copy(), cdd.copy(), con.copy()
+        oracle.pdipm_condense_batch(L, grids, rows, kk, nn)
+        oracle.wrench_condense_batch(L, grids, MC, cone, cc, nn)
+        C = Records(L, "cdd")
+        for f in ("Qff", "lf"):
+            assert rel_err(C.f(cdd_gpu, f), C.f(cc, f)) < 1e-12, f
+        assert (oracle.condense_batch(L, grids, kk, cc) == 0).all()
+        K = Records(L, "kkt")
+        for f in ("Qxx", "Qxu", "Quu", "lx", "lu", "Fxx", "Fvu", "Fx"):
+            assert rel_err(K.f(kkt_gpu, f), K.f(kk, f)) < 1e-9, f
+        R, D, N = Records(L, "ric"), Records(L, "dir"), Records(L, "con")
+        ric_ref, d_ref = R.zeros(batch, len(grids)), D.zeros(batch, len(grids))
+        oracle.riccati_sweep_batch(L, grids, kk, ric_ref, d_ref, dx0=dx0)
+        oracle.expand_batch(L, grids, cc, d_ref)
+        for f in ("dx", "du", "dlmdgmm", "daf", "dbetamu"):
+            assert rel_err(D.f(d_gpu, f), D.f(d_ref, f)) < 1e-7, f
+        steps_ref = oracle.pdipm_expand_batch(L, grids, rows, nn, d_ref, 0.995)
+        oracle.wrench_expand_batch(L, grids, MC, cone, nn, d_ref, 0.995, steps_ref)
+        for f in ("cond", "dslack", "ddual"):
+            assert rel_err(N.f(con_exp, f), N.f(nn, f)) < 1e-7, f
+        assert np.allclose(steps_gpu, steps_ref, rtol=1e-6), (steps_gpu, steps_ref)
+        oracle.pdipm_update_batch(L, grids, rows, nn, steps_gpu)
+        oracle.wrench_update_batch(L, grids, MC, nn, steps_gpu)
+        for f in ("slack", "dual"):
+            assert rel_err(N.f(con_upd, f), N.f(nn, f)) < 1e-9, f
+    finally:
+        ctx.close()
+    # the dump restores the wrench set-up (rtoc_dump_header::cone_rows = 17) and replays identically
+    from robotoc_amd import replay
+    hdr = replay.read_dump(dump)
+    assert hdr["cone_rows"] == 17 and hdr["cone_contacts"] == MC and hdr["cone_dim"] == 6
+    ctx2 = capi.Context.from_stage_dump(dump)
+    try:
+        ctx2.condense()
+        assert np.array_equal(ctx2.download_records(BUF_KKT, "kkt"), kkt_gpu)
+        assert np.array_equal(ctx2.download_records(BUF_CDD, "cdd"), cdd_gpu)
+    finally:
+        ctx2.close()
+
+
+@pytest.mark.gpu
+def test_wrench_cone_rows_need_room_and_surface_contacts():
+    from robotoc_amd import capi
+    dims, grids = _icub()
+    tight = icub_dims(32, nc_max=6 * 26)  # exactly the joint-limit rows
+    ctx = capi.Context(tight, len(grids), 1, 0)
+    try:
+        ctx.set_grid(grids)
+        ctx.set_constraint_rows(joint_limit_rows(tight))
+        with pytest.raises(capi.RtocError):
+            ctx.set_wrench_cones(MC)
+    finally:
+        ctx.close()
+    ctx = capi.Context(dims, len(grids), 1, 0)
+    try:
+        with pytest.raises(capi.RtocError):
+            ctx.set_wrench_cones(3)   # 3 surface contacts need nf_max >= 18
+    finally:
+        ctx.close()
