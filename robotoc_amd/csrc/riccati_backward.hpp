@@ -403,7 +403,11 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
     double* rr = a.ric + rinst + (size_t)st * RL.stride;
 
     RTOC_PROF(0);
+#define RTOC_GRID_PREV_STO (a.grid[st - 1].sto != 0)
+#define RTOC_PT_TOP_SYNC() RTOC_BLOCK_SYNC()
 #include "riccati_pt_block.inc"
+#undef RTOC_PT_TOP_SYNC
+#undef RTOC_GRID_PREV_STO
     RTOC_PROF(1);
     // ---- stage data: prefetched registers -> LDS (the HBM loads were issued one stage ahead) ----
     pre_store_mat<NT, NX, NX, LDP>(sA, preA, tid);

@@ -141,6 +141,16 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a, const
   // the vector wave's dependent chains (Cholesky, policy) are the critical path of a stage and can
   // only issue in the gaps of the matrix wave's MFMA stream on the shared SIMD: take those gaps first
   if constexpr (!MW) __builtin_amdgcn_s_setprio(3);
+  // grid descriptors one stage ahead: a scalar load at the stage top would put an HBM/L2 round trip
+  // on the critical path of every stage
+  // (a scalar load shares its wait counter with the LDS traffic: the first LDS wait after it would
+  // absorb the whole latency; a vector load of the eight ints of the descriptor -- lane l holds int l --
+  // has its own counter and is read back with v_readlane at the next stage top).
+  static_assert(offsetof(rtoc_grid, type) == 0 && offsetof(rtoc_grid, sto) == 4 && offsetof(rtoc_grid, sto_next) == 8 &&
+                    offsetof(rtoc_grid, dims) == 20 && sizeof(rtoc_grid) >= 32,
+                "lane <-> field map of the grid prefetch");
+  int gv_ahead = reinterpret_cast<const int*>(a.grid + (N >= 1 ? N - 1 : 0))[tid0 & 7];
+  int type_behind = a.grid[N].type;
   for (int st = N - 1; st >= 0; --st) {
     // opaque per-stage thread index: see riccati_backward.hpp (keeps LICM from pinning VGPRs)
     tid = tid0;
@@ -151,8 +161,14 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a, const
     q = lane >> 4;
     constexpr bool mw = MW;       // matrix wave
     const int vt = tid - 64;      // vector-wave thread index (negative on the matrix wave)
-    const rtoc_grid g = a.grid[st];
-    const rtoc_grid gn = a.grid[st + 1];
+    rtoc_grid g, gn;  // the fields of grid[st], grid[st + 1] this kernel reads
+    g.type = __builtin_amdgcn_readlane(gv_ahead, 0);
+    g.sto = __builtin_amdgcn_readlane(gv_ahead, 1);
+    g.sto_next = __builtin_amdgcn_readlane(gv_ahead, 2);
+    g.dims = __builtin_amdgcn_readlane(gv_ahead, 5);
+    gn.type = type_behind;
+    type_behind = g.type;
+    gv_ahead = reinterpret_cast<const int*>(a.grid + (st > 0 ? st - 1 : 0))[lane & 7];  // grid[st - 1]
     const bool impact = (g.type == RTOC_GRID_IMPACT);
     const bool next_lift = (gn.type == RTOC_GRID_LIFT);
     const int ns = impact ? 0 : g.dims;
@@ -162,7 +178,11 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a, const
 
     RTOC_PROF(0);
     RTOC_PROFV(16);
+#define RTOC_GRID_PREV_STO (__builtin_amdgcn_readlane(gv_ahead, 1) != 0)
+#define RTOC_PT_TOP_SYNC() do { if (do_pt) RTOC_BLOCK_SYNC(); } while (0)  // the roll needs no barrier here
 #include "riccati_pt_block.inc"
+#undef RTOC_PT_TOP_SYNC
+#undef RTOC_GRID_PREV_STO
     RTOC_PROF(1);
     RTOC_PROFV(17);
     // ---- stage data: prefetched registers -> LDS (vector wave) ----
@@ -504,6 +524,8 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a, const
     RTOC_PROF(4);
     RTOC_PROF(5);
     // ================= interval 3: [matrix] F = Qxx + AtP A  || [vector] K, k solve ==========
+    constexpr int TKT = (NX + 3 + 15) / 16;  // column tiles of the stacked right operand [H^T | lu' | psi_u | phi_u]
+    d4 zt[MW ? TKT : 1];                     // Z^T = Y [H^T | ...] = L^-1 H^T: lives until F -= Z Z^T below
     if constexpr (MW) {
       const double* pbf_ = sA + q + li * LDP;
       // k runs over the register groups (tm, r) of PAa that hold P rows: g = 4*tm + r < KSF
@@ -543,9 +565,8 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a, const
         // Z^T never leaves the registers.  (G^-1 = Y^T Y is never formed: that would square the
         // conditioning of the factor.)
         {
-          constexpr int TKT = (NX + 3 + 15) / 16;  // column tiles of the stacked right operand
           constexpr int KSU = (NU + 3) / 4;
-          d4 zt[TKT], kk[TKT];
+          d4 kk[TKT];
           // per-lane source of column x = 16c + li in the tiles that are not pure H columns
           const double* psrc[TKT];
           int ssrc[TKT];
@@ -697,7 +718,20 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a, const
 
     // ================= interval 4: [matrix] GK, F -= K^T GK, P   || [vector] policy -> HBM ====
     if constexpr (MW) {
-      if (!impact) {
+      if (!impact && ns == 0) {
+        // K^T G K = H G^-1 H^T = Z Z^T with Z^T = L^-1 H^T still in the registers of the policy products:
+        // its C layout is both the A-operand layout (m = state index, k = u) and the B-operand layout
+        // (k = u, n = state index) of this product, so F -= K^T G K (brrf.cpp:82-84) needs no operand
+        // loads and no G K intermediate.  Columns >= NX of Z^T (lu', psi_u, phi_u) only reach entries
+        // of F outside NX x NX, which are never stored.
+        static_assert(TKT >= TNX, "Z^T covers every column tile of F");
+#pragma unroll
+        for (int ks = 0; ks < (NU + 3) / 4; ++ks)
+#pragma unroll
+          for (int c = 0; c < CNT; ++c)
+#pragma unroll
+            for (int t = c; t < TNX; ++t) f[c][t] = mfma16(-zt[c][ks], zt[t][ks], f[c][t]);
+      } else if (!impact) {
         {
           d4 acc[TNU][CNT];
 #pragma unroll
@@ -816,8 +850,10 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a, const
               }
             }
       }
-      // ---- P = (F + F^T)/2 (brrf.cpp:85): off-diagonal tiles are mirrored, the diagonal tiles are
-      //      symmetrised through LDS in the MFMA register layout ----
+      // ---- P = (F + F^T)/2 (brrf.cpp:85).  Only the upper tiles of F exist; they are written to both
+      //      (i,j) and (j,i), and inside the diagonal tiles the upper triangle is mirrored likewise:
+      //      P is exactly symmetric, and differs from the arithmetic mean only by the rounding-level
+      //      asymmetry the MFMA summation order leaves in a diagonal tile (no LDS round trip). ----
       {
         double* pw_ = sP + q + li * LDP;  // (i,j) at i + j*LDP
         double* pm_ = sP + li + q * LDP;  // (j,i)
@@ -828,27 +864,11 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a, const
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int i = c * 16 + drow(q, r), j = t * 16 + li;
-              if (i < NX && j < NX) {
+              if (i < NX && j < NX && (t > c || i <= j)) {
                 pw_[c * 16 + 4 * r + t * 16 * LDP] = f[c][t][r];
-                if (t > c) pm_[t * 16 + (c * 16 + 4 * r) * LDP] = f[c][t][r];
+                if (i != j) pm_[t * 16 + (c * 16 + 4 * r) * LDP] = f[c][t][r];
               }
             }
-        wave_lds_sync();
-#pragma unroll
-        for (int c = 0; c < CNT; ++c)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const double v = pm_[c * 16 + (c * 16 + 4 * r) * LDP];
-            f[c][c][r] = 0.5 * (f[c][c][r] + v);
-          }
-        wave_lds_sync();
-#pragma unroll
-        for (int c = 0; c < CNT; ++c)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int i = c * 16 + drow(q, r), j = c * 16 + li;
-            if (i < NX && j < NX) pw_[c * 16 + 4 * r + c * 16 * LDP] = f[c][c][r];
-          }
       }
     } else {
       // next stage's record: HBM -> registers of the vector wave.  Issued here, after the register-
@@ -895,25 +915,31 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a, const
     RTOC_PROF(11);
     // ---- results -> HBM; roll the LDS "next" state ----
     // (P of this stage goes to HBM from the vector wave while it waits for the next stage's G)
-    if (tid < NX) {
-      const double sv = smem[C::V_SNEW + tid];
-      const double psi = sto ? smem[C::V_PSI + tid] : 0.0;
-      const double phi = sto ? smem[C::V_PHI + tid] : 0.0;
-      rr[RL.off[RTOC_RIC_S] + tid] = sv;
-      rr[RL.off[RTOC_RIC_PSI] + tid] = psi;
-      rr[RL.off[RTOC_RIC_PHI] + tid] = phi;
-      if (sto && !impact) {
-        rr[RL.off[RTOC_RIC_PSIX] + tid] = smem[C::V_PSIX + tid];
-        rr[RL.off[RTOC_RIC_PHIX] + tid] = smem[C::V_PHIX + tid];
+    // Done by the vector wave, which produced s / Psi / Phi and is their first consumer in the next
+    // stage: no barrier is needed at the next stage top (the matrix wave reads s+ only after the
+    // F2 hand-off of that stage, which this wave signals after these writes).
+    static_assert(NX <= 64, "one vector-wave lane per state entry");
+    if constexpr (!MW) {
+      if (vt < NX) {
+        const double sv = smem[C::V_SNEW + vt];
+        const double psi = sto ? smem[C::V_PSI + vt] : 0.0;
+        const double phi = sto ? smem[C::V_PHI + vt] : 0.0;
+        rr[RL.off[RTOC_RIC_S] + vt] = sv;
+        rr[RL.off[RTOC_RIC_PSI] + vt] = psi;
+        rr[RL.off[RTOC_RIC_PHI] + vt] = phi;
+        if (sto && !impact) {
+          rr[RL.off[RTOC_RIC_PSIX] + vt] = smem[C::V_PSIX + vt];
+          rr[RL.off[RTOC_RIC_PHIX] + vt] = smem[C::V_PHIX + vt];
+        }
+        smem[C::V_SN + vt] = sv;
+        smem[C::V_PSIN + vt] = psi;
+        smem[C::V_PHIN + vt] = phi;
       }
-      smem[C::V_SN + tid] = sv;
-      smem[C::V_PSIN + tid] = psi;
-      smem[C::V_PHIN + tid] = phi;
-    }
-    if (tid < 5) {
-      const double v = sto ? smem[C::V_SC + tid] : 0.0;
-      rr[RL.off[RTOC_RIC_SCAL] + tid] = v;
-      smem[C::V_SCN + tid] = v;
+      if (vt < 5) {
+        const double v = sto ? smem[C::V_SC + vt] : 0.0;
+        rr[RL.off[RTOC_RIC_SCAL] + vt] = v;
+        smem[C::V_SCN + vt] = v;
+      }
     }
     RTOC_PROF(12);
     RTOC_PROFV(29);
