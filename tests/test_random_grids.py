@@ -9,13 +9,13 @@ import pytest
 from helpers import compare_direction, compare_riccati
 from robotoc_amd import problems as pr
 from robotoc_amd.grid import ContactSequence, Event, discretize
-from robotoc_amd.types import (BUF_DIR, BUF_DX0, BUF_KKT, BUF_RIC, GRID_IMPACT, GRID_LIFT, GRID_TERMINAL,
-                               Records, anymal_dims)
+from robotoc_amd.types import (BUF_CDD, BUF_DIR, BUF_DX0, BUF_KKT, BUF_RIC, GRID_IMPACT, GRID_LIFT, GRID_TERMINAL,
+                               Records, anymal_dims, icub_dims)
 
 
-def random_case(seed):
+def random_case(seed, dims=None, nmax=22):
     rng = np.random.default_rng(1000 + seed)
-    N = int(rng.integers(10, 22))
+    N = int(rng.integers(10, nmax))
     dt = 0.02
     T = N * dt
     nev = int(rng.integers(1, 5))
@@ -40,7 +40,7 @@ def random_case(seed):
         phase_dimf.append(dimf)
     cs = ContactSequence(phase_dimf, events)
     any_sto = any(e.sto for e in events)
-    return anymal_dims(), discretize(N, T, 0.0, cs, phase_based=any_sto), any_sto
+    return (dims if dims is not None else anymal_dims()), discretize(N, T, 0.0, cs, phase_based=any_sto), any_sto
 
 
 def _valid(grids):
@@ -98,5 +98,75 @@ def test_random_event_structures_match_oracle(oracle, seed, waves):
         for b in range(batch):
             compare_riccati(L, grids, ric[b], ric_ref[b], tol, "seed %d inst %d" % (seed, b))
             compare_direction(L, grids, d[b], d_ref[b], tol, "seed %d inst %d" % (seed, b))
+    finally:
+        ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nv,seed", [(32, 3), (32, 8), (35, 5), (35, 11)])
+def test_random_event_structures_icub(oracle, nv, seed):
+    """The tile-split kernel at iCub size (the only variant for nu > 16) on random event structures."""
+    from robotoc_amd import capi
+    dims, grids, any_sto = random_case(seed, icub_dims(nv), nmax=14)
+    batch = 2
+    ctx = capi.Context(dims, len(grids), batch, 0)
+    try:
+        L = ctx.L
+        ctx.set_grid(grids)
+        kkt = pr.make_kkt_batch(L, grids, batch, mode="dynamics", first_instance=seed)
+        dx0 = pr.make_dx0(L, batch, first_instance=seed)
+        ctx.upload(BUF_KKT, kkt)
+        ctx.upload(BUF_DX0, dx0)
+        ctx.riccati_sweep()
+        ric_ref = Records(L, "ric").zeros(batch, len(grids))
+        d_ref = Records(L, "dir").zeros(batch, len(grids))
+        st_ref = oracle.riccati_sweep_batch(L, grids, kkt.copy(), ric_ref, d_ref, dx0=dx0)
+        assert (ctx.status() == st_ref).all()
+        ric, d = ctx.download_records(BUF_RIC, "ric"), ctx.download_records(BUF_DIR, "dir")
+        tol = 1e-7 if any_sto else 1e-8
+        for b in range(batch):
+            compare_riccati(L, grids, ric[b], ric_ref[b], tol, "nv %d seed %d inst %d" % (nv, seed, b))
+            compare_direction(L, grids, d[b], d_ref[b], tol, "nv %d seed %d inst %d" % (nv, seed, b))
+    finally:
+        ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(8))
+def test_random_event_structures_condense_expand(oracle, seed):
+    """Contact-dynamics condensation / expansion on the same random structures: every mix of nf in
+    {0, 6, 12}, impact stages and switching-constraint stages (condenseContactDynamics /
+    condenseImpactDynamics / expand*) against the oracle."""
+    from robotoc_amd import capi
+    dims, grids, _ = random_case(seed)
+    batch = 2
+    ctx = capi.Context(dims, len(grids), batch, 0)
+    try:
+        L = ctx.L
+        ctx.set_grid(grids)
+        kkt, cdd = pr.make_precondense_batch(L, grids, batch, first_instance=seed)
+        dx0 = pr.make_dx0(L, batch, first_instance=seed)
+        for buf, arr in ((BUF_KKT, kkt), (BUF_CDD, cdd), (BUF_DX0, dx0)):
+            ctx.upload(buf, arr)
+        ctx.condense()
+        kkt_gpu = ctx.download_records(BUF_KKT, "kkt")
+        cdd_gpu = ctx.download_records(BUF_CDD, "cdd")
+        ctx.riccati_sweep()
+        ctx.expand(0.995)
+        d_gpu = ctx.download_records(BUF_DIR, "dir")
+        assert (ctx.status() == 0).all()
+        kk, cc = kkt.copy(), cdd.copy()
+        assert (oracle.condense_batch(L, grids, kk, cc) == 0).all()
+        K, C, D = Records(L, "kkt"), Records(L, "cdd"), Records(L, "dir")
+        from helpers import rel_err
+        for f in ("Qxx", "Qxu", "Quu", "lx", "lu", "Fxx", "Fvu", "Fx", "Phix", "Phiu", "Pres"):
+            assert rel_err(K.f(kkt_gpu, f), K.f(kk, f)) < 1e-9, (seed, f)
+        for f in ("MJtJinv", "MJtJinv_dIDCdqv", "MJtJinv_IDC", "Qafqv", "Qafu_full", "laf"):
+            assert rel_err(C.f(cdd_gpu, f), C.f(cc, f)) < 1e-9, (seed, f)
+        ric_ref, d_ref = Records(L, "ric").zeros(batch, len(grids)), D.zeros(batch, len(grids))
+        oracle.riccati_sweep_batch(L, grids, kk, ric_ref, d_ref, dx0=dx0)
+        oracle.expand_batch(L, grids, cc, d_ref)
+        for f in ("dx", "du", "dlmdgmm", "daf", "dbetamu", "dnu_passive"):
+            assert rel_err(D.f(d_gpu, f), D.f(d_ref, f)) < 1e-7, (seed, f)
     finally:
         ctx.close()
