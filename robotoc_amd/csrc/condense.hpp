@@ -24,6 +24,13 @@
 #include "lds_gemm.hpp"
 #include "../../include/rtoc.h"
 
+// Wavefronts per (instance, grid point) of the condensation kernel.  Measured on MI355X (4096 ANYmal x 46 grid
+// points / 512 iCub): 2 waves 6.12 / 3.50 / 5.24 ms, 3 waves 5.90 / 3.20 / 4.54 ms (the 3 x 3 tile grids of the
+// Schur updates deal evenly to three waves), 4 waves 7.09 ms.
+#ifndef RTOC_COND_NW
+#define RTOC_COND_NW 3
+#endif
+
 namespace rtoc {
 
 __device__ __forceinline__ void wave_lds_sync_() {
@@ -72,7 +79,7 @@ struct ExpArgs {
 
 template <int NV, int NU, int NF, int NS>
 struct CondCfg {
-  static constexpr int NW = 2;          // wavefronts per work item (tile pairs dealt round-robin)
+  static constexpr int NW = RTOC_COND_NW;  // wavefronts per work item (tiles dealt round-robin)
   static constexpr int NT = 64 * NW;
   static constexpr int NX = 2 * NV;
   static constexpr int NFP = NF > 0 ? NF : 1;
@@ -291,8 +298,8 @@ __device__ __forceinline__ void wave_gemv(int M, int K, double alpha, const doub
 }
 
 template <int NV, int NU, int NF, int NS>
-__global__ __launch_bounds__(128) void condense_kernel(CondArgs a) {
-  static_assert(CondCfg<NV, NU, NF, NS>::NT == 128, "launch bounds must match CondCfg::NT");
+__global__ __launch_bounds__(64 * RTOC_COND_NW) void condense_kernel(CondArgs a) {
+  static_assert(CondCfg<NV, NU, NF, NS>::NT == 64 * RTOC_COND_NW, "launch bounds must match CondCfg::NT");
   using C = CondCfg<NV, NU, NF, NS>;
   constexpr int NT = C::NT, NW = C::NW;
   constexpr int NX = 2 * NV, NP = NV - NU, LDV = C::LDV, LDF = C::NFP, LDS_ = NS > 0 ? NS : 1;
