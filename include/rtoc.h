@@ -99,7 +99,8 @@ enum rtoc_option {
   RTOC_OPT_MAX_DTS0 = 1,      /* RiccatiRecursion(ocp, max_dts0) / setRegularization; value = double bits */
   RTOC_OPT_BACKWARD_WAVES = 2, /* waves per OCP instance in the backward kernel (0 = default for the dims) */
   RTOC_OPT_CONTACT_INV_DAMPING = 3, /* RobotModelInfo::contact_inv_damping (robot.hxx:662-664); value = double bits */
-  RTOC_OPT_SWEEP_CHUNKS = 4 /* instance chunks of rtoc_riccati_sweep's backward/forward pipeline (1..16, default 1 = plain sequence) */
+  RTOC_OPT_SWEEP_CHUNKS = 4, /* instance chunks of rtoc_riccati_sweep's backward/forward pipeline (1..16, default 1 = plain sequence) */
+  RTOC_OPT_CONDENSE_SPLIT = 5 /* 1 (default): rtoc_condense computes MJtJinv in its own high-occupancy kernel; 0: one fused kernel */
 };
 
 typedef struct rtoc_ctx rtoc_ctx;

@@ -10,7 +10,7 @@ import subprocess
 import numpy as np
 
 from .types import (BoxRow, BUF_CDD, BUF_CON, BUF_DIR, BUF_DX0, BUF_KKT, BUF_RIC, BUF_STEP, Dims, Grid,
-                    Layout, OPT_BACKWARD_WAVES, OPT_MAX_DTS0, OPT_SWEEP_CHUNKS, OPT_WRITEBACK_KKT,
+                    Layout, OPT_BACKWARD_WAVES, OPT_CONDENSE_SPLIT, OPT_MAX_DTS0, OPT_SWEEP_CHUNKS, OPT_WRITEBACK_KKT,
                     grid_array)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -220,6 +220,10 @@ class Context:
 
     def set_sweep_chunks(self, n):
         _chk(lib().rtoc_set_option(self._h, OPT_SWEEP_CHUNKS, int(n)))
+
+    def set_condense_split(self, on):
+        """RTOC_OPT_CONDENSE_SPLIT: MJtJinv in its own kernel (default) or one fused condensation kernel."""
+        _chk(lib().rtoc_set_option(self._h, OPT_CONDENSE_SPLIT, int(bool(on))))
 
     def correct_state_equation(self):
         _chk(lib().rtoc_correct_state_equation(self._h))

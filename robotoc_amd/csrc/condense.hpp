@@ -297,7 +297,10 @@ __device__ __forceinline__ void wave_gemv(int M, int K, double alpha, const doub
   }
 }
 
-template <int NV, int NU, int NF, int NS>
+// SPLIT = false: everything in one kernel.  SPLIT = true: MJtJinv was computed by mjtjinv_kernel (below) and
+// is read back from the ContactDynamicsData record -- the serial factorisations then run at four times the
+// occupancy (16 KB instead of 38 KB of LDS per grid point) and off this kernel's critical path.
+template <int NV, int NU, int NF, int NS, bool SPLIT = false>
 __global__ __launch_bounds__(64 * RTOC_COND_NW) void condense_kernel(CondArgs a) {
   static_assert(CondCfg<NV, NU, NF, NS>::NT == 64 * RTOC_COND_NW, "launch bounds must match CondCfg::NT");
   using C = CondCfg<NV, NU, NF, NS>;
@@ -373,7 +376,8 @@ __global__ __launch_bounds__(64 * RTOC_COND_NW) void condense_kernel(CondArgs a)
   constexpr int N_L = (H_L + NT - 1) / NT, N_D = (H_D + NT - 1) / NT, N_J = (H_J + NT - 1) / NT,
                 N_F = (H_F + NT - 1) / NT;
   typedef double dbl2 __attribute__((ext_vector_type(2)));
-  dbl2 gL[N_L], gD[N_D], gJ[N_J], gF[N_F], gQ[N_J];
+  constexpr int H_LAM = (LDV * LDV + 1) / 2, N_LAM = SPLIT ? (H_LAM + NT - 1) / NT : 1;
+  dbl2 gL[N_L], gD[N_D], gJ[N_J], gF[N_F], gQ[N_J], gLam[N_LAM];
   const dbl2 zero2 = {0.0, 0.0};
   // compile-time trip counts (arrays stay in registers) and unconditional loads from clamped
   // addresses: every field exists in the max-size record whatever dimf is, and a load under a branch
@@ -389,9 +393,13 @@ __global__ __launch_bounds__(64 * RTOC_COND_NW) void condense_kernel(CondArgs a)
     const int e = lane + k * NT;                                                 \
     if (e < (n2)) reinterpret_cast<dbl2*>(dst)[e] = src[k];                      \
   }
-  RTOC_LD2(gL, N_L, cr + CL.off[RTOC_CDD_DIDDA], H_L)
+  if constexpr (!SPLIT) {
+    RTOC_LD2(gL, N_L, cr + CL.off[RTOC_CDD_DIDDA], H_L)
+    RTOC_LD2(gJ, N_J, cr + CL.off[RTOC_CDD_DCDA], H_J)
+  } else {
+    RTOC_LD2(gLam, N_LAM, cr + CL.off[RTOC_CDD_MJTJINV], H_LAM)
+  }
   RTOC_LD2(gD, N_D, cr + CL.off[RTOC_CDD_DIDCDQV], H_D)
-  RTOC_LD2(gJ, N_J, cr + CL.off[RTOC_CDD_DCDA], H_J)
   RTOC_LD2(gF, N_F, cr + CL.off[RTOC_CDD_QFF], H_F)
   RTOC_LD2(gQ, N_J, cr + CL.off[RTOC_CDD_QQF], H_J)
   const int lv_ = lane < NV ? lane : 0, lf_ = lane < nf ? lane : 0, lvf_ = lane < nvf ? lane : 0;
@@ -442,13 +450,18 @@ __global__ __launch_bounds__(64 * RTOC_COND_NW) void condense_kernel(CondArgs a)
   RTOC_CPROF(21);
   // inactive rows / columns (dimf < max_dimf) of the stored blocks stay zero, like the reference's
   // max-size backing matrices
-  for (int e = lane; e < LDV * LDV; e += NT) Lam[e] = 0.0;
+  if constexpr (!SPLIT)
+    for (int e = lane; e < LDV * LDV; e += NT) Lam[e] = 0.0;
   for (int e = lane; e < LDV * NX; e += NT) LD[e] = 0.0;
   RTOC_CPROF(22);
   // ================= registers -> LDS =================
-  RTOC_ST2(sL, gL, N_L, H_L)
+  if constexpr (!SPLIT) {
+    RTOC_ST2(sL, gL, N_L, H_L)
+    RTOC_ST2(sJ, gJ, N_J, H_J)
+  } else {
+    RTOC_ST2(Lam, gLam, N_LAM, H_LAM)
+  }
   RTOC_ST2(D, gD, N_D, H_D)
-  RTOC_ST2(sJ, gJ, N_J, H_J)
   RTOC_ST2(Qff, gF, N_F, H_F)
   RTOC_ST2(Qqf, gQ, N_J, H_J)
 #undef RTOC_LD2
@@ -470,7 +483,8 @@ __global__ __launch_bounds__(64 * RTOC_COND_NW) void condense_kernel(CondArgs a)
     // LDS so that every product below can use its compile-time extents
     for (int e = lane; e < (LDV - nvf) * NX; e += NT) D[nvf + e % (LDV - nvf) + (e / (LDV - nvf)) * LDV] = 0.0;
     if (!impact) {
-      for (int e = lane; e < (NF - nf) * NV; e += NT) sJ[nf + e % (NF - nf) + (e / (NF - nf)) * LDF] = 0.0;
+      if constexpr (!SPLIT)
+        for (int e = lane; e < (NF - nf) * NV; e += NT) sJ[nf + e % (NF - nf) + (e / (NF - nf)) * LDF] = 0.0;
     } else {
       // J = dCdv lives inside D (rows NV.., columns NV..): its inactive rows were zeroed with D's
     }
@@ -483,104 +497,10 @@ __global__ __launch_bounds__(64 * RTOC_COND_NW) void condense_kernel(CondArgs a)
   const double* const J = impact ? D + NV + (size_t)NV * LDV : sJ;
   const int ldj = impact ? LDV : LDF;
 
-  RTOC_CPROF(1);
-  // ================= computeMJtJinv (robot.hxx:642-684) =================
-  constexpr bool FUSED_MINV =
-      NV <= 32 && (NF == 0 || C::O_BR + C::pad8(C::NFP * C::NFP) - C::O_JM >= NV * NV);
-  if constexpr (FUSED_MINV) {
-    // Cholesky of M and, in the same instruction stream, Y = L^-1 (wave_llt_inv); M^-1 = Y^T Y on the
-    // matrix cores.  Y lives in the J M^-1 / S scratch, which is not in use yet.
-    double* const sY = sJM;
-    double* const sYs = (NF == 0) ? LD : sY;  // no contact scratch on fixed-base sets: borrow LD
-    if (wv == 0 && wave_llt_inv<NV, NV, 32>(sL, sL, sLinv, sYs, NV, wl)) stat |= RTOC_STAT_M_NOT_SPD;
-    __syncthreads();
-    RTOC_CPROF(2);
-    lds_gemm<NW, NV, NV, NV, NV, 1, 1, NV>(sYs, sYs, lane,
-                                           [&](int r, int c, double v, int, int) { Lam[r + c * LDV] = v; });  // topLeft = M^-1
-    __syncthreads();
-    if (NF == 0)
-      for (int e = lane; e < LDV * NX; e += NT) LD[e] = 0.0;
-  } else {
-    if (wv == 0 && wave_llt<NV, NV>(sL, sL, sLinv, NV, wl)) stat |= RTOC_STAT_M_NOT_SPD;
-    __syncthreads();
-    RTOC_CPROF(2);
-    if (lane < NV) {  // topLeft = M^-1: lane t solves column t
-      double x[NV];
-#pragma unroll
-      for (int i = 0; i < NV; ++i) x[i] = (i == lane) ? 1.0 : 0.0;
-      llt_solve_reg<NV, NV>(sL, sLinv, x, NV);
-#pragma unroll
-      for (int i = 0; i < NV; ++i) Lam[i + lane * LDV] = x[i];
-    }
-  }
-  __syncthreads();
-  RTOC_CPROF(3);
-  if (nf > 0) {
-    auto st_jm = [&](int r, int c, double v, int, int) { sJM[r + c * LDF] = v; };
-    if (!impact)
-      lds_gemm<NW, C::NFP, NV, NV, 1, LDF, 1, LDV>(sJ, Lam, lane, st_jm);  // J M^-1 (:677)
-    else
-      lds_gemm<NW, C::NFP, NV, NV, 1, LDV, 1, LDV>(J, Lam, lane, st_jm);
-    __syncthreads();
-    RTOC_CPROF(16);
-    auto st_s = [&](int r, int c, double v, int, int) { sS[r + c * LDF] = v; };
-    if (!impact)
-      lds_gemm<NW, C::NFP, C::NFP, NV, 1, LDF, LDF, 1>(sJM, sJ, lane, st_s);  // JMinvJt (:660-661)
-    else
-      lds_gemm<NW, C::NFP, C::NFP, NV, 1, LDF, LDV, 1>(sJM, J, lane, st_s);
-    __syncthreads();
-    if (lane < nf) sS[lane + lane * LDF] += a.damping;  // (:662-664)
-    __syncthreads();
-    RTOC_CPROF(17);
-    if constexpr (C::NFP <= 16) {
-      // LLT(JMinvJt) (:665) with its inverse factor Ys; bottomRight = -(JMinvJt)^-1 = -Ys^T Ys (:673-675)
-      double* const sYs2 = sL;  // the factor of M is dead
-      if (wv == 0) {
-        // the inactive part of S is zero: factorise the full NFP x NFP block with a unit diagonal there
-        // (compile-time size: no per-entry `k < n` tests in the unrolled factorisation)
-        if (wl >= nf && wl < C::NFP) sS[wl + wl * LDF] = 1.0;
-        wave_lds_sync_();
-        if (wave_llt_inv<C::NFP, C::NFP, 16>(sS, sS, sSinv, sYs2, C::NFP, wl)) stat |= RTOC_STAT_M_NOT_SPD;
-      }
-      __syncthreads();
-      RTOC_CPROF(18);
-      lds_gemm<NW, C::NFP, C::NFP, C::NFP, C::NFP, 1, 1, C::NFP>(sYs2, sYs2, lane, [&](int r, int c, double v, int, int) {
-        const double w = (r < nf && c < nf) ? -v : 0.0;  // drop the padded identity block
-        sBR[r + c * LDF] = w;
-        Lam[(NV + r) + (NV + c) * LDV] = w;
-      });
-    } else {
-      if (wv == 0 && wave_llt<C::NFP, C::NFP>(sS, sS, sSinv, nf, wl)) stat |= RTOC_STAT_M_NOT_SPD;  // (:665)
-      __syncthreads();
-      RTOC_CPROF(18);
-      if (lane < nf) {  // bottomRight = -(JMinvJt)^-1 (:673-675)
-        double x[C::NFP];
-#pragma unroll
-        for (int i = 0; i < C::NFP; ++i) x[i] = (i == lane) ? -1.0 : 0.0;
-        llt_solve_reg<C::NFP, C::NFP>(sS, sSinv, x, nf);
-#pragma unroll
-        for (int i = 0; i < C::NFP; ++i)
-          if (i < nf) {
-            sBR[i + lane * LDF] = x[i];
-            Lam[(NV + i) + (NV + lane) * LDV] = x[i];
-          }
-      }
-    }
-    __syncthreads();
-    RTOC_CPROF(19);
-    // topRight = bottomLeft^T * (-bottomRight) (:678)
-    lds_gemm<NW, NV, C::NFP, C::NFP, LDF, 1, 1, LDF>(sJM, sBR, lane,
-                                                     [&](int r, int c, double v, int, int) { Lam[r + (NV + c) * LDV] = -v; });
-    __syncthreads();
-    RTOC_CPROF(20);
-    // topLeft -= topRight * bottomLeft (:679) ; bottomLeft = topRight^T (:680)
-    lds_gemm<NW, NV, NV, C::NFP, 1, LDV, 1, LDF>(Lam + NV * LDV, sJM, lane,
-                                                 [&](int r, int c, double v, int, int) { Lam[r + c * LDV] -= v; });
-    for (int e = lane; e < nf * NV; e += NT) {
-      const int i = e % nf, j = e / nf;
-      Lam[(NV + i) + j * LDV] = Lam[j + (NV + i) * LDV];
-    }
-    __syncthreads();
+  if constexpr (!SPLIT) {
+#define RTOC_J_IN_D impact
+#include "condense_mjtjinv.inc"
+#undef RTOC_J_IN_D
   }
 
   RTOC_CPROF(4);
@@ -750,7 +670,7 @@ __global__ __launch_bounds__(64 * RTOC_COND_NW) void condense_kernel(CondArgs a)
 
   RTOC_CPROF(8);
   // ================= LDS -> HBM: the ContactDynamicsData the expansion needs, each field once ====
-  copy_s2g_flat16<NT>(cr + CL.off[RTOC_CDD_MJTJINV], Lam, LDV * LDV, lane);
+  if constexpr (!SPLIT) copy_s2g_flat16<NT>(cr + CL.off[RTOC_CDD_MJTJINV], Lam, LDV * LDV, lane);
   copy_s2g_flat16<NT>(cr + CL.off[RTOC_CDD_MJD], LD, LDV * NX, lane);
   copy_s2g_flat16<NT>(cr + CL.off[RTOC_CDD_QAFQV], Qafqv, LDV * NX, lane);
   if (!impact) copy_s2g_flat16<NT>(cr + CL.off[RTOC_CDD_QAFU], Qafu, LDV * NV, lane);
@@ -760,6 +680,96 @@ __global__ __launch_bounds__(64 * RTOC_COND_NW) void condense_kernel(CondArgs a)
     if (!impact) cr[CL.off[RTOC_CDD_HAF] + lane] = haf[lane];
   }
   RTOC_CPROF(9);
+  if (stat) atomicOr(&a.status[b], stat);
+}
+
+// ---------------------------------------------------------------------------------------------
+// First kernel of the split condensation: MJtJinv of every (instance, grid point) on ONE wave, into the
+// ContactDynamicsData record.  4.3 KB in (dIDda, dCda | dCdv), 7.2 KB out at ANYmal size; the two serial
+// Cholesky factorisations that dominate it only need the saddle-matrix scratch in LDS.
+// ---------------------------------------------------------------------------------------------
+template <int NV, int NF>
+struct MjCfg {
+  static constexpr int NFP = NF > 0 ? NF : 1, LDV = NV + NF, NX = 2 * NV;
+  static constexpr int pad8(int n) { return (n + 7) & ~7; }
+  static constexpr int O_LAM = 0;
+  static constexpr int O_L = O_LAM + pad8(LDV * LDV);
+  static constexpr int O_J = O_L + pad8(NV * NV);
+  static constexpr int O_JM = O_J + pad8(NFP * NV);
+  static constexpr int O_S = O_JM + pad8(NFP * NV);
+  static constexpr int O_BR = O_S + pad8(NFP * NFP);
+  static constexpr int O_LD = O_BR + pad8(NFP * NFP);  // scratch the fragment borrows on fixed-base sets
+  static constexpr int V_LINV = O_LD + (NF == 0 ? pad8(LDV * NX > NV * NV ? LDV * NX : NV * NV) : 0);
+  static constexpr int V_SINV = V_LINV + pad8(NV);
+  static constexpr int LDS_DOUBLES = V_SINV + pad8(NFP);
+  static constexpr int LDS_BYTES = LDS_DOUBLES * 8;
+};
+
+template <int NV, int NU, int NF, int NS>
+__global__ __launch_bounds__(64) void mjtjinv_kernel(CondArgs a) {
+  using C = MjCfg<NV, NF>;
+  constexpr int NT = 64, NW = 1, NX = 2 * NV, LDV = C::LDV, LDF = C::NFP;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* const Lam = smem + C::O_LAM;
+  double* const sL = smem + C::O_L;
+  double* const sJ = smem + C::O_J;
+  double* const sJM = smem + C::O_JM;
+  double* const sS = smem + C::O_S;
+  double* const sBR = smem + C::O_BR;
+  double* const LD = smem + C::O_LD;
+  double* const sLinv = smem + C::V_LINV;
+  double* const sSinv = smem + C::V_SINV;
+  const int lane = threadIdx.x, wv = 0, wl = lane;
+  const int item = blockIdx.x;
+  const int nst1 = a.nstages - 1;
+  const int b = item / nst1, st = item % nst1;
+  if (b >= a.batch) return;
+  const rtoc_grid g = a.grid[st];
+  const bool impact = g.type == RTOC_GRID_IMPACT;
+  const int nf = g.dimf;
+  constexpr rtoc_layout SL = StaticLayout<NV, NU, NS>::make();
+  constexpr rtoc_record_layout CL = SL.cdd;
+  double* cr = a.cdd + ((size_t)b * a.nstages + st) * CL.stride;
+  unsigned stat = 0;
+  typedef double dbl2 __attribute__((ext_vector_type(2)));
+  constexpr int H_L = (NV * NV + 1) / 2, N_L = (H_L + NT - 1) / NT, N_J = (C::NFP * NV + NT - 1) / NT;
+  dbl2 gL[N_L];
+  double gJ[N_J];
+  const dbl2 zero2 = {0.0, 0.0};
+#pragma unroll
+  for (int k = 0; k < N_L; ++k) {
+    const int e = lane + k * NT;
+    const dbl2 v = reinterpret_cast<const dbl2*>(cr + CL.off[RTOC_CDD_DIDDA])[e < H_L ? e : 0];
+    gL[k] = (e < H_L) ? v : zero2;
+  }
+  // J = dCda (NF x NV, ld NF) on contact grids, dCdv = dIDCdqv[nv:, nv:] (ld LDV) on impact grids
+  // (impact_dynamics.cpp:44-50): both land in sJ with ld NF; rows >= dimf are zero
+  const double* const jsrc = cr + (impact ? CL.off[RTOC_CDD_DIDCDQV] + NV + NV * LDV : CL.off[RTOC_CDD_DCDA]);
+  const int jld = impact ? LDV : LDF;
+#pragma unroll
+  for (int k = 0; k < N_J; ++k) {
+    const int e = lane + k * NT, r = e % LDF, c = e / LDF;
+    const bool ok = NF > 0 && c < NV && r < nf;
+    const double v = jsrc[ok ? r + c * jld : 0];
+    gJ[k] = ok ? v : 0.0;
+  }
+  for (int e = lane; e < LDV * LDV; e += NT) Lam[e] = 0.0;
+#pragma unroll
+  for (int k = 0; k < N_L; ++k) {
+    const int e = lane + k * NT;
+    if (e < H_L) reinterpret_cast<dbl2*>(sL)[e] = gL[k];
+  }
+#pragma unroll
+  for (int k = 0; k < N_J; ++k) {
+    const int e = lane + k * NT;
+    if (e < C::NFP * NV) sJ[e] = gJ[k];
+  }
+  const double* const J = sJ;
+  __syncthreads();
+#define RTOC_J_IN_D false
+#include "condense_mjtjinv.inc"
+#undef RTOC_J_IN_D
+  copy_s2g_flat16<NT>(cr + CL.off[RTOC_CDD_MJTJINV], Lam, LDV * LDV, lane);
   if (stat) atomicOr(&a.status[b], stat);
 }
 

@@ -61,6 +61,8 @@ struct KernelSet {
   cone_fn ccond, cexp;  // friction-cone rows
   cone_fn wcond, wexp;  // contact-wrench-cone rows
   cond_fn cond;
+  cond_fn cond_split, mjt;  // split condensation: MJtJinv kernel + the rest
+  int mjt_lds;
   int cond_threads, cond_lds;
   expd_fn expd;
   int expd_threads;
@@ -111,6 +113,9 @@ static KernelSet make_set() {
   k.wexp = wrench_expand_kernel<NV, NS>;
   constexpr int NF = NS;  // nf_max == ns_max for all supported robots
   k.cond = condense_kernel<NV, NU, NF, NS>;
+  k.cond_split = condense_kernel<NV, NU, NF, NS, true>;
+  k.mjt = mjtjinv_kernel<NV, NU, NF, NS>;
+  k.mjt_lds = MjCfg<NV, NF>::LDS_BYTES;
   k.cond_threads = CondCfg<NV, NU, NF, NS>::NT;
   k.cond_lds = CondCfg<NV, NU, NF, NS>::LDS_BYTES;
   k.expd = expand_kernel<NV, NU, NF, NS>;
@@ -163,6 +168,7 @@ struct rtoc_ctx {
   hipStream_t stream2;  // forward half of the pipelined sweep
   hipEvent_t ev_fork, ev_join, ev_chunk[RTOC_MAX_CHUNK_EVENTS];
   int sweep_chunks;
+  int condense_split;  // 1: MJtJinv in its own kernel ahead of the condensation
   int cone_contacts, cone_dim;  // friction / wrench cones: max contacts (0 = off), force components per contact
   int cone_rows;                // PDIPM rows per contact: 5 friction cone, 17 contact wrench cone
   double* d_kkterr;             // [batch]
@@ -232,6 +238,7 @@ int rtoc_create(const rtoc_dims* dims, int max_stages, int batch, int device, rt
   HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   for (int i = 0; i < RTOC_MAX_CHUNK_EVENTS; ++i)
     HIP_TRY(hipEventCreateWithFlags(&c->ev_chunk[i], hipEventDisableTiming));
+  c->condense_split = 1;
   c->sweep_chunks = 1;  // measured on MI355X: chunked pipelining does not pay (forward waves do not fit next to the backward waves)
   const size_t per = (size_t)batch * max_stages;
   c->count[RTOC_BUF_KKT] = per * c->L.kkt.stride;
@@ -263,6 +270,9 @@ int rtoc_create(const rtoc_dims* dims, int max_stages, int batch, int device, rt
                                 ks->bwd_lds[v]));
   HIP_TRY(hipFuncSetAttribute((const void*)ks->cond, hipFuncAttributeMaxDynamicSharedMemorySize,
                               ks->cond_lds));
+  HIP_TRY(hipFuncSetAttribute((const void*)ks->cond_split, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              ks->cond_lds));
+  HIP_TRY(hipFuncSetAttribute((const void*)ks->mjt, hipFuncAttributeMaxDynamicSharedMemorySize, ks->mjt_lds));
   HIP_TRY(hipStreamSynchronize(c->stream));
   *out = c;
   return RTOC_OK;
@@ -357,6 +367,10 @@ int rtoc_set_option(rtoc_ctx* c, int option, int64_t value) {
         }
       return RTOC_ERR_BAD_ARG;
     }
+    case RTOC_OPT_CONDENSE_SPLIT:
+      if (value != 0 && value != 1) return RTOC_ERR_BAD_ARG;
+      c->condense_split = (int)value;
+      return RTOC_OK;
     case RTOC_OPT_SWEEP_CHUNKS:
       if (value < 1 || value > RTOC_MAX_CHUNK_EVENTS) return RTOC_ERR_BAD_ARG;
       c->sweep_chunks = (int)value;
@@ -508,7 +522,12 @@ static int launch_condense(rtoc_ctx* c) {
   a.kl = c->L.kkt;
   a.cl = c->L.cdd;
   const int nblocks = c->batch * (c->nstages - 1);
-  hipLaunchKernelGGL(c->ks->cond, dim3(nblocks), dim3(c->ks->cond_threads), c->ks->cond_lds, c->stream, a);
+  if (c->condense_split) {
+    hipLaunchKernelGGL(c->ks->mjt, dim3(nblocks), dim3(64), c->ks->mjt_lds, c->stream, a);
+    hipLaunchKernelGGL(c->ks->cond_split, dim3(nblocks), dim3(c->ks->cond_threads), c->ks->cond_lds, c->stream, a);
+  } else {
+    hipLaunchKernelGGL(c->ks->cond, dim3(nblocks), dim3(c->ks->cond_threads), c->ks->cond_lds, c->stream, a);
+  }
   HIP_TRY(hipGetLastError());
   return RTOC_OK;
 }
