@@ -1,4 +1,4 @@
-"""C++ host mirror (robotoc::RiccatiRecursion / UnconstrRiccatiRecursion over the C ABI): compiles with g++
+"""C++ host mirror (robotoc::RiccatiRecursion / UnconstrRiccatiRecursion / contact-dynamics free functions over the C ABI): compiles with g++
 on CPU, runs on the GPU."""
 import os
 import subprocess
@@ -6,7 +6,7 @@ import subprocess
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TESTS = ["riccati_recursion_test", "unconstr_riccati_recursion_test"]
+TESTS = ["riccati_recursion_test", "unconstr_riccati_recursion_test", "contact_dynamics_test"]
 
 
 def _paths(name):
