@@ -108,16 +108,17 @@ class SplitKKTMatrix {
       : Fxx(2 * r.dimv, 2 * r.dimv), Fvu(r.dimv, r.dimu), Qxx(2 * r.dimv, 2 * r.dimv),
         Qxu(2 * r.dimv, r.dimu), Quu(r.dimu, r.dimu), fx(2 * r.dimv), hx(2 * r.dimv), hu(r.dimu),
         Phix_full(r.max_dimf, 2 * r.dimv), Phiu_full(r.max_dimf, r.dimu), Phit_full(r.max_dimf),
-        Qaa(r.dimv, r.dimv), Qff_full(r.max_dimf, r.max_dimf), Qqf_full(r.dimv, r.max_dimf), ha(r.dimv),
-        hf_full(r.max_dimf) {}
+        Qaa(r.dimv, r.dimv), Qdvdv(r.dimv, r.dimv), Qff_full(r.max_dimf, r.max_dimf),
+        Qqf_full(r.dimv, r.max_dimf), ha(r.dimv), hf_full(r.max_dimf) {}
   Mat Fxx, Fvu, Qxx, Qxu, Quu;
   Vec fx, hx, hu;
   double Qtt = 0, Qtt_prev = 0;
   Mat Phix_full, Phiu_full;  // max-size backing; active rows = dims()
   Vec Phit_full;
   // un-condensed acceleration / contact-force blocks (split_kkt_matrix.hpp Qaa, Qff(), Qqf(), ha, hf()):
-  // inputs of condenseContactDynamics (robotoc_hip_dynamics.hpp); only Qaa.diagonal() is read
-  Mat Qaa, Qff_full, Qqf_full;
+  // inputs of condenseContactDynamics / condenseImpactDynamics (robotoc_hip_dynamics.hpp); only
+  // Qaa.diagonal() (Qdvdv.diagonal() on impact stages) is read
+  Mat Qaa, Qdvdv, Qff_full, Qqf_full;
   Vec ha, hf_full;
   void setSwitchingConstraintDimension(int dims) { dims_ = dims; }
   int dims() const { return dims_; }
@@ -130,9 +131,10 @@ class SplitKKTResidual {
  public:
   SplitKKTResidual() {}
   explicit SplitKKTResidual(const RobotDims& r)
-      : Fx(2 * r.dimv), lx(2 * r.dimv), lu(r.dimu), P_full(r.max_dimf), la(r.dimv), lf_full(r.max_dimf) {}
+      : Fx(2 * r.dimv), lx(2 * r.dimv), lu(r.dimu), P_full(r.max_dimf), la(r.dimv), ldv(r.dimv),
+        lf_full(r.max_dimf) {}
   Vec Fx, lx, lu, P_full;
-  Vec la, lf_full;  // split_kkt_residual.hpp la, lf(): inputs of condenseContactDynamics
+  Vec la, ldv, lf_full;  // split_kkt_residual.hpp la, ldv, lf(): inputs of condenseContact/ImpactDynamics
   double h = 0;
 };
 

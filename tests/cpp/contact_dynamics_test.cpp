@@ -1,6 +1,7 @@
 // C++ host-side test of robotoc::condenseContactDynamics / expandContactDynamicsPrimal / expandContactDynamicsDual
+// and condenseImpactDynamics / expandImpactDynamicsPrimal / expandImpactDynamicsDual
 // (robotoc_amd/host/robotoc_hip_dynamics.hpp) on the GPU, after the reference's
-// test/dynamics/contact_dynamics_test.cpp:86-229: a quadruped (dimv 18, dimu 12, 4 point contacts) with an
+// test/dynamics/contact_dynamics_test.cpp:86-229 and test/dynamics/impact_dynamics_test.cpp:73-129: a quadruped (dimv 18, dimu 12, 4 point contacts) with an
 // empty, a half and a full contact status; random linearisation data; every condensed member is checked
 // against the closed form written with naive dense algebra (the saddle-matrix inverse by Gauss-Jordan, i.e.
 // the defining identity of Robot::computeMJtJinv).  Exit code 0 = pass.
@@ -371,6 +372,136 @@ static void run(Robot& robot, const int dimf) {
   }
 }
 
+// after test/dynamics/impact_dynamics_test.cpp:73-129
+static void run_impact(Robot& robot, const int dimf) {
+  const int dimv = robot.dimv(), dimx = 2 * dimv, dimvf = dimv + dimf;
+  const ImpactStatus impact_status(dimf);
+  ContactDynamicsData data(robot);
+  data.setContactDimension(impact_status.dimf());
+  {
+    Mat Lo(dimv, dimv);
+    for (int j = 0; j < dimv; ++j)
+      for (int i = j; i < dimv; ++i) Lo(i, j) = rnd();
+    data.dIDddv = mul(Lo, false, Lo, true);
+    for (int i = 0; i < dimv; ++i) data.dIDddv(i, i) += 1.0;
+  }
+  // dIDCdqv = [dIDdq 0; dCdq dCdv] (RNEAImpactDerivatives has no velocity block)
+  for (int j = 0; j < dimx; ++j)
+    for (int i = 0; i < dimvf; ++i) data.dIDCdqv_full(i, j) = (i < dimv && j >= dimv) ? 0.0 : rnd();
+  for (int i = 0; i < dimvf; ++i) data.IDC_full(i) = rnd();
+  SplitKKTMatrix kkt_matrix(robot.dims());
+  SplitKKTResidual kkt_residual(robot.dims());
+  {
+    Mat S(dimx, dimx);
+    for (int j = 0; j < dimx; ++j)
+      for (int i = 0; i < dimx; ++i) S(i, j) = rnd();
+    kkt_matrix.Qxx = mul(S, false, S, true);
+    Mat F(dimf, dimf);
+    for (int j = 0; j < dimf; ++j)
+      for (int i = 0; i < dimf; ++i) F(i, j) = rnd();
+    const Mat FF = mul(F, false, F, true);
+    for (int j = 0; j < dimf; ++j)
+      for (int i = 0; i < dimf; ++i) kkt_matrix.Qff_full(i, j) = FF(i, j);
+  }
+  for (int i = 0; i < dimv; ++i) kkt_matrix.Qdvdv(i, i) = rnd();  // Qdvdv.setZero(); diagonal().setRandom() (:95-96)
+  for (int j = 0; j < dimf; ++j)
+    for (int i = 0; i < dimv; ++i) kkt_matrix.Qqf_full(i, j) = rnd();
+  // kkt_matrix.Fxx.setZero() (:94)
+  for (int i = 0; i < dimx; ++i) {
+    kkt_residual.Fx(i) = rnd();
+    kkt_residual.lx(i) = rnd();
+  }
+  for (int i = 0; i < dimv; ++i) kkt_residual.ldv(i) = rnd();
+  for (int i = 0; i < dimf; ++i) kkt_residual.lf_full(i) = rnd();
+  SplitKKTMatrix kkt_matrix_ref = kkt_matrix;
+  SplitKKTResidual kkt_residual_ref = kkt_residual;
+
+  condenseImpactDynamics(robot, impact_status, data, kkt_matrix, kkt_residual);
+
+  Mat saddle(dimvf, dimvf);
+  for (int j = 0; j < dimv; ++j)
+    for (int i = 0; i < dimv; ++i) saddle(i, j) = data.dIDddv(i, j);
+  for (int j = 0; j < dimv; ++j)
+    for (int i = 0; i < dimf; ++i) {
+      saddle(dimv + i, j) = data.dIDCdqv_full(dimv + i, dimv + j);  // dCdv
+      saddle(j, dimv + i) = data.dIDCdqv_full(dimv + i, dimv + j);
+    }
+  const Mat MJtJinv = inverse(saddle);  // robot.computeMJtJinv(dIDddv, dCdv) (:99)
+  const Mat dIDCdqv = block(data.dIDCdqv_full, 0, 0, dimvf, dimx);
+  Vec IDC(dimvf);
+  for (int i = 0; i < dimvf; ++i) IDC(i) = data.IDC_full(i);
+  const Mat MJtJinv_dIDCdqv = mul(MJtJinv, false, dIDCdqv, false);
+  const Vec MJtJinv_IDC = mulv(MJtJinv, false, IDC);
+  Mat Qdvdvff(dimvf, dimvf);
+  for (int i = 0; i < dimv; ++i) Qdvdvff(i, i) = kkt_matrix_ref.Qdvdv(i, i);
+  for (int j = 0; j < dimf; ++j)
+    for (int i = 0; i < dimf; ++i) Qdvdvff(dimv + i, dimv + j) = kkt_matrix_ref.Qff_full(i, j);
+  Mat Qdvfqv = mul(Qdvdvff, false, MJtJinv_dIDCdqv, false);
+  for (int j = 0; j < dimx; ++j)
+    for (int i = 0; i < dimvf; ++i) Qdvfqv(i, j) = -Qdvfqv(i, j);
+  for (int j = 0; j < dimv; ++j)
+    for (int i = 0; i < dimf; ++i) Qdvfqv(dimv + i, j) -= kkt_matrix_ref.Qqf_full(j, i);
+  Vec ldvf(dimvf);
+  for (int i = 0; i < dimv; ++i) ldvf(i) = kkt_residual_ref.ldv(i);
+  for (int i = 0; i < dimf; ++i) ldvf(dimv + i) = -kkt_residual_ref.lf_full(i);
+  {
+    const Vec t = mulv(Qdvdvff, false, MJtJinv_IDC);
+    for (int i = 0; i < dimvf; ++i) ldvf(i) -= t(i);
+  }
+  const Mat Qqf = block(kkt_matrix_ref.Qqf_full, 0, 0, dimv, dimf);
+  {
+    const Mat t = mul(MJtJinv_dIDCdqv, true, Qdvfqv, false);
+    const Mat t2 = mul(Qqf, false, block(MJtJinv_dIDCdqv, dimv, 0, dimf, dimx), false);
+    for (int j = 0; j < dimx; ++j)
+      for (int i = 0; i < dimx; ++i) kkt_matrix_ref.Qxx(i, j) -= t(i, j);
+    for (int j = 0; j < dimx; ++j)
+      for (int i = 0; i < dimv; ++i) kkt_matrix_ref.Qxx(i, j) += t2(i, j);
+    const Vec tv = mulv(MJtJinv_dIDCdqv, true, ldvf);
+    for (int i = 0; i < dimx; ++i) kkt_residual_ref.lx(i) -= tv(i);
+    Vec tail(dimf);
+    for (int i = 0; i < dimf; ++i) tail(i) = MJtJinv_IDC(dimv + i);
+    const Vec t3 = mulv(Qqf, false, tail);
+    for (int i = 0; i < dimv; ++i) kkt_residual_ref.lx(i) += t3(i);
+  }
+  for (int j = 0; j < dimv; ++j)
+    for (int i = 0; i < dimv; ++i) kkt_matrix_ref.Fxx(dimv + i, dimv + j) = (i == j) ? 1.0 : 0.0;  // Fvv().setIdentity()
+  for (int j = 0; j < dimx; ++j)
+    for (int i = 0; i < dimv; ++i) kkt_matrix_ref.Fxx(dimv + i, j) -= MJtJinv_dIDCdqv(i, j);
+  for (int i = 0; i < dimv; ++i) kkt_residual_ref.Fx(dimv + i) -= MJtJinv_IDC(i);
+
+  expect_approx("impact MJtJinv", data.MJtJinv_full, MJtJinv, dimvf, dimvf);
+  expect_approx("impact MJtJinv_dIDCdqv", data.MJtJinv_dIDCdqv_full, MJtJinv_dIDCdqv, dimvf, dimx);
+  expect_approx("impact MJtJinv_IDC", data.MJtJinv_IDC_full, MJtJinv_IDC, dimvf);
+  expect_approx("impact Qdvfqv", data.Qafqv_full, Qdvfqv, dimvf, dimx);
+  expect_approx("impact ldvf", data.laf_full, ldvf, dimvf);
+  expect_approx("impact Qxx", kkt_matrix.Qxx, kkt_matrix_ref.Qxx, dimx, dimx);
+  expect_approx("impact Fxx", kkt_matrix.Fxx, kkt_matrix_ref.Fxx, dimx, dimx);
+  expect_approx("impact lx", kkt_residual.lx, kkt_residual_ref.lx, dimx);
+  expect_approx("impact Fx", kkt_residual.Fx, kkt_residual_ref.Fx, dimx);
+
+  SplitDirection d(robot.dims()), d_next(robot.dims());
+  for (int i = 0; i < dimx; ++i) {
+    d.dx(i) = rnd();
+    d_next.dlmdgmm(i) = rnd();
+  }
+  expandImpactDynamicsPrimal(data, d);
+  Vec ddvf_ref(dimvf);
+  {
+    Vec t = mulv(dIDCdqv, false, d.dx);
+    for (int i = 0; i < dimvf; ++i) t(i) += IDC(i);
+    const Vec r = mulv(MJtJinv, false, t);
+    for (int i = 0; i < dimvf; ++i) ddvf_ref(i) = (i < dimv ? -r(i) : r(i));
+  }
+  expect_approx("impact ddvf", d.daf_full, ddvf_ref, dimvf);
+  expandImpactDynamicsDual(data, d_next, d);
+  Vec rhs = mulv(Qdvfqv, false, d.dx);
+  for (int i = 0; i < dimvf; ++i) rhs(i) += ldvf(i);
+  for (int i = 0; i < dimv; ++i) rhs(i) += d_next.dlmdgmm(dimv + i);
+  Vec dbetamu_ref = mulv(MJtJinv, false, rhs);
+  for (int i = 0; i < dimvf; ++i) dbetamu_ref(i) = -dbetamu_ref(i);
+  expect_approx("impact dbetamu", d.dbetamu_full, dbetamu_ref, dimvf);
+}
+
 int main() {
   if (rtoc_device_count() < 1) {
     std::fprintf(stderr, "no HIP device\n");
@@ -379,6 +510,8 @@ int main() {
   Robot robot(18, 12, 6, 12);  // quadruped: floating base, four point contacts
   for (int rep = 0; rep < 3; ++rep)
     for (int dimf : {0, 6, 12}) run(robot, dimf);
+  for (int rep = 0; rep < 2; ++rep)
+    for (int dimf : {6, 12}) run_impact(robot, dimf);
   // argument checks in the reference's style
   bool threw = false;
   try {
