@@ -404,48 +404,57 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a, const
       auto run_pass = [&](auto tm0c, auto tm1c) {
         constexpr int TM0 = decltype(tm0c)::value, TM1 = decltype(tm1c)::value;
         if constexpr (TM1 > TM0) {
-          // operands of k-step ks: software-pipelined one step ahead (the scheduler otherwise hoists
-          // the LDS loads of all nine steps at once and spills)
-          auto load_ops = [&](int ks, double (&av)[TMA], double (&bv)[CNT]) {
+          // Operands of k-step ks, software-pipelined one step ahead in two halves: the LDS reads of step
+          // ks+1 are ISSUED before the MFMAs of step ks (scheduling barrier in between -- left alone, the
+          // scheduler sinks them behind the MFMAs and every step then waits out an LDS round trip), and
+          // only masked / selected into operands after those MFMAs, when they have landed.
+          struct Raw {
+            double a[TMA], amix, b[CNT];
+          };
+          auto load_raw = [&](int ks, Raw& r) {
+            r.amix = 0.0;
+#pragma unroll
+            for (int tm = TM0; tm < TM1; ++tm) {
+              if (tm * 16 + 15 < NX) {
+                r.a[tm] = sP[li + q * LDP + tm * 16 + ks * 4 * LDP];
+              } else if (tm * 16 >= NX) {
+                r.a[tm] = sPB[q + li * LDP + (tm * 16 - NX) * LDP + ks * 4];
+              } else {  // the tile that straddles P+ rows and PB^T rows
+                r.a[tm] = sP[li + q * LDP + tm * 16 + ks * 4 * LDP];
+                r.amix = sPB[q + li * LDP + (tm * 16 - NX) * LDP + ks * 4];
+              }
+            }
+#pragma unroll
+            for (int c = 0; c < CNT; ++c) r.b[c] = (c < CNT - 1) ? pb_[ks * 4 + c * 16 * LDP] : pbl_[ks * 4];
+          };
+          auto finish_ops = [&](int ks, const Raw& r, double (&av)[TMA], double (&bv)[CNT]) {
             const bool kok = (ks * 4 + 3 < NX) || (ks * 4 + q < NX);
 #pragma unroll
             for (int tm = TM0; tm < TM1; ++tm) {
               const int i = tm * 16 + li;
-              double v;
-              if (tm * 16 + 15 < NX) {
-                v = sP[li + q * LDP + tm * 16 + ks * 4 * LDP];
-              } else if (tm * 16 >= NX) {
-                v = sPB[q + li * LDP + (tm * 16 - NX) * LDP + ks * 4];
-                if (tm * 16 + 15 >= NX + NU) v = (i < NX + NU) ? v : 0.0;
-              } else {
-                const double vp = sP[li + q * LDP + tm * 16 + ks * 4 * LDP];
-                const double vb = sPB[q + li * LDP + (tm * 16 - NX) * LDP + ks * 4];
-                v = (i < NX) ? vp : vb;
-                if (tm * 16 + 15 >= NX + NU) v = (i < NX + NU) ? v : 0.0;
-              }
+              double v = r.a[tm];
+              if (tm * 16 + 15 >= NX && tm * 16 < NX) v = (i < NX) ? v : r.amix;
+              if (tm * 16 + 15 >= NX && tm * 16 + 15 >= NX + NU) v = (i < NX + NU) ? v : 0.0;
               av[tm] = kok ? v : 0.0;
             }
+            // B columns are NOT masked: an output column depends on its own B column only, and the columns
+            // beyond A | Fx | fx are never read back (finite or not, whatever LDS holds there is harmless).
+            // Every VALU instruction between two f64 MFMAs costs its full issue time (shared port).
 #pragma unroll
-            for (int c = 0; c < CNT; ++c) {
-              if (c < CNT - 1) {
-                const double v = pb_[ks * 4 + c * 16 * LDP];
-                bv[c] = (kok && (c * 16 + li < NX)) ? v : 0.0;
-              } else {
-                const double v = pbl_[ks * 4];  // A columns, then Fx as column NX
-                bv[c] = (kok && okl) ? v : 0.0;
-              }
-            }
+            for (int c = 0; c < CNT; ++c) bv[c] = kok ? r.b[c] : 0.0;
           };
-          double av[2][TMA], bv[2][CNT];
-          load_ops(0, av[0], bv[0]);
+          Raw raw[2];
+          load_raw(0, raw[0]);
 #pragma unroll
           for (int ks = 0; ks < KSA; ++ks) {
-            if (ks + 1 < KSA) load_ops(ks + 1, av[(ks + 1) & 1], bv[(ks + 1) & 1]);
+            if (ks + 1 < KSA) load_raw(ks + 1, raw[(ks + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            double av[TMA], bv[CNT];
+            finish_ops(ks, raw[ks & 1], av, bv);
 #pragma unroll
             for (int tm = TM0; tm < TM1; ++tm)
 #pragma unroll
-              for (int c = 0; c < CNT; ++c)
-                pa[tm][c] = mfma16(av[ks & 1][tm], bv[ks & 1][c], pa[tm][c]);
+              for (int c = 0; c < CNT; ++c) pa[tm][c] = mfma16(av[tm], bv[c], pa[tm][c]);
             __builtin_amdgcn_sched_barrier(0);
           }
         }
@@ -530,25 +539,27 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a, const
       const double* pbf_ = sA + q + li * LDP;
       // k runs over the register groups (tm, r) of PAa that hold P rows: g = 4*tm + r < KSF
       constexpr int KSF = (NX + 3) / 4;
+      // same two-half software pipeline as the P+ A product: issue the reads of step g+1, barrier, mask and
+      // multiply step g
       auto load_b = [&](int gidx, double (&bv)[TNX]) {
-        const bool kok = (gidx * 4 + 3 < NX) || (gidx * 4 + q < NX);
 #pragma unroll
-        for (int t = 0; t < TNX; ++t) {
-          const double v = pbf_[gidx * 4 + t * 16 * LDP];
-          bv[t] = (kok && (t * 16 + li < NX)) ? v : 0.0;
-        }
+        for (int t = 0; t < TNX; ++t) bv[t] = pbf_[gidx * 4 + t * 16 * LDP];
       };
       double bvf[2][TNX];
       load_b(0, bvf[0]);
 #pragma unroll
       for (int gidx = 0; gidx < KSF; ++gidx) {
         if (gidx + 1 < KSF) load_b(gidx + 1, bvf[(gidx + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
         const bool kok = (gidx * 4 + 3 < NX) || (gidx * 4 + q < NX);
+        double bm[TNX];  // columns >= NX unmasked: they only reach entries of F that are never stored
+#pragma unroll
+        for (int t = 0; t < TNX; ++t) bm[t] = kok ? bvf[gidx & 1][t] : 0.0;
 #pragma unroll
         for (int c = 0; c < CNT; ++c) {
           const double avv = kok ? pa[gidx / 4][c][gidx % 4] : 0.0;
 #pragma unroll
-          for (int t = c; t < TNX; ++t) f[c][t] = mfma16(avv, bvf[gidx & 1][t], f[c][t]);
+          for (int t = c; t < TNX; ++t) f[c][t] = mfma16(avv, bm[t], f[c][t]);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
