@@ -31,6 +31,8 @@
 #define RTOC_COND_NW 3
 #endif
 
+#include "friction_cone.hpp"
+
 namespace rtoc {
 
 __device__ __forceinline__ void wave_lds_sync_() {
@@ -61,6 +63,12 @@ struct CondArgs {
   int nrows;
   rtoc_record_layout nl;
   rtoc_record_layout kl, cl;
+  // friction / wrench cone rows condensed by mjtjinv_kernel (split condensation): 0 = none (or done by their
+  // own kernel), RTOC_FRICTION_ROWS, RTOC_WRENCH_ROWS
+  int cone_rows;
+  const double* cone;
+  double* cone_con;  // constraint records (the box rows' `con` may be null when only cones are set)
+  int cone_contacts, cone_dim, cone_row0, cone_stride, cone_dgdf_off;
 };
 
 struct ExpArgs {
@@ -731,6 +739,38 @@ __global__ __launch_bounds__(64) void mjtjinv_kernel(CondArgs a) {
   constexpr rtoc_record_layout CL = SL.cdd;
   double* cr = a.cdd + ((size_t)b * a.nstages + st) * CL.stride;
   unsigned stat = 0;
+  // Constraints::condenseSlackAndDual of the cone rows (intermediate_stage.cpp:134-135): they only touch
+  // Qqq, Qqf, Qff, lq, lf, which this kernel does not read -- they ride here, in the shadow of the loads
+  // below, and are in HBM before the second kernel starts.  Scratch: the not yet initialised Lam.
+  if constexpr (NF > 0) if (a.cone_rows != 0) {
+    static_assert(ConeScratch<NV, NF>::DOUBLES <= C::O_L, "cone scratch is aliased onto Lam");
+    ConeArgs ca;
+    ca.kkt = a.kkt;
+    ca.cdd = a.cdd;
+    ca.con = a.cone_con;
+    ca.cone = a.cone;
+    ca.dir = nullptr;
+    ca.grid = a.grid;
+    ca.steps = nullptr;
+    ca.nstages = a.nstages;
+    ca.batch = a.batch;
+    ca.max_contacts = a.cone_contacts;
+    ca.contact_dim = a.cone_dim;
+    ca.row0 = a.cone_row0;
+    ca.rows_per_contact = a.cone_rows;
+    ca.cone_stride = a.cone_stride;
+    ca.dgdf_off = a.cone_dgdf_off;
+    ca.tau = 0.0;
+    ca.kl = a.kl;
+    ca.cl = a.cl;
+    ca.nl = a.nl;
+    ca.dl = a.cl;  // unused by the condensation
+    if (a.cone_rows == RTOC_WRENCH_ROWS)
+      wrench_condense_body<NV, NF>(ca, b, st, lane, smem);
+    else
+      cone_condense_body<NV, NF>(ca, b, st, lane, smem);
+    cone_wave_sync();  // scratch is reused below
+  }
   typedef double dbl2 __attribute__((ext_vector_type(2)));
   constexpr int H_L = (NV * NV + 1) / 2, N_L = (H_L + NT - 1) / NT, N_J = (C::NFP * NV + NT - 1) / NT;
   dbl2 gL[N_L];

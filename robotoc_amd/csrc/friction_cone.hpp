@@ -33,14 +33,27 @@ struct ConeArgs {
   rtoc_record_layout kl, cl, nl, dl;
 };
 
+// the LDS writes of this wave become visible to its other lanes (one wave per grid point: no s_barrier needed)
+__device__ __forceinline__ void cone_wave_sync() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// scratch doubles the condensation bodies need (LDS, owned by one wave for the duration of the call)
 template <int NV, int NF>
-__global__ __launch_bounds__(64) void cone_condense_kernel(ConeArgs a) {
+struct ConeScratch {
+  static constexpr int MAXC = NF / 3 > 0 ? NF / 3 : 1, MAXW = NF / 6 > 0 ? NF / 6 : 1;
+  static constexpr int FRICTION = MAXC * (5 * NV + 15 + 5 + 5);
+  static constexpr int WRENCH = MAXW * (RTOC_WRENCH_ROWS * 6 + 2 * RTOC_WRENCH_ROWS);
+  static constexpr int DOUBLES = FRICTION > WRENCH ? FRICTION : WRENCH;
+};
+
+// One wave, one (instance b, grid point st).  Also called from mjtjinv_kernel (condense.hpp), where the
+// rows ride along with the first kernel of the split condensation instead of costing a launch of their own.
+template <int NV, int NF>
+__device__ __forceinline__ void cone_condense_body(const ConeArgs& a, const int b, const int st, const int lane,
+                                                   double* const scratch) {
   constexpr int NX = 2 * NV, NFP = NF > 0 ? NF : 1, MAXC = NF / 3 > 0 ? NF / 3 : 1;
-  const int lane = threadIdx.x;
-  const int item = blockIdx.x;
-  const int nst1 = a.nstages - 1;
-  const int b = item / nst1, st = item % nst1;
-  if (b >= a.batch) return;
   const rtoc_grid g = a.grid[st];
   const int nact = g.dimf / a.contact_dim;
   if (nact == 0) return;
@@ -58,7 +71,10 @@ __global__ __launch_bounds__(64) void cone_condense_kernel(ConeArgs a) {
   // entries are accumulated over the contacts in registers -- in contact order, like the reference's
   // loop (:199-233) -- and get one read-modify-write each: two HBM latencies per grid point instead
   // of two per contact.
-  __shared__ double dq[MAXC][5 * NV], df[MAXC][15], cond[MAXC][5], rr[MAXC][5];
+  double(*const dq)[5 * NV] = reinterpret_cast<double(*)[5 * NV]>(scratch);
+  double(*const df)[15] = reinterpret_cast<double(*)[15]>(scratch + MAXC * 5 * NV);
+  double(*const cond)[5] = reinterpret_cast<double(*)[5]>(scratch + MAXC * (5 * NV + 15));
+  double(*const rr)[5] = reinterpret_cast<double(*)[5]>(scratch + MAXC * (5 * NV + 15 + 5));
   for (int e = lane; e < nact * 5 * NV; e += 64) dq[e / (5 * NV)][e % (5 * NV)] = cone[e];
   for (int e = lane; e < nact * 15; e += 64) df[e / 15][e % 15] = cone[a.dgdf_off + e];
   if (lane < 5 * nact) {
@@ -78,7 +94,7 @@ __global__ __launch_bounds__(64) void cone_condense_kernel(ConeArgs a) {
     cq[p] = Qxx[(e < NV * NV ? e % NV : 0) + (size_t)(e < NV * NV ? e / NV : 0) * NX];
   }
   const double clx = lx[lane < NV ? lane : 0];
-  __syncthreads();
+  cone_wave_sync();
   // lq += dg_dq^T cond (:206)
   if (lane < NV) {
     double v = clx;
@@ -132,6 +148,16 @@ __global__ __launch_bounds__(64) void cone_condense_kernel(ConeArgs a) {
       Qff[(stack + m) + (size_t)(stack + n) * NFP] += acc;
     }
   }
+}
+
+template <int NV, int NF>
+__global__ __launch_bounds__(64) void cone_condense_kernel(ConeArgs a) {
+  __shared__ double scratch[ConeScratch<NV, NF>::DOUBLES];
+  const int item = blockIdx.x;
+  const int nst1 = a.nstages - 1;
+  const int b = item / nst1, st = item % nst1;
+  if (b >= a.batch) return;
+  cone_condense_body<NV, NF>(a, b, st, threadIdx.x, scratch);
 }
 
 // expandSlackAndDual (:238-268) + fraction-to-boundary (pdipm.hxx:121-142)
@@ -202,14 +228,10 @@ __global__ __launch_bounds__(64) void cone_update_kernel(ConeArgs a) {
 // (51 rows) fit the one wave that serves a grid point.
 // ---------------------------------------------------------------------------------------------
 template <int NV, int NF>
-__global__ __launch_bounds__(64) void wrench_condense_kernel(ConeArgs a) {
+__device__ __forceinline__ void wrench_condense_body(const ConeArgs& a, const int b, const int st, const int lane,
+                                                     double* const scratch) {
   constexpr int NFP = NF > 0 ? NF : 1, MAXC = NF / 6 > 0 ? NF / 6 : 1, WR = RTOC_WRENCH_ROWS;
   static_assert(MAXC * WR <= 64, "one lane per wrench-cone row");
-  const int lane = threadIdx.x;
-  const int item = blockIdx.x;
-  const int nst1 = a.nstages - 1;
-  const int b = item / nst1, st = item % nst1;
-  if (b >= a.batch) return;
   const int nact = a.grid[st].dimf / 6;
   if (nact == 0) return;
   const size_t rec = (size_t)b * a.nstages + st;
@@ -218,7 +240,9 @@ __global__ __launch_bounds__(64) void wrench_condense_kernel(ConeArgs a) {
   const double* cone = a.cone + rec * a.cone_stride;
   double* Qff = cr + a.cl.off[RTOC_CDD_QFF];
   double* lf = cr + a.cl.off[RTOC_CDD_LF];
-  __shared__ double J[MAXC][WR * 6], cond[MAXC][WR], rr[MAXC][WR];
+  double(*const J)[WR * 6] = reinterpret_cast<double(*)[WR * 6]>(scratch);
+  double(*const cond)[WR] = reinterpret_cast<double(*)[WR]>(scratch + MAXC * WR * 6);
+  double(*const rr)[WR] = reinterpret_cast<double(*)[WR]>(scratch + MAXC * WR * 7);
   for (int e = lane; e < nact * WR * 6; e += 64) J[e / (WR * 6)][e % (WR * 6)] = cone[e];
   if (lane < WR * nact) {
     const int r = a.row0 + lane;
@@ -230,7 +254,7 @@ __global__ __launch_bounds__(64) void wrench_condense_kernel(ConeArgs a) {
   }
   // inactive rows keep cond = 0 like data.cond.setZero() (:213)
   if (lane >= WR * nact && lane < WR * a.max_contacts) nr[a.nl.off[RTOC_CON_COND] + a.row0 + lane] = 0.0;
-  __syncthreads();
+  cone_wave_sync();
   for (int e = lane; e < nact * 36; e += 64) {
     const int kk = e / 36, ww = e % 36, mm = ww % 6, nn = ww / 6, stack = kk * 6;
     double acc = 0.0;
@@ -245,6 +269,16 @@ __global__ __launch_bounds__(64) void wrench_condense_kernel(ConeArgs a) {
     for (int j = 0; j < WR; ++j) acc += J[kk][j + WR * mm] * cond[kk][j];
     lf[kk * 6 + mm] += acc;  // (:229-230)
   }
+}
+
+template <int NV, int NF>
+__global__ __launch_bounds__(64) void wrench_condense_kernel(ConeArgs a) {
+  __shared__ double scratch[ConeScratch<NV, NF>::DOUBLES];
+  const int item = blockIdx.x;
+  const int nst1 = a.nstages - 1;
+  const int b = item / nst1, st = item % nst1;
+  if (b >= a.batch) return;
+  wrench_condense_body<NV, NF>(a, b, st, threadIdx.x, scratch);
 }
 
 // expandSlackAndDual (:241-270) + fraction-to-boundary (pdipm.hxx:121-142)

@@ -522,6 +522,19 @@ static int launch_condense(rtoc_ctx* c) {
   a.kl = c->L.kkt;
   a.cl = c->L.cdd;
   const int nblocks = c->batch * (c->nstages - 1);
+  a.cone_rows = 0;
+  if (c->condense_split && c->cone_contacts > 0) {  // the cone rows ride with the MJtJinv kernel
+    if (!c->buf[RTOC_BUF_CONE] || !c->buf[RTOC_BUF_CON]) return RTOC_ERR_NOT_READY;
+    const bool wrench = c->cone_rows == RTOC_WRENCH_ROWS;
+    a.cone_rows = c->cone_rows;
+    a.cone_con = c->buf[RTOC_BUF_CON];
+    a.cone = c->buf[RTOC_BUF_CONE];
+    a.cone_contacts = c->cone_contacts;
+    a.cone_dim = c->cone_dim;
+    a.cone_row0 = c->dims.nc_max - c->cone_rows * c->cone_contacts;
+    a.cone_stride = wrench ? rtoc_wrench_cone_stride(c->cone_contacts) : rtoc_cone_stride(c->dims.nv, c->cone_contacts);
+    a.cone_dgdf_off = rtoc_cone_dgdf_off(c->dims.nv, c->cone_contacts);
+  }
   if (c->condense_split) {
     hipLaunchKernelGGL(c->ks->mjt, dim3(nblocks), dim3(64), c->ks->mjt_lds, c->stream, a);
     hipLaunchKernelGGL(c->ks->cond_split, dim3(nblocks), dim3(c->ks->cond_threads), c->ks->cond_lds, c->stream, a);
@@ -644,7 +657,7 @@ int rtoc_compute_initial_state_direction(rtoc_ctx* c) {
 int rtoc_condense(rtoc_ctx* c) {
   CHECK_READY(c);
   int rc = RTOC_OK;
-  if (c->cone_contacts > 0) rc = launch_cones(c, 0, 0.0);  // Constraints::condenseSlackAndDual first
+  if (c->cone_contacts > 0 && !c->condense_split) rc = launch_cones(c, 0, 0.0);  // Constraints::condenseSlackAndDual first
   if (!rc) rc = launch_condense(c);
   if (!rc && c->buf[RTOC_BUF_SE3] && c->dims.np == 6) rc = launch_state_correction(c, 0);
   return rc;

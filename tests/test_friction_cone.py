@@ -170,3 +170,35 @@ def test_friction_cone_rows_need_room_in_the_constraint_record():
             ctx.set_friction_cones(MC, CD)
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cones", ["friction", "none"])
+def test_split_and_fused_condensation_agree(cones):
+    """RTOC_OPT_CONDENSE_SPLIT: MJtJinv (+ the cone rows) in their own kernel vs everything in one kernel."""
+    from robotoc_amd import capi
+    dims, grids, _ = pr.config_anymal_trot()
+    batch = 3
+    out = {}
+    for split in (1, 0):
+        ctx = capi.Context(dims, len(grids), batch, 0)
+        try:
+            L = ctx.L
+            ctx.set_grid(grids)
+            ctx.set_condense_split(split)
+            kkt, cdd = pr.make_precondense_batch(L, grids, batch)
+            con = pr.make_constraint_batch(L, grids, batch)
+            ctx.set_constraint_rows(joint_limit_rows(dims))
+            for buf, arr in ((BUF_KKT, kkt), (BUF_CDD, cdd), (BUF_CON, con)):
+                ctx.upload(buf, arr)
+            if cones == "friction":
+                ctx.set_friction_cones(MC, CD)
+                ctx.upload(BUF_CONE, pr.make_cone_batch(L, grids, batch, MC))
+            ctx.condense()
+            assert (ctx.status() == 0).all()
+            out[split] = (ctx.download_records(BUF_KKT, "kkt"), ctx.download_records(BUF_CDD, "cdd"),
+                          ctx.download_records(BUF_CON, "con"))
+        finally:
+            ctx.close()
+    for a, b in zip(out[1], out[0]):
+        assert np.allclose(a, b, rtol=1e-11, atol=1e-12)
