@@ -60,6 +60,7 @@ struct CondArgs {
   double* con;               // constraint records or nullptr
   const rtoc_box_row* rows;  // [nrows] joint-limit rows (device)
   const int* entry;          // CSR of the rows per primal entry: [2nv+nu+1] offsets, then row ids
+  const int4* pair;          // per primal entry: {row0, row1, sign0 | level0 << 8, sign1 | level1 << 8}, row = -1: none
   int nrows;
   rtoc_record_layout nl;
   rtoc_record_layout kl, cl;
@@ -440,7 +441,30 @@ __global__ __launch_bounds__(64 * RTOC_COND_NW) void condense_kernel(CondArgs a)
       // one lane per primal entry (q_k, v_k, u_k): a lower and an upper limit hit the same diagonal
       // entry, so every entry is accumulated by a single lane in row order (deterministic, no atomics)
       const int* rowid = a.entry + (2 * NV + NU + 1);
-      for (int e = a.entry[t]; e < a.entry[t + 1]; ++e) {
+      // the first two rows of the entry (a lower and an upper limit: all there is for joint limits) come
+      // from one packed descriptor, and their constraint data is fetched unconditionally, all at once:
+      // descriptor -> data is two round trips instead of offsets -> row id -> row -> data, twice over
+      const int4 pd = a.pair[t];
+      {
+        const int r0 = pd.x >= 0 ? pd.x : 0, r1 = pd.y >= 0 ? pd.y : 0;
+        const double s0 = nr[no[RTOC_CON_SLACK] + r0], d0 = nr[no[RTOC_CON_DUAL] + r0],
+                     q0 = nr[no[RTOC_CON_RESIDUAL] + r0], c0 = nr[no[RTOC_CON_CMPL] + r0];
+        const double s1 = nr[no[RTOC_CON_SLACK] + r1], d1 = nr[no[RTOC_CON_DUAL] + r1],
+                     q1 = nr[no[RTOC_CON_RESIDUAL] + r1], c1 = nr[no[RTOC_CON_CMPL] + r1];
+        if (pd.x >= 0 && g.time_stage >= (pd.z >> 8)) {
+          const double cond = (d0 * q0 - c0) / s0;
+          nr[no[RTOC_CON_COND] + r0] = cond;
+          hess += d0 / s0;
+          grad += (double)(signed char)(pd.z & 0xff) * cond;
+        }
+        if (pd.y >= 0 && g.time_stage >= (pd.w >> 8)) {
+          const double cond = (d1 * q1 - c1) / s1;
+          nr[no[RTOC_CON_COND] + r1] = cond;
+          hess += d1 / s1;
+          grad += (double)(signed char)(pd.w & 0xff) * cond;
+        }
+      }
+      for (int e = a.entry[t] + 2; e < a.entry[t + 1]; ++e) {  // further rows on the same entry (none for joint limits)
         const int r = rowid[e];
         const rtoc_box_row row = a.rows[r];
         if (g.time_stage >= row.level) {

@@ -156,6 +156,7 @@ struct rtoc_ctx {
   rtoc_box_row* d_rows;
   rtoc_box_row* h_rows;  // host copies (stage dump)
   rtoc_grid* h_grid;
+  int* d_pair;   // first two rows of every primal entry, packed (int4 per entry)
   int* d_entry;  // CSR over the primal entries (q_0..,v_0..,u_0..): [ne+1] offsets, then [nrows] row ids
   int nrows;
   uint32_t* d_status;
@@ -290,6 +291,7 @@ int rtoc_destroy(rtoc_ctx* c) {
   free(c->h_grid);
   if (c->d_kkterr) (void)hipFree(c->d_kkterr);
   if (c->d_entry) (void)hipFree(c->d_entry);
+  if (c->d_pair) (void)hipFree(c->d_pair);
   (void)hipFree(c->d_status);
   if (c->d_prof) (void)hipFree(c->d_prof);
   (void)hipEventDestroy(c->ev0);
@@ -517,6 +519,7 @@ static int launch_condense(rtoc_ctx* c) {
   a.con = (c->nrows > 0) ? c->buf[RTOC_BUF_CON] : nullptr;
   a.rows = c->d_rows;
   a.entry = c->d_entry;
+  a.pair = reinterpret_cast<const int4*>(c->d_pair);
   a.nrows = c->nrows;
   a.nl = c->L.con;
   a.kl = c->L.kkt;
@@ -854,6 +857,16 @@ int rtoc_set_constraint_rows(rtoc_ctx* c, const rtoc_box_row* rows, int nrows) {
     if (!c->d_entry)
       HIP_TRY(hipMalloc((void**)&c->d_entry, sizeof(int) * (ne + 1 + c->dims.nc_max)));
     HIP_TRY(hipMemcpyAsync(c->d_entry, csr.data(), sizeof(int) * csr.size(), hipMemcpyHostToDevice, c->stream));
+    // the first two rows of every entry, packed (condense.hpp)
+    std::vector<int> pair(4 * (size_t)ne, -1);
+    for (int e = 0; e < ne; ++e)
+      for (int k = 0; k < 2 && csr[e] + k < csr[e + 1]; ++k) {
+        const int r = csr[ne + 1 + csr[e] + k];
+        pair[4 * e + k] = r;
+        pair[4 * e + 2 + k] = (rows[r].sign & 0xff) | (rows[r].level << 8);
+      }
+    if (!c->d_pair) HIP_TRY(hipMalloc((void**)&c->d_pair, sizeof(int) * 4 * ne));
+    HIP_TRY(hipMemcpyAsync(c->d_pair, pair.data(), sizeof(int) * pair.size(), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
   }
   if (nrows > 0) {
