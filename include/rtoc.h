@@ -225,6 +225,18 @@ int rtoc_kkt_error(rtoc_ctx* ctx, double* host_out, int count);
  * part of q (first 7 entries: the SE3 integrateConfiguration of Pinocchio) is left to the CPU side. */
 int rtoc_integrate_solution(rtoc_ctx* ctx);
 
+/* One Newton / SQP iteration of the whole batch as ONE launch sequence without host synchronisation
+ * (OCPSolver::updateSolution, src/solver/ocp_solver.cpp:111-145, downstream of the linearisation):
+ * KKT error of the freshly linearised records -> rtoc_condense -> rtoc_riccati_sweep -> rtoc_expand(tau)
+ * (directions + fraction-to-boundary step sizes, resident in RTOC_BUF_STEP) -> instances whose
+ * sqrt(KKT error) <= kkt_tol get step sizes 0 and keep their iterate (the convergence test of
+ * ocp_solver.cpp:161-166 per instance, on the device) -> rtoc_update -> rtoc_integrate_solution (if
+ * RTOC_BUF_SOL exists).  Needs dx0 (RTOC_BUF_DX0) like rtoc_riccati_forward.  The caller re-linearises
+ * (CPU side) and uploads before the next iteration. */
+int rtoc_newton_iteration(rtoc_ctx* ctx, double kkt_tol, double fraction_to_boundary_rule);
+/* Number of instances the last rtoc_newton_iteration found converged (synchronises). */
+int rtoc_converged_count(rtoc_ctx* ctx, int* host_count);
+
 /* ---- stage dump / replay ----------------------------------------
  * A self-describing file of everything a context holds at the evalKKT boundary
  * (IntermediateStage::evalKKT outputs, src/ocp/intermediate_stage.cpp:113-148): dims, grid, box rows,

@@ -25,7 +25,7 @@ EXPORTS = [
     "rtoc_sync", "rtoc_time_phase", "rtoc_set_constraint_rows", "rtoc_gather_directions", "rtoc_error_string",
     "rtoc_riccati_sweep", "rtoc_correct_state_equation", "rtoc_correct_costate_direction",
     "rtoc_compute_initial_state_direction", "rtoc_unconstr_condense", "rtoc_unconstr_expand",
-    "rtoc_set_friction_cones", "rtoc_set_wrench_cones", "rtoc_wrench_cone_matrix", "rtoc_save_stage_dump", "rtoc_load_stage_dump", "rtoc_kkt_error", "rtoc_integrate_solution",
+    "rtoc_newton_iteration", "rtoc_converged_count", "rtoc_set_friction_cones", "rtoc_set_wrench_cones", "rtoc_wrench_cone_matrix", "rtoc_save_stage_dump", "rtoc_load_stage_dump", "rtoc_kkt_error", "rtoc_integrate_solution",
 ]
 
 
@@ -93,6 +93,8 @@ def lib():
         L.rtoc_set_constraint_rows.argtypes = [vp, C.POINTER(BoxRow), C.c_int]
         L.rtoc_set_friction_cones.argtypes = [vp, C.c_int, C.c_int]
         L.rtoc_set_wrench_cones.argtypes = [vp, C.c_int]
+        L.rtoc_newton_iteration.argtypes = [vp, C.c_double, C.c_double]
+        L.rtoc_converged_count.argtypes = [vp, C.POINTER(C.c_int)]
         L.rtoc_wrench_cone_matrix.argtypes = [C.c_double, C.c_double, C.c_double, C.POINTER(C.c_double)]
         L.rtoc_save_stage_dump.argtypes = [vp, C.c_char_p, C.c_uint]
         L.rtoc_kkt_error.argtypes = [vp, dp, C.c_int]
@@ -220,6 +222,16 @@ class Context:
 
     def set_sweep_chunks(self, n):
         _chk(lib().rtoc_set_option(self._h, OPT_SWEEP_CHUNKS, int(n)))
+
+    def newton_iteration(self, kkt_tol, tau=0.995):
+        """rtoc_newton_iteration: KKT error -> condense -> sweep -> expand -> converged-instance mask ->
+        update -> integrate, one launch sequence; returns nothing (asynchronous)."""
+        _chk(lib().rtoc_newton_iteration(self._h, float(kkt_tol), float(tau)))
+
+    def converged_count(self):
+        n = C.c_int(0)
+        _chk(lib().rtoc_converged_count(self._h, C.byref(n)))
+        return n.value
 
     def set_condense_split(self, on):
         """RTOC_OPT_CONDENSE_SPLIT: MJtJinv in its own kernel (default) or one fused condensation kernel."""

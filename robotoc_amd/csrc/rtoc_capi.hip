@@ -156,6 +156,7 @@ struct rtoc_ctx {
   rtoc_box_row* d_rows;
   rtoc_box_row* h_rows;  // host copies (stage dump)
   rtoc_grid* h_grid;
+  int* d_nconv;  // instances found converged by the last rtoc_newton_iteration
   int* d_pair;   // first two rows of every primal entry, packed (int4 per entry)
   int* d_entry;  // CSR over the primal entries (q_0..,v_0..,u_0..): [ne+1] offsets, then [nrows] row ids
   int nrows;
@@ -292,6 +293,7 @@ int rtoc_destroy(rtoc_ctx* c) {
   if (c->d_kkterr) (void)hipFree(c->d_kkterr);
   if (c->d_entry) (void)hipFree(c->d_entry);
   if (c->d_pair) (void)hipFree(c->d_pair);
+  if (c->d_nconv) (void)hipFree(c->d_nconv);
   (void)hipFree(c->d_status);
   if (c->d_prof) (void)hipFree(c->d_prof);
   (void)hipEventDestroy(c->ev0);
@@ -966,9 +968,7 @@ int rtoc_integrate_solution(rtoc_ctx* c) {
 }
 
 // ---- KKT error ------------------------------------------------------------------------------
-int rtoc_kkt_error(rtoc_ctx* c, double* host_out, int count) {
-  CHECK_READY(c);
-  if (!host_out || count < 0 || count > c->batch) return RTOC_ERR_BAD_ARG;
+static int launch_kkt_error(rtoc_ctx* c) {
   if (!c->d_kkterr) HIP_TRY(hipMalloc((void**)&c->d_kkterr, sizeof(double) * c->batch));
   KktErrArgs a;
   a.kkt = c->buf[RTOC_BUF_KKT];
@@ -993,7 +993,54 @@ int rtoc_kkt_error(rtoc_ctx* c, double* host_out, int count) {
   a.nl = c->L.con;
   hipLaunchKernelGGL(kkt_error_kernel, dim3(c->batch), dim3(64), 0, c->stream, a);
   HIP_TRY(hipGetLastError());
+  return RTOC_OK;
+}
+
+int rtoc_kkt_error(rtoc_ctx* c, double* host_out, int count) {
+  CHECK_READY(c);
+  if (!host_out || count < 0 || count > c->batch) return RTOC_ERR_BAD_ARG;
+  int rc = launch_kkt_error(c);
+  if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(host_out, c->d_kkterr, sizeof(double) * count, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return RTOC_OK;
+}
+
+// ---- one Newton iteration of the whole batch as a single launch sequence ----------
+// steps[b] <- 0 for instances whose KKT error is already below the tolerance: they keep their iterate
+__global__ void mask_converged_kernel(double* steps, const double* kkterr, int* nconv, double tol2, int batch) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= batch) return;
+  if (kkterr[b] <= tol2) {
+    steps[2 * b] = 0.0;
+    steps[2 * b + 1] = 0.0;
+    atomicAdd(nconv, 1);
+  }
+}
+
+int rtoc_newton_iteration(rtoc_ctx* c, double kkt_tol, double tau) {
+  CHECK_READY(c);
+  if (!(kkt_tol >= 0.0) || !(tau > 0.0 && tau <= 1.0)) return RTOC_ERR_BAD_ARG;
+  if (!c->d_nconv) HIP_TRY(hipMalloc((void**)&c->d_nconv, sizeof(int)));
+  HIP_TRY(hipMemsetAsync(c->d_nconv, 0, sizeof(int), c->stream));
+  int rc = launch_kkt_error(c);  // on the freshly linearised (pre-condensation) records
+  if (!rc) rc = rtoc_condense(c);
+  if (!rc) rc = launch_sweep(c);
+  if (!rc) rc = rtoc_expand(c, tau);  // directions + fraction-to-boundary step sizes, on the device
+  if (rc) return rc;
+  hipLaunchKernelGGL(mask_converged_kernel, dim3((c->batch + 255) / 256), dim3(256), 0, c->stream,
+                     c->buf[RTOC_BUF_STEP], c->d_kkterr, c->d_nconv, kkt_tol * kkt_tol, c->batch);
+  HIP_TRY(hipGetLastError());
+  rc = rtoc_update(c);
+  if (!rc && c->buf[RTOC_BUF_SOL]) rc = rtoc_integrate_solution(c);
+  return rc;
+}
+
+int rtoc_converged_count(rtoc_ctx* c, int* host_count) {
+  CHECK_READY(c);
+  if (!host_count) return RTOC_ERR_BAD_ARG;
+  if (!c->d_nconv) return RTOC_ERR_NOT_READY;
+  HIP_TRY(hipMemcpyAsync(host_count, c->d_nconv, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return RTOC_OK;
 }
