@@ -1,0 +1,58 @@
+// Host emulation of the horizon-scan workgroup bodies (robotoc_amd/csrc/riccati_scan_core.hpp) with
+// one "thread" per workgroup: the same source the HIP kernels instantiate, compiled by g++, so that
+// the algebra and the indexing are checked on the CPU against tests/scan_reference.py.
+// TEST INFRASTRUCTURE ONLY: nothing in the product links or loads this file.
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../robotoc_amd/csrc/riccati_scan_core.hpp"
+
+using namespace rtoc::scan;
+
+template <int NV, int NU, int NS>
+static int run(const rtoc_grid* grid, int n, const double* kkt, double* ps, unsigned* stat) {
+  using E = EltLayout<NV>;
+  constexpr rtoc_layout SL = ScanLayout<NV, NU, NS>::make();
+  const int kstride = SL.kkt.stride;
+  std::vector<double> buf0((size_t)n * E::STRIDE, 0.0), buf1((size_t)n * E::STRIDE, 0.0);
+  std::vector<double> smem_e(ElementCfg<NV, NU, NS>::LDS_DOUBLES), smem_c(CombineCfg<NV, 1>::LDS_DOUBLES);
+  *stat = 0;
+  for (int i = 0; i < n; ++i)
+    *stat |= element_body<NV, NU, NS, 1>(grid[i], kkt + (size_t)i * kstride, buf0.data() + (size_t)i * E::STRIDE,
+                                         ps + (size_t)i * E::PS_STRIDE, smem_e.data(), 0);
+  double* src = buf0.data();
+  double* dst = buf1.data();
+  int levels = 0;
+  for (int d = 1; d < n; d *= 2, ++levels) {
+    for (int i = 0; i < n; ++i) {
+      int j;
+      bool closed2;
+      if (!level_plan(n, d, i, &j, &closed2)) continue;
+      const double* e1 = src + (size_t)i * E::STRIDE;
+      const double* e2 = src + (size_t)j * E::STRIDE;
+      const double* p2 = ps + (size_t)j * E::PS_STRIDE;
+      *stat |= combine_body<NV, 1>(e1, closed2 ? p2 + E::PS_P : e2 + E::OFF_J, closed2 ? p2 + E::PS_S : e2 + E::OFF_ETA,
+                                   e2 + E::OFF_A, e2 + E::OFF_B, e2 + E::OFF_C, closed2,
+                                   dst + (size_t)i * E::STRIDE, ps + (size_t)i * E::PS_STRIDE, smem_c.data(), 0);
+    }
+    double* t = src;
+    src = dst;
+    dst = t;
+  }
+  return levels;
+}
+
+extern "C" int scan_emu_ps_stride(int nv) { return ((4 * nv * nv + 7) & ~7) + ((2 * nv + 7) & ~7); }
+
+// kkt: [n][kkt stride] of ONE instance; ps: [n][ps stride] out (P | s of every grid point).
+// Returns the number of combination levels, or -1 for unsupported dimensions.
+extern "C" int scan_emu_backward(int nv, int nu, int ns_max, const rtoc_grid* grid, int n, const double* kkt,
+                                 double* ps, unsigned* stat) {
+  if (nv == 18 && nu == 12 && ns_max == 12) return run<18, 12, 12>(grid, n, kkt, ps, stat);
+  if (nv == 35 && nu == 29 && ns_max == 12) return run<35, 29, 12>(grid, n, kkt, ps, stat);
+  if (nv == 32 && nu == 26 && ns_max == 12) return run<32, 26, 12>(grid, n, kkt, ps, stat);
+  if (nv == 7 && nu == 7 && ns_max == 0) return run<7, 7, 0>(grid, n, kkt, ps, stat);
+  return -1;
+}
