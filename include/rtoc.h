@@ -100,7 +100,13 @@ enum rtoc_option {
   RTOC_OPT_BACKWARD_WAVES = 2, /* waves per OCP instance in the backward kernel (0 = default for the dims) */
   RTOC_OPT_CONTACT_INV_DAMPING = 3, /* RobotModelInfo::contact_inv_damping (robot.hxx:662-664); value = double bits */
   RTOC_OPT_SWEEP_CHUNKS = 4, /* instance chunks of rtoc_riccati_sweep's backward/forward pipeline (1..16, default 1 = plain sequence) */
-  RTOC_OPT_CONDENSE_SPLIT = 5 /* 1 (default): rtoc_condense computes MJtJinv in its own high-occupancy kernel; 0: one fused kernel */
+  RTOC_OPT_CONDENSE_SPLIT = 5, /* 1 (default): rtoc_condense computes MJtJinv in its own high-occupancy kernel; 0: one fused kernel */
+  RTOC_OPT_BACKWARD_SCAN = 6 /* 1: rtoc_riccati_backward (and everything built on it) runs the recursion as a scan
+                              * over the horizon -- interval elements of all grid points, ceil(log2(nstages))
+                              * combination levels, then all policies at once -- instead of the serial chain
+                              * (riccati_recursion.cpp:32-80).  For FEW instances (one MPC problem): latency of a
+                              * sweep, not throughput of a batch.  Same outputs (P, s, K, k, M, m) to <= 1e-8
+                              * relative; grids with switching-time optimisation take the serial kernel.  Default 0. */
 };
 
 typedef struct rtoc_ctx rtoc_ctx;

@@ -10,7 +10,7 @@ import subprocess
 import numpy as np
 
 from .types import (BoxRow, BUF_CDD, BUF_CON, BUF_DIR, BUF_DX0, BUF_KKT, BUF_RIC, BUF_STEP, Dims, Grid,
-                    Layout, OPT_BACKWARD_WAVES, OPT_CONDENSE_SPLIT, OPT_MAX_DTS0, OPT_SWEEP_CHUNKS, OPT_WRITEBACK_KKT,
+                    Layout, OPT_BACKWARD_WAVES, OPT_CONDENSE_SPLIT, OPT_MAX_DTS0, OPT_SWEEP_CHUNKS, OPT_WRITEBACK_KKT, OPT_BACKWARD_SCAN,
                     grid_array)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -232,6 +232,10 @@ class Context:
         n = C.c_int(0)
         _chk(lib().rtoc_converged_count(self._h, C.byref(n)))
         return n.value
+
+    def set_backward_scan(self, on):
+        """RTOC_OPT_BACKWARD_SCAN: backward recursion as a scan over the horizon (few instances, low latency)."""
+        _chk(lib().rtoc_set_option(self._h, OPT_BACKWARD_SCAN, int(bool(on))))
 
     def set_condense_split(self, on):
         """RTOC_OPT_CONDENSE_SPLIT: MJtJinv in its own kernel (default) or one fused condensation kernel."""

@@ -67,6 +67,12 @@ struct BwdArgs {
   int first;
   int writeback;
   double max_dts0;
+  // horizon-scan mode of riccati_backward_kernel (riccati_scan.hpp): value records [P | s] of every
+  // grid point, [batch][nstages][scan_ps_stride]; workgroup (b, st) then does the ONE stage st from
+  // P_{st+1}, s_{st+1} read there.  nullptr = serial recursion.
+  const double* scan_ps;
+  int scan_ps_stride;
+  int scan_ps_soff;  // offset of s inside a value record
 };
 
 template <int NV, int NU, int NS, int NW>
@@ -341,6 +347,23 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
   const size_t rinst = (size_t)b * a.nstages * RL.stride;
   unsigned stat = 0;
 
+  // horizon-scan mode: this workgroup handles grid point blockIdx.y only (no sto grids in this mode)
+  const bool one_stage = a.scan_ps != nullptr;
+  const int my_stage = one_stage ? (int)blockIdx.y : N;
+  if (one_stage && my_stage > N) return;
+  int st_first = N - 1, st_last = 0;
+  if (one_stage && my_stage < N) {
+    const double* pn = a.scan_ps + ((size_t)b * a.nstages + my_stage + 1) * a.scan_ps_stride;
+    copy_g2s_mat<NT, NX, NX, LDP>(sP, pn, tid);
+    if (tid < NX) {
+      smem[C::V_SN + tid] = pn[a.scan_ps_soff + tid];
+      smem[C::V_PSIN + tid] = 0.0;
+      smem[C::V_PHIN + tid] = 0.0;
+    }
+    if (tid < 8) smem[C::V_SCN + tid] = 0.0;
+    __syncthreads();
+    st_first = st_last = my_stage;
+  } else
   // ---- terminal stage: P_N = Qxx_N, s_N = -lx_N (riccati_recursion.cpp:37-38) ----
   {
     const double* kr = a.kkt + kinst + (size_t)N * KL.stride;
@@ -381,9 +404,10 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
     }
     if (!imp && tid < NU) preLu = kp[KL.off[RTOC_KKT_LU] + tid];
   };
-  if (N >= 1) issue_loads(N - 1);
+  if (one_stage && my_stage == N) return;  // the terminal record is written, nothing else to do
+  if (N >= 1) issue_loads(st_first);
 
-  for (int st = N - 1; st >= 0; --st) {
+  for (int st = st_first; st >= st_last; --st) {
     // Opaque re-definition of the thread index per stage: keeps LLVM's LICM from hoisting the
     // (hundreds of) per-lane LDS/HBM address computations of the unrolled copy and MFMA loops
     // out of the stage loop, where they would pin > 256 VGPRs and spill.
@@ -677,7 +701,7 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
             f[c][t][r] = (i < NX && j < NX) ? v : 0.0;
           }
       // next stage's record: HBM -> registers, in flight for the rest of this stage
-      if (st > 0) issue_loads(st - 1);
+      if (st > st_last) issue_loads(st - 1);
       // ---- LLT(G) by wave 0 (riccati_factorizer.cpp:49): VALU / shuffle work issued next to the
       //      independent F-chain MFMAs below so that the two pipes overlap ----
       if (!impact && wave == 0) {

@@ -1,0 +1,70 @@
+// riccati_scan.hpp -- HIP kernels of the horizon scan (see riccati_scan_core.hpp for the algorithm).
+//
+// Launch sequence of one backward recursion with RTOC_OPT_BACKWARD_SCAN (rtoc_capi.hip: launch_backward_scan):
+//   scan_element_kernel    grid (nstages, batch)      every grid point -> its interval element
+//   scan_combine_kernel    grid (nstages - d, batch)  for d = 1, 2, 4, ... : element(i) <- element(i) o element(i+d);
+//                                                     elements that reach the terminal grid point become value
+//                                                     records (P_i, s_i)
+//   riccati_backward_kernel in its one-stage mode, grid (batch, nstages): policies of all grid points
+// One workgroup per (grid point, instance); the elements ping-pong between two HBM buffers
+// (3 NX^2 + 2 NX doubles per grid point: 32 KB for ANYmal), which stay in the 4 MB L2 of the XCD for the
+// handful of instances this path is meant for.
+#pragma once
+#include "device_utils.hpp"
+#include "riccati_scan_core.hpp"
+
+namespace rtoc {
+
+struct ScanArgs {
+  const double* kkt;      // [batch][nstages][kkt stride]
+  const rtoc_grid* grid;  // [nstages] (device)
+  uint32_t* status;       // [batch]
+  const double* src;      // elements before this level [batch][nstages][EltLayout::STRIDE]
+  double* dst;            // elements after this level
+  double* ps;             // value records [batch][nstages][EltLayout::PS_STRIDE]
+  int nstages;
+  int batch;  // instances [first, batch) are processed by this launch
+  int first;
+  int dist;   // distance d of this combination level
+};
+
+constexpr int SCAN_ELT_NT = 256;  // element kernel
+// combination kernel: the waves share the MFMA tiles; up to 8 lanes per column of the elimination (3 NX + 1 columns)
+constexpr int scan_comb_nt(int nv) { return 8 * (6 * nv + 1) <= 512 ? 512 : 1024; }
+
+template <int NV, int NU, int NS>
+__global__ __launch_bounds__(SCAN_ELT_NT) void scan_element_kernel(ScanArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  using E = scan::EltLayout<NV>;
+  constexpr rtoc_layout SL = StaticLayout<NV, NU, NS>::make();
+  const int st = blockIdx.x, b = a.first + blockIdx.y;
+  if (b >= a.batch || st >= a.nstages) return;
+  const rtoc_grid g = a.grid[st];
+  const size_t rec = (size_t)b * a.nstages + st;
+  const unsigned stat = scan::element_body<NV, NU, NS, SCAN_ELT_NT>(
+      g, a.kkt + rec * SL.kkt.stride, a.dst + rec * E::STRIDE, a.ps + rec * E::PS_STRIDE, smem, threadIdx.x);
+  if (stat && threadIdx.x == 0) atomicOr(&a.status[b], stat);
+}
+
+template <int NV>
+__global__ __launch_bounds__(scan_comb_nt(NV)) void scan_combine_kernel(ScanArgs a) {
+  constexpr int SCAN_NT = scan_comb_nt(NV);
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  using E = scan::EltLayout<NV>;
+  const int i = blockIdx.x, b = a.first + blockIdx.y;
+  if (b >= a.batch) return;
+  int j;
+  bool closed2;
+  if (!scan::level_plan(a.nstages, a.dist, i, &j, &closed2)) return;
+  const size_t inst = (size_t)b * a.nstages;
+  const double* e1 = a.src + (inst + i) * E::STRIDE;
+  const double* e2 = a.src + (inst + j) * E::STRIDE;
+  const double* p2 = a.ps + (inst + j) * E::PS_STRIDE;
+  const unsigned stat = scan::combine_body<NV, SCAN_NT>(
+      e1, closed2 ? p2 + E::PS_P : e2 + E::OFF_J, closed2 ? p2 + E::PS_S : e2 + E::OFF_ETA, e2 + E::OFF_A,
+      e2 + E::OFF_B, e2 + E::OFF_C, closed2, a.dst + (inst + i) * E::STRIDE, a.ps + (inst + i) * E::PS_STRIDE,
+      smem, threadIdx.x);
+  if (stat && threadIdx.x == 0) atomicOr(&a.status[b], stat);
+}
+
+}  // namespace rtoc

@@ -40,7 +40,14 @@
 #include <stdint.h>
 
 #include "../../include/rtoc.h"
+#if defined(__HIPCC__)
+#include "lds_gemm.hpp"
+#endif
 
+// tools/probes/scan_probe.hip compiles parts of combine_body out (timing only)
+#ifndef RTOC_SCAN_PROBE
+#define RTOC_SCAN_PROBE 0
+#endif
 #if defined(__HIPCC__)
 #define RTOC_SCAN_DEV __device__ __forceinline__
 #define RTOC_SCAN_SYNC() __syncthreads()
@@ -216,8 +223,9 @@ RTOC_SCAN_DEV unsigned element_body(const rtoc_grid& g, const double* kr, double
     const int j = i % NV, k = i / NV;
     sZ[k + (C::C_B + j) * LDZ] = Fvu[i];
   }
+  const int nsd = ns > 0 ? ns : 1;
   for (int i = tid; i < ns * NU; i += NT) {  // Phiu(j,k), ld ns_max
-    const int j = i % ns, k = i / ns;
+    const int j = i % nsd, k = i / nsd;
     sZ[k + (C::C_D + j) * LDZ] = Phiu[j + k * ldn];
   }
   RTOC_SCAN_SYNC();
@@ -319,193 +327,334 @@ RTOC_SCAN_DEV unsigned element_body(const rtoc_grid& g, const double* kr, double
 }
 
 // ---- combination ---------------------------------------------------------------------------------
+// C(i,j) = sum_k A(i,k) B(k,j) between LDS-resident operands with compile-time shapes and strides,
+// A(i,k) = A[i*ARS + k*ACS], B(k,j) = B[k*BRS + j*BCS]; epilogue(row, col, value).  On the GPU the
+// 16x16 tiles are dealt to the NT/64 waves and computed with v_mfma_f64_16x16x4_f64 (lds_gemm.hpp); the
+// host emulation runs plain loops.
+#if defined(__HIPCC__)
+template <int NT, int M, int N, int K, int ARS, int ACS, int BRS, int BCS, class E>
+RTOC_SCAN_DEV void scan_gemm(const double* A, const double* B, int tid, E&& epilogue) {
+  rtoc::lds_gemm<NT / 64, M, N, K, ARS, ACS, BRS, BCS>(
+      A, B, tid, [&](int row, int col, double v, int, int) { epilogue(row, col, v); });
+}
+#else
+template <int NT, int M, int N, int K, int ARS, int ACS, int BRS, int BCS, class E>
+RTOC_SCAN_DEV void scan_gemm(const double* A, const double* B, int tid, E&& epilogue) {
+  for (int idx = tid; idx < M * N; idx += NT) {
+    const int i = idx % M, j = idx / M;
+    double acc = 0.0;
+    for (int k = 0; k < K; ++k) acc += A[i * ARS + k * ACS] * B[k * BRS + j * BCS];
+    epilogue(i, j, acc);
+  }
+}
+#endif
+
+// exchange between the LPC (<= 8) adjacent lanes that share one column of the elimination (DPP)
+#if defined(__HIPCC__)
+template <int CTRL>
+RTOC_SCAN_DEV int quad_perm_i(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
+}
+template <int CTRL>
+RTOC_SCAN_DEV double quad_perm_d(double v) {
+  const int lo = quad_perm_i<CTRL>(__double2loint(v));
+  const int hi = quad_perm_i<CTRL>(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+#else
+template <int CTRL>
+RTOC_SCAN_DEV int quad_perm_i(int v) { return v; }
+template <int CTRL>
+RTOC_SCAN_DEV double quad_perm_d(double v) { return v; }
+#endif
+// 1/x to fp64 accuracy: hardware estimate + two Newton steps (off the divide's long dependent chain)
+RTOC_SCAN_DEV double fast_rcp(double x) {
+#if defined(__HIPCC__)
+  double r = __builtin_amdgcn_rcp(x);
+  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+  return r;
+#else
+  return 1.0 / x;
+#endif
+}
+// |v| for the pivot search; a used ("dead") row gets its sign and exponent cleared, i.e. at most a
+// denormal that loses against every real candidate (one v_cndmask on the high dword)
+RTOC_SCAN_DEV double masked_abs(double v, bool dead) {
+#if defined(__HIPCC__)
+  const int hi = dead ? 0 : (__double2hiint(v) & 0x7fffffff);
+  return __hiloint2double(hi, __double2loint(v));
+#else
+  return dead ? 0.0 : fabs(v);
+#endif
+}
+constexpr int QUAD_XOR1 = 0xB1;  // quad_perm [1,0,3,2]
+constexpr int QUAD_XOR2 = 0x4E;  // quad_perm [2,3,0,1]
+constexpr int HALF_MIRROR = 0x141;  // row_half_mirror: lane i <-> 7 - i of every 8 lanes (the other quad)
+
+constexpr int scan_lds_ld(int n) { return (n % 4 == 2) ? n : n + 2; }  // as lds_ld (device_utils.hpp)
+
 template <int NV, int NT>
 struct CombineCfg {
   static constexpr int NX = 2 * NV;
-  static constexpr int LDW = 3 * NX + 1;                 // [M | A1 | t | C1], row-major, odd
-  static constexpr int CPT = (LDW + NT - 1) / NT;        // columns per thread (1 on the GPU)
-  static constexpr int LDU = NX | 1;
-  static constexpr int OFF_W = 0;                        // NX x LDW
-  static constexpr int OFF_U = OFF_W + pad8(NX * LDW);   // NX x NX scratch (J2 Ta, then A2 Tc)
-  static constexpr int OFF_MULT = OFF_U + pad8(NX * LDU);  // 2 x NX multipliers (double-buffered)
-  static constexpr int OFF_VEC = OFF_MULT + 2 * pad8(NX);  // u = J2 tb ; w = eta2 - u
-  static constexpr int OFF_PIV = OFF_VEC + 2 * pad8(NX);   // per step: pivot row (as double), 1/pivot
-  static constexpr int OFF_KOF = OFF_PIV + 8;              // kof[r] = elimination step whose pivot row is r
-  static constexpr int OFF_FLAG = OFF_KOF + pad8(NX);
+  static constexpr int LDW = 3 * NX + 1;  // columns of the elimination: [M | A1 | t | C1]
+  // lanes per column (adjacent lanes of one quad), rows per lane, column slots per thread
+  static constexpr int LPC = (NT >= 8 * LDW) ? 8 : (NT >= 4 * LDW) ? 4 : (NT >= 2 * LDW) ? 2 : 1;
+  static constexpr int RPL = (NX + LPC - 1) / LPC;
+  static constexpr int CPT = (LDW * LPC + NT - 1) / NT;  // 1 on the GPU
+  static constexpr int LDM = scan_lds_ld(NX);            // column-major NX x NX operands
+  static constexpr int LDT = NX | 1;                     // row-major Ta / Tc
+  static constexpr int REG = pad8(NX * (LDM > LDT ? LDM : LDT));
+  static constexpr int OFF_R0 = 0, OFF_R1 = REG, OFF_R2 = 2 * REG;
+  static constexpr int MPAD = pad8(LPC * RPL);              // rows incl. the padding of the last lane
+  static constexpr int OFF_MULT = 3 * REG;                  // published pivot column, double-buffered
+  static constexpr int OFF_VT = OFF_MULT + 2 * MPAD;        // t, then tb
+  static constexpr int OFF_VW = OFF_VT + pad8(NX);          // eta2 - J2 tb
+  static constexpr int OFF_ETA2 = OFF_VW + pad8(NX);
+  static constexpr int OFF_PIV = OFF_ETA2 + pad8(NX);       // per step: pivot row, 1/pivot (double-buffered)
+  static constexpr int OFF_KOF = OFF_PIV + 8;               // kof[r] = elimination step whose pivot row is r
+  static constexpr int OFF_FLAG = OFF_KOF + MPAD;
   static constexpr int LDS_DOUBLES = OFF_FLAG + 8;
   static constexpr int LDS_BYTES = LDS_DOUBLES * 8;
+  static_assert(LPC * RPL >= NX && (64 % LPC) == 0, "row split");
 };
+
+// column-major NX x NX matrix, HBM (ld NX) -> LDS (ld LDM)
+template <int NX, int LDM, int NT>
+RTOC_SCAN_DEV void load_mat(double* dst, const double* src, int tid) {
+  for (int e = tid; e < NX * NX; e += NT) dst[(e % NX) + (e / NX) * LDM] = src[e];
+}
 
 // e1 = element of [i, j), (J2, eta2, A2, b2, C2) = element of [j, k).  closed2: [j,k) contains the
 // terminal grid point, then J2 / eta2 are its value record, A2 / b2 / C2 are not read and the result
 // is the closed value record `ps_out`; otherwise the result is the element `out`.
+// Three NX x NX LDS regions are time-shared:  R0: C1 -> Ta -> Tc   R1: J2 -> A1 -> A2   R2: M -> U -> V
 template <int NV, int NT>
 RTOC_SCAN_DEV unsigned combine_body(const double* e1, const double* J2, const double* eta2,
                                     const double* A2, const double* b2, const double* C2, bool closed2,
                                     double* out, double* ps_out, double* smem, int tid) {
   using C = CombineCfg<NV, NT>;
   using E = EltLayout<NV>;
-  constexpr int NX = C::NX, LDW = C::LDW, CPT = C::CPT, LDU = C::LDU;
+  constexpr int NX = C::NX, LDW = C::LDW, CPT = C::CPT, LPC = C::LPC, RPL = C::RPL, LDM = C::LDM,
+                LDT = C::LDT;
   const double* A1 = e1 + E::OFF_A;
   const double* C1 = e1 + E::OFF_C;
   const double* J1 = e1 + E::OFF_J;
   const double* b1 = e1 + E::OFF_B;
   const double* eta1 = e1 + E::OFF_ETA;
-  double* W = smem + C::OFF_W;
-  double* U = smem + C::OFF_U;
+  double* R0 = smem + C::OFF_R0;
+  double* R1 = smem + C::OFF_R1;
+  double* R2 = smem + C::OFF_R2;
   double* mult = smem + C::OFF_MULT;
-  double* vu = smem + C::OFF_VEC;
-  double* vw = vu + pad8(NX);
+  double* vt = smem + C::OFF_VT;
+  double* vw = smem + C::OFF_VW;
+  double* seta2 = smem + C::OFF_ETA2;
   double* piv = smem + C::OFF_PIV;
-  double* kof = smem + C::OFF_KOF;
+  int* kof = reinterpret_cast<int*>(smem + C::OFF_KOF);
   double* flag = smem + C::OFF_FLAG;
   if (tid == 0) flag[0] = 0.0;
-  // ---- W = [I + C1 J2 | A1 | b1 + C1 eta2 | C1] (row-major) ----
-  for (int idx = tid; idx < NX * NX; idx += NT) {
-    const int r = idx % NX, c = idx / NX;
-    double acc = (r == c) ? 1.0 : 0.0;
-    for (int k = 0; k < NX; ++k) acc += C1[r + k * NX] * J2[k + c * NX];
-    W[r * LDW + c] = acc;
-    W[r * LDW + NX + c] = A1[idx];
-    W[r * LDW + 2 * NX + 1 + c] = C1[idx];
-  }
+  for (int r = tid; r < C::MPAD; r += NT) kof[r] = -1;
+  // ---- R0 = C1, R1 = J2 ; M = I + C1 J2 -> R2 ; t = b1 + C1 eta2 ----
+  load_mat<NX, LDM, NT>(R0, C1, tid);
+  load_mat<NX, LDM, NT>(R1, J2, tid);
+  for (int i = tid; i < NX; i += NT) seta2[i] = eta2[i];
+  RTOC_SCAN_SYNC();
+  scan_gemm<NT, NX, NX, NX, 1, LDM, 1, LDM>(R0, R1, tid, [&](int row, int col, double v) {
+    R2[row + col * LDM] = v + (row == col ? 1.0 : 0.0);
+  });
   for (int r = tid; r < NX; r += NT) {
     double acc = b1[r];
-    for (int k = 0; k < NX; ++k) acc += C1[r + k * NX] * eta2[k];
-    W[r * LDW + 2 * NX] = acc;
+    for (int k = 0; k < NX; ++k) acc += R0[r + k * LDM] * seta2[k];
+    vt[r] = acc;
   }
   RTOC_SCAN_SYNC();
-  // ---- Gauss-Jordan with implicit partial pivoting; thread c keeps column c in registers.  Step k:
-  //      the owner of column k picks the pivot among the unused rows and publishes the column, all
-  //      threads eliminate.  One barrier per step (the published column is double-buffered). ----
-  double col[CPT][NX];
+  // ---- Gauss-Jordan elimination of [M | A1 | t | C1] with implicit partial pivoting.  Column c lives
+  //      in the registers of LPC adjacent lanes (lane h owns the rows h, h+LPC, ...).  Step k: the
+  //      lanes of column k pick the pivot among the unused rows and publish the column, then all
+  //      columns > k eliminate.  One barrier per step (the published column is double-buffered). ----
+  double col[CPT][RPL];
   for (int s = 0; s < CPT; ++s) {
-    const int c = tid + s * NT;
+    const int g = tid + s * NT, c = g / LPC, h = g % LPC;
     if (c < LDW) {
 #pragma unroll
-      for (int r = 0; r < NX; ++r) col[s][r] = W[r * LDW + c];
+      for (int t = 0; t < RPL; ++t) {
+        const int r = h + LPC * t;
+        double v = 0.0;
+        if (r < NX) {
+          if (c < NX)
+            v = R2[r + c * LDM];
+          else if (c < 2 * NX)
+            v = A1[r + (c - NX) * NX];
+          else if (c == 2 * NX)
+            v = vt[r];
+          else
+            v = R0[r + (c - 2 * NX - 1) * LDM];
+        }
+        col[s][t] = v;
+      }
     }
   }
-  uint64_t used_lo = 0, used_hi = 0;  // rows already taken as pivots (NX <= 128)
-  for (int k = 0; k < NX; ++k) {
-    double* mk = mult + (k & 1) * pad8(NX);
-    double* pk = piv + (k & 1) * 2;
+  // The loop body is branch-free apart from the column tests: the rows r >= NX that pad the last lane
+  // hold zeros throughout (0 - mk[r] * x with mk[r] = 0) and can never become pivots.  Pivot search of
+  // the owner lanes: |.| of the unused rows (used rows: exponent cleared), maximum by v_max trees and
+  // quad DPP, then the smallest row that attains it; the pivot VALUE is not extracted -- every thread
+  // reads it back as mk[p].
+  constexpr int UW = (RPL + 31) / 32;
+  unsigned used[UW];  // bit t: owned row h + LPC*t has been a pivot row (same for all columns of a lane)
+  for (int w = 0; w < UW; ++w) used[w] = 0u;
+  int* pki = reinterpret_cast<int*>(piv);
+  for (int k = 0; k < ((RTOC_SCAN_PROBE & 1) ? 0 : NX); ++k) {
+    double* mk = mult + (k & 1) * C::MPAD;
     for (int s = 0; s < CPT; ++s) {
-      const int c = tid + s * NT;
+      const int g = tid + s * NT, c = g / LPC, h = g % LPC;
       if (c == k) {
-        int p = -1;
-        double best = -1.0;
+        double a[RPL];
+        double m0 = 0.0, m1 = 0.0;
 #pragma unroll
-        for (int r = 0; r < NX; ++r) {
-          const bool used = r < 64 ? ((used_lo >> r) & 1) : ((used_hi >> (r - 64)) & 1);
-          const double a = fabs(col[s][r]);
-          if (!used && a > best) {
-            best = a;
-            p = r;
+        for (int t = 0; t < RPL; ++t) {
+          const double cv = col[s][t];
+          mk[h + LPC * t] = cv;
+          a[t] = masked_abs(cv, (used[t / 32] >> (t % 32)) & 1u);
+          if (t & 1)
+            m1 = fmax(m1, a[t]);
+          else
+            m0 = fmax(m0, a[t]);
+        }
+        double m = fmax(m0, m1);
+        if (LPC > 1) m = fmax(m, quad_perm_d<QUAD_XOR1>(m));
+        if (LPC > 2) m = fmax(m, quad_perm_d<QUAD_XOR2>(m));
+        if (LPC > 4) m = fmax(m, quad_perm_d<HALF_MIRROR>(m));
+        int p = 1 << 20;
+#pragma unroll
+        for (int t = 0; t < RPL; ++t) {
+          const int cand = (a[t] == m) ? h + LPC * t : (1 << 20);
+          p = cand < p ? cand : p;
+        }
+        if (LPC > 1) {
+          const int o = quad_perm_i<QUAD_XOR1>(p);
+          p = o < p ? o : p;
+        }
+        if (LPC > 2) {
+          const int o = quad_perm_i<QUAD_XOR2>(p);
+          p = o < p ? o : p;
+        }
+        if (LPC > 4) {
+          const int o = quad_perm_i<HALF_MIRROR>(p);
+          p = o < p ? o : p;
+        }
+        if (h == 0) {
+          if (!(m >= 2.3e-308)) {  // no usable pivot: flag, go on with the first unused row
+            flag[0] = 1.0;
+            p = 0;
+            for (int r = NX - 1; r >= 0; --r)
+              if (kof[r] < 0) p = r;
           }
-          mk[r] = col[s][r];
+          pki[k & 1] = p;
+          kof[p] = k;
         }
-        if (!(best > 0.0)) {
-          flag[0] = 1.0;
-          if (p < 0) p = 0;
-        }
-        double pv = 0.0;
-#pragma unroll
-        for (int r = 0; r < NX; ++r)
-          if (r == p) pv = col[s][r];
-        pk[0] = (double)p;
-        pk[1] = 1.0 / pv;
-        kof[p] = (double)k;
       }
     }
     RTOC_SCAN_SYNC();
-    const int p = (int)pk[0];
-    const double ipv = pk[1];
-    if (p < 64)
-      used_lo |= (uint64_t)1 << p;
-    else
-      used_hi |= (uint64_t)1 << (p - 64);
+    const int p = pki[k & 1];
+    const double ipv = fast_rcp(mk[p]);
     for (int s = 0; s < CPT; ++s) {
-      const int c = tid + s * NT;
+      const int g = tid + s * NT, c = g / LPC, h = g % LPC;
+      const bool mine = (p % LPC) == h;  // this lane owns the pivot row
+      const int tp = p / LPC;
+      if (s == CPT - 1) {
+#pragma unroll
+        for (int w = 0; w < UW; ++w) used[w] |= (mine && (tp / 32) == w) ? (1u << (tp % 32)) : 0u;
+      }
       if (c > k && c < LDW) {
         double wp = 0.0;
 #pragma unroll
-        for (int r = 0; r < NX; ++r)
-          if (r == p) wp = col[s][r];
+        for (int t = 0; t < RPL; ++t) wp = (mine && t == tp) ? col[s][t] : wp;
+        if (LPC > 1) wp += quad_perm_d<QUAD_XOR1>(wp);  // the other lanes contribute exact zeros
+        if (LPC > 2) wp += quad_perm_d<QUAD_XOR2>(wp);
+        if (LPC > 4) wp += quad_perm_d<HALF_MIRROR>(wp);
         const double x = wp * ipv;
 #pragma unroll
-        for (int r = 0; r < NX; ++r) col[s][r] = (r == p) ? x : col[s][r] - mk[r] * x;
+        for (int t = 0; t < RPL; ++t) {
+          const double nv = col[s][t] - mk[h + LPC * t] * x;
+          col[s][t] = (mine && t == tp) ? x : nv;
+        }
       }
     }
   }
   RTOC_SCAN_SYNC();
-  // solution row k sits in pivot row p_k: T[k][c] = col[p_k] -> back into W (row-major, rows = k)
+  // the solution row k sits in pivot row p_k.  Ta -> R0 (row-major, ld LDT), tb -> vt; Tc stays in registers.
   for (int s = 0; s < CPT; ++s) {
-    const int c = tid + s * NT;
-    if (c >= NX && c < LDW) {
+    const int g = tid + s * NT, c = g / LPC, h = g % LPC;
+    if (c >= NX && c <= 2 * NX) {
 #pragma unroll
-      for (int r = 0; r < NX; ++r) W[(int)kof[r] * LDW + c] = col[s][r];
+      for (int t = 0; t < RPL; ++t) {
+        const int r = h + LPC * t;
+        if (r < NX) {
+          if (c < 2 * NX)
+            R0[kof[r] * LDT + (c - NX)] = col[s][t];
+          else
+            vt[kof[r]] = col[s][t];
+        }
+      }
     }
   }
   RTOC_SCAN_SYNC();
-  const double* Ta = W + NX;          // Ta[k][j] = W[k*LDW + NX + j]
-  const double* tb = W + 2 * NX;      // tb[k]    = W[k*LDW + 2NX]
-  const double* Tc = W + 2 * NX + 1;  // Tc[k][j]
-  // ---- U = J2 Ta (row-major, ld LDU) ; u = J2 tb ; w = eta2 - u ----
-  for (int idx = tid; idx < NX * NX; idx += NT) {
-    const int i = idx % NX, j = idx / NX;
-    double acc = 0.0;
-    for (int k = 0; k < NX; ++k) acc += J2[i + k * NX] * Ta[k * LDW + j];
-    U[i * LDU + j] = acc;
-  }
+  if (RTOC_SCAN_PROBE & 2) return 0;
+  // ---- U = J2 Ta -> R2 ; w = eta2 - J2 tb ----
+  scan_gemm<NT, NX, NX, NX, 1, LDM, LDT, 1>(R1, R0, tid,
+                                            [&](int row, int col_, double v) { R2[row + col_ * LDM] = v; });
   for (int i = tid; i < NX; i += NT) {
     double acc = 0.0;
-    for (int k = 0; k < NX; ++k) acc += J2[i + k * NX] * tb[k * LDW];
-    vw[i] = eta2[i] - acc;
+    for (int k = 0; k < NX; ++k) acc += R1[i + k * LDM] * vt[k];
+    vw[i] = seta2[i] - acc;
   }
   RTOC_SCAN_SYNC();
-  // ---- J = J1 + A1^T U (stored transposed: J is symmetric) ; eta = eta1 + A1^T w ----
+  // ---- R1 = A1 ; J = J1 + A1^T U (stored transposed: J is symmetric) ; eta = eta1 + A1^T w ----
+  load_mat<NX, LDM, NT>(R1, A1, tid);
+  RTOC_SCAN_SYNC();
   double* Jout = closed2 ? ps_out + E::PS_P : out + E::OFF_J;
   double* eout = closed2 ? ps_out + E::PS_S : out + E::OFF_ETA;
-  for (int idx = tid; idx < NX * NX; idx += NT) {
-    const int j = idx % NX, i = idx / NX;
-    double acc = J1[idx];
-    for (int k = 0; k < NX; ++k) acc += A1[k + i * NX] * U[k * LDU + j];
-    Jout[idx] = acc;
-  }
+  scan_gemm<NT, NX, NX, NX, LDM, 1, 1, LDM>(R1, R2, tid, [&](int row, int col_, double v) {
+    Jout[col_ + row * NX] = v + J1[col_ + row * NX];
+  });
   for (int i = tid; i < NX; i += NT) {
     double acc = eta1[i];
-    for (int k = 0; k < NX; ++k) acc += A1[k + i * NX] * vw[k];
+    for (int k = 0; k < NX; ++k) acc += R1[k + i * LDM] * vw[k];
     eout[i] = acc;
   }
   const unsigned stat = flag[0] != 0.0 ? RTOC_STAT_NAN : 0u;
   if (closed2) return stat;
   RTOC_SCAN_SYNC();
-  // ---- A = A2 Ta ; b = b2 + A2 tb ; V = A2 Tc -> U (column-major, ld LDU) ----
-  for (int idx = tid; idx < NX * NX; idx += NT) {
-    const int i = idx % NX, j = idx / NX;
-    double acc = 0.0, acv = 0.0;
-    for (int k = 0; k < NX; ++k) {
-      const double a2 = A2[i + k * NX];
-      acc += a2 * Ta[k * LDW + j];
-      acv += a2 * Tc[k * LDW + j];
-    }
-    out[E::OFF_A + idx] = acc;
-    U[i + j * LDU] = acv;
-  }
+  // ---- R1 = A2 ; A = A2 Ta (computed as Ta^T A2^T: coalesced stores) ; b = b2 + A2 tb ----
+  load_mat<NX, LDM, NT>(R1, A2, tid);
+  RTOC_SCAN_SYNC();
+  scan_gemm<NT, NX, NX, NX, 1, LDT, LDM, 1>(R0, R1, tid, [&](int row, int col_, double v) {
+    out[E::OFF_A + col_ + row * NX] = v;
+  });
   for (int i = tid; i < NX; i += NT) {
     double acc = b2[i];
-    for (int k = 0; k < NX; ++k) acc += A2[i + k * NX] * tb[k * LDW];
+    for (int k = 0; k < NX; ++k) acc += R1[i + k * LDM] * vt[k];
     out[E::OFF_B + i] = acc;
   }
   RTOC_SCAN_SYNC();
-  // ---- C = C2 + V A2^T ----
-  for (int idx = tid; idx < NX * NX; idx += NT) {
-    const int i = idx % NX, j = idx / NX;
-    double acc = C2[idx];
-    for (int k = 0; k < NX; ++k) acc += U[i + k * LDU] * A2[j + k * NX];
-    out[E::OFF_C + idx] = acc;
+  // ---- Tc (registers) -> R0 ; V = A2 Tc -> R2 ; C = C2 + V A2^T (symmetric, stored transposed) ----
+  for (int s = 0; s < CPT; ++s) {
+    const int g = tid + s * NT, c = g / LPC, h = g % LPC;
+    if (c > 2 * NX && c < LDW) {
+#pragma unroll
+      for (int t = 0; t < RPL; ++t) {
+        const int r = h + LPC * t;
+        if (r < NX) R0[kof[r] * LDT + (c - 2 * NX - 1)] = col[s][t];
+      }
+    }
   }
+  RTOC_SCAN_SYNC();
+  scan_gemm<NT, NX, NX, NX, 1, LDM, LDT, 1>(R1, R0, tid,
+                                            [&](int row, int col_, double v) { R2[row + col_ * LDM] = v; });
+  RTOC_SCAN_SYNC();
+  scan_gemm<NT, NX, NX, NX, 1, LDM, LDM, 1>(R2, R1, tid, [&](int row, int col_, double v) {
+    out[E::OFF_C + col_ + row * NX] = v + C2[col_ + row * NX];
+  });
   return stat;
 }
 

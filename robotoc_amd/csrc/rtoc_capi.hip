@@ -18,6 +18,7 @@
 #include "integrate_solution.hpp"
 #include "riccati_backward.hpp"
 #include "riccati_backward_rs.hpp"
+#include "riccati_scan.hpp"
 #include "riccati_forward.hpp"
 
 using namespace rtoc;
@@ -45,6 +46,7 @@ typedef void (*ud_fn)(UdArgs);
 typedef void (*cone_fn)(ConeArgs);
 typedef void (*cond_fn)(CondArgs);
 typedef void (*expd_fn)(ExpArgs);
+typedef void (*scan_fn)(ScanArgs);
 
 struct KernelSet {
   int nv, nu, ns;
@@ -66,6 +68,11 @@ struct KernelSet {
   int cond_threads, cond_lds;
   expd_fn expd;
   int expd_threads;
+  // horizon scan of the backward recursion (riccati_scan.hpp)
+  scan_fn scan_elt, scan_comb;
+  int scan_elt_lds, scan_comb_lds, scan_comb_threads;
+  int scan_elt_stride, scan_ps_stride, scan_ps_soff;  // doubles per element / value record, offset of s
+  int scan_policy_variant;                            // tile-split backward kernel used in its one-stage mode
 };
 
 template <int NV, int NU, int NS, int NW0, int NW1>
@@ -120,6 +127,16 @@ static KernelSet make_set() {
   k.cond_lds = CondCfg<NV, NU, NF, NS>::LDS_BYTES;
   k.expd = expand_kernel<NV, NU, NF, NS>;
   k.expd_threads = 64;
+  k.scan_elt = scan_element_kernel<NV, NU, NS>;
+  k.scan_comb = scan_combine_kernel<NV>;
+  k.scan_elt_lds = scan::ElementCfg<NV, NU, NS>::LDS_BYTES;
+  k.scan_comb_threads = scan_comb_nt(NV);
+  k.scan_comb_lds = scan::CombineCfg<NV, scan_comb_nt(NV)>::LDS_BYTES;
+  k.scan_elt_stride = scan::EltLayout<NV>::STRIDE;
+  k.scan_ps_stride = scan::EltLayout<NV>::PS_STRIDE;
+  k.scan_ps_soff = scan::EltLayout<NV>::PS_S;
+  k.scan_policy_variant = 1;  // NW1 waves share the tiles of the one stage
+  static_assert(scan::CombineCfg<NV, scan_comb_nt(NV)>::LDS_BYTES <= 160 * 1024, "combination scratch must fit the LDS of a CU");
   return k;
 }
 
@@ -174,6 +191,8 @@ struct rtoc_ctx {
   int cone_contacts, cone_dim;  // friction / wrench cones: max contacts (0 = off), force components per contact
   int cone_rows;                // PDIPM rows per contact: 5 friction cone, 17 contact wrench cone
   double* d_kkterr;             // [batch]
+  int backward_scan;            // RTOC_OPT_BACKWARD_SCAN
+  double* d_scan[3];            // element ping-pong buffers, value records (allocated on first use)
 };
 
 extern "C" {
@@ -275,6 +294,10 @@ int rtoc_create(const rtoc_dims* dims, int max_stages, int batch, int device, rt
   HIP_TRY(hipFuncSetAttribute((const void*)ks->cond_split, hipFuncAttributeMaxDynamicSharedMemorySize,
                               ks->cond_lds));
   HIP_TRY(hipFuncSetAttribute((const void*)ks->mjt, hipFuncAttributeMaxDynamicSharedMemorySize, ks->mjt_lds));
+  HIP_TRY(hipFuncSetAttribute((const void*)ks->scan_elt, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              ks->scan_elt_lds));
+  HIP_TRY(hipFuncSetAttribute((const void*)ks->scan_comb, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              ks->scan_comb_lds));
   HIP_TRY(hipStreamSynchronize(c->stream));
   *out = c;
   return RTOC_OK;
@@ -296,6 +319,8 @@ int rtoc_destroy(rtoc_ctx* c) {
   if (c->d_nconv) (void)hipFree(c->d_nconv);
   (void)hipFree(c->d_status);
   if (c->d_prof) (void)hipFree(c->d_prof);
+  for (int i = 0; i < 3; ++i)
+    if (c->d_scan[i]) (void)hipFree(c->d_scan[i]);
   (void)hipEventDestroy(c->ev0);
   (void)hipEventDestroy(c->ev1);
   (void)hipStreamDestroy(c->own_stream);
@@ -379,6 +404,10 @@ int rtoc_set_option(rtoc_ctx* c, int option, int64_t value) {
       if (value < 1 || value > RTOC_MAX_CHUNK_EVENTS) return RTOC_ERR_BAD_ARG;
       c->sweep_chunks = (int)value;
       return RTOC_OK;
+    case RTOC_OPT_BACKWARD_SCAN:
+      if (value != 0 && value != 1) return RTOC_ERR_BAD_ARG;
+      c->backward_scan = (int)value;
+      return RTOC_OK;
     default:
       return RTOC_ERR_BAD_ARG;
   }
@@ -440,8 +469,71 @@ int rtoc_bind(rtoc_ctx* c, int buffer, void* device_ptr) {
 }
 
 // ---- hot path ---------------------------------------------------------------------------
-static int launch_backward_range(rtoc_ctx* c, int first, int end, hipStream_t stream) {
+// RTOC_OPT_BACKWARD_SCAN: the scan covers grids without switching-time optimisation; others take the serial kernel
+static bool scan_applies(const rtoc_ctx* c) {
+  if (!c->backward_scan || !c->h_grid) return false;
+  for (int i = 0; i < c->nstages; ++i)
+    if (c->h_grid[i].sto || c->h_grid[i].sto_next) return false;
+  return true;
+}
+
+// Backward recursion as a horizon scan (riccati_scan.hpp): elements, log2 combination levels, then the
+// policies of all grid points at once by the tile-split backward kernel in its one-stage mode.
+static int launch_backward_scan(rtoc_ctx* c, int first, int end, hipStream_t stream) {
+  const KernelSet* ks = c->ks;
+  const size_t per = (size_t)c->batch * c->max_stages;
+  for (int i = 0; i < 3; ++i)
+    if (!c->d_scan[i]) {
+      const size_t n = per * (i < 2 ? ks->scan_elt_stride : ks->scan_ps_stride);
+      HIP_TRY(hipMalloc((void**)&c->d_scan[i], n * sizeof(double)));
+    }
+  const int n = c->nstages, nb = end - first;
+  ScanArgs s;
+  s.kkt = c->buf[RTOC_BUF_KKT];
+  s.grid = c->d_grid;
+  s.status = c->d_status;
+  s.src = c->d_scan[1];
+  s.dst = c->d_scan[0];
+  s.ps = c->d_scan[2];
+  s.nstages = n;
+  s.batch = end;
+  s.first = first;
+  s.dist = 0;
+  hipLaunchKernelGGL(ks->scan_elt, dim3(n, nb), dim3(SCAN_ELT_NT), ks->scan_elt_lds, stream, s);
+  int cur = 0;
+  for (int d = 1; d < n; d *= 2) {
+    s.src = c->d_scan[cur];
+    s.dst = c->d_scan[cur ^ 1];
+    s.dist = d;
+    hipLaunchKernelGGL(ks->scan_comb, dim3(n - d, nb), dim3(ks->scan_comb_threads), ks->scan_comb_lds, stream, s);
+    cur ^= 1;
+  }
   BwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.kkt = c->buf[RTOC_BUF_KKT];
+  a.kkt_rw = c->buf[RTOC_BUF_KKT];
+  a.ric = c->buf[RTOC_BUF_RIC];
+  a.grid = c->d_grid;
+  a.status = c->d_status;
+  a.prof = nullptr;
+  a.nstages = n;
+  a.batch = end;
+  a.first = first;
+  a.writeback = c->writeback;
+  a.max_dts0 = c->max_dts0;
+  a.scan_ps = c->d_scan[2];
+  a.scan_ps_stride = ks->scan_ps_stride;
+  a.scan_ps_soff = ks->scan_ps_soff;
+  const int v = ks->scan_policy_variant;
+  hipLaunchKernelGGL(ks->bwd[v], dim3(nb, n), dim3(64 * ks->bwd_waves[v]), ks->bwd_lds[v], stream, a);
+  HIP_TRY(hipGetLastError());
+  return RTOC_OK;
+}
+
+static int launch_backward_range(rtoc_ctx* c, int first, int end, hipStream_t stream) {
+  if (scan_applies(c)) return launch_backward_scan(c, first, end, stream);
+  BwdArgs a;
+  memset(&a, 0, sizeof(a));
   a.kkt = c->buf[RTOC_BUF_KKT];
   a.kkt_rw = c->buf[RTOC_BUF_KKT];
   a.ric = c->buf[RTOC_BUF_RIC];

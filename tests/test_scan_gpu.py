@@ -1,0 +1,156 @@
+"""Horizon scan of the backward recursion (RTOC_OPT_BACKWARD_SCAN) on the GPU, through the C ABI,
+against the serial CPU oracle on identical seeded inputs.
+
+Tolerance: SURVEY 8c states <= 1e-8 relative per stage and field for the scan variant (the scan is a
+different, mathematically equivalent elimination order: interval elements combined in log2(#grid
+points) levels, every level solving a non-symmetric NX x NX system); the policies K, k, M, m come
+from the reference's own one-stage algebra on the scan's P_{i+1}, s_{i+1}.  Worst errors are printed.
+"""
+import numpy as np
+import pytest
+
+from helpers import compare_direction, compare_riccati
+from robotoc_amd import problems as pr
+from robotoc_amd.types import BUF_DIR, BUF_DX0, BUF_KKT, BUF_RIC, Records
+
+pytestmark = pytest.mark.gpu
+
+TOL_SCAN = 1e-8
+
+
+def _sweep(ctx, kkt, dx0):
+    ctx.upload(BUF_KKT, kkt)
+    ctx.upload(BUF_DX0, dx0)
+    ctx.clear_status() if hasattr(ctx, "clear_status") else None
+    ctx.riccati_backward()
+    ctx.riccati_forward()
+    return ctx.status(), ctx.download_records(BUF_RIC, "ric"), ctx.download_records(BUF_DIR, "dir")
+
+
+def _run(oracle, dims, grids, batch, mode, tol=TOL_SCAN):
+    from robotoc_amd import capi
+    ctx = capi.Context(dims, len(grids) + 1, batch, 0)
+    try:
+        L = ctx.L
+        ctx.set_grid(grids)
+        ctx.set_backward_scan(True)
+        kkt = pr.make_kkt_batch(L, grids, batch, mode=mode)
+        dx0 = pr.make_dx0(L, batch)
+        st, ric, d = _sweep(ctx, kkt, dx0)
+        ric_ref = Records(L, "ric").zeros(batch, len(grids))
+        d_ref = Records(L, "dir").zeros(batch, len(grids))
+        st_ref = oracle.riccati_sweep_batch(L, grids, kkt.copy(), ric_ref, d_ref, dx0=dx0)
+        assert (st == st_ref).all(), (st, st_ref)
+        worst = 0.0
+        for b in range(batch):
+            worst = max(worst, compare_riccati(L, grids, ric[b], ric_ref[b], tol, "scan inst %d" % b, check_sto=False))
+            worst = max(worst, compare_direction(L, grids, d[b], d_ref[b], tol, "scan inst %d" % b))
+        # P exactly symmetric like the serial kernels' (brrf.cpp:85)
+        P = Records(L, "ric").f(ric, "P")
+        assert np.array_equal(P, np.swapaxes(P, -1, -2))
+        print("scan worst rel err %.3e (tol %.1e)" % (worst, tol))
+        return worst
+    finally:
+        ctx.close()
+
+
+def _no_sto(grids):
+    for g in grids:
+        g.sto = 0
+        g.sto_next = 0
+    return grids
+
+
+@pytest.mark.parametrize("mode", ["factory", "dynamics"])
+def test_scan_anymal_trot(oracle, mode):
+    """configs[1]: ANYmal trot, 47 grid points (2 lifts, 2 impacts, 2 switching-constraint grids) -> 6 levels."""
+    dims, grids, _ = pr.config_anymal_trot()
+    _run(oracle, dims, grids, 3, mode, tol=TOL_SCAN if mode == "factory" else 1e-7)
+
+
+def test_scan_anymal_short_and_odd_horizons(oracle):
+    """nstages not a power of two, and the smallest horizons (2 and 3 grid points)."""
+    from robotoc_amd import grid as G
+    dims, grids, _ = pr.config_anymal_trot(N=12, dt=0.05)
+    _run(oracle, dims, grids, 2, "factory")
+    for N in (1, 2, 5):
+        _run(oracle, dims, G.uniform_grid(N, 0.02, dimf=12), 1, "factory")
+
+
+@pytest.mark.parametrize("nv", [32, 35])
+def test_scan_icub_jump(oracle, nv):
+    """configs[3]: iCub, stand-flight-stand with a 12-row switching constraint, larger blocks."""
+    dims, grids, _ = pr.config_icub_jump(nv=nv)
+    _run(oracle, dims, _no_sto(grids), 2, "dynamics", tol=1e-7)
+
+
+def test_scan_iiwa14_dense(oracle):
+    dims, grids, _ = pr.config_iiwa14()
+    _run(oracle, dims, grids, 4, "factory")
+
+
+def test_scan_sto_grid_takes_the_serial_kernel(oracle):
+    """Grids with switching-time optimisation are outside the scan: same bits as without the option."""
+    from robotoc_amd import capi
+    dims, grids, _ = pr.config_anymal_jump_sto()
+    assert any(g.sto for g in grids)
+    out = []
+    for scan in (False, True):
+        ctx = capi.Context(dims, len(grids), 2, 0)
+        try:
+            ctx.set_grid(grids)
+            ctx.set_backward_scan(scan)
+            kkt = pr.make_kkt_batch(ctx.L, grids, 2, mode="dynamics")
+            out.append(_sweep(ctx, kkt, pr.make_dx0(ctx.L, 2)))
+        finally:
+            ctx.close()
+    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+
+
+def test_scan_flags_non_spd_quu(oracle):
+    from robotoc_amd import capi
+    dims, grids, _ = pr.config_anymal_trot(N=12, dt=0.05)
+    ctx = capi.Context(dims, len(grids), 2, 0)
+    try:
+        ctx.set_grid(grids)
+        ctx.set_backward_scan(True)
+        kkt = pr.make_kkt_batch(ctx.L, grids, 2, mode="factory")
+        Records(ctx.L, "kkt").f(kkt[1, 3], "Quu")[...] = -np.eye(dims.nu)
+        ctx.upload(BUF_KKT, kkt)
+        ctx.riccati_backward()
+        st = ctx.status()
+        assert st[0] == 0 and (st[1] & 1)
+    finally:
+        ctx.close()
+
+
+def test_scan_latency_vs_serial(oracle):
+    """Single-instance latency of the backward recursion, scan vs serial chain (HIP events); the log line is
+    the measurement DESIGN.md quotes.  The scan must not be slower than the chain it replaces."""
+    from robotoc_amd import capi
+    rows = []
+    for name, cfg in (("anymal_trot", pr.config_anymal_trot), ("icub32", lambda: pr.config_icub_jump(nv=32)),
+                      ("icub35", lambda: pr.config_icub_jump(nv=35))):
+        dims, grids, _ = cfg()
+        grids = _no_sto(grids)
+        t = {}
+        for scan in (False, True):
+            ctx = capi.Context(dims, len(grids), 1, 0)
+            try:
+                ctx.set_grid(grids)
+                ctx.set_backward_scan(scan)
+                ctx.upload(BUF_KKT, pr.make_kkt_batch(ctx.L, grids, 1, mode="dynamics"))
+                ctx.time_phase(0, 5)
+                t[scan] = ctx.time_phase(0, 50)
+            finally:
+                ctx.close()
+        rows.append((name, len(grids), t[False], t[True]))
+        print("backward latency %s (%d grid points, 1 instance): serial %.3f ms, scan %.3f ms, x%.2f"
+              % (name, len(grids), t[False], t[True], t[False] / t[True]))
+    import json, os
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "scan_latency.json"), "w") as f:
+        json.dump([dict(config=r[0], grid_points=r[1], serial_ms=r[2], scan_ms=r[3]) for r in rows], f, indent=1)
+    for r in rows:
+        assert r[3] < r[2], r

@@ -1,0 +1,26 @@
+"""Single-instance latency of the backward recursion: serial chain vs horizon scan (HIP events).
+usage: python tools/scan_latency.py [anymal|icub32|icub35] [batch] [reps]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from robotoc_amd import capi, problems as pr  # noqa: E402
+from robotoc_amd.types import BUF_KKT  # noqa: E402
+
+name = sys.argv[1] if len(sys.argv) > 1 else "anymal"
+batch = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 50
+cfg = {"anymal": pr.config_anymal_trot, "icub32": lambda: pr.config_icub_jump(nv=32),
+       "icub35": lambda: pr.config_icub_jump(nv=35)}[name]
+dims, grids, _ = cfg()
+for g in grids:
+    g.sto = 0
+    g.sto_next = 0
+for scan in (False, True):
+    ctx = capi.Context(dims, len(grids), batch, 0)
+    ctx.set_grid(grids)
+    ctx.set_backward_scan(scan)
+    ctx.upload(BUF_KKT, pr.make_kkt_batch_tiled(ctx.L, grids, batch, unique=min(batch, 4)))
+    ctx.time_phase(0, 5)
+    print("%s batch %d %s: %.4f ms" % (name, batch, "scan" if scan else "serial", ctx.time_phase(0, reps)))
+    ctx.close()
