@@ -336,6 +336,16 @@ def main():
                 ok = int((c2.status() != 0).sum()) == 0
                 if b2 == 1:
                     entry["single_instance_sweep_ms"] = mb + mf
+                    entry["single_instance_backward_ms"] = mb
+                    if not any(g.sto or g.sto_next for g in g2):
+                        # RTOC_OPT_BACKWARD_SCAN: the recursion as a scan over the horizon (latency path)
+                        c2.set_backward_scan(True)
+                        c2.time_phase(0, 2)
+                        ms = c2.time_phase(0, 5)
+                        c2.set_backward_scan(False)
+                        entry["single_instance_backward_scan_ms"] = ms
+                        entry["single_instance_sweep_scan_ms"] = ms + mf
+                        ok = ok and int((c2.status() != 0).sum()) == 0
                 else:
                     entry.update({"batch": b2, "backward_ms": mb, "forward_ms": mf,
                                   "sweeps_per_sec": b2 / (mb + mf) * 1e3,

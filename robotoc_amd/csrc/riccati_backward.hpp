@@ -353,15 +353,6 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
   if (one_stage && my_stage > N) return;
   int st_first = N - 1, st_last = 0;
   if (one_stage && my_stage < N) {
-    const double* pn = a.scan_ps + ((size_t)b * a.nstages + my_stage + 1) * a.scan_ps_stride;
-    copy_g2s_mat<NT, NX, NX, LDP>(sP, pn, tid);
-    if (tid < NX) {
-      smem[C::V_SN + tid] = pn[a.scan_ps_soff + tid];
-      smem[C::V_PSIN + tid] = 0.0;
-      smem[C::V_PHIN + tid] = 0.0;
-    }
-    if (tid < 8) smem[C::V_SCN + tid] = 0.0;
-    __syncthreads();
     st_first = st_last = my_stage;
   } else
   // ---- terminal stage: P_N = Qxx_N, s_N = -lx_N (riccati_recursion.cpp:37-38) ----
@@ -406,6 +397,17 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
   };
   if (one_stage && my_stage == N) return;  // the terminal record is written, nothing else to do
   if (N >= 1) issue_loads(st_first);
+  if (one_stage) {  // P+ / s+ of this grid point from the scan's value records (the record's loads are in flight)
+    const double* pn = a.scan_ps + ((size_t)b * a.nstages + my_stage + 1) * a.scan_ps_stride;
+    copy_g2s_mat<NT, NX, NX, LDP>(sP, pn, tid);
+    if (tid < NX) {
+      smem[C::V_SN + tid] = pn[a.scan_ps_soff + tid];
+      smem[C::V_PSIN + tid] = 0.0;
+      smem[C::V_PHIN + tid] = 0.0;
+    }
+    if (tid < 8) smem[C::V_SCN + tid] = 0.0;
+    __syncthreads();
+  }
 
   for (int st = st_first; st >= st_last; --st) {
     // Opaque re-definition of the thread index per stage: keeps LLVM's LICM from hoisting the

@@ -405,9 +405,14 @@ struct CombineCfg {
   static constexpr int LDM = scan_lds_ld(NX);            // column-major NX x NX operands
   static constexpr int LDT = NX | 1;                     // row-major Ta / Tc
   static constexpr int REG = pad8(NX * (LDM > LDT ? LDM : LDT));
-  static constexpr int OFF_R0 = 0, OFF_R1 = REG, OFF_R2 = 2 * REG;
+  // small robots: A1 and A2 get LDS regions of their own and are fetched up front, under the M product and
+  // the elimination, instead of taking over R1 in the middle of the kernel
+  static constexpr bool PRE = (5 * REG + 16 * pad8(NX + 8)) * 8 <= 150 * 1024;
+  static constexpr int NREG = PRE ? 5 : 3;
+  static constexpr int OFF_R0 = 0, OFF_R1 = REG, OFF_R2 = 2 * REG, OFF_R3 = PRE ? 3 * REG : REG,
+                       OFF_R4 = PRE ? 4 * REG : REG;
   static constexpr int MPAD = pad8(LPC * RPL);              // rows incl. the padding of the last lane
-  static constexpr int OFF_MULT = 3 * REG;                  // published pivot column, double-buffered
+  static constexpr int OFF_MULT = NREG * REG;               // published pivot column, double-buffered
   static constexpr int OFF_VT = OFF_MULT + 2 * MPAD;        // t, then tb
   static constexpr int OFF_VW = OFF_VT + pad8(NX);          // eta2 - J2 tb
   static constexpr int OFF_ETA2 = OFF_VW + pad8(NX);
@@ -429,6 +434,7 @@ RTOC_SCAN_DEV void load_mat(double* dst, const double* src, int tid) {
 // terminal grid point, then J2 / eta2 are its value record, A2 / b2 / C2 are not read and the result
 // is the closed value record `ps_out`; otherwise the result is the element `out`.
 // Three NX x NX LDS regions are time-shared:  R0: C1 -> Ta -> Tc   R1: J2 -> A1 -> A2   R2: M -> U -> V
+// (CombineCfg::PRE: A1 and A2 live in R3 / R4 from the start)
 template <int NV, int NT>
 RTOC_SCAN_DEV unsigned combine_body(const double* e1, const double* J2, const double* eta2,
                                     const double* A2, const double* b2, const double* C2, bool closed2,
@@ -445,6 +451,9 @@ RTOC_SCAN_DEV unsigned combine_body(const double* e1, const double* J2, const do
   double* R0 = smem + C::OFF_R0;
   double* R1 = smem + C::OFF_R1;
   double* R2 = smem + C::OFF_R2;
+  double* RA1 = smem + C::OFF_R3;  // == R1 unless PRE
+  double* RA2 = smem + C::OFF_R4;
+  constexpr bool PRE = C::PRE;
   double* mult = smem + C::OFF_MULT;
   double* vt = smem + C::OFF_VT;
   double* vw = smem + C::OFF_VW;
@@ -457,6 +466,10 @@ RTOC_SCAN_DEV unsigned combine_body(const double* e1, const double* J2, const do
   // ---- R0 = C1, R1 = J2 ; M = I + C1 J2 -> R2 ; t = b1 + C1 eta2 ----
   load_mat<NX, LDM, NT>(R0, C1, tid);
   load_mat<NX, LDM, NT>(R1, J2, tid);
+  if (PRE) {
+    load_mat<NX, LDM, NT>(RA1, A1, tid);
+    if (!closed2) load_mat<NX, LDM, NT>(RA2, A2, tid);
+  }
   for (int i = tid; i < NX; i += NT) seta2[i] = eta2[i];
   RTOC_SCAN_SYNC();
   scan_gemm<NT, NX, NX, NX, 1, LDM, 1, LDM>(R0, R1, tid, [&](int row, int col, double v) {
@@ -484,7 +497,7 @@ RTOC_SCAN_DEV unsigned combine_body(const double* e1, const double* J2, const do
           if (c < NX)
             v = R2[r + c * LDM];
           else if (c < 2 * NX)
-            v = A1[r + (c - NX) * NX];
+            v = PRE ? RA1[r + (c - NX) * LDM] : A1[r + (c - NX) * NX];
           else if (c == 2 * NX)
             v = vt[r];
           else
@@ -610,30 +623,34 @@ RTOC_SCAN_DEV unsigned combine_body(const double* e1, const double* J2, const do
   }
   RTOC_SCAN_SYNC();
   // ---- R1 = A1 ; J = J1 + A1^T U (stored transposed: J is symmetric) ; eta = eta1 + A1^T w ----
-  load_mat<NX, LDM, NT>(R1, A1, tid);
-  RTOC_SCAN_SYNC();
+  if (!PRE) {
+    load_mat<NX, LDM, NT>(RA1, A1, tid);
+    RTOC_SCAN_SYNC();
+  }
   double* Jout = closed2 ? ps_out + E::PS_P : out + E::OFF_J;
   double* eout = closed2 ? ps_out + E::PS_S : out + E::OFF_ETA;
-  scan_gemm<NT, NX, NX, NX, LDM, 1, 1, LDM>(R1, R2, tid, [&](int row, int col_, double v) {
+  scan_gemm<NT, NX, NX, NX, LDM, 1, 1, LDM>(RA1, R2, tid, [&](int row, int col_, double v) {
     Jout[col_ + row * NX] = v + J1[col_ + row * NX];
   });
   for (int i = tid; i < NX; i += NT) {
     double acc = eta1[i];
-    for (int k = 0; k < NX; ++k) acc += R1[k + i * LDM] * vw[k];
+    for (int k = 0; k < NX; ++k) acc += RA1[k + i * LDM] * vw[k];
     eout[i] = acc;
   }
   const unsigned stat = flag[0] != 0.0 ? RTOC_STAT_NAN : 0u;
   if (closed2) return stat;
-  RTOC_SCAN_SYNC();
-  // ---- R1 = A2 ; A = A2 Ta (computed as Ta^T A2^T: coalesced stores) ; b = b2 + A2 tb ----
-  load_mat<NX, LDM, NT>(R1, A2, tid);
-  RTOC_SCAN_SYNC();
-  scan_gemm<NT, NX, NX, NX, 1, LDT, LDM, 1>(R0, R1, tid, [&](int row, int col_, double v) {
+  // ---- A2 in LDS ; A = A2 Ta (computed as Ta^T A2^T: coalesced stores) ; b = b2 + A2 tb ----
+  if (!PRE) {
+    RTOC_SCAN_SYNC();
+    load_mat<NX, LDM, NT>(RA2, A2, tid);
+    RTOC_SCAN_SYNC();
+  }
+  scan_gemm<NT, NX, NX, NX, 1, LDT, LDM, 1>(R0, RA2, tid, [&](int row, int col_, double v) {
     out[E::OFF_A + col_ + row * NX] = v;
   });
   for (int i = tid; i < NX; i += NT) {
     double acc = b2[i];
-    for (int k = 0; k < NX; ++k) acc += R1[i + k * LDM] * vt[k];
+    for (int k = 0; k < NX; ++k) acc += RA2[i + k * LDM] * vt[k];
     out[E::OFF_B + i] = acc;
   }
   RTOC_SCAN_SYNC();
@@ -649,10 +666,10 @@ RTOC_SCAN_DEV unsigned combine_body(const double* e1, const double* J2, const do
     }
   }
   RTOC_SCAN_SYNC();
-  scan_gemm<NT, NX, NX, NX, 1, LDM, LDT, 1>(R1, R0, tid,
+  scan_gemm<NT, NX, NX, NX, 1, LDM, LDT, 1>(RA2, R0, tid,
                                             [&](int row, int col_, double v) { R2[row + col_ * LDM] = v; });
   RTOC_SCAN_SYNC();
-  scan_gemm<NT, NX, NX, NX, 1, LDM, LDM, 1>(R2, R1, tid, [&](int row, int col_, double v) {
+  scan_gemm<NT, NX, NX, NX, 1, LDM, LDM, 1>(R2, RA2, tid, [&](int row, int col_, double v) {
     out[E::OFF_C + col_ + row * NX] = v + C2[col_ + row * NX];
   });
   return stat;

@@ -204,6 +204,13 @@ class RiccatiRecursion {
     check(rtoc_set_option(ctx_, RTOC_OPT_MAX_DTS0, bits), "rtoc_set_option");
   }
 
+  // Not in the reference: run backwardRiccatiRecursion as a scan over the horizon (RTOC_OPT_BACKWARD_SCAN) --
+  // the low-latency path for ONE OCP, which is what this class holds.  Same results to <= 1e-8 relative;
+  // discretisations with switching-time optimisation keep the serial kernel.
+  void setHorizonScan(const bool on) {
+    check(rtoc_set_option(ctx_, RTOC_OPT_BACKWARD_SCAN, on ? 1 : 0), "rtoc_set_option");
+  }
+
   void resizeData(const TimeDiscretization& td) {
     const int N = td.size() - 1;
     while (static_cast<int>(lqr_policy_.size()) < N + 1) lqr_policy_.push_back(lqr_policy_.back());

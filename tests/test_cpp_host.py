@@ -35,3 +35,12 @@ def test_cpp_host_riccati_recursion_on_gpu(name):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     print(out.stdout, out.stderr)
     assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
+
+
+@pytest.mark.gpu
+def test_cpp_host_riccati_recursion_horizon_scan_on_gpu():
+    """robotoc::RiccatiRecursion::setHorizonScan: the same closed-form stage identities with the scan."""
+    exe = _build("riccati_recursion_test")
+    out = subprocess.run([exe, "scan"], capture_output=True, text=True, timeout=300)
+    print(out.stdout, out.stderr)
+    assert out.returncode == 0 and "horizon scan" in out.stdout, (out.returncode, out.stdout, out.stderr)
