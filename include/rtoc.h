@@ -106,7 +106,11 @@ enum rtoc_option {
                               * combination levels, then all policies at once -- instead of the serial chain
                               * (riccati_recursion.cpp:32-80).  For FEW instances (one MPC problem): latency of a
                               * sweep, not throughput of a batch.  Same outputs (P, s, K, k, M, m) to <= 1e-8
-                              * relative; grids with switching-time optimisation take the serial kernel.  Default 0. */
+                              * relative; grids with switching-time optimisation take the serial kernel.
+                              * 2: automatic -- the scan for batches of at most 8 instances (where it is faster
+                              * on MI355X), the serial kernels above.  Needs Quu > 0 of every stage by itself (the
+                              * serial recursion only needs Quu + B^T P+ B > 0); a violation sets
+                              * RTOC_STAT_QUU_NOT_SPD.  Default 0. */
 };
 
 typedef struct rtoc_ctx rtoc_ctx;

@@ -235,7 +235,7 @@ class Context:
 
     def set_backward_scan(self, on):
         """RTOC_OPT_BACKWARD_SCAN: backward recursion as a scan over the horizon (few instances, low latency)."""
-        _chk(lib().rtoc_set_option(self._h, OPT_BACKWARD_SCAN, int(bool(on))))
+        _chk(lib().rtoc_set_option(self._h, OPT_BACKWARD_SCAN, 2 if on == "auto" else int(bool(on))))
 
     def set_condense_split(self, on):
         """RTOC_OPT_CONDENSE_SPLIT: MJtJinv in its own kernel (default) or one fused condensation kernel."""

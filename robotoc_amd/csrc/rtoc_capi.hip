@@ -405,7 +405,7 @@ int rtoc_set_option(rtoc_ctx* c, int option, int64_t value) {
       c->sweep_chunks = (int)value;
       return RTOC_OK;
     case RTOC_OPT_BACKWARD_SCAN:
-      if (value != 0 && value != 1) return RTOC_ERR_BAD_ARG;
+      if (value < 0 || value > 2) return RTOC_ERR_BAD_ARG;
       c->backward_scan = (int)value;
       return RTOC_OK;
     default:
@@ -469,9 +469,12 @@ int rtoc_bind(rtoc_ctx* c, int buffer, void* device_ptr) {
 }
 
 // ---- hot path ---------------------------------------------------------------------------
+// measured on MI355X (gpurun_out/scan_batch_crossover.log): the scan wins up to ~12 ANYmal / ~10 iCub instances
+#define RTOC_SCAN_AUTO_MAX_BATCH 8
 // RTOC_OPT_BACKWARD_SCAN: the scan covers grids without switching-time optimisation; others take the serial kernel
 static bool scan_applies(const rtoc_ctx* c) {
   if (!c->backward_scan || !c->h_grid) return false;
+  if (c->backward_scan == 2 && c->batch > RTOC_SCAN_AUTO_MAX_BATCH) return false;  // auto: latency regime only
   for (int i = 0; i < c->nstages; ++i)
     if (c->h_grid[i].sto || c->h_grid[i].sto_next) return false;
   return true;

@@ -107,6 +107,42 @@ def test_scan_sto_grid_takes_the_serial_kernel(oracle):
     assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
 
 
+def test_scan_auto_mode_switches_on_the_batch_size(oracle):
+    """RTOC_OPT_BACKWARD_SCAN = 2: scan for <= 8 instances, the serial kernel above (bitwise the serial results)."""
+    from robotoc_amd import capi
+    dims, grids, _ = pr.config_anymal_trot(N=12, dt=0.05)
+    for batch, expect_serial_bits in ((2, False), (9, True)):
+        res = {}
+        for mode in (False, "auto"):
+            ctx = capi.Context(dims, len(grids), batch, 0)
+            try:
+                ctx.set_grid(grids)
+                ctx.set_backward_scan(mode)
+                ctx.upload(BUF_KKT, pr.make_kkt_batch(ctx.L, grids, batch, mode="factory"))
+                ctx.riccati_backward()
+                assert (ctx.status() == 0).all()
+                res[mode] = ctx.download_records(BUF_RIC, "ric")
+            finally:
+                ctx.close()
+        same = np.array_equal(res[False], res["auto"])
+        assert same == expect_serial_bits
+        P = Records(capi.layout_for(dims), "ric")
+        assert np.allclose(P.f(res[False], "P"), P.f(res["auto"], "P"), rtol=1e-8, atol=1e-8)
+
+
+def test_scan_option_validation():
+    from robotoc_amd import capi
+    from robotoc_amd.types import OPT_BACKWARD_SCAN
+    dims, grids, _ = pr.config_anymal_trot(N=12, dt=0.05)
+    ctx = capi.Context(dims, len(grids), 1, 0)
+    try:
+        assert capi.lib().rtoc_set_option(ctx._h, OPT_BACKWARD_SCAN, 3) == -1
+        assert capi.lib().rtoc_set_option(ctx._h, OPT_BACKWARD_SCAN, -1) == -1
+        assert capi.lib().rtoc_set_option(ctx._h, OPT_BACKWARD_SCAN, 2) == 0
+    finally:
+        ctx.close()
+
+
 def test_scan_flags_non_spd_quu(oracle):
     from robotoc_amd import capi
     dims, grids, _ = pr.config_anymal_trot(N=12, dt=0.05)
