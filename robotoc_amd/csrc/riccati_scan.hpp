@@ -67,4 +67,65 @@ __global__ __launch_bounds__(scan_comb_nt(NV)) void scan_combine_kernel(ScanArgs
   if (stat && threadIdx.x == 0) atomicOr(&a.status[b], stat);
 }
 
+// ---- forward recursion as a prefix scan of the closed-loop maps (riccati_scan_core.hpp) ------------------
+struct FwdScanArgs {
+  const double* kkt;
+  const double* ric;
+  double* dir;
+  const double* dx0;  // [batch][nx] or nullptr (then dir[...][0].dx is used as given)
+  const rtoc_grid* grid;
+  const double* src;  // maps before this level [batch][nstages][EltLayout::STRIDE]
+  double* dst;
+  int nstages;
+  int batch;
+  int first;
+  int dist;
+};
+constexpr int SCAN_FWD_NT = 256;
+
+template <int NV, int NU, int NS>
+__global__ __launch_bounds__(SCAN_FWD_NT) void fwd_scan_element_kernel(FwdScanArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  using E = scan::EltLayout<NV>;
+  constexpr rtoc_layout SL = StaticLayout<NV, NU, NS>::make();
+  constexpr int NX = 2 * NV;
+  const int st = blockIdx.x, b = a.first + blockIdx.y;
+  if (b >= a.batch || st >= a.nstages - 1) return;
+  const size_t rec = (size_t)b * a.nstages + st;
+  double* dir0 = a.dir + (size_t)b * a.nstages * SL.dir.stride;
+  const double* dx0 = a.dx0 ? a.dx0 + (size_t)b * NX : dir0 + SL.dir.off[RTOC_DIR_DX];
+  scan::fwd_element_body<NV, NU, NS, SCAN_FWD_NT>(a.grid[st], st, a.kkt + rec * SL.kkt.stride,
+                                                  a.ric + rec * SL.ric.stride, dx0, a.dst + rec * E::STRIDE, dir0,
+                                                  smem, threadIdx.x);
+}
+
+template <int NV, int NU, int NS>
+__global__ __launch_bounds__(SCAN_FWD_NT) void fwd_scan_combine_kernel(FwdScanArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  using E = scan::EltLayout<NV>;
+  constexpr rtoc_layout SL = StaticLayout<NV, NU, NS>::make();
+  // maps i = d .. N-1 are still open before the level with distance d (those below are vectors already)
+  const int i = a.dist + blockIdx.x, b = a.first + blockIdx.y;
+  if (b >= a.batch || i >= a.nstages - 1) return;
+  const int j = i - a.dist;
+  const bool closed2 = j < a.dist;
+  const size_t inst = (size_t)b * a.nstages;
+  double* dirb = a.dir + inst * SL.dir.stride;
+  scan::fwd_combine_body<NV, NU, SCAN_FWD_NT>(
+      a.src + (inst + i) * E::STRIDE, a.src + (inst + j) * E::STRIDE,
+      dirb + (size_t)(j + 1) * SL.dir.stride + SL.dir.off[RTOC_DIR_DX], closed2, a.dst + (inst + i) * E::STRIDE,
+      dirb + (size_t)(i + 1) * SL.dir.stride + SL.dir.off[RTOC_DIR_DX], smem, threadIdx.x);
+}
+
+template <int NV, int NU, int NS>
+__global__ __launch_bounds__(64) void fwd_scan_finish_kernel(FwdScanArgs a) {
+  __shared__ double smem[2 * NV + 8];
+  constexpr rtoc_layout SL = StaticLayout<NV, NU, NS>::make();
+  const int st = blockIdx.x, b = a.first + blockIdx.y;
+  if (b >= a.batch || st >= a.nstages) return;
+  const size_t rec = (size_t)b * a.nstages + st;
+  scan::fwd_finish_body<NV, NU, NS, 64>(a.grid[st], st == a.nstages - 1, a.ric + rec * SL.ric.stride,
+                                        a.dir + rec * SL.dir.stride, smem, threadIdx.x);
+}
+
 }  // namespace rtoc

@@ -675,5 +675,153 @@ RTOC_SCAN_DEV unsigned combine_body(const double* e1, const double* J2, const do
   return stat;
 }
 
+// ---- forward recursion as a prefix scan -------------------------------------------------------------
+// RiccatiRecursion::forwardRiccatiRecursion (reference src/riccati/riccati_recursion.cpp:83-131) without
+// switching-time terms is the chain  dx_{i+1} = Phi_i dx_i + phi_i  of the closed-loop maps
+//   Phi_i = Fxx + [0; Fvu K_i],  phi_i = Fx + [0; Fvu k_i]       (riccati_factorizer.cpp:200-216)
+//   Phi_i = Fxx,                 phi_i = Fx  on impact grids      (:219-231)
+// A Hillis-Steele prefix scan composes the maps, (Phi_i, phi_i) <- (Phi_i Phi_j, Phi_i phi_j + phi_i) with
+// j = i - d; a map whose prefix reaches grid point 0 collapses to the vector dx_{i+1} (written straight into
+// the direction record), and composing with such a partner is a mat-vec.  du, dlmdgmm, dxi of all grid points
+// follow at once from dx_i (:200-277).  The element records of the backward scan are reused: [Phi | phi].
+template <int NV>
+struct FwdEltLayout {
+  static constexpr int NX = 2 * NV;
+  static constexpr int OFF_PHI = 0, OFF_VEC = pad8(NX * NX);
+  static_assert(OFF_VEC + pad8(NX) <= EltLayout<NV>::STRIDE, "forward elements fit the backward element records");
+};
+
+template <int NV, int NU>
+struct FwdCfg {
+  static constexpr int NX = 2 * NV;
+  static constexpr int LDM = scan_lds_ld(NX);
+  static constexpr int REG = pad8(NX * LDM);
+  static constexpr int OFF_A = 0, OFF_B = REG;          // two NX x NX operands (element: Phi, [Fvu | K])
+  static constexpr int OFF_X = 2 * REG;                 // a vector
+  static constexpr int LDS_DOUBLES = OFF_X + 2 * pad8(NX + NU);
+  static constexpr int LDS_BYTES = LDS_DOUBLES * 8;
+};
+
+// Grid point st < N -> (Phi, phi) into `elt`; st == 0 also writes dx_0 and dx_1 into the direction records.
+template <int NV, int NU, int NS, int NT>
+RTOC_SCAN_DEV void fwd_element_body(const rtoc_grid& g, int st, const double* kr, const double* rr,
+                                    const double* dx0, double* elt, double* dir0, double* smem, int tid) {
+  constexpr rtoc_layout SL = ScanLayout<NV, NU, NS>::make();
+  constexpr rtoc_record_layout KL = SL.kkt, RL = SL.ric, DL = SL.dir;
+  using C = FwdCfg<NV, NU>;
+  using F = FwdEltLayout<NV>;
+  constexpr int NX = C::NX, LDM = C::LDM;
+  const bool impact = g.type == RTOC_GRID_IMPACT;
+  const double* Fxx = kr + KL.off[RTOC_KKT_FXX];
+  const double* Fvu = kr + KL.off[RTOC_KKT_FVU];
+  const double* Fx = kr + KL.off[RTOC_KKT_FX];
+  const double* K = rr + RL.off[RTOC_RIC_K];  // row-major NU x NX
+  const double* kv = rr + RL.off[RTOC_RIC_KV];
+  double* sPhi = smem + C::OFF_A;
+  double* sB = smem + C::OFF_B;       // Fvu (NV x NU, ld NV) then K (NU x NX row-major)
+  double* sK = sB + pad8(NV * NU);
+  double* sx = smem + C::OFF_X;       // k (NU), then x0
+  if (!impact) {
+    for (int e = tid; e < NV * NU; e += NT) sB[e] = Fvu[e];
+    for (int e = tid; e < NU * NX; e += NT) sK[e] = K[e];
+    for (int e = tid; e < NU; e += NT) sx[e] = kv[e];
+  }
+  if (st == 0)
+    for (int e = tid; e < NX; e += NT) sx[pad8(NU) + e] = dx0[e];
+  RTOC_SCAN_SYNC();
+  for (int idx = tid; idx < NX * NX; idx += NT) {
+    const int r = idx % NX, c = idx / NX;
+    double acc = Fxx[idx];
+    if (!impact && r >= NV)
+      for (int u = 0; u < NU; ++u) acc += sB[(r - NV) + u * NV] * sK[u * NX + c];
+    elt[F::OFF_PHI + idx] = acc;
+    sPhi[r + c * LDM] = acc;
+  }
+  for (int r = tid; r < NX; r += NT) {
+    double acc = Fx[r];
+    if (!impact && r >= NV)
+      for (int u = 0; u < NU; ++u) acc += sB[(r - NV) + u * NV] * sx[u];
+    elt[F::OFF_VEC + r] = acc;
+  }
+  if (st != 0) return;
+  RTOC_SCAN_SYNC();
+  for (int r = tid; r < NX; r += NT) {
+    double acc = elt[F::OFF_VEC + r];  // written by this very thread
+    for (int k = 0; k < NX; ++k) acc += sPhi[r + k * LDM] * sx[pad8(NU) + k];
+    dir0[DL.off[RTOC_DIR_DX] + r] = sx[pad8(NU) + r];
+    dir0[DL.stride + DL.off[RTOC_DIR_DX] + r] = acc;
+  }
+}
+
+// Map of grid point i composed with its partner j = i - d.  closed2: the partner is the vector xj = dx_{j+1};
+// the result is dx_{i+1} -> xout.  Otherwise (Phi_i Phi_j, Phi_i phi_j + phi_i) -> out.
+template <int NV, int NU, int NT>
+RTOC_SCAN_DEV void fwd_combine_body(const double* ei, const double* ej, const double* xj, bool closed2,
+                                    double* out, double* xout, double* smem, int tid) {
+  using C = FwdCfg<NV, NU>;
+  using F = FwdEltLayout<NV>;
+  constexpr int NX = C::NX, LDM = C::LDM;
+  double* sI = smem + C::OFF_A;
+  double* sJ = smem + C::OFF_B;
+  double* sx = smem + C::OFF_X;
+  load_mat<NX, LDM, NT>(sI, ei + F::OFF_PHI, tid);
+  if (!closed2) load_mat<NX, LDM, NT>(sJ, ej + F::OFF_PHI, tid);
+  for (int e = tid; e < NX; e += NT) sx[e] = closed2 ? xj[e] : ej[F::OFF_VEC + e];
+  RTOC_SCAN_SYNC();
+  for (int r = tid; r < NX; r += NT) {
+    double acc = ei[F::OFF_VEC + r];
+    for (int k = 0; k < NX; ++k) acc += sI[r + k * LDM] * sx[k];
+    if (closed2)
+      xout[r] = acc;
+    else
+      out[F::OFF_VEC + r] = acc;
+  }
+  if (closed2) return;
+  // (Phi_i Phi_j)^T = Phi_j^T Phi_i^T: the transposed product makes the stores coalesced
+  scan_gemm<NT, NX, NX, NX, LDM, 1, LDM, 1>(sJ, sI, tid, [&](int row, int col_, double v) {
+    out[F::OFF_PHI + col_ + row * NX] = v;
+  });
+}
+
+// du, dlmdgmm, dxi (and the zero switching-time entries) of grid point st from its dx (riccati_factorizer.cpp:200-277)
+template <int NV, int NU, int NS, int NT>
+RTOC_SCAN_DEV void fwd_finish_body(const rtoc_grid& g, bool terminal, const double* rr, double* dr, double* smem,
+                                   int tid) {
+  constexpr rtoc_layout SL = ScanLayout<NV, NU, NS>::make();
+  constexpr rtoc_record_layout RL = SL.ric, DL = SL.dir;
+  constexpr int NX = 2 * NV;
+  double* sx = smem;
+  for (int e = tid; e < NX; e += NT) sx[e] = dr[DL.off[RTOC_DIR_DX] + e];
+  RTOC_SCAN_SYNC();
+  const bool impact = g.type == RTOC_GRID_IMPACT;
+  const int ns = (NS > 0 && !terminal && !impact && g.switching_constraint) ? g.dims : 0;
+  for (int w = tid; w < NX + NU + ns; w += NT) {
+    if (w < NX) {
+      const double* P = rr + RL.off[RTOC_RIC_P] + w;
+      double acc = -rr[RL.off[RTOC_RIC_S] + w];
+      for (int j = 0; j < NX; ++j) acc += P[j * NX] * sx[j];
+      dr[DL.off[RTOC_DIR_DLMDGMM] + w] = acc;
+    } else if (w < NX + NU) {
+      if (!terminal && !impact) {
+        const int u = w - NX;
+        const double* K = rr + RL.off[RTOC_RIC_K] + u * NX;
+        double acc = rr[RL.off[RTOC_RIC_KV] + u];
+        for (int j = 0; j < NX; ++j) acc += K[j] * sx[j];
+        dr[DL.off[RTOC_DIR_DU] + u] = acc;
+      }
+    } else {
+      const int q = w - NX - NU;
+      const double* M = rr + RL.off[RTOC_RIC_M] + q;
+      double acc = rr[RL.off[RTOC_RIC_MV] + q];
+      for (int j = 0; j < NX; ++j) acc += M[j * (NS > 0 ? NS : 1)] * sx[j];
+      dr[DL.off[RTOC_DIR_DXI] + q] = acc;
+    }
+  }
+  if (tid == 0) {
+    dr[DL.off[RTOC_DIR_DTS] + 0] = 0.0;
+    dr[DL.off[RTOC_DIR_DTS] + 1] = 0.0;
+  }
+}
+
 }  // namespace scan
 }  // namespace rtoc

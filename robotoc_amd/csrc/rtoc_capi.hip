@@ -47,6 +47,7 @@ typedef void (*cone_fn)(ConeArgs);
 typedef void (*cond_fn)(CondArgs);
 typedef void (*expd_fn)(ExpArgs);
 typedef void (*scan_fn)(ScanArgs);
+typedef void (*fscan_fn)(FwdScanArgs);
 
 struct KernelSet {
   int nv, nu, ns;
@@ -73,6 +74,8 @@ struct KernelSet {
   int scan_elt_lds, scan_comb_lds, scan_comb_threads;
   int scan_elt_stride, scan_ps_stride, scan_ps_soff;  // doubles per element / value record, offset of s
   int scan_policy_variant;                            // tile-split backward kernel used in its one-stage mode
+  fscan_fn fscan_elt, fscan_comb, fscan_fin;          // forward recursion as a prefix scan
+  int fscan_lds;
 };
 
 template <int NV, int NU, int NS, int NW0, int NW1>
@@ -136,6 +139,10 @@ static KernelSet make_set() {
   k.scan_ps_stride = scan::EltLayout<NV>::PS_STRIDE;
   k.scan_ps_soff = scan::EltLayout<NV>::PS_S;
   k.scan_policy_variant = 1;  // NW1 waves share the tiles of the one stage
+  k.fscan_elt = fwd_scan_element_kernel<NV, NU, NS>;
+  k.fscan_comb = fwd_scan_combine_kernel<NV, NU, NS>;
+  k.fscan_fin = fwd_scan_finish_kernel<NV, NU, NS>;
+  k.fscan_lds = scan::FwdCfg<NV, NU>::LDS_BYTES;
   static_assert(scan::CombineCfg<NV, scan_comb_nt(NV)>::LDS_BYTES <= 160 * 1024, "combination scratch must fit the LDS of a CU");
   return k;
 }
@@ -298,6 +305,8 @@ int rtoc_create(const rtoc_dims* dims, int max_stages, int batch, int device, rt
                               ks->scan_elt_lds));
   HIP_TRY(hipFuncSetAttribute((const void*)ks->scan_comb, hipFuncAttributeMaxDynamicSharedMemorySize,
                               ks->scan_comb_lds));
+  HIP_TRY(hipFuncSetAttribute((const void*)ks->fscan_elt, hipFuncAttributeMaxDynamicSharedMemorySize, ks->fscan_lds));
+  HIP_TRY(hipFuncSetAttribute((const void*)ks->fscan_comb, hipFuncAttributeMaxDynamicSharedMemorySize, ks->fscan_lds));
   HIP_TRY(hipStreamSynchronize(c->stream));
   *out = c;
   return RTOC_OK;
@@ -482,7 +491,7 @@ static bool scan_applies(const rtoc_ctx* c) {
 
 // Backward recursion as a horizon scan (riccati_scan.hpp): elements, log2 combination levels, then the
 // policies of all grid points at once by the tile-split backward kernel in its one-stage mode.
-static int launch_backward_scan(rtoc_ctx* c, int first, int end, hipStream_t stream) {
+static int ensure_scan_buffers(rtoc_ctx* c) {
   const KernelSet* ks = c->ks;
   const size_t per = (size_t)c->batch * c->max_stages;
   for (int i = 0; i < 3; ++i)
@@ -490,6 +499,13 @@ static int launch_backward_scan(rtoc_ctx* c, int first, int end, hipStream_t str
       const size_t n = per * (i < 2 ? ks->scan_elt_stride : ks->scan_ps_stride);
       HIP_TRY(hipMalloc((void**)&c->d_scan[i], n * sizeof(double)));
     }
+  return RTOC_OK;
+}
+
+static int launch_backward_scan(rtoc_ctx* c, int first, int end, hipStream_t stream) {
+  const KernelSet* ks = c->ks;
+  int rc0 = ensure_scan_buffers(c);
+  if (rc0) return rc0;
   const int n = c->nstages, nb = end - first;
   ScanArgs s;
   s.kkt = c->buf[RTOC_BUF_KKT];
@@ -557,7 +573,41 @@ static int launch_backward_range(rtoc_ctx* c, int first, int end, hipStream_t st
 }
 static int launch_backward(rtoc_ctx* c) { return launch_backward_range(c, 0, c->batch, c->stream); }
 
+// Forward recursion as a prefix scan of the closed-loop maps (riccati_scan.hpp): maps of all grid points,
+// log2 composition levels (dx of every grid point), then du / dlmdgmm / dxi of all grid points at once.
+static int launch_forward_scan(rtoc_ctx* c, int first, int end, hipStream_t stream) {
+  const KernelSet* ks = c->ks;
+  int rc0 = ensure_scan_buffers(c);
+  if (rc0) return rc0;
+  const int n = c->nstages, nb = end - first, N = n - 1;
+  FwdScanArgs s;
+  s.kkt = c->buf[RTOC_BUF_KKT];
+  s.ric = c->buf[RTOC_BUF_RIC];
+  s.dir = c->buf[RTOC_BUF_DIR];
+  s.dx0 = c->buf[RTOC_BUF_DX0];
+  s.grid = c->d_grid;
+  s.src = c->d_scan[1];
+  s.dst = c->d_scan[0];
+  s.nstages = n;
+  s.batch = end;
+  s.first = first;
+  s.dist = 0;
+  hipLaunchKernelGGL(ks->fscan_elt, dim3(N, nb), dim3(SCAN_FWD_NT), ks->fscan_lds, stream, s);
+  int cur = 0;
+  for (int d = 1; d < N; d *= 2) {
+    s.src = c->d_scan[cur];
+    s.dst = c->d_scan[cur ^ 1];
+    s.dist = d;
+    hipLaunchKernelGGL(ks->fscan_comb, dim3(N - d, nb), dim3(SCAN_FWD_NT), ks->fscan_lds, stream, s);
+    cur ^= 1;
+  }
+  hipLaunchKernelGGL(ks->fscan_fin, dim3(n, nb), dim3(64), 0, stream, s);
+  HIP_TRY(hipGetLastError());
+  return RTOC_OK;
+}
+
 static int launch_forward_range(rtoc_ctx* c, int first, int end, hipStream_t stream) {
+  if (scan_applies(c)) return launch_forward_scan(c, first, end, stream);
   FwdArgs a;
   a.kkt = c->buf[RTOC_BUF_KKT];
   a.ric = c->buf[RTOC_BUF_RIC];
@@ -579,7 +629,7 @@ static int launch_forward(rtoc_ctx* c) { return launch_forward_range(c, 0, c->ba
 // those of rtoc_riccati_backward followed by rtoc_riccati_forward.
 static int launch_sweep(rtoc_ctx* c) {
   const int nch = (c->sweep_chunks > 0) ? c->sweep_chunks : 1;
-  if (nch == 1) {
+  if (nch == 1 || scan_applies(c)) {  // the scan's element buffers are not chunked
     int rc = launch_backward(c);
     return rc ? rc : launch_forward(c);
   }

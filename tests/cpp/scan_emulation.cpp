@@ -44,6 +44,47 @@ static int run(const rtoc_grid* grid, int n, const double* kkt, double* ps, unsi
   return levels;
 }
 
+// forward prefix scan of ONE instance: dir [n][dir stride] out
+template <int NV, int NU, int NS>
+static int run_fwd(const rtoc_grid* grid, int n, const double* kkt, const double* ric, const double* dx0, double* dir) {
+  using E = EltLayout<NV>;
+  constexpr rtoc_layout SL = ScanLayout<NV, NU, NS>::make();
+  const int N = n - 1;
+  std::vector<double> buf0((size_t)n * E::STRIDE, 0.0), buf1((size_t)n * E::STRIDE, 0.0);
+  std::vector<double> smem(FwdCfg<NV, NU>::LDS_DOUBLES);
+  for (int i = 0; i < N; ++i)
+    fwd_element_body<NV, NU, NS, 1>(grid[i], i, kkt + (size_t)i * SL.kkt.stride, ric + (size_t)i * SL.ric.stride, dx0,
+                                    buf0.data() + (size_t)i * E::STRIDE, dir, smem.data(), 0);
+  double* src = buf0.data();
+  double* dst = buf1.data();
+  int levels = 0;
+  for (int d = 1; d < N; d *= 2, ++levels) {
+    for (int i = d; i < N; ++i) {
+      const int j = i - d;
+      fwd_combine_body<NV, NU, 1>(src + (size_t)i * E::STRIDE, src + (size_t)j * E::STRIDE,
+                                  dir + (size_t)(j + 1) * SL.dir.stride + SL.dir.off[RTOC_DIR_DX], j < d,
+                                  dst + (size_t)i * E::STRIDE,
+                                  dir + (size_t)(i + 1) * SL.dir.stride + SL.dir.off[RTOC_DIR_DX], smem.data(), 0);
+    }
+    double* t = src;
+    src = dst;
+    dst = t;
+  }
+  for (int i = 0; i < n; ++i)
+    fwd_finish_body<NV, NU, NS, 1>(grid[i], i == N, ric + (size_t)i * SL.ric.stride, dir + (size_t)i * SL.dir.stride,
+                                   smem.data(), 0);
+  return levels;
+}
+
+extern "C" int scan_emu_forward(int nv, int nu, int ns_max, const rtoc_grid* grid, int n, const double* kkt,
+                                const double* ric, const double* dx0, double* dir) {
+  if (nv == 18 && nu == 12 && ns_max == 12) return run_fwd<18, 12, 12>(grid, n, kkt, ric, dx0, dir);
+  if (nv == 35 && nu == 29 && ns_max == 12) return run_fwd<35, 29, 12>(grid, n, kkt, ric, dx0, dir);
+  if (nv == 32 && nu == 26 && ns_max == 12) return run_fwd<32, 26, 12>(grid, n, kkt, ric, dx0, dir);
+  if (nv == 7 && nu == 7 && ns_max == 0) return run_fwd<7, 7, 0>(grid, n, kkt, ric, dx0, dir);
+  return -1;
+}
+
 extern "C" int scan_emu_ps_stride(int nv) { return ((4 * nv * nv + 7) & ~7) + ((2 * nv + 7) & ~7); }
 
 // kkt: [n][kkt stride] of ONE instance; ps: [n][ps stride] out (P | s of every grid point).

@@ -89,6 +89,31 @@ def test_kernel_bodies_emulated_on_host_match_numpy_scan(oracle, case):
         assert rel_err(se, s[i]) <= TOL_EMU, (i, "s", rel_err(se, s[i]))
 
 
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_forward_prefix_scan_bodies_match_serial_oracle(oracle, case):
+    """The forward recursion as a prefix scan of the closed-loop maps (host emulation of the kernel bodies)
+    against the oracle's serial forward recursion on the oracle's own factorisation."""
+    from helpers import compare_direction
+    dims, grids = CASES[case]()
+    L = oracle.layout(dims)
+    n = len(grids)
+    kkt = pr.make_kkt_batch(L, grids, 1, mode="dynamics")
+    dx0 = pr.make_dx0(L, 1)
+    ric = Records(L, "ric").zeros(1, n)
+    d_ref = Records(L, "dir").zeros(1, n)
+    kk = kkt.copy()
+    oracle.riccati_sweep_batch(L, grids, kk, ric, d_ref, dx0=dx0)
+    d = Records(L, "dir").zeros(n)
+    lib = _emu()
+    lib.scan_emu_forward.restype = C.c_int
+    P = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    # the forward pass reads Fxx, Fvu, Fx only, which the backward pass leaves untouched
+    lv = lib.scan_emu_forward(dims.nv, dims.nu, dims.ns_max, grid_array(grids), n, P(kkt[0]), P(ric[0]), P(dx0[0]), P(d))
+    assert lv == int(np.ceil(np.log2(n - 1)))
+    worst = compare_direction(L, grids, d, d_ref[0], TOL_SCAN, "forward scan")
+    print("forward scan worst rel err %.2e" % worst)
+
+
 def test_emulated_scan_flags_non_spd_quu(oracle):
     dims, grids = CASES["anymal_trot_short"]()
     L = oracle.layout(dims)

@@ -5,7 +5,7 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from robotoc_amd import capi, problems as pr  # noqa: E402
-from robotoc_amd.types import BUF_KKT  # noqa: E402
+from robotoc_amd.types import BUF_DX0, BUF_KKT  # noqa: E402
 
 name = sys.argv[1] if len(sys.argv) > 1 else "anymal"
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -21,6 +21,8 @@ for scan in (False, True):
     ctx.set_grid(grids)
     ctx.set_backward_scan(scan)
     ctx.upload(BUF_KKT, pr.make_kkt_batch_tiled(ctx.L, grids, batch, unique=min(batch, 4)))
-    ctx.time_phase(0, 5)
-    print("%s batch %d %s: %.4f ms" % (name, batch, "scan" if scan else "serial", ctx.time_phase(0, reps)))
+    ctx.upload(BUF_DX0, pr.make_dx0(ctx.L, batch))
+    ctx.time_phase(4, 5)
+    print("%s batch %d %s: backward %.4f ms, forward %.4f ms, sweep %.4f ms" % (
+        name, batch, "scan" if scan else "serial", ctx.time_phase(0, reps), ctx.time_phase(1, reps), ctx.time_phase(4, reps)))
     ctx.close()
