@@ -338,13 +338,14 @@ def main():
                     entry["single_instance_sweep_ms"] = mb + mf
                     entry["single_instance_backward_ms"] = mb
                     if not any(g.sto or g.sto_next for g in g2):
-                        # RTOC_OPT_BACKWARD_SCAN: the recursion as a scan over the horizon (latency path)
+                        # RTOC_OPT_BACKWARD_SCAN: both recursions as scans over the horizon (latency path)
                         c2.set_backward_scan(True)
-                        c2.time_phase(0, 2)
-                        ms = c2.time_phase(0, 5)
+                        c2.time_phase(4, 2)
+                        ms, msf = c2.time_phase(0, 5), c2.time_phase(1, 5)
                         c2.set_backward_scan(False)
                         entry["single_instance_backward_scan_ms"] = ms
-                        entry["single_instance_sweep_scan_ms"] = ms + mf
+                        entry["single_instance_forward_scan_ms"] = msf
+                        entry["single_instance_sweep_scan_ms"] = ms + msf
                         ok = ok and int((c2.status() != 0).sum()) == 0
                 else:
                     entry.update({"batch": b2, "backward_ms": mb, "forward_ms": mf,

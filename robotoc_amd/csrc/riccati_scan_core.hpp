@@ -399,9 +399,13 @@ struct CombineCfg {
   static constexpr int NX = 2 * NV;
   static constexpr int LDW = 3 * NX + 1;  // columns of the elimination: [M | A1 | t | C1]
   // lanes per column (adjacent lanes of one quad), rows per lane, column slots per thread
-  static constexpr int LPC = (NT >= 8 * LDW) ? 8 : (NT >= 4 * LDW) ? 4 : (NT >= 2 * LDW) ? 2 : 1;
+  // Big robots take two column slots per thread rather than fewer lanes per column: the pivot columns (< NX)
+  // all sit in slot 0, and the rows per lane set the length of the serial search / elimination chain.
+  static constexpr int LPC = (2 * NT >= 8 * LDW) ? 8 : (2 * NT >= 4 * LDW) ? 4 : (2 * NT >= 2 * LDW) ? 2 : 1;
   static constexpr int RPL = (NX + LPC - 1) / LPC;
-  static constexpr int CPT = (LDW * LPC + NT - 1) / NT;  // 1 on the GPU
+  static constexpr int GPS = NT / LPC;                    // column groups per slot
+  static constexpr int CPT = (LDW + GPS - 1) / GPS;       // column slots per thread: 1 or 2 on the GPU
+  static_assert(NT < 64 || GPS >= NX, "the pivot columns must sit in slot 0");
   static constexpr int LDM = scan_lds_ld(NX);            // column-major NX x NX operands
   static constexpr int LDT = NX | 1;                     // row-major Ta / Tc
   static constexpr int REG = pad8(NX * (LDM > LDT ? LDM : LDT));
@@ -423,6 +427,14 @@ struct CombineCfg {
   static constexpr int LDS_BYTES = LDS_DOUBLES * 8;
   static_assert(LPC * RPL >= NX && (64 % LPC) == 0, "row split");
 };
+
+// column handled by slot s of a thread: slot 0 in group order, the further slots in reverse group order so that
+// the waves that own the pivot columns carry none of them
+template <class C>
+RTOC_SCAN_DEV int slot_col(int tid, int s) {
+  const int q = tid / C::LPC;
+  return s == 0 ? q : s * C::GPS + (C::GPS - 1 - q);
+}
 
 // column-major NX x NX matrix, HBM (ld NX) -> LDS (ld LDM)
 template <int NX, int LDM, int NT>
@@ -486,8 +498,9 @@ RTOC_SCAN_DEV unsigned combine_body(const double* e1, const double* J2, const do
   //      lanes of column k pick the pivot among the unused rows and publish the column, then all
   //      columns > k eliminate.  One barrier per step (the published column is double-buffered). ----
   double col[CPT][RPL];
+#pragma unroll
   for (int s = 0; s < CPT; ++s) {
-    const int g = tid + s * NT, c = g / LPC, h = g % LPC;
+    const int h = tid % LPC, c = slot_col<C>(tid, s);
     if (c < LDW) {
 #pragma unroll
       for (int t = 0; t < RPL; ++t) {
@@ -516,68 +529,72 @@ RTOC_SCAN_DEV unsigned combine_body(const double* e1, const double* J2, const do
   unsigned used[UW];  // bit t: owned row h + LPC*t has been a pivot row (same for all columns of a lane)
   for (int w = 0; w < UW; ++w) used[w] = 0u;
   int* pki = reinterpret_cast<int*>(piv);
-  for (int k = 0; k < ((RTOC_SCAN_PROBE & 1) ? 0 : NX); ++k) {
-    double* mk = mult + (k & 1) * C::MPAD;
-    for (int s = 0; s < CPT; ++s) {
-      const int g = tid + s * NT, c = g / LPC, h = g % LPC;
-      if (c == k) {
-        double a[RPL];
-        double m0 = 0.0, m1 = 0.0;
+  // search + publish of pivot column kk by its LPC owner lanes (slot s)
+  auto publish = [&](const double (&cs)[RPL], int kk, int h) {
+    double* mk = mult + (kk & 1) * C::MPAD;
+    double a[RPL];
+    double m0 = 0.0, m1 = 0.0;
 #pragma unroll
-        for (int t = 0; t < RPL; ++t) {
-          const double cv = col[s][t];
-          mk[h + LPC * t] = cv;
-          a[t] = masked_abs(cv, (used[t / 32] >> (t % 32)) & 1u);
-          if (t & 1)
-            m1 = fmax(m1, a[t]);
-          else
-            m0 = fmax(m0, a[t]);
-        }
-        double m = fmax(m0, m1);
-        if (LPC > 1) m = fmax(m, quad_perm_d<QUAD_XOR1>(m));
-        if (LPC > 2) m = fmax(m, quad_perm_d<QUAD_XOR2>(m));
-        if (LPC > 4) m = fmax(m, quad_perm_d<HALF_MIRROR>(m));
-        int p = 1 << 20;
-#pragma unroll
-        for (int t = 0; t < RPL; ++t) {
-          const int cand = (a[t] == m) ? h + LPC * t : (1 << 20);
-          p = cand < p ? cand : p;
-        }
-        if (LPC > 1) {
-          const int o = quad_perm_i<QUAD_XOR1>(p);
-          p = o < p ? o : p;
-        }
-        if (LPC > 2) {
-          const int o = quad_perm_i<QUAD_XOR2>(p);
-          p = o < p ? o : p;
-        }
-        if (LPC > 4) {
-          const int o = quad_perm_i<HALF_MIRROR>(p);
-          p = o < p ? o : p;
-        }
-        if (h == 0) {
-          if (!(m >= 2.3e-308)) {  // no usable pivot: flag, go on with the first unused row
-            flag[0] = 1.0;
-            p = 0;
-            for (int r = NX - 1; r >= 0; --r)
-              if (kof[r] < 0) p = r;
-          }
-          pki[k & 1] = p;
-          kof[p] = k;
-        }
-      }
+    for (int t = 0; t < RPL; ++t) {
+      const double cv = cs[t];
+      mk[h + LPC * t] = cv;
+      a[t] = masked_abs(cv, (used[t / 32] >> (t % 32)) & 1u);
+      if (t & 1)
+        m1 = fmax(m1, a[t]);
+      else
+        m0 = fmax(m0, a[t]);
     }
+    double m = fmax(m0, m1);
+    if (LPC > 1) m = fmax(m, quad_perm_d<QUAD_XOR1>(m));
+    if (LPC > 2) m = fmax(m, quad_perm_d<QUAD_XOR2>(m));
+    if (LPC > 4) m = fmax(m, quad_perm_d<HALF_MIRROR>(m));
+    int p = 1 << 20;
+#pragma unroll
+    for (int t = 0; t < RPL; ++t) {
+      const int cand = (a[t] == m) ? h + LPC * t : (1 << 20);
+      p = cand < p ? cand : p;
+    }
+    if (LPC > 1) {
+      const int o = quad_perm_i<QUAD_XOR1>(p);
+      p = o < p ? o : p;
+    }
+    if (LPC > 2) {
+      const int o = quad_perm_i<QUAD_XOR2>(p);
+      p = o < p ? o : p;
+    }
+    if (LPC > 4) {
+      const int o = quad_perm_i<HALF_MIRROR>(p);
+      p = o < p ? o : p;
+    }
+    if (h == 0) {
+      if (!(m >= 2.3e-308)) {  // no usable pivot: flag, go on with the first unused row
+        flag[0] = 1.0;
+        p = 0;
+        for (int r = NX - 1; r >= 0; --r)
+          if (kof[r] < 0) p = r;
+      }
+      pki[kk & 1] = p;
+      kof[p] = kk;
+    }
+  };
+  if (!(RTOC_SCAN_PROBE & 1)) {
+#pragma unroll
+    for (int s = 0; s < CPT; ++s)
+      if (slot_col<C>(tid, s) == 0) publish(col[s], 0, tid % LPC);
+  }
+  for (int k = 0; k < ((RTOC_SCAN_PROBE & 1) ? 0 : NX); ++k) {
+    const double* mk = mult + (k & 1) * C::MPAD;
     RTOC_SCAN_SYNC();
     const int p = pki[k & 1];
     const double ipv = fast_rcp(mk[p]);
-    for (int s = 0; s < CPT; ++s) {
-      const int g = tid + s * NT, c = g / LPC, h = g % LPC;
-      const bool mine = (p % LPC) == h;  // this lane owns the pivot row
-      const int tp = p / LPC;
-      if (s == CPT - 1) {
+    const int h = tid % LPC;
+    const bool mine = (p % LPC) == h;  // this lane owns the pivot row
+    const int tp = p / LPC;
 #pragma unroll
-        for (int w = 0; w < UW; ++w) used[w] |= (mine && (tp / 32) == w) ? (1u << (tp % 32)) : 0u;
-      }
+    for (int w = 0; w < UW; ++w) used[w] |= (mine && (tp / 32) == w) ? (1u << (tp % 32)) : 0u;
+#pragma unroll
+    for (int s = 0; s < CPT; ++s) {
+      const int c = slot_col<C>(tid, s);
       if (c > k && c < LDW) {
         double wp = 0.0;
 #pragma unroll
@@ -591,13 +608,16 @@ RTOC_SCAN_DEV unsigned combine_body(const double* e1, const double* J2, const do
           const double nv = col[s][t] - mk[h + LPC * t] * x;
           col[s][t] = (mine && t == tp) ? x : nv;
         }
+        // the next pivot column goes out as soon as it is up to date (before this thread's other slots)
+        if (c == k + 1 && k + 1 < NX) publish(col[s], k + 1, h);
       }
     }
   }
   RTOC_SCAN_SYNC();
   // the solution row k sits in pivot row p_k.  Ta -> R0 (row-major, ld LDT), tb -> vt; Tc stays in registers.
+#pragma unroll
   for (int s = 0; s < CPT; ++s) {
-    const int g = tid + s * NT, c = g / LPC, h = g % LPC;
+    const int h = tid % LPC, c = slot_col<C>(tid, s);
     if (c >= NX && c <= 2 * NX) {
 #pragma unroll
       for (int t = 0; t < RPL; ++t) {
@@ -655,8 +675,9 @@ RTOC_SCAN_DEV unsigned combine_body(const double* e1, const double* J2, const do
   }
   RTOC_SCAN_SYNC();
   // ---- Tc (registers) -> R0 ; V = A2 Tc -> R2 ; C = C2 + V A2^T (symmetric, stored transposed) ----
+#pragma unroll
   for (int s = 0; s < CPT; ++s) {
-    const int g = tid + s * NT, c = g / LPC, h = g % LPC;
+    const int h = tid % LPC, c = slot_col<C>(tid, s);
     if (c > 2 * NX && c < LDW) {
 #pragma unroll
       for (int t = 0; t < RPL; ++t) {

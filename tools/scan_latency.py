@@ -10,7 +10,11 @@ from robotoc_amd.types import BUF_DX0, BUF_KKT  # noqa: E402
 name = sys.argv[1] if len(sys.argv) > 1 else "anymal"
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 50
-cfg = {"anymal": pr.config_anymal_trot, "icub32": lambda: pr.config_icub_jump(nv=32),
+from robotoc_amd import grid as G  # noqa: E402
+from robotoc_amd.types import anymal_dims, icub_dims  # noqa: E402
+cfg = {"anymal_plain": lambda: (anymal_dims(), G.uniform_grid(46, 0.02, 12), None),
+       "icub32_plain": lambda: (icub_dims(32), G.uniform_grid(33, 0.02, 12), None),
+       "anymal": pr.config_anymal_trot, "icub32": lambda: pr.config_icub_jump(nv=32),
        "icub35": lambda: pr.config_icub_jump(nv=35)}[name]
 dims, grids, _ = cfg()
 for g in grids:
