@@ -86,3 +86,33 @@ def test_newton_iteration_argument_checks():
         assert ctx.converged_count() == 2
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+def test_newton_iteration_with_the_horizon_scan():
+    """The whole SQP hot path with RTOC_OPT_BACKWARD_SCAN (condensation -> both recursions as scans -> expansion ->
+    step sizes -> updates): directions, step sizes and the updated iterate agree with the serial recursions
+    to the scan's tolerance (1e-8 relative; 1e-6 on the step sizes, which are ratios of direction entries)."""
+    batch, tau = 3, 0.995
+    serial, _ = _context(batch)
+    scan, _ = _context(batch)
+    try:
+        scan.set_backward_scan(True)
+        serial.newton_iteration(0.0, tau)
+        scan.newton_iteration(0.0, tau)
+        assert (serial.status() == 0).all() and (scan.status() == 0).all()
+        L = serial.L
+        D = Records(L, "dir")
+        a, b = serial.download_records(BUF_DIR, "dir"), scan.download_records(BUF_DIR, "dir")
+        assert not np.array_equal(a, b)  # really a different arithmetic path
+        for f in ("dx", "du", "dlmdgmm", "daf", "dbetamu"):
+            x, y = D.f(a, f), D.f(b, f)
+            assert np.linalg.norm(x - y) <= 1e-8 * np.linalg.norm(x), f
+        sa, sb = serial.download(BUF_STEP, (batch, 2)), scan.download(BUF_STEP, (batch, 2))
+        assert np.allclose(sa, sb, rtol=1e-6, atol=0)
+        for buf, which in ((BUF_CON, "con"), (BUF_SOL, "sol")):
+            x, y = serial.download_records(buf, which), scan.download_records(buf, which)
+            assert np.linalg.norm(x - y) <= 1e-7 * np.linalg.norm(x), which
+    finally:
+        serial.close()
+        scan.close()
