@@ -104,7 +104,8 @@ enum rtoc_option {
   RTOC_OPT_BACKWARD_SCAN = 6 /* 1: rtoc_riccati_backward (and everything built on it) runs the recursion as a scan
                               * over the horizon -- interval elements of all grid points, ceil(log2(nstages))
                               * combination levels, then all policies at once -- instead of the serial chain
-                              * (riccati_recursion.cpp:32-80).  For FEW instances (one MPC problem): latency of a
+                              * (riccati_recursion.cpp:32-80); rtoc_riccati_forward likewise as a prefix scan of
+                              * the closed-loop maps (:83-131).  For FEW instances (one MPC problem): latency of a
                               * sweep, not throughput of a batch.  Same outputs (P, s, K, k, M, m) to <= 1e-8
                               * relative; grids with switching-time optimisation take the serial kernel.
                               * 2: automatic -- the scan for batches of at most 8 instances (where it is faster
