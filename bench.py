@@ -133,18 +133,22 @@ def cpu_baseline(L, grids, dx0_small, kkt_small, budget_s=12.0):
         if time.perf_counter() - t0 > budget_s:
             break
     dt = time.perf_counter() - t0
-    # the reference's Riccati recursion itself is single-threaded (riccati_recursion.cpp): one instance
-    one_k, one_d = np.ascontiguousarray(kkt_small[:1]), np.ascontiguousarray(dx0_small[:1])
-    ric1, d1, w1 = Records(L, "ric").zeros(1, len(grids)), Records(L, "dir").zeros(1, len(grids)), one_k.copy()
+    # the reference's Riccati recursion itself is single-threaded (riccati_recursion.cpp): one instance through
+    # the single-instance entry points (no OpenMP region: forking a 256-thread team costs more than the sweep)
+    one_k, one_d = np.ascontiguousarray(kkt_small[0]), np.ascontiguousarray(dx0_small[0])
+    ric1, d1, w1 = Records(L, "ric").zeros(len(grids)), Records(L, "dir").zeros(len(grids)), one_k.copy()
+    Dv = Records(L, "dir")
     t1 = time.perf_counter()
     n1 = 0
     while time.perf_counter() - t1 < 2.0:
         w1[...] = one_k
-        orc.riccati_sweep_batch(L, grids, w1, ric1, d1, dx0=one_d)
+        Dv.f(d1[0], "dx")[...] = one_d
+        orc.riccati_backward(L, grids, w1, ric1)
+        orc.riccati_forward(L, grids, w1, ric1, d1)
         n1 += 1
     single = n1 / (time.perf_counter() - t1)
     return dict(value=B * reps / dt, unit="sweeps/s", cores=nthreads, kind="port",
-                single_thread_sweeps_per_sec=single,
+                single_thread_sweeps_per_sec=single, single_thread_sweep_ms=1e3 / single,
                 sample="%d instances x %d repeats of the same ANYmal trot sweep, OpenMP over "
                        "instances (%d threads), includes the memcpy that restores the in-place "
                        "mutated KKT blocks" % (B, reps, nthreads))

@@ -40,7 +40,43 @@
  * gcc -O3 -march=native vectorises it (this file doubles as the CPU baseline). */
 static void gemm(int ta, int tb, int M, int N, int K, double alpha, const double* A, int lda,
                  const double* B, int ldb, double beta, double* C, int ldc) {
-  for (int j = 0; j < N; ++j) {
+  int j0 = 0;
+  if (!ta) {
+    /* four columns of C per pass over A (each a[i] is loaded once for four FMAs); the summation order of
+     * every element is the k order of the plain loop below, so results are bit-identical to it */
+    for (; j0 + 4 <= N; j0 += 4) {
+      double* c0 = C + (size_t)j0 * ldc;
+      double* c1 = c0 + ldc;
+      double* c2 = c1 + ldc;
+      double* c3 = c2 + ldc;
+      if (beta == 0.0) {
+        for (int i = 0; i < M; ++i) c0[i] = c1[i] = c2[i] = c3[i] = 0.0;
+      } else if (beta != 1.0) {
+        for (int i = 0; i < M; ++i) {
+          c0[i] *= beta;
+          c1[i] *= beta;
+          c2[i] *= beta;
+          c3[i] *= beta;
+        }
+      }
+      for (int k = 0; k < K; ++k) {
+        const double b0 = alpha * (tb ? B[j0 + (size_t)k * ldb] : B[k + (size_t)j0 * ldb]);
+        const double b1 = alpha * (tb ? B[j0 + 1 + (size_t)k * ldb] : B[k + (size_t)(j0 + 1) * ldb]);
+        const double b2 = alpha * (tb ? B[j0 + 2 + (size_t)k * ldb] : B[k + (size_t)(j0 + 2) * ldb]);
+        const double b3 = alpha * (tb ? B[j0 + 3 + (size_t)k * ldb] : B[k + (size_t)(j0 + 3) * ldb]);
+        const double* a = A + (size_t)k * lda;
+#pragma omp simd
+        for (int i = 0; i < M; ++i) {
+          const double av = a[i];
+          c0[i] += av * b0;
+          c1[i] += av * b1;
+          c2[i] += av * b2;
+          c3[i] += av * b3;
+        }
+      }
+    }
+  }
+  for (int j = j0; j < N; ++j) {
     double* c = C + (size_t)j * ldc;
     if (beta == 0.0) {
       for (int i = 0; i < M; ++i) c[i] = 0.0;
@@ -55,7 +91,31 @@ static void gemm(int ta, int tb, int M, int N, int K, double alpha, const double
         for (int i = 0; i < M; ++i) c[i] += a[i] * b;
       }
     } else {
-      for (int i = 0; i < M; ++i) {
+      int i0 = 0;
+      if (!tb) {
+        /* four dot products per pass over column j of B */
+        const double* b = B + (size_t)j * ldb;
+        for (; i0 + 4 <= M; i0 += 4) {
+          const double* a0 = A + (size_t)i0 * lda;
+          const double* a1 = a0 + lda;
+          const double* a2 = a1 + lda;
+          const double* a3 = a2 + lda;
+          double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma omp simd reduction(+ : s0, s1, s2, s3)
+          for (int k = 0; k < K; ++k) {
+            const double bk = b[k];
+            s0 += a0[k] * bk;
+            s1 += a1[k] * bk;
+            s2 += a2[k] * bk;
+            s3 += a3[k] * bk;
+          }
+          c[i0] += alpha * s0;
+          c[i0 + 1] += alpha * s1;
+          c[i0 + 2] += alpha * s2;
+          c[i0 + 3] += alpha * s3;
+        }
+      }
+      for (int i = i0; i < M; ++i) {
         const double* a = A + (size_t)i * lda;
         double acc = 0.0;
         if (!tb) {
