@@ -140,6 +140,71 @@ RTOC_SCAN_DEV void fwd_subst(const double* L, int n, int ld, double* x) {
   }
 }
 
+// C(i,j) = sum_k A(i,k) B(k,j) between LDS-resident operands with compile-time shapes and strides,
+// A(i,k) = A[i*ARS + k*ACS], B(k,j) = B[k*BRS + j*BCS]; epilogue(row, col, value).  On the GPU the
+// 16x16 tiles are dealt to the NT/64 waves and computed with v_mfma_f64_16x16x4_f64 (lds_gemm.hpp); the
+// host emulation runs plain loops.
+#if defined(__HIPCC__)
+template <int NT, int M, int N, int K, int ARS, int ACS, int BRS, int BCS, class E>
+RTOC_SCAN_DEV void scan_gemm(const double* A, const double* B, int tid, E&& epilogue) {
+  rtoc::lds_gemm<NT / 64, M, N, K, ARS, ACS, BRS, BCS>(
+      A, B, tid, [&](int row, int col, double v, int, int) { epilogue(row, col, v); });
+}
+#else
+template <int NT, int M, int N, int K, int ARS, int ACS, int BRS, int BCS, class E>
+RTOC_SCAN_DEV void scan_gemm(const double* A, const double* B, int tid, E&& epilogue) {
+  for (int idx = tid; idx < M * N; idx += NT) {
+    const int i = idx % M, j = idx / M;
+    double acc = 0.0;
+    for (int k = 0; k < K; ++k) acc += A[i * ARS + k * ACS] * B[k * BRS + j * BCS];
+    epilogue(i, j, acc);
+  }
+}
+#endif
+
+// ---- cooperative Cholesky with ONE barrier per column: the trailing update works on the unscaled column
+//      (A[i][k] -= A[i][j] A[k][j] / d), the scaled column goes to a separate output, so that nothing a
+//      thread reads in a step is written in the same step.  Lout: lower factor (ld as A), linv: 1/diag. ----
+template <int NT>
+RTOC_SCAN_DEV void lds_cholesky_1b(double* A, double* Lout, double* linv, int n, int ld, int tid, double* flag) {
+  for (int j = 0; j < n; ++j) {
+    double d = A[j + j * ld];
+    if (!(d > 0.0)) {
+      if (tid == 0) *flag = 1.0;
+      d = 1.0;
+    }
+    const double rs = 1.0 / sqrt(d), id = 1.0 / d;
+    for (int i = j + tid; i < n; i += NT) Lout[i + j * ld] = A[i + j * ld] * rs;
+    if (tid == 0) linv[j] = rs;
+    const int m = n - j - 1;
+    for (int idx = tid; idx < m * m; idx += NT) {
+      const int ii = idx % m, kk = idx / m;
+      if (ii >= kk) {
+        const int i = j + 1 + ii, k = j + 1 + kk;
+        A[i + k * ld] -= A[i + j * ld] * A[k + j * ld] * id;
+      }
+    }
+    RTOC_SCAN_SYNC();
+  }
+}
+
+// x <- L^-1 x for one column, solved in registers (N compile-time: no dependent LDS round trips)
+template <int N>
+RTOC_SCAN_DEV void fwd_subst_reg(const double* L, const double* linv, int ld, double* xlds) {
+  double x[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) x[k] = xlds[k];
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    double acc = x[k];
+#pragma unroll
+    for (int m = 0; m < k; ++m) acc -= L[k + m * ld] * x[m];
+    x[k] = acc * linv[k];
+  }
+#pragma unroll
+  for (int k = 0; k < N; ++k) xlds[k] = x[k];
+}
+
 template <int NV, int NU, int NS>
 struct ElementCfg {
   static constexpr int NX = 2 * NV;
@@ -147,21 +212,32 @@ struct ElementCfg {
   static constexpr int LDZ = NU | 1;   // odd leading dimensions: conflict-free column walks
   static constexpr int LDS_ = NSP | 1;
   static constexpr int C_S = 0, C_L = NX, C_B = NX + 1, C_D = NX + 1 + NV;  // columns of Z
+  static constexpr int NCOL = C_D;                                          // [Zs | zl | Zb]
   static constexpr int NZ = NX + 1 + NV + NS;
-  static constexpr int OFF_L = 0;                                 // NU x NU
-  static constexpr int OFF_Z = OFF_L + pad8(LDZ * NU);            // NU x NZ
-  static constexpr int OFF_Y = OFF_Z + pad8(LDZ * NZ);            // [Ys | yl]  NU x (NX+1)
-  static constexpr int OFF_ZBP = OFF_Y + pad8(LDZ * (NX + 1));    // Zb'        NU x NV
-  static constexpr int OFF_QD = OFF_ZBP + pad8(LDZ * NV);         // Qd         NU x NS
-  static constexpr int OFF_LS = OFF_QD + pad8(LDZ * NSP);         // Ls         NS x NS
+  static constexpr int OFF_G = 0;                                 // Quu, consumed by the factorisation
+  static constexpr int OFF_L = OFF_G + pad8(LDZ * NU);            // L         NU x NU
+  static constexpr int OFF_Z = OFF_L + pad8(LDZ * NU);            // Z         NU x NZ
+  static constexpr int OFF_T = OFF_Z + pad8(LDZ * NZ);            // [T|tl|Tb] NS x NCOL
+  static constexpr int OFF_QD = OFF_T + pad8(LDS_ * NCOL);        // Qd        NU x NS
+  static constexpr int OFF_SC = OFF_QD + pad8(LDZ * NSP);         // S = Zd^T Zd, consumed
+  static constexpr int OFF_LS = OFF_SC + pad8(LDS_ * NSP);        // Ls        NS x NS
   static constexpr int OFF_RX = OFF_LS + pad8(LDS_ * NSP);        // Ls^-1 [Phix | P]  NS x (NX+1)
-  static constexpr int OFF_FLAG = OFF_RX + pad8(LDS_ * (NX + 1));
+  static constexpr int OFF_LINV = OFF_RX + pad8(LDS_ * (NX + 1)); // 1/diag(L), 1/diag(Ls)
+  static constexpr int OFF_FLAG = OFF_LINV + pad8(NU) + pad8(NSP);
   static constexpr int LDS_DOUBLES = OFF_FLAG + 8;
   static constexpr int LDS_BYTES = LDS_DOUBLES * 8;
 };
 
 // One grid point -> its element.  kr: the KKT record; elt: the element record (open grid points);
-// ps: the closed value record (terminal only).  Returns RTOC_STAT_* bits (valid for tid == 0).
+// ps: the closed value record (terminal only).  Returns RTOC_STAT_* bits.
+//
+// With Zall = [Zs | zl | Zb] = L^-1 [Qxu^T | lu | Fvu^T] and, on a switching-constraint grid point,
+// Tall = [T | tl | Tb] = [Ls^-1 Phix | Ls^-1 P | 0] - Qd^T Zall  (Ys = Zs + Qd T, yl = zl + Qd tl, Zb' = Zb + Qd Tb
+// in the notation of the file header; Qd has orthonormal columns) every block of the element is a block of
+// the two Gram matrices G1 = Zall^T Zall, G2 = Tall^T Tall:
+//   J = Qxx - (G1 - G2)[s,s]   eta = -lx + (G1 - G2)[l,s]   A[v,:] = Fxx[v,:] - (G1 - G2)[b,s]
+//   b[v] = Fx[v] - (G1 - G2)[l,b]   C[v,v] = (G1 - G2)[b,b]
+// computed on the matrix cores; the blocks are picked so that every store runs along a column of the output.
 template <int NV, int NU, int NS, int NT>
 RTOC_SCAN_DEV unsigned element_body(const rtoc_grid& g, const double* kr, double* elt, double* ps,
                                     double* smem, int tid) {
@@ -169,7 +245,7 @@ RTOC_SCAN_DEV unsigned element_body(const rtoc_grid& g, const double* kr, double
   constexpr rtoc_record_layout KL = SL.kkt;
   using C = ElementCfg<NV, NU, NS>;
   using E = EltLayout<NV>;
-  constexpr int NX = C::NX, LDZ = C::LDZ, LDSS = C::LDS_;
+  constexpr int NX = C::NX, LDZ = C::LDZ, LDSS = C::LDS_, NCOL = C::NCOL;
   const double* Qxx = kr + KL.off[RTOC_KKT_QXX];
   const double* lx = kr + KL.off[RTOC_KKT_LX];
   if (g.type == RTOC_GRID_TERMINAL) {
@@ -200,20 +276,30 @@ RTOC_SCAN_DEV unsigned element_body(const rtoc_grid& g, const double* kr, double
   const double* Pres = kr + KL.off[RTOC_KKT_PRES];
   const int ns = NS > 0 ? g.dims : 0;
   constexpr int ldn = NS;  // leading dimension of Phix / Phiu (ns_max)
+  double* sG = smem + C::OFF_G;
   double* sL = smem + C::OFF_L;
   double* sZ = smem + C::OFF_Z;
-  double* sY = smem + C::OFF_Y;
-  double* sZbp = smem + C::OFF_ZBP;
+  double* sT = smem + C::OFF_T;
   double* sQd = smem + C::OFF_QD;
+  double* sSc = smem + C::OFF_SC;
   double* sLs = smem + C::OFF_LS;
   double* sRx = smem + C::OFF_RX;
+  double* linv = smem + C::OFF_LINV;
+  double* linvs = linv + pad8(NU);
   double* flag = smem + C::OFF_FLAG;
   if (tid == 0) {
     flag[0] = 0.0;
     flag[1] = 0.0;
   }
-  // ---- Quu -> sL ; [Qxu^T | lu | Fvu^T | Phiu^T] -> sZ ----
-  for (int i = tid; i < NU * NU; i += NT) sL[(i % NU) + (i / NU) * LDZ] = Quu[i];
+  // ---- plain parts of the element: rows q of A and b, the zero blocks of C ----
+  for (int idx = tid; idx < NX * NX; idx += NT) {
+    const int r = idx % NX, c = idx / NX;
+    if (r < NV) elt[E::OFF_A + idx] = Fxx[idx];
+    if (r < NV || c < NV) elt[E::OFF_C + idx] = 0.0;
+  }
+  for (int r = tid; r < NV; r += NT) elt[E::OFF_B + r] = Fx[r];
+  // ---- Quu -> sG ; [Qxu^T | lu | Fvu^T | Phiu^T] -> sZ ----
+  for (int i = tid; i < NU * NU; i += NT) sG[(i % NU) + (i / NU) * LDZ] = Quu[i];
   for (int i = tid; i < NX * NU; i += NT) {  // Qxu(j,k), j = i % NX fastest (coalesced)
     const int j = i % NX, k = i / NX;
     sZ[k + (C::C_S + j) * LDZ] = Qxu[i];
@@ -229,29 +315,23 @@ RTOC_SCAN_DEV unsigned element_body(const rtoc_grid& g, const double* kr, double
     sZ[k + (C::C_D + j) * LDZ] = Phiu[j + k * ldn];
   }
   RTOC_SCAN_SYNC();
-  lds_cholesky<NT>(sL, NU, LDZ, tid, flag);
-  // ---- Z <- L^-1 Z, one column per thread ----
+  lds_cholesky_1b<NT>(sG, sL, linv, NU, LDZ, tid, flag);
+  // ---- Z <- L^-1 Z, one column per thread, in registers ----
   {
     const int ncol = C::C_D + ns;
-    for (int c = tid; c < ncol; c += NT) fwd_subst(sL, NU, LDZ, sZ + c * LDZ);
+    for (int c = tid; c < ncol; c += NT) fwd_subst_reg<NU>(sL, linv, LDZ, sZ + c * LDZ);
   }
   RTOC_SCAN_SYNC();
-  const double* Zs = sZ + C::C_S * LDZ;
-  const double* zl = sZ + C::C_L * LDZ;
-  const double* Zb = sZ + C::C_B * LDZ;
-  const double* Ys = Zs;
-  const double* yl = zl;
-  const double* Zbp = Zb;
   if (ns > 0) {
     const double* Zd = sZ + C::C_D * LDZ;
     for (int idx = tid; idx < ns * ns; idx += NT) {
       const int i = idx % ns, j = idx / ns;
       double acc = 0.0;
       for (int k = 0; k < NU; ++k) acc += Zd[k + i * LDZ] * Zd[k + j * LDZ];
-      sLs[i + j * LDSS] = acc;
+      sSc[i + j * LDSS] = acc;
     }
     RTOC_SCAN_SYNC();
-    lds_cholesky<NT>(sLs, ns, LDSS, tid, flag + 1);
+    lds_cholesky_1b<NT>(sSc, sLs, linvs, ns, LDSS, tid, flag + 1);
     // Qd = Zd Ls^-T (row k of Zd per thread); Rx = Ls^-1 [Phix | P] (one column per thread)
     for (int w = tid; w < NU + NX + 1; w += NT) {
       if (w < NU) {
@@ -259,67 +339,71 @@ RTOC_SCAN_DEV unsigned element_body(const rtoc_grid& g, const double* kr, double
         for (int j = 0; j < ns; ++j) {
           double acc = Zd[k + j * LDZ];
           for (int m = 0; m < j; ++m) acc -= sQd[k + m * LDZ] * sLs[j + m * LDSS];
-          sQd[k + j * LDZ] = acc / sLs[j + j * LDSS];
+          sQd[k + j * LDZ] = acc * linvs[j];
         }
       } else {
         const int c = w - NU;
         double* x = sRx + c * LDSS;
-        for (int j = 0; j < ns; ++j) x[j] = (c < NX) ? Phix[j + c * ldn] : Pres[j];
-        fwd_subst(sLs, ns, LDSS, x);
+        for (int j = 0; j < ns; ++j) {
+          double acc = (c < NX) ? Phix[j + c * ldn] : Pres[j];
+          for (int m = 0; m < j; ++m) acc -= sLs[j + m * LDSS] * x[m];
+          x[j] = acc * linvs[j];
+        }
       }
     }
     RTOC_SCAN_SYNC();
-    // [Ys | yl] = z + Qd (Rx - Qd^T z) ;  Zb' = z - Qd Qd^T z
-    for (int w = tid; w < NX + 1 + NV; w += NT) {
-      const bool isb = w > NX;
-      const double* z = isb ? Zb + (w - NX - 1) * LDZ : sZ + w * LDZ;
-      double* out = isb ? sZbp + (w - NX - 1) * LDZ : sY + w * LDZ;
-      double t[C::NSP];
-      for (int j = 0; j < ns; ++j) {
-        double acc = isb ? 0.0 : sRx[j + w * LDSS];
-        for (int k = 0; k < NU; ++k) acc -= sQd[k + j * LDZ] * z[k];
-        t[j] = acc;
-      }
-      for (int k = 0; k < NU; ++k) {
-        double acc = z[k];
-        for (int j = 0; j < ns; ++j) acc += sQd[k + j * LDZ] * t[j];
-        out[k] = acc;
+    // Tall = [Rx | 0] - Qd^T Zall, rows >= ns zero (the Gram product runs over all NS rows)
+    for (int c = tid; c < NCOL; c += NT) {
+      const double* z = sZ + c * LDZ;
+      for (int j = 0; j < NS; ++j) {
+        double acc = 0.0;
+        if (j < ns) {
+          acc = (c <= NX) ? sRx[j + c * LDSS] : 0.0;
+          for (int k = 0; k < NU; ++k) acc -= sQd[k + j * LDZ] * z[k];
+        }
+        sT[j + c * LDSS] = acc;
       }
     }
     RTOC_SCAN_SYNC();
-    Ys = sY;
-    yl = sY + NX * LDZ;
-    Zbp = sZbp;
   }
-  // ---- element ----
-  for (int idx = tid; idx < NX * NX; idx += NT) {
-    const int i = idx % NX, j = idx / NX;
-    double aj = 0.0, aa = 0.0, ac = 0.0;
-    for (int k = 0; k < NU; ++k) {
-      const double zsi = Zs[k + i * LDZ], ysi = Ys[k + i * LDZ];
-      const double zsj = Zs[k + j * LDZ], ysj = Ys[k + j * LDZ];
-      aj += zsi * ysj + ysi * (zsj - ysj);
+  // ---- the Gram blocks -> element (sgn: +1 for G1, -1 for G2 which then accumulates) ----
+  auto emit = [&](int row, int col, double v, bool first) {
+    if (col == NX) return;  // no block with the lu column on the right
+    double* dst;
+    double base, sg;
+    if (row < NX) {
+      if (col < NX) {  // J (stored transposed: symmetric)
+        dst = elt + E::OFF_J + col + row * NX;
+        base = Qxx[col + row * NX];
+        sg = -1.0;
+      } else {  // (Zb^T Zs)(cb, row) -> A[NV + cb][row]
+        dst = elt + E::OFF_A + (NV + col - NX - 1) + row * NX;
+        base = Fxx[(NV + col - NX - 1) + row * NX];
+        sg = -1.0;
+      }
+    } else if (row == NX) {
+      if (col < NX) {
+        dst = elt + E::OFF_ETA + col;
+        base = -lx[col];
+        sg = 1.0;
+      } else {
+        dst = elt + E::OFF_B + NV + col - NX - 1;
+        base = Fx[NV + col - NX - 1];
+        sg = -1.0;
+      }
+    } else {
+      if (col < NX) return;
+      dst = elt + E::OFF_C + (NV + col - NX - 1) + (NV + row - NX - 1) * NX;
+      base = 0.0;
+      sg = 1.0;
     }
-    if (i >= NV) {
-      for (int k = 0; k < NU; ++k) aa += Zb[k + (i - NV) * LDZ] * Ys[k + j * LDZ];
-      if (j >= NV)
-        for (int k = 0; k < NU; ++k) ac += Zbp[k + (i - NV) * LDZ] * Zbp[k + (j - NV) * LDZ];
-    }
-    elt[E::OFF_J + idx] = Qxx[idx] - aj;
-    elt[E::OFF_A + idx] = Fxx[idx] - aa;
-    elt[E::OFF_C + idx] = ac;
-  }
-  for (int i = tid; i < NX; i += NT) {
-    double ae = 0.0, ab = 0.0;
-    for (int k = 0; k < NU; ++k) {
-      const double zsi = Zs[k + i * LDZ], ysi = Ys[k + i * LDZ];
-      ae += zsi * yl[k] + ysi * (zl[k] - yl[k]);
-    }
-    if (i >= NV)
-      for (int k = 0; k < NU; ++k) ab += Zb[k + (i - NV) * LDZ] * yl[k];
-    elt[E::OFF_ETA + i] = -lx[i] + ae;
-    elt[E::OFF_B + i] = Fx[i] - ab;
-  }
+    *dst = first ? base + sg * v : *dst - sg * v;
+  };
+  scan_gemm<NT, NCOL, NCOL, NU, LDZ, 1, 1, LDZ>(sZ, sZ, tid,
+                                                [&](int row, int col, double v) { emit(row, col, v, true); });
+  if (NS > 0 && ns > 0)
+    scan_gemm<NT, NCOL, NCOL, (NS > 0 ? NS : 1), LDSS, 1, 1, LDSS>(
+        sT, sT, tid, [&](int row, int col, double v) { emit(row, col, v, false); });
   unsigned stat = 0;
   if (flag[0] != 0.0) stat |= RTOC_STAT_QUU_NOT_SPD;
   if (flag[1] != 0.0) stat |= RTOC_STAT_S_NOT_SPD;
@@ -327,28 +411,6 @@ RTOC_SCAN_DEV unsigned element_body(const rtoc_grid& g, const double* kr, double
 }
 
 // ---- combination ---------------------------------------------------------------------------------
-// C(i,j) = sum_k A(i,k) B(k,j) between LDS-resident operands with compile-time shapes and strides,
-// A(i,k) = A[i*ARS + k*ACS], B(k,j) = B[k*BRS + j*BCS]; epilogue(row, col, value).  On the GPU the
-// 16x16 tiles are dealt to the NT/64 waves and computed with v_mfma_f64_16x16x4_f64 (lds_gemm.hpp); the
-// host emulation runs plain loops.
-#if defined(__HIPCC__)
-template <int NT, int M, int N, int K, int ARS, int ACS, int BRS, int BCS, class E>
-RTOC_SCAN_DEV void scan_gemm(const double* A, const double* B, int tid, E&& epilogue) {
-  rtoc::lds_gemm<NT / 64, M, N, K, ARS, ACS, BRS, BCS>(
-      A, B, tid, [&](int row, int col, double v, int, int) { epilogue(row, col, v); });
-}
-#else
-template <int NT, int M, int N, int K, int ARS, int ACS, int BRS, int BCS, class E>
-RTOC_SCAN_DEV void scan_gemm(const double* A, const double* B, int tid, E&& epilogue) {
-  for (int idx = tid; idx < M * N; idx += NT) {
-    const int i = idx % M, j = idx / M;
-    double acc = 0.0;
-    for (int k = 0; k < K; ++k) acc += A[i * ARS + k * ACS] * B[k * BRS + j * BCS];
-    epilogue(i, j, acc);
-  }
-}
-#endif
-
 // exchange between the LPC (<= 8) adjacent lanes that share one column of the elimination (DPP)
 #if defined(__HIPCC__)
 template <int CTRL>
@@ -497,11 +559,13 @@ RTOC_SCAN_DEV unsigned combine_body(const double* e1, const double* J2, const do
   //      in the registers of LPC adjacent lanes (lane h owns the rows h, h+LPC, ...).  Step k: the
   //      lanes of column k pick the pivot among the unused rows and publish the column, then all
   //      columns > k eliminate.  One barrier per step (the published column is double-buffered). ----
+  // a closed right operand needs no Tc = M^-1 C1: the C1 columns stay out of the elimination
+  const int ncol = closed2 ? 2 * NX + 1 : LDW;
   double col[CPT][RPL];
 #pragma unroll
   for (int s = 0; s < CPT; ++s) {
     const int h = tid % LPC, c = slot_col<C>(tid, s);
-    if (c < LDW) {
+    if (c < ncol) {
 #pragma unroll
       for (int t = 0; t < RPL; ++t) {
         const int r = h + LPC * t;
@@ -595,7 +659,7 @@ RTOC_SCAN_DEV unsigned combine_body(const double* e1, const double* J2, const do
 #pragma unroll
     for (int s = 0; s < CPT; ++s) {
       const int c = slot_col<C>(tid, s);
-      if (c > k && c < LDW) {
+      if (c > k && c < ncol) {
         double wp = 0.0;
 #pragma unroll
         for (int t = 0; t < RPL; ++t) wp = (mine && t == tp) ? col[s][t] : wp;
