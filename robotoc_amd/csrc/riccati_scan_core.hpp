@@ -162,6 +162,19 @@ RTOC_SCAN_DEV void scan_gemm(const double* A, const double* B, int tid, E&& epil
 }
 #endif
 
+// 1/sqrt(d) to fp64 accuracy: hardware estimate + two Newton steps (no sqrt, no divide)
+RTOC_SCAN_DEV double fast_rsqrt(double d) {
+#if defined(__HIPCC__)
+  double y = __builtin_amdgcn_rsq(d);
+  const double h = 0.5 * d;
+  y = y * __builtin_fma(-h * y, y, 1.5);
+  y = y * __builtin_fma(-h * y, y, 1.5);
+  return y;
+#else
+  return 1.0 / sqrt(d);
+#endif
+}
+
 // ---- cooperative Cholesky with ONE barrier per column: the trailing update works on the unscaled column
 //      (A[i][k] -= A[i][j] A[k][j] / d), the scaled column goes to a separate output, so that nothing a
 //      thread reads in a step is written in the same step.  Lout: lower factor (ld as A), linv: 1/diag. ----
@@ -173,7 +186,7 @@ RTOC_SCAN_DEV void lds_cholesky_1b(double* A, double* Lout, double* linv, int n,
       if (tid == 0) *flag = 1.0;
       d = 1.0;
     }
-    const double rs = 1.0 / sqrt(d), id = 1.0 / d;
+    const double rs = fast_rsqrt(d), id = rs * rs;
     for (int i = j + tid; i < n; i += NT) Lout[i + j * ld] = A[i + j * ld] * rs;
     if (tid == 0) linv[j] = rs;
     const int m = n - j - 1;
@@ -224,8 +237,11 @@ struct ElementCfg {
   static constexpr int OFF_RX = OFF_LS + pad8(LDS_ * NSP);        // Ls^-1 [Phix | P]  NS x (NX+1)
   static constexpr int OFF_LINV = OFF_RX + pad8(LDS_ * (NX + 1)); // 1/diag(L), 1/diag(Ls)
   static constexpr int OFF_FLAG = OFF_LINV + pad8(NU) + pad8(NSP);
-  static constexpr int LDS_DOUBLES = OFF_FLAG + 8;
+  static constexpr int LDG = NCOL | 1;
+  static constexpr int OFF_GRAM = OFF_FLAG + 8;                   // G1 - G2, NCOL x NCOL
+  static constexpr int LDS_DOUBLES = OFF_GRAM + pad8(LDG * NCOL);
   static constexpr int LDS_BYTES = LDS_DOUBLES * 8;
+  static_assert(LDS_BYTES <= 160 * 1024, "element scratch must fit the LDS of a CU");
 };
 
 // One grid point -> its element.  kr: the KKT record; elt: the element record (open grid points);
@@ -366,44 +382,28 @@ RTOC_SCAN_DEV unsigned element_body(const rtoc_grid& g, const double* kr, double
     }
     RTOC_SCAN_SYNC();
   }
-  // ---- the Gram blocks -> element (sgn: +1 for G1, -1 for G2 which then accumulates) ----
-  auto emit = [&](int row, int col, double v, bool first) {
-    if (col == NX) return;  // no block with the lu column on the right
-    double* dst;
-    double base, sg;
-    if (row < NX) {
-      if (col < NX) {  // J (stored transposed: symmetric)
-        dst = elt + E::OFF_J + col + row * NX;
-        base = Qxx[col + row * NX];
-        sg = -1.0;
-      } else {  // (Zb^T Zs)(cb, row) -> A[NV + cb][row]
-        dst = elt + E::OFF_A + (NV + col - NX - 1) + row * NX;
-        base = Fxx[(NV + col - NX - 1) + row * NX];
-        sg = -1.0;
-      }
-    } else if (row == NX) {
-      if (col < NX) {
-        dst = elt + E::OFF_ETA + col;
-        base = -lx[col];
-        sg = 1.0;
-      } else {
-        dst = elt + E::OFF_B + NV + col - NX - 1;
-        base = Fx[NV + col - NX - 1];
-        sg = -1.0;
-      }
-    } else {
-      if (col < NX) return;
-      dst = elt + E::OFF_C + (NV + col - NX - 1) + (NV + row - NX - 1) * NX;
-      base = 0.0;
-      sg = 1.0;
-    }
-    *dst = first ? base + sg * v : *dst - sg * v;
-  };
+  // ---- G = G1 - G2 -> LDS (symmetric), then the element in one pass of independent, coalesced HBM accesses
+  //      (an epilogue that fetched its Qxx / Fxx entries tile by tile paid one HBM round trip per tile) ----
+  double* sGr = smem + C::OFF_GRAM;
+  constexpr int LDG = C::LDG;
   scan_gemm<NT, NCOL, NCOL, NU, LDZ, 1, 1, LDZ>(sZ, sZ, tid,
-                                                [&](int row, int col, double v) { emit(row, col, v, true); });
+                                                [&](int row, int col, double v) { sGr[row + col * LDG] = v; });
   if (NS > 0 && ns > 0)
     scan_gemm<NT, NCOL, NCOL, (NS > 0 ? NS : 1), LDSS, 1, 1, LDSS>(
-        sT, sT, tid, [&](int row, int col, double v) { emit(row, col, v, false); });
+        sT, sT, tid, [&](int row, int col, double v) { sGr[row + col * LDG] -= v; });  // same lane as above
+  RTOC_SCAN_SYNC();
+  for (int idx = tid; idx < NX * NX; idx += NT) {
+    const int r = idx % NX, c = idx / NX;
+    elt[E::OFF_J + idx] = Qxx[idx] - sGr[r + c * LDG];
+    if (r >= NV) {
+      elt[E::OFF_A + idx] = Fxx[idx] - sGr[(NX + 1 + r - NV) + c * LDG];
+      if (c >= NV) elt[E::OFF_C + idx] = sGr[(NX + 1 + r - NV) + (NX + 1 + c - NV) * LDG];
+    }
+  }
+  for (int r = tid; r < NX; r += NT) {
+    elt[E::OFF_ETA + r] = -lx[r] + sGr[r + NX * LDG];
+    if (r >= NV) elt[E::OFF_B + r] = Fx[r] - sGr[(NX + 1 + r - NV) + NX * LDG];
+  }
   unsigned stat = 0;
   if (flag[0] != 0.0) stat |= RTOC_STAT_QUU_NOT_SPD;
   if (flag[1] != 0.0) stat |= RTOC_STAT_S_NOT_SPD;
