@@ -30,7 +30,11 @@ struct ScanArgs {
 
 constexpr int SCAN_ELT_NT = 256;  // element kernel
 // combination kernel: the waves share the MFMA tiles; up to 8 lanes per column of the elimination (3 NX + 1 columns)
+#ifdef RTOC_SCAN_FORCE_NT
+constexpr int scan_comb_nt(int) { return RTOC_SCAN_FORCE_NT; }  // tuning probes only
+#else
 constexpr int scan_comb_nt(int nv) { return 8 * (6 * nv + 1) <= 512 ? 512 : 1024; }
+#endif
 
 template <int NV, int NU, int NS>
 __global__ __launch_bounds__(SCAN_ELT_NT) void scan_element_kernel(ScanArgs a) {

@@ -450,6 +450,25 @@ RTOC_SCAN_DEV double masked_abs(double v, bool dead) {
   return dead ? 0.0 : fabs(v);
 #endif
 }
+// A column slice in registers.  On the GPU a clang vector: indexing it with a wave-uniform (scalar-register)
+// index is a register-relative move (s_set_gpr_idx), not a chain of selects.
+#if defined(__HIPCC__)
+template <int N>
+struct ColVec {
+  typedef double type __attribute__((ext_vector_type(N)));
+};
+RTOC_SCAN_DEV int uniform_int(int v) { return __builtin_amdgcn_readfirstlane(v); }
+#else
+template <int N>
+struct ColVec {
+  struct type {
+    double v[N];
+    double& operator[](int i) { return v[i]; }
+    const double& operator[](int i) const { return v[i]; }
+  };
+};
+RTOC_SCAN_DEV int uniform_int(int v) { return v; }
+#endif
 constexpr int QUAD_XOR1 = 0xB1;  // quad_perm [1,0,3,2]
 constexpr int QUAD_XOR2 = 0x4E;  // quad_perm [2,3,0,1]
 constexpr int HALF_MIRROR = 0x141;  // row_half_mirror: lane i <-> 7 - i of every 8 lanes (the other quad)
@@ -463,7 +482,11 @@ struct CombineCfg {
   // lanes per column (adjacent lanes of one quad), rows per lane, column slots per thread
   // Big robots take two column slots per thread rather than fewer lanes per column: the pivot columns (< NX)
   // all sit in slot 0, and the rows per lane set the length of the serial search / elimination chain.
+#ifdef RTOC_SCAN_FORCE_LPC
+  static constexpr int LPC = RTOC_SCAN_FORCE_LPC;  // tuning probes only
+#else
   static constexpr int LPC = (2 * NT >= 8 * LDW) ? 8 : (2 * NT >= 4 * LDW) ? 4 : (2 * NT >= 2 * LDW) ? 2 : 1;
+#endif
   static constexpr int RPL = (NX + LPC - 1) / LPC;
   static constexpr int GPS = NT / LPC;                    // column groups per slot
   static constexpr int CPT = (LDW + GPS - 1) / GPS;       // column slots per thread: 1 or 2 on the GPU
@@ -561,7 +584,11 @@ RTOC_SCAN_DEV unsigned combine_body(const double* e1, const double* J2, const do
   //      columns > k eliminate.  One barrier per step (the published column is double-buffered). ----
   // a closed right operand needs no Tc = M^-1 C1: the C1 columns stay out of the elimination
   const int ncol = closed2 ? 2 * NX + 1 : LDW;
-  double col[CPT][RPL];
+  // (the compiler turns a length of 8 into register-relative moves and expands odd lengths into selects;
+  //  padding 5 to 8 was measured slower than the selects)
+  constexpr int VL = RPL;
+  typedef typename ColVec<VL>::type colvec;
+  colvec col[CPT];
 #pragma unroll
   for (int s = 0; s < CPT; ++s) {
     const int h = tid % LPC, c = slot_col<C>(tid, s);
@@ -594,7 +621,7 @@ RTOC_SCAN_DEV unsigned combine_body(const double* e1, const double* J2, const do
   for (int w = 0; w < UW; ++w) used[w] = 0u;
   int* pki = reinterpret_cast<int*>(piv);
   // search + publish of pivot column kk by its LPC owner lanes (slot s)
-  auto publish = [&](const double (&cs)[RPL], int kk, int h) {
+  auto publish = [&](const colvec& cs, int kk, int h) {
     double* mk = mult + (kk & 1) * C::MPAD;
     double a[RPL];
     double m0 = 0.0, m1 = 0.0;
@@ -653,27 +680,29 @@ RTOC_SCAN_DEV unsigned combine_body(const double* e1, const double* J2, const do
     const double ipv = fast_rcp(mk[p]);
     const int h = tid % LPC;
     const bool mine = (p % LPC) == h;  // this lane owns the pivot row
-    const int tp = p / LPC;
+    const int tp = uniform_int(p / LPC);
 #pragma unroll
     for (int w = 0; w < UW; ++w) used[w] |= (mine && (tp / 32) == w) ? (1u << (tp % 32)) : 0u;
 #pragma unroll
     for (int s = 0; s < CPT; ++s) {
       const int c = slot_col<C>(tid, s);
-      if (c > k && c < ncol) {
-        double wp = 0.0;
-#pragma unroll
-        for (int t = 0; t < RPL; ++t) wp = (mine && t == tp) ? col[s][t] : wp;
+      if (c > k && c < ncol && !(RTOC_SCAN_PROBE & 8)) {
+        // entry of the pivot row: tp is wave-uniform -> register-relative read / write instead of RPL selects
+        double wp = col[s][tp];
+        wp = mine ? wp : 0.0;
         if (LPC > 1) wp += quad_perm_d<QUAD_XOR1>(wp);  // the other lanes contribute exact zeros
         if (LPC > 2) wp += quad_perm_d<QUAD_XOR2>(wp);
         if (LPC > 4) wp += quad_perm_d<HALF_MIRROR>(wp);
         const double x = wp * ipv;
 #pragma unroll
-        for (int t = 0; t < RPL; ++t) {
-          const double nv = col[s][t] - mk[h + LPC * t] * x;
-          col[s][t] = (mine && t == tp) ? x : nv;
-        }
+        for (int t = 0; t < RPL; ++t) col[s][t] -= mk[h + LPC * t] * x;
+        if (mine) col[s][tp] = x;
         // the next pivot column goes out as soon as it is up to date (before this thread's other slots)
-        if (c == k + 1 && k + 1 < NX) publish(col[s], k + 1, h);
+        if (c == k + 1 && k + 1 < NX && !(RTOC_SCAN_PROBE & 16)) publish(col[s], k + 1, h);
+      }
+      if ((RTOC_SCAN_PROBE & 24) && c == k + 1 && k + 1 < NX && h == 0) {  // timing probes: keep the hand-off alive
+        pki[(k + 1) & 1] = k + 1;
+        kof[k + 1] = k + 1;
       }
     }
   }
