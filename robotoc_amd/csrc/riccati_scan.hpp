@@ -2,7 +2,7 @@
 //
 // Launch sequence of one backward recursion with RTOC_OPT_BACKWARD_SCAN (rtoc_capi.hip: launch_backward_scan):
 //   scan_element_kernel    grid (nstages, batch)      every grid point -> its interval element
-//   scan_combine_kernel    grid (nstages - d, batch)  for d = 1, 2, 4, ... : element(i) <- element(i) o element(i+d);
+//   scan_combine_kernel    grid (nstages - d, batch, 2) for d = 1, 2, 4, ... : element(i) <- element(i) o element(i+d);
 //                                                     elements that reach the terminal grid point become value
 //                                                     records (P_i, s_i)
 //   riccati_backward_kernel in its one-stage mode, grid (batch, nstages): policies of all grid points
@@ -29,11 +29,15 @@ struct ScanArgs {
 };
 
 constexpr int SCAN_ELT_NT = 256;  // element kernel
-// combination kernel: the waves share the MFMA tiles; up to 8 lanes per column of the elimination (3 NX + 1 columns)
+// combination kernel, two workgroups per combination (grid z): the waves share the MFMA tiles; up to 8 lanes per
+// column of the elimination (2 NX + 1 columns per workgroup)
 #ifdef RTOC_SCAN_FORCE_NT
 constexpr int scan_comb_nt(int) { return RTOC_SCAN_FORCE_NT; }  // tuning probes only
 #else
-constexpr int scan_comb_nt(int nv) { return 8 * (6 * nv + 1) <= 512 ? 512 : 1024; }
+constexpr int scan_comb_nt(int nv) {
+  const int want = (8 * (4 * nv + 1) + 63) / 64 * 64;
+  return want < 256 ? 256 : want > 1024 ? 1024 : want;
+}
 #endif
 
 template <int NV, int NU, int NS>
@@ -55,19 +59,20 @@ __global__ __launch_bounds__(scan_comb_nt(NV)) void scan_combine_kernel(ScanArgs
   constexpr int SCAN_NT = scan_comb_nt(NV);
   extern __shared__ __attribute__((aligned(16))) double smem[];
   using E = scan::EltLayout<NV>;
-  const int i = blockIdx.x, b = a.first + blockIdx.y;
+  const int i = blockIdx.x, b = a.first + blockIdx.y, part = blockIdx.z;
   if (b >= a.batch) return;
   int j;
   bool closed2;
   if (!scan::level_plan(a.nstages, a.dist, i, &j, &closed2)) return;
+  if (part == 1 && closed2) return;  // value records have no C
   const size_t inst = (size_t)b * a.nstages;
   const double* e1 = a.src + (inst + i) * E::STRIDE;
   const double* e2 = a.src + (inst + j) * E::STRIDE;
   const double* p2 = a.ps + (inst + j) * E::PS_STRIDE;
   const unsigned stat = scan::combine_body<NV, SCAN_NT>(
       e1, closed2 ? p2 + E::PS_P : e2 + E::OFF_J, closed2 ? p2 + E::PS_S : e2 + E::OFF_ETA, e2 + E::OFF_A,
-      e2 + E::OFF_B, e2 + E::OFF_C, closed2, a.dst + (inst + i) * E::STRIDE, a.ps + (inst + i) * E::PS_STRIDE,
-      smem, threadIdx.x);
+      e2 + E::OFF_B, e2 + E::OFF_C, closed2, part, a.dst + (inst + i) * E::STRIDE,
+      a.ps + (inst + i) * E::PS_STRIDE, smem, threadIdx.x);
   if (stat && threadIdx.x == 0) atomicOr(&a.status[b], stat);
 }
 

@@ -478,7 +478,7 @@ constexpr int scan_lds_ld(int n) { return (n % 4 == 2) ? n : n + 2; }  // as lds
 template <int NV, int NT>
 struct CombineCfg {
   static constexpr int NX = 2 * NV;
-  static constexpr int LDW = 3 * NX + 1;  // columns of the elimination: [M | A1 | t | C1]
+  static constexpr int LDW = 2 * NX + 1;  // columns of one workgroup's tableau: [M | A1 | t] or [M | C1]
   // lanes per column (adjacent lanes of one quad), rows per lane, column slots per thread
   // Big robots take two column slots per thread rather than fewer lanes per column: the pivot columns (< NX)
   // all sit in slot 0, and the rows per lane set the length of the serial search / elimination chain.
@@ -530,12 +530,16 @@ RTOC_SCAN_DEV void load_mat(double* dst, const double* src, int tid) {
 // e1 = element of [i, j), (J2, eta2, A2, b2, C2) = element of [j, k).  closed2: [j,k) contains the
 // terminal grid point, then J2 / eta2 are its value record, A2 / b2 / C2 are not read and the result
 // is the closed value record `ps_out`; otherwise the result is the element `out`.
-// Three NX x NX LDS regions are time-shared:  R0: C1 -> Ta -> Tc   R1: J2 -> A1 -> A2   R2: M -> U -> V
+// The work of one combination is split over TWO workgroups that share nothing but their inputs (the
+// elimination is bound by the VALU throughput of a CU, and the pivots depend on M alone, so both run it on M):
+//   part 0: [M | A1 | t]  ->  Ta, tb  ->  J, eta (and A, b)        part 1 (open right operand only): [M | C1] -> Tc -> C
+// Three NX x NX LDS regions are time-shared:  R0: C1 -> Ta (Tc)   R1: J2 -> A1 -> A2   R2: M -> U (V)
 // (CombineCfg::PRE: A1 and A2 live in R3 / R4 from the start)
 template <int NV, int NT>
 RTOC_SCAN_DEV unsigned combine_body(const double* e1, const double* J2, const double* eta2,
-                                    const double* A2, const double* b2, const double* C2, bool closed2,
+                                    const double* A2, const double* b2, const double* C2, bool closed2, int part,
                                     double* out, double* ps_out, double* smem, int tid) {
+  if (part == 1 && closed2) return 0;
   using C = CombineCfg<NV, NT>;
   using E = EltLayout<NV>;
   constexpr int NX = C::NX, LDW = C::LDW, CPT = C::CPT, LPC = C::LPC, RPL = C::RPL, LDM = C::LDM,
@@ -564,7 +568,7 @@ RTOC_SCAN_DEV unsigned combine_body(const double* e1, const double* J2, const do
   load_mat<NX, LDM, NT>(R0, C1, tid);
   load_mat<NX, LDM, NT>(R1, J2, tid);
   if (PRE) {
-    load_mat<NX, LDM, NT>(RA1, A1, tid);
+    if (part == 0) load_mat<NX, LDM, NT>(RA1, A1, tid);
     if (!closed2) load_mat<NX, LDM, NT>(RA2, A2, tid);
   }
   for (int i = tid; i < NX; i += NT) seta2[i] = eta2[i];
@@ -578,12 +582,11 @@ RTOC_SCAN_DEV unsigned combine_body(const double* e1, const double* J2, const do
     vt[r] = acc;
   }
   RTOC_SCAN_SYNC();
-  // ---- Gauss-Jordan elimination of [M | A1 | t | C1] with implicit partial pivoting.  Column c lives
+  // ---- Gauss-Jordan elimination of [M | A1 | t] / [M | C1] with implicit partial pivoting.  Column c lives
   //      in the registers of LPC adjacent lanes (lane h owns the rows h, h+LPC, ...).  Step k: the
   //      lanes of column k pick the pivot among the unused rows and publish the column, then all
   //      columns > k eliminate.  One barrier per step (the published column is double-buffered). ----
-  // a closed right operand needs no Tc = M^-1 C1: the C1 columns stay out of the elimination
-  const int ncol = closed2 ? 2 * NX + 1 : LDW;
+  const int ncol = part == 0 ? 2 * NX + 1 : 2 * NX;
   // (the compiler turns a length of 8 into register-relative moves and expands odd lengths into selects;
   //  padding 5 to 8 was measured slower than the selects)
   constexpr int VL = RPL;
@@ -600,12 +603,12 @@ RTOC_SCAN_DEV unsigned combine_body(const double* e1, const double* J2, const do
         if (r < NX) {
           if (c < NX)
             v = R2[r + c * LDM];
+          else if (part == 1)
+            v = R0[r + (c - NX) * LDM];
           else if (c < 2 * NX)
             v = PRE ? RA1[r + (c - NX) * LDM] : A1[r + (c - NX) * NX];
-          else if (c == 2 * NX)
-            v = vt[r];
           else
-            v = R0[r + (c - 2 * NX - 1) * LDM];
+            v = vt[r];
         }
         col[s][t] = v;
       }
@@ -707,11 +710,11 @@ RTOC_SCAN_DEV unsigned combine_body(const double* e1, const double* J2, const do
     }
   }
   RTOC_SCAN_SYNC();
-  // the solution row k sits in pivot row p_k.  Ta -> R0 (row-major, ld LDT), tb -> vt; Tc stays in registers.
+  // the solution row k sits in pivot row p_k.  Ta (part 1: Tc) -> R0 (row-major, ld LDT), tb -> vt
 #pragma unroll
   for (int s = 0; s < CPT; ++s) {
     const int h = tid % LPC, c = slot_col<C>(tid, s);
-    if (c >= NX && c <= 2 * NX) {
+    if (c >= NX && c < ncol) {
 #pragma unroll
       for (int t = 0; t < RPL; ++t) {
         const int r = h + LPC * t;
@@ -726,6 +729,21 @@ RTOC_SCAN_DEV unsigned combine_body(const double* e1, const double* J2, const do
   }
   RTOC_SCAN_SYNC();
   if (RTOC_SCAN_PROBE & 2) return 0;
+  const unsigned stat = flag[0] != 0.0 ? RTOC_STAT_NAN : 0u;
+  if (part == 1) {
+    // ---- V = A2 Tc -> R2 ; C = C2 + V A2^T (symmetric, stored transposed) ----
+    if (!PRE) {
+      load_mat<NX, LDM, NT>(RA2, A2, tid);  // R1: J2 is dead after the M product
+      RTOC_SCAN_SYNC();
+    }
+    scan_gemm<NT, NX, NX, NX, 1, LDM, LDT, 1>(RA2, R0, tid,
+                                              [&](int row, int col_, double v) { R2[row + col_ * LDM] = v; });
+    RTOC_SCAN_SYNC();
+    scan_gemm<NT, NX, NX, NX, 1, LDM, LDM, 1>(R2, RA2, tid, [&](int row, int col_, double v) {
+      out[E::OFF_C + col_ + row * NX] = v + C2[col_ + row * NX];
+    });
+    return stat;
+  }
   // ---- U = J2 Ta -> R2 ; w = eta2 - J2 tb ----
   scan_gemm<NT, NX, NX, NX, 1, LDM, LDT, 1>(R1, R0, tid,
                                             [&](int row, int col_, double v) { R2[row + col_ * LDM] = v; });
@@ -750,7 +768,6 @@ RTOC_SCAN_DEV unsigned combine_body(const double* e1, const double* J2, const do
     for (int k = 0; k < NX; ++k) acc += RA1[k + i * LDM] * vw[k];
     eout[i] = acc;
   }
-  const unsigned stat = flag[0] != 0.0 ? RTOC_STAT_NAN : 0u;
   if (closed2) return stat;
   // ---- A2 in LDS ; A = A2 Ta (computed as Ta^T A2^T: coalesced stores) ; b = b2 + A2 tb ----
   if (!PRE) {
@@ -766,26 +783,6 @@ RTOC_SCAN_DEV unsigned combine_body(const double* e1, const double* J2, const do
     for (int k = 0; k < NX; ++k) acc += RA2[i + k * LDM] * vt[k];
     out[E::OFF_B + i] = acc;
   }
-  RTOC_SCAN_SYNC();
-  // ---- Tc (registers) -> R0 ; V = A2 Tc -> R2 ; C = C2 + V A2^T (symmetric, stored transposed) ----
-#pragma unroll
-  for (int s = 0; s < CPT; ++s) {
-    const int h = tid % LPC, c = slot_col<C>(tid, s);
-    if (c > 2 * NX && c < LDW) {
-#pragma unroll
-      for (int t = 0; t < RPL; ++t) {
-        const int r = h + LPC * t;
-        if (r < NX) R0[kof[r] * LDT + (c - 2 * NX - 1)] = col[s][t];
-      }
-    }
-  }
-  RTOC_SCAN_SYNC();
-  scan_gemm<NT, NX, NX, NX, 1, LDM, LDT, 1>(RA2, R0, tid,
-                                            [&](int row, int col_, double v) { R2[row + col_ * LDM] = v; });
-  RTOC_SCAN_SYNC();
-  scan_gemm<NT, NX, NX, NX, 1, LDM, LDM, 1>(R2, RA2, tid, [&](int row, int col_, double v) {
-    out[E::OFF_C + col_ + row * NX] = v + C2[col_ + row * NX];
-  });
   return stat;
 }
 

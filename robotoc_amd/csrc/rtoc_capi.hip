@@ -524,7 +524,7 @@ static int launch_backward_scan(rtoc_ctx* c, int first, int end, hipStream_t str
     s.src = c->d_scan[cur];
     s.dst = c->d_scan[cur ^ 1];
     s.dist = d;
-    hipLaunchKernelGGL(ks->scan_comb, dim3(n - d, nb), dim3(ks->scan_comb_threads), ks->scan_comb_lds, stream, s);
+    hipLaunchKernelGGL(ks->scan_comb, dim3(n - d, nb, 2), dim3(ks->scan_comb_threads), ks->scan_comb_lds, stream, s);
     cur ^= 1;
   }
   BwdArgs a;

@@ -33,9 +33,10 @@ static int run(const rtoc_grid* grid, int n, const double* kkt, double* ps, unsi
       const double* e1 = src + (size_t)i * E::STRIDE;
       const double* e2 = src + (size_t)j * E::STRIDE;
       const double* p2 = ps + (size_t)j * E::PS_STRIDE;
-      *stat |= combine_body<NV, 1>(e1, closed2 ? p2 + E::PS_P : e2 + E::OFF_J, closed2 ? p2 + E::PS_S : e2 + E::OFF_ETA,
-                                   e2 + E::OFF_A, e2 + E::OFF_B, e2 + E::OFF_C, closed2,
-                                   dst + (size_t)i * E::STRIDE, ps + (size_t)i * E::PS_STRIDE, smem_c.data(), 0);
+      for (int part = 0; part < 2; ++part)  // the two workgroups of a combination (grid z of the kernel)
+        *stat |= combine_body<NV, 1>(e1, closed2 ? p2 + E::PS_P : e2 + E::OFF_J, closed2 ? p2 + E::PS_S : e2 + E::OFF_ETA,
+                                     e2 + E::OFF_A, e2 + E::OFF_B, e2 + E::OFF_C, closed2, part,
+                                     dst + (size_t)i * E::STRIDE, ps + (size_t)i * E::PS_STRIDE, smem_c.data(), 0);
     }
     double* t = src;
     src = dst;

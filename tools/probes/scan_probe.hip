@@ -65,10 +65,10 @@ int main() {
   hipEventCreate(&e1);
   for (int d : {1, 32}) {  // d = 1: all open; d = 32: right operands closed
     a.dist = d;
-    for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(k, dim3(n - d, 1), dim3(SCAN_NT), lds, 0, a);
+    for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(k, dim3(n - d, 1, 2), dim3(SCAN_NT), lds, 0, a);
     hipEventRecord(e0, 0);
     const int reps = 50;
-    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k, dim3(n - d, 1), dim3(SCAN_NT), lds, 0, a);
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k, dim3(n - d, 1, 2), dim3(SCAN_NT), lds, 0, a);
     hipEventRecord(e1, 0);
     hipEventSynchronize(e1);
     float ms;
