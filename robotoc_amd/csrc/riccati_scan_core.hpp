@@ -469,6 +469,19 @@ struct ColVec {
 };
 RTOC_SCAN_DEV int uniform_int(int v) { return v; }
 #endif
+// value of lane `src_h` of every group of LPC adjacent lanes, for all lanes of the group (LDS crossbar, no LDS memory)
+template <int LPC>
+RTOC_SCAN_DEV double group_bcast_d(double v, int lane, int src_h) {
+#if defined(__HIPCC__)
+  if (LPC == 1) return v;
+  const int addr = ((lane & ~(LPC - 1)) | src_h) << 2;
+  const int lo = __builtin_amdgcn_ds_bpermute(addr, __double2loint(v));
+  const int hi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(v));
+  return __hiloint2double(hi, lo);
+#else
+  return v;
+#endif
+}
 constexpr int QUAD_XOR1 = 0xB1;  // quad_perm [1,0,3,2]
 constexpr int QUAD_XOR2 = 0x4E;  // quad_perm [2,3,0,1]
 constexpr int HALF_MIRROR = 0x141;  // row_half_mirror: lane i <-> 7 - i of every 8 lanes (the other quad)
@@ -491,6 +504,11 @@ struct CombineCfg {
   static constexpr int GPS = NT / LPC;                    // column groups per slot
   static constexpr int CPT = (LDW + GPS - 1) / GPS;       // column slots per thread: 1 or 2 on the GPU
   static_assert(NT < 64 || GPS >= NX, "the pivot columns must sit in slot 0");
+  // Two slots per thread (16 waves, all busy): the step is bound by VALU issue -> the owner publishes 1/pivot and
+  // the pivot-row entry travels by ds_bpermute (fewest instructions).  One slot (ANYmal, 10 waves): the step is
+  // bound by its dependent chain -> every thread takes the reciprocal itself and the entry travels by DPP adds
+  // (shortest latency).  Measured both ways on both robots (tools/probes/scan_probe.hip).
+  static constexpr bool PUBLISH_RCP = CPT > 1;
   static constexpr int LDM = scan_lds_ld(NX);            // column-major NX x NX operands
   static constexpr int LDT = NX | 1;                     // row-major Ta / Tc
   static constexpr int REG = pad8(NX * (LDM > LDT ? LDM : LDT));
@@ -643,11 +661,14 @@ RTOC_SCAN_DEV unsigned combine_body(const double* e1, const double* J2, const do
     if (LPC > 2) m = fmax(m, quad_perm_d<QUAD_XOR2>(m));
     if (LPC > 4) m = fmax(m, quad_perm_d<HALF_MIRROR>(m));
     int p = 1 << 20;
+    double pvl = 1.0;
 #pragma unroll
-    for (int t = 0; t < RPL; ++t) {
-      const int cand = (a[t] == m) ? h + LPC * t : (1 << 20);
-      p = cand < p ? cand : p;
+    for (int t = RPL - 1; t >= 0; --t) {  // descending: the smallest row of this lane that attains m wins
+      const bool hit = a[t] == m;
+      p = hit ? h + LPC * t : p;
+      pvl = hit ? cs[t] : pvl;
     }
+    const int pl = p;
     if (LPC > 1) {
       const int o = quad_perm_i<QUAD_XOR1>(p);
       p = o < p ? o : p;
@@ -660,12 +681,14 @@ RTOC_SCAN_DEV unsigned combine_body(const double* e1, const double* J2, const do
       const int o = quad_perm_i<HALF_MIRROR>(p);
       p = o < p ? o : p;
     }
+    if (C::PUBLISH_RCP && pl == p && p < (1 << 20)) piv[2 + (kk & 1)] = fast_rcp(pvl);  // the lane that holds the pivot
     if (h == 0) {
       if (!(m >= 2.3e-308)) {  // no usable pivot: flag, go on with the first unused row
         flag[0] = 1.0;
         p = 0;
         for (int r = NX - 1; r >= 0; --r)
           if (kof[r] < 0) p = r;
+        piv[2 + (kk & 1)] = 1.0;
       }
       pki[kk & 1] = p;
       kof[p] = kk;
@@ -680,7 +703,8 @@ RTOC_SCAN_DEV unsigned combine_body(const double* e1, const double* J2, const do
     const double* mk = mult + (k & 1) * C::MPAD;
     RTOC_SCAN_SYNC();
     const int p = pki[k & 1];
-    const double ipv = fast_rcp(mk[p]);
+    const double ipv = C::PUBLISH_RCP ? piv[2 + (k & 1)] : fast_rcp(mk[p]);
+    const int hp = uniform_int(p % LPC);
     const int h = tid % LPC;
     const bool mine = (p % LPC) == h;  // this lane owns the pivot row
     const int tp = uniform_int(p / LPC);
@@ -691,11 +715,15 @@ RTOC_SCAN_DEV unsigned combine_body(const double* e1, const double* J2, const do
       const int c = slot_col<C>(tid, s);
       if (c > k && c < ncol && !(RTOC_SCAN_PROBE & 8)) {
         // entry of the pivot row: tp is wave-uniform -> register-relative read / write instead of RPL selects
-        double wp = col[s][tp];
-        wp = mine ? wp : 0.0;
-        if (LPC > 1) wp += quad_perm_d<QUAD_XOR1>(wp);  // the other lanes contribute exact zeros
-        if (LPC > 2) wp += quad_perm_d<QUAD_XOR2>(wp);
-        if (LPC > 4) wp += quad_perm_d<HALF_MIRROR>(wp);
+        double wp = col[s][tp];  // the lane that owns row p has the entry of the pivot row
+        if (C::PUBLISH_RCP) {
+          wp = group_bcast_d<LPC>(wp, tid & 63, hp);
+        } else {
+          wp = mine ? wp : 0.0;
+          if (LPC > 1) wp += quad_perm_d<QUAD_XOR1>(wp);  // the other lanes contribute exact zeros
+          if (LPC > 2) wp += quad_perm_d<QUAD_XOR2>(wp);
+          if (LPC > 4) wp += quad_perm_d<HALF_MIRROR>(wp);
+        }
         const double x = wp * ipv;
 #pragma unroll
         for (int t = 0; t < RPL; ++t) col[s][t] -= mk[h + LPC * t] * x;
