@@ -77,6 +77,14 @@ def test_scan_anymal_short_and_odd_horizons(oracle):
         _run(oracle, dims, G.uniform_grid(N, 0.02, dimf=12), 1, "factory")
 
 
+@pytest.mark.parametrize("N", [62, 63, 64, 100])
+def test_scan_horizons_around_a_power_of_two(oracle, N):
+    """63 / 64 / 65 grid points (6 -> 7 combination levels) and a long horizon (101 grid points, 7 levels)."""
+    from robotoc_amd import grid as G
+    from robotoc_amd.types import anymal_dims
+    _run(oracle, anymal_dims(), G.uniform_grid(N, 0.02, dimf=12), 1, "dynamics", tol=1e-7)
+
+
 @pytest.mark.parametrize("nv", [32, 35])
 def test_scan_icub_jump(oracle, nv):
     """configs[3]: iCub, stand-flight-stand with a 12-row switching constraint, larger blocks."""
