@@ -9,10 +9,11 @@
 //   V(x_i, x_j) = max_lam  1/2 x_i^T J x_i - eta^T x_i - 1/2 lam^T C lam - lam^T (x_j - A x_i - b)
 //
 // (Saerkkae & Garcia-Fernandez, "Temporal parallelization of dynamic programming and linear quadratic
-// control", IEEE TAC 2023) -- in ceil(log2(#grid points)) combination levels, every level one
-// workgroup per grid point.  Then the policies K, k (M, m) of all grid points are computed at once by
+// control", IEEE TAC 2023) -- in ceil(log2(#grid points)) combination levels, every level two
+// workgroups per grid point.  Then the policies K, k (M, m) of all grid points are computed at once by
 // the one-stage mode of riccati_backward_kernel from P_{i+1}, s_{i+1}, i.e. with the reference's own
-// per-stage algebra (riccati_factorizer.cpp:44-90).
+// per-stage algebra (riccati_factorizer.cpp:44-90).  The forward recursion is a prefix scan of the
+// closed-loop maps (end of this file).
 //
 //   element of an intermediate / lift grid point (brrf.cpp:31-45 with P+ = 0, eliminated control):
 //     L L^T = Quu,  Z = L^-1 [Qxu^T | lu | Fvu^T | Phiu^T]  =: [Zs | zl | Zb | Zd]
@@ -32,9 +33,10 @@
 // tests/scan_reference.py states the same formulas in numpy.  Grids with switching-time optimisation
 // (sto flags) are not covered: rtoc_riccati_backward falls back to the serial HIP kernel for them.
 //
-// The bodies are written as barrier-separated phases of "for (i = tid; i < n; i += NT)" loops without
-// wave intrinsics, so that the very same code also compiles for the host with NT = 1
-// (tests/cpp/scan_emulation.cpp checks the algebra and the indexing on the CPU against numpy).
+// The bodies are written as barrier-separated phases of "for (i = tid; i < n; i += NT)" loops; the few wave-level
+// pieces (DPP / ds_bpermute exchange between the lanes of a column, MFMA products, hardware rcp / rsq) sit behind
+// small functions with a plain host version, so that the very same code also compiles for the host with NT = 1
+// (tests/cpp/scan_emulation.cpp checks the algebra and the indexing on the CPU against numpy and the oracle).
 #pragma once
 #include <math.h>
 #include <stdint.h>
@@ -101,44 +103,6 @@ struct ScanLayout {
     return L;
   }
 };
-
-// ---- cooperative Cholesky of an n x n matrix in LDS (lower factor in place; the strict upper
-//      triangle is left untouched).  Ends with a barrier.  *flag is set on a non-positive pivot. ----
-template <int NT>
-RTOC_SCAN_DEV void lds_cholesky(double* A, int n, int ld, int tid, double* flag) {
-  for (int j = 0; j < n; ++j) {
-    if (tid == 0) {
-      double d = A[j + j * ld];
-      if (!(d > 0.0)) {
-        *flag = 1.0;
-        d = 1.0;
-      }
-      A[j + j * ld] = sqrt(d);
-    }
-    RTOC_SCAN_SYNC();
-    const double inv = 1.0 / A[j + j * ld];
-    for (int i = j + 1 + tid; i < n; i += NT) A[i + j * ld] *= inv;
-    RTOC_SCAN_SYNC();
-    const int m = n - j - 1;
-    for (int idx = tid; idx < m * m; idx += NT) {
-      const int ii = idx % m, kk = idx / m;
-      if (ii >= kk) {
-        const int i = j + 1 + ii, k = j + 1 + kk;
-        A[i + k * ld] -= A[i + j * ld] * A[k + j * ld];
-      }
-    }
-    RTOC_SCAN_SYNC();
-  }
-}
-
-// x <- L^-1 x for one column held in LDS
-RTOC_SCAN_DEV void fwd_subst(const double* L, int n, int ld, double* x) {
-  for (int k = 0; k < n; ++k) {
-    double acc = x[k];
-    for (int m = 0; m < k; ++m) acc -= L[k + m * ld] * x[m];
-    x[k] = acc / L[k + k * ld];
-  }
-}
 
 // C(i,j) = sum_k A(i,k) B(k,j) between LDS-resident operands with compile-time shapes and strides,
 // A(i,k) = A[i*ARS + k*ACS], B(k,j) = B[k*BRS + j*BCS]; epilogue(row, col, value).  On the GPU the
@@ -492,7 +456,7 @@ template <int NV, int NT>
 struct CombineCfg {
   static constexpr int NX = 2 * NV;
   static constexpr int LDW = 2 * NX + 1;  // columns of one workgroup's tableau: [M | A1 | t] or [M | C1]
-  // lanes per column (adjacent lanes of one quad), rows per lane, column slots per thread
+  // lanes per column (up to 8 adjacent lanes), rows per lane, column slots per thread.
   // Big robots take two column slots per thread rather than fewer lanes per column: the pivot columns (< NX)
   // all sit in slot 0, and the rows per lane set the length of the serial search / elimination chain.
 #ifdef RTOC_SCAN_FORCE_LPC
