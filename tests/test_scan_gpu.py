@@ -97,6 +97,36 @@ def test_scan_iiwa14_dense(oracle):
     _run(oracle, dims, grids, 4, "factory")
 
 
+def test_scan_iiwa14_unconstr_entry_points(oracle):
+    """configs[0] through rtoc_unconstr_backward / rtoc_unconstr_forward (UnconstrRiccatiRecursion,
+    src/riccati/unconstr_riccati_recursion.cpp:26-48) with the scan option, against the oracle's unconstrained sweep."""
+    from robotoc_amd import capi
+    dims, grids, info = pr.config_iiwa14()
+    batch = 3
+    ctx = capi.Context(dims, len(grids), batch, 0)
+    try:
+        L = ctx.L
+        ctx.set_grid(grids)
+        ctx.set_backward_scan(True)
+        kkt = Records(L, "kkt").zeros(batch, len(grids))
+        for b in range(batch):
+            pr.fill_unconstr_instance(L, len(grids), kkt[b], np.random.default_rng(pr.BASE_SEED + b))
+        dx0 = pr.make_dx0(L, batch)
+        ctx.upload(BUF_KKT, kkt)
+        ctx.upload(BUF_DX0, dx0)
+        ctx.unconstr_backward(info["dt"])
+        ctx.unconstr_forward(info["dt"])
+        assert (ctx.status() == 0).all()
+        ric, d = ctx.download_records(BUF_RIC, "ric"), ctx.download_records(BUF_DIR, "dir")
+        ric_ref, d_ref = Records(L, "ric").zeros(batch, len(grids)), Records(L, "dir").zeros(batch, len(grids))
+        oracle.unconstr_sweep_batch(L, len(grids), info["dt"], kkt.copy(), ric_ref, d_ref, dx0=dx0)
+        for b in range(batch):
+            compare_riccati(L, grids, ric[b], ric_ref[b], TOL_SCAN, "iiwa scan inst %d" % b)
+            compare_direction(L, grids, d[b], d_ref[b], TOL_SCAN, "iiwa scan inst %d" % b)
+    finally:
+        ctx.close()
+
+
 def test_scan_sto_grid_takes_the_serial_kernel(oracle):
     """Grids with switching-time optimisation are outside the scan: same bits as without the option."""
     from robotoc_amd import capi
