@@ -388,6 +388,11 @@ class UnconstrRiccatiRecursion {
   UnconstrRiccatiRecursion(const UnconstrRiccatiRecursion&) = delete;
   UnconstrRiccatiRecursion& operator=(const UnconstrRiccatiRecursion&) = delete;
 
+  // Not in the reference: both recursions as scans over the horizon (RTOC_OPT_BACKWARD_SCAN), see RiccatiRecursion.
+  void setHorizonScan(const bool on) {
+    check(rtoc_set_option(ctx_, RTOC_OPT_BACKWARD_SCAN, on ? 1 : 0), "rtoc_set_option");
+  }
+
   void backwardRiccatiRecursion(KKTMatrix& kkt_matrix, KKTResidual& kkt_residual,
                                 UnconstrRiccatiFactorization& factorization) {
     const int n = N_ + 1, nv = robot_.dimv, nx = 2 * nv;

@@ -38,9 +38,10 @@ def test_cpp_host_riccati_recursion_on_gpu(name):
 
 
 @pytest.mark.gpu
-def test_cpp_host_riccati_recursion_horizon_scan_on_gpu():
-    """robotoc::RiccatiRecursion::setHorizonScan: the same closed-form stage identities with the scan."""
-    exe = _build("riccati_recursion_test")
+@pytest.mark.parametrize("name", ["riccati_recursion_test", "unconstr_riccati_recursion_test"])
+def test_cpp_host_riccati_recursion_horizon_scan_on_gpu(name):
+    """robotoc::(Unconstr)RiccatiRecursion::setHorizonScan: the same closed-form stage identities with the scan."""
+    exe = _build(name)
     out = subprocess.run([exe, "scan"], capture_output=True, text=True, timeout=300)
     print(out.stdout, out.stderr)
     assert out.returncode == 0 and "horizon scan" in out.stdout, (out.returncode, out.stdout, out.stderr)
