@@ -54,8 +54,10 @@ __global__ __launch_bounds__(SCAN_ELT_NT) void scan_element_kernel(ScanArgs a) {
   if (stat && threadIdx.x == 0) atomicOr(&a.status[b], stat);
 }
 
+// two workgroups per CU where a workgroup is at most 10 waves (ANYmal): a few instances then share the chip better
+constexpr int scan_comb_min_waves(int nv) { return scan_comb_nt(nv) <= 640 ? 5 : 1; }
 template <int NV>
-__global__ __launch_bounds__(scan_comb_nt(NV)) void scan_combine_kernel(ScanArgs a) {
+__global__ __launch_bounds__(scan_comb_nt(NV), scan_comb_min_waves(NV)) void scan_combine_kernel(ScanArgs a) {
   constexpr int SCAN_NT = scan_comb_nt(NV);
   extern __shared__ __attribute__((aligned(16))) double smem[];
   using E = scan::EltLayout<NV>;
