@@ -373,6 +373,9 @@ int rtoc_set_stream(rtoc_ctx* c, void* s) {
   return RTOC_OK;
 }
 
+static int ensure_scan_buffers(rtoc_ctx* c);
+#define RTOC_SCAN_AUTO_MAX_BATCH 8  // measured on MI355X (profiles/r01_scan_batch_crossover.log): the scan wins up to ~16 ANYmal / ~10 iCub instances
+
 int rtoc_set_option(rtoc_ctx* c, int option, int64_t value) {
   if (!c) return RTOC_ERR_BAD_ARG;
   switch (option) {
@@ -416,6 +419,8 @@ int rtoc_set_option(rtoc_ctx* c, int option, int64_t value) {
     case RTOC_OPT_BACKWARD_SCAN:
       if (value < 0 || value > 2) return RTOC_ERR_BAD_ARG;
       c->backward_scan = (int)value;
+      // element / value-record buffers now, so that the launches themselves never allocate (stream capture)
+      if (value != 0 && !(value == 2 && c->batch > RTOC_SCAN_AUTO_MAX_BATCH)) return ensure_scan_buffers(c);
       return RTOC_OK;
     default:
       return RTOC_ERR_BAD_ARG;
@@ -478,8 +483,6 @@ int rtoc_bind(rtoc_ctx* c, int buffer, void* device_ptr) {
 }
 
 // ---- hot path ---------------------------------------------------------------------------
-// measured on MI355X (gpurun_out/scan_batch_crossover.log): the scan wins up to ~12 ANYmal / ~10 iCub instances
-#define RTOC_SCAN_AUTO_MAX_BATCH 8
 // RTOC_OPT_BACKWARD_SCAN: the scan covers grids without switching-time optimisation; others take the serial kernel
 static bool scan_applies(const rtoc_ctx* c) {
   if (!c->backward_scan || !c->h_grid) return false;
