@@ -154,6 +154,40 @@ def cpu_baseline(L, grids, dx0_small, kkt_small, budget_s=12.0):
                        "mutated KKT blocks" % (B, reps, nthreads))
 
 
+def sqp_single_instance(dims, grids, device):
+    """SQP hot path of ONE OCP (the regime of a robotoc::OCPSolver call): per-phase HIP-event times with the
+    serial recursions and with both recursions as horizon scans (RTOC_OPT_BACKWARD_SCAN)."""
+    from robotoc_amd import capi, problems as pr
+    from robotoc_amd.types import BUF_CDD, BUF_CON, BUF_CONE, BUF_DX0, BUF_KKT, joint_limit_rows
+    out = {}
+    for mode in ("serial", "scan"):
+        c1 = capi.Context(dims, len(grids), 1, device)
+        L1 = c1.L
+        c1.set_grid(grids)
+        c1.set_constraint_rows(joint_limit_rows(dims))
+        c1.set_friction_cones(4, 3)
+        c1.set_backward_scan(mode == "scan")
+        kkt, cdd = pr.make_precondense_batch(L1, grids, 1)
+        con = pr.make_constraint_batch(L1, grids, 1)
+        c1.upload(BUF_CONE, pr.make_cone_batch(L1, grids, 1, 4))
+        c1.upload(BUF_DX0, pr.make_dx0(L1, 1))
+        ph = {"condense": 2, "backward": 0, "forward": 1, "expand": 3, "update": 5}
+        acc = {k: 0.0 for k in ph}
+        nrep = 3
+        for rep in range(nrep + 1):
+            c1.upload(BUF_KKT, kkt)
+            c1.upload(BUF_CDD, cdd)
+            c1.upload(BUF_CON, con)
+            for name in ("condense", "backward", "forward", "expand", "update"):
+                ms = c1.time_phase(ph[name], 1)
+                if rep > 0:
+                    acc[name] += ms / nrep
+        ok = int((c1.status() != 0).sum()) == 0
+        c1.close()
+        out[mode] = {"ms": acc, "total_ms": sum(acc.values()), "iters_per_sec": 1e3 / sum(acc.values()), "status_ok": ok}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -301,6 +335,7 @@ def main():
         tot = sum(acc.values())
         cb = condense_bytes(L, grids, batch)
         sqp = {"ms": acc, "total_ms": tot, "iters_per_sec_per_gpu": batch / tot * 1e3,
+               "single_instance": sqp_single_instance(dims, grids, local_rank) if rank == 0 else None,
                "condense_algorithmic_bytes": cb, "condense_GBs_algorithmic": cb / (acc["condense"] * 1e-3) / 1e9,
                "status_nonzero_instances": bad_sqp,
                "scope": "hot path downstream of the Pinocchio linearisation: PDIPM condensation of the "
