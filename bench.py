@@ -2,12 +2,12 @@
 """bench.py -- Riccati sweeps/s on the ANYmal trot workload (BASELINE.json metric).
 
 A "step" is one pass of the hot path over one batch: the backward Riccati recursion
-followed by the forward recursion for PER_GPU_BATCH independent ANYmal trot OCP
-instances (nv=18, 4 point contacts, N=40 -> 47 grids with 2 lifts + 2 impacts),
-inputs resident in HBM.  One process per GPU; instances are sharded across ranks
-with no data-path collective (weak scaling: fixed work per GPU); after the timed
-region the step directions are all-gathered over RCCL (the one real exchange step,
-SURVEY 8e) to validate the multi-GPU path.
+followed by the forward recursion for PER_GPU_BATCH independent, DISTINCT ANYmal trot OCP
+instances (nv=18, 4 point contacts, N=40 -> 47 grids with 2 lifts + 2 impacts; randomised
+stage data and initial state directions, generated in HBM), inputs resident in HBM.
+One process per GPU; instances are sharded across ranks with no data-path collective
+(weak scaling: fixed work per GPU); after the timed region the step directions are
+all-gathered over RCCL (the one real exchange step) to validate the multi-GPU path.
 
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
 """
@@ -24,7 +24,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PER_GPU_BATCH = 4096
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+F64_MFMA_PEAK_TFLOPS = 78.6  # MI355X spec sheet, dense fp64 matrix (= the fp64 vector rate)
+PROFILE_ROUND = "r02"
 
 
 def algorithmic_bytes(L, grids, batch, which):
@@ -68,6 +70,25 @@ def algorithmic_bytes(L, grids, batch, which):
     return total * 8 * batch
 
 
+def backward_flops(L, grids, batch):
+    """SURVEY 8(d) flop count of one backward launch (the reference's operation count, dense Fxx):
+    4nx^3 + 2nx^2 nu + 4nu^2 nx + 4nx nv nu + 2nu^2 nv + nu^3/3 + 4nx^2 + 2nx nu per control stage,
+    4nx^3 + 4nx^2 per impact stage."""
+    from robotoc_amd.types import GRID_IMPACT, GRID_TERMINAL
+    d = L.dims
+    nv, nu, nx = d.nv, d.nu, 2 * d.nv
+    total = 0.0
+    for g in grids:
+        if g.type == GRID_TERMINAL:
+            continue
+        if g.type == GRID_IMPACT:
+            total += 4 * nx ** 3 + 4 * nx ** 2
+        else:
+            total += (4 * nx ** 3 + 2 * nx * nx * nu + 4 * nu * nu * nx + 4 * nx * nv * nu + 2 * nu * nu * nv
+                      + nu ** 3 / 3.0 + 4 * nx * nx + 2 * nx * nu)
+    return total * batch
+
+
 def condense_bytes(L, grids, batch):
     """Algorithmic HBM bytes of one rtoc_condense launch: per non-terminal grid point the
     ContactDynamicsData inputs and the un-condensed Hessian / gradient blocks are read once, the condensed
@@ -94,64 +115,104 @@ def condense_bytes(L, grids, batch):
     return total * 8 * batch
 
 
-def pmc_traffic(waves, batch):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this
-    same command (profiles/r01_traffic.json: 2*FETCH_SIZE + WRITE_SIZE, separate --pmc runs).
-    PMC counters cannot be collected from inside the timed process; null if the committed pass
-    does not match the configuration being run."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    if waves not in (0, 8) or batch != PER_GPU_BATCH or not os.path.exists(path):
+def expand_bytes(L, grids, batch, rows, cone_contacts):
+    """Algorithmic HBM bytes of one rtoc_expand launch: per non-terminal grid point what
+    expandContactDynamicsPrimal/Dual read (contact_dynamics.cpp:167-202: MJtJinv, MJtJinv_dIDCdqv,
+    MJtJinv_IDC, Qafqv, Qafu, laf, haf, the passive blocks, Phia; dx, du, dgmm+, dxi) and write
+    (daf, dbetamu, dnu_passive, laf), active views only, plus the PDIPM rows of
+    Constraints::expandSlackAndDual (slack, dual, residual, cmpl in; dslack, ddual out; the cone rows
+    also read their Jacobians)."""
+    from robotoc_amd.types import GRID_IMPACT, GRID_TERMINAL
+    d = L.dims
+    nv, nu, nx, npas = d.nv, d.nu, 2 * d.nv, d.np
+    total = 0
+    for g in grids:
+        if g.type == GRID_TERMINAL:
+            continue
+        imp = g.type == GRID_IMPACT
+        nvf = nv + g.dimf
+        rd = 2 * nvf * nx + nvf * nvf + 3 * nvf + nx + nv
+        wr = 3 * nvf
+        if not imp:
+            rd += 2 * nvf * nu + nu + nx * npas + npas * nu + npas + g.dims * (nv + 1)
+            wr += npas
+            act = sum(1 for r in rows if g.time_stage >= r.level)  # stage mask, constraints_data.cpp:20-45
+            rd += 4 * act
+            wr += 2 * act
+        nc = min(g.dimf // 3, cone_contacts)
+        rd += nc * (4 * 5 + 5 * nv + 15)
+        wr += nc * 2 * 5
+        total += rd + wr
+    return total * 8 * batch
+
+
+def pmc_traffic(kernel_substr):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes of this same command
+    (profiles/<round>_traffic.json: 2*FETCH_SIZE + WRITE_SIZE, separate --pmc runs, the guide's gfx950
+    correction).  PMC counters cannot be collected from inside the timed process; null if no committed
+    pass names the kernel."""
+    path = os.path.join(ROOT, "profiles", "%s_traffic.json" % PROFILE_ROUND)
+    if not os.path.exists(path):
         return None
-    t = json.load(open(path))
-    for k, v in t.items():
-        if "backward_rs" in k:
+    for k, v in json.load(open(path)).items():
+        if kernel_substr in k:
             return v["hbm_bytes"]
     return None
 
 
-def cpu_baseline(L, grids, dx0_small, kkt_small, budget_s=12.0):
-    """Oracle (CPU port of the reference algorithm) timed on this box's host cores, OpenMP over
-    instances.  Bounded sample: repeat a small batch until ~budget_s of CPU work."""
+def cpu_baseline(L, grids, dims, budget_s=8.0):
+    """Oracle (CPU port of the reference algorithm) timed on this box's host cores: Riccati sweeps and SQP
+    hot-path iterations, one thread (the reference's Riccati recursion is single-threaded,
+    riccati_recursion.cpp) and all threads (OpenMP over instances -- the reference's own parallelism is
+    OpenMP over stages of evalKKT, direct_multiple_shooting.cpp:135).  Thread-private working records
+    (oracle/rtoc_oracle_bench.c); bounded sample: distinct instances repeated until ~budget_s per leg."""
     from oracle import oracle as orc
-    from robotoc_amd.types import Records
+    from robotoc_amd import problems as pr
+    from robotoc_amd.types import joint_limit_rows
     nthreads = os.cpu_count() or 1
-    # at least two instances per hardware thread so that every core has work
-    reps_b = max(1, (2 * nthreads + kkt_small.shape[0] - 1) // kkt_small.shape[0])
-    kkt_small = np.ascontiguousarray(np.tile(kkt_small, (reps_b, 1, 1)))
-    dx0_small = np.ascontiguousarray(np.tile(dx0_small, (reps_b, 1)))
-    B = kkt_small.shape[0]
-    ric = Records(L, "ric").zeros(B, len(grids))
-    d = Records(L, "dir").zeros(B, len(grids))
-    work = kkt_small.copy()
-    orc.riccati_sweep_batch(L, grids, work, ric, d, dx0=dx0_small)  # warm-up (page faults)
-    t0 = time.perf_counter()
-    reps = 0
-    while True:
-        work[...] = kkt_small  # the oracle mutates the KKT blocks in place like the reference
-        orc.riccati_sweep_batch(L, grids, work, ric, d, dx0=dx0_small)
-        reps += 1
-        if time.perf_counter() - t0 > budget_s:
-            break
-    dt = time.perf_counter() - t0
-    # the reference's Riccati recursion itself is single-threaded (riccati_recursion.cpp): one instance through
-    # the single-instance entry points (no OpenMP region: forking a 256-thread team costs more than the sweep)
-    one_k, one_d = np.ascontiguousarray(kkt_small[0]), np.ascontiguousarray(dx0_small[0])
-    ric1, d1, w1 = Records(L, "ric").zeros(len(grids)), Records(L, "dir").zeros(len(grids)), one_k.copy()
-    Dv = Records(L, "dir")
-    t1 = time.perf_counter()
-    n1 = 0
-    while time.perf_counter() - t1 < 2.0:
-        w1[...] = one_k
-        Dv.f(d1[0], "dx")[...] = one_d
-        orc.riccati_backward(L, grids, w1, ric1)
-        orc.riccati_forward(L, grids, w1, ric1, d1)
-        n1 += 1
-    single = n1 / (time.perf_counter() - t1)
-    return dict(value=B * reps / dt, unit="sweeps/s", cores=nthreads, kind="port",
-                single_thread_sweeps_per_sec=single, single_thread_sweep_ms=1e3 / single,
-                sample="%d instances x %d repeats of the same ANYmal trot sweep, OpenMP over "
-                       "instances (%d threads), includes the memcpy that restores the in-place "
-                       "mutated KKT blocks" % (B, reps, nthreads))
+    B = max(2 * nthreads, 64)
+    kkt = pr.make_kkt_batch_unique(L, grids, B, seed=99)
+    dx0 = pr.make_dx0_unique(L, B, seed=99)
+    out = {}
+
+    def best_of(fn, n_items, nt, guess_s, legs=3):
+        """Warm up (thread team, page faults, clocks), then `legs` measurements of ~budget_s/legs each;
+        the fastest one is reported (the others are disturbed by whatever else the host is doing)."""
+        fn(1, nt)
+        w = fn(max(1, int(0.5 / max(guess_s * n_items / max(nt, 1), 1e-4))), nt)
+        per_rep = w["seconds"] / max(w[[k for k in w if k in ("sweeps", "iterations")][0]] / n_items, 1)
+        reps = max(1, int(budget_s / legs / max(per_rep, 1e-5)))
+        runs = [fn(reps, nt) for _ in range(legs)]
+        return min(runs, key=lambda r: r["seconds"]), reps
+
+    one, _ = best_of(lambda reps, nt: orc.bench_sweep(L, grids, kkt[:16], dx0[:16], reps, nt), 16, 1, 1.5e-3, legs=2)
+    allt, reps = best_of(lambda reps, nt: orc.bench_sweep(L, grids, kkt, dx0, reps, nt), B, nthreads, 1.5e-3)
+    out.update(value=allt["sweeps"] / allt["seconds"], unit="sweeps/s", cores=allt["threads"], kind="port",
+               value_excluding_refill=allt["sweeps"] / max(allt["seconds"] - allt["refill_seconds"], 1e-9),
+               single_thread_sweeps_per_sec=one["sweeps"] / one["seconds"],
+               single_thread_sweep_ms=1e3 * one["seconds"] / one["sweeps"],
+               single_thread_sweep_ms_excluding_refill=1e3 * (one["seconds"] - one["refill_seconds"]) / one["sweeps"],
+               sample="%d distinct ANYmal trot instances x %d repeats, OpenMP over instances (%d threads), every "
+                      "thread refills a private copy of the in-place-mutated KKT records per sweep (that memcpy is "
+                      "%.1f%% of the time; `value_excluding_refill` leaves it out); one thread: %d sweeps"
+                      % (B, reps, allt["threads"], 100.0 * allt["refill_seconds"] / allt["seconds"], one["sweeps"]))
+    # SQP hot-path iteration (SURVEY 8d: both sides on identical pre-condensation inputs)
+    Bs = max(nthreads, 32)
+    kk, cc = pr.make_precondense_batch_unique(L, grids, Bs, seed=99)
+    con = pr.make_constraint_batch_unique(L, grids, Bs, seed=99)
+    cone = pr.make_cone_batch_unique(L, grids, Bs, 4, seed=99)
+    rows = joint_limit_rows(dims)
+
+    def sqp(n, reps, nt):
+        return orc.bench_sqp(L, grids, kk[:n], cc[:n], con[:n], cone[:n], dx0[:n], rows, 4, 3, 0.995, reps, nt)
+    s1, _ = best_of(lambda reps, nt: sqp(8, reps, nt), 8, 1, 6e-3, legs=2)
+    sa, reps = best_of(lambda reps, nt: sqp(Bs, reps, nt), Bs, nthreads, 6e-3)
+    out["sqp_iteration"] = dict(iters_per_sec=sa["iterations"] / sa["seconds"], threads=sa["threads"],
+                                single_thread_iters_per_sec=s1["iterations"] / s1["seconds"],
+                                single_thread_iter_ms=1e3 * s1["seconds"] / s1["iterations"],
+                                sample="%d distinct instances x %d repeats (all threads), %d iterations (one thread); "
+                                       "72 joint-limit + 20 friction-cone rows" % (Bs, reps, s1["iterations"]))
+    return out
 
 
 def sqp_single_instance(dims, grids, device):
@@ -173,6 +234,7 @@ def sqp_single_instance(dims, grids, device):
         c1.upload(BUF_DX0, pr.make_dx0(L1, 1))
         ph = {"condense": 2, "backward": 0, "forward": 1, "expand": 3, "update": 5}
         acc = {k: 0.0 for k in ph}
+        whole = 0.0
         nrep = 3
         for rep in range(nrep + 1):
             c1.upload(BUF_KKT, kkt)
@@ -182,9 +244,16 @@ def sqp_single_instance(dims, grids, device):
                 ms = c1.time_phase(ph[name], 1)
                 if rep > 0:
                     acc[name] += ms / nrep
+        for rep in range(nrep + 1):
+            c1.upload(BUF_KKT, kkt)
+            c1.upload(BUF_CDD, cdd)
+            c1.upload(BUF_CON, con)
+            ms = c1.time_phase(6, 1)  # rtoc_newton_iteration: the whole iteration as one launch sequence
+            if rep > 0:
+                whole += ms / nrep
         ok = int((c1.status() != 0).sum()) == 0
         c1.close()
-        out[mode] = {"ms": acc, "total_ms": sum(acc.values()), "iters_per_sec": 1e3 / sum(acc.values()), "status_ok": ok}
+        out[mode] = {"ms": acc, "newton_iteration_ms": whole, "iters_per_sec": 1e3 / whole, "status_ok": ok}
     return out
 
 
@@ -211,6 +280,7 @@ def main():
     if os.environ.get("RTOC_BENCH_ONE_DEVICE") == "1":
         local_rank = 0  # functional test of the multi-process path on a single-GPU box
     torch.cuda.set_device(local_rank)
+    dev = "cuda:%d" % local_rank
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
@@ -219,29 +289,30 @@ def main():
         dist.init_process_group(os.environ.get("RTOC_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
 
     from robotoc_amd import capi, problems as pr
-    from robotoc_amd.types import BUF_DIR, BUF_DX0, BUF_KKT
+    from robotoc_amd.types import BUF_CDD, BUF_CON, BUF_CONE, BUF_DIR, BUF_DX0, BUF_KKT, joint_limit_rows
 
     dims, grids, _ = pr.config_anymal_trot()
     batch = args.batch
-    ctx = capi.Context(dims, len(grids), batch, local_rank)
+    n = len(grids)
+    ctx = capi.Context(dims, n, batch, local_rank)
     L = ctx.L
     ctx.set_grid(grids)
     if args.waves:
         ctx.set_backward_waves(args.waves)
-    # per-rank shard of the instance range: seeds are offset by rank*batch
-    uniq = 16
-    kkt_small = pr.make_kkt_batch(L, grids, uniq, first_instance=rank * batch)
-    dx0_small = pr.make_dx0(L, uniq, first_instance=rank * batch)
-    reps = (batch + uniq - 1) // uniq
-    kkt = np.ascontiguousarray(np.tile(kkt_small, (reps, 1, 1))[:batch])
-    dx0 = np.ascontiguousarray(np.tile(dx0_small, (reps, 1))[:batch])
-    # the direction buffer lives in a torch tensor so that torch.distributed (RCCL) can gather it
-    dir_t = torch.zeros(ctx.buffer_count(BUF_DIR), dtype=torch.float64, device="cuda")
-    ctx.bind(BUF_DIR, dir_t.data_ptr())
     stream = torch.cuda.current_stream()
     ctx.set_stream(stream.cuda_stream)
-    ctx.upload(BUF_KKT, kkt)
-    ctx.upload(BUF_DX0, dx0)
+
+    def dev_records(which):
+        return torch.zeros((batch, n, getattr(L, which).stride), dtype=torch.float64, device=dev)
+
+    # every instance of every rank is a different problem: the generator streams are keyed by rank
+    kkt_t = pr.make_kkt_batch_unique(L, grids, batch, seed=rank, backend="torch", device=dev, out=dev_records("kkt"))
+    dx0_t = pr.make_dx0_unique(L, batch, seed=rank, backend="torch", device=dev).contiguous()
+    dir_t = dev_records("dir")  # lives in a torch tensor so that torch.distributed (RCCL) can gather it
+    ctx.bind(BUF_KKT, kkt_t.data_ptr())
+    ctx.bind(BUF_DX0, dx0_t.data_ptr())
+    ctx.bind(BUF_DIR, dir_t.data_ptr())
+    torch.cuda.synchronize()
 
     def step():
         ctx.riccati_backward()
@@ -266,6 +337,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     bad = int((ctx.status() != 0).sum())
+    distinct = int(torch.unique(kkt_t[:, 0, L.kkt.off[2]]).numel())  # Qxx(0,0) of stage 0 of every instance
 
     # attainable HBM bandwidth on this box: device-to-device copy of 1 GiB (read + write), same run
     src = torch.empty(1 << 27, dtype=torch.float64, device="cuda")
@@ -284,68 +356,83 @@ def main():
     # dominant kernel (backward) and forward timed with HIP events on the launch stream
     ms_b = ctx.time_phase(0, max(3, args.steps // 2))
     ms_f = ctx.time_phase(1, max(3, args.steps // 2))
-    nsl = len(grids) * L.dir.stride
     gathered_ok = None
     if world > 1:
         from robotoc_amd.sharding import gather_directions
-        full = gather_directions(dir_t[:batch * nsl].view(batch, len(grids), L.dir.stride),
-                                 world * batch, world, rank)
+        full = gather_directions(dir_t, world * batch, world, rank)
         torch.cuda.synchronize()
         gathered_ok = bool(full.shape[0] == world * batch and torch.isfinite(full).all().item())
 
-    # ---- SQP-iteration hot path (condense -> backward -> forward -> expand) on pre-condensation
-    #      stage data; each phase timed with HIP events on the launch stream, the (untimed)
-    #      device-to-device restore of the in-place-mutated records happens between repetitions ----
+    # ---- SQP-iteration hot path on pre-condensation stage data of `batch` distinct instances:
+    #      rtoc_newton_iteration (KKT error -> condense -> backward -> forward -> expand -> step sizes ->
+    #      convergence mask -> slack/dual update) timed end to end with HIP events on the launch stream, and
+    #      phase by phase; the device-to-device restore of the in-place-mutated records is untimed ----
     sqp = None
     if not args.no_sqp:
-        from robotoc_amd.types import BUF_CDD
-        kkt_pre_s, cdd_pre_s = pr.make_precondense_batch(L, grids, 4, first_instance=rank * batch)
-        rp = (batch + 3) // 4
-        kkt0 = torch.from_numpy(np.ascontiguousarray(np.tile(kkt_pre_s, (rp, 1, 1))[:batch])).cuda()
-        cdd0 = torch.from_numpy(np.ascontiguousarray(np.tile(cdd_pre_s, (rp, 1, 1))[:batch])).cuda()
-        kkt_w = torch.empty(ctx.buffer_count(BUF_KKT), dtype=torch.float64, device="cuda")
-        cdd_w = torch.empty(ctx.buffer_count(BUF_CDD), dtype=torch.float64, device="cuda")
-        ctx.bind(BUF_KKT, kkt_w.data_ptr())
-        ctx.bind(BUF_CDD, cdd_w.data_ptr())
-        # PDIPM joint-limit rows (6 x nu box rows, examples/anymal/trot.cpp:134-146)
-        from robotoc_amd.types import BUF_CON, joint_limit_rows
-        ctx.set_constraint_rows(joint_limit_rows(dims))
-        con_s = pr.make_constraint_batch(L, grids, 4, first_instance=rank * batch)
-        con0 = torch.from_numpy(np.ascontiguousarray(np.tile(con_s, (rp, 1, 1))[:batch])).cuda()
-        con_w = torch.empty(ctx.buffer_count(BUF_CON), dtype=torch.float64, device="cuda")
-        ctx.bind(BUF_CON, con_w.data_ptr())
-        # friction cones of the (up to 4) active point contacts: 5 PDIPM rows each, dense Jacobians
-        from robotoc_amd.types import BUF_CONE
+        del kkt_t
+        rows = joint_limit_rows(dims)
+        ctx.set_constraint_rows(rows)
         ctx.set_friction_cones(4, 3)
-        cone_s = pr.make_cone_batch(L, grids, 4, 4, first_instance=rank * batch)
-        ctx.upload(BUF_CONE, np.ascontiguousarray(np.tile(cone_s, (rp, 1, 1))[:batch]))
+        kkt0, cdd0 = pr.make_precondense_batch_unique(L, grids, batch, seed=rank, backend="torch", device=dev,
+                                                      out=(dev_records("kkt"), dev_records("cdd")))
+        con0 = pr.make_constraint_batch_unique(L, grids, batch, seed=rank, backend="torch", device=dev,
+                                               out=dev_records("con"))
+        cone_t = pr.make_cone_batch_unique(L, grids, batch, 4, seed=rank, backend="torch", device=dev).contiguous()
+        kkt_w, cdd_w, con_w = torch.empty_like(kkt0), torch.empty_like(cdd0), torch.empty_like(con0)
+        for b_, t_ in ((BUF_KKT, kkt_w), (BUF_CDD, cdd_w), (BUF_CON, con_w), (BUF_CONE, cone_t)):
+            ctx.bind(b_, t_.data_ptr())
+
+        def restore():
+            kkt_w.copy_(kkt0)
+            cdd_w.copy_(cdd0)
+            con_w.copy_(con0)
+            torch.cuda.synchronize()
         ph = {"condense": 2, "backward": 0, "forward": 1, "expand": 3, "update": 5}
         acc = {k: 0.0 for k in ph}
         nrep = 3
         for rep in range(nrep + 1):
-            kkt_w[:kkt0.numel()].copy_(kkt0.view(-1))
-            cdd_w[:cdd0.numel()].copy_(cdd0.view(-1))
-            con_w[:con0.numel()].copy_(con0.view(-1))
-            torch.cuda.synchronize()
+            restore()
             for name in ("condense", "backward", "forward", "expand", "update"):
                 ms = ctx.time_phase(ph[name], 1)
                 if rep > 0:
                     acc[name] += ms / nrep
+        whole, wall = 0.0, 0.0
+        for rep in range(nrep + 1):
+            restore()
+            w0 = time.perf_counter()
+            ms = ctx.time_phase(6, 1)  # synchronises on its closing event
+            w1 = time.perf_counter() - w0
+            if rep > 0:
+                whole += ms / nrep
+                wall += w1 * 1e3 / nrep
         bad_sqp = int((ctx.status() != 0).sum())
-        tot = sum(acc.values())
         cb = condense_bytes(L, grids, batch)
-        sqp = {"ms": acc, "total_ms": tot, "iters_per_sec_per_gpu": batch / tot * 1e3,
+        eb = expand_bytes(L, grids, batch, rows, 4)
+        sqp = {"newton_iteration_ms": whole, "newton_iteration_wall_ms": wall,
+               "iters_per_sec_per_gpu": batch / whole * 1e3, "phase_ms": acc, "phase_sum_ms": sum(acc.values()),
+               "distinct_instances": batch,
+               "roofline_condense": {"bound": "hbm", "achieved": cb / (acc["condense"] * 1e-3) / 1e9,
+                                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": cb / (acc["condense"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                     "algorithmic_bytes_per_launch": cb, "kernels": "mjtjinv_kernel + condense_kernel",
+                                     "traffic": (lambda a, b: a + b if a and b else None)(
+                                         pmc_traffic("mjtjinv_kernel"), pmc_traffic("condense_kernel"))},
+               "roofline_expand": {"bound": "hbm", "achieved": eb / (acc["expand"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                                   "unit": "GB/s", "frac": eb / (acc["expand"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                   "algorithmic_bytes_per_launch": eb, "kernels": "expand_kernel + cone_expand_kernel",
+                                   "traffic": pmc_traffic("expand_kernel")},
                "single_instance": sqp_single_instance(dims, grids, local_rank) if rank == 0 else None,
-               "condense_algorithmic_bytes": cb, "condense_GBs_algorithmic": cb / (acc["condense"] * 1e-3) / 1e9,
                "status_nonzero_instances": bad_sqp,
-               "scope": "hot path downstream of the Pinocchio linearisation: PDIPM condensation of the "
-                        "joint-limit and friction-cone rows + computeMJtJinv + condenseContact/ImpactDynamics + Riccati "
-                        "backward/forward + expandContactDynamics primal/dual + PDIPM expansion, "
-                        "fraction-to-boundary step sizes and slack/dual update; linearisation, cost "
-                        "and the manifold update of q are CPU-side and excluded"}
+               "scope": "hot path downstream of the Pinocchio linearisation: KKT error, PDIPM condensation of the "
+                        "72 joint-limit and 20 friction-cone rows + computeMJtJinv + condenseContact/ImpactDynamics + "
+                        "Riccati backward/forward + expandContactDynamics primal/dual + PDIPM expansion, "
+                        "fraction-to-boundary step sizes, convergence mask and slack/dual update; linearisation, "
+                        "cost and the manifold update of q are CPU-side and excluded"}
+        del kkt0, cdd0, con0, kkt_w, cdd_w, con_w, cone_t
 
     # ---- the other BASELINE.json configurations (parity-test cases; reported, not the headline):
-    #      batch throughput and the single-instance sweep latency a robotoc OCPSolver call would see ----
+    #      batch throughput with a roofline block each, and the single-instance sweep latency a robotoc
+    #      OCPSolver call would see ----
     others = None
     if rank == 0 and not args.no_configs:
         others = {}
@@ -361,15 +448,20 @@ def main():
                 c2 = capi.Context(d2, len(g2), b2, local_rank)
                 L2 = c2.L
                 c2.set_grid(g2)
+                k2 = torch.zeros((b2, len(g2), L2.kkt.stride), dtype=torch.float64, device=dev)
                 if name.startswith("iiwa"):
                     from robotoc_amd.types import Records
                     k1 = Records(L2, "kkt").zeros(1, len(g2))
                     pr.fill_unconstr_instance(L2, len(g2), k1[0], np.random.default_rng(1))
-                    c2.upload(BUF_KKT, np.ascontiguousarray(np.tile(k1, (b2, 1, 1))))
+                    k2[...] = torch.from_numpy(k1).to(dev)
+                    c2.bind(BUF_KKT, k2.data_ptr())
                     c2.unconstr_backward(info["dt"])  # materialises the structured A, B once
                 else:
-                    c2.upload(BUF_KKT, pr.make_kkt_batch_tiled(L2, g2, b2, unique=min(b2, 4)))
-                c2.upload(BUF_DX0, np.ascontiguousarray(np.tile(pr.make_dx0(L2, 1), (b2, 1))))
+                    pr.make_kkt_batch_unique(L2, g2, b2, seed=7, backend="torch", device=dev, out=k2)
+                    c2.bind(BUF_KKT, k2.data_ptr())
+                x2 = pr.make_dx0_unique(L2, b2, seed=7, backend="torch", device=dev).contiguous()
+                c2.bind(BUF_DX0, x2.data_ptr())
+                torch.cuda.synchronize()
                 c2.time_phase(4, 1)
                 mb, mf = c2.time_phase(0, 3), c2.time_phase(1, 3)
                 ok = int((c2.status() != 0).sum()) == 0
@@ -387,11 +479,21 @@ def main():
                         entry["single_instance_sweep_scan_ms"] = ms + msf
                         ok = ok and int((c2.status() != 0).sum()) == 0
                 else:
-                    entry.update({"batch": b2, "backward_ms": mb, "forward_ms": mf,
+                    ab, fl = algorithmic_bytes(L2, g2, b2, "backward"), backward_flops(L2, g2, b2)
+                    entry.update({"batch": b2, "distinct_instances": b2, "backward_ms": mb, "forward_ms": mf,
                                   "sweeps_per_sec": b2 / (mb + mf) * 1e3,
-                                  "backward_GBs_algorithmic": algorithmic_bytes(L2, g2, b2, "backward") / mb / 1e6})
+                                  "roofline": {"kernel": "riccati_backward", "kernel_ms": mb,
+                                               "hbm": {"achieved": ab / mb / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                       "frac": ab / mb / 1e6 / HBM_PEAK_GBS,
+                                                       "algorithmic_bytes_per_launch": ab},
+                                               "mfma_f64": {"achieved": fl / mb / 1e9, "peak": F64_MFMA_PEAK_TFLOPS,
+                                                            "unit": "TFLOP/s", "frac": fl / mb / 1e9 / F64_MFMA_PEAK_TFLOPS,
+                                                            "algorithmic_flops_per_launch": fl},
+                                               "bound": "hbm" if ab / (HBM_PEAK_GBS * 1e9) > fl / (F64_MFMA_PEAK_TFLOPS * 1e12)
+                                               else "mfma"}})
                 entry["status_ok"] = entry.get("status_ok", True) and ok
                 c2.close()
+                del k2, x2
             others[name] = entry
 
     if rank == 0:
@@ -399,7 +501,9 @@ def main():
         value = total_sweeps / dt
         bytes_b = algorithmic_bytes(L, grids, batch, "backward")
         bytes_f = algorithmic_bytes(L, grids, batch, "forward")
+        fl_b = backward_flops(L, grids, batch)
         ach = bytes_b / (ms_b * 1e-3) / 1e9
+        kname = "riccati_backward_rs4_kernel" if args.waves in (0, 8) else "riccati_backward_kernel"
         res = {
             "metric": "riccati_sweeps_per_sec",
             "value": value,
@@ -414,18 +518,23 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": "anymal_trot_N40 (nv=18,nu=12, 47 grids: 2 lifts + 2 impacts, "
-                                   "switching constraints ns=6), %d OCP instances per GPU, "
-                                   "backward+forward Riccati sweep" % batch,
-                       "per_gpu_batch": batch, "stages": len(grids), "parallelism": "instances sharded, dp%d" % world,
-                       "backward_waves": args.waves},
+                                   "switching constraints ns=6), %d DISTINCT OCP instances per GPU (randomised "
+                                   "stage data and dx0), backward+forward Riccati sweep" % batch,
+                       "per_gpu_batch": batch, "distinct_instances_per_gpu": distinct, "stages": len(grids),
+                       "parallelism": "instances sharded, dp%d" % world, "backward_waves": args.waves},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(args.waves, batch),
+                         "frac": ach / HBM_PEAK_GBS,
+                         "traffic": pmc_traffic(kname) if batch == PER_GPU_BATCH else None,
                          "measured_copy_GBs": copy_gbs, "frac_of_measured_copy": ach / copy_gbs,
-                         "kernel": "riccati_backward_rs4_kernel" if args.waves in (0, 8) else "riccati_backward_kernel", "kernel_ms": ms_b,
+                         "kernel": kname, "kernel_ms": ms_b,
                          "algorithmic_bytes_per_launch": bytes_b,
+                         "mfma_f64_achieved_TFLOPs": fl_b / (ms_b * 1e-3) / 1e12,
+                         "mfma_f64_frac": fl_b / (ms_b * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS,
                          "forward_kernel_ms": ms_f,
                          "forward_achieved": bytes_f / (ms_f * 1e-3) / 1e9,
-                         "forward_algorithmic_bytes_per_launch": bytes_f},
+                         "forward_frac": bytes_f / (ms_f * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "forward_algorithmic_bytes_per_launch": bytes_f,
+                         "forward_traffic": pmc_traffic("riccati_forward_kernel") if batch == PER_GPU_BATCH else None},
             "status_nonzero_instances": bad,
         }
         if sqp is not None:
@@ -435,7 +544,7 @@ def main():
         if gathered_ok is not None:
             res["rccl_gather_ok"] = gathered_ok
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(L, grids, dx0_small, kkt_small)
+            res["cpu_baseline"] = cpu_baseline(L, grids, dims)
         print(json.dumps(res))
     ctx.close()
     if world > 1:

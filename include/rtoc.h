@@ -218,7 +218,8 @@ int rtoc_sync(rtoc_ctx* ctx);
 
 /* Time `reps` back-to-back launches of one phase with HIP events recorded on the
  * context's stream; returns the mean milliseconds per launch in *ms.
- * phase: 0 backward, 1 forward, 2 condense, 3 expand, 4 backward+forward, 5 update. */
+ * phase: 0 backward, 1 forward, 2 condense, 3 expand, 4 backward+forward, 5 update,
+ * 6 rtoc_newton_iteration(kkt_tol = 0, tau = 0.995). */
 int rtoc_time_phase(rtoc_ctx* ctx, int phase, int reps, float* ms);
 
 /* ---- KKT error of every instance (first piece of the on-device Newton loop) ----
@@ -240,8 +241,8 @@ int rtoc_integrate_solution(rtoc_ctx* ctx);
  * (OCPSolver::updateSolution, src/solver/ocp_solver.cpp:111-145, downstream of the linearisation):
  * KKT error of the freshly linearised records -> rtoc_condense -> rtoc_riccati_sweep -> rtoc_expand(tau)
  * (directions + fraction-to-boundary step sizes, resident in RTOC_BUF_STEP) -> instances whose
- * sqrt(KKT error) <= kkt_tol get step sizes 0 and keep their iterate (the convergence test of
- * ocp_solver.cpp:161-166 per instance, on the device) -> rtoc_update -> rtoc_integrate_solution (if
+ * KKT error (rtoc_kkt_error, i.e. OCPSolver::KKTError()) < kkt_tol get step sizes 0 and keep their iterate (the convergence test of
+ * ocp_solver.cpp:200,206 per instance, on the device) -> rtoc_update -> rtoc_integrate_solution (if
  * RTOC_BUF_SOL exists).  Needs dx0 (RTOC_BUF_DX0) like rtoc_riccati_forward.  The caller re-linearises
  * (CPU side) and uploads before the next iteration. */
 int rtoc_newton_iteration(rtoc_ctx* ctx, double kkt_tol, double fraction_to_boundary_rule);

@@ -20,7 +20,7 @@
 #ifndef RTOC_LAYOUT_H_
 #define RTOC_LAYOUT_H_
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define RTOC_HD __host__ __device__
 #else
 #define RTOC_HD

@@ -18,7 +18,7 @@ _LIB = None
 
 def build(force=False):
     so = os.path.join(_HERE, "librtoc_oracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("rtoc_oracle.c", "rtoc_oracle_condense.c")]
+    srcs = [os.path.join(_HERE, f) for f in ("rtoc_oracle.c", "rtoc_oracle_condense.c", "rtoc_oracle_bench.c")]
     srcs += [os.path.join(_HERE, "..", "include", f) for f in ("rtoc.h", "rtoc_layout.h")]
     stale = force or not os.path.exists(so) or any(
         os.path.getmtime(s) > os.path.getmtime(so) for s in srcs if os.path.exists(s))
@@ -79,6 +79,13 @@ def lib():
                                           dp, C.c_double, dp, C.c_int]
         _LIB.orc_wrench_batch.restype = None
         _LIB.orc_integrate_solution_batch.argtypes = [C.POINTER(Layout), C.POINTER(Grid), C.c_int, C.c_int, dp, dp, dp]
+        _LIB.orc_bench_sweep.argtypes = [C.POINTER(Layout), C.POINTER(Grid), C.c_int, C.c_int, dp, dp, C.c_double,
+                                         C.c_int, C.c_int, dp]
+        _LIB.orc_bench_sweep.restype = C.c_uint
+        _LIB.orc_bench_sqp.argtypes = [C.POINTER(Layout), C.POINTER(Grid), C.c_int, C.c_int, dp, dp, dp, dp, dp,
+                                       C.POINTER(BoxRow), C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
+                                       C.c_int, C.c_int, dp]
+        _LIB.orc_bench_sqp.restype = C.c_uint
     return _LIB
 
 
@@ -287,3 +294,23 @@ def integrate_solution_batch(L, grids, steps, dirs, sol):
     steps = np.ascontiguousarray(steps, dtype=np.float64)
     lib().orc_integrate_solution_batch(C.byref(L), grid_array(grids), len(grids), sol.shape[0], _p(steps), _p(dirs),
                                        _p(sol))
+
+
+def bench_sweep(L, grids, kkt, dx0, reps, nthreads=0, max_dts0=0.1):
+    """Timed backward+forward sweeps of reps x batch instances, thread-private working records
+    (rtoc_oracle_bench.c).  The inputs are read-only.  Returns dict(seconds, refill_seconds, threads, sweeps)."""
+    out = np.zeros(4)
+    st = lib().orc_bench_sweep(C.byref(L), grid_array(grids), len(grids), kkt.shape[0], _p(kkt), _p(dx0), max_dts0,
+                               reps, nthreads, _p(out))
+    return dict(seconds=out[0], refill_seconds=out[1], threads=int(out[2]), sweeps=reps * kkt.shape[0], status=st)
+
+
+def bench_sqp(L, grids, kkt, cdd, con, cone, dx0, rows, max_contacts, contact_dim, tau, reps, nthreads=0,
+              max_dts0=0.1):
+    """Timed SQP hot-path iterations (condense -> sweep -> expand -> step sizes -> update) of reps x batch instances
+    on pre-condensation records, thread-private working records.  Inputs are read-only."""
+    out = np.zeros(4)
+    st = lib().orc_bench_sqp(C.byref(L), grid_array(grids), len(grids), kkt.shape[0], _p(kkt), _p(cdd), _p(con),
+                             _p(cone) if cone is not None else None, _p(dx0), _rows(rows), len(rows), max_contacts,
+                             contact_dim, tau, max_dts0, reps, nthreads, _p(out))
+    return dict(seconds=out[0], refill_seconds=out[1], threads=int(out[2]), iterations=reps * kkt.shape[0], status=st)

@@ -230,15 +230,10 @@ const char* rtoc_error_string(int code) {
   }
 }
 
-int rtoc_create(const rtoc_dims* dims, int max_stages, int batch, int device, rtoc_ctx** out) {
-  if (!dims || !out || max_stages < 2 || batch < 1) return RTOC_ERR_BAD_ARG;
-  const KernelSet* ks = find_set(dims);
-  if (!ks) return RTOC_ERR_UNSUPPORTED_DIMS;
-  if (rtoc_device_count() <= device || device < 0) return RTOC_ERR_NO_DEVICE;
-  HIP_TRY(hipSetDevice(device));
-  rtoc_ctx* c = new (std::nothrow) rtoc_ctx();
-  if (!c) return RTOC_ERR_BAD_ARG;
-  memset(c, 0, sizeof(*c));
+int rtoc_destroy(rtoc_ctx* c);
+// everything of rtoc_create that can fail after the context object exists; the caller destroys the
+// half-built context on failure (rtoc_destroy tolerates members that were never created)
+static int create_members(rtoc_ctx* c, const rtoc_dims* dims, const KernelSet* ks, int max_stages, int batch, int device) {
   c->dims = *dims;
   rtoc_compute_layout(dims, &c->L);
   // the backward kernels carry their record offsets as immediates: they must be the ones the host
@@ -247,7 +242,6 @@ int rtoc_create(const rtoc_dims* dims, int max_stages, int batch, int device, rt
       memcmp(&ks->rl, &c->L.ric, sizeof(rtoc_record_layout)) != 0 ||
       memcmp(&ks->dl, &c->L.dir, sizeof(rtoc_record_layout)) != 0 ||
       memcmp(&ks->cl, &c->L.cdd, sizeof(rtoc_record_layout)) != 0) {
-    delete c;
     return RTOC_ERR_BAD_ARG;
   }
   c->ks = ks;
@@ -308,6 +302,24 @@ int rtoc_create(const rtoc_dims* dims, int max_stages, int batch, int device, rt
   HIP_TRY(hipFuncSetAttribute((const void*)ks->fscan_elt, hipFuncAttributeMaxDynamicSharedMemorySize, ks->fscan_lds));
   HIP_TRY(hipFuncSetAttribute((const void*)ks->fscan_comb, hipFuncAttributeMaxDynamicSharedMemorySize, ks->fscan_lds));
   HIP_TRY(hipStreamSynchronize(c->stream));
+  return RTOC_OK;
+}
+
+int rtoc_create(const rtoc_dims* dims, int max_stages, int batch, int device, rtoc_ctx** out) {
+  if (!dims || !out || max_stages < 2 || batch < 1) return RTOC_ERR_BAD_ARG;
+  const KernelSet* ks = find_set(dims);
+  if (!ks) return RTOC_ERR_UNSUPPORTED_DIMS;
+  if (rtoc_device_count() <= device || device < 0) return RTOC_ERR_NO_DEVICE;
+  HIP_TRY(hipSetDevice(device));
+  rtoc_ctx* c = new (std::nothrow) rtoc_ctx();
+  if (!c) return RTOC_ERR_BAD_ARG;
+  memset(c, 0, sizeof(*c));
+  c->device = device;
+  int rc = create_members(c, dims, ks, max_stages, batch, device);
+  if (rc) {
+    (void)rtoc_destroy(c);
+    return rc;
+  }
   *out = c;
   return RTOC_OK;
 }
@@ -315,10 +327,10 @@ int rtoc_create(const rtoc_dims* dims, int max_stages, int batch, int device, rt
 int rtoc_destroy(rtoc_ctx* c) {
   if (!c) return RTOC_ERR_BAD_ARG;
   (void)hipSetDevice(c->device);
-  (void)hipStreamSynchronize(c->stream);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
   for (int i = 0; i < RTOC_NUM_BUFFERS; ++i)
     if (c->owned[i] && c->buf[i]) (void)hipFree(c->buf[i]);
-  (void)hipFree(c->d_grid);
+  if (c->d_grid) (void)hipFree(c->d_grid);
   if (c->d_rows) (void)hipFree(c->d_rows);
   free(c->h_rows);
   free(c->h_grid);
@@ -326,17 +338,18 @@ int rtoc_destroy(rtoc_ctx* c) {
   if (c->d_entry) (void)hipFree(c->d_entry);
   if (c->d_pair) (void)hipFree(c->d_pair);
   if (c->d_nconv) (void)hipFree(c->d_nconv);
-  (void)hipFree(c->d_status);
+  if (c->d_status) (void)hipFree(c->d_status);
   if (c->d_prof) (void)hipFree(c->d_prof);
   for (int i = 0; i < 3; ++i)
     if (c->d_scan[i]) (void)hipFree(c->d_scan[i]);
-  (void)hipEventDestroy(c->ev0);
-  (void)hipEventDestroy(c->ev1);
-  (void)hipStreamDestroy(c->own_stream);
-  (void)hipStreamDestroy(c->stream2);
-  (void)hipEventDestroy(c->ev_fork);
-  (void)hipEventDestroy(c->ev_join);
-  for (int i = 0; i < RTOC_MAX_CHUNK_EVENTS; ++i) (void)hipEventDestroy(c->ev_chunk[i]);
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  if (c->stream2) (void)hipStreamDestroy(c->stream2);
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+  for (int i = 0; i < RTOC_MAX_CHUNK_EVENTS; ++i)
+    if (c->ev_chunk[i]) (void)hipEventDestroy(c->ev_chunk[i]);
   delete c;
   return RTOC_OK;
 }
@@ -438,7 +451,7 @@ static int ensure_buffer(rtoc_ctx* c, int b) {
 
 int rtoc_upload(rtoc_ctx* c, int buffer, size_t offset, const double* host, size_t count) {
   if (!c || buffer < 0 || buffer >= RTOC_NUM_BUFFERS || !host) return RTOC_ERR_BAD_ARG;
-  if (offset + count > c->count[buffer]) return RTOC_ERR_BAD_ARG;
+  if (count > c->count[buffer] || offset > c->count[buffer] - count) return RTOC_ERR_BAD_ARG;
   int rc = ensure_buffer(c, buffer);
   if (rc) return rc;
   HIP_TRY(hipSetDevice(c->device));
@@ -450,7 +463,7 @@ int rtoc_upload(rtoc_ctx* c, int buffer, size_t offset, const double* host, size
 
 int rtoc_download(rtoc_ctx* c, int buffer, size_t offset, double* host, size_t count) {
   if (!c || buffer < 0 || buffer >= RTOC_NUM_BUFFERS || !host) return RTOC_ERR_BAD_ARG;
-  if (offset + count > c->count[buffer] || !c->buf[buffer]) return RTOC_ERR_BAD_ARG;
+  if (count > c->count[buffer] || offset > c->count[buffer] - count || !c->buf[buffer]) return RTOC_ERR_BAD_ARG;
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipMemcpyAsync(host, c->buf[buffer] + offset, count * sizeof(double), hipMemcpyDeviceToHost,
                          c->stream));
@@ -460,7 +473,11 @@ int rtoc_download(rtoc_ctx* c, int buffer, size_t offset, double* host, size_t c
 
 void* rtoc_device_ptr(rtoc_ctx* c, int buffer) {
   if (!c || buffer < 0 || buffer >= RTOC_NUM_BUFFERS) return nullptr;
+  const bool fresh = !c->buf[buffer];
   if (ensure_buffer(c, buffer)) return nullptr;
+  // the zero fill of a lazily allocated buffer runs on the context's stream: it must have landed before a
+  // caller writes through the pointer on a stream of its own
+  if (fresh && hipStreamSynchronize(c->stream) != hipSuccess) return nullptr;
   return c->buf[buffer];
 }
 
@@ -1068,9 +1085,10 @@ int rtoc_sync(rtoc_ctx* c) {
   return RTOC_OK;
 }
 
+int rtoc_newton_iteration(rtoc_ctx* c, double kkt_tol, double tau);
 int rtoc_time_phase(rtoc_ctx* c, int phase, int reps, float* ms) {
   CHECK_READY(c);
-  if (!ms || reps < 1 || phase < 0 || phase > 5) return RTOC_ERR_BAD_ARG;
+  if (!ms || reps < 1 || phase < 0 || phase > 6) return RTOC_ERR_BAD_ARG;
   HIP_TRY(hipEventRecord(c->ev0, c->stream));
   for (int r = 0; r < reps; ++r) {
     int rc = RTOC_OK;
@@ -1081,6 +1099,7 @@ int rtoc_time_phase(rtoc_ctx* c, int phase, int reps, float* ms) {
       case 3: rc = rtoc_expand(c, 0.995); break;
       case 4: rc = launch_sweep(c); break;
       case 5: rc = rtoc_update(c); break;
+      case 6: rc = rtoc_newton_iteration(c, 0.0, 0.995); break;  // the whole iteration as one launch sequence
     }
     if (rc) return rc;
   }
@@ -1156,10 +1175,12 @@ int rtoc_kkt_error(rtoc_ctx* c, double* host_out, int count) {
 
 // ---- one Newton iteration of the whole batch as a single launch sequence ----------
 // steps[b] <- 0 for instances whose KKT error is already below the tolerance: they keep their iterate
-__global__ void mask_converged_kernel(double* steps, const double* kkterr, int* nconv, double tol2, int batch) {
+// kkterr holds OCPSolver::KKTError() itself (the sqrt, kkt_error.hpp); the reference tests KKTError() < kkt_tol
+// (ocp_solver.cpp:200,206)
+__global__ void mask_converged_kernel(double* steps, const double* kkterr, int* nconv, double tol, int batch) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= batch) return;
-  if (kkterr[b] <= tol2) {
+  if (kkterr[b] < tol) {
     steps[2 * b] = 0.0;
     steps[2 * b + 1] = 0.0;
     atomicAdd(nconv, 1);
@@ -1177,7 +1198,7 @@ int rtoc_newton_iteration(rtoc_ctx* c, double kkt_tol, double tau) {
   if (!rc) rc = rtoc_expand(c, tau);  // directions + fraction-to-boundary step sizes, on the device
   if (rc) return rc;
   hipLaunchKernelGGL(mask_converged_kernel, dim3((c->batch + 255) / 256), dim3(256), 0, c->stream,
-                     c->buf[RTOC_BUF_STEP], c->d_kkterr, c->d_nconv, kkt_tol * kkt_tol, c->batch);
+                     c->buf[RTOC_BUF_STEP], c->d_kkterr, c->d_nconv, kkt_tol, c->batch);
   HIP_TRY(hipGetLastError());
   rc = rtoc_update(c);
   if (!rc && c->buf[RTOC_BUF_SOL]) rc = rtoc_integrate_solution(c);

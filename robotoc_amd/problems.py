@@ -109,6 +109,143 @@ def make_kkt_batch_tiled(L, grids, batch, unique=8, mode="dynamics", first_insta
     return np.ascontiguousarray(np.tile(base, (reps, 1, 1))[:batch])
 
 
+class _NumpyGen:
+    """Random source + the few array helpers the vectorised generators need, numpy flavour."""
+
+    def __init__(self, key, device=None):
+        self.rng = np.random.default_rng([BASE_SEED] + list(key))
+
+    def U(self, *shape):
+        return self.rng.uniform(-1.0, 1.0, size=shape)
+
+    def zeros(self, *shape):
+        return np.zeros(shape)
+
+    eye = staticmethod(np.eye)
+    tril = staticmethod(np.tril)
+    abs = staticmethod(np.abs)
+
+    @staticmethod
+    def diag(A):  # writable view of the diagonals of a stack of square matrices
+        return np.einsum("...ii->...i", A)
+
+
+class _TorchGen:
+    """The same on a torch device (bench.py: 4096 instances are generated in HBM in well under a second)."""
+
+    def __init__(self, key, device="cuda"):
+        import torch
+        self.t = torch
+        self.dev = device
+        self.g = torch.Generator(device=device)
+        self.g.manual_seed(int(np.random.SeedSequence([BASE_SEED] + list(key)).generate_state(1, np.uint64)[0] >> 1))
+
+    def U(self, *shape):
+        return self.t.rand(shape, generator=self.g, dtype=self.t.float64, device=self.dev) * 2.0 - 1.0
+
+    def zeros(self, *shape):
+        return self.t.zeros(shape, dtype=self.t.float64, device=self.dev)
+
+    def eye(self, n):
+        return self.t.eye(n, dtype=self.t.float64, device=self.dev)
+
+    def tril(self, a):
+        return self.t.tril(a)
+
+    def abs(self, a):
+        return self.t.abs(a)
+
+    @staticmethod
+    def diag(A):
+        return A.diagonal(dim1=-2, dim2=-1)
+
+
+def _gen(backend, key, device):
+    return (_TorchGen if backend == "torch" else _NumpyGen)(key, device)
+
+
+def _spd_b(G, b, n):
+    s = G.U(b, n, n)
+    return s @ s.swapaxes(-1, -2)
+
+
+def make_kkt_batch_unique(L, grids, batch, mode="dynamics", seed=0, chunk=256, out=None, backend="numpy",
+                          device="cuda"):
+    """`batch` DISTINCT instances with the statistics of fill_kkt_instance, generated stage by stage for a
+    whole chunk of instances at once (vectorised over the instance axis; backend="torch" generates straight
+    into HBM).  Chunk c draws from the stream keyed (BASE_SEED, seed, c); the values differ from
+    make_kkt_batch's per-instance streams, the distribution does not (BASELINE config 5: "randomised"
+    instances).  out: a zeroed [batch, stages, stride] array / tensor to fill."""
+    d = L.dims
+    nv, nu, nx = d.nv, d.nu, 2 * d.nv
+    K = Records(L, "kkt")
+    if backend == "torch":
+        chunk = batch
+    kkt = out if out is not None else _gen(backend, (seed,), device).zeros(batch, len(grids), K.stride)
+    fb = d.np > 0
+    for c0 in range(0, batch, chunk):
+        nb = min(chunk, batch - c0)
+        G = _gen(backend, (seed, c0 // chunk), device)
+        U = lambda *shape: G.U(nb, *shape)
+        eye_v = G.eye(nv)
+        blk = kkt[c0:c0 + nb]
+        for i, g in enumerate(grids):
+            rec = blk[:, i]
+            if g.type == GRID_TERMINAL:
+                K.f(rec, "Qxx")[...] = _spd_b(G, nb, nx)
+                K.f(rec, "lx")[...] = U(nx)
+                continue
+            dt = g.dt if g.dt > 0 else 0.0
+            imp = g.type == GRID_IMPACT
+            Fxx = K.f(rec, "Fxx")
+            Fxx[...] = 0.0
+            Fxx[:, :nv, :nv] = eye_v
+            if not imp:
+                Fxx[:, :nv, nv:] = dt * eye_v
+            if fb:
+                Fxx[:, :6, :6] = U(6, 6)
+                if not imp:
+                    Fxx[:, :6, nv:nv + 6] = U(6, 6) * (dt if mode == "dynamics" else 1.0)
+            if mode == "factory":
+                Fxx[:, nv:, :nv] = U(nv, nv)
+                Fxx[:, nv:, nv:] = U(nv, nv)
+            else:
+                sc = dt if not imp else 0.1
+                Fxx[:, nv:, :nv] = sc * U(nv, nv)
+                Fxx[:, nv:, nv:] = eye_v + sc * U(nv, nv)
+            K.f(rec, "Fx")[...] = U(nx)
+            K.f(rec, "lx")[...] = U(nx)
+            if imp:
+                K.f(rec, "Qxx")[...] = _spd_b(G, nb, nx)
+                continue
+            K.f(rec, "Fvu")[...] = U(nv, nu) * (dt if mode == "dynamics" else 1.0)
+            H = _spd_b(G, nb, nx + nu)
+            K.f(rec, "Qxx")[...] = H[:, :nx, :nx]
+            K.f(rec, "Qxu")[...] = H[:, :nx, nx:]
+            K.f(rec, "Quu")[...] = H[:, nx:, nx:]
+            K.f(rec, "lu")[...] = U(nu)
+            K.f(rec, "fx")[...] = U(nx)
+            K.f(rec, "hx")[...] = U(nx)
+            K.f(rec, "hu")[...] = U(nu)
+            scal = K.f(rec, "scal")
+            qtt = G.abs(U()) + 0.1
+            scal[:, 0] = qtt
+            scal[:, 1] = -qtt
+            scal[:, 2] = U()
+            if g.dims > 0:
+                m = g.dims
+                K.f(rec, "Phix")[:, :m, :] = U(m, nx)
+                K.f(rec, "Phiu")[:, :m, :] = U(m, nu)
+                K.f(rec, "Phit")[:, :m] = U(m)
+                K.f(rec, "Pres")[:, :m] = U(m)
+    return kkt
+
+
+def make_dx0_unique(L, batch, seed=0, scale=0.1, backend="numpy", device="cuda"):
+    """`batch` distinct initial state directions ~ U[-scale, scale] from one stream."""
+    return scale * _gen(backend, (7919, seed), device).U(batch, 2 * L.dims.nv)
+
+
 def make_dx0(L, batch, first_instance=0, scale=0.1):
     """d[0].dx = (q0 - q, v0 - v) ~ U[-0.1, 0.1]."""
     out = np.zeros((batch, 2 * L.dims.nv))
@@ -243,6 +380,119 @@ def make_precondense_batch(L, grids, batch, first_instance=0):
         rng = np.random.default_rng(BASE_SEED + 104729 + first_instance + b)
         fill_precondense_instance(L, grids, kkt[b], cdd[b], rng)
     return kkt, cdd
+
+
+def make_precondense_batch_unique(L, grids, batch, seed=0, chunk=128, backend="numpy", device="cuda", out=None):
+    """`batch` DISTINCT instances with the statistics of fill_precondense_instance, vectorised over the
+    instance axis (see make_kkt_batch_unique).  out: zeroed (kkt, cdd) arrays / tensors to fill."""
+    d = L.dims
+    nv, nu, nx, npv = d.nv, d.nu, 2 * d.nv, d.np
+    K, Cd = Records(L, "kkt"), Records(L, "cdd")
+    if backend == "torch":
+        chunk = batch
+    G0 = _gen(backend, (104729, seed), device)
+    kkt, cdd = out if out is not None else (G0.zeros(batch, len(grids), K.stride), G0.zeros(batch, len(grids), Cd.stride))
+    for c0 in range(0, batch, chunk):
+        nb = min(chunk, batch - c0)
+        G = _gen(backend, (104729, seed, c0 // chunk), device)
+        U = lambda *shape: G.U(nb, *shape)
+        eye_v = G.eye(nv)
+        for i, g in enumerate(grids):
+            kr, cr = kkt[c0:c0 + nb, i], cdd[c0:c0 + nb, i]
+            if g.type == GRID_TERMINAL:
+                K.f(kr, "Qxx")[...] = _spd_b(G, nb, nx)
+                K.f(kr, "lx")[...] = U(nx)
+                continue
+            nf, ns = g.dimf, g.dims
+            nvf = nv + nf
+            impact = g.type == GRID_IMPACT
+            A = K.f(kr, "Fxx")
+            A[:, :nv, :nv] = eye_v
+            if npv > 0:
+                A[:, :6, :6] = U(6, 6)
+            if not impact:
+                A[:, :nv, nv:] = g.dt * eye_v
+            K.f(kr, "Fx")[...] = U(nx)
+            K.f(kr, "lx")[...] = U(nx)
+            K.f(kr, "Qxx")[...] = _spd_b(G, nb, nx)
+            if not impact:
+                K.f(kr, "Qxu")[...] = 0.1 * U(nx, nu)
+                G.diag(K.f(kr, "Quu"))[...] = G.abs(U(nu)) + 0.1
+                K.f(kr, "lu")[...] = U(nu)
+                K.f(kr, "hx")[...] = U(nx)
+                K.f(kr, "hu")[...] = U(nu)
+                K.f(kr, "fx")[...] = U(nx)
+                sc = K.f(kr, "scal")
+                sc[:, 0] = G.abs(U()) + 0.1
+                sc[:, 1] = -sc[:, 0]
+                sc[:, 2] = U()
+                if ns > 0:
+                    K.f(kr, "Phix")[:, :ns] = U(ns, nx)
+                    K.f(kr, "Phit")[:, :ns] = U(ns)
+                    K.f(kr, "Pres")[:, :ns] = U(ns)
+                    Cd.f(cr, "Phia")[:, :ns] = U(ns, nv)
+            Lm = G.tril(U(nv, nv))
+            Cd.f(cr, "dIDda")[...] = Lm @ Lm.swapaxes(-1, -2) + eye_v
+            D = Cd.f(cr, "dIDCdqv")
+            D[:, :nvf, :] = U(nvf, nx)
+            if impact:
+                D[:, :nv, nv:] = 0.0
+            elif nf > 0:
+                Cd.f(cr, "dCda")[:, :nf] = U(nf, nv)
+            Cd.f(cr, "IDC")[:, :nvf] = U(nvf)
+            Cd.f(cr, "Qaa")[...] = G.abs(U(nv)) + 0.1
+            if nf > 0:
+                Cd.f(cr, "Qff")[:, :nf, :nf] = _spd_b(G, nb, nf)
+                Cd.f(cr, "Qqf")[:, :, :nf] = U(nv, nf)
+                Cd.f(cr, "lf")[:, :nf] = U(nf)
+                Cd.f(cr, "hf")[:, :nf] = U(nf)
+            Cd.f(cr, "la")[...] = U(nv)
+            Cd.f(cr, "ha")[...] = U(nv)
+            if npv > 0:
+                Cd.f(cr, "lu_passive")[:, :npv] = U(npv)
+    return kkt, cdd
+
+
+def make_constraint_batch_unique(L, grids, batch, barrier=1.0e-3, seed=0, backend="numpy", device="cuda", out=None):
+    """make_constraint_batch for `batch` distinct instances from one stream."""
+    N = Records(L, "con")
+    G = _gen(backend, (15485863, seed), device)
+    con = out if out is not None else G.zeros(batch, len(grids), N.stride)
+    shp = (batch, len(grids), L.dims.nc_max)
+    slack = G.abs(G.U(*shp)) + 0.05
+    dual = barrier / slack * (1.0 + 0.3 * G.U(*shp))
+    N.f(con, "slack")[...] = slack
+    N.f(con, "dual")[...] = dual
+    N.f(con, "residual")[...] = 0.01 * G.U(*shp)
+    N.f(con, "cmpl")[...] = slack * dual - barrier
+    return con
+
+
+def make_cone_batch_unique(L, grids, batch, max_contacts, seed=0, backend="numpy", device="cuda"):
+    """make_cone_batch for `batch` distinct instances from one stream."""
+    from .types import cone_dgdf_off, cone_stride
+    nv = L.dims.nv
+    cs, off = cone_stride(nv, max_contacts), cone_dgdf_off(nv, max_contacts)
+    n = len(grids)
+    G = _gen(backend, (7919, 1, seed), device)
+    out = G.zeros(batch, n, cs)
+    mu = 0.7 / np.sqrt(2.0)
+    cone = G.zeros(5, 3)
+    for r, row in enumerate([[0, 0, -1.0], [1, 0, -mu], [-1, 0, -mu], [0, 1, -mu], [0, -1, -mu]]):
+        for c_, v in enumerate(row):
+            cone[r, c_] = v
+    for k in range(max_contacts):
+        dq = 0.3 * G.U(batch, n, 5, nv)
+        a = 0.3 * G.U(batch, n, 3)
+        Rm = G.zeros(batch, n, 3, 3)
+        Rm[..., 0, 1], Rm[..., 0, 2] = -a[..., 2], a[..., 1]
+        Rm[..., 1, 0], Rm[..., 1, 2] = a[..., 2], -a[..., 0]
+        Rm[..., 2, 0], Rm[..., 2, 1] = -a[..., 1], a[..., 0]
+        Rm += G.eye(3)
+        df = cone @ Rm.swapaxes(-1, -2)                     # [batch, n, 5, 3]
+        out[..., k * 5 * nv:(k + 1) * 5 * nv] = dq.swapaxes(-1, -2).reshape(batch, n, -1)
+        out[..., off + k * 15:off + (k + 1) * 15] = df.swapaxes(-1, -2).reshape(batch, n, -1)
+    return out
 
 
 def make_constraint_batch(L, grids, batch, barrier=1.0e-3, first_instance=0):

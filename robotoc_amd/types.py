@@ -156,8 +156,8 @@ class Records:
         if len(shp) == 1:
             return flat
         r, c = shp
-        v = flat.reshape(buf.shape[:-1] + (c, r))
-        return np.swapaxes(v, -1, -2)  # A[..., i, j] = flat[i + j*r]
+        v = flat.reshape(tuple(buf.shape[:-1]) + (c, r))  # a view (the last axis is split) -- numpy and torch alike
+        return v.swapaxes(-1, -2)  # A[..., i, j] = flat[i + j*r]
 
     def zeros(self, *lead):
         return np.zeros(tuple(lead) + (self.stride,), dtype=np.float64)

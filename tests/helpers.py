@@ -87,3 +87,60 @@ def compare_direction(L, grids, d_gpu, d_ref, tol, what=""):
             bad.append((i, "dts", e))
     assert not bad, "%s direction mismatch (stage, field, rel_err): %s" % (what, bad[:12])
     return worst
+
+
+def _rel_err_rows(a, b, floor=1e-300):
+    """rel_err per leading index: a, b are [batch, ...]; returns [batch]."""
+    a = np.asarray(a, dtype=np.float64).reshape(a.shape[0], -1)
+    b = np.asarray(b, dtype=np.float64).reshape(b.shape[0], -1)
+    den = np.maximum(np.maximum(np.linalg.norm(a, axis=1), np.linalg.norm(b, axis=1)), floor)
+    return np.linalg.norm(a - b, axis=1) / den
+
+
+def compare_batch(L, grids, ric_gpu, ric_ref, d_gpu, d_ref, tol, what="", check_sto=True):
+    """compare_riccati + compare_direction for whole batches ([batch, stages, stride] arrays), vectorised over
+    the instance axis: the same per-instance, per-stage, per-field relative errors (so that thousands of
+    instances are checked in seconds).  Returns the worst error; raises with (instance, stage, field) on failure."""
+    R, D = Records(L, "ric"), Records(L, "dir")
+    worst, bad = 0.0, []
+    N = len(grids) - 1
+
+    def chk(i, f, e):
+        nonlocal worst
+        w = float(e.max())
+        worst = max(worst, w)
+        if not (w <= tol):
+            bad.append((int(e.argmax()), i, f, w))
+    for i, g in enumerate(grids):
+        fields = ["P", "s"]
+        if i < N and g.type != GRID_IMPACT:
+            fields += ["K", "k"]
+        if i < N and g.dims > 0:
+            fields += ["M", "m"]
+        if check_sto and i < N and g.sto:
+            fields += ["Psi", "Phi"]
+            if g.type != GRID_IMPACT:
+                fields += ["T", "W", "psi_x", "psi_u"]
+                if g.dims > 0:
+                    fields += ["mt", "mt_next"]
+        for f in fields:
+            a, b = R.f(ric_gpu[:, i], f), R.f(ric_ref[:, i], f)
+            if f in ("M", "m", "mt", "mt_next"):
+                a, b = a[:, :g.dims], b[:, :g.dims]
+            chk(i, f, _rel_err_rows(a, b, 1.0 if f in ("T", "W", "mt", "mt_next") else 1e-300))
+        if check_sto and i < N and g.sto:
+            a, b = R.f(ric_gpu[:, i], "scal")[:, :5], R.f(ric_ref[:, i], "scal")[:, :5]
+            chk(i, "scal", np.abs(a - b).max(axis=1) / np.maximum(np.abs(b).max(axis=1), 1.0))
+        if d_gpu is None:
+            continue
+        fields = ["dx", "dlmdgmm"]
+        if i < N and g.type != GRID_IMPACT:
+            fields.append("du")
+        for f in fields:
+            chk(i, f, _rel_err_rows(D.f(d_gpu[:, i], f), D.f(d_ref[:, i], f)))
+        if i < N and g.switching_constraint and g.dims > 0:
+            chk(i, "dxi", _rel_err_rows(D.f(d_gpu[:, i], "dxi")[:, :g.dims], D.f(d_ref[:, i], "dxi")[:, :g.dims]))
+        a, b = D.f(d_gpu[:, i], "dts")[:, :2], D.f(d_ref[:, i], "dts")[:, :2]
+        chk(i, "dts", np.abs(a - b).max(axis=1) / np.maximum(np.abs(b).max(axis=1), 1.0))
+    assert not bad, "%s mismatch (instance, stage, field, rel_err): %s" % (what, bad[:12])
+    return worst

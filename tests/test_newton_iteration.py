@@ -1,7 +1,11 @@
 """rtoc_newton_iteration: one Newton / SQP iteration of the batch as a single launch sequence
-with the convergence test on the device.  GPU only: the fused entry point against the same steps issued one by
-one through the C ABI (each of which has its own parity test against the oracle), bit for bit; instances whose
-KKT error is below the tolerance keep their iterate and are counted."""
+with the convergence test on the device (OCPSolver::updateSolution + the KKTError() < kkt_tol test of
+OCPSolver::solve, src/solver/ocp_solver.cpp:111-145, 200-206).  GPU only:
+  * against the ORACLE-side sequence of the same iteration (KKT error -> PDIPM / cone condensation -> contact
+    dynamics condensation -> Riccati sweep -> expansions -> step sizes -> convergence mask -> slack / dual update
+    -> SplitSolution::integrate), every output buffer compared;
+  * against the same steps issued one by one through the C ABI, bit for bit;
+instances whose KKT error is below the tolerance keep their iterate and are counted."""
 import numpy as np
 import pytest
 
@@ -42,17 +46,17 @@ def test_newton_iteration_equals_the_sequence_of_its_steps():
     ref, sol0 = _context(batch)
     fused, _ = _context(batch)
     try:
-        err = np.sqrt(ref.kkt_error())
+        err = ref.kkt_error()  # OCPSolver::KKTError() itself (the sqrt is taken on the device)
         assert err.max() > 1.2 * err.min()
         tol = float(np.sort(err)[batch // 2 - 1]) * (1 + 1e-12)  # the smaller half counts as converged
-        nconv = int((err <= tol).sum())
+        nconv = int((err < tol).sum())
         assert 0 < nconv < batch
         ref.condense()
         ref.riccati_sweep()
         ref.expand(tau)
         steps = ref.download(BUF_STEP, (batch, 2))
         assert (steps > 0).all()
-        steps[err <= tol] = 0.0
+        steps[err < tol] = 0.0
         ref.upload(BUF_STEP, steps)
         ref.update()
         ref.integrate_solution()
@@ -63,13 +67,80 @@ def test_newton_iteration_equals_the_sequence_of_its_steps():
             assert np.array_equal(fused.download_records(buf, which), ref.download_records(buf, which)), which
         assert np.array_equal(fused.download(BUF_STEP, (batch, 2)), steps)
         sol1 = fused.download_records(BUF_SOL, "sol")
-        conv = err <= tol
+        conv = err < tol
         S = Records(fused.L, "sol")
         for f in ("q", "v", "a", "f", "lmd", "gmm", "beta", "mu"):  # (u is zeroed on impact grids whatever the step)
             assert np.array_equal(S.f(sol1[conv], f), S.f(sol0[conv], f)), f  # converged instances keep their iterate
         assert not np.array_equal(S.f(sol1[~conv], "v"), S.f(sol0[~conv], "v"))
     finally:
         ref.close()
+        fused.close()
+
+
+@pytest.mark.gpu
+def test_newton_iteration_against_the_oracle_sequence(oracle):
+    """The fused iteration vs the CPU oracle running OCPSolver::updateSolution's hot path step by step
+    (ocp_solver.cpp:118-142 downstream of the linearisation) on the same pre-condensation records."""
+    from helpers import rel_err
+    batch, tau = 6, 0.995
+    fused, sol0 = _context(batch)
+    try:
+        L = fused.L
+        dims, grids, _ = pr.config_anymal_trot()
+        rows = joint_limit_rows(dims)
+        kkt, cdd = (fused.download_records(b, w) for b, w in ((BUF_KKT, "kkt"), (BUF_CDD, "cdd")))
+        con = fused.download_records(BUF_CON, "con")
+        cone = pr.make_cone_batch(L, grids, batch, MC)
+        dx0 = pr.make_dx0(L, batch)
+        # oracle: KKTError() on the freshly linearised records
+        err_ref = oracle.kkt_error(L, grids, kkt, cdd, con, rows, MC, CD, 5)
+        err_gpu = fused.kkt_error()
+        assert np.allclose(err_gpu, err_ref, rtol=1e-12), (err_gpu, err_ref)
+        tol = float(np.sort(err_ref)[batch // 2 - 1]) * (1 + 1e-9)
+        conv = err_ref < tol
+        assert 0 < conv.sum() < batch
+        fused.newton_iteration(tol, tau)
+        assert fused.converged_count() == int(conv.sum())
+        assert (fused.status() == 0).all()
+        # oracle: condenseSlackAndDual (box rows, cones) -> contact dynamics -> sweep -> expansions
+        kk, cc, nn = kkt.copy(), cdd.copy(), con.copy()
+        oracle.pdipm_condense_batch(L, grids, rows, kk, nn)
+        oracle.cone_condense_batch(L, grids, MC, CD, cone, kk, cc, nn)
+        assert (oracle.condense_batch(L, grids, kk, cc) == 0).all()
+        R, D, N, S = (Records(L, w) for w in ("ric", "dir", "con", "sol"))
+        ric_ref, d_ref = R.zeros(batch, len(grids)), D.zeros(batch, len(grids))
+        oracle.riccati_sweep_batch(L, grids, kk, ric_ref, d_ref, dx0=dx0)
+        oracle.expand_batch(L, grids, cc, d_ref)
+        steps_ref = oracle.pdipm_expand_batch(L, grids, rows, nn, d_ref, tau)
+        oracle.cone_expand_batch(L, grids, MC, CD, cone, nn, d_ref, tau, steps_ref)
+        steps_ref[conv] = 0.0
+        steps_gpu = fused.download(BUF_STEP, (batch, 2))
+        assert np.allclose(steps_gpu, steps_ref, rtol=1e-6, atol=0), (steps_gpu, steps_ref)
+        d_gpu = fused.download_records(BUF_DIR, "dir")
+        worst = 0.0
+        for f in ("dx", "du", "dlmdgmm", "daf", "dbetamu", "dnu_passive"):
+            e = rel_err(D.f(d_gpu, f), D.f(d_ref, f))
+            worst = max(worst, e)
+            assert e < 1e-7, (f, e)
+        # the updates with the GPU's own step sizes (ratios of direction entries: compared above at 1e-6)
+        oracle.pdipm_update_batch(L, grids, rows, nn, steps_gpu)
+        oracle.cone_update_batch(L, grids, MC, CD, nn, steps_gpu)
+        con_gpu = fused.download_records(BUF_CON, "con")
+        for f in ("slack", "dual", "dslack", "ddual", "cond"):
+            e = rel_err(N.f(con_gpu, f), N.f(nn, f))
+            worst = max(worst, e)
+            assert e < 1e-7, (f, e)
+        sol_ref = sol0.copy()
+        oracle.integrate_solution_batch(L, grids, steps_gpu, d_ref, sol_ref)
+        sol_gpu = fused.download_records(BUF_SOL, "sol")
+        for f in ("q", "v", "a", "u", "f", "lmd", "gmm", "beta", "mu", "nu_passive", "xi"):
+            e = rel_err(S.f(sol_gpu, f), S.f(sol_ref, f))
+            worst = max(worst, e)
+            assert e < 1e-8, (f, e)
+        for f in ("q", "v", "a", "f", "lmd", "gmm", "beta", "mu"):
+            assert np.array_equal(S.f(sol_gpu[conv], f), S.f(sol0[conv], f)), f
+        print("newton iteration vs oracle sequence: worst rel err %.3e" % worst)
+    finally:
         fused.close()
 
 

@@ -6,7 +6,7 @@ R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(R, "gpurun_out")
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 note = sys.argv[2] if len(sys.argv) > 2 else ""
-lines = ["# rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-sqp   (%s)" % note,
+lines = ["# rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline   (%s)" % note,
          "# Name, Calls, TotalDurationNs, AverageNs, Percentage, MinNs, MaxNs, StdDev"]
 for r in csv.DictReader(open(os.path.join(OUT, "prof_stats", "stats_kernel_stats.csv"))):
     lines.append(", ".join(r[k] for k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev")))
@@ -26,6 +26,20 @@ for cname, d in (("FETCH_SIZE", "prof_fetch/fetch"), ("WRITE_SIZE", "prof_write/
 for k, v in traffic.items():
     v["hbm_bytes"] = (2.0 * v.get("fetch_size_kb", 0.0) + v.get("write_size_kb", 0.0)) * 1024.0
     v["note"] = "2*FETCH_SIZE (gfx950 correction, MI355X_MICROARCH.md HBM) + WRITE_SIZE (calibrated on a 295.7 MB torch fill: exact)"
+# SQ counter passes (tools/gpu_round2.sh): mean per dispatch and kernel
+for d in ("prof_sq1/sq1", "prof_sq2/sq2"):
+    path = os.path.join(OUT, d + "_counter_collection.csv")
+    if not os.path.exists(path):
+        continue
+    acc = collections.OrderedDict()
+    for r in csv.DictReader(open(path)):
+        if "rtoc::" in r["Kernel_Name"]:
+            acc.setdefault(r["Kernel_Name"].split("(")[0].replace("void ", ""), collections.OrderedDict()).setdefault(
+                r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    lines.append("# rocprofv3 --pmc (own pass, %s): mean per dispatch" % d.split("/")[0])
+    for k, cs in acc.items():
+        lines.append("%s: %s n=%d" % (k, ", ".join("%s=%.4g" % (c, sum(v) / len(v)) for c, v in cs.items()),
+                                      len(next(iter(cs.values())))))
 open(os.path.join(R, "profiles", tag + "_rocprof_summary.txt"), "w").write("\n".join(lines) + "\n")
 json.dump(traffic, open(os.path.join(R, "profiles", tag + "_traffic.json"), "w"), indent=1)
 shutil.copy(os.path.join(OUT, "bench.json"), os.path.join(R, "profiles", tag + "_bench.json"))
