@@ -1,0 +1,152 @@
+// Stand-in for include/robotoc/robot/robot.hpp.  TEST INFRASTRUCTURE ONLY (oracle/_ref).
+//
+// The real Robot wraps pinocchio::Model / Data (third-party, absent from the image).  The reference's Riccati,
+// core and dynamics sources use it for (a) dimensions and (b) a handful of rigid-body routines.  This stand-in
+// provides (a) exactly, computeMJtJinv (robot.hxx:642-684) as the same formula on dense LLT factorisations (the
+// reference uses Pinocchio's sparse Cholesky of M: same matrix, different elimination order), the Euclidean
+// configuration arithmetic of fixed-base robots, and ABORTS in everything that needs Pinocchio's kinematics
+// (RNEA, Baumgarte, frame Jacobians, SE3 integration): the linearize* halves of the dynamics sources compile but
+// are never called by oracle/ref_shim/ref_capi.cpp.
+#ifndef ROBOTOC_ROBOT_HPP_
+#define ROBOTOC_ROBOT_HPP_
+
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "Eigen/Core"
+#include "Eigen/LU"
+
+#include "robotoc/robot/contact_model_info.hpp"
+#include "robotoc/robot/robot_model_info.hpp"
+#include "robotoc/robot/se3.hpp"
+#include "robotoc/robot/contact_status.hpp"
+#include "robotoc/robot/impact_status.hpp"
+#include "robotoc/utils/aligned_vector.hpp"
+
+namespace robotoc {
+
+class Robot {
+ public:
+  using Vector6d = Eigen::Matrix<double, 6, 1>;
+
+  // dimv generalized velocities, dimu actuated joints, one ContactType per contact frame
+  Robot(const int dimv, const int dimu, const std::vector<ContactType>& contact_types,
+        const double contact_inv_damping = 0.0)
+      : dimv_(dimv), dimu_(dimu), contact_types_(contact_types), contact_inv_damping_(contact_inv_damping), max_dimf_(0) {
+    for (const auto t : contact_types_) max_dimf_ += (t == ContactType::PointContact) ? 3 : 6;
+    for (size_t i = 0; i < contact_types_.size(); ++i) contact_frame_names_.push_back("contact_" + std::to_string(i));
+  }
+  Robot() : dimv_(0), dimu_(0), contact_inv_damping_(0.0), max_dimf_(0) {}
+
+  int dimq() const { return hasFloatingBase() ? dimv_ + 1 : dimv_; }
+  int dimv() const { return dimv_; }
+  int dimu() const { return dimu_; }
+  int max_dimf() const { return max_dimf_; }
+  int dim_passive() const { return dimv_ - dimu_; }
+  bool hasFloatingBase() const { return dimv_ != dimu_; }
+  int maxNumContacts() const { return (int)contact_types_.size(); }
+  int maxNumPointContacts() const {
+    int n = 0;
+    for (const auto t : contact_types_) n += (t == ContactType::PointContact);
+    return n;
+  }
+  int maxNumSurfaceContacts() const { return maxNumContacts() - maxNumPointContacts(); }
+  ContactType contactType(const int i) const { return contact_types_[i]; }
+  std::vector<ContactType> contactTypes() const { return contact_types_; }
+  std::vector<std::string> contactFrameNames() const { return contact_frame_names_; }
+  ContactStatus createContactStatus() const { return ContactStatus(contact_types_, contact_frame_names_); }
+  ImpactStatus createImpactStatus() const { return ImpactStatus(contact_types_, contact_frame_names_); }
+
+  // Robot::computeMJtJinv (include/robotoc/robot/robot.hxx:642-684): inverse of [[M, J^T], [J, 0]]
+  //   Minv, JMinvJt = J Minv J^T (+ contact_inv_damping on its diagonal), its inverse by LLT, then the blocks
+  //   [[Minv - Minv J^T S^-1 J Minv,  Minv J^T S^-1], [S^-1 J Minv, -S^-1]].
+  template <typename MatrixType1, typename MatrixType2, typename MatrixType3>
+  void computeMJtJinv(const Eigen::MatrixBase<MatrixType1>& M, const Eigen::MatrixBase<MatrixType2>& J,
+                      const Eigen::MatrixBase<MatrixType3>& MJtJinv) {
+    const int dimv = dimv_, dimf = (int)J.rows();
+    Eigen::MatrixBase<MatrixType3>& out = const_cast<Eigen::MatrixBase<MatrixType3>&>(MJtJinv);
+    Eigen::LLT<Eigen::MatrixXd> lltM(M);
+    const Eigen::MatrixXd Minv = lltM.solve(Eigen::MatrixXd::Identity(dimv, dimv));
+    if (dimf == 0) {
+      out.topLeftCorner(dimv, dimv) = Minv;
+      return;
+    }
+    const Eigen::MatrixXd MinvJt = lltM.solve(Eigen::MatrixXd(J.transpose()));
+    Eigen::MatrixXd S = J * MinvJt;
+    for (int i = 0; i < dimf; ++i) S(i, i) += contact_inv_damping_;
+    Eigen::LLT<Eigen::MatrixXd> lltS(S);
+    const Eigen::MatrixXd Sinv = lltS.solve(Eigen::MatrixXd::Identity(dimf, dimf));
+    const Eigen::MatrixXd SinvJMinv = Sinv * MinvJt.transpose();
+    out.topLeftCorner(dimv, dimv) = Minv - MinvJt * SinvJMinv;
+    out.topRightCorner(dimv, dimf) = SinvJMinv.transpose();
+    out.bottomLeftCorner(dimf, dimv) = SinvJMinv;
+    out.bottomRightCorner(dimf, dimf) = -Sinv;
+  }
+
+  // fixed-base (Euclidean) configuration arithmetic; floating bases need Pinocchio's SE3 maps
+  template <typename A, typename B, typename C>
+  void subtractConfiguration(const Eigen::MatrixBase<A>& qf, const Eigen::MatrixBase<B>& q0,
+                             const Eigen::MatrixBase<C>& qdiff) const {
+    needFixedBase("subtractConfiguration");
+    const_cast<Eigen::MatrixBase<C>&>(qdiff) = qf - q0;
+  }
+  template <typename A, typename C>
+  void integrateConfiguration(const Eigen::MatrixBase<A>& v, const double h, const Eigen::MatrixBase<C>& q) const {
+    needFixedBase("integrateConfiguration");
+    const_cast<Eigen::MatrixBase<C>&>(q) += h * v;
+  }
+  template <typename A, typename B, typename C>
+  void integrateConfiguration(const Eigen::MatrixBase<A>& q, const Eigen::MatrixBase<B>& v, const double h,
+                              const Eigen::MatrixBase<C>& q_integrated) const {
+    needFixedBase("integrateConfiguration");
+    const_cast<Eigen::MatrixBase<C>&>(q_integrated) = q + h * v;
+  }
+  template <typename A>
+  void normalizeConfiguration(const Eigen::MatrixBase<A>&) const {}
+
+  // ---- everything below needs Pinocchio: present so that the reference sources compile, never called ----
+#define RTOC_NEEDS_PINOCCHIO(name)                    \
+  template <typename... Args>                         \
+  void name(const Args&...) const {                   \
+    unavailable(#name);                               \
+  }
+  RTOC_NEEDS_PINOCCHIO(dSubtractConfiguration_dqf)
+  RTOC_NEEDS_PINOCCHIO(dSubtractConfiguration_dq0)
+  RTOC_NEEDS_PINOCCHIO(dIntegrateTransport_dq)
+  RTOC_NEEDS_PINOCCHIO(dIntegrateTransport_dv)
+  RTOC_NEEDS_PINOCCHIO(updateKinematics)
+  RTOC_NEEDS_PINOCCHIO(updateFrameKinematics)
+  RTOC_NEEDS_PINOCCHIO(computeBaumgarteResidual)
+  RTOC_NEEDS_PINOCCHIO(computeBaumgarteDerivatives)
+  RTOC_NEEDS_PINOCCHIO(computeImpactVelocityResidual)
+  RTOC_NEEDS_PINOCCHIO(computeImpactVelocityDerivatives)
+  RTOC_NEEDS_PINOCCHIO(computeContactPositionResidual)
+  RTOC_NEEDS_PINOCCHIO(computeContactPositionDerivative)
+  RTOC_NEEDS_PINOCCHIO(setContactForces)
+  RTOC_NEEDS_PINOCCHIO(setImpactForces)
+  RTOC_NEEDS_PINOCCHIO(RNEA)
+  RTOC_NEEDS_PINOCCHIO(RNEADerivatives)
+  RTOC_NEEDS_PINOCCHIO(RNEAImpact)
+  RTOC_NEEDS_PINOCCHIO(RNEAImpactDerivatives)
+#undef RTOC_NEEDS_PINOCCHIO
+
+ private:
+  static void unavailable(const char* what) {
+    std::fprintf(stderr, "oracle/_ref: Robot::%s needs Pinocchio, which is absent from this image\n", what);
+    std::abort();
+  }
+  void needFixedBase(const char* what) const {
+    if (hasFloatingBase()) unavailable(what);
+  }
+  int dimv_, dimu_;
+  std::vector<ContactType> contact_types_;
+  std::vector<std::string> contact_frame_names_;
+  double contact_inv_damping_;
+  int max_dimf_;
+};
+
+}  // namespace robotoc
+#endif  // ROBOTOC_ROBOT_HPP_

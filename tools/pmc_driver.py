@@ -1,0 +1,83 @@
+"""Counter-collection driver (rocprofv3 --pmc ... -- python tools/pmc_driver.py): launches every hot-path kernel
+DESIGN.md quotes at its bench.py size, through the C ABI only -- no torch in the process (rocprofv3's counter
+collection segfaults inside torch's first copy kernel on this image; profiles/r02_pmc_notes.txt).  Stage data:
+64 distinct instances tiled to the batch (counter values do not depend on the data values: no data-dependent
+branches in the kernels).  Usage: pmc_driver.py [reps]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+from robotoc_amd import capi, problems as pr
+from robotoc_amd.types import BUF_CDD, BUF_CON, BUF_CONE, BUF_DX0, BUF_KKT, joint_limit_rows
+
+
+def tile(a, batch):
+    reps = (batch + a.shape[0] - 1) // a.shape[0]
+    return np.ascontiguousarray(np.tile(a, (reps,) + (1,) * (a.ndim - 1))[:batch])
+
+
+def main():
+    reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+    uniq = 64
+    # ---- ANYmal trot, 4096 instances: sweep + SQP hot path ----
+    dims, grids, _ = pr.config_anymal_trot()
+    batch = 4096
+    ctx = capi.Context(dims, len(grids), batch, 0)
+    L = ctx.L
+    ctx.set_grid(grids)
+    ctx.upload(BUF_KKT, tile(pr.make_kkt_batch_unique(L, grids, uniq), batch))
+    ctx.upload(BUF_DX0, tile(pr.make_dx0_unique(L, uniq), batch))
+    for _ in range(reps):
+        ctx.riccati_backward()
+        ctx.riccati_forward()
+    assert (ctx.status() == 0).all()
+    rows = joint_limit_rows(dims)
+    ctx.set_constraint_rows(rows)
+    ctx.set_friction_cones(4, 3)
+    kkt, cdd = pr.make_precondense_batch_unique(L, grids, uniq)
+    kkt, cdd = tile(kkt, batch), tile(cdd, batch)
+    con = tile(pr.make_constraint_batch_unique(L, grids, uniq), batch)
+    ctx.upload(BUF_CONE, tile(pr.make_cone_batch_unique(L, grids, uniq, 4), batch))
+    for _ in range(reps):
+        ctx.upload(BUF_KKT, kkt)
+        ctx.upload(BUF_CDD, cdd)
+        ctx.upload(BUF_CON, con)
+        ctx.condense()
+        ctx.riccati_backward()
+        ctx.riccati_forward()
+        ctx.expand(0.995)
+        ctx.update()
+    assert (ctx.status() == 0).all()
+    ctx.close()
+    del kkt, cdd, con
+    # ---- iCub nv=32 / nv=35, 1024 instances: backward + forward, condense + expand ----
+    for nv in (32, 35):
+        dims, grids, _ = pr.config_icub_jump(nv=nv)
+        batch = 1024
+        ctx = capi.Context(dims, len(grids), batch, 0)
+        L = ctx.L
+        ctx.set_grid(grids)
+        ctx.upload(BUF_KKT, tile(pr.make_kkt_batch_unique(L, grids, 16, seed=7), batch))
+        ctx.upload(BUF_DX0, tile(pr.make_dx0_unique(L, 16, seed=7), batch))
+        for _ in range(reps):
+            ctx.riccati_backward()
+            ctx.riccati_forward()
+        assert (ctx.status() == 0).all()
+        kkt, cdd = pr.make_precondense_batch_unique(L, grids, 16, seed=7)
+        kkt, cdd = tile(kkt, batch), tile(cdd, batch)
+        for _ in range(reps):
+            ctx.upload(BUF_KKT, kkt)
+            ctx.upload(BUF_CDD, cdd)
+            ctx.condense()
+            ctx.riccati_backward()
+            ctx.riccati_forward()
+            ctx.expand(0.995)
+        assert (ctx.status() == 0).all()
+        ctx.close()
+    print("pmc_driver done")
+
+
+if __name__ == "__main__":
+    main()

@@ -7,9 +7,24 @@ OUT = os.path.join(R, "gpurun_out")
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 note = sys.argv[2] if len(sys.argv) > 2 else ""
 lines = ["# rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline   (%s)" % note,
+         "# counter passes: rocprofv3 --pmc <set> -- python tools/pmc_driver.py 3   (tools/gpu_pmc2.sh; same kernels, same sizes, no torch in the process)",
          "# Name, Calls, TotalDurationNs, AverageNs, Percentage, MinNs, MaxNs, StdDev"]
 for r in csv.DictReader(open(os.path.join(OUT, "prof_stats", "stats_kernel_stats.csv"))):
     lines.append(", ".join(r[k] for k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev")))
+# per launch geometry (the whole-bench trace mixes batch and single-instance launches of the same kernel)
+trace = os.path.join(OUT, "prof_stats", "stats_kernel_trace.csv")
+if os.path.exists(trace):
+    acc = collections.OrderedDict()
+    for r in csv.DictReader(open(trace)):
+        if "rtoc::" not in r["Kernel_Name"] and "mask_converged" not in r["Kernel_Name"]:
+            continue
+        key = (r["Kernel_Name"].split("(")[0].replace("void ", ""), int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]),
+               int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"]), int(r["Workgroup_Size_X"]), r["LDS_Block_Size"], r["Scratch_Size"],
+               r["VGPR_Count"], r["Accum_VGPR_Count"], r["SGPR_Count"])
+        acc.setdefault(key, []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+    lines.append("# same trace grouped by launch geometry: kernel, workgroups(x), y*z, threads, LDS bytes, scratch bytes/lane, VGPR, AGPR, SGPR, calls, avg ms, min ms, max ms")
+    for k, v in acc.items():
+        lines.append("%s, %d, %d, %d, %s, %s, %s, %s, %s, n=%d, avg %.4f, min %.4f, max %.4f" % (k + (len(v), sum(v) / len(v), min(v), max(v))))
 traffic = {}
 for cname, d in (("FETCH_SIZE", "prof_fetch/fetch"), ("WRITE_SIZE", "prof_write/write")):
     acc = collections.OrderedDict()
