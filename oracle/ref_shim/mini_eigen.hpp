@@ -145,7 +145,9 @@ class MatrixBase {
   inline View segment(Index i) const;
   inline View transpose() const;
   inline View diagonal() const;
-  inline View noalias() const;
+  // Eigen: `m.noalias() = expr` still RESIZES a plain matrix (robotoc relies on it, e.g. DtM in
+  // riccati_factorizer.cpp:84), so noalias() hands back the object itself, not a fixed-size view
+  D& noalias() const { return const_cast<D&>(derived()); }
   inline View array() const;
   inline View matrix() const;
   inline Diag asDiagonal() const;
@@ -268,6 +270,19 @@ class MatrixBase {
       s += (a.c == 1 ? a.at(i, 0) : a.at(0, i)) * (b.c == 1 ? b.at(i, 0) : b.at(0, i));
     return s;
   }
+
+  // ---- assignment through a MatrixBase reference (the reference's `const_cast<MatrixBase<T>&>(x) = ...` idiom) ----
+  template <class E>
+  D& operator=(const MatrixBase<E>& o) {
+    derived() = o;
+    return derived();
+  }
+  MatrixBase& operator=(const MatrixBase& o) {
+    if (this != &o) derived() = o.derived();
+    return *this;
+  }
+  MatrixBase() = default;
+  MatrixBase(const MatrixBase&) = default;
 
   // ---- compound assignment (rhs is always materialised or independent storage) ----
   template <class E>
@@ -661,8 +676,6 @@ View MatrixBase<D>::diagonal() const {
   const RawView v = raw();
   return View(v.p, std::min(v.r, v.c), 1, v.rs + v.cs, 0);
 }
-template <class D>
-View MatrixBase<D>::noalias() const { return View(raw()); }
 template <class D>
 View MatrixBase<D>::array() const { return View(raw()); }
 template <class D>

@@ -6,10 +6,15 @@
  * `cpu_baseline` leg of bench.py use it, and only as the checker / the timed
  * CPU baseline -- never as the thing shipped.
  *
- * PARITY STATUS: "parity unpinned" against a reference *binary*.  The reference
- * cannot be compiled here (hard deps Eigen3 + Pinocchio are absent from the
- * image, CMakeLists.txt:27-31) and it ships no golden vectors (its tests are
- * differential tests on srand(time(0)) inputs).  What pins this file instead:
+ * PARITY STATUS: pinned against the reference's own SOURCES, not against a robotoc binary built with
+ * Eigen + Pinocchio (both absent from the image, CMakeLists.txt:27-31; the reference ships no golden
+ * vectors, its tests are differential tests on srand(time(0)) inputs).  What pins this file:
+ *   (o)  oracle/_ref/librtoc_ref.so -- robotoc's src/riccati, src/dynamics, src/core .cpp files compiled
+ *        where they lie (oracle/Makefile.ref) against oracle/ref_shim (an eager stand-in for the Eigen API,
+ *        dimension-only stand-ins for Robot / OCP / TimeDiscretization): tests/test_oracle_vs_reference.py
+ *        runs both on the same seeded inputs (1e-15 ... 1e-10 on every grid kind incl. switching constraints,
+ *        STO terms, phase transitions, condensation and expansion), tests/test_golden_ref.py checks this file
+ *        and the HIP path against the fixtures those sources generated (tests/golden/ref_*.npz);
  *   (i)  the closed-form expectations of the reference's own unit tests,
  *        re-stated in numpy in tests/test_oracle_reference_identities.py
  *        (test/riccati/backward_riccati_recursion_factorizer_test.cpp:31-138,
@@ -19,6 +24,8 @@
  *   (ii) a dense assembly of the whole-horizon KKT system solved with LAPACK
  *        (tests/test_oracle_dense_kkt.py) -- the horizon-level check the
  *        reference lacks (test/riccati/riccati_recursion_test.cpp:56-63 is empty).
+ *   Not pinned by (o): Eigen's summation order, Pinocchio's arithmetic (computeMJtJinv's elimination
+ *   order), the PDIPM row classes and the evalKKT-tail scalings (closed-form tests only).
  *
  * Every function cites the reference lines it follows; operation order inside a
  * function follows the cited lines (products accumulate in k-order).

@@ -95,7 +95,11 @@ struct BwdCfg {
   static constexpr int OFF_H = OFF_PB + NU * LDP;   // H = Qxu'; dead after the K solve -> reused for GK
   static constexpr int OFF_GK = OFF_H;
   static constexpr int OFF_BV = OFF_H + NU * LDP;
-  static constexpr int OFF_G = OFF_BV + pad8(NV * NU);
+  // leading dimension of Bv in LDS: the MFMA operand reads walk it as q + li * LDB (16 rows x 4 k of a tile); with
+  // NV = 32 a stride of NV doubles puts all 16 rows of a half-wave in ONE bank pair (53 % of the LDS cycles of the
+  // nv = 32 kernel were bank conflicts, profiles/r02_rocprof_summary.txt); even and LDB/2 odd spreads them
+  static constexpr int LDB = (NV % 2 == 0) ? lds_ld(NV) : NV;
+  static constexpr int OFF_G = OFF_BV + pad8(LDB * NU);
   static constexpr int OFF_L = OFF_G + pad8(NU * NU);
   static constexpr int OFF_VEC = OFF_L + pad8(NU * NU);
   // ---- switching-constraint scratch, aliased on A after the F product ----
@@ -186,6 +190,26 @@ __device__ __forceinline__ void pre_store_mat(double* __restrict__ dst,
 #pragma unroll
   for (int k = 0; k < M::passes(COLS); ++k)
     if (act && (k * M::CPP + c0 < COLS)) *reinterpret_cast<d2*>(d + k * M::CPP * LD) = buf.v[k];
+}
+
+// flat prefetch registers of a ROWS x cols column-major block -> LDS with leading dimension LD (ROWS even: a d2
+// never straddles two columns)
+template <int NT, int N2, int ROWS, int LD>
+__device__ __forceinline__ void pre_store_ld(double* __restrict__ dst, const PreBuf<PreCnt<NT, N2>::value>& buf, int tid) {
+  if constexpr (ROWS == LD) {
+#pragma unroll
+    for (int k = 0; k < PreCnt<NT, N2>::value; ++k) {
+      const int e = tid + k * NT;
+      if (e < N2) reinterpret_cast<d2*>(dst)[e] = buf.v[k];
+    }
+  } else {
+    static_assert(ROWS % 2 == 0 && LD % 2 == 0, "pairs must not straddle columns");
+#pragma unroll
+    for (int k = 0; k < PreCnt<NT, N2>::value; ++k) {
+      const int e = tid + k * NT;
+      if (e < N2) *reinterpret_cast<d2*>(dst + (2 * e) % ROWS + ((2 * e) / ROWS) * LD) = buf.v[k];
+    }
+  }
 }
 
 template <int NT, int N2>
@@ -438,7 +462,7 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
     // ---- stage data: prefetched registers -> LDS (the HBM loads were issued one stage ahead) ----
     pre_store_mat<NT, NX, NX, LDP>(sA, preA, tid);
     if (!impact) {
-      pre_store_flat<NT, N2B>(sBv, preB, tid);
+      pre_store_ld<NT, N2B, NV, C::LDB>(sBv, preB, tid);
       pre_store_mat<NT, NX, NU, LDP>(sH, preH, tid);
       pre_store_flat<NT, N2G>(sG, preG, tid);
     }
@@ -494,14 +518,14 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
 #pragma unroll
           for (int t = 0; t < TNU; ++t) acc[c][t] = zero4();
         const double* pa_ = sP + (wave * 16 + li) + (NV + q) * LDP;  // P+[i][NV+k]
-        const double* pb_ = sBv + q + li * NV;                        // Bv[k][u]
+        const double* pb_ = sBv + q + li * C::LDB;                    // Bv[k][u]
 #pragma unroll
         for (int ks = 0; ks < (NV + 3) / 4; ++ks) {
           const bool kok = (ks * 4 + 3 < NV) || (ks * 4 + q < NV);
           double bv[TNU];
 #pragma unroll
           for (int t = 0; t < TNU; ++t) {
-            const double v = pb_[ks * 4 + t * 16 * NV];
+            const double v = pb_[ks * 4 + t * 16 * C::LDB];
             bv[t] = (kok && (t * 16 + li < NU)) ? v : 0.0;
           }
 #pragma unroll
@@ -527,7 +551,7 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
       __syncthreads();
       // ---- G = Quu + Bv^T PB[v,:] (its TNU x TNU tiles dealt to the waves) ; lu' = lu - Bv^T z[v] ----
       {
-        const double* pa_ = sBv + q + li * NV;        // Bv^T[u][k] = Bv[k][u]
+        const double* pa_ = sBv + q + li * C::LDB;    // Bv^T[u][k] = Bv[k][u]
         const double* pb_ = sPB + NV + q + li * LDP;  // PB[NV+k][u]
 #pragma unroll
         for (int t = 0; t < TNU * TNU; ++t) {
@@ -537,7 +561,7 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
 #pragma unroll
           for (int ks = 0; ks < (NV + 3) / 4; ++ks) {
             const bool kok = (ks * 4 + 3 < NV) || (ks * 4 + q < NV);
-            const double va = pa_[ks * 4 + t0 * 16 * NV];
+            const double va = pa_[ks * 4 + t0 * 16 * C::LDB];
             const double vb = pb_[ks * 4 + t1 * 16 * LDP];
             acc = mfma16((kok && t0 * 16 + li < NU) ? va : 0.0, (kok && t1 * 16 + li < NU) ? vb : 0.0, acc);
           }
@@ -554,16 +578,16 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
           double b0 = 0.0, b1 = 0.0;
 #pragma unroll
           for (int k = 0; k + 1 < NV; k += 2) {
-            b0 += sBv[k + tid * NV] * smem[C::V_Z + NV + k];
-            b1 += sBv[k + 1 + tid * NV] * smem[C::V_Z + NV + k + 1];
+            b0 += sBv[k + tid * C::LDB] * smem[C::V_Z + NV + k];
+            b1 += sBv[k + 1 + tid * C::LDB] * smem[C::V_Z + NV + k + 1];
           }
-          if (NV & 1) b0 += sBv[NV - 1 + tid * NV] * smem[C::V_Z + 2 * NV - 1];
+          if (NV & 1) b0 += sBv[NV - 1 + tid * C::LDB] * smem[C::V_Z + 2 * NV - 1];
           acc = b0 + b1;
         }
         if (sto) {
 #pragma unroll
           for (int k = 0; k < NV; ++k) {
-            const double bv = sBv[k + tid * NV];
+            const double bv = sBv[k + tid * C::LDB];
             ap += bv * smem[C::V_Y + NV + k];
             aph += bv * (sto_next ? smem[C::V_PHIN + NV + k] : 0.0);
           }

@@ -114,11 +114,12 @@ def test_anymal_jump_sto_ill_conditioned(oracle):
         ctx.close()
 
 
-@pytest.mark.parametrize("nv", [35, 32])
-def test_icub_jump_sweep(oracle, nv):
-    """configs[3]: iCub jump; nv=35 (reference URDF) and nv=32 (as named by BASELINE.json)."""
+@pytest.mark.parametrize("nv,waves", [(35, 0), (35, 4), (35, 5), (32, 0)])
+def test_icub_jump_sweep(oracle, nv, waves):
+    """configs[3]: iCub jump; nv=35 (reference URDF; 5 or 4 waves per instance) and nv=32 (as named by
+    BASELINE.json)."""
     dims, grids, _ = pr.config_icub_jump(nv=nv)
-    _run_case(oracle, dims, grids, 3, "factory")
+    _run_case(oracle, dims, grids, 3, "factory", waves=waves)
 
 
 def test_plain_horizon_no_events(oracle):

