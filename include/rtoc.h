@@ -128,6 +128,11 @@ int rtoc_dims_supported(const rtoc_dims* dims);
  * Mirrors the sizing done in OCPSolver's constructor (src/solver/ocp_solver.cpp:20-24). */
 int rtoc_create(const rtoc_dims* dims, int max_stages, int batch, int device, rtoc_ctx** out);
 int rtoc_destroy(rtoc_ctx* ctx);
+/* Deep copy of a context on its device: dimensions, grid, constraint rows, cone set-up, options and every
+ * allocated buffer (device-to-device).  Gives the C++ mirrors the value semantics of the reference's solver
+ * objects (RiccatiRecursion / OCPSolver are copyable, riccati_recursion.hpp:40-60, ocp_solver.hpp:62-77).
+ * Buffers bound to caller-owned memory (rtoc_bind) are copied into buffers the clone owns. */
+int rtoc_clone(rtoc_ctx* ctx, rtoc_ctx** out);
 
 /* Layout actually used by the context (identical to rtoc_compute_layout(dims)). */
 int rtoc_get_layout(const rtoc_ctx* ctx, rtoc_layout* out);

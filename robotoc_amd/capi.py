@@ -25,7 +25,7 @@ EXPORTS = [
     "rtoc_sync", "rtoc_time_phase", "rtoc_set_constraint_rows", "rtoc_gather_directions", "rtoc_error_string",
     "rtoc_riccati_sweep", "rtoc_correct_state_equation", "rtoc_correct_costate_direction",
     "rtoc_compute_initial_state_direction", "rtoc_unconstr_condense", "rtoc_unconstr_expand",
-    "rtoc_newton_iteration", "rtoc_converged_count", "rtoc_set_friction_cones", "rtoc_set_wrench_cones", "rtoc_wrench_cone_matrix", "rtoc_save_stage_dump", "rtoc_load_stage_dump", "rtoc_kkt_error", "rtoc_integrate_solution",
+    "rtoc_newton_iteration", "rtoc_converged_count", "rtoc_clone", "rtoc_set_friction_cones", "rtoc_set_wrench_cones", "rtoc_wrench_cone_matrix", "rtoc_save_stage_dump", "rtoc_load_stage_dump", "rtoc_kkt_error", "rtoc_integrate_solution",
 ]
 
 

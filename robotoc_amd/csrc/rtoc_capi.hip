@@ -356,6 +356,53 @@ int rtoc_destroy(rtoc_ctx* c) {
   return RTOC_OK;
 }
 
+int rtoc_set_grid(rtoc_ctx* c, const rtoc_grid* grid, int nstages);
+int rtoc_set_constraint_rows(rtoc_ctx* c, const rtoc_box_row* rows, int nrows);
+int rtoc_set_friction_cones(rtoc_ctx* c, int max_contacts, int contact_dim);
+int rtoc_set_wrench_cones(rtoc_ctx* c, int max_contacts);
+int rtoc_set_option(rtoc_ctx* c, int option, int64_t value);
+
+int rtoc_clone(rtoc_ctx* c, rtoc_ctx** out) {
+  if (!c || !out) return RTOC_ERR_BAD_ARG;
+  rtoc_ctx* n = nullptr;
+  int rc = rtoc_create(&c->dims, c->max_stages, c->batch, c->device, &n);
+  if (rc) return rc;
+  if (c->nstages >= 2 && c->h_grid) rc = rtoc_set_grid(n, c->h_grid, c->nstages);
+  if (!rc && c->nrows > 0 && c->h_rows) rc = rtoc_set_constraint_rows(n, c->h_rows, c->nrows);
+  if (!rc && c->cone_contacts > 0)
+    rc = c->cone_rows == RTOC_WRENCH_ROWS ? rtoc_set_wrench_cones(n, c->cone_contacts)
+                                          : rtoc_set_friction_cones(n, c->cone_contacts, c->cone_dim);
+  if (!rc) {
+    n->writeback = c->writeback;
+    n->max_dts0 = c->max_dts0;
+    n->contact_inv_damping = c->contact_inv_damping;
+    n->bwd_variant = c->bwd_variant;
+    n->sweep_chunks = c->sweep_chunks;
+    n->condense_split = c->condense_split;
+    if (c->backward_scan) rc = rtoc_set_option(n, RTOC_OPT_BACKWARD_SCAN, c->backward_scan);
+  }
+  hipError_t e = hipStreamSynchronize(c->stream);
+  for (int b = 0; !rc && e == hipSuccess && b < RTOC_NUM_BUFFERS; ++b) {
+    if (!c->buf[b]) continue;
+    if (!n->buf[b]) {
+      n->count[b] = c->count[b];
+      e = hipMalloc((void**)&n->buf[b], n->count[b] * sizeof(double));
+      if (e != hipSuccess) break;
+      n->owned[b] = true;
+    }
+    e = hipMemcpyAsync(n->buf[b], c->buf[b], c->count[b] * sizeof(double), hipMemcpyDeviceToDevice, n->stream);
+  }
+  if (!rc && e == hipSuccess) e = hipMemcpyAsync(n->d_status, c->d_status, sizeof(uint32_t) * c->batch, hipMemcpyDeviceToDevice, n->stream);
+  if (!rc && e == hipSuccess) e = hipStreamSynchronize(n->stream);
+  if (rc || e != hipSuccess) {
+    if (e != hipSuccess) ctx_set_err(e, __LINE__);
+    (void)rtoc_destroy(n);
+    return rc ? rc : RTOC_ERR_HIP;
+  }
+  *out = n;
+  return RTOC_OK;
+}
+
 int rtoc_get_layout(const rtoc_ctx* c, rtoc_layout* out) {
   if (!c || !out) return RTOC_ERR_BAD_ARG;
   *out = c->L;

@@ -183,19 +183,65 @@ class RiccatiRecursion {
  public:
   RiccatiRecursion(const OCP& ocp, const double max_dts0 = 0.1, const int device = 0)
       : robot_(ocp.robot), max_stages_(ocp.N + 1 + 3 * ocp.reserved_num_discrete_events + 1),
-        lqr_policy_(ocp.N + 1 + ocp.reserved_num_discrete_events, LQRPolicy(ocp.robot)), ctx_(nullptr) {
+        lqr_policy_(ocp.N + 1 + ocp.reserved_num_discrete_events, LQRPolicy(ocp.robot)), ctx_(nullptr), owns_(true),
+        resident_hash_(0) {
     if (max_dts0 <= 0) throw std::out_of_range("[RiccatiRecursion] invalid argument: max_dts0 must be positive!");
     const rtoc_dims d = robot_.c();
     check(rtoc_create(&d, max_stages_, 1, device, &ctx_), "rtoc_create");
+    try {
+      check(rtoc_get_layout(ctx_, &L_), "rtoc_get_layout");
+      check(rtoc_set_option(ctx_, RTOC_OPT_WRITEBACK_KKT, 1), "rtoc_set_option");  // reference in-place semantics
+      setRegularization(max_dts0);
+    } catch (...) {
+      rtoc_destroy(ctx_);
+      ctx_ = nullptr;
+      throw;
+    }
+  }
+  // Over a context someone else owns (robotoc::OCPSolver shares ONE device context between its
+  // DirectMultipleShooting and RiccatiRecursion members so that the stage data stay resident in HBM).
+  RiccatiRecursion(const OCP& ocp, rtoc_ctx* shared)
+      : robot_(ocp.robot), max_stages_(0), lqr_policy_(ocp.N + 1 + ocp.reserved_num_discrete_events, LQRPolicy(ocp.robot)),
+        ctx_(shared), owns_(false), resident_hash_(0) {
+    if (!shared) throw std::invalid_argument("[RiccatiRecursion] null device context");
     check(rtoc_get_layout(ctx_, &L_), "rtoc_get_layout");
-    check(rtoc_set_option(ctx_, RTOC_OPT_WRITEBACK_KKT, 1), "rtoc_set_option");  // reference in-place semantics
-    setRegularization(max_dts0);
+    max_stages_ = static_cast<int>(rtoc_buffer_count(ctx_, RTOC_BUF_KKT) / L_.kkt.stride);
   }
-  ~RiccatiRecursion() {
-    if (ctx_) rtoc_destroy(ctx_);
+  // Default constructor like the reference's (riccati_recursion.hpp:40): an empty object, usable after assignment.
+  RiccatiRecursion() : robot_{0, 0, 0, 0}, max_stages_(0), ctx_(nullptr), owns_(true), resident_hash_(0) {}
+  ~RiccatiRecursion() { release(); }
+  // Value semantics like the reference (riccati_recursion.hpp:50-60): a copy owns a deep copy of the device context.
+  RiccatiRecursion(const RiccatiRecursion& o)
+      : robot_(o.robot_), max_stages_(o.max_stages_), lqr_policy_(o.lqr_policy_), ctx_(nullptr), owns_(true), L_(o.L_),
+        resident_hash_(o.resident_hash_) {
+    if (o.ctx_) check(rtoc_clone(o.ctx_, &ctx_), "rtoc_clone");
   }
-  RiccatiRecursion(const RiccatiRecursion&) = delete;
-  RiccatiRecursion& operator=(const RiccatiRecursion&) = delete;
+  RiccatiRecursion& operator=(const RiccatiRecursion& o) {
+    if (this != &o) {
+      RiccatiRecursion tmp(o);
+      swap(tmp);
+    }
+    return *this;
+  }
+  RiccatiRecursion(RiccatiRecursion&& o) noexcept
+      : robot_(o.robot_), max_stages_(o.max_stages_), lqr_policy_(std::move(o.lqr_policy_)), ctx_(o.ctx_), owns_(o.owns_),
+        L_(o.L_), resident_hash_(o.resident_hash_) {
+    o.ctx_ = nullptr;
+  }
+  RiccatiRecursion& operator=(RiccatiRecursion&& o) noexcept {
+    if (this != &o) {
+      release();
+      robot_ = o.robot_;
+      max_stages_ = o.max_stages_;
+      lqr_policy_ = std::move(o.lqr_policy_);
+      ctx_ = o.ctx_;
+      owns_ = o.owns_;
+      L_ = o.L_;
+      resident_hash_ = o.resident_hash_;
+      o.ctx_ = nullptr;
+    }
+    return *this;
+  }
 
   void setRegularization(const double max_dts0) {
     if (max_dts0 <= 0) throw std::out_of_range("[RiccatiRecursion] invalid argument: max_dts0 must be positive!");
@@ -218,59 +264,113 @@ class RiccatiRecursion {
 
   void backwardRiccatiRecursion(const TimeDiscretization& td, KKTMatrix& kkt_matrix,
                                 KKTResidual& kkt_residual, RiccatiFactorization& factorization) {
+    need_ctx();
     resizeData(td);
     const int n = td.size();
     if (n > max_stages_ || static_cast<int>(kkt_matrix.size()) < n || static_cast<int>(kkt_residual.size()) < n ||
         static_cast<int>(factorization.size()) < n)
       throw std::invalid_argument("[RiccatiRecursion] horizon containers smaller than the discretisation");
     setGrid(td);
-    std::vector<double> buf(static_cast<size_t>(n) * L_.kkt.stride, 0.0);
-    for (int i = 0; i < n; ++i) packKKT(kkt_matrix[i], kkt_residual[i], &buf[static_cast<size_t>(i) * L_.kkt.stride]);
-    check(rtoc_upload(ctx_, RTOC_BUF_KKT, 0, buf.data(), buf.size()), "rtoc_upload");
+    // staging buffers live as long as the object: no allocation per call
+    kkt_stage_.assign(static_cast<size_t>(n) * L_.kkt.stride, 0.0);
+    for (int i = 0; i < n; ++i) packKKT(kkt_matrix[i], kkt_residual[i], &kkt_stage_[static_cast<size_t>(i) * L_.kkt.stride]);
+    check(rtoc_upload(ctx_, RTOC_BUF_KKT, 0, kkt_stage_.data(), kkt_stage_.size()), "rtoc_upload");
     check(rtoc_clear_status(ctx_), "rtoc_clear_status");
     check(rtoc_riccati_backward(ctx_), "rtoc_riccati_backward");
-    check(rtoc_download(ctx_, RTOC_BUF_KKT, 0, buf.data(), buf.size()), "rtoc_download");
+    check(rtoc_download(ctx_, RTOC_BUF_KKT, 0, kkt_stage_.data(), kkt_stage_.size()), "rtoc_download");
     for (int i = 0; i < n - 1; ++i)  // mutated blocks, like the reference (brrf.cpp:37-44,82-83)
-      unpackMutatedKKT(&buf[static_cast<size_t>(i) * L_.kkt.stride], td[i], kkt_matrix[i], kkt_residual[i]);
-    std::vector<double> rb(static_cast<size_t>(n) * L_.ric.stride);
-    check(rtoc_download(ctx_, RTOC_BUF_RIC, 0, rb.data(), rb.size()), "rtoc_download");
-    for (int i = 0; i < n; ++i) unpackRiccati(&rb[static_cast<size_t>(i) * L_.ric.stride], factorization[i], lqr_policy_[i]);
+      unpackMutatedKKT(&kkt_stage_[static_cast<size_t>(i) * L_.kkt.stride], td[i], kkt_matrix[i], kkt_residual[i]);
+    ric_stage_.resize(static_cast<size_t>(n) * L_.ric.stride);
+    check(rtoc_download(ctx_, RTOC_BUF_RIC, 0, ric_stage_.data(), ric_stage_.size()), "rtoc_download");
+    for (int i = 0; i < n; ++i) unpackRiccati(&ric_stage_[static_cast<size_t>(i) * L_.ric.stride], factorization[i], lqr_policy_[i]);
+    // fingerprint of what is resident in HBM now (the mutated KKT blocks and the factorisation): the forward
+    // recursion compares it with the containers it is handed
+    resident_hash_ = hashHorizon(n, kkt_matrix, kkt_residual, factorization);
   }
 
-  void forwardRiccatiRecursion(const TimeDiscretization& td, const KKTMatrix&, const KKTResidual&,
-                               const RiccatiFactorization&, Direction& d) const {
-    // kkt_matrix / kkt_residual / factorization of the preceding backward pass are resident in HBM
+  // The reference's forward recursion reads the kkt_matrix / kkt_residual / factorization it is handed
+  // (riccati_recursion.cpp:83-131).  Normally these are the containers of the preceding backward pass, whose
+  // contents are still resident in HBM; if the caller edited them in between (fingerprint mismatch) they are
+  // packed and uploaded again, so the arguments are always honoured.
+  void forwardRiccatiRecursion(const TimeDiscretization& td, const KKTMatrix& kkt_matrix, const KKTResidual& kkt_residual,
+                               const RiccatiFactorization& factorization, Direction& d) {
+    need_ctx();
     const int n = td.size();
-    if (static_cast<int>(d.size()) < n) throw std::invalid_argument("[RiccatiRecursion] direction too short");
+    if (static_cast<int>(d.size()) < n || static_cast<int>(kkt_matrix.size()) < n || static_cast<int>(kkt_residual.size()) < n ||
+        static_cast<int>(factorization.size()) < n)
+      throw std::invalid_argument("[RiccatiRecursion] horizon containers smaller than the discretisation");
+    if (hashHorizon(n, kkt_matrix, kkt_residual, factorization) != resident_hash_) {
+      setGrid(td);
+      kkt_stage_.assign(static_cast<size_t>(n) * L_.kkt.stride, 0.0);
+      ric_stage_.assign(static_cast<size_t>(n) * L_.ric.stride, 0.0);
+      for (int i = 0; i < n; ++i) {
+        packKKT(kkt_matrix[i], kkt_residual[i], &kkt_stage_[static_cast<size_t>(i) * L_.kkt.stride]);
+        packRiccati(factorization[i], lqr_policy_[i], &ric_stage_[static_cast<size_t>(i) * L_.ric.stride]);
+      }
+      check(rtoc_upload(ctx_, RTOC_BUF_KKT, 0, kkt_stage_.data(), kkt_stage_.size()), "rtoc_upload");
+      // the STO policy entries of the records (dtsdx, dtsdts, dts0) have no host container in the reference
+      // (RiccatiRecursion::sto_policy_ is private): keep the resident ones
+      std::vector<double> cur(ric_stage_.size());
+      check(rtoc_download(ctx_, RTOC_BUF_RIC, 0, cur.data(), cur.size()), "rtoc_download");
+      for (int i = 0; i < n; ++i) {
+        double* r = &ric_stage_[static_cast<size_t>(i) * L_.ric.stride];
+        const double* c0 = &cur[static_cast<size_t>(i) * L_.ric.stride];
+        cp(r + L_.ric.off[RTOC_RIC_DTSDX], c0 + L_.ric.off[RTOC_RIC_DTSDX], 2 * robot_.dimv);
+        r[L_.ric.off[RTOC_RIC_SCAL] + RTOC_RIC_SCAL_DTSDTS] = c0[L_.ric.off[RTOC_RIC_SCAL] + RTOC_RIC_SCAL_DTSDTS];
+        r[L_.ric.off[RTOC_RIC_SCAL] + RTOC_RIC_SCAL_DTS0] = c0[L_.ric.off[RTOC_RIC_SCAL] + RTOC_RIC_SCAL_DTS0];
+      }
+      check(rtoc_upload(ctx_, RTOC_BUF_RIC, 0, ric_stage_.data(), ric_stage_.size()), "rtoc_upload");
+      resident_hash_ = hashHorizon(n, kkt_matrix, kkt_residual, factorization);
+    }
     check(rtoc_upload(ctx_, RTOC_BUF_DX0, 0, d[0].dx.data(), 2 * robot_.dimv), "rtoc_upload");
     check(rtoc_riccati_forward(ctx_), "rtoc_riccati_forward");
-    std::vector<double> db(static_cast<size_t>(n) * L_.dir.stride);
-    check(rtoc_download(ctx_, RTOC_BUF_DIR, 0, db.data(), db.size()), "rtoc_download");
-    for (int i = 0; i < n; ++i) {
-      const double* r = &db[static_cast<size_t>(i) * L_.dir.stride];
-      std::memcpy(d[i].dx.data(), r + L_.dir.off[RTOC_DIR_DX], sizeof(double) * 2 * robot_.dimv);
-      std::memcpy(d[i].du.data(), r + L_.dir.off[RTOC_DIR_DU], sizeof(double) * robot_.dimu);
-      std::memcpy(d[i].dlmdgmm.data(), r + L_.dir.off[RTOC_DIR_DLMDGMM], sizeof(double) * 2 * robot_.dimv);
-      std::memcpy(d[i].dxi_full.data(), r + L_.dir.off[RTOC_DIR_DXI], sizeof(double) * robot_.max_dimf);
-      d[i].dts = r[L_.dir.off[RTOC_DIR_DTS] + 0];
-      d[i].dts_next = r[L_.dir.off[RTOC_DIR_DTS] + 1];
-    }
+    dir_stage_.resize(static_cast<size_t>(n) * L_.dir.stride);
+    check(rtoc_download(ctx_, RTOC_BUF_DIR, 0, dir_stage_.data(), dir_stage_.size()), "rtoc_download");
+    for (int i = 0; i < n; ++i) unpackDirection(&dir_stage_[static_cast<size_t>(i) * L_.dir.stride], d[i]);
+  }
+
+  // Device-resident forms used by robotoc::OCPSolver (robotoc_hip_solver.hpp): the stage data are already in HBM
+  // (RTOC_BUF_KKT after rtoc_condense, RTOC_BUF_DX0), nothing crosses PCIe.
+  void backwardRiccatiRecursionResident(const TimeDiscretization& td) {
+    need_ctx();
+    resizeData(td);
+    check(rtoc_riccati_backward(ctx_), "rtoc_riccati_backward");
+  }
+  void forwardRiccatiRecursionResident() {
+    need_ctx();
+    check(rtoc_riccati_forward(ctx_), "rtoc_riccati_forward");
+  }
+  // factorisation + LQR policies / directions of the resident horizon into host containers (on demand)
+  void downloadFactorization(const TimeDiscretization& td, RiccatiFactorization& factorization) {
+    need_ctx();
+    const int n = td.size();
+    resizeData(td);
+    if (static_cast<int>(factorization.size()) < n) throw std::invalid_argument("[RiccatiRecursion] factorization too short");
+    ric_stage_.resize(static_cast<size_t>(n) * L_.ric.stride);
+    check(rtoc_download(ctx_, RTOC_BUF_RIC, 0, ric_stage_.data(), ric_stage_.size()), "rtoc_download");
+    for (int i = 0; i < n; ++i) unpackRiccati(&ric_stage_[static_cast<size_t>(i) * L_.ric.stride], factorization[i], lqr_policy_[i]);
+  }
+  void downloadDirection(const TimeDiscretization& td, Direction& d) {
+    need_ctx();
+    const int n = td.size();
+    if (static_cast<int>(d.size()) < n) throw std::invalid_argument("[RiccatiRecursion] direction too short");
+    dir_stage_.resize(static_cast<size_t>(n) * L_.dir.stride);
+    check(rtoc_download(ctx_, RTOC_BUF_DIR, 0, dir_stage_.data(), dir_stage_.size()), "rtoc_download");
+    for (int i = 0; i < n; ++i) unpackDirection(&dir_stage_[static_cast<size_t>(i) * L_.dir.stride], d[i]);
   }
 
   const std::vector<LQRPolicy>& getLQRPolicy() const { return lqr_policy_; }
 
   // RTOC_STAT_* bits of the last backward pass (the reference asserts in Debug builds only)
   unsigned status() const {
+    need_ctx();
     uint32_t s = 0;
     check(rtoc_status(ctx_, &s, 1), "rtoc_status");
     return s;
   }
+  rtoc_ctx* context() const { return ctx_; }
 
- private:
-  static void check(int rc, const char* what) {
-    if (rc != RTOC_OK) throw std::runtime_error(std::string("[RiccatiRecursion] ") + what + ": " + rtoc_error_string(rc));
-  }
-  void setGrid(const TimeDiscretization& td) {
+  static void setGridOf(rtoc_ctx* ctx, const TimeDiscretization& td) {
     std::vector<rtoc_grid> g(td.size());
     for (int i = 0; i < td.size(); ++i) {
       const GridInfo& gi = td[i];
@@ -284,8 +384,61 @@ class RiccatiRecursion {
       g[i].time_stage = gi.type == GridType::Impact ? -1 : gi.stage;
       g[i].dt = gi.dt;
     }
-    check(rtoc_set_grid(ctx_, g.data(), td.size()), "rtoc_set_grid");
+    check(rtoc_set_grid(ctx, g.data(), td.size()), "rtoc_set_grid");
   }
+
+ private:
+  static void check(int rc, const char* what) {
+    if (rc != RTOC_OK) throw std::runtime_error(std::string("[RiccatiRecursion] ") + what + ": " + rtoc_error_string(rc));
+  }
+  void need_ctx() const {
+    if (!ctx_) throw std::logic_error("[RiccatiRecursion] default-constructed object: assign a constructed one first");
+  }
+  void release() {
+    if (ctx_ && owns_) rtoc_destroy(ctx_);
+    ctx_ = nullptr;
+  }
+  void swap(RiccatiRecursion& o) {
+    std::swap(robot_, o.robot_);
+    std::swap(max_stages_, o.max_stages_);
+    lqr_policy_.swap(o.lqr_policy_);
+    std::swap(ctx_, o.ctx_);
+    std::swap(owns_, o.owns_);
+    std::swap(L_, o.L_);
+    std::swap(resident_hash_, o.resident_hash_);
+  }
+  // FNV-1a over the bytes the forward recursion reads
+  static void fnv(unsigned long long& h, const double* p, size_t n) {
+    const unsigned char* b = reinterpret_cast<const unsigned char*>(p);
+    for (size_t i = 0; i < n * sizeof(double); ++i) {
+      h ^= b[i];
+      h *= 1099511628211ull;
+    }
+  }
+  unsigned long long hashHorizon(int n, const KKTMatrix& m, const KKTResidual& r, const RiccatiFactorization& f) const {
+    unsigned long long h = 1469598103934665603ull;
+    const size_t nx = 2 * static_cast<size_t>(robot_.dimv);
+    for (int i = 0; i < n; ++i) {
+      fnv(h, m[i].Fxx.data(), nx * nx);
+      fnv(h, m[i].Fvu.data(), static_cast<size_t>(robot_.dimv) * robot_.dimu);
+      fnv(h, m[i].fx.data(), nx);
+      fnv(h, r[i].Fx.data(), nx);
+      fnv(h, f[i].P.data(), nx * nx);
+      fnv(h, f[i].s.data(), nx);
+      fnv(h, f[i].Psi.data(), nx);
+      fnv(h, f[i].Phi.data(), nx);
+      if (robot_.max_dimf > 0) {
+        fnv(h, f[i].M_full.data(), static_cast<size_t>(robot_.max_dimf) * nx);
+        fnv(h, f[i].m_full.data(), robot_.max_dimf);
+      }
+      if (i < static_cast<int>(lqr_policy_.size())) {
+        fnv(h, lqr_policy_[i].Kt.data(), nx * robot_.dimu);
+        fnv(h, lqr_policy_[i].k.data(), robot_.dimu);
+      }
+    }
+    return h;
+  }
+  void setGrid(const TimeDiscretization& td) { setGridOf(ctx_, td); }
   static void cp(double* dst, const double* src, size_t n) { std::memcpy(dst, src, n * sizeof(double)); }
   void packKKT(const SplitKKTMatrix& m, const SplitKKTResidual& r, double* rec) const {
     const int nv = robot_.dimv, nu = robot_.dimu, nx = 2 * nv, ns = robot_.max_dimf;
@@ -350,11 +503,54 @@ class RiccatiRecursion {
     cp(p.W.data(), rec + o[RTOC_RIC_W], nu);
   }
 
+  void packRiccati(const SplitRiccatiFactorization& f, const LQRPolicy& p, double* rec) const {
+    const int nv = robot_.dimv, nu = robot_.dimu, nx = 2 * nv, ns = robot_.max_dimf;
+    const int* o = L_.ric.off;
+    cp(rec + o[RTOC_RIC_P], f.P.data(), static_cast<size_t>(nx) * nx);
+    cp(rec + o[RTOC_RIC_S], f.s.data(), nx);
+    cp(rec + o[RTOC_RIC_PSI], f.Psi.data(), nx);
+    cp(rec + o[RTOC_RIC_PHI], f.Phi.data(), nx);
+    cp(rec + o[RTOC_RIC_PSIX], f.psi_x.data(), nx);
+    cp(rec + o[RTOC_RIC_PHIX], f.phi_x.data(), nx);
+    cp(rec + o[RTOC_RIC_PSIU], f.psi_u.data(), nu);
+    cp(rec + o[RTOC_RIC_PHIU], f.phi_u.data(), nu);
+    double* sc = rec + o[RTOC_RIC_SCAL];
+    sc[RTOC_RIC_SCAL_XI] = f.xi;
+    sc[RTOC_RIC_SCAL_CHI] = f.chi;
+    sc[RTOC_RIC_SCAL_RHO] = f.rho;
+    sc[RTOC_RIC_SCAL_ETA] = f.eta;
+    sc[RTOC_RIC_SCAL_IOTA] = f.iota;
+    if (ns > 0) {
+      cp(rec + o[RTOC_RIC_M], f.M_full.data(), static_cast<size_t>(ns) * nx);
+      cp(rec + o[RTOC_RIC_MV], f.m_full.data(), ns);
+      cp(rec + o[RTOC_RIC_MT], f.mt_full.data(), ns);
+      cp(rec + o[RTOC_RIC_MTN], f.mt_next_full.data(), ns);
+    }
+    cp(rec + o[RTOC_RIC_K], p.Kt.data(), static_cast<size_t>(nx) * nu);
+    cp(rec + o[RTOC_RIC_KV], p.k.data(), nu);
+    cp(rec + o[RTOC_RIC_T], p.T.data(), nu);
+    cp(rec + o[RTOC_RIC_W], p.W.data(), nu);
+  }
+  void unpackDirection(const double* r, SplitDirection& d) const {
+    cp(d.dx.data(), r + L_.dir.off[RTOC_DIR_DX], 2 * robot_.dimv);
+    cp(d.du.data(), r + L_.dir.off[RTOC_DIR_DU], robot_.dimu);
+    cp(d.dlmdgmm.data(), r + L_.dir.off[RTOC_DIR_DLMDGMM], 2 * robot_.dimv);
+    cp(d.dxi_full.data(), r + L_.dir.off[RTOC_DIR_DXI], robot_.max_dimf);
+    cp(d.daf_full.data(), r + L_.dir.off[RTOC_DIR_DAF], robot_.dimv + robot_.max_dimf);
+    cp(d.dbetamu_full.data(), r + L_.dir.off[RTOC_DIR_DBETAMU], robot_.dimv + robot_.max_dimf);
+    cp(d.dnu_passive.data(), r + L_.dir.off[RTOC_DIR_DNUP], robot_.dim_passive);
+    d.dts = r[L_.dir.off[RTOC_DIR_DTS] + 0];
+    d.dts_next = r[L_.dir.off[RTOC_DIR_DTS] + 1];
+  }
+
   RobotDims robot_;
   int max_stages_;
   std::vector<LQRPolicy> lqr_policy_;
   rtoc_ctx* ctx_;
+  bool owns_;
   rtoc_layout L_;
+  unsigned long long resident_hash_;
+  std::vector<double> kkt_stage_, ric_stage_, dir_stage_;  // persistent host staging
 };
 
 typedef RiccatiFactorization UnconstrRiccatiFactorization;

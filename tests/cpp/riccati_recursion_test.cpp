@@ -191,5 +191,31 @@ int main(int argc, char** argv) {
   } catch (const std::out_of_range&) {
     threw = true;
   }
+  // forwardRiccatiRecursion honours the containers it is handed (riccati_recursion.cpp:83-131): an edit of
+  // kkt_residual between the two passes changes the result exactly as the recursion says, and undoing it restores it
+  {
+    Direction d1 = d;
+    const double old = kkt_residual[2].Fx(0);
+    kkt_residual[2].Fx(0) = old + 1.0;
+    riccati_recursion.forwardRiccatiRecursion(td, kkt_matrix, kkt_residual, factorization, d);
+    if (std::fabs((d[3].dx(0) - d1[3].dx(0)) - 1.0) > 1e-9) return 4;  // dx_3 = Fx_2 + ...
+    kkt_residual[2].Fx(0) = old;
+    riccati_recursion.forwardRiccatiRecursion(td, kkt_matrix, kkt_residual, factorization, d);
+    for (int i = 0; i <= N; ++i)
+      for (int k = 0; k < nx; ++k)
+        if (d[i].dx(k) != d1[i].dx(k)) return 5;
+  }
+  // value semantics (riccati_recursion.hpp:50-60): a copy runs on its own device context
+  {
+    RiccatiRecursion copy(riccati_recursion);
+    if (copy.context() == riccati_recursion.context()) return 6;
+    Direction d2 = d;
+    copy.forwardRiccatiRecursion(td, kkt_matrix, kkt_residual, factorization, d2);
+    for (int k = 0; k < nx; ++k)
+      if (d2[N].dx(k) != d[N].dx(k)) return 7;
+    RiccatiRecursion assigned;
+    assigned = copy;
+    if (assigned.status() != 0) return 8;
+  }
   return (worst < (scan ? 1e-8 : 1e-9) && threw) ? 0 : 1;
 }

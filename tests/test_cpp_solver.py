@@ -1,0 +1,88 @@
+"""robotoc::OCPSolver / robotoc::DirectMultipleShooting shells (robotoc_amd/host/robotoc_hip_solver.hpp) on the GPU:
+Python records a stage dump of an ANYmal trot problem at the evalKKT boundary (pre-condensation records, the 72
+joint-limit rows, the friction cones, initial state direction and iterate), the C++ program
+tests/cpp/ocp_solver_test.cpp runs OCPSolver::updateSolution on it through the shells, and its outputs are compared
+with the CPU oracle's sequence of the same iteration (ocp_solver.cpp:111-145 downstream of the linearisation)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from helpers import rel_err
+from robotoc_amd import problems as pr
+from robotoc_amd.types import (BUF_CDD, BUF_CON, BUF_CONE, BUF_DX0, BUF_KKT, BUF_SOL, Records, joint_limit_rows)
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MC, CD = 4, 3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scan", [False])
+def test_ocp_solver_update_solution_matches_the_oracle(tmp_path, oracle, scan):
+    from robotoc_amd import capi
+    from test_cpp_host import _build
+    exe = _build("ocp_solver_test")
+    dims, grids, _ = pr.config_anymal_trot()
+    n = len(grids)
+    ctx = capi.Context(dims, n, 1, 0)
+    L = ctx.L
+    ctx.set_grid(grids)
+    rows = joint_limit_rows(dims)
+    ctx.set_constraint_rows(rows)
+    ctx.set_friction_cones(MC, CD)
+    kkt, cdd = pr.make_precondense_batch(L, grids, 1)
+    con = pr.make_constraint_batch(L, grids, 1)
+    cone = pr.make_cone_batch(L, grids, 1, MC)
+    dx0 = pr.make_dx0(L, 1)
+    sol = np.random.default_rng(5).uniform(-1, 1, (1, n, L.sol.stride))
+    for buf, arr in ((BUF_KKT, kkt), (BUF_CDD, cdd), (BUF_CON, con), (BUF_CONE, cone), (BUF_DX0, dx0), (BUF_SOL, sol)):
+        ctx.upload(buf, arr)
+    dump = str(tmp_path / "anymal_trot.rtocdump")
+    ctx.save_stage_dump(dump, (BUF_KKT, BUF_CDD, BUF_CON, BUF_CONE, BUF_DX0, BUF_SOL))
+    ctx.close()
+    out_path = str(tmp_path / "solver_out.bin")
+    run = subprocess.run([exe, dump, out_path], capture_output=True, text=True, timeout=300)
+    print(run.stdout, run.stderr)
+    assert run.returncode == 0, (run.returncode, run.stdout, run.stderr)
+    raw = np.fromfile(out_path)
+    kkt_error, primal, dual, nn = raw[:4]
+    assert int(nn) == n
+    nv, nu, nx, nvf = dims.nv, dims.nu, 2 * dims.nv, dims.nv + dims.nf_max
+    sizes = [("dx", nx), ("du", nu), ("dlmdgmm", nx), ("daf", nvf), ("dbetamu", nvf), ("q", nv + 1), ("v", nv), ("a", nv), ("u", nu),
+             ("lmd", nv), ("gmm", nv), ("s", nx), ("k", nu)]
+    per = sum(sz for _, sz in sizes)
+    body = raw[4:].reshape(n, per)
+    got, o = {}, 0
+    for name, sz in sizes:
+        got[name] = body[:, o:o + sz]
+        o += sz
+    # ---- the oracle's sequence of the same iteration ----
+    tau = 0.995
+    err_ref = oracle.kkt_error(L, grids, kkt, cdd, con, rows, MC, CD, 5)[0]
+    assert abs(kkt_error - err_ref) <= 1e-12 * err_ref
+    kk, cc, nn_ = kkt.copy(), cdd.copy(), con.copy()
+    oracle.pdipm_condense_batch(L, grids, rows, kk, nn_)
+    oracle.cone_condense_batch(L, grids, MC, CD, cone, kk, cc, nn_)
+    assert (oracle.condense_batch(L, grids, kk, cc) == 0).all()
+    R, D, S = Records(L, "ric"), Records(L, "dir"), Records(L, "sol")
+    ric_ref, d_ref = R.zeros(1, n), D.zeros(1, n)
+    oracle.riccati_sweep_batch(L, grids, kk, ric_ref, d_ref, dx0=dx0)
+    oracle.expand_batch(L, grids, cc, d_ref)
+    steps_ref = oracle.pdipm_expand_batch(L, grids, rows, nn_, d_ref, tau)
+    oracle.cone_expand_batch(L, grids, MC, CD, cone, nn_, d_ref, tau, steps_ref)
+    assert np.allclose([primal, dual], steps_ref[0], rtol=1e-6), ((primal, dual), steps_ref)
+    worst = 0.0
+    for f in ("dx", "du", "dlmdgmm", "daf", "dbetamu"):
+        e = rel_err(got[f], D.f(d_ref[0], f))
+        worst = max(worst, e)
+        assert e < 1e-7, (f, e)
+    assert rel_err(got["s"], R.f(ric_ref[0], "s")) < 1e-7
+    assert rel_err(got["k"][:-1], R.f(ric_ref[0], "k")[:-1]) < 1e-7
+    sol_ref = sol.copy()
+    oracle.integrate_solution_batch(L, grids, np.array([[primal, dual]]), d_ref, sol_ref)
+    for f in ("q", "v", "a", "u", "lmd", "gmm"):
+        e = rel_err(got[f], S.f(sol_ref[0], f))
+        worst = max(worst, e)
+        assert e < 1e-8, (f, e)
+    print("OCPSolver::updateSolution (C++ shell) vs oracle sequence: worst rel err %.3e" % worst)
