@@ -92,8 +92,10 @@ def backward_flops(L, grids, batch):
 def condense_bytes(L, grids, batch):
     """Algorithmic HBM bytes of one rtoc_condense launch: per non-terminal grid point the
     ContactDynamicsData inputs and the un-condensed Hessian / gradient blocks are read once, the condensed
-    blocks, the new dynamics rows and the data the expansion needs (MJtJinv, MJtJinv_dIDCdqv, Qafqv,
-    Qafu) are written once; max-size backing blocks are moved whole, like the reference stores them."""
+    blocks, the new dynamics rows and the data the expansion needs (MJtJinv, MJtJinv_dIDCdqv, MJtJinv_IDC, laf,
+    haf) are written once; max-size backing blocks are moved whole, like the reference stores them.  Qafqv and
+    Qafu_full -- scratch the reference keeps for expandContactDynamicsDual -- are not counted since round 2:
+    rtoc_expand rebuilds their products from Qaa, Qff, Qqf (RTOC_OPT_CONDENSE_KEEP_QAF)."""
     from robotoc_amd.types import GRID_IMPACT, GRID_TERMINAL
     d = L.dims
     nv, nu, nx, nf, npas = d.nv, d.nu, 2 * d.nv, d.nf_max, d.np
@@ -104,10 +106,10 @@ def condense_bytes(L, grids, batch):
             continue
         imp = g.type == GRID_IMPACT
         rd = nv * nv + nvf * nx + nvf + nv + nf * nf + nv * nf + 2 * nvf + nx * nx + 2 * nx + nv
-        wr = nx * nx + nv * nx + nx + nv + nvf * nvf + 2 * nvf * nx + 2 * nvf
+        wr = nx * nx + nv * nx + nx + nv + nvf * nvf + nvf * nx + 2 * nvf  # (Qafqv is not stored: RTOC_OPT_CONDENSE_KEEP_QAF = 0)
         if not imp:
             rd += nf * nv + nx * nu + nu * nu + 2 * nx + 2 * nu + 2 * nvf
-            wr += nx * nu + nu * nu + nv * nu + 2 * nx + 2 * nu + nvf * nv + nx * npas + npas * nu + nvf
+            wr += nx * nu + nu * nu + nv * nu + 2 * nx + 2 * nu + nx * npas + npas * nu + nvf  # (nor Qafu_full)
             if g.dims:
                 rd += g.dims * (nv + nx + 2)
                 wr += g.dims * (nx + nu + 2)
@@ -117,8 +119,9 @@ def condense_bytes(L, grids, batch):
 
 def expand_bytes(L, grids, batch, rows, cone_contacts):
     """Algorithmic HBM bytes of one rtoc_expand launch: per non-terminal grid point what
-    expandContactDynamicsPrimal/Dual read (contact_dynamics.cpp:167-202: MJtJinv, MJtJinv_dIDCdqv,
-    MJtJinv_IDC, Qafqv, Qafu, laf, haf, the passive blocks, Phia; dx, du, dgmm+, dxi) and write
+    expandContactDynamicsPrimal/Dual need (contact_dynamics.cpp:167-202: MJtJinv, MJtJinv_dIDCdqv,
+    MJtJinv_IDC, laf, haf, the passive blocks, Phia, and Qaa / Qff / Qqf from which Qafqv dx + Qafu du is rebuilt;
+    dx, du, dgmm+, dxi) and write
     (daf, dbetamu, dnu_passive, laf), active views only, plus the PDIPM rows of
     Constraints::expandSlackAndDual (slack, dual, residual, cmpl in; dslack, ddual out; the cone rows
     also read their Jacobians)."""
@@ -131,10 +134,10 @@ def expand_bytes(L, grids, batch, rows, cone_contacts):
             continue
         imp = g.type == GRID_IMPACT
         nvf = nv + g.dimf
-        rd = 2 * nvf * nx + nvf * nvf + 3 * nvf + nx + nv
+        rd = nvf * nx + nvf * nvf + 3 * nvf + nx + nv + nv + g.dimf * g.dimf + nv * g.dimf  # MJtJinv_dIDCdqv, MJtJinv, vectors, Qaa, Qff, Qqf
         wr = 3 * nvf
         if not imp:
-            rd += 2 * nvf * nu + nu + nx * npas + npas * nu + npas + g.dims * (nv + 1)
+            rd += nu + nx * npas + npas * nu + npas + g.dims * (nv + 1)
             wr += npas
             act = sum(1 for r in rows if g.time_stage >= r.level)  # stage mask, constraints_data.cpp:20-45
             rd += 4 * act

@@ -101,7 +101,7 @@ enum rtoc_option {
   RTOC_OPT_CONTACT_INV_DAMPING = 3, /* RobotModelInfo::contact_inv_damping (robot.hxx:662-664); value = double bits */
   RTOC_OPT_SWEEP_CHUNKS = 4, /* instance chunks of rtoc_riccati_sweep's backward/forward pipeline (1..16, default 1 = plain sequence) */
   RTOC_OPT_CONDENSE_SPLIT = 5, /* 1 (default): rtoc_condense computes MJtJinv in its own high-occupancy kernel; 0: one fused kernel */
-  RTOC_OPT_BACKWARD_SCAN = 6 /* 1: rtoc_riccati_backward (and everything built on it) runs the recursion as a scan
+  RTOC_OPT_BACKWARD_SCAN = 6, /* 1: rtoc_riccati_backward (and everything built on it) runs the recursion as a scan
                               * over the horizon -- interval elements of all grid points, ceil(log2(nstages))
                               * combination levels, then all policies at once -- instead of the serial chain
                               * (riccati_recursion.cpp:32-80); rtoc_riccati_forward likewise as a prefix scan of
@@ -112,6 +112,11 @@ enum rtoc_option {
                               * on MI355X), the serial kernels above.  Needs Quu > 0 of every stage by itself (the
                               * serial recursion only needs Quu + B^T P+ B > 0); a violation sets
                               * RTOC_STAT_QUU_NOT_SPD.  Default 0. */
+  RTOC_OPT_CONDENSE_KEEP_QAF = 7 /* 1: rtoc_condense also stores ContactDynamicsData::Qafqv and Qafu_full in the
+                              * RTOC_BUF_CDD record.  The reference keeps them as scratch for
+                              * expandContactDynamicsDual (contact_dynamics.cpp:190-191); rtoc_expand rebuilds the two
+                              * products from Qaa, Qff, Qqf and the primal expansion instead, so by default (0) the
+                              * 1.6k doubles per grid point are neither written nor read back. */
 };
 
 typedef struct rtoc_ctx rtoc_ctx;

@@ -10,7 +10,7 @@ import subprocess
 import numpy as np
 
 from .types import (BoxRow, BUF_CDD, BUF_CON, BUF_DIR, BUF_DX0, BUF_KKT, BUF_RIC, BUF_STEP, Dims, Grid,
-                    Layout, OPT_BACKWARD_WAVES, OPT_CONDENSE_SPLIT, OPT_MAX_DTS0, OPT_SWEEP_CHUNKS, OPT_WRITEBACK_KKT, OPT_BACKWARD_SCAN,
+                    Layout, OPT_BACKWARD_WAVES, OPT_CONDENSE_SPLIT, OPT_CONDENSE_KEEP_QAF, OPT_MAX_DTS0, OPT_SWEEP_CHUNKS, OPT_WRITEBACK_KKT, OPT_BACKWARD_SCAN,
                     grid_array)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -40,16 +40,26 @@ def lib_path():
 
 
 def build(force=False):
-    """Compile the HIP kernels + C ABI for gfx950 (hipcc cross-compiles without a GPU)."""
+    """Compile the HIP kernels + C ABI for gfx950 (hipcc cross-compiles without a GPU): one translation unit per
+    robot shape (csrc/Makefile: SHAPES), built in parallel."""
     src_dir = os.path.join(_HERE, "csrc")
     so = lib_path()
-    deps = [os.path.join(src_dir, f) for f in os.listdir(src_dir)]
+    deps = [os.path.join(src_dir, f) for f in os.listdir(src_dir) if os.path.isfile(os.path.join(src_dir, f))]
     deps += [os.path.join(_HERE, "..", "include", f) for f in ("rtoc.h", "rtoc_layout.h")]
     stale = force or not os.path.exists(so) or any(
         os.path.getmtime(d) > os.path.getmtime(so) for d in deps)
     if stale:
-        subprocess.check_call(["make", "-C", src_dir, "-B"], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", src_dir, "-j%d" % min(8, os.cpu_count() or 1)] + (["-B"] if force else []),
+                              stdout=subprocess.DEVNULL)
     return so
+
+
+def compiled_shapes():
+    """(nv, nu, ns) of every robot shape in csrc/Makefile's SHAPES list."""
+    import re
+    txt = open(os.path.join(_HERE, "csrc", "Makefile")).read()
+    m = re.search(r"^SHAPES \?= (.*)$", txt, re.M)
+    return [tuple(int(v) for v in tok.split(":")[:3]) for tok in m.group(1).split()]
 
 
 def lib():
@@ -240,6 +250,10 @@ class Context:
     def set_condense_split(self, on):
         """RTOC_OPT_CONDENSE_SPLIT: MJtJinv in its own kernel (default) or one fused condensation kernel."""
         _chk(lib().rtoc_set_option(self._h, OPT_CONDENSE_SPLIT, int(bool(on))))
+
+    def set_condense_keep_qaf(self, on):
+        """RTOC_OPT_CONDENSE_KEEP_QAF: also store Qafqv / Qafu_full in the ContactDynamicsData record."""
+        _chk(lib().rtoc_set_option(self._h, OPT_CONDENSE_KEEP_QAF, int(bool(on))))
 
     def correct_state_equation(self):
         _chk(lib().rtoc_correct_state_equation(self._h))

@@ -70,6 +70,7 @@ struct CondArgs {
   const double* cone;
   double* cone_con;  // constraint records (the box rows' `con` may be null when only cones are set)
   int cone_contacts, cone_dim, cone_row0, cone_stride, cone_dgdf_off;
+  int keep_qaf;  // RTOC_OPT_CONDENSE_KEEP_QAF: also store Qafqv / Qafu_full in the ContactDynamicsData record
 };
 
 struct ExpArgs {
@@ -704,8 +705,10 @@ __global__ __launch_bounds__(64 * RTOC_COND_NW) void condense_kernel(CondArgs a)
   // ================= LDS -> HBM: the ContactDynamicsData the expansion needs, each field once ====
   if constexpr (!SPLIT) copy_s2g_flat16<NT>(cr + CL.off[RTOC_CDD_MJTJINV], Lam, LDV * LDV, lane);
   copy_s2g_flat16<NT>(cr + CL.off[RTOC_CDD_MJD], LD, LDV * NX, lane);
-  copy_s2g_flat16<NT>(cr + CL.off[RTOC_CDD_QAFQV], Qafqv, LDV * NX, lane);
-  if (!impact) copy_s2g_flat16<NT>(cr + CL.off[RTOC_CDD_QAFU], Qafu, LDV * NV, lane);
+  if (a.keep_qaf) {  // scratch of the reference's expandContactDynamicsDual; expand_kernel rebuilds what it needs of them
+    copy_s2g_flat16<NT>(cr + CL.off[RTOC_CDD_QAFQV], Qafqv, LDV * NX, lane);
+    if (!impact) copy_s2g_flat16<NT>(cr + CL.off[RTOC_CDD_QAFU], Qafu, LDV * NV, lane);
+  }
   if (lane < nvf) {
     cr[CL.off[RTOC_CDD_MJIDC] + lane] = Lr[lane];
     cr[CL.off[RTOC_CDD_LAF] + lane] = laf[lane];
@@ -857,15 +860,22 @@ __global__ __launch_bounds__(64) void expand_kernel(ExpArgs a) {
   const double* Lam = cr + CL.off[RTOC_CDD_MJTJINV];
   const double* LD = cr + CL.off[RTOC_CDD_MJD];
   const double* Lr = cr + CL.off[RTOC_CDD_MJIDC];
-  const double* Qafqv = cr + CL.off[RTOC_CDD_QAFQV];
-  const double* Qafu = cr + CL.off[RTOC_CDD_QAFU];
+  // Qafqv / Qafu_full are NOT read back: Qafqv dx + Qafu du is rebuilt from t = MJtJinv[:, u] du - MJtJinv_dIDCdqv dx,
+  // which the primal expansion needs anyway, and the small input blocks Qaa (diagonal), Qff, Qqf
+  //   rows < nv :  Qaa_i t_i                         (contact_dynamics.cpp:68-70,76-78)
+  //   rows >= nv:  Qff t_f - Qqf^T dx_q              (:71-75,79-80)
+  // -- 1.6k doubles per grid point that the condensation then need not store (RTOC_OPT_CONDENSE_KEEP_QAF)
+  const double* Qaa = cr + CL.off[RTOC_CDD_QAA];
+  const double* Qff = cr + CL.off[RTOC_CDD_QFF];
+  const double* Qqf = cr + CL.off[RTOC_CDD_QQF];
+  constexpr int LDF = NF > 0 ? NF : 1;
   double* laf = cr + CL.off[RTOC_CDD_LAF];
   const double* haf = cr + CL.off[RTOC_CDD_HAF];
   const double* Qxup = cr + CL.off[RTOC_CDD_QXUP];
   const double* Quuptr = cr + CL.off[RTOC_CDD_QUUPTR];
   const double* lup = cr + CL.off[RTOC_CDD_LUP];
   const double* Phia = cr + CL.off[RTOC_CDD_PHIA];
-  __shared__ double sdx[NX + 8], sdu[NU + 8], sg[NV + 8], sxi[LDS_ + 8], slaf[LDV + 8];
+  __shared__ double sdx[NX + 8], sdu[NU + 8], sg[NV + 8], sxi[LDS_ + 8], slaf[LDV + 8], st_[LDV + 8];
   for (int i = lane; i < NX; i += 64) sdx[i] = dr[DL.off[RTOC_DIR_DX] + i];
   if (lane < NU) sdu[lane] = impact ? 0.0 : dr[DL.off[RTOC_DIR_DU] + lane];
   for (int i = lane; i < NV; i += 64) sg[i] = dn[DL.off[RTOC_DIR_DLMDGMM] + NV + i];
@@ -875,32 +885,48 @@ __global__ __launch_bounds__(64) void expand_kernel(ExpArgs a) {
   if (!impact && g.num_grids_in_phase > 0)
     dtsv = (dr[DL.off[RTOC_DIR_DTS] + 1] - dr[DL.off[RTOC_DIR_DTS] + 0]) / (double)g.num_grids_in_phase;
   const bool use_dts = (dtsv < -2.220446049250313e-16 || dtsv > 2.220446049250313e-16);
+  // rows i of the nvf-row products over the lanes; with nvf <= 32 the two half-waves split the columns
+  constexpr int H = (LDV <= 32) ? 2 : 1;
+  const int hh = (H == 2) ? (lane >> 5) : 0, i0 = (H == 2) ? (lane & 31) : lane;
   // primal (:167-174, impact :83-88) and the laf accumulation of the dual (:190-198, impact :91-95)
-  for (int i = lane; i < nvf; i += 64) {
-    double acc = 0.0, accl = laf[i];
-    for (int j = 0; j < NX; ++j) {
-      const double x = sdx[j];
-      acc -= LD[i + (size_t)j * LDV] * x;
-      accl += Qafqv[i + (size_t)j * LDV] * x;
+  for (int i = i0; i < (H == 2 ? 32 : ((nvf + 63) & ~63)); i += 64 / H) {
+    const bool row = i < nvf;
+    const int ir = row ? i : 0;
+    double acc = 0.0;
+    for (int j = hh; j < NX; j += H) acc -= LD[ir + (size_t)j * LDV] * sdx[j];
+    if (!impact)
+      for (int j = hh; j < NU; j += H) acc += Lam[ir + (size_t)(NP + j) * LDV] * sdu[j];
+    if (H == 2) acc += __shfl_xor(acc, 32, 64);
+    if (row && hh == 0) {
+      st_[i] = acc;  // t_i
+      double daf = acc - Lr[i];
+      if (i >= NV) daf = -daf;
+      dr[DL.off[RTOC_DIR_DAF] + i] = daf;
     }
-    if (!impact) {
-      for (int j = 0; j < NU; ++j) {
-        const double u = sdu[j];
-        acc += Lam[i + (size_t)(NP + j) * LDV] * u;
-        accl += Qafu[i + (size_t)(NP + j) * LDV] * u;
+  }
+  __syncthreads();
+  for (int i = i0; i < (H == 2 ? 32 : ((nvf + 63) & ~63)); i += 64 / H) {
+    const bool row = i < nvf;
+    const int ir = row ? i : 0;
+    double accl = 0.0;
+    if (ir < NV) {
+      if (hh == 0) {
+        accl = laf[ir] + Qaa[ir] * st_[ir] + (impact ? 1.0 : dt) * sg[ir];
+        if (NS > 0 && ns > 0)
+          for (int l = 0; l < ns; ++l) accl += Phia[l + (size_t)ir * LDS_] * sxi[l];
       }
+    } else {
+      const int f = ir - NV;
+      for (int k = hh; k < nf; k += H) accl += Qff[f + (size_t)k * LDF] * st_[NV + k];
+      for (int j = hh; j < NV; j += H) accl -= Qqf[j + (size_t)f * NV] * sdx[j];
+      if (hh == 0) accl += laf[ir];
     }
-    acc -= Lr[i];
-    if (i >= NV) acc = -acc;
-    dr[DL.off[RTOC_DIR_DAF] + i] = acc;
-    if (i < NV) {
-      accl += (impact ? 1.0 : dt) * sg[i];
-      if (NS > 0 && ns > 0)
-        for (int l = 0; l < ns; ++l) accl += Phia[l + (size_t)i * LDS_] * sxi[l];
+    if (H == 2) accl += __shfl_xor(accl, 32, 64);
+    if (use_dts) accl += dtsv * haf[ir];
+    if (row && hh == 0) {
+      laf[i] = accl;  // the reference updates data.laf() in place as well
+      slaf[i] = accl;
     }
-    if (use_dts) accl += dtsv * haf[i];
-    laf[i] = accl;  // the reference updates data.laf() in place as well
-    slaf[i] = accl;
   }
   // dnu_passive (:178-188)
   if (!impact && NP > 0 && lane < NP) {
@@ -943,10 +969,13 @@ __global__ __launch_bounds__(64) void expand_kernel(ExpArgs a) {
     }
   }
   // dbetamu = -MJtJinv * laf (:201, impact :95)
-  for (int i = lane; i < nvf; i += 64) {
+  for (int i = i0; i < (H == 2 ? 32 : ((nvf + 63) & ~63)); i += 64 / H) {
+    const bool row = i < nvf;
+    const int ir = row ? i : 0;
     double acc = 0.0;
-    for (int j = 0; j < nvf; ++j) acc -= Lam[i + (size_t)j * LDV] * slaf[j];
-    dr[DL.off[RTOC_DIR_DBETAMU] + i] = acc;
+    for (int j = hh; j < nvf; j += H) acc -= Lam[ir + (size_t)j * LDV] * slaf[j];
+    if (H == 2) acc += __shfl_xor(acc, 32, 64);
+    if (row && hh == 0) dr[DL.off[RTOC_DIR_DBETAMU] + i] = acc;
   }
 }
 
@@ -960,7 +989,7 @@ struct UpdArgs {
   rtoc_record_layout nl;
 };
 
-__global__ __launch_bounds__(64) void pdipm_update_kernel(UpdArgs a) {
+static __global__ __launch_bounds__(64) void pdipm_update_kernel(UpdArgs a) {
   const int item = blockIdx.x;
   const int nst1 = a.nstages - 1;
   const int b = item / nst1, st = item % nst1;
@@ -978,7 +1007,7 @@ __global__ __launch_bounds__(64) void pdipm_update_kernel(UpdArgs a) {
   }
 }
 
-__global__ void fill_steps_kernel(double* steps, int n) {
+static __global__ void fill_steps_kernel(double* steps, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) steps[i] = 1.0;
 }

@@ -44,7 +44,7 @@ template <int NV, int NF>
 struct ConeScratch {
   static constexpr int MAXC = NF / 3 > 0 ? NF / 3 : 1, MAXW = NF / 6 > 0 ? NF / 6 : 1;
   static constexpr int FRICTION = MAXC * (5 * NV + 15 + 5 + 5);
-  static constexpr int WRENCH = MAXW * (RTOC_WRENCH_ROWS * 6 + 2 * RTOC_WRENCH_ROWS);
+  static constexpr int WRENCH = NF >= 6 ? MAXW * (RTOC_WRENCH_ROWS * 6 + 2 * RTOC_WRENCH_ROWS) : 0;  // a surface contact has 6 force components
   static constexpr int DOUBLES = FRICTION > WRENCH ? FRICTION : WRENCH;
 };
 
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(64) void cone_expand_kernel(ConeArgs a) {
 }
 
 // updateSlack / updateDual of the cone rows (constraints_impl.hxx:167-182)
-__global__ __launch_bounds__(64) void cone_update_kernel(ConeArgs a) {
+static __global__ __launch_bounds__(64) void cone_update_kernel(ConeArgs a) {
   const int lane = threadIdx.x;
   const int item = blockIdx.x;
   const int nst1 = a.nstages - 1;

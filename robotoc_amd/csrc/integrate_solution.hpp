@@ -22,7 +22,7 @@ struct IntArgs {
   rtoc_record_layout sl, dl;
 };
 
-__global__ __launch_bounds__(64) void integrate_solution_kernel(IntArgs a) {
+static __global__ __launch_bounds__(64) void integrate_solution_kernel(IntArgs a) {
   const int lane = threadIdx.x;
   const int item = blockIdx.x;
   const int b = item / a.nstages, st = item % a.nstages;

@@ -1,0 +1,131 @@
+// kernel_set.hpp -- the kernels of ONE robot shape <NV, NU, NS> (NF = NS: the reference sizes the switching-
+// constraint blocks with max_dimf too, split_kkt_matrix.cpp:7-34) gathered behind function pointers, so that the host
+// runtime (rtoc_capi.hip) dispatches by dimensions at run time.  Every shape is compiled in its own translation unit
+// (shape_inst.hip, once per entry of the SHAPES list in the Makefile): adding a robot = one entry + make.
+#pragma once
+#include <cstring>
+
+#include "../../include/rtoc.h"
+#include "condense.hpp"
+#include "state_equation.hpp"
+#include "unconstr_dynamics.hpp"
+#include "friction_cone.hpp"
+#include "kkt_error.hpp"
+#include "integrate_solution.hpp"
+#include "riccati_backward.hpp"
+#include "riccati_backward_rs.hpp"
+#include "riccati_scan.hpp"
+#include "riccati_forward.hpp"
+
+namespace rtoc {
+
+typedef void (*bwd_fn)(BwdArgs);
+typedef void (*fwd_fn)(FwdArgs);
+typedef void (*fill_fn)(FillArgs);
+typedef void (*ud_fn)(UdArgs);
+typedef void (*cone_fn)(ConeArgs);
+typedef void (*cond_fn)(CondArgs);
+typedef void (*expd_fn)(ExpArgs);
+typedef void (*scan_fn)(ScanArgs);
+typedef void (*fscan_fn)(FwdScanArgs);
+
+struct KernelSet {
+  int nv, nu, ns;
+  int nvariants;
+  bwd_fn bwd[4];
+  int bwd_waves[4];   // waves per workgroup
+  int bwd_lds[4];
+  int bwd_inst[4];    // OCP instances per workgroup
+  rtoc_record_layout kl, rl, dl, cl;  // record layouts the kernels were compiled for
+  fwd_fn fwd;
+  int fwd_threads;
+  fill_fn fill;
+  ud_fn ucond, uexp;  // UnconstrDynamics condense / expand
+  cone_fn ccond, cexp;  // friction-cone rows
+  cone_fn wcond, wexp;  // contact-wrench-cone rows
+  cond_fn cond;
+  cond_fn cond_split, mjt;  // split condensation: MJtJinv kernel + the rest
+  int mjt_lds;
+  int cond_threads, cond_lds;
+  expd_fn expd;
+  int expd_threads;
+  // horizon scan of the backward recursion (riccati_scan.hpp)
+  scan_fn scan_elt, scan_comb;
+  int scan_elt_lds, scan_comb_lds, scan_comb_threads;
+  int scan_elt_stride, scan_ps_stride, scan_ps_soff;  // doubles per element / value record, offset of s
+  int scan_policy_variant;                            // tile-split backward kernel used in its one-stage mode
+  fscan_fn fscan_elt, fscan_comb, fscan_fin;          // forward recursion as a prefix scan
+  int fscan_lds;
+};
+
+template <int NV, int NU, int NS, int NW0, int NW1>
+inline KernelSet make_set() {
+  KernelSet k;
+  memset(&k, 0, sizeof(k));
+  k.nv = NV;
+  k.nu = NU;
+  k.ns = NS;
+  k.nvariants = 2;
+  for (int v = 0; v < 4; ++v) k.bwd_inst[v] = 1;
+  k.kl = StaticLayout<NV, NU, NS>::make().kkt;
+  k.rl = StaticLayout<NV, NU, NS>::make().ric;
+  k.bwd[0] = riccati_backward_kernel<NV, NU, NS, NW0>;
+  k.bwd_waves[0] = NW0;
+  k.bwd_lds[0] = BwdCfg<NV, NU, NS, NW0>::LDS_BYTES;
+  k.bwd[1] = riccati_backward_kernel<NV, NU, NS, NW1>;
+  k.bwd_waves[1] = NW1;
+  k.bwd_lds[1] = BwdCfg<NV, NU, NS, NW1>::LDS_BYTES;
+  if constexpr (2 * NV + 1 <= 64) {  // role-split kernel: matrix wave + vector wave per instance
+    k.bwd[2] = riccati_backward_rs_kernel<NV, NU, NS>;
+    k.bwd_waves[2] = 2;
+    k.bwd_lds[2] = BwdCfg<NV, NU, NS, 2>::LDS_BYTES;
+    k.nvariants = 3;
+    // four instances per workgroup, both waves of an instance on one SIMD
+    if (4 * BwdCfg<NV, NU, NS, 2>::LDS_BYTES + 64 <= 160 * 1024) {
+      k.bwd[3] = riccati_backward_rs4_kernel<NV, NU, NS>;
+      k.bwd_waves[3] = 8;
+      k.bwd_lds[3] = 4 * BwdCfg<NV, NU, NS, 2>::LDS_BYTES + 64;
+      k.bwd_inst[3] = 4;
+      k.nvariants = 4;
+    }
+  }
+  constexpr int NWF = (2 * NV + NU + 63) / 64;
+  k.fwd = riccati_forward_kernel<NV, NU, NS, NWF>;
+  k.fwd_threads = 64 * NWF;
+  k.dl = StaticLayout<NV, NU, NS>::make().dir;
+  k.cl = StaticLayout<NV, NU, NS>::make().cdd;
+  k.fill = unconstr_fill_kernel<NV>;
+  k.ucond = unconstr_condense_kernel<NV>;
+  k.uexp = unconstr_expand_kernel<NV>;
+  k.ccond = cone_condense_kernel<NV, NS>;
+  k.cexp = cone_expand_kernel<NV, NS>;
+  k.wcond = wrench_condense_kernel<NV, NS>;
+  k.wexp = wrench_expand_kernel<NV, NS>;
+  constexpr int NF = NS;  // nf_max == ns_max for all supported robots
+  k.cond = condense_kernel<NV, NU, NF, NS>;
+  k.cond_split = condense_kernel<NV, NU, NF, NS, true>;
+  k.mjt = mjtjinv_kernel<NV, NU, NF, NS>;
+  k.mjt_lds = MjCfg<NV, NF>::LDS_BYTES;
+  k.cond_threads = CondCfg<NV, NU, NF, NS>::NT;
+  k.cond_lds = CondCfg<NV, NU, NF, NS>::LDS_BYTES;
+  k.expd = expand_kernel<NV, NU, NF, NS>;
+  k.expd_threads = 64;
+  k.scan_elt = scan_element_kernel<NV, NU, NS>;
+  k.scan_comb = scan_combine_kernel<NV>;
+  k.scan_elt_lds = scan::ElementCfg<NV, NU, NS>::LDS_BYTES;
+  k.scan_comb_threads = scan_comb_nt(NV);
+  k.scan_comb_lds = scan::CombineCfg<NV, scan_comb_nt(NV)>::LDS_BYTES;
+  k.scan_elt_stride = scan::EltLayout<NV>::STRIDE;
+  k.scan_ps_stride = scan::EltLayout<NV>::PS_STRIDE;
+  k.scan_ps_soff = scan::EltLayout<NV>::PS_S;
+  k.scan_policy_variant = 1;  // NW1 waves share the tiles of the one stage
+  k.fscan_elt = fwd_scan_element_kernel<NV, NU, NS>;
+  k.fscan_comb = fwd_scan_combine_kernel<NV, NU, NS>;
+  k.fscan_fin = fwd_scan_finish_kernel<NV, NU, NS>;
+  k.fscan_lds = scan::FwdCfg<NV, NU>::LDS_BYTES;
+  static_assert(scan::CombineCfg<NV, scan_comb_nt(NV)>::LDS_BYTES <= 160 * 1024, "combination scratch must fit the LDS of a CU");
+  return k;
+}
+
+
+}  // namespace rtoc

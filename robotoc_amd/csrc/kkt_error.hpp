@@ -28,7 +28,7 @@ struct KktErrArgs {
   rtoc_record_layout kl, cl, nl;
 };
 
-__global__ __launch_bounds__(64) void kkt_error_kernel(KktErrArgs a) {
+static __global__ __launch_bounds__(64) void kkt_error_kernel(KktErrArgs a) {
   const int lane = threadIdx.x;
   const int b = blockIdx.x;
   if (b >= a.batch) return;

@@ -90,7 +90,11 @@ struct BwdCfg {
   // ---- LDS carve (doubles) ----
   static constexpr int OFF_P = 0;
   static constexpr int OFF_A = OFF_P + NX * LDP;
-  static constexpr int OFF_PB = OFF_A + NX * LDP;   // PB = P+[:,v] Bv; dead after PAa -> reused for K^T
+  // the switching-constraint scratch (S_* below) is aliased onto A after the F product: for small robots with contacts
+  // (iiwa14 + 1 point contact: nx = 14, ns = 3) it is the larger of the two
+  static constexpr int SC_DOUBLES = NS > 0 ? (pad8(NSP * NX) + 3 * pad8(NSP * NU) + pad8(NU * NU) + pad8(NSP * NSP) + 6 * pad8(NSP)) : 0;
+  static constexpr int A_DOUBLES = (NX * LDP > SC_DOUBLES) ? NX * LDP : ((SC_DOUBLES + 1) & ~1);
+  static constexpr int OFF_PB = OFF_A + A_DOUBLES;   // PB = P+[:,v] Bv; dead after PAa -> reused for K^T
   static constexpr int OFF_KT = OFF_PB;
   static constexpr int OFF_H = OFF_PB + NU * LDP;   // H = Qxu'; dead after the K solve -> reused for GK
   static constexpr int OFF_GK = OFF_H;

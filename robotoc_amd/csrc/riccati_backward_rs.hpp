@@ -212,6 +212,13 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a, const
     if constexpr (!MW) {
       if (sto && vt < 8) smem[C::V_KSC + vt] = kr[KL.off[RTOC_KKT_SCAL] + vt];
       lds_signal(sFlag + 2, 3 * (N - st) - 1, lane);
+#ifndef RTOC_RS_LATE_PREFETCH
+      // next stage's record: HBM -> registers as soon as this stage's copy has left them for LDS, a whole stage ahead
+      // of its use (issued at the end of the stage -- "after the register-hungry solve" of earlier versions -- its HBM
+      // latency showed up as a ~2k-cycle wait of the matrix wave for Bv / Quu at the next stage top: 2.77 -> 2.67 ms;
+      // costs two more spilled VGPRs, profiles/r02_kernel_resource_usage.txt)
+      if (st > 0) issue_loads(st - 1);
+#endif
     }
     if constexpr (MW) lds_wait(sFlag + 2, 3 * (N - st) - 2);
 
@@ -897,7 +904,9 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a, const
           smem[C::V_SNEW + vt] -= acc0 + acc1;
         }
       }
+#ifdef RTOC_RS_LATE_PREFETCH
       if (st > 0) issue_loads(st - 1);
+#endif
       RTOC_PROFV(27);
       // vector wave: LQR policy of this stage -> HBM (K row-major == Kt column-major)
       if (!impact) {

@@ -1,0 +1,17 @@
+// shape_inst.hip -- one translation unit per robot shape: compiled once per entry of the Makefile's SHAPES list with
+//   -DRTOC_SHAPE_NV=.. -DRTOC_SHAPE_NU=.. -DRTOC_SHAPE_NS=.. -DRTOC_SHAPE_NW0=.. -DRTOC_SHAPE_NW1=..
+// (NW0 / NW1: wavefronts per instance of the two tile-split backward variants).  Instantiates every kernel of the
+// shape and hands their entry points to the host runtime (rtoc_capi.hip: kernel_table).
+#include <hip/hip_runtime.h>
+
+#include "kernel_set.hpp"
+
+#define RTOC_CAT5_(a, b, c, d, e) a##b##c##d##e
+#define RTOC_CAT5(a, b, c, d, e) RTOC_CAT5_(a, b, c, d, e)
+#define RTOC_SHAPE_FN RTOC_CAT5(rtoc_shape_, RTOC_SHAPE_NV, RTOC_CAT5(_, RTOC_SHAPE_NU, _, RTOC_SHAPE_NS, ), , )
+
+namespace rtoc {
+KernelSet RTOC_SHAPE_FN() {
+  return make_set<RTOC_SHAPE_NV, RTOC_SHAPE_NU, RTOC_SHAPE_NS, RTOC_SHAPE_NW0, RTOC_SHAPE_NW1>();
+}
+}  // namespace rtoc

@@ -35,6 +35,7 @@ class Robot {
       throw std::invalid_argument("[Robot] inconsistent dimensions");
     const rtoc_dims d = dims_.c();
     check(rtoc_create(&d, 4, 1, device, &ctx_), "rtoc_create");  // [filler, THE grid point, filler, terminal]
+    check(rtoc_set_option(ctx_, RTOC_OPT_CONDENSE_KEEP_QAF, 1), "rtoc_set_option");  // ContactDynamicsData exposes Qafqv / Qafu_full
     check(rtoc_get_layout(ctx_, &L_), "rtoc_get_layout");
   }
   ~Robot() {

@@ -317,6 +317,7 @@ def test_sqp_iteration_hot_path(oracle, cfg):
         ctx.upload(BUF_CDD, cdd)
         ctx.upload(BUF_CON, con)
         ctx.upload(BUF_DX0, dx0)
+        ctx.set_condense_keep_qaf(True)  # Qafqv is compared below
         ctx.condense()
         kkt_gpu = ctx.download_records(BUF_KKT, "kkt")
         ctx.riccati_backward()

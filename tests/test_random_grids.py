@@ -148,6 +148,10 @@ def test_random_event_structures_condense_expand(oracle, seed):
         dx0 = pr.make_dx0(L, batch, first_instance=seed)
         for buf, arr in ((BUF_KKT, kkt), (BUF_CDD, cdd), (BUF_DX0, dx0)):
             ctx.upload(buf, arr)
+        # odd seeds: RTOC_OPT_CONDENSE_KEEP_QAF (Qafqv / Qafu_full stored and compared); even seeds: the default, where
+        # the condensation does not store them and the expansion must still come out right
+        keep = bool(seed & 1)
+        ctx.set_condense_keep_qaf(keep)
         ctx.condense()
         kkt_gpu = ctx.download_records(BUF_KKT, "kkt")
         cdd_gpu = ctx.download_records(BUF_CDD, "cdd")
@@ -161,7 +165,7 @@ def test_random_event_structures_condense_expand(oracle, seed):
         from helpers import rel_err
         for f in ("Qxx", "Qxu", "Quu", "lx", "lu", "Fxx", "Fvu", "Fx", "Phix", "Phiu", "Pres"):
             assert rel_err(K.f(kkt_gpu, f), K.f(kk, f)) < 1e-9, (seed, f)
-        for f in ("MJtJinv", "MJtJinv_dIDCdqv", "MJtJinv_IDC", "Qafqv", "Qafu_full", "laf"):
+        for f in ("MJtJinv", "MJtJinv_dIDCdqv", "MJtJinv_IDC", "laf") + (("Qafqv", "Qafu_full") if keep else ()):
             assert rel_err(C.f(cdd_gpu, f), C.f(cc, f)) < 1e-9, (seed, f)
         ric_ref, d_ref = Records(L, "ric").zeros(batch, len(grids)), D.zeros(batch, len(grids))
         oracle.riccati_sweep_batch(L, grids, kk, ric_ref, d_ref, dx0=dx0)
