@@ -148,7 +148,11 @@ struct BwdCfg {
   static constexpr int V_SC = V_SCN + 8;        // new scalars + policy
   static constexpr int V_KSC = V_SC + 8;        // kkt scalars [Qtt,Qtt_prev,h]
   static constexpr int V_FLAG = V_KSC + 8;      // status accumulation (as double bits)
-  static constexpr int LDS_DOUBLES = V_FLAG + 8;
+  // role-split kernel: Bv^T s+_v, Bv^T Psi+_v, Bv^T Phi+_v -- free-rider columns of the G product (matrix wave)
+  static constexpr int V_BTS = V_FLAG + 8;
+  static constexpr int V_BTPSI = V_BTS + VU;
+  static constexpr int V_BTPHI = V_BTPSI + VU;
+  static constexpr int LDS_DOUBLES = V_BTPHI + VU;
   static constexpr int LDS_BYTES = LDS_DOUBLES * 8;
   static_assert(NS == 0 || S_END <= OFF_PB, "switching-constraint scratch must fit in A");
   static_assert(NX + 1 <= NT, "need one thread per state entry plus one");

@@ -254,45 +254,14 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a, const
             }
           }
     }
-    // ================= interval 1: [matrix] PB, G      || [vector] z, lu' =================
+    // ================= interval 1: [matrix] PB, G (+ Bv^T s+_v as a free-rider column)  || [vector] -- ========
+    // lu' = lu - Bv^T z_v with z = s+ - P+ Fx: the P+ Fx part arrives from the matrix wave (it rides as an extra
+    // column of the P+ A product), and so does Bv^T s+_v now -- as column NU of the G product, whose 16-tile has
+    // 16 - NU spare columns (psi_u = hu + Bv^T y_v and phi_u = Bv^T Phi+_v of the STO stages, brrf.cpp:48-66, ride as
+    // columns NU+1, NU+2).  The vector wave used to sum them here, 3k contended cycles in FRONT of the Cholesky,
+    // which is the critical path of the stage from the moment G is ready.
+    static_assert(NU + 3 <= 16, "free-rider columns of the G product");
     if constexpr (!MW) {
-     if (!impact && vt < NU) {
-      // lu' = lu - Bv^T z_v with z = s+ - P+ Fx: the P+ Fx part arrives from the matrix wave (it
-      // rides as an extra column of the P+ A product), so only Bv^T s+_v is summed here.  Same for
-      // the STO vectors: psi_u = hu + Bv^T y_v, y = P+ fx + Psi+ (fx rides as a second column), and
-      // phi_u = Bv^T Phi+_v (brrf.cpp:48-66)
-      double acc0 = 0.0, acc1 = 0.0, ap0 = 0.0, ap1 = 0.0, ah0 = 0.0, ah1 = 0.0;
-      if (!sto) {  // loops unswitched by hand: a uniform test inside would sit in every iteration
-#pragma unroll
-        for (int k = 0; k < NV; ++k) {
-          const double bv = sBv[k + vt * NV];
-          if (k & 1)
-            acc1 += bv * smem[C::V_SN + NV + k];
-          else
-            acc0 += bv * smem[C::V_SN + NV + k];
-        }
-      } else {
-#pragma unroll
-        for (int k = 0; k < NV; ++k) {
-          const double bv = sBv[k + vt * NV];
-          const double ph = sto_next ? smem[C::V_PHIN + NV + k] : 0.0;
-          if (k & 1) {
-            acc1 += bv * smem[C::V_SN + NV + k];
-            ap1 += bv * smem[C::V_PSIN + NV + k];
-            ah1 += bv * ph;
-          } else {
-            acc0 += bv * smem[C::V_SN + NV + k];
-            ap0 += bv * smem[C::V_PSIN + NV + k];
-            ah0 += bv * ph;
-          }
-        }
-      }
-      smem[C::V_LU + vt] -= acc0 + acc1;
-      if (sto) {
-        smem[C::V_PSIU + vt] = (ap0 + ap1) + smem[C::V_HU + vt];
-        smem[C::V_PHIU + vt] = sto_next ? (ah0 + ah1) : 0.0;
-      }
-     }
     } else {
      if (!impact) {
       // ---- PB = P+[:,v] Bv ----
@@ -341,6 +310,10 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a, const
           for (int t1 = 0; t1 < TNU; ++t1) acc[t0][t1] = zero4();
         const double* pa_ = sBv + q + li * NV;
         const double* pb_ = sPB + NV + q + li * LDP;
+        // rider columns (TNU == 1): li == NU: s+_v, NU+1: Psi+_v (sto), NU+2: Phi+_v (sto && sto_next)
+        const int rid = li - NU;
+        const double* pbr_ = (rid < 0) ? pb_ : (smem + (rid == 0 ? C::V_SN : (rid == 1 ? C::V_PSIN : C::V_PHIN)) + NV + q);
+        const bool okr = (rid < 0) || rid == 0 || (sto && (rid == 1 || (rid == 2 && sto_next)));
 #pragma unroll
         for (int ks = 0; ks < (NV + 3) / 4; ++ks) {
           const bool kok = (ks * 4 + 3 < NV) || (ks * 4 + q < NV);
@@ -349,9 +322,9 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a, const
           for (int t = 0; t < TNU; ++t) {
             const bool ok = kok && (t * 16 + li < NU);
             const double va = pa_[ks * 4 + t * 16 * NV];
-            const double vb = pb_[ks * 4 + t * 16 * LDP];
+            const double vb = pbr_[ks * 4 + t * 16 * LDP];  // PB column, or s+_v / Psi+_v / Phi+_v on the rider lanes
             av[t] = ok ? va : 0.0;
-            bv[t] = ok ? vb : 0.0;
+            bv[t] = (kok && okr) ? vb : 0.0;
           }
 #pragma unroll
           for (int t0 = 0; t0 < TNU; ++t0)
@@ -366,6 +339,8 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a, const
             for (int r = 0; r < 4; ++r) {
               const int u0 = t0 * 16 + drow(q, r), u1 = t1 * 16 + li;
               if (u0 < NU && u1 < NU) sG[u0 + u1 * NU] += acc[t0][t1][r];
+              if (u0 < NU && u1 >= NU && u1 < NU + 3)
+                smem[(u1 == NU ? C::V_BTS : (u1 == NU + 1 ? C::V_BTPSI : C::V_BTPHI)) + u0] = acc[t0][t1][r];
             }
       }
      } else {
@@ -374,12 +349,14 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a, const
       lds_signal(sFlag, 3 * (N - st) - 2, lane);  // G ready
     }
     RTOC_PROFV(20);
+#ifdef RTOC_RS_EARLY_PCOPY
     if constexpr (!MW) {
       // P of the previous stage (still intact in sP until the end of this stage) -> HBM, in the
       // shadow of the matrix wave's PB / G products
       if (st < N - 1)
         copy_s2g_mat<64, NX, NX, LDP>(a.ric + rinst + (size_t)(st + 1) * RL.stride + RL.off[RTOC_RIC_P], sP, vt);
     }
+#endif
     if constexpr (!MW) lds_wait(sFlag, 3 * (N - st) - 2);
     RTOC_PROFV(21);
 
@@ -497,6 +474,11 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a, const
       };
       using std::integral_constant;
       lds_wait(sFlag + 2, 3 * (N - st) - 1);  // A, Qxu, Fx in LDS
+#ifdef RTOC_RS_YIELD_CHOL
+      // experiment: leave the SIMD's issue port to the vector wave's Cholesky (a dependent VALU chain that a back-to-
+      // back f64 MFMA stream stretches 2-3x) before starting the P+ A product
+      lds_wait(sFlag + 3, N - st);
+#endif
       run_pass(integral_constant<int, TMH>{}, integral_constant<int, TMA>{});
       if (!impact) {
 #pragma unroll
@@ -523,6 +505,9 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a, const
         // dead Bv buffer): the triangular solves of the policy become two MFMA products below
         if (wave_llt_inv<NU, NU>(sG, sL, smem + C::V_LINV, sBv, NU, lane)) stat |= RTOC_STAT_QUU_NOT_SPD;
       }
+#ifdef RTOC_RS_YIELD_CHOL
+      lds_signal(sFlag + 3, N - st, lane);  // factorisation done: the matrix wave may start its dense MFMA stream
+#endif
       RTOC_PROFV(22);
     }
     RTOC_PROFV(23);
@@ -530,8 +515,11 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a, const
     RTOC_PROFV(24);
     if constexpr (!MW) {
       if (!impact && vt < NU) {
-        smem[C::V_LU + vt] += smem[C::V_TV + vt];                 // + PB^T Fx
-        if (sto) smem[C::V_PSIU + vt] += smem[C::V_WV + vt];     // + PB^T fx
+        smem[C::V_LU + vt] += smem[C::V_TV + vt] - smem[C::V_BTS + vt];  // lu' = lu - Bv^T s+_v + PB^T Fx
+        if (sto) {
+          smem[C::V_PSIU + vt] = (smem[C::V_BTPSI + vt] + smem[C::V_HU + vt]) + smem[C::V_WV + vt];  // + PB^T fx
+          smem[C::V_PHIU + vt] = sto_next ? smem[C::V_BTPHI + vt] : 0.0;
+        }
       }
       // hand-off vector -> matrix: the inverse factor Y and lu' (psi_u, phi_u) are in LDS
       lds_signal(sFlag + 2, 3 * (N - st), lane);
@@ -714,6 +702,14 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a, const
           }
         }
       }
+#ifndef RTOC_RS_EARLY_PCOPY
+      // P of the previous stage (intact in sP until the matrix wave writes the new one after B4) -> HBM.  Here, behind
+      // the Cholesky / inverse factor and w: between the G flag and the Y hand-off the vector wave IS the critical
+      // path of the stage (phase stamps: the matrix wave finished the F product ~3k cycles before Y arrived), and this
+      // copy used to sit in front of the factorisation.
+      if (st < N - 1)
+        copy_s2g_mat<64, NX, NX, LDP>(a.ric + rinst + (size_t)(st + 1) * RL.stride + RL.off[RTOC_RIC_P], sP, vt);
+#endif
     }
     RTOC_PROF(13);
     RTOC_PROFV(14);
@@ -995,7 +991,7 @@ __global__ __launch_bounds__(128, 2) void riccati_backward_rs_kernel(BwdArgs a) 
   if (a.first + (int)blockIdx.x >= a.batch) return;
   extern __shared__ __attribute__((aligned(16))) double smem_all[];
   using C = BwdCfg<NV, NU, NS, 2>;
-  if (threadIdx.x < 3) reinterpret_cast<int*>(smem_all + C::V_FLAG)[threadIdx.x] = 0;
+  if (threadIdx.x < 4) reinterpret_cast<int*>(smem_all + C::V_FLAG)[threadIdx.x] = 0;
   __syncthreads();
   if (threadIdx.x < 64)
     riccati_backward_rs_body<NV, NU, NS, true, 1>(a, 0);
@@ -1023,6 +1019,7 @@ __global__ __launch_bounds__(512) void riccati_backward_rs4_kernel(BwdArgs a) {
     f[0] = 0;
     f[1] = 0;
     f[2] = 0;
+    f[3] = 0;
   }
   __syncthreads();
   unsigned hw;
