@@ -112,11 +112,21 @@ enum rtoc_option {
                               * on MI355X), the serial kernels above.  Needs Quu > 0 of every stage by itself (the
                               * serial recursion only needs Quu + B^T P+ B > 0); a violation sets
                               * RTOC_STAT_QUU_NOT_SPD.  Default 0. */
-  RTOC_OPT_CONDENSE_KEEP_QAF = 7 /* 1: rtoc_condense also stores ContactDynamicsData::Qafqv and Qafu_full in the
+  RTOC_OPT_CONDENSE_KEEP_QAF = 7, /* 1: rtoc_condense also stores ContactDynamicsData::Qafqv and Qafu_full in the
                               * RTOC_BUF_CDD record.  The reference keeps them as scratch for
                               * expandContactDynamicsDual (contact_dynamics.cpp:190-191); rtoc_expand rebuilds the two
                               * products from Qaa, Qff, Qqf and the primal expansion instead, so by default (0) the
                               * 1.6k doubles per grid point are neither written nor read back. */
+  RTOC_OPT_FXX_STRUCTURE = 8 /* How rtoc_riccati_backward treats the top half of Fxx, which linearizeStateEquation /
+                              * correctLinearizeStateEquation leave as [a I | c I] plus two dense 6 x 6 floating-base
+                              * corners (src/dynamics/state_equation.cpp:52-55,80-82).  0 (default): automatic -- the
+                              * records are checked on the device once after they change through this API
+                              * (rtoc_upload / rtoc_bind / rtoc_load_stage_dump; rtoc_check_fxx_structure forces it) and
+                              * the structure-exploiting kernel is used iff EVERY record has the shape, the dense one
+                              * otherwise (same results to round-off).  1: always the dense kernel.  2: the caller
+                              * asserts the structure (no check; wrong results if it does not hold).  A host that
+                              * rewrites a bound buffer in place with a different structure must call
+                              * rtoc_check_fxx_structure again.  Only shapes with a structured kernel (nv = 18) care. */
 };
 
 typedef struct rtoc_ctx rtoc_ctx;
@@ -220,6 +230,11 @@ int rtoc_correct_costate_direction(rtoc_ctx* ctx);
 /* computeInitialStateDirection's floating-base part on RTOC_BUF_DX0, in place
  * (state_equation.cpp:99-109): upload dq0 = q0 (-) q, dv0 = v0 - v, then call this once. */
 int rtoc_compute_initial_state_direction(rtoc_ctx* ctx);
+
+/* Checks (on the device, ~0.2 ms per 4096 x 47 ANYmal records) whether the top half of every Fxx in RTOC_BUF_KKT has the
+ * state-equation structure RTOC_OPT_FXX_STRUCTURE describes, caches the answer for rtoc_riccati_backward and
+ * returns it in *structured (may be NULL).  Synchronises the stream. */
+int rtoc_check_fxx_structure(rtoc_ctx* ctx, int* structured);
 
 /* Per-instance status words (RTOC_STAT_* bits), synchronises the stream. */
 int rtoc_status(rtoc_ctx* ctx, uint32_t* host_flags, int count);

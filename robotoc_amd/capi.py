@@ -10,7 +10,7 @@ import subprocess
 import numpy as np
 
 from .types import (BoxRow, BUF_CDD, BUF_CON, BUF_DIR, BUF_DX0, BUF_KKT, BUF_RIC, BUF_STEP, Dims, Grid,
-                    Layout, OPT_BACKWARD_WAVES, OPT_CONDENSE_SPLIT, OPT_CONDENSE_KEEP_QAF, OPT_MAX_DTS0, OPT_SWEEP_CHUNKS, OPT_WRITEBACK_KKT, OPT_BACKWARD_SCAN,
+                    Layout, OPT_BACKWARD_WAVES, OPT_CONDENSE_SPLIT, OPT_CONDENSE_KEEP_QAF, OPT_FXX_STRUCTURE, OPT_MAX_DTS0, OPT_SWEEP_CHUNKS, OPT_WRITEBACK_KKT, OPT_BACKWARD_SCAN,
                     grid_array)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -25,7 +25,7 @@ EXPORTS = [
     "rtoc_sync", "rtoc_time_phase", "rtoc_set_constraint_rows", "rtoc_gather_directions", "rtoc_error_string",
     "rtoc_riccati_sweep", "rtoc_correct_state_equation", "rtoc_correct_costate_direction",
     "rtoc_compute_initial_state_direction", "rtoc_unconstr_condense", "rtoc_unconstr_expand",
-    "rtoc_newton_iteration", "rtoc_converged_count", "rtoc_clone", "rtoc_set_friction_cones", "rtoc_set_wrench_cones", "rtoc_wrench_cone_matrix", "rtoc_save_stage_dump", "rtoc_load_stage_dump", "rtoc_kkt_error", "rtoc_integrate_solution",
+    "rtoc_newton_iteration", "rtoc_converged_count", "rtoc_clone", "rtoc_check_fxx_structure", "rtoc_set_friction_cones", "rtoc_set_wrench_cones", "rtoc_wrench_cone_matrix", "rtoc_save_stage_dump", "rtoc_load_stage_dump", "rtoc_kkt_error", "rtoc_integrate_solution",
 ]
 
 
@@ -108,6 +108,8 @@ def lib():
         L.rtoc_wrench_cone_matrix.argtypes = [C.c_double, C.c_double, C.c_double, C.POINTER(C.c_double)]
         L.rtoc_save_stage_dump.argtypes = [vp, C.c_char_p, C.c_uint]
         L.rtoc_kkt_error.argtypes = [vp, dp, C.c_int]
+        L.rtoc_check_fxx_structure.argtypes = [vp, C.POINTER(C.c_int)]
+        L.rtoc_clone.argtypes = [vp, C.POINTER(vp)]
         L.rtoc_load_stage_dump.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
         L.rtoc_error_string.argtypes = [C.c_int]
         L.rtoc_error_string.restype = C.c_char_p
@@ -254,6 +256,16 @@ class Context:
     def set_condense_keep_qaf(self, on):
         """RTOC_OPT_CONDENSE_KEEP_QAF: also store Qafqv / Qafu_full in the ContactDynamicsData record."""
         _chk(lib().rtoc_set_option(self._h, OPT_CONDENSE_KEEP_QAF, int(bool(on))))
+
+    def set_fxx_structure(self, mode):
+        """RTOC_OPT_FXX_STRUCTURE: 0 automatic (checked on the device), 1 always dense, 2 caller asserts the structure."""
+        _chk(lib().rtoc_set_option(self._h, OPT_FXX_STRUCTURE, int(mode)))
+
+    def check_fxx_structure(self):
+        """rtoc_check_fxx_structure: True iff every resident Fxx has the state-equation structure."""
+        out = C.c_int(0)
+        _chk(lib().rtoc_check_fxx_structure(self._h, C.byref(out)))
+        return bool(out.value)
 
     def correct_state_equation(self):
         _chk(lib().rtoc_correct_state_equation(self._h))

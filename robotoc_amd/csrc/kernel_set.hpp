@@ -36,6 +36,7 @@ struct KernelSet {
   int bwd_waves[4];   // waves per workgroup
   int bwd_lds[4];
   int bwd_inst[4];    // OCP instances per workgroup
+  bwd_fn bwd_sa;      // structured-Fxx form of variant 3 (role-split, 4 instances per workgroup), or nullptr
   rtoc_record_layout kl, rl, dl, cl;  // record layouts the kernels were compiled for
   fwd_fn fwd;
   int fwd_threads;
@@ -87,6 +88,7 @@ inline KernelSet make_set() {
       k.bwd_lds[3] = 4 * BwdCfg<NV, NU, NS, 2>::LDS_BYTES + 64;
       k.bwd_inst[3] = 4;
       k.nvariants = 4;
+      if constexpr (NV % 4 == 2 && NV > NU) k.bwd_sa = riccati_backward_rs4_kernel<NV, NU, NS, true>;
     }
   }
   constexpr int NWF = (2 * NV + NU + 63) / 64;

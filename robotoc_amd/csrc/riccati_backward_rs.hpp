@@ -64,8 +64,17 @@ __device__ __forceinline__ void rs_sync(volatile int* cnt, int& epoch, int lane)
 }
 #define RTOC_BLOCK_SYNC() rs_sync<NI>(sFlag + 1, epoch, lane)
 
-template <int NV, int NU, int NS, bool MW, int NI>
+// SA ("structured A"): the caller guarantees (rtoc_check_fxx_structure) that the top half of every Fxx has the shape
+// linearizeStateEquation / correctLinearizeStateEquation leave (src/dynamics/state_equation.cpp:52-55,80-82):
+//   rows [NP, NV):  a e_i^T | c e_i^T      (Fqq = a I, Fqv = c I: a = 1, c = dt; c = 0 on impact grids)
+//   rows [0, NP):   dense only inside the two NP x NP corners (the SE3 blocks of a floating base)
+// so that rows [NP, NV) of A -- S = A - A~ -- contribute P+ S = [a P+[:, NP:NV] | c P+[:, NP:NV]] (scaled COPIES of
+// columns of P+, not products) and S^T W = rows of W scaled; only the k-steps over the rows R = [0, NP) u [NV, NX)
+// of A stay MFMA work: 7 of 9 k-steps in P+ A (column tiles without the Fx / fx riders) and in A^T (P+ A).
+template <int NV, int NU, int NS, bool MW, int NI, bool SA = false>
 __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a, const int slot) {
+  static_assert(!SA || (NV % 4 == 2 && NV - NU >= 0), "structured-A path: row shift NV must be 2 mod 4 (quadrupeds, nv = 18)");
+  constexpr int NP_ = NV - NU;  // passive (floating-base) coordinates: corner size of the state-equation blocks
   using C = BwdCfg<NV, NU, NS, 2>;
   constexpr int NX = C::NX, NT = 128, LDP = C::LDP, TNX = C::TNX, TMA = C::TMA, TNU = C::TNU;
   constexpr int CNT = TNX;  // the matrix wave owns every 16-tile
@@ -264,84 +273,73 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a, const
     if constexpr (!MW) {
     } else {
      if (!impact) {
-      // ---- PB = P+[:,v] Bv ----
+      // ---- PB = P+[:,v] Bv, and chained from its accumulators G = Quu + Bv^T PB[v,:] ----
       {
-        d4 acc[CNT][TNU];
+        static_assert(TNU == 1, "one control tile");
+        d4 acc[CNT];
 #pragma unroll
-        for (int c = 0; c < CNT; ++c)
-#pragma unroll
-          for (int t = 0; t < TNU; ++t) acc[c][t] = zero4();
+        for (int c = 0; c < CNT; ++c) acc[c] = zero4();
         const double* pa_ = sP + li + (NV + q) * LDP;
         const double* pb_ = sBv + q + li * NV;
+        // The C layout of PB (row i = q + 4r + 16c, column u = lane & 15) is the B-operand layout (k = q, n = u) of
+        // the G product, so Bv^T PB[v,:] runs straight from the accumulators -- no LDS round trip between the two
+        // products.  The rows of PB[v,:] start at NV, which need not be a multiple of 4: the k-steps walk the
+        // aligned row groups i = 4 (NV/4 + g) + q and the A operand Bv^T[u][k = i - NV] is zero where k < 0.
+        constexpr int G0 = NV / 4, KSG = (NX - 4 * G0 + 3) / 4;
+        double ga[KSG];  // A operand of the G product: Bv[k][u = li], k = 4 (G0 + g) + q - NV (issued ahead of the PB stream)
+#pragma unroll
+        for (int g = 0; g < KSG; ++g) {
+          const int k = 4 * (G0 + g) + q - NV;
+          const bool ok = k >= 0 && k < NV && li < NU;
+          const double v = sBv[(ok ? k : 0) + (li < NU ? li : 0) * NV];
+          ga[g] = ok ? v : 0.0;
+        }
+        // rider columns of G (li == NU: s+_v, NU+1: Psi+_v (sto), NU+2: Phi+_v (sto && sto_next)): B operand from
+        // the vectors, row i of the state
+        const int rid = li - NU;
+        const bool okr = rid == 0 || (sto && (rid == 1 || (rid == 2 && sto_next)));
+        const double* pr_ = smem + (rid == 1 ? C::V_PSIN : (rid == 2 ? C::V_PHIN : C::V_SN)) + q;
+        double gr[KSG];
+#pragma unroll
+        for (int g = 0; g < KSG; ++g) {
+          const int i = 4 * (G0 + g) + q;
+          const double v = pr_[4 * (G0 + g)];  // rows up to 4 ceil(NX / 4) - 1: inside the 8-padded vector slot
+          gr[g] = (okr && i < NX) ? v : 0.0;
+        }
 #pragma unroll
         for (int ks = 0; ks < (NV + 3) / 4; ++ks) {
           const bool kok = (ks * 4 + 3 < NV) || (ks * 4 + q < NV);
-          double bv[TNU];
-#pragma unroll
-          for (int t = 0; t < TNU; ++t) {
-            const double v = pb_[ks * 4 + t * 16 * NV];
-            bv[t] = (kok && (t * 16 + li < NU)) ? v : 0.0;
-          }
+          const double vb = pb_[ks * 4];
+          const double bv = (kok && li < NU) ? vb : 0.0;
 #pragma unroll
           for (int c = 0; c < CNT; ++c) {
             const double v = pa_[c * 16 + ks * 4 * LDP];
             const double av = (kok && (c * 16 + li < NX)) ? v : 0.0;
-#pragma unroll
-            for (int t = 0; t < TNU; ++t) acc[c][t] = mfma16(av, bv[t], acc[c][t]);
+            acc[c] = mfma16(av, bv, acc[c]);
           }
         }
+        d4 gacc = zero4();
+#pragma unroll
+        for (int g = 0; g < KSG; ++g) {
+          const int gg = G0 + g;
+          const double pbv = acc[gg / 4][gg % 4];          // PB[4 gg + q][li] (zero in the columns li >= NU)
+          gacc = mfma16(ga[g], rid >= 0 ? gr[g] : pbv, gacc);
+        }
+        // PB -> LDS (A-operand rows of the [P+; PB^T] A product) while the G chain drains
 #pragma unroll
         for (int c = 0; c < CNT; ++c)
 #pragma unroll
-          for (int t = 0; t < TNU; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int i = c * 16 + drow(q, r), u = t * 16 + li;
-              if (i < NX && u < NU) sPB[i + u * LDP] = acc[c][t][r];
-            }
-      }
-      wave_lds_sync();
-      // ---- G = Quu + Bv^T PB[v,:] ----
-      {
-        d4 acc[TNU][TNU];
-#pragma unroll
-        for (int t0 = 0; t0 < TNU; ++t0)
-#pragma unroll
-          for (int t1 = 0; t1 < TNU; ++t1) acc[t0][t1] = zero4();
-        const double* pa_ = sBv + q + li * NV;
-        const double* pb_ = sPB + NV + q + li * LDP;
-        // rider columns (TNU == 1): li == NU: s+_v, NU+1: Psi+_v (sto), NU+2: Phi+_v (sto && sto_next)
-        const int rid = li - NU;
-        const double* pbr_ = (rid < 0) ? pb_ : (smem + (rid == 0 ? C::V_SN : (rid == 1 ? C::V_PSIN : C::V_PHIN)) + NV + q);
-        const bool okr = (rid < 0) || rid == 0 || (sto && (rid == 1 || (rid == 2 && sto_next)));
-#pragma unroll
-        for (int ks = 0; ks < (NV + 3) / 4; ++ks) {
-          const bool kok = (ks * 4 + 3 < NV) || (ks * 4 + q < NV);
-          double av[TNU], bv[TNU];
-#pragma unroll
-          for (int t = 0; t < TNU; ++t) {
-            const bool ok = kok && (t * 16 + li < NU);
-            const double va = pa_[ks * 4 + t * 16 * NV];
-            const double vb = pbr_[ks * 4 + t * 16 * LDP];  // PB column, or s+_v / Psi+_v / Phi+_v on the rider lanes
-            av[t] = ok ? va : 0.0;
-            bv[t] = (kok && okr) ? vb : 0.0;
+          for (int r = 0; r < 4; ++r) {
+            const int i = c * 16 + drow(q, r), u = li;
+            if (i < NX && u < NU) sPB[i + u * LDP] = acc[c][r];
           }
 #pragma unroll
-          for (int t0 = 0; t0 < TNU; ++t0)
-#pragma unroll
-            for (int t1 = 0; t1 < TNU; ++t1) acc[t0][t1] = mfma16(av[t0], bv[t1], acc[t0][t1]);
+        for (int r = 0; r < 4; ++r) {
+          const int u0 = drow(q, r), u1 = li;
+          if (u0 < NU && u1 < NU) sG[u0 + u1 * NU] += gacc[r];
+          if (u0 < NU && u1 >= NU && u1 < NU + 3)
+            smem[(u1 == NU ? C::V_BTS : (u1 == NU + 1 ? C::V_BTPSI : C::V_BTPHI)) + u0] = gacc[r];
         }
-#pragma unroll
-        for (int t0 = 0; t0 < TNU; ++t0)
-#pragma unroll
-          for (int t1 = 0; t1 < TNU; ++t1)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int u0 = t0 * 16 + drow(q, r), u1 = t1 * 16 + li;
-              if (u0 < NU && u1 < NU) sG[u0 + u1 * NU] += acc[t0][t1][r];
-              if (u0 < NU && u1 >= NU && u1 < NU + 3)
-                smem[(u1 == NU ? C::V_BTS : (u1 == NU + 1 ? C::V_BTPSI : C::V_BTPHI)) + u0] = acc[t0][t1][r];
-            }
       }
      } else {
       for (int e = lane; e < NU * LDP; e += 64) sPB[e] = 0.0;
@@ -370,6 +368,36 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a, const
 #pragma unroll
         for (int c = 0; c < CNT; ++c) pa[tm][c] = zero4();
       const double* pb_ = sA + q + li * LDP;
+      // row k = 4 ks + q of A takes part in the structured k-steps iff it is one of the dense rows R
+      auto in_R = [&](int ks) { return 4 * ks + q < NP_ || 4 * ks + q >= NV; };
+      if constexpr (SA) {
+        // [P+; PB^T] S: column j of the result is a scaled COPY of column src(j) of [P+; PB^T]
+        //   j in [NP, NV): a * col j        j in [NV + NP, NX): c * col (j - NV)
+        // for the column tiles that are multiplied over R only (all but the last, which carries the Fx / fx riders
+        // and stays dense).  a = A[NP][NP], c = A[NP][NV + NP] (checked uniform by rtoc_check_fxx_structure).
+        const double ca = sA[NP_ + NP_ * LDP], cc = sA[NP_ + (NV + NP_) * LDP];
+#pragma unroll
+        for (int c = 0; c < CNT - 1; ++c) {
+          const int j = c * 16 + li;
+          const bool isa = j >= NP_ && j < NV, isc = j >= NV + NP_ && j < NX;
+          const int src = isa ? j : (isc ? j - NV : 0);
+          const double coef = isa ? ca : (isc ? cc : 0.0);
+#pragma unroll
+          for (int tm = 0; tm < TMA; ++tm)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int i = tm * 16 + drow(q, r);
+              double v;
+              if (tm * 16 + 4 * r + 3 < NX)
+                v = sP[i + src * LDP];
+              else if (tm * 16 + 4 * r >= NX)
+                v = (i < NX + NU) ? sPB[src + (i - NX) * LDP] : 0.0;
+              else
+                v = (i < NX) ? sP[i + src * LDP] : ((i < NX + NU) ? sPB[src + (i - NX) * LDP] : 0.0);
+              pa[tm][c][r] = coef * v;
+            }
+        }
+      }
       // last column tile: columns j < NX are A, column NX is Fx (not in STO stages, which keep the
       // VALU path for their extra vectors) -- P+ Fx and PB^T Fx come out of the same MFMAs
       static_assert(TNX * 16 >= NX + 2, "no spare columns for Fx / fx in the last tile");
@@ -426,6 +454,11 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a, const
             // Every VALU instruction between two f64 MFMAs costs its full issue time (shared port).
 #pragma unroll
             for (int c = 0; c < CNT; ++c) bv[c] = kok ? r.b[c] : 0.0;
+            if constexpr (SA) {  // structured column tiles: rows of A outside R are covered by the S copies
+              const bool keep = in_R(ks);
+#pragma unroll
+              for (int c = 0; c < CNT - 1; ++c) bv[c] = keep ? bv[c] : 0.0;
+            }
           };
           Raw raw[2];
           load_raw(0, raw[0]);
@@ -435,10 +468,14 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a, const
             __builtin_amdgcn_sched_barrier(0);
             double av[TMA], bv[CNT];
             finish_ops(ks, raw[ks & 1], av, bv);
+            // k-steps whose four rows all lie in [NP, NV) touch the last (dense) column tile only
+            constexpr int KS_LO = (NP_ + 3) / 4, KS_HI = NV / 4;  // k-steps [KS_LO, KS_HI) are entirely outside R
+            const bool skip_struct = SA && ks >= KS_LO && ks < KS_HI;
 #pragma unroll
             for (int tm = TM0; tm < TM1; ++tm)
 #pragma unroll
-              for (int c = 0; c < CNT; ++c) pa[tm][c] = mfma16(av[tm], bv[c], pa[tm][c]);
+              for (int c = 0; c < CNT; ++c)
+                if (!(skip_struct && c < CNT - 1)) pa[tm][c] = mfma16(av[tm], bv[c], pa[tm][c]);
             __builtin_amdgcn_sched_barrier(0);
           }
         }
@@ -541,6 +578,7 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a, const
         for (int t = 0; t < TNX; ++t) bv[t] = pbf_[gidx * 4 + t * 16 * LDP];
       };
       double bvf[2][TNX];
+      if constexpr (!SA) {
       load_b(0, bvf[0]);
 #pragma unroll
       for (int gidx = 0; gidx < KSF; ++gidx) {
@@ -557,6 +595,68 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a, const
           for (int t = c; t < TNX; ++t) f[c][t] = mfma16(avv, bm[t], f[c][t]);
         }
         __builtin_amdgcn_sched_barrier(0);
+      }
+      } else {
+        // Structured form: F += A^T W with W = P+ A in the accumulators `pa` (their C layout is the B-operand
+        // layout) and A^T as the A operand -- the same LDS words as above, A[k = 4g + q][16c + li], now read as
+        // (m = column of A, k = row of A).  Rows k of A outside R are masked (k-steps wholly outside are skipped) and
+        // their part S^T W is added as scaled rows of W:
+        //   F[i][:] += a W[i][:] (i in [NP, NV)),   F[i][:] += c W[i - NV][:] (i in [NV + NP, NX)).
+        constexpr int KS_LO = (NP_ + 3) / 4, KS_HI = NV / 4;
+        constexpr int FIRST = (KS_LO == 0) ? KS_HI : 0;
+        load_b(FIRST, bvf[0]);
+        int par = 0;
+#pragma unroll
+        for (int gidx = 0; gidx < KSF; ++gidx) {
+          if (gidx >= KS_LO && gidx < KS_HI) continue;  // all four rows in [NP, NV)
+          int nxt = gidx + 1;
+          if (nxt >= KS_LO && nxt < KS_HI) nxt = KS_HI;
+          if (nxt < KSF) load_b(nxt, bvf[par ^ 1]);
+          __builtin_amdgcn_sched_barrier(0);
+          const bool kok = ((gidx * 4 + 3 < NX) || (gidx * 4 + q < NX)) && (4 * gidx + q < NP_ || 4 * gidx + q >= NV);
+          double am[TNX];
+#pragma unroll
+          for (int t = 0; t < TNX; ++t) am[t] = kok ? bvf[par][t] : 0.0;
+#pragma unroll
+          for (int t = 0; t < TNX; ++t) {
+            const double bvv = kok ? pa[gidx / 4][t][gidx % 4] : 0.0;
+#pragma unroll
+            for (int c = 0; c <= t; ++c) f[c][t] = mfma16(am[c], bvv, f[c][t]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          par ^= 1;
+        }
+        const double ca = sA[NP_ + NP_ * LDP], cc = sA[NP_ + (NV + NP_) * LDP];
+#pragma unroll
+        for (int c = 0; c < CNT; ++c)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            // a-part: rows i = 16c + 4r + q in [NP, NV), same lane and register of W
+            if (16 * c + 4 * r + 3 >= NP_ && 16 * c + 4 * r < NV) {
+              const int i = 16 * c + 4 * r + q;
+              const double coef = (i >= NP_ && i < NV) ? ca : 0.0;
+#pragma unroll
+              for (int t = c; t < TNX; ++t) f[c][t][r] += coef * pa[c][t][r];
+            }
+            // c-part: rows i in [NV + NP, NX) take row i - NV of W: NV = 2 (mod 4), so that row sits two q-groups
+            // away (lane ^ 32) in register group r (q >= 2) or r - 1 (q < 2)
+            if (16 * c + 4 * r + 3 >= NV + NP_ && 16 * c + 4 * r < NX) {
+              const int i = 16 * c + 4 * r + q;
+              const double coef = (i >= NV + NP_ && i < NX) ? cc : 0.0;
+              constexpr int SH = (NV + 2) / 4;             // i - NV = 4 (4c + r - SH) + (q + 2)  for q < 2
+              const int g_hi = 4 * c + r - (NV - 2) / 4;   //       = 4 (4c + r - (NV-2)/4) + (q - 2)  for q >= 2
+              const int g_lo = 4 * c + r - SH;
+#pragma unroll
+              for (int t = c; t < TNX; ++t) {
+                // sender lane holds q_s = q ^ 2: q_s < 2 serves a destination with q >= 2 (group g_hi), else g_lo
+                const double hi_v = (g_hi >= 0) ? pa[(g_hi >= 0 ? g_hi : 0) / 4][t][(g_hi >= 0 ? g_hi : 0) % 4] : 0.0;
+                const double lo_v = (g_lo >= 0) ? pa[(g_lo >= 0 ? g_lo : 0) / 4][t][(g_lo >= 0 ? g_lo : 0) % 4] : 0.0;
+                const double send = (q < 2) ? hi_v : lo_v;
+                const double got = __shfl_xor(send, 32, 64);
+                f[c][t][r] += coef * got;
+              }
+            }
+          }
       }
       // the policy products run here, on the wave that owns the MFMA stream of this SIMD: issued
       // from the vector wave they queued behind the F chain above anyway
@@ -1007,7 +1107,7 @@ __global__ __launch_bounds__(128, 2) void riccati_backward_rs_kernel(BwdArgs a) 
 // its dependent chains (Cholesky, solves) stretch 3-4x; sharing with its OWN matrix wave, it runs
 // exactly when that wave is waiting for it.  Pairing is read from HW_ID; if the dispatcher ever
 // places the waves differently the static pairing (wave, wave+4) is used -- still correct.
-template <int NV, int NU, int NS>
+template <int NV, int NU, int NS, bool SA = false>
 __global__ __launch_bounds__(512) void riccati_backward_rs4_kernel(BwdArgs a) {
   using C = BwdCfg<NV, NU, NS, 2>;
   extern __shared__ __attribute__((aligned(16))) double smem_all[];
@@ -1034,10 +1134,41 @@ __global__ __launch_bounds__(512) void riccati_backward_rs4_kernel(BwdArgs a) {
   const int role = __builtin_amdgcn_readfirstlane(paired ? order : (wave >> 2));
   if (a.first + (int)blockIdx.x * 4 + slot >= a.batch) return;
   if (role == 0)
-    riccati_backward_rs_body<NV, NU, NS, true, 4>(a, slot);
+    riccati_backward_rs_body<NV, NU, NS, true, 4, SA>(a, slot);
   else
-    riccati_backward_rs_body<NV, NU, NS, false, 4>(a, slot);
+    riccati_backward_rs_body<NV, NU, NS, false, 4, SA>(a, slot);
 }
 #undef RTOC_BLOCK_SYNC
+
+// Does every Fxx of the batch have the structure the SA kernels assume (see riccati_backward_rs_body)?  One wave per
+// (instance, grid point); any violation sets *flag.  Reads the top NV rows of Fxx only (~1 GB per 4096 x 47 ANYmal
+// records: 0.2 ms), run once per upload of the KKT records, not per sweep.
+struct FxxCheckArgs {
+  const double* kkt;
+  const rtoc_grid* grid;
+  int* flag;
+  int nstages, batch, nv, np, fxx_off, stride;
+};
+static __global__ __launch_bounds__(64) void fxx_structure_kernel(FxxCheckArgs a) {
+  const int item = blockIdx.x, nst1 = a.nstages - 1;
+  const int b = item / nst1, st = item % nst1;
+  if (b >= a.batch) return;
+  const int nv = a.nv, nx = 2 * nv, np = a.np;
+  const double* A = a.kkt + ((size_t)b * a.nstages + st) * a.stride + a.fxx_off;  // column-major nx x nx
+  const double ca = A[np + (size_t)np * nx], cc = A[np + (size_t)(nv + np) * nx];
+  bool bad = false;
+  for (int e = threadIdx.x; e < nv * nx; e += 64) {
+    const int i = e % nv, j = e / nv;  // rows [0, nv) of column j
+    const double v = A[i + (size_t)j * nx];
+    if (i < np) {
+      const bool corner = j < np || (j >= nv && j < nv + np);
+      if (!corner && v != 0.0) bad = true;
+    } else {
+      const double want = (j == i) ? ca : ((j == nv + i) ? cc : 0.0);
+      if (v != want) bad = true;
+    }
+  }
+  if (__any(bad) && threadIdx.x == 0) atomicOr(a.flag, 1);
+}
 
 }  // namespace rtoc

@@ -81,6 +81,9 @@ struct rtoc_ctx {
   int sweep_chunks;
   int condense_split;  // 1: MJtJinv in its own kernel ahead of the condensation
   int keep_qaf;        // RTOC_OPT_CONDENSE_KEEP_QAF
+  int fxx_mode;        // RTOC_OPT_FXX_STRUCTURE: 0 auto, 1 dense, 2 caller asserts the structure
+  int fxx_state;       // auto mode cache: 0 unknown, 1 every Fxx structured, 2 not
+  int* d_fxx_flag;
   int cone_contacts, cone_dim;  // friction / wrench cones: max contacts (0 = off), force components per contact
   int cone_rows;                // PDIPM rows per contact: 5 friction cone, 17 contact wrench cone
   double* d_kkterr;             // [batch]
@@ -176,6 +179,8 @@ static int create_members(rtoc_ctx* c, const rtoc_dims* dims, const KernelSet* k
   for (int v = 0; v < ks->nvariants; ++v)
     HIP_TRY(hipFuncSetAttribute((const void*)ks->bwd[v], hipFuncAttributeMaxDynamicSharedMemorySize,
                                 ks->bwd_lds[v]));
+  if (ks->bwd_sa)
+    HIP_TRY(hipFuncSetAttribute((const void*)ks->bwd_sa, hipFuncAttributeMaxDynamicSharedMemorySize, ks->bwd_lds[3]));
   HIP_TRY(hipFuncSetAttribute((const void*)ks->cond, hipFuncAttributeMaxDynamicSharedMemorySize,
                               ks->cond_lds));
   HIP_TRY(hipFuncSetAttribute((const void*)ks->cond_split, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -224,6 +229,7 @@ int rtoc_destroy(rtoc_ctx* c) {
   if (c->d_entry) (void)hipFree(c->d_entry);
   if (c->d_pair) (void)hipFree(c->d_pair);
   if (c->d_nconv) (void)hipFree(c->d_nconv);
+  if (c->d_fxx_flag) (void)hipFree(c->d_fxx_flag);
   if (c->d_status) (void)hipFree(c->d_status);
   if (c->d_prof) (void)hipFree(c->d_prof);
   for (int i = 0; i < 3; ++i)
@@ -264,6 +270,7 @@ int rtoc_clone(rtoc_ctx* c, rtoc_ctx** out) {
     n->sweep_chunks = c->sweep_chunks;
     n->condense_split = c->condense_split;
     n->keep_qaf = c->keep_qaf;
+    n->fxx_mode = c->fxx_mode;
     if (c->backward_scan) rc = rtoc_set_option(n, RTOC_OPT_BACKWARD_SCAN, c->backward_scan);
   }
   hipError_t e = hipStreamSynchronize(c->stream);
@@ -311,6 +318,7 @@ int rtoc_set_grid(rtoc_ctx* c, const rtoc_grid* grid, int nstages) {
   if (!c->h_grid) c->h_grid = (rtoc_grid*)malloc(sizeof(rtoc_grid) * c->max_stages);
   if (c->h_grid) memcpy(c->h_grid, grid, sizeof(rtoc_grid) * nstages);
   c->nstages = nstages;
+  c->fxx_state = 0;
   return RTOC_OK;
 }
 
@@ -359,6 +367,10 @@ int rtoc_set_option(rtoc_ctx* c, int option, int64_t value) {
       if (value != 0 && value != 1) return RTOC_ERR_BAD_ARG;
       c->condense_split = (int)value;
       return RTOC_OK;
+    case RTOC_OPT_FXX_STRUCTURE:
+      if (value < 0 || value > 2) return RTOC_ERR_BAD_ARG;
+      c->fxx_mode = (int)value;
+      return RTOC_OK;
     case RTOC_OPT_CONDENSE_KEEP_QAF:
       if (value != 0 && value != 1) return RTOC_ERR_BAD_ARG;
       c->keep_qaf = (int)value;
@@ -396,6 +408,7 @@ int rtoc_upload(rtoc_ctx* c, int buffer, size_t offset, const double* host, size
   HIP_TRY(hipMemcpyAsync(c->buf[buffer] + offset, host, count * sizeof(double), hipMemcpyHostToDevice,
                          c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
+  if (buffer == RTOC_BUF_KKT) c->fxx_state = 0;  // re-checked by the next backward recursion (RTOC_OPT_FXX_STRUCTURE)
   return RTOC_OK;
 }
 
@@ -416,6 +429,7 @@ void* rtoc_device_ptr(rtoc_ctx* c, int buffer) {
   // the zero fill of a lazily allocated buffer runs on the context's stream: it must have landed before a
   // caller writes through the pointer on a stream of its own
   if (fresh && hipStreamSynchronize(c->stream) != hipSuccess) return nullptr;
+  if (buffer == RTOC_BUF_KKT) c->fxx_state = 0;  // the caller may write through the pointer
   return c->buf[buffer];
 }
 
@@ -434,6 +448,7 @@ int rtoc_bind(rtoc_ctx* c, int buffer, void* device_ptr) {
   }
   c->buf[buffer] = (double*)device_ptr;
   c->owned[buffer] = false;
+  if (buffer == RTOC_BUF_KKT) c->fxx_state = 0;
   return RTOC_OK;
 }
 
@@ -507,6 +522,35 @@ static int launch_backward_scan(rtoc_ctx* c, int first, int end, hipStream_t str
   return RTOC_OK;
 }
 
+// RTOC_OPT_FXX_STRUCTURE: may the structure-exploiting backward kernel run on the resident records?
+static int check_fxx(rtoc_ctx* c) {
+  if (!c->d_fxx_flag) HIP_TRY(hipMalloc((void**)&c->d_fxx_flag, sizeof(int)));
+  HIP_TRY(hipMemsetAsync(c->d_fxx_flag, 0, sizeof(int), c->stream));
+  FxxCheckArgs a;
+  a.kkt = c->buf[RTOC_BUF_KKT];
+  a.grid = c->d_grid;
+  a.flag = c->d_fxx_flag;
+  a.nstages = c->nstages;
+  a.batch = c->batch;
+  a.nv = c->dims.nv;
+  a.np = c->dims.np;
+  a.fxx_off = c->L.kkt.off[RTOC_KKT_FXX];
+  a.stride = c->L.kkt.stride;
+  hipLaunchKernelGGL(fxx_structure_kernel, dim3(c->batch * (c->nstages - 1)), dim3(64), 0, c->stream, a);
+  HIP_TRY(hipGetLastError());
+  int bad = 1;
+  HIP_TRY(hipMemcpyAsync(&bad, c->d_fxx_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->fxx_state = bad ? 2 : 1;
+  return RTOC_OK;
+}
+static bool fxx_structured(rtoc_ctx* c) {
+  if (c->fxx_mode == 1) return false;
+  if (c->fxx_mode == 2) return true;
+  if (c->fxx_state == 0 && check_fxx(c) != RTOC_OK) return false;
+  return c->fxx_state == 1;
+}
+
 static int launch_backward_range(rtoc_ctx* c, int first, int end, hipStream_t stream) {
   if (scan_applies(c)) return launch_backward_scan(c, first, end, stream);
   BwdArgs a;
@@ -524,8 +568,8 @@ static int launch_backward_range(rtoc_ctx* c, int first, int end, hipStream_t st
   a.max_dts0 = c->max_dts0;
   const int v = c->bwd_variant;
   const int ni = c->ks->bwd_inst[v];
-  hipLaunchKernelGGL(c->ks->bwd[v], dim3((end - first + ni - 1) / ni), dim3(64 * c->ks->bwd_waves[v]),
-                     c->ks->bwd_lds[v], stream, a);
+  const bwd_fn kern = (v == 3 && c->ks->bwd_sa && fxx_structured(c)) ? c->ks->bwd_sa : c->ks->bwd[v];
+  hipLaunchKernelGGL(kern, dim3((end - first + ni - 1) / ni), dim3(64 * c->ks->bwd_waves[v]), c->ks->bwd_lds[v], stream, a);
   HIP_TRY(hipGetLastError());
   return RTOC_OK;
 }
@@ -980,6 +1024,14 @@ int rtoc_set_constraint_rows(rtoc_ctx* c, const rtoc_box_row* rows, int nrows) {
     if (c->h_rows) memcpy(c->h_rows, rows, sizeof(rtoc_box_row) * nrows);
   }
   c->nrows = nrows;
+  return RTOC_OK;
+}
+
+int rtoc_check_fxx_structure(rtoc_ctx* c, int* structured) {
+  CHECK_READY(c);
+  int rc = check_fxx(c);
+  if (rc) return rc;
+  if (structured) *structured = c->fxx_state == 1;
   return RTOC_OK;
 }
 

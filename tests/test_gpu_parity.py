@@ -402,3 +402,48 @@ def test_minimal_horizon_and_ragged_batches(oracle, waves):
                 compare_direction(L, grids, d[b], d_ref[b], TOL)
         finally:
             ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["factory", "dynamics"])
+def test_structured_fxx_kernel_and_its_fallback(oracle, mode):
+    """RTOC_OPT_FXX_STRUCTURE: records with the state-equation structure (Fqq = I + 6 x 6 corner, Fqv = dt I + corner,
+    src/dynamics/state_equation.cpp:52-55,80-82) take the structure-exploiting backward kernel; one stray entry in ONE
+    record sends the whole batch to the dense kernel.  Both against the oracle, and the two kernels against each other."""
+    from robotoc_amd import capi
+    dims, grids, _ = pr.config_anymal_trot()
+    batch = 9
+    kkt = pr.make_kkt_batch(L=oracle.layout(dims), grids=grids, batch=batch, mode=mode)
+    dx0 = pr.make_dx0(oracle.layout(dims), batch)
+    K = Records(oracle.layout(dims), "kkt")
+    out = {}
+    for case in ("structured", "forced_dense", "stray_entry"):
+        ctx = capi.Context(dims, len(grids), batch, 0)
+        try:
+            L = ctx.L
+            ctx.set_grid(grids)
+            k = kkt.copy()
+            if case == "stray_entry":
+                K.f(k[5, 11], "Fxx")[9, 3] = 1e-3  # row 9 in [NP, NV): must be a multiple of e_9 | e_27
+            if case == "forced_dense":
+                ctx.set_fxx_structure(1)
+            ctx.upload(BUF_KKT, k)
+            ctx.upload(BUF_DX0, dx0)
+            assert ctx.check_fxx_structure() == (case != "stray_entry")
+            ctx.riccati_sweep()
+            assert (ctx.status() == 0).all()
+            ric, d = ctx.download_records(BUF_RIC, "ric"), ctx.download_records(BUF_DIR, "dir")
+            ric_ref, d_ref = Records(L, "ric").zeros(batch, len(grids)), Records(L, "dir").zeros(batch, len(grids))
+            oracle.riccati_sweep_batch(L, grids, k.copy(), ric_ref, d_ref, dx0=dx0)
+            tol = TOL if mode == "factory" else 1e-7
+            worst = 0.0
+            for b in range(batch):
+                worst = max(worst, compare_riccati(L, grids, ric[b], ric_ref[b], tol, "%s inst %d" % (case, b)))
+                worst = max(worst, compare_direction(L, grids, d[b], d_ref[b], tol, "%s inst %d" % (case, b)))
+            P = Records(L, "ric").f(ric, "P")
+            assert np.abs(P - np.swapaxes(P, -1, -2)).max() == 0.0
+            print("%s / %s: worst rel err %.3e" % (case, mode, worst))
+            out[case] = ric
+        finally:
+            ctx.close()
+    assert not np.array_equal(out["structured"], out["forced_dense"])  # really two arithmetic paths
