@@ -255,6 +255,17 @@ int rtoc_time_phase(rtoc_ctx* ctx, int phase, int reps, float* ms);
  * active box / cone rows (constraint_component_data.hpp:122-124, if rows are set).  host_out: [count<=batch]. */
 int rtoc_kkt_error(rtoc_ctx* ctx, double* host_out, int count);
 
+/* SwitchingTimeOptimization::evalKKT downstream of the (host-side, scalar) STO cost and dwell-time constraints
+ * (src/sto/switching_time_optimization.cpp:105-137), after rtoc_condense like OCPSolver::updateSolution orders them
+ * (ocp_solver.cpp:118-119): for every instance the gradient lt and the diagonal of the Hessian Qtt_ of its
+ * `num_events` discrete events (host arrays [batch][num_events], event order = grid order) are scattered into h / Qtt
+ * of the grid point after an impact and of the lift grid point, and the STO term of the squared KKT error -- the
+ * squared differences of the per-phase Hamiltonian sums across STO-enabled events -- is returned in
+ * host_err_sq[count <= batch] (may be NULL).  OCPSolver::KKTError() = sqrt(rtoc_kkt_error^2 + that + the STO
+ * constraints' own residual, which stays on the host). */
+int rtoc_sto_eval_kkt(rtoc_ctx* ctx, const double* host_lt, const double* host_qtt_diag, int num_events,
+                      double* host_err_sq, int count);
+
 /* SplitSolution::integrate (src/core/split_solution.cpp:58-90) on every grid point, as the
  * updatePrimal half of DirectMultipleShooting::integrateSolution (direct_multiple_shooting.cpp:212-241)
  * does after rtoc_expand: RTOC_BUF_SOL += primal step (RTOC_BUF_STEP) x RTOC_BUF_DIR for v, a (dv on

@@ -79,6 +79,8 @@ def lib():
                                           dp, C.c_double, dp, C.c_int]
         _LIB.orc_wrench_batch.restype = None
         _LIB.orc_integrate_solution_batch.argtypes = [C.POINTER(Layout), C.POINTER(Grid), C.c_int, C.c_int, dp, dp, dp]
+        _LIB.orc_sto_eval_kkt.argtypes = [C.POINTER(Layout), C.POINTER(Grid), C.c_int, dp, dp, dp, C.c_int]
+        _LIB.orc_sto_eval_kkt.restype = C.c_double
         _LIB.orc_bench_sweep.argtypes = [C.POINTER(Layout), C.POINTER(Grid), C.c_int, C.c_int, dp, dp, C.c_double,
                                          C.c_int, C.c_int, dp]
         _LIB.orc_bench_sweep.restype = C.c_uint
@@ -314,3 +316,16 @@ def bench_sqp(L, grids, kkt, cdd, con, cone, dx0, rows, max_contacts, contact_di
                              _p(cone) if cone is not None else None, _p(dx0), _rows(rows), len(rows), max_contacts,
                              contact_dim, tau, max_dts0, reps, nthreads, _p(out))
     return dict(seconds=out[0], refill_seconds=out[1], threads=int(out[2]), iterations=reps * kkt.shape[0], status=st)
+
+
+def sto_eval_kkt(L, grids, kkt, lt, qtt_diag):
+    """SwitchingTimeOptimization::evalKKT scatter + STO KKT-error term (switching_time_optimization.cpp:105-137) of
+    every instance: kkt [batch, stages, stride] (condensed records, mutated), lt / qtt_diag [batch, num_events].
+    Returns the squared STO KKT error per instance."""
+    lt = np.ascontiguousarray(lt, dtype=np.float64)
+    qtt_diag = np.ascontiguousarray(qtt_diag, dtype=np.float64)
+    out = np.zeros(kkt.shape[0])
+    for b in range(kkt.shape[0]):
+        out[b] = lib().orc_sto_eval_kkt(C.byref(L), grid_array(grids), len(grids), _p(kkt[b]), _p(lt[b]), _p(qtt_diag[b]),
+                                        lt.shape[1])
+    return out

@@ -989,3 +989,49 @@ void orc_integrate_solution_batch(const rtoc_layout* L, const rtoc_grid* grid, i
       orc_integrate_solution_stage(L, &grid[i], steps[2 * b], dir + rec * L->dir.stride, sol + rec * L->sol.stride);
     }
 }
+
+/* ======================================================================================
+ * SwitchingTimeOptimization::evalKKT, the part downstream of the STO cost / dwell-time constraints
+ * (src/sto/switching_time_optimization.cpp:105-137): scatter of the per-event gradient lt and Hessian diagonal
+ * diag(Qtt_) into the stage right after an impact (:108-112) / the lift stage (:113-117), then the STO term of the
+ * KKT error: squared differences of the per-phase Hamiltonian sums across events with STO enabled (:120-136).
+ * GridInfo::phase = number of impact / lift grids up to and including the grid (time_discretization.cpp:70-126).
+ * kkt: ONE instance's records AFTER the condensation (DirectMultipleShooting::evalKKT runs first, ocp_solver.cpp:118-119).
+ * Returns the squared STO KKT error (PerformanceIndex::kkt_error of the STO problem without its constraint part).
+ * ====================================================================================== */
+double orc_sto_eval_kkt(const rtoc_layout* L, const rtoc_grid* grid, int nstages, double* kkt, const double* lt,
+                        const double* qtt_diag, int num_events) {
+  const int N = nstages - 1;
+  const int so = L->kkt.off[RTOC_KKT_SCAL];
+  int event_index = 0;
+  for (int i = 0; i < N && event_index < num_events; ++i) {
+    if (grid[i].type == RTOC_GRID_IMPACT) {
+      double* sc = kkt + (size_t)(i + 1) * L->kkt.stride + so;
+      sc[RTOC_KKT_SCAL_H] -= lt[event_index];
+      sc[RTOC_KKT_SCAL_QTT] += qtt_diag[event_index];
+      ++event_index;
+    } else if (grid[i].type == RTOC_GRID_LIFT) {
+      double* sc = kkt + (size_t)i * L->kkt.stride + so;
+      sc[RTOC_KKT_SCAL_H] -= lt[event_index];
+      sc[RTOC_KKT_SCAL_QTT] += qtt_diag[event_index];
+      ++event_index;
+    }
+  }
+  double h[64];
+  for (int p = 0; p < 64; ++p) h[p] = 0.0;
+  int phase = 0;
+  for (int i = 0; i < N; ++i) {
+    if (grid[i].type == RTOC_GRID_IMPACT || grid[i].type == RTOC_GRID_LIFT) ++phase;
+    if (phase < 64) h[phase] += kkt[(size_t)i * L->kkt.stride + so + RTOC_KKT_SCAL_H];
+  }
+  double err = 0.0;
+  event_index = 0;
+  for (int i = 0; i < N; ++i) {
+    if ((grid[i].type == RTOC_GRID_IMPACT && grid[i + 1].sto) || (grid[i].type == RTOC_GRID_LIFT && grid[i].sto)) {
+      const double hdiff = h[event_index] - h[event_index + 1];
+      err += hdiff * hdiff;
+      ++event_index;
+    }
+  }
+  return err;
+}

@@ -25,7 +25,7 @@ EXPORTS = [
     "rtoc_sync", "rtoc_time_phase", "rtoc_set_constraint_rows", "rtoc_gather_directions", "rtoc_error_string",
     "rtoc_riccati_sweep", "rtoc_correct_state_equation", "rtoc_correct_costate_direction",
     "rtoc_compute_initial_state_direction", "rtoc_unconstr_condense", "rtoc_unconstr_expand",
-    "rtoc_newton_iteration", "rtoc_converged_count", "rtoc_clone", "rtoc_check_fxx_structure", "rtoc_set_friction_cones", "rtoc_set_wrench_cones", "rtoc_wrench_cone_matrix", "rtoc_save_stage_dump", "rtoc_load_stage_dump", "rtoc_kkt_error", "rtoc_integrate_solution",
+    "rtoc_newton_iteration", "rtoc_converged_count", "rtoc_clone", "rtoc_check_fxx_structure", "rtoc_sto_eval_kkt", "rtoc_set_friction_cones", "rtoc_set_wrench_cones", "rtoc_wrench_cone_matrix", "rtoc_save_stage_dump", "rtoc_load_stage_dump", "rtoc_kkt_error", "rtoc_integrate_solution",
 ]
 
 
@@ -109,6 +109,7 @@ def lib():
         L.rtoc_save_stage_dump.argtypes = [vp, C.c_char_p, C.c_uint]
         L.rtoc_kkt_error.argtypes = [vp, dp, C.c_int]
         L.rtoc_check_fxx_structure.argtypes = [vp, C.POINTER(C.c_int)]
+        L.rtoc_sto_eval_kkt.argtypes = [vp, dp, dp, C.c_int, dp, C.c_int]
         L.rtoc_clone.argtypes = [vp, C.POINTER(vp)]
         L.rtoc_load_stage_dump.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
         L.rtoc_error_string.argtypes = [C.c_int]
@@ -256,6 +257,15 @@ class Context:
     def set_condense_keep_qaf(self, on):
         """RTOC_OPT_CONDENSE_KEEP_QAF: also store Qafqv / Qafu_full in the ContactDynamicsData record."""
         _chk(lib().rtoc_set_option(self._h, OPT_CONDENSE_KEEP_QAF, int(bool(on))))
+
+    def sto_eval_kkt(self, lt, qtt_diag):
+        """rtoc_sto_eval_kkt: lt, qtt_diag [batch, num_events]; returns the squared STO KKT-error term per instance."""
+        lt = np.ascontiguousarray(lt, dtype=np.float64)
+        qtt_diag = np.ascontiguousarray(qtt_diag, dtype=np.float64)
+        assert lt.shape == qtt_diag.shape and lt.shape[0] == self.batch
+        out = np.zeros(self.batch)
+        _chk(lib().rtoc_sto_eval_kkt(self._h, _dp(lt), _dp(qtt_diag), lt.shape[1], _dp(out), self.batch))
+        return out
 
     def set_fxx_structure(self, mode):
         """RTOC_OPT_FXX_STRUCTURE: 0 automatic (checked on the device), 1 always dense, 2 caller asserts the structure."""

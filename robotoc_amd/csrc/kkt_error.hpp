@@ -80,4 +80,58 @@ static __global__ __launch_bounds__(64) void kkt_error_kernel(KktErrArgs a) {
   if (lane == 0) a.out[b] = sqrt(acc);
 }
 
+// SwitchingTimeOptimization::evalKKT downstream of the STO cost / dwell-time constraints (reference
+// src/sto/switching_time_optimization.cpp:105-137): scatter of the per-event gradient lt and of diag(Qtt_) into the grid
+// point after an impact / the lift grid point, then the STO term of the KKT error (squared differences of the per-phase
+// Hamiltonian sums across STO-enabled events).  One thread per instance: O(#grid points) scalar work.
+struct StoArgs {
+  double* kkt;
+  const rtoc_grid* grid;
+  const double* lt;    // [batch][nev]
+  const double* qtt;   // [batch][nev]
+  double* err;         // [batch] squared STO KKT error
+  int nstages, batch, nev, stride, scal_off;
+};
+
+static __global__ void sto_eval_kkt_kernel(StoArgs a) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.batch) return;
+  const int N = a.nstages - 1;
+  double* k = a.kkt + (size_t)b * a.nstages * a.stride + a.scal_off;
+  int ev = 0;
+  for (int i = 0; i < N && ev < a.nev; ++i) {
+    const int ty = a.grid[i].type;
+    if (ty == RTOC_GRID_IMPACT || ty == RTOC_GRID_LIFT) {
+      double* sc = k + (size_t)(ty == RTOC_GRID_IMPACT ? i + 1 : i) * a.stride;
+      sc[RTOC_KKT_SCAL_H] -= a.lt[(size_t)b * a.nev + ev];
+      sc[RTOC_KKT_SCAL_QTT] += a.qtt[(size_t)b * a.nev + ev];
+      ++ev;
+    }
+  }
+  // per-phase Hamiltonian sums h_[grid.phase] (:120-124), GridInfo::phase = number of impact / lift grids so far;
+  // then, exactly as the reference walks them (:126-136), ONE running index over the STO-enabled events
+  constexpr int MAXP = 32;
+  double h[MAXP];
+  for (int p = 0; p < MAXP; ++p) h[p] = 0.0;
+  int phase = 0;
+  for (int i = 0; i < N; ++i) {
+    const int ty = a.grid[i].type;
+    if (ty == RTOC_GRID_IMPACT || ty == RTOC_GRID_LIFT) ++phase;
+    if (phase < MAXP) h[phase] += k[(size_t)i * a.stride + RTOC_KKT_SCAL_H];
+  }
+  double err = 0.0;
+  int e2 = 0;
+  for (int i = 0; i < N; ++i) {
+    const rtoc_grid g = a.grid[i];
+    if ((g.type == RTOC_GRID_IMPACT && a.grid[i + 1].sto) || (g.type == RTOC_GRID_LIFT && g.sto)) {
+      if (e2 + 1 < MAXP) {
+        const double hd = h[e2] - h[e2 + 1];
+        err += hd * hd;
+      }
+      ++e2;
+    }
+  }
+  a.err[b] = err;
+}
+
 }  // namespace rtoc

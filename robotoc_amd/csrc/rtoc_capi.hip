@@ -84,6 +84,8 @@ struct rtoc_ctx {
   int fxx_mode;        // RTOC_OPT_FXX_STRUCTURE: 0 auto, 1 dense, 2 caller asserts the structure
   int fxx_state;       // auto mode cache: 0 unknown, 1 every Fxx structured, 2 not
   int* d_fxx_flag;
+  double* d_sto;       // rtoc_sto_eval_kkt staging: lt, diag(Qtt), squared error
+  size_t sto_cap;
   int cone_contacts, cone_dim;  // friction / wrench cones: max contacts (0 = off), force components per contact
   int cone_rows;                // PDIPM rows per contact: 5 friction cone, 17 contact wrench cone
   double* d_kkterr;             // [batch]
@@ -230,6 +232,7 @@ int rtoc_destroy(rtoc_ctx* c) {
   if (c->d_pair) (void)hipFree(c->d_pair);
   if (c->d_nconv) (void)hipFree(c->d_nconv);
   if (c->d_fxx_flag) (void)hipFree(c->d_fxx_flag);
+  if (c->d_sto) (void)hipFree(c->d_sto);
   if (c->d_status) (void)hipFree(c->d_status);
   if (c->d_prof) (void)hipFree(c->d_prof);
   for (int i = 0; i < 3; ++i)
@@ -1160,6 +1163,43 @@ int rtoc_kkt_error(rtoc_ctx* c, double* host_out, int count) {
   int rc = launch_kkt_error(c);
   if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(host_out, c->d_kkterr, sizeof(double) * count, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return RTOC_OK;
+}
+
+// ---- SwitchingTimeOptimization::evalKKT: scatter + STO KKT-error term ----------------------
+int rtoc_sto_eval_kkt(rtoc_ctx* c, const double* host_lt, const double* host_qtt, int nev, double* host_err_sq, int count) {
+  CHECK_READY(c);
+  if (nev < 0 || nev > 31 || count < 0 || count > c->batch || (nev > 0 && (!host_lt || !host_qtt))) return RTOC_ERR_BAD_ARG;
+  const size_t n = (size_t)c->batch * (nev > 0 ? nev : 1);
+  if (c->sto_cap < n) {
+    if (c->d_sto) (void)hipFree(c->d_sto);
+    c->d_sto = nullptr;
+    HIP_TRY(hipMalloc((void**)&c->d_sto, (2 * n + c->batch) * sizeof(double)));
+    c->sto_cap = n;
+  }
+  double* d_lt = c->d_sto;
+  double* d_qtt = c->d_sto + n;
+  double* d_err = c->d_sto + 2 * n;
+  if (nev > 0) {
+    HIP_TRY(hipMemcpyAsync(d_lt, host_lt, (size_t)c->batch * nev * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_qtt, host_qtt, (size_t)c->batch * nev * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  }
+  StoArgs a;
+  a.kkt = c->buf[RTOC_BUF_KKT];
+  a.grid = c->d_grid;
+  a.lt = d_lt;
+  a.qtt = d_qtt;
+  a.err = d_err;
+  a.nstages = c->nstages;
+  a.batch = c->batch;
+  a.nev = nev;
+  a.stride = c->L.kkt.stride;
+  a.scal_off = c->L.kkt.off[RTOC_KKT_SCAL];
+  hipLaunchKernelGGL(sto_eval_kkt_kernel, dim3((c->batch + 63) / 64), dim3(64), 0, c->stream, a);
+  HIP_TRY(hipGetLastError());
+  if (host_err_sq && count > 0)
+    HIP_TRY(hipMemcpyAsync(host_err_sq, d_err, sizeof(double) * count, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return RTOC_OK;
 }
