@@ -242,13 +242,14 @@ def sqp_single_instance(dims, grids, device):
     from robotoc_amd import capi, problems as pr
     from robotoc_amd.types import BUF_CDD, BUF_CON, BUF_CONE, BUF_DX0, BUF_KKT, joint_limit_rows
     out = {}
-    for mode in ("serial", "scan"):
+    for mode in ("serial", "scan", "scan_graph"):
         c1 = capi.Context(dims, len(grids), 1, device)
         L1 = c1.L
         c1.set_grid(grids)
         c1.set_constraint_rows(joint_limit_rows(dims))
         c1.set_friction_cones(4, 3)
-        c1.set_backward_scan(mode == "scan")
+        c1.set_backward_scan(mode.startswith("scan"))
+        c1.set_graph(mode.endswith("graph"))  # RTOC_OPT_GRAPH: the iteration replayed from a captured hipGraph
         kkt, cdd = pr.make_precondense_batch(L1, grids, 1)
         con = pr.make_constraint_batch(L1, grids, 1)
         c1.upload(BUF_CONE, pr.make_cone_batch(L1, grids, 1, 4))
@@ -265,12 +266,12 @@ def sqp_single_instance(dims, grids, device):
                 ms = c1.time_phase(ph[name], 1)
                 if rep > 0:
                     acc[name] += ms / nrep
-        for rep in range(nrep + 1):
+        for rep in range(nrep + 3):
             c1.upload(BUF_KKT, kkt)
             c1.upload(BUF_CDD, cdd)
             c1.upload(BUF_CON, con)
             ms = c1.time_phase(6, 1)  # rtoc_newton_iteration: the whole iteration as one launch sequence
-            if rep > 0:
+            if rep > 2:  # (graph mode: call 1 warms up, call 2 captures, then replays)
                 whole += ms / nrep
         ok = int((c1.status() != 0).sum()) == 0
         c1.close()

@@ -117,7 +117,7 @@ enum rtoc_option {
                               * expandContactDynamicsDual (contact_dynamics.cpp:190-191); rtoc_expand rebuilds the two
                               * products from Qaa, Qff, Qqf and the primal expansion instead, so by default (0) the
                               * 1.6k doubles per grid point are neither written nor read back. */
-  RTOC_OPT_FXX_STRUCTURE = 8 /* How rtoc_riccati_backward treats the top half of Fxx, which linearizeStateEquation /
+  RTOC_OPT_FXX_STRUCTURE = 8, /* How rtoc_riccati_backward treats the top half of Fxx, which linearizeStateEquation /
                               * correctLinearizeStateEquation leave as [a I | c I] plus two dense 6 x 6 floating-base
                               * corners (src/dynamics/state_equation.cpp:52-55,80-82).  0 (default): automatic -- the
                               * records are checked on the device once after they change through this API
@@ -127,6 +127,11 @@ enum rtoc_option {
                               * asserts the structure (no check; wrong results if it does not hold).  A host that
                               * rewrites a bound buffer in place with a different structure must call
                               * rtoc_check_fxx_structure again.  Only shapes with a structured kernel (nv = 18) care. */
+  RTOC_OPT_GRAPH = 9 /* 1: rtoc_riccati_sweep and rtoc_newton_iteration replay their launch sequence from a captured
+                      * hipGraph (captured on the second call after any change of grid, options, buffers, rows or
+                      * cones; arguments kkt_tol / tau are part of the key).  For the single-OCP latency path, whose
+                      * ~25 small kernels are launch-bound.  The calls stay asynchronous on the context's stream; the
+                      * stream must not be capturing already.  Default 0. */
 };
 
 typedef struct rtoc_ctx rtoc_ctx;

@@ -23,15 +23,19 @@ struct KktErrArgs {
   const rtoc_box_row* rows;
   const rtoc_grid* grid;
   double* out;         // [batch] sqrt of the sum
+  double* partial;     // [batch][nstages] squared residual per grid point
   int nstages, batch, nrows, cone_contacts, cone_dim, cone_rows, nc_max;
   int nv, nu, np, nx;
   rtoc_record_layout kl, cl, nl;
 };
 
+// One wave per (grid point, instance): the squared residual of that grid point into partial[b][st]; the second kernel
+// adds the grid points of an instance in grid order and takes the root -- the same fixed summation order for every
+// launch geometry (deterministic), and a single OCP no longer walks its horizon serially (0.2 ms -> a few us).
 static __global__ __launch_bounds__(64) void kkt_error_kernel(KktErrArgs a) {
   const int lane = threadIdx.x;
-  const int b = blockIdx.x;
-  if (b >= a.batch) return;
+  const int st = blockIdx.x, b = blockIdx.y;
+  if (b >= a.batch || st >= a.nstages) return;
   double acc = 0.0;
   auto sq = [&](const double* p, int n) {
     for (int i = lane; i < n; i += 64) {
@@ -39,45 +43,54 @@ static __global__ __launch_bounds__(64) void kkt_error_kernel(KktErrArgs a) {
       acc += v * v;
     }
   };
-  for (int st = 0; st < a.nstages; ++st) {
+  {
     const rtoc_grid g = a.grid[st];
     const size_t rec = (size_t)b * a.nstages + st;
     const double* kr = a.kkt + rec * a.kl.stride;
     const bool terminal = g.type == RTOC_GRID_TERMINAL, impact = g.type == RTOC_GRID_IMPACT;
     sq(kr + a.kl.off[RTOC_KKT_LX], a.nx);
-    if (terminal) continue;
-    sq(kr + a.kl.off[RTOC_KKT_FX], a.nx);
-    if (!impact) {
-      sq(kr + a.kl.off[RTOC_KKT_LU], a.nu);
-      if (g.dims > 0) sq(kr + a.kl.off[RTOC_KKT_PRES], g.dims);
-    }
-    if (a.cdd) {
-      const double* cr = a.cdd + rec * a.cl.stride;
-      sq(cr + a.cl.off[RTOC_CDD_LA], a.nv);  // la (contact grids) / ldv (impact grids)
-      sq(cr + a.cl.off[RTOC_CDD_LF], g.dimf);
-      sq(cr + a.cl.off[RTOC_CDD_IDC], a.nv + g.dimf);
-      if (!impact) sq(cr + a.cl.off[RTOC_CDD_LUP], a.np);
-    }
-    if (a.con) {
-      const double* nr = a.con + rec * a.nl.stride;
-      if (!impact)
-        for (int r = lane; r < a.nrows; r += 64)
-          if (g.time_stage >= a.rows[r].level) {
-            const double x = nr[a.nl.off[RTOC_CON_RESIDUAL] + r], y = nr[a.nl.off[RTOC_CON_CMPL] + r];
+    if (!terminal) {
+      sq(kr + a.kl.off[RTOC_KKT_FX], a.nx);
+      if (!impact) {
+        sq(kr + a.kl.off[RTOC_KKT_LU], a.nu);
+        if (g.dims > 0) sq(kr + a.kl.off[RTOC_KKT_PRES], g.dims);
+      }
+      if (a.cdd) {
+        const double* cr = a.cdd + rec * a.cl.stride;
+        sq(cr + a.cl.off[RTOC_CDD_LA], a.nv);  // la (contact grids) / ldv (impact grids)
+        sq(cr + a.cl.off[RTOC_CDD_LF], g.dimf);
+        sq(cr + a.cl.off[RTOC_CDD_IDC], a.nv + g.dimf);
+        if (!impact) sq(cr + a.cl.off[RTOC_CDD_LUP], a.np);
+      }
+      if (a.con) {
+        const double* nr = a.con + rec * a.nl.stride;
+        if (!impact)
+          for (int r = lane; r < a.nrows; r += 64)
+            if (g.time_stage >= a.rows[r].level) {
+              const double x = nr[a.nl.off[RTOC_CON_RESIDUAL] + r], y = nr[a.nl.off[RTOC_CON_CMPL] + r];
+              acc += x * x + y * y;
+            }
+        if (a.cone_contacts > 0) {
+          const int row0 = a.nc_max - a.cone_rows * a.cone_contacts, n = a.cone_rows * (g.dimf / a.cone_dim);
+          for (int r = lane; r < n; r += 64) {
+            const double x = nr[a.nl.off[RTOC_CON_RESIDUAL] + row0 + r], y = nr[a.nl.off[RTOC_CON_CMPL] + row0 + r];
             acc += x * x + y * y;
           }
-      if (a.cone_contacts > 0) {
-        const int row0 = a.nc_max - a.cone_rows * a.cone_contacts, n = a.cone_rows * (g.dimf / a.cone_dim);
-        for (int r = lane; r < n; r += 64) {
-          const double x = nr[a.nl.off[RTOC_CON_RESIDUAL] + row0 + r], y = nr[a.nl.off[RTOC_CON_CMPL] + row0 + r];
-          acc += x * x + y * y;
         }
       }
     }
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-  if (lane == 0) a.out[b] = sqrt(acc);
+  if (lane == 0) a.partial[(size_t)b * a.nstages + st] = acc;
+}
+
+static __global__ void kkt_error_reduce_kernel(const double* partial, double* out, int nstages, int batch) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= batch) return;
+  double acc = 0.0;
+  for (int st = 0; st < nstages; ++st) acc += partial[(size_t)b * nstages + st];
+  out[b] = sqrt(acc);
 }
 
 // SwitchingTimeOptimization::evalKKT downstream of the STO cost / dwell-time constraints (reference

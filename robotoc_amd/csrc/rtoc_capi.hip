@@ -85,6 +85,15 @@ struct rtoc_ctx {
   int fxx_state;       // auto mode cache: 0 unknown, 1 every Fxx structured, 2 not
   int* d_fxx_flag;
   double* d_sto;       // rtoc_sto_eval_kkt staging: lt, diag(Qtt), squared error
+  // RTOC_OPT_GRAPH: launch sequences replayed from captured hipGraphs
+  int use_graph;
+  unsigned long long epoch;  // bumped by everything that changes a launch parameter baked into a captured graph
+  struct GraphSlot {
+    hipGraphExec_t exec;
+    unsigned long long epoch, warm_epoch;
+    double p0, p1;
+    bool warm;
+  } g_sweep, g_newton;
   size_t sto_cap;
   int cone_contacts, cone_dim;  // friction / wrench cones: max contacts (0 = off), force components per contact
   int cone_rows;                // PDIPM rows per contact: 5 friction cone, 17 contact wrench cone
@@ -233,6 +242,8 @@ int rtoc_destroy(rtoc_ctx* c) {
   if (c->d_nconv) (void)hipFree(c->d_nconv);
   if (c->d_fxx_flag) (void)hipFree(c->d_fxx_flag);
   if (c->d_sto) (void)hipFree(c->d_sto);
+  if (c->g_sweep.exec) (void)hipGraphExecDestroy(c->g_sweep.exec);
+  if (c->g_newton.exec) (void)hipGraphExecDestroy(c->g_newton.exec);
   if (c->d_status) (void)hipFree(c->d_status);
   if (c->d_prof) (void)hipFree(c->d_prof);
   for (int i = 0; i < 3; ++i)
@@ -274,6 +285,7 @@ int rtoc_clone(rtoc_ctx* c, rtoc_ctx** out) {
     n->condense_split = c->condense_split;
     n->keep_qaf = c->keep_qaf;
     n->fxx_mode = c->fxx_mode;
+    n->use_graph = c->use_graph;
     if (c->backward_scan) rc = rtoc_set_option(n, RTOC_OPT_BACKWARD_SCAN, c->backward_scan);
   }
   hipError_t e = hipStreamSynchronize(c->stream);
@@ -322,11 +334,13 @@ int rtoc_set_grid(rtoc_ctx* c, const rtoc_grid* grid, int nstages) {
   if (c->h_grid) memcpy(c->h_grid, grid, sizeof(rtoc_grid) * nstages);
   c->nstages = nstages;
   c->fxx_state = 0;
+  c->epoch++;
   return RTOC_OK;
 }
 
 int rtoc_set_stream(rtoc_ctx* c, void* s) {
   if (!c) return RTOC_ERR_BAD_ARG;
+  c->epoch++;
   c->stream = s ? (hipStream_t)s : c->own_stream;
   return RTOC_OK;
 }
@@ -336,6 +350,7 @@ static int ensure_scan_buffers(rtoc_ctx* c);
 
 int rtoc_set_option(rtoc_ctx* c, int option, int64_t value) {
   if (!c) return RTOC_ERR_BAD_ARG;
+  c->epoch++;
   switch (option) {
     case RTOC_OPT_WRITEBACK_KKT:
       c->writeback = value ? 1 : 0;
@@ -370,6 +385,10 @@ int rtoc_set_option(rtoc_ctx* c, int option, int64_t value) {
       if (value != 0 && value != 1) return RTOC_ERR_BAD_ARG;
       c->condense_split = (int)value;
       return RTOC_OK;
+    case RTOC_OPT_GRAPH:
+      if (value != 0 && value != 1) return RTOC_ERR_BAD_ARG;
+      c->use_graph = (int)value;
+      return RTOC_OK;
     case RTOC_OPT_FXX_STRUCTURE:
       if (value < 0 || value > 2) return RTOC_ERR_BAD_ARG;
       c->fxx_mode = (int)value;
@@ -399,6 +418,7 @@ static int ensure_buffer(rtoc_ctx* c, int b) {
   HIP_TRY(hipMalloc((void**)&c->buf[b], c->count[b] * sizeof(double)));
   HIP_TRY(hipMemsetAsync(c->buf[b], 0, c->count[b] * sizeof(double), c->stream));
   c->owned[b] = true;
+  c->epoch++;
   return RTOC_OK;
 }
 
@@ -452,6 +472,7 @@ int rtoc_bind(rtoc_ctx* c, int buffer, void* device_ptr) {
   c->buf[buffer] = (double*)device_ptr;
   c->owned[buffer] = false;
   if (buffer == RTOC_BUF_KKT) c->fxx_state = 0;
+  c->epoch++;
   return RTOC_OK;
 }
 
@@ -544,6 +565,7 @@ static int check_fxx(rtoc_ctx* c) {
   int bad = 1;
   HIP_TRY(hipMemcpyAsync(&bad, c->d_fxx_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
+  if (c->fxx_state != (bad ? 2 : 1)) c->epoch++;  // the kernel choice of the backward recursion is part of a captured graph
   c->fxx_state = bad ? 2 : 1;
   return RTOC_OK;
 }
@@ -622,6 +644,8 @@ static int launch_forward_range(rtoc_ctx* c, int first, int end, hipStream_t str
   a.nstages = c->nstages;
   a.batch = end;
   a.first = first;
+  // (a structured-Fxx form of this kernel -- top half of Fxx not read, 15 % fewer bytes -- was measured at 1.27 vs
+  // 1.28 ms: the kernel is bound by its load queue, not by the bytes it requests; not kept)
   hipLaunchKernelGGL(c->ks->fwd, dim3(end - first), dim3(c->ks->fwd_threads), 0, stream, a);
   HIP_TRY(hipGetLastError());
   return RTOC_OK;
@@ -829,9 +853,56 @@ int rtoc_riccati_forward(rtoc_ctx* c) {
   return launch_forward(c);
 }
 
+// RTOC_OPT_GRAPH: run `body` (a sequence of kernel launches on c->stream, no allocation, no synchronisation) from a
+// captured hipGraph.  The first call at a given configuration epoch runs it plainly (lazy allocations happen there),
+// the second captures and instantiates, later calls are one hipGraphLaunch -- a single-OCP Newton iteration is ~25
+// small kernels, whose launch gaps are a third of its latency.
+extern "C++" {
+template <class Body>
+static int run_graphed(rtoc_ctx* c, rtoc_ctx::GraphSlot* g, double p0, double p1, Body body) {
+  if (!c->use_graph) return body();
+  (void)fxx_structured(c);  // may check the records (synchronises): before, never inside, a capture
+  if (g->exec && g->epoch == c->epoch && g->p0 == p0 && g->p1 == p1) {
+    HIP_TRY(hipGraphLaunch(g->exec, c->stream));
+    return RTOC_OK;
+  }
+  if (!(g->warm && g->warm_epoch == c->epoch)) {
+    const int rc = body();
+    g->warm = true;
+    g->warm_epoch = c->epoch;  // after the body: its lazy allocations bump the epoch
+    return rc;
+  }
+  if (g->exec) {
+    (void)hipGraphExecDestroy(g->exec);
+    g->exec = nullptr;
+  }
+  hipGraph_t graph = nullptr;
+  HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
+  const int rc = body();
+  const hipError_t e = hipStreamEndCapture(c->stream, &graph);
+  if (rc || e != hipSuccess || !graph) {
+    if (graph) (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) ctx_set_err(e, __LINE__);
+    return rc ? rc : RTOC_ERR_HIP;
+  }
+  const hipError_t e2 = hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (e2 != hipSuccess) {
+    g->exec = nullptr;
+    ctx_set_err(e2, __LINE__);
+    return RTOC_ERR_HIP;
+  }
+  g->epoch = c->epoch;
+  g->p0 = p0;
+  g->p1 = p1;
+  HIP_TRY(hipGraphLaunch(g->exec, c->stream));
+  return RTOC_OK;
+}
+}  // extern "C++"
+
 int rtoc_riccati_sweep(rtoc_ctx* c) {
   CHECK_READY(c);
-  return launch_sweep(c);
+  return run_graphed(c, &c->g_sweep, 0.0, 0.0, [&]() { return launch_sweep(c); });
 }
 
 static int launch_fill(rtoc_ctx* c, double dt) {
@@ -944,6 +1015,7 @@ static int set_cones(rtoc_ctx* c, int max_contacts, int contact_dim, int rows_pe
   c->cone_contacts = max_contacts;
   c->cone_dim = contact_dim;
   c->cone_rows = rows_per_contact;
+  c->epoch++;
   return RTOC_OK;
 }
 
@@ -1027,6 +1099,7 @@ int rtoc_set_constraint_rows(rtoc_ctx* c, const rtoc_box_row* rows, int nrows) {
     if (c->h_rows) memcpy(c->h_rows, rows, sizeof(rtoc_box_row) * nrows);
   }
   c->nrows = nrows;
+  c->epoch++;
   return RTOC_OK;
 }
 
@@ -1130,7 +1203,7 @@ int rtoc_integrate_solution(rtoc_ctx* c) {
 
 // ---- KKT error ------------------------------------------------------------------------------
 static int launch_kkt_error(rtoc_ctx* c) {
-  if (!c->d_kkterr) HIP_TRY(hipMalloc((void**)&c->d_kkterr, sizeof(double) * c->batch));
+  if (!c->d_kkterr) HIP_TRY(hipMalloc((void**)&c->d_kkterr, sizeof(double) * c->batch * (size_t)(1 + c->max_stages)));
   KktErrArgs a;
   a.kkt = c->buf[RTOC_BUF_KKT];
   a.cdd = c->buf[RTOC_BUF_CDD];
@@ -1152,7 +1225,10 @@ static int launch_kkt_error(rtoc_ctx* c) {
   a.kl = c->L.kkt;
   a.cl = c->L.cdd;
   a.nl = c->L.con;
-  hipLaunchKernelGGL(kkt_error_kernel, dim3(c->batch), dim3(64), 0, c->stream, a);
+  a.partial = c->d_kkterr + c->batch;
+  hipLaunchKernelGGL(kkt_error_kernel, dim3(c->nstages, c->batch), dim3(64), 0, c->stream, a);
+  hipLaunchKernelGGL(kkt_error_reduce_kernel, dim3((c->batch + 63) / 64), dim3(64), 0, c->stream, a.partial, c->d_kkterr,
+                     c->nstages, c->batch);
   HIP_TRY(hipGetLastError());
   return RTOC_OK;
 }
@@ -1174,6 +1250,8 @@ int rtoc_sto_eval_kkt(rtoc_ctx* c, const double* host_lt, const double* host_qtt
   const size_t n = (size_t)c->batch * (nev > 0 ? nev : 1);
   if (c->sto_cap < n) {
     if (c->d_sto) (void)hipFree(c->d_sto);
+  if (c->g_sweep.exec) (void)hipGraphExecDestroy(c->g_sweep.exec);
+  if (c->g_newton.exec) (void)hipGraphExecDestroy(c->g_newton.exec);
     c->d_sto = nullptr;
     HIP_TRY(hipMalloc((void**)&c->d_sto, (2 * n + c->batch) * sizeof(double)));
     c->sto_cap = n;
@@ -1218,10 +1296,7 @@ __global__ void mask_converged_kernel(double* steps, const double* kkterr, int* 
   }
 }
 
-int rtoc_newton_iteration(rtoc_ctx* c, double kkt_tol, double tau) {
-  CHECK_READY(c);
-  if (!(kkt_tol >= 0.0) || !(tau > 0.0 && tau <= 1.0)) return RTOC_ERR_BAD_ARG;
-  if (!c->d_nconv) HIP_TRY(hipMalloc((void**)&c->d_nconv, sizeof(int)));
+static int newton_iteration_body(rtoc_ctx* c, double kkt_tol, double tau) {
   HIP_TRY(hipMemsetAsync(c->d_nconv, 0, sizeof(int), c->stream));
   int rc = launch_kkt_error(c);  // on the freshly linearised (pre-condensation) records
   if (!rc) rc = rtoc_condense(c);
@@ -1234,6 +1309,13 @@ int rtoc_newton_iteration(rtoc_ctx* c, double kkt_tol, double tau) {
   rc = rtoc_update(c);
   if (!rc && c->buf[RTOC_BUF_SOL]) rc = rtoc_integrate_solution(c);
   return rc;
+}
+
+int rtoc_newton_iteration(rtoc_ctx* c, double kkt_tol, double tau) {
+  CHECK_READY(c);
+  if (!(kkt_tol >= 0.0) || !(tau > 0.0 && tau <= 1.0)) return RTOC_ERR_BAD_ARG;
+  if (!c->d_nconv) HIP_TRY(hipMalloc((void**)&c->d_nconv, sizeof(int)));
+  return run_graphed(c, &c->g_newton, kkt_tol, tau, [&]() { return newton_iteration_body(c, kkt_tol, tau); });
 }
 
 int rtoc_converged_count(rtoc_ctx* c, int* host_count) {

@@ -187,3 +187,44 @@ def test_newton_iteration_with_the_horizon_scan():
     finally:
         serial.close()
         scan.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scan", [False, True])
+def test_graph_replay_is_bit_identical(scan):
+    """RTOC_OPT_GRAPH: the Newton iteration and the sweep replayed from captured hipGraphs give the bits of the plain
+    launch sequences -- across the warm-up call, the capturing call and the replays, after a re-upload, and after a
+    change of configuration (new tolerance arguments, an option) that forces a re-capture."""
+    batch, tau = 2, 0.995
+    plain, _ = _context(batch)
+    graph, _ = _context(batch)
+    try:
+        graph.set_graph(True)
+        plain.set_backward_scan(scan)
+        graph.set_backward_scan(scan)
+        L = plain.L
+        dims, grids, _ = pr.config_anymal_trot()
+        kkt, cdd = pr.make_precondense_batch(L, grids, batch)
+        con = pr.make_constraint_batch(L, grids, batch)
+        sol = np.random.default_rng(5).uniform(-1, 1, (batch, len(grids), L.sol.stride))
+
+        def restore(c):
+            for buf, arr in ((BUF_KKT, kkt), (BUF_CDD, cdd), (BUF_CON, con), (BUF_SOL, sol)):
+                c.upload(buf, arr)
+        for it, tol in enumerate((0.0, 0.0, 0.0, 0.0, 1e30, 1e30, 1e30)):
+            restore(plain)
+            restore(graph)
+            plain.newton_iteration(tol, tau)
+            graph.newton_iteration(tol, tau)
+            for buf, which in ((BUF_DIR, "dir"), (BUF_CON, "con"), (BUF_SOL, "sol")):
+                assert np.array_equal(graph.download_records(buf, which), plain.download_records(buf, which)), (it, which)
+            assert graph.converged_count() == plain.converged_count() == (batch if tol > 1 else 0)
+        # the sweep alone, on the condensed records of the last iteration
+        for it in range(4):
+            plain.riccati_sweep()
+            graph.riccati_sweep()
+            assert np.array_equal(graph.download_records(BUF_DIR, "dir"), plain.download_records(BUF_DIR, "dir"))
+        assert (graph.status() == 0).all()
+    finally:
+        plain.close()
+        graph.close()
