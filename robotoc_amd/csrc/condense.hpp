@@ -375,10 +375,6 @@ __global__ __launch_bounds__(64 * RTOC_COND_NW) void condense_kernel(CondArgs a)
   unsigned stat = 0;
 
   RTOC_CPROF(0);
-  // ================= PDIPM slack/dual elimination of the joint-limit rows =================
-  // Constraints::condenseSlackAndDual (constraints.cpp:322-357, joint_*_limit.cpp, pdipm.hxx:66-69):
-  // purely additive on diag(Qqq), diag(Qvv), diag(Quu), lq, lv, lu, so it commutes with the
-  // contact-dynamics condensation below; done first, like intermediate_stage.cpp:134-136.
   // ================= HBM -> registers: every input field once, all loads in flight together ======
   // 16 B per lane; odd-sized fields read/write one double of their 64-B padding
   constexpr int H_L = (NV * NV + 1) / 2, H_D = (LDV * NX + 1) / 2, H_J = (C::NFP * NV + 1) / 2,
@@ -430,55 +426,21 @@ __global__ __launch_bounds__(64 * RTOC_COND_NW) void condense_kernel(CondArgs a)
   prefetch_tiles<NW, NX, NU, NX>(Qxu, lane, cQxu);
   prefetch_tiles<NW, NU, NU, NU>(Quu, lane, cQuu);
   // The sums stay in LDS and enter the Hessian / gradient entries where those get their one
-  // read-modify-write below: the constraint records are then just one more set of loads in flight,
-  // not a dependent HBM round trip ahead of everything else.
+  // read-modify-write below.  Descriptor -> row data is a dependent pair of HBM round trips: the descriptor
+  // load rides with the field loads above, the row data is requested as soon as it is back (after the
+  // registers -> LDS stage) and consumed ahead of the Schur updates, ~15k cycles of products later.
   double* const sPH = smem + C::V_PH;
   double* const sPG = smem + C::V_PG;
-  for (int t = lane; t < 2 * NV + NU; t += NT) {
-    double hess = 0.0, grad = 0.0;
-    if (a.con && !impact) {
-      double* nr = a.con + ((size_t)b * a.nstages + st) * a.nl.stride;
-      const int* no = a.nl.off;
-      // one lane per primal entry (q_k, v_k, u_k): a lower and an upper limit hit the same diagonal
-      // entry, so every entry is accumulated by a single lane in row order (deterministic, no atomics)
-      const int* rowid = a.entry + (2 * NV + NU + 1);
-      // the first two rows of the entry (a lower and an upper limit: all there is for joint limits) come
-      // from one packed descriptor, and their constraint data is fetched unconditionally, all at once:
-      // descriptor -> data is two round trips instead of offsets -> row id -> row -> data, twice over
-      const int4 pd = a.pair[t];
-      {
-        const int r0 = pd.x >= 0 ? pd.x : 0, r1 = pd.y >= 0 ? pd.y : 0;
-        const double s0 = nr[no[RTOC_CON_SLACK] + r0], d0 = nr[no[RTOC_CON_DUAL] + r0],
-                     q0 = nr[no[RTOC_CON_RESIDUAL] + r0], c0 = nr[no[RTOC_CON_CMPL] + r0];
-        const double s1 = nr[no[RTOC_CON_SLACK] + r1], d1 = nr[no[RTOC_CON_DUAL] + r1],
-                     q1 = nr[no[RTOC_CON_RESIDUAL] + r1], c1 = nr[no[RTOC_CON_CMPL] + r1];
-        if (pd.x >= 0 && g.time_stage >= (pd.z >> 8)) {
-          const double cond = (d0 * q0 - c0) / s0;
-          nr[no[RTOC_CON_COND] + r0] = cond;
-          hess += d0 / s0;
-          grad += (double)(signed char)(pd.z & 0xff) * cond;
-        }
-        if (pd.y >= 0 && g.time_stage >= (pd.w >> 8)) {
-          const double cond = (d1 * q1 - c1) / s1;
-          nr[no[RTOC_CON_COND] + r1] = cond;
-          hess += d1 / s1;
-          grad += (double)(signed char)(pd.w & 0xff) * cond;
-        }
-      }
-      for (int e = a.entry[t] + 2; e < a.entry[t + 1]; ++e) {  // further rows on the same entry (none for joint limits)
-        const int r = rowid[e];
-        const rtoc_box_row row = a.rows[r];
-        if (g.time_stage >= row.level) {
-          const double slack = nr[no[RTOC_CON_SLACK] + r], dual = nr[no[RTOC_CON_DUAL] + r];
-          const double cond = (dual * nr[no[RTOC_CON_RESIDUAL] + r] - nr[no[RTOC_CON_CMPL] + r]) / slack;
-          nr[no[RTOC_CON_COND] + r] = cond;
-          hess += dual / slack;
-          grad += row.sign * cond;
-        }
-      }
-    }
-    sPH[t] = hess;
-    sPG[t] = grad;
+  static_assert(2 * NV + NU <= NT, "one lane per primal entry");
+  const bool box_on = a.con != nullptr && !impact;
+  const bool box_lane = box_on && lane < 2 * NV + NU;
+  int4 pd = make_int4(-1, -1, 0, 0);
+  int ent0 = 0, ent1 = 0;  // rows of the entry beyond the first two: CSR range
+  if (box_on) {
+    const int t = lane < 2 * NV + NU ? lane : 0;
+    pd = a.pair[t];
+    ent0 = a.entry[t] + 2;
+    ent1 = a.entry[t + 1];
   }
   RTOC_CPROF(21);
   // inactive rows / columns (dimf < max_dimf) of the stored blocks stay zero, like the reference's
@@ -499,6 +461,18 @@ __global__ __launch_bounds__(64 * RTOC_COND_NW) void condense_kernel(CondArgs a)
   RTOC_ST2(Qqf, gQ, N_J, H_J)
 #undef RTOC_LD2
 #undef RTOC_ST2
+  // one lane per primal entry (q_k, v_k, u_k): the first two rows of the entry (a lower and an upper limit:
+  // all there is for joint limits) come from the packed descriptor; their data is fetched unconditionally
+  double* const nr = box_on ? a.con + ((size_t)b * a.nstages + st) * a.nl.stride : nullptr;
+  double bs0 = 1.0, bd0 = 0.0, bq0 = 0.0, bc0 = 0.0, bs1 = 1.0, bd1 = 0.0, bq1 = 0.0, bc1 = 0.0;
+  if (box_on) {
+    const int* no = a.nl.off;
+    const int r0 = pd.x >= 0 ? pd.x : 0, r1 = pd.y >= 0 ? pd.y : 0;
+    bs0 = nr[no[RTOC_CON_SLACK] + r0], bd0 = nr[no[RTOC_CON_DUAL] + r0], bq0 = nr[no[RTOC_CON_RESIDUAL] + r0],
+    bc0 = nr[no[RTOC_CON_CMPL] + r0];
+    bs1 = nr[no[RTOC_CON_SLACK] + r1], bd1 = nr[no[RTOC_CON_DUAL] + r1], bq1 = nr[no[RTOC_CON_RESIDUAL] + r1],
+    bc1 = nr[no[RTOC_CON_CMPL] + r1];
+  }
   RTOC_CPROF(23);
   if (lane < NV) {
     Qaa[lane] = vQaa;
@@ -577,6 +551,43 @@ __global__ __launch_bounds__(64 * RTOC_COND_NW) void condense_kernel(CondArgs a)
       for (int k = 0; k < nf; ++k) acc += Qff[lane + k * LDF] * Lr[NV + k];
       laf[NV + lane] -= acc;
     }
+  }
+  // ================= PDIPM slack/dual elimination of the joint-limit rows =================
+  // Constraints::condenseSlackAndDual (constraints.cpp:322-357, joint_*_limit.cpp, pdipm.hxx:66-69):
+  // purely additive on diag(Qqq), diag(Qvv), diag(Quu), lq, lv, lu, so it commutes with the
+  // contact-dynamics condensation; every entry is accumulated by a single lane in row order
+  // (deterministic, no atomics).
+  if (lane < 2 * NV + NU) {
+    double hess = 0.0, grad = 0.0;
+    if (box_lane) {
+      const int* no = a.nl.off;
+      if (pd.x >= 0 && g.time_stage >= (pd.z >> 8)) {
+        const double cond = (bd0 * bq0 - bc0) / bs0;
+        nr[no[RTOC_CON_COND] + pd.x] = cond;
+        hess += bd0 / bs0;
+        grad += (double)(signed char)(pd.z & 0xff) * cond;
+      }
+      if (pd.y >= 0 && g.time_stage >= (pd.w >> 8)) {
+        const double cond = (bd1 * bq1 - bc1) / bs1;
+        nr[no[RTOC_CON_COND] + pd.y] = cond;
+        hess += bd1 / bs1;
+        grad += (double)(signed char)(pd.w & 0xff) * cond;
+      }
+      const int* rowid = a.entry + (2 * NV + NU + 1);
+      for (int e = ent0; e < ent1; ++e) {  // further rows on the same entry (none for joint limits)
+        const int r = rowid[e];
+        const rtoc_box_row row = a.rows[r];
+        if (g.time_stage >= row.level) {
+          const double slack = nr[no[RTOC_CON_SLACK] + r], dual = nr[no[RTOC_CON_DUAL] + r];
+          const double cond = (dual * nr[no[RTOC_CON_RESIDUAL] + r] - nr[no[RTOC_CON_CMPL] + r]) / slack;
+          nr[no[RTOC_CON_COND] + r] = cond;
+          hess += dual / slack;
+          grad += row.sign * cond;
+        }
+      }
+    }
+    sPH[lane] = hess;
+    sPG[lane] = grad;
   }
   __syncthreads();
 
@@ -766,11 +777,36 @@ __global__ __launch_bounds__(64) void mjtjinv_kernel(CondArgs a) {
   constexpr rtoc_record_layout CL = SL.cdd;
   double* cr = a.cdd + ((size_t)b * a.nstages + st) * CL.stride;
   unsigned stat = 0;
+  RTOC_CPROF(14);
+  // the factorisation inputs are requested first: they arrive with the cone data, one HBM round trip for both
+  typedef double dbl2 __attribute__((ext_vector_type(2)));
+  constexpr int H_L = (NV * NV + 1) / 2, N_L = (H_L + NT - 1) / NT, N_J = (C::NFP * NV + NT - 1) / NT;
+  dbl2 gL[N_L];
+  double gJ[N_J];
+  const dbl2 zero2 = {0.0, 0.0};
+#pragma unroll
+  for (int k = 0; k < N_L; ++k) {
+    const int e = lane + k * NT;
+    const dbl2 v = reinterpret_cast<const dbl2*>(cr + CL.off[RTOC_CDD_DIDDA])[e < H_L ? e : 0];
+    gL[k] = (e < H_L) ? v : zero2;
+  }
+  // J = dCda (NF x NV, ld NF) on contact grids, dCdv = dIDCdqv[nv:, nv:] (ld LDV) on impact grids
+  // (impact_dynamics.cpp:44-50): both land in sJ with ld NF; rows >= dimf are zero
+  // Both candidates are requested, from addresses that do not depend on the grid descriptor: nothing here
+  // waits for the descriptor's own fetch.
+  double gJi[N_J];
+#pragma unroll
+  for (int k = 0; k < N_J; ++k) {
+    const int e = lane + k * NT, r = e % LDF, c = e / LDF;
+    const bool ok = NF > 0 && c < NV;
+    gJ[k] = cr[CL.off[RTOC_CDD_DCDA] + (ok ? r + c * LDF : 0)];
+    gJi[k] = cr[CL.off[RTOC_CDD_DIDCDQV] + NV + NV * LDV + (ok ? r + c * LDV : 0)];
+  }
   // Constraints::condenseSlackAndDual of the cone rows (intermediate_stage.cpp:134-135): they only touch
   // Qqq, Qqf, Qff, lq, lf, which this kernel does not read -- they ride here, in the shadow of the loads
   // below, and are in HBM before the second kernel starts.  Scratch: the not yet initialised Lam.
   if constexpr (NF > 0) if (a.cone_rows != 0) {
-    static_assert(ConeScratch<NV, NF>::DOUBLES <= C::O_L, "cone scratch is aliased onto Lam");
+    static_assert(ConeScratch<NV, NF>::DOUBLES <= C::LDS_DOUBLES, "cone scratch is aliased onto the (not yet initialised) LDS carve");
     ConeArgs ca;
     ca.kkt = a.kkt;
     ca.cdd = a.cdd;
@@ -792,34 +828,14 @@ __global__ __launch_bounds__(64) void mjtjinv_kernel(CondArgs a) {
     ca.cl = a.cl;
     ca.nl = a.nl;
     ca.dl = a.cl;  // unused by the condensation
+    ca.prof = a.prof;
     if (a.cone_rows == RTOC_WRENCH_ROWS)
       wrench_condense_body<NV, NF>(ca, b, st, lane, smem);
     else
       cone_condense_body<NV, NF>(ca, b, st, lane, smem);
     cone_wave_sync();  // scratch is reused below
   }
-  typedef double dbl2 __attribute__((ext_vector_type(2)));
-  constexpr int H_L = (NV * NV + 1) / 2, N_L = (H_L + NT - 1) / NT, N_J = (C::NFP * NV + NT - 1) / NT;
-  dbl2 gL[N_L];
-  double gJ[N_J];
-  const dbl2 zero2 = {0.0, 0.0};
-#pragma unroll
-  for (int k = 0; k < N_L; ++k) {
-    const int e = lane + k * NT;
-    const dbl2 v = reinterpret_cast<const dbl2*>(cr + CL.off[RTOC_CDD_DIDDA])[e < H_L ? e : 0];
-    gL[k] = (e < H_L) ? v : zero2;
-  }
-  // J = dCda (NF x NV, ld NF) on contact grids, dCdv = dIDCdqv[nv:, nv:] (ld LDV) on impact grids
-  // (impact_dynamics.cpp:44-50): both land in sJ with ld NF; rows >= dimf are zero
-  const double* const jsrc = cr + (impact ? CL.off[RTOC_CDD_DIDCDQV] + NV + NV * LDV : CL.off[RTOC_CDD_DCDA]);
-  const int jld = impact ? LDV : LDF;
-#pragma unroll
-  for (int k = 0; k < N_J; ++k) {
-    const int e = lane + k * NT, r = e % LDF, c = e / LDF;
-    const bool ok = NF > 0 && c < NV && r < nf;
-    const double v = jsrc[ok ? r + c * jld : 0];
-    gJ[k] = ok ? v : 0.0;
-  }
+  RTOC_CPROF(15);
   for (int e = lane; e < LDV * LDV; e += NT) Lam[e] = 0.0;
 #pragma unroll
   for (int k = 0; k < N_L; ++k) {
@@ -829,7 +845,7 @@ __global__ __launch_bounds__(64) void mjtjinv_kernel(CondArgs a) {
 #pragma unroll
   for (int k = 0; k < N_J; ++k) {
     const int e = lane + k * NT;
-    if (e < C::NFP * NV) sJ[e] = gJ[k];
+    if (e < C::NFP * NV) sJ[e] = (NF > 0 && e % LDF < nf) ? (impact ? gJi[k] : gJ[k]) : 0.0;
   }
   const double* const J = sJ;
   __syncthreads();
@@ -837,6 +853,7 @@ __global__ __launch_bounds__(64) void mjtjinv_kernel(CondArgs a) {
 #include "condense_mjtjinv.inc"
 #undef RTOC_J_IN_D
   copy_s2g_flat16<NT>(cr + CL.off[RTOC_CDD_MJTJINV], Lam, LDV * LDV, lane);
+  RTOC_CPROF(24);
   if (stat) atomicOr(&a.status[b], stat);
 }
 

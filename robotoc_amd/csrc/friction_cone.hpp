@@ -31,7 +31,13 @@ struct ConeArgs {
   int cone_stride, dgdf_off;
   double tau;
   rtoc_record_layout kl, cl, nl, dl;
+  long long* prof;
 };
+#ifdef RTOC_ENABLE_PROF
+#define RTOC_KPROF(k) do { if (a.prof && blockIdx.x == (gridDim.x >> 1) && threadIdx.x == 0) a.prof[(k)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define RTOC_KPROF(k) do { } while (0)
+#endif
 
 // the LDS writes of this wave become visible to its other lanes (one wave per grid point: no s_barrier needed)
 __device__ __forceinline__ void cone_wave_sync() {
@@ -39,115 +45,183 @@ __device__ __forceinline__ void cone_wave_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// The Hessian / gradient contributions of the rows of one grid point are ONE Gram product: with G the stacked
+// Jacobian of the active rows (K rows; columns = the primal entries they touch), R = diag(dual / slack) and
+// c the condensing coefficients,  [H | g] += G^T [R G | c].  G is staged K-major in LDS (leading dimension
+// LD = 16 T, the rider column c right after the NC Jacobian columns), so that both MFMA operands of every
+// k-step are the same conflict-free row read.  Scratch: 4 KS x LD for G and 4 KS for diag R.
+template <int K, int NC>
+struct ConeGram {
+  static constexpr int KS = (K + 3) / 4, T = (NC + 1 + 15) / 16, LD = 16 * T, DOUBLES = 4 * KS * LD + 4 * KS;
+};
+
 // scratch doubles the condensation bodies need (LDS, owned by one wave for the duration of the call)
 template <int NV, int NF>
 struct ConeScratch {
   static constexpr int MAXC = NF / 3 > 0 ? NF / 3 : 1, MAXW = NF / 6 > 0 ? NF / 6 : 1;
-  static constexpr int FRICTION = MAXC * (5 * NV + 15 + 5 + 5);
-  static constexpr int WRENCH = NF >= 6 ? MAXW * (RTOC_WRENCH_ROWS * 6 + 2 * RTOC_WRENCH_ROWS) : 0;  // a surface contact has 6 force components
+  static constexpr int FRICTION = ConeGram<5 * MAXC, NV + NF>::DOUBLES;
+  static constexpr int WRENCH = NF >= 6 ? ConeGram<RTOC_WRENCH_ROWS * MAXW, NF>::DOUBLES : 0;  // a surface contact has 6 force components
   static constexpr int DOUBLES = FRICTION > WRENCH ? FRICTION : WRENCH;
 };
 
+// acc[ta][tb] = tile (ta, tb) of G^T [R G | c]; lane (li, q) holds rows 16 ta + drow(q, r), column 16 tb + li.
+// `need(ta, tb)` (compile-time foldable) drops tiles nobody reads.
+template <int K, int NC, class Need>
+__device__ __forceinline__ void cone_gram_tiles(const double* const Gs, const double* const rs, const int lane,
+                                                d4 (&acc)[ConeGram<K, NC>::T][ConeGram<K, NC>::T], Need need) {
+  using CG = ConeGram<K, NC>;
+  const int li = lane & 15, q = lane >> 4;
+#pragma unroll
+  for (int ta = 0; ta < CG::T; ++ta)
+#pragma unroll
+    for (int tb = 0; tb < CG::T; ++tb) acc[ta][tb] = zero4();
+#pragma unroll
+  for (int s = 0; s < CG::KS; ++s) {
+    const int kk = 4 * s + q;
+    const double r = rs[kk];
+    double gv[CG::T], bv[CG::T];
+#pragma unroll
+    for (int t = 0; t < CG::T; ++t) {
+      gv[t] = Gs[kk * CG::LD + 16 * t + li];
+      bv[t] = gv[t] * ((16 * t + li == NC) ? 1.0 : r);
+    }
+#pragma unroll
+    for (int ta = 0; ta < CG::T; ++ta)
+#pragma unroll
+      for (int tb = 0; tb < CG::T; ++tb)
+        if (need(ta, tb)) acc[ta][tb] = mfma16(gv[ta], bv[tb], acc[ta][tb]);
+  }
+}
+
 // One wave, one (instance b, grid point st).  Also called from mjtjinv_kernel (condense.hpp), where the
 // rows ride along with the first kernel of the split condensation instead of costing a launch of their own.
+template <int NV, int NF, int CD>
+__device__ __forceinline__ void cone_condense_body_cd(const ConeArgs& a, const int b, const int st, const int lane,
+                                                      double* const scratch) {
+  constexpr int NX = 2 * NV, NFP = NF > 0 ? NF : 1, MAXC = NF / 3 > 0 ? NF / 3 : 1;
+  constexpr int K = 5 * MAXC, NC = NV + NF;
+  using CG = ConeGram<K, NC>;
+  constexpr int T = CG::T, LD = CG::LD;
+  static_assert(4 * CG::KS <= 64, "one lane per cone row");
+  const int li = lane & 15, q = lane >> 4;
+  const size_t rec = (size_t)b * a.nstages + st;
+  double* const kr = a.kkt + rec * a.kl.stride;
+  double* const cr = a.cdd + rec * a.cl.stride;
+  double* const nr = a.con + rec * a.nl.stride;
+  const double* const cone = a.cone + rec * a.cone_stride;
+  constexpr int cd = CD;  // compile-time: the entry -> target map below divides by it 8 times per entry
+  // ---- every load of the grid point is requested here, from addresses that do not depend on the grid
+  // descriptor (the records are max-size): one HBM round trip, the descriptor's own fetch inside it.
+  constexpr int ND = (MAXC * 5 * NV + 63) / 64, NG = (MAXC * 15 + 63) / 64;
+  double gdq[ND], gdf[NG];
+#pragma unroll
+  for (int p = 0; p < ND; ++p) {
+    const int e = lane + 64 * p;
+    gdq[p] = cone[e < a.max_contacts * 5 * NV ? e : 0];  // the record holds max_contacts blocks
+  }
+#pragma unroll
+  for (int p = 0; p < NG; ++p) {
+    const int e = lane + 64 * p;
+    gdf[p] = cone[a.dgdf_off + (e < a.max_contacts * 15 ? e : 0)];
+  }
+  const int rw = a.row0 + (lane < 5 * a.max_contacts ? lane : 0);
+  const double slack = nr[a.nl.off[RTOC_CON_SLACK] + rw], dual = nr[a.nl.off[RTOC_CON_DUAL] + rw],
+               resid = nr[a.nl.off[RTOC_CON_RESIDUAL] + rw], cmpl = nr[a.nl.off[RTOC_CON_CMPL] + rw];
+  // Entry (row, col) of G^T [R G | c] -> the Hessian / gradient entry it is added to (friction_cone.cpp):
+  //   (q, q) Qqq (:215-216)   (q, f) Qqf (:217-218)   (f, f) Qff, diagonal 3x3 block of the contact (:219-220)
+  //   (q, rider) lq (:206)    (f, rider) lf (:207-208);  nullptr: nothing (Qfq is not stored, and the blocks
+  // between different contacts are zero).  `kc` = the contact whose activity gates the write, -1: always.
+  auto target = [&](const int row, const int col, int& kc) -> double* {
+    kc = -1;
+    const int fr = row - NV, fc = col - NV;
+    const int kr_ = fr / cd, mr = fr % cd, kc_ = fc / cd, mc = fc % cd;
+    const bool frow = row >= NV && row < NC && mr < 3 && kr_ < MAXC, fcol = col >= NV && col < NC && mc < 3 && kc_ < MAXC;
+    if (row < NV) {
+      if (col < NV) return kr + a.kl.off[RTOC_KKT_QXX] + row + (size_t)col * NX;
+      if (col == NC) return kr + a.kl.off[RTOC_KKT_LX] + row;
+      if (fcol) {
+        kc = kc_;
+        return cr + a.cl.off[RTOC_CDD_QQF] + row + (size_t)fc * NV;
+      }
+      return nullptr;
+    }
+    if (!frow) return nullptr;
+    kc = kr_;
+    if (col == NC) return cr + a.cl.off[RTOC_CDD_LF] + fr;
+    if (fcol && kc_ == kr_) return cr + a.cl.off[RTOC_CDD_QFF] + fr + (size_t)fc * NFP;
+    return nullptr;
+  };
+  auto need = [](const int ta, const int tb) { return !(16 * ta >= NV && 16 * tb + 15 < NV); };  // not all-(f, q)
+  double ce[T][T][4];
+#pragma unroll
+  for (int ta = 0; ta < T; ++ta)
+#pragma unroll
+    for (int tb = 0; tb < T; ++tb)
+      if (need(ta, tb)) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int kc;
+          const double* const p = target(16 * ta + drow(q, r), 16 * tb + li, kc);
+          ce[ta][tb][r] = *(p ? p : cr);
+        }
+      }
+  const int nact = a.grid[st].dimf / cd;
+  if (nact == 0) return;
+  RTOC_KPROF(25);
+  // ---- G, diag R and the rider column into LDS
+  double* const Gs = scratch;
+  double* const rs = scratch + 4 * CG::KS * LD;
+  for (int e = lane; e < 4 * CG::KS * LD; e += 64) Gs[e] = 0.0;
+  cone_wave_sync();
+#pragma unroll
+  for (int p = 0; p < ND; ++p) {  // dg_dq of contact k: 5 x NV, column-major
+    const int e = lane + 64 * p, k = e / (5 * NV), w = e % (5 * NV);
+    if (e < nact * 5 * NV) Gs[(5 * k + w % 5) * LD + w / 5] = gdq[p];
+  }
+#pragma unroll
+  for (int p = 0; p < NG; ++p) {  // dg_df of contact k: 5 x 3, on the contact's own force columns
+    const int e = lane + 64 * p, k = e / 15, w = e % 15;
+    if (e < nact * 15) Gs[(5 * k + w % 5) * LD + NV + k * cd + w / 5] = gdf[p];
+  }
+  if (lane < 4 * CG::KS) {
+    const bool on = lane < 5 * nact;
+    if (on) {
+      const double c = (dual * resid - cmpl) / slack;
+      nr[a.nl.off[RTOC_CON_COND] + rw] = c;  // computeCondensingCoeffcient<5> (:202)
+      Gs[lane * LD + NC] = c;
+    }
+    rs[lane] = on ? dual / slack : 0.0;  // (:211-212)
+  }
+  cone_wave_sync();
+  RTOC_KPROF(26);
+  d4 acc[T][T];
+  cone_gram_tiles<K, NC>(Gs, rs, lane, acc, need);
+  RTOC_KPROF(27);
+  {
+#pragma unroll
+    for (int ta = 0; ta < T; ++ta)
+#pragma unroll
+      for (int tb = 0; tb < T; ++tb)
+        if (need(ta, tb)) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            int kc;
+            double* const p = target(16 * ta + drow(q, r), 16 * tb + li, kc);
+            if (p && kc < nact) *p = ce[ta][tb][r] + acc[ta][tb][r];
+          }
+        }
+  }
+  RTOC_KPROF(28);
+}
+
+// contact_dim: 3 (point contacts) or 6 (surface contacts, friction on the force part) -- rtoc_set_friction_cones
 template <int NV, int NF>
 __device__ __forceinline__ void cone_condense_body(const ConeArgs& a, const int b, const int st, const int lane,
                                                    double* const scratch) {
-  constexpr int NX = 2 * NV, NFP = NF > 0 ? NF : 1, MAXC = NF / 3 > 0 ? NF / 3 : 1;
-  const rtoc_grid g = a.grid[st];
-  const int nact = g.dimf / a.contact_dim;
-  if (nact == 0) return;
-  const size_t rec = (size_t)b * a.nstages + st;
-  double* kr = a.kkt + rec * a.kl.stride;
-  double* cr = a.cdd + rec * a.cl.stride;
-  double* nr = a.con + rec * a.nl.stride;
-  const double* cone = a.cone + rec * a.cone_stride;
-  double* Qxx = kr + a.kl.off[RTOC_KKT_QXX];
-  double* lx = kr + a.kl.off[RTOC_KKT_LX];
-  double* Qff = cr + a.cl.off[RTOC_CDD_QFF];
-  double* Qqf = cr + a.cl.off[RTOC_CDD_QQF];
-  double* lf = cr + a.cl.off[RTOC_CDD_LF];
-  // Everything the rows need is fetched in ONE round trip (all contacts), the Hessian / gradient
-  // entries are accumulated over the contacts in registers -- in contact order, like the reference's
-  // loop (:199-233) -- and get one read-modify-write each: two HBM latencies per grid point instead
-  // of two per contact.
-  double(*const dq)[5 * NV] = reinterpret_cast<double(*)[5 * NV]>(scratch);
-  double(*const df)[15] = reinterpret_cast<double(*)[15]>(scratch + MAXC * 5 * NV);
-  double(*const cond)[5] = reinterpret_cast<double(*)[5]>(scratch + MAXC * (5 * NV + 15));
-  double(*const rr)[5] = reinterpret_cast<double(*)[5]>(scratch + MAXC * (5 * NV + 15 + 5));
-  for (int e = lane; e < nact * 5 * NV; e += 64) dq[e / (5 * NV)][e % (5 * NV)] = cone[e];
-  for (int e = lane; e < nact * 15; e += 64) df[e / 15][e % 15] = cone[a.dgdf_off + e];
-  if (lane < 5 * nact) {
-    const int r = a.row0 + lane;
-    const double slack = nr[a.nl.off[RTOC_CON_SLACK] + r], dual = nr[a.nl.off[RTOC_CON_DUAL] + r];
-    const double c = (dual * nr[a.nl.off[RTOC_CON_RESIDUAL] + r] - nr[a.nl.off[RTOC_CON_CMPL] + r]) / slack;
-    nr[a.nl.off[RTOC_CON_COND] + r] = c;  // computeCondensingCoeffcient<5> (:202)
-    cond[lane / 5][lane % 5] = c;
-    rr[lane / 5][lane % 5] = dual / slack;  // (:211-212)
-  }
-  // read-modify-write targets: issued now, consumed after the sums
-  constexpr int NQ = (NV * NV + 63) / 64;
-  double cq[NQ];
-#pragma unroll
-  for (int p = 0; p < NQ; ++p) {
-    const int e = lane + 64 * p;
-    cq[p] = Qxx[(e < NV * NV ? e % NV : 0) + (size_t)(e < NV * NV ? e / NV : 0) * NX];
-  }
-  const double clx = lx[lane < NV ? lane : 0];
-  cone_wave_sync();
-  // lq += dg_dq^T cond (:206)
-  if (lane < NV) {
-    double v = clx;
-    for (int k = 0; k < nact; ++k) {
-      double acc = 0.0;
-#pragma unroll
-      for (int j = 0; j < 5; ++j) acc += dq[k][j + 5 * lane] * cond[k][j];
-      v += acc;
-    }
-    lx[lane] = v;
-  }
-  // lf += dg_df^T cond (:207-208): one lane per (contact, component)
-  if (lane >= 32 && lane < 32 + 3 * nact) {
-    const int k = (lane - 32) / 3, m = (lane - 32) % 3;
-    double acc = 0.0;
-#pragma unroll
-    for (int j = 0; j < 5; ++j) acc += df[k][j + 5 * m] * cond[k][j];
-    lf[k * a.contact_dim + m] += acc;
-  }
-  // Qqq += sum_k dg_dq^T (r dg_dq) (:215-216)
-#pragma unroll
-  for (int p = 0; p < NQ; ++p) {
-    const int e = lane + 64 * p;
-    if (e < NV * NV) {
-      const int r = e % NV, c = e / NV;
-      double v = cq[p];
-      for (int k = 0; k < nact; ++k) {
-        double acc = 0.0;
-#pragma unroll
-        for (int j = 0; j < 5; ++j) acc += dq[k][j + 5 * r] * (rr[k][j] * dq[k][j + 5 * c]);
-        v += acc;
-      }
-      Qxx[r + (size_t)c * NX] = v;
-    }
-  }
-  // Qqf[:, stack..+3] += dg_dq^T (r dg_df) (:217-218) ; Qff block += dg_df^T (r dg_df) (:219-220):
-  // every (contact, entry) is a distinct memory location
-  for (int e = lane; e < nact * (NV * 3 + 9); e += 64) {
-    const int k = e / (NV * 3 + 9), w = e % (NV * 3 + 9), stack = k * a.contact_dim;
-    if (w < NV * 3) {
-      const int r = w % NV, m = w / NV;
-      double acc = 0.0;
-#pragma unroll
-      for (int j = 0; j < 5; ++j) acc += dq[k][j + 5 * r] * (rr[k][j] * df[k][j + 5 * m]);
-      Qqf[r + (size_t)(stack + m) * NV] += acc;
-    } else {
-      const int m = (w - NV * 3) % 3, n = (w - NV * 3) / 3;
-      double acc = 0.0;
-#pragma unroll
-      for (int j = 0; j < 5; ++j) acc += df[k][j + 5 * m] * (rr[k][j] * df[k][j + 5 * n]);
-      Qff[(stack + m) + (size_t)(stack + n) * NFP] += acc;
-    }
-  }
+  if (a.contact_dim == 3)
+    cone_condense_body_cd<NV, NF, 3>(a, b, st, lane, scratch);
+  else
+    cone_condense_body_cd<NV, NF, 6>(a, b, st, lane, scratch);
 }
 
 template <int NV, int NF>
@@ -231,44 +305,81 @@ template <int NV, int NF>
 __device__ __forceinline__ void wrench_condense_body(const ConeArgs& a, const int b, const int st, const int lane,
                                                      double* const scratch) {
   constexpr int NFP = NF > 0 ? NF : 1, MAXC = NF / 6 > 0 ? NF / 6 : 1, WR = RTOC_WRENCH_ROWS;
-  static_assert(MAXC * WR <= 64, "one lane per wrench-cone row");
-  const int nact = a.grid[st].dimf / 6;
-  if (nact == 0) return;
+  constexpr int K = WR * MAXC, NC = NF;
+  using CG = ConeGram<K, NC>;
+  constexpr int T = CG::T, LD = CG::LD;
+  static_assert(4 * CG::KS <= 64, "one lane per wrench-cone row");
+  const int li = lane & 15, q = lane >> 4;
   const size_t rec = (size_t)b * a.nstages + st;
-  double* cr = a.cdd + rec * a.cl.stride;
-  double* nr = a.con + rec * a.nl.stride;
-  const double* cone = a.cone + rec * a.cone_stride;
-  double* Qff = cr + a.cl.off[RTOC_CDD_QFF];
-  double* lf = cr + a.cl.off[RTOC_CDD_LF];
-  double(*const J)[WR * 6] = reinterpret_cast<double(*)[WR * 6]>(scratch);
-  double(*const cond)[WR] = reinterpret_cast<double(*)[WR]>(scratch + MAXC * WR * 6);
-  double(*const rr)[WR] = reinterpret_cast<double(*)[WR]>(scratch + MAXC * WR * 7);
-  for (int e = lane; e < nact * WR * 6; e += 64) J[e / (WR * 6)][e % (WR * 6)] = cone[e];
-  if (lane < WR * nact) {
-    const int r = a.row0 + lane;
-    const double slack = nr[a.nl.off[RTOC_CON_SLACK] + r], dual = nr[a.nl.off[RTOC_CON_DUAL] + r];
-    const double c = (dual * nr[a.nl.off[RTOC_CON_RESIDUAL] + r] - nr[a.nl.off[RTOC_CON_CMPL] + r]) / slack;
-    nr[a.nl.off[RTOC_CON_COND] + r] = c;       // computeCondensingCoeffcient<17> (:228)
-    cond[lane / WR][lane % WR] = c;
-    rr[lane / WR][lane % WR] = dual / slack;  // (:224-225)
+  double* const cr = a.cdd + rec * a.cl.stride;
+  double* const nr = a.con + rec * a.nl.stride;
+  const double* const cone = a.cone + rec * a.cone_stride;
+  // all loads up front, from addresses independent of the grid descriptor (cf. cone_condense_body)
+  constexpr int NJ = (MAXC * WR * 6 + 63) / 64;
+  double gj[NJ];
+#pragma unroll
+  for (int p = 0; p < NJ; ++p) {
+    const int e = lane + 64 * p;
+    gj[p] = cone[e < a.max_contacts * WR * 6 ? e : 0];  // the record holds max_contacts blocks
   }
+  const int rw = a.row0 + (lane < WR * a.max_contacts ? lane : 0);
+  const double slack = nr[a.nl.off[RTOC_CON_SLACK] + rw], dual = nr[a.nl.off[RTOC_CON_DUAL] + rw],
+               resid = nr[a.nl.off[RTOC_CON_RESIDUAL] + rw], cmpl = nr[a.nl.off[RTOC_CON_CMPL] + rw];
+  // (f, f) within one contact -> Qff (:226-227) ; (f, rider) -> lf (:229-230); `kc` = the gating contact
+  auto target = [&](const int row, const int col, int& kc) -> double* {
+    kc = row / 6;
+    if (row >= NF || kc >= MAXC) return nullptr;
+    if (col == NC) return cr + a.cl.off[RTOC_CDD_LF] + row;
+    if (col < NF && col / 6 == kc) return cr + a.cl.off[RTOC_CDD_QFF] + row + (size_t)col * NFP;
+    return nullptr;
+  };
+  auto need = [](const int, const int) { return true; };
+  double ce[T][T][4];
+#pragma unroll
+  for (int ta = 0; ta < T; ++ta)
+#pragma unroll
+    for (int tb = 0; tb < T; ++tb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int kc;
+        const double* const p = target(16 * ta + drow(q, r), 16 * tb + li, kc);
+        ce[ta][tb][r] = *(p ? p : cr);
+      }
+  const int nact = a.grid[st].dimf / 6;
   // inactive rows keep cond = 0 like data.cond.setZero() (:213)
   if (lane >= WR * nact && lane < WR * a.max_contacts) nr[a.nl.off[RTOC_CON_COND] + a.row0 + lane] = 0.0;
+  if (nact == 0) return;
+  double* const Gs = scratch;
+  double* const rs = scratch + 4 * CG::KS * LD;
+  for (int e = lane; e < 4 * CG::KS * LD; e += 64) Gs[e] = 0.0;
   cone_wave_sync();
-  for (int e = lane; e < nact * 36; e += 64) {
-    const int kk = e / 36, ww = e % 36, mm = ww % 6, nn = ww / 6, stack = kk * 6;
-    double acc = 0.0;
 #pragma unroll
-    for (int j = 0; j < WR; ++j) acc += J[kk][j + WR * mm] * (rr[kk][j] * J[kk][j + WR * nn]);
-    Qff[(stack + mm) + (size_t)(stack + nn) * NFP] += acc;  // (:226-227)
+  for (int p = 0; p < NJ; ++p) {  // the 17 x 6 cone matrix of contact k on the contact's own force columns
+    const int e = lane + 64 * p, k = e / (WR * 6), w = e % (WR * 6);
+    if (e < nact * WR * 6) Gs[(WR * k + w % WR) * LD + 6 * k + w / WR] = gj[p];
   }
-  if (lane < 6 * nact) {
-    const int kk = lane / 6, mm = lane % 6;
-    double acc = 0.0;
+  if (lane < 4 * CG::KS) {
+    const bool on = lane < WR * nact;
+    if (on) {
+      const double c = (dual * resid - cmpl) / slack;
+      nr[a.nl.off[RTOC_CON_COND] + rw] = c;  // computeCondensingCoeffcient<17> (:228)
+      Gs[lane * LD + NC] = c;
+    }
+    rs[lane] = on ? dual / slack : 0.0;  // (:224-225)
+  }
+  cone_wave_sync();
+  d4 acc[T][T];
+  cone_gram_tiles<K, NC>(Gs, rs, lane, acc, need);
 #pragma unroll
-    for (int j = 0; j < WR; ++j) acc += J[kk][j + WR * mm] * cond[kk][j];
-    lf[kk * 6 + mm] += acc;  // (:229-230)
-  }
+  for (int ta = 0; ta < T; ++ta)
+#pragma unroll
+    for (int tb = 0; tb < T; ++tb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int kc;
+        double* const p = target(16 * ta + drow(q, r), 16 * tb + li, kc);
+        if (p && kc < nact) *p = ce[ta][tb][r] + acc[ta][tb][r];
+      }
 }
 
 template <int NV, int NF>

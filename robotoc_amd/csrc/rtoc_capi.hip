@@ -766,6 +766,7 @@ static int launch_cones(rtoc_ctx* c, int phase, double tau) {  // 0 condense, 1 
   a.batch = c->batch;
   a.max_contacts = c->cone_contacts;
   a.contact_dim = c->cone_dim;
+  a.prof = nullptr;
   const bool wrench = c->cone_rows == RTOC_WRENCH_ROWS;
   a.rows_per_contact = c->cone_rows;
   a.row0 = c->dims.nc_max - c->cone_rows * c->cone_contacts;
