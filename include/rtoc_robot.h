@@ -1,0 +1,74 @@
+/* rtoc_robot.h -- rigid-body model table + batched linearisation of the contact / impact dynamics.
+ *
+ * What the reference's Robot gets from Pinocchio (include/robotoc/robot/robot.hxx:524-583 RNEA / RNEADerivatives /
+ * RNEAImpact / RNEAImpactDerivatives, :291-360 Baumgarte residual and derivatives, src/robot/point_contact.cpp,
+ * include/robotoc/robot/point_contact.hxx:14-140) restated for the device: one model table per context, every
+ * (instance, grid point) of RTOC_BUF_SOL linearised in one launch into the pre-condensation fields of RTOC_BUF_CDD.
+ * Pinocchio (3rd party, not vendored in the reference tree; robotoc's CMake asks for pinocchio >= 2.x) is absent here:
+ * the algorithm is Featherstone's recursive Newton-Euler in body coordinates ([linear; angular] spatial vectors,
+ * Pinocchio's convention), its partial derivatives by forward-mode differentiation of that recursion along the
+ * 3 nv tangent directions (q on the configuration manifold, v, a) -- parity with Pinocchio itself is UNPINNED
+ * (DESIGN.md); the derivatives are validated against finite differences of the CPU restatement.
+ *
+ * Conventions (Pinocchio's): q = [x y z qx qy qz qw, joint angles] for a floating base, v = [linear; angular] of the
+ * base in the BASE frame followed by joint rates; joints in depth-first order, children in name order (what
+ * pinocchio::urdf::buildModel produces; tools/urdf_to_model.py restates it).  3x3 matrices row-major.
+ */
+#ifndef RTOC_ROBOT_H_
+#define RTOC_ROBOT_H_
+
+#include "rtoc.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTOC_MAX_JOINTS 48
+#define RTOC_MAX_CONTACTS 8
+
+enum rtoc_joint_type { RTOC_JOINT_FREE_FLYER = 0, RTOC_JOINT_REVOLUTE = 1 };
+
+typedef struct rtoc_robot_model {
+  int njoints, nq, nv, ncontacts;
+  int parent[RTOC_MAX_JOINTS];             /* index of the parent joint, -1: the world; parent[i] < i                 */
+  int type[RTOC_MAX_JOINTS];               /* rtoc_joint_type; a free flyer only as joint 0                           */
+  int idx_q[RTOC_MAX_JOINTS];              /* first entry of the joint in q / v                                       */
+  int idx_v[RTOC_MAX_JOINTS];
+  double placement_R[RTOC_MAX_JOINTS][9];  /* joint frame in the parent joint's frame (pinocchio jointPlacements)     */
+  double placement_p[RTOC_MAX_JOINTS][3];
+  double axis[RTOC_MAX_JOINTS][3];         /* revolute: unit axis in the joint frame                                  */
+  double mass[RTOC_MAX_JOINTS];            /* body of the joint (links behind fixed joints welded in)                 */
+  double com[RTOC_MAX_JOINTS][3];          /* centre of mass in the joint frame                                       */
+  double inertia[RTOC_MAX_JOINTS][9];      /* rotational inertia about the centre of mass, joint-frame axes           */
+  int contact_parent[RTOC_MAX_CONTACTS];   /* point contacts (PointContact): joint the contact frame is attached to   */
+  double contact_R[RTOC_MAX_CONTACTS][9];  /* contact frame in that joint's frame (model.frames[id].placement)        */
+  double contact_p[RTOC_MAX_CONTACTS][3];
+  double contact_kp[RTOC_MAX_CONTACTS];    /* ContactModelInfo::baumgarte_position_gain / velocity_gain               */
+  double contact_kd[RTOC_MAX_CONTACTS];
+  double gravity[3];                       /* world frame, (0, 0, -9.81)                                              */
+} rtoc_robot_model;
+
+/* Copies the table to the device.  RTOC_ERR_BAD_ARG unless nv == dims.nv, nq is nv (fixed base) or nv + 1 (free-flyer
+ * root), joints are depth-first ordered, 3 * ncontacts <= dims.nf_max. */
+int rtoc_set_robot_model(rtoc_ctx* ctx, const rtoc_robot_model* model);
+
+/* Per grid point: bit k of active[i] = contact k is active (ContactStatus::isContactActive; on impact grids:
+ * ImpactStatus::isImpactActive), positions[i][k][0..2] = ContactStatus::contactPosition(k) (world frame; NULL: zeros).
+ * popcount(active[i]) * 3 must equal the grid's dimf. */
+int rtoc_set_contact_schedule(rtoc_ctx* ctx, const unsigned* active, const double* positions);
+
+/* linearizeContactDynamics (src/dynamics/contact_dynamics.cpp:12-33) on intermediate / lift grids and
+ * linearizeImpactDynamics (src/dynamics/impact_dynamics.cpp:12-27) on impact grids, for every (instance, grid point)
+ * but the terminal one: from RTOC_BUF_SOL (q, v, a | dv, f_stack, u) to RTOC_BUF_CDD
+ *   IDC      [ID; C]            ID = RNEA(q, v, a, f) - [0; u]        C = Baumgarte residual (impact: contact velocity)
+ *   DIDDA    dID/da  (= M(q); impact: dID/ddv)          DCDA   dC/da  (impact: unused, dC/dv is in DIDCDQV)
+ *   DIDCDQV  [dID/dq dID/dv; dC/dq dC/dv]
+ * i.e. everything computeMJtJinv / condenseContactDynamics read.  The augmentation of the KKT residual with the
+ * multipliers (contact_dynamics.cpp:35-52) is linear in these fields and stays with the cost derivatives on the
+ * caller's side. */
+int rtoc_linearize_contact_dynamics(rtoc_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

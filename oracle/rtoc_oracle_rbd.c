@@ -1,0 +1,429 @@
+/*
+ * rtoc_oracle_rbd.c -- CPU restatement of the rigid-body side of robotoc's evalKKT (TEST INFRASTRUCTURE ONLY: the
+ * checker of rtoc_linearize_contact_dynamics; nothing in robotoc_amd/ may call it -- see rtoc_oracle.c for the rules).
+ *
+ * PARITY UNPINNED for this file: the reference delegates these functions to Pinocchio (third party, not in
+ * /root/reference, not installed here), so there is nothing to compile or import to pin them against.  What is
+ * restated, from the reference's call sites:
+ *   Robot::RNEA / RNEAImpact                  include/robotoc/robot/robot.hxx:524-546, 590-600 (pinocchio::rnea with
+ *                                             external forces in the joint frames; the impact model has zero gravity, v = 0)
+ *   Robot::setContactForces                   robot.hxx:455-517, PointContact::computeJointForceFromContactForce
+ *                                             (src/robot/point_contact.cpp:55-60: force given in the LOCAL contact frame)
+ *   PointContact::computeBaumgarteResidual    include/robotoc/robot/point_contact.hxx:14-31 (classical LOCAL linear
+ *                                             acceleration + kd * LOCAL linear velocity + kp * (world position - desired))
+ *   PointContact::computeContactVelocityResidual  point_contact.hxx:84-92 (impact grids; kinematics at v + dv,
+ *                                             src/ocp/impact_stage.cpp:61)
+ *   evalContactDynamics / evalImpactDynamics  src/dynamics/contact_dynamics.cpp:12-20, impact_dynamics.cpp:8-14
+ *   pinocchio::integrate                      q (+) dq on the configuration manifold (SE(3) exponential on a free-flyer root)
+ * Algorithm: Featherstone's recursive Newton-Euler in body coordinates, spatial vectors [linear; angular] as in Pinocchio.
+ * Derivatives: central finite differences of the above on the manifold (orc_rbd_linearize_fd) -- the device computes
+ * them analytically; agreement to ~1e-7 relative is the check.  Independent sanity checks of THIS file live in
+ * tests/test_rigid_body.py (composite-rigid-body mass matrix, Newton-Euler of the welded robot, Lagrange's equations
+ * on the fixed-base arm).
+ */
+#include <math.h>
+#include <string.h>
+
+#include "../include/rtoc_robot.h"
+
+typedef struct { double l[3], a[3]; } sv6; /* spatial motion or force: linear, angular */
+
+static void cross3(const double* x, const double* y, double* z) {
+  const double z0 = x[1] * y[2] - x[2] * y[1], z1 = x[2] * y[0] - x[0] * y[2], z2 = x[0] * y[1] - x[1] * y[0];
+  z[0] = z0, z[1] = z1, z[2] = z2;
+}
+static void mat3_mul(const double* A, const double* B, double* C) { /* row-major 3x3 */
+  double t[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) t[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+  memcpy(C, t, sizeof t);
+}
+static void mat3_vec(const double* A, const double* x, double* y) {
+  const double y0 = A[0] * x[0] + A[1] * x[1] + A[2] * x[2], y1 = A[3] * x[0] + A[4] * x[1] + A[5] * x[2],
+               y2 = A[6] * x[0] + A[7] * x[1] + A[8] * x[2];
+  y[0] = y0, y[1] = y1, y[2] = y2;
+}
+static void mat3t_vec(const double* A, const double* x, double* y) {
+  const double y0 = A[0] * x[0] + A[3] * x[1] + A[6] * x[2], y1 = A[1] * x[0] + A[4] * x[1] + A[7] * x[2],
+               y2 = A[2] * x[0] + A[5] * x[1] + A[8] * x[2];
+  y[0] = y0, y[1] = y1, y[2] = y2;
+}
+static void rodrigues(const double* axis, double th, double* R) { /* exp(th [axis]x), unit axis */
+  const double c = cos(th), s = sin(th), t = 1.0 - c, x = axis[0], y = axis[1], z = axis[2];
+  R[0] = t * x * x + c, R[1] = t * x * y - s * z, R[2] = t * x * z + s * y;
+  R[3] = t * x * y + s * z, R[4] = t * y * y + c, R[5] = t * y * z - s * x;
+  R[6] = t * x * z - s * y, R[7] = t * y * z + s * x, R[8] = t * z * z + c;
+}
+static void quat_to_R(const double* q, double* R) { /* (x, y, z, w), unit */
+  const double x = q[0], y = q[1], z = q[2], w = q[3];
+  R[0] = 1 - 2 * (y * y + z * z), R[1] = 2 * (x * y - z * w), R[2] = 2 * (x * z + y * w);
+  R[3] = 2 * (x * y + z * w), R[4] = 1 - 2 * (x * x + z * z), R[5] = 2 * (y * z - x * w);
+  R[6] = 2 * (x * z - y * w), R[7] = 2 * (y * z + x * w), R[8] = 1 - 2 * (x * x + y * y);
+}
+
+/* m' = X^-1 m for X = (R, p): child-frame coordinates of a parent-frame motion (SE3::actInv on a Motion) */
+static void motion_act_inv(const double* R, const double* p, const sv6* m, sv6* out) {
+  double t[3], pxw[3];
+  cross3(p, m->a, pxw);
+  for (int k = 0; k < 3; ++k) t[k] = m->l[k] - pxw[k];
+  sv6 r;
+  mat3t_vec(R, t, r.l);
+  mat3t_vec(R, m->a, r.a);
+  *out = r;
+}
+/* f' = X f: parent-frame coordinates of a child-frame force (SE3::act on a Force) */
+static void force_act(const double* R, const double* p, const sv6* f, sv6* out) {
+  sv6 r;
+  double pxf[3];
+  mat3_vec(R, f->l, r.l);
+  mat3_vec(R, f->a, r.a);
+  cross3(p, r.l, pxf);
+  for (int k = 0; k < 3; ++k) r.a[k] += pxf[k];
+  *out = r;
+}
+static void motion_cross(const sv6* v, const sv6* m, sv6* out) { /* v x m */
+  sv6 r;
+  double t[3];
+  cross3(v->a, m->l, r.l);
+  cross3(v->l, m->a, t);
+  for (int k = 0; k < 3; ++k) r.l[k] += t[k];
+  cross3(v->a, m->a, r.a);
+  *out = r;
+}
+static void force_cross(const sv6* v, const sv6* f, sv6* out) { /* v x* f */
+  sv6 r;
+  double t[3];
+  cross3(v->a, f->l, r.l);
+  cross3(v->a, f->a, r.a);
+  cross3(v->l, f->l, t);
+  for (int k = 0; k < 3; ++k) r.a[k] += t[k];
+  *out = r;
+}
+static void inertia_mul(double mass, const double* c, const double* I, const sv6* v, sv6* out) { /* Y v */
+  sv6 r;
+  double cxw[3], Iw[3], cxf[3];
+  cross3(c, v->a, cxw);
+  for (int k = 0; k < 3; ++k) r.l[k] = mass * (v->l[k] - cxw[k]);
+  mat3_vec(I, v->a, Iw);
+  cross3(c, r.l, cxf);
+  for (int k = 0; k < 3; ++k) r.a[k] = Iw[k] + cxf[k];
+  *out = r;
+}
+
+typedef struct {
+  double R[RTOC_MAX_JOINTS][9], p[RTOC_MAX_JOINTS][3];   /* joint frame in the parent joint frame (placement * joint motion) */
+  double oR[RTOC_MAX_JOINTS][9], op[RTOC_MAX_JOINTS][3]; /* joint frame in the world */
+  sv6 v[RTOC_MAX_JOINTS], a[RTOC_MAX_JOINTS];            /* spatial velocity, acceleration (no gravity), body coordinates */
+} rbd_kin;
+
+/* forwardKinematics(q, v, a) */
+static void kinematics(const rtoc_robot_model* m, const double* q, const double* v, const double* a, rbd_kin* k) {
+  for (int i = 0; i < m->njoints; ++i) {
+    double Rj[9], pj[3] = {0, 0, 0};
+    sv6 vj, aj;
+    memset(&vj, 0, sizeof vj);
+    memset(&aj, 0, sizeof aj);
+    const int iq = m->idx_q[i], iv = m->idx_v[i];
+    if (m->type[i] == RTOC_JOINT_FREE_FLYER) {
+      quat_to_R(q + iq + 3, Rj);
+      memcpy(pj, q + iq, sizeof pj);
+      for (int c = 0; c < 3; ++c) vj.l[c] = v[iv + c], vj.a[c] = v[iv + 3 + c], aj.l[c] = a[iv + c], aj.a[c] = a[iv + 3 + c];
+    } else {
+      rodrigues(m->axis[i], q[iq], Rj);
+      for (int c = 0; c < 3; ++c) vj.a[c] = m->axis[i][c] * v[iv], aj.a[c] = m->axis[i][c] * a[iv];
+    }
+    mat3_mul(m->placement_R[i], Rj, k->R[i]);
+    mat3_vec(m->placement_R[i], pj, k->p[i]);
+    for (int c = 0; c < 3; ++c) k->p[i][c] += m->placement_p[i][c];
+    const int par = m->parent[i];
+    if (par < 0) {
+      memcpy(k->oR[i], k->R[i], sizeof k->R[i]);
+      memcpy(k->op[i], k->p[i], sizeof k->p[i]);
+      k->v[i] = vj;
+      k->a[i] = aj;
+    } else {
+      double t[3];
+      mat3_mul(k->oR[par], k->R[i], k->oR[i]);
+      mat3_vec(k->oR[par], k->p[i], t);
+      for (int c = 0; c < 3; ++c) k->op[i][c] = k->op[par][c] + t[c];
+      sv6 vp, ap, cx;
+      motion_act_inv(k->R[i], k->p[i], &k->v[par], &vp);
+      motion_act_inv(k->R[i], k->p[i], &k->a[par], &ap);
+      for (int c = 0; c < 3; ++c) k->v[i].l[c] = vp.l[c] + vj.l[c], k->v[i].a[c] = vp.a[c] + vj.a[c];
+      motion_cross(&k->v[i], &vj, &cx);
+      for (int c = 0; c < 3; ++c) k->a[i].l[c] = ap.l[c] + aj.l[c] + cx.l[c], k->a[i].a[c] = ap.a[c] + aj.a[c] + cx.a[c];
+    }
+  }
+}
+
+/* tau = rnea(q, v, a, fext), fext[i] in the frame of joint i; gravity[] in the world frame */
+static void rnea(const rtoc_robot_model* m, const rbd_kin* k, const double* gravity, const sv6* fext, double* tau) {
+  sv6 f[RTOC_MAX_JOINTS];
+  for (int i = 0; i < m->njoints; ++i) {
+    sv6 ag = k->a[i], h, t;
+    double g[3];
+    mat3t_vec(k->oR[i], gravity, g); /* the gravity field is a uniform acceleration: a_gf = a - R^T g */
+    for (int c = 0; c < 3; ++c) ag.l[c] -= g[c];
+    inertia_mul(m->mass[i], m->com[i], m->inertia[i], &ag, &f[i]);
+    inertia_mul(m->mass[i], m->com[i], m->inertia[i], &k->v[i], &h);
+    force_cross(&k->v[i], &h, &t);
+    for (int c = 0; c < 3; ++c) f[i].l[c] += t.l[c] - fext[i].l[c], f[i].a[c] += t.a[c] - fext[i].a[c];
+  }
+  for (int i = m->njoints - 1; i >= 0; --i) {
+    const int iv = m->idx_v[i];
+    if (m->type[i] == RTOC_JOINT_FREE_FLYER) {
+      for (int c = 0; c < 3; ++c) tau[iv + c] = f[i].l[c], tau[iv + 3 + c] = f[i].a[c];
+    } else {
+      tau[iv] = m->axis[i][0] * f[i].a[0] + m->axis[i][1] * f[i].a[1] + m->axis[i][2] * f[i].a[2];
+    }
+    if (m->parent[i] >= 0) {
+      sv6 t;
+      force_act(k->R[i], k->p[i], &f[i], &t);
+      for (int c = 0; c < 3; ++c) f[m->parent[i]].l[c] += t.l[c], f[m->parent[i]].a[c] += t.a[c];
+    }
+  }
+}
+
+/* q (+) scale * dq */
+void orc_rbd_integrate(const rtoc_robot_model* m, const double* q, const double* dq, double scale, double* qout) {
+  for (int i = 0; i < m->njoints; ++i) {
+    const int iq = m->idx_q[i], iv = m->idx_v[i];
+    if (m->type[i] != RTOC_JOINT_FREE_FLYER) {
+      qout[iq] = q[iq] + scale * dq[iv];
+      continue;
+    }
+    /* M <- M exp6(dq): rotation exp(w), translation V(w) v, V = I + (1-cos t)/t^2 [w]x + (t - sin t)/t^3 [w]x^2 */
+    double vl[3], w[3], R[9], E[9], Vv[3], wxv[3], wxwxv[3], t[3];
+    for (int c = 0; c < 3; ++c) vl[c] = scale * dq[iv + c], w[c] = scale * dq[iv + 3 + c];
+    const double th = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+    double A, B;
+    if (th < 1e-8) {
+      A = 0.5, B = 1.0 / 6.0;
+    } else {
+      A = (1.0 - cos(th)) / (th * th), B = (th - sin(th)) / (th * th * th);
+    }
+    cross3(w, vl, wxv);
+    cross3(w, wxv, wxwxv);
+    for (int c = 0; c < 3; ++c) Vv[c] = vl[c] + A * wxv[c] + B * wxwxv[c];
+    quat_to_R(q + iq + 3, R);
+    mat3_vec(R, Vv, t);
+    for (int c = 0; c < 3; ++c) qout[iq + c] = q[iq + c] + t[c];
+    /* quaternion of exp(w): (sin(t/2)/t w, cos(t/2)) */
+    const double s = th < 1e-8 ? 0.5 - th * th / 48.0 : sin(0.5 * th) / th, cw = cos(0.5 * th);
+    const double e[4] = {s * w[0], s * w[1], s * w[2], cw};
+    const double* a = q + iq + 3;
+    double r[4];
+    r[0] = a[3] * e[0] + a[0] * e[3] + a[1] * e[2] - a[2] * e[1];
+    r[1] = a[3] * e[1] - a[0] * e[2] + a[1] * e[3] + a[2] * e[0];
+    r[2] = a[3] * e[2] + a[0] * e[1] - a[1] * e[0] + a[2] * e[3];
+    r[3] = a[3] * e[3] - a[0] * e[0] - a[1] * e[1] - a[2] * e[2];
+    const double n = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3]);
+    for (int c = 0; c < 4; ++c) qout[iq + 3 + c] = r[c] / n;
+    (void)E;
+  }
+}
+
+static int popcount_(unsigned x) {
+  int n = 0;
+  for (; x; x &= x - 1) ++n;
+  return n;
+}
+
+/* [ID; C] of evalContactDynamics (impact = 0: a = s.a) / evalImpactDynamics (impact = 1: a = s.dv).
+ * fstack: forces of the ACTIVE contacts, 3 each, local contact frames; u: nu = nv - 6 (floating base) or nv joint torques
+ * (impact: ignored); pref[k][3]: desired world position of contact k.  Returns dimf. */
+int orc_rbd_eval(const rtoc_robot_model* m, int impact, const double* q, const double* v, const double* a,
+                 const double* fstack, const double* u, unsigned active, const double* pref, double* IDC) {
+  static const double zero[3] = {0, 0, 0};
+  double vz[RTOC_MAX_JOINTS + 6], vk[RTOC_MAX_JOINTS + 6];
+  memset(vz, 0, sizeof vz);
+  rbd_kin kd, kk;
+  /* dynamics: impact model = zero gravity, zero velocity, acceleration = dv (robot.hxx:590-600) */
+  kinematics(m, q, impact ? vz : v, a, &kd);
+  /* kinematics of the contact frames: at v + dv on impact grids (impact_stage.cpp:61) */
+  for (int i = 0; i < m->nv; ++i) vk[i] = impact ? v[i] + a[i] : v[i];
+  kinematics(m, q, vk, impact ? vz : a, &kk);
+  sv6 fext[RTOC_MAX_JOINTS];
+  memset(fext, 0, sizeof fext);
+  int nact = 0;
+  for (int c = 0; c < m->ncontacts; ++c) {
+    if (!((active >> c) & 1u)) continue;
+    sv6 fc, fj;
+    memcpy(fc.l, fstack + 3 * nact, sizeof fc.l);
+    memset(fc.a, 0, sizeof fc.a);
+    force_act(m->contact_R[c], m->contact_p[c], &fc, &fj);
+    const int j = m->contact_parent[c];
+    for (int t = 0; t < 3; ++t) fext[j].l[t] += fj.l[t], fext[j].a[t] += fj.a[t];
+    ++nact;
+  }
+  rnea(m, &kd, impact ? zero : m->gravity, fext, IDC);
+  if (!impact) {
+    const int nu = (m->type[0] == RTOC_JOINT_FREE_FLYER) ? m->nv - 6 : m->nv;
+    for (int i = 0; i < nu; ++i) IDC[m->nv - nu + i] -= u[i];
+  }
+  nact = 0;
+  for (int c = 0; c < m->ncontacts; ++c) {
+    if (!((active >> c) & 1u)) continue;
+    const int j = m->contact_parent[c];
+    sv6 vf, af;
+    motion_act_inv(m->contact_R[c], m->contact_p[c], &kk.v[j], &vf);
+    motion_act_inv(m->contact_R[c], m->contact_p[c], &kk.a[j], &af);
+    double* C = IDC + m->nv + 3 * nact;
+    if (impact) {
+      for (int t = 0; t < 3; ++t) C[t] = vf.l[t];
+    } else {
+      double wxv[3], Rf[9], pw[3], t3[3];
+      cross3(vf.a, vf.l, wxv); /* classical acceleration = spatial + w x v */
+      mat3_mul(kk.oR[j], m->contact_R[c], Rf);
+      mat3_vec(kk.oR[j], m->contact_p[c], t3);
+      for (int t = 0; t < 3; ++t) pw[t] = kk.op[j][t] + t3[t];
+      (void)Rf;
+      for (int t = 0; t < 3; ++t)
+        C[t] = af.l[t] + wxv[t] + m->contact_kd[c] * vf.l[t] + m->contact_kp[c] * (pw[t] - pref[3 * c + t]);
+    }
+    ++nact;
+  }
+  return 3 * popcount_(active);
+}
+
+/* Central differences of orc_rbd_eval along the 3 nv tangent directions: D* are (nv + dimf) x nv, column-major with
+ * leading dimension ld.  impact: Dv = d/dv (kinematics only), Da = d/d(dv). */
+void orc_rbd_linearize_fd(const rtoc_robot_model* m, int impact, const double* q, const double* v, const double* a,
+                          const double* fstack, const double* u, unsigned active, const double* pref, double eps,
+                          double* Dq, double* Dv, double* Da, int ld) {
+  const int nv = m->nv, n = nv + 3 * popcount_(active);
+  double qp[RTOC_MAX_JOINTS + 8], xp[RTOC_MAX_JOINTS + 6], e[RTOC_MAX_JOINTS + 6], rp[2 * RTOC_MAX_JOINTS], rm[2 * RTOC_MAX_JOINTS];
+  for (int j = 0; j < nv; ++j) {
+    memset(e, 0, sizeof e);
+    e[j] = 1.0;
+    orc_rbd_integrate(m, q, e, eps, qp);
+    orc_rbd_eval(m, impact, qp, v, a, fstack, u, active, pref, rp);
+    orc_rbd_integrate(m, q, e, -eps, qp);
+    orc_rbd_eval(m, impact, qp, v, a, fstack, u, active, pref, rm);
+    for (int i = 0; i < n; ++i) Dq[i + (size_t)j * ld] = (rp[i] - rm[i]) / (2 * eps);
+    memcpy(xp, v, sizeof(double) * nv);
+    xp[j] = v[j] + eps;
+    orc_rbd_eval(m, impact, q, xp, a, fstack, u, active, pref, rp);
+    xp[j] = v[j] - eps;
+    orc_rbd_eval(m, impact, q, xp, a, fstack, u, active, pref, rm);
+    for (int i = 0; i < n; ++i) Dv[i + (size_t)j * ld] = (rp[i] - rm[i]) / (2 * eps);
+    memcpy(xp, a, sizeof(double) * nv);
+    xp[j] = a[j] + eps;
+    orc_rbd_eval(m, impact, q, v, xp, fstack, u, active, pref, rp);
+    xp[j] = a[j] - eps;
+    orc_rbd_eval(m, impact, q, v, xp, fstack, u, active, pref, rm);
+    for (int i = 0; i < n; ++i) Da[i + (size_t)j * ld] = (rp[i] - rm[i]) / (2 * eps);
+  }
+}
+
+/* ---- independent cross-checks of the recursion above (used by tests/test_rigid_body.py only) ---- */
+
+/* Composite-rigid-body mass matrix in WORLD coordinates: M = sum_i J_i^T Y_i J_i with the world-frame spatial
+ * Jacobians of the bodies -- none of the body-frame transforms of rnea() is reused. */
+void orc_rbd_mass_matrix_world(const rtoc_robot_model* m, const double* q, double* M /* nv x nv col-major */) {
+  const int nv = m->nv;
+  double vz[RTOC_MAX_JOINTS + 6];
+  memset(vz, 0, sizeof vz);
+  rbd_kin k;
+  kinematics(m, q, vz, vz, &k);
+  memset(M, 0, sizeof(double) * nv * nv);
+  /* world-frame unit twists of every dof: linear part at the world origin */
+  double S[RTOC_MAX_JOINTS + 6][6];
+  for (int i = 0; i < m->njoints; ++i) {
+    const int iv = m->idx_v[i];
+    if (m->type[i] == RTOC_JOINT_FREE_FLYER) {
+      for (int c = 0; c < 3; ++c) {
+        double e[3] = {0, 0, 0}, w[3], pxw[3];
+        e[c] = 1.0;
+        mat3_vec(k.oR[i], e, w);
+        for (int t = 0; t < 3; ++t) S[iv + c][t] = w[t], S[iv + c][3 + t] = 0.0; /* translation along a base axis */
+        cross3(k.op[i], w, pxw);
+        for (int t = 0; t < 3; ++t) S[iv + 3 + c][t] = pxw[t], S[iv + 3 + c][3 + t] = w[t]; /* rotation about a base axis through the base origin */
+      }
+    } else {
+      double w[3], pxw[3];
+      mat3_vec(k.oR[i], m->axis[i], w);
+      cross3(k.op[i], w, pxw);
+      for (int t = 0; t < 3; ++t) S[iv][t] = pxw[t], S[iv][3 + t] = w[t];
+    }
+  }
+  for (int b = 0; b < m->njoints; ++b) {
+    /* world inertia of body b: mass, world com, world rotational inertia */
+    double cw[3], Iw[9], t9[9], Rt[9];
+    mat3_vec(k.oR[b], m->com[b], cw);
+    for (int t = 0; t < 3; ++t) cw[t] += k.op[b][t];
+    mat3_mul(k.oR[b], m->inertia[b], t9);
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) Rt[3 * r + c] = k.oR[b][3 * c + r];
+    mat3_mul(t9, Rt, Iw);
+    /* dofs that move body b: its ancestors' (and its own) */
+    for (int i = b; i >= 0; i = m->parent[i]) {
+      const int ni = m->type[i] == RTOC_JOINT_FREE_FLYER ? 6 : 1;
+      for (int ci = 0; ci < ni; ++ci) {
+        const double* si = S[m->idx_v[i] + ci];
+        /* velocity of the com and angular velocity for unit rate of dof i */
+        double vi[3], wxc[3];
+        cross3(si + 3, cw, wxc);
+        for (int t = 0; t < 3; ++t) vi[t] = si[t] + wxc[t];
+        for (int j = b; j >= 0; j = m->parent[j]) {
+          const int nj = m->type[j] == RTOC_JOINT_FREE_FLYER ? 6 : 1;
+          for (int cj = 0; cj < nj; ++cj) {
+            const double* sj = S[m->idx_v[j] + cj];
+            double vj[3], wxc2[3], Iwj[3];
+            cross3(sj + 3, cw, wxc2);
+            for (int t = 0; t < 3; ++t) vj[t] = sj[t] + wxc2[t];
+            mat3_vec(Iw, sj + 3, Iwj);
+            M[(m->idx_v[i] + ci) + (size_t)(m->idx_v[j] + cj) * nv] +=
+                m->mass[b] * (vi[0] * vj[0] + vi[1] * vj[1] + vi[2] * vj[2]) + si[3] * Iwj[0] + si[4] * Iwj[1] + si[5] * Iwj[2];
+          }
+        }
+      }
+    }
+  }
+}
+
+/* kinetic + potential energy in world coordinates (for the Lagrange-equation check on fixed-base models) */
+double orc_rbd_energy(const rtoc_robot_model* m, const double* q, const double* v, double* potential) {
+  double az[RTOC_MAX_JOINTS + 6];
+  memset(az, 0, sizeof az);
+  rbd_kin k;
+  kinematics(m, q, v, az, &k);
+  double T = 0.0, U = 0.0;
+  for (int b = 0; b < m->njoints; ++b) {
+    sv6 h;
+    inertia_mul(m->mass[b], m->com[b], m->inertia[b], &k.v[b], &h);
+    for (int t = 0; t < 3; ++t) T += 0.5 * (h.l[t] * k.v[b].l[t] + h.a[t] * k.v[b].a[t]);
+    double cw[3];
+    mat3_vec(k.oR[b], m->com[b], cw);
+    for (int t = 0; t < 3; ++t) U -= m->mass[b] * m->gravity[t] * (cw[t] + k.op[b][t]);
+  }
+  if (potential) *potential = U;
+  return T;
+}
+
+/* total spatial momentum about the world origin, world coordinates: h = sum_b oX_b* (Y_b v_b) */
+void orc_rbd_momentum_world(const rtoc_robot_model* m, const double* q, const double* v, double* h6) {
+  double az[RTOC_MAX_JOINTS + 6];
+  memset(az, 0, sizeof az);
+  rbd_kin k;
+  kinematics(m, q, v, az, &k);
+  memset(h6, 0, 6 * sizeof(double));
+  for (int b = 0; b < m->njoints; ++b) {
+    sv6 h, hw;
+    inertia_mul(m->mass[b], m->com[b], m->inertia[b], &k.v[b], &h);
+    force_act(k.oR[b], k.op[b], &h, &hw);
+    for (int t = 0; t < 3; ++t) h6[t] += hw.l[t], h6[3 + t] += hw.a[t];
+  }
+}
+
+/* world position of contact frame c */
+void orc_rbd_contact_position(const rtoc_robot_model* m, const double* q, int c, double* pw) {
+  double z[RTOC_MAX_JOINTS + 6];
+  memset(z, 0, sizeof z);
+  rbd_kin k;
+  kinematics(m, q, z, z, &k);
+  const int j = m->contact_parent[c];
+  double t3[3];
+  mat3_vec(k.oR[j], m->contact_p[c], t3);
+  for (int t = 0; t < 3; ++t) pw[t] = k.op[j][t] + t3[t];
+}

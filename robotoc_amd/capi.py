@@ -26,6 +26,7 @@ EXPORTS = [
     "rtoc_riccati_sweep", "rtoc_correct_state_equation", "rtoc_correct_costate_direction",
     "rtoc_compute_initial_state_direction", "rtoc_unconstr_condense", "rtoc_unconstr_expand",
     "rtoc_newton_iteration", "rtoc_converged_count", "rtoc_clone", "rtoc_check_fxx_structure", "rtoc_sto_eval_kkt", "rtoc_set_friction_cones", "rtoc_set_wrench_cones", "rtoc_wrench_cone_matrix", "rtoc_save_stage_dump", "rtoc_load_stage_dump", "rtoc_kkt_error", "rtoc_integrate_solution",
+    "rtoc_set_robot_model", "rtoc_set_contact_schedule", "rtoc_linearize_contact_dynamics",
 ]
 
 
@@ -91,7 +92,7 @@ def lib():
         for f in ("rtoc_condense", "rtoc_riccati_backward", "rtoc_riccati_forward", "rtoc_riccati_sweep", "rtoc_update",
                   "rtoc_correct_state_equation", "rtoc_correct_costate_direction",
                   "rtoc_compute_initial_state_direction", "rtoc_unconstr_condense", "rtoc_integrate_solution",
-                  "rtoc_clear_status", "rtoc_sync"):
+                  "rtoc_linearize_contact_dynamics", "rtoc_clear_status", "rtoc_sync"):
             getattr(L, f).argtypes = [vp]
         L.rtoc_unconstr_backward.argtypes = [vp, C.c_double]
         L.rtoc_unconstr_forward.argtypes = [vp, C.c_double]
@@ -111,6 +112,8 @@ def lib():
         L.rtoc_check_fxx_structure.argtypes = [vp, C.POINTER(C.c_int)]
         L.rtoc_sto_eval_kkt.argtypes = [vp, dp, dp, C.c_int, dp, C.c_int]
         L.rtoc_clone.argtypes = [vp, C.POINTER(vp)]
+        L.rtoc_set_robot_model.argtypes = [vp, vp]
+        L.rtoc_set_contact_schedule.argtypes = [vp, C.POINTER(C.c_uint), dp]
         L.rtoc_load_stage_dump.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
         L.rtoc_error_string.argtypes = [C.c_int]
         L.rtoc_error_string.restype = C.c_char_p
@@ -292,6 +295,25 @@ class Context:
 
     def integrate_solution(self):
         _chk(lib().rtoc_integrate_solution(self._h))
+
+    # ---- rigid-body linearisation (include/rtoc_robot.h) ----
+    def set_robot_model(self, model):
+        """rtoc_set_robot_model: `model` = robotoc_amd.robot_model.RobotModel"""
+        _chk(lib().rtoc_set_robot_model(self._h, C.byref(model)))
+        self._model_ncontacts = model.ncontacts
+
+    def set_contact_schedule(self, active, positions=None):
+        """rtoc_set_contact_schedule: active [nstages] bit masks, positions [nstages, ncontacts, 3] or None"""
+        act = np.ascontiguousarray(active, dtype=np.uint32)
+        assert act.shape == (self.nstages,)
+        pos = None
+        if positions is not None:
+            pos = np.ascontiguousarray(positions, dtype=np.float64)
+            assert pos.shape == (self.nstages, self._model_ncontacts, 3)
+        _chk(lib().rtoc_set_contact_schedule(self._h, act.ctypes.data_as(C.POINTER(C.c_uint)), _dp(pos) if pos is not None else None))
+
+    def linearize_contact_dynamics(self):
+        _chk(lib().rtoc_linearize_contact_dynamics(self._h))
 
     def kkt_error(self):
         """rtoc_kkt_error: sqrt of the squared KKT residual of every instance."""

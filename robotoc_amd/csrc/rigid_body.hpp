@@ -1,0 +1,351 @@
+// rigid_body.hpp -- batched linearisation of the contact / impact dynamics.
+//
+// Replaces, per (instance, grid point): Robot::RNEA / RNEADerivatives / RNEAImpact / RNEAImpactDerivatives (reference
+// include/robotoc/robot/robot.hxx:524-624, thin wrappers over pinocchio::rnea / computeRNEADerivatives), setContactForces
+// (:455-517), computeBaumgarteResidual / Derivatives (:291-360 -> point_contact.hxx:14-83) and computeImpactVelocity
+// Residual / Derivatives (point_contact.hxx:84-117), i.e. linearizeContactDynamics (src/dynamics/contact_dynamics.cpp:12-33)
+// and linearizeImpactDynamics (impact_dynamics.cpp:8-27) up to the multiplier terms.
+//
+// Mapping: one wave per grid point, one LANE per tangent direction (dof j, kind in {q, v, a}): 21 dofs per pass.  Every
+// lane walks the kinematic tree depth first and carries the forward-mode derivative of Featherstone's recursive
+// Newton-Euler along its direction:
+//     v_i = X v_p + S vq                      dv_i = X dv_p - [own q] S_k x (X v_p) + [own v] S_k
+//     a_i = X a_p + S aq + v_i x S vq         da_i = X da_p - [own q] S_k x (X a_p) + [own a] S_k + dv_i x S vq + [own v] v_i x S_k
+//     f_i = Y (a_i + g_i) + v_i x* Y v_i - fext_i
+//     f_p += X* f_i                           df_p += X* df_i + [own q] X* (S_k x* f_i)          tau_i = S^T f_i
+// (d(X m)/dq_k = -S_k x (X m), d(X* f)/dq_k = X* (S_k x* f) for the joint's own coordinate k; q perturbed on the
+// manifold, q (+) dq: local translation / rotation of a free-flyer root.)  The VALUES are the same in every lane and
+// live once per tree level in LDS; the TANGENTS (dv, da, dg, df: 21 doubles) live per lane and level in LDS,
+// lane-strided (conflict-free).  Only the current root-to-body path is live: LDS = levels x (21 x 64 + ~60) doubles.
+// The contact rows ride on the visit of the body that carries the frame; d(position)/dq = R_of * (frame Jacobian), whose
+// column j is the v-tangent of the frame velocity -- held by the neighbouring lane (point_contact.hxx:78-80).
+#pragma once
+#include "device_utils.hpp"
+#include "../../include/rtoc_robot.h"
+
+namespace rtoc {
+namespace rbd {
+
+struct DevModel {
+  rtoc_robot_model m;
+  int depth[RTOC_MAX_JOINTS];
+  int nlevels;
+};
+
+struct V3 {
+  double x, y, z;
+};
+struct SV {  // spatial motion or force: linear, angular
+  V3 l, a;
+};
+__device__ __forceinline__ V3 mk(double x, double y, double z) { return V3{x, y, z}; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator*(double s, V3 a) { return mk(s * a.x, s * a.y, s * a.z); }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) { return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+__device__ __forceinline__ double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ SV operator+(SV a, SV b) { return SV{a.l + b.l, a.a + b.a}; }
+__device__ __forceinline__ SV operator-(SV a, SV b) { return SV{a.l - b.l, a.a - b.a}; }
+__device__ __forceinline__ SV sv0() { return SV{mk(0, 0, 0), mk(0, 0, 0)}; }
+
+struct M3 {  // row-major
+  double m[9];
+};
+__device__ __forceinline__ V3 mul(const M3& R, V3 v) {
+  return mk(R.m[0] * v.x + R.m[1] * v.y + R.m[2] * v.z, R.m[3] * v.x + R.m[4] * v.y + R.m[5] * v.z,
+            R.m[6] * v.x + R.m[7] * v.y + R.m[8] * v.z);
+}
+__device__ __forceinline__ V3 mulT(const M3& R, V3 v) {
+  return mk(R.m[0] * v.x + R.m[3] * v.y + R.m[6] * v.z, R.m[1] * v.x + R.m[4] * v.y + R.m[7] * v.z,
+            R.m[2] * v.x + R.m[5] * v.y + R.m[8] * v.z);
+}
+__device__ __forceinline__ M3 mul(const M3& A, const M3& B) {
+  M3 C;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) C.m[3 * i + j] = A.m[3 * i] * B.m[j] + A.m[3 * i + 1] * B.m[3 + j] + A.m[3 * i + 2] * B.m[6 + j];
+  return C;
+}
+// child-frame coordinates of a parent-frame motion, X = (R, p)
+__device__ __forceinline__ SV act_inv(const M3& R, V3 p, SV m) { return SV{mulT(R, m.l - cross(p, m.a)), mulT(R, m.a)}; }
+// parent-frame coordinates of a child-frame force
+__device__ __forceinline__ SV act_f(const M3& R, V3 p, SV f) {
+  const V3 l = mul(R, f.l);
+  return SV{l, mul(R, f.a) + cross(p, l)};
+}
+__device__ __forceinline__ SV mcross(SV v, SV m) { return SV{cross(v.a, m.l) + cross(v.l, m.a), cross(v.a, m.a)}; }   // v x m
+__device__ __forceinline__ SV fcross(SV v, SV f) { return SV{cross(v.a, f.l), cross(v.a, f.a) + cross(v.l, f.l)}; }   // v x* f
+__device__ __forceinline__ SV inertia_mul(double mass, V3 c, const M3& I, SV v) {
+  const V3 l = mass * (v.l - cross(c, v.a));
+  return SV{l, mul(I, v.a) + cross(c, l)};
+}
+__device__ __forceinline__ M3 ldm3(const double* p) {
+  M3 r;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) r.m[i] = p[i];
+  return r;
+}
+__device__ __forceinline__ V3 ldv3(const double* p) { return mk(p[0], p[1], p[2]); }
+
+struct LinArgs {
+  const DevModel* model;
+  const double* sol;
+  double* cdd;
+  const rtoc_grid* grid;
+  const unsigned* active;    // [nstages]
+  const double* positions;   // [nstages][ncontacts][3] or nullptr
+  int nstages, batch;
+  int sol_stride, cdd_stride;
+  int o_q, o_v, o_a, o_u, o_f;                 // RTOC_BUF_SOL field offsets
+  int o_idc, o_didda, o_dcda, o_didcdqv;       // RTOC_BUF_CDD field offsets
+  int ldv, nf_max;                             // leading dimensions of DIDCDQV / DCDA
+};
+
+// per-level storage in LDS
+constexpr int VAL_DOUBLES = 64;  // R 9, p 3, oR 9, op 3, v 6, a 6, g 3, f 6, vpar 6, apar 6 -> 57, padded
+constexpr int TAN_SLOTS = 21;    // dv 6, da 6, dg 3, df 6
+__host__ __device__ constexpr size_t lin_lds_bytes(int nlevels) {
+  return sizeof(double) * ((size_t)nlevels * (VAL_DOUBLES + TAN_SLOTS * 64) + 3 * (RTOC_MAX_JOINTS + 8) + 3 * RTOC_MAX_CONTACTS + RTOC_MAX_JOINTS);
+}
+
+static __global__ __launch_bounds__(64) void linearize_contact_dynamics_kernel(LinArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int lane = threadIdx.x;
+  const int item = blockIdx.x;
+  const int nst1 = a.nstages - 1;
+  const int b = item / nst1, st = item % nst1;
+  if (b >= a.batch) return;
+  const rtoc_robot_model& m = a.model->m;
+  const int* const depth = a.model->depth;
+  const int nlev = a.model->nlevels, nv = m.nv, nb = m.njoints;
+  const rtoc_grid g = a.grid[st];
+  const bool impact = g.type == RTOC_GRID_IMPACT;
+  const unsigned active = a.active[st];
+  double* const lval = smem;                                      // [nlev][VAL_DOUBLES]
+  double* const ltan = lval + (size_t)nlev * VAL_DOUBLES;         // [nlev][TAN_SLOTS][64]
+  double* const sq = ltan + (size_t)nlev * TAN_SLOTS * 64;        // q, v, a, f, u of the grid point
+  double* const sv = sq + RTOC_MAX_JOINTS + 8;
+  double* const sa = sv + RTOC_MAX_JOINTS + 8;
+  double* const sf = sa + RTOC_MAX_JOINTS + 8;
+  double* const su = sf + 3 * RTOC_MAX_CONTACTS;
+  const size_t rec = (size_t)b * a.nstages + st;
+  const double* const sr = a.sol + rec * a.sol_stride;
+  double* const cr = a.cdd + rec * a.cdd_stride;
+  const int nu = (m.type[0] == RTOC_JOINT_FREE_FLYER) ? nv - 6 : nv;
+  for (int e = lane; e < m.nq; e += 64) sq[e] = sr[a.o_q + e];
+  for (int e = lane; e < nv; e += 64) {
+    sv[e] = sr[a.o_v + e];
+    sa[e] = sr[a.o_a + e];
+  }
+  for (int e = lane; e < g.dimf; e += 64) sf[e] = sr[a.o_f + e];
+  for (int e = lane; e < nu; e += 64) su[e] = sr[a.o_u + e];
+  __syncthreads();
+  const V3 grav = ldv3(m.gravity);
+  // impact grids: a dynamics traversal (zero gravity, zero velocity, acceleration = dv; robot.hxx:590-624) and a
+  // kinematics traversal at v + dv for the contact-velocity rows (impact_stage.cpp:61); other grids: one traversal
+  const int ntrav = impact ? 2 : 1;
+  for (int trav = 0; trav < ntrav; ++trav) {
+    const bool dyn = trav == 0;                 // writes ID and its derivatives
+    const bool rows = !impact || trav == 1;     // writes C and its derivatives
+    for (int j0 = 0; j0 < nv; j0 += 21) {
+      const int j = j0 + lane / 3, kind = lane % 3;  // 0: q, 1: v, 2: a
+      const bool lane_on = lane < 63 && j < nv;
+      int top = -1;
+      // body of the level that is being closed / visited is kept in LDS as an int in the value block
+      auto LV = [&](int lev, int k) -> double& { return lval[lev * VAL_DOUBLES + k]; };
+      auto LT = [&](int lev, int k) -> double& { return ltan[((size_t)lev * TAN_SLOTS + k) * 64 + lane]; };
+      auto ld_sv = [&](int lev, int k0) { return SV{mk(LV(lev, k0), LV(lev, k0 + 1), LV(lev, k0 + 2)), mk(LV(lev, k0 + 3), LV(lev, k0 + 4), LV(lev, k0 + 5))}; };
+      auto st_sv = [&](int lev, int k0, SV x) {
+        LV(lev, k0) = x.l.x, LV(lev, k0 + 1) = x.l.y, LV(lev, k0 + 2) = x.l.z, LV(lev, k0 + 3) = x.a.x, LV(lev, k0 + 4) = x.a.y, LV(lev, k0 + 5) = x.a.z;
+      };
+      auto ld_tv = [&](int lev, int k0) { return SV{mk(LT(lev, k0), LT(lev, k0 + 1), LT(lev, k0 + 2)), mk(LT(lev, k0 + 3), LT(lev, k0 + 4), LT(lev, k0 + 5))}; };
+      auto st_tv = [&](int lev, int k0, SV x) {
+        LT(lev, k0) = x.l.x, LT(lev, k0 + 1) = x.l.y, LT(lev, k0 + 2) = x.l.z, LT(lev, k0 + 3) = x.a.x, LT(lev, k0 + 4) = x.a.y, LT(lev, k0 + 5) = x.a.z;
+      };
+      // value slots: 0 R, 9 p, 12 oR, 21 op, 24 v, 30 a, 36 g, 39 f, 45 body index
+      // tangent slots: 0 dv, 6 da, 12 dg, 15 df
+      auto unit_twist = [&](int i, int k) -> SV {  // S_k of joint i
+        if (m.type[i] == RTOC_JOINT_FREE_FLYER)
+          return SV{mk(k == 0, k == 1, k == 2), mk(k == 3, k == 4, k == 5)};
+        return SV{mk(0, 0, 0), ldv3(m.axis[i])};
+      };
+      auto close = [&](int lev) {
+        const int i = (int)LV(lev, 45);
+        const M3 R = ldm3(&LV(lev, 0));
+        const V3 p = ldv3(&LV(lev, 9));
+        const SV f = ld_sv(lev, 39), df = ld_tv(lev, 15);
+        const int iv = m.idx_v[i];
+        const bool own = lane_on && j >= iv && j < iv + (m.type[i] == RTOC_JOINT_FREE_FLYER ? 6 : 1);
+        if (dyn) {
+          // tau = S^T f: value (lane 0) and this lane's column
+          double* const dcol = kind == 2 ? cr + a.o_didda + (size_t)j * nv : cr + a.o_didcdqv + (size_t)(kind == 1 ? nv + j : j) * a.ldv;
+          if (m.type[i] == RTOC_JOINT_FREE_FLYER) {
+            const double fv[6] = {f.l.x, f.l.y, f.l.z, f.a.x, f.a.y, f.a.z}, dv6[6] = {df.l.x, df.l.y, df.l.z, df.a.x, df.a.y, df.a.z};
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+              if (lane == 0 && j0 == 0) cr[a.o_idc + iv + k] = fv[k] - ((!impact && iv + k >= nv - nu) ? su[iv + k - (nv - nu)] : 0.0);
+              if (lane_on) dcol[iv + k] = dv6[k];
+            }
+          } else {
+            const V3 ax = ldv3(m.axis[i]);
+            if (lane == 0 && j0 == 0) cr[a.o_idc + iv] = dot(ax, f.a) - ((!impact && iv >= nv - nu) ? su[iv - (nv - nu)] : 0.0);
+            if (lane_on) dcol[iv] = dot(ax, df.a);
+          }
+        }
+        if (lev > 0) {
+          SV dfp = act_f(R, p, df);
+          if (own && kind == 0) dfp = dfp + act_f(R, p, fcross(unit_twist(i, j - iv), f));
+          st_sv(lev - 1, 39, ld_sv(lev - 1, 39) + act_f(R, p, f));
+          st_tv(lev - 1, 15, ld_tv(lev - 1, 15) + dfp);
+        }
+      };
+      for (int i = 0; i < nb; ++i) {
+        const int d = depth[i];
+        while (top >= d) {
+          close(top);
+          --top;
+        }
+        // ---- visit body i at level d ----
+        const int iq = m.idx_q[i], iv = m.idx_v[i];
+        const bool ff = m.type[i] == RTOC_JOINT_FREE_FLYER;
+        const bool own = lane_on && j >= iv && j < iv + (ff ? 6 : 1);
+        M3 Rj;
+        V3 pj = mk(0, 0, 0);
+        SV vj, aj;  // S vq, S aq
+        if (ff) {
+          const double x = sq[iq + 3], y = sq[iq + 4], z = sq[iq + 5], w = sq[iq + 6];
+          Rj.m[0] = 1 - 2 * (y * y + z * z), Rj.m[1] = 2 * (x * y - z * w), Rj.m[2] = 2 * (x * z + y * w);
+          Rj.m[3] = 2 * (x * y + z * w), Rj.m[4] = 1 - 2 * (x * x + z * z), Rj.m[5] = 2 * (y * z - x * w);
+          Rj.m[6] = 2 * (x * z - y * w), Rj.m[7] = 2 * (y * z + x * w), Rj.m[8] = 1 - 2 * (x * x + y * y);
+          pj = mk(sq[iq], sq[iq + 1], sq[iq + 2]);
+          vj = SV{mk(sv[iv], sv[iv + 1], sv[iv + 2]), mk(sv[iv + 3], sv[iv + 4], sv[iv + 5])};
+          aj = SV{mk(sa[iv], sa[iv + 1], sa[iv + 2]), mk(sa[iv + 3], sa[iv + 4], sa[iv + 5])};
+          if (impact && !dyn) vj = vj + aj;  // kinematics at v + dv
+        } else {
+          const V3 ax = ldv3(m.axis[i]);
+          const double th = sq[iq], c = cos(th), s = sin(th), t = 1.0 - c;
+          Rj.m[0] = t * ax.x * ax.x + c, Rj.m[1] = t * ax.x * ax.y - s * ax.z, Rj.m[2] = t * ax.x * ax.z + s * ax.y;
+          Rj.m[3] = t * ax.x * ax.y + s * ax.z, Rj.m[4] = t * ax.y * ax.y + c, Rj.m[5] = t * ax.y * ax.z - s * ax.x;
+          Rj.m[6] = t * ax.x * ax.z - s * ax.y, Rj.m[7] = t * ax.y * ax.z + s * ax.x, Rj.m[8] = t * ax.z * ax.z + c;
+          const double vq = (impact && !dyn) ? sv[iv] + sa[iv] : sv[iv];
+          vj = SV{mk(0, 0, 0), vq * ax};
+          aj = SV{mk(0, 0, 0), sa[iv] * ax};
+        }
+        if (impact && dyn) vj = sv0();   // impact model: v = 0
+        if (impact && !dyn) aj = sv0();  // velocity-level rows only
+        const M3 Rp = ldm3(m.placement_R[i]);
+        const M3 R = mul(Rp, Rj);
+        const V3 p = mul(Rp, pj) + ldv3(m.placement_p[i]);
+        M3 oR = R;
+        V3 op = p;
+        SV vpar = sv0(), apar = sv0(), dvp = sv0(), dap = sv0();
+        V3 gi = mulT(R, mk(-grav.x, -grav.y, -grav.z)), dgp = mk(0, 0, 0);
+        if (d > 0) {
+          const M3 oRp = ldm3(&LV(d - 1, 12));
+          oR = mul(oRp, R);
+          op = ldv3(&LV(d - 1, 21)) + mul(oRp, p);
+          vpar = act_inv(R, p, ld_sv(d - 1, 24));
+          apar = act_inv(R, p, ld_sv(d - 1, 30));
+          gi = mulT(R, ldv3(&LV(d - 1, 36)));
+          dvp = act_inv(R, p, ld_tv(d - 1, 0));
+          dap = act_inv(R, p, ld_tv(d - 1, 6));
+          dgp = mulT(R, mk(LT(d - 1, 12), LT(d - 1, 13), LT(d - 1, 14)));
+        }
+        if (impact) gi = mk(0, 0, 0), dgp = mk(0, 0, 0);  // the impact model has no gravity
+        const SV v = vpar + vj;
+        const SV acc = apar + aj + mcross(v, vj);
+        SV dv = dvp, da = dap;
+        V3 dg = dgp;
+        if (own) {
+          const SV S = unit_twist(i, j - iv);
+          if (kind == 0) {
+            dv = dv - mcross(S, vpar);
+            da = da - mcross(S, apar);
+            dg = dg - cross(S.a, gi);
+          } else if (kind == 1) {
+            if (!(impact && dyn)) dv = dv + S;
+          } else {
+            if (!(impact && !dyn)) da = da + S;
+            if (impact && !dyn) dv = dv + S;  // d(v + dv)/d(dv)
+          }
+        }
+        da = da + mcross(dv, vj);
+        if (own && (kind == 1 || (impact && !dyn && kind == 2)) && !(impact && dyn)) da = da + mcross(v, unit_twist(i, j - iv));
+        // own force and its tangent
+        const double mass = m.mass[i];
+        const V3 com = ldv3(m.com[i]);
+        const M3 I = ldm3(m.inertia[i]);
+        const SV h = inertia_mul(mass, com, I, v);
+        SV f = inertia_mul(mass, com, I, SV{acc.l + gi, acc.a}) + fcross(v, h);
+        const SV df = inertia_mul(mass, com, I, SV{da.l + dg, da.a}) + fcross(dv, h) + fcross(v, inertia_mul(mass, com, I, dv));
+        // contacts carried by this body
+        int nact = 0;
+        for (int c = 0; c < m.ncontacts; ++c) {
+          const bool on = (active >> c) & 1u;
+          if (on && m.contact_parent[c] == i) {
+            const M3 Rf = ldm3(m.contact_R[c]);
+            const V3 pf = ldv3(m.contact_p[c]);
+            f = f - act_f(Rf, pf, SV{mk(sf[3 * nact], sf[3 * nact + 1], sf[3 * nact + 2]), mk(0, 0, 0)});
+            if (rows) {
+              const SV vf = act_inv(Rf, pf, v), dvf = act_inv(Rf, pf, dv);
+              V3 C, dC;
+              if (impact) {
+                C = vf.l;
+                dC = dvf.l;
+              } else {
+                const SV af = act_inv(Rf, pf, acc), daf = act_inv(Rf, pf, da);
+                const double kp = m.contact_kp[c], kd = m.contact_kd[c];
+                const V3 pw = op + mul(oR, pf);
+                const V3 pr = a.positions ? ldv3(a.positions + ((size_t)st * m.ncontacts + c) * 3) : mk(0, 0, 0);
+                C = af.l + cross(vf.a, vf.l) + kd * vf.l + kp * (pw - pr);
+                dC = daf.l + cross(dvf.a, vf.l) + cross(vf.a, dvf.l) + kd * dvf.l;
+                // kp * R_of * J_lin(:, j): the frame Jacobian column is the v-tangent of vf, one lane up
+                const V3 jl = mk(__shfl_down(dvf.l.x, 1, 64), __shfl_down(dvf.l.y, 1, 64), __shfl_down(dvf.l.z, 1, 64));
+                if (kind == 0) dC = dC + kp * mul(mul(oR, Rf), jl);
+              }
+              const int r0 = nv + 3 * nact;
+              if (lane == 0 && j0 == 0) {
+                cr[a.o_idc + r0] = C.x, cr[a.o_idc + r0 + 1] = C.y, cr[a.o_idc + r0 + 2] = C.z;
+              }
+              if (lane_on) {
+                // impact: dC/dv = dC/d(dv) goes where the condensation reads it (the v block of DIDCDQV) and into DCDA
+                if (kind == 2 || (impact && kind == 1)) {
+                  double* const o = cr + a.o_dcda + (size_t)j * a.nf_max + (r0 - nv);
+                  o[0] = dC.x, o[1] = dC.y, o[2] = dC.z;
+                }
+                if (kind != 2) {
+                  double* const o = cr + a.o_didcdqv + (size_t)(kind == 1 ? nv + j : j) * a.ldv + r0;
+                  o[0] = dC.x, o[1] = dC.y, o[2] = dC.z;
+                }
+              }
+            }
+          }
+          nact += on;
+        }
+        // ---- store the level ----
+#pragma unroll
+        for (int k = 0; k < 9; ++k) LV(d, k) = R.m[k], LV(d, 12 + k) = oR.m[k];
+        LV(d, 9) = p.x, LV(d, 10) = p.y, LV(d, 11) = p.z;
+        LV(d, 21) = op.x, LV(d, 22) = op.y, LV(d, 23) = op.z;
+        st_sv(d, 24, v);
+        st_sv(d, 30, acc);
+        LV(d, 36) = gi.x, LV(d, 37) = gi.y, LV(d, 38) = gi.z;
+        st_sv(d, 39, f);
+        LV(d, 45) = (double)i;
+        st_tv(d, 0, dv);
+        st_tv(d, 6, da);
+        LT(d, 12) = dg.x, LT(d, 13) = dg.y, LT(d, 14) = dg.z;
+        st_tv(d, 15, df);
+        top = d;
+      }
+      while (top >= 0) {
+        close(top);
+        --top;
+      }
+    }
+  }
+}
+
+}  // namespace rbd
+}  // namespace rtoc

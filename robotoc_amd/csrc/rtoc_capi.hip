@@ -10,7 +10,9 @@
 #include <vector>
 
 #include "../../include/rtoc.h"
+#include "../../include/rtoc_robot.h"
 #include "kernel_set.hpp"
+#include "rigid_body.hpp"
 
 using namespace rtoc;
 
@@ -100,6 +102,12 @@ struct rtoc_ctx {
   double* d_kkterr;             // [batch]
   int backward_scan;            // RTOC_OPT_BACKWARD_SCAN
   double* d_scan[3];            // element ping-pong buffers, value records (allocated on first use)
+  // rigid-body model (rtoc_set_robot_model) and contact schedule (rtoc_set_contact_schedule)
+  rbd::DevModel* d_model;
+  rbd::DevModel* h_model;
+  unsigned* d_active;
+  double* d_cpos;
+  bool has_cpos;
 };
 
 extern "C" {
@@ -245,6 +253,10 @@ int rtoc_destroy(rtoc_ctx* c) {
   if (c->g_sweep.exec) (void)hipGraphExecDestroy(c->g_sweep.exec);
   if (c->g_newton.exec) (void)hipGraphExecDestroy(c->g_newton.exec);
   if (c->d_status) (void)hipFree(c->d_status);
+  if (c->d_model) (void)hipFree(c->d_model);
+  delete c->h_model;
+  if (c->d_active) (void)hipFree(c->d_active);
+  if (c->d_cpos) (void)hipFree(c->d_cpos);
   if (c->d_prof) (void)hipFree(c->d_prof);
   for (int i = 0; i < 3; ++i)
     if (c->d_scan[i]) (void)hipFree(c->d_scan[i]);
@@ -1198,6 +1210,104 @@ int rtoc_integrate_solution(rtoc_ctx* c) {
   a.sl = c->L.sol;
   a.dl = c->L.dir;
   hipLaunchKernelGGL(integrate_solution_kernel, dim3(c->batch * c->nstages), dim3(64), 0, c->stream, a);
+  HIP_TRY(hipGetLastError());
+  return RTOC_OK;
+}
+
+// ---- rigid-body linearisation (include/rtoc_robot.h) ------------------------------------------
+int rtoc_set_robot_model(rtoc_ctx* c, const rtoc_robot_model* m) {
+  if (!c || !m) return RTOC_ERR_BAD_ARG;
+  if (m->njoints < 1 || m->njoints > RTOC_MAX_JOINTS || m->ncontacts < 0 || m->ncontacts > RTOC_MAX_CONTACTS) return RTOC_ERR_BAD_ARG;
+  if (m->nv != c->dims.nv || 3 * m->ncontacts > c->dims.nf_max) return RTOC_ERR_BAD_ARG;
+  const bool ff = m->type[0] == RTOC_JOINT_FREE_FLYER;
+  if (m->nq != m->nv + (ff ? 1 : 0) || (ff ? m->nv - 6 : m->nv) != c->dims.nu) return RTOC_ERR_BAD_ARG;
+  rbd::DevModel* h = new (std::nothrow) rbd::DevModel;
+  if (!h) return RTOC_ERR_HIP;
+  h->m = *m;
+  // depth-first order: when joint i is visited, the joint open one level up must be its parent
+  int open[RTOC_MAX_JOINTS], iq = 0, iv = 0, nlev = 0;
+  bool ok = true;
+  for (int i = 0; i < m->njoints && ok; ++i) {
+    const int par = m->parent[i];
+    ok = par < i && par >= -1 && (m->type[i] == RTOC_JOINT_REVOLUTE || (m->type[i] == RTOC_JOINT_FREE_FLYER && i == 0 && par == -1));
+    if (!ok) break;
+    const int d = par < 0 ? 0 : h->depth[par] + 1;
+    ok = (d == 0 || open[d - 1] == par) && m->idx_q[i] == iq && m->idx_v[i] == iv;
+    h->depth[i] = d;
+    open[d] = i;
+    nlev = d + 1 > nlev ? d + 1 : nlev;
+    iq += m->type[i] == RTOC_JOINT_FREE_FLYER ? 7 : 1;
+    iv += m->type[i] == RTOC_JOINT_FREE_FLYER ? 6 : 1;
+  }
+  ok = ok && iq == m->nq && iv == m->nv && rbd::lin_lds_bytes(nlev) <= 160 * 1024;
+  for (int k = 0; k < m->ncontacts && ok; ++k) ok = m->contact_parent[k] >= 0 && m->contact_parent[k] < m->njoints;
+  if (!ok) {
+    delete h;
+    return RTOC_ERR_BAD_ARG;
+  }
+  h->nlevels = nlev;
+  HIP_TRY(hipSetDevice(c->device));
+  if (!c->d_model) HIP_TRY(hipMalloc((void**)&c->d_model, sizeof(rbd::DevModel)));
+  delete c->h_model;
+  c->h_model = h;
+  HIP_TRY(hipMemcpyAsync(c->d_model, h, sizeof(rbd::DevModel), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(hipFuncSetAttribute((const void*)rbd::linearize_contact_dynamics_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)rbd::lin_lds_bytes(nlev)));
+  c->epoch++;
+  return RTOC_OK;
+}
+
+int rtoc_set_contact_schedule(rtoc_ctx* c, const unsigned* active, const double* positions) {
+  CHECK_READY(c);
+  if (!c->h_model || !active) return RTOC_ERR_BAD_ARG;
+  const int nc = c->h_model->m.ncontacts;
+  for (int i = 0; i < c->nstages; ++i) {
+    if (nc < 32 && (active[i] >> nc) != 0) return RTOC_ERR_BAD_ARG;
+    if (i < c->nstages - 1 && 3 * __builtin_popcount(active[i]) != c->h_grid[i].dimf) return RTOC_ERR_BAD_ARG;
+  }
+  HIP_TRY(hipSetDevice(c->device));
+  if (!c->d_active) HIP_TRY(hipMalloc((void**)&c->d_active, sizeof(unsigned) * c->max_stages));
+  if (!c->d_cpos) HIP_TRY(hipMalloc((void**)&c->d_cpos, sizeof(double) * c->max_stages * RTOC_MAX_CONTACTS * 3));
+  HIP_TRY(hipMemcpyAsync(c->d_active, active, sizeof(unsigned) * c->nstages, hipMemcpyHostToDevice, c->stream));
+  if (positions)
+    HIP_TRY(hipMemcpyAsync(c->d_cpos, positions, sizeof(double) * c->nstages * nc * 3, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->has_cpos = positions != nullptr;
+  c->epoch++;
+  return RTOC_OK;
+}
+
+int rtoc_linearize_contact_dynamics(rtoc_ctx* c) {
+  CHECK_READY(c);
+  if (!c->h_model || !c->d_active || !c->buf[RTOC_BUF_SOL]) return RTOC_ERR_NOT_READY;
+  int rc = ensure_buffer(c, RTOC_BUF_CDD);
+  if (rc) return rc;
+  rbd::LinArgs a;
+  a.model = c->d_model;
+  a.sol = c->buf[RTOC_BUF_SOL];
+  a.cdd = c->buf[RTOC_BUF_CDD];
+  a.grid = c->d_grid;
+  a.active = c->d_active;
+  a.positions = c->has_cpos ? c->d_cpos : nullptr;
+  a.nstages = c->nstages;
+  a.batch = c->batch;
+  a.sol_stride = c->L.sol.stride;
+  a.cdd_stride = c->L.cdd.stride;
+  a.o_q = c->L.sol.off[RTOC_SOL_Q];
+  a.o_v = c->L.sol.off[RTOC_SOL_V];
+  a.o_a = c->L.sol.off[RTOC_SOL_A];
+  a.o_u = c->L.sol.off[RTOC_SOL_U];
+  a.o_f = c->L.sol.off[RTOC_SOL_F];
+  a.o_idc = c->L.cdd.off[RTOC_CDD_IDC];
+  a.o_didda = c->L.cdd.off[RTOC_CDD_DIDDA];
+  a.o_dcda = c->L.cdd.off[RTOC_CDD_DCDA];
+  a.o_didcdqv = c->L.cdd.off[RTOC_CDD_DIDCDQV];
+  a.ldv = c->dims.nv + c->dims.nf_max;
+  a.nf_max = c->dims.nf_max;
+  if (c->nstages < 2) return RTOC_OK;
+  hipLaunchKernelGGL(rbd::linearize_contact_dynamics_kernel, dim3(c->batch * (c->nstages - 1)), dim3(64),
+                     rbd::lin_lds_bytes(c->h_model->nlevels), c->stream, a);
   HIP_TRY(hipGetLastError());
   return RTOC_OK;
 }

@@ -1,0 +1,67 @@
+"""Host-side mirror of `rtoc_robot_model` (include/rtoc_robot.h) and a loader for the committed model tables
+(tests/golden/models/*.json, written by tools/urdf_to_model.py from the reference's test URDFs)."""
+import ctypes as C
+import json
+
+import numpy as np
+
+MAX_JOINTS = 48
+MAX_CONTACTS = 8
+JOINT_FREE_FLYER, JOINT_REVOLUTE = 0, 1
+
+
+class RobotModel(C.Structure):
+    _fields_ = [
+        ("njoints", C.c_int), ("nq", C.c_int), ("nv", C.c_int), ("ncontacts", C.c_int),
+        ("parent", C.c_int * MAX_JOINTS), ("type", C.c_int * MAX_JOINTS),
+        ("idx_q", C.c_int * MAX_JOINTS), ("idx_v", C.c_int * MAX_JOINTS),
+        ("placement_R", (C.c_double * 9) * MAX_JOINTS), ("placement_p", (C.c_double * 3) * MAX_JOINTS),
+        ("axis", (C.c_double * 3) * MAX_JOINTS), ("mass", C.c_double * MAX_JOINTS),
+        ("com", (C.c_double * 3) * MAX_JOINTS), ("inertia", (C.c_double * 9) * MAX_JOINTS),
+        ("contact_parent", C.c_int * MAX_CONTACTS), ("contact_R", (C.c_double * 9) * MAX_CONTACTS),
+        ("contact_p", (C.c_double * 3) * MAX_CONTACTS), ("contact_kp", C.c_double * MAX_CONTACTS),
+        ("contact_kd", C.c_double * MAX_CONTACTS), ("gravity", C.c_double * 3),
+    ]
+
+    @property
+    def floating_base(self):
+        return self.njoints > 0 and self.type[0] == JOINT_FREE_FLYER
+
+    @property
+    def nu(self):
+        return self.nv - 6 if self.floating_base else self.nv
+
+
+def from_dict(d):
+    m = RobotModel()
+    js, cs = d["joints"], d["contacts"]
+    assert len(js) <= MAX_JOINTS and len(cs) <= MAX_CONTACTS
+    m.njoints, m.nq, m.nv, m.ncontacts = len(js), d["nq"], d["nv"], len(cs)
+    for i, j in enumerate(js):
+        m.parent[i], m.type[i], m.idx_q[i], m.idx_v[i] = j["parent"], j["type"], j["idx_q"], j["idx_v"]
+        m.placement_R[i][:] = np.asarray(j["placement_R"], dtype=float).reshape(9)
+        m.placement_p[i][:] = j["placement_p"]
+        m.axis[i][:] = j["axis"]
+        m.mass[i] = j["mass"]
+        m.com[i][:] = j["com"]
+        m.inertia[i][:] = np.asarray(j["inertia"], dtype=float).reshape(9)
+    for k, c in enumerate(cs):
+        m.contact_parent[k] = c["parent"]
+        m.contact_R[k][:] = np.asarray(c["R"], dtype=float).reshape(9)
+        m.contact_p[k][:] = c["p"]
+        m.contact_kp[k], m.contact_kd[k] = c["baumgarte_position_gain"], c["baumgarte_velocity_gain"]
+    m.gravity[:] = d["gravity"]
+    return m
+
+
+def load(path):
+    return from_dict(json.load(open(path)))
+
+
+def random_configuration(model, rng, scale=1.0):
+    """q on the manifold (unit quaternion for a free-flyer root), v, a"""
+    q = scale * rng.uniform(-1.0, 1.0, model.nq)
+    if model.floating_base:
+        quat = rng.normal(size=4)
+        q[3:7] = quat / np.linalg.norm(quat)
+    return q, scale * rng.uniform(-1.0, 1.0, model.nv), scale * rng.uniform(-1.0, 1.0, model.nv)

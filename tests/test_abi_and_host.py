@@ -1,4 +1,4 @@
-"""CPU-side checks: the C-ABI library loads and exports every symbol include/rtoc.h declares
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/rtoc.h and include/rtoc_robot.h declare
 (no compute calls without a GPU), layouts agree between product and oracle, grid construction."""
 import ctypes as C
 import os
@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_exports_every_declared_symbol():
     capi.build()
     lib = C.CDLL(capi.lib_path())
-    hdr = open(os.path.join(ROOT, "include", "rtoc.h")).read()
+    hdr = open(os.path.join(ROOT, "include", "rtoc.h")).read() + open(os.path.join(ROOT, "include", "rtoc_robot.h")).read()
     declared = set(re.findall(r"\b(rtoc_[a-z_0-9]+)\s*\(", hdr))
     declared -= {"rtoc_compute_layout", "rtoc_cone_stride", "rtoc_cone_dgdf_off", "rtoc_wrench_cone_stride"}  # static inline in rtoc_layout.h
     assert len(declared) >= 25

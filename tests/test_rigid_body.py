@@ -1,0 +1,192 @@
+"""Rigid-body side of evalKKT: rtoc_linearize_contact_dynamics vs the CPU restatement
+(oracle/rtoc_oracle_rbd.c), and cross-checks of that restatement itself.
+
+PARITY UNPINNED: the reference delegates these functions to Pinocchio, which is neither vendored nor installed, so no
+fixture of the reference's own numbers exists.  What anchors the restatement instead:
+  * the model tables come from the reference's test URDFs (tools/urdf_to_model.py), and the reference's own standing pose
+    of ANYmal (examples/anymal/*.cpp: base height 0.4792) puts all four feet on the ground to 1e-5 m;
+  * the joint-space inertia from the recursion equals a composite-rigid-body sum written in world coordinates;
+  * the bias forces satisfy Lagrange's equations (fixed-base arm) and the momentum balance of the floating base,
+    both evaluated from kinematics only;
+  * the device derivatives (analytical, forward mode) agree with central differences of the restatement.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from robotoc_amd import capi, problems as pr, robot_model as rm
+from robotoc_amd.types import BUF_CDD, BUF_SOL, GRID_IMPACT, Dims
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MODELS = os.path.join(ROOT, "tests", "golden", "models")
+
+
+def model(name):
+    return rm.load(os.path.join(MODELS, name + ".json"))
+
+
+def rnea(orc, m, q, v, a):
+    z = np.zeros(3 * m.ncontacts)
+    return orc.rbd_eval(m, 0, q, v, a, z, np.zeros(m.nu), 0, z)[:m.nv]
+
+
+def test_anymal_standing_pose_of_the_reference_examples_touches_the_ground(oracle):
+    m = model("anymal")
+    q = np.array([0, 0, 0.4792, 0, 0, 0, 1, -0.1, 0.7, -1.0, -0.1, -0.7, 1.0, 0.1, 0.7, -1.0, 0.1, -0.7, 1.0])
+    feet = np.array([oracle.rbd_contact_position(m, q, c) for c in range(4)])
+    assert np.abs(feet[:, 2]).max() < 1e-5
+    assert np.allclose(np.abs(feet[:, 0]), abs(feet[0, 0])) and np.allclose(np.abs(feet[:, 1]), abs(feet[0, 1]))
+    assert abs(sum(m.mass[i] for i in range(m.njoints)) - 30.4754) < 1e-3
+
+
+@pytest.mark.parametrize("name", ["anymal", "icub", "iiwa14"])
+def test_mass_matrix_from_the_recursion_equals_world_frame_composite_sum(oracle, name):
+    m = model(name)
+    rng = np.random.default_rng(1)
+    for _ in range(3):
+        q, v, _ = rm.random_configuration(m, rng)
+        z, f = np.zeros(m.nv), np.zeros(3 * m.ncontacts)
+        M = np.array([oracle.rbd_eval(m, 1, q, z, e, f, np.zeros(m.nu), 0, f)[:m.nv] for e in np.eye(m.nv)]).T
+        Mw = oracle.rbd_mass_matrix_world(m, q)
+        assert np.abs(M - Mw).max() < 1e-12 * max(1.0, np.abs(Mw).max())
+        assert np.linalg.eigvalsh(Mw).min() > 0
+        T, _ = oracle.rbd_energy(m, q, v)
+        assert abs(T - 0.5 * v @ Mw @ v) < 1e-12 * max(1.0, T)
+
+
+def test_lagrange_equations_on_the_fixed_base_arm(oracle):
+    """tau = d/dt (dT/dv) - dL/dq with T, U from kinematics only (no force recursion involved)"""
+    m = model("iiwa14")
+    rng = np.random.default_rng(2)
+    h = 1e-5
+    for _ in range(3):
+        q, v, a = rm.random_configuration(m, rng)
+        L = lambda q_: (lambda TU: TU[0] - TU[1])(oracle.rbd_energy(m, q_, v))
+        p = lambda q_: oracle.rbd_mass_matrix_world(m, q_) @ v
+        dLdq = np.array([(L(q + h * e) - L(q - h * e)) / (2 * h) for e in np.eye(m.nv)])
+        dpdt = oracle.rbd_mass_matrix_world(m, q) @ a + sum(((p(q + h * e) - p(q - h * e)) / (2 * h)) * v[j] for j, e in enumerate(np.eye(m.nv)))
+        tau = rnea(oracle, m, q, v, a)
+        assert np.abs(tau - (dpdt - dLdq)).max() < 1e-6 * max(1.0, np.abs(tau).max())
+
+
+@pytest.mark.parametrize("name", ["anymal", "icub"])
+def test_floating_base_rows_balance_the_rate_of_total_momentum(oracle, name):
+    """The base wrench of the recursion = d/dt(total momentum) - gravity wrench, in the base frame."""
+    m = model(name)
+    rng = np.random.default_rng(3)
+    h = 1e-6
+    for _ in range(3):
+        q, v, a = rm.random_configuration(m, rng)
+        mom = lambda s: oracle.rbd_momentum_world(m, oracle.rbd_integrate(m, q, s * v + 0.5 * s * s * a), v + s * a)
+        hdot = (mom(h) - mom(-h)) / (2 * h)  # world frame, about the world origin
+        # gravity wrench about the world origin
+        mass = sum(m.mass[i] for i in range(m.njoints))
+        z = np.zeros(m.nv)
+        # world com from the potential energy gradient: U = -m g . c
+        com = np.zeros(3)
+        for k in range(3):
+            mk = rm.RobotModel.from_buffer_copy(m)
+            mk.gravity[:] = [0.0, 0.0, 0.0]
+            mk.gravity[k] = -1.0
+            com[k] = oracle.rbd_energy(mk, q, z)[1] / mass
+        g = np.array(m.gravity[:])
+        wg = np.concatenate([mass * g, np.cross(com, mass * g)])
+        w_world = hdot - wg
+        # to the base frame: f_b = R^T f, n_b = R^T (n - p x f)
+        x, y, zq, w = q[3:7]
+        R = np.array([[1 - 2 * (y * y + zq * zq), 2 * (x * y - zq * w), 2 * (x * zq + y * w)],
+                      [2 * (x * y + zq * w), 1 - 2 * (x * x + zq * zq), 2 * (y * zq - x * w)],
+                      [2 * (x * zq - y * w), 2 * (y * zq + x * w), 1 - 2 * (x * x + y * y)]])
+        fb = R.T @ w_world[:3]
+        nb = R.T @ (w_world[3:] - np.cross(q[:3], w_world[:3]))
+        tau = rnea(oracle, m, q, v, a)
+        assert np.abs(tau[:6] - np.concatenate([fb, nb])).max() < 2e-6 * max(1.0, np.abs(tau[:6]).max())
+
+
+def test_model_table_is_validated():
+    capi.build()
+    lib = capi.lib()
+    assert hasattr(lib, "rtoc_set_robot_model") and hasattr(lib, "rtoc_linearize_contact_dynamics")
+
+
+def _masks(grids):
+    """contact masks with popcount * 3 == dimf: all four feet, or alternating diagonal pairs"""
+    out, flip = [], False
+    for g in grids:
+        if g.dimf == 12:
+            out.append(0b1111)
+        elif g.dimf == 6:
+            out.append(0b0110 if flip else 0b1001)
+            flip = not flip
+        elif g.dimf == 0:
+            out.append(0)
+        else:
+            raise AssertionError(g.dimf)
+    return np.array(out, dtype=np.uint32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", ["anymal_trot", "anymal_jump_sto"])
+def test_gpu_linearisation_matches_the_restatement_and_its_finite_differences(oracle, cfg):
+    m = model("anymal")
+    dims, grids, _ = getattr(pr, "config_" + cfg)()
+    batch = 3
+    ctx = capi.Context(dims, len(grids), batch, 0)
+    L = ctx.L
+    ctx.set_grid(grids)
+    ctx.set_robot_model(m)
+    masks = _masks(grids)
+    rng = np.random.default_rng(4)
+    pos = rng.uniform(-0.5, 0.5, (len(grids), 4, 3))
+    ctx.set_contact_schedule(masks, pos)
+    sol = np.zeros(ctx.shape("sol"))
+    o = L.sol.off
+    for b in range(batch):
+        for i in range(len(grids)):
+            q, v, a = rm.random_configuration(m, rng, 0.8)
+            sol[b, i, o[0]:o[0] + m.nq] = q
+            sol[b, i, o[1]:o[1] + m.nv] = v
+            sol[b, i, o[2]:o[2] + m.nv] = a
+            sol[b, i, o[3]:o[3] + m.nu] = rng.uniform(-5, 5, m.nu)
+            sol[b, i, o[4]:o[4] + 12] = rng.uniform(-20, 20, 12)
+    ctx.upload(BUF_SOL, sol)
+    ctx.linearize_contact_dynamics()
+    ctx.sync()
+    cdd = ctx.download(BUF_CDD, ctx.shape("cdd"))
+    co = L.cdd.off
+    nv, ldv, nfm = m.nv, dims.nv + dims.nf_max, dims.nf_max
+    worst = dict(val=0.0, dq=0.0, dv=0.0, da=0.0)
+    for b in range(batch):
+        for i in range(len(grids) - 1):
+            g, act = grids[i], int(masks[i])
+            impact = g.type == GRID_IMPACT
+            n = nv + g.dimf
+            s = sol[b, i]
+            q, v, a = s[o[0]:o[0] + m.nq], s[o[1]:o[1] + nv], s[o[2]:o[2] + nv]
+            u, f = s[o[3]:o[3] + m.nu], s[o[4]:o[4] + 12]
+            ref = oracle.rbd_eval(m, impact, q, v, a, f, u, act, pos[i].reshape(-1))
+            Dq, Dv, Da = oracle.rbd_linearize_fd(m, impact, q, v, a, f, u, act, pos[i].reshape(-1), 1e-6)
+            rec = cdd[b, i]
+            idc = rec[co[3]:co[3] + n]
+            D = rec[co[1]:co[1] + ldv * 2 * nv].reshape(2 * nv, ldv).T  # [row, col]
+            M = rec[co[0]:co[0] + nv * nv].reshape(nv, nv).T
+            J = rec[co[2]:co[2] + nfm * nv].reshape(nv, nfm).T[:g.dimf]
+            scale = lambda x: max(1.0, np.abs(x).max())
+            worst["val"] = max(worst["val"], np.abs(idc - ref).max() / scale(ref))
+            worst["dq"] = max(worst["dq"], np.abs(D[:n, :nv] - Dq).max() / scale(Dq))
+            worst["da"] = max(worst["da"], np.abs(M - Da[:nv]).max() / scale(Da))
+            assert np.abs(M - M.T).max() < 1e-12 * scale(M)
+            if g.dimf == 0:
+                worst["dv"] = max(worst["dv"], np.abs(D[:n, nv:] - Dv).max() / scale(Dv))
+            elif impact:
+                # the v block: only the contact-velocity rows are defined (= dC/d(dv))
+                worst["dv"] = max(worst["dv"], np.abs(D[nv:n, nv:] - Dv[nv:]).max() / scale(Dv))
+                worst["dv"] = max(worst["dv"], np.abs(J - Da[nv:]).max() / scale(Da))
+            else:
+                worst["dv"] = max(worst["dv"], np.abs(D[:n, nv:] - Dv).max() / scale(Dv))
+                worst["da"] = max(worst["da"], np.abs(J - Da[nv:]).max() / scale(Da))
+    print("worst relative deviation:", worst)
+    assert worst["val"] < 1e-12
+    assert worst["dq"] < 2e-7 and worst["dv"] < 2e-7 and worst["da"] < 2e-7
+    ctx.close()
