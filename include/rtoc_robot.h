@@ -63,10 +63,14 @@ int rtoc_set_contact_schedule(rtoc_ctx* ctx, const unsigned* active, const doubl
  *   IDC      [ID; C]            ID = RNEA(q, v, a, f) - [0; u]        C = Baumgarte residual (impact: contact velocity)
  *   DIDDA    dID/da  (= M(q); impact: dID/ddv)          DCDA   dC/da  (impact: unused, dC/dv is in DIDCDQV)
  *   DIDCDQV  [dID/dq dID/dv; dC/dq dC/dv]
- * i.e. everything computeMJtJinv / condenseContactDynamics read.  The augmentation of the KKT residual with the
- * multipliers (contact_dynamics.cpp:35-52) is linear in these fields and stays with the cost derivatives on the
- * caller's side. */
-int rtoc_linearize_contact_dynamics(rtoc_ctx* ctx);
+ * i.e. everything computeMJtJinv / condenseContactDynamics read.
+ * augment_residual != 0: also the multiplier terms of the same functions (contact_dynamics.cpp:35-52,
+ * impact_dynamics.cpp:19-27), ADDED to what the cost / constraint stages left in the residuals (so once per iteration):
+ *   lq += dIDdq^T beta + dCdq^T mu   lv += dIDdv^T beta + dCdv^T mu   la += dIDda^T beta + dCda^T mu   lf -= dCda beta
+ *   lu -= beta (actuated part)       lu_passive = nu_passive - beta (floating base)
+ * (impact grids: ldv instead of la, dCdv instead of dCda, lu_passive = 0); beta, mu_stack, nu_passive from RTOC_BUF_SOL,
+ * lq / lv / lu in RTOC_BUF_KKT, la / lf / lu_passive in RTOC_BUF_CDD. */
+int rtoc_linearize_contact_dynamics(rtoc_ctx* ctx, int augment_residual);
 
 #ifdef __cplusplus
 }

@@ -92,7 +92,7 @@ def lib():
         for f in ("rtoc_condense", "rtoc_riccati_backward", "rtoc_riccati_forward", "rtoc_riccati_sweep", "rtoc_update",
                   "rtoc_correct_state_equation", "rtoc_correct_costate_direction",
                   "rtoc_compute_initial_state_direction", "rtoc_unconstr_condense", "rtoc_integrate_solution",
-                  "rtoc_linearize_contact_dynamics", "rtoc_clear_status", "rtoc_sync"):
+                  "rtoc_clear_status", "rtoc_sync"):
             getattr(L, f).argtypes = [vp]
         L.rtoc_unconstr_backward.argtypes = [vp, C.c_double]
         L.rtoc_unconstr_forward.argtypes = [vp, C.c_double]
@@ -113,6 +113,7 @@ def lib():
         L.rtoc_sto_eval_kkt.argtypes = [vp, dp, dp, C.c_int, dp, C.c_int]
         L.rtoc_clone.argtypes = [vp, C.POINTER(vp)]
         L.rtoc_set_robot_model.argtypes = [vp, vp]
+        L.rtoc_linearize_contact_dynamics.argtypes = [vp, C.c_int]
         L.rtoc_set_contact_schedule.argtypes = [vp, C.POINTER(C.c_uint), dp]
         L.rtoc_load_stage_dump.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
         L.rtoc_error_string.argtypes = [C.c_int]
@@ -312,8 +313,8 @@ class Context:
             assert pos.shape == (self.nstages, self._model_ncontacts, 3)
         _chk(lib().rtoc_set_contact_schedule(self._h, act.ctypes.data_as(C.POINTER(C.c_uint)), _dp(pos) if pos is not None else None))
 
-    def linearize_contact_dynamics(self):
-        _chk(lib().rtoc_linearize_contact_dynamics(self._h))
+    def linearize_contact_dynamics(self, augment_residual=False):
+        _chk(lib().rtoc_linearize_contact_dynamics(self._h, int(bool(augment_residual))))
 
     def kkt_error(self):
         """rtoc_kkt_error: sqrt of the squared KKT residual of every instance."""

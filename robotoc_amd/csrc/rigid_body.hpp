@@ -23,6 +23,10 @@
 #include "device_utils.hpp"
 #include "../../include/rtoc_robot.h"
 
+#ifndef RTOC_RBD_WAVES
+#define RTOC_RBD_WAVES
+#endif
+
 namespace rtoc {
 namespace rbd {
 
@@ -100,16 +104,21 @@ struct LinArgs {
   int o_q, o_v, o_a, o_u, o_f;                 // RTOC_BUF_SOL field offsets
   int o_idc, o_didda, o_dcda, o_didcdqv;       // RTOC_BUF_CDD field offsets
   int ldv, nf_max;                             // leading dimensions of DIDCDQV / DCDA
+  // multiplier terms of linearizeContactDynamics / linearizeImpactDynamics (kkt == nullptr: left out)
+  double* kkt;
+  int kkt_stride, o_lx, o_lu;                  // RTOC_BUF_KKT: lx = [lq; lv], lu
+  int o_la, o_lf, o_lup;                       // RTOC_BUF_CDD: la (ldv on impact grids), lf, lu_passive
+  int o_beta, o_mu, o_nup;                     // RTOC_BUF_SOL
 };
 
 // per-level storage in LDS
 constexpr int VAL_DOUBLES = 64;  // R 9, p 3, oR 9, op 3, v 6, a 6, g 3, f 6, vpar 6, apar 6 -> 57, padded
 constexpr int TAN_SLOTS = 21;    // dv 6, da 6, dg 3, df 6
 __host__ __device__ constexpr size_t lin_lds_bytes(int nlevels) {
-  return sizeof(double) * ((size_t)nlevels * (VAL_DOUBLES + TAN_SLOTS * 64) + 3 * (RTOC_MAX_JOINTS + 8) + 3 * RTOC_MAX_CONTACTS + RTOC_MAX_JOINTS);
+  return sizeof(double) * ((size_t)nlevels * (VAL_DOUBLES + TAN_SLOTS * 64) + 4 * (RTOC_MAX_JOINTS + 8) + 9 * RTOC_MAX_CONTACTS + RTOC_MAX_JOINTS);
 }
 
-static __global__ __launch_bounds__(64) void linearize_contact_dynamics_kernel(LinArgs a) {
+static __global__ __launch_bounds__(64) RTOC_RBD_WAVES void linearize_contact_dynamics_kernel(LinArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x;
   const int item = blockIdx.x;
@@ -129,6 +138,10 @@ static __global__ __launch_bounds__(64) void linearize_contact_dynamics_kernel(L
   double* const sa = sv + RTOC_MAX_JOINTS + 8;
   double* const sf = sa + RTOC_MAX_JOINTS + 8;
   double* const su = sf + 3 * RTOC_MAX_CONTACTS;
+  double* const sbeta = su + RTOC_MAX_JOINTS;           // multipliers of the dynamics (beta) and of the contact rows (mu)
+  double* const smu = sbeta + RTOC_MAX_JOINTS + 8;
+  double* const slf = smu + 3 * RTOC_MAX_CONTACTS;      // dC/da beta, accumulated over the passes
+  const bool aug = a.kkt != nullptr;
   const size_t rec = (size_t)b * a.nstages + st;
   const double* const sr = a.sol + rec * a.sol_stride;
   double* const cr = a.cdd + rec * a.cdd_stride;
@@ -140,6 +153,11 @@ static __global__ __launch_bounds__(64) void linearize_contact_dynamics_kernel(L
   }
   for (int e = lane; e < g.dimf; e += 64) sf[e] = sr[a.o_f + e];
   for (int e = lane; e < nu; e += 64) su[e] = sr[a.o_u + e];
+  if (aug) {
+    for (int e = lane; e < nv; e += 64) sbeta[e] = sr[a.o_beta + e];
+    for (int e = lane; e < g.dimf; e += 64) smu[e] = sr[a.o_mu + e];
+    for (int e = lane; e < 3 * RTOC_MAX_CONTACTS; e += 64) slf[e] = 0.0;
+  }
   __syncthreads();
   const V3 grav = ldv3(m.gravity);
   // impact grids: a dynamics traversal (zero gravity, zero velocity, acceleration = dv; robot.hxx:590-624) and a
@@ -152,6 +170,7 @@ static __global__ __launch_bounds__(64) void linearize_contact_dynamics_kernel(L
       const int j = j0 + lane / 3, kind = lane % 3;  // 0: q, 1: v, 2: a
       const bool lane_on = lane < 63 && j < nv;
       int top = -1;
+      double wsum = 0.0;  // this lane's column of [dID; dC] against [beta; mu]
       // body of the level that is being closed / visited is kept in LDS as an int in the value block
       auto LV = [&](int lev, int k) -> double& { return lval[lev * VAL_DOUBLES + k]; };
       auto LT = [&](int lev, int k) -> double& { return ltan[((size_t)lev * TAN_SLOTS + k) * 64 + lane]; };
@@ -186,11 +205,13 @@ static __global__ __launch_bounds__(64) void linearize_contact_dynamics_kernel(L
             for (int k = 0; k < 6; ++k) {
               if (lane == 0 && j0 == 0) cr[a.o_idc + iv + k] = fv[k] - ((!impact && iv + k >= nv - nu) ? su[iv + k - (nv - nu)] : 0.0);
               if (lane_on) dcol[iv + k] = dv6[k];
+              if (aug) wsum += dv6[k] * sbeta[iv + k];
             }
           } else {
             const V3 ax = ldv3(m.axis[i]);
             if (lane == 0 && j0 == 0) cr[a.o_idc + iv] = dot(ax, f.a) - ((!impact && iv >= nv - nu) ? su[iv - (nv - nu)] : 0.0);
             if (lane_on) dcol[iv] = dot(ax, df.a);
+            if (aug) wsum += dot(ax, df.a) * sbeta[iv];
           }
         }
         if (lev > 0) {
@@ -305,6 +326,19 @@ static __global__ __launch_bounds__(64) void linearize_contact_dynamics_kernel(L
                 if (kind == 0) dC = dC + kp * mul(mul(oR, Rf), jl);
               }
               const int r0 = nv + 3 * nact;
+              if (aug) {
+                wsum += dC.x * smu[3 * nact] + dC.y * smu[3 * nact + 1] + dC.z * smu[3 * nact + 2];
+                // lf -= dC/da beta (contact_dynamics.cpp:38; impact: dC/dv, impact_dynamics.cpp:21): sum over the a-lanes
+                const bool al = lane_on && kind == 2;
+                double rx = al ? dC.x * sbeta[j] : 0.0, ry = al ? dC.y * sbeta[j] : 0.0, rz = al ? dC.z * sbeta[j] : 0.0;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                  rx += __shfl_xor(rx, off, 64);
+                  ry += __shfl_xor(ry, off, 64);
+                  rz += __shfl_xor(rz, off, 64);
+                }
+                if (lane == 0) slf[3 * nact] += rx, slf[3 * nact + 1] += ry, slf[3 * nact + 2] += rz;
+              }
               if (lane == 0 && j0 == 0) {
                 cr[a.o_idc + r0] = C.x, cr[a.o_idc + r0 + 1] = C.y, cr[a.o_idc + r0 + 2] = C.z;
               }
@@ -343,7 +377,20 @@ static __global__ __launch_bounds__(64) void linearize_contact_dynamics_kernel(L
         close(top);
         --top;
       }
+      if (aug && lane_on) {
+        // lq / lv / la (ldv) += (this lane's column)^T [beta; mu]  (contact_dynamics.cpp:35-37,49-51; impact_dynamics.cpp:19-25)
+        double* const kr = a.kkt + rec * a.kkt_stride;
+        double* const dst = kind == 0 ? kr + a.o_lx + j : kind == 1 ? kr + a.o_lx + nv + j : cr + a.o_la + j;
+        if (!(impact && dyn && kind == 1)) *dst += wsum;
+      }
     }
+  }
+  if (aug) {
+    __syncthreads();
+    double* const kr = a.kkt + rec * a.kkt_stride;
+    if (lane < g.dimf) cr[a.o_lf + lane] -= slf[lane];
+    if (!impact && lane < nu) kr[a.o_lu + lane] -= sbeta[nv - nu + lane];                  // lu -= beta (actuated part)
+    if (nu < nv && lane < nv - nu) cr[a.o_lup + lane] = impact ? 0.0 : sr[a.o_nup + lane] - sbeta[lane];  // lu_passive
   }
 }
 

@@ -1278,9 +1278,10 @@ int rtoc_set_contact_schedule(rtoc_ctx* c, const unsigned* active, const double*
   return RTOC_OK;
 }
 
-int rtoc_linearize_contact_dynamics(rtoc_ctx* c) {
+int rtoc_linearize_contact_dynamics(rtoc_ctx* c, int augment_residual) {
   CHECK_READY(c);
   if (!c->h_model || !c->d_active || !c->buf[RTOC_BUF_SOL]) return RTOC_ERR_NOT_READY;
+  if (augment_residual && !c->buf[RTOC_BUF_KKT]) return RTOC_ERR_NOT_READY;
   int rc = ensure_buffer(c, RTOC_BUF_CDD);
   if (rc) return rc;
   rbd::LinArgs a;
@@ -1305,6 +1306,16 @@ int rtoc_linearize_contact_dynamics(rtoc_ctx* c) {
   a.o_didcdqv = c->L.cdd.off[RTOC_CDD_DIDCDQV];
   a.ldv = c->dims.nv + c->dims.nf_max;
   a.nf_max = c->dims.nf_max;
+  a.kkt = augment_residual ? c->buf[RTOC_BUF_KKT] : nullptr;
+  a.kkt_stride = c->L.kkt.stride;
+  a.o_lx = c->L.kkt.off[RTOC_KKT_LX];
+  a.o_lu = c->L.kkt.off[RTOC_KKT_LU];
+  a.o_la = c->L.cdd.off[RTOC_CDD_LA];
+  a.o_lf = c->L.cdd.off[RTOC_CDD_LF];
+  a.o_lup = c->L.cdd.off[RTOC_CDD_LUP];
+  a.o_beta = c->L.sol.off[RTOC_SOL_BETA];
+  a.o_mu = c->L.sol.off[RTOC_SOL_MU];
+  a.o_nup = c->L.sol.off[RTOC_SOL_NUP];
   if (c->nstages < 2) return RTOC_OK;
   hipLaunchKernelGGL(rbd::linearize_contact_dynamics_kernel, dim3(c->batch * (c->nstages - 1)), dim3(64),
                      rbd::lin_lds_bytes(c->h_model->nlevels), c->stream, a);

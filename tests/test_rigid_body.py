@@ -16,7 +16,7 @@ import numpy as np
 import pytest
 
 from robotoc_amd import capi, problems as pr, robot_model as rm
-from robotoc_amd.types import BUF_CDD, BUF_SOL, GRID_IMPACT, Dims
+from robotoc_amd.types import BUF_CDD, BUF_KKT, BUF_SOL, GRID_IMPACT, Dims
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 MODELS = os.path.join(ROOT, "tests", "golden", "models")
@@ -188,5 +188,111 @@ def test_gpu_linearisation_matches_the_restatement_and_its_finite_differences(or
                 worst["da"] = max(worst["da"], np.abs(J - Da[nv:]).max() / scale(Da))
     print("worst relative deviation:", worst)
     assert worst["val"] < 1e-12
-    assert worst["dq"] < 2e-7 and worst["dv"] < 2e-7 and worst["da"] < 2e-7
+    assert worst["dq"] < 1e-7 and worst["dv"] < 1e-7 and worst["da"] < 1e-7
+    # ---- multiplier terms (contact_dynamics.cpp:35-52, impact_dynamics.cpp:19-27) against the same algebra in numpy,
+    # on the derivative blocks the device just produced ----
+    kkt0 = rng.uniform(-1, 1, ctx.shape("kkt"))
+    cdd0 = cdd.copy()
+    for fld, size in ((7, nv), (8, nfm), (12, 8)):  # RTOC_CDD_LA, LF, LUP
+        cdd0[:, :, co[fld]:co[fld] + size] = rng.uniform(-1, 1, (batch, len(grids), size))
+    for b in range(batch):
+        for i in range(len(grids)):
+            sol[b, i, o[7]:o[7] + nv] = rng.uniform(-1, 1, nv)     # beta
+            sol[b, i, o[8]:o[8] + 12] = rng.uniform(-1, 1, 12)     # mu_stack
+            sol[b, i, o[9]:o[9] + 6] = rng.uniform(-1, 1, 6)       # nu_passive
+    ctx.upload(BUF_SOL, sol)
+    ctx.upload(BUF_KKT, kkt0)
+    ctx.upload(BUF_CDD, cdd0)
+    ctx.linearize_contact_dynamics(augment_residual=True)
+    ctx.sync()
+    kkt1, cdd1 = ctx.download(BUF_KKT, ctx.shape("kkt")), ctx.download(BUF_CDD, ctx.shape("cdd"))
+    ko = L.kkt.off
+    KKT_LX, KKT_LU = 6, 7  # RTOC_KKT_LX, RTOC_KKT_LU (include/rtoc_layout.h)
+    wa = 0.0
+    for b in range(batch):
+        for i in range(len(grids) - 1):
+            g = grids[i]
+            impact = g.type == GRID_IMPACT
+            nf, n = g.dimf, nv + g.dimf
+            s = sol[b, i]
+            beta, mu, nup = s[o[7]:o[7] + nv], s[o[8]:o[8] + nf], s[o[9]:o[9] + 6]
+            rec = cdd1[b, i]
+            D = rec[co[1]:co[1] + ldv * 2 * nv].reshape(2 * nv, ldv).T
+            M = rec[co[0]:co[0] + nv * nv].reshape(nv, nv).T
+            J = rec[co[2]:co[2] + nfm * nv].reshape(nv, nfm).T[:nf]
+            w = np.concatenate([beta, mu])
+            lx0, lx1 = kkt0[b, i, ko[KKT_LX]:ko[KKT_LX] + 2 * nv], kkt1[b, i, ko[KKT_LX]:ko[KKT_LX] + 2 * nv]
+            la0, la1 = cdd0[b, i, co[7]:co[7] + nv], rec[co[7]:co[7] + nv]
+            lf0, lf1 = cdd0[b, i, co[8]:co[8] + nf], rec[co[8]:co[8] + nf]
+            lu0, lu1 = kkt0[b, i, ko[KKT_LU]:ko[KKT_LU] + m.nu], kkt1[b, i, ko[KKT_LU]:ko[KKT_LU] + m.nu]
+            if impact:
+                exp_lq = lx0[:nv] + D[:n, :nv].T @ w
+                exp_lv = lx0[nv:] + D[nv:n, nv:].T @ mu
+                exp_la = la0 + M.T @ beta + D[nv:n, nv:].T @ mu
+                exp_lf = lf0 - D[nv:n, nv:] @ beta
+                exp_lu, exp_lup = lu0, np.zeros(6)
+            else:
+                exp_lq = lx0[:nv] + D[:n, :nv].T @ w
+                exp_lv = lx0[nv:] + D[:n, nv:].T @ w
+                exp_la = la0 + M.T @ beta + J.T @ mu
+                exp_lf = lf0 - J @ beta
+                exp_lu, exp_lup = lu0 - beta[6:], nup - beta[:6]
+            for got, exp in ((lx1[:nv], exp_lq), (lx1[nv:], exp_lv), (la1, exp_la), (lf1, exp_lf), (lu1, exp_lu), (rec[co[12]:co[12] + 6], exp_lup)):
+                if exp.size:
+                    wa = max(wa, np.abs(got - exp).max() / max(1.0, np.abs(exp).max()))
+    print("multiplier terms, worst relative deviation:", wa)
+    assert wa < 1e-12
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_linearisation_icub_two_passes_eleven_levels(oracle):
+    """nv = 35: 2 passes of 21 dofs, 11 tree levels (118 KB of LDS per wave); two foot point contacts"""
+    from robotoc_amd.types import Grid, GRID_INTERMEDIATE, GRID_TERMINAL
+    m = model("icub")
+    dims = Dims(35, 29, 6, 12, 12, 0)
+    inter = lambda dimf: Grid(GRID_INTERMEDIATE, 0, 0, 0, dimf, 0, 8, 2, 0.02)
+    grids = [inter(3), inter(6), Grid(GRID_IMPACT, 0, 0, 0, 3, 0, 1, -1, 0.0), inter(6), inter(0), Grid(GRID_TERMINAL, 0, 0, 0, 0, 0, 1, 2, 0.0)]
+    masks = np.array([0b11 if g.dimf == 6 else (0b10 if g.dimf == 3 else 0) for g in grids], dtype=np.uint32)
+    batch = 2
+    ctx = capi.Context(dims, len(grids), batch, 0)
+    L = ctx.L
+    ctx.set_grid(grids)
+    ctx.set_robot_model(m)
+    rng = np.random.default_rng(5)
+    pos = rng.uniform(-0.5, 0.5, (len(grids), 2, 3))
+    ctx.set_contact_schedule(masks, pos)
+    sol = np.zeros(ctx.shape("sol"))
+    o, co = L.sol.off, L.cdd.off
+    for b in range(batch):
+        for i in range(len(grids)):
+            q, v, a = rm.random_configuration(m, rng, 0.6)
+            sol[b, i, o[0]:o[0] + m.nq], sol[b, i, o[1]:o[1] + m.nv], sol[b, i, o[2]:o[2] + m.nv] = q, v, a
+            sol[b, i, o[3]:o[3] + m.nu] = rng.uniform(-5, 5, m.nu)
+            sol[b, i, o[4]:o[4] + 6] = rng.uniform(-20, 20, 6)
+    ctx.upload(BUF_SOL, sol)
+    ctx.linearize_contact_dynamics()
+    ctx.sync()
+    cdd = ctx.download(BUF_CDD, ctx.shape("cdd"))
+    nv, ldv = m.nv, dims.nv + dims.nf_max
+    worst = 0.0
+    for b in range(batch):
+        for i in range(len(grids) - 1):
+            g, act = grids[i], int(masks[i])
+            impact = g.type == GRID_IMPACT
+            n = nv + g.dimf
+            s = sol[b, i]
+            args = (m, impact, s[o[0]:o[0] + m.nq], s[o[1]:o[1] + nv], s[o[2]:o[2] + nv], s[o[4]:o[4] + 6], s[o[3]:o[3] + m.nu], act, pos[i].reshape(-1))
+            ref = oracle.rbd_eval(*args)
+            Dq, Dv, Da = oracle.rbd_linearize_fd(*args, 1e-6)
+            rec = cdd[b, i]
+            D = rec[co[1]:co[1] + ldv * 2 * nv].reshape(2 * nv, ldv).T
+            M = rec[co[0]:co[0] + nv * nv].reshape(nv, nv).T
+            assert np.abs(rec[co[3]:co[3] + n] - ref).max() < 1e-12 * max(1.0, np.abs(ref).max())
+            sc = lambda x: max(1.0, np.abs(x).max())
+            worst = max(worst, np.abs(D[:n, :nv] - Dq).max() / sc(Dq), np.abs(M - Da[:nv]).max() / sc(Da))
+            if not impact:
+                worst = max(worst, np.abs(D[:n, nv:] - Dv).max() / sc(Dv))
+    print("iCub worst relative deviation of the derivatives:", worst)
+    assert worst < 1e-7
     ctx.close()
