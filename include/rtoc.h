@@ -271,6 +271,20 @@ int rtoc_kkt_error(rtoc_ctx* ctx, double* host_out, int count);
 int rtoc_sto_eval_kkt(rtoc_ctx* ctx, const double* host_lt, const double* host_qtt_diag, int num_events,
                       double* host_err_sq, int count);
 
+/* LineSearchFilter (src/line_search/line_search_filter.cpp:26-60) of every instance, resident on the device: one call is
+ * the accept test of LineSearch::lineSearchFilterMethod (src/line_search/line_search.cpp:63-83) for one trial step of
+ * the whole batch.  For instance b with trial pair (cost[b], violation[b]) -- DirectMultipleShooting::getEval() of the
+ * trial iterate: cost + cost_barrier, primal_feasibility -- isAccepted() is evaluated against its filter; accepted pairs
+ * are augment()ed (dominated entries erased, order kept), and accepted[b] is set to 1, else 0.  An empty filter accepts
+ * everything, so the first call seeds the filters with the current iterates (:58-62).  mask[b] == 0 skips the instance
+ * (its step was accepted earlier in the backtracking loop); mask may be NULL.  Host arrays of `count` <= batch entries.
+ * RTOC_LINE_SEARCH_FILTER_CAPACITY pairs per instance; an instance whose filter is full keeps its newest entries. */
+#define RTOC_LINE_SEARCH_FILTER_CAPACITY 32
+int rtoc_line_search_filter(rtoc_ctx* ctx, const double* cost, const double* violation, const int* mask, int count,
+                            double cost_reduction_rate, double constraint_violation_reduction_rate, int* accepted);
+/* LineSearch::clearHistory (line_search.cpp:52-54) for every instance. */
+int rtoc_line_search_clear(rtoc_ctx* ctx);
+
 /* SplitSolution::integrate (src/core/split_solution.cpp:58-90) on every grid point, as the
  * updatePrimal half of DirectMultipleShooting::integrateSolution (direct_multiple_shooting.cpp:212-241)
  * does after rtoc_expand: RTOC_BUF_SOL += primal step (RTOC_BUF_STEP) x RTOC_BUF_DIR for v, a (dv on

@@ -71,3 +71,57 @@ def expand_stage(L, g, cdd_rec, dir_rec, dir_next_rec, contact_dim=3):
 
 def correct_costate(L, se3_rec, dir_rec):
     lib().ref_correct_costate(C.byref(L), _p(se3_rec), _p(dir_rec))
+
+
+# ---- the reference's own TimeDiscretization and LineSearchFilter (oracle/_ref/librtoc_ref_td.so) ----
+_LIB_TD = None
+
+
+def lib_td():
+    global _LIB_TD
+    if _LIB_TD is None:
+        build()
+        L = C.CDLL(os.path.join(_HERE, "_ref", "librtoc_ref_td.so"))
+        ip, dp = C.POINTER(C.c_int), C.POINTER(C.c_double)
+        L.ref_td_discretize.argtypes = [C.c_double, C.c_int, C.c_double, C.c_int, ip, dp, ip, C.c_int, ip, dp, dp]
+        L.ref_td_discretize.restype = C.c_int
+        L.ref_filter_create.argtypes = [C.c_double, C.c_double]
+        L.ref_filter_create.restype = C.c_void_p
+        L.ref_filter_destroy.argtypes = [C.c_void_p]
+        L.ref_filter_clear.argtypes = [C.c_void_p]
+        L.ref_filter_try.argtypes = [C.c_void_p, C.c_double, C.c_double]
+        L.ref_filter_try.restype = C.c_int
+        _LIB_TD = L
+    return _LIB_TD
+
+
+def discretize(T, N, t, events, phase_based):
+    """TimeDiscretization::discretize (+ correctTimeSteps): events = [(kind 'impact'|'lift', time, sto)].
+    Returns (table [n+1, 11] ints: type, phase, sto, sto_next, switching_constraint, stage_in_phase, num_grids_in_phase,
+    impact_index, lift_index, stage, 0; dt [n+1]; t [n+1]; maxTimeStep)."""
+    ne = len(events)
+    kind = np.array([0 if e[0] == "impact" else 1 for e in events], dtype=np.int32)
+    time = np.array([e[1] for e in events], dtype=np.float64)
+    sto = np.array([int(e[2]) for e in events], dtype=np.int32)
+    cap = N + 2 + 3 * ne
+    oi, od, mx = np.zeros((cap, 11), dtype=np.int32), np.zeros((cap, 2)), C.c_double()
+    ip, dp = C.POINTER(C.c_int), C.POINTER(C.c_double)
+    n = lib_td().ref_td_discretize(T, N, t, ne, kind.ctypes.data_as(ip), time.ctypes.data_as(dp), sto.ctypes.data_as(ip),
+                                   int(phase_based), oi.ctypes.data_as(ip), od.ctypes.data_as(dp), C.byref(mx))
+    return oi[:n + 1], od[:n + 1, 0].copy(), od[:n + 1, 1].copy(), mx.value
+
+
+class LineSearchFilter:
+    def __init__(self, cost_reduction_rate=0.005, constraint_violation_reduction_rate=0.005):
+        self._h = lib_td().ref_filter_create(cost_reduction_rate, constraint_violation_reduction_rate)
+
+    def try_step(self, cost, violation):
+        return lib_td().ref_filter_try(self._h, cost, violation)
+
+    def clear(self):
+        lib_td().ref_filter_clear(self._h)
+
+    def __del__(self):
+        if self._h:
+            lib_td().ref_filter_destroy(self._h)
+            self._h = None

@@ -27,7 +27,11 @@ EXPORTS = [
     "rtoc_compute_initial_state_direction", "rtoc_unconstr_condense", "rtoc_unconstr_expand",
     "rtoc_newton_iteration", "rtoc_converged_count", "rtoc_clone", "rtoc_check_fxx_structure", "rtoc_sto_eval_kkt", "rtoc_set_friction_cones", "rtoc_set_wrench_cones", "rtoc_wrench_cone_matrix", "rtoc_save_stage_dump", "rtoc_load_stage_dump", "rtoc_kkt_error", "rtoc_integrate_solution",
     "rtoc_set_robot_model", "rtoc_set_contact_schedule", "rtoc_linearize_contact_dynamics",
+    "rtoc_line_search_filter", "rtoc_line_search_clear",
 ]
+
+
+LINE_SEARCH_FILTER_CAPACITY = 32  # RTOC_LINE_SEARCH_FILTER_CAPACITY
 
 
 class RtocError(RuntimeError):
@@ -113,6 +117,8 @@ def lib():
         L.rtoc_sto_eval_kkt.argtypes = [vp, dp, dp, C.c_int, dp, C.c_int]
         L.rtoc_clone.argtypes = [vp, C.POINTER(vp)]
         L.rtoc_set_robot_model.argtypes = [vp, vp]
+        L.rtoc_line_search_filter.argtypes = [vp, dp, dp, C.POINTER(C.c_int), C.c_int, C.c_double, C.c_double, C.POINTER(C.c_int)]
+        L.rtoc_line_search_clear.argtypes = [vp]
         L.rtoc_linearize_contact_dynamics.argtypes = [vp, C.c_int]
         L.rtoc_set_contact_schedule.argtypes = [vp, C.POINTER(C.c_uint), dp]
         L.rtoc_load_stage_dump.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
@@ -296,6 +302,23 @@ class Context:
 
     def integrate_solution(self):
         _chk(lib().rtoc_integrate_solution(self._h))
+
+    # ---- filter line search (line_search_filter.cpp), batched ----
+    def line_search_filter(self, cost, violation, mask=None, cost_reduction_rate=0.005, constraint_violation_reduction_rate=0.005):
+        """rtoc_line_search_filter: accept test + filter update of every instance; returns accepted [batch] (0/1).
+        Default rates: LineSearchSettings (include/robotoc/line_search/line_search_settings.hpp)."""
+        cost = np.ascontiguousarray(cost, dtype=np.float64)
+        violation = np.ascontiguousarray(violation, dtype=np.float64)
+        n = cost.shape[0]
+        acc = np.zeros(n, dtype=np.int32)
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.int32)
+        ip = C.POINTER(C.c_int)
+        _chk(lib().rtoc_line_search_filter(self._h, _dp(cost), _dp(violation), m.ctypes.data_as(ip) if m is not None else None, n,
+                                           cost_reduction_rate, constraint_violation_reduction_rate, acc.ctypes.data_as(ip)))
+        return acc
+
+    def line_search_clear(self):
+        _chk(lib().rtoc_line_search_clear(self._h))
 
     # ---- rigid-body linearisation (include/rtoc_robot.h) ----
     def set_robot_model(self, model):

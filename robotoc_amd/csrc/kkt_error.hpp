@@ -147,4 +147,55 @@ static __global__ void sto_eval_kkt_kernel(StoArgs a) {
   a.err[b] = err;
 }
 
+
+// ---- LineSearchFilter of every instance (src/line_search/line_search_filter.cpp) -------------------
+struct FilterArgs {
+  double* filt;      // [batch][CAP][2] (cost, violation)
+  int* nfilt;        // [batch]
+  const double* cost;
+  const double* viol;
+  const int* mask;   // may be nullptr
+  int* accepted;
+  int count, cap;
+  double cost_rate, viol_rate;
+};
+
+static __global__ void line_search_filter_kernel(FilterArgs a) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.count) return;
+  if (a.mask && !a.mask[b]) {
+    a.accepted[b] = 0;
+    return;
+  }
+  double* f = a.filt + (size_t)b * a.cap * 2;
+  int n = a.nfilt[b];
+  const double c = a.cost[b], v = a.viol[b];
+  // isAccepted (:26-39): an empty filter accepts; otherwise ANY entry that the pair improves on
+  bool ok = n == 0;
+  for (int e = 0; e < n && !ok; ++e)
+    ok = (c < f[2 * e] - a.cost_rate * f[2 * e + 1]) || (v < (1.0 - a.viol_rate) * f[2 * e + 1]);
+  a.accepted[b] = ok ? 1 : 0;
+  if (!ok) return;
+  // augment (:42-60): erase the entries the new pair dominates, keep the order, append
+  int w = 0;
+  for (int e = 0; e < n; ++e) {
+    const double ce = f[2 * e], ve = f[2 * e + 1];
+    if (!(ce <= c && ve <= v)) {
+      f[2 * w] = ce;
+      f[2 * w + 1] = ve;
+      ++w;
+    }
+  }
+  if (w == a.cap) {  // full: drop the oldest
+    for (int e = 1; e < w; ++e) {
+      f[2 * (e - 1)] = f[2 * e];
+      f[2 * (e - 1) + 1] = f[2 * e + 1];
+    }
+    --w;
+  }
+  f[2 * w] = c;
+  f[2 * w + 1] = v;
+  a.nfilt[b] = w + 1;
+}
+
 }  // namespace rtoc

@@ -108,6 +108,11 @@ struct rtoc_ctx {
   unsigned* d_active;
   double* d_cpos;
   bool has_cpos;
+  // rtoc_line_search_filter: filters [batch][CAP][2], sizes [batch], staging (cost, violation | mask, accepted)
+  double* d_filter;
+  int* d_nfilter;
+  double* d_ls_in;
+  int* d_ls_flags;
 };
 
 extern "C" {
@@ -256,6 +261,10 @@ int rtoc_destroy(rtoc_ctx* c) {
   if (c->d_model) (void)hipFree(c->d_model);
   delete c->h_model;
   if (c->d_active) (void)hipFree(c->d_active);
+  if (c->d_filter) (void)hipFree(c->d_filter);
+  if (c->d_nfilter) (void)hipFree(c->d_nfilter);
+  if (c->d_ls_in) (void)hipFree(c->d_ls_in);
+  if (c->d_ls_flags) (void)hipFree(c->d_ls_flags);
   if (c->d_cpos) (void)hipFree(c->d_cpos);
   if (c->d_prof) (void)hipFree(c->d_prof);
   for (int i = 0; i < 3; ++i)
@@ -1372,8 +1381,6 @@ int rtoc_sto_eval_kkt(rtoc_ctx* c, const double* host_lt, const double* host_qtt
   const size_t n = (size_t)c->batch * (nev > 0 ? nev : 1);
   if (c->sto_cap < n) {
     if (c->d_sto) (void)hipFree(c->d_sto);
-  if (c->g_sweep.exec) (void)hipGraphExecDestroy(c->g_sweep.exec);
-  if (c->g_newton.exec) (void)hipGraphExecDestroy(c->g_newton.exec);
     c->d_sto = nullptr;
     HIP_TRY(hipMalloc((void**)&c->d_sto, (2 * n + c->batch) * sizeof(double)));
     c->sto_cap = n;
@@ -1400,6 +1407,55 @@ int rtoc_sto_eval_kkt(rtoc_ctx* c, const double* host_lt, const double* host_qtt
   HIP_TRY(hipGetLastError());
   if (host_err_sq && count > 0)
     HIP_TRY(hipMemcpyAsync(host_err_sq, d_err, sizeof(double) * count, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return RTOC_OK;
+}
+
+// ---- filter line search (line_search_filter.cpp), batched ---------------------------------------
+static int ensure_filter(rtoc_ctx* c) {
+  if (c->d_filter) return RTOC_OK;
+  HIP_TRY(hipMalloc((void**)&c->d_filter, sizeof(double) * 2 * RTOC_LINE_SEARCH_FILTER_CAPACITY * c->batch));
+  HIP_TRY(hipMalloc((void**)&c->d_nfilter, sizeof(int) * c->batch));
+  HIP_TRY(hipMalloc((void**)&c->d_ls_in, sizeof(double) * 2 * c->batch));
+  HIP_TRY(hipMalloc((void**)&c->d_ls_flags, sizeof(int) * 2 * c->batch));
+  HIP_TRY(hipMemsetAsync(c->d_nfilter, 0, sizeof(int) * c->batch, c->stream));
+  return RTOC_OK;
+}
+
+int rtoc_line_search_clear(rtoc_ctx* c) {
+  if (!c) return RTOC_ERR_BAD_ARG;
+  HIP_TRY(hipSetDevice(c->device));
+  int rc = ensure_filter(c);
+  if (rc) return rc;
+  HIP_TRY(hipMemsetAsync(c->d_nfilter, 0, sizeof(int) * c->batch, c->stream));
+  return RTOC_OK;
+}
+
+int rtoc_line_search_filter(rtoc_ctx* c, const double* cost, const double* violation, const int* mask, int count,
+                            double cost_rate, double viol_rate, int* accepted) {
+  if (!c || !cost || !violation || !accepted || count < 0 || count > c->batch) return RTOC_ERR_BAD_ARG;
+  if (!(cost_rate > 0.0) || !(viol_rate > 0.0)) return RTOC_ERR_BAD_ARG;  // line_search_filter.cpp:14-19
+  HIP_TRY(hipSetDevice(c->device));
+  int rc = ensure_filter(c);
+  if (rc) return rc;
+  if (count == 0) return RTOC_OK;
+  HIP_TRY(hipMemcpyAsync(c->d_ls_in, cost, sizeof(double) * count, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->d_ls_in + c->batch, violation, sizeof(double) * count, hipMemcpyHostToDevice, c->stream));
+  if (mask) HIP_TRY(hipMemcpyAsync(c->d_ls_flags, mask, sizeof(int) * count, hipMemcpyHostToDevice, c->stream));
+  FilterArgs a;
+  a.filt = c->d_filter;
+  a.nfilt = c->d_nfilter;
+  a.cost = c->d_ls_in;
+  a.viol = c->d_ls_in + c->batch;
+  a.mask = mask ? c->d_ls_flags : nullptr;
+  a.accepted = c->d_ls_flags + c->batch;
+  a.count = count;
+  a.cap = RTOC_LINE_SEARCH_FILTER_CAPACITY;
+  a.cost_rate = cost_rate;
+  a.viol_rate = viol_rate;
+  hipLaunchKernelGGL(line_search_filter_kernel, dim3((count + 255) / 256), dim3(256), 0, c->stream, a);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(accepted, c->d_ls_flags + c->batch, sizeof(int) * count, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return RTOC_OK;
 }

@@ -217,3 +217,63 @@ def jump_sto_sequence(ground_time=0.31, flying_time=0.2, nf=12):
     return ContactSequence([nf, 0, nf], [Event("lift", ground_time, sto=True),
                                          Event("impact", ground_time + flying_time, sto=True,
                                                impact_dimf=nf)])
+
+
+def max_time_step(grids):
+    """TimeDiscretization::maxTimeStep (time_discretization.hpp:121-127)"""
+    return max(g.dt for g in grids[:-1])
+
+
+def correct_time_steps(grids, T, t, cs):
+    """TimeDiscretization::correctTimeSteps (time_discretization.cpp:186-262) after the switching times in `cs` moved:
+    same grid structure, time steps of every phase re-spread between its (new) event times."""
+    N = len(grids) - 1 - len(cs.lifts()) - 2 * len(cs.impacts())
+    new = discretize_structure_preserving(grids, T, t, cs)
+    assert len(new) == len(grids) and N > 0
+    return new
+
+
+def discretize_structure_preserving(grids, T, t, cs):
+    out = [Grid(g.type, g.sto, g.sto_next, g.switching_constraint, g.dimf, g.dims, g.num_grids_in_phase, g.time_stage, g.dt)
+           for g in grids]
+    impacts, lifts = cs.impacts(), cs.lifts()
+    n = len(out) - 1
+    prev_stage, prev_time, ii, li, i = 0, t, 0, 0, 0
+    while ii < len(impacts) and impacts[ii].time <= t:
+        ii += 1
+    while li < len(lifts) and lifts[li].time <= t:
+        li += 1
+    while i < n:
+        if out[i].type == GRID_IMPACT:
+            ev = impacts[ii].time
+            ii += 1
+            d = (ev - prev_time) / out[i - 1].num_grids_in_phase
+            for j in range(prev_stage, i):
+                out[j].dt = d
+            out[i].dt = 0.0
+            prev_time, prev_stage = ev, i + 1
+            i += 1
+        elif out[i + 1].type == GRID_LIFT:
+            ev = lifts[li].time
+            li += 1
+            d = (ev - prev_time) / out[i].num_grids_in_phase
+            for j in range(prev_stage, i + 1):
+                out[j].dt = d
+            prev_time, prev_stage = ev, i + 1
+        elif out[i + 1].type == GRID_TERMINAL:
+            d = (t + T - prev_time) / out[i].num_grids_in_phase
+            for j in range(prev_stage, i + 1):
+                out[j].dt = d
+        i += 1
+    out[n].dt = 0.0
+    return out
+
+
+def mesh_refinement(grids, N, T, t, cs, max_dt_mesh):
+    """The mesh-refinement step of OCPSolver::solve (ocp_solver.cpp:184-199) for a phase-based discretisation: if the
+    largest time step exceeds max_dt_mesh the horizon is re-discretised at the current switching times (discretize(t) ->
+    TimeDiscretization::discretize + correctTimeSteps), which moves grid points between the phases; the caller then
+    re-initialises the constraints and clears the line-search filter (rtoc_line_search_clear).  Returns (grids, refined)."""
+    if max_time_step(grids) > max_dt_mesh:
+        return discretize(N, T, t, cs, phase_based=True), True
+    return grids, False
