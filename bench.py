@@ -450,6 +450,48 @@ def main():
                         "Riccati backward/forward + expandContactDynamics primal/dual + PDIPM expansion, "
                         "fraction-to-boundary step sizes, convergence mask and slack/dual update; linearisation, "
                         "cost and the manifold update of q are CPU-side and excluded"}
+        # ---- the rigid-body linearisation upstream of the condensation: ANYmal model table, trot contact
+        #      schedule, a distinct random (q, v, a, f, u, beta, mu) per grid point generated in HBM ----
+        if rank == 0:
+            from robotoc_amd import robot_model as rm
+            from robotoc_amd.types import BUF_SOL
+            model = rm.load_named("anymal")
+            ctx.set_robot_model(model)
+            masks, flip = [], False
+            for g in grids:
+                masks.append(0b1111 if g.dimf == 12 else 0 if g.dimf == 0 else (0b0110 if flip else 0b1001))
+                flip = flip != (g.dimf == 6)
+            ctx.set_contact_schedule(np.array(masks, dtype=np.uint32), np.zeros((len(grids), 4, 3)))
+            gen = torch.Generator(device=dev)
+            gen.manual_seed(4242)
+            sol_t = torch.zeros(batch, len(grids), L.sol.stride, dtype=torch.float64, device=dev)
+            o = L.sol.off
+            U = lambda n, s: s * (2.0 * torch.rand(batch, len(grids), n, dtype=torch.float64, device=dev, generator=gen) - 1.0)
+            sol_t[:, :, o[0]:o[0] + 19] = U(19, 0.8)
+            quat = torch.randn(batch, len(grids), 4, dtype=torch.float64, device=dev, generator=gen)
+            sol_t[:, :, o[0] + 3:o[0] + 7] = quat / quat.norm(dim=-1, keepdim=True)
+            for fld, n, sc in ((1, 18, 0.8), (2, 18, 0.8), (3, 12, 5.0), (4, 12, 20.0), (7, 18, 1.0), (8, 12, 1.0), (9, 6, 1.0)):
+                sol_t[:, :, o[fld]:o[fld] + n] = U(n, sc)
+            ctx.bind(BUF_SOL, sol_t.data_ptr())
+            restore()
+            ctx.time_phase(8, 1)
+            lin_ms = min(ctx.time_phase(8, 1) for _ in range(3))
+            lin_ms0 = min(ctx.time_phase(7, 1) for _ in range(3))
+            nvm, nfm = 18, 12
+            per_point = 8 * ((19 + 18 + 18 + 12 + 12 + 18 + 12 + 6)            # q, v, a, u, f, beta, mu, nu_passive in
+                             + nvm * nvm + (nvm + nfm) * 2 * nvm + nfm * nvm + (nvm + nfm)  # dIDda, dIDCdqv, dCda, IDC out
+                             + 2 * (2 * nvm + nvm + nfm + 12) + 6)              # lx, la, lf, lu read-modify-write, lu_passive
+            lb = per_point * batch * (len(grids) - 1)
+            sqp["linearize"] = {"ms": lin_ms, "ms_without_multiplier_terms": lin_ms0, "grid_points": batch * (len(grids) - 1),
+                                "ns_per_grid_point": lin_ms * 1e6 / (batch * (len(grids) - 1)),
+                                "roofline": {"bound": "valu_f64", "achieved": lb / (lin_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                             "frac": lb / (lin_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": lb,
+                                             "note": "instruction-bound: 13.4k fp64 VALU instructions per grid point (one wave, one lane per "
+                                                     "tangent direction), profiles/%s_rocprof_summary.txt" % PROFILE_ROUND},
+                                "scope": "linearizeContactDynamics / linearizeImpactDynamics incl. the multiplier terms; NOT part of "
+                                         "newton_iteration_ms (cost / constraint derivatives stay on the CPU side)",
+                                "status_nonzero_instances": int((ctx.status() != 0).sum())}
+            del sol_t
         del kkt0, cdd0, con0, kkt_w, cdd_w, con_w, cone_t
 
     # ---- the other BASELINE.json configurations (parity-test cases; reported, not the headline):

@@ -249,7 +249,8 @@ int rtoc_sync(rtoc_ctx* ctx);
 /* Time `reps` back-to-back launches of one phase with HIP events recorded on the
  * context's stream; returns the mean milliseconds per launch in *ms.
  * phase: 0 backward, 1 forward, 2 condense, 3 expand, 4 backward+forward, 5 update,
- * 6 rtoc_newton_iteration(kkt_tol = 0, tau = 0.995). */
+ * 6 rtoc_newton_iteration(kkt_tol = 0, tau = 0.995), 7 / 8 rtoc_linearize_contact_dynamics(augment_residual = 0 / 1)
+ * (rtoc_robot.h). */
 int rtoc_time_phase(rtoc_ctx* ctx, int phase, int reps, float* ms);
 
 /* ---- KKT error of every instance (first piece of the on-device Newton loop) ----

@@ -30,11 +30,33 @@
 namespace rtoc {
 namespace rbd {
 
+// per-joint / per-contact constants as the kernel reads them, packed by rtoc_set_robot_model: one coalesced copy into
+// LDS per grid point instead of ~30 dependent L2 round trips per visited body
+constexpr int JP = 32;  // doubles per joint: R 9, p 3, axis 3, mass 1, com 3, I 9 (28), type, idx_q, idx_v, depth
+constexpr int CP = 16;  // doubles per contact: R 9, p 3, kp, kd, parent
 struct DevModel {
   rtoc_robot_model m;
   int depth[RTOC_MAX_JOINTS];
   int nlevels;
+  double joint[RTOC_MAX_JOINTS][JP];
+  double contact[RTOC_MAX_CONTACTS][CP];
 };
+inline void pack_model(DevModel* h) {
+  const rtoc_robot_model& m = h->m;
+  for (int i = 0; i < m.njoints; ++i) {
+    double* o = h->joint[i];
+    for (int k = 0; k < 9; ++k) o[k] = m.placement_R[i][k], o[19 + k] = m.inertia[i][k];
+    for (int k = 0; k < 3; ++k) o[9 + k] = m.placement_p[i][k], o[12 + k] = m.axis[i][k], o[16 + k] = m.com[i][k];
+    o[15] = m.mass[i];
+    o[28] = m.type[i], o[29] = m.idx_q[i], o[30] = m.idx_v[i], o[31] = h->depth[i];
+  }
+  for (int c = 0; c < m.ncontacts; ++c) {
+    double* o = h->contact[c];
+    for (int k = 0; k < 9; ++k) o[k] = m.contact_R[c][k];
+    for (int k = 0; k < 3; ++k) o[9 + k] = m.contact_p[c][k];
+    o[12] = m.contact_kp[c], o[13] = m.contact_kd[c], o[14] = m.contact_parent[c], o[15] = 0.0;
+  }
+}
 
 struct V3 {
   double x, y, z;
@@ -104,6 +126,8 @@ struct LinArgs {
   int o_q, o_v, o_a, o_u, o_f;                 // RTOC_BUF_SOL field offsets
   int o_idc, o_didda, o_dcda, o_didcdqv;       // RTOC_BUF_CDD field offsets
   int ldv, nf_max;                             // leading dimensions of DIDCDQV / DCDA
+  int nlevels, nv, nq, njoints, ncontacts, nu;
+  double gx, gy, gz;                           // gravity
   // multiplier terms of linearizeContactDynamics / linearizeImpactDynamics (kkt == nullptr: left out)
   double* kkt;
   int kkt_stride, o_lx, o_lu;                  // RTOC_BUF_KKT: lx = [lq; lv], lu
@@ -114,8 +138,9 @@ struct LinArgs {
 // per-level storage in LDS
 constexpr int VAL_DOUBLES = 64;  // R 9, p 3, oR 9, op 3, v 6, a 6, g 3, f 6, vpar 6, apar 6 -> 57, padded
 constexpr int TAN_SLOTS = 21;    // dv 6, da 6, dg 3, df 6
-__host__ __device__ constexpr size_t lin_lds_bytes(int nlevels) {
-  return sizeof(double) * ((size_t)nlevels * (VAL_DOUBLES + TAN_SLOTS * 64) + 4 * (RTOC_MAX_JOINTS + 8) + 9 * RTOC_MAX_CONTACTS + RTOC_MAX_JOINTS);
+__host__ __device__ constexpr size_t lin_lds_bytes(int nlevels, int njoints, int ncontacts) {
+  return sizeof(double) * ((size_t)nlevels * (VAL_DOUBLES + TAN_SLOTS * 64) + 4 * (RTOC_MAX_JOINTS + 8) + 9 * RTOC_MAX_CONTACTS + RTOC_MAX_JOINTS +
+                           njoints * JP + ncontacts * CP);
 }
 
 static __global__ __launch_bounds__(64) RTOC_RBD_WAVES void linearize_contact_dynamics_kernel(LinArgs a) {
@@ -125,9 +150,7 @@ static __global__ __launch_bounds__(64) RTOC_RBD_WAVES void linearize_contact_dy
   const int nst1 = a.nstages - 1;
   const int b = item / nst1, st = item % nst1;
   if (b >= a.batch) return;
-  const rtoc_robot_model& m = a.model->m;
-  const int* const depth = a.model->depth;
-  const int nlev = a.model->nlevels, nv = m.nv, nb = m.njoints;
+  const int nlev = a.nlevels, nv = a.nv, nb = a.njoints, ncon = a.ncontacts;
   const rtoc_grid g = a.grid[st];
   const bool impact = g.type == RTOC_GRID_IMPACT;
   const unsigned active = a.active[st];
@@ -141,12 +164,20 @@ static __global__ __launch_bounds__(64) RTOC_RBD_WAVES void linearize_contact_dy
   double* const sbeta = su + RTOC_MAX_JOINTS;           // multipliers of the dynamics (beta) and of the contact rows (mu)
   double* const smu = sbeta + RTOC_MAX_JOINTS + 8;
   double* const slf = smu + 3 * RTOC_MAX_CONTACTS;      // dC/da beta, accumulated over the passes
+  double* const sjm = slf + 3 * RTOC_MAX_CONTACTS;      // model: [njoints][JP], then [ncontacts][CP]
+  double* const scm = sjm + a.njoints * JP;
   const bool aug = a.kkt != nullptr;
   const size_t rec = (size_t)b * a.nstages + st;
   const double* const sr = a.sol + rec * a.sol_stride;
   double* const cr = a.cdd + rec * a.cdd_stride;
-  const int nu = (m.type[0] == RTOC_JOINT_FREE_FLYER) ? nv - 6 : nv;
-  for (int e = lane; e < m.nq; e += 64) sq[e] = sr[a.o_q + e];
+  const int nu = a.nu;
+  {
+    const double* const gj = &a.model->joint[0][0];
+    const double* const gc = &a.model->contact[0][0];
+    for (int e = lane; e < nb * JP; e += 64) sjm[e] = gj[e];
+    for (int e = lane; e < ncon * CP; e += 64) scm[e] = gc[e];
+  }
+  for (int e = lane; e < a.nq; e += 64) sq[e] = sr[a.o_q + e];
   for (int e = lane; e < nv; e += 64) {
     sv[e] = sr[a.o_v + e];
     sa[e] = sr[a.o_a + e];
@@ -159,7 +190,7 @@ static __global__ __launch_bounds__(64) RTOC_RBD_WAVES void linearize_contact_dy
     for (int e = lane; e < 3 * RTOC_MAX_CONTACTS; e += 64) slf[e] = 0.0;
   }
   __syncthreads();
-  const V3 grav = ldv3(m.gravity);
+  const V3 grav = mk(a.gx, a.gy, a.gz);
   // impact grids: a dynamics traversal (zero gravity, zero velocity, acceleration = dv; robot.hxx:590-624) and a
   // kinematics traversal at v + dv for the contact-velocity rows (impact_stage.cpp:61); other grids: one traversal
   const int ntrav = impact ? 2 : 1;
@@ -184,22 +215,24 @@ static __global__ __launch_bounds__(64) RTOC_RBD_WAVES void linearize_contact_dy
       };
       // value slots: 0 R, 9 p, 12 oR, 21 op, 24 v, 30 a, 36 g, 39 f, 45 body index
       // tangent slots: 0 dv, 6 da, 12 dg, 15 df
+      auto JM = [&](int i, int k) -> const double& { return sjm[i * JP + k]; };
       auto unit_twist = [&](int i, int k) -> SV {  // S_k of joint i
-        if (m.type[i] == RTOC_JOINT_FREE_FLYER)
+        if ((int)JM(i, 28) == RTOC_JOINT_FREE_FLYER)
           return SV{mk(k == 0, k == 1, k == 2), mk(k == 3, k == 4, k == 5)};
-        return SV{mk(0, 0, 0), ldv3(m.axis[i])};
+        return SV{mk(0, 0, 0), ldv3(&JM(i, 12))};
       };
       auto close = [&](int lev) {
         const int i = (int)LV(lev, 45);
         const M3 R = ldm3(&LV(lev, 0));
         const V3 p = ldv3(&LV(lev, 9));
         const SV f = ld_sv(lev, 39), df = ld_tv(lev, 15);
-        const int iv = m.idx_v[i];
-        const bool own = lane_on && j >= iv && j < iv + (m.type[i] == RTOC_JOINT_FREE_FLYER ? 6 : 1);
+        const int iv = (int)JM(i, 30);
+        const bool cff = (int)JM(i, 28) == RTOC_JOINT_FREE_FLYER;
+        const bool own = lane_on && j >= iv && j < iv + (cff ? 6 : 1);
         if (dyn) {
           // tau = S^T f: value (lane 0) and this lane's column
           double* const dcol = kind == 2 ? cr + a.o_didda + (size_t)j * nv : cr + a.o_didcdqv + (size_t)(kind == 1 ? nv + j : j) * a.ldv;
-          if (m.type[i] == RTOC_JOINT_FREE_FLYER) {
+          if (cff) {
             const double fv[6] = {f.l.x, f.l.y, f.l.z, f.a.x, f.a.y, f.a.z}, dv6[6] = {df.l.x, df.l.y, df.l.z, df.a.x, df.a.y, df.a.z};
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
@@ -208,7 +241,7 @@ static __global__ __launch_bounds__(64) RTOC_RBD_WAVES void linearize_contact_dy
               if (aug) wsum += dv6[k] * sbeta[iv + k];
             }
           } else {
-            const V3 ax = ldv3(m.axis[i]);
+            const V3 ax = ldv3(&JM(i, 12));
             if (lane == 0 && j0 == 0) cr[a.o_idc + iv] = dot(ax, f.a) - ((!impact && iv >= nv - nu) ? su[iv - (nv - nu)] : 0.0);
             if (lane_on) dcol[iv] = dot(ax, df.a);
             if (aug) wsum += dot(ax, df.a) * sbeta[iv];
@@ -222,14 +255,14 @@ static __global__ __launch_bounds__(64) RTOC_RBD_WAVES void linearize_contact_dy
         }
       };
       for (int i = 0; i < nb; ++i) {
-        const int d = depth[i];
+        const int d = (int)JM(i, 31);
         while (top >= d) {
           close(top);
           --top;
         }
         // ---- visit body i at level d ----
-        const int iq = m.idx_q[i], iv = m.idx_v[i];
-        const bool ff = m.type[i] == RTOC_JOINT_FREE_FLYER;
+        const int iq = (int)JM(i, 29), iv = (int)JM(i, 30);
+        const bool ff = (int)JM(i, 28) == RTOC_JOINT_FREE_FLYER;
         const bool own = lane_on && j >= iv && j < iv + (ff ? 6 : 1);
         M3 Rj;
         V3 pj = mk(0, 0, 0);
@@ -244,7 +277,7 @@ static __global__ __launch_bounds__(64) RTOC_RBD_WAVES void linearize_contact_dy
           aj = SV{mk(sa[iv], sa[iv + 1], sa[iv + 2]), mk(sa[iv + 3], sa[iv + 4], sa[iv + 5])};
           if (impact && !dyn) vj = vj + aj;  // kinematics at v + dv
         } else {
-          const V3 ax = ldv3(m.axis[i]);
+          const V3 ax = ldv3(&JM(i, 12));
           const double th = sq[iq], c = cos(th), s = sin(th), t = 1.0 - c;
           Rj.m[0] = t * ax.x * ax.x + c, Rj.m[1] = t * ax.x * ax.y - s * ax.z, Rj.m[2] = t * ax.x * ax.z + s * ax.y;
           Rj.m[3] = t * ax.x * ax.y + s * ax.z, Rj.m[4] = t * ax.y * ax.y + c, Rj.m[5] = t * ax.y * ax.z - s * ax.x;
@@ -255,9 +288,9 @@ static __global__ __launch_bounds__(64) RTOC_RBD_WAVES void linearize_contact_dy
         }
         if (impact && dyn) vj = sv0();   // impact model: v = 0
         if (impact && !dyn) aj = sv0();  // velocity-level rows only
-        const M3 Rp = ldm3(m.placement_R[i]);
+        const M3 Rp = ldm3(&JM(i, 0));
         const M3 R = mul(Rp, Rj);
-        const V3 p = mul(Rp, pj) + ldv3(m.placement_p[i]);
+        const V3 p = mul(Rp, pj) + ldv3(&JM(i, 9));
         M3 oR = R;
         V3 op = p;
         SV vpar = sv0(), apar = sv0(), dvp = sv0(), dap = sv0();
@@ -294,19 +327,19 @@ static __global__ __launch_bounds__(64) RTOC_RBD_WAVES void linearize_contact_dy
         da = da + mcross(dv, vj);
         if (own && (kind == 1 || (impact && !dyn && kind == 2)) && !(impact && dyn)) da = da + mcross(v, unit_twist(i, j - iv));
         // own force and its tangent
-        const double mass = m.mass[i];
-        const V3 com = ldv3(m.com[i]);
-        const M3 I = ldm3(m.inertia[i]);
+        const double mass = JM(i, 15);
+        const V3 com = ldv3(&JM(i, 16));
+        const M3 I = ldm3(&JM(i, 19));
         const SV h = inertia_mul(mass, com, I, v);
         SV f = inertia_mul(mass, com, I, SV{acc.l + gi, acc.a}) + fcross(v, h);
         const SV df = inertia_mul(mass, com, I, SV{da.l + dg, da.a}) + fcross(dv, h) + fcross(v, inertia_mul(mass, com, I, dv));
         // contacts carried by this body
         int nact = 0;
-        for (int c = 0; c < m.ncontacts; ++c) {
+        for (int c = 0; c < ncon; ++c) {
           const bool on = (active >> c) & 1u;
-          if (on && m.contact_parent[c] == i) {
-            const M3 Rf = ldm3(m.contact_R[c]);
-            const V3 pf = ldv3(m.contact_p[c]);
+          if (on && (int)scm[c * CP + 14] == i) {
+            const M3 Rf = ldm3(&scm[c * CP]);
+            const V3 pf = ldv3(&scm[c * CP + 9]);
             f = f - act_f(Rf, pf, SV{mk(sf[3 * nact], sf[3 * nact + 1], sf[3 * nact + 2]), mk(0, 0, 0)});
             if (rows) {
               const SV vf = act_inv(Rf, pf, v), dvf = act_inv(Rf, pf, dv);
@@ -316,9 +349,9 @@ static __global__ __launch_bounds__(64) RTOC_RBD_WAVES void linearize_contact_dy
                 dC = dvf.l;
               } else {
                 const SV af = act_inv(Rf, pf, acc), daf = act_inv(Rf, pf, da);
-                const double kp = m.contact_kp[c], kd = m.contact_kd[c];
+                const double kp = scm[c * CP + 12], kd = scm[c * CP + 13];
                 const V3 pw = op + mul(oR, pf);
-                const V3 pr = a.positions ? ldv3(a.positions + ((size_t)st * m.ncontacts + c) * 3) : mk(0, 0, 0);
+                const V3 pr = a.positions ? ldv3(a.positions + ((size_t)st * ncon + c) * 3) : mk(0, 0, 0);
                 C = af.l + cross(vf.a, vf.l) + kd * vf.l + kp * (pw - pr);
                 dC = daf.l + cross(dvf.a, vf.l) + cross(vf.a, dvf.l) + kd * dvf.l;
                 // kp * R_of * J_lin(:, j): the frame Jacobian column is the v-tangent of vf, one lane up

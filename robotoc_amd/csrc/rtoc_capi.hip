@@ -1175,9 +1175,10 @@ int rtoc_sync(rtoc_ctx* c) {
 }
 
 int rtoc_newton_iteration(rtoc_ctx* c, double kkt_tol, double tau);
+int rtoc_linearize_contact_dynamics(rtoc_ctx* c, int augment_residual);
 int rtoc_time_phase(rtoc_ctx* c, int phase, int reps, float* ms) {
   CHECK_READY(c);
-  if (!ms || reps < 1 || phase < 0 || phase > 6) return RTOC_ERR_BAD_ARG;
+  if (!ms || reps < 1 || phase < 0 || phase > 8) return RTOC_ERR_BAD_ARG;
   HIP_TRY(hipEventRecord(c->ev0, c->stream));
   for (int r = 0; r < reps; ++r) {
     int rc = RTOC_OK;
@@ -1189,6 +1190,8 @@ int rtoc_time_phase(rtoc_ctx* c, int phase, int reps, float* ms) {
       case 4: rc = launch_sweep(c); break;
       case 5: rc = rtoc_update(c); break;
       case 6: rc = rtoc_newton_iteration(c, 0.0, 0.995); break;  // the whole iteration as one launch sequence
+      case 7: rc = rtoc_linearize_contact_dynamics(c, 0); break;
+      case 8: rc = rtoc_linearize_contact_dynamics(c, 1); break;
     }
     if (rc) return rc;
   }
@@ -1248,13 +1251,14 @@ int rtoc_set_robot_model(rtoc_ctx* c, const rtoc_robot_model* m) {
     iq += m->type[i] == RTOC_JOINT_FREE_FLYER ? 7 : 1;
     iv += m->type[i] == RTOC_JOINT_FREE_FLYER ? 6 : 1;
   }
-  ok = ok && iq == m->nq && iv == m->nv && rbd::lin_lds_bytes(nlev) <= 160 * 1024;
+  ok = ok && iq == m->nq && iv == m->nv && rbd::lin_lds_bytes(nlev, m->njoints, m->ncontacts) <= 160 * 1024;
   for (int k = 0; k < m->ncontacts && ok; ++k) ok = m->contact_parent[k] >= 0 && m->contact_parent[k] < m->njoints;
   if (!ok) {
     delete h;
     return RTOC_ERR_BAD_ARG;
   }
   h->nlevels = nlev;
+  rbd::pack_model(h);
   HIP_TRY(hipSetDevice(c->device));
   if (!c->d_model) HIP_TRY(hipMalloc((void**)&c->d_model, sizeof(rbd::DevModel)));
   delete c->h_model;
@@ -1262,7 +1266,7 @@ int rtoc_set_robot_model(rtoc_ctx* c, const rtoc_robot_model* m) {
   HIP_TRY(hipMemcpyAsync(c->d_model, h, sizeof(rbd::DevModel), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   HIP_TRY(hipFuncSetAttribute((const void*)rbd::linearize_contact_dynamics_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)rbd::lin_lds_bytes(nlev)));
+                              (int)rbd::lin_lds_bytes(nlev, m->njoints, m->ncontacts)));
   c->epoch++;
   return RTOC_OK;
 }
@@ -1315,6 +1319,13 @@ int rtoc_linearize_contact_dynamics(rtoc_ctx* c, int augment_residual) {
   a.o_didcdqv = c->L.cdd.off[RTOC_CDD_DIDCDQV];
   a.ldv = c->dims.nv + c->dims.nf_max;
   a.nf_max = c->dims.nf_max;
+  {
+    const rtoc_robot_model& m = c->h_model->m;
+    a.nlevels = c->h_model->nlevels;
+    a.nv = m.nv, a.nq = m.nq, a.njoints = m.njoints, a.ncontacts = m.ncontacts;
+    a.nu = m.type[0] == RTOC_JOINT_FREE_FLYER ? m.nv - 6 : m.nv;
+    a.gx = m.gravity[0], a.gy = m.gravity[1], a.gz = m.gravity[2];
+  }
   a.kkt = augment_residual ? c->buf[RTOC_BUF_KKT] : nullptr;
   a.kkt_stride = c->L.kkt.stride;
   a.o_lx = c->L.kkt.off[RTOC_KKT_LX];
@@ -1327,7 +1338,7 @@ int rtoc_linearize_contact_dynamics(rtoc_ctx* c, int augment_residual) {
   a.o_nup = c->L.sol.off[RTOC_SOL_NUP];
   if (c->nstages < 2) return RTOC_OK;
   hipLaunchKernelGGL(rbd::linearize_contact_dynamics_kernel, dim3(c->batch * (c->nstages - 1)), dim3(64),
-                     rbd::lin_lds_bytes(c->h_model->nlevels), c->stream, a);
+                     rbd::lin_lds_bytes(c->h_model->nlevels, c->h_model->m.njoints, c->h_model->m.ncontacts), c->stream, a);
   HIP_TRY(hipGetLastError());
   return RTOC_OK;
 }

@@ -1,10 +1,12 @@
 """Host-side mirror of `rtoc_robot_model` (include/rtoc_robot.h) and a loader for the committed model tables
-(tests/golden/models/*.json, written by tools/urdf_to_model.py from the reference's test URDFs)."""
+(robotoc_amd/models/*.json, written by tools/urdf_to_model.py from the reference's test URDFs)."""
 import ctypes as C
 import json
+import os
 
 import numpy as np
 
+MODEL_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "models")
 MAX_JOINTS = 48
 MAX_CONTACTS = 8
 JOINT_FREE_FLYER, JOINT_REVOLUTE = 0, 1
@@ -56,6 +58,11 @@ def from_dict(d):
 
 def load(path):
     return from_dict(json.load(open(path)))
+
+
+def load_named(name):
+    """one of the bundled tables: anymal (floating base, 4 point feet), icub (floating base, 2 soles), iiwa14"""
+    return load(os.path.join(MODEL_DIR, name + ".json"))
 
 
 def random_configuration(model, rng, scale=1.0):

@@ -19,11 +19,11 @@ from robotoc_amd import capi, problems as pr, robot_model as rm
 from robotoc_amd.types import BUF_CDD, BUF_KKT, BUF_SOL, GRID_IMPACT, Dims
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-MODELS = os.path.join(ROOT, "tests", "golden", "models")
+MODELS = rm.MODEL_DIR
 
 
 def model(name):
-    return rm.load(os.path.join(MODELS, name + ".json"))
+    return rm.load_named(name)
 
 
 def rnea(orc, m, q, v, a):

@@ -6,7 +6,7 @@ from robotoc_amd import capi, problems as pr, robot_model as rm
 from robotoc_amd.types import BUF_SOL
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-m = rm.load(os.path.join(root, "tests", "golden", "models", "anymal.json"))
+m = rm.load_named("anymal")
 dims, grids, _ = pr.config_anymal_trot()
 ctx = capi.Context(dims, len(grids), batch, 0)
 ctx.set_grid(grids)

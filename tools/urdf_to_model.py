@@ -8,10 +8,10 @@ pinocchio::urdf::buildModel); this script restates what that parser builds, as f
     joint's frame), like Pinocchio does when it appends a body through a fixed joint;
   * contact frames: named links, placement relative to their moving ancestor joint.
 Run here (the URDFs are the reference's test robots, /root/reference/test/urdf); the JSON tables it writes are the
-committed fixtures tests/golden/models/*.json -- nothing reads the URDFs at run time.
+committed fixtures robotoc_amd/models/*.json -- nothing reads the URDFs at run time.
 
   python tools/urdf_to_model.py /root/reference/test/urdf/anymal/anymal.urdf --floating-base \
-      --contacts LF_FOOT LH_FOOT RF_FOOT RH_FOOT -o tests/golden/models/anymal.json
+      --contacts LF_FOOT LH_FOOT RF_FOOT RH_FOOT -o robotoc_amd/models/anymal.json
 """
 import argparse
 import json
