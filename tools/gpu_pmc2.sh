@@ -32,4 +32,4 @@ timeout 600 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_
 timeout 600 rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --output-format csv -d $OUT/prof_sq2 -o sq2 -- $D > $OUT/prof_sq2.log 2>&1
 cd $R
 cat $OUT/host_cpu.txt $OUT/cpu_scaling.txt
-tail -2 $OUT/prof_fetch.log $OUT/prof_sq2.log
+tail -n 2 $OUT/prof_fetch.log; tail -n 2 $OUT/prof_sq2.log

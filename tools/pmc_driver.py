@@ -50,8 +50,33 @@ def main():
         ctx.expand(0.995)
         ctx.update()
     assert (ctx.status() == 0).all()
-    ctx.close()
     del kkt, cdd, con
+    # ---- rigid-body linearisation of the same batch ----
+    from robotoc_amd import robot_model as rm
+    from robotoc_amd.types import BUF_SOL
+    model = rm.load_named("anymal")
+    ctx.set_robot_model(model)
+    masks, flip = [], False
+    for g in grids:
+        masks.append(0b1111 if g.dimf == 12 else 0 if g.dimf == 0 else (0b0110 if flip else 0b1001))
+        flip = flip != (g.dimf == 6)
+    ctx.set_contact_schedule(np.array(masks, dtype=np.uint32), np.zeros((len(grids), 4, 3)))
+    rng = np.random.default_rng(0)
+    o = L.sol.off
+    sol = np.zeros((uniq, len(grids), L.sol.stride))
+    for b in range(uniq):
+        for i in range(len(grids)):
+            q, v, a = rm.random_configuration(model, rng, 0.8)
+            sol[b, i, o[0]:o[0] + 19], sol[b, i, o[1]:o[1] + 18], sol[b, i, o[2]:o[2] + 18] = q, v, a
+            sol[b, i, o[3]:o[3] + 12] = rng.uniform(-5, 5, 12)
+            sol[b, i, o[4]:o[4] + 12] = rng.uniform(-20, 20, 12)
+            sol[b, i, o[7]:o[7] + 18] = rng.uniform(-1, 1, 18)
+            sol[b, i, o[8]:o[8] + 12] = rng.uniform(-1, 1, 12)
+    ctx.upload(BUF_SOL, tile(sol, batch))
+    for _ in range(reps):
+        ctx.linearize_contact_dynamics(True)
+    ctx.sync()
+    ctx.close()
     # ---- iCub nv=32 / nv=35, 1024 instances: backward + forward, condense + expand ----
     for nv in (32, 35):
         dims, grids, _ = pr.config_icub_jump(nv=nv)
