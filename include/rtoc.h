@@ -212,7 +212,8 @@ int rtoc_unconstr_forward(rtoc_ctx* ctx, double dt);
 /* UnconstrDynamics::condenseUnconstrDynamics on every non-terminal grid point
  * (src/dynamics/unconstr_dynamics.cpp:67-88).  Records: KKT.Quu/lu/Qxu hold Qaa/la/[Qqa;Qva] (the
  * acceleration is the Riccati control); CDD.dIDCdqv = [dID_dq | dID_dv], CDD.dIDda = dID_da,
- * CDD.IDC = ID, CDD.Qaa = diag(Quu) and CDD.la = lu of the torque cost.  nu == nv, nf_max == 0 only. */
+ * CDD.IDC = ID, CDD.Qaa = diag(Quu) and CDD.la = lu of the torque cost; CDD.MJtJinv = the full Quu (nv x nv), of which
+ * only the off-diagonal entries are read, by expandDual (leave it zero for a diagonal cost).  nu == nv, nf_max == 0 only. */
 int rtoc_unconstr_condense(rtoc_ctx* ctx);
 /* UnconstrDynamics::expandPrimal + expandDual (unconstr_dynamics.cpp:91-104) after
  * rtoc_unconstr_forward: DIR.daf <- da (the Riccati control), DIR.du <- torque direction,

@@ -634,7 +634,14 @@ void orc_unconstr_expand_stage(const rtoc_layout* L, const double* cdd_rec, doub
     for (int k = 0; k < nv; ++k) acc += da[i + (size_t)k * nv] * dacc[k];
     t += acc;
     du[i] = t;
-    dbeta[i] = (lut[i] + w[i] * t) / dt;
+  }
+  /* expandDual (unconstr_dynamics.cpp:99-104): the full Quu; diagonal in QAA, off-diagonal part in the MJTJINV field */
+  const double* Qfull = cdd_rec + L->cdd.off[RTOC_CDD_MJTJINV];
+  for (int i = 0; i < nv; ++i) {
+    double off = 0.0;
+    for (int k = 0; k < nv; ++k)
+      if (k != i) off += Qfull[i + (size_t)k * nv] * du[k];
+    dbeta[i] = (lut[i] + (w[i] * du[i] + off)) / dt;
   }
 }
 

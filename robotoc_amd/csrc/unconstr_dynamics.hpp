@@ -7,7 +7,8 @@
 //   KKT.Quu := Qaa, KKT.lu := la, KKT.Qxu := [Qqa; Qva]  ("this is actually Qqa and Qqv", :86-88),
 // and the torque-level quantities ride in the ContactDynamicsData record:
 //   CDD.dIDCdqv = [dID_dq | dID_dv], CDD.dIDda = dID_da, CDD.IDC = ID,
-//   CDD.Qaa = diag(Quu) of the torque cost (only the diagonal enters, :71,:76-78),
+//   CDD.Qaa = diag(Quu) of the torque cost (only the diagonal enters the condensation, :71,:76-78),
+//   CDD.MJtJinv = Quu itself (nv x nv; only its off-diagonal entries are read, by expandDual :99-104; zero = diagonal cost),
 //   CDD.la  = lu of the torque cost.
 // After rtoc_unconstr_expand the direction record reads like the reference's SplitDirection:
 //   DIR.daf = da (the Riccati control), DIR.du = torque direction, DIR.dbetamu = dbeta.
@@ -127,9 +128,21 @@ __global__ __launch_bounds__(64) void unconstr_expand_kernel(UdArgs a) {
     for (int k = 0; k < NV; ++k) acc += cr[a.cl.off[RTOC_CDD_DIDDA] + lane + k * NV] * x[2 * NV + k];
     du += acc;
     dr[a.dl.off[RTOC_DIR_DU] + lane] = du;
-    // expandDual (:99-104): dbeta = (lu + Quu du) / dt, Quu diagonal
+    x[lane] = du;  // dx is consumed: du of all joints for the off-diagonal part below
+  }
+  __syncthreads();
+  if (lane < NV) {
+    // expandDual (:99-104): dbeta = (lu + Quu du) / dt with the FULL torque-cost Hessian: its diagonal is CDD.Qaa (all
+    // the condensation uses, :71,:76-78), its strictly off-diagonal part is read from the MJTJINV field (nv x nv,
+    // column-major), which the unconstrained path does not use otherwise and which is zero unless the caller fills
+    // it -- robotoc's own costs have a diagonal Quu
+    const double du = x[lane];
+    double off = 0.0;
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+      off += (k == lane) ? 0.0 : cr[a.cl.off[RTOC_CDD_MJTJINV] + lane + k * NV] * x[k];
     dr[a.dl.off[RTOC_DIR_DBETAMU] + lane] =
-        (cr[a.cl.off[RTOC_CDD_LA] + lane] + cr[a.cl.off[RTOC_CDD_QAA] + lane] * du) / a.dt;
+        (cr[a.cl.off[RTOC_CDD_LA] + lane] + (cr[a.cl.off[RTOC_CDD_QAA] + lane] * du + off)) / a.dt;
   }
 }
 

@@ -23,6 +23,12 @@ def _data(L, nstages, batch, seed=11):
     C.f(cdd, "IDC")[...] = rng.uniform(-1, 1, (batch, nstages, nv))
     C.f(cdd, "Qaa")[...] = rng.uniform(0.1, 1.0, (batch, nstages, nv))
     C.f(cdd, "la")[...] = rng.uniform(-1, 1, (batch, nstages, nv))
+    # the full torque-cost Hessian for expandDual (unconstr_dynamics.cpp:99-104): symmetric, its diagonal = Qaa above
+    Q = rng.uniform(-0.2, 0.2, (batch, nstages, nv, nv))
+    Q = 0.5 * (Q + np.swapaxes(Q, -1, -2))
+    idx = np.arange(nv)
+    Q[..., idx, idx] = C.f(cdd, "Qaa")
+    C.f(cdd, "MJtJinv")[...] = Q
     return kkt, cdd
 
 
@@ -77,7 +83,7 @@ def test_oracle_unconstr_expand_closed_form(oracle):
             du = C.f(cdd[b, i], "IDC") + J[:, :nv] @ dx[:nv] + J[:, nv:] @ dx[nv:] + C.f(cdd[b, i], "dIDda") @ da
             D.f(ref[b, i], "daf")[:nv] = da
             D.f(ref[b, i], "du")[:] = du
-            D.f(ref[b, i], "dbetamu")[:nv] = (C.f(cdd[b, i], "la") + C.f(cdd[b, i], "Qaa") * du) / dt
+            D.f(ref[b, i], "dbetamu")[:nv] = (C.f(cdd[b, i], "la") + C.f(cdd[b, i], "MJtJinv") @ du) / dt  # FULL Quu
     oracle.unconstr_expand_batch(L, n, cdd, d, dt)
     assert np.allclose(d, ref, rtol=1e-13, atol=1e-13)
 
