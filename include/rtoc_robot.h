@@ -72,6 +72,29 @@ int rtoc_set_contact_schedule(rtoc_ctx* ctx, const unsigned* active, const doubl
  * lq / lv / lu in RTOC_BUF_KKT, la / lf / lu_passive in RTOC_BUF_CDD. */
 int rtoc_linearize_contact_dynamics(rtoc_ctx* ctx, int augment_residual);
 
+/* ---- the unconstrained solver iteration closed on the device (BASELINE configuration 1: fixed base, no contacts) ----
+ * ConfigurationSpaceCost of a fixed-base robot (src/cost/configuration_space_cost.cpp:274-378): diagonal weights,
+ * Euclidean q - q_ref; weights must be non-negative. */
+typedef struct rtoc_configuration_cost {
+  double q_ref[RTOC_MAX_JOINTS], v_ref[RTOC_MAX_JOINTS], u_ref[RTOC_MAX_JOINTS];
+  double q_weight[RTOC_MAX_JOINTS], v_weight[RTOC_MAX_JOINTS], a_weight[RTOC_MAX_JOINTS], u_weight[RTOC_MAX_JOINTS];
+  double q_weight_terminal[RTOC_MAX_JOINTS], v_weight_terminal[RTOC_MAX_JOINTS];
+} rtoc_configuration_cost;
+int rtoc_set_configuration_cost(rtoc_ctx* ctx, const rtoc_configuration_cost* cost);
+/* (q, v) of UnconstrOCPSolver::updateSolution(t, q, v) for every instance: x0[batch][2 nv]. */
+int rtoc_set_initial_state(rtoc_ctx* ctx, const double* x0, int count);
+/* UnconstrDirectMultipleShooting::evalKKT up to the condensation, on every grid point: kkt_matrix / kkt_residual zeroed,
+ * quadratizeStageCost / TerminalCost of the cost above, linearizeUnconstrForwardEuler(+Terminal)
+ * (src/dynamics/unconstr_state_equation.cpp:8-24), linearizeUnconstrDynamics (src/dynamics/unconstr_dynamics.cpp:52-64:
+ * RNEA, its derivatives, the dt-scaled multiplier terms), and computeInitialStateDirection (x0 - s[0].x into
+ * RTOC_BUF_DX0) -- from RTOC_BUF_SOL into RTOC_BUF_KKT / RTOC_BUF_CDD in the record convention of rtoc_unconstr_condense.
+ * Inequality constraints (joint limits) are not part of this path. */
+int rtoc_unconstr_eval_kkt(rtoc_ctx* ctx, double dt);
+/* UnconstrOCPSolver::updateSolution (src/solver/unconstr_ocp_solver.cpp:96-118): rtoc_unconstr_eval_kkt, the KKT error
+ * of the iterate it linearised at (host_kkt_error[count <= batch], may be NULL / 0), rtoc_unconstr_condense, backward,
+ * forward, rtoc_unconstr_expand, and SplitSolution::integrate with step size 1 -- RTOC_BUF_SOL holds the next iterate. */
+int rtoc_unconstr_update_solution(rtoc_ctx* ctx, double dt, double* host_kkt_error, int count);
+
 #ifdef __cplusplus
 }
 #endif

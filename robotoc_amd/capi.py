@@ -27,7 +27,8 @@ EXPORTS = [
     "rtoc_compute_initial_state_direction", "rtoc_unconstr_condense", "rtoc_unconstr_expand",
     "rtoc_newton_iteration", "rtoc_converged_count", "rtoc_clone", "rtoc_check_fxx_structure", "rtoc_sto_eval_kkt", "rtoc_set_friction_cones", "rtoc_set_wrench_cones", "rtoc_wrench_cone_matrix", "rtoc_save_stage_dump", "rtoc_load_stage_dump", "rtoc_kkt_error", "rtoc_integrate_solution",
     "rtoc_set_robot_model", "rtoc_set_contact_schedule", "rtoc_linearize_contact_dynamics",
-    "rtoc_line_search_filter", "rtoc_line_search_clear",
+    "rtoc_line_search_filter", "rtoc_line_search_clear", "rtoc_set_configuration_cost", "rtoc_set_initial_state",
+    "rtoc_unconstr_eval_kkt", "rtoc_unconstr_update_solution",
 ]
 
 
@@ -117,6 +118,10 @@ def lib():
         L.rtoc_sto_eval_kkt.argtypes = [vp, dp, dp, C.c_int, dp, C.c_int]
         L.rtoc_clone.argtypes = [vp, C.POINTER(vp)]
         L.rtoc_set_robot_model.argtypes = [vp, vp]
+        L.rtoc_set_configuration_cost.argtypes = [vp, vp]
+        L.rtoc_set_initial_state.argtypes = [vp, dp, C.c_int]
+        L.rtoc_unconstr_eval_kkt.argtypes = [vp, C.c_double]
+        L.rtoc_unconstr_update_solution.argtypes = [vp, C.c_double, dp, C.c_int]
         L.rtoc_line_search_filter.argtypes = [vp, dp, dp, C.POINTER(C.c_int), C.c_int, C.c_double, C.c_double, C.POINTER(C.c_int)]
         L.rtoc_line_search_clear.argtypes = [vp]
         L.rtoc_linearize_contact_dynamics.argtypes = [vp, C.c_int]
@@ -335,6 +340,29 @@ class Context:
             pos = np.ascontiguousarray(positions, dtype=np.float64)
             assert pos.shape == (self.nstages, self._model_ncontacts, 3)
         _chk(lib().rtoc_set_contact_schedule(self._h, act.ctypes.data_as(C.POINTER(C.c_uint)), _dp(pos) if pos is not None else None))
+
+    def set_configuration_cost(self, q_ref, v_ref, u_ref, q_weight, v_weight, a_weight, u_weight, q_weight_terminal, v_weight_terminal):
+        """rtoc_set_configuration_cost (ConfigurationSpaceCost of a fixed-base robot)"""
+        from .robot_model import MAX_JOINTS
+        arr = np.zeros((9, MAX_JOINTS))
+        for k, v in enumerate((q_ref, v_ref, u_ref, q_weight, v_weight, a_weight, u_weight, q_weight_terminal, v_weight_terminal)):
+            v = np.asarray(v, dtype=np.float64)
+            arr[k, :v.size] = v
+        _chk(lib().rtoc_set_configuration_cost(self._h, arr.ctypes.data_as(C.c_void_p)))
+
+    def set_initial_state(self, x0):
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        assert x0.shape == (self.batch, 2 * self.dims.nv)
+        _chk(lib().rtoc_set_initial_state(self._h, _dp(x0), self.batch))
+
+    def unconstr_eval_kkt(self, dt):
+        _chk(lib().rtoc_unconstr_eval_kkt(self._h, dt))
+
+    def unconstr_update_solution(self, dt, want_kkt_error=True):
+        """rtoc_unconstr_update_solution; returns the KKT error of the iterate it linearised at ([batch]) or None"""
+        out = np.zeros(self.batch) if want_kkt_error else None
+        _chk(lib().rtoc_unconstr_update_solution(self._h, dt, _dp(out) if want_kkt_error else None, self.batch if want_kkt_error else 0))
+        return out
 
     def linearize_contact_dynamics(self, augment_residual=False):
         _chk(lib().rtoc_linearize_contact_dynamics(self._h, int(bool(augment_residual))))

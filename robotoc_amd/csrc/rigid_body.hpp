@@ -133,6 +133,10 @@ struct LinArgs {
   int kkt_stride, o_lx, o_lu;                  // RTOC_BUF_KKT: lx = [lq; lv], lu
   int o_la, o_lf, o_lup;                       // RTOC_BUF_CDD: la (ldv on impact grids), lf, lu_passive
   int o_beta, o_mu, o_nup;                     // RTOC_BUF_SOL
+  // UnconstrDynamics::linearizeUnconstrDynamics (unconstr_dynamics.cpp:52-64): the multiplier terms carry dt, and the
+  // records follow the convention of rtoc_unconstr_condense (la lives in KKT.lu, lu in CDD.la)
+  int unconstr;
+  double scale;
 };
 
 // per-level storage in LDS
@@ -413,8 +417,8 @@ static __global__ __launch_bounds__(64) RTOC_RBD_WAVES void linearize_contact_dy
       if (aug && lane_on) {
         // lq / lv / la (ldv) += (this lane's column)^T [beta; mu]  (contact_dynamics.cpp:35-37,49-51; impact_dynamics.cpp:19-25)
         double* const kr = a.kkt + rec * a.kkt_stride;
-        double* const dst = kind == 0 ? kr + a.o_lx + j : kind == 1 ? kr + a.o_lx + nv + j : cr + a.o_la + j;
-        if (!(impact && dyn && kind == 1)) *dst += wsum;
+        double* const dst = kind == 0 ? kr + a.o_lx + j : kind == 1 ? kr + a.o_lx + nv + j : a.unconstr ? kr + a.o_lu + j : cr + a.o_la + j;
+        if (!(impact && dyn && kind == 1)) *dst += a.scale * wsum;
       }
     }
   }
@@ -422,8 +426,86 @@ static __global__ __launch_bounds__(64) RTOC_RBD_WAVES void linearize_contact_dy
     __syncthreads();
     double* const kr = a.kkt + rec * a.kkt_stride;
     if (lane < g.dimf) cr[a.o_lf + lane] -= slf[lane];
-    if (!impact && lane < nu) kr[a.o_lu + lane] -= sbeta[nv - nu + lane];                  // lu -= beta (actuated part)
+    if (a.unconstr) {
+      if (lane < nv) cr[a.o_la + lane] -= a.scale * sbeta[lane];                         // lu -= dt beta (:63)
+    } else if (!impact && lane < nu) kr[a.o_lu + lane] -= sbeta[nv - nu + lane];           // lu -= beta (actuated part)
     if (nu < nv && lane < nv - nu) cr[a.o_lup + lane] = impact ? 0.0 : sr[a.o_nup + lane] - sbeta[lane];  // lu_passive
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// UnconstrIntermediateStage / UnconstrTerminalStage::evalKKT up to the dynamics (reference src/unconstr/
+// unconstr_intermediate_stage.cpp:64-78, unconstr_terminal_stage.cpp): kkt_matrix / kkt_residual.setZero(), the
+// ConfigurationSpaceCost of a fixed-base robot (src/cost/configuration_space_cost.cpp:274-324 stage, :343-378 terminal:
+// diagonal weights, q - q_ref Euclidean) and linearizeUnconstrForwardEuler (src/dynamics/unconstr_state_equation.cpp:8-24,
+// 56-62).  rtoc_linearize in unconstrained mode then adds the dynamics terms.  Records in the convention of
+// rtoc_unconstr_condense: KKT.Quu := Qaa, KKT.lu := la, CDD.Qaa := diag(Quu), CDD.la := lu.
+// cost: [q_ref | v_ref | u_ref | wq | wv | wa | wu | wq_terminal | wv_terminal], nv doubles each.
+struct UkArgs {
+  const double* sol;
+  double* kkt;
+  double* cdd;
+  const double* cost;
+  const double* x0;   // [batch][2 nv] initial state of the horizon (q, v of updateSolution(t, q, v)); may be nullptr
+  double* dx0;        // [batch][2 nv] computeInitialStateDirection: x0 - s[0].x
+  int nstages, batch, nv;
+  double dt;
+  int sol_stride, kkt_stride, cdd_stride;
+  int o_q, o_v, o_a, o_u, o_lmd, o_gmm;
+  int o_qxx, o_qxu, o_quu, o_fx, o_lx, o_lu;
+  int o_qaa, o_la, o_mj;
+};
+
+static __global__ __launch_bounds__(64) void unconstr_eval_kkt_kernel(UkArgs a) {
+  const int lane = threadIdx.x;
+  const int b = blockIdx.x / a.nstages, st = blockIdx.x % a.nstages;
+  if (b >= a.batch) return;
+  const int nv = a.nv, nx = 2 * nv;
+  const bool terminal = st == a.nstages - 1;
+  const size_t rec = (size_t)b * a.nstages + st;
+  const double* const s = a.sol + rec * a.sol_stride;
+  const double* const sn = s + a.sol_stride;  // next grid point (not read on the terminal one)
+  double* const kr = a.kkt + rec * a.kkt_stride;
+  double* const cr = a.cdd + rec * a.cdd_stride;
+  const double *qr = a.cost, *vr = qr + nv, *ur = vr + nv, *wq = ur + nv, *wv = wq + nv, *wa = wv + nv, *wu = wa + nv,
+               *wqf = wu + nv, *wvf = wqf + nv;
+  const double dt = a.dt;
+  // Hessian blocks: zero, then the diagonals (Qqq, Qvv; Qaa in the Quu slot)
+  for (int e = lane; e < nx * nx; e += 64) {
+    const int r = e % nx, c = e / nx;
+    double v = 0.0;
+    if (r == c) v = terminal ? (r < nv ? wqf[r] : wvf[r - nv]) : dt * (r < nv ? wq[r] : wv[r - nv]);
+    kr[a.o_qxx + e] = v;
+  }
+  for (int e = lane; e < nx * nv; e += 64) kr[a.o_qxu + e] = 0.0;
+  for (int e = lane; e < nv * nv; e += 64) kr[a.o_quu + e] = (!terminal && e % nv == e / nv) ? dt * wa[e % nv] : 0.0;
+  for (int e = lane; e < nv * nv; e += 64) cr[a.o_mj + e] = 0.0;  // off-diagonal part of Quu: a diagonal cost
+  for (int i = lane; i < nv; i += 64) {
+    const double q = s[a.o_q + i], v = s[a.o_v + i], lmd = s[a.o_lmd + i], gmm = s[a.o_gmm + i];
+    if (terminal) {
+      kr[a.o_lx + i] = wqf[i] * (q - qr[i]) - lmd;        // evalTerminalCostDerivatives + ...ForwardEulerTerminal
+      kr[a.o_lx + nv + i] = wvf[i] * (v - vr[i]) - gmm;
+      kr[a.o_fx + i] = 0.0, kr[a.o_fx + nv + i] = 0.0;
+      kr[a.o_lu + i] = 0.0;
+      cr[a.o_qaa + i] = 0.0, cr[a.o_la + i] = 0.0;
+    } else {
+      const double acc = s[a.o_a + i], u = s[a.o_u + i];
+      const double qn = sn[a.o_q + i], vn = sn[a.o_v + i], lmdn = sn[a.o_lmd + i], gmmn = sn[a.o_gmm + i];
+      kr[a.o_fx + i] = q + dt * v - qn;                                            // Fq (:60)
+      kr[a.o_fx + nv + i] = v + dt * acc - vn;                                     // Fv (:61)
+      kr[a.o_lx + i] = dt * wq[i] * (q - qr[i]) + (lmdn - lmd);                    // lq
+      kr[a.o_lx + nv + i] = dt * wv[i] * (v - vr[i]) + (dt * lmdn + gmmn - gmm);   // lv
+      kr[a.o_lu + i] = dt * wa[i] * acc + dt * gmmn;                               // la (in the lu slot)
+      cr[a.o_la + i] = dt * wu[i] * (u - ur[i]);                                   // lu (in CDD.la)
+      cr[a.o_qaa + i] = dt * wu[i];                                                // diag(Quu)
+    }
+  }
+  if (st == 0 && a.x0 && a.dx0) {
+    for (int i = lane; i < nv; i += 64) {
+      a.dx0[(size_t)b * nx + i] = a.x0[(size_t)b * nx + i] - s[a.o_q + i];
+      a.dx0[(size_t)b * nx + nv + i] = a.x0[(size_t)b * nx + nv + i] - s[a.o_v + i];
+    }
   }
 }
 

@@ -109,6 +109,8 @@ struct rtoc_ctx {
   double* d_cpos;
   bool has_cpos;
   // rtoc_line_search_filter: filters [batch][CAP][2], sizes [batch], staging (cost, violation | mask, accepted)
+  double* d_cost;      // rtoc_set_configuration_cost: 9 nv doubles
+  double* d_x0;        // rtoc_set_initial_state: [batch][2 nv]
   double* d_filter;
   int* d_nfilter;
   double* d_ls_in;
@@ -261,6 +263,8 @@ int rtoc_destroy(rtoc_ctx* c) {
   if (c->d_model) (void)hipFree(c->d_model);
   delete c->h_model;
   if (c->d_active) (void)hipFree(c->d_active);
+  if (c->d_cost) (void)hipFree(c->d_cost);
+  if (c->d_x0) (void)hipFree(c->d_x0);
   if (c->d_filter) (void)hipFree(c->d_filter);
   if (c->d_nfilter) (void)hipFree(c->d_nfilter);
   if (c->d_ls_in) (void)hipFree(c->d_ls_in);
@@ -1291,8 +1295,7 @@ int rtoc_set_contact_schedule(rtoc_ctx* c, const unsigned* active, const double*
   return RTOC_OK;
 }
 
-int rtoc_linearize_contact_dynamics(rtoc_ctx* c, int augment_residual) {
-  CHECK_READY(c);
+static int launch_linearize(rtoc_ctx* c, int augment_residual, bool unconstr, double scale) {
   if (!c->h_model || !c->d_active || !c->buf[RTOC_BUF_SOL]) return RTOC_ERR_NOT_READY;
   if (augment_residual && !c->buf[RTOC_BUF_KKT]) return RTOC_ERR_NOT_READY;
   int rc = ensure_buffer(c, RTOC_BUF_CDD);
@@ -1336,11 +1339,84 @@ int rtoc_linearize_contact_dynamics(rtoc_ctx* c, int augment_residual) {
   a.o_beta = c->L.sol.off[RTOC_SOL_BETA];
   a.o_mu = c->L.sol.off[RTOC_SOL_MU];
   a.o_nup = c->L.sol.off[RTOC_SOL_NUP];
+  a.unconstr = unconstr ? 1 : 0;
+  a.scale = scale;
   if (c->nstages < 2) return RTOC_OK;
   hipLaunchKernelGGL(rbd::linearize_contact_dynamics_kernel, dim3(c->batch * (c->nstages - 1)), dim3(64),
                      rbd::lin_lds_bytes(c->h_model->nlevels, c->h_model->m.njoints, c->h_model->m.ncontacts), c->stream, a);
   HIP_TRY(hipGetLastError());
   return RTOC_OK;
+}
+
+int rtoc_linearize_contact_dynamics(rtoc_ctx* c, int augment_residual) {
+  CHECK_READY(c);
+  return launch_linearize(c, augment_residual, false, 1.0);
+}
+
+// ---- the unconstrained (fixed-base, contact-free) solver iteration closed on the device -------
+int rtoc_set_configuration_cost(rtoc_ctx* c, const rtoc_configuration_cost* cost) {
+  if (!c || !cost) return RTOC_ERR_BAD_ARG;
+  const int nv = c->dims.nv;
+  if (nv > RTOC_MAX_JOINTS || c->dims.nu != nv || c->dims.nf_max != 0) return RTOC_ERR_BAD_ARG;
+  HIP_TRY(hipSetDevice(c->device));
+  std::vector<double> h((size_t)9 * nv);
+  const double* src[9] = {cost->q_ref, cost->v_ref, cost->u_ref, cost->q_weight, cost->v_weight, cost->a_weight, cost->u_weight,
+                          cost->q_weight_terminal, cost->v_weight_terminal};
+  for (int k = 0; k < 9; ++k)
+    for (int i = 0; i < nv; ++i) {
+      if (k >= 3 && !(src[k][i] >= 0.0)) return RTOC_ERR_BAD_ARG;  // configuration_space_cost.cpp: weights must be non-negative
+      h[(size_t)k * nv + i] = src[k][i];
+    }
+  if (!c->d_cost) HIP_TRY(hipMalloc((void**)&c->d_cost, sizeof(double) * 9 * nv));
+  HIP_TRY(hipMemcpyAsync(c->d_cost, h.data(), sizeof(double) * 9 * nv, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return RTOC_OK;
+}
+
+int rtoc_set_initial_state(rtoc_ctx* c, const double* x0, int count) {
+  if (!c || !x0 || count != c->batch) return RTOC_ERR_BAD_ARG;
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t n = (size_t)c->batch * 2 * c->dims.nv;
+  if (!c->d_x0) HIP_TRY(hipMalloc((void**)&c->d_x0, sizeof(double) * n));
+  HIP_TRY(hipMemcpyAsync(c->d_x0, x0, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return RTOC_OK;
+}
+
+int rtoc_unconstr_eval_kkt(rtoc_ctx* c, double dt) {
+  CHECK_READY(c);
+  if (!(dt > 0.0) || c->dims.nu != c->dims.nv || c->dims.nf_max != 0) return RTOC_ERR_BAD_ARG;
+  if (!c->h_model || !c->d_cost || !c->buf[RTOC_BUF_SOL]) return RTOC_ERR_NOT_READY;
+  if (c->h_model->m.type[0] == RTOC_JOINT_FREE_FLYER || c->h_model->m.ncontacts != 0) return RTOC_ERR_BAD_ARG;  // unconstr_dynamics.cpp:22-29
+  int rc = ensure_buffer(c, RTOC_BUF_KKT);
+  if (!rc) rc = ensure_buffer(c, RTOC_BUF_CDD);
+  if (!rc) rc = ensure_buffer(c, RTOC_BUF_DX0);
+  if (rc) return rc;
+  if (!c->d_active) {  // no contacts: an all-zero schedule
+    HIP_TRY(hipMalloc((void**)&c->d_active, sizeof(unsigned) * c->max_stages));
+    HIP_TRY(hipMemsetAsync(c->d_active, 0, sizeof(unsigned) * c->max_stages, c->stream));
+  }
+  rbd::UkArgs a;
+  a.sol = c->buf[RTOC_BUF_SOL];
+  a.kkt = c->buf[RTOC_BUF_KKT];
+  a.cdd = c->buf[RTOC_BUF_CDD];
+  a.cost = c->d_cost;
+  a.x0 = c->d_x0;
+  a.dx0 = c->buf[RTOC_BUF_DX0];
+  a.nstages = c->nstages;
+  a.batch = c->batch;
+  a.nv = c->dims.nv;
+  a.dt = dt;
+  a.sol_stride = c->L.sol.stride, a.kkt_stride = c->L.kkt.stride, a.cdd_stride = c->L.cdd.stride;
+  a.o_q = c->L.sol.off[RTOC_SOL_Q], a.o_v = c->L.sol.off[RTOC_SOL_V], a.o_a = c->L.sol.off[RTOC_SOL_A], a.o_u = c->L.sol.off[RTOC_SOL_U];
+  a.o_lmd = c->L.sol.off[RTOC_SOL_LMD], a.o_gmm = c->L.sol.off[RTOC_SOL_GMM];
+  a.o_qxx = c->L.kkt.off[RTOC_KKT_QXX], a.o_qxu = c->L.kkt.off[RTOC_KKT_QXU], a.o_quu = c->L.kkt.off[RTOC_KKT_QUU];
+  a.o_fx = c->L.kkt.off[RTOC_KKT_FX], a.o_lx = c->L.kkt.off[RTOC_KKT_LX], a.o_lu = c->L.kkt.off[RTOC_KKT_LU];
+  a.o_qaa = c->L.cdd.off[RTOC_CDD_QAA], a.o_la = c->L.cdd.off[RTOC_CDD_LA], a.o_mj = c->L.cdd.off[RTOC_CDD_MJTJINV];
+  hipLaunchKernelGGL(rbd::unconstr_eval_kkt_kernel, dim3(c->batch * c->nstages), dim3(64), 0, c->stream, a);
+  HIP_TRY(hipGetLastError());
+  c->fxx_state = 0;
+  return launch_linearize(c, 1, true, dt);
 }
 
 // ---- KKT error ------------------------------------------------------------------------------
@@ -1382,6 +1458,32 @@ int rtoc_kkt_error(rtoc_ctx* c, double* host_out, int count) {
   if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(host_out, c->d_kkterr, sizeof(double) * count, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
+  return RTOC_OK;
+}
+
+// UnconstrOCPSolver::updateSolution (src/solver/unconstr_ocp_solver.cpp:96-118) of every instance, one launch
+// sequence, no host synchronisation unless host_kkt_error is asked for
+int rtoc_unconstr_update_solution(rtoc_ctx* c, double dt, double* host_kkt_error, int count) {
+  CHECK_READY(c);
+  if (count < 0 || count > c->batch || (count > 0 && !host_kkt_error)) return RTOC_ERR_BAD_ARG;
+  int rc = rtoc_unconstr_eval_kkt(c, dt);            // dms_.evalKKT up to the condensation, + computeInitialStateDirection
+  if (!rc) rc = launch_kkt_error(c);                  // performance_index.kkt_error (pre-condensation, like :74-75)
+  if (!rc) rc = rtoc_unconstr_condense(c);
+  if (!rc) rc = rtoc_unconstr_backward(c, dt);
+  if (!rc) rc = rtoc_unconstr_forward(c, dt);
+  if (!rc) rc = rtoc_unconstr_expand(c, dt);
+  if (rc) return rc;
+  // no inequality constraints on this path: maxPrimalStepSize = maxDualStepSize = 1
+  rc = ensure_buffer(c, RTOC_BUF_STEP);
+  if (rc) return rc;
+  hipLaunchKernelGGL(fill_steps_kernel, dim3((2 * c->batch + 255) / 256), dim3(256), 0, c->stream, c->buf[RTOC_BUF_STEP], 2 * c->batch);
+  HIP_TRY(hipGetLastError());
+  rc = rtoc_integrate_solution(c);
+  if (rc) return rc;
+  if (count > 0) {
+    HIP_TRY(hipMemcpyAsync(host_kkt_error, c->d_kkterr, sizeof(double) * count, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+  }
   return RTOC_OK;
 }
 

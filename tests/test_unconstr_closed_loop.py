@@ -1,0 +1,124 @@
+"""BASELINE configuration 1 closed on the device: UnconstrOCPSolver::updateSolution (src/solver/unconstr_ocp_solver.cpp:
+96-118) for iiwa14 with a ConfigurationSpaceCost -- cost + state equation + rigid-body linearisation
+(rtoc_unconstr_eval_kkt), condensation, Riccati sweep, expansion and solution update, iterated without the host touching
+the data (rtoc_unconstr_update_solution).  Checks: (i) the pre-condensation records of the first iteration against a
+numpy restatement of the cited reference lines, with the dynamics terms from the CPU rigid-body restatement (its values,
+and central differences for the Jacobians); (ii) Newton convergence of the KKT error; (iii) the converged trajectory
+against the CPU restatement: inverse dynamics, state equation, initial state.  The rigid-body part is parity-unpinned
+(Pinocchio absent, tests/test_rigid_body.py); everything else follows pinned code."""
+import numpy as np
+import pytest
+
+from robotoc_amd import capi, problems as pr, robot_model as rm
+from robotoc_amd.types import BUF_CDD, BUF_DX0, BUF_KKT, BUF_SOL, Records
+
+
+def _setup(batch, seed=0):
+    dims, grids, meta = pr.config_iiwa14()
+    m = rm.load_named("iiwa14")
+    n, nv, dt = len(grids), m.nv, meta["dt"]
+    ctx = capi.Context(dims, n, batch, 0)
+    ctx.set_grid(grids)
+    ctx.set_robot_model(m)
+    rng = np.random.default_rng(seed)
+    cost = dict(q_ref=rng.uniform(-0.8, 0.8, nv), v_ref=np.zeros(nv), u_ref=np.zeros(nv), q_weight=np.full(nv, 10.0),
+                v_weight=np.full(nv, 0.1), a_weight=np.full(nv, 0.01), u_weight=np.full(nv, 0.001),
+                q_weight_terminal=np.full(nv, 10.0), v_weight_terminal=np.full(nv, 0.1))
+    ctx.set_configuration_cost(**cost)
+    x0 = np.concatenate([rng.uniform(-0.5, 0.5, (batch, nv)), np.zeros((batch, nv))], axis=1)
+    ctx.set_initial_state(x0)
+    return ctx, m, grids, dt, cost, x0, rng
+
+
+@pytest.mark.gpu
+def test_unconstr_eval_kkt_matches_the_restated_reference_lines(oracle):
+    batch = 2
+    ctx, m, grids, dt, cost, x0, rng = _setup(batch)
+    L, n, nv = ctx.L, len(grids), m.nv
+    S, K, C = Records(L, "sol"), Records(L, "kkt"), Records(L, "cdd")
+    sol = S.zeros(batch, n)
+    for f in ("q", "v", "a", "u", "lmd", "gmm", "beta"):
+        S.f(sol, f)[...] = rng.uniform(-1, 1, S.f(sol, f).shape)
+    ctx.upload(BUF_SOL, sol)
+    ctx.unconstr_eval_kkt(dt)
+    err = ctx.kkt_error()
+    kkt, cdd = ctx.download_records(BUF_KKT, "kkt"), ctx.download_records(BUF_CDD, "cdd")
+    dx0 = ctx.download(BUF_DX0, (batch, 2 * nv))
+    z = np.zeros(0)
+    worst, acc = 0.0, np.zeros(batch)
+    for b in range(batch):
+        assert np.allclose(dx0[b], x0[b] - np.concatenate([S.f(sol[b, 0], "q")[:nv], S.f(sol[b, 0], "v")]), atol=1e-15)
+        for i in range(n):
+            s = sol[b, i]
+            q, v, a, u = S.f(s, "q")[:nv], S.f(s, "v"), S.f(s, "a"), S.f(s, "u")
+            lmd, gmm, beta = S.f(s, "lmd"), S.f(s, "gmm"), S.f(s, "beta")
+            Qxx, lx = np.zeros((2 * nv, 2 * nv)), np.zeros(2 * nv)
+            if i == n - 1:  # unconstr_terminal_stage.cpp: terminal cost + linearizeUnconstrForwardEulerTerminal
+                lx[:nv] = cost["q_weight_terminal"] * (q - cost["q_ref"]) - lmd
+                lx[nv:] = cost["v_weight_terminal"] * (v - cost["v_ref"]) - gmm
+                Qxx[np.arange(nv), np.arange(nv)] = cost["q_weight_terminal"]
+                Qxx[nv + np.arange(nv), nv + np.arange(nv)] = cost["v_weight_terminal"]
+                got = [(K.f(kkt[b, i], "Qxx"), Qxx, 1e-14), (K.f(kkt[b, i], "lx"), lx, 1e-14)]
+                acc[b] += lx @ lx
+            else:
+                sn = sol[b, i + 1]
+                qn, vn, lmdn, gmmn = S.f(sn, "q")[:nv], S.f(sn, "v"), S.f(sn, "lmd"), S.f(sn, "gmm")
+                ID = oracle.rbd_eval(m, 0, q, v, a, z, u, 0, z)
+                Dq, Dv, Da = oracle.rbd_linearize_fd(m, 0, q, v, a, z, u, 0, z, 1e-6)
+                Fx = np.concatenate([q + dt * v - qn, v + dt * a - vn])                       # unconstr_state_equation.cpp:56-62
+                lx[:nv] = dt * cost["q_weight"] * (q - cost["q_ref"]) + (lmdn - lmd) + dt * Dq.T @ beta   # :14, unconstr_dynamics.cpp:60
+                lx[nv:] = dt * cost["v_weight"] * (v - cost["v_ref"]) + (dt * lmdn + gmmn - gmm) + dt * Dv.T @ beta
+                la = dt * cost["a_weight"] * a + dt * gmmn + dt * Da.T @ beta
+                lu = dt * cost["u_weight"] * (u - cost["u_ref"]) - dt * beta
+                Qxx[np.arange(nv), np.arange(nv)] = dt * cost["q_weight"]
+                Qxx[nv + np.arange(nv), nv + np.arange(nv)] = dt * cost["v_weight"]
+                J = C.f(cdd[b, i], "dIDCdqv")
+                got = [(K.f(kkt[b, i], "Qxx"), Qxx, 1e-14), (K.f(kkt[b, i], "Fx"), Fx, 1e-14), (K.f(kkt[b, i], "lx"), lx, 1e-7),
+                       (K.f(kkt[b, i], "lu"), la, 1e-7), (C.f(cdd[b, i], "la"), lu, 1e-14),
+                       (K.f(kkt[b, i], "Quu"), np.diag(dt * cost["a_weight"]), 1e-14), (C.f(cdd[b, i], "Qaa"), dt * cost["u_weight"], 1e-14),
+                       (C.f(cdd[b, i], "IDC"), ID, 1e-13), (J[:, :nv], Dq, 1e-7), (J[:, nv:], Dv, 1e-7), (C.f(cdd[b, i], "dIDda"), Da, 1e-7),
+                       (K.f(kkt[b, i], "Qxu"), np.zeros((2 * nv, nv)), 1e-14)]
+                acc[b] += Fx @ Fx + lx @ lx + la @ la + lu @ lu + ID @ ID   # split_kkt_residual.hxx:90-104 + UnconstrOCPData::KKTError
+            for g, e, tol in got:
+                d = np.abs(np.asarray(g).reshape(np.asarray(e).shape) - e).max() / max(1.0, np.abs(e).max())
+                worst = max(worst, d / tol)
+                assert d < tol, (b, i, d, tol)
+    assert np.allclose(err, np.sqrt(acc), rtol=1e-7)
+    print("worst deviation / tolerance:", worst)
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_unconstr_solver_iterations_converge_on_the_device(oracle):
+    batch = 8
+    ctx, m, grids, dt, cost, x0, rng = _setup(batch, seed=3)
+    L, n, nv = ctx.L, len(grids), m.nv
+    S = Records(L, "sol")
+    sol = S.zeros(batch, n)
+    S.f(sol, "q")[..., :nv] = x0[:, None, :nv]  # the reference's initial guess: the initial state everywhere, all else zero
+    ctx.upload(BUF_SOL, sol)
+    hist = []
+    for it in range(25):
+        hist.append(ctx.unconstr_update_solution(dt))
+        if hist[-1].max() < 1e-10:
+            break
+    hist = np.array(hist)
+    print("KKT error per iteration (worst instance):", ["%.2e" % e for e in hist.max(axis=1)])
+    assert hist[-1].max() < 1e-8 and len(hist) <= 20
+    assert (ctx.status() == 0).all()
+    sol = ctx.download_records(BUF_SOL, "sol")
+    z = np.zeros(0)
+    worst = dict(ID=0.0, Fx=0.0, x0=0.0)
+    for b in range(batch):
+        worst["x0"] = max(worst["x0"], np.abs(np.concatenate([S.f(sol[b, 0], "q")[:nv], S.f(sol[b, 0], "v")]) - x0[b]).max())
+        for i in range(n - 1):
+            s, sn = sol[b, i], sol[b, i + 1]
+            q, v, a, u = S.f(s, "q")[:nv], S.f(s, "v"), S.f(s, "a"), S.f(s, "u")
+            worst["ID"] = max(worst["ID"], np.abs(oracle.rbd_eval(m, 0, q, v, a, z, u, 0, z)).max())
+            worst["Fx"] = max(worst["Fx"], np.abs(q + dt * v - S.f(sn, "q")[:nv]).max(), np.abs(v + dt * a - S.f(sn, "v")).max())
+    print("converged trajectory, worst residuals by the CPU restatement:", worst)
+    assert worst["ID"] < 1e-8 and worst["Fx"] < 1e-8 and worst["x0"] < 1e-8
+    # the optimum moves every joint towards the reference
+    qT = np.array([S.f(sol[b, n - 1], "q")[:nv] for b in range(batch)])
+    assert (np.abs(qT - cost["q_ref"]) < np.abs(x0[:, :nv] - cost["q_ref"]) + 1e-9).all()
+    ctx.close()
