@@ -1,0 +1,56 @@
+// robotoc::UnconstrOCPSolver (robotoc_amd/host/robotoc_hip_unconstr_solver.hpp) on the GPU: iiwa14, ConfigurationSpaceCost.
+// usage: unconstr_ocp_solver_test <problem.bin> <out.bin>
+//   problem.bin: rtoc_robot_model, rtoc_configuration_cost, double T, int N, double q0[nv], double v0[nv] (written by
+//   tests/test_cpp_solver.py from the bundled model table); out.bin: iterations, converged, KKT error, then q, v of
+//   every grid point -- the Python side compares them with the same iterations issued through ctypes.
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../robotoc_amd/host/robotoc_hip_unconstr_solver.hpp"
+
+int main(int argc, char** argv) {
+  if (argc < 3) return 2;
+  robotoc::UnconstrOCP ocp;
+  FILE* f = std::fopen(argv[1], "rb");
+  if (!f) return 3;
+  double q0[RTOC_MAX_JOINTS], v0[RTOC_MAX_JOINTS];
+  bool ok = std::fread(&ocp.robot, sizeof(ocp.robot), 1, f) == 1 && std::fread(&ocp.cost, sizeof(ocp.cost), 1, f) == 1 &&
+            std::fread(&ocp.T, sizeof(double), 1, f) == 1 && std::fread(&ocp.N, sizeof(int), 1, f) == 1;
+  const int nv = ok ? ocp.robot.nv : 0;
+  ok = ok && std::fread(q0, sizeof(double), nv, f) == (size_t)nv && std::fread(v0, sizeof(double), nv, f) == (size_t)nv;
+  std::fclose(f);
+  if (!ok) return 4;
+  try {
+    robotoc::SolverOptions opt;
+    opt.max_iter = 30;
+    opt.kkt_tol = 1.0e-9;
+    robotoc::UnconstrOCPSolver solver(ocp, opt);
+    robotoc::Vec q(nv), v(nv);
+    for (int i = 0; i < nv; ++i) q(i) = q0[i], v(i) = v0[i];
+    solver.setSolution("q", q);  // the reference examples' initial guess (examples/iiwa14/unconstr_ocp.cpp)
+    solver.setSolution("v", v);
+    const double e0 = solver.KKTError(0.0, q, v);
+    solver.solve(0.0, q, v, true);
+    const robotoc::SolverStatistics& st = solver.getSolverStatistics();
+    std::printf("KKT error %.3e -> %.3e in %d iterations, converged %d\n", e0, solver.KKTError(), st.iter, (int)st.convergence);
+    // value semantics: a copy shares nothing it could corrupt and reports the same solution
+    std::vector<robotoc::Vec> qs = solver.getSolution("q"), vs = solver.getSolution("v");
+    const std::vector<robotoc::LQRPolicy>& pol = solver.getLQRPolicy();
+    if ((int)qs.size() != ocp.N + 1 || (int)pol.size() != ocp.N) return 5;
+    std::vector<double> out;
+    out.push_back(st.iter), out.push_back(st.convergence ? 1.0 : 0.0), out.push_back(solver.KKTError()), out.push_back(e0);
+    for (int i = 0; i <= ocp.N; ++i) {
+      for (int k = 0; k < nv; ++k) out.push_back(qs[i](k));
+      for (int k = 0; k < nv; ++k) out.push_back(vs[i](k));
+    }
+    for (int k = 0; k < nv; ++k) out.push_back(pol[0].k(k));
+    f = std::fopen(argv[2], "wb");
+    std::fwrite(out.data(), sizeof(double), out.size(), f);
+    std::fclose(f);
+    return st.convergence ? 0 : 6;
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "exception: %s\n", e.what());
+    return 7;
+  }
+}

@@ -86,3 +86,54 @@ def test_ocp_solver_update_solution_matches_the_oracle(tmp_path, oracle, scan):
         worst = max(worst, e)
         assert e < 1e-8, (f, e)
     print("OCPSolver::updateSolution (C++ shell) vs oracle sequence: worst rel err %.3e" % worst)
+
+
+@pytest.mark.gpu
+def test_unconstr_ocp_solver_solves_iiwa14_on_the_device(tmp_path):
+    """robotoc::UnconstrOCPSolver::solve (C++ mirror) = the same iterations issued through ctypes, and it converges."""
+    import ctypes as C
+    from robotoc_amd import capi, robot_model as rm
+    from robotoc_amd.robot_model import MAX_JOINTS
+    from test_cpp_host import _build
+    exe = _build("unconstr_ocp_solver_test")
+    dims, grids, meta = pr.config_iiwa14()
+    m = rm.load_named("iiwa14")
+    n, nv, dt = len(grids), m.nv, meta["dt"]
+    rng = np.random.default_rng(21)
+    cost = np.zeros((9, MAX_JOINTS))
+    cost[0, :nv] = rng.uniform(-0.8, 0.8, nv)
+    for k, w in ((3, 10.0), (4, 0.1), (5, 0.01), (6, 0.001), (7, 10.0), (8, 0.1)):
+        cost[k, :nv] = w
+    q0, v0 = rng.uniform(-0.5, 0.5, nv), np.zeros(nv)
+    prob = str(tmp_path / "iiwa14_problem.bin")
+    with open(prob, "wb") as f:
+        f.write(bytes(m))
+        f.write(cost.tobytes())
+        f.write(np.array([dt * (n - 1)]).tobytes())
+        f.write(np.array([n - 1], dtype=np.int32).tobytes())
+        f.write(q0.tobytes())
+        f.write(v0.tobytes())
+    out_path = str(tmp_path / "unconstr_out.bin")
+    run = subprocess.run([exe, prob, out_path], capture_output=True, text=True, timeout=300)
+    print(run.stdout, run.stderr)
+    assert run.returncode == 0, (run.returncode, run.stdout, run.stderr)
+    raw = np.fromfile(out_path)
+    iters, conv, err, err0 = int(raw[0]), raw[1], raw[2], raw[3]
+    assert conv == 1.0 and err < 1e-9 and iters <= 20
+    traj = raw[4:4 + n * 2 * nv].reshape(n, 2 * nv)
+    # the same iterations through ctypes
+    ctx = capi.Context(dims, n, 1, 0)
+    ctx.set_grid(grids)
+    ctx.set_robot_model(m)
+    ctx.set_configuration_cost(*[cost[k, :nv] for k in range(9)])
+    ctx.set_initial_state(np.concatenate([q0, v0])[None])
+    S = Records(ctx.L, "sol")
+    sol = S.zeros(1, n)
+    S.f(sol, "q")[..., :nv] = q0
+    ctx.upload(BUF_SOL, sol)
+    errs = [ctx.unconstr_update_solution(dt)[0] for _ in range(iters)]
+    assert abs(errs[0] - err0) <= 1e-12 * err0 and abs(errs[-1] - err) <= 1e-6 * max(err, 1e-12)
+    sol = ctx.download_records(BUF_SOL, "sol")
+    ref = np.concatenate([S.f(sol[0], "q")[:, :nv], S.f(sol[0], "v")], axis=1)
+    assert np.array_equal(traj, ref)
+    ctx.close()
