@@ -559,6 +559,48 @@ def main():
                 c2.close()
                 del k2, x2
             others[name] = entry
+        # ---- BASELINE configuration 1 closed on the device: UnconstrOCPSolver::updateSolution (cost, state equation,
+        #      rigid-body linearisation, condensation, Riccati sweep, expansion, solution update) per iteration ----
+        try:
+            from robotoc_amd import robot_model as rm
+            from robotoc_amd.types import BUF_SOL, Records
+            d2, g2, info = pr.config_iiwa14()
+            m2 = rm.load_named("iiwa14")
+            nv2, n2 = m2.nv, len(g2)
+            rng2 = np.random.default_rng(77)
+            loop = {}
+            for label, b2 in (("single_instance", 1), ("batch", 4096)):
+                c2 = capi.Context(d2, n2, b2, local_rank)
+                c2.set_grid(g2)
+                c2.set_robot_model(m2)
+                c2.set_configuration_cost(rng2.uniform(-0.8, 0.8, nv2), np.zeros(nv2), np.zeros(nv2), np.full(nv2, 10.0), np.full(nv2, 0.1),
+                                          np.full(nv2, 0.01), np.full(nv2, 0.001), np.full(nv2, 10.0), np.full(nv2, 0.1))
+                x0 = np.concatenate([rng2.uniform(-0.5, 0.5, (b2, nv2)), np.zeros((b2, nv2))], axis=1)  # a distinct initial state per instance
+                c2.set_initial_state(x0)
+                S2 = Records(c2.L, "sol")
+                sol2 = S2.zeros(b2, n2)
+                S2.f(sol2, "q")[..., :nv2] = x0[:, None, :nv2]
+                c2.upload(BUF_SOL, sol2)
+                errs = [c2.unconstr_update_solution(info["dt"]).max() for _ in range(12)]   # solve: the iterates converge
+                c2.upload(BUF_SOL, sol2)
+                c2.unconstr_update_solution(info["dt"], want_kkt_error=False)
+                c2.sync()
+                t0 = time.perf_counter()
+                reps = 20
+                for _ in range(reps):
+                    c2.unconstr_update_solution(info["dt"], want_kkt_error=False)
+                c2.sync()
+                ms = (time.perf_counter() - t0) / reps * 1e3
+                loop[label] = {"batch": b2, "update_solution_ms": ms, "iterations_per_sec": b2 / ms * 1e3,
+                               "kkt_error_after_12_iterations": float(errs[-1]), "kkt_error_first": float(errs[0]),
+                               "status_ok": bool((c2.status() == 0).all())}
+                c2.close()
+            loop["scope"] = ("the WHOLE UnconstrOCPSolver::updateSolution on the device (ConfigurationSpaceCost, forward-Euler state "
+                             "equation, RNEA + derivatives, condensation, Riccati sweep, expansion, update; no joint-limit rows); wall clock "
+                             "around asynchronous launches, synchronised once")
+            others["iiwa14_unconstr_N20"]["closed_loop"] = loop
+        except Exception as e:  # the sweep numbers above stand on their own
+            others["iiwa14_unconstr_N20"]["closed_loop"] = {"error": repr(e)}
 
     if rank == 0:
         total_sweeps = world * batch * args.steps
