@@ -27,6 +27,7 @@ extern "C" {
 #define RTOC_MAX_CONTACTS 8
 
 enum rtoc_joint_type { RTOC_JOINT_FREE_FLYER = 0, RTOC_JOINT_REVOLUTE = 1 };
+enum rtoc_contact_type { RTOC_CONTACT_POINT = 0, RTOC_CONTACT_SURFACE = 1 }; /* ContactType::PointContact / SurfaceContact */
 
 typedef struct rtoc_robot_model {
   int njoints, nq, nv, ncontacts;
@@ -40,7 +41,9 @@ typedef struct rtoc_robot_model {
   double mass[RTOC_MAX_JOINTS];            /* body of the joint (links behind fixed joints welded in)                 */
   double com[RTOC_MAX_JOINTS][3];          /* centre of mass in the joint frame                                       */
   double inertia[RTOC_MAX_JOINTS][9];      /* rotational inertia about the centre of mass, joint-frame axes           */
-  int contact_parent[RTOC_MAX_CONTACTS];   /* point contacts (PointContact): joint the contact frame is attached to   */
+  int contact_type[RTOC_MAX_CONTACTS];     /* rtoc_contact_type: 3 rows (force) or 6 rows (wrench); points first, as
+                                            * the reference stacks them (robot.hxx:291-320)                           */
+  int contact_parent[RTOC_MAX_CONTACTS];   /* joint the contact frame is attached to (PointContact / SurfaceContact)  */
   double contact_R[RTOC_MAX_CONTACTS][9];  /* contact frame in that joint's frame (model.frames[id].placement)        */
   double contact_p[RTOC_MAX_CONTACTS][3];
   double contact_kp[RTOC_MAX_CONTACTS];    /* ContactModelInfo::baumgarte_position_gain / velocity_gain               */
@@ -53,14 +56,17 @@ typedef struct rtoc_robot_model {
 int rtoc_set_robot_model(rtoc_ctx* ctx, const rtoc_robot_model* model);
 
 /* Per grid point: bit k of active[i] = contact k is active (ContactStatus::isContactActive; on impact grids:
- * ImpactStatus::isImpactActive), positions[i][k][0..2] = ContactStatus::contactPosition(k) (world frame; NULL: zeros).
- * popcount(active[i]) * 3 must equal the grid's dimf. */
-int rtoc_set_contact_schedule(rtoc_ctx* ctx, const unsigned* active, const double* positions);
+ * ImpactStatus::isImpactActive), positions[i][k][0..2] = ContactStatus::contactPosition(k) (world frame; NULL: zeros),
+ * rotations[i][k][0..8] = ContactStatus::contactRotation(k) (row-major; only read for surface contacts; NULL: identity).
+ * The rows of the active contacts (3 per point, 6 per surface contact) must add up to the grid's dimf. */
+int rtoc_set_contact_schedule(rtoc_ctx* ctx, const unsigned* active, const double* positions, const double* rotations);
 
 /* linearizeContactDynamics (src/dynamics/contact_dynamics.cpp:12-33) on intermediate / lift grids and
  * linearizeImpactDynamics (src/dynamics/impact_dynamics.cpp:12-27) on impact grids, for every (instance, grid point)
  * but the terminal one: from RTOC_BUF_SOL (q, v, a | dv, f_stack, u) to RTOC_BUF_CDD
- *   IDC      [ID; C]            ID = RNEA(q, v, a, f) - [0; u]        C = Baumgarte residual (impact: contact velocity)
+ *   IDC      [ID; C]            ID = RNEA(q, v, a, f) - [0; u]        C = Baumgarte residual (impact: contact velocity);
+ *                               point contact: 3 rows, classical linear acceleration (point_contact.hxx:14-31); surface
+ *                               contact: 6 rows, spatial acceleration + kp Log6(X_ref^-1 X) (surface_contact.hxx:12-29)
  *   DIDDA    dID/da  (= M(q); impact: dID/ddv)          DCDA   dC/da  (impact: unused, dC/dv is in DIDCDQV)
  *   DIDCDQV  [dID/dq dID/dv; dC/dq dC/dv]
  * i.e. everything computeMJtJinv / condenseContactDynamics read.

@@ -340,12 +340,18 @@ def _rbd():
         L.orc_rbd_integrate.argtypes = [mp, dp, dp, C.c_double, dp]
         L.orc_rbd_eval.argtypes = [mp, C.c_int, dp, dp, dp, dp, dp, C.c_uint, dp, dp]
         L.orc_rbd_eval.restype = C.c_int
+        L.orc_rbd_eval_ex.argtypes = [mp, C.c_int, dp, dp, dp, dp, dp, C.c_uint, dp, dp, dp]
+        L.orc_rbd_eval_ex.restype = C.c_int
+        L.orc_rbd_linearize_fd_ex.argtypes = [mp, C.c_int, dp, dp, dp, dp, dp, C.c_uint, dp, dp, C.c_double, dp, dp, dp, C.c_int]
+        L.orc_rbd_log6.argtypes = [dp, dp, dp]
+        L.orc_rbd_exp6.argtypes = [dp, dp, dp]
         L.orc_rbd_linearize_fd.argtypes = [mp, C.c_int, dp, dp, dp, dp, dp, C.c_uint, dp, C.c_double, dp, dp, dp, C.c_int]
         L.orc_rbd_mass_matrix_world.argtypes = [mp, dp, dp]
         L.orc_rbd_energy.argtypes = [mp, dp, dp, dp]
         L.orc_rbd_energy.restype = C.c_double
         L.orc_rbd_momentum_world.argtypes = [mp, dp, dp, dp]
         L.orc_rbd_contact_position.argtypes = [mp, dp, C.c_int, dp]
+        L.orc_rbd_contact_placement.argtypes = [mp, dp, C.c_int, dp, dp]
         L._rbd_ready = True
     return L
 
@@ -365,21 +371,38 @@ def rbd_integrate(model, q, dq, scale=1.0):
     return out
 
 
-def rbd_eval(model, impact, q, v, a, fstack, u, active, pref):
-    """[ID; C] of evalContactDynamics / evalImpactDynamics"""
+def rbd_eval(model, impact, q, v, a, fstack, u, active, pref, rref=None):
+    """[ID; C] of evalContactDynamics / evalImpactDynamics; rref: desired rotations [ncontacts, 9] of surface contacts"""
     q, v, a, fstack, u, pref = _c(q), _c(v), _c(a), _c(fstack), _c(u), _c(pref)
-    out = np.zeros(model.nv + 3 * model.ncontacts)
-    n = _rbd().orc_rbd_eval(C.byref(model), int(impact), _d(q), _d(v), _d(a), _d(fstack), _d(u), int(active), _d(pref), _d(out))
+    rr = None if rref is None else _c(rref)
+    out = np.zeros(model.nv + 6 * model.ncontacts)
+    n = _rbd().orc_rbd_eval_ex(C.byref(model), int(impact), _d(q), _d(v), _d(a), _d(fstack), _d(u), int(active), _d(pref),
+                               _d(rr) if rr is not None else None, _d(out))
     return out[:model.nv + n]
 
 
-def rbd_linearize_fd(model, impact, q, v, a, fstack, u, active, pref, eps=1e-6):
+def rbd_linearize_fd(model, impact, q, v, a, fstack, u, active, pref, eps=1e-6, rref=None):
     q, v, a, fstack, u, pref = _c(q), _c(v), _c(a), _c(fstack), _c(u), _c(pref)
-    n = model.nv + 3 * bin(active).count("1")
+    rr = None if rref is None else _c(rref)
+    n = model.nv + model.active_rows(int(active))
     D = [np.zeros((model.nv, n)) for _ in range(3)]  # column-major (n x nv) seen from C
-    _rbd().orc_rbd_linearize_fd(C.byref(model), int(impact), _d(q), _d(v), _d(a), _d(fstack), _d(u), int(active), _d(pref),
-                                eps, _d(D[0]), _d(D[1]), _d(D[2]), n)
+    _rbd().orc_rbd_linearize_fd_ex(C.byref(model), int(impact), _d(q), _d(v), _d(a), _d(fstack), _d(u), int(active), _d(pref),
+                                   _d(rr) if rr is not None else None, eps, _d(D[0]), _d(D[1]), _d(D[2]), n)
     return tuple(d.T.copy() for d in D)
+
+
+def rbd_log6(R, p):
+    R, p = _c(R), _c(p)
+    xi = np.zeros(6)
+    _rbd().orc_rbd_log6(_d(R), _d(p), _d(xi))
+    return xi
+
+
+def rbd_exp6(xi):
+    xi = _c(xi)
+    R, p = np.zeros(9), np.zeros(3)
+    _rbd().orc_rbd_exp6(_d(xi), _d(R), _d(p))
+    return R.reshape(3, 3), p
 
 
 def rbd_mass_matrix_world(model, q):
@@ -408,3 +431,10 @@ def rbd_contact_position(model, q, c):
     p = np.zeros(3)
     _rbd().orc_rbd_contact_position(C.byref(model), _d(q), int(c), _d(p))
     return p
+
+
+def rbd_contact_placement(model, q, c):
+    q = _c(q)
+    R, p = np.zeros(9), np.zeros(3)
+    _rbd().orc_rbd_contact_placement(C.byref(model), _d(q), int(c), _d(R), _d(p))
+    return R.reshape(3, 3), p

@@ -11,6 +11,9 @@
  *                                             (src/robot/point_contact.cpp:55-60: force given in the LOCAL contact frame)
  *   PointContact::computeBaumgarteResidual    include/robotoc/robot/point_contact.hxx:14-31 (classical LOCAL linear
  *                                             acceleration + kd * LOCAL linear velocity + kp * (world position - desired))
+ *   SurfaceContact::computeBaumgarteResidual  include/robotoc/robot/surface_contact.hxx:12-29 (spatial LOCAL acceleration
+ *                                             + kd * LOCAL velocity + kp * Log6(X_desired^-1 * X_frame), 6 rows; the wrench in
+ *                                             the LOCAL frame, src/robot/surface_contact.cpp) -- pinocchio::log6 restated
  *   PointContact::computeContactVelocityResidual  point_contact.hxx:84-92 (impact grids; kinematics at v + dv,
  *                                             src/ocp/impact_stage.cpp:61)
  *   evalContactDynamics / evalImpactDynamics  src/dynamics/contact_dynamics.cpp:12-20, impact_dynamics.cpp:8-14
@@ -108,6 +111,46 @@ static void inertia_mul(double mass, const double* c, const double* I, const sv6
   cross3(c, r.l, cxf);
   for (int k = 0; k < 3; ++k) r.a[k] = Iw[k] + cxf[k];
   *out = r;
+}
+
+/* log of a rotation (axis * angle), angle in [0, pi) */
+static void log3(const double* R, double* w) {
+  const double tr = R[0] + R[4] + R[8];
+  double c = 0.5 * (tr - 1.0);
+  c = c > 1.0 ? 1.0 : (c < -1.0 ? -1.0 : c);
+  const double th = acos(c);
+  const double vx = R[7] - R[5], vy = R[2] - R[6], vz = R[3] - R[1]; /* vee(R - R^T) */
+  const double k = th < 1e-6 ? 0.5 + th * th / 12.0 : th / (2.0 * sin(th));
+  w[0] = k * vx, w[1] = k * vy, w[2] = k * vz;
+}
+/* pinocchio::log6 of (R, p): [V^-1 p; log3 R] with V^-1 p = p - w x p / 2 + beta w x (w x p),
+ * beta = 1/t^2 - sin t / (2 t (1 - cos t)) */
+void orc_rbd_log6(const double* R, const double* p, double* xi) {
+  double w[3], wxp[3], wxwxp[3];
+  log3(R, w);
+  const double t = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+  const double beta = t < 1e-4 ? 1.0 / 12.0 + t * t / 720.0 : 1.0 / (t * t) - sin(t) / (2.0 * t * (1.0 - cos(t)));
+  cross3(w, p, wxp);
+  cross3(w, wxp, wxwxp);
+  for (int k = 0; k < 3; ++k) xi[k] = p[k] - 0.5 * wxp[k] + beta * wxwxp[k], xi[3 + k] = w[k];
+}
+/* exp of a twist [v; w] -> (R, p): the pair orc_rbd_integrate applies on a free-flyer root */
+void orc_rbd_exp6(const double* xi, double* R, double* p) {
+  const double* vl = xi;
+  const double* w = xi + 3;
+  const double th = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+  double A, B, ax[3] = {1, 0, 0}, wxv[3], wxwxv[3];
+  if (th > 0.0)
+    for (int k = 0; k < 3; ++k) ax[k] = w[k] / th;
+  if (th < 1e-8) {
+    A = 0.5, B = 1.0 / 6.0;
+  } else {
+    A = (1.0 - cos(th)) / (th * th), B = (th - sin(th)) / (th * th * th);
+  }
+  rodrigues(ax, th, R);
+  cross3(w, vl, wxv);
+  cross3(w, wxv, wxwxv);
+  for (int k = 0; k < 3; ++k) p[k] = vl[k] + A * wxv[k] + B * wxwxv[k];
 }
 
 typedef struct {
@@ -232,8 +275,10 @@ static int popcount_(unsigned x) {
 /* [ID; C] of evalContactDynamics (impact = 0: a = s.a) / evalImpactDynamics (impact = 1: a = s.dv).
  * fstack: forces of the ACTIVE contacts, 3 each, local contact frames; u: nu = nv - 6 (floating base) or nv joint torques
  * (impact: ignored); pref[k][3]: desired world position of contact k.  Returns dimf. */
-int orc_rbd_eval(const rtoc_robot_model* m, int impact, const double* q, const double* v, const double* a,
-                 const double* fstack, const double* u, unsigned active, const double* pref, double* IDC) {
+static int contact_rows(const rtoc_robot_model* m, int c) { return m->contact_type[c] == RTOC_CONTACT_SURFACE ? 6 : 3; }
+
+int orc_rbd_eval_ex(const rtoc_robot_model* m, int impact, const double* q, const double* v, const double* a,
+                    const double* fstack, const double* u, unsigned active, const double* pref, const double* rref, double* IDC) {
   static const double zero[3] = {0, 0, 0};
   double vz[RTOC_MAX_JOINTS + 6], vk[RTOC_MAX_JOINTS + 6];
   memset(vz, 0, sizeof vz);
@@ -249,12 +294,13 @@ int orc_rbd_eval(const rtoc_robot_model* m, int impact, const double* q, const d
   for (int c = 0; c < m->ncontacts; ++c) {
     if (!((active >> c) & 1u)) continue;
     sv6 fc, fj;
-    memcpy(fc.l, fstack + 3 * nact, sizeof fc.l);
+    memcpy(fc.l, fstack + nact, sizeof fc.l);
     memset(fc.a, 0, sizeof fc.a);
+    if (contact_rows(m, c) == 6) memcpy(fc.a, fstack + nact + 3, sizeof fc.a); /* wrench: force, then moment */
     force_act(m->contact_R[c], m->contact_p[c], &fc, &fj);
     const int j = m->contact_parent[c];
     for (int t = 0; t < 3; ++t) fext[j].l[t] += fj.l[t], fext[j].a[t] += fj.a[t];
-    ++nact;
+    nact += contact_rows(m, c);
   }
   rnea(m, &kd, impact ? zero : m->gravity, fext, IDC);
   if (!impact) {
@@ -268,52 +314,89 @@ int orc_rbd_eval(const rtoc_robot_model* m, int impact, const double* q, const d
     sv6 vf, af;
     motion_act_inv(m->contact_R[c], m->contact_p[c], &kk.v[j], &vf);
     motion_act_inv(m->contact_R[c], m->contact_p[c], &kk.a[j], &af);
-    double* C = IDC + m->nv + 3 * nact;
+    double* C = IDC + m->nv + nact;
+    const int surf = contact_rows(m, c) == 6;
     if (impact) {
       for (int t = 0; t < 3; ++t) C[t] = vf.l[t];
-    } else {
-      double wxv[3], Rf[9], pw[3], t3[3];
+      if (surf)
+        for (int t = 0; t < 3; ++t) C[3 + t] = vf.a[t];
+    } else if (!surf) {
+      double wxv[3], pw[3], t3[3];
       cross3(vf.a, vf.l, wxv); /* classical acceleration = spatial + w x v */
-      mat3_mul(kk.oR[j], m->contact_R[c], Rf);
       mat3_vec(kk.oR[j], m->contact_p[c], t3);
       for (int t = 0; t < 3; ++t) pw[t] = kk.op[j][t] + t3[t];
-      (void)Rf;
       for (int t = 0; t < 3; ++t)
         C[t] = af.l[t] + wxv[t] + m->contact_kd[c] * vf.l[t] + m->contact_kp[c] * (pw[t] - pref[3 * c + t]);
+    } else {
+      /* X_diff = X_desired^-1 * X_frame ; residual += kp * log6(X_diff) */
+      static const double eye[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+      const double* Rd = rref ? rref + 9 * c : eye;
+      double Rf[9], pw[3], t3[3], Rdt[9], Rx[9], px[3], xi[6];
+      mat3_mul(kk.oR[j], m->contact_R[c], Rf);
+      mat3_vec(kk.oR[j], m->contact_p[c], t3);
+      for (int t = 0; t < 3; ++t) pw[t] = kk.op[j][t] + t3[t] - pref[3 * c + t];
+      for (int r = 0; r < 3; ++r)
+        for (int cc = 0; cc < 3; ++cc) Rdt[3 * r + cc] = Rd[3 * cc + r];
+      mat3_mul(Rdt, Rf, Rx);
+      mat3_vec(Rdt, pw, px);
+      orc_rbd_log6(Rx, px, xi);
+      for (int t = 0; t < 3; ++t) {
+        C[t] = af.l[t] + m->contact_kd[c] * vf.l[t] + m->contact_kp[c] * xi[t];
+        C[3 + t] = af.a[t] + m->contact_kd[c] * vf.a[t] + m->contact_kp[c] * xi[3 + t];
+      }
     }
-    ++nact;
+    nact += contact_rows(m, c);
   }
-  return 3 * popcount_(active);
+  return nact;
+}
+
+int orc_rbd_eval(const rtoc_robot_model* m, int impact, const double* q, const double* v, const double* a,
+                 const double* fstack, const double* u, unsigned active, const double* pref, double* IDC) {
+  return orc_rbd_eval_ex(m, impact, q, v, a, fstack, u, active, pref, NULL, IDC);
+}
+
+static int active_rows(const rtoc_robot_model* m, unsigned active) {
+  int n = 0;
+  for (int c = 0; c < m->ncontacts; ++c)
+    if ((active >> c) & 1u) n += contact_rows(m, c);
+  return n;
 }
 
 /* Central differences of orc_rbd_eval along the 3 nv tangent directions: D* are (nv + dimf) x nv, column-major with
  * leading dimension ld.  impact: Dv = d/dv (kinematics only), Da = d/d(dv). */
-void orc_rbd_linearize_fd(const rtoc_robot_model* m, int impact, const double* q, const double* v, const double* a,
-                          const double* fstack, const double* u, unsigned active, const double* pref, double eps,
-                          double* Dq, double* Dv, double* Da, int ld) {
-  const int nv = m->nv, n = nv + 3 * popcount_(active);
-  double qp[RTOC_MAX_JOINTS + 8], xp[RTOC_MAX_JOINTS + 6], e[RTOC_MAX_JOINTS + 6], rp[2 * RTOC_MAX_JOINTS], rm[2 * RTOC_MAX_JOINTS];
+void orc_rbd_linearize_fd_ex(const rtoc_robot_model* m, int impact, const double* q, const double* v, const double* a,
+                             const double* fstack, const double* u, unsigned active, const double* pref, const double* rref,
+                             double eps, double* Dq, double* Dv, double* Da, int ld) {
+  const int nv = m->nv, n = nv + active_rows(m, active);
+  double qp[RTOC_MAX_JOINTS + 8], xp[RTOC_MAX_JOINTS + 6], e[RTOC_MAX_JOINTS + 6];
+  double rp[RTOC_MAX_JOINTS + 6 * RTOC_MAX_CONTACTS], rm[RTOC_MAX_JOINTS + 6 * RTOC_MAX_CONTACTS];
   for (int j = 0; j < nv; ++j) {
     memset(e, 0, sizeof e);
     e[j] = 1.0;
     orc_rbd_integrate(m, q, e, eps, qp);
-    orc_rbd_eval(m, impact, qp, v, a, fstack, u, active, pref, rp);
+    orc_rbd_eval_ex(m, impact, qp, v, a, fstack, u, active, pref, rref, rp);
     orc_rbd_integrate(m, q, e, -eps, qp);
-    orc_rbd_eval(m, impact, qp, v, a, fstack, u, active, pref, rm);
+    orc_rbd_eval_ex(m, impact, qp, v, a, fstack, u, active, pref, rref, rm);
     for (int i = 0; i < n; ++i) Dq[i + (size_t)j * ld] = (rp[i] - rm[i]) / (2 * eps);
     memcpy(xp, v, sizeof(double) * nv);
     xp[j] = v[j] + eps;
-    orc_rbd_eval(m, impact, q, xp, a, fstack, u, active, pref, rp);
+    orc_rbd_eval_ex(m, impact, q, xp, a, fstack, u, active, pref, rref, rp);
     xp[j] = v[j] - eps;
-    orc_rbd_eval(m, impact, q, xp, a, fstack, u, active, pref, rm);
+    orc_rbd_eval_ex(m, impact, q, xp, a, fstack, u, active, pref, rref, rm);
     for (int i = 0; i < n; ++i) Dv[i + (size_t)j * ld] = (rp[i] - rm[i]) / (2 * eps);
     memcpy(xp, a, sizeof(double) * nv);
     xp[j] = a[j] + eps;
-    orc_rbd_eval(m, impact, q, v, xp, fstack, u, active, pref, rp);
+    orc_rbd_eval_ex(m, impact, q, v, xp, fstack, u, active, pref, rref, rp);
     xp[j] = a[j] - eps;
-    orc_rbd_eval(m, impact, q, v, xp, fstack, u, active, pref, rm);
+    orc_rbd_eval_ex(m, impact, q, v, xp, fstack, u, active, pref, rref, rm);
     for (int i = 0; i < n; ++i) Da[i + (size_t)j * ld] = (rp[i] - rm[i]) / (2 * eps);
   }
+}
+
+void orc_rbd_linearize_fd(const rtoc_robot_model* m, int impact, const double* q, const double* v, const double* a,
+                          const double* fstack, const double* u, unsigned active, const double* pref, double eps,
+                          double* Dq, double* Dv, double* Da, int ld) {
+  orc_rbd_linearize_fd_ex(m, impact, q, v, a, fstack, u, active, pref, NULL, eps, Dq, Dv, Da, ld);
 }
 
 /* ---- independent cross-checks of the recursion above (used by tests/test_rigid_body.py only) ---- */
@@ -414,6 +497,19 @@ void orc_rbd_momentum_world(const rtoc_robot_model* m, const double* q, const do
     force_act(k.oR[b], k.op[b], &h, &hw);
     for (int t = 0; t < 3; ++t) h6[t] += hw.l[t], h6[3 + t] += hw.a[t];
   }
+}
+
+/* world placement of contact frame c (row-major rotation) */
+void orc_rbd_contact_placement(const rtoc_robot_model* m, const double* q, int c, double* Rw, double* pw) {
+  double z[RTOC_MAX_JOINTS + 6];
+  memset(z, 0, sizeof z);
+  rbd_kin k;
+  kinematics(m, q, z, z, &k);
+  const int j = m->contact_parent[c];
+  double t3[3];
+  mat3_mul(k.oR[j], m->contact_R[c], Rw);
+  mat3_vec(k.oR[j], m->contact_p[c], t3);
+  for (int t = 0; t < 3; ++t) pw[t] = k.op[j][t] + t3[t];
 }
 
 /* world position of contact frame c */

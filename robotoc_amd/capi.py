@@ -125,7 +125,7 @@ def lib():
         L.rtoc_line_search_filter.argtypes = [vp, dp, dp, C.POINTER(C.c_int), C.c_int, C.c_double, C.c_double, C.POINTER(C.c_int)]
         L.rtoc_line_search_clear.argtypes = [vp]
         L.rtoc_linearize_contact_dynamics.argtypes = [vp, C.c_int]
-        L.rtoc_set_contact_schedule.argtypes = [vp, C.POINTER(C.c_uint), dp]
+        L.rtoc_set_contact_schedule.argtypes = [vp, C.POINTER(C.c_uint), dp, dp]
         L.rtoc_load_stage_dump.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
         L.rtoc_error_string.argtypes = [C.c_int]
         L.rtoc_error_string.restype = C.c_char_p
@@ -331,15 +331,19 @@ class Context:
         _chk(lib().rtoc_set_robot_model(self._h, C.byref(model)))
         self._model_ncontacts = model.ncontacts
 
-    def set_contact_schedule(self, active, positions=None):
-        """rtoc_set_contact_schedule: active [nstages] bit masks, positions [nstages, ncontacts, 3] or None"""
+    def set_contact_schedule(self, active, positions=None, rotations=None):
+        """rtoc_set_contact_schedule: active [nstages] bit masks, positions [nstages, ncontacts, 3] or None,
+        rotations [nstages, ncontacts, 3, 3] (row-major; surface contacts) or None"""
         act = np.ascontiguousarray(active, dtype=np.uint32)
         assert act.shape == (self.nstages,)
-        pos = None
+        pos = rot = None
         if positions is not None:
             pos = np.ascontiguousarray(positions, dtype=np.float64)
             assert pos.shape == (self.nstages, self._model_ncontacts, 3)
-        _chk(lib().rtoc_set_contact_schedule(self._h, act.ctypes.data_as(C.POINTER(C.c_uint)), _dp(pos) if pos is not None else None))
+        if rotations is not None:
+            rot = np.ascontiguousarray(rotations, dtype=np.float64).reshape(self.nstages, self._model_ncontacts, 9)
+        _chk(lib().rtoc_set_contact_schedule(self._h, act.ctypes.data_as(C.POINTER(C.c_uint)), _dp(pos) if pos is not None else None,
+                                             _dp(rot) if rot is not None else None))
 
     def set_configuration_cost(self, q_ref, v_ref, u_ref, q_weight, v_weight, a_weight, u_weight, q_weight_terminal, v_weight_terminal):
         """rtoc_set_configuration_cost (ConfigurationSpaceCost of a fixed-base robot)"""

@@ -33,7 +33,7 @@ namespace rbd {
 // per-joint / per-contact constants as the kernel reads them, packed by rtoc_set_robot_model: one coalesced copy into
 // LDS per grid point instead of ~30 dependent L2 round trips per visited body
 constexpr int JP = 32;  // doubles per joint: R 9, p 3, axis 3, mass 1, com 3, I 9 (28), type, idx_q, idx_v, depth
-constexpr int CP = 16;  // doubles per contact: R 9, p 3, kp, kd, parent
+constexpr int CP = 16;  // doubles per contact: R 9, p 3, kp, kd, parent, type
 struct DevModel {
   rtoc_robot_model m;
   int depth[RTOC_MAX_JOINTS];
@@ -54,7 +54,7 @@ inline void pack_model(DevModel* h) {
     double* o = h->contact[c];
     for (int k = 0; k < 9; ++k) o[k] = m.contact_R[c][k];
     for (int k = 0; k < 3; ++k) o[9 + k] = m.contact_p[c][k];
-    o[12] = m.contact_kp[c], o[13] = m.contact_kd[c], o[14] = m.contact_parent[c], o[15] = 0.0;
+    o[12] = m.contact_kp[c], o[13] = m.contact_kd[c], o[14] = m.contact_parent[c], o[15] = m.contact_type[c];
   }
 }
 
@@ -114,6 +114,37 @@ __device__ __forceinline__ M3 ldm3(const double* p) {
 }
 __device__ __forceinline__ V3 ldv3(const double* p) { return mk(p[0], p[1], p[2]); }
 
+// pinocchio::log6 of X = (R, p) and its derivative along the right perturbation X exp(twist) (what Jlog6 * twist is):
+//   w = log3 R,  lin = p - w x p / 2 + beta w x (w x p),  beta(t) = 1/t^2 - cot(t/2) / (2 t)  (= the Jlog3 coefficient too)
+//   dw = twist.a + w x twist.a / 2 + beta w x (w x twist.a),  dp = R twist.l,  dt = w.dw / t
+__device__ __forceinline__ void log6_fwd(const M3& R, V3 p, SV twist, SV& val, SV& der) {
+  const double tr = R.m[0] + R.m[4] + R.m[8];
+  double c = 0.5 * (tr - 1.0);
+  c = c > 1.0 ? 1.0 : (c < -1.0 ? -1.0 : c);
+  const double th = acos(c);
+  const double k = th < 1e-6 ? 0.5 + th * th / 12.0 : th / (2.0 * sin(th));
+  const V3 w = mk(k * (R.m[7] - R.m[5]), k * (R.m[2] - R.m[6]), k * (R.m[3] - R.m[1]));
+  const double t = sqrt(dot(w, w));
+  double beta, dbeta;
+  if (t < 1e-3) {
+    beta = 1.0 / 12.0 + t * t / 720.0;
+    dbeta = t / 360.0 + t * t * t / 7560.0;
+  } else {
+    const double h = 0.5 * t, ct = cos(h) / sin(h), cs2 = 1.0 / (sin(h) * sin(h));
+    beta = 1.0 / (t * t) - ct / (2.0 * t);
+    dbeta = -2.0 / (t * t * t) + ct / (2.0 * t * t) + cs2 / (4.0 * t);
+  }
+  const V3 wxp = cross(w, p), wxwxp = cross(w, wxp);
+  val = SV{p - 0.5 * wxp + beta * wxwxp, w};
+  const V3 ta = twist.a;
+  const V3 dw = ta + 0.5 * cross(w, ta) + beta * cross(w, cross(w, ta));
+  const V3 dp = mul(R, twist.l);
+  const double dt = t > 1e-12 ? dot(w, dw) / t : 0.0;
+  const V3 dlin = dp - 0.5 * (cross(dw, p) + cross(w, dp)) + (dbeta * dt) * wxwxp +
+                  beta * (cross(dw, wxp) + cross(w, cross(dw, p)) + cross(w, cross(w, dp)));
+  der = SV{dlin, dw};
+}
+
 struct LinArgs {
   const DevModel* model;
   const double* sol;
@@ -121,6 +152,7 @@ struct LinArgs {
   const rtoc_grid* grid;
   const unsigned* active;    // [nstages]
   const double* positions;   // [nstages][ncontacts][3] or nullptr
+  const double* rotations;   // [nstages][ncontacts][9] or nullptr (surface contacts: desired rotation)
   int nstages, batch;
   int sol_stride, cdd_stride;
   int o_q, o_v, o_a, o_u, o_f;                 // RTOC_BUF_SOL field offsets
@@ -143,7 +175,7 @@ struct LinArgs {
 constexpr int VAL_DOUBLES = 64;  // R 9, p 3, oR 9, op 3, v 6, a 6, g 3, f 6, vpar 6, apar 6 -> 57, padded
 constexpr int TAN_SLOTS = 21;    // dv 6, da 6, dg 3, df 6
 __host__ __device__ constexpr size_t lin_lds_bytes(int nlevels, int njoints, int ncontacts) {
-  return sizeof(double) * ((size_t)nlevels * (VAL_DOUBLES + TAN_SLOTS * 64) + 4 * (RTOC_MAX_JOINTS + 8) + 9 * RTOC_MAX_CONTACTS + RTOC_MAX_JOINTS +
+  return sizeof(double) * ((size_t)nlevels * (VAL_DOUBLES + TAN_SLOTS * 64) + 4 * (RTOC_MAX_JOINTS + 8) + 18 * RTOC_MAX_CONTACTS + RTOC_MAX_JOINTS +
                            njoints * JP + ncontacts * CP);
 }
 
@@ -164,11 +196,11 @@ static __global__ __launch_bounds__(64) RTOC_RBD_WAVES void linearize_contact_dy
   double* const sv = sq + RTOC_MAX_JOINTS + 8;
   double* const sa = sv + RTOC_MAX_JOINTS + 8;
   double* const sf = sa + RTOC_MAX_JOINTS + 8;
-  double* const su = sf + 3 * RTOC_MAX_CONTACTS;
+  double* const su = sf + 6 * RTOC_MAX_CONTACTS;
   double* const sbeta = su + RTOC_MAX_JOINTS;           // multipliers of the dynamics (beta) and of the contact rows (mu)
   double* const smu = sbeta + RTOC_MAX_JOINTS + 8;
-  double* const slf = smu + 3 * RTOC_MAX_CONTACTS;      // dC/da beta, accumulated over the passes
-  double* const sjm = slf + 3 * RTOC_MAX_CONTACTS;      // model: [njoints][JP], then [ncontacts][CP]
+  double* const slf = smu + 6 * RTOC_MAX_CONTACTS;      // dC/da beta, accumulated over the passes
+  double* const sjm = slf + 6 * RTOC_MAX_CONTACTS;      // model: [njoints][JP], then [ncontacts][CP]
   double* const scm = sjm + a.njoints * JP;
   const bool aug = a.kkt != nullptr;
   const size_t rec = (size_t)b * a.nstages + st;
@@ -191,7 +223,7 @@ static __global__ __launch_bounds__(64) RTOC_RBD_WAVES void linearize_contact_dy
   if (aug) {
     for (int e = lane; e < nv; e += 64) sbeta[e] = sr[a.o_beta + e];
     for (int e = lane; e < g.dimf; e += 64) smu[e] = sr[a.o_mu + e];
-    for (int e = lane; e < 3 * RTOC_MAX_CONTACTS; e += 64) slf[e] = 0.0;
+    for (int e = lane; e < 6 * RTOC_MAX_CONTACTS; e += 64) slf[e] = 0.0;
   }
   __syncthreads();
   const V3 grav = mk(a.gx, a.gy, a.gz);
@@ -337,62 +369,90 @@ static __global__ __launch_bounds__(64) RTOC_RBD_WAVES void linearize_contact_dy
         const SV h = inertia_mul(mass, com, I, v);
         SV f = inertia_mul(mass, com, I, SV{acc.l + gi, acc.a}) + fcross(v, h);
         const SV df = inertia_mul(mass, com, I, SV{da.l + dg, da.a}) + fcross(dv, h) + fcross(v, inertia_mul(mass, com, I, dv));
-        // contacts carried by this body
-        int nact = 0;
+        // contacts carried by this body; roff = rows of the active contacts before c (3 per point, 6 per surface contact)
+        int roff = 0;
         for (int c = 0; c < ncon; ++c) {
           const bool on = (active >> c) & 1u;
+          const bool surf = (int)scm[c * CP + 15] == RTOC_CONTACT_SURFACE;
+          const int nr = surf ? 6 : 3;
           if (on && (int)scm[c * CP + 14] == i) {
             const M3 Rf = ldm3(&scm[c * CP]);
             const V3 pf = ldv3(&scm[c * CP + 9]);
-            f = f - act_f(Rf, pf, SV{mk(sf[3 * nact], sf[3 * nact + 1], sf[3 * nact + 2]), mk(0, 0, 0)});
+            // the contact force / wrench is given in the LOCAL contact frame (point_contact.cpp:55-60, surface_contact.cpp)
+            const SV fc = SV{mk(sf[roff], sf[roff + 1], sf[roff + 2]), surf ? mk(sf[roff + 3], sf[roff + 4], sf[roff + 5]) : mk(0, 0, 0)};
+            f = f - act_f(Rf, pf, fc);
             if (rows) {
               const SV vf = act_inv(Rf, pf, v), dvf = act_inv(Rf, pf, dv);
-              V3 C, dC;
+              SV C, dC;  // angular parts only used by surface contacts
               if (impact) {
-                C = vf.l;
-                dC = dvf.l;
+                C = vf;
+                dC = dvf;
               } else {
                 const SV af = act_inv(Rf, pf, acc), daf = act_inv(Rf, pf, da);
                 const double kp = scm[c * CP + 12], kd = scm[c * CP + 13];
+                const M3 oRf = mul(oR, Rf);
                 const V3 pw = op + mul(oR, pf);
                 const V3 pr = a.positions ? ldv3(a.positions + ((size_t)st * ncon + c) * 3) : mk(0, 0, 0);
-                C = af.l + cross(vf.a, vf.l) + kd * vf.l + kp * (pw - pr);
-                dC = daf.l + cross(dvf.a, vf.l) + cross(vf.a, dvf.l) + kd * dvf.l;
-                // kp * R_of * J_lin(:, j): the frame Jacobian column is the v-tangent of vf, one lane up
-                const V3 jl = mk(__shfl_down(dvf.l.x, 1, 64), __shfl_down(dvf.l.y, 1, 64), __shfl_down(dvf.l.z, 1, 64));
-                if (kind == 0) dC = dC + kp * mul(mul(oR, Rf), jl);
+                // the frame Jacobian column of dof j is the v-tangent of vf, one lane up (kind 0 lanes only use it)
+                const SV jc = SV{mk(__shfl_down(dvf.l.x, 1, 64), __shfl_down(dvf.l.y, 1, 64), __shfl_down(dvf.l.z, 1, 64)),
+                                 mk(__shfl_down(dvf.a.x, 1, 64), __shfl_down(dvf.a.y, 1, 64), __shfl_down(dvf.a.z, 1, 64))};
+                if (!surf) {
+                  // classical linear acceleration + kd v + kp (p - p_desired)   (point_contact.hxx:14-31, :33-83)
+                  C.l = af.l + cross(vf.a, vf.l) + kd * vf.l + kp * (pw - pr);
+                  dC.l = daf.l + cross(dvf.a, vf.l) + cross(vf.a, dvf.l) + kd * dvf.l;
+                  if (kind == 0) dC.l = dC.l + kp * mul(oRf, jc.l);
+                  C.a = mk(0, 0, 0), dC.a = mk(0, 0, 0);
+                } else {
+                  // spatial acceleration + kd v + kp Log6(X_desired^-1 X_frame)   (surface_contact.hxx:12-29, :31-68)
+                  M3 Rd;
+                  if (a.rotations) {
+                    Rd = ldm3(a.rotations + ((size_t)st * ncon + c) * 9);
+                  } else {
+#pragma unroll
+                    for (int e = 0; e < 9; ++e) Rd.m[e] = (e % 4 == 0) ? 1.0 : 0.0;
+                  }
+                  M3 Rdt;
+#pragma unroll
+                  for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int cc = 0; cc < 3; ++cc) Rdt.m[3 * r + cc] = Rd.m[3 * cc + r];
+                  SV lg, dlg;
+                  log6_fwd(mul(Rdt, oRf), mul(Rdt, pw - pr), jc, lg, dlg);
+                  C = SV{af.l + kd * vf.l + kp * lg.l, af.a + kd * vf.a + kp * lg.a};
+                  dC = SV{daf.l + kd * dvf.l, daf.a + kd * dvf.a};
+                  if (kind == 0) dC = SV{dC.l + kp * dlg.l, dC.a + kp * dlg.a};
+                }
               }
-              const int r0 = nv + 3 * nact;
+              const double Cv[6] = {C.l.x, C.l.y, C.l.z, C.a.x, C.a.y, C.a.z}, dCv[6] = {dC.l.x, dC.l.y, dC.l.z, dC.a.x, dC.a.y, dC.a.z};
+              const int r0 = nv + roff;
               if (aug) {
-                wsum += dC.x * smu[3 * nact] + dC.y * smu[3 * nact + 1] + dC.z * smu[3 * nact + 2];
                 // lf -= dC/da beta (contact_dynamics.cpp:38; impact: dC/dv, impact_dynamics.cpp:21): sum over the a-lanes
                 const bool al = lane_on && kind == 2;
-                double rx = al ? dC.x * sbeta[j] : 0.0, ry = al ? dC.y * sbeta[j] : 0.0, rz = al ? dC.z * sbeta[j] : 0.0;
 #pragma unroll
-                for (int off = 32; off > 0; off >>= 1) {
-                  rx += __shfl_xor(rx, off, 64);
-                  ry += __shfl_xor(ry, off, 64);
-                  rz += __shfl_xor(rz, off, 64);
+                for (int t = 0; t < 6; ++t) {
+                  if (t < nr) {
+                    wsum += dCv[t] * smu[roff + t];
+                    double rx = al ? dCv[t] * sbeta[j] : 0.0;
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) rx += __shfl_xor(rx, off, 64);
+                    if (lane == 0) slf[roff + t] += rx;
+                  }
                 }
-                if (lane == 0) slf[3 * nact] += rx, slf[3 * nact + 1] += ry, slf[3 * nact + 2] += rz;
               }
-              if (lane == 0 && j0 == 0) {
-                cr[a.o_idc + r0] = C.x, cr[a.o_idc + r0 + 1] = C.y, cr[a.o_idc + r0 + 2] = C.z;
-              }
-              if (lane_on) {
-                // impact: dC/dv = dC/d(dv) goes where the condensation reads it (the v block of DIDCDQV) and into DCDA
-                if (kind == 2 || (impact && kind == 1)) {
-                  double* const o = cr + a.o_dcda + (size_t)j * a.nf_max + (r0 - nv);
-                  o[0] = dC.x, o[1] = dC.y, o[2] = dC.z;
-                }
-                if (kind != 2) {
-                  double* const o = cr + a.o_didcdqv + (size_t)(kind == 1 ? nv + j : j) * a.ldv + r0;
-                  o[0] = dC.x, o[1] = dC.y, o[2] = dC.z;
+#pragma unroll
+              for (int t = 0; t < 6; ++t) {
+                if (t < nr) {
+                  if (lane == 0 && j0 == 0) cr[a.o_idc + r0 + t] = Cv[t];
+                  if (lane_on) {
+                    // impact: dC/dv = dC/d(dv) goes where the condensation reads it (the v block of DIDCDQV) and into DCDA
+                    if (kind == 2 || (impact && kind == 1)) cr[a.o_dcda + (size_t)j * a.nf_max + (r0 - nv) + t] = dCv[t];
+                    if (kind != 2) cr[a.o_didcdqv + (size_t)(kind == 1 ? nv + j : j) * a.ldv + r0 + t] = dCv[t];
+                  }
                 }
               }
             }
           }
-          nact += on;
+          roff += on ? nr : 0;
         }
         // ---- store the level ----
 #pragma unroll

@@ -107,7 +107,8 @@ struct rtoc_ctx {
   rbd::DevModel* h_model;
   unsigned* d_active;
   double* d_cpos;
-  bool has_cpos;
+  double* d_crot;
+  bool has_cpos, has_crot;
   // rtoc_line_search_filter: filters [batch][CAP][2], sizes [batch], staging (cost, violation | mask, accepted)
   double* d_cost;      // rtoc_set_configuration_cost: 9 nv doubles
   double* d_x0;        // rtoc_set_initial_state: [batch][2 nv]
@@ -270,6 +271,7 @@ int rtoc_destroy(rtoc_ctx* c) {
   if (c->d_ls_in) (void)hipFree(c->d_ls_in);
   if (c->d_ls_flags) (void)hipFree(c->d_ls_flags);
   if (c->d_cpos) (void)hipFree(c->d_cpos);
+  if (c->d_crot) (void)hipFree(c->d_crot);
   if (c->d_prof) (void)hipFree(c->d_prof);
   for (int i = 0; i < 3; ++i)
     if (c->d_scan[i]) (void)hipFree(c->d_scan[i]);
@@ -1234,7 +1236,13 @@ int rtoc_integrate_solution(rtoc_ctx* c) {
 int rtoc_set_robot_model(rtoc_ctx* c, const rtoc_robot_model* m) {
   if (!c || !m) return RTOC_ERR_BAD_ARG;
   if (m->njoints < 1 || m->njoints > RTOC_MAX_JOINTS || m->ncontacts < 0 || m->ncontacts > RTOC_MAX_CONTACTS) return RTOC_ERR_BAD_ARG;
-  if (m->nv != c->dims.nv || 3 * m->ncontacts > c->dims.nf_max) return RTOC_ERR_BAD_ARG;
+  int max_dimf = 0;
+  for (int k = 0; k < m->ncontacts; ++k) {
+    if (m->contact_type[k] != RTOC_CONTACT_POINT && m->contact_type[k] != RTOC_CONTACT_SURFACE) return RTOC_ERR_BAD_ARG;
+    if (k > 0 && m->contact_type[k] < m->contact_type[k - 1]) return RTOC_ERR_BAD_ARG;  // points first
+    max_dimf += m->contact_type[k] == RTOC_CONTACT_SURFACE ? 6 : 3;
+  }
+  if (m->nv != c->dims.nv || max_dimf > c->dims.nf_max) return RTOC_ERR_BAD_ARG;
   const bool ff = m->type[0] == RTOC_JOINT_FREE_FLYER;
   if (m->nq != m->nv + (ff ? 1 : 0) || (ff ? m->nv - 6 : m->nv) != c->dims.nu) return RTOC_ERR_BAD_ARG;
   rbd::DevModel* h = new (std::nothrow) rbd::DevModel;
@@ -1275,22 +1283,30 @@ int rtoc_set_robot_model(rtoc_ctx* c, const rtoc_robot_model* m) {
   return RTOC_OK;
 }
 
-int rtoc_set_contact_schedule(rtoc_ctx* c, const unsigned* active, const double* positions) {
+int rtoc_set_contact_schedule(rtoc_ctx* c, const unsigned* active, const double* positions, const double* rotations) {
   CHECK_READY(c);
   if (!c->h_model || !active) return RTOC_ERR_BAD_ARG;
-  const int nc = c->h_model->m.ncontacts;
+  const rtoc_robot_model& m = c->h_model->m;
+  const int nc = m.ncontacts;
   for (int i = 0; i < c->nstages; ++i) {
     if (nc < 32 && (active[i] >> nc) != 0) return RTOC_ERR_BAD_ARG;
-    if (i < c->nstages - 1 && 3 * __builtin_popcount(active[i]) != c->h_grid[i].dimf) return RTOC_ERR_BAD_ARG;
+    int rows = 0;
+    for (int k = 0; k < nc; ++k)
+      if ((active[i] >> k) & 1u) rows += m.contact_type[k] == RTOC_CONTACT_SURFACE ? 6 : 3;
+    if (i < c->nstages - 1 && rows != c->h_grid[i].dimf) return RTOC_ERR_BAD_ARG;
   }
   HIP_TRY(hipSetDevice(c->device));
   if (!c->d_active) HIP_TRY(hipMalloc((void**)&c->d_active, sizeof(unsigned) * c->max_stages));
   if (!c->d_cpos) HIP_TRY(hipMalloc((void**)&c->d_cpos, sizeof(double) * c->max_stages * RTOC_MAX_CONTACTS * 3));
+  if (rotations && !c->d_crot) HIP_TRY(hipMalloc((void**)&c->d_crot, sizeof(double) * c->max_stages * RTOC_MAX_CONTACTS * 9));
   HIP_TRY(hipMemcpyAsync(c->d_active, active, sizeof(unsigned) * c->nstages, hipMemcpyHostToDevice, c->stream));
   if (positions)
     HIP_TRY(hipMemcpyAsync(c->d_cpos, positions, sizeof(double) * c->nstages * nc * 3, hipMemcpyHostToDevice, c->stream));
+  if (rotations)
+    HIP_TRY(hipMemcpyAsync(c->d_crot, rotations, sizeof(double) * c->nstages * nc * 9, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->has_cpos = positions != nullptr;
+  c->has_crot = rotations != nullptr;
   c->epoch++;
   return RTOC_OK;
 }
@@ -1307,6 +1323,7 @@ static int launch_linearize(rtoc_ctx* c, int augment_residual, bool unconstr, do
   a.grid = c->d_grid;
   a.active = c->d_active;
   a.positions = c->has_cpos ? c->d_cpos : nullptr;
+  a.rotations = c->has_crot ? c->d_crot : nullptr;
   a.nstages = c->nstages;
   a.batch = c->batch;
   a.sol_stride = c->L.sol.stride;

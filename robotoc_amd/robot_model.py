@@ -10,6 +10,7 @@ MODEL_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "models")
 MAX_JOINTS = 48
 MAX_CONTACTS = 8
 JOINT_FREE_FLYER, JOINT_REVOLUTE = 0, 1
+CONTACT_POINT, CONTACT_SURFACE = 0, 1
 
 
 class RobotModel(C.Structure):
@@ -20,7 +21,7 @@ class RobotModel(C.Structure):
         ("placement_R", (C.c_double * 9) * MAX_JOINTS), ("placement_p", (C.c_double * 3) * MAX_JOINTS),
         ("axis", (C.c_double * 3) * MAX_JOINTS), ("mass", C.c_double * MAX_JOINTS),
         ("com", (C.c_double * 3) * MAX_JOINTS), ("inertia", (C.c_double * 9) * MAX_JOINTS),
-        ("contact_parent", C.c_int * MAX_CONTACTS), ("contact_R", (C.c_double * 9) * MAX_CONTACTS),
+        ("contact_type", C.c_int * MAX_CONTACTS), ("contact_parent", C.c_int * MAX_CONTACTS), ("contact_R", (C.c_double * 9) * MAX_CONTACTS),
         ("contact_p", (C.c_double * 3) * MAX_CONTACTS), ("contact_kp", C.c_double * MAX_CONTACTS),
         ("contact_kd", C.c_double * MAX_CONTACTS), ("gravity", C.c_double * 3),
     ]
@@ -28,6 +29,16 @@ class RobotModel(C.Structure):
     @property
     def floating_base(self):
         return self.njoints > 0 and self.type[0] == JOINT_FREE_FLYER
+
+    def contact_rows(self, k):
+        return 6 if self.contact_type[k] == CONTACT_SURFACE else 3
+
+    def active_rows(self, mask):
+        return sum(self.contact_rows(k) for k in range(self.ncontacts) if (mask >> k) & 1)
+
+    @property
+    def max_dimf(self):
+        return sum(self.contact_rows(k) for k in range(self.ncontacts))
 
     @property
     def nu(self):
@@ -49,6 +60,7 @@ def from_dict(d):
         m.inertia[i][:] = np.asarray(j["inertia"], dtype=float).reshape(9)
     for k, c in enumerate(cs):
         m.contact_parent[k] = c["parent"]
+        m.contact_type[k] = CONTACT_SURFACE if c.get("type", "point") == "surface" else CONTACT_POINT
         m.contact_R[k][:] = np.asarray(c["R"], dtype=float).reshape(9)
         m.contact_p[k][:] = c["p"]
         m.contact_kp[k], m.contact_kd[k] = c["baumgarte_position_gain"], c["baumgarte_velocity_gain"]

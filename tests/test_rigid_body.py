@@ -104,6 +104,17 @@ def test_floating_base_rows_balance_the_rate_of_total_momentum(oracle, name):
         assert np.abs(tau[:6] - np.concatenate([fb, nb])).max() < 2e-6 * max(1.0, np.abs(tau[:6]).max())
 
 
+def test_log6_inverts_exp6(oracle):
+    """pinocchio::log6 restated in the oracle against the SE(3) exponential of orc_rbd_integrate: log6(exp6(xi)) = xi"""
+    rng = np.random.default_rng(9)
+    for scale in (1e-9, 1e-5, 1e-2, 0.5, 1.5):  # |w| < pi
+        for _ in range(20):
+            xi = rng.uniform(-1, 1, 6) * scale
+            R, p = oracle.rbd_exp6(xi)
+            assert np.abs(R @ R.T - np.eye(3)).max() < 1e-14
+            assert np.abs(oracle.rbd_log6(R, p) - xi).max() < 1e-9 * max(1.0, scale) + 1e-15
+
+
 def test_model_table_is_validated():
     capi.build()
     lib = capi.lib()
@@ -246,35 +257,45 @@ def test_gpu_linearisation_matches_the_restatement_and_its_finite_differences(or
 
 
 @pytest.mark.gpu
-def test_gpu_linearisation_icub_two_passes_eleven_levels(oracle):
-    """nv = 35: 2 passes of 21 dofs, 11 tree levels (118 KB of LDS per wave); two foot point contacts"""
+def test_gpu_linearisation_icub_surface_contacts_two_passes_eleven_levels(oracle):
+    """nv = 35: 2 passes of 21 dofs, 11 tree levels (128 KB of LDS per wave); two SURFACE contacts (the soles: 6 rows
+    each, wrench in the local frame, Log6 position / orientation error against a desired placement)"""
     from robotoc_amd.types import Grid, GRID_INTERMEDIATE, GRID_TERMINAL
     m = model("icub")
+    assert m.contact_rows(0) == 6 and m.max_dimf == 12
     dims = Dims(35, 29, 6, 12, 12, 0)
     inter = lambda dimf: Grid(GRID_INTERMEDIATE, 0, 0, 0, dimf, 0, 8, 2, 0.02)
-    grids = [inter(3), inter(6), Grid(GRID_IMPACT, 0, 0, 0, 3, 0, 1, -1, 0.0), inter(6), inter(0), Grid(GRID_TERMINAL, 0, 0, 0, 0, 0, 1, 2, 0.0)]
-    masks = np.array([0b11 if g.dimf == 6 else (0b10 if g.dimf == 3 else 0) for g in grids], dtype=np.uint32)
+    grids = [inter(6), inter(12), Grid(GRID_IMPACT, 0, 0, 0, 6, 0, 1, -1, 0.0), inter(12), inter(0), Grid(GRID_TERMINAL, 0, 0, 0, 0, 0, 1, 2, 0.0)]
+    masks = np.array([0b10, 0b11, 0b01, 0b11, 0, 0], dtype=np.uint32)
     batch = 2
     ctx = capi.Context(dims, len(grids), batch, 0)
     L = ctx.L
     ctx.set_grid(grids)
     ctx.set_robot_model(m)
     rng = np.random.default_rng(5)
-    pos = rng.uniform(-0.5, 0.5, (len(grids), 2, 3))
-    ctx.set_contact_schedule(masks, pos)
+    # one configuration per grid point (the schedule is shared by the instances); the desired placements are the actual
+    # ones moved by a twist of up to ~0.3 (a contact that drifted: Log6 stays away from its singularity at pi)
+    qs = [rm.random_configuration(m, rng, 0.6)[0] for _ in grids]
+    pos, rot = np.zeros((len(grids), 2, 3)), np.zeros((len(grids), 2, 3, 3))
+    for i in range(len(grids)):
+        for c in range(2):
+            Rw, pw = oracle.rbd_contact_placement(m, qs[i], c)
+            dR, dp = oracle.rbd_exp6(rng.uniform(-0.3, 0.3, 6))
+            rot[i, c], pos[i, c] = Rw @ dR, pw + Rw @ dp
+    ctx.set_contact_schedule(masks, pos, rot)
     sol = np.zeros(ctx.shape("sol"))
     o, co = L.sol.off, L.cdd.off
     for b in range(batch):
         for i in range(len(grids)):
-            q, v, a = rm.random_configuration(m, rng, 0.6)
-            sol[b, i, o[0]:o[0] + m.nq], sol[b, i, o[1]:o[1] + m.nv], sol[b, i, o[2]:o[2] + m.nv] = q, v, a
+            _, v, a = rm.random_configuration(m, rng, 0.6)
+            sol[b, i, o[0]:o[0] + m.nq], sol[b, i, o[1]:o[1] + m.nv], sol[b, i, o[2]:o[2] + m.nv] = qs[i], v, a
             sol[b, i, o[3]:o[3] + m.nu] = rng.uniform(-5, 5, m.nu)
-            sol[b, i, o[4]:o[4] + 6] = rng.uniform(-20, 20, 6)
+            sol[b, i, o[4]:o[4] + 12] = rng.uniform(-20, 20, 12)
     ctx.upload(BUF_SOL, sol)
     ctx.linearize_contact_dynamics()
     ctx.sync()
     cdd = ctx.download(BUF_CDD, ctx.shape("cdd"))
-    nv, ldv = m.nv, dims.nv + dims.nf_max
+    nv, ldv, nfm = m.nv, dims.nv + dims.nf_max, dims.nf_max
     worst = 0.0
     for b in range(batch):
         for i in range(len(grids) - 1):
@@ -282,17 +303,22 @@ def test_gpu_linearisation_icub_two_passes_eleven_levels(oracle):
             impact = g.type == GRID_IMPACT
             n = nv + g.dimf
             s = sol[b, i]
-            args = (m, impact, s[o[0]:o[0] + m.nq], s[o[1]:o[1] + nv], s[o[2]:o[2] + nv], s[o[4]:o[4] + 6], s[o[3]:o[3] + m.nu], act, pos[i].reshape(-1))
-            ref = oracle.rbd_eval(*args)
-            Dq, Dv, Da = oracle.rbd_linearize_fd(*args, 1e-6)
+            args = (m, impact, s[o[0]:o[0] + m.nq], s[o[1]:o[1] + nv], s[o[2]:o[2] + nv], s[o[4]:o[4] + 12], s[o[3]:o[3] + m.nu], act, pos[i].reshape(-1))
+            ref = oracle.rbd_eval(*args, rref=rot[i].reshape(2, 9))
+            Dq, Dv, Da = oracle.rbd_linearize_fd(*args, 1e-6, rref=rot[i].reshape(2, 9))
             rec = cdd[b, i]
             D = rec[co[1]:co[1] + ldv * 2 * nv].reshape(2 * nv, ldv).T
             M = rec[co[0]:co[0] + nv * nv].reshape(nv, nv).T
-            assert np.abs(rec[co[3]:co[3] + n] - ref).max() < 1e-12 * max(1.0, np.abs(ref).max())
+            J = rec[co[2]:co[2] + nfm * nv].reshape(nv, nfm).T[:g.dimf]
+            assert np.abs(rec[co[3]:co[3] + n] - ref).max() < 1e-12 * max(1.0, np.abs(ref).max()), (b, i)
             sc = lambda x: max(1.0, np.abs(x).max())
             worst = max(worst, np.abs(D[:n, :nv] - Dq).max() / sc(Dq), np.abs(M - Da[:nv]).max() / sc(Da))
-            if not impact:
+            if impact:
+                worst = max(worst, np.abs(D[nv:n, nv:] - Dv[nv:]).max() / sc(Dv), np.abs(J - Da[nv:]).max() / sc(Da))
+            else:
                 worst = max(worst, np.abs(D[:n, nv:] - Dv).max() / sc(Dv))
-    print("iCub worst relative deviation of the derivatives:", worst)
+                if g.dimf:
+                    worst = max(worst, np.abs(J - Da[nv:]).max() / sc(Da))
+    print("iCub (surface contacts) worst relative deviation of the derivatives:", worst)
     assert worst < 1e-7
     ctx.close()

@@ -70,7 +70,7 @@ def link_inertia(link):
     return Inertia(m, p, R @ I @ R.T)
 
 
-def build(urdf, floating_base, contacts, kp, kd):
+def build(urdf, floating_base, contacts, kp, kd, surface_contacts=()):
     root = ET.parse(urdf).getroot()
     links = {l.get("name"): l for l in root.findall("link")}
     joints = root.findall("joint")
@@ -133,10 +133,10 @@ def build(urdf, floating_base, contacts, kp, kd):
         iq += nq
         iv += nv
     cs = []
-    for name in contacts:
+    for name, kind in [(n, "point") for n in contacts] + [(n, "surface") for n in surface_contacts]:  # points first (robot.hxx:291-320)
         body, R, p = frames[name]
         assert body >= 0, "contact frame on the fixed base"
-        cs.append(dict(frame=name, parent=body, R=R.tolist(), p=p.tolist(), baumgarte_position_gain=kp, baumgarte_velocity_gain=kd))
+        cs.append(dict(frame=name, type=kind, parent=body, R=R.tolist(), p=p.tolist(), baumgarte_position_gain=kp, baumgarte_velocity_gain=kd))
     return dict(source=urdf.split("/reference/")[-1], floating_base=bool(floating_base), nq=iq, nv=iv, gravity=[0.0, 0.0, -9.81],
                 joints=out, contacts=cs)
 
@@ -145,10 +145,11 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("urdf")
     ap.add_argument("--floating-base", action="store_true")
-    ap.add_argument("--contacts", nargs="*", default=[])
+    ap.add_argument("--contacts", nargs="*", default=[], help="point contacts (3 rows each)")
+    ap.add_argument("--surface-contacts", nargs="*", default=[], help="surface contacts (6 rows each)")
     ap.add_argument("--time-step", type=float, default=0.05, help="Baumgarte gains: kd = 2/dt, kp = 1/dt^2 (contact_model_info.cpp)")
     ap.add_argument("-o", "--out", required=True)
     a = ap.parse_args()
-    m = build(a.urdf, a.floating_base, a.contacts, 1.0 / a.time_step**2, 2.0 / a.time_step)
+    m = build(a.urdf, a.floating_base, a.contacts, 1.0 / a.time_step**2, 2.0 / a.time_step, a.surface_contacts)
     json.dump(m, open(a.out, "w"), indent=1)
     print(a.out, "joints", len(m["joints"]), "nq", m["nq"], "nv", m["nv"], "mass", sum(j["mass"] for j in m["joints"]))
