@@ -94,11 +94,20 @@ int rtoc_set_initial_state(rtoc_ctx* ctx, const double* x0, int count);
  * (src/dynamics/unconstr_state_equation.cpp:8-24), linearizeUnconstrDynamics (src/dynamics/unconstr_dynamics.cpp:52-64:
  * RNEA, its derivatives, the dt-scaled multiplier terms), and computeInitialStateDirection (x0 - s[0].x into
  * RTOC_BUF_DX0) -- from RTOC_BUF_SOL into RTOC_BUF_KKT / RTOC_BUF_CDD in the record convention of rtoc_unconstr_condense.
- * Inequality constraints (joint limits) are not part of this path. */
+ * With joint-limit rows and bounds set (below): constraints_->linearizeConstraints as well (residual, cmpl into
+ * RTOC_BUF_CON, the duals into the gradients). */
 int rtoc_unconstr_eval_kkt(rtoc_ctx* ctx, double dt);
+/* The joint-limit rows of this path live on the device for their whole life.  After rtoc_set_constraint_rows: the bound
+ * of every row, g(z) = sign * z - bound <= 0 (lower limit zmin: sign -1, bound -zmin; upper limit zmax: sign +1, bound
+ * zmax), the barrier parameter and the fraction-to-boundary rule (ConstraintsBase setters; 1e-3 / 0.995 in the
+ * reference).  rtoc_unconstr_init_constraints = initConstraints (setSlackAndDual at the current iterate). */
+int rtoc_set_constraint_bounds(rtoc_ctx* ctx, const double* bounds, int nrows, double barrier_param, double fraction_to_boundary_rule);
+int rtoc_unconstr_init_constraints(rtoc_ctx* ctx);
 /* UnconstrOCPSolver::updateSolution (src/solver/unconstr_ocp_solver.cpp:96-118): rtoc_unconstr_eval_kkt, the KKT error
  * of the iterate it linearised at (host_kkt_error[count <= batch], may be NULL / 0), rtoc_unconstr_condense, backward,
- * forward, rtoc_unconstr_expand, and SplitSolution::integrate with step size 1 -- RTOC_BUF_SOL holds the next iterate. */
+ * forward, rtoc_unconstr_expand, and SplitSolution::integrate -- RTOC_BUF_SOL holds the next iterate.  Step size 1, or,
+ * with joint-limit rows, condenseSlackAndDual / expandSlackAndDual, the fraction-to-boundary step sizes and the slack / dual
+ * update as well (unconstr_intermediate_stage.cpp:76-118). */
 int rtoc_unconstr_update_solution(rtoc_ctx* ctx, double dt, double* host_kkt_error, int count);
 
 #ifdef __cplusplus

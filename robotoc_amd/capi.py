@@ -28,7 +28,7 @@ EXPORTS = [
     "rtoc_newton_iteration", "rtoc_converged_count", "rtoc_clone", "rtoc_check_fxx_structure", "rtoc_sto_eval_kkt", "rtoc_set_friction_cones", "rtoc_set_wrench_cones", "rtoc_wrench_cone_matrix", "rtoc_save_stage_dump", "rtoc_load_stage_dump", "rtoc_kkt_error", "rtoc_integrate_solution",
     "rtoc_set_robot_model", "rtoc_set_contact_schedule", "rtoc_linearize_contact_dynamics",
     "rtoc_line_search_filter", "rtoc_line_search_clear", "rtoc_set_configuration_cost", "rtoc_set_initial_state",
-    "rtoc_unconstr_eval_kkt", "rtoc_unconstr_update_solution",
+    "rtoc_unconstr_eval_kkt", "rtoc_unconstr_update_solution", "rtoc_set_constraint_bounds", "rtoc_unconstr_init_constraints",
 ]
 
 
@@ -121,6 +121,8 @@ def lib():
         L.rtoc_set_configuration_cost.argtypes = [vp, vp]
         L.rtoc_set_initial_state.argtypes = [vp, dp, C.c_int]
         L.rtoc_unconstr_eval_kkt.argtypes = [vp, C.c_double]
+        L.rtoc_set_constraint_bounds.argtypes = [vp, dp, C.c_int, C.c_double, C.c_double]
+        L.rtoc_unconstr_init_constraints.argtypes = [vp]
         L.rtoc_unconstr_update_solution.argtypes = [vp, C.c_double, dp, C.c_int]
         L.rtoc_line_search_filter.argtypes = [vp, dp, dp, C.POINTER(C.c_int), C.c_int, C.c_double, C.c_double, C.POINTER(C.c_int)]
         L.rtoc_line_search_clear.argtypes = [vp]
@@ -358,6 +360,13 @@ class Context:
         x0 = np.ascontiguousarray(x0, dtype=np.float64)
         assert x0.shape == (self.batch, 2 * self.dims.nv)
         _chk(lib().rtoc_set_initial_state(self._h, _dp(x0), self.batch))
+
+    def set_constraint_bounds(self, bounds, barrier_param=1.0e-3, fraction_to_boundary_rule=0.995):
+        bounds = np.ascontiguousarray(bounds, dtype=np.float64)
+        _chk(lib().rtoc_set_constraint_bounds(self._h, _dp(bounds), bounds.size, barrier_param, fraction_to_boundary_rule))
+
+    def unconstr_init_constraints(self):
+        _chk(lib().rtoc_unconstr_init_constraints(self._h))
 
     def unconstr_eval_kkt(self, dt):
         _chk(lib().rtoc_unconstr_eval_kkt(self._h, dt))

@@ -13,6 +13,7 @@
 #include "../../include/rtoc_robot.h"
 #include "kernel_set.hpp"
 #include "rigid_body.hpp"
+#include "unconstr_constraints.hpp"
 
 using namespace rtoc;
 
@@ -111,6 +112,8 @@ struct rtoc_ctx {
   bool has_cpos, has_crot;
   // rtoc_line_search_filter: filters [batch][CAP][2], sizes [batch], staging (cost, violation | mask, accepted)
   double* d_cost;      // rtoc_set_configuration_cost: 9 nv doubles
+  double* d_bounds;    // rtoc_set_constraint_bounds: [nrows]
+  double barrier, ftb_rule;
   double* d_x0;        // rtoc_set_initial_state: [batch][2 nv]
   double* d_filter;
   int* d_nfilter;
@@ -265,6 +268,7 @@ int rtoc_destroy(rtoc_ctx* c) {
   delete c->h_model;
   if (c->d_active) (void)hipFree(c->d_active);
   if (c->d_cost) (void)hipFree(c->d_cost);
+  if (c->d_bounds) (void)hipFree(c->d_bounds);
   if (c->d_x0) (void)hipFree(c->d_x0);
   if (c->d_filter) (void)hipFree(c->d_filter);
   if (c->d_nfilter) (void)hipFree(c->d_nfilter);
@@ -1400,6 +1404,55 @@ int rtoc_set_initial_state(rtoc_ctx* c, const double* x0, int count) {
   return RTOC_OK;
 }
 
+int rtoc_set_constraint_bounds(rtoc_ctx* c, const double* bounds, int nrows, double barrier_param, double fraction_to_boundary_rule) {
+  if (!c || !bounds || nrows != c->nrows || nrows <= 0) return RTOC_ERR_BAD_ARG;
+  if (!(barrier_param > 0.0) || !(fraction_to_boundary_rule > 0.0) || !(fraction_to_boundary_rule < 1.0)) return RTOC_ERR_BAD_ARG;  // constraints.cpp setters
+  HIP_TRY(hipSetDevice(c->device));
+  if (!c->d_bounds) HIP_TRY(hipMalloc((void**)&c->d_bounds, sizeof(double) * c->dims.nc_max));
+  HIP_TRY(hipMemcpyAsync(c->d_bounds, bounds, sizeof(double) * nrows, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->barrier = barrier_param;
+  c->ftb_rule = fraction_to_boundary_rule;
+  return RTOC_OK;
+}
+
+static int launch_ubox(rtoc_ctx* c, int mode) {
+  UboxArgs a;
+  a.sol = c->buf[RTOC_BUF_SOL];
+  a.kkt = c->buf[RTOC_BUF_KKT];
+  a.cdd = c->buf[RTOC_BUF_CDD];
+  a.con = c->buf[RTOC_BUF_CON];
+  a.dir = c->buf[RTOC_BUF_DIR];
+  a.rows = c->d_rows;
+  a.entry = c->d_entry;
+  a.bounds = c->d_bounds;
+  a.grid = c->d_grid;
+  a.steps = (unsigned long long*)c->buf[RTOC_BUF_STEP];
+  a.nstages = c->nstages, a.batch = c->batch, a.nrows = c->nrows, a.nv = c->dims.nv, a.mode = mode;
+  a.barrier = c->barrier, a.tau = c->ftb_rule;
+  a.sol_stride = c->L.sol.stride, a.kkt_stride = c->L.kkt.stride, a.cdd_stride = c->L.cdd.stride;
+  a.con_stride = c->L.con.stride, a.dir_stride = c->L.dir.stride;
+  a.o_q = c->L.sol.off[RTOC_SOL_Q], a.o_v = c->L.sol.off[RTOC_SOL_V], a.o_u = c->L.sol.off[RTOC_SOL_U];
+  a.o_qxx = c->L.kkt.off[RTOC_KKT_QXX], a.o_lx = c->L.kkt.off[RTOC_KKT_LX];
+  a.o_qaa = c->L.cdd.off[RTOC_CDD_QAA], a.o_la = c->L.cdd.off[RTOC_CDD_LA];
+  a.o_dx = c->L.dir.off[RTOC_DIR_DX], a.o_du = c->L.dir.off[RTOC_DIR_DU];
+  a.nl = c->L.con;
+  hipLaunchKernelGGL(unconstr_box_kernel, dim3(c->batch * (c->nstages - 1)), dim3(64), 0, c->stream, a);
+  HIP_TRY(hipGetLastError());
+  return RTOC_OK;
+}
+static bool ubox_on(const rtoc_ctx* c) { return c->nrows > 0 && c->d_bounds != nullptr; }
+
+// UnconstrOCPSolver::initConstraints (unconstr_ocp_solver.cpp:91-93): setSlackAndDual of every row at the current iterate
+int rtoc_unconstr_init_constraints(rtoc_ctx* c) {
+  CHECK_READY(c);
+  if (!ubox_on(c) || !c->buf[RTOC_BUF_SOL]) return RTOC_ERR_NOT_READY;
+  if (c->dims.nu != c->dims.nv || c->dims.nf_max != 0) return RTOC_ERR_BAD_ARG;
+  int rc = ensure_buffer(c, RTOC_BUF_CON);
+  if (rc) return rc;
+  return launch_ubox(c, UBOX_INIT);
+}
+
 int rtoc_unconstr_eval_kkt(rtoc_ctx* c, double dt) {
   CHECK_READY(c);
   if (!(dt > 0.0) || c->dims.nu != c->dims.nv || c->dims.nf_max != 0) return RTOC_ERR_BAD_ARG;
@@ -1433,7 +1486,9 @@ int rtoc_unconstr_eval_kkt(rtoc_ctx* c, double dt) {
   hipLaunchKernelGGL(rbd::unconstr_eval_kkt_kernel, dim3(c->batch * c->nstages), dim3(64), 0, c->stream, a);
   HIP_TRY(hipGetLastError());
   c->fxx_state = 0;
-  return launch_linearize(c, 1, true, dt);
+  rc = launch_linearize(c, 1, true, dt);
+  if (!rc && ubox_on(c)) rc = launch_ubox(c, UBOX_LINEARIZE);  // constraints_->linearizeConstraints (unconstr_intermediate_stage.cpp:68-69)
+  return rc;
 }
 
 // ---- KKT error ------------------------------------------------------------------------------
@@ -1483,18 +1538,24 @@ int rtoc_kkt_error(rtoc_ctx* c, double* host_out, int count) {
 int rtoc_unconstr_update_solution(rtoc_ctx* c, double dt, double* host_kkt_error, int count) {
   CHECK_READY(c);
   if (count < 0 || count > c->batch || (count > 0 && !host_kkt_error)) return RTOC_ERR_BAD_ARG;
+  const bool rows = ubox_on(c);
   int rc = rtoc_unconstr_eval_kkt(c, dt);            // dms_.evalKKT up to the condensation, + computeInitialStateDirection
   if (!rc) rc = launch_kkt_error(c);                  // performance_index.kkt_error (pre-condensation, like :74-75)
+  if (!rc && rows) rc = launch_ubox(c, UBOX_CONDENSE);  // constraints_->condenseSlackAndDual (:76-77), ahead of the dynamics
   if (!rc) rc = rtoc_unconstr_condense(c);
   if (!rc) rc = rtoc_unconstr_backward(c, dt);
   if (!rc) rc = rtoc_unconstr_forward(c, dt);
   if (!rc) rc = rtoc_unconstr_expand(c, dt);
   if (rc) return rc;
-  // no inequality constraints on this path: maxPrimalStepSize = maxDualStepSize = 1
   rc = ensure_buffer(c, RTOC_BUF_STEP);
   if (rc) return rc;
   hipLaunchKernelGGL(fill_steps_kernel, dim3((2 * c->batch + 255) / 256), dim3(256), 0, c->stream, c->buf[RTOC_BUF_STEP], 2 * c->batch);
   HIP_TRY(hipGetLastError());
+  if (rows) {
+    rc = launch_ubox(c, UBOX_EXPAND);                 // expandSlackAndDual + maxSlack/DualStepSize (:80-97)
+    if (!rc) rc = rtoc_update(c);                     // updateSlack / updateDual (:106-118)
+    if (rc) return rc;
+  }
   rc = rtoc_integrate_solution(c);
   if (rc) return rc;
   if (count > 0) {

@@ -6,8 +6,9 @@
 // updateSolution (:96-118) is left on the host here: for a fixed-base robot without contacts the cost
 // (ConfigurationSpaceCost), the state equation, the rigid-body linearisation, the condensation, the Riccati recursion,
 // the expansion and the solution update all run in rtoc_unconstr_update_solution (include/rtoc_robot.h).
-// What the reference's UnconstrOCP carries beyond that -- other cost components, joint-limit constraints, the line
-// search -- is not part of this path (std::logic_error if the line search is requested).
+// The six joint-limit components of the reference's examples run on the device too (unconstr_constraints.hpp).  What the
+// reference's OCP can carry beyond that -- other cost components, the line search -- is not part of this path
+// (std::logic_error if the line search is requested).
 #ifndef ROBOTOC_HIP_UNCONSTR_SOLVER_HPP_
 #define ROBOTOC_HIP_UNCONSTR_SOLVER_HPP_
 
@@ -27,6 +28,11 @@ struct UnconstrOCP {
   double T = 0.0;
   int N = 0;
   int device = 0;
+  // the joint-limit components of the reference's Constraints (Joint{Position,Velocity,Torques}{Lower,Upper}Limit): one
+  // rtoc_box_row + bound per row, g(z) = sign z - bound <= 0; empty = no inequality constraints
+  std::vector<rtoc_box_row> constraint_rows;
+  std::vector<double> constraint_bounds;
+  double barrier_param = 1.0e-03;  // ConstraintsBase default
 };
 
 class UnconstrOCPSolver {
@@ -37,13 +43,16 @@ class UnconstrOCPSolver {
     if (ocp.N <= 0) throw std::out_of_range("[UnconstrOCPSolver] invalid argument: N must be positive!");
     const int nv = ocp.robot.nv;
     dims_.dimv = nv, dims_.dimu = nv, dims_.dim_passive = 0, dims_.max_dimf = 0;
-    rtoc_dims d = {nv, nv, 0, 0, 0, 0};
+    if (ocp.constraint_rows.size() != ocp.constraint_bounds.size()) throw std::invalid_argument("[UnconstrOCPSolver] one bound per constraint row");
+    rtoc_dims d = {nv, nv, 0, 0, 0, static_cast<int>((ocp.constraint_rows.size() + 7) / 8 * 8)};
     rtoc_ctx* c = nullptr;
     check(rtoc_create(&d, ocp.N + 1, 1, ocp.device, &c), "rtoc_create");
     ctx_.reset(c, [](rtoc_ctx* p) { rtoc_destroy(p); });
     check(rtoc_get_layout(c, &L_), "rtoc_get_layout");
     check(rtoc_set_robot_model(c, &ocp.robot), "rtoc_set_robot_model");
     check(rtoc_set_configuration_cost(c, &ocp.cost), "rtoc_set_configuration_cost");
+    if (!ocp.constraint_rows.empty())
+      check(rtoc_set_constraint_rows(c, ocp.constraint_rows.data(), static_cast<int>(ocp.constraint_rows.size())), "rtoc_set_constraint_rows");
     s_.assign(ocp.N + 1, SplitSolution(dims_));
     setSolverOptions(solver_options);
     discretize(0.0);
@@ -54,6 +63,9 @@ class UnconstrOCPSolver {
     if (solver_options.enable_line_search)
       throw std::logic_error("[UnconstrOCPSolver] the line search is outside the accelerated path (off by default, solver_options.hpp:70)");
     solver_options_ = solver_options;
+    if (!ocp_.constraint_rows.empty())
+      check(rtoc_set_constraint_bounds(ctx_.get(), ocp_.constraint_bounds.data(), static_cast<int>(ocp_.constraint_bounds.size()),
+                                       ocp_.barrier_param, solver_options.fraction_to_boundary_rule), "rtoc_set_constraint_bounds");
   }
   // discretize (:85-88): N uniform intervals, no events
   void discretize(const double) {
@@ -67,7 +79,12 @@ class UnconstrOCPSolver {
     }
     check(rtoc_set_grid(ctx_.get(), g.data(), ocp_.N + 1), "rtoc_set_grid");
   }
-  void initConstraints() {}  // no inequality constraints on this path
+  // initConstraints (:91-93): setSlackAndDual of the joint-limit rows at the current iterate
+  void initConstraints() {
+    if (ocp_.constraint_rows.empty()) return;
+    if (!device_solution_valid_) uploadSolution();
+    check(rtoc_unconstr_init_constraints(ctx_.get()), "rtoc_unconstr_init_constraints");
+  }
 
   // updateSolution (:96-118)
   void updateSolution(const double, const Vec& q, const Vec& v) {
@@ -81,8 +98,10 @@ class UnconstrOCPSolver {
     check(rtoc_unconstr_update_solution(ctx_.get(), dt_, &err, 1), "rtoc_unconstr_update_solution");
     kkt_error_ = err;
     host_solution_valid_ = false;
-    solver_statistics_.primal_step_size.push_back(1.0);
-    solver_statistics_.dual_step_size.push_back(1.0);
+    double steps[2] = {1.0, 1.0};
+    if (!ocp_.constraint_rows.empty()) check(rtoc_download(ctx_.get(), RTOC_BUF_STEP, 0, steps, 2), "rtoc_download(RTOC_BUF_STEP)");
+    solver_statistics_.primal_step_size.push_back(steps[0]);
+    solver_statistics_.dual_step_size.push_back(steps[1]);
   }
 
   // solve (:121-160)

@@ -122,3 +122,106 @@ def test_unconstr_solver_iterations_converge_on_the_device(oracle):
     qT = np.array([S.f(sol[b, n - 1], "q")[:nv] for b in range(batch)])
     assert (np.abs(qT - cost["q_ref"]) < np.abs(x0[:, :nv] - cost["q_ref"]) + 1e-9).all()
     ctx.close()
+
+
+def _limits(nv, rows):
+    """bounds of the six joint-limit components in rtoc_box_row convention: g = sign z - bound"""
+    from robotoc_amd.types import VAR_Q, VAR_U, VAR_V
+    qmax, vmax, umax = 0.6, 1.5, 60.0
+    lim = {VAR_Q: qmax, VAR_V: vmax, VAR_U: umax}
+    return np.array([lim[r.var] for r in rows])  # symmetric limits: lower  -z - zmax <= 0, upper  z - zmax <= 0
+
+
+@pytest.mark.gpu
+def test_unconstr_solver_with_joint_limits_converges_to_the_barrier_problem(oracle):
+    """The reference's iiwa14 example has the six joint-limit components (examples/iiwa14/unconstr_ocp.cpp); here their whole
+    PDIPM life runs on the device.  The reference configuration is placed OUTSIDE the position limits: the optimum rides
+    the limit at a distance set by the barrier."""
+    from robotoc_amd.types import Dims, joint_limit_rows, VAR_Q
+    batch = 4
+    dims0, grids, meta = pr.config_iiwa14()
+    dims = Dims(dims0.nv, dims0.nu, 0, 0, 0, 48)
+    m = rm.load_named("iiwa14")
+    n, nv, dt = len(grids), m.nv, meta["dt"]
+    ctx = capi.Context(dims, n, batch, 0)
+    ctx.set_grid(grids)
+    ctx.set_robot_model(m)
+    rows = joint_limit_rows(dims)
+    ctx.set_constraint_rows(rows)
+    bounds = _limits(nv, rows)
+    barrier = 1.0e-3
+    ctx.set_constraint_bounds(bounds, barrier, 0.995)
+    rng = np.random.default_rng(8)
+    q_ref = rng.uniform(-0.5, 0.5, nv)
+    q_ref[1], q_ref[4] = 0.9, -0.85  # beyond the +-0.6 position limits
+    ctx.set_configuration_cost(q_ref, np.zeros(nv), np.zeros(nv), np.full(nv, 10.0), np.full(nv, 0.1), np.full(nv, 0.01), np.full(nv, 0.001),
+                               np.full(nv, 10.0), np.full(nv, 0.1))
+    x0 = np.concatenate([rng.uniform(-0.4, 0.4, (batch, nv)), np.zeros((batch, nv))], axis=1)
+    ctx.set_initial_state(x0)
+    L = ctx.L
+    S, K, C, N = Records(L, "sol"), Records(L, "kkt"), Records(L, "cdd"), Records(L, "con")
+    sol = S.zeros(batch, n)
+    S.f(sol, "q")[..., :nv] = x0[:, None, :nv]
+    ctx.upload(BUF_SOL, sol)
+    ctx.unconstr_init_constraints()
+    # ---- first linearisation: the rows' share against the restated reference lines (pdipm.hxx, joint_*_limit.cpp) ----
+    ctx.unconstr_eval_kkt(dt)
+    from robotoc_amd.types import BUF_CON
+    con = ctx.download_records(BUF_CON, "con")
+    kkt1, cdd1 = ctx.download_records(BUF_KKT, "kkt"), ctx.download_records(BUF_CDD, "cdd")
+    ctx2 = capi.Context(dims0, n, batch, 0)  # the same iterate without rows: the difference is the rows' gradient
+    ctx2.set_grid(grids)
+    ctx2.set_robot_model(m)
+    ctx2.set_configuration_cost(q_ref, np.zeros(nv), np.zeros(nv), np.full(nv, 10.0), np.full(nv, 0.1), np.full(nv, 0.01), np.full(nv, 0.001),
+                                np.full(nv, 10.0), np.full(nv, 0.1))
+    ctx2.set_initial_state(x0)
+    ctx2.upload(BUF_SOL, sol[..., :ctx2.L.sol.stride] if ctx2.L.sol.stride == L.sol.stride else sol)
+    ctx2.unconstr_eval_kkt(dt)
+    kkt0, cdd0 = ctx2.download_records(BUF_KKT, "kkt"), ctx2.download_records(BUF_CDD, "cdd")
+    K0, C0 = Records(ctx2.L, "kkt"), Records(ctx2.L, "cdd")
+    ctx2.close()
+    sb = np.sqrt(barrier)
+    for b in range(batch):
+        for i in range(n - 1):
+            dlx, dlu = np.zeros(2 * nv), np.zeros(nv)
+            for r, w in enumerate(rows):
+                if i < w.level:
+                    continue
+                z = (S.f(sol[b, i], "q")[:nv], S.f(sol[b, i], "v"), S.f(sol[b, i], "u"))[w.var][w.index]
+                g = w.sign * z - bounds[r]
+                slack = max(-g, sb)
+                dual = barrier / slack
+                assert abs(N.f(con[b, i], "slack")[r] - slack) < 1e-15 and abs(N.f(con[b, i], "dual")[r] - dual) < 1e-15
+                assert abs(N.f(con[b, i], "residual")[r] - (g + slack)) < 1e-15
+                assert abs(N.f(con[b, i], "cmpl")[r] - (slack * dual - barrier)) < 1e-15
+                if w.var == 2:
+                    dlu[w.index] += w.sign * dual
+                else:
+                    dlx[(nv if w.var == 1 else 0) + w.index] += w.sign * dual
+            assert np.allclose(K.f(kkt1[b, i], "lx") - K0.f(kkt0[b, i], "lx"), dlx, atol=1e-12)
+            assert np.allclose(C.f(cdd1[b, i], "la") - C0.f(cdd0[b, i], "la"), dlu, atol=1e-12)
+    # ---- the solver loop ----
+    hist = []
+    for it in range(40):
+        hist.append(ctx.unconstr_update_solution(dt))
+        if hist[-1].max() < 1e-9:
+            break
+    hist = np.array(hist)
+    print("KKT error per iteration (worst instance):", ["%.1e" % e for e in hist.max(axis=1)])
+    assert hist[-1].max() < 1e-8
+    assert (ctx.status() == 0).all()
+    sol = ctx.download_records(BUF_SOL, "sol")
+    con = ctx.download_records(BUF_CON, "con")
+    q, v, u = S.f(sol, "q")[..., :nv], S.f(sol, "v"), S.f(sol, "u")
+    # strictly inside on the grid points where the rows are active (position from stage 2, velocity from 1, never the terminal one)
+    assert np.abs(q[:, 2:n - 1]).max() < 0.6 and np.abs(v[:, 1:n - 1]).max() < 1.5 and np.abs(u[:, :n - 1]).max() < 60.0
+    assert q[:, n - 2, 1].min() > 0.55 and q[:, n - 2, 4].max() < -0.55   # and riding the position limits where the reference pulls outside
+    act = np.array([[i >= w.level for w in rows] for i in range(n - 1)])
+    sl, du = N.f(con, "slack")[:, :n - 1, :len(rows)], N.f(con, "dual")[:, :n - 1, :len(rows)]
+    assert (sl[:, act] > 0).all() and (du[:, act] > 0).all()
+    assert np.abs(sl[:, act] * du[:, act] - barrier).max() < 1e-8   # complementarity of the barrier problem
+    z = np.zeros(0)
+    worst = max(np.abs(oracle.rbd_eval(m, 0, q[b, i], v[b, i], S.f(sol[b, i], "a"), z, u[b, i], 0, z)).max() for b in range(batch) for i in range(n - 1))
+    assert worst < 1e-8
+    print("dynamics residual of the converged trajectory:", worst, " min slack:", sl[:, act].min())
+    ctx.close()
