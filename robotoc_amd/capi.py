@@ -60,6 +60,21 @@ def build(force=False):
     return so
 
 
+def build_plugin(nv, nu, ns, nw0=None, nw1=None, force=False):
+    """Kernel set of one more robot shape as robotoc_amd/librtoc_shape_<nv>_<nu>_<ns>.so (csrc/Makefile: plugin), picked up by
+    rtoc_create / rtoc_dims_supported at run time.  Wave counts of the tile-split backward variants default like the library's
+    own JIT (RTOC_SHAPE_JIT=1): 1 / 3 up to a 36-wide state, 4 / 4 (5 beyond 64) above."""
+    nx = 2 * nv
+    nw0 = nw0 if nw0 is not None else (1 if nx <= 36 else 4)
+    nw1 = nw1 if nw1 is not None else (3 if nx <= 36 else (5 if nx > 64 else 4))
+    so = os.path.join(_HERE, "librtoc_shape_%d_%d_%d.so" % (nv, nu, ns))
+    src_dir = os.path.join(_HERE, "csrc")
+    deps = [os.path.join(src_dir, f) for f in os.listdir(src_dir) if os.path.isfile(os.path.join(src_dir, f))]
+    if force or not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+        subprocess.check_call(["make", "-C", src_dir, "plugin", "SHAPE=%d:%d:%d:%d:%d" % (nv, nu, ns, nw0, nw1)], stdout=subprocess.DEVNULL)
+    return so
+
+
 def compiled_shapes():
     """(nv, nu, ns) of every robot shape in csrc/Makefile's SHAPES list."""
     import re

@@ -76,7 +76,9 @@ inline KernelSet make_set() {
   k.bwd[1] = riccati_backward_kernel<NV, NU, NS, NW1>;
   k.bwd_waves[1] = NW1;
   k.bwd_lds[1] = BwdCfg<NV, NU, NS, NW1>::LDS_BYTES;
-  if constexpr (2 * NV + 1 <= 64) {  // role-split kernel: matrix wave + vector wave per instance
+  // role-split kernel: matrix wave + vector wave per instance; needs the state in 4 tiles, the control Hessian and the
+  // three free-rider columns of the G product in one 16-column tile
+  if constexpr (2 * NV + 1 <= 64 && NU + 3 <= 16) {
     k.bwd[2] = riccati_backward_rs_kernel<NV, NU, NS>;
     k.bwd_waves[2] = 2;
     k.bwd_lds[2] = BwdCfg<NV, NU, NS, 2>::LDS_BYTES;

@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <string>
 #include <vector>
 
 #include "../../include/rtoc.h"
@@ -45,12 +46,65 @@ static const std::vector<KernelSet>& kernel_table() {
   return t;
 }
 
+// Shapes beyond the compiled-in table: librtoc_shape_<nv>_<nu>_<ns>.so next to this library (or in $RTOC_SHAPE_DIR),
+// built by `make -C robotoc_amd/csrc plugin SHAPE=nv:nu:ns:nw0:nw1`; with RTOC_SHAPE_JIT=1 rtoc_create builds it itself
+// (hipcc + the source directory this library was built from must be present; ~1 min, once).
+#include <mutex>
+static std::vector<KernelSet>& plugin_table() {
+  static std::vector<KernelSet> t;
+  return t;
+}
+static std::string library_dir() {
+  Dl_info info;
+  if (dladdr((const void*)&library_dir, &info) && info.dli_fname) {
+    std::string p(info.dli_fname);
+    const size_t k = p.find_last_of('/');
+    return k == std::string::npos ? std::string(".") : p.substr(0, k);
+  }
+  return ".";
+}
+static const KernelSet* load_plugin(const rtoc_dims* d) {
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
+  for (const auto& k : plugin_table())
+    if (k.nv == d->nv && k.nu == d->nu && k.ns == d->ns_max) return &k;
+  char name[96];
+  snprintf(name, sizeof name, "librtoc_shape_%d_%d_%d.so", d->nv, d->nu, d->ns_max);
+  std::vector<std::string> dirs;
+  if (const char* e = getenv("RTOC_SHAPE_DIR")) dirs.push_back(e);
+  dirs.push_back(library_dir());
+  void* h = nullptr;
+  for (const auto& dir : dirs)
+    if ((h = dlopen((dir + "/" + name).c_str(), RTLD_NOW | RTLD_LOCAL))) break;
+#ifdef RTOC_CSRC_DIR
+  const char* jit = getenv("RTOC_SHAPE_JIT");
+  if (!h && jit && jit[0] == '1') {
+    // tile-split wave counts by state dimension, like the compiled-in shapes: one / three waves up to 36, four beyond
+    const int nx = 2 * d->nv, nw0 = nx <= 36 ? 1 : 4, nw1 = nx <= 36 ? 3 : (nx > 64 ? 5 : 4);
+    char cmd[1024];
+    snprintf(cmd, sizeof cmd, "make -s -C '%s' plugin SHAPE=%d:%d:%d:%d:%d >/dev/null 2>&1", RTOC_CSRC_DIR, d->nv, d->nu, d->ns_max, nw0, nw1);
+    if (system(cmd) == 0) h = dlopen((std::string(RTOC_CSRC_DIR) + "/../" + name).c_str(), RTLD_NOW | RTLD_LOCAL);
+  }
+#endif
+  if (!h) return nullptr;
+  typedef int (*entry_t)(KernelSet*, size_t);
+  entry_t entry = (entry_t)dlsym(h, "rtoc_shape_plugin");
+  KernelSet k;
+  if (!entry || entry(&k, sizeof(KernelSet)) != 0 || k.nv != d->nv || k.nu != d->nu || k.ns != d->ns_max) {
+    dlclose(h);
+    return nullptr;
+  }
+  plugin_table().reserve(64);  // handed-out pointers stay valid
+  if (plugin_table().size() >= 64) return nullptr;
+  plugin_table().push_back(k);
+  return &plugin_table().back();
+}
+
 static const KernelSet* find_set(const rtoc_dims* d) {
+  if (d->nf_max != d->ns_max || d->np != d->nv - d->nu) return nullptr;
   for (const auto& k : kernel_table())
-    if (k.nv == d->nv && k.nu == d->nu && k.ns == d->ns_max && d->nf_max == d->ns_max &&
-        d->np == d->nv - d->nu)
-      return &k;
-  return nullptr;
+    if (k.nv == d->nv && k.nu == d->nu && k.ns == d->ns_max) return &k;
+  return load_plugin(d);
 }
 
 // ---- context --------------------------------------------------------------------------

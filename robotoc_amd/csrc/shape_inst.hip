@@ -15,3 +15,13 @@ KernelSet RTOC_SHAPE_FN() {
   return make_set<RTOC_SHAPE_NV, RTOC_SHAPE_NU, RTOC_SHAPE_NS, RTOC_SHAPE_NW0, RTOC_SHAPE_NW1>();
 }
 }  // namespace rtoc
+
+#ifdef RTOC_SHAPE_PLUGIN
+// Built on its own (make plugin SHAPE=nv:nu:ns:nw0:nw1 -> ../librtoc_shape_<nv>_<nu>_<ns>.so): the host runtime loads the
+// kernel set of a shape that is not in its compiled-in table through this one entry point (rtoc_capi.hip: load_plugin).
+extern "C" int rtoc_shape_plugin(rtoc::KernelSet* out, size_t size_of_kernel_set) {
+  if (!out || size_of_kernel_set != sizeof(rtoc::KernelSet)) return -1;  // built from another revision of kernel_set.hpp
+  *out = rtoc::RTOC_SHAPE_FN();
+  return 0;
+}
+#endif
