@@ -374,6 +374,34 @@ int rtoc_clone(rtoc_ctx* c, rtoc_ctx** out) {
     if (c->backward_scan) rc = rtoc_set_option(n, RTOC_OPT_BACKWARD_SCAN, c->backward_scan);
   }
   hipError_t e = hipStreamSynchronize(c->stream);
+  // the rigid-body model, contact schedule, cost, initial states, constraint bounds and line-search filters (rtoc_robot.h)
+  auto dup = [&](void** dst, const void* src, size_t bytes) {
+    if (!src || rc || e != hipSuccess) return;
+    e = hipMalloc(dst, bytes);
+    if (e == hipSuccess) e = hipMemcpyAsync(*dst, src, bytes, hipMemcpyDeviceToDevice, n->stream);
+  };
+  if (!rc && c->h_model) {
+    n->h_model = new (std::nothrow) rbd::DevModel(*c->h_model);
+    if (!n->h_model) rc = RTOC_ERR_HIP;
+    dup((void**)&n->d_model, c->d_model, sizeof(rbd::DevModel));
+    if (!rc && e == hipSuccess)
+      e = hipFuncSetAttribute((const void*)rbd::linearize_contact_dynamics_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)rbd::lin_lds_bytes(n->h_model->nlevels, n->h_model->m.njoints, n->h_model->m.ncontacts));
+  }
+  dup((void**)&n->d_active, c->d_active, sizeof(unsigned) * c->max_stages);
+  dup((void**)&n->d_cpos, c->d_cpos, sizeof(double) * c->max_stages * RTOC_MAX_CONTACTS * 3);
+  dup((void**)&n->d_crot, c->d_crot, sizeof(double) * c->max_stages * RTOC_MAX_CONTACTS * 9);
+  n->has_cpos = c->has_cpos, n->has_crot = c->has_crot;
+  dup((void**)&n->d_cost, c->d_cost, sizeof(double) * 9 * c->dims.nv);
+  dup((void**)&n->d_x0, c->d_x0, sizeof(double) * c->batch * 2 * c->dims.nv);
+  dup((void**)&n->d_bounds, c->d_bounds, sizeof(double) * c->dims.nc_max);
+  n->barrier = c->barrier, n->ftb_rule = c->ftb_rule;
+  if (c->d_filter) {
+    dup((void**)&n->d_filter, c->d_filter, sizeof(double) * 2 * RTOC_LINE_SEARCH_FILTER_CAPACITY * c->batch);
+    dup((void**)&n->d_nfilter, c->d_nfilter, sizeof(int) * c->batch);
+    dup((void**)&n->d_ls_in, c->d_ls_in, sizeof(double) * 2 * c->batch);
+    dup((void**)&n->d_ls_flags, c->d_ls_flags, sizeof(int) * 2 * c->batch);
+  }
   for (int b = 0; !rc && e == hipSuccess && b < RTOC_NUM_BUFFERS; ++b) {
     if (!c->buf[b]) continue;
     if (!n->buf[b]) {

@@ -58,6 +58,27 @@ class UnconstrOCPSolver {
     discretize(0.0);
   }
   UnconstrOCPSolver() {}
+  // value semantics like the reference (unconstr_ocp_solver.hpp:58-73): a copy owns a deep copy of the device context
+  // (rtoc_clone: buffers, model, cost, bounds, slack / dual state)
+  UnconstrOCPSolver(const UnconstrOCPSolver& o)
+      : ocp_(o.ocp_), dt_(o.dt_), dims_(o.dims_), L_(o.L_), s_(o.s_), lqr_policy_(o.lqr_policy_), solver_options_(o.solver_options_),
+        solver_statistics_(o.solver_statistics_), kkt_error_(o.kkt_error_), host_solution_valid_(o.host_solution_valid_),
+        device_solution_valid_(o.device_solution_valid_) {
+    if (o.ctx_) {
+      rtoc_ctx* c = nullptr;
+      check(rtoc_clone(o.ctx_.get(), &c), "rtoc_clone");
+      ctx_.reset(c, [](rtoc_ctx* p) { rtoc_destroy(p); });
+    }
+  }
+  UnconstrOCPSolver& operator=(const UnconstrOCPSolver& o) {
+    if (this != &o) {
+      UnconstrOCPSolver tmp(o);
+      *this = std::move(tmp);
+    }
+    return *this;
+  }
+  UnconstrOCPSolver(UnconstrOCPSolver&&) = default;
+  UnconstrOCPSolver& operator=(UnconstrOCPSolver&&) = default;
 
   void setSolverOptions(const SolverOptions& solver_options) {
     if (solver_options.enable_line_search)

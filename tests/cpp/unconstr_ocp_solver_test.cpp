@@ -31,7 +31,15 @@ int main(int argc, char** argv) {
     solver.setSolution("q", q);  // the reference examples' initial guess (examples/iiwa14/unconstr_ocp.cpp)
     solver.setSolution("v", v);
     const double e0 = solver.KKTError(0.0, q, v);
+    // value semantics: a copy taken now solves the same problem on its own device context, after the original has moved on
+    robotoc::UnconstrOCPSolver copy(solver);
     solver.solve(0.0, q, v, true);
+    copy.solve(0.0, q, v, true);
+    if (copy.getSolverStatistics().iter != solver.getSolverStatistics().iter || copy.KKTError() != solver.KKTError()) {
+      std::fprintf(stderr, "copy diverged from the original: %d vs %d iterations, %.3e vs %.3e\n", copy.getSolverStatistics().iter,
+                   solver.getSolverStatistics().iter, copy.KKTError(), solver.KKTError());
+      return 8;
+    }
     const robotoc::SolverStatistics& st = solver.getSolverStatistics();
     std::printf("KKT error %.3e -> %.3e in %d iterations, converged %d\n", e0, solver.KKTError(), st.iter, (int)st.convergence);
     // value semantics: a copy shares nothing it could corrupt and reports the same solution
