@@ -555,6 +555,44 @@ def main():
                                                             "algorithmic_flops_per_launch": fl},
                                                "bound": "hbm" if ab / (HBM_PEAK_GBS * 1e9) > fl / (F64_MFMA_PEAK_TFLOPS * 1e12)
                                                else "mfma"}})
+                    if name.startswith("icub") or name.startswith("anymal_jump"):
+                        # SQP iterations/s of this configuration (north_star names it for iCub too): one rtoc_newton_iteration
+                        # on distinct pre-condensation records with the joint-limit rows (no cones: the wrench-cone rows of
+                        # iCub are covered by tests/test_contact_wrench_cone.py, not timed here)
+                        from robotoc_amd.types import BUF_CDD, BUF_CON, joint_limit_rows
+                        rows2 = joint_limit_rows(d2)
+                        if len(rows2) <= d2.nc_max:
+                            c2.set_constraint_rows(rows2)
+                            kk = torch.zeros((b2, len(g2), L2.kkt.stride), dtype=torch.float64, device=dev)  # the generators fill fields, not padding
+                            cc = torch.zeros((b2, len(g2), L2.cdd.stride), dtype=torch.float64, device=dev)
+                            nn = torch.zeros((b2, len(g2), L2.con.stride), dtype=torch.float64, device=dev)
+                            flagged, seed2 = -1, 0
+                            # random stage data: a seed whose every instance stays positive definite through the iteration
+                            # (the kernels have no data-dependent branches; a flagged instance costs the same)
+                            for seed2 in (11, 12, 13, 14, 15):
+                                pr.make_precondense_batch_unique(L2, g2, b2, seed=seed2, backend="torch", device=dev, out=(kk, cc))
+                                pr.make_constraint_batch_unique(L2, g2, b2, seed=seed2, backend="torch", device=dev, out=nn)
+                                kw, cw, nw = kk.clone(), cc.clone(), nn.clone()
+                                for b_, t_ in ((BUF_KKT, kw), (BUF_CDD, cw), (BUF_CON, nw)):
+                                    c2.bind(b_, t_.data_ptr())
+                                torch.cuda.synchronize()
+                                c2.clear_status()
+                                c2.time_phase(6, 1)
+                                flagged = int((c2.status() != 0).sum())
+                                if flagged == 0:
+                                    break
+                            best = 1e9
+                            for rep in range(3):
+                                kw.copy_(kk), cw.copy_(cc), nw.copy_(nn)
+                                torch.cuda.synchronize()
+                                best = min(best, c2.time_phase(6, 1))
+                            entry["sqp_newton_iteration_ms"] = best
+                            entry["sqp_iters_per_sec"] = b2 / best * 1e3
+                            entry["sqp_data_seed"] = seed2
+                            entry["sqp_status_nonzero_instances"] = flagged
+                            c2.clear_status()
+                            c2.bind(BUF_KKT, k2.data_ptr())
+                            del kk, cc, nn, kw, cw, nw
                 entry["status_ok"] = entry.get("status_ok", True) and ok
                 c2.close()
                 del k2, x2
