@@ -179,7 +179,10 @@ __host__ __device__ constexpr size_t lin_lds_bytes(int nlevels, int njoints, int
                            njoints * JP + ncontacts * CP);
 }
 
-static __global__ __launch_bounds__(64) RTOC_RBD_WAVES void linearize_contact_dynamics_kernel(LinArgs a) {
+// SURF: the model has surface contacts (6 rows, Log6 of the placement error); compiled out for point-contact robots, where
+// its registers and branches cost 10 % of the kernel
+template <bool SURF>
+__global__ __launch_bounds__(64) RTOC_RBD_WAVES void linearize_contact_dynamics_kernel(LinArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x;
   const int item = blockIdx.x;
@@ -373,7 +376,7 @@ static __global__ __launch_bounds__(64) RTOC_RBD_WAVES void linearize_contact_dy
         int roff = 0;
         for (int c = 0; c < ncon; ++c) {
           const bool on = (active >> c) & 1u;
-          const bool surf = (int)scm[c * CP + 15] == RTOC_CONTACT_SURFACE;
+          const bool surf = SURF && (int)scm[c * CP + 15] == RTOC_CONTACT_SURFACE;
           const int nr = surf ? 6 : 3;
           if (on && (int)scm[c * CP + 14] == i) {
             const M3 Rf = ldm3(&scm[c * CP]);

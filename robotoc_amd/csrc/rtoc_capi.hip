@@ -107,6 +107,19 @@ static const KernelSet* find_set(const rtoc_dims* d) {
   return load_plugin(d);
 }
 
+static bool model_has_surface_contacts(const rtoc_robot_model& m) {
+  for (int k = 0; k < m.ncontacts; ++k)
+    if (m.contact_type[k] == RTOC_CONTACT_SURFACE) return true;
+  return false;
+}
+static hipError_t set_linearize_lds(const rtoc_robot_model& m, int nlevels) {
+  const int bytes = (int)rbd::lin_lds_bytes(nlevels, m.njoints, m.ncontacts);
+  hipError_t e = hipFuncSetAttribute((const void*)rbd::linearize_contact_dynamics_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute((const void*)rbd::linearize_contact_dynamics_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  return e;
+}
+
 // ---- context --------------------------------------------------------------------------
 #define RTOC_MAX_CHUNK_EVENTS 16
 struct rtoc_ctx {
@@ -385,8 +398,7 @@ int rtoc_clone(rtoc_ctx* c, rtoc_ctx** out) {
     if (!n->h_model) rc = RTOC_ERR_HIP;
     dup((void**)&n->d_model, c->d_model, sizeof(rbd::DevModel));
     if (!rc && e == hipSuccess)
-      e = hipFuncSetAttribute((const void*)rbd::linearize_contact_dynamics_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)rbd::lin_lds_bytes(n->h_model->nlevels, n->h_model->m.njoints, n->h_model->m.ncontacts));
+      e = set_linearize_lds(n->h_model->m, n->h_model->nlevels);
   }
   dup((void**)&n->d_active, c->d_active, sizeof(unsigned) * c->max_stages);
   dup((void**)&n->d_cpos, c->d_cpos, sizeof(double) * c->max_stages * RTOC_MAX_CONTACTS * 3);
@@ -1363,8 +1375,7 @@ int rtoc_set_robot_model(rtoc_ctx* c, const rtoc_robot_model* m) {
   c->h_model = h;
   HIP_TRY(hipMemcpyAsync(c->d_model, h, sizeof(rbd::DevModel), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
-  HIP_TRY(hipFuncSetAttribute((const void*)rbd::linearize_contact_dynamics_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)rbd::lin_lds_bytes(nlev, m->njoints, m->ncontacts)));
+  HIP_TRY(set_linearize_lds(*m, nlev));
   c->epoch++;
   return RTOC_OK;
 }
@@ -1445,8 +1456,11 @@ static int launch_linearize(rtoc_ctx* c, int augment_residual, bool unconstr, do
   a.unconstr = unconstr ? 1 : 0;
   a.scale = scale;
   if (c->nstages < 2) return RTOC_OK;
-  hipLaunchKernelGGL(rbd::linearize_contact_dynamics_kernel, dim3(c->batch * (c->nstages - 1)), dim3(64),
-                     rbd::lin_lds_bytes(c->h_model->nlevels, c->h_model->m.njoints, c->h_model->m.ncontacts), c->stream, a);
+  const size_t lds = rbd::lin_lds_bytes(c->h_model->nlevels, c->h_model->m.njoints, c->h_model->m.ncontacts);
+  if (model_has_surface_contacts(c->h_model->m))
+    hipLaunchKernelGGL(rbd::linearize_contact_dynamics_kernel<true>, dim3(c->batch * (c->nstages - 1)), dim3(64), lds, c->stream, a);
+  else
+    hipLaunchKernelGGL(rbd::linearize_contact_dynamics_kernel<false>, dim3(c->batch * (c->nstages - 1)), dim3(64), lds, c->stream, a);
   HIP_TRY(hipGetLastError());
   return RTOC_OK;
 }

@@ -4,6 +4,10 @@ import collections, csv, json, os, shutil, sys
 
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(R, "gpurun_out")
+# RTOC_PROFILE_OUT: write the summaries somewhere else than profiles/ (on the GPU box: into gpurun_out/summary, so that the raw
+# traces, which exceed what gpurun copies back, can be deleted there)
+DST = os.environ.get("RTOC_PROFILE_OUT", os.path.join(R, "profiles"))
+os.makedirs(DST, exist_ok=True)
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 note = sys.argv[2] if len(sys.argv) > 2 else ""
 lines = ["# rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline   (%s)" % note,
@@ -55,8 +59,8 @@ for d in ("prof_sq1/sq1", "prof_sq2/sq2"):
     for k, cs in acc.items():
         lines.append("%s: %s n=%d" % (k, ", ".join("%s=%.4g" % (c, sum(v) / len(v)) for c, v in cs.items()),
                                       len(next(iter(cs.values())))))
-open(os.path.join(R, "profiles", tag + "_rocprof_summary.txt"), "w").write("\n".join(lines) + "\n")
-json.dump(traffic, open(os.path.join(R, "profiles", tag + "_traffic.json"), "w"), indent=1)
-shutil.copy(os.path.join(OUT, "bench.json"), os.path.join(R, "profiles", tag + "_bench.json"))
-shutil.copy(os.path.join(OUT, "host.txt"), os.path.join(R, "profiles", tag + "_host.txt"))
+open(os.path.join(DST, tag + "_rocprof_summary.txt"), "w").write("\n".join(lines) + "\n")
+json.dump(traffic, open(os.path.join(DST, tag + "_traffic.json"), "w"), indent=1)
+shutil.copy(os.path.join(OUT, "bench.json"), os.path.join(DST, tag + "_bench.json"))
+shutil.copy(os.path.join(OUT, "host.txt"), os.path.join(DST, tag + "_host.txt"))
 print("\n".join(lines[:6])); print(json.dumps(traffic, indent=1))
