@@ -669,6 +669,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(kname) if batch == PER_GPU_BATCH else None,
+                         "traffic_source": "profiles/%s_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same kernels at the "
+                                           "same sizes (tools/gpu_pmc2.sh), committed with the round; not collected inside this run" % PROFILE_ROUND,
                          "measured_copy_GBs": copy_gbs, "frac_of_measured_copy": ach / copy_gbs,
                          "kernel": kname, "kernel_ms": ms_b,
                          "algorithmic_bytes_per_launch": bytes_b,
