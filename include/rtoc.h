@@ -290,8 +290,9 @@ int rtoc_line_search_clear(rtoc_ctx* ctx);
 /* SplitSolution::integrate (src/core/split_solution.cpp:58-90) on every grid point, as the
  * updatePrimal half of DirectMultipleShooting::integrateSolution (direct_multiple_shooting.cpp:212-241)
  * does after rtoc_expand: RTOC_BUF_SOL += primal step (RTOC_BUF_STEP) x RTOC_BUF_DIR for v, a (dv on
- * impact grids), u, lmd, gmm, beta, nu_passive, f, mu, xi and the joint part of q.  The floating-base
- * part of q (first 7 entries: the SE3 integrateConfiguration of Pinocchio) is left to the CPU side. */
+ * impact grids), u, lmd, gmm, beta, nu_passive, f, mu, xi, and q on the configuration manifold
+ * (Robot::integrateConfiguration): joints additively, the 7 entries [x y z qx qy qz qw] of a free-flyer base
+ * (dims.np == 6) by the SE(3) exponential of step x dq[0..5], quaternion re-normalised. */
 int rtoc_integrate_solution(rtoc_ctx* ctx);
 
 /* One Newton / SQP iteration of the whole batch as ONE launch sequence without host synchronisation

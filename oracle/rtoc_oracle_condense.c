@@ -950,9 +950,11 @@ double orc_kkt_error(const rtoc_layout* L, const rtoc_grid* grid, int nstages, c
 }
 
 /* ======================================================================================
- * SplitSolution::integrate (src/core/split_solution.cpp:58-90), Euclidean members; of q only the joint
- * part (the 7 floating-base entries need Pinocchio's integrateConfiguration).
+ * SplitSolution::integrate (src/core/split_solution.cpp:58-90): every member advanced by step x direction;
+ * q on the manifold (robot.integrateConfiguration, :62): joints additively, a free-flyer base by the SE(3)
+ * exponential (orc_se3_integrate, rtoc_oracle_rbd.c: pinocchio::integrate restated, parity unpinned).
  * ====================================================================================== */
+void orc_se3_integrate(const double* q7, const double* v6, double scale, double* out7);
 void orc_integrate_solution_stage(const rtoc_layout* L, const rtoc_grid* g, double step, const double* dir_rec,
                                   double* sol_rec) {
   const int nv = L->dims.nv, nu = L->dims.nu, np = L->dims.np;
@@ -964,6 +966,11 @@ void orc_integrate_solution_stage(const rtoc_layout* L, const rtoc_grid* g, doub
   const double* daf = dir_rec + dof[RTOC_DIR_DAF];
   const double* dbm = dir_rec + dof[RTOC_DIR_DBETAMU];
   const int nb = np == 6 ? 6 : 0;
+  if (nb && step != 0.0) { /* step 0: the iterate is kept as it is */
+    double q7[7];
+    orc_se3_integrate(sol_rec + so[RTOC_SOL_Q], dx, step, q7);
+    for (int i = 0; i < 7; ++i) sol_rec[so[RTOC_SOL_Q] + i] = q7[i];
+  }
   for (int i = 0; i < nv - nb; ++i) sol_rec[so[RTOC_SOL_Q] + (nb ? 7 : 0) + i] += step * dx[nb + i]; /* (:62) */
   for (int i = 0; i < nv; ++i) sol_rec[so[RTOC_SOL_V] + i] += step * dx[nv + i];                      /* (:63) */
   for (int i = 0; i < nv; ++i) sol_rec[so[RTOC_SOL_A] + i] += step * daf[i];                          /* (:65 / :71) */

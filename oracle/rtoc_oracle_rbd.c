@@ -227,6 +227,37 @@ static void rnea(const rtoc_robot_model* m, const rbd_kin* k, const double* grav
   }
 }
 
+/* pinocchio::integrate on a free-flyer: M <- M exp6(scale * v6), q7 = [x y z qx qy qz qw], v6 = [linear; angular] in the body
+ * frame: rotation exp(w), translation R V(w) v, V = I + (1-cos t)/t^2 [w]x + (t - sin t)/t^3 [w]x^2; the quaternion is
+ * re-normalised (Pinocchio: first-order normalisation, the same to rounding for a unit input) */
+void orc_se3_integrate(const double* q7, const double* v6, double scale, double* out7) {
+  double vl[3], w[3], R[9], Vv[3], wxv[3], wxwxv[3], t[3];
+  for (int c = 0; c < 3; ++c) vl[c] = scale * v6[c], w[c] = scale * v6[3 + c];
+  const double th = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+  double A, B;
+  if (th < 1e-8) {
+    A = 0.5, B = 1.0 / 6.0;
+  } else {
+    A = (1.0 - cos(th)) / (th * th), B = (th - sin(th)) / (th * th * th);
+  }
+  cross3(w, vl, wxv);
+  cross3(w, wxv, wxwxv);
+  for (int c = 0; c < 3; ++c) Vv[c] = vl[c] + A * wxv[c] + B * wxwxv[c];
+  quat_to_R(q7 + 3, R);
+  mat3_vec(R, Vv, t);
+  const double s = th < 1e-8 ? 0.5 - th * th / 48.0 : sin(0.5 * th) / th, cw = cos(0.5 * th);
+  const double e[4] = {s * w[0], s * w[1], s * w[2], cw};
+  const double a[4] = {q7[3], q7[4], q7[5], q7[6]};
+  double r[4];
+  r[0] = a[3] * e[0] + a[0] * e[3] + a[1] * e[2] - a[2] * e[1];
+  r[1] = a[3] * e[1] - a[0] * e[2] + a[1] * e[3] + a[2] * e[0];
+  r[2] = a[3] * e[2] + a[0] * e[1] - a[1] * e[0] + a[2] * e[3];
+  r[3] = a[3] * e[3] - a[0] * e[0] - a[1] * e[1] - a[2] * e[2];
+  const double n = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3]);
+  for (int c = 0; c < 3; ++c) out7[c] = q7[c] + t[c];
+  for (int c = 0; c < 4; ++c) out7[3 + c] = r[c] / n;
+}
+
 /* q (+) scale * dq */
 void orc_rbd_integrate(const rtoc_robot_model* m, const double* q, const double* dq, double scale, double* qout) {
   for (int i = 0; i < m->njoints; ++i) {
@@ -235,34 +266,7 @@ void orc_rbd_integrate(const rtoc_robot_model* m, const double* q, const double*
       qout[iq] = q[iq] + scale * dq[iv];
       continue;
     }
-    /* M <- M exp6(dq): rotation exp(w), translation V(w) v, V = I + (1-cos t)/t^2 [w]x + (t - sin t)/t^3 [w]x^2 */
-    double vl[3], w[3], R[9], E[9], Vv[3], wxv[3], wxwxv[3], t[3];
-    for (int c = 0; c < 3; ++c) vl[c] = scale * dq[iv + c], w[c] = scale * dq[iv + 3 + c];
-    const double th = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
-    double A, B;
-    if (th < 1e-8) {
-      A = 0.5, B = 1.0 / 6.0;
-    } else {
-      A = (1.0 - cos(th)) / (th * th), B = (th - sin(th)) / (th * th * th);
-    }
-    cross3(w, vl, wxv);
-    cross3(w, wxv, wxwxv);
-    for (int c = 0; c < 3; ++c) Vv[c] = vl[c] + A * wxv[c] + B * wxwxv[c];
-    quat_to_R(q + iq + 3, R);
-    mat3_vec(R, Vv, t);
-    for (int c = 0; c < 3; ++c) qout[iq + c] = q[iq + c] + t[c];
-    /* quaternion of exp(w): (sin(t/2)/t w, cos(t/2)) */
-    const double s = th < 1e-8 ? 0.5 - th * th / 48.0 : sin(0.5 * th) / th, cw = cos(0.5 * th);
-    const double e[4] = {s * w[0], s * w[1], s * w[2], cw};
-    const double* a = q + iq + 3;
-    double r[4];
-    r[0] = a[3] * e[0] + a[0] * e[3] + a[1] * e[2] - a[2] * e[1];
-    r[1] = a[3] * e[1] - a[0] * e[2] + a[1] * e[3] + a[2] * e[0];
-    r[2] = a[3] * e[2] + a[0] * e[1] - a[1] * e[0] + a[2] * e[3];
-    r[3] = a[3] * e[3] - a[0] * e[0] - a[1] * e[1] - a[2] * e[2];
-    const double n = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3]);
-    for (int c = 0; c < 4; ++c) qout[iq + 3 + c] = r[c] / n;
-    (void)E;
+    orc_se3_integrate(q + iq, dq + iv, scale, qout + iq);
   }
 }
 

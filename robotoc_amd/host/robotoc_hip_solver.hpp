@@ -20,8 +20,8 @@
 // DirectMultipleShooting and RiccatiRecursion members, so the stage data never leave HBM inside an iteration
 // and the host containers (getSolution, getLQRPolicy, getRiccatiFactorization) are filled on demand.
 // Not in the shell: the STO problem (SwitchingTimeOptimization, scalar), the line search (off by default,
-// solver_options.hpp:70) -- both raise std::logic_error if requested -- and the SE3 part of
-// integrateConfiguration (first 7 entries of q: Pinocchio).
+// solver_options.hpp:70) -- both raise std::logic_error if requested.
+// (rtoc_integrate_solution updates q on the manifold, free-flyer base included.)
 #ifndef ROBOTOC_HIP_SOLVER_HPP_
 #define ROBOTOC_HIP_SOLVER_HPP_
 

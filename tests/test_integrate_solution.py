@@ -16,7 +16,17 @@ def _data(L, grids, batch):
     sol[...] = rng.uniform(-1, 1, sol.shape)
     d[...] = rng.uniform(-1, 1, d.shape)
     steps = np.stack([rng.uniform(0.2, 1.0, batch), rng.uniform(0.2, 1.0, batch)], axis=1)
+    if L.dims.np == 6:  # a configuration on the manifold: unit quaternion of the free-flyer base
+        o = L.sol.off[0]
+        sol[..., o + 3:o + 7] /= np.linalg.norm(sol[..., o + 3:o + 7], axis=-1, keepdims=True)
     return sol, d, steps
+
+
+def _quat_R(q):
+    x, y, z, w = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
 
 
 def test_oracle_integrate_closed_form(oracle):
@@ -45,10 +55,21 @@ def test_oracle_integrate_closed_form(oracle):
             S.f(s_, "beta")[:] += a * D.f(d_, "dbetamu")[:nv]
             S.f(s_, "f")[:g.dimf] += a * D.f(d_, "daf")[nv:nv + g.dimf]
             S.f(s_, "mu")[:g.dimf] += a * D.f(d_, "dbetamu")[nv:nv + g.dimf]
-    base = sol[:, :, L.sol.off[0]:L.sol.off[0] + 7].copy()
+    o = L.sol.off[0]
+    base = sol[:, :, o:o + 7].copy()
     oracle.integrate_solution_batch(L, grids, steps, d, sol)
-    assert np.allclose(sol, ref, rtol=1e-15, atol=1e-15)
-    assert np.array_equal(sol[:, :, L.sol.off[0]:L.sol.off[0] + 7], base)  # floating-base part of q untouched
+    new_base = sol[:, :, o:o + 7].copy()
+    sol[:, :, o:o + 7] = base
+    assert np.allclose(sol, ref, rtol=1e-15, atol=1e-15)  # everything but the base
+    # the free-flyer base: M <- M exp6(step dq[:6]) as 4x4 matrices (the SE(3) exponential restated independently: scipy-free series)
+    for b in range(2):
+        for i in range(len(grids)):
+            xi = steps[b, 0] * D.f(d[b, i], "dx")[:6]
+            E, pe = oracle.rbd_exp6(xi)
+            R0 = _quat_R(base[b, i, 3:7])
+            assert np.abs(_quat_R(new_base[b, i, 3:7]) - R0 @ E).max() < 1e-14
+            assert np.abs(new_base[b, i, :3] - (base[b, i, :3] + R0 @ pe)).max() < 1e-14
+            assert abs(np.linalg.norm(new_base[b, i, 3:7]) - 1.0) < 1e-15
 
 
 @pytest.mark.gpu

@@ -33,6 +33,8 @@ def _context(batch):
         Records(L, "cdd").f(cdd[b], "IDC")[...] *= 1e-3
     rng = np.random.default_rng(5)
     sol = rng.uniform(-1, 1, (batch, len(grids), L.sol.stride))
+    o = L.sol.off[0]
+    sol[..., o + 3:o + 7] /= np.linalg.norm(sol[..., o + 3:o + 7], axis=-1, keepdims=True)  # q on the manifold
     for buf, arr in ((BUF_KKT, kkt), (BUF_CDD, cdd), (BUF_CON, pr.make_constraint_batch(L, grids, batch)),
                      (BUF_CONE, pr.make_cone_batch(L, grids, batch, MC)), (BUF_DX0, pr.make_dx0(L, batch)),
                      (BUF_SOL, sol)):
