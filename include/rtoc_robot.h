@@ -87,8 +87,18 @@ typedef struct rtoc_configuration_cost {
   double q_weight_terminal[RTOC_MAX_JOINTS], v_weight_terminal[RTOC_MAX_JOINTS];
 } rtoc_configuration_cost;
 int rtoc_set_configuration_cost(rtoc_ctx* ctx, const rtoc_configuration_cost* cost);
-/* (q, v) of UnconstrOCPSolver::updateSolution(t, q, v) for every instance: x0[batch][2 nv]. */
+/* (q, v) of OCPSolver / UnconstrOCPSolver::updateSolution(t, q, v) for every instance: x0[batch][nq + nv], nq = nv, or
+ * nv + 1 with a free-flyer base (dims.np == 6: [x y z qx qy qz qw, joints]). */
 int rtoc_set_initial_state(rtoc_ctx* ctx, const double* x0, int count);
+/* linearizeStateEquation (src/dynamics/state_equation.cpp:29-66) on intermediate / lift grids, linearizeImpactStateEquation
+ * (impact_state_equation.cpp:27-57) on impact grids, from RTOC_BUF_SOL (q, v, a | dv, lmd, gmm of the grid point, its
+ * successor and -- for Fqq_prev -- its predecessor; the initial state of rtoc_set_initial_state ahead of grid point 0):
+ * Fx and the top half of Fxx are written, the multiplier and STO terms are ADDED to lx, la (CDD.la), h, hv, ha, fx like
+ * the reference adds them to what the cost left there.  Floating base: the SE(3) difference and its Jacobians
+ * (Pinocchio's difference / dDifference restated: log6 and Jlog6 by forward mode), and RTOC_BUF_SE3 = {Fqq_inv,
+ * Fqq_prev_inv} as correctLinearizeStateEquation computes them -- rtoc_condense then applies the corrections.  With an
+ * initial state set: RTOC_BUF_DX0 = computeInitialStateDirection (state_equation.cpp:99-109). */
+int rtoc_linearize_state_equation(rtoc_ctx* ctx);
 /* UnconstrDirectMultipleShooting::evalKKT up to the condensation, on every grid point: kkt_matrix / kkt_residual zeroed,
  * quadratizeStageCost / TerminalCost of the cost above, linearizeUnconstrForwardEuler(+Terminal)
  * (src/dynamics/unconstr_state_equation.cpp:8-24), linearizeUnconstrDynamics (src/dynamics/unconstr_dynamics.cpp:52-64:

@@ -344,6 +344,8 @@ def _rbd():
         L.orc_rbd_eval_ex.restype = C.c_int
         L.orc_rbd_linearize_fd_ex.argtypes = [mp, C.c_int, dp, dp, dp, dp, dp, C.c_uint, dp, dp, C.c_double, dp, dp, dp, C.c_int]
         L.orc_rbd_log6.argtypes = [dp, dp, dp]
+        L.orc_se3_integrate.argtypes = [dp, dp, C.c_double, dp]
+        L.orc_se3_difference.argtypes = [dp, dp, dp]
         L.orc_rbd_exp6.argtypes = [dp, dp, dp]
         L.orc_rbd_linearize_fd.argtypes = [mp, C.c_int, dp, dp, dp, dp, dp, C.c_uint, dp, C.c_double, dp, dp, dp, C.c_int]
         L.orc_rbd_mass_matrix_world.argtypes = [mp, dp, dp]
@@ -438,3 +440,19 @@ def rbd_contact_placement(model, q, c):
     R, p = np.zeros(9), np.zeros(3)
     _rbd().orc_rbd_contact_placement(C.byref(model), _d(q), int(c), _d(R), _d(p))
     return R.reshape(3, 3), p
+
+
+def se3_integrate(q7, v6, scale=1.0):
+    """pinocchio::integrate on a free-flyer: M exp6(scale v6)"""
+    q7, v6 = _c(q7), _c(v6)
+    out = np.zeros(7)
+    _rbd().orc_se3_integrate(_d(q7), _d(v6), scale, _d(out))
+    return out
+
+
+def se3_difference(q0_7, qf_7):
+    """pinocchio::difference on a free-flyer: log6(M0^-1 Mf)"""
+    q0_7, qf_7 = _c(q0_7), _c(qf_7)
+    out = np.zeros(6)
+    _rbd().orc_se3_difference(_d(q0_7), _d(qf_7), _d(out))
+    return out

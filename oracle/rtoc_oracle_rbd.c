@@ -258,6 +258,19 @@ void orc_se3_integrate(const double* q7, const double* v6, double scale, double*
   for (int c = 0; c < 4; ++c) out7[3 + c] = r[c] / n;
 }
 
+/* pinocchio::difference on a free-flyer: log6(M0^-1 Mf), q7 = [x y z qx qy qz qw] */
+void orc_se3_difference(const double* q0_7, const double* qf_7, double* out6) {
+  double R0[9], Rf[9], R0t[9], Rx[9], d[3], px[3];
+  quat_to_R(q0_7 + 3, R0);
+  quat_to_R(qf_7 + 3, Rf);
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) R0t[3 * r + c] = R0[3 * c + r];
+  mat3_mul(R0t, Rf, Rx);
+  for (int c = 0; c < 3; ++c) d[c] = qf_7[c] - q0_7[c];
+  mat3_vec(R0t, d, px);
+  orc_rbd_log6(Rx, px, out6);
+}
+
 /* q (+) scale * dq */
 void orc_rbd_integrate(const rtoc_robot_model* m, const double* q, const double* dq, double scale, double* qout) {
   for (int i = 0; i < m->njoints; ++i) {

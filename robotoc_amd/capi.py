@@ -28,7 +28,7 @@ EXPORTS = [
     "rtoc_newton_iteration", "rtoc_converged_count", "rtoc_clone", "rtoc_check_fxx_structure", "rtoc_sto_eval_kkt", "rtoc_set_friction_cones", "rtoc_set_wrench_cones", "rtoc_wrench_cone_matrix", "rtoc_save_stage_dump", "rtoc_load_stage_dump", "rtoc_kkt_error", "rtoc_integrate_solution",
     "rtoc_set_robot_model", "rtoc_set_contact_schedule", "rtoc_linearize_contact_dynamics",
     "rtoc_line_search_filter", "rtoc_line_search_clear", "rtoc_set_configuration_cost", "rtoc_set_initial_state",
-    "rtoc_unconstr_eval_kkt", "rtoc_unconstr_update_solution", "rtoc_set_constraint_bounds", "rtoc_unconstr_init_constraints",
+    "rtoc_unconstr_eval_kkt", "rtoc_unconstr_update_solution", "rtoc_set_constraint_bounds", "rtoc_unconstr_init_constraints", "rtoc_linearize_state_equation",
 ]
 
 
@@ -112,7 +112,7 @@ def lib():
         for f in ("rtoc_condense", "rtoc_riccati_backward", "rtoc_riccati_forward", "rtoc_riccati_sweep", "rtoc_update",
                   "rtoc_correct_state_equation", "rtoc_correct_costate_direction",
                   "rtoc_compute_initial_state_direction", "rtoc_unconstr_condense", "rtoc_integrate_solution",
-                  "rtoc_clear_status", "rtoc_sync"):
+                  "rtoc_linearize_state_equation", "rtoc_clear_status", "rtoc_sync"):
             getattr(L, f).argtypes = [vp]
         L.rtoc_unconstr_backward.argtypes = [vp, C.c_double]
         L.rtoc_unconstr_forward.argtypes = [vp, C.c_double]
@@ -373,7 +373,7 @@ class Context:
 
     def set_initial_state(self, x0):
         x0 = np.ascontiguousarray(x0, dtype=np.float64)
-        assert x0.shape == (self.batch, 2 * self.dims.nv)
+        assert x0.shape == (self.batch, 2 * self.dims.nv + (1 if self.dims.np == 6 else 0))
         _chk(lib().rtoc_set_initial_state(self._h, _dp(x0), self.batch))
 
     def set_constraint_bounds(self, bounds, barrier_param=1.0e-3, fraction_to_boundary_rule=0.995):
@@ -382,6 +382,9 @@ class Context:
 
     def unconstr_init_constraints(self):
         _chk(lib().rtoc_unconstr_init_constraints(self._h))
+
+    def linearize_state_equation(self):
+        _chk(lib().rtoc_linearize_state_equation(self._h))
 
     def unconstr_eval_kkt(self, dt):
         _chk(lib().rtoc_unconstr_eval_kkt(self._h, dt))

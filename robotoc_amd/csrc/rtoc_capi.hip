@@ -15,6 +15,7 @@
 #include "kernel_set.hpp"
 #include "rigid_body.hpp"
 #include "unconstr_constraints.hpp"
+#include "state_equation_lin.hpp"
 
 using namespace rtoc;
 
@@ -405,7 +406,7 @@ int rtoc_clone(rtoc_ctx* c, rtoc_ctx** out) {
   dup((void**)&n->d_crot, c->d_crot, sizeof(double) * c->max_stages * RTOC_MAX_CONTACTS * 9);
   n->has_cpos = c->has_cpos, n->has_crot = c->has_crot;
   dup((void**)&n->d_cost, c->d_cost, sizeof(double) * 9 * c->dims.nv);
-  dup((void**)&n->d_x0, c->d_x0, sizeof(double) * c->batch * 2 * c->dims.nv);
+  dup((void**)&n->d_x0, c->d_x0, sizeof(double) * c->batch * (2 * c->dims.nv + (c->dims.np == 6 ? 1 : 0)));
   dup((void**)&n->d_bounds, c->d_bounds, sizeof(double) * c->dims.nc_max);
   n->barrier = c->barrier, n->ftb_rule = c->ftb_rule;
   if (c->d_filter) {
@@ -1493,10 +1494,42 @@ int rtoc_set_configuration_cost(rtoc_ctx* c, const rtoc_configuration_cost* cost
 int rtoc_set_initial_state(rtoc_ctx* c, const double* x0, int count) {
   if (!c || !x0 || count != c->batch) return RTOC_ERR_BAD_ARG;
   HIP_TRY(hipSetDevice(c->device));
-  const size_t n = (size_t)c->batch * 2 * c->dims.nv;
+  const int nq = c->dims.nv + (c->dims.np == 6 ? 1 : 0);  // a free-flyer base carries a quaternion
+  const size_t n = (size_t)c->batch * (nq + c->dims.nv);
   if (!c->d_x0) HIP_TRY(hipMalloc((void**)&c->d_x0, sizeof(double) * n));
   HIP_TRY(hipMemcpyAsync(c->d_x0, x0, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
+  return RTOC_OK;
+}
+
+// linearizeStateEquation / linearizeImpactStateEquation of every non-terminal grid point (state_equation_lin.hpp)
+int rtoc_linearize_state_equation(rtoc_ctx* c) {
+  CHECK_READY(c);
+  if (!c->buf[RTOC_BUF_SOL]) return RTOC_ERR_NOT_READY;
+  if (c->dims.np != 0 && c->dims.np != 6) return RTOC_ERR_BAD_ARG;
+  int rc = ensure_buffer(c, RTOC_BUF_KKT);
+  if (!rc) rc = ensure_buffer(c, RTOC_BUF_CDD);
+  if (!rc) rc = ensure_buffer(c, RTOC_BUF_DX0);
+  if (!rc && c->dims.np == 6) rc = ensure_buffer(c, RTOC_BUF_SE3);
+  if (rc) return rc;
+  SeLinArgs a;
+  a.sol = c->buf[RTOC_BUF_SOL];
+  a.x0 = c->d_x0;
+  a.kkt = c->buf[RTOC_BUF_KKT];
+  a.cdd = c->buf[RTOC_BUF_CDD];
+  a.se3 = c->dims.np == 6 ? c->buf[RTOC_BUF_SE3] : nullptr;
+  a.dx0 = c->d_x0 ? c->buf[RTOC_BUF_DX0] : nullptr;
+  a.grid = c->d_grid;
+  a.nstages = c->nstages, a.batch = c->batch, a.nv = c->dims.nv, a.floating = c->dims.np == 6;
+  a.sol_stride = c->L.sol.stride, a.kkt_stride = c->L.kkt.stride, a.cdd_stride = c->L.cdd.stride;
+  a.o_q = c->L.sol.off[RTOC_SOL_Q], a.o_v = c->L.sol.off[RTOC_SOL_V], a.o_a = c->L.sol.off[RTOC_SOL_A];
+  a.o_lmd = c->L.sol.off[RTOC_SOL_LMD], a.o_gmm = c->L.sol.off[RTOC_SOL_GMM];
+  a.o_fxx = c->L.kkt.off[RTOC_KKT_FXX], a.o_fx = c->L.kkt.off[RTOC_KKT_FX], a.o_lx = c->L.kkt.off[RTOC_KKT_LX];
+  a.o_hx = c->L.kkt.off[RTOC_KKT_HX], a.o_ffx = c->L.kkt.off[RTOC_KKT_FFX], a.o_scal = c->L.kkt.off[RTOC_KKT_SCAL];
+  a.o_la = c->L.cdd.off[RTOC_CDD_LA], a.o_ha = c->L.cdd.off[RTOC_CDD_HA];
+  hipLaunchKernelGGL(state_equation_lin_kernel, dim3(c->batch * (c->nstages - 1)), dim3(64), 0, c->stream, a);
+  HIP_TRY(hipGetLastError());
+  c->fxx_state = 0;
   return RTOC_OK;
 }
 
