@@ -78,13 +78,30 @@ int rtoc_set_contact_schedule(rtoc_ctx* ctx, const unsigned* active, const doubl
  * lq / lv / lu in RTOC_BUF_KKT, la / lf / lu_passive in RTOC_BUF_CDD. */
 int rtoc_linearize_contact_dynamics(rtoc_ctx* ctx, int augment_residual);
 
+/* ---- evalKKT of the contact path on the device (no inequality rows, no switching constraints) ----
+ * {Intermediate,Impact,Terminal}Stage::evalKKT up to the condensation (src/ocp/intermediate_stage.cpp:94-132,
+ * impact_stage.cpp:82-114, terminal_stage.cpp:72-100) for an OCP whose cost is the ConfigurationSpaceCost of
+ * rtoc_set_configuration_cost: setZero, quadratize{Stage,Impact,Terminal}Cost, linearize{,Impact,Terminal}StateEquation
+ * (rtoc_linearize_state_equation), linearizeContactDynamics / linearizeImpactDynamics with the multiplier terms
+ * (rtoc_linearize_contact_dynamics(ctx, 1)) -- RTOC_BUF_SOL in, the pre-condensation records RTOC_BUF_KKT / RTOC_BUF_CDD,
+ * RTOC_BUF_SE3 and RTOC_BUF_DX0 out; rtoc_newton_iteration takes it from there.  Needs rtoc_set_robot_model,
+ * rtoc_set_contact_schedule, rtoc_set_configuration_cost, rtoc_set_initial_state.  RTOC_ERR_BAD_ARG on grids with a
+ * switching constraint (its linearisation is not on the device). */
+int rtoc_contact_eval_kkt(rtoc_ctx* ctx);
+/* OCPSolver::updateSolution (src/solver/ocp_solver.cpp:111-145) for that OCP, one launch sequence: rtoc_contact_eval_kkt,
+ * then rtoc_newton_iteration(ctx, 0, fraction_to_boundary_rule).  host_kkt_error[count <= batch] (may be NULL / 0): the KKT
+ * error of the iterate it linearised at. */
+int rtoc_contact_update_solution(rtoc_ctx* ctx, double fraction_to_boundary_rule, double* host_kkt_error, int count);
+
 /* ---- the unconstrained solver iteration closed on the device (BASELINE configuration 1: fixed base, no contacts) ----
- * ConfigurationSpaceCost of a fixed-base robot (src/cost/configuration_space_cost.cpp:274-378): diagonal weights,
- * Euclidean q - q_ref; weights must be non-negative. */
+ * ConfigurationSpaceCost (src/cost/configuration_space_cost.cpp:274-470): diagonal weights on q - q_ref (on the manifold:
+ * q_ref has nq entries, the first 7 a free-flyer placement if dims.np == 6; weights nv entries, the first 6 on the base's
+ * log6 difference), v - v_ref, a, u - u_ref, the terminal and the impact weights; all weights non-negative. */
 typedef struct rtoc_configuration_cost {
   double q_ref[RTOC_MAX_JOINTS], v_ref[RTOC_MAX_JOINTS], u_ref[RTOC_MAX_JOINTS];
   double q_weight[RTOC_MAX_JOINTS], v_weight[RTOC_MAX_JOINTS], a_weight[RTOC_MAX_JOINTS], u_weight[RTOC_MAX_JOINTS];
   double q_weight_terminal[RTOC_MAX_JOINTS], v_weight_terminal[RTOC_MAX_JOINTS];
+  double q_weight_impact[RTOC_MAX_JOINTS], v_weight_impact[RTOC_MAX_JOINTS], dv_weight_impact[RTOC_MAX_JOINTS];
 } rtoc_configuration_cost;
 int rtoc_set_configuration_cost(rtoc_ctx* ctx, const rtoc_configuration_cost* cost);
 /* (q, v) of OCPSolver / UnconstrOCPSolver::updateSolution(t, q, v) for every instance: x0[batch][nq + nv], nq = nv, or

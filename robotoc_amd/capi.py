@@ -28,7 +28,7 @@ EXPORTS = [
     "rtoc_newton_iteration", "rtoc_converged_count", "rtoc_clone", "rtoc_check_fxx_structure", "rtoc_sto_eval_kkt", "rtoc_set_friction_cones", "rtoc_set_wrench_cones", "rtoc_wrench_cone_matrix", "rtoc_save_stage_dump", "rtoc_load_stage_dump", "rtoc_kkt_error", "rtoc_integrate_solution",
     "rtoc_set_robot_model", "rtoc_set_contact_schedule", "rtoc_linearize_contact_dynamics",
     "rtoc_line_search_filter", "rtoc_line_search_clear", "rtoc_set_configuration_cost", "rtoc_set_initial_state",
-    "rtoc_unconstr_eval_kkt", "rtoc_unconstr_update_solution", "rtoc_set_constraint_bounds", "rtoc_unconstr_init_constraints", "rtoc_linearize_state_equation",
+    "rtoc_unconstr_eval_kkt", "rtoc_unconstr_update_solution", "rtoc_set_constraint_bounds", "rtoc_unconstr_init_constraints", "rtoc_linearize_state_equation", "rtoc_contact_eval_kkt", "rtoc_contact_update_solution",
 ]
 
 
@@ -112,7 +112,7 @@ def lib():
         for f in ("rtoc_condense", "rtoc_riccati_backward", "rtoc_riccati_forward", "rtoc_riccati_sweep", "rtoc_update",
                   "rtoc_correct_state_equation", "rtoc_correct_costate_direction",
                   "rtoc_compute_initial_state_direction", "rtoc_unconstr_condense", "rtoc_integrate_solution",
-                  "rtoc_linearize_state_equation", "rtoc_clear_status", "rtoc_sync"):
+                  "rtoc_linearize_state_equation", "rtoc_contact_eval_kkt", "rtoc_clear_status", "rtoc_sync"):
             getattr(L, f).argtypes = [vp]
         L.rtoc_unconstr_backward.argtypes = [vp, C.c_double]
         L.rtoc_unconstr_forward.argtypes = [vp, C.c_double]
@@ -139,6 +139,7 @@ def lib():
         L.rtoc_set_constraint_bounds.argtypes = [vp, dp, C.c_int, C.c_double, C.c_double]
         L.rtoc_unconstr_init_constraints.argtypes = [vp]
         L.rtoc_unconstr_update_solution.argtypes = [vp, C.c_double, dp, C.c_int]
+        L.rtoc_contact_update_solution.argtypes = [vp, C.c_double, dp, C.c_int]
         L.rtoc_line_search_filter.argtypes = [vp, dp, dp, C.POINTER(C.c_int), C.c_int, C.c_double, C.c_double, C.POINTER(C.c_int)]
         L.rtoc_line_search_clear.argtypes = [vp]
         L.rtoc_linearize_contact_dynamics.argtypes = [vp, C.c_int]
@@ -362,14 +363,28 @@ class Context:
         _chk(lib().rtoc_set_contact_schedule(self._h, act.ctypes.data_as(C.POINTER(C.c_uint)), _dp(pos) if pos is not None else None,
                                              _dp(rot) if rot is not None else None))
 
-    def set_configuration_cost(self, q_ref, v_ref, u_ref, q_weight, v_weight, a_weight, u_weight, q_weight_terminal, v_weight_terminal):
-        """rtoc_set_configuration_cost (ConfigurationSpaceCost of a fixed-base robot)"""
+    def set_configuration_cost(self, q_ref, v_ref, u_ref, q_weight, v_weight, a_weight, u_weight, q_weight_terminal, v_weight_terminal,
+                               q_weight_impact=None, v_weight_impact=None, dv_weight_impact=None):
+        """rtoc_set_configuration_cost (ConfigurationSpaceCost; q_ref on the manifold: nq entries)"""
         from .robot_model import MAX_JOINTS
-        arr = np.zeros((9, MAX_JOINTS))
-        for k, v in enumerate((q_ref, v_ref, u_ref, q_weight, v_weight, a_weight, u_weight, q_weight_terminal, v_weight_terminal)):
+        arr = np.zeros((12, MAX_JOINTS))
+        z = np.zeros(self.dims.nv)
+        vals = (q_ref, v_ref, u_ref, q_weight, v_weight, a_weight, u_weight, q_weight_terminal, v_weight_terminal,
+                z if q_weight_impact is None else q_weight_impact, z if v_weight_impact is None else v_weight_impact,
+                z if dv_weight_impact is None else dv_weight_impact)
+        for k, v in enumerate(vals):
             v = np.asarray(v, dtype=np.float64)
             arr[k, :v.size] = v
         _chk(lib().rtoc_set_configuration_cost(self._h, arr.ctypes.data_as(C.c_void_p)))
+
+    def contact_eval_kkt(self):
+        _chk(lib().rtoc_contact_eval_kkt(self._h))
+
+    def contact_update_solution(self, fraction_to_boundary_rule=0.995, want_kkt_error=True):
+        out = np.zeros(self.batch) if want_kkt_error else None
+        _chk(lib().rtoc_contact_update_solution(self._h, fraction_to_boundary_rule, _dp(out) if want_kkt_error else None,
+                                                self.batch if want_kkt_error else 0))
+        return out
 
     def set_initial_state(self, x0):
         x0 = np.ascontiguousarray(x0, dtype=np.float64)

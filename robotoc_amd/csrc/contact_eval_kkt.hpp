@@ -1,0 +1,133 @@
+// contact_eval_kkt.hpp -- the cost part of {Intermediate,Impact,Terminal}Stage::evalKKT on the device, for the contact path.
+//
+// kkt_matrix.setZero() / kkt_residual.setZero() (reference src/ocp/intermediate_stage.cpp:100-103) and
+// cost_->quadratizeStageCost / ImpactCost / TerminalCost for a ConfigurationSpaceCost
+// (src/cost/configuration_space_cost.cpp:274-324 stage, :381-470 impact, :343-378 terminal): diagonal weights on
+// q - q_ref, v - v_ref, a, u - u_ref (dv on impact grids), with q - q_ref on the configuration manifold:
+//   qdiff = log6(M_ref^-1 M) for a free-flyer base (Robot::subtractConfiguration(q, q_ref)), joints Euclidean
+//   lq += dt J^T W qdiff,  Qqq += dt J^T W J,  J = Jlog6(M_ref^-1 M) (dSubtractConfiguration_dqf; forward mode through the log)
+// The state equation (state_equation_lin.hpp) and the contact dynamics (rigid_body.hpp) then ADD their terms, in the order
+// of the reference.  Records: the un-condensed contact-path convention (Qaa / la / lf ... in RTOC_BUF_CDD).
+// cost table (device): 12 arrays of M = nv + 1 doubles: q_ref | v_ref | u_ref | wq | wv | wa | wu | wq_T | wv_T | wq_I | wv_I | wdv_I
+#pragma once
+#include "state_equation_lin.hpp"
+
+namespace rtoc {
+
+struct CostArgs {
+  const double* sol;
+  const double* cost;
+  double* kkt;
+  double* cdd;
+  const rtoc_grid* grid;
+  int nstages, batch, nv, nu, nf_max, ns_max, floating;
+  int sol_stride, kkt_stride, cdd_stride;
+  int o_q, o_v, o_a, o_u;
+  rtoc_record_layout kl, cl;
+};
+
+static __global__ __launch_bounds__(64) void contact_cost_kernel(CostArgs a) {
+  using namespace selin;
+  __shared__ double J[36], wd[6];
+  const int lane = threadIdx.x;
+  const int b = blockIdx.x / a.nstages, st = blockIdx.x % a.nstages;
+  if (b >= a.batch) return;
+  const rtoc_grid g = a.grid[st];
+  const bool impact = g.type == RTOC_GRID_IMPACT, terminal = st == a.nstages - 1;
+  const int nv = a.nv, nu = a.nu, nx = 2 * nv, nb = a.floating ? 6 : 0, M = nv + 1, np = nv - nu;
+  const size_t rec = (size_t)b * a.nstages + st;
+  const double* const s = a.sol + rec * a.sol_stride;
+  double* const kr = a.kkt + rec * a.kkt_stride;
+  double* const cr = a.cdd + rec * a.cdd_stride;
+  const double *qr = a.cost, *vr = qr + M, *ur = vr + M, *wq = ur + M, *wv = wq + M, *wa = wv + M, *wu = wa + M, *wqT = wu + M,
+               *wvT = wqT + M, *wqI = wvT + M, *wvI = wqI + M, *wdvI = wvI + M;
+  const double scale = (impact || terminal) ? 1.0 : g.dt;
+  const double* const Wq = terminal ? wqT : impact ? wqI : wq;
+  const double* const Wv = terminal ? wvT : impact ? wvI : wv;
+  // ---- setZero of everything the stages below accumulate into ----
+  auto zero = [&](double* p, int n) {
+    for (int e = lane; e < n; e += 64) p[e] = 0.0;
+  };
+  zero(kr + a.kl.off[RTOC_KKT_FXX], nx * nx);
+  zero(kr + a.kl.off[RTOC_KKT_QXX], nx * nx);
+  zero(kr + a.kl.off[RTOC_KKT_QXU], nx * nu);
+  zero(kr + a.kl.off[RTOC_KKT_QUU], nu * nu);
+  zero(kr + a.kl.off[RTOC_KKT_FX], nx);
+  zero(kr + a.kl.off[RTOC_KKT_LX], nx);
+  zero(kr + a.kl.off[RTOC_KKT_LU], nu);
+  zero(kr + a.kl.off[RTOC_KKT_FFX], nx);
+  zero(kr + a.kl.off[RTOC_KKT_HX], nx);
+  zero(kr + a.kl.off[RTOC_KKT_HU], nu);
+  zero(kr + a.kl.off[RTOC_KKT_SCAL], 8);
+  if (a.ns_max > 0) {
+    zero(kr + a.kl.off[RTOC_KKT_PHIX], a.ns_max * nx);
+    zero(kr + a.kl.off[RTOC_KKT_PHIU], a.ns_max * nu);
+    zero(kr + a.kl.off[RTOC_KKT_PHIT], a.ns_max);
+    zero(kr + a.kl.off[RTOC_KKT_PRES], a.ns_max);
+    zero(cr + a.cl.off[RTOC_CDD_PHIA], a.ns_max * nv);
+  }
+  zero(cr + a.cl.off[RTOC_CDD_QAA], nv);
+  zero(cr + a.cl.off[RTOC_CDD_LA], nv);
+  zero(cr + a.cl.off[RTOC_CDD_HA], nv);
+  zero(cr + a.cl.off[RTOC_CDD_LUP], 8);
+  if (a.nf_max > 0) {
+    zero(cr + a.cl.off[RTOC_CDD_QFF], a.nf_max * a.nf_max);
+    zero(cr + a.cl.off[RTOC_CDD_QQF], nv * a.nf_max);
+    zero(cr + a.cl.off[RTOC_CDD_LF], a.nf_max);
+    zero(cr + a.cl.off[RTOC_CDD_HF], a.nf_max);
+  }
+  __syncthreads();
+  const double *q = s + a.o_q, *v = s + a.o_v, *acc = s + a.o_a, *u = s + a.o_u;
+  double* const Qxx = kr + a.kl.off[RTOC_KKT_QXX];
+  double* const lx = kr + a.kl.off[RTOC_KKT_LX];
+  // ---- joints of q, v, a, u ----
+  for (int i = lane; i < nv; i += 64) {
+    if (i >= nb) {
+      lx[i] = scale * Wq[i] * (q[(nb ? 1 : 0) + i] - qr[(nb ? 1 : 0) + i]);
+      Qxx[i + (size_t)i * nx] = scale * Wq[i];
+    }
+    lx[nv + i] = scale * Wv[i] * (v[i] - vr[i]);
+    Qxx[(nv + i) + (size_t)(nv + i) * nx] = scale * Wv[i];
+    if (!terminal) {
+      const double w = impact ? wdvI[i] : scale * wa[i];   // a on contact grids, dv on impact grids (both in the A slot)
+      cr[a.cl.off[RTOC_CDD_LA] + i] = w * acc[i];
+      cr[a.cl.off[RTOC_CDD_QAA] + i] = w;
+    }
+  }
+  if (!terminal && !impact)
+    for (int i = lane; i < nu; i += 64) {
+      kr[a.kl.off[RTOC_KKT_LU] + i] = scale * wu[i] * (u[i] - ur[i]);
+      kr[a.kl.off[RTOC_KKT_QUU] + i + (size_t)i * nu] = scale * wu[i];
+    }
+  (void)np;
+  // ---- the free-flyer base of q: qdiff = log6(M_ref^-1 M), J = Jlog6 ----
+  if (a.floating) {
+    M3 Rx;
+    V3 px;
+    rel(quat_R(qr + 3), rbd::ldv3(qr), quat_R(q + 3), rbd::ldv3(q), Rx, px);
+    if (lane < 6) {
+      SV val, der;
+      rbd::log6_fwd(Rx, px, unit_twist(lane), val, der);
+      const double c[6] = {der.l.x, der.l.y, der.l.z, der.a.x, der.a.y, der.a.z}, d[6] = {val.l.x, val.l.y, val.l.z, val.a.x, val.a.y, val.a.z};
+#pragma unroll
+      for (int r = 0; r < 6; ++r) J[r + 6 * lane] = c[r];
+      wd[lane] = Wq[lane] * d[lane];
+    }
+    __syncthreads();
+    if (lane < 36) {
+      const int r = lane % 6, c = lane / 6;
+      double t = 0.0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) t += J[k + 6 * r] * Wq[k] * J[k + 6 * c];
+      Qxx[r + (size_t)c * nx] = scale * t;
+    }
+    if (lane < 6) {
+      double t = 0.0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) t += J[k + 6 * lane] * wd[k];
+      lx[lane] = scale * t;
+    }
+  }
+}
+
+}  // namespace rtoc

@@ -504,7 +504,8 @@ __global__ __launch_bounds__(64) RTOC_RBD_WAVES void linearize_contact_dynamics_
 // diagonal weights, q - q_ref Euclidean) and linearizeUnconstrForwardEuler (src/dynamics/unconstr_state_equation.cpp:8-24,
 // 56-62).  rtoc_linearize in unconstrained mode then adds the dynamics terms.  Records in the convention of
 // rtoc_unconstr_condense: KKT.Quu := Qaa, KKT.lu := la, CDD.Qaa := diag(Quu), CDD.la := lu.
-// cost: [q_ref | v_ref | u_ref | wq | wv | wa | wu | wq_terminal | wv_terminal], nv doubles each.
+// cost: [q_ref | v_ref | u_ref | wq | wv | wa | wu | wq_terminal | wv_terminal | impact weights x 3], nv + 1 doubles each
+// (the table of contact_eval_kkt.hpp).
 struct UkArgs {
   const double* sol;
   double* kkt;
@@ -531,8 +532,9 @@ static __global__ __launch_bounds__(64) void unconstr_eval_kkt_kernel(UkArgs a) 
   const double* const sn = s + a.sol_stride;  // next grid point (not read on the terminal one)
   double* const kr = a.kkt + rec * a.kkt_stride;
   double* const cr = a.cdd + rec * a.cdd_stride;
-  const double *qr = a.cost, *vr = qr + nv, *ur = vr + nv, *wq = ur + nv, *wv = wq + nv, *wa = wv + nv, *wu = wa + nv,
-               *wqf = wu + nv, *wvf = wqf + nv;
+  const int M = nv + 1;
+  const double *qr = a.cost, *vr = qr + M, *ur = vr + M, *wq = ur + M, *wv = wq + M, *wa = wv + M, *wu = wa + M,
+               *wqf = wu + M, *wvf = wqf + M;
   const double dt = a.dt;
   // Hessian blocks: zero, then the diagonals (Qqq, Qvv; Qaa in the Quu slot)
   for (int e = lane; e < nx * nx; e += 64) {

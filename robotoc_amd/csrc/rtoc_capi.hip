@@ -16,6 +16,7 @@
 #include "rigid_body.hpp"
 #include "unconstr_constraints.hpp"
 #include "state_equation_lin.hpp"
+#include "contact_eval_kkt.hpp"
 
 using namespace rtoc;
 
@@ -405,7 +406,7 @@ int rtoc_clone(rtoc_ctx* c, rtoc_ctx** out) {
   dup((void**)&n->d_cpos, c->d_cpos, sizeof(double) * c->max_stages * RTOC_MAX_CONTACTS * 3);
   dup((void**)&n->d_crot, c->d_crot, sizeof(double) * c->max_stages * RTOC_MAX_CONTACTS * 9);
   n->has_cpos = c->has_cpos, n->has_crot = c->has_crot;
-  dup((void**)&n->d_cost, c->d_cost, sizeof(double) * 9 * c->dims.nv);
+  dup((void**)&n->d_cost, c->d_cost, sizeof(double) * 12 * (c->dims.nv + 1));
   dup((void**)&n->d_x0, c->d_x0, sizeof(double) * c->batch * (2 * c->dims.nv + (c->dims.np == 6 ? 1 : 0)));
   dup((void**)&n->d_bounds, c->d_bounds, sizeof(double) * c->dims.nc_max);
   n->barrier = c->barrier, n->ftb_rule = c->ftb_rule;
@@ -1474,19 +1475,22 @@ int rtoc_linearize_contact_dynamics(rtoc_ctx* c, int augment_residual) {
 // ---- the unconstrained (fixed-base, contact-free) solver iteration closed on the device -------
 int rtoc_set_configuration_cost(rtoc_ctx* c, const rtoc_configuration_cost* cost) {
   if (!c || !cost) return RTOC_ERR_BAD_ARG;
-  const int nv = c->dims.nv;
-  if (nv > RTOC_MAX_JOINTS || c->dims.nu != nv || c->dims.nf_max != 0) return RTOC_ERR_BAD_ARG;
+  const int nv = c->dims.nv, M = nv + 1;
+  if (M > RTOC_MAX_JOINTS || (c->dims.np != 0 && c->dims.np != 6)) return RTOC_ERR_BAD_ARG;
   HIP_TRY(hipSetDevice(c->device));
-  std::vector<double> h((size_t)9 * nv);
-  const double* src[9] = {cost->q_ref, cost->v_ref, cost->u_ref, cost->q_weight, cost->v_weight, cost->a_weight, cost->u_weight,
-                          cost->q_weight_terminal, cost->v_weight_terminal};
-  for (int k = 0; k < 9; ++k)
-    for (int i = 0; i < nv; ++i) {
+  std::vector<double> h((size_t)12 * M, 0.0);
+  const double* src[12] = {cost->q_ref, cost->v_ref, cost->u_ref, cost->q_weight, cost->v_weight, cost->a_weight, cost->u_weight,
+                           cost->q_weight_terminal, cost->v_weight_terminal, cost->q_weight_impact, cost->v_weight_impact,
+                           cost->dv_weight_impact};
+  for (int k = 0; k < 12; ++k) {
+    const int n = k == 0 ? nv + (c->dims.np == 6 ? 1 : 0) : (k == 2 || k == 6 ? c->dims.nu : nv);
+    for (int i = 0; i < n; ++i) {
       if (k >= 3 && !(src[k][i] >= 0.0)) return RTOC_ERR_BAD_ARG;  // configuration_space_cost.cpp: weights must be non-negative
-      h[(size_t)k * nv + i] = src[k][i];
+      h[(size_t)k * M + i] = src[k][i];
     }
-  if (!c->d_cost) HIP_TRY(hipMalloc((void**)&c->d_cost, sizeof(double) * 9 * nv));
-  HIP_TRY(hipMemcpyAsync(c->d_cost, h.data(), sizeof(double) * 9 * nv, hipMemcpyHostToDevice, c->stream));
+  }
+  if (!c->d_cost) HIP_TRY(hipMalloc((void**)&c->d_cost, sizeof(double) * 12 * M));
+  HIP_TRY(hipMemcpyAsync(c->d_cost, h.data(), sizeof(double) * 12 * M, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return RTOC_OK;
 }
@@ -1527,7 +1531,7 @@ int rtoc_linearize_state_equation(rtoc_ctx* c) {
   a.o_fxx = c->L.kkt.off[RTOC_KKT_FXX], a.o_fx = c->L.kkt.off[RTOC_KKT_FX], a.o_lx = c->L.kkt.off[RTOC_KKT_LX];
   a.o_hx = c->L.kkt.off[RTOC_KKT_HX], a.o_ffx = c->L.kkt.off[RTOC_KKT_FFX], a.o_scal = c->L.kkt.off[RTOC_KKT_SCAL];
   a.o_la = c->L.cdd.off[RTOC_CDD_LA], a.o_ha = c->L.cdd.off[RTOC_CDD_HA];
-  hipLaunchKernelGGL(state_equation_lin_kernel, dim3(c->batch * (c->nstages - 1)), dim3(64), 0, c->stream, a);
+  hipLaunchKernelGGL(state_equation_lin_kernel, dim3(c->batch * c->nstages), dim3(64), 0, c->stream, a);
   HIP_TRY(hipGetLastError());
   c->fxx_state = 0;
   return RTOC_OK;
@@ -1659,6 +1663,47 @@ int rtoc_kkt_error(rtoc_ctx* c, double* host_out, int count) {
   if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(host_out, c->d_kkterr, sizeof(double) * count, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
+  return RTOC_OK;
+}
+
+// ---- evalKKT / updateSolution of the contact path closed on the device (ConfigurationSpaceCost, no inequality rows) ----
+int rtoc_newton_iteration(rtoc_ctx* c, double kkt_tol, double tau);
+int rtoc_contact_eval_kkt(rtoc_ctx* c) {
+  CHECK_READY(c);
+  if (!c->h_model || !c->d_active || !c->d_cost || !c->buf[RTOC_BUF_SOL]) return RTOC_ERR_NOT_READY;
+  for (int i = 0; i < c->nstages; ++i)
+    if (c->h_grid[i].switching_constraint) return RTOC_ERR_BAD_ARG;
+  int rc = ensure_buffer(c, RTOC_BUF_KKT);
+  if (!rc) rc = ensure_buffer(c, RTOC_BUF_CDD);
+  if (rc) return rc;
+  CostArgs a;
+  a.sol = c->buf[RTOC_BUF_SOL];
+  a.cost = c->d_cost;
+  a.kkt = c->buf[RTOC_BUF_KKT];
+  a.cdd = c->buf[RTOC_BUF_CDD];
+  a.grid = c->d_grid;
+  a.nstages = c->nstages, a.batch = c->batch, a.nv = c->dims.nv, a.nu = c->dims.nu;
+  a.nf_max = c->dims.nf_max, a.ns_max = c->dims.ns_max, a.floating = c->dims.np == 6;
+  a.sol_stride = c->L.sol.stride, a.kkt_stride = c->L.kkt.stride, a.cdd_stride = c->L.cdd.stride;
+  a.o_q = c->L.sol.off[RTOC_SOL_Q], a.o_v = c->L.sol.off[RTOC_SOL_V], a.o_a = c->L.sol.off[RTOC_SOL_A], a.o_u = c->L.sol.off[RTOC_SOL_U];
+  a.kl = c->L.kkt, a.cl = c->L.cdd;
+  hipLaunchKernelGGL(contact_cost_kernel, dim3(c->batch * c->nstages), dim3(64), 0, c->stream, a);
+  HIP_TRY(hipGetLastError());
+  rc = rtoc_linearize_state_equation(c);
+  if (!rc) rc = launch_linearize(c, 1, false, 1.0);
+  return rc;
+}
+
+int rtoc_contact_update_solution(rtoc_ctx* c, double tau, double* host_kkt_error, int count) {
+  CHECK_READY(c);
+  if (count < 0 || count > c->batch || (count > 0 && !host_kkt_error)) return RTOC_ERR_BAD_ARG;
+  int rc = rtoc_contact_eval_kkt(c);
+  if (!rc) rc = rtoc_newton_iteration(c, 0.0, tau);  // KKT error, condensation, sweep, expansion, steps, update, integrate
+  if (rc) return rc;
+  if (count > 0) {
+    HIP_TRY(hipMemcpyAsync(host_kkt_error, c->d_kkterr, sizeof(double) * count, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+  }
   return RTOC_OK;
 }
 

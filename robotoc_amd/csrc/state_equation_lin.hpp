@@ -93,11 +93,51 @@ static __global__ __launch_bounds__(64) void state_equation_lin_kernel(SeLinArgs
   using namespace selin;
   __shared__ double J[3][36];  // Fqq, Fqq_prev, d/dq0 of (q (-) q_next): 6 x 6, column-major
   const int lane = threadIdx.x;
-  const int nst1 = a.nstages - 1;
-  const int b = blockIdx.x / nst1, st = blockIdx.x % nst1;  // the terminal grid point has no state equation
+  const int b = blockIdx.x / a.nstages, st = blockIdx.x % a.nstages;
   if (b >= a.batch) return;
   const rtoc_grid g = a.grid[st];
   const bool impact = g.type == RTOC_GRID_IMPACT;
+  if (st == a.nstages - 1) {
+    // linearizeTerminalStateEquation (src/dynamics/terminal_state_equation.cpp:8-28): lq -= lmd (base: += Fqq_prev^T lmd),
+    // lv -= gmm; Fqq_prev_inv for correctCostateDirection / correctLinearizeTerminalStateEquation
+    const int nv = a.nv, nb = a.floating ? 6 : 0;
+    const size_t rec = (size_t)b * a.nstages + st;
+    const double* const s = a.sol + rec * a.sol_stride;
+    double* const kr = a.kkt + rec * a.kkt_stride;
+    for (int i = lane; i < nv; i += 64) {
+      if (i >= nb) kr[a.o_lx + i] -= s[a.o_lmd + i];
+      kr[a.o_lx + nv + i] -= s[a.o_gmm + i];
+    }
+    if (a.floating) {
+      const double* q = s + a.o_q;
+      const double* qp = s - a.sol_stride + a.o_q;
+      M3 R0;
+      V3 p0;
+      rel(quat_R(q + 3), rbd::ldv3(q), quat_R(qp + 3), rbd::ldv3(qp), R0, p0);
+      if (lane < 6) {
+        SV val, der;
+        rbd::log6_fwd(R0, p0, rbd::sv0() - rbd::act_inv(R0, p0, unit_twist(lane)), val, der);
+        const double c0[6] = {der.l.x, der.l.y, der.l.z, der.a.x, der.a.y, der.a.z};
+#pragma unroll
+        for (int r = 0; r < 6; ++r) J[1][r + 6 * lane] = c0[r];
+      }
+      __syncthreads();
+      if (lane < 6) {
+        double t = 0.0;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) t += J[1][r + 6 * lane] * s[a.o_lmd + r];
+        kr[a.o_lx + lane] += t;
+      }
+      if (lane == 0 && a.se3) {
+        double* const se = a.se3 + rec * RTOC_SE3_STRIDE;
+        double A[36];
+        for (int e = 0; e < 36; ++e) A[e] = J[1][e];
+        inv6(A);
+        for (int e = 0; e < 36; ++e) se[e] = 0.0, se[36 + e] = A[e];
+      }
+    }
+    return;
+  }
   const double dt = impact ? 0.0 : g.dt;
   const int nv = a.nv, nx = 2 * nv, nb = a.floating ? 6 : 0, nq = nv + (a.floating ? 1 : 0);
   const size_t rec = (size_t)b * a.nstages + st;

@@ -1,0 +1,82 @@
+"""OCPSolver::updateSolution (src/solver/ocp_solver.cpp:111-145) closed on the device for a floating-base robot in contact:
+ANYmal on its four feet, ConfigurationSpaceCost, no inequality rows, no discrete events.  Cost (SE(3) difference of the base
+included), state equation, contact-dynamics linearisation, condensation, Riccati sweep, expansion and the solution update
+on the manifold all run in rtoc_contact_update_solution; the host only reads the KKT error.  Checks: Newton convergence from
+the reference examples' kind of initial guess (the initial state on every grid point, gravity-compensating contact forces);
+the converged trajectory against the CPU restatement -- inverse dynamics with the contact forces, Baumgarte contact rows,
+state equation on SE(3), initial state.  The rigid-body parts are parity-unpinned (Pinocchio absent)."""
+import numpy as np
+import pytest
+
+from robotoc_amd import capi, robot_model as rm
+from robotoc_amd.grid import uniform_grid
+from robotoc_amd.types import BUF_SOL, Records, anymal_dims
+
+Q_STAND = np.array([0, 0, 0.4792, 0, 0, 0, 1, -0.1, 0.7, -1.0, -0.1, -0.7, 1.0, 0.1, 0.7, -1.0, 0.1, -0.7, 1.0])  # examples/anymal
+
+
+@pytest.mark.gpu
+def test_anymal_standing_solver_iterations_converge_on_the_device(oracle):
+    m = rm.load_named("anymal")
+    dims = anymal_dims()
+    N, dt, batch = 20, 0.02, 4
+    grids = uniform_grid(N, dt, dimf=12)
+    n, nv, nq = len(grids), m.nv, m.nq
+    ctx = capi.Context(dims, n, batch, 0)
+    ctx.set_grid(grids)
+    ctx.set_robot_model(m)
+    feet = np.array([oracle.rbd_contact_position(m, Q_STAND, c) for c in range(4)])
+    ctx.set_contact_schedule(np.full(n, 0b1111, dtype=np.uint32), np.tile(feet[None], (n, 1, 1)))
+    # track a base placement 3 cm forward, 2 cm down and slightly pitched, joints near the standing pose
+    q_ref = Q_STAND.copy()
+    q_ref[:7] = oracle.se3_integrate(Q_STAND[:7], np.array([0.03, 0.0, -0.02, 0.0, 0.05, 0.0]))
+    wq = np.concatenate([np.full(6, 10.0), np.full(12, 0.1)])
+    ctx.set_configuration_cost(q_ref, np.zeros(nv), np.zeros(12), wq, np.full(nv, 1.0), np.full(nv, 1e-3), np.full(12, 1e-3),
+                               10.0 * wq, np.full(nv, 1.0))
+    rng = np.random.default_rng(31)
+    x0 = np.tile(np.concatenate([Q_STAND, np.zeros(nv)]), (batch, 1))
+    for b in range(batch):  # a different initial state per instance: the base nudged, joints moved so that the feet stay put is NOT required
+        x0[b, :7] = oracle.se3_integrate(Q_STAND[:7], 0.01 * rng.uniform(-1, 1, 6))
+        x0[b, nq:] = 0.02 * rng.uniform(-1, 1, nv)
+    ctx.set_initial_state(x0)
+    S = Records(ctx.L, "sol")
+    sol = S.zeros(batch, n)
+    mass = sum(m.mass[i] for i in range(m.njoints))
+    for b in range(batch):
+        q0 = x0[b, :nq]
+        f = np.concatenate([oracle.rbd_contact_placement(m, q0, c)[0].T @ np.array([0.0, 0.0, 9.81 * mass / 4]) for c in range(4)])
+        u = oracle.rbd_eval(m, 0, q0, np.zeros(nv), np.zeros(nv), f, np.zeros(12), 0b1111, feet.reshape(-1))[6:nv]
+        for i in range(n):
+            S.f(sol[b, i], "q")[:nq] = q0
+            S.f(sol[b, i], "f")[:12] = f
+            S.f(sol[b, i], "u")[:12] = u
+    ctx.upload(BUF_SOL, sol)
+    hist = []
+    for it in range(60):
+        hist.append(ctx.contact_update_solution())
+        if hist[-1].max() < 1e-9:
+            break
+    hist = np.array(hist)
+    print("KKT error per iteration (worst instance):", ["%.1e" % e for e in hist.max(axis=1)])
+    assert (ctx.status() == 0).all()
+    assert hist[-1].max() < 1e-7 and hist[-1].max() < 1e-8 * hist[0].max()
+    # ---- the converged trajectory, by the CPU restatement ----
+    sol = ctx.download_records(BUF_SOL, "sol")
+    worst = dict(IDC=0.0, Fx=0.0, x0=0.0)
+    for b in range(batch):
+        q, v = S.f(sol[b, 0], "q")[:nq], S.f(sol[b, 0], "v")
+        worst["x0"] = max(worst["x0"], np.abs(oracle.se3_difference(q[:7], x0[b, :7])).max(), np.abs(q[7:] - x0[b, 7:nq]).max(), np.abs(v - x0[b, nq:]).max())
+        for i in range(n - 1):
+            s, sn = sol[b, i], sol[b, i + 1]
+            q, v, a, u, f = S.f(s, "q")[:nq], S.f(s, "v"), S.f(s, "a"), S.f(s, "u")[:12], S.f(s, "f")[:12]
+            qn, vn = S.f(sn, "q")[:nq], S.f(sn, "v")
+            worst["IDC"] = max(worst["IDC"], np.abs(oracle.rbd_eval(m, 0, q, v, a, f, u, 0b1111, feet.reshape(-1))).max())
+            Fq = np.concatenate([oracle.se3_difference(qn[:7], q[:7]), q[7:] - qn[7:]]) + dt * v
+            worst["Fx"] = max(worst["Fx"], np.abs(Fq).max(), np.abs(v + dt * a - vn).max())
+    print("converged trajectory, worst residuals by the CPU restatement:", worst)
+    assert worst["IDC"] < 1e-7 and worst["Fx"] < 1e-8 and worst["x0"] < 1e-8
+    # the base moves towards the reference placement, the feet stay where they were
+    qT = S.f(sol[0, n - 1], "q")[:nq]
+    assert np.linalg.norm(oracle.se3_difference(q_ref[:7], qT[:7])) < 0.8 * np.linalg.norm(oracle.se3_difference(q_ref[:7], x0[0, :7]))
+    assert max(np.abs(oracle.rbd_contact_position(m, qT, c) - feet[c]).max() for c in range(4)) < 5e-3
+    ctx.close()

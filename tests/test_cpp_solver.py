@@ -100,7 +100,7 @@ def test_unconstr_ocp_solver_solves_iiwa14_on_the_device(tmp_path):
     m = rm.load_named("iiwa14")
     n, nv, dt = len(grids), m.nv, meta["dt"]
     rng = np.random.default_rng(21)
-    cost = np.zeros((9, MAX_JOINTS))
+    cost = np.zeros((12, MAX_JOINTS))
     cost[0, :nv] = rng.uniform(-0.8, 0.8, nv)
     for k, w in ((3, 10.0), (4, 0.1), (5, 0.01), (6, 0.001), (7, 10.0), (8, 0.1)):
         cost[k, :nv] = w

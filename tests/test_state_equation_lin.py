@@ -99,6 +99,16 @@ def test_state_equation_linearisation_floating_base(oracle):
                 d0[:6] = -np.linalg.inv(Fqq_prev) @ d0[:6]
                 worst["jac"] = max(worst["jac"], np.abs(dx0[b, :nv] - d0).max())
                 assert np.allclose(dx0[b, nv:], x0[b, nv + 1:] - v, atol=1e-15)
+        # terminal grid point (terminal_state_equation.cpp:8-28)
+        sT, qpT = sol[b, n - 1], S.f(sol[b, n - 2], "q")
+        qT, lmdT, gmmT = S.f(sT, "q"), S.f(sT, "lmd"), S.f(sT, "gmm")
+        FqqT = _fd_jac(lambda x: oracle.se3_difference(x, qpT[:7]), qT[:7])
+        lx = K.f(kkt0[b, n - 1], "lx").copy()
+        lx[:6] += FqqT.T @ lmdT[:6]
+        lx[6:nv] -= lmdT[6:]
+        lx[nv:] -= gmmT
+        worst["jac"] = max(worst["jac"], np.abs(K.f(kkt[b, n - 1], "lx") - lx).max(),
+                           np.abs(se3[b, n - 1, 36:].reshape(6, 6).T - np.linalg.inv(FqqT)).max())
     print("worst deviation: values %.2e, Jacobian-dependent %.2e" % (worst["val"], worst["jac"]))
     assert worst["val"] < 1e-13 and worst["jac"] < 2e-7
     ctx.close()
