@@ -89,8 +89,13 @@ class StageDataSource {
   virtual int ncMax() const = 0;
   virtual const TimeDiscretization& timeDiscretization() const = 0;
   virtual void configure(rtoc_ctx* ctx) = 0;  // constraint rows, cones: once after rtoc_create
+  // the (q, v) of updateSolution(t, q, v), ahead of linearize(): sources that linearise on the device need it for
+  // Fqq_prev of grid point 0 and the initial state direction; host-side sources ignore it
+  virtual void setInitialState(rtoc_ctx*, const Vec&, const Vec&) {}
   virtual void linearize(rtoc_ctx* ctx, const Solution& s) = 0;
   virtual void initialStateDirection(const Vec& q, const Vec& v, const Solution& s, Vec& dx0) const = 0;
+  // true: linearize() already left computeInitialStateDirection's result in RTOC_BUF_DX0 (nothing to compute or upload here)
+  virtual bool initialStateDirectionOnDevice() const { return false; }
   virtual void initialSolution(Solution& s) const = 0;
 };
 
@@ -301,8 +306,9 @@ class DirectMultipleShooting {
   // evalKKT (direct_multiple_shooting.cpp:129-159): linearise (source), KKT error of the linearised records
   // (:155-158), then the condensation tail of every stage (intermediate_stage.cpp:134-148) on the GPU.
   // kkt_matrix / kkt_residual stay device resident (the reference's containers are not filled).
-  void evalKKT(const TimeDiscretization& td, const Vec&, const Vec&, const Solution& s, KKTMatrix&, KKTResidual&) {
+  void evalKKT(const TimeDiscretization& td, const Vec& q, const Vec& v, const Solution& s, KKTMatrix&, KKTResidual&) {
     RiccatiRecursion::setGridOf(ctx(), td);
+    source_->setInitialState(ctx(), q, v);
     source_->linearize(ctx(), s);
     chk(rtoc_clear_status(ctx()), "rtoc_clear_status");
     double e = 0.0;
@@ -312,6 +318,7 @@ class DirectMultipleShooting {
   }
   // computeInitialStateDirection (direct_multiple_shooting.cpp:162-171 -> state_equation.cpp:98-109)
   void computeInitialStateDirection(const Vec& q, const Vec& v, const Solution& s, Direction& d) const {
+    if (source_->initialStateDirectionOnDevice()) return;
     source_->initialStateDirection(q, v, s, d[0].dx);
     chk(rtoc_upload(ctx(), RTOC_BUF_DX0, 0, d[0].dx.data(), d[0].dx.size()), "rtoc_upload");
   }

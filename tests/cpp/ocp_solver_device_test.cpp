@@ -1,0 +1,77 @@
+// robotoc::OCPSolver (robotoc_amd/host/robotoc_hip_solver.hpp) with the device-side linearisation
+// (robotoc_hip_device_source.hpp): ANYmal on four feet, ConfigurationSpaceCost -- OCPSolver::solve with nothing of the
+// iteration on the host.   usage: ocp_solver_device_test <problem.bin> <out.bin>
+//   problem.bin: rtoc_robot_model, rtoc_configuration_cost, int N, double dt, double q0[nq], double v0[nv],
+//   double contact_positions[ncontacts][3], double f0[max_dimf], double u0[nu]   (tests/test_cpp_solver.py writes it)
+#include <cstdio>
+#include <vector>
+
+#include "../../robotoc_amd/host/robotoc_hip_device_source.hpp"
+
+using namespace robotoc;
+
+int main(int argc, char** argv) {
+  if (argc < 3) return 2;
+  rtoc_robot_model model;
+  rtoc_configuration_cost cost;
+  int N = 0;
+  double dt = 0.0;
+  FILE* f = std::fopen(argv[1], "rb");
+  if (!f) return 3;
+  bool ok = std::fread(&model, sizeof(model), 1, f) == 1 && std::fread(&cost, sizeof(cost), 1, f) == 1 && std::fread(&N, sizeof(int), 1, f) == 1 &&
+            std::fread(&dt, sizeof(double), 1, f) == 1;
+  if (!ok) return 4;
+  const int nv = model.nv, nq = model.nq, nc = model.ncontacts, nu = nv - 6, dimf = 3 * nc;
+  std::vector<double> q0(nq), v0(nv), cpos(3 * nc), f0(dimf), u0(nu);
+  ok = std::fread(q0.data(), 8, nq, f) == (size_t)nq && std::fread(v0.data(), 8, nv, f) == (size_t)nv && std::fread(cpos.data(), 8, 3 * nc, f) == (size_t)(3 * nc) &&
+       std::fread(f0.data(), 8, dimf, f) == (size_t)dimf && std::fread(u0.data(), 8, nu, f) == (size_t)nu;
+  std::fclose(f);
+  if (!ok) return 4;
+  try {
+    std::vector<GridInfo> grid(N + 1);
+    std::vector<unsigned> active(N + 1, (1u << nc) - 1);
+    std::vector<double> positions;
+    for (int i = 0; i <= N; ++i) {
+      grid[i].type = i == N ? GridType::Terminal : GridType::Intermediate;
+      grid[i].dt = i == N ? 0.0 : dt;
+      grid[i].stage = i;
+      grid[i].num_grids_in_phase = N;
+      grid[i].dimf = i == N ? 0 : dimf;
+      positions.insert(positions.end(), cpos.begin(), cpos.end());
+    }
+    RobotDims dims;
+    dims.dimv = nv, dims.dimu = nu, dims.dim_passive = 6, dims.max_dimf = dimf;
+    Solution s0(N + 1, SplitSolution(dims));
+    for (int i = 0; i <= N; ++i) {
+      for (int k = 0; k < nq; ++k) s0[i].q(k) = q0[k];
+      for (int k = 0; k < dimf; ++k) s0[i].f_full(k) = f0[k];
+      for (int k = 0; k < nu; ++k) s0[i].u(k) = u0[k];
+    }
+    auto source = std::make_shared<ConfigurationCostSource>(model, cost, grid, active, positions, s0);
+    SolverOCP ocp(source);
+    SolverOptions opt;
+    opt.max_iter = 40;
+    opt.kkt_tol = 1.0e-8;
+    OCPSolver solver(ocp, opt);
+    Vec q(nq), v(nv);
+    for (int k = 0; k < nq; ++k) q(k) = q0[k];
+    for (int k = 0; k < nv; ++k) v(k) = v0[k];
+    solver.solve(0.0, q, v, true);
+    const SolverStatistics& st = solver.getSolverStatistics();
+    std::printf("OCPSolver::solve on the device: KKT error %.3e -> %.3e in %d iterations, converged %d\n", st.performance_index.front(),
+                solver.KKTError(), st.iter, (int)st.convergence);
+    if (solver.status() != 0) return 5;
+    const Solution& s = solver.getSolution();
+    std::vector<double> out;
+    out.push_back(st.iter), out.push_back(st.convergence ? 1.0 : 0.0), out.push_back(solver.KKTError()), out.push_back(st.performance_index.front());
+    for (int i = 0; i <= N; ++i)
+      for (int k = 0; k < nq; ++k) out.push_back(s[i].q(k));
+    f = std::fopen(argv[2], "wb");
+    std::fwrite(out.data(), sizeof(double), out.size(), f);
+    std::fclose(f);
+    return st.convergence ? 0 : 6;
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "exception: %s\n", e.what());
+    return 7;
+  }
+}

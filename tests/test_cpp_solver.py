@@ -137,3 +137,67 @@ def test_unconstr_ocp_solver_solves_iiwa14_on_the_device(tmp_path):
     ref = np.concatenate([S.f(sol[0], "q")[:, :nv], S.f(sol[0], "v")], axis=1)
     assert np.array_equal(traj, ref)
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_ocp_solver_with_device_linearisation_solves_anymal_standing(tmp_path, oracle):
+    """robotoc::OCPSolver::solve through the ConfigurationCostSource (robotoc_hip_device_source.hpp): the whole iteration on
+    the device; the trajectory equals the ctypes loop of rtoc_contact_update_solution bit for bit."""
+    from robotoc_amd import capi, robot_model as rm
+    from robotoc_amd.grid import uniform_grid
+    from robotoc_amd.robot_model import MAX_JOINTS
+    from robotoc_amd.types import anymal_dims
+    from test_cpp_host import _build
+    from test_contact_closed_loop import Q_STAND
+    exe = _build("ocp_solver_device_test")
+    m = rm.load_named("anymal")
+    N, dt = 20, 0.02
+    nv, nq = m.nv, m.nq
+    feet = np.array([oracle.rbd_contact_position(m, Q_STAND, c) for c in range(4)])
+    q_ref = Q_STAND.copy()
+    q_ref[:7] = oracle.se3_integrate(Q_STAND[:7], np.array([0.03, 0.0, -0.02, 0.0, 0.05, 0.0]))
+    wq = np.concatenate([np.full(6, 10.0), np.full(12, 0.1)])
+    cost = np.zeros((12, MAX_JOINTS))
+    for k, val in ((0, q_ref), (3, wq), (4, np.full(nv, 1.0)), (5, np.full(nv, 1e-3)), (6, np.full(12, 1e-3)), (7, 10.0 * wq), (8, np.full(nv, 1.0))):
+        cost[k, :len(val)] = val
+    q0 = Q_STAND.copy()
+    q0[:7] = oracle.se3_integrate(Q_STAND[:7], np.array([0.005, -0.004, 0.003, 0.01, -0.006, 0.004]))
+    v0 = np.zeros(nv)
+    mass = sum(m.mass[i] for i in range(m.njoints))
+    f0 = np.concatenate([oracle.rbd_contact_placement(m, q0, c)[0].T @ np.array([0.0, 0.0, 9.81 * mass / 4]) for c in range(4)])
+    u0 = oracle.rbd_eval(m, 0, q0, np.zeros(nv), np.zeros(nv), f0, np.zeros(12), 0b1111, feet.reshape(-1))[6:nv]
+    prob = str(tmp_path / "anymal_standing.bin")
+    with open(prob, "wb") as f:
+        f.write(bytes(m))
+        f.write(cost.tobytes())
+        f.write(np.array([N], dtype=np.int32).tobytes())
+        f.write(np.array([dt]).tobytes())
+        for arr in (q0, v0, feet.reshape(-1), f0, u0):
+            f.write(np.ascontiguousarray(arr, dtype=np.float64).tobytes())
+    out_path = str(tmp_path / "ocp_device_out.bin")
+    run = subprocess.run([exe, prob, out_path], capture_output=True, text=True, timeout=300)
+    print(run.stdout, run.stderr)
+    assert run.returncode == 0, (run.returncode, run.stdout, run.stderr)
+    raw = np.fromfile(out_path)
+    iters, conv, err = int(raw[0]), raw[1], raw[2]
+    assert conv == 1.0 and err < 1e-8 and iters <= 20
+    traj = raw[4:].reshape(N + 1, nq)
+    # the same iterations through ctypes
+    grids = uniform_grid(N, dt, dimf=12)
+    ctx = capi.Context(anymal_dims(), N + 1, 1, 0)
+    ctx.set_grid(grids)
+    ctx.set_robot_model(m)
+    ctx.set_contact_schedule(np.full(N + 1, 0b1111, dtype=np.uint32), np.tile(feet[None], (N + 1, 1, 1)))
+    ctx.set_configuration_cost(*[cost[k, :(nq if k == 0 else nv)] for k in range(12)])
+    ctx.set_initial_state(np.concatenate([q0, v0])[None])
+    S = Records(ctx.L, "sol")
+    sol = S.zeros(1, N + 1)
+    S.f(sol, "q")[..., :nq] = q0
+    S.f(sol, "f")[..., :12] = f0
+    S.f(sol, "u")[..., :12] = u0
+    ctx.upload(BUF_SOL, sol)
+    for _ in range(iters):
+        ctx.contact_update_solution()
+    ref = S.f(ctx.download_records(BUF_SOL, "sol")[0], "q")[:, :nq]
+    assert np.array_equal(traj, ref)
+    ctx.close()
