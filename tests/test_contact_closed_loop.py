@@ -80,3 +80,62 @@ def test_anymal_standing_solver_iterations_converge_on_the_device(oracle):
     assert np.linalg.norm(oracle.se3_difference(q_ref[:7], qT[:7])) < 0.8 * np.linalg.norm(oracle.se3_difference(q_ref[:7], x0[0, :7]))
     assert max(np.abs(oracle.rbd_contact_position(m, qT, c) - feet[c]).max() for c in range(4)) < 5e-3
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_anymal_lifting_two_feet_converges_on_the_device(oracle):
+    """The same OCP with a lift event half way (ContactSequence: four feet -> the LF / RH diagonal): lift grid, a change of
+    contact dimension along the horizon, swing legs free.  (Touch-downs need the switching constraint, which is not part of
+    the device-side linearisation.)"""
+    from robotoc_amd.grid import ContactSequence, Event, discretize
+    from robotoc_amd.types import GRID_LIFT
+    m = rm.load_named("anymal")
+    dims = anymal_dims()
+    N, dt, batch = 20, 0.02, 2
+    grids = discretize(N, N * dt, 0.0, ContactSequence([12, 6], [Event("lift", 0.205)]))
+    n, nv, nq = len(grids), m.nv, m.nq
+    assert any(g.type == GRID_LIFT for g in grids) and {g.dimf for g in grids[:-1]} == {12, 6}
+    ctx = capi.Context(dims, n, batch, 0)
+    ctx.set_grid(grids)
+    ctx.set_robot_model(m)
+    feet = np.array([oracle.rbd_contact_position(m, Q_STAND, c) for c in range(4)])
+    masks = np.array([0b1111 if g.dimf == 12 else (0b1001 if g.dimf == 6 else 0) for g in grids], dtype=np.uint32)
+    ctx.set_contact_schedule(masks, np.tile(feet[None], (n, 1, 1)))
+    wq = np.concatenate([np.full(6, 10.0), np.full(12, 1.0)])
+    ctx.set_configuration_cost(Q_STAND, np.zeros(nv), np.zeros(12), wq, np.full(nv, 1.0), np.full(nv, 1e-3), np.full(12, 1e-3),
+                               10.0 * wq, np.full(nv, 1.0))
+    x0 = np.tile(np.concatenate([Q_STAND, np.zeros(nv)]), (batch, 1))
+    x0[1, :7] = oracle.se3_integrate(Q_STAND[:7], np.array([0.01, 0.005, -0.005, 0.0, 0.02, 0.01]))
+    ctx.set_initial_state(x0)
+    S = Records(ctx.L, "sol")
+    sol = S.zeros(batch, n)
+    mass = sum(m.mass[i] for i in range(m.njoints))
+    for b in range(batch):
+        q0 = x0[b, :nq]
+        for i in range(n):
+            act = [c for c in range(4) if (int(masks[i]) >> c) & 1]
+            S.f(sol[b, i], "q")[:nq] = q0
+            if act:
+                S.f(sol[b, i], "f")[:3 * len(act)] = np.concatenate([oracle.rbd_contact_placement(m, q0, c)[0].T @ np.array([0.0, 0.0, 9.81 * mass / len(act)]) for c in act])
+    ctx.upload(BUF_SOL, sol)
+    hist = []
+    for it in range(80):
+        hist.append(ctx.contact_update_solution())
+        if hist[-1].max() < 1e-9:
+            break
+    hist = np.array(hist)
+    print("KKT error per iteration (worst instance):", ["%.1e" % e for e in hist.max(axis=1)])
+    assert (ctx.status() == 0).all() and hist[-1].max() < 1e-7
+    sol = ctx.download_records(BUF_SOL, "sol")
+    worst = 0.0
+    for b in range(batch):
+        for i in range(n - 1):
+            s = sol[b, i]
+            act = int(masks[i])
+            nf = 3 * bin(act).count("1")
+            r = oracle.rbd_eval(m, 0, S.f(s, "q")[:nq], S.f(s, "v"), S.f(s, "a"), S.f(s, "f")[:12], S.f(s, "u")[:12], act, feet.reshape(-1))
+            assert r.size == nv + nf
+            worst = max(worst, np.abs(r).max())
+    print("dynamics + contact rows of the converged trajectory:", worst)
+    assert worst < 1e-7
+    ctx.close()
