@@ -127,11 +127,16 @@ enum rtoc_option {
                               * asserts the structure (no check; wrong results if it does not hold).  A host that
                               * rewrites a bound buffer in place with a different structure must call
                               * rtoc_check_fxx_structure again.  Only shapes with a structured kernel (nv = 18) care. */
-  RTOC_OPT_GRAPH = 9 /* 1: rtoc_riccati_sweep and rtoc_newton_iteration replay their launch sequence from a captured
+  RTOC_OPT_GRAPH = 9, /* 1: rtoc_riccati_sweep and rtoc_newton_iteration replay their launch sequence from a captured
                       * hipGraph (captured on the second call after any change of grid, options, buffers, rows or
                       * cones; arguments kkt_tol / tau are part of the key).  For the single-OCP latency path, whose
                       * ~25 small kernels are launch-bound.  The calls stay asynchronous on the context's stream; the
                       * stream must not be capturing already.  Default 0. */
+  RTOC_OPT_SWITCHING_TRANSPORT = 10 /* Free-flyer block of Phiq / Phiv / Phia in rtoc_contact_eval_kkt's switching-constraint
+                      * rows.  0 (default): as the reference composes it -- it hands pinocchio::dIntegrateTransport the
+                      * transposed Jacobian (robot.hxx:69-72, :88-91), which yields Pq dIntegrate^T.  1: the chain rule
+                      * Pq dIntegrate (what finite differences of P give).  The two agree to first order in the base
+                      * displacement (dt1 + dt2) v + dt1 dt2 a. */
 };
 
 typedef struct rtoc_ctx rtoc_ctx;

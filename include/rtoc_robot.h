@@ -78,15 +78,18 @@ int rtoc_set_contact_schedule(rtoc_ctx* ctx, const unsigned* active, const doubl
  * lq / lv / lu in RTOC_BUF_KKT, la / lf / lu_passive in RTOC_BUF_CDD. */
 int rtoc_linearize_contact_dynamics(rtoc_ctx* ctx, int augment_residual);
 
-/* ---- evalKKT of the contact path on the device (no inequality rows, no switching constraints) ----
+/* ---- evalKKT of the contact path on the device (no inequality rows) ----
  * {Intermediate,Impact,Terminal}Stage::evalKKT up to the condensation (src/ocp/intermediate_stage.cpp:94-132,
  * impact_stage.cpp:82-114, terminal_stage.cpp:72-100) for an OCP whose cost is the ConfigurationSpaceCost of
  * rtoc_set_configuration_cost: setZero, quadratize{Stage,Impact,Terminal}Cost, linearize{,Impact,Terminal}StateEquation
  * (rtoc_linearize_state_equation), linearizeContactDynamics / linearizeImpactDynamics with the multiplier terms
- * (rtoc_linearize_contact_dynamics(ctx, 1)) -- RTOC_BUF_SOL in, the pre-condensation records RTOC_BUF_KKT / RTOC_BUF_CDD,
- * RTOC_BUF_SE3 and RTOC_BUF_DX0 out; rtoc_newton_iteration takes it from there.  Needs rtoc_set_robot_model,
- * rtoc_set_contact_schedule, rtoc_set_configuration_cost, rtoc_set_initial_state.  RTOC_ERR_BAD_ARG on grids with a
- * switching constraint (its linearisation is not on the device). */
+ * (rtoc_linearize_contact_dynamics(ctx, 1)) and, on grids with GridInfo::switching_constraint, linearizeSwitchingConstraint
+ * (src/dynamics/switching_constraint.cpp:26-70: P, Phix, Phia, Phit, the xi terms of lx / la and the STO terms of h, Qtt,
+ * hv, ha; the impacting contacts and their positions are those of the impact grid two points ahead in the contact
+ * schedule; free-flyer transport: RTOC_OPT_SWITCHING_TRANSPORT) -- RTOC_BUF_SOL in, the pre-condensation records
+ * RTOC_BUF_KKT / RTOC_BUF_CDD, RTOC_BUF_SE3 and RTOC_BUF_DX0 out; rtoc_newton_iteration takes it from there.  Needs
+ * rtoc_set_robot_model, rtoc_set_contact_schedule, rtoc_set_configuration_cost, rtoc_set_initial_state.
+ * RTOC_ERR_BAD_ARG for a switching constraint on a model with surface contacts (point contacts only). */
 int rtoc_contact_eval_kkt(rtoc_ctx* ctx);
 /* OCPSolver::updateSolution (src/solver/ocp_solver.cpp:111-145) for that OCP, one launch sequence: rtoc_contact_eval_kkt,
  * then rtoc_newton_iteration(ctx, 0, fraction_to_boundary_rule).  host_kkt_error[count <= batch] (may be NULL / 0): the KKT

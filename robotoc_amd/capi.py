@@ -10,7 +10,7 @@ import subprocess
 import numpy as np
 
 from .types import (BoxRow, BUF_CDD, BUF_CON, BUF_DIR, BUF_DX0, BUF_KKT, BUF_RIC, BUF_STEP, Dims, Grid,
-                    Layout, OPT_BACKWARD_WAVES, OPT_CONDENSE_SPLIT, OPT_CONDENSE_KEEP_QAF, OPT_FXX_STRUCTURE, OPT_GRAPH, OPT_MAX_DTS0, OPT_SWEEP_CHUNKS, OPT_WRITEBACK_KKT, OPT_BACKWARD_SCAN,
+                    Layout, OPT_BACKWARD_WAVES, OPT_CONDENSE_SPLIT, OPT_CONDENSE_KEEP_QAF, OPT_FXX_STRUCTURE, OPT_GRAPH, OPT_SWITCHING_TRANSPORT, OPT_MAX_DTS0, OPT_SWEEP_CHUNKS, OPT_WRITEBACK_KKT, OPT_BACKWARD_SCAN,
                     grid_array)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -303,6 +303,11 @@ class Context:
     def set_graph(self, on):
         """RTOC_OPT_GRAPH: replay rtoc_riccati_sweep / rtoc_newton_iteration from captured hipGraphs."""
         _chk(lib().rtoc_set_option(self._h, OPT_GRAPH, int(bool(on))))
+
+    def set_switching_transport(self, exact):
+        """RTOC_OPT_SWITCHING_TRANSPORT: free-flyer block of the switching-constraint Jacobians -- False (default): as the
+        reference composes it (Pq dIntegrate^T); True: the chain rule (Pq dIntegrate)."""
+        _chk(lib().rtoc_set_option(self._h, OPT_SWITCHING_TRANSPORT, int(bool(exact))))
 
     def set_fxx_structure(self, mode):
         """RTOC_OPT_FXX_STRUCTURE: 0 automatic (checked on the device), 1 always dense, 2 caller asserts the structure."""

@@ -16,6 +16,7 @@
 #include "rigid_body.hpp"
 #include "unconstr_constraints.hpp"
 #include "state_equation_lin.hpp"
+#include "switching_constraint_lin.hpp"
 #include "contact_eval_kkt.hpp"
 
 using namespace rtoc;
@@ -159,6 +160,7 @@ struct rtoc_ctx {
   double* d_sto;       // rtoc_sto_eval_kkt staging: lt, diag(Qtt), squared error
   // RTOC_OPT_GRAPH: launch sequences replayed from captured hipGraphs
   int use_graph;
+  int exact_transport = 0;  // RTOC_OPT_SWITCHING_TRANSPORT
   unsigned long long epoch;  // bumped by everything that changes a launch parameter baked into a captured graph
   struct GraphSlot {
     hipGraphExec_t exec;
@@ -386,6 +388,7 @@ int rtoc_clone(rtoc_ctx* c, rtoc_ctx** out) {
     n->keep_qaf = c->keep_qaf;
     n->fxx_mode = c->fxx_mode;
     n->use_graph = c->use_graph;
+    n->exact_transport = c->exact_transport;
     if (c->backward_scan) rc = rtoc_set_option(n, RTOC_OPT_BACKWARD_SCAN, c->backward_scan);
   }
   hipError_t e = hipStreamSynchronize(c->stream);
@@ -489,6 +492,9 @@ int rtoc_set_option(rtoc_ctx* c, int option, int64_t value) {
       c->max_dts0 = d;
       return RTOC_OK;
     }
+    case RTOC_OPT_SWITCHING_TRANSPORT:
+      c->exact_transport = value ? 1 : 0;
+      return RTOC_OK;
     case RTOC_OPT_CONTACT_INV_DAMPING: {
       double d;
       memcpy(&d, &value, sizeof(d));
@@ -1668,11 +1674,40 @@ int rtoc_kkt_error(rtoc_ctx* c, double* host_out, int count) {
 
 // ---- evalKKT / updateSolution of the contact path closed on the device (ConfigurationSpaceCost, no inequality rows) ----
 int rtoc_newton_iteration(rtoc_ctx* c, double kkt_tol, double tau);
+// linearizeSwitchingConstraint (src/dynamics/switching_constraint.cpp:26-70) on the grids that carry one
+static int launch_switching_constraint(rtoc_ctx* c) {
+  const rtoc_robot_model& m = c->h_model->m;
+  SwLinArgs a;
+  a.model = c->d_model;
+  a.sol = c->buf[RTOC_BUF_SOL];
+  a.kkt = c->buf[RTOC_BUF_KKT];
+  a.cdd = c->buf[RTOC_BUF_CDD];
+  a.grid = c->d_grid;
+  a.active = c->d_active;
+  a.positions = c->has_cpos ? c->d_cpos : nullptr;
+  a.nstages = c->nstages, a.batch = c->batch, a.nv = m.nv, a.nq = m.nq, a.njoints = m.njoints, a.ncontacts = m.ncontacts;
+  a.nlevels = c->h_model->nlevels, a.floating = m.type[0] == RTOC_JOINT_FREE_FLYER, a.ns_max = c->dims.ns_max;
+  a.exact_transport = c->exact_transport;
+  a.sol_stride = c->L.sol.stride, a.kkt_stride = c->L.kkt.stride, a.cdd_stride = c->L.cdd.stride;
+  a.o_q = c->L.sol.off[RTOC_SOL_Q], a.o_v = c->L.sol.off[RTOC_SOL_V], a.o_a = c->L.sol.off[RTOC_SOL_A], a.o_xi = c->L.sol.off[RTOC_SOL_XI];
+  a.o_phix = c->L.kkt.off[RTOC_KKT_PHIX], a.o_phit = c->L.kkt.off[RTOC_KKT_PHIT], a.o_pres = c->L.kkt.off[RTOC_KKT_PRES];
+  a.o_lx = c->L.kkt.off[RTOC_KKT_LX], a.o_hx = c->L.kkt.off[RTOC_KKT_HX], a.o_scal = c->L.kkt.off[RTOC_KKT_SCAL];
+  a.o_phia = c->L.cdd.off[RTOC_CDD_PHIA], a.o_la = c->L.cdd.off[RTOC_CDD_LA], a.o_ha = c->L.cdd.off[RTOC_CDD_HA];
+  for (int i = 0; i < c->nstages; ++i)
+    if (c->h_grid[i].switching_constraint && c->h_grid[i].dims > c->dims.ns_max) return RTOC_ERR_BAD_ARG;
+  const size_t lds = sw_lds_bytes(a.nlevels, a.njoints, a.ncontacts);
+  HIP_TRY(hipFuncSetAttribute((const void*)switching_constraint_lin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(switching_constraint_lin_kernel, dim3(c->batch * (c->nstages - 1)), dim3(64), lds, c->stream, a);
+  HIP_TRY(hipGetLastError());
+  return RTOC_OK;
+}
+
 int rtoc_contact_eval_kkt(rtoc_ctx* c) {
   CHECK_READY(c);
   if (!c->h_model || !c->d_active || !c->d_cost || !c->buf[RTOC_BUF_SOL]) return RTOC_ERR_NOT_READY;
-  for (int i = 0; i < c->nstages; ++i)
-    if (c->h_grid[i].switching_constraint) return RTOC_ERR_BAD_ARG;
+  bool switching = false;
+  for (int i = 0; i < c->nstages; ++i) switching = switching || c->h_grid[i].switching_constraint;
+  if (switching && model_has_surface_contacts(c->h_model->m)) return RTOC_ERR_BAD_ARG;
   int rc = ensure_buffer(c, RTOC_BUF_KKT);
   if (!rc) rc = ensure_buffer(c, RTOC_BUF_CDD);
   if (rc) return rc;
@@ -1691,6 +1726,7 @@ int rtoc_contact_eval_kkt(rtoc_ctx* c) {
   HIP_TRY(hipGetLastError());
   rc = rtoc_linearize_state_equation(c);
   if (!rc) rc = launch_linearize(c, 1, false, 1.0);
+  if (!rc && switching) rc = launch_switching_constraint(c);
   return rc;
 }
 

@@ -139,3 +139,88 @@ def test_anymal_lifting_two_feet_converges_on_the_device(oracle):
     print("dynamics + contact rows of the converged trajectory:", worst)
     assert worst < 1e-7
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_anymal_trot_with_touch_downs_converges_on_the_device(oracle):
+    """BASELINE configs[1]'s contact sequence (examples/anymal/trot.cpp:162-190: stand, LH / RF swing, stand, LF / RH swing,
+    stand; N = 40, 47 grid points) closed on the device: lift grids, impact grids with the impact dynamics, and the
+    switching constraints two grid points ahead of each touch-down (rtoc_contact_eval_kkt's switching-constraint rows).
+    Each swing foot touches down 3 cm ahead of where it lifted off; the cost tracks the standing configuration."""
+    from robotoc_amd.problems import config_anymal_trot
+    from robotoc_amd.types import GRID_IMPACT
+    from test_switching_constraint_lin import trot_masks
+    m = rm.load_named("anymal")
+    dims, grids, _ = config_anymal_trot()
+    n, nv, nq, batch = len(grids), m.nv, m.nq, 2
+    assert n == 47 and sum(g.switching_constraint for g in grids) == 2
+    # contact order of the model: LF, LH, RF, RH
+    masks = trot_masks(grids, [0b1111, 0b1001, 0b1111, 0b0110, 0b1111], [0b0110, 0b1001])
+    for g, k in zip(grids, masks):
+        assert 3 * bin(int(k)).count("1") == g.dimf
+    ctx = capi.Context(dims, n, batch, 0)
+    ctx.set_grid(grids)
+    ctx.set_robot_model(m)
+    feet = np.array([oracle.rbd_contact_position(m, Q_STAND, c) for c in range(4)])
+    # each swing foot touches down 3 cm ahead of where it lifted off
+    pos = np.tile(feet[None], (n, 1, 1))
+    impacts = [i for i, g in enumerate(grids) if g.type == GRID_IMPACT]
+    pos[impacts[0]:, [1, 2], 0] += 0.03
+    pos[impacts[1]:, [0, 3], 0] += 0.03
+    ctx.set_contact_schedule(masks, pos)
+    wq = np.concatenate([np.full(6, 10.0), np.full(12, 1.0)])
+    ctx.set_configuration_cost(Q_STAND, np.zeros(nv), np.zeros(12), wq, np.full(nv, 1.0), np.full(nv, 1e-3), np.full(12, 1e-3),
+                               10.0 * wq, np.full(nv, 1.0), q_weight_impact=wq, v_weight_impact=np.full(nv, 1.0), dv_weight_impact=np.full(nv, 1e-3))
+    x0 = np.tile(np.concatenate([Q_STAND, np.zeros(nv)]), (batch, 1))
+    x0[1, :7] = oracle.se3_integrate(Q_STAND[:7], np.array([0.01, 0.005, -0.005, 0.0, 0.02, 0.01]))
+    x0[1, nq:] = 0.02 * np.random.default_rng(3).uniform(-1, 1, nv)
+    ctx.set_initial_state(x0)
+    S = Records(ctx.L, "sol")
+    sol = S.zeros(batch, n)
+    mass = sum(m.mass[i] for i in range(m.njoints))
+    for b in range(batch):
+        q0 = x0[b, :nq]
+        for i in range(n):
+            act = [c for c in range(4) if (int(masks[i]) >> c) & 1]
+            S.f(sol[b, i], "q")[:nq] = q0
+            if act and grids[i].type != GRID_IMPACT:
+                S.f(sol[b, i], "f")[:3 * len(act)] = np.concatenate([oracle.rbd_contact_placement(m, q0, c)[0].T @ np.array([0.0, 0.0, 9.81 * mass / len(act)]) for c in act])
+    ctx.upload(BUF_SOL, sol)
+    hist = []
+    for it in range(100):
+        hist.append(ctx.contact_update_solution())
+        if hist[-1].max() < 1e-9:
+            break
+    hist = np.array(hist)
+    print("KKT error per iteration (worst instance):", ["%.1e" % e for e in hist.max(axis=1)])
+    assert (ctx.status() == 0).all() and hist[-1].max() < 1e-7
+    sol = ctx.download_records(BUF_SOL, "sol")
+    worst = dict(IDC=0.0, impact=0.0, switching=0.0, Fx=0.0)
+    for b in range(batch):
+        for i in range(n - 1):
+            s, sn, g = sol[b, i], sol[b, i + 1], grids[i]
+            act = int(masks[i])
+            q, v, a = S.f(s, "q")[:nq], S.f(s, "v"), S.f(s, "a")
+            qn, vn = S.f(sn, "q")[:nq], S.f(sn, "v")
+            r = oracle.rbd_eval(m, int(g.type == GRID_IMPACT), q, v, a, S.f(s, "f")[:12], S.f(s, "u")[:12], act, pos[i].reshape(-1))
+            key = "impact" if g.type == GRID_IMPACT else "IDC"
+            worst[key] = max(worst[key], np.abs(r).max())
+            if g.type == GRID_IMPACT:   # q+ = q, v+ = v + dv; the touching feet at their positions (impact_dynamics rows carry velocity only)
+                worst["Fx"] = max(worst["Fx"], np.abs(oracle.se3_difference(qn[:7], q[:7])).max(), np.abs(q[7:] - qn[7:]).max(), np.abs(v + a - vn).max())
+            else:
+                Fq = np.concatenate([oracle.se3_difference(qn[:7], q[:7]), q[7:] - qn[7:]]) + g.dt * v
+                worst["Fx"] = max(worst["Fx"], np.abs(Fq).max(), np.abs(v + g.dt * a - vn).max())
+            if g.switching_constraint:
+                dt1, dt2 = g.dt, grids[i + 1].dt
+                qp = oracle.rbd_integrate(m, q, (dt1 + dt2) * v + dt1 * dt2 * a)
+                imp = [c for c in range(4) if (int(masks[i + 2]) >> c) & 1]
+                worst["switching"] = max(worst["switching"], max(np.abs(oracle.rbd_contact_position(m, qp, c) - pos[i + 2, c]).max() for c in imp))
+    print("converged trot, worst residuals by the CPU restatement:", worst)
+    assert worst["IDC"] < 1e-7 and worst["impact"] < 1e-7 and worst["Fx"] < 1e-8 and worst["switching"] < 1e-8
+    # the swing feet are free in between: they leave the ground or stay, but the stance feet do not move
+    for i in range(n - 1):
+        q = S.f(sol[0, i], "q")[:nq]
+        for c in range(4):
+            if (int(masks[i]) >> c) & 1 and grids[i].type != GRID_IMPACT:
+                assert np.abs(oracle.rbd_contact_position(m, q, c) - pos[i, c]).max() < 5e-3
+    ctx.close()
