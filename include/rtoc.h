@@ -132,6 +132,10 @@ enum rtoc_option {
                       * cones; arguments kkt_tol / tau are part of the key).  For the single-OCP latency path, whose
                       * ~25 small kernels are launch-bound.  The calls stay asynchronous on the context's stream; the
                       * stream must not be capturing already.  Default 0. */
+  RTOC_OPT_IMPACT_CONES = 11, /* 1 (default): the friction / wrench cone rows also act on impact grids (a Constraints object
+                      * holding FrictionCone AND ImpactFrictionCone, examples/anymal/run.cpp:173-181); 0: impact grids carry no
+                      * cone rows (FrictionCone only, examples/anymal/trot.cpp:134-146) -- condensation, expansion, step
+                      * sizes, update and KKT error skip them. */
   RTOC_OPT_SWITCHING_TRANSPORT = 10 /* Free-flyer block of Phiq / Phiv / Phia in rtoc_contact_eval_kkt's switching-constraint
                       * rows.  0 (default): as the reference composes it -- it hands pinocchio::dIntegrateTransport the
                       * transposed Jacobian (robot.hxx:69-72, :88-91), which yields Pq dIntegrate^T.  1: the chain rule

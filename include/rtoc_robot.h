@@ -91,6 +91,23 @@ int rtoc_linearize_contact_dynamics(rtoc_ctx* ctx, int augment_residual);
  * rtoc_set_robot_model, rtoc_set_contact_schedule, rtoc_set_configuration_cost, rtoc_set_initial_state.
  * RTOC_ERR_BAD_ARG for a switching constraint on a model with surface contacts (point contacts only). */
 int rtoc_contact_eval_kkt(rtoc_ctx* ctx);
+
+/* ---- inequality rows of the contact path evaluated on the device (the Constraints object of examples/anymal/trot.cpp:
+ * six joint-limit components + FrictionCone) ----
+ * Joint limits: the rows of rtoc_set_constraint_rows with their bounds from rtoc_set_constraint_bounds.  Friction cones: the
+ * rows of rtoc_set_friction_cones with ContactStatus::frictionCoefficient(k) from rtoc_set_friction_coefficients
+ * (mu[k] > 0, k < ncontacts <= RTOC_MAX_CONTACTS) and contactRotation(k) from rtoc_set_contact_schedule's rotations; whether
+ * impact grids carry them: RTOC_OPT_IMPACT_CONES.  Once bounds / coefficients are on the device, rtoc_contact_eval_kkt also
+ * runs Constraints::linearizeConstraints for those rows -- residual = g + slack, cmpl = slack dual - barrier, the cone
+ * Jacobians into RTOC_BUF_CONE, l += dg^T dual (joint_position_lower_limit.cpp:58-77 and its siblings, friction_cone.cpp:
+ * 119-191) -- and rtoc_newton_iteration condenses, expands and updates them as before.  Rows without bounds / cones without
+ * coefficients stay host-evaluated (RTOC_BUF_CON / RTOC_BUF_CONE uploaded by the caller).
+ * rtoc_set_barrier_param: Constraints::setBarrierParam / setFractionToBoundaryRule (also set by rtoc_set_constraint_bounds).
+ * rtoc_contact_init_constraints: OCPSolver::initConstraints (src/solver/ocp_solver.cpp:92-96) -- slack = -g clipped at
+ * sqrt(barrier), dual = barrier / slack (pdipm.hxx:12-23) at the iterate in RTOC_BUF_SOL; zeroes RTOC_BUF_CON first. */
+int rtoc_set_barrier_param(rtoc_ctx* ctx, double barrier_param, double fraction_to_boundary_rule);
+int rtoc_set_friction_coefficients(rtoc_ctx* ctx, const double* mu, int ncontacts);
+int rtoc_contact_init_constraints(rtoc_ctx* ctx);
 /* OCPSolver::updateSolution (src/solver/ocp_solver.cpp:111-145) for that OCP, one launch sequence: rtoc_contact_eval_kkt,
  * then rtoc_newton_iteration(ctx, 0, fraction_to_boundary_rule).  host_kkt_error[count <= batch] (may be NULL / 0): the KKT
  * error of the iterate it linearised at. */

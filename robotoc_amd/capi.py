@@ -10,7 +10,7 @@ import subprocess
 import numpy as np
 
 from .types import (BoxRow, BUF_CDD, BUF_CON, BUF_DIR, BUF_DX0, BUF_KKT, BUF_RIC, BUF_STEP, Dims, Grid,
-                    Layout, OPT_BACKWARD_WAVES, OPT_CONDENSE_SPLIT, OPT_CONDENSE_KEEP_QAF, OPT_FXX_STRUCTURE, OPT_GRAPH, OPT_SWITCHING_TRANSPORT, OPT_MAX_DTS0, OPT_SWEEP_CHUNKS, OPT_WRITEBACK_KKT, OPT_BACKWARD_SCAN,
+                    Layout, OPT_BACKWARD_WAVES, OPT_CONDENSE_SPLIT, OPT_CONDENSE_KEEP_QAF, OPT_FXX_STRUCTURE, OPT_GRAPH, OPT_SWITCHING_TRANSPORT, OPT_IMPACT_CONES, OPT_MAX_DTS0, OPT_SWEEP_CHUNKS, OPT_WRITEBACK_KKT, OPT_BACKWARD_SCAN,
                     grid_array)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -29,6 +29,7 @@ EXPORTS = [
     "rtoc_set_robot_model", "rtoc_set_contact_schedule", "rtoc_linearize_contact_dynamics",
     "rtoc_line_search_filter", "rtoc_line_search_clear", "rtoc_set_configuration_cost", "rtoc_set_initial_state",
     "rtoc_unconstr_eval_kkt", "rtoc_unconstr_update_solution", "rtoc_set_constraint_bounds", "rtoc_unconstr_init_constraints", "rtoc_linearize_state_equation", "rtoc_contact_eval_kkt", "rtoc_contact_update_solution",
+    "rtoc_set_barrier_param", "rtoc_set_friction_coefficients", "rtoc_contact_init_constraints",
 ]
 
 
@@ -138,6 +139,9 @@ def lib():
         L.rtoc_unconstr_eval_kkt.argtypes = [vp, C.c_double]
         L.rtoc_set_constraint_bounds.argtypes = [vp, dp, C.c_int, C.c_double, C.c_double]
         L.rtoc_unconstr_init_constraints.argtypes = [vp]
+        L.rtoc_contact_init_constraints.argtypes = [vp]
+        L.rtoc_set_barrier_param.argtypes = [vp, C.c_double, C.c_double]
+        L.rtoc_set_friction_coefficients.argtypes = [vp, dp, C.c_int]
         L.rtoc_unconstr_update_solution.argtypes = [vp, C.c_double, dp, C.c_int]
         L.rtoc_contact_update_solution.argtypes = [vp, C.c_double, dp, C.c_int]
         L.rtoc_line_search_filter.argtypes = [vp, dp, dp, C.POINTER(C.c_int), C.c_int, C.c_double, C.c_double, C.POINTER(C.c_int)]
@@ -399,6 +403,22 @@ class Context:
     def set_constraint_bounds(self, bounds, barrier_param=1.0e-3, fraction_to_boundary_rule=0.995):
         bounds = np.ascontiguousarray(bounds, dtype=np.float64)
         _chk(lib().rtoc_set_constraint_bounds(self._h, _dp(bounds), bounds.size, barrier_param, fraction_to_boundary_rule))
+
+    def set_barrier_param(self, barrier_param=1.0e-3, fraction_to_boundary_rule=0.995):
+        _chk(lib().rtoc_set_barrier_param(self._h, barrier_param, fraction_to_boundary_rule))
+
+    def set_friction_coefficients(self, mu):
+        """ContactStatus::frictionCoefficient per contact: switches the device-side evaluation of the friction-cone rows on"""
+        mu = np.ascontiguousarray(mu, dtype=np.float64)
+        _chk(lib().rtoc_set_friction_coefficients(self._h, _dp(mu), mu.size))
+
+    def contact_init_constraints(self):
+        """OCPSolver::initConstraints for the rows evaluated on the device (joint limits with bounds, friction cones with mu)"""
+        _chk(lib().rtoc_contact_init_constraints(self._h))
+
+    def set_impact_cones(self, on):
+        """RTOC_OPT_IMPACT_CONES: cone rows on impact grids (ImpactFrictionCone) or not"""
+        _chk(lib().rtoc_set_option(self._h, OPT_IMPACT_CONES, int(bool(on))))
 
     def unconstr_init_constraints(self):
         _chk(lib().rtoc_unconstr_init_constraints(self._h))

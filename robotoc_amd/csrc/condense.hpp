@@ -69,7 +69,7 @@ struct CondArgs {
   int cone_rows;
   const double* cone;
   double* cone_con;  // constraint records (the box rows' `con` may be null when only cones are set)
-  int cone_contacts, cone_dim, cone_row0, cone_stride, cone_dgdf_off;
+  int cone_contacts, cone_dim, cone_row0, cone_stride, cone_dgdf_off, cone_impact;
   int keep_qaf;  // RTOC_OPT_CONDENSE_KEEP_QAF: also store Qafqv / Qafu_full in the ContactDynamicsData record
 };
 
@@ -823,6 +823,7 @@ __global__ __launch_bounds__(64) void mjtjinv_kernel(CondArgs a) {
     ca.rows_per_contact = a.cone_rows;
     ca.cone_stride = a.cone_stride;
     ca.dgdf_off = a.cone_dgdf_off;
+    ca.impact_cones = a.cone_impact;
     ca.tau = 0.0;
     ca.kl = a.kl;
     ca.cl = a.cl;

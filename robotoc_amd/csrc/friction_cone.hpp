@@ -29,6 +29,7 @@ struct ConeArgs {
   int nstages, batch;
   int max_contacts, contact_dim, row0, rows_per_contact;
   int cone_stride, dgdf_off;
+  int impact_cones;  // RTOC_OPT_IMPACT_CONES: 0 = no rows on impact grids (a Constraints object without ImpactFrictionCone)
   double tau;
   rtoc_record_layout kl, cl, nl, dl;
   long long* prof;
@@ -38,6 +39,11 @@ struct ConeArgs {
 #else
 #define RTOC_KPROF(k) do { } while (0)
 #endif
+
+// active contacts of a grid point that carry cone rows
+__device__ __forceinline__ int cone_nact(const rtoc_grid& g, int contact_dim, int impact_cones) {
+  return (g.type == RTOC_GRID_IMPACT && !impact_cones) ? 0 : g.dimf / contact_dim;
+}
 
 // the LDS writes of this wave become visible to its other lanes (one wave per grid point: no s_barrier needed)
 __device__ __forceinline__ void cone_wave_sync() {
@@ -165,7 +171,7 @@ __device__ __forceinline__ void cone_condense_body_cd(const ConeArgs& a, const i
           ce[ta][tb][r] = *(p ? p : cr);
         }
       }
-  const int nact = a.grid[st].dimf / cd;
+  const int nact = cone_nact(a.grid[st], cd, a.impact_cones);
   if (nact == 0) return;
   RTOC_KPROF(25);
   // ---- G, diag R and the rider column into LDS
@@ -243,7 +249,7 @@ __global__ __launch_bounds__(64) void cone_expand_kernel(ConeArgs a) {
   const int b = item / nst1, st = item % nst1;
   if (b >= a.batch) return;
   const rtoc_grid g = a.grid[st];
-  const int nact = g.dimf / a.contact_dim;
+  const int nact = cone_nact(g, a.contact_dim, a.impact_cones);
   if (nact == 0) return;
   const size_t rec = (size_t)b * a.nstages + st;
   double* nr = a.con + rec * a.nl.stride;
@@ -286,7 +292,7 @@ static __global__ __launch_bounds__(64) void cone_update_kernel(ConeArgs a) {
   const int nst1 = a.nstages - 1;
   const int b = item / nst1, st = item % nst1;
   if (b >= a.batch) return;
-  const int nact = a.grid[st].dimf / a.contact_dim;
+  const int nact = cone_nact(a.grid[st], a.contact_dim, a.impact_cones);
   if (lane >= a.rows_per_contact * nact) return;  // <= 5*4 friction rows, <= 17*2 wrench rows
   double* nr = a.con + ((size_t)b * a.nstages + st) * a.nl.stride;
   const double* steps = reinterpret_cast<const double*>(a.steps);
@@ -345,7 +351,7 @@ __device__ __forceinline__ void wrench_condense_body(const ConeArgs& a, const in
         const double* const p = target(16 * ta + drow(q, r), 16 * tb + li, kc);
         ce[ta][tb][r] = *(p ? p : cr);
       }
-  const int nact = a.grid[st].dimf / 6;
+  const int nact = cone_nact(a.grid[st], 6, a.impact_cones);
   // inactive rows keep cond = 0 like data.cond.setZero() (:213)
   if (lane >= WR * nact && lane < WR * a.max_contacts) nr[a.nl.off[RTOC_CON_COND] + a.row0 + lane] = 0.0;
   if (nact == 0) return;
@@ -401,7 +407,7 @@ __global__ __launch_bounds__(64) void wrench_expand_kernel(ConeArgs a) {
   const int nst1 = a.nstages - 1;
   const int b = item / nst1, st = item % nst1;
   if (b >= a.batch) return;
-  const int nact = a.grid[st].dimf / 6;
+  const int nact = cone_nact(a.grid[st], 6, a.impact_cones);
   if (nact == 0) return;
   const size_t rec = (size_t)b * a.nstages + st;
   double* nr = a.con + rec * a.nl.stride;

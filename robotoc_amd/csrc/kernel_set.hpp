@@ -28,6 +28,14 @@ typedef void (*cond_fn)(CondArgs);
 typedef void (*expd_fn)(ExpArgs);
 typedef void (*scan_fn)(ScanArgs);
 typedef void (*fscan_fn)(FwdScanArgs);
+// what a shape plugin must agree on with the runtime that loads it: the kernel-set table and every argument block
+constexpr size_t kernel_abi_stamp() {
+  size_t h = 1469598103934665603ull;
+  const size_t parts[] = {sizeof(BwdArgs), sizeof(FwdArgs), sizeof(FillArgs), sizeof(UdArgs), sizeof(ConeArgs), sizeof(CondArgs),
+                          sizeof(ExpArgs), sizeof(ScanArgs), sizeof(FwdScanArgs)};
+  for (size_t v : parts) h = (h ^ v) * 1099511628211ull;
+  return h;
+}
 
 struct KernelSet {
   int nv, nu, ns;

@@ -24,7 +24,7 @@ struct KktErrArgs {
   const rtoc_grid* grid;
   double* out;         // [batch] sqrt of the sum
   double* partial;     // [batch][nstages] squared residual per grid point
-  int nstages, batch, nrows, cone_contacts, cone_dim, cone_rows, nc_max;
+  int nstages, batch, nrows, cone_contacts, cone_dim, cone_rows, nc_max, impact_cones;
   int nv, nu, np, nx;
   rtoc_record_layout kl, cl, nl;
 };
@@ -70,7 +70,7 @@ static __global__ __launch_bounds__(64) void kkt_error_kernel(KktErrArgs a) {
               const double x = nr[a.nl.off[RTOC_CON_RESIDUAL] + r], y = nr[a.nl.off[RTOC_CON_CMPL] + r];
               acc += x * x + y * y;
             }
-        if (a.cone_contacts > 0) {
+        if (a.cone_contacts > 0 && (!impact || a.impact_cones)) {
           const int row0 = a.nc_max - a.cone_rows * a.cone_contacts, n = a.cone_rows * (g.dimf / a.cone_dim);
           for (int r = lane; r < n; r += 64) {
             const double x = nr[a.nl.off[RTOC_CON_RESIDUAL] + row0 + r], y = nr[a.nl.off[RTOC_CON_CMPL] + row0 + r];

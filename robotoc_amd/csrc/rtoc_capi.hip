@@ -17,6 +17,7 @@
 #include "unconstr_constraints.hpp"
 #include "state_equation_lin.hpp"
 #include "switching_constraint_lin.hpp"
+#include "contact_constraints.hpp"
 #include "contact_eval_kkt.hpp"
 
 using namespace rtoc;
@@ -90,10 +91,10 @@ static const KernelSet* load_plugin(const rtoc_dims* d) {
   }
 #endif
   if (!h) return nullptr;
-  typedef int (*entry_t)(KernelSet*, size_t);
+  typedef int (*entry_t)(KernelSet*, size_t, size_t);
   entry_t entry = (entry_t)dlsym(h, "rtoc_shape_plugin");
   KernelSet k;
-  if (!entry || entry(&k, sizeof(KernelSet)) != 0 || k.nv != d->nv || k.nu != d->nu || k.ns != d->ns_max) {
+  if (!entry || entry(&k, sizeof(KernelSet), kernel_abi_stamp()) != 0 || k.nv != d->nv || k.nu != d->nu || k.ns != d->ns_max) {
     dlclose(h);
     return nullptr;
   }
@@ -160,7 +161,9 @@ struct rtoc_ctx {
   double* d_sto;       // rtoc_sto_eval_kkt staging: lt, diag(Qtt), squared error
   // RTOC_OPT_GRAPH: launch sequences replayed from captured hipGraphs
   int use_graph;
-  int exact_transport = 0;  // RTOC_OPT_SWITCHING_TRANSPORT
+  int exact_transport;  // RTOC_OPT_SWITCHING_TRANSPORT
+  int impact_cones;     // RTOC_OPT_IMPACT_CONES (default 1, rtoc_create)
+  double* d_mu;         // rtoc_set_friction_coefficients
   unsigned long long epoch;  // bumped by everything that changes a launch parameter baked into a captured graph
   struct GraphSlot {
     hipGraphExec_t exec;
@@ -307,6 +310,7 @@ int rtoc_create(const rtoc_dims* dims, int max_stages, int batch, int device, rt
   if (!c) return RTOC_ERR_BAD_ARG;
   memset(c, 0, sizeof(*c));
   c->device = device;
+  c->impact_cones = 1;
   int rc = create_members(c, dims, ks, max_stages, batch, device);
   if (rc) {
     (void)rtoc_destroy(c);
@@ -340,6 +344,7 @@ int rtoc_destroy(rtoc_ctx* c) {
   if (c->d_active) (void)hipFree(c->d_active);
   if (c->d_cost) (void)hipFree(c->d_cost);
   if (c->d_bounds) (void)hipFree(c->d_bounds);
+  if (c->d_mu) (void)hipFree(c->d_mu);
   if (c->d_x0) (void)hipFree(c->d_x0);
   if (c->d_filter) (void)hipFree(c->d_filter);
   if (c->d_nfilter) (void)hipFree(c->d_nfilter);
@@ -389,6 +394,7 @@ int rtoc_clone(rtoc_ctx* c, rtoc_ctx** out) {
     n->fxx_mode = c->fxx_mode;
     n->use_graph = c->use_graph;
     n->exact_transport = c->exact_transport;
+    n->impact_cones = c->impact_cones;
     if (c->backward_scan) rc = rtoc_set_option(n, RTOC_OPT_BACKWARD_SCAN, c->backward_scan);
   }
   hipError_t e = hipStreamSynchronize(c->stream);
@@ -412,6 +418,7 @@ int rtoc_clone(rtoc_ctx* c, rtoc_ctx** out) {
   dup((void**)&n->d_cost, c->d_cost, sizeof(double) * 12 * (c->dims.nv + 1));
   dup((void**)&n->d_x0, c->d_x0, sizeof(double) * c->batch * (2 * c->dims.nv + (c->dims.np == 6 ? 1 : 0)));
   dup((void**)&n->d_bounds, c->d_bounds, sizeof(double) * c->dims.nc_max);
+  dup((void**)&n->d_mu, c->d_mu, sizeof(double) * RTOC_MAX_CONTACTS);
   n->barrier = c->barrier, n->ftb_rule = c->ftb_rule;
   if (c->d_filter) {
     dup((void**)&n->d_filter, c->d_filter, sizeof(double) * 2 * RTOC_LINE_SEARCH_FILTER_CAPACITY * c->batch);
@@ -492,6 +499,9 @@ int rtoc_set_option(rtoc_ctx* c, int option, int64_t value) {
       c->max_dts0 = d;
       return RTOC_OK;
     }
+    case RTOC_OPT_IMPACT_CONES:
+      c->impact_cones = value ? 1 : 0;
+      return RTOC_OK;
     case RTOC_OPT_SWITCHING_TRANSPORT:
       c->exact_transport = value ? 1 : 0;
       return RTOC_OK;
@@ -847,6 +857,7 @@ static int launch_condense(rtoc_ctx* c) {
     a.cone_row0 = c->dims.nc_max - c->cone_rows * c->cone_contacts;
     a.cone_stride = wrench ? rtoc_wrench_cone_stride(c->cone_contacts) : rtoc_cone_stride(c->dims.nv, c->cone_contacts);
     a.cone_dgdf_off = rtoc_cone_dgdf_off(c->dims.nv, c->cone_contacts);
+    a.cone_impact = c->impact_cones;
   }
   if (c->condense_split) {
     hipLaunchKernelGGL(c->ks->mjt, dim3(nblocks), dim3(64), c->ks->mjt_lds, c->stream, a);
@@ -905,6 +916,7 @@ static int launch_cones(rtoc_ctx* c, int phase, double tau) {  // 0 condense, 1 
   a.row0 = c->dims.nc_max - c->cone_rows * c->cone_contacts;
   a.cone_stride = wrench ? rtoc_wrench_cone_stride(c->cone_contacts) : rtoc_cone_stride(c->dims.nv, c->cone_contacts);
   a.dgdf_off = rtoc_cone_dgdf_off(c->dims.nv, c->cone_contacts);
+  a.impact_cones = c->impact_cones;
   a.tau = tau;
   a.kl = c->L.kkt;
   a.cl = c->L.cdd;
@@ -1555,7 +1567,7 @@ int rtoc_set_constraint_bounds(rtoc_ctx* c, const double* bounds, int nrows, dou
   return RTOC_OK;
 }
 
-static int launch_ubox(rtoc_ctx* c, int mode) {
+static int launch_ubox(rtoc_ctx* c, int mode, bool contact = false) {
   UboxArgs a;
   a.sol = c->buf[RTOC_BUF_SOL];
   a.kkt = c->buf[RTOC_BUF_KKT];
@@ -1567,7 +1579,7 @@ static int launch_ubox(rtoc_ctx* c, int mode) {
   a.bounds = c->d_bounds;
   a.grid = c->d_grid;
   a.steps = (unsigned long long*)c->buf[RTOC_BUF_STEP];
-  a.nstages = c->nstages, a.batch = c->batch, a.nrows = c->nrows, a.nv = c->dims.nv, a.mode = mode;
+  a.nstages = c->nstages, a.batch = c->batch, a.nrows = c->nrows, a.nv = c->dims.nv, a.nu = c->dims.nu, a.mode = mode;
   a.barrier = c->barrier, a.tau = c->ftb_rule;
   a.sol_stride = c->L.sol.stride, a.kkt_stride = c->L.kkt.stride, a.cdd_stride = c->L.cdd.stride;
   a.con_stride = c->L.con.stride, a.dir_stride = c->L.dir.stride;
@@ -1576,6 +1588,9 @@ static int launch_ubox(rtoc_ctx* c, int mode) {
   a.o_qaa = c->L.cdd.off[RTOC_CDD_QAA], a.o_la = c->L.cdd.off[RTOC_CDD_LA];
   a.o_dx = c->L.dir.off[RTOC_DIR_DX], a.o_du = c->L.dir.off[RTOC_DIR_DU];
   a.nl = c->L.con;
+  a.contact = contact ? 1 : 0;
+  a.q_shift = (contact && c->dims.np == 6) ? 1 : 0;
+  a.o_lu = c->L.kkt.off[RTOC_KKT_LU];
   hipLaunchKernelGGL(unconstr_box_kernel, dim3(c->batch * (c->nstages - 1)), dim3(64), 0, c->stream, a);
   HIP_TRY(hipGetLastError());
   return RTOC_OK;
@@ -1646,6 +1661,7 @@ static int launch_kkt_error(rtoc_ctx* c) {
   a.cone_contacts = c->cone_contacts;
   a.cone_dim = c->cone_dim > 0 ? c->cone_dim : 3;
   a.cone_rows = c->cone_rows;
+  a.impact_cones = c->impact_cones;
   a.nc_max = c->dims.nc_max;
   a.nv = c->dims.nv;
   a.nu = c->dims.nu;
@@ -1674,6 +1690,77 @@ int rtoc_kkt_error(rtoc_ctx* c, double* host_out, int count) {
 
 // ---- evalKKT / updateSolution of the contact path closed on the device (ConfigurationSpaceCost, no inequality rows) ----
 int rtoc_newton_iteration(rtoc_ctx* c, double kkt_tol, double tau);
+// ---- inequality rows of the contact path evaluated on the device --------------------------------------------
+int rtoc_set_barrier_param(rtoc_ctx* c, double barrier_param, double fraction_to_boundary_rule) {
+  if (!c) return RTOC_ERR_BAD_ARG;
+  if (!(barrier_param > 0.0) || !(fraction_to_boundary_rule > 0.0) || !(fraction_to_boundary_rule < 1.0)) return RTOC_ERR_BAD_ARG;
+  c->barrier = barrier_param;
+  c->ftb_rule = fraction_to_boundary_rule;
+  c->epoch++;
+  return RTOC_OK;
+}
+
+int rtoc_set_friction_coefficients(rtoc_ctx* c, const double* mu, int ncontacts) {
+  if (!c || !mu || ncontacts < 1 || ncontacts > RTOC_MAX_CONTACTS) return RTOC_ERR_BAD_ARG;
+  for (int i = 0; i < ncontacts; ++i)
+    if (!(mu[i] > 0.0)) return RTOC_ERR_BAD_ARG;   // ContactStatus::setFrictionCoefficient
+  HIP_TRY(hipSetDevice(c->device));
+  if (!c->d_mu) HIP_TRY(hipMalloc((void**)&c->d_mu, sizeof(double) * RTOC_MAX_CONTACTS));
+  HIP_TRY(hipMemcpyAsync(c->d_mu, mu, sizeof(double) * ncontacts, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return RTOC_OK;
+}
+
+static bool device_cones_on(const rtoc_ctx* c) { return c->cone_contacts > 0 && c->cone_rows == RTOC_FRICTION_ROWS && c->d_mu != nullptr; }
+
+static int launch_contact_cones(rtoc_ctx* c, int mode) {
+  const rtoc_robot_model& m = c->h_model->m;
+  if (m.ncontacts > c->cone_contacts) return RTOC_ERR_BAD_ARG;
+  for (int k = 0; k < m.ncontacts; ++k)
+    if ((m.contact_type[k] == RTOC_CONTACT_SURFACE ? 6 : 3) != c->cone_dim) return RTOC_ERR_BAD_ARG;
+  CcArgs a;
+  a.model = c->d_model;
+  a.sol = c->buf[RTOC_BUF_SOL];
+  a.kkt = c->buf[RTOC_BUF_KKT];
+  a.cdd = c->buf[RTOC_BUF_CDD];
+  a.con = c->buf[RTOC_BUF_CON];
+  a.cone = c->buf[RTOC_BUF_CONE];
+  a.grid = c->d_grid;
+  a.active = c->d_active;
+  a.rotations = c->has_crot ? c->d_crot : nullptr;
+  a.mu = c->d_mu;
+  a.nstages = c->nstages, a.batch = c->batch, a.nv = m.nv, a.njoints = m.njoints, a.ncontacts = m.ncontacts;
+  a.nlevels = c->h_model->nlevels, a.mode = mode;
+  a.contact_dim = c->cone_dim, a.row0 = c->dims.nc_max - RTOC_FRICTION_ROWS * c->cone_contacts;
+  a.cone_stride = rtoc_cone_stride(c->dims.nv, c->cone_contacts), a.dgdf_off = rtoc_cone_dgdf_off(c->dims.nv, c->cone_contacts);
+  a.impact_cones = c->impact_cones;
+  a.barrier = c->barrier;
+  a.sol_stride = c->L.sol.stride, a.kkt_stride = c->L.kkt.stride, a.cdd_stride = c->L.cdd.stride, a.con_stride = c->L.con.stride;
+  a.o_q = c->L.sol.off[RTOC_SOL_Q], a.o_f = c->L.sol.off[RTOC_SOL_F], a.o_lx = c->L.kkt.off[RTOC_KKT_LX], a.o_lf = c->L.cdd.off[RTOC_CDD_LF];
+  a.nl = c->L.con;
+  const size_t lds = cc_lds_bytes(a.nlevels, a.njoints, a.ncontacts);
+  HIP_TRY(hipFuncSetAttribute((const void*)contact_cone_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(contact_cone_kernel, dim3(c->batch * (c->nstages - 1)), dim3(64), lds, c->stream, a);
+  HIP_TRY(hipGetLastError());
+  return RTOC_OK;
+}
+
+// OCPSolver::initConstraints (src/solver/ocp_solver.cpp:92-96 -> DirectMultipleShooting::initConstraints): setSlackAndDual of
+// the joint-limit rows (those with bounds on the device) and of the friction-cone rows (those with friction coefficients)
+int rtoc_contact_init_constraints(rtoc_ctx* c) {
+  CHECK_READY(c);
+  if (!c->buf[RTOC_BUF_SOL] || !(c->barrier > 0.0)) return RTOC_ERR_NOT_READY;
+  const bool rows = c->nrows > 0 && c->d_bounds != nullptr, cones = device_cones_on(c);
+  if (!rows && !cones) return RTOC_ERR_NOT_READY;
+  if (cones && (!c->h_model || !c->d_active)) return RTOC_ERR_NOT_READY;
+  int rc = ensure_buffer(c, RTOC_BUF_CON);
+  if (rc) return rc;
+  HIP_TRY(hipMemsetAsync(c->buf[RTOC_BUF_CON], 0, sizeof(double) * c->count[RTOC_BUF_CON], c->stream));
+  if (rows) rc = launch_ubox(c, UBOX_INIT, true);
+  if (!rc && cones) rc = launch_contact_cones(c, CC_INIT);
+  return rc;
+}
+
 // linearizeSwitchingConstraint (src/dynamics/switching_constraint.cpp:26-70) on the grids that carry one
 static int launch_switching_constraint(rtoc_ctx* c) {
   const rtoc_robot_model& m = c->h_model->m;
@@ -1724,7 +1811,10 @@ int rtoc_contact_eval_kkt(rtoc_ctx* c) {
   a.kl = c->L.kkt, a.cl = c->L.cdd;
   hipLaunchKernelGGL(contact_cost_kernel, dim3(c->batch * c->nstages), dim3(64), 0, c->stream, a);
   HIP_TRY(hipGetLastError());
-  rc = rtoc_linearize_state_equation(c);
+  // constraints_->linearizeConstraints (intermediate_stage.cpp:109-110, impact_stage.cpp:95-96) of the rows evaluated here
+  if (c->nrows > 0 && c->d_bounds && c->buf[RTOC_BUF_CON]) rc = launch_ubox(c, UBOX_LINEARIZE, true);
+  if (!rc && device_cones_on(c) && c->buf[RTOC_BUF_CON]) rc = launch_contact_cones(c, CC_LINEARIZE);
+  if (!rc) rc = rtoc_linearize_state_equation(c);
   if (!rc) rc = launch_linearize(c, 1, false, 1.0);
   if (!rc && switching) rc = launch_switching_constraint(c);
   return rc;

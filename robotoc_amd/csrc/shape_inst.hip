@@ -19,8 +19,9 @@ KernelSet RTOC_SHAPE_FN() {
 #ifdef RTOC_SHAPE_PLUGIN
 // Built on its own (make plugin SHAPE=nv:nu:ns:nw0:nw1 -> ../librtoc_shape_<nv>_<nu>_<ns>.so): the host runtime loads the
 // kernel set of a shape that is not in its compiled-in table through this one entry point (rtoc_capi.hip: load_plugin).
-extern "C" int rtoc_shape_plugin(rtoc::KernelSet* out, size_t size_of_kernel_set) {
-  if (!out || size_of_kernel_set != sizeof(rtoc::KernelSet)) return -1;  // built from another revision of kernel_set.hpp
+extern "C" int rtoc_shape_plugin(rtoc::KernelSet* out, size_t size_of_kernel_set, size_t abi_stamp) {
+  // built from another revision of the kernel headers (table or argument blocks differ): refuse
+  if (!out || size_of_kernel_set != sizeof(rtoc::KernelSet) || abi_stamp != rtoc::kernel_abi_stamp()) return -1;
   *out = rtoc::RTOC_SHAPE_FN();
   return 0;
 }

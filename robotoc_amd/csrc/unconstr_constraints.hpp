@@ -13,6 +13,9 @@
 // with g = sign * z - bound (rtoc_box_row), z an entry of q, v or u.  Record convention of the unconstrained path
 // (rtoc_unconstr_condense): the u rows act on CDD.la (= lu) and CDD.Qaa (= diag Quu); q / v rows on KKT.lx and diag Qxx.
 // A row is active on a grid point iff time_stage >= level, never on the terminal one (constraints_data.cpp:20-45).
+// The contact path (rtoc_contact_init_constraints / rtoc_contact_eval_kkt) uses INIT and LINEARIZE with `contact` set: the
+// u rows then act on KKT.lu, impact grids (time_stage = -1) carry no rows; condensation and expansion of the rows are the
+// contact path's own kernels (condense.hpp).
 #pragma once
 #include "device_utils.hpp"
 #include "../../include/rtoc.h"
@@ -30,13 +33,15 @@ struct UboxArgs {
   const double* bounds;
   const rtoc_grid* grid;
   unsigned long long* steps;  // [batch][2] bit patterns
-  int nstages, batch, nrows, nv, mode;
+  int nstages, batch, nrows, nv, nu, mode;
   double barrier, tau;
   int sol_stride, kkt_stride, cdd_stride, con_stride, dir_stride;
   int o_q, o_v, o_u;            // RTOC_BUF_SOL
   int o_qxx, o_lx;              // RTOC_BUF_KKT
   int o_qaa, o_la;              // RTOC_BUF_CDD (diag Quu, lu)
   int o_dx, o_du;               // RTOC_BUF_DIR
+  int contact;                  // contact path (rtoc_contact_eval_kkt): the u rows act on KKT.lu; INIT / LINEARIZE only
+  int q_shift, o_lu;            // nq - nv (the joint entries of q sit one further with a free-flyer's quaternion)
   rtoc_record_layout nl;
 };
 enum { UBOX_INIT = 0, UBOX_LINEARIZE = 1, UBOX_CONDENSE = 2, UBOX_EXPAND = 3 };
@@ -57,12 +62,12 @@ static __global__ __launch_bounds__(64) void unconstr_box_kernel(UboxArgs a) {
   const int nv = a.nv, nx = 2 * nv;
   double fp = 1.0, fd = 1.0;
   auto value_of = [&](const rtoc_box_row& w) {
-    return w.var == RTOC_VAR_Q ? s[a.o_q + w.index] : w.var == RTOC_VAR_V ? s[a.o_v + w.index] : s[a.o_u + w.index];
+    return w.var == RTOC_VAR_Q ? s[a.o_q + w.index + a.q_shift] : w.var == RTOC_VAR_V ? s[a.o_v + w.index] : s[a.o_u + w.index];
   };
   if (a.mode == UBOX_LINEARIZE || a.mode == UBOX_CONDENSE) {
     // one lane per primal entry, its rows in row order: a lower and an upper limit meet on the same entry, and every
     // entry is accumulated by a single lane (deterministic, no atomics) -- like the box rows of condense_kernel
-    const int ne = 3 * nv;
+    const int ne = 2 * nv + a.nu;
     const int* const rowid = a.entry + (ne + 1);
     for (int t = lane; t < ne; t += 64) {
       double grad = 0.0, hess = 0.0;
@@ -82,7 +87,10 @@ static __global__ __launch_bounds__(64) void unconstr_box_kernel(UboxArgs a) {
           grad += w.sign * cond;
         }
       }
-      if (t < 2 * nv) {
+      if (a.contact) {   // LINEARIZE only: the condensation of these rows is condense_kernel's
+        if (t < 2 * nv) kr[a.o_lx + t] += grad;
+        else if (a.entry[t + 1] > a.entry[t]) kr[a.o_lu + (t - 2 * nv)] += grad;
+      } else if (t < 2 * nv) {
         kr[a.o_lx + t] += grad;
         kr[a.o_qxx + t + (size_t)t * nx] += hess;
       } else {
