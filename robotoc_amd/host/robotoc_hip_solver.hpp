@@ -93,6 +93,9 @@ class StageDataSource {
   // Fqq_prev of grid point 0 and the initial state direction; host-side sources ignore it
   virtual void setInitialState(rtoc_ctx*, const Vec&, const Vec&) {}
   virtual void linearize(rtoc_ctx* ctx, const Solution& s) = 0;
+  // slack / dual start values (OCPSolver::initConstraints).  Host-side sources deliver them with the linearised stage data
+  // (RTOC_BUF_CON), so the default only pulls the first linearisation in; device-side sources initialise them there.
+  virtual void initConstraints(rtoc_ctx* ctx, const Solution& s) { linearize(ctx, s); }
   virtual void initialStateDirection(const Vec& q, const Vec& v, const Solution& s, Vec& dx0) const = 0;
   // true: linearize() already left computeInitialStateDirection's result in RTOC_BUF_DX0 (nothing to compute or upload here)
   virtual bool initialStateDirectionOnDevice() const { return false; }
@@ -278,7 +281,7 @@ class DirectMultipleShooting {
   // linearised stage data the source delivers (RTOC_BUF_CON), so this only pulls the first linearisation in.
   void initConstraints(const TimeDiscretization& td, const Solution& s) {
     RiccatiRecursion::setGridOf(ctx(), td);
-    source_->linearize(ctx(), s);
+    source_->initConstraints(ctx(), s);
   }
   // isFeasible (direct_multiple_shooting.cpp:72-97): all slacks positive
   bool isFeasible(const TimeDiscretization& td, const Solution&) {

@@ -201,3 +201,86 @@ def test_ocp_solver_with_device_linearisation_solves_anymal_standing(tmp_path, o
     ref = S.f(ctx.download_records(BUF_SOL, "sol")[0], "q")[:, :nq]
     assert np.array_equal(traj, ref)
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_ocp_solver_constrained_trot_on_the_device(tmp_path, oracle):
+    """robotoc::OCPSolver::solve over ConfigurationCostSource with joint limits and friction cones on BASELINE configs[1]'s
+    contact sequence (47 grid points: lifts, touch-downs with switching constraints): every part of the iteration on the
+    device, and bit-identical to the same launch sequence driven through ctypes."""
+    from robotoc_amd import capi, robot_model as rm
+    from robotoc_amd.problems import config_anymal_trot
+    from robotoc_amd.robot_model import MAX_JOINTS
+    from robotoc_amd.types import GRID_IMPACT, joint_limit_rows
+    from test_cpp_host import _build
+    from test_contact_closed_loop import Q_STAND
+    from test_contact_constraints import limits
+    from test_switching_constraint_lin import trot_masks
+    exe = _build("ocp_solver_trot_test")
+    m = rm.load_named("anymal")
+    dims, grids, _ = config_anymal_trot()
+    n, nv, nq, nu = len(grids), m.nv, m.nq, 12
+    masks = trot_masks(grids, [0b1111, 0b1001, 0b1111, 0b0110, 0b1111], [0b0110, 0b1001])
+    feet = np.array([oracle.rbd_contact_position(m, Q_STAND, c) for c in range(4)])
+    pos = np.tile(feet[None], (n, 1, 1))
+    impacts = [i for i, g in enumerate(grids) if g.type == GRID_IMPACT]
+    pos[impacts[0]:, [1, 2], 0] += 0.05
+    pos[impacts[1]:, [0, 3], 0] += 0.05
+    q_ref = Q_STAND.copy()
+    q_ref[0] += 0.15
+    wq = np.concatenate([np.full(6, 10.0), np.full(12, 1.0)])
+    cost = np.zeros((12, MAX_JOINTS))
+    for k, val in ((0, q_ref), (3, wq), (4, np.full(nv, 1.0)), (5, np.full(nv, 1e-3)), (6, np.full(12, 1e-3)), (7, 10.0 * wq), (8, np.full(nv, 1.0)),
+                   (9, wq), (10, np.full(nv, 1.0)), (11, np.full(nv, 1e-3))):
+        cost[k, :len(val)] = val
+    q0, v0 = Q_STAND.copy(), np.zeros(nv)
+    mass = sum(m.mass[i] for i in range(m.njoints))
+    finit = np.zeros((n, 12))
+    for i in range(n):
+        act = [c for c in range(4) if (int(masks[i]) >> c) & 1]
+        if act and grids[i].type != GRID_IMPACT:
+            finit[i, :3 * len(act)] = np.concatenate([oracle.rbd_contact_placement(m, q0, c)[0].T @ np.array([0.0, 0.0, 9.81 * mass / len(act)]) for c in act])
+    qmax, vmax, umax, mu, barrier = 1.2, 3.0, 17.34, 0.2, 1.0e-3
+    prob = str(tmp_path / "anymal_trot.bin")
+    with open(prob, "wb") as f:
+        f.write(bytes(m))
+        f.write(cost.tobytes())
+        f.write(np.array([n], dtype=np.int32).tobytes())
+        for g in grids:
+            f.write(bytes(g))
+        f.write(masks.astype(np.uint32).tobytes())
+        for arr in (pos, q0, v0, finit, np.array([qmax, vmax, umax, mu, barrier])):
+            f.write(np.ascontiguousarray(arr, dtype=np.float64).tobytes())
+    out_path = str(tmp_path / "ocp_trot_out.bin")
+    run = subprocess.run([exe, prob, out_path], capture_output=True, text=True, timeout=300)
+    print(run.stdout, run.stderr)
+    assert run.returncode == 0, (run.returncode, run.stdout, run.stderr)
+    raw = np.fromfile(out_path)
+    iters, conv, err = int(raw[0]), raw[1], raw[2]
+    assert conv == 1.0 and err < 1e-8 and iters <= 40
+    traj = raw[4:4 + n * nq].reshape(n, nq)
+    torque = raw[4 + n * nq:].reshape(n, nu)
+    assert np.abs(torque).max() < umax
+    # the same iterations through ctypes
+    ctx = capi.Context(dims, n, 1, 0)
+    ctx.set_grid(grids)
+    ctx.set_robot_model(m)
+    ctx.set_contact_schedule(masks, pos)
+    ctx.set_constraint_rows(joint_limit_rows(dims))
+    ctx.set_friction_cones(4, 3)
+    ctx.set_impact_cones(False)
+    ctx.set_constraint_bounds(limits(nu, qmax, vmax, umax), barrier, 0.995)
+    ctx.set_friction_coefficients(np.full(4, mu))
+    ctx.set_configuration_cost(*[cost[k, :(nq if k == 0 else nv)] for k in range(12)])
+    ctx.set_initial_state(np.concatenate([q0, v0])[None])
+    S = Records(ctx.L, "sol")
+    sol = S.zeros(1, n)
+    S.f(sol, "q")[..., :nq] = q0
+    S.f(sol, "f")[0, :, :12] = finit
+    ctx.upload(BUF_SOL, sol)
+    ctx.contact_init_constraints()
+    for _ in range(iters):
+        ctx.contact_update_solution(0.995)
+    ref = ctx.download_records(BUF_SOL, "sol")[0]
+    assert np.array_equal(traj, S.f(ref, "q")[:, :nq]) and np.array_equal(torque, S.f(ref, "u")[:, :nu])
+    ctx.close()
