@@ -279,6 +279,76 @@ def sqp_single_instance(dims, grids, device):
     return out
 
 
+def closed_loop_trot(local_rank, batch, iters=30, timed=10):
+    """OCPSolver::updateSolution of BASELINE configs[1] with NOTHING on the host: ANYmal trot (47 grid points: 2 lifts,
+    2 touch-downs with switching constraints), ConfigurationSpaceCost, the Constraints object of examples/anymal/trot.cpp
+    (six joint-limit components + FrictionCone), a distinct initial state per instance.  One iteration =
+    rtoc_contact_update_solution: cost, inequality rows, state equation on SE(3), RNEA + derivatives, switching constraints,
+    KKT error, condensation, Riccati sweep, expansion, fraction-to-boundary steps, update on the manifold."""
+    from robotoc_amd import capi, problems as pr, robot_model as rm
+    from robotoc_amd.grid import ANYMAL_Q_STANDING, ANYMAL_TROT_IMPACT_MASKS, ANYMAL_TROT_PHASE_MASKS, contact_masks
+    from robotoc_amd.types import BUF_SOL, GRID_IMPACT, Records, joint_limit_rows
+    m = rm.load_named("anymal")
+    dims, grids, _ = pr.config_anymal_trot()
+    n, nv, nq, nu = len(grids), m.nv, m.nq, 12
+    qs = np.array(ANYMAL_Q_STANDING, dtype=float)
+    masks = contact_masks(grids, ANYMAL_TROT_PHASE_MASKS, ANYMAL_TROT_IMPACT_MASKS)
+    feet = np.array([m.frame_placement(qs, c)[1] for c in range(4)])
+    pos = np.tile(feet[None], (n, 1, 1))
+    impacts = [i for i, g in enumerate(grids) if g.type == GRID_IMPACT]
+    pos[impacts[0]:, [1, 2], 0] += 0.05   # each swing foot touches down 5 cm ahead
+    pos[impacts[1]:, [0, 3], 0] += 0.05
+    c = capi.Context(dims, n, batch, local_rank)
+    c.set_grid(grids)
+    c.set_robot_model(m)
+    c.set_contact_schedule(masks, pos)
+    c.set_constraint_rows(joint_limit_rows(dims))
+    c.set_friction_cones(4, 3)
+    c.set_impact_cones(False)
+    c.set_constraint_bounds(np.concatenate([np.full(2 * nu, 1.2), np.full(2 * nu, 3.0), np.full(2 * nu, 17.34)]), 1.0e-3, 0.995)
+    c.set_friction_coefficients(np.full(4, 0.2))
+    q_ref = qs.copy()
+    q_ref[0] += 0.15
+    wq = np.concatenate([np.full(6, 10.0), np.full(12, 1.0)])
+    c.set_configuration_cost(q_ref, np.zeros(nv), np.zeros(12), wq, np.full(nv, 1.0), np.full(nv, 1e-3), np.full(12, 1e-3), 10.0 * wq,
+                             np.full(nv, 1.0), q_weight_impact=wq, v_weight_impact=np.full(nv, 1.0), dv_weight_impact=np.full(nv, 1e-3))
+    rng = np.random.default_rng(99)
+    x0 = np.tile(np.concatenate([qs, np.zeros(nv)]), (batch, 1))
+    x0[:, :3] += 0.01 * rng.uniform(-1, 1, (batch, 3))           # a distinct initial state per instance
+    x0[:, 7:nq] += 0.02 * rng.uniform(-1, 1, (batch, nq - 7))
+    x0[:, nq:] = 0.05 * rng.uniform(-1, 1, (batch, nv))
+    c.set_initial_state(x0)
+    S = Records(c.L, "sol")
+    sol = S.zeros(batch, n)
+    S.f(sol, "q")[..., :nq] = x0[:, None, :nq]
+    mass = sum(m.mass[i] for i in range(m.njoints))
+    for i in range(n):   # gravity-compensating contact forces at the standing pose as the initial guess
+        act = [k for k in range(4) if (int(masks[i]) >> k) & 1]
+        if act and grids[i].type != GRID_IMPACT:
+            S.f(sol, "f")[:, i, :3 * len(act)] = np.concatenate([m.frame_placement(qs, k)[0].T @ np.array([0.0, 0.0, 9.81 * mass / len(act)]) for k in act])
+    c.upload(BUF_SOL, sol)
+    c.contact_init_constraints()
+    errs = np.array([c.contact_update_solution(0.995) for _ in range(iters)])
+    converged = int((errs[-1] < 1e-6).sum())
+    c.upload(BUF_SOL, sol)
+    c.contact_init_constraints()
+    c.contact_update_solution(0.995, want_kkt_error=False)
+    c.sync()
+    t0 = time.perf_counter()
+    for _ in range(timed):
+        c.contact_update_solution(0.995, want_kkt_error=False)
+    c.sync()
+    ms = (time.perf_counter() - t0) / timed * 1e3
+    out = {"batch": batch, "grid_points": n, "update_solution_ms": ms, "iterations_per_sec": batch / ms * 1e3,
+           "kkt_error_first_worst": float(errs[0].max()), "kkt_error_after_%d_iterations_worst" % iters: float(errs[-1].max()),
+           "kkt_error_after_%d_iterations_median" % iters: float(np.median(errs[-1])),
+           "instances_below_1e-6": converged, "status_ok": bool((c.status() == 0).all()),
+           "scope": "the WHOLE OCPSolver::updateSolution on the device, rigid-body linearisation, cost and inequality rows included "
+                    "(joint limits + friction cones, barrier 1e-3); wall clock around asynchronous launches, synchronised once"}
+    c.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -685,6 +755,12 @@ def main():
         }
         if sqp is not None:
             res["sqp_iteration"] = sqp
+            if world == 1:
+                try:
+                    res["sqp_iteration"]["closed_loop_constrained_trot"] = {"single_instance": closed_loop_trot(local_rank, 1),
+                                                                            "batch": closed_loop_trot(local_rank, PER_GPU_BATCH)}
+                except Exception as e:  # the hot-path numbers stand on their own
+                    res["sqp_iteration"]["closed_loop_constrained_trot"] = {"error": repr(e)}
         if others is not None:
             res["other_configs"] = others
         if gathered_ok is not None:

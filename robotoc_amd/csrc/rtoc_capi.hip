@@ -1525,7 +1525,11 @@ int rtoc_set_initial_state(rtoc_ctx* c, const double* x0, int count) {
 }
 
 // linearizeStateEquation / linearizeImpactStateEquation of every non-terminal grid point (state_equation_lin.hpp)
-int rtoc_linearize_state_equation(rtoc_ctx* c) {
+static int launch_state_equation(rtoc_ctx* c, bool zeroed);
+int rtoc_linearize_state_equation(rtoc_ctx* c) { return launch_state_equation(c, false); }
+// zeroed: the caller has just zeroed the KKT records (rtoc_contact_eval_kkt) -- only the non-zero entries of the Fxx top
+// half are written, and the records are known to have the structure RTOC_OPT_FXX_STRUCTURE's check would find
+static int launch_state_equation(rtoc_ctx* c, bool zeroed) {
   CHECK_READY(c);
   if (!c->buf[RTOC_BUF_SOL]) return RTOC_ERR_NOT_READY;
   if (c->dims.np != 0 && c->dims.np != 6) return RTOC_ERR_BAD_ARG;
@@ -1549,9 +1553,11 @@ int rtoc_linearize_state_equation(rtoc_ctx* c) {
   a.o_fxx = c->L.kkt.off[RTOC_KKT_FXX], a.o_fx = c->L.kkt.off[RTOC_KKT_FX], a.o_lx = c->L.kkt.off[RTOC_KKT_LX];
   a.o_hx = c->L.kkt.off[RTOC_KKT_HX], a.o_ffx = c->L.kkt.off[RTOC_KKT_FFX], a.o_scal = c->L.kkt.off[RTOC_KKT_SCAL];
   a.o_la = c->L.cdd.off[RTOC_CDD_LA], a.o_ha = c->L.cdd.off[RTOC_CDD_HA];
+  a.zeroed = zeroed ? 1 : 0;
   hipLaunchKernelGGL(state_equation_lin_kernel, dim3(c->batch * c->nstages), dim3(64), 0, c->stream, a);
   HIP_TRY(hipGetLastError());
-  c->fxx_state = 0;
+  if (zeroed && c->fxx_state == 2) c->epoch++;  // the kernel choice of the backward recursion is part of a captured graph
+  c->fxx_state = zeroed ? 1 : 0;
   return RTOC_OK;
 }
 
@@ -1814,7 +1820,7 @@ int rtoc_contact_eval_kkt(rtoc_ctx* c) {
   // constraints_->linearizeConstraints (intermediate_stage.cpp:109-110, impact_stage.cpp:95-96) of the rows evaluated here
   if (c->nrows > 0 && c->d_bounds && c->buf[RTOC_BUF_CON]) rc = launch_ubox(c, UBOX_LINEARIZE, true);
   if (!rc && device_cones_on(c) && c->buf[RTOC_BUF_CON]) rc = launch_contact_cones(c, CC_LINEARIZE);
-  if (!rc) rc = rtoc_linearize_state_equation(c);
+  if (!rc) rc = launch_state_equation(c, true);
   if (!rc) rc = launch_linearize(c, 1, false, 1.0);
   if (!rc && switching) rc = launch_switching_constraint(c);
   return rc;

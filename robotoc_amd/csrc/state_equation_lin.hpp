@@ -10,8 +10,8 @@
 //   Fqq_prev  = d/dM of log6(M^-1 M_prev) = -Jlog6(X0) Ad_{X0^-1},  X0 = M^-1 M_prev   (dSubtractConfiguration_dq0(q_prev, q))
 //   Fqq_inv   = [ -Jlog6(X1) Ad_{X1^-1} ]^-1           (dSubtractConfiguration_dq0(q, q_next), state_equation.cpp:78-79)
 // Jlog6 x twist is evaluated by forward mode through the log (rbd::log6_fwd); Ad_{X^-1} is the motion actInv.  Six lanes
-// carry the six unit twists, lane 0 inverts the two 6 x 6 Jacobians (Gauss-Jordan with partial pivoting; the reference's
-// SE3JacobianInverse exploits their block-triangular shape -- same result).  Everything else is elementwise.
+// carry the six unit twists, lane 0 inverts the two 6 x 6 Jacobians by their block-triangular shape (3 x 3 cofactor inverses,
+// like the reference's SE3JacobianInverse).  Everything else is elementwise.
 // One wave per (instance, grid point).  Records: the un-condensed contact-path convention (la in CDD.la).
 #pragma once
 #include "rigid_body.hpp"
@@ -27,6 +27,7 @@ struct SeLinArgs {
   double* dx0;           // may be nullptr: computeInitialStateDirection (state_equation.cpp:99-109) into RTOC_BUF_DX0
   const rtoc_grid* grid;
   int nstages, batch, nv, floating;
+  int zeroed;            // the KKT record was zeroed just before: only the non-zero entries of the Fxx top half are written
   int sol_stride, kkt_stride, cdd_stride;
   int o_q, o_v, o_a, o_lmd, o_gmm;
   int o_fxx, o_fx, o_lx, o_hx, o_ffx, o_scal;
@@ -87,6 +88,40 @@ __device__ inline bool inv6(double* A) {
   for (int e = 0; e < 36; ++e) A[e] = B[e];
   return true;
 }
+// Inverse of a 6 x 6 block upper-triangular matrix [[A, B], [0, D]] (column-major, 3 x 3 blocks) -- the shape of Jlog6 and
+// of Ad in the (linear, angular) ordering, hence of every SE(3) difference Jacobian here: [[A^-1, -A^-1 B D^-1], [0, D^-1]]
+// with the 3 x 3 inverses by cofactors (what the reference's SE3JacobianInverse exploits, se3_jacobian_inverse.hxx).  All
+// indices are compile-time constants: the arrays stay in registers (the general inv6 above pivots, i.e. indexes at run time,
+// which puts its 72 doubles into scratch memory).
+__device__ __forceinline__ void inv3(const double (&m)[3][3], double (&o)[3][3]) {
+  const double c00 = m[1][1] * m[2][2] - m[1][2] * m[2][1], c01 = m[1][2] * m[2][0] - m[1][0] * m[2][2], c02 = m[1][0] * m[2][1] - m[1][1] * m[2][0];
+  const double id = 1.0 / (m[0][0] * c00 + m[0][1] * c01 + m[0][2] * c02);
+  o[0][0] = c00 * id, o[1][0] = c01 * id, o[2][0] = c02 * id;
+  o[0][1] = (m[0][2] * m[2][1] - m[0][1] * m[2][2]) * id, o[1][1] = (m[0][0] * m[2][2] - m[0][2] * m[2][0]) * id, o[2][1] = (m[0][1] * m[2][0] - m[0][0] * m[2][1]) * id;
+  o[0][2] = (m[0][1] * m[1][2] - m[0][2] * m[1][1]) * id, o[1][2] = (m[0][2] * m[1][0] - m[0][0] * m[1][2]) * id, o[2][2] = (m[0][0] * m[1][1] - m[0][1] * m[1][0]) * id;
+}
+__device__ __forceinline__ void inv6_block_ut(const double* J, double* out) {
+  double A[3][3], B[3][3], D[3][3], Ai[3][3], Di[3][3], T[3][3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) A[r][c] = J[r + 6 * c], B[r][c] = J[r + 6 * (c + 3)], D[r][c] = J[r + 3 + 6 * (c + 3)];
+  inv3(A, Ai);
+  inv3(D, Di);
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) T[r][c] = Ai[r][0] * B[0][c] + Ai[r][1] * B[1][c] + Ai[r][2] * B[2][c];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      out[r + 6 * c] = Ai[r][c];
+      out[r + 3 + 6 * c] = 0.0;
+      out[r + 3 + 6 * (c + 3)] = Di[r][c];
+      out[r + 6 * (c + 3)] = -(T[r][0] * Di[0][c] + T[r][1] * Di[1][c] + T[r][2] * Di[2][c]);
+    }
+}
 }  // namespace selin
 
 static __global__ __launch_bounds__(64) void state_equation_lin_kernel(SeLinArgs a) {
@@ -131,8 +166,8 @@ static __global__ __launch_bounds__(64) void state_equation_lin_kernel(SeLinArgs
       if (lane == 0 && a.se3) {
         double* const se = a.se3 + rec * RTOC_SE3_STRIDE;
         double A[36];
-        for (int e = 0; e < 36; ++e) A[e] = J[1][e];
-        inv6(A);
+        inv6_block_ut(J[1], A);
+#pragma unroll
         for (int e = 0; e < 36; ++e) se[e] = 0.0, se[36 + e] = A[e];
       }
     }
@@ -149,9 +184,15 @@ static __global__ __launch_bounds__(64) void state_equation_lin_kernel(SeLinArgs
   const double *q = s + a.o_q, *v = s + a.o_v, *acc = s + a.o_a, *lmd = s + a.o_lmd, *gmm = s + a.o_gmm;
   const double *qn = sn + a.o_q, *vn = sn + a.o_v, *lmdn = sn + a.o_lmd, *gmmn = sn + a.o_gmm;
   // ---- Fxx top half: Fqq = I (joints), Fqv = dt I; the bottom half belongs to the dynamics condensation ----
-  for (int e = lane; e < nx * nx; e += 64) {
-    const int r = e % nx, c = e / nx;
-    if (r < nv) kr[a.o_fxx + e] = (c == r) ? 1.0 : (c == nv + r ? dt : 0.0);
+  if (a.zeroed) {   // rtoc_contact_eval_kkt: the cost kernel has just zeroed the record (kkt_matrix.setZero)
+    for (int r = lane; r < nv; r += 64) kr[a.o_fxx + r + (size_t)r * nx] = 1.0, kr[a.o_fxx + r + (size_t)(nv + r) * nx] = dt;
+  } else {
+    int r = lane % nx, c = lane / nx;
+    for (int e = lane; e < nx * nx; e += 64) {
+      if (r < nv) kr[a.o_fxx + e] = (c == r) ? 1.0 : (c == nv + r ? dt : 0.0);
+      r += 64;
+      while (r >= nx) r -= nx, ++c;
+    }
   }
   // ---- joints and velocities ----
   for (int i = lane; i < nv; i += 64) {
@@ -218,11 +259,11 @@ static __global__ __launch_bounds__(64) void state_equation_lin_kernel(SeLinArgs
   if (lane == 0 && a.se3) {
     double* const se = a.se3 + rec * RTOC_SE3_STRIDE;
     double A[36];
-    for (int e = 0; e < 36; ++e) A[e] = J[2][e];
-    inv6(A);
+    inv6_block_ut(J[2], A);
+#pragma unroll
     for (int e = 0; e < 36; ++e) se[e] = A[e];           // Fqq_inv
-    for (int e = 0; e < 36; ++e) A[e] = J[1][e];
-    inv6(A);
+    inv6_block_ut(J[1], A);
+#pragma unroll
     for (int e = 0; e < 36; ++e) se[36 + e] = A[e];      // Fqq_prev_inv
     if (st == 0 && a.dx0 && a.x0) {
       // computeInitialStateDirection (:99-109): dq0 = q0 (-) s0.q = log6(M^-1 M0) = log6(X0) for the base, with the
@@ -231,8 +272,10 @@ static __global__ __launch_bounds__(64) void state_equation_lin_kernel(SeLinArgs
       rbd::log6_fwd(R0, p0, rbd::sv0(), val, der);
       const double d6[6] = {val.l.x, val.l.y, val.l.z, val.a.x, val.a.y, val.a.z};
       double* const o = a.dx0 + (size_t)b * nx;
+#pragma unroll
       for (int r = 0; r < 6; ++r) {
         double t = 0.0;
+#pragma unroll
         for (int c = 0; c < 6; ++c) t += A[r + 6 * c] * d6[c];
         o[r] = -t;
       }

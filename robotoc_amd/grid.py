@@ -211,6 +211,30 @@ def anymal_trot_sequence(t0=0.11, swing=0.2, double_support=0.1, cycles=1):
     return ContactSequence(phase_dimf, ev)
 
 
+def contact_masks(grids, phase_masks, impact_masks):
+    """Bit mask of the active contacts per grid point (rtoc_set_contact_schedule): ContactStatus of the phase the grid
+    point lies in -- phases advance at lift and impact grids -- and ImpactStatus on the impact grids themselves."""
+    import numpy as np
+    masks, phase, nimp = [], 0, 0
+    for g in grids:
+        if g.type == GRID_IMPACT:
+            masks.append(impact_masks[nimp])
+            nimp += 1
+            phase += 1
+        else:
+            if g.type == GRID_LIFT:
+                phase += 1
+            masks.append(phase_masks[phase])
+    return np.array(masks, dtype=np.uint32)
+
+
+# examples/anymal/trot.cpp:162-190 in the contact order of models/anymal.json (LF, LH, RF, RH): stand, LH + RF swing, stand,
+# LF + RH swing, stand; the two touch-downs
+ANYMAL_TROT_PHASE_MASKS = [0b1111, 0b1001, 0b1111, 0b0110, 0b1111]
+ANYMAL_TROT_IMPACT_MASKS = [0b0110, 0b1001]
+ANYMAL_Q_STANDING = [0, 0, 0.4792, 0, 0, 0, 1, -0.1, 0.7, -1.0, -0.1, -0.7, 1.0, 0.1, 0.7, -1.0, 0.1, -0.7, 1.0]  # examples/anymal/trot.cpp:60-66
+
+
 def jump_sto_sequence(ground_time=0.31, flying_time=0.2, nf=12):
     """stand -> flight -> stand with both events STO-enabled
     (examples/anymal/python/jump_sto.py:96-103)."""

@@ -44,6 +44,35 @@ class RobotModel(C.Structure):
     def nu(self):
         return self.nv - 6 if self.floating_base else self.nv
 
+    def frame_placement(self, q, k):
+        """World placement (R, p) of contact frame k at configuration q -- what a caller of the reference gets from
+        Robot::framePosition / frameRotation (robot.hxx) to set up contact positions and an initial guess of the contact
+        forces (examples/anymal/trot.cpp:150-160).  Problem set-up on the host; the solver's own kinematics run on the device."""
+        q = np.asarray(q, dtype=float)
+        R, p = [None] * self.njoints, [None] * self.njoints
+        for i in range(self.njoints):
+            Rp, pp = np.array(self.placement_R[i]).reshape(3, 3), np.array(self.placement_p[i])
+            iq = self.idx_q[i]
+            if self.type[i] == JOINT_FREE_FLYER:
+                x, y, z, w = q[iq + 3:iq + 7]
+                Rj = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                               [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                               [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+                pj = q[iq:iq + 3]
+            else:
+                a = np.array(self.axis[i])
+                c, s_ = np.cos(q[iq]), np.sin(q[iq])
+                K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+                Rj, pj = c * np.eye(3) + s_ * K + (1 - c) * np.outer(a, a), np.zeros(3)
+            Rl, pl = Rp @ Rj, Rp @ pj + pp
+            par = self.parent[i]
+            if par >= 0 and par != i and R[par] is not None:
+                R[i], p[i] = R[par] @ Rl, p[par] + R[par] @ pl
+            else:
+                R[i], p[i] = Rl, pl
+        b = self.contact_parent[k]
+        return R[b] @ np.array(self.contact_R[k]).reshape(3, 3), p[b] + R[b] @ np.array(self.contact_p[k])
+
 
 def from_dict(d):
     m = RobotModel()

@@ -115,6 +115,27 @@ def test_log6_inverts_exp6(oracle):
             assert np.abs(oracle.rbd_log6(R, p) - xi).max() < 1e-9 * max(1.0, scale) + 1e-15
 
 
+@pytest.mark.parametrize("name", ["anymal", "icub"])
+def test_host_side_frame_placement_and_contact_masks(oracle, name):
+    """RobotModel.frame_placement (problem set-up on the host: contact positions, initial contact forces) against the
+    restatement's kinematics; contact_masks against the phase structure of the trot grid"""
+    m = rm.load_named(name)
+    rng = np.random.default_rng(2)
+    for _ in range(5):
+        q = rm.random_configuration(m, rng)[0]
+        for k in range(m.ncontacts):
+            R, p = m.frame_placement(q, k)
+            R2, p2 = oracle.rbd_contact_placement(m, q, k)
+            assert np.abs(R - R2).max() < 1e-14 and np.abs(p - p2).max() < 1e-14
+    from robotoc_amd.grid import ANYMAL_TROT_IMPACT_MASKS, ANYMAL_TROT_PHASE_MASKS, contact_masks
+    _, grids, _ = pr.config_anymal_trot()
+    masks = contact_masks(grids, ANYMAL_TROT_PHASE_MASKS, ANYMAL_TROT_IMPACT_MASKS)
+    assert all(3 * bin(int(k)).count("1") == g.dimf for k, g in zip(masks, grids))
+    for i, g in enumerate(grids):
+        if g.switching_constraint:   # the feet that touch down two grid points ahead are in the air now
+            assert grids[i + 2].type == GRID_IMPACT and int(masks[i]) & int(masks[i + 2]) == 0 and 3 * bin(int(masks[i + 2])).count("1") == g.dims
+
+
 def test_model_table_is_validated():
     capi.build()
     lib = capi.lib()

@@ -10,24 +10,10 @@ import pytest
 
 from robotoc_amd import capi, robot_model as rm
 from robotoc_amd.grid import ContactSequence, Event, discretize
-from robotoc_amd.types import BUF_CDD, BUF_KKT, BUF_SOL, GRID_IMPACT, GRID_LIFT, Records, anymal_dims
+from robotoc_amd.grid import contact_masks as trot_masks  # the other closed-loop tests import it from here
+from robotoc_amd.types import BUF_CDD, BUF_KKT, BUF_SOL, GRID_IMPACT, Records, anymal_dims
 
 Q_STAND = np.array([0, 0, 0.4792, 0, 0, 0, 1, -0.1, 0.7, -1.0, -0.1, -0.7, 1.0, 0.1, 0.7, -1.0, 0.1, -0.7, 1.0])
-
-
-def trot_masks(grids, phase_masks, impact_masks):
-    """bit masks per grid point from the phase the grid lies in (phases advance at lift / impact grids)"""
-    masks, phase, nimp = [], 0, 0
-    for g in grids:
-        if g.type == GRID_IMPACT:
-            masks.append(impact_masks[nimp])
-            nimp += 1
-            phase += 1
-        else:
-            if g.type == GRID_LIFT:
-                phase += 1
-            masks.append(phase_masks[phase])
-    return np.array(masks, dtype=np.uint32)
 
 
 def q_plus(oracle, m, q, d):
