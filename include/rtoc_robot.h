@@ -108,6 +108,12 @@ int rtoc_contact_eval_kkt(rtoc_ctx* ctx);
 int rtoc_set_barrier_param(rtoc_ctx* ctx, double barrier_param, double fraction_to_boundary_rule);
 int rtoc_set_friction_coefficients(rtoc_ctx* ctx, const double* mu, int ncontacts);
 int rtoc_contact_init_constraints(rtoc_ctx* ctx);
+/* Contact wrench cones of surface contacts on the device (rtoc_set_wrench_cones rows; ContactWrenchCone,
+ * src/constraints/contact_wrench_cone.cpp:114-204): xy_mu[k] = {X, Y, mu} of contact k -- the sole rectangle 2X x 2Y and
+ * ContactStatus::frictionCoefficient -- from which the 17 x 6 cone matrices are built (rtoc_wrench_cone_matrix).  Once set,
+ * rtoc_contact_init_constraints also writes the matrices into RTOC_BUF_CONE and initialises these rows, and
+ * rtoc_contact_eval_kkt evaluates them (g = cone f on the local contact wrench; lf += cone^T dual). */
+int rtoc_set_wrench_cone_params(rtoc_ctx* ctx, const double* xy_mu, int ncontacts);
 /* OCPSolver::updateSolution (src/solver/ocp_solver.cpp:111-145) for that OCP, one launch sequence: rtoc_contact_eval_kkt,
  * then rtoc_newton_iteration(ctx, 0, fraction_to_boundary_rule).  host_kkt_error[count <= batch] (may be NULL / 0): the KKT
  * error of the iterate it linearised at. */

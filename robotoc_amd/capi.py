@@ -29,7 +29,7 @@ EXPORTS = [
     "rtoc_set_robot_model", "rtoc_set_contact_schedule", "rtoc_linearize_contact_dynamics",
     "rtoc_line_search_filter", "rtoc_line_search_clear", "rtoc_set_configuration_cost", "rtoc_set_initial_state",
     "rtoc_unconstr_eval_kkt", "rtoc_unconstr_update_solution", "rtoc_set_constraint_bounds", "rtoc_unconstr_init_constraints", "rtoc_linearize_state_equation", "rtoc_contact_eval_kkt", "rtoc_contact_update_solution",
-    "rtoc_set_barrier_param", "rtoc_set_friction_coefficients", "rtoc_contact_init_constraints",
+    "rtoc_set_barrier_param", "rtoc_set_friction_coefficients", "rtoc_contact_init_constraints", "rtoc_set_wrench_cone_params",
 ]
 
 
@@ -142,6 +142,7 @@ def lib():
         L.rtoc_contact_init_constraints.argtypes = [vp]
         L.rtoc_set_barrier_param.argtypes = [vp, C.c_double, C.c_double]
         L.rtoc_set_friction_coefficients.argtypes = [vp, dp, C.c_int]
+        L.rtoc_set_wrench_cone_params.argtypes = [vp, dp, C.c_int]
         L.rtoc_unconstr_update_solution.argtypes = [vp, C.c_double, dp, C.c_int]
         L.rtoc_contact_update_solution.argtypes = [vp, C.c_double, dp, C.c_int]
         L.rtoc_line_search_filter.argtypes = [vp, dp, dp, C.POINTER(C.c_int), C.c_int, C.c_double, C.c_double, C.POINTER(C.c_int)]
@@ -411,6 +412,11 @@ class Context:
         """ContactStatus::frictionCoefficient per contact: switches the device-side evaluation of the friction-cone rows on"""
         mu = np.ascontiguousarray(mu, dtype=np.float64)
         _chk(lib().rtoc_set_friction_coefficients(self._h, _dp(mu), mu.size))
+
+    def set_wrench_cone_params(self, xy_mu):
+        """[ncontacts][3] = sole half-extents X, Y and the friction coefficient: device-side evaluation of the wrench-cone rows"""
+        xy_mu = np.ascontiguousarray(xy_mu, dtype=np.float64).reshape(-1, 3)
+        _chk(lib().rtoc_set_wrench_cone_params(self._h, _dp(xy_mu), xy_mu.shape[0]))
 
     def contact_init_constraints(self):
         """OCPSolver::initConstraints for the rows evaluated on the device (joint limits with bounds, friction cones with mu)"""

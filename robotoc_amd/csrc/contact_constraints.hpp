@@ -175,3 +175,81 @@ static __global__ __launch_bounds__(64) void contact_cone_kernel(CcArgs a) {
 }
 
 }  // namespace rtoc
+
+namespace rtoc {
+
+// ContactWrenchCone / ImpactWrenchCone (reference src/constraints/contact_wrench_cone.cpp:114-204): 17 rows per ACTIVE surface
+// contact, g = cone f with the constant 17 x 6 cone matrix of the sole (computeCone / updateCone, :282-313; the host builds
+// it with rtoc_wrench_cone_matrix and hands a table over) acting on the local 6-d contact wrench -- no kinematics:
+//   INIT       cone matrix into the RTOC_BUF_CONE record (what rtoc_condense / rtoc_expand read), slack = -g clipped at
+//              sqrt(barrier), dual = barrier / slack
+//   LINEARIZE  residual = g + slack, cmpl = slack dual - barrier, lf += cone^T dual
+// One wave per (instance, grid point), lane r < 17 = row r of a contact.
+struct WcArgs {
+  const double* sol;
+  double* cdd;
+  double* con;
+  double* cone;
+  const double* table;   // [ncontacts][17 x 6], column-major (ld 17)
+  const rtoc_grid* grid;
+  const unsigned* active;
+  int nstages, batch, ncontacts, mode, row0, cone_stride, impact_cones;
+  double barrier;
+  int sol_stride, cdd_stride, con_stride;
+  int o_f, o_lf;
+  rtoc_record_layout nl;
+};
+
+static __global__ __launch_bounds__(64) void wrench_cone_eval_kernel(WcArgs a) {
+  __shared__ double sd[RTOC_WRENCH_ROWS];
+  const int lane = threadIdx.x;
+  const int nst1 = a.nstages - 1;
+  const int b = blockIdx.x / nst1, st = blockIdx.x % nst1;
+  if (b >= a.batch) return;
+  const rtoc_grid g = a.grid[st];
+  if (g.dimf == 0 || (g.type == RTOC_GRID_IMPACT && !a.impact_cones)) return;
+  const unsigned act = a.active[st];
+  const size_t rec = (size_t)b * a.nstages + st;
+  const double* const s = a.sol + rec * a.sol_stride;
+  double* const cr = a.cdd ? a.cdd + rec * a.cdd_stride : nullptr;
+  double* const nr = a.con + rec * a.con_stride;
+  double* const gr = a.cone + rec * a.cone_stride;
+  const int* const no = a.nl.off;
+  int k = 0;
+  for (int c = 0; c < a.ncontacts; ++c) {
+    if (!((act >> c) & 1u)) continue;
+    const double* const A = a.table + (size_t)c * RTOC_WRENCH_ROWS * 6;
+    const int r0 = a.row0 + RTOC_WRENCH_ROWS * k;
+    if (a.mode == CC_INIT)
+      for (int e = lane; e < RTOC_WRENCH_ROWS * 6; e += 64) gr[k * RTOC_WRENCH_ROWS * 6 + e] = A[e];
+    if (lane < RTOC_WRENCH_ROWS) {
+      double gval = 0.0;
+#pragma unroll
+      for (int t = 0; t < 6; ++t) gval += A[lane + RTOC_WRENCH_ROWS * t] * s[a.o_f + 6 * k + t];
+      if (a.mode == CC_INIT) {
+        double slack = -gval;
+        const double sb = sqrt(a.barrier);
+        if (slack < sb) slack = sb;
+        nr[no[RTOC_CON_SLACK] + r0 + lane] = slack;
+        nr[no[RTOC_CON_DUAL] + r0 + lane] = a.barrier / slack;
+      } else {
+        const double slack = nr[no[RTOC_CON_SLACK] + r0 + lane], dual = nr[no[RTOC_CON_DUAL] + r0 + lane];
+        nr[no[RTOC_CON_RESIDUAL] + r0 + lane] = gval + slack;
+        nr[no[RTOC_CON_CMPL] + r0 + lane] = slack * dual - a.barrier;
+        sd[lane] = dual;
+      }
+    }
+    if (a.mode == CC_LINEARIZE) {
+      __syncthreads();
+      if (lane < 6) {
+        double acc = 0.0;
+        for (int r = 0; r < RTOC_WRENCH_ROWS; ++r) acc += A[r + RTOC_WRENCH_ROWS * lane] * sd[r];
+        cr[a.o_lf + 6 * k + lane] += acc;
+      }
+      __syncthreads();
+    }
+    ++k;
+  }
+}
+
+}  // namespace rtoc

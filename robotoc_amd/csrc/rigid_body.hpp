@@ -174,9 +174,17 @@ struct LinArgs {
 // per-level storage in LDS
 constexpr int VAL_DOUBLES = 64;  // R 9, p 3, oR 9, op 3, v 6, a 6, g 3, f 6, vpar 6, apar 6 -> 57, padded
 constexpr int TAN_SLOTS = 21;    // dv 6, da 6, dg 3, df 6
-__host__ __device__ constexpr size_t lin_lds_bytes(int nlevels, int njoints, int ncontacts) {
-  return sizeof(double) * ((size_t)nlevels * (VAL_DOUBLES + TAN_SLOTS * 64) + 4 * (RTOC_MAX_JOINTS + 8) + 18 * RTOC_MAX_CONTACTS + RTOC_MAX_JOINTS +
-                           njoints * JP + ncontacts * CP);
+constexpr int FWD_SLOTS = 15;    // dv, da, dg: read by the children only, so the deepest level keeps none
+constexpr int DF_SLOTS = 6;
+__host__ __device__ constexpr int lin_pad8(int n) { return (n + 7) & ~7; }
+// lanes per tangent slot: 3 nv tangent directions when they fit one pass (quadrupeds: 54 -> 56), else 64
+__host__ __device__ constexpr int lin_lane_stride(int nv) { return 3 * nv <= 56 ? 56 : 64; }
+// What decides the speed of this kernel is how many grid points a CU holds at once (the walk is one long dependent
+// instruction stream per wave, issue-bound, one wave per SIMD at best): ANYmal's 4 levels need 40,128 B, i.e. FOUR waves
+// per CU (160 KB) instead of the three that a uniform [level][21][64] carve gave (14.4 -> see DESIGN.md 3.4).
+__host__ __device__ constexpr size_t lin_lds_bytes(int nlevels, int njoints, int ncontacts, int nv) {
+  return sizeof(double) * ((size_t)nlevels * VAL_DOUBLES + (size_t)((nlevels > 1 ? nlevels - 1 : 0) * FWD_SLOTS + nlevels * DF_SLOTS) * lin_lane_stride(nv) +
+                           lin_pad8(nv + 1) + 4 * lin_pad8(nv) + 3 * lin_pad8(6 * ncontacts) + njoints * JP + ncontacts * CP);
 }
 
 // SURF: the model has surface contacts (6 rows, Log6 of the placement error); compiled out for point-contact robots, where
@@ -194,16 +202,18 @@ __global__ __launch_bounds__(64) RTOC_RBD_WAVES void linearize_contact_dynamics_
   const bool impact = g.type == RTOC_GRID_IMPACT;
   const unsigned active = a.active[st];
   double* const lval = smem;                                      // [nlev][VAL_DOUBLES]
-  double* const ltan = lval + (size_t)nlev * VAL_DOUBLES;         // [nlev][TAN_SLOTS][64]
-  double* const sq = ltan + (size_t)nlev * TAN_SLOTS * 64;        // q, v, a, f, u of the grid point
-  double* const sv = sq + RTOC_MAX_JOINTS + 8;
-  double* const sa = sv + RTOC_MAX_JOINTS + 8;
-  double* const sf = sa + RTOC_MAX_JOINTS + 8;
-  double* const su = sf + 6 * RTOC_MAX_CONTACTS;
-  double* const sbeta = su + RTOC_MAX_JOINTS;           // multipliers of the dynamics (beta) and of the contact rows (mu)
-  double* const smu = sbeta + RTOC_MAX_JOINTS + 8;
-  double* const slf = smu + 6 * RTOC_MAX_CONTACTS;      // dC/da beta, accumulated over the passes
-  double* const sjm = slf + 6 * RTOC_MAX_CONTACTS;      // model: [njoints][JP], then [ncontacts][CP]
+  const int LW = lin_lane_stride(nv);
+  double* const lfwd = lval + (size_t)nlev * VAL_DOUBLES;         // [nlev - 1][FWD_SLOTS][LW]: dv, da, dg
+  double* const ldf = lfwd + (size_t)(nlev > 1 ? nlev - 1 : 0) * FWD_SLOTS * LW;   // [nlev][DF_SLOTS][LW]
+  double* const sq = ldf + (size_t)nlev * DF_SLOTS * LW;          // q, v, a, f, u of the grid point
+  double* const sv = sq + lin_pad8(nv + 1);
+  double* const sa = sv + lin_pad8(nv);
+  double* const sf = sa + lin_pad8(nv);
+  double* const su = sf + lin_pad8(6 * ncon);
+  double* const sbeta = su + lin_pad8(nv);              // multipliers of the dynamics (beta) and of the contact rows (mu)
+  double* const smu = sbeta + lin_pad8(nv);
+  double* const slf = smu + lin_pad8(6 * ncon);         // dC/da beta, accumulated over the passes
+  double* const sjm = slf + lin_pad8(6 * ncon);         // model: [njoints][JP], then [ncontacts][CP]
   double* const scm = sjm + a.njoints * JP;
   const bool aug = a.kkt != nullptr;
   const size_t rec = (size_t)b * a.nstages + st;
@@ -226,7 +236,7 @@ __global__ __launch_bounds__(64) RTOC_RBD_WAVES void linearize_contact_dynamics_
   if (aug) {
     for (int e = lane; e < nv; e += 64) sbeta[e] = sr[a.o_beta + e];
     for (int e = lane; e < g.dimf; e += 64) smu[e] = sr[a.o_mu + e];
-    for (int e = lane; e < 6 * RTOC_MAX_CONTACTS; e += 64) slf[e] = 0.0;
+    for (int e = lane; e < 6 * ncon; e += 64) slf[e] = 0.0;
   }
   __syncthreads();
   const V3 grav = mk(a.gx, a.gy, a.gz);
@@ -243,7 +253,12 @@ __global__ __launch_bounds__(64) RTOC_RBD_WAVES void linearize_contact_dynamics_
       double wsum = 0.0;  // this lane's column of [dID; dC] against [beta; mu]
       // body of the level that is being closed / visited is kept in LDS as an int in the value block
       auto LV = [&](int lev, int k) -> double& { return lval[lev * VAL_DOUBLES + k]; };
-      auto LT = [&](int lev, int k) -> double& { return ltan[((size_t)lev * TAN_SLOTS + k) * 64 + lane]; };
+      // tangent slot k of level lev for this lane; lanes beyond the stride (idle ones) share its last column.  The forward
+      // tangents of the deepest level have no storage: nothing reads them (stores go through st_fwd)
+      const int ln = lane < LW ? lane : LW - 1;
+      auto LT = [&](int lev, int k) -> double& {
+        return k < FWD_SLOTS ? lfwd[((size_t)lev * FWD_SLOTS + k) * LW + ln] : ldf[((size_t)lev * DF_SLOTS + (k - FWD_SLOTS)) * LW + ln];
+      };
       auto ld_sv = [&](int lev, int k0) { return SV{mk(LV(lev, k0), LV(lev, k0 + 1), LV(lev, k0 + 2)), mk(LV(lev, k0 + 3), LV(lev, k0 + 4), LV(lev, k0 + 5))}; };
       auto st_sv = [&](int lev, int k0, SV x) {
         LV(lev, k0) = x.l.x, LV(lev, k0 + 1) = x.l.y, LV(lev, k0 + 2) = x.l.z, LV(lev, k0 + 3) = x.a.x, LV(lev, k0 + 4) = x.a.y, LV(lev, k0 + 5) = x.a.z;
@@ -467,9 +482,11 @@ __global__ __launch_bounds__(64) RTOC_RBD_WAVES void linearize_contact_dynamics_
         LV(d, 36) = gi.x, LV(d, 37) = gi.y, LV(d, 38) = gi.z;
         st_sv(d, 39, f);
         LV(d, 45) = (double)i;
-        st_tv(d, 0, dv);
-        st_tv(d, 6, da);
-        LT(d, 12) = dg.x, LT(d, 13) = dg.y, LT(d, 14) = dg.z;
+        if (d < nlev - 1) {
+          st_tv(d, 0, dv);
+          st_tv(d, 6, da);
+          LT(d, 12) = dg.x, LT(d, 13) = dg.y, LT(d, 14) = dg.z;
+        }
         st_tv(d, 15, df);
         top = d;
       }

@@ -117,7 +117,7 @@ static bool model_has_surface_contacts(const rtoc_robot_model& m) {
   return false;
 }
 static hipError_t set_linearize_lds(const rtoc_robot_model& m, int nlevels) {
-  const int bytes = (int)rbd::lin_lds_bytes(nlevels, m.njoints, m.ncontacts);
+  const int bytes = (int)rbd::lin_lds_bytes(nlevels, m.njoints, m.ncontacts, m.nv);
   hipError_t e = hipFuncSetAttribute((const void*)rbd::linearize_contact_dynamics_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   if (e == hipSuccess)
     e = hipFuncSetAttribute((const void*)rbd::linearize_contact_dynamics_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -164,6 +164,7 @@ struct rtoc_ctx {
   int exact_transport;  // RTOC_OPT_SWITCHING_TRANSPORT
   int impact_cones;     // RTOC_OPT_IMPACT_CONES (default 1, rtoc_create)
   double* d_mu;         // rtoc_set_friction_coefficients
+  double* d_wcone;      // rtoc_set_wrench_cone_params: [RTOC_MAX_CONTACTS][17 x 6]
   unsigned long long epoch;  // bumped by everything that changes a launch parameter baked into a captured graph
   struct GraphSlot {
     hipGraphExec_t exec;
@@ -345,6 +346,7 @@ int rtoc_destroy(rtoc_ctx* c) {
   if (c->d_cost) (void)hipFree(c->d_cost);
   if (c->d_bounds) (void)hipFree(c->d_bounds);
   if (c->d_mu) (void)hipFree(c->d_mu);
+  if (c->d_wcone) (void)hipFree(c->d_wcone);
   if (c->d_x0) (void)hipFree(c->d_x0);
   if (c->d_filter) (void)hipFree(c->d_filter);
   if (c->d_nfilter) (void)hipFree(c->d_nfilter);
@@ -419,6 +421,7 @@ int rtoc_clone(rtoc_ctx* c, rtoc_ctx** out) {
   dup((void**)&n->d_x0, c->d_x0, sizeof(double) * c->batch * (2 * c->dims.nv + (c->dims.np == 6 ? 1 : 0)));
   dup((void**)&n->d_bounds, c->d_bounds, sizeof(double) * c->dims.nc_max);
   dup((void**)&n->d_mu, c->d_mu, sizeof(double) * RTOC_MAX_CONTACTS);
+  dup((void**)&n->d_wcone, c->d_wcone, sizeof(double) * RTOC_MAX_CONTACTS * RTOC_WRENCH_ROWS * 6);
   n->barrier = c->barrier, n->ftb_rule = c->ftb_rule;
   if (c->d_filter) {
     dup((void**)&n->d_filter, c->d_filter, sizeof(double) * 2 * RTOC_LINE_SEARCH_FILTER_CAPACITY * c->batch);
@@ -1381,7 +1384,7 @@ int rtoc_set_robot_model(rtoc_ctx* c, const rtoc_robot_model* m) {
     iq += m->type[i] == RTOC_JOINT_FREE_FLYER ? 7 : 1;
     iv += m->type[i] == RTOC_JOINT_FREE_FLYER ? 6 : 1;
   }
-  ok = ok && iq == m->nq && iv == m->nv && rbd::lin_lds_bytes(nlev, m->njoints, m->ncontacts) <= 160 * 1024;
+  ok = ok && iq == m->nq && iv == m->nv && rbd::lin_lds_bytes(nlev, m->njoints, m->ncontacts, m->nv) <= 160 * 1024;
   for (int k = 0; k < m->ncontacts && ok; ++k) ok = m->contact_parent[k] >= 0 && m->contact_parent[k] < m->njoints;
   if (!ok) {
     delete h;
@@ -1476,7 +1479,7 @@ static int launch_linearize(rtoc_ctx* c, int augment_residual, bool unconstr, do
   a.unconstr = unconstr ? 1 : 0;
   a.scale = scale;
   if (c->nstages < 2) return RTOC_OK;
-  const size_t lds = rbd::lin_lds_bytes(c->h_model->nlevels, c->h_model->m.njoints, c->h_model->m.ncontacts);
+  const size_t lds = rbd::lin_lds_bytes(c->h_model->nlevels, c->h_model->m.njoints, c->h_model->m.ncontacts, c->h_model->m.nv);
   if (model_has_surface_contacts(c->h_model->m))
     hipLaunchKernelGGL(rbd::linearize_contact_dynamics_kernel<true>, dim3(c->batch * (c->nstages - 1)), dim3(64), lds, c->stream, a);
   else
@@ -1718,6 +1721,46 @@ int rtoc_set_friction_coefficients(rtoc_ctx* c, const double* mu, int ncontacts)
 }
 
 static bool device_cones_on(const rtoc_ctx* c) { return c->cone_contacts > 0 && c->cone_rows == RTOC_FRICTION_ROWS && c->d_mu != nullptr; }
+static bool device_wrench_on(const rtoc_ctx* c) { return c->cone_contacts > 0 && c->cone_rows == RTOC_WRENCH_ROWS && c->d_wcone != nullptr; }
+
+int rtoc_set_wrench_cone_params(rtoc_ctx* c, const double* xy_mu, int ncontacts) {
+  if (!c || !xy_mu || ncontacts < 1 || ncontacts > RTOC_MAX_CONTACTS) return RTOC_ERR_BAD_ARG;
+  std::vector<double> table((size_t)RTOC_MAX_CONTACTS * RTOC_WRENCH_ROWS * 6, 0.0);
+  for (int k = 0; k < ncontacts; ++k) {
+    const int rc = rtoc_wrench_cone_matrix(xy_mu[3 * k], xy_mu[3 * k + 1], xy_mu[3 * k + 2], &table[(size_t)k * RTOC_WRENCH_ROWS * 6]);
+    if (rc) return rc;
+  }
+  HIP_TRY(hipSetDevice(c->device));
+  if (!c->d_wcone) HIP_TRY(hipMalloc((void**)&c->d_wcone, sizeof(double) * table.size()));
+  HIP_TRY(hipMemcpyAsync(c->d_wcone, table.data(), sizeof(double) * table.size(), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return RTOC_OK;
+}
+
+static int launch_wrench_cones(rtoc_ctx* c, int mode) {
+  const rtoc_robot_model& m = c->h_model->m;
+  if (m.ncontacts > c->cone_contacts) return RTOC_ERR_BAD_ARG;
+  for (int k = 0; k < m.ncontacts; ++k)
+    if (m.contact_type[k] != RTOC_CONTACT_SURFACE) return RTOC_ERR_BAD_ARG;
+  WcArgs a;
+  a.sol = c->buf[RTOC_BUF_SOL];
+  a.cdd = c->buf[RTOC_BUF_CDD];
+  a.con = c->buf[RTOC_BUF_CON];
+  a.cone = c->buf[RTOC_BUF_CONE];
+  a.table = c->d_wcone;
+  a.grid = c->d_grid;
+  a.active = c->d_active;
+  a.nstages = c->nstages, a.batch = c->batch, a.ncontacts = m.ncontacts, a.mode = mode;
+  a.row0 = c->dims.nc_max - RTOC_WRENCH_ROWS * c->cone_contacts, a.cone_stride = rtoc_wrench_cone_stride(c->cone_contacts);
+  a.impact_cones = c->impact_cones;
+  a.barrier = c->barrier;
+  a.sol_stride = c->L.sol.stride, a.cdd_stride = c->L.cdd.stride, a.con_stride = c->L.con.stride;
+  a.o_f = c->L.sol.off[RTOC_SOL_F], a.o_lf = c->L.cdd.off[RTOC_CDD_LF];
+  a.nl = c->L.con;
+  hipLaunchKernelGGL(wrench_cone_eval_kernel, dim3(c->batch * (c->nstages - 1)), dim3(64), 0, c->stream, a);
+  HIP_TRY(hipGetLastError());
+  return RTOC_OK;
+}
 
 static int launch_contact_cones(rtoc_ctx* c, int mode) {
   const rtoc_robot_model& m = c->h_model->m;
@@ -1756,14 +1799,15 @@ static int launch_contact_cones(rtoc_ctx* c, int mode) {
 int rtoc_contact_init_constraints(rtoc_ctx* c) {
   CHECK_READY(c);
   if (!c->buf[RTOC_BUF_SOL] || !(c->barrier > 0.0)) return RTOC_ERR_NOT_READY;
-  const bool rows = c->nrows > 0 && c->d_bounds != nullptr, cones = device_cones_on(c);
-  if (!rows && !cones) return RTOC_ERR_NOT_READY;
-  if (cones && (!c->h_model || !c->d_active)) return RTOC_ERR_NOT_READY;
+  const bool rows = c->nrows > 0 && c->d_bounds != nullptr, cones = device_cones_on(c), wrench = device_wrench_on(c);
+  if (!rows && !cones && !wrench) return RTOC_ERR_NOT_READY;
+  if ((cones || wrench) && (!c->h_model || !c->d_active)) return RTOC_ERR_NOT_READY;
   int rc = ensure_buffer(c, RTOC_BUF_CON);
   if (rc) return rc;
   HIP_TRY(hipMemsetAsync(c->buf[RTOC_BUF_CON], 0, sizeof(double) * c->count[RTOC_BUF_CON], c->stream));
   if (rows) rc = launch_ubox(c, UBOX_INIT, true);
   if (!rc && cones) rc = launch_contact_cones(c, CC_INIT);
+  if (!rc && wrench) rc = launch_wrench_cones(c, CC_INIT);
   return rc;
 }
 
@@ -1820,6 +1864,7 @@ int rtoc_contact_eval_kkt(rtoc_ctx* c) {
   // constraints_->linearizeConstraints (intermediate_stage.cpp:109-110, impact_stage.cpp:95-96) of the rows evaluated here
   if (c->nrows > 0 && c->d_bounds && c->buf[RTOC_BUF_CON]) rc = launch_ubox(c, UBOX_LINEARIZE, true);
   if (!rc && device_cones_on(c) && c->buf[RTOC_BUF_CON]) rc = launch_contact_cones(c, CC_LINEARIZE);
+  if (!rc && device_wrench_on(c) && c->buf[RTOC_BUF_CON]) rc = launch_wrench_cones(c, CC_LINEARIZE);
   if (!rc) rc = launch_state_equation(c, true);
   if (!rc) rc = launch_linearize(c, 1, false, 1.0);
   if (!rc && switching) rc = launch_switching_constraint(c);

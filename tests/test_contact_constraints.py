@@ -238,3 +238,106 @@ def test_anymal_trot_with_joint_limits_and_friction_cones_converges_on_the_devic
     assert worst["g_max"] < 0.0 and worst["slack_gap"] < 1e-7 and worst["central_path"] < 1e-7 and worst["IDC"] < 1e-7
     assert near["torque"] > 0 or near["cone"] > 0   # the limits shape the solution
     ctx.close()
+
+
+Q_ICUB = np.array([0, 0, 0.592, 0, 0, 1, 0,
+                   0.20944, 0.08727, 0, -0.1745, -0.0279, -0.08726, 0.20944, 0.08727, 0, -0.1745, -0.0279, -0.08726,
+                   0, 0, 0, 0, 0.35, 0.5, 0.5, 0, 0, 0, 0, 0.35, 0.5, 0.5, 0, 0, 0])   # examples/icub/python/jump_sto.py:21-26
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cones", ["friction", "wrench"])
+def test_icub_on_two_soles_with_limits_and_cones_converges_on_the_device(oracle, cones):
+    """iCub (nv = 35, two surface contacts: six contact rows each, Log6 placement error) standing on both soles, N = 15:
+    ConfigurationSpaceCost, the six joint-limit components and either FrictionCone on the first three wrench components
+    (examples/icub/python/jump_sto.py:60-68) or ContactWrenchCone (17 rows per sole: friction pyramid, centre of pressure
+    inside the 0.2 x 0.1 sole, yaw torque) -- every part of the iteration on the device."""
+    from robotoc_amd.grid import uniform_grid
+    from robotoc_amd.types import icub_dims
+    m = rm.load_named("icub")
+    nv, nq, nu = m.nv, m.nq, m.nv - 6
+    cone_rows = 10 if cones == "friction" else 34
+    dims = icub_dims(nv, nc_max=(6 * nu + cone_rows + 7) & ~7)
+    N, dt, batch = 15, 0.02, 2
+    grids = uniform_grid(N, dt, dimf=12)
+    n = len(grids)
+    placements = [oracle.rbd_contact_placement(m, Q_ICUB, c) for c in range(2)]
+    pos = np.tile(np.array([p for _, p in placements])[None], (n, 1, 1))
+    rot = np.tile(np.array([R.reshape(9) for R, _ in placements])[None], (n, 1, 1))
+    ctx = capi.Context(dims, n, batch, 0)
+    ctx.set_grid(grids)
+    ctx.set_robot_model(m)
+    ctx.set_contact_schedule(np.full(n, 0b11, dtype=np.uint32), pos, rot)
+    rows = joint_limit_rows(dims)
+    ctx.set_constraint_rows(rows)
+    mu = 0.6
+    if cones == "friction":
+        ctx.set_friction_cones(2, 6)
+    else:
+        ctx.set_wrench_cones(2)
+    bounds = limits(nu, qmax=2.5, vmax=5.0, umax=60.0)
+    ctx.set_constraint_bounds(bounds, BARRIER, 0.995)
+    if cones == "friction":
+        ctx.set_friction_coefficients(np.full(2, mu))
+    else:
+        ctx.set_wrench_cone_params(np.array([[0.1, 0.05, mu], [0.1, 0.05, mu]]))
+    q_ref = Q_ICUB.copy()
+    q_ref[2] -= 0.03   # squat a little
+    wq = np.concatenate([np.full(6, 10.0), np.full(nu, 0.1)])
+    ctx.set_configuration_cost(q_ref, np.zeros(nv), np.zeros(nu), wq, np.full(nv, 0.1), np.full(nv, 1e-3), np.full(nu, 1e-4), 10.0 * wq, np.full(nv, 0.1))
+    x0 = np.tile(np.concatenate([Q_ICUB, np.zeros(nv)]), (batch, 1))
+    x0[1, nq:] = 0.02 * np.random.default_rng(8).uniform(-1, 1, nv)
+    ctx.set_initial_state(x0)
+    S, Nn = Records(ctx.L, "sol"), Records(ctx.L, "con")
+    sol = S.zeros(batch, n)
+    mass = sum(m.mass[i] for i in range(m.njoints))
+    f0 = np.concatenate([np.concatenate([R.T @ np.array([0.0, 0.0, 9.81 * mass / 2]), np.zeros(3)]) for R, _ in placements])
+    for b in range(batch):
+        S.f(sol[b], "q")[:, :nq] = x0[b, :nq]
+        S.f(sol[b], "f")[:, :12] = f0
+    ctx.upload(BUF_SOL, sol)
+    ctx.contact_init_constraints()
+    hist = []
+    for it in range(120):
+        hist.append(ctx.contact_update_solution(0.995))
+        if hist[-1].max() < 1e-8:
+            break
+    hist = np.array(hist)
+    print("iCub, %s cones: KKT error per iteration (worst instance):" % cones, ["%.1e" % e for e in hist.max(axis=1)])
+    assert (ctx.status() == 0).all() and hist[-1].max() < 1e-6
+    sol, con = ctx.download_records(BUF_SOL, "sol"), ctx.download_records(BUF_CON, "con")
+    row0 = dims.nc_max - cone_rows
+    worst = dict(g_max=-np.inf, slack_gap=0.0, central_path=0.0, IDC=0.0)
+    A = None
+    if cones == "wrench":
+        A = np.zeros((17, 6), order="F")
+        capi.lib().rtoc_wrench_cone_matrix(0.1, 0.05, mu, A.ctypes.data_as(capi.C.POINTER(capi.C.c_double)))
+    for b in range(batch):
+        for i in range(n - 1):
+            s = sol[b, i]
+            q, v, a, u, f = S.f(s, "q")[:nq], S.f(s, "v"), S.f(s, "a"), S.f(s, "u"), S.f(s, "f")
+            slack, dual = Nn.f(con[b, i], "slack"), Nn.f(con[b, i], "dual")
+            r = oracle.rbd_eval(m, 0, q, v, a, f[:12], u[:nu], 0b11, pos[i].reshape(-1), rot[i].reshape(-1))
+            worst["IDC"] = max(worst["IDC"], np.abs(r).max())
+            for k in range(2):
+                if cones == "friction":
+                    # the cone stands on the contact surface: ContactStatus::contactRotation = the desired sole rotation
+                    gval = cone_world(mu) @ rot[i, k].reshape(3, 3).T @ (oracle.rbd_contact_placement(m, q, k)[0] @ f[6 * k:6 * k + 3])
+                    rr = slice(row0 + 5 * k, row0 + 5 * k + 5)
+                else:
+                    gval = A @ f[6 * k:6 * k + 6]
+                    rr = slice(row0 + 17 * k, row0 + 17 * k + 17)
+                worst["g_max"] = max(worst["g_max"], gval.max())
+                worst["slack_gap"] = max(worst["slack_gap"], np.abs(gval + slack[rr]).max())
+                worst["central_path"] = max(worst["central_path"], np.abs(slack[rr] * dual[rr] - BARRIER).max())
+            for k, w in enumerate(rows):
+                if grids[i].time_stage < w.level:
+                    continue
+                z = q[w.index + 1] if w.var == 0 else (v[w.index] if w.var == 1 else u[w.index])
+                worst["g_max"] = max(worst["g_max"], w.sign * z - bounds[k])
+                gap = abs(w.sign * z - bounds[k] + slack[k])
+                assert gap < 1e-6, ("joint-limit row", k, w.var, w.index, w.sign, w.level, i, z, bounds[k], slack[k])
+                worst["slack_gap"] = max(worst["slack_gap"], gap)
+    print("converged iCub stand:", worst)
+    assert worst["g_max"] < 0.0 and worst["slack_gap"] < 1e-6 and worst["central_path"] < 1e-6 and worst["IDC"] < 1e-6
+    ctx.close()

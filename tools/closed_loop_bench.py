@@ -1,5 +1,5 @@
 """Times bench.closed_loop_trot (the whole constrained ANYmal-trot solver iteration on the device) on its own.
-usage: python tools/closed_loop_bench.py [batch]"""
+usage: python tools/closed_loop_bench.py [batch] [--batch-only]"""
 import json
 import os
 import sys
@@ -9,4 +9,7 @@ import bench  # noqa: E402
 
 if __name__ == "__main__":
     batch = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-    print(json.dumps({"single_instance": bench.closed_loop_trot(0, 1), "batch": bench.closed_loop_trot(0, batch)}, indent=1))
+    out = {"batch": bench.closed_loop_trot(0, batch)}
+    if "--batch-only" not in sys.argv:
+        out["single_instance"] = bench.closed_loop_trot(0, 1)
+    print(json.dumps(out, indent=1))
