@@ -88,8 +88,7 @@ int rtoc_linearize_contact_dynamics(rtoc_ctx* ctx, int augment_residual);
  * hv, ha; the impacting contacts and their positions are those of the impact grid two points ahead in the contact
  * schedule; free-flyer transport: RTOC_OPT_SWITCHING_TRANSPORT) -- RTOC_BUF_SOL in, the pre-condensation records
  * RTOC_BUF_KKT / RTOC_BUF_CDD, RTOC_BUF_SE3 and RTOC_BUF_DX0 out; rtoc_newton_iteration takes it from there.  Needs
- * rtoc_set_robot_model, rtoc_set_contact_schedule, rtoc_set_configuration_cost, rtoc_set_initial_state.
- * RTOC_ERR_BAD_ARG for a switching constraint on a model with surface contacts (point contacts only). */
+ * rtoc_set_robot_model, rtoc_set_contact_schedule, rtoc_set_configuration_cost, rtoc_set_initial_state. */
 int rtoc_contact_eval_kkt(rtoc_ctx* ctx);
 
 /* ---- inequality rows of the contact path evaluated on the device (the Constraints object of examples/anymal/trot.cpp:

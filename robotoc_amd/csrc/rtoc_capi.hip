@@ -1822,6 +1822,7 @@ static int launch_switching_constraint(rtoc_ctx* c) {
   a.grid = c->d_grid;
   a.active = c->d_active;
   a.positions = c->has_cpos ? c->d_cpos : nullptr;
+  a.rotations = c->has_crot ? c->d_crot : nullptr;
   a.nstages = c->nstages, a.batch = c->batch, a.nv = m.nv, a.nq = m.nq, a.njoints = m.njoints, a.ncontacts = m.ncontacts;
   a.nlevels = c->h_model->nlevels, a.floating = m.type[0] == RTOC_JOINT_FREE_FLYER, a.ns_max = c->dims.ns_max;
   a.exact_transport = c->exact_transport;
@@ -1844,7 +1845,6 @@ int rtoc_contact_eval_kkt(rtoc_ctx* c) {
   if (!c->h_model || !c->d_active || !c->d_cost || !c->buf[RTOC_BUF_SOL]) return RTOC_ERR_NOT_READY;
   bool switching = false;
   for (int i = 0; i < c->nstages; ++i) switching = switching || c->h_grid[i].switching_constraint;
-  if (switching && model_has_surface_contacts(c->h_model->m)) return RTOC_ERR_BAD_ARG;
   int rc = ensure_buffer(c, RTOC_BUF_KKT);
   if (!rc) rc = ensure_buffer(c, RTOC_BUF_CDD);
   if (rc) return rc;

@@ -1,9 +1,10 @@
-// switching_constraint_lin.hpp -- linearizeSwitchingConstraint on the device (point contacts).
+// switching_constraint_lin.hpp -- linearizeSwitchingConstraint on the device.
 //
 // Replaces linearizeSwitchingConstraint (reference src/dynamics/switching_constraint.cpp:26-70) on the grid point two ahead
 // of an impact (GridInfo::switching_constraint): the contacts that become active at the impact must sit at their desired
 // positions at the configuration predicted two steps ahead,
 //     q+ = q (+) dq,   dq = (dt1 + dt2) v + dt1 dt2 a,   P = position(q+) - desired          (:14-23)
+//     (surface contacts: P = Log6(X_desired^-1 X_frame(q+)), six rows, Pq = Jlog6 J_frame,local: surface_contact.hxx:106-128)
 //     Pq = R_of J_frame,lin at q+ (point_contact.hxx:133-142),  Phiq = Pq dIntegrate_dq(q, dq),  Phiv = (dt1+dt2) Pq dIntegrate_dv(q, dq),
 //     Phia = dt1 dt2 Pq dIntegrate_dv(q, dq)                                                  (:41-51)
 // with Pinocchio's dIntegrate on the free-flyer base restated: dIntegrate_dq = Ad_{exp(dq_b)}^-1 (the motion actInv),
@@ -25,6 +26,7 @@ struct SwLinArgs {
   const rtoc_grid* grid;
   const unsigned* active;
   const double* positions;  // [nstages][ncontacts][3] or nullptr
+  const double* rotations;  // [nstages][ncontacts][9] or nullptr (surface contacts)
   int nstages, batch, nv, nq, njoints, ncontacts, nlevels, floating, ns_max;
   int exact_transport;  // RTOC_OPT_SWITCHING_TRANSPORT
   int sol_stride, kkt_stride, cdd_stride;
@@ -35,7 +37,7 @@ struct SwLinArgs {
 
 __host__ __device__ constexpr size_t sw_lds_bytes(int nlevels, int njoints, int ncontacts) {
   return sizeof(double) * ((size_t)nlevels * (32 + 6 * 64) + njoints * rbd::JP + ncontacts * rbd::CP + 3 * (RTOC_MAX_JOINTS + 8) +
-                           6 * RTOC_MAX_CONTACTS * 8 + 2 * 36 + 3 * RTOC_MAX_CONTACTS * (RTOC_MAX_JOINTS + 8));
+                           6 * RTOC_MAX_CONTACTS * 8 + 2 * 36 + 6 * RTOC_MAX_CONTACTS * (RTOC_MAX_JOINTS + 8));
 }
 
 static __global__ __launch_bounds__(64) void switching_constraint_lin_kernel(SwLinArgs a) {
@@ -155,16 +157,38 @@ static __global__ __launch_bounds__(64) void switching_constraint_lin_kernel(SwL
     int r0 = 0;
     for (int c = 0; c < ncon; ++c) {
       const bool on = (impact >> c) & 1u;
+      const bool surf = (int)scm[c * CP + 15] == RTOC_CONTACT_SURFACE;
       if (on && (int)scm[c * CP + 14] == i) {
         const M3 Rf = rbd::ldm3(&scm[c * CP]);
         const V3 pf = rbd::ldv3(&scm[c * CP + 9]);
+        const M3 oRf = rbd::mul(oR, Rf);
         const V3 pw = op + rbd::mul(oR, pf);
         const V3 pr = a.positions ? rbd::ldv3(a.positions + ((size_t)(st + 2) * ncon + c) * 3) : rbd::mk(0, 0, 0);
-        const V3 col = rbd::mul(rbd::mul(oR, Rf), rbd::act_inv(Rf, pf, Jc).l);   // R_of J_frame,lin
-        if (lane == 0) spq[6 * RTOC_MAX_CONTACTS * 4 + r0] = pw.x - pr.x, spq[6 * RTOC_MAX_CONTACTS * 4 + r0 + 1] = pw.y - pr.y, spq[6 * RTOC_MAX_CONTACTS * 4 + r0 + 2] = pw.z - pr.z;
-        if (lane_on) sPq[(r0 + 0) * nv + j] = col.x, sPq[(r0 + 1) * nv + j] = col.y, sPq[(r0 + 2) * nv + j] = col.z;
+        const SV jf = rbd::act_inv(Rf, pf, Jc);   // this lane's column of the LOCAL frame Jacobian
+        double* const Pres = spq + 6 * RTOC_MAX_CONTACTS * 4;
+        if (!surf) {
+          const V3 col = rbd::mul(oRf, jf.l);     // R_of J_frame,lin (point_contact.hxx:133-142)
+          if (lane == 0) Pres[r0] = pw.x - pr.x, Pres[r0 + 1] = pw.y - pr.y, Pres[r0 + 2] = pw.z - pr.z;
+          if (lane_on) sPq[(r0 + 0) * nv + j] = col.x, sPq[(r0 + 1) * nv + j] = col.y, sPq[(r0 + 2) * nv + j] = col.z;
+        } else {
+          // P = Log6(X_desired^-1 X_frame), Pq = Jlog6(X_diff) J_frame,local (surface_contact.hxx:106-128): forward mode
+          M3 Rdt;   // transpose of the desired rotation (identity if none was set)
+#pragma unroll
+          for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc)
+              Rdt.m[3 * r + cc] = a.rotations ? a.rotations[((size_t)(st + 2) * ncon + c) * 9 + 3 * cc + r] : (r == cc ? 1.0 : 0.0);
+          SV lg, dlg;
+          rbd::log6_fwd(rbd::mul(Rdt, oRf), rbd::mul(Rdt, pw - pr), jf, lg, dlg);
+          const double pv[6] = {lg.l.x, lg.l.y, lg.l.z, lg.a.x, lg.a.y, lg.a.z}, dv6[6] = {dlg.l.x, dlg.l.y, dlg.l.z, dlg.a.x, dlg.a.y, dlg.a.z};
+#pragma unroll
+          for (int t = 0; t < 6; ++t) {
+            if (lane == 0) Pres[r0 + t] = pv[t];
+            if (lane_on) sPq[(r0 + t) * nv + j] = dv6[t];
+          }
+        }
       }
-      r0 += on ? 3 : 0;
+      r0 += on ? (surf ? 6 : 3) : 0;
     }
   }
   // ---- transports of the base block: Tq = Ad_{exp(dq_b)}^-1, Jr = Jlog6(exp6(dq_b))^-1 ----
