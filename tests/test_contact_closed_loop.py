@@ -224,3 +224,64 @@ def test_anymal_trot_with_touch_downs_converges_on_the_device(oracle):
             if (int(masks[i]) >> c) & 1 and grids[i].type != GRID_IMPACT:
                 assert np.abs(oracle.rbd_contact_position(m, q, c) - pos[i, c]).max() < 5e-3
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_icub_hop_with_surface_contacts_converges_on_the_device(oracle):
+    """BASELINE configs[3]'s robot and horizon (iCub, nv = 35, N = 30) through stand - flight - stand: lift grid, a flight
+    phase without contact rows, the touch-down of both soles with its switching constraint (Log6 placement rows of surface
+    contacts, 12 of them), the impact dynamics -- cost and dynamics only (Gauss-Newton iterations without a line search: the
+    inequality rows make this particular problem stall; they are covered on the stand, tests/test_contact_constraints.py)."""
+    from robotoc_amd.grid import ContactSequence, Event, contact_masks, discretize
+    from robotoc_amd.types import GRID_IMPACT, icub_dims
+    from test_switching_constraint_lin import Q_ICUB
+    m = rm.load_named("icub")
+    nv, nq, nu = m.nv, m.nq, m.nv - 6
+    dims = icub_dims(nv)
+    grids = discretize(30, 0.6, 0.0, ContactSequence([12, 0, 12], [Event("lift", 0.25), Event("impact", 0.36, impact_dimf=12)]))
+    n = len(grids)
+    masks = contact_masks(grids, [0b11, 0, 0b11], [0b11])
+    place = [oracle.rbd_contact_placement(m, Q_ICUB, c) for c in range(2)]
+    pos = np.tile(np.array([p for _, p in place])[None], (n, 1, 1))
+    rot = np.tile(np.array([R.reshape(9) for R, _ in place])[None], (n, 1, 1))
+    ctx = capi.Context(dims, n, 1, 0)
+    ctx.set_grid(grids)
+    ctx.set_robot_model(m)
+    ctx.set_contact_schedule(masks, pos, rot)
+    wq = np.concatenate([np.full(6, 10.0), np.full(nu, 0.1)])
+    ctx.set_configuration_cost(Q_ICUB, np.zeros(nv), np.zeros(nu), wq, np.full(nv, 0.1), np.full(nv, 1e-3), np.full(nu, 1e-4), 10 * wq, np.full(nv, 0.1),
+                               q_weight_impact=wq, v_weight_impact=np.full(nv, 0.1), dv_weight_impact=np.full(nv, 1e-3))
+    ctx.set_initial_state(np.concatenate([Q_ICUB, np.zeros(nv)])[None])
+    S = Records(ctx.L, "sol")
+    sol = S.zeros(1, n)
+    mass = sum(m.mass[i] for i in range(m.njoints))
+    f0 = np.concatenate([np.concatenate([R.T @ np.array([0, 0, 9.81 * mass / 2]), np.zeros(3)]) for R, _ in place])
+    S.f(sol[0], "q")[:, :nq] = Q_ICUB
+    for i in range(n):
+        if masks[i] and grids[i].type != GRID_IMPACT:
+            S.f(sol[0, i], "f")[:12] = f0
+    ctx.upload(BUF_SOL, sol)
+    hist = []
+    for it in range(150):
+        hist.append(ctx.contact_update_solution()[0])
+        if hist[-1] < 1e-8:
+            break
+    print("iCub hop: %d iterations," % len(hist), ["%.1e" % e for e in hist[:4]], "...", ["%.1e" % e for e in hist[-3:]])
+    assert (ctx.status() == 0).all() and hist[-1] < 1e-8
+    sol = ctx.download_records(BUF_SOL, "sol")[0]
+    worst = dict(IDC=0.0, switching=0.0, air=np.inf)
+    for i in range(n - 1):
+        s, g = sol[i], grids[i]
+        q, v, a = S.f(s, "q")[:nq], S.f(s, "v"), S.f(s, "a")
+        r = oracle.rbd_eval(m, int(g.type == GRID_IMPACT), q, v, a, S.f(s, "f")[:12], S.f(s, "u")[:nu], int(masks[i]), pos[i].reshape(-1), rot[i].reshape(-1))
+        worst["IDC"] = max(worst["IDC"], np.abs(r).max())
+        if g.switching_constraint:
+            dt1, dt2 = g.dt, grids[i + 1].dt
+            qp = oracle.rbd_integrate(m, q, (dt1 + dt2) * v + dt1 * dt2 * a)
+            for c in range(2):
+                R, p = oracle.rbd_contact_placement(m, qp, c)
+                Rd = rot[i + 2, c].reshape(3, 3)
+                worst["switching"] = max(worst["switching"], np.abs(oracle.rbd_log6(Rd.T @ R, Rd.T @ (p - pos[i + 2, c]))).max())
+    print("converged hop, worst residuals by the CPU restatement:", worst)
+    assert worst["IDC"] < 1e-6 and worst["switching"] < 1e-7
+    ctx.close()
