@@ -559,7 +559,7 @@ def main():
                                              "note": "instruction-bound: 13.4k fp64 VALU instructions per grid point (one wave, one lane per "
                                                      "tangent direction), profiles/%s_rocprof_summary.txt" % PROFILE_ROUND},
                                 "scope": "linearizeContactDynamics / linearizeImpactDynamics incl. the multiplier terms; NOT part of "
-                                         "newton_iteration_ms (cost / constraint derivatives stay on the CPU side)",
+                                         "newton_iteration_ms, which starts from pre-condensation records; part of closed_loop_constrained_trot",
                                 "status_nonzero_instances": int((ctx.status() != 0).sum())}
             del sol_t
         del kkt0, cdd0, con0, kkt_w, cdd_w, con_w, cone_t
@@ -589,7 +589,8 @@ def main():
                     pr.fill_unconstr_instance(L2, len(g2), k1[0], np.random.default_rng(1))
                     k2[...] = torch.from_numpy(k1).to(dev)
                     c2.bind(BUF_KKT, k2.data_ptr())
-                    c2.unconstr_backward(info["dt"])  # materialises the structured A, B once
+                    c2.set_unconstr_dense(True)       # the general kernels (timed first, for comparison) ...
+                    c2.unconstr_backward(info["dt"])  # ... need the structured A, B materialised once
                 else:
                     pr.make_kkt_batch_unique(L2, g2, b2, seed=7, backend="torch", device=dev, out=k2)
                     c2.bind(BUF_KKT, k2.data_ptr())
@@ -599,11 +600,30 @@ def main():
                 c2.time_phase(4, 1)
                 mb, mf = c2.time_phase(0, 3), c2.time_phase(1, 3)
                 ok = int((c2.status() != 0).sum()) == 0
+                if name.startswith("iiwa"):
+                    # the path rtoc_unconstr_backward / _forward take by default: the structured recursion (block adds of P+,
+                    # unconstr_riccati.hpp); wall clock around asynchronous launches.  mb / mf above: the general kernels on
+                    # materialised A, B (RTOC_OPT_UNCONSTR_DENSE), kept as `dense_*`.
+                    c2.set_unconstr_dense(False)
+
+                    def wall(fn, reps=100 if b2 == 1 else 30):
+                        fn()
+                        c2.sync()
+                        t0 = time.perf_counter()
+                        for _ in range(reps):
+                            fn()
+                        c2.sync()
+                        return (time.perf_counter() - t0) / reps * 1e3
+                    sb, sf = wall(lambda: c2.unconstr_backward(info["dt"])), wall(lambda: c2.unconstr_forward(info["dt"]))
+                    ok = ok and int((c2.status() != 0).sum()) == 0
+                    entry["dense_%s_backward_ms" % label], entry["dense_%s_forward_ms" % label] = mb, mf
+                    mb, mf = sb, sf
                 if b2 == 1:
                     entry["single_instance_sweep_ms"] = mb + mf
                     entry["single_instance_backward_ms"] = mb
                     if not any(g.sto or g.sto_next for g in g2):
                         # RTOC_OPT_BACKWARD_SCAN: both recursions as scans over the horizon (latency path)
+                        c2.set_unconstr_dense(True)   # (the scan works on the general elements)
                         c2.set_backward_scan(True)
                         c2.time_phase(4, 2)
                         ms, msf = c2.time_phase(0, 5), c2.time_phase(1, 5)
@@ -614,6 +634,9 @@ def main():
                         ok = ok and int((c2.status() != 0).sum()) == 0
                 else:
                     ab, fl = algorithmic_bytes(L2, g2, b2, "backward"), backward_flops(L2, g2, b2)
+                    if name.startswith("iiwa"):   # structured: Fxx / Fvu are never read (nor exist)
+                        nx_, nv_ = L2.nx, d2.nv
+                        ab = 8 * b2 * ((len(g2) - 1) * (2 * nx_ * nx_ + 2 * nx_ * nv_ + nv_ * nv_ + 3 * nx_ + 2 * nv_) + 2 * (nx_ * nx_ + nx_))
                     entry.update({"batch": b2, "distinct_instances": b2, "backward_ms": mb, "forward_ms": mf,
                                   "sweeps_per_sec": b2 / (mb + mf) * 1e3,
                                   "roofline": {"kernel": "riccati_backward", "kernel_ms": mb,

@@ -132,6 +132,9 @@ enum rtoc_option {
                       * cones; arguments kkt_tol / tau are part of the key).  For the single-OCP latency path, whose
                       * ~25 small kernels are launch-bound.  The calls stay asynchronous on the context's stream; the
                       * stream must not be capturing already.  Default 0. */
+  RTOC_OPT_UNCONSTR_DENSE = 12, /* 0 (default): rtoc_unconstr_backward / _forward run the structured recursion (block adds of P+,
+                      * unconstr_backward_riccati_recursion_factorizer.cpp:27-70); 1: the general kernels on materialised A, B
+                      * (what RTOC_OPT_BACKWARD_SCAN needs; same results to round-off) */
   RTOC_OPT_IMPACT_CONES = 11, /* 1 (default): the friction / wrench cone rows also act on impact grids (a Constraints object
                       * holding FrictionCone AND ImpactFrictionCone, examples/anymal/run.cpp:173-181); 0: impact grids carry no
                       * cone rows (FrictionCone only, examples/anymal/trot.cpp:134-146) -- condensation, expansion, step

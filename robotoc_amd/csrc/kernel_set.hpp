@@ -16,6 +16,7 @@
 #include "riccati_backward_rs.hpp"
 #include "riccati_scan.hpp"
 #include "riccati_forward.hpp"
+#include "unconstr_riccati.hpp"
 
 namespace rtoc {
 
@@ -28,11 +29,12 @@ typedef void (*cond_fn)(CondArgs);
 typedef void (*expd_fn)(ExpArgs);
 typedef void (*scan_fn)(ScanArgs);
 typedef void (*fscan_fn)(FwdScanArgs);
+typedef void (*ur_fn)(UrArgs);
 // what a shape plugin must agree on with the runtime that loads it: the kernel-set table and every argument block
 constexpr size_t kernel_abi_stamp() {
   size_t h = 1469598103934665603ull;
   const size_t parts[] = {sizeof(BwdArgs), sizeof(FwdArgs), sizeof(FillArgs), sizeof(UdArgs), sizeof(ConeArgs), sizeof(CondArgs),
-                          sizeof(ExpArgs), sizeof(ScanArgs), sizeof(FwdScanArgs)};
+                          sizeof(ExpArgs), sizeof(ScanArgs), sizeof(FwdScanArgs), sizeof(UrArgs)};
   for (size_t v : parts) h = (h ^ v) * 1099511628211ull;
   return h;
 }
@@ -50,6 +52,7 @@ struct KernelSet {
   int fwd_threads;
   fill_fn fill;
   ud_fn ucond, uexp;  // UnconstrDynamics condense / expand
+  ur_fn ubwd, ufwd;   // structured unconstrained Riccati recursion (unconstr_riccati.hpp); nullptr unless nu == nv, ns == 0
   cone_fn ccond, cexp;  // friction-cone rows
   cone_fn wcond, wexp;  // contact-wrench-cone rows
   cond_fn cond;
@@ -109,6 +112,11 @@ inline KernelSet make_set() {
   k.fill = unconstr_fill_kernel<NV>;
   k.ucond = unconstr_condense_kernel<NV>;
   k.uexp = unconstr_expand_kernel<NV>;
+  if constexpr (NU == NV && NS == 0 && 2 * NV + 1 <= 64) {
+    if constexpr (NV <= 8) k.ubwd = unconstr_riccati_backward_kernel<NV>;
+    else k.ubwd = unconstr_riccati_backward_lds_kernel<NV>;
+    k.ufwd = unconstr_riccati_forward_kernel<NV>;
+  }
   k.ccond = cone_condense_kernel<NV, NS>;
   k.cexp = cone_expand_kernel<NV, NS>;
   k.wcond = wrench_condense_kernel<NV, NS>;

@@ -162,6 +162,7 @@ struct rtoc_ctx {
   // RTOC_OPT_GRAPH: launch sequences replayed from captured hipGraphs
   int use_graph;
   int exact_transport;  // RTOC_OPT_SWITCHING_TRANSPORT
+  int unconstr_dense;   // RTOC_OPT_UNCONSTR_DENSE
   int impact_cones;     // RTOC_OPT_IMPACT_CONES (default 1, rtoc_create)
   double* d_mu;         // rtoc_set_friction_coefficients
   double* d_wcone;      // rtoc_set_wrench_cone_params: [RTOC_MAX_CONTACTS][17 x 6]
@@ -397,6 +398,7 @@ int rtoc_clone(rtoc_ctx* c, rtoc_ctx** out) {
     n->use_graph = c->use_graph;
     n->exact_transport = c->exact_transport;
     n->impact_cones = c->impact_cones;
+    n->unconstr_dense = c->unconstr_dense;
     if (c->backward_scan) rc = rtoc_set_option(n, RTOC_OPT_BACKWARD_SCAN, c->backward_scan);
   }
   hipError_t e = hipStreamSynchronize(c->stream);
@@ -502,6 +504,9 @@ int rtoc_set_option(rtoc_ctx* c, int option, int64_t value) {
       c->max_dts0 = d;
       return RTOC_OK;
     }
+    case RTOC_OPT_UNCONSTR_DENSE:
+      c->unconstr_dense = value ? 1 : 0;
+      return RTOC_OK;
     case RTOC_OPT_IMPACT_CONES:
       c->impact_cones = value ? 1 : 0;
       return RTOC_OK;
@@ -1066,9 +1071,35 @@ static int launch_fill(rtoc_ctx* c, double dt) {
   return RTOC_OK;
 }
 
+// UnconstrRiccatiRecursion in its structured form (unconstr_riccati.hpp): whenever the shape has the kernels and the
+// horizon scan is not asked for (the scan works on the general elements, i.e. on materialised A, B)
+static bool unconstr_structured(const rtoc_ctx* c) {
+  return c->ks->ubwd != nullptr && c->dims.nf_max == 0 && !scan_applies(c) && !c->unconstr_dense;
+}
+static int launch_unconstr_riccati(rtoc_ctx* c, double dt, bool forward) {
+  int rc = ensure_buffer(c, RTOC_BUF_RIC);
+  if (!rc && forward) rc = ensure_buffer(c, RTOC_BUF_DIR);
+  if (rc) return rc;
+  if (!c->buf[RTOC_BUF_KKT]) return RTOC_ERR_NOT_READY;
+  UrArgs a;
+  a.kkt = c->buf[RTOC_BUF_KKT];
+  a.kkt_rw = c->buf[RTOC_BUF_KKT];
+  a.ric = c->buf[RTOC_BUF_RIC];
+  a.dir = c->buf[RTOC_BUF_DIR];
+  a.dx0 = c->buf[RTOC_BUF_DX0];
+  a.status = c->d_status;
+  a.nstages = c->nstages, a.batch = c->batch, a.writeback = c->writeback;
+  a.dt = dt;
+  a.kl = c->L.kkt, a.rl = c->L.ric, a.dl = c->L.dir;
+  hipLaunchKernelGGL(forward ? c->ks->ufwd : c->ks->ubwd, dim3(c->batch), dim3(64), 0, c->stream, a);
+  HIP_TRY(hipGetLastError());
+  return RTOC_OK;
+}
+
 int rtoc_unconstr_backward(rtoc_ctx* c, double dt) {
   CHECK_READY(c);
   if (c->dims.nu != c->dims.nv || !(dt > 0.0)) return RTOC_ERR_BAD_ARG;
+  if (unconstr_structured(c)) return launch_unconstr_riccati(c, dt, false);
   int rc = launch_fill(c, dt);
   if (rc) return rc;
   return launch_backward(c);
@@ -1108,6 +1139,7 @@ int rtoc_unconstr_expand(rtoc_ctx* c, double dt) {
 int rtoc_unconstr_forward(rtoc_ctx* c, double dt) {
   CHECK_READY(c);
   if (c->dims.nu != c->dims.nv || !(dt > 0.0)) return RTOC_ERR_BAD_ARG;
+  if (unconstr_structured(c)) return launch_unconstr_riccati(c, dt, true);
   return launch_forward(c);
 }
 

@@ -10,7 +10,7 @@ Tolerance (SURVEY 8c / BASELINE north_star "stated fp64 tolerance"):
 import numpy as np
 import pytest
 
-from helpers import compare_direction, compare_riccati
+from helpers import compare_direction, compare_riccati, rel_err
 from robotoc_amd import problems as pr
 from robotoc_amd.types import BUF_DIR, BUF_DX0, BUF_KKT, BUF_RIC, Records
 
@@ -128,15 +128,20 @@ def test_plain_horizon_no_events(oracle):
     _run_case(oracle, anymal_dims(), uniform_grid(20, 0.025, dimf=12), 5, "factory")
 
 
-def test_iiwa14_unconstr(oracle):
-    """configs[0]: iiwa14 UnconstrOCPSolver path (structured A, B materialised on device)."""
+@pytest.mark.parametrize("dense", [False, True])
+def test_iiwa14_unconstr(oracle, dense):
+    """configs[0]: iiwa14 UnconstrOCPSolver path -- the structured recursion (block adds of P+, unconstr_riccati.hpp; the
+    default) and the general kernels on materialised A, B (RTOC_OPT_UNCONSTR_DENSE), both against the oracle; with
+    RTOC_OPT_WRITEBACK_KKT the mutated Qxx, Qxu, Qaa, la as the reference leaves them in place."""
     from robotoc_amd import capi
     dims, grids, info = pr.config_iiwa14()
-    batch = 4
+    batch = 70
     ctx = capi.Context(dims, len(grids), batch, 0)
     try:
         L = ctx.L
         ctx.set_grid(grids)
+        ctx.set_unconstr_dense(dense)
+        ctx.set_writeback(True)
         K = Records(L, "kkt")
         kkt = K.zeros(batch, len(grids))
         for b in range(batch):
@@ -146,16 +151,34 @@ def test_iiwa14_unconstr(oracle):
         ctx.upload(BUF_DX0, dx0)
         ctx.unconstr_backward(info["dt"])
         ctx.unconstr_forward(info["dt"])
+        assert (ctx.status() == 0).all()
         ric = ctx.download_records(BUF_RIC, "ric")
         d = ctx.download_records(BUF_DIR, "dir")
+        kkt_gpu = ctx.download_records(BUF_KKT, "kkt")
         R = Records(L, "ric")
         D = Records(L, "dir")
         ric_ref = R.zeros(batch, len(grids))
         d_ref = D.zeros(batch, len(grids))
-        oracle.unconstr_sweep_batch(L, len(grids), info["dt"], kkt.copy(), ric_ref, d_ref, dx0=dx0)
+        kkt_ref = kkt.copy()
+        oracle.unconstr_sweep_batch(L, len(grids), info["dt"], kkt_ref, ric_ref, d_ref, dx0=dx0)
+        worst = 0.0
         for b in range(batch):
-            compare_riccati(L, grids, ric[b], ric_ref[b], TOL, "iiwa inst %d" % b)
-            compare_direction(L, grids, d[b], d_ref[b], TOL, "iiwa inst %d" % b)
+            worst = max(worst, compare_riccati(L, grids, ric[b], ric_ref[b], TOL, "iiwa inst %d" % b))
+            worst = max(worst, compare_direction(L, grids, d[b], d_ref[b], TOL, "iiwa inst %d" % b))
+            if not dense:
+                for f in ("Qxx", "Qxu", "Quu", "lu"):
+                    e = rel_err(K.f(kkt_gpu[b, :-1], f), K.f(kkt_ref[b, :-1], f))
+                    assert e < TOL, (f, e)
+        print("iiwa14 unconstrained sweep (%s): worst rel err %.2e" % ("general kernels" if dense else "structured", worst))
+        # a non-SPD Qaa raises the status bit (the reference asserts in Debug only: unconstr_riccati_factorizer.cpp:32)
+        if not dense:
+            bad = kkt.copy()
+            K.f(bad[3, 5], "Quu")[:] = -np.eye(dims.nv)
+            ctx.upload(BUF_KKT, bad)
+            ctx.clear_status()
+            ctx.unconstr_backward(info["dt"])
+            st = ctx.status()
+            assert st[3] != 0 and (np.delete(st, 3) == 0).all()
     finally:
         ctx.close()
 
