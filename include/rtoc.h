@@ -132,6 +132,9 @@ enum rtoc_option {
                       * cones; arguments kkt_tol / tau are part of the key).  For the single-OCP latency path, whose
                       * ~25 small kernels are launch-bound.  The calls stay asynchronous on the context's stream; the
                       * stream must not be capturing already.  Default 0. */
+  RTOC_OPT_LINEARIZE_FUSED = 13, /* 0 (default): rtoc_linearize_contact_dynamics computes the values of the recursion in a
+                      * level-parallel pre-pass (lanes = bodies; 64 doubles per body and grid point of scratch) and the
+                      * tangent walk reads them; 1: one kernel, every lane recomputes the values along its walk (no scratch) */
   RTOC_OPT_UNCONSTR_DENSE = 12, /* 0 (default): rtoc_unconstr_backward / _forward run the structured recursion (block adds of P+,
                       * unconstr_backward_riccati_recursion_factorizer.cpp:27-70); 1: the general kernels on materialised A, B
                       * (what RTOC_OPT_BACKWARD_SCAN needs; same results to round-off) */

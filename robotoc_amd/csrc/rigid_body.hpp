@@ -169,6 +169,8 @@ struct LinArgs {
   // records follow the convention of rtoc_unconstr_condense (la lives in KKT.lu, lu in CDD.la)
   int unconstr;
   double scale;
+  const double* vals;   // PRE: [batch * nstages][njoints][64] of the dynamics traversal (rbd_values_kernel)
+  const double* vals2;  //      the same for the kinematics traversal of impact grids
 };
 
 // per-level storage in LDS
@@ -187,9 +189,173 @@ __host__ __device__ constexpr size_t lin_lds_bytes(int nlevels, int njoints, int
                            lin_pad8(nv + 1) + 4 * lin_pad8(nv) + 3 * lin_pad8(6 * ncontacts) + njoints * JP + ncontacts * CP);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Values of the recursion, ahead of the tangent walk (PRE mode of linearize_contact_dynamics_kernel).
+//
+// The walk below is one dependent instruction stream per wave, and the lane-invariant VALUES of the recursion (joint
+// transforms incl. a sincos per joint, placements, velocities, accelerations, forces) were ~40 % of it, recomputed by every
+// lane, body after body.  They are level-parallel instead: here lanes = bodies, one pass down the levels of the tree
+// (placements, v, a, own force) and one pass up the bodies in reverse depth-first order (forces of the children), several
+// grid points per wave (64 / next power of two >= njoints).  Out: 64 doubles per body --
+//   0 R, 9 p, 12 oR, 21 op, 24 v, 30 a, 36 g, 39 f (TOTAL: own + children - contact forces), 45 body index,
+//   46 v_parent in body coordinates, 52 a_parent likewise, 58 h = I v
+// the block the walk copies into its per-level value slots when it visits the body -- and the inverse-dynamics residual ID
+// (the value part of RTOC_CDD_IDC).  trav: 0 = the dynamics traversal, 1 = the kinematics traversal at v + dv of impact
+// grids (impact_stage.cpp:61), other grids idle.
+struct ValArgs {
+  const DevModel* model;
+  const double* sol;
+  double* cdd;
+  double* vals;         // [batch * nstages][njoints][64]
+  const rtoc_grid* grid;
+  const unsigned* active;
+  int nstages, batch, nv, nu, njoints, ncontacts, nlevels, gs, trav, unconstr;
+  int nsel, sel[16];    // nsel > 0: only the grid points sel[0..nsel) of every instance (the impact grids of trav 1)
+  int sol_stride, cdd_stride;
+  int o_q, o_v, o_a, o_u, o_f, o_idc;
+  double gx, gy, gz;
+};
+constexpr int VAL_SLOTS = 64;
+
+static __global__ __launch_bounds__(64) void rbd_values_kernel(ValArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];   // [G][njoints][64]
+  const int lane = threadIdx.x, GS = a.gs, G = 64 / GS, nb = a.njoints, ncon = a.ncontacts;
+  const int grp = lane / GS, i = lane % GS;
+  const int nst1 = a.nsel > 0 ? a.nsel : a.nstages - 1;   // grid points per instance this launch covers
+  const long long item = (long long)blockIdx.x * G + grp, nitems = (long long)a.batch * nst1;
+  const bool gvalid = item < nitems;
+  const int b = gvalid ? (int)(item / nst1) : 0;
+  const int st = !gvalid ? 0 : (a.nsel > 0 ? a.sel[item % nst1] : (int)(item % nst1));
+  const rtoc_grid g = a.grid[st];
+  const bool impact = g.type == RTOC_GRID_IMPACT;
+  const bool dyn = a.trav == 0;
+  const bool on = gvalid && i < nb && (dyn || impact);
+  const int ib = i < nb ? i : 0;
+  double* const V = smem + (size_t)grp * nb * VAL_SLOTS;
+  double* const me = V + (size_t)ib * VAL_SLOTS;
+  const size_t rec = (size_t)b * a.nstages + st;
+  const double* const sr = a.sol + rec * a.sol_stride;
+  const unsigned active = a.active[st];
+  const int nv = a.nv, nu = a.nu;
+  // ---- this body's constants and joint state ----
+  const double* const jm = &a.model->joint[ib][0];
+  const int type = (int)jm[28], iq = (int)jm[29], iv = (int)jm[30], depth = (int)jm[31];
+  const int par = a.model->m.parent[ib];
+  const bool ff = type == RTOC_JOINT_FREE_FLYER;
+  const V3 ax = ldv3(jm + 12);
+  M3 Rj;
+  V3 pj = mk(0, 0, 0);
+  SV vj, aj;
+  if (ff) {
+    const double x = sr[a.o_q + iq + 3], y = sr[a.o_q + iq + 4], z = sr[a.o_q + iq + 5], w = sr[a.o_q + iq + 6];
+    Rj.m[0] = 1 - 2 * (y * y + z * z), Rj.m[1] = 2 * (x * y - z * w), Rj.m[2] = 2 * (x * z + y * w);
+    Rj.m[3] = 2 * (x * y + z * w), Rj.m[4] = 1 - 2 * (x * x + z * z), Rj.m[5] = 2 * (y * z - x * w);
+    Rj.m[6] = 2 * (x * z - y * w), Rj.m[7] = 2 * (y * z + x * w), Rj.m[8] = 1 - 2 * (x * x + y * y);
+    pj = ldv3(sr + a.o_q + iq);
+    vj = SV{ldv3(sr + a.o_v + iv), ldv3(sr + a.o_v + iv + 3)};
+    aj = SV{ldv3(sr + a.o_a + iv), ldv3(sr + a.o_a + iv + 3)};
+    if (impact && !dyn) vj = vj + aj;  // kinematics at v + dv
+  } else {
+    const double th = sr[a.o_q + iq], c = cos(th), s = sin(th), t = 1.0 - c;
+    Rj.m[0] = t * ax.x * ax.x + c, Rj.m[1] = t * ax.x * ax.y - s * ax.z, Rj.m[2] = t * ax.x * ax.z + s * ax.y;
+    Rj.m[3] = t * ax.x * ax.y + s * ax.z, Rj.m[4] = t * ax.y * ax.y + c, Rj.m[5] = t * ax.y * ax.z - s * ax.x;
+    Rj.m[6] = t * ax.x * ax.z - s * ax.y, Rj.m[7] = t * ax.y * ax.z + s * ax.x, Rj.m[8] = t * ax.z * ax.z + c;
+    const double vq = (impact && !dyn) ? sr[a.o_v + iv] + sr[a.o_a + iv] : sr[a.o_v + iv];
+    vj = SV{mk(0, 0, 0), vq * ax};
+    aj = SV{mk(0, 0, 0), sr[a.o_a + iv] * ax};
+  }
+  if (impact && dyn) vj = sv0();   // impact model: v = 0
+  if (impact && !dyn) aj = sv0();  // velocity-level rows only
+  const M3 Rp = ldm3(jm);
+  const M3 R = mul(Rp, Rj);
+  const V3 p = mul(Rp, pj) + ldv3(jm + 9);
+  const double mass = jm[15];
+  const V3 com = ldv3(jm + 16);
+  const M3 I = ldm3(jm + 19);
+  auto st_v3 = [&](double* d, V3 x) { d[0] = x.x, d[1] = x.y, d[2] = x.z; };
+  auto st_sv6 = [&](double* d, SV x) { st_v3(d, x.l), st_v3(d + 3, x.a); };
+  auto ld_sv6 = [&](const double* d) { return SV{ldv3(d), ldv3(d + 3)}; };
+  // ---- down the levels: placements, velocities, accelerations, own forces ----
+  for (int d = 0; d < a.nlevels; ++d) {
+    if (on && depth == d) {
+      M3 oR = R;
+      V3 op = p;
+      SV vpar = sv0(), apar = sv0();
+      V3 gi = mulT(R, mk(-a.gx, -a.gy, -a.gz));
+      if (d > 0) {
+        const double* const pa = V + (size_t)par * VAL_SLOTS;
+        const M3 oRp = ldm3(pa + 12);
+        oR = mul(oRp, R);
+        op = ldv3(pa + 21) + mul(oRp, p);
+        vpar = act_inv(R, p, ld_sv6(pa + 24));
+        apar = act_inv(R, p, ld_sv6(pa + 30));
+        gi = mulT(R, ldv3(pa + 36));
+      }
+      if (impact) gi = mk(0, 0, 0);  // the impact model has no gravity
+      const SV v = vpar + vj;
+      const SV acc = apar + aj + mcross(v, vj);
+      const SV h = inertia_mul(mass, com, I, v);
+      SV f = inertia_mul(mass, com, I, SV{acc.l + gi, acc.a}) + fcross(v, h);
+      int roff = 0;
+      for (int c = 0; c < ncon; ++c) {
+        const double* const cm = &a.model->contact[c][0];
+        const bool con_on = (active >> c) & 1u;
+        const bool surf = (int)cm[15] == RTOC_CONTACT_SURFACE;
+        if (con_on && (int)cm[14] == ib) {
+          const SV fc = SV{ldv3(sr + a.o_f + roff), surf ? ldv3(sr + a.o_f + roff + 3) : mk(0, 0, 0)};
+          f = f - act_f(ldm3(cm), ldv3(cm + 9), fc);
+        }
+        roff += con_on ? (surf ? 6 : 3) : 0;
+      }
+#pragma unroll
+      for (int k = 0; k < 9; ++k) me[k] = R.m[k], me[12 + k] = oR.m[k];
+      st_v3(me + 9, p), st_v3(me + 21, op);
+      st_sv6(me + 24, v), st_sv6(me + 30, acc);
+      st_v3(me + 36, gi);
+      st_sv6(me + 39, f);
+      me[45] = (double)ib;
+      st_sv6(me + 46, vpar), st_sv6(me + 52, apar), st_sv6(me + 58, h);
+    }
+    __syncthreads();
+  }
+  // ---- up the bodies, children before parents (reverse depth-first order): total forces ----
+  for (int k = nb - 1; k >= 1; --k) {
+    const int pk = a.model->m.parent[k];
+    if (on && ib == pk) {
+      const double* const ch = V + (size_t)k * VAL_SLOTS;
+      st_sv6(me + 39, ld_sv6(me + 39) + act_f(ldm3(ch), ldv3(ch + 9), ld_sv6(ch + 39)));
+    }
+    __syncthreads();
+  }
+  // ---- ID = S^T f - [0; u] (the value rows of RTOC_CDD_IDC; contact_dynamics.cpp:21-24, impact_dynamics.cpp:12-14) ----
+  if (on && dyn) {
+    double* const cr = a.cdd + rec * a.cdd_stride;
+    const SV f = ld_sv6(me + 39);
+    if (ff) {
+      const double fv[6] = {f.l.x, f.l.y, f.l.z, f.a.x, f.a.y, f.a.z};
+#pragma unroll
+      for (int k = 0; k < 6; ++k) cr[a.o_idc + iv + k] = fv[k] - ((!impact && iv + k >= nv - nu) ? sr[a.o_u + iv + k - (nv - nu)] : 0.0);
+    } else {
+      cr[a.o_idc + iv] = dot(ax, f.a) - ((!impact && iv >= nv - nu) ? sr[a.o_u + iv - (nv - nu)] : 0.0);
+    }
+  }
+  // ---- the blocks out, coalesced ----
+  const int per = nb * VAL_SLOTS;
+  for (int e = lane; e < G * per; e += 64) {
+    const int g2 = e / per;
+    const long long it2 = (long long)blockIdx.x * G + g2;
+    if (it2 >= nitems) continue;
+    const int b2 = (int)(it2 / nst1), st2 = a.nsel > 0 ? a.sel[it2 % nst1] : (int)(it2 % nst1);
+    if (!dyn && a.grid[st2].type != RTOC_GRID_IMPACT) continue;
+    a.vals[((size_t)b2 * a.nstages + st2) * per + (e - g2 * per)] = smem[e];
+  }
+}
+
 // SURF: the model has surface contacts (6 rows, Log6 of the placement error); compiled out for point-contact robots, where
 // its registers and branches cost 10 % of the kernel
-template <bool SURF>
+// PRE: the values of the recursion come from rbd_values_kernel (a.vals / a.vals2): the visit copies the body's block into
+// the level's value slots instead of computing it, and the force accumulation / ID rows are not repeated here.
+template <bool SURF, bool PRE = false>
 __global__ __launch_bounds__(64) RTOC_RBD_WAVES void linearize_contact_dynamics_kernel(LinArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x;
@@ -290,13 +456,13 @@ __global__ __launch_bounds__(64) RTOC_RBD_WAVES void linearize_contact_dynamics_
             const double fv[6] = {f.l.x, f.l.y, f.l.z, f.a.x, f.a.y, f.a.z}, dv6[6] = {df.l.x, df.l.y, df.l.z, df.a.x, df.a.y, df.a.z};
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
-              if (lane == 0 && j0 == 0) cr[a.o_idc + iv + k] = fv[k] - ((!impact && iv + k >= nv - nu) ? su[iv + k - (nv - nu)] : 0.0);
+              if (!PRE && lane == 0 && j0 == 0) cr[a.o_idc + iv + k] = fv[k] - ((!impact && iv + k >= nv - nu) ? su[iv + k - (nv - nu)] : 0.0);
               if (lane_on) dcol[iv + k] = dv6[k];
               if (aug) wsum += dv6[k] * sbeta[iv + k];
             }
           } else {
             const V3 ax = ldv3(&JM(i, 12));
-            if (lane == 0 && j0 == 0) cr[a.o_idc + iv] = dot(ax, f.a) - ((!impact && iv >= nv - nu) ? su[iv - (nv - nu)] : 0.0);
+            if (!PRE && lane == 0 && j0 == 0) cr[a.o_idc + iv] = dot(ax, f.a) - ((!impact && iv >= nv - nu) ? su[iv - (nv - nu)] : 0.0);
             if (lane_on) dcol[iv] = dot(ax, df.a);
             if (aug) wsum += dot(ax, df.a) * sbeta[iv];
           }
@@ -304,10 +470,12 @@ __global__ __launch_bounds__(64) RTOC_RBD_WAVES void linearize_contact_dynamics_
         if (lev > 0) {
           SV dfp = act_f(R, p, df);
           if (own && kind == 0) dfp = dfp + act_f(R, p, fcross(unit_twist(i, j - iv), f));
-          st_sv(lev - 1, 39, ld_sv(lev - 1, 39) + act_f(R, p, f));
+          if (!PRE) st_sv(lev - 1, 39, ld_sv(lev - 1, 39) + act_f(R, p, f));   // PRE: the block already holds the total force
           st_tv(lev - 1, 15, ld_tv(lev - 1, 15) + dfp);
         }
       };
+      const double* const vblk = PRE ? (dyn ? a.vals : a.vals2) + rec * (size_t)nb * VAL_SLOTS : nullptr;
+      double pv = PRE ? vblk[lane] : 0.0;
       for (int i = 0; i < nb; ++i) {
         const int d = (int)JM(i, 31);
         while (top >= d) {
@@ -318,9 +486,22 @@ __global__ __launch_bounds__(64) RTOC_RBD_WAVES void linearize_contact_dynamics_
         const int iq = (int)JM(i, 29), iv = (int)JM(i, 30);
         const bool ff = (int)JM(i, 28) == RTOC_JOINT_FREE_FLYER;
         const bool own = lane_on && j >= iv && j < iv + (ff ? 6 : 1);
+        M3 R, oR;
+        V3 p, op, gi;
+        SV vpar, apar, v, acc, vj;
+        if constexpr (PRE) {
+          // the body's block from rbd_values_kernel (requested one body ahead) into the level's value slots
+          LV(d, lane) = pv;
+          if (i + 1 < nb) pv = vblk[(size_t)(i + 1) * VAL_SLOTS + lane];
+          __builtin_amdgcn_wave_barrier();
+          R = ldm3(&LV(d, 0)), oR = ldm3(&LV(d, 12));
+          p = ldv3(&LV(d, 9)), op = ldv3(&LV(d, 21)), gi = ldv3(&LV(d, 36));
+          v = ld_sv(d, 24), acc = ld_sv(d, 30), vpar = ld_sv(d, 46), apar = ld_sv(d, 52);
+          vj = v - vpar;
+        } else {
         M3 Rj;
         V3 pj = mk(0, 0, 0);
-        SV vj, aj;  // S vq, S aq
+        SV aj;  // S aq (vj = S vq)
         if (ff) {
           const double x = sq[iq + 3], y = sq[iq + 4], z = sq[iq + 5], w = sq[iq + 6];
           Rj.m[0] = 1 - 2 * (y * y + z * z), Rj.m[1] = 2 * (x * y - z * w), Rj.m[2] = 2 * (x * z + y * w);
@@ -343,12 +524,12 @@ __global__ __launch_bounds__(64) RTOC_RBD_WAVES void linearize_contact_dynamics_
         if (impact && dyn) vj = sv0();   // impact model: v = 0
         if (impact && !dyn) aj = sv0();  // velocity-level rows only
         const M3 Rp = ldm3(&JM(i, 0));
-        const M3 R = mul(Rp, Rj);
-        const V3 p = mul(Rp, pj) + ldv3(&JM(i, 9));
-        M3 oR = R;
-        V3 op = p;
-        SV vpar = sv0(), apar = sv0(), dvp = sv0(), dap = sv0();
-        V3 gi = mulT(R, mk(-grav.x, -grav.y, -grav.z)), dgp = mk(0, 0, 0);
+        R = mul(Rp, Rj);
+        p = mul(Rp, pj) + ldv3(&JM(i, 9));
+        oR = R;
+        op = p;
+        vpar = sv0(), apar = sv0();
+        gi = mulT(R, mk(-grav.x, -grav.y, -grav.z));
         if (d > 0) {
           const M3 oRp = ldm3(&LV(d - 1, 12));
           oR = mul(oRp, R);
@@ -356,13 +537,19 @@ __global__ __launch_bounds__(64) RTOC_RBD_WAVES void linearize_contact_dynamics_
           vpar = act_inv(R, p, ld_sv(d - 1, 24));
           apar = act_inv(R, p, ld_sv(d - 1, 30));
           gi = mulT(R, ldv3(&LV(d - 1, 36)));
+        }
+        if (impact) gi = mk(0, 0, 0);  // the impact model has no gravity
+        v = vpar + vj;
+        acc = apar + aj + mcross(v, vj);
+        }
+        SV dvp = sv0(), dap = sv0();
+        V3 dgp = mk(0, 0, 0);
+        if (d > 0) {
           dvp = act_inv(R, p, ld_tv(d - 1, 0));
           dap = act_inv(R, p, ld_tv(d - 1, 6));
           dgp = mulT(R, mk(LT(d - 1, 12), LT(d - 1, 13), LT(d - 1, 14)));
         }
-        if (impact) gi = mk(0, 0, 0), dgp = mk(0, 0, 0);  // the impact model has no gravity
-        const SV v = vpar + vj;
-        const SV acc = apar + aj + mcross(v, vj);
+        if (impact) dgp = mk(0, 0, 0);
         SV dv = dvp, da = dap;
         V3 dg = dgp;
         if (own) {
@@ -384,8 +571,8 @@ __global__ __launch_bounds__(64) RTOC_RBD_WAVES void linearize_contact_dynamics_
         const double mass = JM(i, 15);
         const V3 com = ldv3(&JM(i, 16));
         const M3 I = ldm3(&JM(i, 19));
-        const SV h = inertia_mul(mass, com, I, v);
-        SV f = inertia_mul(mass, com, I, SV{acc.l + gi, acc.a}) + fcross(v, h);
+        const SV h = PRE ? ld_sv(d, 58) : inertia_mul(mass, com, I, v);
+        SV f = PRE ? sv0() : inertia_mul(mass, com, I, SV{acc.l + gi, acc.a}) + fcross(v, h);   // PRE: the block holds the total force
         const SV df = inertia_mul(mass, com, I, SV{da.l + dg, da.a}) + fcross(dv, h) + fcross(v, inertia_mul(mass, com, I, dv));
         // contacts carried by this body; roff = rows of the active contacts before c (3 per point, 6 per surface contact)
         int roff = 0;
@@ -398,7 +585,7 @@ __global__ __launch_bounds__(64) RTOC_RBD_WAVES void linearize_contact_dynamics_
             const V3 pf = ldv3(&scm[c * CP + 9]);
             // the contact force / wrench is given in the LOCAL contact frame (point_contact.cpp:55-60, surface_contact.cpp)
             const SV fc = SV{mk(sf[roff], sf[roff + 1], sf[roff + 2]), surf ? mk(sf[roff + 3], sf[roff + 4], sf[roff + 5]) : mk(0, 0, 0)};
-            f = f - act_f(Rf, pf, fc);
+            if (!PRE) f = f - act_f(Rf, pf, fc);
             if (rows) {
               const SV vf = act_inv(Rf, pf, v), dvf = act_inv(Rf, pf, dv);
               SV C, dC;  // angular parts only used by surface contacts
@@ -473,15 +660,17 @@ __global__ __launch_bounds__(64) RTOC_RBD_WAVES void linearize_contact_dynamics_
           roff += on ? nr : 0;
         }
         // ---- store the level ----
+        if constexpr (!PRE) {
 #pragma unroll
-        for (int k = 0; k < 9; ++k) LV(d, k) = R.m[k], LV(d, 12 + k) = oR.m[k];
-        LV(d, 9) = p.x, LV(d, 10) = p.y, LV(d, 11) = p.z;
-        LV(d, 21) = op.x, LV(d, 22) = op.y, LV(d, 23) = op.z;
-        st_sv(d, 24, v);
-        st_sv(d, 30, acc);
-        LV(d, 36) = gi.x, LV(d, 37) = gi.y, LV(d, 38) = gi.z;
-        st_sv(d, 39, f);
-        LV(d, 45) = (double)i;
+          for (int k = 0; k < 9; ++k) LV(d, k) = R.m[k], LV(d, 12 + k) = oR.m[k];
+          LV(d, 9) = p.x, LV(d, 10) = p.y, LV(d, 11) = p.z;
+          LV(d, 21) = op.x, LV(d, 22) = op.y, LV(d, 23) = op.z;
+          st_sv(d, 24, v);
+          st_sv(d, 30, acc);
+          LV(d, 36) = gi.x, LV(d, 37) = gi.y, LV(d, 38) = gi.z;
+          st_sv(d, 39, f);
+          LV(d, 45) = (double)i;
+        }
         if (d < nlev - 1) {
           st_tv(d, 0, dv);
           st_tv(d, 6, da);

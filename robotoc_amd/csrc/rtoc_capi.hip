@@ -121,6 +121,12 @@ static hipError_t set_linearize_lds(const rtoc_robot_model& m, int nlevels) {
   hipError_t e = hipFuncSetAttribute((const void*)rbd::linearize_contact_dynamics_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   if (e == hipSuccess)
     e = hipFuncSetAttribute((const void*)rbd::linearize_contact_dynamics_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute((const void*)rbd::linearize_contact_dynamics_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute((const void*)rbd::linearize_contact_dynamics_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute((const void*)rbd::rbd_values_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * rbd::VAL_SLOTS * (int)sizeof(double));
   return e;
 }
 
@@ -166,6 +172,9 @@ struct rtoc_ctx {
   int impact_cones;     // RTOC_OPT_IMPACT_CONES (default 1, rtoc_create)
   double* d_mu;         // rtoc_set_friction_coefficients
   double* d_wcone;      // rtoc_set_wrench_cone_params: [RTOC_MAX_CONTACTS][17 x 6]
+  double *d_vals, *d_vals2;  // rbd_values_kernel -> linearize_contact_dynamics_kernel<.., PRE>: [batch * max_stages][njoints][64]
+  size_t vals_cap;
+  int linearize_fused;  // RTOC_OPT_LINEARIZE_FUSED
   unsigned long long epoch;  // bumped by everything that changes a launch parameter baked into a captured graph
   struct GraphSlot {
     hipGraphExec_t exec;
@@ -348,6 +357,8 @@ int rtoc_destroy(rtoc_ctx* c) {
   if (c->d_bounds) (void)hipFree(c->d_bounds);
   if (c->d_mu) (void)hipFree(c->d_mu);
   if (c->d_wcone) (void)hipFree(c->d_wcone);
+  if (c->d_vals) (void)hipFree(c->d_vals);
+  if (c->d_vals2) (void)hipFree(c->d_vals2);
   if (c->d_x0) (void)hipFree(c->d_x0);
   if (c->d_filter) (void)hipFree(c->d_filter);
   if (c->d_nfilter) (void)hipFree(c->d_nfilter);
@@ -399,6 +410,7 @@ int rtoc_clone(rtoc_ctx* c, rtoc_ctx** out) {
     n->exact_transport = c->exact_transport;
     n->impact_cones = c->impact_cones;
     n->unconstr_dense = c->unconstr_dense;
+    n->linearize_fused = c->linearize_fused;
     if (c->backward_scan) rc = rtoc_set_option(n, RTOC_OPT_BACKWARD_SCAN, c->backward_scan);
   }
   hipError_t e = hipStreamSynchronize(c->stream);
@@ -504,6 +516,9 @@ int rtoc_set_option(rtoc_ctx* c, int option, int64_t value) {
       c->max_dts0 = d;
       return RTOC_OK;
     }
+    case RTOC_OPT_LINEARIZE_FUSED:
+      c->linearize_fused = value ? 1 : 0;
+      return RTOC_OK;
     case RTOC_OPT_UNCONSTR_DENSE:
       c->unconstr_dense = value ? 1 : 0;
       return RTOC_OK;
@@ -1512,10 +1527,61 @@ static int launch_linearize(rtoc_ctx* c, int augment_residual, bool unconstr, do
   a.scale = scale;
   if (c->nstages < 2) return RTOC_OK;
   const size_t lds = rbd::lin_lds_bytes(c->h_model->nlevels, c->h_model->m.njoints, c->h_model->m.ncontacts, c->h_model->m.nv);
-  if (model_has_surface_contacts(c->h_model->m))
+  const bool surf = model_has_surface_contacts(c->h_model->m);
+  a.vals = a.vals2 = nullptr;
+  if (!c->linearize_fused) {
+    // the values of the recursion first (level-parallel, lanes = bodies), then the tangent walk reads them (rigid_body.hpp)
+    const rtoc_robot_model& m = c->h_model->m;
+    bool any_impact = false;
+    for (int i = 0; i + 1 < c->nstages; ++i) any_impact = any_impact || c->h_grid[i].type == RTOC_GRID_IMPACT;
+    const size_t need = (size_t)c->batch * c->max_stages * m.njoints * rbd::VAL_SLOTS;
+    if (c->vals_cap < need) {
+      if (c->d_vals) (void)hipFree(c->d_vals);
+      if (c->d_vals2) (void)hipFree(c->d_vals2);
+      c->d_vals = c->d_vals2 = nullptr;
+      c->vals_cap = 0;
+      HIP_TRY(hipMalloc((void**)&c->d_vals, need * sizeof(double)));
+      c->vals_cap = need;
+    }
+    if (any_impact && !c->d_vals2) HIP_TRY(hipMalloc((void**)&c->d_vals2, c->vals_cap * sizeof(double)));
+    rbd::ValArgs v;
+    v.model = c->d_model, v.sol = a.sol, v.cdd = a.cdd, v.grid = a.grid, v.active = a.active;
+    v.nstages = c->nstages, v.batch = c->batch, v.nv = a.nv, v.nu = a.nu, v.njoints = m.njoints, v.ncontacts = m.ncontacts;
+    v.nlevels = c->h_model->nlevels, v.unconstr = a.unconstr;
+    v.gs = 1;
+    while (v.gs < m.njoints) v.gs *= 2;
+    v.sol_stride = a.sol_stride, v.cdd_stride = a.cdd_stride;
+    v.o_q = a.o_q, v.o_v = a.o_v, v.o_a = a.o_a, v.o_u = a.o_u, v.o_f = a.o_f, v.o_idc = a.o_idc;
+    v.gx = a.gx, v.gy = a.gy, v.gz = a.gz;
+    const int G = 64 / v.gs;
+    const long long items = (long long)c->batch * (c->nstages - 1);
+    const size_t vlds = sizeof(double) * G * m.njoints * rbd::VAL_SLOTS;
+    for (int trav = 0; trav < (any_impact ? 2 : 1); ++trav) {
+      v.trav = trav;
+      v.vals = trav == 0 ? c->d_vals : c->d_vals2;
+      v.nsel = 0;
+      long long n = items;
+      if (trav == 1) {   // the kinematics traversal exists on impact grids only: launch just those (if they fit the list)
+        int k = 0;
+        for (int i = 0; i + 1 < c->nstages && k <= 16; ++i)
+          if (c->h_grid[i].type == RTOC_GRID_IMPACT) {
+            if (k < 16) v.sel[k] = i;
+            ++k;
+          }
+        if (k <= 16) v.nsel = k, n = (long long)c->batch * k;
+      }
+      hipLaunchKernelGGL(rbd::rbd_values_kernel, dim3((unsigned)((n + G - 1) / G)), dim3(64), vlds, c->stream, v);
+    }
+    a.vals = c->d_vals, a.vals2 = c->d_vals2;
+    if (surf)
+      hipLaunchKernelGGL((rbd::linearize_contact_dynamics_kernel<true, true>), dim3(c->batch * (c->nstages - 1)), dim3(64), lds, c->stream, a);
+    else
+      hipLaunchKernelGGL((rbd::linearize_contact_dynamics_kernel<false, true>), dim3(c->batch * (c->nstages - 1)), dim3(64), lds, c->stream, a);
+  } else if (surf) {
     hipLaunchKernelGGL(rbd::linearize_contact_dynamics_kernel<true>, dim3(c->batch * (c->nstages - 1)), dim3(64), lds, c->stream, a);
-  else
+  } else {
     hipLaunchKernelGGL(rbd::linearize_contact_dynamics_kernel<false>, dim3(c->batch * (c->nstages - 1)), dim3(64), lds, c->stream, a);
+  }
   HIP_TRY(hipGetLastError());
   return RTOC_OK;
 }

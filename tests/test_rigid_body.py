@@ -159,8 +159,9 @@ def _masks(grids):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("cfg", ["anymal_trot", "anymal_jump_sto"])
-def test_gpu_linearisation_matches_the_restatement_and_its_finite_differences(oracle, cfg):
+def test_gpu_linearisation_matches_the_restatement_and_its_finite_differences(oracle, cfg, fused):
     m = model("anymal")
     dims, grids, _ = getattr(pr, "config_" + cfg)()
     batch = 3
@@ -168,6 +169,7 @@ def test_gpu_linearisation_matches_the_restatement_and_its_finite_differences(or
     L = ctx.L
     ctx.set_grid(grids)
     ctx.set_robot_model(m)
+    ctx.set_linearize_fused(fused)   # one kernel, or values pre-pass + tangent walk (the default)
     masks = _masks(grids)
     rng = np.random.default_rng(4)
     pos = rng.uniform(-0.5, 0.5, (len(grids), 4, 3))
@@ -278,7 +280,8 @@ def test_gpu_linearisation_matches_the_restatement_and_its_finite_differences(or
 
 
 @pytest.mark.gpu
-def test_gpu_linearisation_icub_surface_contacts_two_passes_eleven_levels(oracle):
+@pytest.mark.parametrize("fused", [False, True])
+def test_gpu_linearisation_icub_surface_contacts_two_passes_eleven_levels(oracle, fused):
     """nv = 35: 2 passes of 21 dofs, 11 tree levels (128 KB of LDS per wave); two SURFACE contacts (the soles: 6 rows
     each, wrench in the local frame, Log6 position / orientation error against a desired placement)"""
     from robotoc_amd.types import Grid, GRID_INTERMEDIATE, GRID_TERMINAL
@@ -293,6 +296,7 @@ def test_gpu_linearisation_icub_surface_contacts_two_passes_eleven_levels(oracle
     L = ctx.L
     ctx.set_grid(grids)
     ctx.set_robot_model(m)
+    ctx.set_linearize_fused(fused)
     rng = np.random.default_rng(5)
     # one configuration per grid point (the schedule is shared by the instances); the desired placements are the actual
     # ones moved by a twist of up to ~0.3 (a contact that drifted: Log6 stays away from its singularity at pi)
