@@ -178,6 +178,100 @@ static __global__ __launch_bounds__(64) void contact_cone_kernel(CcArgs a) {
 
 namespace rtoc {
 
+// The same rows (LINEARIZE) from the kinematics the rigid-body pre-pass has already computed (rbd_values_kernel: the world
+// rotation of every body, slots 12..20 of its block): no tree walk.  The world-aligned angular Jacobian column of a contact
+// frame for dof j is oR_body(j) axis_j if the dof lies on the path from the root to the contact's body, else zero.
+// One wave per (instance, grid point), lane j = dof j.
+struct CvArgs {
+  CcArgs c;
+  const double* vals;   // [batch * nstages][njoints][64]
+};
+
+static __global__ __launch_bounds__(64) void contact_cone_vals_kernel(CvArgs v) {
+  using namespace selin;
+  using rbd::CP;
+  const CcArgs& a = v.c;
+  const int lane = threadIdx.x;
+  const int nst1 = a.nstages - 1;
+  const int b = blockIdx.x / nst1, st = blockIdx.x % nst1;
+  if (b >= a.batch) return;
+  const rtoc_grid g = a.grid[st];
+  if (g.dimf == 0 || (g.type == RTOC_GRID_IMPACT && !a.impact_cones)) return;
+  const unsigned act = a.active[st];
+  const int nv = a.nv, nb = a.njoints, ncon = a.ncontacts, cd = a.contact_dim;
+  const size_t rec = (size_t)b * a.nstages + st;
+  const double* const s = a.sol + rec * a.sol_stride;
+  double* const kr = a.kkt + rec * a.kkt_stride;
+  double* const cr = a.cdd + rec * a.cdd_stride;
+  double* const nr = a.con + rec * a.con_stride;
+  double* const gr = a.cone + rec * a.cone_stride;
+  const double* const vb = v.vals + rec * (size_t)nb * rbd::VAL_SLOTS;
+  const int* const no = a.nl.off;
+  const int j = lane;
+  const bool lane_on = j < nv;
+  // this dof's rotation axis in the world frame
+  V3 wj = rbd::mk(0, 0, 0);
+  if (lane_on) {
+    const double* const blk = vb + (size_t)a.model->dof_body[j] * rbd::VAL_SLOTS;
+    wj = rbd::mul(rbd::ldm3(blk + 12), rbd::ldv3(a.model->dof_axis[j]));
+  }
+  double lq = 0.0;
+  int k = 0;
+  for (int c = 0; c < ncon; ++c) {
+    if (!((act >> c) & 1u)) continue;
+    const double* const cm = &a.model->contact[c][0];
+    const double* const blk = vb + (size_t)(int)cm[14] * rbd::VAL_SLOTS;
+    const M3 Rwf = rbd::mul(rbd::ldm3(blk + 12), rbd::ldm3(cm));
+    const V3 fW = rbd::mul(Rwf, rbd::ldv3(s + a.o_f + k * cd));
+    M3 Rs;
+#pragma unroll
+    for (int e = 0; e < 9; ++e) Rs.m[e] = a.rotations ? a.rotations[((size_t)st * ncon + c) * 9 + e] : ((e % 4 == 0) ? 1.0 : 0.0);
+    const double m = a.mu[c] * 0.70710678118654752440;
+    V3 row[5];
+    row[0] = rbd::mul(Rs, rbd::mk(0, 0, -1));
+    row[1] = rbd::mul(Rs, rbd::mk(1, 0, -m));
+    row[2] = rbd::mul(Rs, rbd::mk(-1, 0, -m));
+    row[3] = rbd::mul(Rs, rbd::mk(0, 1, -m));
+    row[4] = rbd::mul(Rs, rbd::mk(0, -1, -m));
+    const int r0 = a.row0 + 5 * k;
+    double dual[5];
+#pragma unroll
+    for (int r = 0; r < 5; ++r) dual[r] = nr[no[RTOC_CON_DUAL] + r0 + r];
+    if (lane < 5) {
+      const double slack = nr[no[RTOC_CON_SLACK] + r0 + lane];
+      nr[no[RTOC_CON_RESIDUAL] + r0 + lane] = rbd::dot(row[lane], fW) + slack;
+      nr[no[RTOC_CON_CMPL] + r0 + lane] = slack * dual[lane] - a.barrier;
+    }
+    if (lane < 3) {
+      const V3 col = rbd::mk(Rwf.m[lane], Rwf.m[3 + lane], Rwf.m[6 + lane]);
+      double acc = 0.0;
+#pragma unroll
+      for (int r = 0; r < 5; ++r) {
+        const double e = rbd::dot(row[r], col);
+        gr[a.dgdf_off + k * 15 + r + 5 * lane] = e;
+        acc += e * dual[r];
+      }
+      cr[a.o_lf + k * cd + lane] += acc;
+    }
+    if (lane_on) {
+      const bool path = (a.model->contact_dofs[c] >> j) & 1ull;
+      const V3 wxf = path ? rbd::cross(wj, fW) : rbd::mk(0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 5; ++r) {
+        const double e = rbd::dot(row[r], wxf);
+        gr[k * 5 * nv + r + 5 * j] = e;
+        lq += e * dual[r];
+      }
+    }
+    ++k;
+  }
+  if (lane_on) kr[a.o_lx + j] += lq;
+}
+
+}  // namespace rtoc
+
+namespace rtoc {
+
 // ContactWrenchCone / ImpactWrenchCone (reference src/constraints/contact_wrench_cone.cpp:114-204): 17 rows per ACTIVE surface
 // contact, g = cone f with the constant 17 x 6 cone matrix of the sole (computeCone / updateCone, :282-313; the host builds
 // it with rtoc_wrench_cone_matrix and hands a table over) acting on the local 6-d contact wrench -- no kinematics:

@@ -40,6 +40,12 @@ struct DevModel {
   int nlevels;
   double joint[RTOC_MAX_JOINTS][JP];
   double contact[RTOC_MAX_CONTACTS][CP];
+  // per dof: the body it moves and its angular axis in that body's frame (zero for the linear dofs of a free-flyer);
+  // per contact: the dofs on the path from the root to the contact's body (bit j): everything the world-aligned angular
+  // Jacobian column of a contact frame needs besides the bodies' world rotations (contact_cone_vals_kernel)
+  int dof_body[RTOC_MAX_JOINTS + 8];
+  double dof_axis[RTOC_MAX_JOINTS + 8][3];
+  unsigned long long contact_dofs[RTOC_MAX_CONTACTS];
 };
 inline void pack_model(DevModel* h) {
   const rtoc_robot_model& m = h->m;
@@ -49,6 +55,30 @@ inline void pack_model(DevModel* h) {
     for (int k = 0; k < 3; ++k) o[9 + k] = m.placement_p[i][k], o[12 + k] = m.axis[i][k], o[16 + k] = m.com[i][k];
     o[15] = m.mass[i];
     o[28] = m.type[i], o[29] = m.idx_q[i], o[30] = m.idx_v[i], o[31] = h->depth[i];
+  }
+  for (int j = 0; j < RTOC_MAX_JOINTS + 8; ++j) h->dof_body[j] = 0, h->dof_axis[j][0] = h->dof_axis[j][1] = h->dof_axis[j][2] = 0.0;
+  for (int i = 0; i < m.njoints; ++i) {
+    const int ndof = m.type[i] == RTOC_JOINT_FREE_FLYER ? 6 : 1;
+    for (int k = 0; k < ndof; ++k) {
+      const int j = m.idx_v[i] + k;
+      if (j < 0 || j >= RTOC_MAX_JOINTS + 8) continue;
+      h->dof_body[j] = i;
+      if (ndof == 6) {
+        if (k >= 3) h->dof_axis[j][k - 3] = 1.0;
+      } else {
+        for (int t = 0; t < 3; ++t) h->dof_axis[j][t] = m.axis[i][t];
+      }
+    }
+  }
+  for (int c = 0; c < m.ncontacts; ++c) {
+    unsigned long long mask = 0;
+    for (int i = m.contact_parent[c]; i >= 0 && i < m.njoints; i = m.parent[i]) {
+      const int ndof = m.type[i] == RTOC_JOINT_FREE_FLYER ? 6 : 1;
+      for (int k = 0; k < ndof; ++k)
+        if (m.idx_v[i] + k >= 0 && m.idx_v[i] + k < 64) mask |= 1ull << (m.idx_v[i] + k);
+      if (m.parent[i] == i) break;
+    }
+    h->contact_dofs[c] = mask;
   }
   for (int c = 0; c < m.ncontacts; ++c) {
     double* o = h->contact[c];

@@ -174,6 +174,7 @@ struct rtoc_ctx {
   double* d_wcone;      // rtoc_set_wrench_cone_params: [RTOC_MAX_CONTACTS][17 x 6]
   double *d_vals, *d_vals2;  // rbd_values_kernel -> linearize_contact_dynamics_kernel<.., PRE>: [batch * max_stages][njoints][64]
   size_t vals_cap;
+  int vals_fresh;       // the values in d_vals belong to the iterate in RTOC_BUF_SOL (consumed by the next launch_linearize)
   int linearize_fused;  // RTOC_OPT_LINEARIZE_FUSED
   unsigned long long epoch;  // bumped by everything that changes a launch parameter baked into a captured graph
   struct GraphSlot {
@@ -1478,6 +1479,61 @@ int rtoc_set_contact_schedule(rtoc_ctx* c, const unsigned* active, const double*
   return RTOC_OK;
 }
 
+// rbd_values_kernel for the iterate in RTOC_BUF_SOL: the lane-invariant values of the rigid-body recursion per body (and the
+// ID rows of RTOC_CDD_IDC), read by the tangent walk and by the friction-cone rows
+static int launch_rbd_values(rtoc_ctx* c, bool unconstr) {
+  if (!c->h_model || !c->d_active || !c->buf[RTOC_BUF_SOL]) return RTOC_ERR_NOT_READY;
+  int rc = ensure_buffer(c, RTOC_BUF_CDD);
+  if (rc) return rc;
+  if (c->nstages < 2) return RTOC_OK;
+  const rtoc_robot_model& m = c->h_model->m;
+  bool any_impact = false;
+  for (int i = 0; i + 1 < c->nstages; ++i) any_impact = any_impact || c->h_grid[i].type == RTOC_GRID_IMPACT;
+  const size_t need = (size_t)c->batch * c->max_stages * m.njoints * rbd::VAL_SLOTS;
+  if (c->vals_cap < need) {
+    if (c->d_vals) (void)hipFree(c->d_vals);
+    if (c->d_vals2) (void)hipFree(c->d_vals2);
+    c->d_vals = c->d_vals2 = nullptr;
+    c->vals_cap = 0;
+    HIP_TRY(hipMalloc((void**)&c->d_vals, need * sizeof(double)));
+    c->vals_cap = need;
+  }
+  if (any_impact && !c->d_vals2) HIP_TRY(hipMalloc((void**)&c->d_vals2, c->vals_cap * sizeof(double)));
+  rbd::ValArgs v;
+  v.model = c->d_model, v.sol = c->buf[RTOC_BUF_SOL], v.cdd = c->buf[RTOC_BUF_CDD], v.grid = c->d_grid, v.active = c->d_active;
+  v.nstages = c->nstages, v.batch = c->batch, v.nv = m.nv, v.njoints = m.njoints, v.ncontacts = m.ncontacts;
+  v.nu = m.type[0] == RTOC_JOINT_FREE_FLYER ? m.nv - 6 : m.nv;
+  v.nlevels = c->h_model->nlevels, v.unconstr = unconstr ? 1 : 0;
+  v.gs = 1;
+  while (v.gs < m.njoints) v.gs *= 2;
+  v.sol_stride = c->L.sol.stride, v.cdd_stride = c->L.cdd.stride;
+  v.o_q = c->L.sol.off[RTOC_SOL_Q], v.o_v = c->L.sol.off[RTOC_SOL_V], v.o_a = c->L.sol.off[RTOC_SOL_A];
+  v.o_u = c->L.sol.off[RTOC_SOL_U], v.o_f = c->L.sol.off[RTOC_SOL_F], v.o_idc = c->L.cdd.off[RTOC_CDD_IDC];
+  v.gx = m.gravity[0], v.gy = m.gravity[1], v.gz = m.gravity[2];
+  const int G = 64 / v.gs;
+  const long long items = (long long)c->batch * (c->nstages - 1);
+  const size_t vlds = sizeof(double) * G * m.njoints * rbd::VAL_SLOTS;
+  for (int trav = 0; trav < (any_impact ? 2 : 1); ++trav) {
+    v.trav = trav;
+    v.vals = trav == 0 ? c->d_vals : c->d_vals2;
+    v.nsel = 0;
+    long long n = items;
+    if (trav == 1) {   // the kinematics traversal exists on impact grids only: launch just those (if they fit the list)
+      int k = 0;
+      for (int i = 0; i + 1 < c->nstages && k <= 16; ++i)
+        if (c->h_grid[i].type == RTOC_GRID_IMPACT) {
+          if (k < 16) v.sel[k] = i;
+          ++k;
+        }
+      if (k <= 16) v.nsel = k, n = (long long)c->batch * k;
+    }
+    hipLaunchKernelGGL(rbd::rbd_values_kernel, dim3((unsigned)((n + G - 1) / G)), dim3(64), vlds, c->stream, v);
+  }
+  HIP_TRY(hipGetLastError());
+  c->vals_fresh = 1;
+  return RTOC_OK;
+}
+
 static int launch_linearize(rtoc_ctx* c, int augment_residual, bool unconstr, double scale) {
   if (!c->h_model || !c->d_active || !c->buf[RTOC_BUF_SOL]) return RTOC_ERR_NOT_READY;
   if (augment_residual && !c->buf[RTOC_BUF_KKT]) return RTOC_ERR_NOT_READY;
@@ -1531,47 +1587,11 @@ static int launch_linearize(rtoc_ctx* c, int augment_residual, bool unconstr, do
   a.vals = a.vals2 = nullptr;
   if (!c->linearize_fused) {
     // the values of the recursion first (level-parallel, lanes = bodies), then the tangent walk reads them (rigid_body.hpp)
-    const rtoc_robot_model& m = c->h_model->m;
-    bool any_impact = false;
-    for (int i = 0; i + 1 < c->nstages; ++i) any_impact = any_impact || c->h_grid[i].type == RTOC_GRID_IMPACT;
-    const size_t need = (size_t)c->batch * c->max_stages * m.njoints * rbd::VAL_SLOTS;
-    if (c->vals_cap < need) {
-      if (c->d_vals) (void)hipFree(c->d_vals);
-      if (c->d_vals2) (void)hipFree(c->d_vals2);
-      c->d_vals = c->d_vals2 = nullptr;
-      c->vals_cap = 0;
-      HIP_TRY(hipMalloc((void**)&c->d_vals, need * sizeof(double)));
-      c->vals_cap = need;
+    if (!c->vals_fresh) {
+      const int rv = launch_rbd_values(c, unconstr);
+      if (rv) return rv;
     }
-    if (any_impact && !c->d_vals2) HIP_TRY(hipMalloc((void**)&c->d_vals2, c->vals_cap * sizeof(double)));
-    rbd::ValArgs v;
-    v.model = c->d_model, v.sol = a.sol, v.cdd = a.cdd, v.grid = a.grid, v.active = a.active;
-    v.nstages = c->nstages, v.batch = c->batch, v.nv = a.nv, v.nu = a.nu, v.njoints = m.njoints, v.ncontacts = m.ncontacts;
-    v.nlevels = c->h_model->nlevels, v.unconstr = a.unconstr;
-    v.gs = 1;
-    while (v.gs < m.njoints) v.gs *= 2;
-    v.sol_stride = a.sol_stride, v.cdd_stride = a.cdd_stride;
-    v.o_q = a.o_q, v.o_v = a.o_v, v.o_a = a.o_a, v.o_u = a.o_u, v.o_f = a.o_f, v.o_idc = a.o_idc;
-    v.gx = a.gx, v.gy = a.gy, v.gz = a.gz;
-    const int G = 64 / v.gs;
-    const long long items = (long long)c->batch * (c->nstages - 1);
-    const size_t vlds = sizeof(double) * G * m.njoints * rbd::VAL_SLOTS;
-    for (int trav = 0; trav < (any_impact ? 2 : 1); ++trav) {
-      v.trav = trav;
-      v.vals = trav == 0 ? c->d_vals : c->d_vals2;
-      v.nsel = 0;
-      long long n = items;
-      if (trav == 1) {   // the kinematics traversal exists on impact grids only: launch just those (if they fit the list)
-        int k = 0;
-        for (int i = 0; i + 1 < c->nstages && k <= 16; ++i)
-          if (c->h_grid[i].type == RTOC_GRID_IMPACT) {
-            if (k < 16) v.sel[k] = i;
-            ++k;
-          }
-        if (k <= 16) v.nsel = k, n = (long long)c->batch * k;
-      }
-      hipLaunchKernelGGL(rbd::rbd_values_kernel, dim3((unsigned)((n + G - 1) / G)), dim3(64), vlds, c->stream, v);
-    }
+    c->vals_fresh = 0;
     a.vals = c->d_vals, a.vals2 = c->d_vals2;
     if (surf)
       hipLaunchKernelGGL((rbd::linearize_contact_dynamics_kernel<true, true>), dim3(c->batch * (c->nstages - 1)), dim3(64), lds, c->stream, a);
@@ -1885,6 +1905,14 @@ static int launch_contact_cones(rtoc_ctx* c, int mode) {
   a.sol_stride = c->L.sol.stride, a.kkt_stride = c->L.kkt.stride, a.cdd_stride = c->L.cdd.stride, a.con_stride = c->L.con.stride;
   a.o_q = c->L.sol.off[RTOC_SOL_Q], a.o_f = c->L.sol.off[RTOC_SOL_F], a.o_lx = c->L.kkt.off[RTOC_KKT_LX], a.o_lf = c->L.cdd.off[RTOC_CDD_LF];
   a.nl = c->L.con;
+  if (mode == CC_LINEARIZE && c->vals_fresh && c->d_vals) {   // kinematics already there: no tree walk (contact_cone_vals_kernel)
+    CvArgs v;
+    v.c = a;
+    v.vals = c->d_vals;
+    hipLaunchKernelGGL(contact_cone_vals_kernel, dim3(c->batch * (c->nstages - 1)), dim3(64), 0, c->stream, v);
+    HIP_TRY(hipGetLastError());
+    return RTOC_OK;
+  }
   const size_t lds = cc_lds_bytes(a.nlevels, a.njoints, a.ncontacts);
   HIP_TRY(hipFuncSetAttribute((const void*)contact_cone_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(contact_cone_kernel, dim3(c->batch * (c->nstages - 1)), dim3(64), lds, c->stream, a);
@@ -1961,6 +1989,8 @@ int rtoc_contact_eval_kkt(rtoc_ctx* c) {
   HIP_TRY(hipGetLastError());
   // constraints_->linearizeConstraints (intermediate_stage.cpp:109-110, impact_stage.cpp:95-96) of the rows evaluated here
   if (c->nrows > 0 && c->d_bounds && c->buf[RTOC_BUF_CON]) rc = launch_ubox(c, UBOX_LINEARIZE, true);
+  c->vals_fresh = 0;
+  if (!rc && !c->linearize_fused && device_cones_on(c) && c->buf[RTOC_BUF_CON]) rc = launch_rbd_values(c, false);   // shared with the cone rows
   if (!rc && device_cones_on(c) && c->buf[RTOC_BUF_CON]) rc = launch_contact_cones(c, CC_LINEARIZE);
   if (!rc && device_wrench_on(c) && c->buf[RTOC_BUF_CON]) rc = launch_wrench_cones(c, CC_LINEARIZE);
   if (!rc) rc = launch_state_equation(c, true);
