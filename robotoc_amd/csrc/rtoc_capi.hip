@@ -1959,9 +1959,18 @@ static int launch_switching_constraint(rtoc_ctx* c) {
   a.o_phia = c->L.cdd.off[RTOC_CDD_PHIA], a.o_la = c->L.cdd.off[RTOC_CDD_LA], a.o_ha = c->L.cdd.off[RTOC_CDD_HA];
   for (int i = 0; i < c->nstages; ++i)
     if (c->h_grid[i].switching_constraint && c->h_grid[i].dims > c->dims.ns_max) return RTOC_ERR_BAD_ARG;
+  a.nsel = 0;
+  int nsw = 0;
+  for (int i = 0; i + 1 < c->nstages; ++i)
+    if (c->h_grid[i].switching_constraint) {
+      if (nsw < 16) a.sel[nsw] = i;
+      ++nsw;
+    }
+  if (nsw <= 16) a.nsel = nsw;
+  const int per = a.nsel > 0 ? a.nsel : c->nstages - 1;
   const size_t lds = sw_lds_bytes(a.nlevels, a.njoints, a.ncontacts);
   HIP_TRY(hipFuncSetAttribute((const void*)switching_constraint_lin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(switching_constraint_lin_kernel, dim3(c->batch * (c->nstages - 1)), dim3(64), lds, c->stream, a);
+  hipLaunchKernelGGL(switching_constraint_lin_kernel, dim3(c->batch * per), dim3(64), lds, c->stream, a);
   HIP_TRY(hipGetLastError());
   return RTOC_OK;
 }

@@ -227,25 +227,31 @@ static __global__ __launch_bounds__(64) void state_equation_lin_kernel(SeLinArgs
   V3 p1, p0;
   rel(Rn, pn, R, p, R1, p1);  // X1 = M_next^-1 M
   rel(R, p, Rp, pp, R0, p0);  // X0 = M^-1 M_prev
-  if (lane < 6) {
+  __shared__ double sLog[2][6];  // log6(X1), log6(X0)
+  if (lane < 18) {
+    // 18 lanes, one forward-mode evaluation through the log each: matrix m, column c
+    //   m = 0: Fqq[:, c] = Jlog6(X1) e_c      m = 1: Fqq_prev[:, c] = -Jlog6(X0) Ad_{X0^-1} e_c      m = 2: d/dq0 of q (-) q_next
+    const int m = lane / 6, c = lane % 6;
+    const M3& Rm = m == 1 ? R0 : R1;
+    const V3 pm = m == 1 ? p0 : p1;
+    const SV e = unit_twist(c);
+    const SV tw = m == 0 ? e : rbd::sv0() - rbd::act_inv(Rm, pm, e);
     SV val, der;
-    rbd::log6_fwd(R1, p1, unit_twist(lane), val, der);                          // Fqq[:, lane] = Jlog6(X1) e
-    const double c1[6] = {der.l.x, der.l.y, der.l.z, der.a.x, der.a.y, der.a.z};
-    rbd::log6_fwd(R0, p0, rbd::sv0() - rbd::act_inv(R0, p0, unit_twist(lane)), val, der);   // Fqq_prev[:, lane]
-    const double c0[6] = {der.l.x, der.l.y, der.l.z, der.a.x, der.a.y, der.a.z};
-    rbd::log6_fwd(R1, p1, rbd::sv0() - rbd::act_inv(R1, p1, unit_twist(lane)), val, der);   // d/dq0 of q (-) q_next
-    const double c2[6] = {der.l.x, der.l.y, der.l.z, der.a.x, der.a.y, der.a.z};
+    rbd::log6_fwd(Rm, pm, tw, val, der);
+    const double col[6] = {der.l.x, der.l.y, der.l.z, der.a.x, der.a.y, der.a.z};
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
-      J[0][r + 6 * lane] = c1[r], J[1][r + 6 * lane] = c0[r], J[2][r + 6 * lane] = c2[r];
-      kr[a.o_fxx + r + (size_t)lane * nx] = c1[r];  // Fqq top-left corner
+      J[m][r + 6 * c] = col[r];
+      if (m == 0) kr[a.o_fxx + r + (size_t)c * nx] = col[r];  // Fqq top-left corner
     }
-    if (lane == 0) {
-      // Fq (base) = log6(X1) + dt v
-      rbd::log6_fwd(R1, p1, rbd::sv0(), val, der);
-      const double f6[6] = {val.l.x, val.l.y, val.l.z, val.a.x, val.a.y, val.a.z};
+    if (c == 0 && m < 2) {
+      const double l6[6] = {val.l.x, val.l.y, val.l.z, val.a.x, val.a.y, val.a.z};
 #pragma unroll
-      for (int r = 0; r < 6; ++r) kr[a.o_fx + r] = f6[r] + dt * v[r];
+      for (int r = 0; r < 6; ++r) sLog[m][r] = l6[r];
+      if (m == 0) {   // Fq (base) = log6(X1) + dt v
+#pragma unroll
+        for (int r = 0; r < 6; ++r) kr[a.o_fx + r] = l6[r] + dt * v[r];
+      }
     }
   }
   __syncthreads();
@@ -256,27 +262,23 @@ static __global__ __launch_bounds__(64) void state_equation_lin_kernel(SeLinArgs
     for (int r = 0; r < 6; ++r) t += J[0][r + 6 * lane] * lmdn[r] + J[1][r + 6 * lane] * lmd[r];
     kr[a.o_lx + lane] += t;
   }
-  if (lane == 0 && a.se3) {
+  if (a.se3 && lane >= 32 && lane < 34) {
+    // two lanes, one block-triangular inverse each: Fqq_inv (from the d/dq0 Jacobian), Fqq_prev_inv
+    const int which = lane - 32;
     double* const se = a.se3 + rec * RTOC_SE3_STRIDE;
     double A[36];
-    inv6_block_ut(J[2], A);
+    inv6_block_ut(J[which == 0 ? 2 : 1], A);
 #pragma unroll
-    for (int e = 0; e < 36; ++e) se[e] = A[e];           // Fqq_inv
-    inv6_block_ut(J[1], A);
-#pragma unroll
-    for (int e = 0; e < 36; ++e) se[36 + e] = A[e];      // Fqq_prev_inv
-    if (st == 0 && a.dx0 && a.x0) {
+    for (int e = 0; e < 36; ++e) se[36 * which + e] = A[e];
+    if (which == 1 && st == 0 && a.dx0 && a.x0) {
       // computeInitialStateDirection (:99-109): dq0 = q0 (-) s0.q = log6(M^-1 M0) = log6(X0) for the base, with the
       // -Fqq_prev_inv correction rtoc_compute_initial_state_direction would apply; joints and velocities plain
-      SV val, der;
-      rbd::log6_fwd(R0, p0, rbd::sv0(), val, der);
-      const double d6[6] = {val.l.x, val.l.y, val.l.z, val.a.x, val.a.y, val.a.z};
       double* const o = a.dx0 + (size_t)b * nx;
 #pragma unroll
       for (int r = 0; r < 6; ++r) {
         double t = 0.0;
 #pragma unroll
-        for (int c = 0; c < 6; ++c) t += A[r + 6 * c] * d6[c];
+        for (int c = 0; c < 6; ++c) t += A[r + 6 * c] * sLog[1][c];
         o[r] = -t;
       }
       const double* x0 = a.x0 + (size_t)b * (nq + nv);

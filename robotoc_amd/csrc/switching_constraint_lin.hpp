@@ -29,6 +29,7 @@ struct SwLinArgs {
   const double* rotations;  // [nstages][ncontacts][9] or nullptr (surface contacts)
   int nstages, batch, nv, nq, njoints, ncontacts, nlevels, floating, ns_max;
   int exact_transport;  // RTOC_OPT_SWITCHING_TRANSPORT
+  int nsel, sel[16];    // the grid points with a switching constraint (nsel == 0: all grid points are launched)
   int sol_stride, kkt_stride, cdd_stride;
   int o_q, o_v, o_a, o_xi;
   int o_phix, o_phit, o_pres, o_lx, o_hx, o_scal;
@@ -46,8 +47,9 @@ static __global__ __launch_bounds__(64) void switching_constraint_lin_kernel(SwL
   using rbd::JP;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x;
-  const int nst1 = a.nstages - 1;
-  const int b = blockIdx.x / nst1, st = blockIdx.x % nst1;
+  // launched over the grid points that carry a switching constraint only (sel), or over all of them (nsel == 0)
+  const int nst1 = a.nsel > 0 ? a.nsel : a.nstages - 1;
+  const int b = blockIdx.x / nst1, st = a.nsel > 0 ? a.sel[blockIdx.x % nst1] : blockIdx.x % nst1;
   if (b >= a.batch) return;
   const rtoc_grid g = a.grid[st];
   if (!g.switching_constraint || st + 2 >= a.nstages) return;
@@ -202,7 +204,12 @@ static __global__ __launch_bounds__(64) void switching_constraint_lin_kernel(SwL
     for (int r = 0; r < 6; ++r) sT[r + 6 * lane] = tc[r], sT[36 + r + 6 * lane] = jc[r];
   }
   __syncthreads();
-  if (a.floating && lane == 0) inv6(sT + 36);
+  if (a.floating && lane == 0) {   // Jlog6 is block upper-triangular in the (linear, angular) ordering: 3 x 3 cofactor inverses
+    double A[36];
+    inv6_block_ut(sT + 36, A);
+#pragma unroll
+    for (int e = 0; e < 36; ++e) sT[36 + e] = A[e];
+  }
   __syncthreads();
   // ---- Phiq, Phiv, Phia, P, Phit and the multiplier / STO terms ----
   const double* const P = spq + 6 * RTOC_MAX_CONTACTS * 4;
