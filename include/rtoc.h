@@ -132,6 +132,10 @@ enum rtoc_option {
                       * cones; arguments kkt_tol / tau are part of the key).  For the single-OCP latency path, whose
                       * ~25 small kernels are launch-bound.  The calls stay asynchronous on the context's stream; the
                       * stream must not be capturing already.  Default 0. */
+  RTOC_OPT_CONE_JACOBIAN = 14, /* dg/dq of the friction-cone rows evaluated on the device (rtoc_contact_eval_kkt).  0 (default): as
+                      * the reference composes it -- the LOCAL-frame angular Jacobian column of the contact frame crossed
+                      * with the WORLD-frame force (robot.hxx:247-253, 275-287).  1: w_world x f_W, the derivative of
+                      * R_wf(q) f (what finite differences give).  They coincide when the contact frame is world-aligned. */
   RTOC_OPT_LINEARIZE_FUSED = 13, /* 0 (default): rtoc_linearize_contact_dynamics computes the values of the recursion in a
                       * level-parallel pre-pass (lanes = bodies; 64 doubles per body and grid point of scratch) and the
                       * tangent walk reads them; 1: one kernel, every lane recomputes the values along its walk (no scratch) */

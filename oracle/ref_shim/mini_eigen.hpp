@@ -15,6 +15,8 @@
 #include <cassert>
 #include <cmath>
 #include <cstddef>
+#include <cstdio>
+#include <vector>
 #include <cstdlib>
 #include <initializer_list>
 #include <iostream>
@@ -53,6 +55,7 @@ typedef Matrix<double, 4, 4> Matrix4d;
 typedef Matrix<int, Dynamic, 1> VectorXi;
 
 class View;
+class ArrayView;
 class Diag;
 template <class D>
 class MatrixBase;
@@ -112,6 +115,15 @@ class MatrixBase {
   inline View leftCols(Index n) const;
   inline View rightCols(Index n) const;
   inline View middleCols(Index j, Index n) const;
+  template <int N>
+  inline View middleCols(Index j) const;
+  bool isIdentity(double prec = 1e-12) const {
+    const RawView v = raw();
+    for (Index j = 0; j < v.c; ++j)
+      for (Index i = 0; i < v.r; ++i)
+        if (std::fabs(v.at(i, j) - (i == j ? 1.0 : 0.0)) > prec) return false;
+    return true;
+  }
   inline View topLeftCorner(Index nr, Index nc) const;
   inline View topRightCorner(Index nr, Index nc) const;
   inline View bottomLeftCorner(Index nr, Index nc) const;
@@ -148,7 +160,7 @@ class MatrixBase {
   // Eigen: `m.noalias() = expr` still RESIZES a plain matrix (robotoc relies on it, e.g. DtM in
   // riccati_factorizer.cpp:84), so noalias() hands back the object itself, not a fixed-size view
   D& noalias() const { return const_cast<D&>(derived()); }
-  inline View array() const;
+  inline ArrayView array() const;
   inline View matrix() const;
   inline Diag asDiagonal() const;
   inline MatrixXd eval() const;
@@ -318,6 +330,8 @@ class MatrixBase {
   template <class E>
   inline MatrixXd cwiseProduct(const MatrixBase<E>& o) const;
   template <class E>
+  inline MatrixXd cross(const MatrixBase<E>& o) const;
+  template <class E>
   inline MatrixXd cwiseQuotient(const MatrixBase<E>& o) const;
   inline MatrixXd cwiseAbs() const;
   inline MatrixXd cwiseInverse() const;
@@ -371,7 +385,155 @@ class View : public MatrixBase<View> {
     return *this;
   }
   inline View& operator=(const Diag& d);
+  // `block << a, b, c, ...;` fills row by row, as Eigen's comma initialiser
+  struct Comma {
+    RawView v;
+    Index k;
+    Comma& operator,(double x) {
+      v.at(k / v.c, k % v.c) = x;
+      ++k;
+      return *this;
+    }
+  };
+  Comma operator<<(double x) {
+    Comma c{v_, 0};
+    c, x;
+    return c;
+  }
 };
+
+// ---- coefficient-wise world: what `.array()` hands out -----------------------------------------
+// ArrayXd: an owning temporary of an array expression; ArrayView: the lvalue `m.array()`.  Binary operators are
+// ELEMENTWISE (the matrix world's View * View is a matrix product).
+class ArrayXd {
+ public:
+  Index r_, c_;
+  std::vector<double> d_;
+  ArrayXd(Index r, Index c) : r_(r), c_(c), d_(static_cast<size_t>(r * c), 0.0) {}
+  double& at(Index i, Index j) { return d_[static_cast<size_t>(i + j * r_)]; }
+  double at(Index i, Index j) const { return d_[static_cast<size_t>(i + j * r_)]; }
+  Index rows() const { return r_; }
+  Index cols() const { return c_; }
+  double sum() const {
+    double s = 0.0;
+    for (double x : d_) s += x;
+    return s;
+  }
+  double minCoeff() const {
+    double m = d_.at(0);
+    for (double x : d_) m = std::min(m, x);
+    return m;
+  }
+  double maxCoeff() const {
+    double m = d_.at(0);
+    for (double x : d_) m = std::max(m, x);
+    return m;
+  }
+  ArrayXd log() const {
+    ArrayXd o(r_, c_);
+    for (size_t k = 0; k < d_.size(); ++k) o.d_[k] = std::log(d_[k]);
+    return o;
+  }
+  ArrayXd abs() const {
+    ArrayXd o(r_, c_);
+    for (size_t k = 0; k < d_.size(); ++k) o.d_[k] = std::fabs(d_[k]);
+    return o;
+  }
+  ArrayXd operator-() const {
+    ArrayXd o(r_, c_);
+    for (size_t k = 0; k < d_.size(); ++k) o.d_[k] = -d_[k];
+    return o;
+  }
+};
+
+class ArrayView {
+ public:
+  RawView v_;
+  explicit ArrayView(const RawView& v) : v_(v) {}
+  Index rows() const { return v_.r; }
+  Index cols() const { return v_.c; }
+  ArrayXd eval() const {
+    ArrayXd o(v_.r, v_.c);
+    for (Index j = 0; j < v_.c; ++j)
+      for (Index i = 0; i < v_.r; ++i) o.at(i, j) = v_.at(i, j);
+    return o;
+  }
+  operator ArrayXd() const { return eval(); }
+  void check(Index r, Index c) const {
+    if (r != v_.r || c != v_.c) {
+      std::fprintf(stderr, "mini_eigen: array shape mismatch %ldx%ld vs %ldx%ld\n", (long)v_.r, (long)v_.c, (long)r, (long)c);
+      std::abort();
+    }
+  }
+  ArrayView& operator=(const ArrayXd& o) {
+    check(o.r_, o.c_);
+    for (Index j = 0; j < v_.c; ++j)
+      for (Index i = 0; i < v_.r; ++i) v_.at(i, j) = o.at(i, j);
+    return *this;
+  }
+  ArrayView& operator=(const ArrayView& o) { return *this = o.eval(); }
+  ArrayView& operator+=(const ArrayXd& o) {
+    check(o.r_, o.c_);
+    for (Index j = 0; j < v_.c; ++j)
+      for (Index i = 0; i < v_.r; ++i) v_.at(i, j) += o.at(i, j);
+    return *this;
+  }
+  ArrayView& operator-=(const ArrayXd& o) {
+    check(o.r_, o.c_);
+    for (Index j = 0; j < v_.c; ++j)
+      for (Index i = 0; i < v_.r; ++i) v_.at(i, j) -= o.at(i, j);
+    return *this;
+  }
+  ArrayView& operator+=(const ArrayView& o) { return *this += o.eval(); }
+  ArrayView& operator*=(double s) {
+    for (Index j = 0; j < v_.c; ++j)
+      for (Index i = 0; i < v_.r; ++i) v_.at(i, j) *= s;
+    return *this;
+  }
+  ArrayView& operator/=(double s) { return *this *= (1.0 / s); }
+  ArrayView& operator+=(double s) {
+    for (Index j = 0; j < v_.c; ++j)
+      for (Index i = 0; i < v_.r; ++i) v_.at(i, j) += s;
+    return *this;
+  }
+  double sum() const { return eval().sum(); }
+  double minCoeff() const { return eval().minCoeff(); }
+  double maxCoeff() const { return eval().maxCoeff(); }
+  ArrayXd log() const { return eval().log(); }
+  ArrayXd abs() const { return eval().abs(); }
+  ArrayXd operator-() const { return -eval(); }
+};
+
+#define MINI_EIGEN_ARRAY_BINOP(OP)                                                                         \
+  inline ArrayXd operator OP(const ArrayXd& a, const ArrayXd& b) {                                          \
+    if (a.r_ != b.r_ || a.c_ != b.c_) {                                                                     \
+      std::fprintf(stderr, "mini_eigen: array operands differ in shape\n");                                 \
+      std::abort();                                                                                         \
+    }                                                                                                       \
+    ArrayXd o(a.r_, a.c_);                                                                                  \
+    for (size_t k = 0; k < o.d_.size(); ++k) o.d_[k] = a.d_[k] OP b.d_[k];                                  \
+    return o;                                                                                               \
+  }                                                                                                         \
+  inline ArrayXd operator OP(const ArrayXd& a, double s) {                                                  \
+    ArrayXd o(a.r_, a.c_);                                                                                  \
+    for (size_t k = 0; k < o.d_.size(); ++k) o.d_[k] = a.d_[k] OP s;                                        \
+    return o;                                                                                               \
+  }                                                                                                         \
+  inline ArrayXd operator OP(double s, const ArrayXd& a) {                                                  \
+    ArrayXd o(a.r_, a.c_);                                                                                  \
+    for (size_t k = 0; k < o.d_.size(); ++k) o.d_[k] = s OP a.d_[k];                                        \
+    return o;                                                                                               \
+  }                                                                                                         \
+  inline ArrayXd operator OP(const ArrayView& a, const ArrayView& b) { return a.eval() OP b.eval(); }       \
+  inline ArrayXd operator OP(const ArrayView& a, const ArrayXd& b) { return a.eval() OP b; }                \
+  inline ArrayXd operator OP(const ArrayXd& a, const ArrayView& b) { return a OP b.eval(); }                \
+  inline ArrayXd operator OP(const ArrayView& a, double s) { return a.eval() OP s; }                        \
+  inline ArrayXd operator OP(double s, const ArrayView& a) { return s OP a.eval(); }
+MINI_EIGEN_ARRAY_BINOP(+)
+MINI_EIGEN_ARRAY_BINOP(-)
+MINI_EIGEN_ARRAY_BINOP(*)
+MINI_EIGEN_ARRAY_BINOP(/)
+#undef MINI_EIGEN_ARRAY_BINOP
 
 template <class T, int BR = Dynamic, int BC = Dynamic, bool Inner = false>
 using Block = View;
@@ -612,6 +774,9 @@ View MatrixBase<D>::rightCols(Index n) const { return block(0, cols() - n, rows(
 template <class D>
 View MatrixBase<D>::middleCols(Index j, Index n) const { return block(0, j, rows(), n); }
 template <class D>
+template <int N>
+View MatrixBase<D>::middleCols(Index j) const { return block(0, j, rows(), N); }
+template <class D>
 View MatrixBase<D>::topLeftCorner(Index nr, Index nc) const { return block(0, 0, nr, nc); }
 template <class D>
 View MatrixBase<D>::topRightCorner(Index nr, Index nc) const { return block(0, cols() - nc, nr, nc); }
@@ -677,7 +842,7 @@ View MatrixBase<D>::diagonal() const {
   return View(v.p, std::min(v.r, v.c), 1, v.rs + v.cs, 0);
 }
 template <class D>
-View MatrixBase<D>::array() const { return View(raw()); }
+ArrayView MatrixBase<D>::array() const { return ArrayView(raw()); }
 template <class D>
 View MatrixBase<D>::matrix() const { return View(raw()); }
 template <class D>
@@ -784,6 +949,22 @@ inline MatrixXd operator/(const MatrixBase<A>& a, double s) {
   for (Index j = 0; j < x.c; ++j)
     for (Index i = 0; i < x.r; ++i) out(i, j) = x.at(i, j) / s;
   return out;
+}
+template <class D>
+template <class E>
+MatrixXd MatrixBase<D>::cross(const MatrixBase<E>& o) const {
+  const RawView a = raw(), b = o.raw();
+  if (a.r * a.c != 3 || b.r * b.c != 3) {
+    std::fprintf(stderr, "mini_eigen: cross needs 3-vectors\n");
+    std::abort();
+  }
+  auto A = [&](Index k) { return a.c == 1 ? a.at(k, 0) : a.at(0, k); };
+  auto B = [&](Index k) { return b.c == 1 ? b.at(k, 0) : b.at(0, k); };
+  MatrixXd r(3, 1);
+  r(0, 0) = A(1) * B(2) - A(2) * B(1);
+  r(1, 0) = A(2) * B(0) - A(0) * B(2);
+  r(2, 0) = A(0) * B(1) - A(1) * B(0);
+  return r;
 }
 template <class D>
 template <class E>

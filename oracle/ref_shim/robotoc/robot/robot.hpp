@@ -107,6 +107,49 @@ class Robot {
   template <typename A>
   void normalizeConfiguration(const Eigen::MatrixBase<A>&) const {}
 
+  // ---- what the constraint components read (src/constraints/*.cpp): joint limits, and the frame kinematics of the contact
+  //      frames -- INJECTED by the test (frame rotation in the world, LOCAL frame Jacobian 6 x dimv, i.e. what
+  //      pinocchio::getFrameJacobian(..., LOCAL, ...) returns), so that the reference's composition of them is what runs ----
+  void setJointLimits(const Eigen::VectorXd& q_min, const Eigen::VectorXd& q_max, const Eigen::VectorXd& v_max, const Eigen::VectorXd& u_max) {
+    q_min_ = q_min, q_max_ = q_max, v_max_ = v_max, u_max_ = u_max;
+  }
+  Eigen::VectorXd lowerJointPositionLimit() const { return q_min_; }
+  Eigen::VectorXd upperJointPositionLimit() const { return q_max_; }
+  Eigen::VectorXd jointVelocityLimit() const { return v_max_; }
+  Eigen::VectorXd jointEffortLimit() const { return u_max_; }
+  std::vector<int> contactFrames() const {
+    std::vector<int> f;
+    for (int i = 0; i < maxNumContacts(); ++i) f.push_back(i);   // frame id = contact index
+    return f;
+  }
+  void setFrameKinematics(const int frame_id, const Eigen::Matrix3d& R_world, const Eigen::MatrixXd& J_local) {
+    if ((int)frame_R_.size() <= frame_id) frame_R_.resize(frame_id + 1), frame_J_.resize(frame_id + 1);
+    frame_R_[frame_id] = R_world, frame_J_[frame_id] = J_local;
+  }
+  template <typename A>
+  void updateFrameKinematics(const Eigen::MatrixBase<A>&) {}   // the injected kinematics stand
+  const Eigen::Matrix3d& frameRotation(const int frame_id) const { return frame_R_.at(frame_id); }
+  template <typename MatrixType>
+  void getFrameJacobian(const int frame_id, const Eigen::MatrixBase<MatrixType>& J) {
+    const_cast<Eigen::MatrixBase<MatrixType>&>(J) = frame_J_.at(frame_id);
+  }
+  // robot.hxx:264-271
+  template <typename Vector3dType>
+  void transformFromLocalToWorld(const int frame_id, const Eigen::Vector3d& vec_local, const Eigen::MatrixBase<Vector3dType>& vec_world) const {
+    const_cast<Eigen::MatrixBase<Vector3dType>&>(vec_world).noalias() = frameRotation(frame_id) * vec_local;
+  }
+  // robot.hxx:274-287, statement for statement
+  template <typename Vector3dType, typename MatrixType>
+  void getJacobianTransformFromLocalToWorld(const int frame_id, const Eigen::MatrixBase<Vector3dType>& vec_world,
+                                            const Eigen::MatrixBase<MatrixType>& J) {
+    const_cast<Eigen::MatrixBase<MatrixType>&>(J).setZero();
+    getFrameJacobian(frame_id, const_cast<Eigen::MatrixBase<MatrixType>&>(J));
+    for (int i = 0; i < dimv_; ++i) {
+      const_cast<Eigen::MatrixBase<MatrixType>&>(J).template topRows<3>().col(i).noalias() =
+          J.template bottomRows<3>().col(i).cross(vec_world.template head<3>());
+    }
+  }
+
   // ---- everything below needs Pinocchio: present so that the reference sources compile, never called ----
 #define RTOC_NEEDS_PINOCCHIO(name)                    \
   template <typename... Args>                         \
@@ -118,7 +161,6 @@ class Robot {
   RTOC_NEEDS_PINOCCHIO(dIntegrateTransport_dq)
   RTOC_NEEDS_PINOCCHIO(dIntegrateTransport_dv)
   RTOC_NEEDS_PINOCCHIO(updateKinematics)
-  RTOC_NEEDS_PINOCCHIO(updateFrameKinematics)
   RTOC_NEEDS_PINOCCHIO(computeBaumgarteResidual)
   RTOC_NEEDS_PINOCCHIO(computeBaumgarteDerivatives)
   RTOC_NEEDS_PINOCCHIO(computeImpactVelocityResidual)
@@ -142,6 +184,9 @@ class Robot {
     if (hasFloatingBase()) unavailable(what);
   }
   int dimv_, dimu_;
+  Eigen::VectorXd q_min_, q_max_, v_max_, u_max_;
+  std::vector<Eigen::Matrix3d> frame_R_;
+  std::vector<Eigen::MatrixXd> frame_J_;
   std::vector<ContactType> contact_types_;
   std::vector<std::string> contact_frame_names_;
   double contact_inv_damping_;

@@ -10,7 +10,7 @@ import subprocess
 import numpy as np
 
 from .types import (BoxRow, BUF_CDD, BUF_CON, BUF_DIR, BUF_DX0, BUF_KKT, BUF_RIC, BUF_STEP, Dims, Grid,
-                    Layout, OPT_BACKWARD_WAVES, OPT_CONDENSE_SPLIT, OPT_CONDENSE_KEEP_QAF, OPT_FXX_STRUCTURE, OPT_GRAPH, OPT_SWITCHING_TRANSPORT, OPT_IMPACT_CONES, OPT_UNCONSTR_DENSE, OPT_LINEARIZE_FUSED, OPT_MAX_DTS0, OPT_SWEEP_CHUNKS, OPT_WRITEBACK_KKT, OPT_BACKWARD_SCAN,
+                    Layout, OPT_BACKWARD_WAVES, OPT_CONDENSE_SPLIT, OPT_CONDENSE_KEEP_QAF, OPT_FXX_STRUCTURE, OPT_GRAPH, OPT_SWITCHING_TRANSPORT, OPT_IMPACT_CONES, OPT_UNCONSTR_DENSE, OPT_LINEARIZE_FUSED, OPT_CONE_JACOBIAN, OPT_MAX_DTS0, OPT_SWEEP_CHUNKS, OPT_WRITEBACK_KKT, OPT_BACKWARD_SCAN,
                     grid_array)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -421,6 +421,11 @@ class Context:
     def contact_init_constraints(self):
         """OCPSolver::initConstraints for the rows evaluated on the device (joint limits with bounds, friction cones with mu)"""
         _chk(lib().rtoc_contact_init_constraints(self._h))
+
+    def set_cone_jacobian(self, exact):
+        """RTOC_OPT_CONE_JACOBIAN: dg/dq of the friction cones -- False (default): as the reference composes it (LOCAL-frame
+        angular Jacobian x world-frame force); True: the derivative of R_wf(q) f"""
+        _chk(lib().rtoc_set_option(self._h, OPT_CONE_JACOBIAN, int(bool(exact))))
 
     def set_linearize_fused(self, on):
         """RTOC_OPT_LINEARIZE_FUSED: rigid-body linearisation as one kernel (values recomputed per lane) instead of pre-pass + walk"""

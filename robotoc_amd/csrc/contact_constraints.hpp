@@ -5,8 +5,9 @@
 //     g = cone_local f_W,   cone_local = cone_world R_surface^T,   cone_world = [0 0 -1; +-1 0 -mu/sqrt2; 0 +-1 -mu/sqrt2]
 // (frictionConeResidual, friction_cone.hpp:102-120) and their Jacobians
 //     dg/df = cone_local R_wf                                           (:180-182)
-//     dg/dq = cone_local (w_j x f_W),  w_j the world-aligned angular Jacobian column of the contact frame
-//             (getJacobianTransformFromLocalToWorld, robot.hxx; :170-176)
+//     dg/dq = cone_local (w_j x f_W),  w_j the angular Jacobian column of the contact frame -- in the LOCAL frame as the
+//             reference takes it (getJacobianTransformFromLocalToWorld over getFrameJacobian(LOCAL), robot.hxx:247-287;
+//             friction_cone.cpp:170-176), or world-aligned (the derivative of R_wf f): RTOC_OPT_CONE_JACOBIAN
 //   INIT       setSlack + setSlackAndDualPositive: slack = -g clipped at sqrt(barrier), dual = barrier / slack  (:100-116, pdipm.hxx:12-23)
 //   LINEARIZE  evalConstraint + evalDerivatives: residual = g + slack, cmpl = slack dual - barrier, the Jacobians into the
 //              RTOC_BUF_CONE record (what rtoc_condense / rtoc_expand read), lq += dg/dq^T dual, lf += dg/df^T dual
@@ -30,6 +31,7 @@ struct CcArgs {
   const double* mu;         // [ncontacts]
   int nstages, batch, nv, njoints, ncontacts, nlevels, mode;
   int contact_dim, row0, cone_stride, dgdf_off, impact_cones;
+  int exact_jacobian;   // RTOC_OPT_CONE_JACOBIAN: 0 = w_local x f_W as the reference composes it, 1 = w_world x f_W
   double barrier;
   int sol_stride, kkt_stride, cdd_stride, con_stride;
   int o_q, o_f, o_lx, o_lf;
@@ -158,7 +160,9 @@ static __global__ __launch_bounds__(64) void contact_cone_kernel(CcArgs a) {
             cr[a.o_lf + k * cd + lane] += acc;
           }
           if (lane_on) {    // column j of dg/dq
-            const V3 wxf = rbd::cross(rbd::mul(oR, wj), fW);
+            // the reference crosses the LOCAL-frame angular Jacobian column with the WORLD-frame force (robot.hxx:247-253,
+            // 275-287: getFrameJacobian(..., pinocchio::LOCAL, ...)); the derivative of R_wf f is w_world x f_W
+            const V3 wxf = rbd::cross(a.exact_jacobian ? rbd::mul(oR, wj) : rbd::mulT(rbd::ldm3(&scm[c * CP]), wj), fW);
 #pragma unroll
             for (int r = 0; r < 5; ++r) {
               const double e = rbd::dot(row[r], wxf);
@@ -255,7 +259,8 @@ static __global__ __launch_bounds__(64) void contact_cone_vals_kernel(CvArgs v) 
     }
     if (lane_on) {
       const bool path = (a.model->contact_dofs[c] >> j) & 1ull;
-      const V3 wxf = path ? rbd::cross(wj, fW) : rbd::mk(0, 0, 0);
+      // reference: LOCAL-frame angular Jacobian column x WORLD-frame force (see contact_cone_kernel); exact: w_world x f_W
+      const V3 wxf = path ? rbd::cross(a.exact_jacobian ? wj : rbd::mulT(Rwf, wj), fW) : rbd::mk(0, 0, 0);
 #pragma unroll
       for (int r = 0; r < 5; ++r) {
         const double e = rbd::dot(row[r], wxf);

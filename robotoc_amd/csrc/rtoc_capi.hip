@@ -169,6 +169,7 @@ struct rtoc_ctx {
   int use_graph;
   int exact_transport;  // RTOC_OPT_SWITCHING_TRANSPORT
   int unconstr_dense;   // RTOC_OPT_UNCONSTR_DENSE
+  int exact_cone_jacobian;  // RTOC_OPT_CONE_JACOBIAN
   int impact_cones;     // RTOC_OPT_IMPACT_CONES (default 1, rtoc_create)
   double* d_mu;         // rtoc_set_friction_coefficients
   double* d_wcone;      // rtoc_set_wrench_cone_params: [RTOC_MAX_CONTACTS][17 x 6]
@@ -412,6 +413,7 @@ int rtoc_clone(rtoc_ctx* c, rtoc_ctx** out) {
     n->impact_cones = c->impact_cones;
     n->unconstr_dense = c->unconstr_dense;
     n->linearize_fused = c->linearize_fused;
+    n->exact_cone_jacobian = c->exact_cone_jacobian;
     if (c->backward_scan) rc = rtoc_set_option(n, RTOC_OPT_BACKWARD_SCAN, c->backward_scan);
   }
   hipError_t e = hipStreamSynchronize(c->stream);
@@ -517,6 +519,9 @@ int rtoc_set_option(rtoc_ctx* c, int option, int64_t value) {
       c->max_dts0 = d;
       return RTOC_OK;
     }
+    case RTOC_OPT_CONE_JACOBIAN:
+      c->exact_cone_jacobian = value ? 1 : 0;
+      return RTOC_OK;
     case RTOC_OPT_LINEARIZE_FUSED:
       c->linearize_fused = value ? 1 : 0;
       return RTOC_OK;
@@ -1901,6 +1906,7 @@ static int launch_contact_cones(rtoc_ctx* c, int mode) {
   a.contact_dim = c->cone_dim, a.row0 = c->dims.nc_max - RTOC_FRICTION_ROWS * c->cone_contacts;
   a.cone_stride = rtoc_cone_stride(c->dims.nv, c->cone_contacts), a.dgdf_off = rtoc_cone_dgdf_off(c->dims.nv, c->cone_contacts);
   a.impact_cones = c->impact_cones;
+  a.exact_jacobian = c->exact_cone_jacobian;
   a.barrier = c->barrier;
   a.sol_stride = c->L.sol.stride, a.kkt_stride = c->L.kkt.stride, a.cdd_stride = c->L.cdd.stride, a.con_stride = c->L.con.stride;
   a.o_q = c->L.sol.off[RTOC_SOL_Q], a.o_f = c->L.sol.off[RTOC_SOL_F], a.o_lx = c->L.kkt.off[RTOC_KKT_LX], a.o_lf = c->L.cdd.off[RTOC_CDD_LF];

@@ -10,6 +10,7 @@ from robotoc_amd import capi, robot_model as rm
 from robotoc_amd.grid import ContactSequence, Event, discretize
 from robotoc_amd.types import (BUF_CDD, BUF_CON, BUF_CONE, BUF_KKT, BUF_SOL, GRID_IMPACT, Records, anymal_dims, cone_dgdf_off,
                                joint_limit_rows)
+from constraint_restatement import friction_cone_rows
 from test_switching_constraint_lin import fd_cols, trot_masks
 
 Q_STAND = np.array([0, 0, 0.4792, 0, 0, 0, 1, -0.1, 0.7, -1.0, -0.1, -0.7, 1.0, 0.1, 0.7, -1.0, 0.1, -0.7, 1.0])
@@ -27,7 +28,11 @@ def limits(nu, qmax=2.0, vmax=7.5, umax=40.0):
 
 
 @pytest.mark.gpu
-def test_cone_and_joint_limit_rows_against_the_numpy_restatement(oracle):
+@pytest.mark.parametrize("exact", [False, True])
+def test_cone_and_joint_limit_rows_against_the_numpy_restatement(oracle, exact):
+    """exact: RTOC_OPT_CONE_JACOBIAN -- False: dg/dq as the reference composes it (LOCAL-frame angular Jacobian x world-frame
+    force; the restatement tests/constraint_restatement.py is pinned to the reference's sources by
+    tests/test_constraints_vs_reference.py), True: the derivative of R_wf(q) f, checked against central differences of g."""
     m = rm.load_named("anymal")
     dims = anymal_dims()
     cs = ContactSequence([12, 6, 12], [Event("lift", 0.105), Event("impact", 0.265, impact_dimf=6)])
@@ -51,6 +56,7 @@ def test_cone_and_joint_limit_rows_against_the_numpy_restatement(oracle):
     ctx.set_friction_cones(4, 3)
     ctx.set_constraint_bounds(bounds, BARRIER, 0.995)
     ctx.set_friction_coefficients(mu)
+    ctx.set_cone_jacobian(exact)
     wq = np.concatenate([np.full(6, 10.0), np.full(12, 1.0)])
     ctx.set_configuration_cost(Q_STAND, np.zeros(nv), np.zeros(12), wq, np.full(nv, 1.0), np.full(nv, 1e-3), np.full(12, 1e-3),
                                10.0 * wq, np.full(nv, 1.0), q_weight_impact=wq, v_weight_impact=np.full(nv, 1.0), dv_weight_impact=np.full(nv, 1e-3))
@@ -121,8 +127,19 @@ def test_cone_and_joint_limit_rows_against_the_numpy_restatement(oracle):
                 worst["dual"] = max(worst["dual"], np.abs(dual[rr] - BARRIER / slack[rr]).max())
                 worst["residual"] = max(worst["residual"], np.abs(N.f(con1[b, i], "residual")[rr] - (gval + slack[rr])).max())
                 worst["cmpl"] = max(worst["cmpl"], np.abs(N.f(con1[b, i], "cmpl")[rr] - (slack[rr] * dual[rr] - BARRIER)).max())
-                dgdf = Cl @ oracle.rbd_contact_placement(m, q, c)[0]
-                dgdq = fd_cols(lambda e: gfun(oracle.rbd_integrate(m, q, e)), nv)
+                Rwf = oracle.rbd_contact_placement(m, q, c)[0]
+                dgdf = Cl @ Rwf
+                if exact:
+                    dgdq = fd_cols(lambda e: gfun(oracle.rbd_integrate(m, q, e)), nv)
+                else:
+                    # world-aligned angular Jacobian of the frame from central differences of its rotation: [w]x = dR R^T
+                    dR = fd_cols(lambda e: oracle.rbd_contact_placement(m, oracle.rbd_integrate(m, q, e), c)[0].reshape(-1), nv)
+                    ww = np.zeros((3, nv))
+                    for jj in range(nv):
+                        W = dR[:, jj].reshape(3, 3) @ Rwf.T
+                        ww[:, jj] = [W[2, 1], W[0, 2], W[1, 0]]
+                    g_r, dgdq, dgdf_r = friction_cone_rows(mu[c], rot[i, c], Rwf, ww, f[3 * k:3 * k + 3], exact_jacobian=False)
+                    assert np.abs(g_r - gval).max() < 1e-12 and np.abs(dgdf_r - dgdf).max() < 1e-12
                 dev_dgdq = cone[b, i, k * 5 * nv:(k + 1) * 5 * nv].reshape(nv, 5).T
                 o = cone_dgdf_off(nv, 4) + 15 * k
                 dev_dgdf = cone[b, i, o:o + 15].reshape(3, 5).T
