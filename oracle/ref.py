@@ -44,6 +44,28 @@ def lib():
     return _LIB
 
 
+def unconstr_update_solution(nv, N, dt, cost, limits, barrier, tau, x0, sol, rnea, con=None, init_constraints=True):
+    """UnconstrOCPSolver::updateSolution with the reference's own stage / cost / constraints / dynamics / Riccati sources and
+    injected inverse dynamics (oracle/ref_shim/ref_unconstr_solver_capi.cpp).  sol [N+1, 7 nv] is updated in place; returns
+    (condensed KKT blocks per grid point, KKT error (sum of squares), primal step, dual step, con)."""
+    L = lib()
+    dp = C.POINTER(C.c_double)
+    L.ref_unconstr_update_solution.argtypes = [C.c_int, C.c_int, C.c_double, dp, dp, C.c_double, C.c_double, dp, dp, dp, dp, dp, C.c_int, dp, dp]
+    nx = 2 * nv
+    per = nx * nx + nx * nv + nv * nv + nx + nv + nx
+    kkt = np.zeros((N + 1, per))
+    out = np.zeros(3)
+    cost = np.ascontiguousarray(cost, dtype=np.float64)
+    lim = None if limits is None else np.ascontiguousarray(limits, dtype=np.float64)
+    if con is None:
+        con = np.zeros((N, 2, 6 * nv))
+    q0, v0 = np.ascontiguousarray(x0[:nv]), np.ascontiguousarray(x0[nv:])
+    rc = L.ref_unconstr_update_solution(nv, N, dt, _p(cost), _p(lim) if lim is not None else None, barrier, tau, _p(q0), _p(v0), _p(sol),
+                                        _p(rnea), _p(con), int(init_constraints), _p(kkt), _p(out))
+    assert rc == 0
+    return kkt, out[0], out[1], out[2], con
+
+
 def _p(a):
     assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
     return a.ctypes.data_as(C.POINTER(C.c_double))

@@ -150,6 +150,28 @@ class Robot {
     }
   }
 
+  // ---- inverse dynamics and its partial derivatives: INJECTED per call by the test (computed by this repository's CPU
+  //      restatement at the same (q, v, a)), so that the reference's composition around them is what runs ----
+  void setInverseDynamics(const Eigen::VectorXd& ID, const Eigen::MatrixXd& dIDdq, const Eigen::MatrixXd& dIDdv, const Eigen::MatrixXd& dIDda) {
+    id_ = ID, did_dq_ = dIDdq, did_dv_ = dIDdv, did_da_ = dIDda;
+    has_id_ = true;
+  }
+  template <typename... Args>
+  void updateKinematics(const Args&...) {}   // the injected quantities stand
+  template <typename A, typename B, typename C, typename D>
+  void RNEA(const Eigen::MatrixBase<A>&, const Eigen::MatrixBase<B>&, const Eigen::MatrixBase<C>&, const Eigen::MatrixBase<D>& tau) {
+    if (!has_id_) unavailable("RNEA");
+    const_cast<Eigen::MatrixBase<D>&>(tau) = id_;
+  }
+  template <typename A, typename B, typename C, typename D, typename E, typename F>
+  void RNEADerivatives(const Eigen::MatrixBase<A>&, const Eigen::MatrixBase<B>&, const Eigen::MatrixBase<C>&,
+                       const Eigen::MatrixBase<D>& dq, const Eigen::MatrixBase<E>& dv, const Eigen::MatrixBase<F>& da) {
+    if (!has_id_) unavailable("RNEADerivatives");
+    const_cast<Eigen::MatrixBase<D>&>(dq) = did_dq_;
+    const_cast<Eigen::MatrixBase<E>&>(dv) = did_dv_;
+    const_cast<Eigen::MatrixBase<F>&>(da) = did_da_;
+  }
+
   // ---- everything below needs Pinocchio: present so that the reference sources compile, never called ----
 #define RTOC_NEEDS_PINOCCHIO(name)                    \
   template <typename... Args>                         \
@@ -160,7 +182,6 @@ class Robot {
   RTOC_NEEDS_PINOCCHIO(dSubtractConfiguration_dq0)
   RTOC_NEEDS_PINOCCHIO(dIntegrateTransport_dq)
   RTOC_NEEDS_PINOCCHIO(dIntegrateTransport_dv)
-  RTOC_NEEDS_PINOCCHIO(updateKinematics)
   RTOC_NEEDS_PINOCCHIO(computeBaumgarteResidual)
   RTOC_NEEDS_PINOCCHIO(computeBaumgarteDerivatives)
   RTOC_NEEDS_PINOCCHIO(computeImpactVelocityResidual)
@@ -169,8 +190,6 @@ class Robot {
   RTOC_NEEDS_PINOCCHIO(computeContactPositionDerivative)
   RTOC_NEEDS_PINOCCHIO(setContactForces)
   RTOC_NEEDS_PINOCCHIO(setImpactForces)
-  RTOC_NEEDS_PINOCCHIO(RNEA)
-  RTOC_NEEDS_PINOCCHIO(RNEADerivatives)
   RTOC_NEEDS_PINOCCHIO(RNEAImpact)
   RTOC_NEEDS_PINOCCHIO(RNEAImpactDerivatives)
 #undef RTOC_NEEDS_PINOCCHIO
@@ -185,6 +204,9 @@ class Robot {
   }
   int dimv_, dimu_;
   Eigen::VectorXd q_min_, q_max_, v_max_, u_max_;
+  Eigen::VectorXd id_;
+  Eigen::MatrixXd did_dq_, did_dv_, did_da_;
+  bool has_id_ = false;
   std::vector<Eigen::Matrix3d> frame_R_;
   std::vector<Eigen::MatrixXd> frame_J_;
   std::vector<ContactType> contact_types_;

@@ -97,5 +97,47 @@ def main():
             print(f, os.path.getsize(os.path.join(HERE, f)))
 
 
+
+
+
+def unconstr_solver_fixture(name, with_limits):
+    """One UnconstrOCPSolver::updateSolution of the iiwa14 OCP (BASELINE configs[0]) run by the REFERENCE'S OWN sources --
+    stages, ConfigurationSpaceCost, joint-limit components, forward-Euler state equation, UnconstrDynamics, Riccati recursion,
+    step sizes, update (oracle/ref_shim/ref_unconstr_solver_capi.cpp) -- with the inverse dynamics and its partial
+    derivatives of every grid point injected from this repository's CPU rigid-body restatement (Richardson-extrapolated
+    central differences: ~1e-11).  Inputs and outputs for the GPU test, where /root/reference does not exist."""
+    from robotoc_amd import robot_model as rm
+    m = rm.load_named("iiwa14")
+    nv, N, dt = m.nv, 20, 0.05
+    rng = np.random.default_rng(4242 + int(with_limits))
+    cost = np.stack([rng.uniform(-0.8, 0.8, nv), np.zeros(nv), np.zeros(nv), np.full(nv, 10.0), np.full(nv, 0.1), np.full(nv, 0.01),
+                     np.full(nv, 0.001), np.full(nv, 10.0), np.full(nv, 0.1)])
+    x0 = np.concatenate([rng.uniform(-0.5, 0.5, nv), np.zeros(nv)])
+    sol = np.zeros((N + 1, 7 * nv))
+    sol[:, :nv] = x0[:nv] + 0.1 * rng.uniform(-1, 1, (N + 1, nv))
+    sol[:, nv:2 * nv] = 0.3 * rng.uniform(-1, 1, (N + 1, nv))
+    sol[:, 2 * nv:3 * nv] = rng.uniform(-1, 1, (N + 1, nv))
+    sol[:, 3 * nv:4 * nv] = 5.0 * rng.uniform(-1, 1, (N + 1, nv))
+    sol[:, 4 * nv:] = 0.5 * rng.uniform(-1, 1, (N + 1, 3 * nv))
+    limits = np.stack([np.full(nv, -1.0), np.full(nv, 1.0), np.full(nv, 1.5), np.full(nv, 40.0)]) if with_limits else None
+    rnea = np.zeros((N, nv + 3 * nv * nv))
+    z = np.zeros(0)
+    for i in range(N):
+        q, v, a = sol[i, :nv], sol[i, nv:2 * nv], sol[i, 2 * nv:3 * nv]
+        rnea[i, :nv] = orc.rbd_eval(m, 0, q, v, a, z, np.zeros(nv), 0, z)[:nv]
+        h = 2.0e-3
+        J1, J2 = orc.rbd_linearize_fd(m, 0, q, v, a, z, np.zeros(nv), 0, z, eps=h), orc.rbd_linearize_fd(m, 0, q, v, a, z, np.zeros(nv), 0, z, eps=h / 2)
+        for k in range(3):   # dID/dq, dID/dv, dID/da: Richardson step on the central differences
+            J = (4.0 * np.asarray(J2[k])[:nv] - np.asarray(J1[k])[:nv]) / 3.0
+            rnea[i, nv + k * nv * nv:nv + (k + 1) * nv * nv] = J.T.reshape(-1)   # column-major
+    sol_in = sol.copy()
+    kkt, err, primal, dual, con = ref.unconstr_update_solution(nv, N, dt, cost, limits, 1.0e-3, 0.995, x0, sol, rnea)
+    np.savez_compressed(os.path.join(HERE, name), cost=cost, x0=x0, sol_in=sol_in, sol_out=sol, rnea=rnea, kkt=kkt,
+                        limits=limits if with_limits else np.zeros(0), scalars=np.array([err, primal, dual, dt, 1.0e-3, 0.995]), con=con)
+    print(name, "KKT error %.6e, steps %.4f / %.4f" % (err, primal, dual))
+
+
 if __name__ == "__main__":
     main()
+    unconstr_solver_fixture("ref_iiwa14_unconstr_solver.npz", False)
+    unconstr_solver_fixture("ref_iiwa14_unconstr_solver_limits.npz", True)
