@@ -81,23 +81,36 @@ static __global__ __launch_bounds__(64) void contact_cost_kernel(CostArgs a) {
   double* const Qxx = kr + a.kl.off[RTOC_KKT_QXX];
   double* const lx = kr + a.kl.off[RTOC_KKT_LX];
   // ---- joints of q, v, a, u ----
+  // The STO sensitivities of the stage cost on intermediate grids (intermediate_stage.cpp:103-108): h = cost / dt and
+  // hx, hu, ha = lx, lu, la / dt BEFORE constraints and dynamics add their terms -- i.e. the cost gradient without the dt
+  const bool sto = !terminal && !impact;
+  double* const hx = kr + a.kl.off[RTOC_KKT_HX];
+  double hval = 0.0;   // this lane's share of cost / dt = 1/2 sum of weight * difference^2
   for (int i = lane; i < nv; i += 64) {
     if (i >= nb) {
-      lx[i] = scale * Wq[i] * (q[(nb ? 1 : 0) + i] - qr[(nb ? 1 : 0) + i]);
+      const double dq = q[(nb ? 1 : 0) + i] - qr[(nb ? 1 : 0) + i];
+      lx[i] = scale * Wq[i] * dq;
       Qxx[i + (size_t)i * nx] = scale * Wq[i];
+      if (sto) hx[i] = Wq[i] * dq, hval += 0.5 * Wq[i] * dq * dq;
     }
-    lx[nv + i] = scale * Wv[i] * (v[i] - vr[i]);
+    const double dv = v[i] - vr[i];
+    lx[nv + i] = scale * Wv[i] * dv;
     Qxx[(nv + i) + (size_t)(nv + i) * nx] = scale * Wv[i];
+    if (sto) hx[nv + i] = Wv[i] * dv, hval += 0.5 * Wv[i] * dv * dv;
     if (!terminal) {
       const double w = impact ? wdvI[i] : scale * wa[i];   // a on contact grids, dv on impact grids (both in the A slot)
       cr[a.cl.off[RTOC_CDD_LA] + i] = w * acc[i];
       cr[a.cl.off[RTOC_CDD_QAA] + i] = w;
+      if (sto) cr[a.cl.off[RTOC_CDD_HA] + i] = wa[i] * acc[i], hval += 0.5 * wa[i] * acc[i] * acc[i];
     }
   }
-  if (!terminal && !impact)
+  if (sto)
     for (int i = lane; i < nu; i += 64) {
-      kr[a.kl.off[RTOC_KKT_LU] + i] = scale * wu[i] * (u[i] - ur[i]);
+      const double du = u[i] - ur[i];
+      kr[a.kl.off[RTOC_KKT_LU] + i] = scale * wu[i] * du;
       kr[a.kl.off[RTOC_KKT_QUU] + i + (size_t)i * nu] = scale * wu[i];
+      kr[a.kl.off[RTOC_KKT_HU] + i] = wu[i] * du;
+      hval += 0.5 * wu[i] * du * du;
     }
   (void)np;
   // ---- the free-flyer base of q: qdiff = log6(M_ref^-1 M), J = Jlog6 ----
@@ -126,7 +139,14 @@ static __global__ __launch_bounds__(64) void contact_cost_kernel(CostArgs a) {
 #pragma unroll
       for (int k = 0; k < 6; ++k) t += J[k + 6 * lane] * wd[k];
       lx[lane] = scale * t;
+      if (sto) hx[lane] = t, hval += 0.5 * wd[lane] * wd[lane] / (Wq[lane] != 0.0 ? Wq[lane] : 1.0);   // 1/2 Wq d^2, wd = Wq d
     }
+  }
+  if (sto) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) hval += __shfl_xor(hval, off, 64);
+    __syncthreads();   // the zeroing of the scalars above is done
+    if (lane == 0) kr[a.kl.off[RTOC_KKT_SCAL] + RTOC_KKT_SCAL_H] = hval;
   }
 }
 

@@ -141,3 +141,111 @@ if __name__ == "__main__":
     main()
     unconstr_solver_fixture("ref_iiwa14_unconstr_solver.npz", False)
     unconstr_solver_fixture("ref_iiwa14_unconstr_solver_limits.npz", True)
+    contact_stage_fixture()
+
+
+def _richardson(fun, n, h=2.0e-3):
+    """Jacobian of fun over an n-dimensional perturbation: central differences at h and h / 2, one Richardson step (O(h^4))"""
+    def central(step):
+        cols = []
+        for k in range(n):
+            e = np.zeros(n)
+            e[k] = step
+            cols.append((np.asarray(fun(e)) - np.asarray(fun(-e))) / (2.0 * step))
+        return np.stack(cols, axis=-1)
+    return (4.0 * central(h / 2) - central(h)) / 3.0
+
+
+def contact_stage_fixture(name="ref_anymal_contact_stage.npz"):
+    """IntermediateStage::evalKKT of ANYmal on four feet (ConfigurationSpaceCost, six joint-limit components, FrictionCone), run
+    by the REFERENCE'S OWN stage / cost / constraints / state-equation / contact-dynamics sources
+    (oracle/ref_shim/ref_contact_stage_capi.cpp); every Pinocchio quantity injected from this repository's CPU restatement
+    (Richardson-extrapolated differences for the Jacobians).  Grid point 2 of a five-point horizon: inputs for the device,
+    the reference's condensed KKT blocks as expected outputs."""
+    import ctypes as C
+    from robotoc_amd import robot_model as rm
+    from robotoc_amd.grid import ANYMAL_Q_STANDING
+    m = rm.load_named("anymal")
+    nv, nq, nu, nc, n, i0, dt = m.nv, m.nq, 12, 4, 5, 2, 0.02
+    rng = np.random.default_rng(777)
+    qs = np.array(ANYMAL_Q_STANDING, dtype=float)
+    feet = np.array([orc.rbd_contact_position(m, qs, c) for c in range(nc)]) + 0.005 * rng.uniform(-1, 1, (nc, 3))
+    q = np.zeros((n, nq))
+    for i in range(n):
+        q[i] = qs
+        q[i, :7] = orc.se3_integrate(qs[:7], 0.05 * rng.uniform(-1, 1, 6))
+        q[i, 7:] += 0.1 * rng.uniform(-1, 1, 12)
+    v, a, u = 0.5 * rng.uniform(-1, 1, (n, nv)), rng.uniform(-1, 1, (n, nv)), 10.0 * rng.uniform(-1, 1, (n, nu))
+    f = 10.0 * rng.uniform(-1, 1, (n, nc, 3))
+    f[:, :, 2] = rng.uniform(40, 90, (n, nc))
+    lmd, gmm, beta = (0.5 * rng.uniform(-1, 1, (n, nv)) for _ in range(3))
+    mus, nup = 0.5 * rng.uniform(-1, 1, (n, nc, 3)), 0.5 * rng.uniform(-1, 1, (n, 6))
+    mu = np.array([0.7, 0.6, 0.8, 0.5])
+    q_ref = qs.copy()
+    q_ref[:7] = orc.se3_integrate(qs[:7], np.array([0.03, 0.0, -0.02, 0.0, 0.05, 0.0]))
+    M = nv + 1
+    cost = np.zeros((12, M))
+    for k, val in ((0, q_ref), (3, np.concatenate([np.full(6, 10.0), np.full(12, 1.0)])), (4, np.full(nv, 1.0)), (5, np.full(nv, 1e-3)),
+                   (6, np.full(nu, 1e-3)), (7, np.full(nv, 10.0)), (8, np.full(nv, 1.0))):
+        cost[k, :len(val)] = val
+    limits = np.stack([np.full(nu, -1.6), np.full(nu, 1.6), np.full(nu, 3.0), np.full(nu, 40.0)])
+    nrow = 6 * nu + 5 * nc
+    slack, dual = rng.uniform(0.1, 2.0, nrow), rng.uniform(0.01, 0.5, nrow)
+    barrier, tau = 1.0e-3, 0.995
+    active = 0b1111
+
+    def sub(qf, q0):
+        return np.concatenate([orc.se3_difference(q0[:7], qf[:7]), qf[7:] - q0[7:]])
+    qi, qn, qp = q[i0], q[i0 + 1], q[i0 - 1]
+    plus = lambda qq, e: orc.rbd_integrate(m, qq, e)
+    L = ref.lib()
+    dp = C.POINTER(C.c_double)
+    ptr = lambda x: np.ascontiguousarray(x, dtype=np.float64).ctypes.data_as(dp)
+    L.ref_stage_begin(nv, nu, nc)
+
+    def inject(key, arr):
+        arr = np.asfortranarray(np.atleast_2d(np.asarray(arr, dtype=np.float64).T).T if np.ndim(arr) == 1 else arr)
+        if arr.ndim == 1 or arr.shape[1] == 0:
+            arr = arr.reshape(-1, 1)
+        keep = np.asfortranarray(arr)
+        assert L.ref_stage_inject(key.encode(), keep.ctypes.data_as(dp), keep.shape[0], keep.shape[1]) == 0
+    # the order IntermediateStage::evalKKT asks for them (intermediate_stage.cpp:94-148)
+    inject("subtractConfiguration", sub(qi, q_ref).reshape(-1, 1))                                  # cost (:277 / hpp:193)
+    inject("dSubtractConfiguration_dqf", _richardson(lambda e: sub(plus(qi, e), q_ref), nv))       # cost (hpp:214)
+    inject("subtractConfiguration", sub(qi, qn).reshape(-1, 1))                                     # state_equation.cpp:16
+    inject("dSubtractConfiguration_dqf", _richardson(lambda e: sub(plus(qi, e), qn), nv))          # :39
+    inject("dSubtractConfiguration_dq0", _richardson(lambda e: sub(qp, plus(qi, e)), nv))          # :41
+    inject("dSubtractConfiguration_dq0", _richardson(lambda e: sub(qi, plus(qn, e)), nv))          # :78
+    fstack = f[i0].reshape(-1)
+    val = orc.rbd_eval(m, 0, qi, v[i0], a[i0], fstack, np.zeros(nu), active, feet.reshape(-1))
+    h = 2.0e-3
+    J1 = orc.rbd_linearize_fd(m, 0, qi, v[i0], a[i0], fstack, np.zeros(nu), active, feet.reshape(-1), eps=h)
+    J2 = orc.rbd_linearize_fd(m, 0, qi, v[i0], a[i0], fstack, np.zeros(nu), active, feet.reshape(-1), eps=h / 2)
+    Jr = [(4.0 * np.asarray(J2[k]) - np.asarray(J1[k])) / 3.0 for k in range(3)]   # [dID; dC] / d(q, v, a): (nv + 12) x nv
+    assert L.ref_stage_inverse_dynamics(ptr(val[:nv]), ptr(np.asfortranarray(Jr[0][:nv]).T.copy()), ptr(np.asfortranarray(Jr[1][:nv]).T.copy()),
+                                        ptr(np.asfortranarray(Jr[2][:nv]).T.copy())) == 0
+    inject("baumgarteResidual", val[nv:].reshape(-1, 1))
+    for k, key in enumerate(("baumgarte_dq", "baumgarte_dv", "baumgarte_da")):
+        inject(key, Jr[k][nv:])
+    frames = []
+    for c in range(nc):
+        R = orc.rbd_contact_placement(m, qi, c)[0]
+        dR = _richardson(lambda e: orc.rbd_contact_placement(m, plus(qi, e), c)[0].reshape(-1), nv)
+        Jl = np.zeros((6, nv))
+        for jj in range(nv):
+            W = dR[:, jj].reshape(3, 3) @ R.T
+            Jl[3:, jj] = R.T @ np.array([W[2, 1], W[0, 2], W[1, 0]])   # LOCAL-frame angular Jacobian column
+        assert L.ref_stage_frame(c, ptr(R), ptr(Jl.T.copy())) == 0
+        frames.append((R, Jl))
+    sol = np.concatenate([qi, v[i0], a[i0], u[i0], f[i0].reshape(-1), lmd[i0], gmm[i0], beta[i0], mus[i0].reshape(-1), nup[i0]])
+    sol_next = np.concatenate([qn, v[i0 + 1], lmd[i0 + 1], gmm[i0 + 1]])
+    nx = 2 * nv
+    out = np.zeros(nx * nx + nx * nu + nu * nu + nx * nx + nv * nu + nx + nu + nx + nx + nu + nx + 4)
+    L.ref_contact_stage_eval_kkt.argtypes = [C.c_uint, dp, dp, C.c_double, C.c_int, C.c_int, dp, dp, C.c_double, C.c_double, dp, dp, dp, dp, dp, dp]
+    rc = L.ref_contact_stage_eval_kkt(active, ptr(feet), ptr(mu), dt, i0, n - 1, ptr(cost), ptr(limits), barrier, tau, ptr(qp), ptr(sol),
+                                      ptr(sol_next), ptr(slack), ptr(dual), out.ctypes.data_as(dp))
+    assert rc == 0, rc
+    np.savez_compressed(os.path.join(HERE, name), q=q, v=v, a=a, u=u, f=f, lmd=lmd, gmm=gmm, beta=beta, mu_stack=mus, nu_passive=nup,
+                        feet=feet, mu=mu, cost=cost, limits=limits, slack=slack, dual=dual, out=out,
+                        scalars=np.array([dt, barrier, tau, i0, active]))
+    print(name, "stage KKT error %.6e, h %.6e" % (out[-1], out[-2]))
