@@ -20,7 +20,9 @@
 #include "robotoc/constraints/joint_velocity_upper_limit.hpp"
 #include "robotoc/cost/configuration_space_cost.hpp"
 #include "robotoc/cost/cost_function.hpp"
+#include "robotoc/ocp/impact_stage.hpp"
 #include "robotoc/ocp/intermediate_stage.hpp"
+#include "robotoc/ocp/terminal_stage.hpp"
 #include "robotoc/planner/contact_sequence.hpp"
 
 using namespace robotoc;
@@ -157,6 +159,161 @@ int ref_contact_stage_eval_kkt(unsigned active, const double* contact_pos, const
   putm(kr.lx), putm(kr.lu), putm(kr.Fx), putm(km.hx), putm(km.hu), putm(km.fx);
   *o++ = km.Qtt, *o++ = km.Qtt_prev, *o++ = kr.h, *o++ = data.performance_index.kkt_error;
   (void)nx;
+  return 0;
+}
+
+// IntermediateStage::evalKKT on the grid point two ahead of a touch-down (GridInfo::switching_constraint): cost, state
+// equation, contact dynamics, linearizeSwitchingConstraint (src/dynamics/switching_constraint.cpp:26-70) and their
+// condensation; no inequality rows (an empty Constraints object).  active: the contacts of the phase, impact: those that
+// touch down.  sol as in ref_contact_stage_eval_kkt plus xi (rows of the impacting contacts) at the end.
+// out: Qxx, Qxu, Quu, Fxx, Fvu, lx, lu, Fx, Phix (ns x nx), Phiu (ns x nu), Phit (ns), P (ns), hx, hu, [Qtt, h]
+int ref_contact_stage_eval_kkt3(unsigned active, unsigned impact, const double* contact_pos, const double* mu, double dt, double dt_next, int stage,
+                                int num_grids_in_phase, const double* cost, const double* q_prev, const double* sol, const double* sol_next,
+                                double* out) {
+  if (!g_robot) return 1;
+  Robot& robot = *g_robot;
+  const int nv = robot.dimv(), nu = robot.dimu(), nq = nv + 1, nc = robot.maxNumContacts();
+  const int M = nv + 1;
+  auto config = std::make_shared<ConfigurationSpaceCost>(robot);
+  config->set_q_ref(vec(cost, nq)), config->set_v_ref(vec(cost + M, nv)), config->set_u_ref(vec(cost + 2 * M, nu));
+  config->set_q_weight(vec(cost + 3 * M, nv)), config->set_v_weight(vec(cost + 4 * M, nv)), config->set_a_weight(vec(cost + 5 * M, nv));
+  config->set_u_weight(vec(cost + 6 * M, nu)), config->set_q_weight_terminal(vec(cost + 7 * M, nv)), config->set_v_weight_terminal(vec(cost + 8 * M, nv));
+  auto cf = std::make_shared<CostFunction>();
+  cf->add("config_cost", config);
+  auto constraints = std::make_shared<Constraints>(1.0e-3, 0.995);
+  ContactStatus pre = robot.createContactStatus(), post = robot.createContactStatus();
+  int ns = 0;
+  for (int c = 0; c < nc; ++c) {
+    if ((active >> c) & 1u) pre.activateContact(c);
+    if (((active | impact) >> c) & 1u) post.activateContact(c);
+    if ((impact >> c) & 1u) ns += 3;
+    pre.setFrictionCoefficient(c, mu[c]), post.setFrictionCoefficient(c, mu[c]);
+    pre.setContactPlacement(c, Eigen::Vector3d(vec(contact_pos + 3 * c, 3)));
+    post.setContactPlacement(c, Eigen::Vector3d(vec(contact_pos + 3 * c, 3)));
+  }
+  auto seq = std::make_shared<ContactSequence>(robot, 2);
+  seq->init(pre);
+  seq->push_back(post, dt * (stage + 2));
+  IntermediateStage st(cf, constraints, seq);
+  GridInfo gi;
+  gi.type = GridType::Intermediate;
+  gi.dt = dt, gi.dt_next = dt_next, gi.stage = stage, gi.phase = 0, gi.impact_index = -1, gi.num_grids_in_phase = num_grids_in_phase, gi.t = dt * stage;
+  gi.switching_constraint = true;
+  SplitSolution s(robot), sn(robot);
+  s.setContactStatus(pre);
+  s.setSwitchingConstraintDimension(ns);
+  const double* p = sol;
+  s.q = vec(p, nq), p += nq;
+  s.v = vec(p, nv), p += nv;
+  s.a = vec(p, nv), p += nv;
+  s.u = vec(p, nu), p += nu;
+  for (int c = 0; c < nc; ++c)
+    for (int k = 0; k < 3; ++k) s.f[c](k) = p[3 * c + k];
+  p += 3 * nc;
+  s.lmd = vec(p, nv), p += nv;
+  s.gmm = vec(p, nv), p += nv;
+  s.beta = vec(p, nv), p += nv;
+  for (int c = 0; c < nc; ++c)
+    for (int k = 0; k < 3; ++k) s.mu[c](k) = p[3 * c + k];
+  p += 3 * nc;
+  s.nu_passive = vec(p, 6), p += 6;
+  s.xi_stack() = vec(p, ns);
+  s.set_f_stack(), s.set_mu_stack();
+  sn.q = vec(sol_next, nq), sn.v = vec(sol_next + nq, nv), sn.lmd = vec(sol_next + nq + nv, nv), sn.gmm = vec(sol_next + nq + 2 * nv, nv);
+  OCPData data = st.createData(robot);
+  st.initConstraints(robot, gi, s, data);
+  SplitKKTMatrix km(robot);
+  SplitKKTResidual kr(robot);
+  st.evalKKT(robot, gi, vec(q_prev, nq), s, sn, data, km, kr);
+  if (robot.pending() != 0) return 2;
+  double* o = out;
+  auto putm = [&](const Eigen::MatrixXd& m) {
+    for (int j = 0; j < m.cols(); ++j)
+      for (int i = 0; i < m.rows(); ++i) *o++ = m(i, j);
+  };
+  putm(km.Qxx), putm(km.Qxu), putm(km.Quu), putm(km.Fxx), putm(km.Fvu), putm(kr.lx), putm(kr.lu), putm(kr.Fx);
+  putm(km.Phix()), putm(km.Phiu()), putm(km.Phit()), putm(kr.P()), putm(km.hx), putm(km.hu);
+  *o++ = km.Qtt, *o++ = kr.h;
+  return 0;
+}
+
+// The impact grid (kind 1: ImpactStage::evalKKT, src/ocp/impact_stage.cpp:78-120) and the terminal grid (kind 2:
+// TerminalStage::evalKKT, src/ocp/terminal_stage.cpp:70-100) of the same OCP.  active_pre: contacts active before the impact,
+// impact: the contacts that touch down (their rows carry the impact forces / multipliers); sol for kind 1: q, v, dv, f ([ncontacts][3]
+// by contact index), lmd, gmm, beta, mu; for kind 2: q, v, lmd, gmm.  out: kind 1: Qxx, Fxx, lx, Fx; kind 2: Qxx, lx.
+int ref_contact_stage_eval_kkt2(int kind, unsigned active_pre, unsigned impact, const double* contact_pos, const double* mu, const double* cost,
+                                const double* limits, double barrier, double tau, const double* q_prev, const double* sol,
+                                const double* sol_next, double* out) {
+  if (!g_robot) return 1;
+  Robot& robot = *g_robot;
+  const int nv = robot.dimv(), nu = robot.dimu(), nq = nv + 1, nc = robot.maxNumContacts();
+  const int M = nv + 1;
+  auto config = std::make_shared<ConfigurationSpaceCost>(robot);
+  config->set_q_ref(vec(cost, nq)), config->set_v_ref(vec(cost + M, nv)), config->set_u_ref(vec(cost + 2 * M, nu));
+  config->set_q_weight(vec(cost + 3 * M, nv)), config->set_v_weight(vec(cost + 4 * M, nv)), config->set_a_weight(vec(cost + 5 * M, nv));
+  config->set_u_weight(vec(cost + 6 * M, nu)), config->set_q_weight_terminal(vec(cost + 7 * M, nv)), config->set_v_weight_terminal(vec(cost + 8 * M, nv));
+  config->set_q_weight_impact(vec(cost + 9 * M, nv)), config->set_v_weight_impact(vec(cost + 10 * M, nv)), config->set_dv_weight_impact(vec(cost + 11 * M, nv));
+  auto cf = std::make_shared<CostFunction>();
+  cf->add("config_cost", config);
+  auto constraints = std::make_shared<Constraints>(barrier, tau);   // joint limits + FrictionCone: none of them acts on these grids
+  robot.setJointLimits(vec(limits, nu), vec(limits + nu, nu), vec(limits + 2 * nu, nu), vec(limits + 3 * nu, nu));
+  constraints->add("joint_position_lower", std::make_shared<JointPositionLowerLimit>(robot));
+  constraints->add("joint_torques_upper", std::make_shared<JointTorquesUpperLimit>(robot));
+  constraints->add("friction_cone", std::make_shared<FrictionCone>(robot));
+  ContactStatus pre = robot.createContactStatus(), post = robot.createContactStatus();
+  for (int c = 0; c < nc; ++c) {
+    if ((active_pre >> c) & 1u) pre.activateContact(c);
+    if (((active_pre | impact) >> c) & 1u) post.activateContact(c);
+    pre.setFrictionCoefficient(c, mu[c]), post.setFrictionCoefficient(c, mu[c]);
+    pre.setContactPlacement(c, Eigen::Vector3d(vec(contact_pos + 3 * c, 3)));
+    post.setContactPlacement(c, Eigen::Vector3d(vec(contact_pos + 3 * c, 3)));
+  }
+  auto seq = std::make_shared<ContactSequence>(robot, 2);
+  seq->init(pre);
+  seq->push_back(post, 0.1);
+  double* o = out;
+  auto putm = [&](const Eigen::MatrixXd& m) {
+    for (int j = 0; j < m.cols(); ++j)
+      for (int i = 0; i < m.rows(); ++i) *o++ = m(i, j);
+  };
+  SplitKKTMatrix km(robot);
+  SplitKKTResidual kr(robot);
+  if (kind == 1) {
+    const ImpactStatus& is = seq->impactStatus(0);
+    ImpactStage st(cf, constraints, seq);
+    GridInfo gi;
+    gi.type = GridType::Impact, gi.dt = 0.0, gi.impact_index = 0, gi.phase = 0, gi.t = 0.1;
+    SplitSolution s(robot), sn(robot);
+    s.setContactStatus(is);
+    const double* p = sol;
+    s.q = vec(p, nq), p += nq;
+    s.v = vec(p, nv), p += nv;
+    s.dv = vec(p, nv), p += nv;
+    for (int c = 0; c < nc; ++c)
+      for (int k = 0; k < 3; ++k) s.f[c](k) = p[3 * c + k];
+    p += 3 * nc;
+    s.lmd = vec(p, nv), p += nv;
+    s.gmm = vec(p, nv), p += nv;
+    s.beta = vec(p, nv), p += nv;
+    for (int c = 0; c < nc; ++c)
+      for (int k = 0; k < 3; ++k) s.mu[c](k) = p[3 * c + k];
+    s.set_f_stack(), s.set_mu_stack();
+    sn.q = vec(sol_next, nq), sn.v = vec(sol_next + nq, nv), sn.lmd = vec(sol_next + nq + nv, nv), sn.gmm = vec(sol_next + nq + 2 * nv, nv);
+    OCPData data = st.createData(robot);
+    st.initConstraints(robot, gi, s, data);
+    st.evalKKT(robot, gi, vec(q_prev, nq), s, sn, data, km, kr);
+    putm(km.Qxx), putm(km.Fxx), putm(kr.lx), putm(kr.Fx);
+  } else {
+    TerminalStage st(cf, constraints, seq);
+    GridInfo gi;
+    gi.type = GridType::Terminal, gi.dt = 0.0, gi.phase = 1, gi.t = 0.2;
+    SplitSolution s(robot);
+    s.q = vec(sol, nq), s.v = vec(sol + nq, nv), s.lmd = vec(sol + nq + nv, nv), s.gmm = vec(sol + nq + 2 * nv, nv);
+    OCPData data = st.createData(robot);
+    st.evalKKT(robot, gi, vec(q_prev, nq), s, data, km, kr);
+    putm(km.Qxx), putm(kr.lx);
+  }
+  if (robot.pending() != 0) return 2;
   return 0;
 }
 

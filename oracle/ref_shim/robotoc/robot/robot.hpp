@@ -104,12 +104,6 @@ class Robot {
     needFixedBase("integrateConfiguration");
     const_cast<Eigen::MatrixBase<C>&>(q) += h * v;
   }
-  template <typename A, typename B, typename C>
-  void integrateConfiguration(const Eigen::MatrixBase<A>& q, const Eigen::MatrixBase<B>& v, const double h,
-                              const Eigen::MatrixBase<C>& q_integrated) const {
-    needFixedBase("integrateConfiguration");
-    const_cast<Eigen::MatrixBase<C>&>(q_integrated) = q + h * v;
-  }
   template <typename A>
   void normalizeConfiguration(const Eigen::MatrixBase<A>&) const {}
 
@@ -212,21 +206,61 @@ class Robot {
     const_cast<Eigen::MatrixBase<D>&>(da) = pop("baumgarte_da");
   }
 
+  // switching constraint (src/dynamics/switching_constraint.cpp): the integrated configuration is not used by the stand-in;
+  // position residual / derivative of the impacting contacts at it are injected.  dIntegrateTransport restates the wrapper
+  // of robot.hxx:59-92 on top of Pinocchio's documented semantics (dIntegrateTransport left-multiplies by dIntegrate): the
+  // reference passes the TRANSPOSED Jacobian, so Jout^T = dIntegrate Jin^T.  dIntegrate_dq / _dv themselves are injected.
+  template <typename A, typename B, typename C>
+  void integrateConfiguration(const Eigen::MatrixBase<A>& q, const Eigen::MatrixBase<B>& v, const double h, const Eigen::MatrixBase<C>& q_int) const {
+    if (hasFloatingBase()) {
+      const_cast<Eigen::MatrixBase<C>&>(q_int) = pop("integrateConfiguration");
+      return;
+    }
+    const_cast<Eigen::MatrixBase<C>&>(q_int) = q + h * v;
+  }
+  template <typename A, typename C>
+  void computeContactPositionResidual(const A&, const Eigen::MatrixBase<C>& res) const { const_cast<Eigen::MatrixBase<C>&>(res) = pop("contactPositionResidual"); }
+  template <typename A, typename C>
+  void computeContactPositionDerivative(const A&, const Eigen::MatrixBase<C>& J) const { const_cast<Eigen::MatrixBase<C>&>(J) = pop("contactPositionDerivative"); }
+  template <typename A, typename B, typename C, typename D>
+  void dIntegrateTransport_dq(const Eigen::MatrixBase<A>&, const Eigen::MatrixBase<B>&, const Eigen::MatrixBase<C>& Jin, const Eigen::MatrixBase<D>& Jout) const {
+    const Eigen::MatrixXd T = pop("dIntegrate_dq");
+    const_cast<Eigen::MatrixBase<D>&>(Jout) = Eigen::MatrixXd(T * Eigen::MatrixXd(Jin.transpose())).transpose();
+  }
+  template <typename A, typename B, typename C, typename D>
+  void dIntegrateTransport_dv(const Eigen::MatrixBase<A>&, const Eigen::MatrixBase<B>&, const Eigen::MatrixBase<C>& Jin, const Eigen::MatrixBase<D>& Jout) const {
+    const Eigen::MatrixXd T = pop("dIntegrate_dv");
+    const_cast<Eigen::MatrixBase<D>&>(Jout) = Eigen::MatrixXd(T * Eigen::MatrixXd(Jin.transpose())).transpose();
+  }
+
+  // impact variants: the same injected inverse dynamics (dID/dv slot = dID/d(dv)), FIFO for the contact-velocity rows
+  template <typename... Args>
+  void setImpactForces(const Args&...) {}
+  template <typename A, typename B, typename D>
+  void RNEAImpact(const Eigen::MatrixBase<A>&, const Eigen::MatrixBase<B>&, const Eigen::MatrixBase<D>& res) {
+    if (!has_id_) unavailable("RNEAImpact");
+    const_cast<Eigen::MatrixBase<D>&>(res) = id_;
+  }
+  template <typename A, typename B, typename D, typename E>
+  void RNEAImpactDerivatives(const Eigen::MatrixBase<A>&, const Eigen::MatrixBase<B>&, const Eigen::MatrixBase<D>& dq, const Eigen::MatrixBase<E>& ddv) {
+    if (!has_id_) unavailable("RNEAImpactDerivatives");
+    const_cast<Eigen::MatrixBase<D>&>(dq) = did_dq_;
+    const_cast<Eigen::MatrixBase<E>&>(ddv) = did_da_;
+  }
+  template <typename A, typename C>
+  void computeImpactVelocityResidual(const A&, const Eigen::MatrixBase<C>& res) const { const_cast<Eigen::MatrixBase<C>&>(res) = pop("impactVelocityResidual"); }
+  template <typename A, typename B, typename C>
+  void computeImpactVelocityDerivatives(const A&, const Eigen::MatrixBase<B>& dq, const Eigen::MatrixBase<C>& dv) {
+    const_cast<Eigen::MatrixBase<B>&>(dq) = pop("impactVelocity_dq");
+    const_cast<Eigen::MatrixBase<C>&>(dv) = pop("impactVelocity_dv");
+  }
+
   // ---- everything below needs Pinocchio: present so that the reference sources compile, never called ----
 #define RTOC_NEEDS_PINOCCHIO(name)                    \
   template <typename... Args>                         \
   void name(const Args&...) const {                   \
     unavailable(#name);                               \
   }
-  RTOC_NEEDS_PINOCCHIO(dIntegrateTransport_dq)
-  RTOC_NEEDS_PINOCCHIO(dIntegrateTransport_dv)
-  RTOC_NEEDS_PINOCCHIO(computeImpactVelocityResidual)
-  RTOC_NEEDS_PINOCCHIO(computeImpactVelocityDerivatives)
-  RTOC_NEEDS_PINOCCHIO(computeContactPositionResidual)
-  RTOC_NEEDS_PINOCCHIO(computeContactPositionDerivative)
-  RTOC_NEEDS_PINOCCHIO(setImpactForces)
-  RTOC_NEEDS_PINOCCHIO(RNEAImpact)
-  RTOC_NEEDS_PINOCCHIO(RNEAImpactDerivatives)
 #undef RTOC_NEEDS_PINOCCHIO
 
  private:

@@ -142,6 +142,7 @@ if __name__ == "__main__":
     unconstr_solver_fixture("ref_iiwa14_unconstr_solver.npz", False)
     unconstr_solver_fixture("ref_iiwa14_unconstr_solver_limits.npz", True)
     contact_stage_fixture()
+    impact_and_terminal_stage_fixture()
 
 
 def _richardson(fun, n, h=2.0e-3):
@@ -249,3 +250,149 @@ def contact_stage_fixture(name="ref_anymal_contact_stage.npz"):
                         feet=feet, mu=mu, cost=cost, limits=limits, slack=slack, dual=dual, out=out,
                         scalars=np.array([dt, barrier, tau, i0, active]))
     print(name, "stage KKT error %.6e, h %.6e" % (out[-1], out[-2]))
+
+
+def impact_and_terminal_stage_fixture(name="ref_anymal_impact_terminal_stage.npz"):
+    """ImpactStage::evalKKT and TerminalStage::evalKKT (src/ocp/impact_stage.cpp:78-120, terminal_stage.cpp:70-100) of ANYmal
+    touching down with two feet, by the REFERENCE'S OWN sources with injected rigid-body quantities
+    (oracle/ref_shim/ref_contact_stage_capi.cpp: ref_contact_stage_eval_kkt2).  The horizon: two feet, touch-down of the other two,
+    four feet; the impact grid and the terminal grid are the ones compared."""
+    import ctypes as C
+    from robotoc_amd import robot_model as rm
+    from robotoc_amd.grid import ANYMAL_Q_STANDING, ContactSequence, Event, contact_masks
+    from robotoc_amd.types import GRID_IMPACT
+    m = rm.load_named("anymal")
+    nv, nq, nu, nc = m.nv, m.nq, 12, 4
+    grids = discretize(8, 0.16, 0.0, ContactSequence([6, 12], [Event("impact", 0.07, impact_dimf=6)]))
+    n = len(grids)
+    masks = contact_masks(grids, [0b1001, 0b1111], [0b0110])
+    i_imp = [i for i, g in enumerate(grids) if g.type == GRID_IMPACT][0]
+    rng = np.random.default_rng(4321)
+    qs = np.array(ANYMAL_Q_STANDING, dtype=float)
+    feet = np.array([orc.rbd_contact_position(m, qs, c) for c in range(nc)]) + 0.005 * rng.uniform(-1, 1, (nc, 3))
+    q = np.zeros((n, nq))
+    for i in range(n):
+        q[i] = qs
+        q[i, :7] = orc.se3_integrate(qs[:7], 0.05 * rng.uniform(-1, 1, 6))
+        q[i, 7:] += 0.1 * rng.uniform(-1, 1, 12)
+    v, a, u = 0.5 * rng.uniform(-1, 1, (n, nv)), rng.uniform(-1, 1, (n, nv)), 10.0 * rng.uniform(-1, 1, (n, nu))
+    f = 10.0 * rng.uniform(-1, 1, (n, nc, 3))
+    f[:, :, 2] = rng.uniform(40, 90, (n, nc))
+    lmd, gmm, beta = (0.5 * rng.uniform(-1, 1, (n, nv)) for _ in range(3))
+    mus = 0.5 * rng.uniform(-1, 1, (n, nc, 3))
+    mu = np.array([0.7, 0.6, 0.8, 0.5])
+    q_ref = qs.copy()
+    q_ref[:7] = orc.se3_integrate(qs[:7], np.array([0.03, 0.0, -0.02, 0.0, 0.05, 0.0]))
+    M = nv + 1
+    cost = np.zeros((12, M))
+    wq = np.concatenate([np.full(6, 10.0), np.full(12, 1.0)])
+    for k, val in ((0, q_ref), (3, wq), (4, np.full(nv, 1.0)), (5, np.full(nv, 1e-3)), (6, np.full(nu, 1e-3)), (7, 10.0 * wq), (8, np.full(nv, 2.0)),
+                   (9, 3.0 * wq), (10, np.full(nv, 0.5)), (11, np.full(nv, 0.05))):
+        cost[k, :len(val)] = val
+    limits = np.stack([np.full(nu, -1.6), np.full(nu, 1.6), np.full(nu, 3.0), np.full(nu, 40.0)])
+    barrier, tau = 1.0e-3, 0.995
+    L = ref.lib()
+    dp = C.POINTER(C.c_double)
+    ptr = lambda x: np.ascontiguousarray(x, dtype=np.float64).ctypes.data_as(dp)
+    L.ref_contact_stage_eval_kkt2.argtypes = [C.c_int, C.c_uint, C.c_uint, dp, dp, dp, dp, C.c_double, C.c_double, dp, dp, dp, dp]
+    plus = lambda qq, e: orc.rbd_integrate(m, qq, e)
+
+    def sub(qf, q0):
+        return np.concatenate([orc.se3_difference(q0[:7], qf[:7]), qf[7:] - q0[7:]])
+
+    def inject(key, arr):
+        keep = np.asfortranarray(np.asarray(arr, dtype=np.float64).reshape(len(arr), -1))
+        assert L.ref_stage_inject(key.encode(), keep.ctypes.data_as(dp), keep.shape[0], keep.shape[1]) == 0
+    nx = 2 * nv
+    # ---- the impact grid ----
+    L.ref_stage_begin(nv, nu, nc)
+    qi, qn, qp = q[i_imp], q[i_imp + 1], q[i_imp - 1]
+    inject("subtractConfiguration", sub(qi, q_ref))
+    inject("dSubtractConfiguration_dqf", _richardson(lambda e: sub(plus(qi, e), q_ref), nv))
+    inject("subtractConfiguration", sub(qi, qn))
+    inject("dSubtractConfiguration_dqf", _richardson(lambda e: sub(plus(qi, e), qn), nv))
+    inject("dSubtractConfiguration_dq0", _richardson(lambda e: sub(qp, plus(qi, e)), nv))
+    inject("dSubtractConfiguration_dq0", _richardson(lambda e: sub(qi, plus(qn, e)), nv))
+    imp_mask = int(masks[i_imp])
+    imp = [c for c in range(nc) if (imp_mask >> c) & 1]
+    fstack = np.concatenate([f[i_imp, c] for c in imp])
+    val = orc.rbd_eval(m, 1, qi, v[i_imp], a[i_imp], fstack, np.zeros(nu), imp_mask, feet.reshape(-1))
+    h = 2.0e-3
+    J1 = orc.rbd_linearize_fd(m, 1, qi, v[i_imp], a[i_imp], fstack, np.zeros(nu), imp_mask, feet.reshape(-1), eps=h)
+    J2 = orc.rbd_linearize_fd(m, 1, qi, v[i_imp], a[i_imp], fstack, np.zeros(nu), imp_mask, feet.reshape(-1), eps=h / 2)
+    Jr = [(4.0 * np.asarray(J2[k]) - np.asarray(J1[k])) / 3.0 for k in range(3)]
+    cm = lambda X: np.asfortranarray(X).T.copy()
+    assert L.ref_stage_inverse_dynamics(ptr(val[:nv]), ptr(cm(Jr[0][:nv])), ptr(cm(Jr[1][:nv])), ptr(cm(Jr[2][:nv]))) == 0
+    inject("impactVelocityResidual", val[nv:])
+    inject("impactVelocity_dq", Jr[0][nv:])
+    inject("impactVelocity_dv", Jr[2][nv:])      # the rows see v + dv: d/dv = d/d(dv)
+    fi = np.zeros((nc, 3))
+    mi = np.zeros((nc, 3))
+    for c in imp:
+        fi[c], mi[c] = f[i_imp, c], mus[i_imp, c]
+    sol = np.concatenate([qi, v[i_imp], a[i_imp], fi.reshape(-1), lmd[i_imp], gmm[i_imp], beta[i_imp], mi.reshape(-1)])
+    sol_next = np.concatenate([qn, v[i_imp + 1], lmd[i_imp + 1], gmm[i_imp + 1]])
+    out_imp = np.zeros(2 * nx * nx + 2 * nx)
+    rc = L.ref_contact_stage_eval_kkt2(1, 0b1001, imp_mask, ptr(feet), ptr(mu), ptr(cost), ptr(limits), barrier, tau, ptr(qp), ptr(sol), ptr(sol_next),
+                                       out_imp.ctypes.data_as(dp))
+    assert rc == 0, rc
+    # ---- the terminal grid ----
+    L.ref_stage_begin(nv, nu, nc)
+    qt, qpt = q[n - 1], q[n - 2]
+    inject("subtractConfiguration", sub(qt, q_ref))
+    inject("dSubtractConfiguration_dqf", _richardson(lambda e: sub(plus(qt, e), q_ref), nv))
+    inject("dSubtractConfiguration_dq0", _richardson(lambda e: sub(qpt, plus(qt, e)), nv))
+    sol_t = np.concatenate([qt, v[n - 1], lmd[n - 1], gmm[n - 1]])
+    out_term = np.zeros(nx * nx + nx)
+    rc = L.ref_contact_stage_eval_kkt2(2, 0b1001, imp_mask, ptr(feet), ptr(mu), ptr(cost), ptr(limits), barrier, tau, ptr(qpt), ptr(sol_t), ptr(sol_t),
+                                       out_term.ctypes.data_as(dp))
+    assert rc == 0, rc
+    # ---- the grid point two ahead of the touch-down: switching constraint (no inequality rows) ----
+    L.ref_stage_begin(nv, nu, nc)
+    L.ref_contact_stage_eval_kkt3.argtypes = [C.c_uint, C.c_uint, dp, dp, C.c_double, C.c_double, C.c_int, C.c_int, dp, dp, dp, dp, dp]
+    i_sw = i_imp - 2
+    assert grids[i_sw].switching_constraint and grids[i_sw].dims == 6
+    qi, qn, qp = q[i_sw], q[i_sw + 1], q[i_sw - 1]
+    dt1, dt2 = grids[i_sw].dt, grids[i_sw + 1].dt
+    act_mask = int(masks[i_sw])
+    act = [c for c in range(nc) if (act_mask >> c) & 1]
+    xi = 0.5 * rng.uniform(-1, 1, 6)
+    inject("subtractConfiguration", sub(qi, q_ref))
+    inject("dSubtractConfiguration_dqf", _richardson(lambda e: sub(plus(qi, e), q_ref), nv))
+    inject("subtractConfiguration", sub(qi, qn))
+    inject("dSubtractConfiguration_dqf", _richardson(lambda e: sub(plus(qi, e), qn), nv))
+    inject("dSubtractConfiguration_dq0", _richardson(lambda e: sub(qp, plus(qi, e)), nv))
+    inject("dSubtractConfiguration_dq0", _richardson(lambda e: sub(qi, plus(qn, e)), nv))
+    fstack = np.concatenate([f[i_sw, c] for c in act])
+    val = orc.rbd_eval(m, 0, qi, v[i_sw], a[i_sw], fstack, np.zeros(nu), act_mask, feet.reshape(-1))
+    J1 = orc.rbd_linearize_fd(m, 0, qi, v[i_sw], a[i_sw], fstack, np.zeros(nu), act_mask, feet.reshape(-1), eps=h)
+    J2 = orc.rbd_linearize_fd(m, 0, qi, v[i_sw], a[i_sw], fstack, np.zeros(nu), act_mask, feet.reshape(-1), eps=h / 2)
+    Jr = [(4.0 * np.asarray(J2[k]) - np.asarray(J1[k])) / 3.0 for k in range(3)]
+    assert L.ref_stage_inverse_dynamics(ptr(val[:nv]), ptr(cm(Jr[0][:nv])), ptr(cm(Jr[1][:nv])), ptr(cm(Jr[2][:nv]))) == 0
+    inject("baumgarteResidual", val[nv:])
+    for k, key in enumerate(("baumgarte_dq", "baumgarte_dv", "baumgarte_da")):
+        inject(key, Jr[k][nv:])
+    dq_sw = (dt1 + dt2) * v[i_sw] + dt1 * dt2 * a[i_sw]
+    q_plus = plus(qi, dq_sw)
+    P_at = lambda qq: np.concatenate([orc.rbd_contact_position(m, qq, c) - feet[c] for c in imp])
+    inject("integrateConfiguration", q_plus)
+    inject("contactPositionResidual", P_at(q_plus))
+    inject("contactPositionDerivative", _richardson(lambda e: P_at(plus(q_plus, e)), nv))
+    inject("dIntegrate_dq", _richardson(lambda e: sub(plus(plus(qi, e), dq_sw), q_plus), nv))
+    inject("dIntegrate_dv", _richardson(lambda e: sub(plus(qi, dq_sw + e), q_plus), nv))
+    fs = np.zeros((nc, 3))
+    ms = np.zeros((nc, 3))
+    for c in act:
+        fs[c], ms[c] = f[i_sw, c], mus[i_sw, c]
+    nup = 0.5 * rng.uniform(-1, 1, 6)
+    sol = np.concatenate([qi, v[i_sw], a[i_sw], u[i_sw], fs.reshape(-1), lmd[i_sw], gmm[i_sw], beta[i_sw], ms.reshape(-1), nup, xi])
+    sol_next = np.concatenate([qn, v[i_sw + 1], lmd[i_sw + 1], gmm[i_sw + 1]])
+    ns = 6
+    out_sw = np.zeros(nx * nx + nx * nu + nu * nu + nx * nx + nv * nu + nx + nu + nx + ns * nx + ns * nu + ns + ns + nx + nu + 2)
+    rc = L.ref_contact_stage_eval_kkt3(act_mask, imp_mask, ptr(feet), ptr(mu), dt1, dt2, grids[i_sw].time_stage, grids[i_sw].num_grids_in_phase,
+                                       ptr(cost), ptr(qp), ptr(sol), ptr(sol_next), out_sw.ctypes.data_as(dp))
+    assert rc == 0, rc
+    np.savez_compressed(os.path.join(HERE, name), q=q, v=v, a=a, u=u, f=f, lmd=lmd, gmm=gmm, beta=beta, mu_stack=mus, feet=feet, mu=mu, cost=cost,
+                        limits=limits, out_impact=out_imp, out_terminal=out_term, out_switching=out_sw, xi=xi, nu_passive=nup,
+                        scalars=np.array([barrier, tau, i_imp]), **grid_table(grids))
+    print(name, "impact grid", i_imp, "of", n)
