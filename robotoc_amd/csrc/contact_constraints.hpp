@@ -131,7 +131,10 @@ static __global__ __launch_bounds__(64) void contact_cone_kernel(CcArgs a) {
         row[4] = rbd::mul(Rs, rbd::mk(0, -1, -m));
         const int r0 = a.row0 + 5 * k;
         if (lane < 5) {
-          const double gval = rbd::dot(row[lane], fW);
+          double gval = 0.0;   // row `lane` by selection (no run-time index into row[])
+#pragma unroll
+          for (int r = 0; r < 5; ++r)
+            if (lane == r) gval = rbd::dot(row[r], fW);
           if (!lin) {
             double slack = -gval;
             const double sb = sqrt(a.barrier);
@@ -242,9 +245,13 @@ static __global__ __launch_bounds__(64) void contact_cone_vals_kernel(CvArgs v) 
 #pragma unroll
     for (int r = 0; r < 5; ++r) dual[r] = nr[no[RTOC_CON_DUAL] + r0 + r];
     if (lane < 5) {
+      double gval = 0.0, dl = 0.0;   // row `lane` by selection: a run-time index would put row[] and dual[] into scratch
+#pragma unroll
+      for (int r = 0; r < 5; ++r)
+        if (lane == r) gval = rbd::dot(row[r], fW), dl = dual[r];
       const double slack = nr[no[RTOC_CON_SLACK] + r0 + lane];
-      nr[no[RTOC_CON_RESIDUAL] + r0 + lane] = rbd::dot(row[lane], fW) + slack;
-      nr[no[RTOC_CON_CMPL] + r0 + lane] = slack * dual[lane] - a.barrier;
+      nr[no[RTOC_CON_RESIDUAL] + r0 + lane] = gval + slack;
+      nr[no[RTOC_CON_CMPL] + r0 + lane] = slack * dl - a.barrier;
     }
     if (lane < 3) {
       const V3 col = rbd::mk(Rwf.m[lane], Rwf.m[3 + lane], Rwf.m[6 + lane]);
