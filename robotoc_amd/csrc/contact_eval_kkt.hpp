@@ -45,8 +45,13 @@ static __global__ __launch_bounds__(64) void contact_cost_kernel(CostArgs a) {
   const double* const Wq = terminal ? wqT : impact ? wqI : wq;
   const double* const Wv = terminal ? wvT : impact ? wvI : wv;
   // ---- setZero of everything the stages below accumulate into ----
+  // 16-byte stores (the fields start on 64-byte boundaries: rtoc_record_finish pads every field to 8 doubles): this kernel is
+  // the memory-bound one of evalKKT, 28 KB of zeros per grid point
   auto zero = [&](double* p, int n) {
-    for (int e = lane; e < n; e += 64) p[e] = 0.0;
+    double2* const p2 = reinterpret_cast<double2*>(p);
+    const int n2 = n >> 1;
+    for (int e = lane; e < n2; e += 64) p2[e] = make_double2(0.0, 0.0);
+    if ((n & 1) && lane == 0) p[n - 1] = 0.0;
   };
   zero(kr + a.kl.off[RTOC_KKT_FXX], nx * nx);
   zero(kr + a.kl.off[RTOC_KKT_QXX], nx * nx);
