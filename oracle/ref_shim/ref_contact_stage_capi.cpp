@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "robotoc/constraints/constraints.hpp"
+#include "robotoc/constraints/contact_wrench_cone.hpp"
 #include "robotoc/constraints/friction_cone.hpp"
 #include "robotoc/constraints/joint_position_lower_limit.hpp"
 #include "robotoc/constraints/joint_position_upper_limit.hpp"
@@ -46,6 +47,10 @@ extern "C" {
 
 int ref_stage_begin(int nv, int nu, int ncontacts) {
   g_robot.reset(new Robot(nv, nu, std::vector<ContactType>(ncontacts, ContactType::PointContact)));
+  return 0;
+}
+int ref_stage_begin_surface(int nv, int nu, int ncontacts) {
+  g_robot.reset(new Robot(nv, nu, std::vector<ContactType>(ncontacts, ContactType::SurfaceContact)));
   return 0;
 }
 int ref_stage_inject(const char* key, const double* data, int rows, int cols) {
@@ -142,6 +147,109 @@ int ref_contact_stage_eval_kkt(unsigned active, const double* contact_pos, const
     int o = 0;
     for (size_t k = 0; k < comp.size(); ++k) {
       const int n = k < 6 ? nu : 5 * nc;
+      for (int r = 0; r < n; ++r) comp[k]->slack(r) = slack[o + r], comp[k]->dual(r) = dual[o + r];
+      o += n;
+    }
+  }
+  SplitKKTMatrix km(robot);
+  SplitKKTResidual kr(robot);
+  st.evalKKT(robot, gi, vec(q_prev, nq), s, sn, data, km, kr);
+  if (robot.pending() != 0) return 2;   // injected more than the stage asked for: the call order assumed by the test is off
+  double* o = out;
+  auto putm = [&](const Eigen::MatrixXd& m) {
+    for (int j = 0; j < m.cols(); ++j)
+      for (int i = 0; i < m.rows(); ++i) *o++ = m(i, j);
+  };
+  putm(km.Qxx), putm(km.Qxu), putm(km.Quu), putm(km.Fxx), putm(km.Fvu);
+  putm(kr.lx), putm(kr.lu), putm(kr.Fx), putm(km.hx), putm(km.hu), putm(km.fx);
+  *o++ = km.Qtt, *o++ = km.Qtt_prev, *o++ = kr.h, *o++ = data.performance_index.kkt_error;
+  (void)nx;
+  return 0;
+}
+
+// The same for SURFACE contacts (six rows each: wrench f, multipliers mu; desired placement = position + rotation) with the
+// ContactWrenchCone of a 2X x 2Y sole instead of the friction cone (cone_kind 2) or the FrictionCone on the first three
+// wrench components (cone_kind 1); slack / dual: joint-limit rows, then 17 (5) rows per contact by contact index.
+// cost: [12][nv + 1] = q_ref (nq), v_ref, u_ref, q / v / a / u weights, terminal q / v weights, impact q / v / dv weights
+// sol / sol_next: q (nq), v, a, u (nu), f ([ncontacts][3] by contact index), lmd, gmm, beta, mu ([ncontacts][3]), nu_passive (6)
+// slack / dual: rows of the six joint-limit components (nu each), then 5 per contact by contact index
+// out: Qxx (nx^2), Qxu (nx nu), Quu (nu^2), Fxx (nx^2), Fvu (nv nu), lx (nx), lu (nu), Fx (nx), hx (nx), hu (nu), fx (nx),
+//      [Qtt, Qtt_prev, h, kkt_error] -- all column-major, after IntermediateStage::evalKKT
+int ref_contact_stage_eval_kkt_surface(int cone_kind, double X, double Y, const double* contact_rot, unsigned active, const double* contact_pos, const double* mu, double dt, int stage, int num_grids_in_phase,
+                               const double* cost, const double* limits, double barrier, double tau, const double* q_prev,
+                               const double* sol, const double* sol_next, const double* slack, const double* dual, double* out) {
+  if (!g_robot) return 1;
+  Robot& robot = *g_robot;
+  const int nv = robot.dimv(), nu = robot.dimu(), nq = nv + 1, nc = robot.maxNumContacts(), nx = 2 * nv;
+  const int M = nv + 1;
+  auto config = std::make_shared<ConfigurationSpaceCost>(robot);
+  config->set_q_ref(vec(cost, nq)), config->set_v_ref(vec(cost + M, nv)), config->set_u_ref(vec(cost + 2 * M, nu));
+  config->set_q_weight(vec(cost + 3 * M, nv)), config->set_v_weight(vec(cost + 4 * M, nv)), config->set_a_weight(vec(cost + 5 * M, nv));
+  config->set_u_weight(vec(cost + 6 * M, nu)), config->set_q_weight_terminal(vec(cost + 7 * M, nv)), config->set_v_weight_terminal(vec(cost + 8 * M, nv));
+  config->set_q_weight_impact(vec(cost + 9 * M, nv)), config->set_v_weight_impact(vec(cost + 10 * M, nv)), config->set_dv_weight_impact(vec(cost + 11 * M, nv));
+  auto cf = std::make_shared<CostFunction>();
+  cf->add("config_cost", config);
+  auto constraints = std::make_shared<Constraints>(barrier, tau);
+  robot.setJointLimits(vec(limits, nu), vec(limits + nu, nu), vec(limits + 2 * nu, nu), vec(limits + 3 * nu, nu));
+  constraints->add("joint_position_lower", std::make_shared<JointPositionLowerLimit>(robot));
+  constraints->add("joint_position_upper", std::make_shared<JointPositionUpperLimit>(robot));
+  constraints->add("joint_velocity_lower", std::make_shared<JointVelocityLowerLimit>(robot));
+  constraints->add("joint_velocity_upper", std::make_shared<JointVelocityUpperLimit>(robot));
+  constraints->add("joint_torques_lower", std::make_shared<JointTorquesLowerLimit>(robot));
+  constraints->add("joint_torques_upper", std::make_shared<JointTorquesUpperLimit>(robot));
+  if (cone_kind == 2) constraints->add("contact_wrench_cone", std::make_shared<ContactWrenchCone>(robot, X, Y));
+  else constraints->add("friction_cone", std::make_shared<FrictionCone>(robot));
+  ContactStatus cs = robot.createContactStatus();
+  for (int c = 0; c < nc; ++c) {
+    if ((active >> c) & 1u) cs.activateContact(c);
+    cs.setFrictionCoefficient(c, mu[c]);
+    {
+      Eigen::Matrix3d Rc;
+      for (int r = 0; r < 3; ++r)
+        for (int k = 0; k < 3; ++k) Rc(r, k) = contact_rot[9 * c + 3 * r + k];
+      cs.setContactPlacement(c, Eigen::Vector3d(vec(contact_pos + 3 * c, 3)), Rc);
+    }
+  }
+  auto seq = std::make_shared<ContactSequence>(robot);
+  seq->init(cs);
+  IntermediateStage st(cf, constraints, seq);
+  GridInfo gi;
+  gi.type = GridType::Intermediate;
+  gi.dt = dt, gi.stage = stage, gi.phase = 0, gi.num_grids_in_phase = num_grids_in_phase, gi.t = dt * stage;
+  auto load = [&](const double* p, SplitSolution& s, bool full) {
+    s.setContactStatus(cs);
+    s.q = vec(p, nq), p += nq;
+    s.v = vec(p, nv), p += nv;
+    if (!full) {
+      s.lmd = vec(p, nv), s.gmm = vec(p + nv, nv);
+      return;
+    }
+    s.a = vec(p, nv), p += nv;
+    s.u = vec(p, nu), p += nu;
+    for (int c = 0; c < nc; ++c)
+      for (int k = 0; k < 6; ++k) s.f[c](k) = p[6 * c + k];
+    p += 6 * nc;
+    s.lmd = vec(p, nv), p += nv;
+    s.gmm = vec(p, nv), p += nv;
+    s.beta = vec(p, nv), p += nv;
+    for (int c = 0; c < nc; ++c)
+      for (int k = 0; k < 6; ++k) s.mu[c](k) = p[6 * c + k];
+    p += 6 * nc;
+    s.nu_passive = vec(p, 6);
+    s.set_f_stack(), s.set_mu_stack();
+  };
+  SplitSolution s(robot), sn(robot);
+  load(sol, s, true), load(sol_next, sn, false);
+  OCPData data = st.createData(robot);
+  st.initConstraints(robot, gi, s, data);   // sets the stage mask; then the caller's slack / dual
+  {
+    std::vector<ConstraintComponentData*> comp;
+    for (auto& c : data.constraints_data.position_level_data) comp.push_back(&c);
+    for (auto& c : data.constraints_data.velocity_level_data) comp.push_back(&c);
+    for (auto& c : data.constraints_data.acceleration_level_data) comp.push_back(&c);
+    int o = 0;
+    for (size_t k = 0; k < comp.size(); ++k) {
+      const int n = k < 6 ? nu : (cone_kind == 2 ? 17 : 5) * nc;
       for (int r = 0; r < n; ++r) comp[k]->slack(r) = slack[o + r], comp[k]->dual(r) = dual[o + r];
       o += n;
     }

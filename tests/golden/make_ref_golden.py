@@ -143,6 +143,7 @@ if __name__ == "__main__":
     unconstr_solver_fixture("ref_iiwa14_unconstr_solver_limits.npz", True)
     contact_stage_fixture()
     impact_and_terminal_stage_fixture()
+    icub_surface_stage_fixture()
 
 
 def _richardson(fun, n, h=2.0e-3):
@@ -396,3 +397,87 @@ def impact_and_terminal_stage_fixture(name="ref_anymal_impact_terminal_stage.npz
                         limits=limits, out_impact=out_imp, out_terminal=out_term, out_switching=out_sw, xi=xi, nu_passive=nup,
                         scalars=np.array([barrier, tau, i_imp]), **grid_table(grids))
     print(name, "impact grid", i_imp, "of", n)
+
+
+def icub_surface_stage_fixture(name="ref_icub_surface_stage.npz"):
+    """IntermediateStage::evalKKT of iCub (nv = 35) on its two soles -- SURFACE contacts: six contact rows each with the Log6
+    placement error, ContactWrenchCone (17 rows per sole), six joint-limit components, ConfigurationSpaceCost -- by the REFERENCE'S
+    OWN sources with injected rigid-body quantities (ref_contact_stage_eval_kkt_surface).  Grid point 2 of a five-point horizon."""
+    import ctypes as C
+    from robotoc_amd import robot_model as rm
+    m = rm.load_named("icub")
+    nv, nq, nu, nc, n, i0, dt = m.nv, m.nq, m.nv - 6, 2, 5, 2, 0.02
+    rng = np.random.default_rng(99)
+    qs = np.array([0, 0, 0.592, 0, 0, 1, 0, 0.20944, 0.08727, 0, -0.1745, -0.0279, -0.08726, 0.20944, 0.08727, 0, -0.1745, -0.0279, -0.08726,
+                   0, 0, 0, 0, 0.35, 0.5, 0.5, 0, 0, 0, 0, 0.35, 0.5, 0.5, 0, 0, 0])
+    place = [orc.rbd_contact_placement(m, qs, c) for c in range(nc)]
+    pos = np.array([p for _, p in place]) + 0.003 * rng.uniform(-1, 1, (nc, 3))
+    rot = np.array([R @ orc.rbd_exp6(np.concatenate([np.zeros(3), 0.02 * rng.uniform(-1, 1, 3)]))[0] for R, _ in place])
+    q = np.zeros((n, nq))
+    for i in range(n):
+        q[i] = qs
+        q[i, :7] = orc.se3_integrate(qs[:7], 0.03 * rng.uniform(-1, 1, 6))
+        q[i, 7:] += 0.05 * rng.uniform(-1, 1, nu)
+    v, a, u = 0.3 * rng.uniform(-1, 1, (n, nv)), rng.uniform(-1, 1, (n, nv)), 10.0 * rng.uniform(-1, 1, (n, nu))
+    f = 5.0 * rng.uniform(-1, 1, (n, nc, 6))
+    f[:, :, 2] = rng.uniform(100, 200, (n, nc))
+    lmd, gmm, beta = (0.5 * rng.uniform(-1, 1, (n, nv)) for _ in range(3))
+    mus, nup = 0.5 * rng.uniform(-1, 1, (n, nc, 6)), 0.5 * rng.uniform(-1, 1, (n, 6))
+    mu = np.array([0.6, 0.8])
+    X, Y = 0.1, 0.05
+    q_ref = qs.copy()
+    q_ref[2] -= 0.03
+    M = nv + 1
+    cost = np.zeros((12, M))
+    for k, val in ((0, q_ref), (3, np.concatenate([np.full(6, 10.0), np.full(nu, 0.1)])), (4, np.full(nv, 0.1)), (5, np.full(nv, 1e-3)),
+                   (6, np.full(nu, 1e-4)), (7, np.full(nv, 10.0)), (8, np.full(nv, 0.1))):
+        cost[k, :len(val)] = val
+    limits = np.stack([np.full(nu, -2.5), np.full(nu, 2.5), np.full(nu, 5.0), np.full(nu, 60.0)])
+    nrow = 6 * nu + 17 * nc
+    slack, dual = rng.uniform(0.1, 2.0, nrow), rng.uniform(0.01, 0.5, nrow)
+    barrier, tau, active = 1.0e-3, 0.995, 0b11
+    qi, qn, qp = q[i0], q[i0 + 1], q[i0 - 1]
+    plus = lambda qq, e: orc.rbd_integrate(m, qq, e)
+
+    def sub(qf, q0):
+        return np.concatenate([orc.se3_difference(q0[:7], qf[:7]), qf[7:] - q0[7:]])
+    L = ref.lib()
+    dp = C.POINTER(C.c_double)
+    ptr = lambda x: np.ascontiguousarray(x, dtype=np.float64).ctypes.data_as(dp)
+    L.ref_stage_begin_surface(nv, nu, nc)
+
+    def inject(key, arr):
+        keep = np.asfortranarray(np.asarray(arr, dtype=np.float64).reshape(len(arr), -1))
+        assert L.ref_stage_inject(key.encode(), keep.ctypes.data_as(dp), keep.shape[0], keep.shape[1]) == 0
+    inject("subtractConfiguration", sub(qi, q_ref))
+    inject("dSubtractConfiguration_dqf", _richardson(lambda e: sub(plus(qi, e), q_ref), nv))
+    inject("subtractConfiguration", sub(qi, qn))
+    inject("dSubtractConfiguration_dqf", _richardson(lambda e: sub(plus(qi, e), qn), nv))
+    inject("dSubtractConfiguration_dq0", _richardson(lambda e: sub(qp, plus(qi, e)), nv))
+    inject("dSubtractConfiguration_dq0", _richardson(lambda e: sub(qi, plus(qn, e)), nv))
+    fstack = f[i0].reshape(-1)
+    val = orc.rbd_eval(m, 0, qi, v[i0], a[i0], fstack, np.zeros(nu), active, pos.reshape(-1), rot.reshape(nc, 9))
+    h = 2.0e-3
+    J1 = orc.rbd_linearize_fd(m, 0, qi, v[i0], a[i0], fstack, np.zeros(nu), active, pos.reshape(-1), eps=h, rref=rot.reshape(nc, 9))
+    J2 = orc.rbd_linearize_fd(m, 0, qi, v[i0], a[i0], fstack, np.zeros(nu), active, pos.reshape(-1), eps=h / 2, rref=rot.reshape(nc, 9))
+    Jr = [(4.0 * np.asarray(J2[k]) - np.asarray(J1[k])) / 3.0 for k in range(3)]
+    cm = lambda Xm: np.asfortranarray(Xm).T.copy()
+    assert L.ref_stage_inverse_dynamics(ptr(val[:nv]), ptr(cm(Jr[0][:nv])), ptr(cm(Jr[1][:nv])), ptr(cm(Jr[2][:nv]))) == 0
+    inject("baumgarteResidual", val[nv:])
+    for k, key in enumerate(("baumgarte_dq", "baumgarte_dv", "baumgarte_da")):
+        inject(key, Jr[k][nv:])
+    # the wrench cone reads no kinematics; frames only for completeness
+    for c in range(nc):
+        assert L.ref_stage_frame(c, ptr(orc.rbd_contact_placement(m, qi, c)[0]), ptr(np.zeros((nv, 6)))) == 0
+    sol = np.concatenate([qi, v[i0], a[i0], u[i0], f[i0].reshape(-1), lmd[i0], gmm[i0], beta[i0], mus[i0].reshape(-1), nup[i0]])
+    sol_next = np.concatenate([qn, v[i0 + 1], lmd[i0 + 1], gmm[i0 + 1]])
+    nx = 2 * nv
+    out = np.zeros(nx * nx + nx * nu + nu * nu + nx * nx + nv * nu + nx + nu + nx + nx + nu + nx + 4)
+    L.ref_contact_stage_eval_kkt_surface.argtypes = [C.c_int, C.c_double, C.c_double, dp, C.c_uint, dp, dp, C.c_double, C.c_int, C.c_int, dp, dp,
+                                                     C.c_double, C.c_double, dp, dp, dp, dp, dp, dp]
+    rc = L.ref_contact_stage_eval_kkt_surface(2, X, Y, ptr(rot.reshape(-1)), active, ptr(pos), ptr(mu), dt, i0, n - 1, ptr(cost), ptr(limits), barrier,
+                                              tau, ptr(qp), ptr(sol), ptr(sol_next), ptr(slack), ptr(dual), out.ctypes.data_as(dp))
+    assert rc == 0, rc
+    np.savez_compressed(os.path.join(HERE, name), q=q, v=v, a=a, u=u, f=f, lmd=lmd, gmm=gmm, beta=beta, mu_stack=mus, nu_passive=nup, pos=pos, rot=rot,
+                        mu=mu, cost=cost, limits=limits, slack=slack, dual=dual, out=out, scalars=np.array([dt, barrier, tau, i0, active, X, Y]))
+    print(name, "stage KKT error %.6e" % out[-1])
