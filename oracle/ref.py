@@ -91,6 +91,14 @@ def expand_stage(L, g, cdd_rec, dir_rec, dir_next_rec, contact_dim=3):
     lib().ref_expand_stage(C.byref(L), C.byref(g), _p(cdd_rec), _p(dir_rec), _p(dir_next_rec), contact_dim)
 
 
+def split_solution_integrate(L, g, step, dir_rec, sol_rec, q_integrated=None, contact_dim=3):
+    """SplitSolution::integrate (src/core/split_solution.cpp:58-90) by the reference's own source on one record pair; sol_rec is
+    updated in place.  q_integrated: robot.integrateConfiguration's result for a floating base (injected)."""
+    fn = lib().ref_split_solution_integrate
+    fn.argtypes = [C.POINTER(Layout), C.POINTER(Grid), C.c_int, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    assert fn(C.byref(L), C.byref(g), contact_dim, step, _p(dir_rec), _p(sol_rec), _p(q_integrated) if q_integrated is not None else None) == 0
+
+
 def correct_costate(L, se3_rec, dir_rec):
     lib().ref_correct_costate(C.byref(L), _p(se3_rec), _p(dir_rec))
 

@@ -437,6 +437,68 @@ int ref_correct_costate(const rtoc_layout* L, const double* se3_rec, double* dir
   return 0;
 }
 
+// SplitSolution::integrate (src/core/split_solution.cpp:58-90) on one packed record pair.  q_integrated: the result of
+// robot.integrateConfiguration for a floating base (injected; NULL for a fixed base, where it is q + step dq).
+int ref_split_solution_integrate(const rtoc_layout* L, const rtoc_grid* g, int contact_dim, double step, const double* dir_rec,
+                                 double* sol_rec, const double* q_integrated) {
+  Robot robot = make_robot(L, contact_dim);
+  const int nv = L->dims.nv, nu = L->dims.nu, np = L->dims.np, nq = nv + (np == 6 ? 1 : 0);
+  const bool impact = g->type == RTOC_GRID_IMPACT;
+  const int ns = impact ? 0 : g->dims;
+  SplitSolution s(robot);
+  SplitDirection d(robot);
+  {
+    const int nact = contact_dim > 0 ? g->dimf / contact_dim : 0;
+    if (impact) {
+      ImpactStatus is = robot.createImpactStatus();
+      for (int c = 0; c < nact; ++c) is.activateImpact(c);
+      s.setContactStatus(is);
+    } else {
+      ContactStatus cs = robot.createContactStatus();
+      for (int c = 0; c < nact; ++c) cs.activateContact(c);
+      s.setContactStatus(cs);
+    }
+  }
+  d.setContactDimension(g->dimf);
+  s.setSwitchingConstraintDimension(ns), d.setSwitchingConstraintDimension(ns);
+  const int* so = L->sol.off;
+  const int* dof = L->dir.off;
+  for (int i = 0; i < nq; ++i) s.q(i) = sol_rec[so[RTOC_SOL_Q] + i];
+  for (int i = 0; i < nv; ++i) {
+    s.v(i) = sol_rec[so[RTOC_SOL_V] + i];
+    (impact ? s.dv(i) : s.a(i)) = sol_rec[so[RTOC_SOL_A] + i];
+    s.lmd(i) = sol_rec[so[RTOC_SOL_LMD] + i], s.gmm(i) = sol_rec[so[RTOC_SOL_GMM] + i], s.beta(i) = sol_rec[so[RTOC_SOL_BETA] + i];
+    d.dq()(i) = dir_rec[dof[RTOC_DIR_DX] + i], d.dv()(i) = dir_rec[dof[RTOC_DIR_DX] + nv + i];
+    d.daf()(i) = dir_rec[dof[RTOC_DIR_DAF] + i];
+    d.dlmd()(i) = dir_rec[dof[RTOC_DIR_DLMDGMM] + i], d.dgmm()(i) = dir_rec[dof[RTOC_DIR_DLMDGMM] + nv + i];
+    d.dbetamu()(i) = dir_rec[dof[RTOC_DIR_DBETAMU] + i];
+  }
+  for (int i = 0; i < nu; ++i) s.u(i) = sol_rec[so[RTOC_SOL_U] + i], d.du(i) = dir_rec[dof[RTOC_DIR_DU] + i];
+  for (int i = 0; i < g->dimf; ++i) {
+    s.f_stack()(i) = sol_rec[so[RTOC_SOL_F] + i], s.mu_stack()(i) = sol_rec[so[RTOC_SOL_MU] + i];
+    d.daf()(nv + i) = dir_rec[dof[RTOC_DIR_DAF] + nv + i], d.dbetamu()(nv + i) = dir_rec[dof[RTOC_DIR_DBETAMU] + nv + i];
+  }
+  for (int i = 0; i < np; ++i) s.nu_passive(i) = sol_rec[so[RTOC_SOL_NUP] + i], d.dnu_passive(i) = dir_rec[dof[RTOC_DIR_DNUP] + i];
+  for (int i = 0; i < ns; ++i) s.xi_stack()(i) = sol_rec[so[RTOC_SOL_XI] + i], d.dxi()(i) = dir_rec[dof[RTOC_DIR_DXI] + i];
+  if (np == 6) {
+    Eigen::VectorXd qi(nq);
+    for (int i = 0; i < nq; ++i) qi(i) = q_integrated[i];
+    robot.inject("integrateConfiguration", qi);
+  }
+  s.integrate(robot, step, d, impact);
+  for (int i = 0; i < nq; ++i) sol_rec[so[RTOC_SOL_Q] + i] = s.q(i);
+  for (int i = 0; i < nv; ++i) {
+    sol_rec[so[RTOC_SOL_V] + i] = s.v(i);
+    sol_rec[so[RTOC_SOL_A] + i] = impact ? s.dv(i) : s.a(i);
+    sol_rec[so[RTOC_SOL_LMD] + i] = s.lmd(i), sol_rec[so[RTOC_SOL_GMM] + i] = s.gmm(i), sol_rec[so[RTOC_SOL_BETA] + i] = s.beta(i);
+  }
+  for (int i = 0; i < nu; ++i) sol_rec[so[RTOC_SOL_U] + i] = s.u(i);
+  for (int i = 0; i < g->dimf; ++i) sol_rec[so[RTOC_SOL_F] + i] = s.f_stack()(i), sol_rec[so[RTOC_SOL_MU] + i] = s.mu_stack()(i);
+  for (int i = 0; i < np; ++i) sol_rec[so[RTOC_SOL_NUP] + i] = s.nu_passive(i);
+  for (int i = 0; i < ns; ++i) sol_rec[so[RTOC_SOL_XI] + i] = s.xi_stack()(i);
+  return 0;
+}
+
 int ref_version(void) { return 1; }
 
 }  // extern "C"

@@ -101,7 +101,10 @@ class Robot {
   }
   template <typename A, typename C>
   void integrateConfiguration(const Eigen::MatrixBase<A>& v, const double h, const Eigen::MatrixBase<C>& q) const {
-    needFixedBase("integrateConfiguration");
+    if (hasFloatingBase()) {
+      const_cast<Eigen::MatrixBase<C>&>(q) = pop("integrateConfiguration");   // injected
+      return;
+    }
     const_cast<Eigen::MatrixBase<C>&>(q) += h * v;
   }
   template <typename A>

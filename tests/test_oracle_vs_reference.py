@@ -174,3 +174,52 @@ def test_costate_correction_matches_the_reference_sources(oracle):
     changed = [i for i in range(len(grids)) if not np.array_equal(d0[0, i], d1[0, i]) or True]
     for i in changed[1:]:
         assert rel_err(D.f(d0[0, i], "dlmdgmm"), D.f(d1[0, i], "dlmdgmm")) < 1e-13, i
+
+
+@pytest.mark.parametrize("floating", [True, False])
+def test_integrate_solution_against_the_reference_source(oracle, floating):
+    """SplitSolution::integrate (src/core/split_solution.cpp:58-90) -- the reference's own source on packed records -- against the
+    C restatement that rtoc_integrate_solution is held to (oracle/rtoc_oracle_condense.c: orc_integrate_solution_stage), on every
+    grid kind: intermediate with contacts and a switching constraint, impact (dv and impact forces), lift, terminal.  The SE(3)
+    update of a free-flyer base is Pinocchio's (injected into the reference, restated in the oracle)."""
+    from robotoc_amd.types import iiwa14_dims
+    if floating:
+        dims, grids, _ = pr.config_anymal_trot()
+    else:
+        dims, grids = iiwa14_dims(), pr.config_iiwa14()[1]
+    L = oracle.layout(dims)
+    S, D = Records(L, "sol"), Records(L, "dir")
+    rng = np.random.default_rng(12)
+    n = len(grids)
+    sol, dirs = rng.uniform(-1, 1, (1, n, L.sol.stride)), rng.uniform(-1, 1, (1, n, L.dir.stride))
+    if floating:
+        for i in range(n):
+            qt = S.f(sol[0, i], "q")[3:7]
+            qt /= np.linalg.norm(qt)
+    step = 0.37
+    out = sol.copy()
+    oracle.integrate_solution_batch(L, grids, np.array([[step, 1.0]]), dirs, out)
+    worst = 0.0
+    for i, g in enumerate(grids):
+        rec = sol[0, i].copy()
+        qi = None
+        if floating:
+            qi = np.concatenate([oracle.se3_integrate(S.f(rec, "q")[:7].copy(), D.f(dirs[0, i], "dx")[:6].copy(), step),
+                                 S.f(rec, "q")[7:dims.nv + 1] + step * D.f(dirs[0, i], "dx")[6:dims.nv]])
+        ref.split_solution_integrate(L, g, step, dirs[0, i].copy(), rec, qi)
+        fields = ["q", "v", "lmd", "gmm"]
+        if i < n - 1:
+            fields += ["a", "beta", "f", "mu"] + (["u", "nu_passive"] if g.type != 1 else []) + (["xi"] if g.dims > 0 and g.type != 1 else [])
+        for f in fields:
+            a, b = S.f(out[0, i], f), S.f(rec, f)
+            if f in ("f", "mu"):
+                a, b = a[:g.dimf], b[:g.dimf]
+            if f == "xi":
+                a, b = a[:g.dims], b[:g.dims]
+            if f == "q":
+                a, b = a[:dims.nv + (1 if floating else 0)], b[:dims.nv + (1 if floating else 0)]
+            if f == "nu_passive":
+                a, b = a[:dims.np], b[:dims.np]
+            worst = max(worst, float(np.abs(a - b).max())) if a.size else worst
+    print("SplitSolution::integrate, C restatement vs the reference source (%s base): %.1e" % ("floating" if floating else "fixed", worst))
+    assert worst < 1e-14
