@@ -1,0 +1,261 @@
+// ref_ocp_capi.cpp -- OCPSolver::updateSolution (src/solver/ocp_solver.cpp:111-145) of a floating-base robot over a contact
+// sequence with lifts and touch-downs, run by the REFERENCE'S OWN sources.  TEST INFRASTRUCTURE ONLY (oracle/_ref).
+//
+// Reference code that runs here: DirectMultipleShooting (src/ocp/direct_multiple_shooting.cpp: evalKKT, computeInitialStateDirection,
+// computeStepSizes, integrateSolution), IntermediateStage / ImpactStage / TerminalStage, ContactSequence, CostFunction +
+// ConfigurationSpaceCost, Constraints (six joint-limit components + FrictionCone), the state-equation, contact / impact dynamics
+// and switching-constraint sources, RiccatiRecursion with its factorizers, SplitSolution::integrate.  The ten lines of
+// updateSolution that string them together are restated below (OCPSolver's constructor wants an OCP built from a URDF).
+// NOT reference code: Eigen (mini_eigen.hpp); every Pinocchio quantity, injected by the caller in the order the stages ask for
+// them (FIFO, oracle/ref_shim/robotoc/robot/robot.hpp) from this repository's CPU rigid-body restatement.  Because the update of a
+// free-flyer configuration needs the Newton direction, the iteration is split: ref_ocp_direction() runs everything up to the
+// step sizes and hands back the directions; the caller computes q (+) step dq and ref_ocp_integrate() finishes.
+#include <memory>
+#include <vector>
+
+#include "../../include/rtoc.h"
+#include "robotoc/constraints/constraints.hpp"
+#include "robotoc/constraints/friction_cone.hpp"
+#include "robotoc/constraints/joint_position_lower_limit.hpp"
+#include "robotoc/constraints/joint_position_upper_limit.hpp"
+#include "robotoc/constraints/joint_torques_lower_limit.hpp"
+#include "robotoc/constraints/joint_torques_upper_limit.hpp"
+#include "robotoc/constraints/joint_velocity_lower_limit.hpp"
+#include "robotoc/constraints/joint_velocity_upper_limit.hpp"
+#include "robotoc/cost/configuration_space_cost.hpp"
+#include "robotoc/cost/cost_function.hpp"
+#define private public
+#include "robotoc/ocp/direct_multiple_shooting.hpp"
+#undef private
+#include "robotoc/planner/contact_sequence.hpp"
+#include "robotoc/riccati/riccati_recursion.hpp"
+
+using namespace robotoc;
+
+namespace {
+struct State {
+  int nv, nu, nc, n;
+  aligned_vector<Robot> robots;
+  OCP ocp;
+  std::unique_ptr<DirectMultipleShooting> dms;
+  std::unique_ptr<RiccatiRecursion> riccati;
+  TimeDiscretization td;
+  Solution s;
+  Direction d;
+  KKTMatrix km;
+  KKTResidual kr;
+  RiccatiFactorization fact;
+  double primal, dual;
+};
+std::unique_ptr<State> G;
+Eigen::VectorXd vec(const double* p, int n) {
+  Eigen::VectorXd v(n);
+  for (int i = 0; i < n; ++i) v(i) = p[i];
+  return v;
+}
+int sol_len(int nv, int nu, int nc) { return (nv + 1) + 2 * nv + nu + 3 * nc + 3 * nv + 3 * nc + 6 + 3 * nc; }
+}  // namespace
+
+extern "C" {
+
+int ref_ocp_sol_len(int nv, int nu, int nc) { return sol_len(nv, nu, nc); }
+
+// Injections are pushed with ref_ocp_inject between ref_ocp_begin and ref_ocp_direction.
+int ref_ocp_begin(int nv, int nu, int ncontacts) {
+  G.reset(new State());
+  G->nv = nv, G->nu = nu, G->nc = ncontacts;
+  G->robots.push_back(Robot(nv, nu, std::vector<ContactType>(ncontacts, ContactType::PointContact)));
+  return 0;
+}
+int ref_ocp_inject(const char* key, const double* data, int rows, int cols) {
+  if (!G) return 1;
+  Eigen::MatrixXd m(rows, cols);
+  for (int j = 0; j < cols; ++j)
+    for (int i = 0; i < rows; ++i) m(i, j) = data[i + (size_t)j * rows];
+  G->robots[0].inject(key, m);
+  return 0;
+}
+
+// grid / masks / positions: the discretisation and contact schedule (rtoc_set_grid / rtoc_set_contact_schedule); sol: [n][sol_len]
+// = q (nq), v, a (dv on impact grids), u, f ([nc][3] by contact index), lmd, gmm, beta, mu ([nc][3]), nu_passive (6), xi ([nc][3]
+// slots, the first GridInfo::dims used); slack / dual: [n][6 nu + 5 nc] (cone rows by contact index);
+// out_dq: [n][nv] the configuration directions; out_steps: primal, dual, KKT error (sum of squares)
+int ref_ocp_direction(const rtoc_grid* grid, const unsigned* masks, const double* positions, int n, const double* mu, const double* cost,
+                      const double* limits, double barrier, double tau, const double* q0, const double* v0, const double* sol,
+                      const double* slack, const double* dual, double* out_dq, double* out_steps) {
+  if (!G) return 1;
+  State& g = *G;
+  Robot& robot = g.robots[0];
+  const int nv = g.nv, nu = g.nu, nc = g.nc, nq = nv + 1, M = nv + 1;
+  g.n = n;
+  auto config = std::make_shared<ConfigurationSpaceCost>(robot);
+  config->set_q_ref(vec(cost, nq)), config->set_v_ref(vec(cost + M, nv)), config->set_u_ref(vec(cost + 2 * M, nu));
+  config->set_q_weight(vec(cost + 3 * M, nv)), config->set_v_weight(vec(cost + 4 * M, nv)), config->set_a_weight(vec(cost + 5 * M, nv));
+  config->set_u_weight(vec(cost + 6 * M, nu)), config->set_q_weight_terminal(vec(cost + 7 * M, nv)), config->set_v_weight_terminal(vec(cost + 8 * M, nv));
+  config->set_q_weight_impact(vec(cost + 9 * M, nv)), config->set_v_weight_impact(vec(cost + 10 * M, nv)), config->set_dv_weight_impact(vec(cost + 11 * M, nv));
+  auto cf = std::make_shared<CostFunction>();
+  cf->add("config_cost", config);
+  auto constraints = std::make_shared<Constraints>(barrier, tau);
+  robot.setJointLimits(vec(limits, nu), vec(limits + nu, nu), vec(limits + 2 * nu, nu), vec(limits + 3 * nu, nu));
+  constraints->add("joint_position_lower", std::make_shared<JointPositionLowerLimit>(robot));
+  constraints->add("joint_position_upper", std::make_shared<JointPositionUpperLimit>(robot));
+  constraints->add("joint_velocity_lower", std::make_shared<JointVelocityLowerLimit>(robot));
+  constraints->add("joint_velocity_upper", std::make_shared<JointVelocityUpperLimit>(robot));
+  constraints->add("joint_torques_lower", std::make_shared<JointTorquesLowerLimit>(robot));
+  constraints->add("joint_torques_upper", std::make_shared<JointTorquesUpperLimit>(robot));
+  constraints->add("friction_cone", std::make_shared<FrictionCone>(robot));
+  // ---- contact sequence and grid infos from the grid table: phases advance at lift and impact grids ----
+  auto status_of = [&](unsigned mask, int i) {
+    ContactStatus cs = robot.createContactStatus();
+    for (int c = 0; c < nc; ++c) {
+      if ((mask >> c) & 1u) cs.activateContact(c);
+      cs.setFrictionCoefficient(c, mu[c]);
+      cs.setContactPlacement(c, Eigen::Vector3d(vec(positions + ((size_t)i * nc + c) * 3, 3)));
+    }
+    return cs;
+  };
+  int nevents = 0;
+  for (int i = 0; i < n; ++i) nevents += grid[i].type == RTOC_GRID_IMPACT || grid[i].type == RTOC_GRID_LIFT;
+  auto seq = std::make_shared<ContactSequence>(robot, nevents + 1);
+  std::vector<GridInfo> gi(n);
+  int phase = 0, impact_index = -1, lift_index = -1;
+  double t = 0.0;
+  seq->init(status_of(masks[0], 0));
+  for (int i = 0; i < n; ++i) {
+    GridInfo& o = gi[i];
+    o.type = grid[i].type == RTOC_GRID_IMPACT ? GridType::Impact : grid[i].type == RTOC_GRID_LIFT ? GridType::Lift
+             : grid[i].type == RTOC_GRID_TERMINAL ? GridType::Terminal : GridType::Intermediate;
+    if (grid[i].type == RTOC_GRID_IMPACT) {
+      // the phase after the touch-down: the contacts of the next grid point
+      seq->push_back(status_of(masks[i + 1], i + 1), t);
+      ++impact_index;
+      o.phase = phase, o.impact_index = impact_index, o.lift_index = lift_index;
+      ++phase;
+    } else {
+      if (grid[i].type == RTOC_GRID_LIFT) {
+        seq->push_back(status_of(masks[i], i), t);
+        ++lift_index;
+        ++phase;
+      }
+      o.phase = phase, o.impact_index = impact_index, o.lift_index = lift_index;
+    }
+    o.t = t, o.dt = grid[i].dt, o.dt_next = i + 1 < n ? grid[i + 1].dt : 0.0;
+    o.stage = grid[i].time_stage < 0 ? 0 : grid[i].time_stage;
+    o.num_grids_in_phase = grid[i].num_grids_in_phase;
+    o.switching_constraint = grid[i].switching_constraint != 0;
+    o.sto = false, o.sto_next = false;
+    t += grid[i].dt;
+  }
+  g.td = TimeDiscretization(gi);
+  g.ocp.robot = robot, g.ocp.N = n - 1, g.ocp.T = t, g.ocp.reserved_num_discrete_events = nevents + 1;
+  g.ocp.cost = cf, g.ocp.constraints = constraints, g.ocp.contact_sequence = seq;
+  g.dms.reset(new DirectMultipleShooting(g.ocp, 1));
+  g.dms->resizeData(g.td);
+  g.riccati.reset(new RiccatiRecursion(g.ocp, 0.1));
+  g.s = Solution(n, SplitSolution(robot));
+  g.d = Direction(n, SplitDirection(robot));
+  g.km = KKTMatrix(n, SplitKKTMatrix(robot));
+  g.kr = KKTResidual(n, SplitKKTResidual(robot));
+  g.fact = RiccatiFactorization(n, SplitRiccatiFactorization(robot));
+  const int SL = sol_len(nv, nu, nc);
+  for (int i = 0; i < n; ++i) {
+    SplitSolution& s = g.s[i];
+    const bool impact = grid[i].type == RTOC_GRID_IMPACT, terminal = grid[i].type == RTOC_GRID_TERMINAL;
+    // OCPSolver::resizeData (src/solver/ocp_solver.cpp:461-478): the terminal grid carries no contact status
+    if (impact) s.setContactStatus(seq->impactStatus(gi[i].impact_index));
+    else if (!terminal) s.setContactStatus(seq->contactStatus(gi[i].phase));
+    const int ns = (!impact && !terminal && grid[i].switching_constraint) ? grid[i].dims : 0;
+    s.setSwitchingConstraintDimension(ns);
+    const double* p = sol + (size_t)i * SL;
+    s.q = vec(p, nq), p += nq;
+    s.v = vec(p, nv), p += nv;
+    (impact ? s.dv : s.a) = vec(p, nv), p += nv;
+    s.u = vec(p, nu), p += nu;
+    for (int c = 0; c < nc; ++c)
+      for (int k = 0; k < 3; ++k) s.f[c](k) = terminal ? 0.0 : p[3 * c + k];
+    p += 3 * nc;
+    s.lmd = vec(p, nv), p += nv;
+    s.gmm = vec(p, nv), p += nv;
+    s.beta = vec(p, nv), p += nv;
+    for (int c = 0; c < nc; ++c)
+      for (int k = 0; k < 3; ++k) s.mu[c](k) = terminal ? 0.0 : p[3 * c + k];
+    p += 3 * nc;
+    s.nu_passive = vec(p, 6), p += 6;
+    for (int k = 0; k < ns; ++k) s.xi_stack()(k) = p[k];
+    s.set_f_stack(), s.set_mu_stack();
+  }
+  // initConstraints sets the stage masks of the data (and pops nothing: the slacks are overwritten next); then the caller's slack / dual
+  {
+    const int nrow = 6 * nu + 5 * nc;
+    for (int i = 0; i < n; ++i) {
+      OCPData& data = g.dms->ocp_data_[i];
+      const int st = grid[i].type == RTOC_GRID_IMPACT ? -1 : (grid[i].type == RTOC_GRID_TERMINAL ? -1 : gi[i].stage);
+      data.constraints_data = constraints->createConstraintsData(robot, st);
+      std::vector<ConstraintComponentData*> comp;
+      for (auto& c : data.constraints_data.position_level_data) comp.push_back(&c);
+      for (auto& c : data.constraints_data.velocity_level_data) comp.push_back(&c);
+      for (auto& c : data.constraints_data.acceleration_level_data) comp.push_back(&c);
+      int o = 0;
+      for (size_t k = 0; k < comp.size(); ++k) {
+        const int m = k < 6 ? nu : 5 * nc;
+        for (int r = 0; r < m; ++r) comp[k]->slack(r) = slack[(size_t)i * nrow + o + r], comp[k]->dual(r) = dual[(size_t)i * nrow + o + r];
+        o += m;
+      }
+    }
+  }
+  // ---- OCPSolver::updateSolution (ocp_solver.cpp:118-132) ----
+  const Eigen::VectorXd q = vec(q0, nq), v = vec(v0, nv);
+  g.dms->evalKKT(g.robots, g.td, q, v, g.s, g.km, g.kr);
+  g.riccati->backwardRiccatiRecursion(g.td, g.km, g.kr, g.fact);
+  g.dms->computeInitialStateDirection(robot, q, v, g.s, g.d);
+  g.riccati->forwardRiccatiRecursion(g.td, g.km, g.kr, g.fact, g.d);
+  g.dms->computeStepSizes(g.td, g.d);
+  g.primal = g.dms->maxPrimalStepSize(), g.dual = g.dms->maxDualStepSize();
+  for (int i = 0; i < n; ++i)
+    for (int k = 0; k < nv; ++k) out_dq[(size_t)i * nv + k] = g.d[i].dq()(k);
+  out_steps[0] = g.primal, out_steps[1] = g.dual, out_steps[2] = g.dms->getEval().kkt_error;
+  return (int)robot.pending() == 0 ? 0 : 2;
+}
+
+// q_integrated: [n][nq] = s[i].q (+) primal_step d[i].dq (pushed as the integrateConfiguration injections, in grid order)
+int ref_ocp_integrate(const double* q_integrated, double* sol_out, double* slack_out, double* dual_out) {
+  if (!G || !G->dms) return 1;
+  State& g = *G;
+  Robot& robot = g.robots[0];
+  const int nv = g.nv, nu = g.nu, nc = g.nc, nq = nv + 1, n = g.n;
+  for (int i = 0; i < n; ++i) robot.inject("integrateConfiguration", vec(q_integrated + (size_t)i * nq, nq));
+  g.dms->integrateSolution(g.robots, g.td, g.primal, g.dual, g.d, g.s);   // ocp_solver.cpp:142
+  const int SL = sol_len(nv, nu, nc), nrow = 6 * nu + 5 * nc;
+  for (int i = 0; i < n; ++i) {
+    const SplitSolution& s = g.s[i];
+    const bool impact = g.td[i].type == GridType::Impact;
+    double* p = sol_out + (size_t)i * SL;
+    for (int k = 0; k < nq; ++k) *p++ = s.q(k);
+    for (int k = 0; k < nv; ++k) *p++ = s.v(k);
+    for (int k = 0; k < nv; ++k) *p++ = impact ? s.dv(k) : s.a(k);
+    for (int k = 0; k < nu; ++k) *p++ = s.u(k);
+    for (int c = 0; c < nc; ++c)
+      for (int k = 0; k < 3; ++k) *p++ = s.f[c](k);
+    for (int k = 0; k < nv; ++k) *p++ = s.lmd(k);
+    for (int k = 0; k < nv; ++k) *p++ = s.gmm(k);
+    for (int k = 0; k < nv; ++k) *p++ = s.beta(k);
+    for (int c = 0; c < nc; ++c)
+      for (int k = 0; k < 3; ++k) *p++ = s.mu[c](k);
+    for (int k = 0; k < 6; ++k) *p++ = s.nu_passive(k);
+    for (int k = 0; k < 3 * nc; ++k) *p++ = k < s.dims() ? s.xi_stack()(k) : 0.0;
+    OCPData& data = g.dms->ocp_data_[i];
+    std::vector<ConstraintComponentData*> comp;
+    for (auto& c : data.constraints_data.position_level_data) comp.push_back(&c);
+    for (auto& c : data.constraints_data.velocity_level_data) comp.push_back(&c);
+    for (auto& c : data.constraints_data.acceleration_level_data) comp.push_back(&c);
+    int o = 0;
+    for (size_t k = 0; k < comp.size(); ++k) {
+      const int m = k < 6 ? nu : 5 * nc;
+      for (int r = 0; r < m; ++r) slack_out[(size_t)i * nrow + o + r] = comp[k]->slack(r), dual_out[(size_t)i * nrow + o + r] = comp[k]->dual(r);
+      o += m;
+    }
+  }
+  return (int)robot.pending() == 0 ? 0 : 2;
+}
+
+}  // extern "C"

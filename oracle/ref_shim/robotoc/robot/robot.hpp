@@ -159,16 +159,48 @@ class Robot {
     id_ = ID, did_dq_ = dIDdq, did_dv_ = dIDdv, did_da_ = dIDda;
     has_id_ = true;
   }
-  template <typename... Args>
-  void updateKinematics(const Args&...) {}   // the injected quantities stand
+  // the injected quantities stand.  Horizon mode (ref_ocp_capi.cpp): every stage's evalKKT opens with updateKinematics(q, v[, a])
+  // -- that call pops the stage's frame kinematics (one matrix per contact: R row-major 3 x 3 stacked on the 6 x nv LOCAL
+  // Jacobian, i.e. (3 + 6) ... packed as [9 + 6 nv] x 1); the one-argument call of the switching constraint pops nothing
+  template <typename A>
+  void updateKinematics(const Eigen::MatrixBase<A>&) {}
+  template <typename A, typename B, typename... Rest>
+  void updateKinematics(const Eigen::MatrixBase<A>&, const Eigen::MatrixBase<B>&, const Rest&...) {
+    auto it = fifo_->find("frames");
+    if (it == fifo_->end() || it->second.empty()) return;
+    for (int c = 0; c < maxNumContacts(); ++c) {
+      const Eigen::MatrixXd m = pop("frames");
+      Eigen::Matrix3d R;
+      for (int r = 0; r < 3; ++r)
+        for (int k = 0; k < 3; ++k) R(r, k) = m(3 * r + k, 0);
+      Eigen::MatrixXd J(6, dimv_);
+      for (int j = 0; j < dimv_; ++j)
+        for (int r = 0; r < 6; ++r) J(r, j) = m(9 + r + 6 * j, 0);
+      setFrameKinematics(c, R, J);
+    }
+  }
+  bool queued(const char* key) const {
+    auto it = fifo_->find(key);
+    return it != fifo_->end() && !it->second.empty();
+  }
   template <typename A, typename B, typename C, typename D>
   void RNEA(const Eigen::MatrixBase<A>&, const Eigen::MatrixBase<B>&, const Eigen::MatrixBase<C>&, const Eigen::MatrixBase<D>& tau) {
+    if (queued("ID")) {
+      const_cast<Eigen::MatrixBase<D>&>(tau) = pop("ID");
+      return;
+    }
     if (!has_id_) unavailable("RNEA");
     const_cast<Eigen::MatrixBase<D>&>(tau) = id_;
   }
   template <typename A, typename B, typename C, typename D, typename E, typename F>
   void RNEADerivatives(const Eigen::MatrixBase<A>&, const Eigen::MatrixBase<B>&, const Eigen::MatrixBase<C>&,
                        const Eigen::MatrixBase<D>& dq, const Eigen::MatrixBase<E>& dv, const Eigen::MatrixBase<F>& da) {
+    if (queued("dIDdq")) {
+      const_cast<Eigen::MatrixBase<D>&>(dq) = pop("dIDdq");
+      const_cast<Eigen::MatrixBase<E>&>(dv) = pop("dIDdv");
+      const_cast<Eigen::MatrixBase<F>&>(da) = pop("dIDda");
+      return;
+    }
     if (!has_id_) unavailable("RNEADerivatives");
     const_cast<Eigen::MatrixBase<D>&>(dq) = did_dq_;
     const_cast<Eigen::MatrixBase<E>&>(dv) = did_dv_;
@@ -241,11 +273,21 @@ class Robot {
   void setImpactForces(const Args&...) {}
   template <typename A, typename B, typename D>
   void RNEAImpact(const Eigen::MatrixBase<A>&, const Eigen::MatrixBase<B>&, const Eigen::MatrixBase<D>& res) {
+    if (queued("ID")) {
+      const_cast<Eigen::MatrixBase<D>&>(res) = pop("ID");
+      return;
+    }
     if (!has_id_) unavailable("RNEAImpact");
     const_cast<Eigen::MatrixBase<D>&>(res) = id_;
   }
   template <typename A, typename B, typename D, typename E>
   void RNEAImpactDerivatives(const Eigen::MatrixBase<A>&, const Eigen::MatrixBase<B>&, const Eigen::MatrixBase<D>& dq, const Eigen::MatrixBase<E>& ddv) {
+    if (queued("dIDdq")) {
+      const_cast<Eigen::MatrixBase<D>&>(dq) = pop("dIDdq");
+      (void)pop("dIDdv");
+      const_cast<Eigen::MatrixBase<E>&>(ddv) = pop("dIDda");
+      return;
+    }
     if (!has_id_) unavailable("RNEAImpactDerivatives");
     const_cast<Eigen::MatrixBase<D>&>(dq) = did_dq_;
     const_cast<Eigen::MatrixBase<E>&>(ddv) = did_da_;

@@ -144,6 +144,7 @@ if __name__ == "__main__":
     contact_stage_fixture()
     impact_and_terminal_stage_fixture()
     icub_surface_stage_fixture()
+    ocp_solver_iteration_fixture()
 
 
 def _richardson(fun, n, h=2.0e-3):
@@ -481,3 +482,137 @@ def icub_surface_stage_fixture(name="ref_icub_surface_stage.npz"):
     np.savez_compressed(os.path.join(HERE, name), q=q, v=v, a=a, u=u, f=f, lmd=lmd, gmm=gmm, beta=beta, mu_stack=mus, nu_passive=nup, pos=pos, rot=rot,
                         mu=mu, cost=cost, limits=limits, slack=slack, dual=dual, out=out, scalars=np.array([dt, barrier, tau, i0, active, X, Y]))
     print(name, "stage KKT error %.6e" % out[-1])
+
+
+def ocp_solver_iteration_fixture(name="ref_anymal_ocp_solver_iteration.npz"):
+    """ONE OCPSolver::updateSolution (src/solver/ocp_solver.cpp:111-145) of ANYmal over a short trot -- lifts, touch-downs with
+    switching constraints, ConfigurationSpaceCost, six joint-limit components, FrictionCone -- run by the REFERENCE'S OWN
+    DirectMultipleShooting, stages, ContactSequence, cost, constraints, dynamics and RiccatiRecursion sources
+    (oracle/ref_shim/ref_ocp_capi.cpp), every Pinocchio quantity of every grid point injected from this repository's CPU
+    restatement.  The fixture: the iterate, and the reference's next iterate, slacks / duals, step sizes and KKT error."""
+    import ctypes as C
+    from robotoc_amd import robot_model as rm
+    from robotoc_amd.grid import (ANYMAL_Q_STANDING, ANYMAL_TROT_IMPACT_MASKS, ANYMAL_TROT_PHASE_MASKS, contact_masks)
+    from robotoc_amd.types import GRID_IMPACT as GI, GRID_TERMINAL as GT
+    m = rm.load_named("anymal")
+    nv, nq, nu, nc = m.nv, m.nq, 12, 4
+    grids = discretize(10, 0.2, 0.0, anymal_trot_sequence(t0=0.03, swing=0.05, double_support=0.03, cycles=1))
+    n = len(grids)
+    masks = contact_masks(grids, ANYMAL_TROT_PHASE_MASKS, ANYMAL_TROT_IMPACT_MASKS)
+    rng = np.random.default_rng(2468)
+    qs = np.array(ANYMAL_Q_STANDING, dtype=float)
+    feet = np.array([orc.rbd_contact_position(m, qs, c) for c in range(nc)])
+    pos = np.tile(feet[None], (n, 1, 1)) + 0.003 * rng.uniform(-1, 1, (n, nc, 3))
+    q = np.zeros((n, nq))
+    for i in range(n):
+        q[i] = qs
+        q[i, :7] = orc.se3_integrate(qs[:7], 0.02 * rng.uniform(-1, 1, 6))
+        q[i, 7:] += 0.05 * rng.uniform(-1, 1, 12)
+    v, a, u = 0.2 * rng.uniform(-1, 1, (n, nv)), 0.5 * rng.uniform(-1, 1, (n, nv)), 5.0 * rng.uniform(-1, 1, (n, nu))
+    f = 5.0 * rng.uniform(-1, 1, (n, nc, 3))
+    f[:, :, 2] = rng.uniform(60, 120, (n, nc))
+    lmd, gmm, beta = (0.2 * rng.uniform(-1, 1, (n, nv)) for _ in range(3))
+    mus, nup, xi = 0.2 * rng.uniform(-1, 1, (n, nc, 3)), 0.2 * rng.uniform(-1, 1, (n, 6)), 0.2 * rng.uniform(-1, 1, (n, 3 * nc))
+    mu = np.array([0.7, 0.6, 0.8, 0.5])
+    wq = np.concatenate([np.full(6, 10.0), np.full(12, 1.0)])
+    M = nv + 1
+    cost = np.zeros((12, M))
+    for k, val in ((0, qs), (3, wq), (4, np.full(nv, 1.0)), (5, np.full(nv, 1e-2)), (6, np.full(nu, 1e-2)), (7, 10.0 * wq), (8, np.full(nv, 1.0)),
+                   (9, wq), (10, np.full(nv, 1.0)), (11, np.full(nv, 1e-2))):
+        cost[k, :len(val)] = val
+    limits = np.stack([np.full(nu, -1.8), np.full(nu, 1.8), np.full(nu, 4.0), np.full(nu, 60.0)])
+    nrow = 6 * nu + 5 * nc
+    slack, dual = rng.uniform(0.2, 2.0, (n, nrow)), rng.uniform(0.01, 0.3, (n, nrow))
+    barrier, tau = 1.0e-3, 0.995
+    x0 = np.concatenate([orc.se3_integrate(qs[:7], 0.01 * rng.uniform(-1, 1, 6)), qs[7:] + 0.02 * rng.uniform(-1, 1, 12), 0.05 * rng.uniform(-1, 1, nv)])
+    L = ref.lib()
+    dp = C.POINTER(C.c_double)
+    ptr = lambda x: np.ascontiguousarray(x, dtype=np.float64).ctypes.data_as(dp)
+    plus = lambda qq, e: orc.rbd_integrate(m, qq, e)
+
+    def sub(qf, q0):
+        return np.concatenate([orc.se3_difference(q0[:7], qf[:7]), qf[7:] - q0[7:]])
+    L.ref_ocp_begin(nv, nu, nc)
+
+    def inject(key, arr):
+        keep = np.asfortranarray(np.asarray(arr, dtype=np.float64).reshape(len(arr), -1))
+        assert L.ref_ocp_inject(key.encode(), keep.ctypes.data_as(dp), keep.shape[0], keep.shape[1]) == 0
+    h = 2.0e-3
+    for i, g in enumerate(grids):
+        impact, terminal = g.type == GI, g.type == GT
+        qi = q[i]
+        qp = q[i - 1] if i > 0 else x0[:nq]
+        # frame kinematics of every contact, popped by the stage's opening updateKinematics
+        for c in range(nc):
+            R = orc.rbd_contact_placement(m, qi, c)[0]
+            dR = _richardson(lambda e: orc.rbd_contact_placement(m, plus(qi, e), c)[0].reshape(-1), nv)
+            Jl = np.zeros((6, nv))
+            for jj in range(nv):
+                W = dR[:, jj].reshape(3, 3) @ R.T
+                Jl[3:, jj] = R.T @ np.array([W[2, 1], W[0, 2], W[1, 0]])
+            inject("frames", np.concatenate([R.reshape(-1), Jl.T.reshape(-1)]))
+        inject("subtractConfiguration", sub(qi, qs))
+        inject("dSubtractConfiguration_dqf", _richardson(lambda e: sub(plus(qi, e), qs), nv))
+        if terminal:
+            inject("dSubtractConfiguration_dq0", _richardson(lambda e: sub(qp, plus(qi, e)), nv))
+            continue
+        qn = q[i + 1]
+        inject("subtractConfiguration", sub(qi, qn))
+        inject("dSubtractConfiguration_dqf", _richardson(lambda e: sub(plus(qi, e), qn), nv))
+        inject("dSubtractConfiguration_dq0", _richardson(lambda e: sub(qp, plus(qi, e)), nv))
+        mask = int(masks[i])
+        act = [c for c in range(nc) if (mask >> c) & 1]
+        fstack = np.concatenate([f[i, c] for c in act])
+        val = orc.rbd_eval(m, int(impact), qi, v[i], a[i], fstack, np.zeros(nu), mask, pos[i].reshape(-1))
+        J1 = orc.rbd_linearize_fd(m, int(impact), qi, v[i], a[i], fstack, np.zeros(nu), mask, pos[i].reshape(-1), eps=h)
+        J2 = orc.rbd_linearize_fd(m, int(impact), qi, v[i], a[i], fstack, np.zeros(nu), mask, pos[i].reshape(-1), eps=h / 2)
+        Jr = [(4.0 * np.asarray(J2[k]) - np.asarray(J1[k])) / 3.0 for k in range(3)]
+        inject("ID", val[:nv])
+        if impact:
+            inject("impactVelocityResidual", val[nv:])
+        else:
+            inject("baumgarteResidual", val[nv:])
+        inject("dIDdq", Jr[0][:nv]), inject("dIDdv", Jr[1][:nv]), inject("dIDda", Jr[2][:nv])
+        if impact:
+            inject("impactVelocity_dq", Jr[0][nv:]), inject("impactVelocity_dv", Jr[2][nv:])
+        else:
+            inject("baumgarte_dq", Jr[0][nv:]), inject("baumgarte_dv", Jr[1][nv:]), inject("baumgarte_da", Jr[2][nv:])
+        if g.switching_constraint and not impact:
+            dt1, dt2 = g.dt, grids[i + 1].dt
+            dq_sw = (dt1 + dt2) * v[i] + dt1 * dt2 * a[i]
+            q_plus = plus(qi, dq_sw)
+            imp = [c for c in range(nc) if (int(masks[i + 2]) >> c) & 1]
+            P_at = lambda qq: np.concatenate([orc.rbd_contact_position(m, qq, c) - pos[i + 2, c] for c in imp])
+            inject("integrateConfiguration", q_plus)
+            inject("contactPositionResidual", P_at(q_plus))
+            inject("contactPositionDerivative", _richardson(lambda e: P_at(plus(q_plus, e)), nv))
+            inject("dIntegrate_dq", _richardson(lambda e: sub(plus(plus(qi, e), dq_sw), q_plus), nv))
+            inject("dIntegrate_dv", _richardson(lambda e: sub(plus(qi, dq_sw + e), q_plus), nv))
+        inject("dSubtractConfiguration_dq0", _richardson(lambda e: sub(qi, plus(qn, e)), nv))
+    inject("subtractConfiguration", sub(x0[:nq], q[0]))    # computeInitialStateDirection (state_equation.cpp:103)
+    SL = L.ref_ocp_sol_len(nv, nu, nc)
+    sol = np.zeros((n, SL))
+    for i in range(n):
+        mask = int(masks[i])
+        fi, mi = np.zeros((nc, 3)), np.zeros((nc, 3))
+        for c in range(nc):
+            if (mask >> c) & 1:
+                fi[c], mi[c] = f[i, c], mus[i, c]
+        sol[i] = np.concatenate([q[i], v[i], a[i], u[i], fi.reshape(-1), lmd[i], gmm[i], beta[i], mi.reshape(-1), nup[i], xi[i]])
+    from robotoc_amd.types import Grid
+    garr = (Grid * n)(*grids)
+    marr = np.ascontiguousarray(masks, dtype=np.uint32)
+    out_dq, steps = np.zeros((n, nv)), np.zeros(3)
+    L.ref_ocp_direction.argtypes = [C.POINTER(Grid), C.POINTER(C.c_uint), dp, C.c_int, dp, dp, dp, C.c_double, C.c_double, dp, dp, dp, dp, dp, dp, dp]
+    rc = L.ref_ocp_direction(garr, marr.ctypes.data_as(C.POINTER(C.c_uint)), ptr(pos), n, ptr(mu), ptr(cost), ptr(limits), barrier, tau, ptr(x0[:nq]),
+                             ptr(x0[nq:]), ptr(sol), ptr(slack), ptr(dual), out_dq.ctypes.data_as(dp), steps.ctypes.data_as(dp))
+    assert rc == 0, rc
+    q_int = np.array([plus(q[i], steps[0] * out_dq[i]) for i in range(n)])
+    sol_out, slack_out, dual_out = np.zeros((n, SL)), np.zeros((n, nrow)), np.zeros((n, nrow))
+    L.ref_ocp_integrate.argtypes = [dp, dp, dp, dp]
+    rc = L.ref_ocp_integrate(ptr(q_int), sol_out.ctypes.data_as(dp), slack_out.ctypes.data_as(dp), dual_out.ctypes.data_as(dp))
+    assert rc == 0, rc
+    np.savez_compressed(os.path.join(HERE, name), sol_in=sol, sol_out=sol_out, slack=slack, dual=dual, slack_out=slack_out, dual_out=dual_out,
+                        steps=steps, x0=x0, pos=pos, mu=mu, cost=cost, limits=limits, masks=masks, scalars=np.array([barrier, tau]),
+                        **grid_table(grids))
+    print(name, "n %d, KKT error %.6e, steps %.4f / %.4f" % (n, steps[2], steps[0], steps[1]))
