@@ -99,6 +99,29 @@ def split_solution_integrate(L, g, step, dir_rec, sol_rec, q_integrated=None, co
     assert fn(C.byref(L), C.byref(g), contact_dim, step, _p(dir_rec), _p(sol_rec), _p(q_integrated) if q_integrated is not None else None) == 0
 
 
+def sto_eval_kkt(grids, t, h, qtt, min_dwell, barrier=1.0e-3, fraction=0.995, sto_reg=0.0, cost_w=None, cost_tref=None):
+    """SwitchingTimeOptimization::evalKKT (src/sto/switching_time_optimization.cpp:79-137) by the reference's own sources, with
+    its STOCostFunction and minimum-dwell-time STOConstraints (oracle/ref_shim/ref_sto_capi.cpp).  h / qtt: [stages] the per-grid
+    SplitKKTResidual::h / SplitKKTMatrix::Qtt, updated in place.  Returns lt_, diag(Qtt_) as the reference scattered them and
+    [STO kkt_error, the dwell-time constraints' KKTError, dual feasibility, cost]."""
+    fn = lib().ref_sto_eval_kkt
+    dp = C.POINTER(C.c_double)
+    fn.argtypes = [C.POINTER(Grid), dp, C.c_int, dp, dp, dp, C.c_double, C.c_double, C.c_double, dp, dp, dp, dp, dp]
+    fn.restype = C.c_int
+    n = len(grids)
+    nev = sum(1 for g in grids[:-1] if g.type in (1, 2))
+    t = np.ascontiguousarray(t, dtype=np.float64)
+    min_dwell = np.ascontiguousarray(min_dwell, dtype=np.float64)
+    assert t.shape == (n,) and h.shape == (n,) and qtt.shape == (n,) and min_dwell.shape == (nev + 1,)
+    lt, qd, perf = np.zeros(max(nev, 1)), np.zeros(max(nev, 1)), np.zeros(4)
+    w = np.ascontiguousarray(cost_w, dtype=np.float64) if cost_w is not None else None
+    tr = np.ascontiguousarray(cost_tref, dtype=np.float64) if cost_tref is not None else None
+    got = fn(grid_array(grids), _p(t), n, _p(h), _p(qtt), _p(min_dwell), barrier, fraction, sto_reg, _p(w) if w is not None else None,
+             _p(tr) if tr is not None else None, _p(lt), _p(qd), _p(perf))
+    assert got == nev, (got, nev)
+    return lt[:nev], qd[:nev], perf
+
+
 def correct_costate(L, se3_rec, dir_rec):
     lib().ref_correct_costate(C.byref(L), _p(se3_rec), _p(dir_rec))
 

@@ -45,6 +45,10 @@ class Matrix;
 typedef Matrix<double, Dynamic, Dynamic> MatrixXd;
 typedef Matrix<double, Dynamic, 1> VectorXd;
 typedef Matrix<double, 1, Dynamic> RowVectorXd;
+// Eigen::Map<const VectorXd>(ptr, n): only ever used by the reference's STO constraints to hand a std::vector to a
+// `const VectorXd&` parameter (src/sto/sto_constraints.cpp:23,75) -- an owning copy serves.
+template <class T> class Map;
+
 typedef Matrix<double, 2, 1> Vector2d;
 typedef Matrix<double, 3, 1> Vector3d;
 typedef Matrix<double, 4, 1> Vector4d;
@@ -1116,6 +1120,14 @@ class LLT {
   void solveInPlace(const MatrixBase<D>& b) const {
     const MatrixXd x = solve(b);
     assign_view(b.raw(), x.raw());
+  }
+};
+
+template <>
+class Map<const VectorXd> : public VectorXd {
+ public:
+  Map(const double* p, Index n) : VectorXd(n) {
+    for (Index i = 0; i < n; ++i) (*this)(i) = p[i];
   }
 };
 

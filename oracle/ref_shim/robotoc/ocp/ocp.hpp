@@ -9,6 +9,8 @@
 #include "robotoc/cost/cost_function.hpp"
 #include "robotoc/planner/contact_sequence.hpp"
 #include "robotoc/robot/robot.hpp"
+#include "robotoc/sto/sto_constraints.hpp"
+#include "robotoc/sto/sto_cost_function.hpp"
 namespace robotoc {
 struct OCP {
   Robot robot;
@@ -19,6 +21,9 @@ struct OCP {
   std::shared_ptr<CostFunction> cost;
   std::shared_ptr<Constraints> constraints;
   std::shared_ptr<ContactSequence> contact_sequence;
+  // what SwitchingTimeOptimization's constructor reads (src/sto/switching_time_optimization.cpp:8-12)
+  std::shared_ptr<STOCostFunction> sto_cost;
+  std::shared_ptr<STOConstraints> sto_constraints;
 };
 }  // namespace robotoc
 #endif

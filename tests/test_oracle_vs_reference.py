@@ -223,3 +223,50 @@ def test_integrate_solution_against_the_reference_source(oracle, floating):
             worst = max(worst, float(np.abs(a - b).max())) if a.size else worst
     print("SplitSolution::integrate, C restatement vs the reference source (%s base): %.1e" % ("floating" if floating else "fixed", worst))
     assert worst < 1e-14
+
+
+def _sto_cases():
+    from test_random_grids import random_case
+    yield "anymal jump, STO on every event", pr.config_anymal_jump_sto()[:2]
+    yield "anymal trot, no STO", pr.config_anymal_trot()[:2]
+    for seed in (1, 3, 4, 8, 11):
+        d, g, _ = random_case(seed)
+        yield "random events %d (mixed STO flags)" % seed, (d, g)
+
+
+def test_sto_scatter_and_kkt_term_match_the_reference_sources(oracle):
+    """rtoc_sto_eval_kkt's restatement (orc_sto_eval_kkt) against SwitchingTimeOptimization::evalKKT itself
+    (src/sto/switching_time_optimization.cpp:79-137), run with the reference's STOCostFunction and its minimum-dwell-time
+    STOConstraints: the gradient / Hessian diagonal the reference scatters are taken from the reference run and handed to
+    the restatement, as the host hands them to the device; h, Qtt of every grid point and the Hamiltonian term of the
+    squared KKT error (= the STO problem's kkt_error minus the dwell-time constraints' own) must agree."""
+    from robotoc_amd.types import GRID_LIFT
+    worst = 0.0
+    for name, (dims, grids) in _sto_cases():
+        L = oracle.layout(dims)
+        K = Records(L, "kkt")
+        n = len(grids)
+        nev = sum(1 for g in grids[:-1] if g.type in (GRID_IMPACT, GRID_LIFT))
+        kkt = pr.make_kkt_batch(L, grids, 1)
+        rng = np.random.default_rng(n + nev)
+        sc = K.f(kkt[0], "scal")
+        sc[:, 2] = rng.uniform(-2.0, 2.0, n)  # a Hamiltonian on every grid point, whatever the factory left there
+        t = np.concatenate([[0.0], np.cumsum([g.dt for g in grids[:-1]])])
+        event_t = [t[i] for i, g in enumerate(grids[:-1]) if g.type in (GRID_IMPACT, GRID_LIFT)]
+        dwell = np.diff(np.concatenate([[t[0]], event_t, [t[-1]]]))
+        min_dwell = 0.5 * np.maximum(dwell, 0.0) + 1e-3 * (dwell <= 0.0)  # strictly inside wherever the table allows it
+        if nev and (dwell - min_dwell).min() <= 0.0:
+            min_dwell = np.minimum(min_dwell, dwell - 1e-3)
+        h, qtt = sc[:, 2].copy(), sc[:, 0].copy()
+        lt, qd, perf = ref.sto_eval_kkt(grids, t, h, qtt, min_dwell, barrier=1.0e-2, sto_reg=0.3,
+                                        cost_w=rng.uniform(0.5, 2.0, max(nev, 1)), cost_tref=rng.uniform(0.0, t[-1], max(nev, 1)))
+        k = kkt.copy()
+        err = oracle.sto_eval_kkt(L, grids, k, lt[None], qd[None])[0] if nev else 0.0
+        so = K.f(k[0], "scal")
+        assert np.array_equal(so[:, 2], h) and np.array_equal(so[:, 0], qtt), name
+        if nev:
+            assert np.abs(lt).max() > 0 and qd.min() >= 0.3  # the cost, the barrier and the regularisation all arrived
+            term = perf[0] - perf[1]
+            worst = max(worst, abs(err - term) / max(term, 1.0))
+            assert abs(err - term) <= 1e-12 * max(perf[0], 1.0), (name, err, term)
+    print("STO scatter identical; Hamiltonian KKT term vs the reference sources: %.1e" % worst)
