@@ -11,13 +11,13 @@
 //
 // Mapping.  Unlike the Riccati recursion this work has no chain over the horizon: every
 // (instance, grid point) pair is independent, i.e. batch x stages ~ 1.9e5 work items for the
-// headline workload.  One wavefront per work item; the dense products run on the f64 matrix
-// cores straight from the (L2-resident, 64-byte aligned) records -- there is no reuse across
-// work items to stage in LDS, and 8 resident waves per SIMD hide the operand latency, which a
-// LDS-staged, 40 KB-per-item design (3 items per CU) could not.  The intermediate blocks
-// (MJtJinv, MJtJinv_dIDCdqv, Qafqv, Qafu_full) are outputs of the reference as well
-// (ContactDynamicsData keeps them for the expansion), so they are produced in place in the
-// contact-dynamics record and re-read from there.
+// headline workload.  Split pipeline (default): mjtjinv_kernel -- one wave per work item, the saddle-matrix
+// factorisations and the cone rows, MJtJinv into the ContactDynamicsData record -- then condense_kernel<SPLIT> -- three
+// waves per work item, every input field once into LDS, ~15 barrier-separated phases of compile-time-shaped f64-MFMA
+// products (lds_gemm.hpp), the Hessian blocks read-modify-written once in HBM.  Both kernels are occupancy x chain
+// bound, so their LDS carves and register budgets are sized by work items per CU (160 KB LDS in granules of 1280 B;
+// ANYmal: 10 and 5 work items per CU, CondCfg / MjCfg below).  The intermediate blocks the reference keeps for the
+// expansion (MJtJinv, MJtJinv_dIDCdqv; Qafqv / Qafu_full on request) are produced in the contact-dynamics record.
 #pragma once
 #include "device_utils.hpp"
 #include "riccati_backward.hpp"  // wave_llt, llt_solve_reg
@@ -87,7 +87,7 @@ struct ExpArgs {
   double tau;
 };
 
-template <int NV, int NU, int NF, int NS>
+template <int NV, int NU, int NF, int NS, bool SPLIT = false>
 struct CondCfg {
   static constexpr int NW = RTOC_COND_NW;  // wavefronts per work item (tiles dealt round-robin)
   static constexpr int NT = 64 * NW;
@@ -108,9 +108,18 @@ struct CondCfg {
   static constexpr int O_S = O_JM + pad8(NFP * NV);            // NF x NF
   static constexpr int O_BR = O_S + pad8(NFP * NFP);           // NF x NF
   static constexpr int X_A = O_BR + pad8(NFP * NFP) - O_X;
+  static constexpr int Y_ROOM = O_BR + pad8(NFP * NFP) - O_JM;  // J M^-1, S, bottomRight: free while M is factorised
   static constexpr int X_B = pad8(LDV * NV);                   // Qafu_full LDV x NV
+  // The split kernel gets MJtJinv from mjtjinv_kernel: no factorisation scratch (X_A).  And once MJtJinv_dIDCdqv and
+  // MJtJinv_IDC exist, the columns NV.. of MJtJinv are only read through their exact mirror images in the rows NV..
+  // (bottomLeft is stored as a copy of topRight^T, condense_mjtjinv.inc): with nu <= nf_max the actuated columns of
+  // Qafu_full live there (TAIL) and region X holds its passive columns only.  ANYmal: 37.2 -> 29.9 KB = 24 of the 128
+  // LDS granules (1280 B) of a CU, five work items per CU instead of four.
+  static constexpr bool TAIL = SPLIT && NF > 0 && NU <= NF;
+  static constexpr int X_T = pad8(LDV * (NV - NU) > 8 ? LDV * (NV - NU) : 8);
+  static constexpr int X_SZ = TAIL ? X_T : (SPLIT ? X_B : (X_A > X_B ? X_A : X_B));
   static constexpr int O_QAFU = O_X;
-  static constexpr int O_QFF = O_X + (X_A > X_B ? X_A : X_B);  // NF x NF
+  static constexpr int O_QFF = O_X + X_SZ;                     // NF x NF
   static constexpr int O_QQF = O_QFF + pad8(NFP * NFP);        // NV x NF
   static constexpr int O_VEC = O_QQF + pad8(NV * NFP);
   static constexpr int V_IDC = O_VEC, V_LR = V_IDC + pad8(LDV), V_LAF = V_LR + pad8(LDV),
@@ -120,6 +129,9 @@ struct CondCfg {
   static constexpr int V_PH = V_SINV + pad8(NFP), V_PG = V_PH + pad8(2 * NV + NU);
   static constexpr int LDS_DOUBLES = V_PG + pad8(2 * NV + NU);
   static constexpr int LDS_BYTES = LDS_DOUBLES * 8;
+  // work items per CU by LDS (160 KB in granules of 1280 B) -> waves per SIMD the register budget has to allow
+  static constexpr int ITEMS = 128 / ((LDS_BYTES + 1279) / 1280);
+  static constexpr int MIN_WAVES = TAIL && (ITEMS * NW + 3) / 4 >= 4 ? 4 : 1;
 };
 
 // One-wave dense product on the f64 matrix cores with generic (row, column) strides:
@@ -311,9 +323,10 @@ __device__ __forceinline__ void wave_gemv(int M, int K, double alpha, const doub
 // is read back from the ContactDynamicsData record -- the serial factorisations then run at four times the
 // occupancy (16 KB instead of 38 KB of LDS per grid point) and off this kernel's critical path.
 template <int NV, int NU, int NF, int NS, bool SPLIT = false>
-__global__ __launch_bounds__(64 * RTOC_COND_NW) void condense_kernel(CondArgs a) {
+__global__ __launch_bounds__(64 * RTOC_COND_NW, (CondCfg<NV, NU, NF, NS, SPLIT>::MIN_WAVES)) void condense_kernel(CondArgs a) {
   static_assert(CondCfg<NV, NU, NF, NS>::NT == 64 * RTOC_COND_NW, "launch bounds must match CondCfg::NT");
-  using C = CondCfg<NV, NU, NF, NS>;
+  using C = CondCfg<NV, NU, NF, NS, SPLIT>;
+  constexpr bool TAIL = C::TAIL;
   constexpr int NT = C::NT, NW = C::NW;
   constexpr int NX = 2 * NV, NP = NV - NU, LDV = C::LDV, LDF = C::NFP, LDS_ = NS > 0 ? NS : 1;
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -326,7 +339,8 @@ __global__ __launch_bounds__(64 * RTOC_COND_NW) void condense_kernel(CondArgs a)
   double* const sJM = smem + C::O_JM;
   double* const sS = smem + C::O_S;
   double* const sBR = smem + C::O_BR;
-  double* const Qafu = smem + C::O_QAFU;
+  double* const Qafu = smem + C::O_QAFU;                               // passive columns first (all of it unless TAIL)
+  double* const QafuU = TAIL ? Lam + NV * LDV : Qafu + (NV - NU) * LDV;  // actuated columns
   double* const Qff = smem + C::O_QFF;
   double* const Qqf = smem + C::O_QQF;
   double* const IDC = smem + C::V_IDC;
@@ -522,8 +536,10 @@ __global__ __launch_bounds__(64 * RTOC_COND_NW) void condense_kernel(CondArgs a)
   wave_gemv<NT>(LDV, LDV, 1.0, Lam, 1, LDV, IDC, 0.0, Lr, lane);  // full extents: zero rows give Lr = 0 there
   __syncthreads();  // D (and J inside it) is dead from here on: its space becomes Qafqv; region X becomes Qafu
   for (int e = lane; e < LDV * NX; e += NT) Qafqv[e] = 0.0;
-  if (!impact)
-    for (int e = lane; e < LDV * NV; e += NT) Qafu[e] = 0.0;
+  if (!impact) {
+    for (int e = lane; e < LDV * NP; e += NT) Qafu[e] = 0.0;
+    for (int e = lane; e < LDV * NU; e += NT) QafuU[e] = 0.0;
+  }
   __syncthreads();
 
   RTOC_CPROF(5);
@@ -535,7 +551,7 @@ __global__ __launch_bounds__(64 * RTOC_COND_NW) void condense_kernel(CondArgs a)
   if (!impact)
     for (int e = lane; e < NV * NV; e += NT) {
       const int i = e % NV, j = e / NV;
-      Qafu[i + j * LDV] = Qaa[i] * Lam[i + j * LDV];
+      (j < NP ? Qafu + j * LDV : QafuU + (j - NP) * LDV)[i] = Qaa[i] * Lam[i + j * LDV];
     }
   if (lane < NV) laf[lane] -= Qaa[lane] * Lr[lane];
   if (nf > 0) {
@@ -545,7 +561,9 @@ __global__ __launch_bounds__(64 * RTOC_COND_NW) void condense_kernel(CondArgs a)
     });
     if (!impact)
       lds_gemm<NW, C::NFP, NV, C::NFP, 1, LDF, 1, LDV>(Qff, Lam + NV, lane,
-                                                       [&](int r, int c, double v, int, int) { Qafu[(NV + r) + c * LDV] = v; });
+                                                       [&](int r, int c, double v, int, int) {
+                                                         (c < NP ? Qafu + c * LDV : QafuU + (c - NP) * LDV)[NV + r] = v;
+                                                       });
     if (lane < nf) {
       double acc = 0.0;
       for (int k = 0; k < nf; ++k) acc += Qff[lane + k * LDF] * Lr[NV + k];
@@ -605,21 +623,33 @@ __global__ __launch_bounds__(64 * RTOC_COND_NW) void condense_kernel(CondArgs a)
       lds_gemm2<NW, NX, NP, LDV, LDV, 1, 1, LDV, NV, C::NFP, 1, NV, 1, LDV>(
           LD, Qafu, Qqf, Lam + NV, nf > 0, lane,
           [&](int r, int c, double v1, double v2, int, int) { Qxup[r + (size_t)c * NX] = -v1 - v2; });
-      lds_gemm<NW, NP, NU, LDV, 1, LDV, 1, LDV>(Lam, Qafu + NP * LDV, lane, [&](int r, int c, double v, int, int) {
-        Quuptr[r + (size_t)c * NP] = v;
-      });
+      if constexpr (!TAIL) {
+        lds_gemm<NW, NP, NU, LDV, 1, LDV, 1, LDV>(Lam, QafuU, lane, [&](int r, int c, double v, int, int) {
+          Quuptr[r + (size_t)c * NP] = v;
+        });
+      } else {  // MJtJinv[p, nv:] through its mirror image MJtJinv[nv:, p]
+        lds_gemm2<NW, NP, NU, NV, 1, LDV, 1, LDV, NP, C::NFP, LDV, 1, 1, LDV>(
+            Lam, QafuU, Lam + NV, QafuU + NV, nf > 0, lane,
+            [&](int r, int c, double v1, double v2, int, int) { Quuptr[r + (size_t)c * NP] = v1 + v2; });
+      }
     }
     RTOC_CPROF(11);
     lds_gemm2<NW, NX, NU, LDV, LDV, 1, 1, LDV, NV, C::NFP, 1, NV, 1, LDV>(
-        LD, Qafu + NP * LDV, Qqf, Lam + NV + NP * LDV, nf > 0, lane,
+        LD, QafuU, Qqf, Lam + NV + NP * LDV, nf > 0, lane,
         [&](int r, int c, double v1, double v2, int slot, int reg) {
           Qxu[r + (size_t)c * NX] = cQxu[slot][reg] - v1 - v2;
         });
-    lds_gemm<NW, NU, NU, LDV, 1, LDV, 1, LDV>(Lam + NP, Qafu + NP * LDV, lane,
-                                              [&](int r, int c, double v, int slot, int reg) {
-                                                Quu[r + (size_t)c * NU] =
-                                                    (cQuu[slot][reg] + (r == c ? sPH[2 * NV + r] : 0.0)) + v;
-                                              });
+    if constexpr (!TAIL) {
+      lds_gemm<NW, NU, NU, LDV, 1, LDV, 1, LDV>(Lam + NP, QafuU, lane, [&](int r, int c, double v, int slot, int reg) {
+        Quu[r + (size_t)c * NU] = (cQuu[slot][reg] + (r == c ? sPH[2 * NV + r] : 0.0)) + v;
+      });
+    } else {
+      lds_gemm2<NW, NU, NU, NV, 1, LDV, 1, LDV, NU, C::NFP, LDV, 1, 1, LDV>(
+          Lam + NP, QafuU, Lam + NV + NP * LDV, QafuU + NV, nf > 0, lane,
+          [&](int r, int c, double v1, double v2, int slot, int reg) {
+            Quu[r + (size_t)c * NU] = (cQuu[slot][reg] + (r == c ? sPH[2 * NV + r] : 0.0)) + (v1 + v2);
+          });
+    }
   }
   RTOC_CPROF(12);
   // gradients: one lane per entry, every term of an entry in the same lane (:110-113,:123-130,:156-163);
@@ -660,7 +690,7 @@ __global__ __launch_bounds__(64 * RTOC_COND_NW) void condense_kernel(CondArgs a)
     double al[4] = {0.0, 0.0, 0.0, 0.0}, ah[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int k = 0; k < LDV; ++k) {
-      const double lm = Lam[i + k * LDV];
+      const double lm = (TAIL && k >= NV) ? Lam[k + i * LDV] : Lam[i + k * LDV];  // (TAIL: the exact mirror image)
       al[k & 3] += lm * laf[k];
       ah[k & 3] += lm * haf[k];
     }
@@ -718,7 +748,13 @@ __global__ __launch_bounds__(64 * RTOC_COND_NW) void condense_kernel(CondArgs a)
   copy_s2g_flat16<NT>(cr + CL.off[RTOC_CDD_MJD], LD, LDV * NX, lane);
   if (a.keep_qaf) {  // scratch of the reference's expandContactDynamicsDual; expand_kernel rebuilds what it needs of them
     copy_s2g_flat16<NT>(cr + CL.off[RTOC_CDD_QAFQV], Qafqv, LDV * NX, lane);
-    if (!impact) copy_s2g_flat16<NT>(cr + CL.off[RTOC_CDD_QAFU], Qafu, LDV * NV, lane);
+    if (!impact) {
+      if constexpr (!TAIL) {
+        copy_s2g_flat16<NT>(cr + CL.off[RTOC_CDD_QAFU], Qafu, LDV * NV, lane);
+      } else {
+        for (int e = lane; e < LDV * NV; e += NT) cr[CL.off[RTOC_CDD_QAFU] + e] = e < LDV * NP ? Qafu[e] : QafuU[e - LDV * NP];
+      }
+    }
   }
   if (lane < nvf) {
     cr[CL.off[RTOC_CDD_MJIDC] + lane] = Lr[lane];
@@ -743,16 +779,25 @@ struct MjCfg {
   static constexpr int O_J = O_L + pad8(NV * NV);
   static constexpr int O_JM = O_J + pad8(NFP * NV);
   static constexpr int O_S = O_JM + pad8(NFP * NV);
-  static constexpr int O_BR = O_S + pad8(NFP * NFP);
-  static constexpr int O_LD = O_BR + pad8(NFP * NFP);  // scratch the fragment borrows on fixed-base sets
+  // bottomRight is born when the factor of M is dead and the inverse factor of S (NFP x NFP) sits at the head of that
+  // region: it takes the doubles behind it when they are there (ANYmal: 15.6 -> 14.4 KB = 12 LDS granules, ten work
+  // items per CU)
+  static constexpr bool BR_IN_L = NF > 0 && NFP <= 16 && 2 * pad8(NFP * NFP) <= pad8(NV * NV);
+  static constexpr int O_BR = BR_IN_L ? O_L + pad8(NFP * NFP) : O_S + pad8(NFP * NFP);
+  static constexpr int Y_ROOM = (BR_IN_L ? O_S : O_BR) + pad8(NFP * NFP) - O_JM;
+  static constexpr int O_LD = O_S + pad8(NFP * NFP) + (BR_IN_L ? 0 : pad8(NFP * NFP));  // scratch the fragment borrows on fixed-base sets
   static constexpr int V_LINV = O_LD + (NF == 0 ? pad8(LDV * NX > NV * NV ? LDV * NX : NV * NV) : 0);
   static constexpr int V_SINV = V_LINV + pad8(NV);
   static constexpr int LDS_DOUBLES = V_SINV + pad8(NFP);
   static constexpr int LDS_BYTES = LDS_DOUBLES * 8;
+  // one wave per work item: work items per CU by LDS -> waves per SIMD the register budget should allow (at most 3:
+  // the factorisations want their ~170 registers)
+  static constexpr int ITEMS = 128 / ((LDS_BYTES + 1279) / 1280);
+  static constexpr int MIN_WAVES = (ITEMS + 3) / 4 >= 3 ? 3 : ((ITEMS + 3) / 4 >= 2 ? 2 : 1);
 };
 
 template <int NV, int NU, int NF, int NS>
-__global__ __launch_bounds__(64) void mjtjinv_kernel(CondArgs a) {
+__global__ __launch_bounds__(64, (MjCfg<NV, NF>::MIN_WAVES)) void mjtjinv_kernel(CondArgs a) {
   using C = MjCfg<NV, NF>;
   constexpr int NT = 64, NW = 1, NX = 2 * NV, LDV = C::LDV, LDF = C::NFP;
   extern __shared__ __attribute__((aligned(16))) double smem[];

@@ -58,7 +58,7 @@ struct KernelSet {
   cond_fn cond;
   cond_fn cond_split, mjt;  // split condensation: MJtJinv kernel + the rest
   int mjt_lds;
-  int cond_threads, cond_lds;
+  int cond_threads, cond_lds, cond_split_lds;
   expd_fn expd;
   int expd_threads;
   // horizon scan of the backward recursion (riccati_scan.hpp)
@@ -128,6 +128,7 @@ inline KernelSet make_set() {
   k.mjt_lds = MjCfg<NV, NF>::LDS_BYTES;
   k.cond_threads = CondCfg<NV, NU, NF, NS>::NT;
   k.cond_lds = CondCfg<NV, NU, NF, NS>::LDS_BYTES;
+  k.cond_split_lds = CondCfg<NV, NU, NF, NS, true>::LDS_BYTES;
   k.expd = expand_kernel<NV, NU, NF, NS>;
   k.expd_threads = 64;
   k.scan_elt = scan_element_kernel<NV, NU, NS>;

@@ -301,7 +301,7 @@ static int create_members(rtoc_ctx* c, const rtoc_dims* dims, const KernelSet* k
   HIP_TRY(hipFuncSetAttribute((const void*)ks->cond, hipFuncAttributeMaxDynamicSharedMemorySize,
                               ks->cond_lds));
   HIP_TRY(hipFuncSetAttribute((const void*)ks->cond_split, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              ks->cond_lds));
+                              ks->cond_split_lds));
   HIP_TRY(hipFuncSetAttribute((const void*)ks->mjt, hipFuncAttributeMaxDynamicSharedMemorySize, ks->mjt_lds));
   HIP_TRY(hipFuncSetAttribute((const void*)ks->scan_elt, hipFuncAttributeMaxDynamicSharedMemorySize,
                               ks->scan_elt_lds));
@@ -890,7 +890,7 @@ static int launch_condense(rtoc_ctx* c) {
   }
   if (c->condense_split) {
     hipLaunchKernelGGL(c->ks->mjt, dim3(nblocks), dim3(64), c->ks->mjt_lds, c->stream, a);
-    hipLaunchKernelGGL(c->ks->cond_split, dim3(nblocks), dim3(c->ks->cond_threads), c->ks->cond_lds, c->stream, a);
+    hipLaunchKernelGGL(c->ks->cond_split, dim3(nblocks), dim3(c->ks->cond_threads), c->ks->cond_split_lds, c->stream, a);
   } else {
     hipLaunchKernelGGL(c->ks->cond, dim3(nblocks), dim3(c->ks->cond_threads), c->ks->cond_lds, c->stream, a);
   }
