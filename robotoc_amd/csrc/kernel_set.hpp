@@ -129,6 +129,10 @@ inline KernelSet make_set() {
   k.cond_threads = CondCfg<NV, NU, NF, NS>::NT;
   k.cond_lds = CondCfg<NV, NU, NF, NS>::LDS_BYTES;
   k.cond_split_lds = CondCfg<NV, NU, NF, NS, true>::LDS_BYTES;
+  // regression guard for the occupancy the quadruped shape is sized for (condense.hpp: five / ten work items per CU)
+  static_assert(!(NV == 18 && NU == 12 && NS == 12) ||
+                    (CondCfg<NV, NU, NF, NS, true>::ITEMS >= 5 && CondCfg<NV, NU, NF, NS, true>::MIN_WAVES == 4 && MjCfg<NV, NF>::ITEMS >= 10),
+                "LDS carve of the split condensation grew past its granule budget");
   k.expd = expand_kernel<NV, NU, NF, NS>;
   k.expd_threads = 64;
   k.scan_elt = scan_element_kernel<NV, NU, NS>;
