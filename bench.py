@@ -26,7 +26,22 @@ if ROOT not in sys.path:
 PER_GPU_BATCH = 4096
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 F64_MFMA_PEAK_TFLOPS = 78.6  # MI355X spec sheet, dense fp64 matrix (= the fp64 vector rate)
-PROFILE_ROUND = "r02"
+PROFILE_ROUND = "r03"
+
+
+def kernel_source_hash():
+    """sha256 over the kernel sources the library is built from (robotoc_amd/csrc/*.hpp|*.inc|*.hip, include/*.h): the
+    committed counter passes (profiles/<round>_traffic.json, written by tools/pmc_driver.py) carry the hash of the sources
+    they profiled, and a pass taken from other sources is refused (traffic = null) instead of silently going stale."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "robotoc_amd", "csrc", "*.hpp")) + glob.glob(os.path.join(ROOT, "robotoc_amd", "csrc", "*.inc"))
+                   + glob.glob(os.path.join(ROOT, "robotoc_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "include", "*.h")))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def algorithmic_bytes(L, grids, batch, which):
@@ -157,10 +172,24 @@ def pmc_traffic(kernel_substr):
     path = os.path.join(ROOT, "profiles", "%s_traffic.json" % PROFILE_ROUND)
     if not os.path.exists(path):
         return None
-    for k, v in json.load(open(path)).items():
-        if kernel_substr in k:
+    table = json.load(open(path))
+    if table.get("_kernel_source_hash") != kernel_source_hash():
+        return None   # counters of other kernel sources: stale (traffic_source says so)
+    for k, v in table.items():
+        if not k.startswith("_") and kernel_substr in k:
             return v["hbm_bytes"]
     return None
+
+
+def traffic_state():
+    path = os.path.join(ROOT, "profiles", "%s_traffic.json" % PROFILE_ROUND)
+    if not os.path.exists(path):
+        return "no committed counter pass for this round: traffic null"
+    ok = json.load(open(path)).get("_kernel_source_hash") == kernel_source_hash()
+    return ("profiles/%s_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs) of the same kernels at the same "
+            "sizes (tools/gpu_pmc2.sh -> tools/pmc_driver.py), kernel-source hash %s %s" % (
+                PROFILE_ROUND, kernel_source_hash(), "matches the library's sources" if ok else
+                "DOES NOT match the sources of this library: refused as stale, traffic null"))
 
 
 def cpu_baseline(L, grids, dims, budget_s=8.0):
@@ -349,6 +378,35 @@ def closed_loop_trot(local_rank, batch, iters=30, timed=10):
     return out
 
 
+def dry_run(args, rank, world):
+    """The multi-rank plumbing of this file without a GPU: rendezvous (gloo), barrier + max-over-ranks timing, the
+    all-gather of (dummy) direction records through robotoc_amd.sharding, one JSON line from rank 0."""
+    import torch
+    import torch.distributed as dist
+    from robotoc_amd.sharding import gather_directions
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    batch = 3
+    local = torch.full((batch, 2, 4), float(rank), dtype=torch.float64)
+    t0 = time.perf_counter()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    full = gather_directions(local, world * batch, world, rank)
+    ok = full.shape[0] == world * batch and all(float(full[r * batch, 0, 0]) == float(r) for r in range(world))
+    if rank == 0:
+        print(json.dumps({"metric": "riccati_sweeps_per_sec", "dry_run": True, "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "gather_ok": bool(ok), "value": None}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -359,7 +417,24 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sqp", action="store_true", help="skip the SQP-iteration phase timing")
     ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE.json configurations")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / rendezvous / gather plumbing only, no GPU work (tests/test_bench_launcher.py)")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` launches its N ranks itself (one process per GPU under torch.distributed.run); when the
+    # driver has already done so (WORLD_SIZE in the environment) this process IS one of the ranks.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        import subprocess
+        s_ = socket.socket()
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+        s_.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        sys.exit(subprocess.call(cmd, env=env))
 
     import torch
     import torch.distributed as dist
@@ -367,6 +442,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise RuntimeError("--gpus %d but WORLD_SIZE=%d: launch one rank per GPU" % (args.gpus, world))
+    if args.dry_run:
+        return dry_run(args, rank, world)
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs a GPU: the hot path has no CPU fallback")
     if os.environ.get("RTOC_BENCH_ONE_DEVICE") == "1":
@@ -419,11 +498,20 @@ def main():
     for _ in range(args.warmup):
         step()
     sync_all()
+    # HIP events on the launch stream (the context runs on torch's current stream: ctx.set_stream above) INSIDE the timed
+    # region, so that the kernel times reported under `roofline` are those of exactly the launches `ms_per_step` covers
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for k in range(args.steps):
+        ev[k][0].record(stream)
+        ctx.riccati_backward()
+        ev[k][1].record(stream)
+        ctx.riccati_forward()
+        ev[k][2].record(stream)
     sync_all()
     dt = time.perf_counter() - t0
+    ms_b = sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps
+    ms_f = sum(e[1].elapsed_time(e[2]) for e in ev) / args.steps
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -445,15 +533,23 @@ def main():
     copy_gbs = 5 * 2 * src.numel() * 8 / (e0.elapsed_time(e1) * 1e-3) / 1e9
     del src, dst
 
-    # dominant kernel (backward) and forward timed with HIP events on the launch stream
-    ms_b = ctx.time_phase(0, max(3, args.steps // 2))
-    ms_f = ctx.time_phase(1, max(3, args.steps // 2))
-    gathered_ok = None
+    gathered_ok, gathered_c_ok = None, None
     if world > 1:
-        from robotoc_amd.sharding import gather_directions
+        # the one exchange step: all-gather of the step directions, through torch.distributed (RCCL) and through
+        # the C ABI's rtoc_gather_directions on an ncclComm_t of its own (what a C++ host calls)
+        from robotoc_amd.sharding import RcclComm, gather_directions
         full = gather_directions(dir_t, world * batch, world, rank)
         torch.cuda.synchronize()
         gathered_ok = bool(full.shape[0] == world * batch and torch.isfinite(full).all().item())
+        if dist.get_backend() == "nccl":
+            comm = RcclComm(world, rank)
+            out_c = torch.full((world,) + tuple(dir_t.shape), float("nan"), dtype=torch.float64, device=dev)
+            ctx.gather_directions(comm.handle, out_c.data_ptr())
+            ctx.sync()
+            torch.cuda.synchronize()
+            gathered_c_ok = bool(torch.equal(out_c.reshape(full.shape), full))
+            comm.close()
+        del full
 
     # ---- SQP-iteration hot path on pre-condensation stage data of `batch` distinct instances:
     #      rtoc_newton_iteration (KKT error -> condense -> backward -> forward -> expand -> step sizes ->
@@ -762,8 +858,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(kname) if batch == PER_GPU_BATCH else None,
-                         "traffic_source": "profiles/%s_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same kernels at the "
-                                           "same sizes (tools/gpu_pmc2.sh), committed with the round; not collected inside this run" % PROFILE_ROUND,
+                         "traffic_source": traffic_state(),
                          "measured_copy_GBs": copy_gbs, "frac_of_measured_copy": ach / copy_gbs,
                          "kernel": kname, "kernel_ms": ms_b,
                          "algorithmic_bytes_per_launch": bytes_b,
@@ -788,6 +883,8 @@ def main():
             res["other_configs"] = others
         if gathered_ok is not None:
             res["rccl_gather_ok"] = gathered_ok
+            res["rccl_gather_c_abi_ok"] = gathered_c_ok   # null: gloo functional test (RCCL refuses two ranks on one device)
+            res["gather_backend"] = dist.get_backend()
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(L, grids, dims)
         print(json.dumps(res))

@@ -323,6 +323,9 @@ int rtoc_integrate_solution(rtoc_ctx* ctx);
  * RTOC_BUF_SOL exists).  Needs dx0 (RTOC_BUF_DX0) like rtoc_riccati_forward.  The caller re-linearises
  * (CPU side) and uploads before the next iteration. */
 int rtoc_newton_iteration(rtoc_ctx* ctx, double kkt_tol, double fraction_to_boundary_rule);
+/* How often RTOC_OPT_GRAPH has replayed a captured hipGraph (rtoc_riccati_sweep + rtoc_newton_iteration) on this
+ * context: diagnostics, and what the tests assert instead of assuming a replay happened. */
+int rtoc_graph_replay_count(rtoc_ctx* ctx, unsigned long long* out);
 /* Number of instances the last rtoc_newton_iteration found converged (synchronises). */
 int rtoc_converged_count(rtoc_ctx* ctx, int* host_count);
 

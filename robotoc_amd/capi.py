@@ -30,6 +30,7 @@ EXPORTS = [
     "rtoc_line_search_filter", "rtoc_line_search_clear", "rtoc_set_configuration_cost", "rtoc_set_initial_state",
     "rtoc_unconstr_eval_kkt", "rtoc_unconstr_update_solution", "rtoc_set_constraint_bounds", "rtoc_unconstr_init_constraints", "rtoc_linearize_state_equation", "rtoc_contact_eval_kkt", "rtoc_contact_update_solution",
     "rtoc_set_barrier_param", "rtoc_set_friction_coefficients", "rtoc_contact_init_constraints", "rtoc_set_wrench_cone_params",
+    "rtoc_graph_replay_count",
 ]
 
 
@@ -150,6 +151,7 @@ def lib():
         L.rtoc_linearize_contact_dynamics.argtypes = [vp, C.c_int]
         L.rtoc_set_contact_schedule.argtypes = [vp, C.POINTER(C.c_uint), dp, dp]
         L.rtoc_load_stage_dump.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
+        L.rtoc_graph_replay_count.argtypes = [vp, C.POINTER(C.c_ulonglong)]
         L.rtoc_error_string.argtypes = [C.c_int]
         L.rtoc_error_string.restype = C.c_char_p
         _LIB = L
@@ -304,6 +306,11 @@ class Context:
         out = np.zeros(self.batch)
         _chk(lib().rtoc_sto_eval_kkt(self._h, _dp(lt), _dp(qtt_diag), lt.shape[1], _dp(out), self.batch))
         return out
+
+    def graph_replay_count(self):
+        n = C.c_ulonglong()
+        _chk(lib().rtoc_graph_replay_count(self._h, C.byref(n)))
+        return int(n.value)
 
     def set_graph(self, on):
         """RTOC_OPT_GRAPH: replay rtoc_riccati_sweep / rtoc_newton_iteration from captured hipGraphs."""
@@ -505,6 +512,12 @@ class Context:
 
     def sync(self):
         _chk(lib().rtoc_sync(self._h))
+
+    def gather_directions(self, nccl_comm, out_device_ptr):
+        """rtoc_gather_directions: RCCL all-gather of RTOC_BUF_DIR of every rank into device memory of
+        world_size * buffer_count(BUF_DIR) doubles; nccl_comm: ncclComm_t as an int / c_void_p."""
+        _chk(lib().rtoc_gather_directions(self._h, C.c_void_p(nccl_comm if isinstance(nccl_comm, int) else nccl_comm.value),
+                                          C.cast(C.c_void_p(out_device_ptr), C.POINTER(C.c_double))))
 
     def time_phase(self, phase, reps):
         ms = C.c_float()

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -116,8 +117,14 @@ static bool model_has_surface_contacts(const rtoc_robot_model& m) {
     if (m.contact_type[k] == RTOC_CONTACT_SURFACE) return true;
   return false;
 }
+// hipFuncAttributeMaxDynamicSharedMemorySize is per function and process-wide, not per context: two live contexts with
+// different models (iCub: 11 tree levels, ANYmal: 4) share it, so it only ever grows (the launch passes its own size)
 static hipError_t set_linearize_lds(const rtoc_robot_model& m, int nlevels) {
-  const int bytes = (int)rbd::lin_lds_bytes(nlevels, m.njoints, m.ncontacts, m.nv);
+  static std::mutex mu;
+  static int max_bytes = 0;
+  std::lock_guard<std::mutex> lock(mu);
+  int bytes = (int)rbd::lin_lds_bytes(nlevels, m.njoints, m.ncontacts, m.nv);
+  if (bytes <= max_bytes) return hipSuccess;
   hipError_t e = hipFuncSetAttribute((const void*)rbd::linearize_contact_dynamics_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   if (e == hipSuccess)
     e = hipFuncSetAttribute((const void*)rbd::linearize_contact_dynamics_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -127,6 +134,7 @@ static hipError_t set_linearize_lds(const rtoc_robot_model& m, int nlevels) {
     e = hipFuncSetAttribute((const void*)rbd::linearize_contact_dynamics_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   if (e == hipSuccess)
     e = hipFuncSetAttribute((const void*)rbd::rbd_values_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * rbd::VAL_SLOTS * (int)sizeof(double));
+  if (e == hipSuccess) max_bytes = bytes;
   return e;
 }
 
@@ -162,7 +170,9 @@ struct rtoc_ctx {
   int condense_split;  // 1: MJtJinv in its own kernel ahead of the condensation
   int keep_qaf;        // RTOC_OPT_CONDENSE_KEEP_QAF
   int fxx_mode;        // RTOC_OPT_FXX_STRUCTURE: 0 auto, 1 dense, 2 caller asserts the structure
-  int fxx_state;       // auto mode cache: 0 unknown, 1 every Fxx structured, 2 not
+  int fxx_state;       // auto mode cache: 0 unknown (re-check before the next backward recursion), 1 every Fxx structured, 2 not
+  int fxx_last;        // the last check's answer (1 / 2; 0 never checked): the kernel choice baked into captured graphs
+  unsigned long long graph_replays;  // hipGraphLaunch count of RTOC_OPT_GRAPH (rtoc_graph_replay_count)
   int* d_fxx_flag;
   double* d_sto;       // rtoc_sto_eval_kkt staging: lt, diag(Qtt), squared error
   // RTOC_OPT_GRAPH: launch sequences replayed from captured hipGraphs
@@ -172,6 +182,7 @@ struct rtoc_ctx {
   int exact_cone_jacobian;  // RTOC_OPT_CONE_JACOBIAN
   int impact_cones;     // RTOC_OPT_IMPACT_CONES (default 1, rtoc_create)
   double* d_mu;         // rtoc_set_friction_coefficients
+  int n_mu;             // how many of its RTOC_MAX_CONTACTS entries the caller set
   double* d_wcone;      // rtoc_set_wrench_cone_params: [RTOC_MAX_CONTACTS][17 x 6]
   double *d_vals, *d_vals2;  // rbd_values_kernel -> linearize_contact_dynamics_kernel<.., PRE>: [batch * max_stages][njoints][64]
   size_t vals_cap;
@@ -438,6 +449,7 @@ int rtoc_clone(rtoc_ctx* c, rtoc_ctx** out) {
   dup((void**)&n->d_x0, c->d_x0, sizeof(double) * c->batch * (2 * c->dims.nv + (c->dims.np == 6 ? 1 : 0)));
   dup((void**)&n->d_bounds, c->d_bounds, sizeof(double) * c->dims.nc_max);
   dup((void**)&n->d_mu, c->d_mu, sizeof(double) * RTOC_MAX_CONTACTS);
+  n->n_mu = c->n_mu;
   dup((void**)&n->d_wcone, c->d_wcone, sizeof(double) * RTOC_MAX_CONTACTS * RTOC_WRENCH_ROWS * 6);
   n->barrier = c->barrier, n->ftb_rule = c->ftb_rule;
   if (c->d_filter) {
@@ -604,6 +616,7 @@ int rtoc_upload(rtoc_ctx* c, int buffer, size_t offset, const double* host, size
                          c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   if (buffer == RTOC_BUF_KKT) c->fxx_state = 0;  // re-checked by the next backward recursion (RTOC_OPT_FXX_STRUCTURE)
+  if (buffer == RTOC_BUF_SOL) c->vals_fresh = 0;  // the pre-pass kinematics belong to the previous iterate
   return RTOC_OK;
 }
 
@@ -737,11 +750,14 @@ static int check_fxx(rtoc_ctx* c) {
   int bad = 1;
   HIP_TRY(hipMemcpyAsync(&bad, c->d_fxx_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
-  if (c->fxx_state != (bad ? 2 : 1)) c->epoch++;  // the kernel choice of the backward recursion is part of a captured graph
-  c->fxx_state = bad ? 2 : 1;
+  // the kernel choice of the backward recursion is part of a captured graph: a new epoch only when the ANSWER changes, not
+  // whenever the records were re-uploaded (the documented loop re-linearises and uploads before every iteration)
+  if (c->fxx_last != (bad ? 2 : 1)) c->epoch++;
+  c->fxx_state = c->fxx_last = bad ? 2 : 1;
   return RTOC_OK;
 }
 static bool fxx_structured(rtoc_ctx* c) {
+  if (!c->ks->bwd_sa || c->bwd_variant != 3) return false;  // no structured kernel for this shape / variant: nothing to check
   if (c->fxx_mode == 1) return false;
   if (c->fxx_mode == 2) return true;
   if (c->fxx_state == 0 && check_fxx(c) != RTOC_OK) return false;
@@ -765,7 +781,7 @@ static int launch_backward_range(rtoc_ctx* c, int first, int end, hipStream_t st
   a.max_dts0 = c->max_dts0;
   const int v = c->bwd_variant;
   const int ni = c->ks->bwd_inst[v];
-  const bwd_fn kern = (v == 3 && c->ks->bwd_sa && fxx_structured(c)) ? c->ks->bwd_sa : c->ks->bwd[v];
+  const bwd_fn kern = fxx_structured(c) ? c->ks->bwd_sa : c->ks->bwd[v];
   hipLaunchKernelGGL(kern, dim3((end - first + ni - 1) / ni), dim3(64 * c->ks->bwd_waves[v]), c->ks->bwd_lds[v], stream, a);
   HIP_TRY(hipGetLastError());
   return RTOC_OK;
@@ -1039,6 +1055,7 @@ static int run_graphed(rtoc_ctx* c, rtoc_ctx::GraphSlot* g, double p0, double p1
   (void)fxx_structured(c);  // may check the records (synchronises): before, never inside, a capture
   if (g->exec && g->epoch == c->epoch && g->p0 == p0 && g->p1 == p1) {
     HIP_TRY(hipGraphLaunch(g->exec, c->stream));
+    c->graph_replays++;
     return RTOC_OK;
   }
   if (!(g->warm && g->warm_epoch == c->epoch)) {
@@ -1071,9 +1088,16 @@ static int run_graphed(rtoc_ctx* c, rtoc_ctx::GraphSlot* g, double p0, double p1
   g->p0 = p0;
   g->p1 = p1;
   HIP_TRY(hipGraphLaunch(g->exec, c->stream));
+  c->graph_replays++;
   return RTOC_OK;
 }
 }  // extern "C++"
+
+int rtoc_graph_replay_count(rtoc_ctx* c, unsigned long long* out) {
+  if (!c || !out) return RTOC_ERR_BAD_ARG;
+  *out = c->graph_replays;
+  return RTOC_OK;
+}
 
 int rtoc_riccati_sweep(rtoc_ctx* c) {
   CHECK_READY(c);
@@ -1682,8 +1706,9 @@ static int launch_state_equation(rtoc_ctx* c, bool zeroed) {
   a.zeroed = zeroed ? 1 : 0;
   hipLaunchKernelGGL(state_equation_lin_kernel, dim3(c->batch * c->nstages), dim3(64), 0, c->stream, a);
   HIP_TRY(hipGetLastError());
-  if (zeroed && c->fxx_state == 2) c->epoch++;  // the kernel choice of the backward recursion is part of a captured graph
+  if (zeroed && c->fxx_last != 1) c->epoch++;  // the kernel choice of the backward recursion is part of a captured graph
   c->fxx_state = zeroed ? 1 : 0;
+  if (zeroed) c->fxx_last = 1;
   return RTOC_OK;
 }
 
@@ -1838,8 +1863,11 @@ int rtoc_set_friction_coefficients(rtoc_ctx* c, const double* mu, int ncontacts)
     if (!(mu[i] > 0.0)) return RTOC_ERR_BAD_ARG;   // ContactStatus::setFrictionCoefficient
   HIP_TRY(hipSetDevice(c->device));
   if (!c->d_mu) HIP_TRY(hipMalloc((void**)&c->d_mu, sizeof(double) * RTOC_MAX_CONTACTS));
-  HIP_TRY(hipMemcpyAsync(c->d_mu, mu, sizeof(double) * ncontacts, hipMemcpyHostToDevice, c->stream));
+  double full[RTOC_MAX_CONTACTS] = {0.0};
+  memcpy(full, mu, sizeof(double) * ncontacts);
+  HIP_TRY(hipMemcpyAsync(c->d_mu, full, sizeof(full), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
+  c->n_mu = ncontacts;
   return RTOC_OK;
 }
 
@@ -1888,6 +1916,7 @@ static int launch_wrench_cones(rtoc_ctx* c, int mode) {
 static int launch_contact_cones(rtoc_ctx* c, int mode) {
   const rtoc_robot_model& m = c->h_model->m;
   if (m.ncontacts > c->cone_contacts) return RTOC_ERR_BAD_ARG;
+  if (c->n_mu < m.ncontacts) return RTOC_ERR_NOT_READY;  // a friction coefficient for every contact of the model
   for (int k = 0; k < m.ncontacts; ++k)
     if ((m.contact_type[k] == RTOC_CONTACT_SURFACE ? 6 : 3) != c->cone_dim) return RTOC_ERR_BAD_ARG;
   CcArgs a;
@@ -2011,6 +2040,7 @@ int rtoc_contact_eval_kkt(rtoc_ctx* c) {
   if (!rc) rc = launch_state_equation(c, true);
   if (!rc) rc = launch_linearize(c, 1, false, 1.0);
   if (!rc && switching) rc = launch_switching_constraint(c);
+  if (rc) c->vals_fresh = 0;  // a failed sequence leaves no kinematics a later stand-alone linearisation may reuse
   return rc;
 }
 

@@ -98,6 +98,7 @@ class ConfigurationCostSource : public StageDataSource {
   }
   // computed on the device with the linearisation (state_equation.cpp:99-109, Fqq_prev_inv correction included)
   bool initialStateDirectionOnDevice() const override { return true; }
+  bool needsHostSolution() const override { return false; }
   void initialStateDirection(const Vec&, const Vec&, const Solution&, Vec&) const override {}
   void initialSolution(Solution& s) const override {
     for (size_t i = 0; i < s.size() && i < s0_.size(); ++i) s[i] = s0_[i];

@@ -47,7 +47,7 @@ struct SolverOptions {
   double mu_superlinear_decrease_power = 1.5;
   bool enable_line_search = false;
   double fraction_to_boundary_rule = 0.995;  // ConstraintComponentBase default (constraint_component_base.hpp)
-  int max_dt_mesh = 0;
+  double max_dt_mesh = 0.0;                  // solver_options.hpp:119
   bool enable_solution_interpolation = true;
   bool enable_benchmark = false;
   bool horizon_scan = false;  // not in the reference: RTOC_OPT_BACKWARD_SCAN for the single-OCP latency path
@@ -57,7 +57,7 @@ struct SolverOptions {
 struct SolverStatistics {
   bool convergence = false;
   int iter = 0;
-  std::vector<double> performance_index;  // KKT error per iteration (PerformanceIndex::kkt_error)
+  std::vector<double> performance_index;  // per iteration: PerformanceIndex::kkt_error, i.e. the SQUARED KKT error, in both solver shells
   std::vector<double> primal_step_size, dual_step_size;
   double cpu_time = 0.0;  // [ms], if SolverOptions::enable_benchmark
   void clear() { *this = SolverStatistics(); }
@@ -99,6 +99,9 @@ class StageDataSource {
   virtual void initialStateDirection(const Vec& q, const Vec& v, const Solution& s, Vec& dx0) const = 0;
   // true: linearize() already left computeInitialStateDirection's result in RTOC_BUF_DX0 (nothing to compute or upload here)
   virtual bool initialStateDirectionOnDevice() const { return false; }
+  // false: linearize() / initialStateDirection() never read their `s` argument (the source linearises at the iterate in
+  // RTOC_BUF_SOL on the device), so OCPSolver::updateSolution need not download the iterate before calling them
+  virtual bool needsHostSolution() const { return true; }
   virtual void initialSolution(Solution& s) const = 0;
 };
 
@@ -288,7 +291,8 @@ class DirectMultipleShooting {
     const size_t n = rtoc_buffer_count(ctx(), RTOC_BUF_CON);
     if (n == 0 || L_.dims.nc_max == 0) return true;
     std::vector<double> con(static_cast<size_t>(td.size()) * L_.con.stride);
-    if (rtoc_download(ctx(), RTOC_BUF_CON, 0, con.data(), con.size()) != RTOC_OK) return true;  // no constraint buffer yet
+    if (!rtoc_device_ptr(ctx(), RTOC_BUF_CON)) return true;  // no inequality rows on this context
+    chk(rtoc_download(ctx(), RTOC_BUF_CON, 0, con.data(), con.size()), "rtoc_download(RTOC_BUF_CON)");  // an error is an error, not "feasible"
     // rows that are never written stay zero; the active ones carry positive slacks
     for (int i = 0; i + 1 < td.size(); ++i)
       for (int r = 0; r < L_.dims.nc_max; ++r) {
@@ -443,6 +447,8 @@ class OCPSolver {
   void updateSolution(const double t, const Vec& q, const Vec& v) {
     (void)t;
     if (time_discretization_.size() < 2) discretize(t);
+    // the iterate lives in RTOC_BUF_SOL: a source that linearises on the host must see the current one, not the initial guess
+    if (ocp_.source->needsHostSolution()) syncSolution();
     dms_.evalKKT(time_discretization_, q, v, s_, kkt_matrix_, kkt_residual_);                  // :118
     // sto_.evalKKT(...)                                                                        // :119 (no STO problem here)
     riccati_recursion_.backwardRiccatiRecursionResident(time_discretization_);                  // :120
@@ -471,7 +477,7 @@ class OCPSolver {
     for (int iter = 0; iter < solver_options_.max_iter; ++iter) {
       updateSolution(t, q, v);
       const double kkt_error = KKTError();
-      solver_statistics_.performance_index.push_back(kkt_error);
+      solver_statistics_.performance_index.push_back(kkt_error * kkt_error);  // PerformanceIndex::kkt_error is the squared residual
       solver_statistics_.iter = iter + 1;
       if (kkt_error < solver_options_.kkt_tol) {  // :200-210
         solver_statistics_.convergence = true;

@@ -34,3 +34,46 @@ def gather_directions(local_dir, total, world, rank):
     out = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(out, pad.contiguous())
     return torch.cat([o[:n] for o, n in zip(out, sizes)], dim=0)
+
+
+class RcclComm:
+    """An ncclComm_t of this process's own (librccl through ctypes) for the C ABI's rtoc_gather_directions -- what a C++
+    host holds; torch.distributed keeps its communicator to itself.  Rank 0 draws the ncclUniqueId and the ranks exchange
+    it through the torch.distributed group that is already up.  One process per GPU, the device set beforehand."""
+
+    def __init__(self, world, rank):
+        import ctypes as C
+        import os
+
+        class _UniqueId(C.Structure):
+            _fields_ = [("internal", C.c_char * 128)]   # rccl.h: NCCL_UNIQUE_ID_BYTES
+
+        lib = None
+        for name in ("librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"):
+            try:
+                lib = C.CDLL(name, mode=os.RTLD_GLOBAL)
+                break
+            except OSError:
+                continue
+        if lib is None:
+            raise RuntimeError("librccl not found")
+        lib.ncclGetUniqueId.argtypes = [C.POINTER(_UniqueId)]
+        lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _UniqueId, C.c_int]
+        lib.ncclCommDestroy.argtypes = [C.c_void_p]
+        uid = _UniqueId()
+        if rank == 0 and lib.ncclGetUniqueId(C.byref(uid)) != 0:
+            raise RuntimeError("ncclGetUniqueId failed")
+        box = [bytes(bytearray(uid))]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0)
+            C.memmove(C.byref(uid), box[0], 128)
+        comm = C.c_void_p()
+        rc = lib.ncclCommInitRank(C.byref(comm), world, uid, rank)
+        if rc != 0:
+            raise RuntimeError("ncclCommInitRank failed: %d" % rc)
+        self._lib, self.handle = lib, comm.value
+
+    def close(self):
+        if self.handle:
+            self._lib.ncclCommDestroy(self.handle)
+            self.handle = None

@@ -65,11 +65,11 @@ int main(int argc, char** argv) {
     solver.solve(0.0, q, v, true);
     const SolverStatistics& st = solver.getSolverStatistics();
     std::printf("OCPSolver::solve, constrained trot on the device: KKT error %.3e -> %.3e in %d iterations, converged %d\n",
-                st.performance_index.front(), solver.KKTError(), st.iter, (int)st.convergence);
+                std::sqrt(st.performance_index.front()), solver.KKTError(), st.iter, (int)st.convergence);
     if (solver.status() != 0) return 5;
     const Solution& s = solver.getSolution();
     std::vector<double> out;
-    out.push_back(st.iter), out.push_back(st.convergence ? 1.0 : 0.0), out.push_back(solver.KKTError()), out.push_back(st.performance_index.front());
+    out.push_back(st.iter), out.push_back(st.convergence ? 1.0 : 0.0), out.push_back(solver.KKTError()), out.push_back(std::sqrt(st.performance_index.front()));
     for (int i = 0; i < n; ++i)
       for (int k = 0; k < nq; ++k) out.push_back(s[i].q(k));
     for (int i = 0; i < n; ++i)

@@ -221,11 +221,17 @@ def test_graph_replay_is_bit_identical(scan):
             for buf, which in ((BUF_DIR, "dir"), (BUF_CON, "con"), (BUF_SOL, "sol")):
                 assert np.array_equal(graph.download_records(buf, which), plain.download_records(buf, which)), (it, which)
             assert graph.converged_count() == plain.converged_count() == (batch if tol > 1 else 0)
+        # the records were re-uploaded before every iteration (the documented loop): the graph must have been REPLAYED all the
+        # same -- call 0 warms up, call 1 captures, 2 and 3 replay; the new tolerance re-captures at 4, then 5 and 6 replay
+        n_newton = graph.graph_replay_count()
+        assert n_newton >= 6, n_newton
         # the sweep alone, on the condensed records of the last iteration
         for it in range(4):
             plain.riccati_sweep()
             graph.riccati_sweep()
             assert np.array_equal(graph.download_records(BUF_DIR, "dir"), plain.download_records(BUF_DIR, "dir"))
+        assert graph.graph_replay_count() - n_newton >= 3   # warm-up, capture (+ launch), two replays
+        assert plain.graph_replay_count() == 0
         assert (graph.status() == 0).all()
     finally:
         plain.close()

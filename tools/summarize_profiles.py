@@ -42,7 +42,7 @@ for cname, d in (("FETCH_SIZE", "prof_fetch/fetch"), ("WRITE_SIZE", "prof_write/
         if "rtoc::" in k:
             short = k.split("(")[0].replace("void ", "")
             traffic.setdefault(short, {})["fetch_size_kb" if cname == "FETCH_SIZE" else "write_size_kb"] = m
-for k, v in traffic.items():
+for k, v in list(traffic.items()):
     v["hbm_bytes"] = (2.0 * v.get("fetch_size_kb", 0.0) + v.get("write_size_kb", 0.0)) * 1024.0
     v["note"] = "2*FETCH_SIZE (gfx950 correction, MI355X_MICROARCH.md HBM) + WRITE_SIZE (calibrated on a 295.7 MB torch fill: exact)"
 # SQ counter passes (tools/gpu_round2.sh): mean per dispatch and kernel
@@ -59,6 +59,9 @@ for d in ("prof_sq1/sq1", "prof_sq2/sq2"):
     for k, cs in acc.items():
         lines.append("%s: %s n=%d" % (k, ", ".join("%s=%.4g" % (c, sum(v) / len(v)) for c, v in cs.items()),
                                       len(next(iter(cs.values())))))
+sys.path.insert(0, R)
+import bench  # kernel_source_hash: bench.py refuses counter passes taken from other kernel sources
+traffic["_kernel_source_hash"] = bench.kernel_source_hash()
 open(os.path.join(DST, tag + "_rocprof_summary.txt"), "w").write("\n".join(lines) + "\n")
 json.dump(traffic, open(os.path.join(DST, tag + "_traffic.json"), "w"), indent=1)
 shutil.copy(os.path.join(OUT, "bench.json"), os.path.join(DST, tag + "_bench.json"))
