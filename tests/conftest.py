@@ -18,3 +18,47 @@ def oracle():
     from oracle import oracle as orc
     orc.lib()
     return orc
+
+
+@pytest.fixture(autouse=True)
+def _parity_scope(request):
+    import helpers
+    helpers.CURRENT_TEST[0] = request.node.nodeid
+    yield
+    helpers.CURRENT_TEST[0] = None
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """Observed parity errors of the run (tests/helpers.py: record_parity): per test the comparison that came closest to its
+    tolerance.  Printed under -q as well, so that the driver's log of a green run carries numbers, and written to
+    gpurun_out/parity_summary.json (merged back from the GPU box)."""
+    import json
+    import helpers
+    if not helpers.PARITY:
+        return
+    rows = []
+    for test, items in helpers.PARITY.items():
+        label, obs, tol = max(items, key=lambda it: it[1] / it[2] if it[2] > 0 else 0.0)
+        rows.append({"test": test, "checks": len(items), "closest": label.strip(), "observed": obs, "tolerance": tol,
+                     "worst_observed": max(it[1] for it in items), "loosest_tolerance": max(it[2] for it in items)})
+    rows.sort(key=lambda r: -(r["observed"] / r["tolerance"] if r["tolerance"] > 0 else 0.0))
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out_dir, exist_ok=True)
+        with open(os.path.join(out_dir, "parity_summary.json"), "w") as f:
+            json.dump(rows, f, indent=1)
+    except OSError:
+        pass
+    tr = terminalreporter
+    tr.write_line("")
+    tr.write_line("PARITY: %d tests registered %d comparisons (observed error / asserted tolerance; closest to its bound first)"
+                  % (len(rows), sum(r["checks"] for r in rows)))
+    for r in rows[:45]:
+        name = r["test"].split("tests/")[-1]
+        tr.write_line("  %-98s %9.2e / %7.0e  [%s]" % (name[:98], r["observed"], r["tolerance"], r["closest"][:40]))
+    if len(rows) > 45:
+        rest = rows[45:]
+        tr.write_line("  ... %d more tests, every one below %.1e of its tolerance" % (len(rest), max(r["observed"] / r["tolerance"] for r in rest)))
+    loose = [r for r in rows if r["observed"] > 0 and r["tolerance"] / r["observed"] > 1e3]
+    tr.write_line("PARITY: largest observed error %.2e; %d tests run more than 1000x inside their tolerance"
+                  % (max(r["worst_observed"] for r in rows), len(loose)))
