@@ -470,7 +470,10 @@ def main():
     ctx.set_grid(grids)
     if args.waves:
         ctx.set_backward_waves(args.waves)
-    stream = torch.cuda.current_stream()
+    # a stream of this process's own (torch's default stream has the null handle, which rtoc_set_stream reads as "the
+    # context's own stream"): the context launches on it and the torch events below are recorded on it
+    stream = torch.cuda.Stream(device=dev)
+    assert stream.cuda_stream != 0
     ctx.set_stream(stream.cuda_stream)
 
     def dev_records(which):
@@ -498,7 +501,7 @@ def main():
     for _ in range(args.warmup):
         step()
     sync_all()
-    # HIP events on the launch stream (the context runs on torch's current stream: ctx.set_stream above) INSIDE the timed
+    # HIP events on the launch stream (the stream handed to ctx.set_stream above) INSIDE the timed
     # region, so that the kernel times reported under `roofline` are those of exactly the launches `ms_per_step` covers
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
     t0 = time.perf_counter()

@@ -292,6 +292,47 @@ int rtoc_kkt_error(rtoc_ctx* ctx, double* host_out, int count);
 int rtoc_sto_eval_kkt(rtoc_ctx* ctx, const double* host_lt, const double* host_qtt_diag, int num_events,
                       double* host_err_sq, int count);
 
+/* ---- SwitchingTimeOptimization resident on the device (src/sto/switching_time_optimization.cpp, src/sto/sto_constraints.cpp) ----
+ * The batch shares the grid STRUCTURE (rtoc_set_grid: event order, grid points per phase -- DiscretizationMethod::PhaseBased,
+ * which OCPSolver selects whenever the OCP has an STO problem, ocp_solver.cpp:46-48); every instance owns its event times, hence
+ * its own time steps, dwell-time rows and switching-time step.
+ * rtoc_sto_set_problem: t0 = the `t` of OCPSolver::updateSolution, T = OCP::T, event_times = ContactSequence::impactTime /
+ * liftTime of the `num_events` <= 15 discrete events on the horizon in grid order ([num_events], or [batch][num_events] if
+ * per_instance), min_dwell_times[num_events + 1] / barrier_param / fraction_to_boundary_rule = the STOConstraints object
+ * (sto_constraints.cpp:12-59).  num_events must equal the number of impact + lift grid points of the grid; num_events == 0
+ * switches the STO problem off.  Once set:
+ *   - every kernel that reads GridInfo::dt reads the instance's own time step, recomputed from its event times by
+ *     rtoc_sto_correct_time_steps = TimeDiscretization::correctTimeSteps (time_discretization.cpp:179-221), which
+ *     rtoc_contact_eval_kkt calls first like updateSolution does (ocp_solver.cpp:115-117);
+ *   - rtoc_newton_iteration (and rtoc_contact_update_solution) run the STO half of updateSolution: rtoc_sto_eval_kkt_device
+ *     after the condensation (sto_.evalKKT :119 -- STO cost terms + regularisation, linearizeConstraints and
+ *     condenseSlackAndDual of the dwell-time rows, scatter into h / Qtt, STO term of the KKT error; rtoc_kkt_error's value
+ *     becomes OCPSolver::KKTError() = sqrt(dms + sto) :429-431), rtoc_sto_compute_step_sizes after the expansion
+ *     (sto_.computeStepSizes + min with the stages' step sizes :128-132), rtoc_sto_integrate_solution (:143: event times,
+ *     slack, dual).  The three are also callable on their own (a host that drives the iteration call by call).
+ * rtoc_sto_set_regularization: sto_.setRegularization (ocp_solver.cpp:169-176; the host owns the schedule).
+ * rtoc_sto_set_cost_terms: gradient / Hessian diagonal of an STOCostFunction evaluated by the host ([batch][num_events] each;
+ * NULL, NULL: none -- the reference ships no STO cost component, its examples pass an empty STOCostFunction).
+ * rtoc_sto_init_constraints: sto_.initConstraints (STOConstraints::setSlackAndDual, sto_constraints.cpp:148-172).
+ * Getters (synchronise): event times [count][num_events], time steps [count][nstages], the dwell-time rows' data
+ * [count][6][16] = slack, dual, residual, cmpl, dslack, ddual, and what the last evalKKT scattered (lt, diag Qtt, squared
+ * STO KKT term; any pointer may be NULL). */
+int rtoc_sto_set_problem(rtoc_ctx* ctx, double t0, double T, const double* event_times, int num_events, int per_instance,
+                         const double* min_dwell_times, double barrier_param, double fraction_to_boundary_rule);
+int rtoc_sto_set_regularization(rtoc_ctx* ctx, double sto_reg);
+int rtoc_sto_set_cost_terms(rtoc_ctx* ctx, const double* host_lt, const double* host_qtt_diag);
+int rtoc_sto_init_constraints(rtoc_ctx* ctx);
+/* slack / dual of the dwell-time rows from the host instead ([batch][num_events + 1] each, positive): a warm start */
+int rtoc_sto_set_slack_dual(rtoc_ctx* ctx, const double* host_slack, const double* host_dual);
+int rtoc_sto_correct_time_steps(rtoc_ctx* ctx);
+int rtoc_sto_eval_kkt_device(rtoc_ctx* ctx);
+int rtoc_sto_compute_step_sizes(rtoc_ctx* ctx);
+int rtoc_sto_integrate_solution(rtoc_ctx* ctx);
+int rtoc_sto_get_event_times(rtoc_ctx* ctx, double* host_out, int count);
+int rtoc_sto_get_time_steps(rtoc_ctx* ctx, double* host_out, int count);
+int rtoc_sto_get_constraint_data(rtoc_ctx* ctx, double* host_out, int count);
+int rtoc_sto_get_kkt_terms(rtoc_ctx* ctx, double* host_lt, double* host_qtt_diag, double* host_err_sq, int count);
+
 /* LineSearchFilter (src/line_search/line_search_filter.cpp:26-60) of every instance, resident on the device: one call is
  * the accept test of LineSearch::lineSearchFilterMethod (src/line_search/line_search.cpp:63-83) for one trial step of
  * the whole batch.  For instance b with trial pair (cost[b], violation[b]) -- DirectMultipleShooting::getEval() of the

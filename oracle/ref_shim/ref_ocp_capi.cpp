@@ -29,6 +29,11 @@
 #undef private
 #include "robotoc/planner/contact_sequence.hpp"
 #include "robotoc/riccati/riccati_recursion.hpp"
+#include "robotoc/sto/sto_constraints.hpp"
+#include "robotoc/sto/sto_cost_function.hpp"
+#define private public
+#include "robotoc/sto/switching_time_optimization.hpp"
+#undef private
 
 using namespace robotoc;
 
@@ -46,6 +51,13 @@ struct State {
   KKTResidual kr;
   RiccatiFactorization fact;
   double primal, dual;
+  // switching-time optimisation (ref_ocp_sto_setup): the reference's SwitchingTimeOptimization over its STOConstraints
+  bool sto_on = false;
+  std::vector<int> event_sto;
+  std::vector<double> min_dwell, sto_slack, sto_dual;
+  double sto_barrier = 1e-3, sto_tau = 0.995, sto_reg = 0.0;
+  std::unique_ptr<SwitchingTimeOptimization> sto;
+  std::shared_ptr<ContactSequence> seq;
 };
 std::unique_ptr<State> G;
 Eigen::VectorXd vec(const double* p, int n) {
@@ -73,6 +85,21 @@ int ref_ocp_inject(const char* key, const double* data, int rows, int cols) {
   for (int j = 0; j < cols; ++j)
     for (int i = 0; i < rows; ++i) m(i, j) = data[i + (size_t)j * rows];
   G->robots[0].inject(key, m);
+  return 0;
+}
+
+// The STO half of the iteration (ocp_solver.cpp:119, 128-132, 143), between ref_ocp_begin and ref_ocp_direction: event_sto[nev] =
+// ContactSequence's sto flag of every discrete event in time order, min_dwell[nev + 1] / barrier / tau = the STOConstraints,
+// sto_reg = sto_.setRegularization, slack / dual [nev + 1] = the dwell-time rows' ConstraintComponentData (NULL: initConstraints).
+// The grid table handed to ref_ocp_direction then carries the sto / sto_next flags and the PhaseBased time steps.
+int ref_ocp_sto_setup(const int* event_sto, int nev, const double* min_dwell, double barrier, double tau, double sto_reg,
+                      const double* slack, const double* dual) {
+  if (!G) return 1;
+  G->sto_on = true;
+  G->event_sto.assign(event_sto, event_sto + nev);
+  G->min_dwell.assign(min_dwell, min_dwell + nev + 1);
+  G->sto_barrier = barrier, G->sto_tau = tau, G->sto_reg = sto_reg;
+  if (slack && dual) G->sto_slack.assign(slack, slack + nev + 1), G->sto_dual.assign(dual, dual + nev + 1);
   return 0;
 }
 
@@ -118,8 +145,9 @@ int ref_ocp_direction(const rtoc_grid* grid, const unsigned* masks, const double
   for (int i = 0; i < n; ++i) nevents += grid[i].type == RTOC_GRID_IMPACT || grid[i].type == RTOC_GRID_LIFT;
   auto seq = std::make_shared<ContactSequence>(robot, nevents + 1);
   std::vector<GridInfo> gi(n);
-  int phase = 0, impact_index = -1, lift_index = -1;
+  int phase = 0, impact_index = -1, lift_index = -1, event = 0;
   double t = 0.0;
+  auto event_flag = [&]() { return g.sto_on && event < (int)g.event_sto.size() && g.event_sto[event++] != 0; };
   seq->init(status_of(masks[0], 0));
   for (int i = 0; i < n; ++i) {
     GridInfo& o = gi[i];
@@ -127,13 +155,13 @@ int ref_ocp_direction(const rtoc_grid* grid, const unsigned* masks, const double
              : grid[i].type == RTOC_GRID_TERMINAL ? GridType::Terminal : GridType::Intermediate;
     if (grid[i].type == RTOC_GRID_IMPACT) {
       // the phase after the touch-down: the contacts of the next grid point
-      seq->push_back(status_of(masks[i + 1], i + 1), t);
+      seq->push_back(status_of(masks[i + 1], i + 1), t, event_flag());
       ++impact_index;
       o.phase = phase, o.impact_index = impact_index, o.lift_index = lift_index;
       ++phase;
     } else {
       if (grid[i].type == RTOC_GRID_LIFT) {
-        seq->push_back(status_of(masks[i], i), t);
+        seq->push_back(status_of(masks[i], i), t, event_flag());
         ++lift_index;
         ++phase;
       }
@@ -143,12 +171,23 @@ int ref_ocp_direction(const rtoc_grid* grid, const unsigned* masks, const double
     o.stage = grid[i].time_stage < 0 ? 0 : grid[i].time_stage;
     o.num_grids_in_phase = grid[i].num_grids_in_phase;
     o.switching_constraint = grid[i].switching_constraint != 0;
-    o.sto = false, o.sto_next = false;
+    o.sto = g.sto_on && grid[i].sto != 0, o.sto_next = g.sto_on && grid[i].sto_next != 0;
     t += grid[i].dt;
   }
   g.td = TimeDiscretization(gi);
   g.ocp.robot = robot, g.ocp.N = n - 1, g.ocp.T = t, g.ocp.reserved_num_discrete_events = nevents + 1;
   g.ocp.cost = cf, g.ocp.constraints = constraints, g.ocp.contact_sequence = seq;
+  g.seq = seq;
+  if (g.sto_on) {
+    g.ocp.sto_cost = std::make_shared<STOCostFunction>();   // empty, like the reference's examples (examples/anymal/python/jump_sto.py:104)
+    g.ocp.sto_constraints = std::make_shared<STOConstraints>(g.min_dwell, g.sto_barrier, g.sto_tau);
+    g.sto.reset(new SwitchingTimeOptimization(g.ocp));
+    g.sto->setRegularization(g.sto_reg);
+    g.sto->initConstraints(g.td);
+    if (!g.sto_slack.empty())
+      for (size_t p = 0; p < g.sto_slack.size(); ++p)
+        g.sto->constraint_data_.slack((int)p) = g.sto_slack[p], g.sto->constraint_data_.dual((int)p) = g.sto_dual[p];
+  }
   g.dms.reset(new DirectMultipleShooting(g.ocp, 1));
   g.dms->resizeData(g.td);
   g.riccati.reset(new RiccatiRecursion(g.ocp, 0.1));
@@ -206,14 +245,20 @@ int ref_ocp_direction(const rtoc_grid* grid, const unsigned* masks, const double
   // ---- OCPSolver::updateSolution (ocp_solver.cpp:118-132) ----
   const Eigen::VectorXd q = vec(q0, nq), v = vec(v0, nv);
   g.dms->evalKKT(g.robots, g.td, q, v, g.s, g.km, g.kr);
+  if (g.sto_on) g.sto->evalKKT(g.td, g.km, g.kr);                                               // :119
   g.riccati->backwardRiccatiRecursion(g.td, g.km, g.kr, g.fact);
   g.dms->computeInitialStateDirection(robot, q, v, g.s, g.d);
   g.riccati->forwardRiccatiRecursion(g.td, g.km, g.kr, g.fact, g.d);
   g.dms->computeStepSizes(g.td, g.d);
   g.primal = g.dms->maxPrimalStepSize(), g.dual = g.dms->maxDualStepSize();
+  if (g.sto_on) {                                                                                // :128-132
+    g.sto->computeStepSizes(g.td, g.d);
+    g.primal = std::min(g.primal, g.sto->maxPrimalStepSize()), g.dual = std::min(g.dual, g.sto->maxDualStepSize());
+  }
   for (int i = 0; i < n; ++i)
     for (int k = 0; k < nv; ++k) out_dq[(size_t)i * nv + k] = g.d[i].dq()(k);
   out_steps[0] = g.primal, out_steps[1] = g.dual, out_steps[2] = g.dms->getEval().kkt_error;
+  if (g.sto_on) out_steps[2] += g.sto->getEval().kkt_error;   // OCPSolver::KKTError()^2 (:429-431)
   return (int)robot.pending() == 0 ? 0 : 2;
 }
 
@@ -225,6 +270,7 @@ int ref_ocp_integrate(const double* q_integrated, double* sol_out, double* slack
   const int nv = g.nv, nu = g.nu, nc = g.nc, nq = nv + 1, n = g.n;
   for (int i = 0; i < n; ++i) robot.inject("integrateConfiguration", vec(q_integrated + (size_t)i * nq, nq));
   g.dms->integrateSolution(g.robots, g.td, g.primal, g.dual, g.d, g.s);   // ocp_solver.cpp:142
+  if (g.sto_on) g.sto->integrateSolution(g.td, g.primal, g.dual, g.d);     // :143
   const int SL = sol_len(nv, nu, nc), nrow = 6 * nu + 5 * nc;
   for (int i = 0; i < n; ++i) {
     const SplitSolution& s = g.s[i];
@@ -256,6 +302,27 @@ int ref_ocp_integrate(const double* q_integrated, double* sol_out, double* slack
     }
   }
   return (int)robot.pending() == 0 ? 0 : 2;
+}
+
+// After ref_ocp_direction (stage 0) / ref_ocp_integrate (stage 1) of an STO iteration: event_times[nev] = ContactSequence's event
+// times, con[6][nev + 1] = slack, dual, residual, cmpl, dslack, ddual of the dwell-time rows, lt_qtt[2][nev] = the gradient and
+// Hessian diagonal SwitchingTimeOptimization::evalKKT scattered, perf[2] = its kkt_error and the rows' own KKTError(),
+// dts[n][2] = SplitDirection::dts, dts_next of every grid point.
+int ref_ocp_sto_result(double* event_times, double* con, double* lt_qtt, double* perf, double* dts) {
+  if (!G || !G->sto_on || !G->sto) return 1;
+  State& g = *G;
+  const int nev = (int)g.event_sto.size(), np = nev + 1;
+  const auto& et = g.seq->eventTimes();
+  for (int e = 0; e < nev; ++e) event_times[e] = et[e];
+  const ConstraintComponentData& c = g.sto->constraint_data_;
+  for (int p = 0; p < np; ++p) {
+    con[0 * np + p] = c.slack(p), con[1 * np + p] = c.dual(p), con[2 * np + p] = c.residual(p), con[3 * np + p] = c.cmpl(p);
+    con[4 * np + p] = c.dslack(p), con[5 * np + p] = c.ddual(p);
+  }
+  for (int e = 0; e < nev; ++e) lt_qtt[e] = g.sto->lt_.coeff(e), lt_qtt[nev + e] = g.sto->Qtt_.coeff(e, e);
+  perf[0] = g.sto->getEval().kkt_error, perf[1] = c.KKTError();
+  for (int i = 0; i < g.n; ++i) dts[2 * i] = g.d[i].dts, dts[2 * i + 1] = g.d[i].dts_next;
+  return 0;
 }
 
 }  // extern "C"

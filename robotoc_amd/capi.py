@@ -31,6 +31,10 @@ EXPORTS = [
     "rtoc_unconstr_eval_kkt", "rtoc_unconstr_update_solution", "rtoc_set_constraint_bounds", "rtoc_unconstr_init_constraints", "rtoc_linearize_state_equation", "rtoc_contact_eval_kkt", "rtoc_contact_update_solution",
     "rtoc_set_barrier_param", "rtoc_set_friction_coefficients", "rtoc_contact_init_constraints", "rtoc_set_wrench_cone_params",
     "rtoc_graph_replay_count",
+    "rtoc_sto_set_problem", "rtoc_sto_set_regularization", "rtoc_sto_set_cost_terms", "rtoc_sto_init_constraints",
+    "rtoc_sto_correct_time_steps", "rtoc_sto_eval_kkt_device", "rtoc_sto_compute_step_sizes", "rtoc_sto_integrate_solution",
+    "rtoc_sto_get_event_times", "rtoc_sto_get_time_steps", "rtoc_sto_get_constraint_data", "rtoc_sto_get_kkt_terms",
+    "rtoc_sto_set_slack_dual",
 ]
 
 
@@ -152,6 +156,16 @@ def lib():
         L.rtoc_set_contact_schedule.argtypes = [vp, C.POINTER(C.c_uint), dp, dp]
         L.rtoc_load_stage_dump.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
         L.rtoc_graph_replay_count.argtypes = [vp, C.POINTER(C.c_ulonglong)]
+        L.rtoc_sto_set_problem.argtypes = [vp, C.c_double, C.c_double, dp, C.c_int, C.c_int, dp, C.c_double, C.c_double]
+        L.rtoc_sto_set_regularization.argtypes = [vp, C.c_double]
+        L.rtoc_sto_set_cost_terms.argtypes = [vp, dp, dp]
+        for f in ("rtoc_sto_init_constraints", "rtoc_sto_correct_time_steps", "rtoc_sto_eval_kkt_device",
+                  "rtoc_sto_compute_step_sizes", "rtoc_sto_integrate_solution"):
+            getattr(L, f).argtypes = [vp]
+        for f in ("rtoc_sto_get_event_times", "rtoc_sto_get_time_steps", "rtoc_sto_get_constraint_data"):
+            getattr(L, f).argtypes = [vp, dp, C.c_int]
+        L.rtoc_sto_get_kkt_terms.argtypes = [vp, dp, dp, dp, C.c_int]
+        L.rtoc_sto_set_slack_dual.argtypes = [vp, dp, dp]
         L.rtoc_error_string.argtypes = [C.c_int]
         L.rtoc_error_string.restype = C.c_char_p
         _LIB = L
@@ -306,6 +320,71 @@ class Context:
         out = np.zeros(self.batch)
         _chk(lib().rtoc_sto_eval_kkt(self._h, _dp(lt), _dp(qtt_diag), lt.shape[1], _dp(out), self.batch))
         return out
+
+    # ---- SwitchingTimeOptimization resident on the device (rtoc.h: rtoc_sto_*) ----
+    STO_MAX_ROWS = 16
+
+    def sto_set_problem(self, t0, T, event_times, min_dwell_times, barrier_param=1.0e-3, fraction_to_boundary_rule=0.995):
+        """event_times: [num_events] (shared by the batch) or [batch, num_events]; min_dwell_times: [num_events + 1]."""
+        et = np.ascontiguousarray(event_times, dtype=np.float64)
+        md = np.ascontiguousarray(min_dwell_times, dtype=np.float64)
+        nev = et.shape[-1] if et.size else 0
+        assert et.ndim in (1, 2) and (et.ndim == 1 or et.shape[0] == self.batch) and md.size == nev + 1
+        _chk(lib().rtoc_sto_set_problem(self._h, t0, T, _dp(et), nev, int(et.ndim == 2), _dp(md), barrier_param, fraction_to_boundary_rule))
+        self.sto_nev = nev
+
+    def sto_set_regularization(self, sto_reg):
+        _chk(lib().rtoc_sto_set_regularization(self._h, sto_reg))
+
+    def sto_set_cost_terms(self, lt=None, qtt_diag=None):
+        if lt is None:
+            _chk(lib().rtoc_sto_set_cost_terms(self._h, None, None))
+            return
+        lt, qtt_diag = np.ascontiguousarray(lt, dtype=np.float64), np.ascontiguousarray(qtt_diag, dtype=np.float64)
+        assert lt.shape == qtt_diag.shape == (self.batch, self.sto_nev)
+        _chk(lib().rtoc_sto_set_cost_terms(self._h, _dp(lt), _dp(qtt_diag)))
+
+    def sto_init_constraints(self):
+        _chk(lib().rtoc_sto_init_constraints(self._h))
+
+    def sto_set_slack_dual(self, slack, dual):
+        slack, dual = np.ascontiguousarray(slack, dtype=np.float64), np.ascontiguousarray(dual, dtype=np.float64)
+        assert slack.shape == dual.shape == (self.batch, self.sto_nev + 1)
+        _chk(lib().rtoc_sto_set_slack_dual(self._h, _dp(slack), _dp(dual)))
+
+    def sto_correct_time_steps(self):
+        _chk(lib().rtoc_sto_correct_time_steps(self._h))
+
+    def sto_eval_kkt_device(self):
+        _chk(lib().rtoc_sto_eval_kkt_device(self._h))
+
+    def sto_compute_step_sizes(self):
+        _chk(lib().rtoc_sto_compute_step_sizes(self._h))
+
+    def sto_integrate_solution(self):
+        _chk(lib().rtoc_sto_integrate_solution(self._h))
+
+    def sto_event_times(self):
+        out = np.zeros((self.batch, self.sto_nev))
+        _chk(lib().rtoc_sto_get_event_times(self._h, _dp(out), self.batch))
+        return out
+
+    def sto_time_steps(self):
+        out = np.zeros((self.batch, self.nstages))
+        _chk(lib().rtoc_sto_get_time_steps(self._h, _dp(out), self.batch))
+        return out
+
+    def sto_constraint_data(self):
+        """[batch, 6, num_events + 1]: slack, dual, residual, cmpl, dslack, ddual of the dwell-time rows."""
+        out = np.zeros((self.batch, 6, self.STO_MAX_ROWS))
+        _chk(lib().rtoc_sto_get_constraint_data(self._h, _dp(out), self.batch))
+        return out[:, :, :self.sto_nev + 1].copy()
+
+    def sto_kkt_terms(self):
+        """(lt, diag Qtt, squared STO KKT term) of the last SwitchingTimeOptimization::evalKKT on the device."""
+        lt, qtt, err = np.zeros((self.batch, self.sto_nev)), np.zeros((self.batch, self.sto_nev)), np.zeros(self.batch)
+        _chk(lib().rtoc_sto_get_kkt_terms(self._h, _dp(lt), _dp(qtt), _dp(err), self.batch))
+        return lt, qtt, err
 
     def graph_replay_count(self):
         n = C.c_ulonglong()

@@ -71,6 +71,7 @@ struct CondArgs {
   double* cone_con;  // constraint records (the box rows' `con` may be null when only cones are set)
   int cone_contacts, cone_dim, cone_row0, cone_stride, cone_dgdf_off, cone_impact;
   int keep_qaf;  // RTOC_OPT_CONDENSE_KEEP_QAF: also store Qafqv / Qafu_full in the ContactDynamicsData record
+  const double* dt_inst;  // [batch][nstages] per-instance time steps (switching-time optimisation) or nullptr (device_utils.hpp: grid_dt)
 };
 
 struct ExpArgs {
@@ -85,6 +86,7 @@ struct ExpArgs {
   int nstages, batch;
   rtoc_record_layout cl, dl;
   double tau;
+  const double* dt_inst;  // per-instance time steps or nullptr (grid_dt)
 };
 
 template <int NV, int NU, int NF, int NS, bool SPLIT = false>
@@ -359,7 +361,7 @@ __global__ __launch_bounds__(64 * RTOC_COND_NW, (CondCfg<NV, NU, NF, NS, SPLIT>:
   const rtoc_grid g = a.grid[st];
   const bool impact = g.type == RTOC_GRID_IMPACT;
   const int nf = g.dimf, nvf = NV + nf, ns = impact ? 0 : g.dims;
-  const double dt = g.dt;
+  const double dt = grid_dt(a.grid, a.dt_inst, b, a.nstages, st);
   // record offsets as immediates (StaticLayout: the host checks them against the run-time layout)
   constexpr rtoc_layout SL = StaticLayout<NV, NU, NS>::make();
   constexpr rtoc_record_layout KL = SL.kkt, CL = SL.cdd;
@@ -914,7 +916,7 @@ __global__ __launch_bounds__(64) void expand_kernel(ExpArgs a) {
   const rtoc_grid g = a.grid[st];
   const bool impact = g.type == RTOC_GRID_IMPACT;
   const int nf = g.dimf, nvf = NV + nf, ns = impact ? 0 : g.dims;
-  const double dt = g.dt;
+  const double dt = grid_dt(a.grid, a.dt_inst, b, a.nstages, st);
   constexpr rtoc_layout SL = StaticLayout<NV, NU, NS>::make();
   constexpr rtoc_record_layout CL = SL.cdd, DL = SL.dir;
   double* cr = a.cdd + ((size_t)b * a.nstages + st) * CL.stride;

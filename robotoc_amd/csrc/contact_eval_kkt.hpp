@@ -24,6 +24,8 @@ struct CostArgs {
   int sol_stride, kkt_stride, cdd_stride;
   int o_q, o_v, o_a, o_u;
   rtoc_record_layout kl, cl;
+  const double* dt_inst;  // per-instance time steps or nullptr (grid_dt)
+  double* cost_out;       // [batch][nstages] value of the stage / impact / terminal cost (evalOCP: line search), or nullptr
 };
 
 static __global__ __launch_bounds__(64) void contact_cost_kernel(CostArgs a) {
@@ -41,7 +43,7 @@ static __global__ __launch_bounds__(64) void contact_cost_kernel(CostArgs a) {
   double* const cr = a.cdd + rec * a.cdd_stride;
   const double *qr = a.cost, *vr = qr + M, *ur = vr + M, *wq = ur + M, *wv = wq + M, *wa = wv + M, *wu = wa + M, *wqT = wu + M,
                *wvT = wqT + M, *wqI = wvT + M, *wvI = wqI + M, *wdvI = wvI + M;
-  const double scale = (impact || terminal) ? 1.0 : g.dt;
+  const double scale = (impact || terminal) ? 1.0 : grid_dt(a.grid, a.dt_inst, b, a.nstages, st);
   const double* const Wq = terminal ? wqT : impact ? wqI : wq;
   const double* const Wv = terminal ? wvT : impact ? wvI : wv;
   // ---- setZero of everything the stages below accumulate into ----
@@ -90,23 +92,26 @@ static __global__ __launch_bounds__(64) void contact_cost_kernel(CostArgs a) {
   // hx, hu, ha = lx, lu, la / dt BEFORE constraints and dynamics add their terms -- i.e. the cost gradient without the dt
   const bool sto = !terminal && !impact;
   double* const hx = kr + a.kl.off[RTOC_KKT_HX];
-  double hval = 0.0;   // this lane's share of cost / dt = 1/2 sum of weight * difference^2
+  double hval = 0.0;   // this lane's share of cost / dt (cost itself on impact / terminal grids) = 1/2 sum of weight * difference^2
   for (int i = lane; i < nv; i += 64) {
     if (i >= nb) {
       const double dq = q[(nb ? 1 : 0) + i] - qr[(nb ? 1 : 0) + i];
       lx[i] = scale * Wq[i] * dq;
       Qxx[i + (size_t)i * nx] = scale * Wq[i];
-      if (sto) hx[i] = Wq[i] * dq, hval += 0.5 * Wq[i] * dq * dq;
+      if (sto) hx[i] = Wq[i] * dq;
+      hval += 0.5 * Wq[i] * dq * dq;
     }
     const double dv = v[i] - vr[i];
     lx[nv + i] = scale * Wv[i] * dv;
     Qxx[(nv + i) + (size_t)(nv + i) * nx] = scale * Wv[i];
-    if (sto) hx[nv + i] = Wv[i] * dv, hval += 0.5 * Wv[i] * dv * dv;
+    if (sto) hx[nv + i] = Wv[i] * dv;
+    hval += 0.5 * Wv[i] * dv * dv;
     if (!terminal) {
       const double w = impact ? wdvI[i] : scale * wa[i];   // a on contact grids, dv on impact grids (both in the A slot)
       cr[a.cl.off[RTOC_CDD_LA] + i] = w * acc[i];
       cr[a.cl.off[RTOC_CDD_QAA] + i] = w;
-      if (sto) cr[a.cl.off[RTOC_CDD_HA] + i] = wa[i] * acc[i], hval += 0.5 * wa[i] * acc[i] * acc[i];
+      if (sto) cr[a.cl.off[RTOC_CDD_HA] + i] = wa[i] * acc[i];
+      hval += 0.5 * (impact ? wdvI[i] : wa[i]) * acc[i] * acc[i];
     }
   }
   if (sto)
@@ -144,14 +149,17 @@ static __global__ __launch_bounds__(64) void contact_cost_kernel(CostArgs a) {
 #pragma unroll
       for (int k = 0; k < 6; ++k) t += J[k + 6 * lane] * wd[k];
       lx[lane] = scale * t;
-      if (sto) hx[lane] = t, hval += 0.5 * wd[lane] * wd[lane] / (Wq[lane] != 0.0 ? Wq[lane] : 1.0);   // 1/2 Wq d^2, wd = Wq d
+      if (sto) hx[lane] = t;
+      hval += 0.5 * wd[lane] * wd[lane] / (Wq[lane] != 0.0 ? Wq[lane] : 1.0);   // 1/2 Wq d^2, wd = Wq d
     }
   }
-  if (sto) {
+  if (sto || a.cost_out) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) hval += __shfl_xor(hval, off, 64);
     __syncthreads();   // the zeroing of the scalars above is done
-    if (lane == 0) kr[a.kl.off[RTOC_KKT_SCAL] + RTOC_KKT_SCAL_H] = hval;
+    if (lane == 0 && sto) kr[a.kl.off[RTOC_KKT_SCAL] + RTOC_KKT_SCAL_H] = hval;
+    // the value of the cost itself (evalStageCost / evalImpactCost / evalTerminalCost): what evalOCP sums for the line search
+    if (lane == 0 && a.cost_out) a.cost_out[rec] = scale * hval;
   }
 }
 

@@ -129,6 +129,16 @@ __device__ __forceinline__ double rsqrt_d(double d) {
 
 __device__ __forceinline__ bool is_bad(double v) { return !(fabs(v) <= 1.79769313486231570815e308); }
 
+// Time step of grid point `st` of instance `b`: the batch shares the grid STRUCTURE (rtoc_set_grid), but with switching-time
+// optimisation every instance moves its own event times, i.e. has its own time steps (TimeDiscretization::correctTimeSteps,
+// time_discretization.cpp:179-221): `dt_inst` = [batch][nstages] table written by sto_time_steps_kernel (sto.hpp), or
+// nullptr -> the shared grid's dt.  One unconditional load through a selected address (a predicated load would compile to a
+// branch with its own s_waitcnt: one more dependent round trip ahead of everything).
+__device__ __forceinline__ double grid_dt(const rtoc_grid* grid, const double* dt_inst, int b, int nstages, int st) {
+  const double* const p = dt_inst ? dt_inst + (size_t)b * nstages + st : &grid[st].dt;
+  return *p;
+}
+
 // Field offsets of the KKT / Riccati records for a robot known at compile time: the same
 // rtoc_compute_layout() the host uses, evaluated as a constant expression, so that every offset is
 // an instruction immediate instead of a scalar register (the runtime table cost ~60 SGPRs and made

@@ -20,6 +20,7 @@
 #include "switching_constraint_lin.hpp"
 #include "contact_constraints.hpp"
 #include "contact_eval_kkt.hpp"
+#include "sto.hpp"
 
 using namespace rtoc;
 
@@ -217,6 +218,16 @@ struct rtoc_ctx {
   int* d_nfilter;
   double* d_ls_in;
   int* d_ls_flags;
+  // switching-time optimisation on the device (rtoc_sto_set_problem; sto.hpp)
+  int sto_on, sto_nev;
+  double sto_t0, sto_T, sto_barrier, sto_tau, sto_reg;
+  double* d_ts;         // [batch][nev] event times of every instance
+  double* d_dt;         // [batch][max_stages] time steps of every instance (grid_dt)
+  double* d_sto_con;    // [batch][RTOC_STO_CON_STRIDE] dwell-time rows
+  double* d_min_dwell;  // [RTOC_STO_MAX_EVENTS + 1]
+  double* d_sto_cost;   // [2][batch][nev] STO cost gradient / Hessian diagonal handed over by the host, or nullptr
+  double* d_sto_out;    // [2][batch][nev] + [batch]: lt, Qtt diagonal as scattered, squared STO KKT term
+  double* d_costval;    // [batch][max_stages] cost values of the last rtoc_contact_eval_kkt (rtoc_eval_ocp), or nullptr
 };
 
 extern "C" {
@@ -377,6 +388,13 @@ int rtoc_destroy(rtoc_ctx* c) {
   if (c->d_nfilter) (void)hipFree(c->d_nfilter);
   if (c->d_ls_in) (void)hipFree(c->d_ls_in);
   if (c->d_ls_flags) (void)hipFree(c->d_ls_flags);
+  if (c->d_ts) (void)hipFree(c->d_ts);
+  if (c->d_dt) (void)hipFree(c->d_dt);
+  if (c->d_sto_con) (void)hipFree(c->d_sto_con);
+  if (c->d_min_dwell) (void)hipFree(c->d_min_dwell);
+  if (c->d_sto_cost) (void)hipFree(c->d_sto_cost);
+  if (c->d_sto_out) (void)hipFree(c->d_sto_out);
+  if (c->d_costval) (void)hipFree(c->d_costval);
   if (c->d_cpos) (void)hipFree(c->d_cpos);
   if (c->d_crot) (void)hipFree(c->d_crot);
   if (c->d_prof) (void)hipFree(c->d_prof);
@@ -458,6 +476,17 @@ int rtoc_clone(rtoc_ctx* c, rtoc_ctx** out) {
     dup((void**)&n->d_ls_in, c->d_ls_in, sizeof(double) * 2 * c->batch);
     dup((void**)&n->d_ls_flags, c->d_ls_flags, sizeof(int) * 2 * c->batch);
   }
+  if (c->sto_on) {
+    n->sto_on = 1, n->sto_nev = c->sto_nev, n->sto_t0 = c->sto_t0, n->sto_T = c->sto_T;
+    n->sto_barrier = c->sto_barrier, n->sto_tau = c->sto_tau, n->sto_reg = c->sto_reg;
+    const size_t ne = (size_t)c->batch * (c->sto_nev > 0 ? c->sto_nev : 1);
+    dup((void**)&n->d_ts, c->d_ts, sizeof(double) * ne);
+    dup((void**)&n->d_dt, c->d_dt, sizeof(double) * c->batch * c->max_stages);
+    dup((void**)&n->d_sto_con, c->d_sto_con, sizeof(double) * c->batch * RTOC_STO_CON_STRIDE);
+    dup((void**)&n->d_min_dwell, c->d_min_dwell, sizeof(double) * (RTOC_STO_MAX_EVENTS + 1));
+    dup((void**)&n->d_sto_cost, c->d_sto_cost, sizeof(double) * 2 * ne);
+    dup((void**)&n->d_sto_out, c->d_sto_out, sizeof(double) * (2 * ne + c->batch));
+  }
   for (int b = 0; !rc && e == hipSuccess && b < RTOC_NUM_BUFFERS; ++b) {
     if (!c->buf[b]) continue;
     if (!n->buf[b]) {
@@ -504,6 +533,12 @@ int rtoc_set_grid(rtoc_ctx* c, const rtoc_grid* grid, int nstages) {
   c->nstages = nstages;
   c->fxx_state = 0;
   c->epoch++;
+  if (c->sto_on) {  // the event times on the device belong to the previous grid structure unless the events are the same
+    int nev = 0;
+    for (int i = 0; i + 1 < nstages; ++i)
+      if (grid[i].type == RTOC_GRID_IMPACT || grid[i].type == RTOC_GRID_LIFT) ++nev;
+    if (nev != c->sto_nev) c->sto_on = 0;   // rtoc_sto_set_problem again
+  }
   return RTOC_OK;
 }
 
@@ -605,6 +640,44 @@ static int ensure_buffer(rtoc_ctx* c, int b) {
   c->epoch++;
   return RTOC_OK;
 }
+
+// switching-time optimisation on the device (sto.hpp): kernel arguments, one thread per instance
+static int sto_count_events(const rtoc_ctx* c) {
+  int n = 0;
+  for (int i = 0; i + 1 < c->nstages; ++i)
+    if (c->h_grid[i].type == RTOC_GRID_IMPACT || c->h_grid[i].type == RTOC_GRID_LIFT) ++n;
+  return n;
+}
+
+static StoDevArgs sto_args(rtoc_ctx* c) {
+  StoDevArgs a;
+  memset(&a, 0, sizeof(a));
+  const size_t ne = (size_t)c->batch * (c->sto_nev > 0 ? c->sto_nev : 1);
+  a.kkt = c->buf[RTOC_BUF_KKT];
+  a.dir = c->buf[RTOC_BUF_DIR];
+  a.grid = c->d_grid;
+  a.ts = c->d_ts;
+  a.dt_inst = c->d_dt;
+  a.con = c->d_sto_con;
+  a.min_dwell = c->d_min_dwell;
+  a.cost_lt = c->d_sto_cost;
+  a.cost_qtt = c->d_sto_cost ? c->d_sto_cost + ne : nullptr;
+  a.lt = c->d_sto_out;
+  a.qtt = c->d_sto_out + ne;
+  a.err = c->d_sto_out + 2 * ne;
+  a.kkterr = c->d_kkterr;
+  a.steps = c->buf[RTOC_BUF_STEP];
+  a.nstages = c->nstages, a.batch = c->batch, a.nev = c->sto_nev;
+  a.kkt_stride = c->L.kkt.stride, a.scal_off = c->L.kkt.off[RTOC_KKT_SCAL];
+  a.dir_stride = c->L.dir.stride, a.dts_off = c->L.dir.off[RTOC_DIR_DTS];
+  a.t0 = c->sto_t0, a.T = c->sto_T, a.barrier = c->sto_barrier, a.tau = c->sto_tau, a.sto_reg = c->sto_reg;
+  return a;
+}
+#define STO_LAUNCH(kernel, c)                                                                                   \
+  do {                                                                                                          \
+    hipLaunchKernelGGL(kernel, dim3(((c)->batch + 63) / 64), dim3(64), 0, (c)->stream, sto_args(c));            \
+    HIP_TRY(hipGetLastError());                                                                                 \
+  } while (0)
 
 int rtoc_upload(rtoc_ctx* c, int buffer, size_t offset, const double* host, size_t count) {
   if (!c || buffer < 0 || buffer >= RTOC_NUM_BUFFERS || !host) return RTOC_ERR_BAD_ARG;
@@ -891,6 +964,7 @@ static int launch_condense(rtoc_ctx* c) {
   const int nblocks = c->batch * (c->nstages - 1);
   a.cone_rows = 0;
   a.keep_qaf = c->keep_qaf;
+  a.dt_inst = c->sto_on ? c->d_dt : nullptr;
   if (c->condense_split && c->cone_contacts > 0) {  // the cone rows ride with the MJtJinv kernel
     if (!c->buf[RTOC_BUF_CONE] || !c->buf[RTOC_BUF_CON]) return RTOC_ERR_NOT_READY;
     const bool wrench = c->cone_rows == RTOC_WRENCH_ROWS;
@@ -931,6 +1005,7 @@ static int launch_expand(rtoc_ctx* c, double tau) {
   a.nrows = c->nrows;
   a.nl = c->L.con;
   a.steps = (unsigned long long*)c->buf[RTOC_BUF_STEP];
+  a.dt_inst = c->sto_on ? c->d_dt : nullptr;
   hipLaunchKernelGGL(fill_steps_kernel, dim3((2 * c->batch + 255) / 256), dim3(256), 0, c->stream,
                      c->buf[RTOC_BUF_STEP], 2 * c->batch);
   const int nblocks = c->batch * (c->nstages - 1);
@@ -996,6 +1071,7 @@ static int launch_state_correction(rtoc_ctx* c, int mode) {
   a.kl = c->L.kkt;
   a.dl = c->L.dir;
   a.nx = c->L.nx;
+  a.dt_inst = c->sto_on ? c->d_dt : nullptr;
   const int nblocks = (mode == 2) ? c->batch : c->batch * c->nstages;
   if (mode == 0)
     hipLaunchKernelGGL(state_correction_kernel<0>, dim3(nblocks), dim3(64), 0, c->stream, a);
@@ -1704,6 +1780,7 @@ static int launch_state_equation(rtoc_ctx* c, bool zeroed) {
   a.o_hx = c->L.kkt.off[RTOC_KKT_HX], a.o_ffx = c->L.kkt.off[RTOC_KKT_FFX], a.o_scal = c->L.kkt.off[RTOC_KKT_SCAL];
   a.o_la = c->L.cdd.off[RTOC_CDD_LA], a.o_ha = c->L.cdd.off[RTOC_CDD_HA];
   a.zeroed = zeroed ? 1 : 0;
+  a.dt_inst = c->sto_on ? c->d_dt : nullptr;
   hipLaunchKernelGGL(state_equation_lin_kernel, dim3(c->batch * c->nstages), dim3(64), 0, c->stream, a);
   HIP_TRY(hipGetLastError());
   if (zeroed && c->fxx_last != 1) c->epoch++;  // the kernel choice of the backward recursion is part of a captured graph
@@ -1992,6 +2069,7 @@ static int launch_switching_constraint(rtoc_ctx* c) {
   a.o_phix = c->L.kkt.off[RTOC_KKT_PHIX], a.o_phit = c->L.kkt.off[RTOC_KKT_PHIT], a.o_pres = c->L.kkt.off[RTOC_KKT_PRES];
   a.o_lx = c->L.kkt.off[RTOC_KKT_LX], a.o_hx = c->L.kkt.off[RTOC_KKT_HX], a.o_scal = c->L.kkt.off[RTOC_KKT_SCAL];
   a.o_phia = c->L.cdd.off[RTOC_CDD_PHIA], a.o_la = c->L.cdd.off[RTOC_CDD_LA], a.o_ha = c->L.cdd.off[RTOC_CDD_HA];
+  a.dt_inst = c->sto_on ? c->d_dt : nullptr;
   for (int i = 0; i < c->nstages; ++i)
     if (c->h_grid[i].switching_constraint && c->h_grid[i].dims > c->dims.ns_max) return RTOC_ERR_BAD_ARG;
   a.nsel = 0;
@@ -2018,6 +2096,8 @@ int rtoc_contact_eval_kkt(rtoc_ctx* c) {
   int rc = ensure_buffer(c, RTOC_BUF_KKT);
   if (!rc) rc = ensure_buffer(c, RTOC_BUF_CDD);
   if (rc) return rc;
+  // PhaseBased discretisation: time_discretization_.correctTimeSteps(contact_sequence_, t) ahead of evalKKT (ocp_solver.cpp:115-117)
+  if (c->sto_on) STO_LAUNCH(sto_time_steps_kernel, c);
   CostArgs a;
   a.sol = c->buf[RTOC_BUF_SOL];
   a.cost = c->d_cost;
@@ -2029,6 +2109,8 @@ int rtoc_contact_eval_kkt(rtoc_ctx* c) {
   a.sol_stride = c->L.sol.stride, a.kkt_stride = c->L.kkt.stride, a.cdd_stride = c->L.cdd.stride;
   a.o_q = c->L.sol.off[RTOC_SOL_Q], a.o_v = c->L.sol.off[RTOC_SOL_V], a.o_a = c->L.sol.off[RTOC_SOL_A], a.o_u = c->L.sol.off[RTOC_SOL_U];
   a.kl = c->L.kkt, a.cl = c->L.cdd;
+  a.dt_inst = c->sto_on ? c->d_dt : nullptr;
+  a.cost_out = c->d_costval;
   hipLaunchKernelGGL(contact_cost_kernel, dim3(c->batch * c->nstages), dim3(64), 0, c->stream, a);
   HIP_TRY(hipGetLastError());
   // constraints_->linearizeConstraints (intermediate_stage.cpp:109-110, impact_stage.cpp:95-96) of the rows evaluated here
@@ -2126,6 +2208,162 @@ int rtoc_sto_eval_kkt(rtoc_ctx* c, const double* host_lt, const double* host_qtt
   return RTOC_OK;
 }
 
+// ---- switching-time optimisation resident on the device (sto.hpp) ------------------------------------------------
+int rtoc_sto_set_problem(rtoc_ctx* c, double t0, double T, const double* event_times, int num_events, int per_instance,
+                         const double* min_dwell_times, double barrier_param, double fraction_to_boundary_rule) {
+  CHECK_READY(c);
+  if (num_events == 0) {  // no discrete events on this horizon: nothing to optimise (switching_time_optimization.cpp:85-90)
+    c->sto_on = 0;
+    c->epoch++;
+    return RTOC_OK;
+  }
+  if (num_events < 0 || num_events > RTOC_STO_MAX_EVENTS || !event_times || !min_dwell_times || !(T > 0.0)) return RTOC_ERR_BAD_ARG;
+  if (!(barrier_param > 0.0) || !(fraction_to_boundary_rule > 0.0) || !(fraction_to_boundary_rule < 1.0)) return RTOC_ERR_BAD_ARG;  // sto_constraints.cpp:44-59
+  if (!c->h_grid || num_events != sto_count_events(c)) return RTOC_ERR_BAD_ARG;
+  for (int p = 0; p <= num_events; ++p)
+    if (!(min_dwell_times[p] >= 0.0)) return RTOC_ERR_BAD_ARG;  // :38-43
+  const size_t ne = (size_t)c->batch * num_events;
+  std::vector<double> ts(ne);
+  for (int b = 0; b < c->batch; ++b)
+    for (int e = 0; e < num_events; ++e) {
+      const double te = event_times[(per_instance ? (size_t)b * num_events : 0) + e];
+      const double prev = e > 0 ? ts[(size_t)b * num_events + e - 1] : t0;
+      if (!(te > prev) || !(te < t0 + T)) return RTOC_ERR_BAD_ARG;  // events ordered, inside the horizon
+      ts[(size_t)b * num_events + e] = te;
+    }
+  if (c->sto_nev != num_events) {
+    for (double** p : {&c->d_ts, &c->d_sto_cost, &c->d_sto_out})
+      if (*p) (void)hipFree(*p), *p = nullptr;
+  }
+  if (!c->d_ts) HIP_TRY(hipMalloc((void**)&c->d_ts, sizeof(double) * ne));
+  if (!c->d_sto_out) HIP_TRY(hipMalloc((void**)&c->d_sto_out, sizeof(double) * (2 * ne + c->batch)));
+  if (!c->d_dt) HIP_TRY(hipMalloc((void**)&c->d_dt, sizeof(double) * c->batch * c->max_stages));
+  if (!c->d_sto_con) HIP_TRY(hipMalloc((void**)&c->d_sto_con, sizeof(double) * c->batch * RTOC_STO_CON_STRIDE));
+  if (!c->d_min_dwell) HIP_TRY(hipMalloc((void**)&c->d_min_dwell, sizeof(double) * (RTOC_STO_MAX_EVENTS + 1)));
+  if (!c->d_kkterr) HIP_TRY(hipMalloc((void**)&c->d_kkterr, sizeof(double) * c->batch * (size_t)(1 + c->max_stages)));
+  int rc = ensure_buffer(c, RTOC_BUF_STEP);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(c->d_ts, ts.data(), sizeof(double) * ne, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->d_min_dwell, min_dwell_times, sizeof(double) * (num_events + 1), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemsetAsync(c->d_sto_con, 0, sizeof(double) * c->batch * RTOC_STO_CON_STRIDE, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->sto_on = 1, c->sto_nev = num_events, c->sto_t0 = t0, c->sto_T = T;
+  c->sto_barrier = barrier_param, c->sto_tau = fraction_to_boundary_rule;
+  c->epoch++;
+  STO_LAUNCH(sto_time_steps_kernel, c);  // the time steps that belong to these event times
+  return RTOC_OK;
+}
+
+int rtoc_sto_set_regularization(rtoc_ctx* c, double sto_reg) {
+  if (!c || !(sto_reg >= 0.0)) return RTOC_ERR_BAD_ARG;
+  if (c->sto_reg != sto_reg) c->epoch++;
+  c->sto_reg = sto_reg;
+  return RTOC_OK;
+}
+
+int rtoc_sto_set_cost_terms(rtoc_ctx* c, const double* lt, const double* qtt_diag) {
+  CHECK_READY(c);
+  if (!c->sto_on || (!lt) != (!qtt_diag)) return RTOC_ERR_BAD_ARG;
+  const size_t ne = (size_t)c->batch * c->sto_nev;
+  if (!lt) {
+    if (c->d_sto_cost) (void)hipFree(c->d_sto_cost);
+    c->d_sto_cost = nullptr;
+    c->epoch++;
+    return RTOC_OK;
+  }
+  if (!c->d_sto_cost) {
+    HIP_TRY(hipMalloc((void**)&c->d_sto_cost, sizeof(double) * 2 * ne));
+    c->epoch++;
+  }
+  HIP_TRY(hipMemcpyAsync(c->d_sto_cost, lt, sizeof(double) * ne, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->d_sto_cost + ne, qtt_diag, sizeof(double) * ne, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return RTOC_OK;
+}
+
+int rtoc_sto_init_constraints(rtoc_ctx* c) {
+  CHECK_READY(c);
+  if (!c->sto_on) return RTOC_OK;  // sto_.initConstraints returns when STO is disabled (:47)
+  STO_LAUNCH(sto_init_kernel, c);
+  return RTOC_OK;
+}
+
+// the dwell-time rows' slack / dual handed over by the host ([batch][num_events + 1] each): a warm start, or a test's iterate
+int rtoc_sto_set_slack_dual(rtoc_ctx* c, const double* slack, const double* dual) {
+  CHECK_READY(c);
+  if (!c->sto_on) return RTOC_ERR_NOT_READY;
+  if (!slack || !dual) return RTOC_ERR_BAD_ARG;
+  const int np = c->sto_nev + 1, NP = RTOC_STO_MAX_EVENTS + 1;
+  std::vector<double> h((size_t)c->batch * RTOC_STO_CON_STRIDE, 0.0);
+  for (int b = 0; b < c->batch; ++b)
+    for (int p = 0; p < np; ++p) {
+      if (!(slack[(size_t)b * np + p] > 0.0) || !(dual[(size_t)b * np + p] > 0.0)) return RTOC_ERR_BAD_ARG;
+      h[(size_t)b * RTOC_STO_CON_STRIDE + 0 * NP + p] = slack[(size_t)b * np + p];
+      h[(size_t)b * RTOC_STO_CON_STRIDE + 1 * NP + p] = dual[(size_t)b * np + p];
+    }
+  HIP_TRY(hipMemcpyAsync(c->d_sto_con, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return RTOC_OK;
+}
+
+int rtoc_sto_correct_time_steps(rtoc_ctx* c) {
+  CHECK_READY(c);
+  if (!c->sto_on) return RTOC_OK;
+  STO_LAUNCH(sto_time_steps_kernel, c);
+  return RTOC_OK;
+}
+
+static int sto_download(rtoc_ctx* c, const double* src, size_t per, double* host_out, int count) {
+  if (!c->sto_on) return RTOC_ERR_NOT_READY;
+  if (!host_out || count < 0 || count > c->batch) return RTOC_ERR_BAD_ARG;
+  HIP_TRY(hipMemcpyAsync(host_out, src, sizeof(double) * per * count, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return RTOC_OK;
+}
+int rtoc_sto_get_event_times(rtoc_ctx* c, double* host_out, int count) {
+  CHECK_READY(c);
+  return sto_download(c, c->d_ts, c->sto_nev, host_out, count);
+}
+int rtoc_sto_get_time_steps(rtoc_ctx* c, double* host_out, int count) {
+  CHECK_READY(c);
+  return sto_download(c, c->d_dt, c->nstages, host_out, count);
+}
+int rtoc_sto_get_constraint_data(rtoc_ctx* c, double* host_out, int count) {
+  CHECK_READY(c);
+  return sto_download(c, c->d_sto_con, RTOC_STO_CON_STRIDE, host_out, count);
+}
+int rtoc_sto_get_kkt_terms(rtoc_ctx* c, double* host_lt, double* host_qtt, double* host_err_sq, int count) {
+  CHECK_READY(c);
+  if (!c->sto_on) return RTOC_ERR_NOT_READY;
+  const size_t ne = (size_t)c->batch * c->sto_nev;
+  int rc = RTOC_OK;
+  if (host_lt) rc = sto_download(c, c->d_sto_out, c->sto_nev, host_lt, count);
+  if (!rc && host_qtt) rc = sto_download(c, c->d_sto_out + ne, c->sto_nev, host_qtt, count);
+  if (!rc && host_err_sq) rc = sto_download(c, c->d_sto_out + 2 * ne, 1, host_err_sq, count);
+  return rc;
+}
+
+// SwitchingTimeOptimization::evalKKT of every instance from the event times on the device (after rtoc_condense, like
+// ocp_solver.cpp:118-119); rtoc_kkt_error's result (RTOC's d_kkterr) becomes OCPSolver::KKTError() incl. the STO term
+int rtoc_sto_eval_kkt_device(rtoc_ctx* c) {
+  CHECK_READY(c);
+  if (!c->sto_on) return RTOC_OK;
+  STO_LAUNCH(sto_eval_kkt_dev_kernel, c);
+  return RTOC_OK;
+}
+int rtoc_sto_compute_step_sizes(rtoc_ctx* c) {
+  CHECK_READY(c);
+  if (!c->sto_on) return RTOC_OK;
+  STO_LAUNCH(sto_step_sizes_kernel, c);
+  return RTOC_OK;
+}
+int rtoc_sto_integrate_solution(rtoc_ctx* c) {
+  CHECK_READY(c);
+  if (!c->sto_on) return RTOC_OK;
+  STO_LAUNCH(sto_integrate_kernel, c);
+  return RTOC_OK;
+}
+
 // ---- filter line search (line_search_filter.cpp), batched ---------------------------------------
 static int ensure_filter(rtoc_ctx* c) {
   if (c->d_filter) return RTOC_OK;
@@ -2193,14 +2431,17 @@ static int newton_iteration_body(rtoc_ctx* c, double kkt_tol, double tau) {
   HIP_TRY(hipMemsetAsync(c->d_nconv, 0, sizeof(int), c->stream));
   int rc = launch_kkt_error(c);  // on the freshly linearised (pre-condensation) records
   if (!rc) rc = rtoc_condense(c);
+  if (!rc && c->sto_on) STO_LAUNCH(sto_eval_kkt_dev_kernel, c);   // sto_.evalKKT (ocp_solver.cpp:119); KKTError() gains the STO term
   if (!rc) rc = launch_sweep(c);
   if (!rc) rc = rtoc_expand(c, tau);  // directions + fraction-to-boundary step sizes, on the device
   if (rc) return rc;
+  if (c->sto_on) STO_LAUNCH(sto_step_sizes_kernel, c);             // sto_.computeStepSizes, min with the stages' steps (:128-132)
   hipLaunchKernelGGL(mask_converged_kernel, dim3((c->batch + 255) / 256), dim3(256), 0, c->stream,
                      c->buf[RTOC_BUF_STEP], c->d_kkterr, c->d_nconv, kkt_tol, c->batch);
   HIP_TRY(hipGetLastError());
   rc = rtoc_update(c);
   if (!rc && c->buf[RTOC_BUF_SOL]) rc = rtoc_integrate_solution(c);
+  if (!rc && c->sto_on) STO_LAUNCH(sto_integrate_kernel, c);       // sto_.integrateSolution (:143)
   return rc;
 }
 

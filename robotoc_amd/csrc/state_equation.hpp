@@ -23,6 +23,7 @@ struct SeArgs {
   int nstages, batch;
   rtoc_record_layout kl, dl;
   int nx;
+  const double* dt_inst;  // per-instance time steps or nullptr (grid_dt)
 };
 
 // mode 0: correctLinearize(Impact)StateEquation on every non-terminal grid point
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(64) void state_correction_kernel(SeArgs a) {
 #pragma unroll
     for (int k = 0; k < 6; ++k) acc += inv[i + 6 * k] * sIn[k + 6 * j];
     Fxx[i + (size_t)j * nx] = -acc;                                        // Fqq corner (:81 / impact :69)
-    if (!impact) Fxx[i + (size_t)(nv + j) * nx] = -g.dt * inv[i + 6 * j];  // Fqv corner (:82)
+    if (!impact) Fxx[i + (size_t)(nv + j) * nx] = -grid_dt(a.grid, a.dt_inst, b, a.nstages, st) * inv[i + 6 * j];  // Fqv corner (:82)
   } else if (lane < 42) {
     const int r = lane - 36;
     double acc = 0.0;

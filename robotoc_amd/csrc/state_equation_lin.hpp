@@ -32,6 +32,7 @@ struct SeLinArgs {
   int o_q, o_v, o_a, o_lmd, o_gmm;
   int o_fxx, o_fx, o_lx, o_hx, o_ffx, o_scal;
   int o_la, o_ha;
+  const double* dt_inst;  // per-instance time steps or nullptr (grid_dt)
 };
 
 namespace selin {
@@ -173,7 +174,7 @@ static __global__ __launch_bounds__(64) void state_equation_lin_kernel(SeLinArgs
     }
     return;
   }
-  const double dt = impact ? 0.0 : g.dt;
+  const double dt = impact ? 0.0 : grid_dt(a.grid, a.dt_inst, b, a.nstages, st);
   const int nv = a.nv, nx = 2 * nv, nb = a.floating ? 6 : 0, nq = nv + (a.floating ? 1 : 0);
   const size_t rec = (size_t)b * a.nstages + st;
   const double* const s = a.sol + rec * a.sol_stride;

@@ -34,6 +34,7 @@ struct SwLinArgs {
   int o_q, o_v, o_a, o_xi;
   int o_phix, o_phit, o_pres, o_lx, o_hx, o_scal;
   int o_phia, o_la, o_ha;
+  const double* dt_inst;  // per-instance time steps or nullptr (grid_dt)
 };
 
 __host__ __device__ constexpr size_t sw_lds_bytes(int nlevels, int njoints, int ncontacts) {
@@ -54,7 +55,7 @@ static __global__ __launch_bounds__(64) void switching_constraint_lin_kernel(SwL
   const rtoc_grid g = a.grid[st];
   if (!g.switching_constraint || st + 2 >= a.nstages) return;
   const int nv = a.nv, nx = 2 * nv, nb = a.njoints, ncon = a.ncontacts, nlev = a.nlevels, ns = g.dims, LDSW = a.ns_max;
-  const double dt1 = g.dt, dt2 = a.grid[st + 1].dt;
+  const double dt1 = grid_dt(a.grid, a.dt_inst, b, a.nstages, st), dt2 = grid_dt(a.grid, a.dt_inst, b, a.nstages, st + 1);
   const unsigned impact = a.active[st + 2];  // ImpactStatus of the impact two grid points ahead
   double* const lval = smem;                               // [nlev][32]: R 9, p 3, oR 9, op 3, body index
   double* const ltan = lval + (size_t)nlev * 32;           // [nlev][6][64]

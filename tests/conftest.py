@@ -33,14 +33,20 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
     tolerance.  Printed under -q as well, so that the driver's log of a green run carries numbers, and written to
     gpurun_out/parity_summary.json (merged back from the GPU box)."""
     import json
+    import re
     import helpers
     if not helpers.PARITY:
         return
     rows = []
     for test, items in helpers.PARITY.items():
         label, obs, tol = max(items, key=lambda it: it[1] / it[2] if it[2] > 0 else 0.0)
+        agg = {}
+        for lb, ob, tl in items:   # per comparison kind (instance / seed numbers stripped): worst observed, its tolerance
+            key = re.sub(r"\s*(inst|seed)\s*\d+", "", lb).strip()
+            if key not in agg or ob > agg[key][0]:
+                agg[key] = [ob, tl]
         rows.append({"test": test, "checks": len(items), "closest": label.strip(), "observed": obs, "tolerance": tol,
-                     "worst_observed": max(it[1] for it in items), "loosest_tolerance": max(it[2] for it in items)})
+                     "worst_observed": max(it[1] for it in items), "loosest_tolerance": max(it[2] for it in items), "items": agg})
     rows.sort(key=lambda r: -(r["observed"] / r["tolerance"] if r["tolerance"] > 0 else 0.0))
     out_dir = os.path.join(ROOT, "gpurun_out")
     try:
