@@ -1,0 +1,405 @@
+"""Host-side mirror of robotoc::OCPSolver (include/robotoc/solver/ocp_solver.hpp:41-241, src/solver/ocp_solver.cpp:96-225) for
+OCPs whose whole iteration is resident on the device (ConfigurationSpaceCost, joint limits, friction cones, contact sequence
+with lifts / touch-downs, optionally switching-time optimisation): what stays on the host is what the reference keeps outside
+updateSolution's kernels -- the contact sequence, the (re-)discretisation, the STO regularisation schedule, the mesh-refinement
+branch with its solution interpolation, the convergence test.  One `OCPSolver` drives a BATCH of instances that share the
+contact-sequence structure (initial states, and with STO the event times, are per instance); batch = 1 is the reference's solver.
+
+The C++ mirror with the reference's signatures is robotoc_amd/host/robotoc_hip_solver.hpp; this one is what tests / bench use.
+"""
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+
+from . import capi
+from .grid import ContactSequence, Event, contact_masks, discretize, discretize_structure_preserving, max_time_step
+from .types import BUF_SOL, GRID_IMPACT, GRID_LIFT, GRID_TERMINAL, Dims, Records, joint_limit_rows
+
+
+@dataclass
+class SolverOptions:
+    """include/robotoc/solver/solver_options.hpp:17-130 (the members this path reads)"""
+    max_iter: int = 100
+    kkt_tol: float = 1.0e-7
+    initial_sto_reg_iter: int = 0
+    initial_sto_reg: float = 1.0e30
+    kkt_tol_mesh: float = 0.1
+    max_dt_mesh: float = 0.0
+    max_dts_riccati: float = 0.1
+    enable_solution_interpolation: bool = True
+    enable_line_search: bool = False
+
+
+@dataclass
+class ContactPlan:
+    """The ContactSequence of the OCP (src/planner/contact_sequence.cpp) as the device needs it: per contact phase the
+    active-contact mask and the contact positions [ncontacts, 3]; per discrete event its kind, time and STO flag."""
+    phase_masks: List[int]
+    phase_positions: List[np.ndarray]
+    events: List[Event] = field(default_factory=list)
+
+    def impact_masks(self):
+        out, p = [], 0
+        for e in self.events:
+            if e.kind == "impact":
+                out.append(self.phase_masks[p + 1] & ~self.phase_masks[p])
+            p += 1
+        return out
+
+
+@dataclass
+class STOConstraints:
+    """src/sto/sto_constraints.cpp:12-59"""
+    minimum_dwell_times: List[float]
+    barrier_param: float = 1.0e-3
+    fraction_to_boundary_rule: float = 0.995
+
+
+@dataclass
+class SolverStatistics:
+    convergence: bool = False
+    iter: int = 0
+    kkt_error: List[np.ndarray] = field(default_factory=list)        # OCPSolver::KKTError() per iteration, [batch]
+    ts: List[np.ndarray] = field(default_factory=list)               # event times per iteration, [batch, nev]
+    mesh_refinement_iter: List[int] = field(default_factory=list)
+
+
+# ---- SE(3) helpers for the solution interpolation (Robot::interpolateConfiguration = pinocchio::interpolate) ----
+def _quat_R(q):
+    x, y, z, w = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def _R_quat(R):
+    w = np.sqrt(max(0.0, 1.0 + R[0, 0] + R[1, 1] + R[2, 2])) / 2.0
+    if w > 1e-6:
+        return np.array([(R[2, 1] - R[1, 2]) / (4 * w), (R[0, 2] - R[2, 0]) / (4 * w), (R[1, 0] - R[0, 1]) / (4 * w), w])
+    i = int(np.argmax(np.diag(R)))
+    j, k = (i + 1) % 3, (i + 2) % 3
+    s = np.sqrt(max(0.0, 1.0 + R[i, i] - R[j, j] - R[k, k])) * 2.0
+    q = np.zeros(4)
+    q[i], q[j], q[k], q[3] = 0.25 * s, (R[j, i] + R[i, j]) / s, (R[k, i] + R[i, k]) / s, (R[k, j] - R[j, k]) / s
+    return q
+
+
+def _skew(a):
+    return np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+
+
+def _log3(R):
+    c = min(1.0, max(-1.0, (np.trace(R) - 1.0) / 2.0))
+    th = np.arccos(c)
+    if th < 1e-10:
+        return 0.5 * np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+    return th / (2.0 * np.sin(th)) * np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+
+
+def _exp3(w):
+    th = np.linalg.norm(w)
+    K = _skew(w)
+    if th < 1e-10:
+        return np.eye(3) + K
+    return np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th ** 2 * K @ K
+
+
+def _V(w):   # exp6: p = V(w) v
+    th = np.linalg.norm(w)
+    K = _skew(w)
+    if th < 1e-10:
+        return np.eye(3) + 0.5 * K
+    return np.eye(3) + (1 - np.cos(th)) / th ** 2 * K + (th - np.sin(th)) / th ** 3 * K @ K
+
+
+def interpolate_configuration(q1, q2, alpha, floating):
+    """q1 (+) alpha (q2 (-) q1): joints linearly, a free-flyer base along the screw motion between the two placements"""
+    q = (1.0 - alpha) * q1 + alpha * q2
+    if floating:
+        R1, R2 = _quat_R(q1[3:7]), _quat_R(q2[3:7])
+        Rr, pr = R1.T @ R2, R1.T @ (q2[:3] - q1[:3])
+        w = _log3(Rr)
+        v = np.linalg.solve(_V(w), pr)
+        Ra, pa = _exp3(alpha * w), _V(alpha * w) @ (alpha * v)
+        q[:3] = q1[:3] + R1 @ pa
+        quat = _R_quat(R1 @ Ra)
+        q[3:7] = quat / np.linalg.norm(quat)
+    return q
+
+
+class OCPSolver:
+    def __init__(self, model, plan: ContactPlan, T, N, cost, joint_limits=None, friction_coefficients=None, barrier_param=1.0e-3,
+                 fraction_to_boundary_rule=0.995, sto_constraints: Optional[STOConstraints] = None, options: Optional[SolverOptions] = None,
+                 batch=1, device=0, impact_cones=False):
+        """cost: keyword arguments of capi.Context.set_configuration_cost; joint_limits: (q_min, q_max, v_max, u_max) over the
+        actuated joints or None; friction_coefficients: per contact or None."""
+        self.model, self.plan, self.T, self.N = model, plan, float(T), int(N)
+        self.options = options or SolverOptions()
+        self.sto = sto_constraints
+        self.batch = batch
+        nu = model.nu
+        self.nc = model.ncontacts
+        rows = joint_limit_rows_for(model) if joint_limits is not None else []
+        nc_max = (len(rows) + (5 * self.nc if friction_coefficients is not None else 0) + 7) & ~7
+        self.dims = Dims(model.nv, nu, model.nv - nu, model.max_dimf, model.max_dimf, nc_max)
+        nlift = sum(1 for e in plan.events if e.kind == "lift")
+        nimp = len(plan.events) - nlift
+        self.max_stages = self.N + 1 + nlift + 2 * nimp
+        self.ctx = capi.Context(self.dims, self.max_stages, batch, device)
+        c = self.ctx
+        c.set_robot_model(model)
+        c.set_configuration_cost(**cost)
+        c.set_max_dts0(self.options.max_dts_riccati)
+        self.tau = fraction_to_boundary_rule
+        if rows:
+            q_min, q_max, v_max, u_max = (np.asarray(x, dtype=float) for x in joint_limits)
+            c.set_constraint_rows(rows)
+            c.set_constraint_bounds(np.concatenate([-q_min, q_max, v_max, v_max, u_max, u_max]), barrier_param, fraction_to_boundary_rule)
+        if friction_coefficients is not None:
+            c.set_friction_cones(self.nc, 3)
+            c.set_impact_cones(impact_cones)
+            c.set_barrier_param(barrier_param, fraction_to_boundary_rule)
+            c.set_friction_coefficients(np.asarray(friction_coefficients, dtype=float))
+        self.has_rows = bool(rows) or friction_coefficients is not None
+        self.event_times = np.tile(np.array([e.time for e in plan.events], dtype=float), (batch, 1))   # per instance
+        self.grids, self.masks, self.t_grid = None, None, None
+        self.S = Records(c.L, "sol")
+        self.stats = SolverStatistics()
+        self._sol_guess = None
+
+    # ---- discretisation (ocp_solver.cpp:96-102) ----
+    def _sequence(self, ts):
+        return ContactSequence([self.model.active_rows(m) for m in self.plan.phase_masks],
+                               [Event(e.kind, float(t), e.sto, self.model.active_rows(self.plan.phase_masks[p + 1] & ~self.plan.phase_masks[p])
+                                      if e.kind == "impact" else 0) for p, (e, t) in enumerate(zip(self.plan.events, ts))])
+
+    def discretize(self, t):
+        """TimeDiscretization::discretize (+ correctTimeSteps with an STO problem).  The batch shares the structure: it is that
+        of the mean event times; every instance gets its own time steps from its own event times (rtoc_sto_set_problem)."""
+        self.t0 = float(t)
+        cs = self._sequence(self.event_times.mean(axis=0))
+        grids = discretize(self.N, self.T, t, cs, phase_based=self.sto is not None)
+        if len(grids) != self.max_stages:
+            raise RuntimeError("the discretisation has %d grid points, the context was sized for %d (an event left the horizon?)"
+                               % (len(grids), self.max_stages))
+        self.grids = grids
+        c = self.ctx
+        c.set_grid(grids)
+        self.masks = contact_masks(grids, self.plan.phase_masks, self.plan.impact_masks())
+        pos, phase = np.zeros((len(grids), self.nc, 3)), 0
+        for i, g in enumerate(grids):
+            if g.type in (GRID_IMPACT, GRID_LIFT):
+                phase += 1
+            pos[i] = self.plan.phase_positions[min(phase, len(self.plan.phase_positions) - 1)]
+        c.set_contact_schedule(self.masks, pos)
+        if self.sto is not None and len(self.plan.events) > 0:
+            c.sto_set_problem(self.t0, self.T, self.event_times, self.sto.minimum_dwell_times, self.sto.barrier_param,
+                              self.sto.fraction_to_boundary_rule)
+
+    def grid_times(self, b=0):
+        """t of every grid point of instance b (TimeDiscretization::grid(i).t)"""
+        dt = self.ctx.sto_time_steps()[b] if self.sto is not None and self.plan.events else np.array([g.dt for g in self.grids])
+        return self.t0 + np.concatenate([[0.0], np.cumsum(dt[:-1])]), dt
+
+    # ---- solution access ----
+    def set_solution(self, sol):
+        """sol: [batch, nstages, stride] SplitSolution records (Records(ctx.L, "sol"))"""
+        self.ctx.upload(BUF_SOL, np.ascontiguousarray(sol))
+
+    def get_solution(self):
+        return self.ctx.download_records(BUF_SOL, "sol")
+
+    def init_constraints(self):
+        """OCPSolver::initConstraints (ocp_solver.cpp:105-108)"""
+        if self.has_rows:
+            self.ctx.contact_init_constraints()
+        self.ctx.sto_init_constraints()
+
+    # ---- iteration ----
+    def update_solution(self, t, x0=None):
+        """OCPSolver::updateSolution (ocp_solver.cpp:111-145) of every instance; returns KKTError() of the iterate it linearised at"""
+        if x0 is not None:
+            self.ctx.set_initial_state(x0)
+        return self.ctx.contact_update_solution(self.tau)
+
+    def solve(self, t, x0, init_solver=True):
+        """OCPSolver::solve (ocp_solver.cpp:148-225).  Convergence / mesh-refinement decisions are taken for the batch as a whole
+        (every instance below the tolerance); with batch = 1 that is the reference's loop."""
+        o = self.options
+        c = self.ctx
+        c.set_initial_state(x0)
+        if init_solver:
+            self.discretize(t)
+            self.init_constraints()
+            c.line_search_clear()
+        st = self.stats = SolverStatistics()
+        sto_on = self.sto is not None and len(self.plan.events) > 0
+        inner = 0
+        for it in range(o.max_iter):
+            if sto_on:
+                c.sto_set_regularization(o.initial_sto_reg if inner < o.initial_sto_reg_iter else 0.0)   # :169-176
+                st.ts.append(c.sto_event_times())
+            err = self.update_solution(t)
+            st.kkt_error.append(err)
+            inner += 1
+            st.iter = it + 1
+            worst = float(np.max(err))
+            if sto_on and worst < o.kkt_tol_mesh:                                                      # :181-199
+                self.event_times = c.sto_event_times()
+                if self._max_time_step() > o.max_dt_mesh:
+                    self._mesh_refinement(t)
+                    inner = 0
+                    st.mesh_refinement_iter.append(it + 1)
+                    continue
+            if worst < o.kkt_tol:
+                st.convergence = True
+                break
+        if sto_on:
+            self.event_times = c.sto_event_times()
+        return st
+
+    def kkt_error(self):
+        """OCPSolver::KKTError(t, q, v) (ocp_solver.cpp:414-426) at the current iterate, without moving it"""
+        c = self.ctx
+        c.contact_eval_kkt()
+        err = c.kkt_error()
+        if self.sto is not None and self.plan.events:
+            c.condense()
+            c.sto_eval_kkt_device()
+            err = np.sqrt(err ** 2 + c.sto_kkt_terms()[2])
+        return err
+
+    # ---- mesh refinement (ocp_solver.cpp:184-199) ----
+    def _max_time_step(self):
+        dt = self.ctx.sto_time_steps()
+        return float(dt[:, :-1].max())
+
+    def _mesh_refinement(self, t):
+        old_grids, old_masks = self.grids, self.masks
+        old_sol = self.get_solution()
+        old_dt = self.ctx.sto_time_steps()
+        self.discretize(t)   # new structure at the current event times, per-instance time steps on the device
+        new_dt = self.ctx.sto_time_steps()
+        if self.options.enable_solution_interpolation:
+            new_sol = self.S.zeros(self.batch, len(self.grids))
+            for b in range(self.batch):
+                t_old = self.t0 + np.concatenate([[0.0], np.cumsum(old_dt[b, :-1])])
+                t_new = self.t0 + np.concatenate([[0.0], np.cumsum(new_dt[b, :-1])])
+                self._interpolate(old_grids, old_masks, t_old, old_dt[b], old_sol[b], self.grids, self.masks, t_new, new_sol[b])
+            self.set_solution(new_sol)
+        self.init_constraints()
+        self.ctx.line_search_clear()
+
+    def _expand(self, rec, mask, name):
+        """contact-indexed [ncontacts, 3] view of the compacted f / mu stack of a record"""
+        out, k = np.zeros((self.nc, 3)), 0
+        x = self.S.f(rec, name)
+        for cidx in range(self.nc):
+            if (int(mask) >> cidx) & 1:
+                out[cidx] = x[3 * k:3 * k + 3]
+                k += 1
+        return out
+
+    def _interpolate(self, g0, m0, t0s, dt0, s0, g1, m1, t1s, s1):
+        """SolutionInterpolator::interpolate (src/solver/solution_interpolator.cpp:33-116) on the packed records"""
+        S, nq, fl = self.S, self.model.nq, self.model.floating_base
+        n0 = len(g0)
+
+        def field(rec, name):
+            return S.f(rec, name)
+
+        def put_stack(rec, mask, name, by_contact):
+            k = 0
+            x = field(rec, name)
+            x[:] = 0.0
+            for cidx in range(self.nc):
+                if (int(mask) >> cidx) & 1:
+                    x[3 * k:3 * k + 3] = by_contact[cidx]
+                    k += 1
+
+        def blend(i, a, b, alpha, mode):
+            """mode: full (interpolate :119-146), partial (:149-172), event (initEventSolution :175-198)"""
+            ra, rb, out = s0[a], s0[b], s1[i]
+            field(out, "q")[:nq] = interpolate_configuration(field(ra, "q")[:nq], field(rb, "q")[:nq], alpha, fl)
+            for name in ("v", "lmd", "gmm"):
+                field(out, name)[:] = (1 - alpha) * field(ra, name) + alpha * field(rb, name)
+            fa, fb = self._expand(ra, m0[a], "f"), self._expand(rb, m0[b], "f")
+            ma, mb = self._expand(ra, m0[a], "mu"), self._expand(rb, m0[b], "mu")
+            if mode == "full":
+                for name in ("u", "a", "beta", "nu_passive"):
+                    field(out, name)[:] = (1 - alpha) * field(ra, name) + alpha * field(rb, name)
+                act_b = np.array([(int(m0[b]) >> cidx) & 1 for cidx in range(self.nc)], dtype=bool)[:, None]
+                f_, mu_ = np.where(act_b, (1 - alpha) * fa + alpha * fb, fa), np.where(act_b, (1 - alpha) * ma + alpha * mb, ma)
+            elif mode == "partial":
+                for name in ("u", "a", "beta", "nu_passive"):
+                    field(out, name)[:] = field(ra, name)
+                f_, mu_ = fa, ma
+            else:
+                field(out, "a")[:] = (1 - alpha) * field(ra, "a") + alpha * field(rb, "a")
+                for name in ("u", "beta", "nu_passive"):
+                    field(out, name)[:] = field(rb, name)
+                f_, mu_ = fb, mb
+            put_stack(out, m1[i], "f", f_)
+            put_stack(out, m1[i], "mu", mu_)
+
+        def copy(i, a):
+            s1[i][:] = s0[a]
+            # the stacks are compacted by the active contacts of the grid point: re-pack for the new grid point's mask
+            put_stack(s1[i], m1[i], "f", self._expand(s0[a], m0[a], "f"))
+            put_stack(s1[i], m1[i], "mu", self._expand(s0[a], m0[a], "mu"))
+
+        def before(tt):   # findStoredGridIndexBeforeTime
+            k = int(np.searchsorted(t0s, tt, side="right") - 1)
+            k = min(max(k, 0), n0 - 2)
+            while k > 0 and dt0[k] <= 0.0:   # an impact grid point has no extent in time
+                k -= 1
+            return k
+
+        def stored_event(tt, kind):
+            for k in range(n0 - 1):
+                if g0[k].type == kind and abs(t0s[k] - tt) < 1e-9:
+                    return k
+            return -1
+        N1 = len(g1) - 1
+        for i, g in enumerate(g1):
+            tt = t1s[i]
+            if tt <= t0s[0]:
+                copy(i, 0)
+                continue
+            if tt >= t0s[-1]:
+                copy(i, n0 - 1)
+                continue
+            if g.type in (GRID_IMPACT, GRID_LIFT):
+                k = stored_event(tt, g.type)
+                if k >= 0:
+                    copy(i, k)
+                    if g.type == GRID_IMPACT:
+                        for name in ("u", "a", "nu_passive"):
+                            field(s1[i], name)[:] = 0.0
+                        if i >= 2 and k >= 2:
+                            field(s1[i - 2], "xi")[:] = field(s0[k - 2], "xi")
+                    continue
+                a = before(tt)
+                alpha = min(max((tt - t0s[a]) / dt0[a], 0.0), 1.0)
+                if g0[a + 1].type == GRID_TERMINAL:
+                    blend(i, a, a + 1, alpha, "partial")
+                    if g.type == GRID_IMPACT:
+                        for name in ("u", "a", "nu_passive"):
+                            field(s1[i], name)[:] = 0.0
+                else:
+                    blend(i, a, a + 1, alpha, "event")
+                continue
+            a = before(tt)
+            alpha = min(max((tt - t0s[a]) / dt0[a], 0.0), 1.0)
+            blend(i, a, a + 1, alpha, "full" if g0[a + 1].type == 0 else "partial")
+        for name in ("u", "a", "f", "beta", "mu", "nu_passive"):   # modifyTerminalSolution
+            field(s1[N1], name)[:] = 0.0
+
+    def close(self):
+        self.ctx.close()
+
+
+def joint_limit_rows_for(model):
+    """the six joint-limit components over the actuated joints, in the order examples/anymal/trot.cpp:134-146 adds them"""
+    return joint_limit_rows(Dims(model.nv, model.nu, model.nv - model.nu, model.max_dimf, model.max_dimf, 0))
