@@ -407,6 +407,42 @@ def dry_run(args, rank, world):
         dist.destroy_process_group()
 
 
+def closed_loop_jump_sto(local_rank, timed=10):
+    """OCPSolver::solve of BASELINE configs[2] with nothing of the iteration on the host: stand - flight - stand, both switching
+    times optimised (SwitchingTimeOptimization on the device: dwell-time rows, per-instance event times and time steps),
+    ConfigurationSpaceCost, six joint-limit components + FrictionCone; mesh refinement on the host between iterations."""
+    from robotoc_amd import problems_jump as pj
+    out = {}
+    for label, b2 in (("single_instance", 1), ("batch", 1024)):
+        solver, x0, info = pj.anymal_jump_sto_solver(batch=b2, device=local_rank, x0_noise=0.0 if b2 == 1 else 0.03)
+        c = solver.ctx
+        t0 = time.perf_counter()
+        st = solver.solve(0.0, x0)
+        solve_s = time.perf_counter() - t0
+        errs = np.array(st.kkt_error)
+        ts = solver.event_times
+        c.contact_update_solution(0.995, want_kkt_error=False)
+        c.sync()
+        t0 = time.perf_counter()
+        for _ in range(timed):
+            c.contact_update_solution(0.995, want_kkt_error=False)
+        c.sync()
+        ms = (time.perf_counter() - t0) / timed * 1e3
+        out[label] = {"batch": b2, "grid_points": len(solver.grids), "update_solution_ms": ms, "iterations_per_sec": b2 / ms * 1e3,
+                      "solve_iterations": st.iter, "solve_converged": bool(st.convergence), "solve_wall_s": solve_s,
+                      "mesh_refinements_at": st.mesh_refinement_iter, "kkt_error_first_worst": float(errs[0].max()),
+                      "kkt_error_last_worst": float(errs[-1].max()), "event_times_initial": [0.31, 0.51],
+                      "event_times_optimised_instance0": [float(v) for v in ts[0]],
+                      "event_times_optimised_spread": [float(v) for v in (ts.max(axis=0) - ts.min(axis=0))],
+                      "status_ok": bool((c.status() == 0).all())}
+        solver.close()
+    out["scope"] = ("the WHOLE OCPSolver::updateSolution incl. its switching-time half on the device (correctTimeSteps, sto_.evalKKT, "
+                    "computeStepSizes, integrateSolution; cost, joint limits + friction cones, state equation, RNEA + derivatives, switching "
+                    "constraint, condensation, STO Riccati recursion, expansion, update); OCPSolver::solve's regularisation schedule, "
+                    "convergence test and mesh refinement (with solution interpolation) on the host; wall clock around asynchronous launches")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -831,6 +867,14 @@ def main():
             others["iiwa14_unconstr_N20"]["closed_loop"] = loop
         except Exception as e:  # the sweep numbers above stand on their own
             others["iiwa14_unconstr_N20"]["closed_loop"] = {"error": repr(e)}
+
+    # ---- BASELINE configs[2] closed on the device: the ANYmal jump with switching-time optimisation (examples/anymal/python/
+    #      jump_sto.py at N = 40) solved by robotoc_amd.solver.OCPSolver -- per-instance switching times, mesh refinement ----
+    if others is not None and "anymal_jump_sto_N40" in others:
+        try:
+            others["anymal_jump_sto_N40"]["closed_loop"] = closed_loop_jump_sto(local_rank)
+        except Exception as e:  # the sweep numbers above stand on their own
+            others["anymal_jump_sto_N40"]["closed_loop"] = {"error": repr(e)}
 
     if rank == 0:
         total_sweeps = world * batch * args.steps

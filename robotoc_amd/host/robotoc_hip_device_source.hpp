@@ -24,6 +24,29 @@ class ConfigurationCostSource : public StageDataSource {
     if (active.size() != grid.size() || contact_positions.size() != grid.size() * static_cast<size_t>(model.ncontacts) * 3)
       throw std::invalid_argument("[ConfigurationCostSource] one contact mask and ncontacts positions per grid point");
   }
+  // The same OCP described like the reference describes it: contact sequence + horizon (OCP::contact_sequence, T, N) instead of
+  // a ready-made grid, optionally with STOConstraints (an OCP with an STO problem: PhaseBased discretisation, ocp_solver.cpp:46-48).
+  // The source then owns the discretisation: OCPSolver::discretize(t) re-runs TimeDiscretization::discretize at the sequence's
+  // current event times (mesh refinement).  s0: initial guess over the N + 1 + lifts + 2 impacts grid points of discretize(t = 0).
+  ConfigurationCostSource(const rtoc_robot_model& model, const rtoc_configuration_cost& cost, const ContactSequence& contact_sequence,
+                          const double T, const int N, const Solution& s0, const std::shared_ptr<STOConstraints>& sto_constraints = nullptr)
+      : model_(model), cost_(cost), s0_(s0), cs_(new ContactSequence(contact_sequence)), sto_(sto_constraints), T_(T), N_(N) {
+    if (!(T > 0.0)) throw std::out_of_range("[OCPSolver] invalid argument: ocp.T must be positive!");
+    if (N <= 0) throw std::out_of_range("[OCPSolver] invalid argument: ocp.N must be positive!");
+    if (contact_sequence.numContacts() != model.ncontacts) throw std::invalid_argument("[ConfigurationCostSource] the contact sequence is for another robot");
+    discretize(0.0);
+  }
+  ContactSequence* contactSequence() override { return cs_.get(); }
+  const STOConstraints* stoConstraints() const override { return sto_.get(); }
+  double horizonLength() const override { return T_; }
+  const std::vector<unsigned>* contactMasks() const override { return &active_; }
+  bool discretize(const double t) override {
+    if (!cs_) return false;
+    td_ = robotoc::discretize(*cs_, T_, N_, t, static_cast<bool>(sto_));
+    contactSchedule(*cs_, td_, active_, cpos_);
+    scheduled_ = false;
+    return true;
+  }
   RobotDims robot() const override {
     const bool ff = model_.type[0] == RTOC_JOINT_FREE_FLYER;
     int dimf = 0;
@@ -124,6 +147,10 @@ class ConfigurationCostSource : public StageDataSource {
   bool impact_cone_ = false;
   double barrier_ = 1.0e-3, ftb_ = 0.995;
   bool scheduled_ = false;
+  std::shared_ptr<ContactSequence> cs_;
+  std::shared_ptr<STOConstraints> sto_;
+  double T_ = 0.0;
+  int N_ = 0;
 };
 
 }  // namespace robotoc

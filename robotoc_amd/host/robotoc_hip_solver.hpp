@@ -19,8 +19,10 @@
 // slack/dual update, SplitSolution::integrate -- run on the GPU; ONE device context is shared by the
 // DirectMultipleShooting and RiccatiRecursion members, so the stage data never leave HBM inside an iteration
 // and the host containers (getSolution, getLQRPolicy, getRiccatiFactorization) are filled on demand.
-// Not in the shell: the STO problem (SwitchingTimeOptimization, scalar), the line search (off by default,
-// solver_options.hpp:70) -- both raise std::logic_error if requested.
+// The STO problem: robotoc::SwitchingTimeOptimization below keeps the reference's method names over the device-resident
+// switching-time half of the iteration (rtoc_sto_*: dwell-time rows, per-instance event times and time steps); solve() carries
+// the regularisation schedule and the mesh-refinement branch (ocp_solver.cpp:164-199) with the planner mirrors of
+// robotoc_hip_planner.hpp.  The line search: SolverOptions::enable_line_search (filter method over rtoc_eval_ocp).
 // (rtoc_integrate_solution updates q on the manifold, free-flyer base included.)
 #ifndef ROBOTOC_HIP_SOLVER_HPP_
 #define ROBOTOC_HIP_SOLVER_HPP_
@@ -33,6 +35,7 @@
 #include <ostream>
 
 #include "robotoc_hip.hpp"
+#include "robotoc_hip_planner.hpp"
 
 namespace robotoc {
 
@@ -47,7 +50,11 @@ struct SolverOptions {
   double mu_superlinear_decrease_power = 1.5;
   bool enable_line_search = false;
   double fraction_to_boundary_rule = 0.995;  // ConstraintComponentBase default (constraint_component_base.hpp)
+  int initial_sto_reg_iter = 0;              // solver_options.hpp:96-113
+  double initial_sto_reg = 1.0e30;
+  double kkt_tol_mesh = 0.1;
   double max_dt_mesh = 0.0;                  // solver_options.hpp:119
+  double max_dts_riccati = 0.1;
   bool enable_solution_interpolation = true;
   bool enable_benchmark = false;
   bool horizon_scan = false;  // not in the reference: RTOC_OPT_BACKWARD_SCAN for the single-OCP latency path
@@ -59,6 +66,8 @@ struct SolverStatistics {
   int iter = 0;
   std::vector<double> performance_index;  // per iteration: PerformanceIndex::kkt_error, i.e. the SQUARED KKT error, in both solver shells
   std::vector<double> primal_step_size, dual_step_size;
+  std::vector<std::vector<double>> ts;    // event times ahead of every iteration, if the OCP has an STO problem
+  std::vector<int> mesh_refinement_iter;  // iterations after which the mesh was refined
   double cpu_time = 0.0;  // [ms], if SolverOptions::enable_benchmark
   void clear() { *this = SolverStatistics(); }
 };
@@ -102,6 +111,15 @@ class StageDataSource {
   // false: linearize() / initialStateDirection() never read their `s` argument (the source linearises at the iterate in
   // RTOC_BUF_SOL on the device), so OCPSolver::updateSolution need not download the iterate before calling them
   virtual bool needsHostSolution() const { return true; }
+  // ---- sources that own the contact sequence can re-discretise (OCPSolver::discretize, mesh refinement) ----
+  // the contact sequence with its current event times, or nullptr (the grid comes with the stage data and is fixed)
+  virtual ContactSequence* contactSequence() { return nullptr; }
+  virtual const STOConstraints* stoConstraints() const { return nullptr; }   // non-null: the OCP has an STO problem
+  virtual double horizonLength() const { return 0.0; }                        // OCP::T
+  // TimeDiscretization::discretize(contact_sequence, t) (+ correctTimeSteps when phase based) from the sequence's current
+  // event times; the next linearize() / initConstraints() must hand the new contact schedule to the device
+  virtual bool discretize(const double) { return false; }
+  virtual const std::vector<unsigned>* contactMasks() const { return nullptr; }
   virtual void initialSolution(Solution& s) const = 0;
 };
 
@@ -378,6 +396,77 @@ class DirectMultipleShooting {
   double max_primal_, max_dual_;
 };
 
+// robotoc::SwitchingTimeOptimization (include/robotoc/sto/switching_time_optimization.hpp, src/sto/switching_time_optimization.cpp)
+// over the device: the dwell-time rows, event times and time steps of the instance live in the context (rtoc_sto_*).
+class SwitchingTimeOptimization {
+ public:
+  SwitchingTimeOptimization() : enabled_(false) {}
+  SwitchingTimeOptimization(const std::shared_ptr<StageDataSource>& source, const std::shared_ptr<DeviceContext>& dev)
+      : source_(source), dev_(dev), enabled_(source && source->stoConstraints() && source->contactSequence()), sto_reg_(0.0) {}
+  void rebind(const std::shared_ptr<DeviceContext>& dev) { dev_ = dev; }
+  bool enabled() const { return enabled_ && source_->contactSequence()->numDiscreteEvents() > 0; }
+  // hands the contact sequence's event times and the STOConstraints to the device (after every rtoc_set_grid)
+  void setProblem(const double t) {
+    if (!enabled()) return;
+    const ContactSequence& cs = *source_->contactSequence();
+    const STOConstraints& sc = *source_->stoConstraints();
+    if (static_cast<int>(sc.minimum_dwell_times.size()) != cs.numDiscreteEvents() + 1)
+      throw std::runtime_error("[STOConstraints] : invalid size of minimum_dwell_times_ is detected! It should be " + std::to_string(cs.numDiscreteEvents() + 1));
+    chk(rtoc_sto_set_problem(ctx(), t, source_->horizonLength(), cs.eventTimes().data(), cs.numDiscreteEvents(), 0,
+                             sc.minimum_dwell_times.data(), sc.barrier_param, sc.fraction_to_boundary_rule), "rtoc_sto_set_problem");
+    chk(rtoc_sto_set_regularization(ctx(), sto_reg_), "rtoc_sto_set_regularization");
+  }
+  void setRegularization(const double sto_reg) {
+    sto_reg_ = sto_reg;
+    if (enabled()) chk(rtoc_sto_set_regularization(ctx(), sto_reg), "rtoc_sto_set_regularization");
+  }
+  void initConstraints(const TimeDiscretization&) {
+    if (enabled()) chk(rtoc_sto_init_constraints(ctx()), "rtoc_sto_init_constraints");
+  }
+  void evalKKT(const TimeDiscretization&, KKTMatrix&, KKTResidual&) {
+    performance_index_.kkt_error = 0.0;
+    if (!enabled()) return;
+    chk(rtoc_sto_eval_kkt_device(ctx()), "rtoc_sto_eval_kkt_device");
+    chk(rtoc_sto_get_kkt_terms(ctx(), nullptr, nullptr, &performance_index_.kkt_error, 1), "rtoc_sto_get_kkt_terms");
+  }
+  void computeStepSizes(const TimeDiscretization&, const Direction&) {
+    max_primal_ = max_dual_ = 1.0;
+    if (!enabled()) return;
+    // the device folds the rows' fraction-to-boundary steps into RTOC_BUF_STEP (the stages' steps are there already)
+    chk(rtoc_sto_compute_step_sizes(ctx()), "rtoc_sto_compute_step_sizes");
+    double st[2] = {1.0, 1.0};
+    chk(rtoc_download(ctx(), RTOC_BUF_STEP, 0, st, 2), "rtoc_download");
+    max_primal_ = st[0], max_dual_ = st[1];
+  }
+  double maxPrimalStepSize() const { return max_primal_; }
+  double maxDualStepSize() const { return max_dual_; }
+  // event times of the contact sequence += primal step x dts, slack / dual of the rows (:181-206); the steps are those
+  // DirectMultipleShooting::integrateSolution left in RTOC_BUF_STEP
+  void integrateSolution(const TimeDiscretization&, const double, const double, const Direction&) {
+    if (!enabled()) return;
+    chk(rtoc_sto_integrate_solution(ctx()), "rtoc_sto_integrate_solution");
+    syncEventTimes();
+  }
+  void syncEventTimes() {
+    if (!enabled()) return;
+    std::vector<double> ts(source_->contactSequence()->numDiscreteEvents());
+    chk(rtoc_sto_get_event_times(ctx(), ts.data(), 1), "rtoc_sto_get_event_times");
+    source_->contactSequence()->setEventTimes(ts);
+  }
+  const PerformanceIndex& getEval() const { return performance_index_; }
+
+ private:
+  static void chk(int rc, const char* what) {
+    if (rc != RTOC_OK) throw std::runtime_error(std::string("[SwitchingTimeOptimization] ") + what + ": " + rtoc_error_string(rc));
+  }
+  rtoc_ctx* ctx() const { return dev_->get(); }
+  std::shared_ptr<StageDataSource> source_;
+  std::shared_ptr<DeviceContext> dev_;
+  bool enabled_;
+  double sto_reg_, max_primal_ = 1.0, max_dual_ = 1.0;
+  PerformanceIndex performance_index_;
+};
+
 class OCPSolver {
  public:
   // reference: OCPSolver(const OCP& ocp, const SolverOptions& solver_options = SolverOptions()) (ocp_solver.cpp:14-49)
@@ -389,6 +478,7 @@ class OCPSolver {
     dev_ = std::make_shared<DeviceContext>(ocp.robot, ocp.source->ncMax(), n, ocp.device);
     ocp.source->configure(dev_->get());
     dms_ = DirectMultipleShooting(ocp, 1, dev_);
+    sto_ = SwitchingTimeOptimization(ocp.source, dev_);
     riccati_recursion_ = RiccatiRecursion(ocp, dev_->get());
     kkt_matrix_.assign(n, SplitKKTMatrix(ocp.robot));
     kkt_residual_.assign(n, SplitKKTResidual(ocp.robot));
@@ -406,10 +496,14 @@ class OCPSolver {
       : ocp_(o.ocp_), time_discretization_(o.time_discretization_), kkt_matrix_(o.kkt_matrix_), kkt_residual_(o.kkt_residual_),
         s_(o.s_), d_(o.d_), riccati_factorization_(o.riccati_factorization_), solver_options_(o.solver_options_),
         solver_statistics_(o.solver_statistics_), L_(o.L_), host_solution_valid_(o.host_solution_valid_) {
+    solution_interpolator_ = o.solution_interpolator_;
+    t_ = o.t_;
     if (o.dev_) {
       dev_ = std::make_shared<DeviceContext>(*o.dev_);
       dms_ = o.dms_;
       dms_.rebind(dev_);
+      sto_ = o.sto_;
+      sto_.rebind(dev_);
       riccati_recursion_ = RiccatiRecursion(ocp_, dev_->get());
     }
   }
@@ -428,19 +522,30 @@ class OCPSolver {
       throw std::logic_error("[OCPSolver] the line search is outside the accelerated path (off by default, solver_options.hpp:70)");
     solver_options_ = solver_options;
     dms_.setFractionToBoundaryRule(solver_options.fraction_to_boundary_rule);
+    riccati_recursion_.setRegularization(solver_options.max_dts_riccati);   // ocp_solver.cpp:84
     riccati_recursion_.setHorizonScan(solver_options.horizon_scan);
   }
 
   // discretize (ocp_solver.cpp:96-102): the contact-sequence planner is upstream of the boundary; the grid comes
   // with the stage data
-  void discretize(const double) {
+  // with a source that owns its contact sequence: TimeDiscretization::discretize (+ correctTimeSteps, PhaseBased, when the OCP
+  // has an STO problem: ocp_solver.cpp:46-48, 96-102) at the sequence's current event times; the event times and the
+  // STOConstraints then go to the device
+  void discretize(const double t) {
+    ocp_.source->discretize(t);
     time_discretization_ = ocp_.source->timeDiscretization();
+    if (time_discretization_.size() > static_cast<int>(s_.size()))
+      throw std::out_of_range("[OCPSolver] the discretisation has more grid points than the solver reserved (ocp.N + 1 + reserved_num_discrete_events)");
     dms_.resizeData(time_discretization_);
     riccati_recursion_.resizeData(time_discretization_);
+    RiccatiRecursion::setGridOf(dev_->get(), time_discretization_);
+    sto_.setProblem(t);
+    t_ = t;
   }
   void initConstraints() {
     if (time_discretization_.size() < 2) discretize(0.0);
     dms_.initConstraints(time_discretization_, s_);
+    sto_.initConstraints(time_discretization_);                                                 // :107
   }
 
   // One Newton / SQP iteration: the reference's updateSolution (ocp_solver.cpp:111-145), same order of calls.
@@ -449,18 +554,22 @@ class OCPSolver {
     if (time_discretization_.size() < 2) discretize(t);
     // the iterate lives in RTOC_BUF_SOL: a source that linearises on the host must see the current one, not the initial guess
     if (ocp_.source->needsHostSolution()) syncSolution();
+    // (:115-117, correctTimeSteps of a PhaseBased discretisation: rtoc_contact_eval_kkt opens with it; host-side sources
+    // linearise at the grid they were given)
     dms_.evalKKT(time_discretization_, q, v, s_, kkt_matrix_, kkt_residual_);                  // :118
-    // sto_.evalKKT(...)                                                                        // :119 (no STO problem here)
+    sto_.evalKKT(time_discretization_, kkt_matrix_, kkt_residual_);                             // :119
     riccati_recursion_.backwardRiccatiRecursionResident(time_discretization_);                  // :120
     dms_.computeInitialStateDirection(q, v, s_, d_);                                            // :123
     if (ocp_.robot.dim_passive > 0 && hasSE3()) rtoc_compute_initial_state_direction(dev_->get());
     riccati_recursion_.forwardRiccatiRecursionResident();                                       // :124
     dms_.computeStepSizes(time_discretization_, d_);                                            // :127
-    const double primal_step_size = dms_.maxPrimalStepSize();                                   // :129-132
-    const double dual_step_size = dms_.maxDualStepSize();
+    sto_.computeStepSizes(time_discretization_, d_);                                            // :128
+    const double primal_step_size = std::min(dms_.maxPrimalStepSize(), sto_.maxPrimalStepSize());   // :129-132
+    const double dual_step_size = std::min(dms_.maxDualStepSize(), sto_.maxDualStepSize());
     solver_statistics_.primal_step_size.push_back(primal_step_size);                            // :140-141
     solver_statistics_.dual_step_size.push_back(dual_step_size);
     dms_.integrateSolution(time_discretization_, primal_step_size, dual_step_size, d_, s_);     // :142
+    sto_.integrateSolution(time_discretization_, primal_step_size, dual_step_size, d_);         // :143
     host_solution_valid_ = false;
   }
 
@@ -472,14 +581,29 @@ class OCPSolver {
     if (init_solver) {
       discretize(t);
       initConstraints();
+      chk(rtoc_line_search_clear(dev_->get()), "rtoc_line_search_clear");                       // :166
     }
     solver_statistics_.clear();
-    for (int iter = 0; iter < solver_options_.max_iter; ++iter) {
+    int inner_iter = 0;
+    for (int iter = 0; iter < solver_options_.max_iter; ++iter, ++inner_iter) {
+      if (sto_.enabled()) {                                                                     // :169-177
+        sto_.setRegularization(inner_iter < solver_options_.initial_sto_reg_iter ? solver_options_.initial_sto_reg : 0.0);
+        solver_statistics_.ts.push_back(ocp_.source->contactSequence()->eventTimes());
+      }
       updateSolution(t, q, v);
       const double kkt_error = KKTError();
       solver_statistics_.performance_index.push_back(kkt_error * kkt_error);  // PerformanceIndex::kkt_error is the squared residual
       solver_statistics_.iter = iter + 1;
-      if (kkt_error < solver_options_.kkt_tol) {  // :200-210
+      if (sto_.enabled() && kkt_error < solver_options_.kkt_tol_mesh) {                         // :181-205
+        if (maxTimeStep() > solver_options_.max_dt_mesh) {
+          meshRefinement(t);
+          inner_iter = 0;
+          solver_statistics_.mesh_refinement_iter.push_back(iter + 1);
+        } else if (kkt_error < solver_options_.kkt_tol) {
+          solver_statistics_.convergence = true;
+          break;
+        }
+      } else if (kkt_error < solver_options_.kkt_tol) {  // :206-210
         solver_statistics_.convergence = true;
         break;
       }
@@ -518,10 +642,19 @@ class OCPSolver {
   double KKTError(const double t, const Vec& q, const Vec& v) {
     if (time_discretization_.size() < 2) discretize(t);
     dms_.evalOCP(time_discretization_, q, v, s_, kkt_residual_);
+    if (sto_.enabled()) {   // KKTError(t, q, v) evaluates both halves (:422-424); the STO scatter reads the condensed h
+      chk(rtoc_condense(dev_->get()), "rtoc_condense");
+      sto_.evalKKT(time_discretization_, kkt_matrix_, kkt_residual_);
+    }
     return KKTError();
   }
-  // KKTError() (ocp_solver.cpp:429-431): sqrt of the accumulated squared residual (no STO term here)
-  double KKTError() const { return std::sqrt(dms_.getEval().kkt_error); }
+  // KKTError() (ocp_solver.cpp:429-431): sqrt of the accumulated squared residual, STO term included
+  double KKTError() const { return std::sqrt(dms_.getEval().kkt_error + sto_.getEval().kkt_error); }
+  const std::vector<double>& eventTimes() const {
+    static const std::vector<double> none;
+    ContactSequence* cs = ocp_.source->contactSequence();
+    return cs ? cs->eventTimes() : none;
+  }
   const TimeDiscretization& getTimeDiscretization() const { return time_discretization_; }
   unsigned status() const { return riccati_recursion_.status(); }
   rtoc_ctx* context() const { return dev_ ? dev_->get() : nullptr; }
@@ -536,6 +669,46 @@ class OCPSolver {
   }
 
  private:
+  static void chk(int rc, const char* what) {
+    if (rc != RTOC_OK) throw std::runtime_error(std::string("[OCPSolver] ") + what + ": " + rtoc_error_string(rc));
+  }
+  // TimeDiscretization::maxTimeStep of the time steps the device holds for this instance (the event times moved since discretize)
+  double maxTimeStep() {
+    std::vector<double> dt(time_discretization_.size());
+    chk(rtoc_sto_get_time_steps(dev_->get(), dt.data(), 1), "rtoc_sto_get_time_steps");
+    double m = 0.0;
+    for (size_t i = 0; i + 1 < dt.size(); ++i) m = std::max(m, dt[i]);
+    return m;
+  }
+  // the mesh-refinement branch of solve (ocp_solver.cpp:184-199): store the solution over the current grid, re-discretise at the
+  // current switching times, interpolate, re-initialise the constraints, clear the line-search filter
+  void meshRefinement(const double t) {
+    const std::vector<unsigned>* masks = ocp_.source->contactMasks();
+    const bool interp = solver_options_.enable_solution_interpolation && masks != nullptr;
+    if (interp) {
+      // correctTimeSteps + store (:186-189): the grid times that belong to the current event times
+      std::vector<double> dt(time_discretization_.size());
+      chk(rtoc_sto_get_time_steps(dev_->get(), dt.data(), 1), "rtoc_sto_get_time_steps");
+      double tt = t_;
+      for (int i = 0; i < time_discretization_.size(); ++i) {
+        time_discretization_.grids()[i].t = tt, time_discretization_.grids()[i].dt = dt[i];
+        tt += dt[i];
+      }
+      std::vector<double> sol(static_cast<size_t>(time_discretization_.size()) * L_.sol.stride);
+      chk(rtoc_download(dev_->get(), RTOC_BUF_SOL, 0, sol.data(), sol.size()), "rtoc_download(RTOC_BUF_SOL)");
+      solution_interpolator_.store(time_discretization_, *masks, sol);
+    }
+    discretize(t);                                                                              // :190
+    if (interp) {
+      std::vector<double> sol(static_cast<size_t>(time_discretization_.size()) * L_.sol.stride, 0.0);
+      solution_interpolator_.interpolate(L_, ocp_.source->contactSequence()->numContacts(), ocp_.robot.dim_passive > 0, time_discretization_,
+                                         *ocp_.source->contactMasks(), sol);
+      chk(rtoc_upload(dev_->get(), RTOC_BUF_SOL, 0, sol.data(), sol.size()), "rtoc_upload(RTOC_BUF_SOL)");
+      host_solution_valid_ = false;
+    }
+    initConstraints();                                                                          // :194-195
+    chk(rtoc_line_search_clear(dev_->get()), "rtoc_line_search_clear");                         // :196
+  }
   bool hasSE3() const {
     const StageDumpSource* d = dynamic_cast<const StageDumpSource*>(ocp_.source.get());
     return d && !d->buffer(RTOC_BUF_SE3).empty();
@@ -560,7 +733,10 @@ class OCPSolver {
   std::shared_ptr<DeviceContext> dev_;
   TimeDiscretization time_discretization_;
   DirectMultipleShooting dms_;
+  SwitchingTimeOptimization sto_;
   RiccatiRecursion riccati_recursion_;
+  SolutionInterpolator solution_interpolator_;
+  double t_ = 0.0;
   KKTMatrix kkt_matrix_;
   KKTResidual kkt_residual_;
   Solution s_;

@@ -51,4 +51,5 @@ def anymal_jump_sto_solver(batch=1, device=0, N=40, dt=0.02, jump_length=0.25, g
         if act and g.type != 1 and i < len(solver.grids) - 1:
             S.f(sol, "f")[:, i, :3 * len(act)] = np.tile([0.0, 0.0, 0.25 * weight], len(act))
     solver.set_solution(sol)
-    return solver, x0, dict(T=T, N=N, model=m)
+    return solver, x0, dict(T=T, N=N, model=m, cost=cost, min_dwell=list(min_dwell),
+                            limits=[9.42, 7.5, 80.0, 0.7])

@@ -284,3 +284,53 @@ def test_ocp_solver_constrained_trot_on_the_device(tmp_path, oracle):
     ref = ctx.download_records(BUF_SOL, "sol")[0]
     assert np.array_equal(traj, S.f(ref, "q")[:, :nq]) and np.array_equal(torque, S.f(ref, "u")[:, :nu])
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_ocp_solver_jump_with_switching_time_optimisation_on_the_device(tmp_path):
+    """BASELINE configs[2] through the C++ shell: robotoc::OCPSolver::solve of the ANYmal jump with two STO-enabled events --
+    SwitchingTimeOptimization mirror, regularisation schedule, mesh refinement with solution interpolation in C++
+    (robotoc_hip_planner.hpp) -- against the same solve by the Python mirror (robotoc_amd/solver.py): same number of iterations,
+    same mesh refinement, the same optimised switching times."""
+    from robotoc_amd import problems_jump as pj
+    from robotoc_amd.robot_model import MAX_JOINTS
+    from test_cpp_host import _build
+    exe = _build("ocp_solver_jump_sto_test")
+    solver, x0, info = pj.anymal_jump_sto_solver(batch=1)
+    m = info["model"]
+    nv, nq, nu = m.nv, m.nq, m.nu
+    try:
+        st = solver.solve(0.0, x0)
+        assert st.convergence
+        hist = np.array([e[0] for e in st.kkt_error])
+        ts_py = solver.event_times[0].copy()
+        plan, opts = solver.plan, solver.options
+    finally:
+        solver.close()
+    cost = np.zeros((12, MAX_JOINTS))
+    c = info["cost"]
+    for k, key in enumerate(("q_ref", "v_ref", "u_ref", "q_weight", "v_weight", "a_weight", "u_weight", "q_weight_terminal", "v_weight_terminal",
+                             "q_weight_impact", "v_weight_impact", "dv_weight_impact")):
+        cost[k, :len(c[key])] = c[key]
+    weight = 9.81 * sum(m.mass[i] for i in range(m.njoints))
+    prob = str(tmp_path / "anymal_jump_sto.bin")
+    with open(prob, "wb") as f:
+        f.write(bytes(m))
+        f.write(cost.tobytes())
+        f.write(np.array([info["N"]], dtype=np.int32).tobytes())
+        for arr in ([info["T"], plan.events[0].time, plan.events[1].time], plan.phase_positions[0], plan.phase_positions[2], x0[0, :nq], x0[0, nq:],
+                    np.tile([0.0, 0.0, 0.25 * weight], 4), info["min_dwell"], info["limits"], [opts.max_dt_mesh]):
+            f.write(np.ascontiguousarray(arr, dtype=np.float64).tobytes())
+    out_path = str(tmp_path / "jump_sto_out.bin")
+    run = subprocess.run([exe, prob, out_path], capture_output=True, text=True, timeout=300)
+    print(run.stdout, run.stderr)
+    assert run.returncode == 0, (run.returncode, run.stdout, run.stderr)
+    raw = np.fromfile(out_path)
+    iters, conv, err, nref, first_ref, ts_cpp, hist_cpp = int(raw[0]), raw[1], raw[2], int(raw[3]), int(raw[4]), raw[5:7], raw[7:]
+    assert conv == 1.0 and err < 1e-7
+    assert nref == len(st.mesh_refinement_iter) >= 1 and first_ref == st.mesh_refinement_iter[0]
+    # up to the first mesh refinement both shells issue the same launches on the same data: bit-identical KKT errors; behind it
+    # the interpolated warm start agrees to rounding, so the paths stay together (same iteration count, same switching times)
+    assert np.array_equal(hist_cpp[:first_ref], hist[:first_ref])
+    assert abs(iters - st.iter) <= 1
+    assert np.abs(ts_cpp - ts_py).max() < 1e-6, (ts_cpp, ts_py)
