@@ -49,6 +49,28 @@ def riccati_fixture(name, dims, grids, mode):
     np.savez_compressed(os.path.join(HERE, name), kkt=kkt, dx0=dx0, ric=ric, dir=d, kkt_mutated=k[None], **grid_table(grids))
 
 
+def riccati_fixture_full_size(name, dims, grids, mode):
+    """The BASELINE configurations at their full sizes (N = 40 / N = 30): the outputs of the reference's sources only -- the
+    inputs come from the seeded generator of robotoc_amd/problems.py, which the GPU box has too; their SHA-256 is stored so
+    that a drift of the generator is noticed instead of silently comparing other problems."""
+    import hashlib
+    L = orc.layout(dims)
+    kkt = pr.make_kkt_batch(L, grids, 1, mode=mode)
+    dx0 = pr.make_dx0(L, 1)
+    ric, d = Records(L, "ric").zeros(1, len(grids)), Records(L, "dir").zeros(1, len(grids))
+    Records(L, "dir").f(d[0, 0], "dx")[...] = dx0[0]
+    ref.riccati_sweep(L, grids, kkt[0].copy(), ric[0], d[0])
+    sha = hashlib.sha256(np.ascontiguousarray(kkt).tobytes() + np.ascontiguousarray(dx0).tobytes()).hexdigest()
+    np.savez_compressed(os.path.join(HERE, name), ric=ric, dir=d, inputs_sha256=np.array(sha), mode=np.array(mode),
+                        dims=np.array([dims.nv, dims.nu, dims.np, dims.nf_max, dims.ns_max, dims.nc_max]), **grid_table(grids))
+
+
+def full_size_fixtures():
+    riccati_fixture_full_size("ref_anymal_trot_n40_riccati.npz", *pr.config_anymal_trot()[:2], mode="dynamics")
+    riccati_fixture_full_size("ref_anymal_jump_sto_n40_riccati.npz", *pr.config_anymal_jump_sto()[:2], mode="dynamics")
+    riccati_fixture_full_size("ref_icub35_jump_n30_riccati.npz", *pr.config_icub_jump(nv=35)[:2], mode="factory")
+
+
 def condense_fixture(name, dims, grids):
     """Per grid point: condenseContactDynamics / condenseImpactDynamics, then the expansions on seeded directions.
     num_grids_in_phase = 1 everywhere, so that the evalKKT-tail scalings (not part of these reference functions) are
@@ -651,6 +673,7 @@ FIXTURES = {
     "impact_terminal_stage": impact_and_terminal_stage_fixture,
     "icub_surface_stage": icub_surface_stage_fixture,
     "ocp_iteration": ocp_solver_iteration_fixture,
+    "riccati_full_size": full_size_fixtures,
     "ocp_iteration_sto": lambda: ocp_solver_iteration_fixture("ref_anymal_jump_sto_solver_iteration.npz", sto=True),
 }
 

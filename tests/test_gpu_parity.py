@@ -62,23 +62,23 @@ def test_anymal_trot_sweep(oracle, waves, mode):
     """configs[1]: ANYmal trot, N=40, 2 lifts + 2 impacts, switching constraints (ns=6)."""
     dims, grids, _ = pr.config_anymal_trot()
     _run_case(oracle, dims, grids, 6, mode, waves=waves,
-              tol=TOL if mode == "factory" else 1e-7)
+              tol=TOL)   # both data kinds at SURVEY 8c's 1e-9 (observed: 4e-11 factory, 1.5e-10 "dynamics")
 
 
 @pytest.mark.parametrize("waves", [1, 2, 3, 8])
 def test_anymal_jump_sto_sweep(oracle, waves):
     """configs[2]: ANYmal jump with switching-time optimisation (STO policy, phase transitions, ns=12).
     "dynamics"-scaled data keep the 44-grid STO system well conditioned (a 1e-15 relative input
-    perturbation moves the oracle's own dxi by ~3e-11), so the 1e-8 tolerance is meaningful."""
+    perturbation moves the oracle's own dxi by ~3e-11): held to the 1e-9 of SURVEY 8c (observed 1.7e-10)."""
     dims, grids, _ = pr.config_anymal_jump_sto()
     assert any(g.sto for g in grids)
-    _run_case(oracle, dims, grids, 4, "dynamics", waves=waves, tol=1e-8)
+    _run_case(oracle, dims, grids, 4, "dynamics", waves=waves, tol=TOL)
 
 
 def test_anymal_jump_sto_ill_conditioned(oracle):
     """Same grid with the reference's fully random factory data (kkt_factory.cpp:21-23): the STO
     system is ill conditioned (fx, Fvq ~ U[-1,1]); the GPU must stay within the oracle's own
-    sensitivity to a 1e-15 relative perturbation of the inputs (x100 safety factor)."""
+    sensitivity to a 1e-15 relative perturbation of the inputs (x10; observed: at or below that sensitivity itself)."""
     from robotoc_amd import capi
     dims, grids, _ = pr.config_anymal_jump_sto()
     batch = 2
@@ -110,8 +110,8 @@ def test_anymal_jump_sto_ill_conditioned(oracle):
             err = rel_err(D.f(d, f), D.f(d_ref, f))
             print("%s: gpu-vs-oracle %.2e, oracle sensitivity %.2e" % (f, err, sens))
             from helpers import check_parity
-            check_parity("%s (bound = 100 x the oracle's own sensitivity %.1e to a 1e-15 input perturbation)" % (f, sens), err,
-                         max(1e-9, 100.0 * sens))
+            check_parity("%s (bound = 10 x the oracle's own sensitivity %.1e to a 1e-15 input perturbation)" % (f, sens), err,
+                         max(1e-9, 10.0 * sens))
     finally:
         ctx.close()
 
@@ -237,8 +237,10 @@ def test_full_size_batch_4096_unique_instances(oracle):
         d_ref = Records(L, "dir").zeros(batch, len(grids))
         st = oracle.riccati_sweep_batch(L, grids, kkt, ric_ref, d_ref, dx0=dx0)  # mutates kkt (no longer needed)
         assert (st == 0).all()
-        worst = compare_batch(L, grids, ric, ric_ref, d, d_ref, 1e-7, "4096 instances")
-        print("4096 unique ANYmal trot instances: worst rel err %.3e (tol 1e-7, 'dynamics' data)" % worst)
+        # the worst of 4096 x 47 x ~8 comparisons sits in the tail of the conditioning of the random "dynamics" data: observed
+        # 3.1e-9 (one instance / stage / field; the median instance is at 1e-11), so 1e-8 here against 1e-9 on the small batches
+        worst = compare_batch(L, grids, ric, ric_ref, d, d_ref, 1e-8, "4096 instances")
+        print("4096 unique ANYmal trot instances: worst rel err %.3e (tol 1e-8, 'dynamics' data)" % worst)
     finally:
         ctx.close()
 
@@ -299,8 +301,10 @@ def test_pipelined_sweep_equals_backward_then_forward(chunks):
     assert np.array_equal(out[0][1], out[1][1])
 
 
-# tolerances of the SQP hot-path test on "dynamics" data (see DYN_TOL below for where they come from)
-SQP_TOL = {"cdd": 1e-8, "sweep": 1e-7, "pdipm": 1e-7, "steps": 1e-6}
+# tolerances of the SQP hot-path test ("dynamics" data), each within 10x of the worst error observed on the MI355X over the four
+# configurations (gpurun_out/parity_summary.json): contact-dynamics data 5.9e-11, sweep / expansion 1.9e-10, PDIPM directions
+# 9.4e-13, fraction-to-boundary steps 1.1e-11
+SQP_TOL = {"cdd": 5e-10, "sweep": 1e-9, "pdipm": 1e-11, "steps": 1e-10}
 
 
 def _compare_records(R, gpu, ref, fields, tol, what, grids=None, skip_terminal=True):
@@ -466,7 +470,7 @@ def test_structured_fxx_kernel_and_its_fallback(oracle, mode):
             ric, d = ctx.download_records(BUF_RIC, "ric"), ctx.download_records(BUF_DIR, "dir")
             ric_ref, d_ref = Records(L, "ric").zeros(batch, len(grids)), Records(L, "dir").zeros(batch, len(grids))
             oracle.riccati_sweep_batch(L, grids, k.copy(), ric_ref, d_ref, dx0=dx0)
-            tol = TOL if mode == "factory" else 1e-7
+            tol = TOL   # 1e-9 on both data kinds (observed 2.5e-11 / 1.5e-10)
             worst = 0.0
             for b in range(batch):
                 worst = max(worst, compare_riccati(L, grids, ric[b], ric_ref[b], tol, "%s inst %d" % (case, b)))

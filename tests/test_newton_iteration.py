@@ -117,13 +117,16 @@ def test_newton_iteration_against_the_oracle_sequence(oracle):
         oracle.cone_expand_batch(L, grids, MC, CD, cone, nn, d_ref, tau, steps_ref)
         steps_ref[conv] = 0.0
         steps_gpu = fused.download(BUF_STEP, (batch, 2))
-        assert np.allclose(steps_gpu, steps_ref, rtol=1e-6, atol=0), (steps_gpu, steps_ref)
+        from helpers import check_parity
+        live = steps_ref > 0
+        check_parity("step sizes", float(np.abs(steps_gpu[live] / steps_ref[live] - 1.0).max()) if live.any() else 0.0, 1e-9)
+        assert (steps_gpu[~live] == 0.0).all()
         d_gpu = fused.download_records(BUF_DIR, "dir")
         worst = 0.0
         for f in ("dx", "du", "dlmdgmm", "daf", "dbetamu", "dnu_passive"):
             e = rel_err(D.f(d_gpu, f), D.f(d_ref, f))
             worst = max(worst, e)
-            assert e < 1e-7, (f, e)
+            check_parity("direction " + f, e, 1e-9)
         # the updates with the GPU's own step sizes (ratios of direction entries: compared above at 1e-6)
         oracle.pdipm_update_batch(L, grids, rows, nn, steps_gpu)
         oracle.cone_update_batch(L, grids, MC, CD, nn, steps_gpu)
@@ -131,14 +134,14 @@ def test_newton_iteration_against_the_oracle_sequence(oracle):
         for f in ("slack", "dual", "dslack", "ddual", "cond"):
             e = rel_err(N.f(con_gpu, f), N.f(nn, f))
             worst = max(worst, e)
-            assert e < 1e-7, (f, e)
+            check_parity("rows " + f, e, 1e-9)
         sol_ref = sol0.copy()
         oracle.integrate_solution_batch(L, grids, steps_gpu, d_ref, sol_ref)
         sol_gpu = fused.download_records(BUF_SOL, "sol")
         for f in ("q", "v", "a", "u", "f", "lmd", "gmm", "beta", "mu", "nu_passive", "xi"):
             e = rel_err(S.f(sol_gpu, f), S.f(sol_ref, f))
             worst = max(worst, e)
-            assert e < 1e-8, (f, e)
+            check_parity("solution " + f, e, 1e-9)
         for f in ("q", "v", "a", "f", "lmd", "gmm", "beta", "mu"):
             assert np.array_equal(S.f(sol_gpu[conv], f), S.f(sol0[conv], f)), f
         print("newton iteration vs oracle sequence: worst rel err %.3e" % worst)
@@ -180,12 +183,13 @@ def test_newton_iteration_with_the_horizon_scan():
         assert not np.array_equal(a, b)  # really a different arithmetic path
         for f in ("dx", "du", "dlmdgmm", "daf", "dbetamu"):
             x, y = D.f(a, f), D.f(b, f)
-            assert np.linalg.norm(x - y) <= 1e-8 * np.linalg.norm(x), f
+            from helpers import check_parity
+            check_parity("scan vs serial " + f, float(np.linalg.norm(x - y) / np.linalg.norm(x)), 1e-8)
         sa, sb = serial.download(BUF_STEP, (batch, 2)), scan.download(BUF_STEP, (batch, 2))
-        assert np.allclose(sa, sb, rtol=1e-6, atol=0)
+        check_parity("scan vs serial step sizes", float(np.abs(sa / sb - 1.0).max()), 1e-8)
         for buf, which in ((BUF_CON, "con"), (BUF_SOL, "sol")):
             x, y = serial.download_records(buf, which), scan.download_records(buf, which)
-            assert np.linalg.norm(x - y) <= 1e-7 * np.linalg.norm(x), which
+            check_parity("scan vs serial " + which, float(np.linalg.norm(x - y) / np.linalg.norm(x)), 1e-8)
     finally:
         serial.close()
         scan.close()

@@ -94,7 +94,7 @@ def test_random_event_structures_match_oracle(oracle, seed, waves):
         st_ref = oracle.riccati_sweep_batch(L, grids, kkt.copy(), ric_ref, d_ref, dx0=dx0)
         assert (st == st_ref).all(), (st, st_ref)
         ric, d = ctx.download_records(BUF_RIC, "ric"), ctx.download_records(BUF_DIR, "dir")
-        tol = 1e-7 if any_sto else 1e-8
+        tol = 1e-9   # SURVEY 8c (observed over all seeds: 2.2e-11 with STO grids, 9.4e-12 without)
         for b in range(batch):
             compare_riccati(L, grids, ric[b], ric_ref[b], tol, "seed %d inst %d" % (seed, b))
             compare_direction(L, grids, d[b], d_ref[b], tol, "seed %d inst %d" % (seed, b))
@@ -123,7 +123,7 @@ def test_random_event_structures_icub(oracle, nv, seed):
         st_ref = oracle.riccati_sweep_batch(L, grids, kkt.copy(), ric_ref, d_ref, dx0=dx0)
         assert (ctx.status() == st_ref).all()
         ric, d = ctx.download_records(BUF_RIC, "ric"), ctx.download_records(BUF_DIR, "dir")
-        tol = 1e-7 if any_sto else 1e-8
+        tol = 1e-9   # SURVEY 8c (observed over all seeds: 2.2e-11 with STO grids, 9.4e-12 without)
         for b in range(batch):
             compare_riccati(L, grids, ric[b], ric_ref[b], tol, "nv %d seed %d inst %d" % (nv, seed, b))
             compare_direction(L, grids, d[b], d_ref[b], tol, "nv %d seed %d inst %d" % (nv, seed, b))
@@ -171,6 +171,7 @@ def test_random_event_structures_condense_expand(oracle, seed):
         oracle.riccati_sweep_batch(L, grids, kk, ric_ref, d_ref, dx0=dx0)
         oracle.expand_batch(L, grids, cc, d_ref)
         for f in ("dx", "du", "dlmdgmm", "daf", "dbetamu", "dnu_passive"):
-            assert rel_err(D.f(d_gpu, f), D.f(d_ref, f)) < 1e-7, (seed, f)
+            from helpers import check_parity
+            check_parity("sqp directions " + f, rel_err(D.f(d_gpu, f), D.f(d_ref, f)), 1e-9)
     finally:
         ctx.close()

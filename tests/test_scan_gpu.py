@@ -65,7 +65,7 @@ def _no_sto(grids):
 def test_scan_anymal_trot(oracle, mode):
     """configs[1]: ANYmal trot, 47 grid points (2 lifts, 2 impacts, 2 switching-constraint grids) -> 6 levels."""
     dims, grids, _ = pr.config_anymal_trot()
-    _run(oracle, dims, grids, 3, mode, tol=TOL_SCAN if mode == "factory" else 1e-7)
+    _run(oracle, dims, grids, 3, mode, tol=TOL_SCAN)   # 1e-8 on both data kinds (observed 6e-12 / 2.2e-10)
 
 
 def test_scan_anymal_short_and_odd_horizons(oracle):
@@ -82,14 +82,16 @@ def test_scan_horizons_around_a_power_of_two(oracle, N):
     """63 / 64 / 65 grid points (6 -> 7 combination levels) and a long horizon (101 grid points, 7 levels)."""
     from robotoc_amd import grid as G
     from robotoc_amd.types import anymal_dims
-    _run(oracle, anymal_dims(), G.uniform_grid(N, 0.02, dimf=12), 1, "dynamics", tol=1e-7)
+    # composing 62 ... 100 maps on the marginally stable "dynamics" data costs two digits (DESIGN 6b): observed 8.0e-9 at N = 100,
+    # 7.0e-9 at 62 ... 64 -- beyond the N = 40 horizons SURVEY 8c's 1e-8 speaks about, hence 5e-8 here
+    _run(oracle, anymal_dims(), G.uniform_grid(N, 0.02, dimf=12), 1, "dynamics", tol=5e-8)
 
 
 @pytest.mark.parametrize("nv", [32, 35])
 def test_scan_icub_jump(oracle, nv):
     """configs[3]: iCub, stand-flight-stand with a 12-row switching constraint, larger blocks."""
     dims, grids, _ = pr.config_icub_jump(nv=nv)
-    _run(oracle, dims, _no_sto(grids), 2, "dynamics", tol=1e-7)
+    _run(oracle, dims, _no_sto(grids), 2, "dynamics", tol=TOL_SCAN)   # observed 6.4e-12
 
 
 def test_scan_iiwa14_dense(oracle):
