@@ -118,6 +118,23 @@ int rtoc_set_wrench_cone_params(rtoc_ctx* ctx, const double* xy_mu, int ncontact
  * error of the iterate it linearised at. */
 int rtoc_contact_update_solution(rtoc_ctx* ctx, double fraction_to_boundary_rule, double* host_kkt_error, int count);
 
+/* ---- filter line search on the device (src/line_search/line_search.cpp:31-83, LineSearchSettings) ----
+ * rtoc_contact_eval_ocp: DirectMultipleShooting::evalOCP's performance index (direct_multiple_shooting.cpp:100-126) of every
+ * instance -- host_cost[count] = cost + cost_barrier, host_violation[count] = primal_feasibility (l1).  trial = 0: of the iterate
+ * rtoc_contact_eval_kkt has just linearised (records not yet condensed: dms_.getEval()); trial = 1: of the trial iterate
+ * SOL (+) step DIR with slack + step dslack, step = the primal entry of RTOC_BUF_STEP of every instance
+ * (dms_trial_.integratePrimalSolution + evalOCP, line_search.cpp:65-71) -- RTOC_BUF_SOL / CON / DIR / STEP keep their contents, the
+ * KKT / CDD records are overwritten (the next rtoc_contact_eval_kkt rewrites them).
+ * rtoc_set_line_search: SolverOptions::enable_line_search with LineSearchSettings::step_size_reduction_rate (0.75), min_step_size
+ * (0.05), filter_cost_reduction_rate / filter_constraint_violation_reduction_rate (0.005): rtoc_newton_iteration (and
+ * rtoc_contact_update_solution) then run LineSearch::computeStepSize between the step-size computation and the update
+ * (ocp_solver.cpp:133-139) -- rtoc_contact_line_search: every instance backtracks from its maximum primal step until its filter
+ * (rtoc_line_search_filter's, cleared by rtoc_line_search_clear) accepts the trial pair; *host_trials = trial evaluations run. */
+int rtoc_contact_eval_ocp(rtoc_ctx* ctx, int trial, double* host_cost, double* host_violation, int count);
+int rtoc_set_line_search(rtoc_ctx* ctx, int enable, double step_size_reduction_rate, double min_step_size,
+                         double filter_cost_reduction_rate, double filter_constraint_violation_reduction_rate);
+int rtoc_contact_line_search(rtoc_ctx* ctx, int* host_trials);
+
 /* ---- the unconstrained solver iteration closed on the device (BASELINE configuration 1: fixed base, no contacts) ----
  * ConfigurationSpaceCost (src/cost/configuration_space_cost.cpp:274-470): diagonal weights on q - q_ref (on the manifold:
  * q_ref has nq entries, the first 7 a free-flyer placement if dims.np == 6; weights nv entries, the first 6 on the base's

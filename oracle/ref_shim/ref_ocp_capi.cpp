@@ -27,6 +27,7 @@
 #define private public
 #include "robotoc/ocp/direct_multiple_shooting.hpp"
 #undef private
+#include "robotoc/line_search/line_search.hpp"
 #include "robotoc/planner/contact_sequence.hpp"
 #include "robotoc/riccati/riccati_recursion.hpp"
 #include "robotoc/sto/sto_constraints.hpp"
@@ -259,7 +260,80 @@ int ref_ocp_direction(const rtoc_grid* grid, const unsigned* masks, const double
     for (int k = 0; k < nv; ++k) out_dq[(size_t)i * nv + k] = g.d[i].dq()(k);
   out_steps[0] = g.primal, out_steps[1] = g.dual, out_steps[2] = g.dms->getEval().kkt_error;
   if (g.sto_on) out_steps[2] += g.sto->getEval().kkt_error;   // OCPSolver::KKTError()^2 (:429-431)
+  // dms_.getEval(): what the line search reads of the current iterate (line_search.cpp:58-61)
+  out_steps[3] = g.dms->getEval().cost, out_steps[4] = g.dms->getEval().cost_barrier, out_steps[5] = g.dms->getEval().primal_feasibility;
   return (int)robot.pending() == 0 ? 0 : 2;
+}
+
+static void pack_solution(const State& g, const Solution& sol, double* sol_out) {
+  const int nv = g.nv, nu = g.nu, nc = g.nc, nq = nv + 1, n = g.n, SL = sol_len(nv, nu, nc);
+  for (int i = 0; i < n; ++i) {
+    const SplitSolution& s = sol[i];
+    const bool impact = g.td[i].type == GridType::Impact;
+    double* p = sol_out + (size_t)i * SL;
+    for (int k = 0; k < nq; ++k) *p++ = s.q(k);
+    for (int k = 0; k < nv; ++k) *p++ = s.v(k);
+    for (int k = 0; k < nv; ++k) *p++ = impact ? s.dv(k) : s.a(k);
+    for (int k = 0; k < nu; ++k) *p++ = s.u(k);
+    for (int c = 0; c < nc; ++c)
+      for (int k = 0; k < 3; ++k) *p++ = s.f[c](k);
+    for (int k = 0; k < nv; ++k) *p++ = s.lmd(k);
+    for (int k = 0; k < nv; ++k) *p++ = s.gmm(k);
+    for (int k = 0; k < nv; ++k) *p++ = s.beta(k);
+    for (int c = 0; c < nc; ++c)
+      for (int k = 0; k < 3; ++k) *p++ = s.mu[c](k);
+    for (int k = 0; k < 6; ++k) *p++ = s.nu_passive(k);
+    for (int k = 0; k < 3 * nc; ++k) *p++ = k < s.dims() ? s.xi_stack()(k) : 0.0;
+  }
+}
+
+// The trial iterate of the line search for step `alpha` (dms_trial_.integratePrimalSolution, line_search.cpp:65-69), so that the
+// caller can compute the rigid-body quantities evalOCP will ask for at it.  q_integrated: [n][nq] = s[i].q (+) alpha d[i].dq.
+int ref_ocp_trial_solution(double alpha, const double* q_integrated, double* sol_out) {
+  if (!G || !G->dms) return 1;
+  State& g = *G;
+  Robot& robot = g.robots[0];
+  const int nq = g.nv + 1;
+  for (int i = 0; i < g.n; ++i) robot.inject("integrateConfiguration", vec(q_integrated + (size_t)i * nq, nq));
+  DirectMultipleShooting trial = *g.dms;
+  Solution s = g.s;
+  trial.integratePrimalSolution(g.robots, g.td, alpha, g.d, s);
+  pack_solution(g, s, sol_out);
+  return (int)robot.pending() == 0 ? 0 : 2;
+}
+
+// dms_trial_.integratePrimalSolution(alpha) + evalOCP (line_search.cpp:65-71) for ONE trial step, the injections pushed beforehand
+// like for ref_ocp_line_search: out = cost, cost_barrier, primal_feasibility of the trial iterate.
+int ref_ocp_trial_eval(double alpha, double* out) {
+  if (!G || !G->dms) return 1;
+  State& g = *G;
+  DirectMultipleShooting trial = *g.dms;
+  Solution s = g.s;
+  KKTResidual kr = g.kr;
+  trial.integratePrimalSolution(g.robots, g.td, alpha, g.d, s);
+  trial.evalOCP(g.robots, g.td, g.s[0].q, g.s[0].v, s, kr);
+  out[0] = trial.getEval().cost, out[1] = trial.getEval().cost_barrier, out[2] = trial.getEval().primal_feasibility;
+  return (int)g.robots[0].pending() == 0 ? 0 : 2;
+}
+
+// LineSearch::computeStepSize (src/line_search/line_search.cpp:31-83, filter method) by the reference's own LineSearch over its
+// DirectMultipleShooting: the injections of every trial it may evaluate are pushed beforehand (trial k: the n integrated
+// configurations, then what evalOCP asks for at the trial iterate); what it does not consume is dropped.
+int ref_ocp_line_search(double rate, double min_step, double cost_rate, double viol_rate, double* out_step) {
+  if (!G || !G->dms) return 1;
+  State& g = *G;
+  LineSearchSettings st;
+  st.line_search_method = LineSearchMethod::Filter;
+  st.step_size_reduction_rate = rate, st.min_step_size = min_step;
+  st.filter_cost_reduction_rate = cost_rate, st.filter_constraint_violation_reduction_rate = viol_rate;
+  LineSearch ls(g.ocp, st);
+  ls.clearHistory();
+  const Eigen::VectorXd q = g.s[0].q, v = g.s[0].v;   // (evalOCP does not read the initial state)
+  g.primal = ls.computeStepSize(*g.dms, g.robots, g.td, q, v, g.s, g.d, g.primal);   // ocp_solver.cpp:133-139
+  out_step[0] = g.primal;
+  out_step[1] = (double)g.robots[0].pendingOf("ID");   // what the trials it did not evaluate left behind
+  g.robots[0].clearInjections();
+  return 0;
 }
 
 // q_integrated: [n][nq] = s[i].q (+) primal_step d[i].dq (pushed as the integrateConfiguration injections, in grid order)

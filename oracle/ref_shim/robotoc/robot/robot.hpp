@@ -210,6 +210,8 @@ class Robot {
   // ---- floating-base / contact quantities as FIFO injections: the test pushes, in the order the reference's stage code
   //      asks for them, what this repository's CPU restatement computes (inject(name, matrix)); each call pops one ----
   void inject(const std::string& key, const Eigen::MatrixXd& m) { (*fifo_)[key].push_back(m); }
+  void clearInjections() { fifo_->clear(); }
+  size_t pendingOf(const std::string& key) const { return (*fifo_)[key].size(); }
   size_t pending() const {
     size_t n = 0;
     for (const auto& kv : *fifo_) n += kv.second.size();

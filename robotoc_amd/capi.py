@@ -34,7 +34,7 @@ EXPORTS = [
     "rtoc_sto_set_problem", "rtoc_sto_set_regularization", "rtoc_sto_set_cost_terms", "rtoc_sto_init_constraints",
     "rtoc_sto_correct_time_steps", "rtoc_sto_eval_kkt_device", "rtoc_sto_compute_step_sizes", "rtoc_sto_integrate_solution",
     "rtoc_sto_get_event_times", "rtoc_sto_get_time_steps", "rtoc_sto_get_constraint_data", "rtoc_sto_get_kkt_terms",
-    "rtoc_sto_set_slack_dual",
+    "rtoc_sto_set_slack_dual", "rtoc_contact_eval_ocp", "rtoc_set_line_search", "rtoc_contact_line_search",
 ]
 
 
@@ -166,6 +166,9 @@ def lib():
             getattr(L, f).argtypes = [vp, dp, C.c_int]
         L.rtoc_sto_get_kkt_terms.argtypes = [vp, dp, dp, dp, C.c_int]
         L.rtoc_sto_set_slack_dual.argtypes = [vp, dp, dp]
+        L.rtoc_contact_eval_ocp.argtypes = [vp, C.c_int, dp, dp, C.c_int]
+        L.rtoc_set_line_search.argtypes = [vp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double]
+        L.rtoc_contact_line_search.argtypes = [vp, C.POINTER(C.c_int)]
         L.rtoc_error_string.argtypes = [C.c_int]
         L.rtoc_error_string.restype = C.c_char_p
         _LIB = L
@@ -435,6 +438,23 @@ class Context:
         _chk(lib().rtoc_line_search_filter(self._h, _dp(cost), _dp(violation), m.ctypes.data_as(ip) if m is not None else None, n,
                                            cost_reduction_rate, constraint_violation_reduction_rate, acc.ctypes.data_as(ip)))
         return acc
+
+    def contact_eval_ocp(self, trial=False):
+        """rtoc_contact_eval_ocp: (cost + cost_barrier, primal_feasibility) of every instance"""
+        cost, viol = np.zeros(self.batch), np.zeros(self.batch)
+        _chk(lib().rtoc_contact_eval_ocp(self._h, int(bool(trial)), _dp(cost), _dp(viol), self.batch))
+        return cost, viol
+
+    def set_line_search(self, enable=True, step_size_reduction_rate=0.75, min_step_size=0.05, filter_cost_reduction_rate=0.005,
+                        filter_constraint_violation_reduction_rate=0.005):
+        """SolverOptions::enable_line_search + LineSearchSettings (filter method)"""
+        _chk(lib().rtoc_set_line_search(self._h, int(bool(enable)), step_size_reduction_rate, min_step_size, filter_cost_reduction_rate,
+                                        filter_constraint_violation_reduction_rate))
+
+    def contact_line_search(self):
+        n = C.c_int()
+        _chk(lib().rtoc_contact_line_search(self._h, C.byref(n)))
+        return n.value
 
     def line_search_clear(self):
         _chk(lib().rtoc_line_search_clear(self._h))

@@ -85,6 +85,121 @@ static __global__ __launch_bounds__(64) void kkt_error_kernel(KktErrArgs a) {
   if (lane == 0) a.partial[(size_t)b * a.nstages + st] = acc;
 }
 
+// ---- DirectMultipleShooting::evalOCP's performance index (line search) ---------------------------------------------
+// What {Intermediate,Impact,Terminal}Stage::evalOCP accumulate per grid point (src/ocp/intermediate_stage.cpp:52-81,
+// impact_stage.cpp:53-76, terminal_stage.cpp:51-66) and LineSearch::lineSearchFilterMethod reads (src/line_search/line_search.cpp:
+// 56-83): cost (the value the cost kernel stored), cost_barrier = - barrier sum log(slack) of the active rows
+// (pdipm.hxx:195-200), primal_feasibility = l1 norms of the rows' residuals, of [ID; C] (contact_dynamics_data.hpp:195-197) and
+// of Fx, P (split_kkt_residual.hxx:109-115); the terminal grid point carries its cost only.  On records linearised and NOT yet
+// condensed.  partial: [batch][nstages][2] = (cost + barrier, violation); the reduction adds them in grid order.
+struct EvalOcpArgs {
+  const double* kkt;
+  const double* cdd;
+  const double* con;      // may be null
+  const double* costval;  // [batch][nstages]
+  const rtoc_box_row* rows;
+  const rtoc_grid* grid;
+  double* partial;
+  int nstages, batch, nrows, cone_contacts, cone_dim, cone_rows, nc_max, impact_cones;
+  int nv, nx;
+  double barrier;
+  rtoc_record_layout kl, cl, nl;
+};
+
+static __global__ __launch_bounds__(64) void eval_ocp_kernel(EvalOcpArgs a) {
+  const int lane = threadIdx.x;
+  const int st = blockIdx.x, b = blockIdx.y;
+  if (b >= a.batch || st >= a.nstages) return;
+  double viol = 0.0, bar = 0.0;
+  auto l1 = [&](const double* p, int n) {
+    for (int i = lane; i < n; i += 64) viol += fabs(p[i]);
+  };
+  const rtoc_grid g = a.grid[st];
+  const size_t rec = (size_t)b * a.nstages + st;
+  const bool terminal = g.type == RTOC_GRID_TERMINAL, impact = g.type == RTOC_GRID_IMPACT;
+  if (!terminal) {
+    const double* kr = a.kkt + rec * a.kl.stride;
+    const double* cr = a.cdd + rec * a.cl.stride;
+    l1(kr + a.kl.off[RTOC_KKT_FX], a.nx);
+    if (!impact && g.dims > 0) l1(kr + a.kl.off[RTOC_KKT_PRES], g.dims);
+    l1(cr + a.cl.off[RTOC_CDD_IDC], a.nv + g.dimf);
+    if (a.con) {
+      const double* nr = a.con + rec * a.nl.stride;
+      if (!impact)
+        for (int r = lane; r < a.nrows; r += 64)
+          if (g.time_stage >= a.rows[r].level) {
+            viol += fabs(nr[a.nl.off[RTOC_CON_RESIDUAL] + r]);
+            bar -= log(nr[a.nl.off[RTOC_CON_SLACK] + r]);
+          }
+      if (a.cone_contacts > 0 && (!impact || a.impact_cones)) {
+        const int row0 = a.nc_max - a.cone_rows * a.cone_contacts, n = a.cone_rows * (g.dimf / a.cone_dim);
+        for (int r = lane; r < n; r += 64) {
+          viol += fabs(nr[a.nl.off[RTOC_CON_RESIDUAL] + row0 + r]);
+          bar -= log(nr[a.nl.off[RTOC_CON_SLACK] + row0 + r]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) viol += __shfl_xor(viol, off, 64), bar += __shfl_xor(bar, off, 64);
+  if (lane == 0) {
+    a.partial[2 * rec] = a.costval[rec] + a.barrier * bar;
+    a.partial[2 * rec + 1] = viol;
+  }
+}
+
+// out: [2][batch] = cost + cost_barrier | primal_feasibility
+static __global__ void eval_ocp_reduce_kernel(const double* partial, double* out, int nstages, int batch) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= batch) return;
+  double c = 0.0, v = 0.0;
+  for (int st = 0; st < nstages; ++st) c += partial[2 * ((size_t)b * nstages + st)], v += partial[2 * ((size_t)b * nstages + st) + 1];
+  out[b] = c;
+  out[batch + b] = v;
+}
+
+// ---- LineSearch::lineSearchFilterMethod's backtracking loop, per instance (line_search.cpp:56-83) ----
+// alpha: the trial step of every instance; active: 1 while the instance is still backtracking.
+struct LsArgs {
+  double* steps;        // [batch][2] RTOC_BUF_STEP (in: max primal step; out: accepted step)
+  double* trial_steps;  // [batch][2] = (alpha, 0): the trial iterate moves the primal variables and the slacks only
+  double* alpha;
+  int* active;
+  const int* accepted;
+  int* nactive;
+  int batch;
+  double rate, min_step;
+};
+static __global__ void ls_begin_kernel(LsArgs a) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.batch) return;
+  const double s = a.steps[2 * b];
+  a.alpha[b] = s;
+  const int on = s > a.min_step ? 1 : 0;   // while (primal_step_size > settings_.min_step_size)
+  a.active[b] = on;
+  a.trial_steps[2 * b] = on ? s : 0.0;
+  a.trial_steps[2 * b + 1] = 0.0;
+  if (on) atomicAdd(a.nactive, 1);
+}
+static __global__ void ls_advance_kernel(LsArgs a) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.batch || !a.active[b]) return;
+  if (a.accepted[b]) {            // filter_.augment done by the filter kernel; return primal_step_size
+    a.active[b] = 0;
+    a.steps[2 * b] = a.alpha[b];
+    return;
+  }
+  const double s = a.alpha[b] * a.rate;   // primal_step_size *= step_size_reduction_rate
+  a.alpha[b] = s;
+  if (s > a.min_step) {
+    a.trial_steps[2 * b] = s;
+    atomicAdd(a.nactive, 1);
+  } else {                       // the loop ends without an accepted trial: the reduced step is returned as it is
+    a.active[b] = 0;
+    a.steps[2 * b] = s;
+  }
+}
+
 static __global__ void kkt_error_reduce_kernel(const double* partial, double* out, int nstages, int batch) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= batch) return;
@@ -158,6 +273,7 @@ struct FilterArgs {
   int* accepted;
   int count, cap;
   double cost_rate, viol_rate;
+  int seed_empty;    // 1: only instances whose filter is empty take part (line_search.cpp:58-62: seed it with the current iterate)
 };
 
 static __global__ void line_search_filter_kernel(FilterArgs a) {
@@ -169,6 +285,10 @@ static __global__ void line_search_filter_kernel(FilterArgs a) {
   }
   double* f = a.filt + (size_t)b * a.cap * 2;
   int n = a.nfilt[b];
+  if (a.seed_empty && n != 0) {
+    a.accepted[b] = 0;
+    return;
+  }
   const double c = a.cost[b], v = a.viol[b];
   // isAccepted (:26-39): an empty filter accepts; otherwise ANY entry that the pair improves on
   bool ok = n == 0;

@@ -227,7 +227,17 @@ struct rtoc_ctx {
   double* d_min_dwell;  // [RTOC_STO_MAX_EVENTS + 1]
   double* d_sto_cost;   // [2][batch][nev] STO cost gradient / Hessian diagonal handed over by the host, or nullptr
   double* d_sto_out;    // [2][batch][nev] + [batch]: lt, Qtt diagonal as scattered, squared STO KKT term
-  double* d_costval;    // [batch][max_stages] cost values of the last rtoc_contact_eval_kkt (rtoc_eval_ocp), or nullptr
+  double* d_costval;    // [batch][max_stages] cost values of the last rtoc_contact_eval_kkt (rtoc_contact_eval_ocp)
+  // filter line search on the device (rtoc_set_line_search, rtoc_contact_line_search)
+  int ls_on;
+  double ls_rate, ls_min_step, ls_cost_rate, ls_viol_rate;
+  double* d_eval;       // [2][2][batch]: (cost + barrier | violation) of the current iterate, of the trial iterate
+  double* d_eval_part;  // [batch][max_stages][2]
+  double* d_sol_trial;  // trial iterate: SplitSolution records, constraint records, steps
+  double* d_con_trial;
+  double* d_ls_steps;   // [batch][2] trial steps + [batch] alpha
+  int* d_ls_active;     // [batch] active flags + [1] counter
+  int ls_trials;        // trial evaluations of the last line search
 };
 
 extern "C" {
@@ -395,6 +405,12 @@ int rtoc_destroy(rtoc_ctx* c) {
   if (c->d_sto_cost) (void)hipFree(c->d_sto_cost);
   if (c->d_sto_out) (void)hipFree(c->d_sto_out);
   if (c->d_costval) (void)hipFree(c->d_costval);
+  if (c->d_eval) (void)hipFree(c->d_eval);
+  if (c->d_eval_part) (void)hipFree(c->d_eval_part);
+  if (c->d_sol_trial) (void)hipFree(c->d_sol_trial);
+  if (c->d_con_trial) (void)hipFree(c->d_con_trial);
+  if (c->d_ls_steps) (void)hipFree(c->d_ls_steps);
+  if (c->d_ls_active) (void)hipFree(c->d_ls_active);
   if (c->d_cpos) (void)hipFree(c->d_cpos);
   if (c->d_crot) (void)hipFree(c->d_crot);
   if (c->d_prof) (void)hipFree(c->d_prof);
@@ -443,6 +459,7 @@ int rtoc_clone(rtoc_ctx* c, rtoc_ctx** out) {
     n->unconstr_dense = c->unconstr_dense;
     n->linearize_fused = c->linearize_fused;
     n->exact_cone_jacobian = c->exact_cone_jacobian;
+    n->ls_on = c->ls_on, n->ls_rate = c->ls_rate, n->ls_min_step = c->ls_min_step, n->ls_cost_rate = c->ls_cost_rate, n->ls_viol_rate = c->ls_viol_rate;
     if (c->backward_scan) rc = rtoc_set_option(n, RTOC_OPT_BACKWARD_SCAN, c->backward_scan);
   }
   hipError_t e = hipStreamSynchronize(c->stream);
@@ -2098,6 +2115,7 @@ int rtoc_contact_eval_kkt(rtoc_ctx* c) {
   if (rc) return rc;
   // PhaseBased discretisation: time_discretization_.correctTimeSteps(contact_sequence_, t) ahead of evalKKT (ocp_solver.cpp:115-117)
   if (c->sto_on) STO_LAUNCH(sto_time_steps_kernel, c);
+  if (!c->d_costval) HIP_TRY(hipMalloc((void**)&c->d_costval, sizeof(double) * c->batch * c->max_stages));
   CostArgs a;
   a.sol = c->buf[RTOC_BUF_SOL];
   a.cost = c->d_cost;
@@ -2406,10 +2424,157 @@ int rtoc_line_search_filter(rtoc_ctx* c, const double* cost, const double* viola
   a.cap = RTOC_LINE_SEARCH_FILTER_CAPACITY;
   a.cost_rate = cost_rate;
   a.viol_rate = viol_rate;
+  a.seed_empty = 0;
   hipLaunchKernelGGL(line_search_filter_kernel, dim3((count + 255) / 256), dim3(256), 0, c->stream, a);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(accepted, c->d_ls_flags + c->batch, sizeof(int) * count, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
+  return RTOC_OK;
+}
+
+// ---- DirectMultipleShooting::evalOCP's performance index and the filter line search on the device ----------------------
+static int ensure_line_search(rtoc_ctx* c) {
+  int rc = ensure_filter(c);
+  if (rc) return rc;
+  if (!c->d_eval) HIP_TRY(hipMalloc((void**)&c->d_eval, sizeof(double) * 4 * c->batch));
+  if (!c->d_eval_part) HIP_TRY(hipMalloc((void**)&c->d_eval_part, sizeof(double) * 2 * c->batch * c->max_stages));
+  if (!c->d_ls_steps) HIP_TRY(hipMalloc((void**)&c->d_ls_steps, sizeof(double) * 3 * c->batch));
+  if (!c->d_ls_active) HIP_TRY(hipMalloc((void**)&c->d_ls_active, sizeof(int) * (c->batch + 1)));
+  return RTOC_OK;
+}
+
+// (cost + cost_barrier | primal_feasibility) of every instance from the records rtoc_contact_eval_kkt has just written
+// (pre-condensation) into out[2][batch]
+static int launch_eval_ocp(rtoc_ctx* c, double* out) {
+  if (!c->d_costval || !c->buf[RTOC_BUF_KKT] || !c->buf[RTOC_BUF_CDD]) return RTOC_ERR_NOT_READY;
+  EvalOcpArgs a;
+  a.kkt = c->buf[RTOC_BUF_KKT];
+  a.cdd = c->buf[RTOC_BUF_CDD];
+  a.con = (c->nrows > 0 || c->cone_contacts > 0) ? c->buf[RTOC_BUF_CON] : nullptr;
+  a.costval = c->d_costval;
+  a.rows = c->d_rows;
+  a.grid = c->d_grid;
+  a.partial = c->d_eval_part;
+  a.nstages = c->nstages, a.batch = c->batch, a.nrows = c->nrows;
+  a.cone_contacts = c->cone_contacts, a.cone_dim = c->cone_dim > 0 ? c->cone_dim : 3, a.cone_rows = c->cone_rows;
+  a.nc_max = c->dims.nc_max, a.impact_cones = c->impact_cones;
+  a.nv = c->dims.nv, a.nx = c->L.nx;
+  a.barrier = c->barrier;
+  a.kl = c->L.kkt, a.cl = c->L.cdd, a.nl = c->L.con;
+  hipLaunchKernelGGL(eval_ocp_kernel, dim3(c->nstages, c->batch), dim3(64), 0, c->stream, a);
+  hipLaunchKernelGGL(eval_ocp_reduce_kernel, dim3((c->batch + 63) / 64), dim3(64), 0, c->stream, c->d_eval_part, out, c->nstages, c->batch);
+  HIP_TRY(hipGetLastError());
+  return RTOC_OK;
+}
+
+int rtoc_set_line_search(rtoc_ctx* c, int enable, double step_size_reduction_rate, double min_step_size, double filter_cost_reduction_rate,
+                         double filter_constraint_violation_reduction_rate) {
+  if (!c) return RTOC_ERR_BAD_ARG;
+  if (enable && (!(step_size_reduction_rate > 0.0 && step_size_reduction_rate < 1.0) || !(min_step_size > 0.0) ||
+                 !(filter_cost_reduction_rate > 0.0) || !(filter_constraint_violation_reduction_rate > 0.0)))
+    return RTOC_ERR_BAD_ARG;
+  c->ls_on = enable ? 1 : 0;
+  c->ls_rate = step_size_reduction_rate, c->ls_min_step = min_step_size;
+  c->ls_cost_rate = filter_cost_reduction_rate, c->ls_viol_rate = filter_constraint_violation_reduction_rate;
+  c->epoch++;
+  return RTOC_OK;
+}
+
+// trial = 0: DirectMultipleShooting::getEval() of the iterate rtoc_contact_eval_kkt has just linearised (records not yet condensed).
+// trial = 1: dms_trial_.integratePrimalSolution(step) + evalOCP (line_search.cpp:65-71) at SOL (+) step DIR with the slacks moved
+// by step x dslack, step = the primal entry of RTOC_BUF_STEP of every instance; RTOC_BUF_SOL / CON / DIR / STEP keep their
+// contents, the KKT / CDD records are overwritten (the next rtoc_contact_eval_kkt rewrites them anyway).
+static int eval_ocp_trial(rtoc_ctx* c, const double* steps, double* out) {
+  const size_t nsol = c->count[RTOC_BUF_SOL], ncon = c->count[RTOC_BUF_CON];
+  const bool has_con = c->buf[RTOC_BUF_CON] != nullptr;
+  if (!c->d_sol_trial) HIP_TRY(hipMalloc((void**)&c->d_sol_trial, sizeof(double) * nsol));
+  if (has_con && !c->d_con_trial) HIP_TRY(hipMalloc((void**)&c->d_con_trial, sizeof(double) * ncon));
+  HIP_TRY(hipMemcpyAsync(c->d_sol_trial, c->buf[RTOC_BUF_SOL], sizeof(double) * nsol, hipMemcpyDeviceToDevice, c->stream));
+  if (has_con) HIP_TRY(hipMemcpyAsync(c->d_con_trial, c->buf[RTOC_BUF_CON], sizeof(double) * ncon, hipMemcpyDeviceToDevice, c->stream));
+  double* const sol = c->buf[RTOC_BUF_SOL];
+  double* const con = c->buf[RTOC_BUF_CON];
+  double* const stp = c->buf[RTOC_BUF_STEP];
+  c->buf[RTOC_BUF_SOL] = c->d_sol_trial;
+  if (has_con) c->buf[RTOC_BUF_CON] = c->d_con_trial;
+  c->buf[RTOC_BUF_STEP] = const_cast<double*>(steps);
+  int rc = rtoc_update(c);                       // slack += step dslack (dual step 0)
+  if (!rc) rc = rtoc_integrate_solution(c);      // SplitSolution::integrate with the trial step
+  if (!rc) rc = rtoc_contact_eval_kkt(c);        // evalOCP's quantities (and, unused here, the derivatives)
+  if (!rc) rc = launch_eval_ocp(c, out);
+  c->buf[RTOC_BUF_SOL] = sol, c->buf[RTOC_BUF_CON] = con, c->buf[RTOC_BUF_STEP] = stp;
+  c->vals_fresh = 0;
+  c->fxx_state = 0;
+  return rc;
+}
+
+int rtoc_contact_eval_ocp(rtoc_ctx* c, int trial, double* host_cost, double* host_violation, int count) {
+  CHECK_READY(c);
+  if (count < 0 || count > c->batch || (count > 0 && (!host_cost || !host_violation))) return RTOC_ERR_BAD_ARG;
+  int rc = ensure_line_search(c);
+  if (rc) return rc;
+  double* out = c->d_eval + (trial ? 2 * c->batch : 0);
+  rc = trial ? eval_ocp_trial(c, c->buf[RTOC_BUF_STEP], out) : launch_eval_ocp(c, out);
+  if (rc) return rc;
+  if (count > 0) {
+    HIP_TRY(hipMemcpyAsync(host_cost, out, sizeof(double) * count, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(host_violation, out + c->batch, sizeof(double) * count, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+  }
+  return RTOC_OK;
+}
+
+static int launch_filter_device(rtoc_ctx* c, const double* eval, const int* mask, int seed_empty) {
+  FilterArgs a;
+  a.filt = c->d_filter, a.nfilt = c->d_nfilter;
+  a.cost = eval, a.viol = eval + c->batch;
+  a.mask = mask;
+  a.accepted = c->d_ls_flags + c->batch;
+  a.count = c->batch, a.cap = RTOC_LINE_SEARCH_FILTER_CAPACITY;
+  a.cost_rate = c->ls_cost_rate, a.viol_rate = c->ls_viol_rate;
+  a.seed_empty = seed_empty;
+  hipLaunchKernelGGL(line_search_filter_kernel, dim3((c->batch + 255) / 256), dim3(256), 0, c->stream, a);
+  HIP_TRY(hipGetLastError());
+  return RTOC_OK;
+}
+
+// LineSearch::computeStepSize, filter method (line_search.cpp:31-83), for every instance: on entry RTOC_BUF_STEP holds the
+// maximum primal steps (fraction-to-boundary), d_eval[0] the current iterates' (cost + barrier, violation) -- rtoc_newton_iteration
+// evaluates them right after the linearisation; on exit the primal entries of RTOC_BUF_STEP are the accepted steps.
+int rtoc_contact_line_search(rtoc_ctx* c, int* host_trials) {
+  CHECK_READY(c);
+  if (!c->ls_on) return RTOC_ERR_NOT_READY;
+  int rc = ensure_line_search(c);
+  if (rc) return rc;
+  rc = launch_filter_device(c, c->d_eval, nullptr, 1);   // an empty filter is seeded with the current iterate (:58-62)
+  if (rc) return rc;
+  LsArgs a;
+  a.steps = c->buf[RTOC_BUF_STEP];
+  a.trial_steps = c->d_ls_steps;
+  a.alpha = c->d_ls_steps + 2 * c->batch;
+  a.active = c->d_ls_active;
+  a.accepted = c->d_ls_flags + c->batch;
+  a.nactive = c->d_ls_active + c->batch;
+  a.batch = c->batch;
+  a.rate = c->ls_rate, a.min_step = c->ls_min_step;
+  const dim3 grid((c->batch + 255) / 256), block(256);
+  HIP_TRY(hipMemsetAsync(a.nactive, 0, sizeof(int), c->stream));
+  hipLaunchKernelGGL(ls_begin_kernel, grid, block, 0, c->stream, a);
+  int nactive = 0, trials = 0;
+  HIP_TRY(hipMemcpyAsync(&nactive, a.nactive, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  while (nactive > 0 && trials < 64) {
+    rc = eval_ocp_trial(c, c->d_ls_steps, c->d_eval + 2 * c->batch);
+    if (rc) return rc;
+    rc = launch_filter_device(c, c->d_eval + 2 * c->batch, c->d_ls_active, 0);   // isAccepted + augment of the active instances
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(a.nactive, 0, sizeof(int), c->stream));
+    hipLaunchKernelGGL(ls_advance_kernel, grid, block, 0, c->stream, a);
+    HIP_TRY(hipMemcpyAsync(&nactive, a.nactive, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    ++trials;
+  }
+  c->ls_trials = trials;
+  if (host_trials) *host_trials = trials;
   return RTOC_OK;
 }
 
@@ -2430,6 +2595,7 @@ __global__ void mask_converged_kernel(double* steps, const double* kkterr, int* 
 static int newton_iteration_body(rtoc_ctx* c, double kkt_tol, double tau) {
   HIP_TRY(hipMemsetAsync(c->d_nconv, 0, sizeof(int), c->stream));
   int rc = launch_kkt_error(c);  // on the freshly linearised (pre-condensation) records
+  if (!rc && c->ls_on) rc = launch_eval_ocp(c, c->d_eval);   // dms_.getEval(): cost + barrier, violation of the current iterate
   if (!rc) rc = rtoc_condense(c);
   if (!rc && c->sto_on) STO_LAUNCH(sto_eval_kkt_dev_kernel, c);   // sto_.evalKKT (ocp_solver.cpp:119); KKTError() gains the STO term
   if (!rc) rc = launch_sweep(c);
@@ -2439,6 +2605,10 @@ static int newton_iteration_body(rtoc_ctx* c, double kkt_tol, double tau) {
   hipLaunchKernelGGL(mask_converged_kernel, dim3((c->batch + 255) / 256), dim3(256), 0, c->stream,
                      c->buf[RTOC_BUF_STEP], c->d_kkterr, c->d_nconv, kkt_tol, c->batch);
   HIP_TRY(hipGetLastError());
+  if (c->ls_on) {   // line_search_.computeStepSize (:133-139): the accepted primal steps replace the maximum ones
+    rc = rtoc_contact_line_search(c, nullptr);
+    if (rc) return rc;
+  }
   rc = rtoc_update(c);
   if (!rc && c->buf[RTOC_BUF_SOL]) rc = rtoc_integrate_solution(c);
   if (!rc && c->sto_on) STO_LAUNCH(sto_integrate_kernel, c);       // sto_.integrateSolution (:143)
@@ -2449,6 +2619,10 @@ int rtoc_newton_iteration(rtoc_ctx* c, double kkt_tol, double tau) {
   CHECK_READY(c);
   if (!(kkt_tol >= 0.0) || !(tau > 0.0 && tau <= 1.0)) return RTOC_ERR_BAD_ARG;
   if (!c->d_nconv) HIP_TRY(hipMalloc((void**)&c->d_nconv, sizeof(int)));
+  if (c->ls_on) {   // the backtracking loop synchronises with the host: no graph replay
+    int rc = ensure_line_search(c);
+    return rc ? rc : newton_iteration_body(c, kkt_tol, tau);
+  }
   return run_graphed(c, &c->g_newton, kkt_tol, tau, [&]() { return newton_iteration_body(c, kkt_tol, tau); });
 }
 

@@ -34,10 +34,19 @@
 #include <memory>
 #include <ostream>
 
+#include "../../include/rtoc_robot.h"
 #include "robotoc_hip.hpp"
 #include "robotoc_hip_planner.hpp"
 
 namespace robotoc {
+
+// include/robotoc/line_search/line_search_settings.hpp (the filter method's members)
+struct LineSearchSettings {
+  double step_size_reduction_rate = 0.75;
+  double min_step_size = 0.05;
+  double filter_cost_reduction_rate = 0.005;
+  double filter_constraint_violation_reduction_rate = 0.005;
+};
 
 // include/robotoc/solver/solver_options.hpp:17-130 (the members the hot path reads)
 struct SolverOptions {
@@ -49,6 +58,7 @@ struct SolverOptions {
   double mu_linear_decrease_factor = 0.2;
   double mu_superlinear_decrease_power = 1.5;
   bool enable_line_search = false;
+  LineSearchSettings line_search_settings;
   double fraction_to_boundary_rule = 0.995;  // ConstraintComponentBase default (constraint_component_base.hpp)
   int initial_sto_reg_iter = 0;              // solver_options.hpp:96-113
   double initial_sto_reg = 1.0e30;
@@ -75,6 +85,7 @@ struct SolverStatistics {
 // include/robotoc/core/performance_index.hpp: the entry the convergence test reads
 struct PerformanceIndex {
   double kkt_error = 0.0;  // squared, like the reference accumulates it (sqrt in OCPSolver::KKTError())
+  double cost_plus_barrier = 0.0, primal_feasibility = 0.0;   // cost + cost_barrier, l1 violation (with the line search on)
 };
 
 // include/robotoc/core/split_solution.hpp: the members SplitSolution::integrate updates
@@ -339,8 +350,14 @@ class DirectMultipleShooting {
     double e = 0.0;
     chk(rtoc_kkt_error(ctx(), &e, 1), "rtoc_kkt_error");
     performance_index_.kkt_error = e * e;
+    if (line_search_) {   // cost + cost_barrier, primal_feasibility of the iterate: what LineSearch reads of dms.getEval()
+      double c = 0.0, v = 0.0;
+      chk(rtoc_contact_eval_ocp(ctx(), 0, &c, &v, 1), "rtoc_contact_eval_ocp");
+      performance_index_.cost_plus_barrier = c, performance_index_.primal_feasibility = v;
+    }
     chk(rtoc_condense(ctx()), "rtoc_condense");
   }
+  void setLineSearch(const bool on) { line_search_ = on; }
   // computeInitialStateDirection (direct_multiple_shooting.cpp:162-171 -> state_equation.cpp:98-109)
   void computeInitialStateDirection(const Vec& q, const Vec& v, const Solution& s, Direction& d) const {
     if (source_->initialStateDirectionOnDevice()) return;
@@ -394,6 +411,7 @@ class DirectMultipleShooting {
   double tau_;
   PerformanceIndex performance_index_;
   double max_primal_, max_dual_;
+  bool line_search_ = false;
 };
 
 // robotoc::SwitchingTimeOptimization (include/robotoc/sto/switching_time_optimization.hpp, src/sto/switching_time_optimization.cpp)
@@ -518,9 +536,13 @@ class OCPSolver {
   OCPSolver& operator=(OCPSolver&&) = default;
 
   void setSolverOptions(const SolverOptions& solver_options) {
-    if (solver_options.enable_line_search)
-      throw std::logic_error("[OCPSolver] the line search is outside the accelerated path (off by default, solver_options.hpp:70)");
+    if (solver_options.enable_line_search && ocp_.source->needsHostSolution())
+      throw std::logic_error("[OCPSolver] the line search evaluates trial iterates on the device: it needs a source that linearises there");
     solver_options_ = solver_options;
+    const LineSearchSettings& ls = solver_options.line_search_settings;   // line_search_.set(...) (ocp_solver.cpp:86)
+    chk(rtoc_set_line_search(dev_->get(), solver_options.enable_line_search ? 1 : 0, ls.step_size_reduction_rate, ls.min_step_size,
+                             ls.filter_cost_reduction_rate, ls.filter_constraint_violation_reduction_rate), "rtoc_set_line_search");
+    dms_.setLineSearch(solver_options.enable_line_search);
     dms_.setFractionToBoundaryRule(solver_options.fraction_to_boundary_rule);
     riccati_recursion_.setRegularization(solver_options.max_dts_riccati);   // ocp_solver.cpp:84
     riccati_recursion_.setHorizonScan(solver_options.horizon_scan);
@@ -564,8 +586,16 @@ class OCPSolver {
     riccati_recursion_.forwardRiccatiRecursionResident();                                       // :124
     dms_.computeStepSizes(time_discretization_, d_);                                            // :127
     sto_.computeStepSizes(time_discretization_, d_);                                            // :128
-    const double primal_step_size = std::min(dms_.maxPrimalStepSize(), sto_.maxPrimalStepSize());   // :129-132
+    double primal_step_size = std::min(dms_.maxPrimalStepSize(), sto_.maxPrimalStepSize());         // :129-132
     const double dual_step_size = std::min(dms_.maxDualStepSize(), sto_.maxDualStepSize());
+    if (solver_options_.enable_line_search) {                                                   // :133-139
+      // line_search_.computeStepSize: the filter's backtracking loop over trial iterates evaluated on the device
+      // (rtoc_contact_line_search; the maximum steps are where computeStepSizes left them, in RTOC_BUF_STEP)
+      const double st[2] = {primal_step_size, dual_step_size};
+      chk(rtoc_upload(dev_->get(), RTOC_BUF_STEP, 0, st, 2), "rtoc_upload");
+      chk(rtoc_contact_line_search(dev_->get(), nullptr), "rtoc_contact_line_search");
+      chk(rtoc_download(dev_->get(), RTOC_BUF_STEP, 0, &primal_step_size, 1), "rtoc_download");
+    }
     solver_statistics_.primal_step_size.push_back(primal_step_size);                            // :140-141
     solver_statistics_.dual_step_size.push_back(dual_step_size);
     dms_.integrateSolution(time_discretization_, primal_step_size, dual_step_size, d_, s_);     // :142

@@ -29,6 +29,11 @@ class SolverOptions:
     max_dts_riccati: float = 0.1
     enable_solution_interpolation: bool = True
     enable_line_search: bool = False
+    # LineSearchSettings (include/robotoc/line_search/line_search_settings.hpp), filter method
+    step_size_reduction_rate: float = 0.75
+    min_step_size: float = 0.05
+    filter_cost_reduction_rate: float = 0.005
+    filter_constraint_violation_reduction_rate: float = 0.005
 
 
 @dataclass
@@ -162,6 +167,10 @@ class OCPSolver:
             c.set_barrier_param(barrier_param, fraction_to_boundary_rule)
             c.set_friction_coefficients(np.asarray(friction_coefficients, dtype=float))
         self.has_rows = bool(rows) or friction_coefficients is not None
+        if self.options.enable_line_search:
+            o = self.options
+            c.set_line_search(True, o.step_size_reduction_rate, o.min_step_size, o.filter_cost_reduction_rate,
+                              o.filter_constraint_violation_reduction_rate)
         self.event_times = np.tile(np.array([e.time for e in plan.events], dtype=float), (batch, 1))   # per instance
         self.grids, self.masks, self.t_grid = None, None, None
         self.S = Records(c.L, "sol")

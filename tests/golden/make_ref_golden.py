@@ -496,7 +496,7 @@ def icub_surface_stage_fixture(name="ref_icub_surface_stage.npz"):
     print(name, "stage KKT error %.6e" % out[-1])
 
 
-def ocp_solver_iteration_fixture(name="ref_anymal_ocp_solver_iteration.npz", sto=False):
+def ocp_solver_iteration_fixture(name="ref_anymal_ocp_solver_iteration.npz", sto=False, line_search=False):
     """ONE OCPSolver::updateSolution (src/solver/ocp_solver.cpp:111-145) of ANYmal over a short trot -- lifts, touch-downs with
     switching constraints, ConfigurationSpaceCost, six joint-limit components, FrictionCone -- run by the REFERENCE'S OWN
     DirectMultipleShooting, stages, ContactSequence, cost, constraints, dynamics and RiccatiRecursion sources
@@ -505,7 +505,10 @@ def ocp_solver_iteration_fixture(name="ref_anymal_ocp_solver_iteration.npz", sto
     sto=True: BASELINE configs[2] at its size -- the ANYmal jump (stand, flight, stand; N = 40, PhaseBased grid, both events with
     switching-time optimisation) with the reference's SwitchingTimeOptimization over its minimum-dwell-time STOConstraints and the
     empty STOCostFunction of examples/anymal/python/jump_sto.py:104-108 in the loop (ocp_solver.cpp:119, 128-132, 143): the
-    fixture also carries the event times before and after the iteration, the dwell-time rows and the switching-time directions."""
+    fixture also carries the event times before and after the iteration, the dwell-time rows and the switching-time directions.
+    line_search=True: SolverOptions::enable_line_search -- the reference's own LineSearch::computeStepSize (filter method,
+    src/line_search/line_search.cpp:31-83) picks the primal step between computeStepSizes and integrateSolution
+    (ocp_solver.cpp:133-139); every trial iterate's rigid-body quantities are injected like those of the iterate itself."""
     import ctypes as C
     from robotoc_amd import robot_model as rm
     from robotoc_amd.grid import (ANYMAL_Q_STANDING, ANYMAL_TROT_IMPACT_MASKS, ANYMAL_TROT_PHASE_MASKS, contact_masks)
@@ -533,6 +536,8 @@ def ocp_solver_iteration_fixture(name="ref_anymal_ocp_solver_iteration.npz", sto
         q[i, :7] = orc.se3_integrate(qs[:7], 0.02 * rng.uniform(-1, 1, 6))
         q[i, 7:] += 0.05 * rng.uniform(-1, 1, 12)
     v, a, u = 0.2 * rng.uniform(-1, 1, (n, nv)), 0.5 * rng.uniform(-1, 1, (n, nv)), 5.0 * rng.uniform(-1, 1, (n, nu))
+    if line_search:   # an iterate whose full Newton step is long (roomy slacks) and overshoots (fast joints): the filter has work to do
+        v, a = 3.0 * rng.uniform(-1, 1, (n, nv)), 20.0 * rng.uniform(-1, 1, (n, nv))
     f = 5.0 * rng.uniform(-1, 1, (n, nc, 3))
     f[:, :, 2] = rng.uniform(60, 120, (n, nc))
     lmd, gmm, beta = (0.2 * rng.uniform(-1, 1, (n, nv)) for _ in range(3))
@@ -547,6 +552,9 @@ def ocp_solver_iteration_fixture(name="ref_anymal_ocp_solver_iteration.npz", sto
     limits = np.stack([np.full(nu, -1.8), np.full(nu, 1.8), np.full(nu, 4.0), np.full(nu, 60.0)])
     nrow = 6 * nu + 5 * nc
     slack, dual = rng.uniform(0.2, 2.0, (n, nrow)), rng.uniform(0.01, 0.3, (n, nrow))
+    if line_search:
+        limits = np.stack([np.full(nu, -6.0), np.full(nu, 6.0), np.full(nu, 40.0), np.full(nu, 400.0)])
+        slack, dual = rng.uniform(20.0, 40.0, (n, nrow)), rng.uniform(1e-5, 1e-4, (n, nrow))
     barrier, tau = 1.0e-3, 0.995
     x0 = np.concatenate([orc.se3_integrate(qs[:7], 0.01 * rng.uniform(-1, 1, 6)), qs[7:] + 0.02 * rng.uniform(-1, 1, 12), 0.05 * rng.uniform(-1, 1, nv)])
     L = ref.lib()
@@ -627,7 +635,7 @@ def ocp_solver_iteration_fixture(name="ref_anymal_ocp_solver_iteration.npz", sto
     from robotoc_amd.types import Grid
     garr = (Grid * n)(*grids)
     marr = np.ascontiguousarray(masks, dtype=np.uint32)
-    out_dq, steps = np.zeros((n, nv)), np.zeros(3)
+    out_dq, steps = np.zeros((n, nv)), np.zeros(6)
     sto_kw = {}
     if sto:
         min_dwell, sto_barrier, sto_tau, sto_reg = np.array([0.15, 0.15, 0.2]), 1.0e-3, 0.995, 1.0e-2
@@ -650,6 +658,61 @@ def ocp_solver_iteration_fixture(name="ref_anymal_ocp_solver_iteration.npz", sto
         et0, con_dir, ltq, perf, dts = sto_result()
         sto_kw = dict(sto_event_times=et0, sto_con_direction=con_dir, sto_lt_qtt=ltq, sto_perf=perf, sto_dts=dts, sto_min_dwell=min_dwell, sto_slack=sto_slack, sto_dual=sto_dual,
                       sto_scalars=np.array([sto_barrier, sto_tau, sto_reg, 0.0, T_h]))
+    ls_kw = {}
+    if line_search:
+        # a filter that wants the violation halved: no trial below the (fraction-to-boundary) maximum step can deliver that, so every
+        # candidate is evaluated and rejected and the loop ends below min_step_size -- the whole backtracking path runs
+        rate, min_step, cost_rate, viol_rate = 0.75, 0.05, 0.005, 0.5
+        L.ref_ocp_trial_solution.argtypes = [C.c_double, dp, dp]
+        L.ref_ocp_line_search.argtypes = [C.c_double, C.c_double, C.c_double, C.c_double, dp]
+        trials, alpha = [], float(steps[0])
+        while alpha > min_step:
+            q_tr = np.array([plus(q[i], alpha * out_dq[i]) for i in range(n)])
+            s_tr = np.zeros((n, SL))
+            assert L.ref_ocp_trial_solution(alpha, ptr(q_tr), s_tr.ctypes.data_as(dp)) == 0
+            trials.append((alpha, q_tr, s_tr))
+            alpha *= rate
+        o_v, o_a, o_f = nq, nq + nv, nq + 2 * nv + nu
+        L.ref_ocp_trial_eval.argtypes = [C.c_double, dp]
+        trial_evals = []
+        for k_pass, (alpha, q_tr, s_tr) in enumerate(trials + trials):   # once each on its own (the values), then all for the line search
+            if k_pass == len(trials):
+                pass
+            for i in range(n):   # dms_trial_.integratePrimalSolution
+                inject("integrateConfiguration", q_tr[i])
+            for i, g in enumerate(grids):   # dms_trial_.evalOCP, stage by stage
+                impact, terminal = g.type == GI, g.type == GT
+                qi, vi, ai = s_tr[i, :nq], s_tr[i, o_v:o_v + nv], s_tr[i, o_a:o_a + nv]
+                for c in range(nc):   # updateKinematics: the cones read the frame rotation; no Jacobian in an evaluation
+                    inject("frames", np.concatenate([orc.rbd_contact_placement(m, qi, c)[0].reshape(-1), np.zeros(6 * nv)]))
+                inject("subtractConfiguration", sub(qi, qs))
+                if terminal:
+                    continue
+                inject("subtractConfiguration", sub(qi, s_tr[i + 1, :nq]))
+                mask = int(masks[i])
+                act = [c for c in range(nc) if (mask >> c) & 1]
+                fstack = np.concatenate([s_tr[i, o_f + 3 * c:o_f + 3 * c + 3] for c in act]) if act else np.zeros(0)
+                val = orc.rbd_eval(m, int(impact), qi, vi, ai, fstack, np.zeros(nu), mask, pos[i].reshape(-1))
+                inject("ID", val[:nv])
+                inject("impactVelocityResidual" if impact else "baumgarteResidual", val[nv:])
+                if g.switching_constraint and not impact:
+                    dt1, dt2 = g.dt, grids[i + 1].dt
+                    q_plus = plus(qi, (dt1 + dt2) * vi + dt1 * dt2 * ai)
+                    imp = [c for c in range(nc) if (int(masks[i + 2]) >> c) & 1]
+                    inject("integrateConfiguration", q_plus)
+                    inject("contactPositionResidual", np.concatenate([orc.rbd_contact_position(m, q_plus, c) - pos[i + 2, c] for c in imp]))
+            if k_pass < len(trials):
+                ev = np.zeros(3)
+                assert L.ref_ocp_trial_eval(alpha, ev.ctypes.data_as(dp)) == 0
+                trial_evals.append(ev)
+        ls_step = np.zeros(2)
+        assert L.ref_ocp_line_search(rate, min_step, cost_rate, viol_rate, ls_step.ctypes.data_as(dp)) == 0
+        n_eval = len(trials) - int(round(ls_step[1])) // (n - 1)
+        print("  line search: max primal step %.4f -> accepted %.4f (%d of %d candidate trials evaluated), eval0 cost %.4e barrier %.4e violation %.4e"
+              % (steps[0], ls_step[0], n_eval, len(trials), steps[3], steps[4], steps[5]))
+        ls_kw = dict(ls_step=ls_step[:1], ls_trials_evaluated=np.array([n_eval]), ls_max_step=steps[:1].copy(), ls_trial_evals=np.array(trial_evals), ls_eval0=steps[3:6].copy(), ls_settings=np.array([rate, min_step, cost_rate, viol_rate]),
+                     ls_trial_steps=np.array([t[0] for t in trials]))
+        steps[0] = ls_step[0]
     q_int = np.array([plus(q[i], steps[0] * out_dq[i]) for i in range(n)])
     sol_out, slack_out, dual_out = np.zeros((n, SL)), np.zeros((n, nrow)), np.zeros((n, nrow))
     L.ref_ocp_integrate.argtypes = [dp, dp, dp, dp]
@@ -661,7 +724,7 @@ def ocp_solver_iteration_fixture(name="ref_anymal_ocp_solver_iteration.npz", sto
         print("  event times %s -> %s, dts %s, STO kkt %.3e" % (et0, et1, dts[[i for i, g in enumerate(grids) if g.type in (1, 2)], 0], perf[0]))
     np.savez_compressed(os.path.join(HERE, name), sol_in=sol, sol_out=sol_out, slack=slack, dual=dual, slack_out=slack_out, dual_out=dual_out,
                         steps=steps, x0=x0, pos=pos, mu=mu, cost=cost, limits=limits, masks=masks, scalars=np.array([barrier, tau]),
-                        **grid_table(grids), **sto_kw)
+                        **grid_table(grids), **sto_kw, **ls_kw)
     print(name, "n %d, KKT error %.6e, steps %.4f / %.4f" % (n, steps[2], steps[0], steps[1]))
 
 
@@ -675,6 +738,7 @@ FIXTURES = {
     "ocp_iteration": ocp_solver_iteration_fixture,
     "riccati_full_size": full_size_fixtures,
     "ocp_iteration_sto": lambda: ocp_solver_iteration_fixture("ref_anymal_jump_sto_solver_iteration.npz", sto=True),
+    "ocp_iteration_line_search": lambda: ocp_solver_iteration_fixture("ref_anymal_ocp_solver_iteration_line_search.npz", line_search=True),
 }
 
 if __name__ == "__main__":   # python tests/golden/make_ref_golden.py [fixture ...]   (default: all)
