@@ -756,17 +756,19 @@ def main():
                 if b2 == 1:
                     entry["single_instance_sweep_ms"] = mb + mf
                     entry["single_instance_backward_ms"] = mb
-                    if not any(g.sto or g.sto_next for g in g2):
-                        # RTOC_OPT_BACKWARD_SCAN: both recursions as scans over the horizon (latency path)
-                        c2.set_unconstr_dense(True)   # (the scan works on the general elements)
-                        c2.set_backward_scan(True)
-                        c2.time_phase(4, 2)
-                        ms, msf = c2.time_phase(0, 5), c2.time_phase(1, 5)
-                        c2.set_backward_scan(False)
-                        entry["single_instance_backward_scan_ms"] = ms
-                        entry["single_instance_forward_scan_ms"] = msf
-                        entry["single_instance_sweep_scan_ms"] = ms + msf
-                        ok = ok and int((c2.status() != 0).sum()) == 0
+                    # RTOC_OPT_BACKWARD_SCAN: both recursions as scans over the horizon (latency path); on grids with
+                    # switching-time optimisation the backward recursion is "matrix scan + serial vector pass"
+                    # (riccati_scan_sto.hpp) and the forward recursion stays the serial kernel
+                    c2.set_unconstr_dense(True)   # (the scan works on the general elements)
+                    c2.set_backward_scan(True)
+                    c2.time_phase(4, 2)
+                    ms, msf = c2.time_phase(0, 5), c2.time_phase(1, 5)
+                    c2.set_backward_scan(False)
+                    entry["single_instance_backward_scan_ms"] = ms
+                    entry["single_instance_forward_scan_ms"] = msf
+                    entry["single_instance_sweep_scan_ms"] = ms + msf
+                    entry["forward_scan"] = not any(g.sto or g.sto_next for g in g2)
+                    ok = ok and int((c2.status() != 0).sum()) == 0
                 else:
                     ab, fl = algorithmic_bytes(L2, g2, b2, "backward"), backward_flops(L2, g2, b2)
                     if name.startswith("iiwa"):   # structured: Fxx / Fvu are never read (nor exist)

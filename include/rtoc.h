@@ -107,7 +107,9 @@ enum rtoc_option {
                               * (riccati_recursion.cpp:32-80); rtoc_riccati_forward likewise as a prefix scan of
                               * the closed-loop maps (:83-131).  For FEW instances (one MPC problem): latency of a
                               * sweep, not throughput of a batch.  Same outputs (P, s, K, k, M, m) to <= 1e-8
-                              * relative; grids with switching-time optimisation take the serial kernel.
+                              * relative.  Grids with switching-time optimisation: the MATRIX half (P, K, M) is the same scan,
+                              * the vector half (s, k, m, Psi, Phi, the STO scalars and policies) one serial pass of four barrier-
+                              * separated phases per grid point behind it (riccati_scan_sto.hpp); the forward recursion stays serial there.
                               * 2: automatic -- the scan for batches of at most 8 instances (where it is faster
                               * on MI355X), the serial kernels above.  Needs Quu > 0 of every stage by itself (the
                               * serial recursion only needs Quu + B^T P+ B > 0); a violation sets

@@ -29,12 +29,13 @@ typedef void (*cond_fn)(CondArgs);
 typedef void (*expd_fn)(ExpArgs);
 typedef void (*scan_fn)(ScanArgs);
 typedef void (*fscan_fn)(FwdScanArgs);
+typedef void (*stoscan_fn)(StoScanArgs);
 typedef void (*ur_fn)(UrArgs);
 // what a shape plugin must agree on with the runtime that loads it: the kernel-set table and every argument block
 constexpr size_t kernel_abi_stamp() {
   size_t h = 1469598103934665603ull;
   const size_t parts[] = {sizeof(BwdArgs), sizeof(FwdArgs), sizeof(FillArgs), sizeof(UdArgs), sizeof(ConeArgs), sizeof(CondArgs),
-                          sizeof(ExpArgs), sizeof(ScanArgs), sizeof(FwdScanArgs), sizeof(UrArgs)};
+                          sizeof(ExpArgs), sizeof(ScanArgs), sizeof(FwdScanArgs), sizeof(UrArgs), sizeof(StoScanArgs)};
   for (size_t v : parts) h = (h ^ v) * 1099511628211ull;
   return h;
 }
@@ -68,6 +69,8 @@ struct KernelSet {
   int scan_policy_variant;                            // tile-split backward kernel used in its one-stage mode
   fscan_fn fscan_elt, fscan_comb, fscan_fin;          // forward recursion as a prefix scan
   int fscan_lds;
+  stoscan_fn sto_prep, sto_vec;                       // scan on grids with switching-time optimisation (riccati_scan_sto.hpp)
+  int sto_prep_lds, sto_vec_lds, sto_vec_threads, sto_scr_stride;
 };
 
 template <int NV, int NU, int NS, int NW0, int NW1>
@@ -148,6 +151,13 @@ inline KernelSet make_set() {
   k.fscan_comb = fwd_scan_combine_kernel<NV, NU, NS>;
   k.fscan_fin = fwd_scan_finish_kernel<NV, NU, NS>;
   k.fscan_lds = scan::FwdCfg<NV, NU>::LDS_BYTES;
+  k.sto_prep = scan_sto_prep_kernel<NV, NU, NS>;
+  k.sto_vec = scan_sto_vector_kernel<NV, NU, NS>;
+  k.sto_prep_lds = scan::StoPrepCfg<NV, NU, NS>::LDS_DOUBLES * (int)sizeof(double);
+  k.sto_vec_lds = scan::StoVecCfg<NV, NU, NS>::LDS_BYTES;
+  k.sto_vec_threads = scan_sto_vec_nt(NV);
+  k.sto_scr_stride = scan::StoScratch<NV, NU, NS>::STRIDE;
+  static_assert(scan::StoVecCfg<NV, NU, NS>::LDS_BYTES <= 160 * 1024, "the vector pass keeps one grid point's bundle in LDS");
   static_assert(scan::CombineCfg<NV, scan_comb_nt(NV)>::LDS_BYTES <= 160 * 1024, "combination scratch must fit the LDS of a CU");
   return k;
 }

@@ -463,7 +463,9 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
     RTOC_PROF(0);
 #define RTOC_GRID_PREV_STO (a.grid[st - 1].sto != 0)
 #define RTOC_PT_TOP_SYNC() RTOC_BLOCK_SYNC()
+#define RTOC_PT_SKIP one_stage
 #include "riccati_pt_block.inc"
+#undef RTOC_PT_SKIP
 #undef RTOC_PT_TOP_SYNC
 #undef RTOC_GRID_PREV_STO
     RTOC_PROF(1);

@@ -12,6 +12,7 @@
 #pragma once
 #include "device_utils.hpp"
 #include "riccati_scan_core.hpp"
+#include "riccati_scan_sto.hpp"
 
 namespace rtoc {
 
@@ -76,6 +77,51 @@ __global__ __launch_bounds__(scan_comb_nt(NV), scan_comb_min_waves(NV)) void sca
       e2 + E::OFF_B, e2 + E::OFF_C, closed2, part, a.dst + (inst + i) * E::STRIDE,
       a.ps + (inst + i) * E::PS_STRIDE, smem, threadIdx.x);
   if (stat && threadIdx.x == 0) atomicOr(&a.status[b], stat);
+}
+
+// ---- grids with switching-time optimisation: stage-parallel preparation + serial vector pass (riccati_scan_sto.hpp) ----
+struct StoScanArgs {
+  const double* kkt;
+  double* ric;
+  const rtoc_grid* grid;
+  uint32_t* status;
+  const double* ps;   // the scan's value records [batch][nstages][PS_STRIDE]
+  double* scr;        // [batch][nstages][StoScratch::STRIDE]
+  int nstages, batch, first;
+  double max_dts0;
+  long long* prof;    // phase stamps of instance 0 (RTOC_ENABLE_PROF builds), else nullptr
+};
+constexpr int SCAN_STO_PREP_NT = 128;
+
+template <int NV, int NU, int NS>
+__global__ __launch_bounds__(SCAN_STO_PREP_NT) void scan_sto_prep_kernel(StoScanArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  using E = scan::EltLayout<NV>;
+  constexpr rtoc_layout SL = StaticLayout<NV, NU, NS>::make();
+  const int st = blockIdx.x, b = a.first + blockIdx.y;
+  if (b >= a.batch || st >= a.nstages - 1) return;
+  const size_t rec = (size_t)b * a.nstages + st;
+  const unsigned stat = scan::sto_prep_body<NV, NU, NS, SCAN_STO_PREP_NT>(
+      a.grid[st], a.kkt + rec * SL.kkt.stride, a.ps + (rec + 1) * E::PS_STRIDE, a.scr + rec * scan::StoScratch<NV, NU, NS>::STRIDE, smem,
+      threadIdx.x);
+  if (stat && threadIdx.x == 0) atomicOr(&a.status[b], stat);
+}
+
+// five wavefronts per instance: a row of the step's products is shared by up to four neighbouring lanes of the first four, the fifth
+// stores the previous grid point's results meanwhile (the bundle of a grid point is prefetched into registers: 14 doubles per lane for ANYmal)
+constexpr int SCAN_STO_MAX_STAGES = 512;   // = scan::StoVecCfg::MAX_STAGES (grids beyond take the serial kernel)
+constexpr int scan_sto_vec_nt(int) { return 320; }
+template <int NV, int NU, int NS, int SCAN_STO_VEC_NT = scan_sto_vec_nt(NV)>
+__global__ __launch_bounds__(SCAN_STO_VEC_NT) void scan_sto_vector_kernel(StoScanArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  constexpr rtoc_layout SL = StaticLayout<NV, NU, NS>::make();
+  const int b = a.first + blockIdx.x;
+  if (b >= a.batch) return;
+  const size_t inst = (size_t)b * a.nstages;
+  const unsigned stat = scan::sto_vector_body<NV, NU, NS, SCAN_STO_VEC_NT>(
+      a.grid, a.nstages, a.kkt + inst * SL.kkt.stride, a.ric + inst * SL.ric.stride, a.scr + inst * scan::StoScratch<NV, NU, NS>::STRIDE,
+      a.max_dts0, smem, threadIdx.x, b == 0 ? a.prof : nullptr);
+  if (stat) atomicOr(&a.status[b], stat);
 }
 
 // ---- forward recursion as a prefix scan of the closed-loop maps (riccati_scan_core.hpp) ------------------

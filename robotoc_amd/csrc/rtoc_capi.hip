@@ -166,6 +166,8 @@ struct rtoc_ctx {
   int bwd_variant;
   hipEvent_t ev0, ev1;
   hipStream_t stream2;  // forward half of the pipelined sweep
+  hipStream_t stream3;  // preparation of the vector pass of the scan with STO, next to the policy kernel
+  hipEvent_t ev_sto_fork, ev_sto_join;
   hipEvent_t ev_fork, ev_join, ev_chunk[RTOC_MAX_CHUNK_EVENTS];
   int sweep_chunks;
   int condense_split;  // 1: MJtJinv in its own kernel ahead of the condensation
@@ -202,6 +204,7 @@ struct rtoc_ctx {
   double* d_kkterr;             // [batch]
   int backward_scan;            // RTOC_OPT_BACKWARD_SCAN
   double* d_scan[3];            // element ping-pong buffers, value records (allocated on first use)
+  double* d_scan_sto;           // riccati_scan_sto.hpp: per grid point At, P+ Fx, P+ fx, factors of G
   // rigid-body model (rtoc_set_robot_model) and contact schedule (rtoc_set_contact_schedule)
   rbd::DevModel* d_model;
   rbd::DevModel* h_model;
@@ -294,6 +297,9 @@ static int create_members(rtoc_ctx* c, const rtoc_dims* dims, const KernelSet* k
   HIP_TRY(hipEventCreate(&c->ev0));
   HIP_TRY(hipEventCreate(&c->ev1));
   HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+  HIP_TRY(hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreateWithFlags(&c->ev_sto_fork, hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&c->ev_sto_join, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   for (int i = 0; i < RTOC_MAX_CHUNK_EVENTS; ++i)
@@ -341,6 +347,8 @@ static int create_members(rtoc_ctx* c, const rtoc_dims* dims, const KernelSet* k
                               ks->scan_comb_lds));
   HIP_TRY(hipFuncSetAttribute((const void*)ks->fscan_elt, hipFuncAttributeMaxDynamicSharedMemorySize, ks->fscan_lds));
   HIP_TRY(hipFuncSetAttribute((const void*)ks->fscan_comb, hipFuncAttributeMaxDynamicSharedMemorySize, ks->fscan_lds));
+  HIP_TRY(hipFuncSetAttribute((const void*)ks->sto_prep, hipFuncAttributeMaxDynamicSharedMemorySize, ks->sto_prep_lds));
+  HIP_TRY(hipFuncSetAttribute((const void*)ks->sto_vec, hipFuncAttributeMaxDynamicSharedMemorySize, ks->sto_vec_lds));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return RTOC_OK;
 }
@@ -416,10 +424,14 @@ int rtoc_destroy(rtoc_ctx* c) {
   if (c->d_prof) (void)hipFree(c->d_prof);
   for (int i = 0; i < 3; ++i)
     if (c->d_scan[i]) (void)hipFree(c->d_scan[i]);
+  if (c->d_scan_sto) (void)hipFree(c->d_scan_sto);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
+  if (c->stream3) (void)hipStreamDestroy(c->stream3);
+  if (c->ev_sto_fork) (void)hipEventDestroy(c->ev_sto_fork);
+  if (c->ev_sto_join) (void)hipEventDestroy(c->ev_sto_join);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   for (int i = 0; i < RTOC_MAX_CHUNK_EVENTS; ++i)
@@ -753,13 +765,20 @@ int rtoc_bind(rtoc_ctx* c, int buffer, void* device_ptr) {
 
 // ---- hot path ---------------------------------------------------------------------------
 // RTOC_OPT_BACKWARD_SCAN: the scan covers grids without switching-time optimisation; others take the serial kernel
+static bool grid_has_sto(const rtoc_ctx* c) {
+  for (int i = 0; i < c->nstages; ++i)
+    if (c->h_grid[i].sto || c->h_grid[i].sto_next) return true;
+  return false;
+}
+// the backward recursion: every grid (with switching-time optimisation: matrix scan + serial vector pass, riccati_scan_sto.hpp)
 static bool scan_applies(const rtoc_ctx* c) {
   if (!c->backward_scan || !c->h_grid) return false;
   if (c->backward_scan == 2 && c->batch > RTOC_SCAN_AUTO_MAX_BATCH) return false;  // auto: latency regime only
-  for (int i = 0; i < c->nstages; ++i)
-    if (c->h_grid[i].sto || c->h_grid[i].sto_next) return false;
+  if (c->nstages > SCAN_STO_MAX_STAGES && grid_has_sto(c)) return false;            // the vector pass keeps the grid in LDS
   return true;
 }
+// the forward recursion as a prefix scan: grids without switching-time optimisation (the dts chain is not a fixed affine map)
+static bool forward_scan_applies(const rtoc_ctx* c) { return scan_applies(c) && !grid_has_sto(c); }
 
 // Backward recursion as a horizon scan (riccati_scan.hpp): elements, log2 combination levels, then the
 // policies of all grid points at once by the tile-split backward kernel in its one-stage mode.
@@ -771,6 +790,7 @@ static int ensure_scan_buffers(rtoc_ctx* c) {
       const size_t n = per * (i < 2 ? ks->scan_elt_stride : ks->scan_ps_stride);
       HIP_TRY(hipMalloc((void**)&c->d_scan[i], n * sizeof(double)));
     }
+  if (!c->d_scan_sto) HIP_TRY(hipMalloc((void**)&c->d_scan_sto, per * ks->sto_scr_stride * sizeof(double)));
   return RTOC_OK;
 }
 
@@ -816,7 +836,25 @@ static int launch_backward_scan(rtoc_ctx* c, int first, int end, hipStream_t str
   a.scan_ps_stride = ks->scan_ps_stride;
   a.scan_ps_soff = ks->scan_ps_soff;
   const int v = ks->scan_policy_variant;
+  const bool sto = grid_has_sto(c);
+  StoScanArgs t;
+  if (sto) {   // everything of the vector recursion that does not depend on the chain, next to the policies
+    t.kkt = c->buf[RTOC_BUF_KKT], t.ric = c->buf[RTOC_BUF_RIC], t.grid = c->d_grid, t.status = c->d_status;
+    t.ps = c->d_scan[2], t.scr = c->d_scan_sto;
+    t.nstages = n, t.batch = end, t.first = first, t.max_dts0 = c->max_dts0, t.prof = c->d_prof;
+    // Next to the policy kernel on its own stream: both read the scan's value records, neither the other's output -- unless
+    // the policy kernel writes the mutated Quu, lu back into the KKT records (RTOC_OPT_WRITEBACK_KKT), which this one reads.
+    hipStream_t ps = c->writeback ? stream : c->stream3;
+    if (!c->writeback) {
+      HIP_TRY(hipEventRecord(c->ev_sto_fork, stream));
+      HIP_TRY(hipStreamWaitEvent(ps, c->ev_sto_fork, 0));
+    }
+    hipLaunchKernelGGL(ks->sto_prep, dim3(n - 1, nb), dim3(SCAN_STO_PREP_NT), ks->sto_prep_lds, ps, t);
+    if (!c->writeback) HIP_TRY(hipEventRecord(c->ev_sto_join, ps));
+  }
   hipLaunchKernelGGL(ks->bwd[v], dim3(nb, n), dim3(64 * ks->bwd_waves[v]), ks->bwd_lds[v], stream, a);
+  if (sto && !c->writeback) HIP_TRY(hipStreamWaitEvent(stream, c->ev_sto_join, 0));
+  if (sto) hipLaunchKernelGGL(ks->sto_vec, dim3(nb), dim3(ks->sto_vec_threads), ks->sto_vec_lds, stream, t);   // s, k, m, the STO quantities
   HIP_TRY(hipGetLastError());
   return RTOC_OK;
 }
@@ -912,7 +950,7 @@ static int launch_forward_scan(rtoc_ctx* c, int first, int end, hipStream_t stre
 }
 
 static int launch_forward_range(rtoc_ctx* c, int first, int end, hipStream_t stream) {
-  if (scan_applies(c)) return launch_forward_scan(c, first, end, stream);
+  if (forward_scan_applies(c)) return launch_forward_scan(c, first, end, stream);
   FwdArgs a;
   a.kkt = c->buf[RTOC_BUF_KKT];
   a.ric = c->buf[RTOC_BUF_RIC];

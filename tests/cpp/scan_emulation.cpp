@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "../../robotoc_amd/csrc/riccati_scan_core.hpp"
+#include "../../robotoc_amd/csrc/riccati_scan_sto.hpp"
 
 using namespace rtoc::scan;
 
@@ -96,5 +97,32 @@ extern "C" int scan_emu_backward(int nv, int nu, int ns_max, const rtoc_grid* gr
   if (nv == 35 && nu == 29 && ns_max == 12) return run<35, 29, 12>(grid, n, kkt, ps, stat);
   if (nv == 32 && nu == 26 && ns_max == 12) return run<32, 26, 12>(grid, n, kkt, ps, stat);
   if (nv == 7 && nu == 7 && ns_max == 0) return run<7, 7, 0>(grid, n, kkt, ps, stat);
+  return -1;
+}
+
+// Grids with switching-time optimisation (riccati_scan_sto.hpp): the stage-parallel preparation of every grid point from the
+// scan's value records `ps` (P+ first), then the serial vector pass of ONE instance.  ric: [n][ric stride], in: the matrix half
+// (K, M of every grid point and the terminal s -- the caller takes them from the serial recursion), out: s, k, m and every STO
+// quantity.  Returns the status bits, or -1 for unsupported dimensions.
+template <int NV, int NU, int NS>
+static int run_sto(const rtoc_grid* grid, int n, const double* kkt, const double* ps, double* ric, double max_dts0) {
+  using E = EltLayout<NV>;
+  using W = StoScratch<NV, NU, NS>;
+  constexpr rtoc_layout SL = ScanLayout<NV, NU, NS>::make();
+  std::vector<double> scr((size_t)n * W::STRIDE, 0.0), smem_p(StoPrepCfg<NV, NU, NS>::LDS_DOUBLES), smem_v(StoVecCfg<NV, NU, NS>::LDS_DOUBLES);
+  unsigned stat = 0;
+  for (int i = 0; i + 1 < n; ++i)
+    stat |= sto_prep_body<NV, NU, NS, 1>(grid[i], kkt + (size_t)i * SL.kkt.stride, ps + (size_t)(i + 1) * E::PS_STRIDE,
+                                         scr.data() + (size_t)i * W::STRIDE, smem_p.data(), 0);
+  stat |= sto_vector_body<NV, NU, NS, 1>(grid, n, kkt, ric, scr.data(), max_dts0, smem_v.data(), 0);
+  return (int)stat;
+}
+
+extern "C" int scan_emu_backward_sto(int nv, int nu, int ns_max, const rtoc_grid* grid, int n, const double* kkt, const double* ps,
+                                     double* ric, double max_dts0) {
+  if (nv == 18 && nu == 12 && ns_max == 12) return run_sto<18, 12, 12>(grid, n, kkt, ps, ric, max_dts0);
+  if (nv == 35 && nu == 29 && ns_max == 12) return run_sto<35, 29, 12>(grid, n, kkt, ps, ric, max_dts0);
+  if (nv == 32 && nu == 26 && ns_max == 12) return run_sto<32, 26, 12>(grid, n, kkt, ps, ric, max_dts0);
+  if (nv == 7 && nu == 7 && ns_max == 0) return run_sto<7, 7, 0>(grid, n, kkt, ps, ric, max_dts0);
   return -1;
 }
