@@ -181,6 +181,23 @@ def pmc_traffic(kernel_substr):
     return None
 
 
+VALU_F64_PEAK_TFLOPS = 78.6   # MI355X fp64 vector peak (MI355X_MICROARCH.md: 256 CU x 4 SIMD x 16 FMA lanes/clk x 2 x 2.4 GHz)
+
+
+def linearize_flops():
+    """fp64 VALU flops per grid point of the rigid-body linearisation, from the committed counter pass
+    (profiles/<round>_linearize_flops.json, tools/gpu_pmc_lin_flops.sh): 64 x (ADD_F64 + MUL_F64 + 2 FMA_F64) wave-instructions
+    of rbd_values_kernel + linearize_contact_dynamics_kernel.  (None, why) when no pass of THESE kernel sources is committed."""
+    path = os.path.join(ROOT, "profiles", "%s_linearize_flops.json" % PROFILE_ROUND)
+    if not os.path.exists(path):
+        return None, "no committed fp64-instruction counter pass for this round"
+    t = json.load(open(path))
+    if t.get("_kernel_source_hash") != kernel_source_hash():
+        return None, "profiles/%s_linearize_flops.json was counted on other kernel sources: refused as stale" % PROFILE_ROUND
+    return t["flops_per_grid_point"], ("profiles/%s_linearize_flops.json: rocprofv3 --pmc SQ_INSTS_VALU_{ADD,MUL,FMA}_F64 x 64 lanes, every "
+                                       "lane slot counted, at %d grid points" % (PROFILE_ROUND, t["grid_points"]))
+
+
 def traffic_state():
     path = os.path.join(ROOT, "profiles", "%s_traffic.json" % PROFILE_ROUND)
     if not os.path.exists(path):
@@ -687,12 +704,22 @@ def main():
                              + nvm * nvm + (nvm + nfm) * 2 * nvm + nfm * nvm + (nvm + nfm)  # dIDda, dIDCdqv, dCda, IDC out
                              + 2 * (2 * nvm + nvm + nfm + 12) + 6)              # lx, la, lf, lu read-modify-write, lu_passive
             lb = per_point * batch * (len(grids) - 1)
-            sqp["linearize"] = {"ms": lin_ms, "ms_without_multiplier_terms": lin_ms0, "grid_points": batch * (len(grids) - 1),
-                                "ns_per_grid_point": lin_ms * 1e6 / (batch * (len(grids) - 1)),
-                                "roofline": {"bound": "valu_f64", "achieved": lb / (lin_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                             "frac": lb / (lin_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": lb,
-                                             "note": "instruction-bound: 13.4k fp64 VALU instructions per grid point (one wave, one lane per "
-                                                     "tangent direction), profiles/%s_rocprof_summary.txt" % PROFILE_ROUND},
+            points = batch * (len(grids) - 1)
+            fpp, fsrc = linearize_flops()
+            tf = fpp * points / (lin_ms0 * 1e-3) / 1e12 if fpp else None
+            sqp["linearize"] = {"ms": lin_ms, "ms_without_multiplier_terms": lin_ms0, "grid_points": points,
+                                "ns_per_grid_point": lin_ms * 1e6 / points,
+                                # the roof of this kernel pair is the fp64 vector unit, not HBM: executed fp64 flops per grid point
+                                # (counter pass) / time against the 78.6 TFLOP/s vector peak.  The counter pass runs the call
+                                # without the multiplier terms, so ms_without_multiplier_terms is the time it is divided by.
+                                "roofline": {"bound": "valu_f64", "achieved": tf, "peak": VALU_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                             "frac": tf / VALU_F64_PEAK_TFLOPS if tf else None, "flops_per_grid_point": fpp,
+                                             "flops_source": fsrc,
+                                             "hbm": {"algorithmic_bytes_per_launch": lb, "achieved_GBps": lb / (lin_ms * 1e-3) / 1e9,
+                                                     "frac_of_hbm_peak": lb / (lin_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                                             "note": "one wave per grid point, one lane per tangent direction behind a level-parallel "
+                                                     "values pre-pass; profiles/%s_rocprof_summary.txt has the SQ counters "
+                                                     "(VALU issue, LDS, waits)" % PROFILE_ROUND},
                                 "scope": "linearizeContactDynamics / linearizeImpactDynamics incl. the multiplier terms; NOT part of "
                                          "newton_iteration_ms, which starts from pre-condensation records; part of closed_loop_constrained_trot",
                                 "status_nonzero_instances": int((ctx.status() != 0).sum())}

@@ -18,7 +18,7 @@ _LIB = None
 
 def build(force=False):
     so = os.path.join(_HERE, "librtoc_oracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("rtoc_oracle.c", "rtoc_oracle_condense.c", "rtoc_oracle_bench.c", "rtoc_oracle_rbd.c")]
+    srcs = [os.path.join(_HERE, f) for f in ("rtoc_oracle.c", "rtoc_oracle_condense.c", "rtoc_oracle_bench.c", "rtoc_oracle_rbd.c", "rtoc_oracle_rbd_cs.c")]
     srcs += [os.path.join(_HERE, "..", "include", f) for f in ("rtoc.h", "rtoc_layout.h", "rtoc_robot.h")]
     stale = force or not os.path.exists(so) or any(
         os.path.getmtime(s) > os.path.getmtime(so) for s in srcs if os.path.exists(s))
@@ -343,6 +343,7 @@ def _rbd():
         L.orc_rbd_eval_ex.argtypes = [mp, C.c_int, dp, dp, dp, dp, dp, C.c_uint, dp, dp, dp]
         L.orc_rbd_eval_ex.restype = C.c_int
         L.orc_rbd_linearize_fd_ex.argtypes = [mp, C.c_int, dp, dp, dp, dp, dp, C.c_uint, dp, dp, C.c_double, dp, dp, dp, C.c_int]
+        L.orc_rbd_linearize_cs.argtypes = [mp, C.c_int, dp, dp, dp, dp, C.c_int, dp, C.c_int, C.c_uint, dp, dp, dp, dp, dp, C.c_int]
         L.orc_rbd_log6.argtypes = [dp, dp, dp]
         L.orc_se3_integrate.argtypes = [dp, dp, C.c_double, dp]
         L.orc_se3_difference.argtypes = [dp, dp, dp]
@@ -390,6 +391,17 @@ def rbd_linearize_fd(model, impact, q, v, a, fstack, u, active, pref, eps=1e-6, 
     D = [np.zeros((model.nv, n)) for _ in range(3)]  # column-major (n x nv) seen from C
     _rbd().orc_rbd_linearize_fd_ex(C.byref(model), int(impact), _d(q), _d(v), _d(a), _d(fstack), _d(u), int(active), _d(pref),
                                    _d(rr) if rr is not None else None, eps, _d(D[0]), _d(D[1]), _d(D[2]), n)
+    return tuple(d.T.copy() for d in D)
+
+
+def rbd_linearize_cs(model, impact, q, v, a, fstack, u, active, pref, rref=None):
+    """Complex-step derivatives of rbd_eval (rtoc_oracle_rbd_cs.c): exact to rounding, no step size.  Same return as rbd_linearize_fd."""
+    q, v, a, fstack, u, pref = _c(q), _c(v), _c(a), _c(fstack), _c(u), _c(pref)
+    rr = None if rref is None else _c(rref)
+    n = model.nv + model.active_rows(int(active))
+    D = [np.zeros((model.nv, n)) for _ in range(3)]  # column-major (n x nv) seen from C
+    _rbd().orc_rbd_linearize_cs(C.byref(model), int(impact), _d(q), _d(v), _d(a), _d(fstack), int(fstack.size), _d(u), int(u.size),
+                                int(active), _d(pref), _d(rr) if rr is not None else None, _d(D[0]), _d(D[1]), _d(D[2]), n)
     return tuple(d.T.copy() for d in D)
 
 

@@ -29,6 +29,13 @@
 
 #include "../include/rtoc_robot.h"
 
+/* Branches on a scalar: its real part / its modulus.  Identities here; the complex-step build (rtoc_oracle_rbd_cs.c compiles this
+ * file once more with complex scalars: the second witness of the derivatives) defines them as creal / cabs. */
+#ifndef ORC_RE
+#define ORC_RE(x) (x)
+#define ORC_MAG(x) fabs(x)
+#endif
+
 typedef struct { double l[3], a[3]; } sv6; /* spatial motion or force: linear, angular */
 
 static void cross3(const double* x, const double* y, double* z) {
@@ -117,10 +124,10 @@ static void inertia_mul(double mass, const double* c, const double* I, const sv6
 static void log3(const double* R, double* w) {
   const double tr = R[0] + R[4] + R[8];
   double c = 0.5 * (tr - 1.0);
-  c = c > 1.0 ? 1.0 : (c < -1.0 ? -1.0 : c);
+  c = ORC_RE(c) > 1.0 ? 1.0 : (ORC_RE(c) < -1.0 ? -1.0 : c);
   const double th = acos(c);
   const double vx = R[7] - R[5], vy = R[2] - R[6], vz = R[3] - R[1]; /* vee(R - R^T) */
-  const double k = th < 1e-6 ? 0.5 + th * th / 12.0 : th / (2.0 * sin(th));
+  const double k = ORC_MAG(th) < 1e-6 ? 0.5 + th * th / 12.0 : th / (2.0 * sin(th));
   w[0] = k * vx, w[1] = k * vy, w[2] = k * vz;
 }
 /* pinocchio::log6 of (R, p): [V^-1 p; log3 R] with V^-1 p = p - w x p / 2 + beta w x (w x p),
@@ -129,7 +136,7 @@ void orc_rbd_log6(const double* R, const double* p, double* xi) {
   double w[3], wxp[3], wxwxp[3];
   log3(R, w);
   const double t = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
-  const double beta = t < 1e-4 ? 1.0 / 12.0 + t * t / 720.0 : 1.0 / (t * t) - sin(t) / (2.0 * t * (1.0 - cos(t)));
+  const double beta = ORC_MAG(t) < 1e-4 ? 1.0 / 12.0 + t * t / 720.0 : 1.0 / (t * t) - sin(t) / (2.0 * t * (1.0 - cos(t)));
   cross3(w, p, wxp);
   cross3(w, wxp, wxwxp);
   for (int k = 0; k < 3; ++k) xi[k] = p[k] - 0.5 * wxp[k] + beta * wxwxp[k], xi[3 + k] = w[k];
@@ -140,9 +147,9 @@ void orc_rbd_exp6(const double* xi, double* R, double* p) {
   const double* w = xi + 3;
   const double th = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
   double A, B, ax[3] = {1, 0, 0}, wxv[3], wxwxv[3];
-  if (th > 0.0)
+  if (ORC_MAG(th) > 0.0)
     for (int k = 0; k < 3; ++k) ax[k] = w[k] / th;
-  if (th < 1e-8) {
+  if (ORC_MAG(th) < 1e-8) {
     A = 0.5, B = 1.0 / 6.0;
   } else {
     A = (1.0 - cos(th)) / (th * th), B = (th - sin(th)) / (th * th * th);
@@ -235,7 +242,7 @@ void orc_se3_integrate(const double* q7, const double* v6, double scale, double*
   for (int c = 0; c < 3; ++c) vl[c] = scale * v6[c], w[c] = scale * v6[3 + c];
   const double th = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
   double A, B;
-  if (th < 1e-8) {
+  if (ORC_MAG(th) < 1e-8) {
     A = 0.5, B = 1.0 / 6.0;
   } else {
     A = (1.0 - cos(th)) / (th * th), B = (th - sin(th)) / (th * th * th);
@@ -245,7 +252,7 @@ void orc_se3_integrate(const double* q7, const double* v6, double scale, double*
   for (int c = 0; c < 3; ++c) Vv[c] = vl[c] + A * wxv[c] + B * wxwxv[c];
   quat_to_R(q7 + 3, R);
   mat3_vec(R, Vv, t);
-  const double s = th < 1e-8 ? 0.5 - th * th / 48.0 : sin(0.5 * th) / th, cw = cos(0.5 * th);
+  const double s = ORC_MAG(th) < 1e-8 ? 0.5 - th * th / 48.0 : sin(0.5 * th) / th, cw = cos(0.5 * th);
   const double e[4] = {s * w[0], s * w[1], s * w[2], cw};
   const double a[4] = {q7[3], q7[4], q7[5], q7[6]};
   double r[4];

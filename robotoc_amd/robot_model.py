@@ -106,6 +106,11 @@ def load_named(name):
     return load(os.path.join(MODEL_DIR, name + ".json"))
 
 
+def joint_names(name):
+    """names of the moving joints of a bundled table, in its order (the root joint of a floating base first, as Pinocchio names it)"""
+    return [j["name"] for j in json.load(open(os.path.join(MODEL_DIR, name + ".json")))["joints"]]
+
+
 def random_configuration(model, rng, scale=1.0):
     """q on the manifold (unit quaternion for a free-flyer root), v, a"""
     q = scale * rng.uniform(-1.0, 1.0, model.nq)
