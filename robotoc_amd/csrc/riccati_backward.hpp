@@ -34,6 +34,7 @@
 #pragma once
 #include "device_utils.hpp"
 #include "../../include/rtoc.h"
+#include "riccati_scan_sto.hpp"   // sto_prep_body: rides in the one-stage launch of riccati_backward_kernel
 
 namespace rtoc {
 
@@ -73,6 +74,10 @@ struct BwdArgs {
   const double* scan_ps;
   int scan_ps_stride;
   int scan_ps_soff;  // offset of s inside a value record
+  // Scan on a grid with switching-time optimisation (riccati_scan_sto.hpp): workgroups (b, nstages + st) of the same launch prepare
+  // the bundle of grid point st for the serial vector pass -- they read what the policy workgroups read (the scan's value records,
+  // the KKT records), none of their output, so they need neither a launch nor an event of their own.  nullptr: no such workgroups.
+  double* sto_scr;   // [batch][nstages][scan::StoScratch::STRIDE]
 };
 
 template <int NV, int NU, int NS, int NW>
@@ -382,7 +387,16 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
   // horizon-scan mode: this workgroup handles grid point blockIdx.y only (no sto grids in this mode)
   const bool one_stage = a.scan_ps != nullptr;
   const int my_stage = one_stage ? (int)blockIdx.y : N;
-  if (one_stage && my_stage > N) return;
+  if (one_stage && my_stage > N) {
+    const int st = my_stage - a.nstages;   // grid point whose bundle this workgroup prepares
+    if (a.sto_scr && st < N) {
+      const size_t rec = (size_t)b * a.nstages + st;
+      const unsigned ps = scan::sto_prep_body<NV, NU, NS, NT>(a.grid[st], a.kkt + rec * KL.stride, a.scan_ps + (rec + 1) * (size_t)a.scan_ps_stride,
+                                                            a.sto_scr + rec * scan::StoScratch<NV, NU, NS>::STRIDE, smem, tid0);
+      if (ps && tid0 == 0) atomicOr(&a.status[b], ps);
+    }
+    return;
+  }
   int st_first = N - 1, st_last = 0;
   if (one_stage && my_stage < N) {
     st_first = st_last = my_stage;

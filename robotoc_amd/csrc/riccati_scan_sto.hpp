@@ -7,8 +7,9 @@
 // half -- s, k, m and the STO quantities Psi, Phi, psi_x, psi_u, phi_x, phi_u, T, W, mt, mt_next, xi, chi, rho, eta, iota, the
 // STOPolicy of every transition -- is NOT a composition of fixed affine maps: sgm = xi - 2 chi + rho is regularised by a
 // data-dependent branch (:159-162) and divides the update of s and Phi (:168-175).  It is a chain of O(nx^2) mat-vecs per grid
-// point once the matrices are there, run serially by ONE wavefront per instance (sto_vector_body), after a stage-parallel
-// preparation (sto_prep_body) has taken everything off the chain that does not depend on it:
+// point once the matrices are there, run serially by ONE workgroup per instance (sto_vector_body), after a stage-parallel
+// preparation (sto_prep_body: extra workgroups of the policy kernel's launch) has taken everything off the chain that does not
+// depend on it:
 //   P+ Fx, P+ fx, and the inverse of G = Quu + Bv^T P+[v,v] Bv:
 //     no switching constraint:  Ginv = Y^T Y, Y = L^-1 (L L^T = G);  k = -Ginv lu' is ONE product on the chain (the reference's
 //     llt.solve is two dependent triangular ones; same conditioning)

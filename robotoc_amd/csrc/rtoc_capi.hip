@@ -166,8 +166,6 @@ struct rtoc_ctx {
   int bwd_variant;
   hipEvent_t ev0, ev1;
   hipStream_t stream2;  // forward half of the pipelined sweep
-  hipStream_t stream3;  // preparation of the vector pass of the scan with STO, next to the policy kernel
-  hipEvent_t ev_sto_fork, ev_sto_join;
   hipEvent_t ev_fork, ev_join, ev_chunk[RTOC_MAX_CHUNK_EVENTS];
   int sweep_chunks;
   int condense_split;  // 1: MJtJinv in its own kernel ahead of the condensation
@@ -297,9 +295,6 @@ static int create_members(rtoc_ctx* c, const rtoc_dims* dims, const KernelSet* k
   HIP_TRY(hipEventCreate(&c->ev0));
   HIP_TRY(hipEventCreate(&c->ev1));
   HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-  HIP_TRY(hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));
-  HIP_TRY(hipEventCreateWithFlags(&c->ev_sto_fork, hipEventDisableTiming));
-  HIP_TRY(hipEventCreateWithFlags(&c->ev_sto_join, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   for (int i = 0; i < RTOC_MAX_CHUNK_EVENTS; ++i)
@@ -429,9 +424,6 @@ int rtoc_destroy(rtoc_ctx* c) {
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
-  if (c->stream3) (void)hipStreamDestroy(c->stream3);
-  if (c->ev_sto_fork) (void)hipEventDestroy(c->ev_sto_fork);
-  if (c->ev_sto_join) (void)hipEventDestroy(c->ev_sto_join);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   for (int i = 0; i < RTOC_MAX_CHUNK_EVENTS; ++i)
@@ -838,22 +830,18 @@ static int launch_backward_scan(rtoc_ctx* c, int first, int end, hipStream_t str
   const int v = ks->scan_policy_variant;
   const bool sto = grid_has_sto(c);
   StoScanArgs t;
-  if (sto) {   // everything of the vector recursion that does not depend on the chain, next to the policies
+  // Grids with switching-time optimisation: the bundles of the vector pass (everything of the vector recursion that does not depend
+  // on the chain) are prepared by n - 1 more workgroups per instance of the SAME launch -- unless the policy workgroups write the
+  // mutated Quu, lu back into the KKT records (RTOC_OPT_WRITEBACK_KKT), which the preparation reads: then it runs first, by itself.
+  const bool ride = sto && !c->writeback && ks->sto_prep_lds <= ks->bwd_lds[v];
+  if (sto) {
     t.kkt = c->buf[RTOC_BUF_KKT], t.ric = c->buf[RTOC_BUF_RIC], t.grid = c->d_grid, t.status = c->d_status;
     t.ps = c->d_scan[2], t.scr = c->d_scan_sto;
     t.nstages = n, t.batch = end, t.first = first, t.max_dts0 = c->max_dts0, t.prof = c->d_prof;
-    // Next to the policy kernel on its own stream: both read the scan's value records, neither the other's output -- unless
-    // the policy kernel writes the mutated Quu, lu back into the KKT records (RTOC_OPT_WRITEBACK_KKT), which this one reads.
-    hipStream_t ps = c->writeback ? stream : c->stream3;
-    if (!c->writeback) {
-      HIP_TRY(hipEventRecord(c->ev_sto_fork, stream));
-      HIP_TRY(hipStreamWaitEvent(ps, c->ev_sto_fork, 0));
-    }
-    hipLaunchKernelGGL(ks->sto_prep, dim3(n - 1, nb), dim3(SCAN_STO_PREP_NT), ks->sto_prep_lds, ps, t);
-    if (!c->writeback) HIP_TRY(hipEventRecord(c->ev_sto_join, ps));
+    if (!ride) hipLaunchKernelGGL(ks->sto_prep, dim3(n - 1, nb), dim3(SCAN_STO_PREP_NT), ks->sto_prep_lds, stream, t);
   }
-  hipLaunchKernelGGL(ks->bwd[v], dim3(nb, n), dim3(64 * ks->bwd_waves[v]), ks->bwd_lds[v], stream, a);
-  if (sto && !c->writeback) HIP_TRY(hipStreamWaitEvent(stream, c->ev_sto_join, 0));
+  a.sto_scr = ride ? c->d_scan_sto : nullptr;
+  hipLaunchKernelGGL(ks->bwd[v], dim3(nb, ride ? 2 * n - 1 : n), dim3(64 * ks->bwd_waves[v]), ks->bwd_lds[v], stream, a);
   if (sto) hipLaunchKernelGGL(ks->sto_vec, dim3(nb), dim3(ks->sto_vec_threads), ks->sto_vec_lds, stream, t);   // s, k, m, the STO quantities
   HIP_TRY(hipGetLastError());
   return RTOC_OK;

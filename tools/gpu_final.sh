@@ -6,7 +6,7 @@
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out
-TAG=${1:-r02}
+TAG=${1:-r03}
 mkdir -p $OUT
 cd $R
 SKIP_PMC=1 bash tools/gpu_round2.sh > $OUT/round.log 2>&1
@@ -15,6 +15,12 @@ python -c "import __graft_entry__ as g; g.smoke(); print(\"smoke ok\")" 2>&1 | t
 bash tools/gpu_pmc2.sh > $OUT/pmc2.log 2>&1
 bash tools/gpu_closed_loop_prof.sh > $OUT/closed_loop.log 2>&1
 mkdir -p $OUT/summary
+bash tools/gpu_pmc_lin_flops.sh $TAG 1024 > $OUT/lin_flops.log 2>&1
+# kernel statistics of the single-instance scan on the grid with switching-time optimisation (ANYmal jump_sto), and its phase stamps
+( export TMPDIR=/tmp; cd /tmp; timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_sto -o sto -- python $R/tools/scan_sto_latency.py > $OUT/scan_sto_latency.txt 2>&1 )
+{ cat $OUT/scan_sto_latency.txt | grep "bwd/fwd"; echo; echo "kernel, calls, total ns, avg ns, %, min, max, stddev"; grep -i "sto\|riccati_backward\|scan_" $(find $OUT/prof_sto -name "*kernel_stats.csv" | head -1); } > $OUT/summary/${TAG}_scan_sto_kernel_stats.txt 2>/dev/null
+if [ -f $R/robotoc_amd/librtoc_hip_prof.so ]; then RTOC_HIP_LIB=$R/robotoc_amd/librtoc_hip_prof.so timeout 100 python tools/phase_profile_sto.py >> $OUT/summary/${TAG}_scan_sto_kernel_stats.txt 2>&1; fi
+rm -rf $OUT/prof_sto
 RTOC_PROFILE_OUT=$OUT/summary python tools/summarize_profiles.py $TAG "closing run of the round" > $OUT/summarize.log 2>&1
 cp $OUT/closed_loop_kernel_stats.txt $OUT/summary/${TAG}_closed_loop_kernel_stats.txt
 cp $OUT/host_cpu.txt $OUT/summary/${TAG}_host_cpu.txt 2>/dev/null
