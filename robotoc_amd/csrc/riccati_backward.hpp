@@ -176,8 +176,8 @@ __device__ __forceinline__ void pre_load(PreBuf<PreCnt<NT, N2>::value>& buf, con
 #pragma unroll
   for (int k = 0; k < PreCnt<NT, N2>::value; ++k) {
     const int e = tid + k * NT;
-    if (e < N2) v[k] = s2[e];
-  }
+    v[k] = s2[e < N2 ? e : N2 - 1];   // unconditional (clamped): a branch around a load makes the compiler wait for ALL outstanding
+  }                                   // loads at the next use of any loaded register (pre_store never stores the clamped ones)
 }
 
 template <int NT, int ROWS, int COLS>
@@ -185,11 +185,13 @@ __device__ __forceinline__ void pre_load_mat(PreBuf<MatMap<NT, ROWS>::passes(COL
                                              const double* __restrict__ src, int tid) {
   using M = MatMap<NT, ROWS>;
   const int r2 = tid % M::CPL, c0 = tid / M::CPL;
-  const d2* s2 = reinterpret_cast<const d2*>(src) + r2 + c0 * M::CPL;
+  const d2* s2 = reinterpret_cast<const d2*>(src);
   const bool act = c0 < M::CPP;
 #pragma unroll
-  for (int k = 0; k < M::passes(COLS); ++k)
-    if (act && (k * M::CPP + c0 < COLS)) buf.v[k] = s2[k * M::CPP * M::CPL];
+  for (int k = 0; k < M::passes(COLS); ++k) {   // unconditional, clamped to the first entry (see pre_load)
+    const bool ok = act && (k * M::CPP + c0 < COLS);
+    buf.v[k] = s2[ok ? r2 + c0 * M::CPL + k * M::CPP * M::CPL : 0];
+  }
 }
 
 template <int NT, int ROWS, int COLS, int LD>
@@ -280,49 +282,71 @@ __device__ __forceinline__ bool wave_llt(const double* __restrict__ A, double* _
 // entry k", with the same broadcast scalars L[k][j], so ONE instruction stream serves both -- the
 // inverse factor costs no instructions beyond the Cholesky's own.
 // Writes L / 1/diag like wave_llt and Y column-major (ld NMAX) to Ydst.  Returns true on failure.
-template <int NMAX, int LD, int YOFF = 16>
-__device__ __forceinline__ bool wave_llt_inv(const double* __restrict__ A, double* __restrict__ Ldst,
-                                             double* __restrict__ linv, double* __restrict__ Ydst,
-                                             int n, int lane) {
+// The same in three parts, so that a wave can run the column steps in the gaps its other work leaves (the tile-split kernel gives
+// the first columns to a wave that would otherwise wait at the barrier behind P+ A): the state -- row lane's entries of G / L, or
+// one column of Y -- stays in registers between the calls.
+template <int NMAX>
+struct LltInvState {
+  double g[NMAX];
+  bool bad;
+};
+template <int NMAX, int LD, int YOFF>
+__device__ __forceinline__ void llt_inv_load(LltInvState<NMAX>& s, const double* __restrict__ A, int n, int lane) {
   // rows in lanes [0, YOFF), columns of Y in lanes [YOFF, 2*YOFF): YOFF = 16 (n <= 16) or 32 (n <= 32)
   static_assert(NMAX <= YOFF && 2 * YOFF <= 64, "rows of G and columns of Y share one wave");
-  double g[NMAX];
   const int li = lane < n ? lane : 0;
   const bool ylane = lane >= YOFF;
 #pragma unroll
   for (int k = 0; k < NMAX; ++k) {
     const double a = (k < n) ? A[li + k * LD] : 0.0;
-    g[k] = ylane ? ((k == lane - YOFF) ? 1.0 : 0.0) : a;
+    s.g[k] = ylane ? ((k == lane - YOFF) ? 1.0 : 0.0) : a;
   }
-  bool bad = false;
+  s.bad = false;
+}
+template <int NMAX, int J0, int J1>
+__device__ __forceinline__ void llt_inv_steps(LltInvState<NMAX>& s, double* __restrict__ linv, int n, int lane) {
 #pragma unroll
-  for (int j = 0; j < NMAX; ++j) {
+  for (int j = J0; j < J1; ++j) {
     if (j < n) {
-      const double d = readlane_d(g[j], j);
-      if (!(d > 0.0)) bad = true;
+      const double d = readlane_d(s.g[j], j);
+      if (!(d > 0.0)) s.bad = true;
       const double inv = rsqrt_d(d);
-      const double xj = g[j] * inv;  // L[lane][j] | Y[j][lane-YOFF]
-      g[j] = xj;
+      const double xj = s.g[j] * inv;  // L[lane][j] | Y[j][lane-YOFF]
+      s.g[j] = xj;
       if (lane == j) linv[j] = inv;
 #pragma unroll
       for (int k = j + 1; k < NMAX; ++k) {
         if (k < n) {
           const double lkj = readlane_d(xj, k);
-          g[k] -= xj * lkj;
+          s.g[k] -= xj * lkj;
         }
       }
     }
   }
+}
+template <int NMAX, int LD, int YOFF>
+__device__ __forceinline__ bool llt_inv_store(const LltInvState<NMAX>& s, double* __restrict__ Ldst, double* __restrict__ Ydst, int n,
+                                              int lane) {
+  const bool ylane = lane >= YOFF;
   if (lane < n) {
 #pragma unroll
     for (int k = 0; k < NMAX; ++k)
-      if (k < n) Ldst[lane + k * LD] = (k <= lane) ? g[k] : 0.0;
+      if (k < n) Ldst[lane + k * LD] = (k <= lane) ? s.g[k] : 0.0;
   } else if (ylane && lane < YOFF + NMAX) {
     const int c = lane - YOFF;
 #pragma unroll
-    for (int k = 0; k < NMAX; ++k) Ydst[k + c * NMAX] = (c < n && k < n) ? g[k] : 0.0;
+    for (int k = 0; k < NMAX; ++k) Ydst[k + c * NMAX] = (c < n && k < n) ? s.g[k] : 0.0;
   }
-  return bad;
+  return s.bad;
+}
+template <int NMAX, int LD, int YOFF = 16>
+__device__ __forceinline__ bool wave_llt_inv(const double* __restrict__ A, double* __restrict__ Ldst,
+                                             double* __restrict__ linv, double* __restrict__ Ydst,
+                                             int n, int lane) {
+  LltInvState<NMAX> s;
+  llt_inv_load<NMAX, LD, YOFF>(s, A, n, lane);
+  llt_inv_steps<NMAX, 0, NMAX>(s, linv, n, lane);
+  return llt_inv_store<NMAX, LD, YOFF>(s, Ldst, Ydst, n, lane);
 }
 
 // x <- (L L^T)^-1 x for one right-hand side held in registers (x[NMAX]); L in LDS.
@@ -420,26 +444,29 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
 
   // prefetch registers (next stage's record, loaded one stage ahead)
   constexpr int N2B = (NV * NU + 1) / 2, N2G = (NU * NU + 1) / 2;
-  PreBuf<MatMap<NT, NX>::passes(NX)> preA, preQ;
-  PreBuf<MatMap<NT, NX>::passes(NU)> preH;
-  PreBuf<PreCnt<NT, N2B>::value> preB;
-  PreBuf<PreCnt<NT, N2G>::value> preG;
+  // Who prefetches (PW0 = first prefetching wave, PT threads, ptid = index among them): every wave.  The 84 KB of an iCub record
+  // arrive at the ~11 B/clk a CU gets when all CUs burst at once, and the issuing waves stall for those ~6k cycles (the queues
+  // fill).  Leaving wave 0 -- which owns two of the five column tiles of nv = 35 and is the critical wave of every interval -- out
+  // of it (PW0 = 1) was measured: 5.82 -> 6.19 ms per 1024 instances; three waves take longer over the same bytes than wave 0 saves.
+  constexpr int PW0 = 0, PT = NT - 64 * PW0;
+  const int ptid = tid0 - 64 * PW0;
+  PreBuf<MatMap<PT, NX>::passes(NX)> preA;
+  PreBuf<MatMap<PT, NX>::passes(NU)> preH;
+  PreBuf<PreCnt<PT, N2B>::value> preB;
+  PreBuf<PreCnt<PT, N2G>::value> preG;
   double preFx = 0.0, preLx = 0.0, preLu = 0.0;
   auto issue_loads = [&](int stage) {
     const double* kp = a.kkt + kinst + (size_t)stage * KL.stride;
     const bool imp = a.grid[stage].type == RTOC_GRID_IMPACT;
-    pre_load_mat<NT, NX, NX>(preA, kp + KL.off[RTOC_KKT_FXX], tid);
-    pre_load_mat<NT, NX, NX>(preQ, kp + KL.off[RTOC_KKT_QXX], tid);
-    if (!imp) {
-      pre_load_mat<NT, NX, NU>(preH, kp + KL.off[RTOC_KKT_QXU], tid);
-      pre_load<NT, N2B>(preB, kp + KL.off[RTOC_KKT_FVU], tid);
-      pre_load<NT, N2G>(preG, kp + KL.off[RTOC_KKT_QUU], tid);
-    }
-    if (tid < NX) {
-      preFx = kp[KL.off[RTOC_KKT_FX] + tid];
-      preLx = kp[KL.off[RTOC_KKT_LX] + tid];
-    }
-    if (!imp && tid < NU) preLu = kp[KL.off[RTOC_KKT_LU] + tid];
+    (void)imp;   // every load is issued on every grid point (an impact record has the fields too; they are not stored to LDS there):
+    if (ptid < 0) return;   // wave-uniform
+    pre_load_mat<PT, NX, NX>(preA, kp + KL.off[RTOC_KKT_FXX], ptid);   // no branch between the loads, so the compiler counts them
+    pre_load_mat<PT, NX, NU>(preH, kp + KL.off[RTOC_KKT_QXU], ptid);
+    pre_load<PT, N2B>(preB, kp + KL.off[RTOC_KKT_FVU], ptid);
+    pre_load<PT, N2G>(preG, kp + KL.off[RTOC_KKT_QUU], ptid);
+    preFx = kp[KL.off[RTOC_KKT_FX] + (ptid < NX ? ptid : 0)];
+    preLx = kp[KL.off[RTOC_KKT_LX] + (ptid < NX ? ptid : 0)];
+    preLu = kp[KL.off[RTOC_KKT_LU] + (ptid < NU ? ptid : 0)];
   };
   if (one_stage && my_stage == N) return;  // the terminal record is written, nothing else to do
   if (N >= 1) issue_loads(st_first);
@@ -484,22 +511,23 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
 #undef RTOC_GRID_PREV_STO
     RTOC_PROF(1);
     // ---- stage data: prefetched registers -> LDS (the HBM loads were issued one stage ahead) ----
-    pre_store_mat<NT, NX, NX, LDP>(sA, preA, tid);
-    if (!impact) {
-      pre_store_ld<NT, N2B, NV, C::LDB>(sBv, preB, tid);
-      pre_store_mat<NT, NX, NU, LDP>(sH, preH, tid);
-      pre_store_flat<NT, N2G>(sG, preG, tid);
+    if (ptid >= 0) {
+      pre_store_mat<PT, NX, NX, LDP>(sA, preA, ptid);
+      if (!impact) {
+        pre_store_ld<PT, N2B, NV, C::LDB>(sBv, preB, ptid);
+        pre_store_mat<PT, NX, NU, LDP>(sH, preH, ptid);
+        pre_store_flat<PT, N2G>(sG, preG, ptid);
+      }
+      if (ptid < NX) smem[C::V_FX + ptid] = preFx, smem[C::V_LX + ptid] = preLx;
+      if (!impact && ptid < NU) smem[C::V_LU + ptid] = preLu;
     }
     if (tid < NX) {
-      smem[C::V_FX + tid] = preFx;
-      smem[C::V_LX + tid] = preLx;
       if (sto) {
         smem[C::V_FFX + tid] = kr[KL.off[RTOC_KKT_FFX] + tid];
         smem[C::V_HX + tid] = kr[KL.off[RTOC_KKT_HX] + tid];
       }
     }
     if (!impact && tid < NU) {
-      smem[C::V_LU + tid] = preLu;
       if (sto) smem[C::V_HU + tid] = kr[KL.off[RTOC_KKT_HU] + tid];
     }
     if (sto && tid < 8) smem[C::V_KSC + tid] = kr[KL.off[RTOC_KKT_SCAL] + tid];
@@ -541,7 +569,7 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
         for (int c = 0; c < CNT; ++c)
 #pragma unroll
           for (int t = 0; t < TNU; ++t) acc[c][t] = zero4();
-        const double* pa_ = sP + (wave * 16 + li) + (NV + q) * LDP;  // P+[i][NV+k]
+        const double* pa_ = sP + (NV + q) + (wave * 16 + li) * LDP;  // P+[NV+k][i] = P+[i][NV+k]: k contiguous, conflict-free
         const double* pb_ = sBv + q + li * C::LDB;                    // Bv[k][u]
 #pragma unroll
         for (int ks = 0; ks < (NV + 3) / 4; ++ks) {
@@ -554,7 +582,7 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
           }
 #pragma unroll
           for (int c = 0; c < CNT; ++c) {
-            const double v = pa_[c * NW * 16 + ks * 4 * LDP];
+            const double v = pa_[c * NW * 16 * LDP + ks * 4];
             const double av = (kok && ((wave + c * NW) * 16 + li < NX)) ? v : 0.0;
 #pragma unroll
             for (int t = 0; t < TNU; ++t) acc[c][t] = mfma16(av, bv[t], acc[c][t]);
@@ -648,12 +676,12 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
           const int i = tm * 16 + li;
           double v;
           if (tm * 16 + 15 < NX) {
-            v = sP[li + q * LDP + tm * 16 + ks * 4 * LDP];  // P+[i][k]
+            v = sP[q + ks * 4 + (li + tm * 16) * LDP];  // P+[k][i] = P+[i][k]: k contiguous, conflict-free (riccati_backward_rs.hpp)
           } else if (tm * 16 >= NX) {
             v = sPB[q + li * LDP + (tm * 16 - NX) * LDP + ks * 4];  // PB[k][i-NX]
             if (tm * 16 + 15 >= NX + NU) v = (i < NX + NU) ? v : 0.0;
           } else {
-            const double vp = sP[li + q * LDP + tm * 16 + ks * 4 * LDP];
+            const double vp = sP[q + ks * 4 + (li + tm * 16) * LDP];
             const double vb = sPB[q + li * LDP + (tm * 16 - NX) * LDP + ks * 4];
             v = (i < NX) ? vp : vb;
             if (tm * 16 + 15 >= NX + NU) v = (i < NX + NU) ? v : 0.0;
@@ -665,10 +693,14 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
           const double v = pb_[ks * 4 + c * NW * 16 * LDP];
           bv[c] = (kok && ((wave + c * NW) * 16 + li < NX)) ? v : 0.0;
         }
+        // a wave whose second column tile lies beyond the matrix (TNX tiles over NW waves: iCub nv = 35 has 5 over 4) skips its
+        // products instead of multiplying zeros -- it is the wave that takes the Cholesky below in the time this leaves
 #pragma unroll
-        for (int tm = 0; tm < TMA; ++tm)
+        for (int c = 0; c < CNT; ++c)
+          if (c == 0 || wave + c * NW < TNX) {
 #pragma unroll
-          for (int c = 0; c < CNT; ++c) pa[tm][c] = mfma16(av[tm], bv[c], pa[tm][c]);
+            for (int tm = 0; tm < TMA; ++tm) pa[tm][c] = mfma16(av[tm], bv[c], pa[tm][c]);
+          }
       }
     }
     // H += (A^T PB)  : rows >= NX of PAa hold (H - Qxu)^T
@@ -688,6 +720,38 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
     }
 
     RTOC_PROF(4);
+    // Qxx of THIS stage straight from HBM into the accumulators of the F product, in the MFMA C layout (row i = q + 4r of the
+    // owned row tile, column j = lane & 15 of tile t): no prefetch registers, no LDS staging, no barriers -- the loads fly while
+    // w = A^T z and the Cholesky run.  The four r of a lane read the same 128-byte line of column j.
+    d4 f[CNT][TNX];
+    {
+      const double* qx_ = kr + KL.off[RTOC_KKT_QXX] + (wave * 16 + q) + li * NX;   // Qxx[i][j]
+#pragma unroll
+      for (int c = 0; c < CNT; ++c)
+#pragma unroll
+        for (int t = 0; t < TNX; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = (wave + c * NW) * 16 + drow(q, r), j = t * 16 + li;
+            const bool ok = i < NX && j < NX;
+            const double v = qx_[ok ? (c * NW * 16 + 4 * r + t * 16 * NX) : 0];
+            f[c][t][r] = ok ? v : 0.0;
+          }
+    }
+    // ---- LLT(G) (riccati_factorizer.cpp:49) by the LAST wave, right behind its P+ A tiles: there is no barrier between P+ A and
+    //      the end of the F chain, and the last wave owns the fewest column tiles (iCub nv = 35: one of five, wave 0 two) and no
+    //      rows of w = A^T z -- 19k cycles of dependent VALU / readlane work that used to sit on wave 0 on top of its two tiles ----
+    RTOC_PROF(13);
+    if (!impact && wave == NW - 1) {
+      if constexpr (NU <= 32) {
+        // with the inverse factor Y = L^-1 in the same instruction stream (dead Bv buffer): the
+        // triangular solves of the policy become MFMA products below
+        if (wave_llt_inv<NU, NU, 32>(sG, sL, smem + C::V_LINV, sBv, NU, lane)) stat |= RTOC_STAT_QUU_NOT_SPD;
+      } else {
+        if (wave_llt<NU, NU>(sG, sL, smem + C::V_LINV, NU, lane)) stat |= RTOC_STAT_QUU_NOT_SPD;
+      }
+    }
+    RTOC_PROF(14);
     // ---- s-vector part that needs A: w = A^T z  (and STO: psi_x, phi_x) ----
     if (tid < NX) {
       double acc = 0.0, ap = 0.0, aph = 0.0;
@@ -733,36 +797,8 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
 
     RTOC_PROF(5);
     // ---- F = Qxx + AtP A, chained: A-operand = PAa registers (row-tile = owned column tile) ----
-    d4 f[CNT][TNX];
     {
-      // Qxx (prefetched, coalesced) -> sP staging (P+ is dead: every wave finished PAa) -> MFMA C layout
-      __syncthreads();
-      pre_store_mat<NT, NX, NX, LDP>(sP, preQ, tid);
-      __syncthreads();
-      const double* pq_ = sP + (wave * 16 + q) + li * LDP;
-#pragma unroll
-      for (int c = 0; c < CNT; ++c)
-#pragma unroll
-        for (int t = 0; t < TNX; ++t)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int i = (wave + c * NW) * 16 + drow(q, r), j = t * 16 + li;
-            const double v = pq_[c * NW * 16 + 4 * r + t * 16 * LDP];
-            f[c][t][r] = (i < NX && j < NX) ? v : 0.0;
-          }
-      // next stage's record: HBM -> registers, in flight for the rest of this stage
-      if (st > st_last) issue_loads(st - 1);
-      // ---- LLT(G) by wave 0 (riccati_factorizer.cpp:49): VALU / shuffle work issued next to the
-      //      independent F-chain MFMAs below so that the two pipes overlap ----
-      if (!impact && wave == 0) {
-        if constexpr (NU <= 32) {
-          // with the inverse factor Y = L^-1 in the same instruction stream (dead Bv buffer): the
-          // triangular solves of the policy become MFMA products below
-          if (wave_llt_inv<NU, NU, 32>(sG, sL, smem + C::V_LINV, sBv, NU, lane)) stat |= RTOC_STAT_QUU_NOT_SPD;
-        } else {
-          if (wave_llt<NU, NU>(sG, sL, smem + C::V_LINV, NU, lane)) stat |= RTOC_STAT_QUU_NOT_SPD;
-        }
-      }
+      // (f holds Qxx of this stage since the top of interval 4: straight from HBM in the MFMA C layout)
       const double* pbf_ = sA + q + li * LDP;  // A[k][j]
 #pragma unroll
       for (int tm = 0; tm < TMA; ++tm)
@@ -777,16 +813,23 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
               bv[t] = (kok && (t * 16 + li < NX)) ? v : 0.0;
             }
 #pragma unroll
-            for (int c = 0; c < CNT; ++c) {
-              const double av = kok ? pa[tm][c][r] : 0.0;
+            for (int c = 0; c < CNT; ++c)
+              if (c == 0 || wave + c * NW < TNX) {
+                const double av = kok ? pa[tm][c][r] : 0.0;
 #pragma unroll
-              for (int t = 0; t < TNX; ++t) f[c][t] = mfma16(av, bv[t], f[c][t]);
-            }
+                for (int t = 0; t < TNX; ++t) f[c][t] = mfma16(av, bv[t], f[c][t]);
+              }
           }
         }
     }
     RTOC_PROF(6);
     __syncthreads();  // L published; sA / sPB no longer read by MFMA after this point
+    // next stage's record: HBM -> registers, in flight for the rest of this stage (policy solve, K^T G K, symmetrisation, copy-out:
+    // several memory latencies).  Issued here rather than ahead of the F chain: its ~100 registers are not live next to the
+    // accumulators of P+ A and F, and the loads of Qxx into F above are the only ones in flight when F is first used.
+    RTOC_PROF(15);
+    if (st > st_last) issue_loads(st - 1);
+    RTOC_PROF(16);
 
     if (impact) {
       // riccati_factorizer.cpp:178-197 -- no policy

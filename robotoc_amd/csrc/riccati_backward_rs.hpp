@@ -131,18 +131,14 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a, const
     if constexpr (!MW) {
       const int v_ = tid - 64;
       const double* kp = a.kkt + kinst + (size_t)stage * KL.stride;
-      const bool imp = a.grid[stage].type == RTOC_GRID_IMPACT;
+      // every load on every grid point, unconditionally (riccati_backward.hpp: issue_loads): no branch between the loads
       pre_load_mat<64, NX, NX>(preA, kp + KL.off[RTOC_KKT_FXX], v_);
-      if (!imp) {
-        pre_load_mat<64, NX, NU>(preH, kp + KL.off[RTOC_KKT_QXU], v_);
-        pre_load<64, N2B>(preB, kp + KL.off[RTOC_KKT_FVU], v_);
-        pre_load<64, N2G>(preG, kp + KL.off[RTOC_KKT_QUU], v_);
-      }
-      if (v_ < NX) {
-        preFx = kp[KL.off[RTOC_KKT_FX] + v_];
-        preLx = kp[KL.off[RTOC_KKT_LX] + v_];
-      }
-      if (!imp && v_ < NU) preLu = kp[KL.off[RTOC_KKT_LU] + v_];
+      pre_load_mat<64, NX, NU>(preH, kp + KL.off[RTOC_KKT_QXU], v_);
+      pre_load<64, N2B>(preB, kp + KL.off[RTOC_KKT_FVU], v_);
+      pre_load<64, N2G>(preG, kp + KL.off[RTOC_KKT_QUU], v_);
+      preFx = kp[KL.off[RTOC_KKT_FX] + (v_ < NX ? v_ : 0)];
+      preLx = kp[KL.off[RTOC_KKT_LX] + (v_ < NX ? v_ : 0)];
+      preLu = kp[KL.off[RTOC_KKT_LU] + (v_ < NU ? v_ : 0)];
     }
   };
   if (N >= 1) issue_loads(N - 1);
@@ -279,7 +275,10 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a, const
         d4 acc[CNT];
 #pragma unroll
         for (int c = 0; c < CNT; ++c) acc[c] = zero4();
-        const double* pa_ = sP + li + (NV + q) * LDP;
+        // P+ is exactly symmetric: its A-operand fragments are read TRANSPOSED (k contiguous, row li strided by LDP) -- with
+        // LDP = 2 mod 4 the sixteen rows of a half-wave land 12 words apart (an odd multiple of 4 words: all 64 banks once), whereas
+        // li contiguous / k strided puts the two k-columns of a half-wave 12 words apart on top of each other (2-way conflicts)
+        const double* pa_ = sP + (NV + q) + li * LDP;
         const double* pb_ = sBv + q + li * NV;
         // The C layout of PB (row i = q + 4r + 16c, column u = lane & 15) is the B-operand layout (k = q, n = u) of
         // the G product, so Bv^T PB[v,:] runs straight from the accumulators -- no LDS round trip between the two
@@ -313,7 +312,7 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a, const
           const double bv = (kok && li < NU) ? vb : 0.0;
 #pragma unroll
           for (int c = 0; c < CNT; ++c) {
-            const double v = pa_[c * 16 + ks * 4 * LDP];
+            const double v = pa_[c * 16 * LDP + ks * 4];
             const double av = (kok && (c * 16 + li < NX)) ? v : 0.0;
             acc[c] = mfma16(av, bv, acc[c]);
           }
@@ -428,11 +427,11 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a, const
 #pragma unroll
             for (int tm = TM0; tm < TM1; ++tm) {
               if (tm * 16 + 15 < NX) {
-                r.a[tm] = sP[li + q * LDP + tm * 16 + ks * 4 * LDP];
+                r.a[tm] = sP[q + ks * 4 + (li + tm * 16) * LDP];   // P+[k][i] = P+[i][k], conflict-free (see the PB product)
               } else if (tm * 16 >= NX) {
                 r.a[tm] = sPB[q + li * LDP + (tm * 16 - NX) * LDP + ks * 4];
               } else {  // the tile that straddles P+ rows and PB^T rows
-                r.a[tm] = sP[li + q * LDP + tm * 16 + ks * 4 * LDP];
+                r.a[tm] = sP[q + ks * 4 + (li + tm * 16) * LDP];   // P+[k][i] = P+[i][k], conflict-free (see the PB product)
                 r.amix = sPB[q + li * LDP + (tm * 16 - NX) * LDP + ks * 4];
               }
             }

@@ -17,7 +17,7 @@ from test_contact_constraints import Q_ICUB, limits
 m = rm.load_named("icub")
 nv, nq, nu = m.nv, m.nq, m.nv - 6
 for cones in ("friction", "wrench"):
-    for ls in (False, True):
+    for ls in ((False, True) if not os.environ.get("HOP_NO_LS") else (False,)):
         cone_rows = 10 if cones == "friction" else 34
         dims = icub_dims(nv, nc_max=(6 * nu + cone_rows + 7) & ~7)
         cs = ContactSequence([12, 0, 12], [Event("lift", 0.25), Event("impact", 0.36, impact_dimf=12)])
@@ -37,7 +37,8 @@ for cones in ("friction", "wrench"):
         else:
             ctx.set_wrench_cones(2)
         ctx.set_impact_cones(False)
-        ctx.set_constraint_bounds(limits(nu, 2.5, 8.0, 120.0), 1e-3, 0.995)
+        LIM = [float(x) for x in os.environ.get("HOP_LIMITS", "2.5,8.0,120.0").split(",")]
+        ctx.set_constraint_bounds(limits(nu, *LIM), float(os.environ.get("HOP_BARRIER", "1e-3")), 0.995)
         if cones == "friction":
             ctx.set_friction_coefficients(np.full(2, 0.6))
         else:

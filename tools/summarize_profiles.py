@@ -18,17 +18,30 @@ for r in csv.DictReader(open(os.path.join(OUT, "prof_stats", "stats_kernel_stats
 # per launch geometry (the whole-bench trace mixes batch and single-instance launches of the same kernel)
 trace = os.path.join(OUT, "prof_stats", "stats_kernel_trace.csv")
 if os.path.exists(trace):
-    acc = collections.OrderedDict()
-    for r in csv.DictReader(open(trace)):
+    # every launch with the idle time of the GPU in front of it (end of the previous kernel of ANY kind to this start): after
+    # ~50 ms of idling the chip needs a few ms to clock up again, and the first kernels behind a host synchronisation run ~10 %
+    # slower (tools/dvfs_probe.py) -- the geometry groups therefore also report the launches that ran back to back (gap < 50 us)
+    rows = sorted(csv.DictReader(open(trace)), key=lambda r: int(r["Start_Timestamp"]))
+    acc, b2b = collections.OrderedDict(), collections.OrderedDict()
+    prev_end = None
+    for r in rows:
+        start, end = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        gap = None if prev_end is None else start - prev_end
+        prev_end = max(prev_end or 0, end)
         if "rtoc::" not in r["Kernel_Name"] and "mask_converged" not in r["Kernel_Name"]:
             continue
         key = (r["Kernel_Name"].split("(")[0].replace("void ", ""), int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]),
                int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"]), int(r["Workgroup_Size_X"]), r["LDS_Block_Size"], r["Scratch_Size"],
                r["VGPR_Count"], r["Accum_VGPR_Count"], r["SGPR_Count"])
-        acc.setdefault(key, []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
-    lines.append("# same trace grouped by launch geometry: kernel, workgroups(x), y*z, threads, LDS bytes, scratch bytes/lane, VGPR, AGPR, SGPR, calls, avg ms, min ms, max ms")
+        acc.setdefault(key, []).append((end - start) / 1e6)
+        if gap is not None and gap < 50000:
+            b2b.setdefault(key, []).append((end - start) / 1e6)
+    lines.append("# same trace grouped by launch geometry: kernel, workgroups(x), y*z, threads, LDS bytes, scratch bytes/lane, VGPR, AGPR, SGPR, calls, avg ms, min ms, max ms"
+                 " | the launches that started < 50 us behind the previous kernel (back to back): calls, avg ms")
     for k, v in acc.items():
-        lines.append("%s, %d, %d, %d, %s, %s, %s, %s, %s, n=%d, avg %.4f, min %.4f, max %.4f" % (k + (len(v), sum(v) / len(v), min(v), max(v))))
+        w = b2b.get(k, [])
+        lines.append("%s, %d, %d, %d, %s, %s, %s, %s, %s, n=%d, avg %.4f, min %.4f, max %.4f" % (k + (len(v), sum(v) / len(v), min(v), max(v)))
+                     + (" | back to back n=%d, avg %.4f" % (len(w), sum(w) / len(w)) if w else " | back to back n=0"))
 traffic = {}
 for cname, d in (("FETCH_SIZE", "prof_fetch/fetch"), ("WRITE_SIZE", "prof_write/write")):
     acc = collections.OrderedDict()
