@@ -21,6 +21,8 @@ bash tools/gpu_pmc_lin_flops.sh $TAG 1024 > $OUT/lin_flops.log 2>&1
 { cat $OUT/scan_sto_latency.txt | grep "bwd/fwd"; echo; echo "kernel, calls, total ns, avg ns, %, min, max, stddev"; grep -i "sto\|riccati_backward\|scan_" $(find $OUT/prof_sto -name "*kernel_stats.csv" | head -1); } > $OUT/summary/${TAG}_scan_sto_kernel_stats.txt 2>/dev/null
 if [ -f $R/robotoc_amd/librtoc_hip_prof.so ]; then RTOC_HIP_LIB=$R/robotoc_amd/librtoc_hip_prof.so timeout 100 python tools/phase_profile_sto.py >> $OUT/summary/${TAG}_scan_sto_kernel_stats.txt 2>&1; fi
 rm -rf $OUT/prof_sto
+timeout 200 python tools/dvfs_probe.py > $OUT/summary/${TAG}_dvfs_probe.txt 2>&1
+timeout 200 python tools/icub_bwd_bench.py > $OUT/summary/${TAG}_icub_backward.txt 2>&1
 RTOC_PROFILE_OUT=$OUT/summary python tools/summarize_profiles.py $TAG "closing run of the round" > $OUT/summarize.log 2>&1
 cp $OUT/closed_loop_kernel_stats.txt $OUT/summary/${TAG}_closed_loop_kernel_stats.txt
 cp $OUT/host_cpu.txt $OUT/summary/${TAG}_host_cpu.txt 2>/dev/null
