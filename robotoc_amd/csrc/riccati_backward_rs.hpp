@@ -35,12 +35,25 @@ __device__ __forceinline__ void wave_lds_sync() {
 // mid-stage block barriers would only couple the two instruction streams; a flag lets the matrix
 // wave run PB -> G -> PAa -> H -> F back to back while the vector wave trails it.  LDS is a single
 // in-order unit per CU: once the flag store is visible, the wave's earlier LDS stores are too.
+// The flag words are read and written with explicit DS instructions.  Through a `volatile int*` the compiler does not see the LDS
+// address space and emits flat_load / flat_store with system coherence bits, each followed by `s_waitcnt vmcnt(0) lgkmcnt(0)`:
+// every poll of a flag then DRAINS the wave's outstanding HBM traffic -- the record prefetch of the vector wave, the Qxx loads
+// into the F accumulators of the matrix wave, the policy / P stores -- several times per stage.  (A generic pointer into LDS is
+// the aperture base in the high word and the LDS byte offset in the low one.)
+__device__ __forceinline__ int lds_flag_read(const volatile int* p) {
+  int v;
+  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((unsigned)(unsigned long long)p) : "memory");
+  return v;
+}
+__device__ __forceinline__ void lds_flag_write(volatile int* p, int v) {
+  asm volatile("ds_write_b32 %0, %1" ::"v"((unsigned)(unsigned long long)p), "v"(v) : "memory");
+}
 __device__ __forceinline__ void lds_signal(volatile int* flag, int seq, int lane) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  if (lane == 0) *flag = seq;
+  if (lane == 0) lds_flag_write(flag, seq);
 }
 __device__ __forceinline__ void lds_wait(volatile int* flag, int seq) {
-  while (*flag < seq) __builtin_amdgcn_s_sleep(1);
+  while (__builtin_amdgcn_readfirstlane(lds_flag_read(flag)) < seq) __builtin_amdgcn_s_sleep(1);
   asm volatile("" ::: "memory");
 }
 
@@ -58,7 +71,7 @@ __device__ __forceinline__ void rs_sync(volatile int* cnt, int& epoch, int lane)
     epoch += 2;
     if (lane == 0)
       __hip_atomic_fetch_add(const_cast<int*>(cnt), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    while (__builtin_amdgcn_readfirstlane(*cnt) < epoch) __builtin_amdgcn_s_sleep(1);
+    while (__builtin_amdgcn_readfirstlane(lds_flag_read(cnt)) < epoch) __builtin_amdgcn_s_sleep(1);
     asm volatile("" ::: "memory");
   }
 }
