@@ -13,7 +13,8 @@ from .types import Records
 
 
 def anymal_jump_sto_solver(batch=1, device=0, N=40, dt=0.02, jump_length=0.25, ground_time=0.31, flying_time=0.2,
-                           min_dwell=(0.1, 0.1, 0.2), with_limits=True, with_cones=True, max_iter=200, seed=7, x0_noise=0.0):
+                           min_dwell=(0.1, 0.1, 0.2), with_limits=True, with_cones=True, max_iter=200, seed=7, x0_noise=0.0,
+                           horizon_scan="auto"):
     m = rm.load_named("anymal")
     nv, nq, nu = m.nv, m.nq, m.nu
     qs = np.array(ANYMAL_Q_STANDING, dtype=float)
@@ -31,7 +32,7 @@ def anymal_jump_sto_solver(batch=1, device=0, N=40, dt=0.02, jump_length=0.25, g
                 v_weight_impact=np.full(nv, 1.0), dv_weight_impact=np.full(nv, 1e-6))
     # joint limits of the ANYmal URDF (anymal_b_simple_description): position +-9.42 (continuous joints), velocity 7.5 rad/s, effort 80 N m
     limits = (np.full(nu, -9.42), np.full(nu, 9.42), np.full(nu, 7.5), np.full(nu, 80.0)) if with_limits else None
-    opts = SolverOptions(max_iter=max_iter, kkt_tol=1e-7, kkt_tol_mesh=1.0, max_dt_mesh=T / N)
+    opts = SolverOptions(max_iter=max_iter, kkt_tol=1e-7, kkt_tol_mesh=1.0, max_dt_mesh=T / N, horizon_scan=horizon_scan)
     solver = OCPSolver(m, plan, T, N, cost, joint_limits=limits, friction_coefficients=np.full(4, 0.7) if with_cones else None,
                        sto_constraints=STOConstraints(list(min_dwell)), options=opts, batch=batch, device=device)
     rng = np.random.default_rng(seed)

@@ -29,6 +29,9 @@ class SolverOptions:
     max_dts_riccati: float = 0.1
     enable_solution_interpolation: bool = True
     enable_line_search: bool = False
+    # not in the reference: how the Riccati recursion runs on the device -- "auto": the horizon scans for batches of at most 8 OCPs
+    # (RTOC_OPT_BACKWARD_SCAN = 2: latency of one MPC problem), the serial kernels above; "on" / "off" force either
+    horizon_scan: str = "auto"
     # LineSearchSettings (include/robotoc/line_search/line_search_settings.hpp), filter method
     step_size_reduction_rate: float = 0.75
     min_step_size: float = 0.05
@@ -156,6 +159,7 @@ class OCPSolver:
         c.set_robot_model(model)
         c.set_configuration_cost(**cost)
         c.set_max_dts0(self.options.max_dts_riccati)
+        c.set_backward_scan({"auto": "auto", "on": True, "off": False}[self.options.horizon_scan])
         self.tau = fraction_to_boundary_rule
         if rows:
             q_min, q_max, v_max, u_max = (np.asarray(x, dtype=float) for x in joint_limits)
