@@ -157,7 +157,10 @@ struct BwdCfg {
   static constexpr int V_BTS = V_FLAG + 8;
   static constexpr int V_BTPSI = V_BTS + VU;
   static constexpr int V_BTPHI = V_BTPSI + VU;
-  static constexpr int LDS_DOUBLES = V_BTPHI + VU;
+  // Z^T = L^-1 H^T (nu x nx, ld NU) of the tile-split shapes (nx > 63: one instance per CU, LDS to spare): F -= Z Z^T instead of
+  // G K and F -= K^T G K on grid points without a switching constraint
+  static constexpr int OFF_ZT = V_BTPHI + VU;
+  static constexpr int LDS_DOUBLES = OFF_ZT + (NX > 63 ? pad8(NU * NX) : 0);
   static constexpr int LDS_BYTES = LDS_DOUBLES * 8;
   static_assert(NS == 0 || S_END <= OFF_PB, "switching-constraint scratch must fit in A");
   static_assert(NX + 1 <= NT, "need one thread per state entry plus one");
@@ -831,6 +834,12 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
     if (st > st_last) issue_loads(st - 1);
     RTOC_PROF(16);
 
+    // Without a switching constraint K^T G K = H G^-1 H^T = Z Z^T with Z^T = L^-1 H^T, which the policy products form anyway: the
+    // tile-split shapes (one instance per CU, LDS to spare) park Z^T in LDS and run F -= Z Z^T from there -- no G K product and
+    // one barrier less.  (riccati_backward_rs.hpp does the same from registers; here the row blocks of F belong to different waves.)
+    constexpr bool ZZ_SHAPE = NX > 63 && NU <= 32;
+    double* const sZt = smem + C::OFF_ZT;
+    const bool zz = ZZ_SHAPE && !impact && ns == 0;
     if (impact) {
       // riccati_factorizer.cpp:178-197 -- no policy
     } else {
@@ -867,6 +876,15 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
               const double yv = sY[(i < NU ? i : 0) + ((kok ? ks * 4 + q : 0)) * NU];  // Y[i][u]
               zt[t] = mfma16((kok && i < NU) ? yv : 0.0, bv, zt[t]);
             }
+          }
+          if constexpr (ZZ_SHAPE) {
+#pragma unroll
+            for (int t = 0; t < TU; ++t)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int u = t * 16 + drow(q, r);
+                if (u < NU && x < NX) sZt[u + x * NU] = zt[t][r];
+              }
           }
 #pragma unroll
           for (int ks = 0; ks < KSU; ++ks) {  // k = i = 4 ks + q
@@ -951,6 +969,7 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
         if (tid < NU) kw[KL.off[RTOC_KKT_LU] + tid] = smem[C::V_LU + tid];
         __syncthreads();
       }
+      if (!zz)
       // ---- GK = G K (+ 2 Phiu^T M on switching-constraint grids, which folds
       //      P -= KtDtM + KtDtM^T (:84-87) into the symmetrised F - K^T GK) ----
       {
@@ -1000,19 +1019,20 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
               }
             }
       }
-      __syncthreads();
+      if (!zz) __syncthreads();   // (wave-uniform)
       RTOC_PROF(8);
-      // ---- F -= K^T GK ----
+      // ---- F -= K^T GK  (zz: F -= Z Z^T, A operand Z[i][k] = Z^T[k][i] from the same buffer) ----
       {
-        const double* pa_ = sKt + (wave * 16 + li) + q * LDP;  // K^T[i][k] = Kt[i][k]
-        const double* pb_ = sGK + q + li * NU;                 // GK[k][j]
+        const double* pa_ = zz ? sZt + q + (wave * 16 + li) * NU : sKt + (wave * 16 + li) + q * LDP;  // Z^T[k][i] | K^T[i][k]
+        const int pa_c = zz ? NW * 16 * NU : NW * 16, pa_k = zz ? 4 : 4 * LDP;
+        const double* pb_ = (zz ? sZt : sGK) + q + li * NU;    // Z^T[k][j] | GK[k][j]
 #pragma unroll
         for (int ks = 0; ks < (NU + 3) / 4; ++ks) {
           const bool kok = (ks * 4 + 3 < NU) || (ks * 4 + q < NU);
           double av[CNT], bv[TNX];
 #pragma unroll
           for (int c = 0; c < CNT; ++c) {
-            const double v = pa_[c * NW * 16 + ks * 4 * LDP];
+            const double v = pa_[c * pa_c + ks * pa_k];
             av[c] = (kok && ((wave + c * NW) * 16 + li < NX)) ? -v : 0.0;
           }
 #pragma unroll
