@@ -252,10 +252,12 @@ class RiccatiRecursion {
 
   // Not in the reference: run backwardRiccatiRecursion as a scan over the horizon (RTOC_OPT_BACKWARD_SCAN) --
   // the low-latency path for ONE OCP, which is what this class holds.  Same results to <= 1e-8 relative;
-  // discretisations with switching-time optimisation keep the serial kernel.
+  // with switching-time optimisation the matrix half is the scan, the vector half a serial pass behind it (riccati_scan_sto.hpp).
   void setHorizonScan(const bool on) {
     check(rtoc_set_option(ctx_, RTOC_OPT_BACKWARD_SCAN, on ? 1 : 0), "rtoc_set_option");
   }
+  // 0: serial kernels, 1: scans, 2: automatic (scans for batches of at most 8 instances) -- RTOC_OPT_BACKWARD_SCAN as it is
+  void setHorizonScanMode(const int mode) { check(rtoc_set_option(ctx_, RTOC_OPT_BACKWARD_SCAN, mode), "rtoc_set_option"); }
 
   void resizeData(const TimeDiscretization& td) {
     const int N = td.size() - 1;

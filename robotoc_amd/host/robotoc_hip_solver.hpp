@@ -67,7 +67,8 @@ struct SolverOptions {
   double max_dts_riccati = 0.1;
   bool enable_solution_interpolation = true;
   bool enable_benchmark = false;
-  bool horizon_scan = false;  // not in the reference: RTOC_OPT_BACKWARD_SCAN for the single-OCP latency path
+  int horizon_scan = 0;  // not in the reference: RTOC_OPT_BACKWARD_SCAN -- 0 (default) serial kernels, 1 horizon scans, 2 as the
+                         // Python shell's "auto": scans for batches of at most 8 OCPs, the latency path of one MPC problem
 };
 
 // include/robotoc/solver/solver_statistics.hpp
@@ -545,7 +546,7 @@ class OCPSolver {
     dms_.setLineSearch(solver_options.enable_line_search);
     dms_.setFractionToBoundaryRule(solver_options.fraction_to_boundary_rule);
     riccati_recursion_.setRegularization(solver_options.max_dts_riccati);   // ocp_solver.cpp:84
-    riccati_recursion_.setHorizonScan(solver_options.horizon_scan);
+    riccati_recursion_.setHorizonScanMode(solver_options.horizon_scan);
   }
 
   // discretize (ocp_solver.cpp:96-102): the contact-sequence planner is upstream of the boundary; the grid comes

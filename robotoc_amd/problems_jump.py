@@ -14,7 +14,7 @@ from .types import Records
 
 def anymal_jump_sto_solver(batch=1, device=0, N=40, dt=0.02, jump_length=0.25, ground_time=0.31, flying_time=0.2,
                            min_dwell=(0.1, 0.1, 0.2), with_limits=True, with_cones=True, max_iter=200, seed=7, x0_noise=0.0,
-                           horizon_scan="auto"):
+                           horizon_scan="off"):
     m = rm.load_named("anymal")
     nv, nq, nu = m.nv, m.nq, m.nu
     qs = np.array(ANYMAL_Q_STANDING, dtype=float)

@@ -29,9 +29,9 @@ class SolverOptions:
     max_dts_riccati: float = 0.1
     enable_solution_interpolation: bool = True
     enable_line_search: bool = False
-    # not in the reference: how the Riccati recursion runs on the device -- "auto": the horizon scans for batches of at most 8 OCPs
-    # (RTOC_OPT_BACKWARD_SCAN = 2: latency of one MPC problem), the serial kernels above; "on" / "off" force either
-    horizon_scan: str = "auto"
+    # not in the reference: how the Riccati recursion runs on the device -- "off" (default, as the C API): the serial kernels;
+    # "auto": the horizon scans for batches of at most 8 OCPs (RTOC_OPT_BACKWARD_SCAN = 2: latency of one MPC problem); "on": always
+    horizon_scan: str = "off"
     # LineSearchSettings (include/robotoc/line_search/line_search_settings.hpp), filter method
     step_size_reduction_rate: float = 0.75
     min_step_size: float = 0.05

@@ -19,7 +19,7 @@ def main():
         kw = dict(with_limits=False, with_cones=False)
     elif variant == "nolimits":
         kw = dict(with_limits=False)
-    kw["horizon_scan"] = os.environ.get("RTOC_HORIZON_SCAN", "auto")
+    kw["horizon_scan"] = os.environ.get("RTOC_HORIZON_SCAN", "off")
     solver, x0, info = pj.anymal_jump_sto_solver(batch=batch, **kw)
     t0 = time.perf_counter()
     st = solver.solve(0.0, x0)
