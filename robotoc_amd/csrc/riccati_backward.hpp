@@ -382,6 +382,132 @@ __device__ __forceinline__ void llt_solve_reg(const double* __restrict__ L,
   }
 }
 
+// The same factorisation and inverse factor for 16 < n <= 32, blocked 16 + (n - 16) with the trailing update and the off-diagonal
+// block of the inverse on the matrix cores.  The column steps of wave_llt_inv cost (n - j) broadcasts each -- n^2 / 2 readlane
+// pairs, every one of them spilled through a VGPR lane in the register-starved tile-split kernels (19k cycles at n = 29).  Here:
+//   panel     columns 0..15 of ALL n rows (lanes = rows) by the column steps, 16 - j broadcasts each: L11, L21; Y11 = L11^-1 on
+//             lanes 32..47 in the same stream
+//   trailing  S = G22 - L21 L21^T: 4 MFMAs, both operands the same fragment of L21
+//   block 2   S = L22 L22^T by the column steps (n - 16 columns), Y22 = L22^-1 beside it
+//   inverse   Y21 = -Y22 (L21 Y11): two MFMA products chained through the C layout
+// Same outputs as wave_llt_inv: L (lower, zeros above) at Ldst (ld LD), 1/diag(L) at linv, Y column-major (ld NMAX) at Ydst; scr: 256
+// doubles of LDS scratch.  One wave; LDS hand-offs inside it are ordered by wave_lds_fence.
+__device__ __forceinline__ void wave_lds_fence() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+template <int NMAX, int LD>
+__device__ __forceinline__ bool wave_llt_inv_blocked(const double* __restrict__ A, double* __restrict__ Ldst, double* __restrict__ linv,
+                                                     double* __restrict__ Ydst, double* __restrict__ scr, int lane) {
+  static_assert(NMAX > 16 && NMAX <= 32, "two blocks");
+  constexpr int n = NMAX, N2 = NMAX - 16;
+  const int li = lane & 15, q = lane >> 4;
+  const bool ylane = lane >= 32;
+  const int yc = lane - 32;            // column of Y11 / Y22 this lane carries
+  const int row = lane < n ? lane : 0;
+  bool bad = false;
+  // ---- panel: columns 0..15 ----
+  double g[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) g[k] = ylane ? ((k == yc) ? 1.0 : 0.0) : A[row + k * LD];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const double d = readlane_d(g[j], j);
+    if (!(d > 0.0)) bad = true;
+    const double inv = rsqrt_d(d);
+    const double xj = g[j] * inv;   // L[lane][j] | Y11[j][yc]
+    g[j] = xj;
+    if (lane == j) linv[j] = inv;
+#pragma unroll
+    for (int k = j + 1; k < 16; ++k) {
+      const double lkj = readlane_d(xj, k);
+      g[k] -= xj * lkj;
+    }
+  }
+  if (lane < n) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) Ldst[lane + k * LD] = (k <= lane) ? g[k] : 0.0;
+#pragma unroll
+    for (int k = 16; k < n; ++k)
+      if (lane < 16) Ldst[lane + k * LD] = 0.0;   // the block above the diagonal
+  } else if (ylane && yc < 16) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) Ydst[k + yc * NMAX] = g[k];
+#pragma unroll
+    for (int k = 16; k < n; ++k) Ydst[k + yc * NMAX] = 0.0;   // placeholder of Y21 (overwritten below)
+  }
+  wave_lds_fence();
+  // ---- trailing update on the matrix cores: S = G22 - L21 L21^T (C layout: row q + 4r, column li) ----
+  {
+    d4 acc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int u0 = drow(q, r), u1 = li;
+      acc[r] = (u0 < N2 && u1 < N2) ? A[(16 + u0) + (16 + u1) * LD] : ((u0 == u1) ? 1.0 : 0.0);   // padding: identity
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const double v = (li < N2) ? Ldst[(16 + li) + (ks * 4 + q) * LD] : 0.0;   // L21[li][4 ks + q]: A and B fragment alike
+      acc = mfma16(-v, v, acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) scr[drow(q, r) + li * 16] = acc[r];
+  }
+  wave_lds_fence();
+  // ---- block 2 ----
+  double h[16];
+  const int row2 = lane < N2 ? lane : 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) h[k] = ylane ? ((k == yc) ? 1.0 : 0.0) : scr[row2 + k * 16];
+#pragma unroll
+  for (int j = 0; j < N2; ++j) {
+    const double d = readlane_d(h[j], j);
+    if (!(d > 0.0)) bad = true;
+    const double inv = rsqrt_d(d);
+    const double xj = h[j] * inv;   // L22[lane][j] | Y22[j][yc]
+    h[j] = xj;
+    if (lane == j) linv[16 + j] = inv;
+#pragma unroll
+    for (int k = j + 1; k < N2; ++k) {
+      const double lkj = readlane_d(xj, k);
+      h[k] -= xj * lkj;
+    }
+  }
+  if (lane < N2) {
+#pragma unroll
+    for (int k = 0; k < N2; ++k) Ldst[(16 + lane) + (16 + k) * LD] = (k <= lane) ? h[k] : 0.0;
+  } else if (ylane && yc < N2) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) Ydst[k + (16 + yc) * NMAX] = 0.0;            // Y12 = 0
+#pragma unroll
+    for (int k = 0; k < N2; ++k) Ydst[(16 + k) + (16 + yc) * NMAX] = h[k];   // Y22
+  }
+  wave_lds_fence();
+  // ---- Y21 = -Y22 (L21 Y11) ----
+  {
+    d4 t = zero4(), y = zero4();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const double a_ = (li < N2) ? Ldst[(16 + li) + (ks * 4 + q) * LD] : 0.0;   // L21[i = li][k]
+      const double b_ = Ydst[(ks * 4 + q) + li * NMAX];                            // Y11[k][n = li]
+      t = mfma16(a_, b_, t);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {   // k = 4 ks + q < N2 (Y22 is zero-padded by the masks)
+      const int k = ks * 4 + q;
+      const double a_ = (li < N2 && k < N2) ? Ydst[(16 + li) + (16 + k) * NMAX] : 0.0;   // Y22[i = li][k]
+      y = mfma16(-a_, t[ks], y);   // the C layout of T (row q + 4 ks, column li) is the B fragment of k-step ks
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = drow(q, r);
+      if (i < N2) Ydst[(16 + i) + li * NMAX] = y[r];
+    }
+  }
+  wave_lds_fence();
+  return bad;
+}
+
 // the shared stage fragments (*.inc) synchronise the threads of ONE instance through this macro
 #define RTOC_BLOCK_SYNC() __syncthreads()
 template <int NV, int NU, int NS, int NW>
@@ -599,7 +725,8 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int i = tm * 16 + drow(q, r), u = t * 16 + li;
-              if (i < NX && u < NU) sPB[i + u * LDP] = acc[c][t][r];
+              double* const d = (i < NX && u < NU) ? sPB + i + u * LDP : smem + C::V_BTS + (lane & 7);
+              *d = acc[c][t][r];
             }
         }
       }
@@ -623,7 +750,8 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int u0 = t0 * 16 + drow(q, r), u1 = t1 * 16 + li;
-            if (u0 < NU && u1 < NU) sG[u0 + u1 * NU] += acc[r];
+            double* const d = (u0 < NU && u1 < NU) ? sG + u0 + u1 * NU : smem + C::V_BTS + (lane & 7);
+            *d += acc[r];
           }
         }
       }
@@ -717,7 +845,9 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
             const int row = tm * 16 + drow(q, r);
             const int j = (wave + c * NW) * 16 + li;
             if (tm * 16 + 4 * r + 3 >= NX) {  // compile-time prune of pure-P register groups
-              if (row >= NX && row < NX + NU && j < NX) sH[j + (row - NX) * LDP] += pa[tm][c][r];
+              const bool ok = row >= NX && row < NX + NU && j < NX;   // branch-free: the others add into a dummy slot
+              double* const d = ok ? sH + j + (row - NX) * LDP : smem + C::V_BTS + (lane & 7);
+              *d += pa[tm][c][r];
             }
           }
     }
@@ -749,7 +879,11 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
       if constexpr (NU <= 32) {
         // with the inverse factor Y = L^-1 in the same instruction stream (dead Bv buffer): the
         // triangular solves of the policy become MFMA products below
-        if (wave_llt_inv<NU, NU, 32>(sG, sL, smem + C::V_LINV, sBv, NU, lane)) stat |= RTOC_STAT_QUU_NOT_SPD;
+        if constexpr (NU > 16 && NX > 63) {   // blocked, trailing update and Y21 on the matrix cores (scratch: the Z^T slot, free now)
+          if (wave_llt_inv_blocked<NU, NU>(sG, sL, smem + C::V_LINV, sBv, smem + C::OFF_ZT, lane)) stat |= RTOC_STAT_QUU_NOT_SPD;
+        } else {
+          if (wave_llt_inv<NU, NU, 32>(sG, sL, smem + C::V_LINV, sBv, NU, lane)) stat |= RTOC_STAT_QUU_NOT_SPD;
+        }
       } else {
         if (wave_llt<NU, NU>(sG, sL, smem + C::V_LINV, NU, lane)) stat |= RTOC_STAT_QUU_NOT_SPD;
       }
@@ -877,13 +1011,17 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
               zt[t] = mfma16((kok && i < NU) ? yv : 0.0, bv, zt[t]);
             }
           }
+          // results leave branch-free: every lane stores every value, the ones that have no home go to a dummy slot (the per-value
+          // "if (u < NU) if (x < NX) ... else if ..." nests compiled to ~150 exec-mask branches per tile: 10k cycles for 32 MFMAs)
+          double* const dummy = smem + C::V_BTS + (lane & 7);   // unused by this kernel (the role-split kernel's rider slots)
           if constexpr (ZZ_SHAPE) {
 #pragma unroll
             for (int t = 0; t < TU; ++t)
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
                 const int u = t * 16 + drow(q, r);
-                if (u < NU && x < NX) sZt[u + x * NU] = zt[t][r];
+                double* const dz = (u < NU && x < NX) ? sZt + u + x * NU : dummy;
+                *dz = zt[t][r];
               }
           }
 #pragma unroll
@@ -896,28 +1034,27 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
               kk[t] = mfma16((kok && u < NU) ? -yv : 0.0, zt[ks / 4][ks % 4], kk[t]);
             }
           }
+          {
+            // column x of the right-hand side: K^T (x < NX), k (NX), T (NX + 1), W (NX + 2; zero without sto_next)
+            double* const dbase = x < NX ? sKt + x : smem + (x == NX ? C::V_KV : (x == NX + 1 ? C::V_TV : C::V_WV));
+            const int dstr = x < NX ? LDP : 1;
+            const bool okx = x <= NX || (sto && x <= NX + 2);
+            const bool zero = x == NX + 2 && !sto_next;
 #pragma unroll
-          for (int t = 0; t < TU; ++t)
+            for (int t = 0; t < TU; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int u = t * 16 + drow(q, r);
-              const double v = kk[t][r];
-              if (u < NU) {
-                if (x < NX) {
-                  sKt[x + u * LDP] = v;
-                  chk = __builtin_fma(v, 0.0, chk);
-                } else if (x == NX) {
-                  smem[C::V_KV + u] = v;
-                  chk = __builtin_fma(v, 0.0, chk);
-                } else if (x == NX + 1) {
-                  if (sto) smem[C::V_TV + u] = v;
-                } else if (x == NX + 2) {
-                  if (sto) smem[C::V_WV + u] = sto_next ? v : 0.0;
-                }
+              for (int r = 0; r < 4; ++r) {
+                const int u = t * 16 + drow(q, r);
+                const double v = kk[t][r];
+                const bool ok = okx && u < NU;
+                double* const d = ok ? dbase + u * dstr : dummy;
+                *d = zero ? 0.0 : v;
+                chk = __builtin_fma((ok && x <= NX) ? v : 0.0, 0.0, chk);
               }
-            }
+          }
         }
         if (is_bad(chk)) stat |= RTOC_STAT_NAN;
+        RTOC_PROF(17);
       } else if (ns == 0) {
         // K = -G^-1 H^T, k = -G^-1 lu   (:55-56); thread t < NX owns column t, thread NX owns k
         if (tid <= NX) {
@@ -1076,6 +1213,7 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
     //      P is exactly symmetric. ----
     {
       double* pw_ = sP + (wave * 16 + q) + li * LDP;        // F[i][j] at i + j*LDP
+      double* const pdummy = smem + C::V_BTS + (lane & 7);   // home of the entries beyond the matrix (unused slot of this kernel)
       const double* pr_ = sP + li + (wave * 16 + q) * LDP;  // F[j][i]
 #pragma unroll
       for (int c = 0; c < CNT; ++c)
@@ -1084,7 +1222,8 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int i = (wave + c * NW) * 16 + drow(q, r), j = t * 16 + li;
-            if (i < NX && j < NX) pw_[c * NW * 16 + 4 * r + t * 16 * LDP] = f[c][t][r];
+            double* const d = (i < NX && j < NX) ? pw_ + (c * NW * 16 + 4 * r + t * 16 * LDP) : pdummy;   // branch-free (see the policy products)
+            *d = f[c][t][r];
           }
       __syncthreads();
 #pragma unroll
@@ -1104,7 +1243,8 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int i = (wave + c * NW) * 16 + drow(q, r), j = t * 16 + li;
-            if (i < NX && j < NX) pw_[c * NW * 16 + 4 * r + t * 16 * LDP] = f[c][t][r];
+            double* const d = (i < NX && j < NX) ? pw_ + (c * NW * 16 + 4 * r + t * 16 * LDP) : pdummy;
+            *d = f[c][t][r];
           }
     }
 

@@ -19,7 +19,7 @@ for st in (len(grids) - 3, 5):
     row = p[st]; d = np.diff(row[:13])
     print(" stage %2d (type %d dims %d sto %d) total %7d: " % (st, grids[st].type, grids[st].dims, grids[st].sto, row[12] - row[0]) + " | ".join("%s %d" % (n, x) for n, x in zip(names, d)))
     print("    tile-split kernel: F accumulators loaded at +%d (from phase 5 start), LLT + inverse by wave 0 took %d, F chain %d" % (row[13] - row[5], row[14] - row[13], row[6] - row[14]))
-    print("    solve phase: barrier passed at +%d, prefetch issued +%d, rest %d" % (row[15] - row[6], row[16] - row[15], row[7] - row[16]))
+    print("    solve phase: barrier passed at +%d, prefetch issued +%d, policy products of this wave %d, wait for the others %d" % (row[15] - row[6], row[16] - row[15], row[17] - row[16], row[7] - row[17]))
     print("    matrix wave F done at +%d, vector wave solve done at +%d (B4 at +%d); vector wave interval-4 done at +%d (B5 at +%d)" % (row[13] - row[0], row[14] - row[0], row[6] - row[0], row[15] - row[0], row[10] - row[0]))
     v = row[16:30] - row[0]
     vn = ["stage top", "pt done", "B1 passed", "z done", "lu' done (wait G)", "G flag seen", "LLT+Ginv done", "w done (wait H)", "H flag seen", "Kt mfma done", "B4 passed", "prefetch issued", "B5 passed", "stage end"]
