@@ -961,11 +961,7 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
     }
     RTOC_PROF(6);
     __syncthreads();  // L published; sA / sPB no longer read by MFMA after this point
-    // next stage's record: HBM -> registers, in flight for the rest of this stage (policy solve, K^T G K, symmetrisation, copy-out:
-    // several memory latencies).  Issued here rather than ahead of the F chain: its ~100 registers are not live next to the
-    // accumulators of P+ A and F, and the loads of Qxx into F above are the only ones in flight when F is first used.
     RTOC_PROF(15);
-    if (st > st_last) issue_loads(st - 1);
     RTOC_PROF(16);
 
     // Without a switching constraint K^T G K = H G^-1 H^T = Z Z^T with Z^T = L^-1 H^T, which the policy products form anyway: the
@@ -1099,6 +1095,8 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
       __syncthreads();
 
       RTOC_PROF(7);
+      // (the record prefetch of the next stage is issued below, behind the policy products: in front of them the compiler made the
+      //  first instruction of this path wait for ALL of it -- s_waitcnt vmcnt(0), ~8k cycles of HBM time on every wave)
       if (a.writeback) {  // mutated Qxu, Quu, lu (reference in-place semantics), before H is reused
         double* kw = a.kkt_rw + kinst + (size_t)st * KL.stride;
         copy_s2g_mat<NT, NX, NU, LDP>(kw + KL.off[RTOC_KKT_QXU], sH, tid);
@@ -1194,6 +1192,7 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
     }
 
     RTOC_PROF(9);
+    if (st > st_last) issue_loads(st - 1);   // HBM -> registers, in flight during the symmetrisation, the copy-out and the next stage's top
     // ---- optional write-back of the mutated KKT blocks (reference in-place semantics) ----
     if (a.writeback) {
       double* kw = a.kkt_rw + kinst + (size_t)st * KL.stride;
