@@ -20,6 +20,9 @@ namespace rtoc {
 #ifndef FWD_UNROLL
 #define FWD_UNROLL 18
 #endif
+#ifndef FWD_HEAD
+#define FWD_HEAD 8  // columns of the next stage requested ahead of the tail of this one
+#endif
 
 struct FwdArgs {
   const double* kkt;
@@ -32,16 +35,34 @@ struct FwdArgs {
   int first;
 };
 
+// Hand-over of dx / du / dts between the threads of an instance goes through LDS only: one wavefront needs no barrier
+// at all (its LDS operations complete in order), several need s_barrier behind their own LDS traffic -- and neither
+// needs the s_waitcnt vmcnt(0) that __syncthreads() puts in front of it, which would drain the loads in flight.
+template <int NWF>
+__device__ __forceinline__ void fwd_sync() {
+  if constexpr (NWF == 1)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  else
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 template <int NV, int NU, int NS, int NWF>
-__global__ __launch_bounds__(64 * NWF) void riccati_forward_kernel(FwdArgs a) {
+__global__ __launch_bounds__(64 * NWF, 4) void riccati_forward_kernel(FwdArgs a) {
   constexpr int NX = 2 * NV, NT = 64 * NWF;
+  constexpr bool MFOLD = NS > 0 && NX + NU + NS <= NT;  // the rows of M have threads of their own
   static_assert(NX + NU <= NT, "one thread per row of [Fxx;K]");
   __shared__ double sDx[2][NX + 8];
   __shared__ double sDu[NU + 8];
   __shared__ double sRed[8];
+  extern __shared__ int sGridTab[];  // [nstages] (dynamic): type | sto << 4 | sto_next << 5 | switching_constraint << 6 | dims << 8
   const int tid = threadIdx.x;
   const int b = a.first + blockIdx.x;
   if (b >= a.batch) return;
+  for (int st = tid; st < a.nstages; st += NT) {
+    const rtoc_grid* gp = a.grid + st;
+    sGridTab[st] = (gp->type & 15) | ((gp->sto != 0) << 4) | ((gp->sto_next != 0) << 5) |
+                   ((gp->switching_constraint != 0) << 6) | (gp->dims << 8);
+  }
   const int N = a.nstages - 1;
   constexpr rtoc_layout SL = StaticLayout<NV, NU, NS>::make();
   constexpr rtoc_record_layout KL = SL.kkt, RL = SL.ric, DL = SL.dir;
@@ -71,8 +92,55 @@ __global__ __launch_bounds__(64 * NWF) void riccati_forward_kernel(FwdArgs a) {
     }
   }
   int cur = 0;
+  struct GridBits { int type, sto, sto_next, switching_constraint, dims; };
+  // ---- Row walks.  Every HBM read of a stage that does not depend on dx: the rows of Fxx / P (threads < NX), of K
+  //      (threads NX..NX+NU-1) and of M (the NS threads behind them, switching-constraint stages) share the SAME two load
+  //      instructions per column -- a divergent branch per role used to serialise them into ~13 dependent round trips per
+  //      stage --, Fx / k / m and s ride along.  Threads without a role read element 0 of a live field; nothing consumes
+  //      what they load.  The first FWD_HEAD columns (and the two vectors) of stage st + 1 are requested BEFORE the tail
+  //      of stage st (du -> LDS -> dx+ -> LDS, stores): all 4096 instances run in step, so without that the memory system
+  //      idles during the tail of every stage (tools/probes/read_bw_probe.hip: the walks alone stream at 5.6 TB/s). ----
+  struct StageRows {
+    const double *pa, *pp, *pv, *ps;
+    int sa;
+  };
+  auto stage_rows = [&](int st) {
+    const int gb = __builtin_amdgcn_readfirstlane(sGridTab[st]);
+    const bool imp = (gb & 15) == RTOC_GRID_IMPACT;
+    const bool xrow = tid < NX;
+    const bool krow = !imp && tid >= NX && tid < NX + NU;
+    const bool mrow = MFOLD && ((gb >> 6) & 1) && tid >= NX + NU && tid < NX + NU + (gb >> 8);
+    const int u = krow ? tid - NX : 0;
+    const int m = mrow ? tid - NX - NU : 0;
+    const int t = xrow ? tid : 0;
+    const double* kr = kb + (size_t)st * KL.stride;
+    const double* rr = rb + (size_t)st * RL.stride;
+    StageRows r;
+    r.pa = xrow ? kr + KL.off[RTOC_KKT_FXX] + tid
+                : (mrow ? rr + RL.off[RTOC_RIC_M] + m : rr + RL.off[RTOC_RIC_K] + (size_t)u * NX);
+    r.sa = xrow ? NX : (mrow ? NS : 1);
+    r.pp = rr + RL.off[RTOC_RIC_P] + t;
+    r.pv = xrow ? kr + KL.off[RTOC_KKT_FX] + tid : (mrow ? rr + RL.off[RTOC_RIC_MV] + m : rr + RL.off[RTOC_RIC_KV] + u);
+    r.ps = rr + RL.off[RTOC_RIC_S] + t;
+    return r;
+  };
+  constexpr int H = NX < FWD_HEAD ? NX : FWD_HEAD;
+  double ha[H], hp[H], vec, sv;
+  {
+    const StageRows r0 = stage_rows(0);
+#pragma unroll
+    for (int j = 0; j < H; ++j) {
+      ha[j] = r0.pa[j * r0.sa];
+      hp[j] = r0.pp[j * NX];
+    }
+    vec = *r0.pv;  // Fx[t] | k[u] | m[m]
+    sv = *r0.ps;
+  }
   for (int st = 0; st < N; ++st) {
-    const rtoc_grid g = a.grid[st];
+    // grid descriptor from the LDS table: a global read here waits, on gfx9's single vector-memory counter, for the
+    // acknowledgement of the previous stage's stores as well -- a write round trip per stage with nothing else in flight
+    const int gb = __builtin_amdgcn_readfirstlane(sGridTab[st]);
+    const GridBits g = {gb & 15, (gb >> 4) & 1, (gb >> 5) & 1, (gb >> 6) & 1, gb >> 8};
     const bool impact = g.type == RTOC_GRID_IMPACT, lift = g.type == RTOC_GRID_LIFT;
     const bool sto = g.sto != 0, sto_next = g.sto_next != 0;
     const double* kr = kb + (size_t)st * KL.stride;
@@ -92,29 +160,50 @@ __global__ __launch_bounds__(64 * NWF) void riccati_forward_kernel(FwdArgs a) {
           if (sto) acc += rr[RL.off[RTOC_RIC_SCAL] + RTOC_RIC_SCAL_DTSDTS] * dts;
           sRed[0] = acc;
         }
-        __syncthreads();
+        fwd_sync<NWF>();
         dtsn = sRed[0];
-        __syncthreads();
+        fwd_sync<NWF>();
       }
     }
 
-    // ---- row products: threads < NX: Fxx dx and P dx ; threads NX..NX+NU-1: K dx ----
+    const bool xrow = tid < NX;
+    const bool krow = !impact && tid >= NX && tid < NX + NU;
+    const bool mrow = MFOLD && g.switching_constraint && tid >= NX + NU && tid < NX + NU + g.dims;
+    const int u = krow ? tid - NX : 0;
+    const int m = mrow ? tid - NX - NU : 0;
+    const StageRows r = stage_rows(st);
+    double bv[NU];
     double acc_a = 0.0, acc_p = 0.0;
-    if (tid < NX) {
-      const double* A = kr + KL.off[RTOC_KKT_FXX] + tid;
-      const double* P = rr + RL.off[RTOC_RIC_P] + tid;
-#pragma unroll FWD_UNROLL
-      for (int j = 0; j < NX; ++j) {
-        const double x = dx[j];
-        acc_a += A[j * NX] * x;
-        acc_p += P[j * NX] * x;
+#pragma unroll
+    for (int j = 0; j < H; ++j) {  // the head, in flight since the previous stage
+      const double x = dx[j];
+      acc_a += ha[j] * x;
+      acc_p += hp[j] * x;
+    }
+#pragma unroll((NX - H + 1) / 2 > 0 ? (NX - H + 1) / 2 : 1)
+    for (int j = H; j < NX; ++j) {
+      const double x = dx[j];
+      acc_a += r.pa[j * r.sa] * x;
+      acc_p += r.pp[j * NX] * x;
+    }
+    {  // the row of Fvu, needed by the tail: behind the last column, in front of the next head
+      const double* Bv = kr + KL.off[RTOC_KKT_FVU] + ((tid >= NV && tid < NX) ? tid - NV : 0);
+#pragma unroll
+      for (int c = 0; c < NU; ++c) bv[c] = Bv[c * NV];
+    }
+    double vec_n, sv_n;
+    {
+      const StageRows rn = stage_rows(st + 1);  // st + 1 <= N: the terminal records exist, what is read there is dropped
+#pragma unroll
+      for (int j = 0; j < H; ++j) {
+        ha[j] = rn.pa[j * rn.sa];
+        hp[j] = rn.pp[j * NX];
       }
-    } else if (!impact && tid < NX + NU) {
-      const int u = tid - NX;
-      const double* K = rr + RL.off[RTOC_RIC_K] + (size_t)u * NX;  // row u of row-major K
-#pragma unroll 6
-      for (int j = 0; j < NX; ++j) acc_a += K[j] * dx[j];
-      double du = acc_a + rr[RL.off[RTOC_RIC_KV] + u];
+      vec_n = *rn.pv;
+      sv_n = *rn.ps;
+    }
+    if (krow) {
+      double du = acc_a + vec;
       if (sto) {
         du += rr[RL.off[RTOC_RIC_T] + u] * (dtsn - dts);
         if (sto_next) du -= rr[RL.off[RTOC_RIC_W] + u] * dtsn;
@@ -122,14 +211,13 @@ __global__ __launch_bounds__(64 * NWF) void riccati_forward_kernel(FwdArgs a) {
       sDu[u] = du;
       dr[DL.off[RTOC_DIR_DU] + u] = du;
     }
-    __syncthreads();
-    if (tid < NX) {
-      double v = kr[KL.off[RTOC_KKT_FX] + tid] + acc_a;
+    fwd_sync<NWF>();
+    if (xrow) {
+      double v = vec + acc_a;
       if (!impact) {
         if (tid >= NV) {
-          const double* Bv = kr + KL.off[RTOC_KKT_FVU] + (tid - NV);
-#pragma unroll 4
-          for (int u = 0; u < NU; ++u) v += Bv[u * NV] * sDu[u];
+#pragma unroll
+          for (int c = 0; c < NU; ++c) v += bv[c] * sDu[c];
         }
         if (sto) v += kr[KL.off[RTOC_KKT_FFX] + tid] * (dtsn - dts);
       }
@@ -138,7 +226,7 @@ __global__ __launch_bounds__(64 * NWF) void riccati_forward_kernel(FwdArgs a) {
     }
     if (impact && sto_next) {
       // riccati_recursion.cpp:101-107: dts_next of d[i+1] from sto_policy_[i] and dx[i+1]
-      __syncthreads();
+      fwd_sync<NWF>();
       if (tid == 0) {
         double acc = 0.0;
         for (int k = 0; k < NX; ++k) acc += rr[RL.off[RTOC_RIC_DTSDX] + k] * dxn[k];
@@ -146,12 +234,12 @@ __global__ __launch_bounds__(64 * NWF) void riccati_forward_kernel(FwdArgs a) {
         if (sto) acc += rr[RL.off[RTOC_RIC_SCAL] + RTOC_RIC_SCAL_DTSDTS] * dts;
         sRed[0] = acc;
       }
-      __syncthreads();
+      fwd_sync<NWF>();
       dtsn = sRed[0];
     }
     // ---- costate (riccati_factorizer.cpp:243-262) ----
     if (tid < NX) {
-      double lam = acc_p - rr[RL.off[RTOC_RIC_S] + tid];
+      double lam = acc_p - sv;
       if (sto) {
         if (impact) {
           lam -= rr[RL.off[RTOC_RIC_PHI] + tid] * dtsn;
@@ -163,7 +251,16 @@ __global__ __launch_bounds__(64 * NWF) void riccati_forward_kernel(FwdArgs a) {
       dr[DL.off[RTOC_DIR_DLMDGMM] + tid] = lam;
     }
     // ---- switching-constraint multiplier (:265-277) ----
-    if (NS > 0 && g.switching_constraint && tid < g.dims) {
+    if constexpr (MFOLD) {
+      if (mrow) {
+        double acc = acc_a + vec;
+        if (sto) {
+          acc += rr[RL.off[RTOC_RIC_MT] + m] * (dtsn - dts);
+          if (sto_next) acc -= rr[RL.off[RTOC_RIC_MTN] + m] * dtsn;
+        }
+        dr[DL.off[RTOC_DIR_DXI] + m] = acc;
+      }
+    } else if (NS > 0 && g.switching_constraint && tid < g.dims) {
       const double* M = rr + RL.off[RTOC_RIC_M] + tid;
       double acc = 0.0;
       for (int j = 0; j < NX; ++j) acc += M[j * NS] * dx[j];
@@ -178,8 +275,10 @@ __global__ __launch_bounds__(64 * NWF) void riccati_forward_kernel(FwdArgs a) {
       dr[DL.off[RTOC_DIR_DTS] + 0] = dts;
       dr[DL.off[RTOC_DIR_DTS] + 1] = dtsn;
     }
-    __syncthreads();
+    fwd_sync<NWF>();
     cur ^= 1;
+    vec = vec_n;
+    sv = sv_n;
   }
   // terminal costate (riccati_recursion.cpp:128-130)
   {
@@ -189,7 +288,7 @@ __global__ __launch_bounds__(64 * NWF) void riccati_forward_kernel(FwdArgs a) {
     if (tid < NX) {
       const double* P = rr + RL.off[RTOC_RIC_P] + tid;
       double acc = 0.0;
-#pragma unroll 6
+#pragma unroll FWD_UNROLL
       for (int j = 0; j < NX; ++j) acc += P[j * NX] * dx[j];
       dr[DL.off[RTOC_DIR_DLMDGMM] + tid] = acc - rr[RL.off[RTOC_RIC_S] + tid];
     }

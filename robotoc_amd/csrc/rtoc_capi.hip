@@ -950,7 +950,7 @@ static int launch_forward_range(rtoc_ctx* c, int first, int end, hipStream_t str
   a.first = first;
   // (a structured-Fxx form of this kernel -- top half of Fxx not read, 15 % fewer bytes -- was measured at 1.27 vs
   // 1.28 ms: the kernel is bound by its load queue, not by the bytes it requests; not kept)
-  hipLaunchKernelGGL(c->ks->fwd, dim3(end - first), dim3(c->ks->fwd_threads), 0, stream, a);
+  hipLaunchKernelGGL(c->ks->fwd, dim3(end - first), dim3(c->ks->fwd_threads), (size_t)((a.nstages + 3) & ~3) * sizeof(int), stream, a);  // grid table in LDS
   HIP_TRY(hipGetLastError());
   return RTOC_OK;
 }

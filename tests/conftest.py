@@ -41,8 +41,8 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
     for test, items in helpers.PARITY.items():
         label, obs, tol = max(items, key=lambda it: it[1] / it[2] if it[2] > 0 else 0.0)
         agg = {}
-        for lb, ob, tl in items:   # per comparison kind (instance / seed numbers stripped): worst observed, its tolerance
-            key = re.sub(r"\s*(inst|seed)\s*\d+", "", lb).strip()
+        for lb, ob, tl in items:   # per comparison kind (instance / seed numbers stripped): worst observed, its bound
+            key = helpers.parity_key(lb)
             if key not in agg or ob > agg[key][0]:
                 agg[key] = [ob, tl]
         rows.append({"test": test, "checks": len(items), "closest": label.strip(), "observed": obs, "tolerance": tol,
@@ -57,8 +57,9 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
         pass
     tr = terminalreporter
     tr.write_line("")
-    tr.write_line("PARITY: %d tests registered %d comparisons (observed error / asserted tolerance; closest to its bound first)"
-                  % (len(rows), sum(r["checks"] for r in rows)))
+    pinned = sum(len(v) for v in helpers.parity_pins().values())
+    tr.write_line("PARITY: %d tests registered %d comparisons (observed error / bound = min(asserted tolerance, regression pin); "
+                  "closest to its bound first; %d pins loaded)" % (len(rows), sum(r["checks"] for r in rows), pinned))
     for r in rows[:45]:
         name = r["test"].split("tests/")[-1]
         tr.write_line("  %-98s %9.2e / %7.0e  [%s]" % (name[:98], r["observed"], r["tolerance"], r["closest"][:40]))
