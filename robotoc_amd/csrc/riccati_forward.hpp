@@ -20,6 +20,9 @@ namespace rtoc {
 #ifndef FWD_UNROLL
 #define FWD_UNROLL 18
 #endif
+#ifndef FWD_REST_PARTS
+#define FWD_REST_PARTS 2  // the remaining columns are walked in this many load batches
+#endif
 #ifndef FWD_HEAD
 #define FWD_HEAD 8  // columns of the next stage requested ahead of the tail of this one
 #endif
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(64 * NWF, 4) void riccati_forward_kernel(FwdArgs a)
       acc_a += ha[j] * x;
       acc_p += hp[j] * x;
     }
-#pragma unroll((NX - H + 1) / 2 > 0 ? (NX - H + 1) / 2 : 1)
+#pragma unroll((NX - H + FWD_REST_PARTS - 1) / FWD_REST_PARTS > 0 ? (NX - H + FWD_REST_PARTS - 1) / FWD_REST_PARTS : 1)
     for (int j = H; j < NX; ++j) {
       const double x = dx[j];
       acc_a += r.pa[j * r.sa] * x;
