@@ -108,7 +108,10 @@ inline KernelSet make_set() {
     }
   }
   constexpr int NWF = (2 * NV + NU + 63) / 64;
-  k.fwd = riccati_forward_kernel<NV, NU, NS, NWF>;
+  if constexpr (NWF == 1)
+    k.fwd = riccati_forward_kernel<NV, NU, NS, 1>;
+  else
+    k.fwd = riccati_forward_mw_kernel<NV, NU, NS, NWF>;
   k.fwd_threads = 64 * NWF;
   k.dl = StaticLayout<NV, NU, NS>::make().dir;
   k.cl = StaticLayout<NV, NU, NS>::make().cdd;

@@ -159,18 +159,16 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a, const
   // the vector wave's dependent chains (Cholesky, policy) are the critical path of a stage and can
   // only issue in the gaps of the matrix wave's MFMA stream on the shared SIMD: take those gaps first
   if constexpr (!MW) __builtin_amdgcn_s_setprio(3);
-  // Grid descriptors through the SCALAR cache (constant address space: s_load, counted by lgkmcnt).  A vector load --
-  // also the one-stage-ahead per-lane prefetch this kernel used to carry -- is counted by vmcnt together with the STORES
-  // of the stage before (gfx9 has one vector-memory counter), and the compiler waits for it with vmcnt(0): the vector
-  // wave then sat at every stage top until the last store of the previous stage was acknowledged, the matrix wave behind
-  // it waiting for Bv / Quu.  The table is a few hundred bytes that every wave of the chip reads: scalar-cache hits.
+  // grid descriptors one stage ahead: a scalar load at the stage top would put an HBM/L2 round trip
+  // on the critical path of every stage
+  // (a scalar load shares its wait counter with the LDS traffic: the first LDS wait after it would
+  // absorb the whole latency; a vector load of the eight ints of the descriptor -- lane l holds int l --
+  // has its own counter and is read back with v_readlane at the next stage top).
   static_assert(offsetof(rtoc_grid, type) == 0 && offsetof(rtoc_grid, sto) == 4 && offsetof(rtoc_grid, sto_next) == 8 &&
-                    offsetof(rtoc_grid, dims) == 20 && sizeof(rtoc_grid) % 4 == 0,
-                "field map of the scalar grid reads");
-  typedef const int __attribute__((address_space(4))) * grid_words;
-  constexpr int GW = sizeof(rtoc_grid) / 4;
-  const grid_words gtab = (grid_words)(unsigned long long)a.grid;
-  int type_behind = gtab[N * GW];
+                    offsetof(rtoc_grid, dims) == 20 && sizeof(rtoc_grid) >= 32,
+                "lane <-> field map of the grid prefetch");
+  int gv_ahead = reinterpret_cast<const int*>(a.grid + (N >= 1 ? N - 1 : 0))[tid0 & 7];
+  int type_behind = a.grid[N].type;
   for (int st = N - 1; st >= 0; --st) {
     // opaque per-stage thread index: see riccati_backward.hpp (keeps LICM from pinning VGPRs)
     tid = tid0;
@@ -182,13 +180,13 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a, const
     constexpr bool mw = MW;       // matrix wave
     const int vt = tid - 64;      // vector-wave thread index (negative on the matrix wave)
     rtoc_grid g, gn;  // the fields of grid[st], grid[st + 1] this kernel reads
-    g.type = gtab[st * GW + 0];
-    g.sto = gtab[st * GW + 1];
-    g.sto_next = gtab[st * GW + 2];
-    g.dims = gtab[st * GW + 5];
-    const int sto_prev = gtab[(st > 0 ? st - 1 : 0) * GW + 1];  // grid[st - 1].sto
+    g.type = __builtin_amdgcn_readlane(gv_ahead, 0);
+    g.sto = __builtin_amdgcn_readlane(gv_ahead, 1);
+    g.sto_next = __builtin_amdgcn_readlane(gv_ahead, 2);
+    g.dims = __builtin_amdgcn_readlane(gv_ahead, 5);
     gn.type = type_behind;
     type_behind = g.type;
+    gv_ahead = reinterpret_cast<const int*>(a.grid + (st > 0 ? st - 1 : 0))[lane & 7];  // grid[st - 1]
     const bool impact = (g.type == RTOC_GRID_IMPACT);
     const bool next_lift = (gn.type == RTOC_GRID_LIFT);
     const int ns = impact ? 0 : g.dims;
@@ -198,7 +196,7 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a, const
 
     RTOC_PROF(0);
     RTOC_PROFV(16);
-#define RTOC_GRID_PREV_STO (sto_prev != 0)
+#define RTOC_GRID_PREV_STO (__builtin_amdgcn_readlane(gv_ahead, 1) != 0)
 #define RTOC_PT_TOP_SYNC() do { if (do_pt) RTOC_BLOCK_SYNC(); } while (0)  // the roll needs no barrier here
 #include "riccati_pt_block.inc"
 #undef RTOC_PT_TOP_SYNC
