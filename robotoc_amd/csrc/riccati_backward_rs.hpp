@@ -383,6 +383,12 @@ __device__ __forceinline__ void riccati_backward_rs_body(const BwdArgs& a, const
       // row k = 4 ks + q of A takes part in the structured k-steps iff it is one of the dense rows R
       auto in_R = [&](int ks) { return 4 * ks + q < NP_ || 4 * ks + q >= NV; };
       if constexpr (SA) {
+        // The two scale factors below are read from A in LDS: A must be THERE.  On an impact grid this wave gets here
+        // straight from the Bv / Quu flag (no PB / G products in between) while the vector wave is still unpacking A --
+        // and c differs between impact grids (0) and their neighbours (dt).  The stale read never showed with the
+        // vector wave's loads drained in front of the flag (its vmcnt(0) at the stage top), and at 7 of 100k
+        // instance-sweeps without (tools/determinism_probe.py).
+        lds_wait(sFlag + 2, 3 * (N - st) - 1);  // A, Qxu, Fx in LDS
         // [P+; PB^T] S: column j of the result is a scaled COPY of column src(j) of [P+; PB^T]
         //   j in [NP, NV): a * col j        j in [NV + NP, NX): c * col (j - NV)
         // for the column tiles that are multiplied over R only (all but the last, which carries the Fx / fx riders

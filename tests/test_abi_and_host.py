@@ -85,3 +85,18 @@ def test_jump_sto_grid_flags():
 def test_uniform_grid():
     g = G.uniform_grid(20, 0.05)
     assert len(g) == 21 and all(x.type == GRID_INTERMEDIATE for x in g[:-1])
+
+
+def test_bench_counter_pass_is_refused_unless_measured_on_or_carried_over_to_these_sources(monkeypatch):
+    """bench.py: a committed counter pass (traffic, fp64 flops) counts only if it carries the hash of the library's kernel
+    sources, or names that hash in a hand-written carry-over entry with its justification -- which then appears in the line."""
+    import bench
+    monkeypatch.setattr(bench, "kernel_source_hash", lambda: "aaaa")
+    ok, note = bench.counter_pass_valid({"_kernel_source_hash": "aaaa"})
+    assert ok and "matches" in note
+    ok, note = bench.counter_pass_valid({"_kernel_source_hash": "bbbb"})
+    assert not ok and "stale" in note
+    ok, note = bench.counter_pass_valid({"_kernel_source_hash": "bbbb", "_carried_over": [{"to": "cccc", "change": "x"}]})
+    assert not ok
+    ok, note = bench.counter_pass_valid({"_kernel_source_hash": "bbbb", "_carried_over": [{"to": "aaaa", "change": "flag wait moved"}]})
+    assert ok and "CARRIED OVER" in note and "flag wait moved" in note and "bbbb" in note
