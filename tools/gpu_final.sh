@@ -3,6 +3,8 @@
 # counter passes (tools/gpu_pmc2.sh: FETCH / WRITE / two SQ sets over tools/pmc_driver.py), kernel statistics of the closed-loop
 # iteration, and the summaries written ON THE BOX into gpurun_out/summary (the raw traces exceed what gpurun copies back).
 # Afterwards, locally:  cp gpurun_out/summary/* profiles/
+# After a kernel change that moves a summation order: record the regression pins again first --
+#   gpurun -- 'RTOC_PARITY_PINS=0 python -m pytest tests -q -m gpu'  &&  python tools/make_parity_pins.py   (tests/golden/parity_pins.json)
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out
@@ -23,6 +25,8 @@ if [ -f $R/robotoc_amd/librtoc_hip_prof.so ]; then RTOC_HIP_LIB=$R/robotoc_amd/l
 rm -rf $OUT/prof_sto
 timeout 200 python tools/dvfs_probe.py > $OUT/summary/${TAG}_dvfs_probe.txt 2>&1
 timeout 200 python tools/icub_bwd_bench.py > $OUT/summary/${TAG}_icub_backward.txt 2>&1
+# run-to-run determinism of the headline sweep, records compared bit for bit (instance / stage / field of anything that differs)
+timeout 150 python tools/determinism_probe.py 40 > $OUT/summary/${TAG}_determinism.txt 2>&1
 RTOC_PROFILE_OUT=$OUT/summary python tools/summarize_profiles.py $TAG "closing run of the round" > $OUT/summarize.log 2>&1
 cp $OUT/closed_loop_kernel_stats.txt $OUT/summary/${TAG}_closed_loop_kernel_stats.txt
 cp $OUT/host_cpu.txt $OUT/summary/${TAG}_host_cpu.txt 2>/dev/null
