@@ -8,8 +8,10 @@ from robotoc_amd import capi, problems as pr
 from robotoc_amd.types import BUF_KKT, BUF_DX0, BUF_RIC, BUF_DIR, Records
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-batch = 4096
-dims, grids, _ = pr.config_anymal_trot()
+cfg = os.environ.get("PROBE_CONFIG", "anymal_trot")   # anymal_trot | anymal_jump_sto | icub35 | icub32
+batch = int(os.environ.get("PROBE_BATCH", "4096" if cfg.startswith("anymal") else "512"))
+dims, grids, _ = {"anymal_trot": pr.config_anymal_trot, "anymal_jump_sto": pr.config_anymal_jump_sto,
+                  "icub35": lambda: pr.config_icub_jump(nv=35), "icub32": lambda: pr.config_icub_jump(nv=32)}[cfg]()
 ctx = capi.Context(dims, len(grids), batch, 0)
 L = ctx.L
 ctx.set_grid(grids)
@@ -45,5 +47,5 @@ for it in range(reps):
                     fields.append(f)
             print("run %d: %s differs in %d words, instances %s%s, stages %s..%s, fields %s" % (
                 it, name, int(ne.sum()), inst[:8], "..." if len(inst) > 8 else "", stages[0], stages[-1], fields))
-print("%d runs, %d record sets differ from the first run" % (reps, bad))
+print("%s x %d: %d runs, %d record sets differ from the first run" % (cfg, batch, reps, bad))
 ctx.close()
