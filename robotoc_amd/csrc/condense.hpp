@@ -104,12 +104,16 @@ struct CondCfg {
   static constexpr int O_LD = O_D + pad8(LDV * NX);            // MJtJinv_dIDCdqv    LDV x NX
   // region X: {M -> L, J, J Minv, S, -(S)^-1} while MJtJinv is built, then Qafu_full
   static constexpr int O_X = O_LD + pad8(LDV * NX);
-  static constexpr int O_L = O_X;                              // NV x NV
+  static constexpr int X_A = pad8(NV * NV) + 2 * pad8(NFP * NV) + 2 * pad8(NFP * NFP);
+  // FUSE (the one-kernel condensation on contact shapes): the factorisation scratch is dead before MJtJinv_dIDCdqv is born
+  // and lives in ITS region; the cone rows ride in wave 1 while wave 0 factorises M (their scratch: the not yet initialised
+  // MJtJinv).  ANYmal: 37.2 -> 31.1 KB = 25 LDS granules, five work items per CU like the split kernel.
+  static constexpr bool FUSE = !SPLIT && NF > 0 && X_A <= pad8(LDV * NX) && RTOC_COND_NW >= 2 && ConeScratch<NV, NF>::DOUBLES <= LDV * LDV;
+  static constexpr int O_L = FUSE ? O_LD : O_X;                // NV x NV
   static constexpr int O_J = O_L + pad8(NV * NV);              // NF x NV (ld NFP)
   static constexpr int O_JM = O_J + pad8(NFP * NV);            // NF x NV
   static constexpr int O_S = O_JM + pad8(NFP * NV);            // NF x NF
   static constexpr int O_BR = O_S + pad8(NFP * NFP);           // NF x NF
-  static constexpr int X_A = O_BR + pad8(NFP * NFP) - O_X;
   static constexpr int Y_ROOM = O_BR + pad8(NFP * NFP) - O_JM;  // J M^-1, S, bottomRight: free while M is factorised
   static constexpr int X_B = pad8(LDV * NV);                   // Qafu_full LDV x NV
   // The split kernel gets MJtJinv from mjtjinv_kernel: no factorisation scratch (X_A).  And once MJtJinv_dIDCdqv and
@@ -117,9 +121,9 @@ struct CondCfg {
   // (bottomLeft is stored as a copy of topRight^T, condense_mjtjinv.inc): with nu <= nf_max the actuated columns of
   // Qafu_full live there (TAIL) and region X holds its passive columns only.  ANYmal: 37.2 -> 29.9 KB = 24 of the 128
   // LDS granules (1280 B) of a CU, five work items per CU instead of four.
-  static constexpr bool TAIL = SPLIT && NF > 0 && NU <= NF;
+  static constexpr bool TAIL = (SPLIT || FUSE) && NF > 0 && NU <= NF;
   static constexpr int X_T = pad8(LDV * (NV - NU) > 8 ? LDV * (NV - NU) : 8);
-  static constexpr int X_SZ = TAIL ? X_T : (SPLIT ? X_B : (X_A > X_B ? X_A : X_B));
+  static constexpr int X_SZ = TAIL ? X_T : ((SPLIT || FUSE) ? X_B : (X_A > X_B ? X_A : X_B));
   static constexpr int O_QAFU = O_X;
   static constexpr int O_QFF = O_X + X_SZ;                     // NF x NF
   static constexpr int O_QQF = O_QFF + pad8(NFP * NFP);        // NV x NF
@@ -133,7 +137,7 @@ struct CondCfg {
   static constexpr int LDS_BYTES = LDS_DOUBLES * 8;
   // work items per CU by LDS (160 KB in granules of 1280 B) -> waves per SIMD the register budget has to allow
   static constexpr int ITEMS = 128 / ((LDS_BYTES + 1279) / 1280);
-  static constexpr int MIN_WAVES = TAIL && (ITEMS * NW + 3) / 4 >= 4 ? 4 : 1;
+  static constexpr int MIN_WAVES = TAIL && (ITEMS * NW + 3) / 4 >= 4 ? 4 : ((FUSE && (ITEMS * NW + 3) / 4 >= 2) ? ((ITEMS * NW + 3) / 4 >= 3 ? 3 : 2) : 1);
 };
 
 // One-wave dense product on the f64 matrix cores with generic (row, column) strides:
@@ -393,6 +397,7 @@ __global__ __launch_bounds__(64 * RTOC_COND_NW, (CondCfg<NV, NU, NF, NS, SPLIT>:
   RTOC_CPROF(0);
   // ================= HBM -> registers: every input field once, all loads in flight together ======
   // 16 B per lane; odd-sized fields read/write one double of their 64-B padding
+  constexpr bool FUSE = C::FUSE;
   constexpr int H_L = (NV * NV + 1) / 2, H_D = (LDV * NX + 1) / 2, H_J = (C::NFP * NV + 1) / 2,
                 H_F = (C::NFP * C::NFP + 1) / 2;
   constexpr int N_L = (H_L + NT - 1) / NT, N_D = (H_D + NT - 1) / NT, N_J = (H_J + NT - 1) / NT,
@@ -403,47 +408,62 @@ __global__ __launch_bounds__(64 * RTOC_COND_NW, (CondCfg<NV, NU, NF, NS, SPLIT>:
   const dbl2 zero2 = {0.0, 0.0};
   // compile-time trip counts (arrays stay in registers) and unconditional loads from clamped
   // addresses: every field exists in the max-size record whatever dimf is, and a load under a branch
-  // would get its own s_waitcnt -- one HBM round trip per field
+  // would get its own s_waitcnt -- one HBM round trip per field.  (Lanes past the end hold a copy of element 0 and
+  // never store it: no select.)
 #define RTOC_LD2(dst, CNT, src, n2)                                              \
   _Pragma("unroll") for (int k = 0; k < (CNT); ++k) {                            \
     const int e = lane + k * NT;                                                 \
-    const dbl2 v = reinterpret_cast<const dbl2*>(src)[e < (n2) ? e : 0];         \
-    dst[k] = (e < (n2)) ? v : zero2;                                             \
+    dst[k] = reinterpret_cast<const dbl2*>(src)[e < (n2) ? e : 0];               \
   }
 #define RTOC_ST2(dst, src, CNT, n2)                                              \
   _Pragma("unroll") for (int k = 0; k < (CNT); ++k) {                            \
     const int e = lane + k * NT;                                                 \
     if (e < (n2)) reinterpret_cast<dbl2*>(dst)[e] = src[k];                      \
   }
-  if constexpr (!SPLIT) {
+  // FUSE: wave 0 alone fetches what it factorises -- M and both candidates of J (dCda on contact grids, dCdv inside
+  // dIDCdqv on impact grids), from addresses that do not depend on the grid descriptor -- and starts on them while the
+  // other waves are still waiting for their loads
+  constexpr int N_L0 = (H_L + 63) / 64, N_J0 = (C::NFP * NV + 63) / 64;
+  dbl2 fL[FUSE ? N_L0 : 1];
+  double fJ[FUSE ? N_J0 : 1], fJi[FUSE ? N_J0 : 1];
+  if constexpr (FUSE) {
+    if (wv == 0) {
+#pragma unroll
+      for (int k = 0; k < N_L0; ++k) {
+        const int e = wl + k * 64;
+        fL[k] = reinterpret_cast<const dbl2*>(cr + CL.off[RTOC_CDD_DIDDA])[e < H_L ? e : 0];
+      }
+#pragma unroll
+      for (int k = 0; k < N_J0; ++k) {
+        const int e = wl + k * 64, r = e % LDF, c = e / LDF;
+        const bool ok = c < NV;
+        fJ[k] = cr[CL.off[RTOC_CDD_DCDA] + (ok ? r + c * LDF : 0)];
+        fJi[k] = cr[CL.off[RTOC_CDD_DIDCDQV] + NV + NV * LDV + (ok ? r + c * LDV : 0)];
+      }
+    }
+  } else if constexpr (!SPLIT) {
     RTOC_LD2(gL, N_L, cr + CL.off[RTOC_CDD_DIDDA], H_L)
     RTOC_LD2(gJ, N_J, cr + CL.off[RTOC_CDD_DCDA], H_J)
   } else {
     RTOC_LD2(gLam, N_LAM, cr + CL.off[RTOC_CDD_MJTJINV], H_LAM)
   }
-  RTOC_LD2(gD, N_D, cr + CL.off[RTOC_CDD_DIDCDQV], H_D)
-  RTOC_LD2(gF, N_F, cr + CL.off[RTOC_CDD_QFF], H_F)
-  RTOC_LD2(gQ, N_J, cr + CL.off[RTOC_CDD_QQF], H_J)
+  // Everything else the work item reads.  !FUSE: requested here, with the first round trip.  FUSE: behind the barrier
+  // that ends the factorisation of M (RTOC_MJ_AFTER_B1 in the fragment below) -- wave 1 of this very work item condenses the
+  // cone rows meanwhile, which add to Qqq (inside Qxx), Qqf, Qff, lq (inside lx) and lf, and the factorisation / the cone
+  // Gram product want the registers these values would occupy; they arrive while MJtJinv is assembled.
   const int lv_ = lane < NV ? lane : 0, lf_ = lane < nf ? lane : 0, lvf_ = lane < nvf ? lane : 0;
-  const double vQaa = cr[CL.off[RTOC_CDD_QAA] + lv_], vLa = cr[CL.off[RTOC_CDD_LA] + lv_],
-               vHa = cr[CL.off[RTOC_CDD_HA] + lv_], vLf = cr[CL.off[RTOC_CDD_LF] + lf_],
-               vHf = cr[CL.off[RTOC_CDD_HF] + lf_], vIdc = cr[CL.off[RTOC_CDD_IDC] + lvf_];
-  // gradient / sensitivity entries that get one read-modify-write at the end: fetched now as well
   const int ix_ = lane < NX ? lane : 0, iv_ = lane < NV ? lane : 0;
-  const double pLx = lx[ix_], pHx = hx[ix_], pFf = fx[ix_], pFxv = Fx[NV + iv_];
-  const double pLup = lup[iv_ < NP ? iv_ : 0], pLu = lu[iv_ >= NP ? iv_ - NP : 0], pHu = hu[iv_ >= NP ? iv_ - NP : 0];
-  const double pSh = scal[RTOC_KKT_SCAL_H], pSq = scal[RTOC_KKT_SCAL_QTT];
-  // the Hessian blocks the Schur updates read-modify-write: fetched now, consumed ~60k cycles later --
-  // their HBM latency is off the chain
+  double vQaa, vLa, vHa, vHf, vIdc, vLf;
+  // gradient / sensitivity entries that get one read-modify-write at the end
+  double pLx, pHx, pFf, pFxv, pLup, pLu, pHu, pSh, pSq;
+  // the Hessian blocks the Schur updates read-modify-write: fetched early, consumed ~40k cycles later -- their HBM latency
+  // is off the chain
   double cQxx[TileSlots<NW, NX, NX>::value][4];
   double cQxu[TileSlots<NW, NX, NU>::value][4];
   double cQuu[TileSlots<NW, NU, NU>::value][4];
-  prefetch_tiles<NW, NX, NX, NX>(Qxx, lane, cQxx);
-  prefetch_tiles<NW, NX, NU, NX>(Qxu, lane, cQxu);
-  prefetch_tiles<NW, NU, NU, NU>(Quu, lane, cQuu);
-  // The sums stay in LDS and enter the Hessian / gradient entries where those get their one
+  // PDIPM box rows: the sums stay in LDS and enter the Hessian / gradient entries where those get their one
   // read-modify-write below.  Descriptor -> row data is a dependent pair of HBM round trips: the descriptor
-  // load rides with the field loads above, the row data is requested as soon as it is back (after the
+  // load rides with the field loads, the row data is requested as soon as it is back (after the
   // registers -> LDS stage) and consumed ahead of the Schur updates, ~15k cycles of products later.
   double* const sPH = smem + C::V_PH;
   double* const sPG = smem + C::V_PG;
@@ -452,79 +472,169 @@ __global__ __launch_bounds__(64 * RTOC_COND_NW, (CondCfg<NV, NU, NF, NS, SPLIT>:
   const bool box_lane = box_on && lane < 2 * NV + NU;
   int4 pd = make_int4(-1, -1, 0, 0);
   int ent0 = 0, ent1 = 0;  // rows of the entry beyond the first two: CSR range
-  if (box_on) {
-    const int t = lane < 2 * NV + NU ? lane : 0;
-    pd = a.pair[t];
-    ent0 = a.entry[t] + 2;
-    ent1 = a.entry[t + 1];
+#define RTOC_FIELD_LOADS                                                                                     \
+  RTOC_LD2(gD, N_D, cr + CL.off[RTOC_CDD_DIDCDQV], H_D)                                                       \
+  RTOC_LD2(gF, N_F, cr + CL.off[RTOC_CDD_QFF], H_F)                                                           \
+  RTOC_LD2(gQ, N_J, cr + CL.off[RTOC_CDD_QQF], H_J)                                                           \
+  vQaa = cr[CL.off[RTOC_CDD_QAA] + lv_], vLa = cr[CL.off[RTOC_CDD_LA] + lv_], vHa = cr[CL.off[RTOC_CDD_HA] + lv_]; \
+  vLf = cr[CL.off[RTOC_CDD_LF] + lf_], vHf = cr[CL.off[RTOC_CDD_HF] + lf_], vIdc = cr[CL.off[RTOC_CDD_IDC] + lvf_]; \
+  pLx = lx[ix_], pHx = hx[ix_], pFf = fx[ix_], pFxv = Fx[NV + iv_];                                            \
+  pLup = lup[iv_ < NP ? iv_ : 0], pLu = lu[iv_ >= NP ? iv_ - NP : 0], pHu = hu[iv_ >= NP ? iv_ - NP : 0];      \
+  pSh = scal[RTOC_KKT_SCAL_H], pSq = scal[RTOC_KKT_SCAL_QTT];                                                  \
+  prefetch_tiles<NW, NX, NX, NX>(Qxx, lane, cQxx);                                                             \
+  prefetch_tiles<NW, NX, NU, NX>(Qxu, lane, cQxu);                                                             \
+  prefetch_tiles<NW, NU, NU, NU>(Quu, lane, cQuu);                                                             \
+  if (box_on) {                                                                                                \
+    const int t = lane < 2 * NV + NU ? lane : 0;                                                               \
+    pd = a.pair[t];                                                                                            \
+    ent0 = a.entry[t] + 2;                                                                                     \
+    ent1 = a.entry[t + 1];                                                                                     \
+  }
+  if constexpr (!FUSE) {
+    RTOC_FIELD_LOADS
   }
   RTOC_CPROF(21);
-  // inactive rows / columns (dimf < max_dimf) of the stored blocks stay zero, like the reference's
-  // max-size backing matrices
-  if constexpr (!SPLIT)
-    for (int e = lane; e < LDV * LDV; e += NT) Lam[e] = 0.0;
-  for (int e = lane; e < LDV * NX; e += NT) LD[e] = 0.0;
-  RTOC_CPROF(22);
-  // ================= registers -> LDS =================
-  if constexpr (!SPLIT) {
-    RTOC_ST2(sL, gL, N_L, H_L)
-    RTOC_ST2(sJ, gJ, N_J, H_J)
-  } else {
-    RTOC_ST2(Lam, gLam, N_LAM, H_LAM)
-  }
-  RTOC_ST2(D, gD, N_D, H_D)
-  RTOC_ST2(Qff, gF, N_F, H_F)
-  RTOC_ST2(Qqf, gQ, N_J, H_J)
-#undef RTOC_LD2
-#undef RTOC_ST2
   // one lane per primal entry (q_k, v_k, u_k): the first two rows of the entry (a lower and an upper limit:
   // all there is for joint limits) come from the packed descriptor; their data is fetched unconditionally
   double* const nr = box_on ? a.con + ((size_t)b * a.nstages + st) * a.nl.stride : nullptr;
   double bs0 = 1.0, bd0 = 0.0, bq0 = 0.0, bc0 = 0.0, bs1 = 1.0, bd1 = 0.0, bq1 = 0.0, bc1 = 0.0;
-  if (box_on) {
-    const int* no = a.nl.off;
-    const int r0 = pd.x >= 0 ? pd.x : 0, r1 = pd.y >= 0 ? pd.y : 0;
-    bs0 = nr[no[RTOC_CON_SLACK] + r0], bd0 = nr[no[RTOC_CON_DUAL] + r0], bq0 = nr[no[RTOC_CON_RESIDUAL] + r0],
-    bc0 = nr[no[RTOC_CON_CMPL] + r0];
-    bs1 = nr[no[RTOC_CON_SLACK] + r1], bd1 = nr[no[RTOC_CON_DUAL] + r1], bq1 = nr[no[RTOC_CON_RESIDUAL] + r1],
-    bc1 = nr[no[RTOC_CON_CMPL] + r1];
+#define RTOC_BOX_LOADS                                                                                              \
+  if (box_on) {                                                                                                     \
+    const int* no = a.nl.off;                                                                                       \
+    const int r0 = pd.x >= 0 ? pd.x : 0, r1 = pd.y >= 0 ? pd.y : 0;                                                \
+    bs0 = nr[no[RTOC_CON_SLACK] + r0], bd0 = nr[no[RTOC_CON_DUAL] + r0], bq0 = nr[no[RTOC_CON_RESIDUAL] + r0],      \
+    bc0 = nr[no[RTOC_CON_CMPL] + r0];                                                                               \
+    bs1 = nr[no[RTOC_CON_SLACK] + r1], bd1 = nr[no[RTOC_CON_DUAL] + r1], bq1 = nr[no[RTOC_CON_RESIDUAL] + r1],      \
+    bc1 = nr[no[RTOC_CON_CMPL] + r1];                                                                               \
   }
-  RTOC_CPROF(23);
-  if (lane < NV) {
-    Qaa[lane] = vQaa;
-    laf[lane] = vLa;
-    haf[lane] = vHa;
-  }
-  if (lane < NF) {  // zero beyond the active contact dimension: the products run over the full extents
-    laf[NV + lane] = lane < nf ? -vLf : 0.0;
-    haf[NV + lane] = lane < nf ? -vHf : 0.0;
-  }
+  // registers -> LDS; vectors zero beyond the active contact dimension (the products run over the full extents)
+#define RTOC_FIELD_STORES                            \
+  RTOC_ST2(D, gD, N_D, H_D)                          \
+  RTOC_ST2(Qff, gF, N_F, H_F)                        \
+  RTOC_ST2(Qqf, gQ, N_J, H_J)                        \
+  RTOC_BOX_LOADS                                     \
+  RTOC_CPROF(23);                                    \
+  if (lane < NV) {                                   \
+    Qaa[lane] = vQaa;                                \
+    laf[lane] = vLa;                                 \
+    haf[lane] = vHa;                                 \
+  }                                                  \
+  if (lane < NF) {                                   \
+    laf[NV + lane] = lane < nf ? -vLf : 0.0;         \
+    haf[NV + lane] = lane < nf ? -vHf : 0.0;         \
+  }                                                  \
   if (lane < LDV) IDC[lane] = lane < nvf ? vIdc : 0.0;
-  __syncthreads();
-  if (nf < NF) {
-    // inactive rows / columns of the max-size blocks are unspecified in the record: zero them in
-    // LDS so that every product below can use its compile-time extents
-    for (int e = lane; e < (LDV - nvf) * NX; e += NT) D[nvf + e % (LDV - nvf) + (e / (LDV - nvf)) * LDV] = 0.0;
-    if (!impact) {
-      if constexpr (!SPLIT)
-        for (int e = lane; e < (NF - nf) * NV; e += NT) sJ[nf + e % (NF - nf) + (e / (NF - nf)) * LDF] = 0.0;
+  if constexpr (!FUSE) {
+    // inactive rows / columns (dimf < max_dimf) of the stored blocks stay zero, like the reference's
+    // max-size backing matrices
+    if constexpr (!SPLIT)
+      for (int e = lane; e < LDV * LDV; e += NT) Lam[e] = 0.0;
+    for (int e = lane; e < LDV * NX; e += NT) LD[e] = 0.0;
+    RTOC_CPROF(22);
+    // ================= registers -> LDS =================
+    if constexpr (!SPLIT) {
+      RTOC_ST2(sL, gL, N_L, H_L)
+      RTOC_ST2(sJ, gJ, N_J, H_J)
     } else {
-      // J = dCdv lives inside D (rows NV.., columns NV..): its inactive rows were zeroed with D's
+      RTOC_ST2(Lam, gLam, N_LAM, H_LAM)
     }
-    for (int e = lane; e < LDF * LDF; e += NT)
-      if (e % LDF >= nf || e / LDF >= nf) Qff[e] = 0.0;
-    for (int e = lane; e < NV * (NF - nf); e += NT) Qqf[nf * NV + e] = 0.0;
+    RTOC_FIELD_STORES
     __syncthreads();
   }
+  // inactive rows / columns of the max-size blocks are unspecified in the record: zero them in
+  // LDS so that every product below can use its compile-time extents
+#define RTOC_ZERO_PADDING                                                                                           \
+  if (nf < NF) {                                                                                                    \
+    for (int e = lane; e < (LDV - nvf) * NX; e += NT) D[nvf + e % (LDV - nvf) + (e / (LDV - nvf)) * LDV] = 0.0;    \
+    if constexpr (!SPLIT && !FUSE)                                                                                  \
+      if (!impact) /* (impact: J = dCdv lives inside D, its inactive rows were zeroed with D's) */                  \
+        for (int e = lane; e < (NF - nf) * NV; e += NT) sJ[nf + e % (NF - nf) + (e / (NF - nf)) * LDF] = 0.0;       \
+    for (int e = lane; e < LDF * LDF; e += NT)                                                                      \
+      if (e % LDF >= nf || e / LDF >= nf) Qff[e] = 0.0;                                                             \
+    for (int e = lane; e < NV * (NF - nf); e += NT) Qqf[nf * NV + e] = 0.0;                                         \
+    __syncthreads();                                                                                                \
+  }
+  if constexpr (!FUSE) {
+    RTOC_ZERO_PADDING
+  }
   // J: dCda (ld NF) on contact grids, dCdv = D[nv:, nv:] (ld LDV) on impact grids
-  const double* const J = impact ? D + NV + (size_t)NV * LDV : sJ;
+  const double* const Jd = impact ? D + NV + (size_t)NV * LDV : sJ;
+  const double* const J = FUSE ? sJ : Jd;
   const int ldj = impact ? LDV : LDF;
 
-  if constexpr (!SPLIT) {
+  if constexpr (FUSE) {
+    // ---- wave roles until the factor of M exists: 0 factorises, 1 condenses the cone rows ----
+    if (wv == 0) {
+#pragma unroll
+      for (int k = 0; k < N_L0; ++k) {
+        const int e = wl + k * 64;
+        if (e < H_L) reinterpret_cast<dbl2*>(sL)[e] = fL[k];
+      }
+#pragma unroll
+      for (int k = 0; k < N_J0; ++k) {  // rows >= dimf are zero; J in sJ with ld NF on contact and impact grids alike
+        const int e = wl + k * 64;
+        if (e < C::NFP * NV) sJ[e] = (e % LDF < nf) ? (impact ? fJi[k] : fJ[k]) : 0.0;
+      }
+      wave_lds_sync_();
+    } else if (wv == 1) {
+      // Constraints::condenseSlackAndDual of the cone rows (intermediate_stage.cpp:134-135) ahead of everything that reads
+      // Qqq, Qqf, Qff, lq, lf; scratch: the not yet initialised MJtJinv
+      if (a.cone_rows != 0) {
+        static_assert(ConeScratch<NV, NF>::DOUBLES <= LDV * LDV, "cone scratch is aliased onto MJtJinv");
+        ConeArgs ca;
+        ca.kkt = a.kkt;
+        ca.cdd = a.cdd;
+        ca.con = a.cone_con;
+        ca.cone = a.cone;
+        ca.dir = nullptr;
+        ca.grid = a.grid;
+        ca.steps = nullptr;
+        ca.nstages = a.nstages;
+        ca.batch = a.batch;
+        ca.max_contacts = a.cone_contacts;
+        ca.contact_dim = a.cone_dim;
+        ca.row0 = a.cone_row0;
+        ca.rows_per_contact = a.cone_rows;
+        ca.cone_stride = a.cone_stride;
+        ca.dgdf_off = a.cone_dgdf_off;
+        ca.impact_cones = a.cone_impact;
+        ca.tau = 0.0;
+        ca.kl = a.kl;
+        ca.cl = a.cl;
+        ca.nl = a.nl;
+        ca.dl = a.cl;  // unused by the condensation
+        ca.prof = nullptr;
+        if (a.cone_rows == RTOC_WRENCH_ROWS)
+          wrench_condense_body<NV, NF>(ca, b, st, wl, Lam);
+        else
+          cone_condense_body<NV, NF>(ca, b, st, wl, Lam);
+        cone_wave_sync();
+      }
+      for (int e = wl; e < LDV * LDV; e += 64) Lam[e] = 0.0;
+    }
+#define RTOC_MJ_AFTER_LLT
+#define RTOC_MJ_AFTER_B1 RTOC_FIELD_LOADS
+#define RTOC_J_IN_D false
+#include "condense_mjtjinv.inc"
+#undef RTOC_J_IN_D
+#undef RTOC_MJ_AFTER_LLT
+#undef RTOC_MJ_AFTER_B1
+    // MJtJinv is complete: out to HBM before its columns nv.. are recycled (TAIL); the fields into LDS
+    copy_s2g_flat16<NT>(cr + CL.off[RTOC_CDD_MJTJINV], Lam, LDV * LDV, lane);
+    RTOC_FIELD_STORES
+    __syncthreads();
+    RTOC_ZERO_PADDING
+  } else if constexpr (!SPLIT) {
 #define RTOC_J_IN_D impact
 #include "condense_mjtjinv.inc"
 #undef RTOC_J_IN_D
   }
+#undef RTOC_LD2
+#undef RTOC_ST2
+#undef RTOC_FIELD_LOADS
+#undef RTOC_FIELD_STORES
+#undef RTOC_ZERO_PADDING
+#undef RTOC_BOX_LOADS
 
   RTOC_CPROF(4);
   // ================= MJtJinv_dIDCdqv, MJtJinv_IDC (contact_dynamics.cpp:64-65 / impact :44-50) ===
@@ -532,7 +642,7 @@ __global__ __launch_bounds__(64 * RTOC_COND_NW, (CondCfg<NV, NU, NF, NS, SPLIT>:
     lds_gemm<NW, LDV, NX, LDV, 1, LDV, 1, LDV>(Lam, D, lane, [&](int r, int c, double v, int, int) { LD[r + c * LDV] = v; });
   } else {
     lds_gemm<NW, LDV, NV, LDV, 1, LDV, 1, LDV>(Lam, D, lane, [&](int r, int c, double v, int, int) { LD[r + c * LDV] = v; });
-    lds_gemm<NW, LDV, NV, C::NFP, 1, LDV, 1, LDV>(Lam + NV * LDV, J, lane,
+    lds_gemm<NW, LDV, NV, C::NFP, 1, LDV, 1, LDV>(Lam + NV * LDV, Jd, lane,
                                                   [&](int r, int c, double v, int, int) { LD[r + (NV + c) * LDV] = v; });
   }
   wave_gemv<NT>(LDV, LDV, 1.0, Lam, 1, LDV, IDC, 0.0, Lr, lane);  // full extents: zero rows give Lr = 0 there
@@ -746,7 +856,7 @@ __global__ __launch_bounds__(64 * RTOC_COND_NW, (CondCfg<NV, NU, NF, NS, SPLIT>:
 
   RTOC_CPROF(8);
   // ================= LDS -> HBM: the ContactDynamicsData the expansion needs, each field once ====
-  if constexpr (!SPLIT) copy_s2g_flat16<NT>(cr + CL.off[RTOC_CDD_MJTJINV], Lam, LDV * LDV, lane);
+  if constexpr (!SPLIT && !C::FUSE) copy_s2g_flat16<NT>(cr + CL.off[RTOC_CDD_MJTJINV], Lam, LDV * LDV, lane);
   copy_s2g_flat16<NT>(cr + CL.off[RTOC_CDD_MJD], LD, LDV * NX, lane);
   if (a.keep_qaf) {  // scratch of the reference's expandContactDynamicsDual; expand_kernel rebuilds what it needs of them
     copy_s2g_flat16<NT>(cr + CL.off[RTOC_CDD_QAFQV], Qafqv, LDV * NX, lane);

@@ -60,6 +60,7 @@ struct KernelSet {
   cond_fn cond_split, mjt;  // split condensation: MJtJinv kernel + the rest
   int mjt_lds;
   int cond_threads, cond_lds, cond_split_lds;
+  int cond_fuses_cones;  // the one-kernel condensation condenses the friction / wrench cone rows itself (CondCfg::FUSE)
   expd_fn expd;
   int expd_threads;
   // horizon scan of the backward recursion (riccati_scan.hpp)
@@ -135,6 +136,7 @@ inline KernelSet make_set() {
   k.cond_threads = CondCfg<NV, NU, NF, NS>::NT;
   k.cond_lds = CondCfg<NV, NU, NF, NS>::LDS_BYTES;
   k.cond_split_lds = CondCfg<NV, NU, NF, NS, true>::LDS_BYTES;
+  k.cond_fuses_cones = CondCfg<NV, NU, NF, NS>::FUSE ? 1 : 0;
   // regression guard for the occupancy the quadruped shape is sized for (condense.hpp: five / ten work items per CU)
   static_assert(!(NV == 18 && NU == 12 && NS == 12) ||
                     (CondCfg<NV, NU, NF, NS, true>::ITEMS >= 5 && CondCfg<NV, NU, NF, NS, true>::MIN_WAVES == 4 && MjCfg<NV, NF>::ITEMS >= 10),

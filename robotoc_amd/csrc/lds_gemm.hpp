@@ -31,13 +31,21 @@ struct TileOps {
     const bool iok = i < M, jok = j < N;
     const double* ap = A + (iok ? i : 0) * ARS + q * ACS;
     const double* bp = B + (jok ? j : 0) * BCS + q * BRS;
+    // Rows i >= M of A / columns j >= N of B only reach output rows / columns the epilogue never sees: they read the
+    // (finite) clamped row / column 0 and need no select.  Only the k-steps that run past K are zeroed (in both
+    // operands: whatever lies behind the operand in LDS may not be finite).
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      const bool kok = (ks * 4 + 3 < K) || (ks * 4 + q < K);
-      const double a = ap[(kok ? ks : 0) * 4 * ACS];
-      const double b = bp[(kok ? ks : 0) * 4 * BRS];
-      av[ks] = (iok && kok) ? a : 0.0;
-      bv[ks] = (jok && kok) ? b : 0.0;
+      if (ks * 4 + 3 < K) {
+        av[ks] = ap[ks * 4 * ACS];
+        bv[ks] = bp[ks * 4 * BRS];
+      } else {
+        const bool kok = ks * 4 + q < K;
+        const double a = ap[(kok ? ks : 0) * 4 * ACS];
+        const double b = bp[(kok ? ks : 0) * 4 * BRS];
+        av[ks] = kok ? a : 0.0;
+        bv[ks] = kok ? b : 0.0;
+      }
     }
   }
 };
@@ -101,7 +109,8 @@ __device__ __forceinline__ void lds_gemm2(const double* __restrict__ A1, const d
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = tm * 16 + drow(q, r), col = tn * 16 + li;
-      if (row < M && col < N) epilogue(row, col, acc[r], acc2[r], t / NW, r);
+      // (the second product's operand rows >= M2 are not zeroed on load, TileOps::load: drop them here)
+      if (row < M && col < N) epilogue(row, col, acc[r], ((tm + 1) * 16 <= M2 || row < M2) ? acc2[r] : 0.0, t / NW, r);
     }
   }
 }

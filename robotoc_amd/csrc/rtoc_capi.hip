@@ -300,6 +300,9 @@ static int create_members(rtoc_ctx* c, const rtoc_dims* dims, const KernelSet* k
   for (int i = 0; i < RTOC_MAX_CHUNK_EVENTS; ++i)
     HIP_TRY(hipEventCreateWithFlags(&c->ev_chunk[i], hipEventDisableTiming));
   c->condense_split = 1;
+  // RTOC_CONDENSE_SPLIT=0|1 in the environment: default of RTOC_OPT_CONDENSE_SPLIT for contexts created afterwards (runs the
+  // whole test suite / bench on the other condensation pipeline without touching the callers)
+  if (const char* e = getenv("RTOC_CONDENSE_SPLIT")) c->condense_split = (e[0] == '0') ? 0 : 1;
   c->sweep_chunks = 1;  // measured on MI355X: chunked pipelining does not pay (forward waves do not fit next to the backward waves)
   const size_t per = (size_t)batch * max_stages;
   c->count[RTOC_BUF_KKT] = per * c->L.kkt.stride;
@@ -1008,7 +1011,7 @@ static int launch_condense(rtoc_ctx* c) {
   a.cone_rows = 0;
   a.keep_qaf = c->keep_qaf;
   a.dt_inst = c->sto_on ? c->d_dt : nullptr;
-  if (c->condense_split && c->cone_contacts > 0) {  // the cone rows ride with the MJtJinv kernel
+  if ((c->condense_split || c->ks->cond_fuses_cones) && c->cone_contacts > 0) {  // the cone rows ride with the MJtJinv kernel / in wave 1 of the fused kernel
     if (!c->buf[RTOC_BUF_CONE] || !c->buf[RTOC_BUF_CON]) return RTOC_ERR_NOT_READY;
     const bool wrench = c->cone_rows == RTOC_WRENCH_ROWS;
     a.cone_rows = c->cone_rows;
@@ -1147,7 +1150,7 @@ int rtoc_compute_initial_state_direction(rtoc_ctx* c) {
 int rtoc_condense(rtoc_ctx* c) {
   CHECK_READY(c);
   int rc = RTOC_OK;
-  if (c->cone_contacts > 0 && !c->condense_split) rc = launch_cones(c, 0, 0.0);  // Constraints::condenseSlackAndDual first
+  if (c->cone_contacts > 0 && !c->condense_split && !c->ks->cond_fuses_cones) rc = launch_cones(c, 0, 0.0);  // Constraints::condenseSlackAndDual first
   if (!rc) rc = launch_condense(c);
   if (!rc && c->buf[RTOC_BUF_SE3] && c->dims.np == 6) rc = launch_state_correction(c, 0);
   return rc;
