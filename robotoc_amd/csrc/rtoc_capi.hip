@@ -122,8 +122,11 @@ static bool model_has_surface_contacts(const rtoc_robot_model& m) {
 // different models (iCub: 11 tree levels, ANYmal: 4) share it, so it only ever grows (the launch passes its own size)
 static hipError_t set_linearize_lds(const rtoc_robot_model& m, int nlevels) {
   static std::mutex mu;
-  static int max_bytes = 0;
+  static int max_bytes_of[64] = {};   // the attribute is per DEVICE: one running maximum for each (the current one: callers hipSetDevice first)
   std::lock_guard<std::mutex> lock(mu);
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  int& max_bytes = max_bytes_of[dev];
   int bytes = (int)rbd::lin_lds_bytes(nlevels, m.njoints, m.ncontacts, m.nv);
   if (bytes <= max_bytes) return hipSuccess;
   hipError_t e = hipFuncSetAttribute((const void*)rbd::linearize_contact_dynamics_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -785,7 +788,7 @@ static int ensure_scan_buffers(rtoc_ctx* c) {
       const size_t n = per * (i < 2 ? ks->scan_elt_stride : ks->scan_ps_stride);
       HIP_TRY(hipMalloc((void**)&c->d_scan[i], n * sizeof(double)));
     }
-  if (!c->d_scan_sto) HIP_TRY(hipMalloc((void**)&c->d_scan_sto, per * ks->sto_scr_stride * sizeof(double)));
+  if (!c->d_scan_sto && grid_has_sto(c)) HIP_TRY(hipMalloc((void**)&c->d_scan_sto, per * ks->sto_scr_stride * sizeof(double)));  // (grids with STO only)
   return RTOC_OK;
 }
 
@@ -2591,7 +2594,10 @@ int rtoc_contact_line_search(rtoc_ctx* c, int* host_trials) {
   int nactive = 0, trials = 0;
   HIP_TRY(hipMemcpyAsync(&nactive, a.nactive, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
-  while (nactive > 0 && trials < 64) {
+  // the backtracking of one instance ends once its step falls below min_step_size (line_search.cpp:64-80): at most
+  // log(min_step) / log(rate) reductions from a full step; the bound only guards against a loop that never drains
+  const int max_trials = (int)ceil(log(c->ls_min_step < 1.0 ? c->ls_min_step : 1.0) / log(c->ls_rate)) + 2;
+  while (nactive > 0 && trials < max_trials) {
     rc = eval_ocp_trial(c, c->d_ls_steps, c->d_eval + 2 * c->batch);
     if (rc) return rc;
     rc = launch_filter_device(c, c->d_eval + 2 * c->batch, c->d_ls_active, 0);   // isAccepted + augment of the active instances

@@ -72,6 +72,7 @@ class ContactSequence {
   unsigned phaseMask(const int phase) const { return masks_.at(std::min(phase, numContactPhases() - 1)); }
   const std::vector<double>& phasePositions(const int phase) const { return pos_.at(std::min(phase, numContactPhases() - 1)); }
   unsigned impactMask(const int event) const { return masks_.at(event + 1) & ~masks_.at(event); }
+  int contactRows(const int k) const { return rows_.at(k); }
   int dimf(const unsigned mask) const {
     int d = 0;
     for (int k = 0; k < nc_; ++k)
@@ -237,20 +238,27 @@ class SolutionInterpolator {
   }
   bool hasStoredSolution() const { return has_; }
   // sol: [td.size()][L.sol.stride] zero-initialised records of the new discretisation
+  // contact_rows[c]: 3 (point) or 6 (surface contact) stack rows of contact c (ContactSequence::contactRows); empty: 3 each
   void interpolate(const rtoc_layout& L, const int ncontacts, const bool floating_base, const TimeDiscretization& td,
-                   const std::vector<unsigned>& masks, std::vector<double>& sol) const {
+                   const std::vector<unsigned>& masks, std::vector<double>& sol, const std::vector<int>& contact_rows = {}) const {
     if (!has_) return;
+    std::vector<int> rw(ncontacts, 3), ro(ncontacts + 1, 0);   // rows and by-contact offsets
+    for (int c = 0; c < ncontacts; ++c) {
+      if (!contact_rows.empty()) rw[c] = contact_rows.at(c);
+      ro[c + 1] = ro[c] + rw[c];
+    }
+    const int nrows = ro[ncontacts];
     const int n0 = td_.size(), N1 = td.size() - 1, stride = L.sol.stride, nv = L.dims.nv, nu = L.dims.nu, nq = nv + (floating_base ? 1 : 0);
     const int* o = L.sol.off;
     auto rec0 = [&](int i) { return sol_.data() + static_cast<size_t>(i) * stride; };
     auto rec1 = [&](int i) { return sol.data() + static_cast<size_t>(i) * stride; };
-    auto expand = [&](const double* r, unsigned mask, int field, std::vector<double>& out) {   // [ncontacts][3] by contact index
-      out.assign(static_cast<size_t>(ncontacts) * 3, 0.0);
-      int k = 0;
+    auto expand = [&](const double* r, unsigned mask, int field, std::vector<double>& out) {   // rows of contact c at ro[c], by contact index
+      out.assign(static_cast<size_t>(nrows), 0.0);
+      int k = 0;   // rows of the active contacts so far (the compacted stack)
       for (int c = 0; c < ncontacts; ++c)
         if ((mask >> c) & 1u) {
-          for (int j = 0; j < 3; ++j) out[3 * c + j] = r[o[field] + 3 * k + j];
-          ++k;
+          for (int j = 0; j < rw[c]; ++j) out[ro[c] + j] = r[o[field] + k + j];
+          k += rw[c];
         }
     };
     auto put_stack = [&](double* r, unsigned mask, int field, const std::vector<double>& by_contact) {
@@ -258,8 +266,8 @@ class SolutionInterpolator {
       int k = 0;
       for (int c = 0; c < ncontacts; ++c)
         if ((mask >> c) & 1u) {
-          for (int j = 0; j < 3; ++j) r[o[field] + 3 * k + j] = by_contact[3 * c + j];
-          ++k;
+          for (int j = 0; j < rw[c]; ++j) r[o[field] + k + j] = by_contact[ro[c] + j];
+          k += rw[c];
         }
     };
     auto lerp = [&](double* out, const double* a, const double* b, int field, int n, double alpha) {
@@ -287,8 +295,8 @@ class SolutionInterpolator {
         f = fa, mu = ma;
         for (int c = 0; c < ncontacts; ++c)
           if ((masks_[b] >> c) & 1u)
-            for (int j = 0; j < 3; ++j)
-              f[3 * c + j] = (1.0 - alpha) * fa[3 * c + j] + alpha * fb[3 * c + j], mu[3 * c + j] = (1.0 - alpha) * ma[3 * c + j] + alpha * mb[3 * c + j];
+            for (int j = ro[c]; j < ro[c + 1]; ++j)
+              f[j] = (1.0 - alpha) * fa[j] + alpha * fb[j], mu[j] = (1.0 - alpha) * ma[j] + alpha * mb[j];
       } else if (mode == PARTIAL) {   // interpolatePartial (:149-172)
         take(out, ra, RTOC_SOL_U, nu), take(out, ra, RTOC_SOL_A, nv), take(out, ra, RTOC_SOL_BETA, nv), take(out, ra, RTOC_SOL_NUP, np);
         f = fa, mu = ma;

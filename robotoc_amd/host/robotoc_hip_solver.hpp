@@ -718,6 +718,10 @@ class OCPSolver {
     const bool interp = solver_options_.enable_solution_interpolation && masks != nullptr;
     if (interp) {
       // correctTimeSteps + store (:186-189): the grid times that belong to the current event times
+      // (the device's time steps date from the last evalKKT, BEFORE integrateSolution moved the event times: correct them first,
+      // as the reference does, or the stored impact / lift times never match the new grid's and the event solutions are rebuilt
+      // by the initEventSolution blend instead of being copied)
+      chk(rtoc_sto_correct_time_steps(dev_->get()), "rtoc_sto_correct_time_steps");
       std::vector<double> dt(time_discretization_.size());
       chk(rtoc_sto_get_time_steps(dev_->get(), dt.data(), 1), "rtoc_sto_get_time_steps");
       double tt = t_;
@@ -732,8 +736,11 @@ class OCPSolver {
     discretize(t);                                                                              // :190
     if (interp) {
       std::vector<double> sol(static_cast<size_t>(time_discretization_.size()) * L_.sol.stride, 0.0);
-      solution_interpolator_.interpolate(L_, ocp_.source->contactSequence()->numContacts(), ocp_.robot.dim_passive > 0, time_discretization_,
-                                         *ocp_.source->contactMasks(), sol);
+      const ContactSequence* cs = ocp_.source->contactSequence();
+      std::vector<int> contact_rows(cs->numContacts());
+      for (int c = 0; c < cs->numContacts(); ++c) contact_rows[c] = cs->contactRows(c);
+      solution_interpolator_.interpolate(L_, cs->numContacts(), ocp_.robot.dim_passive > 0, time_discretization_,
+                                         *ocp_.source->contactMasks(), sol, contact_rows);
       chk(rtoc_upload(dev_->get(), RTOC_BUF_SOL, 0, sol.data(), sol.size()), "rtoc_upload(RTOC_BUF_SOL)");
       host_solution_valid_ = false;
     }

@@ -291,6 +291,9 @@ class OCPSolver:
     def _mesh_refinement(self, t):
         old_grids, old_masks = self.grids, self.masks
         old_sol = self.get_solution()
+        # correctTimeSteps(contact_sequence_, t) ahead of solution_interpolator_.store (ocp_solver.cpp:186-189): the device's time
+        # steps date from the last evalKKT, before integrateSolution moved the event times
+        self.ctx.sto_correct_time_steps()
         old_dt = self.ctx.sto_time_steps()
         self.discretize(t)   # new structure at the current event times, per-instance time steps on the device
         new_dt = self.ctx.sto_time_steps()
@@ -305,13 +308,14 @@ class OCPSolver:
         self.ctx.line_search_clear()
 
     def _expand(self, rec, mask, name):
-        """contact-indexed [ncontacts, 3] view of the compacted f / mu stack of a record"""
-        out, k = np.zeros((self.nc, 3)), 0
+        """contact-indexed [ncontacts, 6] view (3 or 6 rows used per contact: point / surface) of the compacted f / mu stack"""
+        out, k = np.zeros((self.nc, 6)), 0
         x = self.S.f(rec, name)
         for cidx in range(self.nc):
             if (int(mask) >> cidx) & 1:
-                out[cidx] = x[3 * k:3 * k + 3]
-                k += 1
+                r = self.model.contact_rows(cidx)
+                out[cidx, :r] = x[k:k + r]
+                k += r
         return out
 
     def _interpolate(self, g0, m0, t0s, dt0, s0, g1, m1, t1s, s1):
@@ -328,8 +332,9 @@ class OCPSolver:
             x[:] = 0.0
             for cidx in range(self.nc):
                 if (int(mask) >> cidx) & 1:
-                    x[3 * k:3 * k + 3] = by_contact[cidx]
-                    k += 1
+                    r = self.model.contact_rows(cidx)
+                    x[k:k + r] = by_contact[cidx, :r]
+                    k += r
 
         def blend(i, a, b, alpha, mode):
             """mode: full (interpolate :119-146), partial (:149-172), event (initEventSolution :175-198)"""

@@ -7,7 +7,8 @@
 
 Per test and comparison kind (instance / seed numbers stripped) the pin is 10x the worst observed error, rounded up to
 two significant digits, never above the tolerance the test asserts; comparisons that came out exactly equal get no pin
-(their tolerance stays the bound).  tests/helpers.py: record_parity asserts against min(tolerance, pin)."""
+(their tolerance stays the bound).  tests/helpers.py: record_parity asserts against min(tolerance, max(pin, 1e-13)):
+a pin never binds below a few hundred ulps."""
 import json
 import math
 import os
