@@ -162,16 +162,20 @@ enum {
   RTOC_CDD_NFIELDS
 };
 
-/* One PDIPM inequality row of a joint-limit component (the six Joint{Position,Velocity,Torques}
- * {Lower,Upper}Limit classes, e.g. src/constraints/joint_torques_lower_limit.cpp:50-83): a bound on a
- * single primal variable.  g(z) = sign * z[index] - bound <= 0, i.e. sign = -1 for a lower limit
- * (xmin - x <= 0) and +1 for an upper limit (x - xmax <= 0). */
+/* One PDIPM inequality row of a joint-limit component (the eight Joint{Position,Velocity,Acceleration,Torques}
+ * {Lower,Upper}Limit classes, e.g. src/constraints/joint_torques_lower_limit.cpp:50-83,
+ * joint_acceleration_lower_limit.cpp:50-95): a bound on a single primal variable.  g(z) = sign * z[index] - bound <= 0,
+ * i.e. sign = -1 for a lower limit (xmin - x <= 0) and +1 for an upper limit (x - xmax <= 0).
+ * RTOC_VAR_A rows act on Qaa.diagonal() / la of the ContactDynamicsData record (RTOC_CDD_QAA, RTOC_CDD_LA) BEFORE the
+ * contact-dynamics condensation reads them (contact_dynamics.cpp:68-86), level 0, contact path only; rtoc_condense
+ * leaves the updated diagonal in RTOC_CDD_QAA like the reference leaves it in kkt_matrix.Qaa. */
 #define RTOC_VAR_Q 0
 #define RTOC_VAR_V 1
 #define RTOC_VAR_U 2
+#define RTOC_VAR_A 3
 typedef struct rtoc_box_row {
-  int var;   /* RTOC_VAR_Q / _V / _U                                                       */
-  int index; /* entry of q / v (0..nv-1; joint limits use the tail nu entries) or u (0..nu-1) */
+  int var;   /* RTOC_VAR_Q / _V / _U / _A                                                  */
+  int index; /* entry of q / v / a (0..nv-1; joint limits use the tail nu entries) or u (0..nu-1) */
   int sign;  /* -1 lower limit, +1 upper limit                                            */
   int level; /* KinematicsLevel: 0 acceleration (torques), 1 velocity, 2 position;
                 active on a grid iff time_stage >= level (src/constraints/constraints_data.cpp:20-45),

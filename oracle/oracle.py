@@ -63,7 +63,7 @@ def lib():
                                             C.c_double, C.POINTER(C.c_uint)]
         _LIB.orc_expand_batch.argtypes = [C.POINTER(Layout), C.POINTER(Grid), C.c_int, C.c_int, dp, dp]
         _LIB.orc_pdipm_batch.argtypes = [C.POINTER(Layout), C.POINTER(Grid), C.c_int, C.c_int,
-                                         C.POINTER(BoxRow), C.c_int, dp, dp, dp, C.c_double, dp, C.c_int]
+                                         C.POINTER(BoxRow), C.c_int, dp, dp, dp, C.c_double, dp, C.c_int, dp]
         _LIB.orc_state_correction_batch.argtypes = [C.POINTER(Layout), C.POINTER(Grid), C.c_int, C.c_int,
                                                     dp, dp, dp, dp]
         _LIB.orc_unconstr_dynamics_batch.argtypes = [C.POINTER(Layout), C.c_int, C.c_int, dp, dp, dp,
@@ -197,22 +197,24 @@ def _rows(rows):
     return arr
 
 
-def pdipm_condense_batch(L, grids, rows, kkt, con):
+def pdipm_condense_batch(L, grids, rows, kkt, con, cdd=None):
+    """cdd: the ContactDynamicsData records (Qaa diagonal, la) the acceleration-limit rows (VAR_A) act on"""
+    assert cdd is not None or not any(r.var == 3 for r in rows)
     lib().orc_pdipm_batch(C.byref(L), grid_array(grids), len(grids), kkt.shape[0], _rows(rows), len(rows),
-                          _p(kkt), _p(con), None, 0.0, None, 0)
+                          _p(kkt), _p(con), None, 0.0, None, 0, _p(cdd) if cdd is not None else None)
 
 
 def pdipm_expand_batch(L, grids, rows, con, dirs, tau):
     steps = np.ones((con.shape[0], 2))
     lib().orc_pdipm_batch(C.byref(L), grid_array(grids), len(grids), con.shape[0], _rows(rows), len(rows),
-                          None, _p(con), _p(dirs), tau, _p(steps), 1)
+                          None, _p(con), _p(dirs), tau, _p(steps), 1, None)
     return steps
 
 
 def pdipm_update_batch(L, grids, rows, con, steps):
     steps = np.ascontiguousarray(steps, dtype=np.float64)
     lib().orc_pdipm_batch(C.byref(L), grid_array(grids), len(grids), con.shape[0], _rows(rows), len(rows),
-                          None, _p(con), None, 0.0, _p(steps), 2)
+                          None, _p(con), None, 0.0, _p(steps), 2, None)
 
 
 def state_correction_batch(L, grids, se3, kkt=None, dirs=None, dx0=None):

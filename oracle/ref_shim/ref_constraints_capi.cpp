@@ -2,8 +2,8 @@
 // TEST INFRASTRUCTURE ONLY (oracle/_ref/librtoc_ref.so, built by oracle/Makefile.ref from the sources under /root/reference).
 //
 // Reference code that runs here: Constraints (src/constraints/constraints.cpp) with the six joint-limit components
-// (joint_{position,velocity,torques}_{lower,upper}_limit.cpp), FrictionCone / ImpactFrictionCone (friction_cone.cpp,
-// impact_friction_cone.cpp) or ContactWrenchCone (contact_wrench_cone.cpp), ConstraintsData's stage mask
+// (joint_{position,velocity,torques}_{lower,upper}_limit.cpp; ref_accel_limits_stage: joint_acceleration_{lower,upper}_limit.cpp), FrictionCone / ImpactFrictionCone (friction_cone.cpp,
+// impact_friction_cone.cpp) or ContactWrenchCone / ImpactWrenchCone (contact_wrench_cone.cpp, impact_wrench_cone.cpp), ConstraintsData's stage mask
 // (constraints_data.cpp), pdipm.hxx.  What does not: Eigen (oracle/ref_shim/mini_eigen.hpp) and Pinocchio -- the frame
 // kinematics the cones read (world rotation and LOCAL Jacobian of the contact frames) are INJECTED by the caller, so what is
 // pinned is the reference's composition of them (the rigid-body kinematics themselves stay unpinned).
@@ -14,6 +14,9 @@
 #include "robotoc/constraints/contact_wrench_cone.hpp"
 #include "robotoc/constraints/friction_cone.hpp"
 #include "robotoc/constraints/impact_friction_cone.hpp"
+#include "robotoc/constraints/impact_wrench_cone.hpp"
+#include "robotoc/constraints/joint_acceleration_lower_limit.hpp"
+#include "robotoc/constraints/joint_acceleration_upper_limit.hpp"
 #include "robotoc/constraints/joint_position_lower_limit.hpp"
 #include "robotoc/constraints/joint_position_upper_limit.hpp"
 #include "robotoc/constraints/joint_torques_lower_limit.hpp"
@@ -77,6 +80,7 @@ int ref_constraints_stage(int nv, int nu, int ncontacts, int contact_dim, int ti
     constraints->add("impact_friction_cone", std::make_shared<ImpactFrictionCone>(robot));
   } else if (cone_kind == 2) {
     constraints->add("contact_wrench_cone", std::make_shared<ContactWrenchCone>(robot, X, Y));
+    constraints->add("impact_wrench_cone", std::make_shared<ImpactWrenchCone>(robot, X, Y));   // the impact-level twin (impact grids)
   }
   // contact status of the grid point
   ContactStatus cs = robot.createContactStatus();
@@ -192,6 +196,49 @@ int ref_constraints_stage(int nv, int nu, int ncontacts, int contact_dim, int ti
   for (int i = 0; i < nx; ++i) lx[i] = kr.lx(i);
   for (int i = 0; i < nu; ++i) lu[i] = kr.lu(i);
   for (int i = 0; i < dimf; ++i) lf[i] = kr.lf()(i);
+  return 0;
+}
+
+// JointAccelerationLowerLimit / JointAccelerationUpperLimit (src/constraints/joint_acceleration_{lower,upper}_limit.cpp) inside the
+// reference's Constraints object, one grid point.  Rows: lower limits (nu), then upper limits (nu).  phase_mask as above.
+// Qaa_diag / la: SplitKKTMatrix::Qaa.diagonal() / SplitKKTResidual::la (nv each, in / out); a, da: nv each.
+int ref_accel_limits_stage(int nv, int nu, int time_stage, int impact, const double* amin, const double* amax, double barrier, double tau,
+                           const double* a, int phase_mask, double* slack, double* dual, double* residual, double* cmpl, double* cond,
+                           double* dslack, double* ddual, double* Qaa_diag, double* la, const double* da, double* steps) {
+  Robot robot(nv, nu, std::vector<ContactType>());
+  Eigen::VectorXd lo(nu), hi(nu);
+  for (int i = 0; i < nu; ++i) lo(i) = amin[i], hi(i) = amax[i];
+  auto constraints = std::make_shared<Constraints>(barrier, tau);
+  constraints->add("joint_acceleration_lower", std::make_shared<JointAccelerationLowerLimit>(robot, lo));
+  constraints->add("joint_acceleration_upper", std::make_shared<JointAccelerationUpperLimit>(robot, hi));
+  ContactStatus cs = robot.createContactStatus();
+  ImpactStatus is = robot.createImpactStatus();
+  SplitSolution s(robot);
+  if (impact) s.setContactStatus(is);
+  else s.setContactStatus(cs);
+  for (int i = 0; i < nv; ++i) s.a(i) = a[i];
+  SplitKKTMatrix km(robot);
+  SplitKKTResidual kr(robot);
+  SplitDirection d(robot);
+  km.setZero(), kr.setZero();
+  for (int i = 0; i < nv; ++i) km.Qaa(i, i) = Qaa_diag[i], kr.la(i) = la[i];
+  ConstraintsData data = constraints->createConstraintsData(robot, impact ? -1 : time_stage);
+  if (!data.isAccelerationLevelValid()) return 1;   // impact grids carry no acceleration-level rows (constraints_data.cpp:20-45)
+  if (data.acceleration_level_data.size() != 2) return -1;
+  for (int c = 0; c < 2; ++c) load(data.acceleration_level_data[c], slack + c * nu, dual + c * nu, residual + c * nu, cmpl + c * nu, nu);
+  if (phase_mask & 1) constraints->setSlackAndDual(robot, cs, data, s);
+  if (phase_mask & 2) constraints->linearizeConstraints(robot, cs, data, s, kr);
+  if (phase_mask & 4) constraints->condenseSlackAndDual(cs, data, km, kr);
+  if (phase_mask & 8) {
+    for (int i = 0; i < nv; ++i) d.da()(i) = da[i];
+    constraints->expandSlackAndDual(cs, data, d);
+    steps[0] = constraints->maxSlackStepSize(data);
+    steps[1] = constraints->maxDualStepSize(data);
+  }
+  for (int c = 0; c < 2; ++c)
+    store(data.acceleration_level_data[c], slack + c * nu, dual + c * nu, residual + c * nu, cmpl + c * nu, cond + c * nu, dslack + c * nu,
+          ddual + c * nu, nu);
+  for (int i = 0; i < nv; ++i) Qaa_diag[i] = km.Qaa(i, i), la[i] = kr.la(i);
   return 0;
 }
 

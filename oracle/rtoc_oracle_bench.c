@@ -31,7 +31,7 @@ unsigned orc_condense_impact_stage(const rtoc_layout* L, const rtoc_grid* g, dou
                                    double damping);
 void orc_expand_stage(const rtoc_layout* L, const rtoc_grid* g, double* cdd_rec, double* dir_rec, double* dir_next_rec);
 void orc_pdipm_condense_stage(const rtoc_layout* L, const rtoc_grid* g, const rtoc_box_row* rows, int nrows,
-                              double* kkt_rec, double* con_rec);
+                              double* kkt_rec, double* con_rec, double* cdd_rec);
 void orc_pdipm_expand_stage(const rtoc_layout* L, const rtoc_grid* g, const rtoc_box_row* rows, int nrows,
                             const double* dir_rec, double* con_rec, double tau, double* steps);
 void orc_pdipm_update_stage(const rtoc_layout* L, const rtoc_grid* g, const rtoc_box_row* rows, int nrows,
@@ -120,7 +120,7 @@ unsigned orc_bench_sqp(const rtoc_layout* L, const rtoc_grid* grid, int nstages,
           double* kr = k + (size_t)i * L->kkt.stride;
           double* cr = c + (size_t)i * L->cdd.stride;
           double* nr = n + (size_t)i * L->con.stride;
-          if (nrows > 0) orc_pdipm_condense_stage(L, &grid[i], rows, nrows, kr, nr);
+          if (nrows > 0) orc_pdipm_condense_stage(L, &grid[i], rows, nrows, kr, nr, cr);
           if (e) orc_cone_condense_stage(L, &grid[i], max_contacts, contact_dim, e + i * est, kr, cr, nr);
           status |= grid[i].type == RTOC_GRID_IMPACT ? orc_condense_impact_stage(L, &grid[i], kr, cr, 0.0)
                                                      : orc_condense_stage(L, &grid[i], kr, cr, 0.0);

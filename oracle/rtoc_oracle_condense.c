@@ -390,9 +390,11 @@ static int row_active(const rtoc_box_row* r, const rtoc_grid* g) {
   return g->time_stage >= r->level;
 }
 
-/* Constraints::condenseSlackAndDual (constraints.cpp:322-357) for box rows */
+/* Constraints::condenseSlackAndDual (constraints.cpp:322-357) for box rows.  cdd_rec: the ContactDynamicsData record
+ * whose Qaa diagonal / la the acceleration limits act on (joint_acceleration_lower_limit.cpp:69-77, _upper_limit.cpp:69-77);
+ * may be NULL when there are no RTOC_VAR_A rows. */
 void orc_pdipm_condense_stage(const rtoc_layout* L, const rtoc_grid* g, const rtoc_box_row* rows,
-                              int nrows, double* kkt_rec, double* con_rec) {
+                              int nrows, double* kkt_rec, double* con_rec, double* cdd_rec) {
   const int nv = L->dims.nv, nu = L->dims.nu, nx = L->nx;
   const int* ko = L->kkt.off;
   const int* o = L->con.off;
@@ -410,6 +412,9 @@ void orc_pdipm_condense_stage(const rtoc_layout* L, const rtoc_grid* g, const rt
     if (rows[r].var == RTOC_VAR_U) {
       AT(Quu, nu, idx, idx) += dual / slack;
       lu[idx] += rows[r].sign * cond;
+    } else if (rows[r].var == RTOC_VAR_A) {
+      cdd_rec[L->cdd.off[RTOC_CDD_QAA] + idx] += dual / slack; /* Qaa.diagonal().tail(dimc) += dual / slack */
+      cdd_rec[L->cdd.off[RTOC_CDD_LA] + idx] += rows[r].sign * cond; /* la.tail(dimc) -/+= cond */
     } else {
       const int k = rows[r].var == RTOC_VAR_V ? nv + idx : idx;
       AT(Qxx, nx, k, k) += dual / slack;
@@ -431,7 +436,10 @@ void orc_pdipm_expand_stage(const rtoc_layout* L, const rtoc_grid* g, const rtoc
   for (int r = 0; r < nrows; ++r) {
     if (!row_active(&rows[r], g)) continue;
     const int idx = rows[r].index;
-    const double dz = rows[r].var == RTOC_VAR_U ? du[idx] : (rows[r].var == RTOC_VAR_V ? dx[nv + idx] : dx[idx]);
+    /* (acceleration limits: dslack = +/- d.da().tail(dimc) - residual, joint_acceleration_lower_limit.cpp:80-85) */
+    const double dz = rows[r].var == RTOC_VAR_U ? du[idx]
+                                                : (rows[r].var == RTOC_VAR_V ? dx[nv + idx]
+                                                                             : (rows[r].var == RTOC_VAR_A ? dir_rec[L->dir.off[RTOC_DIR_DAF] + idx] : dx[idx]));
     const double slack = con_rec[o[RTOC_CON_SLACK] + r], dual = con_rec[o[RTOC_CON_DUAL] + r];
     const double res = con_rec[o[RTOC_CON_RESIDUAL] + r], cmpl = con_rec[o[RTOC_CON_CMPL] + r];
     const double dslack = -rows[r].sign * dz - res;
@@ -457,7 +465,7 @@ void orc_pdipm_update_stage(const rtoc_layout* L, const rtoc_grid* g, const rtoc
 
 void orc_pdipm_batch(const rtoc_layout* L, const rtoc_grid* grid, int nstages, int batch,
                      const rtoc_box_row* rows, int nrows, double* kkt, double* con, double* dir,
-                     double tau, double* steps, int phase) {
+                     double tau, double* steps, int phase, double* cdd) {
 #pragma omp parallel for schedule(static)
   for (int b = 0; b < batch; ++b) {
     if (phase == 1) {
@@ -468,7 +476,7 @@ void orc_pdipm_batch(const rtoc_layout* L, const rtoc_grid* grid, int nstages, i
       double* kr = kkt ? kkt + ((size_t)b * nstages + i) * L->kkt.stride : 0;
       double* cr = con + ((size_t)b * nstages + i) * L->con.stride;
       double* dr = dir ? dir + ((size_t)b * nstages + i) * L->dir.stride : 0;
-      if (phase == 0) orc_pdipm_condense_stage(L, &grid[i], rows, nrows, kr, cr);
+      if (phase == 0) orc_pdipm_condense_stage(L, &grid[i], rows, nrows, kr, cr, cdd ? cdd + ((size_t)b * nstages + i) * L->cdd.stride : 0);
       if (phase == 1) orc_pdipm_expand_stage(L, &grid[i], rows, nrows, dr, cr, tau, steps + 2 * b);
       if (phase == 2) orc_pdipm_update_stage(L, &grid[i], rows, nrows, cr, steps[2 * b], steps[2 * b + 1]);
     }

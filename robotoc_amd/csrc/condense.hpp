@@ -467,9 +467,10 @@ __global__ __launch_bounds__(64 * RTOC_COND_NW, (CondCfg<NV, NU, NF, NS, SPLIT>:
   // registers -> LDS stage) and consumed ahead of the Schur updates, ~15k cycles of products later.
   double* const sPH = smem + C::V_PH;
   double* const sPG = smem + C::V_PG;
-  static_assert(2 * NV + NU <= NT, "one lane per primal entry");
+  constexpr int NE = 3 * NV + NU;  // primal entries with box rows: q, v, u, a
+  static_assert(NE <= NT, "one lane per primal entry");
   const bool box_on = a.con != nullptr && !impact;
-  const bool box_lane = box_on && lane < 2 * NV + NU;
+  const bool box_lane = box_on && lane < NE;
   int4 pd = make_int4(-1, -1, 0, 0);
   int ent0 = 0, ent1 = 0;  // rows of the entry beyond the first two: CSR range
 #define RTOC_FIELD_LOADS                                                                                     \
@@ -485,7 +486,7 @@ __global__ __launch_bounds__(64 * RTOC_COND_NW, (CondCfg<NV, NU, NF, NS, SPLIT>:
   prefetch_tiles<NW, NX, NU, NX>(Qxu, lane, cQxu);                                                             \
   prefetch_tiles<NW, NU, NU, NU>(Quu, lane, cQuu);                                                             \
   if (box_on) {                                                                                                \
-    const int t = lane < 2 * NV + NU ? lane : 0;                                                               \
+    const int t = lane < NE ? lane : 0;                                                                        \
     pd = a.pair[t];                                                                                            \
     ent0 = a.entry[t] + 2;                                                                                     \
     ent1 = a.entry[t + 1];                                                                                     \
@@ -646,6 +647,55 @@ __global__ __launch_bounds__(64 * RTOC_COND_NW, (CondCfg<NV, NU, NF, NS, SPLIT>:
                                                   [&](int r, int c, double v, int, int) { LD[r + (NV + c) * LDV] = v; });
   }
   wave_gemv<NT>(LDV, LDV, 1.0, Lam, 1, LDV, IDC, 0.0, Lr, lane);  // full extents: zero rows give Lr = 0 there
+  // ================= PDIPM slack/dual elimination of the joint-limit rows =================
+  // Constraints::condenseSlackAndDual (constraints.cpp:322-357, joint_*_limit.cpp, pdipm.hxx:66-69):
+  // purely additive on diag(Qqq), diag(Qvv), diag(Quu), lq, lv, lu, so it commutes with the
+  // contact-dynamics condensation -- except the acceleration limits, whose Qaa / la the condensation consumes:
+  // hence here, between MJtJinv_dIDCdqv and Qafqv; every entry is accumulated by a single lane in row order
+  // (deterministic, no atomics).
+  if (lane < NE) {
+    double hess = 0.0, grad = 0.0;
+    if (box_lane) {
+      const int* no = a.nl.off;
+      if (pd.x >= 0 && g.time_stage >= (pd.z >> 8)) {
+        const double cond = (bd0 * bq0 - bc0) / bs0;
+        nr[no[RTOC_CON_COND] + pd.x] = cond;
+        hess += bd0 / bs0;
+        grad += (double)(signed char)(pd.z & 0xff) * cond;
+      }
+      if (pd.y >= 0 && g.time_stage >= (pd.w >> 8)) {
+        const double cond = (bd1 * bq1 - bc1) / bs1;
+        nr[no[RTOC_CON_COND] + pd.y] = cond;
+        hess += bd1 / bs1;
+        grad += (double)(signed char)(pd.w & 0xff) * cond;
+      }
+      const int* rowid = a.entry + (NE + 1);
+      for (int e = ent0; e < ent1; ++e) {  // further rows on the same entry (none for joint limits)
+        const int r = rowid[e];
+        const rtoc_box_row row = a.rows[r];
+        if (g.time_stage >= row.level) {
+          const double slack = nr[no[RTOC_CON_SLACK] + r], dual = nr[no[RTOC_CON_DUAL] + r];
+          const double cond = (dual * nr[no[RTOC_CON_RESIDUAL] + r] - nr[no[RTOC_CON_CMPL] + r]) / slack;
+          nr[no[RTOC_CON_COND] + r] = cond;
+          hess += dual / slack;
+          grad += row.sign * cond;
+        }
+      }
+    }
+    if (lane < 2 * NV + NU) {
+      sPH[lane] = hess;
+      sPG[lane] = grad;
+    } else if (box_lane && pd.x >= 0) {
+      // JointAcceleration{Lower,Upper}Limit (joint_acceleration_lower_limit.cpp:69-77): Qaa.diagonal() and la, ahead of the
+      // contact-dynamics condensation that reads them (contact_dynamics.cpp:68-86); the updated diagonal stays in the record
+      // (the expansion rebuilds Qafqv dx + Qafu du from it), like the reference leaves it in kkt_matrix.Qaa
+      const int i = lane - (2 * NV + NU);
+      const double qn = Qaa[i] + hess;
+      Qaa[i] = qn;
+      laf[i] += grad;
+      cr[CL.off[RTOC_CDD_QAA] + i] = qn;
+    }
+  }
   __syncthreads();  // D (and J inside it) is dead from here on: its space becomes Qafqv; region X becomes Qafu
   for (int e = lane; e < LDV * NX; e += NT) Qafqv[e] = 0.0;
   if (!impact) {
@@ -681,43 +731,6 @@ __global__ __launch_bounds__(64 * RTOC_COND_NW, (CondCfg<NV, NU, NF, NS, SPLIT>:
       for (int k = 0; k < nf; ++k) acc += Qff[lane + k * LDF] * Lr[NV + k];
       laf[NV + lane] -= acc;
     }
-  }
-  // ================= PDIPM slack/dual elimination of the joint-limit rows =================
-  // Constraints::condenseSlackAndDual (constraints.cpp:322-357, joint_*_limit.cpp, pdipm.hxx:66-69):
-  // purely additive on diag(Qqq), diag(Qvv), diag(Quu), lq, lv, lu, so it commutes with the
-  // contact-dynamics condensation; every entry is accumulated by a single lane in row order
-  // (deterministic, no atomics).
-  if (lane < 2 * NV + NU) {
-    double hess = 0.0, grad = 0.0;
-    if (box_lane) {
-      const int* no = a.nl.off;
-      if (pd.x >= 0 && g.time_stage >= (pd.z >> 8)) {
-        const double cond = (bd0 * bq0 - bc0) / bs0;
-        nr[no[RTOC_CON_COND] + pd.x] = cond;
-        hess += bd0 / bs0;
-        grad += (double)(signed char)(pd.z & 0xff) * cond;
-      }
-      if (pd.y >= 0 && g.time_stage >= (pd.w >> 8)) {
-        const double cond = (bd1 * bq1 - bc1) / bs1;
-        nr[no[RTOC_CON_COND] + pd.y] = cond;
-        hess += bd1 / bs1;
-        grad += (double)(signed char)(pd.w & 0xff) * cond;
-      }
-      const int* rowid = a.entry + (2 * NV + NU + 1);
-      for (int e = ent0; e < ent1; ++e) {  // further rows on the same entry (none for joint limits)
-        const int r = rowid[e];
-        const rtoc_box_row row = a.rows[r];
-        if (g.time_stage >= row.level) {
-          const double slack = nr[no[RTOC_CON_SLACK] + r], dual = nr[no[RTOC_CON_DUAL] + r];
-          const double cond = (dual * nr[no[RTOC_CON_RESIDUAL] + r] - nr[no[RTOC_CON_CMPL] + r]) / slack;
-          nr[no[RTOC_CON_COND] + r] = cond;
-          hess += dual / slack;
-          grad += row.sign * cond;
-        }
-      }
-    }
-    sPH[lane] = hess;
-    sPG[lane] = grad;
   }
   __syncthreads();
 
@@ -1050,7 +1063,7 @@ __global__ __launch_bounds__(64) void expand_kernel(ExpArgs a) {
   const double* Quuptr = cr + CL.off[RTOC_CDD_QUUPTR];
   const double* lup = cr + CL.off[RTOC_CDD_LUP];
   const double* Phia = cr + CL.off[RTOC_CDD_PHIA];
-  __shared__ double sdx[NX + 8], sdu[NU + 8], sg[NV + 8], sxi[LDS_ + 8], slaf[LDV + 8], st_[LDV + 8];
+  __shared__ double sdx[NX + 8], sdu[NU + 8], sg[NV + 8], sxi[LDS_ + 8], slaf[LDV + 8], st_[LDV + 8], sda[NV + 8];
   for (int i = lane; i < NX; i += 64) sdx[i] = dr[DL.off[RTOC_DIR_DX] + i];
   if (lane < NU) sdu[lane] = impact ? 0.0 : dr[DL.off[RTOC_DIR_DU] + lane];
   for (int i = lane; i < NV; i += 64) sg[i] = dn[DL.off[RTOC_DIR_DLMDGMM] + NV + i];
@@ -1076,6 +1089,7 @@ __global__ __launch_bounds__(64) void expand_kernel(ExpArgs a) {
       st_[i] = acc;  // t_i
       double daf = acc - Lr[i];
       if (i >= NV) daf = -daf;
+      else sda[i] = daf;  // the acceleration-limit rows expand with da
       dr[DL.off[RTOC_DIR_DAF] + i] = daf;
     }
   }
@@ -1121,7 +1135,8 @@ __global__ __launch_bounds__(64) void expand_kernel(ExpArgs a) {
       const rtoc_box_row row = a.rows[r];
       if (g.time_stage >= row.level) {
         const double dz = row.var == RTOC_VAR_U ? sdu[row.index]
-                                                : (row.var == RTOC_VAR_V ? sdx[NV + row.index] : sdx[row.index]);
+                                                : (row.var == RTOC_VAR_V ? sdx[NV + row.index]
+                                                                         : (row.var == RTOC_VAR_A ? sda[row.index] : sdx[row.index]));
         const double slack = nr[no[RTOC_CON_SLACK] + r], dual = nr[no[RTOC_CON_DUAL] + r];
         const double dslack = -row.sign * dz - nr[no[RTOC_CON_RESIDUAL] + r];
         const double ddual = -(dual * dslack + nr[no[RTOC_CON_CMPL] + r]) / slack;

@@ -1409,9 +1409,11 @@ int rtoc_set_constraint_rows(rtoc_ctx* c, const rtoc_box_row* rows, int nrows) {
   for (int r = 0; r < nrows; ++r) {
     const rtoc_box_row& w = rows[r];
     const int lim = (w.var == RTOC_VAR_U) ? c->dims.nu : c->dims.nv;
-    if (w.var < 0 || w.var > 2 || w.index < 0 || w.index >= lim || (w.sign != 1 && w.sign != -1) ||
+    if (w.var < 0 || w.var > RTOC_VAR_A || w.index < 0 || w.index >= lim || (w.sign != 1 && w.sign != -1) ||
         w.level < 0 || w.level > 2)
       return RTOC_ERR_BAD_ARG;
+    // acceleration limits are acceleration-level rows of the contact path (the unconstrained path has no `a` beside its control)
+    if (w.var == RTOC_VAR_A && (w.level != 0 || c->dims.nf_max == 0)) return RTOC_ERR_BAD_ARG;
   }
   HIP_TRY(hipSetDevice(c->device));
   if (nrows > 0) {
@@ -1421,10 +1423,11 @@ int rtoc_set_constraint_rows(rtoc_ctx* c, const rtoc_box_row* rows, int nrows) {
     HIP_TRY(hipMemcpyAsync(c->d_rows, rows, sizeof(rtoc_box_row) * nrows, hipMemcpyHostToDevice, c->stream));
     // rows grouped by the primal entry they act on (ascending row index inside a group, i.e. the
     // order in which the reference's components touch that entry)
-    const int nv = c->dims.nv, ne = 2 * nv + c->dims.nu;
+    // primal entries: q (nv), v (nv), u (nu), a (nv)
+    const int nv = c->dims.nv, ne = 3 * nv + c->dims.nu;
     std::vector<int> csr(ne + 1 + nrows, 0);
     auto entry_of = [&](const rtoc_box_row& w) {
-      return w.var == RTOC_VAR_Q ? w.index : (w.var == RTOC_VAR_V ? nv + w.index : 2 * nv + w.index);
+      return w.var == RTOC_VAR_Q ? w.index : (w.var == RTOC_VAR_V ? nv + w.index : (w.var == RTOC_VAR_U ? 2 * nv + w.index : 2 * nv + c->dims.nu + w.index));
     };
     for (int r = 0; r < nrows; ++r) csr[entry_of(rows[r]) + 1]++;
     for (int e = 0; e < ne; ++e) csr[e + 1] += csr[e];
@@ -1866,7 +1869,7 @@ static int launch_ubox(rtoc_ctx* c, int mode, bool contact = false) {
   a.barrier = c->barrier, a.tau = c->ftb_rule;
   a.sol_stride = c->L.sol.stride, a.kkt_stride = c->L.kkt.stride, a.cdd_stride = c->L.cdd.stride;
   a.con_stride = c->L.con.stride, a.dir_stride = c->L.dir.stride;
-  a.o_q = c->L.sol.off[RTOC_SOL_Q], a.o_v = c->L.sol.off[RTOC_SOL_V], a.o_u = c->L.sol.off[RTOC_SOL_U];
+  a.o_q = c->L.sol.off[RTOC_SOL_Q], a.o_v = c->L.sol.off[RTOC_SOL_V], a.o_u = c->L.sol.off[RTOC_SOL_U], a.o_a = c->L.sol.off[RTOC_SOL_A];
   a.o_qxx = c->L.kkt.off[RTOC_KKT_QXX], a.o_lx = c->L.kkt.off[RTOC_KKT_LX];
   a.o_qaa = c->L.cdd.off[RTOC_CDD_QAA], a.o_la = c->L.cdd.off[RTOC_CDD_LA];
   a.o_dx = c->L.dir.off[RTOC_DIR_DX], a.o_du = c->L.dir.off[RTOC_DIR_DU];

@@ -10,7 +10,7 @@
 //   CONDENSE  condenseSlackAndDual: Q_zz += dual / slack, cond = (dual residual - cmpl) / slack, l_z += sign cond
 //   EXPAND    expandSlackAndDual: dslack = -sign dz - residual, ddual = -(dual dslack + cmpl) / slack, and the
 //             fraction-to-boundary step sizes (pdipm.hxx:121-142) into RTOC_BUF_STEP (atomicMin on the bit pattern)
-// with g = sign * z - bound (rtoc_box_row), z an entry of q, v or u.  Record convention of the unconstrained path
+// with g = sign * z - bound (rtoc_box_row), z an entry of q, v, u or -- contact path only -- a.  Record convention of the unconstrained path
 // (rtoc_unconstr_condense): the u rows act on CDD.la (= lu) and CDD.Qaa (= diag Quu); q / v rows on KKT.lx and diag Qxx.
 // A row is active on a grid point iff time_stage >= level, never on the terminal one (constraints_data.cpp:20-45).
 // The contact path (rtoc_contact_init_constraints / rtoc_contact_eval_kkt) uses INIT and LINEARIZE with `contact` set: the
@@ -36,7 +36,7 @@ struct UboxArgs {
   int nstages, batch, nrows, nv, nu, mode;
   double barrier, tau;
   int sol_stride, kkt_stride, cdd_stride, con_stride, dir_stride;
-  int o_q, o_v, o_u;            // RTOC_BUF_SOL
+  int o_q, o_v, o_u, o_a;       // RTOC_BUF_SOL
   int o_qxx, o_lx;              // RTOC_BUF_KKT
   int o_qaa, o_la;              // RTOC_BUF_CDD (diag Quu, lu)
   int o_dx, o_du;               // RTOC_BUF_DIR
@@ -62,12 +62,13 @@ static __global__ __launch_bounds__(64) void unconstr_box_kernel(UboxArgs a) {
   const int nv = a.nv, nx = 2 * nv;
   double fp = 1.0, fd = 1.0;
   auto value_of = [&](const rtoc_box_row& w) {
-    return w.var == RTOC_VAR_Q ? s[a.o_q + w.index + a.q_shift] : w.var == RTOC_VAR_V ? s[a.o_v + w.index] : s[a.o_u + w.index];
+    return w.var == RTOC_VAR_Q ? s[a.o_q + w.index + a.q_shift]
+                               : w.var == RTOC_VAR_V ? s[a.o_v + w.index] : w.var == RTOC_VAR_A ? s[a.o_a + w.index] : s[a.o_u + w.index];
   };
   if (a.mode == UBOX_LINEARIZE || a.mode == UBOX_CONDENSE) {
     // one lane per primal entry, its rows in row order: a lower and an upper limit meet on the same entry, and every
     // entry is accumulated by a single lane (deterministic, no atomics) -- like the box rows of condense_kernel
-    const int ne = 2 * nv + a.nu;
+    const int ne = 3 * nv + a.nu;  // q, v, u, a (rtoc_set_constraint_rows)
     const int* const rowid = a.entry + (ne + 1);
     for (int t = lane; t < ne; t += 64) {
       double grad = 0.0, hess = 0.0;
@@ -89,7 +90,12 @@ static __global__ __launch_bounds__(64) void unconstr_box_kernel(UboxArgs a) {
       }
       if (a.contact) {   // LINEARIZE only: the condensation of these rows is condense_kernel's
         if (t < 2 * nv) kr[a.o_lx + t] += grad;
-        else if (a.entry[t + 1] > a.entry[t]) kr[a.o_lu + (t - 2 * nv)] += grad;
+        else if (a.entry[t + 1] > a.entry[t]) {
+          if (t < 2 * nv + a.nu) kr[a.o_lu + (t - 2 * nv)] += grad;
+          else cr[a.o_la + (t - 2 * nv - a.nu)] += grad;   // JointAcceleration*Limit::evalDerivatives: la -/+= dual
+        }
+      } else if (t >= 2 * nv + a.nu) {
+        // (acceleration rows exist on the contact path only: rtoc_set_constraint_rows refuses them without contacts)
       } else if (t < 2 * nv) {
         kr[a.o_lx + t] += grad;
         kr[a.o_qxx + t + (size_t)t * nx] += hess;
@@ -113,7 +119,7 @@ static __global__ __launch_bounds__(64) void unconstr_box_kernel(UboxArgs a) {
     }
     // UBOX_EXPAND
     const double slack = nr[no[RTOC_CON_SLACK] + r], dual = nr[no[RTOC_CON_DUAL] + r];
-    const double dz = w.var == RTOC_VAR_Q ? dr[a.o_dx + w.index] : w.var == RTOC_VAR_V ? dr[a.o_dx + nv + w.index] : dr[a.o_du + w.index];
+    const double dz = w.var == RTOC_VAR_Q ? dr[a.o_dx + w.index] : w.var == RTOC_VAR_V ? dr[a.o_dx + nv + w.index] : dr[a.o_du + w.index];  // (no RTOC_VAR_A here)
     const double residual = nr[no[RTOC_CON_RESIDUAL] + r], cmpl = nr[no[RTOC_CON_CMPL] + r];
     const double dslack = -w.sign * dz - residual;
     const double ddual = -(dual * dslack + cmpl) / slack;

@@ -46,17 +46,19 @@ class BoxRow(C.Structure):
     _fields_ = [("var", C.c_int), ("index", C.c_int), ("sign", C.c_int), ("level", C.c_int)]
 
 
-VAR_Q, VAR_V, VAR_U = 0, 1, 2
+VAR_Q, VAR_V, VAR_U, VAR_A = 0, 1, 2, 3
 CON_FIELDS = ["slack", "dual", "residual", "cmpl", "cond", "dslack", "ddual"]
 
 
-def joint_limit_rows(dims):
+def joint_limit_rows(dims, acceleration=False):
     """The six joint-limit components of examples/anymal/trot.cpp:134-146, in the order they are
     added: position lower/upper (position level), velocity lower/upper (velocity level), torques
-    lower/upper (acceleration level); each acts on the tail nu entries of q / v or on u."""
+    lower/upper (acceleration level); each acts on the tail nu entries of q / v or on u.
+    acceleration=True: JointAccelerationLowerLimit / UpperLimit after them (acceleration level, the tail nu entries of a;
+    src/constraints/joint_acceleration_lower_limit.cpp) -- 8 nu rows."""
     rows = []
     npv, nu = dims.np, dims.nu
-    for var, level in ((VAR_Q, 2), (VAR_V, 1), (VAR_U, 0)):
+    for var, level in ((VAR_Q, 2), (VAR_V, 1), (VAR_U, 0)) + (((VAR_A, 0),) if acceleration else ()):
         for sign in (-1, +1):
             for j in range(nu):
                 rows.append(BoxRow(var, j if var == VAR_U else npv + j, sign, level))

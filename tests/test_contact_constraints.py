@@ -22,19 +22,20 @@ def cone_world(mu):
     return np.array([[0, 0, -1], [1, 0, -m], [-1, 0, -m], [0, 1, -m], [0, -1, -m]], dtype=float)
 
 
-def limits(nu, qmax=2.0, vmax=7.5, umax=40.0):
-    """bounds of joint_limit_rows: g = sign z - bound <= 0, symmetric limits"""
-    return np.concatenate([np.full(2 * nu, qmax), np.full(2 * nu, vmax), np.full(2 * nu, umax)])
+def limits(nu, qmax=2.0, vmax=7.5, umax=40.0, amax=None):
+    """bounds of joint_limit_rows: g = sign z - bound <= 0, symmetric limits (amax: with the acceleration rows)"""
+    return np.concatenate([np.full(2 * nu, qmax), np.full(2 * nu, vmax), np.full(2 * nu, umax)] + ([np.full(2 * nu, amax)] if amax else []))
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("exact", [False, True])
-def test_cone_and_joint_limit_rows_against_the_numpy_restatement(oracle, exact):
-    """exact: RTOC_OPT_CONE_JACOBIAN -- False: dg/dq as the reference composes it (LOCAL-frame angular Jacobian x world-frame
+@pytest.mark.parametrize("exact,accel", [(False, False), (True, False), (False, True)])
+def test_cone_and_joint_limit_rows_against_the_numpy_restatement(oracle, exact, accel):
+    """accel: with JointAcceleration{Lower,Upper}Limit rows (RTOC_VAR_A: g = sign a - bound, la += sign dual,
+    joint_acceleration_lower_limit.cpp:43-66).  exact: RTOC_OPT_CONE_JACOBIAN -- False: dg/dq as the reference composes it (LOCAL-frame angular Jacobian x world-frame
     force; the restatement tests/constraint_restatement.py is pinned to the reference's sources by
     tests/test_constraints_vs_reference.py), True: the derivative of R_wf(q) f, checked against central differences of g."""
     m = rm.load_named("anymal")
-    dims = anymal_dims()
+    dims = anymal_dims(nc_max=120 if accel else 96)
     cs = ContactSequence([12, 6, 12], [Event("lift", 0.105), Event("impact", 0.265, impact_dimf=6)])
     grids = discretize(20, 0.4, 0.0, cs)
     n, nv, nq, nu, batch = len(grids), m.nv, m.nq, 12, 2
@@ -46,8 +47,8 @@ def test_cone_and_joint_limit_rows_against_the_numpy_restatement(oracle, exact):
         for c in range(4):
             rot[i, c] = oracle.rbd_exp6(np.concatenate([np.zeros(3), 0.2 * rng.uniform(-1, 1, 3)]))[0]
     mu = np.array([0.7, 0.6, 0.8, 0.5])
-    rows = joint_limit_rows(dims)
-    bounds = limits(nu)
+    rows = joint_limit_rows(dims, acceleration=accel)
+    bounds = limits(nu, amax=0.8 if accel else None)   # a ~ U(-1, 1): some beyond the limit (slack clipped)
     ctx = capi.Context(dims, n, batch, 0)
     ctx.set_grid(grids)
     ctx.set_robot_model(m)
@@ -90,19 +91,20 @@ def test_cone_and_joint_limit_rows_against_the_numpy_restatement(oracle, exact):
     kkt2, cdd2 = ctx.download_records(BUF_KKT, "kkt"), ctx.download_records(BUF_CDD, "cdd")
     row0 = dims.nc_max - 20
     sb = np.sqrt(BARRIER)
-    worst = dict(slack=0.0, dual=0.0, residual=0.0, cmpl=0.0, dgdf=0.0, dgdq=0.0, lq=0.0, lf=0.0, lv=0.0, lu=0.0)
+    worst = dict(slack=0.0, dual=0.0, residual=0.0, cmpl=0.0, dgdf=0.0, dgdq=0.0, lq=0.0, lf=0.0, lv=0.0, lu=0.0, la=0.0)
+    accel_rows = 0
     for b in range(batch):
         for i in range(n - 1):
             s, g = sol[b, i], grids[i]
             q, v, u, f = S.f(s, "q")[:nq], S.f(s, "v"), S.f(s, "u"), S.f(s, "f")
             slack, dual = N.f(con0[b, i], "slack"), N.f(con0[b, i], "dual")
-            lx_add, lu_add, lf_add = np.zeros(2 * nv), np.zeros(nu), np.zeros(12)
+            lx_add, lu_add, lf_add, la_add = np.zeros(2 * nv), np.zeros(nu), np.zeros(12), np.zeros(nv)
             # ---- joint limits ----
             for r, w in enumerate(rows):
                 if g.type == GRID_IMPACT or g.time_stage < w.level:
                     assert slack[r] == 0.0 and dual[r] == 0.0
                     continue
-                z = q[w.index + 1] if w.var == 0 else (v[w.index] if w.var == 1 else u[w.index])
+                z = q[w.index + 1] if w.var == 0 else (v[w.index] if w.var == 1 else (S.f(s, "a")[w.index] if w.var == 3 else u[w.index]))
                 gval = w.sign * z - bounds[r]
                 worst["slack"] = max(worst["slack"], abs(slack[r] - max(-gval, sb)))
                 worst["dual"] = max(worst["dual"], abs(dual[r] - BARRIER / slack[r]))
@@ -110,6 +112,9 @@ def test_cone_and_joint_limit_rows_against_the_numpy_restatement(oracle, exact):
                 worst["cmpl"] = max(worst["cmpl"], abs(N.f(con1[b, i], "cmpl")[r] - (slack[r] * dual[r] - BARRIER)))
                 if w.var == 2:
                     lu_add[w.index] += w.sign * dual[r]
+                elif w.var == 3:
+                    la_add[w.index] += w.sign * dual[r]
+                    accel_rows += 1
                 else:
                     lx_add[w.index + (nv if w.var == 1 else 0)] += w.sign * dual[r]
             # ---- friction cones: none on the impact grid (RTOC_OPT_IMPACT_CONES is on by default -> rows there too) ----
@@ -152,10 +157,12 @@ def test_cone_and_joint_limit_rows_against_the_numpy_restatement(oracle, exact):
             worst["lv"] = max(worst["lv"], np.abs(dlx[nv:] - lx_add[nv:]).max())
             worst["lu"] = max(worst["lu"], np.abs(K.f(kkt1[b, i], "lu") - K.f(kkt2[b, i], "lu") - lu_add).max())
             worst["lf"] = max(worst["lf"], np.abs(D.f(cdd1[b, i], "lf") - D.f(cdd2[b, i], "lf") - lf_add).max())
+            worst["la"] = max(worst["la"], np.abs(D.f(cdd1[b, i], "la") - D.f(cdd2[b, i], "la") - la_add).max())
     print("constraint rows, worst deviations:", {k: "%.1e" % e for k, e in worst.items()})
     assert max(worst[k] for k in ("slack", "dual", "residual", "cmpl", "dgdf")) < 1e-11
     assert worst["dgdq"] < 1e-6                                    # central differences
-    assert max(worst[k] for k in ("lq", "lv", "lu", "lf")) < 1e-9  # differences of O(100) residual entries
+    assert max(worst[k] for k in ("lq", "lv", "lu", "lf", "la")) < 1e-9  # differences of O(100) residual entries
+    assert accel_rows == (2 * nu * batch * sum(1 for g in grids[:-1] if g.type != GRID_IMPACT) if accel else 0)
     ctx.close()
 
 

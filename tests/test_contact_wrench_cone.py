@@ -179,6 +179,24 @@ def test_gpu_sqp_hot_path_with_wrench_cones_and_joint_limits(oracle, tmp_path):
         oracle.wrench_update_batch(L, grids, MC, nn, steps_gpu)
         for f in ("slack", "dual"):
             assert rel_err(N.f(con_upd, f), N.f(nn, f)) < 1e-9, f
+        # ImpactWrenchCone (src/constraints/impact_wrench_cone.cpp: ContactWrenchCone's algebra on the impulse, impact level) as a
+        # path of its own: the impact grid of the landing carries 2 x 17 rows -- their condensation into Qff / lf, expansion and
+        # update on THAT grid point alone (the oracle's rows there are pinned to the reference's ImpactWrenchCone by
+        # tests/test_constraints_vs_reference.py::test_contact_wrench_cone_against_the_reference_sources[...-True])
+        from robotoc_amd.types import GRID_IMPACT
+        imp = [i for i, g in enumerate(grids) if g.type == GRID_IMPACT and g.dimf >= 6]
+        assert imp, "the grid holds an impact with surface contacts"
+        row0 = dims.nc_max - 17 * MC
+        for i in imp:
+            nrow = 17 * (grids[i].dimf // 6)
+            assert rel_err(C.f(cdd_gpu[:, i], "Qff"), C.f(cdd[:, i], "Qff")) > 1e-6    # the rows did act on the impact grid
+            for f in ("Qff", "lf"):
+                assert rel_err(C.f(cdd_gpu[:, i], f), C.f(cc[:, i], f)) < 1e-12, (i, f)
+            for f in ("cond", "dslack", "ddual"):
+                assert rel_err(N.f(con_exp[:, i], f)[..., row0:row0 + nrow], N.f(nn[:, i], f)[..., row0:row0 + nrow]) < 1e-7, (i, f)
+                assert np.abs(N.f(con_exp[:, i], f)[..., row0:row0 + nrow]).min() > 0.0
+            for f in ("slack", "dual"):
+                assert rel_err(N.f(con_upd[:, i], f)[..., row0:row0 + nrow], N.f(nn[:, i], f)[..., row0:row0 + nrow]) < 1e-9, (i, f)
     finally:
         ctx.close()
     # the dump restores the wrench set-up (rtoc_dump_header::cone_rows = 17) and replays identically
