@@ -26,7 +26,7 @@ if ROOT not in sys.path:
 PER_GPU_BATCH = 4096
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 F64_MFMA_PEAK_TFLOPS = 78.6  # MI355X spec sheet, dense fp64 matrix (= the fp64 vector rate)
-PROFILE_ROUND = "r03"
+PROFILE_ROUND = "r04"
 
 
 def kernel_source_hash():
@@ -132,7 +132,7 @@ def condense_bytes(L, grids, batch):
     return total * 8 * batch
 
 
-def expand_bytes(L, grids, batch, rows, cone_contacts):
+def expand_bytes(L, grids, batch, rows, cone_contacts, wrench=False):
     """Algorithmic HBM bytes of one rtoc_expand launch: per non-terminal grid point what
     expandContactDynamicsPrimal/Dual need (contact_dynamics.cpp:167-202: MJtJinv, MJtJinv_dIDCdqv,
     MJtJinv_IDC, laf, haf, the passive blocks, Phia, and Qaa / Qff / Qqf from which Qafqv dx + Qafu du is rebuilt;
@@ -157,9 +157,14 @@ def expand_bytes(L, grids, batch, rows, cone_contacts):
             act = sum(1 for r in rows if g.time_stage >= r.level)  # stage mask, constraints_data.cpp:20-45
             rd += 4 * act
             wr += 2 * act
-        nc = min(g.dimf // 3, cone_contacts)
-        rd += nc * (4 * 5 + 5 * nv + 15)
-        wr += nc * 2 * 5
+        if wrench:   # 17 rows per active surface contact: slack, dual, residual, cmpl and the 17 x 6 cone matrix in, dslack, ddual out
+            nc = min(g.dimf // 6, cone_contacts)
+            rd += nc * (4 * 17 + 17 * 6)
+            wr += nc * 2 * 17
+        else:
+            nc = min(g.dimf // 3, cone_contacts)
+            rd += nc * (4 * 5 + 5 * nv + 15)
+            wr += nc * 2 * 5
         total += rd + wr
     return total * 8 * batch
 
@@ -193,6 +198,22 @@ def pmc_traffic(kernel_substr):
     for k, v in table.items():
         if not k.startswith("_") and kernel_substr in k:
             return v["hbm_bytes"]
+    return None
+
+
+def rocprof_kernel_ms(kernel_substr):
+    """{avg_ms, calls, back_to_back_avg_ms, ...} of a kernel over ALL launches of its largest geometry in the committed
+    rocprofv3 --kernel-trace of this same command (profiles/<round>_traffic.json: _kernel_ms_rocprof, written by
+    tools/summarize_profiles.py), or None: printed beside the event-timed kernel_ms of the line, which times the sweep loop only."""
+    path = os.path.join(ROOT, "profiles", "%s_traffic.json" % PROFILE_ROUND)
+    if not os.path.exists(path):
+        return None
+    table = json.load(open(path))
+    if not counter_pass_valid(table)[0]:
+        return None
+    for k, v in table.get("_kernel_ms_rocprof", {}).items():
+        if kernel_substr in k:
+            return v
     return None
 
 
@@ -409,6 +430,76 @@ def closed_loop_trot(local_rank, batch, iters=30, timed=10):
     return out
 
 
+def closed_loop_icub(local_rank, batch, nv=32, iters=12, timed=10):
+    """OCPSolver::updateSolution of BASELINE configs[3] with nothing on the host: iCub through stand - flight - touch-down of
+    both soles (N = 30: lift grid, flight phase, impact grid with its 12-row switching constraint), ConfigurationSpaceCost, the
+    six joint-limit components and ContactWrenchCone / ImpactWrenchCone (2 x 17 rows per grid point with both soles down), a
+    distinct initial state per instance.  nv = 32: the reference URDF's iCub with the torso locked (robot_model.lock_joints;
+    BASELINE.json names that size), nv = 35: the URDF as it is.  The plain Gauss-Newton iteration with these inequality rows is
+    what the reference runs without its line search; it is TIMED here (every kernel of the iteration runs whatever the iterate),
+    the KKT errors of the first `iters` iterations are reported beside it."""
+    from robotoc_amd import capi, robot_model as rm
+    from robotoc_amd.grid import ICUB_Q_STANDING, ContactSequence, Event, contact_masks, discretize
+    from robotoc_amd.types import BUF_SOL, GRID_IMPACT, Records, icub_dims, joint_limit_rows
+    m = rm.load_named("icub32" if nv == 32 else "icub")
+    assert m.nv == nv
+    nq, nu = m.nq, nv - 6
+    qs = np.array(ICUB_Q_STANDING, dtype=float)
+    if nv == 32:
+        qs = np.delete(qs, [19, 20, 21])
+    dims = icub_dims(nv, nc_max=(6 * nu + 34 + 7) & ~7)
+    grids = discretize(30, 0.6, 0.0, ContactSequence([12, 0, 12], [Event("lift", 0.25), Event("impact", 0.36, impact_dimf=12)]))
+    n = len(grids)
+    masks = contact_masks(grids, [0b11, 0, 0b11], [0b11])
+    place = [m.frame_placement(qs, c) for c in range(2)]
+    pos = np.tile(np.array([p for _, p in place])[None], (n, 1, 1))
+    rot = np.tile(np.array([R.reshape(9) for R, _ in place])[None], (n, 1, 1))
+    c = capi.Context(dims, n, batch, local_rank)
+    c.set_grid(grids)
+    c.set_robot_model(m)
+    c.set_contact_schedule(masks, pos, rot)
+    c.set_constraint_rows(joint_limit_rows(dims))
+    c.set_wrench_cones(2)
+    c.set_constraint_bounds(np.concatenate([np.full(2 * nu, 2.5), np.full(2 * nu, 5.0), np.full(2 * nu, 60.0)]), 1.0e-3, 0.995)
+    c.set_wrench_cone_params(np.array([[0.1, 0.05, 0.6], [0.1, 0.05, 0.6]]))
+    wq = np.concatenate([np.full(6, 10.0), np.full(nu, 0.1)])
+    c.set_configuration_cost(qs, np.zeros(nv), np.zeros(nu), wq, np.full(nv, 0.1), np.full(nv, 1e-3), np.full(nu, 1e-4), 10 * wq, np.full(nv, 0.1),
+                             q_weight_impact=wq, v_weight_impact=np.full(nv, 0.1), dv_weight_impact=np.full(nv, 1e-3))
+    rng = np.random.default_rng(101)
+    x0 = np.tile(np.concatenate([qs, np.zeros(nv)]), (batch, 1))
+    x0[:, nq:] = 0.02 * rng.uniform(-1, 1, (batch, nv))           # a distinct initial state per instance
+    c.set_initial_state(x0)
+    S = Records(c.L, "sol")
+    sol = S.zeros(batch, n)
+    S.f(sol, "q")[..., :nq] = x0[:, None, :nq]
+    mass = sum(m.mass[i] for i in range(m.njoints))
+    f0 = np.concatenate([np.concatenate([R.T @ np.array([0.0, 0.0, 9.81 * mass / 2]), np.zeros(3)]) for R, _ in place])
+    for i in range(n):
+        if masks[i] and grids[i].type != GRID_IMPACT:
+            S.f(sol, "f")[:, i, :12] = f0
+    c.upload(BUF_SOL, sol)
+    c.contact_init_constraints()
+    errs = np.array([c.contact_update_solution(0.995) for _ in range(iters)])
+    c.upload(BUF_SOL, sol)
+    c.contact_init_constraints()
+    c.contact_update_solution(0.995, want_kkt_error=False)
+    c.sync()
+    t0 = time.perf_counter()
+    for _ in range(timed):
+        c.contact_update_solution(0.995, want_kkt_error=False)
+    c.sync()
+    ms = (time.perf_counter() - t0) / timed * 1e3
+    out = {"batch": batch, "nv": nv, "grid_points": n, "update_solution_ms": ms, "iterations_per_sec": batch / ms * 1e3,
+           "kkt_error_worst_by_iteration": [float(e.max()) for e in errs], "status_ok": bool((c.status() == 0).all()),
+           "inequality_rows_per_grid_point": 6 * nu + 34,
+           "scope": "the WHOLE OCPSolver::updateSolution on the device (cost, joint limits + 2 x 17 wrench-cone rows, state equation on "
+                    "SE(3), RNEA + derivatives, switching constraint, KKT error, condensation, Riccati sweep, expansion, steps, update); "
+                    "Gauss-Newton iterations from the standing guess without the line search (timing; the KKT history is reported, not "
+                    "claimed as converged); wall clock around asynchronous launches, synchronised once"}
+    c.close()
+    return out
+
+
 def dry_run(args, rank, world):
     """The multi-rank plumbing of this file without a GPU: rendezvous (gloo), barrier + max-over-ranks timing, the
     all-gather of (dummy) direction records through robotoc_amd.sharding, one JSON line from rank 0."""
@@ -611,6 +702,12 @@ def main():
     torch.cuda.synchronize()
     copy_gbs = 5 * 2 * src.numel() * 8 / (e0.elapsed_time(e1) * 1e-3) / 1e9
     del src, dst
+    # ... and what tuned streaming kernels reach (rtoc_bandwidth_probe: 16 B per lane, one front over memory, 8 loads in flight):
+    # the better denominator -- torch's copy_ above is the runtime's copyBuffer kernel, which this box's HBM outruns
+    try:
+        stream_read_gbs, stream_copy_gbs = capi.bandwidth_probe(local_rank, 1 << 31)
+    except Exception:
+        stream_read_gbs = stream_copy_gbs = None
 
     gathered_ok, gathered_c_ok = None, None
     if world > 1:
@@ -760,6 +857,9 @@ def main():
                 ("icub_nv35_jump_N30", lambda: pr.config_icub_jump(nv=35), 1024), ("iiwa14_unconstr_N20", pr.config_iiwa14, 4096)]
         for name, fn, nb in cfgs:
             d2, g2, info = fn()
+            if name.startswith("icub"):   # room for the 2 x 17 wrench-cone rows behind the six joint-limit components
+                from robotoc_amd.types import icub_dims
+                d2 = icub_dims(d2.nv, nc_max=(6 * d2.nu + 34 + 7) & ~7)
             entry = {"stages": len(g2)}
             for label, b2 in (("single_instance", 1), ("batch", nb)):
                 if b2 == 0:
@@ -837,12 +937,19 @@ def main():
                                                else "mfma"}})
                     if name.startswith("icub") or name.startswith("anymal_jump"):
                         # SQP iterations/s of this configuration (north_star names it for iCub too): one rtoc_newton_iteration
-                        # on distinct pre-condensation records with the joint-limit rows (no cones: the wrench-cone rows of
-                        # iCub are covered by tests/test_contact_wrench_cone.py, not timed here)
-                        from robotoc_amd.types import BUF_CDD, BUF_CON, joint_limit_rows
+                        # on distinct pre-condensation records with the joint-limit rows and, for iCub (BASELINE configs[3]:
+                        # 2 surface contacts), the 2 x 17 ContactWrenchCone / ImpactWrenchCone rows per grid point with both
+                        # soles down (contact_wrench_cone.cpp:209-270)
+                        from robotoc_amd.types import BUF_CDD, BUF_CON, BUF_CONE, joint_limit_rows
                         rows2 = joint_limit_rows(d2)
-                        if len(rows2) <= d2.nc_max:
+                        wrench2 = name.startswith("icub")
+                        if len(rows2) + (34 if wrench2 else 0) <= d2.nc_max:
                             c2.set_constraint_rows(rows2)
+                            if wrench2:
+                                c2.set_wrench_cones(2)
+                                cones2 = [capi.wrench_cone_matrix(0.1, 0.05, 0.6), capi.wrench_cone_matrix(0.09, 0.055, 0.7)]
+                                cone2 = torch.from_numpy(pr.make_wrench_cone_batch(L2, g2, b2, 2, cones2)).to(dev).contiguous()
+                                c2.bind(BUF_CONE, cone2.data_ptr())
                             kk = torch.zeros((b2, len(g2), L2.kkt.stride), dtype=torch.float64, device=dev)  # the generators fill fields, not padding
                             cc = torch.zeros((b2, len(g2), L2.cdd.stride), dtype=torch.float64, device=dev)
                             nn = torch.zeros((b2, len(g2), L2.con.stride), dtype=torch.float64, device=dev)
@@ -870,6 +977,24 @@ def main():
                             entry["sqp_iters_per_sec"] = b2 / best * 1e3
                             entry["sqp_data_seed"] = seed2
                             entry["sqp_status_nonzero_instances"] = flagged
+                            entry["sqp_inequality_rows"] = {"joint_limit_rows": len(rows2), "wrench_cone_rows_per_contact": 17 if wrench2 else 0,
+                                                            "max_surface_contacts": 2 if wrench2 else 0}
+                            # phase by phase, with the roofline blocks of the two HBM-bound phases
+                            ph2 = {"condense": 2, "backward": 0, "forward": 1, "expand": 3, "update": 5}
+                            acc2 = {k: 1e9 for k in ph2}
+                            for rep in range(2):
+                                kw.copy_(kk), cw.copy_(cc), nw.copy_(nn)
+                                torch.cuda.synchronize()
+                                for pn in ("condense", "backward", "forward", "expand", "update"):
+                                    acc2[pn] = min(acc2[pn], c2.time_phase(ph2[pn], 1))
+                            entry["sqp_phase_ms"] = acc2
+                            cb2, eb2 = condense_bytes(L2, g2, b2), expand_bytes(L2, g2, b2, rows2, 2 if wrench2 else 0, wrench=wrench2)
+                            for key, nbytes, pn in (("roofline_condense", cb2, "condense"), ("roofline_expand", eb2, "expand")):
+                                entry[key] = {"bound": "hbm", "achieved": nbytes / (acc2[pn] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                              "frac": nbytes / (acc2[pn] * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": nbytes,
+                                              "kernel_ms": acc2[pn], "traffic": None}
+                            if wrench2:
+                                del cone2
                             c2.clear_status()
                             c2.bind(BUF_KKT, k2.data_ptr())
                             del kk, cc, nn, kw, cw, nw
@@ -920,6 +1045,15 @@ def main():
         except Exception as e:  # the sweep numbers above stand on their own
             others["iiwa14_unconstr_N20"]["closed_loop"] = {"error": repr(e)}
 
+    # ---- BASELINE configs[3] closed on the device: the iCub hop with joint limits and wrench cones, one instance and 1024 ----
+    if others is not None:
+        for name, nv_ in (("icub_nv32_jump_N30", 32), ("icub_nv35_jump_N30", 35)):
+            if name in others:
+                try:
+                    others[name]["closed_loop"] = {"single_instance": closed_loop_icub(local_rank, 1, nv_), "batch": closed_loop_icub(local_rank, 1024, nv_)}
+                except Exception as e:  # the sweep numbers above stand on their own
+                    others[name]["closed_loop"] = {"error": repr(e)}
+
     # ---- BASELINE configs[2] closed on the device: the ANYmal jump with switching-time optimisation (examples/anymal/python/
     #      jump_sto.py at N = 40) solved by robotoc_amd.solver.OCPSolver -- per-instance switching times, mesh refinement ----
     if others is not None and "anymal_jump_sto_N40" in others:
@@ -959,7 +1093,16 @@ def main():
                          "traffic": pmc_traffic(kname) if batch == PER_GPU_BATCH else None,
                          "traffic_source": traffic_state(),
                          "measured_copy_GBs": copy_gbs, "frac_of_measured_copy": ach / copy_gbs,
+                         "measured_copy_kernel": "torch Tensor.copy_ (runtime copyBuffer), 1 GiB read + write",
+                         "measured_stream_read_GBs": stream_read_gbs, "measured_stream_copy_GBs": stream_copy_gbs,
+                         "frac_of_measured_stream_read": ach / stream_read_gbs if stream_read_gbs else None,
+                         "frac_of_measured_stream_copy": ach / stream_copy_gbs if stream_copy_gbs else None,
+                         "measured_stream_kernel": "rtoc_bandwidth_probe: 2 GiB, 16 B / lane, 8 loads in flight per wave, best of 5",
                          "kernel": kname, "kernel_ms": ms_b,
+                         "kernel_ms_source": "HIP events on the launch stream inside the timed sweep loop of this run",
+                         "kernel_ms_rocprof_all_launches": rocprof_kernel_ms(kname) if batch == PER_GPU_BATCH else None,
+                         "frac_at_rocprof_all_launch_average": (lambda r: (bytes_b / (r["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if r else None)(
+                             rocprof_kernel_ms(kname) if batch == PER_GPU_BATCH else None),
                          "algorithmic_bytes_per_launch": bytes_b,
                          "mfma_f64_achieved_TFLOPs": fl_b / (ms_b * 1e-3) / 1e12,
                          "mfma_f64_frac": fl_b / (ms_b * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS,

@@ -160,6 +160,11 @@ typedef struct rtoc_ctx rtoc_ctx;
 /* Library / device discovery. rtoc_device_count() < 1 means the HIP path is unusable. */
 int rtoc_version(void);
 int rtoc_device_count(void);
+/* Attainable HBM bandwidth of `device`, measured now with this library's own streaming kernels (16 B per lane, all waves
+ * sweeping memory as one front, eight loads in flight per wave): a pure read of `bytes` and a copy of `bytes` (read + write,
+ * counted as 2 x bytes), best of five launches each, GB/s.  The denominators the bench's roofline fractions are quoted against
+ * beside the 8 TB/s spec (a hipMemcpy-style device copy reaches less than these).  Either pointer may be NULL. */
+int rtoc_bandwidth_probe(int device, size_t bytes, double* read_gbs, double* copy_gbs);
 /* 1 if (nv,nu,np) has a compiled kernel specialisation, else 0. */
 int rtoc_dims_supported(const rtoc_dims* dims);
 

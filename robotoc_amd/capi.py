@@ -35,6 +35,7 @@ EXPORTS = [
     "rtoc_sto_correct_time_steps", "rtoc_sto_eval_kkt_device", "rtoc_sto_compute_step_sizes", "rtoc_sto_integrate_solution",
     "rtoc_sto_get_event_times", "rtoc_sto_get_time_steps", "rtoc_sto_get_constraint_data", "rtoc_sto_get_kkt_terms",
     "rtoc_sto_set_slack_dual", "rtoc_contact_eval_ocp", "rtoc_set_line_search", "rtoc_contact_line_search",
+    "rtoc_bandwidth_probe",
 ]
 
 
@@ -644,6 +645,14 @@ def debug_profile(ctx):
     out = np.zeros((ctx.max_stages, 32), dtype=np.int64)
     _chk(L.rtoc_debug_profile(ctx._h, out.ctypes.data_as(C.c_void_p)))
     return out
+
+
+def bandwidth_probe(device=0, nbytes=1 << 31):
+    """rtoc_bandwidth_probe: (read GB/s, copy GB/s) of the library's own streaming kernels on `device`"""
+    r, c = C.c_double(0.0), C.c_double(0.0)
+    lib().rtoc_bandwidth_probe.argtypes = [C.c_int, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    _chk(lib().rtoc_bandwidth_probe(int(device), int(nbytes), C.byref(r), C.byref(c)))
+    return r.value, c.value
 
 
 def wrench_cone_matrix(X, Y, mu):

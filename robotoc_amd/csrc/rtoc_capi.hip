@@ -254,6 +254,70 @@ int rtoc_device_count(void) {
   return n;
 }
 
+// ---- streaming kernels of rtoc_bandwidth_probe: chunk = (block-wave) + k * (waves in the launch), 1 KB per wave-instruction ----
+extern "C++" {
+template <int U, bool COPY>
+static __global__ __launch_bounds__(256) void stream_probe_kernel(const char* __restrict__ src, char* __restrict__ dst, size_t chunks,
+                                                                  double* sink) {
+  const size_t nwaves = (size_t)gridDim.x * 4, w = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  double acc = 0.0;
+  for (size_t c = w; c + (U - 1) * nwaves < chunks; c += U * nwaves) {
+    d2 v[U];
+#pragma unroll
+    for (int k = 0; k < U; ++k) v[k] = *reinterpret_cast<const d2*>(src + (c + k * nwaves) * 1024 + lane * 16);
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      if (COPY) *reinterpret_cast<d2*>(dst + (c + k * nwaves) * 1024 + lane * 16) = v[k];
+      else acc += v[k][0] + v[k][1];
+    }
+  }
+  if (!COPY && acc == 1234.5) sink[w] = acc;
+}
+}  // extern "C++"
+
+int rtoc_bandwidth_probe(int device, size_t bytes, double* read_gbs, double* copy_gbs) {
+  if (bytes < (size_t)1 << 24) return RTOC_ERR_BAD_ARG;
+  HIP_TRY(hipSetDevice(device));
+  const int blocks = 256 * 8;                                  // 8 workgroups of 4 waves per CU
+  const size_t per = (size_t)blocks * 4 * 8;                   // chunks consumed per trip of all waves (U = 8)
+  const size_t chunks = (bytes / 1024) / per * per;
+  char *src = nullptr, *dst = nullptr;
+  double* sink = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  hipError_t e = hipMalloc((void**)&src, chunks * 1024);
+  if (e == hipSuccess) e = hipMalloc((void**)&dst, chunks * 1024);
+  if (e == hipSuccess) e = hipMalloc((void**)&sink, sizeof(double) * blocks * 4);
+  if (e == hipSuccess) e = hipMemset(src, 0, chunks * 1024);
+  if (e == hipSuccess) e = hipEventCreate(&e0);
+  if (e == hipSuccess) e = hipEventCreate(&e1);
+  double best[2] = {0.0, 0.0};
+  for (int mode = 0; mode < 2 && e == hipSuccess; ++mode)
+    for (int rep = 0; rep < 6 && e == hipSuccess; ++rep) {   // the first launch warms up
+      (void)hipEventRecord(e0, nullptr);
+      if (mode == 0) hipLaunchKernelGGL((stream_probe_kernel<8, false>), dim3(blocks), dim3(256), 0, nullptr, src, dst, chunks, sink);
+      else hipLaunchKernelGGL((stream_probe_kernel<8, true>), dim3(blocks), dim3(256), 0, nullptr, src, dst, chunks, sink);
+      (void)hipEventRecord(e1, nullptr);
+      e = hipEventSynchronize(e1);
+      float ms = 0.f;
+      if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+      const double gbs = (mode + 1) * (double)chunks * 1024.0 / (ms * 1e-3) / 1e9;
+      if (rep > 0 && gbs > best[mode]) best[mode] = gbs;
+    }
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  if (src) (void)hipFree(src);
+  if (dst) (void)hipFree(dst);
+  if (sink) (void)hipFree(sink);
+  if (e != hipSuccess) {
+    ctx_set_err(e, __LINE__);
+    return RTOC_ERR_HIP;
+  }
+  if (read_gbs) *read_gbs = best[0];
+  if (copy_gbs) *copy_gbs = best[1];
+  return RTOC_OK;
+}
+
 int rtoc_dims_supported(const rtoc_dims* dims) { return dims && find_set(dims) ? 1 : 0; }
 
 void rtoc_layout_for_dims(const rtoc_dims* dims, rtoc_layout* out) { rtoc_compute_layout(dims, out); }

@@ -301,3 +301,8 @@ def mesh_refinement(grids, N, T, t, cs, max_dt_mesh):
     if max_time_step(grids) > max_dt_mesh:
         return discretize(N, T, t, cs, phase_based=True), True
     return grids, False
+# iCub standing pose of examples/icub/python/jump_sto.py:21-26 (reference URDF: nq = 36; robot_model.load_named("icub32") drops the
+# three torso entries, which are zero)
+ICUB_Q_STANDING = [0, 0, 0.592, 0, 0, 1, 0,
+                   0.20944, 0.08727, 0, -0.1745, -0.0279, -0.08726, 0.20944, 0.08727, 0, -0.1745, -0.0279, -0.08726,
+                   0, 0, 0, 0, 0.35, 0.5, 0.5, 0, 0, 0, 0, 0.35, 0.5, 0.5, 0, 0, 0]

@@ -101,8 +101,58 @@ def load(path):
     return from_dict(json.load(open(path)))
 
 
+def lock_joints(d, names):
+    """The model table `d` with the revolute joints `names` locked at angle 0: the body of a locked joint is welded to its
+    parent (composite mass / centre of mass / rotational inertia about the new centre of mass, all in the parent's joint frame),
+    its children and contact frames hang off the parent with the composed fixed placement.  How BASELINE.json's "iCub (nv=32)" is
+    built from the reference's iCub URDF (29 joints, nv = 35): the three torso joints locked."""
+    import copy
+    d = copy.deepcopy(d)
+    js, cs = d["joints"], d["contacts"]
+    lock = sorted((i for i, j in enumerate(js) if j["name"] in names), reverse=True)   # children before their parents
+    assert len(lock) == len(names) and all(js[i]["type"] == JOINT_REVOLUTE and js[i]["parent"] >= 0 for i in lock)
+    for i in lock:
+        j, par = js[i], js[js[i]["parent"]]
+        R, p = np.asarray(j["placement_R"], dtype=float).reshape(3, 3), np.asarray(j["placement_p"], dtype=float)
+        mc, mp = j["mass"], par["mass"]
+        cc, cp = R @ np.asarray(j["com"], dtype=float) + p, np.asarray(par["com"], dtype=float)
+        Ic, Ip = R @ np.asarray(j["inertia"], dtype=float).reshape(3, 3) @ R.T, np.asarray(par["inertia"], dtype=float).reshape(3, 3)
+        m = mc + mp
+        c = (mc * cc + mp * cp) / m if m > 0.0 else cp
+        shift = lambda mass, r: mass * (np.dot(r, r) * np.eye(3) - np.outer(r, r))   # parallel-axis term
+        par["mass"], par["com"] = m, c.tolist()
+        par["inertia"] = (Ip + shift(mp, cp - c) + Ic + shift(mc, cc - c)).tolist()
+        for k in js:
+            if k["parent"] == i:
+                Rk, pk = np.asarray(k["placement_R"], dtype=float).reshape(3, 3), np.asarray(k["placement_p"], dtype=float)
+                k["placement_R"], k["placement_p"], k["parent"] = (R @ Rk).tolist(), (R @ pk + p).tolist(), j["parent"]
+        for k in cs:
+            if k["parent"] == i:
+                k["R"], k["p"], k["parent"] = (R @ np.asarray(k["R"], dtype=float)).tolist(), (R @ np.asarray(k["p"], dtype=float) + p).tolist(), j["parent"]
+    keep = [i for i in range(len(js)) if i not in lock]
+    renum = {old: new for new, old in enumerate(keep)}
+    renum[-1] = -1
+    out, iq, iv = [], 0, 0
+    for i in keep:
+        j = js[i]
+        j["parent"] = renum[j["parent"]]
+        j["idx_q"], j["idx_v"] = iq, iv
+        iq, iv = iq + (7 if j["type"] == JOINT_FREE_FLYER else 1), iv + (6 if j["type"] == JOINT_FREE_FLYER else 1)
+        out.append(j)
+    for k in cs:
+        k["parent"] = renum[k["parent"]]
+    d["joints"], d["nq"], d["nv"] = out, iq, iv
+    return d
+
+
+ICUB32_LOCKED = ("torso_pitch", "torso_roll", "torso_yaw")
+
+
 def load_named(name):
-    """one of the bundled tables: anymal (floating base, 4 point feet), icub (floating base, 2 soles), iiwa14"""
+    """one of the bundled tables: anymal (floating base, 4 point feet), icub (floating base, 2 soles; nv = 35), iiwa14 -- or
+    icub32: the iCub table with the three torso joints locked (nv = 32, the size BASELINE.json names)"""
+    if name == "icub32":
+        return from_dict(lock_joints(json.load(open(os.path.join(MODEL_DIR, "icub.json"))), ICUB32_LOCKED))
     return load(os.path.join(MODEL_DIR, name + ".json"))
 
 

@@ -69,6 +69,12 @@ def full_size_fixtures():
     riccati_fixture_full_size("ref_anymal_trot_n40_riccati.npz", *pr.config_anymal_trot()[:2], mode="dynamics")
     riccati_fixture_full_size("ref_anymal_jump_sto_n40_riccati.npz", *pr.config_anymal_jump_sto()[:2], mode="dynamics")
     riccati_fixture_full_size("ref_icub35_jump_n30_riccati.npz", *pr.config_icub_jump(nv=35)[:2], mode="factory")
+    icub32_full_size()
+
+
+def icub32_full_size():
+    """BASELINE configs[3] at the size BASELINE.json names (nv = 32, N = 30)"""
+    riccati_fixture_full_size("ref_icub32_jump_n30_riccati.npz", *pr.config_icub_jump(nv=32)[:2], mode="factory")
 
 
 def condense_fixture(name, dims, grids):
@@ -737,6 +743,7 @@ FIXTURES = {
     "icub_surface_stage": icub_surface_stage_fixture,
     "ocp_iteration": ocp_solver_iteration_fixture,
     "riccati_full_size": full_size_fixtures,
+    "riccati_icub32": icub32_full_size,
     "ocp_iteration_sto": lambda: ocp_solver_iteration_fixture("ref_anymal_jump_sto_solver_iteration.npz", sto=True),
     "ocp_iteration_line_search": lambda: ocp_solver_iteration_fixture("ref_anymal_ocp_solver_iteration_line_search.npz", line_search=True),
 }

@@ -422,3 +422,33 @@ def test_gpu_linearisation_icub_surface_contacts_two_passes_eleven_levels(oracle
     from helpers import check_parity
     check_parity("iCub d[ID; C]/d(q, v, a) vs complex step", worst, 1e-13)   # observed 2.6e-15 on the MI355X
     ctx.close()
+
+
+def test_icub32_is_the_icub_with_the_torso_locked(oracle):
+    """robot_model.lock_joints: the nv = 32 iCub (BASELINE.json's size) is the reference URDF's nv = 35 model with the three torso
+    joints welded at angle zero.  Inverse dynamics, contact residuals and contact-frame placements of the two models agree when the
+    full model's torso joints rest (q = v = a = 0 there) -- on the rows of the joints both have; the mass is conserved."""
+    full, red = rm.load_named("icub"), rm.load_named("icub32")
+    assert (full.nv, red.nv, red.nq, red.njoints, red.ncontacts) == (35, 32, 33, 27, 2)
+    names = rm.joint_names("icub")
+    locked = [i for i, n in enumerate(names) if n in rm.ICUB32_LOCKED]
+    keep_v = [k for k in range(full.nv) if k not in [full.idx_v[i] for i in locked]]
+    keep_q = [k for k in range(full.nq) if k not in [full.idx_q[i] for i in locked]]
+    assert abs(sum(full.mass[i] for i in range(full.njoints)) - sum(red.mass[i] for i in range(red.njoints))) < 1e-12
+    rng = np.random.default_rng(3)
+    for trial in range(3):
+        q, v, a = rm.random_configuration(full, rng, 0.7)
+        for i in locked:
+            q[full.idx_q[i]] = v[full.idx_v[i]] = a[full.idx_v[i]] = 0.0
+        f = rng.uniform(-30, 30, 12)
+        pref, rref = rng.uniform(-0.3, 0.3, (2, 3)), np.tile(np.eye(3).reshape(9), (2, 1))
+        u_full = rng.uniform(-5, 5, full.nv - 6)
+        u_red = np.array([u_full[k - 6] for k in keep_v[6:]])
+        r_full = oracle.rbd_eval(full, False, q, v, a, f, u_full, 0b11, pref, rref)
+        r_red = oracle.rbd_eval(red, False, q[keep_q], v[keep_v], a[keep_v], f, u_red, 0b11, pref, rref)
+        assert np.abs(r_full[keep_v] - r_red[:32]).max() < 1e-9 * max(1.0, np.abs(r_full).max())   # ID rows of the common joints
+        assert np.abs(r_full[35:] - r_red[32:]).max() < 1e-10                                      # contact rows
+        for c in range(2):
+            Rf, pf = oracle.rbd_contact_placement(full, q, c)
+            Rr, pr_ = oracle.rbd_contact_placement(red, q[keep_q], c)
+            assert np.abs(Rf - Rr).max() < 1e-12 and np.abs(pf - pr_).max() < 1e-12

@@ -53,6 +53,16 @@ if os.path.exists(trace):
         lines.append("%s, %d, %d, %d, %s, %s, %s, %s, %s, n=%d, avg %.4f, min %.4f, max %.4f" % (k + (len(v), sum(v) / len(v), min(v), max(v)))
                      + (" | back to back n=%d, avg %.4f" % (len(w), sum(w) / len(w)) if w else " | back to back n=0"))
 traffic = {}
+# average duration of every kernel over ALL launches of its largest launch geometry in the kernel trace of the bench command
+# (bench.py prints it beside its own event-timed kernel_ms: the trace mixes sweep-loop, in-iteration and other launches)
+kernel_ms = {}
+if os.path.exists(trace):
+    for k, v in acc.items():
+        w = b2b.get(k, [])
+        cur = kernel_ms.get(k[0])
+        if cur is None or k[1] * k[2] > cur["workgroups"]:
+            kernel_ms[k[0]] = {"workgroups": k[1] * k[2], "calls": len(v), "avg_ms": sum(v) / len(v), "min_ms": min(v), "max_ms": max(v),
+                               "back_to_back_calls": len(w), "back_to_back_avg_ms": (sum(w) / len(w)) if w else None}
 for cname, d in (("FETCH_SIZE", "prof_fetch/fetch"), ("WRITE_SIZE", "prof_write/write")):
     acc = collections.OrderedDict()
     for r in csv.DictReader(open(os.path.join(OUT, d + "_counter_collection.csv"))):
@@ -85,6 +95,7 @@ for d in ("prof_sq1/sq1", "prof_sq2/sq2"):
 sys.path.insert(0, R)
 import bench  # kernel_source_hash: bench.py refuses counter passes taken from other kernel sources
 traffic["_kernel_source_hash"] = bench.kernel_source_hash()
+traffic["_kernel_ms_rocprof"] = kernel_ms
 open(os.path.join(DST, tag + "_rocprof_summary.txt"), "w").write("\n".join(lines) + "\n")
 json.dump(traffic, open(os.path.join(DST, tag + "_traffic.json"), "w"), indent=1)
 shutil.copy(os.path.join(OUT, "bench.json"), os.path.join(DST, tag + "_bench.json"))
