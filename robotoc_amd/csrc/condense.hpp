@@ -87,6 +87,7 @@ struct ExpArgs {
   rtoc_record_layout cl, dl;
   double tau;
   const double* dt_inst;  // per-instance time steps or nullptr (grid_dt)
+  long long* prof;        // optional cycle stamps (slots 32..39) of the work item in the middle of the launch (tuning aid)
 };
 
 template <int NV, int NU, int NF, int NS, bool SPLIT = false>
@@ -1028,25 +1029,88 @@ __global__ __launch_bounds__(64, (MjCfg<NV, NF>::MIN_WAVES)) void mjtjinv_kernel
   if (stat) atomicOr(&a.status[b], stat);
 }
 
+// LDS carve of expand_kernel: the blocks of the ContactDynamicsData record its mat-vecs walk, staged once with coalesced
+// 16-B loads that are all in flight together with every other read of the work item (the vectors, the joint-limit rows' data):
+// ONE round trip to HBM per work item.  (The walks used to fetch the blocks column by column, 288 B per load instruction in
+// dependent batches, MJtJinv twice, and the row data in two further dependent round trips.)  Cycle stamps of one work item
+// (tools/expand_profile.py): 15k of its 28k cycles are that one round trip under load -- the kernel is bound by the bytes it can
+// keep in flight (six work items per CU by LDS); a persistent, software-pipelined form (next item's reads in flight during this
+// item's walks) was tried and is slower: its staging registers allow four work items per CU only.
+template <int NV, int NU, int NF>
+struct ExpCfg {
+  static constexpr int NX = 2 * NV, NP = NV - NU, LDV = NV + NF, NFP = NF > 0 ? NF : 1, NPP = NP > 0 ? NP : 1;
+  static constexpr int pad8(int n) { return (n + 7) & ~7; }
+  static constexpr int O_LD = 0, O_LAM = O_LD + pad8(LDV * NX), O_QFF = O_LAM + pad8(LDV * LDV), O_QQF = O_QFF + pad8(NFP * NFP),
+                       O_QXUP = O_QQF + pad8(NV * NFP), O_QUUP = O_QXUP + pad8(NX * NPP), LDS_DOUBLES = O_QUUP + pad8(NPP * NU);
+  static constexpr int LDS_BYTES = LDS_DOUBLES * 8;
+};
+
 template <int NV, int NU, int NF, int NS>
 __global__ __launch_bounds__(64) void expand_kernel(ExpArgs a) {
-  constexpr int NX = 2 * NV, NP = NV - NU, LDV = NV + NF, LDS_ = NS > 0 ? NS : 1;
+  using E = ExpCfg<NV, NU, NF>;
+  constexpr int NX = 2 * NV, NP = NV - NU, LDV = NV + NF, LDS_ = NS > 0 ? NS : 1, NT = 64;
   const int lane = threadIdx.x;
   const int item = blockIdx.x;
   const int nst1 = a.nstages - 1;
   const int b = item / nst1, st = item % nst1;
   if (b >= a.batch) return;
-  const rtoc_grid g = a.grid[st];
-  const bool impact = g.type == RTOC_GRID_IMPACT;
-  const int nf = g.dimf, nvf = NV + nf, ns = impact ? 0 : g.dims;
-  const double dt = grid_dt(a.grid, a.dt_inst, b, a.nstages, st);
   constexpr rtoc_layout SL = StaticLayout<NV, NU, NS>::make();
   constexpr rtoc_record_layout CL = SL.cdd, DL = SL.dir;
   double* cr = a.cdd + ((size_t)b * a.nstages + st) * CL.stride;
   double* dr = a.dir + ((size_t)b * a.nstages + st) * DL.stride;
   const double* dn = dr + DL.stride;
-  const double* Lam = cr + CL.off[RTOC_CDD_MJTJINV];
-  const double* LD = cr + CL.off[RTOC_CDD_MJD];
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* const LD = smem + E::O_LD;      // MJtJinv_dIDCdqv
+  double* const Lam = smem + E::O_LAM;    // MJtJinv
+  double* const Qff = smem + E::O_QFF;
+  double* const Qqf = smem + E::O_QQF;
+  double* const Qxup = smem + E::O_QXUP;
+  double* const Quuptr = smem + E::O_QUUP;
+  RTOC_CPROF(32);
+  // ---- every read of the work item, requested up front (max-size records: no address depends on the grid descriptor) ----
+  typedef double dbl2 __attribute__((ext_vector_type(2)));
+  constexpr int LDF = NF > 0 ? NF : 1;
+  constexpr int H_LD = (LDV * NX + 1) / 2, H_LAM = (LDV * LDV + 1) / 2, H_FF = (LDF * LDF + 1) / 2, H_QF = (NV * LDF + 1) / 2,
+                H_XP = (NX * E::NPP + 1) / 2, H_UP = (E::NPP * NU + 1) / 2;
+  constexpr int N_LD = (H_LD + NT - 1) / NT, N_LAM = (H_LAM + NT - 1) / NT, N_FF = (H_FF + NT - 1) / NT, N_QF = (H_QF + NT - 1) / NT,
+                N_XP = (H_XP + NT - 1) / NT, N_UP = (H_UP + NT - 1) / NT;
+  dbl2 gLD[N_LD], gLam[N_LAM], gFF[N_FF], gQF[N_QF], gXP[N_XP], gUP[N_UP];
+#define RTOC_XLD(dst, CNT, src, n2)                                                  \
+  _Pragma("unroll") for (int k = 0; k < (CNT); ++k) {                                \
+    const int e = lane + k * NT;                                                     \
+    dst[k] = reinterpret_cast<const dbl2*>(src)[e < (n2) ? e : 0];                   \
+  }
+#define RTOC_XST(dst, src, CNT, n2)                                                  \
+  _Pragma("unroll") for (int k = 0; k < (CNT); ++k) {                                \
+    const int e = lane + k * NT;                                                     \
+    if (e < (n2)) reinterpret_cast<dbl2*>(dst)[e] = src[k];                          \
+  }
+  RTOC_XLD(gLD, N_LD, cr + CL.off[RTOC_CDD_MJD], H_LD)
+  RTOC_XLD(gLam, N_LAM, cr + CL.off[RTOC_CDD_MJTJINV], H_LAM)
+  RTOC_XLD(gFF, N_FF, cr + CL.off[RTOC_CDD_QFF], H_FF)
+  RTOC_XLD(gQF, N_QF, cr + CL.off[RTOC_CDD_QQF], H_QF)
+  if constexpr (NP > 0) {
+    RTOC_XLD(gXP, N_XP, cr + CL.off[RTOC_CDD_QXUP], H_XP)
+    RTOC_XLD(gUP, N_UP, cr + CL.off[RTOC_CDD_QUUPTR], H_UP)
+  }
+  // the joint-limit rows' data too: rows r = lane and lane + 64 cover the 72 rows of a quadruped, further rows in the loop below
+  double* const nr = a.con ? a.con + ((size_t)b * a.nstages + st) * a.nl.stride : nullptr;
+  constexpr int PRE = 2;
+  rtoc_box_row prow[PRE];
+  double pslack[PRE], pdual[PRE], pres[PRE], pcmpl[PRE];
+  if (a.con) {
+#pragma unroll
+    for (int k = 0; k < PRE; ++k) {
+      const int r = lane + 64 * k, rc = r < a.nrows ? r : 0;
+      prow[k] = a.rows[rc];
+      pslack[k] = nr[a.nl.off[RTOC_CON_SLACK] + rc], pdual[k] = nr[a.nl.off[RTOC_CON_DUAL] + rc];
+      pres[k] = nr[a.nl.off[RTOC_CON_RESIDUAL] + rc], pcmpl[k] = nr[a.nl.off[RTOC_CON_CMPL] + rc];
+    }
+  }
+  const rtoc_grid g = a.grid[st];
+  const bool impact = g.type == RTOC_GRID_IMPACT;
+  const int nf = g.dimf, nvf = NV + nf, ns = impact ? 0 : g.dims;
+  const double dt = grid_dt(a.grid, a.dt_inst, b, a.nstages, st);
   const double* Lr = cr + CL.off[RTOC_CDD_MJIDC];
   // Qafqv / Qafu_full are NOT read back: Qafqv dx + Qafu du is rebuilt from t = MJtJinv[:, u] du - MJtJinv_dIDCdqv dx,
   // which the primal expansion needs anyway, and the small input blocks Qaa (diagonal), Qff, Qqf
@@ -1054,13 +1118,8 @@ __global__ __launch_bounds__(64) void expand_kernel(ExpArgs a) {
   //   rows >= nv:  Qff t_f - Qqf^T dx_q              (:71-75,79-80)
   // -- 1.6k doubles per grid point that the condensation then need not store (RTOC_OPT_CONDENSE_KEEP_QAF)
   const double* Qaa = cr + CL.off[RTOC_CDD_QAA];
-  const double* Qff = cr + CL.off[RTOC_CDD_QFF];
-  const double* Qqf = cr + CL.off[RTOC_CDD_QQF];
-  constexpr int LDF = NF > 0 ? NF : 1;
   double* laf = cr + CL.off[RTOC_CDD_LAF];
   const double* haf = cr + CL.off[RTOC_CDD_HAF];
-  const double* Qxup = cr + CL.off[RTOC_CDD_QXUP];
-  const double* Quuptr = cr + CL.off[RTOC_CDD_QUUPTR];
   const double* lup = cr + CL.off[RTOC_CDD_LUP];
   const double* Phia = cr + CL.off[RTOC_CDD_PHIA];
   __shared__ double sdx[NX + 8], sdu[NU + 8], sg[NV + 8], sxi[LDS_ + 8], slaf[LDV + 8], st_[LDV + 8], sda[NV + 8];
@@ -1068,85 +1127,115 @@ __global__ __launch_bounds__(64) void expand_kernel(ExpArgs a) {
   if (lane < NU) sdu[lane] = impact ? 0.0 : dr[DL.off[RTOC_DIR_DU] + lane];
   for (int i = lane; i < NV; i += 64) sg[i] = dn[DL.off[RTOC_DIR_DLMDGMM] + NV + i];
   if (lane < ns) sxi[lane] = dr[DL.off[RTOC_DIR_DXI] + lane];
-  __syncthreads();
+  // the row-wise vectors of the walks, one per lane
+  static_assert(LDV <= 64, "one lane per row of the nvf-row products");
+  constexpr int H = (LDV <= 32) ? 2 : 1;  // with nvf <= 32 the two half-waves split the columns
+  const int hh = (H == 2) ? (lane >> 5) : 0, i0 = (H == 2) ? (lane & 31) : lane;
+  const int ir0 = i0 < nvf ? i0 : 0;
+  const double vLr = Lr[ir0], vLaf = laf[ir0], vHaf = haf[ir0], vQaa = Qaa[ir0 < NV ? ir0 : 0];
   double dtsv = 0.0;
   if (!impact && g.num_grids_in_phase > 0)
     dtsv = (dr[DL.off[RTOC_DIR_DTS] + 1] - dr[DL.off[RTOC_DIR_DTS] + 0]) / (double)g.num_grids_in_phase;
   const bool use_dts = (dtsv < -2.220446049250313e-16 || dtsv > 2.220446049250313e-16);
-  // rows i of the nvf-row products over the lanes; with nvf <= 32 the two half-waves split the columns
-  constexpr int H = (LDV <= 32) ? 2 : 1;
-  const int hh = (H == 2) ? (lane >> 5) : 0, i0 = (H == 2) ? (lane & 31) : lane;
+  RTOC_CPROF(33);
+  RTOC_XST(LD, gLD, N_LD, H_LD)
+  RTOC_XST(Lam, gLam, N_LAM, H_LAM)
+  RTOC_XST(Qff, gFF, N_FF, H_FF)
+  RTOC_XST(Qqf, gQF, N_QF, H_QF)
+  if constexpr (NP > 0) {
+    RTOC_XST(Qxup, gXP, N_XP, H_XP)
+    RTOC_XST(Quuptr, gUP, N_UP, H_UP)
+  }
+#undef RTOC_XLD
+#undef RTOC_XST
+  RTOC_CPROF(34);
+  __syncthreads();
+  RTOC_CPROF(35);
   // primal (:167-174, impact :83-88) and the laf accumulation of the dual (:190-198, impact :91-95)
-  for (int i = i0; i < (H == 2 ? 32 : ((nvf + 63) & ~63)); i += 64 / H) {
-    const bool row = i < nvf;
-    const int ir = row ? i : 0;
+  {
+    const bool row = i0 < nvf;
     double acc = 0.0;
-    for (int j = hh; j < NX; j += H) acc -= LD[ir + (size_t)j * LDV] * sdx[j];
+    for (int j = hh; j < NX; j += H) acc -= LD[ir0 + j * LDV] * sdx[j];
     if (!impact)
-      for (int j = hh; j < NU; j += H) acc += Lam[ir + (size_t)(NP + j) * LDV] * sdu[j];
+      for (int j = hh; j < NU; j += H) acc += Lam[ir0 + (NP + j) * LDV] * sdu[j];
     if (H == 2) acc += __shfl_xor(acc, 32, 64);
     if (row && hh == 0) {
-      st_[i] = acc;  // t_i
-      double daf = acc - Lr[i];
-      if (i >= NV) daf = -daf;
-      else sda[i] = daf;  // the acceleration-limit rows expand with da
-      dr[DL.off[RTOC_DIR_DAF] + i] = daf;
+      st_[i0] = acc;  // t_i
+      double daf = acc - vLr;
+      if (i0 >= NV) daf = -daf;
+      else sda[i0] = daf;  // the acceleration-limit rows expand with da
+      dr[DL.off[RTOC_DIR_DAF] + i0] = daf;
     }
   }
   __syncthreads();
-  for (int i = i0; i < (H == 2 ? 32 : ((nvf + 63) & ~63)); i += 64 / H) {
-    const bool row = i < nvf;
-    const int ir = row ? i : 0;
+  {
+    const bool row = i0 < nvf;
     double accl = 0.0;
-    if (ir < NV) {
+    if (ir0 < NV) {
       if (hh == 0) {
-        accl = laf[ir] + Qaa[ir] * st_[ir] + (impact ? 1.0 : dt) * sg[ir];
+        accl = vLaf + vQaa * st_[ir0] + (impact ? 1.0 : dt) * sg[ir0];
         if (NS > 0 && ns > 0)
-          for (int l = 0; l < ns; ++l) accl += Phia[l + (size_t)ir * LDS_] * sxi[l];
+          for (int l = 0; l < ns; ++l) accl += Phia[l + (size_t)ir0 * LDS_] * sxi[l];
       }
     } else {
-      const int f = ir - NV;
-      for (int k = hh; k < nf; k += H) accl += Qff[f + (size_t)k * LDF] * st_[NV + k];
-      for (int j = hh; j < NV; j += H) accl -= Qqf[j + (size_t)f * NV] * sdx[j];
-      if (hh == 0) accl += laf[ir];
+      const int f = ir0 - NV;
+      for (int k = hh; k < nf; k += H) accl += Qff[f + k * LDF] * st_[NV + k];
+      for (int j = hh; j < NV; j += H) accl -= Qqf[j + f * NV] * sdx[j];
+      if (hh == 0) accl += vLaf;
     }
     if (H == 2) accl += __shfl_xor(accl, 32, 64);
-    if (use_dts) accl += dtsv * haf[ir];
+    if (use_dts) accl += dtsv * vHaf;
     if (row && hh == 0) {
-      laf[i] = accl;  // the reference updates data.laf() in place as well
-      slaf[i] = accl;
+      laf[i0] = accl;  // the reference updates data.laf() in place as well
+      slaf[i0] = accl;
     }
   }
-  // dnu_passive (:178-188)
-  if (!impact && NP > 0 && lane < NP) {
-    double acc = -lup[lane];
-    for (int j = 0; j < NU; ++j) acc -= Quuptr[lane + j * NP] * sdu[j];
-    for (int j = 0; j < NX; ++j) acc -= Qxup[j + (size_t)lane * NX] * sdx[j];
-    for (int j = 0; j < NV; ++j) acc -= dt * Lam[lane + (size_t)j * LDV] * sg[j];
-    dr[DL.off[RTOC_DIR_DNUP] + lane] = acc;
+  RTOC_CPROF(36);
+  // dnu_passive (:178-188): NP rows of NU + NX + NV terms, each row over PARTS lanes (lane = row + NP * part), summed through LDS
+  if constexpr (NP > 0) {
+    constexpr int PARTS = 64 / NP;
+    __shared__ double spart[64];
+    const int prow_ = lane % NP, part = lane / NP;
+    double acc = 0.0;
+    if (!impact && part < PARTS) {
+      for (int j = part; j < NU; j += PARTS) acc -= Quuptr[prow_ + j * NP] * sdu[j];
+      for (int j = part; j < NX; j += PARTS) acc -= Qxup[j + prow_ * NX] * sdx[j];
+      for (int j = part; j < NV; j += PARTS) acc -= dt * Lam[prow_ + j * LDV] * sg[j];
+    }
+    spart[lane] = (part < PARTS) ? acc : 0.0;
+    __syncthreads();
+    if (!impact && lane < NP) {
+      double sum = -lup[lane];
+#pragma unroll
+      for (int p_ = 0; p_ < PARTS; ++p_) sum += spart[lane + NP * p_];
+      dr[DL.off[RTOC_DIR_DNUP] + lane] = sum;
+    }
+  } else {
+    __syncthreads();
   }
-  __syncthreads();
+  RTOC_CPROF(37);
   // ================= PDIPM expansion + fraction-to-boundary (constraints.cpp:360-458) =================
   if (a.con && !impact) {
-    double* nr = a.con + ((size_t)b * a.nstages + st) * a.nl.stride;
     const int* no = a.nl.off;
     double fp = 1.0, fd = 1.0;
-    for (int r = lane; r < a.nrows; r += 64) {
-      const rtoc_box_row row = a.rows[r];
-      if (g.time_stage >= row.level) {
+    auto one_row = [&](const int r, const rtoc_box_row& row, const double slack, const double dual, const double res, const double cmpl) {
+      if (r < a.nrows && g.time_stage >= row.level) {
         const double dz = row.var == RTOC_VAR_U ? sdu[row.index]
                                                 : (row.var == RTOC_VAR_V ? sdx[NV + row.index]
                                                                          : (row.var == RTOC_VAR_A ? sda[row.index] : sdx[row.index]));
-        const double slack = nr[no[RTOC_CON_SLACK] + r], dual = nr[no[RTOC_CON_DUAL] + r];
-        const double dslack = -row.sign * dz - nr[no[RTOC_CON_RESIDUAL] + r];
-        const double ddual = -(dual * dslack + nr[no[RTOC_CON_CMPL] + r]) / slack;
+        const double dslack = -row.sign * dz - res;
+        const double ddual = -(dual * dslack + cmpl) / slack;
         nr[no[RTOC_CON_DSLACK] + r] = dslack;
         nr[no[RTOC_CON_DDUAL] + r] = ddual;
         const double fs = -a.tau * (slack / dslack), fdd = -a.tau * (dual / ddual);  // pdipm.hxx:121-142
         if (fs > 0.0 && fs < 1.0) fp = fmin(fp, fs);
         if (fdd > 0.0 && fdd < 1.0) fd = fmin(fd, fdd);
       }
-    }
+    };
+#pragma unroll
+    for (int k = 0; k < PRE; ++k) one_row(lane + 64 * k, prow[k], pslack[k], pdual[k], pres[k], pcmpl[k]);
+    for (int r = lane + 64 * PRE; r < a.nrows; r += 64)
+      one_row(r, a.rows[r], nr[no[RTOC_CON_SLACK] + r], nr[no[RTOC_CON_DUAL] + r], nr[no[RTOC_CON_RESIDUAL] + r], nr[no[RTOC_CON_CMPL] + r]);
     // min over the wave, then over the instance: positive doubles order like their bit patterns
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -1158,15 +1247,16 @@ __global__ __launch_bounds__(64) void expand_kernel(ExpArgs a) {
       atomicMin(&a.steps[2 * b + 1], (unsigned long long)__double_as_longlong(fd));
     }
   }
+  RTOC_CPROF(38);
   // dbetamu = -MJtJinv * laf (:201, impact :95)
-  for (int i = i0; i < (H == 2 ? 32 : ((nvf + 63) & ~63)); i += 64 / H) {
-    const bool row = i < nvf;
-    const int ir = row ? i : 0;
+  {
+    const bool row = i0 < nvf;
     double acc = 0.0;
-    for (int j = hh; j < nvf; j += H) acc -= Lam[ir + (size_t)j * LDV] * slaf[j];
+    for (int j = hh; j < nvf; j += H) acc -= Lam[ir0 + j * LDV] * slaf[j];
     if (H == 2) acc += __shfl_xor(acc, 32, 64);
-    if (row && hh == 0) dr[DL.off[RTOC_DIR_DBETAMU] + i] = acc;
+    if (row && hh == 0) dr[DL.off[RTOC_DIR_DBETAMU] + i0] = acc;
   }
+  RTOC_CPROF(39);
 }
 
 // updateSlack / updateDual (constraints_impl.hxx:167-182) with the per-instance step sizes

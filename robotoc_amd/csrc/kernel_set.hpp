@@ -62,7 +62,7 @@ struct KernelSet {
   int cond_threads, cond_lds, cond_split_lds;
   int cond_fuses_cones;  // the one-kernel condensation condenses the friction / wrench cone rows itself (CondCfg::FUSE)
   expd_fn expd;
-  int expd_threads;
+  int expd_threads, expd_lds;
   // horizon scan of the backward recursion (riccati_scan.hpp)
   scan_fn scan_elt, scan_comb;
   int scan_elt_lds, scan_comb_lds, scan_comb_threads;
@@ -143,6 +143,7 @@ inline KernelSet make_set() {
                 "LDS carve of the split condensation grew past its granule budget");
   k.expd = expand_kernel<NV, NU, NF, NS>;
   k.expd_threads = 64;
+  k.expd_lds = ExpCfg<NV, NU, NF>::LDS_BYTES;
   k.scan_elt = scan_element_kernel<NV, NU, NS>;
   k.scan_comb = scan_combine_kernel<NV>;
   k.scan_elt_lds = scan::ElementCfg<NV, NU, NS>::LDS_BYTES;

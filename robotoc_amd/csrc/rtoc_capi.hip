@@ -406,6 +406,7 @@ static int create_members(rtoc_ctx* c, const rtoc_dims* dims, const KernelSet* k
   HIP_TRY(hipFuncSetAttribute((const void*)ks->cond_split, hipFuncAttributeMaxDynamicSharedMemorySize,
                               ks->cond_split_lds));
   HIP_TRY(hipFuncSetAttribute((const void*)ks->mjt, hipFuncAttributeMaxDynamicSharedMemorySize, ks->mjt_lds));
+  HIP_TRY(hipFuncSetAttribute((const void*)ks->expd, hipFuncAttributeMaxDynamicSharedMemorySize, ks->expd_lds));
   HIP_TRY(hipFuncSetAttribute((const void*)ks->scan_elt, hipFuncAttributeMaxDynamicSharedMemorySize,
                               ks->scan_elt_lds));
   HIP_TRY(hipFuncSetAttribute((const void*)ks->scan_comb, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1119,10 +1120,11 @@ static int launch_expand(rtoc_ctx* c, double tau) {
   a.nl = c->L.con;
   a.steps = (unsigned long long*)c->buf[RTOC_BUF_STEP];
   a.dt_inst = c->sto_on ? c->d_dt : nullptr;
+  a.prof = c->d_prof;
   hipLaunchKernelGGL(fill_steps_kernel, dim3((2 * c->batch + 255) / 256), dim3(256), 0, c->stream,
                      c->buf[RTOC_BUF_STEP], 2 * c->batch);
   const int nblocks = c->batch * (c->nstages - 1);
-  hipLaunchKernelGGL(c->ks->expd, dim3(nblocks), dim3(c->ks->expd_threads), 0, c->stream, a);
+  hipLaunchKernelGGL(c->ks->expd, dim3(nblocks), dim3(c->ks->expd_threads), c->ks->expd_lds, c->stream, a);
   HIP_TRY(hipGetLastError());
   return RTOC_OK;
 }
