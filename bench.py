@@ -770,6 +770,17 @@ def main():
                 whole += ms / nrep
                 wall += w1 * 1e3 / nrep
         bad_sqp = int((ctx.status() != 0).sum())
+        # the one-kernel condensation (RTOC_OPT_CONDENSE_SPLIT = 0: MJtJinv never leaves the chip between its assembly and its use,
+        # the cone rows ride in wave 1) beside the default two-kernel pipeline
+        ctx.set_condense_split(False)
+        fused_ms = 0.0
+        for rep in range(nrep + 1):
+            restore()
+            ms = ctx.time_phase(ph["condense"], 1)
+            if rep > 0:
+                fused_ms += ms / nrep
+        bad_sqp += int((ctx.status() != 0).sum())
+        ctx.set_condense_split(True)
         cb = condense_bytes(L, grids, batch)
         eb = expand_bytes(L, grids, batch, rows, 4)
         sqp = {"newton_iteration_ms": whole, "newton_iteration_wall_ms": wall,
@@ -780,7 +791,11 @@ def main():
                                      "frac": cb / (acc["condense"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                      "algorithmic_bytes_per_launch": cb, "kernels": "mjtjinv_kernel + condense_kernel",
                                      "traffic": (lambda a, b: a + b if a and b else None)(
-                                         pmc_traffic("mjtjinv_kernel"), pmc_traffic("condense_kernel"))},
+                                         pmc_traffic("mjtjinv_kernel"), pmc_traffic("condense_kernel<18, 12, 12, 12, true>"))},
+               "roofline_condense_fused": {"bound": "hbm", "kernel_ms": fused_ms, "achieved": cb / (fused_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                                           "unit": "GB/s", "frac": cb / (fused_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": cb,
+                                           "kernels": "condense_kernel<.., SPLIT = false> (RTOC_OPT_CONDENSE_SPLIT = 0; not the default: slower)",
+                                           "traffic": pmc_traffic("condense_kernel<18, 12, 12, 12, false>")},
                "roofline_expand": {"bound": "hbm", "achieved": eb / (acc["expand"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                                    "unit": "GB/s", "frac": eb / (acc["expand"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                    "algorithmic_bytes_per_launch": eb, "kernels": "expand_kernel + cone_expand_kernel",

@@ -107,9 +107,10 @@ struct CondCfg {
   static constexpr int O_X = O_LD + pad8(LDV * NX);
   static constexpr int X_A = pad8(NV * NV) + 2 * pad8(NFP * NV) + 2 * pad8(NFP * NFP);
   // FUSE (the one-kernel condensation on contact shapes): the factorisation scratch is dead before MJtJinv_dIDCdqv is born
-  // and lives in ITS region; the cone rows ride in wave 1 while wave 0 factorises M (their scratch: the not yet initialised
-  // MJtJinv).  ANYmal: 37.2 -> 31.1 KB = 25 LDS granules, five work items per CU like the split kernel.
-  static constexpr bool FUSE = !SPLIT && NF > 0 && X_A <= pad8(LDV * NX) && RTOC_COND_NW >= 2 && ConeScratch<NV, NF>::DOUBLES <= LDV * LDV;
+  // and lives in ITS region; wave 0 assembles MJtJinv ALONE (the serial factorisations dominate it) while wave 1 condenses the
+  // cone rows (scratch: the dIDCdqv region, not staged yet) and wave 2 fetches dIDCdqv and IDC.  ANYmal: 37.2 -> 31.1 KB = 25
+  // LDS granules, five work items per CU like the split kernel.
+  static constexpr bool FUSE = !SPLIT && NF > 0 && X_A <= pad8(LDV * NX) && RTOC_COND_NW >= 3 && ConeScratch<NV, NF>::DOUBLES <= LDV * NX;
   static constexpr int O_L = FUSE ? O_LD : O_X;                // NV x NV
   static constexpr int O_J = O_L + pad8(NV * NV);              // NF x NV (ld NFP)
   static constexpr int O_JM = O_J + pad8(NFP * NV);            // NF x NV
@@ -474,26 +475,37 @@ __global__ __launch_bounds__(64 * RTOC_COND_NW, (CondCfg<NV, NU, NF, NS, SPLIT>:
   const bool box_lane = box_on && lane < NE;
   int4 pd = make_int4(-1, -1, 0, 0);
   int ent0 = 0, ent1 = 0;  // rows of the entry beyond the first two: CSR range
+  // the packed row descriptor of the lane's primal entry: the same for every work item (an L2 hit), requested first -- in the
+  // fused kernel at the very top, so that the row data can be requested the moment the cone rows are done
+#define RTOC_BOX_DESCRIPTOR                                  \
+  if (box_on) {                                              \
+    const int t = lane < NE ? lane : 0;                      \
+    pd = a.pair[t];                                          \
+    ent0 = a.entry[t] + 2;                                   \
+    ent1 = a.entry[t + 1];                                   \
+  }
 #define RTOC_FIELD_LOADS                                                                                     \
-  RTOC_LD2(gD, N_D, cr + CL.off[RTOC_CDD_DIDCDQV], H_D)                                                       \
+  if constexpr (!FUSE) {                                                                                      \
+    RTOC_BOX_DESCRIPTOR                                                                                       \
+  }                                                                                                           \
+  if constexpr (!FUSE) {                                                                                      \
+    RTOC_LD2(gD, N_D, cr + CL.off[RTOC_CDD_DIDCDQV], H_D)                                                     \
+    vIdc = cr[CL.off[RTOC_CDD_IDC] + lvf_];                                                                   \
+  }                                                                                                           \
   RTOC_LD2(gF, N_F, cr + CL.off[RTOC_CDD_QFF], H_F)                                                           \
   RTOC_LD2(gQ, N_J, cr + CL.off[RTOC_CDD_QQF], H_J)                                                           \
   vQaa = cr[CL.off[RTOC_CDD_QAA] + lv_], vLa = cr[CL.off[RTOC_CDD_LA] + lv_], vHa = cr[CL.off[RTOC_CDD_HA] + lv_]; \
-  vLf = cr[CL.off[RTOC_CDD_LF] + lf_], vHf = cr[CL.off[RTOC_CDD_HF] + lf_], vIdc = cr[CL.off[RTOC_CDD_IDC] + lvf_]; \
+  vLf = cr[CL.off[RTOC_CDD_LF] + lf_], vHf = cr[CL.off[RTOC_CDD_HF] + lf_];                                    \
   pLx = lx[ix_], pHx = hx[ix_], pFf = fx[ix_], pFxv = Fx[NV + iv_];                                            \
   pLup = lup[iv_ < NP ? iv_ : 0], pLu = lu[iv_ >= NP ? iv_ - NP : 0], pHu = hu[iv_ >= NP ? iv_ - NP : 0];      \
   pSh = scal[RTOC_KKT_SCAL_H], pSq = scal[RTOC_KKT_SCAL_QTT];                                                  \
   prefetch_tiles<NW, NX, NX, NX>(Qxx, lane, cQxx);                                                             \
   prefetch_tiles<NW, NX, NU, NX>(Qxu, lane, cQxu);                                                             \
-  prefetch_tiles<NW, NU, NU, NU>(Quu, lane, cQuu);                                                             \
-  if (box_on) {                                                                                                \
-    const int t = lane < NE ? lane : 0;                                                                        \
-    pd = a.pair[t];                                                                                            \
-    ent0 = a.entry[t] + 2;                                                                                     \
-    ent1 = a.entry[t + 1];                                                                                     \
-  }
+  prefetch_tiles<NW, NU, NU, NU>(Quu, lane, cQuu);
   if constexpr (!FUSE) {
     RTOC_FIELD_LOADS
+  } else {
+    RTOC_BOX_DESCRIPTOR
   }
   RTOC_CPROF(21);
   // one lane per primal entry (q_k, v_k, u_k): the first two rows of the entry (a lower and an upper limit:
@@ -511,10 +523,15 @@ __global__ __launch_bounds__(64 * RTOC_COND_NW, (CondCfg<NV, NU, NF, NS, SPLIT>:
   }
   // registers -> LDS; vectors zero beyond the active contact dimension (the products run over the full extents)
 #define RTOC_FIELD_STORES                            \
-  RTOC_ST2(D, gD, N_D, H_D)                          \
+  if constexpr (!FUSE) {                             \
+    RTOC_ST2(D, gD, N_D, H_D)                        \
+    if (lane < LDV) IDC[lane] = lane < nvf ? vIdc : 0.0; \
+  }                                                  \
   RTOC_ST2(Qff, gF, N_F, H_F)                        \
   RTOC_ST2(Qqf, gQ, N_J, H_J)                        \
-  RTOC_BOX_LOADS                                     \
+  if constexpr (!FUSE) {                             \
+    RTOC_BOX_LOADS                                   \
+  }                                                  \
   RTOC_CPROF(23);                                    \
   if (lane < NV) {                                   \
     Qaa[lane] = vQaa;                                \
@@ -524,8 +541,7 @@ __global__ __launch_bounds__(64 * RTOC_COND_NW, (CondCfg<NV, NU, NF, NS, SPLIT>:
   if (lane < NF) {                                   \
     laf[NV + lane] = lane < nf ? -vLf : 0.0;         \
     haf[NV + lane] = lane < nf ? -vHf : 0.0;         \
-  }                                                  \
-  if (lane < LDV) IDC[lane] = lane < nvf ? vIdc : 0.0;
+  }
   if constexpr (!FUSE) {
     // inactive rows / columns (dimf < max_dimf) of the stored blocks stay zero, like the reference's
     // max-size backing matrices
@@ -547,7 +563,8 @@ __global__ __launch_bounds__(64 * RTOC_COND_NW, (CondCfg<NV, NU, NF, NS, SPLIT>:
   // LDS so that every product below can use its compile-time extents
 #define RTOC_ZERO_PADDING                                                                                           \
   if (nf < NF) {                                                                                                    \
-    for (int e = lane; e < (LDV - nvf) * NX; e += NT) D[nvf + e % (LDV - nvf) + (e / (LDV - nvf)) * LDV] = 0.0;    \
+    if constexpr (!FUSE)                                                                                            \
+      for (int e = lane; e < (LDV - nvf) * NX; e += NT) D[nvf + e % (LDV - nvf) + (e / (LDV - nvf)) * LDV] = 0.0;  \
     if constexpr (!SPLIT && !FUSE)                                                                                  \
       if (!impact) /* (impact: J = dCdv lives inside D, its inactive rows were zeroed with D's) */                  \
         for (int e = lane; e < (NF - nf) * NV; e += NT) sJ[nf + e % (NF - nf) + (e / (NF - nf)) * LDF] = 0.0;       \
@@ -564,9 +581,13 @@ __global__ __launch_bounds__(64 * RTOC_COND_NW, (CondCfg<NV, NU, NF, NS, SPLIT>:
   const double* const J = FUSE ? sJ : Jd;
   const int ldj = impact ? LDV : LDF;
 
+  // FUSE: wave 2's early reads -- dIDCdqv (all of it, over 64 lanes) and IDC, which no cone row touches and the first products need
+  constexpr int N_D2 = (H_D + 63) / 64;
+  dbl2 gD2[FUSE ? N_D2 : 1];
   if constexpr (FUSE) {
-    // ---- wave roles until the factor of M exists: 0 factorises, 1 condenses the cone rows ----
+    // ---- wave roles until MJtJinv exists: 0 assembles it alone, 1 condenses the cone rows, 2 fetches dIDCdqv / IDC ----
     if (wv == 0) {
+      for (int e = wl; e < LDV * LDV; e += 64) Lam[e] = 0.0;   // inactive rows / columns stay zero
 #pragma unroll
       for (int k = 0; k < N_L0; ++k) {
         const int e = wl + k * 64;
@@ -578,11 +599,22 @@ __global__ __launch_bounds__(64 * RTOC_COND_NW, (CondCfg<NV, NU, NF, NS, SPLIT>:
         if (e < C::NFP * NV) sJ[e] = (e % LDF < nf) ? (impact ? fJi[k] : fJ[k]) : 0.0;
       }
       wave_lds_sync_();
+      {
+        // computeMJtJinv by this wave alone: the fragment with one wave's worth of "work item" (names shadowed on purpose)
+        const int lane = wl;
+        constexpr int NT = 64, NW = 1;
+#define RTOC_MJ_SYNC() wave_lds_sync_()
+#define RTOC_J_IN_D false
+#include "condense_mjtjinv.inc"
+#undef RTOC_J_IN_D
+#undef RTOC_MJ_SYNC
+        // out to HBM now: its columns nv.. are recycled once MJtJinv_dIDCdqv exists (TAIL)
+        copy_s2g_flat16<NT>(cr + CL.off[RTOC_CDD_MJTJINV], Lam, LDV * LDV, lane);
+      }
     } else if (wv == 1) {
       // Constraints::condenseSlackAndDual of the cone rows (intermediate_stage.cpp:134-135) ahead of everything that reads
-      // Qqq, Qqf, Qff, lq, lf; scratch: the not yet initialised MJtJinv
+      // Qqq, Qqf, Qff, lq, lf; scratch: the dIDCdqv region, which is staged behind the barrier
       if (a.cone_rows != 0) {
-        static_assert(ConeScratch<NV, NF>::DOUBLES <= LDV * LDV, "cone scratch is aliased onto MJtJinv");
         ConeArgs ca;
         ca.kkt = a.kkt;
         ca.cdd = a.cdd;
@@ -607,36 +639,44 @@ __global__ __launch_bounds__(64 * RTOC_COND_NW, (CondCfg<NV, NU, NF, NS, SPLIT>:
         ca.dl = a.cl;  // unused by the condensation
         ca.prof = nullptr;
         if (a.cone_rows == RTOC_WRENCH_ROWS)
-          wrench_condense_body<NV, NF>(ca, b, st, wl, Lam);
+          wrench_condense_body<NV, NF>(ca, b, st, wl, D);
         else
-          cone_condense_body<NV, NF>(ca, b, st, wl, Lam);
+          cone_condense_body<NV, NF>(ca, b, st, wl, D);
         cone_wave_sync();
       }
-      for (int e = wl; e < LDV * LDV; e += 64) Lam[e] = 0.0;
+    } else if (wv == 2) {
+#pragma unroll
+      for (int k = 0; k < N_D2; ++k) {
+        const int e = wl + k * 64;
+        gD2[k] = reinterpret_cast<const dbl2*>(cr + CL.off[RTOC_CDD_DIDCDQV])[e < H_D ? e : 0];
+      }
+      vIdc = cr[CL.off[RTOC_CDD_IDC] + (wl < nvf ? wl : 0)];
     }
-#define RTOC_MJ_AFTER_LLT
-#define RTOC_MJ_AFTER_B1 RTOC_FIELD_LOADS
-#define RTOC_J_IN_D false
-#include "condense_mjtjinv.inc"
-#undef RTOC_J_IN_D
-#undef RTOC_MJ_AFTER_LLT
-#undef RTOC_MJ_AFTER_B1
-    // MJtJinv is complete: out to HBM before its columns nv.. are recycled (TAIL); the fields into LDS
-    copy_s2g_flat16<NT>(cr + CL.off[RTOC_CDD_MJTJINV], Lam, LDV * LDV, lane);
-    RTOC_FIELD_STORES
+    __syncthreads();   // MJtJinv assembled (and in flight to HBM), cone rows condensed (their writes visible), scratch free
+    RTOC_CPROF(3);
+    if (wv == 2) {   // dIDCdqv and IDC into LDS, zero beyond the active contact dimension
+#pragma unroll
+      for (int k = 0; k < N_D2; ++k) {
+        const int e = wl + k * 64;
+        if (e < H_D) {
+          dbl2 v = gD2[k];
+          if (nf < NF) {
+            if ((2 * e) % LDV >= nvf) v.x = 0.0;
+            if ((2 * e + 1) % LDV >= nvf) v.y = 0.0;
+          }
+          reinterpret_cast<dbl2*>(D)[e] = v;
+        }
+      }
+      if (wl < LDV) IDC[wl] = wl < nvf ? vIdc : 0.0;
+    }
+    RTOC_BOX_LOADS     // the joint-limit rows' data (descriptor requested at the top) ...
+    RTOC_FIELD_LOADS   // ... and everything else: it arrives during MJtJinv_dIDCdqv
     __syncthreads();
-    RTOC_ZERO_PADDING
   } else if constexpr (!SPLIT) {
 #define RTOC_J_IN_D impact
 #include "condense_mjtjinv.inc"
 #undef RTOC_J_IN_D
   }
-#undef RTOC_LD2
-#undef RTOC_ST2
-#undef RTOC_FIELD_LOADS
-#undef RTOC_FIELD_STORES
-#undef RTOC_ZERO_PADDING
-#undef RTOC_BOX_LOADS
 
   RTOC_CPROF(4);
   // ================= MJtJinv_dIDCdqv, MJtJinv_IDC (contact_dynamics.cpp:64-65 / impact :44-50) ===
@@ -648,6 +688,19 @@ __global__ __launch_bounds__(64 * RTOC_COND_NW, (CondCfg<NV, NU, NF, NS, SPLIT>:
                                                   [&](int r, int c, double v, int, int) { LD[r + (NV + c) * LDV] = v; });
   }
   wave_gemv<NT>(LDV, LDV, 1.0, Lam, 1, LDV, IDC, 0.0, Lr, lane);  // full extents: zero rows give Lr = 0 there
+  if constexpr (FUSE) {
+    // the fields requested behind the assembly of MJtJinv have arrived during the product above: registers -> LDS
+    RTOC_FIELD_STORES
+    __syncthreads();
+    RTOC_ZERO_PADDING
+  }
+#undef RTOC_LD2
+#undef RTOC_ST2
+#undef RTOC_FIELD_LOADS
+#undef RTOC_BOX_DESCRIPTOR
+#undef RTOC_FIELD_STORES
+#undef RTOC_ZERO_PADDING
+#undef RTOC_BOX_LOADS
   // ================= PDIPM slack/dual elimination of the joint-limit rows =================
   // Constraints::condenseSlackAndDual (constraints.cpp:322-357, joint_*_limit.cpp, pdipm.hxx:66-69):
   // purely additive on diag(Qqq), diag(Qvv), diag(Quu), lq, lv, lu, so it commutes with the

@@ -13,6 +13,20 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """On a GPU box: bring up torch's HIP runtime BEFORE the first rtoc context of the process.  torch ships its own copy of the
+    HIP runtime; the tests that hold device tensors (tests/test_determinism.py, the RCCL gather) initialise it lazily, and after
+    ~70 tests' worth of contexts of the library's runtime that late initialisation was seen to fail with "No HIP GPUs are
+    available" (order-dependent: the same tests pass on their own and in the full suite's order).  bench.py has torch first too."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+            torch.zeros(1, device="cuda:0")
+    except Exception:
+        pass
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from oracle import oracle as orc

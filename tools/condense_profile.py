@@ -24,7 +24,7 @@ ctx.condense(); ctx.sync()
 p = capi.debug_profile(ctx).astype(np.int64).reshape(-1)[:32]
 print("condense %.3f ms (best of 5: %.3f)" % (ctx.time_phase(2, 3), min(ctx.time_phase(2, 1) for _ in range(5))))
 fused = os.environ.get("RTOC_CONDENSE_SPLIT", "1") == "0"
-for name, slots in ((("fused condense_kernel (wave 0)", (0, 21, 1, 2, 3, 16, 17, 18, 19, 20, 23, 4, 5, 6, 10, 11, 12, 13, 7, 8, 9)),) if fused else
+for name, slots in ((("fused condense_kernel (wave 0)", (0, 1, 2, 16, 17, 18, 19, 20, 3, 4, 23, 5, 6, 10, 11, 12, 13, 7, 8, 9)),) if fused else
                     (("mjtjinv_kernel", (14, 25, 26, 27, 28, 15, 1, 2, 3, 16, 17, 18, 19, 20, 24)), ("condense_kernel", (0, 21, 22, 23, 4, 5, 6, 10, 11, 12, 13, 7, 8, 9)))):
     vals = [(k, p[k]) for k in slots if p[k]]
     if vals:

@@ -50,6 +50,15 @@ def main():
         ctx.expand(0.995)
         ctx.update()
     assert (ctx.status() == 0).all()
+    # the one-kernel condensation (RTOC_OPT_CONDENSE_SPLIT = 0: condense_kernel<..., false> with the cone rows inside)
+    ctx.set_condense_split(False)
+    for _ in range(reps):
+        ctx.upload(BUF_KKT, kkt)
+        ctx.upload(BUF_CDD, cdd)
+        ctx.upload(BUF_CON, con)
+        ctx.condense()
+    ctx.set_condense_split(True)
+    assert (ctx.status() == 0).all()
     del kkt, cdd, con
     # ---- rigid-body linearisation of the same batch ----
     from robotoc_amd import robot_model as rm
