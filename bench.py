@@ -132,6 +132,22 @@ def condense_bytes(L, grids, batch):
     return total * 8 * batch
 
 
+def constraint_row_bytes(grids, batch, rows, cone_contacts, nv):
+    """HBM bytes of the PDIPM rows' own data that one rtoc_condense launch moves: per active joint-limit row slack, dual, residual,
+    cmpl in and cond out; per active friction cone (5 rows) the same plus dg_dq (5 x nv) and dg_df (5 x 3).  Reported beside the
+    algorithmic bytes of the contact-dynamics condensation (condense_bytes), not inside them."""
+    from robotoc_amd.types import GRID_IMPACT, GRID_TERMINAL
+    total = 0
+    for g in grids:
+        if g.type == GRID_TERMINAL:
+            continue
+        if g.type != GRID_IMPACT:
+            total += 5 * sum(1 for r in rows if g.time_stage >= r.level)
+        nc = min(g.dimf // 3, cone_contacts)
+        total += nc * (5 * 5 + 5 * nv + 15)
+    return total * 8 * batch
+
+
 def expand_bytes(L, grids, batch, rows, cone_contacts, wrench=False):
     """Algorithmic HBM bytes of one rtoc_expand launch: per non-terminal grid point what
     expandContactDynamicsPrimal/Dual need (contact_dynamics.cpp:167-202: MJtJinv, MJtJinv_dIDCdqv,
@@ -770,18 +786,24 @@ def main():
                 whole += ms / nrep
                 wall += w1 * 1e3 / nrep
         bad_sqp = int((ctx.status() != 0).sum())
-        # the one-kernel condensation (RTOC_OPT_CONDENSE_SPLIT = 0: MJtJinv never leaves the chip between its assembly and its use,
-        # the cone rows ride in wave 1) beside the default two-kernel pipeline
-        ctx.set_condense_split(False)
-        fused_ms = 0.0
+        # the condensation pipeline that is NOT this shape's default (RTOC_OPT_CONDENSE_SPLIT: 0 = one kernel -- wave 0 assembles
+        # MJtJinv, wave 1 condenses the cone rows, wave 2 stages the inputs --, 1 = mjtjinv_kernel + condense_kernel), beside it
+        from robotoc_amd.types import OPT_CONDENSE_SPLIT
+        split_default = ctx.get_option(OPT_CONDENSE_SPLIT)
+        ctx.set_condense_split(not split_default)
+        other_ms = 0.0
         for rep in range(nrep + 1):
             restore()
             ms = ctx.time_phase(ph["condense"], 1)
             if rep > 0:
-                fused_ms += ms / nrep
+                other_ms += ms / nrep
         bad_sqp += int((ctx.status() != 0).sum())
-        ctx.set_condense_split(True)
+        ctx.set_condense_split(split_default)
+        k_fused, k_split = "condense_kernel<.., SPLIT = false> (one kernel)", "mjtjinv_kernel + condense_kernel<.., SPLIT = true>"
+        t_fused = pmc_traffic("condense_kernel<18, 12, 12, 12, false>")
+        t_split = (lambda a, b: a + b if a and b else None)(pmc_traffic("mjtjinv_kernel<18, 12, 12, 12>"), pmc_traffic("condense_kernel<18, 12, 12, 12, true>"))
         cb = condense_bytes(L, grids, batch)
+        crb = constraint_row_bytes(grids, batch, rows, 4, dims.nv)
         eb = expand_bytes(L, grids, batch, rows, 4)
         sqp = {"newton_iteration_ms": whole, "newton_iteration_wall_ms": wall,
                "iters_per_sec_per_gpu": batch / whole * 1e3, "phase_ms": acc, "phase_sum_ms": sum(acc.values()),
@@ -789,13 +811,18 @@ def main():
                "roofline_condense": {"bound": "hbm", "achieved": cb / (acc["condense"] * 1e-3) / 1e9,
                                      "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                      "frac": cb / (acc["condense"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                     "algorithmic_bytes_per_launch": cb, "kernels": "mjtjinv_kernel + condense_kernel",
-                                     "traffic": (lambda a, b: a + b if a and b else None)(
-                                         pmc_traffic("mjtjinv_kernel"), pmc_traffic("condense_kernel<18, 12, 12, 12, true>"))},
-               "roofline_condense_fused": {"bound": "hbm", "kernel_ms": fused_ms, "achieved": cb / (fused_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                                           "unit": "GB/s", "frac": cb / (fused_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": cb,
-                                           "kernels": "condense_kernel<.., SPLIT = false> (RTOC_OPT_CONDENSE_SPLIT = 0; not the default: slower)",
-                                           "traffic": pmc_traffic("condense_kernel<18, 12, 12, 12, false>")},
+                                     "algorithmic_bytes_per_launch": cb, "kernel_ms": acc["condense"],
+                                     "kernels": k_split if split_default else k_fused, "RTOC_OPT_CONDENSE_SPLIT": split_default,
+                                     "traffic": t_split if split_default else t_fused,
+                                     "constraint_row_bytes_per_launch": crb,
+                                     "constraint_row_bytes_note": "the PDIPM rows' own data (cone Jacobians, slack / dual / residual / cmpl in, cond "
+                                                                  "out: Constraints::condenseSlackAndDual reads and writes them too) -- NOT in "
+                                                                  "algorithmic_bytes_per_launch (SURVEY 8d counts the contact-dynamics condensation); "
+                                                                  "the counted traffic includes them"},
+               "roofline_condense_other_pipeline": {"bound": "hbm", "kernel_ms": other_ms, "achieved": cb / (other_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                                                    "unit": "GB/s", "frac": cb / (other_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": cb,
+                                                    "kernels": k_fused if split_default else k_split, "RTOC_OPT_CONDENSE_SPLIT": int(not split_default),
+                                                    "traffic": t_fused if split_default else t_split},
                "roofline_expand": {"bound": "hbm", "achieved": eb / (acc["expand"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                                    "unit": "GB/s", "frac": eb / (acc["expand"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                    "algorithmic_bytes_per_launch": eb, "kernels": "expand_kernel + cone_expand_kernel",

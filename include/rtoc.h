@@ -100,7 +100,12 @@ enum rtoc_option {
   RTOC_OPT_BACKWARD_WAVES = 2, /* waves per OCP instance in the backward kernel (0 = default for the dims) */
   RTOC_OPT_CONTACT_INV_DAMPING = 3, /* RobotModelInfo::contact_inv_damping (robot.hxx:662-664); value = double bits */
   RTOC_OPT_SWEEP_CHUNKS = 4, /* instance chunks of rtoc_riccati_sweep's backward/forward pipeline (1..16, default 1 = plain sequence) */
-  RTOC_OPT_CONDENSE_SPLIT = 5, /* 1 (default): rtoc_condense computes MJtJinv in its own high-occupancy kernel; 0: one fused kernel */
+  RTOC_OPT_CONDENSE_SPLIT = 5, /* rtoc_condense: 1 = MJtJinv (and the cone rows) in a high-occupancy kernel of their own ahead of the
+                              * condensation kernel; 0 = ONE kernel per grid point (wave 0 assembles MJtJinv, wave 1 condenses the cone
+                              * rows, wave 2 stages the inputs; MJtJinv goes to HBM once, for the expansion only).  Default per robot
+                              * shape: 0 where five work items of the one-kernel form fit a CU (quadruped-size shapes: same time,
+                              * one launch and ~5 % of the HBM traffic less), 1 otherwise (iCub-size shapes: 3.2 vs 3.6 ms).
+                              * rtoc_get_option reads the value in force. */
   RTOC_OPT_BACKWARD_SCAN = 6, /* 1: rtoc_riccati_backward (and everything built on it) runs the recursion as a scan
                               * over the horizon -- interval elements of all grid points, ceil(log2(nstages))
                               * combination levels, then all policies at once -- instead of the serial chain
@@ -191,6 +196,8 @@ int rtoc_set_grid(rtoc_ctx* ctx, const rtoc_grid* grid, int nstages);
 /* Use a caller-owned HIP stream (hipStream_t passed as void*); NULL = the context's own stream. */
 int rtoc_set_stream(rtoc_ctx* ctx, void* hip_stream);
 int rtoc_set_option(rtoc_ctx* ctx, int option, int64_t value);
+/* the value in force of an integer-valued option (RTOC_ERR_BAD_ARG for the double-valued ones) */
+int rtoc_get_option(rtoc_ctx* ctx, int option, int64_t* value);
 
 /* Host <-> HBM transfers of whole buffers (count in doubles, from the buffer start +offset). */
 int rtoc_upload(rtoc_ctx* ctx, int buffer, size_t offset, const double* host, size_t count);

@@ -35,7 +35,7 @@ EXPORTS = [
     "rtoc_sto_correct_time_steps", "rtoc_sto_eval_kkt_device", "rtoc_sto_compute_step_sizes", "rtoc_sto_integrate_solution",
     "rtoc_sto_get_event_times", "rtoc_sto_get_time_steps", "rtoc_sto_get_constraint_data", "rtoc_sto_get_kkt_terms",
     "rtoc_sto_set_slack_dual", "rtoc_contact_eval_ocp", "rtoc_set_line_search", "rtoc_contact_line_search",
-    "rtoc_bandwidth_probe",
+    "rtoc_bandwidth_probe", "rtoc_get_option",
 ]
 
 
@@ -309,8 +309,15 @@ class Context:
         _chk(lib().rtoc_set_option(self._h, OPT_BACKWARD_SCAN, 2 if on == "auto" else int(bool(on))))
 
     def set_condense_split(self, on):
-        """RTOC_OPT_CONDENSE_SPLIT: MJtJinv in its own kernel (default) or one fused condensation kernel."""
+        """RTOC_OPT_CONDENSE_SPLIT: MJtJinv in its own kernel or one fused condensation kernel (default per robot shape)."""
         _chk(lib().rtoc_set_option(self._h, OPT_CONDENSE_SPLIT, int(bool(on))))
+
+    def get_option(self, option):
+        """rtoc_get_option: the value in force of an integer-valued option"""
+        v = C.c_int64(0)
+        lib().rtoc_get_option.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64)]
+        _chk(lib().rtoc_get_option(self._h, int(option), C.byref(v)))
+        return int(v.value)
 
     def set_condense_keep_qaf(self, on):
         """RTOC_OPT_CONDENSE_KEEP_QAF: also store Qafqv / Qafu_full in the ContactDynamicsData record."""

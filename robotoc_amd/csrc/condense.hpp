@@ -484,6 +484,13 @@ __global__ __launch_bounds__(64 * RTOC_COND_NW, (CondCfg<NV, NU, NF, NS, SPLIT>:
     ent0 = a.entry[t] + 2;                                   \
     ent1 = a.entry[t + 1];                                   \
   }
+  // the gradient / sensitivity entries that get one read-modify-write at the very end: with the first round trip -- or, in the
+  // fused kernel (whose register budget they would overrun for 40k cycles: they were spilled, 8 KB of scratch traffic per work
+  // item), ahead of the Schur updates, one phase before they are consumed
+#define RTOC_GRADIENT_LOADS                                                                                    \
+  pLx = lx[ix_], pHx = hx[ix_], pFf = fx[ix_], pFxv = Fx[NV + iv_];                                            \
+  pLup = lup[iv_ < NP ? iv_ : 0], pLu = lu[iv_ >= NP ? iv_ - NP : 0], pHu = hu[iv_ >= NP ? iv_ - NP : 0];      \
+  pSh = scal[RTOC_KKT_SCAL_H], pSq = scal[RTOC_KKT_SCAL_QTT];
 #define RTOC_FIELD_LOADS                                                                                     \
   if constexpr (!FUSE) {                                                                                      \
     RTOC_BOX_DESCRIPTOR                                                                                       \
@@ -496,9 +503,9 @@ __global__ __launch_bounds__(64 * RTOC_COND_NW, (CondCfg<NV, NU, NF, NS, SPLIT>:
   RTOC_LD2(gQ, N_J, cr + CL.off[RTOC_CDD_QQF], H_J)                                                           \
   vQaa = cr[CL.off[RTOC_CDD_QAA] + lv_], vLa = cr[CL.off[RTOC_CDD_LA] + lv_], vHa = cr[CL.off[RTOC_CDD_HA] + lv_]; \
   vLf = cr[CL.off[RTOC_CDD_LF] + lf_], vHf = cr[CL.off[RTOC_CDD_HF] + lf_];                                    \
-  pLx = lx[ix_], pHx = hx[ix_], pFf = fx[ix_], pFxv = Fx[NV + iv_];                                            \
-  pLup = lup[iv_ < NP ? iv_ : 0], pLu = lu[iv_ >= NP ? iv_ - NP : 0], pHu = hu[iv_ >= NP ? iv_ - NP : 0];      \
-  pSh = scal[RTOC_KKT_SCAL_H], pSq = scal[RTOC_KKT_SCAL_QTT];                                                  \
+  if constexpr (!FUSE) {                                                                                       \
+    RTOC_GRADIENT_LOADS                                                                                        \
+  }                                                                                                            \
   prefetch_tiles<NW, NX, NX, NX>(Qxx, lane, cQxx);                                                             \
   prefetch_tiles<NW, NX, NU, NX>(Qxu, lane, cQxu);                                                             \
   prefetch_tiles<NW, NU, NU, NU>(Quu, lane, cQuu);
@@ -789,6 +796,10 @@ __global__ __launch_bounds__(64 * RTOC_COND_NW, (CondCfg<NV, NU, NF, NS, SPLIT>:
   __syncthreads();
 
   RTOC_CPROF(6);
+  if constexpr (FUSE) {
+    RTOC_GRADIENT_LOADS
+  }
+#undef RTOC_GRADIENT_LOADS
   // ================= Schur updates of the Hessian blocks and gradients (:90-130), in place in HBM ==
   // Each block gets ONE read-modify-write: the Qqf corrections (:92-93,:99-100,:106-107), which touch
   // the rows < NV only, ride along as a second product in the same tiles.

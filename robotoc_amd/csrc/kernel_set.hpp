@@ -61,6 +61,7 @@ struct KernelSet {
   int mjt_lds;
   int cond_threads, cond_lds, cond_split_lds;
   int cond_fuses_cones;  // the one-kernel condensation condenses the friction / wrench cone rows itself (CondCfg::FUSE)
+  int cond_fused_default;  // ... and is the default pipeline of this shape: five of its work items fit the LDS of a CU
   expd_fn expd;
   int expd_threads, expd_lds;
   // horizon scan of the backward recursion (riccati_scan.hpp)
@@ -137,6 +138,7 @@ inline KernelSet make_set() {
   k.cond_lds = CondCfg<NV, NU, NF, NS>::LDS_BYTES;
   k.cond_split_lds = CondCfg<NV, NU, NF, NS, true>::LDS_BYTES;
   k.cond_fuses_cones = CondCfg<NV, NU, NF, NS>::FUSE ? 1 : 0;
+  k.cond_fused_default = (CondCfg<NV, NU, NF, NS>::FUSE && CondCfg<NV, NU, NF, NS>::ITEMS >= 5) ? 1 : 0;
   // regression guard for the occupancy the quadruped shape is sized for (condense.hpp: five / ten work items per CU)
   static_assert(!(NV == 18 && NU == 12 && NS == 12) ||
                     (CondCfg<NV, NU, NF, NS, true>::ITEMS >= 5 && CondCfg<NV, NU, NF, NS, true>::MIN_WAVES == 4 && MjCfg<NV, NF>::ITEMS >= 10),

@@ -366,7 +366,7 @@ static int create_members(rtoc_ctx* c, const rtoc_dims* dims, const KernelSet* k
   HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   for (int i = 0; i < RTOC_MAX_CHUNK_EVENTS; ++i)
     HIP_TRY(hipEventCreateWithFlags(&c->ev_chunk[i], hipEventDisableTiming));
-  c->condense_split = 1;
+  c->condense_split = c->ks->cond_fused_default ? 0 : 1;   // per robot shape (rtoc.h: RTOC_OPT_CONDENSE_SPLIT)
   // RTOC_CONDENSE_SPLIT=0|1 in the environment: default of RTOC_OPT_CONDENSE_SPLIT for contexts created afterwards (runs the
   // whole test suite / bench on the other condensation pipeline without touching the callers)
   if (const char* e = getenv("RTOC_CONDENSE_SPLIT")) c->condense_split = (e[0] == '0') ? 0 : 1;
@@ -643,6 +643,21 @@ int rtoc_set_stream(rtoc_ctx* c, void* s) {
 
 static int ensure_scan_buffers(rtoc_ctx* c);
 #define RTOC_SCAN_AUTO_MAX_BATCH 8  // measured on MI355X (profiles/r01_scan_batch_crossover.log): the scan wins up to ~16 ANYmal / ~10 iCub instances
+
+int rtoc_get_option(rtoc_ctx* c, int option, int64_t* value) {
+  if (!c || !value) return RTOC_ERR_BAD_ARG;
+  switch (option) {
+    case RTOC_OPT_WRITEBACK_KKT: *value = c->writeback; return RTOC_OK;
+    case RTOC_OPT_SWEEP_CHUNKS: *value = c->sweep_chunks; return RTOC_OK;
+    case RTOC_OPT_CONDENSE_SPLIT: *value = c->condense_split; return RTOC_OK;
+    case RTOC_OPT_BACKWARD_SCAN: *value = c->backward_scan; return RTOC_OK;
+    case RTOC_OPT_CONDENSE_KEEP_QAF: *value = c->keep_qaf; return RTOC_OK;
+    case RTOC_OPT_FXX_STRUCTURE: *value = c->fxx_mode; return RTOC_OK;
+    case RTOC_OPT_GRAPH: *value = c->use_graph; return RTOC_OK;
+    case RTOC_OPT_IMPACT_CONES: *value = c->impact_cones; return RTOC_OK;
+    default: return RTOC_ERR_BAD_ARG;
+  }
+}
 
 int rtoc_set_option(rtoc_ctx* c, int option, int64_t value) {
   if (!c) return RTOC_ERR_BAD_ARG;

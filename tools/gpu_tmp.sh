@@ -1,5 +1,4 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/dev
-T="tests/test_friction_cone.py tests/test_contact_wrench_cone.py tests/test_golden_ref.py tests/test_gpu_parity.py tests/test_newton_iteration.py tests/test_shapes.py tests/test_acceleration_limits.py tests/test_stage_dump.py tests/test_determinism.py tests/test_contact_closed_loop.py tests/test_sto_closed_loop.py"
-RTOC_PARITY_PINS=0 RTOC_CONDENSE_SPLIT=0 timeout 600 python -m pytest $T -m gpu -q -x 2>&1 | tail -12 > gpurun_out/dev/pytest_s0.log; grep -n "passed\|failed\|FAILED" gpurun_out/dev/pytest_s0.log
-for i in 1 2 3; do for split in 0 1; do echo "split=$split"; RTOC_CONDENSE_SPLIT=$split timeout 200 python tools/sqp_bench.py 4096 2>&1 | tail -1; done; done
-RTOC_HIP_LIB=$GRAFT_REPO_ROOT/robotoc_amd/librtoc_hip_prof.so RTOC_CONDENSE_SPLIT=0 timeout 200 python tools/condense_profile.py 2>&1 | tail -2
+RTOC_PARITY_PINS=1 timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -25 > gpurun_out/dev/pytest_all.log
+grep -n "passed\|failed\|FAILED" gpurun_out/dev/pytest_all.log
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1

@@ -50,14 +50,17 @@ def main():
         ctx.expand(0.995)
         ctx.update()
     assert (ctx.status() == 0).all()
-    # the one-kernel condensation (RTOC_OPT_CONDENSE_SPLIT = 0: condense_kernel<..., false> with the cone rows inside)
-    ctx.set_condense_split(False)
+    # the condensation pipeline that is not this shape's default (RTOC_OPT_CONDENSE_SPLIT: 0 = one kernel with the cone rows inside,
+    # 1 = mjtjinv_kernel + condense_kernel)
+    from robotoc_amd.types import OPT_CONDENSE_SPLIT
+    default = ctx.get_option(OPT_CONDENSE_SPLIT)
+    ctx.set_condense_split(not default)
     for _ in range(reps):
         ctx.upload(BUF_KKT, kkt)
         ctx.upload(BUF_CDD, cdd)
         ctx.upload(BUF_CON, con)
         ctx.condense()
-    ctx.set_condense_split(True)
+    ctx.set_condense_split(default)
     assert (ctx.status() == 0).all()
     del kkt, cdd, con
     # ---- rigid-body linearisation of the same batch ----
