@@ -758,12 +758,9 @@ __global__ __launch_bounds__(64 * RTOC_COND_NW, (CondCfg<NV, NU, NF, NS, SPLIT>:
     }
   }
   __syncthreads();  // D (and J inside it) is dead from here on: its space becomes Qafqv; region X becomes Qafu
-  for (int e = lane; e < LDV * NX; e += NT) Qafqv[e] = 0.0;
-  if (!impact) {
-    for (int e = lane; e < LDV * NP; e += NT) Qafu[e] = 0.0;
-    for (int e = lane; e < LDV * NU; e += NT) QafuU[e] = 0.0;
-  }
-  __syncthreads();
+  // (no zero fill + barrier ahead of the writes below: together they cover every entry of Qafqv / Qafu_full -- the rows of
+  // the inactive contact dimensions come out as exact zeros from the zero-padded Qff / Qqf, and a grid point without contacts
+  // zeroes its force rows itself)
 
   RTOC_CPROF(5);
   // ================= Qafqv, Qafu_full, laf (:67-88) =================
@@ -792,6 +789,13 @@ __global__ __launch_bounds__(64 * RTOC_COND_NW, (CondCfg<NV, NU, NF, NS, SPLIT>:
       for (int k = 0; k < nf; ++k) acc += Qff[lane + k * LDF] * Lr[NV + k];
       laf[NV + lane] -= acc;
     }
+  } else if constexpr (NF > 0) {
+    for (int e = lane; e < NF * NX; e += NT) Qafqv[NV + e % NF + (e / NF) * LDV] = 0.0;
+    if (!impact)
+      for (int e = lane; e < NF * NV; e += NT) {
+        const int c = e / NF;
+        (c < NP ? Qafu + c * LDV : QafuU + (c - NP) * LDV)[NV + e % NF] = 0.0;
+      }
   }
   __syncthreads();
 
