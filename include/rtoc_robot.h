@@ -176,7 +176,13 @@ int rtoc_unconstr_init_constraints(rtoc_ctx* ctx);
  * of the iterate it linearised at (host_kkt_error[count <= batch], may be NULL / 0), rtoc_unconstr_condense, backward,
  * forward, rtoc_unconstr_expand, and SplitSolution::integrate -- RTOC_BUF_SOL holds the next iterate.  Step size 1, or,
  * with joint-limit rows, condenseSlackAndDual / expandSlackAndDual, the fraction-to-boundary step sizes and the slack / dual
- * update as well (unconstr_intermediate_stage.cpp:76-118). */
+ * update as well (unconstr_intermediate_stage.cpp:76-118).  With rtoc_set_line_search(enable = 1): the filter line search of
+ * UnconstrLineSearch::computeStepSize (src/line_search/unconstr_line_search.cpp:37-67; unconstr_ocp_solver.cpp:107-111) between
+ * the step sizes and the update -- every instance backtracks from its maximum primal step over trial iterates evaluated on
+ * the device (integratePrimalSolution + UnconstrDirectMultipleShooting::evalOCP: cost value + log barrier, l1 norm of the
+ * state-equation, inverse-dynamics and row residuals); RTOC_BUF_STEP then holds the accepted primal steps.
+ * rtoc_contact_eval_ocp / rtoc_contact_line_search serve this path as well: they evaluate with whichever of
+ * rtoc_unconstr_eval_kkt / rtoc_contact_eval_kkt ran last. */
 int rtoc_unconstr_update_solution(rtoc_ctx* ctx, double dt, double* host_kkt_error, int count);
 
 #ifdef __cplusplus

@@ -755,6 +755,7 @@ struct UkArgs {
   int o_q, o_v, o_a, o_u, o_lmd, o_gmm;
   int o_qxx, o_qxu, o_quu, o_fx, o_lx, o_lu;
   int o_qaa, o_la, o_mj;
+  double* cost_out;   // [batch][nstages] value of the stage / terminal cost (the line search's evalOCP reads it), or nullptr
 };
 
 static __global__ __launch_bounds__(64) void unconstr_eval_kkt_kernel(UkArgs a) {
@@ -801,6 +802,22 @@ static __global__ __launch_bounds__(64) void unconstr_eval_kkt_kernel(UkArgs a) 
       cr[a.o_la + i] = dt * wu[i] * (u - ur[i]);                                   // lu (in CDD.la)
       cr[a.o_qaa + i] = dt * wu[i];                                                // diag(Quu)
     }
+  }
+  if (a.cost_out) {
+    // ConfigurationSpaceCost::evalStageCost / evalTerminalCost (configuration_space_cost.cpp:251-271, :323-338): the VALUE
+    double l = 0.0;
+    for (int i = lane; i < nv; i += 64) {
+      const double dq = s[a.o_q + i] - qr[i], dv = s[a.o_v + i] - vr[i];
+      if (terminal) {
+        l += wqf[i] * dq * dq + wvf[i] * dv * dv;
+      } else {
+        const double acc = s[a.o_a + i], du = s[a.o_u + i] - ur[i];
+        l += wq[i] * dq * dq + wv[i] * dv * dv + wa[i] * acc * acc + wu[i] * du * du;
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) l += __shfl_xor(l, off, 64);
+    if (lane == 0) a.cost_out[rec] = (terminal ? 0.5 : 0.5 * dt) * l;
   }
   if (st == 0 && a.x0 && a.dx0) {
     for (int i = lane; i < nv; i += 64) {

@@ -235,6 +235,7 @@ struct rtoc_ctx {
   // filter line search on the device (rtoc_set_line_search, rtoc_contact_line_search)
   int ls_on;
   double ls_rate, ls_min_step, ls_cost_rate, ls_viol_rate;
+  double ls_unconstr_dt;   // > 0: the last evalKKT was rtoc_unconstr_eval_kkt(dt) -- trial iterates of the line search are evaluated by it
   double* d_eval;       // [2][2][batch]: (cost + barrier | violation) of the current iterate, of the trial iterate
   double* d_eval_part;  // [batch][max_stages][2]
   double* d_sol_trial;  // trial iterate: SplitSolution records, constraint records, steps
@@ -2004,6 +2005,9 @@ int rtoc_unconstr_eval_kkt(rtoc_ctx* c, double dt) {
   a.o_qxx = c->L.kkt.off[RTOC_KKT_QXX], a.o_qxu = c->L.kkt.off[RTOC_KKT_QXU], a.o_quu = c->L.kkt.off[RTOC_KKT_QUU];
   a.o_fx = c->L.kkt.off[RTOC_KKT_FX], a.o_lx = c->L.kkt.off[RTOC_KKT_LX], a.o_lu = c->L.kkt.off[RTOC_KKT_LU];
   a.o_qaa = c->L.cdd.off[RTOC_CDD_QAA], a.o_la = c->L.cdd.off[RTOC_CDD_LA], a.o_mj = c->L.cdd.off[RTOC_CDD_MJTJINV];
+  c->ls_unconstr_dt = dt;
+  if (c->ls_on && !c->d_costval) HIP_TRY(hipMalloc((void**)&c->d_costval, sizeof(double) * c->batch * c->max_stages));
+  a.cost_out = c->ls_on ? c->d_costval : nullptr;   // the line search's evalOCP (unconstr_line_search.cpp:56-83)
   hipLaunchKernelGGL(rbd::unconstr_eval_kkt_kernel, dim3(c->batch * c->nstages), dim3(64), 0, c->stream, a);
   HIP_TRY(hipGetLastError());
   c->fxx_state = 0;
@@ -2229,6 +2233,7 @@ int rtoc_contact_eval_kkt(rtoc_ctx* c) {
   int rc = ensure_buffer(c, RTOC_BUF_KKT);
   if (!rc) rc = ensure_buffer(c, RTOC_BUF_CDD);
   if (rc) return rc;
+  c->ls_unconstr_dt = 0.0;
   // PhaseBased discretisation: time_discretization_.correctTimeSteps(contact_sequence_, t) ahead of evalKKT (ocp_solver.cpp:115-117)
   if (c->sto_on) STO_LAUNCH(sto_time_steps_kernel, c);
   if (!c->d_costval) HIP_TRY(hipMalloc((void**)&c->d_costval, sizeof(double) * c->batch * c->max_stages));
@@ -2275,12 +2280,19 @@ int rtoc_contact_update_solution(rtoc_ctx* c, double tau, double* host_kkt_error
 
 // UnconstrOCPSolver::updateSolution (src/solver/unconstr_ocp_solver.cpp:96-118) of every instance, one launch
 // sequence, no host synchronisation unless host_kkt_error is asked for
+static int ensure_line_search(rtoc_ctx* c);
+static int launch_eval_ocp(rtoc_ctx* c, double* out);
+
 int rtoc_unconstr_update_solution(rtoc_ctx* c, double dt, double* host_kkt_error, int count) {
   CHECK_READY(c);
   if (count < 0 || count > c->batch || (count > 0 && !host_kkt_error)) return RTOC_ERR_BAD_ARG;
   const bool rows = ubox_on(c);
   int rc = rtoc_unconstr_eval_kkt(c, dt);            // dms_.evalKKT up to the condensation, + computeInitialStateDirection
   if (!rc) rc = launch_kkt_error(c);                  // performance_index.kkt_error (pre-condensation, like :74-75)
+  if (!rc && c->ls_on) {                              // dms_.getEval() of the iterate: what UnconstrLineSearch::computeStepSize reads first
+    rc = ensure_line_search(c);
+    if (!rc) rc = launch_eval_ocp(c, c->d_eval);
+  }
   if (!rc && rows) rc = launch_ubox(c, UBOX_CONDENSE);  // constraints_->condenseSlackAndDual (:76-77), ahead of the dynamics
   if (!rc) rc = rtoc_unconstr_condense(c);
   if (!rc) rc = rtoc_unconstr_backward(c, dt);
@@ -2291,11 +2303,12 @@ int rtoc_unconstr_update_solution(rtoc_ctx* c, double dt, double* host_kkt_error
   if (rc) return rc;
   hipLaunchKernelGGL(fill_steps_kernel, dim3((2 * c->batch + 255) / 256), dim3(256), 0, c->stream, c->buf[RTOC_BUF_STEP], 2 * c->batch);
   HIP_TRY(hipGetLastError());
-  if (rows) {
-    rc = launch_ubox(c, UBOX_EXPAND);                 // expandSlackAndDual + maxSlack/DualStepSize (:80-97)
-    if (!rc) rc = rtoc_update(c);                     // updateSlack / updateDual (:106-118)
-    if (rc) return rc;
-  }
+  if (rows) rc = launch_ubox(c, UBOX_EXPAND);         // expandSlackAndDual + maxSlack/DualStepSize (:80-97)
+  // line_search_.computeStepSize (unconstr_ocp_solver.cpp:107-111, unconstr_line_search.cpp:37-67): the filter's backtracking loop of
+  // every instance over trial iterates evaluated on the device; the accepted primal steps replace the maximum ones
+  if (!rc && c->ls_on) rc = rtoc_contact_line_search(c, nullptr);
+  if (!rc && rows) rc = rtoc_update(c);               // updateSlack / updateDual (:106-118)
+  if (rc) return rc;
   rc = rtoc_integrate_solution(c);
   if (rc) return rc;
   if (count > 0) {
@@ -2615,7 +2628,7 @@ static int eval_ocp_trial(rtoc_ctx* c, const double* steps, double* out) {
   c->buf[RTOC_BUF_STEP] = const_cast<double*>(steps);
   int rc = rtoc_update(c);                       // slack += step dslack (dual step 0)
   if (!rc) rc = rtoc_integrate_solution(c);      // SplitSolution::integrate with the trial step
-  if (!rc) rc = rtoc_contact_eval_kkt(c);        // evalOCP's quantities (and, unused here, the derivatives)
+  if (!rc) rc = c->ls_unconstr_dt > 0.0 ? rtoc_unconstr_eval_kkt(c, c->ls_unconstr_dt) : rtoc_contact_eval_kkt(c);   // evalOCP's quantities (and, unused here, the derivatives)
   if (!rc) rc = launch_eval_ocp(c, out);
   c->buf[RTOC_BUF_SOL] = sol, c->buf[RTOC_BUF_CON] = con, c->buf[RTOC_BUF_STEP] = stp;
   c->vals_fresh = 0;

@@ -81,8 +81,12 @@ class UnconstrOCPSolver {
   UnconstrOCPSolver& operator=(UnconstrOCPSolver&&) = default;
 
   void setSolverOptions(const SolverOptions& solver_options) {
-    if (solver_options.enable_line_search)
-      throw std::logic_error("[UnconstrOCPSolver] the line search is outside the accelerated path (off by default, solver_options.hpp:70)");
+    // line_search_.set(solver_options.line_search_settings) (unconstr_ocp_solver.cpp:80): the filter method of
+    // UnconstrLineSearch::computeStepSize (unconstr_line_search.cpp:37-67) runs on the device inside rtoc_unconstr_update_solution --
+    // trial iterates, evalOCP, the filter of every instance
+    const LineSearchSettings& ls = solver_options.line_search_settings;
+    check(rtoc_set_line_search(ctx_.get(), solver_options.enable_line_search ? 1 : 0, ls.step_size_reduction_rate, ls.min_step_size,
+                               ls.filter_cost_reduction_rate, ls.filter_constraint_violation_reduction_rate), "rtoc_set_line_search");
     solver_options_ = solver_options;
     if (!ocp_.constraint_rows.empty())
       check(rtoc_set_constraint_bounds(ctx_.get(), ocp_.constraint_bounds.data(), static_cast<int>(ocp_.constraint_bounds.size()),
@@ -120,7 +124,8 @@ class UnconstrOCPSolver {
     kkt_error_ = err;
     host_solution_valid_ = false;
     double steps[2] = {1.0, 1.0};
-    if (!ocp_.constraint_rows.empty()) check(rtoc_download(ctx_.get(), RTOC_BUF_STEP, 0, steps, 2), "rtoc_download(RTOC_BUF_STEP)");
+    if (!ocp_.constraint_rows.empty() || solver_options_.enable_line_search)
+      check(rtoc_download(ctx_.get(), RTOC_BUF_STEP, 0, steps, 2), "rtoc_download(RTOC_BUF_STEP)");
     solver_statistics_.primal_step_size.push_back(steps[0]);
     solver_statistics_.dual_step_size.push_back(steps[1]);
   }
@@ -128,7 +133,10 @@ class UnconstrOCPSolver {
   // solve (:121-160)
   void solve(const double t, const Vec& q, const Vec& v, const bool init_solver = true) {
     const auto t0 = std::chrono::high_resolution_clock::now();
-    if (init_solver) initConstraints();
+    if (init_solver) {
+      initConstraints();
+      if (solver_options_.enable_line_search) check(rtoc_line_search_clear(ctx_.get()), "rtoc_line_search_clear");   // line_search_.clearHistory() (:135)
+    }
     solver_statistics_.clear();
     for (int iter = 0; iter < solver_options_.max_iter; ++iter) {
       updateSolution(t, q, v);

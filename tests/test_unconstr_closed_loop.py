@@ -225,3 +225,127 @@ def test_unconstr_solver_with_joint_limits_converges_to_the_barrier_problem(orac
     assert worst < 1e-8
     print("dynamics residual of the converged trajectory:", worst, " min slack:", sl[:, act].min())
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_unconstr_line_search_backtracks_like_the_reference_algorithm(oracle):
+    """UnconstrLineSearch::computeStepSize (src/line_search/unconstr_line_search.cpp:37-67) inside rtoc_unconstr_update_solution:
+    iiwa14 with the six joint-limit components, four instances of one problem whose filters differ -- empty (seeded with the
+    iterate), holding an entry nothing can improve on (every trial rejected: the step ends below min_step_size), holding an
+    entry at the iterate's own (cost, violation) shifted so that only sufficiently good trials pass, and an empty filter with
+    another reduction rate's worth of candidates.  Expected steps: the reference's loop restated on the host -- trial iterate
+    s + alpha d with slack + alpha dslack, cost (configuration_space_cost.cpp:251-271, :323-338), log barrier, l1 violation of Fx,
+    ID (CPU rigid-body restatement) and the rows' residuals, LineSearchFilter::isAccepted / augment
+    (tests/test_discretization_and_filter_vs_reference.py: the restatement pinned to the reference's filter)."""
+    from robotoc_amd.types import BUF_CON, BUF_DIR, BUF_STEP, Dims, joint_limit_rows
+    from test_discretization_and_filter_vs_reference import py_filter_try
+    batch, rate, min_step, cr, vr = 4, 0.75, 0.05, 0.005, 0.005
+    dims0, grids, meta = pr.config_iiwa14()
+    dims = Dims(dims0.nv, dims0.nu, 0, 0, 0, 48)
+    m = rm.load_named("iiwa14")
+    n, nv, dt = len(grids), m.nv, meta["dt"]
+    rows = joint_limit_rows(dims)
+    bounds = _limits(nv, rows)
+    barrier = 1.0e-3
+    rng = np.random.default_rng(21)
+    q_ref = rng.uniform(-0.5, 0.5, nv)
+    cost = dict(q_ref=q_ref, v_ref=np.zeros(nv), u_ref=np.zeros(nv), q_weight=np.full(nv, 10.0), v_weight=np.full(nv, 0.1),
+                a_weight=np.full(nv, 0.01), u_weight=np.full(nv, 0.001), q_weight_terminal=np.full(nv, 10.0), v_weight_terminal=np.full(nv, 0.1))
+    x0 = np.tile(np.concatenate([rng.uniform(-0.4, 0.4, nv), np.zeros(nv)]), (batch, 1))
+
+    def make(line_search):
+        c = capi.Context(dims, n, batch, 0)
+        c.set_grid(grids)
+        c.set_robot_model(m)
+        c.set_constraint_rows(rows)
+        c.set_constraint_bounds(bounds, barrier, 0.995)
+        c.set_configuration_cost(**cost)
+        c.set_initial_state(x0)
+        c.set_line_search(line_search, rate, min_step, cr, vr)
+        return c
+    L = capi.layout_for(dims)
+    S, N, D = Records(L, "sol"), Records(L, "con"), Records(L, "dir")
+    sol = S.zeros(batch, n)
+    S.f(sol, "q")[..., :nv] = x0[:, None, :nv]
+    one = S.zeros(1, n)   # a rough iterate, the same in every instance: accelerations and torques far from consistent
+    for f, sc in (("v", 0.5), ("a", 3.0), ("u", 20.0), ("lmd", 0.5), ("gmm", 0.5), ("beta", 0.5)):
+        S.f(one, f)[...] = sc * rng.uniform(-1, 1, S.f(one, f).shape)
+    for f in ("v", "a", "u", "lmd", "gmm", "beta"):
+        S.f(sol, f)[...] = S.f(one, f)
+    # ---- context B, no line search: direction, maximum steps, dslack of this very iterate ----
+    B = make(False)
+    B.upload(BUF_SOL, sol)
+    B.unconstr_init_constraints()
+    con_in = B.download_records(BUF_CON, "con")
+    B.unconstr_update_solution(dt)
+    d = B.download_records(BUF_DIR, "dir")
+    con_b = B.download_records(BUF_CON, "con")   # dslack of the rows (slack / dual already updated there)
+    smax = B.download(BUF_STEP, (batch, 2))[:, 0]
+    B.close()
+    assert np.ptp(smax) == 0.0 and smax[0] > min_step
+
+    def evaluate(b, alpha):
+        """(cost + barrier, violation) of instance b's trial iterate at step alpha, as UnconstrDirectMultipleShooting::evalOCP sums them"""
+        c_, viol, bar = 0.0, 0.0, 0.0
+        z = np.zeros(0)
+        q = S.f(sol[b], "q")[:, :nv] + alpha * D.f(d[b], "dx")[:, :nv]
+        v = S.f(sol[b], "v") + alpha * D.f(d[b], "dx")[:, nv:]
+        a = S.f(sol[b], "a") + alpha * D.f(d[b], "daf")[:, :nv]     # rtoc_unconstr_expand: da (the Riccati control) in daf, ...
+        u = S.f(sol[b], "u") + alpha * D.f(d[b], "du")[:, :nv]      # ... the torque direction of expandPrimal in du
+        slack = N.f(con_in[b], "slack") + alpha * N.f(con_b[b], "dslack")
+        for i in range(n):
+            if i == n - 1:
+                c_ += 0.5 * (cost["q_weight_terminal"] * (q[i] - q_ref) ** 2 + cost["v_weight_terminal"] * v[i] ** 2).sum()
+                continue
+            c_ += 0.5 * dt * (cost["q_weight"] * (q[i] - q_ref) ** 2 + cost["v_weight"] * v[i] ** 2 + cost["a_weight"] * a[i] ** 2
+                              + cost["u_weight"] * u[i] ** 2).sum()
+            viol += np.abs(q[i] + dt * v[i] - q[i + 1]).sum() + np.abs(v[i] + dt * a[i] - v[i + 1]).sum()
+            viol += np.abs(oracle.rbd_eval(m, 0, q[i], v[i], a[i], z, u[i], 0, z)).sum()
+            for r, w in enumerate(rows):
+                if grids[i].time_stage >= w.level:
+                    zz = (q[i], v[i], u[i])[w.var][w.index]
+                    viol += abs(w.sign * zz - bounds[r] + slack[i, r])
+                    bar -= np.log(slack[i, r])
+        return c_ + barrier * bar, viol
+
+    c0, v0 = evaluate(0, 0.0)
+    # filters: 0 empty | 1 an entry nothing improves on | 2 an entry that turns the full step down and lets the first reduced step
+    # pass (built from the two trial evaluations: by cost if the shorter step is the cheaper one, else by violation) | 3 empty
+    (c1, v1), (c2, v2) = evaluate(0, smax[0]), evaluate(0, smax[0] * rate)
+    if c2 < c1:
+        vE = 1e-3 * min(v1, v2)
+        mid = (0.5 * (c1 + c2) + cr * vE, vE)
+    elif v2 < v1:
+        mid = (-1e30, 0.5 * (v1 + v2) / (1.0 - vr))
+    else:
+        mid = (c0 * (1.0 - 1e-3), v0 * (1.0 - 1e-3))
+    pre = [None, (-1e30, 0.0), mid, None]
+    expect = np.zeros(batch)
+    for b in range(batch):
+        filt = [pre[b]] if pre[b] else []
+        if not filt:
+            py_filter_try(filt, c0, v0, cr, vr)      # empty filter: seeded with the iterate (:44-48)
+        alpha = smax[b]
+        while alpha > min_step:
+            ct, vt = evaluate(b, alpha)
+            if py_filter_try(filt, ct, vt, cr, vr):
+                break
+            alpha *= rate
+        expect[b] = alpha
+    # ---- context A: the same iteration with the line search on the device ----
+    A = make(True)
+    A.upload(BUF_SOL, sol)
+    A.unconstr_init_constraints()
+    A.line_search_clear()
+    mask = np.array([0 if p is None else 1 for p in pre], dtype=np.int32)
+    acc = A.line_search_filter(np.array([p[0] if p else 0.0 for p in pre]), np.array([p[1] if p else 0.0 for p in pre]), mask=mask)
+    assert list(acc) == list(mask)
+    A.unconstr_update_solution(dt)
+    got = A.download(BUF_STEP, (batch, 2))[:, 0]
+    cg, vg = A.contact_eval_ocp(trial=False)   # (the last evaluation of the device: the last trial iterate of the slowest instance)
+    A.close()
+    print("unconstrained line search: max step %.4f, accepted steps %s, expected %s; iterate (cost %.6e, violation %.6e)" % (smax[0], got, expect, c0, v0))
+    assert np.allclose(got, expect, rtol=1e-12, atol=0.0)
+    assert got[1] < min_step < got[0] and len(set(np.round(got, 12))) >= 2
+    if c2 < c1 or v2 < v1:
+        assert abs(got[2] - smax[2] * rate) < 1e-12   # one reduction: rejected at the full step, accepted at the first shorter one
