@@ -40,6 +40,22 @@ int main(int argc, char** argv) {
                    solver.getSolverStatistics().iter, copy.KKTError(), solver.KKTError());
       return 8;
     }
+    // SolverOptions::enable_line_search (unconstr_ocp_solver.cpp:107-111): the same problem with the filter line search on the
+    // device -- it converges too, and every iteration reports the primal step the filter accepted
+    {
+      robotoc::SolverOptions ols = opt;
+      ols.enable_line_search = true;
+      robotoc::UnconstrOCPSolver ls(ocp, ols);
+      ls.setSolution("q", q);
+      ls.setSolution("v", v);
+      ls.solve(0.0, q, v, true);
+      const robotoc::SolverStatistics& sl = ls.getSolverStatistics();
+      double smin = 1.0;
+      for (double a : sl.primal_step_size) smin = a < smin ? a : smin;
+      std::printf("with the line search: KKT error %.3e in %d iterations, converged %d, smallest accepted step %.4f\n", ls.KKTError(), sl.iter,
+                  (int)sl.convergence, smin);
+      if (!sl.convergence || (int)sl.primal_step_size.size() != sl.iter || !(smin > 0.0 && smin <= 1.0)) return 9;
+    }
     const robotoc::SolverStatistics& st = solver.getSolverStatistics();
     std::printf("KKT error %.3e -> %.3e in %d iterations, converged %d\n", e0, solver.KKTError(), st.iter, (int)st.convergence);
     // value semantics: a copy shares nothing it could corrupt and reports the same solution
