@@ -721,7 +721,7 @@ def main():
     # ... and what tuned streaming kernels reach (rtoc_bandwidth_probe: 16 B per lane, one front over memory, 8 loads in flight):
     # the better denominator -- torch's copy_ above is the runtime's copyBuffer kernel, which this box's HBM outruns
     try:
-        stream_read_gbs, stream_copy_gbs = capi.bandwidth_probe(local_rank, 1 << 31)
+        stream_read_gbs, stream_copy_gbs = capi.bandwidth_probe(local_rank, 1 << 32)
     except Exception:
         stream_read_gbs = stream_copy_gbs = None
 
@@ -1139,7 +1139,7 @@ def main():
                          "measured_stream_read_GBs": stream_read_gbs, "measured_stream_copy_GBs": stream_copy_gbs,
                          "frac_of_measured_stream_read": ach / stream_read_gbs if stream_read_gbs else None,
                          "frac_of_measured_stream_copy": ach / stream_copy_gbs if stream_copy_gbs else None,
-                         "measured_stream_kernel": "rtoc_bandwidth_probe: 2 GiB, 16 B / lane, 8 loads in flight per wave, best of 5",
+                         "measured_stream_kernel": "rtoc_bandwidth_probe: 4 GiB, 16 B / lane, 8 loads in flight per wave, best of 5",
                          "kernel": kname, "kernel_ms": ms_b,
                          "kernel_ms_source": "HIP events on the launch stream inside the timed sweep loop of this run",
                          "kernel_ms_rocprof_all_launches": rocprof_kernel_ms(kname) if batch == PER_GPU_BATCH else None,

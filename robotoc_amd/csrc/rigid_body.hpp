@@ -38,6 +38,12 @@ struct DevModel {
   rtoc_robot_model m;
   int depth[RTOC_MAX_JOINTS];
   int nlevels;
+  // storage plan of the tangent walk, per body: bit 0 = its parent is the body visited just before it (the parent's forward
+  // tangents are still in registers), bit 1 = leaf (its force tangent is closed from registers), bits 4-7 = 1 + the LDS slot
+  // its own forward tangents are kept in (bodies with two or more children; 0 = none), bits 8-11 = 1 + its parent's slot.
+  // Slots are numbered by the count of branching ancestors: two bodies with the same count are never open at once.
+  int walk[RTOC_MAX_JOINTS];
+  int nbranch;
   double joint[RTOC_MAX_JOINTS][JP];
   double contact[RTOC_MAX_CONTACTS][CP];
   // per dof: the body it moves and its angular axis in that body's frame (zero for the linear dofs of a free-flyer);
@@ -47,8 +53,27 @@ struct DevModel {
   double dof_axis[RTOC_MAX_JOINTS + 8][3];
   unsigned long long contact_dofs[RTOC_MAX_CONTACTS];
 };
+// nbranch of a model (the number of LDS slots the walk needs for forward tangents): 1 + the largest count of branching
+// ancestors of a branching body, 0 for a chain
+inline int walk_plan(const rtoc_robot_model& m, int* walk) {
+  int nchild[RTOC_MAX_JOINTS] = {}, slot[RTOC_MAX_JOINTS], nbranch = 0;
+  for (int i = 1; i < m.njoints; ++i)
+    if (m.parent[i] >= 0 && m.parent[i] < i) nchild[m.parent[i]]++;
+  for (int i = 0; i < m.njoints; ++i) {
+    const int par = (i > 0 && m.parent[i] >= 0 && m.parent[i] < i) ? m.parent[i] : -1;
+    // slot[i]: the slot a branching body i would use = the number of branching bodies above it
+    slot[i] = par < 0 ? 0 : slot[par] + (nchild[par] >= 2 ? 1 : 0);
+    const int own = nchild[i] >= 2 ? slot[i] + 1 : 0;
+    const int pslot = (par >= 0 && nchild[par] >= 2) ? slot[par] + 1 : 0;
+    if (own > nbranch) nbranch = own;
+    if (walk) walk[i] = ((par >= 0 && par == i - 1) ? 1 : 0) | (nchild[i] == 0 ? 2 : 0) | (own << 4) | (pslot << 8);
+  }
+  return nbranch;
+}
 inline void pack_model(DevModel* h) {
   const rtoc_robot_model& m = h->m;
+  for (int i = 0; i < RTOC_MAX_JOINTS; ++i) h->walk[i] = 0;
+  h->nbranch = walk_plan(m, h->walk);
   for (int i = 0; i < m.njoints; ++i) {
     double* o = h->joint[i];
     for (int k = 0; k < 9; ++k) o[k] = m.placement_R[i][k], o[19 + k] = m.inertia[i][k];
@@ -188,7 +213,7 @@ struct LinArgs {
   int o_q, o_v, o_a, o_u, o_f;                 // RTOC_BUF_SOL field offsets
   int o_idc, o_didda, o_dcda, o_didcdqv;       // RTOC_BUF_CDD field offsets
   int ldv, nf_max;                             // leading dimensions of DIDCDQV / DCDA
-  int nlevels, nv, nq, njoints, ncontacts, nu;
+  int nlevels, nbranch, nv, nq, njoints, ncontacts, nu;
   double gx, gy, gz;                           // gravity
   // multiplier terms of linearizeContactDynamics / linearizeImpactDynamics (kkt == nullptr: left out)
   double* kkt;
@@ -212,11 +237,17 @@ __host__ __device__ constexpr int lin_pad8(int n) { return (n + 7) & ~7; }
 // lanes per tangent slot: 3 nv tangent directions when they fit one pass (quadrupeds: 54 -> 56), else 64
 __host__ __device__ constexpr int lin_lane_stride(int nv) { return 3 * nv <= 56 ? 56 : 64; }
 // What decides the speed of this kernel is how many grid points a CU holds at once (the walk is one long dependent
-// instruction stream per wave, issue-bound, one wave per SIMD at best): ANYmal's 4 levels need 40,128 B, i.e. FOUR waves
-// per CU (160 KB) instead of the three that a uniform [level][21][64] carve gave (14.4 -> see DESIGN.md 3.4).
-__host__ __device__ constexpr size_t lin_lds_bytes(int nlevels, int njoints, int ncontacts, int nv) {
-  return sizeof(double) * ((size_t)nlevels * VAL_DOUBLES + (size_t)((nlevels > 1 ? nlevels - 1 : 0) * FWD_SLOTS + nlevels * DF_SLOTS) * lin_lane_stride(nv) +
-                           lin_pad8(nv + 1) + 4 * lin_pad8(nv) + 3 * lin_pad8(6 * ncontacts) + njoints * JP + ncontacts * CP);
+// instruction stream per wave, issue-bound): only what the walk cannot carry in registers lives in LDS -- the forward tangents
+// (dv, da, dg) of the bodies with two or more children (nbranch slots: a body whose parent was visited just before it takes
+// them from registers) and the force tangents df of the open non-leaf levels (a leaf is closed from registers).  ANYmal:
+// 1 slot + 3 levels = 22 KB (was 4 + 4 levels = 38 KB), iCub: 2 slots + 10 levels (was 11 + 11 = 128 KB); DESIGN.md 3.4.
+// pre: the walk reads the values of the recursion from rbd_values_kernel (PRE): no q, v, a, f, u staging, and of the joint
+// constants only axis .. depth (JP_PRE doubles from JP_PRE_OFF on) -- 20,000 B for ANYmal: EIGHT waves per CU (8 x 20,480 B).
+constexpr int JP_PRE_OFF = 12, JP_PRE = JP - JP_PRE_OFF;
+__host__ __device__ constexpr size_t lin_lds_bytes(int nlevels, int nbranch, int njoints, int ncontacts, int nv, bool pre) {
+  return sizeof(double) * ((size_t)nlevels * VAL_DOUBLES + (size_t)(nbranch * FWD_SLOTS + (nlevels > 1 ? nlevels - 1 : 0) * DF_SLOTS) * lin_lane_stride(nv) +
+                           (pre ? 0 : lin_pad8(nv + 1) + 3 * lin_pad8(nv) + lin_pad8(6 * ncontacts)) + lin_pad8(nv) + 2 * lin_pad8(6 * ncontacts) +
+                           njoints * (pre ? JP_PRE : JP) + ncontacts * CP);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -399,18 +430,19 @@ __global__ __launch_bounds__(64) RTOC_RBD_WAVES void linearize_contact_dynamics_
   const unsigned active = a.active[st];
   double* const lval = smem;                                      // [nlev][VAL_DOUBLES]
   const int LW = lin_lane_stride(nv);
-  double* const lfwd = lval + (size_t)nlev * VAL_DOUBLES;         // [nlev - 1][FWD_SLOTS][LW]: dv, da, dg
-  double* const ldf = lfwd + (size_t)(nlev > 1 ? nlev - 1 : 0) * FWD_SLOTS * LW;   // [nlev][DF_SLOTS][LW]
-  double* const sq = ldf + (size_t)nlev * DF_SLOTS * LW;          // q, v, a, f, u of the grid point
-  double* const sv = sq + lin_pad8(nv + 1);
-  double* const sa = sv + lin_pad8(nv);
-  double* const sf = sa + lin_pad8(nv);
-  double* const su = sf + lin_pad8(6 * ncon);
-  double* const sbeta = su + lin_pad8(nv);              // multipliers of the dynamics (beta) and of the contact rows (mu)
+  double* const lfwd = lval + (size_t)nlev * VAL_DOUBLES;         // [nbranch][FWD_SLOTS][LW]: dv, da, dg of the branching bodies
+  double* const ldf = lfwd + (size_t)a.nbranch * FWD_SLOTS * LW;  // [nlev - 1][DF_SLOTS][LW]: df of the open non-leaf levels
+  double* const sq = ldf + (size_t)(nlev > 1 ? nlev - 1 : 0) * DF_SLOTS * LW;   // q, v, a, f, u of the grid point
+  double* const sv = sq + (PRE ? 0 : lin_pad8(nv + 1));   // (PRE: the staging vectors of the values are not allocated)
+  double* const sa = sv + (PRE ? 0 : lin_pad8(nv));
+  double* const sf = sa + (PRE ? 0 : lin_pad8(nv));
+  double* const su = sf + (PRE ? 0 : lin_pad8(6 * ncon));
+  double* const sbeta = su + (PRE ? 0 : lin_pad8(nv));  // multipliers of the dynamics (beta) and of the contact rows (mu)
   double* const smu = sbeta + lin_pad8(nv);
   double* const slf = smu + lin_pad8(6 * ncon);         // dC/da beta, accumulated over the passes
-  double* const sjm = slf + lin_pad8(6 * ncon);         // model: [njoints][JP], then [ncontacts][CP]
-  double* const scm = sjm + a.njoints * JP;
+  constexpr int JPW = PRE ? JP_PRE : JP, JOFF = PRE ? JP_PRE_OFF : 0;
+  double* const sjm = slf + lin_pad8(6 * ncon);         // model: [njoints][JPW] (PRE: axis .. depth only), then [ncontacts][CP]
+  double* const scm = sjm + a.njoints * JPW;
   const bool aug = a.kkt != nullptr;
   const size_t rec = (size_t)b * a.nstages + st;
   const double* const sr = a.sol + rec * a.sol_stride;
@@ -419,16 +451,18 @@ __global__ __launch_bounds__(64) RTOC_RBD_WAVES void linearize_contact_dynamics_
   {
     const double* const gj = &a.model->joint[0][0];
     const double* const gc = &a.model->contact[0][0];
-    for (int e = lane; e < nb * JP; e += 64) sjm[e] = gj[e];
+    for (int e = lane; e < nb * JPW; e += 64) sjm[e] = gj[(e / JPW) * JP + JOFF + e % JPW];
     for (int e = lane; e < ncon * CP; e += 64) scm[e] = gc[e];
   }
-  for (int e = lane; e < a.nq; e += 64) sq[e] = sr[a.o_q + e];
-  for (int e = lane; e < nv; e += 64) {
-    sv[e] = sr[a.o_v + e];
-    sa[e] = sr[a.o_a + e];
+  if constexpr (!PRE) {
+    for (int e = lane; e < a.nq; e += 64) sq[e] = sr[a.o_q + e];
+    for (int e = lane; e < nv; e += 64) {
+      sv[e] = sr[a.o_v + e];
+      sa[e] = sr[a.o_a + e];
+    }
+    for (int e = lane; e < g.dimf; e += 64) sf[e] = sr[a.o_f + e];
+    for (int e = lane; e < nu; e += 64) su[e] = sr[a.o_u + e];
   }
-  for (int e = lane; e < g.dimf; e += 64) sf[e] = sr[a.o_f + e];
-  for (int e = lane; e < nu; e += 64) su[e] = sr[a.o_u + e];
   if (aug) {
     for (int e = lane; e < nv; e += 64) sbeta[e] = sr[a.o_beta + e];
     for (int e = lane; e < g.dimf; e += 64) smu[e] = sr[a.o_mu + e];
@@ -449,33 +483,36 @@ __global__ __launch_bounds__(64) RTOC_RBD_WAVES void linearize_contact_dynamics_
       double wsum = 0.0;  // this lane's column of [dID; dC] against [beta; mu]
       // body of the level that is being closed / visited is kept in LDS as an int in the value block
       auto LV = [&](int lev, int k) -> double& { return lval[lev * VAL_DOUBLES + k]; };
-      // tangent slot k of level lev for this lane; lanes beyond the stride (idle ones) share its last column.  The forward
-      // tangents of the deepest level have no storage: nothing reads them (stores go through st_fwd)
+      // forward-tangent slot / force-tangent level of this lane; lanes beyond the stride (idle ones) share the last column
       const int ln = lane < LW ? lane : LW - 1;
-      auto LT = [&](int lev, int k) -> double& {
-        return k < FWD_SLOTS ? lfwd[((size_t)lev * FWD_SLOTS + k) * LW + ln] : ldf[((size_t)lev * DF_SLOTS + (k - FWD_SLOTS)) * LW + ln];
-      };
+      auto FT = [&](int slot, int k) -> double& { return lfwd[((size_t)slot * FWD_SLOTS + k) * LW + ln]; };
+      auto DT = [&](int lev, int k) -> double& { return ldf[((size_t)lev * DF_SLOTS + k) * LW + ln]; };
       auto ld_sv = [&](int lev, int k0) { return SV{mk(LV(lev, k0), LV(lev, k0 + 1), LV(lev, k0 + 2)), mk(LV(lev, k0 + 3), LV(lev, k0 + 4), LV(lev, k0 + 5))}; };
       auto st_sv = [&](int lev, int k0, SV x) {
         LV(lev, k0) = x.l.x, LV(lev, k0 + 1) = x.l.y, LV(lev, k0 + 2) = x.l.z, LV(lev, k0 + 3) = x.a.x, LV(lev, k0 + 4) = x.a.y, LV(lev, k0 + 5) = x.a.z;
       };
-      auto ld_tv = [&](int lev, int k0) { return SV{mk(LT(lev, k0), LT(lev, k0 + 1), LT(lev, k0 + 2)), mk(LT(lev, k0 + 3), LT(lev, k0 + 4), LT(lev, k0 + 5))}; };
-      auto st_tv = [&](int lev, int k0, SV x) {
-        LT(lev, k0) = x.l.x, LT(lev, k0 + 1) = x.l.y, LT(lev, k0 + 2) = x.l.z, LT(lev, k0 + 3) = x.a.x, LT(lev, k0 + 4) = x.a.y, LT(lev, k0 + 5) = x.a.z;
+      auto ld_ft = [&](int slot, int k0) { return SV{mk(FT(slot, k0), FT(slot, k0 + 1), FT(slot, k0 + 2)), mk(FT(slot, k0 + 3), FT(slot, k0 + 4), FT(slot, k0 + 5))}; };
+      auto st_ft = [&](int slot, int k0, SV x) {
+        FT(slot, k0) = x.l.x, FT(slot, k0 + 1) = x.l.y, FT(slot, k0 + 2) = x.l.z, FT(slot, k0 + 3) = x.a.x, FT(slot, k0 + 4) = x.a.y, FT(slot, k0 + 5) = x.a.z;
       };
+      auto ld_dt = [&](int lev) { return SV{mk(DT(lev, 0), DT(lev, 1), DT(lev, 2)), mk(DT(lev, 3), DT(lev, 4), DT(lev, 5))}; };
+      auto st_dt = [&](int lev, SV x) { DT(lev, 0) = x.l.x, DT(lev, 1) = x.l.y, DT(lev, 2) = x.l.z, DT(lev, 3) = x.a.x, DT(lev, 4) = x.a.y, DT(lev, 5) = x.a.z; };
       // value slots: 0 R, 9 p, 12 oR, 21 op, 24 v, 30 a, 36 g, 39 f, 45 body index
-      // tangent slots: 0 dv, 6 da, 12 dg, 15 df
-      auto JM = [&](int i, int k) -> const double& { return sjm[i * JP + k]; };
+      // forward-tangent slots: 0 dv, 6 da, 12 dg
+      SV tdv = sv0(), tda = sv0(), cdf = sv0();   // forward tangents of the body visited last; force tangent of an open leaf
+      V3 tdg = mk(0, 0, 0);
+      bool topreg = false;                        // the force tangent of level `top` is cdf (a leaf), not in LDS
+      auto JM = [&](int i, int k) -> const double& { return sjm[i * JPW + k - JOFF]; };
       auto unit_twist = [&](int i, int k) -> SV {  // S_k of joint i
         if ((int)JM(i, 28) == RTOC_JOINT_FREE_FLYER)
           return SV{mk(k == 0, k == 1, k == 2), mk(k == 3, k == 4, k == 5)};
         return SV{mk(0, 0, 0), ldv3(&JM(i, 12))};
       };
-      auto close = [&](int lev) {
+      auto close = [&](int lev, bool from_reg) {
         const int i = (int)LV(lev, 45);
         const M3 R = ldm3(&LV(lev, 0));
         const V3 p = ldv3(&LV(lev, 9));
-        const SV f = ld_sv(lev, 39), df = ld_tv(lev, 15);
+        const SV f = ld_sv(lev, 39), df = from_reg ? cdf : ld_dt(lev);
         const int iv = (int)JM(i, 30);
         const bool cff = (int)JM(i, 28) == RTOC_JOINT_FREE_FLYER;
         const bool own = lane_on && j >= iv && j < iv + (cff ? 6 : 1);
@@ -501,7 +538,7 @@ __global__ __launch_bounds__(64) RTOC_RBD_WAVES void linearize_contact_dynamics_
           SV dfp = act_f(R, p, df);
           if (own && kind == 0) dfp = dfp + act_f(R, p, fcross(unit_twist(i, j - iv), f));
           if (!PRE) st_sv(lev - 1, 39, ld_sv(lev - 1, 39) + act_f(R, p, f));   // PRE: the block already holds the total force
-          st_tv(lev - 1, 15, ld_tv(lev - 1, 15) + dfp);
+          st_dt(lev - 1, ld_dt(lev - 1) + dfp);
         }
       };
       const double* const vblk = PRE ? (dyn ? a.vals : a.vals2) + rec * (size_t)nb * VAL_SLOTS : nullptr;
@@ -509,10 +546,14 @@ __global__ __launch_bounds__(64) RTOC_RBD_WAVES void linearize_contact_dynamics_
       for (int i = 0; i < nb; ++i) {
         const int d = (int)JM(i, 31);
         while (top >= d) {
-          close(top);
+          close(top, topreg);
+          topreg = false;
           --top;
         }
         // ---- visit body i at level d ----
+        const int wk = a.model->walk[i];
+        const bool chain = wk & 1, leaf = wk & 2;
+        const int sslot = ((wk >> 4) & 15) - 1, pslot = ((wk >> 8) & 15) - 1;
         const int iq = (int)JM(i, 29), iv = (int)JM(i, 30);
         const bool ff = (int)JM(i, 28) == RTOC_JOINT_FREE_FLYER;
         const bool own = lane_on && j >= iv && j < iv + (ff ? 6 : 1);
@@ -575,9 +616,13 @@ __global__ __launch_bounds__(64) RTOC_RBD_WAVES void linearize_contact_dynamics_
         SV dvp = sv0(), dap = sv0();
         V3 dgp = mk(0, 0, 0);
         if (d > 0) {
-          dvp = act_inv(R, p, ld_tv(d - 1, 0));
-          dap = act_inv(R, p, ld_tv(d - 1, 6));
-          dgp = mulT(R, mk(LT(d - 1, 12), LT(d - 1, 13), LT(d - 1, 14)));
+          if (!chain) {   // the parent is not the body visited just before: its tangents are in its slot
+            tdv = ld_ft(pslot, 0), tda = ld_ft(pslot, 6);
+            tdg = mk(FT(pslot, 12), FT(pslot, 13), FT(pslot, 14));
+          }
+          dvp = act_inv(R, p, tdv);
+          dap = act_inv(R, p, tda);
+          dgp = mulT(R, tdg);
         }
         if (impact) dgp = mk(0, 0, 0);
         SV dv = dvp, da = dap;
@@ -614,7 +659,7 @@ __global__ __launch_bounds__(64) RTOC_RBD_WAVES void linearize_contact_dynamics_
             const M3 Rf = ldm3(&scm[c * CP]);
             const V3 pf = ldv3(&scm[c * CP + 9]);
             // the contact force / wrench is given in the LOCAL contact frame (point_contact.cpp:55-60, surface_contact.cpp)
-            const SV fc = SV{mk(sf[roff], sf[roff + 1], sf[roff + 2]), surf ? mk(sf[roff + 3], sf[roff + 4], sf[roff + 5]) : mk(0, 0, 0)};
+            const SV fc = PRE ? sv0() : SV{mk(sf[roff], sf[roff + 1], sf[roff + 2]), surf ? mk(sf[roff + 3], sf[roff + 4], sf[roff + 5]) : mk(0, 0, 0)};
             if (!PRE) f = f - act_f(Rf, pf, fc);
             if (rows) {
               const SV vf = act_inv(Rf, pf, v), dvf = act_inv(Rf, pf, dv);
@@ -701,16 +746,20 @@ __global__ __launch_bounds__(64) RTOC_RBD_WAVES void linearize_contact_dynamics_
           st_sv(d, 39, f);
           LV(d, 45) = (double)i;
         }
-        if (d < nlev - 1) {
-          st_tv(d, 0, dv);
-          st_tv(d, 6, da);
-          LT(d, 12) = dg.x, LT(d, 13) = dg.y, LT(d, 14) = dg.z;
+        tdv = dv, tda = da, tdg = dg;
+        if (sslot >= 0) {
+          st_ft(sslot, 0, dv);
+          st_ft(sslot, 6, da);
+          FT(sslot, 12) = dg.x, FT(sslot, 13) = dg.y, FT(sslot, 14) = dg.z;
         }
-        st_tv(d, 15, df);
+        if (leaf) cdf = df;
+        else st_dt(d, df);
         top = d;
+        topreg = leaf;
       }
       while (top >= 0) {
-        close(top);
+        close(top, topreg);
+        topreg = false;
         --top;
       }
       if (aug && lane_on) {

@@ -120,14 +120,14 @@ static bool model_has_surface_contacts(const rtoc_robot_model& m) {
 }
 // hipFuncAttributeMaxDynamicSharedMemorySize is per function and process-wide, not per context: two live contexts with
 // different models (iCub: 11 tree levels, ANYmal: 4) share it, so it only ever grows (the launch passes its own size)
-static hipError_t set_linearize_lds(const rtoc_robot_model& m, int nlevels) {
+static hipError_t set_linearize_lds(const rtoc_robot_model& m, int nlevels, int nbranch) {
   static std::mutex mu;
   static int max_bytes_of[64] = {};   // the attribute is per DEVICE: one running maximum for each (the current one: callers hipSetDevice first)
   std::lock_guard<std::mutex> lock(mu);
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
   int& max_bytes = max_bytes_of[dev];
-  int bytes = (int)rbd::lin_lds_bytes(nlevels, m.njoints, m.ncontacts, m.nv);
+  int bytes = (int)rbd::lin_lds_bytes(nlevels, nbranch, m.njoints, m.ncontacts, m.nv, false);   // the larger of the two modes
   if (bytes <= max_bytes) return hipSuccess;
   hipError_t e = hipFuncSetAttribute((const void*)rbd::linearize_contact_dynamics_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   if (e == hipSuccess)
@@ -280,7 +280,7 @@ static __global__ __launch_bounds__(256) void stream_probe_kernel(const char* __
 int rtoc_bandwidth_probe(int device, size_t bytes, double* read_gbs, double* copy_gbs) {
   if (bytes < (size_t)1 << 24) return RTOC_ERR_BAD_ARG;
   HIP_TRY(hipSetDevice(device));
-  const int blocks = 256 * 8;                                  // 8 workgroups of 4 waves per CU
+  const int blocks = 256 * 64;                                 // 64 workgroups of 4 waves per CU: 6.2 TB/s read (256 * 8: 5.7)
   const size_t per = (size_t)blocks * 4 * 8;                   // chunks consumed per trip of all waves (U = 8)
   const size_t chunks = (bytes / 1024) / per * per;
   char *src = nullptr, *dst = nullptr;
@@ -550,7 +550,7 @@ int rtoc_clone(rtoc_ctx* c, rtoc_ctx** out) {
     if (!n->h_model) rc = RTOC_ERR_HIP;
     dup((void**)&n->d_model, c->d_model, sizeof(rbd::DevModel));
     if (!rc && e == hipSuccess)
-      e = set_linearize_lds(n->h_model->m, n->h_model->nlevels);
+      e = set_linearize_lds(n->h_model->m, n->h_model->nlevels, n->h_model->nbranch);
   }
   dup((void**)&n->d_active, c->d_active, sizeof(unsigned) * c->max_stages);
   dup((void**)&n->d_cpos, c->d_cpos, sizeof(double) * c->max_stages * RTOC_MAX_CONTACTS * 3);
@@ -1658,6 +1658,7 @@ int rtoc_set_robot_model(rtoc_ctx* c, const rtoc_robot_model* m) {
   h->m = *m;
   // depth-first order: when joint i is visited, the joint open one level up must be its parent
   int open[RTOC_MAX_JOINTS], iq = 0, iv = 0, nlev = 0;
+  for (int k = 0; k < RTOC_MAX_JOINTS; ++k) open[k] = -1;
   bool ok = true;
   for (int i = 0; i < m->njoints && ok; ++i) {
     const int par = m->parent[i];
@@ -1667,11 +1668,12 @@ int rtoc_set_robot_model(rtoc_ctx* c, const rtoc_robot_model* m) {
     ok = (d == 0 || open[d - 1] == par) && m->idx_q[i] == iq && m->idx_v[i] == iv;
     h->depth[i] = d;
     open[d] = i;
+    for (int k = d + 1; k < RTOC_MAX_JOINTS; ++k) open[k] = -1;   // the levels below are closed for good
     nlev = d + 1 > nlev ? d + 1 : nlev;
     iq += m->type[i] == RTOC_JOINT_FREE_FLYER ? 7 : 1;
     iv += m->type[i] == RTOC_JOINT_FREE_FLYER ? 6 : 1;
   }
-  ok = ok && iq == m->nq && iv == m->nv && rbd::lin_lds_bytes(nlev, m->njoints, m->ncontacts, m->nv) <= 160 * 1024;
+  ok = ok && iq == m->nq && iv == m->nv && rbd::lin_lds_bytes(nlev, rbd::walk_plan(*m, nullptr), m->njoints, m->ncontacts, m->nv, false) <= 160 * 1024;
   for (int k = 0; k < m->ncontacts && ok; ++k) ok = m->contact_parent[k] >= 0 && m->contact_parent[k] < m->njoints;
   if (!ok) {
     delete h;
@@ -1685,7 +1687,7 @@ int rtoc_set_robot_model(rtoc_ctx* c, const rtoc_robot_model* m) {
   c->h_model = h;
   HIP_TRY(hipMemcpyAsync(c->d_model, h, sizeof(rbd::DevModel), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
-  HIP_TRY(set_linearize_lds(*m, nlev));
+  HIP_TRY(set_linearize_lds(*m, nlev, h->nbranch));
   c->epoch++;
   return RTOC_OK;
 }
@@ -1803,7 +1805,7 @@ static int launch_linearize(rtoc_ctx* c, int augment_residual, bool unconstr, do
   a.nf_max = c->dims.nf_max;
   {
     const rtoc_robot_model& m = c->h_model->m;
-    a.nlevels = c->h_model->nlevels;
+    a.nlevels = c->h_model->nlevels, a.nbranch = c->h_model->nbranch;
     a.nv = m.nv, a.nq = m.nq, a.njoints = m.njoints, a.ncontacts = m.ncontacts;
     a.nu = m.type[0] == RTOC_JOINT_FREE_FLYER ? m.nv - 6 : m.nv;
     a.gx = m.gravity[0], a.gy = m.gravity[1], a.gz = m.gravity[2];
@@ -1821,7 +1823,7 @@ static int launch_linearize(rtoc_ctx* c, int augment_residual, bool unconstr, do
   a.unconstr = unconstr ? 1 : 0;
   a.scale = scale;
   if (c->nstages < 2) return RTOC_OK;
-  const size_t lds = rbd::lin_lds_bytes(c->h_model->nlevels, c->h_model->m.njoints, c->h_model->m.ncontacts, c->h_model->m.nv);
+  const size_t lds = rbd::lin_lds_bytes(c->h_model->nlevels, c->h_model->nbranch, c->h_model->m.njoints, c->h_model->m.ncontacts, c->h_model->m.nv, !c->linearize_fused);
   const bool surf = model_has_surface_contacts(c->h_model->m);
   a.vals = a.vals2 = nullptr;
   if (!c->linearize_fused) {
