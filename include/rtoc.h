@@ -143,6 +143,10 @@ enum rtoc_option {
                       * the reference composes it -- the LOCAL-frame angular Jacobian column of the contact frame crossed
                       * with the WORLD-frame force (robot.hxx:247-253, 275-287).  1: w_world x f_W, the derivative of
                       * R_wf(q) f (what finite differences give).  They coincide when the contact frame is world-aligned. */
+  RTOC_OPT_LINEARIZE_DOFS_PER_PASS = 15, /* tangent directions (dofs, three lanes each) one pass of rtoc_linearize_contact_dynamics'
+                      * walk carries, 1..21; 0 (default): chosen per robot model -- fewer lanes per pass = less LDS per wave = more
+                      * waves per CU, against more passes over the bodies the pass's dofs reach (ANYmal: 18 = one pass, iCub: 12).
+                      * rtoc_get_option reads the value in force (0 before rtoc_set_robot_model). */
   RTOC_OPT_LINEARIZE_FUSED = 13, /* 0 (default): rtoc_linearize_contact_dynamics computes the values of the recursion in a
                       * level-parallel pre-pass (lanes = bodies; 64 doubles per body and grid point of scratch) and the
                       * tangent walk reads them; 1: one kernel, every lane recomputes the values along its walk (no scratch) */

@@ -10,7 +10,7 @@ import subprocess
 import numpy as np
 
 from .types import (BoxRow, BUF_CDD, BUF_CON, BUF_DIR, BUF_DX0, BUF_KKT, BUF_RIC, BUF_STEP, Dims, Grid,
-                    Layout, OPT_BACKWARD_WAVES, OPT_CONDENSE_SPLIT, OPT_CONDENSE_KEEP_QAF, OPT_FXX_STRUCTURE, OPT_GRAPH, OPT_SWITCHING_TRANSPORT, OPT_IMPACT_CONES, OPT_UNCONSTR_DENSE, OPT_LINEARIZE_FUSED, OPT_CONE_JACOBIAN, OPT_MAX_DTS0, OPT_SWEEP_CHUNKS, OPT_WRITEBACK_KKT, OPT_BACKWARD_SCAN,
+                    Layout, OPT_BACKWARD_WAVES, OPT_CONDENSE_SPLIT, OPT_CONDENSE_KEEP_QAF, OPT_FXX_STRUCTURE, OPT_GRAPH, OPT_SWITCHING_TRANSPORT, OPT_IMPACT_CONES, OPT_UNCONSTR_DENSE, OPT_LINEARIZE_FUSED, OPT_LINEARIZE_DOFS_PER_PASS, OPT_CONE_JACOBIAN, OPT_MAX_DTS0, OPT_SWEEP_CHUNKS, OPT_WRITEBACK_KKT, OPT_BACKWARD_SCAN,
                     grid_array)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -544,6 +544,10 @@ class Context:
     def set_linearize_fused(self, on):
         """RTOC_OPT_LINEARIZE_FUSED: rigid-body linearisation as one kernel (values recomputed per lane) instead of pre-pass + walk"""
         _chk(lib().rtoc_set_option(self._h, OPT_LINEARIZE_FUSED, int(bool(on))))
+
+    def set_linearize_dofs_per_pass(self, dofs):
+        """RTOC_OPT_LINEARIZE_DOFS_PER_PASS: tangent directions per pass of the rigid-body walk (0 = chosen per model)"""
+        _chk(lib().rtoc_set_option(self._h, OPT_LINEARIZE_DOFS_PER_PASS, int(dofs)))
 
     def set_unconstr_dense(self, on):
         """RTOC_OPT_UNCONSTR_DENSE: the unconstrained recursion on materialised A, B (general kernels) instead of the structured one"""

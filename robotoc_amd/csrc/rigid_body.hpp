@@ -44,6 +44,13 @@ struct DevModel {
   // Slots are numbered by the count of branching ancestors: two bodies with the same count are never open at once.
   int walk[RTOC_MAX_JOINTS];
   int nbranch;
+  // passes of the tangent walk: pass p carries the dofs [p dpp, (p + 1) dpp), three lanes each; pass_bodies[p] = the bodies
+  // a direction of the pass can move or load (bit i: some dof of the pass sits on the path root -> i or in the subtree of i);
+  // the other bodies are skipped by the whole wave (their columns are zero)
+  int dpp, npass;
+  unsigned long long pass_bodies[RTOC_MAX_JOINTS + 8];
+  int pass_nvisit[RTOC_MAX_JOINTS + 8];                          // the same as lists, in depth-first order
+  int pass_visit[RTOC_MAX_JOINTS + 8][RTOC_MAX_JOINTS];       // (ints: read through the scalar cache)
   double joint[RTOC_MAX_JOINTS][JP];
   double contact[RTOC_MAX_CONTACTS][CP];
   // per dof: the body it moves and its angular axis in that body's frame (zero for the linear dofs of a free-flyer);
@@ -70,10 +77,12 @@ inline int walk_plan(const rtoc_robot_model& m, int* walk) {
   }
   return nbranch;
 }
+inline void plan_passes(DevModel* h, int forced_dpp = 0);
 inline void pack_model(DevModel* h) {
   const rtoc_robot_model& m = h->m;
   for (int i = 0; i < RTOC_MAX_JOINTS; ++i) h->walk[i] = 0;
   h->nbranch = walk_plan(m, h->walk);
+  plan_passes(h);
   for (int i = 0; i < m.njoints; ++i) {
     double* o = h->joint[i];
     for (int k = 0; k < 9; ++k) o[k] = m.placement_R[i][k], o[19 + k] = m.inertia[i][k];
@@ -200,6 +209,11 @@ __device__ __forceinline__ void log6_fwd(const M3& R, V3 p, SV twist, SV& val, S
   der = SV{dlin, dw};
 }
 
+// an int of the device model through the scalar cache: the model is read-only while a kernel runs, but the compiler cannot know
+// (the kernel stores through other pointers) and would issue a vector load + v_readfirstlane on the walk's critical path
+typedef const int __attribute__((address_space(4))) lin_const_int;
+__device__ __forceinline__ int sload_int(const int* p) { return *(lin_const_int*)(unsigned long long)p; }
+
 struct LinArgs {
   const DevModel* model;
   const double* sol;
@@ -213,7 +227,7 @@ struct LinArgs {
   int o_q, o_v, o_a, o_u, o_f;                 // RTOC_BUF_SOL field offsets
   int o_idc, o_didda, o_dcda, o_didcdqv;       // RTOC_BUF_CDD field offsets
   int ldv, nf_max;                             // leading dimensions of DIDCDQV / DCDA
-  int nlevels, nbranch, nv, nq, njoints, ncontacts, nu;
+  int nlevels, nbranch, dpp, nv, nq, njoints, ncontacts, nu;
   double gx, gy, gz;                           // gravity
   // multiplier terms of linearizeContactDynamics / linearizeImpactDynamics (kkt == nullptr: left out)
   double* kkt;
@@ -234,8 +248,9 @@ constexpr int TAN_SLOTS = 21;    // dv 6, da 6, dg 3, df 6
 constexpr int FWD_SLOTS = 15;    // dv, da, dg: read by the children only, so the deepest level keeps none
 constexpr int DF_SLOTS = 6;
 __host__ __device__ constexpr int lin_pad8(int n) { return (n + 7) & ~7; }
-// lanes per tangent slot: 3 nv tangent directions when they fit one pass (quadrupeds: 54 -> 56), else 64
-__host__ __device__ constexpr int lin_lane_stride(int nv) { return 3 * nv <= 56 ? 56 : 64; }
+// lanes per tangent slot: three per dof of a pass plus a column the idle lanes share, even (quadrupeds: 54 -> 56; 21 dofs: 64)
+__host__ __device__ constexpr int lin_lane_stride(int dpp) { return (3 * dpp + 2) & ~1; }
+constexpr int LIN_MAX_DPP = 21;
 // What decides the speed of this kernel is how many grid points a CU holds at once (the walk is one long dependent
 // instruction stream per wave, issue-bound): only what the walk cannot carry in registers lives in LDS -- the forward tangents
 // (dv, da, dg) of the bodies with two or more children (nbranch slots: a body whose parent was visited just before it takes
@@ -244,10 +259,68 @@ __host__ __device__ constexpr int lin_lane_stride(int nv) { return 3 * nv <= 56 
 // pre: the walk reads the values of the recursion from rbd_values_kernel (PRE): no q, v, a, f, u staging, and of the joint
 // constants only axis .. depth (JP_PRE doubles from JP_PRE_OFF on) -- 20,000 B for ANYmal: EIGHT waves per CU (8 x 20,480 B).
 constexpr int JP_PRE_OFF = 12, JP_PRE = JP - JP_PRE_OFF;
-__host__ __device__ constexpr size_t lin_lds_bytes(int nlevels, int nbranch, int njoints, int ncontacts, int nv, bool pre) {
-  return sizeof(double) * ((size_t)nlevels * VAL_DOUBLES + (size_t)(nbranch * FWD_SLOTS + (nlevels > 1 ? nlevels - 1 : 0) * DF_SLOTS) * lin_lane_stride(nv) +
+__host__ __device__ constexpr size_t lin_lds_bytes(int nlevels, int nbranch, int njoints, int ncontacts, int nv, int dpp, bool pre) {
+  return sizeof(double) * ((size_t)nlevels * VAL_DOUBLES + (size_t)(nbranch * FWD_SLOTS + (nlevels > 1 ? nlevels - 1 : 0) * DF_SLOTS) * lin_lane_stride(dpp) +
                            (pre ? 0 : lin_pad8(nv + 1) + 3 * lin_pad8(nv) + lin_pad8(6 * ncontacts)) + lin_pad8(nv) + 2 * lin_pad8(6 * ncontacts) +
                            njoints * (pre ? JP_PRE : JP) + ncontacts * CP);
+}
+
+// bodies a pass with the dofs [j0, j1) has to visit
+inline unsigned long long pass_body_mask(const rtoc_robot_model& m, int j0, int j1) {
+  unsigned long long mask = 0;
+  for (int b = 0; b < m.njoints; ++b) {
+    const int ndof = m.type[b] == RTOC_JOINT_FREE_FLYER ? 6 : 1;
+    if (m.idx_v[b] + ndof <= j0 || m.idx_v[b] >= j1) continue;   // no dof of body b in the pass
+    for (int i = 0; i < m.njoints; ++i) {
+      bool up = false, down = false;   // b above-or-at i; b below i
+      for (int k = i; k >= 0; k = m.parent[k]) {
+        if (k == b) up = true;
+        if (m.parent[k] < 0 || m.parent[k] >= k) break;
+      }
+      for (int k = b; k >= 0; k = m.parent[k]) {
+        if (k == i) down = true;
+        if (m.parent[k] < 0 || m.parent[k] >= k) break;
+      }
+      if (up || down) mask |= 1ull << i;
+    }
+  }
+  return mask;
+}
+// dofs per pass: what minimises (bodies visited over all passes) / (waves a CU holds).  The walk is one dependent instruction
+// stream per wave, so a CU's rate is its resident waves -- set by the LDS of the per-lane tangents, i.e. by the lanes of a pass --
+// over the visits per grid point: ANYmal one pass of 18 dofs (8 waves per CU), iCub 3 passes of 12 instead of 2 of 21.
+// max_waves: what the registers of the kernel allow per CU (8; 4 with surface contacts: 256 VGPRs + AGPRs).
+inline int choose_dofs_per_pass(const rtoc_robot_model& m, int nlevels, int nbranch, int max_waves) {
+  const int dmax = m.nv < LIN_MAX_DPP ? m.nv : LIN_MAX_DPP, dmin = dmax < 6 ? dmax : 6;
+  int best = dmax;
+  double best_cost = 1e300;
+  for (int d = dmax; d >= dmin && d >= 1; --d) {   // ties: the larger pass
+    const size_t bytes = (lin_lds_bytes(nlevels, nbranch, m.njoints, m.ncontacts, m.nv, d, true) + 1279) / 1280 * 1280;
+    int waves = (int)(160 * 1024 / bytes);
+    waves = waves > max_waves ? max_waves : waves;
+    if (waves < 1) continue;
+    int visits = m.njoints;   // the first pass visits every body
+    for (int j0 = d; j0 < m.nv; j0 += d) visits += __builtin_popcountll(pass_body_mask(m, j0, j0 + d < m.nv ? j0 + d : m.nv));
+    const double cost = (double)visits / waves;
+    if (cost < best_cost - 1e-9) best_cost = cost, best = d;
+  }
+  return best;
+}
+inline void plan_passes(DevModel* h, int forced_dpp) {
+  const rtoc_robot_model& m = h->m;
+  bool surf = false;
+  for (int c = 0; c < m.ncontacts; ++c) surf = surf || m.contact_type[c] == RTOC_CONTACT_SURFACE;
+  h->dpp = forced_dpp > 0 ? (forced_dpp < m.nv ? forced_dpp : (m.nv < LIN_MAX_DPP ? m.nv : LIN_MAX_DPP)) : choose_dofs_per_pass(m, h->nlevels, h->nbranch, surf ? 4 : 8);
+  for (int p = 0; p < RTOC_MAX_JOINTS + 8; ++p) {
+    h->pass_bodies[p] = 0, h->pass_nvisit[p] = 0;
+    for (int i = 0; i < RTOC_MAX_JOINTS; ++i) h->pass_visit[p][i] = 0;
+  }
+  h->npass = (m.nv + h->dpp - 1) / h->dpp;
+  for (int p = 0; p < h->npass; ++p) h->pass_bodies[p] = pass_body_mask(m, p * h->dpp, (p + 1) * h->dpp < m.nv ? (p + 1) * h->dpp : m.nv);
+  h->pass_bodies[0] |= m.njoints >= 64 ? ~0ull : (1ull << m.njoints) - 1;   // the first pass writes the values of the contact rows: every body
+  for (int p = 0; p < h->npass; ++p)
+    for (int i = 0; i < m.njoints; ++i)
+      if ((h->pass_bodies[p] >> i) & 1ull) h->pass_visit[p][h->pass_nvisit[p]++] = i;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -417,7 +490,7 @@ static __global__ __launch_bounds__(64) void rbd_values_kernel(ValArgs a) {
 // PRE: the values of the recursion come from rbd_values_kernel (a.vals / a.vals2): the visit copies the body's block into
 // the level's value slots instead of computing it, and the force accumulation / ID rows are not repeated here.
 template <bool SURF, bool PRE = false>
-__global__ __launch_bounds__(64) RTOC_RBD_WAVES void linearize_contact_dynamics_kernel(LinArgs a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((PRE && !SURF) ? 2 : 1))) void linearize_contact_dynamics_kernel(LinArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = threadIdx.x;
   const int item = blockIdx.x;
@@ -429,7 +502,7 @@ __global__ __launch_bounds__(64) RTOC_RBD_WAVES void linearize_contact_dynamics_
   const bool impact = g.type == RTOC_GRID_IMPACT;
   const unsigned active = a.active[st];
   double* const lval = smem;                                      // [nlev][VAL_DOUBLES]
-  const int LW = lin_lane_stride(nv);
+  const int LW = lin_lane_stride(a.dpp);
   double* const lfwd = lval + (size_t)nlev * VAL_DOUBLES;         // [nbranch][FWD_SLOTS][LW]: dv, da, dg of the branching bodies
   double* const ldf = lfwd + (size_t)a.nbranch * FWD_SLOTS * LW;  // [nlev - 1][DF_SLOTS][LW]: df of the open non-leaf levels
   double* const sq = ldf + (size_t)(nlev > 1 ? nlev - 1 : 0) * DF_SLOTS * LW;   // q, v, a, f, u of the grid point
@@ -476,9 +549,11 @@ __global__ __launch_bounds__(64) RTOC_RBD_WAVES void linearize_contact_dynamics_
   for (int trav = 0; trav < ntrav; ++trav) {
     const bool dyn = trav == 0;                 // writes ID and its derivatives
     const bool rows = !impact || trav == 1;     // writes C and its derivatives
-    for (int j0 = 0; j0 < nv; j0 += 21) {
+    for (int j0 = 0, ps = 0; j0 < nv; j0 += a.dpp, ++ps) {
       const int j = j0 + lane / 3, kind = lane % 3;  // 0: q, 1: v, 2: a
-      const bool lane_on = lane < 63 && j < nv;
+      const bool lane_on = lane < 3 * a.dpp && j < nv;
+      // (without the values pre-pass every pass accumulates the forces of all bodies: no skipping)
+      const unsigned long long visit_mask = PRE ? a.model->pass_bodies[ps] : ~0ull;
       int top = -1;
       double wsum = 0.0;  // this lane's column of [dID; dC] against [beta; mu]
       // body of the level that is being closed / visited is kept in LDS as an int in the value block
@@ -541,9 +616,36 @@ __global__ __launch_bounds__(64) RTOC_RBD_WAVES void linearize_contact_dynamics_
           st_dt(lev - 1, ld_dt(lev - 1) + dfp);
         }
       };
+      // bodies no direction of this pass moves or loads: their entries of the pass's columns are zero
+      if (PRE && ps > 0)
+        for (int i = 0; i < nb; ++i) {
+          if ((visit_mask >> i) & 1ull) continue;
+          const int iv = (int)JM(i, 30);
+          if (dyn && lane_on) {
+            double* const dcol = kind == 2 ? cr + a.o_didda + (size_t)j * nv : cr + a.o_didcdqv + (size_t)(kind == 1 ? nv + j : j) * a.ldv;
+            const int ndof = (int)JM(i, 28) == RTOC_JOINT_FREE_FLYER ? 6 : 1;
+            for (int k = 0; k < ndof; ++k) dcol[iv + k] = 0.0;
+          }
+          if (rows) {
+            int roff = 0;
+            for (int c = 0; c < ncon; ++c) {
+              const bool on = (active >> c) & 1u;
+              const int nr = (SURF && (int)scm[c * CP + 15] == RTOC_CONTACT_SURFACE) ? 6 : 3;
+              if (on && (int)scm[c * CP + 14] == i && lane_on)
+                for (int t = 0; t < nr; ++t) {
+                  if (kind == 2 || (impact && kind == 1)) cr[a.o_dcda + (size_t)j * a.nf_max + roff + t] = 0.0;
+                  if (kind != 2) cr[a.o_didcdqv + (size_t)(kind == 1 ? nv + j : j) * a.ldv + nv + roff + t] = 0.0;
+                }
+              roff += on ? nr : 0;
+            }
+          }
+        }
       const double* const vblk = PRE ? (dyn ? a.vals : a.vals2) + rec * (size_t)nb * VAL_SLOTS : nullptr;
-      double pv = PRE ? vblk[lane] : 0.0;
-      for (int i = 0; i < nb; ++i) {
+      double pv = PRE ? vblk[lane] : 0.0;   // body 0 is in every pass
+      const int* const vlist = a.model->pass_visit[ps];
+      const int nvisit = PRE ? sload_int(a.model->pass_nvisit + ps) : nb;
+      for (int t = 0; t < nvisit; ++t) {
+        const int i = PRE ? sload_int(vlist + t) : t;   // the bodies a direction of this pass moves or loads, depth first
         const int d = (int)JM(i, 31);
         while (top >= d) {
           close(top, topreg);
@@ -551,7 +653,7 @@ __global__ __launch_bounds__(64) RTOC_RBD_WAVES void linearize_contact_dynamics_
           --top;
         }
         // ---- visit body i at level d ----
-        const int wk = a.model->walk[i];
+        const int wk = sload_int(a.model->walk + i);
         const bool chain = wk & 1, leaf = wk & 2;
         const int sslot = ((wk >> 4) & 15) - 1, pslot = ((wk >> 8) & 15) - 1;
         const int iq = (int)JM(i, 29), iv = (int)JM(i, 30);
@@ -563,7 +665,7 @@ __global__ __launch_bounds__(64) RTOC_RBD_WAVES void linearize_contact_dynamics_
         if constexpr (PRE) {
           // the body's block from rbd_values_kernel (requested one body ahead) into the level's value slots
           LV(d, lane) = pv;
-          if (i + 1 < nb) pv = vblk[(size_t)(i + 1) * VAL_SLOTS + lane];
+          if (t + 1 < nvisit) pv = vblk[(size_t)sload_int(vlist + t + 1) * VAL_SLOTS + lane];
           __builtin_amdgcn_wave_barrier();
           R = ldm3(&LV(d, 0)), oR = ldm3(&LV(d, 12));
           p = ldv3(&LV(d, 9)), op = ldv3(&LV(d, 21)), gi = ldv3(&LV(d, 36));

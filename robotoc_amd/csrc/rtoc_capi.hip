@@ -120,14 +120,14 @@ static bool model_has_surface_contacts(const rtoc_robot_model& m) {
 }
 // hipFuncAttributeMaxDynamicSharedMemorySize is per function and process-wide, not per context: two live contexts with
 // different models (iCub: 11 tree levels, ANYmal: 4) share it, so it only ever grows (the launch passes its own size)
-static hipError_t set_linearize_lds(const rtoc_robot_model& m, int nlevels, int nbranch) {
+static hipError_t set_linearize_lds(const rtoc_robot_model& m, int nlevels, int nbranch, int dpp) {
   static std::mutex mu;
   static int max_bytes_of[64] = {};   // the attribute is per DEVICE: one running maximum for each (the current one: callers hipSetDevice first)
   std::lock_guard<std::mutex> lock(mu);
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
   int& max_bytes = max_bytes_of[dev];
-  int bytes = (int)rbd::lin_lds_bytes(nlevels, nbranch, m.njoints, m.ncontacts, m.nv, false);   // the larger of the two modes
+  int bytes = (int)rbd::lin_lds_bytes(nlevels, nbranch, m.njoints, m.ncontacts, m.nv, dpp, false);   // the larger of the two modes
   if (bytes <= max_bytes) return hipSuccess;
   hipError_t e = hipFuncSetAttribute((const void*)rbd::linearize_contact_dynamics_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   if (e == hipSuccess)
@@ -192,6 +192,7 @@ struct rtoc_ctx {
   size_t vals_cap;
   int vals_fresh;       // the values in d_vals belong to the iterate in RTOC_BUF_SOL (consumed by the next launch_linearize)
   int linearize_fused;  // RTOC_OPT_LINEARIZE_FUSED
+  int lin_dpp;          // RTOC_OPT_LINEARIZE_DOFS_PER_PASS (0 = per model)
   unsigned long long epoch;  // bumped by everything that changes a launch parameter baked into a captured graph
   struct GraphSlot {
     hipGraphExec_t exec;
@@ -534,6 +535,7 @@ int rtoc_clone(rtoc_ctx* c, rtoc_ctx** out) {
     n->impact_cones = c->impact_cones;
     n->unconstr_dense = c->unconstr_dense;
     n->linearize_fused = c->linearize_fused;
+    n->lin_dpp = c->lin_dpp;
     n->exact_cone_jacobian = c->exact_cone_jacobian;
     n->ls_on = c->ls_on, n->ls_rate = c->ls_rate, n->ls_min_step = c->ls_min_step, n->ls_cost_rate = c->ls_cost_rate, n->ls_viol_rate = c->ls_viol_rate;
     if (c->backward_scan) rc = rtoc_set_option(n, RTOC_OPT_BACKWARD_SCAN, c->backward_scan);
@@ -550,7 +552,7 @@ int rtoc_clone(rtoc_ctx* c, rtoc_ctx** out) {
     if (!n->h_model) rc = RTOC_ERR_HIP;
     dup((void**)&n->d_model, c->d_model, sizeof(rbd::DevModel));
     if (!rc && e == hipSuccess)
-      e = set_linearize_lds(n->h_model->m, n->h_model->nlevels, n->h_model->nbranch);
+      e = set_linearize_lds(n->h_model->m, n->h_model->nlevels, n->h_model->nbranch, n->h_model->dpp);
   }
   dup((void**)&n->d_active, c->d_active, sizeof(unsigned) * c->max_stages);
   dup((void**)&n->d_cpos, c->d_cpos, sizeof(double) * c->max_stages * RTOC_MAX_CONTACTS * 3);
@@ -645,6 +647,22 @@ int rtoc_set_stream(rtoc_ctx* c, void* s) {
 static int ensure_scan_buffers(rtoc_ctx* c);
 #define RTOC_SCAN_AUTO_MAX_BATCH 8  // measured on MI355X (profiles/r01_scan_batch_crossover.log): the scan wins up to ~16 ANYmal / ~10 iCub instances
 
+// (re)plans the passes of the tangent walk for the context's model and sends the model to the device
+static int apply_linearize_plan(rtoc_ctx* c) {
+  rbd::DevModel* h = c->h_model;
+  const int old_dpp = h->dpp;
+  rbd::plan_passes(h, c->lin_dpp);
+  if (rbd::lin_lds_bytes(h->nlevels, h->nbranch, h->m.njoints, h->m.ncontacts, h->m.nv, h->dpp, false) > 160 * 1024) {
+    rbd::plan_passes(h, old_dpp);
+    return RTOC_ERR_BAD_ARG;
+  }
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipMemcpyAsync(c->d_model, h, sizeof(rbd::DevModel), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(set_linearize_lds(h->m, h->nlevels, h->nbranch, h->dpp));
+  return RTOC_OK;
+}
+
 int rtoc_get_option(rtoc_ctx* c, int option, int64_t* value) {
   if (!c || !value) return RTOC_ERR_BAD_ARG;
   switch (option) {
@@ -656,6 +674,7 @@ int rtoc_get_option(rtoc_ctx* c, int option, int64_t* value) {
     case RTOC_OPT_FXX_STRUCTURE: *value = c->fxx_mode; return RTOC_OK;
     case RTOC_OPT_GRAPH: *value = c->use_graph; return RTOC_OK;
     case RTOC_OPT_IMPACT_CONES: *value = c->impact_cones; return RTOC_OK;
+    case RTOC_OPT_LINEARIZE_DOFS_PER_PASS: *value = c->h_model ? c->h_model->dpp : 0; return RTOC_OK;
     default: return RTOC_ERR_BAD_ARG;
   }
 }
@@ -680,6 +699,10 @@ int rtoc_set_option(rtoc_ctx* c, int option, int64_t value) {
     case RTOC_OPT_LINEARIZE_FUSED:
       c->linearize_fused = value ? 1 : 0;
       return RTOC_OK;
+    case RTOC_OPT_LINEARIZE_DOFS_PER_PASS:
+      if (value < 0 || value > rbd::LIN_MAX_DPP) return RTOC_ERR_BAD_ARG;
+      c->lin_dpp = (int)value;
+      return c->h_model ? apply_linearize_plan(c) : RTOC_OK;
     case RTOC_OPT_UNCONSTR_DENSE:
       c->unconstr_dense = value ? 1 : 0;
       return RTOC_OK;
@@ -1673,7 +1696,7 @@ int rtoc_set_robot_model(rtoc_ctx* c, const rtoc_robot_model* m) {
     iq += m->type[i] == RTOC_JOINT_FREE_FLYER ? 7 : 1;
     iv += m->type[i] == RTOC_JOINT_FREE_FLYER ? 6 : 1;
   }
-  ok = ok && iq == m->nq && iv == m->nv && rbd::lin_lds_bytes(nlev, rbd::walk_plan(*m, nullptr), m->njoints, m->ncontacts, m->nv, false) <= 160 * 1024;
+  ok = ok && iq == m->nq && iv == m->nv;
   for (int k = 0; k < m->ncontacts && ok; ++k) ok = m->contact_parent[k] >= 0 && m->contact_parent[k] < m->njoints;
   if (!ok) {
     delete h;
@@ -1681,13 +1704,18 @@ int rtoc_set_robot_model(rtoc_ctx* c, const rtoc_robot_model* m) {
   }
   h->nlevels = nlev;
   rbd::pack_model(h);
+  if (c->lin_dpp) rbd::plan_passes(h, c->lin_dpp);
+  if (rbd::lin_lds_bytes(nlev, h->nbranch, m->njoints, m->ncontacts, m->nv, h->dpp, false) > 160 * 1024) {
+    delete h;
+    return RTOC_ERR_BAD_ARG;
+  }
   HIP_TRY(hipSetDevice(c->device));
   if (!c->d_model) HIP_TRY(hipMalloc((void**)&c->d_model, sizeof(rbd::DevModel)));
   delete c->h_model;
   c->h_model = h;
   HIP_TRY(hipMemcpyAsync(c->d_model, h, sizeof(rbd::DevModel), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
-  HIP_TRY(set_linearize_lds(*m, nlev, h->nbranch));
+  HIP_TRY(set_linearize_lds(*m, nlev, h->nbranch, h->dpp));
   c->epoch++;
   return RTOC_OK;
 }
@@ -1805,7 +1833,7 @@ static int launch_linearize(rtoc_ctx* c, int augment_residual, bool unconstr, do
   a.nf_max = c->dims.nf_max;
   {
     const rtoc_robot_model& m = c->h_model->m;
-    a.nlevels = c->h_model->nlevels, a.nbranch = c->h_model->nbranch;
+    a.nlevels = c->h_model->nlevels, a.nbranch = c->h_model->nbranch, a.dpp = c->h_model->dpp;
     a.nv = m.nv, a.nq = m.nq, a.njoints = m.njoints, a.ncontacts = m.ncontacts;
     a.nu = m.type[0] == RTOC_JOINT_FREE_FLYER ? m.nv - 6 : m.nv;
     a.gx = m.gravity[0], a.gy = m.gravity[1], a.gz = m.gravity[2];
@@ -1823,7 +1851,7 @@ static int launch_linearize(rtoc_ctx* c, int augment_residual, bool unconstr, do
   a.unconstr = unconstr ? 1 : 0;
   a.scale = scale;
   if (c->nstages < 2) return RTOC_OK;
-  const size_t lds = rbd::lin_lds_bytes(c->h_model->nlevels, c->h_model->nbranch, c->h_model->m.njoints, c->h_model->m.ncontacts, c->h_model->m.nv, !c->linearize_fused);
+  const size_t lds = rbd::lin_lds_bytes(c->h_model->nlevels, c->h_model->nbranch, c->h_model->m.njoints, c->h_model->m.ncontacts, c->h_model->m.nv, c->h_model->dpp, !c->linearize_fused);
   const bool surf = model_has_surface_contacts(c->h_model->m);
   a.vals = a.vals2 = nullptr;
   if (!c->linearize_fused) {

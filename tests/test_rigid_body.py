@@ -212,6 +212,24 @@ def test_model_table_is_validated():
     assert hasattr(lib, "rtoc_set_robot_model") and hasattr(lib, "rtoc_linearize_contact_dynamics")
 
 
+@pytest.mark.gpu
+def test_model_joints_must_come_depth_first():
+    """rtoc_set_robot_model: the walk keeps one value block per OPEN tree level, so when a joint is visited its parent has to be
+    the joint open one level up.  A table whose joint 5 hangs under joint 3 AFTER joint 4 (a sibling of joint 1) has closed that
+    branch is refused (the check used to look only at the level of the parent, which joint 3 still occupied)."""
+    m = model("anymal")
+    ctx = capi.Context(pr.config_anymal_trot()[0], 4, 1, 0)
+    try:
+        ctx.set_robot_model(m)
+        bad = type(m).from_buffer_copy(m)
+        assert list(bad.parent[:6]) == [-1, 0, 1, 2, 0, 4]
+        bad.parent[5] = 3
+        with pytest.raises(capi.RtocError):
+            ctx.set_robot_model(bad)
+    finally:
+        ctx.close()
+
+
 def _masks(grids):
     """contact masks with popcount * 3 == dimf: all four feet, or alternating diagonal pairs"""
     out, flip = [], False
@@ -354,10 +372,66 @@ def test_gpu_linearisation_matches_the_restatement_and_its_complex_step_derivati
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("fused", [False, True])
-def test_gpu_linearisation_icub_surface_contacts_two_passes_eleven_levels(oracle, fused):
-    """nv = 35: 2 passes of 21 dofs, 11 tree levels (128 KB of LDS per wave); two SURFACE contacts (the soles: 6 rows
-    each, wrench in the local frame, Log6 position / orientation error against a desired placement)"""
+@pytest.mark.parametrize("dpp", [9, 6, 5])
+def test_gpu_linearisation_does_not_depend_on_the_passes(dpp):
+    """ANYmal trot (ordinary, impact and flight grids): the linearisation and its multiplier terms with 2, 3 and 4 passes
+    (RTOC_OPT_LINEARIZE_DOFS_PER_PASS; passes behind the first skip the legs none of their dofs sits in) against the single pass
+    of 18 dofs the library chooses; NaN-filled records beforehand: every entry the passes skip is written as zero."""
+    from robotoc_amd.types import OPT_LINEARIZE_DOFS_PER_PASS, Records
+    m = model("anymal")
+    dims, grids, _ = pr.config_anymal_trot()
+    batch = 2
+    ctx = capi.Context(dims, len(grids), batch, 0)
+    try:
+        L = ctx.L
+        Rc = Records(L, "cdd")
+        ctx.set_grid(grids)
+        ctx.set_robot_model(m)
+        assert ctx.get_option(OPT_LINEARIZE_DOFS_PER_PASS) == 18
+        rng = np.random.default_rng(14)
+        ctx.set_contact_schedule(_masks(grids), rng.uniform(-0.5, 0.5, (len(grids), 4, 3)))
+        sol = np.zeros(ctx.shape("sol"))
+        o = L.sol.off
+        for b in range(batch):
+            for i in range(len(grids)):
+                q, v, a = rm.random_configuration(m, rng, 0.8)
+                sol[b, i, o[0]:o[0] + m.nq], sol[b, i, o[1]:o[1] + m.nv], sol[b, i, o[2]:o[2] + m.nv] = q, v, a
+                sol[b, i, o[3]:o[3] + m.nu] = rng.uniform(-5, 5, m.nu)
+                sol[b, i, o[4]:o[4] + 12] = rng.uniform(-20, 20, 12)
+                sol[b, i, o[7]:o[7] + m.nv] = rng.uniform(-1, 1, m.nv)
+                sol[b, i, o[8]:o[8] + 12] = rng.uniform(-1, 1, 12)
+        ctx.upload(BUF_SOL, sol)
+        out = []
+        for d in (0, dpp):
+            ctx.set_linearize_dofs_per_pass(d)
+            assert ctx.get_option(OPT_LINEARIZE_DOFS_PER_PASS) == (d if d else 18)
+            ctx.upload(BUF_KKT, np.zeros(ctx.shape("kkt")))
+            cdd0 = np.full(ctx.shape("cdd"), np.nan)
+            for f in ("la", "lf"):   # the residuals the multiplier terms are accumulated into
+                Rc.f(cdd0, f)[...] = 0.0
+            ctx.upload(BUF_CDD, cdd0)
+            ctx.linearize_contact_dynamics(True)
+            ctx.sync()
+            out.append((ctx.download(BUF_KKT, ctx.shape("kkt")), ctx.download(BUF_CDD, ctx.shape("cdd"))))
+            assert (ctx.status() == 0).all()
+        for f in ("IDC", "dIDda", "dCda", "dIDCdqv", "la", "lf"):
+            a0, a1 = Rc.f(out[0][1], f)[:, :-1], Rc.f(out[1][1], f)[:, :-1]
+            assert np.array_equal(np.isnan(a0), np.isnan(a1)), f          # the same entries written
+            ok = ~np.isnan(a0)
+            assert ok.any() and np.abs(a0[ok] - a1[ok]).max() <= 1e-13 * max(1.0, np.abs(a0[ok]).max()), f
+        assert np.abs(out[0][0] - out[1][0]).max() <= 1e-13 * max(1.0, np.abs(out[0][0]).max())
+        assert np.abs(out[0][0]).max() > 1e-3
+    finally:
+        ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fused,dpp", [(False, 0), (True, 0), (False, 21), (False, 12), (False, 7), (True, 12)])
+def test_gpu_linearisation_icub_surface_contacts_two_passes_eleven_levels(oracle, fused, dpp):
+    """nv = 35: several passes over 11 tree levels (RTOC_OPT_LINEARIZE_DOFS_PER_PASS; 0: the library's choice, 19 dofs per pass;
+    a pass visits only the bodies its dofs can move or load and writes zeros for the others -- the records are filled with NaN
+    beforehand); two SURFACE contacts (the soles: 6 rows each, wrench in the local frame, Log6 position / orientation error
+    against a desired placement).  The multiplier terms must not depend on the split into passes."""
     from robotoc_amd.types import Grid, GRID_INTERMEDIATE, GRID_TERMINAL
     m = model("icub")
     assert m.contact_rows(0) == 6 and m.max_dimf == 12
@@ -371,6 +445,9 @@ def test_gpu_linearisation_icub_surface_contacts_two_passes_eleven_levels(oracle
     ctx.set_grid(grids)
     ctx.set_robot_model(m)
     ctx.set_linearize_fused(fused)
+    ctx.set_linearize_dofs_per_pass(dpp)
+    from robotoc_amd.types import OPT_LINEARIZE_DOFS_PER_PASS
+    assert ctx.get_option(OPT_LINEARIZE_DOFS_PER_PASS) == (dpp if dpp else 19)
     rng = np.random.default_rng(5)
     # one configuration per grid point (the schedule is shared by the instances); the desired placements are the actual
     # ones moved by a twist of up to ~0.3 (a contact that drifted: Log6 stays away from its singularity at pi)
@@ -390,7 +467,23 @@ def test_gpu_linearisation_icub_surface_contacts_two_passes_eleven_levels(oracle
             sol[b, i, o[0]:o[0] + m.nq], sol[b, i, o[1]:o[1] + m.nv], sol[b, i, o[2]:o[2] + m.nv] = qs[i], v, a
             sol[b, i, o[3]:o[3] + m.nu] = rng.uniform(-5, 5, m.nu)
             sol[b, i, o[4]:o[4] + 12] = rng.uniform(-20, 20, 12)
+            sol[b, i, o[7]:o[7] + m.nv] = rng.uniform(-1, 1, m.nv)     # beta, mu: the multiplier terms below
+            sol[b, i, o[8]:o[8] + 12] = rng.uniform(-1, 1, 12)
     ctx.upload(BUF_SOL, sol)
+    # the multiplier terms (accumulated into zeroed residuals) with this split into passes and with one of 21 dofs per pass
+    aug = []
+    for d in (dpp, 21):
+        ctx.set_linearize_dofs_per_pass(d)
+        ctx.upload(BUF_KKT, np.zeros(ctx.shape("kkt")))
+        ctx.upload(BUF_CDD, np.zeros(ctx.shape("cdd")))
+        ctx.linearize_contact_dynamics(True)
+        ctx.sync()
+        aug.append((ctx.download(BUF_KKT, ctx.shape("kkt")), ctx.download(BUF_CDD, ctx.shape("cdd"))))
+    for x, y in zip(*aug):
+        assert np.abs(x - y).max() <= 1e-13 * max(1.0, np.abs(y).max())
+    assert np.abs(aug[0][0]).max() > 1e-3
+    ctx.set_linearize_dofs_per_pass(dpp)
+    ctx.upload(BUF_CDD, np.full(ctx.shape("cdd"), np.nan))
     ctx.linearize_contact_dynamics()
     ctx.sync()
     cdd = ctx.download(BUF_CDD, ctx.shape("cdd"))
@@ -410,6 +503,9 @@ def test_gpu_linearisation_icub_surface_contacts_two_passes_eleven_levels(oracle
             M = rec[co[0]:co[0] + nv * nv].reshape(nv, nv).T
             J = rec[co[2]:co[2] + nfm * nv].reshape(nv, nfm).T[:g.dimf]
             assert np.abs(rec[co[3]:co[3] + n] - ref).max() < 1e-12 * max(1.0, np.abs(ref).max()), (b, i)
+            # every entry the condensation reads has been written (zeros included), whatever the passes skipped
+            assert np.isfinite(D[:n, :nv]).all() and np.isfinite(M).all() and np.isfinite(J).all(), (b, i)
+            assert np.isfinite(D[nv:n, nv:] if impact else D[:n, nv:]).all(), (b, i)
             sc = lambda x: max(1.0, np.abs(x).max())
             worst = max(worst, np.abs(D[:n, :nv] - Dq).max() / sc(Dq), np.abs(M - Da[:nv]).max() / sc(Da))
             if impact:
