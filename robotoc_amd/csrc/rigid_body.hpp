@@ -611,7 +611,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((PRE && !SUR
         }
         if (lev > 0) {
           SV dfp = act_f(R, p, df);
-          if (own && kind == 0) dfp = dfp + act_f(R, p, fcross(unit_twist(i, j - iv), f));
+          if (own && kind == 0) {   // a body with a parent is a revolute joint: S = (0, axis)
+            const V3 ax = ldv3(&JM(i, 12));
+            dfp = dfp + act_f(R, p, SV{cross(ax, f.l), cross(ax, f.a)});
+          }
           if (!PRE) st_sv(lev - 1, 39, ld_sv(lev - 1, 39) + act_f(R, p, f));   // PRE: the block already holds the total force
           st_dt(lev - 1, ld_dt(lev - 1) + dfp);
         }
@@ -729,21 +732,41 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((PRE && !SUR
         if (impact) dgp = mk(0, 0, 0);
         SV dv = dvp, da = dap;
         V3 dg = dgp;
-        if (own) {
-          const SV S = unit_twist(i, j - iv);
-          if (kind == 0) {
-            dv = dv - mcross(S, vpar);
-            da = da - mcross(S, apar);
-            dg = dg - cross(S.a, gi);
-          } else if (kind == 1) {
-            if (!(impact && dyn)) dv = dv + S;
-          } else {
-            if (!(impact && !dyn)) da = da + S;
-            if (impact && !dyn) dv = dv + S;  // d(v + dv)/d(dv)
+        const bool vdir = (kind == 1 || (impact && !dyn && kind == 2)) && !(impact && dyn);   // the lane's direction moves v
+        if (ff) {
+          if (own) {
+            const SV S = unit_twist(i, j - iv);
+            if (kind == 0) {
+              dv = dv - mcross(S, vpar);
+              da = da - mcross(S, apar);
+              dg = dg - cross(S.a, gi);
+            } else if (kind == 1) {
+              if (!(impact && dyn)) dv = dv + S;
+            } else {
+              if (!(impact && !dyn)) da = da + S;
+              if (impact && !dyn) dv = dv + S;  // d(v + dv)/d(dv)
+            }
           }
+          da = da + mcross(dv, vj);
+          if (own && vdir) da = da + mcross(v, unit_twist(i, j - iv));
+        } else {
+          // revolute joint: S = (0, axis), so S x m = (axis x m.l, axis x m.a) and m x S = (m.l x axis, m.a x axis)
+          const V3 ax = ldv3(&JM(i, 12));
+          if (own) {
+            if (kind == 0) {
+              dv = dv - SV{cross(ax, vpar.l), cross(ax, vpar.a)};
+              da = da - SV{cross(ax, apar.l), cross(ax, apar.a)};
+              dg = dg - cross(ax, gi);
+            } else if (kind == 1) {
+              if (!(impact && dyn)) dv.a = dv.a + ax;
+            } else {
+              if (!(impact && !dyn)) da.a = da.a + ax;
+              if (impact && !dyn) dv.a = dv.a + ax;  // d(v + dv)/d(dv)
+            }
+          }
+          da = da + SV{cross(dv.l, vj.a), cross(dv.a, vj.a)};   // dv x vj with vj = (0, vq axis)
+          if (own && vdir) da = da + SV{cross(v.l, ax), cross(v.a, ax)};
         }
-        da = da + mcross(dv, vj);
-        if (own && (kind == 1 || (impact && !dyn && kind == 2)) && !(impact && dyn)) da = da + mcross(v, unit_twist(i, j - iv));
         // own force and its tangent
         const double mass = JM(i, 15);
         const V3 com = ldv3(&JM(i, 16));
