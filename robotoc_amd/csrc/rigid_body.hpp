@@ -348,6 +348,8 @@ struct ValArgs {
   int sol_stride, cdd_stride;
   int o_q, o_v, o_a, o_u, o_f, o_idc;
   double gx, gy, gz;
+  const double* positions;   // [nstages][ncontacts][3] or nullptr: desired contact positions (the value rows of C below)
+  const double* rotations;   // [nstages][ncontacts][9] or nullptr (surface contacts)
 };
 constexpr int VAL_SLOTS = 64;
 
@@ -471,6 +473,49 @@ static __global__ __launch_bounds__(64) void rbd_values_kernel(ValArgs a) {
       for (int k = 0; k < 6; ++k) cr[a.o_idc + iv + k] = fv[k] - ((!impact && iv + k >= nv - nu) ? sr[a.o_u + iv + k - (nv - nu)] : 0.0);
     } else {
       cr[a.o_idc + iv] = dot(ax, f.a) - ((!impact && iv >= nv - nu) ? sr[a.o_u + iv - (nv - nu)] : 0.0);
+    }
+  }
+  // ---- C = the Baumgarte residual of the contacts this body carries (point_contact.hxx:14-31, surface_contact.hxx:12-29), on
+  //      impact grids the contact velocity at v + dv from the kinematics traversal (point_contact.hxx:84-96): the value rows
+  //      nv.. of RTOC_CDD_IDC.  Lane-invariant in the tangent walk, which used to evaluate them in every lane. ----
+  if (on && (impact ? !dyn : dyn)) {
+    double* const cr = a.cdd + rec * a.cdd_stride;
+    const SV v = ld_sv6(me + 24), acc = ld_sv6(me + 30);
+    const M3 oR = ldm3(me + 12);
+    const V3 op = ldv3(me + 21);
+    int roff = 0;
+    for (int c = 0; c < ncon; ++c) {
+      const double* const cm = &a.model->contact[c][0];
+      const bool con_on = (active >> c) & 1u;
+      const bool surf = (int)cm[15] == RTOC_CONTACT_SURFACE;
+      const int nr = surf ? 6 : 3;
+      if (con_on && (int)cm[14] == ib) {
+        const M3 Rf = ldm3(cm);
+        const V3 pf = ldv3(cm + 9);
+        const SV vf = act_inv(Rf, pf, v);
+        SV C = vf;
+        if (!impact) {
+          const SV af = act_inv(Rf, pf, acc);
+          const double kp = cm[12], kd = cm[13];
+          const V3 pw = op + mul(oR, pf);
+          const V3 pr = a.positions ? ldv3(a.positions + ((size_t)st * ncon + c) * 3) : mk(0, 0, 0);
+          if (!surf) {
+            C.l = af.l + cross(vf.a, vf.l) + kd * vf.l + kp * (pw - pr);
+          } else {
+            M3 Rdt;   // transpose of the desired rotation
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+              for (int cc = 0; cc < 3; ++cc) Rdt.m[3 * r + cc] = a.rotations ? a.rotations[((size_t)st * ncon + c) * 9 + 3 * cc + r] : (r == cc ? 1.0 : 0.0);
+            SV lg, dlg;
+            log6_fwd(mul(Rdt, mul(oR, Rf)), mul(Rdt, pw - pr), sv0(), lg, dlg);
+            C = SV{af.l + kd * vf.l + kp * lg.l, af.a + kd * vf.a + kp * lg.a};
+          }
+        }
+        const double Cv[6] = {C.l.x, C.l.y, C.l.z, C.a.x, C.a.y, C.a.z};
+        for (int t = 0; t < nr; ++t) cr[a.o_idc + nv + roff + t] = Cv[t];
+      }
+      roff += con_on ? nr : 0;
     }
   }
   // ---- the blocks out, coalesced ----
@@ -847,7 +892,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((PRE && !SUR
 #pragma unroll
               for (int t = 0; t < 6; ++t) {
                 if (t < nr) {
-                  if (lane == 0 && j0 == 0) cr[a.o_idc + r0 + t] = Cv[t];
+                  if (!PRE && lane == 0 && j0 == 0) cr[a.o_idc + r0 + t] = Cv[t];   // PRE: rbd_values_kernel wrote the values
                   if (lane_on) {
                     // impact: dC/dv = dC/d(dv) goes where the condensation reads it (the v block of DIDCDQV) and into DCDA
                     if (kind == 2 || (impact && kind == 1)) cr[a.o_dcda + (size_t)j * a.nf_max + (r0 - nv) + t] = dCv[t];

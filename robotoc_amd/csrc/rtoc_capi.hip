@@ -1779,6 +1779,7 @@ static int launch_rbd_values(rtoc_ctx* c, bool unconstr) {
   v.o_q = c->L.sol.off[RTOC_SOL_Q], v.o_v = c->L.sol.off[RTOC_SOL_V], v.o_a = c->L.sol.off[RTOC_SOL_A];
   v.o_u = c->L.sol.off[RTOC_SOL_U], v.o_f = c->L.sol.off[RTOC_SOL_F], v.o_idc = c->L.cdd.off[RTOC_CDD_IDC];
   v.gx = m.gravity[0], v.gy = m.gravity[1], v.gz = m.gravity[2];
+  v.positions = c->has_cpos ? c->d_cpos : nullptr, v.rotations = c->has_crot ? c->d_crot : nullptr;
   const int G = 64 / v.gs;
   const long long items = (long long)c->batch * (c->nstages - 1);
   const size_t vlds = sizeof(double) * G * m.njoints * rbd::VAL_SLOTS;
