@@ -701,8 +701,13 @@ int rtoc_set_option(rtoc_ctx* c, int option, int64_t value) {
       return RTOC_OK;
     case RTOC_OPT_LINEARIZE_DOFS_PER_PASS:
       if (value < 0 || value > rbd::LIN_MAX_DPP) return RTOC_ERR_BAD_ARG;
-      c->lin_dpp = (int)value;
-      return c->h_model ? apply_linearize_plan(c) : RTOC_OK;
+      {
+        const int before = c->lin_dpp;
+        c->lin_dpp = (int)value;
+        const int rc = c->h_model ? apply_linearize_plan(c) : RTOC_OK;
+        if (rc) c->lin_dpp = before;   // refused (LDS): the plan in force is the old one
+        return rc;
+      }
     case RTOC_OPT_UNCONSTR_DENSE:
       c->unconstr_dense = value ? 1 : 0;
       return RTOC_OK;
@@ -1705,7 +1710,8 @@ int rtoc_set_robot_model(rtoc_ctx* c, const rtoc_robot_model* m) {
   h->nlevels = nlev;
   rbd::pack_model(h);
   if (c->lin_dpp) rbd::plan_passes(h, c->lin_dpp);
-  if (rbd::lin_lds_bytes(nlev, h->nbranch, m->njoints, m->ncontacts, m->nv, h->dpp, false) > 160 * 1024) {
+  // (the walk's plan word has four bits for a forward-tangent slot: at most 14 branching bodies on a root-to-leaf path)
+  if (h->nbranch > 14 || rbd::lin_lds_bytes(nlev, h->nbranch, m->njoints, m->ncontacts, m->nv, h->dpp, false) > 160 * 1024) {
     delete h;
     return RTOC_ERR_BAD_ARG;
   }
