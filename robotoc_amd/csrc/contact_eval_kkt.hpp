@@ -28,6 +28,16 @@ struct CostArgs {
   double* cost_out;       // [batch][nstages] value of the stage / impact / terminal cost (evalOCP: line search), or nullptr
 };
 
+// kkt_matrix.setZero() / kkt_residual.setZero() of every grid point as one stream over the (contiguous) KKT records: one front
+// over memory, 16 B per lane, 64 workgroups per CU -- 6+ TB/s, where the same zeros written field by field from inside
+// contact_cost_kernel (whose waves then sit on their slots through the cost evaluation) reached 2.5 TB/s.
+static __global__ __launch_bounds__(256) void zero_records_kernel(double* __restrict__ p, size_t n2) {
+  typedef double dbl2 __attribute__((ext_vector_type(2)));
+  dbl2* const p2 = reinterpret_cast<dbl2*>(p);
+  const dbl2 z = {0.0, 0.0};
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n2; e += (size_t)gridDim.x * 256) p2[e] = z;
+}
+
 static __global__ __launch_bounds__(64) void contact_cost_kernel(CostArgs a) {
   using namespace selin;
   __shared__ double J[36], wd[6];
@@ -46,44 +56,32 @@ static __global__ __launch_bounds__(64) void contact_cost_kernel(CostArgs a) {
   const double scale = (impact || terminal) ? 1.0 : grid_dt(a.grid, a.dt_inst, b, a.nstages, st);
   const double* const Wq = terminal ? wqT : impact ? wqI : wq;
   const double* const Wv = terminal ? wvT : impact ? wvI : wv;
-  // ---- setZero of everything the stages below accumulate into ----
-  // 16-byte stores (the fields start on 64-byte boundaries: rtoc_record_finish pads every field to 8 doubles): this kernel is
-  // the memory-bound one of evalKKT, 28 KB of zeros per grid point
+  // ---- setZero of the RTOC_BUF_CDD fields the stages below accumulate into (the KKT record: zero_records_kernel) ----
+  // 16-byte stores (the fields start on 64-byte boundaries: rtoc_record_finish pads every field to 8 doubles)
   auto zero = [&](double* p, int n) {
     double2* const p2 = reinterpret_cast<double2*>(p);
     const int n2 = n >> 1;
     for (int e = lane; e < n2; e += 64) p2[e] = make_double2(0.0, 0.0);
     if ((n & 1) && lane == 0) p[n - 1] = 0.0;
   };
-  zero(kr + a.kl.off[RTOC_KKT_FXX], nx * nx);
-  zero(kr + a.kl.off[RTOC_KKT_QXX], nx * nx);
-  zero(kr + a.kl.off[RTOC_KKT_QXU], nx * nu);
-  zero(kr + a.kl.off[RTOC_KKT_QUU], nu * nu);
-  zero(kr + a.kl.off[RTOC_KKT_FX], nx);
-  zero(kr + a.kl.off[RTOC_KKT_LX], nx);
-  zero(kr + a.kl.off[RTOC_KKT_LU], nu);
-  zero(kr + a.kl.off[RTOC_KKT_FFX], nx);
-  zero(kr + a.kl.off[RTOC_KKT_HX], nx);
-  zero(kr + a.kl.off[RTOC_KKT_HU], nu);
-  zero(kr + a.kl.off[RTOC_KKT_SCAL], 8);
-  if (a.ns_max > 0) {
-    zero(kr + a.kl.off[RTOC_KKT_PHIX], a.ns_max * nx);
-    zero(kr + a.kl.off[RTOC_KKT_PHIU], a.ns_max * nu);
-    zero(kr + a.kl.off[RTOC_KKT_PHIT], a.ns_max);
-    zero(kr + a.kl.off[RTOC_KKT_PRES], a.ns_max);
-    zero(cr + a.cl.off[RTOC_CDD_PHIA], a.ns_max * nv);
-  }
-  zero(cr + a.cl.off[RTOC_CDD_QAA], nv);
-  zero(cr + a.cl.off[RTOC_CDD_LA], nv);
-  zero(cr + a.cl.off[RTOC_CDD_HA], nv);
-  zero(cr + a.cl.off[RTOC_CDD_LUP], 8);
-  if (a.nf_max > 0) {
-    zero(cr + a.cl.off[RTOC_CDD_QFF], a.nf_max * a.nf_max);
-    zero(cr + a.cl.off[RTOC_CDD_QQF], nv * a.nf_max);
-    zero(cr + a.cl.off[RTOC_CDD_LF], a.nf_max);
-    zero(cr + a.cl.off[RTOC_CDD_HF], a.nf_max);
-  }
-  __syncthreads();
+  // the CDD fields the stages below accumulate into, except what the cost terms write themselves (QAA, LA, HA of a grid point
+  // with accelerations): the fill needs no ordering against them and runs at the END of the kernel, behind the loads and the
+  // arithmetic.  The KKT record was zeroed as a whole by zero_records_kernel.
+  auto zero_cdd = [&]() {
+    if (a.ns_max > 0) zero(cr + a.cl.off[RTOC_CDD_PHIA], a.ns_max * nv);
+    if (terminal) {
+      zero(cr + a.cl.off[RTOC_CDD_QAA], nv);
+      zero(cr + a.cl.off[RTOC_CDD_LA], nv);
+      zero(cr + a.cl.off[RTOC_CDD_HA], nv);
+    }
+    zero(cr + a.cl.off[RTOC_CDD_LUP], 8);
+    if (a.nf_max > 0) {
+      zero(cr + a.cl.off[RTOC_CDD_QFF], a.nf_max * a.nf_max);
+      zero(cr + a.cl.off[RTOC_CDD_QQF], nv * a.nf_max);
+      zero(cr + a.cl.off[RTOC_CDD_LF], a.nf_max);
+      zero(cr + a.cl.off[RTOC_CDD_HF], a.nf_max);
+    }
+  };
   const double *q = s + a.o_q, *v = s + a.o_v, *acc = s + a.o_a, *u = s + a.o_u;
   double* const Qxx = kr + a.kl.off[RTOC_KKT_QXX];
   double* const lx = kr + a.kl.off[RTOC_KKT_LX];
@@ -110,7 +108,7 @@ static __global__ __launch_bounds__(64) void contact_cost_kernel(CostArgs a) {
       const double w = impact ? wdvI[i] : scale * wa[i];   // a on contact grids, dv on impact grids (both in the A slot)
       cr[a.cl.off[RTOC_CDD_LA] + i] = w * acc[i];
       cr[a.cl.off[RTOC_CDD_QAA] + i] = w;
-      if (sto) cr[a.cl.off[RTOC_CDD_HA] + i] = wa[i] * acc[i];
+      cr[a.cl.off[RTOC_CDD_HA] + i] = sto ? wa[i] * acc[i] : 0.0;
       hval += 0.5 * (impact ? wdvI[i] : wa[i]) * acc[i] * acc[i];
     }
   }
@@ -156,11 +154,11 @@ static __global__ __launch_bounds__(64) void contact_cost_kernel(CostArgs a) {
   if (sto || a.cost_out) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) hval += __shfl_xor(hval, off, 64);
-    __syncthreads();   // the zeroing of the scalars above is done
     if (lane == 0 && sto) kr[a.kl.off[RTOC_KKT_SCAL] + RTOC_KKT_SCAL_H] = hval;
     // the value of the cost itself (evalStageCost / evalImpactCost / evalTerminalCost): what evalOCP sums for the line search
     if (lane == 0 && a.cost_out) a.cost_out[rec] = scale * hval;
   }
+  zero_cdd();
 }
 
 }  // namespace rtoc

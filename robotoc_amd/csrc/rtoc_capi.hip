@@ -2287,6 +2287,13 @@ int rtoc_contact_eval_kkt(rtoc_ctx* c) {
   a.kl = c->L.kkt, a.cl = c->L.cdd;
   a.dt_inst = c->sto_on ? c->d_dt : nullptr;
   a.cost_out = c->d_costval;
+  {
+    // setZero of the KKT records as one stream (the record stride is a multiple of 8 doubles: 16-B stores)
+    const size_t n2 = (size_t)c->batch * c->nstages * c->L.kkt.stride / 2;
+    const size_t want = (n2 + 255) / 256;
+    const int blocks = (int)(want < (size_t)256 * 64 ? (want ? want : 1) : (size_t)256 * 64);
+    hipLaunchKernelGGL(zero_records_kernel, dim3(blocks), dim3(256), 0, c->stream, c->buf[RTOC_BUF_KKT], n2);
+  }
   hipLaunchKernelGGL(contact_cost_kernel, dim3(c->batch * c->nstages), dim3(64), 0, c->stream, a);
   HIP_TRY(hipGetLastError());
   // constraints_->linearizeConstraints (intermediate_stage.cpp:109-110, impact_stage.cpp:95-96) of the rows evaluated here
