@@ -145,7 +145,7 @@ enum rtoc_option {
                       * R_wf(q) f (what finite differences give).  They coincide when the contact frame is world-aligned. */
   RTOC_OPT_LINEARIZE_DOFS_PER_PASS = 15, /* tangent directions (dofs, three lanes each) one pass of rtoc_linearize_contact_dynamics'
                       * walk carries, 1..21; 0 (default): chosen per robot model -- fewer lanes per pass = less LDS per wave = more
-                      * waves per CU, against more passes over the bodies the pass's dofs reach (ANYmal: 18 = one pass, iCub: 12).
+                      * waves per CU, against more passes over the bodies the pass's dofs reach (ANYmal: 18 = one pass; iCub nv = 32: 21, nv = 35: 19).
                       * rtoc_get_option reads the value in force (0 before rtoc_set_robot_model). */
   RTOC_OPT_LINEARIZE_FUSED = 13, /* 0 (default): rtoc_linearize_contact_dynamics computes the values of the recursion in a
                       * level-parallel pre-pass (lanes = bodies; 64 doubles per body and grid point of scratch) and the
@@ -197,7 +197,9 @@ int rtoc_get_layout(const rtoc_ctx* ctx, rtoc_layout* out);
  * instances of the batch. Mirrors RiccatiRecursion::resizeData. */
 int rtoc_set_grid(rtoc_ctx* ctx, const rtoc_grid* grid, int nstages);
 
-/* Use a caller-owned HIP stream (hipStream_t passed as void*); NULL = the context's own stream. */
+/* Use a caller-owned HIP stream (hipStream_t passed as void*); NULL = the context's own stream.  (The context owns a second
+ * stream for work it runs beside that one -- the chunks of rtoc_riccati_sweep, the setZero of rtoc_contact_eval_kkt --, forked
+ * from and joined to this stream by events: callers only ever order against the stream given here.) */
 int rtoc_set_stream(rtoc_ctx* ctx, void* hip_stream);
 int rtoc_set_option(rtoc_ctx* ctx, int option, int64_t value);
 /* the value in force of an integer-valued option (RTOC_ERR_BAD_ARG for the double-valued ones) */

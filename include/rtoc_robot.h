@@ -55,6 +55,18 @@ typedef struct rtoc_robot_model {
  * root), joints are depth-first ordered, 3 * ncontacts <= dims.nf_max. */
 int rtoc_set_robot_model(rtoc_ctx* ctx, const rtoc_robot_model* model);
 
+/* What rtoc_set_robot_model would plan for rtoc_linearize_contact_dynamics' tangent walk, without a context or a device (host
+ * arithmetic only): tree levels, LDS slots for forward tangents (= the largest number of branching joints on a root-to-leaf
+ * path), tangent directions per pass (RTOC_OPT_LINEARIZE_DOFS_PER_PASS; forced_dofs_per_pass = 0: the library's choice),
+ * passes, LDS bytes per wave of the walk behind the values pre-pass, and pass_bodies[p] = bit i set if pass p visits joint i
+ * (room for RTOC_MAX_JOINTS + 8 passes; may be NULL).  RTOC_ERR_BAD_ARG for a table rtoc_set_robot_model would refuse on its
+ * own grounds (joints not depth first, index maps inconsistent, more LDS than a CU has). */
+typedef struct rtoc_linearize_plan {
+  int nlevels, nbranch, dofs_per_pass, npass, lds_bytes;
+} rtoc_linearize_plan;
+int rtoc_robot_model_plan(const rtoc_robot_model* model, int forced_dofs_per_pass, rtoc_linearize_plan* plan,
+                          unsigned long long* pass_bodies);
+
 /* Per grid point: bit k of active[i] = contact k is active (ContactStatus::isContactActive; on impact grids:
  * ImpactStatus::isImpactActive), positions[i][k][0..2] = ContactStatus::contactPosition(k) (world frame; NULL: zeros),
  * rotations[i][k][0..8] = ContactStatus::contactRotation(k) (row-major; only read for surface contacts; NULL: identity).

@@ -26,7 +26,7 @@ EXPORTS = [
     "rtoc_riccati_sweep", "rtoc_correct_state_equation", "rtoc_correct_costate_direction",
     "rtoc_compute_initial_state_direction", "rtoc_unconstr_condense", "rtoc_unconstr_expand",
     "rtoc_newton_iteration", "rtoc_converged_count", "rtoc_clone", "rtoc_check_fxx_structure", "rtoc_sto_eval_kkt", "rtoc_set_friction_cones", "rtoc_set_wrench_cones", "rtoc_wrench_cone_matrix", "rtoc_save_stage_dump", "rtoc_load_stage_dump", "rtoc_kkt_error", "rtoc_integrate_solution",
-    "rtoc_set_robot_model", "rtoc_set_contact_schedule", "rtoc_linearize_contact_dynamics",
+    "rtoc_set_robot_model", "rtoc_robot_model_plan", "rtoc_set_contact_schedule", "rtoc_linearize_contact_dynamics",
     "rtoc_line_search_filter", "rtoc_line_search_clear", "rtoc_set_configuration_cost", "rtoc_set_initial_state",
     "rtoc_unconstr_eval_kkt", "rtoc_unconstr_update_solution", "rtoc_set_constraint_bounds", "rtoc_unconstr_init_constraints", "rtoc_linearize_state_equation", "rtoc_contact_eval_kkt", "rtoc_contact_update_solution",
     "rtoc_set_barrier_param", "rtoc_set_friction_coefficients", "rtoc_contact_init_constraints", "rtoc_set_wrench_cone_params",
@@ -656,6 +656,20 @@ def debug_profile(ctx):
     out = np.zeros((ctx.max_stages, 32), dtype=np.int64)
     _chk(L.rtoc_debug_profile(ctx._h, out.ctypes.data_as(C.c_void_p)))
     return out
+
+
+class LinearizePlan(C.Structure):
+    _fields_ = [("nlevels", C.c_int), ("nbranch", C.c_int), ("dofs_per_pass", C.c_int), ("npass", C.c_int), ("lds_bytes", C.c_int)]
+
+
+def robot_model_plan(model, forced_dofs_per_pass=0):
+    """rtoc_robot_model_plan: the storage plan and the passes rtoc_set_robot_model would give the tangent walk of `model`
+    (host arithmetic: no device needed).  Returns (LinearizePlan, [bodies pass p visits])."""
+    plan = LinearizePlan()
+    masks = (C.c_ulonglong * 64)()
+    lib().rtoc_robot_model_plan.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    _chk(lib().rtoc_robot_model_plan(C.byref(model), int(forced_dofs_per_pass), C.byref(plan), masks))
+    return plan, [[i for i in range(model.njoints) if (masks[p] >> i) & 1] for p in range(plan.npass)]
 
 
 def bandwidth_probe(device=0, nbytes=1 << 31):

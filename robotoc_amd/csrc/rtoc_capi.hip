@@ -1669,8 +1669,11 @@ int rtoc_integrate_solution(rtoc_ctx* c) {
 }
 
 // ---- rigid-body linearisation (include/rtoc_robot.h) ------------------------------------------
-int rtoc_set_robot_model(rtoc_ctx* c, const rtoc_robot_model* m) {
-  if (!c || !m) return RTOC_ERR_BAD_ARG;
+// The checks of a robot-model table that do not depend on a context, and everything the kernels precompute from it (tree levels,
+// packed constants, the tangent walk's storage plan and passes).  *out: a new DevModel (caller deletes) or nullptr.
+static int build_dev_model(const rtoc_robot_model* m, int forced_dpp, rbd::DevModel** out, int* max_dimf_out) {
+  *out = nullptr;
+  if (!m) return RTOC_ERR_BAD_ARG;
   if (m->njoints < 1 || m->njoints > RTOC_MAX_JOINTS || m->ncontacts < 0 || m->ncontacts > RTOC_MAX_CONTACTS) return RTOC_ERR_BAD_ARG;
   int max_dimf = 0;
   for (int k = 0; k < m->ncontacts; ++k) {
@@ -1678,9 +1681,9 @@ int rtoc_set_robot_model(rtoc_ctx* c, const rtoc_robot_model* m) {
     if (k > 0 && m->contact_type[k] < m->contact_type[k - 1]) return RTOC_ERR_BAD_ARG;  // points first
     max_dimf += m->contact_type[k] == RTOC_CONTACT_SURFACE ? 6 : 3;
   }
-  if (m->nv != c->dims.nv || max_dimf > c->dims.nf_max) return RTOC_ERR_BAD_ARG;
+  if (max_dimf_out) *max_dimf_out = max_dimf;
   const bool ff = m->type[0] == RTOC_JOINT_FREE_FLYER;
-  if (m->nq != m->nv + (ff ? 1 : 0) || (ff ? m->nv - 6 : m->nv) != c->dims.nu) return RTOC_ERR_BAD_ARG;
+  if (m->nv < 1 || m->nv > RTOC_MAX_JOINTS + 8 || m->nq != m->nv + (ff ? 1 : 0)) return RTOC_ERR_BAD_ARG;
   rbd::DevModel* h = new (std::nothrow) rbd::DevModel;
   if (!h) return RTOC_ERR_HIP;
   h->m = *m;
@@ -1709,9 +1712,37 @@ int rtoc_set_robot_model(rtoc_ctx* c, const rtoc_robot_model* m) {
   }
   h->nlevels = nlev;
   rbd::pack_model(h);
-  if (c->lin_dpp) rbd::plan_passes(h, c->lin_dpp);
+  if (forced_dpp) rbd::plan_passes(h, forced_dpp);
   // (the walk's plan word has four bits for a forward-tangent slot: at most 14 branching bodies on a root-to-leaf path)
   if (h->nbranch > 14 || rbd::lin_lds_bytes(nlev, h->nbranch, m->njoints, m->ncontacts, m->nv, h->dpp, false) > 160 * 1024) {
+    delete h;
+    return RTOC_ERR_BAD_ARG;
+  }
+  *out = h;
+  return RTOC_OK;
+}
+
+int rtoc_robot_model_plan(const rtoc_robot_model* m, int forced_dofs_per_pass, rtoc_linearize_plan* plan, unsigned long long* pass_bodies) {
+  if (!plan || forced_dofs_per_pass < 0 || forced_dofs_per_pass > rbd::LIN_MAX_DPP) return RTOC_ERR_BAD_ARG;
+  rbd::DevModel* h = nullptr;
+  const int rc = build_dev_model(m, forced_dofs_per_pass, &h, nullptr);
+  if (rc) return rc;
+  plan->nlevels = h->nlevels, plan->nbranch = h->nbranch, plan->dofs_per_pass = h->dpp, plan->npass = h->npass;
+  plan->lds_bytes = (int)rbd::lin_lds_bytes(h->nlevels, h->nbranch, m->njoints, m->ncontacts, m->nv, h->dpp, true);
+  if (pass_bodies)
+    for (int p = 0; p < RTOC_MAX_JOINTS + 8; ++p) pass_bodies[p] = p < h->npass ? h->pass_bodies[p] : 0ull;
+  delete h;
+  return RTOC_OK;
+}
+
+int rtoc_set_robot_model(rtoc_ctx* c, const rtoc_robot_model* m) {
+  if (!c || !m) return RTOC_ERR_BAD_ARG;
+  rbd::DevModel* h = nullptr;
+  int max_dimf = 0;
+  const int brc = build_dev_model(m, c->lin_dpp, &h, &max_dimf);
+  if (brc) return brc;
+  const bool ff = m->type[0] == RTOC_JOINT_FREE_FLYER;
+  if (m->nv != c->dims.nv || max_dimf > c->dims.nf_max || (ff ? m->nv - 6 : m->nv) != c->dims.nu) {
     delete h;
     return RTOC_ERR_BAD_ARG;
   }
@@ -1721,7 +1752,7 @@ int rtoc_set_robot_model(rtoc_ctx* c, const rtoc_robot_model* m) {
   c->h_model = h;
   HIP_TRY(hipMemcpyAsync(c->d_model, h, sizeof(rbd::DevModel), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
-  HIP_TRY(set_linearize_lds(*m, nlev, h->nbranch, h->dpp));
+  HIP_TRY(set_linearize_lds(*m, h->nlevels, h->nbranch, h->dpp));
   c->epoch++;
   return RTOC_OK;
 }

@@ -212,6 +212,56 @@ def test_model_table_is_validated():
     assert hasattr(lib, "rtoc_set_robot_model") and hasattr(lib, "rtoc_linearize_contact_dynamics")
 
 
+def test_tangent_walk_plans_of_the_bundled_robots():
+    """rtoc_robot_model_plan (host arithmetic, no device): what rtoc_set_robot_model plans for the tangent walk of
+    rtoc_linearize_contact_dynamics -- LDS slots for forward tangents = branching joints on a path (ANYmal: the base; iCub: base
+    and chest; a chain: none), dofs per pass chosen per model, the bodies a pass visits = ancestors and subtrees of its dofs, and
+    the LDS bytes per wave that decide how many grid points a CU holds (ANYmal: 20,000 B = eight waves per CU)."""
+    plan, bodies = capi.robot_model_plan(model("anymal"))
+    assert (plan.nlevels, plan.nbranch, plan.dofs_per_pass, plan.npass, plan.lds_bytes) == (4, 1, 18, 1, 20000)
+    assert bodies == [list(range(13))]
+    assert 8 * ((plan.lds_bytes + 1279) // 1280 * 1280) <= 160 * 1024
+    # two passes of 9 dofs: the second (RF, LH, RH legs... dofs 9..17) does not visit the leg whose dofs all sit in the first
+    plan, bodies = capi.robot_model_plan(model("anymal"), 9)
+    assert plan.npass == 2 and bodies[0] == list(range(13)) and bodies[1] == [0] + list(range(4, 13))
+    m = model("icub")
+    plan, bodies = capi.robot_model_plan(m)
+    assert (plan.nlevels, plan.nbranch, plan.dofs_per_pass, plan.npass) == (11, 2, 19, 2)
+    assert bodies[0] == list(range(m.njoints))
+    # dofs 19..34: the second half of the right leg, the torso and the arms -- no body of the left leg, none of the right leg above
+    par = list(m.parent[:m.njoints])
+    dof_body = {m.idx_v[i] + k: i for i in range(m.njoints) for k in range(6 if i == 0 and m.floating_base else 1)}
+    want = set()
+    for j in range(19, m.nv):
+        b = dof_body[j]
+        k = b
+        while k >= 0:              # ancestors
+            want.add(k)
+            k = par[k]
+        want |= {i for i in range(m.njoints) if b in _ancestors(par, i)}   # subtree
+    assert bodies[1] == sorted(want) and len(bodies[1]) < m.njoints
+    plan, _ = capi.robot_model_plan(model("icub32"))
+    assert (plan.nlevels, plan.nbranch, plan.dofs_per_pass, plan.npass) == (8, 1, 21, 2)
+    plan, bodies = capi.robot_model_plan(model("iiwa14"))
+    assert (plan.nlevels, plan.nbranch, plan.dofs_per_pass, plan.npass) == (7, 0, 7, 1) and bodies == [list(range(7))]
+    # a table whose joints do not come depth first is refused here as by rtoc_set_robot_model
+    a = model("anymal")
+    bad = type(a).from_buffer_copy(a)
+    bad.parent[5] = 3
+    with pytest.raises(capi.RtocError):
+        capi.robot_model_plan(bad)
+    with pytest.raises(capi.RtocError):
+        capi.robot_model_plan(a, 22)
+
+
+def _ancestors(par, i):
+    out = []
+    while i >= 0:
+        out.append(i)
+        i = par[i]
+    return out
+
+
 @pytest.mark.gpu
 def test_model_joints_must_come_depth_first():
     """rtoc_set_robot_model: the walk keeps one value block per OPEN tree level, so when a joint is visited its parent has to be
