@@ -885,6 +885,14 @@ def main():
                                 "scope": "linearizeContactDynamics / linearizeImpactDynamics incl. the multiplier terms; NOT part of "
                                          "newton_iteration_ms, which starts from pre-condensation records; part of closed_loop_constrained_trot",
                                 "status_nonzero_instances": int((ctx.status() != 0).sum())}
+            # the storage plan of the tangent walk (rtoc_robot_model_plan: LDS per wave -> waves per CU, passes and the bodies each visits)
+            plans = {}
+            for rname in ("anymal", "icub32", "icub"):
+                pl, bodies = capi.robot_model_plan(rm.load_named(rname))
+                plans[rname] = {"tree_levels": pl.nlevels, "forward_tangent_slots": pl.nbranch, "dofs_per_pass": pl.dofs_per_pass,
+                                "passes": pl.npass, "bodies_visited_per_pass": [len(b) for b in bodies], "lds_bytes_per_wave": pl.lds_bytes,
+                                "waves_per_cu_by_lds": (160 * 1024) // ((pl.lds_bytes + 1279) // 1280 * 1280)}
+            sqp["linearize"]["walk_plan"] = plans
             del sol_t
         del kkt0, cdd0, con0, kkt_w, cdd_w, con_w, cone_t
 
