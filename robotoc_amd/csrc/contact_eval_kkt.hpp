@@ -28,22 +28,77 @@ struct CostArgs {
   double* cost_out;       // [batch][nstages] value of the stage / impact / terminal cost (evalOCP: line search), or nullptr
 };
 
-// kkt_matrix.setZero() / kkt_residual.setZero() of every grid point as one stream over the (contiguous) KKT records: one front
-// over memory, 16 B per lane, 64 workgroups per CU -- 6+ TB/s, where the same zeros written field by field from inside
-// contact_cost_kernel (whose waves then sit on their slots through the cost evaluation) reached 2.5 TB/s.
-static __global__ __launch_bounds__(256) void zero_records_kernel(double* __restrict__ p, size_t n2) {
+// kkt_matrix.setZero() / kkt_residual.setZero() of every grid point as one stream over the (contiguous) KKT records -- 16 B per
+// lane, a workgroup per record and trip: 6 TB/s, where the same zeros written field by field from inside contact_cost_kernel
+// (whose waves then sat on their slots through the cost evaluation) reached 2.5 TB/s -- AND the constant part of
+// quadratizeStageCost / ImpactCost / TerminalCost of a ConfigurationSpaceCost, the diagonals dt W of Qqq (joints), Qvv and Quu:
+// written from the cost kernel they were 8-byte stores 37 doubles apart, a partial line each (0.4 of its 0.9 ms) -- and, for the
+// same reason, the constant part of linearizeStateEquation: Fqq = I, Fqv = dt I (state_equation.cpp:29-40; the base corner of a
+// floating base is overwritten by state_equation_lin_kernel).
+struct InitArgs {
+  double* kkt;
+  const double* cost;      // the table of contact_cost_kernel
+  const rtoc_grid* grid;
+  const double* dt_inst;
+  int nstages, batch, nv, nu, floating, kkt_stride, o_qxx, o_quu, o_fxx;
+};
+static __global__ __launch_bounds__(256) void init_records_kernel(InitArgs a) {
   typedef double dbl2 __attribute__((ext_vector_type(2)));
-  dbl2* const p2 = reinterpret_cast<dbl2*>(p);
-  const dbl2 z = {0.0, 0.0};
-  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n2; e += (size_t)gridDim.x * 256) p2[e] = z;
+  const int nv = a.nv, nu = a.nu, nx = 2 * nv, M = nv + 1, nb = a.floating ? 6 : 0;
+  const double *wq = a.cost + 3 * M, *wv = wq + M, *wu = wv + 2 * M, *wqT = wu + M, *wvT = wqT + M, *wqI = wvT + M, *wvI = wqI + M;
+  const int half = a.kkt_stride / 2, qxx0 = a.o_qxx, qxx1 = a.o_qxx + nx * nx, quu0 = a.o_quu, quu1 = a.o_quu + nu * nu;
+  const int fxx0 = a.o_fxx, fxx1 = a.o_fxx + nx * nx;
+  const long long nrec = (long long)a.batch * a.nstages;
+  for (long long rec = blockIdx.x; rec < nrec; rec += gridDim.x) {
+    const int b = (int)(rec / a.nstages), st = (int)(rec % a.nstages);
+    const bool impact = a.grid[st].type == RTOC_GRID_IMPACT, terminal = st == a.nstages - 1;
+    const double scale = (impact || terminal) ? 1.0 : grid_dt(a.grid, a.dt_inst, b, a.nstages, st);
+    const double* const Wq = terminal ? wqT : impact ? wqI : wq;
+    const double* const Wv = terminal ? wvT : impact ? wvI : wv;
+    const bool sto = !terminal && !impact;
+    const double dt = impact ? 0.0 : scale;   // terminal records: no state equation
+    dbl2* const p2 = reinterpret_cast<dbl2*>(a.kkt + rec * a.kkt_stride);
+    for (int t = threadIdx.x; t < half; t += 256) {
+      dbl2 v = {0.0, 0.0};
+      const int w = 2 * t;   // the pair (w, w + 1) of the record; fields start on multiples of 8 doubles
+      if (w >= qxx0 && w < qxx1) {
+        const int d = w - qxx0, c = d / nx, r = d - c * nx;   // column-major: rows r, r + 1 of column c (nx is even)
+        if (r == c || r + 1 == c) {
+          const double dv = c < nv ? (c >= nb ? scale * Wq[c] : 0.0) : scale * Wv[c - nv];   // the base block: contact_cost_kernel
+          if (r == c) v.x = dv;
+          else v.y = dv;
+        }
+      } else if (!terminal && w >= fxx0 && w < fxx1) {
+        const int d = w - fxx0, c = d / nx, r = d - c * nx;   // rows r, r + 1 of column c; the top half of Fxx only
+        if (r < nv) v.x = c == r ? 1.0 : (c == nv + r ? dt : 0.0);
+        if (r + 1 < nv) v.y = c == r + 1 ? 1.0 : (c == nv + r + 1 ? dt : 0.0);
+      } else if (sto && w >= quu0 && w < quu1) {
+        const int d = w - quu0, c = d / nu, r = d - c * nu;
+        // nu may be odd: the pair can straddle two columns
+        if (r == c) v.x = scale * wu[c];
+        const int r1 = r + 1 < nu ? r + 1 : 0, c1 = r + 1 < nu ? c : c + 1;
+        if (r1 == c1 && c1 < nu && w + 1 < quu1) v.y = scale * wu[c1];
+      }
+      p2[t] = v;
+    }
+  }
 }
 
+// COST_GP grid points per wave, COST_LW lanes each: the arithmetic of a grid point lives in a handful of lanes (the Log6 of the base
+// placement and its derivative in six), and one wave per grid point spent ~1.5k instructions on mostly idle lanes -- four grid
+// points share the instruction stream now (the per-joint loops take two trips at nv = 18).  A wave whose last grid points lie
+// beyond the batch repeats the last one (identical values to identical addresses).
+constexpr int COST_GP = 4, COST_LW = 64 / COST_GP;
 static __global__ __launch_bounds__(64) void contact_cost_kernel(CostArgs a) {
   using namespace selin;
-  __shared__ double J[36], wd[6];
-  const int lane = threadIdx.x;
-  const int b = blockIdx.x / a.nstages, st = blockIdx.x % a.nstages;
-  if (b >= a.batch) return;
+  __shared__ double Js[COST_GP][36], wds[COST_GP][8];
+  const int lane = threadIdx.x % COST_LW, grp = threadIdx.x / COST_LW;   // `lane`: within the grid point's COST_LW lanes
+  double* const J = Js[grp];
+  double* const wd = wds[grp];
+  const long long nitems = (long long)a.batch * a.nstages;
+  long long item = (long long)blockIdx.x * COST_GP + grp;
+  item = item < nitems ? item : nitems - 1;
+  const int b = (int)(item / a.nstages), st = (int)(item % a.nstages);
   const rtoc_grid g = a.grid[st];
   const bool impact = g.type == RTOC_GRID_IMPACT, terminal = st == a.nstages - 1;
   const int nv = a.nv, nu = a.nu, nx = 2 * nv, nb = a.floating ? 6 : 0, M = nv + 1, np = nv - nu;
@@ -56,17 +111,18 @@ static __global__ __launch_bounds__(64) void contact_cost_kernel(CostArgs a) {
   const double scale = (impact || terminal) ? 1.0 : grid_dt(a.grid, a.dt_inst, b, a.nstages, st);
   const double* const Wq = terminal ? wqT : impact ? wqI : wq;
   const double* const Wv = terminal ? wvT : impact ? wvI : wv;
-  // ---- setZero of the RTOC_BUF_CDD fields the stages below accumulate into (the KKT record: zero_records_kernel) ----
+  // ---- setZero of the RTOC_BUF_CDD fields the stages below accumulate into (the KKT record: init_records_kernel) ----
   // 16-byte stores (the fields start on 64-byte boundaries: rtoc_record_finish pads every field to 8 doubles)
   auto zero = [&](double* p, int n) {
     double2* const p2 = reinterpret_cast<double2*>(p);
     const int n2 = n >> 1;
-    for (int e = lane; e < n2; e += 64) p2[e] = make_double2(0.0, 0.0);
+    for (int e = lane; e < n2; e += COST_LW) p2[e] = make_double2(0.0, 0.0);
     if ((n & 1) && lane == 0) p[n - 1] = 0.0;
   };
   // the CDD fields the stages below accumulate into, except what the cost terms write themselves (QAA, LA, HA of a grid point
   // with accelerations): the fill needs no ordering against them and runs at the END of the kernel, behind the loads and the
-  // arithmetic.  The KKT record was zeroed as a whole by zero_records_kernel.
+  // arithmetic.  The KKT record was zeroed as a whole by init_records_kernel, which also wrote the diagonals dt W of Qqq (joints),
+  // Qvv and Quu.
   auto zero_cdd = [&]() {
     if (a.ns_max > 0) zero(cr + a.cl.off[RTOC_CDD_PHIA], a.ns_max * nv);
     if (terminal) {
@@ -91,17 +147,15 @@ static __global__ __launch_bounds__(64) void contact_cost_kernel(CostArgs a) {
   const bool sto = !terminal && !impact;
   double* const hx = kr + a.kl.off[RTOC_KKT_HX];
   double hval = 0.0;   // this lane's share of cost / dt (cost itself on impact / terminal grids) = 1/2 sum of weight * difference^2
-  for (int i = lane; i < nv; i += 64) {
+  for (int i = lane; i < nv; i += COST_LW) {
     if (i >= nb) {
       const double dq = q[(nb ? 1 : 0) + i] - qr[(nb ? 1 : 0) + i];
       lx[i] = scale * Wq[i] * dq;
-      Qxx[i + (size_t)i * nx] = scale * Wq[i];
       if (sto) hx[i] = Wq[i] * dq;
       hval += 0.5 * Wq[i] * dq * dq;
     }
     const double dv = v[i] - vr[i];
     lx[nv + i] = scale * Wv[i] * dv;
-    Qxx[(nv + i) + (size_t)(nv + i) * nx] = scale * Wv[i];
     if (sto) hx[nv + i] = Wv[i] * dv;
     hval += 0.5 * Wv[i] * dv * dv;
     if (!terminal) {
@@ -113,10 +167,9 @@ static __global__ __launch_bounds__(64) void contact_cost_kernel(CostArgs a) {
     }
   }
   if (sto)
-    for (int i = lane; i < nu; i += 64) {
+    for (int i = lane; i < nu; i += COST_LW) {
       const double du = u[i] - ur[i];
       kr[a.kl.off[RTOC_KKT_LU] + i] = scale * wu[i] * du;
-      kr[a.kl.off[RTOC_KKT_QUU] + i + (size_t)i * nu] = scale * wu[i];
       kr[a.kl.off[RTOC_KKT_HU] + i] = wu[i] * du;
       hval += 0.5 * wu[i] * du * du;
     }
@@ -135,8 +188,8 @@ static __global__ __launch_bounds__(64) void contact_cost_kernel(CostArgs a) {
       wd[lane] = Wq[lane] * d[lane];
     }
     __syncthreads();
-    if (lane < 36) {
-      const int r = lane % 6, c = lane / 6;
+    for (int e = lane; e < 36; e += COST_LW) {
+      const int r = e % 6, c = e / 6;
       double t = 0.0;
 #pragma unroll
       for (int k = 0; k < 6; ++k) t += J[k + 6 * r] * Wq[k] * J[k + 6 * c];
@@ -153,7 +206,7 @@ static __global__ __launch_bounds__(64) void contact_cost_kernel(CostArgs a) {
   }
   if (sto || a.cost_out) {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) hval += __shfl_xor(hval, off, 64);
+    for (int off = COST_LW / 2; off > 0; off >>= 1) hval += __shfl_xor(hval, off, 64);   // within the grid point's lanes
     if (lane == 0 && sto) kr[a.kl.off[RTOC_KKT_SCAL] + RTOC_KKT_SCAL_H] = hval;
     // the value of the cost itself (evalStageCost / evalImpactCost / evalTerminalCost): what evalOCP sums for the line search
     if (lane == 0 && a.cost_out) a.cost_out[rec] = scale * hval;

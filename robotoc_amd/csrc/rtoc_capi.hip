@@ -2319,24 +2319,27 @@ int rtoc_contact_eval_kkt(rtoc_ctx* c) {
   a.dt_inst = c->sto_on ? c->d_dt : nullptr;
   a.cost_out = c->d_costval;
   {
-    // setZero of the KKT records as one stream (the record stride is a multiple of 8 doubles: 16-B stores) on the context's second stream (rtoc_riccati_sweep's), BESIDE
+    // setZero of the KKT records (+ the constant diagonals of the cost) as one stream on the context's second stream (rtoc_riccati_sweep's), BESIDE
     // the values pre-pass of the rigid-body linearisation (lanes = bodies; writes its scratch and RTOC_CDD_IDC, which nothing
     // here zeroes): the one is bound by HBM writes, the other by latency -- 1.1 ms each per 4096 x 47 grid points, one after the
     // other on one stream.  The cost kernel and everything behind it wait for both.
-    const size_t n2 = (size_t)c->batch * c->nstages * c->L.kkt.stride / 2;
-    const size_t want = (n2 + 255) / 256;
+    InitArgs ia;
+    ia.kkt = c->buf[RTOC_BUF_KKT], ia.cost = c->d_cost, ia.grid = c->d_grid, ia.dt_inst = a.dt_inst;
+    ia.nstages = c->nstages, ia.batch = c->batch, ia.nv = c->dims.nv, ia.nu = c->dims.nu, ia.floating = a.floating;
+    ia.kkt_stride = c->L.kkt.stride, ia.o_qxx = c->L.kkt.off[RTOC_KKT_QXX], ia.o_quu = c->L.kkt.off[RTOC_KKT_QUU], ia.o_fxx = c->L.kkt.off[RTOC_KKT_FXX];
+    const long long nrec = (long long)c->batch * c->nstages;
     // four workgroups per CU: half of the wave slots, so that the pre-pass's waves are resident beside them
-    const int blocks = (int)(want < (size_t)256 * 4 ? (want ? want : 1) : (size_t)256 * 4);
+    const int blocks = (int)(nrec < 256 * 4 ? nrec : 256 * 4);
     HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
     HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-    hipLaunchKernelGGL(zero_records_kernel, dim3(blocks), dim3(256), 0, c->stream2, c->buf[RTOC_BUF_KKT], n2);
+    hipLaunchKernelGGL(init_records_kernel, dim3(blocks), dim3(256), 0, c->stream2, ia);
     HIP_TRY(hipEventRecord(c->ev_join, c->stream2));
     c->vals_fresh = 0;
     if (!c->linearize_fused) rc = launch_rbd_values(c, false);   // shared by the cone rows and the tangent walk below
     HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
     if (rc) return rc;
   }
-  hipLaunchKernelGGL(contact_cost_kernel, dim3(c->batch * c->nstages), dim3(64), 0, c->stream, a);
+  hipLaunchKernelGGL(contact_cost_kernel, dim3((c->batch * c->nstages + COST_GP - 1) / COST_GP), dim3(64), 0, c->stream, a);
   HIP_TRY(hipGetLastError());
   // constraints_->linearizeConstraints (intermediate_stage.cpp:109-110, impact_stage.cpp:95-96) of the rows evaluated here
   if (c->nrows > 0 && c->d_bounds && c->buf[RTOC_BUF_CON]) rc = launch_ubox(c, UBOX_LINEARIZE, true);

@@ -27,7 +27,7 @@ struct SeLinArgs {
   double* dx0;           // may be nullptr: computeInitialStateDirection (state_equation.cpp:99-109) into RTOC_BUF_DX0
   const rtoc_grid* grid;
   int nstages, batch, nv, floating;
-  int zeroed;            // the KKT record was zeroed just before: only the non-zero entries of the Fxx top half are written
+  int zeroed;            // the KKT record was initialised just before (init_records_kernel: zeros, Fqq = I, Fqv = dt I): only the base corner is written
   int sol_stride, kkt_stride, cdd_stride;
   int o_q, o_v, o_a, o_lmd, o_gmm;
   int o_fxx, o_fx, o_lx, o_hx, o_ffx, o_scal;
@@ -185,8 +185,9 @@ static __global__ __launch_bounds__(64) void state_equation_lin_kernel(SeLinArgs
   const double *q = s + a.o_q, *v = s + a.o_v, *acc = s + a.o_a, *lmd = s + a.o_lmd, *gmm = s + a.o_gmm;
   const double *qn = sn + a.o_q, *vn = sn + a.o_v, *lmdn = sn + a.o_lmd, *gmmn = sn + a.o_gmm;
   // ---- Fxx top half: Fqq = I (joints), Fqv = dt I; the bottom half belongs to the dynamics condensation ----
-  if (a.zeroed) {   // rtoc_contact_eval_kkt: the cost kernel has just zeroed the record (kkt_matrix.setZero)
-    for (int r = lane; r < nv; r += 64) kr[a.o_fxx + r + (size_t)r * nx] = 1.0, kr[a.o_fxx + r + (size_t)(nv + r) * nx] = dt;
+  if (a.zeroed) {
+    // rtoc_contact_eval_kkt: init_records_kernel has just written the record, zeros and the diagonals Fqq = I, Fqv = dt I with
+    // them (scattered 8-byte stores from here were a partial line each)
   } else {
     int r = lane % nx, c = lane / nx;
     for (int e = lane; e < nx * nx; e += 64) {
