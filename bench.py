@@ -310,6 +310,7 @@ def cpu_baseline(L, grids, dims, budget_s=8.0):
                single_thread_sweep_ms=1e3 * one["seconds"] / one["sweeps"],
                single_thread_sweep_ms_excluding_refill=1e3 * (one["seconds"] - one["refill_seconds"]) / one["sweeps"],
                host_hardware_threads=hw_threads, cpu_quota=quota,
+               sample_short="%d distinct ANYmal trot N40 instances x %d repeats on %d threads; 1 thread: %d sweeps" % (B, reps, allt["threads"], one["sweeps"]),
                sample="%d distinct ANYmal trot instances x %d repeats, OpenMP over instances (%d threads), every "
                       "thread refills a private copy of the in-place-mutated KKT records per sweep (that memcpy is "
                       "%.1f%% of the time; `value_excluding_refill` leaves it out); one thread: %d sweeps"
@@ -331,6 +332,118 @@ def cpu_baseline(L, grids, dims, budget_s=8.0):
                                 sample="%d distinct instances x %d repeats (all threads), %d iterations (one thread); "
                                        "72 joint-limit + 20 friction-cone rows" % (Bs, reps, s1["iterations"]))
     return out
+
+
+COMPACT_LIMIT = 4096   # bytes; the driver keeps an 8 KB tail of stdout and parses its last line
+
+
+def _r(x, sig=6):
+    """Round a float to `sig` significant digits (the compact line has no use for 17)."""
+    if isinstance(x, float):
+        return float("%.*g" % (sig, x))
+    return x
+
+
+def compact_line(res):
+    """The ONE line the driver parses (<= COMPACT_LIMIT bytes, strict JSON): the contract keys, `roofline` and `cpu_baseline`
+    of the headline workload, and one figure per other BASELINE configuration -- the convention of the reference's own
+    benchmark printer, include/robotoc/utils/ocp_benchmarker.hxx:14-32 (one short figure per run).  Everything else
+    (per-phase times, every other roofline block, the scopes and notes) is in the detail file."""
+    def pick(d, keys):
+        return {k: _r(d[k]) for k in keys if d is not None and k in d}
+    out = pick(res, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                     "vs_baseline", "dtype", "data"))
+    cfg = res.get("config", {})
+    out["config"] = pick(cfg, ("workload", "per_gpu_batch", "distinct_instances_per_gpu", "stages", "parallelism"))
+    rf = res.get("roofline")
+    if rf is not None:
+        o = pick(rf, ("bound", "kernel", "kernel_ms", "achieved", "peak", "unit", "frac", "algorithmic_bytes_per_launch", "traffic",
+                      "forward_kernel_ms", "forward_frac", "mfma_f64_frac", "measured_stream_read_GBs"))
+        # the counter traffic comes from the committed rocprofv3 --pmc passes of these kernel sources (hash-guarded), never
+        # from inside the timed process
+        o["traffic_measured_in_this_run"] = False
+        rp = rf.get("kernel_ms_rocprof_all_launches")
+        if rp:
+            o["kernel_ms_rocprof_avg"] = _r(rp.get("avg_ms"))
+        out["roofline"] = o
+    cb = res.get("cpu_baseline")
+    if cb is not None:
+        o = pick(cb, ("value", "unit", "cores", "kind", "single_thread_sweeps_per_sec"))
+        o["sample"] = cb.get("sample_short", "")
+        if "sqp_iteration" in cb:
+            o["sqp_iters_per_sec"] = _r(cb["sqp_iteration"].get("iters_per_sec"))
+        out["cpu_baseline"] = o
+    sq = res.get("sqp_iteration")
+    if sq is not None:
+        out["sqp_iters_per_sec"] = _r(sq.get("iters_per_sec_per_gpu", 0.0) * res.get("n_gpus", 1))
+        out["sqp_newton_iteration_ms"] = _r(sq.get("newton_iteration_ms"))
+        out["sqp_phase_ms"] = {k: _r(v, 4) for k, v in sq.get("phase_ms", {}).items()}
+        for key in ("roofline_condense", "roofline_expand"):
+            if key in sq:
+                out[key] = pick(sq[key], ("kernel_ms", "frac", "algorithmic_bytes_per_launch", "traffic"))
+        cl = sq.get("closed_loop_constrained_trot", {}).get("batch")
+        if cl:
+            out["closed_loop_update_solution_ms"] = _r(cl.get("update_solution_ms"))
+    oc = res.get("other_configs")
+    if oc:
+        o = {}
+        for name, e in oc.items():
+            c = pick(e, ("batch", "backward_ms", "forward_ms", "sweeps_per_sec", "single_instance_sweep_ms",
+                         "single_instance_sweep_scan_ms", "sqp_iters_per_sec"))
+            r2 = e.get("roofline")
+            if r2:
+                c["bound"] = r2.get("bound")
+                c["hbm_frac"] = _r(r2["hbm"]["frac"], 4)
+                c["mfma_f64_frac"] = _r(r2["mfma_f64"]["frac"], 4)
+            if "roofline_condense" in e:
+                c["condense_frac"] = _r(e["roofline_condense"].get("frac"), 4)
+            sv = e.get("solve")
+            if sv:
+                c["solve"] = pick(sv, ("iterations", "converged", "final_kkt", "ms_per_iteration"))
+            o[name] = c
+        out["other_configs"] = o
+    out["status_nonzero_instances"] = res.get("status_nonzero_instances", 0) + (sq or {}).get("status_nonzero_instances", 0)
+    for k in ("rccl_gather_ok", "rccl_gather_c_abi_ok", "gather_backend", "dry_run", "gather_ok"):
+        if k in res:
+            out[k] = res[k]
+    out["detail"] = res.get("detail_file")
+    line = json.dumps(out, allow_nan=False, separators=(",", ":"))
+    if len(line) > COMPACT_LIMIT:   # never let the line outgrow the driver's tail again: shed the optional blocks
+        for k in ("other_configs", "sqp_phase_ms", "roofline_expand", "roofline_condense"):
+            out.pop(k, None)
+            line = json.dumps(out, allow_nan=False, separators=(",", ":"))
+            if len(line) <= COMPACT_LIMIT:
+                break
+    assert len(line) <= COMPACT_LIMIT, len(line)
+    return line
+
+
+def _finite(o):
+    """NaN / inf -> None, so that the detail file is strict JSON too."""
+    if isinstance(o, float):
+        return o if np.isfinite(o) else None
+    if isinstance(o, dict):
+        return {k: _finite(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_finite(v) for v in o]
+    if isinstance(o, (np.floating, np.integer)):
+        return _finite(o.item())
+    return o
+
+
+def emit(res, detail_path):
+    """Write the full record to `detail_path` (best effort) and print the compact line as the LAST line of stdout."""
+    res = _finite(res)
+    try:
+        os.makedirs(os.path.dirname(detail_path), exist_ok=True)
+        with open(detail_path, "w") as f:
+            json.dump(res, f, allow_nan=False)
+            f.write("\n")
+        res["detail_file"] = os.path.relpath(detail_path, ROOT)
+    except OSError as e:
+        res["detail_file"] = "not written: %r" % (e,)
+    sys.stdout.flush()
+    print(compact_line(res), flush=True)
 
 
 def sqp_single_instance(dims, grids, device):
@@ -539,8 +652,8 @@ def dry_run(args, rank, world):
     full = gather_directions(local, world * batch, world, rank)
     ok = full.shape[0] == world * batch and all(float(full[r * batch, 0, 0]) == float(r) for r in range(world))
     if rank == 0:
-        print(json.dumps({"metric": "riccati_sweeps_per_sec", "dry_run": True, "n_gpus": world, "steps": args.steps,
-                          "warmup": args.warmup, "gather_ok": bool(ok), "value": None}))
+        emit({"metric": "riccati_sweeps_per_sec", "dry_run": True, "n_gpus": world, "steps": args.steps,
+              "warmup": args.warmup, "gather_ok": bool(ok), "value": None}, args.detail_out)
     if world > 1:
         dist.destroy_process_group()
 
@@ -600,6 +713,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sqp", action="store_true", help="skip the SQP-iteration phase timing")
     ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE.json configurations")
+    ap.add_argument("--detail-out", default=os.path.join(ROOT, "gpurun_out", "bench_detail.json"),
+                    help="file the full (20+ KB) record goes to; stdout carries only the compact line")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous / gather plumbing only, no GPU work (tests/test_bench_launcher.py)")
     args = ap.parse_args()
@@ -1179,7 +1294,7 @@ def main():
             res["gather_backend"] = dist.get_backend()
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(L, grids, dims)
-        print(json.dumps(res))
+        emit(res, args.detail_out)
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
