@@ -14,6 +14,7 @@
 #include "integrate_solution.hpp"
 #include "riccati_backward.hpp"
 #include "riccati_backward_rs.hpp"
+#include "riccati_backward_rv.hpp"
 #include "riccati_scan.hpp"
 #include "riccati_forward.hpp"
 #include "unconstr_riccati.hpp"
@@ -48,6 +49,8 @@ struct KernelSet {
   int bwd_lds[4];
   int bwd_inst[4];    // OCP instances per workgroup
   bwd_fn bwd_sa;      // structured-Fxx form of variant 3 (role-split, 4 instances per workgroup), or nullptr
+  bwd_fn bwd_rv;      // register-resident kernel, one wave per instance (riccati_backward_rv.hpp), or nullptr
+  int bwd_rv_lds;
   rtoc_record_layout kl, rl, dl, cl;  // record layouts the kernels were compiled for
   fwd_fn fwd;
   int fwd_threads;
@@ -108,6 +111,10 @@ inline KernelSet make_set() {
       k.nvariants = 4;
       if constexpr (NV % 4 == 2 && NV > NU) k.bwd_sa = riccati_backward_rs4_kernel<NV, NU, NS, true>;
     }
+  }
+  if constexpr (RvCfg<NV, NU>::OK) {
+    k.bwd_rv = riccati_backward_rv_kernel<NV, NU, NS>;
+    k.bwd_rv_lds = rv_lds_bytes<NV, NU, NS>();
   }
   constexpr int NWF = (2 * NV + NU + 63) / 64;
   if constexpr (NWF == 1)

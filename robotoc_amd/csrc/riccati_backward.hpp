@@ -78,6 +78,10 @@ struct BwdArgs {
   // the bundle of grid point st for the serial vector pass -- they read what the policy workgroups read (the scan's value records,
   // the KKT records), none of their output, so they need neither a launch nor an event of their own.  nullptr: no such workgroups.
   double* sto_scr;   // [batch][nstages][scan::StoScratch::STRIDE]
+  // Segment of the horizon (riccati_backward_rv.hpp): the register-resident kernel walks the grid points seg_hi .. seg_lo and takes
+  // P+ / s+ of grid point seg_hi + 1 from the Riccati records unless that is the terminal one; in the one-stage mode above the
+  // tile-split kernel does grid point blockIdx.y + seg_lo.  Zero in every other launch.
+  int seg_hi, seg_lo;
 };
 
 template <int NV, int NU, int NS, int NW>
@@ -539,7 +543,7 @@ __global__ __launch_bounds__(64 * NW) void riccati_backward_kernel(BwdArgs a) {
 
   // horizon-scan mode: this workgroup handles grid point blockIdx.y only (no sto grids in this mode)
   const bool one_stage = a.scan_ps != nullptr;
-  const int my_stage = one_stage ? (int)blockIdx.y : N;
+  const int my_stage = one_stage ? (int)blockIdx.y + a.seg_lo : N;
   if (one_stage && my_stage > N) {
     const int st = my_stage - a.nstages;   // grid point whose bundle this workgroup prepares
     if (a.sto_scr && st < N) {

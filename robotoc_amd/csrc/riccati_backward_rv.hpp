@@ -1,0 +1,517 @@
+// riccati_backward_rv.hpp -- backward Riccati recursion with the value function in REGISTERS: one wavefront per OCP instance.
+//
+// Same recursion and HBM record contract as riccati_backward.hpp (reference: src/riccati/riccati_recursion.cpp:32-80,
+// riccati_factorizer.cpp:44-56,178-197, backward_riccati_recursion_factorizer.cpp:31-91), different machine mapping.  The
+// role-split kernel (riccati_backward_rs.hpp) keeps P+, A, PB, H, K^T and a dozen vectors of an instance in 39 KB of LDS, so a
+// CU holds four instances -- ONE dependency chain per SIMD, which waits 41 % of its cycles (profiles/r04_rocprof_summary.txt).
+// Here an instance is one wave and needs 20 KB of LDS (A, Bv, Quu, three vectors, the inverse Cholesky factor, a transpose
+// scratch): EIGHT instances per CU, two independent chains per SIMD, no hand-off between waves at all.
+//
+//   * P+ lives in 9 (= T x T) accumulator tiles in the f64 MFMA C layout (lane (li, q), register r <-> row q + 4r, column li).
+//     For a symmetric matrix the C layout of tile (kt, mt) IS the A-operand fragment (m = 16 mt + li, k = 16 kt + 4r + q) of
+//     k-step (kt, r): P+ [.] and [P+; PB^T] [.] run straight from registers -- no LDS copy of P+, no operand reads for it.
+//   * PB = P+[:, v] Bv is computed with its control columns shifted by SCOL lanes (u <-> lane li = u + SCOL, SCOL = NX - 16 (T - 1)):
+//     then the accumulators of PB are, lane for lane, the A-operand fragments of the PB^T rows (NX.. of the stacked operand
+//     [P+; PB^T], which fills its T row tiles exactly: 36 + 12 = 48) -- PB never leaves the registers either.
+//   * The accumulators of the PB^T rows start from Qxu^T (loaded from HBM in the C layout), so they END as H^T = Qxu^T + PB^T A,
+//     which is the B-operand fragment of the policy product Z^T = L^-1 H^T: H never exists in LDS.
+//   * Every vector rides as a column of a matrix product: Bv^T s+_v as column 0 of the G product; Fx as column NX of [A | Fx]
+//     (-> P+ Fx and PB^T Fx); z = s+ - P+ Fx replaces that column in the accumulators, and column NX of F = Qxx + A^T W -- started
+//     from -lx -- is then w = A^T z - lx; -lu' rides as column NX of H^T, so that column NX of K is -k and column NX of
+//     F -= Z Z^T receives + H G^-1 lu' = -H k: after the last product column NX of F IS the new s.  s+ is carried from stage to
+//     stage in exactly the registers it is produced in (lanes li = SCOL of the last column tile).
+//   * The stage record comes in by LDS-DMA (global_load_lds_dwordx4: no prefetch registers, no VALU unpack): A into a padded
+//     (conflict-free) layout by per-lane source addresses, Bv | Quu | Fx lx lu as one strip; Qxx and Qxu^T by per-lane loads
+//     straight into accumulators.  The DMA of stage st - 1 is issued when the F product of stage st has read A for the last time.
+//   * new P = sym(F): upper tiles computed, diagonal tiles mirrored, lower tiles transposed through a 16 x 17 LDS scratch;
+//     P goes to HBM from the registers during the NEXT stage (coalesced through the symmetric index pair).
+//
+// Scope: grid points without switching-time terms and without a switching constraint (regular and impact grid points).  The
+// host (rtoc_capi.hip: launch_backward_range) cuts the horizon into segments [seg_hi .. seg_lo] at switching-constraint grid
+// points, which the tile-split kernel handles in its one-stage mode, P+ / s+ handed over through the Riccati records; grids
+// with switching-time optimisation, RTOC_OPT_WRITEBACK_KKT and shapes whose stacked operand does not fill its tiles
+// (RvCfg::OK) keep the role-split / tile-split kernels.  tools/rv_model.py states the lane algebra in numpy against the oracle.
+#pragma once
+#include "riccati_backward.hpp"
+
+namespace rtoc {
+
+template <int NV, int NU>
+struct RvCfg {
+  static constexpr int NX = 2 * NV;
+  static constexpr int T = (NX + 15) / 16;            // 16-tiles of the state, and row tiles of [P+; PB^T]
+  static constexpr int LDP = lds_ld(NX);
+  static constexpr int KG = (NX + 3) / 4;             // aligned k groups of the state
+  static constexpr int KSU = (NU + 3) / 4;
+  static constexpr int SCOL = NX - 16 * (T - 1);      // lane of column NX in the last column tile = lane shift of the controls
+  static constexpr int G0 = NV / 4;                   // first k group that meets the rows [NV, NX)
+  static constexpr int GS = 4 * (T - 1) + SCOL / 4;   // k group of row NX (the first PB^T row) of the stacked operand
+  static constexpr bool OK = (NX + NU == 16 * T) && (NX % 4 == 0) && (NU % 4 == 0) && (SCOL % 4 == 0) && (SCOL >= 1) &&
+                             ((NV * NU) % 2 == 0) && (LDP % 2 == 0);
+  // ---- LDS carve (doubles) ----
+  static constexpr int HL = LDP / 2;                  // 16-byte chunks per padded column of A
+  static constexpr int NCH_A = NX * HL;               // chunk slots of A (one per column is padding)
+  static constexpr int PA = (NCH_A + 63) / 64;        // DMA pieces (one wave instruction = 64 chunks = 1 KiB)
+  static constexpr int OFF_A = 0;
+  static constexpr int OFF_ST = NX * LDP;             // strip: Bv | Quu | Fx .. lu (as they lie in the record)
+  static constexpr int CB = NV * NU / 2, CG = NU * NU / 2;
+  static constexpr int pad8(int n) { return (n + 7) & ~7; }
+};
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+// v <- the value `n` lanes to the RIGHT / LEFT within the 16-lane row (v_mov_b32_dpp row_shl / row_shr), 0 beyond the row.
+template <int N>
+__device__ __forceinline__ double dpp_from_right(double v) {   // lane li reads lane li + N
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x100 + N, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x100 + N, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+template <int N>
+__device__ __forceinline__ double dpp_from_left(double v) {    // lane li reads lane li - N
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x110 + N, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x110 + N, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+
+// the n-th upper tile (c, t) of a T x T tiling in the order the transposes take them: off-diagonal tiles first, then the diagonal
+__host__ __device__ constexpr int rv_tile_row(int T, int n) {
+  int k = 0;
+  for (int c = 0; c < T; ++c)
+    for (int t = c + 1; t < T; ++t) {
+      if (k == n) return c;
+      ++k;
+    }
+  return n - k;
+}
+__host__ __device__ constexpr int rv_tile_col(int T, int n) {
+  int k = 0;
+  for (int c = 0; c < T; ++c)
+    for (int t = c + 1; t < T; ++t) {
+      if (k == n) return t;
+      ++k;
+    }
+  return n - k;
+}
+
+__device__ __forceinline__ void rv_lds_sync() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <int NV, int NU, int NS>
+__global__ __launch_bounds__(64, 2) void riccati_backward_rv_kernel(BwdArgs a) {
+  using C = RvCfg<NV, NU>;
+  static_assert(C::OK, "shape does not fill the tiles of the stacked operand");
+  constexpr int NX = C::NX, T = C::T, LDP = C::LDP, KG = C::KG, KSU = C::KSU, SCOL = C::SCOL, G0 = C::G0, GS = C::GS;
+  constexpr int RS = SCOL / 4;   // first register group of the last row tile that holds PB^T rows
+  constexpr rtoc_layout SL = StaticLayout<NV, NU, NS>::make();
+  constexpr rtoc_record_layout KL = SL.kkt, RL = SL.ric;
+  // strip layout
+  constexpr int VOFF_LX = KL.off[RTOC_KKT_LX] - KL.off[RTOC_KKT_FX], VOFF_LU = KL.off[RTOC_KKT_LU] - KL.off[RTOC_KKT_FX];
+  static_assert(VOFF_LX > 0 && VOFF_LU > VOFF_LX && VOFF_LX % 2 == 0 && VOFF_LU % 2 == 0, "Fx, lx, lu lie behind one another in the record");
+  static_assert(KL.off[RTOC_KKT_FXX] % 2 == 0 && KL.off[RTOC_KKT_FVU] % 2 == 0 && KL.off[RTOC_KKT_QUU] % 2 == 0 && KL.off[RTOC_KKT_FX] % 2 == 0 &&
+                    KL.stride % 2 == 0, "16-byte chunks");
+  constexpr int CB = C::CB, CG = C::CG, CV = (VOFF_LU + NU + 1) / 2, NCH_S = CB + CG + CV, PS = (NCH_S + 63) / 64;
+  constexpr int ST_BV = C::OFF_ST, ST_G = ST_BV + 2 * CB, ST_FX = ST_G + 2 * CG, ST_LX = ST_FX + VOFF_LX, ST_LU = ST_FX + VOFF_LU;
+  constexpr int OFF_Y = ST_FX + 2 * CV, OFF_LINV = OFF_Y + C::pad8(NU * NU), OFF_SCR = OFF_LINV + C::pad8(NU), SCR_LD = 17,
+                SCR_TILE = C::pad8(16 * SCR_LD), LDS_DOUBLES = OFF_SCR + 2 * SCR_TILE;
+  static_assert(NU * NU <= 2 * SCR_TILE, "the Cholesky factor is parked in the transpose scratch");
+  static_assert(LDS_DOUBLES * 8 <= 20 * 1024, "eight instances per CU");
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* const sA = smem + C::OFF_A;
+  double* const sBv = smem + ST_BV;
+  double* const sG = smem + ST_G;
+  double* const sY = smem + OFF_Y;
+  double* const scr = smem + OFF_SCR;
+
+  const int b = a.first + (int)blockIdx.x;
+  if (b >= a.batch) return;
+  const int lane0 = threadIdx.x;
+  int lane = lane0 & 63, li = lane & 15, q = lane >> 4;   // (& 63: tells the compiler li < 16, q < 4 -- the tile predicates fold)
+  const int N = a.nstages - 1;
+  const size_t kinst = (size_t)b * a.nstages * KL.stride;
+  const size_t rinst = (size_t)b * a.nstages * RL.stride;
+  const int hi = a.seg_hi, lo = a.seg_lo;
+  unsigned stat = 0;
+
+  // The record of grid point `stage` -> LDS by DMA (16 B per lane and instruction, LDS address = piece base + 16 lane).
+  auto issue_dma = [&](int stage) {
+    const double* kp = a.kkt + kinst + (size_t)stage * KL.stride;
+#pragma unroll
+    for (int p = 0; p < PS; ++p) {   // the strip first: the PB / G products at the stage top need Bv and Quu
+      const int n = lane + 64 * p;
+      const int off = (n < CB) ? (KL.off[RTOC_KKT_FVU] + 2 * n)
+                               : ((n < CB + CG) ? (KL.off[RTOC_KKT_QUU] + 2 * (n - CB)) : (KL.off[RTOC_KKT_FX] + 2 * (n - CB - CG)));
+      if (64 * (p + 1) <= NCH_S || n < NCH_S)   // (only the last piece is partial)
+        __builtin_amdgcn_global_load_lds(kp + off, (lds_ptr_t)(smem + C::OFF_ST + 128 * p), 16, 0, 0);
+    }
+#pragma unroll
+    for (int p = 0; p < C::PA; ++p) {
+      const int n = lane + 64 * p;
+      const int col = n / C::HL, ch = n - col * C::HL;
+      const int off = KL.off[RTOC_KKT_FXX] + ((ch < NX / 2) ? (col * NX + 2 * ch) : 0);   // the padding chunk of a column loads anything
+      if (64 * (p + 1) <= C::NCH_A || n < C::NCH_A) __builtin_amdgcn_global_load_lds(kp + off, (lds_ptr_t)(sA + 128 * p), 16, 0, 0);
+    }
+  };
+  // Qxu^T of grid point `stage` in the C layout of the PB^T rows: hq[c][ks] = Qxu[x = 16c + li][u = 4 ks + q].  RAW: lanes beyond the
+  // matrix load a clamped address and are masked where hq is USED -- a select here would wait for the loads on the spot.
+  double hq[T][KSU];
+  auto issue_hq = [&](int stage) {
+    const double* kp = a.kkt + kinst + (size_t)stage * KL.stride + KL.off[RTOC_KKT_QXU];
+#pragma unroll
+    for (int c = 0; c < T; ++c)
+#pragma unroll
+      for (int ks = 0; ks < KSU; ++ks) {
+        const int x = 16 * c + li, u = 4 * ks + q;
+        hq[c][ks] = kp[((x < NX) ? x : NX - 1) + u * NX];   // (a distinct address per ks: a common clamp target becomes a branch)
+      }
+  };
+
+  // ---- value function of grid point hi + 1 -> registers: the terminal one (P_N = Qxx_N, s_N = -lx_N,
+  //      riccati_recursion.cpp:37-38) or the one a previous segment left in the Riccati records ----
+  d4 pp[T][T];
+  double sv[KG];
+  {
+    const bool term = (hi == N - 1);
+    const double* psrc = term ? (a.kkt + kinst + (size_t)N * KL.stride + KL.off[RTOC_KKT_QXX])
+                              : (a.ric + rinst + (size_t)(hi + 1) * RL.stride + RL.off[RTOC_RIC_P]);
+    const double* ssrc = term ? (a.kkt + kinst + (size_t)N * KL.stride + KL.off[RTOC_KKT_LX])
+                              : (a.ric + rinst + (size_t)(hi + 1) * RL.stride + RL.off[RTOC_RIC_S]);
+#pragma unroll
+    for (int kt = 0; kt < T; ++kt)
+#pragma unroll
+      for (int mt = 0; mt < T; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 16 * kt + 4 * r + q, j = 16 * mt + li;
+          const bool ok = i < NX && j < NX;
+          const double v = psrc[ok ? i + j * NX : 0];
+          pp[kt][mt][r] = ok ? v : 0.0;
+        }
+#pragma unroll
+    for (int g = 0; g < KG; ++g) {
+      const double v = ssrc[4 * g + q];
+      sv[g] = (li == SCOL) ? (term ? -v : v) : 0.0;
+    }
+    if (term) {
+      double* rr = a.ric + rinst + (size_t)N * RL.stride;
+      const d2* s2 = reinterpret_cast<const d2*>(psrc);
+      d2* t2 = reinterpret_cast<d2*>(rr + RL.off[RTOC_RIC_P]);
+      for (int e = lane; e < NX * NX / 2; e += 64) t2[e] = s2[e];
+      if (lane < NX) rr[RL.off[RTOC_RIC_S] + lane] = -ssrc[lane];
+    }
+  }
+  issue_dma(hi);
+  issue_hq(hi);
+  // grid descriptors one stage ahead, by a vector load (lane l = int l of rtoc_grid; see riccati_backward_rs.hpp)
+  int gv_ahead = reinterpret_cast<const int*>(a.grid + hi)[lane0 & 7];
+
+  for (int st = hi; st >= lo; --st) {
+    lane = lane0;
+    asm volatile("" : "+v"(lane));   // opaque per stage: keeps LICM from pinning the per-lane addresses of every unrolled loop
+    lane &= 63;
+    li = lane & 15;
+    q = lane >> 4;
+    const bool impact = __builtin_amdgcn_readlane(gv_ahead, 0) == RTOC_GRID_IMPACT;
+    const double* kr = a.kkt + kinst + (size_t)st * KL.stride;
+    double* rr = a.ric + rinst + (size_t)st * RL.stride;
+    // everything this stage reads from LDS or was promised in registers has landed (DMA of A and the strip, Qxu^T, the grid
+    // descriptor); the stores of the previous stage (K, k, s) have left too
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    gv_ahead = reinterpret_cast<const int*>(a.grid + (st > lo ? st - 1 : st))[lane & 7];
+
+    // ---- Qxx of this stage -> accumulators of the F product (upper tiles; off-diagonal ones symmetrised,
+    //      brrf.cpp:85 folded into the start value), used two products from here ----
+    d4 f[T][T];
+    {
+      const double* qx_ = kr + KL.off[RTOC_KKT_QXX] + q + li * NX;    // Qxx[i][j]
+      const double* qxt_ = kr + KL.off[RTOC_KKT_QXX] + li + q * NX;   // Qxx[j][i]
+#pragma unroll
+      for (int c = 0; c < T; ++c)
+#pragma unroll
+        for (int t = c; t < T; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            // unconditional loads (lanes beyond the matrix read a clamped address): the columns >= NX of the last column tile
+            // are masked where column NX gets its start value below, rows >= NX are whole register groups
+            if (16 * c + 4 * r >= NX) {
+              f[c][t][r] = 0.0;
+              continue;
+            }
+            const bool okj = (t < T - 1) || li < SCOL;
+            const double v = qx_[okj ? 16 * c + 4 * r + 16 * t * NX : 0];
+            if (t == c) {
+              f[c][t][r] = v;
+            } else {
+              const double vt_ = qxt_[okj ? 16 * t + (16 * c + 4 * r) * NX : 0];
+              f[c][t][r] = 0.5 * (v + vt_);
+            }
+          }
+    }
+
+    // ================= PB = P+[:, v] Bv (controls shifted by SCOL lanes), G = Quu + Bv^T PB[v, :] ==================
+    d4 acc[T];
+    double bts[KSU];   // Bv^T s+_v, rider column 0 of the G product (valid on lanes li == 0)
+#pragma unroll
+    for (int c = 0; c < T; ++c) acc[c] = zero4();
+#pragma unroll
+    for (int ks = 0; ks < KSU; ++ks) bts[ks] = 0.0;
+    if (!impact) {
+#pragma unroll
+      for (int g = G0; g < KG; ++g) {
+        const int k = 4 * g + q - NV, u = li - SCOL;
+        const bool ok = k >= 0 && u >= 0;
+        const double v = sBv[ok ? k + u * NV : 0];
+        const double bv = ok ? v : 0.0;
+#pragma unroll
+        for (int c = 0; c < T; ++c) acc[c] = mfma16(pp[g / 4][c][g % 4], bv, acc[c]);   // P+[16c + li][4g + q] = P+[4g + q][16c + li]
+      }
+      d4 gacc = zero4();
+#pragma unroll
+      for (int g = G0; g < KG; ++g) {
+        const int k = 4 * g + q - NV;
+        const bool ok = k >= 0 && li < NU;
+        const double v = sBv[ok ? k + li * NV : 0];
+        const double av = ok ? v : 0.0;                       // Bv^T[u' = li][k]
+        const double srow = dpp_from_right<SCOL>(sv[g]);      // s+[4g + q], lane SCOL -> lane 0
+        const double bv = (li == 0) ? srow : acc[g / 4][g % 4];   // PB[4g + q][u = li - SCOL]: the C layout is the B fragment
+        gacc = mfma16(av, bv, gacc);
+      }
+#pragma unroll
+      for (int r = 0; r < KSU; ++r) {
+        const int u0 = q + 4 * r, u1 = li - SCOL;
+        if (u0 < NU && u1 >= 0) sG[u0 + u1 * NU] += gacc[r];
+        bts[r] = gacc[r];
+      }
+    }
+    // ---- P of grid point st + 1 -> HBM, from the registers that still hold it as P+ (element (i, j) is written
+    //      through its mirror (j, i): li runs along the contiguous index) ----
+    if (st < hi) {
+      double* pw = a.ric + rinst + (size_t)(st + 1) * RL.stride + RL.off[RTOC_RIC_P];
+#pragma unroll
+      for (int kt = 0; kt < T; ++kt)
+#pragma unroll
+        for (int mt = 0; mt < T; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = 16 * kt + 4 * r + q, j = 16 * mt + li;
+            if (i < NX && j < NX) pw[j + i * NX] = pp[kt][mt][r];
+          }
+    }
+    if (!impact) {
+      rv_lds_sync();
+      // LLT(G) (riccati_factorizer.cpp:49) and Y = L^-1 in the same instruction stream; L itself is not used again
+      if (wave_llt_inv<NU, NU>(sG, scr, smem + OFF_LINV, sY, NU, lane)) stat |= RTOC_STAT_QUU_NOT_SPD;
+      rv_lds_sync();
+    }
+
+    // ================= column tile by column tile: W[:, t] = [P+; PB^T] [A | Fx][:, t], F[c][t] += A^T[c] W[:, t] ===========
+    double hT[T][KSU];   // H^T = Qxu^T + PB^T A (rows NX.. of W), B fragments of the policy product
+    double lup[KSU];     // lu' = lu - Bv^T s+_v + PB^T Fx on lanes li == SCOL
+#pragma unroll
+    for (int ks = 0; ks < KSU; ++ks) lup[ks] = 0.0;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      d4 w[T];
+#pragma unroll
+      for (int tm = 0; tm < T; ++tm) w[tm] = zero4();
+#pragma unroll
+      for (int ks = 0; ks < KSU; ++ks) w[T - 1][RS + ks] = (impact || (t == T - 1 && li >= SCOL)) ? 0.0 : hq[t][ks];
+      // B fragment of k group g: A[4g + q][16t + li]; last tile: columns >= NX are Fx (lane SCOL) and nothing
+      const double* pb_ = (t < T - 1 || li < SCOL) ? (sA + q + (16 * t + li) * LDP) : (smem + ST_FX + q);
+      const bool okb = (t < T - 1) || li <= SCOL;
+      double braw[2];
+      braw[0] = pb_[0];
+#pragma unroll
+      for (int g = 0; g < KG; ++g) {
+        if (g + 1 < KG) braw[(g + 1) & 1] = pb_[4 * (g + 1)];
+        __builtin_amdgcn_sched_barrier(0);
+        const double bv = okb ? braw[g & 1] : 0.0;
+#pragma unroll
+        for (int tm = 0; tm < T; ++tm) {
+          double av = pp[g / 4][tm][g % 4];
+          if (tm == T - 1) av = (li >= SCOL) ? acc[g / 4][g % 4] : av;   // PB^T[u = li - SCOL][4g + q]
+          w[tm] = mfma16(av, bv, w[tm]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (t == T - 1) {
+        // lane masks as numbers: selects on just-loaded values become branches around the loads (with a full vmcnt wait at the join)
+        const double m_eq = (li == SCOL) ? 1.0 : 0.0, m_lt = (li < SCOL) ? 1.0 : 0.0, sgn_col = (li == SCOL) ? -1.0 : 1.0;
+        // column NX: rows < NX hold P+ Fx -> z = s+ - P+ Fx (brrf.cpp:86); rows NX.. hold PB^T Fx -> lu'
+#pragma unroll
+        for (int g = 0; g < KG; ++g) w[g / 4][g % 4] = __builtin_fma(sgn_col, w[g / 4][g % 4], sv[g]);   // sv is zero off lane SCOL
+        if (!impact) {
+#pragma unroll
+          for (int ks = 0; ks < KSU; ++ks) {
+            const double luv = smem[ST_LU + 4 * ks + q];
+            lup[ks] = luv - dpp_from_left<SCOL>(bts[ks]) + w[T - 1][RS + ks];
+          }
+        }
+        // ... and column NX of F starts from -lx, so that it ends as w = A^T z - lx (brrf.cpp:87-88)
+#pragma unroll
+        for (int g = 0; g < KG; ++g) {
+          const double lxv = smem[ST_LX + 4 * g + q];
+          f[g / 4][T - 1][g % 4] = __builtin_fma(-m_eq, lxv, m_lt * f[g / 4][T - 1][g % 4]);
+        }
+      }
+#pragma unroll
+      for (int ks = 0; ks < KSU; ++ks) hT[t][ks] = w[T - 1][RS + ks];
+      // F[c][t] += A^T[c] W[:, t]: A fragment A[k = 4g + q][m = 16c + li] (the same LDS words as above), B fragment W in its C layout
+      double araw[2][T];
+      auto load_a = [&](int g, double (&d)[T]) {
+#pragma unroll
+        for (int c = 0; c <= t; ++c) d[c] = sA[q + 4 * g + (16 * c + li) * LDP];
+      };
+      load_a(0, araw[0]);
+#pragma unroll
+      for (int g = 0; g < KG; ++g) {
+        if (g + 1 < KG) load_a(g + 1, araw[(g + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        const double bw = w[g / 4][g % 4];
+#pragma unroll
+        for (int c = 0; c <= t; ++c) {
+          const double av = (c < T - 1 || li < SCOL) ? araw[g & 1][c] : 0.0;
+          f[c][t] = mfma16(av, bw, f[c][t]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+
+    // ---- A, Bv, Quu and the vectors of this stage have been read for the last time: the record of the next grid point ----
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (st > lo) {
+      issue_dma(st - 1);
+      issue_hq(st - 1);
+    }
+    asm volatile("" ::: "memory");
+
+    // ================= policy: Z^T = Y [H^T | -lu'],  [K | -k] = -Y^T Z^T  (riccati_factorizer.cpp:55-56) ============
+    if (!impact) {
+      d4 zt[T], kk[T];
+      double y1[KSU], y2[KSU];
+#pragma unroll
+      for (int ks = 0; ks < KSU; ++ks) {
+        const bool ok = li < NU;
+        const double v1 = sY[(ok ? li : 0) + (4 * ks + q) * NU];   // A[m = i = li][k = u]: Y[i][u]
+        const double v2 = sY[(4 * ks + q) + (ok ? li : 0) * NU];   // A[m = u = li][k = i]: Y[i][u]
+        y1[ks] = ok ? v1 : 0.0;
+        y2[ks] = ok ? -v2 : 0.0;
+      }
+#pragma unroll
+      for (int c = 0; c < T; ++c) {
+        zt[c] = zero4();
+        kk[c] = zero4();
+      }
+#pragma unroll
+      for (int ks = 0; ks < KSU; ++ks)
+#pragma unroll
+        for (int c = 0; c < T; ++c) {
+          double bv = hT[c][ks];
+          if (c == T - 1) bv = (li < SCOL) ? bv : ((li == SCOL) ? -lup[ks] : 0.0);
+          zt[c] = mfma16(y1[ks], bv, zt[c]);
+        }
+#pragma unroll
+      for (int ks = 0; ks < KSU; ++ks)
+#pragma unroll
+        for (int c = 0; c < T; ++c) kk[c] = mfma16(y2[ks], zt[c][ks], kk[c]);
+      // K[u = q + 4r][x = 16c + li] -> HBM (K row-major, lqr_policy.hpp:18-19); column NX is -k
+      double chk = 0.0;
+#pragma unroll
+      for (int c = 0; c < T; ++c)
+#pragma unroll
+        for (int r = 0; r < KSU; ++r) {
+          const int u = q + 4 * r, x = 16 * c + li;
+          if (x < NX) rr[RL.off[RTOC_RIC_K] + u * NX + x] = kk[c][r];
+          if (c == T - 1 && li == SCOL) rr[RL.off[RTOC_RIC_KV] + u] = -kk[c][r];
+          chk = __builtin_fma((x <= NX) ? kk[c][r] : 0.0, 0.0, chk);
+        }
+      if (is_bad(chk)) stat |= RTOC_STAT_NAN;
+      // F -= K^T G K = Z Z^T (brrf.cpp:82-84); column NX: + H G^-1 lu' = - H k
+#pragma unroll
+      for (int ks = 0; ks < KSU; ++ks)
+#pragma unroll
+        for (int c = 0; c < T; ++c)
+#pragma unroll
+          for (int t = c; t < T; ++t) f[c][t] = mfma16(-zt[c][ks], zt[t][ks], f[c][t]);
+    }
+
+    // ================= s <- column NX of F;  P <- sym(F) as nine operand tiles ==================
+#pragma unroll
+    for (int g = 0; g < KG; ++g) sv[g] = (li == SCOL) ? f[g / 4][T - 1][g % 4] : 0.0;
+    {
+      // mask of tile (c, t): rows 16c + 4r + q < NX is a property of the register (NX % 4 == 0), columns 16t + li < NX of the lane
+      auto masked = [&](int c, int t, int r, double v) -> double {
+        if (16 * c + 4 * r >= NX) return 0.0;
+        if (t == T - 1) return (li < SCOL) ? v : 0.0;
+        return v;
+      };
+      // transposes in pairs through the two scratch tiles: (row q + 4r, column li) in, (row li, column q + 4r) out
+      constexpr int NTR = T * (T + 1) / 2;
+#pragma unroll
+      for (int n0 = 0; n0 < NTR; n0 += 2) {
+#pragma unroll
+        for (int n = n0; n < n0 + 2 && n < NTR; ++n) {
+          const int c = rv_tile_row(T, n), t = rv_tile_col(T, n);
+          double* s_ = scr + (n - n0) * SCR_TILE;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s_[(q + 4 * r) * SCR_LD + li] = masked(c, t, r, f[c][t][r]);
+        }
+        rv_lds_sync();
+#pragma unroll
+        for (int n = n0; n < n0 + 2 && n < NTR; ++n) {
+          const int c = rv_tile_row(T, n), t = rv_tile_col(T, n);
+          const double* s_ = scr + (n - n0) * SCR_TILE;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const double tr = s_[li * SCR_LD + q + 4 * r];
+            if (t > c) {
+              pp[c][t][r] = masked(c, t, r, f[c][t][r]);
+              pp[t][c][r] = tr;                                  // zero outside the matrix: the tile was masked on its way in
+            } else {
+              pp[c][c][r] = (q + 4 * r <= li) ? masked(c, c, r, f[c][c][r]) : tr;   // upper triangle mirrored (P exactly symmetric)
+            }
+          }
+        }
+        rv_lds_sync();
+      }
+    }
+    // ---- s (and the zero switching-time fields of the record) -> HBM ----
+    if (li == SCOL) {
+#pragma unroll
+      for (int g = 0; g < KG; ++g) rr[RL.off[RTOC_RIC_S] + 4 * g + q] = sv[g];
+    }
+    if (lane < NX) {
+      rr[RL.off[RTOC_RIC_PSI] + lane] = 0.0;
+      rr[RL.off[RTOC_RIC_PHI] + lane] = 0.0;
+    }
+    if (lane < 5) rr[RL.off[RTOC_RIC_SCAL] + lane] = 0.0;
+  }
+
+  // ---- P of the last grid point of the segment ----
+  {
+    double* pw = a.ric + rinst + (size_t)lo * RL.stride + RL.off[RTOC_RIC_P];
+#pragma unroll
+    for (int kt = 0; kt < T; ++kt)
+#pragma unroll
+      for (int mt = 0; mt < T; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 16 * kt + 4 * r + q, j = 16 * mt + li;
+          if (i < NX && j < NX) pw[j + i * NX] = pp[kt][mt][r];
+        }
+  }
+  if (stat) atomicOr(&a.status[b], stat);
+}
+
+template <int NV, int NU, int NS>
+constexpr int rv_lds_bytes() {
+  using C = RvCfg<NV, NU>;
+  constexpr rtoc_record_layout KL = StaticLayout<NV, NU, NS>::make().kkt;
+  constexpr int CV = (KL.off[RTOC_KKT_LU] - KL.off[RTOC_KKT_FX] + NU + 1) / 2;
+  constexpr int ST_FX = C::OFF_ST + 2 * C::CB + 2 * C::CG;
+  return 8 * (ST_FX + 2 * CV + C::pad8(NU * NU) + C::pad8(NU) + 2 * C::pad8(16 * 17));
+}
+
+}  // namespace rtoc

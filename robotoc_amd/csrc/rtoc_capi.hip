@@ -174,6 +174,7 @@ struct rtoc_ctx {
   int condense_split;  // 1: MJtJinv in its own kernel ahead of the condensation
   int keep_qaf;        // RTOC_OPT_CONDENSE_KEEP_QAF
   int fxx_mode;        // RTOC_OPT_FXX_STRUCTURE: 0 auto, 1 dense, 2 caller asserts the structure
+  int bwd_register;    // RTOC_OPT_BACKWARD_REGISTER: the register-resident backward kernel where it applies
   int fxx_state;       // auto mode cache: 0 unknown (re-check before the next backward recursion), 1 every Fxx structured, 2 not
   int fxx_last;        // the last check's answer (1 / 2; 0 never checked): the kernel choice baked into captured graphs
   unsigned long long graph_replays;  // hipGraphLaunch count of RTOC_OPT_GRAPH (rtoc_graph_replay_count)
@@ -523,6 +524,7 @@ int rtoc_clone(rtoc_ctx* c, rtoc_ctx** out) {
                                           : rtoc_set_friction_cones(n, c->cone_contacts, c->cone_dim);
   if (!rc) {
     n->writeback = c->writeback;
+    n->bwd_register = c->bwd_register;
     n->max_dts0 = c->max_dts0;
     n->contact_inv_damping = c->contact_inv_damping;
     n->bwd_variant = c->bwd_variant;
@@ -675,7 +677,13 @@ int rtoc_get_option(rtoc_ctx* c, int option, int64_t* value) {
     case RTOC_OPT_GRAPH: *value = c->use_graph; return RTOC_OK;
     case RTOC_OPT_IMPACT_CONES: *value = c->impact_cones; return RTOC_OK;
     case RTOC_OPT_LINEARIZE_DOFS_PER_PASS: *value = c->h_model ? c->h_model->dpp : 0; return RTOC_OK;
-    default: return RTOC_ERR_BAD_ARG;
+    case RTOC_OPT_BACKWARD_REGISTER: *value = c->bwd_register; return RTOC_OK;
+    case RTOC_OPT_BACKWARD_WAVES: *value = c->ks->bwd_waves[c->bwd_variant]; return RTOC_OK;
+    case RTOC_OPT_SWITCHING_TRANSPORT: *value = c->exact_transport; return RTOC_OK;
+    case RTOC_OPT_UNCONSTR_DENSE: *value = c->unconstr_dense; return RTOC_OK;
+    case RTOC_OPT_LINEARIZE_FUSED: *value = c->linearize_fused; return RTOC_OK;
+    case RTOC_OPT_CONE_JACOBIAN: *value = c->exact_cone_jacobian; return RTOC_OK;
+    default: return RTOC_ERR_BAD_ARG;   // the double-valued options (RTOC_OPT_MAX_DTS0, RTOC_OPT_CONTACT_INV_DAMPING)
   }
 }
 
@@ -739,6 +747,10 @@ int rtoc_set_option(rtoc_ctx* c, int option, int64_t value) {
     case RTOC_OPT_CONDENSE_SPLIT:
       if (value != 0 && value != 1) return RTOC_ERR_BAD_ARG;
       c->condense_split = (int)value;
+      return RTOC_OK;
+    case RTOC_OPT_BACKWARD_REGISTER:
+      if (value != 0 && value != 1) return RTOC_ERR_BAD_ARG;
+      c->bwd_register = (int)value;
       return RTOC_OK;
     case RTOC_OPT_GRAPH:
       if (value != 0 && value != 1) return RTOC_ERR_BAD_ARG;
@@ -995,8 +1007,59 @@ static bool fxx_structured(rtoc_ctx* c) {
   return c->fxx_state == 1;
 }
 
+// RTOC_OPT_BACKWARD_REGISTER: the register-resident kernel (riccati_backward_rv.hpp) walks the stretches of the horizon between
+// switching-constraint grid points; those grid points are single launches of the tile-split kernel in its one-stage mode, with
+// the Riccati records as its value records (P+ / s+ of grid point st + 1 are what either kernel left there).
+static bool rv_applies(const rtoc_ctx* c) {
+  return c->bwd_register && c->ks->bwd_rv && c->h_grid && !c->writeback && !c->d_prof && !grid_has_sto(c) &&
+         c->bwd_variant == ((c->ks->nvariants >= 3) ? c->ks->nvariants - 1 : 0);   // (an explicit RTOC_OPT_BACKWARD_WAVES keeps its kernel)
+}
+static int launch_backward_rv(rtoc_ctx* c, int first, int end, hipStream_t stream) {
+  const KernelSet* ks = c->ks;
+  const int N = c->nstages - 1, nb = end - first;
+  BwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.kkt = c->buf[RTOC_BUF_KKT];
+  a.kkt_rw = c->buf[RTOC_BUF_KKT];
+  a.ric = c->buf[RTOC_BUF_RIC];
+  a.grid = c->d_grid;
+  a.status = c->d_status;
+  a.nstages = c->nstages;
+  a.batch = end;
+  a.first = first;
+  a.max_dts0 = c->max_dts0;
+  const int v1 = ks->scan_policy_variant;
+  auto constrained = [&](int st) { return c->h_grid[st].type != RTOC_GRID_IMPACT && c->h_grid[st].dims > 0; };
+  auto one_stage = [&](int st) {   // tile-split kernel, grid point st only (st == N: the terminal record)
+    BwdArgs o = a;
+    o.scan_ps = c->buf[RTOC_BUF_RIC] + c->L.ric.off[RTOC_RIC_P];
+    o.scan_ps_stride = c->L.ric.stride;
+    o.scan_ps_soff = c->L.ric.off[RTOC_RIC_S] - c->L.ric.off[RTOC_RIC_P];
+    o.seg_hi = o.seg_lo = st;
+    hipLaunchKernelGGL(ks->bwd[v1], dim3(nb, 1), dim3(64 * ks->bwd_waves[v1]), ks->bwd_lds[v1], stream, o);
+  };
+  if (N == 0 || constrained(N - 1)) one_stage(N);   // nobody else writes the terminal record then
+  int hi = N - 1;
+  while (hi >= 0) {
+    if (constrained(hi)) {
+      one_stage(hi);
+      --hi;
+      continue;
+    }
+    int lo = hi;
+    while (lo > 0 && !constrained(lo - 1)) --lo;
+    a.seg_hi = hi;
+    a.seg_lo = lo;
+    hipLaunchKernelGGL(ks->bwd_rv, dim3(nb), dim3(64), ks->bwd_rv_lds, stream, a);
+    hi = lo - 1;
+  }
+  HIP_TRY(hipGetLastError());
+  return RTOC_OK;
+}
+
 static int launch_backward_range(rtoc_ctx* c, int first, int end, hipStream_t stream) {
   if (scan_applies(c)) return launch_backward_scan(c, first, end, stream);
+  if (rv_applies(c)) return launch_backward_rv(c, first, end, stream);
   BwdArgs a;
   memset(&a, 0, sizeof(a));
   a.kkt = c->buf[RTOC_BUF_KKT];
