@@ -99,6 +99,16 @@ __device__ __forceinline__ void rv_lds_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// cycle stamps of instance 0 (tools/phase_profile_rv.py; compiled in with make PROF=1 only)
+#ifdef RTOC_ENABLE_PROF
+#define RV_PROF(k)                                                                                        \
+  do {                                                                                                    \
+    if (a.prof && b == 0 && lane0 == 0) a.prof[st * 32 + (k)] = (long long)__builtin_readcyclecounter(); \
+  } while (0)
+#else
+#define RV_PROF(k) do { } while (0)
+#endif
+
 template <int NV, int NU, int NS>
 __global__ __launch_bounds__(64, 2) void riccati_backward_rv_kernel(BwdArgs a) {
   using C = RvCfg<NV, NU>;
@@ -214,11 +224,14 @@ __global__ __launch_bounds__(64, 2) void riccati_backward_rv_kernel(BwdArgs a) {
     li = lane & 15;
     q = lane >> 4;
     const bool impact = __builtin_amdgcn_readlane(gv_ahead, 0) == RTOC_GRID_IMPACT;
+    const int ns = impact ? 0 : __builtin_amdgcn_readlane(gv_ahead, 5);   // rtoc_grid::dims: rows of the switching constraint
     const double* kr = a.kkt + kinst + (size_t)st * KL.stride;
     double* rr = a.ric + rinst + (size_t)st * RL.stride;
+    RV_PROF(0);
     // everything this stage reads from LDS or was promised in registers has landed (DMA of A and the strip, Qxu^T, the grid
     // descriptor); the stores of the previous stage (K, k, s) have left too
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    RV_PROF(1);
     gv_ahead = reinterpret_cast<const int*>(a.grid + (st > lo ? st - 1 : st))[lane & 7];
 
     // ---- Qxx of this stage -> accumulators of the F product (upper tiles; off-diagonal ones symmetrised,
@@ -250,6 +263,7 @@ __global__ __launch_bounds__(64, 2) void riccati_backward_rv_kernel(BwdArgs a) {
           }
     }
 
+    RV_PROF(2);
     // ================= PB = P+[:, v] Bv (controls shifted by SCOL lanes), G = Quu + Bv^T PB[v, :] ==================
     d4 acc[T];
     double bts[KSU];   // Bv^T s+_v, rider column 0 of the G product (valid on lanes li == 0)
@@ -285,6 +299,7 @@ __global__ __launch_bounds__(64, 2) void riccati_backward_rv_kernel(BwdArgs a) {
         bts[r] = gacc[r];
       }
     }
+    RV_PROF(3);
     // ---- P of grid point st + 1 -> HBM, from the registers that still hold it as P+ (element (i, j) is written
     //      through its mirror (j, i): li runs along the contiguous index) ----
     if (st < hi) {
@@ -299,6 +314,7 @@ __global__ __launch_bounds__(64, 2) void riccati_backward_rv_kernel(BwdArgs a) {
             if (i < NX && j < NX) pw[j + i * NX] = pp[kt][mt][r];
           }
     }
+    RV_PROF(4);
     if (!impact) {
       rv_lds_sync();
       // LLT(G) (riccati_factorizer.cpp:49) and Y = L^-1 in the same instruction stream; L itself is not used again
@@ -306,6 +322,7 @@ __global__ __launch_bounds__(64, 2) void riccati_backward_rv_kernel(BwdArgs a) {
       rv_lds_sync();
     }
 
+    RV_PROF(5);
     // ================= column tile by column tile: W[:, t] = [P+; PB^T] [A | Fx][:, t], F[c][t] += A^T[c] W[:, t] ===========
     double hT[T][KSU];   // H^T = Qxu^T + PB^T A (rows NX.. of W), B fragments of the policy product
     double lup[KSU];     // lu' = lu - Bv^T s+_v + PB^T Fx on lanes li == SCOL
@@ -356,6 +373,7 @@ __global__ __launch_bounds__(64, 2) void riccati_backward_rv_kernel(BwdArgs a) {
           f[g / 4][T - 1][g % 4] = __builtin_fma(-m_eq, lxv, m_lt * f[g / 4][T - 1][g % 4]);
         }
       }
+      RV_PROF(6 + 2 * t);
 #pragma unroll
       for (int ks = 0; ks < KSU; ++ks) hT[t][ks] = w[T - 1][RS + ks];
       // F[c][t] += A^T[c] W[:, t]: A fragment A[k = 4g + q][m = 16c + li] (the same LDS words as above), B fragment W in its C layout
@@ -377,6 +395,7 @@ __global__ __launch_bounds__(64, 2) void riccati_backward_rv_kernel(BwdArgs a) {
         }
         __builtin_amdgcn_sched_barrier(0);
       }
+      RV_PROF(7 + 2 * t);
     }
 
     // ---- A, Bv, Quu and the vectors of this stage have been read for the last time: the record of the next grid point ----
@@ -387,6 +406,7 @@ __global__ __launch_bounds__(64, 2) void riccati_backward_rv_kernel(BwdArgs a) {
     }
     asm volatile("" ::: "memory");
 
+    RV_PROF(12);
     // ================= policy: Z^T = Y [H^T | -lu'],  [K | -k] = -Y^T Z^T  (riccati_factorizer.cpp:55-56) ============
     if (!impact) {
       d4 zt[T], kk[T];
@@ -412,10 +432,122 @@ __global__ __launch_bounds__(64, 2) void riccati_backward_rv_kernel(BwdArgs a) {
           if (c == T - 1) bv = (li < SCOL) ? bv : ((li == SCOL) ? -lup[ks] : 0.0);
           zt[c] = mfma16(y1[ks], bv, zt[c]);
         }
+      d4 ys[T];
+#pragma unroll
+      for (int c = 0; c < T; ++c) ys[c] = zt[c];
+      if constexpr (NS > 0) {
+        if (ns > 0) {
+          // ---- switching constraint (riccati_factorizer.cpp:58-89) in factorised form.  With Zh = Z^T above (rider column: -L^-1 lu'),
+          //      Zd = Y Phiu^T, S = Phiu G^-1 Phiu^T = Zd^T Zd = Ls Ls^T, Ws = Ls^-1:
+          //        Eh = Ws (Zd^T Zh - [Phix | -Pres]),   M = -Ws^T Eh  (rider column: -m),   Ys = Zh + Zd M,   K = -Y^T Ys,
+          //        K^T G K + K^T Phiu^T M + M^T Phiu K = Zh^T Zh - Eh^T Eh,
+          //      so the update of F (and, in its column NX, s -= Phix^T m + H k) is F -= Zh^T Zh, F += Eh^T Eh: every product runs
+          //      from accumulators (tools/rv_model.py checks the identities against the oracle); LDS: S, Ls, Ws in the transpose scratch ----
+          constexpr int NSK = (NS + 3) / 4;
+          static_assert(NS <= 16 && 3 * C::pad8(NS * NS) + C::pad8(NS) <= 2 * SCR_TILE, "S, Ls, Ws and 1/diag(Ls) in the transpose scratch");
+          double* const sS = scr;
+          double* const sLs = scr + C::pad8(NS * NS);
+          double* const sWs = scr + 2 * C::pad8(NS * NS);
+          double* const sLsInv = scr + 3 * C::pad8(NS * NS);
+          d4 t1[T];
+          {
+            const double* px_ = kr + KL.off[RTOC_KKT_PHIX];
+            const double* pr_ = kr + KL.off[RTOC_KKT_PRES];
+#pragma unroll
+            for (int c = 0; c < T; ++c)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int l = q + 4 * r, x = 16 * c + li;
+                if (4 * r >= NS) {
+                  t1[c][r] = 0.0;
+                  continue;
+                }
+                const bool okl = l < ns;
+                const bool isx = (c < T - 1) || li < SCOL;
+                const double vx = px_[(okl ? l : 0) + (isx ? x : 0) * NS];
+                double v = (okl && isx) ? -vx : 0.0;
+                if (c == T - 1) {
+                  const double vp = pr_[okl ? l : 0];
+                  v = (okl && li == SCOL) ? vp : v;
+                }
+                t1[c][r] = v;
+              }
+          }
+          double pu[KSU];
+#pragma unroll
+          for (int ks = 0; ks < KSU; ++ks) {
+            const bool ok = li < ns;
+            const double v = kr[KL.off[RTOC_KKT_PHIU] + (ok ? li : 0) + (4 * ks + q) * NS];   // Phiu[l = li][u = 4 ks + q]
+            pu[ks] = ok ? v : 0.0;
+          }
+          d4 zd = zero4(), zdt = zero4(), sacc = zero4();
+#pragma unroll
+          for (int ks = 0; ks < KSU; ++ks) {
+            zd = mfma16(y1[ks], pu[ks], zd);     // Zd = Y Phiu^T            (rows u, columns l)
+            zdt = mfma16(pu[ks], y1[ks], zdt);   // Zd^T = Phiu Y^T          (rows l, columns u)
+          }
+#pragma unroll
+          for (int ks = 0; ks < KSU; ++ks) sacc = mfma16(zd[ks], zd[ks], sacc);   // S = Zd^T Zd
+#pragma unroll
+          for (int r = 0; r < NSK; ++r) {
+            const int i = q + 4 * r;
+            if (i < NS && li < NS) sS[i + li * NS] = sacc[r];
+          }
+#pragma unroll
+          for (int ks = 0; ks < KSU; ++ks)
+#pragma unroll
+            for (int c = 0; c < T; ++c) t1[c] = mfma16(zd[ks], zt[c][ks], t1[c]);   // Zd^T Zh - [Phix | -Pres]
+          rv_lds_sync();
+          if (wave_llt_inv<NS, NS>(sS, sLs, sLsInv, sWs, ns, lane)) stat |= RTOC_STAT_S_NOT_SPD;
+          rv_lds_sync();
+          d4 eh[T], mm[T];
+#pragma unroll
+          for (int c = 0; c < T; ++c) {
+            eh[c] = zero4();
+            mm[c] = zero4();
+          }
+#pragma unroll
+          for (int ks = 0; ks < NSK; ++ks) {
+            const bool ok = li < NS && 4 * ks + q < NS;
+            const double v = sWs[(ok ? li : 0) + (ok ? 4 * ks + q : 0) * NS];      // Ws[l = li][l' = 4 ks + q]
+            const double av = ok ? v : 0.0;
+#pragma unroll
+            for (int c = 0; c < T; ++c) eh[c] = mfma16(av, t1[c][ks], eh[c]);
+          }
+#pragma unroll
+          for (int ks = 0; ks < NSK; ++ks) {
+            const bool ok = li < NS && 4 * ks + q < NS;
+            const double v = sWs[(ok ? 4 * ks + q : 0) + (ok ? li : 0) * NS];      // Ws[l' = 4 ks + q][l = li]
+            const double av = ok ? -v : 0.0;
+#pragma unroll
+            for (int c = 0; c < T; ++c) mm[c] = mfma16(av, eh[c][ks], mm[c]);       // M = -Ws^T Eh
+          }
+#pragma unroll
+          for (int ks = 0; ks < NSK; ++ks)
+#pragma unroll
+            for (int c = 0; c < T; ++c) {
+              ys[c] = mfma16(zdt[ks], mm[c][ks], ys[c]);                             // Ys = Zh + Zd M
+#pragma unroll
+              for (int t = c; t < T; ++t) f[c][t] = mfma16(eh[c][ks], eh[t][ks], f[c][t]);   // F += Eh^T Eh
+            }
+          // M[l = q + 4r][x = 16c + li] -> HBM (ns x NX, ld NS); column NX is -m
+          double chkm = 0.0;
+#pragma unroll
+          for (int c = 0; c < T; ++c)
+#pragma unroll
+            for (int r = 0; r < NSK; ++r) {
+              const int l = q + 4 * r, x = 16 * c + li;
+              if (l < ns && x < NX) rr[RL.off[RTOC_RIC_M] + l + x * NS] = mm[c][r];
+              if (c == T - 1 && l < ns && li == SCOL) rr[RL.off[RTOC_RIC_MV] + l] = -mm[c][r];
+              chkm = __builtin_fma(mm[c][r], 0.0, chkm);
+            }
+          if (is_bad(chkm)) stat |= RTOC_STAT_NAN;
+        }
+      }
 #pragma unroll
       for (int ks = 0; ks < KSU; ++ks)
 #pragma unroll
-        for (int c = 0; c < T; ++c) kk[c] = mfma16(y2[ks], zt[c][ks], kk[c]);
+        for (int c = 0; c < T; ++c) kk[c] = mfma16(y2[ks], ys[c][ks], kk[c]);
       // K[u = q + 4r][x = 16c + li] -> HBM (K row-major, lqr_policy.hpp:18-19); column NX is -k
       double chk = 0.0;
 #pragma unroll
@@ -428,6 +560,7 @@ __global__ __launch_bounds__(64, 2) void riccati_backward_rv_kernel(BwdArgs a) {
           chk = __builtin_fma((x <= NX) ? kk[c][r] : 0.0, 0.0, chk);
         }
       if (is_bad(chk)) stat |= RTOC_STAT_NAN;
+      RV_PROF(13);
       // F -= K^T G K = Z Z^T (brrf.cpp:82-84); column NX: + H G^-1 lu' = - H k
 #pragma unroll
       for (int ks = 0; ks < KSU; ++ks)
@@ -437,6 +570,7 @@ __global__ __launch_bounds__(64, 2) void riccati_backward_rv_kernel(BwdArgs a) {
           for (int t = c; t < T; ++t) f[c][t] = mfma16(-zt[c][ks], zt[t][ks], f[c][t]);
     }
 
+    RV_PROF(14);
     // ================= s <- column NX of F;  P <- sym(F) as nine operand tiles ==================
 #pragma unroll
     for (int g = 0; g < KG; ++g) sv[g] = (li == SCOL) ? f[g / 4][T - 1][g % 4] : 0.0;
@@ -477,6 +611,7 @@ __global__ __launch_bounds__(64, 2) void riccati_backward_rv_kernel(BwdArgs a) {
         rv_lds_sync();
       }
     }
+    RV_PROF(15);
     // ---- s (and the zero switching-time fields of the record) -> HBM ----
     if (li == SCOL) {
 #pragma unroll
@@ -487,6 +622,7 @@ __global__ __launch_bounds__(64, 2) void riccati_backward_rv_kernel(BwdArgs a) {
       rr[RL.off[RTOC_RIC_PHI] + lane] = 0.0;
     }
     if (lane < 5) rr[RL.off[RTOC_RIC_SCAL] + lane] = 0.0;
+    RV_PROF(16);
   }
 
   // ---- P of the last grid point of the segment ----

@@ -1007,11 +1007,9 @@ static bool fxx_structured(rtoc_ctx* c) {
   return c->fxx_state == 1;
 }
 
-// RTOC_OPT_BACKWARD_REGISTER: the register-resident kernel (riccati_backward_rv.hpp) walks the stretches of the horizon between
-// switching-constraint grid points; those grid points are single launches of the tile-split kernel in its one-stage mode, with
-// the Riccati records as its value records (P+ / s+ of grid point st + 1 are what either kernel left there).
+// RTOC_OPT_BACKWARD_REGISTER: the register-resident kernel (riccati_backward_rv.hpp), one launch for the whole horizon.
 static bool rv_applies(const rtoc_ctx* c) {
-  return c->bwd_register && c->ks->bwd_rv && c->h_grid && !c->writeback && !c->d_prof && !grid_has_sto(c) &&
+  return c->bwd_register && c->ks->bwd_rv && c->h_grid && c->nstages >= 2 && !c->writeback && !grid_has_sto(c) &&
          c->bwd_variant == ((c->ks->nvariants >= 3) ? c->ks->nvariants - 1 : 0);   // (an explicit RTOC_OPT_BACKWARD_WAVES keeps its kernel)
 }
 static int launch_backward_rv(rtoc_ctx* c, int first, int end, hipStream_t stream) {
@@ -1028,31 +1026,11 @@ static int launch_backward_rv(rtoc_ctx* c, int first, int end, hipStream_t strea
   a.batch = end;
   a.first = first;
   a.max_dts0 = c->max_dts0;
-  const int v1 = ks->scan_policy_variant;
-  auto constrained = [&](int st) { return c->h_grid[st].type != RTOC_GRID_IMPACT && c->h_grid[st].dims > 0; };
-  auto one_stage = [&](int st) {   // tile-split kernel, grid point st only (st == N: the terminal record)
-    BwdArgs o = a;
-    o.scan_ps = c->buf[RTOC_BUF_RIC] + c->L.ric.off[RTOC_RIC_P];
-    o.scan_ps_stride = c->L.ric.stride;
-    o.scan_ps_soff = c->L.ric.off[RTOC_RIC_S] - c->L.ric.off[RTOC_RIC_P];
-    o.seg_hi = o.seg_lo = st;
-    hipLaunchKernelGGL(ks->bwd[v1], dim3(nb, 1), dim3(64 * ks->bwd_waves[v1]), ks->bwd_lds[v1], stream, o);
-  };
-  if (N == 0 || constrained(N - 1)) one_stage(N);   // nobody else writes the terminal record then
-  int hi = N - 1;
-  while (hi >= 0) {
-    if (constrained(hi)) {
-      one_stage(hi);
-      --hi;
-      continue;
-    }
-    int lo = hi;
-    while (lo > 0 && !constrained(lo - 1)) --lo;
-    a.seg_hi = hi;
-    a.seg_lo = lo;
-    hipLaunchKernelGGL(ks->bwd_rv, dim3(nb), dim3(64), ks->bwd_rv_lds, stream, a);
-    hi = lo - 1;
-  }
+  a.prof = c->d_prof;
+  // one launch for the whole horizon: regular, lift, impact and switching-constraint grid points are all the kernel's own
+  a.seg_hi = N - 1;
+  a.seg_lo = 0;
+  if (N >= 1) hipLaunchKernelGGL(ks->bwd_rv, dim3(nb), dim3(64), ks->bwd_rv_lds, stream, a);
   HIP_TRY(hipGetLastError());
   return RTOC_OK;
 }

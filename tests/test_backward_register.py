@@ -149,7 +149,9 @@ def test_register_sweep_repeats_bit_for_bit():
             assert int((ctx.status() != 0).sum()) == 0
             if first is None:
                 first = ric.clone()
-                assert bool(torch.isfinite(first[:, :, :L.ric.off[2]]).all())   # P, s of every grid point written
+                nx, o = 2 * dims.nv, L.ric.off
+                assert bool(torch.isfinite(first[:, :, o[0]:o[0] + nx * nx]).all())   # P, s of every grid point written
+                assert bool(torch.isfinite(first[:, :, o[1]:o[1] + nx]).all())
             else:
                 ne = first.view(torch.int64) != ric.view(torch.int64)
                 ne &= ~(torch.isnan(first) & torch.isnan(ric))   # fields this grid never writes stay NaN in both

@@ -24,6 +24,8 @@ res = {}
 for name, on in (("role-split", False), ("register", True), ("role-split", False), ("register", True)):
     ctx.set_backward_register(on)
     ric.fill_(float("nan"))
+    torch.cuda.synchronize()   # (torch's stream, not the context's)
+    ctx.clear_status()
     for _ in range(5):
         ctx.riccati_backward()
     ctx.sync()

@@ -42,9 +42,10 @@ def row_shift(v, n):
     return out
 
 
-def stage(NV, NU, pp, sv, A, Bv, Qxx, Qxu, Quu, Fx, lx, lu, impact):
+def stage(NV, NU, pp, sv, A, Bv, Qxx, Qxu, Quu, Fx, lx, lu, impact, sc=None):
     """pp[kt][mt]: (64,4) tiles of P+ in C layout, zero outside NX x NX; sv[c]: (64,4), s+[16c + 4r + q] on lanes li == SCOL.
-    Returns (pp_new, sv_new, K, k)."""
+    sc = (Phix [ns x NX], Phiu [ns x NU], Pres [ns]) on a grid point with a switching constraint (riccati_factorizer.cpp:58-89).
+    Returns (pp_new, sv_new, K, k) and, with sc, (.., M, m)."""
     NX = 2 * NV
     T = (NX + 15) // 16                      # tiles of the state
     TM = (NX + NU + 15) // 16                # row tiles of S = [P+; PB^T]
@@ -160,11 +161,79 @@ def stage(NV, NU, pp, sv, A, Bv, Qxx, Qxu, Quu, Fx, lx, lu, impact):
                     b = np.where(LI < SCOL, b, np.where(LI == SCOL, -lup[:, ks], 0.0))
                 b = np.where(u < NU, b, 0.0)
                 zt[c] = mfma16(a, b, zt[c])
+        ys = zt
+        Mout = mv = None
+        if sc is not None:
+            # ---- switching constraint, factorised: with Zd = Y Phiu^T, S = Zd^T Zd = Ls Ls^T, Ws = Ls^-1,
+            #      Eh = Ws (Zd^T Zh - [Phix | -Pres]),  M = -Ws^T Eh,  Ys = Zh + Zd M,  K = -Y^T Ys,  F -= Zh^T Zh - Eh^T Eh ----
+            Phix, Phiu, Pres = sc
+            ns = Phix.shape[0]
+            zd, zdt = z4(), z4()
+            for ks in range(KSU):
+                u = 4 * ks + Q
+                # zd = Y Phiu^T: A = Y[m = i = li][k = u], B = Phiu^T[k = u][n = l = li]
+                a = np.where((u < NU) & (LI < NU), Y[np.clip(LI, 0, NU - 1), np.clip(u, 0, NU - 1)], 0.0)
+                b = np.where((u < NU) & (LI < ns), Phiu[np.clip(LI, 0, ns - 1), np.clip(u, 0, NU - 1)], 0.0)
+                zd = mfma16(a, b, zd)
+                # zdt = Phiu Y^T: A = Phiu[m = l = li][k = u'], B = Y^T[k = u'][n = u = li] = Y[li][u']
+                a = np.where((u < NU) & (LI < ns), Phiu[np.clip(LI, 0, ns - 1), np.clip(u, 0, NU - 1)], 0.0)
+                b = np.where((u < NU) & (LI < NU), Y[np.clip(LI, 0, NU - 1), np.clip(u, 0, NU - 1)], 0.0)
+                zdt = mfma16(a, b, zdt)
+            S = z4()
+            for ks in range(KSU):
+                S = mfma16(zd[:, ks], zd[:, ks], S)       # A' = C^T: Zd^T (m = l, k = u); B' = C: Zd (k = u, n = l)
+            Sm = np.eye(16)
+            for r in range(4):
+                for lane in range(64):
+                    i, j = Q[lane] + 4 * r, LI[lane]
+                    if i < ns and j < ns:
+                        Sm[i, j] = S[lane, r]
+            Ws = np.linalg.inv(np.linalg.cholesky(Sm[:ns, :ns]))        # wave_llt_inv
+            Wsp = np.zeros((16, 16))
+            Wsp[:ns, :ns] = Ws
+            NSK = (ns + 3) // 4
+            t1 = [z4() for _ in range(T)]
+            for c in range(T):
+                for r in range(4):
+                    l, x = Q + 4 * r, 16 * c + LI
+                    v = np.where((l < ns) & (x < NX), -Phix[np.clip(l, 0, ns - 1), np.clip(x, 0, NX - 1)], 0.0)
+                    if c == T - 1:
+                        v = np.where((l < ns) & (LI == SCOL), Pres[np.clip(l, 0, ns - 1)], v)
+                    t1[c][:, r] = v
+            for ks in range(KSU):
+                for c in range(T):
+                    t1[c] = mfma16(zd[:, ks], zt[c][:, ks], t1[c])
+            eh = [z4() for _ in range(T)]
+            mm = [z4() for _ in range(T)]
+            for ks in range(NSK):
+                l2 = 4 * ks + Q
+                a = np.where(l2 < 16, Wsp[LI, np.clip(l2, 0, 15)], 0.0)        # Ws[m = l = li][k = l']
+                for c in range(T):
+                    eh[c] = mfma16(a, t1[c][:, ks], eh[c])
+            for ks in range(NSK):
+                l2 = 4 * ks + Q
+                a = -Wsp[np.clip(l2, 0, 15), LI]                                # -Ws^T[m = l = li][k = l'] = -Ws[l'][l]
+                for c in range(T):
+                    mm[c] = mfma16(a, eh[c][:, ks], mm[c])
+            ys = [zt[c].copy() for c in range(T)]
+            for ks in range(NSK):
+                for c in range(T):
+                    ys[c] = mfma16(zdt[:, ks], mm[c][:, ks], ys[c])             # A' = C^T of zdt: Zd (m = u, k = l)
+            Mout = np.zeros((ns, NX))
+            mv = np.zeros(ns)
+            for c in range(T):
+                for r in range(4):
+                    for lane in range(64):
+                        l, x = Q[lane] + 4 * r, 16 * c + LI[lane]
+                        if l < ns and x < NX:
+                            Mout[l, x] = mm[c][lane, r]
+                        if l < ns and x == NX:
+                            mv[l] = -mm[c][lane, r]
         for ks in range(KSU):
             i = 4 * ks + Q
             a = np.where((i < NU) & (LI < NU), -Y[np.clip(i, 0, NU - 1), np.clip(LI, 0, NU - 1)], 0.0)      # -Y^T[u = li][i]
             for c in range(T):
-                kk[c] = mfma16(a, zt[c][:, ks], kk[c])
+                kk[c] = mfma16(a, ys[c][:, ks], kk[c])
         for c in range(T):
             for r in range(4):
                 u, x = Q + 4 * r, 16 * c + LI
@@ -178,6 +247,11 @@ def stage(NV, NU, pp, sv, A, Bv, Qxx, Qxu, Quu, Fx, lx, lu, impact):
             for c in range(T):
                 for t in range(c, T):
                     f[c][t] = mfma16(-zt[c][:, ks], zt[t][:, ks], f[c][t])
+        if sc is not None:
+            for ks in range(NSK):
+                for c in range(T):
+                    for t in range(c, T):
+                        f[c][t] = mfma16(eh[c][:, ks], eh[t][:, ks], f[c][t])
     # ---- s+ <- column NX; P+ <- sym(F): upper tiles as they are, diagonal tiles mirrored, lower tiles transposed ----
     sv_new = [np.where((LI == SCOL)[:, None] & ((16 * c + 4 * np.arange(4)[None, :] + Q[:, None]) < NX), f[c][T - 1], 0.0) for c in range(T)]
 
@@ -208,6 +282,8 @@ def stage(NV, NU, pp, sv, A, Bv, Qxx, Qxu, Quu, Fx, lx, lu, impact):
             else:
                 pn[c][t] = mask(f[c][t], c, t)
                 pn[t][c] = mask(transpose_tile(mask(f[c][t], c, t)), t, c)
+    if sc is not None:
+        return pn, sv_new, K, kv, Mout, mv
     return pn, sv_new, K, kv
 
 
@@ -249,7 +325,7 @@ def main():
     kk = kkt.copy()
     orc.riccati_backward(L, grids, kk, ric)
     worst = 0.0
-    for st in (45, 35, 20):
+    for st in (45, 35, 33, 20, 15):
         g = grids[st]
         rec, nxt, out = kkt[st], ric[st + 1], ric[st]
         P1 = Rr.f(nxt, "P").copy()
@@ -262,8 +338,12 @@ def main():
                 i = 16 * c + 4 * r + Q
                 sv[c][:, r] = np.where((LI == SCOL) & (i < NX), s1[np.clip(i, 0, NX - 1)], 0.0)
         f = lambda n: Kr.f(rec, n).copy()
-        pn, svn, K, k = stage(NV, NU, to_tiles(P1, NX), sv, f("Fxx"), f("Fvu"), f("Qxx"), f("Qxu"), f("Quu"), f("Fx"), f("lx"), f("lu"),
-                              g.type == GRID_IMPACT)
+        sc = None
+        if g.type != GRID_IMPACT and g.dims > 0:
+            sc = (f("Phix")[:g.dims], f("Phiu")[:g.dims], f("Pres")[:g.dims])
+        out_ = stage(NV, NU, to_tiles(P1, NX), sv, f("Fxx"), f("Fvu"), f("Qxx"), f("Qxu"), f("Quu"), f("Fx"), f("lx"), f("lu"),
+                     g.type == GRID_IMPACT, sc)
+        pn, svn, K, k = out_[:4]
         P = from_tiles(pn, NX)
         s = np.zeros(NX)
         for c in range(T):
@@ -278,7 +358,10 @@ def main():
         if g.type != GRID_IMPACT:
             errs["K"] = np.abs(K.T - Rr.f(out, "K")).max() / np.abs(Rr.f(out, "K")).max()
             errs["k"] = np.abs(k - Rr.f(out, "k")).max() / max(np.abs(Rr.f(out, "k")).max(), 1e-300)
-        print("stage", st, "type", g.type, {n: float("%.2e" % v) for n, v in errs.items()})
+        if sc is not None:
+            errs["M"] = np.abs(out_[4] - Rr.f(out, "M")[:g.dims]).max() / np.abs(Rr.f(out, "M")[:g.dims]).max()
+            errs["m"] = np.abs(out_[5] - Rr.f(out, "m")[:g.dims]).max() / max(np.abs(Rr.f(out, "m")[:g.dims]).max(), 1e-300)
+        print("stage", st, "type", g.type, "dims", g.dims, {n: float("%.2e" % v) for n, v in errs.items()})
         worst = max(worst, max(v for n, v in errs.items()))
     assert worst < 1e-10, worst
     print("rv lane model: ok")
