@@ -26,7 +26,7 @@ if ROOT not in sys.path:
 PER_GPU_BATCH = 4096
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 F64_MFMA_PEAK_TFLOPS = 78.6  # MI355X spec sheet, dense fp64 matrix (= the fp64 vector rate)
-PROFILE_ROUND = "r04"
+PROFILE_ROUND = "r05"
 
 
 def kernel_source_hash():
@@ -358,7 +358,7 @@ def compact_line(res):
     rf = res.get("roofline")
     if rf is not None:
         o = pick(rf, ("bound", "kernel", "kernel_ms", "achieved", "peak", "unit", "frac", "algorithmic_bytes_per_launch", "traffic",
-                      "forward_kernel_ms", "forward_frac", "mfma_f64_frac", "measured_stream_read_GBs"))
+                      "forward_kernel_ms", "forward_frac", "mfma_f64_frac", "measured_stream_read_GBs", "role_split_kernel_ms"))
         # the counter traffic comes from the committed rocprofv3 --pmc passes of these kernel sources (hash-guarded), never
         # from inside the timed process
         o["traffic_measured_in_this_run"] = False
@@ -707,7 +707,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=10)   # (the clock settles over the first ~8 launches: profiles/r03_dvfs_probe.txt)
     ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="instances per GPU")
     ap.add_argument("--waves", type=int, default=0, help="backward-kernel waves per instance (0=default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -818,6 +818,16 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     bad = int((ctx.status() != 0).sum())
+    # the role-split kernel (the default up to round 4; what RTOC_OPT_BACKWARD_REGISTER = 0 runs) on the same records, for the record
+    ms_b_rs = None
+    if args.waves == 0:
+        from robotoc_amd.types import OPT_BACKWARD_REGISTER
+        if ctx.get_option(OPT_BACKWARD_REGISTER):
+            ctx.set_backward_register(False)
+            ctx.time_phase(0, 3)
+            ms_b_rs = ctx.time_phase(0, 10)
+            ctx.set_backward_register(True)
+            bad += int((ctx.status() != 0).sum())
     distinct = int(torch.unique(kkt_t[:, 0, L.kkt.off[2]]).numel())  # Qxx(0,0) of stage 0 of every instance
 
     # attainable HBM bandwidth on this box: device-to-device copy of 1 GiB (read + write), same run
@@ -1234,7 +1244,9 @@ def main():
         bytes_f = algorithmic_bytes(L, grids, batch, "forward")
         fl_b = backward_flops(L, grids, batch)
         ach = bytes_b / (ms_b * 1e-3) / 1e9
-        kname = "riccati_backward_rs4_kernel" if args.waves in (0, 8) else "riccati_backward_kernel"
+        from robotoc_amd.types import OPT_BACKWARD_REGISTER
+        kname = ("riccati_backward_rv_kernel" if args.waves == 0 and ctx.get_option(OPT_BACKWARD_REGISTER) else
+                 "riccati_backward_rs4_kernel" if args.waves in (0, 8) else "riccati_backward_kernel")
         res = {
             "metric": "riccati_sweeps_per_sec",
             "value": value,
@@ -1269,6 +1281,7 @@ def main():
                          "frac_at_rocprof_all_launch_average": (lambda r: (bytes_b / (r["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if r else None)(
                              rocprof_kernel_ms(kname) if batch == PER_GPU_BATCH else None),
                          "algorithmic_bytes_per_launch": bytes_b,
+                         "role_split_kernel_ms": ms_b_rs,
                          "mfma_f64_achieved_TFLOPs": fl_b / (ms_b * 1e-3) / 1e12,
                          "mfma_f64_frac": fl_b / (ms_b * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS,
                          "forward_kernel_ms": ms_f,

@@ -157,12 +157,12 @@ enum rtoc_option {
                       * holding FrictionCone AND ImpactFrictionCone, examples/anymal/run.cpp:173-181); 0: impact grids carry no
                       * cone rows (FrictionCone only, examples/anymal/trot.cpp:134-146) -- condensation, expansion, step
                       * sizes, update and KKT error skip them. */
-  RTOC_OPT_BACKWARD_REGISTER = 16, /* 1: rtoc_riccati_backward runs the register-resident kernel (one wavefront per instance, P+ / s+ in
-                      * MFMA accumulators, the stage record by LDS-DMA; riccati_backward_rv.hpp) on the stretches of the horizon between
-                      * switching-constraint grid points, those grid points as single launches of the tile-split kernel.  Applies to
-                      * shapes whose stacked operand [P+; PB^T] fills its 16-row tiles (nv = 18, nu = 12), grids without switching-time
-                      * optimisation, RTOC_OPT_WRITEBACK_KKT = 0 and the default RTOC_OPT_BACKWARD_WAVES; elsewhere the option is
-                      * accepted and has no effect.  Same results to fp64 round-off (tests/test_backward_register.py). */
+  RTOC_OPT_BACKWARD_REGISTER = 16, /* 1 (default): rtoc_riccati_backward runs the register-resident kernel (one wavefront per instance,
+                      * P+ / s+ in MFMA accumulators, the stage record by LDS-DMA, switching-constraint grid points in factorised
+                      * form; riccati_backward_rv.hpp) where it applies: shapes whose stacked operand [P+; PB^T] fills its 16-row
+                      * tiles (nv = 18, nu = 12: ANYmal, A1), grids without switching-time optimisation, RTOC_OPT_WRITEBACK_KKT = 0
+                      * and the default RTOC_OPT_BACKWARD_WAVES.  Elsewhere, and with 0, the role-split / tile-split kernels run.
+                      * Same results to fp64 round-off (tests/test_backward_register.py). */
   RTOC_OPT_SWITCHING_TRANSPORT = 10 /* Free-flyer block of Phiq / Phiv / Phia in rtoc_contact_eval_kkt's switching-constraint
                       * rows.  0 (default): as the reference composes it -- it hands pinocchio::dIntegrateTransport the
                       * transposed Jacobian (robot.hxx:69-72, :88-91), which yields Pq dIntegrate^T.  1: the chain rule

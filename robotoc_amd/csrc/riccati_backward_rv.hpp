@@ -156,12 +156,18 @@ __global__ __launch_bounds__(64, 2) void riccati_backward_rv_kernel(BwdArgs a) {
       if (64 * (p + 1) <= NCH_S || n < NCH_S)   // (only the last piece is partial)
         __builtin_amdgcn_global_load_lds(kp + off, (lds_ptr_t)(smem + C::OFF_ST + 128 * p), 16, 0, 0);
     }
+    // A: CPP whole padded columns per piece (the other lanes idle), so that the per-lane source offset is the same in every
+    // piece and a piece differs from the next by a scalar: no per-piece address arithmetic on the vector unit
+    constexpr int CPP = 64 / C::HL, NPC = (NX + CPP - 1) / CPP;
+    const unsigned col0 = (unsigned)lane / C::HL, ch0 = (unsigned)lane - col0 * C::HL;
+    const unsigned voff = col0 * NX + ((ch0 < NX / 2) ? 2 * ch0 : 0);   // (the padding chunk of a column loads anything)
+    if (col0 < CPP) {
 #pragma unroll
-    for (int p = 0; p < C::PA; ++p) {
-      const int n = lane + 64 * p;
-      const int col = n / C::HL, ch = n - col * C::HL;
-      const int off = KL.off[RTOC_KKT_FXX] + ((ch < NX / 2) ? (col * NX + 2 * ch) : 0);   // the padding chunk of a column loads anything
-      if (64 * (p + 1) <= C::NCH_A || n < C::NCH_A) __builtin_amdgcn_global_load_lds(kp + off, (lds_ptr_t)(sA + 128 * p), 16, 0, 0);
+      for (int p = 0; p < NPC; ++p) {
+        const double* kpp = kp + KL.off[RTOC_KKT_FXX] + p * CPP * NX;
+        if ((p + 1) * CPP <= NX || p * CPP + (int)col0 < NX)
+          __builtin_amdgcn_global_load_lds(kpp + voff, (lds_ptr_t)(sA + p * CPP * LDP), 16, 0, 0);
+      }
     }
   };
   // Qxu^T of grid point `stage` in the C layout of the PB^T rows: hq[c][ks] = Qxu[x = 16c + li][u = 4 ks + q].  RAW: lanes beyond the
@@ -238,8 +244,10 @@ __global__ __launch_bounds__(64, 2) void riccati_backward_rv_kernel(BwdArgs a) {
     //      brrf.cpp:85 folded into the start value), used two products from here ----
     d4 f[T][T];
     {
-      const double* qx_ = kr + KL.off[RTOC_KKT_QXX] + q + li * NX;    // Qxx[i][j]
-      const double* qxt_ = kr + KL.off[RTOC_KKT_QXX] + li + q * NX;   // Qxx[j][i]
+      const double* qb_ = kr + KL.off[RTOC_KKT_QXX];
+      const unsigned lic = (li < SCOL) ? li : SCOL - 1;                  // last column tile: lanes beyond the matrix read a clamped column
+      const unsigned vx = q + li * NX, vxl = q + lic * NX;               // Qxx[i][j]: i = .. + q, j = .. + li
+      const unsigned vt = li + q * NX, vtl = lic + q * NX;               // Qxx[j][i]
 #pragma unroll
       for (int c = 0; c < T; ++c)
 #pragma unroll
@@ -252,12 +260,11 @@ __global__ __launch_bounds__(64, 2) void riccati_backward_rv_kernel(BwdArgs a) {
               f[c][t][r] = 0.0;
               continue;
             }
-            const bool okj = (t < T - 1) || li < SCOL;
-            const double v = qx_[okj ? 16 * c + 4 * r + 16 * t * NX : 0];
+            const double v = qb_[((t < T - 1) ? vx : vxl) + (16 * c + 4 * r + 16 * t * NX)];
             if (t == c) {
               f[c][t][r] = v;
             } else {
-              const double vt_ = qxt_[okj ? 16 * t + (16 * c + 4 * r) * NX : 0];
+              const double vt_ = qb_[((t < T - 1) ? vt : vtl) + (16 * t + (16 * c + 4 * r) * NX)];
               f[c][t][r] = 0.5 * (v + vt_);
             }
           }

@@ -360,6 +360,7 @@ static int create_members(rtoc_ctx* c, const rtoc_dims* dims, const KernelSet* k
   c->device = device;
   c->max_dts0 = 0.1;  // RiccatiRecursion(ocp, max_dts0 = 0.1), riccati_recursion.hpp:35
   c->bwd_variant = (ks->nvariants >= 3) ? ks->nvariants - 1 : 0;  // role-split kernel where it exists
+  c->bwd_register = 1;   // ... and the register-resident kernel wherever it applies (rv_applies)
   HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
   c->stream = c->own_stream;
   HIP_TRY(hipEventCreate(&c->ev0));

@@ -5,6 +5,7 @@ nine times out of ten with it.  These tests repeat the same launch on one contex
 the Riccati factorisation (RTOC_BUF_RIC) as well as the directions (RTOC_BUF_DIR) -- with the first run's, bit for bit.
 
 protocol under test                                   case
+  register-resident kernel (LDS-DMA, deferred P stores)  trot-register         (riccati_backward_rv.hpp, the default for this shape)
   rs4 role-split, structured Fxx (flag words, rs_sync)  trot-structured       (riccati_backward_rs.hpp, SA = true)
   rs4 role-split, dense-Fxx fallback                    trot-dense            (SA = false: RTOC_OPT_FXX_STRUCTURE = 1)
   rs4 + STO block + phase transition                    jump_sto              (riccati_sto_block.inc, riccati_pt_block.inc)
@@ -21,8 +22,9 @@ from robotoc_amd.types import (BUF_CDD, BUF_CON, BUF_CONE, BUF_DIR, BUF_DX0, BUF
 
 CASES = {
     # name: (configuration, batch, repetitions, context set-up)
-    "trot-structured": (pr.config_anymal_trot, 4096, 30, lambda c: c.set_fxx_structure(2)),
-    "trot-dense": (pr.config_anymal_trot, 4096, 30, lambda c: c.set_fxx_structure(1)),
+    "trot-register": (pr.config_anymal_trot, 4096, 30, lambda c: c.set_backward_register(True)),
+    "trot-structured": (pr.config_anymal_trot, 4096, 30, lambda c: (c.set_backward_register(False), c.set_fxx_structure(2))),
+    "trot-dense": (pr.config_anymal_trot, 4096, 30, lambda c: (c.set_backward_register(False), c.set_fxx_structure(1))),
     "jump_sto": (pr.config_anymal_jump_sto, 4096, 30, None),
     "icub32": (lambda: pr.config_icub_jump(nv=32), 1024, 20, None),
     "icub35": (lambda: pr.config_icub_jump(nv=35), 1024, 20, None),

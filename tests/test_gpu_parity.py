@@ -488,6 +488,7 @@ def test_structured_fxx_kernel_and_its_fallback(oracle, mode):
         try:
             L = ctx.L
             ctx.set_grid(grids)
+            ctx.set_backward_register(False)   # the role-split kernels are the ones with a structured and a dense form
             k = kkt.copy()
             if case == "stray_entry":
                 K.f(k[5, 11], "Fxx")[9, 3] = 1e-3  # row 9 in [NP, NV): must be a multiple of e_9 | e_27

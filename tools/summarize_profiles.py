@@ -40,10 +40,11 @@ if os.path.exists(trace):
     seq, prev_name = [], "-"
     for r in rows:
         nm = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("rtoc::", "")
-        if "riccati_backward_rs4_kernel" in nm and int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]) >= 1024:
+        if ("riccati_backward_rs4_kernel" in nm and int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]) >= 1024) or \
+                ("riccati_backward_rv_kernel" in nm and int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]) >= 4096):
             seq.append("%.3f<%s" % ((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6, prev_name.split("<")[0][:22]))
         prev_name = nm
-    lines.append("# riccati_backward_rs4_kernel at the headline batch, every launch of the trace in time order: ms<kernel in front of it")
+    lines.append("# the dominant backward kernel (riccati_backward_rv_kernel, or rs4 where RTOC_OPT_BACKWARD_REGISTER is off) at the headline batch, every launch of the trace in time order: ms<kernel in front of it")
     for i in range(0, len(seq), 8):
         lines.append("#   " + "  ".join(seq[i:i + 8]))
     lines.append("# same trace grouped by launch geometry: kernel, workgroups(x), y*z, threads, LDS bytes, scratch bytes/lane, VGPR, AGPR, SGPR, calls, avg ms, min ms, max ms"
