@@ -50,6 +50,7 @@ struct KernelSet {
   int bwd_inst[4];    // OCP instances per workgroup
   bwd_fn bwd_sa;      // structured-Fxx form of variant 3 (role-split, 4 instances per workgroup), or nullptr
   bwd_fn bwd_rv;      // register-resident kernel, one wave per instance (riccati_backward_rv.hpp), or nullptr
+  bwd_fn bwd_rv_sa;   // ... its structured-Fxx form, or nullptr
   int bwd_rv_lds;
   rtoc_record_layout kl, rl, dl, cl;  // record layouts the kernels were compiled for
   fwd_fn fwd;
@@ -113,7 +114,9 @@ inline KernelSet make_set() {
     }
   }
   if constexpr (RvCfg<NV, NU>::OK) {
-    k.bwd_rv = riccati_backward_rv_kernel<NV, NU, NS>;
+    k.bwd_rv = riccati_backward_rv_kernel<NV, NU, NS, false>;
+    if constexpr (NV % 16 == 2 && RvCfg<NV, NU>::T == 3 && NV - NU > 0 && NV - NU <= 8 && (NV - NU) % 2 == 0)
+      k.bwd_rv_sa = riccati_backward_rv_kernel<NV, NU, NS, true>;
     k.bwd_rv_lds = rv_lds_bytes<NV, NU, NS>();
   }
   constexpr int NWF = (2 * NV + NU + 63) / 64;

@@ -59,6 +59,28 @@ struct RvCfg {
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
+constexpr int RV_MAX_STAGES = 64;   // grid points of a horizon the kernel keeps a kind table for (in the slack of its LDS carve)
+
+// Streaming policy of the record traffic (every byte is touched once per sweep): RTOC_RV_NT = 1 marks the loads / DMA / stores
+// non-temporal.  Measured both ways.
+#ifndef RTOC_RV_NT
+#define RTOC_RV_NT 0
+#endif
+__device__ __forceinline__ double rv_ld(const double* p) {
+#if RTOC_RV_NT
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
+__device__ __forceinline__ void rv_st(double* p, double v) {
+#if RTOC_RV_NT
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+constexpr int RV_DMA_AUX = RTOC_RV_NT ? 2 : 0;
 
 // v <- the value `n` lanes to the RIGHT / LEFT within the 16-lane row (v_mov_b32_dpp row_shl / row_shr), 0 beyond the row.
 template <int N>
@@ -109,10 +131,21 @@ __device__ __forceinline__ void rv_lds_sync() {
 #define RV_PROF(k) do { } while (0)
 #endif
 
-template <int NV, int NU, int NS>
+// SA ("structured A", RTOC_OPT_FXX_STRUCTURE; the caller has checked it: rtoc_check_fxx_structure): rows [NP, NV) of Fxx are
+// a e_k^T | c e_k^T and rows [0, NP) are dense only in the two NP x NP corners (src/dynamics/state_equation.cpp:52-55,80-82).  Then
+//   W = [P+; PB^T] A:  for the P+ row tiles of the column tiles without riders, the k groups made of structured rows only are
+//                      skipped and the structured rows masked out of the others; their part is W[:, k] += a S[:, k],
+//                      W[:, NV + k] += c S[:, k] -- scaled copies of P+ tiles in place (a) or two lanes to the side (c);
+//   F += A^T W:        the same k groups skipped / rows masked (and the corner rows only multiplied into the corner column tiles);
+//                      their part is F[k][:] += a W[k][:], F[NV + k][:] += c W[k][:] -- the same register, or two q-groups away.
+// 114 instead of 135 MFMAs in the two NX^3 products (tools/rv_model.py --dense shows the other count).
+template <int NV, int NU, int NS, bool SA>
 __global__ __launch_bounds__(64, 2) void riccati_backward_rv_kernel(BwdArgs a) {
   using C = RvCfg<NV, NU>;
   static_assert(C::OK, "shape does not fill the tiles of the stacked operand");
+  constexpr int NP_ = NV - NU;
+  static_assert(!SA || (NV % 16 == 2 && C::T == 3 && NP_ > 0 && NP_ <= 8 && NP_ % 2 == 0),
+                "structured form: the lane shift of the c-part is NV mod 16 = 2, corner columns in tiles 0 and 1");
   constexpr int NX = C::NX, T = C::T, LDP = C::LDP, KG = C::KG, KSU = C::KSU, SCOL = C::SCOL, G0 = C::G0, GS = C::GS;
   constexpr int RS = SCOL / 4;   // first register group of the last row tile that holds PB^T rows
   constexpr rtoc_layout SL = StaticLayout<NV, NU, NS>::make();
@@ -127,6 +160,11 @@ __global__ __launch_bounds__(64, 2) void riccati_backward_rv_kernel(BwdArgs a) {
   constexpr int OFF_Y = ST_FX + 2 * CV, OFF_LINV = OFF_Y + C::pad8(NU * NU), OFF_SCR = OFF_LINV + C::pad8(NU), SCR_LD = 17,
                 SCR_TILE = C::pad8(16 * SCR_LD), LDS_DOUBLES = OFF_SCR + 2 * SCR_TILE;
   static_assert(NU * NU <= 2 * SCR_TILE, "the Cholesky factor is parked in the transpose scratch");
+  // grid-point kinds of the whole horizon, one int each (type | dims << 8), behind the carve: read with a DS instruction at the stage
+  // top.  (A vector load carried over the loop's back edge makes the compiler open every stage with s_waitcnt vmcnt(0), which also
+  // waits for the stores the counted wait below leaves in flight; a scalar load shares its counter with the LDS traffic.)
+  constexpr int OFF_GRID = LDS_DOUBLES, GRID_INTS = 2 * (20 * 1024 / 8 - LDS_DOUBLES);
+  static_assert(GRID_INTS >= 64, "room for the grid table");
   static_assert(LDS_DOUBLES * 8 <= 20 * 1024, "eight instances per CU");
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* const sA = smem + C::OFF_A;
@@ -144,6 +182,12 @@ __global__ __launch_bounds__(64, 2) void riccati_backward_rv_kernel(BwdArgs a) {
   const size_t rinst = (size_t)b * a.nstages * RL.stride;
   const int hi = a.seg_hi, lo = a.seg_lo;
   unsigned stat = 0;
+#ifdef RTOC_RV_DEBUG_MASK   // timing experiments (wrong results): bit 0 no Qxx loads, 1 no P stores, 2 no record DMA, 3 no K stores, 4 no Qxu loads
+  const int dbg = a.scan_ps_soff;
+#define RV_DBG(bit) (dbg & (1 << (bit)))
+#else
+#define RV_DBG(bit) false
+#endif
 
   // The record of grid point `stage` -> LDS by DMA (16 B per lane and instruction, LDS address = piece base + 16 lane).
   auto issue_dma = [&](int stage) {
@@ -154,7 +198,7 @@ __global__ __launch_bounds__(64, 2) void riccati_backward_rv_kernel(BwdArgs a) {
       const int off = (n < CB) ? (KL.off[RTOC_KKT_FVU] + 2 * n)
                                : ((n < CB + CG) ? (KL.off[RTOC_KKT_QUU] + 2 * (n - CB)) : (KL.off[RTOC_KKT_FX] + 2 * (n - CB - CG)));
       if (64 * (p + 1) <= NCH_S || n < NCH_S)   // (only the last piece is partial)
-        __builtin_amdgcn_global_load_lds(kp + off, (lds_ptr_t)(smem + C::OFF_ST + 128 * p), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(kp + off, (lds_ptr_t)(smem + C::OFF_ST + 128 * p), 16, 0, RV_DMA_AUX);
     }
     // A: CPP whole padded columns per piece (the other lanes idle), so that the per-lane source offset is the same in every
     // piece and a piece differs from the next by a scalar: no per-piece address arithmetic on the vector unit
@@ -166,7 +210,7 @@ __global__ __launch_bounds__(64, 2) void riccati_backward_rv_kernel(BwdArgs a) {
       for (int p = 0; p < NPC; ++p) {
         const double* kpp = kp + KL.off[RTOC_KKT_FXX] + p * CPP * NX;
         if ((p + 1) * CPP <= NX || p * CPP + (int)col0 < NX)
-          __builtin_amdgcn_global_load_lds(kpp + voff, (lds_ptr_t)(sA + p * CPP * LDP), 16, 0, 0);
+          __builtin_amdgcn_global_load_lds(kpp + voff, (lds_ptr_t)(sA + p * CPP * LDP), 16, 0, RV_DMA_AUX);
       }
     }
   };
@@ -180,7 +224,7 @@ __global__ __launch_bounds__(64, 2) void riccati_backward_rv_kernel(BwdArgs a) {
 #pragma unroll
       for (int ks = 0; ks < KSU; ++ks) {
         const int x = 16 * c + li, u = 4 * ks + q;
-        hq[c][ks] = kp[((x < NX) ? x : NX - 1) + u * NX];   // (a distinct address per ks: a common clamp target becomes a branch)
+        hq[c][ks] = rv_ld(kp + ((x < NX) ? x : NX - 1) + u * NX);   // (a distinct address per ks: a common clamp target becomes a branch)
       }
   };
 
@@ -219,9 +263,9 @@ __global__ __launch_bounds__(64, 2) void riccati_backward_rv_kernel(BwdArgs a) {
     }
   }
   issue_dma(hi);
-  issue_hq(hi);
-  // grid descriptors one stage ahead, by a vector load (lane l = int l of rtoc_grid; see riccati_backward_rs.hpp)
-  int gv_ahead = reinterpret_cast<const int*>(a.grid + hi)[lane0 & 7];
+  int* const sGrid = reinterpret_cast<int*>(smem + OFF_GRID);
+  for (int e = lane; e < a.nstages; e += 64) sGrid[e] = a.grid[e].type | (a.grid[e].dims << 8);   // (the host keeps nstages <= RV_MAX_STAGES)
+  rv_lds_sync();
 
   for (int st = hi; st >= lo; --st) {
     lane = lane0;
@@ -229,21 +273,35 @@ __global__ __launch_bounds__(64, 2) void riccati_backward_rv_kernel(BwdArgs a) {
     lane &= 63;
     li = lane & 15;
     q = lane >> 4;
-    const bool impact = __builtin_amdgcn_readlane(gv_ahead, 0) == RTOC_GRID_IMPACT;
-    const int ns = impact ? 0 : __builtin_amdgcn_readlane(gv_ahead, 5);   // rtoc_grid::dims: rows of the switching constraint
+    const int gword = __builtin_amdgcn_readfirstlane(sGrid[st]);
+    const bool impact = (gword & 0xff) == RTOC_GRID_IMPACT;
+    const int ns = impact ? 0 : (gword >> 8);   // rtoc_grid::dims: rows of the switching constraint
     const double* kr = a.kkt + kinst + (size_t)st * KL.stride;
     double* rr = a.ric + rinst + (size_t)st * RL.stride;
     RV_PROF(0);
     // everything this stage reads from LDS or was promised in registers has landed (DMA of A and the strip, Qxu^T, the grid
     // descriptor); the stores of the previous stage (K, k, s) have left too
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ... except the KG stores of s, the youngest vector-memory operations of the previous stage (issued after every load and after
+    // the K stores): vmcnt counts in order, so "all but the last KG" leaves exactly those in flight instead of waiting out their latency
+    static_assert(KG == 9, "literal below");
+    if (st < hi)
+      asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     RV_PROF(1);
-    gv_ahead = reinterpret_cast<const int*>(a.grid + (st > lo ? st - 1 : st))[lane & 7];
 
+    // Qxu^T of this stage -> start values of the PB^T rows (used after the factorisation, like Qxx below; loaded here, not with the
+    // DMA of the record: held across the policy / switching-constraint products its registers would be spilled)
+    if (!RV_DBG(4)) issue_hq(st);
     // ---- Qxx of this stage -> accumulators of the F product (upper tiles; off-diagonal ones symmetrised,
     //      brrf.cpp:85 folded into the start value), used two products from here ----
     d4 f[T][T];
-    {
+    if (RV_DBG(0)) {
+#pragma unroll
+      for (int c = 0; c < T; ++c)
+#pragma unroll
+        for (int t = c; t < T; ++t) f[c][t] = zero4();
+    } else {
       const double* qb_ = kr + KL.off[RTOC_KKT_QXX];
       const unsigned lic = (li < SCOL) ? li : SCOL - 1;                  // last column tile: lanes beyond the matrix read a clamped column
       const unsigned vx = q + li * NX, vxl = q + lic * NX;               // Qxx[i][j]: i = .. + q, j = .. + li
@@ -260,11 +318,14 @@ __global__ __launch_bounds__(64, 2) void riccati_backward_rv_kernel(BwdArgs a) {
               f[c][t][r] = 0.0;
               continue;
             }
-            const double v = qb_[((t < T - 1) ? vx : vxl) + (16 * c + 4 * r + 16 * t * NX)];
+            // transposed element Qxx[j][i]: li runs along the contiguous index (16 lanes = one 128-byte line); the direct element
+            // Qxx[i][j] puts four lanes on 32 bytes of sixteen different lines.  Diagonal tiles take the transposed one alone: their
+            // upper triangle is mirrored at the end of the stage, so which triangle of a (to round-off) symmetric Qxx feeds it is free
+            const double vt_ = rv_ld(qb_ + ((t < T - 1) ? vt : vtl) + (16 * t + (16 * c + 4 * r) * NX));
             if (t == c) {
-              f[c][t][r] = v;
+              f[c][t][r] = vt_;
             } else {
-              const double vt_ = qb_[((t < T - 1) ? vt : vtl) + (16 * t + (16 * c + 4 * r) * NX)];
+              const double v = rv_ld(qb_ + ((t < T - 1) ? vx : vxl) + (16 * c + 4 * r + 16 * t * NX));
               f[c][t][r] = 0.5 * (v + vt_);
             }
           }
@@ -307,20 +368,6 @@ __global__ __launch_bounds__(64, 2) void riccati_backward_rv_kernel(BwdArgs a) {
       }
     }
     RV_PROF(3);
-    // ---- P of grid point st + 1 -> HBM, from the registers that still hold it as P+ (element (i, j) is written
-    //      through its mirror (j, i): li runs along the contiguous index) ----
-    if (st < hi) {
-      double* pw = a.ric + rinst + (size_t)(st + 1) * RL.stride + RL.off[RTOC_RIC_P];
-#pragma unroll
-      for (int kt = 0; kt < T; ++kt)
-#pragma unroll
-        for (int mt = 0; mt < T; ++mt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int i = 16 * kt + 4 * r + q, j = 16 * mt + li;
-            if (i < NX && j < NX) pw[j + i * NX] = pp[kt][mt][r];
-          }
-    }
     RV_PROF(4);
     if (!impact) {
       rv_lds_sync();
@@ -345,6 +392,10 @@ __global__ __launch_bounds__(64, 2) void riccati_backward_rv_kernel(BwdArgs a) {
       // B fragment of k group g: A[4g + q][16t + li]; last tile: columns >= NX are Fx (lane SCOL) and nothing
       const double* pb_ = (t < T - 1 || li < SCOL) ? (sA + q + (16 * t + li) * LDP) : (smem + ST_FX + q);
       const bool okb = (t < T - 1) || li <= SCOL;
+      // structured form: does k group g hold a dense row of A (a corner row or a velocity row)?  is row 4g + q one?
+      auto group_dense = [](int g) { return 4 * g < NP_ || 4 * g + 3 >= NV; };
+      auto row_dense = [&](int g) { return 4 * g + q < NP_ || 4 * g + q >= NV; };
+      const bool sa_tile = SA && t < T - 1;   // (the last column tile carries the riders and stays dense)
       double braw[2];
       braw[0] = pb_[0];
 #pragma unroll
@@ -352,13 +403,33 @@ __global__ __launch_bounds__(64, 2) void riccati_backward_rv_kernel(BwdArgs a) {
         if (g + 1 < KG) braw[(g + 1) & 1] = pb_[4 * (g + 1)];
         __builtin_amdgcn_sched_barrier(0);
         const double bv = okb ? braw[g & 1] : 0.0;
+        const double bm = (!sa_tile || row_dense(g)) ? bv : 0.0;
 #pragma unroll
         for (int tm = 0; tm < T; ++tm) {
           double av = pp[g / 4][tm][g % 4];
           if (tm == T - 1) av = (li >= SCOL) ? acc[g / 4][g % 4] : av;   // PB^T[u = li - SCOL][4g + q]
-          w[tm] = mfma16(av, bv, w[tm]);
+          if (sa_tile && tm < T - 1) {
+            if (group_dense(g)) w[tm] = mfma16(av, bm, w[tm]);
+          } else {
+            w[tm] = mfma16(av, bv, w[tm]);
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
+      }
+      if (sa_tile) {
+        // the structured rows' part of the P+ row tiles: column j = 16t + li takes a S[:, j] (j in [NP, NV): same tile, lane, register
+        // of P+) or c S[:, j - NV] (j in [NV + NP, NX): NV = 2 mod 16, i.e. the previous tile two lanes to the left)
+        const double ca = sA[NP_ + NP_ * LDP], cc = sA[NP_ + (NV + NP_) * LDP];
+        const int j = 16 * t + li;
+        const double ca_l = (j >= NP_ && j < NV) ? ca : 0.0;
+        const double cc_l = (j >= NV + NP_ && li >= NV % 16) ? cc : 0.0;
+#pragma unroll
+        for (int tm = 0; tm < T - 1; ++tm)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            w[tm][r] = __builtin_fma(ca_l, pp[tm][t][r], w[tm][r]);
+            if (t >= 1 && 16 * t + 15 >= NV + NP_) w[tm][r] = __builtin_fma(cc_l, dpp_from_left<NV % 16>(pp[tm][t - 1][r]), w[tm][r]);
+          }
       }
       if (t == T - 1) {
         // lane masks as numbers: selects on just-loaded values become branches around the loads (with a full vmcnt wait at the join)
@@ -381,6 +452,20 @@ __global__ __launch_bounds__(64, 2) void riccati_backward_rv_kernel(BwdArgs a) {
         }
       }
       RV_PROF(6 + 2 * t);
+      // ---- P of grid point st + 1 -> HBM, a third per column tile, from the registers that hold it as P+ until the last of these
+      //      products (element (i, j) is written through its mirror (j, i): li runs along the contiguous index).  Spread over the
+      //      stage: a wave has 6 bits of vmcnt, and 36 Qxx loads + 28 stores in one burst stall the issue at the 64th ----
+      if (st < hi && !RV_DBG(1)) {
+        double* pw = a.ric + rinst + (size_t)(st + 1) * RL.stride + RL.off[RTOC_RIC_P];
+        const unsigned vst = li + q * NX;   // per-lane part of the address, 32 bits; the rest is compile-time
+#pragma unroll
+        for (int mt = 0; mt < T; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = 16 * t + 4 * r + q, j = 16 * mt + li;
+            if (i < NX && j < NX) rv_st(pw + (vst + (16 * mt + (16 * t + 4 * r) * NX)), pp[t][mt][r]);
+          }
+      }
 #pragma unroll
       for (int ks = 0; ks < KSU; ++ks) hT[t][ks] = w[T - 1][RS + ks];
       // F[c][t] += A^T[c] W[:, t]: A fragment A[k = 4g + q][m = 16c + li] (the same LDS words as above), B fragment W in its C layout
@@ -389,6 +474,7 @@ __global__ __launch_bounds__(64, 2) void riccati_backward_rv_kernel(BwdArgs a) {
 #pragma unroll
         for (int c = 0; c <= t; ++c) d[c] = sA[q + 4 * g + (16 * c + li) * LDP];
       };
+      if constexpr (!SA) {
       load_a(0, araw[0]);
 #pragma unroll
       for (int g = 0; g < KG; ++g) {
@@ -402,14 +488,63 @@ __global__ __launch_bounds__(64, 2) void riccati_backward_rv_kernel(BwdArgs a) {
         }
         __builtin_amdgcn_sched_barrier(0);
       }
+      } else {
+        // structured form: only the k groups with dense rows (the others: scaled rows of W below), corner rows only into the
+        // column tiles of A that hold corner columns (tiles 0 and 1)
+        constexpr int GFIRST = 0;
+        static_assert(NP_ >= 1, "group 0 holds corner rows");
+        auto next_dense = [&](int g) { int n = g + 1; while (n < KG && !group_dense(n)) ++n; return n; };
+        load_a(GFIRST, araw[0]);
+        int par = 0;
+#pragma unroll
+        for (int g = 0; g < KG; ++g) {
+          if (!group_dense(g)) continue;
+          const int gn = next_dense(g);
+          if (gn < KG) load_a(gn, araw[par ^ 1]);
+          __builtin_amdgcn_sched_barrier(0);
+          const double bw = w[g / 4][g % 4];
+          const bool corner_only = 4 * g + 3 < NV;   // a dense group below the velocity rows: corner rows (and masked structured ones)
+#pragma unroll
+          for (int c = 0; c <= t; ++c) {
+            if (corner_only && c == T - 1) continue;
+            double av = (c < T - 1 || li < SCOL) ? araw[par][c] : 0.0;
+            av = row_dense(g) ? av : 0.0;
+            f[c][t] = mfma16(av, bw, f[c][t]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          par ^= 1;
+        }
+        // rows [NP, NV) of A: F[i][:] += a W[i][:]; rows i in [NV + NP, NX): F[i][:] += c W[i - NV][:], and i - NV = 4 (g' - 5) + (q + 2)
+        // for q < 2, 4 (g' - 4) + (q - 2) for q >= 2: the value sits two q-groups away (lane ^ 32) in group g' - 5 or g' - 4
+        const double ca = sA[NP_ + NP_ * LDP], cc = sA[NP_ + (NV + NP_) * LDP];
+#pragma unroll
+        for (int c = 0; c <= t; ++c)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int gp = 4 * c + r;
+            if (4 * gp + 3 >= NP_ && 4 * gp < NV) {
+              const double coef = (4 * gp + q >= NP_ && 4 * gp + q < NV) ? ca : 0.0;
+              f[c][t][r] = __builtin_fma(coef, w[c][r], f[c][t][r]);
+            }
+            if (4 * gp + 3 >= NV + NP_ && 4 * gp < NX) {
+              constexpr int DHI = (NV - 2) / 4, DLO = (NV + 2) / 4;
+              const int ghi = gp - DHI, glo = gp - DLO;
+              const double hi_v = (ghi >= 0) ? w[(ghi >= 0 ? ghi : 0) / 4][(ghi >= 0 ? ghi : 0) % 4] : 0.0;
+              const double lo_v = (glo >= 0) ? w[(glo >= 0 ? glo : 0) / 4][(glo >= 0 ? glo : 0) % 4] : 0.0;
+              const double send = (q < 2) ? hi_v : lo_v;
+              const double got = __shfl_xor(send, 32, 64);
+              const double coef = (4 * gp + q >= NV + NP_) ? cc : 0.0;
+              f[c][t][r] = __builtin_fma(coef, got, f[c][t][r]);
+            }
+          }
+      }
       RV_PROF(7 + 2 * t);
     }
 
     // ---- A, Bv, Quu and the vectors of this stage have been read for the last time: the record of the next grid point ----
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (st > lo) {
-      issue_dma(st - 1);
-      issue_hq(st - 1);
+      if (!RV_DBG(2)) issue_dma(st - 1);
     }
     asm volatile("" ::: "memory");
 
@@ -562,7 +697,7 @@ __global__ __launch_bounds__(64, 2) void riccati_backward_rv_kernel(BwdArgs a) {
 #pragma unroll
         for (int r = 0; r < KSU; ++r) {
           const int u = q + 4 * r, x = 16 * c + li;
-          if (x < NX) rr[RL.off[RTOC_RIC_K] + u * NX + x] = kk[c][r];
+          if (x < NX && !RV_DBG(3)) rv_st(rr + RL.off[RTOC_RIC_K] + u * NX + x, kk[c][r]);
           if (c == T - 1 && li == SCOL) rr[RL.off[RTOC_RIC_KV] + u] = -kk[c][r];
           chk = __builtin_fma((x <= NX) ? kk[c][r] : 0.0, 0.0, chk);
         }
@@ -620,15 +755,21 @@ __global__ __launch_bounds__(64, 2) void riccati_backward_rv_kernel(BwdArgs a) {
     }
     RV_PROF(15);
     // ---- s (and the zero switching-time fields of the record) -> HBM ----
-    if (li == SCOL) {
+    {
+      double zero = 0.0;
+      asm volatile("" : "+v"(zero));   // (materialised here: hoisted out of the loop the constant gets spilled and RELOADED -- a scratch load and a full wait)
+      if (lane < NX) {
+        rr[RL.off[RTOC_RIC_PSI] + lane] = zero;
+        rr[RL.off[RTOC_RIC_PHI] + lane] = zero;
+      }
+      if (lane < 5) rr[RL.off[RTOC_RIC_SCAL] + lane] = zero;
+    }
+    asm volatile("" ::: "memory");
+    if (li == SCOL) {   // KG stores, the LAST vector-memory operations of the stage (the wait at the next stage top counts on it)
 #pragma unroll
       for (int g = 0; g < KG; ++g) rr[RL.off[RTOC_RIC_S] + 4 * g + q] = sv[g];
     }
-    if (lane < NX) {
-      rr[RL.off[RTOC_RIC_PSI] + lane] = 0.0;
-      rr[RL.off[RTOC_RIC_PHI] + lane] = 0.0;
-    }
-    if (lane < 5) rr[RL.off[RTOC_RIC_SCAL] + lane] = 0.0;
+    asm volatile("" ::: "memory");
     RV_PROF(16);
   }
 
@@ -648,13 +789,10 @@ __global__ __launch_bounds__(64, 2) void riccati_backward_rv_kernel(BwdArgs a) {
   if (stat) atomicOr(&a.status[b], stat);
 }
 
+// the carve plus the grid-kind table fill the 20 KB an eighth of a CU's LDS offers
 template <int NV, int NU, int NS>
 constexpr int rv_lds_bytes() {
-  using C = RvCfg<NV, NU>;
-  constexpr rtoc_record_layout KL = StaticLayout<NV, NU, NS>::make().kkt;
-  constexpr int CV = (KL.off[RTOC_KKT_LU] - KL.off[RTOC_KKT_FX] + NU + 1) / 2;
-  constexpr int ST_FX = C::OFF_ST + 2 * C::CB + 2 * C::CG;
-  return 8 * (ST_FX + 2 * CV + C::pad8(NU * NU) + C::pad8(NU) + 2 * C::pad8(16 * 17));
+  return 20 * 1024;
 }
 
 }  // namespace rtoc

@@ -1010,7 +1010,7 @@ static bool fxx_structured(rtoc_ctx* c) {
 
 // RTOC_OPT_BACKWARD_REGISTER: the register-resident kernel (riccati_backward_rv.hpp), one launch for the whole horizon.
 static bool rv_applies(const rtoc_ctx* c) {
-  return c->bwd_register && c->ks->bwd_rv && c->h_grid && c->nstages >= 2 && !c->writeback && !grid_has_sto(c) &&
+  return c->bwd_register && c->ks->bwd_rv && c->h_grid && c->nstages >= 2 && c->nstages <= RV_MAX_STAGES && !c->writeback && !grid_has_sto(c) &&
          c->bwd_variant == ((c->ks->nvariants >= 3) ? c->ks->nvariants - 1 : 0);   // (an explicit RTOC_OPT_BACKWARD_WAVES keeps its kernel)
 }
 static int launch_backward_rv(rtoc_ctx* c, int first, int end, hipStream_t stream) {
@@ -1031,7 +1031,11 @@ static int launch_backward_rv(rtoc_ctx* c, int first, int end, hipStream_t strea
   // one launch for the whole horizon: regular, lift, impact and switching-constraint grid points are all the kernel's own
   a.seg_hi = N - 1;
   a.seg_lo = 0;
-  if (N >= 1) hipLaunchKernelGGL(ks->bwd_rv, dim3(nb), dim3(64), ks->bwd_rv_lds, stream, a);
+#ifdef RTOC_RV_DEBUG_MASK
+  if (const char* e = getenv("RTOC_RV_DEBUG")) a.scan_ps_soff = atoi(e);
+#endif
+  const bwd_fn kern = (ks->bwd_rv_sa && fxx_structured(c)) ? ks->bwd_rv_sa : ks->bwd_rv;   // RTOC_OPT_FXX_STRUCTURE, as for the role-split kernel
+  if (N >= 1) hipLaunchKernelGGL(kern, dim3(nb), dim3(64), ks->bwd_rv_lds, stream, a);
   HIP_TRY(hipGetLastError());
   return RTOC_OK;
 }

@@ -60,6 +60,17 @@ def test_register_kernel_reproduces_the_oracle_on_the_trot(oracle, mode):
         assert (st2 == st).all()
         for b in range(batch):
             compare_riccati(L, grids, ric[b], ric2[b], TOL, "register vs role-split inst %d" % b, check_sto=False)
+        # the structured-Fxx form (RTOC_OPT_FXX_STRUCTURE: taken when every record has the state-equation structure) and the dense
+        # form of the register kernel, each against the oracle; where the records are structured they are two arithmetic paths
+        structured = ctx.check_fxx_structure()
+        ctx.set_fxx_structure(1)
+        st3, ric3, d3 = _sweep(ctx, kkt, dx0, True)
+        assert (st3 == st_ref).all()
+        for b in range(batch):
+            compare_riccati(L, grids, ric3[b], ric_ref[b], TOL, "register dense inst %d" % b, check_sto=False)
+            compare_direction(L, grids, d3[b], d_ref[b], TOL, "register dense inst %d" % b)
+        assert np.array_equal(ric3, ric) != structured
+        print("records structured: %s" % structured)
     finally:
         ctx.close()
 

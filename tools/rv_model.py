@@ -42,7 +42,7 @@ def row_shift(v, n):
     return out
 
 
-def stage(NV, NU, pp, sv, A, Bv, Qxx, Qxu, Quu, Fx, lx, lu, impact, sc=None):
+def stage(NV, NU, pp, sv, A, Bv, Qxx, Qxu, Quu, Fx, lx, lu, impact, sc=None, sa=False):
     """pp[kt][mt]: (64,4) tiles of P+ in C layout, zero outside NX x NX; sv[c]: (64,4), s+[16c + 4r + q] on lanes li == SCOL.
     sc = (Phix [ns x NX], Phiu [ns x NU], Pres [ns]) on a grid point with a switching constraint (riccati_factorizer.cpp:58-89).
     Returns (pp_new, sv_new, K, k) and, with sc, (.., M, m)."""
@@ -92,22 +92,53 @@ def stage(NV, NU, pp, sv, A, Bv, Qxx, Qxu, Quu, Fx, lx, lu, impact, sc=None):
                 u, x = 16 * (TM - 1) + 4 * r + Q - NX, 16 * c + LI
                 ok = (u >= 0) & (x < NX)
                 pa[TM - 1][c][:, r] = np.where(ok, Qxu[np.clip(x, 0, NX - 1), np.clip(u, 0, NU - 1)], 0.0)
+    NP = NV - NU
+    nmf = 0
+    in_R = lambda k: (k < NP) | (k >= NV)          # rows of A that are dense (corner rows, velocity rows)
     for g in range(KG):
         k = 4 * g + Q
         kok = k < NX
-        bs = []
+        bs, bsm = [], []
         for c in range(T):
             j = 16 * c + LI
             b = np.where(kok & (j < NX), A[np.clip(k, 0, NX - 1), np.clip(j, 0, NX - 1)], 0.0)
             if c == T - 1:
                 b = np.where(kok & (LI == SCOL), Fx[np.clip(k, 0, NX - 1)], b)
             bs.append(b)
+            bsm.append(np.where(in_R(k), b, 0.0))   # structured rows masked
         for tm in range(TM):
             a = pp[g // 4][tm][:, g % 4] if tm < T else z4()[:, 0]
             if tm == TM - 1:   # lanes li >= SH: PB^T[u = li - SH][4g + q] = acc at the same lane
                 a = np.where(LI >= SH, acc[g // 4][:, g % 4], a)
             for c in range(T):
-                pa[tm][c] = mfma16(a, bs[c], pa[tm][c])
+                if sa and c < T - 1 and tm < TM - 1:
+                    # structured column tiles, P+ row tiles: only the k groups that meet dense rows; corner rows (g with rows < NP) only
+                    # reach the column tiles that hold corner columns -- all of them here (columns [0, NP) in tile 0, [NV, NV + NP) in tile 1)
+                    if not (in_R(4 * g + np.arange(4))).any():
+                        continue
+                    pa[tm][c] = mfma16(a, bsm[c], pa[tm][c])
+                else:
+                    pa[tm][c] = mfma16(a, bs[c], pa[tm][c])
+                nmf += 1
+    if sa:
+        # structured rows k in [NP, NV) of A: W[:, k] += a S[:, k], W[:, NV + k] += c S[:, k] for the P+ row tiles of the structured
+        # column tiles (the PB^T rows and the last column tile went through the dense products above)
+        ca, cc = A[NP, NP], A[NP, NV + NP]
+        for tm in range(TM - 1):
+            for c in range(T - 1):
+                for r in range(4):
+                    j = 16 * c + LI
+                    # a-part: column j = k, same tile, lane and register of P+
+                    isa = (j >= NP) & (j < NV)
+                    pa[tm][c][:, r] += np.where(isa, ca * pp[tm][c][:, r], 0.0)
+                    # c-part: column j = NV + k: k = j - NV = 16 (c - 1) + (li - 2): lanes li >= 2 read lane li - 2 of tile c - 1,
+                    # lanes li < 2 read lane li + 14 of tile c - 2
+                    isc = (j >= NV + NP) & (j < NX)
+                    if c >= 1:
+                        src = row_shift(pp[tm][c - 1][:, r], NV % 16)
+                        pa[tm][c][:, r] += np.where(isc & (LI >= NV % 16), cc * src, 0.0)
+                    if c >= 2:
+                        raise NotImplementedError
     # column NX: z = s+ - P+ Fx (rows < NX), lu' = lu - Bv^T s+_v + PB^T Fx (rows NX..)
     lup = np.zeros((64, 4))
     for tm in range(TM):
@@ -139,11 +170,37 @@ def stage(NV, NU, pp, sv, A, Bv, Qxx, Qxu, Quu, Fx, lx, lu, impact, sc=None):
     for g in range(KG):
         k = 4 * g + Q
         kok = k < NX
+        if sa and not (in_R(4 * g + np.arange(4))).any():
+            continue
         for c in range(T):
             m = 16 * c + LI
             a = np.where(kok & (m < NX), A[np.clip(k, 0, NX - 1), np.clip(m, 0, NX - 1)], 0.0)   # A^T[m][k]
+            if sa:
+                a = np.where(in_R(k), a, 0.0)
+                # corner rows only meet the corner columns of A: tiles 0 and 1 here
+                if (4 * g + 3 < NP) and c == T - 1:
+                    continue
             for t in range(c, T):
                 f[c][t] = mfma16(a, pa[g // 4][t][:, g % 4], f[c][t])
+                nmf += 1
+    if sa:
+        ca, cc = A[NP, NP], A[NP, NV + NP]
+        for c in range(T):
+            for t in range(c, T):
+                for r in range(4):
+                    i = 16 * c + 4 * r + Q
+                    # a-part: F[i][:] += a W[i][:] for i in [NP, NV): same lane and register
+                    f[c][t][:, r] += np.where((i >= NP) & (i < NV), ca * pa[c][t][:, r], 0.0)
+                    # c-part: F[i][:] += c W[i - NV][:] for i in [NV + NP, NX); i - NV = 4 (g' - 5) + (q + 2) for q < 2, 4 (g' - 4) + (q - 2) else
+                    gp = 4 * c + r
+                    if 4 * gp + 3 >= NV + NP and 4 * gp < NX:
+                        ghi, glo = gp - (NV - 2) // 4, gp - (NV + 2) // 4
+                        hi_v = pa[ghi // 4][t][:, ghi % 4] if ghi >= 0 else np.zeros(64)
+                        lo_v = pa[glo // 4][t][:, glo % 4] if glo >= 0 else np.zeros(64)
+                        send = np.where(Q < 2, hi_v, lo_v)
+                        got = send[LANES ^ 32]
+                        f[c][t][:, r] += np.where((i >= NV + NP) & (i < NX), cc * got, 0.0)
+    stage.mfma_wf = nmf
     K = np.zeros((NU, NX))
     kv = np.zeros(NU)
     if not impact:
@@ -325,6 +382,7 @@ def main():
     kk = kkt.copy()
     orc.riccati_backward(L, grids, kk, ric)
     worst = 0.0
+    SA = "--dense" not in sys.argv
     for st in (45, 35, 33, 20, 15):
         g = grids[st]
         rec, nxt, out = kkt[st], ric[st + 1], ric[st]
@@ -342,7 +400,7 @@ def main():
         if g.type != GRID_IMPACT and g.dims > 0:
             sc = (f("Phix")[:g.dims], f("Phiu")[:g.dims], f("Pres")[:g.dims])
         out_ = stage(NV, NU, to_tiles(P1, NX), sv, f("Fxx"), f("Fvu"), f("Qxx"), f("Qxu"), f("Quu"), f("Fx"), f("lx"), f("lu"),
-                     g.type == GRID_IMPACT, sc)
+                     g.type == GRID_IMPACT, sc, sa=SA)
         pn, svn, K, k = out_[:4]
         P = from_tiles(pn, NX)
         s = np.zeros(NX)
@@ -361,6 +419,7 @@ def main():
         if sc is not None:
             errs["M"] = np.abs(out_[4] - Rr.f(out, "M")[:g.dims]).max() / np.abs(Rr.f(out, "M")[:g.dims]).max()
             errs["m"] = np.abs(out_[5] - Rr.f(out, "m")[:g.dims]).max() / max(np.abs(Rr.f(out, "m")[:g.dims]).max(), 1e-300)
+        print("W + F products: %d MFMAs;" % stage.mfma_wf, end=" ")
         print("stage", st, "type", g.type, "dims", g.dims, {n: float("%.2e" % v) for n, v in errs.items()})
         worst = max(worst, max(v for n, v in errs.items()))
     assert worst < 1e-10, worst
