@@ -281,11 +281,10 @@ __global__ __launch_bounds__(64, 2) void riccati_backward_rv_kernel(BwdArgs a) {
     RV_PROF(0);
     // everything this stage reads from LDS or was promised in registers has landed (DMA of A and the strip, Qxu^T, the grid
     // descriptor); the stores of the previous stage (K, k, s) have left too
-    // ... except the KG stores of s, the youngest vector-memory operations of the previous stage (issued after every load and after
-    // the K stores): vmcnt counts in order, so "all but the last KG" leaves exactly those in flight instead of waiting out their latency
-    static_assert(KG == 9, "literal below");
+    // ... except the store of s, the youngest vector-memory operation of the previous stage (issued after every load and after the K
+    // stores): vmcnt counts in order, so "all but the last one" leaves exactly that store in flight instead of waiting out its latency
     if (st < hi)
-      asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
     else
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     RV_PROF(1);
@@ -754,20 +753,26 @@ __global__ __launch_bounds__(64, 2) void riccati_backward_rv_kernel(BwdArgs a) {
       }
     }
     RV_PROF(15);
-    // ---- s (and the zero switching-time fields of the record) -> HBM ----
+    // ---- s and the (zero) switching-time fields Psi, Phi of the record -> HBM as ONE 16-byte-per-lane store: s is gathered from
+    //      the four lanes that hold it through the transpose scratch; the three fields lie behind one another in the record.
+    //      It is the LAST vector-memory operation of the stage -- the wait at the next stage top counts on that ----
     {
+      static_assert(RL.off[RTOC_RIC_PSI] == RL.off[RTOC_RIC_S] + C::pad8(NX) && RL.off[RTOC_RIC_PHI] == RL.off[RTOC_RIC_PSI] + C::pad8(NX) &&
+                        RL.off[RTOC_RIC_S] % 2 == 0 && NX % 2 == 0 && 2 * C::pad8(NX) + NX <= 128, "s | Psi | Phi: one strip of <= 64 chunks");
+      if (li == SCOL) {
+#pragma unroll
+        for (int g = 0; g < KG; ++g) scr[4 * g + q] = sv[g];
+      }
       double zero = 0.0;
       asm volatile("" : "+v"(zero));   // (materialised here: hoisted out of the loop the constant gets spilled and RELOADED -- a scratch load and a full wait)
-      if (lane < NX) {
-        rr[RL.off[RTOC_RIC_PSI] + lane] = zero;
-        rr[RL.off[RTOC_RIC_PHI] + lane] = zero;
-      }
       if (lane < 5) rr[RL.off[RTOC_RIC_SCAL] + lane] = zero;
-    }
-    asm volatile("" ::: "memory");
-    if (li == SCOL) {   // KG stores, the LAST vector-memory operations of the stage (the wait at the next stage top counts on it)
-#pragma unroll
-      for (int g = 0; g < KG; ++g) rr[RL.off[RTOC_RIC_S] + 4 * g + q] = sv[g];
+      rv_lds_sync();
+      const d2 sv2 = *reinterpret_cast<const d2*>(scr + ((2 * lane < NX) ? 2 * lane : 0));
+      d2 out;
+      out.x = (2 * lane < NX) ? sv2.x : zero;
+      out.y = (2 * lane < NX) ? sv2.y : zero;
+      asm volatile("" ::: "memory");
+      if (2 * lane < 2 * C::pad8(NX) + NX) *reinterpret_cast<d2*>(rr + RL.off[RTOC_RIC_S] + 2 * lane) = out;
     }
     asm volatile("" ::: "memory");
     RV_PROF(16);
