@@ -105,7 +105,9 @@ enum rtoc_option {
                               * rows, wave 2 stages the inputs; MJtJinv goes to HBM once, for the expansion only).  Default per robot
                               * shape: 0 where five work items of the one-kernel form fit a CU (quadruped-size shapes: same time,
                               * one launch and ~5 % of the HBM traffic less), 1 otherwise (iCub-size shapes: 3.2 vs 3.6 ms).
-                              * rtoc_get_option reads the value in force. */
+                              * rtoc_get_option reads the value in force.  Environment: RTOC_CONDENSE_SPLIT=0|1, read by rtoc_create,
+                              * replaces the per-shape default of contexts created afterwards (how tools/gpu_dev.sh runs the
+                              * whole GPU suite on both pipelines); rtoc_set_option still overrides it. */
   RTOC_OPT_BACKWARD_SCAN = 6, /* 1: rtoc_riccati_backward (and everything built on it) runs the recursion as a scan
                               * over the horizon -- interval elements of all grid points, ceil(log2(nstages))
                               * combination levels, then all policies at once -- instead of the serial chain
@@ -178,7 +180,10 @@ int rtoc_device_count(void);
 /* Attainable HBM bandwidth of `device`, measured now with this library's own streaming kernels (16 B per lane, all waves
  * sweeping memory as one front, eight loads in flight per wave): a pure read of `bytes` and a copy of `bytes` (read + write,
  * counted as 2 x bytes), best of five launches each, GB/s.  The denominators the bench's roofline fractions are quoted against
- * beside the 8 TB/s spec (a hipMemcpy-style device copy reaches less than these).  Either pointer may be NULL. */
+ * beside the 8 TB/s spec (a hipMemcpy-style device copy reaches less than these).  Either pointer may be NULL.
+ * `bytes` >= RTOC_BANDWIDTH_PROBE_MIN_BYTES (one trip of every wave of the probe: 512 MiB), else RTOC_ERR_BAD_ARG; it is rounded
+ * down to a multiple of that. */
+#define RTOC_BANDWIDTH_PROBE_MIN_BYTES ((size_t)512 << 20)
 int rtoc_bandwidth_probe(int device, size_t bytes, double* read_gbs, double* copy_gbs);
 /* 1 if (nv,nu,np) has a compiled kernel specialisation, else 0. */
 int rtoc_dims_supported(const rtoc_dims* dims);
@@ -208,7 +213,8 @@ int rtoc_set_grid(rtoc_ctx* ctx, const rtoc_grid* grid, int nstages);
  * from and joined to this stream by events: callers only ever order against the stream given here.) */
 int rtoc_set_stream(rtoc_ctx* ctx, void* hip_stream);
 int rtoc_set_option(rtoc_ctx* ctx, int option, int64_t value);
-/* the value in force of an integer-valued option (RTOC_ERR_BAD_ARG for the double-valued ones) */
+/* the value in force of an integer-valued option (RTOC_ERR_BAD_ARG for the double-valued ones: RTOC_OPT_MAX_DTS0,
+ * RTOC_OPT_CONTACT_INV_DAMPING, and for RTOC_OPT_IMPACT_CONES-style numbers this header does not list) */
 int rtoc_get_option(rtoc_ctx* ctx, int option, int64_t* value);
 
 /* Host <-> HBM transfers of whole buffers (count in doubles, from the buffer start +offset). */

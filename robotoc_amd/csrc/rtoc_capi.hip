@@ -280,10 +280,10 @@ static __global__ __launch_bounds__(256) void stream_probe_kernel(const char* __
 }  // extern "C++"
 
 int rtoc_bandwidth_probe(int device, size_t bytes, double* read_gbs, double* copy_gbs) {
-  if (bytes < (size_t)1 << 24) return RTOC_ERR_BAD_ARG;
-  HIP_TRY(hipSetDevice(device));
   const int blocks = 256 * 64;                                 // 64 workgroups of 4 waves per CU: 6.2 TB/s read (256 * 8: 5.7)
   const size_t per = (size_t)blocks * 4 * 8;                   // chunks consumed per trip of all waves (U = 8)
+  if (bytes < per * 1024) return RTOC_ERR_BAD_ARG;             // RTOC_BANDWIDTH_PROBE_MIN_BYTES: one trip of every wave (512 MiB)
+  HIP_TRY(hipSetDevice(device));
   const size_t chunks = (bytes / 1024) / per * per;
   char *src = nullptr, *dst = nullptr;
   double* sink = nullptr;
@@ -1833,11 +1833,9 @@ int rtoc_set_contact_schedule(rtoc_ctx* c, const unsigned* active, const double*
 
 // rbd_values_kernel for the iterate in RTOC_BUF_SOL: the lane-invariant values of the rigid-body recursion per body (and the
 // ID rows of RTOC_CDD_IDC), read by the tangent walk and by the friction-cone rows
-static int launch_rbd_values(rtoc_ctx* c, bool unconstr) {
-  if (!c->h_model || !c->d_active || !c->buf[RTOC_BUF_SOL]) return RTOC_ERR_NOT_READY;
-  int rc = ensure_buffer(c, RTOC_BUF_CDD);
-  if (rc) return rc;
-  if (c->nstages < 2) return RTOC_OK;
+// scratch of the values pre-pass (hipFree / hipMalloc synchronise the device: callers that fork a stream call this first)
+static int ensure_rbd_values(rtoc_ctx* c) {
+  if (!c->h_model) return RTOC_ERR_NOT_READY;
   const rtoc_robot_model& m = c->h_model->m;
   bool any_impact = false;
   for (int i = 0; i + 1 < c->nstages; ++i) any_impact = any_impact || c->h_grid[i].type == RTOC_GRID_IMPACT;
@@ -1851,6 +1849,19 @@ static int launch_rbd_values(rtoc_ctx* c, bool unconstr) {
     c->vals_cap = need;
   }
   if (any_impact && !c->d_vals2) HIP_TRY(hipMalloc((void**)&c->d_vals2, c->vals_cap * sizeof(double)));
+  return RTOC_OK;
+}
+
+static int launch_rbd_values(rtoc_ctx* c, bool unconstr) {
+  if (!c->h_model || !c->d_active || !c->buf[RTOC_BUF_SOL]) return RTOC_ERR_NOT_READY;
+  int rc = ensure_buffer(c, RTOC_BUF_CDD);
+  if (rc) return rc;
+  if (c->nstages < 2) return RTOC_OK;
+  const rtoc_robot_model& m = c->h_model->m;
+  bool any_impact = false;
+  for (int i = 0; i + 1 < c->nstages; ++i) any_impact = any_impact || c->h_grid[i].type == RTOC_GRID_IMPACT;
+  rc = ensure_rbd_values(c);
+  if (rc) return rc;
   rbd::ValArgs v;
   v.model = c->d_model, v.sol = c->buf[RTOC_BUF_SOL], v.cdd = c->buf[RTOC_BUF_CDD], v.grid = c->d_grid, v.active = c->d_active;
   v.nstages = c->nstages, v.batch = c->batch, v.nv = m.nv, v.njoints = m.njoints, v.ncontacts = m.ncontacts;
@@ -2375,14 +2386,32 @@ int rtoc_contact_eval_kkt(rtoc_ctx* c) {
     ia.kkt_stride = c->L.kkt.stride, ia.o_qxx = c->L.kkt.off[RTOC_KKT_QXX], ia.o_quu = c->L.kkt.off[RTOC_KKT_QUU], ia.o_fxx = c->L.kkt.off[RTOC_KKT_FXX];
     const long long nrec = (long long)c->batch * c->nstages;
     // four workgroups per CU: half of the wave slots, so that the pre-pass's waves are resident beside them
-    const int blocks = (int)(nrec < 256 * 4 ? nrec : 256 * 4);
+    // (CUs from the device: four workgroups each)
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
+    const int blocks = (int)(nrec < (long long)cus * 4 ? nrec : (long long)cus * 4);
+    // init_records_kernel moves 16-byte pairs that must not straddle a field: record stride, the three fields it writes constants
+    // into and the state dimension are even (rtoc_compute_layout pads fields to 64 B; checked here so that a layout change cannot
+    // silently misplace the cost diagonals)
+    if ((ia.kkt_stride | ia.o_qxx | ia.o_quu | ia.o_fxx) & 1) return RTOC_ERR_BAD_ARG;
+    // the (re)allocation of the pre-pass's scratch synchronises the device: ahead of the fork, never under it
+    if (!c->linearize_fused) {
+      rc = ensure_rbd_values(c);
+      if (rc) return rc;
+    }
     HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
     HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
     hipLaunchKernelGGL(init_records_kernel, dim3(blocks), dim3(256), 0, c->stream2, ia);
-    HIP_TRY(hipEventRecord(c->ev_join, c->stream2));
+    // from here on the second stream is forked: whatever fails below, c->stream is joined to it before this call returns
+    hipError_t ej = hipEventRecord(c->ev_join, c->stream2);
     c->vals_fresh = 0;
-    if (!c->linearize_fused) rc = launch_rbd_values(c, false);   // shared by the cone rows and the tangent walk below
-    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    if (ej == hipSuccess && !c->linearize_fused) rc = launch_rbd_values(c, false);   // shared by the cone rows and the tangent walk below
+    if (ej == hipSuccess) ej = hipStreamWaitEvent(c->stream, c->ev_join, 0);
+    else (void)hipStreamSynchronize(c->stream2);   // no event to wait on: drain the fork on the host
+    if (ej != hipSuccess) {
+      ctx_set_err(ej, __LINE__);
+      return RTOC_ERR_HIP;
+    }
     if (rc) return rc;
   }
   hipLaunchKernelGGL(contact_cost_kernel, dim3((c->batch * c->nstages + COST_GP - 1) / COST_GP), dim3(64), 0, c->stream, a);
