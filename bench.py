@@ -686,7 +686,7 @@ def closed_loop_jump_sto(local_rank, timed=10):
                       "event_times_optimised_instance0": [float(v) for v in ts[0]],
                       "event_times_optimised_spread": [float(v) for v in (ts.max(axis=0) - ts.min(axis=0))],
                       "status_ok": bool((c.status() == 0).all())}
-        if b2 == 1:   # the same iteration with the backward recursion as a horizon scan (RTOC_OPT_BACKWARD_SCAN)
+        if b2 == 1:   # the same iteration with the backward recursion as a horizon scan (RTOC_OPT_BACKWARD_SCAN, DESIGN 3.6 (profiles/HISTORY.md 6b))
             c.set_backward_scan(True)
             c.contact_update_solution(0.995, want_kkt_error=False)
             c.sync()

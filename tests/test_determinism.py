@@ -1,4 +1,4 @@
-"""Run-to-run determinism of every kernel with an inter-wave hand-off, on the GPU.
+"""Run-to-run determinism of every kernel with an inter-wave hand-off (profiles/HISTORY.md 3.1 (e)), on the GPU.
 
 A hand-off race shows as a wrong record in a handful of instance-sweeps out of 100k: one sweep compared with the oracle passes
 nine times out of ten with it.  These tests repeat the same launch on one context and compare EVERY downloaded record --

@@ -82,7 +82,7 @@ def test_scan_horizons_around_a_power_of_two(oracle, N):
     """63 / 64 / 65 grid points (6 -> 7 combination levels) and a long horizon (101 grid points, 7 levels)."""
     from robotoc_amd import grid as G
     from robotoc_amd.types import anymal_dims
-    # composing 62 ... 100 maps on the marginally stable "dynamics" data costs two digits (DESIGN 6b): observed 8.0e-9 at N = 100,
+    # composing 62 ... 100 maps on the marginally stable "dynamics" data costs two digits (DESIGN 3.6 (profiles/HISTORY.md 6b)): observed 8.0e-9 at N = 100,
     # 7.0e-9 at 62 ... 64 -- beyond the N = 40 horizons SURVEY 8c's 1e-8 speaks about, hence 5e-8 here
     _run(oracle, anymal_dims(), G.uniform_grid(N, 0.02, dimf=12), 1, "dynamics", tol=5e-8)
 
@@ -169,7 +169,7 @@ def test_scan_with_switching_time_optimisation(oracle, mode):
     else:
         # ill-conditioned: per field, 100 x what a 1e-15 relative perturbation of the inputs does to the oracle itself (and the
         # scan's 1e-8 at least).  tests/test_gpu_parity.py::test_anymal_jump_sto_ill_conditioned holds the serial kernel to 10 x;
-        # composing the interval maps costs the scan about a digit and a half more on such data (DESIGN 6b's accuracy table:
+        # composing the interval maps costs the scan about a digit and a half more on such data (DESIGN 3.6 (profiles/HISTORY.md 6b)'s accuracy table:
         # observed here 42 x on dlmdgmm = P dx - s, a cancellation; 2.4 x on dx, du)
         rp, dp = Records(L, "ric").zeros(batch, len(grids)), Records(L, "dir").zeros(batch, len(grids))
         oracle.riccati_sweep_batch(L, grids, kkt * (1.0 + 1e-15 * np.random.default_rng(1).standard_normal(kkt.shape)), rp, dp, dx0=dx0)

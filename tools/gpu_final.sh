@@ -8,7 +8,7 @@
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out
-TAG=${1:-r04}
+TAG=${1:-r05}
 mkdir -p $OUT
 cd $R
 SKIP_PMC=1 bash tools/gpu_round2.sh > $OUT/round.log 2>&1
@@ -35,7 +35,8 @@ cp $OUT/pytest_gpu.log $OUT/summary/${TAG}_pytest_gpu.log
 # the bench line once more, now that the counter passes of THESE kernel sources exist: the driver's own run at round end reads
 # the committed profiles/<tag>_traffic.json / _linearize_flops.json, this is the same line taken on this box
 cp $OUT/summary/${TAG}_traffic.json $OUT/summary/${TAG}_linearize_flops.json $R/profiles/ 2>/dev/null
-timeout 600 python bench.py > $OUT/summary/${TAG}_bench.json 2> $OUT/bench2.err
+timeout 600 python bench.py > $OUT/summary/${TAG}_bench.json 2> $OUT/bench2.err   # the compact line the driver parses ...
+cp $OUT/bench_detail.json $OUT/summary/${TAG}_bench_detail.json 2>/dev/null             # ... and the full record behind it
 rm -rf $OUT/prof_stats $OUT/prof_fetch $OUT/prof_write $OUT/prof_sq1 $OUT/prof_sq2
 ls -la $OUT/summary
 tail -2 $OUT/summarize.log

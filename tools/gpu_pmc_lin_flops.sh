@@ -6,7 +6,7 @@
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out
-TAG=${1:-r03}
+TAG=${1:-r05}
 BATCH=${2:-1024}
 mkdir -p $OUT/summary
 export TMPDIR=/tmp
