@@ -146,6 +146,16 @@ int rtoc_contact_eval_ocp(rtoc_ctx* ctx, int trial, double* host_cost, double* h
 int rtoc_set_line_search(rtoc_ctx* ctx, int enable, double step_size_reduction_rate, double min_step_size,
                          double filter_cost_reduction_rate, double filter_constraint_violation_reduction_rate);
 int rtoc_contact_line_search(rtoc_ctx* ctx, int* host_trials);
+/* LineSearchSettings::line_search_method (include/robotoc/line_search/line_search_settings.hpp:13-29): 0 = LineSearchMethod::Filter
+ * (default), 1 = MeritBacktracking -- LineSearch::meritBacktrackingLineSearch (src/line_search/line_search.cpp:87-128): penalty
+ * parameter (1 + margin_rate) x max over the grid of SplitSolution::lagrangeMultiplierLinfNorm (:120-128), directional derivative of
+ * cost + barrier + penalty x violation from one trial at step eps, then backtracking until armijoCondition (:111-117) holds with
+ * armijo_control_rate; the reference's defaults are 0.001, 0.05, 1e-8.  rtoc_line_search_merit_terms: the penalty parameters and
+ * directional derivatives of the last rtoc_contact_line_search (either pointer may be NULL). */
+int rtoc_set_line_search_method(rtoc_ctx* ctx, int method, double armijo_control_rate, double margin_rate, double eps);
+int rtoc_line_search_merit_terms(rtoc_ctx* ctx, double* host_penalty, double* host_directional_derivative, int count);
+/* trial evaluations (dms_trial_.evalOCP calls, line_search.cpp:70, :99, :109) of the last line search, whichever entry point ran it */
+int rtoc_line_search_trials(rtoc_ctx* ctx, int* trials);
 
 /* ---- the unconstrained solver iteration closed on the device (BASELINE configuration 1: fixed base, no contacts) ----
  * ConfigurationSpaceCost (src/cost/configuration_space_cost.cpp:274-470): diagonal weights on q - q_ref (on the manifold:

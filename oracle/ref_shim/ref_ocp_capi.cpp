@@ -336,6 +336,25 @@ int ref_ocp_line_search(double rate, double min_step, double cost_rate, double v
   return 0;
 }
 
+// LineSearch::computeStepSize with LineSearchMethod::MeritBacktracking (src/line_search/line_search.cpp:87-128): penalty parameter
+// from the multipliers, directional derivative of the merit function from a trial at step `eps`, Armijo backtracking.  Injections as
+// for ref_ocp_line_search, the eps-trial's first.
+int ref_ocp_line_search_merit(double rate, double min_step, double armijo_control_rate, double margin_rate, double eps, double* out_step) {
+  if (!G || !G->dms) return 1;
+  State& g = *G;
+  LineSearchSettings st;
+  st.line_search_method = LineSearchMethod::MeritBacktracking;
+  st.step_size_reduction_rate = rate, st.min_step_size = min_step;
+  st.armijo_control_rate = armijo_control_rate, st.margin_rate = margin_rate, st.eps = eps;
+  LineSearch ls(g.ocp, st);
+  const Eigen::VectorXd q = g.s[0].q, v = g.s[0].v;
+  g.primal = ls.computeStepSize(*g.dms, g.robots, g.td, q, v, g.s, g.d, g.primal);
+  out_step[0] = g.primal;
+  out_step[1] = (double)g.robots[0].pendingOf("ID");
+  g.robots[0].clearInjections();
+  return 0;
+}
+
 // q_integrated: [n][nq] = s[i].q (+) primal_step d[i].dq (pushed as the integrateConfiguration injections, in grid order)
 int ref_ocp_integrate(const double* q_integrated, double* sol_out, double* slack_out, double* dual_out) {
   if (!G || !G->dms) return 1;

@@ -463,6 +463,22 @@ class Context:
         _chk(lib().rtoc_set_line_search(self._h, int(bool(enable)), step_size_reduction_rate, min_step_size, filter_cost_reduction_rate,
                                         filter_constraint_violation_reduction_rate))
 
+    def set_line_search_method(self, method="filter", armijo_control_rate=0.001, margin_rate=0.05, eps=1.0e-8):
+        """LineSearchSettings::line_search_method: "filter" (default) or "merit" (LineSearch::meritBacktrackingLineSearch)"""
+        lib().rtoc_set_line_search_method.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double]
+        _chk(lib().rtoc_set_line_search_method(self._h, {"filter": 0, "merit": 1}[method], armijo_control_rate, margin_rate, eps))
+
+    def line_search_trials(self):
+        n = C.c_int()
+        _chk(lib().rtoc_line_search_trials(self._h, C.byref(n)))
+        return n.value
+
+    def line_search_merit_terms(self):
+        p, d = np.zeros(self.batch), np.zeros(self.batch)
+        lib().rtoc_line_search_merit_terms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]
+        _chk(lib().rtoc_line_search_merit_terms(self._h, _dp(p), _dp(d), self.batch))
+        return p, d
+
     def contact_line_search(self):
         n = C.c_int()
         _chk(lib().rtoc_contact_line_search(self._h, C.byref(n)))

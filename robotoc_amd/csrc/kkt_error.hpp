@@ -200,6 +200,72 @@ static __global__ void ls_advance_kernel(LsArgs a) {
   }
 }
 
+// ---- LineSearch::meritBacktrackingLineSearch (line_search.cpp:87-128), per instance ----
+// penaltyParam (:120-128): (1 + margin_rate) x the largest SplitSolution::lagrangeMultiplierLinfNorm over the grid
+// (split_solution.cpp:126-134: lmd, gmm, beta, nu_passive of a floating base, mu of the active contact dimensions, xi of the active
+// switching-constraint rows).  One wave per instance.
+struct LsPenaltyArgs {
+  const double* sol;
+  const rtoc_grid* grid;
+  double* penalty;   // [batch]
+  int nstages, batch, nv, np;
+  rtoc_record_layout sl;
+  double margin;
+};
+static __global__ __launch_bounds__(64) void ls_penalty_kernel(LsPenaltyArgs a) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  if (b >= a.batch) return;
+  double m = 0.0;
+  auto linf = [&](const double* p, int n) {
+    for (int i = lane; i < n; i += 64) m = fmax(m, fabs(p[i]));
+  };
+  for (int st = 0; st < a.nstages; ++st) {
+    const rtoc_grid g = a.grid[st];
+    const double* s = a.sol + ((size_t)b * a.nstages + st) * a.sl.stride;
+    linf(s + a.sl.off[RTOC_SOL_LMD], a.nv);
+    linf(s + a.sl.off[RTOC_SOL_GMM], a.nv);
+    if (g.type == RTOC_GRID_TERMINAL) continue;
+    linf(s + a.sl.off[RTOC_SOL_BETA], a.nv);
+    if (a.np > 0) linf(s + a.sl.off[RTOC_SOL_NUP], a.np);
+    linf(s + a.sl.off[RTOC_SOL_MU], g.dimf);
+    if (g.type != RTOC_GRID_IMPACT && g.switching_constraint) linf(s + a.sl.off[RTOC_SOL_XI], g.dims);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, 64));
+  if (lane == 0) a.penalty[b] = m * (1.0 + a.margin);
+}
+// phase 0: every instance gets the trial step eps (the directional derivative's trial, :96-103);
+// phase 1: dd = (merit(eps) - merit) / eps;
+// phase 2: armijoCondition (:111-117) of the active instances' trial at step alpha -> accepted.
+struct LsMeritArgs {
+  const double* cur;      // [2][batch] cost + barrier | violation of the iterate
+  const double* trial;    // [2][batch] of the trial iterate
+  const double* penalty;  // [batch]
+  double* dd;             // [batch] directional derivative of the merit function
+  double* trial_steps;    // [batch][2]
+  const double* alpha;    // [batch]
+  const int* active;
+  int* accepted;
+  int batch, phase;
+  double eps, armijo;
+};
+static __global__ void ls_merit_kernel(LsMeritArgs a) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.batch) return;
+  if (a.phase == 0) {
+    a.trial_steps[2 * b] = a.eps;
+    a.trial_steps[2 * b + 1] = 0.0;
+    return;
+  }
+  const double merit = a.cur[b] + a.penalty[b] * a.cur[a.batch + b];
+  const double merit_trial = a.trial[b] + a.penalty[b] * a.trial[a.batch + b];
+  if (a.phase == 1) {
+    a.dd[b] = (1.0 / a.eps) * (merit_trial - merit);
+    return;
+  }
+  a.accepted[b] = (a.active[b] && merit_trial < merit + a.armijo * a.alpha[b] * a.dd[b]) ? 1 : 0;
+}
+
 static __global__ void kkt_error_reduce_kernel(const double* partial, double* out, int nstages, int batch) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= batch) return;

@@ -237,6 +237,9 @@ struct rtoc_ctx {
   // filter line search on the device (rtoc_set_line_search, rtoc_contact_line_search)
   int ls_on;
   double ls_rate, ls_min_step, ls_cost_rate, ls_viol_rate;
+  int ls_method;        // 0 LineSearchMethod::Filter, 1 MeritBacktracking (rtoc_set_line_search_method)
+  double ls_armijo, ls_margin, ls_eps;
+  double* d_ls_merit;   // [batch] penalty parameter + [batch] directional derivative
   double ls_unconstr_dt;   // > 0: the last evalKKT was rtoc_unconstr_eval_kkt(dt) -- trial iterates of the line search are evaluated by it
   double* d_eval;       // [2][2][batch]: (cost + barrier | violation) of the current iterate, of the trial iterate
   double* d_eval_part;  // [batch][max_stages][2]
@@ -488,6 +491,7 @@ int rtoc_destroy(rtoc_ctx* c) {
   if (c->d_sol_trial) (void)hipFree(c->d_sol_trial);
   if (c->d_con_trial) (void)hipFree(c->d_con_trial);
   if (c->d_ls_steps) (void)hipFree(c->d_ls_steps);
+  if (c->d_ls_merit) (void)hipFree(c->d_ls_merit);
   if (c->d_ls_active) (void)hipFree(c->d_ls_active);
   if (c->d_cpos) (void)hipFree(c->d_cpos);
   if (c->d_crot) (void)hipFree(c->d_crot);
@@ -541,6 +545,7 @@ int rtoc_clone(rtoc_ctx* c, rtoc_ctx** out) {
     n->lin_dpp = c->lin_dpp;
     n->exact_cone_jacobian = c->exact_cone_jacobian;
     n->ls_on = c->ls_on, n->ls_rate = c->ls_rate, n->ls_min_step = c->ls_min_step, n->ls_cost_rate = c->ls_cost_rate, n->ls_viol_rate = c->ls_viol_rate;
+    n->ls_method = c->ls_method, n->ls_armijo = c->ls_armijo, n->ls_margin = c->ls_margin, n->ls_eps = c->ls_eps;
     if (c->backward_scan) rc = rtoc_set_option(n, RTOC_OPT_BACKWARD_SCAN, c->backward_scan);
   }
   hipError_t e = hipStreamSynchronize(c->stream);
@@ -2731,6 +2736,7 @@ static int ensure_line_search(rtoc_ctx* c) {
   if (!c->d_eval_part) HIP_TRY(hipMalloc((void**)&c->d_eval_part, sizeof(double) * 2 * c->batch * c->max_stages));
   if (!c->d_ls_steps) HIP_TRY(hipMalloc((void**)&c->d_ls_steps, sizeof(double) * 3 * c->batch));
   if (!c->d_ls_active) HIP_TRY(hipMalloc((void**)&c->d_ls_active, sizeof(int) * (c->batch + 1)));
+  if (!c->d_ls_merit) HIP_TRY(hipMalloc((void**)&c->d_ls_merit, sizeof(double) * 2 * c->batch));
   return RTOC_OK;
 }
 
@@ -2831,13 +2837,61 @@ static int launch_filter_device(rtoc_ctx* c, const double* eval, const int* mask
 // LineSearch::computeStepSize, filter method (line_search.cpp:31-83), for every instance: on entry RTOC_BUF_STEP holds the
 // maximum primal steps (fraction-to-boundary), d_eval[0] the current iterates' (cost + barrier, violation) -- rtoc_newton_iteration
 // evaluates them right after the linearisation; on exit the primal entries of RTOC_BUF_STEP are the accepted steps.
+int rtoc_set_line_search_method(rtoc_ctx* c, int method, double armijo_control_rate, double margin_rate, double eps) {
+  if (!c) return RTOC_ERR_BAD_ARG;
+  if (method != 0 && method != 1) return RTOC_ERR_BAD_ARG;
+  if (method == 1 && (!(armijo_control_rate > 0.0) || !(margin_rate >= 0.0) || !(eps > 0.0))) return RTOC_ERR_BAD_ARG;
+  c->ls_method = method;
+  if (method == 1) c->ls_armijo = armijo_control_rate, c->ls_margin = margin_rate, c->ls_eps = eps;
+  c->epoch++;
+  return RTOC_OK;
+}
+
+int rtoc_line_search_trials(rtoc_ctx* c, int* trials) {
+  if (!c || !trials) return RTOC_ERR_BAD_ARG;
+  *trials = c->ls_trials;
+  return RTOC_OK;
+}
+
+int rtoc_line_search_merit_terms(rtoc_ctx* c, double* host_penalty, double* host_directional_derivative, int count) {
+  CHECK_READY(c);
+  if (count < 0 || count > c->batch || !c->d_ls_merit) return RTOC_ERR_BAD_ARG;
+  if (host_penalty) HIP_TRY(hipMemcpyAsync(host_penalty, c->d_ls_merit, sizeof(double) * count, hipMemcpyDeviceToHost, c->stream));
+  if (host_directional_derivative)
+    HIP_TRY(hipMemcpyAsync(host_directional_derivative, c->d_ls_merit + c->batch, sizeof(double) * count, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return RTOC_OK;
+}
+
 int rtoc_contact_line_search(rtoc_ctx* c, int* host_trials) {
   CHECK_READY(c);
   if (!c->ls_on) return RTOC_ERR_NOT_READY;
   int rc = ensure_line_search(c);
   if (rc) return rc;
-  rc = launch_filter_device(c, c->d_eval, nullptr, 1);   // an empty filter is seeded with the current iterate (:58-62)
-  if (rc) return rc;
+  const bool merit = c->ls_method == 1;
+  LsMeritArgs ma;
+  if (!merit) {
+    rc = launch_filter_device(c, c->d_eval, nullptr, 1);   // an empty filter is seeded with the current iterate (:58-62)
+    if (rc) return rc;
+  } else {
+    // meritBacktrackingLineSearch (:87-109): penalty parameter from the multipliers of the iterate, directional derivative of the
+    // merit function from ONE more trial at step eps for every instance
+    if (!c->buf[RTOC_BUF_SOL]) return RTOC_ERR_NOT_READY;
+    LsPenaltyArgs pa;
+    pa.sol = c->buf[RTOC_BUF_SOL], pa.grid = c->d_grid, pa.penalty = c->d_ls_merit;
+    pa.nstages = c->nstages, pa.batch = c->batch, pa.nv = c->dims.nv, pa.np = c->dims.np, pa.sl = c->L.sol, pa.margin = c->ls_margin;
+    hipLaunchKernelGGL(ls_penalty_kernel, dim3(c->batch), dim3(64), 0, c->stream, pa);
+    ma.cur = c->d_eval, ma.trial = c->d_eval + 2 * c->batch, ma.penalty = c->d_ls_merit, ma.dd = c->d_ls_merit + c->batch;
+    ma.trial_steps = c->d_ls_steps, ma.alpha = c->d_ls_steps + 2 * c->batch, ma.active = c->d_ls_active, ma.accepted = c->d_ls_flags + c->batch;
+    ma.batch = c->batch, ma.eps = c->ls_eps, ma.armijo = c->ls_armijo;
+    ma.phase = 0;
+    hipLaunchKernelGGL(ls_merit_kernel, dim3((c->batch + 255) / 256), dim3(256), 0, c->stream, ma);
+    rc = eval_ocp_trial(c, c->d_ls_steps, c->d_eval + 2 * c->batch);
+    if (rc) return rc;
+    ma.phase = 1;
+    hipLaunchKernelGGL(ls_merit_kernel, dim3((c->batch + 255) / 256), dim3(256), 0, c->stream, ma);
+    HIP_TRY(hipGetLastError());
+  }
   LsArgs a;
   a.steps = c->buf[RTOC_BUF_STEP];
   a.trial_steps = c->d_ls_steps;
@@ -2850,17 +2904,22 @@ int rtoc_contact_line_search(rtoc_ctx* c, int* host_trials) {
   const dim3 grid((c->batch + 255) / 256), block(256);
   HIP_TRY(hipMemsetAsync(a.nactive, 0, sizeof(int), c->stream));
   hipLaunchKernelGGL(ls_begin_kernel, grid, block, 0, c->stream, a);
-  int nactive = 0, trials = 0;
+  int nactive = 0, trials = merit ? 1 : 0;   // (the trial at step eps counts as an evaluation)
   HIP_TRY(hipMemcpyAsync(&nactive, a.nactive, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   // the backtracking of one instance ends once its step falls below min_step_size (line_search.cpp:64-80): at most
   // log(min_step) / log(rate) reductions from a full step; the bound only guards against a loop that never drains
   const int max_trials = (int)ceil(log(c->ls_min_step < 1.0 ? c->ls_min_step : 1.0) / log(c->ls_rate)) + 2;
-  while (nactive > 0 && trials < max_trials) {
+  while (nactive > 0 && trials < max_trials + (merit ? 1 : 0)) {
     rc = eval_ocp_trial(c, c->d_ls_steps, c->d_eval + 2 * c->batch);
     if (rc) return rc;
-    rc = launch_filter_device(c, c->d_eval + 2 * c->batch, c->d_ls_active, 0);   // isAccepted + augment of the active instances
-    if (rc) return rc;
+    if (!merit) {
+      rc = launch_filter_device(c, c->d_eval + 2 * c->batch, c->d_ls_active, 0);   // isAccepted + augment of the active instances
+      if (rc) return rc;
+    } else {
+      ma.phase = 2;   // armijoCondition of the active instances
+      hipLaunchKernelGGL(ls_merit_kernel, dim3((c->batch + 255) / 256), dim3(256), 0, c->stream, ma);
+    }
     HIP_TRY(hipMemsetAsync(a.nactive, 0, sizeof(int), c->stream));
     hipLaunchKernelGGL(ls_advance_kernel, grid, block, 0, c->stream, a);
     HIP_TRY(hipMemcpyAsync(&nactive, a.nactive, sizeof(int), hipMemcpyDeviceToHost, c->stream));

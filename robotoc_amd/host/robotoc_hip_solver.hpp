@@ -40,12 +40,17 @@
 
 namespace robotoc {
 
-// include/robotoc/line_search/line_search_settings.hpp (the filter method's members)
+// include/robotoc/line_search/line_search_settings.hpp
+enum class LineSearchMethod { Filter, MeritBacktracking };
 struct LineSearchSettings {
+  LineSearchMethod line_search_method = LineSearchMethod::Filter;
   double step_size_reduction_rate = 0.75;
   double min_step_size = 0.05;
   double filter_cost_reduction_rate = 0.005;
   double filter_constraint_violation_reduction_rate = 0.005;
+  double armijo_control_rate = 0.001;
+  double margin_rate = 0.05;
+  double eps = 1.0e-08;
 };
 
 // include/robotoc/solver/solver_options.hpp:17-130 (the members the hot path reads)
@@ -543,6 +548,8 @@ class OCPSolver {
     const LineSearchSettings& ls = solver_options.line_search_settings;   // line_search_.set(...) (ocp_solver.cpp:86)
     chk(rtoc_set_line_search(dev_->get(), solver_options.enable_line_search ? 1 : 0, ls.step_size_reduction_rate, ls.min_step_size,
                              ls.filter_cost_reduction_rate, ls.filter_constraint_violation_reduction_rate), "rtoc_set_line_search");
+    chk(rtoc_set_line_search_method(dev_->get(), ls.line_search_method == LineSearchMethod::MeritBacktracking ? 1 : 0, ls.armijo_control_rate,
+                                    ls.margin_rate, ls.eps), "rtoc_set_line_search_method");
     dms_.setLineSearch(solver_options.enable_line_search);
     dms_.setFractionToBoundaryRule(solver_options.fraction_to_boundary_rule);
     riccati_recursion_.setRegularization(solver_options.max_dts_riccati);   // ocp_solver.cpp:84

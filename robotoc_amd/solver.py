@@ -37,6 +37,10 @@ class SolverOptions:
     min_step_size: float = 0.05
     filter_cost_reduction_rate: float = 0.005
     filter_constraint_violation_reduction_rate: float = 0.005
+    line_search_method: str = "filter"   # LineSearchMethod::Filter | "merit": MeritBacktracking (line_search.cpp:87-128)
+    armijo_control_rate: float = 0.001
+    margin_rate: float = 0.05
+    eps: float = 1.0e-8
 
 
 @dataclass
@@ -175,6 +179,7 @@ class OCPSolver:
             o = self.options
             c.set_line_search(True, o.step_size_reduction_rate, o.min_step_size, o.filter_cost_reduction_rate,
                               o.filter_constraint_violation_reduction_rate)
+            c.set_line_search_method(o.line_search_method, o.armijo_control_rate, o.margin_rate, o.eps)
         self.event_times = np.tile(np.array([e.time for e in plan.events], dtype=float), (batch, 1))   # per instance
         self.grids, self.masks, self.t_grid = None, None, None
         self.S = Records(c.L, "sol")

@@ -502,7 +502,7 @@ def icub_surface_stage_fixture(name="ref_icub_surface_stage.npz"):
     print(name, "stage KKT error %.6e" % out[-1])
 
 
-def ocp_solver_iteration_fixture(name="ref_anymal_ocp_solver_iteration.npz", sto=False, line_search=False):
+def ocp_solver_iteration_fixture(name="ref_anymal_ocp_solver_iteration.npz", sto=False, line_search=False, armijo=0.001):
     """ONE OCPSolver::updateSolution (src/solver/ocp_solver.cpp:111-145) of ANYmal over a short trot -- lifts, touch-downs with
     switching constraints, ConfigurationSpaceCost, six joint-limit components, FrictionCone -- run by the REFERENCE'S OWN
     DirectMultipleShooting, stages, ContactSequence, cost, constraints, dynamics and RiccatiRecursion sources
@@ -512,6 +512,9 @@ def ocp_solver_iteration_fixture(name="ref_anymal_ocp_solver_iteration.npz", sto
     switching-time optimisation) with the reference's SwitchingTimeOptimization over its minimum-dwell-time STOConstraints and the
     empty STOCostFunction of examples/anymal/python/jump_sto.py:104-108 in the loop (ocp_solver.cpp:119, 128-132, 143): the
     fixture also carries the event times before and after the iteration, the dwell-time rows and the switching-time directions.
+    line_search="merit": the same with LineSearchMethod::MeritBacktracking (line_search.cpp:87-128): penalty parameter, directional
+    derivative from a trial at step eps, Armijo backtracking; armijo = LineSearchSettings::armijo_control_rate (1.5 asks for more
+    decrease than the linear model promises: every candidate is evaluated and rejected, the loop ends below min_step_size).
     line_search=True: SolverOptions::enable_line_search -- the reference's own LineSearch::computeStepSize (filter method,
     src/line_search/line_search.cpp:31-83) picks the primal step between computeStepSizes and integrateSolution
     (ocp_solver.cpp:133-139); every trial iterate's rigid-body quantities are injected like those of the iterate itself."""
@@ -669,9 +672,17 @@ def ocp_solver_iteration_fixture(name="ref_anymal_ocp_solver_iteration.npz", sto
         # a filter that wants the violation halved: no trial below the (fraction-to-boundary) maximum step can deliver that, so every
         # candidate is evaluated and rejected and the loop ends below min_step_size -- the whole backtracking path runs
         rate, min_step, cost_rate, viol_rate = 0.75, 0.05, 0.005, 0.5
+        merit = line_search == "merit"
+        margin, eps = 0.05, 1.0e-8   # LineSearchSettings' defaults; armijo_control_rate: the default 0.001, or the caller's (see FIXTURES)
         L.ref_ocp_trial_solution.argtypes = [C.c_double, dp, dp]
         L.ref_ocp_line_search.argtypes = [C.c_double, C.c_double, C.c_double, C.c_double, dp]
+        L.ref_ocp_line_search_merit.argtypes = [C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, dp]
         trials, alpha = [], float(steps[0])
+        if merit:   # the directional derivative's trial at step eps comes first (line_search.cpp:98-103)
+            q_tr = np.array([plus(q[i], eps * out_dq[i]) for i in range(n)])
+            s_tr = np.zeros((n, SL))
+            assert L.ref_ocp_trial_solution(eps, ptr(q_tr), s_tr.ctypes.data_as(dp)) == 0
+            trials.append((eps, q_tr, s_tr))
         while alpha > min_step:
             q_tr = np.array([plus(q[i], alpha * out_dq[i]) for i in range(n)])
             s_tr = np.zeros((n, SL))
@@ -712,12 +723,32 @@ def ocp_solver_iteration_fixture(name="ref_anymal_ocp_solver_iteration.npz", sto
                 assert L.ref_ocp_trial_eval(alpha, ev.ctypes.data_as(dp)) == 0
                 trial_evals.append(ev)
         ls_step = np.zeros(2)
-        assert L.ref_ocp_line_search(rate, min_step, cost_rate, viol_rate, ls_step.ctypes.data_as(dp)) == 0
+        if merit:
+            assert L.ref_ocp_line_search_merit(rate, min_step, armijo, margin, eps, ls_step.ctypes.data_as(dp)) == 0
+        else:
+            assert L.ref_ocp_line_search(rate, min_step, cost_rate, viol_rate, ls_step.ctypes.data_as(dp)) == 0
         n_eval = len(trials) - int(round(ls_step[1])) // (n - 1)
         print("  line search: max primal step %.4f -> accepted %.4f (%d of %d candidate trials evaluated), eval0 cost %.4e barrier %.4e violation %.4e"
               % (steps[0], ls_step[0], n_eval, len(trials), steps[3], steps[4], steps[5]))
         ls_kw = dict(ls_step=ls_step[:1], ls_trials_evaluated=np.array([n_eval]), ls_max_step=steps[:1].copy(), ls_trial_evals=np.array(trial_evals), ls_eval0=steps[3:6].copy(), ls_settings=np.array([rate, min_step, cost_rate, viol_rate]),
                      ls_trial_steps=np.array([t[0] for t in trials]))
+        if merit:
+            # LineSearch::penaltyParam restated on the iterate (line_search.cpp:120-128; SplitSolution::lagrangeMultiplierLinfNorm,
+            # split_solution.cpp:126-134) and the merit values the reference's decisions rest on, for the test's report
+            o_l = nq + 2 * nv + nu + 3 * nc
+            pen = 0.0
+            for i, g in enumerate(grids):
+                act = [c for c in range(nc) if (int(masks[i]) >> c) & 1]
+                vals = [np.abs(sol[i, o_l:o_l + 2 * nv]).max()]                      # lmd, gmm
+                if g.type != GT:
+                    vals.append(np.abs(sol[i, o_l + 2 * nv:o_l + 3 * nv]).max())     # beta
+                    vals.append(np.abs(sol[i, o_l + 3 * nv + 3 * nc:o_l + 3 * nv + 3 * nc + 6]).max())   # nu_passive
+                    if act:
+                        vals.append(max(np.abs(sol[i, o_l + 3 * nv + 3 * c:o_l + 3 * nv + 3 * c + 3]).max() for c in act))   # mu of the active contacts
+                    if g.switching_constraint and g.type != GI:
+                        vals.append(np.abs(sol[i, o_l + 3 * nv + 3 * nc + 6:o_l + 3 * nv + 3 * nc + 6 + g.dims]).max())      # xi
+                pen = max(pen, max(vals))
+            ls_kw.update(ls_merit_settings=np.array([armijo, margin, eps]), ls_penalty=np.array([pen * (1.0 + margin)]))
         steps[0] = ls_step[0]
     q_int = np.array([plus(q[i], steps[0] * out_dq[i]) for i in range(n)])
     sol_out, slack_out, dual_out = np.zeros((n, SL)), np.zeros((n, nrow)), np.zeros((n, nrow))
@@ -746,6 +777,8 @@ FIXTURES = {
     "riccati_icub32": icub32_full_size,
     "ocp_iteration_sto": lambda: ocp_solver_iteration_fixture("ref_anymal_jump_sto_solver_iteration.npz", sto=True),
     "ocp_iteration_line_search": lambda: ocp_solver_iteration_fixture("ref_anymal_ocp_solver_iteration_line_search.npz", line_search=True),
+    "ocp_iteration_line_search_merit": lambda: (ocp_solver_iteration_fixture("ref_anymal_ocp_solver_iteration_line_search_merit.npz", line_search="merit"),
+                                                ocp_solver_iteration_fixture("ref_anymal_ocp_solver_iteration_line_search_merit_reject.npz", line_search="merit", armijo=1.5)),
 }
 
 if __name__ == "__main__":   # python tests/golden/make_ref_golden.py [fixture ...]   (default: all)
