@@ -66,6 +66,49 @@ def unconstr_update_solution(nv, N, dt, cost, limits, barrier, tau, x0, sol, rne
     return kkt, out[0], out[1], out[2], con
 
 
+def unconstr_line_search_iteration(nv, N, dt, cost, limits, barrier, tau, x0, sol, rnea, inverse_dynamics, settings, con=None,
+                                   init_constraints=True, max_trials=24):
+    """UnconstrOCPSolver::updateSolution WITH enable_line_search (unconstr_ocp_solver.cpp:96-118): the reference's own
+    UnconstrDirectMultipleShooting, UnconstrRiccatiRecursion and UnconstrLineSearch (oracle/ref_shim/ref_unconstr_ls_capi.cpp).
+    inverse_dynamics(q, v, a) -> ID supplies what the trial iterates' stages ask of Pinocchio; settings = (step_size_reduction_rate,
+    min_step_size, filter_cost_reduction_rate, filter_constraint_violation_reduction_rate).  sol [N+1, 7 nv] is updated in place.
+    Returns dict(direction [N+1, 4 nv], dslack, kkt_error (sum of squares), max_primal, max_dual, eval (cost, barrier, violation),
+    step, trials (filter evaluations consumed), con)."""
+    L = lib()
+    dp = C.POINTER(C.c_double)
+    L.ref_uls_direction.argtypes = [C.c_int, C.c_int, C.c_double, dp, dp, C.c_double, C.c_double, dp, dp, dp, dp, dp, C.c_int, dp, dp, dp]
+    L.ref_uls_line_search.argtypes = [dp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, dp]
+    L.ref_uls_integrate.argtypes = [dp, dp]
+    cost = np.ascontiguousarray(cost, dtype=np.float64)
+    lim = None if limits is None else np.ascontiguousarray(limits, dtype=np.float64)
+    if con is None:
+        con = np.zeros((N, 2, 6 * nv))
+    q0, v0 = np.ascontiguousarray(x0[:nv]), np.ascontiguousarray(x0[nv:])
+    d = np.zeros((N + 1, 4 * nv))
+    dslack = np.zeros((N, 6 * nv))
+    out = np.zeros(6)
+    rc = L.ref_uls_direction(nv, N, dt, _p(cost), _p(lim) if lim is not None else None, barrier, tau, _p(q0), _p(v0), _p(sol), _p(rnea),
+                             _p(con), int(init_constraints), _p(d), _p(dslack), _p(out))
+    assert rc == 0
+    rate, min_step, cost_rate, viol_rate = settings
+    trial = np.zeros((max_trials, N, nv))
+    alpha = out[1]
+    for k in range(max_trials):   # the loop of unconstr_line_search.cpp:51-64 visits max, max rate, max rate^2, ... until accepted or <= min
+        for i in range(N):
+            trial[k, i] = inverse_dynamics(sol[i, :nv] + alpha * d[i, :nv], sol[i, nv:2 * nv] + alpha * d[i, nv:2 * nv],
+                                           sol[i, 2 * nv:3 * nv] + alpha * d[i, 2 * nv:3 * nv])
+        alpha *= rate
+    ls = np.zeros(2)
+    rc = L.ref_uls_line_search(_p(trial), max_trials, rate, min_step, cost_rate, viol_rate, _p(ls))
+    assert rc == 0
+    used = max_trials - int(round(ls[1]))
+    assert 0 < used < max_trials, "the reference asked for more trial iterates than were prepared"
+    rc = L.ref_uls_integrate(_p(sol), _p(con))
+    assert rc == 0
+    return dict(direction=d, dslack=dslack, kkt_error=out[0], max_primal=out[1], max_dual=out[2], eval=out[3:6].copy(), step=ls[0],
+                trials=used, con=con)
+
+
 def _p(a):
     assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
     return a.ctypes.data_as(C.POINTER(C.c_double))

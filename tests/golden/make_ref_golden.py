@@ -165,6 +165,62 @@ def unconstr_solver_fixture(name, with_limits):
     print(name, "KKT error %.6e, steps %.4f / %.4f" % (err, primal, dual))
 
 
+def unconstr_line_search_fixture(name, with_limits, backtrack):
+    """One UnconstrOCPSolver::updateSolution of the iiwa14 OCP WITH SolverOptions::enable_line_search
+    (unconstr_ocp_solver.cpp:96-118), run by the REFERENCE'S OWN UnconstrDirectMultipleShooting, UnconstrRiccatiRecursion and
+    UnconstrLineSearch (src/line_search/unconstr_line_search.cpp; oracle/ref_shim/ref_unconstr_ls_capi.cpp).  The inverse
+    dynamics of the iterate (with its partial derivatives) and of every trial iterate the filter loop visits is injected from this
+    repository's CPU rigid-body restatement.  backtrack = False: a random inconsistent iterate (the full step closes most of the
+    violation: accepted at the first trial).  backtrack = True: the arm at rest in a bent pose that is also the cost's reference,
+    zero torques, torques weighted a thousand times the configuration -- the Newton step swings the arm by more than a radian to where
+    the LINEARISED gravity torque vanishes, the cost rises, the real violation does not fall by the filter's margin: the reference
+    rejects several trials before it accepts."""
+    from robotoc_amd import robot_model as rm
+    m = rm.load_named("iiwa14")
+    nv, N, dt = m.nv, 20, 0.05
+    rng = np.random.default_rng(9090 + int(with_limits) + 10 * int(backtrack))
+    sol = np.zeros((N + 1, 7 * nv))
+    if backtrack:
+        q = 1.5 * rng.uniform(-1, 1, nv)
+        cost = np.stack([q, np.zeros(nv), np.zeros(nv), np.full(nv, 0.01), np.full(nv, 0.1), np.full(nv, 0.01), np.full(nv, 10.0),
+                         np.full(nv, 0.01), np.full(nv, 0.1)])
+        x0 = np.concatenate([q, np.zeros(nv)])
+        sol[:, :nv] = q
+        limits = np.stack([np.full(nv, -4.0), np.full(nv, 4.0), np.full(nv, 30.0), np.full(nv, 500.0)]) if with_limits else None
+    else:
+        cost = np.stack([rng.uniform(-0.8, 0.8, nv), np.zeros(nv), np.zeros(nv), np.full(nv, 10.0), np.full(nv, 0.1), np.full(nv, 0.01),
+                         np.full(nv, 0.001), np.full(nv, 10.0), np.full(nv, 0.1)])
+        x0 = np.concatenate([rng.uniform(-0.5, 0.5, nv), np.zeros(nv)])
+        sol[:, :nv] = x0[:nv] + 0.1 * rng.uniform(-1, 1, (N + 1, nv))
+        sol[:, nv:2 * nv] = 0.3 * rng.uniform(-1, 1, (N + 1, nv))
+        sol[:, 2 * nv:3 * nv] = rng.uniform(-1, 1, (N + 1, nv))
+        sol[:, 3 * nv:4 * nv] = 5.0 * rng.uniform(-1, 1, (N + 1, nv))
+        sol[:, 4 * nv:] = 0.5 * rng.uniform(-1, 1, (N + 1, 3 * nv))
+        limits = np.stack([np.full(nv, -1.0), np.full(nv, 1.0), np.full(nv, 1.5), np.full(nv, 40.0)]) if with_limits else None
+    rnea = np.zeros((N, nv + 3 * nv * nv))
+    z = np.zeros(0)
+
+    def inverse_dynamics(q, v, a):
+        return orc.rbd_eval(m, 0, q, v, a, z, np.zeros(nv), 0, z)[:nv]
+    for i in range(N):
+        q, v, a = sol[i, :nv], sol[i, nv:2 * nv], sol[i, 2 * nv:3 * nv]
+        rnea[i, :nv] = inverse_dynamics(q, v, a)
+        h = 2.0e-3
+        J1, J2 = orc.rbd_linearize_fd(m, 0, q, v, a, z, np.zeros(nv), 0, z, eps=h), orc.rbd_linearize_fd(m, 0, q, v, a, z, np.zeros(nv), 0, z, eps=h / 2)
+        for k in range(3):
+            J = (4.0 * np.asarray(J2[k])[:nv] - np.asarray(J1[k])[:nv]) / 3.0
+            rnea[i, nv + k * nv * nv:nv + (k + 1) * nv * nv] = J.T.reshape(-1)
+    sol_in = sol.copy()
+    settings = (0.75, 0.05, 0.005, 0.005)   # LineSearchSettings' defaults (line_search_settings.hpp)
+    r = ref.unconstr_line_search_iteration(nv, N, dt, cost, limits, 1.0e-3, 0.995, x0, sol, rnea, inverse_dynamics, settings)
+    np.savez_compressed(os.path.join(HERE, name), cost=cost, x0=x0, sol_in=sol_in, sol_out=sol, limits=limits if with_limits else np.zeros(0),
+                        direction=r["direction"], dslack=r["dslack"], con=r["con"], settings=np.array(settings),
+                        scalars=np.array([r["kkt_error"], r["max_primal"], r["max_dual"], dt, 1.0e-3, 0.995, r["step"], r["trials"]]),
+                        eval=r["eval"])
+    print(name, "KKT error %.6e, max steps %.4f / %.4f, accepted %.6f after %d trials; cost %.4e barrier %.4e violation %.4e"
+          % (r["kkt_error"], r["max_primal"], r["max_dual"], r["step"], r["trials"], *r["eval"]))
+
+
 def _richardson(fun, n, h=2.0e-3):
     """Jacobian of fun over an n-dimensional perturbation: central differences at h and h / 2, one Richardson step (O(h^4))"""
     def central(step):
@@ -769,6 +825,9 @@ FIXTURES = {
     "riccati": main,
     "unconstr_solver": lambda: (unconstr_solver_fixture("ref_iiwa14_unconstr_solver.npz", False),
                                 unconstr_solver_fixture("ref_iiwa14_unconstr_solver_limits.npz", True)),
+    "unconstr_line_search": lambda: [unconstr_line_search_fixture("ref_iiwa14_unconstr_line_search%s.npz" % tag, lim, back)
+                                     for tag, lim, back in (("", False, False), ("_limits", True, False), ("_backtrack", False, True),
+                                                            ("_limits_backtrack", True, True))],
     "contact_stage": contact_stage_fixture,
     "impact_terminal_stage": impact_and_terminal_stage_fixture,
     "icub_surface_stage": icub_surface_stage_fixture,
