@@ -165,6 +165,14 @@ enum rtoc_option {
                       * tiles (nv = 18, nu = 12: ANYmal, A1), grids without switching-time optimisation, RTOC_OPT_WRITEBACK_KKT = 0
                       * and the default RTOC_OPT_BACKWARD_WAVES.  Elsewhere, and with 0, the role-split / tile-split kernels run.
                       * Same results to fp64 round-off (tests/test_backward_register.py). */
+  RTOC_OPT_CONDENSE_REGISTER = 17, /* 1 (default): rtoc_condense runs the register-chained kernel (one wavefront per grid point, the saddle
+                      * inverse read once into MFMA accumulators, every product of condenseContactDynamics chained through
+                      * register layouts; condense_rv.hpp) on the CONTACT grid points of shapes it is laid out for (nv + nf_max <= 32,
+                      * 32 < 2 nv <= 46: ANYmal, A1) in contexts WITHOUT friction / wrench cone rows -- impact grid points,
+                      * RTOC_OPT_CONDENSE_SPLIT = 1 and RTOC_OPT_CONDENSE_KEEP_QAF = 1 run the role-split kernels.  2: also with cone
+                      * rows (their own kernel first: no faster than the role-split kernel, which hides them under its assembly of
+                      * MJtJinv).  0: never.  Same results to fp64 round-off (tests/test_condense_register.py).
+                      * RTOC_CONDENSE_REGISTER=0|1|2 in the environment sets the default of contexts created afterwards. */
   RTOC_OPT_SWITCHING_TRANSPORT = 10 /* Free-flyer block of Phiq / Phiv / Phia in rtoc_contact_eval_kkt's switching-constraint
                       * rows.  0 (default): as the reference composes it -- it hands pinocchio::dIntegrateTransport the
                       * transposed Jacobian (robot.hxx:69-72, :88-91), which yields Pq dIntegrate^T.  1: the chain rule

@@ -10,7 +10,7 @@ import subprocess
 import numpy as np
 
 from .types import (BoxRow, BUF_CDD, BUF_CON, BUF_DIR, BUF_DX0, BUF_KKT, BUF_RIC, BUF_STEP, Dims, Grid,
-                    Layout, OPT_BACKWARD_WAVES, OPT_CONDENSE_SPLIT, OPT_CONDENSE_KEEP_QAF, OPT_FXX_STRUCTURE, OPT_GRAPH, OPT_SWITCHING_TRANSPORT, OPT_IMPACT_CONES, OPT_UNCONSTR_DENSE, OPT_LINEARIZE_FUSED, OPT_LINEARIZE_DOFS_PER_PASS, OPT_CONE_JACOBIAN, OPT_MAX_DTS0, OPT_SWEEP_CHUNKS, OPT_WRITEBACK_KKT, OPT_BACKWARD_SCAN, OPT_BACKWARD_REGISTER,
+                    Layout, OPT_BACKWARD_WAVES, OPT_CONDENSE_SPLIT, OPT_CONDENSE_KEEP_QAF, OPT_FXX_STRUCTURE, OPT_GRAPH, OPT_SWITCHING_TRANSPORT, OPT_IMPACT_CONES, OPT_UNCONSTR_DENSE, OPT_LINEARIZE_FUSED, OPT_LINEARIZE_DOFS_PER_PASS, OPT_CONE_JACOBIAN, OPT_MAX_DTS0, OPT_SWEEP_CHUNKS, OPT_WRITEBACK_KKT, OPT_BACKWARD_SCAN, OPT_BACKWARD_REGISTER, OPT_CONDENSE_REGISTER,
                     grid_array)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -307,6 +307,11 @@ class Context:
     def set_backward_scan(self, on):
         """RTOC_OPT_BACKWARD_SCAN: backward recursion as a scan over the horizon (few instances, low latency)."""
         _chk(lib().rtoc_set_option(self._h, OPT_BACKWARD_SCAN, 2 if on == "auto" else int(bool(on))))
+
+    def set_condense_register(self, on=True):
+        """RTOC_OPT_CONDENSE_REGISTER: the register-chained condensation kernel (one wave per contact grid point) where it applies;
+        "cones": also in contexts with friction / wrench cone rows."""
+        _chk(lib().rtoc_set_option(self._h, OPT_CONDENSE_REGISTER, 2 if on == "cones" else int(bool(on))))
 
     def set_backward_register(self, on):
         """RTOC_OPT_BACKWARD_REGISTER: the register-resident backward kernel (one wave per instance) where it applies."""

@@ -72,6 +72,9 @@ struct CondArgs {
   int cone_contacts, cone_dim, cone_row0, cone_stride, cone_dgdf_off, cone_impact;
   int keep_qaf;  // RTOC_OPT_CONDENSE_KEEP_QAF: also store Qafqv / Qafu_full in the ContactDynamicsData record
   const double* dt_inst;  // [batch][nstages] per-instance time steps (switching-time optimisation) or nullptr (device_utils.hpp: grid_dt)
+  // work items = batch x these grid points (nullptr: all of 0 .. nstages - 2): the impact grid points behind condense_rv_kernel
+  const int* stage_list;
+  int nlist;
 };
 
 struct ExpArgs {
@@ -361,8 +364,9 @@ __global__ __launch_bounds__(64 * RTOC_COND_NW, (CondCfg<NV, NU, NF, NS, SPLIT>:
   const int lane = threadIdx.x;  // thread index within the work item (NT threads)
   const int wv = lane >> 6, wl = lane & 63;
   const int item = blockIdx.x;  // instance * (nstages-1) + stage
-  const int nst1 = a.nstages - 1;
-  const int b = item / nst1, st = item % nst1;
+  const int nst1 = a.stage_list ? a.nlist : a.nstages - 1;
+  const int b = item / nst1;
+  const int st = a.stage_list ? a.stage_list[item % nst1] : item % nst1;
   if (b >= a.batch) return;
   const rtoc_grid g = a.grid[st];
   const bool impact = g.type == RTOC_GRID_IMPACT;

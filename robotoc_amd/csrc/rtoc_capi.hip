@@ -175,6 +175,9 @@ struct rtoc_ctx {
   int keep_qaf;        // RTOC_OPT_CONDENSE_KEEP_QAF
   int fxx_mode;        // RTOC_OPT_FXX_STRUCTURE: 0 auto, 1 dense, 2 caller asserts the structure
   int bwd_register;    // RTOC_OPT_BACKWARD_REGISTER: the register-resident backward kernel where it applies
+  int cond_register;   // RTOC_OPT_CONDENSE_REGISTER: the register-chained condensation of the contact grid points where it applies
+  int* d_stage_list;   // [max_stages] grid points 0 .. nstages - 2: the contact ones first (n_stage_contact), then the impact ones
+  int n_stage_contact, n_stage_impact;
   int fxx_state;       // auto mode cache: 0 unknown (re-check before the next backward recursion), 1 every Fxx structured, 2 not
   int fxx_last;        // the last check's answer (1 / 2; 0 never checked): the kernel choice baked into captured graphs
   unsigned long long graph_replays;  // hipGraphLaunch count of RTOC_OPT_GRAPH (rtoc_graph_replay_count)
@@ -364,6 +367,8 @@ static int create_members(rtoc_ctx* c, const rtoc_dims* dims, const KernelSet* k
   c->max_dts0 = 0.1;  // RiccatiRecursion(ocp, max_dts0 = 0.1), riccati_recursion.hpp:35
   c->bwd_variant = (ks->nvariants >= 3) ? ks->nvariants - 1 : 0;  // role-split kernel where it exists
   c->bwd_register = 1;   // ... and the register-resident kernel wherever it applies (rv_applies)
+  c->cond_register = 1;  // likewise the condensation (cond_rv_applies)
+  if (const char* e = getenv("RTOC_CONDENSE_REGISTER")) c->cond_register = (e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1;
   HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
   c->stream = c->own_stream;
   HIP_TRY(hipEventCreate(&c->ev0));
@@ -401,6 +406,7 @@ static int create_members(rtoc_ctx* c, const rtoc_dims* dims, const KernelSet* k
     c->owned[i] = true;
   }
   HIP_TRY(hipMalloc((void**)&c->d_grid, sizeof(rtoc_grid) * max_stages));
+  HIP_TRY(hipMalloc((void**)&c->d_stage_list, sizeof(int) * max_stages));
   HIP_TRY(hipMalloc((void**)&c->d_status, sizeof(uint32_t) * batch));
   HIP_TRY(hipMemsetAsync(c->d_status, 0, sizeof(uint32_t) * batch, c->stream));
   for (int v = 0; v < ks->nvariants; ++v)
@@ -453,6 +459,7 @@ int rtoc_destroy(rtoc_ctx* c) {
   for (int i = 0; i < RTOC_NUM_BUFFERS; ++i)
     if (c->owned[i] && c->buf[i]) (void)hipFree(c->buf[i]);
   if (c->d_grid) (void)hipFree(c->d_grid);
+  if (c->d_stage_list) (void)hipFree(c->d_stage_list);
   if (c->d_rows) (void)hipFree(c->d_rows);
   free(c->h_rows);
   free(c->h_grid);
@@ -530,6 +537,7 @@ int rtoc_clone(rtoc_ctx* c, rtoc_ctx** out) {
   if (!rc) {
     n->writeback = c->writeback;
     n->bwd_register = c->bwd_register;
+    n->cond_register = c->cond_register;
     n->max_dts0 = c->max_dts0;
     n->contact_inv_damping = c->contact_inv_damping;
     n->bwd_variant = c->bwd_variant;
@@ -630,6 +638,18 @@ int rtoc_set_grid(rtoc_ctx* c, const rtoc_grid* grid, int nstages) {
   }
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipMemcpyAsync(c->d_grid, grid, sizeof(rtoc_grid) * nstages, hipMemcpyHostToDevice, c->stream));
+  {
+    // the grid points a condensation launch covers, by kind (condense_rv_kernel takes the contact ones, condense_kernel the impact ones)
+    std::vector<int> list;
+    for (int i = 0; i + 1 < nstages; ++i)
+      if (grid[i].type != RTOC_GRID_IMPACT) list.push_back(i);
+    c->n_stage_contact = (int)list.size();
+    for (int i = 0; i + 1 < nstages; ++i)
+      if (grid[i].type == RTOC_GRID_IMPACT) list.push_back(i);
+    c->n_stage_impact = (int)list.size() - c->n_stage_contact;
+    HIP_TRY(hipMemcpyAsync(c->d_stage_list, list.data(), sizeof(int) * list.size(), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));   // (the pageable source dies with this scope)
+  }
   HIP_TRY(hipStreamSynchronize(c->stream));
   if (!c->h_grid) c->h_grid = (rtoc_grid*)malloc(sizeof(rtoc_grid) * c->max_stages);
   if (c->h_grid) memcpy(c->h_grid, grid, sizeof(rtoc_grid) * nstages);
@@ -684,6 +704,7 @@ int rtoc_get_option(rtoc_ctx* c, int option, int64_t* value) {
     case RTOC_OPT_IMPACT_CONES: *value = c->impact_cones; return RTOC_OK;
     case RTOC_OPT_LINEARIZE_DOFS_PER_PASS: *value = c->h_model ? c->h_model->dpp : 0; return RTOC_OK;
     case RTOC_OPT_BACKWARD_REGISTER: *value = c->bwd_register; return RTOC_OK;
+    case RTOC_OPT_CONDENSE_REGISTER: *value = c->cond_register; return RTOC_OK;
     case RTOC_OPT_BACKWARD_WAVES: *value = c->ks->bwd_waves[c->bwd_variant]; return RTOC_OK;
     case RTOC_OPT_SWITCHING_TRANSPORT: *value = c->exact_transport; return RTOC_OK;
     case RTOC_OPT_UNCONSTR_DENSE: *value = c->unconstr_dense; return RTOC_OK;
@@ -757,6 +778,10 @@ int rtoc_set_option(rtoc_ctx* c, int option, int64_t value) {
     case RTOC_OPT_BACKWARD_REGISTER:
       if (value != 0 && value != 1) return RTOC_ERR_BAD_ARG;
       c->bwd_register = (int)value;
+      return RTOC_OK;
+    case RTOC_OPT_CONDENSE_REGISTER:
+      if (value != 0 && value != 1 && value != 2) return RTOC_ERR_BAD_ARG;
+      c->cond_register = (int)value;
       return RTOC_OK;
     case RTOC_OPT_GRAPH:
       if (value != 0 && value != 1) return RTOC_ERR_BAD_ARG;
@@ -1150,10 +1175,23 @@ static int launch_sweep(rtoc_ctx* c) {
   return RTOC_OK;
 }
 
+// RTOC_OPT_CONDENSE_REGISTER: the contact grid points by condense_rv_kernel (one wave per work item, products chained through
+// registers), the impact grid points by condense_kernel.  1 (default): contexts WITHOUT friction / wrench cone rows -- the one-kernel
+// role-split condensation hides the cone rows under its solo assembly of MJtJinv, here they would need their own kernel ahead of
+// condense_rv_kernel (0.81 ms per 4096 x 46), which eats the gain (measured per 4096 ANYmal trot instances: 4.80 -> 4.00 ms without
+// rows, 5.29 -> 5.24 ms with 72 joint-limit rows and 4 cones).  2: also with cone rows (cone kernel first).
+static bool cond_rv_applies(const rtoc_ctx* c) {
+  if (!c->cond_register || !c->ks->cond_rv || c->condense_split || c->keep_qaf) return false;
+  if (c->cone_contacts > 0 && c->cond_register < 2) return false;
+  return c->n_stage_contact + c->n_stage_impact == c->nstages - 1;
+}
+
 static int launch_condense(rtoc_ctx* c) {
   int rc = ensure_buffer(c, RTOC_BUF_CDD);
   if (rc) return rc;
   CondArgs a;
+  a.stage_list = nullptr;
+  a.nlist = 0;
   a.kkt = c->buf[RTOC_BUF_KKT];
   a.cdd = c->buf[RTOC_BUF_CDD];
   a.grid = c->d_grid;
@@ -1174,7 +1212,8 @@ static int launch_condense(rtoc_ctx* c) {
   a.cone_rows = 0;
   a.keep_qaf = c->keep_qaf;
   a.dt_inst = c->sto_on ? c->d_dt : nullptr;
-  if ((c->condense_split || c->ks->cond_fuses_cones) && c->cone_contacts > 0) {  // the cone rows ride with the MJtJinv kernel / in wave 1 of the fused kernel
+  const bool rv = cond_rv_applies(c);
+  if (!rv && (c->condense_split || c->ks->cond_fuses_cones) && c->cone_contacts > 0) {  // the cone rows ride with the MJtJinv kernel / in wave 1 of the fused kernel
     if (!c->buf[RTOC_BUF_CONE] || !c->buf[RTOC_BUF_CON]) return RTOC_ERR_NOT_READY;
     const bool wrench = c->cone_rows == RTOC_WRENCH_ROWS;
     a.cone_rows = c->cone_rows;
@@ -1187,7 +1226,15 @@ static int launch_condense(rtoc_ctx* c) {
     a.cone_dgdf_off = rtoc_cone_dgdf_off(c->dims.nv, c->cone_contacts);
     a.cone_impact = c->impact_cones;
   }
-  if (c->condense_split) {
+  if (rv) {
+    a.stage_list = c->d_stage_list;
+    a.nlist = c->n_stage_contact;
+    static const int lds_pad = getenv("RTOC_CRV_LDS_PAD") ? atoi(getenv("RTOC_CRV_LDS_PAD")) : 0;   // occupancy experiments
+    if (a.nlist > 0) hipLaunchKernelGGL(c->ks->cond_rv, dim3(c->batch * a.nlist), dim3(64), c->ks->cond_rv_lds + lds_pad, c->stream, a);
+    a.stage_list = c->d_stage_list + c->n_stage_contact;
+    a.nlist = c->n_stage_impact;
+    if (a.nlist > 0) hipLaunchKernelGGL(c->ks->cond, dim3(c->batch * a.nlist), dim3(c->ks->cond_threads), c->ks->cond_lds, c->stream, a);
+  } else if (c->condense_split) {
     hipLaunchKernelGGL(c->ks->mjt, dim3(nblocks), dim3(64), c->ks->mjt_lds, c->stream, a);
     hipLaunchKernelGGL(c->ks->cond_split, dim3(nblocks), dim3(c->ks->cond_threads), c->ks->cond_split_lds, c->stream, a);
   } else {
@@ -1314,7 +1361,7 @@ int rtoc_compute_initial_state_direction(rtoc_ctx* c) {
 int rtoc_condense(rtoc_ctx* c) {
   CHECK_READY(c);
   int rc = RTOC_OK;
-  if (c->cone_contacts > 0 && !c->condense_split && !c->ks->cond_fuses_cones) rc = launch_cones(c, 0, 0.0);  // Constraints::condenseSlackAndDual first
+  if (c->cone_contacts > 0 && ((!c->condense_split && !c->ks->cond_fuses_cones) || cond_rv_applies(c))) rc = launch_cones(c, 0, 0.0);  // Constraints::condenseSlackAndDual first
   if (!rc) rc = launch_condense(c);
   if (!rc && c->buf[RTOC_BUF_SE3] && c->dims.np == 6) rc = launch_state_correction(c, 0);
   return rc;

@@ -24,7 +24,7 @@ STAT_QUU_NOT_SPD, STAT_S_NOT_SPD, STAT_NAN, STAT_M_NOT_SPD = 1, 2, 4, 8
 BUF_KKT, BUF_RIC, BUF_DIR, BUF_CDD, BUF_CON, BUF_DX0, BUF_STEP, BUF_SE3, BUF_CONE, BUF_SOL = range(10)
 SOL_FIELDS = ["q", "v", "a", "u", "f", "lmd", "gmm", "beta", "mu", "nu_passive", "xi"]
 SE3_STRIDE, SE3_FQQ_INV, SE3_FQQ_PREV_INV = 72, 0, 36
-OPT_WRITEBACK_KKT, OPT_MAX_DTS0, OPT_BACKWARD_WAVES, OPT_CONTACT_INV_DAMPING, OPT_SWEEP_CHUNKS, OPT_CONDENSE_SPLIT, OPT_BACKWARD_SCAN, OPT_CONDENSE_KEEP_QAF, OPT_FXX_STRUCTURE, OPT_GRAPH, OPT_SWITCHING_TRANSPORT, OPT_IMPACT_CONES, OPT_UNCONSTR_DENSE, OPT_LINEARIZE_FUSED, OPT_CONE_JACOBIAN, OPT_LINEARIZE_DOFS_PER_PASS, OPT_BACKWARD_REGISTER = range(17)
+OPT_WRITEBACK_KKT, OPT_MAX_DTS0, OPT_BACKWARD_WAVES, OPT_CONTACT_INV_DAMPING, OPT_SWEEP_CHUNKS, OPT_CONDENSE_SPLIT, OPT_BACKWARD_SCAN, OPT_CONDENSE_KEEP_QAF, OPT_FXX_STRUCTURE, OPT_GRAPH, OPT_SWITCHING_TRANSPORT, OPT_IMPACT_CONES, OPT_UNCONSTR_DENSE, OPT_LINEARIZE_FUSED, OPT_CONE_JACOBIAN, OPT_LINEARIZE_DOFS_PER_PASS, OPT_BACKWARD_REGISTER, OPT_CONDENSE_REGISTER = range(18)
 
 
 class Dims(C.Structure):
