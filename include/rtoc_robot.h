@@ -130,6 +130,38 @@ int rtoc_set_wrench_cone_params(rtoc_ctx* ctx, const double* xy_mu, int ncontact
  * error of the iterate it linearised at. */
 int rtoc_contact_update_solution(rtoc_ctx* ctx, double fraction_to_boundary_rule, double* host_kkt_error, int count);
 
+/* ---- OCPSolver::solve (src/solver/ocp_solver.cpp:169-213): the iteration schedule, ONE owner for every host shell ----
+ * The loop of solve() between its `init_solver` prologue and its epilogue: the STO regularisation of the first
+ * initial_sto_reg_iter iterations since the last (re-)discretisation (:171-177), updateSolution, the mesh-refinement branch
+ * (KKT error below kkt_tol_mesh and TimeDiscretization::maxTimeStep above max_dt_mesh, :181-199; `inner_iter` restarts at 0 and is
+ * incremented by the loop header like the reference's), convergence (:200-210), `iter = max_iter` without it (:212-214).  Pure host
+ * logic -- what an iteration, a refinement and the largest time step ARE is the shell's business (callbacks; a non-zero return
+ * aborts the loop and is returned): robotoc_amd/solver.py (batched: the KKT error it reports is the largest of the batch) and
+ * robotoc::OCPSolver::solve of robotoc_amd/host/robotoc_hip_solver.hpp both run THIS function.  No device call, no context. */
+#define RTOC_SOLVE_MAX_REFINEMENTS 64
+typedef struct rtoc_solve_options {
+  int max_iter;              /* SolverOptions::max_iter */
+  double kkt_tol;            /* SolverOptions::kkt_tol */
+  int sto_enabled;           /* ocp_.sto_cost && ocp_.sto_constraints (and at least one discrete event) */
+  int initial_sto_reg_iter;  /* SolverOptions::initial_sto_reg_iter */
+  double initial_sto_reg;    /* SolverOptions::initial_sto_reg */
+  double kkt_tol_mesh;       /* SolverOptions::kkt_tol_mesh */
+  double max_dt_mesh;        /* SolverOptions::max_dt_mesh */
+} rtoc_solve_options;
+typedef struct rtoc_solve_callbacks {
+  void* user;
+  int (*set_sto_regularization)(void* user, double sto_reg);  /* sto_.setRegularization + the statistics' event times; STO problems only */
+  int (*update_solution)(void* user, double* kkt_error);      /* updateSolution; *kkt_error = KKTError() */
+  int (*max_time_step)(void* user, double* max_dt);           /* time_discretization_.maxTimeStep(); STO problems only */
+  int (*mesh_refinement)(void* user);                         /* :185-196: store, discretize, interpolate, initConstraints, clearHistory */
+} rtoc_solve_callbacks;
+typedef struct rtoc_solve_stats {
+  int convergence, iter;
+  int num_mesh_refinements;
+  int mesh_refinement_iter[RTOC_SOLVE_MAX_REFINEMENTS];       /* iter + 1 of every refinement (the first RTOC_SOLVE_MAX_REFINEMENTS) */
+} rtoc_solve_stats;
+int rtoc_solve_loop(const rtoc_solve_options* options, const rtoc_solve_callbacks* callbacks, rtoc_solve_stats* stats);
+
 /* ---- filter line search on the device (src/line_search/line_search.cpp:31-83, LineSearchSettings) ----
  * rtoc_contact_eval_ocp: DirectMultipleShooting::evalOCP's performance index (direct_multiple_shooting.cpp:100-126) of every
  * instance -- host_cost[count] = cost + cost_barrier, host_violation[count] = primal_feasibility (l1).  trial = 0: of the iterate

@@ -674,6 +674,70 @@ class Context:
         return self.download(buffer, self.shape(which))
 
 
+class SolveOptions(C.Structure):
+    _fields_ = [("max_iter", C.c_int), ("kkt_tol", C.c_double), ("sto_enabled", C.c_int), ("initial_sto_reg_iter", C.c_int),
+                ("initial_sto_reg", C.c_double), ("kkt_tol_mesh", C.c_double), ("max_dt_mesh", C.c_double)]
+
+
+_REG_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_double)
+_UPD_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double))
+_REF_CB = C.CFUNCTYPE(C.c_int, C.c_void_p)
+
+
+class SolveCallbacks(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("set_sto_regularization", _REG_CB), ("update_solution", _UPD_CB), ("max_time_step", _UPD_CB),
+                ("mesh_refinement", _REF_CB)]
+
+
+class SolveStats(C.Structure):
+    _fields_ = [("convergence", C.c_int), ("iter", C.c_int), ("num_mesh_refinements", C.c_int), ("mesh_refinement_iter", C.c_int * 64)]
+
+
+def solve_loop(max_iter, kkt_tol, update_solution, sto_enabled=False, initial_sto_reg_iter=0, initial_sto_reg=0.0, kkt_tol_mesh=0.0,
+               max_dt_mesh=0.0, set_sto_regularization=None, max_time_step=None, mesh_refinement=None):
+    """rtoc_solve_loop (include/rtoc_robot.h): OCPSolver::solve's iteration schedule (ocp_solver.cpp:169-213), the one the C++ shell
+    runs too.  update_solution() -> KKT error; max_time_step() -> float; set_sto_regularization(reg), mesh_refinement() -> None.
+    Returns (convergence, iter, mesh_refinement_iter).  An exception raised by a callback aborts the loop and is re-raised."""
+    pending = []
+
+    def guard(fn):
+        def run(*args):
+            try:
+                return fn(*args)
+            except BaseException as e:   # (must not propagate through the C frame)
+                pending.append(e)
+                return -100
+        return run
+
+    def _upd(_, out):
+        out[0] = float(update_solution())
+        return 0
+
+    def _mdt(_, out):
+        out[0] = float(max_time_step())
+        return 0
+
+    def _reg(_, reg):
+        set_sto_regularization(reg)
+        return 0
+
+    def _ref(_):
+        mesh_refinement()
+        return 0
+    cb = SolveCallbacks(None, _REG_CB(guard(_reg)) if set_sto_regularization else _REG_CB(), _UPD_CB(guard(_upd)),
+                        _UPD_CB(guard(_mdt)) if max_time_step else _UPD_CB(), _REF_CB(guard(_ref)) if mesh_refinement else _REF_CB())
+    opt = SolveOptions(int(max_iter), float(kkt_tol), int(bool(sto_enabled)), int(initial_sto_reg_iter), float(initial_sto_reg),
+                       float(kkt_tol_mesh), float(max_dt_mesh))
+    st = SolveStats()
+    L = lib()
+    L.rtoc_solve_loop.argtypes = [C.POINTER(SolveOptions), C.POINTER(SolveCallbacks), C.POINTER(SolveStats)]
+    rc = L.rtoc_solve_loop(C.byref(opt), C.byref(cb), C.byref(st))
+    if pending:
+        raise pending[0]
+    _chk(rc)
+    return bool(st.convergence), st.iter, [st.mesh_refinement_iter[k] for k in range(min(st.num_mesh_refinements, 64))]
+
+
 def debug_profile(ctx):
     """Tuning aid: first call attaches the stamp buffer, later calls return [max_stages,32] int64."""
     L = lib()

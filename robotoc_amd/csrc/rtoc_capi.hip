@@ -2479,6 +2479,44 @@ int rtoc_contact_eval_kkt(rtoc_ctx* c) {
   return rc;
 }
 
+// OCPSolver::solve's iteration schedule (ocp_solver.cpp:169-213), shared by the host shells (include/rtoc_robot.h)
+int rtoc_solve_loop(const rtoc_solve_options* o, const rtoc_solve_callbacks* cb, rtoc_solve_stats* st) {
+  if (!o || !cb || !st || !cb->update_solution || o->max_iter < 0) return RTOC_ERR_BAD_ARG;
+  if (o->sto_enabled && (!cb->max_time_step || !cb->mesh_refinement)) return RTOC_ERR_BAD_ARG;
+  st->convergence = 0, st->iter = 0, st->num_mesh_refinements = 0;
+  int inner_iter = 0;
+  for (int iter = 0; iter < o->max_iter; ++iter, ++inner_iter) {
+    if (o->sto_enabled && cb->set_sto_regularization) {                                         // :171-177
+      const int rc = cb->set_sto_regularization(cb->user, inner_iter < o->initial_sto_reg_iter ? o->initial_sto_reg : 0.0);
+      if (rc) return rc;
+    }
+    double kkt_error = 0.0;
+    int rc = cb->update_solution(cb->user, &kkt_error);                                         // :178-180
+    if (rc) return rc;
+    st->iter = iter + 1;
+    if (o->sto_enabled && kkt_error < o->kkt_tol_mesh) {                                        // :181
+      double max_dt = 0.0;
+      rc = cb->max_time_step(cb->user, &max_dt);
+      if (rc) return rc;
+      if (max_dt > o->max_dt_mesh) {                                                            // :182-199
+        rc = cb->mesh_refinement(cb->user);
+        if (rc) return rc;
+        inner_iter = 0;   // (the loop header makes it 1 for the next iteration, as in the reference)
+        if (st->num_mesh_refinements < RTOC_SOLVE_MAX_REFINEMENTS) st->mesh_refinement_iter[st->num_mesh_refinements] = iter + 1;
+        ++st->num_mesh_refinements;
+      } else if (kkt_error < o->kkt_tol) {                                                      // :200-204
+        st->convergence = 1;
+        break;
+      }
+    } else if (kkt_error < o->kkt_tol) {                                                        // :206-210
+      st->convergence = 1;
+      break;
+    }
+  }
+  if (!st->convergence) st->iter = o->max_iter;                                                 // :212-214
+  return RTOC_OK;
+}
+
 int rtoc_contact_update_solution(rtoc_ctx* c, double tau, double* host_kkt_error, int count) {
   CHECK_READY(c);
   if (count < 0 || count > c->batch || (count > 0 && !host_kkt_error)) return RTOC_ERR_BAD_ARG;

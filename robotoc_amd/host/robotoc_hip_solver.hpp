@@ -29,6 +29,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <exception>
 #include <cmath>
 #include <cstdio>
 #include <memory>
@@ -622,30 +623,55 @@ class OCPSolver {
       chk(rtoc_line_search_clear(dev_->get()), "rtoc_line_search_clear");                       // :166
     }
     solver_statistics_.clear();
-    int inner_iter = 0;
-    for (int iter = 0; iter < solver_options_.max_iter; ++iter, ++inner_iter) {
-      if (sto_.enabled()) {                                                                     // :169-177
-        sto_.setRegularization(inner_iter < solver_options_.initial_sto_reg_iter ? solver_options_.initial_sto_reg : 0.0);
-        solver_statistics_.ts.push_back(ocp_.source->contactSequence()->eventTimes());
-      }
-      updateSolution(t, q, v);
-      const double kkt_error = KKTError();
-      solver_statistics_.performance_index.push_back(kkt_error * kkt_error);  // PerformanceIndex::kkt_error is the squared residual
-      solver_statistics_.iter = iter + 1;
-      if (sto_.enabled() && kkt_error < solver_options_.kkt_tol_mesh) {                         // :181-205
-        if (maxTimeStep() > solver_options_.max_dt_mesh) {
-          meshRefinement(t);
-          inner_iter = 0;
-          solver_statistics_.mesh_refinement_iter.push_back(iter + 1);
-        } else if (kkt_error < solver_options_.kkt_tol) {
-          solver_statistics_.convergence = true;
-          break;
-        }
-      } else if (kkt_error < solver_options_.kkt_tol) {  // :206-210
-        solver_statistics_.convergence = true;
-        break;
-      }
-    }
+    // the iteration schedule (ocp_solver.cpp:169-213) is rtoc_solve_loop's (include/rtoc_robot.h) -- the function the Python shell
+    // (robotoc_amd/solver.py) runs too; what an iteration and a refinement ARE is this class's (the callbacks below)
+    struct Frame {
+      OCPSolver* self;
+      double t;
+      const Vec* q;
+      const Vec* v;
+      std::exception_ptr error;
+    } frame{this, t, &q, &v, nullptr};
+    rtoc_solve_callbacks cb;
+    cb.user = &frame;
+    cb.set_sto_regularization = [](void* u, double sto_reg) -> int {                            // :169-177
+      Frame& f = *static_cast<Frame*>(u);
+      try {
+        f.self->sto_.setRegularization(sto_reg);
+        f.self->solver_statistics_.ts.push_back(f.self->ocp_.source->contactSequence()->eventTimes());
+      } catch (...) { f.error = std::current_exception(); return -100; }
+      return 0;
+    };
+    cb.update_solution = [](void* u, double* kkt_error) -> int {                                // :178-180
+      Frame& f = *static_cast<Frame*>(u);
+      try {
+        f.self->updateSolution(f.t, *f.q, *f.v);
+        *kkt_error = f.self->KKTError();
+        f.self->solver_statistics_.performance_index.push_back(*kkt_error * *kkt_error);  // PerformanceIndex::kkt_error is the squared residual
+      } catch (...) { f.error = std::current_exception(); return -100; }
+      return 0;
+    };
+    cb.max_time_step = [](void* u, double* max_dt) -> int {
+      Frame& f = *static_cast<Frame*>(u);
+      try { *max_dt = f.self->maxTimeStep(); } catch (...) { f.error = std::current_exception(); return -100; }
+      return 0;
+    };
+    cb.mesh_refinement = [](void* u) -> int {                                                   // :184-196
+      Frame& f = *static_cast<Frame*>(u);
+      try { f.self->meshRefinement(f.t); } catch (...) { f.error = std::current_exception(); return -100; }
+      return 0;
+    };
+    rtoc_solve_options so;
+    so.max_iter = solver_options_.max_iter, so.kkt_tol = solver_options_.kkt_tol, so.sto_enabled = sto_.enabled() ? 1 : 0;
+    so.initial_sto_reg_iter = solver_options_.initial_sto_reg_iter, so.initial_sto_reg = solver_options_.initial_sto_reg;
+    so.kkt_tol_mesh = solver_options_.kkt_tol_mesh, so.max_dt_mesh = solver_options_.max_dt_mesh;
+    rtoc_solve_stats ss;
+    const int rc = rtoc_solve_loop(&so, &cb, &ss);
+    if (frame.error) std::rethrow_exception(frame.error);
+    chk(rc, "rtoc_solve_loop");
+    solver_statistics_.convergence = ss.convergence != 0;
+    solver_statistics_.iter = ss.iter;
+    for (int k = 0; k < ss.num_mesh_refinements && k < RTOC_SOLVE_MAX_REFINEMENTS; ++k) solver_statistics_.mesh_refinement_iter.push_back(ss.mesh_refinement_iter[k]);
     if (solver_options_.enable_benchmark)
       solver_statistics_.cpu_time = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
   }

@@ -253,26 +253,25 @@ class OCPSolver:
             c.line_search_clear()
         st = self.stats = SolverStatistics()
         sto_on = self.sto is not None and len(self.plan.events) > 0
-        inner = 0
-        for it in range(o.max_iter):
-            if sto_on:
-                c.sto_set_regularization(o.initial_sto_reg if inner < o.initial_sto_reg_iter else 0.0)   # :169-176
-                st.ts.append(c.sto_event_times())
+
+        def set_reg(reg):                                                                              # :169-176
+            c.sto_set_regularization(reg)
+            st.ts.append(c.sto_event_times())
+
+        def update():
             err = self.update_solution(t)
             st.kkt_error.append(err)
-            inner += 1
-            st.iter = it + 1
-            worst = float(np.max(err))
-            if sto_on and worst < o.kkt_tol_mesh:                                                      # :181-199
-                self.event_times = c.sto_event_times()
-                if self._max_time_step() > o.max_dt_mesh:
-                    self._mesh_refinement(t)
-                    inner = 0
-                    st.mesh_refinement_iter.append(it + 1)
-                    continue
-            if worst < o.kkt_tol:
-                st.convergence = True
-                break
+            return float(np.max(err))
+
+        def max_dt():                                                                                  # :181-182
+            self.event_times = c.sto_event_times()
+            return self._max_time_step()
+        # the schedule itself -- regularisation of the first iterations, mesh-refinement branch, convergence -- is rtoc_solve_loop's
+        # (include/rtoc_robot.h): the same function the C++ shell runs
+        st.convergence, st.iter, st.mesh_refinement_iter = capi.solve_loop(
+            o.max_iter, o.kkt_tol, update, sto_enabled=sto_on, initial_sto_reg_iter=o.initial_sto_reg_iter, initial_sto_reg=o.initial_sto_reg,
+            kkt_tol_mesh=o.kkt_tol_mesh, max_dt_mesh=o.max_dt_mesh, set_sto_regularization=set_reg if sto_on else None,
+            max_time_step=max_dt if sto_on else None, mesh_refinement=(lambda: self._mesh_refinement(t)) if sto_on else None)
         if sto_on:
             self.event_times = c.sto_event_times()
         return st
