@@ -381,6 +381,8 @@ def compact_line(res):
         for key in ("roofline_condense", "roofline_expand"):
             if key in sq:
                 out[key] = pick(sq[key], ("kernel_ms", "frac", "algorithmic_bytes_per_launch", "traffic"))
+        if (sq.get("condense_register") or {}).get("ms"):
+            out["condense_register_ms"] = _r(sq["condense_register"]["ms"], 4)   # cone kernel + condense_rv_kernel (not the default with cones)
         cl = sq.get("closed_loop_constrained_trot", {}).get("batch")
         if cl:
             out["closed_loop_update_solution_ms"] = _r(cl.get("update_solution_ms"))
@@ -928,6 +930,17 @@ def main():
                 other_ms += ms / nrep
         bad_sqp += int((ctx.status() != 0).sum())
         ctx.set_condense_split(split_default)
+        # the register-chained condensation kernel (condense_rv.hpp, RTOC_OPT_CONDENSE_REGISTER) beside the default pipeline, interleaved;
+        # with cone rows set (as here) it is NOT the default: the cones need their own kernel in front of it
+        reg_ms = {"default": [], "register": []}
+        if not split_default:
+            for rep in range(3):
+                for key, opt in (("default", False), ("register", "cones")):
+                    ctx.set_condense_register(opt)
+                    restore()
+                    reg_ms[key].append(ctx.time_phase(ph["condense"], 1))
+            bad_sqp += int((ctx.status() != 0).sum())
+            ctx.set_condense_register(True)
         k_fused, k_split = "condense_kernel<.., SPLIT = false> (one kernel)", "mjtjinv_kernel + condense_kernel<.., SPLIT = true>"
         t_fused = pmc_traffic("condense_kernel<18, 12, 12, 12, false>")
         t_split = (lambda a, b: a + b if a and b else None)(pmc_traffic("mjtjinv_kernel<18, 12, 12, 12>"), pmc_traffic("condense_kernel<18, 12, 12, 12, true>"))
@@ -956,6 +969,10 @@ def main():
                                    "unit": "GB/s", "frac": eb / (acc["expand"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                    "algorithmic_bytes_per_launch": eb, "kernels": "expand_kernel + cone_expand_kernel",
                                    "traffic": pmc_traffic("expand_kernel")},
+               "condense_register": {"kernels": "cone_condense_kernel + condense_rv_kernel<18, 12, 12, 12> (+ condense_kernel on the impact grid points)",
+                                     "ms": min(reg_ms["register"]) if reg_ms["register"] else None,
+                                     "default_pipeline_same_loop_ms": min(reg_ms["default"]) if reg_ms["default"] else None,
+                                     "without_cone_rows": "4.77-4.81 -> 4.00-4.19 ms (tools/cond_bench.py norows, profiles/r05_condense_register.txt): its default scope"},
                "single_instance": sqp_single_instance(dims, grids, local_rank) if rank == 0 else None,
                "status_nonzero_instances": bad_sqp,
                "scope": "hot path downstream of the Pinocchio linearisation: KKT error, PDIPM condensation of the "

@@ -24,6 +24,9 @@ bash tools/gpu_pmc_lin_flops.sh $TAG 1024 > $OUT/lin_flops.log 2>&1
 if [ -f $R/robotoc_amd/librtoc_hip_prof.so ]; then RTOC_HIP_LIB=$R/robotoc_amd/librtoc_hip_prof.so timeout 100 python tools/phase_profile_sto.py >> $OUT/summary/${TAG}_scan_sto_kernel_stats.txt 2>&1; fi
 rm -rf $OUT/prof_sto
 timeout 200 python tools/dvfs_probe.py > $OUT/summary/${TAG}_dvfs_probe.txt 2>&1
+# the register-chained condensation kernel beside the role-split one: with rows and cones, without, per-kernel durations, cycle stamps
+{ echo "== 72 joint-limit rows + 4 friction cones =="; bash tools/gpu_cond.sh prof 2>&1 | grep -v amdgpu.ids; echo "== no rows =="; bash tools/gpu_cond.sh x norows 2>&1 | grep -v amdgpu.ids;
+  if [ -f $R/robotoc_amd/librtoc_hip_prof.so ]; then echo "== cycle stamps of one work item (two waves per SIMD) =="; RTOC_HIP_LIB=$R/robotoc_amd/librtoc_hip_prof.so timeout 100 python tools/phase_profile_cond.py 4096 2>&1 | grep -v amdgpu.ids; fi; } > $OUT/summary/${TAG}_condense_register.txt 2>&1
 timeout 200 python tools/icub_bwd_bench.py > $OUT/summary/${TAG}_icub_backward.txt 2>&1
 # run-to-run determinism of the headline sweep, records compared bit for bit (instance / stage / field of anything that differs)
 timeout 150 python tools/determinism_probe.py 40 > $OUT/summary/${TAG}_determinism.txt 2>&1
