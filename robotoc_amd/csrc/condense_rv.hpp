@@ -58,8 +58,13 @@ struct CrvCfg {
   static constexpr int O_VEC = O_W + W_SZ;
   static constexpr int V_LINV = O_VEC, V_SINV = V_LINV + pad8(NV), V_R36 = V_SINV + pad8(NFP), V_R37 = V_R36 + 32, V_QAA = V_R37 + 32,
                        V_LR = V_QAA + 32, V_LAF = V_LR + 32, V_PH = V_LAF + 32, V_PG = V_PH + pad8(2 * NV + NU);
-  static constexpr int LDS_DOUBLES = V_PG + pad8(2 * NV + NU);
+  // friction-cone rows condensed in the kernel (cone_rows == RTOC_FRICTION_ROWS): the lower triangle of their Qqq contribution and
+  // their gradient column [lq; lf], parked until the seeds / riders that take them exist
+  static constexpr int V_CQQ = V_PG + pad8(2 * NV + NU), V_CG = V_CQQ + pad8(NV * (NV + 1) / 2);
+  static constexpr int LDS_DOUBLES = V_CG + 32;
   static constexpr int LDS_BYTES = LDS_DOUBLES * 8;
+  static constexpr int MAXC = NF / 3, CONE_K = 5 * MAXC, CONE_KS = (CONE_K + 3) / 4;   // friction cones of point contacts
+  static constexpr bool CONES = NF % 3 == 0 && NV + NF + 1 <= 32 && 4 * CONE_KS * 32 + 4 * CONE_KS <= W_SZ && LDS_BYTES <= 20 * 1024;
 };
 
 template <int NV, int NU, int NF, int NS>
@@ -88,6 +93,8 @@ __global__ __launch_bounds__(64, 2) void condense_rv_kernel(CondArgs a) {
   double* const sLaf = smem + C::V_LAF;
   double* const sPH = smem + C::V_PH;
   double* const sPG = smem + C::V_PG;
+  double* const sCqq = smem + C::V_CQQ;
+  double* const sCg = smem + C::V_CG;
   const int lane = threadIdx.x & 63, li = lane & 15, q = lane >> 4;
   const int wv = 0, wl = lane;
   const int item = blockIdx.x;
@@ -126,6 +133,8 @@ __global__ __launch_bounds__(64, 2) void condense_rv_kernel(CondArgs a) {
   const double* const Dg = cr + CL.off[RTOC_CDD_DIDCDQV];
   const double* const Qffg = cr + CL.off[RTOC_CDD_QFF];
   const double* const Qqfg = cr + CL.off[RTOC_CDD_QQF];
+  double* const Qffg_w = cr + CL.off[RTOC_CDD_QFF];
+  double* const Qqfg_w = cr + CL.off[RTOC_CDD_QQF];
   unsigned stat = 0;
   typedef double dbl2 __attribute__((ext_vector_type(2)));
   CRV_PROF(0);
@@ -165,6 +174,114 @@ __global__ __launch_bounds__(64, 2) void condense_rv_kernel(CondArgs a) {
       ent1[k] = a.entry[t + 1];
     }
   }
+  // ================= friction-cone rows (Constraints::condenseSlackAndDual, friction_cone.cpp:194-233) inside the kernel ============
+  // With G the stacked Jacobian of the active cone rows (5 per active contact; columns: q and the contact's own force), R = diag(dual /
+  // slack) and c the condensing coefficients, every contribution is a block of the ONE Gram product G^T [R G | c] (cone_condense_body,
+  // friction_cone.hpp -- which read-modify-writes them in HBM ahead of the condensation).  Here its tiles go where the condensation
+  // takes them from: (q, q) -> the seeds of V (lower triangle parked in LDS), (f, q) -> E' (same C layout), (f, f) -> W1 (symmetric:
+  // its C layout IS the A fragment), the rider column -> lx / lf.  The updated Qqf, Qff, lf go back to the record for the expansion.
+  const bool cones = C::CONES && a.cone_rows == RTOC_FRICTION_ROWS && a.cone_dim == 3;
+  const int nact = cones ? nf / 3 : 0;
+  d4 cep[2];      // what the cone rows add to E' (tile row 1: rows f = q + 4r - RU, columns li + 16 tc)
+  double cw1[4];  // ... and to W1 (A fragment)
+#pragma unroll
+  for (int tc = 0; tc < 2; ++tc) cep[tc] = zero4();
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) cw1[ks] = 0.0;
+  if constexpr (C::CONES) {
+    if (lane < 32) sCg[lane] = 0.0;
+    for (int e = lane; e < NV * (NV + 1) / 2; e += 64) sCqq[e] = 0.0;
+    if (nact > 0) {
+      constexpr int K = C::CONE_K, KS = C::CONE_KS, GLD = 32, NC = NV + NF, MAXC = C::MAXC;
+      constexpr int ND = (MAXC * 5 * NV + 63) / 64, NG = (MAXC * 15 + 63) / 64;
+      const double* const cone = a.cone + ((size_t)b * a.nstages + st) * a.cone_stride;
+      double* const cnr = a.cone_con + ((size_t)b * a.nstages + st) * a.nl.stride;
+      double gdq[ND], gdf[NG];
+#pragma unroll
+      for (int p = 0; p < ND; ++p) {
+        const int e = lane + 64 * p;
+        gdq[p] = cone[e < a.cone_contacts * 5 * NV ? e : 0];
+      }
+#pragma unroll
+      for (int p = 0; p < NG; ++p) {
+        const int e = lane + 64 * p;
+        gdf[p] = cone[a.cone_dgdf_off + (e < a.cone_contacts * 15 ? e : 0)];
+      }
+      const int rw = a.cone_row0 + (lane < 5 * a.cone_contacts ? lane : 0);
+      const double cslack = cnr[a.nl.off[RTOC_CON_SLACK] + rw], cdual = cnr[a.nl.off[RTOC_CON_DUAL] + rw],
+                   cresid = cnr[a.nl.off[RTOC_CON_RESIDUAL] + rw], ccmpl = cnr[a.nl.off[RTOC_CON_CMPL] + rw];
+      // G (K-major, leading dimension 32: columns q | f | rider c) and diag R into the work region (free until the factorisation)
+      double* const Gs = stg;
+      double* const rs = stg + 4 * KS * GLD;
+      for (int e = lane; e < 4 * KS * GLD; e += 64) Gs[e] = 0.0;
+      wave_lds_sync_();
+#pragma unroll
+      for (int p = 0; p < ND; ++p) {   // dg_dq of contact k: 5 x NV, column-major
+        const int e = lane + 64 * p, k = e / (5 * NV), w = e % (5 * NV);
+        if (e < nact * 5 * NV) Gs[(5 * k + w % 5) * GLD + w / 5] = gdq[p];
+      }
+#pragma unroll
+      for (int p = 0; p < NG; ++p) {   // dg_df of contact k: 5 x 3, on the contact's own force columns
+        const int e = lane + 64 * p, k = e / 15, w = e % 15;
+        if (e < nact * 15) Gs[(5 * k + w % 5) * GLD + NV + k * 3 + w / 5] = gdf[p];
+      }
+      if (lane < 4 * KS) {
+        const bool on = lane < 5 * nact;
+        if (on) {
+          const double c = (cdual * cresid - ccmpl) / cslack;   // computeCondensingCoeffcient<5> (:202)
+          cnr[a.nl.off[RTOC_CON_COND] + rw] = c;
+          Gs[lane * GLD + NC] = c;
+        }
+        rs[lane] = on ? cdual / cslack : 0.0;                   // (:211-212)
+      }
+      wave_lds_sync_();
+      d4 g4[2][2];
+#pragma unroll
+      for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb) g4[ta][tb] = zero4();
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int kk = 4 * ks + q;
+        const double r = rs[kk];
+        double gv[2], bv[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          gv[t] = Gs[kk * GLD + 16 * t + li];
+          bv[t] = gv[t] * ((16 * t + li == NC) ? 1.0 : r);
+        }
+#pragma unroll
+        for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+          for (int tb = 0; tb < 2; ++tb) g4[ta][tb] = mfma16(gv[ta], bv[tb], g4[ta][tb]);
+      }
+      // where the tiles go
+#pragma unroll
+      for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = q + 4 * r + 16 * ta, col = li + 16 * tb;
+            if (row < NV && col <= row) sCqq[row * (row + 1) / 2 + col] = g4[ta][tb][r];   // (q, q): Qqq (:215-216), lower triangle
+            if (tb == 1 && col == NC && row < NC) sCg[row] = g4[ta][tb][r];               // rider column: lq (:206) | lf (:207-208)
+          }
+#pragma unroll
+      for (int tc = 0; tc < 2; ++tc)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int f = q + 4 * r - RU, col = li + 16 * tc;
+          cep[tc][r] = (f >= 0 && f < NF && col < NV) ? g4[1][tc][r] : 0.0;                 // (f, q): Qqf^T (:217-218)
+        }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int m = li - RU, k = 4 * ks + q - RU;
+        cw1[ks] = (m >= 0 && m < NF && k >= 0 && k < NF && m / 3 == k / 3) ? g4[1][1][ks] : 0.0;   // (f, f): Qff, the contact's own 3 x 3 block (:219-220)
+      }
+      wave_lds_sync_();   // the work region is the factorisation's from here on
+    }
+  }
+
   // ---- everything else the work item reads is requested by issue_loads(), called right behind the factorisation of M (hook of the
   //      fragment): ~150 fewer registers live across its column steps, and the loads arrive under the rest of the assembly (requested
   //      at the very top instead: the same time to 0.5 %, measured in one process) ----
@@ -286,7 +403,9 @@ __global__ __launch_bounds__(64, 2) void condense_rv_kernel(CondArgs a) {
   CRV_PROF(3);
   if (lane < 32) {   // (their loads came in behind the 24 loads of D: written here, not ahead of the factorisation)
     sQaa[lane] = arow ? vQaa : 0.0;
-    sR36[lane] = arow ? -vLa : ((lane - NV < nf) ? vLa : 0.0);   // -[la; -lf]
+    const double lfc = vLa + (C::CONES ? sCg[lane] : 0.0);       // lf with the cone rows' gradient (zero without cone rows)
+    sR36[lane] = arow ? -vLa : ((lane - NV < nf) ? lfc : 0.0);   // -[la; -lf]
+    if (C::CONES && nact > 0 && !arow && lane - NV < nf) cr[CL.off[RTOC_CDD_LF] + lane - NV] = lfc;
     sR37[lane] = arow ? -vHa : ((lane - NV < nf) ? vHa : 0.0);   // -[ha; -hf]
   }
   wave_lds_sync_();
@@ -364,7 +483,8 @@ __global__ __launch_bounds__(64, 2) void condense_rv_kernel(CondArgs a) {
     const int m = li, k = 4 * ks + q;
     const bool fblk = m >= RU && k >= RU && m - RU < nf && k - RU < nf;
     const double va = sQaa[16 + (m < RU ? m : 0)];
-    w1[ks] = (m < RU) ? ((k == m) ? va : 0.0) : (fblk ? w1raw[ks] : 0.0);
+    w1[ks] = (m < RU) ? ((k == m) ? va : 0.0) : (fblk ? w1raw[ks] + cw1[ks] : 0.0);
+    if (C::CONES && nact > 0 && fblk && (m - RU) / 3 == (k - RU) / 3) Qffg_w[(m - RU) + (k - RU) * LDF] = w1[ks];   // for the expansion
   }
   d4 ep[2];
 #pragma unroll
@@ -372,7 +492,9 @@ __global__ __launch_bounds__(64, 2) void condense_rv_kernel(CondArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int f = q + 4 * r - RU, col = li + 16 * tc;
-      ep[tc][r] = (f >= 0 && f < nf && col < NV) ? epraw[tc][r] : 0.0;
+      const bool ok = f >= 0 && f < nf && col < NV;
+      ep[tc][r] = ok ? epraw[tc][r] + cep[tc][r] : 0.0;
+      if (C::CONES && nact > 0 && ok) Qqfg_w[col + f * NV] = ep[tc][r];   // for the expansion
     }
   double qaa0[4];
 #pragma unroll
@@ -493,8 +615,13 @@ __global__ __launch_bounds__(64, 2) void condense_rv_kernel(CondArgs a) {
         const int m = q + 4 * r + 16 * tm;
         if (tm < 2 || r == 0) {
           if (tm == tn) acc[tn][r] = __builtin_fma((m == n) ? 1.0 : 0.0, sPH[nc], acc[tn][r]);   // the joint-limit rows' Hessian
+          if (C::CONES && tm < 2 && tn < 2) {                                                    // the cone rows' Qqq (symmetric)
+            const int hi = m > n ? m : n, lo = m > n ? n : m;
+            const bool in = hi < NV;
+            acc[tn][r] += in ? sCqq[in ? hi * (hi + 1) / 2 + lo : 0] : 0.0;
+          }
         } else if (r == 1) {
-          acc[tn][r] = __builtin_fma((q == 0) ? 1.0 : 0.0, sPG[nc], acc[tn][r]);                 // ... and gradient
+          acc[tn][r] = __builtin_fma((q == 0) ? 1.0 : 0.0, sPG[nc] + ((C::CONES && nc < NV) ? sCg[nc < NV ? nc : 0] : 0.0), acc[tn][r]);   // ... and gradient, the cone rows' lq
         }
       }
     }

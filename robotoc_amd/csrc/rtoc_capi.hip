@@ -1180,9 +1180,14 @@ static int launch_sweep(rtoc_ctx* c) {
 // role-split condensation hides the cone rows under its solo assembly of MJtJinv, here they would need their own kernel ahead of
 // condense_rv_kernel (0.81 ms per 4096 x 46), which eats the gain (measured per 4096 ANYmal trot instances: 4.80 -> 4.00 ms without
 // rows, 5.29 -> 5.24 ms with 72 joint-limit rows and 4 cones).  2: also with cone rows (cone kernel first).
+// friction cones of point contacts are condensed INSIDE condense_rv_kernel (their Gram product's tiles go straight into the seeds and
+// operands of the condensation); wrench cones need their own kernel ahead of it
+static bool cond_rv_fuses_cones(const rtoc_ctx* c) {
+  return c->cone_contacts > 0 && c->cone_rows == RTOC_FRICTION_ROWS && c->cone_dim == 3 && c->ks->cond_fuses_cones;
+}
 static bool cond_rv_applies(const rtoc_ctx* c) {
   if (!c->cond_register || !c->ks->cond_rv || c->condense_split || c->keep_qaf) return false;
-  if (c->cone_contacts > 0 && c->cond_register < 2) return false;
+  if (c->cone_contacts > 0 && !cond_rv_fuses_cones(c) && c->cond_register < 2) return false;
   return c->n_stage_contact + c->n_stage_impact == c->nstages - 1;
 }
 
@@ -1213,7 +1218,7 @@ static int launch_condense(rtoc_ctx* c) {
   a.keep_qaf = c->keep_qaf;
   a.dt_inst = c->sto_on ? c->d_dt : nullptr;
   const bool rv = cond_rv_applies(c);
-  if (!rv && (c->condense_split || c->ks->cond_fuses_cones) && c->cone_contacts > 0) {  // the cone rows ride with the MJtJinv kernel / in wave 1 of the fused kernel
+  if ((rv ? cond_rv_fuses_cones(c) : (c->condense_split || c->ks->cond_fuses_cones)) && c->cone_contacts > 0) {  // the cone rows ride with the MJtJinv kernel / in wave 1 of the fused kernel / inside condense_rv_kernel
     if (!c->buf[RTOC_BUF_CONE] || !c->buf[RTOC_BUF_CON]) return RTOC_ERR_NOT_READY;
     const bool wrench = c->cone_rows == RTOC_WRENCH_ROWS;
     a.cone_rows = c->cone_rows;
@@ -1361,7 +1366,8 @@ int rtoc_compute_initial_state_direction(rtoc_ctx* c) {
 int rtoc_condense(rtoc_ctx* c) {
   CHECK_READY(c);
   int rc = RTOC_OK;
-  if (c->cone_contacts > 0 && ((!c->condense_split && !c->ks->cond_fuses_cones) || cond_rv_applies(c))) rc = launch_cones(c, 0, 0.0);  // Constraints::condenseSlackAndDual first
+  if (c->cone_contacts > 0 && (cond_rv_applies(c) ? !cond_rv_fuses_cones(c) : (!c->condense_split && !c->ks->cond_fuses_cones)))
+    rc = launch_cones(c, 0, 0.0);  // Constraints::condenseSlackAndDual first
   if (!rc) rc = launch_condense(c);
   if (!rc && c->buf[RTOC_BUF_SE3] && c->dims.np == 6) rc = launch_state_correction(c, 0);
   return rc;

@@ -88,8 +88,9 @@ def test_register_condensation_reproduces_the_oracle(oracle, cfg, rows):
 
 
 def test_register_condensation_with_cone_rows_agrees_with_the_role_split_kernel():
-    """RTOC_OPT_CONDENSE_REGISTER = 2: friction-cone rows by their own kernel ahead of condense_rv_kernel -- the same records as the
-    one-kernel condensation leaves (which condenses them in its second wave), 72 joint-limit rows beside them."""
+    """Friction-cone rows condensed INSIDE condense_rv_kernel (the tiles of their Gram product go into the seeds and operands of the
+    condensation; Qqf, Qff, lf and the rows' condensing coefficients back to the records) -- the same records as the one-kernel
+    role-split condensation leaves, which condenses them in its second wave; 72 joint-limit rows beside them."""
     from helpers import check_parity, rel_err
     from robotoc_amd import capi
     dims, grids, _ = pr.config_anymal_trot()
@@ -104,7 +105,7 @@ def test_register_condensation_with_cone_rows_agrees_with_the_role_split_kernel(
         con = pr.make_constraint_batch_unique(L, grids, batch)
         cone = pr.make_cone_batch_unique(L, grids, batch, 4)
         out = {}
-        for name, opt in (("default", None), ("register", "cones"), ("role-split", False)):
+        for name, opt in (("register", None), ("role-split", False)):   # (the default: friction-cone rows are condensed inside the kernel)
             if opt is not None:
                 ctx.set_condense_register(opt)
             for buf, arr in ((BUF_KKT, kkt), (BUF_CDD, cdd), (BUF_CON, con), (BUF_CONE, cone)):
@@ -112,14 +113,11 @@ def test_register_condensation_with_cone_rows_agrees_with_the_role_split_kernel(
             ctx.condense()
             assert (ctx.status() == 0).all()
             out[name] = (ctx.download_records(BUF_KKT, "kkt"), ctx.download_records(BUF_CDD, "cdd"), ctx.download_records(BUF_CON, "con"))
-        # with cone rows the default (1) keeps the role-split kernel: bit for bit what option 0 leaves
-        for x, y in zip(out["default"], out["role-split"]):
-            assert np.array_equal(x, y)
         K, Cd, Nn = Records(L, "kkt"), Records(L, "cdd"), Records(L, "con")
         ek, wk = _worst(K, out["register"][0], out["role-split"][0], KKT_FIELDS, n)
         ec, wc = _worst(Cd, out["register"][1], out["role-split"][1], CDD_FIELDS + ["Qff", "Qqf", "lf"], n)
         en = max(rel_err(Nn.f(out["register"][2], f), Nn.f(out["role-split"][2], f)) for f in ("cond", "slack", "dual"))
-        print("register (cone kernel first) vs one-kernel condensation: KKT %.2e %s, contact-dynamics data %.2e %s, rows %.2e" % (ek, wk, ec, wc, en))
+        print("register (cone rows inside) vs one-kernel condensation: KKT %.2e %s, contact-dynamics data %.2e %s, rows %.2e" % (ek, wk, ec, wc, en))
         check_parity("condensed KKT", ek, 1e-10)
         check_parity("contact-dynamics data", ec, 1e-10)
         check_parity("constraint rows", en, 1e-12)

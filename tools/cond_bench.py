@@ -38,7 +38,7 @@ def restore():
 
 res, times = {}, {}
 for name, on in (("role-split", False), ("register", True)) * 3:
-    ctx.set_condense_register("cones" if on else False)
+    ctx.set_condense_register(bool(on))
     ctx.clear_status()
     t = []
     for _ in range(4):

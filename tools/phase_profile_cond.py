@@ -18,7 +18,7 @@ kkt, cdd = pr.make_precondense_batch_unique(L, grids, 32)
 ctx.upload(BUF_KKT, tile(kkt)); ctx.upload(BUF_CDD, tile(cdd))
 ctx.upload(BUF_CON, tile(pr.make_constraint_batch_unique(L, grids, 32)))
 ctx.upload(BUF_CONE, tile(pr.make_cone_batch_unique(L, grids, 32, 4)))
-ctx.set_condense_register("cones")
+ctx.set_condense_register(True)
 capi.debug_profile(ctx)
 ctx.condense(); ctx.sync()
 ctx.upload(BUF_KKT, tile(kkt)); ctx.upload(BUF_CDD, tile(cdd))
