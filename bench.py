@@ -381,8 +381,8 @@ def compact_line(res):
         for key in ("roofline_condense", "roofline_expand"):
             if key in sq:
                 out[key] = pick(sq[key], ("kernel_ms", "frac", "algorithmic_bytes_per_launch", "traffic"))
-        if (sq.get("condense_register") or {}).get("ms"):
-            out["condense_register_ms"] = _r(sq["condense_register"]["ms"], 4)   # cone kernel + condense_rv_kernel (not the default with cones)
+        if (sq.get("condense_register") or {}).get("role_split_ms"):
+            out["condense_role_split_ms"] = _r(sq["condense_register"]["role_split_ms"], 4)   # RTOC_OPT_CONDENSE_REGISTER = 0 in the same loop
         cl = sq.get("closed_loop_constrained_trot", {}).get("batch")
         if cl:
             out["closed_loop_update_solution_ms"] = _r(cl.get("update_solution_ms"))
@@ -930,19 +930,26 @@ def main():
                 other_ms += ms / nrep
         bad_sqp += int((ctx.status() != 0).sum())
         ctx.set_condense_split(split_default)
-        # the register-chained condensation kernel (condense_rv.hpp, RTOC_OPT_CONDENSE_REGISTER) beside the default pipeline, interleaved;
-        # with cone rows set (as here) it is NOT the default: the cones need their own kernel in front of it
-        reg_ms = {"default": [], "register": []}
+        # the register-chained condensation kernel (condense_rv.hpp, RTOC_OPT_CONDENSE_REGISTER = 1: the default where it applies,
+        # friction-cone rows condensed inside it) and the role-split one-kernel condensation (= 0), interleaved in one loop
+        from robotoc_amd.types import OPT_CONDENSE_REGISTER
+        register_default = bool(ctx.get_option(OPT_CONDENSE_REGISTER)) and not split_default
+        reg_ms = {"role_split": [], "register": []}
         if not split_default:
             for rep in range(3):
-                for key, opt in (("default", False), ("register", "cones")):
+                for key, opt in (("role_split", False), ("register", True)):
                     ctx.set_condense_register(opt)
                     restore()
                     reg_ms[key].append(ctx.time_phase(ph["condense"], 1))
             bad_sqp += int((ctx.status() != 0).sum())
-            ctx.set_condense_register(True)
+            ctx.set_condense_register(register_default)
+        k_rv = "condense_rv_kernel<18, 12, 12, 12> (contact grid points, friction-cone rows inside) + condense_kernel<.., SPLIT = false> (impact grid points)"
         k_fused, k_split = "condense_kernel<.., SPLIT = false> (one kernel)", "mjtjinv_kernel + condense_kernel<.., SPLIT = true>"
         t_fused = pmc_traffic("condense_kernel<18, 12, 12, 12, false>")
+        # condense_rv_kernel's own counted bytes + the impact grid points' share of the role-split kernel's (its launch on those few grid
+        # points is not the geometry the counter summary keeps)
+        n_imp = sum(1 for g in grids[:-1] if g.type == 1)
+        t_rv = (lambda a, b: a + b * n_imp / (len(grids) - 1) if a and b else None)(pmc_traffic("condense_rv_kernel<18, 12, 12, 12>"), t_fused)
         t_split = (lambda a, b: a + b if a and b else None)(pmc_traffic("mjtjinv_kernel<18, 12, 12, 12>"), pmc_traffic("condense_kernel<18, 12, 12, 12, true>"))
         cb = condense_bytes(L, grids, batch)
         crb = constraint_row_bytes(grids, batch, rows, 4, dims.nv)
@@ -954,8 +961,9 @@ def main():
                                      "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                      "frac": cb / (acc["condense"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                      "algorithmic_bytes_per_launch": cb, "kernel_ms": acc["condense"],
-                                     "kernels": k_split if split_default else k_fused, "RTOC_OPT_CONDENSE_SPLIT": split_default,
-                                     "traffic": t_split if split_default else t_fused,
+                                     "kernels": k_split if split_default else (k_rv if register_default else k_fused), "RTOC_OPT_CONDENSE_SPLIT": split_default,
+                                     "RTOC_OPT_CONDENSE_REGISTER": int(register_default),
+                                     "traffic": t_split if split_default else (t_rv if register_default else t_fused),
                                      "constraint_row_bytes_per_launch": crb,
                                      "constraint_row_bytes_note": "the PDIPM rows' own data (cone Jacobians, slack / dual / residual / cmpl in, cond "
                                                                   "out: Constraints::condenseSlackAndDual reads and writes them too) -- NOT in "
@@ -969,10 +977,10 @@ def main():
                                    "unit": "GB/s", "frac": eb / (acc["expand"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                    "algorithmic_bytes_per_launch": eb, "kernels": "expand_kernel + cone_expand_kernel",
                                    "traffic": pmc_traffic("expand_kernel")},
-               "condense_register": {"kernels": "cone_condense_kernel + condense_rv_kernel<18, 12, 12, 12> (+ condense_kernel on the impact grid points)",
-                                     "ms": min(reg_ms["register"]) if reg_ms["register"] else None,
-                                     "default_pipeline_same_loop_ms": min(reg_ms["default"]) if reg_ms["default"] else None,
-                                     "without_cone_rows": "4.77-4.81 -> 4.00-4.19 ms (tools/cond_bench.py norows, profiles/r05_condense_register.txt): its default scope"},
+               "condense_register": {"register_ms": min(reg_ms["register"]) if reg_ms["register"] else None,
+                                     "role_split_ms": min(reg_ms["role_split"]) if reg_ms["role_split"] else None,
+                                     "note": "RTOC_OPT_CONDENSE_REGISTER = 1 | 0 timed alternately in one loop (the second timing in a process runs at a "
+                                             "higher clock); profiles/r05_condense_register.txt has the same with and without rows"},
                "single_instance": sqp_single_instance(dims, grids, local_rank) if rank == 0 else None,
                "status_nonzero_instances": bad_sqp,
                "scope": "hot path downstream of the Pinocchio linearisation: KKT error, PDIPM condensation of the "

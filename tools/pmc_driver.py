@@ -62,6 +62,15 @@ def main():
         ctx.condense()
     ctx.set_condense_split(default)
     assert (ctx.status() == 0).all()
+    # ... and the role-split one-kernel condensation (RTOC_OPT_CONDENSE_REGISTER = 0) where the register-chained kernel is the default
+    ctx.set_condense_register(False)
+    for _ in range(reps):
+        ctx.upload(BUF_KKT, kkt)
+        ctx.upload(BUF_CDD, cdd)
+        ctx.upload(BUF_CON, con)
+        ctx.condense()
+    ctx.set_condense_register(True)
+    assert (ctx.status() == 0).all()
     del kkt, cdd, con
     # ---- rigid-body linearisation of the same batch ----
     from robotoc_amd import robot_model as rm

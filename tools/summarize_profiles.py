@@ -66,10 +66,13 @@ if os.path.exists(trace):
                                "back_to_back_calls": len(w), "back_to_back_avg_ms": (sum(w) / len(w)) if w else None}
 for cname, d in (("FETCH_SIZE", "prof_fetch/fetch"), ("WRITE_SIZE", "prof_write/write")):
     acc = collections.OrderedDict()
+    bygrid = {}
     for r in csv.DictReader(open(os.path.join(OUT, d + "_counter_collection.csv"))):
         if r["Counter_Name"] == cname:
-            acc.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
-    lines.append("# rocprofv3 --pmc %s (own pass); mean per dispatch, unit KB (rocprofv3 FETCH_SIZE/WRITE_SIZE)" % cname)
+            bygrid.setdefault(r["Kernel_Name"], {}).setdefault(int(float(r.get("Grid_Size", 0) or 0)), []).append(float(r["Counter_Value"]))
+    for k, g in bygrid.items():   # a kernel launched with several geometries (condense_kernel: all grid points | the impact ones): the largest
+        acc[k] = g[max(g)]
+    lines.append("# rocprofv3 --pmc %s (own pass); mean per dispatch of the kernel's largest launch geometry, unit KB (rocprofv3 FETCH_SIZE/WRITE_SIZE)" % cname)
     for k, v in acc.items():
         m = sum(v) / len(v)
         lines.append("%s, %s, %.1f, n=%d" % (k, cname, m, len(v)))
