@@ -167,12 +167,12 @@ enum rtoc_option {
                       * Same results to fp64 round-off (tests/test_backward_register.py). */
   RTOC_OPT_CONDENSE_REGISTER = 17, /* 1 (default): rtoc_condense runs the register-chained kernel (one wavefront per grid point, the saddle
                       * inverse read once into MFMA accumulators, every product of condenseContactDynamics chained through
-                      * register layouts; condense_rv.hpp) on the CONTACT grid points of shapes it is laid out for (nv + nf_max <= 32,
-                      * 32 < 2 nv <= 46: ANYmal, A1) in contexts WITHOUT friction / wrench cone rows -- impact grid points,
-                      * RTOC_OPT_CONDENSE_SPLIT = 1 and RTOC_OPT_CONDENSE_KEEP_QAF = 1 run the role-split kernels.  2: also with cone
-                      * rows (their own kernel first: no faster than the role-split kernel, which hides them under its assembly of
-                      * MJtJinv).  0: never.  Same results to fp64 round-off (tests/test_condense_register.py).
-                      * RTOC_CONDENSE_REGISTER=0|1|2 in the environment sets the default of contexts created afterwards. */
+                      * register layouts, friction-cone rows condensed inside it; condense_rv.hpp) on the CONTACT grid points of shapes
+                      * it is laid out for (nv + nf_max <= 32, 32 < 2 nv <= 46: ANYmal, A1) -- impact grid points,
+                      * RTOC_OPT_CONDENSE_SPLIT = 1, RTOC_OPT_CONDENSE_KEEP_QAF = 1 and contexts with WRENCH cone rows run the
+                      * role-split kernels.  2: also with wrench cone rows (their own kernel first).  0: never.  Same results to fp64
+                      * round-off (tests/test_condense_register.py).  RTOC_CONDENSE_REGISTER=0|1|2 in the environment sets the
+                      * default of contexts created afterwards. */
   RTOC_OPT_SWITCHING_TRANSPORT = 10 /* Free-flyer block of Phiq / Phiv / Phia in rtoc_contact_eval_kkt's switching-constraint
                       * rows.  0 (default): as the reference composes it -- it hands pinocchio::dIntegrateTransport the
                       * transposed Jacobian (robot.hxx:69-72, :88-91), which yields Pq dIntegrate^T.  1: the chain rule

@@ -1176,10 +1176,8 @@ static int launch_sweep(rtoc_ctx* c) {
 }
 
 // RTOC_OPT_CONDENSE_REGISTER: the contact grid points by condense_rv_kernel (one wave per work item, products chained through
-// registers), the impact grid points by condense_kernel.  1 (default): contexts WITHOUT friction / wrench cone rows -- the one-kernel
-// role-split condensation hides the cone rows under its solo assembly of MJtJinv, here they would need their own kernel ahead of
-// condense_rv_kernel (0.81 ms per 4096 x 46), which eats the gain (measured per 4096 ANYmal trot instances: 4.80 -> 4.00 ms without
-// rows, 5.29 -> 5.24 ms with 72 joint-limit rows and 4 cones).  2: also with cone rows (cone kernel first).
+// registers), the impact grid points by condense_kernel.  Measured per 4096 ANYmal trot instances: 4.80 -> 4.00 ms without rows,
+// 5.16 -> 4.55 ms with 72 joint-limit rows and 4 friction cones.
 // friction cones of point contacts are condensed INSIDE condense_rv_kernel (their Gram product's tiles go straight into the seeds and
 // operands of the condensation); wrench cones need their own kernel ahead of it
 static bool cond_rv_fuses_cones(const rtoc_ctx* c) {
