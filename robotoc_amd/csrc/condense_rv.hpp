@@ -67,9 +67,12 @@ struct CrvCfg {
   static constexpr bool CONES = NF % 3 == 0 && NV + NF + 1 <= 32 && 4 * CONE_KS * 32 + 4 * CONE_KS <= W_SZ && LDS_BYTES <= 20 * 1024;
 };
 
-template <int NV, int NU, int NF, int NS>
+// WITH_CONES = false: the same kernel without the cone-row code (contexts that have none: its registers and LDS traffic cost 0.2-0.3 ms
+// per 4096 x 46 even when no row is active)
+template <int NV, int NU, int NF, int NS, bool WITH_CONES = true>
 __global__ __launch_bounds__(64, 2) void condense_rv_kernel(CondArgs a) {
   using C = CrvCfg<NV, NU, NF, NS>;
+  constexpr bool CONES = C::CONES && WITH_CONES;
   static_assert(C::OK, "shape outside the register plan");
   constexpr int NX = C::NX, NP = C::NP, LDV = C::LDV, LDF = C::NFP, RC = C::RC, RU = C::RU, LDS_ = NS > 0 ? NS : 1;
   constexpr int NT = 64, NW = 1;
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(64, 2) void condense_rv_kernel(CondArgs a) {
   // friction_cone.hpp -- which read-modify-writes them in HBM ahead of the condensation).  Here its tiles go where the condensation
   // takes them from: (q, q) -> the seeds of V (lower triangle parked in LDS), (f, q) -> E' (same C layout), (f, f) -> W1 (symmetric:
   // its C layout IS the A fragment), the rider column -> lx / lf.  The updated Qqf, Qff, lf go back to the record for the expansion.
-  const bool cones = C::CONES && a.cone_rows == RTOC_FRICTION_ROWS && a.cone_dim == 3;
+  const bool cones = CONES && a.cone_rows == RTOC_FRICTION_ROWS && a.cone_dim == 3;
   const int nact = cones ? nf / 3 : 0;
   d4 cep[2];      // what the cone rows add to E' (tile row 1: rows f = q + 4r - RU, columns li + 16 tc)
   double cw1[4];  // ... and to W1 (A fragment)
@@ -188,7 +191,7 @@ __global__ __launch_bounds__(64, 2) void condense_rv_kernel(CondArgs a) {
   for (int tc = 0; tc < 2; ++tc) cep[tc] = zero4();
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) cw1[ks] = 0.0;
-  if constexpr (C::CONES) {
+  if constexpr (CONES) {
     if (lane < 32) sCg[lane] = 0.0;
     for (int e = lane; e < NV * (NV + 1) / 2; e += 64) sCqq[e] = 0.0;
     if (nact > 0) {
@@ -403,9 +406,9 @@ __global__ __launch_bounds__(64, 2) void condense_rv_kernel(CondArgs a) {
   CRV_PROF(3);
   if (lane < 32) {   // (their loads came in behind the 24 loads of D: written here, not ahead of the factorisation)
     sQaa[lane] = arow ? vQaa : 0.0;
-    const double lfc = vLa + (C::CONES ? sCg[lane] : 0.0);       // lf with the cone rows' gradient (zero without cone rows)
+    const double lfc = vLa + (CONES ? sCg[lane] : 0.0);       // lf with the cone rows' gradient (zero without cone rows)
     sR36[lane] = arow ? -vLa : ((lane - NV < nf) ? lfc : 0.0);   // -[la; -lf]
-    if (C::CONES && nact > 0 && !arow && lane - NV < nf) cr[CL.off[RTOC_CDD_LF] + lane - NV] = lfc;
+    if (CONES && nact > 0 && !arow && lane - NV < nf) cr[CL.off[RTOC_CDD_LF] + lane - NV] = lfc;
     sR37[lane] = arow ? -vHa : ((lane - NV < nf) ? vHa : 0.0);   // -[ha; -hf]
   }
   wave_lds_sync_();
@@ -484,7 +487,7 @@ __global__ __launch_bounds__(64, 2) void condense_rv_kernel(CondArgs a) {
     const bool fblk = m >= RU && k >= RU && m - RU < nf && k - RU < nf;
     const double va = sQaa[16 + (m < RU ? m : 0)];
     w1[ks] = (m < RU) ? ((k == m) ? va : 0.0) : (fblk ? w1raw[ks] + cw1[ks] : 0.0);
-    if (C::CONES && nact > 0 && fblk && (m - RU) / 3 == (k - RU) / 3) Qffg_w[(m - RU) + (k - RU) * LDF] = w1[ks];   // for the expansion
+    if (CONES && nact > 0 && fblk && (m - RU) / 3 == (k - RU) / 3) Qffg_w[(m - RU) + (k - RU) * LDF] = w1[ks];   // for the expansion
   }
   d4 ep[2];
 #pragma unroll
@@ -494,7 +497,7 @@ __global__ __launch_bounds__(64, 2) void condense_rv_kernel(CondArgs a) {
       const int f = q + 4 * r - RU, col = li + 16 * tc;
       const bool ok = f >= 0 && f < nf && col < NV;
       ep[tc][r] = ok ? epraw[tc][r] + cep[tc][r] : 0.0;
-      if (C::CONES && nact > 0 && ok) Qqfg_w[col + f * NV] = ep[tc][r];   // for the expansion
+      if (CONES && nact > 0 && ok) Qqfg_w[col + f * NV] = ep[tc][r];   // for the expansion
     }
   double qaa0[4];
 #pragma unroll
@@ -615,13 +618,13 @@ __global__ __launch_bounds__(64, 2) void condense_rv_kernel(CondArgs a) {
         const int m = q + 4 * r + 16 * tm;
         if (tm < 2 || r == 0) {
           if (tm == tn) acc[tn][r] = __builtin_fma((m == n) ? 1.0 : 0.0, sPH[nc], acc[tn][r]);   // the joint-limit rows' Hessian
-          if (C::CONES && tm < 2 && tn < 2) {                                                    // the cone rows' Qqq (symmetric)
+          if (CONES && tm < 2 && tn < 2) {                                                    // the cone rows' Qqq (symmetric)
             const int hi = m > n ? m : n, lo = m > n ? n : m;
             const bool in = hi < NV;
             acc[tn][r] += in ? sCqq[in ? hi * (hi + 1) / 2 + lo : 0] : 0.0;
           }
         } else if (r == 1) {
-          acc[tn][r] = __builtin_fma((q == 0) ? 1.0 : 0.0, sPG[nc] + ((C::CONES && nc < NV) ? sCg[nc < NV ? nc : 0] : 0.0), acc[tn][r]);   // ... and gradient, the cone rows' lq
+          acc[tn][r] = __builtin_fma((q == 0) ? 1.0 : 0.0, sPG[nc] + ((CONES && nc < NV) ? sCg[nc < NV ? nc : 0] : 0.0), acc[tn][r]);   // ... and gradient, the cone rows' lq
         }
       }
     }

@@ -67,6 +67,7 @@ struct KernelSet {
   int cond_threads, cond_lds, cond_split_lds;
   int cond_fuses_cones;  // the one-kernel condensation condenses the friction / wrench cone rows itself (CondCfg::FUSE)
   int cond_fused_default;  // ... and is the default pipeline of this shape: five of its work items fit the LDS of a CU
+  cond_fn cond_rv_nc;      // ... without the cone-row code (contexts without cone rows)
   cond_fn cond_rv;         // register-chained condensation of the contact grid points, one wave per work item (condense_rv.hpp), or nullptr
   int cond_rv_lds;
   expd_fn expd;
@@ -153,9 +154,11 @@ inline KernelSet make_set() {
   k.cond_fuses_cones = CondCfg<NV, NU, NF, NS>::FUSE ? 1 : 0;
   k.cond_fused_default = (CondCfg<NV, NU, NF, NS>::FUSE && CondCfg<NV, NU, NF, NS>::ITEMS >= 5) ? 1 : 0;
   k.cond_rv = nullptr;
+  k.cond_rv_nc = nullptr;
   k.cond_rv_lds = 0;
   if constexpr (CrvCfg<NV, NU, NF, NS>::OK) {
     k.cond_rv = condense_rv_kernel<NV, NU, NF, NS>;
+    k.cond_rv_nc = condense_rv_kernel<NV, NU, NF, NS, false>;
     k.cond_rv_lds = CrvCfg<NV, NU, NF, NS>::LDS_BYTES;
   }
   // regression guard for the occupancy the quadruped shape is sized for (condense.hpp: five / ten work items per CU)

@@ -1233,7 +1233,7 @@ static int launch_condense(rtoc_ctx* c) {
     a.stage_list = c->d_stage_list;
     a.nlist = c->n_stage_contact;
     static const int lds_pad = getenv("RTOC_CRV_LDS_PAD") ? atoi(getenv("RTOC_CRV_LDS_PAD")) : 0;   // occupancy experiments
-    if (a.nlist > 0) hipLaunchKernelGGL(c->ks->cond_rv, dim3(c->batch * a.nlist), dim3(64), c->ks->cond_rv_lds + lds_pad, c->stream, a);
+    if (a.nlist > 0) hipLaunchKernelGGL(a.cone_rows ? c->ks->cond_rv : c->ks->cond_rv_nc, dim3(c->batch * a.nlist), dim3(64), c->ks->cond_rv_lds + lds_pad, c->stream, a);
     a.stage_list = c->d_stage_list + c->n_stage_contact;
     a.nlist = c->n_stage_impact;
     if (a.nlist > 0) hipLaunchKernelGGL(c->ks->cond, dim3(c->batch * a.nlist), dim3(c->ks->cond_threads), c->ks->cond_lds, c->stream, a);
