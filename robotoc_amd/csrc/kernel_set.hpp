@@ -70,6 +70,7 @@ struct KernelSet {
   cond_fn cond_rv_nc;      // ... without the cone-row code (contexts without cone rows)
   cond_fn cond_rv;         // register-chained condensation of the contact grid points, one wave per work item (condense_rv.hpp), or nullptr
   int cond_rv_lds;
+  int cond_rv_cones;       // ... condenses friction-cone rows of point contacts itself (CrvCfg::CONES)
   expd_fn expd;
   int expd_threads, expd_lds;
   // horizon scan of the backward recursion (riccati_scan.hpp)
@@ -156,10 +157,12 @@ inline KernelSet make_set() {
   k.cond_rv = nullptr;
   k.cond_rv_nc = nullptr;
   k.cond_rv_lds = 0;
+  k.cond_rv_cones = 0;
   if constexpr (CrvCfg<NV, NU, NF, NS>::OK) {
     k.cond_rv = condense_rv_kernel<NV, NU, NF, NS>;
     k.cond_rv_nc = condense_rv_kernel<NV, NU, NF, NS, false>;
     k.cond_rv_lds = CrvCfg<NV, NU, NF, NS>::LDS_BYTES;
+    k.cond_rv_cones = CrvCfg<NV, NU, NF, NS>::CONES ? 1 : 0;
   }
   // regression guard for the occupancy the quadruped shape is sized for (condense.hpp: five / ten work items per CU)
   static_assert(!(NV == 18 && NU == 12 && NS == 12) ||

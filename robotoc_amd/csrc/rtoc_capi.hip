@@ -1181,7 +1181,7 @@ static int launch_sweep(rtoc_ctx* c) {
 // friction cones of point contacts are condensed INSIDE condense_rv_kernel (their Gram product's tiles go straight into the seeds and
 // operands of the condensation); wrench cones need their own kernel ahead of it
 static bool cond_rv_fuses_cones(const rtoc_ctx* c) {
-  return c->cone_contacts > 0 && c->cone_rows == RTOC_FRICTION_ROWS && c->cone_dim == 3 && c->ks->cond_fuses_cones;
+  return c->cone_contacts > 0 && c->cone_rows == RTOC_FRICTION_ROWS && c->cone_dim == 3 && c->ks->cond_fuses_cones && c->ks->cond_rv_cones;
 }
 static bool cond_rv_applies(const rtoc_ctx* c) {
   if (!c->cond_register || !c->ks->cond_rv || c->condense_split || c->keep_qaf) return false;
