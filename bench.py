@@ -943,13 +943,13 @@ def main():
                     reg_ms[key].append(ctx.time_phase(ph["condense"], 1))
             bad_sqp += int((ctx.status() != 0).sum())
             ctx.set_condense_register(register_default)
-        k_rv = "condense_rv_kernel<18, 12, 12, 12> (contact grid points, friction-cone rows inside) + condense_kernel<.., SPLIT = false> (impact grid points)"
+        k_rv = "condense_rv_kernel<18, 12, 12, 12, true> (contact grid points, friction-cone rows inside) + condense_kernel<.., SPLIT = false> (impact grid points)"
         k_fused, k_split = "condense_kernel<.., SPLIT = false> (one kernel)", "mjtjinv_kernel + condense_kernel<.., SPLIT = true>"
         t_fused = pmc_traffic("condense_kernel<18, 12, 12, 12, false>")
         # condense_rv_kernel's own counted bytes + the impact grid points' share of the role-split kernel's (its launch on those few grid
         # points is not the geometry the counter summary keeps)
         n_imp = sum(1 for g in grids[:-1] if g.type == 1)
-        t_rv = (lambda a, b: a + b * n_imp / (len(grids) - 1) if a and b else None)(pmc_traffic("condense_rv_kernel<18, 12, 12, 12>"), t_fused)
+        t_rv = (lambda a, b: a + b * n_imp / (len(grids) - 1) if a and b else None)(pmc_traffic("condense_rv_kernel<18, 12, 12, 12, true>"), t_fused)
         t_split = (lambda a, b: a + b if a and b else None)(pmc_traffic("mjtjinv_kernel<18, 12, 12, 12>"), pmc_traffic("condense_kernel<18, 12, 12, 12, true>"))
         cb = condense_bytes(L, grids, batch)
         crb = constraint_row_bytes(grids, batch, rows, 4, dims.nv)
