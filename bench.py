@@ -664,6 +664,28 @@ def dry_run(args, rank, world):
         dist.destroy_process_group()
 
 
+def solve_icub_jump_sto_example(local_rank):
+    """BASELINE configs[3] as the reference poses it (examples/icub/python/jump_sto.py; robotoc_amd.problems_jump.icub_jump_sto_solver):
+    iCub nv = 35 on its two soles (surface contacts), two jumps, four switching times optimised, the example's cost weights, joint limits
+    of its URDF, FrictionCone on the soles, minimum dwell times, N = 130, max_iter = 350 -- OCPSolver::solve of ONE OCP on the device."""
+    from robotoc_amd import problems_jump as pj
+    solver, x0, info = pj.icub_jump_sto_solver(batch=1, device=local_rank)
+    t0 = time.perf_counter()
+    st = solver.solve(0.0, x0)
+    wall = time.perf_counter() - t0
+    errs = np.array(st.kkt_error)
+    out = {"batch": 1, "nv": 35, "N": info["N"], "grid_points": len(solver.grids),
+           "solve": {"iterations": int(st.iter), "converged": bool(st.convergence), "final_kkt": float(errs[-1].max()),
+                     "ms_per_iteration": wall * 1e3 / max(int(st.iter), 1)},
+           "kkt_error_first": float(errs[0].max()), "mesh_refinements_at": list(st.mesh_refinement_iter),
+           "event_times_initial": [0.7, 0.95, 1.65, 1.9], "event_times_optimised": [float(v) for v in solver.event_times[0]],
+           "status_ok": bool((solver.ctx.status() == 0).all()),
+           "scope": "the reference example's OCP and solver options; every iteration (evalKKT incl. RNEA + derivatives of the 35-dof model, "
+                    "condensation, STO Riccati recursion, expansion, step sizes, update) on the device, schedule and mesh refinement on the host"}
+    solver.close()
+    return out
+
+
 def closed_loop_jump_sto(local_rank, timed=10):
     """OCPSolver::solve of BASELINE configs[2] with nothing of the iteration on the host: stand - flight - stand, both switching
     times optimised (SwitchingTimeOptimization on the device: dwell-time rows, per-instance event times and time steps),
@@ -1265,6 +1287,13 @@ def main():
             others["anymal_jump_sto_N40"]["closed_loop"] = closed_loop_jump_sto(local_rank)
         except Exception as e:  # the sweep numbers above stand on their own
             others["anymal_jump_sto_N40"]["closed_loop"] = {"error": repr(e)}
+
+    # ---- BASELINE configs[3] as the reference example poses it, solved: one OCP, N = 130 ----
+    if others is not None and rank == 0:
+        try:
+            others["icub_jump_sto_example_N130"] = solve_icub_jump_sto_example(local_rank)
+        except Exception as e:
+            others["icub_jump_sto_example_N130"] = {"error": repr(e)}
 
     if rank == 0:
         total_sweeps = world * batch * args.steps

@@ -54,3 +54,64 @@ def anymal_jump_sto_solver(batch=1, device=0, N=40, dt=0.02, jump_length=0.25, g
     solver.set_solution(sol)
     return solver, x0, dict(T=T, N=N, model=m, cost=cost, min_dwell=list(min_dwell),
                             limits=[9.42, 7.5, 80.0, 0.7])
+
+
+# joint limits of the example's iCub URDF (examples/icub/icub_description/urdf/icub.urdf: <limit lower upper velocity effort>), in the
+# order of the actuated joints of robotoc_amd/models/icub.json (legs, torso, arms)
+ICUB_Q_MIN = [-0.767945, -2.07694, -1.37881, -2.18166, -0.733038, -0.418879, -0.767945, -2.07694, -1.37881, -2.18166, -0.733038, -0.418879,
+              -0.383972, -0.680678, -1.02974, -1.65806, 0.0, -0.645772, 0.0959931, -0.872665, -1.13446, -0.436332, -1.65806, 0.0, -0.645772,
+              0.0959931, -0.872665, -1.13446, -0.436332]
+ICUB_Q_MAX = [2.30383, 0.296706, 1.37881, 0.401426, 0.366519, 0.418879, 2.30383, 0.296706, 1.37881, 0.401426, 0.366519, 0.418879, 1.46608,
+              0.680678, 1.02974, 0.0872665, 2.80649, 1.74533, 1.85005, 0.872665, 0.174533, 0.436332, 0.0872665, 2.80649, 1.74533, 1.85005,
+              0.872665, 0.174533, 0.436332]
+ICUB_V_MAX = [100.0] * 29
+ICUB_U_MAX = [84.0, 84.0, 40.0, 30.0, 24.0, 11.0, 84.0, 84.0, 40.0, 30.0, 24.0, 11.0, 36.0, 80.0, 80.0, 84.0, 84.0, 34.0, 20.0, 0.45, 0.65, 0.65,
+              84.0, 84.0, 34.0, 20.0, 0.45, 0.65, 0.65]
+
+
+def icub_jump_sto_solver(batch=1, device=0, dt=0.02, jump_length=0.5, ground_time=0.7, flying_time=0.25,
+                         min_dwell=(0.6, 0.2, 0.6, 0.2, 0.6), max_iter=350, initial_sto_reg_iter=10, with_limits=True, with_cones=True,
+                         jumps=2, horizon_scan="off"):
+    """BASELINE configs[3] as the reference poses it (examples/icub/python/jump_sto.py): iCub (nv = 35, the example's URDF) on its two
+    soles -- SURFACE contacts --, two jumps of 0.5 m (four discrete events, all with switching-time optimisation), ConfigurationSpaceCost
+    with the example's weights (:30-50), its Constraints object (six joint-limit components + FrictionCone on the soles, mu = 0.6,
+    :53-70), STOConstraints with the example's minimum dwell times (:104-106), T = 2.6 s, N = 130, kkt_tol_mesh = 0.1,
+    max_dt_mesh = T / N, initial_sto_reg_iter = 10, max_iter = 350 (:108-121).  jumps = 1: the first jump only (two events, T = 1.65 s)."""
+    from .grid import ICUB_Q_STANDING
+    m = rm.load_named("icub")
+    nv, nq, nu = m.nv, m.nq, m.nu
+    qs = np.array(ICUB_Q_STANDING, dtype=float)
+    place = [m.frame_placement(qs, c) for c in range(2)]
+    pos0 = np.array([p for _, p in place])
+    rot0 = np.array([R for R, _ in place])
+    step = np.array([jump_length, 0.0, 0.0])
+    masks, positions, events, t = [0b11], [pos0], [], 0.0
+    for j in range(jumps):
+        t += ground_time
+        events.append(Event("lift", t, sto=True))
+        masks.append(0)
+        positions.append(pos0 + j * step)
+        t += flying_time
+        events.append(Event("impact", t, sto=True))
+        masks.append(0b11)
+        positions.append(pos0 + (j + 1) * step)
+    T = t + ground_time
+    N = int(np.floor(T / dt + 1e-9))
+    plan = ContactPlan(masks, positions, events, phase_rotations=[rot0] * len(masks))
+    wq = np.concatenate([[0, 1, 1, 100, 100, 100], np.full(12, 0.001), [0.001, 1, 1], np.full(14, 0.001)])
+    cost = dict(q_ref=qs, v_ref=np.zeros(nv), u_ref=np.zeros(nu), q_weight=wq, v_weight=np.full(nv, 1e-3), a_weight=np.full(nv, 1e-5),
+                u_weight=np.zeros(nu), q_weight_terminal=wq, v_weight_terminal=np.full(nv, 1e-3), q_weight_impact=wq,
+                v_weight_impact=np.full(nv, 1e-3), dv_weight_impact=np.zeros(nv))
+    limits = (np.array(ICUB_Q_MIN), np.array(ICUB_Q_MAX), np.array(ICUB_V_MAX), np.array(ICUB_U_MAX)) if with_limits else None
+    opts = SolverOptions(max_iter=max_iter, kkt_tol=1e-7, kkt_tol_mesh=0.1, max_dt_mesh=T / N, initial_sto_reg_iter=initial_sto_reg_iter,
+                         horizon_scan=horizon_scan)
+    solver = OCPSolver(m, plan, T, N, cost, joint_limits=limits, friction_coefficients=np.full(2, 0.6) if with_cones else None,
+                       sto_constraints=STOConstraints(list(min_dwell[:len(events) + 1])), options=opts, batch=batch, device=device)
+    x0 = np.tile(np.concatenate([qs, np.zeros(nv)]), (batch, 1))
+    solver.discretize(0.0)
+    # the example's initial guess: q, v = the initial state on every grid point (:127-130), forces left at zero
+    S = Records(solver.ctx.L, "sol")
+    sol = S.zeros(batch, len(solver.grids))
+    S.f(sol, "q")[..., :nq] = x0[:, None, :nq]
+    solver.set_solution(sol)
+    return solver, x0, dict(T=T, N=N, model=m, cost=cost, min_dwell=list(min_dwell))

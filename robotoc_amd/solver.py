@@ -50,6 +50,7 @@ class ContactPlan:
     phase_masks: List[int]
     phase_positions: List[np.ndarray]
     events: List[Event] = field(default_factory=list)
+    phase_rotations: Optional[List[np.ndarray]] = None   # surface contacts: per phase [ncontacts, 3, 3] (ContactStatus::setContactPlacements)
 
     def impact_masks(self):
         out, p = [], 0
@@ -154,6 +155,7 @@ class OCPSolver:
         self.nc = model.ncontacts
         rows = joint_limit_rows_for(model) if joint_limits is not None else []
         nc_max = (len(rows) + (5 * self.nc if friction_coefficients is not None else 0) + 7) & ~7
+        self.cone_dim = model.contact_rows(0) if self.nc else 3   # FrictionCone acts on the force part of a surface contact's wrench
         self.dims = Dims(model.nv, nu, model.nv - nu, model.max_dimf, model.max_dimf, nc_max)
         nlift = sum(1 for e in plan.events if e.kind == "lift")
         nimp = len(plan.events) - nlift
@@ -170,7 +172,7 @@ class OCPSolver:
             c.set_constraint_rows(rows)
             c.set_constraint_bounds(np.concatenate([-q_min, q_max, v_max, v_max, u_max, u_max]), barrier_param, fraction_to_boundary_rule)
         if friction_coefficients is not None:
-            c.set_friction_cones(self.nc, 3)
+            c.set_friction_cones(self.nc, self.cone_dim)
             c.set_impact_cones(impact_cones)
             c.set_barrier_param(barrier_param, fraction_to_boundary_rule)
             c.set_friction_coefficients(np.asarray(friction_coefficients, dtype=float))
@@ -198,9 +200,10 @@ class OCPSolver:
         self.t0 = float(t)
         cs = self._sequence(self.event_times.mean(axis=0))
         grids = discretize(self.N, self.T, t, cs, phase_based=self.sto is not None)
-        if len(grids) != self.max_stages:
-            raise RuntimeError("the discretisation has %d grid points, the context was sized for %d (an event left the horizon?)"
-                               % (len(grids), self.max_stages))
+        nev = sum(1 for g in grids if g.type in (GRID_IMPACT, GRID_LIFT))
+        if len(grids) > self.max_stages or nev != len(self.plan.events):
+            raise RuntimeError("the discretisation has %d grid points with %d events, the context was sized for %d with %d (an event left the horizon?)"
+                               % (len(grids), nev, self.max_stages, len(self.plan.events)))
         self.grids = grids
         c = self.ctx
         c.set_grid(grids)
@@ -210,7 +213,14 @@ class OCPSolver:
             if g.type in (GRID_IMPACT, GRID_LIFT):
                 phase += 1
             pos[i] = self.plan.phase_positions[min(phase, len(self.plan.phase_positions) - 1)]
-        c.set_contact_schedule(self.masks, pos)
+        rot = None
+        if self.plan.phase_rotations is not None:
+            rot, phase = np.zeros((len(grids), self.nc, 3, 3)), 0
+            for i, g in enumerate(grids):
+                if g.type in (GRID_IMPACT, GRID_LIFT):
+                    phase += 1
+                rot[i] = self.plan.phase_rotations[min(phase, len(self.plan.phase_rotations) - 1)]
+        c.set_contact_schedule(self.masks, pos, rot)
         if self.sto is not None and len(self.plan.events) > 0:
             c.sto_set_problem(self.t0, self.T, self.event_times, self.sto.minimum_dwell_times, self.sto.barrier_param,
                               self.sto.fraction_to_boundary_rule)

@@ -105,3 +105,34 @@ def test_batched_jump_instances_optimise_their_own_switching_times(oracle):
             assert worst["IDC"] < 1e-7 and worst["Fx"] < 1e-8 and worst["switching"] < 1e-8, (b, worst)
     finally:
         solver.close()
+
+
+@pytest.mark.gpu
+def test_icub_jump_example_converges_on_the_device():
+    """BASELINE configs[3] as the reference poses it (examples/icub/python/jump_sto.py): iCub, nv = 35, two SURFACE contacts, two jumps of
+    0.5 m, all four switching times optimised, the example's ConfigurationSpaceCost weights, the joint limits of its URDF, FrictionCone on
+    the soles (mu = 0.6), minimum dwell times [0.6, 0.2, 0.6, 0.2, 0.6], T = 2.6 s, N = 130, kkt_tol_mesh = 0.1, max_dt_mesh = T / N,
+    initial_sto_reg_iter = 10, max_iter = 350 -- OCPSolver::solve from the example's initial guess (the standing pose on every grid
+    point) converges to its kkt_tol with two mesh refinements; every iteration runs on the device."""
+    from robotoc_amd import problems_jump as pj
+    solver, x0, info = pj.icub_jump_sto_solver(batch=1)
+    try:
+        assert info["N"] == 130 and solver.dims.nv == 35 and solver.cone_dim == 6
+        st = solver.solve(0.0, x0)
+        errs = np.array([float(np.max(e)) for e in st.kkt_error])
+        ts = solver.event_times[0]
+        print("iCub jump_sto example: %d iterations, converged %s, KKT %.2e -> %.2e, mesh refinements at %s, event times %s"
+              % (st.iter, st.convergence, errs[0], errs[-1], st.mesh_refinement_iter, np.array2string(ts, precision=4)))
+        assert st.convergence and st.iter < 350 and errs[-1] < 1e-7 and errs[0] > 1e3
+        assert (solver.ctx.status() == 0).all()
+        assert len(st.mesh_refinement_iter) >= 1
+        # the optimised switching times respect the minimum dwell times and moved off the initial ones
+        gaps = np.diff(np.concatenate([[0.0], ts, [info["T"]]]))
+        assert (gaps >= np.array(info["min_dwell"]) - 1e-9).all()
+        assert np.abs(ts - np.array([0.7, 0.95, 1.65, 1.9])).max() > 0.02
+        # the solution is dynamically consistent: the base travels the two jump lengths
+        S = Records(solver.ctx.L, "sol")
+        q = S.f(solver.get_solution()[0], "q")
+        assert abs(q[len(solver.grids) - 1, 0] - 1.0) < 0.15
+    finally:
+        solver.close()

@@ -20,7 +20,13 @@ def main():
     elif variant == "nolimits":
         kw = dict(with_limits=False)
     kw["horizon_scan"] = os.environ.get("RTOC_HORIZON_SCAN", "off")
-    solver, x0, info = pj.anymal_jump_sto_solver(batch=batch, **kw)
+    if variant.startswith("icub"):   # BASELINE configs[3] as examples/icub/python/jump_sto.py poses it; icub1: its first jump only
+        kw = dict(horizon_scan=kw["horizon_scan"], jumps=1 if variant == "icub1" else 2)
+        if len(sys.argv) > 3:
+            kw["max_iter"] = int(sys.argv[3])
+        solver, x0, info = pj.icub_jump_sto_solver(batch=batch, **kw)
+    else:
+        solver, x0, info = pj.anymal_jump_sto_solver(batch=batch, **kw)
     t0 = time.perf_counter()
     st = solver.solve(0.0, x0)
     dt = time.perf_counter() - t0
