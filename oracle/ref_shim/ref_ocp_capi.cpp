@@ -41,6 +41,8 @@ using namespace robotoc;
 namespace {
 struct State {
   int nv, nu, nc, n;
+  int cd = 3;                      // rows per contact: 3 (point contacts) or 6 (surface contacts: ref_ocp_begin_surface)
+  std::vector<double> rotations;   // [n][nc][9] row-major contact-frame rotations of the schedule (surface contacts)
   aligned_vector<Robot> robots;
   OCP ocp;
   std::unique_ptr<DirectMultipleShooting> dms;
@@ -66,18 +68,28 @@ Eigen::VectorXd vec(const double* p, int n) {
   for (int i = 0; i < n; ++i) v(i) = p[i];
   return v;
 }
-int sol_len(int nv, int nu, int nc) { return (nv + 1) + 2 * nv + nu + 3 * nc + 3 * nv + 3 * nc + 6 + 3 * nc; }
+int sol_len(int nv, int nu, int nc, int cd = 3) { return (nv + 1) + 2 * nv + nu + cd * nc + 3 * nv + cd * nc + 6 + cd * nc; }
 }  // namespace
 
 extern "C" {
 
 int ref_ocp_sol_len(int nv, int nu, int nc) { return sol_len(nv, nu, nc); }
+int ref_ocp_sol_len_cd(int nv, int nu, int nc, int cd) { return sol_len(nv, nu, nc, cd); }
 
 // Injections are pushed with ref_ocp_inject between ref_ocp_begin and ref_ocp_direction.
 int ref_ocp_begin(int nv, int nu, int ncontacts) {
   G.reset(new State());
   G->nv = nv, G->nu = nu, G->nc = ncontacts;
   G->robots.push_back(Robot(nv, nu, std::vector<ContactType>(ncontacts, ContactType::PointContact)));
+  return 0;
+}
+// the same for a robot on SURFACE contacts (iCub's soles): six rows per contact in f, mu, xi and in the switching constraints;
+// rotations: [n][ncontacts][9] row-major frame rotations of the contact schedule (ContactStatus::setContactPlacement)
+int ref_ocp_begin_surface(int nv, int nu, int ncontacts, const double* rotations, int n) {
+  G.reset(new State());
+  G->nv = nv, G->nu = nu, G->nc = ncontacts, G->cd = 6;
+  G->rotations.assign(rotations, rotations + (size_t)n * ncontacts * 9);
+  G->robots.push_back(Robot(nv, nu, std::vector<ContactType>(ncontacts, ContactType::SurfaceContact)));
   return 0;
 }
 int ref_ocp_inject(const char* key, const double* data, int rows, int cols) {
@@ -138,7 +150,15 @@ int ref_ocp_direction(const rtoc_grid* grid, const unsigned* masks, const double
     for (int c = 0; c < nc; ++c) {
       if ((mask >> c) & 1u) cs.activateContact(c);
       cs.setFrictionCoefficient(c, mu[c]);
-      cs.setContactPlacement(c, Eigen::Vector3d(vec(positions + ((size_t)i * nc + c) * 3, 3)));
+      if (g.cd == 6) {
+        Eigen::Matrix3d R;
+        const double* r = g.rotations.data() + ((size_t)i * nc + c) * 9;
+        for (int a_ = 0; a_ < 3; ++a_)
+          for (int b_ = 0; b_ < 3; ++b_) R(a_, b_) = r[3 * a_ + b_];
+        cs.setContactPlacement(c, Eigen::Vector3d(vec(positions + ((size_t)i * nc + c) * 3, 3)), R);
+      } else {
+        cs.setContactPlacement(c, Eigen::Vector3d(vec(positions + ((size_t)i * nc + c) * 3, 3)));
+      }
     }
     return cs;
   };
@@ -197,7 +217,7 @@ int ref_ocp_direction(const rtoc_grid* grid, const unsigned* masks, const double
   g.km = KKTMatrix(n, SplitKKTMatrix(robot));
   g.kr = KKTResidual(n, SplitKKTResidual(robot));
   g.fact = RiccatiFactorization(n, SplitRiccatiFactorization(robot));
-  const int SL = sol_len(nv, nu, nc);
+  const int SL = sol_len(nv, nu, nc, g.cd), cd = g.cd;
   for (int i = 0; i < n; ++i) {
     SplitSolution& s = g.s[i];
     const bool impact = grid[i].type == RTOC_GRID_IMPACT, terminal = grid[i].type == RTOC_GRID_TERMINAL;
@@ -212,14 +232,14 @@ int ref_ocp_direction(const rtoc_grid* grid, const unsigned* masks, const double
     (impact ? s.dv : s.a) = vec(p, nv), p += nv;
     s.u = vec(p, nu), p += nu;
     for (int c = 0; c < nc; ++c)
-      for (int k = 0; k < 3; ++k) s.f[c](k) = terminal ? 0.0 : p[3 * c + k];
-    p += 3 * nc;
+      for (int k = 0; k < cd; ++k) s.f[c](k) = terminal ? 0.0 : p[cd * c + k];
+    p += cd * nc;
     s.lmd = vec(p, nv), p += nv;
     s.gmm = vec(p, nv), p += nv;
     s.beta = vec(p, nv), p += nv;
     for (int c = 0; c < nc; ++c)
-      for (int k = 0; k < 3; ++k) s.mu[c](k) = terminal ? 0.0 : p[3 * c + k];
-    p += 3 * nc;
+      for (int k = 0; k < cd; ++k) s.mu[c](k) = terminal ? 0.0 : p[cd * c + k];
+    p += cd * nc;
     s.nu_passive = vec(p, 6), p += 6;
     for (int k = 0; k < ns; ++k) s.xi_stack()(k) = p[k];
     s.set_f_stack(), s.set_mu_stack();
@@ -266,7 +286,7 @@ int ref_ocp_direction(const rtoc_grid* grid, const unsigned* masks, const double
 }
 
 static void pack_solution(const State& g, const Solution& sol, double* sol_out) {
-  const int nv = g.nv, nu = g.nu, nc = g.nc, nq = nv + 1, n = g.n, SL = sol_len(nv, nu, nc);
+  const int nv = g.nv, nu = g.nu, nc = g.nc, nq = nv + 1, n = g.n, cd = g.cd, SL = sol_len(nv, nu, nc, cd);
   for (int i = 0; i < n; ++i) {
     const SplitSolution& s = sol[i];
     const bool impact = g.td[i].type == GridType::Impact;
@@ -276,14 +296,14 @@ static void pack_solution(const State& g, const Solution& sol, double* sol_out) 
     for (int k = 0; k < nv; ++k) *p++ = impact ? s.dv(k) : s.a(k);
     for (int k = 0; k < nu; ++k) *p++ = s.u(k);
     for (int c = 0; c < nc; ++c)
-      for (int k = 0; k < 3; ++k) *p++ = s.f[c](k);
+      for (int k = 0; k < cd; ++k) *p++ = s.f[c](k);
     for (int k = 0; k < nv; ++k) *p++ = s.lmd(k);
     for (int k = 0; k < nv; ++k) *p++ = s.gmm(k);
     for (int k = 0; k < nv; ++k) *p++ = s.beta(k);
     for (int c = 0; c < nc; ++c)
-      for (int k = 0; k < 3; ++k) *p++ = s.mu[c](k);
+      for (int k = 0; k < cd; ++k) *p++ = s.mu[c](k);
     for (int k = 0; k < 6; ++k) *p++ = s.nu_passive(k);
-    for (int k = 0; k < 3 * nc; ++k) *p++ = k < s.dims() ? s.xi_stack()(k) : 0.0;
+    for (int k = 0; k < cd * nc; ++k) *p++ = k < s.dims() ? s.xi_stack()(k) : 0.0;
   }
 }
 
@@ -364,7 +384,7 @@ int ref_ocp_integrate(const double* q_integrated, double* sol_out, double* slack
   for (int i = 0; i < n; ++i) robot.inject("integrateConfiguration", vec(q_integrated + (size_t)i * nq, nq));
   g.dms->integrateSolution(g.robots, g.td, g.primal, g.dual, g.d, g.s);   // ocp_solver.cpp:142
   if (g.sto_on) g.sto->integrateSolution(g.td, g.primal, g.dual, g.d);     // :143
-  const int SL = sol_len(nv, nu, nc), nrow = 6 * nu + 5 * nc;
+  const int cd = g.cd, SL = sol_len(nv, nu, nc, cd), nrow = 6 * nu + 5 * nc;
   for (int i = 0; i < n; ++i) {
     const SplitSolution& s = g.s[i];
     const bool impact = g.td[i].type == GridType::Impact;
@@ -374,14 +394,14 @@ int ref_ocp_integrate(const double* q_integrated, double* sol_out, double* slack
     for (int k = 0; k < nv; ++k) *p++ = impact ? s.dv(k) : s.a(k);
     for (int k = 0; k < nu; ++k) *p++ = s.u(k);
     for (int c = 0; c < nc; ++c)
-      for (int k = 0; k < 3; ++k) *p++ = s.f[c](k);
+      for (int k = 0; k < cd; ++k) *p++ = s.f[c](k);
     for (int k = 0; k < nv; ++k) *p++ = s.lmd(k);
     for (int k = 0; k < nv; ++k) *p++ = s.gmm(k);
     for (int k = 0; k < nv; ++k) *p++ = s.beta(k);
     for (int c = 0; c < nc; ++c)
-      for (int k = 0; k < 3; ++k) *p++ = s.mu[c](k);
+      for (int k = 0; k < cd; ++k) *p++ = s.mu[c](k);
     for (int k = 0; k < 6; ++k) *p++ = s.nu_passive(k);
-    for (int k = 0; k < 3 * nc; ++k) *p++ = k < s.dims() ? s.xi_stack()(k) : 0.0;
+    for (int k = 0; k < cd * nc; ++k) *p++ = k < s.dims() ? s.xi_stack()(k) : 0.0;
     OCPData& data = g.dms->ocp_data_[i];
     std::vector<ConstraintComponentData*> comp;
     for (auto& c : data.constraints_data.position_level_data) comp.push_back(&c);

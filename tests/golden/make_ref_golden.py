@@ -558,7 +558,7 @@ def icub_surface_stage_fixture(name="ref_icub_surface_stage.npz"):
     print(name, "stage KKT error %.6e" % out[-1])
 
 
-def ocp_solver_iteration_fixture(name="ref_anymal_ocp_solver_iteration.npz", sto=False, line_search=False, armijo=0.001):
+def ocp_solver_iteration_fixture(name="ref_anymal_ocp_solver_iteration.npz", sto=False, line_search=False, armijo=0.001, robot="anymal"):
     """ONE OCPSolver::updateSolution (src/solver/ocp_solver.cpp:111-145) of ANYmal over a short trot -- lifts, touch-downs with
     switching constraints, ConfigurationSpaceCost, six joint-limit components, FrictionCone -- run by the REFERENCE'S OWN
     DirectMultipleShooting, stages, ContactSequence, cost, constraints, dynamics and RiccatiRecursion sources
@@ -573,14 +573,26 @@ def ocp_solver_iteration_fixture(name="ref_anymal_ocp_solver_iteration.npz", sto
     decrease than the linear model promises: every candidate is evaluated and rejected, the loop ends below min_step_size).
     line_search=True: SolverOptions::enable_line_search -- the reference's own LineSearch::computeStepSize (filter method,
     src/line_search/line_search.cpp:31-83) picks the primal step between computeStepSizes and integrateSolution
-    (ocp_solver.cpp:133-139); every trial iterate's rigid-body quantities are injected like those of the iterate itself."""
+    (ocp_solver.cpp:133-139); every trial iterate's rigid-body quantities are injected like those of the iterate itself.
+    robot="icub": BASELINE configs[3]'s robot -- iCub (nv = 35) on its two soles, SURFACE contacts (six rows per contact in f, mu and
+    the switching constraint, Log6 placement residuals, frame rotations in the contact schedule), stand -> lift-off of both soles ->
+    flight -> touch-down -> stand over eleven grid points, FrictionCone on the force part of the wrenches."""
     import ctypes as C
     from robotoc_amd import robot_model as rm
     from robotoc_amd.grid import (ANYMAL_Q_STANDING, ANYMAL_TROT_IMPACT_MASKS, ANYMAL_TROT_PHASE_MASKS, contact_masks)
     from robotoc_amd.types import GRID_IMPACT as GI, GRID_TERMINAL as GT
-    m = rm.load_named("anymal")
-    nv, nq, nu, nc = m.nv, m.nq, 12, 4
-    if sto:
+    icub = robot == "icub"
+    assert not (icub and (sto or line_search))
+    m = rm.load_named("icub" if icub else "anymal")
+    nv, nq, nu, nc, cd = m.nv, m.nq, m.nv - 6, (2 if icub else 4), (6 if icub else 3)
+    if icub:
+        from robotoc_amd.grid import ICUB_Q_STANDING
+        cs_ = jump_sto_sequence(ground_time=0.07, flying_time=0.06, nf=12)
+        for e_ in cs_.events:
+            e_.sto = False
+        grids = discretize(10, 0.2, 0.0, cs_)
+        masks = contact_masks(grids, [0b11, 0, 0b11], [0b11])
+    elif sto:
         T_h, t_lift, t_land = 0.8, 0.31, 0.51
         grids = discretize(40, T_h, 0.0, jump_sto_sequence(ground_time=t_lift, flying_time=t_land - t_lift, nf=12), phase_based=True)
         masks = contact_masks(grids, [0b1111, 0, 0b1111], [0b1111])
@@ -589,9 +601,20 @@ def ocp_solver_iteration_fixture(name="ref_anymal_ocp_solver_iteration.npz", sto
         masks = contact_masks(grids, ANYMAL_TROT_PHASE_MASKS, ANYMAL_TROT_IMPACT_MASKS)
     n = len(grids)
     rng = np.random.default_rng(2468)
-    qs = np.array(ANYMAL_Q_STANDING, dtype=float)
+    qs = np.array(ICUB_Q_STANDING if icub else ANYMAL_Q_STANDING, dtype=float)
     feet = np.array([orc.rbd_contact_position(m, qs, c) for c in range(nc)])
     pos = np.tile(feet[None], (n, 1, 1)) + 0.003 * rng.uniform(-1, 1, (n, nc, 3))
+    rot = None
+    if icub:   # the soles' reference placements: the standing pose's, turned by a few hundredths of a radian
+        R0 = [orc.rbd_contact_placement(m, qs, c)[0] for c in range(nc)]
+        # (one placement per contact PHASE: FrictionCone reads ContactStatus::contactRotation, which a phase holds once -- the rigid-body
+        # quantities are injected per grid point and would tolerate a placement of their own each, the cone would not)
+        rot, ph = np.zeros((n, nc, 3, 3)), None
+        for i, g in enumerate(grids):
+            if ph is None or g.type in (GI, 2):
+                ph = np.array([R0[c] @ orc.rbd_exp6(np.concatenate([np.zeros(3), 0.02 * rng.uniform(-1, 1, 3)]))[0] for c in range(nc)])
+            rot[i] = ph
+    rkw = lambda i: dict(rref=rot[i].reshape(nc, 9)) if icub else {}
     if sto:
         land = next(i for i, g in enumerate(grids) if g.type == GI)
         pos[land:, :, 0] += 0.1   # the feet land 10 cm ahead
@@ -599,16 +622,16 @@ def ocp_solver_iteration_fixture(name="ref_anymal_ocp_solver_iteration.npz", sto
     for i in range(n):
         q[i] = qs
         q[i, :7] = orc.se3_integrate(qs[:7], 0.02 * rng.uniform(-1, 1, 6))
-        q[i, 7:] += 0.05 * rng.uniform(-1, 1, 12)
+        q[i, 7:] += 0.05 * rng.uniform(-1, 1, nu)
     v, a, u = 0.2 * rng.uniform(-1, 1, (n, nv)), 0.5 * rng.uniform(-1, 1, (n, nv)), 5.0 * rng.uniform(-1, 1, (n, nu))
     if line_search:   # an iterate whose full Newton step is long (roomy slacks) and overshoots (fast joints): the filter has work to do
         v, a = 3.0 * rng.uniform(-1, 1, (n, nv)), 20.0 * rng.uniform(-1, 1, (n, nv))
-    f = 5.0 * rng.uniform(-1, 1, (n, nc, 3))
+    f = 5.0 * rng.uniform(-1, 1, (n, nc, cd))
     f[:, :, 2] = rng.uniform(60, 120, (n, nc))
     lmd, gmm, beta = (0.2 * rng.uniform(-1, 1, (n, nv)) for _ in range(3))
-    mus, nup, xi = 0.2 * rng.uniform(-1, 1, (n, nc, 3)), 0.2 * rng.uniform(-1, 1, (n, 6)), 0.2 * rng.uniform(-1, 1, (n, 3 * nc))
-    mu = np.array([0.7, 0.6, 0.8, 0.5])
-    wq = np.concatenate([np.full(6, 10.0), np.full(12, 1.0)])
+    mus, nup, xi = 0.2 * rng.uniform(-1, 1, (n, nc, cd)), 0.2 * rng.uniform(-1, 1, (n, 6)), 0.2 * rng.uniform(-1, 1, (n, cd * nc))
+    mu = np.array([0.7, 0.6, 0.8, 0.5])[:nc]
+    wq = np.concatenate([np.full(6, 10.0), np.full(nu, 1.0)])
     M = nv + 1
     cost = np.zeros((12, M))
     for k, val in ((0, qs), (3, wq), (4, np.full(nv, 1.0)), (5, np.full(nv, 1e-2)), (6, np.full(nu, 1e-2)), (7, 10.0 * wq), (8, np.full(nv, 1.0)),
@@ -621,7 +644,7 @@ def ocp_solver_iteration_fixture(name="ref_anymal_ocp_solver_iteration.npz", sto
         limits = np.stack([np.full(nu, -6.0), np.full(nu, 6.0), np.full(nu, 40.0), np.full(nu, 400.0)])
         slack, dual = rng.uniform(20.0, 40.0, (n, nrow)), rng.uniform(1e-5, 1e-4, (n, nrow))
     barrier, tau = 1.0e-3, 0.995
-    x0 = np.concatenate([orc.se3_integrate(qs[:7], 0.01 * rng.uniform(-1, 1, 6)), qs[7:] + 0.02 * rng.uniform(-1, 1, 12), 0.05 * rng.uniform(-1, 1, nv)])
+    x0 = np.concatenate([orc.se3_integrate(qs[:7], 0.01 * rng.uniform(-1, 1, 6)), qs[7:] + 0.02 * rng.uniform(-1, 1, nu), 0.05 * rng.uniform(-1, 1, nv)])
     L = ref.lib()
     dp = C.POINTER(C.c_double)
     ptr = lambda x: np.ascontiguousarray(x, dtype=np.float64).ctypes.data_as(dp)
@@ -629,7 +652,11 @@ def ocp_solver_iteration_fixture(name="ref_anymal_ocp_solver_iteration.npz", sto
 
     def sub(qf, q0):
         return np.concatenate([orc.se3_difference(q0[:7], qf[:7]), qf[7:] - q0[7:]])
-    L.ref_ocp_begin(nv, nu, nc)
+    if icub:
+        L.ref_ocp_begin_surface.argtypes = [C.c_int, C.c_int, C.c_int, dp, C.c_int]
+        assert L.ref_ocp_begin_surface(nv, nu, nc, ptr(rot), n) == 0
+    else:
+        L.ref_ocp_begin(nv, nu, nc)
 
     def inject(key, arr):
         arr = np.asarray(arr, dtype=np.float64)
@@ -661,9 +688,9 @@ def ocp_solver_iteration_fixture(name="ref_anymal_ocp_solver_iteration.npz", sto
         mask = int(masks[i])
         act = [c for c in range(nc) if (mask >> c) & 1]
         fstack = np.concatenate([f[i, c] for c in act]) if act else np.zeros(0)
-        val = orc.rbd_eval(m, int(impact), qi, v[i], a[i], fstack, np.zeros(nu), mask, pos[i].reshape(-1))
-        J1 = orc.rbd_linearize_fd(m, int(impact), qi, v[i], a[i], fstack, np.zeros(nu), mask, pos[i].reshape(-1), eps=h)
-        J2 = orc.rbd_linearize_fd(m, int(impact), qi, v[i], a[i], fstack, np.zeros(nu), mask, pos[i].reshape(-1), eps=h / 2)
+        val = orc.rbd_eval(m, int(impact), qi, v[i], a[i], fstack, np.zeros(nu), mask, pos[i].reshape(-1), **rkw(i))
+        J1 = orc.rbd_linearize_fd(m, int(impact), qi, v[i], a[i], fstack, np.zeros(nu), mask, pos[i].reshape(-1), eps=h, **rkw(i))
+        J2 = orc.rbd_linearize_fd(m, int(impact), qi, v[i], a[i], fstack, np.zeros(nu), mask, pos[i].reshape(-1), eps=h / 2, **rkw(i))
         Jr = [(4.0 * np.asarray(J2[k]) - np.asarray(J1[k])) / 3.0 for k in range(3)]
         inject("ID", val[:nv])
         if impact:
@@ -681,6 +708,14 @@ def ocp_solver_iteration_fixture(name="ref_anymal_ocp_solver_iteration.npz", sto
             q_plus = plus(qi, dq_sw)
             imp = [c for c in range(nc) if (int(masks[i + 2]) >> c) & 1]
             P_at = lambda qq: np.concatenate([orc.rbd_contact_position(m, qq, c) - pos[i + 2, c] for c in imp])
+            if icub:   # SurfaceContact::computeContactPositionResidual (surface_contact.hxx:106-114): Log6(X_ref^-1 X)
+                def P_at(qq):
+                    out_ = []
+                    for c in imp:
+                        Rc, pc = orc.rbd_contact_placement(m, qq, c)
+                        Rr = rot[i + 2, c]
+                        out_.append(orc.rbd_log6(Rr.T @ Rc, Rr.T @ (pc - pos[i + 2, c])))
+                    return np.concatenate(out_)
             inject("integrateConfiguration", q_plus)
             inject("contactPositionResidual", P_at(q_plus))
             inject("contactPositionDerivative", _richardson(lambda e: P_at(plus(q_plus, e)), nv))
@@ -688,11 +723,11 @@ def ocp_solver_iteration_fixture(name="ref_anymal_ocp_solver_iteration.npz", sto
             inject("dIntegrate_dv", _richardson(lambda e: sub(plus(qi, dq_sw + e), q_plus), nv))
         inject("dSubtractConfiguration_dq0", _richardson(lambda e: sub(qi, plus(qn, e)), nv))
     inject("subtractConfiguration", sub(x0[:nq], q[0]))    # computeInitialStateDirection (state_equation.cpp:103)
-    SL = L.ref_ocp_sol_len(nv, nu, nc)
+    SL = L.ref_ocp_sol_len_cd(nv, nu, nc, cd)
     sol = np.zeros((n, SL))
     for i in range(n):
         mask = int(masks[i])
-        fi, mi = np.zeros((nc, 3)), np.zeros((nc, 3))
+        fi, mi = np.zeros((nc, cd)), np.zeros((nc, cd))
         for c in range(nc):
             if (mask >> c) & 1:
                 fi[c], mi[c] = f[i, c], mus[i, c]
@@ -817,7 +852,7 @@ def ocp_solver_iteration_fixture(name="ref_anymal_ocp_solver_iteration.npz", sto
         print("  event times %s -> %s, dts %s, STO kkt %.3e" % (et0, et1, dts[[i for i, g in enumerate(grids) if g.type in (1, 2)], 0], perf[0]))
     np.savez_compressed(os.path.join(HERE, name), sol_in=sol, sol_out=sol_out, slack=slack, dual=dual, slack_out=slack_out, dual_out=dual_out,
                         steps=steps, x0=x0, pos=pos, mu=mu, cost=cost, limits=limits, masks=masks, scalars=np.array([barrier, tau]),
-                        **grid_table(grids), **sto_kw, **ls_kw)
+                        **(dict(rot=rot, robot=np.array("icub")) if icub else {}), **grid_table(grids), **sto_kw, **ls_kw)
     print(name, "n %d, KKT error %.6e, steps %.4f / %.4f" % (n, steps[2], steps[0], steps[1]))
 
 
@@ -834,6 +869,7 @@ FIXTURES = {
     "ocp_iteration": ocp_solver_iteration_fixture,
     "riccati_full_size": full_size_fixtures,
     "riccati_icub32": icub32_full_size,
+    "ocp_iteration_icub": lambda: ocp_solver_iteration_fixture("ref_icub_ocp_solver_iteration.npz", robot="icub"),
     "ocp_iteration_sto": lambda: ocp_solver_iteration_fixture("ref_anymal_jump_sto_solver_iteration.npz", sto=True),
     "ocp_iteration_line_search": lambda: ocp_solver_iteration_fixture("ref_anymal_ocp_solver_iteration_line_search.npz", line_search=True),
     "ocp_iteration_line_search_merit": lambda: (ocp_solver_iteration_fixture("ref_anymal_ocp_solver_iteration_line_search_merit.npz", line_search="merit"),
