@@ -680,8 +680,17 @@ def solve_icub_jump_sto_example(local_rank):
            "kkt_error_first": float(errs[0].max()), "mesh_refinements_at": list(st.mesh_refinement_iter),
            "event_times_initial": [0.7, 0.95, 1.65, 1.9], "event_times_optimised": [float(v) for v in solver.event_times[0]],
            "status_ok": bool((solver.ctx.status() == 0).all()),
+           "with_horizon_scan": None,
            "scope": "the reference example's OCP and solver options; every iteration (evalKKT incl. RNEA + derivatives of the 35-dof model, "
                     "condensation, STO Riccati recursion, expansion, step sizes, update) on the device, schedule and mesh refinement on the host"}
+    solver.close()
+    # the same solve with the backward / forward recursions as horizon scans (RTOC_OPT_BACKWARD_SCAN: stage parallelism for ONE OCP)
+    solver, x0, info = pj.icub_jump_sto_solver(batch=1, device=local_rank, horizon_scan="on")
+    t0 = time.perf_counter()
+    st = solver.solve(0.0, x0)
+    wall = time.perf_counter() - t0
+    out["with_horizon_scan"] = {"iterations": int(st.iter), "converged": bool(st.convergence), "final_kkt": float(np.array(st.kkt_error)[-1].max()),
+                                "ms_per_iteration": wall * 1e3 / max(int(st.iter), 1)}
     solver.close()
     return out
 
