@@ -40,10 +40,13 @@ class ConfigurationCostSource : public StageDataSource {
   const STOConstraints* stoConstraints() const override { return sto_.get(); }
   double horizonLength() const override { return T_; }
   const std::vector<unsigned>* contactMasks() const override { return &active_; }
+  int maxGridPoints() const override {
+    return cs_ ? N_ + 1 + cs_->numLiftEvents() + 2 * cs_->numImpactEvents() : td_.size();
+  }
   bool discretize(const double t) override {
     if (!cs_) return false;
     td_ = robotoc::discretize(*cs_, T_, N_, t, static_cast<bool>(sto_));
-    contactSchedule(*cs_, td_, active_, cpos_);
+    contactSchedule(*cs_, td_, active_, cpos_, &crot_);
     scheduled_ = false;
     return true;
   }
@@ -130,7 +133,7 @@ class ConfigurationCostSource : public StageDataSource {
  private:
   void schedule(rtoc_ctx* ctx) {
     if (scheduled_) return;  // needs the grid, which the solver sets after configure()
-    chk(rtoc_set_contact_schedule(ctx, active_.data(), cpos_.data(), nullptr), "rtoc_set_contact_schedule");
+    chk(rtoc_set_contact_schedule(ctx, active_.data(), cpos_.data(), crot_.empty() ? nullptr : crot_.data()), "rtoc_set_contact_schedule");
     scheduled_ = true;
   }
   static void chk(const int rc, const char* what) {
@@ -141,6 +144,7 @@ class ConfigurationCostSource : public StageDataSource {
   TimeDiscretization td_;
   std::vector<unsigned> active_;
   std::vector<double> cpos_;
+  std::vector<double> crot_;   // [grid point][contact][9] or empty (surface contacts: ContactSequence rotations)
   Solution s0_;
   std::vector<rtoc_box_row> rows_;
   std::vector<double> bounds_, mu_;

@@ -43,18 +43,23 @@ class ContactSequence {
   ContactSequence() : nc_(0) {}
   // contact_rows[k]: 3 (point contact) or 6 (surface contact) of contact k
   explicit ContactSequence(const std::vector<int>& contact_rows) : nc_(static_cast<int>(contact_rows.size())), rows_(contact_rows) {}
-  void init(const unsigned mask, const std::vector<double>& positions) {
+  // rotations: [ncontacts][9] row-major rotations of the contact placements (ContactStatus::setContactPlacements; surface
+  // contacts: the reference frame of the Log6 residual and of the friction cone), or empty = identity
+  void init(const unsigned mask, const std::vector<double>& positions, const std::vector<double>& rotations = {}) {
     checkPositions(positions);
-    masks_.assign(1, mask), pos_.assign(1, positions);
+    checkRotations(rotations);
+    masks_.assign(1, mask), pos_.assign(1, positions), rot_.assign(1, rotations);
     impact_.clear(), time_.clear(), sto_.clear();
   }
-  void push_back(const unsigned mask, const std::vector<double>& positions, const double switching_time, const bool sto = false) {
+  void push_back(const unsigned mask, const std::vector<double>& positions, const double switching_time, const bool sto = false,
+                 const std::vector<double>& rotations = {}) {
     if (masks_.empty()) throw std::runtime_error("[ContactSequence] init() first");
     checkPositions(positions);
+    checkRotations(rotations);
     if (!time_.empty() && switching_time <= time_.back()) throw std::runtime_error("[ContactSequence] event times must increase");
     impact_.push_back((mask & ~masks_.back()) != 0u);  // a contact becomes active: impact (discrete_event.cpp)
     time_.push_back(switching_time), sto_.push_back(sto);
-    masks_.push_back(mask), pos_.push_back(positions);
+    masks_.push_back(mask), pos_.push_back(positions), rot_.push_back(rotations);
   }
   int numContacts() const { return nc_; }
   int numContactPhases() const { return static_cast<int>(masks_.size()); }
@@ -71,6 +76,12 @@ class ContactSequence {
   bool anySTO() const { return std::find(sto_.begin(), sto_.end(), true) != sto_.end(); }
   unsigned phaseMask(const int phase) const { return masks_.at(std::min(phase, numContactPhases() - 1)); }
   const std::vector<double>& phasePositions(const int phase) const { return pos_.at(std::min(phase, numContactPhases() - 1)); }
+  const std::vector<double>& phaseRotations(const int phase) const { return rot_.at(std::min(phase, numContactPhases() - 1)); }   // empty: identity
+  bool hasRotations() const {
+    for (const auto& r : rot_)
+      if (!r.empty()) return true;
+    return false;
+  }
   unsigned impactMask(const int event) const { return masks_.at(event + 1) & ~masks_.at(event); }
   int contactRows(const int k) const { return rows_.at(k); }
   int dimf(const unsigned mask) const {
@@ -84,10 +95,13 @@ class ContactSequence {
   void checkPositions(const std::vector<double>& p) const {
     if (p.size() != static_cast<size_t>(nc_) * 3) throw std::invalid_argument("[ContactSequence] positions: [ncontacts][3]");
   }
+  void checkRotations(const std::vector<double>& r) const {
+    if (!r.empty() && r.size() != static_cast<size_t>(nc_) * 9) throw std::invalid_argument("[ContactSequence] rotations: [ncontacts][9] or none");
+  }
   int nc_;
   std::vector<int> rows_;
   std::vector<unsigned> masks_;
-  std::vector<std::vector<double>> pos_;
+  std::vector<std::vector<double>> pos_, rot_;
   std::vector<bool> impact_, sto_;
   std::vector<double> time_;
 };
@@ -218,14 +232,23 @@ inline double maxTimeStep(const TimeDiscretization& td) {   // time_discretizati
 }
 
 // contact mask / positions of every grid point (ContactStatus of its phase; ImpactStatus on impact grids)
-inline void contactSchedule(const ContactSequence& cs, const TimeDiscretization& td, std::vector<unsigned>& active, std::vector<double>& positions) {
+// rotations (optional): [grid point][contact][9], filled when the sequence carries contact placements (identity where a phase has none)
+inline void contactSchedule(const ContactSequence& cs, const TimeDiscretization& td, std::vector<unsigned>& active, std::vector<double>& positions,
+                            std::vector<double>* rotations = nullptr) {
   const int n = td.size(), nc = cs.numContacts();
   active.assign(n, 0u), positions.assign(static_cast<size_t>(n) * nc * 3, 0.0);
+  if (rotations) rotations->clear();
+  if (rotations && cs.hasRotations()) rotations->assign(static_cast<size_t>(n) * nc * 9, 0.0);
   for (int i = 0; i < n; ++i) {
     const GridInfo& g = td[i];   // GridInfo::phase = number of discrete events up to and including this grid point
     active[i] = g.type == GridType::Impact ? cs.impactMask(g.phase - 1) : cs.phaseMask(g.phase);
     const std::vector<double>& p = cs.phasePositions(g.phase);
     std::copy(p.begin(), p.end(), positions.begin() + static_cast<size_t>(i) * nc * 3);
+    if (rotations && !rotations->empty()) {
+      const std::vector<double>& r = cs.phaseRotations(g.phase);
+      for (int c = 0; c < nc; ++c)
+        for (int e = 0; e < 9; ++e) (*rotations)[(static_cast<size_t>(i) * nc + c) * 9 + e] = r.empty() ? ((e % 4 == 0) ? 1.0 : 0.0) : r[c * 9 + e];
+    }
   }
 }
 

@@ -137,6 +137,9 @@ class StageDataSource {
   // TimeDiscretization::discretize(contact_sequence, t) (+ correctTimeSteps when phase based) from the sequence's current
   // event times; the next linearize() / initConstraints() must hand the new contact schedule to the device
   virtual bool discretize(const double) { return false; }
+  // the most grid points a re-discretisation can produce (mesh refinement moves grid points between the phases of a PhaseBased
+  // discretisation): N + 1 + lifts + 2 impacts for a source that owns its contact sequence; the solver reserves that many
+  virtual int maxGridPoints() const { return timeDiscretization().size(); }
   virtual const std::vector<unsigned>* contactMasks() const { return nullptr; }
   virtual void initialSolution(Solution& s) const = 0;
 };
@@ -266,7 +269,7 @@ struct SolverOCP : public OCP {
   explicit SolverOCP(const std::shared_ptr<StageDataSource>& src, const int dev = 0) : source(src), device(dev) {
     robot = src->robot();
     N = src->timeDiscretization().size() - 1;
-    reserved_num_discrete_events = 0;
+    reserved_num_discrete_events = std::max(0, src->maxGridPoints() - (N + 1));   // (ocp.hpp: reserved_num_discrete_events)
   }
   SolverOCP() {}
 };

@@ -7,7 +7,8 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TESTS = ["riccati_recursion_test", "unconstr_riccati_recursion_test", "contact_dynamics_test"]
-BUILD_ONLY = TESTS + ["ocp_solver_test", "unconstr_ocp_solver_test", "ocp_solver_device_test", "ocp_solver_trot_test", "ocp_solver_jump_sto_test"]  # ocp_solver_test needs a stage dump: run by tests/test_cpp_solver.py
+BUILD_ONLY = TESTS + ["ocp_solver_test", "unconstr_ocp_solver_test", "ocp_solver_device_test", "ocp_solver_trot_test", "ocp_solver_jump_sto_test",
+                      "ocp_solver_icub_jump_sto_test"]  # ocp_solver_test needs a stage dump: run by tests/test_cpp_solver.py
 
 
 def _paths(name):

@@ -334,3 +334,51 @@ def test_ocp_solver_jump_with_switching_time_optimisation_on_the_device(tmp_path
     assert np.array_equal(hist_cpp[:first_ref], hist[:first_ref])
     assert abs(iters - st.iter) <= 1
     assert np.abs(ts_cpp - ts_py).max() < 1e-6, (ts_cpp, ts_py)
+
+
+@pytest.mark.gpu
+def test_ocp_solver_icub_jump_example_through_the_cpp_shell(tmp_path):
+    """BASELINE configs[3] as the reference poses it (examples/icub/python/jump_sto.py) through the C++ shell: a robotoc::ContactSequence
+    of SURFACE contacts with their placements (positions + rotations), four STO-enabled events, the example's cost, limits, FrictionCone,
+    STOConstraints and solver options; robotoc::OCPSolver::solve converges like the Python mirror does -- same iteration count (+-1),
+    the same mesh refinements, the same optimised switching times."""
+    from robotoc_amd import problems_jump as pj
+    from robotoc_amd.robot_model import MAX_JOINTS
+    from test_cpp_host import _build
+    exe = _build("ocp_solver_icub_jump_sto_test")
+    solver, x0, info = pj.icub_jump_sto_solver(batch=1)
+    m = info["model"]
+    nv, nq, nu = m.nv, m.nq, m.nu
+    try:
+        st = solver.solve(0.0, x0)
+        assert st.convergence
+        hist = np.array([e[0] for e in st.kkt_error])
+        ts_py = solver.event_times[0].copy()
+        plan, opts = solver.plan, solver.options
+    finally:
+        solver.close()
+    cost = np.zeros((12, MAX_JOINTS))
+    c = info["cost"]
+    for k, key in enumerate(("q_ref", "v_ref", "u_ref", "q_weight", "v_weight", "a_weight", "u_weight", "q_weight_terminal", "v_weight_terminal",
+                             "q_weight_impact", "v_weight_impact", "dv_weight_impact")):
+        cost[k, :len(c[key])] = c[key]
+    nev = len(plan.events)
+    prob = str(tmp_path / "icub_jump_sto.bin")
+    with open(prob, "wb") as f:
+        f.write(bytes(m))
+        f.write(cost.tobytes())
+        f.write(np.array([info["N"], nev], dtype=np.int32).tobytes())
+        for arr in ([info["T"]], [e.time for e in plan.events], np.array(plan.phase_positions), plan.phase_rotations[0], x0[0, :nq], x0[0, nq:],
+                    info["min_dwell"][:nev + 1], pj.ICUB_Q_MIN, pj.ICUB_Q_MAX, pj.ICUB_V_MAX, pj.ICUB_U_MAX, [0.6], [opts.max_dt_mesh]):
+            f.write(np.ascontiguousarray(arr, dtype=np.float64).tobytes())
+    out_path = str(tmp_path / "icub_jump_sto_out.bin")
+    run = subprocess.run([exe, prob, out_path], capture_output=True, text=True, timeout=600)
+    print(run.stdout, run.stderr)
+    assert run.returncode == 0, (run.returncode, run.stdout, run.stderr)
+    raw = np.fromfile(out_path)
+    iters, conv, err, nref, first_ref, ts_cpp, hist_cpp = int(raw[0]), raw[1], raw[2], int(raw[3]), int(raw[4]), raw[5:5 + nev], raw[5 + nev:]
+    assert conv == 1.0 and err < 1e-7
+    assert nref == len(st.mesh_refinement_iter) >= 1 and abs(first_ref - st.mesh_refinement_iter[0]) <= 1
+    assert np.allclose(hist_cpp[:10], hist[:10], rtol=1e-9)   # the same launches on the same data up to the end of the regularised iterations
+    assert abs(iters - st.iter) <= 3
+    assert np.abs(ts_cpp - ts_py).max() < 1e-5, (ts_cpp, ts_py)
