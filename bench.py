@@ -391,7 +391,7 @@ def compact_line(res):
         o = {}
         for name, e in oc.items():
             c = pick(e, ("batch", "backward_ms", "forward_ms", "sweeps_per_sec", "single_instance_sweep_ms",
-                         "single_instance_sweep_scan_ms", "sqp_iters_per_sec"))
+                         "single_instance_sweep_scan_ms", "sqp_iters_per_sec", "update_solution_iters_per_sec_batch256"))
             r2 = e.get("roofline")
             if r2:
                 c["bound"] = r2.get("bound")
@@ -691,6 +691,24 @@ def solve_icub_jump_sto_example(local_rank):
     wall = time.perf_counter() - t0
     out["with_horizon_scan"] = {"iterations": int(st.iter), "converged": bool(st.convergence), "final_kkt": float(np.array(st.kkt_error)[-1].max()),
                                 "ms_per_iteration": wall * 1e3 / max(int(st.iter), 1)}
+    solver.close()
+    # throughput: the same OCP in 256 instances with distinct initial states, OCPSolver::updateSolution of the whole batch timed
+    b2 = 256
+    solver, x0, info = pj.icub_jump_sto_solver(batch=b2, device=local_rank, x0_noise=0.01)
+    c = solver.ctx
+    c.set_initial_state(x0)
+    solver.init_constraints()
+    c.sto_set_regularization(1.0e30)
+    errs = [c.contact_update_solution(0.995) for _ in range(3)]
+    c.sync()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        c.contact_update_solution(0.995, want_kkt_error=False)
+    c.sync()
+    ms = (time.perf_counter() - t0) / 5 * 1e3
+    out["batch_throughput"] = {"batch": b2, "grid_points": len(solver.grids), "update_solution_ms": ms, "iterations_per_sec": b2 / ms * 1e3,
+                               "kkt_error_worst_first_iterations": [float(np.max(e)) for e in errs], "status_ok": bool((c.status() == 0).all())}
+    out["update_solution_iters_per_sec_batch256"] = b2 / ms * 1e3
     solver.close()
     return out
 

@@ -71,7 +71,7 @@ ICUB_U_MAX = [84.0, 84.0, 40.0, 30.0, 24.0, 11.0, 84.0, 84.0, 40.0, 30.0, 24.0, 
 
 def icub_jump_sto_solver(batch=1, device=0, dt=0.02, jump_length=0.5, ground_time=0.7, flying_time=0.25,
                          min_dwell=(0.6, 0.2, 0.6, 0.2, 0.6), max_iter=350, initial_sto_reg_iter=10, with_limits=True, with_cones=True,
-                         jumps=2, horizon_scan="off"):
+                         jumps=2, horizon_scan="off", x0_noise=0.0, seed=11):
     """BASELINE configs[3] as the reference poses it (examples/icub/python/jump_sto.py): iCub (nv = 35, the example's URDF) on its two
     soles -- SURFACE contacts --, two jumps of 0.5 m (four discrete events, all with switching-time optimisation), ConfigurationSpaceCost
     with the example's weights (:30-50), its Constraints object (six joint-limit components + FrictionCone on the soles, mu = 0.6,
@@ -108,6 +108,10 @@ def icub_jump_sto_solver(batch=1, device=0, dt=0.02, jump_length=0.5, ground_tim
     solver = OCPSolver(m, plan, T, N, cost, joint_limits=limits, friction_coefficients=np.full(2, 0.6) if with_cones else None,
                        sto_constraints=STOConstraints(list(min_dwell[:len(events) + 1])), options=opts, batch=batch, device=device)
     x0 = np.tile(np.concatenate([qs, np.zeros(nv)]), (batch, 1))
+    if x0_noise > 0.0:   # a distinct initial state per instance (batched runs)
+        rng = np.random.default_rng(seed)
+        x0[:, 7:nq] += x0_noise * rng.uniform(-1, 1, (batch, nq - 7))
+        x0[:, nq:] = x0_noise * rng.uniform(-1, 1, (batch, nv))
     solver.discretize(0.0)
     # the example's initial guess: q, v = the initial state on every grid point (:127-130), forces left at zero
     S = Records(solver.ctx.L, "sol")
