@@ -1246,6 +1246,12 @@ def main():
                                 entry[key] = {"bound": "hbm", "achieved": nbytes / (acc2[pn] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                               "frac": nbytes / (acc2[pn] * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": nbytes,
                                               "kernel_ms": acc2[pn], "traffic": None}
+                            if wrench2 and b2 == 1024:   # the counter passes ran this iteration at this size (tools/pmc_driver.py)
+                                tail = "<%d, %d, %d, %d" % (d2.nv, d2.nu, d2.nf_max, d2.ns_max)
+                                parts = [pmc_traffic("mjtjinv_kernel" + tail), pmc_traffic("condense_kernel" + tail)]
+                                entry["roofline_condense"]["traffic"] = sum(parts) if all(parts) else None
+                                parts = [pmc_traffic("expand_kernel<%d," % d2.nv), pmc_traffic("wrench_expand_kernel<%d," % d2.nv)]
+                                entry["roofline_expand"]["traffic"] = sum(parts) if all(parts) else None
                             if wrench2:
                                 del cone2
                             c2.clear_status()
