@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 
 from robotoc_amd import capi, problems as pr
-from robotoc_amd.types import BUF_CDD, BUF_CON, BUF_CONE, BUF_DX0, BUF_KKT, joint_limit_rows
+from robotoc_amd.types import BUF_CDD, BUF_CON, BUF_CONE, BUF_DX0, BUF_KKT, icub_dims, joint_limit_rows
 
 
 def tile(a, batch):
@@ -101,6 +101,7 @@ def main():
     # ---- iCub nv=32 / nv=35, 1024 instances: backward + forward, condense + expand ----
     for nv in (32, 35):
         dims, grids, _ = pr.config_icub_jump(nv=nv)
+        dims = icub_dims(dims.nv, nc_max=(6 * dims.nu + 34 + 7) & ~7)   # room for the joint-limit and wrench-cone rows (as bench.py)
         batch = 1024
         ctx = capi.Context(dims, len(grids), batch, 0)
         L = ctx.L
