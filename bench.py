@@ -399,9 +399,13 @@ def compact_line(res):
                 c["mfma_f64_frac"] = _r(r2["mfma_f64"]["frac"], 4)
             if "roofline_condense" in e:
                 c["condense_frac"] = _r(e["roofline_condense"].get("frac"), 4)
-            sv = e.get("solve") or ((e.get("closed_loop") or {}).get("single_instance") or {}).get("solve")
+            if e.get("solve"):
+                c["solve"] = pick(e["solve"], ("iterations", "converged", "final_kkt", "ms_per_iteration"))
+            # this repo's own hop with the 2 x 17 wrench-cone rows, a fixed number of Gauss-Newton iterations without line search
+            # (a timing; the reference's example of the configuration is icub_jump_sto_example_N130 above / below)
+            sv = ((e.get("closed_loop") or {}).get("single_instance") or {}).get("solve")
             if sv:
-                c["solve"] = pick(sv, ("iterations", "converged", "final_kkt", "ms_per_iteration"))
+                c["wrench_cone_hop_fixed_iterations"] = pick(sv, ("iterations", "final_kkt", "ms_per_iteration"))
             o[name] = c
         out["other_configs"] = o
     out["status_nonzero_instances"] = res.get("status_nonzero_instances", 0) + (sq or {}).get("status_nonzero_instances", 0)
