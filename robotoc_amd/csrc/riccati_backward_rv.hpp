@@ -66,6 +66,10 @@ constexpr int RV_MAX_STAGES = 64;   // grid points of a horizon the kernel keeps
 #ifndef RTOC_RV_NT
 #define RTOC_RV_NT 0
 #endif
+// RTOC_RV_MERGE_PBT = 1: PB^T rides in the idle lanes of P+'s last column tile during the W products (see the stage loop)
+#ifndef RTOC_RV_MERGE_PBT
+#define RTOC_RV_MERGE_PBT 1
+#endif
 __device__ __forceinline__ double rv_ld(const double* p) {
 #if RTOC_RV_NT
   return __builtin_nontemporal_load(p);
@@ -367,6 +371,12 @@ __global__ __launch_bounds__(64, 2) void riccati_backward_rv_kernel(BwdArgs a) {
       }
     }
     RV_PROF(3);
+#if RTOC_RV_MERGE_PBT
+    // PB^T takes the idle lanes of P+'s last column tile (li >= SCOL: columns beyond the matrix, zero): the row tile T - 1 of the
+    // stacked operand [P+; PB^T] is then one register file, no select per product below -- and the accumulators of PB are dead here
+#pragma unroll
+    for (int g = 0; g < KG; ++g) pp[g / 4][T - 1][g % 4] = (li >= SCOL) ? acc[g / 4][g % 4] : pp[g / 4][T - 1][g % 4];
+#endif
     RV_PROF(4);
     if (!impact) {
       rv_lds_sync();
@@ -406,7 +416,9 @@ __global__ __launch_bounds__(64, 2) void riccati_backward_rv_kernel(BwdArgs a) {
 #pragma unroll
         for (int tm = 0; tm < T; ++tm) {
           double av = pp[g / 4][tm][g % 4];
+#if !RTOC_RV_MERGE_PBT
           if (tm == T - 1) av = (li >= SCOL) ? acc[g / 4][g % 4] : av;   // PB^T[u = li - SCOL][4g + q]
+#endif
           if (sa_tile && tm < T - 1) {
             if (group_dense(g)) w[tm] = mfma16(av, bm, w[tm]);
           } else {
