@@ -183,7 +183,9 @@ int rtoc_contact_line_search(rtoc_ctx* ctx, int* host_trials);
  * parameter (1 + margin_rate) x max over the grid of SplitSolution::lagrangeMultiplierLinfNorm (:120-128), directional derivative of
  * cost + barrier + penalty x violation from one trial at step eps, then backtracking until armijoCondition (:111-117) holds with
  * armijo_control_rate; the reference's defaults are 0.001, 0.05, 1e-8.  rtoc_line_search_merit_terms: the penalty parameters and
- * directional derivatives of the last rtoc_contact_line_search (either pointer may be NULL). */
+ * directional derivatives of the last rtoc_contact_line_search (either pointer may be NULL).
+ * The unconstrained solver is filter-only, like UnconstrLineSearch (src/line_search/unconstr_line_search.cpp, which never reads
+ * line_search_method): after rtoc_unconstr_eval_kkt the line search takes the filter path whatever `method` says. */
 int rtoc_set_line_search_method(rtoc_ctx* ctx, int method, double armijo_control_rate, double margin_rate, double eps);
 int rtoc_line_search_merit_terms(rtoc_ctx* ctx, double* host_penalty, double* host_directional_derivative, int count);
 /* trial evaluations (dms_trial_.evalOCP calls, line_search.cpp:70, :99, :109) of the last line search, whichever entry point ran it */

@@ -28,6 +28,55 @@ def build(force=False):
     return so
 
 
+_SRCS = ("rtoc_oracle.c", "rtoc_oracle_condense.c", "rtoc_oracle_bench.c", "rtoc_oracle_rbd.c", "rtoc_oracle_rbd_cs.c")
+_NATIVE = None
+
+
+def _host_tag():
+    """Names the host CPU (model + ISA flags): a -march=native object must never be loaded on another machine."""
+    import hashlib
+    model, flags = "", ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and not model:
+                model = line.split(":", 1)[1].strip()
+            if line.startswith("flags") and not flags:
+                flags = line.split(":", 1)[1].strip()
+            if model and flags:
+                break
+    except OSError:
+        pass
+    return hashlib.sha1((model + "|" + flags).encode()).hexdigest()[:12], model, ("avx512f" in flags.split())
+
+
+def native_lib():
+    """The same C restatement built -O3 -march=native ON THIS HOST (the CPU baseline's build), for bench.py's
+    cpu_baseline leg only -- the parity suite keeps the portable x86-64-v3 object that travels with the snapshot.
+    Returns (CDLL with the orc_bench_* entry points typed, description dict)."""
+    global _NATIVE
+    if _NATIVE is None:
+        tag, model, avx512 = _host_tag()
+        out_dir = os.path.join(_HERE, "_native")
+        os.makedirs(out_dir, exist_ok=True)
+        so = os.path.join(out_dir, "librtoc_oracle_%s.so" % tag)
+        srcs = [os.path.join(_HERE, f) for f in _SRCS]
+        if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+            subprocess.check_call(["gcc", "-O3", "-march=native", "-fopenmp", "-fPIC", "-std=c99", "-w", "-shared", "-o", so] + srcs + ["-lm"])
+        L = C.CDLL(so)
+        _type_bench(L)
+        _NATIVE = (L, dict(flags="-O3 -march=native -fopenmp", host_cpu=model, avx512=bool(avx512)))
+    return _NATIVE
+
+
+def _type_bench(L):
+    dp = C.POINTER(C.c_double)
+    L.orc_bench_sweep.argtypes = [C.POINTER(Layout), C.POINTER(Grid), C.c_int, C.c_int, dp, dp, C.c_double, C.c_int, C.c_int, dp]
+    L.orc_bench_sweep.restype = C.c_uint
+    L.orc_bench_sqp.restype = C.c_uint
+    L.orc_bench_sqp.argtypes = [C.POINTER(Layout), C.POINTER(Grid), C.c_int, C.c_int, dp, dp, dp, dp, dp, C.POINTER(BoxRow), C.c_int,
+                                C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int, dp]
+
+
 def lib():
     global _LIB
     if _LIB is None:
@@ -300,21 +349,22 @@ def integrate_solution_batch(L, grids, steps, dirs, sol):
                                        _p(sol))
 
 
-def bench_sweep(L, grids, kkt, dx0, reps, nthreads=0, max_dts0=0.1):
+def bench_sweep(L, grids, kkt, dx0, reps, nthreads=0, max_dts0=0.1, native=False):
     """Timed backward+forward sweeps of reps x batch instances, thread-private working records
-    (rtoc_oracle_bench.c).  The inputs are read-only.  Returns dict(seconds, refill_seconds, threads, sweeps)."""
+    (rtoc_oracle_bench.c).  The inputs are read-only.  Returns dict(seconds, refill_seconds, threads, sweeps).
+    native: the -march=native build of this host (native_lib)."""
     out = np.zeros(4)
-    st = lib().orc_bench_sweep(C.byref(L), grid_array(grids), len(grids), kkt.shape[0], _p(kkt), _p(dx0), max_dts0,
+    st = (native_lib()[0] if native else lib()).orc_bench_sweep(C.byref(L), grid_array(grids), len(grids), kkt.shape[0], _p(kkt), _p(dx0), max_dts0,
                                reps, nthreads, _p(out))
     return dict(seconds=out[0], refill_seconds=out[1], threads=int(out[2]), sweeps=reps * kkt.shape[0], status=st)
 
 
 def bench_sqp(L, grids, kkt, cdd, con, cone, dx0, rows, max_contacts, contact_dim, tau, reps, nthreads=0,
-              max_dts0=0.1):
+              max_dts0=0.1, native=False):
     """Timed SQP hot-path iterations (condense -> sweep -> expand -> step sizes -> update) of reps x batch instances
     on pre-condensation records, thread-private working records.  Inputs are read-only."""
     out = np.zeros(4)
-    st = lib().orc_bench_sqp(C.byref(L), grid_array(grids), len(grids), kkt.shape[0], _p(kkt), _p(cdd), _p(con),
+    st = (native_lib()[0] if native else lib()).orc_bench_sqp(C.byref(L), grid_array(grids), len(grids), kkt.shape[0], _p(kkt), _p(cdd), _p(con),
                              _p(cone) if cone is not None else None, _p(dx0), _rows(rows), len(rows), max_contacts,
                              contact_dim, tau, max_dts0, reps, nthreads, _p(out))
     return dict(seconds=out[0], refill_seconds=out[1], threads=int(out[2]), iterations=reps * kkt.shape[0], status=st)

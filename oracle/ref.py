@@ -121,6 +121,19 @@ def riccati_sweep(L, grids, kkt, ric, dirs, max_dts0=0.1, contact_dim=3, forward
                             contact_dim, int(forward))
 
 
+def riccati_sweep_bench(L, grids, kkt, dx0, reps, max_dts0=0.1, contact_dim=3):
+    """`reps` timed backward + forward recursions of ONE instance ([stages, stride] record, read-only) by the reference's own
+    RiccatiRecursion, one thread.  Returns dict(seconds, reload_seconds, sweeps).  What this build of the reference sources is:
+    see ref_capi.cpp: ref_riccati_sweep_bench."""
+    f = lib().ref_riccati_sweep_bench
+    f.argtypes = [C.POINTER(Layout), C.POINTER(Grid), C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.c_int, C.c_int,
+                  C.POINTER(C.c_double)]
+    out = np.zeros(2)
+    rc = f(C.byref(L), grid_array(grids), len(grids), _p(kkt), _p(dx0), max_dts0, contact_dim, reps, _p(out))
+    assert rc == 0
+    return dict(seconds=out[0], reload_seconds=out[1], sweeps=reps)
+
+
 def unconstr_sweep(L, nstages, dt, kkt, ric, dirs, forward=True):
     lib().ref_unconstr_sweep(C.byref(L), nstages, dt, _p(kkt), _p(ric), _p(dirs), int(forward))
 

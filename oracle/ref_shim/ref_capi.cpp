@@ -209,6 +209,52 @@ int ref_riccati_sweep(const rtoc_layout* L, const rtoc_grid* grid, int nstages, 
   return 0;
 }
 
+// The same sweep, timed (bench.py: cpu_baseline.reference_sources): `reps` backward + forward recursions of ONE instance by the
+// reference's RiccatiRecursion.  The recursion mutates its KKT containers, so they are reloaded from the (read-only) record before
+// every repetition; only the two recursion calls are inside the clock -- the way OCPBenchmarker times updateSolution
+// (include/robotoc/utils/ocp_benchmarker.hxx:14-32: a steady clock around the solver call).  out[0] = seconds inside the clock,
+// out[1] = seconds of the reloads.  NOTE what this measures: the reference's sources at -O2 with assertions on, their Eigen
+// expressions evaluated eagerly by oracle/ref_shim/mini_eigen.hpp (temporaries, no vectorised kernels) -- NOT an Eigen build.
+}  // extern "C"
+#include <chrono>
+extern "C" {
+int ref_riccati_sweep_bench(const rtoc_layout* L, const rtoc_grid* grid, int nstages, const double* kkt, const double* dx0,
+                            double max_dts0, int contact_dim, int reps, double* out) {
+  Robot robot = make_robot(L, contact_dim);
+  OCP ocp;
+  ocp.robot = robot;
+  ocp.N = nstages - 1;
+  ocp.reserved_num_discrete_events = 0;
+  std::vector<GridInfo> gi;
+  for (int i = 0; i < nstages; ++i) gi.push_back(to_grid(grid[i]));
+  TimeDiscretization td(gi);
+  KKTMatrix km(nstages, SplitKKTMatrix(robot));
+  KKTResidual kr(nstages, SplitKKTResidual(robot));
+  RiccatiFactorization fac(nstages, SplitRiccatiFactorization(robot));
+  Direction d(nstages, SplitDirection(robot));
+  RiccatiRecursion rec(ocp, max_dts0);
+  for (int i = 0; i < nstages; ++i) {
+    const bool plain = i < nstages - 1 && grid[i].type != RTOC_GRID_IMPACT;
+    d[i].setSwitchingConstraintDimension(plain ? grid[i].dims : 0);
+  }
+  double t_rec = 0.0, t_load = 0.0;
+  typedef std::chrono::steady_clock clk;
+  for (int r = 0; r < reps; ++r) {
+    const clk::time_point t0 = clk::now();
+    for (int i = 0; i < nstages; ++i) load_kkt(L, grid[i], kkt + (size_t)i * L->kkt.stride, km[i], kr[i]);
+    get_vec(d[0].dx, dx0);
+    const clk::time_point t1 = clk::now();
+    rec.backwardRiccatiRecursion(td, km, kr, fac);
+    rec.forwardRiccatiRecursion(td, km, kr, fac, d);
+    const clk::time_point t2 = clk::now();
+    t_load += std::chrono::duration<double>(t1 - t0).count();
+    t_rec += std::chrono::duration<double>(t2 - t1).count();
+  }
+  out[0] = t_rec;
+  out[1] = t_load;
+  return 0;
+}
+
 // UnconstrRiccatiRecursion::{backward,forward}RiccatiRecursion of one instance (uniform dt = T / N).
 // Records: Quu / lu / Qxu slots hold Qaa / la / [Qqa; Qva] (the acceleration is the control).
 int ref_unconstr_sweep(const rtoc_layout* L, int nstages, double dt, double* kkt, double* ric, double* dir, int do_forward) {

@@ -224,9 +224,12 @@ static __global__ __launch_bounds__(64) void ls_penalty_kernel(LsPenaltyArgs a) 
     const double* s = a.sol + ((size_t)b * a.nstages + st) * a.sl.stride;
     linf(s + a.sl.off[RTOC_SOL_LMD], a.nv);
     linf(s + a.sl.off[RTOC_SOL_GMM], a.nv);
-    if (g.type == RTOC_GRID_TERMINAL) continue;
+    // (the terminal record too: SplitSolution::lagrangeMultiplierLinfNorm of s[N] takes every field, line_search.cpp:120-128 --
+    //  beta, nu_passive are zero there unless the caller uploaded something else; the terminal stage has no contact forces, mu of
+    //  s[N] is never written by the solver and stays out)
     linf(s + a.sl.off[RTOC_SOL_BETA], a.nv);
     if (a.np > 0) linf(s + a.sl.off[RTOC_SOL_NUP], a.np);
+    if (g.type == RTOC_GRID_TERMINAL) continue;
     linf(s + a.sl.off[RTOC_SOL_MU], g.dimf);
     if (g.type != RTOC_GRID_IMPACT && g.switching_constraint) linf(s + a.sl.off[RTOC_SOL_XI], g.dims);
   }

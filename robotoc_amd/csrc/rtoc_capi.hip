@@ -286,8 +286,9 @@ static __global__ __launch_bounds__(256) void stream_probe_kernel(const char* __
 }  // extern "C++"
 
 int rtoc_bandwidth_probe(int device, size_t bytes, double* read_gbs, double* copy_gbs) {
-  const int blocks = 256 * 64;                                 // 64 workgroups of 4 waves per CU: 6.2 TB/s read (256 * 8: 5.7)
-  const size_t per = (size_t)blocks * 4 * 8;                   // chunks consumed per trip of all waves (U = 8)
+  constexpr int blocks = 256 * 64;                             // 64 workgroups of 4 waves per CU: 6.2 TB/s read (256 * 8: 5.7)
+  constexpr size_t per = (size_t)blocks * 4 * 8;               // chunks consumed per trip of all waves (U = 8)
+  static_assert(per * 1024 == RTOC_BANDWIDTH_PROBE_MIN_BYTES, "include/rtoc.h states the probe's minimum size: one trip of every wave");
   if (bytes < per * 1024) return RTOC_ERR_BAD_ARG;             // RTOC_BANDWIDTH_PROBE_MIN_BYTES: one trip of every wave (512 MiB)
   HIP_TRY(hipSetDevice(device));
   const size_t chunks = (bytes / 1024) / per * per;
@@ -1232,8 +1233,17 @@ static int launch_condense(rtoc_ctx* c) {
   if (rv) {
     a.stage_list = c->d_stage_list;
     a.nlist = c->n_stage_contact;
-    static const int lds_pad = getenv("RTOC_CRV_LDS_PAD") ? atoi(getenv("RTOC_CRV_LDS_PAD")) : 0;   // occupancy experiments
-    if (a.nlist > 0) hipLaunchKernelGGL(a.cone_rows ? c->ks->cond_rv : c->ks->cond_rv_nc, dim3(c->batch * a.nlist), dim3(64), c->ks->cond_rv_lds + lds_pad, c->stream, a);
+#ifdef RTOC_CRV_DEBUG_LDS_PAD   // occupancy experiments (debug builds only): extra dynamic LDS per work item, clamped to what a launch accepts
+    static const int lds_pad_env = getenv("RTOC_CRV_LDS_PAD") ? atoi(getenv("RTOC_CRV_LDS_PAD")) : 0;
+    const int lds_room = 64 * 1024 - c->ks->cond_rv_lds;
+    const int lds_pad = lds_pad_env < 0 ? 0 : (lds_pad_env > lds_room ? lds_room : lds_pad_env);
+#else
+    constexpr int lds_pad = 0;
+#endif
+    if (a.nlist > 0) {
+      hipLaunchKernelGGL(a.cone_rows ? c->ks->cond_rv : c->ks->cond_rv_nc, dim3(c->batch * a.nlist), dim3(64), c->ks->cond_rv_lds + lds_pad, c->stream, a);
+      HIP_TRY(hipGetLastError());
+    }
     a.stage_list = c->d_stage_list + c->n_stage_contact;
     a.nlist = c->n_stage_impact;
     if (a.nlist > 0) hipLaunchKernelGGL(c->ks->cond, dim3(c->batch * a.nlist), dim3(c->ks->cond_threads), c->ks->cond_lds, c->stream, a);
@@ -2957,7 +2967,9 @@ int rtoc_contact_line_search(rtoc_ctx* c, int* host_trials) {
   if (!c->ls_on) return RTOC_ERR_NOT_READY;
   int rc = ensure_line_search(c);
   if (rc) return rc;
-  const bool merit = c->ls_method == 1;
+  // UnconstrLineSearch (src/line_search/unconstr_line_search.cpp) has the filter method only and ignores line_search_method: an
+  // unconstrained context takes the filter path whatever rtoc_set_line_search_method said (its SOL records have no beta / mu / xi)
+  const bool merit = c->ls_method == 1 && !(c->ls_unconstr_dt > 0.0);
   LsMeritArgs ma;
   if (!merit) {
     rc = launch_filter_device(c, c->d_eval, nullptr, 1);   // an empty filter is seeded with the current iterate (:58-62)
