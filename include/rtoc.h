@@ -163,8 +163,13 @@ enum rtoc_option {
                       * P+ / s+ in MFMA accumulators, the stage record by LDS-DMA, switching-constraint grid points in factorised
                       * form; riccati_backward_rv.hpp) where it applies: shapes whose stacked operand [P+; PB^T] fills its 16-row
                       * tiles (nv = 18, nu = 12: ANYmal, A1), grids without switching-time optimisation, RTOC_OPT_WRITEBACK_KKT = 0
-                      * and the default RTOC_OPT_BACKWARD_WAVES.  Elsewhere, and with 0, the role-split / tile-split kernels run.
-                      * Same results to fp64 round-off (tests/test_backward_register.py). */
+                      * and the default RTOC_OPT_BACKWARD_WAVES.  On the iCub-size shapes (nx = 64 / 70) its counterpart is the
+                      * register-wide kernel (riccati_backward_rw.hpp: one wavefront per instance and SIMD, P+ in 16 / 25 accumulator
+                      * tiles, the dense rows of a STRUCTURED Fxx staged in LDS; checked on the device like RTOC_OPT_FXX_STRUCTURE;
+                      * switching-constraint grid points as one-stage launches of the tile-split kernel): with 1 on batches of more
+                      * instances than the device has compute units (below that the tile-split kernel's four waves per instance
+                      * finish a horizon sooner), with 2 on every batch.  Elsewhere, and with 0, the role-split / tile-split
+                      * kernels run.  Same results to fp64 round-off (tests/test_backward_register.py). */
   RTOC_OPT_CONDENSE_REGISTER = 17, /* 1 (default): rtoc_condense runs the register-chained kernel (one wavefront per grid point, the saddle
                       * inverse read once into MFMA accumulators, every product of condenseContactDynamics chained through
                       * register layouts, friction-cone rows condensed inside it; condense_rv.hpp) on the CONTACT grid points of shapes

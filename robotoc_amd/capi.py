@@ -314,8 +314,9 @@ class Context:
         _chk(lib().rtoc_set_option(self._h, OPT_CONDENSE_REGISTER, 2 if on == "cones" else int(bool(on))))
 
     def set_backward_register(self, on):
-        """RTOC_OPT_BACKWARD_REGISTER: the register-resident backward kernel (one wave per instance) where it applies."""
-        _chk(lib().rtoc_set_option(self._h, OPT_BACKWARD_REGISTER, int(bool(on))))
+        """RTOC_OPT_BACKWARD_REGISTER: the register-resident backward kernel (one wave per instance) where it applies;
+        2: the iCub-size shapes' register-wide kernel on every batch size (1: on batches larger than the device's CU count)."""
+        _chk(lib().rtoc_set_option(self._h, OPT_BACKWARD_REGISTER, 2 if on == 2 else int(bool(on))))
 
     def set_condense_split(self, on):
         """RTOC_OPT_CONDENSE_SPLIT: MJtJinv in its own kernel or one fused condensation kernel (default per robot shape)."""

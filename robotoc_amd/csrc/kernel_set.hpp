@@ -15,6 +15,7 @@
 #include "riccati_backward.hpp"
 #include "riccati_backward_rs.hpp"
 #include "riccati_backward_rv.hpp"
+#include "riccati_backward_rw.hpp"
 #include "condense_rv.hpp"
 #include "riccati_scan.hpp"
 #include "riccati_forward.hpp"
@@ -53,6 +54,8 @@ struct KernelSet {
   bwd_fn bwd_rv;      // register-resident kernel, one wave per instance (riccati_backward_rv.hpp), or nullptr
   bwd_fn bwd_rv_sa;   // ... its structured-Fxx form, or nullptr
   int bwd_rv_lds;
+  bwd_fn bwd_rw;      // register-wide kernel of the iCub-size shapes, one wave per instance and SIMD (riccati_backward_rw.hpp), or nullptr
+  int bwd_rw_lds;
   rtoc_record_layout kl, rl, dl, cl;  // record layouts the kernels were compiled for
   fwd_fn fwd;
   int fwd_threads;
@@ -123,6 +126,10 @@ inline KernelSet make_set() {
     if constexpr (NV % 16 == 2 && RvCfg<NV, NU>::T == 3 && NV - NU > 0 && NV - NU <= 8 && (NV - NU) % 2 == 0)
       k.bwd_rv_sa = riccati_backward_rv_kernel<NV, NU, NS, true>;
     k.bwd_rv_lds = rv_lds_bytes<NV, NU, NS>();
+  }
+  if constexpr (RwCfg<NV, NU>::OK) {
+    k.bwd_rw = riccati_backward_rw_kernel<NV, NU, NS>;
+    k.bwd_rw_lds = RwLds<NV, NU, NS>::BYTES;
   }
   constexpr int NWF = (2 * NV + NU + 63) / 64;
   if constexpr (NWF == 1)

@@ -175,6 +175,7 @@ struct rtoc_ctx {
   int keep_qaf;        // RTOC_OPT_CONDENSE_KEEP_QAF
   int fxx_mode;        // RTOC_OPT_FXX_STRUCTURE: 0 auto, 1 dense, 2 caller asserts the structure
   int bwd_register;    // RTOC_OPT_BACKWARD_REGISTER: the register-resident backward kernel where it applies
+  int num_cus;         // compute units of the device (the register-wide iCub kernel runs where the batch fills them)
   int cond_register;   // RTOC_OPT_CONDENSE_REGISTER: the register-chained condensation of the contact grid points where it applies
   int* d_stage_list;   // [max_stages] grid points 0 .. nstages - 2: the contact ones first (n_stage_contact), then the impact ones
   int n_stage_contact, n_stage_impact;
@@ -367,7 +368,12 @@ static int create_members(rtoc_ctx* c, const rtoc_dims* dims, const KernelSet* k
   c->device = device;
   c->max_dts0 = 0.1;  // RiccatiRecursion(ocp, max_dts0 = 0.1), riccati_recursion.hpp:35
   c->bwd_variant = (ks->nvariants >= 3) ? ks->nvariants - 1 : 0;  // role-split kernel where it exists
-  c->bwd_register = 1;   // ... and the register-resident kernel wherever it applies (rv_applies)
+  c->bwd_register = 1;   // ... and the register-resident kernel wherever it applies (rv_applies, rw_applies)
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
+    c->num_cus = cus;
+  }
   c->cond_register = 1;  // likewise the condensation (cond_rv_applies)
   if (const char* e = getenv("RTOC_CONDENSE_REGISTER")) c->cond_register = (e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1;
   HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
@@ -777,7 +783,7 @@ int rtoc_set_option(rtoc_ctx* c, int option, int64_t value) {
       c->condense_split = (int)value;
       return RTOC_OK;
     case RTOC_OPT_BACKWARD_REGISTER:
-      if (value != 0 && value != 1) return RTOC_ERR_BAD_ARG;
+      if (value != 0 && value != 1 && value != 2) return RTOC_ERR_BAD_ARG;
       c->bwd_register = (int)value;
       return RTOC_OK;
     case RTOC_OPT_CONDENSE_REGISTER:
@@ -1031,8 +1037,11 @@ static int check_fxx(rtoc_ctx* c) {
   c->fxx_state = c->fxx_last = bad ? 2 : 1;
   return RTOC_OK;
 }
+// does the backward recursion of this context have a structure-exploiting kernel to choose? (quadruped shapes: the structured forms of
+// the role-split / register-resident kernels; iCub-size shapes: riccati_backward_rw_kernel, which exists in the structured form only)
+static bool rw_configured(const rtoc_ctx* c);
 static bool fxx_structured(rtoc_ctx* c) {
-  if (!c->ks->bwd_sa || c->bwd_variant != 3) return false;  // no structured kernel for this shape / variant: nothing to check
+  if (!((c->ks->bwd_sa && c->bwd_variant == 3) || rw_configured(c))) return false;  // no structured kernel for this shape / variant: nothing to check
   if (c->fxx_mode == 1) return false;
   if (c->fxx_mode == 2) return true;
   if (c->fxx_state == 0 && check_fxx(c) != RTOC_OK) return false;
@@ -1071,9 +1080,63 @@ static int launch_backward_rv(rtoc_ctx* c, int first, int end, hipStream_t strea
   return RTOC_OK;
 }
 
+// RTOC_OPT_BACKWARD_REGISTER on the iCub-size shapes: the register-wide kernel (riccati_backward_rw.hpp; one wave per instance and
+// SIMD, structured Fxx).  1 (default): batches that fill the machine -- below one instance per CU the tile-split kernel's four waves
+// per instance finish a horizon sooner --, 2: always.  Switching-constraint grid points are one-stage launches of the tile-split
+// kernel between the segments (P+ / s+ through the Riccati records).
+static bool rw_configured(const rtoc_ctx* c) {
+  return c->bwd_register && c->ks->bwd_rw && c->h_grid && c->nstages >= 2 && c->nstages <= RV_MAX_STAGES && !c->writeback && !grid_has_sto(c) &&
+         c->bwd_variant == ((c->ks->nvariants >= 3) ? c->ks->nvariants - 1 : 0) && (c->bwd_register >= 2 || c->batch > c->num_cus);
+}
+static bool rw_applies(rtoc_ctx* c) { return rw_configured(c) && fxx_structured(c); }
+static int launch_backward_rw(rtoc_ctx* c, int first, int end, hipStream_t stream) {
+  const KernelSet* ks = c->ks;
+  const int N = c->nstages - 1, nb = end - first;
+  BwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.kkt = c->buf[RTOC_BUF_KKT];
+  a.kkt_rw = c->buf[RTOC_BUF_KKT];
+  a.ric = c->buf[RTOC_BUF_RIC];
+  a.grid = c->d_grid;
+  a.status = c->d_status;
+  a.nstages = c->nstages;
+  a.batch = end;
+  a.first = first;
+  a.max_dts0 = c->max_dts0;
+  a.prof = c->d_prof;
+  const int v1 = ks->scan_policy_variant;
+  auto constrained = [&](int st) { return c->h_grid[st].type != RTOC_GRID_IMPACT && c->h_grid[st].dims > 0; };
+  auto one_stage = [&](int st) {   // tile-split kernel, grid point st only (st == N: the terminal record)
+    BwdArgs o = a;
+    o.scan_ps = c->buf[RTOC_BUF_RIC] + c->L.ric.off[RTOC_RIC_P];
+    o.scan_ps_stride = c->L.ric.stride;
+    o.scan_ps_soff = c->L.ric.off[RTOC_RIC_S] - c->L.ric.off[RTOC_RIC_P];
+    o.seg_hi = o.seg_lo = st;
+    hipLaunchKernelGGL(ks->bwd[v1], dim3(nb, 1), dim3(64 * ks->bwd_waves[v1]), ks->bwd_lds[v1], stream, o);
+  };
+  if (N == 0 || constrained(N - 1)) one_stage(N);   // nobody else writes the terminal record then
+  int hi = N - 1;
+  while (hi >= 0) {
+    if (constrained(hi)) {
+      one_stage(hi);
+      --hi;
+      continue;
+    }
+    int lo = hi;
+    while (lo > 0 && !constrained(lo - 1)) --lo;
+    a.seg_hi = hi;
+    a.seg_lo = lo;
+    hipLaunchKernelGGL(ks->bwd_rw, dim3(nb), dim3(64), ks->bwd_rw_lds, stream, a);
+    hi = lo - 1;
+  }
+  HIP_TRY(hipGetLastError());
+  return RTOC_OK;
+}
+
 static int launch_backward_range(rtoc_ctx* c, int first, int end, hipStream_t stream) {
   if (scan_applies(c)) return launch_backward_scan(c, first, end, stream);
   if (rv_applies(c)) return launch_backward_rv(c, first, end, stream);
+  if (rw_applies(c)) return launch_backward_rw(c, first, end, stream);
   BwdArgs a;
   memset(&a, 0, sizeof(a));
   a.kkt = c->buf[RTOC_BUF_KKT];

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Headline backward sweep (4096 distinct ANYmal trot instances) with the role-split and with the register-resident kernel
-(RTOC_OPT_BACKWARD_REGISTER), timed with events on the context's stream; the two results compared on the device."""
+"""Backward sweep of a batch of distinct instances with RTOC_OPT_BACKWARD_REGISTER off and on (the register-resident kernels where
+they apply), interleaved A B A B, timed with events on the context's stream; the two results compared on the device.
+usage: rv_bench.py [batch] [trot | jump_sto | icub32 | icub35]"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -8,7 +9,9 @@ from robotoc_amd import capi, problems as pr
 from robotoc_amd.types import BUF_KKT, BUF_RIC, BUF_DX0, BUF_DIR
 
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-dims, grids, _ = pr.config_anymal_trot()
+cfg = sys.argv[2] if len(sys.argv) > 2 else "trot"
+dims, grids, _ = {"trot": pr.config_anymal_trot, "jump_sto": pr.config_anymal_jump_sto, "icub32": lambda: pr.config_icub_jump(nv=32),
+                  "icub35": lambda: pr.config_icub_jump(nv=35)}[cfg]()
 n = len(grids)
 ctx = capi.Context(dims, n, batch, 0)
 L = ctx.L
@@ -21,7 +24,7 @@ for b_, t_ in ((BUF_KKT, kkt), (BUF_DX0, dx0), (BUF_RIC, ric), (BUF_DIR, d)):
     ctx.bind(b_, t_.data_ptr())
 torch.cuda.synchronize()
 res = {}
-for name, on in (("role-split", False), ("register", True), ("role-split", False), ("register", True)):
+for name, on in (("role-split", 0), ("register", 2), ("role-split", 0), ("register", 2)):
     ctx.set_backward_register(on)
     ric.fill_(float("nan"))
     torch.cuda.synchronize()   # (torch's stream, not the context's)
