@@ -74,6 +74,10 @@ extern "C" {
 #define RTOC_STAT_S_NOT_SPD 0x2u    /* LLT(S) of the switching-constraint Schur complement (:63-64)   */
 #define RTOC_STAT_NAN 0x4u          /* NaN/Inf in K, k, M, m (:75-79)                                   */
 #define RTOC_STAT_M_NOT_SPD 0x8u    /* LLT(dIDda) or LLT(J Minv J^T) failed in computeMJtJinv           */
+#define RTOC_STAT_FXX_UNSTRUCTURED 0x10u /* the structure-exploiting backward kernel met an Fxx whose top half is not
+                                     * [a I | c I] + two corners (a bound buffer rewritten behind the runtime's back,
+                                     * RTOC_OPT_FXX_STRUCTURE): the instance's factorisation is not to be used; call
+                                     * rtoc_check_fxx_structure (or set the option to 1) and repeat the sweep */
 
 /* ---- buffers ---------------------------------------------------------------- */
 enum rtoc_buffer {
@@ -134,8 +138,13 @@ enum rtoc_option {
                               * the structure-exploiting kernel is used iff EVERY record has the shape, the dense one
                               * otherwise (same results to round-off).  1: always the dense kernel.  2: the caller
                               * asserts the structure (no check; wrong results if it does not hold).  A host that
-                              * rewrites a bound buffer in place with a different structure must call
-                              * rtoc_check_fxx_structure again.  Only shapes with a structured kernel (nv = 18) care. */
+                              * rewrites a BOUND buffer in place (rtoc_bind / rtoc_device_ptr: the runtime cannot see the
+                              * writes) is covered in mode 0 all the same: the quadruped shapes' register-resident kernel
+                              * verifies the structured rows of every record it factorises -- they are in its LDS anyway --
+                              * and sets RTOC_STAT_FXX_UNSTRUCTURED on an instance that breaks the shape; the iCub-size
+                              * shapes' register-wide kernel never loads those rows, so on a bound buffer the device check
+                              * runs again before every backward recursion (one pass over the top halves: ~8 % of that
+                              * recursion; rtoc_upload-ed buffers are checked once per upload).  Mode 2 switches both off. */
   RTOC_OPT_GRAPH = 9, /* 1: rtoc_riccati_sweep and rtoc_newton_iteration replay their launch sequence from a captured
                       * hipGraph (captured on the second call after any change of grid, options, buffers, rows or
                       * cones; arguments kkt_tol / tau are part of the key).  For the single-OCP latency path, whose

@@ -82,6 +82,10 @@ struct BwdArgs {
   // P+ / s+ of grid point seg_hi + 1 from the Riccati records unless that is the terminal one; in the one-stage mode above the
   // tile-split kernel does grid point blockIdx.y + seg_lo.  Zero in every other launch.
   int seg_hi, seg_lo;
+  // Structured-Fxx forms on records the runtime cannot vouch for (a bound buffer the caller may have rewritten since the last
+  // device check, RTOC_OPT_FXX_STRUCTURE = 0): the kernel verifies the rows it does NOT multiply -- it has them in LDS anyway --
+  // and raises RTOC_STAT_FXX_UNSTRUCTURED on the instance instead of returning a silently wrong factorisation.
+  int check_fxx;
 };
 
 template <int NV, int NU, int NS, int NW>

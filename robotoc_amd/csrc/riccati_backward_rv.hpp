@@ -292,6 +292,32 @@ __global__ __launch_bounds__(64, 2) void riccati_backward_rv_kernel(BwdArgs a) {
     else
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     RV_PROF(1);
+    if constexpr (SA) {
+      // ---- BwdArgs::check_fxx: do the rows this form does not multiply have the shape it assumes?  Lane j < NX owns column j of the
+      //      LDS copy of A and counts its non-zero entries in rows [NP, NV) -- at most the ONE the structure allows (a on the
+      //      diagonal, c on the diagonal of the right half: read back and compared exactly) -- and in rows [0, NP) outside the corners ----
+      if (a.check_fxx) {
+        const int j = (lane < NX) ? lane : 0;
+        const double* colp = sA + j * LDP;
+        int cnt_s = 0, cnt_c = 0;
+#pragma unroll
+        for (int i = 0; i < NV; i += 2) {
+          const d2 v = *reinterpret_cast<const d2*>(colp + i);
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            if (i + e < NP_) cnt_c += (v[e] != 0.0) ? 1 : 0;
+            else cnt_s += (v[e] != 0.0) ? 1 : 0;
+          }
+        }
+        const bool on_a = j >= NP_ && j < NV, on_c = j >= NV + NP_;
+        const double want = on_a ? sA[NP_ + NP_ * LDP] : (on_c ? sA[NP_ + (NV + NP_) * LDP] : 0.0);
+        const double got = colp[on_a ? j : (on_c ? j - NV : NP_)];   // the one entry the column may have in these rows
+        const bool corner_col = j < NP_ || (j >= NV && j < NV + NP_);
+        const int allowed = ((on_a || on_c) && got != 0.0) ? 1 : 0;
+        const bool bad = ((on_a || on_c) && got != want) || cnt_s != allowed || (!corner_col && cnt_c != 0);
+        if (lane < NX && bad) stat |= RTOC_STAT_FXX_UNSTRUCTURED;
+      }
+    }
 
     // Qxu^T of this stage -> start values of the PB^T rows (used after the factorisation, like Qxx below; loaded here, not with the
     // DMA of the record: held across the policy / switching-constraint products its registers would be spilled)

@@ -153,6 +153,8 @@ struct rtoc_ctx {
   double* buf[RTOC_NUM_BUFFERS];
   size_t count[RTOC_NUM_BUFFERS];
   bool owned[RTOC_NUM_BUFFERS];
+  bool kkt_exposed;    // rtoc_device_ptr(RTOC_BUF_KKT) was handed out: the caller can rewrite the records without the runtime seeing it
+  bool capturing;      // inside run_graphed's stream capture (nothing that synchronises may run)
   rtoc_grid* d_grid;
   rtoc_box_row* d_rows;
   rtoc_box_row* h_rows;  // host copies (stage dump)
@@ -896,7 +898,10 @@ void* rtoc_device_ptr(rtoc_ctx* c, int buffer) {
   // the zero fill of a lazily allocated buffer runs on the context's stream: it must have landed before a
   // caller writes through the pointer on a stream of its own
   if (fresh && hipStreamSynchronize(c->stream) != hipSuccess) return nullptr;
-  if (buffer == RTOC_BUF_KKT) c->fxx_state = 0;  // the caller may write through the pointer
+  if (buffer == RTOC_BUF_KKT) {
+    c->fxx_state = 0;  // the caller may write through the pointer
+    c->kkt_exposed = true;
+  }
   return c->buf[buffer];
 }
 
@@ -1075,6 +1080,8 @@ static int launch_backward_rv(rtoc_ctx* c, int first, int end, hipStream_t strea
   if (const char* e = getenv("RTOC_RV_DEBUG")) a.scan_ps_soff = atoi(e);
 #endif
   const bwd_fn kern = (ks->bwd_rv_sa && fxx_structured(c)) ? ks->bwd_rv_sa : ks->bwd_rv;   // RTOC_OPT_FXX_STRUCTURE, as for the role-split kernel
+  // a bound buffer may have been rewritten since the device check that chose the structured form: the kernel verifies as it goes
+  a.check_fxx = (kern == ks->bwd_rv_sa && c->fxx_mode == 0 && (!c->owned[RTOC_BUF_KKT] || c->kkt_exposed)) ? 1 : 0;
   if (N >= 1) hipLaunchKernelGGL(kern, dim3(nb), dim3(64), ks->bwd_rv_lds, stream, a);
   HIP_TRY(hipGetLastError());
   return RTOC_OK;
@@ -1088,7 +1095,13 @@ static bool rw_configured(const rtoc_ctx* c) {
   return c->bwd_register && c->ks->bwd_rw && c->h_grid && c->nstages >= 2 && c->nstages <= RV_MAX_STAGES && !c->writeback && !grid_has_sto(c) &&
          c->bwd_variant == ((c->ks->nvariants >= 3) ? c->ks->nvariants - 1 : 0) && (c->bwd_register >= 2 || c->batch > c->num_cus);
 }
-static bool rw_applies(rtoc_ctx* c) { return rw_configured(c) && fxx_structured(c); }
+static bool rw_applies(rtoc_ctx* c) {
+  if (!rw_configured(c)) return false;
+  // the kernel never loads the structured rows of Fxx, so it cannot verify them: on a bound buffer (the caller may have rewritten the
+  // records since the last check) the device check runs again before every recursion, unless the caller asserts the structure
+  if (c->fxx_mode == 0 && (!c->owned[RTOC_BUF_KKT] || c->kkt_exposed) && !c->capturing) c->fxx_state = 0;
+  return fxx_structured(c);
+}
 static int launch_backward_rw(rtoc_ctx* c, int first, int end, hipStream_t stream) {
   const KernelSet* ks = c->ks;
   const int N = c->nstages - 1, nb = end - first;
@@ -1462,6 +1475,7 @@ extern "C++" {
 template <class Body>
 static int run_graphed(rtoc_ctx* c, rtoc_ctx::GraphSlot* g, double p0, double p1, Body body) {
   if (!c->use_graph) return body();
+  (void)rw_applies(c);      // (bound buffers of the iCub-size shapes: the re-check of every recursion, see rw_applies)
   (void)fxx_structured(c);  // may check the records (synchronises): before, never inside, a capture
   if (g->exec && g->epoch == c->epoch && g->p0 == p0 && g->p1 == p1) {
     HIP_TRY(hipGraphLaunch(g->exec, c->stream));
@@ -1480,7 +1494,9 @@ static int run_graphed(rtoc_ctx* c, rtoc_ctx::GraphSlot* g, double p0, double p1
   }
   hipGraph_t graph = nullptr;
   HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
+  c->capturing = true;
   const int rc = body();
+  c->capturing = false;
   const hipError_t e = hipStreamEndCapture(c->stream, &graph);
   if (rc || e != hipSuccess || !graph) {
     if (graph) (void)hipGraphDestroy(graph);

@@ -19,7 +19,7 @@ CDD_FIELDS = ["dIDda", "dIDCdqv", "dCda", "IDC", "Qaa", "Qff", "Qqf", "la", "lf"
               "Phia", "lu_passive", "MJtJinv", "MJtJinv_dIDCdqv", "MJtJinv_IDC", "Qafqv",
               "Qafu_full", "laf", "Qxu_passive", "Quu_passive_topRight", "haf"]
 
-STAT_QUU_NOT_SPD, STAT_S_NOT_SPD, STAT_NAN, STAT_M_NOT_SPD = 1, 2, 4, 8
+STAT_QUU_NOT_SPD, STAT_S_NOT_SPD, STAT_NAN, STAT_M_NOT_SPD, STAT_FXX_UNSTRUCTURED = 1, 2, 4, 8, 16
 
 BUF_KKT, BUF_RIC, BUF_DIR, BUF_CDD, BUF_CON, BUF_DX0, BUF_STEP, BUF_SE3, BUF_CONE, BUF_SOL = range(10)
 SOL_FIELDS = ["q", "v", "a", "u", "f", "lmd", "gmm", "beta", "mu", "nu_passive", "xi"]

@@ -169,3 +169,62 @@ def test_register_sweep_repeats_bit_for_bit():
                 assert not bool(ne.any()), "run %d: %d words differ" % (rep, int(ne.sum()))
     finally:
         ctx.close()
+
+
+def test_register_kernel_flags_a_bound_record_rewritten_behind_the_runtime(oracle):
+    """rtoc_bind + RTOC_OPT_FXX_STRUCTURE = 0: the device check runs once after the bind; a host that then rewrites an Fxx in place (the
+    runtime cannot see it) must not get a silently wrong factorisation from the structured form -- the kernel verifies the rows it
+    does not multiply and raises RTOC_STAT_FXX_UNSTRUCTURED on that instance; after rtoc_check_fxx_structure the dense form runs."""
+    import torch
+    from robotoc_amd import capi
+    from robotoc_amd.types import STAT_FXX_UNSTRUCTURED
+    dims, grids, _ = pr.config_anymal_trot()
+    batch, n = 8, len(grids)
+    ctx = capi.Context(dims, n, batch, 0)
+    try:
+        L = ctx.L
+        ctx.set_grid(grids)
+        kkt_h = pr.make_kkt_batch(L, grids, batch, mode="dynamics")
+        kkt = torch.from_numpy(kkt_h).to("cuda:0")
+        ctx.bind(BUF_KKT, kkt.data_ptr())
+        torch.cuda.synchronize()
+        ctx.riccati_backward()
+        assert (ctx.status() == 0).all() and ctx.check_fxx_structure()
+        ctx.riccati_backward()   # (the structured form, chosen by the check above)
+        assert (ctx.status() == 0).all()
+        nx, o = 2 * dims.nv, L.kkt.off[0]
+        # instance 5, grid point 17: a stray entry in a structured row of Fxx (row 9, column 30), written through torch
+        kkt[5, 17, o + 9 + 30 * nx] = 0.125
+        kkt_h[5, 17, o + 9 + 30 * nx] = 0.125
+        torch.cuda.synchronize()
+        ctx.clear_status()
+        ctx.riccati_backward()
+        st = ctx.status()
+        assert st[5] & STAT_FXX_UNSTRUCTURED and not (np.delete(st, 5) & STAT_FXX_UNSTRUCTURED).any(), st
+        # ... and a wrong diagonal value (a != the record's own a) is caught as well
+        kkt[5, 17, o + 9 + 30 * nx] = 0.0
+        kkt[2, 3, o + 10 + 10 * nx] = 0.75
+        torch.cuda.synchronize()
+        ctx.clear_status()
+        ctx.riccati_backward()
+        st = ctx.status()
+        assert st[2] & STAT_FXX_UNSTRUCTURED and not (np.delete(st, 2) & STAT_FXX_UNSTRUCTURED).any(), st
+        kkt[2, 3, o + 10 + 10 * nx] = 1.0
+        kkt[5, 17, o + 9 + 30 * nx] = 0.125
+        torch.cuda.synchronize()
+        # the caller does what the status word asks for: the check refuses the structure, the dense form reproduces the oracle
+        assert not ctx.check_fxx_structure()
+        ctx.clear_status()
+        ctx.upload(BUF_DX0, pr.make_dx0(L, batch))
+        ctx.riccati_backward()
+        ctx.riccati_forward()
+        assert (ctx.status() == 0).all()
+        ric, d = ctx.download_records(BUF_RIC, "ric"), ctx.download_records(BUF_DIR, "dir")
+        R, D = Records(L, "ric"), Records(L, "dir")
+        ric_ref, d_ref = R.zeros(batch, n), D.zeros(batch, n)
+        oracle.riccati_sweep_batch(L, grids, kkt_h.copy(), ric_ref, d_ref, dx0=pr.make_dx0(L, batch))
+        for b in range(batch):
+            compare_riccati(L, grids, ric[b], ric_ref[b], TOL, "rewritten record inst %d" % b, check_sto=False)
+            compare_direction(L, grids, d[b], d_ref[b], TOL, "rewritten record inst %d" % b)
+    finally:
+        ctx.close()

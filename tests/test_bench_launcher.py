@@ -48,6 +48,11 @@ def test_bench_two_ranks_on_one_device():
     assert r["value"] > 0 and r["config"]["per_gpu_batch"] == 64
     # the kernel times come from events inside the timed loop: they cannot exceed the step
     assert r["roofline"]["kernel_ms"] + r["roofline"]["forward_kernel_ms"] <= r["ms_per_step"] * 1.001
+    # BASELINE configs[4] both ways: the weak line above (64 per GPU) and the strong block (64 in total, 32 per GPU, gather timed)
+    assert r["scaling"] == "weak"
+    ss = r["strong_scaling"]
+    assert ss["total_instances"] == 64 and ss["per_gpu_batch"] == 32 and ss["value"] > 0
+    assert ss["backward_kernel_ms"] + ss["forward_kernel_ms"] <= ss["ms_per_step"] * 1.001
 
 
 def test_compact_line_of_a_full_record_fits_the_drivers_tail():

@@ -23,6 +23,8 @@ ric, d = z("ric"), z("dir")
 for b_, t_ in ((BUF_KKT, kkt), (BUF_DX0, dx0), (BUF_RIC, ric), (BUF_DIR, d)):
     ctx.bind(b_, t_.data_ptr())
 torch.cuda.synchronize()
+if os.environ.get("RTOC_FXX"):   # 2: the caller asserts the structure of Fxx (no in-kernel verification of a bound buffer)
+    ctx.set_fxx_structure(int(os.environ["RTOC_FXX"]))
 res = {}
 for name, on in (("role-split", 0), ("register", 2), ("role-split", 0), ("register", 2)):
     ctx.set_backward_register(on)
