@@ -53,6 +53,7 @@ struct KernelSet {
   bwd_fn bwd_sa;      // structured-Fxx form of variant 3 (role-split, 4 instances per workgroup), or nullptr
   bwd_fn bwd_rv;      // register-resident kernel, one wave per instance (riccati_backward_rv.hpp), or nullptr
   bwd_fn bwd_rv_sa;   // ... its structured-Fxx form, or nullptr
+  bwd_fn bwd_rv_sto;  // ... the structured form for grids with switching-time optimisation, or nullptr
   int bwd_rv_lds;
   bwd_fn bwd_rw;      // register-wide kernel of the iCub-size shapes, one wave per instance and SIMD (riccati_backward_rw.hpp), or nullptr
   int bwd_rw_lds;
@@ -124,7 +125,10 @@ inline KernelSet make_set() {
   if constexpr (RvCfg<NV, NU>::OK) {
     k.bwd_rv = riccati_backward_rv_kernel<NV, NU, NS, false>;
     if constexpr (NV % 16 == 2 && RvCfg<NV, NU>::T == 3 && NV - NU > 0 && NV - NU <= 8 && (NV - NU) % 2 == 0)
+    {
       k.bwd_rv_sa = riccati_backward_rv_kernel<NV, NU, NS, true>;
+      k.bwd_rv_sto = riccati_backward_rv_kernel<NV, NU, NS, true, true>;
+    }
     k.bwd_rv_lds = rv_lds_bytes<NV, NU, NS>();
   }
   if constexpr (RwCfg<NV, NU>::OK) {

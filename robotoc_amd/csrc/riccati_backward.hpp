@@ -78,9 +78,10 @@ struct BwdArgs {
   // the bundle of grid point st for the serial vector pass -- they read what the policy workgroups read (the scan's value records,
   // the KKT records), none of their output, so they need neither a launch nor an event of their own.  nullptr: no such workgroups.
   double* sto_scr;   // [batch][nstages][scan::StoScratch::STRIDE]
-  // Segment of the horizon (riccati_backward_rv.hpp): the register-resident kernel walks the grid points seg_hi .. seg_lo and takes
-  // P+ / s+ of grid point seg_hi + 1 from the Riccati records unless that is the terminal one; in the one-stage mode above the
-  // tile-split kernel does grid point blockIdx.y + seg_lo.  Zero in every other launch.
+  // Segment of the horizon: the register kernels (riccati_backward_rv.hpp, _rw.hpp) walk the grid points seg_hi .. seg_lo and take
+  // P+ / s+ of grid point seg_hi + 1 from the Riccati records unless that is the terminal one -- the quadruped kernel is launched
+  // once per horizon (seg_hi = N - 1, seg_lo = 0), the iCub one between its switching-constraint grid points; in the one-stage
+  // mode above the tile-split kernel does grid point blockIdx.y + seg_lo.  Zero in every other launch.
   int seg_hi, seg_lo;
   // Structured-Fxx forms on records the runtime cannot vouch for (a bound buffer the caller may have rewritten since the last
   // device check, RTOC_OPT_FXX_STRUCTURE = 0): the kernel verifies the rows it does NOT multiply -- it has them in LDS anyway --

@@ -26,11 +26,12 @@
 //   * new P = sym(F): upper tiles computed, diagonal tiles mirrored, lower tiles transposed through a 16 x 17 LDS scratch;
 //     P goes to HBM from the registers during the NEXT stage (coalesced through the symmetric index pair).
 //
-// Scope: grid points without switching-time terms and without a switching constraint (regular and impact grid points).  The
-// host (rtoc_capi.hip: launch_backward_range) cuts the horizon into segments [seg_hi .. seg_lo] at switching-constraint grid
-// points, which the tile-split kernel handles in its one-stage mode, P+ / s+ handed over through the Riccati records; grids
-// with switching-time optimisation, RTOC_OPT_WRITEBACK_KKT and shapes whose stacked operand does not fill its tiles
-// (RvCfg::OK) keep the role-split / tile-split kernels.  tools/rv_model.py states the lane algebra in numpy against the oracle.
+// Scope (rv_applies, rtoc_capi.hip): shapes whose stacked operand fills its tiles (RvCfg::OK: nv = 18, nu = 12), horizons of at most
+// RV_MAX_STAGES grid points, RTOC_OPT_WRITEBACK_KKT = 0, the default RTOC_OPT_BACKWARD_WAVES.  ONE launch walks the whole horizon
+// (seg_hi = N - 1, seg_lo = 0): regular, lift, impact and switching-constraint grid points (factorised Schur form, below) are all
+// the kernel's own; grids with switching-time optimisation run the STO instantiation (structured Fxx only; the phase transition
+// and the five scalars on the carried rider lanes).  Elsewhere the role-split / tile-split kernels run.  tools/rv_model.py states
+// the lane algebra in numpy against the oracle.
 #pragma once
 #include "riccati_backward.hpp"
 
@@ -67,6 +68,10 @@ constexpr int RV_MAX_STAGES = 64;   // grid points of a horizon the kernel keeps
 #define RTOC_RV_NT 0
 #endif
 // RTOC_RV_MERGE_PBT = 1: PB^T rides in the idle lanes of P+'s last column tile during the W products (see the stage loop)
+// RTOC_RV_ONE_SCRATCH = 1: the transposes at the stage end go through ONE scratch tile (six round trips instead of three)
+#ifndef RTOC_RV_ONE_SCRATCH
+#define RTOC_RV_ONE_SCRATCH 0
+#endif
 #ifndef RTOC_RV_MERGE_PBT
 #define RTOC_RV_MERGE_PBT 1
 #endif
@@ -143,7 +148,13 @@ __device__ __forceinline__ void rv_lds_sync() {
 //   F += A^T W:        the same k groups skipped / rows masked (and the corner rows only multiplied into the corner column tiles);
 //                      their part is F[k][:] += a W[k][:], F[NV + k][:] += c W[k][:] -- the same register, or two q-groups away.
 // 114 instead of 135 MFMAs in the two NX^3 products (tools/rv_model.py --dense shows the other count).
-template <int NV, int NU, int NS, bool SA>
+// STO: grids with switching-time optimisation (riccati_factorizer.cpp:93-175, brrf.cpp:48-66,94-143,160-174).  Psi+ and Phi+ ride beside
+// s+ as columns NX + 1, NX + 2 of every product the vector algebra shares with s (lanes SCOL + 1, SCOL + 2 of the last column
+// tile): W's column NX + 1 is P+ fx -> y = P+ fx + Psi+, F's columns start from hx / 0 and end as Psi / Phi, the G product's idle
+// lanes 1, 2 give Bv^T Psi+_v, Bv^T Phi+_v, H^T's columns carry +psi_u, +phi_u so that K's columns are T and W, the switching
+// constraint's columns -Phit, 0 so that M's are mt, mt_next; the five scalars are eleven dot products of those lanes; the phase
+// transition acts on the carried lanes at the stage top.  Its own instantiation: the headline kernel pays nothing for it.
+template <int NV, int NU, int NS, bool SA, bool STO = false>
 __global__ __launch_bounds__(64, 2) void riccati_backward_rv_kernel(BwdArgs a) {
   using C = RvCfg<NV, NU>;
   static_assert(C::OK, "shape does not fill the tiles of the stacked operand");
@@ -159,11 +170,22 @@ __global__ __launch_bounds__(64, 2) void riccati_backward_rv_kernel(BwdArgs a) {
   static_assert(VOFF_LX > 0 && VOFF_LU > VOFF_LX && VOFF_LX % 2 == 0 && VOFF_LU % 2 == 0, "Fx, lx, lu lie behind one another in the record");
   static_assert(KL.off[RTOC_KKT_FXX] % 2 == 0 && KL.off[RTOC_KKT_FVU] % 2 == 0 && KL.off[RTOC_KKT_QUU] % 2 == 0 && KL.off[RTOC_KKT_FX] % 2 == 0 &&
                     KL.stride % 2 == 0, "16-byte chunks");
-  constexpr int CB = C::CB, CG = C::CG, CV = (VOFF_LU + NU + 1) / 2, NCH_S = CB + CG + CV, PS = (NCH_S + 63) / 64;
+  // STO: the strip runs on through fx (FFX), hx, hu and the scalars [Qtt, Qtt_prev, h], which lie behind lu in the record
+  constexpr int VOFF_FFX = KL.off[RTOC_KKT_FFX] - KL.off[RTOC_KKT_FX], VOFF_HX = KL.off[RTOC_KKT_HX] - KL.off[RTOC_KKT_FX],
+                VOFF_HU = KL.off[RTOC_KKT_HU] - KL.off[RTOC_KKT_FX], VOFF_SCAL = KL.off[RTOC_KKT_SCAL] - KL.off[RTOC_KKT_FX];
+  static_assert(!STO || (VOFF_FFX > VOFF_LU && VOFF_HX > VOFF_FFX && VOFF_HU > VOFF_HX && VOFF_SCAL > VOFF_HU && VOFF_SCAL % 2 == 0), "fx, hx, hu, scalars behind lu");
+  static_assert(!STO || SCOL + 2 < 16, "two more rider lanes in the last column tile");
+  static_assert(!STO || SCOL >= 3, "lanes 0..2 of the G product are idle (the controls are shifted by SCOL lanes)");
+  constexpr int CB = C::CB, CG = C::CG, CV = STO ? (VOFF_SCAL + 8) / 2 : (VOFF_LU + NU + 1) / 2, NCH_S = CB + CG + CV, PS = (NCH_S + 63) / 64;
   constexpr int ST_BV = C::OFF_ST, ST_G = ST_BV + 2 * CB, ST_FX = ST_G + 2 * CG, ST_LX = ST_FX + VOFF_LX, ST_LU = ST_FX + VOFF_LU;
+  constexpr int ST_FFX = ST_FX + VOFF_FFX, ST_HX = ST_FX + VOFF_HX, ST_HU = ST_FX + VOFF_HU, ST_SCAL = ST_FX + VOFF_SCAL;
+  // STO: ONE transpose tile (the longer strip takes the other's place in the 20 KB); the switching constraint's S, Ls, Ws then live
+  // in the place of A, and the DMA of the next record waits for them on those grid points
+  constexpr int NSCR = (STO || RTOC_RV_ONE_SCRATCH) ? 1 : 2;
   constexpr int OFF_Y = ST_FX + 2 * CV, OFF_LINV = OFF_Y + C::pad8(NU * NU), OFF_SCR = OFF_LINV + C::pad8(NU), SCR_LD = 17,
-                SCR_TILE = C::pad8(16 * SCR_LD), LDS_DOUBLES = OFF_SCR + 2 * SCR_TILE;
-  static_assert(NU * NU <= 2 * SCR_TILE, "the Cholesky factor is parked in the transpose scratch");
+                SCR_TILE = C::pad8(16 * SCR_LD), LDS_DOUBLES = OFF_SCR + NSCR * SCR_TILE;
+  static_assert(NU * NU <= NSCR * SCR_TILE, "the Cholesky factor is parked in the transpose scratch");
+  static_assert(!STO || 2 * C::pad8(NX) + NX <= SCR_TILE, "s | Psi | Phi gathered in the scratch");
   // grid-point kinds of the whole horizon, one int each (type | dims << 8), behind the carve: read with a DS instruction at the stage
   // top.  (A vector load carried over the loop's back edge makes the compiler open every stage with s_waitcnt vmcnt(0), which also
   // waits for the stores the counted wait below leaves in flight; a scalar load shares its counter with the LDS traffic.)
@@ -268,7 +290,43 @@ __global__ __launch_bounds__(64, 2) void riccati_backward_rv_kernel(BwdArgs a) {
   }
   issue_dma(hi);
   int* const sGrid = reinterpret_cast<int*>(smem + OFF_GRID);
-  for (int e = lane; e < a.nstages; e += 64) sGrid[e] = a.grid[e].type | (a.grid[e].dims << 8);   // (the host keeps nstages <= RV_MAX_STAGES)
+  for (int e = lane; e < a.nstages; e += 64)   // (the host keeps nstages <= RV_MAX_STAGES)
+    sGrid[e] = (a.grid[e].type & 15) | ((a.grid[e].sto != 0) << 4) | ((a.grid[e].sto_next != 0) << 5) | (a.grid[e].dims << 8);
+  double sc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};   // STO: xi, chi, rho, eta, iota of grid point st + 1 (uniform)
+  auto phase_transition = [&](int pol, bool has_next) __attribute__((always_inline)) {
+    double* pr = a.ric + rinst + (size_t)pol * RL.stride;
+    const double xi = sc[0], chi = sc[1], rho = sc[2], eta = sc[3], iota = sc[4];
+    double isg = 0.0;
+    if (has_next) {
+      double sgm = xi - 2.0 * chi + rho;
+      const double eps = 1.4901161193847656e-08;  // sqrt(DBL_EPSILON)
+      if ((sgm * a.max_dts0) < fabs(eta - iota) || sgm < eps) sgm = fabs(sgm) + fabs(eta - iota) / a.max_dts0;
+      isg = 1.0 / sgm;
+    }
+#pragma unroll
+    for (int g = 0; g < KG; ++g) {
+      const double v = sv[g];
+      const double r1 = dpp_from_right<1>(v), r2 = dpp_from_right<2>(v), l1 = dpp_from_left<1>(v);
+      const double d = (li == SCOL) ? (r1 - r2) : (l1 - v);   // Psi+ - Phi+ as lanes SCOL and SCOL + 2 see it
+      double nv = 0.0;                                          // Psi_m = 0
+      if (li == SCOL) nv = has_next ? __builtin_fma(isg * (eta - iota), d, v) : v;
+      if (li == SCOL + 2) nv = has_next ? __builtin_fma(-isg * (xi - chi), d, l1) : l1;   // Phi_m = Psi - ...
+      sv[g] = (li >= SCOL && li <= SCOL + 2) ? nv : 0.0;
+      if (has_next && li == SCOL) pr[RL.off[RTOC_RIC_DTSDX] + 4 * g + q] = -isg * d;
+    }
+    sc[0] = 0.0, sc[1] = 0.0, sc[3] = 0.0;
+    if (has_next) {
+      if (lane0 == 0) {
+        pr[RL.off[RTOC_RIC_SCAL] + RTOC_RIC_SCAL_DTSDTS] = isg * (xi - chi);
+        pr[RL.off[RTOC_RIC_SCAL] + RTOC_RIC_SCAL_DTS0] = -isg * (eta - iota);
+      }
+      sc[2] = xi - isg * (xi - chi) * (xi - chi);
+      sc[4] = eta - isg * (xi - chi) * (eta - iota);
+    } else {
+      sc[2] = xi;
+      sc[4] = eta;
+    }
+  };
   rv_lds_sync();
 
   for (int st = hi; st >= lo; --st) {
@@ -278,10 +336,31 @@ __global__ __launch_bounds__(64, 2) void riccati_backward_rv_kernel(BwdArgs a) {
     li = lane & 15;
     q = lane >> 4;
     const int gword = __builtin_amdgcn_readfirstlane(sGrid[st]);
-    const bool impact = (gword & 0xff) == RTOC_GRID_IMPACT;
+    const bool impact = (gword & 15) == RTOC_GRID_IMPACT;
+    const bool sto = STO && ((gword >> 4) & 1), sto_next = STO && ((gword >> 5) & 1);
     const int ns = impact ? 0 : (gword >> 8);   // rtoc_grid::dims: rows of the switching constraint
     const double* kr = a.kkt + kinst + (size_t)st * KL.stride;
     double* rr = a.ric + rinst + (size_t)st * RL.stride;
+    if constexpr (STO) {
+      // ---- phase transition (riccati_factorizer.cpp:145-175; dispatch riccati_recursion.cpp:41-70) on the carried lanes: s+ at lane
+      //      SCOL, Psi+ at SCOL + 1, Phi+ at SCOL + 2 of sv, the five scalars in sc ----
+      const bool next_lift = (__builtin_amdgcn_readfirstlane(sGrid[st + 1]) & 15) == RTOC_GRID_LIFT;
+      const bool prev_sto = st > 0 && ((__builtin_amdgcn_readfirstlane(sGrid[st > 0 ? st - 1 : 0]) >> 4) & 1);
+      bool do_pt = false;
+      int pol = st;
+      if (impact) {
+        do_pt = prev_sto || sto;
+      } else if (next_lift) {
+        do_pt = sto || sto_next;
+        pol = st + 1;
+      }
+      if (do_pt) phase_transition(pol, sto_next);
+      // without a next switching time Phi+ plays no part in a control grid point (brrf.cpp:61-65, 124-128, 139-141)
+      if (!impact && !sto_next) {
+#pragma unroll
+        for (int g = 0; g < KG; ++g) sv[g] = (li == SCOL + 2) ? 0.0 : sv[g];
+      }
+    }
     RV_PROF(0);
     // everything this stage reads from LDS or was promised in registers has landed (DMA of A and the strip, Qxu^T, the grid
     // descriptor); the stores of the previous stage (K, k, s) have left too
@@ -386,7 +465,7 @@ __global__ __launch_bounds__(64, 2) void riccati_backward_rv_kernel(BwdArgs a) {
         const double v = sBv[ok ? k + li * NV : 0];
         const double av = ok ? v : 0.0;                       // Bv^T[u' = li][k]
         const double srow = dpp_from_right<SCOL>(sv[g]);      // s+[4g + q], lane SCOL -> lane 0
-        const double bv = (li == 0) ? srow : acc[g / 4][g % 4];   // PB[4g + q][u = li - SCOL]: the C layout is the B fragment
+        const double bv = (li < (STO ? 3 : 1)) ? srow : acc[g / 4][g % 4];   // PB[4g + q][u = li - SCOL]: the C layout is the B fragment
         gacc = mfma16(av, bv, gacc);
       }
 #pragma unroll
@@ -413,6 +492,7 @@ __global__ __launch_bounds__(64, 2) void riccati_backward_rv_kernel(BwdArgs a) {
 
     RV_PROF(5);
     // ================= column tile by column tile: W[:, t] = [P+; PB^T] [A | Fx][:, t], F[c][t] += A^T[c] W[:, t] ===========
+    double xd[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // STO: dot products over the state (set in the last column tile)
     double hT[T][KSU];   // H^T = Qxu^T + PB^T A (rows NX.. of W), B fragments of the policy product
     double lup[KSU];     // lu' = lu - Bv^T s+_v + PB^T Fx on lanes li == SCOL
 #pragma unroll
@@ -425,8 +505,8 @@ __global__ __launch_bounds__(64, 2) void riccati_backward_rv_kernel(BwdArgs a) {
 #pragma unroll
       for (int ks = 0; ks < KSU; ++ks) w[T - 1][RS + ks] = (impact || (t == T - 1 && li >= SCOL)) ? 0.0 : hq[t][ks];
       // B fragment of k group g: A[4g + q][16t + li]; last tile: columns >= NX are Fx (lane SCOL) and nothing
-      const double* pb_ = (t < T - 1 || li < SCOL) ? (sA + q + (16 * t + li) * LDP) : (smem + ST_FX + q);
-      const bool okb = (t < T - 1) || li <= SCOL;
+      const double* pb_ = (t < T - 1 || li < SCOL) ? (sA + q + (16 * t + li) * LDP) : (smem + ((STO && li == SCOL + 1) ? ST_FFX : ST_FX) + q);
+      const bool okb = (t < T - 1) || li <= SCOL || (STO && sto && !impact && li == SCOL + 1);   // STO: column NX + 1 is fx
       // structured form: does k group g hold a dense row of A (a corner row or a velocity row)?  is row 4g + q one?
       auto group_dense = [](int g) { return 4 * g < NP_ || 4 * g + 3 >= NV; };
       auto row_dense = [&](int g) { return 4 * g + q < NP_ || 4 * g + q >= NV; };
@@ -477,15 +557,49 @@ __global__ __launch_bounds__(64, 2) void riccati_backward_rv_kernel(BwdArgs a) {
         if (!impact) {
 #pragma unroll
           for (int ks = 0; ks < KSU; ++ks) {
-            const double luv = smem[ST_LU + 4 * ks + q];
-            lup[ks] = luv - dpp_from_left<SCOL>(bts[ks]) + w[T - 1][RS + ks];
+            if constexpr (!STO) {
+              const double luv = smem[ST_LU + 4 * ks + q];
+              lup[ks] = luv - dpp_from_left<SCOL>(bts[ks]) + w[T - 1][RS + ks];
+            } else {
+              // lane SCOL: lu' = lu - Bv^T s+_v + PB^T Fx; SCOL + 1: psi_u = hu + Bv^T Psi+_v + PB^T fx; SCOL + 2: phi_u = Bv^T Phi+_v (brrf.cpp:52-60)
+              const double seed = smem[((li == SCOL + 1) ? ST_HU : ST_LU) + 4 * ks + q];
+              const double sgn = (li == SCOL) ? -1.0 : 1.0;
+              const double v = ((li == SCOL + 2) ? 0.0 : seed) + sgn * dpp_from_left<SCOL>(bts[ks]) + w[T - 1][RS + ks];
+              lup[ks] = (li >= SCOL && li <= SCOL + 2) ? v : 0.0;
+            }
           }
         }
         // ... and column NX of F starts from -lx, so that it ends as w = A^T z - lx (brrf.cpp:87-88)
 #pragma unroll
         for (int g = 0; g < KG; ++g) {
-          const double lxv = smem[ST_LX + 4 * g + q];
-          f[g / 4][T - 1][g % 4] = __builtin_fma(-m_eq, lxv, m_lt * f[g / 4][T - 1][g % 4]);
+          if constexpr (!STO) {
+            const double lxv = smem[ST_LX + 4 * g + q];
+            f[g / 4][T - 1][g % 4] = __builtin_fma(-m_eq, lxv, m_lt * f[g / 4][T - 1][g % 4]);
+          } else {   // column NX + 1 starts from hx (psi_x = A^T y + hx, brrf.cpp:52-55), NX + 2 from zero
+            const double xv = smem[((li == SCOL + 1) ? ST_HX : ST_LX) + 4 * g + q];
+            const double cf = (li == SCOL) ? -1.0 : ((li == SCOL + 1 && sto && !impact) ? 1.0 : 0.0);
+            f[g / 4][T - 1][g % 4] = __builtin_fma(cf, xv, m_lt * f[g / 4][T - 1][g % 4]);
+          }
+        }
+        if constexpr (STO) {
+          // ---- the six dot products over the state the scalars need (brrf.cpp:110-142): on the rider lanes W now holds z (SCOL),
+          //      y = P+ fx + Psi+ (SCOL + 1), Phi+ (SCOL + 2), sv holds s+, Psi+, Phi+ ----
+          double da = 0.0, db = 0.0, dc = 0.0;
+#pragma unroll
+          for (int g = 0; g < KG; ++g) {
+            const double fxv = smem[ST_FFX + 4 * g + q], Fxv = smem[ST_FX + 4 * g + q];
+            da = __builtin_fma(fxv, w[g / 4][g % 4], da);
+            db = __builtin_fma(fxv, sv[g], db);
+            dc = __builtin_fma(Fxv, sv[g], dc);
+          }
+          da += __shfl_xor(da, 16, 64), db += __shfl_xor(db, 16, 64), dc += __shfl_xor(dc, 16, 64);
+          da += __shfl_xor(da, 32, 64), db += __shfl_xor(db, 32, 64), dc += __shfl_xor(dc, 32, 64);
+          xd[0] = readlane_d(da, SCOL);                                 // fz   = fx . z
+          xd[1] = readlane_d(da, SCOL + 1) - readlane_d(db, SCOL + 1);  // fPf  = fx . P+ fx
+          xd[2] = readlane_d(db, SCOL + 1);                             // psif = Psi+ . fx
+          xd[3] = readlane_d(dc, SCOL + 1);                             // psiF = Psi+ . Fx
+          xd[4] = readlane_d(db, SCOL + 2);                             // phif = Phi+ . fx
+          xd[5] = readlane_d(dc, SCOL + 2);                             // phiF = Phi+ . Fx
         }
       }
       RV_PROF(6 + 2 * t);
@@ -579,8 +693,21 @@ __global__ __launch_bounds__(64, 2) void riccati_backward_rv_kernel(BwdArgs a) {
     }
 
     // ---- A, Bv, Quu and the vectors of this stage have been read for the last time: the record of the next grid point ----
+    double ksc[3] = {0.0, 0.0, 0.0};   // STO: Qtt, Qtt_prev, h of this grid point (the strip is about to be overwritten)
+    double scn[5] = {0.0, 0.0, 0.0, 0.0, 0.0};   // STO: xi, chi, rho, eta, iota of THIS grid point
+    if constexpr (STO) {
+      if (sto && !impact) {
+        ksc[0] = smem[ST_SCAL + RTOC_KKT_SCAL_QTT], ksc[1] = smem[ST_SCAL + RTOC_KKT_SCAL_QTT_PREV], ksc[2] = smem[ST_SCAL + RTOC_KKT_SCAL_H];
+        // psi_x = A^T y + hx, phi_x = A^T Phi+ (brrf.cpp:52-65): columns NX + 1, NX + 2 of F before the policy terms
+#pragma unroll
+        for (int g = 0; g < KG; ++g)
+          if (li == SCOL + 1 || li == SCOL + 2) rr[((li == SCOL + 1) ? RL.off[RTOC_RIC_PSIX] : RL.off[RTOC_RIC_PHIX]) + 4 * g + q] = f[g / 4][T - 1][g % 4];
+      }
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (st > lo) {
+    // (STO form: on a switching-constraint grid point S, Ls, Ws take the place of A -- the DMA waits for that block)
+    const bool dma_late = STO && NS > 0 && ns > 0;
+    if (st > lo && !dma_late) {
       if (!RV_DBG(2)) issue_dma(st - 1);
     }
     asm volatile("" ::: "memory");
@@ -590,6 +717,7 @@ __global__ __launch_bounds__(64, 2) void riccati_backward_rv_kernel(BwdArgs a) {
     if (!impact) {
       d4 zt[T], kk[T];
       double y1[KSU], y2[KSU];
+      double scm[3] = {0.0, 0.0, 0.0};   // STO: m . Phit, mt . Phit, mt_next . Phit
 #pragma unroll
       for (int ks = 0; ks < KSU; ++ks) {
         const bool ok = li < NU;
@@ -608,7 +736,7 @@ __global__ __launch_bounds__(64, 2) void riccati_backward_rv_kernel(BwdArgs a) {
 #pragma unroll
         for (int c = 0; c < T; ++c) {
           double bv = hT[c][ks];
-          if (c == T - 1) bv = (li < SCOL) ? bv : ((li == SCOL) ? -lup[ks] : 0.0);
+          if (c == T - 1) bv = (li < SCOL) ? bv : ((li == SCOL) ? -lup[ks] : ((STO && li <= SCOL + 2) ? lup[ks] : 0.0));   // STO: +psi_u, +phi_u
           zt[c] = mfma16(y1[ks], bv, zt[c]);
         }
       d4 ys[T];
@@ -623,11 +751,13 @@ __global__ __launch_bounds__(64, 2) void riccati_backward_rv_kernel(BwdArgs a) {
           //      so the update of F (and, in its column NX, s -= Phix^T m + H k) is F -= Zh^T Zh, F += Eh^T Eh: every product runs
           //      from accumulators (tools/rv_model.py checks the identities against the oracle); LDS: S, Ls, Ws in the transpose scratch ----
           constexpr int NSK = (NS + 3) / 4;
-          static_assert(NS <= 16 && 3 * C::pad8(NS * NS) + C::pad8(NS) <= 2 * SCR_TILE, "S, Ls, Ws and 1/diag(Ls) in the transpose scratch");
-          double* const sS = scr;
-          double* const sLs = scr + C::pad8(NS * NS);
-          double* const sWs = scr + 2 * C::pad8(NS * NS);
-          double* const sLsInv = scr + 3 * C::pad8(NS * NS);
+          static_assert(NS <= 16 && (STO || 3 * C::pad8(NS * NS) + C::pad8(NS) <= 2 * SCR_TILE), "S, Ls, Ws and 1/diag(Ls) in the transpose scratch");
+          static_assert(3 * C::pad8(NS * NS) + C::pad8(NS) <= NX * LDP, "... or in the place of A");
+          double* const scb = STO ? sA : scr;   // (STO form: one scratch tile only; A is dead and the next record's DMA is held back)
+          double* const sS = scb;
+          double* const sLs = scb + C::pad8(NS * NS);
+          double* const sWs = scb + 2 * C::pad8(NS * NS);
+          double* const sLsInv = scb + 3 * C::pad8(NS * NS);
           d4 t1[T];
           {
             const double* px_ = kr + KL.off[RTOC_KKT_PHIX];
@@ -648,6 +778,10 @@ __global__ __launch_bounds__(64, 2) void riccati_backward_rv_kernel(BwdArgs a) {
                 if (c == T - 1) {
                   const double vp = pr_[okl ? l : 0];
                   v = (okl && li == SCOL) ? vp : v;
+                  if constexpr (STO) {   // column NX + 1: -Phit, so that M's column NX + 1 is mt (riccati_factorizer.cpp:117-118)
+                    const double vt = kr[KL.off[RTOC_KKT_PHIT] + (okl ? l : 0)];
+                    v = (okl && sto && li == SCOL + 1) ? -vt : v;
+                  }
                 }
                 t1[c][r] = v;
               }
@@ -718,10 +852,31 @@ __global__ __launch_bounds__(64, 2) void riccati_backward_rv_kernel(BwdArgs a) {
               const int l = q + 4 * r, x = 16 * c + li;
               if (l < ns && x < NX) rr[RL.off[RTOC_RIC_M] + l + x * NS] = mm[c][r];
               if (c == T - 1 && l < ns && li == SCOL) rr[RL.off[RTOC_RIC_MV] + l] = -mm[c][r];
+              if constexpr (STO) {   // columns NX + 1, NX + 2: mt, mt_next (:117-124)
+                if (c == T - 1 && l < ns && sto && (li == SCOL + 1 || li == SCOL + 2))
+                  rr[((li == SCOL + 1) ? RL.off[RTOC_RIC_MT] : RL.off[RTOC_RIC_MTN]) + l] = mm[c][r];
+              }
               chkm = __builtin_fma(mm[c][r], 0.0, chkm);
             }
           if (is_bad(chkm)) stat |= RTOC_STAT_NAN;
+          if constexpr (STO) {   // -m . Phit, mt . Phit, mt_next . Phit on lanes SCOL, SCOL + 1, SCOL + 2 (riccati_factorizer.cpp:137-141)
+            double dm = 0.0;
+#pragma unroll
+            for (int r = 0; r < NSK; ++r) {
+              const int l = q + 4 * r;
+              const double pt = kr[KL.off[RTOC_KKT_PHIT] + ((l < ns) ? l : 0)];
+              dm = __builtin_fma(mm[T - 1][r], (l < ns) ? pt : 0.0, dm);
+            }
+            dm += __shfl_xor(dm, 16, 64);
+            dm += __shfl_xor(dm, 32, 64);
+            scm[0] = -readlane_d(dm, SCOL), scm[1] = readlane_d(dm, SCOL + 1), scm[2] = readlane_d(dm, SCOL + 2);
+          }
         }
+      }
+      if (dma_late && st > lo) {   // (the switching constraint's scratch in the place of A has been read for the last time)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        issue_dma(st - 1);
+        asm volatile("" ::: "memory");
       }
 #pragma unroll
       for (int ks = 0; ks < KSU; ++ks)
@@ -736,9 +891,42 @@ __global__ __launch_bounds__(64, 2) void riccati_backward_rv_kernel(BwdArgs a) {
           const int u = q + 4 * r, x = 16 * c + li;
           if (x < NX && !RV_DBG(3)) rv_st(rr + RL.off[RTOC_RIC_K] + u * NX + x, kk[c][r]);
           if (c == T - 1 && li == SCOL) rr[RL.off[RTOC_RIC_KV] + u] = -kk[c][r];
-          chk = __builtin_fma((x <= NX) ? kk[c][r] : 0.0, 0.0, chk);
+          if constexpr (STO) {   // columns NX + 1, NX + 2 of K: T, W (riccati_factorizer.cpp:109-127); psi_u, phi_u beside them
+            if (c == T - 1 && sto && (li == SCOL + 1 || li == SCOL + 2)) {
+              rr[((li == SCOL + 1) ? RL.off[RTOC_RIC_T] : RL.off[RTOC_RIC_W]) + u] = kk[c][r];
+              rr[((li == SCOL + 1) ? RL.off[RTOC_RIC_PSIU] : RL.off[RTOC_RIC_PHIU]) + u] = lup[r];
+            }
+          }
+          chk = __builtin_fma((x <= NX + ((STO && sto) ? 2 : 0)) ? kk[c][r] : 0.0, 0.0, chk);
         }
       if (is_bad(chk)) stat |= RTOC_STAT_NAN;
+      if constexpr (STO) {
+        if (sto) {
+          // ---- the five dot products over the controls and the scalars xi, chi, rho, eta, iota (brrf.cpp:110-142).  Rows u = q + 4r of
+          //      the last tile of K: -k at lane SCOL, T at SCOL + 1, W at SCOL + 2; lup: lu', psi_u, phi_u at the same lanes ----
+          double d0 = 0.0, d1 = 0.0, d2_ = 0.0, d3 = 0.0;
+#pragma unroll
+          for (int r = 0; r < KSU; ++r) {
+            const double kv = kk[T - 1][r], lv = lup[r];
+            d0 = __builtin_fma(kv, lv, d0);                      // SCOL + 1: T . psi_u     SCOL + 2: W . phi_u
+            d1 = __builtin_fma(kv, dpp_from_right<1>(lv), d1);   // SCOL + 1: T . phi_u
+            d2_ = __builtin_fma(lv, dpp_from_left<1>(kv), d2_);  // SCOL + 1: psi_u . (-k)
+            d3 = __builtin_fma(lv, dpp_from_left<2>(kv), d3);    // SCOL + 2: phi_u . (-k)
+          }
+          d0 += __shfl_xor(d0, 16, 64), d1 += __shfl_xor(d1, 16, 64), d2_ += __shfl_xor(d2_, 16, 64), d3 += __shfl_xor(d3, 16, 64);
+          d0 += __shfl_xor(d0, 32, 64), d1 += __shfl_xor(d1, 32, 64), d2_ += __shfl_xor(d2_, 32, 64), d3 += __shfl_xor(d3, 32, 64);
+          const double Tpsi = readlane_d(d0, SCOL + 1), Wphi = readlane_d(d0, SCOL + 2), Tphi = readlane_d(d1, SCOL + 1);
+          const double psik = -readlane_d(d2_, SCOL + 1), phik = -readlane_d(d3, SCOL + 2);
+          const double fz = xd[0], fPf = xd[1], psif = xd[2], psiF = xd[3], phif = xd[4], phiF = xd[5];
+          scn[0] = fPf + ksc[0] + 2.0 * psif + Tpsi + sc[0] + scm[1];
+          scn[3] = -fz + ksc[2] + psiF + psik + sc[3] + scm[0];
+          if (sto_next) {
+            scn[1] = ksc[1] + phif + Tphi + sc[1] + scm[2];
+            scn[2] = Wphi + sc[2];
+            scn[4] = phiF + phik + sc[4];
+          }
+        }
+      }
       RV_PROF(13);
       // F -= K^T G K = Z Z^T (brrf.cpp:82-84); column NX: + H G^-1 lu' = - H k
 #pragma unroll
@@ -753,6 +941,22 @@ __global__ __launch_bounds__(64, 2) void riccati_backward_rv_kernel(BwdArgs a) {
     // ================= s <- column NX of F;  P <- sym(F) as nine operand tiles ==================
 #pragma unroll
     for (int g = 0; g < KG; ++g) sv[g] = (li == SCOL) ? f[g / 4][T - 1][g % 4] : 0.0;
+    if constexpr (STO) {
+      // columns NX + 1, NX + 2 of F are Psi, Phi of this grid point (brrf.cpp:98-107); on an impact grid point Psi = 0, Phi = A^T Phi+ and
+      // rho, iota pass through (:160-174); without switching-time optimisation everything is zero (riccati_factorizer.cpp:99-105)
+      const bool keep_psi = sto && !impact, keep_phi = sto && (impact || sto_next);
+#pragma unroll
+      for (int g = 0; g < KG; ++g) {
+        const double v = f[g / 4][T - 1][g % 4];
+        sv[g] = (li == SCOL + 1) ? (keep_psi ? v : 0.0) : ((li == SCOL + 2) ? (keep_phi ? v : 0.0) : sv[g]);
+      }
+      if (sto && impact) {
+        scn[2] = sc[2];
+        scn[4] = sc[4] + xd[5];
+      }
+#pragma unroll
+      for (int e = 0; e < 5; ++e) sc[e] = scn[e];
+    }
     {
       // mask of tile (c, t): rows 16c + 4r + q < NX is a property of the register (NX % 4 == 0), columns 16t + li < NX of the lane
       auto masked = [&](int c, int t, int r, double v) -> double {
@@ -763,9 +967,9 @@ __global__ __launch_bounds__(64, 2) void riccati_backward_rv_kernel(BwdArgs a) {
       // transposes in pairs through the two scratch tiles: (row q + 4r, column li) in, (row li, column q + 4r) out
       constexpr int NTR = T * (T + 1) / 2;
 #pragma unroll
-      for (int n0 = 0; n0 < NTR; n0 += 2) {
+      for (int n0 = 0; n0 < NTR; n0 += NSCR) {
 #pragma unroll
-        for (int n = n0; n < n0 + 2 && n < NTR; ++n) {
+        for (int n = n0; n < n0 + NSCR && n < NTR; ++n) {
           const int c = rv_tile_row(T, n), t = rv_tile_col(T, n);
           double* s_ = scr + (n - n0) * SCR_TILE;
 #pragma unroll
@@ -773,7 +977,7 @@ __global__ __launch_bounds__(64, 2) void riccati_backward_rv_kernel(BwdArgs a) {
         }
         rv_lds_sync();
 #pragma unroll
-        for (int n = n0; n < n0 + 2 && n < NTR; ++n) {
+        for (int n = n0; n < n0 + NSCR && n < NTR; ++n) {
           const int c = rv_tile_row(T, n), t = rv_tile_col(T, n);
           const double* s_ = scr + (n - n0) * SCR_TILE;
 #pragma unroll
@@ -797,18 +1001,35 @@ __global__ __launch_bounds__(64, 2) void riccati_backward_rv_kernel(BwdArgs a) {
     {
       static_assert(RL.off[RTOC_RIC_PSI] == RL.off[RTOC_RIC_S] + C::pad8(NX) && RL.off[RTOC_RIC_PHI] == RL.off[RTOC_RIC_PSI] + C::pad8(NX) &&
                         RL.off[RTOC_RIC_S] % 2 == 0 && NX % 2 == 0 && 2 * C::pad8(NX) + NX <= 128, "s | Psi | Phi: one strip of <= 64 chunks");
-      if (li == SCOL) {
-#pragma unroll
-        for (int g = 0; g < KG; ++g) scr[4 * g + q] = sv[g];
-      }
       double zero = 0.0;
       asm volatile("" : "+v"(zero));   // (materialised here: hoisted out of the loop the constant gets spilled and RELOADED -- a scratch load and a full wait)
-      if (lane < 5) rr[RL.off[RTOC_RIC_SCAL] + lane] = zero;
-      rv_lds_sync();
-      const d2 sv2 = *reinterpret_cast<const d2*>(scr + ((2 * lane < NX) ? 2 * lane : 0));
       d2 out;
-      out.x = (2 * lane < NX) ? sv2.x : zero;
-      out.y = (2 * lane < NX) ? sv2.y : zero;
+      if constexpr (!STO) {
+        if (li == SCOL) {
+#pragma unroll
+          for (int g = 0; g < KG; ++g) scr[4 * g + q] = sv[g];
+        }
+        if (lane < 5) rr[RL.off[RTOC_RIC_SCAL] + lane] = zero;
+        rv_lds_sync();
+        const d2 sv2 = *reinterpret_cast<const d2*>(scr + ((2 * lane < NX) ? 2 * lane : 0));
+        out.x = (2 * lane < NX) ? sv2.x : zero;
+        out.y = (2 * lane < NX) ? sv2.y : zero;
+      } else {
+        // s, Psi, Phi from the lanes SCOL, SCOL + 1, SCOL + 2 into the scratch as they lie in the record (each field padded to 8)
+        if (li >= SCOL && li <= SCOL + 2) {
+#pragma unroll
+          for (int g = 0; g < KG; ++g) scr[(li - SCOL) * C::pad8(NX) + 4 * g + q] = sv[g];
+        }
+        if (lane < 5) {
+          const double v = (lane == 0) ? sc[0] : ((lane == 1) ? sc[1] : ((lane == 2) ? sc[2] : ((lane == 3) ? sc[3] : sc[4])));
+          rr[RL.off[RTOC_RIC_SCAL] + lane] = v;
+        }
+        rv_lds_sync();
+        const bool in = 2 * lane < 2 * C::pad8(NX) + NX && (2 * lane) % C::pad8(NX) < NX;   // (NX even: a pair never straddles a field's padding)
+        const d2 sv2 = *reinterpret_cast<const d2*>(scr + (in ? 2 * lane : 0));
+        out.x = in ? sv2.x : zero;
+        out.y = in ? sv2.y : zero;
+      }
       asm volatile("" ::: "memory");
       if (2 * lane < 2 * C::pad8(NX) + NX) *reinterpret_cast<d2*>(rr + RL.off[RTOC_RIC_S] + 2 * lane) = out;
     }
@@ -816,6 +1037,11 @@ __global__ __launch_bounds__(64, 2) void riccati_backward_rv_kernel(BwdArgs a) {
     RV_PROF(16);
   }
 
+  if constexpr (STO) {
+    // ---- grid[0].sto: the trailing phase transition writes sto_policy_[0] (riccati_recursion.cpp:75-79) ----
+    const int g0 = __builtin_amdgcn_readfirstlane(sGrid[0]);
+    if (lo == 0 && ((g0 >> 4) & 1) && ((g0 >> 5) & 1)) phase_transition(0, true);
+  }
   // ---- P of the last grid point of the segment ----
   {
     double* pw = a.ric + rinst + (size_t)lo * RL.stride + RL.off[RTOC_RIC_P];

@@ -1054,9 +1054,13 @@ static bool fxx_structured(rtoc_ctx* c) {
 }
 
 // RTOC_OPT_BACKWARD_REGISTER: the register-resident kernel (riccati_backward_rv.hpp), one launch for the whole horizon.
-static bool rv_applies(const rtoc_ctx* c) {
-  return c->bwd_register && c->ks->bwd_rv && c->h_grid && c->nstages >= 2 && c->nstages <= RV_MAX_STAGES && !c->writeback && !grid_has_sto(c) &&
-         c->bwd_variant == ((c->ks->nvariants >= 3) ? c->ks->nvariants - 1 : 0);   // (an explicit RTOC_OPT_BACKWARD_WAVES keeps its kernel)
+static bool rv_applies(rtoc_ctx* c) {
+  if (!(c->bwd_register && c->ks->bwd_rv && c->h_grid && c->nstages >= 2 && c->nstages <= RV_MAX_STAGES && !c->writeback &&
+        c->bwd_variant == ((c->ks->nvariants >= 3) ? c->ks->nvariants - 1 : 0)))   // (an explicit RTOC_OPT_BACKWARD_WAVES keeps its kernel)
+    return false;
+  // grids with switching-time optimisation: the STO instantiation, which exists in the structured-Fxx form only
+  if (grid_has_sto(c)) return c->ks->bwd_rv_sto && fxx_structured(c);
+  return true;
 }
 static int launch_backward_rv(rtoc_ctx* c, int first, int end, hipStream_t stream) {
   const KernelSet* ks = c->ks;
@@ -1079,9 +1083,10 @@ static int launch_backward_rv(rtoc_ctx* c, int first, int end, hipStream_t strea
 #ifdef RTOC_RV_DEBUG_MASK
   if (const char* e = getenv("RTOC_RV_DEBUG")) a.scan_ps_soff = atoi(e);
 #endif
-  const bwd_fn kern = (ks->bwd_rv_sa && fxx_structured(c)) ? ks->bwd_rv_sa : ks->bwd_rv;   // RTOC_OPT_FXX_STRUCTURE, as for the role-split kernel
+  const bool sto = grid_has_sto(c);
+  const bwd_fn kern = sto ? ks->bwd_rv_sto : ((ks->bwd_rv_sa && fxx_structured(c)) ? ks->bwd_rv_sa : ks->bwd_rv);   // RTOC_OPT_FXX_STRUCTURE, as for the role-split kernel
   // a bound buffer may have been rewritten since the device check that chose the structured form: the kernel verifies as it goes
-  a.check_fxx = (kern == ks->bwd_rv_sa && c->fxx_mode == 0 && (!c->owned[RTOC_BUF_KKT] || c->kkt_exposed)) ? 1 : 0;
+  a.check_fxx = (kern != ks->bwd_rv && c->fxx_mode == 0 && (!c->owned[RTOC_BUF_KKT] || c->kkt_exposed)) ? 1 : 0;
   if (N >= 1) hipLaunchKernelGGL(kern, dim3(nb), dim3(64), ks->bwd_rv_lds, stream, a);
   HIP_TRY(hipGetLastError());
   return RTOC_OK;
