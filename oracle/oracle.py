@@ -18,7 +18,8 @@ _LIB = None
 
 def build(force=False):
     so = os.path.join(_HERE, "librtoc_oracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("rtoc_oracle.c", "rtoc_oracle_condense.c", "rtoc_oracle_bench.c", "rtoc_oracle_rbd.c", "rtoc_oracle_rbd_cs.c")]
+    srcs = [os.path.join(_HERE, f) for f in ("rtoc_oracle.c", "rtoc_oracle_condense.c", "rtoc_oracle_bench.c", "rtoc_oracle_rbd.c", "rtoc_oracle_rbd_cs.c",
+                                              "rtoc_oracle_aba.c", "rtoc_oracle_aba_cs.c")]
     srcs += [os.path.join(_HERE, "..", "include", f) for f in ("rtoc.h", "rtoc_layout.h", "rtoc_robot.h")]
     stale = force or not os.path.exists(so) or any(
         os.path.getmtime(s) > os.path.getmtime(so) for s in srcs if os.path.exists(s))
@@ -28,7 +29,8 @@ def build(force=False):
     return so
 
 
-_SRCS = ("rtoc_oracle.c", "rtoc_oracle_condense.c", "rtoc_oracle_bench.c", "rtoc_oracle_rbd.c", "rtoc_oracle_rbd_cs.c")
+_SRCS = ("rtoc_oracle.c", "rtoc_oracle_condense.c", "rtoc_oracle_bench.c", "rtoc_oracle_rbd.c", "rtoc_oracle_rbd_cs.c", "rtoc_oracle_aba.c",
+         "rtoc_oracle_aba_cs.c")
 _NATIVE = None
 
 
@@ -407,6 +409,9 @@ def _rbd():
         L.orc_rbd_momentum_world.argtypes = [mp, dp, dp, dp]
         L.orc_rbd_contact_position.argtypes = [mp, dp, C.c_int, dp]
         L.orc_rbd_contact_placement.argtypes = [mp, dp, C.c_int, dp, dp]
+        L.orc_aba_forward_dynamics.argtypes = [mp, dp, dp, dp, dp, C.c_uint, dp]
+        L.orc_aba_crba.argtypes = [mp, dp, dp]
+        L.orc_aba_linearize_cs.argtypes = [mp, dp, dp, dp, dp, C.c_int, C.c_uint, dp, dp]
         L._rbd_ready = True
     return L
 
@@ -455,6 +460,30 @@ def rbd_linearize_cs(model, impact, q, v, a, fstack, u, active, pref, rref=None)
     _rbd().orc_rbd_linearize_cs(C.byref(model), int(impact), _d(q), _d(v), _d(a), _d(fstack), int(fstack.size), _d(u), int(u.size),
                                 int(active), _d(pref), _d(rr) if rr is not None else None, _d(D[0]), _d(D[1]), _d(D[2]), n)
     return tuple(d.T.copy() for d in D)
+
+
+# ---- the second formulation (rtoc_oracle_aba.c: articulated-body algorithm + composite-rigid-body algorithm in world coordinates) ----
+def aba_forward_dynamics(model, q, v, tau, fstack, active):
+    """a = FD(q, v, tau, f_ext): pinocchio::aba restated in world coordinates; tau [nv] generalised forces, fstack / active as rbd_eval."""
+    q, v, tau, fstack = _c(q), _c(v), _c(tau), _c(fstack)
+    a = np.zeros(model.nv)
+    _rbd().orc_aba_forward_dynamics(C.byref(model), _d(q), _d(v), _d(tau), _d(fstack), int(active), _d(a))
+    return a
+
+
+def aba_crba(model, q):
+    q = _c(q)
+    M = np.zeros((model.nv, model.nv))
+    _rbd().orc_aba_crba(C.byref(model), _d(q), _d(M))
+    return M.T.copy()
+
+
+def aba_linearize_cs(model, q, v, tau, fstack, active):
+    """(dFD/dq, dFD/dv) [nv x nv] of aba_forward_dynamics by the complex step (rtoc_oracle_aba_cs.c), q on the manifold."""
+    q, v, tau, fstack = _c(q), _c(v), _c(tau), _c(fstack)
+    D = [np.zeros((model.nv, model.nv)) for _ in range(2)]
+    _rbd().orc_aba_linearize_cs(C.byref(model), _d(q), _d(v), _d(tau), _d(fstack), int(fstack.size), int(active), _d(D[0]), _d(D[1]))
+    return D[0].T.copy(), D[1].T.copy()
 
 
 def rbd_log6(R, p):
