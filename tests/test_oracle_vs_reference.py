@@ -270,3 +270,48 @@ def test_sto_scatter_and_kkt_term_match_the_reference_sources(oracle):
             worst = max(worst, abs(err - term) / max(term, 1.0))
             assert abs(err - term) <= 1e-12 * max(perf[0], 1.0), (name, err, term)
     print("STO scatter identical; Hamiltonian KKT term vs the reference sources: %.1e" % worst)
+
+
+def test_the_thin_margin_of_the_ill_conditioned_jump_is_a_cancellation_in_the_multiplier_direction(oracle):
+    """on anymal_jump_sto / factory the restatement sits at 8.3e-7 of a 1e-6 tolerance against the reference's own
+    sources, in `direction`.  Which term?  Not a re-ordered sum of the STO recursion: every Riccati field of that instance agrees to
+    <= 1.2e-8 (P 2e-10, T 6e-10, the five scalars 7e-9, dtsdx 1.1e-8) and dx, du, dlmdgmm, dts to <= 5e-8.  The whole margin is ONE
+    entry: dxi of the switching-constraint grid point, computeLagrangeMultiplierDirection (riccati_factorizer.cpp:265-277)
+
+        dxi = (M dx + m) + mt (dts_next - dts),
+
+    where on this (uniform-random, kkt_factory.cpp-style) data |mt| = 2e6: the two brackets are ~2e5 each and cancel to ~1e2.  The
+    amplification |mt (dts_next - dts)| / |dxi| ~ 1.7e3 times the 5e-10 the two sides differ in mt IS the 8.3e-7.  Asserted here:
+    the two brackets agree separately to 5e-8 of their own size (1.5e-8 observed: dts itself carries 4e-8); the cancellation factor exceeds 1e3; the dxi discrepancy is inside
+    factor x that agreement."""
+    dims, grids, _ = pr.config_anymal_jump_sto()
+    L = oracle.layout(dims)
+    kkt = pr.make_kkt_batch(L, grids, 1, mode="factory", first_instance=0)[0]
+    dx0 = pr.make_dx0(L, 1, first_instance=0)[0]
+    (r0, d0, _), (r1, d1, _) = _sweep_both(oracle, L, grids, kkt, dx0, 3)
+    R, D = Records(L, "ric"), Records(L, "dir")
+    sc = [i for i, g in enumerate(grids) if g.type != 1 and g.dims > 0]
+    assert len(sc) == 1
+    i, ns = sc[0], grids[sc[0]].dims
+    worst_other = 0.0
+    for f in ("dx", "du", "dlmdgmm", "dts"):
+        for k in range(len(grids)):
+            a, b = D.f(d0[k], f), D.f(d1[k], f)
+            worst_other = max(worst_other, np.abs(a - b).max() / max(np.abs(b).max(), 1e-300) if np.abs(b).max() > 0 else 0.0)
+    assert worst_other < 1e-7, worst_other
+
+    def brackets(r, d):
+        dx, dts = D.f(d[i], "dx"), D.f(d[i], "dts")
+        first = R.f(r[i], "M")[:ns] @ dx + R.f(r[i], "m")[:ns]
+        second = R.f(r[i], "mt")[:ns] * (dts[1] - dts[0])
+        if grids[i].sto_next:
+            second = second - R.f(r[i], "mt_next")[:ns] * dts[1]
+        return first, second
+    (a0, b0), (a1, b1) = brackets(r0, d0), brackets(r1, d1)
+    dxi0, dxi1 = D.f(d0[i], "dxi")[:ns], D.f(d1[i], "dxi")[:ns]
+    assert np.abs(a1 + b1 - dxi1).max() < 1e-9 * np.abs(b1).max()          # the decomposition is the reference's dxi
+    agree = max(np.abs(a0 - a1).max() / np.abs(a1).max(), np.abs(b0 - b1).max() / np.abs(b1).max())
+    factor = np.abs(b1).max() / np.abs(dxi1).max()
+    err = np.abs(dxi0 - dxi1).max() / np.abs(dxi1).max()
+    print("brackets agree to %.1e of their size, cancellation factor %.1e, dxi discrepancy %.1e" % (agree, factor, err))
+    assert agree < 5e-8 and factor > 1e3 and err < 2.0 * factor * agree
