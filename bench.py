@@ -26,7 +26,7 @@ if ROOT not in sys.path:
 PER_GPU_BATCH = 4096
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 F64_MFMA_PEAK_TFLOPS = 78.6  # MI355X spec sheet, dense fp64 matrix (= the fp64 vector rate)
-PROFILE_ROUND = "r05"
+PROFILE_ROUND = "r06"
 
 
 def kernel_source_hash():
@@ -1128,7 +1128,7 @@ def main():
                "condense_register": {"register_ms": min(reg_ms["register"]) if reg_ms["register"] else None,
                                      "role_split_ms": min(reg_ms["role_split"]) if reg_ms["role_split"] else None,
                                      "note": "RTOC_OPT_CONDENSE_REGISTER = 1 | 0 timed alternately in one loop (the second timing in a process runs at a "
-                                             "higher clock); profiles/r05_condense_register.txt has the same with and without rows"},
+                                             "higher clock); profiles/r06_condense_register.txt has the same with and without rows"},
                "single_instance": sqp_single_instance(dims, grids, local_rank) if rank == 0 else None,
                "status_nonzero_instances": bad_sqp,
                "scope": "hot path downstream of the Pinocchio linearisation: KKT error, PDIPM condensation of the "

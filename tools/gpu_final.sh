@@ -8,7 +8,7 @@
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out
-TAG=${1:-r05}
+TAG=${1:-r06}
 mkdir -p $OUT
 cd $R
 SKIP_PMC=1 bash tools/gpu_round2.sh > $OUT/round.log 2>&1

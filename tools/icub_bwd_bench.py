@@ -1,4 +1,5 @@
-"""Backward-kernel timing of the iCub configurations (1024 instances) for every wave count compiled in."""
+"""Backward-kernel timing of the iCub configurations (1024 instances): the default dispatch (nv = 32: the register-wide kernel,
+riccati_backward_rw.hpp; nv = 35: the tile-split kernel) and the tile-split kernel at every wave count compiled in."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -17,6 +18,9 @@ for nv, waves in ((32, (4,)), (35, (5, 4))):
     ctx.set_grid(grids)
     ctx.upload(BUF_KKT, tile(pr.make_kkt_batch_unique(L, grids, 16, seed=7), batch))
     ctx.upload(BUF_DX0, tile(pr.make_dx0_unique(L, 16, seed=7), batch))
+    ctx.time_phase(0, 3)
+    print("iCub nv=%d, default dispatch: backward %.3f ms / %d instances (min of 5 x 3 launches), status nonzero %d" % (
+        nv, min(ctx.time_phase(0, 3) for _ in range(5)), batch, int((ctx.status() != 0).sum())))
     for w in waves:
         ctx.set_backward_waves(w)
         ctx.time_phase(0, 1)

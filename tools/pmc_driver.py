@@ -98,7 +98,19 @@ def main():
         ctx.linearize_contact_dynamics(True)
     ctx.sync()
     ctx.close()
-    # ---- iCub nv=32 / nv=35, 1024 instances: backward + forward, condense + expand ----
+    # ---- ANYmal jump with switching-time optimisation, 4096 instances: the STO instantiation of the register-resident kernel ----
+    dims, grids, _ = pr.config_anymal_jump_sto()
+    batch = 4096
+    ctx = capi.Context(dims, len(grids), batch, 0)
+    ctx.set_grid(grids)
+    ctx.upload(BUF_KKT, tile(pr.make_kkt_batch_unique(ctx.L, grids, uniq, seed=7), batch))
+    ctx.upload(BUF_DX0, tile(pr.make_dx0_unique(ctx.L, uniq, seed=7), batch))
+    for _ in range(reps):
+        ctx.riccati_backward()
+        ctx.riccati_forward()
+    assert (ctx.status() == 0).all()
+    ctx.close()
+    # ---- iCub nv=32 / nv=35, 1024 instances: backward + forward, condense + expand (nv = 32: the register-wide backward kernel) ----
     for nv in (32, 35):
         dims, grids, _ = pr.config_icub_jump(nv=nv)
         dims = icub_dims(dims.nv, nc_max=(6 * dims.nu + 34 + 7) & ~7)   # room for the joint-limit and wrench-cone rows (as bench.py)
