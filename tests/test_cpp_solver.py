@@ -329,9 +329,13 @@ def test_ocp_solver_jump_with_switching_time_optimisation_on_the_device(tmp_path
     iters, conv, err, nref, first_ref, ts_cpp, hist_cpp = int(raw[0]), raw[1], raw[2], int(raw[3]), int(raw[4]), raw[5:7], raw[7:]
     assert conv == 1.0 and err < 1e-7
     assert nref == len(st.mesh_refinement_iter) >= 1 and first_ref == st.mesh_refinement_iter[0]
-    # up to the first mesh refinement both shells issue the same launches on the same data: bit-identical KKT errors; behind it
-    # the interpolated warm start agrees to rounding, so the paths stay together (same iteration count, same switching times)
-    assert np.array_equal(hist_cpp[:first_ref], hist[:first_ref])
+    # up to the first mesh refinement both shells issue the same launches on the same data: the iterates are bit-identical, and so
+    # are the KKT errors up to the LAST rounding of how each shell assembles them -- the Python shell takes sqrt(dms + sto) from the
+    # device, the C++ shell squares the device's sqrt(dms) again before it adds the STO term (PerformanceIndex keeps squares): one ulp
+    # at some iterations, none at the next (round 6: iterations 5 and 7 of 12; that the neighbours agree bit for bit IS the evidence
+    # that the iterates do).  Behind the refinement the interpolated warm start agrees to rounding, so the paths stay together.
+    rel = np.abs(hist_cpp[:first_ref] - hist[:first_ref]) / hist[:first_ref]
+    assert rel.max() <= 4 * np.finfo(float).eps and (rel == 0.0).sum() >= first_ref // 2, rel
     assert abs(iters - st.iter) <= 1
     assert np.abs(ts_cpp - ts_py).max() < 1e-6, (ts_cpp, ts_py)
 

@@ -1,7 +1,5 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-for s in 0 127 254 0 127 64 381; do
-RTOC_RV_STAGGER=$s python tools/rv_bench.py 4096 trot 2>&1 | grep "register\|worst" | sed "s/^/stagger $s: /"
-done > gpurun_out/stagger.log
-cat gpurun_out/stagger.log
+python -m pytest tests -m gpu -q 2>&1 | grep -v amdgpu.ids | tail -40 > gpurun_out/pytest_gpu_full.log
+grep -n "FAILED\|passed\|failed\|ERROR" gpurun_out/pytest_gpu_full.log

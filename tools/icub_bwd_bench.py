@@ -21,6 +21,7 @@ for nv, waves in ((32, (4,)), (35, (5, 4))):
     ctx.time_phase(0, 3)
     print("iCub nv=%d, default dispatch: backward %.3f ms / %d instances (min of 5 x 3 launches), status nonzero %d" % (
         nv, min(ctx.time_phase(0, 3) for _ in range(5)), batch, int((ctx.status() != 0).sum())))
+    ctx.set_backward_register(0)   # the tile-split kernel at every wave count compiled in
     for w in waves:
         ctx.set_backward_waves(w)
         ctx.time_phase(0, 1)
