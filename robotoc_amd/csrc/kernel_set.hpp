@@ -16,6 +16,7 @@
 #include "riccati_backward_rs.hpp"
 #include "riccati_backward_rv.hpp"
 #include "riccati_backward_rw.hpp"
+#include "riccati_backward_rw2.hpp"
 #include "condense_rv.hpp"
 #include "riccati_scan.hpp"
 #include "riccati_forward.hpp"
@@ -57,6 +58,7 @@ struct KernelSet {
   int bwd_rv_lds;
   bwd_fn bwd_rw;      // register-wide kernel of the iCub-size shapes, one wave per instance and SIMD (riccati_backward_rw.hpp), or nullptr
   int bwd_rw_lds;
+  int bwd_rw_threads;  // 64: riccati_backward_rw_kernel (T = 4), 128: riccati_backward_rw2_kernel (T = 5, two waves per instance)
   rtoc_record_layout kl, rl, dl, cl;  // record layouts the kernels were compiled for
   fwd_fn fwd;
   int fwd_threads;
@@ -134,6 +136,11 @@ inline KernelSet make_set() {
   if constexpr (RwCfg<NV, NU>::OK) {
     k.bwd_rw = riccati_backward_rw_kernel<NV, NU, NS>;
     k.bwd_rw_lds = RwLds<NV, NU, NS>::BYTES;
+    k.bwd_rw_threads = 64;
+  } else if constexpr (RwCfg<NV, NU>::OK2) {
+    k.bwd_rw = riccati_backward_rw2_kernel<NV, NU, NS>;
+    k.bwd_rw_lds = Rw2Lds<NV, NU, NS>::BYTES;
+    k.bwd_rw_threads = 128;
   }
   constexpr int NWF = (2 * NV + NU + 63) / 64;
   if constexpr (NWF == 1)

@@ -1,117 +1,104 @@
-// riccati_backward_rw.hpp -- register-resident backward Riccati recursion of the iCub-size shapes (nx = 64 / 70): ONE wavefront
-// per OCP instance with the whole 512-entry register file of its SIMD (VGPR + AGPR, one wave per SIMD, four instances per CU).
+// riccati_backward_rw2.hpp -- the register-wide backward kernel (riccati_backward_rw.hpp) for T = 5 state tiles (iCub nv = 35,
+// nx = 70): TWO wavefronts per OCP instance, each with the whole register file of a SIMD, two instances per CU.
 //
-// Same recursion and HBM record contract as riccati_backward.hpp (reference: src/riccati/riccati_recursion.cpp:32-80,
-// riccati_factorizer.cpp:44-56,178-197, backward_riccati_recursion_factorizer.cpp:31-91); the machine mapping is the one of
-// riccati_backward_rv.hpp carried to T = 4 / 5 state tiles, where the stacked operand [P+; PB^T] no longer fills its tiles and
-// no state column is free for the riders:
+// One wave cannot hold P+ (25 tiles) AND F (15 upper tiles): 320 of 512 registers before the first operand, and the compiler spills
+// 540 (6.7 ms per 1024 instances against the tile-split kernel's 4.8).  What does fit is P+ (200) + HALF of F + one column of W.  So
+// both waves keep the WHOLE value function and run the O(n^2 nu) part of the stage side by side, redundantly and without a word
+// between them -- z, PB, G, the 29 x 29 factorisation, H, Z^T: the same lane algebra as riccati_backward_rw.hpp, which
+// tests/rw_lane_model.py verifies for this shape --, and SPLIT the O(n^3) part: wave 0 owns the column tiles {0, 1, 2} of F, wave 1
+// {3, 4} (6 and 9 upper tiles: 252 and 228 MFMAs in the column loop), each its tiles of K, Z Z^T, the Qxx start values and the rows
+// of P it stores.  At the stage end the fifteen tiles of F meet in LDS -- in the place of A, which is dead by then -- and each wave
+// rebuilds its own copy of P+ = sym(F) from there (direct and transposed reads).  Four workgroup barriers per stage.
+// Shared LDS: the dense rows of A / the F exchange, the strip, the grid table; per wave: s+, G / Y / scratch / vectors (the landing
+// zone of its Qxx panels).  75 KB per instance.
 //
-//   * P+ lives in T x T accumulator tiles in the f64 MFMA C layout (lane (li, q), register r <-> row q + 4r, column li);
-//     for a symmetric matrix that layout IS the A fragment (and the B fragment) of the products P+ [.]: no LDS copy of P+.
-//   * Fxx is taken in its STRUCTURED form (src/dynamics/state_equation.cpp:52-55,80-82, checked on the device by
-//     fxx_structure_kernel before the kernel is chosen): rows [NP, NV) are a e_k^T | c e_k^T.  Only the k groups that hold a
-//     dense row -- the NP corner rows and the NV velocity rows -- are staged in LDS (21.5 of 32 KB at nv = 32: that is what
-//     lets FOUR instances share a CU) and multiplied on the matrix cores; the structured rows are scaled copies of P+ / W tiles
-//     in place, TS tiles and LS lanes (rows) away (NV = 16 TS + LS; nv = 32: LS = 0).
-//   * PB = P+[:, v] Bv stays in accumulators: as B fragment of G = Quu + Bv^T PB[v, :] and of H = A^T PB, and its idle column NU
-//     carries z = s+ - P+ Fx through both: column NU of G is Bv^T z_v (-> lu'), column NU of H is A^T z (-> s).
-//   * H is produced rows = state (the structured rows of A^T [.] are row copies there) and transposed tile by tile through a
-//     16 x 17 LDS scratch, Qxu^T added on the way (li along the contiguous index of Qxu): H^T is the B fragment of Z^T = Y H^T.
-//   * LLT(G), Y = L^-1 by wave_llt_inv_blocked (16 + (NU - 16) columns, trailing update on the matrix cores);
-//     K = -Y^T Z^T tile by tile to HBM; F = Qxx - Z Z^T + A^T (P+ A) column tile by column tile; P = sym(F).
-//   * z, A^T z, lu', t = Y lu', k = -Y^T t and s = A^T z - lx + Z t are vectors in LDS / per-lane partial sums with a q-reduction
-//     (no free column for riders at nx = 64).
-//   * Record traffic: the dense k groups of A and the strip Fx | lx | lu by LDS-DMA; Bv, Quu, Qxu^T, Qxx by per-lane loads
-//     straight into operand / accumulator registers.
-//
-// Scope (rw_applies, rtoc_capi.hip): grids without switching-time optimisation; switching-constraint grid points are single
-// launches of the tile-split kernel (its one-stage mode), P+ / s+ handed over through the Riccati records -- the host cuts the
-// horizon into segments [seg_hi .. seg_lo]; structured Fxx; RTOC_OPT_WRITEBACK_KKT = 0.  tests/rw_lane_model.py states the lane
-// algebra in numpy against the oracle (tests/test_rw_lane_model.py).
+// Same scope as riccati_backward_rw.hpp (rw_applies, rtoc_capi.hip): structured Fxx, no switching-time optimisation, switching-
+// constraint grid points as one-stage launches of the tile-split kernel, batches larger than the device's CU count.
 #pragma once
-#include "riccati_backward_rv.hpp"
+#include "riccati_backward_rw.hpp"
 
 namespace rtoc {
 
-template <int NV, int NU>
-struct RwCfg {
-  static constexpr int NX = 2 * NV, NP = NV - NU;
-  static constexpr int T = (NX + 15) / 16, TU = (NU + 15) / 16;
-  static constexpr int KG = (NX + 3) / 4, KGU = (NU + 3) / 4;
-  static constexpr int G0 = NV / 4;                 // first aligned k group that meets the velocity rows [NV, NX)
-  static constexpr int G1 = (NP + 3) / 4;           // k groups [0, G1) meet the corner rows [0, NP)
-  static constexpr int NDG = G1 + KG - G0;          // k groups with a dense row of A (staged in LDS)
-  static constexpr int NUC = NU - 16 * (TU - 1);    // lane of the rider column NU in the last control tile
-  static constexpr int TS = NV / 16, LS = NV % 16, QS = LS % 4, RS = LS / 4;
-  static constexpr int LDA = lds_ld(4 * NDG), HL = LDA / 2;
-  // T = 4 only: at T = 5 (nx = 70) P+ and F alone are 40 tiles = 320 registers and the compiler spills 540 of them -- measured 6.7 ms
-  // per 1024 against the tile-split kernel's 4.8; the code below is written for general T (tests/rw_lane_model.py checks the lane
-  // algebra of both shapes); T = 5 runs the two-wave form, riccati_backward_rw2.hpp
-  static constexpr bool SHAPE_OK = (TU == 2) && (NU > 16) && (NU < 32) && (NP > 0) && (G1 < G0) && (NX % 2 == 0) && (NUC > 0) && (NUC < 16);
-  static constexpr bool OK = (T == 4) && SHAPE_OK;    // one wave per instance (this file)
-  static constexpr bool OK2 = (T == 5) && SHAPE_OK;   // two waves per instance (riccati_backward_rw2.hpp)
-  static constexpr int cg(int g) { return g < G1 ? g : g - G0 + G1; }   // compact index of the dense k group g
-  static constexpr int pad8(int n) { return (n + 7) & ~7; }
-  static constexpr int SCR_LD = 17, SCR_TILE = pad8(16 * SCR_LD);
-};
-
 template <int NV, int NU, int NS>
-struct RwLds {
+struct Rw2Lds {
   using C = RwCfg<NV, NU>;
   static constexpr rtoc_layout SL = StaticLayout<NV, NU, NS>::make();
   static constexpr int VOFF_LX = SL.kkt.off[RTOC_KKT_LX] - SL.kkt.off[RTOC_KKT_FX], VOFF_LU = SL.kkt.off[RTOC_KKT_LU] - SL.kkt.off[RTOC_KKT_FX];
   static constexpr int CV = (VOFF_LU + NU + 1) / 2, PS = (CV + 63) / 64;   // 16-byte chunks / DMA pieces of the strip Fx | lx | lu
-  static constexpr int OFF_A = 0;
-  static constexpr int OFF_ST = C::NX * C::LDA;
-  static constexpr int OFF_S = OFF_ST + C::pad8(2 * CV);         // s+ (the last strip piece is partial: the strip takes 2 CV doubles)
-  // ---- the landing zone of the Qxx panels: everything from here to the grid table is dead between the policy products and the
-  //      transposes at the stage end ----
-  static constexpr int OFF_G = OFF_S + C::pad8(C::NX);           // Quu (by DMA) -> G, factorised in place (L)
-  static constexpr int OFF_Y = OFF_G + C::pad8(NU * NU);
-  static constexpr int OFF_LINV = OFF_Y + C::pad8(NU * NU);
-  static constexpr int OFF_SCR = OFF_LINV + C::pad8(NU);         // two transpose tiles; the Cholesky's 256-double scratch
-  static constexpr int OFF_Z = OFF_SCR + 2 * C::SCR_TILE;
-  static constexpr int OFF_W0 = OFF_Z + C::pad8(C::NX);
-  static constexpr int OFF_LUP = OFF_W0 + C::pad8(C::NX);
-  static constexpr int OFF_T = OFF_LUP + C::pad8(NU);
-  static constexpr int OFF_GRID = OFF_T + C::pad8(NU);           // grid-point kinds of the horizon (ints)
-  static constexpr int LDQ = lds_ld(C::NX), PANEL = 16 * LDQ;    // one column tile of Qxx (16 columns, padded: conflict-free both ways)
-  static constexpr int OFF_Q = OFF_G;
-  static_assert(OFF_Q + 2 * PANEL <= OFF_GRID, "two Qxx panels in the dead zone");
-  static constexpr int DOUBLES = OFF_GRID + RV_MAX_STAGES / 2;
+  static constexpr int NTR = C::T * (C::T + 1) / 2;                          // upper tiles of F
+  // ---- shared by the two waves ----
+  static constexpr int OFF_A = 0;                                            // the dense rows of A; at the stage end: the fifteen tiles of F
+  static constexpr int SH_A = (C::NX * C::LDA > NTR * C::SCR_TILE) ? C::NX * C::LDA : NTR * C::SCR_TILE;
+  static constexpr int OFF_ST = SH_A;
+  static constexpr int STRIP = C::pad8(2 * CV);                              // TWO strips, by the parity of the grid point: the next one's is
+  static constexpr int OFF_GRID = OFF_ST + 2 * STRIP;                        // requested at the stage top.  Behind them: grid-point kinds (ints)
+  static constexpr int OFF_BV = OFF_GRID + RV_MAX_STAGES / 2;                // Fvu, flat as in the record (NV x NU, by DMA)
+  static constexpr int OFF_PW = OFF_BV + C::pad8(NV * NU + 1);
+  // ---- per wave (offsets inside its block) ----
+  static constexpr int P_S = 0;                                              // s+
+  static constexpr int P_G = P_S + C::pad8(C::NX);                           // Quu (by DMA) -> G, factorised in place; from here on: the Qxx panels' zone
+  static constexpr int P_Y = P_G + C::pad8(NU * NU);
+  static constexpr int P_LINV = P_Y + C::pad8(NU * NU);
+  static constexpr int P_SCR = P_LINV + C::pad8(NU);
+  static constexpr int NSCR = 1;                                             // transpose tiles of a wave (the Cholesky's 256 doubles fit one)
+  static constexpr int P_Z = P_SCR + NSCR * C::SCR_TILE;
+  static constexpr int P_W0 = P_Z + C::pad8(C::NX);
+  static constexpr int P_LUP = P_W0 + C::pad8(C::NX);
+  static constexpr int P_T = P_LUP + C::pad8(NU);
+  static constexpr int LDQ_ = lds_ld(C::NX);
+  static constexpr int PWD = (P_T + C::pad8(NU) > P_G + 2 * 16 * LDQ_) ? P_T + C::pad8(NU) : P_G + 2 * 16 * LDQ_;   // (room for two Qxx panels)
+  static constexpr int LDQ = lds_ld(C::NX), PANEL = 16 * LDQ;
+  static constexpr int P_Q = P_G;
+  static_assert(P_Q + 2 * PANEL <= PWD, "two Qxx panels in a wave's dead zone");
+  static constexpr int DOUBLES = OFF_PW + 2 * PWD;
   static constexpr int BYTES = DOUBLES * 8;
-  static_assert(2 * C::SCR_TILE >= 256, "the blocked Cholesky's scratch");
+  static_assert(BYTES <= 80 * 1024, "two instances per CU");
+  static_assert(PS * 128 <= STRIP + 128, "the last DMA piece of a strip is partial");
+  static_assert(NSCR * C::SCR_TILE >= 256, "the blocked Cholesky's scratch");
 };
 
-template <int NV, int NU, int NS>
-__global__ __launch_bounds__(64, 1) void riccati_backward_rw_kernel(BwdArgs a) {
+// cycle stamps of instance 0 (tools/phase_profile_rv.py; make PROF=1): wave 0 in slots 0..15, wave 1 in 16..31 of its stage's row
+#ifdef RTOC_ENABLE_PROF
+#define RW2_PROF(k) do { if (a.prof && b == 0 && lane0 == 0) a.prof[st * 32 + (k) + 16 * W] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define RW2_PROF(k) do { } while (0)
+#endif
+
+// the wave-uniform barrier of the two waves of an instance (their own LDS traffic first)
+__device__ __forceinline__ void rw2_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// W: which of the two waves of the instance this is (compile-time: each wave's register arrays are sized for its own share)
+template <int NV, int NU, int NS, int W>
+__device__ __forceinline__ void rw2_body(BwdArgs a) {
   using C = RwCfg<NV, NU>;
-  using M = RwLds<NV, NU, NS>;
-  static_assert(C::OK, "shape outside the register-wide kernel's tiling");
+  using M = Rw2Lds<NV, NU, NS>;
+  static_assert(C::T == 5 || C::T == 4, "column tiles {0 .. (T-1)/2} | the rest");
+  // column tiles of F (and of K, and row tiles of the P stores) this wave owns
+  constexpr int TSPLIT = (C::T - 1) / 2;   // T = 5: wave 0 owns {0, 1, 2} (6 upper tiles), wave 1 {3, 4} (9)
+  auto own = [](int t) constexpr { return (t <= TSPLIT) == (W == 0); };
   constexpr int NX = C::NX, NP_ = C::NP, T = C::T, TU = C::TU, KG = C::KG, KGU = C::KGU, G0 = C::G0, G1 = C::G1, NUC = C::NUC;
   constexpr int TS = C::TS, LS = C::LS, QS = C::QS, RS = C::RS, LDA = C::LDA, HL = C::HL, SCR_LD = C::SCR_LD, SCR_TILE = C::SCR_TILE;
   constexpr rtoc_layout SL = StaticLayout<NV, NU, NS>::make();
   constexpr rtoc_record_layout KL = SL.kkt, RL = SL.ric;
   static_assert(M::VOFF_LX > 0 && M::VOFF_LU > M::VOFF_LX && M::VOFF_LX % 2 == 0 && M::VOFF_LU % 2 == 0, "Fx, lx, lu lie behind one another in the record");
   static_assert(KL.off[RTOC_KKT_FXX] % 2 == 0 && KL.off[RTOC_KKT_FX] % 2 == 0 && KL.off[RTOC_KKT_QUU] % 2 == 0 && KL.off[RTOC_KKT_QXX] % 2 == 0 && KL.stride % 2 == 0 && NX % 2 == 0, "16-byte chunks");
-  constexpr int ST_FX = M::OFF_ST, ST_LX = ST_FX + M::VOFF_LX, ST_LU = ST_FX + M::VOFF_LU;
-  constexpr int NPC_A = (NX + 64 / HL - 1) / (64 / HL);   // DMA instructions of A per grid point
-  static_assert(NPC_A < 64, "counted wait");
+  constexpr int ST_LXO = M::VOFF_LX, ST_LUO = M::VOFF_LU;   // offsets inside a strip (Fx at 0)
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* const sA = smem + M::OFF_A;
-  double* const sG = smem + M::OFF_G;
-  double* const sY = smem + M::OFF_Y;
-  double* const scr = smem + M::OFF_SCR;
-  double* const sS = smem + M::OFF_S;
-  double* const sZ = smem + M::OFF_Z;
-  double* const sW0 = smem + M::OFF_W0;
-  double* const sLup = smem + M::OFF_LUP;
-  double* const sT = smem + M::OFF_T;
+  double* const pw_ = smem + M::OFF_PW + W * M::PWD;   // this wave's own block
+  double* const sG = pw_ + M::P_G;
+  double* const sY = pw_ + M::P_Y;
+  double* const scr = pw_ + M::P_SCR;
+  double* const sS = pw_ + M::P_S;
+  double* const sZ = pw_ + M::P_Z;
+  double* const sW0 = pw_ + M::P_W0;
+  double* const sLup = pw_ + M::P_LUP;
+  double* const sT = pw_ + M::P_T;
   int* const sGrid = reinterpret_cast<int*>(smem + M::OFF_GRID);
 
   const int b = a.first + (int)blockIdx.x;
   if (b >= a.batch) return;
-  const int lane0 = threadIdx.x;
+  const int lane0 = threadIdx.x & 63;
   int lane = lane0 & 63, li = lane & 15, q = lane >> 4;
   const int N = a.nstages - 1;
   const size_t kinst = (size_t)b * a.nstages * KL.stride;
@@ -145,12 +132,22 @@ __global__ __launch_bounds__(64, 1) void riccati_backward_rw_kernel(BwdArgs a) {
       }
     }
   };
+  auto issue_dma_bv = [&](int stage) __attribute__((always_inline)) {
+    const double* kp = a.kkt + kinst + (size_t)stage * KL.stride + KL.off[RTOC_KKT_FVU];
+    constexpr int CBV = (NV * NU + 1) / 2, PBV = (CBV + 63) / 64;
+#pragma unroll
+    for (int p = 0; p < PBV; ++p) {
+      const int n = lane + 64 * p;
+      if (64 * (p + 1) <= CBV || n < CBV) __builtin_amdgcn_global_load_lds(kp + 2 * n, (lds_ptr_t)(smem + M::OFF_BV + 128 * p), 16, 0, 0);
+    }
+  };
   auto issue_dma_strip = [&](int stage) __attribute__((always_inline)) {
     const double* kp = a.kkt + kinst + (size_t)stage * KL.stride + KL.off[RTOC_KKT_FX];
 #pragma unroll
     for (int p = 0; p < M::PS; ++p) {
       const int n = lane + 64 * p;
-      if (64 * (p + 1) <= M::CV || n < M::CV) __builtin_amdgcn_global_load_lds(kp + 2 * n, (lds_ptr_t)(smem + M::OFF_ST + 128 * p), 16, 0, 0);
+      if (64 * (p + 1) <= M::CV || n < M::CV)
+        __builtin_amdgcn_global_load_lds(kp + 2 * n, (lds_ptr_t)(smem + M::OFF_ST + (stage & 1) * M::STRIP + 128 * p), 16, 0, 0);
     }
   };
 
@@ -175,7 +172,7 @@ __global__ __launch_bounds__(64, 1) void riccati_backward_rw_kernel(BwdArgs a) {
           pp[kt][mt][r] = ok ? v : 0.0;
         }
     for (int e = lane; e < NX; e += 64) sS[e] = term ? -ssrc[e] : ssrc[e];
-    if (term) {
+    if (term && W == 0) {
       double* rr = a.ric + rinst + (size_t)N * RL.stride;
       const d2* s2 = reinterpret_cast<const d2*>(psrc);
       d2* t2 = reinterpret_cast<d2*>(rr + RL.off[RTOC_RIC_P]);
@@ -185,25 +182,17 @@ __global__ __launch_bounds__(64, 1) void riccati_backward_rw_kernel(BwdArgs a) {
   }
   // ---- operands that come straight from HBM, requested one stage ahead: Bv fragments (B operand of PB, A operand of G), Quu in the C
   //      layout.  RAW: lanes beyond the matrices load a clamped address and are masked where the value is USED ----
-  double bvr[KG - G0][TU];
+  // (Bv is NOT requested a stage ahead here: twenty registers carried over the stage boundary, where P+ is being rebuilt, were spilled
+  //  load by load -- each with a full wait; they are requested at the stage top, ahead of z)
   auto issue_bq = [&](int stage) __attribute__((always_inline)) {
     const double* kp = a.kkt + kinst + (size_t)stage * KL.stride;
-    const double* bp = kp + KL.off[RTOC_KKT_FVU];
-#pragma unroll
-    for (int g = G0; g < KG; ++g)
-#pragma unroll
-      for (int tu = 0; tu < TU; ++tu) {
-        const int k = 4 * g + q - NV, u = 16 * tu + li;
-        const bool ok = k >= 0 && k < NV && u < NU;
-        bvr[g - G0][tu] = bp[ok ? k + u * NV : (g - G0) * TU + tu];
-      }
     // Quu -> the LDS place of G by DMA (flat: G's leading dimension is NU); the G product adds itself onto it
     constexpr int CQ = (NU * NU + 1) / 2, PQ = (CQ + 63) / 64;
     const double* gp = kp + KL.off[RTOC_KKT_QUU];
 #pragma unroll
     for (int p = 0; p < PQ; ++p) {
       const int n = lane + 64 * p;
-      if (64 * (p + 1) <= CQ || n < CQ) __builtin_amdgcn_global_load_lds(gp + 2 * n, (lds_ptr_t)(smem + M::OFF_G + 128 * p), 16, 0, 0);
+      if (64 * (p + 1) <= CQ || n < CQ) __builtin_amdgcn_global_load_lds(gp + 2 * n, (lds_ptr_t)(sG + 128 * p), 16, 0, 0);
     }
   };
   // Qxx comes in by DMA too, one column tile (16 columns, all rows: 8 KB, contiguous in the record) at a time into one of two padded
@@ -212,12 +201,10 @@ __global__ __launch_bounds__(64, 1) void riccati_backward_rw_kernel(BwdArgs a) {
   // brrf.cpp:85 folded in): panel p holds the transposed elements of the tiles (p, t >= p) -- read with li along the contiguous
   // index -- and the direct elements of the tiles (c < p, p).  No registers wait for these 32 KB.
   constexpr int LDQ = M::LDQ;
-  constexpr bool EARLY = (T <= 4);   // Qxu^T requested at the stage top (64 registers for ~12k cycles) or just ahead of the H product
-  auto NQ_NEXT = [](int t) constexpr { return (16 * (t + 2) <= NX) ? 16 : NX - 16 * (t + 1); };   // DMA instructions of panel t + 1
   d4 f[T][T];
   auto issue_qxx_panel = [&](const double* kr_, int p) __attribute__((always_inline)) {
     const double* qb_ = kr_ + KL.off[RTOC_KKT_QXX] + (size_t)16 * p * NX;
-    double* dst = smem + M::OFF_Q + (p & 1) * M::PANEL;
+    double* dst = pw_ + M::P_Q + (p & 1) * M::PANEL;
 #pragma unroll
     for (int col = 0; col < 16; ++col) {
       if (16 * p + col >= NX) continue;
@@ -225,11 +212,12 @@ __global__ __launch_bounds__(64, 1) void riccati_backward_rw_kernel(BwdArgs a) {
     }
   };
   auto qxx_seed_panel = [&](int p) __attribute__((always_inline)) {
-    const double* pan = smem + M::OFF_Q + (p & 1) * M::PANEL;
+    const double* pan = pw_ + M::P_Q + (p & 1) * M::PANEL;
 #pragma unroll
     for (int t = p; t < T; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {   // tile (p, t): element (16p + 4r + q, 16t + li) <- Qxx[16t + li][16p + 4r + q], column 4r + q of the panel
+        if (!own(t)) continue;
         const int i = 16 * p + 4 * r + q, j = 16 * t + li;
         if (16 * p + 4 * r >= NX) continue;
         const bool ok = ((16 * p + 4 * r + 3 < NX) || i < NX) && ((16 * t + 15 < NX) || j < NX);
@@ -240,17 +228,41 @@ __global__ __launch_bounds__(64, 1) void riccati_backward_rw_kernel(BwdArgs a) {
     for (int c = 0; c < p; ++c)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {   // tile (c, p): element (16c + 4r + q, 16p + li) <- Qxx[16c + 4r + q][16p + li], column li of the panel
+        if (!own(p)) continue;
         const int j = 16 * p + li;
         const bool ok = (16 * p + 15 < NX) || j < NX;
         const double v = pan[16 * c + 4 * r + q + (ok ? li : 0) * LDQ];
         f[c][p][r] = __builtin_fma(0.5, ok ? v : 0.0, f[c][p][r]);
       }
   };
-  issue_dma_strip(hi);
+  if (W == 0) {
+    issue_dma_strip(hi);
+    issue_dma_bv(hi);
+    issue_dma_A(hi);
+    for (int e = lane; e < a.nstages; e += 64) sGrid[e] = a.grid[e].type | (a.grid[e].dims << 8);   // (the host keeps nstages <= RV_MAX_STAGES)
+  }
   issue_bq(hi);
-  issue_dma_A(hi);
-  for (int e = lane; e < a.nstages; e += 64) sGrid[e] = a.grid[e].type | (a.grid[e].dims << 8);   // (the host keeps nstages <= RV_MAX_STAGES)
-  rv_lds_sync();
+  // z = s+ - P+ Fx (brrf.cpp:86) of the first grid point of the segment: per-lane partial sums over the rows a lane holds, q-reduction
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  rw2_sync();   // the strip of grid point hi has landed (wave 0's DMA)
+  {
+    double fxr[KG];
+#pragma unroll
+    for (int g = 0; g < KG; ++g) {
+      const double v = smem[M::OFF_ST + (hi & 1) * M::STRIP + 4 * g + q];
+      fxr[g] = (4 * g + 3 < NX || 4 * g + q < NX) ? v : 0.0;
+    }
+#pragma unroll
+    for (int mt = 0; mt < T; ++mt) {
+      double part = 0.0;
+#pragma unroll
+      for (int g = 0; g < KG; ++g) part = __builtin_fma(pp[g / 4][mt][g % 4], fxr[g], part);
+      part = qsum(part);
+      const int j = 16 * mt + li;
+      const double sv = sS[(j < NX) ? j : 0];
+      if (q == 0 && j < NX) sZ[j] = sv - part;
+    }
+  }
 
   for (int st = hi; st >= lo; --st) {
     lane = lane0;
@@ -258,56 +270,52 @@ __global__ __launch_bounds__(64, 1) void riccati_backward_rw_kernel(BwdArgs a) {
     lane &= 63;
     li = lane & 15;
     q = lane >> 4;
+    // everything this grid point reads from LDS has landed: wave 0's DMA of A and of the strip, this wave's own Quu and Bv
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    rw2_sync();
     const int gword = __builtin_amdgcn_readfirstlane(sGrid[st]);
-    const bool impact = (gword & 0xff) == RTOC_GRID_IMPACT;
+    const bool impact = (gword & 0xff) == RTOC_GRID_IMPACT;   // (read behind the barrier below: wave 0 writes the table)
     const double* kr = a.kkt + kinst + (size_t)st * KL.stride;
     double* rr = a.ric + rinst + (size_t)st * RL.stride;
 
-    RV_PROF(0);
-    // the strip of this grid point and its Bv / Quu registers have landed; the DMA pieces of A -- the youngest vector-memory
-    // operations of the previous stage, NPC_A instructions -- may still be in flight (A is first read by the H product)
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPC_A) : "memory");
-    __builtin_amdgcn_wave_barrier();
-    RV_PROF(1);
-    // ================= 1. z = s+ - P+ Fx (brrf.cpp:86): per-lane partial sums over the rows a lane holds, q-reduction =========
-    {
-      double fxr[KG];
+    const double* const sStrip = smem + M::OFF_ST + (st & 1) * M::STRIP;          // Fx | lx | lu of this grid point
+    const double* const sStripN = smem + M::OFF_ST + ((st - 1) & 1) * M::STRIP;   // ... of the next one
+    if (W == 0 && st > lo) issue_dma_strip(st - 1);   // (into the other strip: it has a whole stage to land)
+    RW2_PROF(0);
+    // ---- P of grid point st + 1 -> HBM from the registers that hold it as P+ all stage long: this wave's row tiles, at the stage top --
+    //      they drain behind the PB / G / H products and never stand between a Qxx panel and its counted wait (element (i, j)
+    //      through its mirror (j, i): li along the contiguous index) ----
+    if (st < hi) {
+      double* pw = a.ric + rinst + (size_t)(st + 1) * RL.stride + RL.off[RTOC_RIC_P];
 #pragma unroll
-      for (int g = 0; g < KG; ++g) {
-        const double v = smem[ST_FX + 4 * g + q];
-        fxr[g] = (4 * g + 3 < NX || 4 * g + q < NX) ? v : 0.0;
-      }
+      for (int t = 0; t < T; ++t)
 #pragma unroll
-      for (int mt = 0; mt < T; ++mt) {
-        double part = 0.0;
+        for (int mt = 0; mt < T; ++mt)
 #pragma unroll
-        for (int g = 0; g < KG; ++g) part = __builtin_fma(pp[g / 4][mt][g % 4], fxr[g], part);
-        part = qsum(part);
-        const int j = 16 * mt + li;
-        const double sv = sS[(j < NX) ? j : 0];
-        if (q == 0 && j < NX) sZ[j] = sv - part;
-      }
+          for (int r = 0; r < 4; ++r) {
+            const int i = 16 * t + 4 * r + q, j = 16 * mt + li;
+            if (own(t) && i < NX && j < NX) pw[j + i * NX] = pp[t][mt][r];
+          }
     }
-    rv_lds_sync();
+    RW2_PROF(1);
+    // (1. z = s+ - P+ Fx of this grid point was formed where P+ was rebuilt: at the end of the previous stage / in the prologue)
     auto zrow = [&](int g) __attribute__((always_inline)) -> double {   // z in the row layout: z[4g + q] (re-read where it rides: no registers held)
       const double v = sZ[4 * g + q];
       return (4 * g + 3 < NX || 4 * g + q < NX) ? v : 0.0;
     };
 
-    RV_PROF(2);
+    RW2_PROF(2);
     // Qxu^T in the layout of H^T (row u = 16 tu + 4r + q, column x = 16c + li), RAW
     d4 hq[TU][T];
-    auto issue_hq = [&]() __attribute__((always_inline)) {
+    auto issue_hq = [&](int tu) __attribute__((always_inline)) {   // (one control tile at a time: 40 registers, not 80, beside P+)
       const double* hp = kr + KL.off[RTOC_KKT_QXU];
 #pragma unroll
-      for (int tu = 0; tu < TU; ++tu)
+      for (int c = 0; c < T; ++c)
 #pragma unroll
-        for (int c = 0; c < T; ++c)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int u = 16 * tu + 4 * r + q, x = 16 * c + li;
-            hq[tu][c][r] = hp[((x < NX) ? x : NX - 1) + ((u < NU) ? u : NU - 1) * NX];
-          }
+        for (int r = 0; r < 4; ++r) {
+          const int u = 16 * tu + 4 * r + q, x = 16 * c + li;
+          hq[tu][c][r] = hp[((x < NX) ? x : NX - 1) + ((u < NU) ? u : NU - 1) * NX];
+        }
     };
     d4 acc[T][TU];   // PB = P+[:, v] Bv: rows x = 16c + .., columns u = 16 tu + li; column NU: z
 #pragma unroll
@@ -322,7 +330,9 @@ __global__ __launch_bounds__(64, 1) void riccati_backward_rw_kernel(BwdArgs a) {
 #pragma unroll
         for (int tu = 0; tu < TU; ++tu) {
           const int k = 4 * g + q - NV, u = 16 * tu + li;
-          bvf[g - G0][tu] = (k >= 0 && k < NV && u < NU) ? bvr[g - G0][tu] : 0.0;
+          const bool ok = k >= 0 && k < NV && u < NU;
+          const double v = smem[M::OFF_BV + (ok ? k + u * NV : 0)];   // Bv[k][u] (flat, as in the record)
+          bvf[g - G0][tu] = ok ? v : 0.0;
         }
 #pragma unroll
       for (int g = G0; g < KG; ++g)
@@ -352,13 +362,11 @@ __global__ __launch_bounds__(64, 1) void riccati_backward_rw_kernel(BwdArgs a) {
           for (int r = 0; r < 4; ++r) {
             const int u0 = 16 * tr + 4 * r + q, u1 = 16 * tu + li;
             if (u0 < NU && u1 < NU) sG[u0 + u1 * NU] += gacc[tr][tu][r];
-            if (tu == TU - 1 && u0 < NU && li == NUC) sLup[u0] = smem[ST_LU + u0] - gacc[tr][tu][r];   // lu' = lu - Bv^T z_v
+            if (tu == TU - 1 && u0 < NU && li == NUC) sLup[u0] = sStrip[ST_LUO + u0] - gacc[tr][tu][r];   // lu' = lu - Bv^T z_v
           }
       rv_lds_sync();
     }
-    RV_PROF(3);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // A has landed
-    __builtin_amdgcn_wave_barrier();
+    RW2_PROF(3);
     // z into the idle column NU of PB: column NU of H = A^T PB is then A^T z (on an impact grid point PB is that column alone)
 #pragma unroll
     for (int g = 0; g < KG; ++g) acc[g / 4][TU - 1][g % 4] = (li == NUC) ? zrow(g) : acc[g / 4][TU - 1][g % 4];
@@ -409,11 +417,11 @@ __global__ __launch_bounds__(64, 1) void riccati_backward_rw_kernel(BwdArgs a) {
 
     d4 zt[TU][T];   // Z^T = Y H^T
     if (!impact) {
-      issue_hq();
       // ================= 4. H = A^T PB (rows x, columns u; column NU: A^T z) =================
       d4 hT[TU][T];
 #pragma unroll
       for (int tu = 0; tu < TU; ++tu) {
+        issue_hq(tu);
         d4 hx[T];
 #pragma unroll
         for (int c = 0; c < T; ++c) hx[c] = zero4();
@@ -438,16 +446,16 @@ __global__ __launch_bounds__(64, 1) void riccati_backward_rw_kernel(BwdArgs a) {
         }
         // ================= 5. H^T = transpose(H) + Qxu^T, two tiles per round trip through the scratch =================
 #pragma unroll
-        for (int c0 = 0; c0 < T; c0 += 2) {
+        for (int c0 = 0; c0 < T; c0 += M::NSCR) {
 #pragma unroll
-          for (int c = c0; c < c0 + 2 && c < T; ++c) {
+          for (int c = c0; c < c0 + M::NSCR && c < T; ++c) {
             double* s_ = scr + (c - c0) * SCR_TILE;
 #pragma unroll
             for (int r = 0; r < 4; ++r) s_[(q + 4 * r) * SCR_LD + li] = hx[c][r];
           }
           rv_lds_sync();
 #pragma unroll
-          for (int c = c0; c < c0 + 2 && c < T; ++c) {
+          for (int c = c0; c < c0 + M::NSCR && c < T; ++c) {
             const double* s_ = scr + (c - c0) * SCR_TILE;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -459,11 +467,11 @@ __global__ __launch_bounds__(64, 1) void riccati_backward_rw_kernel(BwdArgs a) {
           rv_lds_sync();
         }
       }
-      RV_PROF(4);
+      RW2_PROF(4);
       // ================= 3. LLT(G) (riccati_factorizer.cpp:49), Y = L^-1; t = Y lu', k = -Y^T t =================
-      if (wave_llt_inv_blocked<NU, NU>(sG, sG, smem + M::OFF_LINV, sY, scr, lane)) stat |= RTOC_STAT_QUU_NOT_SPD;
+      if (wave_llt_inv_blocked<NU, NU>(sG, sG, pw_ + M::P_LINV, sY, scr, lane)) stat |= RTOC_STAT_QUU_NOT_SPD;
       rv_lds_sync();
-      RV_PROF(5);
+      RW2_PROF(5);
       {
         const int u = (lane < NU) ? lane : 0;
         double tv = 0.0;
@@ -474,10 +482,10 @@ __global__ __launch_bounds__(64, 1) void riccati_backward_rw_kernel(BwdArgs a) {
         double kv = 0.0;
 #pragma unroll
         for (int j = 0; j < NU; ++j) kv = __builtin_fma(sY[j + u * NU], sT[j], kv);
-        if (lane < NU) rr[RL.off[RTOC_RIC_KV] + lane] = -kv;
+        if (W == 0 && lane < NU) rr[RL.off[RTOC_RIC_KV] + lane] = -kv;
         if (is_bad(kv)) stat |= RTOC_STAT_NAN;
       }
-      RV_PROF(6);
+      RW2_PROF(6);
       // ================= 6. Z^T = Y H^T (Y lower triangular: the tile above the diagonal is skipped) =================
 #pragma unroll
       for (int tu = 0; tu < TU; ++tu) {
@@ -494,7 +502,7 @@ __global__ __launch_bounds__(64, 1) void riccati_backward_rw_kernel(BwdArgs a) {
           for (int c = 0; c < T; ++c) zt[tu][c] = mfma16(av, hT[gj / 4][c][gj % 4], zt[tu][c]);
         }
       }
-      RV_PROF(7);
+      RW2_PROF(7);
       // ================= 7. K = -Y^T Z^T (riccati_factorizer.cpp:55), tile by tile -> HBM (K row-major) =================
       double chk = 0.0;
 #pragma unroll
@@ -509,6 +517,7 @@ __global__ __launch_bounds__(64, 1) void riccati_backward_rw_kernel(BwdArgs a) {
         }
 #pragma unroll
         for (int c = 0; c < T; ++c) {
+          if (!own(c)) continue;   // this wave's column tiles of K
           d4 kk = zero4();
 #pragma unroll
           for (int gj = 0; gj < KGU; ++gj) {
@@ -552,26 +561,46 @@ __global__ __launch_bounds__(64, 1) void riccati_backward_rw_kernel(BwdArgs a) {
         for (int c = 0; c < T; ++c) zt[tu][c] = zero4();
     }
 
-    RV_PROF(8);
+    RW2_PROF(8);
     // ================= 8. F starts from Qxx (upper tiles; off-diagonal ones symmetrised: brrf.cpp:85 folded into the start
     //                      value), F -= Z Z^T (brrf.cpp:82-84) =================
     // F accumulates from ZERO (-Z Z^T, then A^T W column by column); G, Y and the scratch are dead: the first two panels of Qxx
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
+    // The panels this wave needs: every p that meets one of its tiles -- (p, t >= p) with t its own, (c < p, p) with p its own --,
+    // i.e. 0 .. its last column tile.  Panel k is consumed at slot k of the sequence [behind s; then, per column iteration of this
+    // wave: behind its W product, at its end]; panel k + 2 takes its buffer there (two panels in flight).
+    constexpr int NPAN = (W == 0) ? TSPLIT + 1 : T;
+    auto panel_slot = [&](int k) __attribute__((always_inline)) {
+      if (k >= NPAN) return;
+      // panel k has landed: only the DMA instructions of panel k + 1 -- issued one slot ago, nothing behind them -- may be in flight
+      if (k + 1 < NPAN && 16 * (k + 2) <= NX) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else if (k + 1 < NPAN) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NX % 16) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      qxx_seed_panel(k);
+      if (k + 2 < NPAN) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        issue_qxx_panel(kr, k + 2);
+      }
+    };
     issue_qxx_panel(kr, 0);   // (panel 1 covers A^T z and t, which the update of s below still reads: behind it)
 #pragma unroll
     for (int c = 0; c < T; ++c)
 #pragma unroll
-      for (int t = c; t < T; ++t) f[c][t] = zero4();
+      for (int t = c; t < T; ++t)
+        if (own(t)) f[c][t] = zero4();
     if (!impact) {
 #pragma unroll
       for (int gu = 0; gu < KGU; ++gu)
 #pragma unroll
         for (int c = 0; c < T; ++c)
 #pragma unroll
-          for (int t = c; t < T; ++t) f[c][t] = mfma16(-zt[gu / 4][c][gu % 4], zt[gu / 4][t][gu % 4], f[c][t]);
+          for (int t = c; t < T; ++t)
+            if (own(t)) f[c][t] = mfma16(-zt[gu / 4][c][gu % 4], zt[gu / 4][t][gu % 4], f[c][t]);
     }
-    RV_PROF(9);
+    RW2_PROF(9);
     // ---- s = A^T z - lx - H k = w0 - lx + Z t (brrf.cpp:86-90): column layout, per-lane partial sums + q-reduction; -> LDS (the s+
     //      of the next grid point) and HBM, with the (zero) switching-time fields of the record ----
     rv_lds_sync();
@@ -590,27 +619,29 @@ __global__ __launch_bounds__(64, 1) void riccati_backward_rw_kernel(BwdArgs a) {
         part = qsum(part);
         const int j = 16 * c + li;
         const int jc = (j < NX) ? j : 0;
-        const double sn = sW0[jc] - smem[ST_LX + jc] + part;
+        const double sn = sW0[jc] - sStrip[ST_LXO + jc] + part;
         if (q == 0 && j < NX) {
           sS[j] = sn;
-          rr[RL.off[RTOC_RIC_S] + j] = sn;
+          if (W == 0) rr[RL.off[RTOC_RIC_S] + j] = sn;
         }
-        if (q == 1 && j < NX) rr[RL.off[RTOC_RIC_PSI] + j] = 0.0;
-        if (q == 2 && j < NX) rr[RL.off[RTOC_RIC_PHI] + j] = 0.0;
+        if (W == 0 && q == 1 && j < NX) rr[RL.off[RTOC_RIC_PSI] + j] = 0.0;
+        if (W == 0 && q == 2 && j < NX) rr[RL.off[RTOC_RIC_PHI] + j] = 0.0;
       }
-      if (lane < 5) rr[RL.off[RTOC_RIC_SCAL] + lane] = 0.0;
+      if (W == 0 && lane < 5) rr[RL.off[RTOC_RIC_SCAL] + lane] = 0.0;
     }
-    // the strip (Fx, lx, lu) has been read for the last time: the one of the next grid point
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    issue_qxx_panel(kr, 1);
-    if (st > lo) issue_dma_strip(st - 1);
+    if (NPAN > 1) issue_qxx_panel(kr, 1);
     asm volatile("" ::: "memory");
+    panel_slot(0);
 
-    RV_PROF(10);
+    RW2_PROF(10);
     // ================= 9. column tile by column tile: W[:, t] = P+ A[:, t], F[c][t] += A^T[c] W[:, t] =================
 #pragma unroll
     for (int t = 0; t < T; ++t) {
+      if (!own(t)) continue;   // this wave's column tiles of F
+      constexpr int T0 = (W == 0) ? 0 : TSPLIT + 1;
+      const int ord = t - T0;   // which of this wave's iterations
       d4 w[T];
 #pragma unroll
       for (int tm = 0; tm < T; ++tm) w[tm] = zero4();
@@ -643,6 +674,7 @@ __global__ __launch_bounds__(64, 1) void riccati_backward_rw_kernel(BwdArgs a) {
             }
           }
       }
+      panel_slot(1 + 2 * ord);
 #pragma unroll
       for (int g = 0; g < KG; ++g) {
         if (!group_dense(g)) continue;
@@ -658,80 +690,80 @@ __global__ __launch_bounds__(64, 1) void riccati_backward_rw_kernel(BwdArgs a) {
 #pragma unroll
         for (int c = 0; c <= t; ++c) f[c][t] = col[c];
       }
-      // ---- panel t of Qxx has landed: every vector-memory operation older than the DMA of panel t + 1 is waited for (counted
-      //      conservatively: only that younger panel's instructions may still be in flight); its part of the start value of F ----
-      if (t + 1 < T) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NQ_NEXT(t)) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_wave_barrier();
-      qxx_seed_panel(t);
-      // ---- P of grid point st + 1 -> HBM, a T-th per column tile, from the registers that hold it as P+ until the last of these
-      //      products (element (i, j) through its mirror (j, i): li along the contiguous index) ----
-      if (st < hi) {
-        double* pw = a.ric + rinst + (size_t)(st + 1) * RL.stride + RL.off[RTOC_RIC_P];
+      panel_slot(2 + 2 * ord);
+    }
+    RW2_PROF(11);
+    // ================= 10. the fifteen tiles of F meet in LDS, in the place of A; each wave rebuilds P+ = sym(F) from there ==========
+    auto masked = [&](int c, int t, int r, double v) -> double {
+      const int i = 16 * c + 4 * r + q, j = 16 * t + li;
+      if (16 * c + 4 * r >= NX) return 0.0;
+      const bool rowok = (16 * c + 4 * r + 3 < NX) || i < NX;
+      const bool colok = (16 * t + 15 < NX) || j < NX;
+      return (rowok && colok) ? v : 0.0;
+    };
+    auto tile_at = [](int c, int t) constexpr { return c * T - c * (c - 1) / 2 + (t - c); };   // index of the upper tile (c, t), c <= t
+    rw2_sync();   // both waves have read A -- and the strip -- for the last time
 #pragma unroll
-        for (int mt = 0; mt < T; ++mt)
+    for (int c = 0; c < T; ++c)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int i = 16 * t + 4 * r + q, j = 16 * mt + li;
-            if (i < NX && j < NX) pw[j + i * NX] = pp[t][mt][r];
-          }
+      for (int t = c; t < T; ++t) {
+        if (!own(t)) continue;
+        double* x_ = sA + tile_at(c, t) * SCR_TILE;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x_[(q + 4 * r) * SCR_LD + li] = masked(c, t, r, f[c][t][r]);
       }
-      if (t + 2 < T) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the panel's reads are done: its buffer takes panel t + 2
-        __builtin_amdgcn_wave_barrier();
-        issue_qxx_panel(kr, t + 2);
+    RW2_PROF(12);
+    rw2_sync();   // all of F is in LDS, and the next strip
+    // z = s+ - P+ Fx of the NEXT grid point rides along: the elements of P+ pass through the vector registers once, here -- formed at
+    // the stage top from the resident P+ it made the allocator keep all 200 registers of it in the architectural half
+    double zpart[T];
+#pragma unroll
+    for (int mt = 0; mt < T; ++mt) zpart[mt] = 0.0;
+#pragma unroll
+    for (int kt = 0; kt < T; ++kt)
+#pragma unroll
+      for (int mt = 0; mt < T; ++mt) {
+        const double* x_ = sA + ((kt <= mt) ? tile_at(kt, mt) : tile_at(mt, kt)) * SCR_TILE;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          // upper tiles as computed (this wave's own: straight from its accumulators), lower ones transposed, diagonal ones mirrored
+          // from their upper triangle (P exactly symmetric)
+          double pv;
+          if (kt < mt) {
+            pv = own(mt) ? masked(kt, mt, r, f[kt][mt][r]) : x_[(q + 4 * r) * SCR_LD + li];
+          } else if (kt > mt) {
+            pv = x_[li * SCR_LD + q + 4 * r];
+          } else {
+            const double dv = own(mt) ? masked(kt, mt, r, f[kt][mt][r]) : x_[(q + 4 * r) * SCR_LD + li];
+            const double tv = x_[li * SCR_LD + q + 4 * r];
+            pv = (q + 4 * r <= li) ? dv : tv;
+          }
+          pp[kt][mt][r] = pv;
+          if (4 * kt + r < KG) {   // (Fx re-read where it is used: eighteen registers less while P+ passes through the vector file)
+            const double fv = sStripN[4 * (4 * kt + r) + q];   // Fx of the next grid point (its strip was requested at the stage top)
+            zpart[mt] = __builtin_fma(pv, (st > lo && (16 * kt + 4 * r + 3 < NX || 16 * kt + 4 * r + q < NX)) ? fv : 0.0, zpart[mt]);
+          }
+        }
+      }
+    if (st > lo) {
+#pragma unroll
+      for (int mt = 0; mt < T; ++mt) {
+        const double part = qsum(zpart[mt]);
+        const int j = 16 * mt + li;
+        const double sv = sS[(j < NX) ? j : 0];
+        if (q == 0 && j < NX) sZ[j] = sv - part;
       }
     }
-    RV_PROF(11);
-    // ---- A has been read for the last time: the dense rows of the next grid point's ----
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
+    rw2_sync();   // ... and has been read: the place belongs to A again
     if (st > lo) {
       issue_bq(st - 1);
-      issue_dma_A(st - 1);   // (the LAST vector-memory operations of the stage: the counted wait at the next stage top)
-    }
-    asm volatile("" ::: "memory");
-
-    RV_PROF(12);
-    // ================= 10. P <- sym(F): upper tiles as computed, diagonal tiles mirrored, lower tiles transposed =================
-    {
-      auto masked = [&](int c, int t, int r, double v) -> double {
-        const int i = 16 * c + 4 * r + q, j = 16 * t + li;
-        if (16 * c + 4 * r >= NX) return 0.0;
-        const bool rowok = (16 * c + 4 * r + 3 < NX) || i < NX;
-        const bool colok = (16 * t + 15 < NX) || j < NX;
-        return (rowok && colok) ? v : 0.0;
-      };
-      constexpr int NTR = T * (T + 1) / 2;
-#pragma unroll
-      for (int n0 = 0; n0 < NTR; n0 += 2) {
-#pragma unroll
-        for (int n = n0; n < n0 + 2 && n < NTR; ++n) {
-          const int c = rv_tile_row(T, n), t = rv_tile_col(T, n);
-          double* s_ = scr + (n - n0) * SCR_TILE;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) s_[(q + 4 * r) * SCR_LD + li] = masked(c, t, r, f[c][t][r]);
-        }
-        rv_lds_sync();
-#pragma unroll
-        for (int n = n0; n < n0 + 2 && n < NTR; ++n) {
-          const int c = rv_tile_row(T, n), t = rv_tile_col(T, n);
-          const double* s_ = scr + (n - n0) * SCR_TILE;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const double tr = s_[li * SCR_LD + q + 4 * r];
-            if (t > c) {
-              pp[c][t][r] = masked(c, t, r, f[c][t][r]);
-              pp[t][c][r] = tr;                                  // zero outside the matrix: the tile was masked on its way in
-            } else {
-              pp[c][c][r] = (q + 4 * r <= li) ? masked(c, c, r, f[c][c][r]) : tr;   // upper triangle mirrored (P exactly symmetric)
-            }
-          }
-        }
-        rv_lds_sync();
+      if (W == 0) {
+        issue_dma_bv(st - 1);
+        issue_dma_A(st - 1);
       }
     }
-    RV_PROF(13);
+    asm volatile("" ::: "memory");
+    RW2_PROF(13);
   }
 
   // ---- P of the last grid point of the segment ----
@@ -744,10 +776,17 @@ __global__ __launch_bounds__(64, 1) void riccati_backward_rw_kernel(BwdArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int i = 16 * kt + 4 * r + q, j = 16 * mt + li;
-          if (i < NX && j < NX) pw[j + i * NX] = pp[kt][mt][r];
+          if (own(kt) && i < NX && j < NX) pw[j + i * NX] = pp[kt][mt][r];
         }
   }
-  if (stat) atomicOr(&a.status[b], stat);
+  if (W == 0 && stat) atomicOr(&a.status[b], stat);
+}
+
+template <int NV, int NU, int NS>
+__global__ __launch_bounds__(128, 1) void riccati_backward_rw2_kernel(BwdArgs a) {
+  // (wave-uniform branch: each wave runs the body compiled for its share; the barriers inside pair up one to one)
+  if (__builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) == 0) rw2_body<NV, NU, NS, 0>(a);
+  else rw2_body<NV, NU, NS, 1>(a);
 }
 
 }  // namespace rtoc

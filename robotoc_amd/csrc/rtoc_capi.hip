@@ -1144,7 +1144,7 @@ static int launch_backward_rw(rtoc_ctx* c, int first, int end, hipStream_t strea
     while (lo > 0 && !constrained(lo - 1)) --lo;
     a.seg_hi = hi;
     a.seg_lo = lo;
-    hipLaunchKernelGGL(ks->bwd_rw, dim3(nb), dim3(64), ks->bwd_rw_lds, stream, a);
+    hipLaunchKernelGGL(ks->bwd_rw, dim3(nb), dim3(ks->bwd_rw_threads), ks->bwd_rw_lds, stream, a);
     hi = lo - 1;
   }
   HIP_TRY(hipGetLastError());

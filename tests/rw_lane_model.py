@@ -135,7 +135,7 @@ def struct_rows_add(c_, dst, src, ca, cc):
             dst[c][:, r] += np.where(c_.row_struct(k) & (i < c_.NX), cc * got, 0.0)
 
 
-def stage(c_, pp, s_next, A, Bv, Qxx, Qxu, Quu, Fx, lx, lu, impact):
+def stage(c_, pp, s_next, A, Bv, Qxx, Qxu, Quu, Fx, lx, lu, impact, direct_ht=False):
     """pp[kt][mt]: (64,4) C tiles of P+ (zero outside NX x NX); s_next: s+ [NX] (lives in LDS).
     Returns (pp_new, s_new, K [NU x NX], k [NU]); stage.mfma counts the matrix instructions."""
     NV, NU, NP, NX, T, TU, KG, KGU, G0, NUC = c_.NV, c_.NU, c_.NP, c_.NX, c_.T, c_.TU, c_.KG, c_.KGU, c_.G0, c_.NUC
@@ -218,6 +218,47 @@ def stage(c_, pp, s_next, A, Bv, Qxx, Qxu, Quu, Fx, lx, lu, impact):
         Y = np.linalg.inv(np.linalg.cholesky(G))
         tvec = Y @ lup
         kvec = -Y.T @ tvec
+        if direct_ht:
+            # ---- 4'. H^T = Qxu^T + PB^T A DIRECTLY (riccati_backward_rw2.hpp): the accumulators of PB are, lane for lane, the A fragments
+            #      of PB^T (lane (li, q) <-> PB[4g + q][16 tu + li]); the dense k groups take A from LDS, the structured rows a SYNTHESISED
+            #      B fragment (ca on the diagonal, cc NV columns to the right) -- 2 or 3 column tiles per group, no transposes, no lane
+            #      rotations; z in the idle column NU of PB makes row NU of H^T the rider A^T z ----
+            for g in range(KG):
+                accz = acc[g // 4][TU - 1][:, g % 4]
+                acc[g // 4][TU - 1][:, g % 4] = np.where(LI == NUC, z_row(g), accz)
+            hT = [[z4() for _ in range(T)] for _ in range(TU)]
+            for tu in range(TU):
+                for c in range(T):
+                    for r in range(4):
+                        u, x = 16 * tu + 4 * r + Q, 16 * c + LI
+                        ok = (u < NU) & (x < NX)
+                        hT[tu][c][:, r] = np.where(ok, Qxu[np.clip(x, 0, NX - 1), np.clip(u, 0, NU - 1)], 0.0)
+            for g in range(KG):
+                k = 4 * g + Q
+                for c in range(T):
+                    x = 16 * c + LI
+                    if g in c_.DG:
+                        b = afrag(g, c)
+                    else:
+                        b = np.zeros(64)
+                    # the structured rows of this group (also those inside a dense group: afrag masks them)
+                    bs = np.where(c_.row_struct(k) & (x == k), ca, 0.0) + np.where(c_.row_struct(k) & (x == NV + k) & (x < NX), cc, 0.0)
+                    if not (np.any(b != 0) or np.any(bs != 0)) and g not in c_.DG:
+                        continue
+                    for tu in range(TU):
+                        if g in c_.DG:
+                            hT[tu][c] = mfma16(acc[g // 4][tu][:, g % 4], b, hT[tu][c])
+                            nmf += 1
+                        if np.any(bs != 0):
+                            hT[tu][c] = mfma16(acc[g // 4][tu][:, g % 4], bs, hT[tu][c])
+                            nmf += 1
+            w0 = np.zeros(NX)
+            rr_, qq_ = (NU - 16 * (TU - 1)) // 4, (NU - 16 * (TU - 1)) % 4
+            for c in range(T):
+                x = 16 * c + LI
+                ok = (x < NX) & (Q == qq_)
+                w0[x[ok]] = hT[TU - 1][c][ok, rr_]
+            hT_direct, w0_direct = hT, w0
         # ---- 4. H = A^T PB (rows x, columns u) with z in the idle column NU of PB: column NU of H is A^T z ----
         for g in range(KG):
             accz = acc[g // 4][TU - 1][:, g % 4]
@@ -249,6 +290,16 @@ def stage(c_, pp, s_next, A, Bv, Qxx, Qxu, Quu, Fx, lx, lu, impact):
                     ok = (u < NU) & (x < NX)
                     tr_[:, r] = np.where(ok, tr_[:, r] + Qxu[np.clip(x, 0, NX - 1), np.clip(u, 0, NU - 1)], 0.0)
                 hT[tu][c] = tr_
+        if direct_ht:   # (the transposed path above ran on the same operands: the two must agree; the direct one is used)
+            for tu in range(TU):
+                for c in range(T):
+                    for r in range(4):
+                        u, x = 16 * tu + 4 * r + Q, 16 * c + LI
+                        ok = (u < NU) & (x < NX)
+                        assert np.abs(np.where(ok, hT_direct[tu][c][:, r] - hT[tu][c][:, r], 0.0)).max() <= 1e-9 * max(1.0, np.abs(hT[tu][c]).max())
+                        hT_direct[tu][c][:, r] = np.where(ok, hT_direct[tu][c][:, r], 0.0)   # (row NU carried the rider)
+            assert np.abs(w0_direct - w0).max() <= 1e-9 * max(1.0, np.abs(w0).max())
+            hT, w0 = hT_direct, w0_direct
         # ---- 6. Z^T = Y H^T (Y lower triangular: the tile above the diagonal is skipped) ----
         def yfrag(tu, gj):      # A operand Y[m = 16 tu + li][k = 4 gj + q]
             m, k = 16 * tu + LI, 4 * gj + Q

@@ -28,7 +28,7 @@ def _sweep(ctx, kkt, dx0, register):
 
 
 @pytest.mark.parametrize("mode", ["dynamics", "factory"])
-@pytest.mark.parametrize("nv", [32])
+@pytest.mark.parametrize("nv", [32, 35])
 def test_register_wide_kernel_reproduces_the_oracle_on_the_icub_jump(oracle, nv, mode):
     from robotoc_amd import capi
     dims, grids, _ = pr.config_icub_jump(nv=nv)
@@ -118,7 +118,7 @@ def test_register_wide_kernel_flags_an_indefinite_control_hessian(oracle):
         ctx.close()
 
 
-@pytest.mark.parametrize("nv", [32])
+@pytest.mark.parametrize("nv", [32, 35])
 def test_register_wide_sweep_repeats_bit_for_bit(nv):
     """DMA landing order, the deferred P stores and the hand-over through the Riccati records at the switching-constraint grid point:
     10 sweeps of 1024 distinct instances (the default dispatch: more instances than CUs), every Riccati record compared with the

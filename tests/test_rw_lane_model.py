@@ -11,8 +11,9 @@ from robotoc_amd.types import GRID_IMPACT, Records
 import rw_lane_model as m
 
 
+@pytest.mark.parametrize("direct_ht", [False, True])
 @pytest.mark.parametrize("nv", [32, 35])
-def test_rw_lane_model_matches_oracle(nv):
+def test_rw_lane_model_matches_oracle(nv, direct_ht):
     dims, grids, _ = pr.config_icub_jump(nv=nv)
     L = orc.layout(dims)
     NV, NU, NX = dims.nv, dims.nu, 2 * dims.nv
@@ -32,7 +33,7 @@ def test_rw_lane_model_matches_oracle(nv):
         rec, nxt, out = kkt[st], ric[st + 1], ric[st]
         f = lambda n: Kr.f(rec, n).copy()   # noqa: E731
         pn, s, K, k = m.stage(c_, m.to_tiles(Rr.f(nxt, "P").copy(), NX), Rr.f(nxt, "s").copy(), f("Fxx"), f("Fvu"), f("Qxx"), f("Qxu"),
-                              f("Quu"), f("Fx"), f("lx"), f("lu"), g.type == GRID_IMPACT)
+                              f("Quu"), f("Fx"), f("lx"), f("lu"), g.type == GRID_IMPACT, direct_ht=direct_ht)
         P = m.from_tiles(pn, NX)
         errs = {"P": np.abs(P - Rr.f(out, "P")).max() / np.abs(Rr.f(out, "P")).max(),
                 "s": np.abs(s - Rr.f(out, "s")).max() / np.abs(Rr.f(out, "s")).max(), "asym": np.abs(P - P.T).max()}

@@ -28,3 +28,5 @@ for st in ((40, 30, 25, 20, 10) if cfg == "trot" else (31, 28, 22, 5)):
     t0 = row[0]
     print("stage %d type %d; next stage top at +%d" % (st, grids[st].type, p[st - 1][0] - t0))
     print("   ", " ".join("%d:%d" % (k, row[k] - t0) for k in range(0, 17) if row[k]))
+    if cfg == "icub35" and row[16]:   # the second wave of the instance (riccati_backward_rw2.hpp), relative to the first wave's stage top
+        print("    wave 1:", " ".join("%d:%d" % (k - 16, row[k] - t0) for k in range(16, 32) if row[k]))
