@@ -20,6 +20,9 @@
 namespace rtoc {
 
 template <int NV, int NU, int NS>
+constexpr bool KL_QXU_EVEN() { return StaticLayout<NV, NU, NS>::make().kkt.off[RTOC_KKT_QXU] % 2 == 0; }
+
+template <int NV, int NU, int NS>
 struct Rw2Lds {
   using C = RwCfg<NV, NU>;
   static constexpr rtoc_layout SL = StaticLayout<NV, NU, NS>::make();
@@ -75,6 +78,11 @@ __device__ __forceinline__ void rw2_body(BwdArgs a) {
   static_assert(C::T == 5 || C::T == 4, "column tiles {0 .. (T-1)/2} | the rest");
   // column tiles of F (and of K, and row tiles of the P stores) this wave owns
   constexpr int TSPLIT = (C::T - 1) / 2;   // T = 5: wave 0 owns {0, 1, 2} (6 upper tiles), wave 1 {3, 4} (9)
+  constexpr int LDH = 16 * (TSPLIT + 1);   // leading dimension of the H^T hand-over
+  constexpr int LDB = 16 * (C::T - TSPLIT - 1);   // ... of wave 1's column tiles
+  static_assert(NU * LDH <= M::P_Z - M::P_G, "H^T of wave 0's column tiles fits the place of wave 1's G, Y and scratch");
+  static_assert(NU * LDB <= C::pad8(NV * NU + 1), "H^T of wave 1's column tiles fits the place of Bv");
+  static_assert(C::NX * NU <= M::P_Z && KL_QXU_EVEN<NV, NU, NS>(), "Qxu fits wave 1's block ahead of z");
   auto own = [](int t) constexpr { return (t <= TSPLIT) == (W == 0); };
   constexpr int NX = C::NX, NP_ = C::NP, T = C::T, TU = C::TU, KG = C::KG, KGU = C::KGU, G0 = C::G0, G1 = C::G1, NUC = C::NUC;
   constexpr int TS = C::TS, LS = C::LS, QS = C::QS, RS = C::RS, LDA = C::LDA, HL = C::HL, SCR_LD = C::SCR_LD, SCR_TILE = C::SCR_TILE;
@@ -85,11 +93,16 @@ __device__ __forceinline__ void rw2_body(BwdArgs a) {
   constexpr int ST_LXO = M::VOFF_LX, ST_LUO = M::VOFF_LU;   // offsets inside a strip (Fx at 0)
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* const sA = smem + M::OFF_A;
-  double* const pw_ = smem + M::OFF_PW + W * M::PWD;   // this wave's own block
-  double* const sG = pw_ + M::P_G;
-  double* const sY = pw_ + M::P_Y;
+  double* const pw0 = smem + M::OFF_PW;                // wave 0's block: G, Y = L^-1, t live there (wave 0 factorises)
+  double* const pw1 = pw0 + M::PWD;                    // wave 1's block: the place of its (unused) G / Y carries H^T to wave 0
+  double* const pw_ = (W == 0) ? pw0 : pw1;            // this wave's own block
+  double* const sG = pw0 + M::P_G;
+  double* const sY = pw0 + M::P_Y;
   double* const scr = pw_ + M::P_SCR;
-  double* const sS = pw_ + M::P_S;
+  double* const sS = pw0 + M::P_S;                     // s+: ONE copy, each wave writes its own column tiles
+  double* const sHX = pw1 + M::P_G;                    // H^T[u][x], x < LDH: the column tiles of wave 0
+  double* const sHB = smem + M::OFF_BV;                // H^T[u][x - LDH], the column tiles of wave 1: in the place of Bv (dead behind PB)
+  const double* const sQxu = pw1;                      // Qxu (flat, as in the record), by wave 1's DMA: under its s+ / G / Y / scratch
   double* const sZ = pw_ + M::P_Z;
   double* const sW0 = pw_ + M::P_W0;
   double* const sLup = pw_ + M::P_LUP;
@@ -139,6 +152,15 @@ __device__ __forceinline__ void rw2_body(BwdArgs a) {
     for (int p = 0; p < PBV; ++p) {
       const int n = lane + 64 * p;
       if (64 * (p + 1) <= CBV || n < CBV) __builtin_amdgcn_global_load_lds(kp + 2 * n, (lds_ptr_t)(smem + M::OFF_BV + 128 * p), 16, 0, 0);
+    }
+  };
+  auto issue_dma_qxu = [&](int stage) __attribute__((always_inline)) {   // (wave 1: the start value of H^T)
+    const double* kp = a.kkt + kinst + (size_t)stage * KL.stride + KL.off[RTOC_KKT_QXU];
+    constexpr int CX = NX * NU / 2, PX = (CX + 63) / 64;
+#pragma unroll
+    for (int p = 0; p < PX; ++p) {
+      const int n = lane + 64 * p;
+      if (64 * (p + 1) <= CX || n < CX) __builtin_amdgcn_global_load_lds(kp + 2 * n, (lds_ptr_t)(pw1 + 128 * p), 16, 0, 0);
     }
   };
   auto issue_dma_strip = [&](int stage) __attribute__((always_inline)) {
@@ -241,7 +263,8 @@ __device__ __forceinline__ void rw2_body(BwdArgs a) {
     issue_dma_A(hi);
     for (int e = lane; e < a.nstages; e += 64) sGrid[e] = a.grid[e].type | (a.grid[e].dims << 8);   // (the host keeps nstages <= RV_MAX_STAGES)
   }
-  issue_bq(hi);
+  if (W == 0) issue_bq(hi);
+  else issue_dma_qxu(hi);
   // z = s+ - P+ Fx (brrf.cpp:86) of the first grid point of the segment: per-lane partial sums over the rows a lane holds, q-reduction
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   rw2_sync();   // the strip of grid point hi has landed (wave 0's DMA)
@@ -282,10 +305,24 @@ __device__ __forceinline__ void rw2_body(BwdArgs a) {
     const double* const sStripN = smem + M::OFF_ST + ((st - 1) & 1) * M::STRIP;   // ... of the next one
     if (W == 0 && st > lo) issue_dma_strip(st - 1);   // (into the other strip: it has a whole stage to land)
     RW2_PROF(0);
-    // ---- P of grid point st + 1 -> HBM from the registers that hold it as P+ all stage long: this wave's row tiles, at the stage top --
-    //      they drain behind the PB / G / H products and never stand between a Qxx panel and its counted wait (element (i, j)
-    //      through its mirror (j, i): li along the contiguous index) ----
-    if (st < hi) {
+    // H^T = Qxu^T + PB^T A (rows u = 16 tu + 4r + q, columns x = 16c + li): all of it in wave 1, handed to wave 0 through LDS.  Qxu^T
+    // is the START VALUE of the accumulators, read from the LDS place wave 1's DMA brought it to
+    d4 hT[TU][T];
+    auto seed = [&](int tu) __attribute__((always_inline)) {
+#pragma unroll
+      for (int c = 0; c < T; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int u = 16 * tu + 4 * r + q, x = 16 * c + li;
+          const bool ok = u < NU && x < NX;
+          const double v = sQxu[ok ? x + u * NX : 0];
+          hT[tu][c][r] = ok ? v : 0.0;
+        }
+    };
+    // ---- P of grid point st + 1 -> HBM from the registers that hold it as P+ all stage long: by wave 1 -- whose way to the
+    //      hand-over of H^T is the shorter one --, at the stage top: the stores drain behind the PB / H products and never stand
+    //      between a Qxx panel and its counted wait (element (i, j) through its mirror (j, i): li along the contiguous index) ----
+    if (W == 1 && st < hi) {
       double* pw = a.ric + rinst + (size_t)(st + 1) * RL.stride + RL.off[RTOC_RIC_P];
 #pragma unroll
       for (int t = 0; t < T; ++t)
@@ -294,7 +331,7 @@ __device__ __forceinline__ void rw2_body(BwdArgs a) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int i = 16 * t + 4 * r + q, j = 16 * mt + li;
-            if (own(t) && i < NX && j < NX) pw[j + i * NX] = pp[t][mt][r];
+            if (i < NX && j < NX) pw[j + i * NX] = pp[t][mt][r];
           }
     }
     RW2_PROF(1);
@@ -305,18 +342,11 @@ __device__ __forceinline__ void rw2_body(BwdArgs a) {
     };
 
     RW2_PROF(2);
-    // Qxu^T in the layout of H^T (row u = 16 tu + 4r + q, column x = 16c + li), RAW
-    d4 hq[TU][T];
-    auto issue_hq = [&](int tu) __attribute__((always_inline)) {   // (one control tile at a time: 40 registers, not 80, beside P+)
-      const double* hp = kr + KL.off[RTOC_KKT_QXU];
-#pragma unroll
-      for (int c = 0; c < T; ++c)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int u = 16 * tu + 4 * r + q, x = 16 * c + li;
-          hq[tu][c][r] = hp[((x < NX) ? x : NX - 1) + ((u < NU) ? u : NU - 1) * NX];
-        }
-    };
+    // ---- the O(n^2 nu) part, split by ROLE: wave 0 forms G (it needs the rows v of PB only), factorises it and solves for t, k;
+    //      wave 1 forms all of PB and H^T beside it.  They meet once: Y = L^-1, t and A^T z cross over, H^T's column tiles of wave 0
+    //      through the place of wave 1's G.  From there each wave forms Z^T, K, Z Z^T and s for its own column tiles (wave 1 Z^T for
+    //      all of them: its tiles (c, t >= 3) of Z Z^T meet every column) ----
+    constexpr int C0 = (W == 0) ? G0 / 4 : 0;   // first row tile of PB this wave forms
     d4 acc[T][TU];   // PB = P+[:, v] Bv: rows x = 16c + .., columns u = 16 tu + li; column NU: z
 #pragma unroll
     for (int c = 0; c < T; ++c)
@@ -339,41 +369,40 @@ __device__ __forceinline__ void rw2_body(BwdArgs a) {
 #pragma unroll
         for (int tu = 0; tu < TU; ++tu)
 #pragma unroll
-          for (int c = 0; c < T; ++c) acc[c][tu] = mfma16(pp[g / 4][c][g % 4], bvf[g - G0][tu], acc[c][tu]);
-      d4 gacc[TU][TU];
+          for (int c = C0; c < T; ++c) acc[c][tu] = mfma16(pp[g / 4][c][g % 4], bvf[g - G0][tu], acc[c][tu]);
+      if constexpr (W == 0) {
+        d4 gacc[TU][TU];
 #pragma unroll
-      for (int tr = 0; tr < TU; ++tr)
+        for (int tr = 0; tr < TU; ++tr)
 #pragma unroll
-        for (int tu = 0; tu < TU; ++tu) gacc[tr][tu] = zero4();
+          for (int tu = 0; tu < TU; ++tu) gacc[tr][tu] = zero4();
 #pragma unroll
-      for (int g = G0; g < KG; ++g)
+        for (int g = G0; g < KG; ++g)
 #pragma unroll
-        for (int tu = 0; tu < TU; ++tu) {
-          double bop = acc[g / 4][tu][g % 4];
-          if (tu == TU - 1) bop = (li == NUC) ? zrow(g) : bop;
+          for (int tu = 0; tu < TU; ++tu) {
+            double bop = acc[g / 4][tu][g % 4];
+            if (tu == TU - 1) bop = (li == NUC) ? zrow(g) : bop;
 #pragma unroll
-          for (int tr = 0; tr < TU; ++tr) gacc[tr][tu] = mfma16(bvf[g - G0][tr], bop, gacc[tr][tu]);
-        }
-#pragma unroll
-      for (int tr = 0; tr < TU; ++tr)
-#pragma unroll
-        for (int tu = 0; tu < TU; ++tu)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int u0 = 16 * tr + 4 * r + q, u1 = 16 * tu + li;
-            if (u0 < NU && u1 < NU) sG[u0 + u1 * NU] += gacc[tr][tu][r];
-            if (tu == TU - 1 && u0 < NU && li == NUC) sLup[u0] = sStrip[ST_LUO + u0] - gacc[tr][tu][r];   // lu' = lu - Bv^T z_v
+            for (int tr = 0; tr < TU; ++tr) gacc[tr][tu] = mfma16(bvf[g - G0][tr], bop, gacc[tr][tu]);
           }
-      rv_lds_sync();
+#pragma unroll
+        for (int tr = 0; tr < TU; ++tr)
+#pragma unroll
+          for (int tu = 0; tu < TU; ++tu)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int u0 = 16 * tr + 4 * r + q, u1 = 16 * tu + li;
+              if (u0 < NU && u1 < NU) sG[u0 + u1 * NU] += gacc[tr][tu][r];
+              if (tu == TU - 1 && u0 < NU && li == NUC) sLup[u0] = sStrip[ST_LUO + u0] - gacc[tr][tu][r];   // lu' = lu - Bv^T z_v
+            }
+        rv_lds_sync();
+      }
     }
     RW2_PROF(3);
-    // z into the idle column NU of PB: column NU of H = A^T PB is then A^T z (on an impact grid point PB is that column alone)
-#pragma unroll
-    for (int g = 0; g < KG; ++g) acc[g / 4][TU - 1][g % 4] = (li == NUC) ? zrow(g) : acc[g / 4][TU - 1][g % 4];
 
+    const double ca = sA[NP_ + NP_ * LDA], cc = sA[NP_ + (NV + NP_) * LDA];   // A[NP][NP], A[NP][NV + NP] (row NP is a corner-group row: staged)
     // structured rows of A^T [.] for one column of C tiles (rows = state rows): dst[k] += ca src[k], dst[NV + k] += cc src[k],
     // k in [NP, NV); NV + k lies TS tiles, RS registers and QS q-groups below k (tests/rw_lane_model.py: struct_rows_add)
-    const double ca = sA[NP_ + NP_ * LDA], cc = sA[NP_ + (NV + NP_) * LDA];   // A[NP][NP], A[NP][NV + NP] (row NP is a corner-group row: staged)
     auto struct_rows_add = [&](d4(&dst)[T], const d4(&src)[T], int cmax) __attribute__((always_inline)) {
       d4 rot[T];
 #pragma unroll
@@ -414,7 +443,6 @@ __device__ __forceinline__ void rw2_body(BwdArgs a) {
       const bool rowok = group_all_dense(g) || (k < NP_ || (k >= NV && k < NX));
       return (rowok && (16 * c + 15 < NX || j < NX)) ? v : 0.0;
     };
-
     // structured rows of k group g as a B fragment of column tile c: B[k = 4g + q][x = 16c + li] = ca (x == k) + cc (x == NV + k), k in [NP, NV)
     auto struct_hit = [](int g, int c) {
       const int k0 = (4 * g > NP_) ? 4 * g : NP_, k1 = (4 * g + 3 < NV - 1) ? 4 * g + 3 : NV - 1;
@@ -427,19 +455,24 @@ __device__ __forceinline__ void rw2_body(BwdArgs a) {
       return (k >= NP_ && k < NV) ? v : 0.0;
     };
 
-    d4 zt[TU][T];   // Z^T = Y H^T
-    if (!impact) {
-      // ================= 4. H^T = Qxu^T + PB^T A DIRECTLY in the layout Z^T = Y H^T reads (rows u, columns x): PB's C tiles are the
-      //                      A operand as they stand, A's fragments the B operand; the structured rows k of A (ca e_k | cc e_NV+k)
-      //                      are synthesised fragments that meet at most three column tiles.  Row NUC of control tile TU - 1 is
-      //                      the rider (A^T z)^T.  No transposes, no rotations (tests/rw_lane_model.py: direct_ht) =================
-      d4 hT[TU][T];
+    if constexpr (W == 1) {
+      // z into the idle column NU of PB: row NU of H^T = PB^T A is then (A^T z)^T (on an impact grid point PB is that column alone)
+#pragma unroll
+      for (int g = 0; g < KG; ++g) acc[g / 4][TU - 1][g % 4] = (li == NUC) ? zrow(g) : acc[g / 4][TU - 1][g % 4];
+      // ================= 4. H^T DIRECTLY in the layout Z^T = Y H^T reads: PB's C tiles are the A operand as they stand, A's fragments
+      //                      the B operand; the structured rows k of A (ca e_k | cc e_NV+k) are synthesised fragments that meet at
+      //                      most three column tiles.  No transposes, no rotations (tests/rw_lane_model.py: direct_ht).  On an
+      //                      impact grid point (riccati_factorizer.cpp:178-197: no controls) the rider row alone =================
 #pragma unroll
       for (int tu = 0; tu < TU; ++tu) {
+        if (impact && tu < TU - 1) continue;
         asm volatile("" ::: "memory");   // (A's fragments are re-read per control tile: held across the tiles they would not fit beside P+)
-        issue_hq(tu);
+        if (!impact) {
+          seed(tu);
+        } else {
 #pragma unroll
-        for (int c = 0; c < T; ++c) hT[tu][c] = zero4();
+          for (int c = 0; c < T; ++c) hT[tu][c] = zero4();
+        }
 #pragma unroll
         for (int g = 0; g < KG; ++g) {
           const double aop = acc[g / 4][tu][g % 4];
@@ -452,27 +485,37 @@ __device__ __forceinline__ void rw2_body(BwdArgs a) {
             hT[tu][c] = mfma16(aop, bop, hT[tu][c]);
           }
         }
-        if (tu == TU - 1) {   // the rider: w0 = A^T z
+        if (tu == TU - 1) {   // the rider: w0 = A^T z; its row leaves H^T (rows u >= NU are zero otherwise: Bv's fragments are masked)
 #pragma unroll
           for (int c = 0; c < T; ++c) {
             const int x = 16 * c + li;
             if (q == NUC % 4 && x < NX) sW0[x] = hT[tu][c][NUC / 4];
+            hT[tu][c][NUC / 4] = (q == NUC % 4) ? 0.0 : hT[tu][c][NUC / 4];
           }
         }
+      }
+      if (!impact) {   // (behind the last read of Qxu: the hand-over takes its place)
+        rv_lds_sync();
 #pragma unroll
-        for (int c = 0; c < T; ++c)
+        for (int tu = 0; tu < TU; ++tu)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int u = 16 * tu + 4 * r + q, x = 16 * c + li;
-            hT[tu][c][r] = (u < NU && x < NX) ? hT[tu][c][r] + hq[tu][c][r] : 0.0;
-          }
+          for (int c = 0; c < T; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int u = 16 * tu + 4 * r + q;
+              if (u < NU) {
+                if (c <= TSPLIT) sHX[u * LDH + 16 * c + li] = hT[tu][c][r];
+                else sHB[u * LDB + 16 * (c - TSPLIT - 1) + li] = hT[tu][c][r];
+              }
+            }
       }
       RW2_PROF(4);
+    } else {
       // ================= 3. LLT(G) (riccati_factorizer.cpp:49), Y = L^-1; t = Y lu', k = -Y^T t =================
-      if (wave_llt_inv_blocked<NU, NU>(sG, sG, pw_ + M::P_LINV, sY, scr, lane)) stat |= RTOC_STAT_QUU_NOT_SPD;
-      rv_lds_sync();
-      RW2_PROF(5);
-      {
+      if (!impact) {
+        if (wave_llt_inv_blocked<NU, NU>(sG, sG, pw_ + M::P_LINV, sY, scr, lane)) stat |= RTOC_STAT_QUU_NOT_SPD;
+        rv_lds_sync();
+        RW2_PROF(5);
         const int u = (lane < NU) ? lane : 0;
         double tv = 0.0;
 #pragma unroll
@@ -482,91 +525,51 @@ __device__ __forceinline__ void rw2_body(BwdArgs a) {
         double kv = 0.0;
 #pragma unroll
         for (int j = 0; j < NU; ++j) kv = __builtin_fma(sY[j + u * NU], sT[j], kv);
-        if (W == 0 && lane < NU) rr[RL.off[RTOC_RIC_KV] + lane] = -kv;
+        if (lane < NU) rr[RL.off[RTOC_RIC_KV] + lane] = -kv;
         if (is_bad(kv)) stat |= RTOC_STAT_NAN;
       }
-      RW2_PROF(6);
-      // ================= 6. Z^T = Y H^T (Y lower triangular: the tile above the diagonal is skipped) =================
-#pragma unroll
-      for (int tu = 0; tu < TU; ++tu) {
-#pragma unroll
-        for (int c = 0; c < T; ++c) zt[tu][c] = zero4();
-#pragma unroll
-        for (int gj = 0; gj < KGU; ++gj) {
-          if (gj >= 4 * (tu + 1)) continue;
-          const int m = 16 * tu + li, k = 4 * gj + q;
-          const bool ok = m < NU && k < NU;
-          const double v = sY[(ok ? m : 0) + (ok ? k : 0) * NU];
-          const double av = ok ? v : 0.0;
-#pragma unroll
-          for (int c = 0; c < T; ++c) zt[tu][c] = mfma16(av, hT[gj / 4][c][gj % 4], zt[tu][c]);
-        }
-      }
-      RW2_PROF(7);
-      // ================= 7. K = -Y^T Z^T (riccati_factorizer.cpp:55), tile by tile -> HBM (K row-major) =================
-      double chk = 0.0;
-#pragma unroll
-      for (int tu = 0; tu < TU; ++tu) {
-        double yv[KGU];
-#pragma unroll
-        for (int gj = 0; gj < KGU; ++gj) {
-          const int m = 16 * tu + li, k = 4 * gj + q;
-          const bool ok = m < NU && k < NU;
-          const double v = sY[(ok ? k : 0) + (ok ? m : 0) * NU];
-          yv[gj] = ok ? -v : 0.0;
-        }
-#pragma unroll
-        for (int c = 0; c < T; ++c) {
-          if (!own(c)) continue;   // this wave's column tiles of K
-          d4 kk = zero4();
-#pragma unroll
-          for (int gj = 0; gj < KGU; ++gj) {
-            if (gj < 4 * tu) continue;
-            kk = mfma16(yv[gj], zt[gj / 4][c][gj % 4], kk);
-          }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int u = 16 * tu + 4 * r + q, x = 16 * c + li;
-            if (u < NU && x < NX) rr[RL.off[RTOC_RIC_K] + u * NX + x] = kk[r];
-            chk = __builtin_fma(kk[r], 0.0, chk);
-          }
-        }
-      }
-      if (is_bad(chk)) stat |= RTOC_STAT_NAN;
-    } else {
-      // impact grid point (riccati_factorizer.cpp:178-197): no controls; A^T z by the rider column alone
-      d4 hx[T];   // row NUC: (A^T z)^T
-#pragma unroll
-      for (int c = 0; c < T; ++c) hx[c] = zero4();
-#pragma unroll
-      for (int g = 0; g < KG; ++g) {
-        const double aop = acc[g / 4][TU - 1][g % 4];
-#pragma unroll
-        for (int c = 0; c < T; ++c) {
-          const bool hit = struct_hit(g, c);
-          if (!group_dense(g) && !hit) continue;
-          double bop = group_dense(g) ? afrag(g, c) : 0.0;
-          if (hit) bop += struct_frag(g, c);
-          hx[c] = mfma16(aop, bop, hx[c]);
-        }
-      }
-#pragma unroll
-      for (int c = 0; c < T; ++c) {
-        const int x = 16 * c + li;
-        if (q == NUC % 4 && x < NX) sW0[x] = hx[c][NUC / 4];
-      }
-#pragma unroll
-      for (int tu = 0; tu < TU; ++tu)
-#pragma unroll
-        for (int c = 0; c < T; ++c) zt[tu][c] = zero4();
     }
-
-    RW2_PROF(8);
-    // ================= 8. F starts from Qxx (upper tiles; off-diagonal ones symmetrised: brrf.cpp:85 folded into the start
-    //                      value), F -= Z Z^T (brrf.cpp:82-84) =================
-    // F accumulates from ZERO (-Z Z^T, then A^T W column by column); G, Y and the scratch are dead: the first two panels of Qxx
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
+    RW2_PROF(6);
+    // ---- the hand-over: behind the first barrier each wave takes what it needs of the other's block into registers / its own block,
+    //      behind the second one nobody reads the other's block any more (its Qxx panels will land there) ----
+    rw2_sync();
+    double ya[TU][KGU];   // wave 1's copy of Y's fragments as the A operand of Z^T = Y H^T
+    auto yaf = [&](int tu, int gj) __attribute__((always_inline)) -> double {
+      const int m = 16 * tu + li, k = 4 * gj + q;
+      const bool ok = m < NU && k < NU;
+      const double v = sY[(ok ? m : 0) + (ok ? k : 0) * NU];
+      return ok ? v : 0.0;
+    };
+    auto ykf = [&](int tu, int gj) __attribute__((always_inline)) -> double {   // -Y[k][m], the A operand of K = -Y^T Z^T (wave 0)
+      const int m = 16 * tu + li, k = 4 * gj + q;
+      const bool ok = m < NU && k < NU;
+      const double v = sY[(ok ? k : 0) + (ok ? m : 0) * NU];
+      return ok ? -v : 0.0;
+    };
+    if constexpr (W == 1) {
+      if (!impact) {
+#pragma unroll
+        for (int tu = 0; tu < TU; ++tu)
+#pragma unroll
+          for (int gj = 0; gj < KGU; ++gj) ya[tu][gj] = (gj < 4 * (tu + 1)) ? yaf(tu, gj) : 0.0;
+        if (lane < NU) sT[lane] = pw0[M::P_T + lane];
+      }
+    } else {
+      if (!impact) {
+#pragma unroll
+        for (int tu = 0; tu < TU; ++tu)
+#pragma unroll
+          for (int c = 0; c <= TSPLIT; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int u = 16 * tu + 4 * r + q;
+              const double v = sHX[((u < NU) ? u : 0) * LDH + 16 * c + li];
+              hT[tu][c][r] = (u < NU) ? v : 0.0;
+            }
+      }
+      for (int e = lane; e < NX; e += 64) sW0[e] = pw1[M::P_W0 + e];
+    }
+    rw2_sync();
     // The panels this wave needs: every p that meets one of its tiles -- (p, t >= p) with t its own, (c < p, p) with p its own --,
     // i.e. 0 .. its last column tile.  Panel k is consumed at slot k of the sequence [behind s; then, per column iteration of this
     // wave: behind its W product, at its end]; panel k + 2 takes its buffer there (two panels in flight).
@@ -585,20 +588,126 @@ __device__ __forceinline__ void rw2_body(BwdArgs a) {
         issue_qxx_panel(kr, k + 2);
       }
     };
-    issue_qxx_panel(kr, 0);   // (panel 1 covers A^T z and t, which the update of s below still reads: behind it)
+    // F accumulates from ZERO (-Z Z^T, then A^T W column by column) and takes its start value Qxx (upper tiles; off-diagonal ones
+    // symmetrised: brrf.cpp:85 folded in) panel by panel.  Wave 1's block is dead from here (the hand-over has been read): its first
+    // panel now; wave 0's behind its last read of Y
+    if (W == 1) issue_qxx_panel(kr, 0);   // (panel 1 covers A^T z and t, which the update of s below still reads: behind it)
 #pragma unroll
     for (int c = 0; c < T; ++c)
 #pragma unroll
       for (int t = c; t < T; ++t)
         if (own(t)) f[c][t] = zero4();
-    if (!impact) {
+    // Z^T = Y H^T of one column tile (Y lower triangular: the tile above the diagonal is skipped); K = -Y^T Z^T of it -> HBM (row-major)
+    auto zt_col = [&](d4(&zc)[TU], const d4(&hc)[TU]) __attribute__((always_inline)) {
 #pragma unroll
-      for (int gu = 0; gu < KGU; ++gu)
+      for (int tu = 0; tu < TU; ++tu) {
+        zc[tu] = zero4();
+#pragma unroll
+        for (int gj = 0; gj < KGU; ++gj) {
+          if (gj >= 4 * (tu + 1)) continue;
+          const double av = (W == 1) ? ya[tu][gj] : yaf(tu, gj);
+          zc[tu] = mfma16(av, hc[gj / 4][gj % 4], zc[tu]);
+        }
+      }
+    };
+    double chk = 0.0;
+    auto k_col = [&](int c, const d4(&zc)[TU]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int tu = 0; tu < TU; ++tu) {
+        d4 kk = zero4();
+#pragma unroll
+        for (int gj = 0; gj < KGU; ++gj) {
+          if (gj < 4 * tu) continue;
+          kk = mfma16(ykf(tu, gj), zc[gj / 4][gj % 4], kk);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int u = 16 * tu + 4 * r + q, x = 16 * c + li;
+          if (u < NU && x < NX) rr[RL.off[RTOC_RIC_K] + u * NX + x] = kk[r];
+          chk = __builtin_fma(kk[r], 0.0, chk);
+        }
+      }
+    };
+    d4 zt[TU][T];   // Z^T = Y H^T: the column tiles this wave owns stay
+    if (!impact) {
+      if constexpr (W == 0) {
+        // ================= 6. / 7. wave 0: Z^T of its column tiles, and K = -Y^T Z^T (riccati_factorizer.cpp:55) of ALL column tiles --
+        //                          wave 1's pass through (H^T from the place of Bv), its way from here is the longer one =================
+#pragma unroll
+        for (int c = 0; c < T; ++c) {
+          d4 hc[TU], zc[TU];
+#pragma unroll
+          for (int tu = 0; tu < TU; ++tu) {
+            if (c <= TSPLIT) {
+              hc[tu] = hT[tu][c];
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int u = 16 * tu + 4 * r + q;
+                const double v = sHB[((u < NU) ? u : 0) * LDB + 16 * (c - TSPLIT - 1) + li];
+                hc[tu][r] = (u < NU) ? v : 0.0;
+              }
+            }
+          }
+          zt_col(zc, hc);
+          k_col(c, zc);
+          if (c <= TSPLIT) {
+#pragma unroll
+            for (int tu = 0; tu < TU; ++tu) zt[tu][c] = zc[tu];
+          }
+        }
+        if (is_bad(chk)) stat |= RTOC_STAT_NAN;
+      } else {
+        // ================= 6. / 8. wave 1: Z^T of its own column tiles first (they stay), F -= Z Z^T (brrf.cpp:82-84) among them; then
+        //                          the column tiles of wave 0 one at a time: each meets wave 1's tiles of its row and dies =================
+#pragma unroll
+        for (int c = TSPLIT + 1; c < T; ++c) {
+          d4 hc[TU], zc[TU];
+#pragma unroll
+          for (int tu = 0; tu < TU; ++tu) hc[tu] = hT[tu][c];
+          zt_col(zc, hc);
+#pragma unroll
+          for (int tu = 0; tu < TU; ++tu) zt[tu][c] = zc[tu];
+        }
+#pragma unroll
+        for (int gu = 0; gu < KGU; ++gu)
+#pragma unroll
+          for (int c = TSPLIT + 1; c < T; ++c)
+#pragma unroll
+            for (int t = c; t < T; ++t) f[c][t] = mfma16(-zt[gu / 4][c][gu % 4], zt[gu / 4][t][gu % 4], f[c][t]);
+#pragma unroll
+        for (int c = 0; c <= TSPLIT; ++c) {
+          d4 hc[TU], zc[TU];
+#pragma unroll
+          for (int tu = 0; tu < TU; ++tu) hc[tu] = hT[tu][c];
+          zt_col(zc, hc);
+#pragma unroll
+          for (int gu = 0; gu < KGU; ++gu)
+#pragma unroll
+            for (int t = TSPLIT + 1; t < T; ++t) f[c][t] = mfma16(-zc[gu / 4][gu % 4], zt[gu / 4][t][gu % 4], f[c][t]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int tu = 0; tu < TU; ++tu)
 #pragma unroll
         for (int c = 0; c < T; ++c)
+          if (own(c)) zt[tu][c] = zero4();
+    }
+    RW2_PROF(8);
+    if constexpr (W == 0) {
+      // ================= 8. wave 0: G, Y and the scratch are dead: the first panel of Qxx; F -= Z Z^T (brrf.cpp:82-84) =================
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      issue_qxx_panel(kr, 0);
+      if (!impact) {
 #pragma unroll
-          for (int t = c; t < T; ++t)
-            if (own(t)) f[c][t] = mfma16(-zt[gu / 4][c][gu % 4], zt[gu / 4][t][gu % 4], f[c][t]);
+        for (int gu = 0; gu < KGU; ++gu)
+#pragma unroll
+          for (int c = 0; c <= TSPLIT; ++c)
+#pragma unroll
+            for (int t = c; t <= TSPLIT; ++t) f[c][t] = mfma16(-zt[gu / 4][c][gu % 4], zt[gu / 4][t][gu % 4], f[c][t]);
+      }
     }
     RW2_PROF(9);
     // ---- s = A^T z - lx - H k = w0 - lx + Z t (brrf.cpp:86-90): column layout, per-lane partial sums + q-reduction; -> LDS (the s+
@@ -613,6 +722,7 @@ __device__ __forceinline__ void rw2_body(BwdArgs a) {
       }
 #pragma unroll
       for (int c = 0; c < T; ++c) {
+        if (!own(c)) continue;   // this wave's column tiles of s
         double part = 0.0;
 #pragma unroll
         for (int gu = 0; gu < KGU; ++gu) part = __builtin_fma(zt[gu / 4][c][gu % 4], tr_[gu], part);
@@ -622,10 +732,10 @@ __device__ __forceinline__ void rw2_body(BwdArgs a) {
         const double sn = sW0[jc] - sStrip[ST_LXO + jc] + part;
         if (q == 0 && j < NX) {
           sS[j] = sn;
-          if (W == 0) rr[RL.off[RTOC_RIC_S] + j] = sn;
+          rr[RL.off[RTOC_RIC_S] + j] = sn;
         }
-        if (W == 0 && q == 1 && j < NX) rr[RL.off[RTOC_RIC_PSI] + j] = 0.0;
-        if (W == 0 && q == 2 && j < NX) rr[RL.off[RTOC_RIC_PHI] + j] = 0.0;
+        if (q == 1 && j < NX) rr[RL.off[RTOC_RIC_PSI] + j] = 0.0;
+        if (q == 2 && j < NX) rr[RL.off[RTOC_RIC_PHI] + j] = 0.0;
       }
       if (W == 0 && lane < 5) rr[RL.off[RTOC_RIC_SCAL] + lane] = 0.0;
     }
@@ -756,8 +866,9 @@ __device__ __forceinline__ void rw2_body(BwdArgs a) {
     }
     rw2_sync();   // ... and has been read: the place belongs to A again
     if (st > lo) {
-      issue_bq(st - 1);
+      if (W == 1) issue_dma_qxu(st - 1);
       if (W == 0) {
+        issue_bq(st - 1);
         issue_dma_bv(st - 1);
         issue_dma_A(st - 1);
       }
@@ -779,7 +890,7 @@ __device__ __forceinline__ void rw2_body(BwdArgs a) {
           if (own(kt) && i < NX && j < NX) pw[j + i * NX] = pp[kt][mt][r];
         }
   }
-  if (W == 0 && stat) atomicOr(&a.status[b], stat);
+  if (stat) atomicOr(&a.status[b], stat);
 }
 
 template <int NV, int NU, int NS>
