@@ -3,14 +3,23 @@
 //
 // One wave cannot hold P+ (25 tiles) AND F (15 upper tiles): 320 of 512 registers before the first operand, and the compiler spills
 // 540 (6.7 ms per 1024 instances against the tile-split kernel's 4.8).  What does fit is P+ (200) + HALF of F + one column of W.  So
-// both waves keep the WHOLE value function and run the O(n^2 nu) part of the stage side by side, redundantly and without a word
-// between them -- z, PB, G, the 29 x 29 factorisation, H, Z^T: the same lane algebra as riccati_backward_rw.hpp, which
-// tests/rw_lane_model.py verifies for this shape --, and SPLIT the O(n^3) part: wave 0 owns the column tiles {0, 1, 2} of F, wave 1
-// {3, 4} (6 and 9 upper tiles: 252 and 228 MFMAs in the column loop), each its tiles of K, Z Z^T, the Qxx start values and the rows
-// of P it stores.  At the stage end the fifteen tiles of F meet in LDS -- in the place of A, which is dead by then -- and each wave
-// rebuilds its own copy of P+ = sym(F) from there (direct and transposed reads).  Four workgroup barriers per stage.
-// Shared LDS: the dense rows of A / the F exchange, the strip, the grid table; per wave: s+, G / Y / scratch / vectors (the landing
-// zone of its Qxx panels).  75 KB per instance.
+// both waves keep the WHOLE value function in registers, and the stage is split twice:
+//
+//  * the O(n^2 nu) part by ROLE.  Wave 0 forms the rows v of PB and G = Quu + Bv^T PB[v, :], factorises it (Y = L^-1) and solves for
+//    t and k; wave 1 stores P, forms all of PB and H^T = Qxu^T + PB^T A directly in the layout Z^T = Y H^T reads -- PB's C tiles are the
+//    A operand as they stand, the structured rows of A synthesised fragments, Qxu^T (by DMA, in wave 1's idle G / Y place) the start
+//    value of the accumulators; no transposes.  The 29 x 29 factorisation, whose column steps leave the matrix pipe idle, runs beside
+//    wave 1's 256 MFMAs.  They meet ONCE (two barriers): Y, t and A^T z cross over, H^T goes to wave 0 through LDS.
+//  * the O(n^3) part by COLUMN TILES of F: wave 0 owns {0, 1, 2}, wave 1 {3, 4} (6 and 9 upper tiles: 252 and 228 MFMAs in the column
+//    loop), each its tiles of Z^T, Z Z^T, s and the Qxx start values; wave 0, whose way is the shorter one, forms K for all column tiles,
+//    wave 1 meets wave 0's column tiles of Z^T one at a time and lets them die.  At the stage end the fifteen tiles of F meet in LDS -- in
+//    the place of A, which is dead by then -- and each wave rebuilds its own copy of P+ = sym(F) from there (direct and transposed reads),
+//    forming z = s+ - P+ Fx of the next grid point as the elements pass.
+//
+// Five workgroup barriers per stage.  Same lane algebra as riccati_backward_rw.hpp, which tests/rw_lane_model.py verifies for this
+// shape (the direct H^T product: direct_ht).  Shared LDS: the dense rows of A / the F exchange, two strips, the grid table, Bv / wave
+// 1's column tiles of H^T; per wave: G / Y / scratch / vectors (wave 0), Qxu / wave 0's column tiles of H^T (wave 1) -- the landing
+// zone of the wave's Qxx panels.  79 KB per instance.
 //
 // Same scope as riccati_backward_rw.hpp (rw_applies, rtoc_capi.hip): structured Fxx, no switching-time optimisation, switching-
 // constraint grid points as one-stage launches of the tile-split kernel, batches larger than the device's CU count.
@@ -80,6 +89,16 @@ __device__ __forceinline__ void rw2_body(BwdArgs a) {
   constexpr int TSPLIT = (C::T - 1) / 2;   // T = 5: wave 0 owns {0, 1, 2} (6 upper tiles), wave 1 {3, 4} (9)
   constexpr int LDH = 16 * (TSPLIT + 1);   // leading dimension of the H^T hand-over
   constexpr int LDB = 16 * (C::T - TSPLIT - 1);   // ... of wave 1's column tiles
+#ifndef RW2_PSPLIT
+#define RW2_PSPLIT 0
+#endif
+#ifndef RW2_S_BY_WAVE1
+#define RW2_S_BY_WAVE1 1
+#endif
+  constexpr bool S_W1 = RW2_S_BY_WAVE1 != 0;      // s of all column tiles by wave 1 (they all pass through its registers) / each wave its own
+  constexpr int PSPLIT = RW2_PSPLIT;                       // row tiles of the P stores wave 0 takes
+  constexpr int RID = C::NX % 16;                 // the idle column of the last column tile that carries lu' -> t -> k
+  static_assert(RID != 0, "an idle column in the last column tile");
   static_assert(NU * LDH <= M::P_Z - M::P_G, "H^T of wave 0's column tiles fits the place of wave 1's G, Y and scratch");
   static_assert(NU * LDB <= C::pad8(NV * NU + 1), "H^T of wave 1's column tiles fits the place of Bv");
   static_assert(C::NX * NU <= M::P_Z && KL_QXU_EVEN<NV, NU, NS>(), "Qxu fits wave 1's block ahead of z");
@@ -92,6 +111,7 @@ __device__ __forceinline__ void rw2_body(BwdArgs a) {
   static_assert(KL.off[RTOC_KKT_FXX] % 2 == 0 && KL.off[RTOC_KKT_FX] % 2 == 0 && KL.off[RTOC_KKT_QUU] % 2 == 0 && KL.off[RTOC_KKT_QXX] % 2 == 0 && KL.stride % 2 == 0 && NX % 2 == 0, "16-byte chunks");
   constexpr int ST_LXO = M::VOFF_LX, ST_LUO = M::VOFF_LU;   // offsets inside a strip (Fx at 0)
   extern __shared__ __attribute__((aligned(16))) double smem[];
+  const LdsAddr ldsp(smem);   // (32-bit LDS addresses for the DMA destinations)
   double* const sA = smem + M::OFF_A;
   double* const pw0 = smem + M::OFF_PW;                // wave 0's block: G, Y = L^-1, t live there (wave 0 factorises)
   double* const pw1 = pw0 + M::PWD;                    // wave 1's block: the place of its (unused) G / Y carries H^T to wave 0
@@ -103,7 +123,7 @@ __device__ __forceinline__ void rw2_body(BwdArgs a) {
   double* const sHX = pw1 + M::P_G;                    // H^T[u][x], x < LDH: the column tiles of wave 0
   double* const sHB = smem + M::OFF_BV;                // H^T[u][x - LDH], the column tiles of wave 1: in the place of Bv (dead behind PB)
   const double* const sQxu = pw1;                      // Qxu (flat, as in the record), by wave 1's DMA: under its s+ / G / Y / scratch
-  double* const sZ = pw_ + M::P_Z;
+  double* const sZ = pw0 + M::P_Z;                     // z: ONE copy, formed where P+ is rebuilt, each wave its column tiles
   double* const sW0 = pw_ + M::P_W0;
   double* const sLup = pw_ + M::P_LUP;
   double* const sT = pw_ + M::P_T;
@@ -130,9 +150,10 @@ __device__ __forceinline__ void rw2_body(BwdArgs a) {
 
   // ---- DMA: the dense k groups of A (rows [0, 4 G1) and [4 G0, 4 KG) of every column) into the padded compact layout; whole
   //      padded columns per piece, so that a piece differs from the next by a scalar ----
+  constexpr int NPC_A = (NX + 64 / HL - 1) / (64 / HL);   // DMA instructions of one A
   auto issue_dma_A = [&](int stage) __attribute__((always_inline)) {
     const double* kp = a.kkt + kinst + (size_t)stage * KL.stride + KL.off[RTOC_KKT_FXX];
-    constexpr int CPP = 64 / HL, NPC = (NX + CPP - 1) / CPP;
+    constexpr int CPP = 64 / HL, NPC = NPC_A;
     const unsigned col0 = (unsigned)lane / HL, ch0 = (unsigned)lane - col0 * HL;
     const unsigned rl = 2 * ch0;                                                        // compact row of the chunk
     const unsigned srow = (rl < 4 * G1) ? rl : ((rl < 4 * C::NDG) ? rl + 4 * (G0 - G1) : 0);   // (the padding chunk loads anything)
@@ -141,7 +162,7 @@ __device__ __forceinline__ void rw2_body(BwdArgs a) {
 #pragma unroll
       for (int p = 0; p < NPC; ++p) {
         if ((p + 1) * CPP <= NX || p * CPP + (int)col0 < NX)
-          __builtin_amdgcn_global_load_lds(kp + p * CPP * NX + voff, (lds_ptr_t)(sA + p * CPP * LDA), 16, 0, 0);
+          __builtin_amdgcn_global_load_lds(kp + p * CPP * NX + voff, ldsp(sA + p * CPP * LDA), 16, 0, 0);
       }
     }
   };
@@ -151,7 +172,7 @@ __device__ __forceinline__ void rw2_body(BwdArgs a) {
 #pragma unroll
     for (int p = 0; p < PBV; ++p) {
       const int n = lane + 64 * p;
-      if (64 * (p + 1) <= CBV || n < CBV) __builtin_amdgcn_global_load_lds(kp + 2 * n, (lds_ptr_t)(smem + M::OFF_BV + 128 * p), 16, 0, 0);
+      if (64 * (p + 1) <= CBV || n < CBV) __builtin_amdgcn_global_load_lds(kp + 2 * n, ldsp(smem + M::OFF_BV + 128 * p), 16, 0, 0);
     }
   };
   auto issue_dma_qxu = [&](int stage) __attribute__((always_inline)) {   // (wave 1: the start value of H^T)
@@ -160,7 +181,7 @@ __device__ __forceinline__ void rw2_body(BwdArgs a) {
 #pragma unroll
     for (int p = 0; p < PX; ++p) {
       const int n = lane + 64 * p;
-      if (64 * (p + 1) <= CX || n < CX) __builtin_amdgcn_global_load_lds(kp + 2 * n, (lds_ptr_t)(pw1 + 128 * p), 16, 0, 0);
+      if (64 * (p + 1) <= CX || n < CX) __builtin_amdgcn_global_load_lds(kp + 2 * n, ldsp(pw1 + 128 * p), 16, 0, 0);
     }
   };
   auto issue_dma_strip = [&](int stage) __attribute__((always_inline)) {
@@ -169,7 +190,7 @@ __device__ __forceinline__ void rw2_body(BwdArgs a) {
     for (int p = 0; p < M::PS; ++p) {
       const int n = lane + 64 * p;
       if (64 * (p + 1) <= M::CV || n < M::CV)
-        __builtin_amdgcn_global_load_lds(kp + 2 * n, (lds_ptr_t)(smem + M::OFF_ST + (stage & 1) * M::STRIP + 128 * p), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(kp + 2 * n, ldsp(smem + M::OFF_ST + (stage & 1) * M::STRIP + 128 * p), 16, 0, 0);
     }
   };
 
@@ -214,7 +235,7 @@ __device__ __forceinline__ void rw2_body(BwdArgs a) {
 #pragma unroll
     for (int p = 0; p < PQ; ++p) {
       const int n = lane + 64 * p;
-      if (64 * (p + 1) <= CQ || n < CQ) __builtin_amdgcn_global_load_lds(gp + 2 * n, (lds_ptr_t)(sG + 128 * p), 16, 0, 0);
+      if (64 * (p + 1) <= CQ || n < CQ) __builtin_amdgcn_global_load_lds(gp + 2 * n, ldsp(sG + 128 * p), 16, 0, 0);
     }
   };
   // Qxx comes in by DMA too, one column tile (16 columns, all rows: 8 KB, contiguous in the record) at a time into one of two padded
@@ -230,7 +251,7 @@ __device__ __forceinline__ void rw2_body(BwdArgs a) {
 #pragma unroll
     for (int col = 0; col < 16; ++col) {
       if (16 * p + col >= NX) continue;
-      if (lane < NX / 2) __builtin_amdgcn_global_load_lds(qb_ + col * NX + 2 * lane, (lds_ptr_t)(dst + col * LDQ), 16, 0, 0);
+      if (lane < NX / 2) __builtin_amdgcn_global_load_lds(qb_ + col * NX + 2 * lane, ldsp(dst + col * LDQ), 16, 0, 0);
     }
   };
   auto qxx_seed_panel = [&](int p) __attribute__((always_inline)) {
@@ -268,7 +289,7 @@ __device__ __forceinline__ void rw2_body(BwdArgs a) {
   // z = s+ - P+ Fx (brrf.cpp:86) of the first grid point of the segment: per-lane partial sums over the rows a lane holds, q-reduction
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   rw2_sync();   // the strip of grid point hi has landed (wave 0's DMA)
-  {
+  if (W == 0) {
     double fxr[KG];
 #pragma unroll
     for (int g = 0; g < KG; ++g) {
@@ -293,8 +314,9 @@ __device__ __forceinline__ void rw2_body(BwdArgs a) {
     lane &= 63;
     li = lane & 15;
     q = lane >> 4;
-    // everything this grid point reads from LDS has landed: wave 0's DMA of A and of the strip, this wave's own Quu and Bv
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // what PB and G read has landed: wave 0's DMA of the strip, Bv and Quu.  A (35 KB) and Qxu are WAVE 1's requests: it waits for
+    // them itself ahead of H, behind PB; wave 0 reads A behind the hand-over barrier, which wave 1 reaches later still
+    if (W == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     rw2_sync();
     const int gword = __builtin_amdgcn_readfirstlane(sGrid[st]);
     const bool impact = (gword & 0xff) == RTOC_GRID_IMPACT;   // (read behind the barrier below: wave 0 writes the table)
@@ -319,10 +341,11 @@ __device__ __forceinline__ void rw2_body(BwdArgs a) {
           hT[tu][c][r] = ok ? v : 0.0;
         }
     };
-    // ---- P of grid point st + 1 -> HBM from the registers that hold it as P+ all stage long: by wave 1 -- whose way to the
-    //      hand-over of H^T is the shorter one --, at the stage top: the stores drain behind the PB / H products and never stand
-    //      between a Qxx panel and its counted wait (element (i, j) through its mirror (j, i): li along the contiguous index) ----
-    if (W == 1 && st < hi) {
+    // ---- P of grid point st + 1 -> HBM from the registers that hold it as P+ all stage long, at the stage top: the stores drain
+    //      behind the PB / G / H products and never stand between a Qxx panel and its counted wait (element (i, j) through its
+    //      mirror (j, i): li along the contiguous index).  Row tiles [0, PSPLIT) by wave 0, the rest by wave 1: what evens out
+    //      their ways to the hand-over ----
+    if (st < hi) {
       double* pw = a.ric + rinst + (size_t)(st + 1) * RL.stride + RL.off[RTOC_RIC_P];
 #pragma unroll
       for (int t = 0; t < T; ++t)
@@ -331,7 +354,7 @@ __device__ __forceinline__ void rw2_body(BwdArgs a) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int i = 16 * t + 4 * r + q, j = 16 * mt + li;
-            if (i < NX && j < NX) pw[j + i * NX] = pp[t][mt][r];
+            if ((t < PSPLIT) == (W == 0) && i < NX && j < NX) pw[j + i * NX] = pp[t][mt][r];
           }
     }
     RW2_PROF(1);
@@ -399,8 +422,13 @@ __device__ __forceinline__ void rw2_body(BwdArgs a) {
       }
     }
     RW2_PROF(3);
-
-    const double ca = sA[NP_ + NP_ * LDA], cc = sA[NP_ + (NV + NP_) * LDA];   // A[NP][NP], A[NP][NV + NP] (row NP is a corner-group row: staged)
+    double ca = 0.0, cc = 0.0;   // A[NP][NP], A[NP][NV + NP] (row NP is a corner-group row: staged)
+    if (W == 1) {                // A and Qxu have landed (this wave's DMA)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      ca = sA[NP_ + NP_ * LDA];
+      cc = sA[NP_ + (NV + NP_) * LDA];
+    }
     // structured rows of A^T [.] for one column of C tiles (rows = state rows): dst[k] += ca src[k], dst[NV + k] += cc src[k],
     // k in [NP, NV); NV + k lies TS tiles, RS registers and QS q-groups below k (tests/rw_lane_model.py: struct_rows_add)
     auto struct_rows_add = [&](d4(&dst)[T], const d4(&src)[T], int cmax) __attribute__((always_inline)) {
@@ -511,29 +539,19 @@ __device__ __forceinline__ void rw2_body(BwdArgs a) {
       }
       RW2_PROF(4);
     } else {
-      // ================= 3. LLT(G) (riccati_factorizer.cpp:49), Y = L^-1; t = Y lu', k = -Y^T t =================
+      // ================= 3. LLT(G) (riccati_factorizer.cpp:49), Y = L^-1.  t = Y lu' and k = -Y^T t ride in Z^T = Y H^T and
+      //                      K = -Y^T Z^T: lu' is the idle column NX of H^T's last column tile (the hand-over below) =================
       if (!impact) {
         if (wave_llt_inv_blocked<NU, NU>(sG, sG, pw_ + M::P_LINV, sY, scr, lane)) stat |= RTOC_STAT_QUU_NOT_SPD;
         rv_lds_sync();
         RW2_PROF(5);
-        const int u = (lane < NU) ? lane : 0;
-        double tv = 0.0;
-#pragma unroll
-        for (int j = 0; j < NU; ++j) tv = __builtin_fma(sY[u + j * NU], sLup[j], tv);
-        if (lane < NU) sT[lane] = tv;
-        rv_lds_sync();
-        double kv = 0.0;
-#pragma unroll
-        for (int j = 0; j < NU; ++j) kv = __builtin_fma(sY[j + u * NU], sT[j], kv);
-        if (lane < NU) rr[RL.off[RTOC_RIC_KV] + lane] = -kv;
-        if (is_bad(kv)) stat |= RTOC_STAT_NAN;
       }
     }
     RW2_PROF(6);
     // ---- the hand-over: behind the first barrier each wave takes what it needs of the other's block into registers / its own block,
     //      behind the second one nobody reads the other's block any more (its Qxx panels will land there) ----
     rw2_sync();
-    double ya[TU][KGU];   // wave 1's copy of Y's fragments as the A operand of Z^T = Y H^T
+    double ya[TU][KGU];   // wave 1's copy of Y's fragments as the A operand of Z^T = Y H^T (five column tiles pass by them)
     auto yaf = [&](int tu, int gj) __attribute__((always_inline)) -> double {
       const int m = 16 * tu + li, k = 4 * gj + q;
       const bool ok = m < NU && k < NU;
@@ -552,7 +570,16 @@ __device__ __forceinline__ void rw2_body(BwdArgs a) {
         for (int tu = 0; tu < TU; ++tu)
 #pragma unroll
           for (int gj = 0; gj < KGU; ++gj) ya[tu][gj] = (gj < 4 * (tu + 1)) ? yaf(tu, gj) : 0.0;
-        if (lane < NU) sT[lane] = pw0[M::P_T + lane];
+        // lu' (wave 0 formed it beside G) -> column NX of H^T: in this wave's registers and in wave 0's copy of the last column tile
+#pragma unroll
+        for (int tu = 0; tu < TU; ++tu)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int u = 16 * tu + 4 * r + q;
+            const double v = pw0[M::P_LUP + ((u < NU) ? u : 0)];
+            hT[tu][T - 1][r] = (li == RID && u < NU) ? v : hT[tu][T - 1][r];
+          }
+        if (lane < NU) sHB[lane * LDB + 16 * (T - TSPLIT - 2) + RID] = pw0[M::P_LUP + lane];
       }
     } else {
       if (!impact) {
@@ -567,7 +594,10 @@ __device__ __forceinline__ void rw2_body(BwdArgs a) {
               hT[tu][c][r] = (u < NU) ? v : 0.0;
             }
       }
-      for (int e = lane; e < NX; e += 64) sW0[e] = pw1[M::P_W0 + e];
+      if (!S_W1)
+        for (int e = lane; e < NX; e += 64) sW0[e] = pw1[M::P_W0 + e];
+      ca = sA[NP_ + NP_ * LDA];   // (wave 1 waited for A ahead of H)
+      cc = sA[NP_ + (NV + NP_) * LDA];
     }
     rw2_sync();
     // The panels this wave needs: every p that meets one of its tiles -- (p, t >= p) with t its own, (c < p, p) with p its own --,
@@ -605,10 +635,18 @@ __device__ __forceinline__ void rw2_body(BwdArgs a) {
 #pragma unroll
         for (int gj = 0; gj < KGU; ++gj) {
           if (gj >= 4 * (tu + 1)) continue;
-          const double av = (W == 1) ? ya[tu][gj] : yaf(tu, gj);
-          zc[tu] = mfma16(av, hc[gj / 4][gj % 4], zc[tu]);
+          zc[tu] = mfma16((W == 1) ? ya[tu][gj] : yaf(tu, gj), hc[gj / 4][gj % 4], zc[tu]);
         }
       }
+    };
+    auto t_out = [&](const d4(&zc)[TU]) __attribute__((always_inline)) {   // the rider of the last column tile: t = Y lu' -> this wave's sT
+#pragma unroll
+      for (int tu = 0; tu < TU; ++tu)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int u = 16 * tu + 4 * r + q;
+          if (li == RID && u < NU) sT[u] = zc[tu][r];
+        }
     };
     double chk = 0.0;
     auto k_col = [&](int c, const d4(&zc)[TU]) __attribute__((always_inline)) {
@@ -624,15 +662,36 @@ __device__ __forceinline__ void rw2_body(BwdArgs a) {
         for (int r = 0; r < 4; ++r) {
           const int u = 16 * tu + 4 * r + q, x = 16 * c + li;
           if (u < NU && x < NX) rr[RL.off[RTOC_RIC_K] + u * NX + x] = kk[r];
+          if (c == T - 1 && u < NU && li == RID) rr[RL.off[RTOC_RIC_KV] + u] = kk[r];   // the rider: k = -Y^T t
           chk = __builtin_fma(kk[r], 0.0, chk);
         }
       }
+    };
+    // s = A^T z - lx - H k = w0 - lx + Z t (brrf.cpp:86-90) of one column tile, by WAVE 1 for all of them (every column tile of Z^T
+    // passes through its registers): column layout, per-lane partial sums + q-reduction; -> LDS (the s+ of the next grid point) and
+    // HBM, with the (zero) switching-time fields of the record
+    double tr_[KGU];   // t in the row layout
+    auto s_col = [&](int c, const d4(&zc)[TU]) __attribute__((always_inline)) {
+      double part = 0.0;
+#pragma unroll
+      for (int gu = 0; gu < KGU; ++gu) part = __builtin_fma(zc[gu / 4][gu % 4], tr_[gu], part);
+      part = qsum(part);
+      const int j = 16 * c + li;
+      const int jc = (j < NX) ? j : 0;
+      const double sn = sW0[jc] - sStrip[ST_LXO + jc] + part;
+      if (q == 0 && j < NX) {
+        sS[j] = sn;
+        rr[RL.off[RTOC_RIC_S] + j] = sn;
+      }
+      if (q == 1 && j < NX) rr[RL.off[RTOC_RIC_PSI] + j] = 0.0;
+      if (q == 2 && j < NX) rr[RL.off[RTOC_RIC_PHI] + j] = 0.0;
     };
     d4 zt[TU][T];   // Z^T = Y H^T: the column tiles this wave owns stay
     if (!impact) {
       if constexpr (W == 0) {
         // ================= 6. / 7. wave 0: Z^T of its column tiles, and K = -Y^T Z^T (riccati_factorizer.cpp:55) of ALL column tiles --
-        //                          wave 1's pass through (H^T from the place of Bv), its way from here is the longer one =================
+        //                          wave 1's pass through (H^T from the place of Bv); the idle column NX of the last one carries
+        //                          lu' -> t = Y lu' -> k = -Y^T t =================
 #pragma unroll
         for (int c = 0; c < T; ++c) {
           d4 hc[TU], zc[TU];
@@ -651,6 +710,7 @@ __device__ __forceinline__ void rw2_body(BwdArgs a) {
           }
           zt_col(zc, hc);
           k_col(c, zc);
+          if (!S_W1 && c == T - 1) t_out(zc);
           if (c <= TSPLIT) {
 #pragma unroll
             for (int tu = 0; tu < TU; ++tu) zt[tu][c] = zc[tu];
@@ -658,14 +718,16 @@ __device__ __forceinline__ void rw2_body(BwdArgs a) {
         }
         if (is_bad(chk)) stat |= RTOC_STAT_NAN;
       } else {
-        // ================= 6. / 8. wave 1: Z^T of its own column tiles first (they stay), F -= Z Z^T (brrf.cpp:82-84) among them; then
-        //                          the column tiles of wave 0 one at a time: each meets wave 1's tiles of its row and dies =================
+        // ================= 6. / 8. wave 1: Z^T of its own column tiles first (they stay; the rider of the last one is t), F -= Z Z^T
+        //                          (brrf.cpp:82-84) among them; then the column tiles of wave 0 one at a time: each meets wave 1's
+        //                          tiles of its row, gives its entries of s, and dies =================
 #pragma unroll
         for (int c = TSPLIT + 1; c < T; ++c) {
           d4 hc[TU], zc[TU];
 #pragma unroll
           for (int tu = 0; tu < TU; ++tu) hc[tu] = hT[tu][c];
           zt_col(zc, hc);
+          if (c == T - 1) t_out(zc);
 #pragma unroll
           for (int tu = 0; tu < TU; ++tu) zt[tu][c] = zc[tu];
         }
@@ -675,6 +737,14 @@ __device__ __forceinline__ void rw2_body(BwdArgs a) {
           for (int c = TSPLIT + 1; c < T; ++c)
 #pragma unroll
             for (int t = c; t < T; ++t) f[c][t] = mfma16(-zt[gu / 4][c][gu % 4], zt[gu / 4][t][gu % 4], f[c][t]);
+        if (S_W1) {
+          rv_lds_sync();
+#pragma unroll
+          for (int gu = 0; gu < KGU; ++gu) {
+            const double v = sT[4 * gu + q];
+            tr_[gu] = (4 * gu + q < NU) ? v : 0.0;
+          }
+        }
 #pragma unroll
         for (int c = 0; c <= TSPLIT; ++c) {
           d4 hc[TU], zc[TU];
@@ -685,6 +755,7 @@ __device__ __forceinline__ void rw2_body(BwdArgs a) {
           for (int gu = 0; gu < KGU; ++gu)
 #pragma unroll
             for (int t = TSPLIT + 1; t < T; ++t) f[c][t] = mfma16(-zc[gu / 4][gu % 4], zt[gu / 4][t][gu % 4], f[c][t]);
+          if (S_W1) s_col(c, zc);
         }
       }
     } else {
@@ -710,11 +781,9 @@ __device__ __forceinline__ void rw2_body(BwdArgs a) {
       }
     }
     RW2_PROF(9);
-    // ---- s = A^T z - lx - H k = w0 - lx + Z t (brrf.cpp:86-90): column layout, per-lane partial sums + q-reduction; -> LDS (the s+
-    //      of the next grid point) and HBM, with the (zero) switching-time fields of the record ----
-    rv_lds_sync();
-    {
-      double tr_[KGU];
+    // ---- s of this grid point: wave 1's own column tiles (wave 0's passed by above); on an impact grid point s = A^T z - lx ----
+    if constexpr (!S_W1) {
+      rv_lds_sync();
 #pragma unroll
       for (int gu = 0; gu < KGU; ++gu) {
         const double v = sT[4 * gu + q];
@@ -722,22 +791,33 @@ __device__ __forceinline__ void rw2_body(BwdArgs a) {
       }
 #pragma unroll
       for (int c = 0; c < T; ++c) {
-        if (!own(c)) continue;   // this wave's column tiles of s
-        double part = 0.0;
+        if (!own(c)) continue;
+        d4 zc[TU];
 #pragma unroll
-        for (int gu = 0; gu < KGU; ++gu) part = __builtin_fma(zt[gu / 4][c][gu % 4], tr_[gu], part);
-        part = qsum(part);
-        const int j = 16 * c + li;
-        const int jc = (j < NX) ? j : 0;
-        const double sn = sW0[jc] - sStrip[ST_LXO + jc] + part;
-        if (q == 0 && j < NX) {
-          sS[j] = sn;
-          rr[RL.off[RTOC_RIC_S] + j] = sn;
-        }
-        if (q == 1 && j < NX) rr[RL.off[RTOC_RIC_PSI] + j] = 0.0;
-        if (q == 2 && j < NX) rr[RL.off[RTOC_RIC_PHI] + j] = 0.0;
+        for (int tu = 0; tu < TU; ++tu) zc[tu] = zt[tu][c];
+        s_col(c, zc);
       }
       if (W == 0 && lane < 5) rr[RL.off[RTOC_RIC_SCAL] + lane] = 0.0;
+    } else if constexpr (W == 1) {
+      rv_lds_sync();
+      d4 z0[TU];
+#pragma unroll
+      for (int tu = 0; tu < TU; ++tu) z0[tu] = zero4();
+      if (impact) {
+#pragma unroll
+        for (int gu = 0; gu < KGU; ++gu) tr_[gu] = 0.0;
+#pragma unroll
+        for (int c = 0; c <= TSPLIT; ++c) s_col(c, z0);
+      }
+#pragma unroll
+      for (int c = TSPLIT + 1; c < T; ++c) {
+        d4 zc[TU];
+#pragma unroll
+        for (int tu = 0; tu < TU; ++tu) zc[tu] = zt[tu][c];
+        s_col(c, zc);
+      }
+    } else {
+      if (lane < 5) rr[RL.off[RTOC_RIC_SCAL] + lane] = 0.0;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
@@ -812,6 +892,10 @@ __device__ __forceinline__ void rw2_body(BwdArgs a) {
       return (rowok && colok) ? v : 0.0;
     };
     auto tile_at = [](int c, int t) constexpr { return c * T - c * (c - 1) / 2 + (t - c); };   // index of the upper tile (c, t), c <= t
+    if (W == 0 && st > lo) {   // Bv and Quu of the next grid point: their places (wave 1's H^T, this wave's last panel) have been read
+      issue_dma_bv(st - 1);
+      issue_bq(st - 1);
+    }
     rw2_sync();   // both waves have read A -- and the strip -- for the last time
 #pragma unroll
     for (int c = 0; c < T; ++c)
@@ -824,8 +908,9 @@ __device__ __forceinline__ void rw2_body(BwdArgs a) {
       }
     RW2_PROF(12);
     rw2_sync();   // all of F is in LDS, and the next strip
-    // z = s+ - P+ Fx of the NEXT grid point rides along: the elements of P+ pass through the vector registers once, here -- formed at
-    // the stage top from the resident P+ it made the allocator keep all 200 registers of it in the architectural half
+    // z = s+ - P+ Fx of the NEXT grid point rides along (one copy in LDS, each wave the entries of its column tiles): the elements of
+    // P+ pass through the vector registers once, here -- formed at the stage top from the resident P+ it made the allocator keep all
+    // 200 registers of it in the architectural half
     double zpart[T];
 #pragma unroll
     for (int mt = 0; mt < T; ++mt) zpart[mt] = 0.0;
@@ -849,27 +934,28 @@ __device__ __forceinline__ void rw2_body(BwdArgs a) {
             pv = (q + 4 * r <= li) ? dv : tv;
           }
           pp[kt][mt][r] = pv;
-          if (4 * kt + r < KG) {   // (Fx re-read where it is used: eighteen registers less while P+ passes through the vector file)
+          if (own(mt) && 4 * kt + r < KG) {   // (z of this wave's column tiles)   // (Fx re-read where it is used: eighteen registers less while P+ passes through the vector file)
             const double fv = sStripN[4 * (4 * kt + r) + q];   // Fx of the next grid point (its strip was requested at the stage top)
-            zpart[mt] = __builtin_fma(pv, (st > lo && (16 * kt + 4 * r + 3 < NX || 16 * kt + 4 * r + q < NX)) ? fv : 0.0, zpart[mt]);
+            zpart[mt] = __builtin_fma(pv, (16 * kt + 4 * r + 3 < NX || 16 * kt + 4 * r + q < NX) ? fv : 0.0, zpart[mt]);   // (st == lo: a stale strip, the sum unused)
           }
         }
       }
     if (st > lo) {
 #pragma unroll
       for (int mt = 0; mt < T; ++mt) {
+        if (!own(mt)) continue;
         const double part = qsum(zpart[mt]);
         const int j = 16 * mt + li;
         const double sv = sS[(j < NX) ? j : 0];
         if (q == 0 && j < NX) sZ[j] = sv - part;
       }
     }
+    RW2_PROF(14);
     rw2_sync();   // ... and has been read: the place belongs to A again
+    RW2_PROF(15);
     if (st > lo) {
-      if (W == 1) issue_dma_qxu(st - 1);
-      if (W == 0) {
-        issue_bq(st - 1);
-        issue_dma_bv(st - 1);
+      if (W == 1) {
+        issue_dma_qxu(st - 1);
         issue_dma_A(st - 1);
       }
     }
