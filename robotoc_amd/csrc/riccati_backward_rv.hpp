@@ -60,6 +60,17 @@ struct RvCfg {
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
+// LDS destinations of the DMA as 32-bit addresses relative to the kernel's shared array: casting a generic pointer to the LDS address
+// space costs a null check (64-bit compare + select into M0) per request once the pointer has passed through a lambda capture.  Used
+// by riccati_backward_rw2.hpp, whose wave 1 issues 51 requests in the tail of a stage; in this file's kernel (and in _rw.hpp) it made no
+// measurable difference and is not used.  Only from __device__ functions: the host pass of a __global__ function that calls it drops
+// the kernel's stub without a diagnostic.
+struct LdsAddr {
+  unsigned a;
+  const char* g;
+  __device__ __forceinline__ explicit LdsAddr(const void* smem) : a((unsigned)(uintptr_t)(lds_ptr_t)smem), g((const char*)smem) {}
+  __device__ __forceinline__ lds_ptr_t operator()(const void* p) const { return (lds_ptr_t)(uintptr_t)(a + (unsigned)((const char*)p - g)); }
+};
 constexpr int RV_MAX_STAGES = 64;   // grid points of a horizon the kernel keeps a kind table for (in the slack of its LDS carve)
 
 // Streaming policy of the record traffic (every byte is touched once per sweep): RTOC_RV_NT = 1 marks the loads / DMA / stores

@@ -407,57 +407,57 @@ __global__ __launch_bounds__(64, 1) void riccati_backward_rw_kernel(BwdArgs a) {
       return (rowok && (16 * c + 15 < NX || j < NX)) ? v : 0.0;
     };
 
+    // structured rows of k group g as a B fragment of column tile c: B[k = 4g + q][x = 16c + li] = ca (x == k) + cc (x == NV + k), k in [NP, NV)
+    auto struct_hit = [](int g, int c) {
+      const int k0 = (4 * g > NP_) ? 4 * g : NP_, k1 = (4 * g + 3 < NV - 1) ? 4 * g + 3 : NV - 1;
+      if (k0 > k1) return false;
+      return (k0 <= 16 * c + 15 && k1 >= 16 * c) || (NV + k0 <= 16 * c + 15 && NV + k1 >= 16 * c);
+    };
+    auto struct_frag = [&](int g, int c) __attribute__((always_inline)) -> double {
+      const int k = 4 * g + q, x = 16 * c + li;
+      const double v = (x == k) ? ca : (x == NV + k) ? cc : 0.0;
+      return (k >= NP_ && k < NV) ? v : 0.0;
+    };
+
     d4 zt[TU][T];   // Z^T = Y H^T
     if (!impact) {
       issue_hq();
-      // ================= 4. H = A^T PB (rows x, columns u; column NU: A^T z) =================
+      // ================= 4. H^T = Qxu^T + PB^T A DIRECTLY in the layout Z^T = Y H^T reads (rows u, columns x): PB's C tiles are the
+      //                      A operand as they stand, A's fragments the B operand; the structured rows k of A (ca e_k | cc e_NV+k)
+      //                      are synthesised fragments that meet two or three column tiles.  Row NUC of control tile TU - 1 is the
+      //                      rider (A^T z)^T.  No transposes, no rotations (tests/rw_lane_model.py: direct_ht) =================
       d4 hT[TU][T];
 #pragma unroll
       for (int tu = 0; tu < TU; ++tu) {
-        d4 hx[T];
+        asm volatile("" ::: "memory");   // (A's fragments are re-read per control tile rather than held across them)
 #pragma unroll
-        for (int c = 0; c < T; ++c) hx[c] = zero4();
+        for (int c = 0; c < T; ++c) hT[tu][c] = zero4();
 #pragma unroll
         for (int g = 0; g < KG; ++g) {
-          if (!group_dense(g)) continue;
+          const double aop = acc[g / 4][tu][g % 4];
 #pragma unroll
-          for (int c = 0; c < T; ++c) hx[c] = mfma16(afrag(g, c), acc[g / 4][tu][g % 4], hx[c]);
+          for (int c = 0; c < T; ++c) {
+            const bool hit = struct_hit(g, c);
+            if (!group_dense(g) && !hit) continue;
+            double bop = group_dense(g) ? afrag(g, c) : 0.0;
+            if (hit) bop += struct_frag(g, c);   // (afrag is zero on the structured rows)
+            hT[tu][c] = mfma16(aop, bop, hT[tu][c]);
+          }
         }
-        d4 src[T];
-#pragma unroll
-        for (int c = 0; c < T; ++c) src[c] = acc[c][tu];
-        struct_rows_add(hx, src, T - 1);
         if (tu == TU - 1) {   // the rider: w0 = A^T z
 #pragma unroll
-          for (int c = 0; c < T; ++c)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int i = 16 * c + 4 * r + q;
-              if (i < NX && li == NUC) sW0[i] = hx[c][r];
-            }
-        }
-        // ================= 5. H^T = transpose(H) + Qxu^T, two tiles per round trip through the scratch =================
-#pragma unroll
-        for (int c0 = 0; c0 < T; c0 += 2) {
-#pragma unroll
-          for (int c = c0; c < c0 + 2 && c < T; ++c) {
-            double* s_ = scr + (c - c0) * SCR_TILE;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) s_[(q + 4 * r) * SCR_LD + li] = hx[c][r];
+          for (int c = 0; c < T; ++c) {
+            const int x = 16 * c + li;
+            if (q == NUC % 4 && x < NX) sW0[x] = hT[tu][c][NUC / 4];
           }
-          rv_lds_sync();
-#pragma unroll
-          for (int c = c0; c < c0 + 2 && c < T; ++c) {
-            const double* s_ = scr + (c - c0) * SCR_TILE;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int u = 16 * tu + 4 * r + q, x = 16 * c + li;
-              const double tr = s_[li * SCR_LD + q + 4 * r];
-              hT[tu][c][r] = (u < NU && x < NX) ? tr + hq[tu][c][r] : 0.0;
-            }
-          }
-          rv_lds_sync();
         }
+#pragma unroll
+        for (int c = 0; c < T; ++c)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int u = 16 * tu + 4 * r + q, x = 16 * c + li;
+            hT[tu][c][r] = (u < NU && x < NX) ? hT[tu][c][r] + hq[tu][c][r] : 0.0;
+          }
       }
       RV_PROF(4);
       // ================= 3. LLT(G) (riccati_factorizer.cpp:49), Y = L^-1; t = Y lu', k = -Y^T t =================
@@ -526,26 +526,26 @@ __global__ __launch_bounds__(64, 1) void riccati_backward_rw_kernel(BwdArgs a) {
       if (is_bad(chk)) stat |= RTOC_STAT_NAN;
     } else {
       // impact grid point (riccati_factorizer.cpp:178-197): no controls; A^T z by the rider column alone
-      d4 hx[T];
+      d4 hx[T];   // row NUC: (A^T z)^T
 #pragma unroll
       for (int c = 0; c < T; ++c) hx[c] = zero4();
 #pragma unroll
       for (int g = 0; g < KG; ++g) {
-        if (!group_dense(g)) continue;
+        const double aop = acc[g / 4][TU - 1][g % 4];
 #pragma unroll
-        for (int c = 0; c < T; ++c) hx[c] = mfma16(afrag(g, c), acc[g / 4][TU - 1][g % 4], hx[c]);
-      }
-      d4 src[T];
-#pragma unroll
-      for (int c = 0; c < T; ++c) src[c] = acc[c][TU - 1];
-      struct_rows_add(hx, src, T - 1);
-#pragma unroll
-      for (int c = 0; c < T; ++c)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int i = 16 * c + 4 * r + q;
-          if (i < NX && li == NUC) sW0[i] = hx[c][r];
+        for (int c = 0; c < T; ++c) {
+          const bool hit = struct_hit(g, c);
+          if (!group_dense(g) && !hit) continue;
+          double bop = group_dense(g) ? afrag(g, c) : 0.0;
+          if (hit) bop += struct_frag(g, c);
+          hx[c] = mfma16(aop, bop, hx[c]);
         }
+      }
+#pragma unroll
+      for (int c = 0; c < T; ++c) {
+        const int x = 16 * c + li;
+        if (q == NUC % 4 && x < NX) sW0[x] = hx[c][NUC / 4];
+      }
 #pragma unroll
       for (int tu = 0; tu < TU; ++tu)
 #pragma unroll

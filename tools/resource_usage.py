@@ -4,6 +4,8 @@ import re, subprocess, sys
 txt = open(sys.argv[1]).read()
 blocks = re.split(r'remark: Function Name: ', txt)[1:]
 names = [b.split()[0] for b in blocks]
+if not names:
+    sys.exit("no kernel-resource-usage remarks in " + sys.argv[1] + " (did the compile fail?)")
 dem = subprocess.run(['c++filt'] + names, capture_output=True, text=True).stdout.strip().split('\n')
 print("# kernel, VGPRs, AGPRs, ScratchSize[bytes/lane], VGPRs Spill, SGPRs, SGPRs Spill, Occupancy[waves/SIMD], LDS[bytes/block]")
 for b, n in zip(blocks, dem):
