@@ -173,8 +173,10 @@ enum rtoc_option {
                       * form; riccati_backward_rv.hpp) where it applies: shapes whose stacked operand [P+; PB^T] fills its 16-row
                       * tiles (nv = 18, nu = 12: ANYmal, A1), grids without switching-time optimisation, RTOC_OPT_WRITEBACK_KKT = 0
                       * and the default RTOC_OPT_BACKWARD_WAVES.  On the iCub-size shapes (nx = 64 / 70) its counterpart is the
-                      * register-wide kernel (riccati_backward_rw.hpp: one wavefront per instance and SIMD, P+ in 16 / 25 accumulator
-                      * tiles, the dense rows of a STRUCTURED Fxx staged in LDS; checked on the device like RTOC_OPT_FXX_STRUCTURE;
+                      * register-wide kernel (riccati_backward_rw.hpp, nx = 64: one wavefront per instance and SIMD, P+ in 16 accumulator
+                      * tiles; riccati_backward_rw2.hpp, nx = 70: two wavefronts per instance, P+ in 25 tiles in each, the stage split
+                      * between them by role and by column tiles; the dense rows of a STRUCTURED Fxx staged in LDS; checked on the device
+                      * like RTOC_OPT_FXX_STRUCTURE -- on a bound record buffer before every recursion unless that option is 2;
                       * switching-constraint grid points as one-stage launches of the tile-split kernel): with 1 on batches of more
                       * instances than the device has compute units (below that the tile-split kernel's four waves per instance
                       * finish a horizon sooner), with 2 on every batch.  Elsewhere, and with 0, the role-split / tile-split

@@ -28,6 +28,8 @@ timeout 200 python tools/dvfs_probe.py > $OUT/summary/${TAG}_dvfs_probe.txt 2>&1
 { echo "== 72 joint-limit rows + 4 friction cones =="; bash tools/gpu_cond.sh prof 2>&1 | grep -v amdgpu.ids; echo "== no rows =="; bash tools/gpu_cond.sh x norows 2>&1 | grep -v amdgpu.ids;
   if [ -f $R/robotoc_amd/librtoc_hip_prof.so ]; then echo "== cycle stamps of one work item (two waves per SIMD) =="; RTOC_HIP_LIB=$R/robotoc_amd/librtoc_hip_prof.so timeout 100 python tools/phase_profile_cond.py 4096 2>&1 | grep -v amdgpu.ids; fi; } > $OUT/summary/${TAG}_condense_register.txt 2>&1
 timeout 200 python tools/icub_bwd_bench.py > $OUT/summary/${TAG}_icub_backward.txt 2>&1
+# cycle stamps of the register-wide kernels (both waves of the nv = 35 one), Fxx structure asserted
+if [ -f $R/robotoc_amd/librtoc_hip_prof.so ]; then for c in icub35 icub32; do echo "== $c"; RTOC_FXX=2 RTOC_HIP_LIB=$R/robotoc_amd/librtoc_hip_prof.so timeout 200 python tools/phase_profile_rv.py 1024 $c 2>&1 | grep -v amdgpu | head -12; done > $OUT/summary/${TAG}_register_wide_phase_stamps.txt; fi
 # run-to-run determinism of the headline sweep, records compared bit for bit (instance / stage / field of anything that differs)
 timeout 150 python tools/determinism_probe.py 40 > $OUT/summary/${TAG}_determinism.txt 2>&1
 RTOC_PROFILE_OUT=$OUT/summary python tools/summarize_profiles.py $TAG "closing run of the round" > $OUT/summarize.log 2>&1

@@ -1,5 +1,5 @@
-"""Backward-kernel timing of the iCub configurations (1024 instances): the default dispatch (nv = 32: the register-wide kernel,
-riccati_backward_rw.hpp; nv = 35: the tile-split kernel) and the tile-split kernel at every wave count compiled in."""
+"""Backward-kernel timing of the iCub configurations (1024 instances): the default dispatch (the register-wide kernels: nv = 32
+riccati_backward_rw.hpp, nv = 35 riccati_backward_rw2.hpp; owned buffers: no per-recursion check of the Fxx structure) and the tile-split kernel at every wave count compiled in."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
