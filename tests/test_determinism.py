@@ -9,7 +9,8 @@ protocol under test                                   case
   rs4 role-split, structured Fxx (flag words, rs_sync)  trot-structured       (riccati_backward_rs.hpp, SA = true)
   rs4 role-split, dense-Fxx fallback                    trot-dense            (SA = false: RTOC_OPT_FXX_STRUCTURE = 1)
   rs4 + STO block + phase transition                    jump_sto              (riccati_sto_block.inc, riccati_pt_block.inc)
-  tile-split kernel, 4 / 5 waves per instance           icub32, icub35        (riccati_backward.hpp: s_barrier hand-offs)
+  register-wide kernels (default dispatch at 1024)      icub32, icub35        (riccati_backward_rw.hpp; _rw2.hpp: two waves per instance,
+                                                                               hand-over of Y / H^T / F through LDS behind s_barrier)
   horizon scan (element / combine kernels + vector pass) trot-scan, jump_sto-scan (riccati_scan_core.hpp, riccati_scan_sto.hpp)
   one Newton iteration as one launch sequence           newton               (condense, sweep, expand, update from restored records)
 """
