@@ -310,6 +310,15 @@ def stage(c_, pp, s_next, A, Bv, Qxx, Qxu, Quu, Fx, lx, lu, impact, direct_ht=Fa
             m, k = 16 * tu + LI, 4 * gj + Q
             ok = (m < NU) & (k < NU)
             return np.where(ok, -Y[np.clip(k, 0, NU - 1), np.clip(m, 0, NU - 1)], 0.0)
+        # riccati_backward_rw2.hpp: lu' rides in the idle column NX of H^T's last column tile -> t = Y lu' in Z^T, k = -Y^T t in K
+        RID = NX % 16
+        riders = direct_ht and RID != 0
+        if riders:
+            for tu in range(TU):
+                for r in range(4):
+                    u = 16 * tu + 4 * r + Q
+                    sel = (LI == RID) & (u < NU)
+                    hT[tu][T - 1][:, r] = np.where(sel, lup[np.clip(u, 0, NU - 1)], hT[tu][T - 1][:, r])
         zt = [[z4() for _ in range(T)] for _ in range(TU)]
         for tu in range(TU):
             for gj in range(min(KGU, 4 * (tu + 1))):
@@ -328,6 +337,10 @@ def stage(c_, pp, s_next, A, Bv, Qxx, Qxu, Quu, Fx, lx, lu, impact, direct_ht=Fa
                     u, x = 16 * tu + 4 * r + Q, 16 * c + LI
                     ok = (u < NU) & (x < NX)
                     K[u[ok], x[ok]] = kk[ok, r]
+                    if riders and c == T - 1:   # the riders against the vector forms of step 3
+                        sel = (LI == RID) & (u < NU)
+                        assert np.abs(kk[sel, r] - kvec[u[sel]]).max() <= 1e-9 * max(1.0, np.abs(kvec).max())
+                        assert np.abs(zt[tu][c][sel, r] - tvec[u[sel]]).max() <= 1e-9 * max(1.0, np.abs(tvec).max())
     # ---- 8. F starts from Qxx (upper tiles, off-diagonal ones symmetrised: brrf.cpp:85 folded into the start value), F -= Z Z^T ----
     f = [[None] * T for _ in range(T)]
     for c in range(T):
