@@ -72,6 +72,41 @@ def test_register_wide_kernel_reproduces_the_oracle_on_the_icub_jump(oracle, nv,
         ctx.close()
 
 
+@pytest.mark.parametrize("nv", [32, 35])
+@pytest.mark.parametrize("horizon", ["one_stage", "two_stages", "uniform_63"])
+def test_register_wide_kernel_on_ragged_horizons(oracle, nv, horizon):
+    """The shortest horizons the kernel accepts (one and two stages ahead of the terminal record: its prologue / stage-end hand-over
+    with nothing in between) and the longest (64 grid points: the size of its grid-kind table) -- against the oracle, batch 3,
+    RTOC_OPT_BACKWARD_REGISTER = 2."""
+    from robotoc_amd import capi
+    from robotoc_amd.grid import uniform_grid
+    from robotoc_amd.types import icub_dims
+    dims = icub_dims(nv)
+    grids = uniform_grid({"one_stage": 1, "two_stages": 2, "uniform_63": 63}[horizon], 0.02, dimf=12)
+    batch = 3
+    ctx = capi.Context(dims, len(grids), batch, 0)
+    try:
+        L = ctx.L
+        ctx.set_grid(grids)
+        kkt = pr.make_kkt_batch(L, grids, batch, mode="dynamics")
+        dx0 = pr.make_dx0(L, batch)
+        st, ric, d = _sweep(ctx, kkt, dx0, 2)
+        R, D = Records(L, "ric"), Records(L, "dir")
+        ric_ref, d_ref = R.zeros(batch, len(grids)), D.zeros(batch, len(grids))
+        st_ref = oracle.riccati_sweep_batch(L, grids, kkt.copy(), ric_ref, d_ref, dx0=dx0)
+        assert (st == st_ref).all(), (st, st_ref)
+        worst = 0.0
+        for b in range(batch):
+            worst = max(worst, compare_riccati(L, grids, ric[b], ric_ref[b], TOL, "%s inst %d" % (horizon, b), check_sto=False))
+            worst = max(worst, compare_direction(L, grids, d[b], d_ref[b], TOL, "%s inst %d" % (horizon, b)))
+        if len(grids) > 2:   # the register-wide kernel ran (needs two stages): not bit-identical to the tile-split kernel
+            _, ric2, _ = _sweep(ctx, kkt, dx0, 0)
+            assert not np.array_equal(ric, ric2)
+        print("register-wide kernel, %s, nv %d: worst rel err %.3e" % (horizon, nv, worst))
+    finally:
+        ctx.close()
+
+
 def test_register_wide_kernel_is_not_chosen_for_an_unstructured_fxx(oracle):
     """One stray entry in the structured half of one Fxx: the device check refuses, the tile-split kernel runs (dense Fxx), the
     oracle is reproduced."""
