@@ -107,6 +107,44 @@ def test_register_wide_kernel_on_ragged_horizons(oracle, nv, horizon):
         ctx.close()
 
 
+@pytest.mark.parametrize("nv", [32, 35])
+def test_register_wide_sweep_as_a_replayed_graph_and_in_chunks(nv):
+    """rtoc_riccati_sweep with the register-wide kernels (a) captured into a HIP graph and replayed (the structure check of Fxx runs
+    ahead of the capture), (b) pipelined over three chunks of instances (launches with a first-instance offset): the directions and
+    the Riccati records equal the plain sweep's bit for bit."""
+    from robotoc_amd import capi
+    dims, grids, _ = pr.config_icub_jump(nv=nv)
+    batch = 7
+    kkt, dx0 = None, None
+    out = {}
+    for name in ("plain", "graph", "chunks"):
+        ctx = capi.Context(dims, len(grids), batch, 0)
+        try:
+            L = ctx.L
+            ctx.set_grid(grids)
+            ctx.set_backward_register(2)
+            if kkt is None:
+                kkt = pr.make_kkt_batch(L, grids, batch, mode="dynamics")
+                dx0 = pr.make_dx0(L, batch)
+            if name == "graph":
+                ctx.set_graph(True)
+            if name == "chunks":
+                ctx.set_sweep_chunks(3)
+            ctx.upload(BUF_KKT, kkt)
+            ctx.upload(BUF_DX0, dx0)
+            for _ in range(4 if name == "graph" else 1):   # warm-up, capture, replays
+                ctx.riccati_sweep()
+            assert (ctx.status() == 0).all()
+            if name == "graph":
+                assert ctx.graph_replay_count() >= 2
+            out[name] = (ctx.download_records(BUF_RIC, "ric"), ctx.download_records(BUF_DIR, "dir"))
+        finally:
+            ctx.close()
+    for name in ("graph", "chunks"):
+        assert np.array_equal(out[name][0], out["plain"][0], equal_nan=True), name
+        assert np.array_equal(out[name][1], out["plain"][1], equal_nan=True), name
+
+
 def test_register_wide_kernel_is_not_chosen_for_an_unstructured_fxx(oracle):
     """One stray entry in the structured half of one Fxx: the device check refuses, the tile-split kernel runs (dense Fxx), the
     oracle is reproduced."""
