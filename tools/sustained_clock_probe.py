@@ -11,6 +11,7 @@ from robotoc_amd.grid import uniform_grid
 from robotoc_amd.types import BUF_KKT, icub_dims
 
 cases = [("anymal (riccati_backward_rv_kernel, 8 instances per CU)", pr.config_anymal_trot()[0], 12, 2048, 16),
+         ("anymal (riccati_backward_rv_kernel, 4 instances per CU: one wave per SIMD)", pr.config_anymal_trot()[0], 12, 1024, 16),
          ("iCub nv = 32 (riccati_backward_rw_kernel, 4 per CU)", icub_dims(32), 12, 1024, 13),
          ("iCub nv = 35 (riccati_backward_rw2_kernel, 2 per CU)", icub_dims(35), 12, 512, 13)]
 for name, dims, dimf, batch, end_slot in cases:
